@@ -1,0 +1,246 @@
+/*
+ * nuts_mi355.h -- C ABI of libnuts_mi355.so, the MI355X-native NUTS/HMC engine.
+ *
+ * Drop-in boundary for the hot path of pymc-devs/pymc.
+ * The reference has no FFI of its own for this path (it is pure Python over
+ * PyTensor), so every entry point cites the reference *Python* interface it
+ * replaces (paths relative to the reference checkout).  Plain C types only:
+ * caller-owned host buffers, library-owned device buffers, integer status
+ * codes (never aborts the process).
+ *
+ * Status codes: 0 = ok; NUTS_E_BAD_ENERGY = non-finite initial energy (the
+ * reference raises SamplingError("Bad initial energy"), base_hmc.py:205-224);
+ * NUTS_E_HIP = a HIP runtime error (text in nuts_last_error());
+ * NUTS_E_ARG = invalid argument.
+ */
+#ifndef NUTS_MI355_H
+#define NUTS_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUTS_OK 0
+#define NUTS_E_BAD_ENERGY 1
+#define NUTS_E_ARG 2
+#define NUTS_E_HIP 3
+#define NUTS_E_LINALG 4
+
+/* ---- model spec: what `Model.logp_dlogp_function` (pymc/model/core.py:464-529)
+ * compiles from the PyTensor graph, restated as a struct-of-arrays IR. -------- */
+
+/* value-variable transforms (pymc/logprob/transforms.py:880-891, 967-1088) */
+enum { NUTS_TR_NONE = 0, NUTS_TR_LOG = 1, NUTS_TR_LOGODDS = 2, NUTS_TR_INTERVAL = 3 };
+/* operand kinds */
+enum { NUTS_OP_CONST = 0, NUTS_OP_DATA = 1, NUTS_OP_VAR = 2 };
+/* element-wise distributions (pymc/distributions/continuous.py, discrete.py) */
+enum {
+  NUTS_D_NORMAL = 0,      /* args: value, mu, sigma         continuous.py:526-532  */
+  NUTS_D_HALFNORMAL = 1,  /* args: value, sigma             continuous.py:909-916  */
+  NUTS_D_CAUCHY = 2,      /* args: value, alpha, beta       continuous.py:2287-2293 */
+  NUTS_D_HALFCAUCHY = 3,  /* args: value, beta              continuous.py:2383-2390 */
+  NUTS_D_STUDENTT = 4,    /* args: value, nu(const), mu, sigma  continuous.py:1935-1950 */
+  NUTS_D_BETA = 5,        /* args: value, alpha(const), beta(const) continuous.py:1248-1262 */
+  NUTS_D_EXPONENTIAL = 6, /* args: value, lam               continuous.py:1478-1486 */
+  NUTS_D_UNIFORM = 7,     /* args: value, lower(const), upper(const) continuous.py:309-321 */
+  NUTS_D_BERNOULLI_LOGIT = 8, /* args: y(data), logit_p     discrete.py:351-352,362-374 */
+  NUTS_D_LOGNORMAL = 9,   /* args: value, mu, sigma         continuous.py:1807-1819 */
+  NUTS_D_BERNOULLI = 10   /* args: y(data), p               discrete.py:362-374 */
+};
+
+typedef struct {
+  int32_t kind; /* NUTS_OP_* */
+  int32_t ref;  /* data id or var id */
+  double c;     /* constant */
+} nuts_operand;
+
+typedef struct { /* value = a + b * c, size-1 operands broadcast */
+  nuts_operand a, b, c;
+} nuts_term;
+
+typedef struct {
+  int32_t dist;  /* NUTS_D_* */
+  int32_t size;  /* number of elements */
+  int32_t nargs; /* incl. value (arg[0]) */
+  int32_t pad;
+  double konst; /* parameter-only normaliser (lgamma terms), computed by caller */
+  nuts_term arg[4];
+} nuts_factor;
+
+typedef struct { /* one value variable = a slice of the raveled vector
+                    (pymc/blocking.py:67-75 fixes the order) */
+  int32_t offset, size, transform, pad;
+  double lower, upper;
+} nuts_var;
+
+typedef struct {
+  int64_t offset, size; /* into data_pool, in doubles */
+} nuts_data_ref;
+
+typedef struct {
+  int32_t n_vars, n_factors, n_data, pad;
+  const nuts_var *vars;
+  const nuts_factor *factors;
+  const nuts_data_ref *data;
+  const double *data_pool;
+  int64_t data_pool_len;
+  /* dense node 1: y_i ~ Bernoulli(logit_p = X_i . beta_g(i)), beta_g = mu + sigma*z_g.
+     rows sorted by group (rows_gid non-decreasing). rows_N == 0 disables. */
+  int64_t rows_N;
+  int32_t rows_D, rows_G;
+  const double *rows_X;    /* [N][D] row-major (re-laid out column-major in HBM) */
+  const int8_t *rows_y;    /* [N] */
+  const int32_t *rows_gid; /* [N] */
+  int32_t rows_mu, rows_sigma, rows_z; /* var ids */
+  int32_t pad2;
+  /* dense node 2: x ~ MvNormal(mu, cov): caller supplies precision = cov^-1 and
+     logdet = sum(log(diag(chol(cov)))) (pymc/distributions/multivariate.py:158-185).
+     mvn_k == 0 disables. */
+  int32_t mvn_var, mvn_k;
+  const double *mvn_mu;   /* [k] */
+  const double *mvn_prec; /* [k][k] symmetric */
+  double mvn_logdet;
+} nuts_model_spec;
+
+typedef struct nuts_model nuts_model;
+typedef struct nuts_chain nuts_chain;
+
+/* ---- runtime --------------------------------------------------------------- */
+int nuts_device_count(void);
+int nuts_set_device(int device);
+const char *nuts_last_error(void);
+
+/* ---- model: replaces ValueGradFunction (pymc/model/core.py:142-305) --------- */
+nuts_model *nuts_model_create(const nuts_model_spec *spec);
+void nuts_model_destroy(nuts_model *m);
+int32_t nuts_model_ndim(const nuts_model *m);
+/* `ValueGradFunction.__call__` / `_pytensor_function(q)` (core.py:286-300,
+ * integration.py:46-52): q[n] -> (logp, dlogp[n]); host buffers. */
+int nuts_model_logp_grad(nuts_model *m, const double *q, double *logp, double *grad);
+/* Device-resident timing of the model pass: `reps` evaluations at q, average
+ * milliseconds per evaluation of the whole pass (ms_total) and of the dominant
+ * (row-streaming / mat-vec) kernel alone (ms_dominant), measured with HIP
+ * events on the library stream. */
+int nuts_model_time_logp_grad(nuts_model *m, const double *q, int reps, double *ms_total, double *ms_dominant);
+/* Algorithmic HBM bytes of one model pass (SURVEY.md section 8d B_model). */
+int64_t nuts_model_algorithmic_bytes(const nuts_model *m);
+
+/* ---- chain: replaces BaseHMC/NUTS + potential + step adaptation ------------- */
+enum { NUTS_POT_DIAG_ADAPT = 0, NUTS_POT_DIAG = 1, NUTS_POT_FULL = 2 };
+
+typedef struct {
+  /* BaseHMC.__init__ (pymc/step_methods/hmc/base_hmc.py:82-187) */
+  double step_scale;    /* 0.25 */
+  double Emax;          /* 1000 */
+  double target_accept; /* 0.8  */
+  double gamma, k, t0;  /* 0.05, 0.75, 10 */
+  int32_t adapt_step_size;
+  /* NUTS.__init__ (pymc/step_methods/hmc/nuts.py:132-202) */
+  int32_t max_treedepth, early_max_treedepth; /* 10, 8 */
+  /* potential (pymc/step_methods/hmc/quadpotential.py) */
+  int32_t potential; /* NUTS_POT_* */
+  const double *initial_mean; /* [n]   QuadPotentialDiagAdapt(n, initial_mean, ...) :211-306 */
+  const double *initial_diag; /* [n]   diag-adapt: initial variance; diag: variance; full: cov [n][n] */
+  double initial_weight;
+  int32_t adaptation_window;            /* 101 */
+  int32_t discard_window;               /* 50  */
+  double adaptation_window_multiplier;  /* 1   */
+  int32_t early_update;                 /* 0   */
+  int32_t pad;
+} nuts_chain_config;
+
+void nuts_chain_config_default(nuts_chain_config *cfg);
+
+/* the NUTS sampler statistics (pymc/step_methods/hmc/nuts.py:110-130) */
+typedef struct {
+  int64_t depth;
+  double step_size;
+  double mean_tree_accept;
+  double step_size_bar;
+  double tree_size;
+  int32_t diverging;
+  int32_t reached_max_treedepth;
+  int64_t divergences;
+  double energy_error;
+  double energy;
+  double max_energy_error;
+  double model_logp;
+  double process_time_diff;
+  double perf_counter_diff;
+  double perf_counter_start;
+  int64_t index_in_trajectory;
+  int32_t n_uniforms_consumed; /* RNG stream identity: how many `step.rng.random()` draws the tree used */
+  int32_t warning;             /* 0 none, 1 divergence ("Energy change in leapfrog step is too large") */
+  double divergence_energy_change;
+  int64_t n_model_evals;
+} nuts_draw_stats;
+
+nuts_chain *nuts_chain_create(nuts_model *m, const nuts_chain_config *cfg);
+void nuts_chain_destroy(nuts_chain *c);
+
+/* BaseHMC.reset_tuning / reset (base_hmc.py:290-298), stop_tuning (compound.py:229-231) */
+int nuts_chain_reset_tuning(nuts_chain *c);
+int nuts_chain_set_tune(nuts_chain *c, int tune);
+int nuts_chain_set_iter_count(nuts_chain *c, int64_t iter_count);
+
+/* One NUTS transition = BaseHMC.astep (base_hmc.py:196-288) with
+ * NUTS._hamiltonian_step (nuts.py:204-225) and the whole tree (nuts.py:270-489)
+ * on device, followed by step-size and mass-matrix adaptation
+ * (base_hmc.py:238-239).
+ *   q0        [n]  current position
+ *   normals   [n]  standard normals for `potential.random()` (quadpotential.py:323-326);
+ *                  the host owns the NumPy stream so draws are seed-identical
+ *   uniforms  [n_uniforms] pre-drawn `step.rng.random()` values; the device
+ *                  consumes a prefix, stats->n_uniforms_consumed says how many
+ *   q_out     [n]  new position;  grad_out [n] its gradient (may be NULL)
+ */
+int nuts_chain_draw(nuts_chain *c, const double *q0, const double *normals, const double *uniforms,
+                    int32_t n_uniforms, double *q_out, double *grad_out, nuts_draw_stats *stats);
+
+/* HamiltonianMC._hamiltonian_step (pymc/step_methods/hmc/hmc.py:130-184):
+ * uniforms[0] jitters the step size (hmc.py:35-36), uniforms[1] is the accept draw. */
+typedef struct {
+  double step_size, step_size_bar, accept, energy_error, energy, model_logp, path_length;
+  int64_t n_steps, divergences;
+  int32_t diverging, accepted;
+  double process_time_diff, perf_counter_diff, perf_counter_start;
+} nuts_hmc_stats;
+int nuts_chain_draw_hmc(nuts_chain *c, const double *q0, const double *normals, const double *uniforms,
+                        double path_length, int32_t max_steps, double *q_out, double *grad_out,
+                        nuts_hmc_stats *stats);
+
+/* Integrator access for property tests (integration.py:68-145): state lives on device. */
+int nuts_chain_leapfrog_test(nuts_chain *c, const double *q, const double *p, double eps, int32_t n_steps,
+                             double *q_out, double *p_out, double *energy_out);
+
+/* `sampling_state` round trip (pymc/step_methods/state.py:54-121;
+ * BaseHMCState base_hmc.py:61-71, QuadPotentialDiagAdaptState quadpotential.py:189-208,
+ * StepSizeState step_sizes.py:26-38): opaque blob, size in bytes. */
+int64_t nuts_chain_state_size(const nuts_chain *c);
+int nuts_chain_get_state(nuts_chain *c, void *blob);
+int nuts_chain_set_state(nuts_chain *c, const void *blob);
+
+/* Named scalar/vector views of the state for tests and the Python mirror. */
+int nuts_chain_get_scalar(nuts_chain *c, const char *name, double *out);
+int nuts_chain_get_vector(nuts_chain *c, const char *name, double *out /* [n] */);
+
+/* Pooled adaptation (opt-in, NOT reference behaviour):
+ * export/import the foreground+background Welford partials as
+ * [count_fg, mean_fg[n], m2_fg[n], count_bg, mean_bg[n], m2_bg[n]] so the caller can
+ * Chan-merge them across ranks with an RCCL all-reduce.  `buf` is a DEVICE
+ * pointer of 2*(2n+1) doubles. */
+int nuts_chain_welford_export(nuts_chain *c, double *buf_dev);
+int nuts_chain_welford_import(nuts_chain *c, const double *buf_dev);
+int nuts_chain_set_log_step_bar(nuts_chain *c, double log_step, double log_bar);
+
+/* Profiling: HIP-event timing of the dominant model kernel inside draws. */
+int nuts_chain_profile(nuts_chain *c, int enable);
+int nuts_chain_profile_read(nuts_chain *c, double *dominant_ms_sum, int64_t *dominant_launches,
+                            int64_t *leapfrogs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUTS_MI355_H */

@@ -1,0 +1,40 @@
+"""ctypes wrapper of the C restatement oracle/csrc/oracle_logit.c (oracle; test + cpu_baseline only).
+
+Built by `__graft_entry__.build()` into oracle/_build/liboracle.so (git-ignored,
+travels to the GPU box).  Validated against the NumPy restatement in
+tests/test_oracle_models.py.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle.so")
+
+
+class CHierLogit:
+    """``q -> (logp, grad)`` for a ModelSpec built by `pymc_amd.models.hier_logit`."""
+
+    def __init__(self, spec):
+        lib = C.CDLL(_SO)
+        self._fn = lib.oracle_hier_logit
+        self._fn.restype = C.c_double
+        self._fn.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        r = spec.logit_rows
+        self.X = np.ascontiguousarray(r.X, dtype="float64")
+        self.y = np.ascontiguousarray(r.y, dtype="int8")
+        self.g = np.ascontiguousarray(r.group_idx, dtype="int32")
+        self.N, self.D = self.X.shape
+        self.n = spec.n
+        self.G = (self.n - 2 * self.D) // self.D
+        names = [v.value_name for v in spec.vars]
+        assert names == ["mu", "sigma_log__", "z"], names
+
+    def __call__(self, q):
+        q = np.ascontiguousarray(q, dtype="float64")
+        grad = np.empty(self.n)
+        lp = self._fn(self.N, self.D, self.G, self.X.ctypes.data, self.y.ctypes.data, self.g.ctypes.data, q.ctypes.data, grad.ctypes.data)
+        return lp, grad

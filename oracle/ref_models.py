@@ -1,0 +1,293 @@
+"""NumPy restatement of the joint log-density + gradient (oracle; test-only).
+
+The reference obtains ``f(q) -> (logp, dlogp)`` by building a PyTensor graph
+(`Model.logp`, pymc/model/core.py:612-695) and differentiating it
+(`ValueGradFunction`, pymc/model/core.py:142-305).  PyTensor
+(``pytensor>=3.2.2,<3.3``, requirements.txt:6) is a third-party dependency
+absent from this image, so the arithmetic is restated here from the published
+log-density formulas in the reference's distribution classes, and every
+hand-written gradient is checked against torch float64 autograd in
+``tests/test_oracle_models.py``.
+
+`evaluate(spec, q)` consumes a ``pymc_amd.model_spec.ModelSpec`` by duck typing
+(attribute access only; nothing from the product package is imported).
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import scipy.linalg
+from scipy.special import expit
+
+LOG_SQRT_2PI = math.log(math.sqrt(2.0 * math.pi))
+LOG_SQRT_2_OVER_PI = math.log(math.sqrt(2.0 / math.pi))
+LOG_PI = math.log(math.pi)
+LOG_2 = math.log(2.0)
+
+# codes duplicated from pymc_amd/model_spec.py on purpose (oracle is independent)
+TR_NONE, TR_LOG, TR_LOGODDS, TR_INTERVAL = 0, 1, 2, 3
+OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
+(
+    D_NORMAL,
+    D_HALFNORMAL,
+    D_CAUCHY,
+    D_HALFCAUCHY,
+    D_STUDENTT,
+    D_BETA,
+    D_EXPONENTIAL,
+    D_UNIFORM,
+    D_BERNOULLI_LOGIT,
+    D_LOGNORMAL,
+    D_BERNOULLI,
+) = range(11)
+
+
+def softplus(x):
+    """PyTensor `softplus` (third party, pytensor/scalar/math.py `Softplus`):
+    the piecewise form of Maechler (2012): exp(x) | log1p(exp(x)) | x+exp(-x) | x."""
+    x = np.asarray(x, dtype="d")
+    out = np.empty_like(x)
+    a = x < -37.0
+    b = (~a) & (x < 18.0)
+    c = (~a) & (~b) & (x < 33.3)
+    d = ~(a | b | c)
+    out[a] = np.exp(x[a])
+    out[b] = np.log1p(np.exp(x[b]))
+    out[c] = x[c] + np.exp(-x[c])
+    out[d] = x[d]
+    return out
+
+
+# ---------------------------------------------------------------------------
+# transforms                      pymc/logprob/transforms.py:880-891,967-1088
+# ---------------------------------------------------------------------------
+
+
+def backward(tr, q, lo, hi):
+    """-> (x, dx/dq, log|J|, dlog|J|/dq)."""
+    if tr == TR_NONE:
+        return q, np.ones_like(q), np.zeros_like(q), np.zeros_like(q)
+    if tr == TR_LOG:  # transforms.py:880-891: x = exp(q), log|J| = q
+        x = np.exp(q)
+        return x, x, q, np.ones_like(q)
+    if tr == TR_LOGODDS:  # transforms.py:1076-1088
+        s = expit(q)
+        # log(s) + log1p(-s), evaluated in its stable softplus form
+        return s, s * (1 - s), -softplus(-q) - softplus(q), 1 - 2 * s
+    if tr == TR_INTERVAL:  # transforms.py:1017-1073 (both bounds finite)
+        s = expit(q)
+        x = s * hi + (1 - s) * lo
+        lj = math.log(hi - lo) - 2 * softplus(-q) - q
+        return x, (hi - lo) * s * (1 - s), lj, 1 - 2 * s
+    raise ValueError(tr)
+
+
+# ---------------------------------------------------------------------------
+# element-wise distributions: logp and partials w.r.t. (value, params...)
+# ---------------------------------------------------------------------------
+
+
+def _dist(dist, konst, a):
+    """a = list of broadcast argument arrays; returns (logp_i, [d/d a_k])."""
+    ninf = -np.inf
+    if dist == D_NORMAL:  # continuous.py:526-532
+        v, mu, sg = a
+        z = (v - mu) / sg
+        lp = -0.5 * z * z - LOG_SQRT_2PI - np.log(sg)
+        lp = np.where(sg > 0, lp, ninf)
+        return lp, [-z / sg, z / sg, (z * z - 1) / sg]
+    if dist == D_HALFNORMAL:  # continuous.py:909-916 (loc = 0)
+        v, sg = a
+        z = v / sg
+        lp = -0.5 * z * z + LOG_SQRT_2_OVER_PI - np.log(sg)
+        lp = np.where(v >= 0, lp, ninf)
+        lp = np.where(sg > 0, lp, ninf)
+        return lp, [-z / sg, (z * z - 1) / sg]
+    if dist == D_CAUCHY:  # continuous.py:2287-2293
+        v, al, be = a
+        z = (v - al) / be
+        lp = -LOG_PI - np.log(be) - np.log1p(z * z)
+        lp = np.where(be > 0, lp, ninf)
+        w = 2 * z / (1 + z * z)
+        return lp, [-w / be, w / be, (-1 + w * z) / be]
+    if dist == D_HALFCAUCHY:  # continuous.py:2383-2390
+        v, be = a
+        z = v / be
+        lp = LOG_2 - LOG_PI - np.log(be) - np.log1p(z * z)
+        lp = np.where(v >= 0, lp, ninf)
+        lp = np.where(be > 0, lp, ninf)
+        w = 2 * z / (1 + z * z)
+        return lp, [-w / be, (-1 + w * z) / be]
+    if dist == D_STUDENTT:  # continuous.py:1935-1950 ; nu constant, lam = sigma^-2
+        v, nu, mu, sg = a
+        z = (v - mu) / sg
+        lp = konst - np.log(sg) - (nu + 1.0) / 2.0 * np.log1p(z * z / nu)
+        lp = np.where(sg > 0, lp, ninf)
+        w = (nu + 1.0) * z / (nu + z * z)
+        return lp, [-w / sg, np.zeros_like(lp), w / sg, (-1 + w * z) / sg]
+    if dist == D_BETA:  # continuous.py:1248-1262 ; alpha, beta constant
+        v, al, be = a
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lp = np.where(al == 1.0, 0.0, (al - 1.0) * np.log(v)) + np.where(be == 1.0, 0.0, (be - 1.0) * np.log1p(-v)) + konst
+            dv = np.where(al == 1.0, 0.0, (al - 1.0) / v) - np.where(be == 1.0, 0.0, (be - 1.0) / (1 - v))
+        lp = np.where((v >= 0) & (v <= 1), lp, ninf)
+        return lp, [dv, np.zeros_like(lp), np.zeros_like(lp)]
+    if dist == D_EXPONENTIAL:  # continuous.py:1478-1486 with mu = 1/lam
+        v, lam = a
+        lp = np.log(lam) - v * lam
+        lp = np.where(v >= 0, lp, ninf)
+        lp = np.where(lam > 0, lp, ninf)
+        return lp, [-lam * np.ones_like(lp), 1 / lam - v]
+    if dist == D_UNIFORM:  # continuous.py:309-321 ; bounds constant
+        v, lo, hi = a
+        lp = np.where((v >= lo) & (v <= hi), -np.log(hi - lo) * np.ones_like(v), ninf)
+        lp = np.where(lo <= hi, lp, ninf)
+        return lp, [np.zeros_like(lp)] * 3
+    if dist == D_BERNOULLI_LOGIT:  # discrete.py:351-352,362-374 ; value is data in {0,1}
+        y, eta = a
+        lp = np.where(y != 0, -softplus(-eta), -softplus(eta))
+        lp = np.where((y < 0) | (y > 1), ninf, lp)
+        return lp, [np.zeros_like(lp), y - expit(eta)]
+    if dist == D_LOGNORMAL:  # continuous.py:1807-1819
+        v, mu, sg = a
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lv = np.log(v)
+            z = (lv - mu) / sg
+            lp = -0.5 * z * z - 0.5 * math.log(2.0 * math.pi) - np.log(sg) - lv
+        lp = np.where(v > 0, lp, ninf)
+        lp = np.where(sg > 0, lp, ninf)
+        return lp, [(-z / sg - 1) / v, z / sg, (z * z - 1) / sg]
+    if dist == D_BERNOULLI:  # discrete.py:362-374
+        y, p = a
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lp = np.where(y != 0, np.log(p), np.log1p(-p))
+            dp = np.where(y != 0, 1 / p, -1 / (1 - p))
+        lp = np.where((y < 0) | (y > 1), ninf, lp)
+        lp = np.where((p >= 0) & (p <= 1), lp, ninf)
+        return lp, [np.zeros_like(lp), dp]
+    raise ValueError(dist)
+
+
+def _operand(op, spec, x):
+    if op.kind == OP_CONST:
+        return np.asarray(op.c, dtype="d")
+    if op.kind == OP_DATA:
+        d = spec.data[op.ref]
+        return d if d.size > 1 else d.reshape(())
+    v = spec.vars[op.ref]
+    s = x[v.offset : v.offset + v.size]
+    return s if v.size > 1 else s.reshape(())
+
+
+def _push(op, spec, gx, g):
+    """Accumulate d logp / d operand into the constrained-space gradient."""
+    if op.kind != OP_VAR:
+        return
+    v = spec.vars[op.ref]
+    if v.size == 1:
+        gx[v.offset] += np.sum(g)
+    else:
+        gx[v.offset : v.offset + v.size] += np.broadcast_to(g, (v.size,))
+
+
+def evaluate(spec, q):
+    """Joint logp and gradient w.r.t. the raveled unconstrained vector.
+
+    Assembly follows pymc/model/core.py:666-695: every factor is summed on its
+    own, then the factor sums are added; Jacobian terms come from
+    pymc/logprob/basic.py:618-667.
+    """
+    q = np.asarray(q, dtype="d")
+    n = spec.n
+    x = np.empty(n)
+    dxdq = np.empty(n)
+    djac = np.empty(n)
+    logp = 0.0
+    for v in spec.vars:
+        sl = slice(v.offset, v.offset + v.size)
+        x[sl], dxdq[sl], lj, djac[sl] = backward(v.transform, q[sl], v.lower, v.upper)
+        logp += float(np.sum(lj))
+    gx = np.zeros(n)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for f in spec.factors:
+            args, ops = [], []
+            for t in f.args:
+                a, b, c = (_operand(o, spec, x) for o in (t.a, t.b, t.c))
+                args.append(np.broadcast_to(a + b * c, (f.size,)))
+                ops.append((t, b, c))
+            lp, partials = _dist(f.dist, f.konst, args)
+            logp += float(np.sum(lp))
+            for (t, b, c), g in zip(ops, partials):
+                _push(t.a, spec, gx, g)
+                _push(t.b, spec, gx, g * c)
+                _push(t.c, spec, gx, g * b)
+        if spec.logit_rows is not None:
+            lp, g_extra = _logit_rows(spec, spec.logit_rows, x)
+            logp += lp
+            gx += g_extra
+        if spec.mvnormal is not None:
+            lp, g_extra = _mvnormal(spec, spec.mvnormal, x)
+            logp += lp
+            gx += g_extra
+    grad = gx * dxdq + djac
+    return logp, grad
+
+
+def _logit_rows(spec, node, x):
+    """Bernoulli(logit_p = X_i . beta_g(i)) rows, beta_g = mu + sigma * z_g.
+
+    discrete.py:351-352 (`logit_p -> sigmoid`), :362-374 (switch(value, log p,
+    log1p(-p))) with PyTensor's stabilising rewrites log(sigmoid(x)) ->
+    -softplus(-x), log1p(-sigmoid(x)) -> -softplus(x).
+    """
+    vm, vs, vz = (spec.vars[i] for i in (node.mu, node.sigma, node.z))
+    D = vm.size
+    mu = x[vm.offset : vm.offset + D]
+    sg = x[vs.offset : vs.offset + D]
+    z = x[vz.offset : vz.offset + vz.size].reshape(-1, D)
+    G = z.shape[0]
+    beta = mu + sg * z
+    eta = np.einsum("nd,nd->n", node.X, beta[node.group_idx])
+    y = node.y
+    lp = np.where(y != 0, -softplus(-eta), -softplus(eta))
+    r = y - expit(eta)
+    dbeta = np.zeros((G, D))
+    np.add.at(dbeta, node.group_idx, r[:, None] * node.X)
+    g = np.zeros(spec.n)
+    g[vm.offset : vm.offset + D] = dbeta.sum(0)
+    g[vs.offset : vs.offset + D] = (dbeta * z).sum(0)
+    g[vz.offset : vz.offset + vz.size] = (dbeta * sg).ravel()
+    return float(lp.sum()), g
+
+
+def _mvnormal(spec, node, x):
+    """multivariate.py:165-185 (Cholesky + lower-triangular solve), :275-295."""
+    v = spec.vars[node.var]
+    k = v.size
+    L = getattr(node, "_oracle_chol", None)
+    if L is None:
+        L = scipy.linalg.cholesky(node.cov, lower=True)
+        node._oracle_chol = L
+    delta = x[v.offset : v.offset + k] - node.mu
+    w = scipy.linalg.solve_triangular(L, delta, lower=True)
+    logdet = np.log(np.diag(L)).sum()
+    lp = -0.5 * k * math.log(2 * math.pi) - 0.5 * np.dot(w, w) - logdet
+    g = np.zeros(spec.n)
+    g[v.offset : v.offset + k] = -scipy.linalg.solve_triangular(L.T, w, lower=False)
+    return float(lp), g
+
+
+class SpecLogpGrad:
+    """Callable ``q -> (logp, grad)`` with the `ValueGradFunction` contract
+    (pymc/model/core.py:286-300) for a ModelSpec."""
+
+    def __init__(self, spec):
+        self.spec = spec
+        self.n = spec.n
+        self.calls = 0
+
+    def __call__(self, q):
+        self.calls += 1
+        return evaluate(self.spec, q)

@@ -1,0 +1,230 @@
+"""ctypes binding of libnuts_mi355.so (the C ABI in include/nuts_mi355.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+visible the product path raises.  The library is built in-tree by
+``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnuts_mi355.so")
+
+NUTS_OK, NUTS_E_BAD_ENERGY, NUTS_E_ARG, NUTS_E_HIP, NUTS_E_LINALG = 0, 1, 2, 3, 4
+
+
+class EngineError(RuntimeError):
+    """A HIP/runtime failure inside libnuts_mi355 (maps to ParallelSamplingError-style reporting)."""
+
+
+class Operand(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ref", C.c_int32), ("c", C.c_double)]
+
+
+class Term(C.Structure):
+    _fields_ = [("a", Operand), ("b", Operand), ("c", Operand)]
+
+
+class Factor(C.Structure):
+    _fields_ = [
+        ("dist", C.c_int32),
+        ("size", C.c_int32),
+        ("nargs", C.c_int32),
+        ("pad", C.c_int32),
+        ("konst", C.c_double),
+        ("arg", Term * 4),
+    ]
+
+
+class Var(C.Structure):
+    _fields_ = [
+        ("offset", C.c_int32),
+        ("size", C.c_int32),
+        ("transform", C.c_int32),
+        ("pad", C.c_int32),
+        ("lower", C.c_double),
+        ("upper", C.c_double),
+    ]
+
+
+class DataRef(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("size", C.c_int64)]
+
+
+class ModelSpecC(C.Structure):
+    _fields_ = [
+        ("n_vars", C.c_int32),
+        ("n_factors", C.c_int32),
+        ("n_data", C.c_int32),
+        ("pad", C.c_int32),
+        ("vars", C.POINTER(Var)),
+        ("factors", C.POINTER(Factor)),
+        ("data", C.POINTER(DataRef)),
+        ("data_pool", C.POINTER(C.c_double)),
+        ("data_pool_len", C.c_int64),
+        ("rows_N", C.c_int64),
+        ("rows_D", C.c_int32),
+        ("rows_G", C.c_int32),
+        ("rows_X", C.POINTER(C.c_double)),
+        ("rows_y", C.POINTER(C.c_int8)),
+        ("rows_gid", C.POINTER(C.c_int32)),
+        ("rows_mu", C.c_int32),
+        ("rows_sigma", C.c_int32),
+        ("rows_z", C.c_int32),
+        ("pad2", C.c_int32),
+        ("mvn_var", C.c_int32),
+        ("mvn_k", C.c_int32),
+        ("mvn_mu", C.POINTER(C.c_double)),
+        ("mvn_prec", C.POINTER(C.c_double)),
+        ("mvn_logdet", C.c_double),
+    ]
+
+
+class ChainConfig(C.Structure):
+    _fields_ = [
+        ("step_scale", C.c_double),
+        ("Emax", C.c_double),
+        ("target_accept", C.c_double),
+        ("gamma", C.c_double),
+        ("k", C.c_double),
+        ("t0", C.c_double),
+        ("adapt_step_size", C.c_int32),
+        ("max_treedepth", C.c_int32),
+        ("early_max_treedepth", C.c_int32),
+        ("potential", C.c_int32),
+        ("initial_mean", C.POINTER(C.c_double)),
+        ("initial_diag", C.POINTER(C.c_double)),
+        ("initial_weight", C.c_double),
+        ("adaptation_window", C.c_int32),
+        ("discard_window", C.c_int32),
+        ("adaptation_window_multiplier", C.c_double),
+        ("early_update", C.c_int32),
+        ("pad", C.c_int32),
+    ]
+
+
+class DrawStats(C.Structure):
+    _fields_ = [
+        ("depth", C.c_int64),
+        ("step_size", C.c_double),
+        ("mean_tree_accept", C.c_double),
+        ("step_size_bar", C.c_double),
+        ("tree_size", C.c_double),
+        ("diverging", C.c_int32),
+        ("reached_max_treedepth", C.c_int32),
+        ("divergences", C.c_int64),
+        ("energy_error", C.c_double),
+        ("energy", C.c_double),
+        ("max_energy_error", C.c_double),
+        ("model_logp", C.c_double),
+        ("process_time_diff", C.c_double),
+        ("perf_counter_diff", C.c_double),
+        ("perf_counter_start", C.c_double),
+        ("index_in_trajectory", C.c_int64),
+        ("n_uniforms_consumed", C.c_int32),
+        ("warning", C.c_int32),
+        ("divergence_energy_change", C.c_double),
+        ("n_model_evals", C.c_int64),
+    ]
+
+
+class HmcStats(C.Structure):
+    _fields_ = [
+        ("step_size", C.c_double),
+        ("step_size_bar", C.c_double),
+        ("accept", C.c_double),
+        ("energy_error", C.c_double),
+        ("energy", C.c_double),
+        ("model_logp", C.c_double),
+        ("path_length", C.c_double),
+        ("n_steps", C.c_int64),
+        ("divergences", C.c_int64),
+        ("diverging", C.c_int32),
+        ("accepted", C.c_int32),
+        ("process_time_diff", C.c_double),
+        ("perf_counter_diff", C.c_double),
+        ("perf_counter_start", C.c_double),
+    ]
+
+
+_PD = C.POINTER(C.c_double)
+_VP = C.c_void_p
+
+# every symbol include/nuts_mi355.h declares: (restype, argtypes)
+SYMBOLS = {
+    "nuts_device_count": (C.c_int, []),
+    "nuts_set_device": (C.c_int, [C.c_int]),
+    "nuts_last_error": (C.c_char_p, []),
+    "nuts_model_create": (_VP, [C.POINTER(ModelSpecC)]),
+    "nuts_model_destroy": (None, [_VP]),
+    "nuts_model_ndim": (C.c_int32, [_VP]),
+    "nuts_model_logp_grad": (C.c_int, [_VP, _PD, _PD, _PD]),
+    "nuts_model_time_logp_grad": (C.c_int, [_VP, _PD, C.c_int, _PD, _PD]),
+    "nuts_model_algorithmic_bytes": (C.c_int64, [_VP]),
+    "nuts_chain_config_default": (None, [C.POINTER(ChainConfig)]),
+    "nuts_chain_create": (_VP, [_VP, C.POINTER(ChainConfig)]),
+    "nuts_chain_destroy": (None, [_VP]),
+    "nuts_chain_reset_tuning": (C.c_int, [_VP]),
+    "nuts_chain_set_tune": (C.c_int, [_VP, C.c_int]),
+    "nuts_chain_set_iter_count": (C.c_int, [_VP, C.c_int64]),
+    "nuts_chain_draw": (C.c_int, [_VP, _PD, _PD, _PD, C.c_int32, _PD, _PD, C.POINTER(DrawStats)]),
+    "nuts_chain_draw_hmc": (C.c_int, [_VP, _PD, _PD, _PD, C.c_double, C.c_int32, _PD, _PD, C.POINTER(HmcStats)]),
+    "nuts_chain_leapfrog_test": (C.c_int, [_VP, _PD, _PD, C.c_double, C.c_int32, _PD, _PD, _PD]),
+    "nuts_chain_state_size": (C.c_int64, [_VP]),
+    "nuts_chain_get_state": (C.c_int, [_VP, _VP]),
+    "nuts_chain_set_state": (C.c_int, [_VP, _VP]),
+    "nuts_chain_get_scalar": (C.c_int, [_VP, C.c_char_p, _PD]),
+    "nuts_chain_get_vector": (C.c_int, [_VP, C.c_char_p, _PD]),
+    "nuts_chain_welford_export": (C.c_int, [_VP, _VP]),
+    "nuts_chain_welford_import": (C.c_int, [_VP, _VP]),
+    "nuts_chain_set_log_step_bar": (C.c_int, [_VP, C.c_double, C.c_double]),
+    "nuts_chain_profile": (C.c_int, [_VP, C.c_int]),
+    "nuts_chain_profile_read": (C.c_int, [_VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libnuts_mi355.so and bind every declared symbol; raise if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). pymc_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().nuts_last_error().decode()
+
+
+def dptr(a: np.ndarray):
+    return a.ctypes.data_as(_PD)
+
+
+def check(rc: int, what: str = ""):
+    if rc == NUTS_OK:
+        return
+    msg = last_error()
+    if rc == NUTS_E_BAD_ENERGY:
+        from pymc_amd.exceptions import SamplingError
+
+        raise SamplingError(f"Bad initial energy: {msg}")
+    if rc == NUTS_E_ARG:
+        raise ValueError(f"{what}: {msg}")
+    raise EngineError(f"{what}: {msg} (code {rc})")

@@ -1,0 +1,80 @@
+// Device-side helpers: wavefront (64-lane) and workgroup reductions with a FIXED
+// summation order (results are bit-reproducible run to run -- the reference
+// promises "same seed => identical draws", tests/sampling/test_mcmc.py:80-109,
+// so no floating-point atomics anywhere), plus the scalar special functions the
+// log-densities need.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+  return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ double wave_sum_all(double v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;  // valid in every lane (butterfly: same order for every lane pair)
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) {
+    int o = __shfl_xor(v, off, WAVE);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// Workgroup sum; `sm` must hold blockDim.x/64 doubles.  Result valid in thread 0
+// (and broadcast through sm[0] after the trailing barrier when BCAST).
+template <bool BCAST>
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6, nw = (blockDim.x + WAVE - 1) >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // protect sm from a previous use
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < nw; ++i) r += sm[i];
+    if (BCAST) sm[0] = r;
+  }
+  if (BCAST) {
+    __syncthreads();
+    r = sm[0];
+  }
+  return r;
+}
+
+// PyTensor's softplus (third-party `pytensor/scalar/math.py` Softplus; Maechler 2012)
+__device__ __forceinline__ double softplus_d(double x) {
+  if (x < -37.0) return exp(x);
+  if (x < 18.0) return log1p(exp(x));
+  if (x < 33.3) return x + exp(-x);
+  return x;
+}
+
+__device__ __forceinline__ double sigmoid_d(double x) {
+  // expit: 1/(1+exp(-x)) evaluated without overflow
+  if (x >= 0) {
+    double e = exp(-x);
+    return 1.0 / (1.0 + e);
+  }
+  double e = exp(x);
+  return e / (1.0 + e);
+}
+
+// numpy.logaddexp semantics (used by nuts.py:374,412,464)
+__host__ __device__ __forceinline__ double logaddexp_d(double x, double y) {
+  if (x == y) return x + 0.6931471805599453094;  // also handles (+-inf, +-inf)
+  double t = x - y;
+  if (t > 0) return x + log1p(exp(-t));
+  if (t <= 0) return y + log1p(exp(t));
+  return t;  // NaN
+}

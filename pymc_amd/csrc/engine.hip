@@ -1,0 +1,883 @@
+// libnuts_mi355.so -- host side of the C ABI declared in include/nuts_mi355.h.
+//
+// One library stream per model; every kernel of a draw is enqueued on it and the
+// host synchronises once per tree doubling (it only needs to know "stop or keep
+// doubling").  All trajectory state stays in HBM for the whole chain; per draw the
+// host uploads (q0, normals, uniforms) in one pinned copy and downloads
+// (q, grad, stats).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "chain_kernels.h"
+#include "model_kernels.h"
+#include "nuts_mi355.h"
+
+static thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(_e);                            \
+      return NUTS_E_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+#define HIPCHK_NULL(expr)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(_e);                            \
+      return nullptr;                                                                       \
+    }                                                                                       \
+  } while (0)
+
+template <typename T>
+static T* dev_alloc(size_t count) {
+  void* p = nullptr;
+  if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+  return static_cast<T*>(p);
+}
+template <typename T>
+static T* dev_upload(const T* src, size_t count) {
+  T* p = dev_alloc<T>(count);
+  if (p && count) hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+  return p;
+}
+
+// ===========================================================================
+// model
+// ===========================================================================
+struct nuts_model {
+  ModelDev md{};
+  hipStream_t stream = nullptr;
+  std::vector<void*> owned;  // device allocations
+  double* q_dev = nullptr;   // [n] staging for nuts_model_logp_grad
+  double* g_dev = nullptr;
+  double* lp_dev = nullptr;
+  double* host_pin = nullptr;  // pinned [2n+2]
+  int rows_grid = 0, groups_grid = 0, final_grid = 0, mvn_grid = 0;
+  int64_t alg_bytes = 0;
+  // profiling of the dominant kernel
+  bool profile = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t ev_used = 0;
+  int64_t dom_launches = 0;
+  int sample_every = 1;
+
+  template <typename T>
+  T* keep(T* p) {
+    owned.push_back((void*)p);
+    return p;
+  }
+};
+
+extern "C" int nuts_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" int nuts_set_device(int device) {
+  HIPCHK(hipSetDevice(device));
+  return NUTS_OK;
+}
+extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
+
+static int model_enqueue(nuts_model* m, const double* q_dev, double* g_dev, double* lp_dev, const int* abort_flag) {
+  ModelDev& md = m->md;
+  hipLaunchKernelGGL(k_model_elem, dim3(1), dim3(ELEM_THREADS), 0, m->stream, md, q_dev, abort_flag);
+  if (md.has_logit) {
+    const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
+    if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
+    switch (md.lg.D) {
+      case 8: hipLaunchKernelGGL(k_logit_rows<8>, dim3(m->rows_grid), dim3(ROWS_BLOCK), 0, m->stream, md.lg, q_dev, abort_flag); break;
+      case 4: hipLaunchKernelGGL(k_logit_rows<4>, dim3(m->rows_grid), dim3(ROWS_BLOCK), 0, m->stream, md.lg, q_dev, abort_flag); break;
+      case 2: hipLaunchKernelGGL(k_logit_rows<2>, dim3(m->rows_grid), dim3(ROWS_BLOCK), 0, m->stream, md.lg, q_dev, abort_flag); break;
+    }
+    if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; }
+    m->dom_launches++;
+    switch (md.lg.D) {
+      case 8: hipLaunchKernelGGL(k_logit_groups<8>, dim3(m->groups_grid), dim3(256), 0, m->stream, md.lg, md, q_dev, abort_flag); break;
+      case 4: hipLaunchKernelGGL(k_logit_groups<4>, dim3(m->groups_grid), dim3(256), 0, m->stream, md.lg, md, q_dev, abort_flag); break;
+      case 2: hipLaunchKernelGGL(k_logit_groups<2>, dim3(m->groups_grid), dim3(256), 0, m->stream, md.lg, md, q_dev, abort_flag); break;
+    }
+  }
+  if (md.has_mvn) {
+    const bool prof = m->profile && !md.has_logit && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
+    if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
+    hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid), dim3(256), 0, m->stream, md.mv, md, q_dev, abort_flag);
+    if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; }
+    if (!md.has_logit) m->dom_launches++;
+  }
+  switch (md.has_logit ? md.lg.D : 8) {
+    case 8: hipLaunchKernelGGL(k_model_final<8>, dim3(m->final_grid), dim3(256), 0, m->stream, md, g_dev, lp_dev, abort_flag); break;
+    case 4: hipLaunchKernelGGL(k_model_final<4>, dim3(m->final_grid), dim3(256), 0, m->stream, md, g_dev, lp_dev, abort_flag); break;
+    case 2: hipLaunchKernelGGL(k_model_final<2>, dim3(m->final_grid), dim3(256), 0, m->stream, md, g_dev, lp_dev, abort_flag); break;
+  }
+  return NUTS_OK;
+}
+
+extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
+  if (!s || s->n_vars <= 0) { g_err = "empty model spec"; return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device visible: libnuts_mi355 requires an MI355X (gfx950); there is no CPU fallback";
+    return nullptr;
+  }
+  auto* m = new nuts_model();
+  ModelDev& md = m->md;
+  HIPCHK_NULL(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  int n = 0;
+  for (int i = 0; i < s->n_vars; ++i) n = std::max(n, s->vars[i].offset + s->vars[i].size);
+  md.n = n; md.n_vars = s->n_vars; md.n_factors = s->n_factors; md.n_data = s->n_data;
+  md.vars = m->keep(dev_upload(s->vars, s->n_vars));
+  md.factors = m->keep(dev_upload(s->factors, s->n_factors));
+  md.data = m->keep(dev_upload(s->data, s->n_data));
+  md.pool = m->keep(dev_upload(s->data_pool, s->data_pool_len));
+  md.x = m->keep(dev_alloc<double>(n));
+  md.dxdq = m->keep(dev_alloc<double>(n));
+  md.djac = m->keep(dev_alloc<double>(n));
+  md.gx = m->keep(dev_alloc<double>(n));
+  md.gdense = m->keep(dev_alloc<double>(n));
+  md.lp_elem = m->keep(dev_alloc<double>(1));
+  hipMemset(md.gdense, 0, n * sizeof(double));
+  m->q_dev = m->keep(dev_alloc<double>(n));
+  m->g_dev = m->keep(dev_alloc<double>(n));
+  m->lp_dev = m->keep(dev_alloc<double>(2));
+  HIPCHK_NULL(hipHostMalloc((void**)&m->host_pin, (2 * (size_t)n + 2) * sizeof(double), hipHostMallocDefault));
+  m->final_grid = std::max(1, std::min(256, (n + 255) / 256));
+  m->alg_bytes = 0;
+
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+  if (s->rows_N > 0) {
+    const int D = s->rows_D;
+    if (!(D == 8 || D == 4 || D == 2)) { g_err = "logit rows: D must be 2, 4 or 8"; delete m; return nullptr; }
+    LogitDev& lg = md.lg;
+    md.has_logit = 1;
+    lg.N = s->rows_N; lg.D = D; lg.G = s->rows_G;
+    lg.Npad = (lg.N + ROWS_PER_SPAN - 1) / ROWS_PER_SPAN * ROWS_PER_SPAN;
+    lg.n_spans = lg.Npad / ROWS_PER_SPAN;
+    const nuts_var &vmu = s->vars[s->rows_mu], &vsg = s->vars[s->rows_sigma], &vz = s->vars[s->rows_z];
+    if (vmu.size != D || vsg.size != D || vz.size != (int64_t)lg.G * D || vmu.transform != NUTS_TR_NONE ||
+        vz.transform != NUTS_TR_NONE || !(vsg.transform == NUTS_TR_NONE || vsg.transform == NUTS_TR_LOG)) {
+      g_err = "logit rows: mu/sigma/z shapes or transforms unsupported"; delete m; return nullptr;
+    }
+    lg.off_mu = vmu.offset; lg.off_sigma = vsg.offset; lg.off_z = vz.offset; lg.sigma_tr = vsg.transform;
+    // HBM layout: X column-major [D][Npad] (one coalesced 16 B load per lane per column), y int8, gid int32
+    {
+      std::vector<double> xt((size_t)D * lg.Npad, 0.0);
+      for (int64_t i = 0; i < lg.N; ++i)
+        for (int d = 0; d < D; ++d) xt[(size_t)d * lg.Npad + i] = s->rows_X[i * D + d];
+      lg.Xt = m->keep(dev_upload(xt.data(), xt.size()));
+    }
+    std::vector<int32_t> gid(lg.Npad);
+    std::vector<int8_t> yy(lg.Npad, 0);
+    for (int64_t i = 0; i < lg.N; ++i) {
+      gid[i] = s->rows_gid[i]; yy[i] = s->rows_y[i];
+      if (i > 0 && gid[i] < gid[i - 1]) { g_err = "logit rows: group ids must be sorted"; delete m; return nullptr; }
+      if (gid[i] < 0 || gid[i] >= lg.G) { g_err = "logit rows: group id out of range"; delete m; return nullptr; }
+    }
+    for (int64_t i = lg.N; i < lg.Npad; ++i) gid[i] = gid[lg.N - 1];
+    lg.gid = m->keep(dev_upload(gid.data(), gid.size()));
+    lg.y = m->keep(dev_upload(yy.data(), yy.size()));
+    // launch geometry: enough waves to fill the chip, at most one span per wave
+    const int waves_per_block = ROWS_BLOCK / WAVE;
+    int64_t want_waves = (int64_t)cus * 8 * waves_per_block;  // 8 workgroups of 4 waves per CU
+    want_waves = std::min<int64_t>(want_waves, lg.n_spans);
+    m->rows_grid = (int)((want_waves + waves_per_block - 1) / waves_per_block);
+    lg.n_waves = m->rows_grid * waves_per_block;
+    // static segment table: runs of equal group id inside each wave's row range
+    std::vector<int32_t> seg_base(lg.n_waves, 0), seg_gid;
+    for (int w = 0; w < lg.n_waves; ++w) {
+      const int64_t s0 = (int64_t)w * lg.n_spans / lg.n_waves, s1 = (int64_t)(w + 1) * lg.n_spans / lg.n_waves;
+      seg_base[w] = (int32_t)seg_gid.size();
+      int prev = -1;
+      for (int64_t r = s0 * ROWS_PER_SPAN; r < s1 * ROWS_PER_SPAN; ++r)
+        if (gid[r] != prev) { prev = gid[r]; seg_gid.push_back(prev); }
+    }
+    lg.n_seg = (int32_t)seg_gid.size();
+    std::vector<int32_t> gptr(lg.G + 1, 0);
+    for (int32_t g : seg_gid) gptr[g + 1]++;
+    for (int g = 0; g < lg.G; ++g) gptr[g + 1] += gptr[g];
+    // segments are emitted in row order and rows are sorted by group => the segments of a group are contiguous
+    lg.seg_base = m->keep(dev_upload(seg_base.data(), seg_base.size()));
+    lg.gseg_ptr = m->keep(dev_upload(gptr.data(), gptr.size()));
+    lg.seg_part = m->keep(dev_alloc<double>((size_t)lg.n_seg * D));
+    lg.wave_lp = m->keep(dev_alloc<double>(lg.n_waves));
+    const int gpb = 256 / D;
+    m->groups_grid = (lg.G + gpb - 1) / gpb;
+    lg.n_gblk = m->groups_grid;
+    lg.gblk_part = m->keep(dev_alloc<double>((size_t)lg.n_gblk * 2 * D));
+    m->alg_bytes += lg.N * (8 * (int64_t)D + 1 + 4);  // X row + y + group id
+  }
+  if (s->mvn_k > 0) {
+    md.has_mvn = 1;
+    MvnDev& mv = md.mv;
+    mv.k = s->mvn_k; mv.off = s->vars[s->mvn_var].offset;
+    mv.mu = m->keep(dev_upload(s->mvn_mu, mv.k));
+    mv.prec = m->keep(dev_upload(s->mvn_prec, (size_t)mv.k * mv.k));
+    mv.rowq = m->keep(dev_alloc<double>(mv.k));
+    mv.konst = -0.5 * mv.k * std::log(2.0 * M_PI) - s->mvn_logdet;
+    m->mvn_grid = (mv.k + (256 / WAVE) - 1) / (256 / WAVE);
+    m->alg_bytes += 8 * (int64_t)mv.k * mv.k;
+  }
+  for (void* p : m->owned)
+    if (!p) { g_err = "device allocation failed"; delete m; return nullptr; }
+  HIPCHK_NULL(hipDeviceSynchronize());
+  return m;
+}
+
+extern "C" void nuts_model_destroy(nuts_model* m) {
+  if (!m) return;
+  hipStreamSynchronize(m->stream);
+  for (void* p : m->owned) hipFree(p);
+  for (auto e : m->ev) hipEventDestroy(e);
+  if (m->host_pin) hipHostFree(m->host_pin);
+  hipStreamDestroy(m->stream);
+  delete m;
+}
+
+extern "C" int32_t nuts_model_ndim(const nuts_model* m) { return m ? m->md.n : -1; }
+extern "C" int64_t nuts_model_algorithmic_bytes(const nuts_model* m) { return m ? m->alg_bytes : 0; }
+
+extern "C" int nuts_model_logp_grad(nuts_model* m, const double* q, double* logp, double* grad) {
+  if (!m || !q || !logp) { g_err = "null argument"; return NUTS_E_ARG; }
+  const int n = m->md.n;
+  std::memcpy(m->host_pin, q, n * sizeof(double));
+  HIPCHK(hipMemcpyAsync(m->q_dev, m->host_pin, n * sizeof(double), hipMemcpyHostToDevice, m->stream));
+  model_enqueue(m, m->q_dev, m->g_dev, m->lp_dev, nullptr);
+  HIPCHK(hipMemcpyAsync(m->host_pin + n, m->g_dev, n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipMemcpyAsync(m->host_pin + 2 * n, m->lp_dev, sizeof(double), hipMemcpyDeviceToHost, m->stream));
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipGetLastError());
+  *logp = m->host_pin[2 * n];
+  if (grad) std::memcpy(grad, m->host_pin + n, n * sizeof(double));
+  return NUTS_OK;
+}
+
+static void profile_enable(nuts_model* m, bool on, int sample_every, size_t max_pairs) {
+  m->profile = on;
+  m->sample_every = std::max(1, sample_every);
+  m->ev_used = 0;
+  m->dom_launches = 0;
+  while (on && m->ev.size() < 2 * max_pairs) {
+    hipEvent_t e;
+    hipEventCreate(&e);
+    m->ev.push_back(e);
+  }
+}
+static double profile_sum_ms(nuts_model* m, int64_t* pairs) {
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) tot += ms;
+  }
+  if (pairs) *pairs = (int64_t)(m->ev_used / 2);
+  return tot;
+}
+
+extern "C" int nuts_model_time_logp_grad(nuts_model* m, const double* q, int reps, double* ms_total, double* ms_dominant) {
+  if (!m || !q || reps <= 0) { g_err = "bad argument"; return NUTS_E_ARG; }
+  const int n = m->md.n;
+  HIPCHK(hipMemcpy(m->q_dev, q, n * sizeof(double), hipMemcpyHostToDevice));
+  for (int i = 0; i < 3; ++i) model_enqueue(m, m->q_dev, m->g_dev, m->lp_dev, nullptr);
+  HIPCHK(hipStreamSynchronize(m->stream));
+  profile_enable(m, true, 1, (size_t)reps);
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  hipEventRecord(a, m->stream);
+  for (int i = 0; i < reps; ++i) model_enqueue(m, m->q_dev, m->g_dev, m->lp_dev, nullptr);
+  hipEventRecord(b, m->stream);
+  HIPCHK(hipStreamSynchronize(m->stream));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a); hipEventDestroy(b);
+  int64_t pairs = 0;
+  const double dom = profile_sum_ms(m, &pairs);
+  if (ms_total) *ms_total = ms / reps;
+  if (ms_dominant) *ms_dominant = pairs ? dom / pairs : 0.0;
+  profile_enable(m, false, 1, 0);
+  return NUTS_OK;
+}
+
+// ===========================================================================
+// chain
+// ===========================================================================
+struct DualAvg {  // pymc/step_methods/step_sizes.py:41-84
+  double initial_step, target, gamma, k, t0;
+  double log_step, log_bar, hbar, mu;
+  int64_t count;
+  void reset() {
+    log_step = std::log(initial_step); log_bar = log_step; hbar = 0.0; count = 1; mu = std::log(10 * initial_step);
+  }
+  double current(bool tune) const { return tune ? std::exp(log_step) : std::exp(log_bar); }
+  void update(double accept, bool tune) {
+    if (!tune) return;
+    const double w = 1.0 / (count + t0);
+    hbar = (1 - w) * hbar + w * (target - accept);
+    log_step = mu - hbar * std::sqrt((double)count) / gamma;
+    const double mk = std::pow((double)count, -k);
+    log_bar = mk * log_step + (1 - mk) * log_bar;
+    count += 1;
+  }
+};
+
+struct StateHeader {  // host scalars of the sampling state
+  int64_t magic, n;
+  DualAvg da;
+  int64_t iter_count, divergences, n_samples, adaptation_window;
+  int32_t tune, fg_is_a, pad0, pad1;
+  double fg_count, bg_count;
+};
+
+struct nuts_chain {
+  nuts_model* m = nullptr;
+  nuts_chain_config cfg{};
+  int n = 0;
+  ArenaDev A{};
+  std::vector<void*> owned;
+  // potential (device)
+  double *var = nullptr, *stds = nullptr, *inv_stds = nullptr;
+  double *wa_mean = nullptr, *wa_m2 = nullptr, *wb_mean = nullptr, *wb_m2 = nullptr;  // two Welford estimators
+  bool fg_is_a = true;
+  double fg_count = 0, bg_count = 0;
+  std::vector<double> initial_mean, initial_diag;
+  int64_t n_samples = 0, adaptation_window = 101;
+  // step
+  DualAvg da{};
+  bool tune = true;
+  int64_t iter_count = 0, divergences = 0;
+  double step_size = 0;
+  // staging
+  double* stage_dev = nullptr;   // [2n + NUNI]
+  double* stage_host = nullptr;  // pinned
+  double* out_dev = nullptr;     // [2n]
+  double* out_host = nullptr;    // pinned [2n]
+  HostStatus* st_dev = nullptr;
+  HostStatus* st_host = nullptr;
+  DrawOut* do_dev = nullptr;
+  DrawOut* do_host = nullptr;
+  int64_t leapfrogs = 0;
+  int n_uni_cap = 0;
+  template <typename T>
+  T* keep(T* p) { owned.push_back((void*)p); return p; }
+};
+
+extern "C" void nuts_chain_config_default(nuts_chain_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->step_scale = 0.25; c->Emax = 1000; c->target_accept = 0.8; c->gamma = 0.05; c->k = 0.75; c->t0 = 10;
+  c->adapt_step_size = 1; c->max_treedepth = 10; c->early_max_treedepth = 8;
+  c->potential = NUTS_POT_DIAG_ADAPT; c->initial_weight = 0; c->adaptation_window = 101; c->discard_window = 50;
+  c->adaptation_window_multiplier = 1; c->early_update = 0;
+}
+
+static int potential_reset(nuts_chain* c) {  // quadpotential.py:297-306
+  const int n = c->n;
+  std::vector<double> st(n), inv(n), m2(n);
+  const double w = c->cfg.initial_weight;
+  for (int i = 0; i < n; ++i) { st[i] = std::sqrt(c->initial_diag[i]); inv[i] = 1.0 / st[i]; m2[i] = c->initial_diag[i] * w; }
+  HIPCHK(hipMemcpy(c->var, c->initial_diag.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->stds, st.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->inv_stds, inv.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  if (c->cfg.potential == NUTS_POT_DIAG_ADAPT) {
+    c->fg_is_a = true;
+    HIPCHK(hipMemcpy(c->wa_mean, c->initial_mean.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->wa_m2, m2.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->wb_mean, 0, n * sizeof(double)));
+    HIPCHK(hipMemset(c->wb_m2, 0, n * sizeof(double)));
+    c->fg_count = w; c->bg_count = 0;
+  }
+  c->n_samples = 0;
+  return NUTS_OK;
+}
+
+extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config* cfg) {
+  if (!m || !cfg) { g_err = "null argument"; return nullptr; }
+  if (cfg->potential != NUTS_POT_DIAG_ADAPT && cfg->potential != NUTS_POT_DIAG) {
+    g_err = "potential kind not implemented on device yet (dense potentials are a later round)"; return nullptr;
+  }
+  if (cfg->max_treedepth < 1 || cfg->max_treedepth > MAX_LEVELS - 1) { g_err = "max_treedepth out of range (1..11)"; return nullptr; }
+  auto* c = new nuts_chain();
+  c->m = m; c->cfg = *cfg; c->n = m->md.n;
+  const int n = c->n;
+  c->initial_mean.assign(n, 0.0);
+  c->initial_diag.assign(n, 1.0);
+  if (cfg->initial_mean) c->initial_mean.assign(cfg->initial_mean, cfg->initial_mean + n);
+  if (cfg->initial_diag) c->initial_diag.assign(cfg->initial_diag, cfg->initial_diag + n);
+  else if (cfg->potential == NUTS_POT_DIAG_ADAPT) c->cfg.initial_weight = 1;  // quadpotential.py:280-282
+  c->cfg.initial_mean = nullptr; c->cfg.initial_diag = nullptr;
+  c->adaptation_window = cfg->adaptation_window;
+  ArenaDev& A = c->A;
+  A.n = n;
+  const int maxd = std::max(cfg->max_treedepth, cfg->early_max_treedepth);
+  A.S = 1 << maxd;
+  A.ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
+  A.nblk = (n + VEC_THREADS * A.ept - 1) / (VEC_THREADS * A.ept);
+  const size_t arena = (size_t)A.S * n;
+  A.Q = c->keep(dev_alloc<double>(arena)); A.P = c->keep(dev_alloc<double>(arena));
+  A.V = c->keep(dev_alloc<double>(arena)); A.G = c->keep(dev_alloc<double>(arena));
+  A.E = c->keep(dev_alloc<double>(A.S)); A.LOGP = c->keep(dev_alloc<double>(A.S));
+  A.PS = c->keep(dev_alloc<double>((size_t)MAX_LEVELS * n));
+  A.PSUM = c->keep(dev_alloc<double>(n));
+  A.dotp = c->keep(dev_alloc<double>((size_t)A.nblk * NDOT));
+  A.ctl = c->keep(dev_alloc<Ctl>(1));
+  c->var = c->keep(dev_alloc<double>(n)); c->stds = c->keep(dev_alloc<double>(n)); c->inv_stds = c->keep(dev_alloc<double>(n));
+  c->wa_mean = c->keep(dev_alloc<double>(n)); c->wa_m2 = c->keep(dev_alloc<double>(n));
+  c->wb_mean = c->keep(dev_alloc<double>(n)); c->wb_m2 = c->keep(dev_alloc<double>(n));
+  A.var = c->var; A.inv_stds = c->inv_stds;
+  c->n_uni_cap = (1 << maxd) + 2 * maxd + 16;
+  c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + c->n_uni_cap));
+  c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
+  c->st_dev = c->keep(dev_alloc<HostStatus>(1));
+  c->do_dev = c->keep(dev_alloc<DrawOut>(1));
+  A.uniforms = c->stage_dev + 2 * (size_t)n;
+  for (void* p : c->owned)
+    if (!p) { g_err = "device allocation failed (trajectory arena needs 4*2^max_treedepth*n*8 bytes)"; nuts_chain_destroy(c); return nullptr; }
+  if (hipHostMalloc((void**)&c->stage_host, (2 * (size_t)n + c->n_uni_cap) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->out_host, 2 * (size_t)n * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->st_host, sizeof(HostStatus), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->do_host, sizeof(DrawOut), hipHostMallocDefault) != hipSuccess) {
+    g_err = "pinned host allocation failed"; nuts_chain_destroy(c); return nullptr;
+  }
+  hipMemset(A.ctl, 0, sizeof(Ctl));
+  c->step_size = cfg->step_scale / std::pow((double)n, 0.25);  // base_hmc.py:161
+  c->da = DualAvg{c->step_size, cfg->target_accept, cfg->gamma, cfg->k, cfg->t0, 0, 0, 0, 0, 1};
+  c->da.reset();
+  if (potential_reset(c) != NUTS_OK) { nuts_chain_destroy(c); return nullptr; }
+  return c;
+}
+
+extern "C" void nuts_chain_destroy(nuts_chain* c) {
+  if (!c) return;
+  if (c->m) hipStreamSynchronize(c->m->stream);
+  for (void* p : c->owned) if (p) hipFree(p);
+  if (c->stage_host) hipHostFree(c->stage_host);
+  if (c->out_host) hipHostFree(c->out_host);
+  if (c->st_host) hipHostFree(c->st_host);
+  if (c->do_host) hipHostFree(c->do_host);
+  delete c;
+}
+
+extern "C" int nuts_chain_reset_tuning(nuts_chain* c) {  // base_hmc.py:290-298
+  if (!c) return NUTS_E_ARG;
+  c->da.reset();
+  c->iter_count = 0; c->divergences = 0; c->tune = true;
+  return potential_reset(c);
+}
+extern "C" int nuts_chain_set_tune(nuts_chain* c, int tune) { if (!c) return NUTS_E_ARG; c->tune = tune != 0; return NUTS_OK; }
+extern "C" int nuts_chain_set_iter_count(nuts_chain* c, int64_t it) { if (!c) return NUTS_E_ARG; c->iter_count = it; return NUTS_OK; }
+
+static int check_mass_matrix(nuts_chain* c) {  // quadpotential.py:357-393 raise_ok
+  std::vector<double> st(c->n);
+  HIPCHK(hipMemcpy(st.data(), c->stds, c->n * sizeof(double), hipMemcpyDeviceToHost));
+  for (double s : st) {
+    if (s == 0) { g_err = "Mass matrix contains zeros on the diagonal. "; return NUTS_E_BAD_ENERGY; }
+    if (!std::isfinite(s)) { g_err = "Mass matrix contains non-finite values on the diagonal. "; return NUTS_E_BAD_ENERGY; }
+  }
+  return NUTS_OK;
+}
+
+static void launch_post(const ArenaDev& A, hipStream_t s, int j, int d) {
+  switch (A.ept) {
+    case 1: hipLaunchKernelGGL(k_leaf_post<1>, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, d); break;
+    case 4: hipLaunchKernelGGL(k_leaf_post<4>, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, d); break;
+    default: hipLaunchKernelGGL(k_leaf_post<16>, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, d); break;
+  }
+}
+
+static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotential.py:335-355
+  if (c->cfg.potential != NUTS_POT_DIAG_ADAPT || !c->tune) return NUTS_OK;
+  hipStream_t s = c->m->stream;
+  int flags = 0;
+  if (c->n_samples > c->cfg.discard_window) { flags |= 1; c->fg_count += 1; c->bg_count += 1; }
+  if (c->cfg.early_update || c->n_samples > c->adaptation_window) flags |= 2;
+  double *fm = c->fg_is_a ? c->wa_mean : c->wb_mean, *f2 = c->fg_is_a ? c->wa_m2 : c->wb_m2;
+  double *bm = c->fg_is_a ? c->wb_mean : c->wa_mean, *b2 = c->fg_is_a ? c->wb_m2 : c->wa_m2;
+  if (flags) {
+    if ((flags & 2) && c->fg_count == 0) { g_err = "Can not compute variance without samples."; return NUTS_E_ARG; }
+    const int grid = std::max(1, std::min(1024, (c->n + VEC_THREADS - 1) / VEC_THREADS));
+    hipLaunchKernelGGL(k_potential_update, dim3(grid), dim3(VEC_THREADS), 0, s, c->n, x_dev, fm, f2, c->fg_count, bm, b2,
+                       c->bg_count, c->var, c->stds, c->inv_stds, flags);
+  }
+  if (c->n_samples > 0 && c->n_samples % c->adaptation_window == 0) {
+    c->fg_is_a = !c->fg_is_a;  // foreground <- background
+    c->fg_count = c->bg_count;
+    HIPCHK(hipMemsetAsync(fm, 0, c->n * sizeof(double), s));  // old foreground becomes the fresh background
+    HIPCHK(hipMemsetAsync(f2, 0, c->n * sizeof(double), s));
+    c->bg_count = 0;
+    c->adaptation_window = (int64_t)(c->adaptation_window * c->cfg.adaptation_window_multiplier);
+  }
+  c->n_samples += 1;
+  return NUTS_OK;
+}
+
+static int draw_begin(nuts_chain* c, const double* q0, const double* normals, const double* uniforms, int n_uniforms,
+                      double step_size, int max_depth) {
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  ArenaDev& A = c->A;
+  const int nu = std::min(n_uniforms, c->n_uni_cap);
+  std::memcpy(c->stage_host, q0, n * sizeof(double));
+  std::memcpy(c->stage_host + n, normals, n * sizeof(double));
+  if (nu > 0) std::memcpy(c->stage_host + 2 * n, uniforms, nu * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + nu) * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  model_enqueue(c->m, A.Q, A.G, A.LOGP, nullptr);
+  hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, c->stage_dev, c->stage_dev + n, 0);
+  hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, step_size, max_depth, c->st_dev);
+  return NUTS_OK;
+}
+
+static int sync_status(nuts_chain* c) {
+  hipStream_t s = c->m->stream;
+  HIPCHK(hipMemcpyAsync(c->st_host, c->st_dev, sizeof(HostStatus), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return NUTS_OK;
+}
+
+// one leapfrog leaf = first half (vector) + model pass + second half (vector).
+static inline void enqueue_leaf_core(nuts_chain* c, int j, int edge, int dir, const int* abort_flag) {
+  ArenaDev& A = c->A;
+  hipStream_t s = c->m->stream;
+  hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j);
+  const int t = edge + dir * (j + 1);
+  const int64_t off = (int64_t)(t & (A.S - 1)) * A.n;
+  model_enqueue(c->m, A.Q + off, A.G + off, A.LOGP + (t & (A.S - 1)), abort_flag);
+  c->leapfrogs++;
+}
+
+extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
+                               int32_t n_uniforms, double* q_out, double* grad_out, nuts_draw_stats* stats) {
+  if (!c || !q0 || !normals || !uniforms || !q_out || !stats) { g_err = "null argument"; return NUTS_E_ARG; }
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  const double perf_start = std::chrono::duration<double>(t0.time_since_epoch()).count();
+  const std::clock_t c0 = std::clock();
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  ArenaDev& A = c->A;
+  // base_hmc.py:226-228 ; nuts.py:205-208
+  const bool adapt = c->tune && c->cfg.adapt_step_size;
+  const double step_size = c->da.current(adapt);
+  c->step_size = step_size;
+  const int max_depth = (c->tune && c->iter_count < 200) ? c->cfg.early_max_treedepth : c->cfg.max_treedepth;
+  const int need_uni = (1 << max_depth) + max_depth + 1;
+  if (n_uniforms < need_uni) { g_err = "not enough uniforms for the worst-case tree"; return NUTS_E_ARG; }
+
+  int rc = draw_begin(c, q0, normals, uniforms, n_uniforms, step_size, max_depth);
+  if (rc) return rc;
+  const int* abort_flag = &A.ctl->aborted;
+  // direction of the first doubling is uniforms[0] (the host owns the stream and can read it too)
+  int dir = uniforms[0] < 0.5 ? 1 : -1, edge = 0;
+  bool exhausted = true;
+  int64_t evals = 1;
+  for (int d = 0; d < max_depth; ++d) {
+    const int nleaf = 1 << d;
+    for (int j = 0; j < nleaf; ++j) {
+      enqueue_leaf_core(c, j, edge, dir, abort_flag);
+      launch_post(A, s, j, d);
+      hipLaunchKernelGGL(k_leaf_ctl, dim3(1), dim3(128), 0, s, A, j, d, c->cfg.Emax, max_depth, c->st_dev);
+    }
+    rc = sync_status(c);
+    if (rc) return rc;
+    const HostStatus& st = *c->st_host;
+    if (st.bad_energy) break;
+    if (st.diverging || st.turning) { exhausted = false; break; }
+    dir = st.dir; edge = st.edge;
+  }
+  if (c->st_host->bad_energy) {
+    // base_hmc.py:205-224: SamplingError("Bad initial energy"), after potential.raise_ok
+    rc = check_mass_matrix(c);
+    if (rc == NUTS_OK) g_err = "Bad initial energy, check any log probabilities that are inf or -inf, nan or very small";
+    return NUTS_E_BAD_ENERGY;
+  }
+  const int fgrid = std::max(1, std::min(256, (n + VEC_THREADS - 1) / VEC_THREADS));
+  hipLaunchKernelGGL(k_draw_finish, dim3(fgrid), dim3(VEC_THREADS), 0, s, A, c->out_dev, c->out_dev + n, c->do_dev);
+  HIPCHK(hipMemcpyAsync(c->out_host, c->out_dev, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(c->do_host, c->do_dev, sizeof(DrawOut), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  const DrawOut& o = *c->do_host;
+  evals += o.n_proposals;
+  const auto t1 = clk::now();
+  const std::clock_t c1 = std::clock();
+
+  // nuts.py:478-489, base_hmc.py:238-282
+  const double accept = std::exp(o.log_accept_sum) / o.n_proposals;
+  c->da.update(accept, adapt);
+  rc = potential_update(c, c->out_dev);
+  if (rc) return rc;
+  const bool diverging = o.diverging != 0;
+  if (!c->tune) c->divergences += diverging;
+  c->iter_count += 1;
+
+  std::memcpy(q_out, c->out_host, n * sizeof(double));
+  if (grad_out) std::memcpy(grad_out, c->out_host + n, n * sizeof(double));
+  std::memset(stats, 0, sizeof(*stats));
+  stats->depth = o.depth;
+  stats->step_size = std::exp(c->da.log_step);
+  stats->step_size_bar = std::exp(c->da.log_bar);
+  stats->mean_tree_accept = accept;
+  stats->tree_size = o.n_proposals;
+  stats->diverging = diverging;
+  stats->reached_max_treedepth = (exhausted && !c->tune) ? 1 : 0;  // nuts.py:220-221
+  stats->divergences = c->divergences;
+  stats->energy_error = o.energy - o.E0;
+  stats->energy = o.energy;
+  stats->max_energy_error = o.max_energy_change;
+  stats->model_logp = o.logp;
+  stats->index_in_trajectory = o.proposal;
+  stats->n_uniforms_consumed = o.cursor;
+  stats->warning = diverging ? 1 : 0;
+  stats->divergence_energy_change = o.div_dE;
+  stats->n_model_evals = evals;
+  stats->perf_counter_start = perf_start;
+  stats->perf_counter_diff = std::chrono::duration<double>(t1 - t0).count();
+  stats->process_time_diff = (double)(c1 - c0) / CLOCKS_PER_SEC;
+  return NUTS_OK;
+}
+
+// HamiltonianMC._hamiltonian_step (pymc/step_methods/hmc/hmc.py:130-184)
+extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
+                                   double path_length, int32_t max_steps, double* q_out, double* grad_out,
+                                   nuts_hmc_stats* stats) {
+  if (!c || !q0 || !normals || !uniforms || !q_out || !stats) { g_err = "null argument"; return NUTS_E_ARG; }
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  const std::clock_t c0 = std::clock();
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  ArenaDev& A = c->A;
+  const bool adapt = c->tune && c->cfg.adapt_step_size;
+  double step_size = c->da.current(adapt);
+  c->step_size = step_size;
+  step_size = (0.85 + (1.15 - 0.85) * uniforms[0]) * step_size;  // `unif` step_rand, hmc.py:35-36
+  int n_steps = std::max(1, (int)(path_length / step_size));
+  n_steps = std::min<int>(max_steps, n_steps);
+  if (n_steps >= A.S) { g_err = "n_steps exceeds the trajectory arena (2^max_treedepth slots)"; return NUTS_E_ARG; }
+  // a direction uniform < 0.5 makes k_draw_ctl_start pick dir=+1, edge=0
+  const double fake_uni[1] = {0.25};
+  int rc = draw_begin(c, q0, normals, fake_uni, 1, step_size, 1);
+  if (rc) return rc;
+  const int* abort_flag = &A.ctl->aborted;
+  for (int j = 0; j < n_steps; ++j) {
+    enqueue_leaf_core(c, j, 0, 1, abort_flag);
+    hipLaunchKernelGGL(k_leaf_post_simple, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j);
+    hipLaunchKernelGGL(k_energy_simple, dim3(1), dim3(64), 0, s, A, j);
+  }
+  std::vector<double> Eh(2), lph(2);
+  const int last = n_steps & (A.S - 1);
+  HIPCHK(hipMemcpyAsync(c->out_host, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(c->out_host + n, A.G + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  rc = sync_status(c);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(&Eh[0], A.E, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&Eh[1], A.E + last, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&lph[0], A.LOGP, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&lph[1], A.LOGP + last, sizeof(double), hipMemcpyDeviceToHost));
+  if (c->st_host->bad_energy) {
+    rc = check_mass_matrix(c);
+    if (rc == NUTS_OK) g_err = "Bad initial energy, check any log probabilities that are inf or -inf, nan or very small";
+    return NUTS_E_BAD_ENERGY;
+  }
+  bool div = false;
+  if (!std::isfinite(Eh[1])) div = true;           // hmc.py:147-148
+  double dE = Eh[1] - Eh[0];
+  if (std::isnan(dE)) dE = INFINITY;
+  if (std::fabs(dE) > c->cfg.Emax) div = true;     // hmc.py:152-158
+  const double accept = std::min(1.0, std::exp(-dE));
+  const bool accepted = !(div || uniforms[1] >= accept);  // hmc.py:162-167
+  const auto t1 = clk::now();
+  const std::clock_t c1 = std::clock();
+  c->da.update(accept, adapt);
+  const double* xsel = accepted ? (A.Q + (int64_t)last * n) : A.Q;
+  rc = potential_update(c, xsel);
+  if (rc) return rc;
+  if (!c->tune) c->divergences += div;
+  c->iter_count += 1;
+  if (accepted) {
+    std::memcpy(q_out, c->out_host, n * sizeof(double));
+    if (grad_out) std::memcpy(grad_out, c->out_host + n, n * sizeof(double));
+  } else {
+    std::memcpy(q_out, q0, n * sizeof(double));
+    if (grad_out) HIPCHK(hipMemcpy(grad_out, A.G, n * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  std::memset(stats, 0, sizeof(*stats));
+  stats->step_size = std::exp(c->da.log_step); stats->step_size_bar = std::exp(c->da.log_bar);
+  stats->accept = accept; stats->energy_error = dE; stats->energy = Eh[1]; stats->model_logp = lph[1];
+  stats->path_length = path_length; stats->n_steps = n_steps; stats->divergences = c->divergences;
+  stats->diverging = div; stats->accepted = accepted;
+  stats->perf_counter_start = std::chrono::duration<double>(t0.time_since_epoch()).count();
+  stats->perf_counter_diff = std::chrono::duration<double>(t1 - t0).count();
+  stats->process_time_diff = (double)(c1 - c0) / CLOCKS_PER_SEC;
+  return NUTS_OK;
+}
+
+// integrator property tests (tests/step_methods/hmc/test_hmc.py:49-74): n_steps leapfrogs from (q, p)
+extern "C" int nuts_chain_leapfrog_test(nuts_chain* c, const double* q, const double* p, double eps, int32_t n_steps,
+                                        double* q_out, double* p_out, double* energy_out) {
+  if (!c || !q || !p || n_steps < 0) { g_err = "bad argument"; return NUTS_E_ARG; }
+  const int n = c->n;
+  ArenaDev& A = c->A;
+  hipStream_t s = c->m->stream;
+  if (n_steps >= A.S) { g_err = "n_steps exceeds the trajectory arena"; return NUTS_E_ARG; }
+  // normals chosen so that p0 = normals * inv_stds == p
+  std::vector<double> inv(n), z(n);
+  HIPCHK(hipMemcpy(inv.data(), c->inv_stds, n * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) z[i] = p[i] / inv[i];
+  const double u[1] = {eps >= 0 ? 0.25 : 0.75};
+  int rc = draw_begin(c, q, z.data(), u, 1, std::fabs(eps), 1);
+  if (rc) return rc;
+  // exact p (avoid the round trip through normals)
+  HIPCHK(hipMemcpyAsync(c->stage_dev, p, n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(A.P, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  const int dir = eps >= 0 ? 1 : -1;
+  for (int j = 0; j < n_steps; ++j) {
+    enqueue_leaf_core(c, j, 0, dir, nullptr);
+    hipLaunchKernelGGL(k_leaf_post_simple, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j);
+    hipLaunchKernelGGL(k_energy_simple, dim3(1), dim3(64), 0, s, A, j);
+  }
+  const int last = (dir * n_steps) & (A.S - 1);
+  HIPCHK(hipStreamSynchronize(s));
+  if (q_out) HIPCHK(hipMemcpy(q_out, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (p_out) HIPCHK(hipMemcpy(p_out, A.P + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (energy_out) HIPCHK(hipMemcpy(energy_out, A.E + last, sizeof(double), hipMemcpyDeviceToHost));
+  return NUTS_OK;
+}
+
+// ---- sampling_state ---------------------------------------------------------
+static const int64_t STATE_MAGIC = 0x4e5554534d493335LL;
+extern "C" int64_t nuts_chain_state_size(const nuts_chain* c) {
+  return c ? (int64_t)(sizeof(StateHeader) + 7 * (size_t)c->n * sizeof(double)) : 0;
+}
+extern "C" int nuts_chain_get_state(nuts_chain* c, void* blob) {
+  if (!c || !blob) return NUTS_E_ARG;
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  StateHeader h{};
+  h.magic = STATE_MAGIC; h.n = c->n; h.da = c->da; h.iter_count = c->iter_count; h.divergences = c->divergences;
+  h.n_samples = c->n_samples; h.adaptation_window = c->adaptation_window; h.tune = c->tune; h.fg_is_a = c->fg_is_a;
+  h.fg_count = c->fg_count; h.bg_count = c->bg_count;
+  std::memcpy(blob, &h, sizeof(h));
+  double* v = reinterpret_cast<double*>(static_cast<char*>(blob) + sizeof(h));
+  const double* src[7] = {c->var, c->stds, c->inv_stds, c->wa_mean, c->wa_m2, c->wb_mean, c->wb_m2};
+  for (int k = 0; k < 7; ++k) HIPCHK(hipMemcpy(v + (size_t)k * c->n, src[k], c->n * sizeof(double), hipMemcpyDeviceToHost));
+  return NUTS_OK;
+}
+extern "C" int nuts_chain_set_state(nuts_chain* c, const void* blob) {
+  if (!c || !blob) return NUTS_E_ARG;
+  StateHeader h;
+  std::memcpy(&h, blob, sizeof(h));
+  if (h.magic != STATE_MAGIC || h.n != c->n) { g_err = "sampling state does not belong to this chain (frozen fields differ)"; return NUTS_E_ARG; }
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  c->da = h.da; c->iter_count = h.iter_count; c->divergences = h.divergences; c->n_samples = h.n_samples;
+  c->adaptation_window = h.adaptation_window; c->tune = h.tune != 0; c->fg_is_a = h.fg_is_a != 0;
+  c->fg_count = h.fg_count; c->bg_count = h.bg_count;
+  const double* v = reinterpret_cast<const double*>(static_cast<const char*>(blob) + sizeof(h));
+  double* dst[7] = {c->var, c->stds, c->inv_stds, c->wa_mean, c->wa_m2, c->wb_mean, c->wb_m2};
+  for (int k = 0; k < 7; ++k) HIPCHK(hipMemcpy(dst[k], v + (size_t)k * c->n, c->n * sizeof(double), hipMemcpyHostToDevice));
+  return NUTS_OK;
+}
+
+extern "C" int nuts_chain_get_scalar(nuts_chain* c, const char* name, double* out) {
+  if (!c || !name || !out) return NUTS_E_ARG;
+  const std::string k(name);
+  if (k == "log_step") *out = c->da.log_step;
+  else if (k == "log_bar") *out = c->da.log_bar;
+  else if (k == "hbar") *out = c->da.hbar;
+  else if (k == "count") *out = (double)c->da.count;
+  else if (k == "mu") *out = c->da.mu;
+  else if (k == "iter_count") *out = (double)c->iter_count;
+  else if (k == "divergences") *out = (double)c->divergences;
+  else if (k == "n_samples") *out = (double)c->n_samples;
+  else if (k == "adaptation_window") *out = (double)c->adaptation_window;
+  else if (k == "tune") *out = c->tune;
+  else if (k == "fg_count") *out = c->fg_count;
+  else if (k == "bg_count") *out = c->bg_count;
+  else if (k == "step_size") *out = c->step_size;
+  else if (k == "leapfrogs") *out = (double)c->leapfrogs;
+  else { g_err = "unknown scalar " + k; return NUTS_E_ARG; }
+  return NUTS_OK;
+}
+extern "C" int nuts_chain_get_vector(nuts_chain* c, const char* name, double* out) {
+  if (!c || !name || !out) return NUTS_E_ARG;
+  const std::string k(name);
+  const double* src = nullptr;
+  if (k == "var") src = c->var;
+  else if (k == "stds") src = c->stds;
+  else if (k == "inv_stds") src = c->inv_stds;
+  else if (k == "fg_mean") src = c->fg_is_a ? c->wa_mean : c->wb_mean;
+  else if (k == "fg_m2") src = c->fg_is_a ? c->wa_m2 : c->wb_m2;
+  else if (k == "bg_mean") src = c->fg_is_a ? c->wb_mean : c->wa_mean;
+  else if (k == "bg_m2") src = c->fg_is_a ? c->wb_m2 : c->wa_m2;
+  else { g_err = "unknown vector " + k; return NUTS_E_ARG; }
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  HIPCHK(hipMemcpy(out, src, c->n * sizeof(double), hipMemcpyDeviceToHost));
+  return NUTS_OK;
+}
+
+// ---- pooled adaptation hooks (opt-in; not reference behaviour) -----------------
+extern "C" int nuts_chain_welford_export(nuts_chain* c, double* buf) {
+  if (!c || !buf) return NUTS_E_ARG;
+  const size_t n = c->n;
+  hipStream_t s = c->m->stream;
+  const double* fm = c->fg_is_a ? c->wa_mean : c->wb_mean; const double* f2 = c->fg_is_a ? c->wa_m2 : c->wb_m2;
+  const double* bm = c->fg_is_a ? c->wb_mean : c->wa_mean; const double* b2 = c->fg_is_a ? c->wb_m2 : c->wa_m2;
+  HIPCHK(hipMemcpyAsync(buf, &c->fg_count, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(buf + 1, fm, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(buf + 1 + n, f2, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(buf + 1 + 2 * n, &c->bg_count, sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(buf + 2 + 2 * n, bm, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(buf + 2 + 3 * n, b2, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return NUTS_OK;
+}
+extern "C" int nuts_chain_welford_import(nuts_chain* c, const double* buf) {
+  if (!c || !buf) return NUTS_E_ARG;
+  const size_t n = c->n;
+  hipStream_t s = c->m->stream;
+  double* fm = c->fg_is_a ? c->wa_mean : c->wb_mean; double* f2 = c->fg_is_a ? c->wa_m2 : c->wb_m2;
+  double* bm = c->fg_is_a ? c->wb_mean : c->wa_mean; double* b2 = c->fg_is_a ? c->wb_m2 : c->wa_m2;
+  HIPCHK(hipMemcpyAsync(&c->fg_count, buf, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(fm, buf + 1, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(f2, buf + 1 + n, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(&c->bg_count, buf + 1 + 2 * n, sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(bm, buf + 2 + 2 * n, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(b2, buf + 2 + 3 * n, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return NUTS_OK;
+}
+extern "C" int nuts_chain_set_log_step_bar(nuts_chain* c, double log_step, double log_bar) {
+  if (!c) return NUTS_E_ARG;
+  c->da.log_step = log_step; c->da.log_bar = log_bar;
+  return NUTS_OK;
+}
+
+extern "C" int nuts_chain_profile(nuts_chain* c, int enable) {
+  if (!c) return NUTS_E_ARG;
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  profile_enable(c->m, enable != 0, 8, 4096);
+  c->leapfrogs = 0;
+  return NUTS_OK;
+}
+extern "C" int nuts_chain_profile_read(nuts_chain* c, double* ms_sum, int64_t* launches, int64_t* leapfrogs) {
+  if (!c) return NUTS_E_ARG;
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  int64_t pairs = 0;
+  const double tot = profile_sum_ms(c->m, &pairs);
+  if (ms_sum) *ms_sum = tot;
+  if (launches) *launches = pairs;
+  if (leapfrogs) *leapfrogs = c->leapfrogs;
+  return NUTS_OK;
+}

@@ -1,0 +1,340 @@
+"""Model specification: the thin IR that is lowered through the C-ABI.
+
+The reference builds the joint log-density as a PyTensor graph
+(`Model.logp`, pymc/model/core.py:612-695 ->
+`transformed_conditional_logp`, pymc/logprob/basic.py:618-667) and compiles it
+with `ValueGradFunction` (pymc/model/core.py:142-305).  PyTensor is not
+available on the build image, so the graph walker is a "next" row (SURVEY.md
+section 8f-2); what crosses the C-ABI today is this *spec*: a struct-of-arrays
+description of
+
+* the free value variables, in `model.value_vars` order, with their default
+  transforms (`log`, `logodds`, `interval`; pymc/logprob/transforms.py:880-891,
+  967-1088) -- this fixes the layout of the raveled parameter vector exactly as
+  `DictToArrayBijection.map` does (pymc/blocking.py:67-75);
+* element-wise factors ``dist(value | args)`` whose arguments are affine terms
+  ``a + b*c`` over constants, data vectors and variables;
+* dense nodes that get their own HBM-streaming kernels: hierarchical
+  logistic-regression rows and an MvNormal with constant covariance.
+
+The small builder below mirrors the PyMC model-building idiom
+(``m.Normal("mu", 0, 1)``, ``observed=``) so that parity tests read like the
+reference's own tests.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+# transform codes (must match csrc/nuts_types.h)
+TR_NONE, TR_LOG, TR_LOGODDS, TR_INTERVAL = 0, 1, 2, 3
+TRANSFORM_NAMES = {TR_NONE: None, TR_LOG: "log", TR_LOGODDS: "logodds", TR_INTERVAL: "interval"}
+
+# operand kinds
+OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
+
+# distribution codes (must match csrc/nuts_types.h)
+(
+    D_NORMAL,
+    D_HALFNORMAL,
+    D_CAUCHY,
+    D_HALFCAUCHY,
+    D_STUDENTT,
+    D_BETA,
+    D_EXPONENTIAL,
+    D_UNIFORM,
+    D_BERNOULLI_LOGIT,
+    D_LOGNORMAL,
+    D_BERNOULLI,
+) = range(11)
+DIST_NAMES = {
+    D_NORMAL: "Normal",
+    D_HALFNORMAL: "HalfNormal",
+    D_CAUCHY: "Cauchy",
+    D_HALFCAUCHY: "HalfCauchy",
+    D_STUDENTT: "StudentT",
+    D_BETA: "Beta",
+    D_EXPONENTIAL: "Exponential",
+    D_UNIFORM: "Uniform",
+    D_BERNOULLI_LOGIT: "BernoulliLogit",
+    D_LOGNORMAL: "LogNormal",
+    D_BERNOULLI: "Bernoulli",
+}
+
+
+@dataclass(frozen=True)
+class Operand:
+    kind: int = OP_CONST
+    c: float = 0.0
+    ref: int = -1  # data id or var id
+
+
+ZERO = Operand(OP_CONST, 0.0)
+ONE = Operand(OP_CONST, 1.0)
+
+
+@dataclass(frozen=True)
+class Term:
+    """value = a + b * c (element-wise, size-1 operands broadcast)."""
+
+    a: Operand = ZERO
+    b: Operand = ZERO
+    c: Operand = ZERO
+
+
+@dataclass
+class FreeVar:
+    """One value variable (a slice of the raveled vector)."""
+
+    name: str  # RV name, e.g. "tau"
+    shape: Tuple[int, ...]
+    transform: int = TR_NONE
+    lower: float = 0.0
+    upper: float = 1.0
+    offset: int = 0
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def value_name(self) -> str:
+        """`{name}_{transform}__` (pymc/util.py:138-155)."""
+        t = TRANSFORM_NAMES[self.transform]
+        return self.name if t is None else f"{self.name}_{t}__"
+
+
+@dataclass
+class Factor:
+    dist: int
+    size: int
+    args: Tuple[Term, ...]  # args[0] is the value
+    konst: float = 0.0  # parameter-only normaliser precomputed on host (lgamma terms)
+    name: str = ""
+
+
+@dataclass
+class LogitRows:
+    """y_i ~ Bernoulli(logit_p = x_i . beta_{g(i)}),  beta_g = mu + sigma * z_g.
+
+    Rows must be sorted by group (`group_idx` non-decreasing).
+    """
+
+    X: np.ndarray  # [N, D] float64
+    y: np.ndarray  # [N] int8
+    group_idx: np.ndarray  # [N] int32, sorted
+    mu: int  # var id, size D
+    sigma: int  # var id, size D (constrained value used)
+    z: int  # var id, size G*D
+    name: str = "y"
+
+
+@dataclass
+class MvNormalNode:
+    """x ~ MvNormal(mu, cov) with constant mu/cov (pymc/distributions/multivariate.py:158-295)."""
+
+    var: int
+    mu: np.ndarray
+    cov: np.ndarray
+    name: str = "x"
+
+
+@dataclass
+class ModelSpec:
+    vars: List[FreeVar] = field(default_factory=list)
+    data: List[np.ndarray] = field(default_factory=list)
+    factors: List[Factor] = field(default_factory=list)
+    logit_rows: Optional[LogitRows] = None
+    mvnormal: Optional[MvNormalNode] = None
+
+    @property
+    def n(self) -> int:
+        return sum(v.size for v in self.vars)
+
+    @property
+    def point_map_info(self):
+        """`RaveledVars.point_map_info` (pymc/blocking.py:40-46)."""
+        return tuple((v.value_name, tuple(v.shape), v.size, np.dtype("float64")) for v in self.vars)
+
+
+# ---------------------------------------------------------------------------
+# PyMC-flavoured builder
+# ---------------------------------------------------------------------------
+
+
+class Expr:
+    """An affine expression over model quantities (at most ``a + b*c``)."""
+
+    def __init__(self, builder: "ModelBuilder", term: Term, size: int):
+        self._b, self.term, self.size = builder, term, size
+
+    # -- helpers -----------------------------------------------------------
+    def _simple(self) -> Optional[Operand]:
+        t = self.term
+        if t.b == ZERO or t.c == ZERO:
+            return t.a
+        return None
+
+    def _product(self) -> Optional[Tuple[Operand, Operand]]:
+        t = self.term
+        if t.a == ZERO:
+            return t.b, t.c
+        return None
+
+    def __add__(self, other):
+        other = self._b.as_expr(other)
+        size = max(self.size, other.size)
+        s, o = self._simple(), other._simple()
+        if s is not None and o is not None:
+            if s.kind == OP_CONST and o.kind == OP_CONST:
+                return Expr(self._b, Term(Operand(OP_CONST, s.c + o.c)), size)
+            return Expr(self._b, Term(s, o, ONE), size)
+        if s is not None and other._product() is not None:
+            return Expr(self._b, Term(s, *other._product()), size)
+        if o is not None and self._product() is not None:
+            return Expr(self._b, Term(o, *self._product()), size)
+        raise NotImplementedError("expression is outside the affine IR `a + b*c` (graph lowering is a next row)")
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        other = self._b.as_expr(other)
+        size = max(self.size, other.size)
+        s, o = self._simple(), other._simple()
+        if s is not None and o is not None:
+            if s.kind == OP_CONST and o.kind == OP_CONST:
+                return Expr(self._b, Term(Operand(OP_CONST, s.c * o.c)), size)
+            return Expr(self._b, Term(ZERO, s, o), size)
+        raise NotImplementedError("expression is outside the affine IR `a + b*c` (graph lowering is a next row)")
+
+    __rmul__ = __mul__
+
+
+_DEFAULT_TRANSFORM = {
+    D_HALFNORMAL: TR_LOG,
+    D_HALFCAUCHY: TR_LOG,
+    D_EXPONENTIAL: TR_LOG,
+    D_LOGNORMAL: TR_LOG,
+    D_BETA: TR_LOGODDS,
+    D_UNIFORM: TR_INTERVAL,
+}
+
+
+class ModelBuilder:
+    """Tiny stand-in for ``pm.Model`` that emits a :class:`ModelSpec`."""
+
+    def __init__(self):
+        self.spec = ModelSpec()
+        self._names: Dict[str, Expr] = {}
+
+    # -- operands ----------------------------------------------------------
+    def as_expr(self, x) -> Expr:
+        if isinstance(x, Expr):
+            return x
+        arr = np.asarray(x, dtype="float64")
+        if arr.ndim == 0 or arr.size == 1:
+            return Expr(self, Term(Operand(OP_CONST, float(arr.reshape(-1)[0]))), 1)
+        self.spec.data.append(np.ascontiguousarray(arr.ravel()))
+        return Expr(self, Term(Operand(OP_DATA, 0.0, len(self.spec.data) - 1)), arr.size)
+
+    def _register(self, dist, name, params, shape, observed, transform, bounds=(0.0, 1.0), konst=0.0):
+        params = [self.as_expr(p) for p in params]
+        if observed is not None:
+            val = self.as_expr(np.asarray(observed, dtype="float64"))
+            if val.term.a.kind == OP_CONST:  # scalar observation: keep as data of size 1
+                self.spec.data.append(np.array([val.term.a.c]))
+                val = Expr(self, Term(Operand(OP_DATA, 0.0, len(self.spec.data) - 1)), 1)
+            size = max([val.size] + [p.size for p in params])
+            self.spec.factors.append(Factor(dist, size, (val.term, *[p.term for p in params]), konst, name))
+            return None
+        if shape is None:
+            shape = ()
+        elif isinstance(shape, int):
+            shape = (shape,)
+        tr = _DEFAULT_TRANSFORM.get(dist, TR_NONE) if transform == "default" else (transform or TR_NONE)
+        var = FreeVar(name, tuple(shape), tr, float(bounds[0]), float(bounds[1]), self.spec.n)
+        self.spec.vars.append(var)
+        vid = len(self.spec.vars) - 1
+        e = Expr(self, Term(Operand(OP_VAR, 0.0, vid)), var.size)
+        for p in params:
+            if p.size not in (1, var.size):
+                raise ValueError(f"parameter of size {p.size} does not broadcast to {name} of size {var.size}")
+        self.spec.factors.append(Factor(dist, var.size, (e.term, *[p.term for p in params]), konst, name))
+        self._names[name] = e
+        return e
+
+    # -- distributions (signatures follow pymc/distributions/continuous.py) --
+    def Normal(self, name, mu=0.0, sigma=1.0, shape=None, observed=None):
+        return self._register(D_NORMAL, name, (mu, sigma), shape, observed, TR_NONE)
+
+    def HalfNormal(self, name, sigma=1.0, shape=None, observed=None, transform="default"):
+        return self._register(D_HALFNORMAL, name, (sigma,), shape, observed, transform)
+
+    def Cauchy(self, name, alpha=0.0, beta=1.0, shape=None, observed=None):
+        return self._register(D_CAUCHY, name, (alpha, beta), shape, observed, TR_NONE)
+
+    def HalfCauchy(self, name, beta=1.0, shape=None, observed=None, transform="default"):
+        return self._register(D_HALFCAUCHY, name, (beta,), shape, observed, transform)
+
+    def Exponential(self, name, lam=1.0, shape=None, observed=None, transform="default"):
+        return self._register(D_EXPONENTIAL, name, (lam,), shape, observed, transform)
+
+    def StudentT(self, name, nu, mu=0.0, sigma=1.0, shape=None, observed=None):
+        nu = float(nu)  # constant-only: keeps digamma out of the device gradient
+        konst = math.lgamma((nu + 1.0) / 2.0) - math.lgamma(nu / 2.0) - 0.5 * math.log(nu * math.pi)
+        return self._register(D_STUDENTT, name, (nu, mu, sigma), shape, observed, TR_NONE, konst=konst)
+
+    def Beta(self, name, alpha, beta, shape=None, observed=None, transform="default"):
+        alpha, beta = float(alpha), float(beta)
+        konst = -(math.lgamma(alpha) + math.lgamma(beta) - math.lgamma(alpha + beta))
+        return self._register(D_BETA, name, (alpha, beta), shape, observed, transform, konst=konst)
+
+    def Uniform(self, name, lower=0.0, upper=1.0, shape=None, observed=None, transform="default"):
+        lower, upper = float(lower), float(upper)
+        return self._register(D_UNIFORM, name, (lower, upper), shape, observed, transform, bounds=(lower, upper))
+
+    def LogNormal(self, name, mu=0.0, sigma=1.0, shape=None, observed=None, transform="default"):
+        return self._register(D_LOGNORMAL, name, (mu, sigma), shape, observed, transform)
+
+    def Bernoulli(self, name, p, observed):
+        """`pm.Bernoulli(name, p=..., observed=...)` (pymc/distributions/discrete.py:362-374)."""
+        return self._register(D_BERNOULLI, name, (p,), None, observed, TR_NONE)
+
+    def BernoulliLogit(self, name, logit_p, observed):
+        """`pm.Bernoulli(name, logit_p=..., observed=...)` (pymc/distributions/discrete.py:343-374)."""
+        return self._register(D_BERNOULLI_LOGIT, name, (logit_p,), None, observed, TR_NONE)
+
+    # -- dense nodes ---------------------------------------------------------
+    def _var_id(self, e: Expr) -> int:
+        op = e._simple()
+        if op is None or op.kind != OP_VAR:
+            raise ValueError("expected a free variable")
+        return op.ref
+
+    def HierLogitRows(self, name, X, y, group_idx, mu: Expr, sigma: Expr, z: Expr):
+        X = np.ascontiguousarray(X, dtype="float64")
+        g = np.ascontiguousarray(group_idx, dtype="int32")
+        if np.any(np.diff(g) < 0):
+            order = np.argsort(g, kind="stable")
+            X, g, y = X[order], g[order], np.asarray(y)[order]
+        self.spec.logit_rows = LogitRows(
+            X, np.ascontiguousarray(y, dtype="int8"), g, self._var_id(mu), self._var_id(sigma), self._var_id(z), name
+        )
+
+    def MvNormal(self, name, mu, cov):
+        mu = np.ascontiguousarray(mu, dtype="float64")
+        cov = np.ascontiguousarray(cov, dtype="float64")
+        var = FreeVar(name, (len(mu),), TR_NONE, 0.0, 1.0, self.spec.n)
+        self.spec.vars.append(var)
+        vid = len(self.spec.vars) - 1
+        self.spec.mvnormal = MvNormalNode(vid, mu, cov, name)
+        e = Expr(self, Term(Operand(OP_VAR, 0.0, vid)), var.size)
+        self._names[name] = e
+        return e
+
+    def build(self) -> ModelSpec:
+        return self.spec

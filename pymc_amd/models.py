@@ -1,0 +1,99 @@
+"""Synthetic model/config builders named in BASELINE.json.
+
+All data are seeded with ``np.random.default_rng(20160911)`` -- the reference's
+fixture seed (tests/sampler_fixtures.py:140).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from pymc_amd.model_spec import ModelBuilder, ModelSpec
+
+DATA_SEED = 20160911
+
+
+def golden_hier_normal() -> ModelSpec:
+    """The documented example of pymc/pytensorf.py:514-546.
+
+    ``logp([0, 1, 0, 1, 2]) == -12.691227342634292``.
+    """
+    m = ModelBuilder()
+    mu_pop = m.Normal("mu_pop")
+    sigma_pop = m.HalfNormal("sigma_pop")
+    mu = m.Normal("mu", mu_pop, sigma_pop, shape=(3,))
+    m.Normal("y", mu, 1.0, observed=[0.0, 1.0, 2.0])
+    return m.build()
+
+
+def eight_schools(J: int = 8, seed: int = DATA_SEED) -> ModelSpec:
+    """Schools model of tests/test_model_graph.py:44-57 (C1).
+
+    J == 8 uses the canonical data; other J use the synthetic data of
+    SURVEY.md section 8d (sigma_j ~ U(9,18), y_j = 4 + 10 z_j + sigma_j e_j).
+    Value-variable order: eta[J], mu, tau_log__  (n = J + 2).
+    """
+    if J == 8:
+        y = np.array([28, 8, -3, 7, -1, 1, 18, 12], dtype="float64")
+        sigma = np.array([15, 10, 16, 11, 9, 11, 10, 18], dtype="float64")
+    else:
+        rng = np.random.default_rng(seed)
+        sigma = rng.uniform(9, 18, size=J)
+        y = 4 + 10 * rng.normal(size=J) + sigma * rng.normal(size=J)
+    m = ModelBuilder()
+    eta = m.Normal("eta", 0.0, 1.0, shape=J)
+    mu = m.Normal("mu", 0.0, 1e6)
+    tau = m.HalfCauchy("tau", 25.0)
+    m.Normal("obs", mu + tau * eta, sigma, observed=y)
+    return m.build()
+
+
+def hier_logit(G: int = 1248, D: int = 8, rows_per_group: int = 80, seed: int = DATA_SEED) -> ModelSpec:
+    """Hierarchical logistic regression, n = 2 D + G D (C2; 10 000 at the defaults).
+
+    mu[D] ~ N(0,1); sigma[D] ~ HalfNormal(1) (log-transformed); z[G,D] ~ N(0,1);
+    beta_g = mu + sigma * z_g;  y_i ~ Bernoulli(logit_p = x_i . beta_{g(i)}),
+    x_i ~ N(0,1)^D with x_{i,0} = 1, rows sorted by group.
+    C2-S: rows_per_group=80 (N = 99 840); C2-L: rows_per_group=4000 (N = 4 992 000).
+    """
+    rng = np.random.default_rng(seed)
+    N = G * rows_per_group
+    mu_true = rng.normal(0, 0.5, size=D)
+    sigma_true = np.full(D, 0.5)
+    beta = mu_true + sigma_true * rng.normal(size=(G, D))
+    gidx = np.repeat(np.arange(G, dtype="int32"), rows_per_group)
+    X = np.empty((N, D))
+    chunk = 1 << 20
+    y = np.empty(N, dtype="int8")
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        xb = rng.normal(size=(e - s, D))
+        xb[:, 0] = 1.0
+        X[s:e] = xb
+        eta = np.einsum("nd,nd->n", xb, beta[gidx[s:e]])
+        y[s:e] = (rng.random(e - s) < 1.0 / (1.0 + np.exp(-eta))).astype("int8")
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 1.0, shape=D)
+    sigma = m.HalfNormal("sigma", 1.0, shape=D)
+    z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    m.HierLogitRows("y", X, y, gidx, mu, sigma, z)
+    return m.build()
+
+
+def mvnormal(n: int = 2048, seed: int = DATA_SEED, cond_lo: float = 0.1, cond_hi: float = 10.0) -> ModelSpec:
+    """x ~ MvNormal(0, Q diag(lambda) Q^T), lambda log-spaced in [0.1, 10] (C3)."""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    lam = np.logspace(np.log10(cond_lo), np.log10(cond_hi), n)
+    cov = (Q * lam) @ Q.T
+    cov = 0.5 * (cov + cov.T)
+    m = ModelBuilder()
+    m.MvNormal("x", np.zeros(n), cov)
+    return m.build()
+
+
+def std_normal(n: int = 10, mu: float = 2.0, sigma: float = np.sqrt(3.0)) -> ModelSpec:
+    """`Normal(mu, sigma, size=n)` fixture of tests/sampler_fixtures.py:75-85."""
+    m = ModelBuilder()
+    m.Normal("a", mu, sigma, shape=n)
+    return m.build()

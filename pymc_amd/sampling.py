@@ -1,0 +1,291 @@
+"""Sampling driver for the device step methods.
+
+Restates the slice of `pm.sample` the hot path needs
+(pymc/sampling/mcmc.py:620-1190): per-chain RNG spawning (`:907-908`),
+`init_nuts` for `adapt_diag` / `jitter+adapt_diag` (`:1759-2021`), the per-chain
+loop of `_iter_sample` (`:1503-1583`), and returns raw arrays (trace backends and
+ArviZ conversion are out of scope).
+
+Multi-GPU: chains are independent.  Under
+``torch.distributed`` (one process per GPU, launched by ``torch.distributed.run``)
+chain c runs on rank ``c % world_size``; there is no data-path collective.  The
+only collectives are the final trace gather and the OPT-IN pooled tuning
+(`pooled_adaptation=True`), which all-reduces the Welford partials at
+adaptation-window boundaries and averages log step sizes at the end of tuning --
+that changes results relative to the reference and is therefore off by default.
+"""
+
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from pymc_amd.blocking import DictToArrayBijection, RaveledVars
+from pymc_amd.model_spec import TR_INTERVAL, TR_LOG, TR_LOGODDS, ModelSpec
+from pymc_amd.quadpotential import QuadPotentialDiagAdapt
+from pymc_amd.step import NUTS, get_random_generator
+
+
+def initial_point(spec: ModelSpec) -> Dict[str, np.ndarray]:
+    """Unconstrained initial point = 0 for every value variable.
+
+    For the distributions of the IR this coincides with the reference's support
+    points mapped through the default transforms for centred priors
+    (pymc/initial_point.py:187-340); models with other support points pass
+    explicit `initvals`.
+    """
+    return {v.value_name: np.zeros(v.shape, dtype="float64") for v in spec.vars}
+
+
+def _jitter_point(point, seed):
+    """U(-1,1) jitter in unconstrained space (`_init_jitter`, mcmc.py:1695-1756).
+
+    The reference draws the jitter through PyTensor RNG ops whose stream order is
+    a PyTensor internal: the jitter VALUES are parity-unpinned.
+    """
+    rng = np.random.default_rng(seed)
+    return {k: v + rng.uniform(-1, 1, size=np.shape(v)) for k, v in point.items()}
+
+
+def init_nuts(
+    spec: ModelSpec,
+    *,
+    init: str = "jitter+adapt_diag",
+    chains: int = 1,
+    random_seed_list: Sequence[int],
+    initvals=None,
+    logp_dlogp_func=None,
+    jitter_max_retries: int = 10,
+    device: Optional[int] = None,
+    **step_kwargs,
+):
+    """`init_nuts` (mcmc.py:1759-2021) for the diag-adapt initialisers."""
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    if logp_dlogp_func is None:
+        logp_dlogp_func = DeviceValueGradFunction(spec, device=device)  # mcmc.py:1865-1866
+    base = initial_point(spec)
+    points = []
+    for c in range(chains):
+        p = dict(base)
+        iv = initvals[c] if isinstance(initvals, (list, tuple)) else initvals
+        if iv:
+            p.update({k: np.asarray(v, dtype="float64") for k, v in iv.items()})
+        if "jitter" in init:
+            seed = random_seed_list[c]
+            rng = np.random.default_rng(seed)
+            for i in range(jitter_max_retries + 1):
+                cand = _jitter_point(p, seed)
+                lp, _ = logp_dlogp_func._pytensor_function(DictToArrayBijection.map(cand).data)
+                if np.isfinite(lp):
+                    break
+                seed = int(rng.integers(2**30, dtype=np.int64))
+            p = cand
+        points.append(p)
+    apoints = [DictToArrayBijection.map(p).data for p in points]
+    if init in ("adapt_diag", "jitter+adapt_diag"):  # mcmc.py:1886-1894
+        mean = np.mean(apoints, axis=0)
+        var = np.ones_like(mean)
+        potential = QuadPotentialDiagAdapt(len(var), mean, var, 10, rng=random_seed_list[0])
+    else:
+        raise ValueError(f"Unknown or unsupported initializer: {init}.")
+    step = NUTS(
+        potential=potential, model=spec, rng=random_seed_list[0], initial_point=points[0],
+        logp_dlogp_func=logp_dlogp_func, **step_kwargs,
+    )
+    return points, step
+
+
+def _dist_info():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def assign_chains(chains: int, rank: int, world: int) -> List[int]:
+    """chain c <-> rank c % world (one chain per GPU when chains == world)."""
+    return [c for c in range(chains) if c % world == rank]
+
+
+def sample_chain(step: NUTS, start, rng, tune: int, draws: int, callback=None, pooled=None):
+    """`_iter_sample` (mcmc.py:1503-1583): returns (draws[tune+draws, n], stats list)."""
+    total = tune + draws
+    step.setup_chain(rng, tune, draws)
+    step.tune = bool(tune)
+    step.reset_tuning()
+    point = start
+    n = step._n
+    out = np.empty((total, n))
+    stats_out = []
+    for i in range(total):
+        if i == 0:
+            step.iter_count = 0
+        if i == tune:
+            step.stop_tuning()
+            if pooled is not None:
+                pooled.end_of_tuning(step)
+        point, stats = step.step(point)
+        out[i] = DictToArrayBijection.map({k: point[k] for k in step.var_names}).data
+        stats_out.append(stats[0])
+        if pooled is not None and i < tune:
+            pooled.after_tuning_draw(step, i)
+        if callback is not None:
+            callback(i, point, stats[0])
+    return out, stats_out
+
+
+class PooledAdaptation:
+    """OPT-IN cross-chain tuning pool over RCCL (NOT reference behaviour).
+
+    At every adaptation-window boundary (quadpotential.py:350-353) each rank
+    exports its foreground/background Welford partials ``(count, mean, M2)``,
+    the partials are Chan-merged with three all-reduces of sufficient statistics
+    (``sum n``, ``sum n*mean``, then ``sum M2 + n*(mean-mean_pooled)^2``) and
+    imported back, so every chain continues with the pooled estimate.  At the end
+    of tuning the log step sizes are averaged.  Message size (2n+1)*8 B per
+    estimator (160 KB at n = 10 000): latency-bound on xGMI.
+    """
+
+    def __init__(self, n: int, device, window: int = 101):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.n, self.window = n, window
+        self.buf = torch.zeros(2 * (2 * n + 1), dtype=torch.float64, device=device)
+
+    def _merge(self, part):
+        """part = [count, mean[n], m2[n]] view; Chan et al. parallel merge via all-reduce."""
+        torch, dist, n = self.torch, self.dist, self.n
+        cnt, mean, m2 = part[0:1], part[1 : 1 + n], part[1 + n : 1 + 2 * n]
+        tot = cnt.clone()
+        dist.all_reduce(tot)
+        wmean = mean * cnt
+        dist.all_reduce(wmean)
+        pooled_mean = wmean / torch.clamp(tot, min=1e-300)
+        m2p = m2 + cnt * (mean - pooled_mean) ** 2
+        dist.all_reduce(m2p)
+        cnt.copy_(tot)
+        mean.copy_(pooled_mean)
+        m2.copy_(m2p)
+
+    def after_tuning_draw(self, step, i):
+        # the window boundary is draw k with k > 0 and k % window == 0 (0-based n_samples)
+        if i == 0 or i % self.window != 0:
+            return
+        from pymc_amd import _lib
+
+        lib = _lib.load()
+        _lib.check(lib.nuts_chain_welford_export(step._chain, self.buf.data_ptr()), "welford_export")
+        self._merge(self.buf[: 2 * self.n + 1])
+        self._merge(self.buf[2 * self.n + 1 :])
+        self.torch.cuda.synchronize() if self.buf.is_cuda else None
+        _lib.check(lib.nuts_chain_welford_import(step._chain, self.buf.data_ptr()), "welford_import")
+
+    def end_of_tuning(self, step):
+        from pymc_amd import _lib
+
+        t = self.torch.tensor([step._scalar("log_step"), step._scalar("log_bar")], dtype=self.torch.float64, device=self.buf.device)
+        self.dist.all_reduce(t)
+        t /= self.dist.get_world_size()
+        _lib.load().nuts_chain_set_log_step_bar(step._chain, float(t[0]), float(t[1]))
+
+
+def sample(
+    draws: int = 1000,
+    *,
+    tune: int = 1000,
+    chains: int = 1,
+    model: ModelSpec,
+    step: Optional[NUTS] = None,
+    init: str = "jitter+adapt_diag",
+    random_seed=None,
+    initvals=None,
+    discard_tuned_samples: bool = True,
+    pooled_adaptation: bool = False,
+    gather: bool = True,
+    device: Optional[int] = None,
+    **step_kwargs,
+):
+    """Reduced `pm.sample` (mcmc.py:620-1190) returning raw arrays.
+
+    Returns a dict with ``draws`` (chains, draws, n), ``stats`` (per chain list of
+    per-draw dicts), ``point_map_info`` and timing.  Under torch.distributed every
+    rank samples its chains and rank 0 receives the gathered draws.
+    """
+    rank, world, local = _dist_info()
+    spec = model
+    if device is None and world > 1:
+        device = local
+    # mcmc.py:907-908 -- every rank derives ALL chain generators so chain c is the same stream on any layout
+    rngs = get_random_generator(random_seed).spawn(chains)
+    random_seed_list = [int(r.integers(2**30)) for r in rngs]
+    mine = assign_chains(chains, rank, world)
+    if step is None:
+        points, step = init_nuts(
+            spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device, **step_kwargs
+        )
+    else:
+        points = [dict(initial_point(spec)) for _ in range(chains)]
+    initial_state = step.sampling_state  # mcmc.py:1411,1423: the same step object is reset between chains
+    pooled = None
+    if pooled_adaptation and world > 1:
+        import torch
+
+        dev = torch.device("cuda", device if device is not None else 0)
+        pooled = PooledAdaptation(spec.n, dev, window=step.potential.adaptation_window)
+    total = tune + draws
+    local_draws = np.empty((len(mine), total, spec.n))
+    local_stats = []
+    t0 = time.perf_counter()
+    t_sampling = 0.0
+    for k, c in enumerate(mine):
+        step.sampling_state = initial_state
+        d, s = sample_chain(step, points[c], rngs[c], tune, draws, pooled=pooled)
+        local_draws[k] = d
+        local_stats.append(s)
+        t_sampling += sum(x["perf_counter_diff"] for x in s[tune:])
+    wall = time.perf_counter() - t0
+    keep = slice(tune, None) if discard_tuned_samples else slice(None)
+    result = {
+        "chains": mine,
+        "draws": local_draws[:, keep],
+        "stats": [s[keep] for s in local_stats],
+        "warmup_stats": [s[:tune] for s in local_stats],
+        "point_map_info": spec.point_map_info,
+        "wall_time": wall,
+        "sampling_time": t_sampling,
+        "step": step,
+    }
+    if gather and world > 1:
+        result = gather_trace(result, chains, rank, world, device)
+    return result
+
+
+def gather_trace(result, chains: int, rank: int, world: int, device):
+    """Final trace gather: draws x n x 8 B per chain to rank 0."""
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend()
+    dev = torch.device("cuda", device if device is not None else 0) if backend == "nccl" else torch.device("cpu")
+    per_rank = (chains + world - 1) // world
+    d = result["draws"]
+    pad = np.zeros((per_rank,) + d.shape[1:])
+    pad[: d.shape[0]] = d
+    t = torch.from_numpy(pad).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, out, dst=0)
+    if rank == 0:
+        full = np.empty((chains,) + d.shape[1:])
+        for r in range(world):
+            for k, c in enumerate(assign_chains(chains, r, world)):
+                full[c] = out[r][k].cpu().numpy()
+        result = dict(result)
+        result["draws"] = full
+        result["chains"] = list(range(chains))
+    return result

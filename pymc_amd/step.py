@@ -1,0 +1,405 @@
+"""Step-method plugin surface: `NUTS` and `HamiltonianMC` backed by the device engine.
+
+Mirrors what `pm.sample` requires from a step method
+(`BlockedStep`, pymc/step_methods/compound.py:108-250; `ArrayStepShared.step`,
+pymc/step_methods/arraystep.py:107-122; `BaseHMC`, pymc/step_methods/hmc/base_hmc.py:74-302;
+`NUTS`, pymc/step_methods/hmc/nuts.py:43-257):
+
+* ``vars``, ``name``, ``default_blocked``, ``stats_dtypes_shapes`` (the 19 NUTS stats);
+* ``step(point) -> (point, [stats])`` on dicts of value variables;
+* ``astep(q0: RaveledVars) -> (RaveledVars, [stats])``;
+* ``tune`` / ``stop_tuning()`` / ``reset_tuning()`` / ``iter_count``;
+* ``setup_chain(rng, tune, draws)`` with the reference's RNG plumbing
+  (`step.rng = rng`, `potential.rng = step.rng.spawn(1)[0]`; compound.py:250,
+  base_hmc.py:300-302);
+* ``sampling_state`` get/set round trip (pymc/step_methods/state.py:54-121).
+
+RNG stream identity: the two NumPy generators stay on the host.  Per draw the
+host draws ``potential.rng.normal(n)`` and pre-draws a buffer of
+``step.rng.random()`` values; the device reports how many it consumed and the
+step generator is rewound and advanced by exactly that count, so the streams are
+consumed exactly as the reference consumes them.
+
+When `pymc` itself is importable the class can be registered as a true
+`BlockedStep` subclass; here it is duck-typed.
+"""
+
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from pymc_amd import _lib
+from pymc_amd.blocking import DictToArrayBijection, PointType, RaveledVars
+from pymc_amd.model_spec import ModelSpec
+from pymc_amd.quadpotential import QuadPotentialDiag, QuadPotentialDiagAdapt
+from pymc_amd.value_grad import DeviceValueGradFunction
+
+
+class SamplerWarning:
+    """Minimal stand-in for pymc/stats/convergence.py:37-61."""
+
+    def __init__(self, kind, message, level, step=None, extra=None):
+        self.kind, self.message, self.level, self.step, self.extra = kind, message, level, step, extra
+
+    def __repr__(self):
+        return f"SamplerWarning({self.kind}, {self.message!r})"
+
+
+@dataclass
+class BaseHMCState:
+    """`BaseHMCState` (base_hmc.py:61-71) + nested states, flattened into one blob."""
+
+    var_names: List[str]
+    rng: Dict[str, Any]
+    potential_rng: Dict[str, Any]
+    engine_blob: bytes
+
+
+def _rng_state(rng: np.random.Generator):
+    """`get_state_from_generator` (pymc/util.py:522-534)."""
+    bg = rng.bit_generator
+    return {"bit_generator_state": copy.deepcopy(bg.state), "seed_seq_state": copy.deepcopy(bg.seed_seq.state)}
+
+
+def _rng_from_state(state) -> np.random.Generator:
+    """`random_generator_from_state` (pymc/util.py:537-542)."""
+    ss = np.random.SeedSequence(**state["seed_seq_state"])
+    bg = getattr(np.random, state["bit_generator_state"]["bit_generator"])(ss)
+    bg.state = state["bit_generator_state"]
+    return np.random.Generator(bg)
+
+
+def get_random_generator(seed=None, copy_: bool = True) -> np.random.Generator:
+    """pymc/util.py:544-594."""
+    if isinstance(seed, np.random.RandomState):
+        raise TypeError("Cannot create a random Generator from a RandomStream object.")
+    if copy_:
+        if isinstance(seed, np.random.Generator):
+            return _rng_from_state(_rng_state(seed))
+        seed = copy.deepcopy(seed)
+    return np.random.default_rng(seed)
+
+
+class _DeviceHMCBase:
+    default_blocked = True
+
+    def __init__(
+        self,
+        vars=None,
+        *,
+        model=None,
+        logp_dlogp_func: Optional[DeviceValueGradFunction] = None,
+        potential=None,
+        scaling=None,
+        is_cov=False,
+        step_scale=0.25,
+        Emax=1000,
+        target_accept=0.8,
+        gamma=0.05,
+        k=0.75,
+        t0=10,
+        adapt_step_size=True,
+        max_treedepth=10,
+        early_max_treedepth=8,
+        rng=None,
+        initial_point: Optional[PointType] = None,
+        device: Optional[int] = None,
+        blocked=True,
+        **_ignored,
+    ):
+        spec = model.spec if hasattr(model, "spec") else model
+        if logp_dlogp_func is None:
+            if not isinstance(spec, ModelSpec):
+                raise TypeError("model must be a pymc_amd ModelSpec (or carry `.spec`) when logp_dlogp_func is not given")
+            logp_dlogp_func = DeviceValueGradFunction(spec, device=device)
+        self._logp_dlogp_func = logp_dlogp_func
+        self.spec = logp_dlogp_func.spec
+        self._model = model
+        self.vars = list(self.spec.vars) if vars is None else list(vars)
+        self.var_names = tuple(v.value_name for v in self.vars)
+        self.shared = {}
+        self.blocked = blocked
+        self.rng = get_random_generator(rng)
+        n = self.spec.n
+        self._n = n
+        self.adapt_step_size = adapt_step_size
+        self.Emax = Emax
+        self.target_accept = target_accept
+        self.max_treedepth = max_treedepth
+        self.early_max_treedepth = early_max_treedepth
+        # base_hmc.py:166-180: default potential / `scaling`
+        if scaling is not None and potential is not None:
+            raise ValueError("Can not specify both potential and scaling.")
+        if potential is None and scaling is None:
+            potential = QuadPotentialDiagAdapt(n, np.zeros(n), np.ones(n), 10, rng=self.rng.spawn(1)[0])
+        elif potential is None:
+            scaling = np.asarray(scaling, dtype="float64")
+            if scaling.ndim != 1:
+                raise NotImplementedError("dense `scaling` needs the dense device potential (later round)")
+            potential = QuadPotentialDiag(scaling if is_cov else 1.0 / scaling, rng=self.rng.spawn(1)[0])
+        self.potential = potential
+        lib = _lib.load()
+        cfg = _lib.ChainConfig()
+        lib.nuts_chain_config_default(C.byref(cfg))
+        cfg.step_scale, cfg.Emax, cfg.target_accept = step_scale, Emax, target_accept
+        cfg.gamma, cfg.k, cfg.t0 = gamma, k, t0
+        cfg.adapt_step_size = int(adapt_step_size)
+        cfg.max_treedepth, cfg.early_max_treedepth = max_treedepth, early_max_treedepth
+        keep = potential._fill_config(cfg)
+        self._chain = lib.nuts_chain_create(logp_dlogp_func._handle, C.byref(cfg))
+        del keep
+        if not self._chain:
+            raise _lib.EngineError(f"nuts_chain_create failed: {_lib.last_error()}")
+        potential._bind(self)
+        self.tune = True
+        self._n_uniforms = (1 << max(max_treedepth, early_max_treedepth)) + 2 * max(max_treedepth, early_max_treedepth) + 4
+        self._q_out = np.empty(n)
+        self._g_out = np.empty(n)
+        self._num_divs_sample = 0
+
+    # ---- tuning control (compound.py:229-231, base_hmc.py:290-298) -------------
+    @property
+    def tune(self):
+        return self._tune
+
+    @tune.setter
+    def tune(self, value):
+        self._tune = bool(value)
+        if getattr(self, "_chain", None):
+            _lib.load().nuts_chain_set_tune(self._chain, int(self._tune))
+
+    def stop_tuning(self):
+        self.tune = False
+
+    def reset_tuning(self, start=None):
+        _lib.check(_lib.load().nuts_chain_reset_tuning(self._chain), "nuts_chain_reset_tuning")
+        self._tune = True
+
+    reset = reset_tuning
+
+    @property
+    def iter_count(self):
+        return int(self._scalar("iter_count"))
+
+    @iter_count.setter
+    def iter_count(self, v):
+        _lib.load().nuts_chain_set_iter_count(self._chain, int(v))
+
+    @property
+    def divergences(self):
+        return int(self._scalar("divergences"))
+
+    @property
+    def step_size(self):
+        return self._scalar("step_size")
+
+    def _scalar(self, name: str) -> float:
+        out = C.c_double()
+        _lib.check(_lib.load().nuts_chain_get_scalar(self._chain, name.encode(), C.byref(out)), name)
+        return out.value
+
+    def _vector(self, name: str) -> np.ndarray:
+        out = np.empty(self._n)
+        _lib.check(_lib.load().nuts_chain_get_vector(self._chain, name.encode(), _lib.dptr(out)), name)
+        return out
+
+    # ---- chain set-up (compound.py:233-250 + base_hmc.py:300-302) ---------------
+    def setup_chain(self, rng, tune: int, draws: int) -> None:
+        self.rng = get_random_generator(rng, copy_=False) if not isinstance(rng, np.random.Generator) else rng
+        self.potential.set_rng(self.rng.spawn(1)[0])
+
+    # ---- dict <-> flat (arraystep.py:107-122) ------------------------------------
+    def step(self, point: PointType):
+        sub = {name: point[name] for name in self.var_names}
+        q = DictToArrayBijection.map(sub)
+        apoint, stats = self.astep(q)
+        if not isinstance(apoint, RaveledVars):
+            apoint = RaveledVars(apoint, q.point_map_info)
+        return DictToArrayBijection.rmap(apoint, start_point=point), stats
+
+    # ---- sampling_state (state.py:54-121) ----------------------------------------
+    @property
+    def sampling_state(self) -> BaseHMCState:
+        lib = _lib.load()
+        size = lib.nuts_chain_state_size(self._chain)
+        buf = C.create_string_buffer(size)
+        _lib.check(lib.nuts_chain_get_state(self._chain, buf), "nuts_chain_get_state")
+        return BaseHMCState(list(self.var_names), _rng_state(self.rng), _rng_state(self.potential.rng), bytes(buf.raw))
+
+    @sampling_state.setter
+    def sampling_state(self, state: BaseHMCState):
+        if list(state.var_names) != list(self.var_names):
+            raise ValueError("The received sampling state must have the same values for the frozen fields. Field 'var_names' differs.")
+        buf = C.create_string_buffer(state.engine_blob, len(state.engine_blob))
+        _lib.check(_lib.load().nuts_chain_set_state(self._chain, buf), "nuts_chain_set_state")
+        self.rng = _rng_from_state(state.rng)
+        self.potential.set_rng(_rng_from_state(state.potential_rng))
+        self._tune = bool(self._scalar("tune"))
+
+    def close(self):
+        if getattr(self, "_chain", None):
+            _lib.load().nuts_chain_destroy(self._chain)
+            self._chain = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # profiling hooks used by bench.py
+    def profile(self, enable: bool):
+        _lib.check(_lib.load().nuts_chain_profile(self._chain, int(enable)), "nuts_chain_profile")
+
+    def profile_read(self):
+        ms, nl, lf = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().nuts_chain_profile_read(self._chain, C.byref(ms), C.byref(nl), C.byref(lf)), "profile_read")
+        return ms.value, nl.value, lf.value
+
+
+class NUTS(_DeviceHMCBase):
+    """No-U-Turn sampler on the MI355X engine (reference: pymc/step_methods/hmc/nuts.py:43-257)."""
+
+    name = "nuts"
+
+    stats_dtypes_shapes = {  # nuts.py:110-130
+        "depth": (np.int64, []),
+        "step_size": (np.float64, []),
+        "mean_tree_accept": (np.float64, []),
+        "step_size_bar": (np.float64, []),
+        "tree_size": (np.float64, []),
+        "diverging": (bool, []),
+        "divergences": (int, []),
+        "energy_error": (np.float64, []),
+        "energy": (np.float64, []),
+        "max_energy_error": (np.float64, []),
+        "model_logp": (np.float64, []),
+        "process_time_diff": (np.float64, []),
+        "perf_counter_diff": (np.float64, []),
+        "perf_counter_start": (np.float64, []),
+        "largest_eigval": (np.float64, []),
+        "smallest_eigval": (np.float64, []),
+        "index_in_trajectory": (np.int64, []),
+        "reached_max_treedepth": (bool, []),
+        "warning": (SamplerWarning, None),
+    }
+    stats_dtypes = [{k: v[0] for k, v in stats_dtypes_shapes.items()}]
+
+    @staticmethod
+    def competence(var, has_grad):  # nuts.py:227-232
+        dt = np.dtype(getattr(var, "dtype", "float64"))
+        return 3 if (dt.kind == "f" and has_grad) else 0  # Competence.PREFERRED / INCOMPATIBLE
+
+    def astep(self, q0: RaveledVars):
+        """BaseHMC.astep (base_hmc.py:196-288) -- one device transition."""
+        q = np.ascontiguousarray(q0.data, dtype="float64")
+        normals = self.potential._draw_normals()  # potential.random(): rng.normal(size=n) (quadpotential.py:323-326)
+        # pre-draw the uniform stream; rewind and advance by what the tree consumed
+        bg = self.rng.bit_generator
+        saved = bg.state
+        uniforms = self.rng.random(self._n_uniforms)
+        st = _lib.DrawStats()
+        rc = _lib.load().nuts_chain_draw(
+            self._chain, _lib.dptr(q), _lib.dptr(normals), _lib.dptr(uniforms), self._n_uniforms,
+            _lib.dptr(self._q_out), _lib.dptr(self._g_out), C.byref(st),
+        )
+        bg.state = saved
+        if rc != _lib.NUTS_OK:
+            _lib.check(rc, "nuts_chain_draw")
+        bg.advance(st.n_uniforms_consumed)
+        warning = None
+        if st.diverging:
+            kind = "TUNING_DIVERGENCE" if self.tune else "DIVERGENCE"
+            if not self.tune:
+                self._num_divs_sample += 1
+            msg = f"Energy change in leapfrog step is too large: {st.divergence_energy_change}."  # nuts.py:434
+            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1)
+        stats = {
+            "diverging": bool(st.diverging),
+            "divergences": int(st.divergences),
+            "perf_counter_diff": st.perf_counter_diff,
+            "process_time_diff": st.process_time_diff,
+            "perf_counter_start": st.perf_counter_start,
+            "warning": warning,
+            "depth": int(st.depth),
+            "mean_tree_accept": st.mean_tree_accept,
+            "energy_error": st.energy_error,
+            "energy": st.energy,
+            "tree_size": st.tree_size,
+            "max_energy_error": st.max_energy_error,
+            "model_logp": st.model_logp,
+            "index_in_trajectory": int(st.index_in_trajectory),
+            "reached_max_treedepth": bool(st.reached_max_treedepth),
+            "step_size": st.step_size,
+            "step_size_bar": st.step_size_bar,
+            "largest_eigval": np.nan,
+            "smallest_eigval": np.nan,
+        }
+        return RaveledVars(self._q_out.copy(), q0.point_map_info), [stats]
+
+
+class HamiltonianMC(_DeviceHMCBase):
+    """Fixed-path-length HMC (reference: pymc/step_methods/hmc/hmc.py:45-236)."""
+
+    name = "hmc"
+
+    stats_dtypes_shapes = {  # hmc.py:53-68
+        "step_size": (np.float64, []),
+        "n_steps": (np.int64, []),
+        "step_size_bar": (np.float64, []),
+        "accept": (np.float64, []),
+        "diverging": (bool, []),
+        "energy_error": (np.float64, []),
+        "divergences": (np.int64, []),
+        "energy": (np.float64, []),
+        "path_length": (np.float64, []),
+        "accepted": (bool, []),
+        "model_logp": (np.float64, []),
+        "process_time_diff": (np.float64, []),
+        "perf_counter_diff": (np.float64, []),
+        "perf_counter_start": (np.float64, []),
+        "largest_eigval": (np.float64, []),
+        "smallest_eigval": (np.float64, []),
+        "warning": (SamplerWarning, None),
+    }
+    stats_dtypes = [{k: v[0] for k, v in stats_dtypes_shapes.items()}]
+
+    def __init__(self, vars=None, path_length=2.0, max_steps=1024, **kwargs):
+        kwargs.setdefault("target_accept", 0.65)  # hmc.py:121
+        kwargs.setdefault("max_treedepth", 10)
+        super().__init__(vars, **kwargs)
+        self.path_length = path_length
+        self.max_steps = min(max_steps, (1 << self.max_treedepth) - 1)
+
+    @staticmethod
+    def competence(var, has_grad):  # hmc.py:186-191
+        dt = np.dtype(getattr(var, "dtype", "float64"))
+        return 1 if (dt.kind == "f" and has_grad) else 0  # COMPATIBLE / INCOMPATIBLE
+
+    def astep(self, q0: RaveledVars):
+        q = np.ascontiguousarray(q0.data, dtype="float64")
+        normals = self.potential._draw_normals()
+        # hmc.py:35-36 `rng.uniform(elow, ehigh)`, then hmc.py:162 `rng.random()`
+        u = np.array([self.rng.random(), self.rng.random()])
+        st = _lib.HmcStats()
+        rc = _lib.load().nuts_chain_draw_hmc(
+            self._chain, _lib.dptr(q), _lib.dptr(normals), _lib.dptr(u), float(self.path_length), int(self.max_steps),
+            _lib.dptr(self._q_out), _lib.dptr(self._g_out), C.byref(st),
+        )
+        if rc != _lib.NUTS_OK:
+            _lib.check(rc, "nuts_chain_draw_hmc")
+        stats = {
+            "diverging": bool(st.diverging), "divergences": int(st.divergences),
+            "perf_counter_diff": st.perf_counter_diff, "process_time_diff": st.process_time_diff,
+            "perf_counter_start": st.perf_counter_start, "warning": None,
+            "path_length": st.path_length, "n_steps": int(st.n_steps), "accept": st.accept,
+            "energy_error": st.energy_error, "energy": st.energy, "accepted": bool(st.accepted),
+            "model_logp": st.model_logp, "step_size": st.step_size, "step_size_bar": st.step_size_bar,
+            "largest_eigval": np.nan, "smallest_eigval": np.nan,
+        }
+        return RaveledVars(self._q_out.copy(), q0.point_map_info), [stats]

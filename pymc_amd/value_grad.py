@@ -1,0 +1,140 @@
+"""`ValueGradFunction` stand-in backed by the HIP model kernels.
+
+Replaces the compiled artefact of pymc/model/core.py:142-305: a callable
+``f(q: float64[n]) -> (logp: float64 scalar, dlogp: float64[n])`` over the
+unconstrained, raveled, concatenated value variables.  Exposes the attributes
+the integrator reads (`_raveled_inputs`, `dtype`, `_extra_vars_shared`,
+`_pytensor_function`; pymc/step_methods/hmc/integration.py:46-61,
+pymc/step_methods/arraystep.py:205).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.linalg
+
+from pymc_amd import _lib
+from pymc_amd.blocking import DictToArrayBijection, RaveledVars
+from pymc_amd.model_spec import ModelSpec
+
+
+def _pack(spec: ModelSpec):
+    """ModelSpec -> nuts_model_spec (+ the numpy buffers that must outlive the call)."""
+    keep = []
+    nv, nf, nd = len(spec.vars), len(spec.factors), len(spec.data)
+    vars_c = (_lib.Var * max(nv, 1))()
+    for i, v in enumerate(spec.vars):
+        vars_c[i] = _lib.Var(v.offset, v.size, v.transform, 0, v.lower, v.upper)
+    fac_c = (_lib.Factor * max(nf, 1))()
+    for i, f in enumerate(spec.factors):
+        fc = _lib.Factor()
+        fc.dist, fc.size, fc.nargs, fc.konst = f.dist, f.size, len(f.args), f.konst
+        for k, t in enumerate(f.args):
+            for nm in ("a", "b", "c"):
+                o = getattr(t, nm)
+                setattr(fc.arg[k], nm, _lib.Operand(o.kind, max(o.ref, 0), o.c))
+        fac_c[i] = fc
+    refs = (_lib.DataRef * max(nd, 1))()
+    off = 0
+    for i, d in enumerate(spec.data):
+        refs[i] = _lib.DataRef(off, d.size)
+        off += d.size
+    pool = np.concatenate(spec.data).astype("float64") if nd else np.zeros(1)
+    keep += [vars_c, fac_c, refs, pool]
+    s = _lib.ModelSpecC()
+    s.n_vars, s.n_factors, s.n_data = nv, nf, nd
+    s.vars, s.factors, s.data = vars_c, fac_c, refs
+    s.data_pool, s.data_pool_len = _lib.dptr(pool), off
+    if spec.logit_rows is not None:
+        r = spec.logit_rows
+        X = np.ascontiguousarray(r.X, dtype="float64")
+        y = np.ascontiguousarray(r.y, dtype="int8")
+        g = np.ascontiguousarray(r.group_idx, dtype="int32")
+        keep += [X, y, g]
+        s.rows_N, s.rows_D = X.shape
+        s.rows_G = spec.vars[r.z].size // X.shape[1]
+        s.rows_X = _lib.dptr(X)
+        s.rows_y = y.ctypes.data_as(C.POINTER(C.c_int8))
+        s.rows_gid = g.ctypes.data_as(C.POINTER(C.c_int32))
+        s.rows_mu, s.rows_sigma, s.rows_z = r.mu, r.sigma, r.z
+    if spec.mvnormal is not None:
+        mv = spec.mvnormal
+        # Cholesky + triangular solves, as quaddist_chol does (pymc/distributions/multivariate.py:165-185);
+        # the device consumes the precision matrix so one leapfrog is a single symmetric mat-vec.
+        L = scipy.linalg.cholesky(mv.cov, lower=True)
+        prec = np.ascontiguousarray(scipy.linalg.cho_solve((L, True), np.eye(len(mv.mu))))
+        prec = 0.5 * (prec + prec.T)
+        mu = np.ascontiguousarray(mv.mu, dtype="float64")
+        keep += [prec, mu]
+        s.mvn_var, s.mvn_k = mv.var, len(mu)
+        s.mvn_mu, s.mvn_prec = _lib.dptr(mu), _lib.dptr(prec)
+        s.mvn_logdet = float(np.log(np.diag(L)).sum())
+    return s, keep
+
+
+class DeviceValueGradFunction:
+    """Device-resident logp/dlogp function of a :class:`ModelSpec`."""
+
+    def __init__(self, spec: ModelSpec, device: int | None = None):
+        lib = _lib.load()
+        if device is not None:
+            _lib.check(lib.nuts_set_device(int(device)), "nuts_set_device")
+        self.spec = spec
+        self.dtype = "float64"
+        self._raveled_inputs = True
+        self._extra_vars_shared = {}
+        self.trust_input = True
+        cspec, keep = _pack(spec)
+        self._handle = lib.nuts_model_create(C.byref(cspec))
+        del keep
+        if not self._handle:
+            raise _lib.EngineError(f"nuts_model_create failed: {_lib.last_error()}")
+        self.n = lib.nuts_model_ndim(self._handle)
+        self._grad = np.empty(self.n)
+        self._lp = np.empty(1)
+
+    # the integrator calls `_pytensor_function(q)` directly (integration.py:46-52)
+    def _pytensor_function(self, q):
+        q = np.ascontiguousarray(q, dtype="float64")
+        grad = np.empty(self.n)
+        lp = np.empty(1)
+        rc = _lib.load().nuts_model_logp_grad(self._handle, _lib.dptr(q), _lib.dptr(lp), _lib.dptr(grad))
+        _lib.check(rc, "nuts_model_logp_grad")
+        return lp[0], grad
+
+    def __call__(self, grad_vars, *, extra_vars=None):
+        """`ValueGradFunction.__call__` (pymc/model/core.py:286-300)."""
+        if isinstance(grad_vars, RaveledVars):
+            q = grad_vars.data
+        elif isinstance(grad_vars, dict):
+            q = DictToArrayBijection.map({v.value_name: grad_vars[v.value_name] for v in self.spec.vars}).data
+        else:
+            q = np.asarray(grad_vars[0] if isinstance(grad_vars, (list, tuple)) else grad_vars)
+        return self._pytensor_function(q)
+
+    def set_extra_values(self, extra_vars):  # core.py:275-278 (no non-gradient value vars in these specs)
+        return None
+
+    def time_kernels(self, q, reps=20):
+        ms_tot, ms_dom = C.c_double(), C.c_double()
+        q = np.ascontiguousarray(q, dtype="float64")
+        rc = _lib.load().nuts_model_time_logp_grad(self._handle, _lib.dptr(q), reps, C.byref(ms_tot), C.byref(ms_dom))
+        _lib.check(rc, "nuts_model_time_logp_grad")
+        return ms_tot.value, ms_dom.value
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return int(_lib.load().nuts_model_algorithmic_bytes(self._handle))
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            _lib.load().nuts_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,357 @@
+"""GPU parity tests: HIP engine (through the C ABI) vs the CPU oracle.
+
+Tolerances: logp / gradient <= 1e-9 relative (north_star bar: 1e-6); identical
+seed => identical integer tree statistics (depth, tree_size,
+index_in_trajectory, diverging) over a prefix of draws and positions within 1e-8.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import ref_models, ref_sampler
+from pymc_amd import models
+from pymc_amd.model_spec import ModelBuilder
+
+pytestmark = pytest.mark.gpu
+
+
+def _vg(spec):
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    return DeviceValueGradFunction(spec, device=0)
+
+
+def _check_logp_grad(spec, qs, rtol=1e-9):
+    f = _vg(spec)
+    for q in qs:
+        lp, g = f._pytensor_function(q)
+        lp0, g0 = ref_models.evaluate(spec, q)
+        if np.isfinite(lp0):
+            assert abs(lp - lp0) <= rtol * max(1.0, abs(lp0)), (lp, lp0)
+            scale = max(1.0, np.abs(g0).max())
+            assert np.max(np.abs(g - g0)) <= rtol * scale, np.max(np.abs(g - g0))
+        else:
+            assert lp == lp0 or (np.isnan(lp) and np.isnan(lp0))
+    f.close()
+
+
+def test_golden_joint_logp():
+    """pymc/pytensorf.py:514-546: -12.691227342634292 at [0, 1, 0, 1, 2]."""
+    f = _vg(models.golden_hier_normal())
+    lp, g = f._pytensor_function(np.array([0.0, 1.0, 0.0, 1.0, 2.0]))
+    assert abs(lp - (-12.691227342634292)) < 1e-12
+    f.close()
+
+
+@pytest.mark.parametrize("J", [8, 24])
+def test_eight_schools_logp_grad(J):
+    spec = models.eight_schools(J)
+    rng = np.random.default_rng(1)
+    _check_logp_grad(spec, [np.zeros(spec.n)] + [rng.normal(size=spec.n) for _ in range(5)])
+
+
+def test_all_elementwise_distributions():
+    m = ModelBuilder()
+    a = m.Normal("a", 0.5, 2.0, shape=5)
+    s = m.HalfNormal("s", 1.5)
+    c = m.Cauchy("c", 0.1, 0.7, shape=5)
+    hc = m.HalfCauchy("hc", 3.0, shape=2)
+    t = m.StudentT("t", 4.0, a, s, shape=5)
+    b = m.Beta("b", 3.0, 2.0, shape=3)
+    e = m.Exponential("e", 2.0)
+    u = m.Uniform("u", -1.0, 3.0, shape=4)
+    ln = m.LogNormal("ln", 0.3, 0.8, shape=2)
+    m.Normal("obs", a + s * c, e, observed=np.linspace(-1, 1, 5))
+    m.BernoulliLogit("yl", a, observed=np.array([0, 1, 1, 0, 1.0]))
+    m.Bernoulli("yb", b, observed=np.array([1, 0, 1.0]))
+    spec = m.build()
+    rng = np.random.default_rng(2)
+    _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.7 for _ in range(6)])
+
+
+@pytest.mark.parametrize(
+    "G,D,rpg",
+    [(1, 8, 7), (3, 8, 1), (5, 8, 300), (40, 8, 13), (17, 4, 129), (9, 2, 1000), (64, 8, 256)],
+)
+def test_hier_logit_logp_grad(G, D, rpg):
+    spec = models.hier_logit(G=G, D=D, rows_per_group=rpg, seed=G * 100 + rpg)
+    rng = np.random.default_rng(3)
+    _check_logp_grad(spec, [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.5 for _ in range(3)])
+
+
+def test_hier_logit_ragged_groups():
+    rng = np.random.default_rng(4)
+    G, D = 23, 8
+    sizes = rng.integers(1, 700, size=G)
+    gidx = np.repeat(np.arange(G), sizes).astype("int32")
+    N = len(gidx)
+    X = rng.normal(size=(N, D))
+    y = (rng.random(N) < 0.4).astype("int8")
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 1.0, shape=D)
+    sg = m.HalfNormal("sigma", 1.0, shape=D)
+    z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    m.HierLogitRows("y", X, y, gidx, mu, sg, z)
+    spec = m.build()
+    _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.5 for _ in range(3)])
+
+
+def test_hier_logit_extreme_eta():
+    spec = models.hier_logit(G=4, D=8, rows_per_group=50, seed=7)
+    q = np.zeros(spec.n)
+    q[:8] = 40.0  # saturates sigmoid / softplus branches
+    _check_logp_grad(spec, [q, -q])
+
+
+def test_mvnormal_logp_grad():
+    spec = models.mvnormal(n=200)
+    rng = np.random.default_rng(5)
+    _check_logp_grad(spec, [rng.normal(size=spec.n) for _ in range(3)], rtol=1e-8)
+
+
+def test_invalid_parameter_gives_minus_inf():
+    """check_parameters -> -inf switch (pymc/logprob/utils.py:209-225)."""
+    m = ModelBuilder()
+    s = m.Normal("s", 0.0, 1.0)  # unconstrained scale: negative values are invalid
+    m.Normal("x", 0.0, s, observed=np.array([0.1, 0.2]))
+    spec = m.build()
+    f = _vg(spec)
+    lp, _ = f._pytensor_function(np.array([-1.0]))
+    assert lp == -np.inf
+    f.close()
+
+
+def test_edge_case_dlogp_zero():
+    """tests/model/test_core.py:404-421: LogNormal(0,1)[3] + HalfCauchy(10) at the initial point."""
+    m = ModelBuilder()
+    m.LogNormal("sigma", np.zeros(3), np.ones(3), shape=3)
+    m.HalfCauchy("nu", 10.0)
+    spec = m.build()
+    f = _vg(spec)
+    q = np.array([0.0, 0.0, 0.0, np.log(10.0)])
+    lp, g = f._pytensor_function(q)
+    assert g.size == 4
+    np.testing.assert_allclose(g, 0.0, atol=1e-5)
+    f.close()
+
+
+def test_bernoulli_logodds_known_answer():
+    """tests/model/test_core.py:457-465: 10 * log(0.5)."""
+    m = ModelBuilder()
+    p = m.Beta("p", 1.0, 1.0)
+    m.Bernoulli("obs", p, observed=np.zeros(10))
+    spec = m.build()
+    f = _vg(spec)
+    lp, _ = f._pytensor_function(np.array([0.0]))
+    lp_prior, _ = ref_models.evaluate(ModelBuilderBetaOnly(), np.array([0.0]))
+    np.testing.assert_allclose(lp - lp_prior, np.log(0.5) * 10, rtol=1e-12)
+    f.close()
+
+
+def ModelBuilderBetaOnly():
+    m = ModelBuilder()
+    m.Beta("p", 1.0, 1.0)
+    return m.build()
+
+
+# ---------------------------------------------------------------------------
+# integrator
+# ---------------------------------------------------------------------------
+
+
+def test_leapfrog_reversible():
+    """tests/step_methods/hmc/test_hmc.py:49-74 on Beta(3,3) without transform."""
+    import ctypes as C
+
+    from pymc_amd import _lib
+    from pymc_amd.step import NUTS
+
+    m = ModelBuilder()
+    m.Beta("x", 3.0, 3.0, shape=3, transform=None)
+    spec = m.build()
+    rng = np.random.default_rng(42)
+    scaling = rng.random(spec.n)
+    step = NUTS(model=spec, scaling=scaling, rng=rng, device=0)
+    q0 = np.full(spec.n, 0.5)
+    p0 = rng.normal(size=spec.n)
+    lib = _lib.load()
+    for eps in [0.01, 0.1]:
+        for n_steps in [1, 2, 3, 4, 20]:
+            q1, p1, q2, p2 = (np.empty(spec.n) for _ in range(4))
+            e = C.c_double()
+            _lib.check(lib.nuts_chain_leapfrog_test(step._chain, _lib.dptr(q0), _lib.dptr(p0), eps, n_steps, _lib.dptr(q1), _lib.dptr(p1), C.byref(e)))
+            _lib.check(lib.nuts_chain_leapfrog_test(step._chain, _lib.dptr(q1), _lib.dptr(p1), -eps, n_steps, _lib.dptr(q2), _lib.dptr(p2), C.byref(e)))
+            np.testing.assert_allclose(q2, q0, rtol=1e-5)
+            np.testing.assert_allclose(p2, p0, rtol=1e-5)
+    step.close()
+
+
+def test_leapfrog_matches_oracle():
+    import ctypes as C
+
+    from pymc_amd import _lib
+    from pymc_amd.step import NUTS
+
+    spec = models.eight_schools()
+    rng = np.random.default_rng(0)
+    var = rng.uniform(0.5, 2.0, size=spec.n)
+    step = NUTS(model=spec, scaling=var, is_cov=True, rng=1, device=0)
+    pot = ref_sampler.DiagPotential(var)
+    integ = ref_sampler.Leapfrog(pot, ref_models.SpecLogpGrad(spec))
+    q0, p0 = rng.normal(size=spec.n) * 0.3, rng.normal(size=spec.n)
+    s = integ.compute_state(q0, p0)
+    for _ in range(7):
+        s = integ.step(0.05, s)
+    q1, p1 = np.empty(spec.n), np.empty(spec.n)
+    e = C.c_double()
+    _lib.check(_lib.load().nuts_chain_leapfrog_test(step._chain, _lib.dptr(q0), _lib.dptr(p0), 0.05, 7, _lib.dptr(q1), _lib.dptr(p1), C.byref(e)))
+    np.testing.assert_allclose(q1, s.q, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(p1, s.p, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(e.value, s.energy, rtol=1e-11)
+    step.close()
+
+
+# ---------------------------------------------------------------------------
+# NUTS draws: same seed => same integers, positions to 1e-8
+# ---------------------------------------------------------------------------
+
+INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
+
+
+def _compare_runs(spec, tune, draws, seed, prefix, **kw):
+    from pymc_amd.sampling import sample
+
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, **kw)
+    f = ref_models.SpecLogpGrad(spec)
+    ref_draws, ref_stats = ref_sampler.sample_reference(
+        f, [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag", **kw
+    )
+    dev_stats = res["warmup_stats"][0] + res["stats"][0]
+    dev_draws = res["draws"][0]
+    for i in range(prefix):
+        for k in INT_KEYS:
+            assert int(dev_stats[i][k]) == int(ref_stats[0][i][k]), (i, k, dev_stats[i][k], ref_stats[0][i][k])
+        for k in ("mean_tree_accept", "energy", "model_logp", "step_size", "step_size_bar", "max_energy_error"):
+            np.testing.assert_allclose(dev_stats[i][k], ref_stats[0][i][k], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
+    n_post = min(prefix - tune, draws)
+    if n_post > 0:
+        np.testing.assert_allclose(dev_draws[:n_post], ref_draws[0, tune : tune + n_post], rtol=1e-8, atol=1e-10)
+    res["step"].close()
+    return res, ref_draws, ref_stats
+
+
+def test_nuts_parity_eight_schools():
+    _compare_runs(models.eight_schools(), tune=30, draws=30, seed=20160911, prefix=60)
+
+
+def test_nuts_parity_hier_logit():
+    _compare_runs(models.hier_logit(G=16, D=8, rows_per_group=33, seed=3), tune=25, draws=15, seed=7, prefix=40)
+
+
+def test_nuts_parity_std_normal_through_adaptation():
+    """Runs past the mass-matrix switch-on (draw 102) and a window swap (quadpotential.py:335-355)."""
+    spec = models.std_normal(10)
+    res, ref_draws, ref_stats = _compare_runs(spec, tune=230, draws=20, seed=99, prefix=250)
+
+
+def test_rng_stream_identity():
+    """After a draw the step generator must sit exactly where the reference's would."""
+    from pymc_amd.sampling import sample
+
+    spec = models.eight_schools()
+    res = sample(draws=5, tune=5, chains=1, model=spec, init="adapt_diag", random_seed=5, device=0)
+    step = res["step"]
+    f = ref_models.SpecLogpGrad(spec)
+    rngs, seeds = ref_sampler.spawn_chain_rngs(5, 1)
+    pot = ref_sampler.adapt_diag_potential([np.zeros(spec.n)], seeds[0])
+    ref = ref_sampler.RefNUTS(f, spec.n, potential=pot, rng=seeds[0])
+    ref_sampler.run_chain(ref, np.zeros(spec.n), rngs[0], 5, 5)
+    assert step.rng.bit_generator.state == ref.rng.bit_generator.state
+    assert step.potential.rng.bit_generator.state == ref.potential.rng.bit_generator.state
+    step.close()
+
+
+def test_sampling_state_roundtrip():
+    """tests/helpers.py:140-187: save -> step -> restore -> step gives the identical value."""
+    from pymc_amd.blocking import DictToArrayBijection
+    from pymc_amd.sampling import init_nuts, initial_point
+
+    spec = models.eight_schools()
+    points, step = init_nuts(spec, init="adapt_diag", chains=1, random_seed_list=[11], device=0)
+    step.setup_chain(np.random.default_rng(3), 10, 10)
+    p = points[0]
+    for _ in range(8):
+        p, _ = step.step(p)
+    state = step.sampling_state
+    a, sa = step.step(p)
+    a2, _ = step.step(a)
+    step.sampling_state = state
+    b, sb = step.step(p)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert sa[0]["tree_size"] == sb[0]["tree_size"]
+    step.close()
+
+
+def test_same_seed_bitwise_reproducible():
+    """tests/sampling/test_mcmc.py:80-109: same seed => bitwise-equal draws."""
+    from pymc_amd.sampling import sample
+
+    spec = models.hier_logit(G=8, D=8, rows_per_group=70, seed=1)
+    a = sample(draws=10, tune=20, chains=2, model=spec, random_seed=42, device=0)
+    b = sample(draws=10, tune=20, chains=2, model=spec, random_seed=42, device=0)
+    assert np.array_equal(a["draws"], b["draws"])
+    a["step"].close(); b["step"].close()
+
+
+def test_bad_initial_energy_raises():
+    from pymc_amd.exceptions import SamplingError
+    from pymc_amd.step import NUTS
+    from pymc_amd.blocking import RaveledVars
+
+    m = ModelBuilder()
+    s = m.Normal("s", 0.0, 1.0)
+    m.Normal("x", 0.0, s, observed=np.array([0.1]))
+    spec = m.build()
+    step = NUTS(model=spec, rng=1, device=0)
+    with pytest.raises(SamplingError, match="Bad initial energy"):
+        step.astep(RaveledVars(np.array([-1.0]), spec.point_map_info))
+    step.close()
+
+
+def test_nuts_statistics_std_normal():
+    """tests/sampler_fixtures.py:75-85,140-171: Normal(2, sqrt(3), size=10): mean/var rtol 0.1 atol 0.05."""
+    from pymc_amd.sampling import sample
+    from pymc_amd.stats import ess_bulk, rhat
+
+    spec = models.std_normal(10, 2.0, np.sqrt(3.0))
+    res = sample(draws=1500, tune=600, chains=2, model=spec, random_seed=20160911, device=0)
+    d = res["draws"]
+    np.testing.assert_allclose(d.mean((0, 1)), 2.0, rtol=0.1, atol=0.05 * 3)
+    np.testing.assert_allclose(d.var((0, 1)), 3.0, rtol=0.15, atol=0.05)
+    assert min(ess_bulk(d[:, :, i]) for i in range(10)) > 500
+    assert max(rhat(d[:, :, i]) for i in range(10)) < 1.02
+    acc = np.mean([s["mean_tree_accept"] for st in res["stats"] for s in st])
+    assert abs(acc - 0.8) < 0.1
+    res["step"].close()
+
+
+def test_hmc_matches_oracle():
+    from pymc_amd.blocking import RaveledVars
+    from pymc_amd.step import HamiltonianMC
+
+    spec = models.std_normal(6)
+    f = ref_models.SpecLogpGrad(spec)
+    step = HamiltonianMC(model=spec, rng=4, device=0)
+    ref = ref_sampler.RefHMC(f, spec.n, rng=4)
+    rng_a, rng_b = np.random.default_rng(8), np.random.default_rng(8)
+    step.setup_chain(rng_a, 10, 10)
+    ref.setup_chain(rng_b, 10, 10)
+    q = RaveledVars(np.zeros(spec.n), spec.point_map_info)
+    qr = np.zeros(spec.n)
+    for i in range(25):
+        q, st = step.astep(q)
+        qr, sr = ref.astep(qr)
+        assert st[0]["n_steps"] == sr["n_steps"] and st[0]["accepted"] == sr["accepted"], i
+        np.testing.assert_allclose(q.data, qr, rtol=1e-9, atol=1e-11)
+    step.close()
