@@ -90,41 +90,62 @@ def backward(tr, q, lo, hi):
 
 
 def _dist(dist, konst, a):
-    """a = list of broadcast argument arrays; returns (logp_i, [d/d a_k])."""
+    """a = list of broadcast argument arrays; returns (logp_i, [d/d a_k]).
+
+    Every support / parameter check of the reference is a ``switch(cond, logp, -inf)``
+    (pymc/distributions/dist_math.py:50-74; `check_parameters` rewritten by
+    pymc/logprob/utils.py:209-225), whose reverse-mode gradient is 0 where the
+    check fails: partials are zeroed wherever logp == -inf.
+    """
+    ok = [np.asarray(True)]
+    lp, partials = _dist_raw(dist, konst, a, ok)
+    dead = ~np.broadcast_to(ok[0], np.shape(lp))
+    if np.any(dead):
+        partials = [np.where(dead, 0.0, g) for g in partials]
+    return lp, partials
+
+
+def _guard(ok, cond, lp):
+    """``switch(cond, lp, -inf)`` that also records where the switch failed."""
+    ok[0] = ok[0] & cond
+    return np.where(cond, lp, -np.inf)
+
+
+def _dist_raw(dist, konst, a, ok):
     ninf = -np.inf
     if dist == D_NORMAL:  # continuous.py:526-532
         v, mu, sg = a
         z = (v - mu) / sg
         lp = -0.5 * z * z - LOG_SQRT_2PI - np.log(sg)
-        lp = np.where(sg > 0, lp, ninf)
+        lp = _guard(ok, sg > 0, lp)
         return lp, [-z / sg, z / sg, (z * z - 1) / sg]
     if dist == D_HALFNORMAL:  # continuous.py:909-916 (loc = 0)
         v, sg = a
         z = v / sg
         lp = -0.5 * z * z + LOG_SQRT_2_OVER_PI - np.log(sg)
-        lp = np.where(v >= 0, lp, ninf)
-        lp = np.where(sg > 0, lp, ninf)
+        lp = _guard(ok, v >= 0, lp)
+        lp = _guard(ok, sg > 0, lp)
         return lp, [-z / sg, (z * z - 1) / sg]
     if dist == D_CAUCHY:  # continuous.py:2287-2293
         v, al, be = a
         z = (v - al) / be
         lp = -LOG_PI - np.log(be) - np.log1p(z * z)
-        lp = np.where(be > 0, lp, ninf)
+        lp = _guard(ok, be > 0, lp)
         w = 2 * z / (1 + z * z)
         return lp, [-w / be, w / be, (-1 + w * z) / be]
     if dist == D_HALFCAUCHY:  # continuous.py:2383-2390
         v, be = a
         z = v / be
         lp = LOG_2 - LOG_PI - np.log(be) - np.log1p(z * z)
-        lp = np.where(v >= 0, lp, ninf)
-        lp = np.where(be > 0, lp, ninf)
+        lp = _guard(ok, v >= 0, lp)
+        lp = _guard(ok, be > 0, lp)
         w = 2 * z / (1 + z * z)
         return lp, [-w / be, (-1 + w * z) / be]
     if dist == D_STUDENTT:  # continuous.py:1935-1950 ; nu constant, lam = sigma^-2
         v, nu, mu, sg = a
         z = (v - mu) / sg
         lp = konst - np.log(sg) - (nu + 1.0) / 2.0 * np.log1p(z * z / nu)
-        lp = np.where(sg > 0, lp, ninf)
+        lp = _guard(ok, sg > 0, lp)
         w = (nu + 1.0) * z / (nu + z * z)
         return lp, [-w / sg, np.zeros_like(lp), w / sg, (-1 + w * z) / sg]
     if dist == D_BETA:  # continuous.py:1248-1262 ; alpha, beta constant
@@ -132,23 +153,23 @@ def _dist(dist, konst, a):
         with np.errstate(divide="ignore", invalid="ignore"):
             lp = np.where(al == 1.0, 0.0, (al - 1.0) * np.log(v)) + np.where(be == 1.0, 0.0, (be - 1.0) * np.log1p(-v)) + konst
             dv = np.where(al == 1.0, 0.0, (al - 1.0) / v) - np.where(be == 1.0, 0.0, (be - 1.0) / (1 - v))
-        lp = np.where((v >= 0) & (v <= 1), lp, ninf)
+        lp = _guard(ok, (v >= 0) & (v <= 1), lp)
         return lp, [dv, np.zeros_like(lp), np.zeros_like(lp)]
     if dist == D_EXPONENTIAL:  # continuous.py:1478-1486 with mu = 1/lam
         v, lam = a
         lp = np.log(lam) - v * lam
-        lp = np.where(v >= 0, lp, ninf)
-        lp = np.where(lam > 0, lp, ninf)
+        lp = _guard(ok, v >= 0, lp)
+        lp = _guard(ok, lam > 0, lp)
         return lp, [-lam * np.ones_like(lp), 1 / lam - v]
     if dist == D_UNIFORM:  # continuous.py:309-321 ; bounds constant
         v, lo, hi = a
-        lp = np.where((v >= lo) & (v <= hi), -np.log(hi - lo) * np.ones_like(v), ninf)
-        lp = np.where(lo <= hi, lp, ninf)
+        lp = _guard(ok, (v >= lo) & (v <= hi), -np.log(hi - lo) * np.ones_like(v))
+        lp = _guard(ok, lo <= hi, lp)
         return lp, [np.zeros_like(lp)] * 3
     if dist == D_BERNOULLI_LOGIT:  # discrete.py:351-352,362-374 ; value is data in {0,1}
         y, eta = a
         lp = np.where(y != 0, -softplus(-eta), -softplus(eta))
-        lp = np.where((y < 0) | (y > 1), ninf, lp)
+        lp = _guard(ok, ~((y < 0) | (y > 1)), lp)
         return lp, [np.zeros_like(lp), y - expit(eta)]
     if dist == D_LOGNORMAL:  # continuous.py:1807-1819
         v, mu, sg = a
@@ -156,16 +177,16 @@ def _dist(dist, konst, a):
             lv = np.log(v)
             z = (lv - mu) / sg
             lp = -0.5 * z * z - 0.5 * math.log(2.0 * math.pi) - np.log(sg) - lv
-        lp = np.where(v > 0, lp, ninf)
-        lp = np.where(sg > 0, lp, ninf)
+        lp = _guard(ok, v > 0, lp)
+        lp = _guard(ok, sg > 0, lp)
         return lp, [(-z / sg - 1) / v, z / sg, (z * z - 1) / sg]
     if dist == D_BERNOULLI:  # discrete.py:362-374
         y, p = a
         with np.errstate(divide="ignore", invalid="ignore"):
             lp = np.where(y != 0, np.log(p), np.log1p(-p))
             dp = np.where(y != 0, 1 / p, -1 / (1 - p))
-        lp = np.where((y < 0) | (y > 1), ninf, lp)
-        lp = np.where((p >= 0) & (p <= 1), lp, ninf)
+        lp = _guard(ok, ~((y < 0) | (y > 1)), lp)
+        lp = _guard(ok, (p >= 0) & (p <= 1), lp)
         return lp, [np.zeros_like(lp), dp]
     raise ValueError(dist)
 

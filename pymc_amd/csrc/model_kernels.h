@@ -97,40 +97,42 @@ __device__ __forceinline__ double dist_eval(int dist, double konst, const double
   const double LOG_PI = 1.14472988584940017414;
   const double LOG_2 = 0.69314718055994530942;
   double lp = 0.0;
+  bool dead = false;
+#define KILL_UNLESS(cond) if (!(cond)) { lp = NINF; dead = true; }
   d[0] = d[1] = d[2] = d[3] = 0.0;
   switch (dist) {
     case NUTS_D_NORMAL: {  // continuous.py:526-532
       double sg = a[2], z = (a[0] - a[1]) / sg;
       lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg);
-      if (!(sg > 0)) lp = NINF;
+      KILL_UNLESS(sg > 0)
       d[0] = -z / sg; d[1] = z / sg; d[2] = (z * z - 1.0) / sg;
     } break;
     case NUTS_D_HALFNORMAL: {  // continuous.py:909-916
       double sg = a[1], z = a[0] / sg;
       lp = -0.5 * z * z + LOG_SQRT_2_OVER_PI - log(sg);
-      if (!(a[0] >= 0)) lp = NINF;
-      if (!(sg > 0)) lp = NINF;
+      KILL_UNLESS(a[0] >= 0)
+      KILL_UNLESS(sg > 0)
       d[0] = -z / sg; d[1] = (z * z - 1.0) / sg;
     } break;
     case NUTS_D_CAUCHY: {  // continuous.py:2287-2293
       double be = a[2], z = (a[0] - a[1]) / be;
       lp = -LOG_PI - log(be) - log1p(z * z);
-      if (!(be > 0)) lp = NINF;
+      KILL_UNLESS(be > 0)
       double w = 2.0 * z / (1.0 + z * z);
       d[0] = -w / be; d[1] = w / be; d[2] = (-1.0 + w * z) / be;
     } break;
     case NUTS_D_HALFCAUCHY: {  // continuous.py:2383-2390
       double be = a[1], z = a[0] / be;
       lp = LOG_2 - LOG_PI - log(be) - log1p(z * z);
-      if (!(a[0] >= 0)) lp = NINF;
-      if (!(be > 0)) lp = NINF;
+      KILL_UNLESS(a[0] >= 0)
+      KILL_UNLESS(be > 0)
       double w = 2.0 * z / (1.0 + z * z);
       d[0] = -w / be; d[1] = (-1.0 + w * z) / be;
     } break;
     case NUTS_D_STUDENTT: {  // continuous.py:1935-1950 (nu constant)
       double nu = a[1], sg = a[3], z = (a[0] - a[2]) / sg;
       lp = konst - log(sg) - (nu + 1.0) / 2.0 * log1p(z * z / nu);
-      if (!(sg > 0)) lp = NINF;
+      KILL_UNLESS(sg > 0)
       double w = (nu + 1.0) * z / (nu + z * z);
       d[0] = -w / sg; d[2] = w / sg; d[3] = (-1.0 + w * z) / sg;
     } break;
@@ -138,42 +140,47 @@ __device__ __forceinline__ double dist_eval(int dist, double konst, const double
       double v = a[0], al = a[1], be = a[2];
       lp = (al == 1.0 ? 0.0 : (al - 1.0) * log(v)) + (be == 1.0 ? 0.0 : (be - 1.0) * log1p(-v)) + konst;
       d[0] = (al == 1.0 ? 0.0 : (al - 1.0) / v) - (be == 1.0 ? 0.0 : (be - 1.0) / (1.0 - v));
-      if (!(v >= 0 && v <= 1)) lp = NINF;
+      KILL_UNLESS(v >= 0 && v <= 1)
     } break;
     case NUTS_D_EXPONENTIAL: {  // continuous.py:1478-1486 (mu = 1/lam)
       double v = a[0], lam = a[1];
       lp = log(lam) - v * lam;
-      if (!(v >= 0)) lp = NINF;
-      if (!(lam > 0)) lp = NINF;
+      KILL_UNLESS(v >= 0)
+      KILL_UNLESS(lam > 0)
       d[0] = -lam; d[1] = 1.0 / lam - v;
     } break;
     case NUTS_D_UNIFORM: {  // continuous.py:309-321
       double v = a[0], lo = a[1], hi = a[2];
-      lp = (v >= lo && v <= hi) ? -log(hi - lo) : NINF;
-      if (!(lo <= hi)) lp = NINF;
+      lp = -log(hi - lo);
+      KILL_UNLESS(v >= lo && v <= hi)
+      KILL_UNLESS(lo <= hi)
     } break;
     case NUTS_D_BERNOULLI_LOGIT: {  // discrete.py:351-352,362-374
       double y = a[0], eta = a[1];
       lp = (y != 0.0) ? -softplus_d(-eta) : -softplus_d(eta);
-      if (y < 0 || y > 1) lp = NINF;
+      KILL_UNLESS(y >= 0 && y <= 1)
       d[1] = y - sigmoid_d(eta);
     } break;
     case NUTS_D_LOGNORMAL: {  // continuous.py:1807-1819
       double v = a[0], sg = a[2], lv = log(v), z = (lv - a[1]) / sg;
       lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg) - lv;
-      if (!(v > 0)) lp = NINF;
-      if (!(sg > 0)) lp = NINF;
+      KILL_UNLESS(v > 0)
+      KILL_UNLESS(sg > 0)
       d[0] = (-z / sg - 1.0) / v; d[1] = z / sg; d[2] = (z * z - 1.0) / sg;
     } break;
     case NUTS_D_BERNOULLI: {  // discrete.py:362-374
       double y = a[0], p = a[1];
       lp = (y != 0.0) ? log(p) : log1p(-p);
       d[1] = (y != 0.0) ? 1.0 / p : -1.0 / (1.0 - p);
-      if (y < 0 || y > 1) lp = NINF;
-      if (!(p >= 0 && p <= 1)) lp = NINF;
+      KILL_UNLESS(y >= 0 && y <= 1)
+      KILL_UNLESS(p >= 0 && p <= 1)
     } break;
     default: lp = NAN;
   }
+  // every support / parameter check is a `switch(cond, logp, -inf)` in the reference graph
+  // (dist_math.py:50-74, logprob/utils.py:209-225): its gradient is 0 where the check fails.
+  if (dead) d[0] = d[1] = d[2] = d[3] = 0.0;
+#undef KILL_UNLESS
   return lp;
 }
 

@@ -1,0 +1,106 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/nuts_mi355.h declares.
+
+No compute calls: on a GPU-less host the only behaviour exercised is that the
+product path FAILS LOUDLY (there is no CPU fallback).
+"""
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nuts_mi355.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    g.build_engine()
+    from pymc_amd import _lib
+
+    return _lib.load()
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(nuts_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    from pymc_amd import _lib
+
+    declared = _declared_functions()
+    assert len(declared) >= 25
+    assert sorted(_lib.SYMBOLS) == declared, "ctypes binding table and header disagree"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    missing = [n for n in declared if n not in exported]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    extra = sorted(n for n in exported if n.startswith("nuts_") and n not in declared)
+    assert not extra, f"exported but not declared in the header: {extra}"
+
+
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """sizeof/offsetof of every ABI struct, compiled by gcc from the header, equals the ctypes mirror."""
+    from pymc_amd import _lib
+
+    structs = {
+        "nuts_operand": _lib.Operand, "nuts_term": _lib.Term, "nuts_factor": _lib.Factor, "nuts_var": _lib.Var,
+        "nuts_data_ref": _lib.DataRef, "nuts_model_spec": _lib.ModelSpecC, "nuts_chain_config": _lib.ChainConfig,
+        "nuts_draw_stats": _lib.DrawStats, "nuts_hmc_stats": _lib.HmcStats,
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_default_config_matches_reference_defaults(lib):
+    """BaseHMC.__init__ / NUTS.__init__ defaults (base_hmc.py:82-100, nuts.py:132-140)."""
+    from pymc_amd import _lib
+
+    cfg = _lib.ChainConfig()
+    lib.nuts_chain_config_default(C.byref(cfg))
+    assert (cfg.step_scale, cfg.Emax, cfg.target_accept) == (0.25, 1000.0, 0.8)
+    assert (cfg.gamma, cfg.k, cfg.t0) == (0.05, 0.75, 10.0)
+    assert (cfg.max_treedepth, cfg.early_max_treedepth, cfg.adapt_step_size) == (10, 8, 1)
+    assert (cfg.adaptation_window, cfg.discard_window, cfg.adaptation_window_multiplier) == (101, 50, 1.0)
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device the product path must raise, never compute on the host."""
+    if lib.nuts_device_count() > 0:
+        pytest.skip("a GPU is visible: the loud-failure path is for GPU-less hosts")
+    from pymc_amd import _lib, models
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    with pytest.raises(_lib.EngineError, match="no HIP device|no CPU fallback"):
+        DeviceValueGradFunction(models.eight_schools())
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pymc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "oracle/" not in txt or f.endswith(".md"), f

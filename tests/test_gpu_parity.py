@@ -160,7 +160,12 @@ def ModelBuilderBetaOnly():
 
 
 def test_leapfrog_reversible():
-    """tests/step_methods/hmc/test_hmc.py:49-74 on Beta(3,3) without transform."""
+    """tests/step_methods/hmc/test_hmc.py:49-74 (`non_normal` = Beta(3,3), default_transform=None).
+
+    Like the reference test the position is `potential.random()` and the momentum a
+    standard normal draw, so most coordinates start OUTSIDE (0,1) where the
+    reference's `switch(in_support, logp, -inf)` has zero gradient.
+    """
     import ctypes as C
 
     from pymc_amd import _lib
@@ -172,7 +177,7 @@ def test_leapfrog_reversible():
     rng = np.random.default_rng(42)
     scaling = rng.random(spec.n)
     step = NUTS(model=spec, scaling=scaling, rng=rng, device=0)
-    q0 = np.full(spec.n, 0.5)
+    q0 = step.potential._draw_normals() * step.potential._inv_stds  # potential.random()
     p0 = rng.normal(size=spec.n)
     lib = _lib.load()
     for eps in [0.01, 0.1]:
@@ -183,6 +188,17 @@ def test_leapfrog_reversible():
             _lib.check(lib.nuts_chain_leapfrog_test(step._chain, _lib.dptr(q1), _lib.dptr(p1), -eps, n_steps, _lib.dptr(q2), _lib.dptr(p2), C.byref(e)))
             np.testing.assert_allclose(q2, q0, rtol=1e-5)
             np.testing.assert_allclose(p2, p0, rtol=1e-5)
+    # inside the support as well (smooth region: no boundary crossing)
+    q0 = np.array([0.45, 0.5, 0.55])
+    p0 = np.array([0.01, -0.02, 0.015])
+    for eps, n_steps in [(0.01, 4), (0.05, 20)]:
+        q1, p1, q2, p2 = (np.empty(spec.n) for _ in range(4))
+        e = C.c_double()
+        _lib.check(lib.nuts_chain_leapfrog_test(step._chain, _lib.dptr(q0), _lib.dptr(p0), eps, n_steps, _lib.dptr(q1), _lib.dptr(p1), C.byref(e)))
+        assert np.all((q1 > 0) & (q1 < 1)) and not np.allclose(q1, q0)
+        _lib.check(lib.nuts_chain_leapfrog_test(step._chain, _lib.dptr(q1), _lib.dptr(p1), -eps, n_steps, _lib.dptr(q2), _lib.dptr(p2), C.byref(e)))
+        np.testing.assert_allclose(q2, q0, rtol=1e-9)
+        np.testing.assert_allclose(p2, p0, rtol=1e-7)
     step.close()
 
 

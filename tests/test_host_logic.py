@@ -1,0 +1,158 @@
+"""Host-side mirror of the reference interface (no GPU): blocking, the spec builder,
+potentials' argument checking, chain assignment, RNG plumbing and the ESS arithmetic."""
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from pymc_amd import models
+from pymc_amd.blocking import DictToArrayBijection, RaveledVars
+from pymc_amd.model_spec import TR_LOG, TR_LOGODDS, TR_NONE, ModelBuilder
+from pymc_amd.quadpotential import PositiveDefiniteError, QuadPotentialDiagAdapt, quad_potential
+from pymc_amd.sampling import assign_chains, initial_point
+from pymc_amd.stats import ess_bulk, min_ess_bulk, rhat
+from pymc_amd.step import NUTS, HamiltonianMC, _rng_from_state, _rng_state, get_random_generator
+
+
+def test_dict_to_array_bijection_roundtrip():
+    """pymc/blocking.py:67-103: C-order ravel, dict order, rmap reshapes + casts and copies."""
+    point = {"a": np.arange(6.0).reshape(2, 3), "b": np.array(7.0), "c": np.array([1, 2], dtype="int64")}
+    rv = DictToArrayBijection.map(point)
+    npt.assert_array_equal(rv.data, [0, 1, 2, 3, 4, 5, 7, 1, 2])
+    assert [i[0] for i in rv.point_map_info] == ["a", "b", "c"]
+    assert [i[1] for i in rv.point_map_info] == [(2, 3), (), (2,)]
+    back = DictToArrayBijection.rmap(rv, start_point={"z": 1})
+    assert back["z"] == 1 and back["c"].dtype == np.int64
+    for k in point:
+        npt.assert_array_equal(back[k], point[k])
+    back["a"][0, 0] = 99  # rmap copies (blocking.py:100)
+    assert rv.data[0] == 0
+
+
+def test_value_variable_layout_and_names():
+    """registration order, `{name}_{transform}__` names, C2 layout mu | sigma_log__ | z."""
+    spec = models.hier_logit(G=5, D=8, rows_per_group=3)
+    assert [v.value_name for v in spec.vars] == ["mu", "sigma_log__", "z"]
+    assert [v.offset for v in spec.vars] == [0, 8, 16] and spec.n == 8 + 8 + 40
+    assert [i[1] for i in spec.point_map_info] == [(8,), (8,), (5, 8)]
+    assert np.all(np.diff(spec.logit_rows.group_idx) >= 0)
+    es = models.eight_schools(24)
+    assert [v.value_name for v in es.vars] == ["eta", "mu", "tau_log__"] and es.n == 26
+    m = ModelBuilder()
+    m.Beta("p", 2.0, 2.0)
+    m.Uniform("u", 0.0, 2.0)
+    m.Normal("x", 0.0, 1.0)
+    s = m.build()
+    assert [v.value_name for v in s.vars] == ["p_logodds__", "u_interval__", "x"]
+    assert [v.transform for v in s.vars[:1]] == [TR_LOGODDS] and s.vars[2].transform == TR_NONE
+    assert models.hier_logit(G=1248, D=8, rows_per_group=1).n == 10_000
+
+
+def test_hier_logit_rows_get_sorted_by_group():
+    rng = np.random.default_rng(0)
+    g = rng.integers(0, 4, size=50).astype("int32")
+    X = rng.normal(size=(50, 8))
+    y = rng.integers(0, 2, size=50)
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0, 1, shape=8)
+    sg = m.HalfNormal("sigma", 1.0, shape=8)
+    z = m.Normal("z", 0, 1, shape=(4, 8))
+    m.HierLogitRows("y", X, y, g, mu, sg, z)
+    r = m.build().logit_rows
+    assert np.all(np.diff(r.group_idx) >= 0)
+    order = np.argsort(g, kind="stable")
+    npt.assert_array_equal(r.X, X[order])
+    npt.assert_array_equal(r.y, y[order])
+
+
+def test_affine_ir_rejects_what_it_cannot_express():
+    m = ModelBuilder()
+    a = m.Normal("a", 0, 1, shape=3)
+    b = m.Normal("b", 0, 1, shape=3)
+    c = m.Normal("c", 0, 1)
+    e = a + b * c  # a + b*c is the IR's shape
+    assert e.size == 3
+    with pytest.raises(NotImplementedError):
+        (a * b) * c
+    with pytest.raises(ValueError):
+        m.Normal("bad", np.zeros(4), 1.0, shape=3)
+
+
+def test_quadpotential_argument_checks():
+    """quadpotential.py:53-105, 262-279; tests/step_methods/hmc/test_quadpotential.py:27-31."""
+    with pytest.raises(PositiveDefiniteError):
+        quad_potential(np.array([0.0, 2.0, 3.0]), True)
+    with pytest.raises(ValueError, match="one-dimensional"):
+        QuadPotentialDiagAdapt(2, np.zeros(2), np.ones((2, 2)))
+    with pytest.raises(ValueError, match="Wrong shape for initial_diag"):
+        QuadPotentialDiagAdapt(2, np.zeros(2), np.ones(3))
+    with pytest.raises(ValueError, match="Wrong shape for initial_mean"):
+        QuadPotentialDiagAdapt(2, np.zeros(3), np.ones(2))
+    pot = QuadPotentialDiagAdapt(3, np.zeros(3))  # initial_diag None -> ones, weight 1 (quadpotential.py:280-282)
+    npt.assert_array_equal(pot._initial_diag, np.ones(3))
+    assert pot._initial_weight == 1
+    assert np.isnan(pot.stats()["largest_eigval"])
+
+
+def test_step_class_surface_matches_reference():
+    """nuts.py:104-130, hmc.py:47-68, compound.py:108-131."""
+    assert NUTS.name == "nuts" and NUTS.default_blocked
+    keys = list(NUTS.stats_dtypes_shapes)
+    assert len(keys) == 19
+    for k in ["depth", "step_size", "tune" if False else "mean_tree_accept", "step_size_bar", "tree_size", "diverging", "divergences",
+              "energy_error", "energy", "max_energy_error", "model_logp", "process_time_diff", "perf_counter_diff",
+              "perf_counter_start", "largest_eigval", "smallest_eigval", "index_in_trajectory", "reached_max_treedepth", "warning"]:
+        assert k in keys
+    assert NUTS.stats_dtypes_shapes["depth"][0] is np.int64 and NUTS.stats_dtypes_shapes["tree_size"][0] is np.float64
+    assert NUTS.competence(np.zeros(1), True) == 3 and NUTS.competence(np.zeros(1, dtype="int64"), True) == 0
+    assert NUTS.competence(np.zeros(1), False) == 0
+    assert HamiltonianMC.name == "hmc" and "n_steps" in HamiltonianMC.stats_dtypes_shapes
+    assert HamiltonianMC.competence(np.zeros(1), True) == 1
+
+
+def test_rng_plumbing():
+    """util.py:519-594: state round trip keeps the spawn counter; copy semantics of get_random_generator."""
+    g = np.random.default_rng(7)
+    g.spawn(2)
+    g.random(3)
+    g2 = _rng_from_state(_rng_state(g))
+    assert g2.random() == g.random()
+    assert g2.spawn(1)[0].random() == g.spawn(1)[0].random()
+    src = np.random.default_rng(1)
+    cp = get_random_generator(src)
+    assert cp is not src and cp.random() == np.random.default_rng(1).random()
+    assert get_random_generator(src, copy_=False) is src
+    with pytest.raises(TypeError):
+        get_random_generator(np.random.RandomState(1))
+
+
+def test_chain_assignment_covers_every_chain_once():
+    for chains, world in [(8, 8), (8, 4), (4, 8), (5, 2), (1, 1)]:
+        got = sorted(c for r in range(world) for c in assign_chains(chains, r, world))
+        assert got == list(range(chains))
+    assert assign_chains(8, 3, 8) == [3]
+
+
+def test_initial_point_is_zero_in_unconstrained_space():
+    p = initial_point(models.eight_schools())
+    assert list(p) == ["eta", "mu", "tau_log__"] and all(np.all(v == 0) for v in p.values())
+
+
+def test_ess_on_ar1_and_iid():
+    """Bulk-ESS of an AR(1) process with coefficient rho is N (1-rho)/(1+rho) (Vehtari et al. 2021)."""
+    rng = np.random.default_rng(0)
+    C, N = 4, 4000
+    iid = rng.normal(size=(C, N))
+    assert ess_bulk(iid) == pytest.approx(C * N, rel=0.1)
+    assert rhat(iid) < 1.01
+    rho = 0.7
+    x = np.empty((C, N))
+    x[:, 0] = rng.normal(size=C)
+    for t in range(1, N):
+        x[:, t] = rho * x[:, t - 1] + np.sqrt(1 - rho**2) * rng.normal(size=C)
+    assert ess_bulk(x) == pytest.approx(C * N * (1 - rho) / (1 + rho), rel=0.15)
+    shifted = iid + np.arange(C)[:, None] * 3.0
+    assert rhat(shifted) > 1.5 and ess_bulk(shifted) < 50
+    d = np.stack([iid, x], axis=-1)
+    m, arg = min_ess_bulk(d)
+    assert arg == 1 and m == pytest.approx(ess_bulk(x))
