@@ -1,9 +1,9 @@
 // libnuts_mi355.so -- host side of the C ABI declared in include/nuts_mi355.h.
 //
-// One library stream per model; every kernel of a draw is enqueued on it and the
-// host synchronises once per tree doubling (it only needs to know "stop or keep
-// doubling").  All trajectory state stays in HBM for the whole chain; per draw the
-// host uploads (q0, normals, uniforms) in one pinned copy and downloads
+// One library stream per model; every kernel of a draw is enqueued on it (three launches per
+// leapfrog, see kernels.h) and the host synchronises once per tree doubling (it only needs to
+// know "stop or keep doubling").  All trajectory state stays in HBM for the whole chain; per
+// draw the host uploads (q0, normals, uniforms) in one pinned copy and downloads
 // (q, grad, stats).
 #include <hip/hip_runtime.h>
 
@@ -11,13 +11,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <string>
 #include <vector>
 
-#include "chain_kernels.h"
-#include "model_kernels.h"
+#include "kernels.h"
 #include "nuts_mi355.h"
 
 static thread_local std::string g_err;
@@ -39,6 +39,11 @@ static thread_local std::string g_err;
       return nullptr;                                                                       \
     }                                                                                       \
   } while (0)
+
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
+}
 
 template <typename T>
 static T* dev_alloc(size_t count) {
@@ -64,7 +69,9 @@ struct nuts_model {
   double* g_dev = nullptr;
   double* lp_dev = nullptr;
   double* host_pin = nullptr;  // pinned [2n+2]
-  int rows_grid = 0, groups_grid = 0, final_grid = 0, mvn_grid = 0;
+  int rows_grid = 0, mvn_grid = 0, ept = 1;
+  int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
+  int explicit_pre = 0;        // the position must be materialised before the dense pass (MvNormal node)
   int64_t alg_bytes = 0;
   // profiling of the dominant kernel
   bool profile = false;
@@ -91,38 +98,141 @@ extern "C" int nuts_set_device(int device) {
 }
 extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
 
-static int model_enqueue(nuts_model* m, const double* q_dev, double* g_dev, double* lp_dev, const int* abort_flag) {
+static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int d) {
+  const ModelDev& md = m->md;
+  switch (m->ept) {
+    case 1: hipLaunchKernelGGL(k_vector<1>, dim3(md.nblk), dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
+    case 4: hipLaunchKernelGGL(k_vector<4>, dim3(md.nblk), dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
+    default: hipLaunchKernelGGL(k_vector<16>, dim3(md.nblk), dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
+  }
+}
+
+// kernel A of the pipeline: the pass over the model data (timed when profiling is on)
+static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j) {
   ModelDev& md = m->md;
-  hipLaunchKernelGGL(k_model_elem, dim3(1), dim3(ELEM_THREADS), 0, m->stream, md, q_dev, abort_flag);
+  if (!md.has_logit && !md.has_mvn) return;
+  const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
+  if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
   if (md.has_logit) {
-    const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
-    if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
-    switch (md.lg.D) {
-      case 8: hipLaunchKernelGGL(k_logit_rows<8>, dim3(m->rows_grid), dim3(ROWS_BLOCK), 0, m->stream, md.lg, q_dev, abort_flag); break;
-      case 4: hipLaunchKernelGGL(k_logit_rows<4>, dim3(m->rows_grid), dim3(ROWS_BLOCK), 0, m->stream, md.lg, q_dev, abort_flag); break;
-      case 2: hipLaunchKernelGGL(k_logit_rows<2>, dim3(m->rows_grid), dim3(ROWS_BLOCK), 0, m->stream, md.lg, q_dev, abort_flag); break;
+    const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
+    const dim3 grid(m->rows_grid), block(ROWS_BLOCK);
+#define ROWS_LAUNCH(DD, RR, OO) hipLaunchKernelGGL((k_rows<DD, RR, OO>), grid, block, 0, m->stream, md.lg, A, io, j, rev)
+#define ROWS_BY_D(RR, OO)                                   \
+    switch (md.lg.D) {                                      \
+      case 8: ROWS_LAUNCH(8, RR, OO); break;                \
+      case 4: ROWS_LAUNCH(4, RR, OO); break;                \
+      default: ROWS_LAUNCH(2, RR, OO); break;               \
     }
-    if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; }
-    m->dom_launches++;
-    switch (md.lg.D) {
-      case 8: hipLaunchKernelGGL(k_logit_groups<8>, dim3(m->groups_grid), dim3(256), 0, m->stream, md.lg, md, q_dev, abort_flag); break;
-      case 4: hipLaunchKernelGGL(k_logit_groups<4>, dim3(m->groups_grid), dim3(256), 0, m->stream, md.lg, md, q_dev, abort_flag); break;
-      case 2: hipLaunchKernelGGL(k_logit_groups<2>, dim3(m->groups_grid), dim3(256), 0, m->stream, md.lg, md, q_dev, abort_flag); break;
+#define ROWS_BY_OCC(RR)                                     \
+    switch (m->rows_occ) {                                  \
+      case 3: ROWS_BY_D(RR, 3) break;                       \
+      case 5: ROWS_BY_D(RR, 5) break;                       \
+      case 6: ROWS_BY_D(RR, 6) break;                       \
+      default: ROWS_BY_D(RR, 4) break;                      \
     }
+    if (m->rows_rpl == 2) { ROWS_BY_OCC(2) } else { ROWS_BY_OCC(4) }
+#undef ROWS_BY_OCC
+#undef ROWS_BY_D
+#undef ROWS_LAUNCH
   }
-  if (md.has_mvn) {
-    const bool prof = m->profile && !md.has_logit && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
-    if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
-    hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid), dim3(256), 0, m->stream, md.mv, md, q_dev, abort_flag);
-    if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; }
-    if (!md.has_logit) m->dom_launches++;
+  if (md.has_mvn) hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid), dim3(256), 0, m->stream, md.mv, A, io, j);
+  if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; }
+  m->dom_launches++;
+}
+
+// logp + gradient at a plain position vector (ValueGradFunction.__call__): A, B, C in MODE_PLAIN
+static void model_enqueue_plain(nuts_model* m, const double* q_dev, double* g_dev, double* lp_dev) {
+  ArenaDev A{};
+  A.n = m->md.n; A.nblk = m->md.nblk; A.ept = m->ept; A.S = 1;
+  EvalIO io{MODE_PLAIN, 0, q_dev, g_dev, lp_dev};
+  launch_dense(m, A, io, 0);
+  launch_vector(m, A, io, 0, 0);
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr);
+}
+
+// "Compile" the spec: contributions per variable, broadcast terms, deferred elements, orphan factors.
+static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<VarDev>& vars) {
+  ModelDev& md = m->md;
+  const int nv = s->n_vars, nf = s->n_factors;
+  vars.resize(nv);
+  for (int k = 0; k < nv; ++k) {
+    const nuts_var& v = s->vars[k];
+    vars[k] = VarDev{v.offset, v.size, v.transform, v.size == 1 ? 1 : 0, v.lower, v.upper};
+    if (v.size <= 0) { g_err = "empty value variable"; return false; }
   }
-  switch (md.has_logit ? md.lg.D : 8) {
-    case 8: hipLaunchKernelGGL(k_model_final<8>, dim3(m->final_grid), dim3(256), 0, m->stream, md, g_dev, lp_dev, abort_flag); break;
-    case 4: hipLaunchKernelGGL(k_model_final<4>, dim3(m->final_grid), dim3(256), 0, m->stream, md, g_dev, lp_dev, abort_flag); break;
-    case 2: hipLaunchKernelGGL(k_model_final<2>, dim3(m->final_grid), dim3(256), 0, m->stream, md, g_dev, lp_dev, abort_flag); break;
+  if (s->rows_N > 0) { vars[s->rows_mu].deferred = 1; vars[s->rows_sigma].deferred = 1; }
+  std::vector<std::vector<Contrib>> per_var(nv);
+  std::vector<FactorBT> fbt(std::max(nf, 1));
+  std::vector<int32_t> bterm_var, orphans;
+  for (int fi = 0; fi < nf; ++fi) {
+    const nuts_factor& f = s->factors[fi];
+    fbt[fi].n = 0; fbt[fi].pad = 0;
+    if (f.nargs < 1 || f.nargs > 4 || f.size < 1) { g_err = "factor with a bad argument count or size"; return false; }
+    bool owned_already = false;
+    for (int a = 0; a < f.nargs; ++a) {
+      const nuts_operand* ops[3] = {&f.arg[a].a, &f.arg[a].b, &f.arg[a].c};
+      for (int sl = 0; sl < 3; ++sl) {
+        const nuts_operand& o = *ops[sl];
+        if (o.kind == NUTS_OP_DATA) {
+          if (o.ref < 0 || o.ref >= s->n_data) { g_err = "factor refers to a missing data vector"; return false; }
+          const int64_t ds = s->data[o.ref].size;
+          if (ds != 1 && ds != f.size) { g_err = "data vector does not broadcast against its factor"; return false; }
+        }
+        if (o.kind != NUTS_OP_VAR) continue;
+        if (o.ref < 0 || o.ref >= nv) { g_err = "factor refers to a missing variable"; return false; }
+        const VarDev& v = vars[o.ref];
+        if (v.size == f.size) {
+          per_var[o.ref].push_back(Contrib{fi, (int16_t)a, (int16_t)sl, owned_already ? 0 : 1, 0});
+          owned_already = true;
+        } else if (v.size == 1) {
+          int b = -1;
+          for (size_t t = 0; t < bterm_var.size(); ++t) if (bterm_var[t] == o.ref) b = (int)t;
+          if (b < 0) {
+            if ((int)bterm_var.size() >= MAX_BTERMS) { g_err = "too many scalar variables broadcast against vector factors (MAX_BTERMS)"; return false; }
+            b = (int)bterm_var.size();
+            bterm_var.push_back(o.ref);
+          }
+          if (fbt[fi].n >= MAX_FACTOR_BT) { g_err = "too many scalar operands in one factor (MAX_FACTOR_BT)"; return false; }
+          fbt[fi].e[fbt[fi].n].arg = (int16_t)a; fbt[fi].e[fbt[fi].n].slot = (int16_t)sl; fbt[fi].e[fbt[fi].n].bterm = b;
+          fbt[fi].n++;
+        } else { g_err = "variable does not broadcast against its factor"; return false; }
+      }
+    }
+    if (!owned_already) orphans.push_back(fi);
   }
-  return NUTS_OK;
+  std::vector<int32_t> cptr(nv + 1, 0);
+  std::vector<Contrib> contrib;
+  for (int k = 0; k < nv; ++k) {
+    cptr[k] = (int32_t)contrib.size();
+    contrib.insert(contrib.end(), per_var[k].begin(), per_var[k].end());
+  }
+  cptr[nv] = (int32_t)contrib.size();
+  std::vector<int32_t> deferred;
+  for (int k = 0; k < nv; ++k)
+    if (vars[k].deferred) for (int i = 0; i < vars[k].size; ++i) deferred.push_back(vars[k].offset + i);
+  if ((int)deferred.size() > MAX_DEFERRED) { g_err = "too many scalar / hyper-parameter elements (MAX_DEFERRED)"; return false; }
+  md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size();
+  md.orphans = m->keep(dev_upload(orphans.data(), orphans.size()));
+  md.deferred = m->keep(dev_upload(deferred.data(), deferred.size()));
+  // pack the interpreter's tables into one blob (copied into LDS by kernels B and C)
+  std::vector<char> blob;
+  auto put = [&](const void* src, size_t bytes) {
+    const size_t off = (blob.size() + 15) & ~(size_t)15;
+    blob.resize(off + std::max<size_t>(bytes, 16), 0);
+    if (bytes) std::memcpy(blob.data() + off, src, bytes);
+    return (int32_t)off;
+  };
+  md.po_vars = put(vars.data(), vars.size() * sizeof(VarDev));
+  md.po_cptr = put(cptr.data(), cptr.size() * sizeof(int32_t));
+  md.po_contrib = put(contrib.data(), contrib.size() * sizeof(Contrib));
+  md.po_factors = put(s->factors, (size_t)nf * sizeof(nuts_factor));
+  md.po_fbt = put(fbt.data(), (size_t)nf * sizeof(FactorBT));
+  md.po_btvar = put(bterm_var.data(), bterm_var.size() * sizeof(int32_t));
+  md.po_data = put(s->data, (size_t)s->n_data * sizeof(nuts_data_ref));
+  blob.resize((blob.size() + 15) & ~(size_t)15, 0);
+  md.prog_bytes = (int32_t)blob.size();
+  md.prog = m->keep(dev_upload(blob.data(), blob.size()));
+  return true;
 }
 
 extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
@@ -138,113 +248,147 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   int n = 0;
   for (int i = 0; i < s->n_vars; ++i) n = std::max(n, s->vars[i].offset + s->vars[i].size);
   md.n = n; md.n_vars = s->n_vars; md.n_factors = s->n_factors; md.n_data = s->n_data;
-  md.vars = m->keep(dev_upload(s->vars, s->n_vars));
-  md.factors = m->keep(dev_upload(s->factors, s->n_factors));
-  md.data = m->keep(dev_upload(s->data, s->n_data));
+  std::vector<VarDev> vars;
+  if (!compile_spec(m, s, vars)) { nuts_model_destroy(m); return nullptr; }
   md.pool = m->keep(dev_upload(s->data_pool, s->data_pool_len));
-  md.x = m->keep(dev_alloc<double>(n));
-  md.dxdq = m->keep(dev_alloc<double>(n));
-  md.djac = m->keep(dev_alloc<double>(n));
-  md.gx = m->keep(dev_alloc<double>(n));
-  md.gdense = m->keep(dev_alloc<double>(n));
-  md.lp_elem = m->keep(dev_alloc<double>(1));
-  hipMemset(md.gdense, 0, n * sizeof(double));
+  m->ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
+  md.nblk = (n + VEC_THREADS * m->ept - 1) / (VEC_THREADS * m->ept);
+  md.part_stride = PART_STRIDE;
+  md.part = m->keep(dev_alloc<double>((size_t)md.nblk * PART_STRIDE));
+  hipMemset(md.part, 0, (size_t)md.nblk * PART_STRIDE * sizeof(double));
   m->q_dev = m->keep(dev_alloc<double>(n));
   m->g_dev = m->keep(dev_alloc<double>(n));
   m->lp_dev = m->keep(dev_alloc<double>(2));
   HIPCHK_NULL(hipHostMalloc((void**)&m->host_pin, (2 * (size_t)n + 2) * sizeof(double), hipHostMallocDefault));
-  m->final_grid = std::max(1, std::min(256, (n + 255) / 256));
   m->alg_bytes = 0;
 
   hipDeviceProp_t prop;
-  hipGetDeviceProperties(&prop, 0);
+  int dev = 0;
+  hipGetDevice(&dev);
+  hipGetDeviceProperties(&prop, dev);
   const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
   if (s->rows_N > 0) {
     const int D = s->rows_D;
-    if (!(D == 8 || D == 4 || D == 2)) { g_err = "logit rows: D must be 2, 4 or 8"; delete m; return nullptr; }
-    LogitDev& lg = md.lg;
+    if (!(D == 8 || D == 4 || D == 2)) { g_err = "logit rows: D must be 2, 4 or 8"; nuts_model_destroy(m); return nullptr; }
+    RowsDev& lg = md.lg;
     md.has_logit = 1;
+    // launch geometry (tunable for experiments; defaults chosen from measurements)
+    m->rows_rpl = env_int("NUTS_ROWS_RPL", 2) == 4 ? 4 : 2;
+    m->rows_alternate = env_int("NUTS_ROWS_ALTERNATE", 1) ? 1 : 0;
+    m->rows_occ = env_int("NUTS_ROWS_OCC", 4);
+    const int wpc = std::max(1, env_int("NUTS_ROWS_WAVES_PER_CU", 16));
+    const int SPAN = WAVE * m->rows_rpl;
     lg.N = s->rows_N; lg.D = D; lg.G = s->rows_G;
-    lg.Npad = (lg.N + ROWS_PER_SPAN - 1) / ROWS_PER_SPAN * ROWS_PER_SPAN;
-    lg.n_spans = lg.Npad / ROWS_PER_SPAN;
+    lg.Npad = (lg.N + SPAN - 1) / SPAN * SPAN;
+    lg.n_spans = lg.Npad / SPAN;
     const nuts_var &vmu = s->vars[s->rows_mu], &vsg = s->vars[s->rows_sigma], &vz = s->vars[s->rows_z];
     if (vmu.size != D || vsg.size != D || vz.size != (int64_t)lg.G * D || vmu.transform != NUTS_TR_NONE ||
         vz.transform != NUTS_TR_NONE || !(vsg.transform == NUTS_TR_NONE || vsg.transform == NUTS_TR_LOG)) {
-      g_err = "logit rows: mu/sigma/z shapes or transforms unsupported"; delete m; return nullptr;
+      g_err = "logit rows: mu/sigma/z shapes or transforms unsupported"; nuts_model_destroy(m); return nullptr;
     }
     lg.off_mu = vmu.offset; lg.off_sigma = vsg.offset; lg.off_z = vz.offset; lg.sigma_tr = vsg.transform;
-    // HBM layout: X column-major [D][Npad] (one coalesced 16 B load per lane per column), y int8, gid int32
+    lg.var_mu = s->rows_mu; lg.var_sigma = s->rows_sigma; lg.var_z = s->rows_z;
+    // HBM layout: X in span tiles [n_spans][D][SPAN] (one contiguous block per wave-iteration, each column a
+    // coalesced 16 B/lane load), y int8, group structure as G+1 row pointers (rows are sorted by group)
     {
       std::vector<double> xt((size_t)D * lg.Npad, 0.0);
-      for (int64_t i = 0; i < lg.N; ++i)
-        for (int d = 0; d < D; ++d) xt[(size_t)d * lg.Npad + i] = s->rows_X[i * D + d];
+      for (int64_t i = 0; i < lg.N; ++i) {
+        const int64_t sp = i / SPAN, r = i % SPAN;
+        for (int d = 0; d < D; ++d) xt[((size_t)sp * D + d) * SPAN + r] = s->rows_X[i * D + d];
+      }
       lg.Xt = m->keep(dev_upload(xt.data(), xt.size()));
     }
-    std::vector<int32_t> gid(lg.Npad);
     std::vector<int8_t> yy(lg.Npad, 0);
+    std::vector<int64_t> gptr(lg.G + 1, 0);
+    const int32_t* gid = s->rows_gid;
     for (int64_t i = 0; i < lg.N; ++i) {
-      gid[i] = s->rows_gid[i]; yy[i] = s->rows_y[i];
-      if (i > 0 && gid[i] < gid[i - 1]) { g_err = "logit rows: group ids must be sorted"; delete m; return nullptr; }
-      if (gid[i] < 0 || gid[i] >= lg.G) { g_err = "logit rows: group id out of range"; delete m; return nullptr; }
+      yy[i] = s->rows_y[i];
+      if (i > 0 && gid[i] < gid[i - 1]) { g_err = "logit rows: group ids must be sorted"; nuts_model_destroy(m); return nullptr; }
+      if (gid[i] < 0 || gid[i] >= lg.G) { g_err = "logit rows: group id out of range"; nuts_model_destroy(m); return nullptr; }
+      gptr[gid[i] + 1] = i + 1;
     }
-    for (int64_t i = lg.N; i < lg.Npad; ++i) gid[i] = gid[lg.N - 1];
-    lg.gid = m->keep(dev_upload(gid.data(), gid.size()));
+    for (int g = 0; g < lg.G; ++g) gptr[g + 1] = std::max(gptr[g + 1], gptr[g]);  // empty groups
+    lg.gptr = m->keep(dev_upload(gptr.data(), gptr.size()));
     lg.y = m->keep(dev_upload(yy.data(), yy.size()));
-    // launch geometry: enough waves to fill the chip, at most one span per wave
     const int waves_per_block = ROWS_BLOCK / WAVE;
-    int64_t want_waves = (int64_t)cus * 8 * waves_per_block;  // 8 workgroups of 4 waves per CU
-    want_waves = std::min<int64_t>(want_waves, lg.n_spans);
-    m->rows_grid = (int)((want_waves + waves_per_block - 1) / waves_per_block);
-    lg.n_waves = m->rows_grid * waves_per_block;
-    // static segment table: runs of equal group id inside each wave's row range
+    int64_t want_waves = std::min<int64_t>((int64_t)cus * wpc, lg.n_spans);
+    const int nb_main = (int)((want_waves + waves_per_block - 1) / waves_per_block);
+    lg.n_waves = nb_main * waves_per_block;
+    // static tables.  A span that lies entirely inside one group is "uniform" (streamed by the main waves);
+    // the others (group boundary or padding rows inside) are "mixed" and get one wave each.
+    std::vector<int32_t> span_gid(lg.n_spans), mixed_g0, mixed_seg_base, mixed_seg_gid;
+    std::vector<int64_t> mixed_span;
+    for (int64_t sp = 0; sp < lg.n_spans; ++sp) {
+      const int64_t r0 = sp * SPAN, r1 = r0 + SPAN;
+      if (r1 <= lg.N && gid[r0] == gid[r1 - 1]) { span_gid[sp] = gid[r0]; continue; }
+      span_gid[sp] = -1;
+      mixed_span.push_back(sp);
+      mixed_g0.push_back(gid[r0]);
+      mixed_seg_base.push_back((int32_t)mixed_seg_gid.size());
+      int prev = -1;
+      for (int64_t r = r0; r < std::min<int64_t>(r1, lg.N); ++r)
+        if (gid[r] != prev) { prev = gid[r]; mixed_seg_gid.push_back(prev); }
+    }
+    lg.n_mixed = (int32_t)mixed_span.size();
+    lg.n_mixed_seg = (int32_t)mixed_seg_gid.size();
     std::vector<int32_t> seg_base(lg.n_waves, 0), seg_gid;
     for (int w = 0; w < lg.n_waves; ++w) {
       const int64_t s0 = (int64_t)w * lg.n_spans / lg.n_waves, s1 = (int64_t)(w + 1) * lg.n_spans / lg.n_waves;
       seg_base[w] = (int32_t)seg_gid.size();
       int prev = -1;
-      for (int64_t r = s0 * ROWS_PER_SPAN; r < s1 * ROWS_PER_SPAN; ++r)
-        if (gid[r] != prev) { prev = gid[r]; seg_gid.push_back(prev); }
+      for (int64_t sp = s0; sp < s1; ++sp)
+        if (span_gid[sp] >= 0 && span_gid[sp] != prev) { prev = span_gid[sp]; seg_gid.push_back(prev); }
     }
     lg.n_seg = (int32_t)seg_gid.size();
-    std::vector<int32_t> gptr(lg.G + 1, 0);
-    for (int32_t g : seg_gid) gptr[g + 1]++;
-    for (int g = 0; g < lg.G; ++g) gptr[g + 1] += gptr[g];
+    auto group_ptr = [&](const std::vector<int32_t>& sg) {
+      std::vector<int32_t> p(lg.G + 1, 0);
+      for (int32_t g : sg) p[g + 1]++;
+      for (int g = 0; g < lg.G; ++g) p[g + 1] += p[g];
+      return p;
+    };
     // segments are emitted in row order and rows are sorted by group => the segments of a group are contiguous
+    const std::vector<int32_t> gsp = group_ptr(seg_gid), gmp = group_ptr(mixed_seg_gid);
+    lg.span_gid = m->keep(dev_upload(span_gid.data(), span_gid.size()));
     lg.seg_base = m->keep(dev_upload(seg_base.data(), seg_base.size()));
-    lg.gseg_ptr = m->keep(dev_upload(gptr.data(), gptr.size()));
+    lg.gseg_ptr = m->keep(dev_upload(gsp.data(), gsp.size()));
     lg.seg_part = m->keep(dev_alloc<double>((size_t)lg.n_seg * D));
-    lg.wave_lp = m->keep(dev_alloc<double>(lg.n_waves));
-    const int gpb = 256 / D;
-    m->groups_grid = (lg.G + gpb - 1) / gpb;
-    lg.n_gblk = m->groups_grid;
-    lg.gblk_part = m->keep(dev_alloc<double>((size_t)lg.n_gblk * 2 * D));
-    m->alg_bytes += lg.N * (8 * (int64_t)D + 1 + 4);  // X row + y + group id
+    lg.mixed_span = m->keep(dev_upload(mixed_span.data(), mixed_span.size()));
+    lg.mixed_g0 = m->keep(dev_upload(mixed_g0.data(), mixed_g0.size()));
+    lg.mixed_seg_base = m->keep(dev_upload(mixed_seg_base.data(), mixed_seg_base.size()));
+    lg.gmix_ptr = m->keep(dev_upload(gmp.data(), gmp.size()));
+    lg.mixed_part = m->keep(dev_alloc<double>((size_t)lg.n_mixed_seg * D));
+    lg.wave_lp = m->keep(dev_alloc<double>((size_t)lg.n_waves + lg.n_mixed));
+    m->rows_grid = nb_main + (lg.n_mixed + waves_per_block - 1) / waves_per_block;
+    m->alg_bytes += lg.N * (8 * (int64_t)D + 1 + 4);  // X row + y + group id per row
   }
   if (s->mvn_k > 0) {
     md.has_mvn = 1;
+    m->explicit_pre = 1;
     MvnDev& mv = md.mv;
     mv.k = s->mvn_k; mv.off = s->vars[s->mvn_var].offset;
     mv.mu = m->keep(dev_upload(s->mvn_mu, mv.k));
     mv.prec = m->keep(dev_upload(s->mvn_prec, (size_t)mv.k * mv.k));
     mv.rowq = m->keep(dev_alloc<double>(mv.k));
+    mv.gdense = m->keep(dev_alloc<double>(n));
+    hipMemset(mv.gdense, 0, n * sizeof(double));
     mv.konst = -0.5 * mv.k * std::log(2.0 * M_PI) - s->mvn_logdet;
     m->mvn_grid = (mv.k + (256 / WAVE) - 1) / (256 / WAVE);
     m->alg_bytes += 8 * (int64_t)mv.k * mv.k;
   }
   for (void* p : m->owned)
-    if (!p) { g_err = "device allocation failed"; delete m; return nullptr; }
+    if (!p) { g_err = "device allocation failed"; nuts_model_destroy(m); return nullptr; }
   HIPCHK_NULL(hipDeviceSynchronize());
   return m;
 }
 
 extern "C" void nuts_model_destroy(nuts_model* m) {
   if (!m) return;
-  hipStreamSynchronize(m->stream);
-  for (void* p : m->owned) hipFree(p);
+  if (m->stream) hipStreamSynchronize(m->stream);
+  for (void* p : m->owned) if (p) hipFree(p);
   for (auto e : m->ev) hipEventDestroy(e);
   if (m->host_pin) hipHostFree(m->host_pin);
-  hipStreamDestroy(m->stream);
+  if (m->stream) hipStreamDestroy(m->stream);
   delete m;
 }
 
@@ -256,7 +400,7 @@ extern "C" int nuts_model_logp_grad(nuts_model* m, const double* q, double* logp
   const int n = m->md.n;
   std::memcpy(m->host_pin, q, n * sizeof(double));
   HIPCHK(hipMemcpyAsync(m->q_dev, m->host_pin, n * sizeof(double), hipMemcpyHostToDevice, m->stream));
-  model_enqueue(m, m->q_dev, m->g_dev, m->lp_dev, nullptr);
+  model_enqueue_plain(m, m->q_dev, m->g_dev, m->lp_dev);
   HIPCHK(hipMemcpyAsync(m->host_pin + n, m->g_dev, n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipMemcpyAsync(m->host_pin + 2 * n, m->lp_dev, sizeof(double), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
@@ -291,13 +435,13 @@ extern "C" int nuts_model_time_logp_grad(nuts_model* m, const double* q, int rep
   if (!m || !q || reps <= 0) { g_err = "bad argument"; return NUTS_E_ARG; }
   const int n = m->md.n;
   HIPCHK(hipMemcpy(m->q_dev, q, n * sizeof(double), hipMemcpyHostToDevice));
-  for (int i = 0; i < 3; ++i) model_enqueue(m, m->q_dev, m->g_dev, m->lp_dev, nullptr);
+  for (int i = 0; i < 3; ++i) model_enqueue_plain(m, m->q_dev, m->g_dev, m->lp_dev);
   HIPCHK(hipStreamSynchronize(m->stream));
   profile_enable(m, true, 1, (size_t)reps);
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
   hipEventRecord(a, m->stream);
-  for (int i = 0; i < reps; ++i) model_enqueue(m, m->q_dev, m->g_dev, m->lp_dev, nullptr);
+  for (int i = 0; i < reps; ++i) model_enqueue_plain(m, m->q_dev, m->g_dev, m->lp_dev);
   hipEventRecord(b, m->stream);
   HIPCHK(hipStreamSynchronize(m->stream));
   float ms = 0.f;
@@ -368,6 +512,7 @@ struct nuts_chain {
   HostStatus* st_host = nullptr;
   DrawOut* do_dev = nullptr;
   DrawOut* do_host = nullptr;
+  double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
   int64_t leapfrogs = 0;
   int n_uni_cap = 0;
   template <typename T>
@@ -422,15 +567,15 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   A.n = n;
   const int maxd = std::max(cfg->max_treedepth, cfg->early_max_treedepth);
   A.S = 1 << maxd;
-  A.ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
-  A.nblk = (n + VEC_THREADS * A.ept - 1) / (VEC_THREADS * A.ept);
+  A.ept = m->ept;
+  A.nblk = m->md.nblk;
   const size_t arena = (size_t)A.S * n;
   A.Q = c->keep(dev_alloc<double>(arena)); A.P = c->keep(dev_alloc<double>(arena));
   A.V = c->keep(dev_alloc<double>(arena)); A.G = c->keep(dev_alloc<double>(arena));
   A.E = c->keep(dev_alloc<double>(A.S)); A.LOGP = c->keep(dev_alloc<double>(A.S));
   A.PS = c->keep(dev_alloc<double>((size_t)MAX_LEVELS * n));
   A.PSUM = c->keep(dev_alloc<double>(n));
-  A.dotp = c->keep(dev_alloc<double>((size_t)A.nblk * NDOT));
+  c->kin_part = c->keep(dev_alloc<double>((size_t)A.nblk));
   A.ctl = c->keep(dev_alloc<Ctl>(1));
   c->var = c->keep(dev_alloc<double>(n)); c->stds = c->keep(dev_alloc<double>(n)); c->inv_stds = c->keep(dev_alloc<double>(n));
   c->wa_mean = c->keep(dev_alloc<double>(n)); c->wa_m2 = c->keep(dev_alloc<double>(n));
@@ -488,14 +633,6 @@ static int check_mass_matrix(nuts_chain* c) {  // quadpotential.py:357-393 raise
   return NUTS_OK;
 }
 
-static void launch_post(const ArenaDev& A, hipStream_t s, int j, int d) {
-  switch (A.ept) {
-    case 1: hipLaunchKernelGGL(k_leaf_post<1>, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, d); break;
-    case 4: hipLaunchKernelGGL(k_leaf_post<4>, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, d); break;
-    default: hipLaunchKernelGGL(k_leaf_post<16>, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, d); break;
-  }
-}
-
 static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotential.py:335-355
   if (c->cfg.potential != NUTS_POT_DIAG_ADAPT || !c->tune) return NUTS_OK;
   hipStream_t s = c->m->stream;
@@ -522,8 +659,11 @@ static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotent
   return NUTS_OK;
 }
 
+// Upload (q0, normals|p, uniforms), evaluate the model at q0 (plain A/B/C) and initialise the trajectory.
+//   p_exact: the second vector is the momentum itself (integrator tests) instead of standard normals
+//   dir_forced: +1/-1 fixes the direction (HMC / integrator tests); 0 = draw it from uniforms[0] (nuts.py:215)
 static int draw_begin(nuts_chain* c, const double* q0, const double* normals, const double* uniforms, int n_uniforms,
-                      double step_size, int max_depth) {
+                      double step_size, int max_depth, bool p_exact, int dir_forced) {
   const int n = c->n;
   hipStream_t s = c->m->stream;
   ArenaDev& A = c->A;
@@ -533,9 +673,10 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
   if (nu > 0) std::memcpy(c->stage_host + 2 * n, uniforms, nu * sizeof(double));
   HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + nu) * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  model_enqueue(c->m, A.Q, A.G, A.LOGP, nullptr);
-  hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, c->stage_dev, c->stage_dev + n, 0);
-  hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, step_size, max_depth, c->st_dev);
+  model_enqueue_plain(c->m, A.Q, A.G, A.LOGP);
+  hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, c->stage_dev + n,
+                     p_exact ? (const double*)(c->stage_dev + n) : (const double*)nullptr, c->kin_part);
+  hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, c->kin_part, step_size, dir_forced, max_depth, c->st_dev);
   return NUTS_OK;
 }
 
@@ -546,14 +687,17 @@ static int sync_status(nuts_chain* c) {
   return NUTS_OK;
 }
 
-// one leapfrog leaf = first half (vector) + model pass + second half (vector).
-static inline void enqueue_leaf_core(nuts_chain* c, int j, int edge, int dir, const int* abort_flag) {
+// one leapfrog leaf = A (data pass) + B (O(n) work) + C (control); see kernels.h
+static inline void enqueue_leaf(nuts_chain* c, int j, int d, int mode, int max_depth) {
   ArenaDev& A = c->A;
-  hipStream_t s = c->m->stream;
-  hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j);
-  const int t = edge + dir * (j + 1);
-  const int64_t off = (int64_t)(t & (A.S - 1)) * A.n;
-  model_enqueue(c->m, A.Q + off, A.G + off, A.LOGP + (t & (A.S - 1)), abort_flag);
+  nuts_model* m = c->m;
+  hipStream_t s = m->stream;
+  EvalIO io{mode, m->explicit_pre, nullptr, nullptr, nullptr};
+  if (m->explicit_pre) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, mode);
+  launch_dense(m, A, io, j);
+  launch_vector(m, A, io, j, d);
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth,
+                     mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr);
   c->leapfrogs++;
 }
 
@@ -575,26 +719,18 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   const int need_uni = (1 << max_depth) + max_depth + 1;
   if (n_uniforms < need_uni) { g_err = "not enough uniforms for the worst-case tree"; return NUTS_E_ARG; }
 
-  int rc = draw_begin(c, q0, normals, uniforms, n_uniforms, step_size, max_depth);
+  int rc = draw_begin(c, q0, normals, uniforms, n_uniforms, step_size, max_depth, false, 0);
   if (rc) return rc;
-  const int* abort_flag = &A.ctl->aborted;
-  // direction of the first doubling is uniforms[0] (the host owns the stream and can read it too)
-  int dir = uniforms[0] < 0.5 ? 1 : -1, edge = 0;
   bool exhausted = true;
   int64_t evals = 1;
   for (int d = 0; d < max_depth; ++d) {
     const int nleaf = 1 << d;
-    for (int j = 0; j < nleaf; ++j) {
-      enqueue_leaf_core(c, j, edge, dir, abort_flag);
-      launch_post(A, s, j, d);
-      hipLaunchKernelGGL(k_leaf_ctl, dim3(1), dim3(128), 0, s, A, j, d, c->cfg.Emax, max_depth, c->st_dev);
-    }
+    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, j, d, MODE_TREE, max_depth);
     rc = sync_status(c);
     if (rc) return rc;
     const HostStatus& st = *c->st_host;
     if (st.bad_energy) break;
     if (st.diverging || st.turning) { exhausted = false; break; }
-    dir = st.dir; edge = st.edge;
   }
   if (c->st_host->bad_energy) {
     // base_hmc.py:205-224: SamplingError("Bad initial energy"), after potential.raise_ok
@@ -666,16 +802,9 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   int n_steps = std::max(1, (int)(path_length / step_size));
   n_steps = std::min<int>(max_steps, n_steps);
   if (n_steps >= A.S) { g_err = "n_steps exceeds the trajectory arena (2^max_treedepth slots)"; return NUTS_E_ARG; }
-  // a direction uniform < 0.5 makes k_draw_ctl_start pick dir=+1, edge=0
-  const double fake_uni[1] = {0.25};
-  int rc = draw_begin(c, q0, normals, fake_uni, 1, step_size, 1);
+  int rc = draw_begin(c, q0, normals, uniforms, 0, step_size, 1, false, +1);
   if (rc) return rc;
-  const int* abort_flag = &A.ctl->aborted;
-  for (int j = 0; j < n_steps; ++j) {
-    enqueue_leaf_core(c, j, 0, 1, abort_flag);
-    hipLaunchKernelGGL(k_leaf_post_simple, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j);
-    hipLaunchKernelGGL(k_energy_simple, dim3(1), dim3(64), 0, s, A, j);
-  }
+  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, j, 0, MODE_SIMPLE, 1);
   std::vector<double> Eh(2), lph(2);
   const int last = n_steps & (A.S - 1);
   HIPCHK(hipMemcpyAsync(c->out_host, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -697,7 +826,8 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   if (std::isnan(dE)) dE = INFINITY;
   if (std::fabs(dE) > c->cfg.Emax) div = true;     // hmc.py:152-158
   const double accept = std::min(1.0, std::exp(-dE));
-  const bool accepted = !(div || uniforms[1] >= accept);  // hmc.py:162-167
+  // hmc.py:162: `div_info is not None or rng.random() >= accept` -- the accept draw is NOT consumed on a divergence
+  const bool accepted = !(div || uniforms[1] >= accept);
   const auto t1 = clk::now();
   const std::clock_t c1 = std::clock();
   c->da.update(accept, adapt);
@@ -725,7 +855,8 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   return NUTS_OK;
 }
 
-// integrator property tests (tests/step_methods/hmc/test_hmc.py:49-74): n_steps leapfrogs from (q, p)
+// integrator property tests (tests/step_methods/hmc/test_hmc.py:49-74): n_steps leapfrogs from (q, p).
+// Like the reference integrator this never looks at the energy of the start state.
 extern "C" int nuts_chain_leapfrog_test(nuts_chain* c, const double* q, const double* p, double eps, int32_t n_steps,
                                         double* q_out, double* p_out, double* energy_out) {
   if (!c || !q || !p || n_steps < 0) { g_err = "bad argument"; return NUTS_E_ARG; }
@@ -733,22 +864,10 @@ extern "C" int nuts_chain_leapfrog_test(nuts_chain* c, const double* q, const do
   ArenaDev& A = c->A;
   hipStream_t s = c->m->stream;
   if (n_steps >= A.S) { g_err = "n_steps exceeds the trajectory arena"; return NUTS_E_ARG; }
-  // normals chosen so that p0 = normals * inv_stds == p
-  std::vector<double> inv(n), z(n);
-  HIPCHK(hipMemcpy(inv.data(), c->inv_stds, n * sizeof(double), hipMemcpyDeviceToHost));
-  for (int i = 0; i < n; ++i) z[i] = p[i] / inv[i];
-  const double u[1] = {eps >= 0 ? 0.25 : 0.75};
-  int rc = draw_begin(c, q, z.data(), u, 1, std::fabs(eps), 1);
-  if (rc) return rc;
-  // exact p (avoid the round trip through normals)
-  HIPCHK(hipMemcpyAsync(c->stage_dev, p, n * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(A.P, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
   const int dir = eps >= 0 ? 1 : -1;
-  for (int j = 0; j < n_steps; ++j) {
-    enqueue_leaf_core(c, j, 0, dir, nullptr);
-    hipLaunchKernelGGL(k_leaf_post_simple, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j);
-    hipLaunchKernelGGL(k_energy_simple, dim3(1), dim3(64), 0, s, A, j);
-  }
+  int rc = draw_begin(c, q, p, nullptr, 0, std::fabs(eps), 1, true, dir);
+  if (rc) return rc;
+  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, j, 0, MODE_SIMPLE, 1);
   const int last = (dir * n_steps) & (A.S - 1);
   HIPCHK(hipStreamSynchronize(s));
   if (q_out) HIPCHK(hipMemcpy(q_out, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost));

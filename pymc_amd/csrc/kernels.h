@@ -1,0 +1,750 @@
+// The leapfrog pipeline: three launches per leapfrog step.
+//
+//   A  k_logit_rows / k_mvn_matvec   the HBM-streaming pass over the model data (dominant kernel).
+//                                    Reads the position through a QView: in chain mode the first half
+//                                    of the leapfrog (p_half = p + eps/2 g ; q' = q + eps M^-1 p_half,
+//                                    integration.py:118-127) is recomputed on the fly for the few
+//                                    parameters a wave needs, so nothing has to be materialised first.
+//   B  k_vector                      everything that is O(n): q' (stored), value transforms + Jacobians,
+//                                    element-wise factors (reverse mode as a gather), combine of the
+//                                    row-pass segments into d/dz, second half kick p' = p_half + eps/2 g',
+//                                    v' = M^-1 p', kinetic energy and all U-turn dot products of the tree
+//                                    merges this leaf completes (nuts.py:452-463, 380-390) as per-workgroup
+//                                    partials.
+//   C  k_control                     one workgroup: fixed-order sum of the partials, the "deferred"
+//                                    elements (scalars and hyper-parameters whose gradient is a
+//                                    cross-workgroup reduction), the energy, and the scalar tree logic of
+//                                    nuts.py:334-476 consuming the pre-drawn uniforms in reference order.
+//
+// All reductions have a fixed order (no FP atomics): results are bit-reproducible run to run, which the
+// reference promises for a fixed seed (tests/sampling/test_mcmc.py:80-109).
+//
+// Trajectory arena.  Every phase-space point of the current trajectory lives in HBM at slot
+// (index_in_trajectory & (S-1)), S = 2^max_treedepth: Q,P,V,G are [S][n].  A trajectory occupies at most S
+// consecutive indices containing 0, so the slot is unique, and tree nodes are plain integers: a proposal is
+// the trajectory index of a leaf (no vector is copied when a proposal is selected), a subtree is
+// (first leaf, last leaf, p_sum).
+//
+// Recursion -> binary counter.  `_build_subtree` (nuts.py:442-476) is a post-order traversal; leaf j of a
+// 2^d-leaf subtree completes m = (number of trailing one bits of j) merges, level l merging the stored left
+// sibling of 2^l leaves with the just-finished right sibling.  The vector work of those merges is static
+// given j, so kernel B computes it speculatively and kernel C replays the scalar decisions.
+#pragma once
+#include "model_dev.h"
+#include "rows_kernel.h"
+
+#define MAX_LEVELS 12            // supports max_treedepth <= 11
+#define NDOT (1 + 6 * (MAX_LEVELS + 1))
+#define DOT_TOP (1 + 6 * MAX_LEVELS)
+#define VEC_THREADS 256
+#define PART_STRIDE (PART_DOT + NDOT)
+
+#define ROWS_BLOCK 256
+
+#define MODE_PLAIN 0
+#define MODE_TREE 1
+#define MODE_SIMPLE 2
+
+struct Ctl {
+  // trajectory-level (nuts.py:318-332)
+  double E0;
+  double log_size, log_accept_sum, max_energy_change;
+  double div_dE;
+  int n_proposals, depth, left, right, proposal, cursor;
+  int aborted, turning, diverging, bad_energy;
+  // current doubling
+  int dir, edge;
+  double eps;      // signed step (nuts.py:348,357)
+  double eps_abs;
+  // pending left siblings of the subtree under construction
+  double st_ls[MAX_LEVELS];
+  int st_prop[MAX_LEVELS];
+  int n_leaves_total;
+  int pad;
+};
+
+struct ArenaDev {
+  int n, S, nblk, ept;     // dimension, slots, vector-kernel workgroups, elements per thread
+  double *Q, *P, *V, *G;   // [S][n]
+  double *E, *LOGP;        // [S]
+  double *PS;              // [MAX_LEVELS][n] pending-sibling p_sum (level 0 unused: read from P)
+  double *PSUM;            // [n] whole-tree p_sum (nuts.py:330)
+  const double *var, *inv_stds;  // diagonal potential (quadpotential.py:308-326)
+  Ctl* ctl;
+  const double* uniforms;
+};
+
+struct HostStatus {
+  int aborted, turning, diverging, bad_energy, depth, cursor, n_proposals, proposal, dir, edge;
+};
+
+struct EvalIO {
+  int mode;          // MODE_*
+  int explicit_pre;  // leaf modes: q' and p_half were materialised by k_leaf_pre
+  const double* q;   // MODE_PLAIN: position in
+  double* grad;      // MODE_PLAIN: gradient out
+  double* logp;      // MODE_PLAIN: logp out
+};
+
+struct Leaf {
+  int dir, edge, src, t;
+  int64_t so, d_o;
+  double eps, half;
+};
+
+__device__ __forceinline__ int64_t slot_off(const ArenaDev& A, int t) { return (int64_t)(t & (A.S - 1)) * A.n; }
+
+// Resolve what this launch works on.  Returns false when the trajectory was already terminated
+// (the host enqueues a whole doubling ahead; the remaining launches drain as no-ops).
+__device__ __forceinline__ bool resolve_leaf(const EvalIO& io, const ArenaDev& A, int j, Leaf& lf, QView& qv) {
+  if (io.mode == MODE_PLAIN) {
+    qv.q = io.q; qv.p = qv.g = qv.var = nullptr; qv.eps = qv.half = 0.0; qv.composed = 0;
+    return true;
+  }
+  const Ctl* c = A.ctl;
+  if (io.mode == MODE_TREE && c->aborted) return false;
+  lf.dir = c->dir; lf.edge = c->edge;
+  lf.src = lf.edge + lf.dir * j;
+  lf.t = lf.src + lf.dir;
+  lf.eps = c->eps; lf.half = 0.5 * c->eps;
+  lf.so = slot_off(A, lf.src); lf.d_o = slot_off(A, lf.t);
+  if (io.explicit_pre) {
+    qv.q = A.Q + lf.d_o; qv.p = qv.g = qv.var = nullptr; qv.eps = qv.half = 0.0; qv.composed = 0;
+  } else {
+    qv.q = A.Q + lf.so; qv.p = A.P + lf.so; qv.g = A.G + lf.so; qv.var = A.var;
+    qv.eps = lf.eps; qv.half = lf.half; qv.composed = 1;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st) {
+  st->aborted = c->aborted; st->turning = c->turning; st->diverging = c->diverging; st->bad_energy = c->bad_energy;
+  st->depth = c->depth; st->cursor = c->cursor; st->n_proposals = c->n_proposals; st->proposal = c->proposal;
+  st->dir = c->dir; st->edge = c->edge;
+}
+
+// ---------------------------------------------------------------------------
+// explicit first half of a leapfrog (only when the position cannot be composed on the fly)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(VEC_THREADS) void k_leaf_pre(ArenaDev A, int j, int mode) {
+  const Ctl* c = A.ctl;
+  if (mode == MODE_TREE && c->aborted) return;
+  const int src = c->edge + c->dir * j, dst = src + c->dir;
+  const double eps = c->eps, half = 0.5 * eps;
+  const int64_t so = slot_off(A, src), d_o = slot_off(A, dst);
+  const int base = blockIdx.x * VEC_THREADS * A.ept;
+  for (int e = 0; e < A.ept; ++e) {
+    const int i = base + e * VEC_THREADS + threadIdx.x;
+    if (i < A.n) {
+      const double ph = fma(half, A.G[so + i], A.P[so + i]);
+      const double v = A.var[i] * ph;
+      A.P[d_o + i] = ph;
+      A.Q[d_o + i] = fma(eps, v, A.Q[so + i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// A: hierarchical Bernoulli-logit rows (the HBM-bound pass; body in rows_kernel.h)
+// ---------------------------------------------------------------------------
+template <int D, int RPL, int OCC>
+__global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(RowsDev R, ArenaDev A, EvalIO io, int j, int rev) {
+  Leaf lf; QView qv;
+  if (!resolve_leaf(io, A, j, lf, qv)) return;
+  const int lane = threadIdx.x & (WAVE - 1);
+  // workgroups [0, nb_mixed) take the mixed spans (dispatched first, so they overlap the streaming workgroups)
+  const int nb_mixed = (R.n_mixed + (ROWS_BLOCK / WAVE) - 1) / (ROWS_BLOCK / WAVE);
+  if ((int)blockIdx.x >= nb_mixed) {
+    int wave = ((int)blockIdx.x - nb_mixed) * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
+    // alternate the traversal direction between launches: the tail of the previous pass is still in the
+    // 256 MiB Infinity Cache when the next pass starts from that end
+    if (rev) wave = R.n_waves - 1 - wave;
+    rows_main<D, RPL>(R, qv, wave, lane);
+  } else {
+    const int mw = (int)blockIdx.x * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (mw < R.n_mixed) rows_mixed<D, RPL>(R, qv, mw, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// A': MvNormal precision mat-vec: one wave per row of P (multivariate.py:165-185, 275-295)
+// (position always materialised: every wave needs all k coordinates)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mvn_matvec(MvnDev mv, ArenaDev A, EvalIO io, int j) {
+  Leaf lf; QView qv;
+  if (!resolve_leaf(io, A, j, lf, qv)) return;
+  const double* __restrict__ q = qv.q;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int row = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+  if (row >= mv.k) return;
+  const double* __restrict__ pr = mv.prec + (int64_t)row * mv.k;
+  double s = 0.0;
+  const int k2 = mv.k & ~1;
+  for (int c = lane * 2; c < k2; c += 2 * WAVE) {
+    const double2 p = *reinterpret_cast<const double2*>(pr + c);
+    s = fma(p.x, q[mv.off + c] - mv.mu[c], s);
+    s = fma(p.y, q[mv.off + c + 1] - mv.mu[c + 1], s);
+  }
+  if (lane == 0 && (mv.k & 1)) s = fma(pr[mv.k - 1], q[mv.off + mv.k - 1] - mv.mu[mv.k - 1], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    mv.gdense[mv.off + row] = -s;
+    mv.rowq[row] = (q[mv.off + row] - mv.mu[row]) * s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// second half of the leapfrog + the vector work of the tree merges a leaf completes
+// (shared by kernel B for ordinary elements and kernel C for the deferred ones)
+// ---------------------------------------------------------------------------
+//
+// On entry ph[e] = p_half and grad[e] = d logp / dq' for the E elements idx[e] of this thread (act[e] false:
+// the element is not this thread's business).  Writes P, V (and PS / PSUM where the reference adds p_sums),
+// returns per-thread partial dot products in dd[NDOT] slots that the caller reduces:
+//   dd[0]               p'.v'                                   (integration.py:133)
+//   dd[1+6l .. 1+6l+5]  the six U-turn dots of the level-l merge  (nuts.py:454-463)
+//   dd[DOT_TOP..+5]     the six dots of `extend`                  (nuts.py:380-390)
+// Reductions are done by the caller through `red`, a [NDOT][waves] LDS scratch.
+template <int E>
+__device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, const Ctl* c, int j, int d, bool tree,
+                                          const int (&idx)[E], const bool (&act)[E], const double (&grad)[E],
+                                          const double (&ph)[E], double* red, int nwaves, int& m_out, bool& last_out) {
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+  const int dir = lf.dir, edge = lf.edge, t = lf.t;
+  const int64_t to = lf.d_o;
+  double acc[E], vt[E];
+  double kin = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    acc[e] = 0.0; vt[e] = 0.0;
+    if (act[e]) {
+      const int i = idx[e];
+      const double p = fma(lf.half, grad[e], ph[e]);  // p' = p_half + eps/2 g'   (integration.py:131)
+      const double v = A.var[i] * p;                  // v' = M^-1 p'
+      A.P[to + i] = p; A.V[to + i] = v;
+      acc[e] = p; vt[e] = v;
+      kin = fma(p, v, kin);
+    }
+  }
+  {
+    const double s = wave_sum(kin);
+    if (lane == 0) red[0 * nwaves + w] = s;
+  }
+  int m = 0;
+  bool last = false;
+  if (tree) {
+    while (((j >> m) & 1) && m < d) ++m;
+    last = (j + 1 == (1 << d));
+    // merges: level l joins leaves [j-2^(l+1)+1, j-2^l] (t1) with [j-2^l+1, j] (t2)   (nuts.py:452-463)
+    for (int l = 0; l < m; ++l) {
+      const int t1_left = edge + dir * (j - (2 << l) + 2);
+      const int t1_right = edge + dir * (j - (1 << l) + 1);
+      const int t2_left = t1_right + dir;
+      const int64_t o1l = slot_off(A, t1_left), o1r = slot_off(A, t1_right), o2l = slot_off(A, t2_left);
+      const double* ps1 = (l == 0) ? (A.P + o1r) : (A.PS + (int64_t)l * A.n);  // a single leaf's p_sum is its p
+      double dd[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (act[e]) {
+          const int i = idx[e];
+          const double s1 = ps1[i], s2 = acc[e];
+          const double rho = s1 + s2;                  // tree1.p_sum + tree2.p_sum
+          const double v1l = A.V[o1l + i];
+          dd[0] = fma(rho, v1l, dd[0]);
+          dd[1] = fma(rho, vt[e], dd[1]);
+          if (l >= 1) {
+            const double rho1 = s1 + A.P[o2l + i];     // tree1.p_sum + tree2.left.p
+            dd[2] = fma(rho1, v1l, dd[2]);
+            dd[3] = fma(rho1, A.V[o2l + i], dd[3]);
+            const double rho2 = A.P[o1r + i] + s2;     // tree1.right.p + tree2.p_sum
+            dd[4] = fma(rho2, A.V[o1r + i], dd[4]);
+            dd[5] = fma(rho2, vt[e], dd[5]);
+          }
+          acc[e] = rho;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(1 + 6 * l + k) * nwaves + w] = s; }
+    }
+    if (!last) {
+      // subtree not complete: park the merged p_sum as the pending left sibling of level m
+      if (m >= 1) {
+        double* ps = A.PS + (int64_t)m * A.n;
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (act[e]) ps[idx[e]] = acc[e];
+      }
+    } else {
+      // subtree complete: top-level merge of `extend` (nuts.py:346-390), speculative
+      const int first = edge + dir;  // first leaf of the new subtree
+      int lm_begin, lm_end, rm_begin, rm_end, new_left, new_right;
+      if (dir > 0) { lm_begin = c->left; lm_end = c->right; rm_begin = first; rm_end = t; new_left = c->left; new_right = t; }
+      else         { lm_begin = t; lm_end = first; rm_begin = c->left; rm_end = c->right; new_left = t; new_right = c->right; }
+      const int64_t onl = slot_off(A, new_left), onr = slot_off(A, new_right);
+      const int64_t olb = slot_off(A, lm_begin), ole = slot_off(A, lm_end), orb = slot_off(A, rm_begin), ore = slot_off(A, rm_end);
+      double dd[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (act[e]) {
+          const int i = idx[e];
+          const double old = A.PSUM[i], sub = acc[e];
+          const double tot = old + sub;                       // p_sum[:] += tree.p_sum
+          A.PSUM[i] = tot;
+          const double lm_sum = dir > 0 ? old : sub, rm_sum = dir > 0 ? sub : old;
+          // the new edge state is this leaf: its v is in registers (the store above may not be visible yet)
+          const double v_nl = (new_left == t) ? vt[e] : A.V[onl + i];
+          const double v_nr = (new_right == t) ? vt[e] : A.V[onr + i];
+          dd[0] = fma(tot, v_nl, dd[0]);
+          dd[1] = fma(tot, v_nr, dd[1]);
+          const double p_rb = (rm_begin == t) ? (fma(lf.half, grad[e], ph[e])) : A.P[orb + i];
+          const double v_rb = (rm_begin == t) ? vt[e] : A.V[orb + i];
+          const double v_lb = (lm_begin == t) ? vt[e] : A.V[olb + i];
+          const double r1 = lm_sum + p_rb;                    // leftmost_p_sum + rightmost_begin.p
+          dd[2] = fma(r1, v_lb, dd[2]);
+          dd[3] = fma(r1, v_rb, dd[3]);
+          const double p_le = (lm_end == t) ? (fma(lf.half, grad[e], ph[e])) : A.P[ole + i];
+          const double v_le = (lm_end == t) ? vt[e] : A.V[ole + i];
+          const double v_re = (rm_end == t) ? vt[e] : A.V[ore + i];
+          const double r2 = p_le + rm_sum;                    // leftmost_end.p + rightmost_p_sum
+          dd[4] = fma(r2, v_le, dd[4]);
+          dd[5] = fma(r2, v_re, dd[5]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(DOT_TOP + k) * nwaves + w] = s; }
+    }
+  }
+  m_out = m; last_out = last;
+}
+
+__device__ __forceinline__ bool dot_needed(int k, int m, bool last) {
+  return (k == 0) || (k >= 1 && k < 1 + 6 * m) || (last && k >= DOT_TOP);
+}
+
+// ---------------------------------------------------------------------------
+// B: the O(n) kernel
+// ---------------------------------------------------------------------------
+template <int EPT>
+__global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A, EvalIO io, int j, int d) {
+  Leaf lf; QView qv;
+  if (!resolve_leaf(io, A, j, lf, qv)) return;
+  constexpr int NW = VEC_THREADS / WAVE;
+  __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
+  __shared__ double s_bacc[MAX_BTERMS][VEC_THREADS];
+  __shared__ double s_red[NDOT * NW];
+  __shared__ double s_dz[2][VEC_THREADS];
+  __shared__ double s_w[NW];
+  __shared__ double s_bw[MAX_BTERMS][NW];
+  const int tid = threadIdx.x;
+  const bool leaf = io.mode != MODE_PLAIN;
+  const RowsDev& lg = md.lg;
+  const int base = blockIdx.x * VEC_THREADS * EPT;
+  double* part = md.part + (int64_t)blockIdx.x * md.part_stride;
+
+  // ---- everything whose address is known up front is loaded before the model tables are needed ----
+  int idx[EPT];
+  bool act[EPT];
+  double grad[EPT], ph[EPT], qn[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = base + e * VEC_THREADS + tid;
+    idx[e] = i; act[e] = false; grad[e] = 0.0; ph[e] = 0.0; qn[e] = 0.0;
+    if (i >= md.n) continue;
+    // first half of the leapfrog for this element (integration.py:118-127); q' is stored for every element
+    if (leaf) {
+      if (io.explicit_pre) { ph[e] = A.P[lf.d_o + i]; qn[e] = A.Q[lf.d_o + i]; }
+      else {
+        ph[e] = fma(lf.half, A.G[lf.so + i], A.P[lf.so + i]);
+        qn[e] = fma(lf.eps, A.var[i] * ph[e], A.Q[lf.so + i]);
+        A.Q[lf.d_o + i] = qn[e];
+      }
+    } else qn[e] = io.q[i];
+  }
+  // a slice of the row-pass log-likelihood partials rides along with this workgroup's logp partial
+  double lp = 0.0;
+  if (md.has_logit) {
+    const int nlp = lg.n_waves + lg.n_mixed;
+    for (int w = blockIdx.x * VEC_THREADS + tid; w < nlp; w += gridDim.x * VEC_THREADS) lp += lg.wave_lp[w];
+  }
+  if (md.has_mvn) for (int r = blockIdx.x * VEC_THREADS + tid; r < md.mv.k; r += gridDim.x * VEC_THREADS) lp -= 0.5 * md.mv.rowq[r];
+
+  const Prog pg = load_prog(md, s_prog);
+  for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
+  double db_acc = 0.0, dbz_acc = 0.0;
+
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int i = idx[e];
+    if (i >= md.n) continue;
+    const int k = find_var(pg, i);
+    const VarDev v = pg.vars[k];
+    if (v.deferred) continue;  // finished by the control kernel
+    double x, dxdq, lj, dj;
+    transform_full(v, qn[e], x, dxdq, lj, dj);
+    double gx = 0.0;
+    lp += lj;
+    gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+    double gd = 0.0;
+    if (md.has_logit && k == lg.var_z) {
+      const int zi = i - lg.off_z, g = zi / lg.D, dd = zi - g * lg.D;
+      const int a0 = lg.gseg_ptr[g], a1 = lg.gseg_ptr[g + 1], b0 = lg.gmix_ptr[g], b1 = lg.gmix_ptr[g + 1];
+      double sgd = qv.at(lg.off_sigma + dd);
+      double db = 0.0;
+      for (int s = a0; s < a1; ++s) db += lg.seg_part[(int64_t)s * lg.D + dd];
+      for (int s = b0; s < b1; ++s) db += lg.mixed_part[(int64_t)s * lg.D + dd];
+      sgd = lg.sigma_tr == NUTS_TR_LOG ? exp(sgd) : sgd;
+      gd = sgd * db;
+      db_acc += db;            // (e*VEC_THREADS) % D == 0: every e of this thread has the same d
+      dbz_acc += db * x;
+    }
+    if (md.has_mvn && i >= md.mv.off && i < md.mv.off + md.mv.k) gd += md.mv.gdense[i];
+    grad[e] = (gx + gd) * dxdq + dj;
+    act[e] = true;
+    if (leaf) A.G[lf.d_o + i] = grad[e];
+    else io.grad[i] = grad[e];
+  }
+
+  // factors without an owning variable (only scalars and data): grid-stride over their elements
+  for (int o = 0; o < md.n_orphans; ++o) {
+    const int fi = md.orphans[o];
+    const nuts_factor& f = pg.factors[fi];
+    const FactorBT& bt = pg.fbt[fi];
+    for (int li = blockIdx.x * VEC_THREADS + tid; li < f.size; li += gridDim.x * VEC_THREADS) {
+      double dv[4], bv[4], cv[4];
+      lp += factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv);
+      for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm][tid] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
+    }
+  }
+
+  // ---- second half kick + tree-merge dot products (wave partials land in s_red) ----
+  int m = 0; bool last = false;
+  if (leaf) leaf_post<EPT>(A, lf, A.ctl, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last);
+
+  // ---- per-workgroup partials: logp, broadcast terms, hyper-parameter sums of the logit node, dots ----
+  {
+    const double w = wave_sum(lp);
+    if ((tid & (WAVE - 1)) == 0) s_w[tid >> 6] = w;
+  }
+  for (int b = 0; b < md.n_bterms; ++b) {
+    const double w = wave_sum(s_bacc[b][tid]);
+    if ((tid & (WAVE - 1)) == 0) s_bw[b][tid >> 6] = w;
+  }
+  if (md.has_logit) { s_dz[0][tid] = db_acc; s_dz[1][tid] = dbz_acc; }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < NW; ++w) t += s_w[w];
+    part[PART_LP] = t;
+  }
+  if (tid >= WAVE && tid < WAVE + md.n_bterms) {   // one thread per broadcast term: fixed-order sum of the wave partials
+    const int b = tid - WAVE;
+    double t = 0.0;
+    for (int w = 0; w < NW; ++w) t += s_bw[b][w];
+    part[PART_BT + b] = t;
+  }
+  if (md.has_logit && tid >= 2 * WAVE && tid < 2 * WAVE + 2 * lg.D) {
+    const int D = lg.D, u = tid - 2 * WAVE;
+    const int which = u / D, dd = u - which * D;
+    // thread t' holds coordinate (base + t' - off_z) mod D
+    int c0 = (base - lg.off_z) % D; if (c0 < 0) c0 += D;
+    int t0 = dd - c0; if (t0 < 0) t0 += D;
+    double sdz = 0.0;
+    for (int t = t0; t < VEC_THREADS; t += D) sdz += s_dz[which][t];
+    part[(which ? PART_DSG : PART_DMU) + dd] = sdz;
+  }
+  if (leaf) {
+    for (int k = tid; k < NDOT; k += VEC_THREADS) {
+      if (!dot_needed(k, m, last)) continue;
+      double r = 0.0;
+      for (int w = 0; w < NW; ++w) r += s_red[k * NW + w];
+      part[PART_DOT + k] = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// C: the control kernel (one workgroup)
+// ---------------------------------------------------------------------------
+
+// direction of the next doubling: `(rng.random() < 0.5) * 2 - 1` (nuts.py:215)
+__device__ __forceinline__ void ctl_next_direction(Ctl* c, const double* uniforms) {
+  const double u = uniforms[c->cursor++];
+  c->dir = (u < 0.5) ? 1 : -1;
+  c->eps = c->dir > 0 ? c->eps_abs : -c->eps_abs;
+  c->edge = c->dir > 0 ? c->right : c->left;
+}
+
+#define CTL_CHUNKS 8   // the per-workgroup partials are summed in CTL_CHUNKS contiguous chunks, then the chunks in order
+
+__global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
+                                                        int max_depth, HostStatus* st) {
+  Leaf lf; QView qv;
+  if (!resolve_leaf(io, A, j, lf, qv)) {
+    if (threadIdx.x == 0 && st) publish_status(A.ctl, st);
+    return;
+  }
+  constexpr int NW = VEC_THREADS / WAVE;
+  __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
+  __shared__ double s_sum[PART_STRIDE];
+  __shared__ double s_chunk[CTL_CHUNKS][PART_STRIDE];
+  __shared__ double s_bacc[MAX_BTERMS][VEC_THREADS];
+  __shared__ double s_red[NDOT * NW];
+  __shared__ double s_w[NW];
+  __shared__ Ctl s_ctl;
+  const int tid = threadIdx.x;
+  const bool leaf = io.mode != MODE_PLAIN;
+  const bool tree = io.mode == MODE_TREE;
+  const RowsDev& lg = md.lg;
+
+  int m = 0;
+  bool last = false;
+  if (tree) {
+    while (((j >> m) & 1) && m < d) ++m;
+    last = (j + 1 == (1 << d));
+  }
+  // ---- fixed-order sums of the per-workgroup partials: (value, chunk) pairs in parallel, then the chunks in order ----
+  {
+    const int per = (md.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
+    for (int t = tid; t < md.part_stride * CTL_CHUNKS; t += VEC_THREADS) {
+      const int k = t % md.part_stride, c = t / md.part_stride;
+      bool need = k < PART_DOT;
+      if (k >= PART_DOT) need = leaf && dot_needed(k - PART_DOT, m, last);
+      double s = 0.0;
+      if (need) {
+        const int b1 = min(md.nblk, (c + 1) * per);
+        for (int b = c * per; b < b1; ++b) s += md.part[(int64_t)b * md.part_stride + k];
+      }
+      s_chunk[c][k] = s;
+    }
+  }
+  if (leaf && tid < (int)(sizeof(Ctl) / sizeof(int))) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(A.ctl)[tid];
+  const Prog pg = load_prog(md, s_prog);   // ends with a barrier (when the program fits in LDS)
+  for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
+  __syncthreads();
+  for (int k = tid; k < md.part_stride; k += VEC_THREADS) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < CTL_CHUNKS; ++c) s += s_chunk[c][k];
+    s_sum[k] = s;
+  }
+  __syncthreads();
+
+  // ---- deferred elements: one thread each ----
+  int idx[1] = {0};
+  bool act[1] = {false};
+  double grad[1] = {0.0}, ph[1] = {0.0};
+  double lp = 0.0, gx = 0.0, dxdq = 1.0, dj = 0.0;
+  int k = -1;
+  const bool mine = tid < md.n_deferred;
+  if (mine) {
+    const int i = md.deferred[tid];
+    k = find_var(pg, i);
+    const VarDev v = pg.vars[k];
+    idx[0] = i;
+    double qn;
+    if (leaf) {
+      if (io.explicit_pre) { ph[0] = A.P[lf.d_o + i]; qn = A.Q[lf.d_o + i]; }
+      else { ph[0] = qv.p_half(i); qn = qv.at(i); }   // q' itself was stored by kernel B
+    } else qn = io.q[i];
+    double x, lj;
+    transform_full(v, qn, x, dxdq, lj, dj);
+    lp += lj;
+    gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+    if (md.has_logit) {
+      if (k == lg.var_mu) gx += s_sum[PART_DMU + (i - lg.off_mu)];
+      else if (k == lg.var_sigma) gx += s_sum[PART_DSG + (i - lg.off_sigma)];
+    }
+  }
+  // broadcast terms: the share of the ordinary elements (kernel B) + the share of deferred vector elements (here)
+  if (md.n_bterms > 0) {
+    __syncthreads();
+    for (int b = 0; b < md.n_bterms; ++b) {
+      const double t = block_sum<true>(s_bacc[b][tid], s_w);
+      if (mine && pg.vars[k].size == 1 && pg.bterm_var[b] == k) gx += s_sum[PART_BT + b] + t;
+    }
+  }
+  if (mine) {
+    grad[0] = gx * dxdq + dj;
+    act[0] = true;
+    if (leaf) A.G[lf.d_o + idx[0]] = grad[0];
+    else io.grad[idx[0]] = grad[0];
+  }
+  int m2 = 0; bool last2 = false;
+  if (leaf) leaf_post<1>(A, lf, &s_ctl, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2);
+  const double lp_def = block_sum<true>(lp, s_w);   // barriers inside also publish s_red
+  double logp = s_sum[PART_LP] + lp_def;
+  if (md.has_mvn) logp += md.mv.konst;
+  if (!leaf) {
+    if (tid == 0) *io.logp = logp;
+    return;
+  }
+  // totals: workgroup partials (in order) + the deferred elements' share
+  for (int q = tid; q < NDOT; q += VEC_THREADS) {
+    if (!dot_needed(q, m, last)) continue;
+    double r = 0.0;
+    for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];
+    s_sum[PART_DOT + q] += r;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const double* dot = &s_sum[PART_DOT];
+  const int t = lf.t, ts = t & (A.S - 1);
+  A.LOGP[ts] = logp;
+  const double E = 0.5 * dot[0] - logp;  // integration.py:133-134
+  A.E[ts] = E;
+  if (!tree) return;
+
+  // ---- scalar decisions of one leaf (nuts.py:394-476 and, on the last leaf, 334-392), on the LDS copy of ctl ----
+  Ctl* c = &s_ctl;
+  const int dir = lf.dir;
+  double dE = E - c->E0;                 // nuts.py:408-410
+  if (isnan(dE)) dE = INFINITY;
+  c->log_accept_sum = logaddexp_d(c->log_accept_sum, dE > 0 ? -dE : 0.0);  // nuts.py:412-414
+  if (fabs(dE) > fabs(c->max_energy_change)) c->max_energy_change = dE;     // nuts.py:417-418
+  c->n_proposals += 1;                                                      // nuts.py:436-437
+  c->n_leaves_total += 1;
+  if (!(dE < Emax)) {                                                       // nuts.py:419,433-435
+    c->diverging = 1; c->aborted = 1; c->div_dE = dE;
+    c->depth += 1;                                                          // extend: self.depth += 1 happens regardless
+  } else {
+    double cur_ls = -dE;
+    int cur_prop = t;
+    bool turning = false;
+    for (int l = 0; l < m && !turning; ++l) {
+      const double* dd = &dot[1 + 6 * l];
+      turning = (dd[0] <= 0) || (dd[1] <= 0);
+      if (!turning && l >= 1) {
+        turning = (dd[2] <= 0) || (dd[3] <= 0);
+        if (!turning) turning = (dd[4] <= 0) || (dd[5] <= 0);
+      }
+      const double ls = logaddexp_d(c->st_ls[l], cur_ls);                   // nuts.py:464
+      const double u = A.uniforms[c->cursor++];
+      if (log(u) < cur_ls - ls) { /* keep tree2's proposal */ } else cur_prop = c->st_prop[l];
+      cur_ls = ls;
+    }
+    if (turning) {
+      c->turning = 1; c->aborted = 1; c->depth += 1;
+    } else if (!last) {
+      c->st_ls[m] = cur_ls; c->st_prop[m] = cur_prop;
+    } else {
+      // extend (nuts.py:365-392)
+      if (dir > 0) c->right = t; else c->left = t;
+      c->depth += 1;
+      const double u = A.uniforms[c->cursor++];
+      if (log(u) < cur_ls - c->log_size) c->proposal = cur_prop;
+      c->log_size = logaddexp_d(cur_ls, c->log_size);
+      const double* dd = &dot[DOT_TOP];
+      bool turn = (dd[0] <= 0) || (dd[1] <= 0);
+      if (!turn) turn = (dd[2] <= 0) || (dd[3] <= 0);
+      if (!turn) turn = (dd[4] <= 0) || (dd[5] <= 0);
+      if (turn) { c->turning = 1; c->aborted = 1; }
+      else if (c->depth < max_depth) ctl_next_direction(c, A.uniforms);
+    }
+  }
+  *A.ctl = *c;
+  if (st) publish_status(c, st);
+}
+
+// ---------------------------------------------------------------------------
+// start / end of a draw
+// ---------------------------------------------------------------------------
+
+// p0 = z / sigma, v0 = var * p0, PSUM = p0 (base_hmc.py:201-202, quadpotential.py:323-326)
+__global__ __launch_bounds__(VEC_THREADS) void k_draw_start(ArenaDev A, const double* __restrict__ normals,
+                                                            const double* __restrict__ p_exact, double* __restrict__ kin_part) {
+  __shared__ double sm[VEC_THREADS / WAVE];
+  double kin = 0.0;
+  const int base = blockIdx.x * VEC_THREADS * A.ept;
+  for (int e = 0; e < A.ept; ++e) {
+    const int i = base + e * VEC_THREADS + threadIdx.x;
+    if (i < A.n) {
+      const double p = p_exact ? p_exact[i] : normals[i] * A.inv_stds[i];
+      const double v = A.var[i] * p;
+      A.P[i] = p; A.V[i] = v; A.PSUM[i] = p;
+      kin = fma(p, v, kin);
+    }
+  }
+  const double tot = block_sum<false>(kin, sm);
+  if (threadIdx.x == 0) kin_part[blockIdx.x] = tot;
+}
+
+__global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part, double step_size, int dir_forced, int max_depth,
+                                 HostStatus* st) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int b = 0; b < A.nblk; ++b) s += kin_part[b];
+    Ctl* c = A.ctl;
+    const double logp = A.LOGP[0];
+    const double E = 0.5 * s - logp;  // integration.py:72-74
+    A.E[0] = E;
+    c->E0 = E;
+    c->log_size = 0.0;
+    c->log_accept_sum = -INFINITY;
+    c->max_energy_change = 0.0;
+    c->div_dE = 0.0;
+    c->n_proposals = 0; c->depth = 0; c->left = 0; c->right = 0; c->proposal = 0; c->cursor = 0;
+    c->turning = 0; c->diverging = 0;
+    c->bad_energy = !isfinite(E);
+    c->aborted = c->bad_energy;
+    c->eps_abs = step_size;
+    c->n_leaves_total = 0;
+    c->dir = 1; c->edge = 0; c->eps = step_size;
+    if (dir_forced != 0) { c->dir = dir_forced; c->eps = dir_forced > 0 ? step_size : -step_size; }
+    else if (!c->aborted && max_depth > 0) ctl_next_direction(c, A.uniforms);
+    if (st) publish_status(c, st);
+  }
+}
+
+// gather the proposal and tree statistics (nuts.py:478-489)
+struct DrawOut {
+  double energy, logp, E0, log_accept_sum, max_energy_change, div_dE;
+  int depth, n_proposals, proposal, cursor, turning, diverging, bad_energy, pad;
+};
+
+__global__ __launch_bounds__(VEC_THREADS) void k_draw_finish(ArenaDev A, double* __restrict__ q_out,
+                                                             double* __restrict__ g_out, DrawOut* out) {
+  const Ctl* c = A.ctl;
+  const int prop = c->proposal;
+  const int64_t po = slot_off(A, prop);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) {
+    q_out[i] = A.Q[po + i];
+    g_out[i] = A.G[po + i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int ps = prop & (A.S - 1);
+    out->energy = A.E[ps]; out->logp = A.LOGP[ps]; out->E0 = c->E0;
+    out->log_accept_sum = c->log_accept_sum; out->max_energy_change = c->max_energy_change; out->div_dE = c->div_dE;
+    out->depth = c->depth; out->n_proposals = c->n_proposals; out->proposal = prop; out->cursor = c->cursor;
+    out->turning = c->turning; out->diverging = c->diverging; out->bad_energy = c->bad_energy;
+  }
+}
+
+// ---- mass-matrix adaptation (quadpotential.py:328-355, 431-437) ----
+//   flags bit0: add sample to fg and bg;  bit1: var = clip(fg.m2 / fg.count)
+__global__ __launch_bounds__(VEC_THREADS) void k_potential_update(int n, const double* __restrict__ x,
+                                                                  double* fg_mean, double* fg_m2, double fg_count_new,
+                                                                  double* bg_mean, double* bg_m2, double bg_count_new,
+                                                                  double* var, double* stds, double* inv_stds, int flags) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    double m2 = fg_m2[i];
+    if (flags & 1) {
+      const double xi = x[i];
+      double mean = fg_mean[i];
+      double od = xi - mean;
+      mean += od / fg_count_new;
+      m2 += od * (xi - mean);
+      fg_mean[i] = mean; fg_m2[i] = m2;
+      double bm = bg_mean[i], b2 = bg_m2[i];
+      od = xi - bm;
+      bm += od / bg_count_new;
+      b2 += od * (xi - bm);
+      bg_mean[i] = bm; bg_m2[i] = b2;
+    }
+    if (flags & 2) {
+      double v = m2 / fg_count_new;
+      v = fmin(fmax(v, 1e-12), 1e12);   // np.clip(var, 1e-12, 1e12)
+      if (isnan(m2 / fg_count_new)) v = m2 / fg_count_new;
+      const double s = sqrt(v);
+      var[i] = v; stds[i] = s; inv_stds[i] = 1.0 / s;
+    }
+  }
+}

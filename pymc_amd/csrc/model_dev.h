@@ -1,0 +1,343 @@
+// Device-side model description and the element-wise log-density interpreter.
+//
+// The reference compiles `Model.logp` + `pytensor.grad` into one function
+// (`ValueGradFunction`, pymc/model/core.py:142-305).  Here the model spec that crosses
+// the C ABI (include/nuts_mi355.h) is "compiled" on the host into flat tables:
+//
+//   * per value variable, the list of factor arguments it appears in ("contributions"),
+//     so that the reverse-mode gradient of element i is a GATHER over a fixed list in a
+//     fixed order (deterministic, no floating-point atomics);
+//   * size-1 variables that broadcast against a larger factor get a "broadcast term":
+//     the thread that owns the factor element accumulates d logp / d (that scalar) and
+//     the per-workgroup partials are summed in workgroup order by the control kernel;
+//   * "deferred" elements (every size-1 variable and the mu/sigma hyper-parameters of
+//     the hierarchical-logit node) need a cross-workgroup reduction before their
+//     gradient is known; the control kernel finishes them.
+#pragma once
+#include "device_math.h"
+#include "nuts_mi355.h"
+
+#define MAX_BTERMS 8        // broadcast terms per model
+#define MAX_FACTOR_BT 6     // broadcast operands per factor
+#define MAX_DEFERRED 256    // deferred elements per model (one control-kernel thread each)
+#define LOGIT_MAXD 8
+
+struct VarDev {  // same layout as nuts_var; `pad` carries the deferred flag
+  int32_t offset, size, transform, deferred;
+  double lower, upper;
+};
+
+struct Contrib {  // "variable k is operand `slot` (0=a,1=b,2=c) of argument `arg` of factor f"
+  int32_t f;
+  int16_t arg, slot;
+  int32_t owner;  // 1: this contribution also accounts for the factor's logp and broadcast terms
+  int32_t pad;
+};
+
+struct FactorBT {  // broadcast (size-1 variable) operands of a factor whose size is > 1
+  int32_t n, pad;
+  struct { int16_t arg, slot; int32_t bterm; } e[MAX_FACTOR_BT];
+};
+
+struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); see rows_kernel.h
+  int64_t N, Npad;
+  int32_t D, G;
+  const double* Xt;        // [n_spans][D][span] span-tiled copy of X: one contiguous 8*D*span-byte block per wave-iteration
+  const int8_t* y;         // [Npad]
+  const int64_t* gptr;     // [G+1] first row of each group
+  int32_t off_mu, off_sigma, off_z, sigma_tr;
+  int32_t var_mu, var_sigma, var_z, pad;
+  int64_t n_spans;         // Npad / span
+  int32_t n_waves, n_seg;  // waves in the row-streaming launch; total (wave, group) segments
+  const int32_t* span_gid; // [n_spans] group of a span that lies entirely inside one group, -1 for a "mixed" span
+  const int32_t* seg_base; // [n_waves] first segment slot of each main wave
+  const int32_t* gseg_ptr; // [G+1] main segments of group g = [gseg_ptr[g], gseg_ptr[g+1])
+  double* seg_part;        // [n_seg][D]  d logp / d beta_g partial of each (wave, group) run
+  // mixed spans (contain a group boundary or padding rows): one wave each, extra workgroups of the same launch
+  int32_t n_mixed, n_mixed_seg;
+  const int64_t* mixed_span;     // [n_mixed] span index
+  const int32_t* mixed_g0;       // [n_mixed] group of the span's first row
+  const int32_t* mixed_seg_base; // [n_mixed]
+  const int32_t* gmix_ptr;       // [G+1] mixed segments of group g
+  double* mixed_part;            // [n_mixed_seg][D]
+  double* wave_lp;         // [n_waves + n_mixed]   log-likelihood partial of each wave
+};
+
+struct MvnDev {
+  int32_t k, off;
+  const double* mu;    // [k]
+  const double* prec;  // [k][k]
+  double konst;        // -k/2 log(2 pi) - logdet
+  double* rowq;        // [k] delta_i * (P delta)_i
+  double* gdense;      // [n] -(P delta)
+};
+
+// per-workgroup partial record written by the vector kernel, summed (in workgroup order) by the control kernel
+#define PART_LP 0
+#define PART_BT 1
+#define PART_DMU (PART_BT + MAX_BTERMS)
+#define PART_DSG (PART_DMU + LOGIT_MAXD)
+#define PART_DOT (PART_DSG + LOGIT_MAXD)
+
+struct ModelDev {
+  int32_t n, n_vars, n_factors, n_data;
+  int32_t n_bterms, n_orphans, n_deferred, nblk;
+  const double* pool;         // data vectors of the spec
+  const int32_t* orphans;     // [n_orphans] factors without an owning variable
+  const int32_t* deferred;    // [n_deferred] element indices
+  int has_logit, has_mvn;
+  RowsDev lg;
+  MvnDev mv;
+  double* part;               // [nblk][part_stride]
+  int32_t part_stride, prog_bytes;
+  // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
+  const char* prog;
+  int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_pad;
+};
+
+#define PROG_LDS_MAX 12288
+
+// The interpreter's view of the model tables (LDS copy when it fits, the global blob otherwise).
+struct Prog {
+  const VarDev* vars;
+  const int32_t* var_cptr;
+  const Contrib* contrib;
+  const nuts_factor* factors;
+  const FactorBT* fbt;
+  const int32_t* bterm_var;
+  const nuts_data_ref* data;
+  const double* pool;
+  int n_vars;
+};
+
+// Cooperative copy of the program blob into LDS (all threads of the workgroup; ends with a barrier).
+__device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog) {
+  const char* base = md.prog;
+  if (md.prog_bytes <= PROG_LDS_MAX) {
+    const int n16 = (md.prog_bytes + 15) >> 4;
+    for (int i = threadIdx.x; i < n16; i += blockDim.x)
+      reinterpret_cast<uint4*>(s_prog)[i] = reinterpret_cast<const uint4*>(md.prog)[i];
+    __syncthreads();
+    base = s_prog;
+  }
+  Prog pg;
+  pg.vars = reinterpret_cast<const VarDev*>(base + md.po_vars);
+  pg.var_cptr = reinterpret_cast<const int32_t*>(base + md.po_cptr);
+  pg.contrib = reinterpret_cast<const Contrib*>(base + md.po_contrib);
+  pg.factors = reinterpret_cast<const nuts_factor*>(base + md.po_factors);
+  pg.fbt = reinterpret_cast<const FactorBT*>(base + md.po_fbt);
+  pg.bterm_var = reinterpret_cast<const int32_t*>(base + md.po_btvar);
+  pg.data = reinterpret_cast<const nuts_data_ref*>(base + md.po_data);
+  pg.pool = md.pool;
+  pg.n_vars = md.n_vars;
+  return pg;
+}
+
+// How a kernel obtains the position vector it evaluates the model at.  In "composed" mode the
+// first half of the leapfrog (integration.py:118-127) is recomputed on the fly from the source
+// slot of the trajectory arena, so no kernel has to materialise q' before the row-streaming pass.
+struct QView {
+  const double* q;
+  const double* p;
+  const double* g;
+  const double* var;
+  double eps, half;
+  int composed;
+  __device__ __forceinline__ double p_half(int64_t i) const { return fma(half, g[i], p[i]); }
+  __device__ __forceinline__ double at(int64_t i) const {
+    if (!composed) return q[i];
+    const double ph = fma(half, g[i], p[i]);
+    const double v = var[i] * ph;
+    return fma(eps, v, q[i]);
+  }
+};
+
+// value transforms: forward value only / full (x, dx/dq, log|J|, dlog|J|/dq)
+// (pymc/logprob/transforms.py:880-891, 1017-1088)
+__device__ __forceinline__ double transform_x(const VarDev& v, double qi) {
+  switch (v.transform) {
+    case NUTS_TR_LOG: return exp(qi);
+    case NUTS_TR_LOGODDS: return sigmoid_d(qi);
+    case NUTS_TR_INTERVAL: { double s = sigmoid_d(qi); return s * v.upper + (1.0 - s) * v.lower; }
+    default: return qi;
+  }
+}
+
+__device__ __forceinline__ void transform_full(const VarDev& v, double qi, double& x, double& dx, double& lj, double& dj) {
+  switch (v.transform) {
+    case NUTS_TR_LOG:
+      x = exp(qi); dx = x; lj = qi; dj = 1.0;
+      break;
+    case NUTS_TR_LOGODDS: {
+      double s = sigmoid_d(qi);
+      x = s; dx = s * (1.0 - s); lj = -softplus_d(-qi) - softplus_d(qi); dj = 1.0 - 2.0 * s;
+    } break;
+    case NUTS_TR_INTERVAL: {
+      double s = sigmoid_d(qi);
+      x = s * v.upper + (1.0 - s) * v.lower;
+      dx = (v.upper - v.lower) * s * (1.0 - s);
+      lj = log(v.upper - v.lower) - 2.0 * softplus_d(-qi) - qi;
+      dj = 1.0 - 2.0 * s;
+    } break;
+    default:
+      x = qi; dx = 1.0; lj = 0.0; dj = 0.0;
+  }
+}
+
+__device__ __forceinline__ int find_var(const Prog& pg, int i) {
+  int k = 0;
+  while (k + 1 < pg.n_vars && i >= pg.vars[k].offset + pg.vars[k].size) ++k;
+  return k;
+}
+
+// `own_var` / `own_x`: the calling thread's own element (same local index li) -- its constrained value is
+// already in a register, everything else is recomposed through the view.
+__device__ __forceinline__ double op_value(const nuts_operand& o, int li, const Prog& pg, const QView& qv, int own_var,
+                                           double own_x) {
+  if (o.kind == NUTS_OP_CONST) return o.c;
+  if (o.kind == NUTS_OP_DATA) {
+    const nuts_data_ref r = pg.data[o.ref];
+    return pg.pool[r.offset + (r.size > 1 ? li : 0)];
+  }
+  if (o.ref == own_var) return own_x;
+  const VarDev v = pg.vars[o.ref];
+  return transform_x(v, qv.at(v.offset + (v.size > 1 ? li : 0)));
+}
+
+// log-density of one element and its partials w.r.t. each argument.
+__device__ __forceinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
+  const double NINF = -INFINITY;
+  const double LOG_SQRT_2PI = 0.91893853320467274178;
+  const double LOG_SQRT_2_OVER_PI = -0.22579135264472743236;
+  const double LOG_PI = 1.14472988584940017414;
+  const double LOG_2 = 0.69314718055994530942;
+  double lp = 0.0;
+  bool dead = false;
+#define KILL_UNLESS(cond) if (!(cond)) { lp = NINF; dead = true; }
+  d[0] = d[1] = d[2] = d[3] = 0.0;
+  switch (dist) {
+    case NUTS_D_NORMAL: {  // continuous.py:526-532
+      double sg = a[2], z = (a[0] - a[1]) / sg;
+      lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg);
+      KILL_UNLESS(sg > 0)
+      d[0] = -z / sg; d[1] = z / sg; d[2] = (z * z - 1.0) / sg;
+    } break;
+    case NUTS_D_HALFNORMAL: {  // continuous.py:909-916
+      double sg = a[1], z = a[0] / sg;
+      lp = -0.5 * z * z + LOG_SQRT_2_OVER_PI - log(sg);
+      KILL_UNLESS(a[0] >= 0)
+      KILL_UNLESS(sg > 0)
+      d[0] = -z / sg; d[1] = (z * z - 1.0) / sg;
+    } break;
+    case NUTS_D_CAUCHY: {  // continuous.py:2287-2293
+      double be = a[2], z = (a[0] - a[1]) / be;
+      lp = -LOG_PI - log(be) - log1p(z * z);
+      KILL_UNLESS(be > 0)
+      double w = 2.0 * z / (1.0 + z * z);
+      d[0] = -w / be; d[1] = w / be; d[2] = (-1.0 + w * z) / be;
+    } break;
+    case NUTS_D_HALFCAUCHY: {  // continuous.py:2383-2390
+      double be = a[1], z = a[0] / be;
+      lp = LOG_2 - LOG_PI - log(be) - log1p(z * z);
+      KILL_UNLESS(a[0] >= 0)
+      KILL_UNLESS(be > 0)
+      double w = 2.0 * z / (1.0 + z * z);
+      d[0] = -w / be; d[1] = (-1.0 + w * z) / be;
+    } break;
+    case NUTS_D_STUDENTT: {  // continuous.py:1935-1950 (nu constant)
+      double nu = a[1], sg = a[3], z = (a[0] - a[2]) / sg;
+      lp = konst - log(sg) - (nu + 1.0) / 2.0 * log1p(z * z / nu);
+      KILL_UNLESS(sg > 0)
+      double w = (nu + 1.0) * z / (nu + z * z);
+      d[0] = -w / sg; d[2] = w / sg; d[3] = (-1.0 + w * z) / sg;
+    } break;
+    case NUTS_D_BETA: {  // continuous.py:1248-1262 (alpha, beta constant)
+      double v = a[0], al = a[1], be = a[2];
+      lp = (al == 1.0 ? 0.0 : (al - 1.0) * log(v)) + (be == 1.0 ? 0.0 : (be - 1.0) * log1p(-v)) + konst;
+      d[0] = (al == 1.0 ? 0.0 : (al - 1.0) / v) - (be == 1.0 ? 0.0 : (be - 1.0) / (1.0 - v));
+      KILL_UNLESS(v >= 0 && v <= 1)
+    } break;
+    case NUTS_D_EXPONENTIAL: {  // continuous.py:1478-1486 (mu = 1/lam)
+      double v = a[0], lam = a[1];
+      lp = log(lam) - v * lam;
+      KILL_UNLESS(v >= 0)
+      KILL_UNLESS(lam > 0)
+      d[0] = -lam; d[1] = 1.0 / lam - v;
+    } break;
+    case NUTS_D_UNIFORM: {  // continuous.py:309-321
+      double v = a[0], lo = a[1], hi = a[2];
+      lp = -log(hi - lo);
+      KILL_UNLESS(v >= lo && v <= hi)
+      KILL_UNLESS(lo <= hi)
+    } break;
+    case NUTS_D_BERNOULLI_LOGIT: {  // discrete.py:351-352,362-374
+      double y = a[0], eta = a[1];
+      lp = (y != 0.0) ? -softplus_d(-eta) : -softplus_d(eta);
+      KILL_UNLESS(y >= 0 && y <= 1)
+      d[1] = y - sigmoid_d(eta);
+    } break;
+    case NUTS_D_LOGNORMAL: {  // continuous.py:1807-1819
+      double v = a[0], sg = a[2], lv = log(v), z = (lv - a[1]) / sg;
+      lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg) - lv;
+      KILL_UNLESS(v > 0)
+      KILL_UNLESS(sg > 0)
+      d[0] = (-z / sg - 1.0) / v; d[1] = z / sg; d[2] = (z * z - 1.0) / sg;
+    } break;
+    case NUTS_D_BERNOULLI: {  // discrete.py:362-374
+      double y = a[0], p = a[1];
+      lp = (y != 0.0) ? log(p) : log1p(-p);
+      d[1] = (y != 0.0) ? 1.0 / p : -1.0 / (1.0 - p);
+      KILL_UNLESS(y >= 0 && y <= 1)
+      KILL_UNLESS(p >= 0 && p <= 1)
+    } break;
+    default: lp = NAN;
+  }
+  // every support / parameter check is a `switch(cond, logp, -inf)` in the reference graph
+  // (dist_math.py:50-74, logprob/utils.py:209-225): its gradient is 0 where the check fails.
+  if (dead) d[0] = d[1] = d[2] = d[3] = 0.0;
+#undef KILL_UNLESS
+  return lp;
+}
+
+// Evaluate element `li` of factor `f`: returns its logp, fills d[k] (partials w.r.t. argument k)
+// and the b / c operand values of every argument (needed for the chain rule through a + b*c).
+__device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var,
+                                              double own_x, double* d, double* bv, double* cv) {
+  double a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < f.nargs) {
+      const nuts_term& t = f.arg[k];
+      const double av = op_value(t.a, li, pg, qv, own_var, own_x);
+      bv[k] = op_value(t.b, li, pg, qv, own_var, own_x);
+      cv[k] = op_value(t.c, li, pg, qv, own_var, own_x);
+      a[k] = av + bv[k] * cv[k];
+    } else {
+      a[k] = 0.0; bv[k] = cv[k] = 0.0;
+    }
+  }
+  return dist_eval(f.dist, f.konst, a, d);
+}
+
+__device__ __forceinline__ double slot_grad(const double* d, const double* bv, const double* cv, int arg, int slot) {
+  return slot == 0 ? d[arg] : (slot == 1 ? d[arg] * cv[arg] : d[arg] * bv[arg]);
+}
+
+// Reverse-mode gather for element i (local index li) of variable k: d logp / d x_i from every factor the
+// variable appears in, plus (for owning contributions) the factor's logp and its broadcast terms.
+// `s_bacc` is the calling thread's column of the LDS broadcast accumulators ([MAX_BTERMS][blockDim]).
+__device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, int k, int li, double x, double& gx, double& lp,
+                                               double* s_bacc, int bstride) {
+  for (int c = pg.var_cptr[k]; c < pg.var_cptr[k + 1]; ++c) {
+    const Contrib cb = pg.contrib[c];
+    const nuts_factor& f = pg.factors[cb.f];
+    double d[4], bv[4], cv[4];
+    const double lpf = factor_eval(pg, qv, f, li, k, x, d, bv, cv);
+    gx += slot_grad(d, bv, cv, cb.arg, cb.slot);
+    if (cb.owner) {
+      lp += lpf;
+      const FactorBT& bt = pg.fbt[cb.f];
+      for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm * bstride] += slot_grad(d, bv, cv, bt.e[b].arg, bt.e[b].slot);
+    }
+  }
+}

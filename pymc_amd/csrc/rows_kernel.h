@@ -1,0 +1,177 @@
+// Kernel A for the hierarchical Bernoulli-logit node: the HBM-streaming pass over the observation rows.
+//
+//   y_i ~ Bernoulli(logit_p = x_i . beta_g(i)),  beta_g = mu + sigma * z_g      (discrete.py:351-374)
+//
+// One fused forward + backward pass: eta_i depends only on row i and beta_g(i), so the log-likelihood and
+// d logp / d beta_g are produced in ONE read of X.  Algorithmic traffic: 8 D + 1 bytes per row (+ the group
+// structure, which this kernel reads as G+1 row pointers instead of one int32 per row).
+//
+// Data layout in HBM: X in span tiles [n_spans][D][SPAN] (SPAN = 64 RPL rows): the 8 D SPAN bytes a wave needs
+// for one iteration are ONE contiguous block (8 KiB at D = 8, RPL = 2), each column a 1 KiB wave-load of
+// 16 B per lane; y int8 [Npad].  Measured on MI355X (tools/rows_lab.hip): the tiled layout streams at
+// 6.1-6.3 TB/s with the full math on, against 5.6-6.0 TB/s for plain column-major.
+//
+// Work decomposition: rows are sorted by group.  Wave w owns the contiguous spans [s0, s1) of SPAN = 64 RPL
+// rows; inside a span lane l holds rows RPL*l .. RPL*l + RPL-1.  beta_g is wave-uniform and lives in SGPRs.
+// The wave keeps per-lane accumulators of d logp / d beta for its current group and, when the group changes,
+// flushes a wave-reduced partial into a static "segment" slot (segments are enumerated on the host in row
+// order, so the combine order in kernel B is fixed -> bit-reproducible results, no atomics).
+#pragma once
+#include "model_dev.h"
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+template <int D>
+__device__ __forceinline__ void rows_flush(double (&acc)[D], double* __restrict__ seg_part, int& seg, int lane) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double s = wave_sum(acc[d]);
+    if (lane == 0) seg_part[(int64_t)seg * D + d] = s;
+    acc[d] = 0.0;
+  }
+  ++seg;
+}
+
+// log-likelihood and residual of one row given eta:  lp = y eta - softplus(eta),  r = y - sigmoid(eta)
+// (PyTensor's stabilised forms: log(sigmoid(x)) = -softplus(-x), log1p(-sigmoid(x)) = -softplus(x))
+__device__ __forceinline__ void logit_row(double eta, double yk, double& lp, double& r) {
+  const double e = exp(-fabs(eta));
+  const double l1p = log1p(e);
+  const double inv = 1.0 / (1.0 + e);
+  const double sgm = eta >= 0 ? inv : e * inv;
+  const double spl = (eta > 0 ? eta : 0.0) + l1p;
+  lp = yk * eta - spl;
+  r = yk - sgm;
+}
+
+// X tile of one span: [D][SPAN] doubles, lane l holds rows RPL*l .. RPL*l+RPL-1 of every column
+template <int D, int RPL>
+__device__ __forceinline__ void rows_load(const RowsDev& R, int64_t sp, int lane, double (&x)[D][RPL], uint32_t& ybits) {
+  constexpr int SPAN = WAVE * RPL;
+  const double* tile = R.Xt + sp * (int64_t)(D * SPAN) + lane * RPL;
+  const int8_t* yp = R.y + sp * SPAN + lane * RPL;
+  if (RPL == 2) ybits = *reinterpret_cast<const uint16_t*>(yp);
+  else ybits = *reinterpret_cast<const uint32_t*>(yp);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int k = 0; k < RPL; k += 2) {
+      const double2 a = *reinterpret_cast<const double2*>(tile + d * SPAN + k);
+      x[d][k] = a.x; x[d][k + 1] = a.y;
+    }
+  }
+}
+
+// Hyper-parameters of coordinate d = lane (lanes >= D replicate lane 0): evaluated once per wave.
+template <int D>
+__device__ __forceinline__ void rows_hyper(const RowsDev& R, const QView& qv, int lane, double& m_lane, double& s_lane) {
+  const int dl = lane < D ? lane : 0;
+  m_lane = qv.at(R.off_mu + dl);
+  const double s = qv.at(R.off_sigma + dl);
+  s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(s) : s;
+}
+
+// beta_g = mu + sigma * z_g as wave-uniform values (lane d evaluates coordinate d, readlane broadcasts into SGPRs)
+template <int D>
+__device__ __forceinline__ void rows_beta(const RowsDev& R, const QView& qv, int g, int lane, double m_lane, double s_lane,
+                                          double (&beta)[D]) {
+  const int dl = lane < D ? lane : 0;
+  const double z = qv.at(R.off_z + (int64_t)g * D + dl);
+  const double b = fma(s_lane, z, m_lane);
+#pragma unroll
+  for (int d = 0; d < D; ++d) beta[d] = readlane_d(b, d);
+}
+
+// ---- main body: a contiguous range of spans, only the spans that lie entirely inside one group ----
+// (spans containing a group boundary or padding rows are listed on the host and handled by rows_mixed below,
+// by extra workgroups of the same launch: the streaming loop carries no rare-path state)
+template <int D, int RPL>
+__device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int wave, int lane) {
+  const int64_t s0 = (int64_t)wave * R.n_spans / R.n_waves;
+  const int64_t s1 = (int64_t)(wave + 1) * R.n_spans / R.n_waves;
+  int seg = R.seg_base[wave];
+  int g_cur = -1;
+  double m_lane, s_lane;
+  rows_hyper<D>(R, qv, lane, m_lane, s_lane);
+  double beta[D], acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { acc[d] = 0.0; beta[d] = 0.0; }
+  double lp = 0.0;
+  for (int64_t sp = s0; sp < s1; ++sp) {
+    const int g = __builtin_amdgcn_readfirstlane(R.span_gid[sp]);
+    if (g < 0) continue;  // mixed span
+    double x[D][RPL];
+    uint32_t yb;
+    rows_load<D, RPL>(R, sp, lane, x, yb);
+    if (g != g_cur) {
+      if (g_cur >= 0) rows_flush<D>(acc, R.seg_part, seg, lane);
+      g_cur = g;
+      rows_beta<D>(R, qv, g, lane, m_lane, s_lane, beta);
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      double eta = 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) eta = fma(x[d][k], beta[d], eta);
+      double l, r;
+      logit_row(eta, (double)((yb >> (8 * k)) & 0xffu), l, r);
+      lp += l;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc[d] = fma(r, x[d][k], acc[d]);
+    }
+  }
+  if (g_cur >= 0) rows_flush<D>(acc, R.seg_part, seg, lane);
+  lp = wave_sum(lp);
+  if (lane == 0) R.wave_lp[wave] = lp;
+}
+
+// ---- one mixed span per wave: a masked pass per group present in the span ----
+template <int D, int RPL>
+__device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, int mw, int lane) {
+  constexpr int SPAN = WAVE * RPL;
+  const int64_t sp = R.mixed_span[mw];
+  int seg = R.mixed_seg_base[mw];
+  const int64_t rs = sp * SPAN, span_end = rs + SPAN;
+  const int64_t r0 = rs + (int64_t)lane * RPL;
+  double x[D][RPL];
+  uint32_t yb;
+  rows_load<D, RPL>(R, sp, lane, x, yb);
+  int g = __builtin_amdgcn_readfirstlane(R.mixed_g0[mw]);  // group of the span's first row
+  double m_lane, s_lane;
+  rows_hyper<D>(R, qv, lane, m_lane, s_lane);
+  double lp = 0.0;
+  while (true) {
+    double beta[D], acc[D];
+    rows_beta<D>(R, qv, g, lane, m_lane, s_lane, beta);
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.0;
+    const int64_t gs = R.gptr[g], ge = R.gptr[g + 1];
+#pragma unroll
+    for (int k = 0; k < RPL; ++k) {
+      const int64_t row = r0 + k;
+      const bool in = row < ge && row >= gs;
+      double eta = 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) eta = fma(x[d][k], beta[d], eta);
+      double l, r;
+      logit_row(eta, (double)((yb >> (8 * k)) & 0xffu), l, r);
+      lp += in ? l : 0.0;
+      r = in ? r : 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc[d] = fma(r, x[d][k], acc[d]);
+    }
+    rows_flush<D>(acc, R.mixed_part, seg, lane);
+    if (ge >= span_end) break;      // the group continues past this span
+    int gn = g + 1;                 // next non-empty group, if any rows are left
+    while (gn < R.G && R.gptr[gn + 1] == R.gptr[gn]) ++gn;
+    if (gn >= R.G) break;           // only padding rows remain
+    g = gn;
+  }
+  lp = wave_sum(lp);
+  if (lane == 0) R.wave_lp[R.n_waves + mw] = lp;
+}

@@ -312,6 +312,11 @@ class NUTS(_DeviceHMCBase):
         if rc != _lib.NUTS_OK:
             _lib.check(rc, "nuts_chain_draw")
         bg.advance(st.n_uniforms_consumed)
+        # `advance` drops the cached half of a 32-bit draw (e.g. the seed draw of mcmc.py:908); `random()` never
+        # touches it, so the reference generator still holds it: put it back for exact stream identity
+        adv = bg.state
+        adv["has_uint32"], adv["uinteger"] = saved["has_uint32"], saved["uinteger"]
+        bg.state = adv
         warning = None
         if st.diverging:
             kind = "TUNING_DIVERGENCE" if self.tune else "DIVERGENCE"
@@ -384,8 +389,11 @@ class HamiltonianMC(_DeviceHMCBase):
     def astep(self, q0: RaveledVars):
         q = np.ascontiguousarray(q0.data, dtype="float64")
         normals = self.potential._draw_normals()
-        # hmc.py:35-36 `rng.uniform(elow, ehigh)`, then hmc.py:162 `rng.random()`
-        u = np.array([self.rng.random(), self.rng.random()])
+        # hmc.py:35-36 `rng.uniform(elow, ehigh)` (one double), then hmc.py:162 `rng.random()` -- which the
+        # reference only draws when the trajectory did not diverge (short-circuit `or`)
+        u0 = self.rng.random()
+        after_jitter = self.rng.bit_generator.state
+        u = np.array([u0, self.rng.random()])
         st = _lib.HmcStats()
         rc = _lib.load().nuts_chain_draw_hmc(
             self._chain, _lib.dptr(q), _lib.dptr(normals), _lib.dptr(u), float(self.path_length), int(self.max_steps),
@@ -393,6 +401,8 @@ class HamiltonianMC(_DeviceHMCBase):
         )
         if rc != _lib.NUTS_OK:
             _lib.check(rc, "nuts_chain_draw_hmc")
+        if st.diverging:
+            self.rng.bit_generator.state = after_jitter
         stats = {
             "diverging": bool(st.diverging), "divergences": int(st.divergences),
             "perf_counter_diff": st.perf_counter_diff, "process_time_diff": st.process_time_diff,
