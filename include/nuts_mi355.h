@@ -124,6 +124,9 @@ int nuts_model_logp_grad(nuts_model *m, const double *q, double *logp, double *g
  * (row-streaming / mat-vec) kernel alone (ms_dominant), measured with HIP
  * events on the library stream. */
 int nuts_model_time_logp_grad(nuts_model *m, const double *q, int reps, double *ms_total, double *ms_dominant);
+/* Diagnostics: 64 shader-clock timestamps of the phases of the last O(n) / control launches (all zero unless
+ * the library was built with -DNUTS_KTIMING). */
+int nuts_model_debug_ticks(nuts_model *m, int64_t *out /* [64] */);
 /* Algorithmic HBM bytes of one model pass (SURVEY.md section 8d B_model). */
 int64_t nuts_model_algorithmic_bytes(const nuts_model *m);
 

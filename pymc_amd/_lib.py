@@ -166,6 +166,7 @@ SYMBOLS = {
     "nuts_model_logp_grad": (C.c_int, [_VP, _PD, _PD, _PD]),
     "nuts_model_time_logp_grad": (C.c_int, [_VP, _PD, C.c_int, _PD, _PD]),
     "nuts_model_algorithmic_bytes": (C.c_int64, [_VP]),
+    "nuts_model_debug_ticks": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
     "nuts_chain_config_default": (None, [C.POINTER(ChainConfig)]),
     "nuts_chain_create": (_VP, [_VP, C.POINTER(ChainConfig)]),
     "nuts_chain_destroy": (None, [_VP]),

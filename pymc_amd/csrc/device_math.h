@@ -10,17 +10,33 @@
 
 #define WAVE 64
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-  return v;  // valid in lane 0
+// Wavefront sum on the DPP cross-lane network (VALU speed; `__shfl_*` would go through the LDS crossbar at ~100
+// cycles per step).  Fixed association order:
+//   rows of 16 lanes: shr 1, 2, 4, 8 (lane 15 of a row holds the row total), then row_bcast:15 folds row 0 into 1
+//   and row 2 into 3, row_bcast:31 folds lanes 0-31 into row 3; lane 63 holds the total, which is read back as a
+//   wave-uniform value (valid in EVERY lane).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_d(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum_all(double v) {
-#pragma unroll
-  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;  // valid in every lane (butterfly: same order for every lane pair)
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_move_d<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_move_d<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_move_d<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_move_d<0x118, 0xf>(v);  // row_shr:8
+  v += dpp_move_d<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+  v += dpp_move_d<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, 63);
+  hi = __builtin_amdgcn_readlane(hi, 63);
+  return __hiloint2double(hi, lo);
 }
+
+__device__ __forceinline__ double wave_sum_all(double v) { return wave_sum(v); }
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll

@@ -71,6 +71,7 @@ struct nuts_model {
   double* host_pin = nullptr;  // pinned [2n+2]
   int rows_grid = 0, mvn_grid = 0, ept = 1;
   int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
+  int vector_one_xcd = 0;
   int explicit_pre = 0;        // the position must be materialised before the dense pass (MvNormal node)
   int64_t alg_bytes = 0;
   // profiling of the dominant kernel
@@ -100,10 +101,12 @@ extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
 
 static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int d) {
   const ModelDev& md = m->md;
+  // small models: 8x oversubscribed launch, one XCD does the work (see k_vector); large ones use the whole chip
+  const dim3 grid(m->vector_one_xcd ? md.nblk * 8 : md.nblk);
   switch (m->ept) {
-    case 1: hipLaunchKernelGGL(k_vector<1>, dim3(md.nblk), dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
-    case 4: hipLaunchKernelGGL(k_vector<4>, dim3(md.nblk), dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
-    default: hipLaunchKernelGGL(k_vector<16>, dim3(md.nblk), dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
+    case 1: hipLaunchKernelGGL(k_vector<1>, grid, dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
+    case 4: hipLaunchKernelGGL(k_vector<4>, grid, dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
+    default: hipLaunchKernelGGL(k_vector<16>, grid, dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
   }
 }
 
@@ -144,7 +147,8 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
 static void model_enqueue_plain(nuts_model* m, const double* q_dev, double* g_dev, double* lp_dev) {
   ArenaDev A{};
   A.n = m->md.n; A.nblk = m->md.nblk; A.ept = m->ept; A.S = 1;
-  EvalIO io{MODE_PLAIN, 0, q_dev, g_dev, lp_dev};
+  EvalIO io{};
+  io.mode = MODE_PLAIN; io.q = q_dev; io.grad = g_dev; io.logp = lp_dev;
   launch_dense(m, A, io, 0);
   launch_vector(m, A, io, 0, 0);
   hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr);
@@ -157,7 +161,9 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   vars.resize(nv);
   for (int k = 0; k < nv; ++k) {
     const nuts_var& v = s->vars[k];
-    vars[k] = VarDev{v.offset, v.size, v.transform, v.size == 1 ? 1 : 0, v.lower, v.upper};
+    vars[k] = VarDev{};
+    vars[k].offset = v.offset; vars[k].size = v.size; vars[k].transform = v.transform; vars[k].deferred = v.size == 1 ? 1 : 0;
+    vars[k].lower = v.lower; vars[k].upper = v.upper;
     if (v.size <= 0) { g_err = "empty value variable"; return false; }
   }
   if (s->rows_N > 0) { vars[s->rows_mu].deferred = 1; vars[s->rows_sigma].deferred = 1; }
@@ -182,7 +188,21 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         if (o.ref < 0 || o.ref >= nv) { g_err = "factor refers to a missing variable"; return false; }
         const VarDev& v = vars[o.ref];
         if (v.size == f.size) {
-          per_var[o.ref].push_back(Contrib{fi, (int16_t)a, (int16_t)sl, owned_already ? 0 : 1, 0});
+          Contrib cb{};
+          cb.f = fi; cb.arg = (int16_t)a; cb.slot = (int16_t)sl; cb.owner = owned_already ? 0 : 1;
+          // fast form: this operand is the whole argument (a + 0), every other argument folds to a constant
+          bool fast = sl == 0;
+          for (int a2 = 0; a2 < f.nargs && fast; ++a2) {
+            const nuts_term& t = f.arg[a2];
+            const bool bc_zero = (t.b.kind == NUTS_OP_CONST && t.b.c == 0.0) || (t.c.kind == NUTS_OP_CONST && t.c.c == 0.0);
+            if (a2 == a) fast = bc_zero && t.b.kind == NUTS_OP_CONST && t.c.kind == NUTS_OP_CONST;
+            else {
+              fast = t.a.kind == NUTS_OP_CONST && t.b.kind == NUTS_OP_CONST && t.c.kind == NUTS_OP_CONST;
+              cb.p[a2] = t.a.c + t.b.c * t.c.c;
+            }
+          }
+          cb.fast = fast ? 1 : 0; cb.dist = f.dist; cb.konst = f.konst;
+          per_var[o.ref].push_back(cb);
           owned_already = true;
         } else if (v.size == 1) {
           int b = -1;
@@ -199,6 +219,16 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       }
     }
     if (!owned_already) orphans.push_back(fi);
+  }
+  // peephole: untransformed vector variable whose only contribution is its own constant-parameter Normal prior
+  for (int k = 0; k < nv; ++k) {
+    if (vars[k].transform != NUTS_TR_NONE || vars[k].deferred || per_var[k].size() != 1) continue;
+    const Contrib& cb = per_var[k][0];
+    if (!cb.fast || !cb.owner || cb.dist != NUTS_D_NORMAL || cb.arg != 0 || !(cb.p[2] > 0)) continue;
+    vars[k].normal_prior = 1;
+    vars[k].np_mu = cb.p[1];
+    vars[k].np_inv_var = 1.0 / (cb.p[2] * cb.p[2]);
+    vars[k].np_lognorm = 0.91893853320467274178 + std::log(cb.p[2]);
   }
   std::vector<int32_t> cptr(nv + 1, 0);
   std::vector<Contrib> contrib;
@@ -253,7 +283,10 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   md.pool = m->keep(dev_upload(s->data_pool, s->data_pool_len));
   m->ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
   md.nblk = (n + VEC_THREADS * m->ept - 1) / (VEC_THREADS * m->ept);
+  md.ticks = m->keep(dev_alloc<long long>(64));
+  hipMemset(md.ticks, 0, 64 * sizeof(long long));
   md.part_stride = PART_STRIDE;
+  m->vector_one_xcd = env_int("NUTS_VECTOR_ONE_XCD", 0);
   md.part = m->keep(dev_alloc<double>((size_t)md.nblk * PART_STRIDE));
   hipMemset(md.part, 0, (size_t)md.nblk * PART_STRIDE * sizeof(double));
   m->q_dev = m->keep(dev_alloc<double>(n));
@@ -390,6 +423,15 @@ extern "C" void nuts_model_destroy(nuts_model* m) {
   if (m->host_pin) hipHostFree(m->host_pin);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
+}
+
+// Diagnostics: shader-clock timestamps of the phases of the last B / C launch (zeros unless the library was
+// built with -DNUTS_KTIMING).  64 entries.
+extern "C" int nuts_model_debug_ticks(nuts_model* m, int64_t* out) {
+  if (!m || !out) return NUTS_E_ARG;
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipMemcpy(out, m->md.ticks, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  return NUTS_OK;
 }
 
 extern "C" int32_t nuts_model_ndim(const nuts_model* m) { return m ? m->md.n : -1; }
@@ -688,12 +730,19 @@ static int sync_status(nuts_chain* c) {
 }
 
 // one leapfrog leaf = A (data pass) + B (O(n) work) + C (control); see kernels.h
-static inline void enqueue_leaf(nuts_chain* c, int j, int d, int mode, int max_depth) {
+struct Geometry {  // of the doubling being built: direction, edge state, current edge indices, signed step
+  int dir, edge, left, right;
+  double eps;
+};
+
+static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d, int mode, int max_depth) {
   ArenaDev& A = c->A;
   nuts_model* m = c->m;
   hipStream_t s = m->stream;
-  EvalIO io{mode, m->explicit_pre, nullptr, nullptr, nullptr};
-  if (m->explicit_pre) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, j, mode);
+  EvalIO io{};
+  io.mode = mode; io.explicit_pre = m->explicit_pre;
+  io.dir = gm.dir; io.edge = gm.edge; io.left = gm.left; io.right = gm.right; io.eps = gm.eps;
+  if (m->explicit_pre) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
   launch_dense(m, A, io, j);
   launch_vector(m, A, io, j, d);
   hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth,
@@ -723,14 +772,21 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   if (rc) return rc;
   bool exhausted = true;
   int64_t evals = 1;
+  // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
+  // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
+  Geometry gm{uniforms[0] < 0.5 ? 1 : -1, 0, 0, 0, 0.0};
+  gm.eps = gm.dir > 0 ? step_size : -step_size;
   for (int d = 0; d < max_depth; ++d) {
     const int nleaf = 1 << d;
-    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, j, d, MODE_TREE, max_depth);
+    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, gm, j, d, MODE_TREE, max_depth);
     rc = sync_status(c);
     if (rc) return rc;
     const HostStatus& st = *c->st_host;
     if (st.bad_energy) break;
     if (st.diverging || st.turning) { exhausted = false; break; }
+    if (gm.dir > 0) gm.right += nleaf; else gm.left -= nleaf;   // nuts.py:353,362: the subtree's far end is the new edge
+    gm.dir = st.dir; gm.edge = st.edge;
+    gm.eps = gm.dir > 0 ? step_size : -step_size;
   }
   if (c->st_host->bad_energy) {
     // base_hmc.py:205-224: SamplingError("Bad initial energy"), after potential.raise_ok
@@ -804,7 +860,8 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   if (n_steps >= A.S) { g_err = "n_steps exceeds the trajectory arena (2^max_treedepth slots)"; return NUTS_E_ARG; }
   int rc = draw_begin(c, q0, normals, uniforms, 0, step_size, 1, false, +1);
   if (rc) return rc;
-  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, j, 0, MODE_SIMPLE, 1);
+  const Geometry gm{+1, 0, 0, 0, step_size};
+  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1);
   std::vector<double> Eh(2), lph(2);
   const int last = n_steps & (A.S - 1);
   HIPCHK(hipMemcpyAsync(c->out_host, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -867,7 +924,8 @@ extern "C" int nuts_chain_leapfrog_test(nuts_chain* c, const double* q, const do
   const int dir = eps >= 0 ? 1 : -1;
   int rc = draw_begin(c, q, p, nullptr, 0, std::fabs(eps), 1, true, dir);
   if (rc) return rc;
-  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, j, 0, MODE_SIMPLE, 1);
+  const Geometry gm{dir, 0, 0, 0, eps};
+  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1);
   const int last = (dir * n_steps) & (A.S - 1);
   HIPCHK(hipStreamSynchronize(s));
   if (q_out) HIPCHK(hipMemcpy(q_out, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost));

@@ -84,29 +84,33 @@ struct EvalIO {
   const double* q;   // MODE_PLAIN: position in
   double* grad;      // MODE_PLAIN: gradient out
   double* logp;      // MODE_PLAIN: logp out
+  // leaf modes: geometry of the current doubling.  The host learns (dir, edge) from the status record it
+  // reads after every doubling, so the kernels get them as arguments and never wait on the control block for
+  // an address; the only thing they read from it is the `aborted` flag.
+  int dir, edge;
+  int left, right;   // trajectory indices of the tree's current edge states (nuts.py:326)
+  double eps;        // signed step (nuts.py:348,357)
 };
 
 struct Leaf {
-  int dir, edge, src, t;
+  int dir, edge, src, t, left, right;
   int64_t so, d_o;
   double eps, half;
 };
 
 __device__ __forceinline__ int64_t slot_off(const ArenaDev& A, int t) { return (int64_t)(t & (A.S - 1)) * A.n; }
 
-// Resolve what this launch works on.  Returns false when the trajectory was already terminated
-// (the host enqueues a whole doubling ahead; the remaining launches drain as no-ops).
-__device__ __forceinline__ bool resolve_leaf(const EvalIO& io, const ArenaDev& A, int j, Leaf& lf, QView& qv) {
+// Resolve what this launch works on (no memory access: everything comes from the kernel arguments).
+__device__ __forceinline__ void resolve_leaf(const EvalIO& io, const ArenaDev& A, int j, Leaf& lf, QView& qv) {
   if (io.mode == MODE_PLAIN) {
     qv.q = io.q; qv.p = qv.g = qv.var = nullptr; qv.eps = qv.half = 0.0; qv.composed = 0;
-    return true;
+    lf.dir = 1; lf.edge = lf.src = lf.t = lf.left = lf.right = 0; lf.so = lf.d_o = 0; lf.eps = lf.half = 0.0;
+    return;
   }
-  const Ctl* c = A.ctl;
-  if (io.mode == MODE_TREE && c->aborted) return false;
-  lf.dir = c->dir; lf.edge = c->edge;
+  lf.dir = io.dir; lf.edge = io.edge; lf.left = io.left; lf.right = io.right;
   lf.src = lf.edge + lf.dir * j;
   lf.t = lf.src + lf.dir;
-  lf.eps = c->eps; lf.half = 0.5 * c->eps;
+  lf.eps = io.eps; lf.half = 0.5 * io.eps;
   lf.so = slot_off(A, lf.src); lf.d_o = slot_off(A, lf.t);
   if (io.explicit_pre) {
     qv.q = A.Q + lf.d_o; qv.p = qv.g = qv.var = nullptr; qv.eps = qv.half = 0.0; qv.composed = 0;
@@ -114,7 +118,12 @@ __device__ __forceinline__ bool resolve_leaf(const EvalIO& io, const ArenaDev& A
     qv.q = A.Q + lf.so; qv.p = A.P + lf.so; qv.g = A.G + lf.so; qv.var = A.var;
     qv.eps = lf.eps; qv.half = lf.half; qv.composed = 1;
   }
-  return true;
+}
+
+// The host enqueues a whole doubling ahead; once the trajectory has terminated the remaining launches drain
+// as no-ops.  The flag is loaded first and tested late, so the load overlaps the first data loads.
+__device__ __forceinline__ int load_aborted(const EvalIO& io, const ArenaDev& A) {
+  return io.mode == MODE_TREE ? __hip_atomic_load(&A.ctl->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 }
 
 __device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st) {
@@ -126,11 +135,10 @@ __device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st) {
 // ---------------------------------------------------------------------------
 // explicit first half of a leapfrog (only when the position cannot be composed on the fly)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(VEC_THREADS) void k_leaf_pre(ArenaDev A, int j, int mode) {
-  const Ctl* c = A.ctl;
-  if (mode == MODE_TREE && c->aborted) return;
-  const int src = c->edge + c->dir * j, dst = src + c->dir;
-  const double eps = c->eps, half = 0.5 * eps;
+__global__ __launch_bounds__(VEC_THREADS) void k_leaf_pre(ArenaDev A, EvalIO io, int j) {
+  if (load_aborted(io, A)) return;
+  const int src = io.edge + io.dir * j, dst = src + io.dir;
+  const double eps = io.eps, half = 0.5 * eps;
   const int64_t so = slot_off(A, src), d_o = slot_off(A, dst);
   const int base = blockIdx.x * VEC_THREADS * A.ept;
   for (int e = 0; e < A.ept; ++e) {
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_leaf_pre(ArenaDev A, int j, int
 template <int D, int RPL, int OCC>
 __global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(RowsDev R, ArenaDev A, EvalIO io, int j, int rev) {
   Leaf lf; QView qv;
-  if (!resolve_leaf(io, A, j, lf, qv)) return;
+  const int aborted = load_aborted(io, A);
+  resolve_leaf(io, A, j, lf, qv);
   const int lane = threadIdx.x & (WAVE - 1);
   // workgroups [0, nb_mixed) take the mixed spans (dispatched first, so they overlap the streaming workgroups)
   const int nb_mixed = (R.n_mixed + (ROWS_BLOCK / WAVE) - 1) / (ROWS_BLOCK / WAVE);
@@ -159,10 +168,10 @@ __global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(RowsDev R, ArenaDev A,
     // alternate the traversal direction between launches: the tail of the previous pass is still in the
     // 256 MiB Infinity Cache when the next pass starts from that end
     if (rev) wave = R.n_waves - 1 - wave;
-    rows_main<D, RPL>(R, qv, wave, lane);
+    rows_main<D, RPL>(R, qv, wave, lane, aborted);
   } else {
     const int mw = (int)blockIdx.x * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
-    if (mw < R.n_mixed) rows_mixed<D, RPL>(R, qv, mw, lane);
+    if (mw < R.n_mixed) rows_mixed<D, RPL>(R, qv, mw, lane, aborted);
   }
 }
 
@@ -172,7 +181,8 @@ __global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(RowsDev R, ArenaDev A,
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mvn_matvec(MvnDev mv, ArenaDev A, EvalIO io, int j) {
   Leaf lf; QView qv;
-  if (!resolve_leaf(io, A, j, lf, qv)) return;
+  if (load_aborted(io, A)) return;
+  resolve_leaf(io, A, j, lf, qv);
   const double* __restrict__ q = qv.q;
   const int lane = threadIdx.x & (WAVE - 1);
   const int row = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(256) void k_mvn_matvec(MvnDev mv, ArenaDev A, EvalI
 //   dd[DOT_TOP..+5]     the six dots of `extend`                  (nuts.py:380-390)
 // Reductions are done by the caller through `red`, a [NDOT][waves] LDS scratch.
 template <int E>
-__device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, const Ctl* c, int j, int d, bool tree,
+__device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int j, int d, bool tree,
                                           const int (&idx)[E], const bool (&act)[E], const double (&grad)[E],
                                           const double (&ph)[E], double* red, int nwaves, int& m_out, bool& last_out) {
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
@@ -247,17 +257,19 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, con
       for (int e = 0; e < E; ++e) {
         if (act[e]) {
           const int i = idx[e];
-          const double s1 = ps1[i], s2 = acc[e];
+          // all six operands are loaded unconditionally (valid slots at every level) so they are in flight together
+          const double s1 = ps1[i], v1l = A.V[o1l + i], p2l = A.P[o2l + i], v2l = A.V[o2l + i], p1r = A.P[o1r + i],
+                       v1r = A.V[o1r + i];
+          const double s2 = acc[e];
           const double rho = s1 + s2;                  // tree1.p_sum + tree2.p_sum
-          const double v1l = A.V[o1l + i];
           dd[0] = fma(rho, v1l, dd[0]);
           dd[1] = fma(rho, vt[e], dd[1]);
           if (l >= 1) {
-            const double rho1 = s1 + A.P[o2l + i];     // tree1.p_sum + tree2.left.p
+            const double rho1 = s1 + p2l;              // tree1.p_sum + tree2.left.p
             dd[2] = fma(rho1, v1l, dd[2]);
-            dd[3] = fma(rho1, A.V[o2l + i], dd[3]);
-            const double rho2 = A.P[o1r + i] + s2;     // tree1.right.p + tree2.p_sum
-            dd[4] = fma(rho2, A.V[o1r + i], dd[4]);
+            dd[3] = fma(rho1, v2l, dd[3]);
+            const double rho2 = p1r + s2;              // tree1.right.p + tree2.p_sum
+            dd[4] = fma(rho2, v1r, dd[4]);
             dd[5] = fma(rho2, vt[e], dd[5]);
           }
           acc[e] = rho;
@@ -277,8 +289,8 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, con
       // subtree complete: top-level merge of `extend` (nuts.py:346-390), speculative
       const int first = edge + dir;  // first leaf of the new subtree
       int lm_begin, lm_end, rm_begin, rm_end, new_left, new_right;
-      if (dir > 0) { lm_begin = c->left; lm_end = c->right; rm_begin = first; rm_end = t; new_left = c->left; new_right = t; }
-      else         { lm_begin = t; lm_end = first; rm_begin = c->left; rm_end = c->right; new_left = t; new_right = c->right; }
+      if (dir > 0) { lm_begin = lf.left; lm_end = lf.right; rm_begin = first; rm_end = t; new_left = lf.left; new_right = t; }
+      else         { lm_begin = t; lm_end = first; rm_begin = lf.left; rm_end = lf.right; new_left = t; new_right = lf.right; }
       const int64_t onl = slot_off(A, new_left), onr = slot_off(A, new_right);
       const int64_t olb = slot_off(A, lm_begin), ole = slot_off(A, lm_end), orb = slot_off(A, rm_begin), ore = slot_off(A, rm_end);
       double dd[6] = {0, 0, 0, 0, 0, 0};
@@ -316,6 +328,20 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, con
   m_out = m; last_out = last;
 }
 
+// sum_{s in [s0, s1)} base[s * stride], in index order, with up to 8 loads in flight at a time
+__device__ __forceinline__ double sum_strided(const double* base, int stride, int s0, int s1) {
+  double acc = 0.0;
+  for (int s = s0; s < s1; s += 8) {
+    double v[8];
+    // unconditional loads from a clamped index (a predicated load would sit in its own branch and serialise)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)min(s + u, s1 - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (s + u < s1) ? v[u] : 0.0;
+  }
+  return acc;
+}
+
 __device__ __forceinline__ bool dot_needed(int k, int m, bool last) {
   return (k == 0) || (k >= 1 && k < 1 + 6 * m) || (last && k >= DOT_TOP);
 }
@@ -326,7 +352,8 @@ __device__ __forceinline__ bool dot_needed(int k, int m, bool last) {
 template <int EPT>
 __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A, EvalIO io, int j, int d) {
   Leaf lf; QView qv;
-  if (!resolve_leaf(io, A, j, lf, qv)) return;
+  const int aborted = load_aborted(io, A);
+  resolve_leaf(io, A, j, lf, qv);
   constexpr int NW = VEC_THREADS / WAVE;
   __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
   __shared__ double s_bacc[MAX_BTERMS][VEC_THREADS];
@@ -337,8 +364,18 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   const int tid = threadIdx.x;
   const bool leaf = io.mode != MODE_PLAIN;
   const RowsDev& lg = md.lg;
-  const int base = blockIdx.x * VEC_THREADS * EPT;
-  double* part = md.part + (int64_t)blockIdx.x * md.part_stride;
+  // XCD affinity (speed only, never correctness): workgroup b is observed to run on XCD b % 8, each XCD has its own
+  // L2.  When the launch is 8x oversubscribed only every 8th workgroup works, so the whole O(n) state of the chain
+  // (arena slots, partials, control block) stays in ONE L2 and kernels B and C hit it instead of going to HBM.
+  if ((int)gridDim.x != md.nblk && (blockIdx.x & 7) != 0) return;
+  const int bid = (int)gridDim.x != md.nblk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int nb = md.nblk;
+  const int base = bid * VEC_THREADS * EPT;
+  double* part = md.part + (int64_t)bid * md.part_stride;
+  const bool tk = bid == nb / 2 && tid == 0;
+  TICK(md, tk, 0);
+  ProgRegs pregs;
+  prog_issue(md, pregs);
 
   // ---- everything whose address is known up front is loaded before the model tables are needed ----
   int idx[EPT];
@@ -349,25 +386,45 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     const int i = base + e * VEC_THREADS + tid;
     idx[e] = i; act[e] = false; grad[e] = 0.0; ph[e] = 0.0; qn[e] = 0.0;
     if (i >= md.n) continue;
-    // first half of the leapfrog for this element (integration.py:118-127); q' is stored for every element
+    // first half of the leapfrog for this element (integration.py:118-127)
     if (leaf) {
       if (io.explicit_pre) { ph[e] = A.P[lf.d_o + i]; qn[e] = A.Q[lf.d_o + i]; }
       else {
         ph[e] = fma(lf.half, A.G[lf.so + i], A.P[lf.so + i]);
         qn[e] = fma(lf.eps, A.var[i] * ph[e], A.Q[lf.so + i]);
-        A.Q[lf.d_o + i] = qn[e];
       }
     } else qn[e] = io.q[i];
+  }
+  // the logit node's z elements: segment ranges (static tables) and the group's sigma, loaded up front
+  int za0[EPT], za1[EPT], zb0[EPT], zb1[EPT];
+  double zsig[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    za0[e] = za1[e] = zb0[e] = zb1[e] = 0; zsig[e] = 0.0;
+    const int zi = idx[e] - lg.off_z;
+    if (md.has_logit && zi >= 0 && zi < lg.G * lg.D) {
+      const int g = zi / lg.D, dd = zi - g * lg.D;
+      za0[e] = lg.gseg_ptr[g]; za1[e] = lg.gseg_ptr[g + 1]; zb0[e] = lg.gmix_ptr[g]; zb1[e] = lg.gmix_ptr[g + 1];
+      zsig[e] = qv.at(lg.off_sigma + dd);
+    }
+  }
+  TICK(md, tk, 1);
+  const Prog pg = load_prog(md, s_prog, pregs);   // -> LDS, ends with a barrier
+  TICK(md, tk, 2);
+  if (aborted) return;
+  TICK(md, tk, 3);
+  if (leaf && !io.explicit_pre) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) if (idx[e] < md.n) A.Q[lf.d_o + idx[e]] = qn[e];   // q' is stored for every element
   }
   // a slice of the row-pass log-likelihood partials rides along with this workgroup's logp partial
   double lp = 0.0;
   if (md.has_logit) {
     const int nlp = lg.n_waves + lg.n_mixed;
-    for (int w = blockIdx.x * VEC_THREADS + tid; w < nlp; w += gridDim.x * VEC_THREADS) lp += lg.wave_lp[w];
+    for (int w = bid * VEC_THREADS + tid; w < nlp; w += nb * VEC_THREADS) lp += lg.wave_lp[w];
   }
-  if (md.has_mvn) for (int r = blockIdx.x * VEC_THREADS + tid; r < md.mv.k; r += gridDim.x * VEC_THREADS) lp -= 0.5 * md.mv.rowq[r];
+  if (md.has_mvn) for (int r = bid * VEC_THREADS + tid; r < md.mv.k; r += nb * VEC_THREADS) lp -= 0.5 * md.mv.rowq[r];
 
-  const Prog pg = load_prog(md, s_prog);
   for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
   double db_acc = 0.0, dbz_acc = 0.0;
 
@@ -375,23 +432,30 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   for (int e = 0; e < EPT; ++e) {
     const int i = idx[e];
     if (i >= md.n) continue;
-    const int k = find_var(pg, i);
+    const bool is_z = md.has_logit && i >= lg.off_z && i < lg.off_z + lg.G * lg.D;
+    const int k = is_z ? lg.var_z : find_var(pg, i);
     const VarDev v = pg.vars[k];
     if (v.deferred) continue;  // finished by the control kernel
-    double x, dxdq, lj, dj;
-    transform_full(v, qn[e], x, dxdq, lj, dj);
-    double gx = 0.0;
-    lp += lj;
-    gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
-    double gd = 0.0;
-    if (md.has_logit && k == lg.var_z) {
-      const int zi = i - lg.off_z, g = zi / lg.D, dd = zi - g * lg.D;
-      const int a0 = lg.gseg_ptr[g], a1 = lg.gseg_ptr[g + 1], b0 = lg.gmix_ptr[g], b1 = lg.gmix_ptr[g + 1];
-      double sgd = qv.at(lg.off_sigma + dd);
-      double db = 0.0;
-      for (int s = a0; s < a1; ++s) db += lg.seg_part[(int64_t)s * lg.D + dd];
-      for (int s = b0; s < b1; ++s) db += lg.mixed_part[(int64_t)s * lg.D + dd];
-      sgd = lg.sigma_tr == NUTS_TR_LOG ? exp(sgd) : sgd;
+    double gd = 0.0, db = 0.0;
+    if (is_z) {
+      // fixed-order sum of the group's segment partials; the loads of a batch are issued together
+      const int dd = (i - lg.off_z) % lg.D;
+      db = sum_strided(lg.seg_part + dd, lg.D, za0[e], za1[e]);
+      db += sum_strided(lg.mixed_part + dd, lg.D, zb0[e], zb1[e]);
+    }
+    double x, dxdq, lj, dj, gx = 0.0;
+    if (v.normal_prior) {
+      x = qn[e]; dxdq = 1.0; dj = 0.0;
+      const double r = x - v.np_mu;
+      gx = -r * v.np_inv_var;
+      lp += -0.5 * r * r * v.np_inv_var - v.np_lognorm;
+    } else {
+      transform_full(v, qn[e], x, dxdq, lj, dj);
+      lp += lj;
+      gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+    }
+    if (is_z) {
+      const double sgd = lg.sigma_tr == NUTS_TR_LOG ? exp(zsig[e]) : zsig[e];
       gd = sgd * db;
       db_acc += db;            // (e*VEC_THREADS) % D == 0: every e of this thread has the same d
       dbz_acc += db * x;
@@ -403,12 +467,13 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     else io.grad[i] = grad[e];
   }
 
+  TICK(md, tk, 4);
   // factors without an owning variable (only scalars and data): grid-stride over their elements
   for (int o = 0; o < md.n_orphans; ++o) {
     const int fi = md.orphans[o];
     const nuts_factor& f = pg.factors[fi];
     const FactorBT& bt = pg.fbt[fi];
-    for (int li = blockIdx.x * VEC_THREADS + tid; li < f.size; li += gridDim.x * VEC_THREADS) {
+    for (int li = bid * VEC_THREADS + tid; li < f.size; li += nb * VEC_THREADS) {
       double dv[4], bv[4], cv[4];
       lp += factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv);
       for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm][tid] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
@@ -417,7 +482,9 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
 
   // ---- second half kick + tree-merge dot products (wave partials land in s_red) ----
   int m = 0; bool last = false;
-  if (leaf) leaf_post<EPT>(A, lf, A.ctl, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last);
+  TICK(md, tk, 5);
+  if (leaf) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last);
+  TICK(md, tk, 6);
 
   // ---- per-workgroup partials: logp, broadcast terms, hyper-parameter sums of the logit node, dots ----
   {
@@ -459,6 +526,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
       part[PART_DOT + k] = r;
     }
   }
+  TICK(md, tk, 7);
 }
 
 // ---------------------------------------------------------------------------
@@ -478,10 +546,7 @@ __device__ __forceinline__ void ctl_next_direction(Ctl* c, const double* uniform
 __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
                                                         int max_depth, HostStatus* st) {
   Leaf lf; QView qv;
-  if (!resolve_leaf(io, A, j, lf, qv)) {
-    if (threadIdx.x == 0 && st) publish_status(A.ctl, st);
-    return;
-  }
+  resolve_leaf(io, A, j, lf, qv);
   constexpr int NW = VEC_THREADS / WAVE;
   __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
   __shared__ double s_sum[PART_STRIDE];
@@ -501,33 +566,54 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
     while (((j >> m) & 1) && m < d) ++m;
     last = (j + 1 == (1 << d));
   }
-  // ---- fixed-order sums of the per-workgroup partials: (value, chunk) pairs in parallel, then the chunks in order ----
+  const bool tk = tid == 0;
+  TICK(md, tk, 16);
+  ProgRegs pregs;
+  prog_issue(md, pregs);
+  // control block -> LDS (first thing: everything else overlaps this round trip)
+  if (leaf && tid < (int)(sizeof(Ctl) / sizeof(int))) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(A.ctl)[tid];
+  // ---- fixed-order sums of the per-workgroup partials this leaf needs: (slot, chunk) pairs in parallel ----
+  const int nbt = md.n_bterms, nlg = md.has_logit ? lg.D : 0;
+  const int nn = 1 + nbt + 2 * nlg + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
+  auto need_slot = [&](int q) {
+    if (q < 1) return PART_LP;
+    q -= 1;
+    if (q < nbt) return PART_BT + q;
+    q -= nbt;
+    if (q < nlg) return PART_DMU + q;
+    q -= nlg;
+    if (q < nlg) return PART_DSG + q;
+    q -= nlg;
+    if (q < 1 + 6 * m) return PART_DOT + q;
+    return PART_DOT + DOT_TOP + (q - 1 - 6 * m);
+  };
   {
     const int per = (md.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
-    for (int t = tid; t < md.part_stride * CTL_CHUNKS; t += VEC_THREADS) {
-      const int k = t % md.part_stride, c = t / md.part_stride;
-      bool need = k < PART_DOT;
-      if (k >= PART_DOT) need = leaf && dot_needed(k - PART_DOT, m, last);
-      double s = 0.0;
-      if (need) {
-        const int b1 = min(md.nblk, (c + 1) * per);
-        for (int b = c * per; b < b1; ++b) s += md.part[(int64_t)b * md.part_stride + k];
-      }
-      s_chunk[c][k] = s;
+    for (int t = tid; t < nn * CTL_CHUNKS; t += VEC_THREADS) {
+      const int c = t % CTL_CHUNKS, k = need_slot(t / CTL_CHUNKS);
+      const int b0 = c * per, b1 = min(md.nblk, (c + 1) * per);
+      s_chunk[c][k] = sum_strided(md.part + k, md.part_stride, b0, b1);
     }
   }
-  if (leaf && tid < (int)(sizeof(Ctl) / sizeof(int))) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(A.ctl)[tid];
-  const Prog pg = load_prog(md, s_prog);   // ends with a barrier (when the program fits in LDS)
+  TICK(md, tk, 17);
+  const Prog pg = load_prog(md, s_prog, pregs);   // ends with a barrier (when the program fits in LDS)
   for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
   __syncthreads();
-  for (int k = tid; k < md.part_stride; k += VEC_THREADS) {
-    double s = 0.0;
+  TICK(md, tk, 18);
+  if (tree && s_ctl.aborted) {   // terminated earlier in this doubling: drain
+    if (tid == 0 && st) publish_status(&s_ctl, st);
+    return;
+  }
+  for (int t = tid; t < nn; t += VEC_THREADS) {
+    const int k = need_slot(t);
+    double sacc = 0.0;
 #pragma unroll
-    for (int c = 0; c < CTL_CHUNKS; ++c) s += s_chunk[c][k];
-    s_sum[k] = s;
+    for (int c = 0; c < CTL_CHUNKS; ++c) sacc += s_chunk[c][k];
+    s_sum[k] = sacc;
   }
   __syncthreads();
 
+  TICK(md, tk, 19);
   // ---- deferred elements: one thread each ----
   int idx[1] = {0};
   bool act[1] = {false};
@@ -554,6 +640,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
       else if (k == lg.var_sigma) gx += s_sum[PART_DSG + (i - lg.off_sigma)];
     }
   }
+  TICK(md, tk, 20);
   // broadcast terms: the share of the ordinary elements (kernel B) + the share of deferred vector elements (here)
   if (md.n_bterms > 0) {
     __syncthreads();
@@ -568,8 +655,10 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
     if (leaf) A.G[lf.d_o + idx[0]] = grad[0];
     else io.grad[idx[0]] = grad[0];
   }
+  TICK(md, tk, 21);
   int m2 = 0; bool last2 = false;
-  if (leaf) leaf_post<1>(A, lf, &s_ctl, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2);
+  if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2);
+  TICK(md, tk, 22);
   const double lp_def = block_sum<true>(lp, s_w);   // barriers inside also publish s_red
   double logp = s_sum[PART_LP] + lp_def;
   if (md.has_mvn) logp += md.mv.konst;
@@ -585,6 +674,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
     s_sum[PART_DOT + q] += r;
   }
   __syncthreads();
+  TICK(md, tk, 23);
   if (tid != 0) return;
   const double* dot = &s_sum[PART_DOT];
   const int t = lf.t, ts = t & (A.S - 1);
@@ -640,8 +730,10 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
       else if (c->depth < max_depth) ctl_next_direction(c, A.uniforms);
     }
   }
+  TICK(md, tk, 24);
   *A.ctl = *c;
   if (st) publish_status(c, st);
+  TICK(md, tk, 25);
 }
 
 // ---------------------------------------------------------------------------

@@ -22,16 +22,26 @@
 #define MAX_DEFERRED 256    // deferred elements per model (one control-kernel thread each)
 #define LOGIT_MAXD 8
 
-struct VarDev {  // same layout as nuts_var; `pad` carries the deferred flag
+struct VarDev {  // nuts_var + what the spec compiler derived
   int32_t offset, size, transform, deferred;
   double lower, upper;
+  // peephole: an untransformed variable whose only factor is its own Normal(mu, sigma) prior with constant
+  // parameters (the non-centred `z ~ N(0, 1)` block of a hierarchical model) is evaluated in closed form:
+  // logp_i = -(x - mu)^2 / (2 sigma^2) - np_lognorm ;  d/dx = -(x - mu) / sigma^2
+  int32_t normal_prior, pad;
+  double np_mu, np_inv_var, np_lognorm;
 };
 
 struct Contrib {  // "variable k is operand `slot` (0=a,1=b,2=c) of argument `arg` of factor f"
   int32_t f;
   int16_t arg, slot;
   int32_t owner;  // 1: this contribution also accounts for the factor's logp and broadcast terms
-  int32_t pad;
+  // pre-decoded form of the common case "the variable itself is argument `arg`, every other argument is a
+  // constant" (priors with fixed parameters): the interpreter evaluates it without touching the factor table
+  int32_t fast;
+  int32_t dist, pad;
+  double konst;
+  double p[4];
 };
 
 struct FactorBT {  // broadcast (size-1 variable) operands of a factor whose size is > 1
@@ -93,7 +103,19 @@ struct ModelDev {
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
   const char* prog;
   int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_pad;
+  long long* ticks;           // [64] phase timestamps of the last B / C launch (only written in -DNUTS_KTIMING builds)
 };
+
+#ifdef NUTS_KTIMING
+__device__ __forceinline__ long long tick_now() {   // drains outstanding memory ops first: true phase boundaries
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return (long long)t;
+}
+#define TICK(md, cond, slot) do { if (cond) (md).ticks[slot] = tick_now(); } while (0)
+#else
+#define TICK(md, cond, slot) do { } while (0)
+#endif
 
 #define PROG_LDS_MAX 12288
 
@@ -110,13 +132,24 @@ struct Prog {
   int n_vars;
 };
 
-// Cooperative copy of the program blob into LDS (all threads of the workgroup; ends with a barrier).
-__device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog) {
+// Cooperative copy of the program blob into LDS (all threads of a 256-thread workgroup; ends with a barrier).
+// Split in two so that the global loads are in flight together with the caller's own first loads.
+struct ProgRegs { uint4 r[PROG_LDS_MAX / 16 / 256]; };
+__device__ __forceinline__ void prog_issue(const ModelDev& md, ProgRegs& pr) {
+  const int n16 = (md.prog_bytes + 15) >> 4;
+#pragma unroll
+  for (int u = 0; u < PROG_LDS_MAX / 16 / 256; ++u)   // unconditional loads from a clamped index
+    pr.r[u] = reinterpret_cast<const uint4*>(md.prog)[min((int)threadIdx.x + u * 256, n16 - 1)];
+}
+__device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog, const ProgRegs& pr) {
   const char* base = md.prog;
   if (md.prog_bytes <= PROG_LDS_MAX) {
     const int n16 = (md.prog_bytes + 15) >> 4;
-    for (int i = threadIdx.x; i < n16; i += blockDim.x)
-      reinterpret_cast<uint4*>(s_prog)[i] = reinterpret_cast<const uint4*>(md.prog)[i];
+#pragma unroll
+    for (int u = 0; u < PROG_LDS_MAX / 16 / 256; ++u) {
+      const int i = threadIdx.x + u * 256;
+      if (i < n16) reinterpret_cast<uint4*>(s_prog)[i] = pr.r[u];
+    }
     __syncthreads();
     base = s_prog;
   }
@@ -205,7 +238,9 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 }
 
 // log-density of one element and its partials w.r.t. each argument.
-__device__ __forceinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
+// (not inlined: one copy of the 11-way switch and its libm expansions per kernel keeps kernels B and C small
+// enough for the instruction cache -- they are launched once per leapfrog between two passes of kernel A)
+__device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
   const double NINF = -INFINITY;
   const double LOG_SQRT_2PI = 0.91893853320467274178;
   const double LOG_SQRT_2_OVER_PI = -0.22579135264472743236;
@@ -330,6 +365,14 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
                                                double* s_bacc, int bstride) {
   for (int c = pg.var_cptr[k]; c < pg.var_cptr[k + 1]; ++c) {
     const Contrib cb = pg.contrib[c];
+    if (cb.fast) {
+      double a[4] = {cb.p[0], cb.p[1], cb.p[2], cb.p[3]}, d[4];
+      a[0] = cb.arg == 0 ? x : a[0]; a[1] = cb.arg == 1 ? x : a[1]; a[2] = cb.arg == 2 ? x : a[2]; a[3] = cb.arg == 3 ? x : a[3];
+      const double lpf = dist_eval(cb.dist, cb.konst, a, d);
+      gx += cb.arg == 0 ? d[0] : (cb.arg == 1 ? d[1] : (cb.arg == 2 ? d[2] : d[3]));
+      if (cb.owner) lp += lpf;
+      continue;
+    }
     const nuts_factor& f = pg.factors[cb.f];
     double d[4], bv[4], cv[4];
     const double lpf = factor_eval(pg, qv, f, li, k, x, d, bv, cv);

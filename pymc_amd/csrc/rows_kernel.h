@@ -91,13 +91,14 @@ __device__ __forceinline__ void rows_beta(const RowsDev& R, const QView& qv, int
 // (spans containing a group boundary or padding rows are listed on the host and handled by rows_mixed below,
 // by extra workgroups of the same launch: the streaming loop carries no rare-path state)
 template <int D, int RPL>
-__device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int wave, int lane) {
+__device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int wave, int lane, int aborted) {
   const int64_t s0 = (int64_t)wave * R.n_spans / R.n_waves;
   const int64_t s1 = (int64_t)(wave + 1) * R.n_spans / R.n_waves;
   int seg = R.seg_base[wave];
   int g_cur = -1;
   double m_lane, s_lane;
   rows_hyper<D>(R, qv, lane, m_lane, s_lane);
+  if (aborted) return;   // tested after the hyper-parameter loads were issued: the flag's round trip is hidden
   double beta[D], acc[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) { acc[d] = 0.0; beta[d] = 0.0; }
@@ -132,7 +133,7 @@ __device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int
 
 // ---- one mixed span per wave: a masked pass per group present in the span ----
 template <int D, int RPL>
-__device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, int mw, int lane) {
+__device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, int mw, int lane, int aborted) {
   constexpr int SPAN = WAVE * RPL;
   const int64_t sp = R.mixed_span[mw];
   int seg = R.mixed_seg_base[mw];
@@ -144,6 +145,7 @@ __device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, in
   int g = __builtin_amdgcn_readfirstlane(R.mixed_g0[mw]);  // group of the span's first row
   double m_lane, s_lane;
   rows_hyper<D>(R, qv, lane, m_lane, s_lane);
+  if (aborted) return;
   double lp = 0.0;
   while (true) {
     double beta[D], acc[D];
