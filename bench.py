@@ -13,10 +13,14 @@ value = aggregate effective samples/s = sum over chains of min-over-parameters
 bulk-ESS of the K timed draws / max-over-ranks wall time.  leapfrog steps/s
 (= sum tree_size / time) is reported next to it.
 
-roofline: dominant kernel = k_logit_rows; algorithmic bytes per launch =
-69 B/row x N (SURVEY.md 8d B_model), divided by the kernel's average duration
-measured with HIP events on the library stream during the timed region
-(1 launch in 8 is bracketed by events).
+roofline: dominant kernel = k_rows (csrc/rows_kernel.h); algorithmic bytes per
+launch = 69 B/row x N (SURVEY.md 8d B_model), divided by the kernel's average
+duration measured with HIP events on the library stream during the timed region
+(1 launch in 8 is bracketed by events; launches that drain after the tree
+terminated are included, exactly as in the rocprofv3 summary under profiles/).
+`traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
+(profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+MI355X_MICROARCH.md), not collected inside this run.
 
 cpu_baseline (rank 0, N=1 only): the oracle's reference-order leapfrog with the
 single-threaded C restatement of the logp+grad (stand-in for PyTensor's C linker,
@@ -42,12 +46,12 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--rows-per-group", type=int, default=4000, help="4000 = C2-L (HBM regime), 80 = C2-S (cache resident)")
     ap.add_argument("--groups", type=int, default=1248)
     ap.add_argument("--seed", type=int, default=20160911)
-    ap.add_argument("--cpu-leapfrogs", type=int, default=30, help="bounded CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-leapfrogs", type=int, default=150, help="bounded CPU-baseline sample, about 18 s of one host core (0 disables)")
     ap.add_argument("--ess-params", type=int, default=1500, help="parameters sampled for the min-ESS (all of mu/sigma + random z)")
     return ap.parse_args()
 
@@ -163,6 +167,11 @@ def main():
         ess_total = float(allv[:, 1].sum())
         leap_total = float(allv[:, 2].sum())
         dom_avg_ms = float(allv[:, 3].sum() / max(allv[:, 4].sum(), 1))
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj) and args.rows_per_group == 4000 and args.groups == 1248:
+            tr = json.load(open(tj))
+            traffic, traffic_src = tr["k_rows_bytes_per_launch"], tr["source"]
         achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
         out = {
             "metric": "effective samples/sec (and leapfrog steps/sec), 10k-param hierarchical logistic regression, one NUTS chain per GPU",
@@ -189,7 +198,7 @@ def main():
             "mean_tree_size": leap_total / (K * world),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_logit_rows<8>",
+                "kernel": "k_rows<8,2,4> (hierarchical-logit row pass)",
                 "achieved": achieved,
                 "peak": 8000.0,
                 "unit": "GB/s",
@@ -198,7 +207,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": dom_avg_ms,
                 "launches_timed": int(allv[:, 4].sum()),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
             },
         }
         if world == 1 and args.cpu_leapfrogs > 0:

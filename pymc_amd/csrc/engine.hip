@@ -202,6 +202,8 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
             }
           }
           cb.fast = fast ? 1 : 0; cb.dist = f.dist; cb.konst = f.konst;
+          if (fast && a == 0 && f.dist == NUTS_D_NORMAL && cb.p[2] > 0) { cb.fast = 2; const double sg = cb.p[2]; cb.p[2] = 1.0 / sg; cb.p[3] = std::log(sg); }
+          if (fast && a == 0 && f.dist == NUTS_D_HALFNORMAL && cb.p[1] > 0) { cb.fast = 2; const double sg = cb.p[1]; cb.p[2] = 1.0 / sg; cb.p[3] = std::log(sg); }
           per_var[o.ref].push_back(cb);
           owned_already = true;
         } else if (v.size == 1) {
@@ -224,11 +226,11 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   for (int k = 0; k < nv; ++k) {
     if (vars[k].transform != NUTS_TR_NONE || vars[k].deferred || per_var[k].size() != 1) continue;
     const Contrib& cb = per_var[k][0];
-    if (!cb.fast || !cb.owner || cb.dist != NUTS_D_NORMAL || cb.arg != 0 || !(cb.p[2] > 0)) continue;
+    if (cb.fast != 2 || !cb.owner || cb.dist != NUTS_D_NORMAL || cb.arg != 0) continue;
     vars[k].normal_prior = 1;
     vars[k].np_mu = cb.p[1];
-    vars[k].np_inv_var = 1.0 / (cb.p[2] * cb.p[2]);
-    vars[k].np_lognorm = 0.91893853320467274178 + std::log(cb.p[2]);
+    vars[k].np_inv_var = cb.p[2] * cb.p[2];                       // p[2] = 1/sigma, p[3] = log sigma
+    vars[k].np_lognorm = 0.91893853320467274178 + cb.p[3];
   }
   std::vector<int32_t> cptr(nv + 1, 0);
   std::vector<Contrib> contrib;
@@ -237,13 +239,12 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     contrib.insert(contrib.end(), per_var[k].begin(), per_var[k].end());
   }
   cptr[nv] = (int32_t)contrib.size();
-  std::vector<int32_t> deferred;
+  std::vector<int32_t> deferred;   // (element, variable) pairs
   for (int k = 0; k < nv; ++k)
-    if (vars[k].deferred) for (int i = 0; i < vars[k].size; ++i) deferred.push_back(vars[k].offset + i);
-  if ((int)deferred.size() > MAX_DEFERRED) { g_err = "too many scalar / hyper-parameter elements (MAX_DEFERRED)"; return false; }
-  md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size();
+    if (vars[k].deferred) for (int i = 0; i < vars[k].size; ++i) { deferred.push_back(vars[k].offset + i); deferred.push_back(k); }
+  if ((int)deferred.size() / 2 > MAX_DEFERRED) { g_err = "too many scalar / hyper-parameter elements (MAX_DEFERRED)"; return false; }
+  md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size() / 2;
   md.orphans = m->keep(dev_upload(orphans.data(), orphans.size()));
-  md.deferred = m->keep(dev_upload(deferred.data(), deferred.size()));
   // pack the interpreter's tables into one blob (copied into LDS by kernels B and C)
   std::vector<char> blob;
   auto put = [&](const void* src, size_t bytes) {
@@ -259,6 +260,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.po_fbt = put(fbt.data(), (size_t)nf * sizeof(FactorBT));
   md.po_btvar = put(bterm_var.data(), bterm_var.size() * sizeof(int32_t));
   md.po_data = put(s->data, (size_t)s->n_data * sizeof(nuts_data_ref));
+  md.po_deferred = put(deferred.data(), deferred.size() * sizeof(int32_t));
   blob.resize((blob.size() + 15) & ~(size_t)15, 0);
   md.prog_bytes = (int32_t)blob.size();
   md.prog = m->keep(dev_upload(blob.data(), blob.size()));
@@ -310,7 +312,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     m->rows_rpl = env_int("NUTS_ROWS_RPL", 2) == 4 ? 4 : 2;
     m->rows_alternate = env_int("NUTS_ROWS_ALTERNATE", 1) ? 1 : 0;
     m->rows_occ = env_int("NUTS_ROWS_OCC", 4);
-    const int wpc = std::max(1, env_int("NUTS_ROWS_WAVES_PER_CU", 16));
+    const int wpc = std::max(1, env_int("NUTS_ROWS_WAVES_PER_CU", 16));  // 4 waves/SIMD resident (117 VGPRs): one full set
     const int SPAN = WAVE * m->rows_rpl;
     lg.N = s->rows_N; lg.D = D; lg.G = s->rows_G;
     lg.Npad = (lg.N + SPAN - 1) / SPAN * SPAN;
@@ -365,14 +367,24 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     }
     lg.n_mixed = (int32_t)mixed_span.size();
     lg.n_mixed_seg = (int32_t)mixed_seg_gid.size();
-    std::vector<int32_t> seg_base(lg.n_waves, 0), seg_gid;
+    std::vector<int32_t> run_ptr(lg.n_waves + 1, 0), seg_gid;
+    std::vector<int4> runs;
     for (int w = 0; w < lg.n_waves; ++w) {
       const int64_t s0 = (int64_t)w * lg.n_spans / lg.n_waves, s1 = (int64_t)(w + 1) * lg.n_spans / lg.n_waves;
-      seg_base[w] = (int32_t)seg_gid.size();
-      int prev = -1;
-      for (int64_t sp = s0; sp < s1; ++sp)
-        if (span_gid[sp] >= 0 && span_gid[sp] != prev) { prev = span_gid[sp]; seg_gid.push_back(prev); }
+      run_ptr[w] = (int32_t)runs.size();
+      for (int64_t sp = s0; sp < s1; ++sp) {
+        if (span_gid[sp] < 0) continue;
+        // runs of the same group inside one wave share a segment even when a mixed span sits between them
+        if (!runs.empty() && (int)runs.size() > run_ptr[w] && runs.back().z == span_gid[sp] && runs.back().x + runs.back().y == sp) {
+          runs.back().y++;
+          continue;
+        }
+        int4 r; r.x = (int)sp; r.y = 1; r.z = span_gid[sp]; r.w = (int)seg_gid.size();
+        runs.push_back(r);
+        seg_gid.push_back(span_gid[sp]);
+      }
     }
+    run_ptr[lg.n_waves] = (int32_t)runs.size();
     lg.n_seg = (int32_t)seg_gid.size();
     auto group_ptr = [&](const std::vector<int32_t>& sg) {
       std::vector<int32_t> p(lg.G + 1, 0);
@@ -382,8 +394,8 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     };
     // segments are emitted in row order and rows are sorted by group => the segments of a group are contiguous
     const std::vector<int32_t> gsp = group_ptr(seg_gid), gmp = group_ptr(mixed_seg_gid);
-    lg.span_gid = m->keep(dev_upload(span_gid.data(), span_gid.size()));
-    lg.seg_base = m->keep(dev_upload(seg_base.data(), seg_base.size()));
+    lg.run_ptr = m->keep(dev_upload(run_ptr.data(), run_ptr.size()));
+    lg.runs = m->keep(dev_upload(runs.data(), runs.size()));
     lg.gseg_ptr = m->keep(dev_upload(gsp.data(), gsp.size()));
     lg.seg_part = m->keep(dev_alloc<double>((size_t)lg.n_seg * D));
     lg.mixed_span = m->keep(dev_upload(mixed_span.data(), mixed_span.size()));
@@ -624,14 +636,15 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->wb_mean = c->keep(dev_alloc<double>(n)); c->wb_m2 = c->keep(dev_alloc<double>(n));
   A.var = c->var; A.inv_stds = c->inv_stds;
   c->n_uni_cap = (1 << maxd) + 2 * maxd + 16;
-  c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + c->n_uni_cap));
+  c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + 2 * (size_t)c->n_uni_cap));
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
   c->st_dev = c->keep(dev_alloc<HostStatus>(1));
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
+  A.log_uniforms = A.uniforms + c->n_uni_cap;
   for (void* p : c->owned)
     if (!p) { g_err = "device allocation failed (trajectory arena needs 4*2^max_treedepth*n*8 bytes)"; nuts_chain_destroy(c); return nullptr; }
-  if (hipHostMalloc((void**)&c->stage_host, (2 * (size_t)n + c->n_uni_cap) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+  if (hipHostMalloc((void**)&c->stage_host, (2 * (size_t)n + 2 * (size_t)c->n_uni_cap) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&c->out_host, 2 * (size_t)n * sizeof(double), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&c->st_host, sizeof(HostStatus), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&c->do_host, sizeof(DrawOut), hipHostMallocDefault) != hipSuccess) {
@@ -712,8 +725,17 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
   const int nu = std::min(n_uniforms, c->n_uni_cap);
   std::memcpy(c->stage_host, q0, n * sizeof(double));
   std::memcpy(c->stage_host + n, normals, n * sizeof(double));
-  if (nu > 0) std::memcpy(c->stage_host + 2 * n, uniforms, nu * sizeof(double));
-  HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + nu) * sizeof(double), hipMemcpyHostToDevice, s));
+  if (nu > 0) {
+    // the uniforms and, right behind them (at a fixed offset), their logarithms: `np.log(rng.random())` is what the
+    // tree compares (nuts.py:371,466); taking the log on the host keeps a long scalar chain off the control kernel
+    double* u = c->stage_host + 2 * n;
+    double* lu = u + c->n_uni_cap;
+    std::memcpy(u, uniforms, nu * sizeof(double));
+    for (int i = 0; i < nu; ++i) lu[i] = std::log(u[i]);
+    HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + c->n_uni_cap + nu) * sizeof(double), hipMemcpyHostToDevice, s));
+  } else {
+    HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  }
   HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
   model_enqueue_plain(c->m, A.Q, A.G, A.LOGP);
   hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, c->stage_dev + n,
@@ -768,7 +790,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   const int need_uni = (1 << max_depth) + max_depth + 1;
   if (n_uniforms < need_uni) { g_err = "not enough uniforms for the worst-case tree"; return NUTS_E_ARG; }
 
-  int rc = draw_begin(c, q0, normals, uniforms, n_uniforms, step_size, max_depth, false, 0);
+  int rc = draw_begin(c, q0, normals, uniforms, need_uni, step_size, max_depth, false, 0);
   if (rc) return rc;
   bool exhausted = true;
   int64_t evals = 1;

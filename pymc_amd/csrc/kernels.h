@@ -71,7 +71,8 @@ struct ArenaDev {
   double *PSUM;            // [n] whole-tree p_sum (nuts.py:330)
   const double *var, *inv_stds;  // diagonal potential (quadpotential.py:308-326)
   Ctl* ctl;
-  const double* uniforms;
+  const double* uniforms;   // pre-drawn `step.rng.random()` values
+  const double* log_uniforms;  // their logarithms, taken on the host (the tree compares log(u), nuts.py:371,466)
 };
 
 struct HostStatus {
@@ -622,8 +623,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   int k = -1;
   const bool mine = tid < md.n_deferred;
   if (mine) {
-    const int i = md.deferred[tid];
-    k = find_var(pg, i);
+    const int i = pg.deferred[2 * tid];
+    k = pg.deferred[2 * tid + 1];
     const VarDev v = pg.vars[k];
     idx[0] = i;
     double qn;
@@ -707,8 +708,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
         if (!turning) turning = (dd[4] <= 0) || (dd[5] <= 0);
       }
       const double ls = logaddexp_d(c->st_ls[l], cur_ls);                   // nuts.py:464
-      const double u = A.uniforms[c->cursor++];
-      if (log(u) < cur_ls - ls) { /* keep tree2's proposal */ } else cur_prop = c->st_prop[l];
+      const double logu = A.log_uniforms[c->cursor++];
+      if (logu < cur_ls - ls) { /* keep tree2's proposal */ } else cur_prop = c->st_prop[l];
       cur_ls = ls;
     }
     if (turning) {
@@ -719,8 +720,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
       // extend (nuts.py:365-392)
       if (dir > 0) c->right = t; else c->left = t;
       c->depth += 1;
-      const double u = A.uniforms[c->cursor++];
-      if (log(u) < cur_ls - c->log_size) c->proposal = cur_prop;
+      const double logu = A.log_uniforms[c->cursor++];
+      if (logu < cur_ls - c->log_size) c->proposal = cur_prop;
       c->log_size = logaddexp_d(cur_ls, c->log_size);
       const double* dd = &dot[DOT_TOP];
       bool turn = (dd[0] <= 0) || (dd[1] <= 0);

@@ -38,7 +38,7 @@ struct Contrib {  // "variable k is operand `slot` (0=a,1=b,2=c) of argument `ar
   int32_t owner;  // 1: this contribution also accounts for the factor's logp and broadcast terms
   // pre-decoded form of the common case "the variable itself is argument `arg`, every other argument is a
   // constant" (priors with fixed parameters): the interpreter evaluates it without touching the factor table
-  int32_t fast;
+  int32_t fast;   // 0 general; 1 constants folded (p[]); 2 = 1 + Normal / HalfNormal closed form (p[2] = 1/sigma, p[3] = log sigma)
   int32_t dist, pad;
   double konst;
   double p[4];
@@ -59,8 +59,8 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   int32_t var_mu, var_sigma, var_z, pad;
   int64_t n_spans;         // Npad / span
   int32_t n_waves, n_seg;  // waves in the row-streaming launch; total (wave, group) segments
-  const int32_t* span_gid; // [n_spans] group of a span that lies entirely inside one group, -1 for a "mixed" span
-  const int32_t* seg_base; // [n_waves] first segment slot of each main wave
+  const int32_t* run_ptr;  // [n_waves+1] runs of main wave w = [run_ptr[w], run_ptr[w+1])
+  const int4* runs;        // {first span, number of spans, group, segment slot}: consecutive spans lying entirely inside one group
   const int32_t* gseg_ptr; // [G+1] main segments of group g = [gseg_ptr[g], gseg_ptr[g+1])
   double* seg_part;        // [n_seg][D]  d logp / d beta_g partial of each (wave, group) run
   // mixed spans (contain a group boundary or padding rows): one wave each, extra workgroups of the same launch
@@ -94,7 +94,6 @@ struct ModelDev {
   int32_t n_bterms, n_orphans, n_deferred, nblk;
   const double* pool;         // data vectors of the spec
   const int32_t* orphans;     // [n_orphans] factors without an owning variable
-  const int32_t* deferred;    // [n_deferred] element indices
   int has_logit, has_mvn;
   RowsDev lg;
   MvnDev mv;
@@ -102,7 +101,7 @@ struct ModelDev {
   int32_t part_stride, prog_bytes;
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
   const char* prog;
-  int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_pad;
+  int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_deferred;
   long long* ticks;           // [64] phase timestamps of the last B / C launch (only written in -DNUTS_KTIMING builds)
 };
 
@@ -128,6 +127,7 @@ struct Prog {
   const FactorBT* fbt;
   const int32_t* bterm_var;
   const nuts_data_ref* data;
+  const int32_t* deferred;   // [n_deferred][2] = (element, variable)
   const double* pool;
   int n_vars;
 };
@@ -161,6 +161,7 @@ __device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog, cons
   pg.fbt = reinterpret_cast<const FactorBT*>(base + md.po_fbt);
   pg.bterm_var = reinterpret_cast<const int32_t*>(base + md.po_btvar);
   pg.data = reinterpret_cast<const nuts_data_ref*>(base + md.po_data);
+  pg.deferred = reinterpret_cast<const int32_t*>(base + md.po_deferred);
   pg.pool = md.pool;
   pg.n_vars = md.n_vars;
   return pg;
@@ -365,6 +366,17 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
                                                double* s_bacc, int bstride) {
   for (int c = pg.var_cptr[k]; c < pg.var_cptr[k + 1]; ++c) {
     const Contrib cb = pg.contrib[c];
+    if (cb.fast == 2) {   // value ~ Normal(p[1], sigma) or HalfNormal(sigma): no division, no log
+      const bool half = cb.dist == NUTS_D_HALFNORMAL;
+      const double r = half ? x : x - cb.p[1];
+      const double z = r * cb.p[2];
+      double lpf = -0.5 * z * z - cb.p[3] + (half ? -0.22579135264472743236 : -0.91893853320467274178);
+      double g = -z * cb.p[2];
+      if (half && !(x >= 0)) { lpf = -INFINITY; g = 0.0; }
+      gx += g;
+      if (cb.owner) lp += lpf;
+      continue;
+    }
     if (cb.fast) {
       double a[4] = {cb.p[0], cb.p[1], cb.p[2], cb.p[3]}, d[4];
       a[0] = cb.arg == 0 ? x : a[0]; a[1] = cb.arg == 1 ? x : a[1]; a[2] = cb.arg == 2 ? x : a[2]; a[3] = cb.arg == 3 ? x : a[3];

@@ -92,41 +92,40 @@ __device__ __forceinline__ void rows_beta(const RowsDev& R, const QView& qv, int
 // by extra workgroups of the same launch: the streaming loop carries no rare-path state)
 template <int D, int RPL>
 __device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int wave, int lane, int aborted) {
-  const int64_t s0 = (int64_t)wave * R.n_spans / R.n_waves;
-  const int64_t s1 = (int64_t)(wave + 1) * R.n_spans / R.n_waves;
-  int seg = R.seg_base[wave];
-  int g_cur = -1;
   double m_lane, s_lane;
   rows_hyper<D>(R, qv, lane, m_lane, s_lane);
+  const int r0 = R.run_ptr[wave], r1 = R.run_ptr[wave + 1];
   if (aborted) return;   // tested after the hyper-parameter loads were issued: the flag's round trip is hidden
-  double beta[D], acc[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) { acc[d] = 0.0; beta[d] = 0.0; }
   double lp = 0.0;
-  for (int64_t sp = s0; sp < s1; ++sp) {
-    const int g = __builtin_amdgcn_readfirstlane(R.span_gid[sp]);
-    if (g < 0) continue;  // mixed span
-    double x[D][RPL];
-    uint32_t yb;
-    rows_load<D, RPL>(R, sp, lane, x, yb);
-    if (g != g_cur) {
-      if (g_cur >= 0) rows_flush<D>(acc, R.seg_part, seg, lane);
-      g_cur = g;
-      rows_beta<D>(R, qv, g, lane, m_lane, s_lane, beta);
+  // a "run" = consecutive uniform spans of one group inside this wave's range (static table): one segment each
+  for (int r = r0; r < r1; ++r) {
+    const int4 run = R.runs[r];   // {first span, number of spans, group, segment slot}
+    const int64_t sp0 = __builtin_amdgcn_readfirstlane(run.x);
+    const int ns = __builtin_amdgcn_readfirstlane(run.y);
+    const int g = __builtin_amdgcn_readfirstlane(run.z);
+    int seg = __builtin_amdgcn_readfirstlane(run.w);
+    double beta[D], acc[D];
+    rows_beta<D>(R, qv, g, lane, m_lane, s_lane, beta);
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.0;
+    for (int64_t sp = sp0; sp < sp0 + ns; ++sp) {
+      double x[D][RPL];
+      uint32_t yb;
+      rows_load<D, RPL>(R, sp, lane, x, yb);
+#pragma unroll
+      for (int k = 0; k < RPL; ++k) {
+        double eta = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) eta = fma(x[d][k], beta[d], eta);
+        double l, rr;
+        logit_row(eta, (double)((yb >> (8 * k)) & 0xffu), l, rr);
+        lp += l;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = fma(rr, x[d][k], acc[d]);
+      }
     }
-#pragma unroll
-    for (int k = 0; k < RPL; ++k) {
-      double eta = 0.0;
-#pragma unroll
-      for (int d = 0; d < D; ++d) eta = fma(x[d][k], beta[d], eta);
-      double l, r;
-      logit_row(eta, (double)((yb >> (8 * k)) & 0xffu), l, r);
-      lp += l;
-#pragma unroll
-      for (int d = 0; d < D; ++d) acc[d] = fma(r, x[d][k], acc[d]);
-    }
+    rows_flush<D>(acc, R.seg_part, seg, lane);
   }
-  if (g_cur >= 0) rows_flush<D>(acc, R.seg_part, seg, lane);
   lp = wave_sum(lp);
   if (lane == 0) R.wave_lp[wave] = lp;
 }
