@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=20160911)
     ap.add_argument("--cpu-leapfrogs", type=int, default=150, help="bounded CPU-baseline sample, about 18 s of one host core (0 disables)")
     ap.add_argument("--ess-params", type=int, default=1500, help="parameters sampled for the min-ESS (all of mu/sigma + random z)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses GPU 0 (exercises the N > 1 logic on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -96,13 +98,19 @@ def main():
     import torch
 
     dist = None
+    if args.share_gpu:
+        local = 0
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
+    comm_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     from pymc_amd import models
     from pymc_amd.sampling import init_nuts
@@ -156,7 +164,7 @@ def main():
     leap = float(tree.sum())
 
     if dist is not None:
-        t = torch.tensor([dt, min_ess, leap, dom_ms, float(dom_n)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, min_ess, leap, dom_ms, float(dom_n)], dtype=torch.float64, device=comm_dev)
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         allv = torch.stack(allt).cpu().numpy()

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -151,7 +152,7 @@ static void model_enqueue_plain(nuts_model* m, const double* q_dev, double* g_de
   io.mode = MODE_PLAIN; io.q = q_dev; io.grad = g_dev; io.logp = lp_dev;
   launch_dense(m, A, io, 0);
   launch_vector(m, A, io, 0, 0);
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr);
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
 }
 
 // "Compile" the spec: contributions per variable, broadcast terms, deferred elements, orphan factors.
@@ -563,7 +564,12 @@ struct nuts_chain {
   double* out_dev = nullptr;     // [2n]
   double* out_host = nullptr;    // pinned [2n]
   HostStatus* st_dev = nullptr;
-  HostStatus* st_host = nullptr;
+  HostStatus* st_host = nullptr;   // pinned + device-mapped; st_dev is its device alias
+  int seq = 0;
+  // start-state cache: (q, grad) of the last returned proposal stay in out_dev, its logp here
+  bool cache_ok = false;
+  std::vector<double> last_q;
+  double last_logp = 0.0;
   DrawOut* do_dev = nullptr;
   DrawOut* do_host = nullptr;
   double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
@@ -638,7 +644,6 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->n_uni_cap = (1 << maxd) + 2 * maxd + 16;
   c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + 2 * (size_t)c->n_uni_cap));
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
-  c->st_dev = c->keep(dev_alloc<HostStatus>(1));
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
   A.log_uniforms = A.uniforms + c->n_uni_cap;
@@ -646,7 +651,8 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
     if (!p) { g_err = "device allocation failed (trajectory arena needs 4*2^max_treedepth*n*8 bytes)"; nuts_chain_destroy(c); return nullptr; }
   if (hipHostMalloc((void**)&c->stage_host, (2 * (size_t)n + 2 * (size_t)c->n_uni_cap) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&c->out_host, 2 * (size_t)n * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void**)&c->st_host, sizeof(HostStatus), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->st_host, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->st_dev, c->st_host, 0) != hipSuccess ||
       hipHostMalloc((void**)&c->do_host, sizeof(DrawOut), hipHostMallocDefault) != hipSuccess) {
     g_err = "pinned host allocation failed"; nuts_chain_destroy(c); return nullptr;
   }
@@ -718,8 +724,12 @@ static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotent
 //   p_exact: the second vector is the momentum itself (integrator tests) instead of standard normals
 //   dir_forced: +1/-1 fixes the direction (HMC / integrator tests); 0 = draw it from uniforms[0] (nuts.py:215)
 static int draw_begin(nuts_chain* c, const double* q0, const double* normals, const double* uniforms, int n_uniforms,
-                      double step_size, int max_depth, bool p_exact, int dir_forced) {
+                      double step_size, int max_depth, bool p_exact, int dir_forced, bool allow_cache = false) {
   const int n = c->n;
+  // the usual case inside a chain: q0 is bit for bit the proposal this chain returned last time, whose gradient and
+  // logp are still on the device -- the model pass at q0 would reproduce exactly those numbers
+  const bool cached = allow_cache && c->cache_ok && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
+  c->cache_ok = false;
   hipStream_t s = c->m->stream;
   ArenaDev& A = c->A;
   const int nu = std::min(n_uniforms, c->n_uni_cap);
@@ -736,18 +746,35 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
   } else {
     HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
   }
-  HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-  model_enqueue_plain(c->m, A.Q, A.G, A.LOGP);
+  if (!cached) {
+    HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    model_enqueue_plain(c->m, A.Q, A.G, A.LOGP);
+  }
   hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, c->stage_dev + n,
-                     p_exact ? (const double*)(c->stage_dev + n) : (const double*)nullptr, c->kin_part);
-  hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, c->kin_part, step_size, dir_forced, max_depth, c->st_dev);
+                     p_exact ? (const double*)(c->stage_dev + n) : (const double*)nullptr, c->kin_part,
+                     cached ? (const double*)c->out_dev : (const double*)nullptr, cached ? (const double*)(c->out_dev + n) : (const double*)nullptr);
+  hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, c->kin_part, step_size, dir_forced, max_depth, c->st_dev,
+                     cached ? 1 : 0, c->last_logp);
   return NUTS_OK;
 }
 
-static int sync_status(nuts_chain* c) {
-  hipStream_t s = c->m->stream;
-  HIPCHK(hipMemcpyAsync(c->st_host, c->st_dev, sizeof(HostStatus), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
+static int sync_status(nuts_chain* c) {   // the status record is host memory: a stream sync makes it current
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  return NUTS_OK;
+}
+
+// Wait until the control kernel of the last leaf of a doubling has published sequence number `seq`
+// (spin on the mapped record; falls back to an error after 60 s so that a lost kernel cannot hang the process).
+static int wait_status(nuts_chain* c, int seq) {
+  volatile int* flag = &c->st_host->seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; *flag != seq; ++spins) {
+    if ((spins & 0xfffff) == 0xfffff) {
+      if (hipStreamQuery(c->m->stream) == hipSuccess && *flag != seq) { g_err = "control kernel finished without publishing its status"; return NUTS_E_HIP; }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { g_err = "timed out waiting for the device"; return NUTS_E_HIP; }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return NUTS_OK;
 }
 
@@ -757,7 +784,7 @@ struct Geometry {  // of the doubling being built: direction, edge state, curren
   double eps;
 };
 
-static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d, int mode, int max_depth) {
+static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d, int mode, int max_depth, int seq = 0) {
   ArenaDev& A = c->A;
   nuts_model* m = c->m;
   hipStream_t s = m->stream;
@@ -768,7 +795,7 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   launch_dense(m, A, io, j);
   launch_vector(m, A, io, j, d);
   hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth,
-                     mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr);
+                     mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr, seq);
   c->leapfrogs++;
 }
 
@@ -790,7 +817,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   const int need_uni = (1 << max_depth) + max_depth + 1;
   if (n_uniforms < need_uni) { g_err = "not enough uniforms for the worst-case tree"; return NUTS_E_ARG; }
 
-  int rc = draw_begin(c, q0, normals, uniforms, need_uni, step_size, max_depth, false, 0);
+  int rc = draw_begin(c, q0, normals, uniforms, need_uni, step_size, max_depth, false, 0, true);
   if (rc) return rc;
   bool exhausted = true;
   int64_t evals = 1;
@@ -800,10 +827,11 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   gm.eps = gm.dir > 0 ? step_size : -step_size;
   for (int d = 0; d < max_depth; ++d) {
     const int nleaf = 1 << d;
-    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, gm, j, d, MODE_TREE, max_depth);
-    rc = sync_status(c);
+    const int seq = ++c->seq;
+    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, gm, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
+    rc = wait_status(c, seq);
     if (rc) return rc;
-    const HostStatus& st = *c->st_host;
+    const HostStatus st = *c->st_host;
     if (st.bad_energy) break;
     if (st.diverging || st.turning) { exhausted = false; break; }
     if (gm.dir > 0) gm.right += nleaf; else gm.left -= nleaf;   // nuts.py:353,362: the subtree's far end is the new edge
@@ -838,6 +866,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
 
   std::memcpy(q_out, c->out_host, n * sizeof(double));
   if (grad_out) std::memcpy(grad_out, c->out_host + n, n * sizeof(double));
+  c->last_q.assign(c->out_host, c->out_host + n); c->last_logp = o.logp; c->cache_ok = true;
   std::memset(stats, 0, sizeof(*stats));
   stats->depth = o.depth;
   stats->step_size = std::exp(c->da.log_step);
@@ -980,6 +1009,7 @@ extern "C" int nuts_chain_set_state(nuts_chain* c, const void* blob) {
   std::memcpy(&h, blob, sizeof(h));
   if (h.magic != STATE_MAGIC || h.n != c->n) { g_err = "sampling state does not belong to this chain (frozen fields differ)"; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(c->m->stream));
+  c->cache_ok = false;
   c->da = h.da; c->iter_count = h.iter_count; c->divergences = h.divergences; c->n_samples = h.n_samples;
   c->adaptation_window = h.adaptation_window; c->tune = h.tune != 0; c->fg_is_a = h.fg_is_a != 0;
   c->fg_count = h.fg_count; c->bg_count = h.bg_count;

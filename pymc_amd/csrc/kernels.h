@@ -75,8 +75,10 @@ struct ArenaDev {
   const double* log_uniforms;  // their logarithms, taken on the host (the tree compares log(u), nuts.py:371,466)
 };
 
-struct HostStatus {
+struct HostStatus {   // lives in pinned, device-mapped host memory: the control kernel writes it over PCIe
   int aborted, turning, diverging, bad_energy, depth, cursor, n_proposals, proposal, dir, edge;
+  int seq;   // written last (after a system-scope fence) by the control kernel of the LAST leaf of a doubling: the host
+  int pad;   // spins on it instead of paying a stream synchronisation + copy per doubling
 };
 
 struct EvalIO {
@@ -127,10 +129,14 @@ __device__ __forceinline__ int load_aborted(const EvalIO& io, const ArenaDev& A)
   return io.mode == MODE_TREE ? __hip_atomic_load(&A.ctl->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 }
 
-__device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st) {
+__device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st, int seq) {
   st->aborted = c->aborted; st->turning = c->turning; st->diverging = c->diverging; st->bad_energy = c->bad_energy;
   st->depth = c->depth; st->cursor = c->cursor; st->n_proposals = c->n_proposals; st->proposal = c->proposal;
   st->dir = c->dir; st->edge = c->edge;
+  if (seq) {
+    __threadfence_system();
+    __hip_atomic_store(&st->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -545,7 +551,7 @@ __device__ __forceinline__ void ctl_next_direction(Ctl* c, const double* uniform
 #define CTL_CHUNKS 8   // the per-workgroup partials are summed in CTL_CHUNKS contiguous chunks, then the chunks in order
 
 __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
-                                                        int max_depth, HostStatus* st) {
+                                                        int max_depth, HostStatus* st, int seq) {
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
   constexpr int NW = VEC_THREADS / WAVE;
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   __syncthreads();
   TICK(md, tk, 18);
   if (tree && s_ctl.aborted) {   // terminated earlier in this doubling: drain
-    if (tid == 0 && st) publish_status(&s_ctl, st);
+    if (tid == 0 && st) publish_status(&s_ctl, st, seq);
     return;
   }
   for (int t = tid; t < nn; t += VEC_THREADS) {
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   }
   TICK(md, tk, 24);
   *A.ctl = *c;
-  if (st) publish_status(c, st);
+  if (st) publish_status(c, st, seq);
   TICK(md, tk, 25);
 }
 
@@ -742,8 +748,11 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
 // ---------------------------------------------------------------------------
 
 // p0 = z / sigma, v0 = var * p0, PSUM = p0 (base_hmc.py:201-202, quadpotential.py:323-326)
+// `q_src` / `g_src` (optional): position and gradient of the start state when it is the previous draw's proposal
+// (the values the model pass would reproduce bit for bit; the reference recomputes them, base_hmc.py:202)
 __global__ __launch_bounds__(VEC_THREADS) void k_draw_start(ArenaDev A, const double* __restrict__ normals,
-                                                            const double* __restrict__ p_exact, double* __restrict__ kin_part) {
+                                                            const double* __restrict__ p_exact, double* __restrict__ kin_part,
+                                                            const double* __restrict__ q_src, const double* __restrict__ g_src) {
   __shared__ double sm[VEC_THREADS / WAVE];
   double kin = 0.0;
   const int base = blockIdx.x * VEC_THREADS * A.ept;
@@ -753,6 +762,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_draw_start(ArenaDev A, const do
       const double p = p_exact ? p_exact[i] : normals[i] * A.inv_stds[i];
       const double v = A.var[i] * p;
       A.P[i] = p; A.V[i] = v; A.PSUM[i] = p;
+      if (q_src) { A.Q[i] = q_src[i]; A.G[i] = g_src[i]; }
       kin = fma(p, v, kin);
     }
   }
@@ -761,11 +771,12 @@ __global__ __launch_bounds__(VEC_THREADS) void k_draw_start(ArenaDev A, const do
 }
 
 __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part, double step_size, int dir_forced, int max_depth,
-                                 HostStatus* st) {
+                                 HostStatus* st, int use_cached_logp, double cached_logp) {
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int b = 0; b < A.nblk; ++b) s += kin_part[b];
     Ctl* c = A.ctl;
+    if (use_cached_logp) A.LOGP[0] = cached_logp;
     const double logp = A.LOGP[0];
     const double E = 0.5 * s - logp;  // integration.py:72-74
     A.E[0] = E;
@@ -783,7 +794,7 @@ __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part
     c->dir = 1; c->edge = 0; c->eps = step_size;
     if (dir_forced != 0) { c->dir = dir_forced; c->eps = dir_forced > 0 ? step_size : -step_size; }
     else if (!c->aborted && max_depth > 0) ctl_next_direction(c, A.uniforms);
-    if (st) publish_status(c, st);
+    if (st) publish_status(c, st, 0);
   }
 }
 

@@ -80,6 +80,18 @@ def test_hier_logit_logp_grad(G, D, rpg):
     _check_logp_grad(spec, [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.5 for _ in range(3)])
 
 
+def test_large_n_multi_element_threads():
+    """n > 65 536 switches the O(n) kernel to 4 elements per thread: logp/grad parity, and one full NUTS run against
+    the oracle (integers identical) on a wide model."""
+    spec = models.hier_logit(G=9000, D=8, rows_per_group=3, seed=11)  # n = 72 016
+    assert spec.n > 65536
+    rng = np.random.default_rng(6)
+    _check_logp_grad(spec, [np.zeros(spec.n), rng.normal(size=spec.n) * 0.4])
+    spec2 = models.std_normal(70000, 1.0, 2.0)
+    _check_logp_grad(spec2, [rng.normal(size=spec2.n)])
+    _compare_runs(spec2, tune=6, draws=4, seed=3, prefix=10)
+
+
 def test_hier_logit_ragged_groups():
     rng = np.random.default_rng(4)
     G, D = 23, 8

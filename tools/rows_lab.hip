@@ -27,7 +27,7 @@ __device__ __forceinline__ void logit_row(double eta, double yk, double& lp, dou
 // MATH 0: sum only; 1: full logit math with uniform beta
 template <int RPL, int LAYOUT, int MATH, int NT>
 __global__ __launch_bounds__(256) void k(const double* __restrict__ X, const int8_t* __restrict__ y, int64_t Npad, int64_t n_spans,
-                                         int n_waves, double* out, int rev) {
+                                         int n_waves, double* out, int rev, int64_t nt_from = -1) {
   constexpr int SPAN = 64 * RPL;
   const int lane = threadIdx.x & 63;
   int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k(const double* __restrict__ X, const int
 #pragma unroll
       for (int k2 = 0; k2 < RPL; k2 += 2) {
         double2 a;
-        if (NT) { a.x = __builtin_nontemporal_load(col + k2); a.y = __builtin_nontemporal_load(col + k2 + 1); }
+        if (NT == 1 || (NT == 2 && sp >= nt_from)) { a.x = __builtin_nontemporal_load(col + k2); a.y = __builtin_nontemporal_load(col + k2 + 1); }
         else a = *reinterpret_cast<const double2*>(col + k2);
         x[d][k2] = a.x; x[d][k2 + 1] = a.y;
       }
@@ -97,6 +97,25 @@ void run(const char* name, const double* X, const int8_t* y, int64_t N, int wpc,
   fflush(stdout);
 }
 
+template <int RPL>
+void run_split(const double* X, const int8_t* y, int64_t N, int wpc, double frac, double* out) {
+  constexpr int SPAN = 64 * RPL;
+  const int64_t n_spans = N / SPAN;
+  int n_waves = (int)std::min<int64_t>(256 * wpc, n_spans);
+  n_waves = (n_waves + 3) / 4 * 4;
+  const int64_t nt_from = (int64_t)(frac * n_spans);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<RPL, 1, 1, 2>), dim3(n_waves / 4), dim3(256), 0, 0, X, y, N, n_spans, n_waves, out, 0, nt_from);
+  hipDeviceSynchronize();
+  const int reps = 30;
+  hipEventRecord(a);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<RPL, 1, 1, 2>), dim3(n_waves / 4), dim3(256), 0, 0, X, y, N, n_spans, n_waves, out, 0, nt_from);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  printf("tiled math, cached fraction %.2f (rest nontemporal), wpc=%d: %7.1f us\n", frac, wpc, ms * 1e3 / reps);
+  fflush(stdout);
+}
+
 int main() {
   const int64_t N = 4992000;
   std::vector<double> hx((size_t)N * D);
@@ -108,6 +127,8 @@ int main() {
   CK(hipMalloc(&X, hx.size() * 8)); CK(hipMalloc(&y, N)); CK(hipMalloc(&out, 1 << 20));
   CK(hipMemcpy(X, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(y, hy.data(), N, hipMemcpyHostToDevice));
+  for (double f : {0.0, 0.3, 0.5, 0.6, 0.7, 0.8, 1.0}) run_split<2>(X, y, N, 16, f, out);
+  if (getenv("SPLIT_ONLY")) return 0;
   for (int alt = 0; alt < 2; ++alt)
     for (int wpc : {8, 16, 32}) {
       run<2, 0, 0, 0>("colmajor sum", X, y, N, wpc, alt, out);
