@@ -246,6 +246,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   if ((int)deferred.size() / 2 > MAX_DEFERRED) { g_err = "too many scalar / hyper-parameter elements (MAX_DEFERRED)"; return false; }
   md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size() / 2;
   md.orphans = m->keep(dev_upload(orphans.data(), orphans.size()));
+  md.deferred_g = m->keep(dev_upload(deferred.data(), deferred.size()));
   // pack the interpreter's tables into one blob (copied into LDS by kernels B and C)
   std::vector<char> blob;
   auto put = [&](const void* src, size_t bytes) {

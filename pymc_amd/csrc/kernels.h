@@ -579,6 +579,18 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   prog_issue(md, pregs);
   // control block -> LDS (first thing: everything else overlaps this round trip)
   if (leaf && tid < (int)(sizeof(Ctl) / sizeof(int))) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(A.ctl)[tid];
+  // the deferred elements' own inputs do not depend on the partials: fetch them now (element index from the global
+  // copy of the list, then the four arena reads), so that both round trips overlap the partial sums below
+  const bool mine = tid < md.n_deferred;
+  int def_i = 0;
+  double def_ph = 0.0, def_q = 0.0;
+  if (mine) {
+    def_i = md.deferred_g[2 * tid];
+    if (leaf) {
+      if (io.explicit_pre) { def_ph = A.P[lf.d_o + def_i]; def_q = A.Q[lf.d_o + def_i]; }
+      else { def_ph = qv.p_half(def_i); def_q = qv.at(def_i); }   // q' itself was stored by kernel B
+    } else def_q = io.q[def_i];
+  }
   // ---- fixed-order sums of the per-workgroup partials this leaf needs: (slot, chunk) pairs in parallel ----
   const int nbt = md.n_bterms, nlg = md.has_logit ? lg.D : 0;
   const int nn = 1 + nbt + 2 * nlg + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
@@ -627,17 +639,13 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   double grad[1] = {0.0}, ph[1] = {0.0};
   double lp = 0.0, gx = 0.0, dxdq = 1.0, dj = 0.0;
   int k = -1;
-  const bool mine = tid < md.n_deferred;
   if (mine) {
-    const int i = pg.deferred[2 * tid];
+    const int i = def_i;
     k = pg.deferred[2 * tid + 1];
     const VarDev v = pg.vars[k];
     idx[0] = i;
-    double qn;
-    if (leaf) {
-      if (io.explicit_pre) { ph[0] = A.P[lf.d_o + i]; qn = A.Q[lf.d_o + i]; }
-      else { ph[0] = qv.p_half(i); qn = qv.at(i); }   // q' itself was stored by kernel B
-    } else qn = io.q[i];
+    ph[0] = def_ph;
+    const double qn = def_q;
     double x, lj;
     transform_full(v, qn, x, dxdq, lj, dj);
     lp += lj;

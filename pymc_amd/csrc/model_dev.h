@@ -94,6 +94,7 @@ struct ModelDev {
   int32_t n_bterms, n_orphans, n_deferred, nblk;
   const double* pool;         // data vectors of the spec
   const int32_t* orphans;     // [n_orphans] factors without an owning variable
+  const int32_t* deferred_g;  // [n_deferred][2] (element, variable): global copy of the program's list
   int has_logit, has_mvn;
   RowsDev lg;
   MvnDev mv;
