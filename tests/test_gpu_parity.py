@@ -122,6 +122,15 @@ def test_mvnormal_logp_grad():
     _check_logp_grad(spec, [rng.normal(size=spec.n) for _ in range(3)], rtol=1e-8)
 
 
+def test_mvnormal_full_size_and_nuts_parity():
+    """C3: MvNormal with a full 2048 x 2048 covariance (logp/grad vs the Cholesky-solve oracle), and a NUTS run on a
+    64-dimensional one against the oracle (integers identical)."""
+    spec = models.mvnormal(n=2048)
+    rng = np.random.default_rng(8)
+    _check_logp_grad(spec, [rng.normal(size=spec.n)], rtol=1e-8)
+    _compare_runs(models.mvnormal(n=64), tune=20, draws=10, seed=12, prefix=30)
+
+
 def test_invalid_parameter_gives_minus_inf():
     """check_parameters -> -inf switch (pymc/logprob/utils.py:209-225)."""
     m = ModelBuilder()
