@@ -377,6 +377,31 @@ def test_nuts_statistics_std_normal():
     res["step"].close()
 
 
+def test_posterior_matches_oracle_within_monte_carlo_error():
+    """north_star: "posterior draws must match the reference CPU sampler within Monte-Carlo error".
+    Independent seeds on both sides; every coordinate's posterior-mean difference is judged against its Monte-Carlo
+    standard error (sd / sqrt(ESS), both chains); where both sides mix well the posterior sds must agree to 25 %."""
+    from pymc_amd.sampling import sample
+    from pymc_amd.stats import ess_bulk
+
+    spec = models.hier_logit(G=10, D=4, rows_per_group=40, seed=21)
+    res = sample(draws=1200, tune=600, chains=2, model=spec, random_seed=101, device=0)
+    dev = res["draws"]
+    f = ref_models.SpecLogpGrad(spec)
+    ref, _ = ref_sampler.sample_reference(f, [np.zeros(spec.n)] * 2, draws=1200, tune=600, random_seed=202, init="jitter+adapt_diag")
+    ref = ref[:, 600:]
+    worst = 0.0
+    for i in range(spec.n):
+        a, b = dev[:, :, i], ref[:, :, i]
+        ea, eb = max(ess_bulk(a), 10.0), max(ess_bulk(b), 10.0)
+        se = np.sqrt(a.var() / ea + b.var() / eb)
+        worst = max(worst, abs(a.mean() - b.mean()) / se)
+        if min(ea, eb) > 400:   # the sd estimate is only meaningful where both chains mix
+            assert abs(a.std() / b.std() - 1.0) < 0.25, (i, a.std(), b.std())
+    assert worst < 4.5, worst  # max of 48 approximately standard-normal z-scores
+    res["step"].close()
+
+
 def test_hmc_matches_oracle():
     from pymc_amd.blocking import RaveledVars
     from pymc_amd.step import HamiltonianMC
