@@ -131,6 +131,9 @@ int nuts_model_debug_ticks(nuts_model *m, int64_t *out /* [64] */);
 int64_t nuts_model_algorithmic_bytes(const nuts_model *m);
 
 /* ---- chain: replaces BaseHMC/NUTS + potential + step adaptation ------------- */
+/* NUTS_POT_FULL covers QuadPotentialFull and QuadPotentialFullInv (quadpotential.py:633-725): the caller passes
+ * the dense covariance C (velocity = C p) and the matrix W with potential.random() = W z
+ * (Full: W = chol(C)^-T ; FullInv(A): C = A^-1, W = chol(A)). */
 enum { NUTS_POT_DIAG_ADAPT = 0, NUTS_POT_DIAG = 1, NUTS_POT_FULL = 2 };
 
 typedef struct {
@@ -152,6 +155,8 @@ typedef struct {
   double adaptation_window_multiplier;  /* 1   */
   int32_t early_update;                 /* 0   */
   int32_t pad;
+  const double *dense_cov;  /* [n][n] row-major, NUTS_POT_FULL only */
+  const double *dense_rand; /* [n][n] row-major, NUTS_POT_FULL only */
 } nuts_chain_config;
 
 void nuts_chain_config_default(nuts_chain_config *cfg);

@@ -105,6 +105,8 @@ class ChainConfig(C.Structure):
         ("adaptation_window_multiplier", C.c_double),
         ("early_update", C.c_int32),
         ("pad", C.c_int32),
+        ("dense_cov", C.POINTER(C.c_double)),
+        ("dense_rand", C.POINTER(C.c_double)),
     ]
 
 

@@ -549,6 +549,8 @@ struct nuts_chain {
   std::vector<void*> owned;
   // potential (device)
   double *var = nullptr, *stds = nullptr, *inv_stds = nullptr;
+  double *dense_C = nullptr, *dense_W = nullptr;   // NUTS_POT_FULL: velocity = C p, random = W z
+  int dense = 0, mv_grid = 0;
   double *wa_mean = nullptr, *wa_m2 = nullptr, *wb_mean = nullptr, *wb_m2 = nullptr;  // two Welford estimators
   bool fg_is_a = true;
   double fg_count = 0, bg_count = 0;
@@ -610,9 +612,10 @@ static int potential_reset(nuts_chain* c) {  // quadpotential.py:297-306
 
 extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config* cfg) {
   if (!m || !cfg) { g_err = "null argument"; return nullptr; }
-  if (cfg->potential != NUTS_POT_DIAG_ADAPT && cfg->potential != NUTS_POT_DIAG) {
-    g_err = "potential kind not implemented on device yet (dense potentials are a later round)"; return nullptr;
+  if (cfg->potential != NUTS_POT_DIAG_ADAPT && cfg->potential != NUTS_POT_DIAG && cfg->potential != NUTS_POT_FULL) {
+    g_err = "potential kind not implemented on device (adaptive dense potentials are a later round)"; return nullptr;
   }
+  if (cfg->potential == NUTS_POT_FULL && (!cfg->dense_cov || !cfg->dense_rand)) { g_err = "dense potential needs dense_cov and dense_rand"; return nullptr; }
   if (cfg->max_treedepth < 1 || cfg->max_treedepth > MAX_LEVELS - 1) { g_err = "max_treedepth out of range (1..11)"; return nullptr; }
   auto* c = new nuts_chain();
   c->m = m; c->cfg = *cfg; c->n = m->md.n;
@@ -623,6 +626,9 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   if (cfg->initial_diag) c->initial_diag.assign(cfg->initial_diag, cfg->initial_diag + n);
   else if (cfg->potential == NUTS_POT_DIAG_ADAPT) c->cfg.initial_weight = 1;  // quadpotential.py:280-282
   c->cfg.initial_mean = nullptr; c->cfg.initial_diag = nullptr;
+  c->dense = cfg->potential == NUTS_POT_FULL;
+  if (c->dense) c->initial_diag.assign(m->md.n, 1.0);  // the diagonal vectors stay allocated (unused)
+  c->cfg.dense_cov = nullptr; c->cfg.dense_rand = nullptr;
   c->adaptation_window = cfg->adaptation_window;
   ArenaDev& A = c->A;
   A.n = n;
@@ -642,6 +648,11 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->wa_mean = c->keep(dev_alloc<double>(n)); c->wa_m2 = c->keep(dev_alloc<double>(n));
   c->wb_mean = c->keep(dev_alloc<double>(n)); c->wb_m2 = c->keep(dev_alloc<double>(n));
   A.var = c->var; A.inv_stds = c->inv_stds;
+  if (c->dense) {
+    c->dense_C = c->keep(dev_upload(cfg->dense_cov, (size_t)n * n));
+    c->dense_W = c->keep(dev_upload(cfg->dense_rand, (size_t)n * n));
+    c->mv_grid = (n + (256 / WAVE) - 1) / (256 / WAVE);
+  }
   c->n_uni_cap = (1 << maxd) + 2 * maxd + 16;
   c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + 2 * (size_t)c->n_uni_cap));
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
@@ -751,9 +762,18 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
     HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     model_enqueue_plain(c->m, A.Q, A.G, A.LOGP);
   }
+  if (c->dense) {
+    // p0 = W z (or the given momentum), v0 = C p0   (quadpotential.py:704-711)
+    if (p_exact) HIPCHK(hipMemcpyAsync(A.P, c->stage_dev + n, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    else hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_W, c->stage_dev + n, A.P, n, (const double*)nullptr,
+                            (double*)nullptr, 0.0, (const int*)nullptr);
+    hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P, A.V, n, (const double*)nullptr, (double*)nullptr, 0.0,
+                       (const int*)nullptr);
+  }
   hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, c->stage_dev + n,
                      p_exact ? (const double*)(c->stage_dev + n) : (const double*)nullptr, c->kin_part,
-                     cached ? (const double*)c->out_dev : (const double*)nullptr, cached ? (const double*)(c->out_dev + n) : (const double*)nullptr);
+                     cached ? (const double*)c->out_dev : (const double*)nullptr, cached ? (const double*)(c->out_dev + n) : (const double*)nullptr,
+                     c->dense);
   hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, c->kin_part, step_size, dir_forced, max_depth, c->st_dev,
                      cached ? 1 : 0, c->last_logp);
   return NUTS_OK;
@@ -790,13 +810,31 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   nuts_model* m = c->m;
   hipStream_t s = m->stream;
   EvalIO io{};
-  io.mode = mode; io.explicit_pre = m->explicit_pre;
+  io.mode = mode; io.explicit_pre = m->explicit_pre || c->dense; io.dense = c->dense;
   io.dir = gm.dir; io.edge = gm.edge; io.left = gm.left; io.right = gm.right; io.eps = gm.eps;
-  if (m->explicit_pre) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
+  const int* abort_flag = mode == MODE_TREE ? &A.ctl->aborted : nullptr;
+  const int t = gm.edge + gm.dir * (j + 1), src = gm.edge + gm.dir * j;
+  const int64_t d_o = (int64_t)(t & (A.S - 1)) * A.n, so = (int64_t)(src & (A.S - 1)) * A.n;
+  if (io.explicit_pre) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
+  if (c->dense)   // v = C p_half ; q' = q + eps v   (integration.py:121-127 with a dense velocity)
+    hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, A.Q + so, A.Q + d_o, gm.eps,
+                       abort_flag);
   launch_dense(m, A, io, j);
   launch_vector(m, A, io, j, d);
   hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth,
                      mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr, seq);
+  if (c->dense) {   // v' = C p', then the tree work on the stored (p', v')
+    hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, (const double*)nullptr,
+                       (double*)nullptr, 0.0, abort_flag);
+    const dim3 grid(m->md.nblk);
+    switch (m->ept) {
+      case 1: hipLaunchKernelGGL(k_tree_vec<1>, grid, dim3(VEC_THREADS), 0, s, m->md, A, io, j, d); break;
+      case 4: hipLaunchKernelGGL(k_tree_vec<4>, grid, dim3(VEC_THREADS), 0, s, m->md, A, io, j, d); break;
+      default: hipLaunchKernelGGL(k_tree_vec<16>, grid, dim3(VEC_THREADS), 0, s, m->md, A, io, j, d); break;
+    }
+    hipLaunchKernelGGL(k_tree_ctl, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth,
+                       mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr, seq);
+  }
   c->leapfrogs++;
 }
 

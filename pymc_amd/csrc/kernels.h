@@ -84,6 +84,8 @@ struct HostStatus {   // lives in pinned, device-mapped host memory: the control
 struct EvalIO {
   int mode;          // MODE_*
   int explicit_pre;  // leaf modes: q' and p_half were materialised by k_leaf_pre
+  int dense;         // dense mass matrix: v = C p is a mat-vec between the kernels, so B/C stop after the kick and the
+                     // tree work runs in its own pair of kernels (k_tree_vec / k_tree_ctl)
   const double* q;   // MODE_PLAIN: position in
   double* grad;      // MODE_PLAIN: gradient out
   double* logp;      // MODE_PLAIN: logp out
@@ -143,7 +145,7 @@ __device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st, int
 // explicit first half of a leapfrog (only when the position cannot be composed on the fly)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(VEC_THREADS) void k_leaf_pre(ArenaDev A, EvalIO io, int j) {
-  if (load_aborted(io, A)) return;
+  if (load_aborted(io, A)) return;  // (MODE_SIMPLE never aborts)
   const int src = io.edge + io.dir * j, dst = src + io.dir;
   const double eps = io.eps, half = 0.5 * eps;
   const int64_t so = slot_off(A, src), d_o = slot_off(A, dst);
@@ -152,10 +154,36 @@ __global__ __launch_bounds__(VEC_THREADS) void k_leaf_pre(ArenaDev A, EvalIO io,
     const int i = base + e * VEC_THREADS + threadIdx.x;
     if (i < A.n) {
       const double ph = fma(half, A.G[so + i], A.P[so + i]);
-      const double v = A.var[i] * ph;
       A.P[d_o + i] = ph;
-      A.Q[d_o + i] = fma(eps, v, A.Q[so + i]);
+      if (!io.dense) A.Q[d_o + i] = fma(eps, A.var[i] * ph, A.Q[so + i]);   // dense: k_dense_mv finishes q'
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dense mass matrix (QuadPotentialFull / FullInv, quadpotential.py:633-725): y = C x, one wave per row
+//   mode 0: y = C x          mode 1: y = C x and  q_out = q_in + eps * y   (first half of the leapfrog, q')
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_mv(const double* __restrict__ C, const double* __restrict__ x, double* __restrict__ y,
+                                                  int n, const double* __restrict__ q_in, double* __restrict__ q_out, double eps,
+                                                  const int* __restrict__ abort_flag) {
+  if (abort_flag && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int row = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* __restrict__ cr = C + (int64_t)row * n;
+  double s = 0.0;
+  const int n2 = n & ~1;
+  for (int c = lane * 2; c < n2; c += 2 * WAVE) {
+    const double2 a = *reinterpret_cast<const double2*>(cr + c);
+    s = fma(a.x, x[c], s);
+    s = fma(a.y, x[c + 1], s);
+  }
+  if (lane == 0 && (n & 1)) s = fma(cr[n - 1], x[n - 1], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    y[row] = s;
+    if (q_out) q_out[row] = fma(eps, s, q_in[row]);
   }
 }
 
@@ -335,6 +363,119 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
   m_out = m; last_out = last;
 }
 
+// The same merges for a dense mass matrix: p' and v' = C p' of the new leaf are read back from the arena
+// (kernel k_tree_vec), every element alike.
+template <int E>
+__device__ __forceinline__ void tree_post(const ArenaDev& A, const Leaf& lf, int j, int d, bool tree,
+                                          const int (&idx)[E], const bool (&act)[E], double* red, int nwaves, int& m_out,
+                                          bool& last_out) {
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+  const int dir = lf.dir, edge = lf.edge, t = lf.t;
+  const int64_t to = lf.d_o;
+  double acc[E], vt[E];
+  double kin = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    acc[e] = 0.0; vt[e] = 0.0;
+    if (act[e]) {
+      const int i = idx[e];
+      const double p = A.P[to + i], v = A.V[to + i];  // p', v' = C p' of the new leaf (stored by B/C and k_dense_mv)
+      acc[e] = p; vt[e] = v;
+      kin = fma(p, v, kin);
+    }
+  }
+  {
+    const double s = wave_sum(kin);
+    if (lane == 0) red[0 * nwaves + w] = s;
+  }
+  int m = 0;
+  bool last = false;
+  if (tree) {
+    while (((j >> m) & 1) && m < d) ++m;
+    last = (j + 1 == (1 << d));
+    // merges: level l joins leaves [j-2^(l+1)+1, j-2^l] (t1) with [j-2^l+1, j] (t2)   (nuts.py:452-463)
+    for (int l = 0; l < m; ++l) {
+      const int t1_left = edge + dir * (j - (2 << l) + 2);
+      const int t1_right = edge + dir * (j - (1 << l) + 1);
+      const int t2_left = t1_right + dir;
+      const int64_t o1l = slot_off(A, t1_left), o1r = slot_off(A, t1_right), o2l = slot_off(A, t2_left);
+      const double* ps1 = (l == 0) ? (A.P + o1r) : (A.PS + (int64_t)l * A.n);  // a single leaf's p_sum is its p
+      double dd[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (act[e]) {
+          const int i = idx[e];
+          // all six operands are loaded unconditionally (valid slots at every level) so they are in flight together
+          const double s1 = ps1[i], v1l = A.V[o1l + i], p2l = A.P[o2l + i], v2l = A.V[o2l + i], p1r = A.P[o1r + i],
+                       v1r = A.V[o1r + i];
+          const double s2 = acc[e];
+          const double rho = s1 + s2;                  // tree1.p_sum + tree2.p_sum
+          dd[0] = fma(rho, v1l, dd[0]);
+          dd[1] = fma(rho, vt[e], dd[1]);
+          if (l >= 1) {
+            const double rho1 = s1 + p2l;              // tree1.p_sum + tree2.left.p
+            dd[2] = fma(rho1, v1l, dd[2]);
+            dd[3] = fma(rho1, v2l, dd[3]);
+            const double rho2 = p1r + s2;              // tree1.right.p + tree2.p_sum
+            dd[4] = fma(rho2, v1r, dd[4]);
+            dd[5] = fma(rho2, vt[e], dd[5]);
+          }
+          acc[e] = rho;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(1 + 6 * l + k) * nwaves + w] = s; }
+    }
+    if (!last) {
+      // subtree not complete: park the merged p_sum as the pending left sibling of level m
+      if (m >= 1) {
+        double* ps = A.PS + (int64_t)m * A.n;
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (act[e]) ps[idx[e]] = acc[e];
+      }
+    } else {
+      // subtree complete: top-level merge of `extend` (nuts.py:346-390), speculative
+      const int first = edge + dir;  // first leaf of the new subtree
+      int lm_begin, lm_end, rm_begin, rm_end, new_left, new_right;
+      if (dir > 0) { lm_begin = lf.left; lm_end = lf.right; rm_begin = first; rm_end = t; new_left = lf.left; new_right = t; }
+      else         { lm_begin = t; lm_end = first; rm_begin = lf.left; rm_end = lf.right; new_left = t; new_right = lf.right; }
+      const int64_t onl = slot_off(A, new_left), onr = slot_off(A, new_right);
+      const int64_t olb = slot_off(A, lm_begin), ole = slot_off(A, lm_end), orb = slot_off(A, rm_begin), ore = slot_off(A, rm_end);
+      double dd[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (act[e]) {
+          const int i = idx[e];
+          const double old = A.PSUM[i], sub = acc[e];
+          const double tot = old + sub;                       // p_sum[:] += tree.p_sum
+          A.PSUM[i] = tot;
+          const double lm_sum = dir > 0 ? old : sub, rm_sum = dir > 0 ? sub : old;
+          // the new edge state is this leaf: its v is in registers (the store above may not be visible yet)
+          const double v_nl = (new_left == t) ? vt[e] : A.V[onl + i];
+          const double v_nr = (new_right == t) ? vt[e] : A.V[onr + i];
+          dd[0] = fma(tot, v_nl, dd[0]);
+          dd[1] = fma(tot, v_nr, dd[1]);
+          const double p_rb = (rm_begin == t) ? A.P[to + i] : A.P[orb + i];
+          const double v_rb = (rm_begin == t) ? vt[e] : A.V[orb + i];
+          const double v_lb = (lm_begin == t) ? vt[e] : A.V[olb + i];
+          const double r1 = lm_sum + p_rb;                    // leftmost_p_sum + rightmost_begin.p
+          dd[2] = fma(r1, v_lb, dd[2]);
+          dd[3] = fma(r1, v_rb, dd[3]);
+          const double p_le = (lm_end == t) ? A.P[to + i] : A.P[ole + i];
+          const double v_le = (lm_end == t) ? vt[e] : A.V[ole + i];
+          const double v_re = (rm_end == t) ? vt[e] : A.V[ore + i];
+          const double r2 = p_le + rm_sum;                    // leftmost_end.p + rightmost_p_sum
+          dd[4] = fma(r2, v_le, dd[4]);
+          dd[5] = fma(r2, v_re, dd[5]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(DOT_TOP + k) * nwaves + w] = s; }
+    }
+  }
+  m_out = m; last_out = last;
+}
+
 // sum_{s in [s0, s1)} base[s * stride], in index order, with up to 8 loads in flight at a time
 __device__ __forceinline__ double sum_strided(const double* base, int stride, int s0, int s1) {
   double acc = 0.0;
@@ -490,7 +631,11 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   // ---- second half kick + tree-merge dot products (wave partials land in s_red) ----
   int m = 0; bool last = false;
   TICK(md, tk, 5);
-  if (leaf) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last);
+  if (leaf && !io.dense) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last);
+  if (leaf && io.dense) {   // dense mass matrix: only the kick here; v' = C p' needs the mat-vec that follows
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) if (act[e]) A.P[lf.d_o + idx[e]] = fma(lf.half, grad[e], ph[e]);
+  }
   TICK(md, tk, 6);
 
   // ---- per-workgroup partials: logp, broadcast terms, hyper-parameter sums of the logit node, dots ----
@@ -525,7 +670,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     for (int t = t0; t < VEC_THREADS; t += D) sdz += s_dz[which][t];
     part[(which ? PART_DSG : PART_DMU) + dd] = sdz;
   }
-  if (leaf) {
+  if (leaf && !io.dense) {
     for (int k = tid; k < NDOT; k += VEC_THREADS) {
       if (!dot_needed(k, m, last)) continue;
       double r = 0.0;
@@ -534,6 +679,34 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     }
   }
   TICK(md, tk, 7);
+}
+
+// ---------------------------------------------------------------------------
+// dense mass matrix: tree vector work of one leaf, after v' = C p' (per-workgroup partial dot products)
+// ---------------------------------------------------------------------------
+template <int EPT>
+__global__ __launch_bounds__(VEC_THREADS) void k_tree_vec(ModelDev md, ArenaDev A, EvalIO io, int j, int d) {
+  Leaf lf; QView qv;
+  if (load_aborted(io, A)) return;
+  resolve_leaf(io, A, j, lf, qv);
+  constexpr int NW = VEC_THREADS / WAVE;
+  __shared__ double s_red[NDOT * NW];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * VEC_THREADS * EPT;
+  double* part = md.part + (int64_t)blockIdx.x * md.part_stride;
+  int idx[EPT];
+  bool act[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) { idx[e] = base + e * VEC_THREADS + tid; act[e] = idx[e] < md.n; }
+  int m = 0; bool last = false;
+  tree_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, s_red, NW, m, last);
+  __syncthreads();
+  for (int k = tid; k < NDOT; k += VEC_THREADS) {
+    if (!dot_needed(k, m, last)) continue;
+    double r = 0.0;
+    for (int w = 0; w < NW; ++w) r += s_red[k * NW + w];
+    part[PART_DOT + k] = r;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -546,6 +719,58 @@ __device__ __forceinline__ void ctl_next_direction(Ctl* c, const double* uniform
   c->dir = (u < 0.5) ? 1 : -1;
   c->eps = c->dir > 0 ? c->eps_abs : -c->eps_abs;
   c->edge = c->dir > 0 ? c->right : c->left;
+}
+
+// Scalar decisions of one leaf (nuts.py:394-476 and, on the last leaf, `extend` 334-392), on the LDS copy of the
+// control block.  `dot` = the reduced dot products of this leaf, E its energy.
+__device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Leaf& lf, const double* dot, double E, int m, bool last,
+                                            double Emax, int max_depth) {
+  const int t = lf.t;
+  const int dir = lf.dir;
+  double dE = E - c->E0;                 // nuts.py:408-410
+  if (isnan(dE)) dE = INFINITY;
+  c->log_accept_sum = logaddexp_d(c->log_accept_sum, dE > 0 ? -dE : 0.0);  // nuts.py:412-414
+  if (fabs(dE) > fabs(c->max_energy_change)) c->max_energy_change = dE;     // nuts.py:417-418
+  c->n_proposals += 1;                                                      // nuts.py:436-437
+  c->n_leaves_total += 1;
+  if (!(dE < Emax)) {                                                       // nuts.py:419,433-435
+    c->diverging = 1; c->aborted = 1; c->div_dE = dE;
+    c->depth += 1;                                                          // extend: self.depth += 1 happens regardless
+  } else {
+    double cur_ls = -dE;
+    int cur_prop = t;
+    bool turning = false;
+    for (int l = 0; l < m && !turning; ++l) {
+      const double* dd = &dot[1 + 6 * l];
+      turning = (dd[0] <= 0) || (dd[1] <= 0);
+      if (!turning && l >= 1) {
+        turning = (dd[2] <= 0) || (dd[3] <= 0);
+        if (!turning) turning = (dd[4] <= 0) || (dd[5] <= 0);
+      }
+      const double ls = logaddexp_d(c->st_ls[l], cur_ls);                   // nuts.py:464
+      const double logu = A.log_uniforms[c->cursor++];
+      if (logu < cur_ls - ls) { /* keep tree2's proposal */ } else cur_prop = c->st_prop[l];
+      cur_ls = ls;
+    }
+    if (turning) {
+      c->turning = 1; c->aborted = 1; c->depth += 1;
+    } else if (!last) {
+      c->st_ls[m] = cur_ls; c->st_prop[m] = cur_prop;
+    } else {
+      // extend (nuts.py:365-392)
+      if (dir > 0) c->right = t; else c->left = t;
+      c->depth += 1;
+      const double logu = A.log_uniforms[c->cursor++];
+      if (logu < cur_ls - c->log_size) c->proposal = cur_prop;
+      c->log_size = logaddexp_d(cur_ls, c->log_size);
+      const double* dd = &dot[DOT_TOP];
+      bool turn = (dd[0] <= 0) || (dd[1] <= 0);
+      if (!turn) turn = (dd[2] <= 0) || (dd[3] <= 0);
+      if (!turn) turn = (dd[4] <= 0) || (dd[5] <= 0);
+      if (turn) { c->turning = 1; c->aborted = 1; }
+      else if (c->depth < max_depth) ctl_next_direction(c, A.uniforms);
+    }
+  }
 }
 
 #define CTL_CHUNKS 8   // the per-workgroup partials are summed in CTL_CHUNKS contiguous chunks, then the chunks in order
@@ -671,6 +896,14 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
     else io.grad[idx[0]] = grad[0];
   }
   TICK(md, tk, 21);
+  if (leaf && io.dense) {
+    // dense mass matrix: kick the deferred elements, publish logp, stop -- energy and tree logic follow in
+    // k_tree_ctl once v' = C p' is known
+    if (mine) A.P[lf.d_o + idx[0]] = fma(lf.half, grad[0], ph[0]);
+    const double lpd = block_sum<true>(lp, s_w);
+    if (tid == 0) A.LOGP[lf.t & (A.S - 1)] = s_sum[PART_LP] + lpd + (md.has_mvn ? md.mv.konst : 0.0);
+    return;
+  }
   int m2 = 0; bool last2 = false;
   if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2);
   TICK(md, tk, 22);
@@ -698,57 +931,65 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   A.E[ts] = E;
   if (!tree) return;
 
-  // ---- scalar decisions of one leaf (nuts.py:394-476 and, on the last leaf, 334-392), on the LDS copy of ctl ----
+  tree_decide(&s_ctl, A, lf, dot, E, m, last, Emax, max_depth);
   Ctl* c = &s_ctl;
-  const int dir = lf.dir;
-  double dE = E - c->E0;                 // nuts.py:408-410
-  if (isnan(dE)) dE = INFINITY;
-  c->log_accept_sum = logaddexp_d(c->log_accept_sum, dE > 0 ? -dE : 0.0);  // nuts.py:412-414
-  if (fabs(dE) > fabs(c->max_energy_change)) c->max_energy_change = dE;     // nuts.py:417-418
-  c->n_proposals += 1;                                                      // nuts.py:436-437
-  c->n_leaves_total += 1;
-  if (!(dE < Emax)) {                                                       // nuts.py:419,433-435
-    c->diverging = 1; c->aborted = 1; c->div_dE = dE;
-    c->depth += 1;                                                          // extend: self.depth += 1 happens regardless
-  } else {
-    double cur_ls = -dE;
-    int cur_prop = t;
-    bool turning = false;
-    for (int l = 0; l < m && !turning; ++l) {
-      const double* dd = &dot[1 + 6 * l];
-      turning = (dd[0] <= 0) || (dd[1] <= 0);
-      if (!turning && l >= 1) {
-        turning = (dd[2] <= 0) || (dd[3] <= 0);
-        if (!turning) turning = (dd[4] <= 0) || (dd[5] <= 0);
-      }
-      const double ls = logaddexp_d(c->st_ls[l], cur_ls);                   // nuts.py:464
-      const double logu = A.log_uniforms[c->cursor++];
-      if (logu < cur_ls - ls) { /* keep tree2's proposal */ } else cur_prop = c->st_prop[l];
-      cur_ls = ls;
-    }
-    if (turning) {
-      c->turning = 1; c->aborted = 1; c->depth += 1;
-    } else if (!last) {
-      c->st_ls[m] = cur_ls; c->st_prop[m] = cur_prop;
-    } else {
-      // extend (nuts.py:365-392)
-      if (dir > 0) c->right = t; else c->left = t;
-      c->depth += 1;
-      const double logu = A.log_uniforms[c->cursor++];
-      if (logu < cur_ls - c->log_size) c->proposal = cur_prop;
-      c->log_size = logaddexp_d(cur_ls, c->log_size);
-      const double* dd = &dot[DOT_TOP];
-      bool turn = (dd[0] <= 0) || (dd[1] <= 0);
-      if (!turn) turn = (dd[2] <= 0) || (dd[3] <= 0);
-      if (!turn) turn = (dd[4] <= 0) || (dd[5] <= 0);
-      if (turn) { c->turning = 1; c->aborted = 1; }
-      else if (c->depth < max_depth) ctl_next_direction(c, A.uniforms);
-    }
-  }
   TICK(md, tk, 24);
   *A.ctl = *c;
   if (st) publish_status(c, st, seq);
   TICK(md, tk, 25);
+}
+
+// ---------------------------------------------------------------------------
+// dense mass matrix: energy + tree logic of one leaf (one workgroup), after k_tree_vec
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(VEC_THREADS) void k_tree_ctl(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
+                                                         int max_depth, HostStatus* st, int seq) {
+  Leaf lf; QView qv;
+  resolve_leaf(io, A, j, lf, qv);
+  __shared__ double s_dot[NDOT];
+  __shared__ double s_chunk[CTL_CHUNKS][NDOT];
+  __shared__ Ctl s_ctl;
+  const int tid = threadIdx.x;
+  const bool tree = io.mode == MODE_TREE;
+  int m = 0;
+  bool last = false;
+  if (tree) {
+    while (((j >> m) & 1) && m < d) ++m;
+    last = (j + 1 == (1 << d));
+  }
+  if (tid < (int)(sizeof(Ctl) / sizeof(int))) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(A.ctl)[tid];
+  const int nn = 1 + 6 * m + (last ? 6 : 0);
+  auto need_dot = [&](int q) { return q < 1 + 6 * m ? q : DOT_TOP + (q - 1 - 6 * m); };
+  {
+    const int per = (md.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
+    for (int t = tid; t < nn * CTL_CHUNKS; t += VEC_THREADS) {
+      const int c = t % CTL_CHUNKS, k = need_dot(t / CTL_CHUNKS);
+      const int b0 = c * per, b1 = min(md.nblk, (c + 1) * per);
+      s_chunk[c][k] = sum_strided(md.part + PART_DOT + k, md.part_stride, b0, b1);
+    }
+  }
+  const int ts = lf.t & (A.S - 1);
+  const double logp = A.LOGP[ts];
+  __syncthreads();
+  if (tree && s_ctl.aborted) {   // terminated earlier in this doubling: drain
+    if (tid == 0 && st) publish_status(&s_ctl, st, seq);
+    return;
+  }
+  for (int t = tid; t < nn; t += VEC_THREADS) {
+    const int k = need_dot(t);
+    double sacc = 0.0;
+#pragma unroll
+    for (int c = 0; c < CTL_CHUNKS; ++c) sacc += s_chunk[c][k];
+    s_dot[k] = sacc;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const double E = 0.5 * s_dot[0] - logp;  // integration.py:133-134
+  A.E[ts] = E;
+  if (!tree) return;
+  tree_decide(&s_ctl, A, lf, s_dot, E, m, last, Emax, max_depth);
+  *A.ctl = s_ctl;
+  if (st) publish_status(&s_ctl, st, seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -760,16 +1001,22 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
 // (the values the model pass would reproduce bit for bit; the reference recomputes them, base_hmc.py:202)
 __global__ __launch_bounds__(VEC_THREADS) void k_draw_start(ArenaDev A, const double* __restrict__ normals,
                                                             const double* __restrict__ p_exact, double* __restrict__ kin_part,
-                                                            const double* __restrict__ q_src, const double* __restrict__ g_src) {
+                                                            const double* __restrict__ q_src, const double* __restrict__ g_src,
+                                                            int dense) {
   __shared__ double sm[VEC_THREADS / WAVE];
   double kin = 0.0;
   const int base = blockIdx.x * VEC_THREADS * A.ept;
   for (int e = 0; e < A.ept; ++e) {
     const int i = base + e * VEC_THREADS + threadIdx.x;
     if (i < A.n) {
-      const double p = p_exact ? p_exact[i] : normals[i] * A.inv_stds[i];
-      const double v = A.var[i] * p;
-      A.P[i] = p; A.V[i] = v; A.PSUM[i] = p;
+      double p, v;
+      if (dense) { p = A.P[i]; v = A.V[i]; }   // p0 = W z and v0 = C p0 were produced by k_dense_mv
+      else {
+        p = p_exact ? p_exact[i] : normals[i] * A.inv_stds[i];
+        v = A.var[i] * p;
+        A.P[i] = p; A.V[i] = v;
+      }
+      A.PSUM[i] = p;
       if (q_src) { A.Q[i] = q_src[i]; A.G[i] = g_src[i]; }
       kin = fma(p, v, kin);
     }

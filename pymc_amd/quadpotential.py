@@ -151,10 +151,54 @@ class QuadPotentialDiag(QuadPotential):
         return [self.v]
 
 
+class QuadPotentialFull(QuadPotential):
+    """Dense covariance (quadpotential.py:680-725): velocity = cov @ p, random = solve(chol^T, z).
+
+    The factorisation happens once, here, on the host (the reference does the same in its constructor); per
+    leapfrog the device runs the mat-vec `v = C p` (`k_dense_mv`), per draw `p0 = W z` with W = chol^-T.
+    """
+
+    def __init__(self, cov, dtype=None, rng=None):
+        import scipy.linalg
+
+        cov = np.array(cov, dtype="float64", copy=True)
+        if cov.ndim != 2 or cov.shape[0] != cov.shape[1]:
+            raise ValueError("covariance must be a square matrix")
+        super().__init__(rng)
+        self._cov = np.ascontiguousarray(cov)
+        self._chol = scipy.linalg.cholesky(self._cov, lower=True)
+        self._n = len(cov)
+        # random(): solve_triangular(chol.T, z)  ==  W z  with  W = (chol^T)^-1
+        self._rand = np.ascontiguousarray(scipy.linalg.solve_triangular(self._chol.T, np.eye(self._n), lower=False))
+
+    def _fill_config(self, cfg):
+        cfg.potential = POT_FULL
+        cfg.dense_cov = _lib.dptr(self._cov)
+        cfg.dense_rand = _lib.dptr(self._rand)
+        return [self._cov, self._rand]
+
+
+class QuadPotentialFullInv(QuadPotentialFull):
+    """Dense precision A (quadpotential.py:633-677): velocity = cho_solve(L, p), random = L z, L = chol(A)."""
+
+    def __init__(self, A, dtype=None, rng=None):
+        import scipy.linalg
+
+        A = np.array(A, dtype="float64", copy=True)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("precision must be a square matrix")
+        QuadPotential.__init__(self, rng)
+        self.L = scipy.linalg.cholesky(A, lower=True)
+        self._n = len(A)
+        cov = scipy.linalg.cho_solve((self.L, True), np.eye(self._n))
+        self._cov = np.ascontiguousarray(0.5 * (cov + cov.T))
+        self._rand = np.ascontiguousarray(self.L)
+
+
 def quad_potential(C, is_cov, rng=None):
-    """Factory of quadpotential.py:53-91 (diagonal scalings; dense ones are a later round)."""
+    """Factory of quadpotential.py:53-91 (sparse scalings need scikit-sparse and are excluded)."""
     C = np.asarray(C, dtype="float64")
     partial_check_positive_definite(C)
     if C.ndim == 1:
         return QuadPotentialDiag(C if is_cov else 1.0 / C, rng=rng)
-    raise NotImplementedError("dense scaling matrices need the dense device potential (later round)")
+    return QuadPotentialFull(C, rng=rng) if is_cov else QuadPotentialFullInv(C, rng=rng)

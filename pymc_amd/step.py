@@ -36,7 +36,7 @@ import numpy as np
 from pymc_amd import _lib
 from pymc_amd.blocking import DictToArrayBijection, PointType, RaveledVars
 from pymc_amd.model_spec import ModelSpec
-from pymc_amd.quadpotential import QuadPotentialDiag, QuadPotentialDiagAdapt
+from pymc_amd.quadpotential import QuadPotentialDiagAdapt, quad_potential
 from pymc_amd.value_grad import DeviceValueGradFunction
 
 
@@ -137,11 +137,8 @@ class _DeviceHMCBase:
             raise ValueError("Can not specify both potential and scaling.")
         if potential is None and scaling is None:
             potential = QuadPotentialDiagAdapt(n, np.zeros(n), np.ones(n), 10, rng=self.rng.spawn(1)[0])
-        elif potential is None:
-            scaling = np.asarray(scaling, dtype="float64")
-            if scaling.ndim != 1:
-                raise NotImplementedError("dense `scaling` needs the dense device potential (later round)")
-            potential = QuadPotentialDiag(scaling if is_cov else 1.0 / scaling, rng=self.rng.spawn(1)[0])
+        elif potential is None:  # base_hmc.py:171-180 -> quad_potential(scaling, is_cov)
+            potential = quad_potential(np.asarray(scaling, dtype="float64"), is_cov, rng=self.rng.spawn(1)[0])
         self.potential = potential
         lib = _lib.load()
         cfg = _lib.ChainConfig()

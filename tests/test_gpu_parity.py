@@ -402,6 +402,84 @@ def test_posterior_matches_oracle_within_monte_carlo_error():
     res["step"].close()
 
 
+def _dense_cov(n, seed):
+    rng = np.random.RandomState(seed)
+    cov = rng.rand(n, n)
+    cov += cov.T
+    cov += 10 * np.eye(n)   # tests/step_methods/hmc/test_quadpotential.py:76-79
+    return cov
+
+
+def test_dense_potential_velocity_energy_and_leapfrog():
+    """QuadPotentialFull / FullInv (quadpotential.py:633-725; test_quadpotential.py:73-95 `test_equal_dense`):
+    kinetic energy 0.5 p.(C p) and leapfrog steps against the oracle's dense potentials."""
+    import ctypes as C
+
+    from pymc_amd import _lib
+    from pymc_amd.quadpotential import QuadPotentialFull, QuadPotentialFullInv, quad_potential
+    from pymc_amd.step import NUTS
+
+    spec = models.eight_schools()
+    n = spec.n
+    cov = _dense_cov(n, 42) / 10.0
+    inv = np.linalg.inv(cov)
+    f = ref_models.SpecLogpGrad(spec)
+    rng = np.random.default_rng(0)
+    q0, p0 = rng.normal(size=n) * 0.3, rng.normal(size=n)
+    assert isinstance(quad_potential(cov, True), QuadPotentialFull) and isinstance(quad_potential(inv, False), QuadPotentialFullInv)
+    for pot_dev, pot_ref in [(QuadPotentialFull(cov), ref_sampler.FullPotential(cov)), (QuadPotentialFullInv(inv), ref_sampler.FullInvPotential(inv))]:
+        step = NUTS(model=spec, potential=pot_dev, rng=1, device=0)
+        integ = ref_sampler.Leapfrog(pot_ref, f)
+        lib = _lib.load()
+        e = C.c_double()
+        q1, p1 = np.empty(n), np.empty(n)
+        _lib.check(lib.nuts_chain_leapfrog_test(step._chain, _lib.dptr(q0), _lib.dptr(p0), 0.05, 0, _lib.dptr(q1), _lib.dptr(p1), C.byref(e)))
+        s = integ.compute_state(q0, p0)
+        np.testing.assert_allclose(e.value + f(q0)[0], 0.5 * p0 @ np.linalg.solve(inv, p0), rtol=1e-10)   # kinetic energy
+        np.testing.assert_allclose(e.value, s.energy, rtol=1e-10)
+        for _ in range(9):
+            s = integ.step(0.05, s)
+        _lib.check(lib.nuts_chain_leapfrog_test(step._chain, _lib.dptr(q0), _lib.dptr(p0), 0.05, 9, _lib.dptr(q1), _lib.dptr(p1), C.byref(e)))
+        np.testing.assert_allclose(q1, s.q, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(p1, s.p, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(e.value, s.energy, rtol=1e-9)
+        step.close()
+
+
+@pytest.mark.parametrize("kind", ["full", "fullinv"])
+def test_nuts_with_dense_potential_matches_oracle(kind):
+    """`pm.NUTS(scaling=<matrix>, is_cov=...)` (base_hmc.py:171-180): same seed => same integers as the oracle."""
+    from pymc_amd.blocking import RaveledVars
+    from pymc_amd.step import NUTS
+
+    spec = models.hier_logit(G=6, D=4, rows_per_group=30, seed=5)
+    n = spec.n
+    cov = _dense_cov(n, 7) / 40.0
+    f = ref_models.SpecLogpGrad(spec)
+    if kind == "full":
+        step = NUTS(model=spec, scaling=cov, is_cov=True, rng=3, device=0)
+        ref = ref_sampler.RefNUTS(f, n, potential=ref_sampler.FullPotential(cov), rng=3)
+    else:
+        A = np.linalg.inv(cov)
+        step = NUTS(model=spec, scaling=A, is_cov=False, rng=3, device=0)
+        ref = ref_sampler.RefNUTS(f, n, potential=ref_sampler.FullInvPotential(A), rng=3)
+    step.setup_chain(np.random.default_rng(11), 20, 10)
+    ref.setup_chain(np.random.default_rng(11), 20, 10)
+    q = RaveledVars(np.zeros(n), spec.point_map_info)
+    qr = np.zeros(n)
+    for i in range(30):
+        if i == 20:
+            step.stop_tuning(); ref.stop_tuning()
+        q, st = step.astep(q)
+        qr, sr = ref.astep(qr)
+        for k in INT_KEYS:
+            assert int(st[0][k]) == int(sr[k]), (i, k, st[0][k], sr[k])
+        rtol = 1e-7 if i < 8 else 2e-2
+        np.testing.assert_allclose(q.data, qr, rtol=rtol, atol=1e-3 if i >= 8 else 1e-9)
+    assert step.rng.bit_generator.state == ref.rng.bit_generator.state
+    step.close()
+
+
 def test_hmc_matches_oracle():
     from pymc_amd.blocking import RaveledVars
     from pymc_amd.step import HamiltonianMC
