@@ -234,6 +234,14 @@ int nuts_chain_set_state(nuts_chain *c, const void *blob);
 int nuts_chain_get_scalar(nuts_chain *c, const char *name, double *out);
 int nuts_chain_get_vector(nuts_chain *c, const char *name, double *out /* [n] */);
 
+/* Host-adapted mass matrices.  QuadPotentialFullAdapt (quadpotential.py:748-852) and QuadPotentialDiagAdaptExp
+ * (:458-579) keep their estimators on the host, exactly where the reference keeps them (the O(n^3) Cholesky of
+ * FullAdapt is a LAPACK call there too); after an update the host pushes the new matrix to the device.
+ *   nuts_chain_set_dense: cov [n][n], rand [n][n] (random() = rand z), chain created with NUTS_POT_FULL
+ *   nuts_chain_set_diag : var, stds, inv_stds [n],                     chain created with NUTS_POT_DIAG        */
+int nuts_chain_set_dense(nuts_chain *c, const double *cov, const double *rand);
+int nuts_chain_set_diag(nuts_chain *c, const double *var, const double *stds, const double *inv_stds);
+
 /* Pooled adaptation (opt-in, NOT reference behaviour):
  * export/import the foreground+background Welford partials as
  * [count_fg, mean_fg[n], m2_fg[n], count_bg, mean_bg[n], m2_bg[n]] so the caller can

@@ -185,6 +185,66 @@ class DiagAdaptPotential(PotentialBase):
             raise ValueError("Mass matrix contains non-finite values on the diagonal. ")
 
 
+class ExpWeightedVariance:
+    """_ExpWeightedVariance (quadpotential.py:458-483)."""
+
+    def __init__(self, mean, var, alpha):
+        self.mean, self.var, self.alpha = mean, var, alpha
+
+    def add(self, x):
+        d = x - self.mean
+        self.mean += self.alpha * d
+        self.var[...] = (1 - self.alpha) * (self.var + self.alpha * d**2)
+
+
+class DiagAdaptExpPotential(PotentialBase):
+    """QuadPotentialDiagAdaptExp (quadpotential.py:486-579), as built by `init="jitter+adapt_diag_grad"`."""
+
+    def __init__(self, n, initial_mean, initial_diag=None, alpha=0.02, use_grads=True, stop_adaptation=None,
+                 discard_window=50, rng=None):
+        self.n = n
+        self.initial_diag = np.ones(n) if initial_diag is None else np.asarray(initial_diag, dtype="d")
+        self.alpha, self.use_grads = alpha, use_grads
+        self.stop = np.inf if stop_adaptation is None else stop_adaptation
+        self.discard_window = discard_window
+        self.rng = np.random.default_rng(rng)
+        self.reset()
+
+    def reset(self):
+        self.var = np.array(self.initial_diag, copy=True)
+        self.stds = np.sqrt(self.var)
+        self.inv_stds = 1.0 / self.stds
+        self.est = self.est_grad = None
+        self.n_samples = 0
+
+    def velocity(self, p):
+        return self.var * p
+
+    def random(self):
+        return self.inv_stds * self.rng.normal(size=self.n)
+
+    def update(self, sample, grad, tune):  # quadpotential.py:534-569
+        if not (tune and self.n_samples < self.stop):
+            return
+        k = self.n_samples
+        if k > self.discard_window:
+            self.est.add(sample)
+            if self.use_grads:
+                self.est_grad.add(grad)
+        elif k == self.discard_window:
+            self.est = ExpWeightedVariance(np.array(sample, copy=True), np.zeros_like(sample), self.alpha)
+            if self.use_grads:
+                self.est_grad = ExpWeightedVariance(np.array(grad, copy=True), np.zeros_like(grad), self.alpha)
+        if k > 2 * self.discard_window:
+            if self.use_grads:  # :571-579
+                self.var = np.sqrt(self.est.var / self.est_grad.var)
+            else:  # :328-333
+                self.var = np.clip(self.est.var, 1e-12, 1e12)
+            self.stds = np.sqrt(self.var)
+            self.inv_stds = 1.0 / self.stds
+        self.n_samples += 1
+
+
 class DiagPotential(PotentialBase):
     """QuadPotentialDiag: fixed diagonal covariance (quadpotential.py:582-630)."""
 
@@ -757,7 +817,16 @@ def sample_reference(
         starts = [jitter_start(q, s, lambda x: logp_grad(x)[0]) for q, s in zip(starts, seeds)]
     all_draws, all_stats = [], []
     for c in range(chains):
-        pot = adapt_diag_potential(starts, seeds[0])
+        mean = np.mean(np.asarray(starts), axis=0)
+        if init in ("adapt_diag", "jitter+adapt_diag"):  # mcmc.py:1884-1893
+            pot = adapt_diag_potential(starts, seeds[0])
+        elif init == "jitter+adapt_diag_grad":  # mcmc.py:1894-1911
+            stop = tune - 50 if tune is not None and tune > 250 else None
+            pot = DiagAdaptExpPotential(n, mean, alpha=0.02, use_grads=True, stop_adaptation=stop, rng=seeds[0])
+        elif init in ("adapt_full", "jitter+adapt_full"):  # mcmc.py:1984-2000
+            pot = FullAdaptPotential(n, mean, np.eye(n), 10, rng=seeds[0])
+        else:
+            raise ValueError(init)
         step = RefNUTS(logp_grad, n, potential=pot, rng=seeds[0], **step_kwargs)
         d, s = run_chain(step, starts[c], rngs[c], tune, draws)
         all_draws.append(d)

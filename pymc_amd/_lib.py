@@ -183,6 +183,8 @@ SYMBOLS = {
     "nuts_chain_set_state": (C.c_int, [_VP, _VP]),
     "nuts_chain_get_scalar": (C.c_int, [_VP, C.c_char_p, _PD]),
     "nuts_chain_get_vector": (C.c_int, [_VP, C.c_char_p, _PD]),
+    "nuts_chain_set_dense": (C.c_int, [_VP, _PD, _PD]),
+    "nuts_chain_set_diag": (C.c_int, [_VP, _PD, _PD, _PD]),
     "nuts_chain_welford_export": (C.c_int, [_VP, _VP]),
     "nuts_chain_welford_import": (C.c_int, [_VP, _VP]),
     "nuts_chain_set_log_step_bar": (C.c_int, [_VP, C.c_double, C.c_double]),

@@ -1095,6 +1095,26 @@ extern "C" int nuts_chain_get_vector(nuts_chain* c, const char* name, double* ou
   return NUTS_OK;
 }
 
+// ---- host-adapted mass matrices: push the new matrix after a host-side update ------------------------------
+extern "C" int nuts_chain_set_dense(nuts_chain* c, const double* cov, const double* rand) {
+  if (!c || !cov || !rand) return NUTS_E_ARG;
+  if (!c->dense) { g_err = "nuts_chain_set_dense: the chain was not created with NUTS_POT_FULL"; return NUTS_E_ARG; }
+  const size_t nn = (size_t)c->n * c->n;
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  HIPCHK(hipMemcpy(c->dense_C, cov, nn * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->dense_W, rand, nn * sizeof(double), hipMemcpyHostToDevice));
+  return NUTS_OK;
+}
+extern "C" int nuts_chain_set_diag(nuts_chain* c, const double* var, const double* stds, const double* inv_stds) {
+  if (!c || !var || !stds || !inv_stds) return NUTS_E_ARG;
+  if (c->dense) { g_err = "nuts_chain_set_diag: the chain has a dense potential"; return NUTS_E_ARG; }
+  HIPCHK(hipStreamSynchronize(c->m->stream));
+  HIPCHK(hipMemcpy(c->var, var, c->n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->stds, stds, c->n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->inv_stds, inv_stds, c->n * sizeof(double), hipMemcpyHostToDevice));
+  return NUTS_OK;
+}
+
 // ---- pooled adaptation hooks (opt-in; not reference behaviour) -----------------
 extern "C" int nuts_chain_welford_export(nuts_chain* c, double* buf) {
   if (!c || !buf) return NUTS_E_ARG;

@@ -58,6 +58,22 @@ class QuadPotential:
     def stats(self):  # quadpotential.py:177-178
         return {"largest_eigval": np.nan, "smallest_eigval": np.nan}
 
+    # potentials whose estimators live on the host (FullAdapt, DiagAdaptExp) override these three
+    def _host_update(self, sample, grad, tune):
+        return None
+
+    def _host_reset(self):
+        return None
+
+    def _host_state(self):
+        return None
+
+    def _set_host_state(self, state):
+        return None
+
+    def raise_ok(self, map_info=None):
+        return None
+
     # device views ---------------------------------------------------------
     def _vec(self, name):
         if self._step is None:
@@ -193,6 +209,234 @@ class QuadPotentialFullInv(QuadPotentialFull):
         cov = scipy.linalg.cho_solve((self.L, True), np.eye(self._n))
         self._cov = np.ascontiguousarray(0.5 * (cov + cov.T))
         self._rand = np.ascontiguousarray(self.L)
+
+
+class _WeightedCovariance:
+    """Welford mean / covariance with a prior block (quadpotential.py:855-910)."""
+
+    def __init__(self, nelem, initial_mean=None, initial_covariance=None, initial_weight=0):
+        self.n_samples = float(initial_weight)
+        self.mean = np.zeros(nelem) if initial_mean is None else np.array(initial_mean, dtype="d", copy=True)
+        self.raw_cov = np.eye(nelem) if initial_covariance is None else np.array(initial_covariance, dtype="d", copy=True)
+        self.raw_cov[:] *= self.n_samples
+        if self.raw_cov.shape != (nelem, nelem):
+            raise ValueError("Invalid shape for initial covariance.")
+        if self.mean.shape != (nelem,):
+            raise ValueError("Invalid shape for initial mean.")
+
+    def add_sample(self, x):
+        x = np.asarray(x)
+        self.n_samples += 1
+        old_diff = x - self.mean
+        self.mean[:] += old_diff / self.n_samples
+        new_diff = x - self.mean
+        self.raw_cov[:] += new_diff[:, None] * old_diff[None, :]
+
+    def current_covariance(self, out=None):
+        if self.n_samples == 0:
+            raise ValueError("Can not compute covariance without samples.")
+        if out is not None:
+            return np.divide(self.raw_cov, self.n_samples - 1, out=out)
+        return self.raw_cov / (self.n_samples - 1)
+
+    def current_mean(self):
+        return np.array(self.mean)
+
+
+class QuadPotentialFullAdapt(QuadPotentialFull):
+    """Dense mass matrix adapted from the sample covariance (quadpotential.py:748-852).
+
+    The estimators and the per-update Cholesky stay on the host (that is where the reference keeps them: an
+    O(n^2) rank-1 update and a LAPACK `potrf` per tuning draw); the adapted covariance and `chol^-T` are pushed to
+    the device (`nuts_chain_set_dense`), where every leapfrog uses them.
+    """
+
+    def __init__(self, n, initial_mean, initial_cov=None, initial_weight=0, adaptation_window=101,
+                 adaptation_window_multiplier=2, update_window=1, dtype=None, rng=None):
+        import warnings
+
+        warnings.warn("QuadPotentialFullAdapt is an experimental feature")
+        initial_mean = np.asarray(initial_mean, dtype="float64")
+        if initial_cov is not None and np.ndim(initial_cov) != 2:
+            raise ValueError("Initial covariance must be two-dimensional.")
+        if initial_mean.ndim != 1:
+            raise ValueError("Initial mean must be one-dimensional.")
+        if initial_cov is not None and np.shape(initial_cov) != (n, n):
+            raise ValueError(f"Wrong shape for initial_cov: expected {n} got {np.shape(initial_cov)}")
+        if len(initial_mean) != n:
+            raise ValueError(f"Wrong shape for initial_mean: expected {n} got {len(initial_mean)}")
+        if initial_cov is None:
+            initial_cov = np.eye(n)
+            initial_weight = 1
+        QuadPotential.__init__(self, rng)
+        self._n = n
+        self._initial_mean = initial_mean
+        self._initial_cov = np.asarray(initial_cov, dtype="float64")
+        self._initial_weight = initial_weight
+        self._adaptation_window0 = int(adaptation_window)
+        self.adaptation_window = int(adaptation_window)
+        self.adaptation_window_multiplier = float(adaptation_window_multiplier)
+        self._update_window = int(update_window)
+        self._host_reset()
+
+    def _factor(self):
+        import scipy.linalg
+
+        self._chol = scipy.linalg.cholesky(self._cov, lower=True)
+        self._rand = np.ascontiguousarray(scipy.linalg.solve_triangular(self._chol.T, np.eye(self._n), lower=False))
+
+    def _host_reset(self):  # quadpotential.py:801-810 (adaptation_window is not reset)
+        self._previous_update = 0
+        self._cov = np.array(self._initial_cov, dtype="float64", copy=True)
+        self._factor()
+        self._chol_error = None
+        self._foreground_cov = _WeightedCovariance(self._n, self._initial_mean, self._initial_cov, self._initial_weight)
+        self._background_cov = _WeightedCovariance(self._n)
+        self._n_samples = 0
+        self._push()
+
+    def _push(self):
+        if self._step is not None:
+            lib = _lib.load()
+            _lib.check(lib.nuts_chain_set_dense(self._step._chain, _lib.dptr(np.ascontiguousarray(self._cov)), _lib.dptr(self._rand)), "nuts_chain_set_dense")
+
+    def _bind(self, step):
+        super()._bind(step)
+        self._push()
+
+    def _host_update(self, sample, grad, tune):  # quadpotential.py:819-843
+        import scipy.linalg
+
+        if not tune:
+            return
+        delta = self._n_samples - self._previous_update
+        self._foreground_cov.add_sample(sample)
+        self._background_cov.add_sample(sample)
+        if (delta + 1) % self._update_window == 0:
+            self._foreground_cov.current_covariance(out=self._cov)
+            try:
+                self._factor()
+            except (scipy.linalg.LinAlgError, ValueError) as error:
+                self._chol_error = error
+            self._push()
+        if delta >= self.adaptation_window:
+            self._foreground_cov = self._background_cov
+            self._background_cov = _WeightedCovariance(self._n)
+            self._previous_update = self._n_samples
+            self.adaptation_window = int(self.adaptation_window * self.adaptation_window_multiplier)
+        self._n_samples += 1
+
+    def raise_ok(self, map_info=None):
+        if self._chol_error is not None:
+            raise ValueError(str(self._chol_error))
+
+    def _host_state(self):
+        import copy
+
+        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step")})
+
+    def _set_host_state(self, state):
+        import copy
+
+        self.__dict__.update(copy.deepcopy(state))
+        self._push()
+
+
+class _ExpWeightedVariance:
+    """quadpotential.py:458-483."""
+
+    def __init__(self, n_vars, *, init_mean, init_var, alpha):
+        self._variance, self._mean, self._alpha = init_var, init_mean, alpha
+
+    def add_sample(self, value):
+        alpha = self._alpha
+        delta = value - self._mean
+        self._mean[...] += alpha * delta
+        self._variance[...] = (1 - alpha) * (self._variance + alpha * delta**2)
+
+    def current_variance(self, out=None):
+        if out is None:
+            out = np.empty_like(self._variance)
+        np.copyto(out, self._variance)
+        return out
+
+
+class QuadPotentialDiagAdaptExp(QuadPotential):
+    """Exponentially weighted diagonal adaptation, optionally using gradients (quadpotential.py:486-579;
+    `init="jitter+adapt_diag_grad"`, mcmc.py:1895-1911).  Estimators on the host, the diagonal on the device."""
+
+    def __init__(self, n, initial_mean, initial_diag=None, *, alpha, use_grads=False, stop_adaptation=None, rng=None,
+                 discard_window=50, dtype=None):
+        initial_mean = np.asarray(initial_mean, dtype="float64")
+        if initial_diag is None:
+            initial_diag = np.ones(n)
+        super().__init__(rng)
+        self._n = n
+        self._initial_mean = initial_mean
+        self._initial_diag = np.ascontiguousarray(initial_diag, dtype="float64")
+        self._alpha, self._use_grads = alpha, use_grads
+        self._stop_adaptation = np.inf if stop_adaptation is None else stop_adaptation
+        self._discard_window = discard_window
+        self._host_reset()
+
+    def _fill_config(self, cfg):
+        cfg.potential = POT_DIAG
+        cfg.initial_diag = _lib.dptr(self._initial_diag)
+        cfg.initial_weight = 0.0
+        return [self._initial_diag]
+
+    def _host_reset(self):
+        self._hvar = np.array(self._initial_diag, copy=True)
+        self._hstds = np.sqrt(self._initial_diag)
+        self._hinv_stds = 1.0 / self._hstds
+        self._variance_estimator = None
+        self._variance_estimator_grad = None
+        self._n_samples_host = 0
+        self._push()
+
+    def _push(self):
+        if self._step is not None:
+            lib = _lib.load()
+            _lib.check(lib.nuts_chain_set_diag(self._step._chain, _lib.dptr(self._hvar), _lib.dptr(self._hstds), _lib.dptr(self._hinv_stds)), "nuts_chain_set_diag")
+
+    def _bind(self, step):
+        super()._bind(step)
+        self._push()
+
+    def _host_update(self, sample, grad, tune):  # quadpotential.py:534-569
+        if not (tune and self._n_samples_host < self._stop_adaptation):
+            return
+        k = self._n_samples_host
+        if k > self._discard_window:
+            self._variance_estimator.add_sample(sample)
+            if self._use_grads:
+                self._variance_estimator_grad.add_sample(grad)
+        elif k == self._discard_window:
+            self._variance_estimator = _ExpWeightedVariance(self._n, init_mean=np.array(sample, copy=True), init_var=np.zeros_like(sample), alpha=self._alpha)
+            if self._use_grads:
+                self._variance_estimator_grad = _ExpWeightedVariance(self._n, init_mean=np.array(grad, copy=True), init_var=np.zeros_like(grad), alpha=self._alpha)
+        if k > 2 * self._discard_window:
+            if self._use_grads:  # quadpotential.py:571-579
+                updated = np.sqrt(self._variance_estimator.current_variance() / self._variance_estimator_grad.current_variance())
+                self._hvar[:] = updated
+            else:  # quadpotential.py:328-333
+                self._variance_estimator.current_variance(out=self._hvar)
+                self._hvar = np.clip(self._hvar, 1e-12, 1e12)
+            self._hstds = np.sqrt(self._hvar)
+            self._hinv_stds = 1.0 / self._hstds
+            self._push()
+        self._n_samples_host += 1
+
+    def _host_state(self):
+        import copy
+
+        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step")})
+
+    def _set_host_state(self, state):
+        import copy
+
+        self.__dict__.update(copy.deepcopy(state))
+        self._push()
 
 
 def quad_potential(C, is_cov, rng=None):

@@ -25,7 +25,7 @@ import numpy as np
 
 from pymc_amd.blocking import DictToArrayBijection, RaveledVars
 from pymc_amd.model_spec import TR_INTERVAL, TR_LOG, TR_LOGODDS, ModelSpec
-from pymc_amd.quadpotential import QuadPotentialDiagAdapt
+from pymc_amd.quadpotential import QuadPotentialDiagAdapt, QuadPotentialDiagAdaptExp, QuadPotentialFullAdapt
 from pymc_amd.step import NUTS, get_random_generator
 
 
@@ -60,9 +60,11 @@ def init_nuts(
     logp_dlogp_func=None,
     jitter_max_retries: int = 10,
     device: Optional[int] = None,
+    tune: Optional[int] = None,
     **step_kwargs,
 ):
-    """`init_nuts` (mcmc.py:1759-2021) for the diag-adapt initialisers."""
+    """`init_nuts` (mcmc.py:1759-2021): adapt_diag, jitter+adapt_diag, jitter+adapt_diag_grad, adapt_full,
+    jitter+adapt_full."""
     from pymc_amd.value_grad import DeviceValueGradFunction
 
     if logp_dlogp_func is None:
@@ -86,11 +88,21 @@ def init_nuts(
             p = cand
         points.append(p)
     apoints = [DictToArrayBijection.map(p).data for p in points]
-    if init in ("adapt_diag", "jitter+adapt_diag"):  # mcmc.py:1886-1894
-        mean = np.mean(apoints, axis=0)
-        var = np.ones_like(mean)
-        potential = QuadPotentialDiagAdapt(len(var), mean, var, 10, rng=random_seed_list[0])
+    mean = np.mean(apoints, axis=0)
+    n = len(mean)
+    if init in ("adapt_diag", "jitter+adapt_diag"):  # mcmc.py:1884-1893
+        potential = QuadPotentialDiagAdapt(n, mean, np.ones_like(mean), 10, rng=random_seed_list[0])
+    elif init == "jitter+adapt_diag_grad":  # mcmc.py:1894-1911
+        stop_adaptation = tune - 50 if tune is not None and tune > 250 else None
+        potential = QuadPotentialDiagAdaptExp(n, mean, alpha=0.02, use_grads=True, stop_adaptation=stop_adaptation, rng=random_seed_list[0])
+    elif init in ("adapt_full", "jitter+adapt_full"):  # mcmc.py:1984-2000
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            potential = QuadPotentialFullAdapt(n, mean, np.eye(n), 10, rng=random_seed_list[0])
     else:
+        # advi / advi_map / map initialisers need variational inference and find_MAP: outside the NUTS path
         raise ValueError(f"Unknown or unsupported initializer: {init}.")
     step = NUTS(
         potential=potential, model=spec, rng=random_seed_list[0], initial_point=points[0],
@@ -227,7 +239,7 @@ def sample(
     mine = assign_chains(chains, rank, world)
     if step is None:
         points, step = init_nuts(
-            spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device, **step_kwargs
+            spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device, tune=tune, **step_kwargs
         )
     else:
         points = [dict(initial_point(spec)) for _ in range(chains)]

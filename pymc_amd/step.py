@@ -58,6 +58,7 @@ class BaseHMCState:
     rng: Dict[str, Any]
     potential_rng: Dict[str, Any]
     engine_blob: bytes
+    potential_host_state: Any = None   # estimators of host-adapted potentials (FullAdapt, DiagAdaptExp)
 
 
 def _rng_state(rng: np.random.Generator):
@@ -176,6 +177,7 @@ class _DeviceHMCBase:
     def reset_tuning(self, start=None):
         _lib.check(_lib.load().nuts_chain_reset_tuning(self._chain), "nuts_chain_reset_tuning")
         self._tune = True
+        self.potential._host_reset()
 
     reset = reset_tuning
 
@@ -226,7 +228,8 @@ class _DeviceHMCBase:
         size = lib.nuts_chain_state_size(self._chain)
         buf = C.create_string_buffer(size)
         _lib.check(lib.nuts_chain_get_state(self._chain, buf), "nuts_chain_get_state")
-        return BaseHMCState(list(self.var_names), _rng_state(self.rng), _rng_state(self.potential.rng), bytes(buf.raw))
+        return BaseHMCState(list(self.var_names), _rng_state(self.rng), _rng_state(self.potential.rng), bytes(buf.raw),
+                            self.potential._host_state())
 
     @sampling_state.setter
     def sampling_state(self, state: BaseHMCState):
@@ -236,6 +239,8 @@ class _DeviceHMCBase:
         _lib.check(_lib.load().nuts_chain_set_state(self._chain, buf), "nuts_chain_set_state")
         self.rng = _rng_from_state(state.rng)
         self.potential.set_rng(_rng_from_state(state.potential_rng))
+        if state.potential_host_state is not None:
+            self.potential._set_host_state(state.potential_host_state)
         self._tune = bool(self._scalar("tune"))
 
     def close(self):
@@ -342,6 +347,7 @@ class NUTS(_DeviceHMCBase):
             "largest_eigval": np.nan,
             "smallest_eigval": np.nan,
         }
+        self.potential._host_update(self._q_out, self._g_out, self.tune)   # base_hmc.py:239 for host-adapted potentials
         return RaveledVars(self._q_out.copy(), q0.point_map_info), [stats]
 
 
@@ -409,4 +415,5 @@ class HamiltonianMC(_DeviceHMCBase):
             "model_logp": st.model_logp, "step_size": st.step_size, "step_size_bar": st.step_size_bar,
             "largest_eigval": np.nan, "smallest_eigval": np.nan,
         }
+        self.potential._host_update(self._q_out, self._g_out, self.tune)
         return RaveledVars(self._q_out.copy(), q0.point_map_info), [stats]

@@ -256,13 +256,13 @@ def test_leapfrog_matches_oracle():
 INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
 
 
-def _compare_runs(spec, tune, draws, seed, prefix, **kw):
+def _compare_runs(spec, tune, draws, seed, prefix, init="adapt_diag", **kw):
     from pymc_amd.sampling import sample
 
-    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, **kw)
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init=init, random_seed=seed, device=0, **kw)
     f = ref_models.SpecLogpGrad(spec)
     ref_draws, ref_stats = ref_sampler.sample_reference(
-        f, [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag", **kw
+        f, [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init=init, **kw
     )
     dev_stats = res["warmup_stats"][0] + res["stats"][0]
     dev_draws = res["draws"][0]
@@ -477,6 +477,42 @@ def test_nuts_with_dense_potential_matches_oracle(kind):
         rtol = 1e-7 if i < 8 else 2e-2
         np.testing.assert_allclose(q.data, qr, rtol=rtol, atol=1e-3 if i >= 8 else 1e-9)
     assert step.rng.bit_generator.state == ref.rng.bit_generator.state
+    step.close()
+
+
+def test_nuts_adapt_full_matches_oracle():
+    """`init="adapt_full"` (mcmc.py:1984-1991): QuadPotentialFullAdapt, covariance + Cholesky refreshed every tuning
+    draw; runs past the first window switch (draw 101)."""
+    _compare_runs(models.std_normal(6, 1.0, 2.0), tune=130, draws=10, seed=4, prefix=140, init="adapt_full")
+    _compare_runs(models.eight_schools(), tune=30, draws=5, seed=4, prefix=35, init="adapt_full")
+
+
+def test_nuts_adapt_diag_grad_matches_oracle():
+    """`init="jitter+adapt_diag_grad"` without the (parity-unpinned) jitter: QuadPotentialDiagAdaptExp with gradients
+    (mcmc.py:1894-1911); the diagonal starts moving after 2 x discard_window = 100 draws."""
+    from pymc_amd.quadpotential import QuadPotentialDiagAdaptExp
+    from pymc_amd.blocking import RaveledVars
+    from pymc_amd.step import NUTS
+
+    spec = models.std_normal(8, 1.0, 2.0)
+    f = ref_models.SpecLogpGrad(spec)
+    n = spec.n
+    step = NUTS(model=spec, potential=QuadPotentialDiagAdaptExp(n, np.zeros(n), alpha=0.02, use_grads=True, rng=1), rng=2, device=0)
+    ref = ref_sampler.RefNUTS(f, n, potential=ref_sampler.DiagAdaptExpPotential(n, np.zeros(n), alpha=0.02, use_grads=True, rng=1), rng=2)
+    step.setup_chain(np.random.default_rng(5), 130, 5)
+    ref.setup_chain(np.random.default_rng(5), 130, 5)
+    q = RaveledVars(np.zeros(n), spec.point_map_info)
+    qr = np.zeros(n)
+    for i in range(135):
+        if i == 130:
+            step.stop_tuning(); ref.stop_tuning()
+        q, st = step.astep(q)
+        qr, sr = ref.astep(qr)
+        for k in INT_KEYS:
+            assert int(st[0][k]) == int(sr[k]), (i, k, st[0][k], sr[k])
+    np.testing.assert_allclose(step.potential._hvar, ref.potential.var, rtol=1e-6)
+    assert not np.allclose(ref.potential.var, 1.0)
+    np.testing.assert_allclose(q.data, qr, rtol=1e-3, atol=1e-5)
     step.close()
 
 

@@ -94,6 +94,53 @@ def test_quadpotential_argument_checks():
     assert np.isnan(pot.stats()["largest_eigval"])
 
 
+def test_host_adapted_potentials_match_the_oracle_restatement():
+    """QuadPotentialFullAdapt / QuadPotentialDiagAdaptExp keep their estimators on the host (as the reference does):
+    the update sequences must reproduce the oracle's restatement of quadpotential.py:486-579, 748-910 and np.cov."""
+    import warnings
+
+    from oracle import ref_sampler
+    from pymc_amd.quadpotential import QuadPotentialDiagAdaptExp, QuadPotentialFullAdapt, _WeightedCovariance
+
+    rng = np.random.RandomState(5432)
+    n = 6
+    L = np.tril(rng.randn(n, n)); L[np.diag_indices(n)] = np.exp(np.diag(L))
+    samples = rng.multivariate_normal(rng.randn(n), L @ L.T, size=260)
+    est = _WeightedCovariance(n)
+    for x in samples[:100]:
+        est.add_sample(x)
+    assert np.allclose(est.current_mean(), samples[:100].mean(0)) and np.allclose(est.current_covariance(), np.cov(samples[:100], rowvar=0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pot = QuadPotentialFullAdapt(n, np.zeros(n), np.eye(n), 10, rng=1)
+    ref = ref_sampler.FullAdaptPotential(n, np.zeros(n), np.eye(n), 10, rng=1)
+    for k, x in enumerate(samples):
+        pot._host_update(x, None, True)
+        ref.update(x, None, True)
+        if k in (0, 50, 101, 102, 203, 259):
+            npt.assert_allclose(pot._cov, ref.cov, rtol=1e-12)
+            npt.assert_allclose(pot._chol, ref.chol, rtol=1e-10)
+            z = rng.randn(n)
+            npt.assert_allclose(pot._rand @ z, np.linalg.solve(ref.chol.T, z), rtol=1e-9)   # random() = solve(chol^T, z)
+    assert pot.adaptation_window == ref.adaptation_window == 202 and pot._n_samples == 260
+    pot._host_update(samples[0] * 50, None, False)   # not tuning: no-op
+    npt.assert_allclose(pot._cov, ref.cov, rtol=1e-12)
+    with pytest.raises(ValueError, match="two-dimensional"):
+        QuadPotentialFullAdapt(n, np.zeros(n), np.ones(n))
+
+    grads = rng.randn(260, n) * np.array([1, 2, 3, 4, 5, 6.0])
+    pe = QuadPotentialDiagAdaptExp(n, np.zeros(n), alpha=0.02, use_grads=True, stop_adaptation=200, rng=1)
+    re = ref_sampler.DiagAdaptExpPotential(n, np.zeros(n), alpha=0.02, use_grads=True, stop_adaptation=200, rng=1)
+    for k, (x, g) in enumerate(zip(samples, grads)):
+        pe._host_update(x, g, True)
+        re.update(x, g, True)
+        npt.assert_allclose(pe._hvar, re.var, rtol=1e-13)
+        if k <= 100:
+            npt.assert_array_equal(pe._hvar, np.ones(n))
+    assert pe._n_samples_host == 200 and not np.allclose(pe._hvar, 1.0)
+    npt.assert_allclose(pe._hinv_stds, 1.0 / np.sqrt(pe._hvar))
+
+
 def test_step_class_surface_matches_reference():
     """nuts.py:104-130, hmc.py:47-68, compound.py:108-131."""
     assert NUTS.name == "nuts" and NUTS.default_blocked
