@@ -569,6 +569,8 @@ struct nuts_chain {
   HostStatus* st_dev = nullptr;
   HostStatus* st_host = nullptr;   // pinned + device-mapped; st_dev is its device alias
   int seq = 0;
+  // divergence points of the last diverging draw (DivergenceInfo.state / state_div, nuts.py:433-440)
+  std::vector<double> div_source, div_dest;
   // start-state cache: (q, grad) of the last returned proposal stay in out_dev, its logp here
   bool cache_ok = false;
   std::vector<double> last_q;
@@ -900,6 +902,12 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   rc = potential_update(c, c->out_dev);
   if (rc) return rc;
   const bool diverging = o.diverging != 0;
+  if (diverging) {   // keep the leaf the integrator started from and the one it diverged to (base_hmc.py:249-258)
+    const int dir = o.div_t > 0 ? 1 : -1;   // a leaf's index is its parent's + sign(eps) and the start state is 0
+    c->div_source.resize(n); c->div_dest.resize(n);
+    HIPCHK(hipMemcpy(c->div_dest.data(), A.Q + (int64_t)(o.div_t & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c->div_source.data(), A.Q + (int64_t)((o.div_t - dir) & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
+  }
   if (!c->tune) c->divergences += diverging;
   c->iter_count += 1;
 
@@ -1089,6 +1097,12 @@ extern "C" int nuts_chain_get_vector(nuts_chain* c, const char* name, double* ou
   else if (k == "fg_m2") src = c->fg_is_a ? c->wa_m2 : c->wb_m2;
   else if (k == "bg_mean") src = c->fg_is_a ? c->wb_mean : c->wa_mean;
   else if (k == "bg_m2") src = c->fg_is_a ? c->wb_m2 : c->wa_m2;
+  else if (k == "divergence_source" || k == "divergence_dest") {
+    const std::vector<double>& v = k == "divergence_source" ? c->div_source : c->div_dest;
+    if ((int)v.size() != c->n) { g_err = "no divergence recorded"; return NUTS_E_ARG; }
+    std::memcpy(out, v.data(), c->n * sizeof(double));
+    return NUTS_OK;
+  }
   else { g_err = "unknown vector " + k; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(c->m->stream));
   HIPCHK(hipMemcpy(out, src, c->n * sizeof(double), hipMemcpyDeviceToHost));

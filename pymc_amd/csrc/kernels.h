@@ -60,7 +60,7 @@ struct Ctl {
   double st_ls[MAX_LEVELS];
   int st_prop[MAX_LEVELS];
   int n_leaves_total;
-  int pad;
+  int div_t;       // trajectory index of the state whose energy error was too large (nuts.py:433-435)
 };
 
 struct ArenaDev {
@@ -734,7 +734,7 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
   c->n_proposals += 1;                                                      // nuts.py:436-437
   c->n_leaves_total += 1;
   if (!(dE < Emax)) {                                                       // nuts.py:419,433-435
-    c->diverging = 1; c->aborted = 1; c->div_dE = dE;
+    c->diverging = 1; c->aborted = 1; c->div_dE = dE; c->div_t = t;
     c->depth += 1;                                                          // extend: self.depth += 1 happens regardless
   } else {
     double cur_ls = -dE;
@@ -1056,7 +1056,7 @@ __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part
 // gather the proposal and tree statistics (nuts.py:478-489)
 struct DrawOut {
   double energy, logp, E0, log_accept_sum, max_energy_change, div_dE;
-  int depth, n_proposals, proposal, cursor, turning, diverging, bad_energy, pad;
+  int depth, n_proposals, proposal, cursor, turning, diverging, bad_energy, div_t;
 };
 
 __global__ __launch_bounds__(VEC_THREADS) void k_draw_finish(ArenaDev A, double* __restrict__ q_out,
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_draw_finish(ArenaDev A, double*
     out->energy = A.E[ps]; out->logp = A.LOGP[ps]; out->E0 = c->E0;
     out->log_accept_sum = c->log_accept_sum; out->max_energy_change = c->max_energy_change; out->div_dE = c->div_dE;
     out->depth = c->depth; out->n_proposals = c->n_proposals; out->proposal = prop; out->cursor = c->cursor;
-    out->turning = c->turning; out->diverging = c->diverging; out->bad_energy = c->bad_energy;
+    out->turning = c->turning; out->diverging = c->diverging; out->bad_energy = c->bad_energy; out->div_t = c->div_t;
   }
 }
 

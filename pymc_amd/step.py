@@ -43,8 +43,9 @@ from pymc_amd.value_grad import DeviceValueGradFunction
 class SamplerWarning:
     """Minimal stand-in for pymc/stats/convergence.py:37-61."""
 
-    def __init__(self, kind, message, level, step=None, extra=None):
+    def __init__(self, kind, message, level, step=None, extra=None, divergence_point_source=None, divergence_point_dest=None):
         self.kind, self.message, self.level, self.step, self.extra = kind, message, level, step, extra
+        self.divergence_point_source, self.divergence_point_dest = divergence_point_source, divergence_point_dest
 
     def __repr__(self):
         return f"SamplerWarning({self.kind}, {self.message!r})"
@@ -325,7 +326,11 @@ class NUTS(_DeviceHMCBase):
             if not self.tune:
                 self._num_divs_sample += 1
             msg = f"Energy change in leapfrog step is too large: {st.divergence_energy_change}."  # nuts.py:434
-            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1)
+            src = dst = None
+            if not self.tune and self._num_divs_sample < 100:  # base_hmc.py:249-258: at most 100 points are kept
+                src = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_source"), q0.point_map_info))
+                dst = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_dest"), q0.point_map_info))
+            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1, None, src, dst)
         stats = {
             "diverging": bool(st.diverging),
             "divergences": int(st.divergences),

@@ -360,6 +360,32 @@ def test_bad_initial_energy_raises():
     step.close()
 
 
+def test_divergence_reporting():
+    """nuts.py:419,433-435 + base_hmc.py:240-268: a step that is far too large diverges on its first leaf; the draw
+    stays where it was, the warning carries the message and (outside tuning) the two points."""
+    from pymc_amd.blocking import RaveledVars
+    from pymc_amd.step import NUTS
+
+    spec = models.std_normal(4, 0.0, 1.0)
+    step = NUTS(model=spec, rng=1, step_scale=1e4 * 4**0.25, adapt_step_size=False, device=0)
+    ref = ref_sampler.RefNUTS(ref_models.SpecLogpGrad(spec), 4, rng=1, step_scale=1e4 * 4**0.25, adapt_step_size=False)
+    step.setup_chain(np.random.default_rng(2), 0, 5)
+    ref.setup_chain(np.random.default_rng(2), 0, 5)
+    step.stop_tuning(); ref.stop_tuning()
+    q0 = np.ones(4)
+    q, st = step.astep(RaveledVars(q0, spec.point_map_info))
+    qr, sr = ref.astep(q0)
+    s = st[0]
+    assert s["diverging"] and sr["diverging"] and s["tree_size"] == sr["tree_size"] == 1 and s["depth"] == sr["depth"] == 1
+    assert s["divergences"] == 1 and s["index_in_trajectory"] == 0
+    np.testing.assert_array_equal(q.data, q0)
+    w = s["warning"]
+    assert w.kind == "DIVERGENCE" and "Energy change in leapfrog step is too large" in w.message
+    np.testing.assert_array_equal(w.divergence_point_source["a"], q0)
+    assert np.all(np.abs(w.divergence_point_dest["a"]) > 100)
+    step.close()
+
+
 def test_nuts_statistics_std_normal():
     """tests/sampler_fixtures.py:75-85,140-171: Normal(2, sqrt(3), size=10): mean/var rtol 0.1 atol 0.05."""
     from pymc_amd.sampling import sample
