@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "small_kernel.h"
 #include "nuts_mi355.h"
 
 static thread_local std::string g_err;
@@ -565,6 +566,8 @@ struct nuts_chain {
   double* stage_dev = nullptr;   // [2n + NUNI]
   double* stage_host = nullptr;  // pinned
   double* out_dev = nullptr;     // [2n]
+  double* out_dev2 = nullptr;    // [2n] second output buffer (single-launch path: output and start-state cache alternate)
+  bool small = false;            // latency regime: whole draw in one launch (small_kernel.h)
   double* out_host = nullptr;    // pinned [2n]
   HostStatus* st_dev = nullptr;
   HostStatus* st_host = nullptr;   // pinned + device-mapped; st_dev is its device alias
@@ -658,6 +661,9 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->n_uni_cap = (1 << maxd) + 2 * maxd + 16;
   c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + 2 * (size_t)c->n_uni_cap));
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
+  c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n));
+  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && m->md.nblk == 1 && n <= VEC_THREADS && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
+             cfg->potential != NUTS_POT_FULL;
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
   A.log_uniforms = A.uniforms + c->n_uni_cap;
@@ -858,10 +864,42 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   const int need_uni = (1 << max_depth) + max_depth + 1;
   if (n_uniforms < need_uni) { g_err = "not enough uniforms for the worst-case tree"; return NUTS_E_ARG; }
 
-  int rc = draw_begin(c, q0, normals, uniforms, need_uni, step_size, max_depth, false, 0, true);
-  if (rc) return rc;
+  int rc = NUTS_OK;
   bool exhausted = true;
   int64_t evals = 1;
+  if (c->small) {
+    // latency regime: the whole transition in one launch of one workgroup (small_kernel.h)
+    const bool cached = c->cache_ok && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
+    c->cache_ok = false;
+    std::memcpy(c->stage_host, q0, n * sizeof(double));
+    std::memcpy(c->stage_host + n, normals, n * sizeof(double));
+    double* u = c->stage_host + 2 * n;
+    double* lu = u + c->n_uni_cap;
+    std::memcpy(u, uniforms, need_uni * sizeof(double));
+    for (int i = 0; i < need_uni; ++i) lu[i] = std::log(u[i]);
+    HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + c->n_uni_cap + need_uni) * sizeof(double), hipMemcpyHostToDevice, s));
+    if (!cached) HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    SmallDrawArgs a{};
+    a.normals = c->stage_dev + n;
+    a.q_src = cached ? c->out_dev2 : nullptr; a.g_src = cached ? c->out_dev2 + n : nullptr; a.cached_logp = c->last_logp;
+    a.step_size = step_size; a.Emax = c->cfg.Emax; a.max_depth = max_depth;
+    a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.out = c->do_dev; a.st = nullptr; a.seq = 0;
+    hipLaunchKernelGGL(k_small_draw, dim3(1), dim3(VEC_THREADS), 0, s, c->m->md, A, a);
+    // the next draw's start-state cache must not alias this draw's output buffer
+    std::swap(c->out_dev, c->out_dev2);
+    HIPCHK(hipMemcpyAsync(c->out_host, c->out_dev2, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(c->do_host, c->do_dev, sizeof(DrawOut), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (c->do_host->bad_energy) {
+      rc = check_mass_matrix(c);
+      if (rc == NUTS_OK) g_err = "Bad initial energy, check any log probabilities that are inf or -inf, nan or very small";
+      return NUTS_E_BAD_ENERGY;
+    }
+    exhausted = !(c->do_host->diverging || c->do_host->turning);
+  } else {
+  rc = draw_begin(c, q0, normals, uniforms, need_uni, step_size, max_depth, false, 0, true);
+  if (rc) return rc;
   // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
   // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
   Geometry gm{uniforms[0] < 0.5 ? 1 : -1, 0, 0, 0, 0.0};
@@ -891,6 +929,8 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   HIPCHK(hipMemcpyAsync(c->do_host, c->do_dev, sizeof(DrawOut), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
+  }
+  const double* const result_dev = c->small ? c->out_dev2 : c->out_dev;   // (q, grad) of the proposal on the device
   const DrawOut& o = *c->do_host;
   evals += o.n_proposals;
   const auto t1 = clk::now();
@@ -899,7 +939,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   // nuts.py:478-489, base_hmc.py:238-282
   const double accept = std::exp(o.log_accept_sum) / o.n_proposals;
   c->da.update(accept, adapt);
-  rc = potential_update(c, c->out_dev);
+  rc = potential_update(c, result_dev);
   if (rc) return rc;
   const bool diverging = o.diverging != 0;
   if (diverging) {   // keep the leaf the integrator started from and the one it diverged to (base_hmc.py:249-258)

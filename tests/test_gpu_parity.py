@@ -285,6 +285,19 @@ def test_nuts_parity_eight_schools():
     _compare_runs(models.eight_schools(), tune=30, draws=30, seed=20160911, prefix=60)
 
 
+def test_nuts_parity_three_kernel_pipeline_on_small_and_multi_workgroup_models(monkeypatch):
+    """Small models normally take the single-launch path (small_kernel.h).  The general three-kernel pipeline must
+    give the same integers: forced on eight schools, and naturally on a schools model that spans two workgroups
+    (n = 302: broadcast terms and deferred scalars across workgroups)."""
+    monkeypatch.setenv("NUTS_SMALL_KERNEL", "0")
+    _compare_runs(models.eight_schools(), tune=30, draws=10, seed=20160911, prefix=40)
+    monkeypatch.delenv("NUTS_SMALL_KERNEL")
+    big = models.eight_schools(300)
+    rng = np.random.default_rng(1)
+    _check_logp_grad(big, [np.zeros(big.n), rng.normal(size=big.n)])
+    _compare_runs(big, tune=15, draws=5, seed=8, prefix=20)
+
+
 def test_nuts_parity_hier_logit():
     _compare_runs(models.hier_logit(G=16, D=8, rows_per_group=33, seed=3), tune=25, draws=15, seed=7, prefix=40)
 
