@@ -358,6 +358,38 @@ def test_same_seed_bitwise_reproducible():
     a["step"].close(); b["step"].close()
 
 
+def test_pooled_adaptation_roundtrip_over_rccl():
+    """The opt-in tuning pool: Welford partials leave the engine as device buffers, are all-reduced with
+    RCCL (`nccl` backend; world size 1 here, so the merge must be the identity) and go back in."""
+    import torch
+    import torch.distributed as dist
+
+    from pymc_amd.sampling import PooledAdaptation, init_nuts
+
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        spec = models.std_normal(12, 1.0, 2.0)
+        points, step = init_nuts(spec, init="adapt_diag", chains=1, random_seed_list=[3], device=0)
+        step.setup_chain(np.random.default_rng(1), 200, 0)
+        p = points[0]
+        for _ in range(102):
+            p, _ = step.step(p)
+        before = {k: step._vector(k) for k in ("fg_mean", "fg_m2", "bg_mean", "bg_m2")}
+        cnt = (step._scalar("fg_count"), step._scalar("bg_count"))
+        pool = PooledAdaptation(spec.n, torch.device("cuda", 0), window=101)
+        pool.after_tuning_draw(step, 101)
+        for k, v in before.items():
+            np.testing.assert_allclose(step._vector(k), v, rtol=1e-14, atol=1e-300)
+        assert (step._scalar("fg_count"), step._scalar("bg_count")) == cnt
+        ls = (step._scalar("log_step"), step._scalar("log_bar"))
+        pool.end_of_tuning(step)
+        np.testing.assert_allclose((step._scalar("log_step"), step._scalar("log_bar")), ls, rtol=1e-15)
+        step.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_bad_initial_energy_raises():
     from pymc_amd.exceptions import SamplingError
     from pymc_amd.step import NUTS
