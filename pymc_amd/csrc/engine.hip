@@ -288,6 +288,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   md.pool = m->keep(dev_upload(s->data_pool, s->data_pool_len));
   m->ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
   md.nblk = (n + VEC_THREADS * m->ept - 1) / (VEC_THREADS * m->ept);
+  md.tick_j = env_int("NUTS_TICK_J", -1);
   md.ticks = m->keep(dev_alloc<long long>(64));
   hipMemset(md.ticks, 0, 64 * sizeof(long long));
   md.part_stride = PART_STRIDE;

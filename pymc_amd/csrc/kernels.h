@@ -520,7 +520,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   const int nb = md.nblk;
   const int base = bid * VEC_THREADS * EPT;
   double* part = md.part + (int64_t)bid * md.part_stride;
-  const bool tk = bid == nb / 2 && tid == 0;
+  const bool tk = bid == nb / 2 && tid == 0 && (md.tick_j < 0 || j == md.tick_j);
   TICK(md, tk, 0);
   ProgRegs pregs;
   prog_issue(md, pregs);
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
     while (((j >> m) & 1) && m < d) ++m;
     last = (j + 1 == (1 << d));
   }
-  const bool tk = tid == 0;
+  const bool tk = tid == 0 && (md.tick_j < 0 || j == md.tick_j);
   TICK(md, tk, 16);
   ProgRegs pregs;
   prog_issue(md, pregs);

@@ -104,6 +104,7 @@ struct ModelDev {
   const char* prog;
   int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_deferred;
   long long* ticks;           // [64] phase timestamps of the last B / C launch (only written in -DNUTS_KTIMING builds)
+  int32_t tick_j, tick_pad;   // restrict the timestamps to leaf j of a doubling (-1: every leaf)
 };
 
 #ifdef NUTS_KTIMING

@@ -67,10 +67,10 @@ __device__ __forceinline__ void rows_load(const RowsDev& R, int64_t sp, int lane
   }
 }
 
-// Hyper-parameters of coordinate d = lane (lanes >= D replicate lane 0): evaluated once per wave.
+// Hyper-parameters of coordinate d = lane mod D: evaluated once per wave.
 template <int D>
 __device__ __forceinline__ void rows_hyper(const RowsDev& R, const QView& qv, int lane, double& m_lane, double& s_lane) {
-  const int dl = lane < D ? lane : 0;
+  const int dl = lane % D;   // every lane holds coordinate (lane mod D)
   m_lane = qv.at(R.off_mu + dl);
   const double s = qv.at(R.off_sigma + dl);
   s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(s) : s;
@@ -80,7 +80,7 @@ __device__ __forceinline__ void rows_hyper(const RowsDev& R, const QView& qv, in
 template <int D>
 __device__ __forceinline__ void rows_beta(const RowsDev& R, const QView& qv, int g, int lane, double m_lane, double s_lane,
                                           double (&beta)[D]) {
-  const int dl = lane < D ? lane : 0;
+  const int dl = lane % D;
   const double z = qv.at(R.off_z + (int64_t)g * D + dl);
   const double b = fma(s_lane, z, m_lane);
 #pragma unroll
@@ -131,9 +131,13 @@ __device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int
 }
 
 // ---- one mixed span per wave: a masked pass per group present in the span ----
+// The betas of up to 64/D consecutive groups are composed in ONE round of loads (lane l: group g + l/D,
+// coordinate l mod D) together with their row pointers, so a span with several short groups does not pay one
+// memory round trip per group.
 template <int D, int RPL>
 __device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, int mw, int lane, int aborted) {
   constexpr int SPAN = WAVE * RPL;
+  constexpr int GB = WAVE / D;   // groups per batch
   const int64_t sp = R.mixed_span[mw];
   int seg = R.mixed_seg_base[mw];
   const int64_t rs = sp * SPAN, span_end = rs + SPAN;
@@ -146,32 +150,41 @@ __device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, in
   rows_hyper<D>(R, qv, lane, m_lane, s_lane);
   if (aborted) return;
   double lp = 0.0;
-  while (true) {
-    double beta[D], acc[D];
-    rows_beta<D>(R, qv, g, lane, m_lane, s_lane, beta);
+  bool done = false;
+  while (!done) {
+    // one round: z' of GB groups, and GB + 1 row pointers
+    const int gl = min(g + lane / D, R.G - 1);
+    const double zb = qv.at(R.off_z + (int64_t)gl * D + (lane % D));
+    const int64_t gp = R.gptr[min(g + lane, R.G)];
+    const double bb = fma(s_lane, zb, m_lane);   // beta of (group g + lane/D, coordinate lane mod D)
+    const int gp_lo = (int)(gp & 0xffffffffll), gp_hi = (int)(gp >> 32);
+    for (int k = 0; k < GB; ++k) {
+      if (g + k >= R.G) { done = true; break; }   // only padding rows remain
+      const int64_t gs = ((int64_t)__builtin_amdgcn_readlane(gp_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(gp_lo, k);
+      const int64_t ge = ((int64_t)__builtin_amdgcn_readlane(gp_hi, k + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane(gp_lo, k + 1);
+      if (ge > gs) {   // (empty groups have no rows and no segment)
+        double beta[D], acc[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) acc[d] = 0.0;
-    const int64_t gs = R.gptr[g], ge = R.gptr[g + 1];
+        for (int d = 0; d < D; ++d) { beta[d] = readlane_d(bb, k * D + d); acc[d] = 0.0; }
 #pragma unroll
-    for (int k = 0; k < RPL; ++k) {
-      const int64_t row = r0 + k;
-      const bool in = row < ge && row >= gs;
-      double eta = 0.0;
+        for (int kk = 0; kk < RPL; ++kk) {
+          const int64_t row = r0 + kk;
+          const bool in = row < ge && row >= gs;
+          double eta = 0.0;
 #pragma unroll
-      for (int d = 0; d < D; ++d) eta = fma(x[d][k], beta[d], eta);
-      double l, r;
-      logit_row(eta, (double)((yb >> (8 * k)) & 0xffu), l, r);
-      lp += in ? l : 0.0;
-      r = in ? r : 0.0;
+          for (int d = 0; d < D; ++d) eta = fma(x[d][kk], beta[d], eta);
+          double l, r;
+          logit_row(eta, (double)((yb >> (8 * kk)) & 0xffu), l, r);
+          lp += in ? l : 0.0;
+          r = in ? r : 0.0;
 #pragma unroll
-      for (int d = 0; d < D; ++d) acc[d] = fma(r, x[d][k], acc[d]);
+          for (int d = 0; d < D; ++d) acc[d] = fma(r, x[d][kk], acc[d]);
+        }
+        rows_flush<D>(acc, R.mixed_part, seg, lane);
+      }
+      if (ge >= span_end) { done = true; break; }   // the group continues past this span
     }
-    rows_flush<D>(acc, R.mixed_part, seg, lane);
-    if (ge >= span_end) break;      // the group continues past this span
-    int gn = g + 1;                 // next non-empty group, if any rows are left
-    while (gn < R.G && R.gptr[gn + 1] == R.gptr[gn]) ++gn;
-    if (gn >= R.G) break;           // only padding rows remain
-    g = gn;
+    g += GB;
   }
   lp = wave_sum(lp);
   if (lane == 0) R.wave_lp[R.n_waves + mw] = lp;
