@@ -298,6 +298,26 @@ class NUTS(_DeviceHMCBase):
         dt = np.dtype(getattr(var, "dtype", "float64"))
         return 3 if (dt.kind == "f" and has_grad) else 0  # Competence.PREFERRED / INCOMPATIBLE
 
+    @staticmethod
+    def _progressbar_config(n_chains=1):  # nuts.py:234-248
+        from rich.progress import TextColumn
+        from rich.table import Column
+
+        columns = [
+            TextColumn("{task.fields[divergences]}", table_column=Column("Divergences", ratio=1)),
+            TextColumn("{task.fields[step_size]:0.3f}", table_column=Column("Step size", ratio=1)),
+            TextColumn("{task.fields[tree_size]}", table_column=Column("Grad evals", ratio=1)),
+        ]
+        stats = {"divergences": [0] * n_chains, "step_size": [0] * n_chains, "tree_size": [0] * n_chains}
+        return columns, stats
+
+    @staticmethod
+    def _make_progressbar_update_functions():  # nuts.py:250-257
+        def update_stats(stats):
+            return {key: stats[key] for key in ("divergences", "step_size", "tree_size")} | {"failing": stats["divergences"] > 0}
+
+        return (update_stats,)
+
     def astep(self, q0: RaveledVars):
         """BaseHMC.astep (base_hmc.py:196-288) -- one device transition."""
         q = np.ascontiguousarray(q0.data, dtype="float64")
@@ -393,6 +413,24 @@ class HamiltonianMC(_DeviceHMCBase):
     def competence(var, has_grad):  # hmc.py:186-191
         dt = np.dtype(getattr(var, "dtype", "float64"))
         return 1 if (dt.kind == "f" and has_grad) else 0  # COMPATIBLE / INCOMPATIBLE
+
+    @staticmethod
+    def _progressbar_config(n_chains=1):  # hmc.py:200-212
+        from rich.progress import TextColumn
+        from rich.table import Column
+
+        columns = [
+            TextColumn("{task.fields[divergences]}", table_column=Column("Divergences", ratio=1)),
+            TextColumn("{task.fields[n_steps]}", table_column=Column("Grad evals", ratio=1)),
+        ]
+        return columns, {"divergences": [0] * n_chains, "n_steps": [0] * n_chains}
+
+    @staticmethod
+    def _make_progressbar_update_functions():  # hmc.py:214-228
+        def update_stats(stats):
+            return {key: stats[key] for key in ("divergences", "n_steps")} | {"failing": stats["divergences"] > 0}
+
+        return (update_stats,)
 
     def astep(self, q0: RaveledVars):
         q = np.ascontiguousarray(q0.data, dtype="float64")

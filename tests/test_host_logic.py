@@ -153,6 +153,12 @@ def test_step_class_surface_matches_reference():
     assert NUTS.stats_dtypes_shapes["depth"][0] is np.int64 and NUTS.stats_dtypes_shapes["tree_size"][0] is np.float64
     assert NUTS.competence(np.zeros(1), True) == 3 and NUTS.competence(np.zeros(1, dtype="int64"), True) == 0
     assert NUTS.competence(np.zeros(1), False) == 0
+    cols, st = NUTS._progressbar_config(3)
+    assert len(cols) == 3 and st == {"divergences": [0] * 3, "step_size": [0] * 3, "tree_size": [0] * 3}
+    (upd,) = NUTS._make_progressbar_update_functions()
+    assert upd({"divergences": 2, "step_size": 0.1, "tree_size": 7.0, "x": 1}) == {"divergences": 2, "step_size": 0.1, "tree_size": 7.0, "failing": True}
+    cols, st = HamiltonianMC._progressbar_config(2)
+    assert len(cols) == 2 and set(st) == {"divergences", "n_steps"}
     assert HamiltonianMC.name == "hmc" and "n_steps" in HamiltonianMC.stats_dtypes_shapes
     assert HamiltonianMC.competence(np.zeros(1), True) == 1
 
