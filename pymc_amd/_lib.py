@@ -195,6 +195,22 @@ SYMBOLS = {
 _lib = None
 
 
+def _init_torch_runtime_first():
+    """PyTorch wheels bundle their own copy of the HIP runtime (torch/lib/libamdhip64.so) while this library links
+    the system one (/opt/rocm).  Both can live in one process, but only if torch's copy initialises FIRST; if the
+    engine touched the GPU before `torch.cuda` did, torch later reports "no GPUs found" and the RCCL plumbing
+    (trace gather, pooled adaptation) cannot start.  So: bring torch's runtime up before loading ours."""
+    if os.environ.get("PYMC_AMD_SKIP_TORCH_INIT"):
+        return
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # torch absent or CPU-only box: the engine itself decides whether a GPU is usable
+        pass
+
+
 def load():
     """Load libnuts_mi355.so and bind every declared symbol; raise if absent."""
     global _lib
@@ -205,6 +221,7 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). pymc_amd has no CPU fallback."
         )
+    _init_torch_runtime_first()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
