@@ -109,6 +109,56 @@ def test_hier_logit_ragged_groups():
     _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.5 for _ in range(3)])
 
 
+def test_hier_logit_empty_groups_and_tiny_inputs():
+    """Groups without any rows (first, middle and last), a single row in total, and every group a single row."""
+    rng = np.random.default_rng(9)
+    G, D = 9, 8
+    sizes = np.array([0, 5, 0, 0, 300, 1, 0, 40, 0])
+    gidx = np.repeat(np.arange(G), sizes).astype("int32")
+    N = len(gidx)
+    X = rng.normal(size=(N, D))
+    y = (rng.random(N) < 0.5).astype("int8")
+
+    def build(X, y, gidx, G):
+        m = ModelBuilder()
+        mu = m.Normal("mu", 0.0, 1.0, shape=D)
+        sg = m.HalfNormal("sigma", 1.0, shape=D)
+        z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+        m.HierLogitRows("y", X, y, gidx, mu, sg, z)
+        return m.build()
+
+    spec = build(X, y, gidx, G)
+    _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.5 for _ in range(2)])
+    one = build(X[:1], y[:1], np.array([2], dtype="int32"), 4)
+    _check_logp_grad(one, [rng.normal(size=one.n) * 0.5])
+    singles = build(X[:200], y[:200], np.arange(200, dtype="int32"), 200)
+    _check_logp_grad(singles, [rng.normal(size=singles.n) * 0.5])
+
+
+def test_abi_rejects_malformed_specs():
+    """Integer status + message, never an abort (include/nuts_mi355.h)."""
+    from pymc_amd import _lib
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    rng = np.random.default_rng(1)
+    spec = models.hier_logit(G=4, D=8, rows_per_group=5, seed=1)
+    spec.logit_rows.group_idx = spec.logit_rows.group_idx[::-1].copy()  # not sorted
+    with pytest.raises(_lib.EngineError, match="sorted"):
+        DeviceValueGradFunction(spec, device=0)
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 1.0, shape=3)
+    sg = m.HalfNormal("sigma", 1.0, shape=3)
+    z = m.Normal("z", 0.0, 1.0, shape=(2, 3))
+    m.HierLogitRows("y", rng.normal(size=(4, 3)), np.zeros(4), np.array([0, 0, 1, 1]), mu, sg, z)
+    with pytest.raises(_lib.EngineError, match="D must be"):
+        DeviceValueGradFunction(m.build(), device=0)
+    step_spec = models.std_normal(3)
+    from pymc_amd.step import NUTS
+
+    with pytest.raises(_lib.EngineError, match="max_treedepth"):
+        NUTS(model=step_spec, max_treedepth=14, device=0)
+
+
 def test_hier_logit_extreme_eta():
     spec = models.hier_logit(G=4, D=8, rows_per_group=50, seed=7)
     q = np.zeros(spec.n)
