@@ -481,6 +481,69 @@ def test_divergence_reporting():
     step.close()
 
 
+def _run_fixture(spec, n_samples, tune, chains, seed):
+    from pymc_amd.sampling import sample
+
+    res = sample(draws=n_samples, tune=tune, chains=chains, model=spec, random_seed=seed, device=0)
+    acc = np.mean([s["mean_tree_accept"] for st in res["stats"] for s in st])
+    res["step"].close()
+    return res["draws"], acc
+
+
+def _ks_ok(samples_2d, cdfs, thin, alpha=0.001):
+    """KnownCDF.test_kstest (tests/sampler_fixtures.py:41-58): per-coordinate KS on thinned draws, p-values combined."""
+    from scipy import stats
+
+    pvals = [stats.kstest(col[::thin], cdf=cdf).pvalue for col, cdf in zip(samples_2d.T, cdfs)]
+    p = pvals[0] if len(pvals) == 1 else stats.combine_pvalues(pvals)[1]
+    return alpha < p
+
+
+def test_reference_fixture_nuts_uniform():
+    """tests/step_methods/hmc/test_nuts.py:31-40 + sampler_fixtures.py:61-71 (`TestNUTSUniform`): Uniform(-1, 1)
+    through its interval transform; 4 chains x 10 000, tune 1000 (burn 1000), ESS > 9000, mean/var rtol .1 atol .05,
+    KS alpha 0.001 on every 5th draw, R-hat within 1 %, target accept."""
+    from scipy import stats
+
+    from pymc_amd.stats import ess_bulk, rhat
+
+    m = ModelBuilder()
+    m.Uniform("a", -1.0, 1.0)
+    d, acc = _run_fixture(m.build(), 10000, 1000, 4, 20160911)
+    a = np.tanh(d[:, 1000:, 0] / 2.0)  # backward interval transform: -1 + 2 sigmoid(q)
+    np.testing.assert_allclose(0.0, a.mean(), 0.1, 0.05)
+    np.testing.assert_allclose(1.0 / 3, a.var(), 0.1, 0.05)
+    assert _ks_ok(a.reshape(-1, 1), [stats.uniform(-1, 2).cdf], thin=5)
+    assert ess_bulk(a) > 9000
+    np.testing.assert_allclose(rhat(a), 1, rtol=0.01)
+    np.testing.assert_allclose(acc, 0.8, 1)
+
+
+def test_reference_fixture_nuts_normal_and_studentt():
+    """`TestNUTSNormal` (test_nuts.py:51-60: 2 x 10 000, ESS > 10 000) and `TestNUTSStudentT` (:73-82: nu = 4,
+    KS on every 10th draw, ESS > 1000)."""
+    from scipy import stats
+
+    from pymc_amd.stats import ess_bulk, rhat
+
+    d, acc = _run_fixture(models.std_normal(10, 2.0, np.sqrt(3.0)), 10000, 1000, 2, 20160911)
+    np.testing.assert_allclose(2 * np.ones(10), d.mean((0, 1)), 0.1, 0.05)
+    np.testing.assert_allclose(3 * np.ones(10), d.var((0, 1)), 0.1, 0.05)
+    flat = d.reshape(-1, 10)
+    assert _ks_ok(flat, [stats.norm(2, np.sqrt(3)).cdf] * 10, thin=5)
+    for i in range(10):
+        assert ess_bulk(d[:, :, i]) > 10000
+        np.testing.assert_allclose(rhat(d[:, :, i]), 1, rtol=0.01)
+    np.testing.assert_allclose(acc, 0.8, 1)
+    m = ModelBuilder()
+    m.StudentT("a", 4.0, 0.0, 1.0)
+    d, acc = _run_fixture(m.build(), 10000, 1000, 2, 20160911)
+    np.testing.assert_allclose(0.0, d.mean(), 0.1, 0.05)
+    assert _ks_ok(d.reshape(-1, 1), [stats.t(df=4).cdf], thin=10)
+    assert ess_bulk(d[:, :, 0]) > 1000
+    np.testing.assert_allclose(rhat(d[:, :, 0]), 1, rtol=0.01)
+
+
 def test_nuts_statistics_std_normal():
     """tests/sampler_fixtures.py:75-85,140-171: Normal(2, sqrt(3), size=10): mean/var rtol 0.1 atol 0.05."""
     from pymc_amd.sampling import sample
