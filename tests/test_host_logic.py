@@ -191,6 +191,32 @@ def test_initial_point_is_zero_in_unconstrained_space():
     assert list(p) == ["eta", "mu", "tau_log__"] and all(np.all(v == 0) for v in p.values())
 
 
+def test_trace_layout_matches_reference_conventions():
+    """(chain, draw, *shape) per untransformed variable, value variables on request, (chain, draw) per statistic."""
+    from pymc_amd.trace import posterior, sample_stats, to_trace
+
+    spec = models.hier_logit(G=3, D=8, rows_per_group=2)
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=(2, 5, spec.n))
+    post = posterior(spec, d, include_transformed=True)
+    assert list(post) == ["mu", "sigma_log__", "sigma", "z"]
+    assert post["mu"].shape == (2, 5, 8) and post["z"].shape == (2, 5, 3, 8)
+    npt.assert_array_equal(post["z"][1, 4], d[1, 4, 16:].reshape(3, 8))
+    npt.assert_allclose(post["sigma"], np.exp(d[..., 8:16]))
+    m = ModelBuilder()
+    m.Uniform("u", -1.0, 3.0, shape=2)
+    m.Beta("b", 2.0, 2.0)
+    s2 = m.build()
+    q = rng.normal(size=(1, 4, 3))
+    p2 = posterior(s2, q)
+    assert np.all((p2["u"] > -1) & (p2["u"] < 3)) and np.all((p2["b"] > 0) & (p2["b"] < 1)) and p2["b"].shape == (1, 4)
+    stats = [[{"depth": 3, "tree_size": 7.0, "diverging": False, "warning": None} for _ in range(4)] for _ in range(1)]
+    ss = sample_stats(stats)
+    assert ss["depth"].shape == (1, 4) and ss["diverging"].dtype == bool and len(ss["warning"][0]) == 4
+    tr = to_trace(s2, {"draws": q, "stats": stats, "warmup_stats": [[]]})
+    assert set(tr) == {"posterior", "sample_stats"}
+
+
 def test_ess_on_ar1_and_iid():
     """Bulk-ESS of an AR(1) process with coefficient rho is N (1-rho)/(1+rho) (Vehtari et al. 2021)."""
     rng = np.random.default_rng(0)
