@@ -1,6 +1,6 @@
 // The leapfrog pipeline: three launches per leapfrog step.
 //
-//   A  k_logit_rows / k_mvn_matvec   the HBM-streaming pass over the model data (dominant kernel).
+//   A  k_rows / k_mvn_matvec         the HBM-streaming pass over the model data (dominant kernel).
 //                                    Reads the position through a QView: in chain mode the first half
 //                                    of the leapfrog (p_half = p + eps/2 g ; q' = q + eps M^-1 p_half,
 //                                    integration.py:118-127) is recomputed on the fly for the few

@@ -30,14 +30,14 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
-# transform codes (must match csrc/nuts_types.h)
+# transform codes (must match include/nuts_mi355.h)
 TR_NONE, TR_LOG, TR_LOGODDS, TR_INTERVAL = 0, 1, 2, 3
 TRANSFORM_NAMES = {TR_NONE: None, TR_LOG: "log", TR_LOGODDS: "logodds", TR_INTERVAL: "interval"}
 
 # operand kinds
 OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
 
-# distribution codes (must match csrc/nuts_types.h)
+# distribution codes (must match include/nuts_mi355.h)
 (
     D_NORMAL,
     D_HALFNORMAL,
