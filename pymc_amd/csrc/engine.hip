@@ -113,15 +113,18 @@ static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, in
 }
 
 // kernel A of the pipeline: the pass over the model data (timed when profiling is on)
-static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j) {
+// `fold` (lean path only, kernels.h): workgroup 0 of the row pass does the control work of leaf j-1
+static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int fold = 0, int d = 0, double Emax = 0.0,
+                         int max_depth = 0, HostStatus* st = nullptr) {
   ModelDev& md = m->md;
   if (!md.has_logit && !md.has_mvn) return;
   const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
   if (md.has_logit) {
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
-    const dim3 grid(m->rows_grid), block(ROWS_BLOCK);
-#define ROWS_LAUNCH(DD, RR, OO) hipLaunchKernelGGL((k_rows<DD, RR, OO>), grid, block, 0, m->stream, md.lg, A, io, j, rev)
+    const dim3 grid(m->rows_grid + (fold ? 1 : 0)), block(ROWS_BLOCK);
+#define ROWS_LAUNCH(DD, RR, OO) \
+    hipLaunchKernelGGL((k_rows<DD, RR, OO>), grid, block, 0, m->stream, md, A, io, j, rev, fold, d, Emax, max_depth, st)
 #define ROWS_BY_D(RR, OO)                                   \
     switch (md.lg.D) {                                      \
       case 8: ROWS_LAUNCH(8, RR, OO); break;                \
@@ -150,10 +153,11 @@ static void model_enqueue_plain(nuts_model* m, const double* q_dev, double* g_de
   ArenaDev A{};
   A.n = m->md.n; A.nblk = m->md.nblk; A.ept = m->ept; A.S = 1;
   EvalIO io{};
-  io.mode = MODE_PLAIN; io.q = q_dev; io.grad = g_dev; io.logp = lp_dev;
+  io.mode = MODE_PLAIN; io.q = q_dev; io.grad = g_dev; io.logp = lp_dev; io.lean = m->md.lean_ok;
   launch_dense(m, A, io, 0);
   launch_vector(m, A, io, 0, 0);
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
+  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
+  else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
 }
 
 // "Compile" the spec: contributions per variable, broadcast terms, deferred elements, orphan factors.
@@ -243,11 +247,23 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   cptr[nv] = (int32_t)contrib.size();
   std::vector<int32_t> deferred;   // (element, variable) pairs
   for (int k = 0; k < nv; ++k)
-    if (vars[k].deferred) for (int i = 0; i < vars[k].size; ++i) { deferred.push_back(vars[k].offset + i); deferred.push_back(k); }
+    if (vars[k].deferred) {
+      vars[k].def_base = (int32_t)deferred.size() / 2;
+      for (int i = 0; i < vars[k].size; ++i) { deferred.push_back(vars[k].offset + i); deferred.push_back(k); }
+    }
   if ((int)deferred.size() / 2 > MAX_DEFERRED) { g_err = "too many scalar / hyper-parameter elements (MAX_DEFERRED)"; return false; }
   md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size() / 2;
   md.orphans = m->keep(dev_upload(orphans.data(), orphans.size()));
   md.deferred_g = m->keep(dev_upload(deferred.data(), deferred.size()));
+  md.def_loc = m->keep(dev_alloc<double>(4 * (size_t)std::max(1, md.n_deferred)));
+  hipMemset(md.def_loc, 0, 4 * (size_t)std::max(1, md.n_deferred) * sizeof(double));
+  // lean control path (kernels.h): the only deferred elements are the logit node's mu / sigma, no broadcast terms
+  md.lean_ok = 0;
+  if (s->rows_N > 0 && s->mvn_k <= 0 && md.n_bterms == 0 && env_int("NUTS_LEAN", 1)) {
+    md.lean_ok = 1;
+    for (int k = 0; k < nv; ++k) if (vars[k].deferred && k != s->rows_mu && k != s->rows_sigma) md.lean_ok = 0;
+    md.lg.def_mu = vars[s->rows_mu].def_base; md.lg.def_sigma = vars[s->rows_sigma].def_base;
+  }
   // pack the interpreter's tables into one blob (copied into LDS by kernels B and C)
   std::vector<char> blob;
   auto put = [&](const void* src, size_t bytes) {
@@ -582,6 +598,7 @@ struct nuts_chain {
   DrawOut* do_dev = nullptr;
   DrawOut* do_host = nullptr;
   double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
+  int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
   int64_t leapfrogs = 0;
   int n_uni_cap = 0;
   template <typename T>
@@ -663,6 +680,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + 2 * (size_t)c->n_uni_cap));
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
   c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n));
+  c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0;
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && m->md.nblk == 1 && n <= VEC_THREADS && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
              cfg->potential != NUTS_POT_FULL;
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
@@ -828,10 +846,22 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   if (c->dense)   // v = C p_half ; q' = q + eps v   (integration.py:121-127 with a dense velocity)
     hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, A.Q + so, A.Q + d_o, gm.eps,
                        abort_flag);
+  HostStatus* const st = mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr;
+  io.lean = m->md.lean_ok && !io.explicit_pre;
+  if (io.lean && mode == MODE_TREE && c->fold_ctl) {
+    // folded control (kernels.h): the control work of leaf j-1 rides in workgroup 0 of this leaf's row pass; only the
+    // last leaf of the doubling -- whose status the host waits for -- gets a control launch of its own
+    const bool last = j + 1 == (1 << d);
+    launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
+    launch_vector(m, A, io, j, d);
+    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+    c->leapfrogs++;
+    return;
+  }
   launch_dense(m, A, io, j);
   launch_vector(m, A, io, j, d);
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth,
-                     mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr, seq);
+  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+  else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
   if (c->dense) {   // v' = C p', then the tree work on the stored (p', v')
     hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, (const double*)nullptr,
                        (double*)nullptr, 0.0, abort_flag);

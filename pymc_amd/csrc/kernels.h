@@ -86,6 +86,7 @@ struct EvalIO {
   int explicit_pre;  // leaf modes: q' and p_half were materialised by k_leaf_pre
   int dense;         // dense mass matrix: v = C p is a mat-vec between the kernels, so B/C stop after the kick and the
                      // tree work runs in its own pair of kernels (k_tree_vec / k_tree_ctl)
+  int lean;          // lean control path: kernel B evaluates the local part of the deferred elements (control_lean)
   const double* q;   // MODE_PLAIN: position in
   double* grad;      // MODE_PLAIN: gradient out
   double* logp;      // MODE_PLAIN: logp out
@@ -184,29 +185,6 @@ __global__ __launch_bounds__(256) void k_dense_mv(const double* __restrict__ C, 
   if (lane == 0) {
     y[row] = s;
     if (q_out) q_out[row] = fma(eps, s, q_in[row]);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// A: hierarchical Bernoulli-logit rows (the HBM-bound pass; body in rows_kernel.h)
-// ---------------------------------------------------------------------------
-template <int D, int RPL, int OCC>
-__global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(RowsDev R, ArenaDev A, EvalIO io, int j, int rev) {
-  Leaf lf; QView qv;
-  const int aborted = load_aborted(io, A);
-  resolve_leaf(io, A, j, lf, qv);
-  const int lane = threadIdx.x & (WAVE - 1);
-  // workgroups [0, nb_mixed) take the mixed spans (dispatched first, so they overlap the streaming workgroups)
-  const int nb_mixed = (R.n_mixed + (ROWS_BLOCK / WAVE) - 1) / (ROWS_BLOCK / WAVE);
-  if ((int)blockIdx.x >= nb_mixed) {
-    int wave = ((int)blockIdx.x - nb_mixed) * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
-    // alternate the traversal direction between launches: the tail of the previous pass is still in the
-    // 256 MiB Infinity Cache when the next pass starts from that end
-    if (rev) wave = R.n_waves - 1 - wave;
-    rows_main<D, RPL>(R, qv, wave, lane, aborted);
-  } else {
-    const int mw = (int)blockIdx.x * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
-    if (mw < R.n_mixed) rows_mixed<D, RPL>(R, qv, mw, lane, aborted);
   }
 }
 
@@ -476,20 +454,6 @@ __device__ __forceinline__ void tree_post(const ArenaDev& A, const Leaf& lf, int
   m_out = m; last_out = last;
 }
 
-// sum_{s in [s0, s1)} base[s * stride], in index order, with up to 8 loads in flight at a time
-__device__ __forceinline__ double sum_strided(const double* base, int stride, int s0, int s1) {
-  double acc = 0.0;
-  for (int s = s0; s < s1; s += 8) {
-    double v[8];
-    // unconditional loads from a clamped index (a predicated load would sit in its own branch and serialise)
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)min(s + u, s1 - 1) * stride];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc += (s + u < s1) ? v[u] : 0.0;
-  }
-  return acc;
-}
-
 __device__ __forceinline__ bool dot_needed(int k, int m, bool last) {
   return (k == 0) || (k >= 1 && k < 1 + 6 * m) || (last && k >= DOT_TOP);
 }
@@ -583,7 +547,20 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     const bool is_z = md.has_logit && i >= lg.off_z && i < lg.off_z + lg.G * lg.D;
     const int k = is_z ? lg.var_z : find_var(pg, i);
     const VarDev v = pg.vars[k];
-    if (v.deferred) continue;  // finished by the control kernel
+    if (v.deferred) {
+      // finished by the control kernel; on the lean path everything that does not need the cross-workgroup sums is
+      // done here: value transform, own factors (their logp goes into this workgroup's partial), local gradient
+      if (io.lean) {
+        double x, dxdq, lj, dj, gx = 0.0;
+        transform_full(v, qn[e], x, dxdq, lj, dj);
+        lp += lj;
+        gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+        double2* loc = reinterpret_cast<double2*>(md.def_loc) + 2 * (v.def_base + (i - v.offset));
+        loc[0] = make_double2(gx, dxdq);
+        loc[1] = make_double2(dj, ph[e]);
+      }
+      continue;
+    }
     double gd = 0.0, db = 0.0;
     if (is_z) {
       // fixed-order sum of the group's segment partials; the loads of a batch are issued together
@@ -773,8 +750,6 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
   }
 }
 
-#define CTL_CHUNKS 8   // the per-workgroup partials are summed in CTL_CHUNKS contiguous chunks, then the chunks in order
-
 __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
                                                         int max_depth, HostStatus* st, int seq) {
   Leaf lf; QView qv;
@@ -937,6 +912,156 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   *A.ctl = *c;
   if (st) publish_status(c, st, seq);
   TICK(md, tk, 25);
+}
+
+// ---------------------------------------------------------------------------
+// C (lean): the control work when the only deferred elements are the logit node's mu / sigma
+// ---------------------------------------------------------------------------
+// Kernel B has already evaluated the local part of those elements (md.def_loc) and their logp, so what is left is
+// arithmetic on the partial sums: no model tables, no interpreter.  That makes the control work small enough to ride
+// in workgroup 0 of the NEXT leaf's kernel A ("folded control", k_rows below): kernel A of leaf j+1 needs from leaf j
+// only the z gradients (kernel B) and mu' / sigma', which its waves finish themselves (rows_hyper_fold) -- the sums
+// of the dot products, the energy and the tree decision of leaf j are off the critical path and overlap the row pass.
+// What a folded launch may observe late is the `aborted` flag: a leaf that starts while its predecessor's control
+// work decides to stop runs its row pass for nothing (it writes only scratch); kernel B of that leaf already sees
+// the flag and the trajectory arena is never touched by a speculative leaf.
+__device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
+                                             int max_depth, HostStatus* st, int seq) {
+  static_assert(ROWS_BLOCK == VEC_THREADS, "control_lean runs in a row-pass workgroup");
+  Leaf lf; QView qv;
+  resolve_leaf(io, A, j, lf, qv);
+  constexpr int NW = VEC_THREADS / WAVE;
+  __shared__ double s_sum[PART_STRIDE];
+  __shared__ double s_chunk[CTL_CHUNKS][PART_STRIDE];
+  __shared__ double s_red[NDOT * NW];
+  __shared__ Ctl s_ctl;
+  const int tid = threadIdx.x;
+  const bool leaf = io.mode != MODE_PLAIN;
+  const bool tree = io.mode == MODE_TREE;
+  const RowsDev& lg = md.lg;
+  int m = 0;
+  bool last = false;
+  if (tree) {
+    while (((j >> m) & 1) && m < d) ++m;
+    last = (j + 1 == (1 << d));
+  }
+  if (leaf && tid < (int)(sizeof(Ctl) / sizeof(int))) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(A.ctl)[tid];
+  const bool mine = tid < md.n_deferred;
+  int def_i = 0, def_k = 0;
+  double2 l01 = make_double2(0.0, 1.0), l23 = make_double2(0.0, 0.0);
+  if (mine) {
+    def_i = md.deferred_g[2 * tid]; def_k = md.deferred_g[2 * tid + 1];
+    l01 = reinterpret_cast<const double2*>(md.def_loc)[2 * tid];
+    l23 = reinterpret_cast<const double2*>(md.def_loc)[2 * tid + 1];
+  }
+  // ---- fixed-order sums of the per-workgroup partials this leaf needs: (slot, chunk) pairs in parallel ----
+  const int nlg = lg.D;
+  const int nn = 1 + 2 * nlg + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
+  auto need_slot = [&](int q) {
+    if (q < 1) return PART_LP;
+    q -= 1;
+    if (q < nlg) return PART_DMU + q;
+    q -= nlg;
+    if (q < nlg) return PART_DSG + q;
+    q -= nlg;
+    if (q < 1 + 6 * m) return PART_DOT + q;
+    return PART_DOT + DOT_TOP + (q - 1 - 6 * m);
+  };
+  {
+    const int per = (md.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
+    for (int t = tid; t < nn * CTL_CHUNKS; t += VEC_THREADS) {
+      const int c = t % CTL_CHUNKS, k = need_slot(t / CTL_CHUNKS);
+      const int b0 = c * per, b1 = min(md.nblk, (c + 1) * per);
+      s_chunk[c][k] = sum_strided(md.part + k, md.part_stride, b0, b1);
+    }
+  }
+  __syncthreads();
+  if (tree && s_ctl.aborted) {   // terminated earlier in this doubling: drain
+    if (tid == 0 && st) publish_status(&s_ctl, st, seq);
+    return;
+  }
+  for (int t = tid; t < nn; t += VEC_THREADS) {
+    const int k = need_slot(t);
+    double sacc = 0.0;
+#pragma unroll
+    for (int c = 0; c < CTL_CHUNKS; ++c) sacc += s_chunk[c][k];
+    s_sum[k] = sacc;
+  }
+  __syncthreads();
+  // ---- deferred elements: one thread each ----
+  int idx[1] = {def_i};
+  bool act[1] = {false};
+  double grad[1] = {0.0}, ph[1] = {l23.y};
+  if (mine) {
+    const double S = def_k == lg.var_mu ? s_sum[PART_DMU + (def_i - lg.off_mu)] : s_sum[PART_DSG + (def_i - lg.off_sigma)];
+    grad[0] = deferred_finish(l01.x, S, l01.y, l23.x);
+    act[0] = true;
+    if (leaf) A.G[lf.d_o + def_i] = grad[0];
+    else io.grad[def_i] = grad[0];
+  }
+  const double logp = s_sum[PART_LP];
+  if (!leaf) {
+    if (tid == 0) *io.logp = logp;
+    return;
+  }
+  int m2 = 0; bool last2 = false;
+  leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2);
+  __syncthreads();
+  // totals: workgroup partials (in order) + the deferred elements' share
+  for (int q = tid; q < NDOT; q += VEC_THREADS) {
+    if (!dot_needed(q, m, last)) continue;
+    double r = 0.0;
+    for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];
+    s_sum[PART_DOT + q] += r;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const double* dot = &s_sum[PART_DOT];
+  const int t = lf.t, ts = t & (A.S - 1);
+  A.LOGP[ts] = logp;
+  const double E = 0.5 * dot[0] - logp;  // integration.py:133-134
+  A.E[ts] = E;
+  if (!tree) return;
+  tree_decide(&s_ctl, A, lf, dot, E, m, last, Emax, max_depth);
+  *A.ctl = s_ctl;
+  if (st) publish_status(&s_ctl, st, seq);
+}
+
+__global__ __launch_bounds__(VEC_THREADS) void k_control_lean(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
+                                                             int max_depth, HostStatus* st, int seq) {
+  control_lean(md, A, io, j, d, Emax, max_depth, st, seq);
+}
+
+// ---------------------------------------------------------------------------
+// A: hierarchical Bernoulli-logit rows (the HBM-bound pass; body in rows_kernel.h)
+// ---------------------------------------------------------------------------
+// `fold` != 0: this is leaf j > 0 of a doubling on the lean path; workgroup 0 does the control work of leaf j-1
+// (control_lean above) and every wave finishes the source state's mu / sigma itself.
+template <int D, int RPL, int OCC>
+__global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(ModelDev md, ArenaDev A, EvalIO io, int j, int rev, int fold, int d,
+                                                        double Emax, int max_depth, HostStatus* st) {
+  int b = (int)blockIdx.x;
+  if (fold) {
+    if (b == 0) { control_lean(md, A, io, j - 1, d, Emax, max_depth, st, 0); return; }
+    --b;
+  }
+  const RowsDev& R = md.lg;
+  Leaf lf; QView qv;
+  const int aborted = load_aborted(io, A);
+  resolve_leaf(io, A, j, lf, qv);
+  const int lane = threadIdx.x & (WAVE - 1);
+  // workgroups [0, nb_mixed) take the mixed spans (dispatched first, so they overlap the streaming workgroups)
+  const int nb_mixed = (R.n_mixed + (ROWS_BLOCK / WAVE) - 1) / (ROWS_BLOCK / WAVE);
+  if (b >= nb_mixed) {
+    int wave = (b - nb_mixed) * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
+    // alternate the traversal direction between launches: the tail of the previous pass is still in the
+    // 256 MiB Infinity Cache when the next pass starts from that end
+    if (rev) wave = R.n_waves - 1 - wave;
+    rows_main<D, RPL>(md, qv, wave, lane, aborted, fold);
+  } else {
+    const int mw = b * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (mw < R.n_mixed) rows_mixed<D, RPL>(md, qv, mw, lane, aborted, fold);
+  }
 }
 
 // ---------------------------------------------------------------------------

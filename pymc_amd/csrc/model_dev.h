@@ -28,7 +28,8 @@ struct VarDev {  // nuts_var + what the spec compiler derived
   // peephole: an untransformed variable whose only factor is its own Normal(mu, sigma) prior with constant
   // parameters (the non-centred `z ~ N(0, 1)` block of a hierarchical model) is evaluated in closed form:
   // logp_i = -(x - mu)^2 / (2 sigma^2) - np_lognorm ;  d/dx = -(x - mu) / sigma^2
-  int32_t normal_prior, pad;
+  int32_t normal_prior;
+  int32_t def_base;   // deferred variables: position of element 0 in the model's deferred list
   double np_mu, np_inv_var, np_lognorm;
 };
 
@@ -57,6 +58,7 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   const int64_t* gptr;     // [G+1] first row of each group
   int32_t off_mu, off_sigma, off_z, sigma_tr;
   int32_t var_mu, var_sigma, var_z, pad;
+  int32_t def_mu, def_sigma;   // positions of mu[0] / sigma[0] in the deferred list
   int64_t n_spans;         // Npad / span
   int32_t n_waves, n_seg;  // waves in the row-streaming launch; total (wave, group) segments
   const int32_t* run_ptr;  // [n_waves+1] runs of main wave w = [run_ptr[w], run_ptr[w+1])
@@ -100,6 +102,11 @@ struct ModelDev {
   MvnDev mv;
   double* part;               // [nblk][part_stride]
   int32_t part_stride, prog_bytes;
+  // "lean" control path (see kernels.h): the only deferred elements are the hierarchical-logit node's mu / sigma, so
+  // kernel B evaluates everything of them that does not need the cross-workgroup sums and leaves
+  // {d logp/dx local part, dx/dq, dlog|J|/dq, p_half} per deferred element here
+  double* def_loc;            // [n_deferred][4]
+  int32_t lean_ok, lean_pad;
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
   const char* prog;
   int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_deferred;
@@ -117,6 +124,28 @@ __device__ __forceinline__ long long tick_now() {   // drains outstanding memory
 #else
 #define TICK(md, cond, slot) do { } while (0)
 #endif
+
+// sum_{s in [s0, s1)} base[s * stride], in index order, with up to 8 loads in flight at a time
+__device__ __forceinline__ double sum_strided(const double* base, int stride, int s0, int s1) {
+  double acc = 0.0;
+  for (int s = s0; s < s1; s += 8) {
+    double v[8];
+    // unconditional loads from a clamped index (a predicated load would sit in its own branch and serialise)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)min(s + u, s1 - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (s + u < s1) ? v[u] : 0.0;
+  }
+  return acc;
+}
+
+#define CTL_CHUNKS 8   // the per-workgroup partials are summed in CTL_CHUNKS contiguous chunks, then the chunks in order
+
+// gradient of a deferred element once the cross-workgroup sum S of its share is known (one explicit form, used by
+// every kernel that finishes such an element, so that all of them produce the same bits)
+__device__ __forceinline__ double deferred_finish(double gx_local, double S, double dxdq, double dj) {
+  return fma(gx_local + S, dxdq, dj);
+}
 
 #define PROG_LDS_MAX 12288
 

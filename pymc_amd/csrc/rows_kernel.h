@@ -76,6 +76,46 @@ __device__ __forceinline__ void rows_hyper(const RowsDev& R, const QView& qv, in
   s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(s) : s;
 }
 
+// The same, for the launch that overlaps the control work of the PREVIOUS leaf (kernels.h, "folded control"): the
+// source state's mu / sigma entries of G and P are being written by the control workgroup of this very launch, so
+// every wave finishes them itself from what kernel B left behind -- the per-workgroup partial sums of
+// d logp / d mu, d logp / d sigma (summed in exactly the control kernel's order) and the local parts in `def_loc`.
+// One round of loads, like the plain version; q' of the source state was stored by kernel B for every element.
+template <int D>
+__device__ __forceinline__ void rows_hyper_fold(const ModelDev& md, const QView& qv, int lane, double& m_lane, double& s_lane) {
+  constexpr int NE = 2 * D;                 // mu[0..D), sigma[0..D)
+  constexpr int NP = NE * CTL_CHUNKS;       // (element, chunk) pairs
+  constexpr int NS = (NP + WAVE - 1) / WAVE;
+  const RowsDev& R = md.lg;
+  const int e = lane % NE;
+  const bool is_mu = e < D;
+  const int dd = is_mu ? e : e - D;
+  const int i = (is_mu ? R.off_mu : R.off_sigma) + dd;
+  const int slot = (is_mu ? R.def_mu : R.def_sigma) + dd;
+  const double2 l01 = reinterpret_cast<const double2*>(md.def_loc)[2 * slot];       // {gx local, dx/dq}
+  const double2 l23 = reinterpret_cast<const double2*>(md.def_loc)[2 * slot + 1];   // {dlog|J|/dq, p_half}
+  const double qi = qv.q[i], vi = qv.var[i];
+  const int per = (md.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
+  double cs[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int pair = (lane + WAVE * s) % NP;
+    const int pe = pair % NE, c = pair / NE;
+    const int k = pe < D ? PART_DMU + pe : PART_DSG + (pe - D);
+    cs[s] = sum_strided(md.part + k, md.part_stride, c * per, min(md.nblk, (c + 1) * per));
+  }
+  double S = 0.0;
+#pragma unroll
+  for (int c = 0; c < CTL_CHUNKS; ++c) S += __shfl(cs[(NE * c) / WAVE], (NE * c) % WAVE + e);
+  const double g = deferred_finish(l01.x, S, l01.y, l23.x);
+  const double p_src = fma(qv.half, g, l23.y);                       // p' of the previous leaf (integration.py:131)
+  const double val = fma(qv.eps, vi * fma(qv.half, g, p_src), qi);    // this leaf's q'
+  const int dl = lane % D;
+  m_lane = __shfl(val, dl);
+  const double sg = __shfl(val, D + dl);
+  s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(sg) : sg;
+}
+
 // beta_g = mu + sigma * z_g as wave-uniform values (lane d evaluates coordinate d, readlane broadcasts into SGPRs)
 template <int D>
 __device__ __forceinline__ void rows_beta(const RowsDev& R, const QView& qv, int g, int lane, double m_lane, double s_lane,
@@ -91,9 +131,11 @@ __device__ __forceinline__ void rows_beta(const RowsDev& R, const QView& qv, int
 // (spans containing a group boundary or padding rows are listed on the host and handled by rows_mixed below,
 // by extra workgroups of the same launch: the streaming loop carries no rare-path state)
 template <int D, int RPL>
-__device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int wave, int lane, int aborted) {
+__device__ __forceinline__ void rows_main(const ModelDev& md, const QView& qv, int wave, int lane, int aborted, int fold) {
+  const RowsDev& R = md.lg;
   double m_lane, s_lane;
-  rows_hyper<D>(R, qv, lane, m_lane, s_lane);
+  if (fold) rows_hyper_fold<D>(md, qv, lane, m_lane, s_lane);
+  else rows_hyper<D>(R, qv, lane, m_lane, s_lane);
   const int r0 = R.run_ptr[wave], r1 = R.run_ptr[wave + 1];
   if (aborted) return;   // tested after the hyper-parameter loads were issued: the flag's round trip is hidden
   double lp = 0.0;
@@ -135,7 +177,8 @@ __device__ __forceinline__ void rows_main(const RowsDev& R, const QView& qv, int
 // coordinate l mod D) together with their row pointers, so a span with several short groups does not pay one
 // memory round trip per group.
 template <int D, int RPL>
-__device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, int mw, int lane, int aborted) {
+__device__ __forceinline__ void rows_mixed(const ModelDev& md, const QView& qv, int mw, int lane, int aborted, int fold) {
+  const RowsDev& R = md.lg;
   constexpr int SPAN = WAVE * RPL;
   constexpr int GB = WAVE / D;   // groups per batch
   const int64_t sp = R.mixed_span[mw];
@@ -147,7 +190,8 @@ __device__ __forceinline__ void rows_mixed(const RowsDev& R, const QView& qv, in
   rows_load<D, RPL>(R, sp, lane, x, yb);
   int g = __builtin_amdgcn_readfirstlane(R.mixed_g0[mw]);  // group of the span's first row
   double m_lane, s_lane;
-  rows_hyper<D>(R, qv, lane, m_lane, s_lane);
+  if (fold) rows_hyper_fold<D>(md, qv, lane, m_lane, s_lane);
+  else rows_hyper<D>(R, qv, lane, m_lane, s_lane);
   if (aborted) return;
   double lp = 0.0;
   bool done = false;

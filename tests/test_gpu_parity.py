@@ -408,6 +408,41 @@ def test_same_seed_bitwise_reproducible():
     a["step"].close(); b["step"].close()
 
 
+def test_folded_control_is_a_pure_rescheduling(monkeypatch):
+    """kernels.h "folded control": on the hierarchical-logit model the control work of leaf j runs inside the row pass
+    of leaf j+1.  That is scheduling only -- the same device functions in the same order -- so the draws must be
+    BITWISE equal to the run with one control launch per leaf; the general control kernel (NUTS_LEAN=0, the path
+    every other model takes) sums the log-density in a different order, so against it the integers are compared
+    exactly and the floats to rounding."""
+    from pymc_amd.sampling import sample
+
+    spec = models.hier_logit(G=24, D=8, rows_per_group=57, seed=5)
+
+    def run():
+        r = sample(draws=12, tune=40, chains=1, model=spec, random_seed=11, device=0)
+        out = (r["draws"].copy(), r["warmup_stats"][0] + r["stats"][0])
+        r["step"].close()
+        return out
+
+    d_fold, s_fold = run()
+    monkeypatch.setenv("NUTS_FOLD_CTL", "0")
+    d_flat, s_flat = run()
+    monkeypatch.delenv("NUTS_FOLD_CTL")
+    assert np.array_equal(d_fold, d_flat)
+    for a, b in zip(s_fold, s_flat):
+        for k in INT_KEYS + ("energy", "model_logp", "mean_tree_accept", "max_energy_error"):
+            assert a[k] == b[k], k
+    assert max(int(s["depth"]) for s in s_fold) >= 3   # trees deep enough that folded launches actually ran
+    monkeypatch.setenv("NUTS_LEAN", "0")
+    d_gen, s_gen = run()
+    for i, (a, b) in enumerate(zip(s_fold, s_gen)):
+        if i >= 10:
+            break
+        for k in INT_KEYS:
+            assert int(a[k]) == int(b[k]), (i, k)
+        np.testing.assert_allclose(a["energy"], b["energy"], rtol=1e-9)
+
+
 def test_pooled_adaptation_roundtrip_over_rccl():
     """The opt-in tuning pool: Welford partials leave the engine as device buffers, are all-reduced with
     RCCL (`nccl` backend; world size 1 here, so the merge must be the identity) and go back in."""
