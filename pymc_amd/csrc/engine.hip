@@ -414,10 +414,21 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     };
     // segments are emitted in row order and rows are sorted by group => the segments of a group are contiguous
     const std::vector<int32_t> gsp = group_ptr(seg_gid), gmp = group_ptr(mixed_seg_gid);
+    // fixed-slot segment layout (model_dev.h) when every group has few main segments and kernel B runs one element per
+    // thread: slot = group * segK + ordinal of the segment inside its group
+    int kmain = 1;
+    for (int g = 0; g < lg.G; ++g) kmain = std::max(kmain, gsp[g + 1] - gsp[g]);
+    lg.segK = 0;
+    if (kmain <= SEG_MAIN_MAX && m->ept == 1 && env_int("NUTS_SEG_FIXED", 1)) {
+      lg.segK = kmain + 2;
+      for (auto& r : runs) r.w = r.z * lg.segK + (r.w - gsp[r.z]);
+    }
+    const size_t seg_doubles = lg.segK ? (size_t)lg.G * lg.segK * D : (size_t)lg.n_seg * D;
     lg.run_ptr = m->keep(dev_upload(run_ptr.data(), run_ptr.size()));
     lg.runs = m->keep(dev_upload(runs.data(), runs.size()));
     lg.gseg_ptr = m->keep(dev_upload(gsp.data(), gsp.size()));
-    lg.seg_part = m->keep(dev_alloc<double>((size_t)lg.n_seg * D));
+    lg.seg_part = m->keep(dev_alloc<double>(std::max<size_t>(seg_doubles, 1)));
+    if (lg.seg_part) hipMemset(lg.seg_part, 0, std::max<size_t>(seg_doubles, 1) * sizeof(double));
     lg.mixed_span = m->keep(dev_upload(mixed_span.data(), mixed_span.size()));
     lg.mixed_g0 = m->keep(dev_upload(mixed_g0.data(), mixed_g0.size()));
     lg.mixed_seg_base = m->keep(dev_upload(mixed_seg_base.data(), mixed_seg_base.size()));

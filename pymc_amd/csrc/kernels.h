@@ -228,10 +228,33 @@ __global__ __launch_bounds__(256) void k_mvn_matvec(MvnDev mv, ArenaDev A, EvalI
 //   dd[1+6l .. 1+6l+5]  the six U-turn dots of the level-l merge  (nuts.py:454-463)
 //   dd[DOT_TOP..+5]     the six dots of `extend`                  (nuts.py:380-390)
 // Reductions are done by the caller through `red`, a [NDOT][waves] LDS scratch.
+// Operands of the first MERGE_PF merge levels of one element.  They belong to earlier leaves of the trajectory, so
+// their addresses are known when the kernel starts: kernel B issues these loads with its very first ones and a merge
+// level then costs arithmetic only (measured before: ~3.5 k cycles per level, mostly the first-touch latency of six
+// dependent-free but late loads).  Slots a level does not use are loaded from valid addresses and ignored.
+#define MERGE_PF 3
+struct MergePrefetch { double v[MERGE_PF][6]; };
+
+__device__ __forceinline__ void merge_prefetch(const ArenaDev& A, const Leaf& lf, int j, int i, MergePrefetch& pf) {
+  const int dir = lf.dir, edge = lf.edge;
+#pragma unroll
+  for (int l = 0; l < MERGE_PF; ++l) {
+    const int t1_left = edge + dir * (j - (2 << l) + 2);
+    const int t1_right = edge + dir * (j - (1 << l) + 1);
+    const int t2_left = t1_right + dir;
+    const int64_t o1l = slot_off(A, t1_left), o1r = slot_off(A, t1_right), o2l = slot_off(A, t2_left);
+    const double* ps1 = (l == 0) ? (A.P + o1r) : (A.PS + (int64_t)l * A.n);
+    pf.v[l][0] = ps1[i]; pf.v[l][1] = A.V[o1l + i];
+    if (l >= 1) { pf.v[l][2] = A.P[o2l + i]; pf.v[l][3] = A.V[o2l + i]; pf.v[l][4] = A.P[o1r + i]; pf.v[l][5] = A.V[o1r + i]; }
+    else { pf.v[l][2] = pf.v[l][3] = pf.v[l][4] = pf.v[l][5] = 0.0; }   // level 0 uses two operands (the other slots alias the new leaf)
+  }
+}
+
 template <int E>
 __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int j, int d, bool tree,
                                           const int (&idx)[E], const bool (&act)[E], const double (&grad)[E],
-                                          const double (&ph)[E], double* red, int nwaves, int& m_out, bool& last_out) {
+                                          const double (&ph)[E], double* red, int nwaves, int& m_out, bool& last_out,
+                                          const MergePrefetch* pf = nullptr) {
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
   const int dir = lf.dir, edge = lf.edge, t = lf.t;
   const int64_t to = lf.d_o;
@@ -259,7 +282,7 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
     while (((j >> m) & 1) && m < d) ++m;
     last = (j + 1 == (1 << d));
     // merges: level l joins leaves [j-2^(l+1)+1, j-2^l] (t1) with [j-2^l+1, j] (t2)   (nuts.py:452-463)
-    for (int l = 0; l < m; ++l) {
+    auto level = [&](int l, const double* pfl) {   // pfl: prefetched operands of this level (E == 1 only)
       const int t1_left = edge + dir * (j - (2 << l) + 2);
       const int t1_right = edge + dir * (j - (1 << l) + 1);
       const int t2_left = t1_right + dir;
@@ -270,9 +293,12 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
       for (int e = 0; e < E; ++e) {
         if (act[e]) {
           const int i = idx[e];
-          // all six operands are loaded unconditionally (valid slots at every level) so they are in flight together
-          const double s1 = ps1[i], v1l = A.V[o1l + i], p2l = A.P[o2l + i], v2l = A.V[o2l + i], p1r = A.P[o1r + i],
-                       v1r = A.V[o1r + i];
+          double s1, v1l, p2l, v2l, p1r, v1r;
+          if (pfl) { s1 = pfl[0]; v1l = pfl[1]; p2l = pfl[2]; v2l = pfl[3]; p1r = pfl[4]; v1r = pfl[5]; }
+          else {
+            // all six operands are loaded unconditionally (valid slots at every level) so they are in flight together
+            s1 = ps1[i]; v1l = A.V[o1l + i]; p2l = A.P[o2l + i]; v2l = A.V[o2l + i]; p1r = A.P[o1r + i]; v1r = A.V[o1r + i];
+          }
           const double s2 = acc[e];
           const double rho = s1 + s2;                  // tree1.p_sum + tree2.p_sum
           dd[0] = fma(rho, v1l, dd[0]);
@@ -290,6 +316,13 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(1 + 6 * l + k) * nwaves + w] = s; }
+    };
+    if (E == 1 && pf) {
+#pragma unroll
+      for (int l = 0; l < MERGE_PF; ++l) if (l < m) level(l, pf->v[l]);
+      for (int l = MERGE_PF; l < m; ++l) level(l, nullptr);
+    } else {
+      for (int l = 0; l < m; ++l) level(l, nullptr);
     }
     if (!last) {
       // subtree not complete: park the merged p_sum as the pending left sibling of level m
@@ -507,18 +540,39 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
       }
     } else qn[e] = io.q[i];
   }
+  MergePrefetch mpf;
+  const bool use_mpf = EPT == 1 && io.mode == MODE_TREE && !io.dense;
+  if (use_mpf) merge_prefetch(A, lf, j, min(idx[0], md.n - 1), mpf);
   // the logit node's z elements: segment ranges (static tables) and the group's sigma, loaded up front
   int za0[EPT], za1[EPT], zb0[EPT], zb1[EPT];
   double zsig[EPT];
+  const bool seg_fixed = EPT == 1 && lg.segK > 0;   // fixed-slot segment layout: addresses follow from the element index
+  double sv[SEG_MAIN_MAX + 2];
+#pragma unroll
+  for (int s = 0; s < SEG_MAIN_MAX + 2; ++s) sv[s] = 0.0;
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     za0[e] = za1[e] = zb0[e] = zb1[e] = 0; zsig[e] = 0.0;
     const int zi = idx[e] - lg.off_z;
     if (md.has_logit && zi >= 0 && zi < lg.G * lg.D) {
       const int g = zi / lg.D, dd = zi - g * lg.D;
-      za0[e] = lg.gseg_ptr[g]; za1[e] = lg.gseg_ptr[g + 1]; zb0[e] = lg.gmix_ptr[g]; zb1[e] = lg.gmix_ptr[g + 1];
+      if (seg_fixed) {
+        const int K = lg.segK;
+        const double* sp = lg.seg_part + (int64_t)g * K * lg.D + dd;
+#pragma unroll
+        for (int s = 0; s < SEG_MAIN_MAX; ++s) sv[s] = sp[min(s, K - 3) * lg.D];
+        sv[SEG_MAIN_MAX] = sp[(K - 2) * lg.D]; sv[SEG_MAIN_MAX + 1] = sp[(K - 1) * lg.D];
+      } else {
+        za0[e] = lg.gseg_ptr[g]; za1[e] = lg.gseg_ptr[g + 1]; zb0[e] = lg.gmix_ptr[g]; zb1[e] = lg.gmix_ptr[g + 1];
+      }
       zsig[e] = qv.at(lg.off_sigma + dd);
     }
+  }
+  // first slice of the row-pass log-likelihood partials (summed below): issued with the loads above
+  double lp_first = 0.0;
+  if (md.has_logit) {
+    const int w0 = bid * VEC_THREADS + tid;
+    if (w0 < lg.n_waves + lg.n_mixed) lp_first = lg.wave_lp[w0];
   }
   TICK(md, tk, 1);
   const Prog pg = load_prog(md, s_prog, pregs);   // -> LDS, ends with a barrier
@@ -533,7 +587,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   double lp = 0.0;
   if (md.has_logit) {
     const int nlp = lg.n_waves + lg.n_mixed;
-    for (int w = bid * VEC_THREADS + tid; w < nlp; w += nb * VEC_THREADS) lp += lg.wave_lp[w];
+    lp += lp_first;
+    for (int w = (bid + nb) * VEC_THREADS + tid; w < nlp; w += nb * VEC_THREADS) lp += lg.wave_lp[w];
   }
   if (md.has_mvn) for (int r = bid * VEC_THREADS + tid; r < md.mv.k; r += nb * VEC_THREADS) lp -= 0.5 * md.mv.rowq[r];
 
@@ -565,8 +620,16 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     if (is_z) {
       // fixed-order sum of the group's segment partials; the loads of a batch are issued together
       const int dd = (i - lg.off_z) % lg.D;
-      db = sum_strided(lg.seg_part + dd, lg.D, za0[e], za1[e]);
-      db += sum_strided(lg.mixed_part + dd, lg.D, zb0[e], zb1[e]);
+      if (seg_fixed) {
+        // same association as the pointer-table path: (main segments in wave order) + (start span + end span)
+        const int km = lg.segK - 2;
+#pragma unroll
+        for (int s = 0; s < SEG_MAIN_MAX; ++s) db = s < km ? db + sv[s] : db;
+        db += (0.0 + sv[SEG_MAIN_MAX]) + sv[SEG_MAIN_MAX + 1];
+      } else {
+        db = sum_strided(lg.seg_part + dd, lg.D, za0[e], za1[e]);
+        db += sum_strided(lg.mixed_part + dd, lg.D, zb0[e], zb1[e]);
+      }
     }
     double x, dxdq, lj, dj, gx = 0.0;
     if (v.normal_prior) {
@@ -608,7 +671,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   // ---- second half kick + tree-merge dot products (wave partials land in s_red) ----
   int m = 0; bool last = false;
   TICK(md, tk, 5);
-  if (leaf && !io.dense) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last);
+  if (leaf && !io.dense) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last, use_mpf ? &mpf : nullptr);
   if (leaf && io.dense) {   // dense mass matrix: only the kick here; v' = C p' needs the mat-vec that follows
 #pragma unroll
     for (int e = 0; e < EPT; ++e) if (act[e]) A.P[lf.d_o + idx[e]] = fma(lf.half, grad[e], ph[e]);

@@ -21,6 +21,7 @@
 #define MAX_FACTOR_BT 6     // broadcast operands per factor
 #define MAX_DEFERRED 256    // deferred elements per model (one control-kernel thread each)
 #define LOGIT_MAXD 8
+#define SEG_MAIN_MAX 10     // fixed-slot segment layout: at most this many main segments per group (else pointer tables)
 
 struct VarDev {  // nuts_var + what the spec compiler derived
   int32_t offset, size, transform, deferred;
@@ -59,6 +60,11 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   int32_t off_mu, off_sigma, off_z, sigma_tr;
   int32_t var_mu, var_sigma, var_z, pad;
   int32_t def_mu, def_sigma;   // positions of mu[0] / sigma[0] in the deferred list
+  // fixed-slot segment layout (segK > 0): seg_part is [G][segK][D]; slots 0 .. segK-3 are the group's main segments in
+  // wave order (unused ones stay zero), slot segK-2 the mixed span in which the group starts, slot segK-1 the mixed
+  // span in which it only ends.  A z element's segment addresses then follow from its index alone, and kernel B can
+  // issue the loads with its very first ones instead of after a round trip through the segment pointers.
+  int32_t segK, seg_pad;
   int64_t n_spans;         // Npad / span
   int32_t n_waves, n_seg;  // waves in the row-streaming launch; total (wave, group) segments
   const int32_t* run_ptr;  // [n_waves+1] runs of main wave w = [run_ptr[w], run_ptr[w+1])

@@ -224,7 +224,10 @@ __device__ __forceinline__ void rows_mixed(const ModelDev& md, const QView& qv, 
 #pragma unroll
           for (int d = 0; d < D; ++d) acc[d] = fma(r, x[d][kk], acc[d]);
         }
-        rows_flush<D>(acc, R.mixed_part, seg, lane);
+        if (R.segK) {   // fixed-slot layout: the span where the group starts / the span where it only ends
+          int slot = (g + k) * R.segK + (R.segK - 2) + (gs >= rs ? 0 : 1);
+          rows_flush<D>(acc, R.seg_part, slot, lane);
+        } else rows_flush<D>(acc, R.mixed_part, seg, lane);
       }
       if (ge >= span_end) { done = true; break; }   // the group continues past this span
     }
