@@ -143,7 +143,11 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
 #undef ROWS_BY_D
 #undef ROWS_LAUNCH
   }
-  if (md.has_mvn) hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid), dim3(256), 0, m->stream, md.mv, A, io, j);
+  if (md.has_mvn) {
+    const int mfold = md.has_logit ? 0 : fold;   // (the control work rides in exactly one launch)
+    hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid + (mfold ? 1 : 0)), dim3(MVN_BLOCK), 0, m->stream, md, A, io, j, mfold, d, Emax,
+                       max_depth, st);
+  }
   if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; }
   m->dom_launches++;
 }
@@ -257,12 +261,18 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.deferred_g = m->keep(dev_upload(deferred.data(), deferred.size()));
   md.def_loc = m->keep(dev_alloc<double>(4 * (size_t)std::max(1, md.n_deferred)));
   hipMemset(md.def_loc, 0, 4 * (size_t)std::max(1, md.n_deferred) * sizeof(double));
-  // lean control path (kernels.h): the only deferred elements are the logit node's mu / sigma, no broadcast terms
+  // lean control path (kernels.h), no broadcast terms and either
+  // (a) the only deferred elements are the logit node's mu / sigma, or
   md.lean_ok = 0;
-  if (s->rows_N > 0 && s->mvn_k <= 0 && md.n_bterms == 0 && env_int("NUTS_LEAN", 1)) {
-    md.lean_ok = 1;
-    for (int k = 0; k < nv; ++k) if (vars[k].deferred && k != s->rows_mu && k != s->rows_sigma) md.lean_ok = 0;
-    md.lg.def_mu = vars[s->rows_mu].def_base; md.lg.def_sigma = vars[s->rows_sigma].def_base;
+  // (b) no deferred element at all and an MvNormal node: the control work is sums and tree logic only
+  if (md.n_bterms == 0 && env_int("NUTS_LEAN", 1)) {
+    if (s->rows_N > 0 && s->mvn_k <= 0) {
+      md.lean_ok = 1;
+      for (int k = 0; k < nv; ++k) if (vars[k].deferred && k != s->rows_mu && k != s->rows_sigma) md.lean_ok = 0;
+      md.lg.def_mu = vars[s->rows_mu].def_base; md.lg.def_sigma = vars[s->rows_sigma].def_base;
+    } else if (s->rows_N <= 0 && s->mvn_k > 0 && md.n_deferred == 0) {
+      md.lean_ok = 1;
+    }
   }
   // pack the interpreter's tables into one blob (copied into LDS by kernels B and C)
   std::vector<char> blob;
@@ -449,7 +459,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     mv.gdense = m->keep(dev_alloc<double>(n));
     hipMemset(mv.gdense, 0, n * sizeof(double));
     mv.konst = -0.5 * mv.k * std::log(2.0 * M_PI) - s->mvn_logdet;
-    m->mvn_grid = (mv.k + (256 / WAVE) - 1) / (256 / WAVE);
+    m->mvn_grid = mv.k;   // one workgroup per row
     m->alg_bytes += 8 * (int64_t)mv.k * mv.k;
   }
   for (void* p : m->owned)
@@ -853,12 +863,24 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   const int* abort_flag = mode == MODE_TREE ? &A.ctl->aborted : nullptr;
   const int t = gm.edge + gm.dir * (j + 1), src = gm.edge + gm.dir * j;
   const int64_t d_o = (int64_t)(t & (A.S - 1)) * A.n, so = (int64_t)(src & (A.S - 1)) * A.n;
+  HostStatus* const st = mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr;
+  io.lean = m->md.lean_ok && !c->dense && (!io.explicit_pre || m->md.n_deferred == 0);
+  if (io.lean && io.explicit_pre && mode == MODE_TREE && c->fold_ctl) {
+    // MvNormal model on the lean path: kernel B of leaf j also materialises the first half of leaf j+1, the control
+    // work of leaf j-1 rides in workgroup 0 of this leaf's mat-vec; the last leaf gets a control launch of its own
+    const bool last = j + 1 == (1 << d);
+    if (j == 0) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
+    io.pre_next = last ? 0 : 1;
+    launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
+    launch_vector(m, A, io, j, d);
+    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+    c->leapfrogs++;
+    return;
+  }
   if (io.explicit_pre) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
   if (c->dense)   // v = C p_half ; q' = q + eps v   (integration.py:121-127 with a dense velocity)
     hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, A.Q + so, A.Q + d_o, gm.eps,
                        abort_flag);
-  HostStatus* const st = mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr;
-  io.lean = m->md.lean_ok && !io.explicit_pre;
   if (io.lean && mode == MODE_TREE && c->fold_ctl) {
     // folded control (kernels.h): the control work of leaf j-1 rides in workgroup 0 of this leaf's row pass; only the
     // last leaf of the doubling -- whose status the host waits for -- gets a control launch of its own

@@ -87,6 +87,8 @@ struct EvalIO {
   int dense;         // dense mass matrix: v = C p is a mat-vec between the kernels, so B/C stop after the kick and the
                      // tree work runs in its own pair of kernels (k_tree_vec / k_tree_ctl)
   int lean;          // lean control path: kernel B evaluates the local part of the deferred elements (control_lean)
+  int pre_next;      // explicit_pre models without deferred elements: kernel B also materialises the first half of the
+                     // NEXT leaf of the doubling (what k_leaf_pre would do), so only leaf 0 needs that launch
   const double* q;   // MODE_PLAIN: position in
   double* grad;      // MODE_PLAIN: gradient out
   double* logp;      // MODE_PLAIN: logp out
@@ -185,34 +187,6 @@ __global__ __launch_bounds__(256) void k_dense_mv(const double* __restrict__ C, 
   if (lane == 0) {
     y[row] = s;
     if (q_out) q_out[row] = fma(eps, s, q_in[row]);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// A': MvNormal precision mat-vec: one wave per row of P (multivariate.py:165-185, 275-295)
-// (position always materialised: every wave needs all k coordinates)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mvn_matvec(MvnDev mv, ArenaDev A, EvalIO io, int j) {
-  Leaf lf; QView qv;
-  if (load_aborted(io, A)) return;
-  resolve_leaf(io, A, j, lf, qv);
-  const double* __restrict__ q = qv.q;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int row = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
-  if (row >= mv.k) return;
-  const double* __restrict__ pr = mv.prec + (int64_t)row * mv.k;
-  double s = 0.0;
-  const int k2 = mv.k & ~1;
-  for (int c = lane * 2; c < k2; c += 2 * WAVE) {
-    const double2 p = *reinterpret_cast<const double2*>(pr + c);
-    s = fma(p.x, q[mv.off + c] - mv.mu[c], s);
-    s = fma(p.y, q[mv.off + c + 1] - mv.mu[c + 1], s);
-  }
-  if (lane == 0 && (mv.k & 1)) s = fma(pr[mv.k - 1], q[mv.off + mv.k - 1] - mv.mu[mv.k - 1], s);
-  s = wave_sum(s);
-  if (lane == 0) {
-    mv.gdense[mv.off + row] = -s;
-    mv.rowq[row] = (q[mv.off + row] - mv.mu[row]) * s;
   }
 }
 
@@ -672,6 +646,18 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   int m = 0; bool last = false;
   TICK(md, tk, 5);
   if (leaf && !io.dense) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last, use_mpf ? &mpf : nullptr);
+  if (leaf && io.pre_next) {
+    // first half of the next leaf (integration.py:118-127) from this leaf's registers: the same arithmetic as k_leaf_pre
+    const int64_t no = slot_off(A, lf.t + lf.dir);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) if (act[e]) {
+      const int i = idx[e];
+      const double p = fma(lf.half, grad[e], ph[e]);   // p' of this leaf, as leaf_post computed it
+      const double phn = fma(lf.half, grad[e], p);
+      A.P[no + i] = phn;
+      A.Q[no + i] = fma(lf.eps, A.var[i] * phn, qn[e]);
+    }
+  }
   if (leaf && io.dense) {   // dense mass matrix: only the kick here; v' = C p' needs the mat-vec that follows
 #pragma unroll
     for (int e = 0; e < EPT; ++e) if (act[e]) A.P[lf.d_o + idx[e]] = fma(lf.half, grad[e], ph[e]);
@@ -1018,7 +1004,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     l23 = reinterpret_cast<const double2*>(md.def_loc)[2 * tid + 1];
   }
   // ---- fixed-order sums of the per-workgroup partials this leaf needs: (slot, chunk) pairs in parallel ----
-  const int nlg = lg.D;
+  const int nlg = md.has_logit ? lg.D : 0;
   const int nn = 1 + 2 * nlg + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
   auto need_slot = [&](int q) {
     if (q < 1) return PART_LP;
@@ -1062,7 +1048,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     if (leaf) A.G[lf.d_o + def_i] = grad[0];
     else io.grad[def_i] = grad[0];
   }
-  const double logp = s_sum[PART_LP];
+  const double logp = s_sum[PART_LP] + (md.has_mvn ? md.mv.konst : 0.0);
   if (!leaf) {
     if (tid == 0) *io.logp = logp;
     return;
@@ -1124,6 +1110,53 @@ __global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(ModelDev md, ArenaDev 
   } else {
     const int mw = b * (ROWS_BLOCK / WAVE) + (threadIdx.x >> 6);
     if (mw < R.n_mixed) rows_mixed<D, RPL>(md, qv, mw, lane, aborted, fold);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// A': MvNormal precision mat-vec (multivariate.py:165-185, 275-295): one workgroup per row of P
+// ---------------------------------------------------------------------------
+// The position is always materialised (every row needs all k coordinates).  P (8 k^2 bytes; 33.5 MB at k = 2048) is
+// cache-resident between leapfrogs; one row per wave left only 8 waves per CU to cover the latency, so a row is
+// spread over the four waves of a workgroup (16 B per lane per load, 8 KiB of the row per iteration), wave partials
+// are combined in wave order.  `fold`: workgroup 0 does the control work of the previous leaf (control_lean).
+#define MVN_BLOCK 256
+__global__ __launch_bounds__(MVN_BLOCK) void k_mvn_matvec(ModelDev md, ArenaDev A, EvalIO io, int j, int fold, int d, double Emax,
+                                                        int max_depth, HostStatus* st) {
+  static_assert(MVN_BLOCK == VEC_THREADS, "control_lean runs in a mat-vec workgroup");
+  int row = (int)blockIdx.x;
+  if (fold) {
+    if (row == 0) { control_lean(md, A, io, j - 1, d, Emax, max_depth, st, 0); return; }
+    --row;
+  }
+  const MvnDev& mv = md.mv;
+  Leaf lf; QView qv;
+  if (load_aborted(io, A)) return;
+  resolve_leaf(io, A, j, lf, qv);
+  __shared__ double s_w[MVN_BLOCK / WAVE];
+  const double* __restrict__ q = qv.q + mv.off;
+  const double* __restrict__ mu = mv.mu;
+  const int tid = threadIdx.x;
+  if (row >= mv.k) return;
+  const double* __restrict__ pr = mv.prec + (int64_t)row * mv.k;
+  double s = 0.0;
+  const int k2 = mv.k & ~1;
+#pragma unroll 4
+  for (int c = 2 * tid; c < k2; c += 2 * MVN_BLOCK) {
+    const double2 p = *reinterpret_cast<const double2*>(pr + c);
+    s = fma(p.x, q[c] - mu[c], s);
+    s = fma(p.y, q[c + 1] - mu[c + 1], s);
+  }
+  if (tid == 0 && (mv.k & 1)) s = fma(pr[mv.k - 1], q[mv.k - 1] - mu[mv.k - 1], s);
+  s = wave_sum(s);
+  if ((tid & (WAVE - 1)) == 0) s_w[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < MVN_BLOCK / WAVE; ++w) t += s_w[w];
+    mv.gdense[mv.off + row] = -t;
+    mv.rowq[row] = (q[row] - mu[row]) * t;
   }
 }
 
