@@ -717,6 +717,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
     g_err = "pinned host allocation failed"; nuts_chain_destroy(c); return nullptr;
   }
   hipMemset(A.ctl, 0, sizeof(Ctl));
+  std::memset(c->st_host, 0, sizeof(HostStatus));
   c->step_size = cfg->step_scale / std::pow((double)n, 0.25);  // base_hmc.py:161
   c->da = DualAvg{c->step_size, cfg->target_accept, cfg->gamma, cfg->k, cfg->t0, 0, 0, 0, 0, 1};
   c->da.reset();
@@ -834,16 +835,21 @@ static int sync_status(nuts_chain* c) {   // the status record is host memory: a
 
 // Wait until the control kernel of the last leaf of a doubling has published sequence number `seq`
 // (spin on the mapped record; falls back to an error after 60 s so that a lost kernel cannot hang the process).
-static int wait_status(nuts_chain* c, int seq) {
-  volatile int* flag = &c->st_host->seq;
+static int wait_status(nuts_chain* c, int seq, unsigned* flags) {
+  volatile unsigned long long* word = &c->st_host->word;
   const auto t0 = std::chrono::steady_clock::now();
-  for (unsigned spins = 0; *flag != seq; ++spins) {
+  unsigned long long w;
+  for (unsigned spins = 0; (unsigned)((w = *word) >> 32) != (unsigned)seq; ++spins) {
     if ((spins & 0xfffff) == 0xfffff) {
-      if (hipStreamQuery(c->m->stream) == hipSuccess && *flag != seq) { g_err = "control kernel finished without publishing its status"; return NUTS_E_HIP; }
+      if (hipStreamQuery(c->m->stream) == hipSuccess && (unsigned)(*word >> 32) != (unsigned)seq) {
+        g_err = "control kernel finished without publishing its status";
+        return NUTS_E_HIP;
+      }
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { g_err = "timed out waiting for the device"; return NUTS_E_HIP; }
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
+  *flags = (unsigned)w;
   return NUTS_OK;
 }
 
@@ -966,22 +972,23 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   if (rc) return rc;
   // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
   // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
+  unsigned flags = 0;
   Geometry gm{uniforms[0] < 0.5 ? 1 : -1, 0, 0, 0, 0.0};
   gm.eps = gm.dir > 0 ? step_size : -step_size;
   for (int d = 0; d < max_depth; ++d) {
     const int nleaf = 1 << d;
     const int seq = ++c->seq;
     for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, gm, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
-    rc = wait_status(c, seq);
+    rc = wait_status(c, seq, &flags);
     if (rc) return rc;
-    const HostStatus st = *c->st_host;
-    if (st.bad_energy) break;
-    if (st.diverging || st.turning) { exhausted = false; break; }
+    if (flags & ST_BAD_ENERGY) break;
+    if (flags & (ST_DIVERGING | ST_TURNING)) { exhausted = false; break; }
     if (gm.dir > 0) gm.right += nleaf; else gm.left -= nleaf;   // nuts.py:353,362: the subtree's far end is the new edge
-    gm.dir = st.dir; gm.edge = st.edge;
+    gm.dir = (flags & ST_DIR_POS) ? 1 : -1;
+    gm.edge = gm.dir > 0 ? gm.right : gm.left;                  // nuts.py:347,356: the next subtree grows from that edge
     gm.eps = gm.dir > 0 ? step_size : -step_size;
   }
-  if (c->st_host->bad_energy) {
+  if (flags & ST_BAD_ENERGY) {
     // base_hmc.py:205-224: SamplingError("Bad initial energy"), after potential.raise_ok
     rc = check_mass_matrix(c);
     if (rc == NUTS_OK) g_err = "Bad initial energy, check any log probabilities that are inf or -inf, nan or very small";

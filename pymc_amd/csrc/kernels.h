@@ -75,10 +75,19 @@ struct ArenaDev {
   const double* log_uniforms;  // their logarithms, taken on the host (the tree compares log(u), nuts.py:371,466)
 };
 
-struct HostStatus {   // lives in pinned, device-mapped host memory: the control kernel writes it over PCIe
+// Lives in pinned, device-mapped host memory.  `word` = (sequence number << 32) | ST_* flags is written with ONE
+// system-scope store by the control work of the LAST leaf of a doubling; the host spins on it instead of paying a stream
+// synchronisation + copy per doubling, and everything it needs to go on (stop / keep doubling, next direction) is in
+// that word -- no fence, no second PCIe write to wait for.  The other fields are written once per draw by
+// k_draw_ctl_start and read after a stream synchronisation (fixed-length HMC).
+#define ST_ABORTED 1u
+#define ST_TURNING 2u
+#define ST_DIVERGING 4u
+#define ST_BAD_ENERGY 8u
+#define ST_DIR_POS 16u
+struct HostStatus {
+  unsigned long long word;
   int aborted, turning, diverging, bad_energy, depth, cursor, n_proposals, proposal, dir, edge;
-  int seq;   // written last (after a system-scope fence) by the control kernel of the LAST leaf of a doubling: the host
-  int pad;   // spins on it instead of paying a stream synchronisation + copy per doubling
 };
 
 struct EvalIO {
@@ -135,13 +144,16 @@ __device__ __forceinline__ int load_aborted(const EvalIO& io, const ArenaDev& A)
 }
 
 __device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st, int seq) {
+  if (!seq) return;   // only the last leaf of a doubling reports
+  const unsigned flags = (c->aborted ? ST_ABORTED : 0u) | (c->turning ? ST_TURNING : 0u) | (c->diverging ? ST_DIVERGING : 0u) |
+                         (c->bad_energy ? ST_BAD_ENERGY : 0u) | (c->dir > 0 ? ST_DIR_POS : 0u);
+  __hip_atomic_store(&st->word, ((unsigned long long)(unsigned)seq << 32) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ void publish_fields(const Ctl* c, HostStatus* st) {
   st->aborted = c->aborted; st->turning = c->turning; st->diverging = c->diverging; st->bad_energy = c->bad_energy;
   st->depth = c->depth; st->cursor = c->cursor; st->n_proposals = c->n_proposals; st->proposal = c->proposal;
   st->dir = c->dir; st->edge = c->edge;
-  if (seq) {
-    __threadfence_system();
-    __hip_atomic_store(&st->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1270,7 +1282,7 @@ __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part
     c->dir = 1; c->edge = 0; c->eps = step_size;
     if (dir_forced != 0) { c->dir = dir_forced; c->eps = dir_forced > 0 ? step_size : -step_size; }
     else if (!c->aborted && max_depth > 0) ctl_next_direction(c, A.uniforms);
-    if (st) publish_status(c, st, 0);
+    if (st) publish_fields(c, st);
   }
 }
 
