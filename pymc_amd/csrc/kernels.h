@@ -16,6 +16,9 @@
 //                                    cross-workgroup reduction), the energy, and the scalar tree logic of
 //                                    nuts.py:334-476 consuming the pre-drawn uniforms in reference order.
 //
+// On the "lean" path (hierarchical-logit and MvNormal models, see control_lean below) kernel C's work of leaf j is
+// folded into workgroup 0 of kernel A of leaf j+1 and overlaps the data pass: two launches per leapfrog.
+//
 // All reductions have a fixed order (no FP atomics): results are bit-reproducible run to run, which the
 // reference promises for a fixed seed (tests/sampling/test_mcmc.py:80-109).
 //
