@@ -620,6 +620,8 @@ struct nuts_chain {
   DrawOut* do_host = nullptr;
   double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
   int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
+  int spec_max = 3, last_depth = 0;   // look-ahead over the short doublings (nuts_chain_draw)
+  int logs_done = 0, logs_total = 0;  // logarithms of the pre-drawn uniforms taken / needed at most this draw
   int64_t leapfrogs = 0;
   int n_uni_cap = 0;
   template <typename T>
@@ -702,6 +704,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
   c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n));
   c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0;
+  c->spec_max = env_int("NUTS_SPEC_MAX", 3);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && m->md.nblk == 1 && n <= VEC_THREADS && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
              cfg->potential != NUTS_POT_FULL;
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
@@ -784,6 +787,22 @@ static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotent
 // Upload (q0, normals|p, uniforms), evaluate the model at q0 (plain A/B/C) and initialise the trajectory.
 //   p_exact: the second vector is the momentum itself (integrator tests) instead of standard normals
 //   dir_forced: +1/-1 fixes the direction (HMC / integrator tests); 0 = draw it from uniforms[0] (nuts.py:215)
+#define LOGS_FIRST 80   // doublings 0..5 consume uniform indices < 2^6 + 6 = 70
+
+// make sure the logarithms of uniforms [0, upto) are on the device before the launches that may read them are queued
+static int ensure_logs(nuts_chain* c, int upto) {
+  upto = std::min(upto, c->logs_total);
+  if (upto <= c->logs_done) return NUTS_OK;
+  const int n = c->n;
+  double* u = c->stage_host + 2 * n;
+  double* lu = u + c->n_uni_cap;
+  for (int i = c->logs_done; i < upto; ++i) lu[i] = std::log(u[i]);
+  HIPCHK(hipMemcpyAsync(c->stage_dev + 2 * (size_t)n + c->n_uni_cap + c->logs_done, lu + c->logs_done,
+                        (size_t)(upto - c->logs_done) * sizeof(double), hipMemcpyHostToDevice, c->m->stream));
+  c->logs_done = upto;
+  return NUTS_OK;
+}
+
 static int draw_begin(nuts_chain* c, const double* q0, const double* normals, const double* uniforms, int n_uniforms,
                       double step_size, int max_depth, bool p_exact, int dir_forced, bool allow_cache = false) {
   const int n = c->n;
@@ -802,8 +821,12 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
     double* u = c->stage_host + 2 * n;
     double* lu = u + c->n_uni_cap;
     std::memcpy(u, uniforms, nu * sizeof(double));
-    for (int i = 0; i < nu; ++i) lu[i] = std::log(u[i]);
-    HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + c->n_uni_cap + nu) * sizeof(double), hipMemcpyHostToDevice, s));
+    // most trees stop long before the worst case: only the logarithms the first doublings can consume are taken
+    // here, the rest just before the doubling that could reach them is queued (ensure_logs)
+    const int first = std::min(nu, LOGS_FIRST);
+    for (int i = 0; i < first; ++i) lu[i] = std::log(u[i]);
+    c->logs_done = first; c->logs_total = nu;
+    HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + c->n_uni_cap + first) * sizeof(double), hipMemcpyHostToDevice, s));
   } else {
     HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
   }
@@ -836,7 +859,7 @@ static int sync_status(nuts_chain* c) {   // the status record is host memory: a
 // Wait until the control kernel of the last leaf of a doubling has published sequence number `seq`
 // (spin on the mapped record; falls back to an error after 60 s so that a lost kernel cannot hang the process).
 static int wait_status(nuts_chain* c, int seq, unsigned* flags) {
-  volatile unsigned long long* word = &c->st_host->word;
+  volatile unsigned long long* word = &c->st_host->word[seq & (ST_SLOTS - 1)];
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long long w;
   for (unsigned spins = 0; (unsigned)((w = *word) >> 32) != (unsigned)seq; ++spins) {
@@ -975,19 +998,54 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   unsigned flags = 0;
   Geometry gm{uniforms[0] < 0.5 ? 1 : -1, 0, 0, 0, 0.0};
   gm.eps = gm.dir > 0 ? step_size : -step_size;
-  for (int d = 0; d < max_depth; ++d) {
+  // geometry of the doubling after `g` (which had 2^d leaves) once its direction is known (nuts.py:347-362)
+  auto next_geometry = [&](const Geometry& g, int d, int dir) {
+    Geometry r = g;
+    if (g.dir > 0) r.right += 1 << d; else r.left -= 1 << d;   // the finished subtree's far end is the new edge state
+    r.dir = dir;
+    r.edge = dir > 0 ? r.right : r.left;
+    r.eps = dir > 0 ? step_size : -step_size;
+    return r;
+  };
+  auto enqueue_doubling = [&](const Geometry& g, int d) {
     const int nleaf = 1 << d;
+    ensure_logs(c, (2 << d) + d + 1);   // this doubling reads uniform indices < 2^(d+1) + d + 1
     const int seq = ++c->seq;
-    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, gm, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
+    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, g, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
+    return seq;
+  };
+  // Look-ahead for the short doublings, where the host round trip (status word over PCIe, then the first launch of
+  // the next doubling) is comparable to the doubling itself: a doubling that runs to completion consumes a fixed
+  // number of uniforms (2^d - 1 merges, the `extend` acceptance, the next direction), so the direction of doubling
+  // d+1 is uniforms[2^(d+1) + d] whenever it is needed at all, and its launches can be queued before the status of
+  // doubling d arrives.  If the tree stops at d they drain as no-ops behind the `aborted` flag.  Only done as far as
+  // the previous draw's tree went, so a wasted look-ahead is rare.  The prediction is checked against the device.
+  const int spec = std::min(c->spec_max, c->last_depth - 1);
+  Geometry ahead{};
+  int ahead_seq = 0;
+  int seq = enqueue_doubling(gm, 0);
+  int depth_done = 0;
+  for (int d = 0; d < max_depth; ++d) {
+    if (d + 1 < max_depth && d + 1 <= spec) {
+      ahead = next_geometry(gm, d, uniforms[(2 << d) + d] < 0.5 ? 1 : -1);
+      ahead_seq = enqueue_doubling(ahead, d + 1);
+    } else ahead_seq = 0;
     rc = wait_status(c, seq, &flags);
     if (rc) return rc;
+    depth_done = d + 1;
     if (flags & ST_BAD_ENERGY) break;
     if (flags & (ST_DIVERGING | ST_TURNING)) { exhausted = false; break; }
-    if (gm.dir > 0) gm.right += nleaf; else gm.left -= nleaf;   // nuts.py:353,362: the subtree's far end is the new edge
-    gm.dir = (flags & ST_DIR_POS) ? 1 : -1;
-    gm.edge = gm.dir > 0 ? gm.right : gm.left;                  // nuts.py:347,356: the next subtree grows from that edge
-    gm.eps = gm.dir > 0 ? step_size : -step_size;
+    if (d + 1 >= max_depth) break;
+    const int dir = (flags & ST_DIR_POS) ? 1 : -1;
+    if (ahead_seq) {
+      if (ahead.dir != dir) { g_err = "internal error: look-ahead mispredicted the direction of a doubling"; return NUTS_E_HIP; }
+      gm = ahead; seq = ahead_seq;
+    } else {
+      gm = next_geometry(gm, d, dir);
+      seq = enqueue_doubling(gm, d + 1);
+    }
   }
+  c->last_depth = depth_done;
   if (flags & ST_BAD_ENERGY) {
     // base_hmc.py:205-224: SamplingError("Bad initial energy"), after potential.raise_ok
     rc = check_mass_matrix(c);

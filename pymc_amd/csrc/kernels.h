@@ -78,7 +78,7 @@ struct ArenaDev {
   const double* log_uniforms;  // their logarithms, taken on the host (the tree compares log(u), nuts.py:371,466)
 };
 
-// Lives in pinned, device-mapped host memory.  `word` = (sequence number << 32) | ST_* flags is written with ONE
+// Lives in pinned, device-mapped host memory.  `word[seq % ST_SLOTS]` = (sequence number << 32) | ST_* flags is written with ONE
 // system-scope store by the control work of the LAST leaf of a doubling; the host spins on it instead of paying a stream
 // synchronisation + copy per doubling, and everything it needs to go on (stop / keep doubling, next direction) is in
 // that word -- no fence, no second PCIe write to wait for.  The other fields are written once per draw by
@@ -88,8 +88,9 @@ struct ArenaDev {
 #define ST_DIVERGING 4u
 #define ST_BAD_ENERGY 8u
 #define ST_DIR_POS 16u
+#define ST_SLOTS 4   // doublings publish round-robin (the host may have queued the next doubling before reading this one)
 struct HostStatus {
-  unsigned long long word;
+  unsigned long long word[ST_SLOTS];
   int aborted, turning, diverging, bad_energy, depth, cursor, n_proposals, proposal, dir, edge;
 };
 
@@ -150,7 +151,8 @@ __device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st, int
   if (!seq) return;   // only the last leaf of a doubling reports
   const unsigned flags = (c->aborted ? ST_ABORTED : 0u) | (c->turning ? ST_TURNING : 0u) | (c->diverging ? ST_DIVERGING : 0u) |
                          (c->bad_energy ? ST_BAD_ENERGY : 0u) | (c->dir > 0 ? ST_DIR_POS : 0u);
-  __hip_atomic_store(&st->word, ((unsigned long long)(unsigned)seq << 32) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&st->word[seq & (ST_SLOTS - 1)], ((unsigned long long)(unsigned)seq << 32) | flags, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ void publish_fields(const Ctl* c, HostStatus* st) {
