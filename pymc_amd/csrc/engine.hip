@@ -622,6 +622,7 @@ struct nuts_chain {
   int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
   int spec_max = 3, last_depth = 0;   // look-ahead over the short doublings (nuts_chain_draw)
   int logs_done = 0, logs_total = 0;  // logarithms of the pre-drawn uniforms taken / needed at most this draw
+  double t_begin = 0, t_loop = 0, t_wait = 0, t_finish = 0, t_post = 0;   // host seconds per phase of nuts_chain_draw, summed
   int64_t leapfrogs = 0;
   int n_uni_cap = 0;
   template <typename T>
@@ -993,6 +994,8 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   } else {
   rc = draw_begin(c, q0, normals, uniforms, need_uni, step_size, max_depth, false, 0, true);
   if (rc) return rc;
+  const auto tb = clk::now();
+  c->t_begin += std::chrono::duration<double>(tb - t0).count();
   // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
   // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
   unsigned flags = 0;
@@ -1030,7 +1033,9 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
       ahead = next_geometry(gm, d, uniforms[(2 << d) + d] < 0.5 ? 1 : -1);
       ahead_seq = enqueue_doubling(ahead, d + 1);
     } else ahead_seq = 0;
+    const auto tw0 = clk::now();
     rc = wait_status(c, seq, &flags);
+    c->t_wait += std::chrono::duration<double>(clk::now() - tw0).count();
     if (rc) return rc;
     depth_done = d + 1;
     if (flags & ST_BAD_ENERGY) break;
@@ -1046,6 +1051,8 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
     }
   }
   c->last_depth = depth_done;
+  const auto tl = clk::now();
+  c->t_loop += std::chrono::duration<double>(tl - tb).count();
   if (flags & ST_BAD_ENERGY) {
     // base_hmc.py:205-224: SamplingError("Bad initial energy"), after potential.raise_ok
     rc = check_mass_matrix(c);
@@ -1058,6 +1065,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   HIPCHK(hipMemcpyAsync(c->do_host, c->do_dev, sizeof(DrawOut), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
+  c->t_finish += std::chrono::duration<double>(clk::now() - tl).count();
   }
   const double* const result_dev = c->small ? c->out_dev2 : c->out_dev;   // (q, grad) of the proposal on the device
   const DrawOut& o = *c->do_host;
@@ -1252,6 +1260,10 @@ extern "C" int nuts_chain_get_scalar(nuts_chain* c, const char* name, double* ou
   else if (k == "bg_count") *out = c->bg_count;
   else if (k == "step_size") *out = c->step_size;
   else if (k == "leapfrogs") *out = (double)c->leapfrogs;
+  else if (k == "t_begin") *out = c->t_begin;
+  else if (k == "t_loop") *out = c->t_loop;
+  else if (k == "t_wait") *out = c->t_wait;
+  else if (k == "t_finish") *out = c->t_finish;
   else { g_err = "unknown scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
 }

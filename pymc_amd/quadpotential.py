@@ -10,11 +10,43 @@ to the reference, and (c) expose the adapted vectors for inspection/tests.
 
 from __future__ import annotations
 
+import os
+import queue
+import threading
+
 import numpy as np
 
 from pymc_amd import _lib
 
 POT_DIAG_ADAPT, POT_DIAG, POT_FULL = 0, 1, 2
+
+_PREFETCH_ON = os.environ.get("PYMC_AMD_PREFETCH_NORMALS", "1") != "0"
+_REQUESTS = None
+_WORKER_LOCK = threading.Lock()
+
+
+def _normals_worker(requests):
+    gen = np.random.Generator(np.random.PCG64(0))
+    while True:
+        state, n, reply = requests.get()
+        gen.bit_generator.state = state
+        z = gen.normal(size=n)          # (NumPy fills the array without the GIL)
+        reply.put((z, gen.bit_generator.state))
+
+
+def _request_normals(state, n):
+    """Ask the worker thread for `normal(size=n)` of a generator in `state`; returns the queue the answer
+    `(vector, state afterwards)` will arrive on."""
+    global _REQUESTS
+    if _REQUESTS is None:
+        with _WORKER_LOCK:
+            if _REQUESTS is None:
+                q = queue.SimpleQueue()
+                threading.Thread(target=_normals_worker, args=(q,), daemon=True, name="pymc_amd_normals").start()
+                _REQUESTS = q
+    reply = queue.SimpleQueue()
+    _REQUESTS.put((state, n, reply))
+    return reply
 
 
 class PositiveDefiniteError(ValueError):
@@ -47,13 +79,44 @@ class QuadPotential:
 
     def set_rng(self, rng):  # quadpotential.py:180-182
         self.rng = rng if isinstance(rng, np.random.Generator) else np.random.default_rng(rng)
+        self._prefetch = None
 
     def _bind(self, step):
         self._step = step
 
+    # The momentum normals of draw k+1 do not depend on draw k (the potential owns its generator,
+    # base_hmc.py:300-302), and `rng.normal(10 000)` costs ~100 us of host time -- as much as a leapfrog and a half
+    # of the benchmark model.  So while the device runs draw k, a worker thread draws the next vector from a private
+    # clone of the generator; `self.rng` itself is only moved forward when that vector is consumed, and only if its
+    # state is still the one the clone started from.  Anyone who looks at, saves or uses `potential.rng` in between
+    # sees exactly what the reference's generator would hold.
+    _prefetch = None   # (reply queue, generator state the clone started from, size)
+    _PREFETCH_MIN = 2048
+
     def _draw_normals(self):
         """The host half of `random()`: `rng.normal(size=n)`; the device multiplies by 1/sigma."""
-        return self.rng.normal(size=self._n)
+        n = self._n
+        if n < self._PREFETCH_MIN or not _PREFETCH_ON:
+            return self.rng.normal(size=n)
+        bg = self.rng.bit_generator
+        z = None
+        pf, self._prefetch = self._prefetch, None
+        if pf is not None:
+            reply, base, size = pf
+            if size == n and bg.state == base:
+                z, after = reply.get()
+                bg.state = after
+        if z is None:
+            z = self.rng.normal(size=n)
+        base = bg.state
+        if base.get("bit_generator") == "PCG64":
+            self._prefetch = (_request_normals(base, n), base, n)
+        return z
+
+    def __getstate__(self):   # a pending prefetch does not travel (cloudpickle of the step for worker processes)
+        d = dict(self.__dict__)
+        d.pop("_prefetch", None)
+        return d
 
     def stats(self):  # quadpotential.py:177-178
         return {"largest_eigval": np.nan, "smallest_eigval": np.nan}

@@ -235,3 +235,29 @@ def test_ess_on_ar1_and_iid():
     d = np.stack([iid, x], axis=-1)
     m, arg = min_ess_bulk(d)
     assert arg == 1 and m == pytest.approx(ess_bulk(x))
+
+
+def test_prefetched_momentum_normals_are_transparent():
+    """The potential draws the next draw's momentum normals on a worker thread (quadpotential.py, `_draw_normals`).
+    Nothing observable may change: values and generator state match `rng.normal(size=n)` call for call
+    (base_hmc.py:300-302, quadpotential.py:323-326), also when the generator is used or replaced in between."""
+    import pickle
+
+    from pymc_amd.quadpotential import QuadPotentialDiag
+
+    n = 4096
+    pot = QuadPotentialDiag(np.ones(n), rng=np.random.default_rng(7))
+    ref = np.random.default_rng(7)
+    for k in range(4):
+        assert np.array_equal(pot._draw_normals(), ref.normal(size=n)), k
+        assert pot.rng.bit_generator.state == ref.bit_generator.state, k
+    assert pot._prefetch is not None
+    assert pot.rng.random() == ref.random()          # someone else uses the generator: the prefetch is dropped
+    assert np.array_equal(pot._draw_normals(), ref.normal(size=n))
+    assert pot.rng.bit_generator.state == ref.bit_generator.state
+    pot.set_rng(np.random.default_rng(9))             # compound.py:233-250 `setup_chain`
+    ref = np.random.default_rng(9)
+    assert np.array_equal(pot._draw_normals(), ref.normal(size=n))
+    clone = pickle.loads(pickle.dumps(pot))           # a pending prefetch does not travel
+    assert clone._prefetch is None
+    assert np.array_equal(clone._draw_normals(), ref.normal(size=n))
