@@ -217,6 +217,10 @@ def main():
                 "launches_timed": int(allv[:, 4].sum()),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                # the whole leapfrog (row pass + kernel B + launch gaps + the per-draw / per-doubling host round trips of
+                # the timed region) against the same line: SURVEY 8d bytes per leapfrog x leapfrogs/s per chain
+                "leapfrog_algorithmic_bytes": alg_bytes + 144 * spec.n,
+                "leapfrog_frac": (alg_bytes + 144 * spec.n) * (leap_total / T / world) / 8.0e12,
             },
         }
         if world == 1 and args.cpu_leapfrogs > 0:

@@ -207,6 +207,20 @@ int nuts_chain_set_iter_count(nuts_chain *c, int64_t iter_count);
 int nuts_chain_draw(nuts_chain *c, const double *q0, const double *normals, const double *uniforms,
                     int32_t n_uniforms, double *q_out, double *grad_out, nuts_draw_stats *stats);
 
+/* K consecutive post-tuning transitions in one device launch (removes the per-draw host round trip
+ * of sampling/mcmc.py:1556-1572 for models on the single-workgroup path).  Between two draws of the sampling phase
+ * the reference changes nothing on the host: `step_adapt.update` and `potential.update` return immediately when
+ * `tune` is false (step_sizes.py:66-68, quadpotential.py:335-337).
+ *   normals  [K][n]      K calls of potential.rng.normal(size=n) == one call of size K*n
+ *   uniforms [n_uniforms] the next values of step.rng.random(); one worst-case tree needs 2^max_treedepth +
+ *                         max_treedepth + 1 of them, the batch stops when fewer are left
+ *   q_out    [K][n]      positions of the draws made;  *n_done how many (fewer than K after a divergent draw,
+ *                         whose two phase-space points stay readable through nuts_chain_get_vector)
+ *   stats    [K]         per draw; n_uniforms_consumed is CUMULATIVE over the batch
+ * Errors: NUTS_E_ARG when the chain is still tuning or the model is not on the single-launch path. */
+int nuts_chain_draw_many(nuts_chain *c, const double *q0, const double *normals, const double *uniforms,
+                         int32_t n_uniforms, int32_t K, double *q_out, nuts_draw_stats *stats, int32_t *n_done);
+
 /* HamiltonianMC._hamiltonian_step (pymc/step_methods/hmc/hmc.py:130-184):
  * uniforms[0] jitters the step size (hmc.py:35-36), uniforms[1] is the accept draw. */
 typedef struct {

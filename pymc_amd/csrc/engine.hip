@@ -622,6 +622,9 @@ struct nuts_chain {
   int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
   int spec_max = 3, last_depth = 0;   // look-ahead over the short doublings (nuts_chain_draw)
   int logs_done = 0, logs_total = 0;  // logarithms of the pre-drawn uniforms taken / needed at most this draw
+  // staging of nuts_chain_draw_many (grown on demand)
+  double* many_in_host = nullptr; double* many_in_dev = nullptr; char* many_out_host = nullptr; char* many_out_dev = nullptr;
+  size_t many_in_cap = 0, many_out_cap = 0;
   double t_begin = 0, t_loop = 0, t_wait = 0, t_finish = 0, t_post = 0;   // host seconds per phase of nuts_chain_draw, summed
   int64_t leapfrogs = 0;
   int n_uni_cap = 0;
@@ -737,6 +740,10 @@ extern "C" void nuts_chain_destroy(nuts_chain* c) {
   if (c->out_host) hipHostFree(c->out_host);
   if (c->st_host) hipHostFree(c->st_host);
   if (c->do_host) hipHostFree(c->do_host);
+  if (c->many_in_host) hipHostFree(c->many_in_host);
+  if (c->many_out_host) hipHostFree(c->many_out_host);
+  if (c->many_in_dev) hipFree(c->many_in_dev);
+  if (c->many_out_dev) hipFree(c->many_out_dev);
   delete c;
 }
 
@@ -967,17 +974,16 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
     c->cache_ok = false;
     std::memcpy(c->stage_host, q0, n * sizeof(double));
     std::memcpy(c->stage_host + n, normals, n * sizeof(double));
-    double* u = c->stage_host + 2 * n;
-    double* lu = u + c->n_uni_cap;
-    std::memcpy(u, uniforms, need_uni * sizeof(double));
-    for (int i = 0; i < need_uni; ++i) lu[i] = std::log(u[i]);
-    HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + c->n_uni_cap + need_uni) * sizeof(double), hipMemcpyHostToDevice, s));
+    // (this path takes log(u) on the device, small_kernel.h: only the uniforms travel)
+    std::memcpy(c->stage_host + 2 * n, uniforms, need_uni * sizeof(double));
+    HIPCHK(hipMemcpyAsync(c->stage_dev, c->stage_host, (2 * (size_t)n + need_uni) * sizeof(double), hipMemcpyHostToDevice, s));
     if (!cached) HIPCHK(hipMemcpyAsync(A.Q, c->stage_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     SmallDrawArgs a{};
     a.normals = c->stage_dev + n;
     a.q_src = cached ? c->out_dev2 : nullptr; a.g_src = cached ? c->out_dev2 + n : nullptr; a.cached_logp = c->last_logp;
     a.step_size = step_size; a.Emax = c->cfg.Emax; a.max_depth = max_depth;
-    a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.out = c->do_dev; a.st = nullptr; a.seq = 0;
+    a.n_draws = 1; a.n_uniforms = need_uni; a.worst_uniforms = need_uni;
+    a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = nullptr; a.out = c->do_dev; a.n_done = nullptr; a.st = nullptr; a.seq = 0;
     hipLaunchKernelGGL(k_small_draw, dim3(1), dim3(VEC_THREADS), 0, s, c->m->md, A, a);
     // the next draw's start-state cache must not alias this draw's output buffer
     std::swap(c->out_dev, c->out_dev2);
@@ -1112,6 +1118,123 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   stats->perf_counter_start = perf_start;
   stats->perf_counter_diff = std::chrono::duration<double>(t1 - t0).count();
   stats->process_time_diff = (double)(c1 - c0) / CLOCKS_PER_SEC;
+  return NUTS_OK;
+}
+
+// K consecutive post-tuning NUTS transitions in ONE launch (single-workgroup models; small_kernel.h).
+// `normals` is [K][n] (K calls of `potential.rng.normal(size=n)` draw exactly the values of one call of size K n),
+// `uniforms` the next `n_uniforms` values of `step.rng.random()`.  On return `*n_done` draws were made (fewer than
+// K after a divergent draw or when the uniforms could not cover another worst-case tree), `q_out` holds their
+// positions [n_done][n], `stats[i].n_uniforms_consumed` the TOTAL consumed up to and including draw i.
+extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
+                                    int32_t n_uniforms, int32_t K, double* q_out, nuts_draw_stats* stats, int32_t* n_done) {
+  if (!c || !q0 || !normals || !uniforms || !q_out || !stats || !n_done || K <= 0) { g_err = "null argument"; return NUTS_E_ARG; }
+  if (!c->small) { g_err = "nuts_chain_draw_many: only models on the single-launch path (n <= 256, element-wise, diagonal mass matrix)"; return NUTS_E_ARG; }
+  if (c->tune) { g_err = "nuts_chain_draw_many: the chain is still tuning (adaptation needs the host between draws)"; return NUTS_E_ARG; }
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  const double perf_start = std::chrono::duration<double>(t0.time_since_epoch()).count();
+  const std::clock_t c0 = std::clock();
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  ArenaDev& A = c->A;
+  const double step_size = c->da.current(false);   // exp(log_step_size_bar) (step_sizes.py:60-64)
+  c->step_size = step_size;
+  const int max_depth = c->cfg.max_treedepth;
+  const int need_uni = (1 << max_depth) + max_depth + 1;
+  if (n_uniforms < need_uni) { g_err = "not enough uniforms for the worst-case tree"; return NUTS_E_ARG; }
+  // staging: q0 | normals [K][n] | uniforms   ->  trace [K][n] | DrawOut [K] | n_done
+  const size_t in_doubles = (size_t)n + (size_t)K * n + (size_t)n_uniforms;
+  const size_t out_bytes = (size_t)K * n * sizeof(double) + (size_t)K * sizeof(DrawOut) + 16;
+  if (in_doubles > c->many_in_cap || out_bytes > c->many_out_cap) {
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->many_in_host) hipHostFree(c->many_in_host);
+    if (c->many_out_host) hipHostFree(c->many_out_host);
+    if (c->many_in_dev) hipFree(c->many_in_dev);
+    if (c->many_out_dev) hipFree(c->many_out_dev);
+    c->many_in_host = nullptr; c->many_out_host = nullptr; c->many_in_dev = nullptr; c->many_out_dev = nullptr;
+    c->many_in_cap = c->many_out_cap = 0;
+    HIPCHK(hipHostMalloc((void**)&c->many_in_host, in_doubles * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->many_out_host, out_bytes, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&c->many_in_dev, in_doubles * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&c->many_out_dev, out_bytes));
+    c->many_in_cap = in_doubles; c->many_out_cap = out_bytes;
+  }
+  const bool cached = c->cache_ok && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
+  c->cache_ok = false;
+  std::memcpy(c->many_in_host, q0, n * sizeof(double));
+  std::memcpy(c->many_in_host + n, normals, (size_t)K * n * sizeof(double));
+  std::memcpy(c->many_in_host + n + (size_t)K * n, uniforms, (size_t)n_uniforms * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c->many_in_dev, c->many_in_host, in_doubles * sizeof(double), hipMemcpyHostToDevice, s));
+  if (!cached) HIPCHK(hipMemcpyAsync(A.Q, c->many_in_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  double* trace_dev = reinterpret_cast<double*>(c->many_out_dev);
+  DrawOut* outs_dev = reinterpret_cast<DrawOut*>(c->many_out_dev + (size_t)K * n * sizeof(double));
+  int* ndone_dev = reinterpret_cast<int*>(c->many_out_dev + (size_t)K * n * sizeof(double) + (size_t)K * sizeof(DrawOut));
+  ArenaDev Am = A;
+  Am.uniforms = c->many_in_dev + n + (size_t)K * n;
+  SmallDrawArgs a{};
+  a.normals = c->many_in_dev + n;
+  a.q_src = cached ? c->out_dev2 : nullptr; a.g_src = cached ? c->out_dev2 + n : nullptr; a.cached_logp = c->last_logp;
+  a.step_size = step_size; a.Emax = c->cfg.Emax; a.max_depth = max_depth;
+  a.n_draws = K; a.n_uniforms = n_uniforms; a.worst_uniforms = need_uni;
+  a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = trace_dev; a.out = outs_dev; a.n_done = ndone_dev; a.st = nullptr; a.seq = 0;
+  hipLaunchKernelGGL(k_small_draw, dim3(1), dim3(VEC_THREADS), 0, s, c->m->md, Am, a);
+  std::swap(c->out_dev, c->out_dev2);   // (q, grad) of the last proposal: the next call's start-state cache
+  HIPCHK(hipMemcpyAsync(c->many_out_host, c->many_out_dev, out_bytes, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  const double* trace_host = reinterpret_cast<const double*>(c->many_out_host);
+  const DrawOut* outs = reinterpret_cast<const DrawOut*>(c->many_out_host + (size_t)K * n * sizeof(double));
+  const int done = *reinterpret_cast<const int*>(c->many_out_host + (size_t)K * n * sizeof(double) + (size_t)K * sizeof(DrawOut));
+  *n_done = done;
+  if (done <= 0 || done > K) { g_err = "nuts_chain_draw_many: the device reported an impossible draw count"; return NUTS_E_HIP; }
+  if (outs[done - 1].bad_energy) {
+    int rc = check_mass_matrix(c);
+    if (rc == NUTS_OK) g_err = "Bad initial energy, check any log probabilities that are inf or -inf, nan or very small";
+    return NUTS_E_BAD_ENERGY;
+  }
+  const auto t1 = clk::now();
+  const std::clock_t c1 = std::clock();
+  const double wall = std::chrono::duration<double>(t1 - t0).count() / done;
+  const double cpu = (double)(c1 - c0) / CLOCKS_PER_SEC / done;
+  for (int i = 0; i < done; ++i) {
+    const DrawOut& o = outs[i];
+    const bool diverging = o.diverging != 0;
+    c->divergences += diverging;          // (not tuning: base_hmc.py:270-273)
+    c->iter_count += 1;
+    nuts_draw_stats* st = stats + i;
+    std::memset(st, 0, sizeof(*st));
+    st->depth = o.depth;
+    st->step_size = std::exp(c->da.log_step);
+    st->step_size_bar = std::exp(c->da.log_bar);
+    st->mean_tree_accept = std::exp(o.log_accept_sum) / o.n_proposals;
+    st->tree_size = o.n_proposals;
+    st->diverging = diverging;
+    st->reached_max_treedepth = !(o.diverging || o.turning) ? 1 : 0;   // nuts.py:220-221 (tune is false here)
+    st->divergences = c->divergences;
+    st->energy_error = o.energy - o.E0;
+    st->energy = o.energy;
+    st->max_energy_error = o.max_energy_change;
+    st->model_logp = o.logp;
+    st->index_in_trajectory = o.proposal;
+    st->n_uniforms_consumed = o.cursor;
+    st->warning = diverging ? 1 : 0;
+    st->divergence_energy_change = o.div_dE;
+    st->n_model_evals = o.n_proposals + (i == 0 && !cached ? 1 : 0);
+    st->perf_counter_start = perf_start + i * wall;
+    st->perf_counter_diff = wall;
+    st->process_time_diff = cpu;
+  }
+  const DrawOut& last = outs[done - 1];
+  if (last.diverging) {   // only the last draw of a batch can be divergent: its two points are still in the arena
+    const int dir = last.div_t > 0 ? 1 : -1;
+    c->div_source.resize(n); c->div_dest.resize(n);
+    HIPCHK(hipMemcpy(c->div_dest.data(), A.Q + (int64_t)(last.div_t & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c->div_source.data(), A.Q + (int64_t)((last.div_t - dir) & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  std::memcpy(q_out, trace_host, (size_t)done * n * sizeof(double));
+  c->last_q.assign(trace_host + (size_t)(done - 1) * n, trace_host + (size_t)done * n);
+  c->last_logp = last.logp; c->cache_ok = true;
   return NUTS_OK;
 }
 
@@ -1260,6 +1383,7 @@ extern "C" int nuts_chain_get_scalar(nuts_chain* c, const char* name, double* ou
   else if (k == "bg_count") *out = c->bg_count;
   else if (k == "step_size") *out = c->step_size;
   else if (k == "leapfrogs") *out = (double)c->leapfrogs;
+  else if (k == "single_launch") *out = c->small ? 1.0 : 0.0;
   else if (k == "t_begin") *out = c->t_begin;
   else if (k == "t_loop") *out = c->t_loop;
   else if (k == "t_wait") *out = c->t_wait;

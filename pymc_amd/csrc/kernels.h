@@ -75,7 +75,8 @@ struct ArenaDev {
   const double *var, *inv_stds;  // diagonal potential (quadpotential.py:308-326)
   Ctl* ctl;
   const double* uniforms;   // pre-drawn `step.rng.random()` values
-  const double* log_uniforms;  // their logarithms, taken on the host (the tree compares log(u), nuts.py:371,466)
+  const double* log_uniforms;  // their logarithms, taken on the host (the tree compares log(u), nuts.py:371,466);
+                               // nullptr (single-launch path): the control code takes log(u) itself
 };
 
 // Lives in pinned, device-mapped host memory.  `word[seq % ST_SLOTS]` = (sequence number << 32) | ST_* flags is written with ONE
@@ -791,7 +792,8 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
         if (!turning) turning = (dd[4] <= 0) || (dd[5] <= 0);
       }
       const double ls = logaddexp_d(c->st_ls[l], cur_ls);                   // nuts.py:464
-      const double logu = A.log_uniforms[c->cursor++];
+      const double logu = A.log_uniforms ? A.log_uniforms[c->cursor] : log(A.uniforms[c->cursor]);
+      c->cursor++;
       if (logu < cur_ls - ls) { /* keep tree2's proposal */ } else cur_prop = c->st_prop[l];
       cur_ls = ls;
     }
@@ -803,7 +805,8 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
       // extend (nuts.py:365-392)
       if (dir > 0) c->right = t; else c->left = t;
       c->depth += 1;
-      const double logu = A.log_uniforms[c->cursor++];
+      const double logu = A.log_uniforms ? A.log_uniforms[c->cursor] : log(A.uniforms[c->cursor]);
+      c->cursor++;
       if (logu < cur_ls - c->log_size) c->proposal = cur_prop;
       c->log_size = logaddexp_d(cur_ls, c->log_size);
       const double* dd = &dot[DOT_TOP];

@@ -1,4 +1,4 @@
-// Latency regime: a whole NUTS draw in ONE launch of ONE workgroup.
+// Latency regime: whole NUTS draws in ONE launch of ONE workgroup.
 //
 // For tiny models (SURVEY.md section 7 "small-n latency": eight schools has n = 10 / 26) a leapfrog is a few
 // hundred flops; three launches per leapfrog plus a host round trip per doubling cost two orders of magnitude more
@@ -9,19 +9,36 @@
 // leaf_post, tree_decide), in the same order, so the results are identical; only the summation of the partial dot
 // products changes (one workgroup instead of per-workgroup partials), which is why the two paths are not bitwise
 // interchangeable within one chain.
+//
+// Multi-draw loop.  After tuning nothing on the host changes between draws (fixed step size, frozen
+// mass matrix; `step_adapt.update` and `potential.update` return immediately when `tune` is false,
+// step_sizes.py:66-68, quadpotential.py:335-337), so `n_draws` consecutive transitions run in one launch: draw k+1
+// starts from draw k's proposal (position, gradient and logp are already in the arena), takes row k+1 of the
+// pre-drawn momentum normals and continues in the SAME pre-drawn uniform stream where draw k stopped -- exactly the
+// values `step.rng.random()` would have handed out.  Positions go to a device trace buffer, statistics to a DrawOut
+// per draw; the host gathers both once.  The batch stops early after a divergent draw (the host wants the two
+// phase-space points of a divergence, base_hmc.py:249-258, which live in the arena until the next draw overwrites
+// them) and when the remaining uniforms could not cover a worst-case tree.
+//
+// log(u): the tree compares `log(rng.random())` (nuts.py:371,466).  The three-kernel pipeline gets those
+// logarithms from the host; here they would cost more host time than the whole tree (a worst-case buffer per draw,
+// of which a typical tree reads ten), so the control thread takes `log` of the uniforms it actually consumes.
 #pragma once
 #include "kernels.h"
 
 struct SmallDrawArgs {
-  const double* normals;   // [n] standard normals of potential.random()
+  const double* normals;   // [n_draws][n] standard normals of potential.random()
   const double* q_src;     // start-state cache (or nullptr: evaluate the model at A.Q slot 0)
   const double* g_src;
   double cached_logp;
   double step_size, Emax;
-  int max_depth, pad;
-  double* q_out;
+  int max_depth, n_draws;
+  int n_uniforms, worst_uniforms;   // uniforms available in A.uniforms; what one worst-case tree can consume
+  double* q_out;           // (q, grad) of the LAST draw's proposal: the next launch's start-state cache
   double* g_out;
-  DrawOut* out;
+  double* trace_q;         // [n_draws][n] proposals (nullptr when n_draws == 1: q_out is the only output)
+  DrawOut* out;            // [n_draws]
+  int* n_done;             // draws actually made (device int)
   HostStatus* st;
   int seq, pad2;
 };
@@ -34,6 +51,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_small_draw(ModelDev md, ArenaDe
   __shared__ double s_dot[NDOT];
   __shared__ double s_w[NW];
   __shared__ Ctl s_ctl;
+  __shared__ int s_stop;
   const int tid = threadIdx.x;
   const int n = md.n;
   const bool mine = tid < n;
@@ -44,6 +62,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_small_draw(ModelDev md, ArenaDe
   VarDev v{};
   if (mine) { k = find_var(pg, tid); v = pg.vars[k]; }
   for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
+  if (tid == 0) { s_ctl.cursor = 0; s_stop = 0; }
   __syncthreads();
 
   // logp and d logp / dq_i at the position seen through `qv` (this thread's coordinate is `qn`)
@@ -81,101 +100,123 @@ __global__ __launch_bounds__(VEC_THREADS) void k_small_draw(ModelDev md, ArenaDe
     logp = block_sum<true>(lp, s_w);
   };
 
-  // ---- start state (base_hmc.py:201-202): q0, its gradient and logp; p0 = z / sigma; E0 ----
-  double logp0 = a.cached_logp;
-  if (a.q_src) {
-    if (mine) { A.Q[tid] = a.q_src[tid]; A.G[tid] = a.g_src[tid]; }
-  } else {
-    QView qv;
-    qv.q = A.Q; qv.p = qv.g = qv.var = nullptr; qv.eps = qv.half = 0.0; qv.composed = 0;
-    double g0;
-    eval_model(qv, mine ? A.Q[tid] : 0.0, g0, logp0);
-    if (mine) A.G[tid] = g0;
-  }
-  double kin = 0.0;
-  if (mine) {
-    const double p = a.normals[tid] * A.inv_stds[tid];
-    const double vv = A.var[tid] * p;
-    A.P[tid] = p; A.V[tid] = vv; A.PSUM[tid] = p;
-    kin = p * vv;
-  }
-  const double kin0 = block_sum<true>(kin, s_w);
-  if (tid == 0) {
-    Ctl* c = &s_ctl;
-    const double E = 0.5 * kin0 - logp0;  // integration.py:72-74
-    A.LOGP[0] = logp0; A.E[0] = E;
-    c->E0 = E; c->log_size = 0.0; c->log_accept_sum = -INFINITY; c->max_energy_change = 0.0; c->div_dE = 0.0;
-    c->n_proposals = 0; c->depth = 0; c->left = 0; c->right = 0; c->proposal = 0; c->cursor = 0;
-    c->turning = 0; c->diverging = 0; c->div_t = 0;
-    c->bad_energy = !isfinite(E);
-    c->aborted = c->bad_energy;
-    c->eps_abs = a.step_size; c->n_leaves_total = 0;
-    c->dir = 1; c->edge = 0; c->eps = a.step_size;
-    if (!c->aborted && a.max_depth > 0) ctl_next_direction(c, A.uniforms);
-  }
-  __syncthreads();
-
-  // ---- the tree (nuts.py:204-225) ----
-  for (int d = 0; d < a.max_depth && !s_ctl.aborted; ++d) {
-    Leaf lf;
-    lf.dir = s_ctl.dir; lf.edge = s_ctl.edge; lf.left = s_ctl.left; lf.right = s_ctl.right;
-    lf.eps = s_ctl.eps; lf.half = 0.5 * s_ctl.eps;
-    const int nleaf = 1 << d;
-    for (int j = 0; j < nleaf; ++j) {
-      lf.src = lf.edge + lf.dir * j;
-      lf.t = lf.src + lf.dir;
-      lf.so = slot_off(A, lf.src); lf.d_o = slot_off(A, lf.t);
+  A.log_uniforms = nullptr;   // log(u) is taken by the control thread (header comment)
+  int done = 0;
+  double q_prop = 0.0, g_prop = 0.0, logp_prop = 0.0;   // previous draw's proposal (this thread's coordinate)
+  for (int it = 0; it < a.n_draws; ++it) {
+    // ---- start state (base_hmc.py:201-202): q0, its gradient and logp; p0 = z / sigma; E0 ----
+    double logp0 = a.cached_logp;
+    if (it > 0) {
+      if (mine) { A.Q[tid] = q_prop; A.G[tid] = g_prop; }
+      logp0 = logp_prop;
+    } else if (a.q_src) {
+      if (mine) { A.Q[tid] = a.q_src[tid]; A.G[tid] = a.g_src[tid]; }
+    } else {
       QView qv;
-      qv.q = A.Q + lf.so; qv.p = A.P + lf.so; qv.g = A.G + lf.so; qv.var = A.var;
-      qv.eps = lf.eps; qv.half = lf.half; qv.composed = 1;
-      // first half of the leapfrog (integration.py:118-127), gradient at q'
-      int idx[1] = {tid};
-      bool act[1] = {mine};
-      double grad[1] = {0.0}, ph[1] = {0.0};
-      double qn = 0.0, logp;
-      if (mine) {
-        ph[0] = qv.p_half(tid);
-        qn = qv.at(tid);
-        A.Q[lf.d_o + tid] = qn;
-      }
-      eval_model(qv, qn, grad[0], logp);
-      if (mine) A.G[lf.d_o + tid] = grad[0];
-      // second half kick, v', kinetic energy and the U-turn dots of the merges this leaf completes
-      int m; bool last;
-      leaf_post<1>(A, lf, j, d, true, idx, act, grad, ph, s_red, NW, m, last);
-      __syncthreads();
-      for (int q = tid; q < NDOT; q += VEC_THREADS) {
-        if (!dot_needed(q, m, last)) continue;
-        double r = 0.0;
-        for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];
-        s_dot[q] = r;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const int ts = lf.t & (A.S - 1);
-        const double E = 0.5 * s_dot[0] - logp;  // integration.py:133-134
-        A.LOGP[ts] = logp; A.E[ts] = E;
-        tree_decide(&s_ctl, A, lf, s_dot, E, m, last, a.Emax, a.max_depth);
-      }
-      __syncthreads();   // also makes this leaf's arena stores visible to the whole workgroup
-      if (s_ctl.aborted) break;
+      qv.q = A.Q; qv.p = qv.g = qv.var = nullptr; qv.eps = qv.half = 0.0; qv.composed = 0;
+      double g0;
+      eval_model(qv, mine ? A.Q[tid] : 0.0, g0, logp0);
+      if (mine) A.G[tid] = g0;
     }
-    if (s_ctl.depth >= a.max_depth) break;
-  }
+    double kin = 0.0;
+    if (mine) {
+      const double p = a.normals[(int64_t)it * n + tid] * A.inv_stds[tid];
+      const double vv = A.var[tid] * p;
+      A.P[tid] = p; A.V[tid] = vv; A.PSUM[tid] = p;
+      kin = p * vv;
+    }
+    const double kin0 = block_sum<true>(kin, s_w);
+    if (tid == 0) {
+      Ctl* c = &s_ctl;
+      const double E = 0.5 * kin0 - logp0;  // integration.py:72-74
+      A.LOGP[0] = logp0; A.E[0] = E;
+      c->E0 = E; c->log_size = 0.0; c->log_accept_sum = -INFINITY; c->max_energy_change = 0.0; c->div_dE = 0.0;
+      c->n_proposals = 0; c->depth = 0; c->left = 0; c->right = 0; c->proposal = 0;   // (the uniform cursor runs on)
+      c->turning = 0; c->diverging = 0; c->div_t = 0;
+      c->bad_energy = !isfinite(E);
+      c->aborted = c->bad_energy;
+      c->eps_abs = a.step_size; c->n_leaves_total = 0;
+      c->dir = 1; c->edge = 0; c->eps = a.step_size;
+      if (!c->aborted && a.max_depth > 0) ctl_next_direction(c, A.uniforms);
+    }
+    __syncthreads();
 
-  // ---- proposal and statistics (nuts.py:478-489) ----
-  const Ctl* c = &s_ctl;
-  const int prop = c->proposal;
-  const int64_t po = slot_off(A, prop);
-  if (mine) { a.q_out[tid] = A.Q[po + tid]; a.g_out[tid] = A.G[po + tid]; }
+    // ---- the tree (nuts.py:204-225) ----
+    for (int d = 0; d < a.max_depth && !s_ctl.aborted; ++d) {
+      Leaf lf;
+      lf.dir = s_ctl.dir; lf.edge = s_ctl.edge; lf.left = s_ctl.left; lf.right = s_ctl.right;
+      lf.eps = s_ctl.eps; lf.half = 0.5 * s_ctl.eps;
+      const int nleaf = 1 << d;
+      for (int j = 0; j < nleaf; ++j) {
+        lf.src = lf.edge + lf.dir * j;
+        lf.t = lf.src + lf.dir;
+        lf.so = slot_off(A, lf.src); lf.d_o = slot_off(A, lf.t);
+        QView qv;
+        qv.q = A.Q + lf.so; qv.p = A.P + lf.so; qv.g = A.G + lf.so; qv.var = A.var;
+        qv.eps = lf.eps; qv.half = lf.half; qv.composed = 1;
+        // first half of the leapfrog (integration.py:118-127), gradient at q'
+        int idx[1] = {tid};
+        bool act[1] = {mine};
+        double grad[1] = {0.0}, ph[1] = {0.0};
+        double qn = 0.0, logp;
+        if (mine) {
+          ph[0] = qv.p_half(tid);
+          qn = qv.at(tid);
+          A.Q[lf.d_o + tid] = qn;
+        }
+        eval_model(qv, qn, grad[0], logp);
+        if (mine) A.G[lf.d_o + tid] = grad[0];
+        // second half kick, v', kinetic energy and the U-turn dots of the merges this leaf completes
+        int m; bool last;
+        leaf_post<1>(A, lf, j, d, true, idx, act, grad, ph, s_red, NW, m, last);
+        __syncthreads();
+        for (int q = tid; q < NDOT; q += VEC_THREADS) {
+          if (!dot_needed(q, m, last)) continue;
+          double r = 0.0;
+          for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];
+          s_dot[q] = r;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const int ts = lf.t & (A.S - 1);
+          const double E = 0.5 * s_dot[0] - logp;  // integration.py:133-134
+          A.LOGP[ts] = logp; A.E[ts] = E;
+          tree_decide(&s_ctl, A, lf, s_dot, E, m, last, a.Emax, a.max_depth);
+        }
+        __syncthreads();   // also makes this leaf's arena stores visible to the whole workgroup
+        if (s_ctl.aborted) break;
+      }
+      if (s_ctl.depth >= a.max_depth) break;
+    }
+
+    // ---- proposal and statistics (nuts.py:478-489) ----
+    const Ctl* c = &s_ctl;
+    const int prop = c->proposal;
+    const int64_t po = slot_off(A, prop);
+    if (mine) {
+      q_prop = A.Q[po + tid]; g_prop = A.G[po + tid];
+      if (a.trace_q) a.trace_q[(int64_t)it * n + tid] = q_prop;
+    }
+    logp_prop = A.LOGP[prop & (A.S - 1)];
+    if (tid == 0) {
+      const int ps = prop & (A.S - 1);
+      DrawOut* o = a.out + it;
+      o->energy = A.E[ps]; o->logp = A.LOGP[ps]; o->E0 = c->E0;
+      o->log_accept_sum = c->log_accept_sum; o->max_energy_change = c->max_energy_change; o->div_dE = c->div_dE;
+      o->depth = c->depth; o->n_proposals = c->n_proposals; o->proposal = prop; o->cursor = c->cursor;
+      o->turning = c->turning; o->diverging = c->diverging; o->bad_energy = c->bad_energy; o->div_t = c->div_t;
+      // stop the batch: bad start energy (the host raises), a divergence (the host fetches the two points from the
+      // arena), or not enough uniforms left for a worst-case tree
+      s_stop = c->bad_energy || c->diverging || (c->cursor + a.worst_uniforms > a.n_uniforms);
+    }
+    done = it + 1;
+    __syncthreads();   // every thread has read the proposal before slot 0 is overwritten; s_stop is visible
+    if (s_stop) break;
+  }
+  if (mine) { a.q_out[tid] = q_prop; a.g_out[tid] = g_prop; }
   if (tid == 0) {
-    const int ps = prop & (A.S - 1);
-    DrawOut* o = a.out;
-    o->energy = A.E[ps]; o->logp = A.LOGP[ps]; o->E0 = c->E0;
-    o->log_accept_sum = c->log_accept_sum; o->max_energy_change = c->max_energy_change; o->div_dE = c->div_dE;
-    o->depth = c->depth; o->n_proposals = c->n_proposals; o->proposal = prop; o->cursor = c->cursor;
-    o->turning = c->turning; o->diverging = c->diverging; o->bad_energy = c->bad_energy; o->div_t = c->div_t;
-    *A.ctl = *c;
-    if (a.st) publish_status(c, a.st, a.seq);
+    if (a.n_done) *a.n_done = done;
+    *A.ctl = s_ctl;
+    if (a.st) publish_status(&s_ctl, a.st, a.seq);
   }
 }

@@ -133,13 +133,22 @@ def sample_chain(step: NUTS, start, rng, tune: int, draws: int, callback=None, p
     n = step._n
     out = np.empty((total, n))
     stats_out = []
-    for i in range(total):
+    batch = int(os.environ.get("PYMC_AMD_DRAW_BATCH", "64"))
+    i = 0
+    while i < total:
         if i == 0:
             step.iter_count = 0
         if i == tune:
             step.stop_tuning()
             if pooled is not None:
                 pooled.end_of_tuning(step)
+        if i >= tune and batch > 1 and callback is None and getattr(step, "can_draw_many", False):
+            # sampling phase of a single-launch model: several transitions per launch, one gather
+            pos, point, st = step.draw_many(point, min(batch, total - i))
+            out[i : i + len(st)] = pos
+            stats_out.extend(st)
+            i += len(st)
+            continue
         point, stats = step.step(point)
         out[i] = DictToArrayBijection.map({k: point[k] for k in step.var_names}).data
         stats_out.append(stats[0])
@@ -147,6 +156,7 @@ def sample_chain(step: NUTS, start, rng, tune: int, draws: int, callback=None, p
             pooled.after_tuning_draw(step, i)
         if callback is not None:
             callback(i, point, stats[0])
+        i += 1
     return out, stats_out
 
 

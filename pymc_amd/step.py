@@ -51,6 +51,9 @@ class SamplerWarning:
         return f"SamplerWarning({self.kind}, {self.message!r})"
 
 
+UNIFORMS_PER_EXTRA_DRAW = 64   # draw_many: uniforms pre-drawn per draw beyond the worst-case tree (a batch that runs out stops early)
+
+
 @dataclass
 class BaseHMCState:
     """`BaseHMCState` (base_hmc.py:61-71) + nested states, flattened into one blob."""
@@ -318,6 +321,85 @@ class NUTS(_DeviceHMCBase):
 
         return (update_stats,)
 
+    def _stats_dict(self, st, point_map_info):
+        """The 19 NUTS statistics (nuts.py:110-130) of one transition + the divergence warning (base_hmc.py:241-268)."""
+        warning = None
+        if st.diverging:
+            kind = "TUNING_DIVERGENCE" if self.tune else "DIVERGENCE"
+            if not self.tune:
+                self._num_divs_sample += 1
+            msg = f"Energy change in leapfrog step is too large: {st.divergence_energy_change}."  # nuts.py:434
+            src = dst = None
+            if not self.tune and self._num_divs_sample < 100:  # base_hmc.py:249-258: at most 100 points are kept
+                src = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_source"), point_map_info))
+                dst = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_dest"), point_map_info))
+            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1, None, src, dst)
+        return {
+            "diverging": bool(st.diverging),
+            "divergences": int(st.divergences),
+            "perf_counter_diff": st.perf_counter_diff,
+            "process_time_diff": st.process_time_diff,
+            "perf_counter_start": st.perf_counter_start,
+            "warning": warning,
+            "depth": int(st.depth),
+            "mean_tree_accept": st.mean_tree_accept,
+            "energy_error": st.energy_error,
+            "energy": st.energy,
+            "tree_size": st.tree_size,
+            "max_energy_error": st.max_energy_error,
+            "model_logp": st.model_logp,
+            "index_in_trajectory": int(st.index_in_trajectory),
+            "reached_max_treedepth": bool(st.reached_max_treedepth),
+            "step_size": st.step_size,
+            "step_size_bar": st.step_size_bar,
+            "largest_eigval": np.nan,
+            "smallest_eigval": np.nan,
+        }
+
+    # ---- several post-tuning transitions per device launch (SURVEY 8f-1) ----------
+    @property
+    def can_draw_many(self) -> bool:
+        """True when `draw_many` applies: tuning is over and the model runs on the single-launch path."""
+        return (not self.tune) and bool(self._scalar("single_launch"))
+
+    def draw_many(self, point: PointType, K: int):
+        """K consecutive transitions from `point` in one launch (`nuts_chain_draw_many`).  Returns
+        `(positions [k][n], last point, [stats] * k)` with k <= K: the device stops a batch after a divergent draw and
+        when the pre-drawn uniforms could not cover another worst-case tree; the caller just asks again.  Both
+        generators end exactly where k calls of `astep` would have left them."""
+        sub = {name: point[name] for name in self.var_names}
+        q0 = DictToArrayBijection.map(sub)
+        q = np.ascontiguousarray(q0.data, dtype="float64")
+        n = self._n
+        prng = self.potential.rng
+        p_saved = prng.bit_generator.state
+        normals = prng.normal(size=(K, n))               # == K calls of potential.random()'s rng.normal(size=n)
+        bg = self.rng.bit_generator
+        saved = bg.state
+        n_uni = self._n_uniforms + UNIFORMS_PER_EXTRA_DRAW * K   # one worst-case tree + a typical tree's worth per further draw
+        uniforms = self.rng.random(n_uni)
+        out = np.empty((K, n))
+        stats = (_lib.DrawStats * K)()
+        n_done = C.c_int32(0)
+        rc = _lib.load().nuts_chain_draw_many(
+            self._chain, _lib.dptr(q), _lib.dptr(normals), _lib.dptr(uniforms), n_uni, K, _lib.dptr(out), stats, C.byref(n_done)
+        )
+        bg.state = saved
+        if rc != _lib.NUTS_OK:
+            prng.bit_generator.state = p_saved
+            _lib.check(rc, "nuts_chain_draw_many")
+        k = n_done.value
+        bg.advance(stats[k - 1].n_uniforms_consumed)      # the count is cumulative over the batch
+        adv = bg.state
+        adv["has_uint32"], adv["uinteger"] = saved["has_uint32"], saved["uinteger"]
+        bg.state = adv
+        if k < K:                                         # give back the momentum normals of the draws not made
+            prng.bit_generator.state = p_saved
+            prng.normal(size=(k, n))
+        stats_out = [self._stats_dict(stats[i], q0.point_map_info) for i in range(k)]
+        last = DictToArrayBijection.rmap(RaveledVars(out[k - 1].copy(), q0.point_map_info), start_point=point)
+        return out[:k], last, stats_out
+
     def astep(self, q0: RaveledVars):
         """BaseHMC.astep (base_hmc.py:196-288) -- one device transition."""
         q = np.ascontiguousarray(q0.data, dtype="float64")
@@ -340,38 +422,7 @@ class NUTS(_DeviceHMCBase):
         adv = bg.state
         adv["has_uint32"], adv["uinteger"] = saved["has_uint32"], saved["uinteger"]
         bg.state = adv
-        warning = None
-        if st.diverging:
-            kind = "TUNING_DIVERGENCE" if self.tune else "DIVERGENCE"
-            if not self.tune:
-                self._num_divs_sample += 1
-            msg = f"Energy change in leapfrog step is too large: {st.divergence_energy_change}."  # nuts.py:434
-            src = dst = None
-            if not self.tune and self._num_divs_sample < 100:  # base_hmc.py:249-258: at most 100 points are kept
-                src = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_source"), q0.point_map_info))
-                dst = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_dest"), q0.point_map_info))
-            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1, None, src, dst)
-        stats = {
-            "diverging": bool(st.diverging),
-            "divergences": int(st.divergences),
-            "perf_counter_diff": st.perf_counter_diff,
-            "process_time_diff": st.process_time_diff,
-            "perf_counter_start": st.perf_counter_start,
-            "warning": warning,
-            "depth": int(st.depth),
-            "mean_tree_accept": st.mean_tree_accept,
-            "energy_error": st.energy_error,
-            "energy": st.energy,
-            "tree_size": st.tree_size,
-            "max_energy_error": st.max_energy_error,
-            "model_logp": st.model_logp,
-            "index_in_trajectory": int(st.index_in_trajectory),
-            "reached_max_treedepth": bool(st.reached_max_treedepth),
-            "step_size": st.step_size,
-            "step_size_bar": st.step_size_bar,
-            "largest_eigval": np.nan,
-            "smallest_eigval": np.nan,
-        }
+        stats = self._stats_dict(st, q0.point_map_info)
         self.potential._host_update(self._q_out, self._g_out, self.tune)   # base_hmc.py:239 for host-adapted potentials
         return RaveledVars(self._q_out.copy(), q0.point_map_info), [stats]
 

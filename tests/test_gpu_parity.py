@@ -443,6 +443,38 @@ def test_folded_control_is_a_pure_rescheduling(monkeypatch):
         np.testing.assert_allclose(a["energy"], b["energy"], rtol=1e-9)
 
 
+def test_draw_many_equals_draw_by_draw(monkeypatch):
+    """the sampling phase of a single-launch model runs several transitions per device launch
+    (`nuts_chain_draw_many`).  Same device code, same pre-drawn streams, so against one launch per draw everything
+    is BITWISE equal: positions, every statistic, and both generators afterwards -- also when batches stop early
+    (here: because the pre-drawn uniforms run out) and across batch boundaries."""
+    import pymc_amd.step as step_mod
+    from pymc_amd.sampling import sample
+
+    spec = models.eight_schools()
+
+    def run():
+        r = sample(draws=70, tune=60, chains=1, model=spec, random_seed=5, device=0)
+        st = r["step"]
+        out = (r["draws"].copy(), r["stats"][0], st.rng.bit_generator.state, st.potential.rng.bit_generator.state)
+        st.close()
+        return out
+
+    monkeypatch.setenv("PYMC_AMD_DRAW_BATCH", "1")
+    d1, s1, g1, p1 = run()
+    keys = INT_KEYS + ("energy", "model_logp", "mean_tree_accept", "max_energy_error", "energy_error", "step_size", "divergences")
+    for batch, per_draw in (("64", 64), ("16", 64), ("32", 1)):   # per_draw = 1: batches run out of uniforms and stop early
+        monkeypatch.setenv("PYMC_AMD_DRAW_BATCH", batch)
+        monkeypatch.setattr(step_mod, "UNIFORMS_PER_EXTRA_DRAW", per_draw)
+        d2, s2, g2, p2 = run()
+        assert np.array_equal(d1, d2), batch
+        assert len(s1) == len(s2)
+        for a, b in zip(s1, s2):
+            for k in keys:
+                assert a[k] == b[k], (batch, k)
+        assert g1 == g2 and p1 == p2, batch
+
+
 def test_pooled_adaptation_roundtrip_over_rccl():
     """The opt-in tuning pool: Welford partials leave the engine as device buffers, are all-reduced with
     RCCL (`nccl` backend; world size 1 here, so the merge must be the identity) and go back in."""
