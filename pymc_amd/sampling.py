@@ -231,6 +231,7 @@ def sample(
     pooled_adaptation: bool = False,
     gather: bool = True,
     device: Optional[int] = None,
+    cores: Optional[int] = None,
     **step_kwargs,
 ):
     """Reduced `pm.sample` (mcmc.py:620-1190) returning raw arrays.
@@ -238,6 +239,13 @@ def sample(
     Returns a dict with ``draws`` (chains, draws, n), ``stats`` (per chain list of
     per-draw dicts), ``point_map_info`` and timing.  Under torch.distributed every
     rank samples its chains and rank 0 receives the gathered draws.
+
+    ``cores`` (mcmc.py:690-693 `cores`: "number of chains to run in parallel"): the reference runs chains in
+    worker processes on host cores (parallel.py:352-372).  Here a chain of a model on the single-launch path keeps
+    ONE workgroup of the GPU busy, so the chains of a rank run concurrently from host threads, each with its own
+    engine handles and stream; default min(4, chains on this rank) for such models, 1 otherwise (a C2-sized chain
+    saturates the GPU by itself).  Every chain starts from the same `sampling_state` and its own generator, so the
+    result does not depend on `cores`.
     """
     rank, world, local = _dist_info()
     spec = model
@@ -247,6 +255,7 @@ def sample(
     rngs = get_random_generator(random_seed).spawn(chains)
     random_seed_list = [int(r.integers(2**30)) for r in rngs]
     mine = assign_chains(chains, rank, world)
+    step_given = step is not None
     if step is None:
         points, step = init_nuts(
             spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device, tune=tune, **step_kwargs
@@ -265,12 +274,45 @@ def sample(
     local_stats = []
     t0 = time.perf_counter()
     t_sampling = 0.0
-    for k, c in enumerate(mine):
-        step.sampling_state = initial_state
-        d, s = sample_chain(step, points[c], rngs[c], tune, draws, pooled=pooled)
-        local_draws[k] = d
-        local_stats.append(s)
-        t_sampling += sum(x["perf_counter_diff"] for x in s[tune:])
+    single_launch = bool(step._scalar("single_launch")) if hasattr(step, "_scalar") else False
+    n_par = min(len(mine), cores if cores is not None else (4 if single_launch else 1))
+    if pooled is not None or step_given or n_par < 1:
+        n_par = 1
+    if n_par > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        # one step object (own model + chain handles, own stream) per concurrent chain; all start from `initial_state`
+        steps = [step] + [
+            init_nuts(spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device,
+                      tune=tune, **step_kwargs)[1]
+            for _ in range(n_par - 1)
+        ]
+
+        def work(w):
+            st = steps[w]
+            st._logp_dlogp_func.bind_thread()
+            res = []
+            for k in range(w, len(mine), n_par):
+                st.sampling_state = initial_state
+                res.append((k, sample_chain(st, points[mine[k]], rngs[mine[k]], tune, draws)))
+            return res
+
+        local_stats = [None] * len(mine)
+        with ThreadPoolExecutor(max_workers=n_par) as ex:
+            for res in ex.map(work, range(n_par)):
+                for k, (d, s) in res:
+                    local_draws[k] = d
+                    local_stats[k] = s
+                    t_sampling += sum(x["perf_counter_diff"] for x in s[tune:])
+        for st in steps[1:]:
+            st.close()
+    else:
+        for k, c in enumerate(mine):
+            step.sampling_state = initial_state
+            d, s = sample_chain(step, points[c], rngs[c], tune, draws, pooled=pooled)
+            local_draws[k] = d
+            local_stats.append(s)
+            t_sampling += sum(x["perf_counter_diff"] for x in s[tune:])
     wall = time.perf_counter() - t0
     keep = slice(tune, None) if discard_tuned_samples else slice(None)
     result = {

@@ -82,6 +82,7 @@ class DeviceValueGradFunction:
         if device is not None:
             _lib.check(lib.nuts_set_device(int(device)), "nuts_set_device")
         self.spec = spec
+        self.device = device
         self.dtype = "float64"
         self._raveled_inputs = True
         self._extra_vars_shared = {}
@@ -94,6 +95,11 @@ class DeviceValueGradFunction:
         self.n = lib.nuts_model_ndim(self._handle)
         self._grad = np.empty(self.n)
         self._lp = np.empty(1)
+
+    def bind_thread(self):
+        """HIP's current device is per host thread: a worker thread that drives this model selects its device first."""
+        if self.device is not None:
+            _lib.check(_lib.load().nuts_set_device(int(self.device)), "nuts_set_device")
 
     # the integrator calls `_pytensor_function(q)` directly (integration.py:46-52)
     def _pytensor_function(self, q):

@@ -475,6 +475,23 @@ def test_draw_many_equals_draw_by_draw(monkeypatch):
         assert g1 == g2 and p1 == p2, batch
 
 
+def test_concurrent_chains_do_not_change_results():
+    """`cores` (mcmc.py:690-693): chains of a single-launch model run concurrently from host threads, one engine
+    stream each.  Every chain starts from the same sampling state with its own generator, so the draws must be
+    bitwise those of the sequential run (tests/sampling/test_parallel.py:270-287 asks the same of worker processes)."""
+    from pymc_amd.sampling import sample
+
+    spec = models.eight_schools()
+    a = sample(draws=40, tune=60, chains=5, model=spec, random_seed=3, device=0, cores=1)
+    b = sample(draws=40, tune=60, chains=5, model=spec, random_seed=3, device=0, cores=4)
+    assert np.array_equal(a["draws"], b["draws"])
+    for sa, sb in zip(a["stats"], b["stats"]):
+        for x, y in zip(sa, sb):
+            for k in INT_KEYS + ("energy", "step_size"):
+                assert x[k] == y[k], k
+    a["step"].close(); b["step"].close()
+
+
 def test_pooled_adaptation_roundtrip_over_rccl():
     """The opt-in tuning pool: Welford partials leave the engine as device buffers, are all-reduced with
     RCCL (`nccl` backend; world size 1 here, so the merge must be the identity) and go back in."""
