@@ -47,7 +47,9 @@ enum {
   NUTS_D_UNIFORM = 7,     /* args: value, lower(const), upper(const) continuous.py:309-321 */
   NUTS_D_BERNOULLI_LOGIT = 8, /* args: y(data), logit_p     discrete.py:351-352,362-374 */
   NUTS_D_LOGNORMAL = 9,   /* args: value, mu, sigma         continuous.py:1807-1819 */
-  NUTS_D_BERNOULLI = 10   /* args: y(data), p               discrete.py:362-374 */
+  NUTS_D_BERNOULLI = 10,  /* args: y(data), p               discrete.py:362-374 */
+  NUTS_D_TRUNCNORMAL = 11 /* args: value, mu, sigma, lower(const); konst = upper (either bound may be infinite)
+                             continuous.py:720-746 with dist_math.py:126-183 */
 };
 
 typedef struct {

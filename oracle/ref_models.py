@@ -19,7 +19,7 @@ import math
 
 import numpy as np
 import scipy.linalg
-from scipy.special import expit
+from scipy.special import erf, erfc, erfcx, expit
 
 LOG_SQRT_2PI = math.log(math.sqrt(2.0 * math.pi))
 LOG_SQRT_2_OVER_PI = math.log(math.sqrt(2.0 / math.pi))
@@ -41,7 +41,8 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_BERNOULLI_LOGIT,
     D_LOGNORMAL,
     D_BERNOULLI,
-) = range(11)
+    D_TRUNCNORMAL,
+) = range(12)
 
 
 def softplus(x):
@@ -188,7 +189,48 @@ def _dist_raw(dist, konst, a, ok):
         lp = _guard(ok, ~((y < 0) | (y > 1)), lp)
         lp = _guard(ok, (p >= 0) & (p <= 1), lp)
         return lp, [np.zeros_like(lp), dp]
+    if dist == D_TRUNCNORMAL:  # continuous.py:720-746 ; bounds constant: lower = a[3], upper = konst
+        v, mu, sg, lo = a
+        hi = konst
+        z = (v - mu) / sg
+        lb, ub = bool(np.all(lo > -np.inf)), bool(hi < np.inf)
+        za, zb = (lo - mu) / sg, (hi - mu) / sg
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            if lb and ub:
+                norm = _log_diff_normal_cdf(zb / math.sqrt(2.0), za / math.sqrt(2.0))
+            elif lb:  # normal_lccdf, dist_math.py:136-142
+                norm = np.where(za > 1.0, np.log(erfcx(za / math.sqrt(2.0)) / 2.0) - za * za / 2.0,
+                                np.log1p(-erfc(-za / math.sqrt(2.0)) / 2.0))
+            elif ub:  # normal_lcdf, dist_math.py:126-133
+                norm = np.where(zb < -1.0, np.log(erfcx(-zb / math.sqrt(2.0)) / 2.0) - zb * zb / 2.0,
+                                np.log1p(-erfc(zb / math.sqrt(2.0)) / 2.0))
+            else:
+                norm = 0.0
+            lp = -0.5 * z * z - LOG_SQRT_2PI - np.log(sg) - norm
+            ra = np.exp(-0.5 * za * za - LOG_SQRT_2PI - norm) if lb else 0.0
+            rb = np.exp(-0.5 * zb * zb - LOG_SQRT_2PI - norm) if ub else 0.0
+        lp = _guard(ok, sg > 0, lp)
+        if lb:
+            lp = _guard(ok, ~(v < lo), lp)
+        if ub:
+            lp = _guard(ok, ~(v > hi), lp)
+        if lb and ub:
+            lp = _guard(ok, lo <= hi, lp)
+        dmu = z / sg - (ra - rb) / sg
+        dsg = (z * z - 1) / sg - ((za * ra if lb else 0.0) - (zb * rb if ub else 0.0)) / sg
+        return lp, [-z / sg, dmu, dsg, np.zeros_like(lp)]
     raise ValueError(dist)
+
+
+def _log_diff_normal_cdf(x, y):
+    """log(Phi(x sqrt 2) - Phi(y sqrt 2)) in the three regimes of pymc/distributions/dist_math.py:145-183
+    (x, y already divided by sqrt 2; x > y)."""
+    x, y = np.asarray(x, dtype="d"), np.asarray(y, dtype="d")
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        r1 = -y * y + np.log(erfcx(y) - np.exp(y * y - x * x) * erfcx(x))
+        r2 = -x * x + np.log(erfcx(-x) - np.exp(x * x - y * y) * erfcx(-y))
+        r3 = np.log(erf(x) - erf(y))
+    return math.log(0.5) + np.where(y > 0, r1, np.where(x < 0, r2, r3))
 
 
 def _operand(op, spec, x):

@@ -276,7 +276,7 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 }
 
 // log-density of one element and its partials w.r.t. each argument.
-// (not inlined: one copy of the 11-way switch and its libm expansions per kernel keeps kernels B and C small
+// (not inlined: one copy of the 12-way switch and its libm expansions per kernel keeps kernels B and C small
 // enough for the instruction cache -- they are launched once per leapfrog between two passes of kernel A)
 __device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
   const double NINF = -INFINITY;
@@ -362,6 +362,37 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       d[1] = (y != 0.0) ? 1.0 / p : -1.0 / (1.0 - p);
       KILL_UNLESS(y >= 0 && y <= 1)
       KILL_UNLESS(p >= 0 && p <= 1)
+    } break;
+    case NUTS_D_TRUNCNORMAL: {  // continuous.py:720-746; bounds constant (lower = a[3], upper = konst)
+      const double v = a[0], mu = a[1], sg = a[2], lo = a[3], hi = konst;
+      const double z = (v - mu) / sg;
+      const bool lb = lo > -INFINITY, ub = hi < INFINITY;
+      const double za = (lo - mu) / sg, zb = (hi - mu) / sg;   // standardised bounds
+      double norm = 0.0;
+      if (lb && ub) {   // log_diff_normal_cdf(mu, sigma, upper, lower), dist_math.py:145-183
+        const double x = zb / 1.4142135623730951, y = za / 1.4142135623730951;
+        double t;
+        if (y > 0) t = -y * y + log(erfcx(y) - exp(y * y - x * x) * erfcx(x));
+        else if (x < 0) t = -x * x + log(erfcx(-x) - exp(x * x - y * y) * erfcx(-y));
+        else t = log(erf(x) - erf(y));
+        norm = log(0.5) + t;
+      } else if (lb) {  // normal_lccdf(mu, sigma, lower), dist_math.py:136-142
+        norm = za > 1.0 ? log(erfcx(za / 1.4142135623730951) / 2.0) - za * za / 2.0 : log1p(-erfc(-za / 1.4142135623730951) / 2.0);
+      } else if (ub) {  // normal_lcdf(mu, sigma, upper), dist_math.py:126-133
+        norm = zb < -1.0 ? log(erfcx(-zb / 1.4142135623730951) / 2.0) - zb * zb / 2.0 : log1p(-erfc(zb / 1.4142135623730951) / 2.0);
+      }
+      lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg) - norm;
+      KILL_UNLESS(sg > 0)
+      if (lb) KILL_UNLESS(!(v < lo))
+      if (ub) KILL_UNLESS(!(v > hi))
+      if (lb && ub) KILL_UNLESS(lo <= hi)
+      // d norm / d mu = (phi(za) - phi(zb)) / (sigma Z), d norm / d sigma = (za phi(za) - zb phi(zb)) / (sigma Z),
+      // with phi / Z taken in log space through `norm` = log Z
+      const double ra = lb ? exp(-0.5 * za * za - LOG_SQRT_2PI - norm) : 0.0;
+      const double rb = ub ? exp(-0.5 * zb * zb - LOG_SQRT_2PI - norm) : 0.0;
+      d[0] = -z / sg;
+      d[1] = z / sg - (ra - rb) / sg;
+      d[2] = (z * z - 1.0) / sg - ((lb ? za * ra : 0.0) - (ub ? zb * rb : 0.0)) / sg;
     } break;
     default: lp = NAN;
   }

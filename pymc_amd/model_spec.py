@@ -50,7 +50,8 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_BERNOULLI_LOGIT,
     D_LOGNORMAL,
     D_BERNOULLI,
-) = range(11)
+    D_TRUNCNORMAL,
+) = range(12)
 DIST_NAMES = {
     D_NORMAL: "Normal",
     D_HALFNORMAL: "HalfNormal",
@@ -63,6 +64,7 @@ DIST_NAMES = {
     D_BERNOULLI_LOGIT: "BernoulliLogit",
     D_LOGNORMAL: "LogNormal",
     D_BERNOULLI: "Bernoulli",
+    D_TRUNCNORMAL: "TruncatedNormal",
 }
 
 
@@ -221,6 +223,7 @@ _DEFAULT_TRANSFORM = {
     D_LOGNORMAL: TR_LOG,
     D_BETA: TR_LOGODDS,
     D_UNIFORM: TR_INTERVAL,
+    D_TRUNCNORMAL: TR_INTERVAL,
 }
 
 
@@ -296,6 +299,16 @@ class ModelBuilder:
     def Uniform(self, name, lower=0.0, upper=1.0, shape=None, observed=None, transform="default"):
         lower, upper = float(lower), float(upper)
         return self._register(D_UNIFORM, name, (lower, upper), shape, observed, transform, bounds=(lower, upper))
+
+    def TruncatedNormal(self, name, mu=0.0, sigma=1.0, lower=None, upper=None, shape=None, observed=None, transform="default"):
+        """`pm.TruncatedNormal` (pymc/distributions/continuous.py:596-746) with constant bounds; a free variable needs
+        both bounds (interval transform, the reference's default for a doubly bounded distribution)."""
+        lo = -math.inf if lower is None else float(lower)
+        hi = math.inf if upper is None else float(upper)
+        if observed is None and not (math.isfinite(lo) and math.isfinite(hi)):
+            raise NotImplementedError("a free TruncatedNormal needs both bounds here (interval transform)")
+        bounds = (lo, hi) if observed is None else (0.0, 1.0)
+        return self._register(D_TRUNCNORMAL, name, (mu, sigma, lo), shape, observed, transform, konst=hi, bounds=bounds)
 
     def LogNormal(self, name, mu=0.0, sigma=1.0, shape=None, observed=None, transform="default"):
         return self._register(D_LOGNORMAL, name, (mu, sigma), shape, observed, transform)

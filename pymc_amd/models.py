@@ -26,6 +26,18 @@ def golden_hier_normal() -> ModelSpec:
     return m.build()
 
 
+TRUNCNORMAL_KAT_DATA = (1.35202174, -0.83690274, 1.11175166, 1.29000367, 0.21282749,
+                        0.84430966, 0.24841369, 0.81803141, 0.20550244, -0.45016253)
+
+
+def truncated_normal_kat() -> ModelSpec:
+    """The model of tests/model/test_core.py:467-479: ``dlogp(mu = 0) == 2.499424682024436`` (rtol 1e-5)."""
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 5.0)
+    m.TruncatedNormal("obs", mu=mu, sigma=1.0, lower=-1.0, upper=2.0, observed=np.array(TRUNCNORMAL_KAT_DATA))
+    return m.build()
+
+
 def eight_schools(J: int = 8, seed: int = DATA_SEED) -> ModelSpec:
     """Schools model of tests/test_model_graph.py:44-57 (C1).
 

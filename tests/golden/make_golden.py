@@ -63,6 +63,7 @@ def main():
         "joint_logp_hier_normal": {"value": -12.691227342634292, "point": [0, 1, 0, 1, 2], "ref": "pymc/pytensorf.py:514-546"},
         "bernoulli_ten_zeros_at_logodds_0": {"value": 10 * float(np.log(0.5)), "ref": "tests/model/test_core.py:457-465"},
         "edge_case_dlogp_atol": {"value": 1e-5, "ref": "tests/model/test_core.py:404-421"},
+        "truncated_normal_dlogp_mu_at_0": {"value": 2.499424682024436, "rtol": 1e-5, "ref": "tests/model/test_core.py:467-479"},
         "leapfrog_reversible_rtol": {"value": 1e-5, "ref": "tests/step_methods/hmc/test_hmc.py:49-74"},
         "scipy_decimals": {"value": 6, "ref": "pymc/testing.py:311-417"},
     }

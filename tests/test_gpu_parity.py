@@ -65,9 +65,27 @@ def test_all_elementwise_distributions():
     m.Normal("obs", a + s * c, e, observed=np.linspace(-1, 1, 5))
     m.BernoulliLogit("yl", a, observed=np.array([0, 1, 1, 0, 1.0]))
     m.Bernoulli("yb", b, observed=np.array([1, 0, 1.0]))
+    tn = m.TruncatedNormal("tn", 0.4, 1.3, lower=-1.0, upper=2.5, shape=3)
+    m.TruncatedNormal("to1", mu=a, sigma=s, lower=-2.0, upper=3.0, observed=np.linspace(-1, 2, 5))
+    m.TruncatedNormal("to2", mu=tn, sigma=0.7, lower=0.2, observed=np.array([0.3, 1.0, 4.0]))
+    m.TruncatedNormal("to3", mu=c, sigma=e, upper=0.5, observed=np.linspace(-3, 0.4, 5))
     spec = m.build()
     rng = np.random.default_rng(2)
     _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.7 for _ in range(6)])
+
+
+def test_truncated_normal_known_answer():
+    """tests/model/test_core.py:467-479 through the C ABI: dlogp(mu = 0) == 2.499424682024436 (rtol 1e-5), and the three
+    regimes of log_diff_normal_cdf (dist_math.py:145-183) against the oracle."""
+    f = _vg(models.truncated_normal_kat())
+    lp, g = f._pytensor_function(np.array([0.0]))
+    np.testing.assert_allclose(g[0], 2.499424682024436, rtol=1e-5)
+    for lo, hi in ((3.0, 9.0), (-9.0, -4.0), (-1.0, 2.0)):
+        m = ModelBuilder()
+        mu = m.Normal("mu", 0, 5)
+        sg = m.HalfNormal("sg", 2.0)
+        m.TruncatedNormal("obs", mu=mu, sigma=sg, lower=lo, upper=hi, observed=np.clip(np.array(models.TRUNCNORMAL_KAT_DATA) * 3, lo, hi))
+        _check_logp_grad(m.build(), [np.array([0.3, -0.2]), np.array([-1.0, 0.5])])
 
 
 @pytest.mark.parametrize(

@@ -143,6 +143,41 @@ def test_edge_case_dlogp_zero_and_sizes():
     np.testing.assert_allclose(g, 0.0, atol=1e-5)
 
 
+def test_truncated_normal_known_answer_and_scipy():
+    """tests/model/test_core.py:467-479: TruncatedNormal(mu, 1, lower=-1, upper=2) on ten listed points,
+    `dlogp(mu = 0) == 2.499424682024436` (rtol 1e-5); and logp against scipy.stats.truncnorm in the three regimes of
+    log_diff_normal_cdf (dist_math.py:145-183) plus the one-sided forms (normal_lcdf / normal_lccdf, :126-142)."""
+    import json
+    import os
+
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))["truncated_normal_dlogp_mu_at_0"]
+    lp, g = ref_models.evaluate(models.truncated_normal_kat(), np.array([0.0]))
+    np.testing.assert_allclose(g[0], kat["value"], rtol=kat["rtol"])
+    data = np.array(models.TRUNCNORMAL_KAT_DATA)
+    for kw in (dict(lower=-1, upper=2), dict(lower=0.3), dict(upper=0.1), dict(lower=3.0, upper=9.0), dict(lower=-9, upper=-4)):
+        lo, hi = kw.get("lower", -np.inf), kw.get("upper", np.inf)
+        d = np.clip(data, lo if np.isfinite(lo) else -10, hi if np.isfinite(hi) else 10)
+        m = ModelBuilder()
+        mu = m.Normal("mu", 0, 5)
+        sg = m.HalfNormal("sg", 2.0)
+        m.TruncatedNormal("obs", mu=mu, sigma=sg, observed=d, **kw)
+        spec = m.build()
+        q = np.array([0.3, -0.2])
+        lp, g = ref_models.evaluate(spec, q)
+        s = np.exp(-0.2)
+        ref = (st.truncnorm.logpdf(d, (lo - 0.3) / s, (hi - 0.3) / s, loc=0.3, scale=s).sum() + st.norm.logpdf(0.3, 0, 5)
+               + st.halfnorm.logpdf(s, scale=2.0) - 0.2)
+        np.testing.assert_allclose(lp, ref, rtol=1e-12)
+        fd = [(ref_models.evaluate(spec, q + e)[0] - ref_models.evaluate(spec, q - e)[0]) / 2e-6 for e in (np.array([1e-6, 0]), np.array([0, 1e-6]))]
+        np.testing.assert_allclose(g, fd, rtol=2e-6)
+    # a value outside the truncation bounds: -inf with zero gradient (continuous.py:733-737)
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0, 5)
+    m.TruncatedNormal("obs", mu=mu, sigma=1.0, lower=-1, upper=2, observed=np.array([0.5, 2.5]))
+    lp, g = ref_models.evaluate(m.build(), np.array([0.1]))
+    assert lp == -np.inf
+
+
 def test_invalid_parameter_is_minus_inf_with_zero_gradient():
     """`check_parameters` -> `switch(cond, logp, -inf)` (pymc/logprob/utils.py:209-225)."""
     m = ModelBuilder()
