@@ -48,8 +48,10 @@ enum {
   NUTS_D_BERNOULLI_LOGIT = 8, /* args: y(data), logit_p     discrete.py:351-352,362-374 */
   NUTS_D_LOGNORMAL = 9,   /* args: value, mu, sigma         continuous.py:1807-1819 */
   NUTS_D_BERNOULLI = 10,  /* args: y(data), p               discrete.py:362-374 */
-  NUTS_D_TRUNCNORMAL = 11 /* args: value, mu, sigma, lower(const); konst = upper (either bound may be infinite)
+  NUTS_D_TRUNCNORMAL = 11,/* args: value, mu, sigma, lower(const); konst = upper (either bound may be infinite)
                              continuous.py:720-746 with dist_math.py:126-183 */
+  NUTS_D_POTENTIAL = 12   /* args: term; contributes sum(term) to the joint log-density: `pm.Potential`
+                             (model/core.py:666-695 adds the potentials to the free and observed logps) */
 };
 
 typedef struct {
@@ -208,6 +210,12 @@ int nuts_chain_set_iter_count(nuts_chain *c, int64_t iter_count);
  */
 int nuts_chain_draw(nuts_chain *c, const double *q0, const double *normals, const double *uniforms,
                     int32_t n_uniforms, double *q_out, double *grad_out, nuts_draw_stats *stats);
+
+/* Replace the contents of data vector `data_id` of the spec (same length): the C-ABI form of
+ * `ValueGradFunction.set_extra_values` (model/core.py:275-278) -- value variables that are inputs of the log-density
+ * but not of its gradient (e.g. discrete latents updated by another step of a CompoundStep, arraystep.py:109-111)
+ * are data vectors that the caller rewrites before a transition.  Invalidates every chain's start-state cache. */
+int nuts_model_set_data(nuts_model *m, int32_t data_id, const double *values, int64_t n);
 
 /* K consecutive post-tuning transitions in one device launch (removes the per-draw host round trip
  * of sampling/mcmc.py:1556-1572 for models on the single-workgroup path).  Between two draws of the sampling phase

@@ -42,7 +42,8 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_LOGNORMAL,
     D_BERNOULLI,
     D_TRUNCNORMAL,
-) = range(12)
+    D_POTENTIAL,
+) = range(13)
 
 
 def softplus(x):
@@ -219,6 +220,9 @@ def _dist_raw(dist, konst, a, ok):
         dmu = z / sg - (ra - rb) / sg
         dsg = (z * z - 1) / sg - ((za * ra if lb else 0.0) - (zb * rb if ub else 0.0)) / sg
         return lp, [-z / sg, dmu, dsg, np.zeros_like(lp)]
+    if dist == D_POTENTIAL:  # pm.Potential: the term is added to the joint log-density (model/core.py:666-695)
+        (v,) = a
+        return np.asarray(v, dtype="d") * 1.0, [np.ones_like(np.asarray(v, dtype="d"))]
     raise ValueError(dist)
 
 
@@ -350,6 +354,13 @@ class SpecLogpGrad:
         self.spec = spec
         self.n = spec.n
         self.calls = 0
+
+    def set_extra_values(self, extra_vars):
+        """`ValueGradFunction.set_extra_values` (model/core.py:275-278): non-gradient inputs are data vectors."""
+        for name, value in extra_vars.items():
+            if name in self.spec.extra:
+                d = self.spec.data[self.spec.extra[name]]
+                d[...] = np.asarray(value, dtype="d").reshape(d.shape)
 
     def __call__(self, q):
         self.calls += 1

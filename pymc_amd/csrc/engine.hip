@@ -71,6 +71,8 @@ struct nuts_model {
   double* g_dev = nullptr;
   double* lp_dev = nullptr;
   double* host_pin = nullptr;  // pinned [2n+2]
+  std::vector<nuts_data_ref> data_refs;   // (offset, size) of every data vector in the device pool
+  int64_t data_epoch = 0;                 // bumped by nuts_model_set_data: start-state caches of older epochs are stale
   int rows_grid = 0, mvn_grid = 0, ept = 1;
   int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
   int vector_one_xcd = 0;
@@ -184,7 +186,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     const nuts_factor& f = s->factors[fi];
     fbt[fi].n = 0; fbt[fi].pad = 0;
     if (f.nargs < 1 || f.nargs > 4 || f.size < 1) { g_err = "factor with a bad argument count or size"; return false; }
-    if (f.dist < 0 || f.dist > NUTS_D_TRUNCNORMAL) { g_err = "factor with an unknown distribution code"; return false; }
+    if (f.dist < 0 || f.dist > NUTS_D_POTENTIAL) { g_err = "factor with an unknown distribution code"; return false; }
     if (f.dist == NUTS_D_TRUNCNORMAL) {   // the bounds carry no gradient here: lower must be a constant (upper is `konst`)
       const nuts_term& lo = f.arg[3];
       if (f.nargs != 4 || lo.a.kind == NUTS_OP_VAR || lo.b.kind == NUTS_OP_VAR || lo.c.kind == NUTS_OP_VAR) {
@@ -320,6 +322,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   std::vector<VarDev> vars;
   if (!compile_spec(m, s, vars)) { nuts_model_destroy(m); return nullptr; }
   md.pool = m->keep(dev_upload(s->data_pool, s->data_pool_len));
+  m->data_refs.assign(s->data, s->data + s->n_data);
   m->ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
   md.nblk = (n + VEC_THREADS * m->ept - 1) / (VEC_THREADS * m->ept);
   md.tick_j = env_int("NUTS_TICK_J", -1);
@@ -476,6 +479,17 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   return m;
 }
 
+extern "C" int nuts_model_set_data(nuts_model* m, int32_t data_id, const double* values, int64_t n) {
+  if (!m || !values) { g_err = "null argument"; return NUTS_E_ARG; }
+  if (data_id < 0 || data_id >= (int)m->data_refs.size()) { g_err = "nuts_model_set_data: no such data vector"; return NUTS_E_ARG; }
+  const nuts_data_ref& r = m->data_refs[data_id];
+  if (n != r.size) { g_err = "nuts_model_set_data: the length of a data vector cannot change"; return NUTS_E_ARG; }
+  HIPCHK(hipStreamSynchronize(m->stream));
+  HIPCHK(hipMemcpy(const_cast<double*>(m->md.pool) + r.offset, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  m->data_epoch++;
+  return NUTS_OK;
+}
+
 extern "C" void nuts_model_destroy(nuts_model* m) {
   if (!m) return;
   if (m->stream) hipStreamSynchronize(m->stream);
@@ -627,6 +641,7 @@ struct nuts_chain {
   DrawOut* do_dev = nullptr;
   DrawOut* do_host = nullptr;
   double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
+  int64_t cache_epoch = -1;      // model data epoch the start-state cache belongs to
   int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
   int spec_max = 3, last_depth = 0;   // look-ahead over the short doublings (nuts_chain_draw)
   int logs_done = 0, logs_total = 0;  // logarithms of the pre-drawn uniforms taken / needed at most this draw
@@ -824,7 +839,7 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
   const int n = c->n;
   // the usual case inside a chain: q0 is bit for bit the proposal this chain returned last time, whose gradient and
   // logp are still on the device -- the model pass at q0 would reproduce exactly those numbers
-  const bool cached = allow_cache && c->cache_ok && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
+  const bool cached = allow_cache && c->cache_ok && c->cache_epoch == c->m->data_epoch && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
   c->cache_ok = false;
   hipStream_t s = c->m->stream;
   ArenaDev& A = c->A;
@@ -978,7 +993,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   int64_t evals = 1;
   if (c->small) {
     // latency regime: the whole transition in one launch of one workgroup (small_kernel.h)
-    const bool cached = c->cache_ok && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
+    const bool cached = c->cache_ok && c->cache_epoch == c->m->data_epoch && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
     c->cache_ok = false;
     std::memcpy(c->stage_host, q0, n * sizeof(double));
     std::memcpy(c->stage_host + n, normals, n * sizeof(double));
@@ -1104,7 +1119,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
 
   std::memcpy(q_out, c->out_host, n * sizeof(double));
   if (grad_out) std::memcpy(grad_out, c->out_host + n, n * sizeof(double));
-  c->last_q.assign(c->out_host, c->out_host + n); c->last_logp = o.logp; c->cache_ok = true;
+  c->last_q.assign(c->out_host, c->out_host + n); c->last_logp = o.logp; c->cache_ok = true; c->cache_epoch = c->m->data_epoch;
   std::memset(stats, 0, sizeof(*stats));
   stats->depth = o.depth;
   stats->step_size = std::exp(c->da.log_step);
@@ -1168,7 +1183,7 @@ extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const doubl
     HIPCHK(hipMalloc((void**)&c->many_out_dev, out_bytes));
     c->many_in_cap = in_doubles; c->many_out_cap = out_bytes;
   }
-  const bool cached = c->cache_ok && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
+  const bool cached = c->cache_ok && c->cache_epoch == c->m->data_epoch && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
   c->cache_ok = false;
   std::memcpy(c->many_in_host, q0, n * sizeof(double));
   std::memcpy(c->many_in_host + n, normals, (size_t)K * n * sizeof(double));
@@ -1242,7 +1257,7 @@ extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const doubl
   }
   std::memcpy(q_out, trace_host, (size_t)done * n * sizeof(double));
   c->last_q.assign(trace_host + (size_t)(done - 1) * n, trace_host + (size_t)done * n);
-  c->last_logp = last.logp; c->cache_ok = true;
+  c->last_logp = last.logp; c->cache_ok = true; c->cache_epoch = c->m->data_epoch;
   return NUTS_OK;
 }
 

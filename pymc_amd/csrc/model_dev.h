@@ -276,7 +276,7 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 }
 
 // log-density of one element and its partials w.r.t. each argument.
-// (not inlined: one copy of the 12-way switch and its libm expansions per kernel keeps kernels B and C small
+// (not inlined: one copy of the 13-way switch and its libm expansions per kernel keeps kernels B and C small
 // enough for the instruction cache -- they are launched once per leapfrog between two passes of kernel A)
 __device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
   const double NINF = -INFINITY;
@@ -393,6 +393,10 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       d[0] = -z / sg;
       d[1] = z / sg - (ra - rb) / sg;
       d[2] = (z * z - 1.0) / sg - ((lb ? za * ra : 0.0) - (ub ? zb * rb : 0.0)) / sg;
+    } break;
+    case NUTS_D_POTENTIAL: {  // pm.Potential: the term itself is the log-density contribution
+      lp = a[0];
+      d[0] = 1.0;
     } break;
     default: lp = NAN;
   }

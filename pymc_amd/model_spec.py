@@ -51,7 +51,8 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_LOGNORMAL,
     D_BERNOULLI,
     D_TRUNCNORMAL,
-) = range(12)
+    D_POTENTIAL,
+) = range(13)
 DIST_NAMES = {
     D_NORMAL: "Normal",
     D_HALFNORMAL: "HalfNormal",
@@ -65,6 +66,7 @@ DIST_NAMES = {
     D_LOGNORMAL: "LogNormal",
     D_BERNOULLI: "Bernoulli",
     D_TRUNCNORMAL: "TruncatedNormal",
+    D_POTENTIAL: "Potential",
 }
 
 
@@ -152,6 +154,9 @@ class ModelSpec:
     factors: List[Factor] = field(default_factory=list)
     logit_rows: Optional[LogitRows] = None
     mvnormal: Optional[MvNormalNode] = None
+    # "extra" inputs of the log-density (model/core.py:142-190 `extra_vars_and_values`): name -> index into `data`;
+    # the caller rewrites them through `set_extra_values` (value variables sampled by another step method)
+    extra: Dict[str, int] = field(default_factory=dict)
 
     @property
     def n(self) -> int:
@@ -244,6 +249,20 @@ class ModelBuilder:
         self.spec.data.append(np.ascontiguousarray(arr.ravel()))
         return Expr(self, Term(Operand(OP_DATA, 0.0, len(self.spec.data) - 1)), arr.size)
 
+    def Extra(self, name, value) -> Expr:
+        """A non-gradient input of the log-density (an `extra_var` of `ValueGradFunction`, model/core.py:142-190):
+        kept as a data vector that `set_extra_values({name: ...})` rewrites."""
+        arr = np.ascontiguousarray(np.asarray(value, dtype="float64").ravel()).copy()
+        self.spec.data.append(arr)
+        self.spec.extra[name] = len(self.spec.data) - 1
+        return Expr(self, Term(Operand(OP_DATA, 0.0, len(self.spec.data) - 1)), arr.size)
+
+    def Potential(self, name, expr):
+        """`pm.Potential(name, expr)`: adds sum(expr) to the joint log-density (model/core.py:666-695)."""
+        e = self.as_expr(expr)
+        self.spec.factors.append(Factor(D_POTENTIAL, e.size, (e.term,), 0.0, name))
+        return None
+
     def _register(self, dist, name, params, shape, observed, transform, bounds=(0.0, 1.0), konst=0.0):
         params = [self.as_expr(p) for p in params]
         if observed is not None:
@@ -267,6 +286,19 @@ class ModelBuilder:
             if p.size not in (1, var.size):
                 raise ValueError(f"parameter of size {p.size} does not broadcast to {name} of size {var.size}")
         self.spec.factors.append(Factor(dist, var.size, (e.term, *[p.term for p in params]), konst, name))
+        self._names[name] = e
+        return e
+
+    def Flat(self, name, shape=None):
+        """`pm.Flat` (pymc/distributions/continuous.py:351-385): improper flat prior, logp = 0 -- a free value variable
+        without a factor of its own (what the raw `pt.vector` inputs of tests/model/test_core.py:318-402 amount to)."""
+        if shape is None:
+            shape = ()
+        elif isinstance(shape, int):
+            shape = (shape,)
+        var = FreeVar(name, tuple(shape), TR_NONE, 0.0, 1.0, self.spec.n)
+        self.spec.vars.append(var)
+        e = Expr(self, Term(Operand(OP_VAR, 0.0, len(self.spec.vars) - 1)), var.size)
         self._names[name] = e
         return e
 

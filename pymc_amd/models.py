@@ -38,6 +38,19 @@ def truncated_normal_kat() -> ModelSpec:
     return m.build()
 
 
+def value_grad_kat() -> ModelSpec:
+    """`TestValueGradFunction` (tests/model/test_core.py:318-402): cost = extra1 * val1.sum() + val2.sum() over the raveled
+    inputs [val1 (3), val2 (2x3)] with the non-gradient input extra1; at ones with extra1 = 5: value 21,
+    gradient [5, 5, 5, 1, 1, 1, 1, 1, 1]."""
+    m = ModelBuilder()
+    extra1 = m.Extra("extra1", 0.0)
+    val1 = m.Flat("val1", shape=3)
+    val2 = m.Flat("val2", shape=(2, 3))
+    m.Potential("cost1", extra1 * val1)
+    m.Potential("cost2", val2)
+    return m.build()
+
+
 def eight_schools(J: int = 8, seed: int = DATA_SEED) -> ModelSpec:
     """Schools model of tests/test_model_graph.py:44-57 (C1).
 

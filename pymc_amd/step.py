@@ -218,6 +218,9 @@ class _DeviceHMCBase:
 
     # ---- dict <-> flat (arraystep.py:107-122) ------------------------------------
     def step(self, point: PointType):
+        extra = self._logp_dlogp_func.spec.extra
+        if extra:   # arraystep.py:109-111: `shared.set_value(point[name])` for the non-gradient value variables
+            self._logp_dlogp_func.set_extra_values({name: point[name] for name in extra})
         sub = {name: point[name] for name in self.var_names}
         q = DictToArrayBijection.map(sub)
         apoint, stats = self.astep(q)
@@ -360,7 +363,7 @@ class NUTS(_DeviceHMCBase):
     @property
     def can_draw_many(self) -> bool:
         """True when `draw_many` applies: tuning is over and the model runs on the single-launch path."""
-        return (not self.tune) and bool(self._scalar("single_launch"))
+        return (not self.tune) and not self._logp_dlogp_func.spec.extra and bool(self._scalar("single_launch"))
 
     def draw_many(self, point: PointType, K: int):
         """K consecutive transitions from `point` in one launch (`nuts_chain_draw_many`).  Returns

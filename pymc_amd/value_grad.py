@@ -86,6 +86,7 @@ class DeviceValueGradFunction:
         self.dtype = "float64"
         self._raveled_inputs = True
         self._extra_vars_shared = {}
+        self._extra_are_set = False
         self.trust_input = True
         cspec, keep = _pack(spec)
         self._handle = lib.nuts_model_create(C.byref(cspec))
@@ -112,6 +113,10 @@ class DeviceValueGradFunction:
 
     def __call__(self, grad_vars, *, extra_vars=None):
         """`ValueGradFunction.__call__` (pymc/model/core.py:286-300)."""
+        if extra_vars is not None:
+            self.set_extra_values(extra_vars)
+        elif self.spec.extra and not self._extra_are_set:
+            raise ValueError("Extra values are not set.")
         if isinstance(grad_vars, RaveledVars):
             q = grad_vars.data
         elif isinstance(grad_vars, dict):
@@ -120,8 +125,23 @@ class DeviceValueGradFunction:
             q = np.asarray(grad_vars[0] if isinstance(grad_vars, (list, tuple)) else grad_vars)
         return self._pytensor_function(q)
 
-    def set_extra_values(self, extra_vars):  # core.py:275-278 (no non-gradient value vars in these specs)
-        return None
+    def set_extra_values(self, extra_vars):
+        """core.py:275-278: the non-gradient inputs are data vectors of the spec, rewritten on the device
+        (`nuts_model_set_data`; values that did not change are not sent again)."""
+        lib = _lib.load()
+        for name, idx in self.spec.extra.items():
+            v = np.ascontiguousarray(np.asarray(extra_vars[name], dtype="float64").ravel())
+            old = self._extra_vars_shared.get(name)
+            if old is not None and old.shape == v.shape and np.array_equal(old, v):
+                continue
+            _lib.check(lib.nuts_model_set_data(self._handle, idx, _lib.dptr(v), v.size), "nuts_model_set_data")
+            self._extra_vars_shared[name] = v.copy()
+        self._extra_are_set = True
+
+    def get_extra_values(self):  # core.py:280-284
+        if self.spec.extra and not self._extra_are_set:
+            raise ValueError("Extra values are not set.")
+        return {name: self._extra_vars_shared[name].copy() for name in self.spec.extra}
 
     def time_kernels(self, q, reps=20):
         ms_tot, ms_dom = C.c_double(), C.c_double()

@@ -74,6 +74,62 @@ def test_all_elementwise_distributions():
     _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.7 for _ in range(6)])
 
 
+def test_value_grad_function_known_answer_and_extra_values():
+    """`TestValueGradFunction` (tests/model/test_core.py:318-402) through the C ABI: calling before the extra values are
+    set raises "Extra values are not set" (:373-384); with extra1 = 5 at ones the value is 21 and the gradient
+    [5, 5, 5, 1, 1, 1, 1, 1, 1] (:386-402); changing the extra value changes the next evaluation (set_extra_values,
+    core.py:275-278)."""
+    f = _vg(models.value_grad_kat())
+    with pytest.raises(ValueError, match="Extra values are not set"):
+        f.get_extra_values()
+    with pytest.raises(ValueError, match="Extra values are not set"):
+        f(np.zeros(9))
+    f.set_extra_values({"extra1": 5})
+    val, grad = f(np.ones(9))
+    assert val == 21
+    np.testing.assert_allclose(grad, [5, 5, 5, 1, 1, 1, 1, 1, 1])
+    assert f.get_extra_values()["extra1"][0] == 5
+    val, grad = f(np.ones(9), extra_vars={"extra1": -2.5})
+    assert val == -1.5
+    np.testing.assert_allclose(grad, [-2.5] * 3 + [1] * 6)
+
+
+def test_extra_values_reach_the_sampler_and_invalidate_the_start_state_cache():
+    """arraystep.py:109-111: before every `astep` the non-gradient value variables of the point are handed to the
+    logp function.  A chain whose extra input changes between two draws must not reuse the cached start state
+    (logp and gradient of the previous proposal under the OLD value): the device run has to follow the oracle, which
+    re-evaluates the start state every draw (base_hmc.py:202)."""
+    from pymc_amd.step import NUTS
+
+    def build():
+        m = ModelBuilder()
+        shift = m.Extra("shift", 0.0)
+        x = m.Normal("x", shift, 1.0, shape=300)     # 300 elements: the three-kernel pipeline with its start-state cache
+        m.Normal("obs", x, 0.5, observed=np.linspace(-1, 1, 300))
+        return m.build()
+
+    spec = build()
+    step = NUTS(model=spec, rng=11, device=0)
+    step.setup_chain(np.random.default_rng(11), 10, 10)
+    ospec = build()
+    f = ref_models.SpecLogpGrad(ospec)
+    ref = ref_sampler.RefNUTS(f, 300, rng=11)
+    ref.setup_chain(np.random.default_rng(11), 10, 10)
+    point = {"x": np.zeros(300), "shift": np.array([0.0])}
+    q = np.zeros(300)
+    for i in range(8):
+        sh = 0.3 * i
+        point["shift"] = np.array([sh])
+        f.set_extra_values({"shift": sh})
+        point, st = step.step(point)
+        q, rst = ref.astep(q)
+        for k in INT_KEYS:
+            assert int(st[0][k]) == int(rst[k]), (i, k)
+        np.testing.assert_allclose(st[0]["model_logp"], rst["model_logp"], rtol=1e-9)
+        np.testing.assert_allclose(point["x"], q, rtol=1e-7, atol=1e-9)
+    step.close()
+
+
 def test_truncated_normal_known_answer():
     """tests/model/test_core.py:467-479 through the C ABI: dlogp(mu = 0) == 2.499424682024436 (rtol 1e-5), and the three
     regimes of log_diff_normal_cdf (dist_math.py:145-183) against the oracle."""

@@ -143,6 +143,18 @@ def test_edge_case_dlogp_zero_and_sizes():
     np.testing.assert_allclose(g, 0.0, atol=1e-5)
 
 
+def test_value_grad_function_known_answer_with_extra_values():
+    """tests/model/test_core.py:386-402: cost = extra1 * val1.sum() + val2.sum(), extra1 = 5, at ones: value 21 and
+    gradient [5, 5, 5, 1, 1, 1, 1, 1, 1] in raveled-input order (val1 then val2)."""
+    spec = models.value_grad_kat()
+    assert [v.value_name for v in spec.vars] == ["val1", "val2"] and spec.n == 9
+    f = ref_models.SpecLogpGrad(spec)
+    f.set_extra_values({"extra1": 5})
+    val, grad = f(np.ones(9))
+    assert val == 21
+    np.testing.assert_allclose(grad, [5, 5, 5, 1, 1, 1, 1, 1, 1])
+
+
 def test_truncated_normal_known_answer_and_scipy():
     """tests/model/test_core.py:467-479: TruncatedNormal(mu, 1, lower=-1, upper=2) on ten listed points,
     `dlogp(mu = 0) == 2.499424682024436` (rtol 1e-5); and logp against scipy.stats.truncnorm in the three regimes of
