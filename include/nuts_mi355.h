@@ -50,8 +50,10 @@ enum {
   NUTS_D_BERNOULLI = 10,  /* args: y(data), p               discrete.py:362-374 */
   NUTS_D_TRUNCNORMAL = 11,/* args: value, mu, sigma, lower(const); konst = upper (either bound may be infinite)
                              continuous.py:720-746 with dist_math.py:126-183 */
-  NUTS_D_POTENTIAL = 12   /* args: term; contributes sum(term) to the joint log-density: `pm.Potential`
+  NUTS_D_POTENTIAL = 12,  /* args: term; contributes sum(term) to the joint log-density: `pm.Potential`
                              (model/core.py:666-695 adds the potentials to the free and observed logps) */
+  NUTS_D_BINOMIAL = 13    /* args: y(data), n(data/const), p, binomln(n, y)(data, taken by the caller: the gammaln terms
+                             carry no gradient)                discrete.py:141-154 with dist_math.py:92-114 */
 };
 
 typedef struct {

@@ -43,7 +43,8 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_BERNOULLI,
     D_TRUNCNORMAL,
     D_POTENTIAL,
-) = range(13)
+    D_BINOMIAL,
+) = range(14)
 
 
 def softplus(x):
@@ -220,6 +221,20 @@ def _dist_raw(dist, konst, a, ok):
         dmu = z / sg - (ra - rb) / sg
         dsg = (z * z - 1) / sg - ((za * ra if lb else 0.0) - (zb * rb if ub else 0.0)) / sg
         return lp, [-z / sg, dmu, dsg, np.zeros_like(lp)]
+    if dist == D_BINOMIAL:  # discrete.py:141-154 ; binomln(n, y) arrives as data (no gradient), logpow dist_math.py:92-107
+        y, nn, p, lbc = a
+        m2 = nn - y
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lx, l1 = np.log(p), np.log1p(-p)
+            z1, z2 = (lx == -np.inf) & (y <= 0), (l1 == -np.inf) & (m2 <= 0)
+            t1 = np.where(z1, np.where(y == 0, 0.0, -np.inf), y * lx)
+            t2 = np.where(z2, np.where(m2 == 0, 0.0, -np.inf), m2 * l1)
+            lp = lbc + t1 + t2
+            dp = np.where(z1, 0.0, y / p) - np.where(z2, 0.0, m2 / (1 - p))
+        lp = _guard(ok, ~((y < 0) | (y > nn)), lp)
+        lp = _guard(ok, nn >= 0, lp)
+        lp = _guard(ok, (p >= 0) & (p <= 1), lp)
+        return lp, [np.zeros_like(lp), np.zeros_like(lp), dp, np.zeros_like(lp)]
     if dist == D_POTENTIAL:  # pm.Potential: the term is added to the joint log-density (model/core.py:666-695)
         (v,) = a
         return np.asarray(v, dtype="d") * 1.0, [np.ones_like(np.asarray(v, dtype="d"))]

@@ -276,7 +276,7 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 }
 
 // log-density of one element and its partials w.r.t. each argument.
-// (not inlined: one copy of the 13-way switch and its libm expansions per kernel keeps kernels B and C small
+// (not inlined: one copy of the 14-way switch and its libm expansions per kernel keeps kernels B and C small
 // enough for the instruction cache -- they are launched once per leapfrog between two passes of kernel A)
 __device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
   const double NINF = -INFINITY;
@@ -393,6 +393,18 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       d[0] = -z / sg;
       d[1] = z / sg - (ra - rb) / sg;
       d[2] = (z * z - 1.0) / sg - ((lb ? za * ra : 0.0) - (ub ? zb * rb : 0.0)) / sg;
+    } break;
+    case NUTS_D_BINOMIAL: {  // discrete.py:141-154; logpow(x, m) of dist_math.py:92-107
+      const double y = a[0], nn = a[1], p = a[2], m2 = nn - y;
+      const double lx = log(p), l1 = log1p(-p);
+      const bool z1 = lx == NINF && y <= 0, z2 = l1 == NINF && m2 <= 0;
+      const double t1 = z1 ? (y == 0 ? 0.0 : NINF) : y * lx;
+      const double t2 = z2 ? (m2 == 0 ? 0.0 : NINF) : m2 * l1;
+      lp = a[3] + t1 + t2;
+      d[2] = (z1 ? 0.0 : y / p) - (z2 ? 0.0 : m2 / (1.0 - p));
+      KILL_UNLESS(!(y < 0 || y > nn))
+      KILL_UNLESS(nn >= 0)
+      KILL_UNLESS(p >= 0 && p <= 1)
     } break;
     case NUTS_D_POTENTIAL: {  // pm.Potential: the term itself is the log-density contribution
       lp = a[0];

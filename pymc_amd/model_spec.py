@@ -52,7 +52,8 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_BERNOULLI,
     D_TRUNCNORMAL,
     D_POTENTIAL,
-) = range(13)
+    D_BINOMIAL,
+) = range(14)
 DIST_NAMES = {
     D_NORMAL: "Normal",
     D_HALFNORMAL: "HalfNormal",
@@ -67,6 +68,7 @@ DIST_NAMES = {
     D_BERNOULLI: "Bernoulli",
     D_TRUNCNORMAL: "TruncatedNormal",
     D_POTENTIAL: "Potential",
+    D_BINOMIAL: "Binomial",
 }
 
 
@@ -348,6 +350,16 @@ class ModelBuilder:
     def Bernoulli(self, name, p, observed):
         """`pm.Bernoulli(name, p=..., observed=...)` (pymc/distributions/discrete.py:362-374)."""
         return self._register(D_BERNOULLI, name, (p,), None, observed, TR_NONE)
+
+    def Binomial(self, name, n, p, observed):
+        """`pm.Binomial(name, n=..., p=..., observed=...)` (pymc/distributions/discrete.py:60-154); `binomln(n, y)`
+        (dist_math.py:109-114) depends on data only and is taken here."""
+        from scipy.special import gammaln
+
+        y = np.asarray(observed, dtype="float64")
+        nn = np.broadcast_to(np.asarray(n, dtype="float64"), y.shape)
+        lbc = gammaln(nn + 1) - gammaln(y + 1) - gammaln(nn - y + 1)
+        return self._register(D_BINOMIAL, name, (nn if nn.size > 1 else float(nn.reshape(-1)[0]), p, lbc), None, y, TR_NONE)
 
     def BernoulliLogit(self, name, logit_p, observed):
         """`pm.Bernoulli(name, logit_p=..., observed=...)` (pymc/distributions/discrete.py:343-374)."""

@@ -65,6 +65,7 @@ def test_all_elementwise_distributions():
     m.Normal("obs", a + s * c, e, observed=np.linspace(-1, 1, 5))
     m.BernoulliLogit("yl", a, observed=np.array([0, 1, 1, 0, 1.0]))
     m.Bernoulli("yb", b, observed=np.array([1, 0, 1.0]))
+    m.Binomial("yn", n=[3, 7, 2], p=b, observed=[0, 7, 1])
     tn = m.TruncatedNormal("tn", 0.4, 1.3, lower=-1.0, upper=2.5, shape=3)
     m.TruncatedNormal("to1", mu=a, sigma=s, lower=-2.0, upper=3.0, observed=np.linspace(-1, 2, 5))
     m.TruncatedNormal("to2", mu=tn, sigma=0.7, lower=0.2, observed=np.array([0.3, 1.0, 4.0]))
@@ -700,6 +701,28 @@ def test_reference_fixture_nuts_normal_and_studentt():
     assert _ks_ok(d.reshape(-1, 1), [stats.t(df=4).cdf], thin=10)
     assert ess_bulk(d[:, :, 0]) > 1000
     np.testing.assert_allclose(rhat(d[:, :, 0]), 1, rtol=0.01)
+
+
+def test_reference_fixture_nuts_beta_binomial():
+    """`TestNUTSBetaBinomial` (test_nuts.py:63-70 + sampler_fixtures.py:88-97): p ~ Beta([.5, .5, 1], [.5, .5, 1]),
+    y ~ Binomial(n = [4, 12, 9], p), observed [1, 2, 9]; the posterior is Beta([1.5, 2.5, 10], [3.5, 10.5, 1]):
+    KS (alpha 0.001) on every 5th of 2 x 2000 draws, ESS > 400, R-hat within 1 %."""
+    from scipy import stats
+
+    from pymc_amd.stats import ess_bulk, rhat
+
+    m = ModelBuilder()
+    p = m.Beta("p", 0.5, 0.5, shape=2)
+    p3 = m.Beta("p3", 1.0, 1.0)
+    m.Binomial("y", n=[4, 12], p=p, observed=[1, 2])
+    m.Binomial("y3", n=9, p=p3, observed=[9])
+    d, acc = _run_fixture(m.build(), 2000, 1000, 2, 20160911)
+    pp = 1.0 / (1.0 + np.exp(-d))   # backward logodds transform
+    cdfs = [stats.beta(a, b).cdf for a, b in zip([1.5, 2.5, 10], [3.5, 10.5, 1])]
+    assert _ks_ok(pp.reshape(-1, 3), cdfs, thin=5)
+    for i in range(3):
+        assert ess_bulk(pp[:, :, i]) > 400
+        np.testing.assert_allclose(rhat(pp[:, :, i]), 1, rtol=0.01)
 
 
 def test_nuts_statistics_std_normal():

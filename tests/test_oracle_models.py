@@ -115,6 +115,25 @@ def test_bernoulli_vs_scipy():
         np.testing.assert_almost_equal(lp - st.norm.logpdf(0.0), 2 * st.bernoulli.logpmf(y, sp.expit(eta)), decimal=6)
 
 
+def test_binomial_vs_scipy_and_logpow_edges():
+    """Binomial logpmf (discrete.py:141-154) against SciPy over the domain the reference checks
+    (tests/distributions/test_discrete.py: n in Nat, p in Unit) incl. p = 0 / p = 1 where `logpow`
+    (dist_math.py:92-107) turns 0 * log 0 into 0."""
+    from oracle.ref_models import D_BINOMIAL
+    from oracle.ref_models import _dist as dist_logp_and_partials
+    from scipy.special import gammaln
+
+    for n in (0, 1, 5, 20):
+        for p in (0.0, 0.01, 0.5, 0.99, 1.0):
+            y = np.arange(0, n + 1, dtype="d")
+            lbc = gammaln(n + 1) - gammaln(y + 1) - gammaln(n - y + 1)
+            lp, _ = dist_logp_and_partials(D_BINOMIAL, 0.0, [y, np.full_like(y, n), np.full_like(y, p), lbc])
+            ref = st.binom.logpmf(y, n, p)
+            np.testing.assert_array_almost_equal(lp, ref, decimal=6)
+    lp, _ = dist_logp_and_partials(D_BINOMIAL, 0.0, [np.array([3.0]), np.array([2.0]), np.array([0.5]), np.array([0.0])])
+    assert lp[0] == -np.inf   # value > n
+
+
 def test_bernoulli_logodds_known_answer():
     """tests/model/test_core.py:457-465: Beta(1,1) prior (logodds-transformed), ten zeros observed,
     `p_logodds__ = 0`  =>  observed-logp = 10 * log(0.5)."""
