@@ -262,6 +262,18 @@ def sample(
         )
     else:
         points = [dict(initial_point(spec)) for _ in range(chains)]
+    # `model.check_start_vals` (mcmc.py:883-887, model/core.py:1319-1373): the log-density must be finite where a chain starts
+    for c in mine:
+        lp, _ = step._logp_dlogp_func._pytensor_function(DictToArrayBijection.map({k: points[c][k] for k in step.var_names}).data)
+        if not np.isfinite(lp):
+            from pymc_amd.exceptions import SamplingError
+
+            raise SamplingError(
+                "Initial evaluation of model at starting point failed!\n"
+                f"Starting values:\n{ {k: np.asarray(v) for k, v in points[c].items()} }\n\n"
+                f"Logp initial evaluation results:\n{ {'joint': lp} }\n"
+                "You can call `model.debug()` for more details."
+            )
     initial_state = step.sampling_state  # mcmc.py:1411,1423: the same step object is reset between chains
     pooled = None
     if pooled_adaptation and world > 1:

@@ -599,6 +599,46 @@ def test_pooled_adaptation_roundtrip_over_rccl():
         dist.destroy_process_group()
 
 
+def test_sampler_stats_names_shapes_and_model_logp():
+    """`TestNutsCheckTrace.test_sampler_stats` (test_nuts.py:142-191): the 19 statistics exist, one value per draw, and
+    the tracked `model_logp` equals the log-density recomputed at the stored point EXACTLY."""
+    from pymc_amd.sampling import sample
+
+    m = ModelBuilder()
+    m.Normal("x", 0.0, 1.0)
+    res = sample(draws=10, tune=1, chains=1, model=m.build(), random_seed=4, device=0)
+    expected = {
+        "depth", "diverging", "divergences", "energy", "energy_error", "model_logp", "max_energy_error",
+        "mean_tree_accept", "step_size", "step_size_bar", "tree_size", "perf_counter_diff", "perf_counter_start",
+        "process_time_diff", "reached_max_treedepth", "index_in_trajectory", "largest_eigval", "smallest_eigval", "warning",
+    }
+    stats = res["stats"][0]
+    assert len(stats) == 10 and all(set(s) == expected for s in stats)
+    f = res["step"]._logp_dlogp_func
+    recomputed = np.array([f._pytensor_function(q)[0] for q in res["draws"][0]])
+    assert (np.array([s["model_logp"] for s in stats]) == recomputed).all()
+    res["step"].close()
+    # the same on the streaming path (position recomposed on the fly during the leapfrog, plain evaluation afterwards)
+    spec = models.hier_logit(G=16, D=8, rows_per_group=70, seed=2)
+    res = sample(draws=6, tune=6, chains=1, model=spec, random_seed=4, device=0)
+    f = res["step"]._logp_dlogp_func
+    recomputed = np.array([f._pytensor_function(q)[0] for q in res["draws"][0]])
+    assert (np.array([s["model_logp"] for s in res["stats"][0]]) == recomputed).all()
+    res["step"].close()
+
+
+def test_bad_init_raises_before_sampling():
+    """`test_bad_init_nonparallel` (test_nuts.py:114-120): HalfNormal without its transform started at -1 -->
+    SamplingError("Initial evaluation ...") from the start-value check (model/core.py:1319-1373)."""
+    from pymc_amd.exceptions import SamplingError
+    from pymc_amd.sampling import sample
+
+    m = ModelBuilder()
+    m.HalfNormal("a", 1.0, transform=None)
+    with pytest.raises(SamplingError, match="Initial evaluation"):
+        sample(draws=5, tune=5, chains=1, model=m.build(), random_seed=1, device=0, init="adapt_diag", initvals={"a": -1.0})
+
+
 def test_bad_initial_energy_raises():
     from pymc_amd.exceptions import SamplingError
     from pymc_amd.step import NUTS
