@@ -261,7 +261,13 @@ def sample(
             spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device, tune=tune, **step_kwargs
         )
     else:
-        points = [dict(initial_point(spec)) for _ in range(chains)]
+        points = []
+        for c in range(chains):   # mcmc.py:867-881: `initvals` also apply when the caller brings the step method
+            pt = dict(initial_point(spec))
+            iv = initvals[c] if isinstance(initvals, (list, tuple)) else initvals
+            if iv:
+                pt.update({k: np.asarray(v, dtype="float64") for k, v in iv.items()})
+            points.append(pt)
     # `model.check_start_vals` (mcmc.py:883-887, model/core.py:1319-1373): the log-density must be finite where a chain starts
     for c in mine:
         lp, _ = step._logp_dlogp_func._pytensor_function(DictToArrayBijection.map({k: points[c][k] for k in step.var_names}).data)

@@ -472,6 +472,43 @@ def test_sampling_state_roundtrip():
     step.close()
 
 
+def test_step_continuous_on_mv_simple_with_dense_scaling():
+    """`TestStepNUTS.test_step_continuous` (test_nuts.py:194-204, tests/helpers.py:140-187) on `mv_simple`
+    (tests/models.py:95-107: x ~ MvNormal(mu, tau = P P^T)) with `NUTS(scaling=C, is_cov=True)`:
+    stepping twice from the same sampling state gives the same value and the same final state; after 1000 tune + 1000
+    draws started at [0.1, 1.0, 0.8] the chain's mean is within sigma/10 of mu and its std within sigma/10 of sigma."""
+    from pymc_amd.sampling import sample
+    from pymc_amd.step import NUTS
+
+    mu = np.array([-0.1, 0.5, 1.1])
+    p = np.array([[2.0, 0, 0], [0.05, 0.1, 0], [1.0, -0.05, 5.5]])
+    tau = p @ p.T
+    C = np.linalg.inv(tau)
+    m = ModelBuilder()
+    m.MvNormal("x", mu, C)
+    spec = m.build()
+    step = NUTS(model=spec, scaling=C, is_cov=True, rng=1, device=0)
+    orig_state = step.sampling_state
+    ip = {"x": np.zeros(3)}
+    value1, _ = step.step(ip)
+    final_state = step.sampling_state
+    step.sampling_state = orig_state
+    value2, _ = step.step(ip)
+    assert np.array_equal(value1["x"], value2["x"])
+    fs2 = step.sampling_state
+    assert fs2.rng == final_state.rng and fs2.potential_rng == final_state.potential_rng and fs2.engine_blob == final_state.engine_blob
+    step.sampling_state = orig_state
+    res = sample(draws=1000, tune=1000, chains=1, model=spec, step=step, initvals={"x": np.array([0.1, 1.0, 0.8])},
+                 random_seed=1, device=0, discard_tuned_samples=False)
+    assert res["draws"].shape == (1, 2000, 3)
+    x = res["draws"][0, 1000:]
+    unc = np.diag(C) ** 0.5
+    assert np.all(np.abs(x.mean(0) - mu) < unc / 10)
+    assert np.all(np.abs(x.std(0) - unc) < unc / 10)
+    assert step.sampling_state.engine_blob != orig_state.engine_blob
+    step.close()
+
+
 def test_same_seed_bitwise_reproducible():
     """tests/sampling/test_mcmc.py:80-109: same seed => bitwise-equal draws."""
     from pymc_amd.sampling import sample
