@@ -509,6 +509,49 @@ def test_step_continuous_on_mv_simple_with_dense_scaling():
     step.close()
 
 
+def test_hmc_step_continuous_on_mv_simple_with_dense_scaling():
+    """`TestStepHamiltonianMC.test_step_continuous` (test_hmc.py:31-40, tests/helpers.py:140-187):
+    `HamiltonianMC(scaling=C, is_cov=True)` on `mv_simple`, 1000 tune + 1000 draws: mean and std within sigma/10."""
+    from pymc_amd.sampling import sample
+    from pymc_amd.step import HamiltonianMC
+
+    mu = np.array([-0.1, 0.5, 1.1])
+    p = np.array([[2.0, 0, 0], [0.05, 0.1, 0], [1.0, -0.05, 5.5]])
+    C = np.linalg.inv(p @ p.T)
+    m = ModelBuilder()
+    m.MvNormal("x", mu, C)
+    spec = m.build()
+    step = HamiltonianMC(model=spec, scaling=C, is_cov=True, rng=1, device=0)
+    orig_state = step.sampling_state
+    v1, _ = step.step({"x": np.zeros(3)})
+    final_state = step.sampling_state
+    step.sampling_state = orig_state
+    v2, _ = step.step({"x": np.zeros(3)})
+    assert np.array_equal(v1["x"], v2["x"]) and step.sampling_state.engine_blob == final_state.engine_blob
+    step.sampling_state = orig_state
+    res = sample(draws=1000, tune=1000, chains=1, model=spec, step=step, initvals={"x": np.array([0.1, 1.0, 0.8])},
+                 random_seed=1, device=0)
+    x = res["draws"][0]
+    unc = np.diag(C) ** 0.5
+    assert np.all(np.abs(x.mean(0) - mu) < unc / 10)
+    assert np.all(np.abs(x.std(0) - unc) < unc / 10)
+    step.close()
+
+
+def test_nuts_tuning_freezes_the_step_size():
+    """`test_nuts_tuning` (test_hmc.py:76-90): after tuning `step.tune` is False and every sampling draw reports the
+    step size of the last tuning draw."""
+    from pymc_amd.sampling import sample
+
+    m = ModelBuilder()
+    m.Normal("mu", 0.0, 1.0)
+    res = sample(draws=10, tune=5, chains=1, model=m.build(), random_seed=2, device=0, discard_tuned_samples=False)
+    assert not res["step"].tune
+    ss_tuned = res["warmup_stats"][0][-1]["step_size"]
+    assert all(s["step_size"] == ss_tuned for s in res["stats"][0][5:])
+    res["step"].close()
+
+
 def test_same_seed_bitwise_reproducible():
     """tests/sampling/test_mcmc.py:80-109: same seed => bitwise-equal draws."""
     from pymc_amd.sampling import sample
