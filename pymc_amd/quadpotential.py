@@ -389,6 +389,10 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
             self.adaptation_window = int(self.adaptation_window * self.adaptation_window_multiplier)
         self._n_samples += 1
 
+    def update(self, sample, grad, tune):
+        """`QuadPotentialFullAdapt.update` (quadpotential.py:819-843): this estimator really lives on the host."""
+        self._host_update(np.asarray(sample, dtype="float64"), grad, tune)
+
     def raise_ok(self, map_info=None):
         if self._chol_error is not None:
             raise ValueError(str(self._chol_error))

@@ -141,6 +141,44 @@ def test_host_adapted_potentials_match_the_oracle_restatement():
     npt.assert_allclose(pe._hinv_stds, 1.0 / np.sqrt(pe._hvar))
 
 
+def test_full_adapt_windows_like_the_reference_tests():
+    """tests/step_methods/hmc/test_quadpotential.py:222-275 restated on the host-side estimator of
+    `QuadPotentialFullAdapt`: `update_window` (the covariance in use only changes every 50th update),
+    `adaptation_window` (estimator swap after `window` updates, window doubled), a non-invertible estimate is
+    reported by `raise_ok`, and the constructor warns that the feature is experimental."""
+    from pymc_amd.quadpotential import QuadPotentialFullAdapt
+
+    rng = np.random.default_rng(1123)
+    init_cov = np.array([[1.0, 0.02], [0.02, 0.8]])
+    with pytest.warns(UserWarning, match="experimental feature"):
+        pot = QuadPotentialFullAdapt(2, np.zeros(2), init_cov, 1, update_window=50)
+    assert np.allclose(pot._cov, init_cov)
+    for _ in range(49):
+        pot.update(rng.normal(size=2), None, True)
+    assert np.allclose(pot._cov, init_cov)
+    pot.update(rng.normal(size=2), None, True)
+    assert not np.allclose(pot._cov, init_cov)
+
+    window = 10
+    with pytest.warns(UserWarning, match="experimental feature"):
+        pot = QuadPotentialFullAdapt(2, np.zeros(2), np.eye(2), 1, adaptation_window=window)
+    for _ in range(window + 1):
+        pot.update(rng.normal(size=2), None, True)
+    assert pot._previous_update == window
+    assert pot.adaptation_window == window * pot.adaptation_window_multiplier
+
+    with pytest.warns(UserWarning, match="experimental feature"):
+        pot = QuadPotentialFullAdapt(2, np.zeros(2), np.eye(2), 0, adaptation_window=window)
+    import warnings
+
+    for _ in range(window + 1):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            pot.update(np.ones(2), None, True)
+    with pytest.raises(ValueError):
+        pot.raise_ok(None)
+
+
 def test_step_class_surface_matches_reference():
     """nuts.py:104-130, hmc.py:47-68, compound.py:108-131."""
     assert NUTS.name == "nuts" and NUTS.default_blocked
