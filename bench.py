@@ -100,6 +100,7 @@ def main():
     dist = None
     if args.share_gpu:
         local = 0
+        args.backend = "gloo"   # RCCL refuses two ranks on one device ("Duplicate GPU detected")
     if world > 1:
         import torch.distributed as dist
 
