@@ -60,6 +60,8 @@ static T* dev_upload(const T* src, size_t count) {
   return p;
 }
 
+#define SMALL_MAX_N 512   // largest model of the single-launch path (small_kernel.h: one thread per parameter)
+
 // ===========================================================================
 // model
 // ===========================================================================
@@ -732,7 +734,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n));
   c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0;
   c->spec_max = env_int("NUTS_SPEC_MAX", 3);
-  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && m->md.nblk == 1 && n <= VEC_THREADS && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
+  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
              cfg->potential != NUTS_POT_FULL;
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
@@ -970,6 +972,12 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   c->leapfrogs++;
 }
 
+// the single-launch path (small_kernel.h): one workgroup, one thread per parameter
+static void launch_small(nuts_chain* c, const ArenaDev& A, const SmallDrawArgs& a) {
+  if (c->n <= 256) hipLaunchKernelGGL(k_small_draw<256>, dim3(1), dim3(256), 0, c->m->stream, c->m->md, A, a);
+  else hipLaunchKernelGGL(k_small_draw<512>, dim3(1), dim3(512), 0, c->m->stream, c->m->md, A, a);
+}
+
 extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
                                int32_t n_uniforms, double* q_out, double* grad_out, nuts_draw_stats* stats) {
   if (!c || !q0 || !normals || !uniforms || !q_out || !stats) { g_err = "null argument"; return NUTS_E_ARG; }
@@ -1007,7 +1015,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
     a.step_size = step_size; a.Emax = c->cfg.Emax; a.max_depth = max_depth;
     a.n_draws = 1; a.n_uniforms = need_uni; a.worst_uniforms = need_uni;
     a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = nullptr; a.out = c->do_dev; a.n_done = nullptr; a.st = nullptr; a.seq = 0;
-    hipLaunchKernelGGL(k_small_draw, dim3(1), dim3(VEC_THREADS), 0, s, c->m->md, A, a);
+    launch_small(c, A, a);
     // the next draw's start-state cache must not alias this draw's output buffer
     std::swap(c->out_dev, c->out_dev2);
     HIPCHK(hipMemcpyAsync(c->out_host, c->out_dev2, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1152,7 +1160,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
 extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
                                     int32_t n_uniforms, int32_t K, double* q_out, nuts_draw_stats* stats, int32_t* n_done) {
   if (!c || !q0 || !normals || !uniforms || !q_out || !stats || !n_done || K <= 0) { g_err = "null argument"; return NUTS_E_ARG; }
-  if (!c->small) { g_err = "nuts_chain_draw_many: only models on the single-launch path (n <= 256, element-wise, diagonal mass matrix)"; return NUTS_E_ARG; }
+  if (!c->small) { g_err = "nuts_chain_draw_many: only models on the single-launch path (n <= 512, element-wise, diagonal mass matrix)"; return NUTS_E_ARG; }
   if (c->tune) { g_err = "nuts_chain_draw_many: the chain is still tuning (adaptation needs the host between draws)"; return NUTS_E_ARG; }
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
@@ -1201,7 +1209,7 @@ extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const doubl
   a.step_size = step_size; a.Emax = c->cfg.Emax; a.max_depth = max_depth;
   a.n_draws = K; a.n_uniforms = n_uniforms; a.worst_uniforms = need_uni;
   a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = trace_dev; a.out = outs_dev; a.n_done = ndone_dev; a.st = nullptr; a.seq = 0;
-  hipLaunchKernelGGL(k_small_draw, dim3(1), dim3(VEC_THREADS), 0, s, c->m->md, Am, a);
+  launch_small(c, Am, a);
   std::swap(c->out_dev, c->out_dev2);   // (q, grad) of the last proposal: the next call's start-state cache
   HIPCHK(hipMemcpyAsync(c->many_out_host, c->many_out_dev, out_bytes, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));

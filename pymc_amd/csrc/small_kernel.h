@@ -2,7 +2,7 @@
 //
 // For tiny models (SURVEY.md section 7 "small-n latency": eight schools has n = 10 / 26) a leapfrog is a few
 // hundred flops; three launches per leapfrog plus a host round trip per doubling cost two orders of magnitude more
-// than the arithmetic.  When the model fits one workgroup (n <= 256, element-wise factors only, diagonal mass
+// than the arithmetic.  When the model fits one workgroup (n <= 512, element-wise factors only, diagonal mass
 // matrix) the whole transition -- momentum refresh, start state, every doubling of the tree, proposal gather -- runs
 // inside this kernel: one thread per parameter, `__syncthreads()` instead of kernel boundaries, the control block in
 // LDS for the whole draw.  The arithmetic is the same device code the three-kernel pipeline uses (gather_element,
@@ -43,10 +43,12 @@ struct SmallDrawArgs {
   int seq, pad2;
 };
 
-__global__ __launch_bounds__(VEC_THREADS) void k_small_draw(ModelDev md, ArenaDev A, SmallDrawArgs a) {
-  constexpr int NW = VEC_THREADS / WAVE;
+// NT = threads of the one workgroup (256 or 512: one thread per parameter, so n <= 512 runs here)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, SmallDrawArgs a) {
+  constexpr int NW = NT / WAVE;
   __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
-  __shared__ double s_bacc[MAX_BTERMS][VEC_THREADS];
+  __shared__ double s_bacc[MAX_BTERMS][NT];
   __shared__ double s_red[NDOT * NW];
   __shared__ double s_dot[NDOT];
   __shared__ double s_w[NW];
@@ -78,14 +80,14 @@ __global__ __launch_bounds__(VEC_THREADS) void k_small_draw(ModelDev md, ArenaDe
       } else {
         transform_full(v, qn, x, dxdq, lj, dj);
         lp = lj;
-        gather_element(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+        gather_element(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], NT);
       }
     }
     for (int o = 0; o < md.n_orphans; ++o) {   // factors without an owning variable
       const int fi = md.orphans[o];
       const nuts_factor& f = pg.factors[fi];
       const FactorBT& bt = pg.fbt[fi];
-      for (int li = tid; li < f.size; li += VEC_THREADS) {
+      for (int li = tid; li < f.size; li += NT) {
         double dv[4], bv[4], cv[4];
         lp += factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv);
         for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm][tid] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_small_draw(ModelDev md, ArenaDe
         int m; bool last;
         leaf_post<1>(A, lf, j, d, true, idx, act, grad, ph, s_red, NW, m, last);
         __syncthreads();
-        for (int q = tid; q < NDOT; q += VEC_THREADS) {
+        for (int q = tid; q < NDOT; q += NT) {
           if (!dot_needed(q, m, last)) continue;
           double r = 0.0;
           for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];

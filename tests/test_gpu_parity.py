@@ -412,15 +412,18 @@ def test_nuts_parity_eight_schools():
 
 def test_nuts_parity_three_kernel_pipeline_on_small_and_multi_workgroup_models(monkeypatch):
     """Small models normally take the single-launch path (small_kernel.h).  The general three-kernel pipeline must
-    give the same integers: forced on eight schools, and naturally on a schools model that spans two workgroups
-    (n = 302: broadcast terms and deferred scalars across workgroups)."""
+    give the same integers: forced on eight schools and on a schools model that spans two workgroups (n = 302:
+    broadcast terms and deferred scalars across workgroups), and by default above 512 parameters (n = 602)."""
     monkeypatch.setenv("NUTS_SMALL_KERNEL", "0")
     _compare_runs(models.eight_schools(), tune=30, draws=10, seed=20160911, prefix=40)
-    monkeypatch.delenv("NUTS_SMALL_KERNEL")
-    big = models.eight_schools(300)
+    big = models.eight_schools(300)   # n = 302: two workgroups of the vector kernel (the single-launch path takes n <= 512)
     rng = np.random.default_rng(1)
     _check_logp_grad(big, [np.zeros(big.n), rng.normal(size=big.n)])
     _compare_runs(big, tune=15, draws=5, seed=8, prefix=20)
+    monkeypatch.delenv("NUTS_SMALL_KERNEL")
+    _compare_runs(big, tune=15, draws=5, seed=8, prefix=20)      # the same model in ONE 512-thread workgroup
+    bigger = models.eight_schools(600)                           # n = 602: three-kernel pipeline by default
+    _compare_runs(bigger, tune=12, draws=4, seed=8, prefix=16)
 
 
 def test_nuts_parity_hier_logit():
