@@ -915,7 +915,10 @@ struct Geometry {  // of the doubling being built: direction, edge state, curren
   double eps;
 };
 
-static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d, int mode, int max_depth, int seq = 0) {
+// `n_simple`: MODE_SIMPLE only -- the length of the fixed trajectory being queued (leaf j of n_simple), so that the folded
+// schedules below know which leaf is the last one
+static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d, int mode, int max_depth, int seq = 0,
+                                int n_simple = 0) {
   ArenaDev& A = c->A;
   nuts_model* m = c->m;
   hipStream_t s = m->stream;
@@ -927,10 +930,11 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   const int64_t d_o = (int64_t)(t & (A.S - 1)) * A.n, so = (int64_t)(src & (A.S - 1)) * A.n;
   HostStatus* const st = mode == MODE_TREE ? c->st_dev : (HostStatus*)nullptr;
   io.lean = m->md.lean_ok && !c->dense && (!io.explicit_pre || m->md.n_deferred == 0);
-  if (io.lean && io.explicit_pre && mode == MODE_TREE && c->fold_ctl) {
+  const bool foldable = c->fold_ctl && (mode == MODE_TREE || (mode == MODE_SIMPLE && n_simple > 0));
+  const bool last = mode == MODE_TREE ? j + 1 == (1 << d) : j + 1 == n_simple;
+  if (io.lean && io.explicit_pre && foldable) {
     // MvNormal model on the lean path: kernel B of leaf j also materialises the first half of leaf j+1, the control
     // work of leaf j-1 rides in workgroup 0 of this leaf's mat-vec; the last leaf gets a control launch of its own
-    const bool last = j + 1 == (1 << d);
     if (j == 0) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
     io.pre_next = last ? 0 : 1;
     launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
@@ -943,10 +947,10 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   if (c->dense)   // v = C p_half ; q' = q + eps v   (integration.py:121-127 with a dense velocity)
     hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, A.Q + so, A.Q + d_o, gm.eps,
                        abort_flag);
-  if (io.lean && mode == MODE_TREE && c->fold_ctl) {
+  if (io.lean && foldable) {
     // folded control (kernels.h): the control work of leaf j-1 rides in workgroup 0 of this leaf's row pass; only the
-    // last leaf of the doubling -- whose status the host waits for -- gets a control launch of its own
-    const bool last = j + 1 == (1 << d);
+    // last leaf of the doubling (of the fixed-length trajectory) -- whose result the host waits for -- gets a control
+    // launch of its own
     launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
     launch_vector(m, A, io, j, d);
     if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
@@ -1290,7 +1294,7 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   int rc = draw_begin(c, q0, normals, uniforms, 0, step_size, 1, false, +1);
   if (rc) return rc;
   const Geometry gm{+1, 0, 0, 0, step_size};
-  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1);
+  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1, 0, n_steps);
   std::vector<double> Eh(2), lph(2);
   const int last = n_steps & (A.S - 1);
   HIPCHK(hipMemcpyAsync(c->out_host, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1354,7 +1358,7 @@ extern "C" int nuts_chain_leapfrog_test(nuts_chain* c, const double* q, const do
   int rc = draw_begin(c, q, p, nullptr, 0, std::fabs(eps), 1, true, dir);
   if (rc) return rc;
   const Geometry gm{dir, 0, 0, 0, eps};
-  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1);
+  for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1, 0, n_steps);
   const int last = (dir * n_steps) & (A.S - 1);
   HIPCHK(hipStreamSynchronize(s));
   if (q_out) HIPCHK(hipMemcpy(q_out, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost));

@@ -349,13 +349,18 @@ def test_leapfrog_reversible():
     step.close()
 
 
-def test_leapfrog_matches_oracle():
+@pytest.mark.parametrize("which", ["schools", "hier_logit", "mvnormal"])
+def test_leapfrog_matches_oracle(which, monkeypatch):
+    """A fixed-length trajectory (`CpuLeapfrogIntegrator.step` x 7, integration.py:77-145) against the oracle integrator:
+    on the element-wise path, and on the two streaming paths whose control work is folded into the next leaf's data
+    pass (also bitwise against one control launch per leaf)."""
     import ctypes as C
 
     from pymc_amd import _lib
     from pymc_amd.step import NUTS
 
-    spec = models.eight_schools()
+    spec = {"schools": models.eight_schools, "hier_logit": lambda: models.hier_logit(G=12, D=8, rows_per_group=90, seed=4),
+            "mvnormal": lambda: models.mvnormal(n=96)}[which]()
     rng = np.random.default_rng(0)
     var = rng.uniform(0.5, 2.0, size=spec.n)
     step = NUTS(model=spec, scaling=var, is_cov=True, rng=1, device=0)
@@ -372,6 +377,13 @@ def test_leapfrog_matches_oracle():
     np.testing.assert_allclose(p1, s.p, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(e.value, s.energy, rtol=1e-11)
     step.close()
+    if which != "schools":
+        monkeypatch.setenv("NUTS_FOLD_CTL", "0")
+        step = NUTS(model=spec, scaling=var, is_cov=True, rng=1, device=0)
+        q2, p2, e2 = np.empty(spec.n), np.empty(spec.n), C.c_double()
+        _lib.check(_lib.load().nuts_chain_leapfrog_test(step._chain, _lib.dptr(q0), _lib.dptr(p0), 0.05, 7, _lib.dptr(q2), _lib.dptr(p2), C.byref(e2)))
+        assert np.array_equal(q1, q2) and np.array_equal(p1, p2) and e.value == e2.value
+        step.close()
 
 
 # ---------------------------------------------------------------------------
