@@ -399,6 +399,9 @@ class IntegrationError(RuntimeError):
     pass
 
 
+_AXPY = scipy.linalg.blas.get_blas_funcs("axpy", dtype="float64")   # integration.py:110
+
+
 class Leapfrog:
     """CpuLeapfrogIntegrator (integration.py:41-145)."""
 
@@ -414,12 +417,18 @@ class Leapfrog:
 
     def step(self, eps, s: PhasePoint):  # integration.py:77-145
         try:
+            # the reference updates in place with BLAS `axpy` (integration.py:110-131): y <- a x + y, which OpenBLAS
+            # evaluates with fused multiply-adds -- one rounding, not two; the same routine is used here so that the
+            # restatement agrees with the reference to the last bit (tests/test_reference_run.py)
+            axpy = _AXPY
             half = 0.5 * eps
-            p_new = s.p + half * s.q_grad  # axpy #1
+            p_new = np.array(s.p, dtype="d", copy=True)
+            axpy(np.ascontiguousarray(s.q_grad, dtype="d"), p_new, a=half)   # p_new = p + dt * q_grad
             v_mid = self.pot.velocity(p_new)
-            q_new = s.q + eps * v_mid  # axpy #2
+            q_new = np.array(s.q, dtype="d", copy=True)
+            axpy(np.ascontiguousarray(v_mid, dtype="d"), q_new, a=eps)       # q_new = q + epsilon * v_new
             logp, g_new = self.f(q_new)
-            p_new = p_new + half * g_new  # axpy #3
+            axpy(np.ascontiguousarray(g_new, dtype="d"), p_new, a=half)      # p_new = p_new + dt * q_new_grad
             v_new = self.pot.velocity(p_new)
             kinetic = 0.5 * np.dot(p_new, v_new)
             energy = kinetic - logp
