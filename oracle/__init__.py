@@ -22,15 +22,17 @@ Parity status
   SciPy logpdf/logpmf agreement to 6 decimals (pymc/testing.py:311-417) and
   torch float64 autograd for every hand-written gradient
   (tests/test_oracle_*.py).
-* integrator / potentials / dual averaging: PINNED by the reference's
-  property tests restated in tests/ (reversibility rtol 1e-5,
-  tests/step_methods/hmc/test_hmc.py:49-74; velocity/energy identities and
-  Welford == np.var, tests/step_methods/hmc/test_quadpotential.py).
-* NUTS draw sequences: PARITY UNPINNED.  The reference holds no golden draw
-  vectors (all of its NUTS assertions are statistical) and
-  cannot be executed here to generate any.  The tree restatement is pinned only
-  by the reference's statistical fixtures (tests/sampler_fixtures.py) and by
-  line-by-line review against pymc/step_methods/hmc/nuts.py:204-489.
+* sampler layer (integrator, every QuadPotential, dual averaging, the NUTS tree, HMC, RNG consumption): PINNED BY
+  EXECUTING THE REFERENCE.  That layer of the reference is pure NumPy/SciPy; ``tests/golden/refrun.py`` loads exactly
+  those source files from /root/reference under their real module names (stand-ins only for the names they import
+  from the PyTensor side) and runs ``NUTS`` / ``HamiltonianMC`` over this oracle's log-density.  The fixtures under
+  ``tests/golden/`` are the outputs of those runs; ``oracle/ref_sampler.py`` reproduces every draw and statistic
+  BITWISE (nine cases: five potentials, adaptation windows, HMC), checked live wherever /root/reference exists
+  (``tests/test_golden.py``).  The reference's property tests are restated as well (reversibility rtol 1e-5,
+  tests/step_methods/hmc/test_hmc.py:49-74; velocity/energy identities and Welford == np.var,
+  tests/step_methods/hmc/test_quadpotential.py).
+  What remains unpinned there: the VALUES of the start-point jitter (drawn through PyTensor RNG ops in the
+  reference) -- everything downstream of a given start point is pinned.
 * ESS arithmetic is third-party (arviz) in the reference and lives in
   ``pymc_amd/stats.py`` (restated from Vehtari et al. 2021): parity unpinned.
 """
