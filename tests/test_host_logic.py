@@ -29,6 +29,35 @@ def test_dict_to_array_bijection_roundtrip():
     assert rv.data[0] == 0
 
 
+def test_bijection_agrees_with_the_reference_module():
+    """`pymc/blocking.py` is pure NumPy: where /root/reference exists it is loaded (tests/golden/refrun.py) and
+    `DictToArrayBijection.map` / `rmap` of this package must give the same raveled data, the same `point_map_info`
+    and the same round trip (blocking.py:67-103)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import refrun
+
+    if not refrun.available():
+        pytest.skip("needs the reference checkout under /root/reference")
+    ref = refrun.load()
+    from pymc_amd.blocking import DictToArrayBijection as Mine
+
+    rng = np.random.default_rng(0)
+    point = {"a": rng.normal(size=()), "b_log__": rng.normal(size=(3,)), "c": rng.normal(size=(2, 4)), "d": rng.normal(size=(1,))}
+    r, m = ref.DictToArrayBijection.map(point), Mine.map(point)
+    assert np.array_equal(r.data, m.data)
+    assert [(n, tuple(s), z, np.dtype(t)) for n, s, z, t in r.point_map_info] == [(n, tuple(s), z, np.dtype(t)) for n, s, z, t in m.point_map_info]
+    back_r, back_m = ref.DictToArrayBijection.rmap(r), Mine.rmap(m)
+    assert list(back_r) == list(back_m)
+    for k in point:
+        assert back_r[k].shape == back_m[k].shape and np.array_equal(back_r[k], back_m[k])
+    start = {"z": np.array([9.0]), **point}
+    sr, sm = ref.DictToArrayBijection.rmap(r, start_point=start), Mine.rmap(m, start_point=start)
+    assert list(sr) == list(sm) and all(np.array_equal(sr[k], sm[k]) for k in sr)
+
+
 def test_value_variable_layout_and_names():
     """registration order, `{name}_{transform}__` names, C2 layout mu | sigma_log__ | z."""
     spec = models.hier_logit(G=5, D=8, rows_per_group=3)
@@ -215,6 +244,35 @@ def test_rng_plumbing():
     assert get_random_generator(src, copy_=False) is src
     with pytest.raises(TypeError):
         get_random_generator(np.random.RandomState(1))
+
+
+def test_rng_helpers_agree_with_the_reference_module():
+    """`pymc/util.py:519-594` loaded from /root/reference (where present): `get_random_generator` and the generator-state
+    round trip give generators in the same state as this package's, for every kind of seed the step methods accept."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import refrun
+
+    if not refrun.available():
+        pytest.skip("needs the reference checkout under /root/reference")
+    util = refrun.load().util
+    for seed in (0, 123, [1, 2, 3], np.random.default_rng(5), np.random.PCG64(9)):
+        import copy
+
+        a = util.get_random_generator(copy.deepcopy(seed) if not isinstance(seed, (np.random.Generator, np.random.BitGenerator)) else seed)
+        b = get_random_generator(seed)
+        assert a.bit_generator.state == b.bit_generator.state
+        assert a.spawn(1)[0].bit_generator.state == b.spawn(1)[0].bit_generator.state   # the spawn counter travels too
+    g = np.random.default_rng(7)
+    g.spawn(2)
+    g.random(3)
+    st_ref = util.get_state_from_generator(g)
+    st_mine = _rng_state(g)
+    assert st_ref.bit_generator_state == st_mine["bit_generator_state"] and st_ref.seed_seq_state == st_mine["seed_seq_state"]
+    r1, r2 = util.random_generator_from_state(st_ref), _rng_from_state(st_mine)
+    assert r1.bit_generator.state == r2.bit_generator.state and r1.spawn(1)[0].random() == r2.spawn(1)[0].random()
 
 
 def test_chain_assignment_covers_every_chain_once():
