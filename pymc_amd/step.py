@@ -302,7 +302,7 @@ class NUTS(_DeviceHMCBase):
     @staticmethod
     def competence(var, has_grad):  # nuts.py:227-232
         dt = np.dtype(getattr(var, "dtype", "float64"))
-        return 3 if (dt.kind == "f" and has_grad) else 0  # Competence.PREFERRED / INCOMPATIBLE
+        return 2 if (dt.kind == "f" and has_grad) else 0  # Competence.PREFERRED (= 2, compound.py:57-60) / INCOMPATIBLE
 
     @staticmethod
     def _progressbar_config(n_chains=1):  # nuts.py:234-248

@@ -218,7 +218,7 @@ def test_step_class_surface_matches_reference():
               "perf_counter_start", "largest_eigval", "smallest_eigval", "index_in_trajectory", "reached_max_treedepth", "warning"]:
         assert k in keys
     assert NUTS.stats_dtypes_shapes["depth"][0] is np.int64 and NUTS.stats_dtypes_shapes["tree_size"][0] is np.float64
-    assert NUTS.competence(np.zeros(1), True) == 3 and NUTS.competence(np.zeros(1, dtype="int64"), True) == 0
+    assert NUTS.competence(np.zeros(1), True) == 2 and NUTS.competence(np.zeros(1, dtype="int64"), True) == 0
     assert NUTS.competence(np.zeros(1), False) == 0
     cols, st = NUTS._progressbar_config(3)
     assert len(cols) == 3 and st == {"divergences": [0] * 3, "step_size": [0] * 3, "tree_size": [0] * 3}
@@ -228,6 +228,38 @@ def test_step_class_surface_matches_reference():
     assert len(cols) == 2 and set(st) == {"divergences", "n_steps"}
     assert HamiltonianMC.name == "hmc" and "n_steps" in HamiltonianMC.stats_dtypes_shapes
     assert HamiltonianMC.competence(np.zeros(1), True) == 1
+
+
+def test_step_class_surface_agrees_with_the_reference_classes():
+    """The reference's `NUTS` / `HamiltonianMC` classes loaded from /root/reference (where present): statistic names,
+    dtypes and shapes (nuts.py:110-130, hmc.py:53-68), `name`, `default_blocked`, the progress-bar configuration
+    (nuts.py:234-257) and `competence` (nuts.py:227-232, hmc.py:202-207) are the same objects' worth of information."""
+    import os
+    import sys
+    import types
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import refrun
+
+    if not refrun.available():
+        pytest.skip("needs the reference checkout under /root/reference")
+    ref = refrun.load()
+    for mine, theirs in ((NUTS, ref.NUTS), (HamiltonianMC, ref.HamiltonianMC)):
+        a, b = theirs.stats_dtypes_shapes, mine.stats_dtypes_shapes
+        assert list(a) == list(b)
+        for k in a:
+            if k != "warning":   # (the dtype of that entry is each package's own SamplerWarning class)
+                assert a[k] == b[k], k
+        assert a["warning"][1] == b["warning"][1]
+        assert theirs.name == mine.name and theirs.default_blocked == mine.default_blocked
+        cols_t, st_t = theirs._progressbar_config(3)
+        cols_m, st_m = mine._progressbar_config(3)
+        assert st_t == st_m and len(cols_t) == len(cols_m)
+        for dtype, grad in (("float64", True), ("float64", False), ("int64", True)):
+            v = types.SimpleNamespace(dtype=dtype)
+            assert int(theirs.competence(v, grad)) == int(mine.competence(np.zeros(1, dtype=dtype), grad))
+    s = {"divergences": 2, "step_size": 0.1, "tree_size": 7.0, "x": 1}
+    assert ref.NUTS._make_progressbar_update_functions()[0](dict(s)) == NUTS._make_progressbar_update_functions()[0](dict(s))
 
 
 def test_rng_plumbing():
