@@ -146,7 +146,7 @@ def load():
     for p in ("pymc", "pymc.step_methods", "pymc.step_methods.hmc", "pymc.stats"):
         _pkg(p)
     _mod("pymc.pytensorf", floatX=lambda x: np.asarray(x, dtype="float64"))
-    _mod("pymc.vartypes", continuous_types={"float16", "float32", "float64"}, discrete_types=set())
+    _load("pymc.vartypes", "pymc/vartypes.py")
     _mod("pymc.tuning", guess_scaling=None)
     _mod("pymc.model", Point=lambda *a, **k: dict(*a), modelcontext=lambda m: m)
 
