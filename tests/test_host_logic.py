@@ -262,6 +262,45 @@ def test_step_class_surface_agrees_with_the_reference_classes():
     assert ref.NUTS._make_progressbar_update_functions()[0](dict(s)) == NUTS._make_progressbar_update_functions()[0](dict(s))
 
 
+def test_quad_potential_factory_agrees_with_the_reference_module():
+    """`quad_potential` / `partial_check_positive_definite` / `PositiveDefiniteError` (quadpotential.py:53-118) of the
+    reference, loaded from /root/reference where present: same class for every (ndim, is_cov), same stored variances,
+    same dense matrices (the device gets `cov` and `chol^-T` from these objects), same error and message."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import refrun
+
+    if not refrun.available():
+        pytest.skip("needs the reference checkout under /root/reference")
+    import pymc_amd.quadpotential as mine
+
+    qp = refrun.load().quadpotential
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0.5, 2.0, size=5)
+    a = rng.normal(size=(5, 5))
+    cov = a @ a.T + 5 * np.eye(5)
+    for C, is_cov in ((d, True), (d, False), (cov, True), (np.linalg.inv(cov), False)):
+        r, m = qp.quad_potential(C, is_cov, rng=1), mine.quad_potential(C, is_cov, rng=1)
+        assert type(r).__name__ == type(m).__name__
+        if C.ndim == 1:
+            npt.assert_array_equal(r.v, m.v)
+        else:
+            p = rng.normal(size=5)
+            npt.assert_allclose(r.velocity(p), m._cov @ p, rtol=1e-12)                      # what k_dense_mv multiplies by
+            z = np.random.default_rng(3).normal(size=5)
+            r.set_rng(np.random.default_rng(3))
+            npt.assert_allclose(r.random(), m._rand @ z, rtol=1e-10, atol=1e-12)            # p0 = W z on the device
+    bad = d.copy()
+    bad[2] = -1.0
+    with pytest.raises(qp.PositiveDefiniteError) as e_ref:
+        qp.quad_potential(bad, True)
+    with pytest.raises(mine.PositiveDefiniteError) as e_mine:
+        mine.quad_potential(bad, True)
+    assert str(e_ref.value) == str(e_mine.value)
+
+
 def test_rng_plumbing():
     """util.py:519-594: state round trip keeps the spawn counter; copy semantics of get_random_generator."""
     g = np.random.default_rng(7)
