@@ -27,7 +27,7 @@ Parity status
   those source files from /root/reference under their real module names (stand-ins only for the names they import
   from the PyTensor side) and runs ``NUTS`` / ``HamiltonianMC`` over this oracle's log-density.  The fixtures under
   ``tests/golden/`` are the outputs of those runs; ``oracle/ref_sampler.py`` reproduces every draw and statistic
-  BITWISE (nine cases: five potentials, adaptation windows, HMC), checked live wherever /root/reference exists
+  BITWISE (ten cases: five potentials, adaptation windows, HMC), checked live wherever /root/reference exists
   (``tests/test_golden.py``).  The reference's property tests are restated as well (reversibility rtol 1e-5,
   tests/step_methods/hmc/test_hmc.py:49-74; velocity/energy identities and Welford == np.var,
   tests/step_methods/hmc/test_quadpotential.py).

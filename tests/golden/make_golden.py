@@ -46,6 +46,8 @@ CASES = {
     "nuts_eight_schools": dict(model=("eight_schools", {}), tune=40, draws=20, seed=20160911),
     "nuts_schools_j24": dict(model=("eight_schools", {"J": 24}), tune=30, draws=10, seed=11),
     "nuts_hier_logit_small": dict(model=("hier_logit", {"G": 12, "D": 8, "rows_per_group": 29, "seed": 3}), tune=25, draws=15, seed=7),
+    # (rows_per_group = 300: spans that lie inside one group AND spans that straddle two -- both row-pass code paths)
+    "nuts_hier_logit_mid": dict(model=("hier_logit", {"G": 24, "D": 8, "rows_per_group": 300, "seed": 5}), tune=40, draws=15, seed=21),
     "nuts_std_normal_adapt": dict(model=("std_normal", {"n": 10}), tune=230, draws=20, seed=99),
     "nuts_schools_full": dict(model=("eight_schools", {}), tune=30, draws=15, seed=5, potential="full"),
     "nuts_schools_fullinv": dict(model=("eight_schools", {}), tune=30, draws=15, seed=6, potential="fullinv"),
