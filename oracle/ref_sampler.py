@@ -11,9 +11,8 @@ Floating point: float64 everywhere (reference default ``floatX``).
 
 from __future__ import annotations
 
-import math
 import time
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Callable, Optional, Sequence
 
 import numpy as np

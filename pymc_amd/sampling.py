@@ -23,8 +23,8 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from pymc_amd.blocking import DictToArrayBijection, RaveledVars
-from pymc_amd.model_spec import TR_INTERVAL, TR_LOG, TR_LOGODDS, ModelSpec
+from pymc_amd.blocking import DictToArrayBijection
+from pymc_amd.model_spec import ModelSpec
 from pymc_amd.quadpotential import QuadPotentialDiagAdapt, QuadPotentialDiagAdaptExp, QuadPotentialFullAdapt
 from pymc_amd.step import NUTS, get_random_generator
 
