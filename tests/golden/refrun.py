@@ -9,9 +9,10 @@ the PyTensor side:
 
 * `pytensor.config.floatX`, `pytensor.utils.lazy_scipy_module`, `pymc.pytensorf.floatX`;
 * `pymc.model.modelcontext` -> a tiny object with `continuous_value_vars` / `initial_point()`;
-* `pymc.step_methods.arraystep.GradientSharedStep` -> keeps the given `logp_dlogp_func` and generator, with the
-  `setup_chain` / `stop_tuning` of `compound.py:229-250`;
-* `pymc.stats.convergence.SamplerWarning`, `pymc.step_methods.compound.{Competence, StepMethodState}`.
+* `pymc.stats.convergence.SamplerWarning` / `WarningType` (the real module imports ArviZ).
+
+`compound.py` (`BlockedStep`, `Competence`, `setup_chain`, `stop_tuning`) and `arraystep.py` (`ArrayStepShared.step`,
+`GradientSharedStep`, which accepts a ready `logp_dlogp_func`, arraystep.py:174-205) are the reference's files too.
 
 The log-density itself comes from `oracle/ref_models.py` (PyTensor is what is missing), so what this pins is the
 SAMPLER: tree, integrator, potentials, adaptation and RNG consumption are the reference's code, executed.
@@ -179,40 +180,8 @@ def load():
     _load("pymc.blocking", "pymc/blocking.py")
     _load("pymc.step_methods.state", "pymc/step_methods/state.py")
 
-    class Competence(enum.IntEnum):  # compound.py:60-75
-        INCOMPATIBLE = 0
-        COMPATIBLE = 1
-        PREFERRED = 2
-        IDEAL = 3
-
-    state_mod = sys.modules["pymc.step_methods.state"]
-
-    @state_mod.dataclass_state
-    class StepMethodState(state_mod.DataClassState):  # compound.py:78-80
-        rng: util.RandomGeneratorState
-
-    _mod("pymc.step_methods.compound", Competence=Competence, StepMethodState=StepMethodState)
-
-    class GradientSharedStep(state_mod.WithSamplingState):
-        """What remains of `BlockedStep` / `ArrayStepShared` / `GradientSharedStep` once the PyTensor compile step is
-        taken out: the caller brings `logp_dlogp_func` (arraystep.py:174-205); `setup_chain` and `stop_tuning` as in
-        compound.py:229-250."""
-
-        def __init__(self, vars, *, model=None, blocked=True, dtype=None, logp_dlogp_func=None, rng=None, initial_point=None, **kw):
-            self.vars = vars
-            self.blocked = blocked
-            self.shared = {}
-            self._logp_dlogp_func = logp_dlogp_func
-            self.rng = util.get_random_generator(rng)
-
-        def stop_tuning(self):
-            if hasattr(self, "tune"):
-                self.tune = False
-
-        def setup_chain(self, rng, tune, draws):
-            self.rng = util.get_random_generator(rng, copy=False)
-
-    _mod("pymc.step_methods.arraystep", GradientSharedStep=GradientSharedStep)
+    _load("pymc.step_methods.compound", "pymc/step_methods/compound.py")     # BlockedStep, Competence, setup_chain ...
+    _load("pymc.step_methods.arraystep", "pymc/step_methods/arraystep.py")   # ArrayStepShared.step, GradientSharedStep
     util.get_value_vars_from_user_vars = lambda vars, model: list(vars)
     _load("pymc.step_methods.step_sizes", "pymc/step_methods/step_sizes.py")
     qp = _load("pymc.step_methods.hmc.quadpotential", "pymc/step_methods/hmc/quadpotential.py")
@@ -239,24 +208,22 @@ def make_step(kind, f, point, **kwargs):
 
 
 def run_chain(step, model, rng, tune, draws):
-    """`_iter_sample` (sampling/mcmc.py:1503-1583) reduced to the step method: returns positions and the per-draw
+    """`_iter_sample` (sampling/mcmc.py:1503-1583) reduced to the step method, points as dicts through the
+    reference's own `ArrayStepShared.step` (arraystep.py:107-122): returns raveled positions and the per-draw
     statistics dicts."""
     ref = load()
     step.setup_chain(rng, tune, draws)
+    point = model.initial_point()
     step.tune = bool(tune)
     if hasattr(step, "reset_tuning"):
         step.reset_tuning()
-    q = ref.DictToArrayBijection.map(model.initial_point())
     out, stats = [], []
     for i in range(tune + draws):
         if i == 0 and hasattr(step, "iter_count"):
             step.iter_count = 0
         if i == tune:
             step.stop_tuning()
-        q_new, st = step.astep(q)
-        if not isinstance(q_new, ref.RaveledVars):   # arraystep.py:118-120: "we assume that the mapping has stayed the same"
-            q_new = ref.RaveledVars(q_new, q.point_map_info)
-        q = q_new
-        out.append(np.array(q.data, dtype="float64", copy=True))
+        point, st = step.step(point)
+        out.append(np.array(ref.DictToArrayBijection.map(point).data, dtype="float64", copy=True))
         stats.append(st[0])
     return np.array(out), stats
