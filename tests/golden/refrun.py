@@ -17,8 +17,8 @@ the PyTensor side:
 The log-density itself comes from `oracle/ref_models.py` (PyTensor is what is missing), so what this pins is the
 SAMPLER: tree, integrator, potentials, adaptation and RNG consumption are the reference's code, executed.
 
-Only `tests/golden/make_reference_golden.py` and `tests/test_reference_run.py` use this, and only where
-`/root/reference` exists; the committed fixtures are what travels.
+Only `tests/golden/make_golden.py`, `tests/test_golden.py` and `tests/test_host_logic.py` use this, and only where
+`/root/reference` exists (`available()`); the committed fixtures are what travels to the GPU box.
 """
 from __future__ import annotations
 
