@@ -52,8 +52,12 @@ enum {
                              continuous.py:720-746 with dist_math.py:126-183 */
   NUTS_D_POTENTIAL = 12,  /* args: term; contributes sum(term) to the joint log-density: `pm.Potential`
                              (model/core.py:666-695 adds the potentials to the free and observed logps) */
-  NUTS_D_BINOMIAL = 13    /* args: y(data), n(data/const), p, binomln(n, y)(data, taken by the caller: the gammaln terms
+  NUTS_D_BINOMIAL = 13,   /* args: y(data), n(data/const), p, binomln(n, y)(data, taken by the caller: the gammaln terms
                              carry no gradient)                discrete.py:141-154 with dist_math.py:92-114 */
+  NUTS_D_GAMMA = 14,      /* args: value, alpha(const), beta; konst = -gammaln(alpha)   continuous.py:2512-2521 */
+  NUTS_D_INVGAMMA = 15,   /* args: value, alpha(const), beta; konst = -gammaln(alpha)   continuous.py:2631-2639 */
+  NUTS_D_LAPLACE = 16,    /* args: value, mu, b                                         continuous.py:1570-1576 */
+  NUTS_D_POISSON = 17     /* args: y(data), mu, factln(y)(data)                         discrete.py:581-597 */
 };
 
 typedef struct {

@@ -44,7 +44,11 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_TRUNCNORMAL,
     D_POTENTIAL,
     D_BINOMIAL,
-) = range(14)
+    D_GAMMA,
+    D_INVGAMMA,
+    D_LAPLACE,
+    D_POISSON,
+) = range(18)
 
 
 def softplus(x):
@@ -235,6 +239,46 @@ def _dist_raw(dist, konst, a, ok):
         lp = _guard(ok, nn >= 0, lp)
         lp = _guard(ok, (p >= 0) & (p <= 1), lp)
         return lp, [np.zeros_like(lp), np.zeros_like(lp), dp, np.zeros_like(lp)]
+    if dist in (D_GAMMA, D_INVGAMMA):  # continuous.py:2512-2521 / 2631-2639 ; alpha constant, konst = -gammaln(alpha)
+        v, al, be = a
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if dist == D_GAMMA:
+                be = 1.0 / (1.0 / be)   # the reference's Gamma carries scale = 1/beta and takes the reciprocal again
+                m2 = al - 1.0
+            else:
+                m2 = -al - 1.0
+            lb, lv = np.log(be), np.log(v)
+            t1 = np.where((lb == -np.inf) & (al <= 0), np.where(al == 0, 0.0, -np.inf), al * lb)   # logpow(beta, alpha)
+            z2 = (lv == -np.inf) & (m2 <= 0)
+            t2 = np.where(z2, np.where(m2 == 0, 0.0, -np.inf), m2 * lv)                          # logpow(value, .)
+            if dist == D_GAMMA:
+                lp = konst + t1 - be * v + t2
+                dv, db = -be + np.where(z2, 0.0, m2 / v), al / be - v
+            else:
+                lp = konst + t1 - be / v + t2
+                dv, db = be / (v * v) + m2 / v, al / be - 1.0 / v
+        lp = _guard(ok, v >= 0, lp)
+        lp = _guard(ok, al > 0, lp)
+        lp = _guard(ok, be > 0, lp)
+        return lp, [dv * np.ones_like(lp), np.zeros_like(lp), db * np.ones_like(lp)]
+    if dist == D_LAPLACE:  # continuous.py:1570-1576
+        v, mu, b = a
+        r = v - mu
+        lp = -np.log(2 * b) - np.abs(r) / b
+        lp = _guard(ok, b > 0, lp)
+        sg = np.sign(r)
+        return lp, [-sg / b, sg / b, -1 / b + np.abs(r) / (b * b)]
+    if dist == D_POISSON:  # discrete.py:581-597 ; factln(y) arrives as data
+        y, mu, fl = a
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lm = np.log(mu)
+            z = (lm == -np.inf) & (y <= 0)
+            lp = np.where(z, np.where(y == 0, 0.0, -np.inf), y * lm) - fl - mu
+            dmu = np.where(z, 0.0, y / mu) - 1.0
+        lp = np.where((mu == 0) & (y == 0), 0.0, lp)
+        lp = _guard(ok, ~(y < 0), lp)
+        lp = _guard(ok, mu >= 0, lp)
+        return lp, [np.zeros_like(lp), dmu * np.ones_like(lp), np.zeros_like(lp)]
     if dist == D_POTENTIAL:  # pm.Potential: the term is added to the joint log-density (model/core.py:666-695)
         (v,) = a
         return np.asarray(v, dtype="d") * 1.0, [np.ones_like(np.asarray(v, dtype="d"))]

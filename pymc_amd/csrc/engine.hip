@@ -188,7 +188,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     const nuts_factor& f = s->factors[fi];
     fbt[fi].n = 0; fbt[fi].pad = 0;
     if (f.nargs < 1 || f.nargs > 4 || f.size < 1) { g_err = "factor with a bad argument count or size"; return false; }
-    if (f.dist < 0 || f.dist > NUTS_D_BINOMIAL) { g_err = "factor with an unknown distribution code"; return false; }
+    if (f.dist < 0 || f.dist > NUTS_D_POISSON) { g_err = "factor with an unknown distribution code"; return false; }
     if (f.dist == NUTS_D_TRUNCNORMAL) {   // the bounds carry no gradient here: lower must be a constant (upper is `konst`)
       const nuts_term& lo = f.arg[3];
       if (f.nargs != 4 || lo.a.kind == NUTS_OP_VAR || lo.b.kind == NUTS_OP_VAR || lo.c.kind == NUTS_OP_VAR) {

@@ -276,7 +276,7 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 }
 
 // log-density of one element and its partials w.r.t. each argument.
-// (not inlined: one copy of the 14-way switch and its libm expansions per kernel keeps kernels B and C small
+// (not inlined: one copy of the 18-way switch and its libm expansions per kernel keeps kernels B and C small
 // enough for the instruction cache -- they are launched once per leapfrog between two passes of kernel A)
 __device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
   const double NINF = -INFINITY;
@@ -405,6 +405,48 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       KILL_UNLESS(!(y < 0 || y > nn))
       KILL_UNLESS(nn >= 0)
       KILL_UNLESS(p >= 0 && p <= 1)
+    } break;
+    case NUTS_D_GAMMA: {  // continuous.py:2512-2521 (alpha constant; the reference goes through scale = 1/beta)
+      const double v = a[0], al = a[1], be = 1.0 / (1.0 / a[2]);
+      const double lb = log(be), lv = log(v), m2 = al - 1.0;
+      const double t1 = (lb == NINF && al <= 0) ? (al == 0 ? 0.0 : NINF) : al * lb;   // logpow(beta, alpha)
+      const bool z2 = lv == NINF && m2 <= 0;
+      const double t2 = z2 ? (m2 == 0 ? 0.0 : NINF) : m2 * lv;                           // logpow(value, alpha - 1)
+      lp = konst + t1 - be * v + t2;
+      d[0] = -be + (z2 ? 0.0 : m2 / v);
+      d[2] = al / be - v;
+      KILL_UNLESS(v >= 0)
+      KILL_UNLESS(al > 0)
+      KILL_UNLESS(be > 0)
+    } break;
+    case NUTS_D_INVGAMMA: {  // continuous.py:2631-2639 (alpha constant)
+      const double v = a[0], al = a[1], be = a[2];
+      const double lb = log(be), lv = log(v), m2 = -al - 1.0;
+      const double t1 = (lb == NINF && al <= 0) ? (al == 0 ? 0.0 : NINF) : al * lb;
+      const double t2 = (lv == NINF && m2 <= 0) ? (m2 == 0 ? 0.0 : NINF) : m2 * lv;
+      lp = konst + t1 - be / v + t2;
+      d[0] = be / (v * v) + m2 / v;
+      d[2] = al / be - 1.0 / v;
+      KILL_UNLESS(v >= 0)
+      KILL_UNLESS(al > 0)
+      KILL_UNLESS(be > 0)
+    } break;
+    case NUTS_D_LAPLACE: {  // continuous.py:1570-1576
+      const double r = a[0] - a[1], b = a[2];
+      const double sg = r > 0 ? 1.0 : (r < 0 ? -1.0 : 0.0);
+      lp = -log(2.0 * b) - fabs(r) / b;
+      d[0] = -sg / b; d[1] = sg / b; d[2] = -1.0 / b + fabs(r) / (b * b);
+      KILL_UNLESS(b > 0)
+    } break;
+    case NUTS_D_POISSON: {  // discrete.py:581-597; factln(y) arrives as data
+      const double y = a[0], mu = a[1];
+      const double lm = log(mu);
+      const bool z = lm == NINF && y <= 0;
+      lp = (z ? (y == 0 ? 0.0 : NINF) : y * lm) - a[2] - mu;
+      d[1] = (z ? 0.0 : y / mu) - 1.0;
+      if (mu == 0 && y == 0) lp = 0.0;
+      KILL_UNLESS(!(y < 0))
+      KILL_UNLESS(mu >= 0)
     } break;
     case NUTS_D_POTENTIAL: {  // pm.Potential: the term itself is the log-density contribution
       lp = a[0];

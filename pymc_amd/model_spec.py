@@ -53,7 +53,11 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_TRUNCNORMAL,
     D_POTENTIAL,
     D_BINOMIAL,
-) = range(14)
+    D_GAMMA,
+    D_INVGAMMA,
+    D_LAPLACE,
+    D_POISSON,
+) = range(18)
 DIST_NAMES = {
     D_NORMAL: "Normal",
     D_HALFNORMAL: "HalfNormal",
@@ -69,6 +73,10 @@ DIST_NAMES = {
     D_TRUNCNORMAL: "TruncatedNormal",
     D_POTENTIAL: "Potential",
     D_BINOMIAL: "Binomial",
+    D_GAMMA: "Gamma",
+    D_INVGAMMA: "InverseGamma",
+    D_LAPLACE: "Laplace",
+    D_POISSON: "Poisson",
 }
 
 
@@ -231,6 +239,8 @@ _DEFAULT_TRANSFORM = {
     D_BETA: TR_LOGODDS,
     D_UNIFORM: TR_INTERVAL,
     D_TRUNCNORMAL: TR_INTERVAL,
+    D_GAMMA: TR_LOG,
+    D_INVGAMMA: TR_LOG,
 }
 
 
@@ -350,6 +360,26 @@ class ModelBuilder:
     def Bernoulli(self, name, p, observed):
         """`pm.Bernoulli(name, p=..., observed=...)` (pymc/distributions/discrete.py:362-374)."""
         return self._register(D_BERNOULLI, name, (p,), None, observed, TR_NONE)
+
+    def Gamma(self, name, alpha, beta, shape=None, observed=None, transform="default"):
+        """`pm.Gamma(name, alpha, beta)` (continuous.py:2400-2521); alpha constant (keeps digamma out of the gradient)."""
+        alpha = float(alpha)
+        return self._register(D_GAMMA, name, (alpha, beta), shape, observed, transform, konst=-math.lgamma(alpha))
+
+    def InverseGamma(self, name, alpha, beta, shape=None, observed=None, transform="default"):
+        """`pm.InverseGamma(name, alpha, beta)` (continuous.py:2540-2639); alpha constant."""
+        alpha = float(alpha)
+        return self._register(D_INVGAMMA, name, (alpha, beta), shape, observed, transform, konst=-math.lgamma(alpha))
+
+    def Laplace(self, name, mu=0.0, b=1.0, shape=None, observed=None):
+        return self._register(D_LAPLACE, name, (mu, b), shape, observed, TR_NONE)
+
+    def Poisson(self, name, mu, observed):
+        """`pm.Poisson(name, mu=..., observed=...)` (discrete.py:520-597); `factln(y)` depends on data only."""
+        from scipy.special import gammaln
+
+        y = np.asarray(observed, dtype="float64")
+        return self._register(D_POISSON, name, (mu, gammaln(y + 1)), None, y, TR_NONE)
 
     def Binomial(self, name, n, p, observed):
         """`pm.Binomial(name, n=..., p=..., observed=...)` (pymc/distributions/discrete.py:60-154); `binomln(n, y)`

@@ -66,6 +66,13 @@ def test_all_elementwise_distributions():
     m.BernoulliLogit("yl", a, observed=np.array([0, 1, 1, 0, 1.0]))
     m.Bernoulli("yb", b, observed=np.array([1, 0, 1.0]))
     m.Binomial("yn", n=[3, 7, 2], p=b, observed=[0, 7, 1])
+    ga = m.Gamma("ga", 2.5, 1.7, shape=3)
+    ig = m.InverseGamma("ig", 3.0, 2.0, shape=2)
+    la = m.Laplace("la", 0.3, 1.2, shape=5)
+    m.Poisson("yp", mu=ga, observed=[0, 3, 7])
+    m.Gamma("og", 2.0, ig, observed=[0.5, 1.5])
+    m.Laplace("ol", la, e, observed=np.linspace(-2, 2, 5))
+    m.InverseGamma("oi", 1.5, ga, observed=[0.4, 2.0, 9.0])
     tn = m.TruncatedNormal("tn", 0.4, 1.3, lower=-1.0, upper=2.5, shape=3)
     m.TruncatedNormal("to1", mu=a, sigma=s, lower=-2.0, upper=3.0, observed=np.linspace(-1, 2, 5))
     m.TruncatedNormal("to2", mu=tn, sigma=0.7, lower=0.2, observed=np.array([0.3, 1.0, 4.0]))

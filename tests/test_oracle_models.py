@@ -115,6 +115,36 @@ def test_bernoulli_vs_scipy():
         np.testing.assert_almost_equal(lp - st.norm.logpdf(0.0), 2 * st.bernoulli.logpmf(y, sp.expit(eta)), decimal=6)
 
 
+def test_gamma_invgamma_laplace_poisson_vs_scipy():
+    """continuous.py:2512-2521 (Gamma), :2631-2639 (InverseGamma), :1570-1576 (Laplace), discrete.py:581-597 (Poisson)
+    against SciPy to 6 decimals over the reference's test domains (Rplus values, Rplusbig parameters), with the
+    support switches (`value < 0` -> -inf) and Poisson's mu = 0, y = 0 -> 0."""
+    from oracle.ref_models import D_GAMMA, D_INVGAMMA, D_LAPLACE, D_POISSON
+    from oracle.ref_models import _dist as dist
+    from scipy.special import gammaln
+
+    v = np.array([0.01, 0.1, 0.5, 1.0, 2.5, 10.0])
+    for al in (0.5, 1.0, 2.5, 20.0):
+        for be in (0.1, 1.0, 7.0):
+            lp, _ = dist(D_GAMMA, -gammaln(al), [v, np.full_like(v, al), np.full_like(v, be)])
+            np.testing.assert_array_almost_equal(lp, st.gamma.logpdf(v, al, scale=1.0 / be), decimal=6)
+            lp, _ = dist(D_INVGAMMA, -gammaln(al), [v, np.full_like(v, al), np.full_like(v, be)])
+            np.testing.assert_array_almost_equal(lp, st.invgamma.logpdf(v, al, scale=be), decimal=6)
+    lp, _ = dist(D_GAMMA, -gammaln(2.0), [np.array([-1.0]), np.array([2.0]), np.array([1.0])])
+    assert lp[0] == -np.inf
+    x = np.array([-3.0, -0.2, 0.0, 0.7, 4.0])
+    for mu in (-1.0, 0.0, 2.0):
+        for b in (0.2, 1.0, 5.0):
+            lp, _ = dist(D_LAPLACE, 0.0, [x, np.full_like(x, mu), np.full_like(x, b)])
+            np.testing.assert_array_almost_equal(lp, st.laplace.logpdf(x, mu, b), decimal=6)
+    y = np.array([0.0, 1.0, 2.0, 7.0, 30.0])
+    for mu in (0.0, 0.3, 4.0, 25.0):
+        lp, _ = dist(D_POISSON, 0.0, [y, np.full_like(y, mu), gammaln(y + 1)])
+        ref = st.poisson.logpmf(y, mu)
+        np.testing.assert_array_almost_equal(lp, ref, decimal=6)
+    assert dist(D_POISSON, 0.0, [np.array([0.0]), np.array([0.0]), np.array([0.0])])[0][0] == 0.0
+
+
 def test_binomial_vs_scipy_and_logpow_edges():
     """Binomial logpmf (discrete.py:141-154) against SciPy over the domain the reference checks
     (tests/distributions/test_discrete.py: n in Nat, p in Unit) incl. p = 0 / p = 1 where `logpow`
