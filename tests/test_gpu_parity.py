@@ -574,6 +574,39 @@ def test_nuts_tuning_freezes_the_step_size():
     res["step"].close()
 
 
+@pytest.mark.parametrize(
+    "kind,kw",
+    [
+        ("nuts", dict(adapt_step_size=False, step_scale=0.1)),
+        ("nuts", dict(Emax=5.0, early_max_treedepth=3, max_treedepth=5)),
+        ("nuts", dict(gamma=0.1, k=0.6, t0=5, target_accept=0.9)),
+        ("hmc", dict(path_length=1.0, max_steps=7)),
+        ("hmc", dict(path_length=3.0, adapt_step_size=False, step_scale=0.2)),
+    ],
+)
+def test_step_options_mean_the_same_on_the_device(kind, kw):
+    """The constructor options of `BaseHMC` / `NUTS` / `HamiltonianMC` (base_hmc.py:82-103, nuts.py:132-147,
+    hmc.py:70-77) cross the C ABI in `nuts_chain_config`; with each of them the device chain follows the oracle, which
+    for exactly these option sets is bitwise the reference (tests/test_golden.py::test_oracle_equals_reference_under_step_options)."""
+    from pymc_amd.sampling import initial_point, sample_chain
+    from pymc_amd.step import NUTS, HamiltonianMC
+
+    spec = models.eight_schools()
+    cls_o = ref_sampler.RefNUTS if kind == "nuts" else ref_sampler.RefHMC
+    orc = cls_o(ref_models.SpecLogpGrad(spec), spec.n, rng=31, **kw)
+    d_orc, s_orc = ref_sampler.run_chain(orc, np.zeros(spec.n), np.random.default_rng(17), 35, 15)
+    step = (NUTS if kind == "nuts" else HamiltonianMC)(model=spec, rng=31, device=0, **kw)
+    d_dev, s_dev = sample_chain(step, dict(initial_point(spec)), np.random.default_rng(17), 35, 15)
+    ints = INT_KEYS + ("divergences",) if kind == "nuts" else ("n_steps", "accepted", "diverging", "divergences")
+    for k in ints:
+        assert [int(s[k]) for s in s_dev] == [int(s[k]) for s in s_orc], k
+    np.testing.assert_allclose(d_dev[:10], d_orc[:10], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose([s["step_size"] for s in s_dev[:10]], [s["step_size"] for s in s_orc[:10]], rtol=1e-8)
+    assert step.rng.bit_generator.state == orc.rng.bit_generator.state
+    assert step.potential.rng.bit_generator.state == orc.potential.rng.bit_generator.state
+    step.close()
+
+
 def test_same_seed_bitwise_reproducible():
     """tests/sampling/test_mcmc.py:80-109: same seed => bitwise-equal draws."""
     from pymc_amd.sampling import sample
