@@ -357,7 +357,13 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     m->rows_occ = env_int("NUTS_ROWS_OCC", 4);
     // 16 waves per CU are resident at a time (4 per SIMD at 113 VGPRs); two such sets of shorter waves balance the
     // tail better than one (measured with the folded control: 61.3 us per pass vs 63.0 us at 16, 62.8 at 48, 65.8 at 64)
-    const int wpc = std::max(1, env_int("NUTS_ROWS_WAVES_PER_CU", 32));
+    // -- for passes long enough to give every wave a few spans (C2-L: 4.8 per wave); shorter, cache-resident passes are
+    // better off with one set (R = 800 rows per group: 23.5 us at 16 vs 26.2 us at 32)
+    int wpc = env_int("NUTS_ROWS_WAVES_PER_CU", 0);
+    if (wpc <= 0) {
+      const int64_t spans = (s->rows_N + (int64_t)WAVE * m->rows_rpl - 1) / ((int64_t)WAVE * m->rows_rpl);
+      wpc = spans >= (int64_t)cus * 32 * 4 ? 32 : 16;
+    }
     const int SPAN = WAVE * m->rows_rpl;
     lg.N = s->rows_N; lg.D = D; lg.G = s->rows_G;
     lg.Npad = (lg.N + SPAN - 1) / SPAN * SPAN;
