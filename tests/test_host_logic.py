@@ -301,6 +301,46 @@ def test_quad_potential_factory_agrees_with_the_reference_module():
     assert str(e_ref.value) == str(e_mine.value)
 
 
+def test_host_adapted_potentials_agree_with_the_reference_classes():
+    """`QuadPotentialFullAdapt` (quadpotential.py:748-852) and `QuadPotentialDiagAdaptExp` (:486-579) keep their
+    estimators on the host in this package as in the reference; fed the same (sample, gradient) stream, the matrices
+    they push to the device are bitwise those the reference's own classes (loaded from /root/reference) end up with."""
+    import os
+    import sys
+    import warnings
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import refrun
+
+    if not refrun.available():
+        pytest.skip("needs the reference checkout under /root/reference")
+    import pymc_amd.quadpotential as mine
+
+    qp = refrun.load().quadpotential
+    n = 4
+    rng = np.random.default_rng(5)
+    xs, gs = rng.normal(size=(260, n)) * [1.0, 0.3, 2.0, 0.7], rng.normal(size=(260, n))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = qp.QuadPotentialFullAdapt(n, np.zeros(n), np.eye(n), 10, adaptation_window=50, rng=1)
+        m = mine.QuadPotentialFullAdapt(n, np.zeros(n), np.eye(n), 10, adaptation_window=50, rng=1)
+    for i, x in enumerate(xs):
+        r.update(x, None, True)
+        m.update(x, None, True)
+        if i in (0, 49, 50, 51, 150, 259):
+            assert np.array_equal(r._cov, m._cov), i
+            assert np.array_equal(r._chol, m._chol), i
+    assert r.adaptation_window == m.adaptation_window and r._previous_update == m._previous_update
+    r2 = qp.QuadPotentialDiagAdaptExp(n, np.zeros(n), alpha=0.05, use_grads=True, stop_adaptation=200, rng=1)
+    m2 = mine.QuadPotentialDiagAdaptExp(n, np.zeros(n), alpha=0.05, use_grads=True, stop_adaptation=200, rng=1)
+    for i, (x, g) in enumerate(zip(xs, gs)):
+        r2.update(x, g, True)
+        m2._host_update(x, g, True)
+        if i in (0, 1, 60, 199, 200, 259):
+            assert np.array_equal(r2._var, m2._hvar), i
+            assert np.array_equal(r2._inv_stds, m2._hinv_stds), i
+
+
 def test_rng_plumbing():
     """util.py:519-594: state round trip keeps the spawn counter; copy semantics of get_random_generator."""
     g = np.random.default_rng(7)
