@@ -92,6 +92,21 @@ def get_random_generator(seed=None, copy_: bool = True) -> np.random.Generator:
 
 class _DeviceHMCBase:
     default_blocked = True
+    default_tune_steps = None          # compound.py:129-130
+    vars: list = []                    # compound.py:126-127 (set per instance)
+    _state_class = BaseHMCState        # base_hmc.py:80
+
+    @classmethod
+    def _competence(cls, vars, have_grad):   # compound.py:216-227: what `assign_step_methods` calls
+        vars = np.atleast_1d(vars)
+        have_grad = np.atleast_1d(have_grad)
+        competences = []
+        for var, has_grad in zip(vars, have_grad):
+            try:
+                competences.append(cls.competence(var, has_grad))
+            except TypeError:
+                competences.append(cls.competence(var))
+        return competences
 
     def __init__(
         self,

@@ -260,6 +260,13 @@ def test_step_class_surface_agrees_with_the_reference_classes():
             assert int(theirs.competence(v, grad)) == int(mine.competence(np.zeros(1, dtype=dtype), grad))
     s = {"divergences": 2, "step_size": 0.1, "tree_size": 7.0, "x": 1}
     assert ref.NUTS._make_progressbar_update_functions()[0](dict(s)) == NUTS._make_progressbar_update_functions()[0](dict(s))
+    # every public name of the reference's step classes exists here (the two exceptions are how the reference splits
+    # its own implementation: the abstract-base registry and the integrator hook the device replaces wholesale)
+    pub = lambda c: {a for a in dir(c) if not a.startswith("__")}  # noqa: E731
+    for mine, theirs in ((NUTS, ref.NUTS), (HamiltonianMC, ref.HamiltonianMC)):
+        assert pub(theirs) - pub(mine) <= {"_abc_impl", "_hamiltonian_step"}
+        vs = [types.SimpleNamespace(dtype="float64"), types.SimpleNamespace(dtype="int64")]
+        assert [int(c) for c in theirs._competence(vs, [True, True])] == [int(c) for c in mine._competence(vs, [True, True])]
 
 
 def test_quad_potential_factory_agrees_with_the_reference_module():
