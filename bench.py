@@ -68,7 +68,7 @@ def cpu_baseline(spec, q, step_size, inv_mass, n_leap, ess_per_leapfrog):
         ctx = threadpoolctl.threadpool_limits(1)
     except Exception:  # pragma: no cover
         ctx = None
-    f = c_logit.CHierLogit(spec)
+    f = c_logit.CHierLogit(spec, so_path=c_logit.build_native())   # compiled for the box it is timed on
     pot = ref_sampler.DiagPotential(inv_mass)
     integ = ref_sampler.Leapfrog(pot, f)
     rng = np.random.default_rng(0)
@@ -85,7 +85,7 @@ def cpu_baseline(spec, q, step_size, inv_mass, n_leap, ess_per_leapfrog):
         "cores": 1,
         "kind": "port",
         "host_cores_available": os.cpu_count(),
-        "sample": f"{n_leap} reference-order leapfrog steps (oracle integrator + single-threaded gcc -O3 fused logp/grad) "
+        "sample": f"{n_leap} reference-order leapfrog steps (oracle integrator + single-threaded gcc -O3 -march=native fused logp/grad, compiled on this box) "
         f"of the same workload in {dt:.1f} s; ESS/s = leapfrog/s x the GPU run's measured ESS per leapfrog ({ess_per_leapfrog:.4g})",
     }
 

@@ -12,14 +12,32 @@ import os
 
 import numpy as np
 
-_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liboracle.so")
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "_build", "liboracle.so")
+
+
+def build_native() -> str:
+    """Compile the restatement for THIS host (`gcc -O3 -march=native`, what PyTensor's C linker would do where the
+    sampler runs) -- used by `bench.py`'s cpu_baseline leg on the GPU box.  The portable build
+    (`__graft_entry__.build_oracle`, x86-64-v3) stays what tests and smoke() load.  Falls back to it if gcc fails."""
+    import subprocess
+
+    out = os.path.join(_DIR, "_build", "liboracle_native.so")
+    src = os.path.join(_DIR, "csrc", "oracle_logit.c")
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", src, "-o", out, "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return out
+    except Exception:
+        return _SO
 
 
 class CHierLogit:
     """``q -> (logp, grad)`` for a ModelSpec built by `pymc_amd.models.hier_logit`."""
 
-    def __init__(self, spec):
-        lib = C.CDLL(_SO)
+    def __init__(self, spec, so_path=None):
+        lib = C.CDLL(so_path or _SO)
         self._fn = lib.oracle_hier_logit
         self._fn.restype = C.c_double
         self._fn.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
