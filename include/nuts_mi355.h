@@ -89,6 +89,9 @@ typedef struct {
   int64_t offset, size; /* into data_pool, in doubles */
 } nuts_data_ref;
 
+/* nuts_model_spec.rows_opts */
+enum { NUTS_ROWS_NO_GROUP_ALIGNED = 1 };
+
 typedef struct {
   int32_t n_vars, n_factors, n_data, pad;
   const nuts_var *vars;
@@ -104,7 +107,7 @@ typedef struct {
   const int8_t *rows_y;    /* [N] */
   const int32_t *rows_gid; /* [N] */
   int32_t rows_mu, rows_sigma, rows_z; /* var ids */
-  int32_t pad2;
+  int32_t rows_opts; /* NUTS_ROWS_* flags */
   /* dense node 2: x ~ MvNormal(mu, cov): caller supplies precision = cov^-1 and
      logdet = sum(log(diag(chol(cov)))) (pymc/distributions/multivariate.py:158-185).
      mvn_k == 0 disables. */
@@ -139,6 +142,11 @@ int nuts_model_time_logp_grad(nuts_model *m, const double *q, int reps, double *
 int nuts_model_debug_ticks(nuts_model *m, int64_t *out /* [64] */);
 /* Algorithmic HBM bytes of one model pass (SURVEY.md section 8d B_model). */
 int64_t nuts_model_algorithmic_bytes(const nuts_model *m);
+/* Named properties of the compiled model (what `compile` decided, cf. pymc/pytensorf.py:924-1008):
+ *   "rows_group_aligned"  1 when the hierarchical-logit rows use the group-aligned pass (one launch per leapfrog;
+ *                         diagonal mass matrices only -- a chain with a dense one needs NUTS_ROWS_NO_GROUP_ALIGNED),
+ *   "rows_waves", "lean", "single_workgroup_ok". */
+int nuts_model_get_scalar(const nuts_model *m, const char *name, double *out);
 
 /* ---- chain: replaces BaseHMC/NUTS + potential + step adaptation ------------- */
 /* NUTS_POT_FULL covers QuadPotentialFull and QuadPotentialFullInv (quadpotential.py:633-725): the caller passes

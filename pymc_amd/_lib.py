@@ -76,7 +76,7 @@ class ModelSpecC(C.Structure):
         ("rows_mu", C.c_int32),
         ("rows_sigma", C.c_int32),
         ("rows_z", C.c_int32),
-        ("pad2", C.c_int32),
+        ("rows_opts", C.c_int32),
         ("mvn_var", C.c_int32),
         ("mvn_k", C.c_int32),
         ("mvn_mu", C.POINTER(C.c_double)),
@@ -169,6 +169,7 @@ SYMBOLS = {
     "nuts_model_time_logp_grad": (C.c_int, [_VP, _PD, C.c_int, _PD, _PD]),
     "nuts_model_algorithmic_bytes": (C.c_int64, [_VP]),
     "nuts_model_debug_ticks": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    "nuts_model_get_scalar": (C.c_int, [_VP, C.c_char_p, _PD]),
     "nuts_chain_config_default": (None, [C.POINTER(ChainConfig)]),
     "nuts_chain_create": (_VP, [_VP, C.POINTER(ChainConfig)]),
     "nuts_chain_destroy": (None, [_VP]),

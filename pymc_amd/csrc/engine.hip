@@ -78,6 +78,8 @@ struct nuts_model {
   int rows_grid = 0, mvn_grid = 0, ept = 1;
   int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
   int vector_one_xcd = 0;
+  int ga_struct_ok = 0;        // the spec is exactly what the group-aligned row pass evaluates in closed form (compile_spec)
+  int ga_par = 0;              // parity of the last group-aligned launch (its block partials / local parts are double-buffered)
   int explicit_pre = 0;        // the position must be materialised before the dense pass (MvNormal node)
   int64_t alg_bytes = 0;
   // profiling of the dominant kernel
@@ -107,6 +109,7 @@ extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
 
 static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int d) {
   const ModelDev& md = m->md;
+  if (md.lg.ga) return;   // group-aligned row pass: the O(n) work rides in the row pass itself (rows_ga_kernel.h)
   // small models: 8x oversubscribed launch, one XCD does the work (see k_vector); large ones use the whole chip
   const dim3 grid(m->vector_one_xcd ? md.nblk * 8 : md.nblk);
   switch (m->ept) {
@@ -124,7 +127,21 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
   if (!md.has_logit && !md.has_mvn) return;
   const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
-  if (md.has_logit) {
+  if (md.has_logit && md.lg.ga) {
+    const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
+    const int par = (m->ga_par ^= 1);
+    const dim3 grid(m->rows_grid + (fold ? 1 : 0)), block(WAVE * md.lg.ga_w);
+#define GA_LAUNCH(DD, RR) hipLaunchKernelGGL((k_rows_ga<DD, RR>), grid, block, 0, m->stream, md, A, io, j, rev, fold, par, d, Emax, max_depth, st)
+#define GA_BY_D(RR)                      \
+    switch (md.lg.D) {                   \
+      case 8: GA_LAUNCH(8, RR); break;   \
+      case 4: GA_LAUNCH(4, RR); break;   \
+      default: GA_LAUNCH(2, RR); break;  \
+    }
+    if (m->rows_rpl == 2) { GA_BY_D(2) } else { GA_BY_D(4) }
+#undef GA_BY_D
+#undef GA_LAUNCH
+  } else if (md.has_logit) {
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
     const dim3 grid(m->rows_grid + (fold ? 1 : 0)), block(ROWS_BLOCK);
 #define ROWS_LAUNCH(DD, RR, OO) \
@@ -164,7 +181,7 @@ static void model_enqueue_plain(nuts_model* m, const double* q_dev, double* g_de
   io.mode = MODE_PLAIN; io.q = q_dev; io.grad = g_dev; io.logp = lp_dev; io.lean = m->md.lean_ok;
   launch_dense(m, A, io, 0);
   launch_vector(m, A, io, 0, 0);
-  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
+  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0, m->ga_par);
   else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
 }
 
@@ -271,8 +288,8 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size() / 2;
   md.orphans = m->keep(dev_upload(orphans.data(), orphans.size()));
   md.deferred_g = m->keep(dev_upload(deferred.data(), deferred.size()));
-  md.def_loc = m->keep(dev_alloc<double>(4 * (size_t)std::max(1, md.n_deferred)));
-  hipMemset(md.def_loc, 0, 4 * (size_t)std::max(1, md.n_deferred) * sizeof(double));
+  md.def_loc = m->keep(dev_alloc<double>(2 * 4 * (size_t)MAX_DEFERRED));
+  hipMemset(md.def_loc, 0, 2 * 4 * (size_t)MAX_DEFERRED * sizeof(double));
   // lean control path (kernels.h), no broadcast terms and either
   // (a) the only deferred elements are the logit node's mu / sigma, or
   md.lean_ok = 0;
@@ -284,6 +301,24 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       md.lg.def_mu = vars[s->rows_mu].def_base; md.lg.def_sigma = vars[s->rows_sigma].def_base;
     } else if (s->rows_N <= 0 && s->mvn_k > 0 && md.n_deferred == 0) {
       md.lean_ok = 1;
+    }
+  }
+  // group-aligned row pass (rows_ga_kernel.h): evaluates mu ~ Normal, sigma ~ HalfNormal (log-transformed or not), z ~ Normal with
+  // constant parameters in closed form and nothing else -- the model must be exactly that
+  m->ga_struct_ok = 0;
+  if (md.lean_ok && s->rows_N > 0 && nv == 3 && orphans.empty()) {
+    const int km = s->rows_mu, ks = s->rows_sigma, kz = s->rows_z;
+    auto only_prior = [&](int k, int dist) {
+      return per_var[k].size() == 1 && per_var[k][0].fast == 2 && per_var[k][0].owner && per_var[k][0].arg == 0 && per_var[k][0].dist == dist;
+    };
+    if (vars[kz].normal_prior && only_prior(km, NUTS_D_NORMAL) && only_prior(ks, NUTS_D_HALFNORMAL) && vars[km].transform == NUTS_TR_NONE &&
+        (vars[ks].transform == NUTS_TR_LOG || vars[ks].transform == NUTS_TR_NONE)) {
+      m->ga_struct_ok = 1;
+      md.lg.z_np_mu = vars[kz].np_mu; md.lg.z_np_inv_var = vars[kz].np_inv_var; md.lg.z_np_lognorm = vars[kz].np_lognorm;
+      const Contrib& cm = per_var[km][0];
+      md.lg.mu_c[0] = cm.p[1]; md.lg.mu_c[1] = cm.p[2]; md.lg.mu_c[2] = cm.p[3];
+      const Contrib& cs = per_var[ks][0];
+      md.lg.sg_c[0] = cs.p[2]; md.lg.sg_c[1] = cs.p[3];
     }
   }
   // pack the interpreter's tables into one blob (copied into LDS by kernels B and C)
@@ -375,6 +410,59 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     }
     lg.off_mu = vmu.offset; lg.off_sigma = vsg.offset; lg.off_z = vz.offset; lg.sigma_tr = vsg.transform;
     lg.var_mu = s->rows_mu; lg.var_sigma = s->rows_sigma; lg.var_z = s->rows_z;
+    std::vector<int8_t> yy;
+    std::vector<int64_t> gptr(lg.G + 1, 0);
+    const int32_t* gid = s->rows_gid;
+    for (int64_t i = 0; i < lg.N; ++i) {
+      if (i > 0 && gid[i] < gid[i - 1]) { g_err = "logit rows: group ids must be sorted"; nuts_model_destroy(m); return nullptr; }
+      if (gid[i] < 0 || gid[i] >= lg.G) { g_err = "logit rows: group id out of range"; nuts_model_destroy(m); return nullptr; }
+      gptr[gid[i] + 1] = i + 1;
+    }
+    for (int g = 0; g < lg.G; ++g) gptr[g + 1] = std::max(gptr[g + 1], gptr[g]);  // empty groups
+    lg.gptr = m->keep(dev_upload(gptr.data(), gptr.size()));
+    // ---- group-aligned row pass (rows_ga_kernel.h)?  NUTS_ROWS_GA: 0 never, 1 when the shape suits it (default), 2 whenever
+    // the model structure allows it (tests: ragged / empty / tiny groups through the same kernel) ----
+    {
+      const int want = (s->rows_opts & NUTS_ROWS_NO_GROUP_ALIGNED) ? 0 : env_int("NUTS_ROWS_GA", 1);
+      std::vector<int32_t> tile0(lg.G + 1, 0);
+      int64_t maxT = 0;
+      for (int g = 0; g < lg.G; ++g) {
+        const int64_t T = (gptr[g + 1] - gptr[g] + SPAN - 1) / SPAN;
+        maxT = std::max(maxT, T);
+        tile0[g + 1] = tile0[g] + (int32_t)T;
+      }
+      const int64_t n_tiles = tile0[lg.G];
+      int W = std::min(GA_MAXW, (16 * cus) / std::max(lg.G, 1));   // all G workgroups resident at once (16 waves per CU)
+      const double meanT = (double)n_tiles / std::max(lg.G, 1);
+      bool use = false;
+      if (want >= 2) { use = m->ga_struct_ok && m->ept == 1; W = std::max(1, std::min(GA_MAXW, env_int("NUTS_ROWS_GA_W", 3))); }
+      else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && W >= 1 && lg.G >= 2 * cus && meanT >= 3.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
+      if (use && n_tiles * (int64_t)SPAN < ((int64_t)1 << 31)) {
+        lg.ga = 1; lg.ga_w = W;
+        lg.ga_bsz = (lg.G + 31) / 32;
+        lg.ga_nblk = (lg.G + lg.ga_bsz - 1) / lg.ga_bsz;
+        lg.Npad = n_tiles * SPAN; lg.n_spans = n_tiles;
+        std::vector<double> xt((size_t)D * std::max<int64_t>(lg.Npad, 1), 0.0);
+        yy.assign(std::max<int64_t>(lg.Npad, 1), 0);
+        for (int g = 0; g < lg.G; ++g)
+          for (int64_t i = gptr[g]; i < gptr[g + 1]; ++i) {
+            const int64_t r = i - gptr[g], sp = tile0[g] + r / SPAN, rr = r % SPAN;
+            for (int d = 0; d < D; ++d) xt[((size_t)sp * D + d) * SPAN + rr] = s->rows_X[i * D + d];
+            yy[(size_t)sp * SPAN + rr] = s->rows_y[i];
+          }
+        lg.Xt = m->keep(dev_upload(xt.data(), xt.size()));
+        lg.y = m->keep(dev_upload(yy.data(), yy.size()));
+        lg.ga_tile0 = m->keep(dev_upload(tile0.data(), tile0.size()));
+        lg.ga_part = m->keep(dev_alloc<double>((size_t)lg.G * PART_STRIDE));
+        lg.ga_bpart = m->keep(dev_alloc<double>(2 * (size_t)lg.ga_nblk * PART_STRIDE));
+        lg.ga_ticket = m->keep(dev_alloc<unsigned>(lg.ga_nblk));
+        if (lg.ga_part) hipMemset(lg.ga_part, 0, (size_t)lg.G * PART_STRIDE * sizeof(double));
+        if (lg.ga_bpart) hipMemset(lg.ga_bpart, 0, 2 * (size_t)lg.ga_nblk * PART_STRIDE * sizeof(double));
+        if (lg.ga_ticket) hipMemset(lg.ga_ticket, 0, lg.ga_nblk * sizeof(unsigned));
+        m->rows_grid = lg.G;
+      }
+    }
+    if (!lg.ga) {
     // HBM layout: X in span tiles [n_spans][D][SPAN] (one contiguous block per wave-iteration, each column a
     // coalesced 16 B/lane load), y int8, group structure as G+1 row pointers (rows are sorted by group)
     {
@@ -385,17 +473,8 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       }
       lg.Xt = m->keep(dev_upload(xt.data(), xt.size()));
     }
-    std::vector<int8_t> yy(lg.Npad, 0);
-    std::vector<int64_t> gptr(lg.G + 1, 0);
-    const int32_t* gid = s->rows_gid;
-    for (int64_t i = 0; i < lg.N; ++i) {
-      yy[i] = s->rows_y[i];
-      if (i > 0 && gid[i] < gid[i - 1]) { g_err = "logit rows: group ids must be sorted"; nuts_model_destroy(m); return nullptr; }
-      if (gid[i] < 0 || gid[i] >= lg.G) { g_err = "logit rows: group id out of range"; nuts_model_destroy(m); return nullptr; }
-      gptr[gid[i] + 1] = i + 1;
-    }
-    for (int g = 0; g < lg.G; ++g) gptr[g + 1] = std::max(gptr[g + 1], gptr[g]);  // empty groups
-    lg.gptr = m->keep(dev_upload(gptr.data(), gptr.size()));
+    yy.assign(lg.Npad, 0);
+    for (int64_t i = 0; i < lg.N; ++i) yy[i] = s->rows_y[i];
     lg.y = m->keep(dev_upload(yy.data(), yy.size()));
     const int waves_per_block = ROWS_BLOCK / WAVE;
     int64_t want_waves = std::min<int64_t>((int64_t)cus * wpc, lg.n_spans);
@@ -467,6 +546,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     lg.mixed_part = m->keep(dev_alloc<double>((size_t)lg.n_mixed_seg * D));
     lg.wave_lp = m->keep(dev_alloc<double>((size_t)lg.n_waves + lg.n_mixed));
     m->rows_grid = nb_main + (lg.n_mixed + waves_per_block - 1) / waves_per_block;
+    }   // span-partitioned pass
     m->alg_bytes += lg.N * (8 * (int64_t)D + 1 + 4);  // X row + y + group id per row
   }
   if (s->mvn_k > 0) {
@@ -520,6 +600,16 @@ extern "C" int nuts_model_debug_ticks(nuts_model* m, int64_t* out) {
 }
 
 extern "C" int32_t nuts_model_ndim(const nuts_model* m) { return m ? m->md.n : -1; }
+extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, double* out) {
+  if (!m || !name || !out) return NUTS_E_ARG;
+  const std::string k(name);
+  if (k == "rows_group_aligned") *out = m->md.lg.ga;
+  else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
+  else if (k == "lean") *out = m->md.lean_ok;
+  else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn) ? 1.0 : 0.0;
+  else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
+  return NUTS_OK;
+}
 extern "C" int64_t nuts_model_algorithmic_bytes(const nuts_model* m) { return m ? m->alg_bytes : 0; }
 
 extern "C" int nuts_model_logp_grad(nuts_model* m, const double* q, double* logp, double* grad) {
@@ -627,6 +717,7 @@ struct nuts_chain {
   double fg_count = 0, bg_count = 0;
   std::vector<double> initial_mean, initial_diag;
   int64_t n_samples = 0, adaptation_window = 101;
+  bool window_switched = false;   // the last potential update swapped foreground <- background (quadpotential.py:350-353)
   // step
   DualAvg da{};
   bool tune = true;
@@ -675,6 +766,9 @@ extern "C" void nuts_chain_config_default(nuts_chain_config* c) {
 
 static int potential_reset(nuts_chain* c) {  // quadpotential.py:297-306
   const int n = c->n;
+  // the blocking copies below run on the null stream; the model stream is non-blocking, so a Welford update queued by the
+  // last tuning draw has to be waited for explicitly
+  HIPCHK(hipStreamSynchronize(c->m->stream));
   std::vector<double> st(n), inv(n), m2(n);
   const double w = c->cfg.initial_weight;
   for (int i = 0; i < n; ++i) { st[i] = std::sqrt(c->initial_diag[i]); inv[i] = 1.0 / st[i]; m2[i] = c->initial_diag[i] * w; }
@@ -700,6 +794,10 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   }
   if (cfg->potential == NUTS_POT_FULL && (!cfg->dense_cov || !cfg->dense_rand)) { g_err = "dense potential needs dense_cov and dense_rand"; return nullptr; }
   if (cfg->max_treedepth < 1 || cfg->max_treedepth > MAX_LEVELS - 1) { g_err = "max_treedepth out of range (1..11)"; return nullptr; }
+  if (cfg->potential == NUTS_POT_FULL && m->md.lg.ga) {
+    g_err = "a dense mass matrix needs the span-partitioned row pass: create the model with NUTS_ROWS_NO_GROUP_ALIGNED";
+    return nullptr;
+  }
   auto* c = new nuts_chain();
   c->m = m; c->cfg = *cfg; c->n = m->md.n;
   const int n = c->n;
@@ -731,6 +829,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->wa_mean = c->keep(dev_alloc<double>(n)); c->wa_m2 = c->keep(dev_alloc<double>(n));
   c->wb_mean = c->keep(dev_alloc<double>(n)); c->wb_m2 = c->keep(dev_alloc<double>(n));
   A.var = c->var; A.inv_stds = c->inv_stds;
+  A.ga_ticket = m->md.lg.ga ? m->md.lg.ga_ticket : nullptr; A.ga_nticket = m->md.lg.ga ? m->md.lg.ga_nblk : 0;
   if (c->dense) {
     c->dense_C = c->keep(dev_upload(cfg->dense_cov, (size_t)n * n));
     c->dense_W = c->keep(dev_upload(cfg->dense_rand, (size_t)n * n));
@@ -739,7 +838,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->n_uni_cap = (1 << maxd) + 2 * maxd + 16;
   c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + 2 * (size_t)c->n_uni_cap));
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
-  c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n));
+  c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n + 2));
   c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0;
   c->spec_max = env_int("NUTS_SPEC_MAX", 3);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
@@ -800,6 +899,7 @@ static int check_mass_matrix(nuts_chain* c) {  // quadpotential.py:357-393 raise
 }
 
 static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotential.py:335-355
+  c->window_switched = false;
   if (c->cfg.potential != NUTS_POT_DIAG_ADAPT || !c->tune) return NUTS_OK;
   hipStream_t s = c->m->stream;
   int flags = 0;
@@ -815,6 +915,7 @@ static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotent
   }
   if (c->n_samples > 0 && c->n_samples % c->adaptation_window == 0) {
     c->fg_is_a = !c->fg_is_a;  // foreground <- background
+    c->window_switched = true;
     c->fg_count = c->bg_count;
     HIPCHK(hipMemsetAsync(fm, 0, c->n * sizeof(double), s));  // old foreground becomes the fresh background
     HIPCHK(hipMemsetAsync(f2, 0, c->n * sizeof(double), s));
@@ -947,7 +1048,7 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
     io.pre_next = last ? 0 : 1;
     launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
     launch_vector(m, A, io, j, d);
-    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
     c->leapfrogs++;
     return;
   }
@@ -961,13 +1062,13 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
     // launch of its own
     launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
     launch_vector(m, A, io, j, d);
-    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
     c->leapfrogs++;
     return;
   }
   launch_dense(m, A, io, j);
   launch_vector(m, A, io, j, d);
-  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
   else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
   if (c->dense) {   // v' = C p', then the tree work on the stored (p', v')
     hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, (const double*)nullptr,
@@ -1298,9 +1399,14 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   step_size = (0.85 + (1.15 - 0.85) * uniforms[0]) * step_size;  // `unif` step_rand, hmc.py:35-36
   int n_steps = std::max(1, (int)(path_length / step_size));
   n_steps = std::min<int>(max_steps, n_steps);
-  if (n_steps >= A.S) { g_err = "n_steps exceeds the trajectory arena (2^max_treedepth slots)"; return NUTS_E_ARG; }
+  // a fixed-length trajectory only ever needs its previous state: the arena is used as a ring (slot = index mod S), and what
+  // the end of the transition needs from the START state is kept aside before the ring can wrap over slot 0
   int rc = draw_begin(c, q0, normals, uniforms, 0, step_size, 1, false, +1);
   if (rc) return rc;
+  double* const start_keep = c->out_dev2;   // [0, n): gradient at the start state ; [n]: E, [n + 1]: logp of the start state
+  HIPCHK(hipMemcpyAsync(start_keep, A.G, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(start_keep + n, A.E, sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(start_keep + n + 1, A.LOGP, sizeof(double), hipMemcpyDeviceToDevice, s));
   const Geometry gm{+1, 0, 0, 0, step_size};
   for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1, 0, n_steps);
   std::vector<double> Eh(2), lph(2);
@@ -1309,9 +1415,9 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   HIPCHK(hipMemcpyAsync(c->out_host + n, A.G + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost, s));
   rc = sync_status(c);
   if (rc) return rc;
-  HIPCHK(hipMemcpy(&Eh[0], A.E, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&Eh[0], start_keep + n, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&Eh[1], A.E + last, sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&lph[0], A.LOGP, sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&lph[0], start_keep + n + 1, sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&lph[1], A.LOGP + last, sizeof(double), hipMemcpyDeviceToHost));
   if (c->st_host->bad_energy) {
     rc = check_mass_matrix(c);
@@ -1329,7 +1435,8 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   const auto t1 = clk::now();
   const std::clock_t c1 = std::clock();
   c->da.update(accept, adapt);
-  const double* xsel = accepted ? (A.Q + (int64_t)last * n) : A.Q;
+  // (a rejected transition stays at q0, which is still in the staging buffer of this draw)
+  const double* xsel = accepted ? (A.Q + (int64_t)last * n) : c->stage_dev;
   rc = potential_update(c, xsel);
   if (rc) return rc;
   if (!c->tune) c->divergences += div;
@@ -1339,7 +1446,7 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
     if (grad_out) std::memcpy(grad_out, c->out_host + n, n * sizeof(double));
   } else {
     std::memcpy(q_out, q0, n * sizeof(double));
-    if (grad_out) HIPCHK(hipMemcpy(grad_out, A.G, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (grad_out) HIPCHK(hipMemcpy(grad_out, start_keep, n * sizeof(double), hipMemcpyDeviceToHost));
   }
   HIPCHK(hipStreamSynchronize(s));
   std::memset(stats, 0, sizeof(*stats));
@@ -1427,6 +1534,7 @@ extern "C" int nuts_chain_get_scalar(nuts_chain* c, const char* name, double* ou
   else if (k == "step_size") *out = c->step_size;
   else if (k == "leapfrogs") *out = (double)c->leapfrogs;
   else if (k == "single_launch") *out = c->small ? 1.0 : 0.0;
+  else if (k == "window_switched") *out = c->window_switched ? 1.0 : 0.0;
   else if (k == "t_begin") *out = c->t_begin;
   else if (k == "t_loop") *out = c->t_loop;
   else if (k == "t_wait") *out = c->t_wait;
@@ -1481,7 +1589,7 @@ extern "C" int nuts_chain_set_diag(nuts_chain* c, const double* var, const doubl
 extern "C" int nuts_chain_welford_export(nuts_chain* c, double* buf) {
   if (!c || !buf) return NUTS_E_ARG;
   const size_t n = c->n;
-  hipStream_t s = c->m->stream;
+  hipStream_t s = c->m->stream;   // (every copy below is queued on the model stream, behind a pending k_potential_update)
   const double* fm = c->fg_is_a ? c->wa_mean : c->wb_mean; const double* f2 = c->fg_is_a ? c->wa_m2 : c->wb_m2;
   const double* bm = c->fg_is_a ? c->wb_mean : c->wa_mean; const double* b2 = c->fg_is_a ? c->wb_m2 : c->wa_m2;
   HIPCHK(hipMemcpyAsync(buf, &c->fg_count, sizeof(double), hipMemcpyHostToDevice, s));

@@ -77,6 +77,8 @@ struct ArenaDev {
   const double* uniforms;   // pre-drawn `step.rng.random()` values
   const double* log_uniforms;  // their logarithms, taken on the host (the tree compares log(u), nuts.py:371,466);
                                // nullptr (single-launch path): the control code takes log(u) itself
+  unsigned* ga_ticket;         // arrival counters of the group-aligned row pass (rows_ga_kernel.h), reset at the end of a draw
+  int ga_nticket;
 };
 
 // Lives in pinned, device-mapped host memory.  `word[seq % ST_SLOTS]` = (sequence number << 32) | ST_* flags is written with ONE
@@ -242,7 +244,9 @@ __device__ __forceinline__ void merge_prefetch(const ArenaDev& A, const Leaf& lf
   }
 }
 
-template <int E>
+// FROM_ARENA (dense mass matrix, k_tree_vec): p' and v' = C p' of the new leaf were stored by B/C and k_dense_mv and are read
+// back instead of being produced here; everything after that is the same code.
+template <int E, bool FROM_ARENA = false>
 __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int j, int d, bool tree,
                                           const int (&idx)[E], const bool (&act)[E], const double (&grad)[E],
                                           const double (&ph)[E], double* red, int nwaves, int& m_out, bool& last_out,
@@ -250,17 +254,21 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
   const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
   const int dir = lf.dir, edge = lf.edge, t = lf.t;
   const int64_t to = lf.d_o;
-  double acc[E], vt[E];
+  double acc[E], vt[E], pt[E];
   double kin = 0.0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    acc[e] = 0.0; vt[e] = 0.0;
+    acc[e] = 0.0; vt[e] = 0.0; pt[e] = 0.0;
     if (act[e]) {
       const int i = idx[e];
-      const double p = fma(lf.half, grad[e], ph[e]);  // p' = p_half + eps/2 g'   (integration.py:131)
-      const double v = A.var[i] * p;                  // v' = M^-1 p'
-      A.P[to + i] = p; A.V[to + i] = v;
-      acc[e] = p; vt[e] = v;
+      double p, v;
+      if (FROM_ARENA) { p = A.P[to + i]; v = A.V[to + i]; }
+      else {
+        p = fma(lf.half, grad[e], ph[e]);  // p' = p_half + eps/2 g'   (integration.py:131)
+        v = A.var[i] * p;                  // v' = M^-1 p'
+        A.P[to + i] = p; A.V[to + i] = v;
+      }
+      acc[e] = p; vt[e] = v; pt[e] = p;
       kin = fma(p, v, kin);
     }
   }
@@ -345,126 +353,13 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
           const double v_nr = (new_right == t) ? vt[e] : A.V[onr + i];
           dd[0] = fma(tot, v_nl, dd[0]);
           dd[1] = fma(tot, v_nr, dd[1]);
-          const double p_rb = (rm_begin == t) ? (fma(lf.half, grad[e], ph[e])) : A.P[orb + i];
+          const double p_rb = (rm_begin == t) ? pt[e] : A.P[orb + i];
           const double v_rb = (rm_begin == t) ? vt[e] : A.V[orb + i];
           const double v_lb = (lm_begin == t) ? vt[e] : A.V[olb + i];
           const double r1 = lm_sum + p_rb;                    // leftmost_p_sum + rightmost_begin.p
           dd[2] = fma(r1, v_lb, dd[2]);
           dd[3] = fma(r1, v_rb, dd[3]);
-          const double p_le = (lm_end == t) ? (fma(lf.half, grad[e], ph[e])) : A.P[ole + i];
-          const double v_le = (lm_end == t) ? vt[e] : A.V[ole + i];
-          const double v_re = (rm_end == t) ? vt[e] : A.V[ore + i];
-          const double r2 = p_le + rm_sum;                    // leftmost_end.p + rightmost_p_sum
-          dd[4] = fma(r2, v_le, dd[4]);
-          dd[5] = fma(r2, v_re, dd[5]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(DOT_TOP + k) * nwaves + w] = s; }
-    }
-  }
-  m_out = m; last_out = last;
-}
-
-// The same merges for a dense mass matrix: p' and v' = C p' of the new leaf are read back from the arena
-// (kernel k_tree_vec), every element alike.
-template <int E>
-__device__ __forceinline__ void tree_post(const ArenaDev& A, const Leaf& lf, int j, int d, bool tree,
-                                          const int (&idx)[E], const bool (&act)[E], double* red, int nwaves, int& m_out,
-                                          bool& last_out) {
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
-  const int dir = lf.dir, edge = lf.edge, t = lf.t;
-  const int64_t to = lf.d_o;
-  double acc[E], vt[E];
-  double kin = 0.0;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    acc[e] = 0.0; vt[e] = 0.0;
-    if (act[e]) {
-      const int i = idx[e];
-      const double p = A.P[to + i], v = A.V[to + i];  // p', v' = C p' of the new leaf (stored by B/C and k_dense_mv)
-      acc[e] = p; vt[e] = v;
-      kin = fma(p, v, kin);
-    }
-  }
-  {
-    const double s = wave_sum(kin);
-    if (lane == 0) red[0 * nwaves + w] = s;
-  }
-  int m = 0;
-  bool last = false;
-  if (tree) {
-    while (((j >> m) & 1) && m < d) ++m;
-    last = (j + 1 == (1 << d));
-    // merges: level l joins leaves [j-2^(l+1)+1, j-2^l] (t1) with [j-2^l+1, j] (t2)   (nuts.py:452-463)
-    for (int l = 0; l < m; ++l) {
-      const int t1_left = edge + dir * (j - (2 << l) + 2);
-      const int t1_right = edge + dir * (j - (1 << l) + 1);
-      const int t2_left = t1_right + dir;
-      const int64_t o1l = slot_off(A, t1_left), o1r = slot_off(A, t1_right), o2l = slot_off(A, t2_left);
-      const double* ps1 = (l == 0) ? (A.P + o1r) : (A.PS + (int64_t)l * A.n);  // a single leaf's p_sum is its p
-      double dd[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        if (act[e]) {
-          const int i = idx[e];
-          // all six operands are loaded unconditionally (valid slots at every level) so they are in flight together
-          const double s1 = ps1[i], v1l = A.V[o1l + i], p2l = A.P[o2l + i], v2l = A.V[o2l + i], p1r = A.P[o1r + i],
-                       v1r = A.V[o1r + i];
-          const double s2 = acc[e];
-          const double rho = s1 + s2;                  // tree1.p_sum + tree2.p_sum
-          dd[0] = fma(rho, v1l, dd[0]);
-          dd[1] = fma(rho, vt[e], dd[1]);
-          if (l >= 1) {
-            const double rho1 = s1 + p2l;              // tree1.p_sum + tree2.left.p
-            dd[2] = fma(rho1, v1l, dd[2]);
-            dd[3] = fma(rho1, v2l, dd[3]);
-            const double rho2 = p1r + s2;              // tree1.right.p + tree2.p_sum
-            dd[4] = fma(rho2, v1r, dd[4]);
-            dd[5] = fma(rho2, vt[e], dd[5]);
-          }
-          acc[e] = rho;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(1 + 6 * l + k) * nwaves + w] = s; }
-    }
-    if (!last) {
-      // subtree not complete: park the merged p_sum as the pending left sibling of level m
-      if (m >= 1) {
-        double* ps = A.PS + (int64_t)m * A.n;
-#pragma unroll
-        for (int e = 0; e < E; ++e) if (act[e]) ps[idx[e]] = acc[e];
-      }
-    } else {
-      // subtree complete: top-level merge of `extend` (nuts.py:346-390), speculative
-      const int first = edge + dir;  // first leaf of the new subtree
-      int lm_begin, lm_end, rm_begin, rm_end, new_left, new_right;
-      if (dir > 0) { lm_begin = lf.left; lm_end = lf.right; rm_begin = first; rm_end = t; new_left = lf.left; new_right = t; }
-      else         { lm_begin = t; lm_end = first; rm_begin = lf.left; rm_end = lf.right; new_left = t; new_right = lf.right; }
-      const int64_t onl = slot_off(A, new_left), onr = slot_off(A, new_right);
-      const int64_t olb = slot_off(A, lm_begin), ole = slot_off(A, lm_end), orb = slot_off(A, rm_begin), ore = slot_off(A, rm_end);
-      double dd[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        if (act[e]) {
-          const int i = idx[e];
-          const double old = A.PSUM[i], sub = acc[e];
-          const double tot = old + sub;                       // p_sum[:] += tree.p_sum
-          A.PSUM[i] = tot;
-          const double lm_sum = dir > 0 ? old : sub, rm_sum = dir > 0 ? sub : old;
-          // the new edge state is this leaf: its v is in registers (the store above may not be visible yet)
-          const double v_nl = (new_left == t) ? vt[e] : A.V[onl + i];
-          const double v_nr = (new_right == t) ? vt[e] : A.V[onr + i];
-          dd[0] = fma(tot, v_nl, dd[0]);
-          dd[1] = fma(tot, v_nr, dd[1]);
-          const double p_rb = (rm_begin == t) ? A.P[to + i] : A.P[orb + i];
-          const double v_rb = (rm_begin == t) ? vt[e] : A.V[orb + i];
-          const double v_lb = (lm_begin == t) ? vt[e] : A.V[olb + i];
-          const double r1 = lm_sum + p_rb;                    // leftmost_p_sum + rightmost_begin.p
-          dd[2] = fma(r1, v_lb, dd[2]);
-          dd[3] = fma(r1, v_rb, dd[3]);
-          const double p_le = (lm_end == t) ? A.P[to + i] : A.P[ole + i];
+          const double p_le = (lm_end == t) ? pt[e] : A.P[ole + i];
           const double v_le = (lm_end == t) ? vt[e] : A.V[ole + i];
           const double v_re = (rm_end == t) ? vt[e] : A.V[ore + i];
           const double r2 = p_le + rm_sum;                    // leftmost_end.p + rightmost_p_sum
@@ -743,7 +638,10 @@ __global__ __launch_bounds__(VEC_THREADS) void k_tree_vec(ModelDev md, ArenaDev 
 #pragma unroll
   for (int e = 0; e < EPT; ++e) { idx[e] = base + e * VEC_THREADS + tid; act[e] = idx[e] < md.n; }
   int m = 0; bool last = false;
-  tree_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, s_red, NW, m, last);
+  double grad[EPT], ph[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) grad[e] = ph[e] = 0.0;
+  leaf_post<EPT, true>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last);
   __syncthreads();
   for (int k = tid; k < NDOT; k += VEC_THREADS) {
     if (!dot_needed(k, m, last)) continue;
@@ -994,15 +892,19 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
 // What a folded launch may observe late is the `aborted` flag: a leaf that starts while its predecessor's control
 // work decides to stop runs its row pass for nothing (it writes only scratch); kernel B of that leaf already sees
 // the flag and the trajectory arena is never touched by a speculative leaf.
+// `part` / `nblk`: the per-workgroup partial records of this leaf (kernel B's, or the block partials of the group-aligned row
+// pass); `def_loc`: the local parts of its deferred elements; runs in any workgroup of 64 .. 256 threads.
+struct LeanSrc { const double* part; int stride, nblk; const double* def_loc; };
+
 __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
-                                             int max_depth, HostStatus* st, int seq) {
-  static_assert(ROWS_BLOCK == VEC_THREADS, "control_lean runs in a row-pass workgroup");
+                                             int max_depth, HostStatus* st, int seq, const LeanSrc src) {
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
-  constexpr int NW = VEC_THREADS / WAVE;
+  constexpr int NWMAX = VEC_THREADS / WAVE;
+  const int NT = (int)blockDim.x, NW = NT / WAVE;
   __shared__ double s_sum[PART_STRIDE];
   __shared__ double s_chunk[CTL_CHUNKS][PART_STRIDE];
-  __shared__ double s_red[NDOT * NW];
+  __shared__ double s_red[NDOT * NWMAX];
   __shared__ Ctl s_ctl;
   const int tid = threadIdx.x;
   const bool leaf = io.mode != MODE_PLAIN;
@@ -1014,14 +916,14 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     while (((j >> m) & 1) && m < d) ++m;
     last = (j + 1 == (1 << d));
   }
-  if (leaf && tid < (int)(sizeof(Ctl) / sizeof(int))) reinterpret_cast<int*>(&s_ctl)[tid] = reinterpret_cast<const int*>(A.ctl)[tid];
+  if (leaf) for (int t = tid; t < (int)(sizeof(Ctl) / sizeof(int)); t += NT) reinterpret_cast<int*>(&s_ctl)[t] = reinterpret_cast<const int*>(A.ctl)[t];
   const bool mine = tid < md.n_deferred;
   int def_i = 0, def_k = 0;
   double2 l01 = make_double2(0.0, 1.0), l23 = make_double2(0.0, 0.0);
   if (mine) {
     def_i = md.deferred_g[2 * tid]; def_k = md.deferred_g[2 * tid + 1];
-    l01 = reinterpret_cast<const double2*>(md.def_loc)[2 * tid];
-    l23 = reinterpret_cast<const double2*>(md.def_loc)[2 * tid + 1];
+    l01 = reinterpret_cast<const double2*>(src.def_loc)[2 * tid];
+    l23 = reinterpret_cast<const double2*>(src.def_loc)[2 * tid + 1];
   }
   // ---- fixed-order sums of the per-workgroup partials this leaf needs: (slot, chunk) pairs in parallel ----
   const int nlg = md.has_logit ? lg.D : 0;
@@ -1037,11 +939,11 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     return PART_DOT + DOT_TOP + (q - 1 - 6 * m);
   };
   {
-    const int per = (md.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
-    for (int t = tid; t < nn * CTL_CHUNKS; t += VEC_THREADS) {
+    const int per = (src.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
+    for (int t = tid; t < nn * CTL_CHUNKS; t += NT) {
       const int c = t % CTL_CHUNKS, k = need_slot(t / CTL_CHUNKS);
-      const int b0 = c * per, b1 = min(md.nblk, (c + 1) * per);
-      s_chunk[c][k] = sum_strided(md.part + k, md.part_stride, b0, b1);
+      const int b0 = c * per, b1 = min(src.nblk, (c + 1) * per);
+      s_chunk[c][k] = sum_strided(src.part + k, src.stride, b0, b1);
     }
   }
   __syncthreads();
@@ -1049,7 +951,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     if (tid == 0 && st) publish_status(&s_ctl, st, seq);
     return;
   }
-  for (int t = tid; t < nn; t += VEC_THREADS) {
+  for (int t = tid; t < nn; t += NT) {
     const int k = need_slot(t);
     double sacc = 0.0;
 #pragma unroll
@@ -1077,7 +979,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2);
   __syncthreads();
   // totals: workgroup partials (in order) + the deferred elements' share
-  for (int q = tid; q < NDOT; q += VEC_THREADS) {
+  for (int q = tid; q < NDOT; q += NT) {
     if (!dot_needed(q, m, last)) continue;
     double r = 0.0;
     for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];
@@ -1096,9 +998,15 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   if (st) publish_status(&s_ctl, st, seq);
 }
 
+// `par`: launch parity of the leaf's row pass (group-aligned row pass only; its partials are double-buffered)
+__device__ __forceinline__ LeanSrc lean_src(const ModelDev& md, int par) {
+  if (md.lg.ga) return LeanSrc{md.lg.ga_bpart + (int64_t)par * md.lg.ga_nblk * PART_STRIDE, PART_STRIDE, md.lg.ga_nblk, md.def_loc + (int64_t)par * 4 * MAX_DEFERRED};
+  return LeanSrc{md.part, md.part_stride, md.nblk, md.def_loc};
+}
+
 __global__ __launch_bounds__(VEC_THREADS) void k_control_lean(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
-                                                             int max_depth, HostStatus* st, int seq) {
-  control_lean(md, A, io, j, d, Emax, max_depth, st, seq);
+                                                             int max_depth, HostStatus* st, int seq, int par) {
+  control_lean(md, A, io, j, d, Emax, max_depth, st, seq, lean_src(md, par));
 }
 
 // ---------------------------------------------------------------------------
@@ -1111,7 +1019,7 @@ __global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(ModelDev md, ArenaDev 
                                                         double Emax, int max_depth, HostStatus* st) {
   int b = (int)blockIdx.x;
   if (fold) {
-    if (b == 0) { control_lean(md, A, io, j - 1, d, Emax, max_depth, st, 0); return; }
+    if (b == 0) { control_lean(md, A, io, j - 1, d, Emax, max_depth, st, 0, lean_src(md, 0)); return; }
     --b;
   }
   const RowsDev& R = md.lg;
@@ -1143,10 +1051,9 @@ __global__ __launch_bounds__(ROWS_BLOCK, OCC) void k_rows(ModelDev md, ArenaDev 
 #define MVN_BLOCK 256
 __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_matvec(ModelDev md, ArenaDev A, EvalIO io, int j, int fold, int d, double Emax,
                                                         int max_depth, HostStatus* st) {
-  static_assert(MVN_BLOCK == VEC_THREADS, "control_lean runs in a mat-vec workgroup");
   int row = (int)blockIdx.x;
   if (fold) {
-    if (row == 0) { control_lean(md, A, io, j - 1, d, Emax, max_depth, st, 0); return; }
+    if (row == 0) { control_lean(md, A, io, j - 1, d, Emax, max_depth, st, 0, lean_src(md, 0)); return; }
     --row;
   }
   const MvnDev& mv = md.mv;
@@ -1305,6 +1212,9 @@ __global__ __launch_bounds__(VEC_THREADS) void k_draw_finish(ArenaDev A, double*
   const Ctl* c = A.ctl;
   const int prop = c->proposal;
   const int64_t po = slot_off(A, prop);
+  // a launch that was in flight while the tree stopped may have left some arrival counters of the group-aligned row pass
+  // half-way (the `aborted` flag flips under it): every draw ends with the counters at zero
+  if (blockIdx.x == 0) for (int t = threadIdx.x; t < A.ga_nticket; t += blockDim.x) A.ga_ticket[t] = 0u;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) {
     q_out[i] = A.Q[po + i];
     g_out[i] = A.G[po + i];
@@ -1348,3 +1258,5 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update(int n, const d
     }
   }
 }
+
+#include "rows_ga_kernel.h"

@@ -79,6 +79,20 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   const int32_t* gmix_ptr;       // [G+1] mixed segments of group g
   double* mixed_part;            // [n_mixed_seg][D]
   double* wave_lp;         // [n_waves + n_mixed]   log-likelihood partial of each wave
+  // ---- group-aligned row pass (rows_ga_kernel.h): workgroup g streams exactly the rows of group g ----
+  // Xt / y are then tiled PER GROUP (group g owns tiles [ga_tile0[g], ga_tile0[g+1]), the last one zero-padded), the
+  // span tables above are not built, and there is no O(n) kernel between two row passes: the workgroup that streamed a
+  // group holds that group's complete d logp / d beta and finishes its D z elements itself.
+  int32_t ga, ga_w;              // active; waves per workgroup
+  int32_t ga_nblk, ga_bsz;       // second-level reduction: blocks of ga_bsz consecutive groups
+  const int32_t* ga_tile0;       // [G+1]
+  unsigned* ga_ticket;           // [ga_nblk] arrivals of the block's groups in the current launch (self-resetting)
+  double* ga_part;               // [G][PART_STRIDE] per-group partial record (written write-through, read by the block's last arriver)
+  double* ga_bpart;              // [2][ga_nblk][PART_STRIDE] block partials, double-buffered by launch parity
+  // closed forms of what the interpreter would evaluate for this model (checked by the spec compiler):
+  double z_np_mu, z_np_inv_var, z_np_lognorm;   // z ~ Normal(mu0, s0) untransformed
+  double mu_c[3];                               // mu ~ Normal(p1, .): {p1, 1/sigma, log sigma}
+  double sg_c[2];                               // sigma ~ HalfNormal(.): {1/sigma, log sigma}
 };
 
 struct MvnDev {
@@ -111,7 +125,7 @@ struct ModelDev {
   // "lean" control path (see kernels.h): the only deferred elements are the hierarchical-logit node's mu / sigma, so
   // kernel B evaluates everything of them that does not need the cross-workgroup sums and leaves
   // {d logp/dx local part, dx/dq, dlog|J|/dq, p_half} per deferred element here
-  double* def_loc;            // [n_deferred][4]
+  double* def_loc;            // [2][MAX_DEFERRED][4] (second copy: the group-aligned row pass double-buffers by launch parity)
   int32_t lean_ok, lean_pad;
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
   const char* prog;

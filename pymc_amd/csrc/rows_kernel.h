@@ -81,35 +81,46 @@ __device__ __forceinline__ void rows_hyper(const RowsDev& R, const QView& qv, in
 // every wave finishes them itself from what kernel B left behind -- the per-workgroup partial sums of
 // d logp / d mu, d logp / d sigma (summed in exactly the control kernel's order) and the local parts in `def_loc`.
 // One round of loads, like the plain version; q' of the source state was stored by kernel B for every element.
+// `part` / `stride` / `nblk` / `def_loc`: where the previous leaf left its partial sums and local parts (kernel B's records, or
+// the block partials of the group-aligned row pass).  Lane l returns, for hyper-parameter element e = l mod 2D
+// (mu[0..D), sigma[0..D)), this leaf's q' (`val`) and p_half (`ph`).
 template <int D>
-__device__ __forceinline__ void rows_hyper_fold(const ModelDev& md, const QView& qv, int lane, double& m_lane, double& s_lane) {
+__device__ __forceinline__ void rows_hyper_fold_elem(const RowsDev& R, const double* part, int stride, int nblk, const double* def_loc,
+                                                     const QView& qv, int lane, double& val, double& ph) {
   constexpr int NE = 2 * D;                 // mu[0..D), sigma[0..D)
   constexpr int NP = NE * CTL_CHUNKS;       // (element, chunk) pairs
   constexpr int NS = (NP + WAVE - 1) / WAVE;
-  const RowsDev& R = md.lg;
   const int e = lane % NE;
   const bool is_mu = e < D;
   const int dd = is_mu ? e : e - D;
   const int i = (is_mu ? R.off_mu : R.off_sigma) + dd;
   const int slot = (is_mu ? R.def_mu : R.def_sigma) + dd;
-  const double2 l01 = reinterpret_cast<const double2*>(md.def_loc)[2 * slot];       // {gx local, dx/dq}
-  const double2 l23 = reinterpret_cast<const double2*>(md.def_loc)[2 * slot + 1];   // {dlog|J|/dq, p_half}
+  const double2 l01 = reinterpret_cast<const double2*>(def_loc)[2 * slot];       // {gx local, dx/dq}
+  const double2 l23 = reinterpret_cast<const double2*>(def_loc)[2 * slot + 1];   // {dlog|J|/dq, p_half}
   const double qi = qv.q[i], vi = qv.var[i];
-  const int per = (md.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
+  const int per = (nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
   double cs[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int pair = (lane + WAVE * s) % NP;
     const int pe = pair % NE, c = pair / NE;
     const int k = pe < D ? PART_DMU + pe : PART_DSG + (pe - D);
-    cs[s] = sum_strided(md.part + k, md.part_stride, c * per, min(md.nblk, (c + 1) * per));
+    cs[s] = sum_strided(part + k, stride, c * per, min(nblk, (c + 1) * per));
   }
   double S = 0.0;
 #pragma unroll
   for (int c = 0; c < CTL_CHUNKS; ++c) S += __shfl(cs[(NE * c) / WAVE], (NE * c) % WAVE + e);
   const double g = deferred_finish(l01.x, S, l01.y, l23.x);
   const double p_src = fma(qv.half, g, l23.y);                       // p' of the previous leaf (integration.py:131)
-  const double val = fma(qv.eps, vi * fma(qv.half, g, p_src), qi);    // this leaf's q'
+  ph = fma(qv.half, g, p_src);                                       // this leaf's p_half
+  val = fma(qv.eps, vi * ph, qi);                                    // this leaf's q'
+}
+
+template <int D>
+__device__ __forceinline__ void rows_hyper_fold(const ModelDev& md, const QView& qv, int lane, double& m_lane, double& s_lane) {
+  const RowsDev& R = md.lg;
+  double val, ph;
+  rows_hyper_fold_elem<D>(R, md.part, md.part_stride, md.nblk, md.def_loc, qv, lane, val, ph);
   const int dl = lane % D;
   m_lane = __shfl(val, dl);
   const double sg = __shfl(val, D + dl);

@@ -237,6 +237,8 @@ class QuadPotentialFull(QuadPotential):
     leapfrog the device runs the mat-vec `v = C p` (`k_dense_mv`), per draw `p0 = W z` with W = chol^-T.
     """
 
+    _dense = True
+
     def __init__(self, cov, dtype=None, rng=None):
         import scipy.linalg
 
@@ -400,7 +402,7 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
     def _host_state(self):
         import copy
 
-        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step")})
+        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step", "_prefetch")})
 
     def _set_host_state(self, state):
         import copy
@@ -497,7 +499,7 @@ class QuadPotentialDiagAdaptExp(QuadPotential):
     def _host_state(self):
         import copy
 
-        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step")})
+        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step", "_prefetch")})
 
     def _set_host_state(self, state):
         import copy

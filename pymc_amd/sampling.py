@@ -123,6 +123,33 @@ def assign_chains(chains: int, rank: int, world: int) -> List[int]:
     return [c for c in range(chains) if c % world == rank]
 
 
+def sample_draws(step: NUTS, point, K: int, callback=None, first_index: int = 0):
+    """K post-tuning transitions from `point`: `(positions [K][n], [stats] * K, last point)`.
+
+    The sampling phase of `_iter_sample` (mcmc.py:1556-1572).  After tuning the reference changes nothing on the host
+    between draws, so the transitions are made in batches inside ONE C call each (`nuts_chain_draw_many`):
+    the trace lives in a device buffer, positions and statistics come back once per batch."""
+    n = step._n
+    out = np.empty((K, n))
+    stats_out = []
+    batch = int(os.environ.get("PYMC_AMD_DRAW_BATCH", "64"))
+    i = 0
+    while i < K:
+        if batch > 1 and callback is None and getattr(step, "can_draw_many", False):
+            pos, point, st = step.draw_many(point, min(batch, K - i))
+            out[i : i + len(st)] = pos
+            stats_out.extend(st)
+            i += len(st)
+            continue
+        point, stats = step.step(point)
+        out[i] = DictToArrayBijection.map({k: point[k] for k in step.var_names}).data
+        stats_out.append(stats[0])
+        if callback is not None:
+            callback(first_index + i, point, stats[0])
+        i += 1
+    return out, stats_out, point
+
+
 def sample_chain(step: NUTS, start, rng, tune: int, draws: int, callback=None, pooled=None):
     """`_iter_sample` (mcmc.py:1503-1583): returns (draws[tune+draws, n], stats list)."""
     total = tune + draws
@@ -133,30 +160,24 @@ def sample_chain(step: NUTS, start, rng, tune: int, draws: int, callback=None, p
     n = step._n
     out = np.empty((total, n))
     stats_out = []
-    batch = int(os.environ.get("PYMC_AMD_DRAW_BATCH", "64"))
-    i = 0
-    while i < total:
+    for i in range(tune):
         if i == 0:
             step.iter_count = 0
-        if i == tune:
-            step.stop_tuning()
-            if pooled is not None:
-                pooled.end_of_tuning(step)
-        if i >= tune and batch > 1 and callback is None and getattr(step, "can_draw_many", False):
-            # sampling phase of a single-launch model: several transitions per launch, one gather
-            pos, point, st = step.draw_many(point, min(batch, total - i))
-            out[i : i + len(st)] = pos
-            stats_out.extend(st)
-            i += len(st)
-            continue
         point, stats = step.step(point)
         out[i] = DictToArrayBijection.map({k: point[k] for k in step.var_names}).data
         stats_out.append(stats[0])
-        if pooled is not None and i < tune:
+        if pooled is not None:
             pooled.after_tuning_draw(step, i)
         if callback is not None:
             callback(i, point, stats[0])
-        i += 1
+    if tune == 0:
+        step.iter_count = 0
+    step.stop_tuning()
+    if pooled is not None:
+        pooled.end_of_tuning(step)
+    d, s, point = sample_draws(step, point, draws, callback=callback, first_index=tune)
+    out[tune:] = d
+    stats_out.extend(s)
     return out, stats_out
 
 
@@ -172,12 +193,12 @@ class PooledAdaptation:
     estimator (160 KB at n = 10 000): latency-bound on xGMI.
     """
 
-    def __init__(self, n: int, device, window: int = 101):
+    def __init__(self, n: int, device):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
-        self.n, self.window = n, window
+        self.n = n
         self.buf = torch.zeros(2 * (2 * n + 1), dtype=torch.float64, device=device)
 
     def _merge(self, part):
@@ -196,8 +217,9 @@ class PooledAdaptation:
         m2.copy_(m2p)
 
     def after_tuning_draw(self, step, i):
-        # the window boundary is draw k with k > 0 and k % window == 0 (0-based n_samples)
-        if i == 0 or i % self.window != 0:
+        # the boundary the chain itself just crossed (quadpotential.py:350-353: foreground <- background): the engine
+        # reports it, so a window multiplier or a non-default window length is followed, not assumed
+        if not int(step._scalar("window_switched")):
             return
         from pymc_amd import _lib
 
@@ -285,8 +307,14 @@ def sample(
     if pooled_adaptation and world > 1:
         import torch
 
+        # every rank enters the same collectives at the same tuning draws: that needs the same number of chains on every
+        # rank, and the windowed Welford estimators of QuadPotentialDiagAdapt on the device
+        if chains % world != 0:
+            raise ValueError(f"pooled_adaptation needs the chains ({chains}) to divide evenly over the ranks ({world})")
+        if type(step.potential) is not QuadPotentialDiagAdapt:
+            raise ValueError("pooled_adaptation pools the Welford windows of QuadPotentialDiagAdapt (init='adapt_diag' / 'jitter+adapt_diag')")
         dev = torch.device("cuda", device if device is not None else 0)
-        pooled = PooledAdaptation(spec.n, dev, window=step.potential.adaptation_window)
+        pooled = PooledAdaptation(spec.n, dev)
     total = tune + draws
     local_draws = np.empty((len(mine), total, spec.n))
     local_stats = []

@@ -130,8 +130,11 @@ class _DeviceHMCBase:
         initial_point: Optional[PointType] = None,
         device: Optional[int] = None,
         blocked=True,
-        **_ignored,
+        compile_kwargs=None,
+        **unknown,
     ):
+        if unknown:   # a typo or an unsupported option must not pass silently
+            raise TypeError(f"{type(self).__name__}.__init__() got unexpected keyword argument(s): {sorted(unknown)}")
         spec = model.spec if hasattr(model, "spec") else model
         if logp_dlogp_func is None:
             if not isinstance(spec, ModelSpec):
@@ -160,6 +163,10 @@ class _DeviceHMCBase:
         elif potential is None:  # base_hmc.py:171-180 -> quad_potential(scaling, is_cov)
             potential = quad_potential(np.asarray(scaling, dtype="float64"), is_cov, rng=self.rng.spawn(1)[0])
         self.potential = potential
+        # a dense mass matrix (velocity = C p between the half kicks) cannot ride in the group-aligned row pass
+        if getattr(potential, "_dense", False) and logp_dlogp_func.model_scalar("rows_group_aligned"):
+            logp_dlogp_func = DeviceValueGradFunction(self.spec, device=logp_dlogp_func.device, rows_group_aligned=False)
+            self._logp_dlogp_func = logp_dlogp_func
         lib = _lib.load()
         cfg = _lib.ChainConfig()
         lib.nuts_chain_config_default(C.byref(cfg))
@@ -476,7 +483,7 @@ class HamiltonianMC(_DeviceHMCBase):
         kwargs.setdefault("max_treedepth", 10)
         super().__init__(vars, **kwargs)
         self.path_length = path_length
-        self.max_steps = min(max_steps, (1 << self.max_treedepth) - 1)
+        self.max_steps = max_steps   # hmc.py:127-132: no clamp (the fixed-length trajectory runs in a ring of arena slots)
 
     @staticmethod
     def competence(var, has_grad):  # hmc.py:186-191
@@ -518,10 +525,18 @@ class HamiltonianMC(_DeviceHMCBase):
             _lib.check(rc, "nuts_chain_draw_hmc")
         if st.diverging:
             self.rng.bit_generator.state = after_jitter
+        warning = None
+        if st.diverging:   # base_hmc.py:241-268 with the messages of hmc.py:143-158
+            kind = "TUNING_DIVERGENCE" if self.tune else "DIVERGENCE"
+            if not self.tune:
+                self._num_divs_sample += 1
+            msg = ("Divergence encountered, bad energy." if not np.isfinite(st.energy)
+                   else f"Divergence encountered, energy change larger than {self.Emax}.")
+            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1, None, None, None)
         stats = {
             "diverging": bool(st.diverging), "divergences": int(st.divergences),
             "perf_counter_diff": st.perf_counter_diff, "process_time_diff": st.process_time_diff,
-            "perf_counter_start": st.perf_counter_start, "warning": None,
+            "perf_counter_start": st.perf_counter_start, "warning": warning,
             "path_length": st.path_length, "n_steps": int(st.n_steps), "accept": st.accept,
             "energy_error": st.energy_error, "energy": st.energy, "accepted": bool(st.accepted),
             "model_logp": st.model_logp, "step_size": st.step_size, "step_size_bar": st.step_size_bar,

@@ -20,7 +20,7 @@ from pymc_amd.blocking import DictToArrayBijection, RaveledVars
 from pymc_amd.model_spec import ModelSpec
 
 
-def _pack(spec: ModelSpec):
+def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
     """ModelSpec -> nuts_model_spec (+ the numpy buffers that must outlive the call)."""
     keep = []
     nv, nf, nd = len(spec.vars), len(spec.factors), len(spec.data)
@@ -59,6 +59,7 @@ def _pack(spec: ModelSpec):
         s.rows_y = y.ctypes.data_as(C.POINTER(C.c_int8))
         s.rows_gid = g.ctypes.data_as(C.POINTER(C.c_int32))
         s.rows_mu, s.rows_sigma, s.rows_z = r.mu, r.sigma, r.z
+        s.rows_opts = 0 if rows_group_aligned else 1   # NUTS_ROWS_NO_GROUP_ALIGNED
     if spec.mvnormal is not None:
         mv = spec.mvnormal
         # Cholesky + triangular solves, as quaddist_chol does (pymc/distributions/multivariate.py:165-185);
@@ -77,7 +78,7 @@ def _pack(spec: ModelSpec):
 class DeviceValueGradFunction:
     """Device-resident logp/dlogp function of a :class:`ModelSpec`."""
 
-    def __init__(self, spec: ModelSpec, device: int | None = None):
+    def __init__(self, spec: ModelSpec, device: int | None = None, rows_group_aligned: bool = True):
         lib = _lib.load()
         if device is not None:
             _lib.check(lib.nuts_set_device(int(device)), "nuts_set_device")
@@ -88,7 +89,8 @@ class DeviceValueGradFunction:
         self._extra_vars_shared = {}
         self._extra_are_set = False
         self.trust_input = True
-        cspec, keep = _pack(spec)
+        self.rows_group_aligned_allowed = rows_group_aligned
+        cspec, keep = _pack(spec, rows_group_aligned)
         self._handle = lib.nuts_model_create(C.byref(cspec))
         del keep
         if not self._handle:
@@ -96,6 +98,11 @@ class DeviceValueGradFunction:
         self.n = lib.nuts_model_ndim(self._handle)
         self._grad = np.empty(self.n)
         self._lp = np.empty(1)
+
+    def model_scalar(self, name: str) -> float:
+        out = C.c_double()
+        _lib.check(_lib.load().nuts_model_get_scalar(self._handle, name.encode(), C.byref(out)), name)
+        return out.value
 
     def bind_thread(self):
         """HIP's current device is per host thread: a worker thread that drives this model selects its device first."""

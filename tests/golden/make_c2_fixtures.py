@@ -1,0 +1,110 @@
+"""Golden fixtures at the BENCHMARK's own shapes (C2-L, C2-S), produced by the CPU oracle.
+
+Two artefacts, both outputs of `oracle/ref_sampler.py` (which reproduces the reference's sampler modules bitwise,
+tests/golden/refrun.py) over the gcc restatement of the hierarchical-logit log-density (`oracle/c_logit.py`):
+
+  nuts_c2l_prefix.npz   one chain of C2-L (G = 1248, 4000 rows per group, N = 4 992 000, n = 10 000), the first
+                        TUNE + DRAWS transitions from q = 0 with `init="adapt_diag"`: every sampler statistic per draw and the
+                        positions of a fixed subset of coordinates.  ~0.12 s per oracle leapfrog -> minutes here, so the
+                        GPU test (`tests/test_gpu_benchmark_shapes.py`) compares against this file instead of re-running it.
+  c2s_chains.npz        four chains of C2-S (80 rows per group, N = 99 840), 1000 tune + 1000 draws each from fixed jittered
+                        starts: per-parameter posterior mean / sd / bulk-ESS / R-hat over the four chains, per-chain
+                        step size and tree sizes, and the full draws of the 16 hyper-parameters.  The device run of the
+                        same configuration must agree within Monte-Carlo error (positions are chaotic beyond a few
+                        dozen draws, so this fixture is statistical by construction).
+
+    python tests/golden/make_c2_fixtures.py [c2l] [c2s]
+"""
+
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+C2L = dict(G=1248, D=8, rows_per_group=4000, tune=20, draws=10, seed=20160911)
+C2S = dict(G=1248, D=8, rows_per_group=80, tune=1000, draws=1000, chains=4, seed=20160911, start_seed=77)
+STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth", "mean_tree_accept", "energy",
+             "energy_error", "max_energy_error", "model_logp", "step_size", "step_size_bar")
+
+
+def c2l_coords(n):
+    """Coordinates whose positions are stored: the 16 hyper-parameters + 112 z elements spread over the groups."""
+    return np.concatenate([np.arange(16), 16 + (np.arange(112) * 89) % (n - 16)])
+
+
+def c2s_starts(n, chains, start_seed):
+    """Over-dispersed starts (U(-1, 1) around 0, what `jitter+adapt_diag` does; the reference's jitter VALUES are
+    unpinned, SURVEY A.6, so they are fixed here and handed to both sides as `initvals`)."""
+    rng = np.random.default_rng(start_seed)
+    return [rng.uniform(-1, 1, size=n) for _ in range(chains)]
+
+
+def make_c2l():
+    from oracle import c_logit, ref_sampler
+    from pymc_amd import models
+
+    cfg = C2L
+    spec = models.hier_logit(G=cfg["G"], D=cfg["D"], rows_per_group=cfg["rows_per_group"])
+    f = c_logit.CHierLogit(spec)
+    t0 = time.time()
+    draws, stats = ref_sampler.sample_reference(f, [np.zeros(spec.n)], draws=cfg["draws"], tune=cfg["tune"], random_seed=cfg["seed"], init="adapt_diag")
+    out = {k: np.array([s[k] for s in stats[0]]) for k in STAT_KEYS}
+    coords = c2l_coords(spec.n)
+    out["coords"] = coords
+    out["draws_subset"] = draws[0][:, coords]
+    out["config"] = np.array([cfg[k] for k in ("G", "D", "rows_per_group", "tune", "draws", "seed")])
+    np.savez_compressed(os.path.join(HERE, "nuts_c2l_prefix.npz"), **out)
+    print(f"c2l: {time.time() - t0:.0f} s, tree sizes {out['tree_size'].astype(int).tolist()}", flush=True)
+
+
+def _c2s_chain(c):
+    from oracle import c_logit, ref_sampler
+    from pymc_amd import models
+
+    cfg = C2S
+    spec = models.hier_logit(G=cfg["G"], D=cfg["D"], rows_per_group=cfg["rows_per_group"])
+    f = c_logit.CHierLogit(spec)
+    starts = c2s_starts(spec.n, cfg["chains"], cfg["start_seed"])
+    rngs, seeds = ref_sampler.spawn_chain_rngs(cfg["seed"], cfg["chains"])      # mcmc.py:907-908
+    pot = ref_sampler.adapt_diag_potential(starts, seeds[0])                     # mcmc.py:1886-1894
+    step = ref_sampler.RefNUTS(f, spec.n, potential=pot, rng=seeds[0])
+    t0 = time.time()
+    d, s = ref_sampler.run_chain(step, starts[c], rngs[c], cfg["tune"], cfg["draws"])
+    print(f"c2s chain {c}: {time.time() - t0:.0f} s", flush=True)
+    return d[cfg["tune"]:], {k: np.array([x[k] for x in s]) for k in STAT_KEYS}
+
+
+def make_c2s():
+    from pymc_amd import stats as st
+
+    cfg = C2S
+    with mp.get_context("fork").Pool(cfg["chains"]) as pool:
+        res = pool.map(_c2s_chain, range(cfg["chains"]))
+    draws = np.stack([r[0] for r in res])                   # (chains, draws, n)
+    out = {
+        "mean": draws.mean(axis=(0, 1)), "sd": draws.std(axis=(0, 1), ddof=1),
+        "chain_mean": draws.mean(axis=1).astype("float32"), "chain_sd": draws.std(axis=1, ddof=1).astype("float32"),
+        "ess_bulk": st.ess_bulk_many(draws), "rhat": st.rhat_many(draws),
+        "hyper_draws": draws[:, :, :16].astype("float32"),
+        "config": np.array([cfg[k] for k in ("G", "D", "rows_per_group", "tune", "draws", "chains", "seed", "start_seed")]),
+    }
+    for k in ("tree_size", "step_size_bar", "depth", "diverging", "mean_tree_accept"):
+        out["stat_" + k] = np.stack([r[1][k] for r in res])
+    np.savez_compressed(os.path.join(HERE, "c2s_chains.npz"), **out)
+    print("c2s: min ESS", out["ess_bulk"].min(), "argmin", int(out["ess_bulk"].argmin()), "max rhat", out["rhat"].max(),
+          "mean tree", out["stat_tree_size"][:, cfg["tune"]:].mean(), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2l", "c2s"]
+    if "c2s" in which:
+        make_c2s()
+    if "c2l" in which:
+        make_c2l()

@@ -1,0 +1,336 @@
+"""GPU parity at the BENCHMARK's own shapes: C2-L (G = 1248, 4000 rows per group, N = 4 992 000 --
+the configuration `bench.py` times and the roofline fraction is quoted on), C2-S (80 rows per group) and C3 (MvNormal,
+k = 2048).  The launch geometry of the row pass depends on the size of the pass (waves per CU, traversal direction,
+folded control, fixed-slot segments, group-aligned workgroups), so the code the benchmark number comes from is compared
+with the oracle here, in the tests the driver runs -- not on scaled-down stand-ins.
+
+Oracle: `oracle/c_logit.py` (gcc restatement of the hierarchical-logit log-density, 0.13 s per evaluation at C2-L) under
+`oracle/ref_sampler.py`; the C2-L NUTS prefix and the C2-S four-chain summary are committed fixtures
+(`tests/golden/make_c2_fixtures.py`: minutes of one host core per chain).
+
+Tolerances: logp / gradient 1e-9 relative (north-star bar 1e-6); leapfrog trajectory 1e-10; identical seed => identical
+integer tree statistics; alternative schedules of the same arithmetic bitwise equal.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_logit, ref_models, ref_sampler
+from pymc_amd import models
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
+
+
+@pytest.fixture(scope="module")
+def c2l():
+    return models.hier_logit(G=1248, D=8, rows_per_group=4000)
+
+
+@pytest.fixture(scope="module")
+def c2s():
+    return models.hier_logit(G=1248, D=8, rows_per_group=80)
+
+
+def _points(n, k=3, seed=5):
+    rng = np.random.default_rng(seed)
+    return [np.zeros(n)] + [rng.normal(size=n) * s for s in (0.3, 0.7, 1.2)[: k - 1]]
+
+
+def _check_against_c_oracle(spec, rtol=1e-9):
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    f_dev = DeviceValueGradFunction(spec, device=0)
+    f_ref = c_logit.CHierLogit(spec)
+    worst = 0.0
+    for q in _points(spec.n):
+        lp, g = f_dev._pytensor_function(q)
+        lp0, g0 = f_ref(q)
+        assert abs(lp - lp0) <= rtol * abs(lp0), (lp, lp0)
+        err = np.max(np.abs(g - g0)) / np.max(np.abs(g0))
+        assert err <= rtol, err
+        worst = max(worst, abs(lp - lp0) / abs(lp0), err)
+    f_dev.close()
+    return worst
+
+
+def test_c2l_logp_grad_matches_c_oracle(c2l):
+    """`ValueGradFunction.__call__` (model/core.py:286-300) at the benchmarked shape, four points."""
+    assert c2l.n == 10_000 and c2l.logit_rows.X.shape == (4_992_000, 8)
+    worst = _check_against_c_oracle(c2l)
+    print(f"C2-L worst relative error (logp, grad) vs the C oracle: {worst:.2e}")
+
+
+def test_c2s_logp_grad_matches_c_oracle(c2s):
+    assert c2s.n == 10_000 and c2s.logit_rows.X.shape == (99_840, 8)
+    _check_against_c_oracle(c2s)
+
+
+def _leapfrog(spec, var, q0, p0, eps, steps):
+    from pymc_amd import _lib
+    from pymc_amd.step import NUTS
+
+    step = NUTS(model=spec, scaling=var, is_cov=True, rng=1, device=0)
+    q1, p1, e = np.empty(spec.n), np.empty(spec.n), C.c_double()
+    _lib.check(_lib.load().nuts_chain_leapfrog_test(step._chain, _lib.dptr(q0), _lib.dptr(p0), eps, steps, _lib.dptr(q1), _lib.dptr(p1), C.byref(e)))
+    step.close()
+    step._logp_dlogp_func.close()
+    return q1, p1, e.value
+
+
+# every schedule of the row pass the engine can be switched to (engine.hip reads these when a model / chain is created)
+SCHEDULES = [
+    {},                                                        # the default = what bench.py runs
+    {"NUTS_FOLD_CTL": "0"},
+    {"NUTS_ROWS_GA": "0"},                                     # span partition + kernel B instead of group-aligned workgroups
+    {"NUTS_ROWS_GA": "0", "NUTS_FOLD_CTL": "0"},
+    {"NUTS_ROWS_GA": "0", "NUTS_ROWS_WAVES_PER_CU": "16"},
+    {"NUTS_ROWS_GA": "0", "NUTS_ROWS_WAVES_PER_CU": "32"},
+    {"NUTS_ROWS_GA": "0", "NUTS_ROWS_ALTERNATE": "0"},
+    {"NUTS_ROWS_ALTERNATE": "0"},
+]
+
+
+@pytest.mark.parametrize("which", ["c2l", "c2s"])
+def test_leapfrog_at_benchmark_shape_matches_oracle_under_every_schedule(which, c2l, c2s, monkeypatch):
+    """Seven steps of `CpuLeapfrogIntegrator.step` (integration.py:77-145) at the benchmarked shape against the oracle
+    integrator over the C log-density, under every launch schedule.  Schedules that only reorder launches (folded
+    control, traversal direction) must agree bitwise with each other; schedules that change the partition of the rows
+    over waves (waves per CU, group-aligned workgroups) change the summation order of the likelihood and agree to
+    rounding."""
+    spec = {"c2l": c2l, "c2s": c2s}[which]
+    rng = np.random.default_rng(0)
+    var = rng.uniform(0.5, 2.0, size=spec.n)
+    q0, p0 = rng.normal(size=spec.n) * 0.3, rng.normal(size=spec.n)
+    eps = 0.01
+    integ = ref_sampler.Leapfrog(ref_sampler.DiagPotential(var), c_logit.CHierLogit(spec))
+    s = integ.compute_state(q0, p0)
+    for _ in range(7):
+        s = integ.step(eps, s)
+    results = []
+    for env in SCHEDULES:
+        for k in ("NUTS_FOLD_CTL", "NUTS_ROWS_GA", "NUTS_ROWS_WAVES_PER_CU", "NUTS_ROWS_ALTERNATE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        q1, p1, e1 = _leapfrog(spec, var, q0, p0, eps, 7)
+        np.testing.assert_allclose(q1, s.q, rtol=1e-10, atol=1e-12, err_msg=str(env))
+        np.testing.assert_allclose(p1, s.p, rtol=1e-10, atol=1e-11, err_msg=str(env))
+        np.testing.assert_allclose(e1, s.energy, rtol=1e-11, err_msg=str(env))
+        results.append((env, q1, p1, e1))
+
+    def same_partition(a, b):   # keys that change which wave sums which rows
+        part = lambda e: (e.get("NUTS_ROWS_GA", "1"), e.get("NUTS_ROWS_WAVES_PER_CU", ""))
+        return part(a) == part(b)
+
+    for i in range(len(results)):
+        for j in range(i + 1, len(results)):
+            (ea, qa, pa, va), (eb, qb, pb, vb) = results[i], results[j]
+            if same_partition(ea, eb):
+                assert np.array_equal(qa, qb) and np.array_equal(pa, pb) and va == vb, (ea, eb)
+
+
+def test_c2s_nuts_integer_parity_through_tuning(c2s):
+    """BaseHMC.astep x 45 (30 tuning + 15 draws) on C2-S: every integer statistic identical to the oracle's, positions
+    and energies to rounding on the first draws (nuts.py:334-476; chaos takes over later, the integers do not move)."""
+    from pymc_amd.sampling import sample
+
+    tune, draws, seed = 30, 15, 31
+    res = sample(draws=draws, tune=tune, chains=1, model=c2s, init="adapt_diag", random_seed=seed, device=0)
+    f = c_logit.CHierLogit(c2s)
+    ref_draws, ref_stats = ref_sampler.sample_reference(f, [np.zeros(c2s.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    dev = res["warmup_stats"][0] + res["stats"][0]
+    for i in range(tune + draws):
+        for k in INT_KEYS:
+            assert int(dev[i][k]) == int(ref_stats[0][i][k]), (i, k, dev[i][k], ref_stats[0][i][k])
+    for i in range(6):
+        for k in ("mean_tree_accept", "energy", "model_logp", "step_size", "step_size_bar"):
+            np.testing.assert_allclose(dev[i][k], ref_stats[0][i][k], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
+    res["step"].close()
+
+
+def test_c2l_nuts_prefix_matches_golden_fixture(c2l):
+    """The first transitions of a C2-L chain (the benchmarked shape, default schedule) against the committed oracle run
+    (`tests/golden/nuts_c2l_prefix.npz`): integer statistics identical, floats to rounding on the first draws."""
+    from pymc_amd.sampling import sample
+
+    gold = np.load(os.path.join(GOLDEN, "nuts_c2l_prefix.npz"))
+    G, D, rpg, tune, draws, seed = (int(x) for x in gold["config"])
+    assert (G, D, rpg) == (1248, 8, 4000)
+    res = sample(draws=draws, tune=tune, chains=1, model=c2l, init="adapt_diag", random_seed=seed, device=0, discard_tuned_samples=False)
+    dev = res["stats"][0]
+    assert len(dev) == tune + draws
+    for i in range(tune + draws):
+        for k in INT_KEYS:
+            assert int(dev[i][k]) == int(gold[k][i]), (i, k, dev[i][k], gold[k][i])
+    for i in range(5):
+        for k in ("mean_tree_accept", "energy", "model_logp", "step_size", "step_size_bar"):
+            np.testing.assert_allclose(dev[i][k], gold[k][i], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
+    coords = gold["coords"]
+    np.testing.assert_allclose(res["draws"][0][:5][:, coords], gold["draws_subset"][:5], rtol=1e-6, atol=1e-8)
+    res["step"].close()
+
+
+def test_c3_mvnormal_2048_nuts_parity():
+    """C3 (`configs[2]`): NUTS on the full 2048 x 2048 MvNormal against the oracle (Cholesky-solve log-density,
+    multivariate.py:158-185), 12 transitions: integers identical."""
+    from pymc_amd.sampling import sample
+
+    spec = models.mvnormal(n=2048)
+    tune, draws, seed = 8, 4, 12
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
+    f = ref_models.SpecLogpGrad(spec)
+    ref_draws, ref_stats = ref_sampler.sample_reference(f, [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    dev = res["warmup_stats"][0] + res["stats"][0]
+    for i in range(tune + draws):
+        for k in INT_KEYS:
+            assert int(dev[i][k]) == int(ref_stats[0][i][k]), (i, k, dev[i][k], ref_stats[0][i][k])
+    for i in range(4):
+        for k in ("mean_tree_accept", "energy", "model_logp"):
+            np.testing.assert_allclose(dev[i][k], ref_stats[0][i][k], rtol=1e-6, atol=1e-8, err_msg=f"{i} {k}")
+    res["step"].close()
+
+
+def test_c2s_four_chains_agree_with_oracle_chains_within_monte_carlo_error(c2s):
+    """`configs[1]` at the cache-resident size, 4 x (1000 + 1000) from fixed over-dispersed starts: the device chains and
+    the oracle chains (committed summary, `tests/golden/c2s_chains.npz`) are two Monte-Carlo estimates of the same
+    posterior.  Means agree within their joint standard errors, spreads agree, and the mixing diagnostics
+    (bulk-ESS, R-hat, tree sizes, adapted step size) are the same to within their own noise -- which is the evidence
+    that a small min-ESS on this model family belongs to the model + diagonal metric, not to the engine."""
+    from pymc_amd import stats as st
+    from pymc_amd.sampling import sample
+
+    gold = np.load(os.path.join(GOLDEN, "c2s_chains.npz"))
+    G, D, rpg, tune, draws, chains, seed, start_seed = (int(x) for x in gold["config"])
+    assert (G, D, rpg) == (1248, 8, 80)
+    rng = np.random.default_rng(start_seed)
+    starts = [rng.uniform(-1, 1, size=c2s.n) for _ in range(chains)]
+    initvals = [{"mu": s[:8], "sigma_log__": s[8:16], "z": s[16:].reshape(G, D)} for s in starts]
+    res = sample(draws=draws, tune=tune, chains=chains, model=c2s, init="adapt_diag", random_seed=seed, initvals=initvals, device=0)
+    d = res["draws"]
+    ess_dev, rhat_dev = st.ess_bulk_many(d), st.rhat_many(d)
+    ess_ref, rhat_ref = gold["ess_bulk"], gold["rhat"]
+    mean_dev, sd_dev = d.mean(axis=(0, 1)), d.std(axis=(0, 1), ddof=1)
+    # means: |difference| against the joint Monte-Carlo standard error (5 sigma + a floor for barely-mixing coordinates)
+    se = np.sqrt(sd_dev**2 / np.maximum(ess_dev, 4.0) + gold["sd"] ** 2 / np.maximum(ess_ref, 4.0))
+    zscore = np.abs(mean_dev - gold["mean"]) / se
+    assert np.mean(zscore > 3.0) < 0.02 and zscore.max() < 6.0, (np.mean(zscore > 3.0), zscore.max())
+    # spreads
+    ratio = sd_dev / gold["sd"]
+    assert np.all(np.abs(np.log(ratio[16:])) < 0.25) and np.all(np.abs(np.log(ratio[:16])) < 0.7), (ratio.min(), ratio.max())
+    # mixing diagnostics: medians within 15 %, the worst coordinates within a factor of 2.5
+    assert abs(np.log(np.median(ess_dev) / np.median(ess_ref))) < 0.15
+    assert abs(np.log(ess_dev.min() / ess_ref.min())) < np.log(2.5)
+    assert abs(np.log(np.median(ess_dev[:16]) / np.median(ess_ref[:16]))) < np.log(2.0)
+    assert abs(rhat_dev.max() - rhat_ref.max()) < 0.1 + 0.5 * (rhat_ref.max() - 1.0)
+    # sampler behaviour after tuning
+    ts_dev = np.array([[s["tree_size"] for s in chain] for chain in res["stats"]])
+    ts_ref = gold["stat_tree_size"][:, tune:]
+    assert abs(np.log(ts_dev.mean() / ts_ref.mean())) < 0.25
+    eps_dev = np.array([chain[-1]["step_size_bar"] for chain in res["stats"]])
+    eps_ref = gold["stat_step_size_bar"][:, -1]
+    assert abs(np.log(eps_dev.mean() / eps_ref.mean())) < 0.25
+    print(f"C2-S device: min ESS {ess_dev.min():.1f} (param {int(ess_dev.argmin())}), median {np.median(ess_dev):.0f}, max R-hat {rhat_dev.max():.3f}, "
+          f"mean tree {ts_dev.mean():.1f} | oracle: min ESS {ess_ref.min():.1f} (param {int(ess_ref.argmin())}), median {np.median(ess_ref):.0f}, "
+          f"max R-hat {rhat_ref.max():.3f}, mean tree {ts_ref.mean():.1f}")
+    res["step"].close()
+
+
+# ---------------------------------------------------------------------------
+# the group-aligned row pass (rows_ga_kernel.h) on shapes it is not selected for by default
+# ---------------------------------------------------------------------------
+
+def _ragged_spec(sizes, D=8, seed=4):
+    from pymc_amd.model_spec import ModelBuilder
+
+    rng = np.random.default_rng(seed)
+    G = len(sizes)
+    gidx = np.repeat(np.arange(G), sizes).astype("int32")
+    N = len(gidx)
+    X = rng.normal(size=(N, D))
+    y = (rng.random(N) < 0.4).astype("int8")
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.3, 1.5, shape=D)
+    sg = m.HalfNormal("sigma", 2.0, shape=D)
+    z = m.Normal("z", -0.1, 0.8, shape=(G, D))
+    m.HierLogitRows("y", X, y, gidx, mu, sg, z)
+    return m.build()
+
+
+@pytest.mark.parametrize("waves", [1, 2, 3, 4])
+def test_group_aligned_rows_on_ragged_empty_and_tiny_groups(waves, monkeypatch):
+    """`NUTS_ROWS_GA=2` forces the group-aligned pass wherever the model structure allows it: ragged groups, groups
+    without rows (first, middle, last), single-row groups, fewer tiles than waves, non-default prior parameters -- logp /
+    gradient against the NumPy oracle, a leapfrog trajectory, and a NUTS run with identical integers."""
+    from pymc_amd.sampling import sample
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    monkeypatch.setenv("NUTS_ROWS_GA_W", str(waves))
+    rng = np.random.default_rng(10 + waves)
+    for sizes in ([0, 5, 0, 0, 300, 1, 0, 40, 0], rng.integers(1, 700, size=23), [1], [128, 256, 127, 129, 1000], rng.integers(0, 90, size=70)):
+        spec = _ragged_spec(np.asarray(sizes), seed=len(sizes))
+        f = DeviceValueGradFunction(spec, device=0)
+        assert f.model_scalar("rows_group_aligned") == 1.0 and f.model_scalar("rows_waves") == waves
+        for q in [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.5 for _ in range(2)]:
+            lp, g = f._pytensor_function(q)
+            lp0, g0 = ref_models.evaluate(spec, q)
+            assert abs(lp - lp0) <= 1e-9 * max(1.0, abs(lp0)), (sizes, lp, lp0)
+            assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.abs(g0).max())
+        f.close()
+    spec = _ragged_spec(rng.integers(20, 400, size=12), seed=2)
+    var = rng.uniform(0.5, 2.0, size=spec.n)
+    q0, p0 = rng.normal(size=spec.n) * 0.3, rng.normal(size=spec.n)
+    integ = ref_sampler.Leapfrog(ref_sampler.DiagPotential(var), ref_models.SpecLogpGrad(spec))
+    s = integ.compute_state(q0, p0)
+    for _ in range(7):
+        s = integ.step(-0.04, s)
+    runs = []
+    for env in ({}, {"NUTS_FOLD_CTL": "0"}, {"NUTS_ROWS_ALTERNATE": "0"}):
+        for k in ("NUTS_FOLD_CTL", "NUTS_ROWS_ALTERNATE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        q1, p1, e1 = _leapfrog(spec, var, q0, p0, -0.04, 7)
+        np.testing.assert_allclose(q1, s.q, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(p1, s.p, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(e1, s.energy, rtol=1e-11)
+        runs.append((q1, p1, e1))
+    for r in runs[1:]:   # folded control and the order of the two half-streams are pure re-orderings
+        assert np.array_equal(r[0], runs[0][0]) and np.array_equal(r[1], runs[0][1]) and r[2] == runs[0][2]
+    for k in ("NUTS_FOLD_CTL", "NUTS_ROWS_ALTERNATE"):
+        monkeypatch.delenv(k, raising=False)
+    tune, draws, seed = 25, 15, 7
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
+    assert res["step"]._logp_dlogp_func.model_scalar("rows_group_aligned") == 1.0
+    ref_draws, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    dev = res["warmup_stats"][0] + res["stats"][0]
+    for i in range(tune + draws):
+        for k in INT_KEYS:
+            assert int(dev[i][k]) == int(ref_stats[0][i][k]), (i, k, dev[i][k], ref_stats[0][i][k])
+    np.testing.assert_allclose(res["draws"][0][:3], ref_draws[0, tune : tune + 3], rtol=1e-2, atol=1e-3)
+    res["step"].close()
+
+
+def test_dense_mass_matrix_on_a_group_aligned_model_switches_the_row_pass(monkeypatch):
+    """A dense potential (`scaling=<matrix>`) cannot ride in the group-aligned pass: the step method rebuilds the model with
+    the span-partitioned pass and samples as before."""
+    from pymc_amd.step import NUTS
+
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    spec = _ragged_spec(np.array([30, 50, 10]), seed=1)
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(spec.n, spec.n))
+    step = NUTS(model=spec, scaling=a @ a.T + spec.n * np.eye(spec.n), is_cov=True, rng=1, device=0)
+    assert step._logp_dlogp_func.model_scalar("rows_group_aligned") == 0.0
+    step.setup_chain(np.random.default_rng(5), 5, 5)
+    point = {v.value_name: np.zeros(v.shape) for v in spec.vars}
+    for _ in range(5):
+        point, st = step.step(point)
+    assert np.isfinite(st[0]["energy"])
+    step.close()

@@ -1,24 +1,48 @@
 #!/bin/bash
 # GPU-box round script: parity tests, bench, rocprofv3 kernel trace + PMC passes, summarised into gpurun_out/.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag>
-TAG=${1:-r01}
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [stages]   stages: any of t(ests) b(ench) p(rofile) c(3) s(C2-S) e(ss study)
+TAG=${1:-r02}
+STAGES=${2:-tbp}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)
 OUT=$R/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 nproc > $OUT/nproc_$TAG.txt
-timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu_$TAG.log
-timeout 900 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$?" >> $OUT/bench_$TAG.err
-cd /tmp
-PROF_ARGS="--steps 30 --warmup 60 --cpu-leapfrogs 0"
-rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o trace -- python $R/bench.py $PROF_ARGS > $OUT/prof_$TAG.log 2>&1; echo "prof rc=$?" >> $OUT/prof_$TAG.log
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 > $OUT/pmc_fetch_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 > $OUT/pmc_write_$TAG.log 2>&1
-{
-  echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py $PROF_ARGS   (tag $TAG)"
-  grep -E '^\{' $OUT/prof_$TAG.log | head -1
-  python $R/tools/rocpd_summary.py $OUT/prof_$TAG/trace_results.db --pmc $OUT/pmc_fetch_$TAG/pmc_results.db $OUT/pmc_write_$TAG/pmc_results.db
-} > $OUT/profile_$TAG.txt 2>&1
-rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG   # raw rocpd databases are large; the summary is what is kept
-tail -3 $OUT/pytest_gpu_$TAG.log; cat $OUT/bench_$TAG.json | head -c 600; echo; head -20 $OUT/profile_$TAG.txt
+HASH=$(python -c "import bench; print(bench.kernel_source_hash())")
+if [[ $STAGES == *t* ]]; then
+  timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -rA 2>&1 | grep -v "^PASSED\|^$" > $OUT/pytest_gpu_$TAG.log; echo "pytest rc=${PIPESTATUS[0]}" >> $OUT/pytest_gpu_$TAG.log
+fi
+if [[ $STAGES == *b* ]]; then
+  timeout 900 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$?" >> $OUT/bench_$TAG.err
+fi
+if [[ $STAGES == *p* ]]; then
+  cd /tmp
+  PROF_ARGS="--steps 30 --warmup 60 --cpu-leapfrogs 0"
+  rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o trace -- python $R/bench.py $PROF_ARGS > $OUT/prof_$TAG.log 2>&1; echo "prof rc=$?" >> $OUT/prof_$TAG.log
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 > $OUT/pmc_fetch_$TAG.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 > $OUT/pmc_write_$TAG.log 2>&1
+  {
+    echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py $PROF_ARGS   (tag $TAG, kernel source hash $HASH)"
+    grep -E '^\{' $OUT/prof_$TAG.log | head -1
+    python $R/tools/rocpd_summary.py $OUT/prof_$TAG/trace_results.db --pmc $OUT/pmc_fetch_$TAG/pmc_results.db $OUT/pmc_write_$TAG/pmc_results.db
+  } > $OUT/profile_$TAG.txt 2>&1
+  python $R/tools/rocpd_summary.py --traffic $OUT/pmc_fetch_$TAG/pmc_results.db $OUT/pmc_write_$TAG/pmc_results.db $OUT/traffic_$TAG.json k_rows $TAG $HASH
+  rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG   # raw rocpd databases are large; the summary is what is kept
+  cd $R
+fi
+if [[ $STAGES == *c* ]]; then
+  timeout 600 python bench.py --workload c3 > $OUT/bench_c3_$TAG.json 2> $OUT/bench_c3_$TAG.err; echo "bench rc=$?" >> $OUT/bench_c3_$TAG.err
+  cd /tmp; rm -rf $OUT/prof_c3_$TAG
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_c3_$TAG -o trace -- python $R/bench.py --workload c3 --steps 100 --warmup 200 --cpu-leapfrogs 0 > $OUT/prof_c3_$TAG.log 2>&1
+  { echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --workload c3 --steps 100 --warmup 200 --cpu-leapfrogs 0 (tag $TAG)"; grep -E '^\{' $OUT/prof_c3_$TAG.log | head -1
+    python $R/tools/rocpd_summary.py $OUT/prof_c3_$TAG/trace_results.db; } > $OUT/profile_c3_$TAG.txt 2>&1
+  rm -rf $OUT/prof_c3_$TAG; cd $R
+fi
+if [[ $STAGES == *s* ]]; then
+  timeout 600 python bench.py --rows-per-group 80 --cpu-leapfrogs 0 > $OUT/bench_c2s_$TAG.json 2> $OUT/bench_c2s_$TAG.err
+fi
+if [[ $STAGES == *e* ]]; then
+  timeout 900 python tools/ess_study.py > $OUT/ess_study_$TAG.json 2> $OUT/ess_study_$TAG.err
+fi
+tail -3 $OUT/pytest_gpu_$TAG.log 2>/dev/null; head -c 1500 $OUT/bench_$TAG.json 2>/dev/null; echo; head -24 $OUT/profile_$TAG.txt 2>/dev/null

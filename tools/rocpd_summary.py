@@ -49,11 +49,39 @@ def pmc_stats(path):
         print(f"{r[0][:70]:70s} {r[1]:>14s} {r[2]:6d} {r[3]:14.3f} {r[4]:14.3f}")
 
 
+def traffic_json(fetch_db, write_db, out_path, kernel_like, tag, src_hash):
+    """HBM bytes per launch of the dominant kernel from the two PMC passes (non-drained launches = the per-kernel maximum),
+    with the guide's gfx950 correction: read side = 2 x FETCH_SIZE (KiB), write side = WRITE_SIZE (KiB)."""
+    import json
+
+    def mx(path, counter):
+        cur = sqlite3.connect(path).cursor()
+        rows = list(cur.execute("select max(value), avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
+                                (counter, f"%{kernel_like}%")))
+        return rows[0]
+
+    f, w = mx(fetch_db, "FETCH_SIZE"), mx(write_db, "WRITE_SIZE")
+    if f[0] is None or w[0] is None:
+        return
+    out = {
+        "k_rows_bytes_per_launch": int(2 * f[0] * 1024 + w[0] * 1024),
+        "fetch_size_kib_max": f[0], "fetch_size_kib_avg": f[1], "write_size_kib_max": w[0], "write_size_kib_avg": w[1], "launches": f[2],
+        "kernel": kernel_like, "kernel_source_hash": src_hash,
+        "source": f"profiles/{tag}_profile.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), non-drained launches "
+                  "(per-kernel maximum); read side doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)",
+    }
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args[0] == "--traffic":   # --traffic <fetch.db> <write.db> <out.json> <kernel substring> <tag> <source hash>
+        traffic_json(*args[1:7])
+        sys.exit(0)
     kernel_stats(args[0])
     gap_stats(args[0])
     rest = args[1:]
     for a in rest:
         if a != "--pmc":
             pmc_stats(a)
+
