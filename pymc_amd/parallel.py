@@ -1,0 +1,94 @@
+"""One OS process per chain on one node (`pm.sample(cores > 1)`, pymc/sampling/parallel.py:352-524).
+
+The reference starts a worker process per chain and sends it the cloudpickled step method
+(`parallel.py:504-507`), the start point and the chain's generator state (`:163-167`).  Here the same happens with
+the device step: what travels is (model spec, options, potential, generators, sampling state); the worker picks
+its GPU (chain c -> device c mod n_devices), re-creates the engine handles on first use and samples its chain.
+`spawn` is the default start method (a forked HIP runtime is not usable in the child; cf. `parallel.py:113-126`).
+
+This is the single-node alternative to the `torch.distributed` launch of `pymc_amd.sampling` (one rank per GPU):
+independent chains need no collective, so plain processes and pipes are enough; the draws come back over the pipe.
+"""
+
+from __future__ import annotations
+
+import multiprocessing as mp
+import pickle
+import traceback
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+def _chain_worker(conn, step_blob, device, start, rng_blob, tune, draws, chain):
+    try:
+        import cloudpickle
+
+        from pymc_amd.sampling import sample_chain
+
+        step = cloudpickle.loads(step_blob)
+        if device is not None:
+            step._device = int(device)
+        rng = pickle.loads(rng_blob)
+        d, stats = sample_chain(step, start, rng, tune, draws)
+        state = step.sampling_state
+        step.close()
+        conn.send(("ok", chain, d, stats, state))
+    except BaseException as e:  # noqa: BLE001 -- reported to the parent, which raises (ParallelSamplingError in the reference)
+        conn.send(("error", chain, f"{type(e).__name__}: {e}", traceback.format_exc(), None))
+    finally:
+        conn.close()
+
+
+class ParallelSamplingError(RuntimeError):
+    """pymc/sampling/parallel.py:41-58."""
+
+    def __init__(self, message, chain):
+        super().__init__(message)
+        self._chain = chain
+
+
+def sample_in_processes(step, starts: Sequence[dict], rngs: Sequence[np.random.Generator], tune: int, draws: int,
+                        devices: Optional[Sequence[int]] = None, mp_ctx: str = "spawn", chains: Optional[Sequence[int]] = None):
+    """Run one chain per worker process.  Returns `(draws [chains][tune + draws][n], stats per chain, final sampling states)`.
+
+    `devices`: the GPU of each chain (default: chain c -> c mod visible devices).  Every worker starts from the state the
+    step object has NOW (the reference resets one step object between sequential chains the same way, mcmc.py:1411,1423),
+    so the result is the one sequential sampling would give."""
+    import cloudpickle
+
+    from pymc_amd import _lib
+
+    n_chains = len(starts)
+    chains = list(range(n_chains)) if chains is None else list(chains)
+    if devices is None:
+        ndev = max(1, _lib.load().nuts_device_count())
+        devices = [c % ndev for c in chains]
+    blob = cloudpickle.dumps(step)
+    ctx = mp.get_context(mp_ctx)
+    procs, conns = [], []
+    for k in range(n_chains):
+        parent, child = ctx.Pipe(duplex=False)
+        p = ctx.Process(target=_chain_worker, args=(child, blob, devices[k], starts[k], pickle.dumps(rngs[k]), tune, draws, chains[k]), daemon=True)
+        p.start()
+        child.close()
+        procs.append(p)
+        conns.append(parent)
+    out_draws: List[Optional[np.ndarray]] = [None] * n_chains
+    out_stats: List[Optional[list]] = [None] * n_chains
+    out_state: List[object] = [None] * n_chains
+    err = None
+    for k, conn in enumerate(conns):
+        try:
+            msg = conn.recv()
+        except EOFError:
+            msg = ("error", chains[k], "worker exited without a result", "", None)
+        if msg[0] == "ok":
+            out_draws[k], out_stats[k], out_state[k] = msg[2], msg[3], msg[4]
+        elif err is None:
+            err = msg
+    for p in procs:
+        p.join(timeout=60)
+    if err is not None:
+        raise ParallelSamplingError(f"Chain {err[1]} failed with: {err[2]}\n{err[3]}", err[1])
+    return np.stack(out_draws), out_stats, out_state

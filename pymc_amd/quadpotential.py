@@ -116,6 +116,7 @@ class QuadPotential:
     def __getstate__(self):   # a pending prefetch does not travel (cloudpickle of the step for worker processes)
         d = dict(self.__dict__)
         d.pop("_prefetch", None)
+        d["_step"] = None    # re-bound when the step re-creates its engine handles
         return d
 
     def stats(self):  # quadpotential.py:177-178

@@ -254,6 +254,7 @@ def sample(
     gather: bool = True,
     device: Optional[int] = None,
     cores: Optional[int] = None,
+    mp_ctx: Optional[str] = None,
     **step_kwargs,
 ):
     """Reduced `pm.sample` (mcmc.py:620-1190) returning raw arrays.
@@ -268,6 +269,11 @@ def sample(
     engine handles and stream; default min(4, chains on this rank) for such models, 1 otherwise (a C2-sized chain
     saturates the GPU by itself).  Every chain starts from the same `sampling_state` and its own generator, so the
     result does not depend on `cores`.
+
+    ``mp_ctx`` (mcmc.py `mp_ctx`: "spawn" / "forkserver"): run the chains of this rank in WORKER PROCESSES instead, one per
+    chain, chain c on GPU c mod (visible devices) -- the reference's `cores > 1` layout (parallel.py:352-524) and the
+    single-node way to use several GPUs without `torch.distributed`.  The step object is cloudpickled to the workers
+    (`pymc_amd/parallel.py`); the result is the one sequential sampling gives.
     """
     rank, world, local = _dist_info()
     spec = model
@@ -324,7 +330,16 @@ def sample(
     n_par = min(len(mine), cores if cores is not None else (4 if single_launch else 1))
     if pooled is not None or step_given or n_par < 1:
         n_par = 1
-    if n_par > 1:
+    if mp_ctx is not None and pooled is None and len(mine) > 0:
+        from pymc_amd.parallel import sample_in_processes
+
+        step.sampling_state = initial_state
+        d, st, _ = sample_in_processes(step, [points[c] for c in mine], [rngs[c] for c in mine], tune, draws, mp_ctx=mp_ctx, chains=mine,
+                                       devices=None if device is None else [device] * len(mine))
+        local_draws[:] = d
+        local_stats = st
+        t_sampling = sum(sum(x["perf_counter_diff"] for x in s_[tune:]) for s_ in st)
+    elif n_par > 1:
         from concurrent.futures import ThreadPoolExecutor
 
         # one step object (own model + chain handles, own stream) per concurrent chain; all start from `initial_state`

@@ -131,17 +131,30 @@ class _DeviceHMCBase:
         device: Optional[int] = None,
         blocked=True,
         compile_kwargs=None,
+        defer_device=False,
         **unknown,
     ):
+        """`defer_device=True` builds the host side only; the engine handles (model + chain on the GPU) are created on
+        first use.  That is also the state an unpickled step is in (`__setstate__`): a step method travels to a worker
+        process as (model spec, options, potential, generators, sampling state) and re-creates its handles there
+        (pymc/sampling/parallel.py:504-507 cloudpickles the step for `spawn` / `forkserver` workers)."""
         if unknown:   # a typo or an unsupported option must not pass silently
             raise TypeError(f"{type(self).__name__}.__init__() got unexpected keyword argument(s): {sorted(unknown)}")
         spec = model.spec if hasattr(model, "spec") else model
-        if logp_dlogp_func is None:
-            if not isinstance(spec, ModelSpec):
-                raise TypeError("model must be a pymc_amd ModelSpec (or carry `.spec`) when logp_dlogp_func is not given")
-            logp_dlogp_func = DeviceValueGradFunction(spec, device=device)
-        self._logp_dlogp_func = logp_dlogp_func
-        self.spec = logp_dlogp_func.spec
+        if logp_dlogp_func is not None:
+            spec = logp_dlogp_func.spec
+        if not isinstance(spec, ModelSpec):
+            raise TypeError("model must be a pymc_amd ModelSpec (or carry `.spec`) when logp_dlogp_func is not given")
+        # (the reference accepts only ONE of the two class attributes, compound.py:62-99; `BlockedStep.__new__` derives the
+        # deprecated list per instance, and so does this class when it is used without that base)
+        if not self.__dict__.get("stats_dtypes"):
+            self.stats_dtypes = [{k: v[0] for k, v in self.stats_dtypes_shapes.items()}]
+        self._func = logp_dlogp_func
+        self._chain_h = None
+        self._device = device if logp_dlogp_func is None else logp_dlogp_func.device
+        self._pending_state = None
+        self._pending_extra = None
+        self.spec = spec
         self._model = model
         self.vars = list(self.spec.vars) if vars is None else list(vars)
         self.var_names = tuple(v.value_name for v in self.vars)
@@ -155,6 +168,8 @@ class _DeviceHMCBase:
         self.target_accept = target_accept
         self.max_treedepth = max_treedepth
         self.early_max_treedepth = early_max_treedepth
+        self._cfg = dict(step_scale=step_scale, Emax=Emax, target_accept=target_accept, gamma=gamma, k=k, t0=t0,
+                         adapt_step_size=int(adapt_step_size), max_treedepth=max_treedepth, early_max_treedepth=early_max_treedepth)
         # base_hmc.py:166-180: default potential / `scaling`
         if scaling is not None and potential is not None:
             raise ValueError("Can not specify both potential and scaling.")
@@ -163,28 +178,67 @@ class _DeviceHMCBase:
         elif potential is None:  # base_hmc.py:171-180 -> quad_potential(scaling, is_cov)
             potential = quad_potential(np.asarray(scaling, dtype="float64"), is_cov, rng=self.rng.spawn(1)[0])
         self.potential = potential
-        # a dense mass matrix (velocity = C p between the half kicks) cannot ride in the group-aligned row pass
-        if getattr(potential, "_dense", False) and logp_dlogp_func.model_scalar("rows_group_aligned"):
-            logp_dlogp_func = DeviceValueGradFunction(self.spec, device=logp_dlogp_func.device, rows_group_aligned=False)
-            self._logp_dlogp_func = logp_dlogp_func
-        lib = _lib.load()
-        cfg = _lib.ChainConfig()
-        lib.nuts_chain_config_default(C.byref(cfg))
-        cfg.step_scale, cfg.Emax, cfg.target_accept = step_scale, Emax, target_accept
-        cfg.gamma, cfg.k, cfg.t0 = gamma, k, t0
-        cfg.adapt_step_size = int(adapt_step_size)
-        cfg.max_treedepth, cfg.early_max_treedepth = max_treedepth, early_max_treedepth
-        keep = potential._fill_config(cfg)
-        self._chain = lib.nuts_chain_create(logp_dlogp_func._handle, C.byref(cfg))
-        del keep
-        if not self._chain:
-            raise _lib.EngineError(f"nuts_chain_create failed: {_lib.last_error()}")
-        potential._bind(self)
-        self.tune = True
+        self._tune = True
         self._n_uniforms = (1 << max(max_treedepth, early_max_treedepth)) + 2 * max(max_treedepth, early_max_treedepth) + 4
         self._q_out = np.empty(n)
         self._g_out = np.empty(n)
         self._num_divs_sample = 0
+        if not defer_device:
+            self._materialize()
+
+    # ---- engine handles: created on first use, re-created after unpickling ----------
+    @property
+    def _logp_dlogp_func(self) -> DeviceValueGradFunction:
+        if self._func is None:
+            # a dense mass matrix (velocity = C p between the half kicks) cannot ride in the group-aligned row pass
+            self._func = DeviceValueGradFunction(self.spec, device=self._device, rows_group_aligned=not getattr(self.potential, "_dense", False))
+            if self._pending_extra:
+                self._func.set_extra_values(self._pending_extra)
+        return self._func
+
+    @property
+    def _chain(self):
+        if self._chain_h is None:
+            self._materialize()
+        return self._chain_h
+
+    def _materialize(self):
+        if self._chain_h is not None:
+            return
+        func = self._logp_dlogp_func
+        if getattr(self.potential, "_dense", False) and func.model_scalar("rows_group_aligned"):
+            func = self._func = DeviceValueGradFunction(self.spec, device=func.device, rows_group_aligned=False)
+        lib = _lib.load()
+        cfg = _lib.ChainConfig()
+        lib.nuts_chain_config_default(C.byref(cfg))
+        for key, val in self._cfg.items():
+            setattr(cfg, key, val)
+        keep = self.potential._fill_config(cfg)
+        chain = lib.nuts_chain_create(func._handle, C.byref(cfg))
+        del keep
+        if not chain:
+            raise _lib.EngineError(f"nuts_chain_create failed: {_lib.last_error()}")
+        self._chain_h = chain
+        self.potential._bind(self)
+        lib.nuts_chain_set_tune(chain, int(self._tune))
+        if self._pending_state is not None:
+            state, self._pending_state = self._pending_state, None
+            self.sampling_state = state
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        if self._chain_h is not None:
+            d["_pending_state"] = self.sampling_state
+        if self._func is not None and self._func._extra_are_set:
+            d["_pending_extra"] = self._func.get_extra_values()
+        d["_chain_h"] = None
+        d["_func"] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._chain_h = None
+        self._func = None
 
     # ---- tuning control (compound.py:229-231, base_hmc.py:290-298) -------------
     @property
@@ -194,8 +248,8 @@ class _DeviceHMCBase:
     @tune.setter
     def tune(self, value):
         self._tune = bool(value)
-        if getattr(self, "_chain", None):
-            _lib.load().nuts_chain_set_tune(self._chain, int(self._tune))
+        if self.__dict__.get("_chain_h"):
+            _lib.load().nuts_chain_set_tune(self._chain_h, int(self._tune))
 
     def stop_tuning(self):
         self.tune = False
@@ -240,7 +294,7 @@ class _DeviceHMCBase:
 
     # ---- dict <-> flat (arraystep.py:107-122) ------------------------------------
     def step(self, point: PointType):
-        extra = self._logp_dlogp_func.spec.extra
+        extra = self.spec.extra
         if extra:   # arraystep.py:109-111: `shared.set_value(point[name])` for the non-gradient value variables
             self._logp_dlogp_func.set_extra_values({name: point[name] for name in extra})
         sub = {name: point[name] for name in self.var_names}
@@ -253,6 +307,14 @@ class _DeviceHMCBase:
     # ---- sampling_state (state.py:54-121) ----------------------------------------
     @property
     def sampling_state(self) -> BaseHMCState:
+        if self._chain_h is None:
+            # no engine handles yet: the state that will be applied when they are created (an empty engine blob = a freshly
+            # created chain)
+            if self._pending_state is not None:
+                st = copy.deepcopy(self._pending_state)
+                st.rng, st.potential_rng = _rng_state(self.rng), _rng_state(self.potential.rng)
+                return st
+            return BaseHMCState(list(self.var_names), _rng_state(self.rng), _rng_state(self.potential.rng), b"", self.potential._host_state())
         lib = _lib.load()
         size = lib.nuts_chain_state_size(self._chain)
         buf = C.create_string_buffer(size)
@@ -264,6 +326,18 @@ class _DeviceHMCBase:
     def sampling_state(self, state: BaseHMCState):
         if list(state.var_names) != list(self.var_names):
             raise ValueError("The received sampling state must have the same values for the frozen fields. Field 'var_names' differs.")
+        if self._chain_h is None:
+            self._pending_state = copy.deepcopy(state)
+            self.rng = _rng_from_state(state.rng)
+            self.potential.set_rng(_rng_from_state(state.potential_rng))
+            return
+        if not state.engine_blob:   # the state of a step whose handles had never been created: a fresh chain
+            _lib.check(_lib.load().nuts_chain_reset_tuning(self._chain_h), "nuts_chain_reset_tuning")
+            self.potential._host_reset()
+            self.rng = _rng_from_state(state.rng)
+            self.potential.set_rng(_rng_from_state(state.potential_rng))
+            self._tune = True
+            return
         buf = C.create_string_buffer(state.engine_blob, len(state.engine_blob))
         _lib.check(_lib.load().nuts_chain_set_state(self._chain, buf), "nuts_chain_set_state")
         self.rng = _rng_from_state(state.rng)
@@ -273,9 +347,10 @@ class _DeviceHMCBase:
         self._tune = bool(self._scalar("tune"))
 
     def close(self):
-        if getattr(self, "_chain", None):
-            _lib.load().nuts_chain_destroy(self._chain)
-            self._chain = None
+        h = self.__dict__.get("_chain_h")
+        if h:
+            _lib.load().nuts_chain_destroy(h)
+            self._chain_h = None
 
     def __del__(self):
         try:
@@ -319,7 +394,6 @@ class NUTS(_DeviceHMCBase):
         "reached_max_treedepth": (bool, []),
         "warning": (SamplerWarning, None),
     }
-    stats_dtypes = [{k: v[0] for k, v in stats_dtypes_shapes.items()}]
 
     @staticmethod
     def competence(var, has_grad):  # nuts.py:227-232
@@ -385,7 +459,7 @@ class NUTS(_DeviceHMCBase):
     @property
     def can_draw_many(self) -> bool:
         """True when `draw_many` applies: tuning is over and the model runs on the single-launch path."""
-        return (not self.tune) and not self._logp_dlogp_func.spec.extra and bool(self._scalar("single_launch"))
+        return (not self.tune) and not self.spec.extra and bool(self._scalar("single_launch"))
 
     def draw_many(self, point: PointType, K: int):
         """K consecutive transitions from `point` in one launch (`nuts_chain_draw_many`).  Returns
@@ -476,7 +550,6 @@ class HamiltonianMC(_DeviceHMCBase):
         "smallest_eigval": (np.float64, []),
         "warning": (SamplerWarning, None),
     }
-    stats_dtypes = [{k: v[0] for k, v in stats_dtypes_shapes.items()}]
 
     def __init__(self, vars=None, path_length=2.0, max_steps=1024, **kwargs):
         kwargs.setdefault("target_accept", 0.65)  # hmc.py:121

@@ -194,6 +194,8 @@ def load():
         NUTS=nuts.NUTS, HamiltonianMC=hmc.HamiltonianMC, quadpotential=qp, integration=integ, base_hmc=base,
         RaveledVars=blocking.RaveledVars, DictToArrayBijection=blocking.DictToArrayBijection, util=util,
         step_sizes=sys.modules["pymc.step_methods.step_sizes"], exceptions=sys.modules["pymc.exceptions"],
+        compound=sys.modules["pymc.step_methods.compound"], state=sys.modules["pymc.step_methods.state"],
+        arraystep=sys.modules["pymc.step_methods.arraystep"],
     )
     return types.SimpleNamespace(**_LOADED)
 

@@ -721,7 +721,8 @@ def test_pooled_adaptation_roundtrip_over_rccl():
             p, _ = step.step(p)
         before = {k: step._vector(k) for k in ("fg_mean", "fg_m2", "bg_mean", "bg_m2")}
         cnt = (step._scalar("fg_count"), step._scalar("bg_count"))
-        pool = PooledAdaptation(spec.n, torch.device("cuda", 0), window=101)
+        assert int(step._scalar("window_switched")) == 1   # draw 101 crossed the window boundary (quadpotential.py:350-353)
+        pool = PooledAdaptation(spec.n, torch.device("cuda", 0))
         pool.after_tuning_draw(step, 101)
         for k, v in before.items():
             np.testing.assert_allclose(step._vector(k), v, rtol=1e-14, atol=1e-300)
