@@ -265,8 +265,7 @@ def main():
     step.reset_tuning()
     point = points[rank]
     step.iter_count = 0
-    for i in range(W):
-        point, _ = step.step(point)
+    _, _, point = sample_draws(step, point, W)
     step.stop_tuning()
 
     step.profile(True)

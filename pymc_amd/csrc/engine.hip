@@ -78,6 +78,7 @@ struct nuts_model {
   int rows_grid = 0, mvn_grid = 0, ept = 1;
   int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
   int vector_one_xcd = 0;
+  int ga_variant = 32;         // 10 x (waves per SIMD of the register budget) + tiles in flight per wave
   int ga_struct_ok = 0;        // the spec is exactly what the group-aligned row pass evaluates in closed form (compile_spec)
   int ga_par = 0;              // parity of the last group-aligned launch (its block partials / local parts are double-buffered)
   int explicit_pre = 0;        // the position must be materialised before the dense pass (MvNormal node)
@@ -131,14 +132,19 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
     const int par = (m->ga_par ^= 1);
     const dim3 grid(m->rows_grid + (fold ? 1 : 0)), block(WAVE * md.lg.ga_w);
-#define GA_LAUNCH(DD, RR) hipLaunchKernelGGL((k_rows_ga<DD, RR>), grid, block, 0, m->stream, md, A, io, j, rev, fold, par, d, Emax, max_depth, st)
-#define GA_BY_D(RR)                      \
-    switch (md.lg.D) {                   \
-      case 8: GA_LAUNCH(8, RR); break;   \
-      case 4: GA_LAUNCH(4, RR); break;   \
-      default: GA_LAUNCH(2, RR); break;  \
+    GaArgs ga{md, A, io, j, rev, fold, par, d, max_depth, Emax, st};
+#define GA_LAUNCH(DD, OO, PP) hipLaunchKernelGGL((k_rows_ga<DD, 2, OO, PP>), grid, block, 0, m->stream, ga)
+#define GA_BY_D(OO, PP)                      \
+    switch (md.lg.D) {                       \
+      case 8: GA_LAUNCH(8, OO, PP); break;   \
+      case 4: GA_LAUNCH(4, OO, PP); break;   \
+      default: GA_LAUNCH(2, OO, PP); break;  \
     }
-    if (m->rows_rpl == 2) { GA_BY_D(2) } else { GA_BY_D(4) }
+    switch (m->ga_variant) {   // (register budget, tiles in flight): see rows_ga_kernel.h
+      case 42: GA_BY_D(4, 2) break;
+      case 33: GA_BY_D(3, 3) break;
+      default: GA_BY_D(3, 2) break;
+    }
 #undef GA_BY_D
 #undef GA_LAUNCH
   } else if (md.has_logit) {
@@ -432,26 +438,63 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         tile0[g + 1] = tile0[g] + (int32_t)T;
       }
       const int64_t n_tiles = tile0[lg.G];
-      int W = std::min(GA_MAXW, (16 * cus) / std::max(lg.G, 1));   // all G workgroups resident at once (16 waves per CU)
+      m->ga_variant = env_int("NUTS_GA_VARIANT", 32);
+      if (m->ga_variant != 42 && m->ga_variant != 33) m->ga_variant = 32;
+      const int occ = m->ga_variant / 10;
+      int W = std::min(GA_MAXW, (4 * occ * cus) / std::max(lg.G, 1));   // all G workgroups resident at once (4 occ waves per CU)
+      if (env_int("NUTS_ROWS_GA_W", 0) > 0) W = std::max(1, std::min(GA_MAXW, env_int("NUTS_ROWS_GA_W", 0)));
       const double meanT = (double)n_tiles / std::max(lg.G, 1);
       bool use = false;
-      if (want >= 2) { use = m->ga_struct_ok && m->ept == 1; W = std::max(1, std::min(GA_MAXW, env_int("NUTS_ROWS_GA_W", 3))); }
-      else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && W >= 1 && lg.G >= 2 * cus && meanT >= 3.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
-      if (use && n_tiles * (int64_t)SPAN < ((int64_t)1 << 31)) {
+      if (want >= 2) { use = m->ga_struct_ok && m->ept == 1; W = std::max(1, W); }
+      else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && W >= 1 && lg.G >= 2 * cus && meanT >= 4.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
+      if (use && n_tiles * (int64_t)SPAN < ((int64_t)1 << 31) && lg.G <= 32 * 8 * GA_MAXCHUNK) {
         lg.ga = 1; lg.ga_w = W;
         lg.ga_bsz = (lg.G + 31) / 32;
+        lg.ga_flags = env_int("NUTS_GA_FLAGS", 0);
+        lg.ga_T_uni = 0; lg.ga_ng_uni = 0;
+        {
+          bool uni = lg.G > 0;
+          for (int g = 1; g < lg.G; ++g) uni = uni && (gptr[g + 1] - gptr[g] == gptr[1] - gptr[0]);
+          if (uni && maxT > 0) { lg.ga_T_uni = (int32_t)maxT; lg.ga_ng_uni = gptr[1] - gptr[0]; }
+        }
         lg.ga_nblk = (lg.G + lg.ga_bsz - 1) / lg.ga_bsz;
-        lg.Npad = n_tiles * SPAN; lg.n_spans = n_tiles;
-        std::vector<double> xt((size_t)D * std::max<int64_t>(lg.Npad, 1), 0.0);
-        yy.assign(std::max<int64_t>(lg.Npad, 1), 0);
-        for (int g = 0; g < lg.G; ++g)
-          for (int64_t i = gptr[g]; i < gptr[g + 1]; ++i) {
-            const int64_t r = i - gptr[g], sp = tile0[g] + r / SPAN, rr = r % SPAN;
-            for (int d = 0; d < D; ++d) xt[((size_t)sp * D + d) * SPAN + rr] = s->rows_X[i * D + d];
-            yy[(size_t)sp * SPAN + rr] = s->rows_y[i];
+        // chunk (g, w) = the tiles wave w of workgroup g streams, [w T_g / W, (w + 1) T_g / W) -- the split the kernel makes.  Chunks
+        // are placed one after the other with `GA_SKEW` doubles (8448 B = 33 x 256 B) between them, so consecutive chunk starts
+        // differ by an ODD multiple of 256 B modulo any power-of-two channel interleave.
+        const int64_t TS = (int64_t)D * SPAN, GA_SKEW = env_int("NUTS_GA_SKEW", 1056);
+        std::vector<int64_t> coff((size_t)lg.G * W, 0);
+        int64_t pos = 0, max_ct = 0;
+        for (int g = 0; g < lg.G; ++g) {
+          const int64_t T = tile0[g + 1] - tile0[g];
+          for (int w = 0; w < W; ++w) {
+            const int64_t ct = (int64_t)(w + 1) * T / W - (int64_t)w * T / W;
+            coff[(size_t)g * W + w] = pos;
+            pos += ct * TS + GA_SKEW;
+            max_ct = std::max(max_ct, ct);
           }
+        }
+        lg.ga_cstride_uni = 0;
+        if (lg.ga_T_uni > 0 && lg.ga_T_uni % W == 0) {   // equal chunks: offsets follow from the chunk index
+          lg.ga_cstride_uni = (lg.ga_T_uni / W) * TS + GA_SKEW;
+        } else lg.ga_T_uni = 0;
+        lg.Npad = n_tiles * SPAN; lg.n_spans = n_tiles;
+        std::vector<double> xt((size_t)std::max<int64_t>(pos, 1), 0.0);
+        yy.assign((size_t)std::max<int64_t>(pos / D + SPAN, 1), 0);
+        for (int g = 0; g < lg.G; ++g) {
+          const int64_t T = tile0[g + 1] - tile0[g];
+          for (int64_t i = gptr[g]; i < gptr[g + 1]; ++i) {
+            const int64_t r = i - gptr[g], t = r / SPAN, rr = r % SPAN;
+            int w = (int)(((t + 1) * W - 1) / std::max<int64_t>(T, 1));          // the wave whose range [w T / W, (w + 1) T / W) holds tile t
+            while (w > 0 && (int64_t)w * T / W > t) --w;
+            while (w + 1 < W && (int64_t)(w + 1) * T / W <= t) ++w;
+            const int64_t base = coff[(size_t)g * W + w] + (t - (int64_t)w * T / W) * TS;
+            for (int d = 0; d < D; ++d) xt[(size_t)(base + (int64_t)d * SPAN + rr)] = s->rows_X[i * D + d];
+            yy[(size_t)(base / D + rr)] = s->rows_y[i];
+          }
+        }
         lg.Xt = m->keep(dev_upload(xt.data(), xt.size()));
         lg.y = m->keep(dev_upload(yy.data(), yy.size()));
+        lg.ga_coff = m->keep(dev_upload(coff.data(), coff.size()));
         lg.ga_tile0 = m->keep(dev_upload(tile0.data(), tile0.size()));
         lg.ga_part = m->keep(dev_alloc<double>((size_t)lg.G * PART_STRIDE));
         lg.ga_bpart = m->keep(dev_alloc<double>(2 * (size_t)lg.ga_nblk * PART_STRIDE));
@@ -741,6 +784,9 @@ struct nuts_chain {
   double last_logp = 0.0;
   DrawOut* do_dev = nullptr;
   DrawOut* do_host = nullptr;
+  DrawOutMapped* dom_host = nullptr;   // pinned + device-mapped copy of the last draw's record (multi-draw calls)
+  DrawOutMapped* dom_dev = nullptr;
+  unsigned dom_seq = 0;
   double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
   int64_t cache_epoch = -1;      // model data epoch the start-state cache belongs to
   int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
@@ -852,11 +898,14 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
       hipHostMalloc((void**)&c->out_host, 2 * (size_t)n * sizeof(double), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&c->st_host, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->st_dev, c->st_host, 0) != hipSuccess ||
-      hipHostMalloc((void**)&c->do_host, sizeof(DrawOut), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&c->do_host, sizeof(DrawOut), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&c->dom_host, sizeof(DrawOutMapped), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->dom_dev, c->dom_host, 0) != hipSuccess) {
     g_err = "pinned host allocation failed"; nuts_chain_destroy(c); return nullptr;
   }
   hipMemset(A.ctl, 0, sizeof(Ctl));
   std::memset(c->st_host, 0, sizeof(HostStatus));
+  std::memset(c->dom_host, 0, sizeof(DrawOutMapped));
   c->step_size = cfg->step_scale / std::pow((double)n, 0.25);  // base_hmc.py:161
   c->da = DualAvg{c->step_size, cfg->target_accept, cfg->gamma, cfg->k, cfg->t0, 0, 0, 0, 0, 1};
   c->da.reset();
@@ -872,6 +921,7 @@ extern "C" void nuts_chain_destroy(nuts_chain* c) {
   if (c->out_host) hipHostFree(c->out_host);
   if (c->st_host) hipHostFree(c->st_host);
   if (c->do_host) hipHostFree(c->do_host);
+  if (c->dom_host) hipHostFree(c->dom_host);
   if (c->many_in_host) hipHostFree(c->many_in_host);
   if (c->many_out_host) hipHostFree(c->many_out_host);
   if (c->many_in_dev) hipFree(c->many_in_dev);
@@ -989,7 +1039,7 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
                      cached ? (const double*)c->out_dev : (const double*)nullptr, cached ? (const double*)(c->out_dev + n) : (const double*)nullptr,
                      c->dense);
   hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, c->kin_part, step_size, dir_forced, max_depth, c->st_dev,
-                     cached ? 1 : 0, c->last_logp);
+                     cached ? 1 : 0, c->last_logp, (const DrawOut*)nullptr);
   return NUTS_OK;
 }
 
@@ -1085,10 +1135,119 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   c->leapfrogs++;
 }
 
+// The doubling loop of one transition (NUTS._hamiltonian_step, nuts.py:204-225): queue the leaves of each doubling, wait for the
+// status word of its last leaf.  `uniforms`: the host copy of the pre-drawn `step.rng.random()` values of THIS draw.
+static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int max_depth, unsigned* flags_out, bool* exhausted_out) {
+  using clk = std::chrono::steady_clock;
+  int rc = NUTS_OK;
+  bool exhausted = true;
+  // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
+  // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
+  unsigned flags = 0;
+  Geometry gm{uniforms[0] < 0.5 ? 1 : -1, 0, 0, 0, 0.0};
+  gm.eps = gm.dir > 0 ? step_size : -step_size;
+  // geometry of the doubling after `g` (which had 2^d leaves) once its direction is known (nuts.py:347-362)
+  auto next_geometry = [&](const Geometry& g, int d, int dir) {
+    Geometry r = g;
+    if (g.dir > 0) r.right += 1 << d; else r.left -= 1 << d;   // the finished subtree's far end is the new edge state
+    r.dir = dir;
+    r.edge = dir > 0 ? r.right : r.left;
+    r.eps = dir > 0 ? step_size : -step_size;
+    return r;
+  };
+  auto enqueue_doubling = [&](const Geometry& g, int d) {
+    const int nleaf = 1 << d;
+    ensure_logs(c, (2 << d) + d + 1);   // this doubling reads uniform indices < 2^(d+1) + d + 1
+    const int seq = ++c->seq;
+    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, g, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
+    return seq;
+  };
+  // Look-ahead for the short doublings, where the host round trip (status word over PCIe, then the first launch of
+  // the next doubling) is comparable to the doubling itself: a doubling that runs to completion consumes a fixed
+  // number of uniforms (2^d - 1 merges, the `extend` acceptance, the next direction), so the direction of doubling
+  // d+1 is uniforms[2^(d+1) + d] whenever it is needed at all, and its launches can be queued before the status of
+  // doubling d arrives.  If the tree stops at d they drain as no-ops behind the `aborted` flag.  Only done as far as
+  // the previous draw's tree went, so a wasted look-ahead is rare.  The prediction is checked against the device.
+  const int spec = std::min(c->spec_max, c->last_depth - 1);
+  Geometry ahead{};
+  int ahead_seq = 0;
+  int seq = enqueue_doubling(gm, 0);
+  int depth_done = 0;
+  for (int d = 0; d < max_depth; ++d) {
+    if (d + 1 < max_depth && d + 1 <= spec) {
+      ahead = next_geometry(gm, d, uniforms[(2 << d) + d] < 0.5 ? 1 : -1);
+      ahead_seq = enqueue_doubling(ahead, d + 1);
+    } else ahead_seq = 0;
+    const auto tw0 = clk::now();
+    rc = wait_status(c, seq, &flags);
+    c->t_wait += std::chrono::duration<double>(clk::now() - tw0).count();
+    if (rc) return rc;
+    depth_done = d + 1;
+    if (flags & ST_BAD_ENERGY) break;
+    if (flags & (ST_DIVERGING | ST_TURNING)) { exhausted = false; break; }
+    if (d + 1 >= max_depth) break;
+    const int dir = (flags & ST_DIR_POS) ? 1 : -1;
+    if (ahead_seq) {
+      if (ahead.dir != dir) { g_err = "internal error: look-ahead mispredicted the direction of a doubling"; return NUTS_E_HIP; }
+      gm = ahead; seq = ahead_seq;
+    } else {
+      gm = next_geometry(gm, d, dir);
+      seq = enqueue_doubling(gm, d + 1);
+    }
+  }
+  c->last_depth = depth_done;
+  *flags_out = flags;
+  *exhausted_out = exhausted;
+  return NUTS_OK;
+}
+
 // the single-launch path (small_kernel.h): one workgroup, one thread per parameter
 static void launch_small(nuts_chain* c, const ArenaDev& A, const SmallDrawArgs& a) {
   if (c->n <= 256) hipLaunchKernelGGL(k_small_draw<256>, dim3(1), dim3(256), 0, c->m->stream, c->m->md, A, a);
   else hipLaunchKernelGGL(k_small_draw<512>, dim3(1), dim3(512), 0, c->m->stream, c->m->md, A, a);
+}
+
+// What the host does after a transition (nuts.py:478-489, base_hmc.py:238-282): step-size adaptation, mass-matrix update
+// (a kernel), divergence bookkeeping, the statistics record.  `result_dev`: (q, grad) of the proposal on the device.
+static int finish_draw_host(nuts_chain* c, const DrawOut& o, bool adapt, bool exhausted, const double* result_dev, int64_t evals,
+                            double perf_start, double perf_diff, double cpu_diff, nuts_draw_stats* stats) {
+  const int n = c->n;
+  ArenaDev& A = c->A;
+  const double accept = std::exp(o.log_accept_sum) / o.n_proposals;
+  c->da.update(accept, adapt);
+  int rc = potential_update(c, result_dev);
+  if (rc) return rc;
+  const bool diverging = o.diverging != 0;
+  if (diverging) {   // keep the leaf the integrator started from and the one it diverged to (base_hmc.py:249-258)
+    const int dir = o.div_t > 0 ? 1 : -1;   // a leaf's index is its parent's + sign(eps) and the start state is 0
+    c->div_source.resize(n); c->div_dest.resize(n);
+    HIPCHK(hipMemcpy(c->div_dest.data(), A.Q + (int64_t)(o.div_t & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(c->div_source.data(), A.Q + (int64_t)((o.div_t - dir) & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (!c->tune) c->divergences += diverging;
+  c->iter_count += 1;
+  std::memset(stats, 0, sizeof(*stats));
+  stats->depth = o.depth;
+  stats->step_size = std::exp(c->da.log_step);
+  stats->step_size_bar = std::exp(c->da.log_bar);
+  stats->mean_tree_accept = accept;
+  stats->tree_size = o.n_proposals;
+  stats->diverging = diverging;
+  stats->reached_max_treedepth = (exhausted && !c->tune) ? 1 : 0;  // nuts.py:220-221
+  stats->divergences = c->divergences;
+  stats->energy_error = o.energy - o.E0;
+  stats->energy = o.energy;
+  stats->max_energy_error = o.max_energy_change;
+  stats->model_logp = o.logp;
+  stats->index_in_trajectory = o.proposal;
+  stats->n_uniforms_consumed = o.cursor;
+  stats->warning = diverging ? 1 : 0;
+  stats->divergence_energy_change = o.div_dE;
+  stats->n_model_evals = evals;
+  stats->perf_counter_start = perf_start;
+  stats->perf_counter_diff = perf_diff;
+  stats->process_time_diff = cpu_diff;
+  return NUTS_OK;
 }
 
 extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
@@ -1146,61 +1305,9 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   if (rc) return rc;
   const auto tb = clk::now();
   c->t_begin += std::chrono::duration<double>(tb - t0).count();
-  // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
-  // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
   unsigned flags = 0;
-  Geometry gm{uniforms[0] < 0.5 ? 1 : -1, 0, 0, 0, 0.0};
-  gm.eps = gm.dir > 0 ? step_size : -step_size;
-  // geometry of the doubling after `g` (which had 2^d leaves) once its direction is known (nuts.py:347-362)
-  auto next_geometry = [&](const Geometry& g, int d, int dir) {
-    Geometry r = g;
-    if (g.dir > 0) r.right += 1 << d; else r.left -= 1 << d;   // the finished subtree's far end is the new edge state
-    r.dir = dir;
-    r.edge = dir > 0 ? r.right : r.left;
-    r.eps = dir > 0 ? step_size : -step_size;
-    return r;
-  };
-  auto enqueue_doubling = [&](const Geometry& g, int d) {
-    const int nleaf = 1 << d;
-    ensure_logs(c, (2 << d) + d + 1);   // this doubling reads uniform indices < 2^(d+1) + d + 1
-    const int seq = ++c->seq;
-    for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, g, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
-    return seq;
-  };
-  // Look-ahead for the short doublings, where the host round trip (status word over PCIe, then the first launch of
-  // the next doubling) is comparable to the doubling itself: a doubling that runs to completion consumes a fixed
-  // number of uniforms (2^d - 1 merges, the `extend` acceptance, the next direction), so the direction of doubling
-  // d+1 is uniforms[2^(d+1) + d] whenever it is needed at all, and its launches can be queued before the status of
-  // doubling d arrives.  If the tree stops at d they drain as no-ops behind the `aborted` flag.  Only done as far as
-  // the previous draw's tree went, so a wasted look-ahead is rare.  The prediction is checked against the device.
-  const int spec = std::min(c->spec_max, c->last_depth - 1);
-  Geometry ahead{};
-  int ahead_seq = 0;
-  int seq = enqueue_doubling(gm, 0);
-  int depth_done = 0;
-  for (int d = 0; d < max_depth; ++d) {
-    if (d + 1 < max_depth && d + 1 <= spec) {
-      ahead = next_geometry(gm, d, uniforms[(2 << d) + d] < 0.5 ? 1 : -1);
-      ahead_seq = enqueue_doubling(ahead, d + 1);
-    } else ahead_seq = 0;
-    const auto tw0 = clk::now();
-    rc = wait_status(c, seq, &flags);
-    c->t_wait += std::chrono::duration<double>(clk::now() - tw0).count();
-    if (rc) return rc;
-    depth_done = d + 1;
-    if (flags & ST_BAD_ENERGY) break;
-    if (flags & (ST_DIVERGING | ST_TURNING)) { exhausted = false; break; }
-    if (d + 1 >= max_depth) break;
-    const int dir = (flags & ST_DIR_POS) ? 1 : -1;
-    if (ahead_seq) {
-      if (ahead.dir != dir) { g_err = "internal error: look-ahead mispredicted the direction of a doubling"; return NUTS_E_HIP; }
-      gm = ahead; seq = ahead_seq;
-    } else {
-      gm = next_geometry(gm, d, dir);
-      seq = enqueue_doubling(gm, d + 1);
-    }
-  }
-  c->last_depth = depth_done;
+  rc = run_tree(c, uniforms, step_size, max_depth, &flags, &exhausted);
+  if (rc) return rc;
   const auto tl = clk::now();
   c->t_loop += std::chrono::duration<double>(tl - tb).count();
   if (flags & ST_BAD_ENERGY) {
@@ -1210,7 +1317,8 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
     return NUTS_E_BAD_ENERGY;
   }
   const int fgrid = std::max(1, std::min(256, (n + VEC_THREADS - 1) / VEC_THREADS));
-  hipLaunchKernelGGL(k_draw_finish, dim3(fgrid), dim3(VEC_THREADS), 0, s, A, c->out_dev, c->out_dev + n, c->do_dev);
+  hipLaunchKernelGGL(k_draw_finish, dim3(fgrid), dim3(VEC_THREADS), 0, s, A, c->out_dev, c->out_dev + n, c->do_dev, (double*)nullptr,
+                     (DrawOutMapped*)nullptr, 0u);
   HIPCHK(hipMemcpyAsync(c->out_host, c->out_dev, 2 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(c->do_host, c->do_dev, sizeof(DrawOut), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1223,46 +1331,149 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   const auto t1 = clk::now();
   const std::clock_t c1 = std::clock();
 
-  // nuts.py:478-489, base_hmc.py:238-282
-  const double accept = std::exp(o.log_accept_sum) / o.n_proposals;
-  c->da.update(accept, adapt);
-  rc = potential_update(c, result_dev);
+  rc = finish_draw_host(c, o, adapt, exhausted, result_dev, evals, perf_start, std::chrono::duration<double>(t1 - t0).count(),
+                        (double)(c1 - c0) / CLOCKS_PER_SEC, stats);
   if (rc) return rc;
-  const bool diverging = o.diverging != 0;
-  if (diverging) {   // keep the leaf the integrator started from and the one it diverged to (base_hmc.py:249-258)
-    const int dir = o.div_t > 0 ? 1 : -1;   // a leaf's index is its parent's + sign(eps) and the start state is 0
-    c->div_source.resize(n); c->div_dest.resize(n);
-    HIPCHK(hipMemcpy(c->div_dest.data(), A.Q + (int64_t)(o.div_t & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(c->div_source.data(), A.Q + (int64_t)((o.div_t - dir) & (A.S - 1)) * n, n * sizeof(double), hipMemcpyDeviceToHost));
-  }
-  if (!c->tune) c->divergences += diverging;
-  c->iter_count += 1;
-
   std::memcpy(q_out, c->out_host, n * sizeof(double));
   if (grad_out) std::memcpy(grad_out, c->out_host + n, n * sizeof(double));
   c->last_q.assign(c->out_host, c->out_host + n); c->last_logp = o.logp; c->cache_ok = true; c->cache_epoch = c->m->data_epoch;
-  std::memset(stats, 0, sizeof(*stats));
-  stats->depth = o.depth;
-  stats->step_size = std::exp(c->da.log_step);
-  stats->step_size_bar = std::exp(c->da.log_bar);
-  stats->mean_tree_accept = accept;
-  stats->tree_size = o.n_proposals;
-  stats->diverging = diverging;
-  stats->reached_max_treedepth = (exhausted && !c->tune) ? 1 : 0;  // nuts.py:220-221
-  stats->divergences = c->divergences;
-  stats->energy_error = o.energy - o.E0;
-  stats->energy = o.energy;
-  stats->max_energy_error = o.max_energy_change;
-  stats->model_logp = o.logp;
-  stats->index_in_trajectory = o.proposal;
-  stats->n_uniforms_consumed = o.cursor;
-  stats->warning = diverging ? 1 : 0;
-  stats->divergence_energy_change = o.div_dE;
-  stats->n_model_evals = evals;
-  stats->perf_counter_start = perf_start;
-  stats->perf_counter_diff = std::chrono::duration<double>(t1 - t0).count();
-  stats->process_time_diff = (double)(c1 - c0) / CLOCKS_PER_SEC;
   return NUTS_OK;
+}
+
+// K consecutive transitions of a model on the GENERAL path (one or more launches per leapfrog) inside one call: the host
+// stays in the doubling loop (it decides what to queue), but nothing else crosses PCIe per draw -- momentum normals and
+// uniforms of the whole batch are uploaded once, a draw starts from the previous proposal where it lies on the device,
+// positions go to a device trace buffer, and the per-draw record comes back through pinned mapped memory (no stream
+// synchronisation).  Tuning draws are allowed (dual averaging is host arithmetic on that record, the mass-matrix update a
+// kernel).  Same semantics as the single-launch variant below: stops early after a divergent draw or when the uniforms could
+// not cover another worst-case tree; `stats[i].n_uniforms_consumed` is cumulative.
+static int draw_many_general(nuts_chain* c, const double* q0, const double* normals, const double* uniforms, int32_t n_uniforms,
+                             int32_t K, double* q_out, nuts_draw_stats* stats, int32_t* n_done) {
+  using clk = std::chrono::steady_clock;
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  ArenaDev& A = c->A;
+  const size_t U = (size_t)n_uniforms;
+  const size_t in_doubles = (size_t)n + (size_t)K * n + 2 * U;
+  const size_t out_bytes = (size_t)K * n * sizeof(double);
+  if (in_doubles > c->many_in_cap || out_bytes > c->many_out_cap) {
+    HIPCHK(hipStreamSynchronize(s));
+    if (c->many_in_host) hipHostFree(c->many_in_host);
+    if (c->many_out_host) hipHostFree(c->many_out_host);
+    if (c->many_in_dev) hipFree(c->many_in_dev);
+    if (c->many_out_dev) hipFree(c->many_out_dev);
+    c->many_in_host = nullptr; c->many_out_host = nullptr; c->many_in_dev = nullptr; c->many_out_dev = nullptr;
+    c->many_in_cap = c->many_out_cap = 0;
+    HIPCHK(hipHostMalloc((void**)&c->many_in_host, in_doubles * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->many_out_host, out_bytes, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&c->many_in_dev, in_doubles * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&c->many_out_dev, out_bytes));
+    c->many_in_cap = in_doubles; c->many_out_cap = out_bytes;
+  }
+  const bool cached0 = c->cache_ok && c->cache_epoch == c->m->data_epoch && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
+  c->cache_ok = false;
+  double* const h_q = c->many_in_host;
+  double* const h_norm = h_q + n;
+  double* const h_u = h_norm + (size_t)K * n;
+  double* const h_lu = h_u + U;
+  std::memcpy(h_q, q0, n * sizeof(double));
+  std::memcpy(h_norm, normals, (size_t)K * n * sizeof(double));
+  std::memcpy(h_u, uniforms, U * sizeof(double));
+  for (size_t i = 0; i < U; ++i) h_lu[i] = std::log(h_u[i]);   // `np.log(rng.random())` is what the tree compares (nuts.py:371,466)
+  HIPCHK(hipMemcpyAsync(c->many_in_dev, c->many_in_host, in_doubles * sizeof(double), hipMemcpyHostToDevice, s));
+  const double* const d_norm = c->many_in_dev + n;
+  const double* const d_u = d_norm + (size_t)K * n;
+  const double* const d_lu = d_u + U;
+  double* const trace_dev = reinterpret_cast<double*>(c->many_out_dev);
+  if (!cached0) {
+    HIPCHK(hipMemcpyAsync(A.Q, c->many_in_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    model_enqueue_plain(c->m, A.Q, A.G, A.LOGP);
+  }
+  const double* const save_u = A.uniforms; const double* const save_lu = A.log_uniforms;
+  const int save_done = c->logs_done, save_total = c->logs_total;
+  c->logs_done = c->logs_total = 1 << 30;   // every logarithm of the batch is already on the device (ensure_logs has nothing to do)
+  int rc = NUTS_OK, done = 0;
+  size_t consumed = 0;
+  const int fgrid = std::max(1, std::min(256, (n + VEC_THREADS - 1) / VEC_THREADS));
+  for (int k = 0; k < K; ++k) {
+    const auto t0 = clk::now();
+    const double perf_start = std::chrono::duration<double>(t0.time_since_epoch()).count();
+    const std::clock_t c0 = std::clock();
+    const bool adapt = c->tune && c->cfg.adapt_step_size;
+    const double step_size = c->da.current(adapt);
+    c->step_size = step_size;
+    const int max_depth = (c->tune && c->iter_count < 200) ? c->cfg.early_max_treedepth : c->cfg.max_treedepth;
+    const size_t need_uni = ((size_t)1 << max_depth) + max_depth + 1;
+    if (U - consumed < need_uni) {
+      if (k == 0) { g_err = "not enough uniforms for the worst-case tree"; rc = NUTS_E_ARG; }
+      break;
+    }
+    A.uniforms = d_u + consumed; A.log_uniforms = d_lu + consumed;
+    const bool from_prev = k > 0 || cached0;   // the start state is the previous proposal, (q, grad) in out_dev, logp in do_dev / last_logp
+    if (c->dense) {
+      hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_W, d_norm + (size_t)k * n, A.P, n, (const double*)nullptr,
+                         (double*)nullptr, 0.0, (const int*)nullptr);
+      hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P, A.V, n, (const double*)nullptr, (double*)nullptr, 0.0,
+                         (const int*)nullptr);
+    }
+    hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, d_norm + (size_t)k * n, (const double*)nullptr, c->kin_part,
+                       from_prev ? (const double*)c->out_dev : (const double*)nullptr,
+                       from_prev ? (const double*)(c->out_dev + n) : (const double*)nullptr, c->dense);
+    hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, c->kin_part, step_size, 0, max_depth, c->st_dev, from_prev ? 1 : 0,
+                       c->last_logp, k > 0 ? (const DrawOut*)c->do_dev : (const DrawOut*)nullptr);
+    unsigned flags = 0;
+    bool exhausted = true;
+    rc = run_tree(c, h_u + consumed, step_size, max_depth, &flags, &exhausted);
+    if (rc) break;
+    if (flags & ST_BAD_ENERGY) {
+      rc = check_mass_matrix(c);
+      if (rc == NUTS_OK) g_err = "Bad initial energy, check any log probabilities that are inf or -inf, nan or very small";
+      rc = NUTS_E_BAD_ENERGY;
+      break;
+    }
+    const unsigned seq = ++c->dom_seq;
+    hipLaunchKernelGGL(k_draw_finish, dim3(fgrid), dim3(VEC_THREADS), 0, s, A, c->out_dev, c->out_dev + n, c->do_dev, trace_dev + (size_t)k * n,
+                       c->dom_dev, seq);
+    {   // the record of this draw, through pinned mapped memory
+      volatile unsigned long long* w = &c->dom_host->seq;
+      const auto tw = clk::now();
+      for (unsigned spins = 0; (unsigned)*w != seq; ++spins) {
+        if ((spins & 0xfffff) == 0xfffff) {
+          if (hipStreamQuery(s) == hipSuccess && (unsigned)*w != seq) { g_err = "k_draw_finish ended without publishing its record"; rc = NUTS_E_HIP; break; }
+          if (clk::now() - tw > std::chrono::seconds(60)) { g_err = "timed out waiting for the device"; rc = NUTS_E_HIP; break; }
+        }
+      }
+      if (rc) break;
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    const DrawOut o = c->dom_host->o;
+    const auto t1 = clk::now();
+    const std::clock_t c1 = std::clock();
+    rc = finish_draw_host(c, o, adapt, exhausted, c->out_dev, o.n_proposals + ((k == 0 && !cached0) ? 1 : 0), perf_start,
+                          std::chrono::duration<double>(t1 - t0).count(), (double)(c1 - c0) / CLOCKS_PER_SEC, stats + k);
+    if (rc) break;
+    consumed += (size_t)o.cursor;
+    stats[k].n_uniforms_consumed = (int32_t)consumed;
+    c->last_logp = o.logp;
+    done = k + 1;
+    if (o.diverging) break;   // its two phase-space points were read from the arena; the caller sees the warning before going on
+  }
+  A.uniforms = save_u; A.log_uniforms = save_lu;
+  c->logs_done = save_done; c->logs_total = save_total;
+  *n_done = done;
+  if (done > 0) {
+    HIPCHK(hipMemcpyAsync(c->many_out_host, c->many_out_dev, (size_t)done * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    const double* trace_host = reinterpret_cast<const double*>(c->many_out_host);
+    std::memcpy(q_out, trace_host, (size_t)done * n * sizeof(double));
+    c->last_q.assign(trace_host + (size_t)(done - 1) * n, trace_host + (size_t)done * n);
+    c->cache_ok = true; c->cache_epoch = c->m->data_epoch;
+  } else {
+    hipStreamSynchronize(s);
+  }
+  if (rc && done > 0 && rc != NUTS_E_BAD_ENERGY) return rc;
+  return done > 0 ? NUTS_OK : (rc ? rc : NUTS_E_ARG);
 }
 
 // K consecutive post-tuning NUTS transitions in ONE launch (single-workgroup models; small_kernel.h).
@@ -1273,8 +1484,8 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
 extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
                                     int32_t n_uniforms, int32_t K, double* q_out, nuts_draw_stats* stats, int32_t* n_done) {
   if (!c || !q0 || !normals || !uniforms || !q_out || !stats || !n_done || K <= 0) { g_err = "null argument"; return NUTS_E_ARG; }
-  if (!c->small) { g_err = "nuts_chain_draw_many: only models on the single-launch path (n <= 512, element-wise, diagonal mass matrix)"; return NUTS_E_ARG; }
-  if (c->tune) { g_err = "nuts_chain_draw_many: the chain is still tuning (adaptation needs the host between draws)"; return NUTS_E_ARG; }
+  if (!c->small) return draw_many_general(c, q0, normals, uniforms, n_uniforms, K, q_out, stats, n_done);
+  if (c->tune) { g_err = "nuts_chain_draw_many: the chain is still tuning (the single-launch batch has no adaptation between its draws)"; return NUTS_E_ARG; }
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
   const double perf_start = std::chrono::duration<double>(t0.time_since_epoch()).count();

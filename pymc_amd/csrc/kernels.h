@@ -1173,13 +1173,19 @@ __global__ __launch_bounds__(VEC_THREADS) void k_draw_start(ArenaDev A, const do
   if (threadIdx.x == 0) kin_part[blockIdx.x] = tot;
 }
 
+// gather the proposal and tree statistics (nuts.py:478-489)
+struct DrawOut {
+  double energy, logp, E0, log_accept_sum, max_energy_change, div_dE;
+  int depth, n_proposals, proposal, cursor, turning, diverging, bad_energy, div_t;
+};
+
 __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part, double step_size, int dir_forced, int max_depth,
-                                 HostStatus* st, int use_cached_logp, double cached_logp) {
+                                 HostStatus* st, int use_cached_logp, double cached_logp, const DrawOut* prev) {
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int b = 0; b < A.nblk; ++b) s += kin_part[b];
     Ctl* c = A.ctl;
-    if (use_cached_logp) A.LOGP[0] = cached_logp;
+    if (use_cached_logp) A.LOGP[0] = prev ? prev->logp : cached_logp;   // (`prev`: the record of the previous draw, still on the device)
     const double logp = A.LOGP[0];
     const double E = 0.5 * s - logp;  // integration.py:72-74
     A.E[0] = E;
@@ -1201,14 +1207,15 @@ __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part
   }
 }
 
-// gather the proposal and tree statistics (nuts.py:478-489)
-struct DrawOut {
-  double energy, logp, E0, log_accept_sum, max_energy_change, div_dE;
-  int depth, n_proposals, proposal, cursor, turning, diverging, bad_energy, div_t;
-};
+
+// `trace_q` (optional): the proposal's position also goes into this row of a device-resident trace buffer (multi-draw
+// calls); `mapped` (optional): the record is also written to pinned, device-mapped host memory and `seq` is published
+// behind it with a system-scope store, so the host learns the outcome of the draw without a stream synchronisation.
+struct DrawOutMapped { DrawOut o; unsigned long long seq; };
 
 __global__ __launch_bounds__(VEC_THREADS) void k_draw_finish(ArenaDev A, double* __restrict__ q_out,
-                                                             double* __restrict__ g_out, DrawOut* out) {
+                                                             double* __restrict__ g_out, DrawOut* out,
+                                                             double* __restrict__ trace_q, DrawOutMapped* mapped, unsigned seq) {
   const Ctl* c = A.ctl;
   const int prop = c->proposal;
   const int64_t po = slot_off(A, prop);
@@ -1216,15 +1223,24 @@ __global__ __launch_bounds__(VEC_THREADS) void k_draw_finish(ArenaDev A, double*
   // half-way (the `aborted` flag flips under it): every draw ends with the counters at zero
   if (blockIdx.x == 0) for (int t = threadIdx.x; t < A.ga_nticket; t += blockDim.x) A.ga_ticket[t] = 0u;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) {
-    q_out[i] = A.Q[po + i];
+    const double qi = A.Q[po + i];
+    q_out[i] = qi;
     g_out[i] = A.G[po + i];
+    if (trace_q) trace_q[i] = qi;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     const int ps = prop & (A.S - 1);
-    out->energy = A.E[ps]; out->logp = A.LOGP[ps]; out->E0 = c->E0;
-    out->log_accept_sum = c->log_accept_sum; out->max_energy_change = c->max_energy_change; out->div_dE = c->div_dE;
-    out->depth = c->depth; out->n_proposals = c->n_proposals; out->proposal = prop; out->cursor = c->cursor;
-    out->turning = c->turning; out->diverging = c->diverging; out->bad_energy = c->bad_energy; out->div_t = c->div_t;
+    DrawOut o;
+    o.energy = A.E[ps]; o.logp = A.LOGP[ps]; o.E0 = c->E0;
+    o.log_accept_sum = c->log_accept_sum; o.max_energy_change = c->max_energy_change; o.div_dE = c->div_dE;
+    o.depth = c->depth; o.n_proposals = c->n_proposals; o.proposal = prop; o.cursor = c->cursor;
+    o.turning = c->turning; o.diverging = c->diverging; o.bad_energy = c->bad_energy; o.div_t = c->div_t;
+    *out = o;
+    if (mapped) {
+      mapped->o = o;
+      __threadfence_system();
+      __hip_atomic_store(&mapped->seq, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

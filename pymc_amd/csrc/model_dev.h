@@ -84,8 +84,15 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   // span tables above are not built, and there is no O(n) kernel between two row passes: the workgroup that streamed a
   // group holds that group's complete d logp / d beta and finishes its D z elements itself.
   int32_t ga, ga_w;              // active; waves per workgroup
-  int32_t ga_nblk, ga_bsz;       // second-level reduction: blocks of ga_bsz consecutive groups
-  const int32_t* ga_tile0;       // [G+1]
+  int32_t ga_nblk, ga_bsz;       // second-level reduction: blocks of ga_bsz consecutive groups (ga_bsz <= 64)
+  int32_t ga_T_uni, ga_flags;    // > 0: every group has this many tiles (and ga_ng_uni rows): geometry without table look-ups
+  int64_t ga_ng_uni;
+  const int32_t* ga_tile0;       // [G+1] tiles of group g = ga_tile0[g+1] - ga_tile0[g]
+  // X / y are laid out per CHUNK = the tiles one wave streams (group g, wave w): chunk (g, w) starts at element ga_coff[g W + w]
+  // of Xt (its y at that offset / D).  Chunk starts are skewed by an odd multiple of 256 B: with a power-of-two group stride
+  // (C2-L: 32 tiles x 8 KiB = 256 KiB) the G W lock-stepped streams would sit on the same memory channels all the time.
+  const int64_t* ga_coff;        // [G W]
+  int64_t ga_cstride_uni;        // uniform geometry: ga_coff[c] = c * ga_cstride_uni (no table look-up)
   unsigned* ga_ticket;           // [ga_nblk] arrivals of the block's groups in the current launch (self-resetting)
   double* ga_part;               // [G][PART_STRIDE] per-group partial record (written write-through, read by the block's last arriver)
   double* ga_bpart;              // [2][ga_nblk][PART_STRIDE] block partials, double-buffered by launch parity

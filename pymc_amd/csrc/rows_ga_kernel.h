@@ -59,6 +59,24 @@ __device__ __forceinline__ double ld_agent(const double* p) {
                                                            __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// X tile at element offset `xoff` of Xt ([D][SPAN] doubles; its y bytes at xoff / D): lane l holds rows RPL*l .. RPL*l+RPL-1
+template <int D, int RPL>
+__device__ __forceinline__ void ga_load(const RowsDev& R, int64_t xoff, int lane, double (&x)[D][RPL], uint32_t& ybits) {
+  constexpr int SPAN = WAVE * RPL;
+  const double* tile = R.Xt + xoff + lane * RPL;
+  const int8_t* yp = R.y + xoff / D + lane * RPL;
+  if (RPL == 2) ybits = *reinterpret_cast<const uint16_t*>(yp);
+  else ybits = *reinterpret_cast<const uint32_t*>(yp);
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int k = 0; k < RPL; k += 2) {
+      const double2 a = *reinterpret_cast<const double2*>(tile + d * SPAN + k);
+      x[d][k] = a.x; x[d][k + 1] = a.y;
+    }
+  }
+}
+
 // one tile of SPAN = 64 RPL rows: forward (eta, log-lik) + backward (d/dbeta) in registers
 template <int D, int RPL>
 __device__ __forceinline__ void ga_tile(const double (&x)[D][RPL], uint32_t yb, const double (&beta)[D], int nvalid, int lane,
@@ -75,15 +93,43 @@ __device__ __forceinline__ void ga_tile(const double (&x)[D][RPL], uint32_t yb, 
     rr = in ? rr : 0.0;
 #pragma unroll
     for (int d = 0; d < D; ++d) acc[d] = fma(rr, x[d][k], acc[d]);
+    // rows are finished one after the other: interleaving the two rows of a lane would double the live temporaries of the
+    // exp / log1p / reciprocal sequences, and the registers are better spent on tiles in flight
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 #define GA_MAXW 4
+#define GA_MAXCHUNK 8      // the block reduce sums chunks of 8 consecutive groups (ga_bsz <= 64)
+#define GA_F_NOTAIL 1      // ga_flags, TIMING EXPERIMENTS ONLY: stop after the stream (results are wrong)
 
-template <int D, int RPL>
-__global__ __launch_bounds__(64 * GA_MAXW, 4) void k_rows_ga(ModelDev md, ArenaDev A, EvalIO io, int j, int rev, int fold, int par, int d,
-                                                             double Emax, int max_depth, HostStatus* st) {
+// OCC: waves per SIMD the register budget is sized for (4: 128 VGPRs, 3: 168); PIPE: tiles in flight per wave (2 or 3).
+// G workgroups of W waves must all be resident: 4 OCC waves per CU >= W (G / CUs).
+struct GaArgs;
+template <int D>
+__device__ __forceinline__ void ga_tail(const GaArgs& T, int g, double (&s_acc)[4][2][D + 1], double (&s_red)[NDOT],
+                                        double (&s_cp)[8][PART_STRIDE], int (&s_info)[4], double (&s_keep)[5][WAVE]);
+
+// The arguments travel as ONE struct: the tail of the kernel reads them from an LDS copy of the kernarg segment (made while the
+// first tile is in flight), so that nothing the tail needs -- a few dozen pointers and scalars -- has to stay in scalar
+// registers across the streaming loop.  (They did: 100+ SGPRs, spilled into VGPR lanes, spilled on into scratch; and a scratch
+// reload inside the loop waits, in order, for every tile load issued before it -- the prefetch was gone.)
+struct GaArgs {
+  ModelDev md; ArenaDev A; EvalIO io;
+  int j, rev, fold, par, d, max_depth;
+  double Emax;
+  HostStatus* st;
+};
+
+template <int D, int RPL, int OCC, int PIPE>
+__global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   constexpr int SPAN = WAVE * RPL;
+  const ModelDev& md = a.md;
+  const ArenaDev& A = a.A;
+  const EvalIO& io = a.io;
+  const int j = a.j, rev = a.rev, fold = a.fold, par = a.par, d = a.d, max_depth = a.max_depth;
+  const double Emax = a.Emax;
+  HostStatus* const st = a.st;
   const RowsDev& R = md.lg;
   int b = (int)blockIdx.x;
   if (fold) {   // workgroup 0: the control work of the previous leaf, from the previous launch's block partials
@@ -91,154 +137,254 @@ __global__ __launch_bounds__(64 * GA_MAXW, 4) void k_rows_ga(ModelDev md, ArenaD
     --b;
   }
   const int g = b;
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6, W = (int)blockDim.x >> 6;
+  // (the wave index is wave-uniform, but only `readfirstlane` tells the compiler: without it every tile address is per-lane
+  // 64-bit VGPR arithmetic, and the streaming loop runs out of registers)
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(tid >> 6), W = (int)blockDim.x >> 6;
   Leaf lf; QView qv;
   const int aborted = load_aborted(io, A);
   resolve_leaf(io, A, j, lf, qv);
   const bool leaf = io.mode != MODE_PLAIN;
   __shared__ double s_acc[GA_MAXW][2][D + 1];   // [wave][first / second half of its tiles][d/dbeta, log-lik]
   __shared__ double s_red[NDOT];
+  __shared__ double s_cp[GA_MAXCHUNK][PART_STRIDE];
+  __shared__ int s_info[4];                      // {this workgroup is its block's last arriver, m, last}
+  __shared__ double s_keep[5][WAVE];             // wave 0's per-lane prologue values the tail needs again (kept out of the stream's registers)
+  __shared__ __attribute__((aligned(16))) char s_args[(sizeof(GaArgs) + 15) / 16 * 16];
+
+  // ---- geometry of this wave's stream (no memory access when every group has the same number of rows) ----
+  int T; int64_t ng, cbase;
+  if (R.ga_T_uni > 0) { T = R.ga_T_uni; ng = R.ga_ng_uni; cbase = (int64_t)(g * W + w) * R.ga_cstride_uni; }
+  else {
+    T = __builtin_amdgcn_readfirstlane(R.ga_tile0[g + 1] - R.ga_tile0[g]);
+    ng = __builtin_amdgcn_readfirstlane((int)(R.gptr[g + 1] - R.gptr[g]));
+    const int64_t cb = R.ga_coff[g * W + w];
+    cbase = ((int64_t)__builtin_amdgcn_readfirstlane((int)(cb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(cb & 0xffffffffll));
+  }
+  // The wave's tiles (its chunk) are streamed in two halves whose order alternates between launches (the tail of the previous
+  // pass is still in the 256 MiB Infinity Cache); each half is summed in fixed tile order, wave-reduced and parked in its own
+  // LDS slot, so the result does not depend on which half was streamed first.
+  const int c0 = (int)((int64_t)w * T / W), c2 = (int)((int64_t)(w + 1) * T / W);   // this wave's tiles of the group: [c0, c2)
+  const int n = c2 - c0;
+  const int nA = (n + 1) / 2;                                   // tiles of the first half (chunk-local [0, nA)), second [nA, n)
+  const int nsw = rev ? n - nA : nA;                            // position in the sequence where the second-streamed half starts
+  constexpr int64_t TS = (int64_t)D * SPAN;                     // doubles per tile
+  auto local_at = [&](int i) { return rev ? (i < nsw ? nA + i : i - nsw) : i; };
+  auto tile_at = [&](int i) { return cbase + (int64_t)local_at(i) * TS; };
+  const int l_last = (c2 == T) ? n - 1 : -1;                    // chunk-local index of the group's last (zero-padded) tile, if it is here
+  const int n_last = (int)(ng - (int64_t)(T - 1) * SPAN);     // its valid rows
+  // PIPE tiles in flight per wave; the first ones are requested before anything else, so HBM is busy during the prologue
+  double xa[D][RPL], xb[D][RPL], xc[PIPE == 3 ? D : 1][RPL];
+  uint32_t ya = 0, yb = 0, yc = 0;
+  if (n > 0) ga_load<D, RPL>(R, tile_at(0), lane, xa, ya);
+  if (PIPE == 3 && n > 1) ga_load<D, RPL>(R, tile_at(1), lane, xb, yb);
+  if (lane == 0) {
+#pragma unroll
+    for (int dd = 0; dd <= D; ++dd) { s_acc[w][0][dd] = 0.0; s_acc[w][1][dd] = 0.0; }
+  }
+  {
+    const uint4* ka = (const uint4*)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int t = tid; t < (int)((sizeof(GaArgs) + 15) / 16); t += (int)blockDim.x) reinterpret_cast<uint4*>(s_args)[t] = ka[t];
+  }
 
   // ---- prologue: mu', sigma' of this leaf (every wave), z' of this group ----
-  const int t0 = R.ga_tile0[g], T = R.ga_tile0[g + 1] - t0;
-  const int64_t ng = R.gptr[g + 1] - R.gptr[g];
-  double hval, hph;   // lane l: q' and p_half of hyper-parameter element l mod 2D
+  double hval0, hph0;   // lane l: q' and p_half of hyper-parameter element l mod 2D
   if (fold) {
     const LeanSrc prev = lean_src(md, par ^ 1);
-    rows_hyper_fold_elem<D>(R, prev.part, prev.stride, prev.nblk, prev.def_loc, qv, lane, hval, hph);
+    rows_hyper_fold_elem<D>(R, prev.part, prev.stride, prev.nblk, prev.def_loc, qv, lane, hval0, hph0);
   } else {
     const int e = lane % (2 * D);
     const int i = e < D ? R.off_mu + e : R.off_sigma + (e - D);
-    if (qv.composed) { hph = qv.p_half(i); hval = fma(qv.eps, qv.var[i] * hph, qv.q[i]); }
-    else { hph = 0.0; hval = qv.q[i]; }
+    if (qv.composed) { hph0 = qv.p_half(i); hval0 = fma(qv.eps, qv.var[i] * hph0, qv.q[i]); }
+    else { hph0 = 0.0; hval0 = qv.q[i]; }
   }
   const int dl = lane % D;
   const int iz = R.off_z + g * D + dl;
-  double zq, zph;
-  if (qv.composed) { zph = fma(qv.half, qv.g[iz], qv.p[iz]); zq = fma(qv.eps, qv.var[iz] * zph, qv.q[iz]); }
-  else { zph = 0.0; zq = qv.q[iz]; }
-  const double m_lane = __shfl(hval, dl);
-  const double sraw = __shfl(hval, D + dl);
-  const double s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(sraw) : sraw;
   double beta[D];
   {
+    double zq, zph;
+    if (qv.composed) { zph = fma(qv.half, qv.g[iz], qv.p[iz]); zq = fma(qv.eps, qv.var[iz] * zph, qv.q[iz]); }
+    else { zph = 0.0; zq = qv.q[iz]; }
+    const double m_lane = __shfl(hval0, dl);
+    const double sraw = __shfl(hval0, D + dl);
+    const double s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(sraw) : sraw;
     const double bl = fma(s_lane, zq, m_lane);
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) beta[dd] = readlane_d(bl, dd);
+    if (w == 0) { s_keep[0][lane] = hval0; s_keep[1][lane] = hph0; s_keep[2][lane] = zq; s_keep[3][lane] = zph; s_keep[4][lane] = s_lane; }
   }
   if (aborted) return;   // (a workgroup that sees the flag takes no ticket: see the header)
 
-  // ---- the stream: this wave's share of the group's tiles, in two halves whose order alternates between launches ----
-  // (the tail of the previous pass is still in the 256 MiB Infinity Cache; each half is summed in fixed tile order,
-  // wave-reduced, and parked in its own LDS slot, so the result does not depend on which half was streamed first)
-  const int a0 = t0 + (int)((int64_t)w * T / W), a2 = t0 + (int)((int64_t)(w + 1) * T / W);
-  const int a1 = a0 + (a2 - a0 + 1) / 2;
-  const int t_last = t0 + T - 1;
-  const int n_last = (int)(ng - (int64_t)(T - 1) * SPAN);   // valid rows of the group's last (zero-padded) tile
-  for (int h = 0; h < 2; ++h) {
-    const int second = ((h == 0) == (rev != 0)) ? 1 : 0;   // rev: second half first
-    const int s0 = second ? a1 : a0, s1 = second ? a2 : a1;
+  // ---- the stream ----
+  {
     double acc[D], lp = 0.0;
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) acc[dd] = 0.0;
-    for (int t = s0; t < s1; ++t) {
-      double x[D][RPL];
-      uint32_t yb;
-      rows_load<D, RPL>(R, t, lane, x, yb);
-      ga_tile<D, RPL>(x, yb, beta, t == t_last ? n_last : SPAN, lane, acc, lp);
-    }
+    int half = rev ? 1 : 0;   // which half of the wave's range the current accumulators belong to
+    auto flush = [&]() {
 #pragma unroll
-    for (int dd = 0; dd < D; ++dd) {
-      const double sum = wave_sum(acc[dd]);
-      if (lane == 0) s_acc[w][second][dd] = sum;
+      for (int dd = 0; dd < D; ++dd) {
+        const double sum = wave_sum(acc[dd]);
+        if (lane == 0) s_acc[w][half][dd] = sum;
+        acc[dd] = 0.0;
+      }
+      const double sum = wave_sum(lp);
+      if (lane == 0) s_acc[w][half][D] = sum;
+      lp = 0.0;
+      half ^= 1;
+    };
+#define GA_STAGE(X, Y, I)                                                                   \
+    {                                                                                        \
+      if ((I) == nsw) flush();                                                               \
+      ga_tile<D, RPL>(X, Y, beta, local_at(I) == l_last ? n_last : SPAN, lane, acc, lp);     \
     }
-    const double sum = wave_sum(lp);
-    if (lane == 0) s_acc[w][second][D] = sum;
+    if constexpr (PIPE == 3) {
+      for (int i = 0; i < n; i += 3) {
+        if (i + 2 < n) ga_load<D, RPL>(R, tile_at(i + 2), lane, xc, yc);
+        GA_STAGE(xa, ya, i)
+        if (i + 1 >= n) break;
+        if (i + 3 < n) ga_load<D, RPL>(R, tile_at(i + 3), lane, xa, ya);
+        GA_STAGE(xb, yb, i + 1)
+        if (i + 2 >= n) break;
+        if (i + 4 < n) ga_load<D, RPL>(R, tile_at(i + 4), lane, xb, yb);
+        GA_STAGE(xc, yc, i + 2)
+      }
+    } else {
+      for (int i = 0; i < n; i += 2) {
+        if (i + 1 < n) ga_load<D, RPL>(R, tile_at(i + 1), lane, xb, yb);
+        GA_STAGE(xa, ya, i)
+        if (i + 1 >= n) break;
+        if (i + 2 < n) ga_load<D, RPL>(R, tile_at(i + 2), lane, xa, ya);
+        GA_STAGE(xb, yb, i + 1)
+      }
+    }
+#undef GA_STAGE
+    if (n > 0) flush();
   }
-
-  // ---- the operands of the first merge levels belong to earlier leaves: in flight during the combine ----
-  MergePrefetch mpf;
-  const bool tree = io.mode == MODE_TREE;
-  if (w == 0 && tree) merge_prefetch(A, lf, j, iz, mpf);
 
   __syncthreads();
-  if (w != 0) return;
+  ga_tail<D>(*reinterpret_cast<const GaArgs*>(s_args), g, s_acc, s_red, s_cp, s_info, s_keep);
+}
 
-  // ---- wave 0: the group's D z elements (lane = coordinate) ----
-  double db = 0.0, lpg = 0.0;
-  for (int ww = 0; ww < W; ++ww) { db += s_acc[ww][0][dl] + s_acc[ww][1][dl]; lpg += s_acc[ww][0][D] + s_acc[ww][1][D]; }
-  const bool zact = lane < D;
-  int idx[1] = {iz};
-  bool act[1] = {zact};
-  double grad[1] = {0.0}, ph[1] = {zph};
+// Everything after the stream; `T` is the LDS copy of the kernel arguments.
+template <int D>
+__device__ __forceinline__ void ga_tail(const GaArgs& T, int g, double (&s_acc)[GA_MAXW][2][D + 1], double (&s_red)[NDOT],
+                                        double (&s_cp)[GA_MAXCHUNK][PART_STRIDE], int (&s_info)[4], double (&s_keep)[5][WAVE]) {
+  const ModelDev& md = T.md;
+  const ArenaDev& A = T.A;
+  const EvalIO& io = T.io;
+  const RowsDev& R = md.lg;
+  const int j = T.j, par = T.par, d = T.d;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6, W = (int)blockDim.x >> 6;
+  if (R.ga_flags & GA_F_NOTAIL) return;
+  Leaf lf; QView qv;
+  resolve_leaf(io, A, j, lf, qv);
+  const bool leaf = io.mode != MODE_PLAIN;
+  const bool tree = io.mode == MODE_TREE;
+  const int dl = lane % D;
+  const int iz = R.off_z + g * D + dl;
+
+  if (w == 0) {
+    // ---- wave 0: the group's D z elements (lane = coordinate) ----
+    // (the operands of the first merge levels belong to earlier leaves: requested first, in flight during the rest)
+    MergePrefetch mpf;
+    if (tree) merge_prefetch(A, lf, j, iz, mpf);
+    const double hval = s_keep[0][lane], hph = s_keep[1][lane], zq = s_keep[2][lane], zph = s_keep[3][lane], s_lane = s_keep[4][lane];
+    double db = 0.0, lpg = 0.0;
+    for (int ww = 0; ww < W; ++ww) { db += s_acc[ww][0][dl] + s_acc[ww][1][dl]; lpg += s_acc[ww][0][D] + s_acc[ww][1][D]; }
+    const bool zact = lane < D;
+    int idx[1] = {iz};
+    bool act[1] = {zact};
+    double grad[1] = {0.0}, ph[1] = {zph};
+    {
+      const double r = zq - R.z_np_mu;                       // z ~ Normal(mu0, s0) in closed form (continuous.py:526-532)
+      const double gx = -r * R.z_np_inv_var;
+      const double lpz = -0.5 * r * r * R.z_np_inv_var - R.z_np_lognorm;
+      grad[0] = gx + s_lane * db;                            // d/dz = prior + sigma_d * d/dbeta_d
+      lpg += wave_sum(zact ? lpz : 0.0);
+      if (zact) {
+        if (leaf) { A.G[lf.d_o + iz] = grad[0]; A.Q[lf.d_o + iz] = zq; }
+        else io.grad[iz] = grad[0];
+      }
+    }
+    // the hyper-parameter elements' local parts + their q' (one workgroup does it for the launch)
+    if (g == 0) {
+      const int e = lane;
+      const bool hact = e < 2 * D, is_mu = e < D;
+      double gx, dxdq, dj, lpd;
+      ga_def_local(R, is_mu, hval, gx, dxdq, dj, lpd);
+      lpg += wave_sum(hact ? lpd : 0.0);
+      if (hact) {
+        const int dd = is_mu ? e : e - D;
+        const int slot = (is_mu ? R.def_mu : R.def_sigma) + dd;
+        double2* loc = reinterpret_cast<double2*>(md.def_loc + (int64_t)par * 4 * MAX_DEFERRED) + 2 * slot;
+        loc[0] = make_double2(gx, dxdq);
+        loc[1] = make_double2(dj, hph);
+        if (leaf) A.Q[lf.d_o + (is_mu ? R.off_mu : R.off_sigma) + dd] = hval;
+      }
+    }
+    int m = 0; bool last = false;
+    if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- this group's record, write-through ----
+    double* rec = R.ga_part + (int64_t)g * PART_STRIDE;
+    if (lane == 0) st_agent(rec + PART_LP, lpg);
+    if (zact) { st_agent(rec + PART_DMU + lane, db); st_agent(rec + PART_DSG + lane, db * zq); }
+    if (leaf) {
+      for (int k = lane; k < NDOT; k += WAVE)
+        if (dot_needed(k, m, last)) st_agent(rec + PART_DOT + k, s_red[k]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has left this CU before the ticket is taken
+
+    // ---- ticket: the block's last arriver sums the block's records in group order ----
+    const int blk = g / R.ga_bsz;
+    const int cnt = min(R.G, (blk + 1) * R.ga_bsz) - blk * R.ga_bsz;
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&R.ga_ticket[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    const int is_last = (int)old + 1 == cnt;
+    if (is_last && lane == 0) __hip_atomic_store(&R.ga_ticket[blk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) { s_info[0] = is_last; s_info[1] = m; s_info[2] = last ? 1 : 0; }
+  }
+  __syncthreads();
+  if (!s_info[0]) return;
+
+  // ---- the last arriver's workgroup: block partial = sum of the block's records, chunks of 8 groups, chunks in order ----
   {
-    const double r = zq - R.z_np_mu;                       // z ~ Normal(mu0, s0) in closed form (continuous.py:526-532)
-    const double gx = -r * R.z_np_inv_var;
-    const double lpz = -0.5 * r * r * R.z_np_inv_var - R.z_np_lognorm;
-    grad[0] = gx + s_lane * db;                            // d/dz = prior + sigma_d * d/dbeta_d
-    lpg += wave_sum(zact ? lpz : 0.0);
-    if (zact) {
-      if (leaf) { A.G[lf.d_o + iz] = grad[0]; A.Q[lf.d_o + iz] = zq; }
-      else io.grad[iz] = grad[0];
-    }
-  }
-  // the hyper-parameter elements' local parts + their q' (one workgroup does it for the launch)
-  if (g == 0) {
-    const int e = lane;
-    const bool hact = e < 2 * D, is_mu = e < D;
-    double gx, dxdq, dj, lpd;
-    ga_def_local(R, is_mu, hval, gx, dxdq, dj, lpd);
-    lpg += wave_sum(hact ? lpd : 0.0);
-    if (hact) {
-      const int dd = is_mu ? e : e - D;
-      const int slot = (is_mu ? R.def_mu : R.def_sigma) + dd;
-      double2* loc = reinterpret_cast<double2*>(md.def_loc + (int64_t)par * 4 * MAX_DEFERRED) + 2 * slot;
-      loc[0] = make_double2(gx, dxdq);
-      loc[1] = make_double2(dj, hph);
-      if (leaf) A.Q[lf.d_o + (is_mu ? R.off_mu : R.off_sigma) + dd] = hval;
-    }
-  }
-  int m = 0; bool last = false;
-  if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- this group's record, write-through ----
-  double* rec = R.ga_part + (int64_t)g * PART_STRIDE;
-  if (lane == 0) st_agent(rec + PART_LP, lpg);
-  if (zact) { st_agent(rec + PART_DMU + lane, db); st_agent(rec + PART_DSG + lane, db * zq); }
-  if (leaf) {
-    for (int k = lane; k < NDOT; k += WAVE)
-      if (dot_needed(k, m, last)) st_agent(rec + PART_DOT + k, s_red[k]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the record has left this CU before the ticket is taken
-
-  // ---- ticket: the block's last arriver sums the block's records in group order ----
-  const int blk = g / R.ga_bsz;
-  const int g0 = blk * R.ga_bsz, g1 = min(R.G, g0 + R.ga_bsz);
-  unsigned old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(&R.ga_ticket[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-  if ((int)old + 1 != g1 - g0) return;
-  if (lane == 0) __hip_atomic_store(&R.ga_ticket[blk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int nn = 1 + 2 * D + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
-  double* bp = R.ga_bpart + ((int64_t)par * R.ga_nblk + blk) * PART_STRIDE;
-  for (int q = lane; q < nn; q += WAVE) {
-    int k;
-    if (q < 1) k = PART_LP;
-    else if (q < 1 + D) k = PART_DMU + (q - 1);
-    else if (q < 1 + 2 * D) k = PART_DSG + (q - 1 - D);
-    else if (q < 1 + 2 * D + 1 + 6 * m) k = PART_DOT + (q - 1 - 2 * D);
-    else k = PART_DOT + DOT_TOP + (q - 1 - 2 * D - 1 - 6 * m);
-    const double* src = R.ga_part + (int64_t)g0 * PART_STRIDE + k;
-    double s = 0.0;
-    for (int gg = 0; gg < g1 - g0; gg += 8) {
+    const int m = s_info[1];
+    const bool last = s_info[2] != 0;
+    const int blk = g / R.ga_bsz, g0 = blk * R.ga_bsz;
+    const int cnt = min(R.G, g0 + R.ga_bsz) - g0;
+    const int nch = (cnt + 7) / 8;
+    const int nn = 1 + 2 * D + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
+    auto need_slot = [&](int q) {
+      if (q < 1) return PART_LP;
+      if (q < 1 + D) return PART_DMU + (q - 1);
+      if (q < 1 + 2 * D) return PART_DSG + (q - 1 - D);
+      if (q < 1 + 2 * D + 1 + 6 * m) return PART_DOT + (q - 1 - 2 * D);
+      return PART_DOT + DOT_TOP + (q - 1 - 2 * D - 1 - 6 * m);
+    };
+    const int NT = (int)blockDim.x;
+    for (int p = tid; p < nn * nch; p += NT) {
+      const int c = p / nn, k = need_slot(p - c * nn);
+      const int gg0 = c * 8, gcnt = min(8, cnt - gg0);
+      const double* src = R.ga_part + (int64_t)(g0 + gg0) * PART_STRIDE + k;
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld_agent(src + (int64_t)min(gg + u, g1 - g0 - 1) * PART_STRIDE);
+      for (int u = 0; u < 8; ++u) v[u] = ld_agent(src + (int64_t)min(u, gcnt - 1) * PART_STRIDE);
+      double sum = 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += (gg + u < g1 - g0) ? v[u] : 0.0;
+      for (int u = 0; u < 8; ++u) sum += (u < gcnt) ? v[u] : 0.0;
+      s_cp[c][k] = sum;
     }
-    bp[k] = s;
+    __syncthreads();
+    double* bp = R.ga_bpart + ((int64_t)par * R.ga_nblk + blk) * PART_STRIDE;
+    for (int q = tid; q < nn; q += NT) {
+      const int k = need_slot(q);
+      double sum = 0.0;
+      for (int c = 0; c < nch; ++c) sum += s_cp[c][k];
+      bp[k] = sum;
+    }
   }
 }

@@ -1,0 +1,425 @@
+"""`lower_to_spec`: the model's log-density GRAPH -> the spec that crosses the C ABI.
+
+The reference compiles `Model.logp()` through PyTensor (`ValueGradFunction`, pymc/model/core.py:213-267; precedent for a
+foreign backend walking that graph: pymc/sampling/jax.py:102-125).  Here the walker turns the per-variable log-density
+graphs `model.logp(sum=False)` (core.py:612-695: one element-wise graph per free RV, observed RV and potential, Jacobian
+terms of the value transforms included) into a `ModelSpec`: free value variables in `model.value_vars` order with their
+transforms, one distribution factor per graph with affine arguments `a + b * c`, and the dense nodes that have their own
+streaming kernels (hierarchical Bernoulli-logit rows, MvNormal).
+
+PyTensor cannot be imported in the build image, so the walker is written against the node PROTOCOL only -- it never
+imports pytensor and looks at nothing but
+
+    var.owner (None for inputs / constants), var.owner.op, var.owner.inputs, var.name,
+    constants: `.data`; shared variables: `.get_value()`,
+    type(op).__name__ in {Elemwise, DimShuffle, Sum / CAReduce, AdvancedSubtensor1, Subtensor, Dot, Join, Cast, Alloc,
+                          CheckParameterValue, SpecifyShape},  Elemwise: type(op.scalar_op).__name__,  Sum: op.axis
+
+-- and is exercised on stub graphs that transcribe what the reference's `logp` methods build (tests/stubgraph.py:
+continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390 HalfCauchy, :1478-1486 Exponential,
+discrete.py:351-374 Bernoulli; transforms.py:880-891 log, :1076-1088 logodds).
+
+How a factor is recognised: the graph is first turned into a small expression tree (constants folded, broadcasts /
+casts / parameter checks stripped -- the device applies its own support and parameter checks), then matched against the
+unrewritten FORM of each distribution's logp (the graph `Model.logp` returns is not rewritten; rewrites happen in
+`compile`, pytensorf.py:924-1008).  The wildcards of the matched form (value, parameters) are lowered to affine terms.
+
+What remains to validate on a box where PyTensor imports (cannot be checked here): (1) the exact op class names above
+against the installed PyTensor (`Sum` vs `CAReduce`, `Second`/`Alloc` for broadcasts, the `Composite` ops that appear if a
+caller hands over a REWRITTEN graph); (2) that `pt.pow(x, 2)` is still emitted as `Pow` with a constant exponent (a `Sqr`
+is accepted too); (3) constant folding of `pt.log(pt.sqrt(2.0 * np.pi))` is done here numerically, the tolerance on
+matched constants is 1e-12; (4) dims / coords, `pm.Data` containers (shared variables are read with `.get_value()` at
+lowering time; re-lowering or `set_extra_values` is needed when they change); (5) the distributions of the spec IR not
+listed above (StudentT, Beta, Gamma, ... have templates to be written the same way) and everything outside the IR, for
+which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU path for that model.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from pymc_amd import model_spec as ms
+
+
+class NotLowerable(NotImplementedError):
+    """The graph is outside what the device IR expresses; the message names the sub-expression."""
+
+
+# ---------------------------------------------------------------------------
+# graph -> expression tree
+# ---------------------------------------------------------------------------
+# nodes: ("const", ndarray) | ("input", var) | (opname, child, ...) ; opname lower-case scalar-op names, plus
+#        ("sum", axis, x), ("take", x, idx), ("dot", a, b)
+
+_ELEMWISE_ALIASES = {"truediv": "div", "true_div": "div", "scalarsigmoid": "sigmoid", "scalarsoftplus": "softplus", "second": "second",
+                     "identity": "identity", "and_": "and", "or_": "or"}
+_NUMPY_FOLD = {
+    "add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "neg": np.negative, "exp": np.exp, "log": np.log,
+    "log1p": np.log1p, "sqrt": np.sqrt, "sqr": np.square, "pow": np.power, "abs": np.abs, "reciprocal": np.reciprocal,
+}
+
+
+def _opname(op) -> str:
+    return type(op).__name__
+
+
+def _scalar_name(op) -> str:
+    n = type(op.scalar_op).__name__.lower()
+    return _ELEMWISE_ALIASES.get(n, n)
+
+
+def _const(x):
+    return ("const", np.asarray(x, dtype="float64"))
+
+
+def build_tree(v, memo: Optional[dict] = None):
+    """Expression tree of graph variable `v` (see the module docstring for the protocol it relies on)."""
+    memo = {} if memo is None else memo
+    key = id(v)
+    if key in memo:
+        return memo[key]
+    owner = getattr(v, "owner", None)
+    if owner is None:
+        if hasattr(v, "data"):
+            out = _const(v.data)
+        elif hasattr(v, "get_value"):
+            out = _const(v.get_value())
+        else:
+            out = ("input", v)
+        memo[key] = out
+        return out
+    op, ins = owner.op, list(owner.inputs)
+    name = _opname(op)
+    if name in ("DimShuffle", "Cast", "SpecifyShape", "Rebroadcast", "Unbroadcast"):
+        out = build_tree(ins[0], memo)
+    elif name in ("CheckParameterValue", "Assert", "CheckAndRaise"):
+        out = build_tree(ins[0], memo)          # the device applies its own parameter checks (model_dev.h KILL_UNLESS)
+    elif name in ("Alloc",):
+        out = build_tree(ins[0], memo)          # pt.full(size, x): a broadcast
+    elif name == "Elemwise":
+        sn = _scalar_name(op)
+        if sn == "cast" or sn == "identity":
+            out = build_tree(ins[0], memo)
+        elif sn == "second":                     # second(a, b) = b broadcast to a
+            out = build_tree(ins[1], memo)
+        else:
+            kids = [build_tree(i, memo) for i in ins]
+            if sn in _NUMPY_FOLD and all(k[0] == "const" for k in kids):
+                with np.errstate(all="ignore"):
+                    out = _const(_NUMPY_FOLD[sn](*[k[1] for k in kids]))
+            else:
+                out = (sn, *kids)
+    elif name in ("Sum", "CAReduce"):
+        out = ("sum", getattr(op, "axis", None), build_tree(ins[0], memo))
+    elif name in ("AdvancedSubtensor1", "AdvancedSubtensor"):
+        out = ("take", build_tree(ins[0], memo), build_tree(ins[1], memo))
+    elif name == "Dot":
+        out = ("dot", build_tree(ins[0], memo), build_tree(ins[1], memo))
+    elif name in ("All", "Any", "MakeVector"):
+        out = (name.lower(), *[build_tree(i, memo) for i in ins])
+    else:
+        raise NotLowerable(f"op {name} is outside the lowering protocol")
+    memo[key] = out
+    return out
+
+
+# ---------------------------------------------------------------------------
+# template matching
+# ---------------------------------------------------------------------------
+class W:
+    """Wildcard of a template."""
+
+    def __init__(self, name):
+        self.name = name
+
+
+def K(x):
+    return ("const", np.asarray(float(x)))
+
+
+_COMMUTATIVE = {"add", "mul"}
+
+
+def _same(a, b) -> bool:
+    """Structural equality of two trees (inputs by identity, constants numerically)."""
+    if a[0] != b[0]:
+        return False
+    if a[0] == "const":
+        return a[1].shape == b[1].shape and np.allclose(a[1], b[1], rtol=1e-12, atol=0)
+    if a[0] == "input":
+        return a[1] is b[1]
+    return len(a) == len(b) and all((_same(x, y) if isinstance(x, tuple) else x == y) for x, y in zip(a[1:], b[1:]))
+
+
+def _solve_const(t, c, env: Dict[str, Any]) -> bool:
+    """Template `t` against a FOLDED constant `c` (e.g. `log(sigma)` with a constant sigma arrives as one number or one array):
+    invert the invertible ops down to a wildcard; bindings made this way are marked derived (a later direct occurrence replaces
+    them, so that the lowered parameter is the number the model states, not exp(log(.)) of it)."""
+    c = np.asarray(c, dtype="float64")
+    if isinstance(t, W):
+        if t.name in env:
+            b = env[t.name]
+            return b[0] == "const" and np.broadcast_shapes(b[1].shape, c.shape) is not None and np.allclose(b[1], c, rtol=1e-12, atol=1e-300)
+        env[t.name] = ("const", c)
+        env.setdefault("__derived__", set()).add(t.name)
+        return True
+    if t[0] == "const":
+        return c.size == 1 and math.isclose(float(t[1]), float(c.reshape(-1)[0]), rel_tol=1e-12, abs_tol=1e-300)
+    if t[0] == "log":
+        return _solve_const(t[1], np.exp(c), env)
+    if t[0] == "neg":
+        return _solve_const(t[1], -c, env)
+    if t[0] in ("sub", "add") and len(t) == 3:
+        for i, o in ((1, 2), (2, 1)):
+            if not isinstance(t[i], W) and t[i][0] == "const":
+                k = float(t[i][1])
+                if t[0] == "add":
+                    return _solve_const(t[o], c - k, env)
+                return _solve_const(t[o], (k - c) if i == 1 else (c + k), env)
+    return False
+
+
+def unify(t, node, env: Dict[str, Any]) -> bool:
+    if isinstance(t, W):
+        if t.name in env:
+            if not _same(env[t.name], node):
+                return False
+            if t.name in env.get("__derived__", ()) :   # prefer the occurrence that was not reconstructed from a folded constant
+                env[t.name] = node
+                env["__derived__"].discard(t.name)
+            return True
+        env[t.name] = node
+        return True
+    if t[0] == "const":
+        return node[0] == "const" and node[1].size == 1 and math.isclose(float(node[1].reshape(-1)[0]), float(t[1]), rel_tol=1e-12, abs_tol=1e-300)
+    if node[0] == "const" and t[0] in ("log", "neg", "sub", "add"):
+        return _solve_const(t, node[1], env)
+    if node[0] != t[0] or len(node) != len(t):
+        return False
+    orders = [list(range(1, len(t)))]
+    if t[0] in _COMMUTATIVE and len(t) == 3:
+        orders.append([2, 1])
+    for order in orders:
+        trial = {k: (set(v) if isinstance(v, set) else v) for k, v in env.items()}
+        if all(unify(t[i], node[j], trial) for i, j in zip(range(1, len(t)), order)):
+            env.clear()
+            env.update(trial)
+            return True
+    return False
+
+
+LOG_SQRT_2PI = math.log(math.sqrt(2.0 * math.pi))
+LOG_SQRT_2_OVER_PI = math.log(math.sqrt(2.0 / math.pi))
+
+
+def _zsq(v, loc, scale):
+    return ("pow", ("div", ("sub", v, loc), scale), K(2))
+
+
+V, MU, SG, AL, BE, P = W("value"), W("mu"), W("sigma"), W("alpha"), W("beta"), W("p")
+_CAUCHY = ("sub", ("sub", K(-math.log(math.pi)), ("log", BE)), ("log1p", _zsq(V, AL, BE)))
+# (distribution code, template, names of the wildcards in argument order) -- each the unrewritten form of the reference's logp
+TEMPLATES: List[Tuple[int, Any, Tuple[str, ...]]] = [
+    (ms.D_NORMAL, ("sub", ("sub", ("mul", K(-0.5), _zsq(V, MU, SG)), K(LOG_SQRT_2PI)), ("log", SG)), ("value", "mu", "sigma")),          # continuous.py:526-532
+    (ms.D_HALFNORMAL, ("switch", ("ge", V, W("loc")), ("sub", ("add", ("mul", K(-0.5), _zsq(V, W("loc"), SG)), K(LOG_SQRT_2_OVER_PI)), ("log", SG)), K(-math.inf)),
+     ("value", "sigma")),                                                                                                                # continuous.py:909-916
+    (ms.D_CAUCHY, _CAUCHY, ("value", "alpha", "beta")),                                                                                   # continuous.py:2287-2293
+    (ms.D_HALFCAUCHY, ("switch", ("ge", V, K(0)), ("add", K(math.log(2.0)), ("sub", ("sub", K(-math.log(math.pi)), ("log", BE)), ("log1p", _zsq(V, K(0), BE)))), K(-math.inf)),
+     ("value", "beta")),                                                                                                                 # continuous.py:2383-2390
+    (ms.D_EXPONENTIAL, ("switch", ("ge", V, K(0)), ("sub", ("neg", ("log", MU)), ("div", V, MU)), K(-math.inf)), ("value", "mu")),          # continuous.py:1478-1486
+    (ms.D_BERNOULLI, ("switch", ("or", ("lt", V, K(0)), ("gt", V, K(1))), K(-math.inf), ("switch", V, ("log", P), ("log1p", ("neg", P)))), ("value", "p")),   # discrete.py:362-374
+]
+
+
+# ---------------------------------------------------------------------------
+# the walker
+# ---------------------------------------------------------------------------
+class _Lowering:
+    def __init__(self, value_vars, transforms, shapes):
+        self.spec = ms.ModelSpec()
+        self.var_id: Dict[int, int] = {}
+        off = 0
+        for v in value_vars:
+            tr, lo, hi = transforms.get(v.name, (ms.TR_NONE, 0.0, 1.0))
+            rv_name = v.name
+            suffix = {ms.TR_LOG: "_log__", ms.TR_LOGODDS: "_logodds__", ms.TR_INTERVAL: "_interval__"}.get(tr)
+            if suffix and rv_name.endswith(suffix):
+                rv_name = rv_name[: -len(suffix)]
+            fv = ms.FreeVar(rv_name, tuple(shapes[v.name]), tr, float(lo), float(hi), off)
+            off += fv.size
+            self.var_id[id(v)] = len(self.spec.vars)
+            self.spec.vars.append(fv)
+
+    # value-variable reference: the input itself (untransformed) or its backward transform
+    def _as_var(self, node) -> Optional[int]:
+        if node[0] == "input" and id(node[1]) in self.var_id:
+            k = self.var_id[id(node[1])]
+            return k if self.spec.vars[k].transform == ms.TR_NONE else None
+        if node[0] == "exp" and node[1][0] == "input" and id(node[1][1]) in self.var_id:
+            k = self.var_id[id(node[1][1])]
+            return k if self.spec.vars[k].transform == ms.TR_LOG else None
+        if node[0] == "sigmoid" and node[1][0] == "input" and id(node[1][1]) in self.var_id:
+            k = self.var_id[id(node[1][1])]
+            return k if self.spec.vars[k].transform == ms.TR_LOGODDS else None
+        return None
+
+    def _operand(self, node) -> Optional[ms.Operand]:
+        k = self._as_var(node)
+        if k is not None:
+            return ms.Operand(ms.OP_VAR, 0.0, k)
+        if node[0] == "const":
+            arr = np.asarray(node[1], dtype="float64")
+            if arr.size == 1:
+                return ms.Operand(ms.OP_CONST, float(arr.reshape(-1)[0]))
+            self.spec.data.append(np.ascontiguousarray(arr.ravel()))
+            return ms.Operand(ms.OP_DATA, 0.0, len(self.spec.data) - 1)
+        return None
+
+    def term(self, node) -> ms.Term:
+        """`a + b * c` over constants, data vectors and value variables."""
+        o = self._operand(node)
+        if o is not None:
+            return ms.Term(o)
+        if node[0] == "mul":
+            b, c = self._operand(node[1]), self._operand(node[2])
+            if b is not None and c is not None:
+                return ms.Term(ms.ZERO, b, c)
+        if node[0] == "add":
+            for x, y in ((node[1], node[2]), (node[2], node[1])):
+                a = self._operand(x)
+                if a is None:
+                    continue
+                o2 = self._operand(y)
+                if o2 is not None:
+                    return ms.Term(a, o2, ms.ONE)
+                if y[0] == "mul":
+                    b, c = self._operand(y[1]), self._operand(y[2])
+                    if b is not None and c is not None:
+                        return ms.Term(a, b, c)
+        raise NotLowerable(f"expression is outside the affine IR `a + b*c`: {_show(node)}")
+
+    def _size(self, t: ms.Term) -> int:
+        n = 1
+        for o in (t.a, t.b, t.c):
+            if o.kind == ms.OP_VAR:
+                n = max(n, self.spec.vars[o.ref].size)
+            elif o.kind == ms.OP_DATA:
+                n = max(n, self.spec.data[o.ref].size)
+        return n
+
+    # Jacobian term of a transformed value variable, added to its own factor (logprob/basic.py:618-667)
+    def _strip_jacobian(self, node, own: Optional[int]):
+        if own is None or node[0] != "add":
+            return node
+        fv = self.spec.vars[own]
+        for x, y in ((node[1], node[2]), (node[2], node[1])):
+            if fv.transform == ms.TR_LOG and y[0] == "input" and self.var_id.get(id(y[1])) == own:   # log|J| = value (transforms.py:880-891)
+                return x
+            if fv.transform == ms.TR_LOGODDS and y[0] == "add":                                        # log|J| = log sigmoid(v) + log1p(-sigmoid(v))
+                return x
+        return node
+
+    def _logit_rows(self, eta, observed) -> bool:
+        """eta_i = sum_d X[i, d] * (mu[d] + sigma[d] z[g(i), d])  ->  the hierarchical-logit rows node."""
+        if eta[0] != "sum":
+            return False
+        body = eta[2]
+        if body[0] != "mul":
+            return False
+        for xs, bs in ((body[1], body[2]), (body[2], body[1])):
+            if xs[0] != "const" or xs[1].ndim != 2 or bs[0] != "take" or bs[2][0] != "const":
+                continue
+            X, gidx, beta = xs[1], bs[2][1], bs[1]
+            if beta[0] != "add":
+                continue
+            for m_, sz in ((beta[1], beta[2]), (beta[2], beta[1])):
+                km = self._as_var(m_)
+                if km is None or sz[0] != "mul":
+                    continue
+                for s_, z_ in ((sz[1], sz[2]), (sz[2], sz[1])):
+                    ks, kz = self._as_var(s_), self._as_var(z_)
+                    if ks is None or kz is None:
+                        continue
+                    D = X.shape[1]
+                    if self.spec.vars[km].size != D or self.spec.vars[ks].size != D or self.spec.vars[kz].size % D:
+                        continue
+                    g = np.ascontiguousarray(gidx, dtype="int32")
+                    if np.any(np.diff(g) < 0):
+                        order = np.argsort(g, kind="stable")
+                        X, g, observed = X[order], g[order], np.asarray(observed)[order]
+                    self.spec.logit_rows = ms.LogitRows(np.ascontiguousarray(X, dtype="float64"), np.ascontiguousarray(observed, dtype="int8"), g, km, ks, kz, "y")
+                    return True
+        return False
+
+    def factor(self, node, name: str, own_value=None):
+        own = self.var_id.get(id(own_value)) if own_value is not None else None
+        node = self._strip_jacobian(node, own)
+        for dist, tmpl, argnames in TEMPLATES:
+            env: Dict[str, Any] = {}
+            if not unify(tmpl, node, env):
+                continue
+            if dist == ms.D_HALFNORMAL and not (env["loc"][0] == "const" and float(env["loc"][1]) == 0.0):
+                continue
+            if dist == ms.D_BERNOULLI and env["p"][0] == "sigmoid":   # Bernoulli(logit_p = eta): p = sigmoid(eta) (discrete.py:351-352)
+                val = env["value"]
+                if val[0] != "const":
+                    raise NotLowerable("a free Bernoulli variable is not a NUTS variable")
+                if self._logit_rows(env["p"][1], val[1]):
+                    return
+                t_eta = self.term(env["p"][1])
+                args = (self.term(val), t_eta)
+                self.spec.factors.append(ms.Factor(ms.D_BERNOULLI_LOGIT, max(self._size(a) for a in args), args, 0.0, name))
+                return
+            # (parameters first, then the value: the order in which `ModelBuilder` registers data vectors)
+            lowered = {a: self.term(env[a]) for a in argnames[1:] + argnames[:1]}
+            args = tuple(lowered[a] for a in argnames)
+            if dist == ms.D_EXPONENTIAL:   # the IR's Exponential takes lam = 1 / mu
+                mu = args[1]
+                if not (mu.b == ms.ZERO or mu.c == ms.ZERO) or mu.a.kind != ms.OP_CONST:
+                    raise NotLowerable("Exponential with a non-constant scale")
+                args = (args[0], ms.Term(ms.Operand(ms.OP_CONST, 1.0 / mu.a.c)))
+            self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), args, 0.0, name))
+            return
+        # a potential: the expression itself is the contribution (model/core.py:666-695)
+        t = self.term(node)
+        self.spec.factors.append(ms.Factor(ms.D_POTENTIAL, self._size(t), (t,), 0.0, name))
+
+
+def _show(node, depth=0) -> str:
+    if node[0] == "const":
+        return f"const{tuple(node[1].shape)}"
+    if node[0] == "input":
+        return getattr(node[1], "name", "input")
+    if depth > 3:
+        return node[0] + "(...)"
+    return node[0] + "(" + ", ".join(_show(k, depth + 1) if isinstance(k, tuple) else str(k) for k in node[1:]) + ")"
+
+
+def lower_to_spec(model) -> ms.ModelSpec:
+    """`model` needs: `value_vars` (ordered; `.name`, static shape via `model.value_shapes[name]` or `.type.shape`),
+    `rvs_to_transforms`-derived `model.value_transforms[name] -> (code, lower, upper)` (or transform objects with a `.name` in
+    {"log", "logodds", "interval"}), `logp(sum=False)` and the aligned list `model.logp_owners` = the value variable of each free
+    RV factor (None for observed RVs / potentials) -- on a real `pm.Model`: `[model.rvs_to_values[rv] for rv in free_RVs]`."""
+    shapes, transforms = {}, {}
+    for v in model.value_vars:
+        shp = getattr(model, "value_shapes", {}).get(v.name)
+        if shp is None:
+            shp = tuple(int(s) for s in v.type.shape)
+        shapes[v.name] = shp
+        tr = getattr(model, "value_transforms", {}).get(v.name)
+        if tr is not None and not isinstance(tr, tuple):
+            code = {"log": ms.TR_LOG, "logodds": ms.TR_LOGODDS, "interval": ms.TR_INTERVAL}[tr.name]
+            tr = (code, getattr(tr, "lower", 0.0), getattr(tr, "upper", 1.0))
+        if tr is not None:
+            transforms[v.name] = tr
+    low = _Lowering(list(model.value_vars), transforms, shapes)
+    factors = model.logp(sum=False)
+    owners = list(getattr(model, "logp_owners", [None] * len(factors)))
+    names = list(getattr(model, "logp_names", [f"factor{i}" for i in range(len(factors))]))
+    memo: dict = {}
+    for g, own, nm in zip(factors, owners, names):
+        low.factor(build_tree(g, memo), nm, own)
+    return low.spec

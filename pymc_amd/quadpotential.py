@@ -93,25 +93,29 @@ class QuadPotential:
     _prefetch = None   # (reply queue, generator state the clone started from, size)
     _PREFETCH_MIN = 2048
 
-    def _draw_normals(self):
-        """The host half of `random()`: `rng.normal(size=n)`; the device multiplies by 1/sigma."""
+    def _draw_normals(self, rows=None):
+        """The host half of `random()`: `rng.normal(size=n)`; the device multiplies by 1/sigma.  `rows` = K asks for the
+        normals of K consecutive draws at once, `(K, n)` -- the same values K calls would return (the generator fills
+        sequentially) -- for a multi-draw call; the NEXT request of the same size is prefetched by the worker thread."""
         n = self._n
-        if n < self._PREFETCH_MIN or not _PREFETCH_ON:
-            return self.rng.normal(size=n)
+        size = n if rows is None else rows * n
+        shape = n if rows is None else (rows, n)
+        if size < self._PREFETCH_MIN or not _PREFETCH_ON:
+            return self.rng.normal(size=shape)
         bg = self.rng.bit_generator
         z = None
         pf, self._prefetch = self._prefetch, None
         if pf is not None:
-            reply, base, size = pf
-            if size == n and bg.state == base:
+            reply, base, psize = pf
+            if psize == size and bg.state == base:
                 z, after = reply.get()
                 bg.state = after
         if z is None:
-            z = self.rng.normal(size=n)
+            z = self.rng.normal(size=size)
         base = bg.state
         if base.get("bit_generator") == "PCG64":
-            self._prefetch = (_request_normals(base, n), base, n)
-        return z
+            self._prefetch = (_request_normals(base, size), base, size)
+        return z if rows is None else z.reshape(rows, n)
 
     def __getstate__(self):   # a pending prefetch does not travel (cloudpickle of the step for worker processes)
         d = dict(self.__dict__)

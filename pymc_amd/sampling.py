@@ -123,19 +123,20 @@ def assign_chains(chains: int, rank: int, world: int) -> List[int]:
     return [c for c in range(chains) if c % world == rank]
 
 
-def sample_draws(step: NUTS, point, K: int, callback=None, first_index: int = 0):
-    """K post-tuning transitions from `point`: `(positions [K][n], [stats] * K, last point)`.
+def sample_draws(step: NUTS, point, K: int, callback=None, first_index: int = 0, each_draw=None):
+    """K transitions from `point` in the step's current mode (tuning or not): `(positions [K][n], [stats] * K, last point)`.
 
-    The sampling phase of `_iter_sample` (mcmc.py:1556-1572).  After tuning the reference changes nothing on the host
-    between draws, so the transitions are made in batches inside ONE C call each (`nuts_chain_draw_many`):
-    the trace lives in a device buffer, positions and statistics come back once per batch."""
+    The body of `_iter_sample` (mcmc.py:1556-1572).  Whenever nothing has to happen on the host between two draws -- after
+    tuning always; during tuning when the potential's estimators live on the device -- the transitions are made in batches
+    inside ONE C call each (`nuts_chain_draw_many`): the trace lives in a device buffer, positions and
+    statistics come back once per batch.  `each_draw(i)` (pooled adaptation) and `callback` force draw-by-draw."""
     n = step._n
     out = np.empty((K, n))
     stats_out = []
     batch = int(os.environ.get("PYMC_AMD_DRAW_BATCH", "64"))
     i = 0
     while i < K:
-        if batch > 1 and callback is None and getattr(step, "can_draw_many", False):
+        if batch > 1 and callback is None and each_draw is None and getattr(step, "can_draw_many", False):
             pos, point, st = step.draw_many(point, min(batch, K - i))
             out[i : i + len(st)] = pos
             stats_out.extend(st)
@@ -144,6 +145,8 @@ def sample_draws(step: NUTS, point, K: int, callback=None, first_index: int = 0)
         point, stats = step.step(point)
         out[i] = DictToArrayBijection.map({k: point[k] for k in step.var_names}).data
         stats_out.append(stats[0])
+        if each_draw is not None:
+            each_draw(first_index + i)
         if callback is not None:
             callback(first_index + i, point, stats[0])
         i += 1
@@ -156,22 +159,11 @@ def sample_chain(step: NUTS, start, rng, tune: int, draws: int, callback=None, p
     step.setup_chain(rng, tune, draws)
     step.tune = bool(tune)
     step.reset_tuning()
-    point = start
-    n = step._n
-    out = np.empty((total, n))
-    stats_out = []
-    for i in range(tune):
-        if i == 0:
-            step.iter_count = 0
-        point, stats = step.step(point)
-        out[i] = DictToArrayBijection.map({k: point[k] for k in step.var_names}).data
-        stats_out.append(stats[0])
-        if pooled is not None:
-            pooled.after_tuning_draw(step, i)
-        if callback is not None:
-            callback(i, point, stats[0])
-    if tune == 0:
-        step.iter_count = 0
+    step.iter_count = 0
+    out = np.empty((total, step._n))
+    each = (lambda i: pooled.after_tuning_draw(step, i)) if pooled is not None else None
+    d, stats_out, point = sample_draws(step, start, tune, callback=callback, each_draw=each)
+    out[:tune] = d
     step.stop_tuning()
     if pooled is not None:
         pooled.end_of_tuning(step)
@@ -392,7 +384,9 @@ def sample(
 
 
 def gather_trace(result, chains: int, rank: int, world: int, device):
-    """Final trace gather: draws x n x 8 B per chain to rank 0."""
+    """Final trace gather to rank 0: positions (draws x n x 8 B per chain) as one padded tensor
+    gather over RCCL / gloo, and the per-draw sampler statistics of every chain (`sample_stats`, the 19 NUTS keys of
+    nuts.py:110-130 incl. the warning objects) with `gather_object` -- a few KB per chain."""
     import torch
     import torch.distributed as dist
 
@@ -405,12 +399,22 @@ def gather_trace(result, chains: int, rank: int, world: int, device):
     t = torch.from_numpy(pad).to(dev)
     out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
     dist.gather(t, out, dst=0)
+    mine_stats = {"stats": result["stats"], "warmup_stats": result.get("warmup_stats", []), "sampling_time": result.get("sampling_time", 0.0)}
+    all_stats = [None] * world if rank == 0 else None
+    dist.gather_object(mine_stats, all_stats, dst=0)
     if rank == 0:
         full = np.empty((chains,) + d.shape[1:])
+        stats = [None] * chains
+        warm = [None] * chains
         for r in range(world):
             for k, c in enumerate(assign_chains(chains, r, world)):
                 full[c] = out[r][k].cpu().numpy()
+                stats[c] = all_stats[r]["stats"][k]
+                warm[c] = all_stats[r]["warmup_stats"][k] if all_stats[r]["warmup_stats"] else []
         result = dict(result)
         result["draws"] = full
+        result["stats"] = stats
+        result["warmup_stats"] = warm
+        result["sampling_time_per_rank"] = [a["sampling_time"] for a in all_stats]
         result["chains"] = list(range(chains))
     return result

@@ -420,19 +420,20 @@ class NUTS(_DeviceHMCBase):
 
         return (update_stats,)
 
-    def _stats_dict(self, st, point_map_info):
+    def _stats_dict(self, st, point_map_info, step_index=None, tune=None):
         """The 19 NUTS statistics (nuts.py:110-130) of one transition + the divergence warning (base_hmc.py:241-268)."""
         warning = None
+        tune = self.tune if tune is None else tune
         if st.diverging:
-            kind = "TUNING_DIVERGENCE" if self.tune else "DIVERGENCE"
-            if not self.tune:
+            kind = "TUNING_DIVERGENCE" if tune else "DIVERGENCE"
+            if not tune:
                 self._num_divs_sample += 1
             msg = f"Energy change in leapfrog step is too large: {st.divergence_energy_change}."  # nuts.py:434
             src = dst = None
-            if not self.tune and self._num_divs_sample < 100:  # base_hmc.py:249-258: at most 100 points are kept
+            if not tune and self._num_divs_sample < 100:  # base_hmc.py:249-258: at most 100 points are kept
                 src = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_source"), point_map_info))
                 dst = DictToArrayBijection.rmap(RaveledVars(self._vector("divergence_dest"), point_map_info))
-            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1, None, src, dst)
+            warning = SamplerWarning(kind, msg, "debug", self.iter_count - 1 if step_index is None else step_index, None, src, dst)
         return {
             "diverging": bool(st.diverging),
             "divergences": int(st.divergences),
@@ -455,15 +456,24 @@ class NUTS(_DeviceHMCBase):
             "smallest_eigval": np.nan,
         }
 
-    # ---- several post-tuning transitions per device launch ----------
+    # ---- several transitions per C call ----------------------------------
     @property
     def can_draw_many(self) -> bool:
-        """True when `draw_many` applies: tuning is over and the model runs on the single-launch path."""
-        return (not self.tune) and not self.spec.extra and bool(self._scalar("single_launch"))
+        """True when `draw_many` applies.  Models on the single-launch path: after tuning (the whole batch is ONE launch).
+        Every other model: whenever nothing on the host has to happen between two draws -- the potential's estimators live
+        on the device (or tuning is over) and no other step method rewrites extra values in between."""
+        if self.spec.extra:
+            return False
+        if bool(self._scalar("single_launch")):
+            return not self.tune
+        from pymc_amd.quadpotential import QuadPotential
+
+        host_adapted = type(self.potential)._host_update is not QuadPotential._host_update
+        return (not self.tune) or not host_adapted
 
     def draw_many(self, point: PointType, K: int):
-        """K consecutive transitions from `point` in one launch (`nuts_chain_draw_many`).  Returns
-        `(positions [k][n], last point, [stats] * k)` with k <= K: the device stops a batch after a divergent draw and
+        """K consecutive transitions from `point` inside one C call (`nuts_chain_draw_many`).  Returns
+        `(positions [k][n], last point, [stats] * k)` with k <= K: the engine stops a batch after a divergent draw and
         when the pre-drawn uniforms could not cover another worst-case tree; the caller just asks again.  Both
         generators end exactly where k calls of `astep` would have left them."""
         sub = {name: point[name] for name in self.var_names}
@@ -472,7 +482,7 @@ class NUTS(_DeviceHMCBase):
         n = self._n
         prng = self.potential.rng
         p_saved = prng.bit_generator.state
-        normals = prng.normal(size=(K, n))               # == K calls of potential.random()'s rng.normal(size=n)
+        normals = self.potential._draw_normals(rows=K)    # == K calls of potential.random()'s rng.normal(size=n)
         bg = self.rng.bit_generator
         saved = bg.state
         n_uni = self._n_uniforms + UNIFORMS_PER_EXTRA_DRAW * K   # one worst-case tree + a typical tree's worth per further draw
@@ -480,11 +490,13 @@ class NUTS(_DeviceHMCBase):
         out = np.empty((K, n))
         stats = (_lib.DrawStats * K)()
         n_done = C.c_int32(0)
+        was_tuning = self.tune
         rc = _lib.load().nuts_chain_draw_many(
             self._chain, _lib.dptr(q), _lib.dptr(normals), _lib.dptr(uniforms), n_uni, K, _lib.dptr(out), stats, C.byref(n_done)
         )
         bg.state = saved
         if rc != _lib.NUTS_OK:
+            self.potential._prefetch = None
             prng.bit_generator.state = p_saved
             _lib.check(rc, "nuts_chain_draw_many")
         k = n_done.value
@@ -493,9 +505,13 @@ class NUTS(_DeviceHMCBase):
         adv["has_uint32"], adv["uinteger"] = saved["has_uint32"], saved["uinteger"]
         bg.state = adv
         if k < K:                                         # give back the momentum normals of the draws not made
+            self.potential._prefetch = None
             prng.bit_generator.state = p_saved
             prng.normal(size=(k, n))
-        stats_out = [self._stats_dict(stats[i], q0.point_map_info) for i in range(k)]
+        stats_out = []
+        for i in range(k):
+            # (the warning of draw i carries `iter_count - 1` of that draw: the engine has already counted the whole batch)
+            stats_out.append(self._stats_dict(stats[i], q0.point_map_info, step_index=self.iter_count - k + i, tune=was_tuning))
         last = DictToArrayBijection.rmap(RaveledVars(out[k - 1].copy(), q0.point_map_info), start_point=point)
         return out[:k], last, stats_out
 

@@ -1,0 +1,225 @@
+"""A stand-in for the slice of PyTensor / PyMC that `pymc_amd.lowering.lower_to_spec` walks (PyTensor cannot be imported in
+the build image).  TEST INFRASTRUCTURE.
+
+* graph protocol: `Variable(owner, name)`, `Apply(op, inputs)`, ops named as PyTensor names them (`Elemwise` with a
+  `scalar_op` object whose class is `Add`, `Mul`, `Sub`, `TrueDiv`, `Pow`, `Exp`, `Log`, `Log1p`, `Sqrt`, `Neg`, `Switch`, `GE`,
+  `GT`, `LT`, `OR`, `Sigmoid`; `DimShuffle`; `Sum` with `.axis`; `AdvancedSubtensor1`; `CheckParameterValue`; constants carry
+  `.data`), with operator overloading so that the distribution code below reads like the reference's;
+* distributions: `logp` bodies TRANSCRIBED from the reference, each citing its lines -- these build exactly the expression a
+  `pm.Model` would hand to the compiler BEFORE rewrites (`Model.logp`, model/core.py:612-695);
+* `StubModel`: `value_vars`, value transforms (`rvs_to_transforms`), `logp(sum=False)` in the reference's order (free RVs,
+  observed RVs, potentials) with the Jacobian term added to transformed variables' own factors
+  (`transformed_conditional_logp`, logprob/basic.py:618-667).
+"""
+import numpy as np
+
+
+class Apply:
+    def __init__(self, op, inputs):
+        self.op, self.inputs = op, list(inputs)
+
+
+class _Type:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class Variable:
+    def __init__(self, owner=None, name=None, shape=()):
+        self.owner, self.name, self.type = owner, name, _Type(shape)
+
+    def _bin(self, other, cls, swap=False):
+        other = as_tensor(other)
+        a, b = (other, self) if swap else (self, other)
+        return elemwise(cls, a, b)
+
+    def __add__(self, o): return self._bin(o, Add)
+    def __radd__(self, o): return self._bin(o, Add, True)
+    def __sub__(self, o): return self._bin(o, Sub)
+    def __rsub__(self, o): return self._bin(o, Sub, True)
+    def __mul__(self, o): return self._bin(o, Mul)
+    def __rmul__(self, o): return self._bin(o, Mul, True)
+    def __truediv__(self, o): return self._bin(o, TrueDiv)
+    def __rtruediv__(self, o): return self._bin(o, TrueDiv, True)
+    def __neg__(self): return elemwise(Neg, self)
+    def __gt__(self, o): return self._bin(o, GT)
+    def __ge__(self, o): return self._bin(o, GE)
+    def __lt__(self, o): return self._bin(o, LT)
+    def __le__(self, o): return self._bin(o, LE)
+    def __getitem__(self, idx): return Variable(Apply(AdvancedSubtensor1(), [self, as_tensor(idx)]), shape=(len(np.asarray(idx)),) + self.type.shape[1:])
+    def sum(self, axis=None): return Variable(Apply(Sum(axis), [self]), shape=())
+
+
+class TensorConstant(Variable):
+    def __init__(self, data):
+        data = np.asarray(data)
+        super().__init__(None, None, data.shape)
+        self.data = data
+
+
+def as_tensor(x):
+    return x if isinstance(x, Variable) else TensorConstant(x)
+
+
+# ---- ops (class names are what the walker keys on) ----
+class Elemwise:
+    def __init__(self, scalar_op):
+        self.scalar_op = scalar_op
+
+
+class DimShuffle:
+    pass
+
+
+class AdvancedSubtensor1:
+    pass
+
+
+class Sum:
+    def __init__(self, axis):
+        self.axis = axis
+
+
+class CheckParameterValue:
+    def __init__(self, msg):
+        self.msg = msg
+
+
+class All:
+    pass
+
+
+for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "OR", "AND", "Sigmoid"):
+    globals()[_n] = type(_n, (), {})
+
+
+def _bshape(*vs):
+    return np.broadcast_shapes(*[v.type.shape for v in vs])
+
+
+def _dimshuffle_to(v, shape):
+    """PyTensor inserts a DimShuffle wherever an operand needs broadcast dimensions."""
+    if v.type.shape == tuple(shape) or isinstance(v, TensorConstant) and v.data.ndim == 0:
+        return v
+    return Variable(Apply(DimShuffle(), [v]), shape=shape)
+
+
+def elemwise(cls, *ins):
+    ins = [as_tensor(i) for i in ins]
+    shape = _bshape(*ins)
+    ins = [_dimshuffle_to(i, shape) if i.type.shape != () else i for i in ins]
+    return Variable(Apply(Elemwise(cls()), ins), shape=shape)
+
+
+class pt:   # the `pytensor.tensor` names the reference's logp bodies use
+    pow = staticmethod(lambda a, b: elemwise(Pow, a, b))
+    log = staticmethod(lambda a: elemwise(Log, a))
+    log1p = staticmethod(lambda a: elemwise(Log1p, a))
+    sqrt = staticmethod(lambda a: elemwise(Sqrt, a))
+    exp = staticmethod(lambda a: elemwise(Exp, a))
+    sigmoid = staticmethod(lambda a: elemwise(Sigmoid, a))
+    switch = staticmethod(lambda c, a, b: elemwise(Switch, c, a, b))
+    ge = staticmethod(lambda a, b: elemwise(GE, a, b))
+    lt = staticmethod(lambda a, b: elemwise(LT, a, b))
+    gt = staticmethod(lambda a, b: elemwise(GT, a, b))
+    or_ = staticmethod(lambda a, b: elemwise(OR, a, b))
+
+
+def check_parameters(expr, *conds, msg=""):   # distributions/dist_math.py:50-74
+    allc = Variable(Apply(All(), [as_tensor(c) for c in conds]), shape=())
+    return Variable(Apply(CheckParameterValue(msg), [expr, allc]), shape=expr.type.shape)
+
+
+# ---- logp bodies, transcribed ----
+def normal_logp(value, mu, sigma):          # distributions/continuous.py:526-532
+    res = -0.5 * pt.pow((value - mu) / sigma, 2) - pt.log(pt.sqrt(2.0 * np.pi)) - pt.log(sigma)
+    return check_parameters(res, sigma > 0, msg="sigma > 0")
+
+
+def halfnormal_logp(value, loc, sigma):     # distributions/continuous.py:909-916
+    res = -0.5 * pt.pow((value - loc) / sigma, 2) + pt.log(pt.sqrt(2.0 / np.pi)) - pt.log(sigma)
+    res = pt.switch(pt.ge(value, loc), res, -np.inf)
+    return check_parameters(res, sigma > 0, msg="sigma > 0")
+
+
+def cauchy_logp(value, alpha, beta):        # distributions/continuous.py:2287-2293
+    res = -pt.log(np.pi) - pt.log(beta) - pt.log1p(pt.pow((value - alpha) / beta, 2))
+    return check_parameters(res, beta > 0, msg="beta > 0")
+
+
+def halfcauchy_logp(value, beta):           # distributions/continuous.py:2383-2390
+    res = pt.log(2) + cauchy_logp(value, 0, beta)
+    res = pt.switch(value >= 0, res, -np.inf)
+    return check_parameters(res, beta > 0, msg="beta > 0")
+
+
+def bernoulli_logp(value, p):               # distributions/discrete.py:362-374
+    res = pt.switch(pt.or_(pt.lt(value, 0), pt.gt(value, 1)), -np.inf, pt.switch(value, pt.log(p), pt.log1p(-p)))
+    return check_parameters(res, 0 <= p, p <= 1, msg="0 <= p <= 1")
+
+
+class _RV:
+    def __init__(self, name, shape, logp_fn, params, transform=None, observed=None):
+        self.name, self.shape, self.logp_fn, self.params, self.transform, self.observed = name, tuple(shape), logp_fn, params, transform, observed
+        if observed is None:
+            vname = name if transform is None else f"{name}_{transform}__"   # util.py:138-155
+            self.value = Variable(None, vname, self.shape)
+            # what the rest of the graph sees in place of the RV: transform.backward(value) (logprob/transforms.py:880-891, 1076-1088)
+            self.expr = {None: self.value, "log": pt.exp(self.value) if transform == "log" else None,
+                         "logodds": pt.sigmoid(self.value) if transform == "logodds" else None}[transform]
+        else:
+            self.value, self.expr = None, TensorConstant(np.asarray(observed, dtype="float64"))
+
+
+class StubModel:
+    """`with pm.Model(): ...` reduced to what the lowering reads."""
+
+    def __init__(self):
+        self.free, self.obs, self.pots = [], [], []
+
+    def _add(self, rv):
+        (self.free if rv.observed is None else self.obs).append(rv)
+        return rv.expr
+
+    def Normal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None):
+        return self._add(_RV(name, shape, normal_logp, (as_tensor(mu), as_tensor(sigma)), None, observed))
+
+    def HalfNormal(self, name, sigma=1.0, shape=()):
+        return self._add(_RV(name, shape, lambda v, s: halfnormal_logp(v, 0.0, s), (as_tensor(sigma),), "log"))
+
+    def HalfCauchy(self, name, beta=1.0, shape=()):
+        return self._add(_RV(name, shape, halfcauchy_logp, (as_tensor(beta),), "log"))
+
+    def Bernoulli(self, name, logit_p, observed):
+        return self._add(_RV(name, np.shape(observed), bernoulli_logp, (pt.sigmoid(logit_p),), None, observed))   # discrete.py:351-352
+
+    # ---- the model protocol of `lower_to_spec` ----
+    @property
+    def value_vars(self):
+        return [rv.value for rv in self.free]
+
+    @property
+    def value_shapes(self):
+        return {rv.value.name: rv.shape for rv in self.free}
+
+    @property
+    def value_transforms(self):
+        code = {"log": 1, "logodds": 2}
+        return {rv.value.name: (code[rv.transform], 0.0, 1.0) for rv in self.free if rv.transform}
+
+    @property
+    def logp_owners(self):
+        return [rv.value for rv in self.free] + [None] * len(self.obs)
+
+    @property
+    def logp_names(self):
+        return [rv.name for rv in self.free + self.obs]
+
+    def logp(self, sum=False):
+        out = []
+        for rv in self.free + self.obs:
+            lp = rv.logp_fn(rv.expr, *rv.params)
+            if rv.transform == "log":      # + log|J| = value (LogTransform.log_jac_det, transforms.py:880-891)
+                lp = lp + rv.value
+            out.append(lp)
+        return out

@@ -33,11 +33,18 @@ def _worker(rank, world, port, q):
     chains, draws, n = 5, 7, 3
     mine = assign_chains(chains, rank, world)
     local = np.stack([np.full((draws, n), float(c)) + np.arange(draws)[:, None] for c in mine])
-    res = gather_trace({"draws": local, "chains": mine}, chains, rank, world, None)
+    local_stats = [[{"depth": c, "tree_size": float(i), "warning": None} for i in range(draws)] for c in mine]
+    res = gather_trace({"draws": local, "chains": mine, "stats": local_stats, "warmup_stats": [[] for _ in mine], "sampling_time": 1.0 + rank},
+                       chains, rank, world, None)
     if rank == 0:
         out["gather_ok"] = bool(
             res["draws"].shape == (chains, draws, n)
             and all(np.array_equal(res["draws"][c], np.full((draws, n), float(c)) + np.arange(draws)[:, None]) for c in range(chains))
+        )
+        # the sampler statistics of EVERY chain arrive on rank 0, in chain order
+        out["stats_ok"] = bool(
+            len(res["stats"]) == chains and all(len(res["stats"][c]) == draws and all(s["depth"] == c for s in res["stats"][c]) for c in range(chains))
+            and res["sampling_time_per_rank"] == [1.0, 2.0]
         )
     # ---- Chan merge of Welford partials == pooled statistics ----
     nn = 6
@@ -68,7 +75,7 @@ def test_gloo_world2_gather_and_pooled_merge():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0]["gather_ok"]
+    assert got[0]["gather_ok"] and got[0]["stats_ok"]
     allx = np.concatenate([got[0]["x"], got[1]["x"]])
     for r in range(2):
         m = got[r]["merged"]

@@ -685,6 +685,43 @@ def test_draw_many_equals_draw_by_draw(monkeypatch):
         assert g1 == g2 and p1 == p2, batch
 
 
+@pytest.mark.parametrize("which", ["hier_logit", "hier_logit_ga", "mvnormal", "schools_big"])
+def test_draw_many_on_the_general_path_equals_draw_by_draw(which, monkeypatch):
+    """The same for models on the general path (one or more launches per leapfrog), where a batch also covers TUNING draws
+    (dual averaging on the host from the per-draw record, Welford update as a kernel): tuning + sampling through
+    `nuts_chain_draw_many` against one C call per draw -- positions of all draws, every statistic, the adapted mass matrix and
+    both generators bitwise equal; batches that stop early (uniforms run out, divergences) included."""
+    import pymc_amd.step as step_mod
+    from pymc_amd.sampling import sample
+
+    if which == "hier_logit_ga":
+        monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    spec = {"hier_logit": lambda: models.hier_logit(G=24, D=8, rows_per_group=150, seed=3), "hier_logit_ga": lambda: models.hier_logit(G=24, D=8, rows_per_group=300, seed=3),
+            "mvnormal": lambda: models.mvnormal(n=80), "schools_big": lambda: models.eight_schools(600)}[which]()
+
+    def run():
+        r = sample(draws=30, tune=130, chains=1, model=spec, random_seed=5, device=0, init="adapt_diag", discard_tuned_samples=False)
+        st = r["step"]
+        out = (r["draws"].copy(), r["stats"][0], st.rng.bit_generator.state, st.potential.rng.bit_generator.state, st._vector("var"))
+        st.close()
+        return out
+
+    monkeypatch.setenv("PYMC_AMD_DRAW_BATCH", "1")
+    d1, s1, g1, p1, v1 = run()
+    assert len(s1) == 160
+    keys = INT_KEYS + ("energy", "model_logp", "mean_tree_accept", "max_energy_error", "energy_error", "step_size", "step_size_bar", "divergences")
+    for batch, per_draw in (("64", 64), ("7", 64), ("32", 1)):
+        monkeypatch.setenv("PYMC_AMD_DRAW_BATCH", batch)
+        monkeypatch.setattr(step_mod, "UNIFORMS_PER_EXTRA_DRAW", per_draw)
+        d2, s2, g2, p2, v2 = run()
+        assert np.array_equal(d1, d2), batch
+        assert len(s1) == len(s2)
+        for i, (a, b) in enumerate(zip(s1, s2)):
+            for k in keys:
+                assert a[k] == b[k], (batch, i, k)
+        assert g1 == g2 and p1 == p2 and np.array_equal(v1, v2), batch
+
+
 def test_concurrent_chains_do_not_change_results():
     """`cores` (mcmc.py:690-693): chains of a single-launch model run concurrently from host threads, one engine
     stream each.  Every chain starts from the same sampling state with its own generator, so the draws must be

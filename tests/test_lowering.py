@@ -1,0 +1,118 @@
+"""`lower_to_spec` on stub graphs that transcribe what `Model.logp(sum=False)` builds for the
+golden hierarchical Normal (pytensorf.py:514-546), eight schools (tests/test_model_graph.py:44-57) and the hierarchical
+logistic regression of the benchmark: the lowered spec must be the `ModelBuilder` spec field for field, and evaluate to the
+reference's literal -12.691227342634292 through the oracle (and, on the GPU box, through the device)."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stubgraph as sg  # noqa: E402
+
+from oracle import ref_models  # noqa: E402
+from pymc_amd import models  # noqa: E402
+from pymc_amd.lowering import NotLowerable, build_tree, lower_to_spec  # noqa: E402
+
+
+def _golden():
+    m = sg.StubModel()
+    mu_pop = m.Normal("mu_pop")
+    sigma_pop = m.HalfNormal("sigma_pop")
+    mu = m.Normal("mu", mu_pop, sigma_pop, shape=(3,))
+    m.Normal("y", mu, 1.0, observed=[0.0, 1.0, 2.0])
+    return m
+
+
+def _schools(J=8):
+    ref = models.eight_schools(J)
+    y, sigma = ref.data[1], ref.data[0]
+    m = sg.StubModel()
+    eta = m.Normal("eta", 0.0, 1.0, shape=(J,))
+    mu = m.Normal("mu", 0.0, 1e6)
+    tau = m.HalfCauchy("tau", 25.0)
+    m.Normal("obs", mu + tau * eta, sigma, observed=y)
+    return m
+
+
+def _hier_logit(G=6, D=8, rpg=5):
+    ref = models.hier_logit(G=G, D=D, rows_per_group=rpg, seed=3)
+    r = ref.logit_rows
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 1.0, shape=(D,))
+    sigma = m.HalfNormal("sigma", 1.0, shape=(D,))
+    z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    beta = mu + sigma * z                                   # (G, D)
+    eta = (sg.as_tensor(r.X) * beta[r.group_idx]).sum(axis=1)
+    m.Bernoulli("y", logit_p=eta, observed=r.y)
+    return m, ref
+
+
+def _assert_same_spec(a, b):
+    assert [(v.name, v.value_name, v.shape, v.transform, v.offset) for v in a.vars] == [(v.name, v.value_name, v.shape, v.transform, v.offset) for v in b.vars]
+    assert len(a.data) == len(b.data) and all(np.array_equal(x, y) for x, y in zip(a.data, b.data))
+    assert len(a.factors) == len(b.factors)
+    for fa, fb in zip(a.factors, b.factors):
+        assert (fa.dist, fa.size, fa.args, fa.konst, fa.name) == (fb.dist, fb.size, fb.args, fb.konst, fb.name), (fa, fb)
+    assert (a.logit_rows is None) == (b.logit_rows is None)
+    if a.logit_rows is not None:
+        ra, rb = a.logit_rows, b.logit_rows
+        assert np.array_equal(ra.X, rb.X) and np.array_equal(ra.y, rb.y) and np.array_equal(ra.group_idx, rb.group_idx)
+        assert (ra.mu, ra.sigma, ra.z) == (rb.mu, rb.sigma, rb.z)
+
+
+def test_golden_hierarchical_normal_lowers_to_the_builder_spec_and_the_reference_literal():
+    spec = lower_to_spec(_golden())
+    _assert_same_spec(spec, models.golden_hier_normal())
+    lp, _ = ref_models.evaluate(spec, np.array([0.0, 1.0, 0.0, 1.0, 2.0]))
+    assert abs(lp - (-12.691227342634292)) < 1e-12            # pymc/pytensorf.py:514-546
+
+
+@pytest.mark.parametrize("J", [8, 24])
+def test_eight_schools_lowers_to_the_builder_spec(J):
+    _assert_same_spec(lower_to_spec(_schools(J)), models.eight_schools(J))
+
+
+def test_hierarchical_logit_rows_are_recognised():
+    m, ref = _hier_logit()
+    _assert_same_spec(lower_to_spec(m), ref)
+
+
+def test_tree_building_strips_broadcasts_and_checks_and_folds_constants():
+    m = _golden()
+    t = build_tree(m.logp(sum=False)[2])                      # mu ~ Normal(mu_pop, sigma_pop), shape (3,)
+    assert t[0] == "sub" and t[2][0] == "log" and t[2][1][0] == "exp"   # (... - log(sqrt(2 pi))) - log(exp(sigma_pop_log__)): no check wrapper
+    flat = str(t)
+    assert "DimShuffle" not in flat and "check" not in flat
+    assert any(k[0] == "const" and abs(float(k[1]) - np.log(np.sqrt(2 * np.pi))) < 1e-15 for k in t[1][1:] if isinstance(k, tuple))
+    t0 = build_tree(m.logp(sum=False)[0])                     # mu_pop ~ Normal(0, 1): log(sigma) is folded to the constant 0
+    assert t0[2][0] == "const" and float(t0[2][1]) == 0.0
+
+
+def test_what_the_ir_cannot_express_is_refused_by_name():
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 1.0, shape=(4,))
+    b = m.Normal("b", 0.0, 1.0, shape=(4,))
+    c = m.Normal("c", 0.0, 1.0, shape=(4,))
+    m.Normal("y", a * b * c + a, 1.0, observed=np.zeros(4))    # a cubic term: outside `a + b*c`
+    with pytest.raises(NotLowerable, match="affine IR"):
+        lower_to_spec(m)
+
+
+@pytest.mark.gpu
+def test_lowered_golden_model_on_the_device():
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    f = DeviceValueGradFunction(lower_to_spec(_golden()), device=0)
+    lp, g = f._pytensor_function(np.array([0.0, 1.0, 0.0, 1.0, 2.0]))
+    assert abs(lp - (-12.691227342634292)) < 1e-12
+    m, ref = _hier_logit(G=40, D=8, rpg=33)
+    spec = lower_to_spec(m)
+    f2 = DeviceValueGradFunction(spec, device=0)
+    q = np.random.default_rng(0).normal(size=spec.n) * 0.4
+    lp2, g2 = f2._pytensor_function(q)
+    lp0, g0 = ref_models.evaluate(ref, q)
+    assert abs(lp2 - lp0) <= 1e-9 * abs(lp0) and np.max(np.abs(g2 - g0)) <= 1e-9 * np.max(np.abs(g0))
+    f.close(); f2.close()
