@@ -294,6 +294,40 @@ int nuts_chain_profile(nuts_chain *c, int enable);
 int nuts_chain_profile_read(nuts_chain *c, double *dominant_ms_sum, int64_t *dominant_launches,
                             int64_t *leapfrogs);
 
+/* ---- categorical Gibbs within Metropolis for mixture assignments (BASELINE configs[4]) ----------
+ * Replaces `CategoricalGibbsMetropolis.astep_unif` (pymc/step_methods/metropolis.py:771-786) for the assignment vector of a
+ * Normal mixture, c_i ~ Categorical(w), y_i ~ Normal(mu[c_i], sigma[c_i]): the reference proposes one element at a time and
+ * evaluates the FULL model log-density for each proposal (O(N) per element, O(N^2) per sweep); given the continuous parameters
+ * the elements are conditionally independent, so the device evaluates all N acceptance tests at once from per-element deltas
+ * (O(N K) -- here O(N): only the proposed and the current component of each element are needed).
+ *
+ * The random numbers are the reference's, in the reference's order: `nuts_gibbs_plan` replays what one sweep draws from
+ * `step.rng` -- `rng.shuffle(dimcats)`, then per element `rng.choice(k - 1)` (`sample_except`, metropolis.py:1225-1229) and
+ * `rng.uniform()` (`metrop_select`, arraystep.py:208-235; the caller takes `np.log` of it -- NumPy's own logarithm differs from
+ * libm's in the last bit for ~0.3 % of the arguments, and the reference compares NumPy's) -- from the PCG64 state, bit for bit
+ * (host arithmetic only: it runs without a GPU).  `order` is the CURRENT list of dimensions (the reference shuffles its `dimcats` list in place, so the
+ * permutation carries over from sweep to sweep) and is updated.  Identical seed => identical assignments. */
+typedef struct {
+  uint64_t state_hi, state_lo, inc_hi, inc_lo; /* PCG64: 128-bit state and increment (`bit_generator.state["state"]`) */
+  int32_t has_uint32;                          /* NumPy's buffered 32-bit half */
+  uint32_t uinteger;
+} nuts_pcg64;
+int nuts_gibbs_plan(nuts_pcg64 *rng, int64_t n, int32_t shuffle, int32_t *order /* [n] in/out */,
+                    const int32_t *k_of_dim /* [n] categories of each dimension */, int32_t *cand_raw /* [n] */,
+                    double *uniform /* [n] */);
+
+typedef struct nuts_gibbs nuts_gibbs;
+nuts_gibbs *nuts_gibbs_create(int64_t n, int32_t K, const double *y /* [n] observations */);
+void nuts_gibbs_destroy(nuts_gibbs *g);
+/* One sweep.  c [n] (component of each observation) is updated in place; position t of the plan belongs to dimension
+ * order[t].  log_w, mu, sigma: [K].  Outputs: number of accepted proposals, and the sufficient statistics of the NEW
+ * assignment per component (count, sum y, sum y^2) that the continuous step's log-density needs.  A proposal whose delta is
+ * not finite is rejected without consuming its uniform in the reference (short-circuit `and`); `*n_nonfinite` reports how
+ * many there were (0 for any proper mixture) -- if it is not 0 the caller must fall back to replaying the sweep. */
+int nuts_gibbs_sweep(nuts_gibbs *g, int32_t *c, const double *log_w, const double *mu, const double *sigma,
+                     const int32_t *order, const int32_t *cand_raw, const double *log_u, int64_t *n_accepted,
+                     int64_t *n_nonfinite, double *cnt, double *s1, double *s2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,54 @@
+"""CPU oracle of `CategoricalGibbsMetropolis.astep_unif` for mixture assignments (TEST INFRASTRUCTURE; see oracle/__init__.py).
+
+A restatement of pymc/step_methods/metropolis.py:761-786 with `sample_except` (:1225-1229) and `metrop_select`
+(pymc/step_methods/arraystep.py:208-235): the same calls on the same NumPy generator in the same order, one element at a
+time.  The only liberty: the full-model log-density difference `logp(q') - logp(q)` is evaluated as the difference of the two
+terms that change (the model is a sum over observations), which the reference obtains by evaluating the full model twice.
+Pinned by executing the reference's own class over a full-model `logp` callable (tests/golden/refrun.py `load_metropolis`,
+fixture tests/golden/gibbs_mixture.npz, tests/test_gibbs.py).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def mixture_full_logp(c, y, mu, log_w, sigma, mu_prior_sd=10.0):
+    """Joint log-density of the mixture model of `pymc_amd.models.normal_mixture` (prior of mu included)."""
+    c = np.asarray(c, dtype=int)
+    z = (y - mu[c]) / sigma[c]
+    lik = np.sum(log_w[c] - np.log(sigma[c]) - 0.5 * np.log(2 * np.pi) - 0.5 * z * z)
+    prior = np.sum(-0.5 * (mu / mu_prior_sd) ** 2 - np.log(mu_prior_sd) - 0.5 * np.log(2 * np.pi))
+    return lik + prior
+
+
+class RefCategoricalGibbs:
+    def __init__(self, y, log_w, sigma, rng, order="random"):
+        self.y, self.log_w, self.sigma = np.asarray(y, float), np.asarray(log_w, float), np.asarray(sigma, float)
+        n, K = len(self.y), len(self.log_w)
+        self.dimcats = [(d, K) for d in range(n)]
+        self.shuffle_dims = order == "random"
+        if not self.shuffle_dims:
+            self.dimcats = [self.dimcats[j] for j in order]
+        self.rng = rng
+
+    def _term(self, i, k, mu):
+        z = (self.y[i] - mu[k]) / self.sigma[k]
+        return self.log_w[k] - np.log(self.sigma[k]) - 0.5 * z * z
+
+    def sweep(self, c, mu):
+        """metropolis.py:761-786."""
+        c = np.array(c, copy=True)
+        if self.shuffle_dims:
+            self.rng.shuffle(self.dimcats)
+        accepted = 0
+        for dim, k in self.dimcats:
+            cur = int(c[dim])
+            cand = self.rng.choice(k - 1)                 # sample_except
+            if cand >= cur:
+                cand += 1
+            mr = self._term(dim, cand, mu) - self._term(dim, cur, mu)
+            if np.isfinite(mr) and np.log(self.rng.uniform()) < mr:   # metrop_select
+                c[dim] = cand
+                accepted += 1
+        return c, accepted

@@ -154,6 +154,11 @@ class HmcStats(C.Structure):
     ]
 
 
+class Pcg64(C.Structure):
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64), ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64),
+                ("has_uint32", C.c_int32), ("uinteger", C.c_uint32)]
+
+
 _PD = C.POINTER(C.c_double)
 _VP = C.c_void_p
 
@@ -191,6 +196,10 @@ SYMBOLS = {
     "nuts_chain_welford_export": (C.c_int, [_VP, _VP]),
     "nuts_chain_welford_import": (C.c_int, [_VP, _VP]),
     "nuts_chain_set_log_step_bar": (C.c_int, [_VP, C.c_double, C.c_double]),
+    "nuts_gibbs_plan": (C.c_int, [C.POINTER(Pcg64), C.c_int64, C.c_int32, _VP, _VP, _VP, _PD]),
+    "nuts_gibbs_create": (_VP, [C.c_int64, C.c_int32, _PD]),
+    "nuts_gibbs_destroy": (None, [_VP]),
+    "nuts_gibbs_sweep": (C.c_int, [_VP, _VP, _PD, _PD, _PD, _VP, _VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _PD, _PD, _PD]),
     "nuts_chain_profile": (C.c_int, [_VP, C.c_int]),
     "nuts_chain_profile_read": (C.c_int, [_VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }

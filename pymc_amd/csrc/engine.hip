@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "small_kernel.h"
 #include "nuts_mi355.h"
+#include "pcg64_stream.h"
 
 static thread_local std::string g_err;
 
@@ -78,7 +79,7 @@ struct nuts_model {
   int rows_grid = 0, mvn_grid = 0, ept = 1;
   int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
   int vector_one_xcd = 0;
-  int ga_variant = 32;         // 10 x (waves per SIMD of the register budget) + tiles in flight per wave
+  int ga_variant = 42;         // 10 x (waves per SIMD of the register budget) + tiles in flight per wave
   int ga_struct_ok = 0;        // the spec is exactly what the group-aligned row pass evaluates in closed form (compile_spec)
   int ga_par = 0;              // parity of the last group-aligned launch (its block partials / local parts are double-buffered)
   int explicit_pre = 0;        // the position must be materialised before the dense pass (MvNormal node)
@@ -141,9 +142,9 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
       default: GA_LAUNCH(2, OO, PP); break;  \
     }
     switch (m->ga_variant) {   // (register budget, tiles in flight): see rows_ga_kernel.h
-      case 42: GA_BY_D(4, 2) break;
+      case 32: GA_BY_D(3, 2) break;
       case 33: GA_BY_D(3, 3) break;
-      default: GA_BY_D(3, 2) break;
+      default: GA_BY_D(4, 2) break;
     }
 #undef GA_BY_D
 #undef GA_LAUNCH
@@ -438,8 +439,8 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         tile0[g + 1] = tile0[g] + (int32_t)T;
       }
       const int64_t n_tiles = tile0[lg.G];
-      m->ga_variant = env_int("NUTS_GA_VARIANT", 32);
-      if (m->ga_variant != 42 && m->ga_variant != 33) m->ga_variant = 32;
+      m->ga_variant = env_int("NUTS_GA_VARIANT", 42);
+      if (m->ga_variant != 32 && m->ga_variant != 33) m->ga_variant = 42;
       const int occ = m->ga_variant / 10;
       int W = std::min(GA_MAXW, (4 * occ * cus) / std::max(lg.G, 1));   // all G workgroups resident at once (4 occ waves per CU)
       if (env_int("NUTS_ROWS_GA_W", 0) > 0) W = std::max(1, std::min(GA_MAXW, env_int("NUTS_ROWS_GA_W", 0)));
@@ -478,8 +479,9 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
           lg.ga_cstride_uni = (lg.ga_T_uni / W) * TS + GA_SKEW;
         } else lg.ga_T_uni = 0;
         lg.Npad = n_tiles * SPAN; lg.n_spans = n_tiles;
-        std::vector<double> xt((size_t)std::max<int64_t>(pos, 1), 0.0);
-        yy.assign((size_t)std::max<int64_t>(pos / D + SPAN, 1), 0);
+        // (one tile of slack at the end: a wave without tiles still issues its unconditional first request)
+        std::vector<double> xt((size_t)(pos + TS), 0.0);
+        yy.assign((size_t)(pos / D + 2 * SPAN), 0);
         for (int g = 0; g < lg.G; ++g) {
           const int64_t T = tile0[g + 1] - tile0[g];
           for (int64_t i = gptr[g]; i < gptr[g + 1]; ++i) {
@@ -1848,5 +1850,152 @@ extern "C" int nuts_chain_profile_read(nuts_chain* c, double* ms_sum, int64_t* l
   if (ms_sum) *ms_sum = tot;
   if (launches) *launches = pairs;
   if (leapfrogs) *leapfrogs = c->leapfrogs;
+  return NUTS_OK;
+}
+
+
+// ===========================================================================
+// categorical Gibbs within Metropolis for mixture assignments (include/nuts_mi355.h)
+// ===========================================================================
+extern "C" int nuts_gibbs_plan(nuts_pcg64* rng, int64_t n, int32_t shuffle, int32_t* order, const int32_t* k_of_dim, int32_t* cand_raw,
+                               double* uniform) {
+  if (!rng || !order || !k_of_dim || !cand_raw || !uniform || n < 0) { g_err = "null argument"; return NUTS_E_ARG; }
+  Pcg64Replay r;
+  r.state = ((unsigned __int128)rng->state_hi << 64) | rng->state_lo;
+  r.inc = ((unsigned __int128)rng->inc_hi << 64) | rng->inc_lo;
+  r.has_uint32 = rng->has_uint32; r.uinteger = rng->uinteger;
+  if (shuffle) {   // Generator.shuffle on a Python list: Fisher-Yates from the top (numpy/random/_generator.pyx, untyped path)
+    for (int64_t i = n - 1; i >= 1; --i) {
+      const int64_t j = (int64_t)r.interval((uint64_t)i);
+      std::swap(order[i], order[j]);
+    }
+  }
+  for (int64_t t = 0; t < n; ++t) {
+    const int32_t k = k_of_dim[order[t]];
+    if (k < 2) { g_err = "a categorical dimension needs at least two categories"; return NUTS_E_ARG; }
+    cand_raw[t] = (int32_t)r.integers((uint32_t)(k - 1));   // rng.choice(k - 1)
+    uniform[t] = r.next_double();                           // rng.uniform()
+  }
+  rng->state_hi = (uint64_t)(r.state >> 64); rng->state_lo = (uint64_t)r.state;
+  rng->has_uint32 = r.has_uint32; rng->uinteger = r.uinteger;
+  return NUTS_OK;
+}
+
+#define GIBBS_BLOCK 256
+#define GIBBS_MAXK 32
+// one thread per position of the plan; per-workgroup sufficient statistics in fixed order (wave sums, waves in order)
+__global__ __launch_bounds__(GIBBS_BLOCK) void k_gibbs_sweep(int64_t n, int K, const double* __restrict__ y, int32_t* __restrict__ c,
+                                                            const double* __restrict__ par /* [3][K]: log w, mu, sigma */,
+                                                            const int32_t* __restrict__ order, const int32_t* __restrict__ cand_raw,
+                                                            const double* __restrict__ log_u, double* __restrict__ part /* [nblk][3 K + 2] */) {
+  __shared__ double s_par[3 * GIBBS_MAXK];
+  __shared__ double s_w[GIBBS_BLOCK / WAVE][3 * GIBBS_MAXK + 2];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+  for (int i = tid; i < 3 * K; i += GIBBS_BLOCK) s_par[i] = par[i];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * GIBBS_BLOCK + tid;
+  int knew = -1;
+  double yi = 0.0, acc = 0.0, nonf = 0.0;
+  if (t < n) {
+    const int dim = order[t];
+    const int cur = c[dim];
+    int cand = cand_raw[t];
+    if (cand >= cur) cand += 1;                                     // sample_except (metropolis.py:1225-1229)
+    yi = y[dim];
+    auto lp = [&](int k) {                                          // log w_k + log Normal(y | mu_k, sigma_k) up to the common constant
+      const double sg = s_par[2 * K + k], z = (yi - s_par[K + k]) / sg;
+      return s_par[k] - log(sg) - 0.5 * z * z;
+    };
+    const double mr = lp(cand) - lp(cur);                           // = logp(proposal) - logp(current) of the full model
+    const bool fin = isfinite(mr);
+    const bool ok = fin && log_u[t] < mr;                           // metrop_select (arraystep.py:208-235)
+    knew = ok ? cand : cur;
+    c[dim] = knew;
+    acc = ok ? 1.0 : 0.0;
+    nonf = fin ? 0.0 : 1.0;
+  }
+  for (int k = 0; k < K; ++k) {
+    const bool m = knew == k;
+    const double a = wave_sum(m ? 1.0 : 0.0), b = wave_sum(m ? yi : 0.0), d2 = wave_sum(m ? yi * yi : 0.0);
+    if (lane == 0) { s_w[w][k] = a; s_w[w][K + k] = b; s_w[w][2 * K + k] = d2; }
+  }
+  {
+    const double a = wave_sum(acc), b = wave_sum(nonf);
+    if (lane == 0) { s_w[w][3 * K] = a; s_w[w][3 * K + 1] = b; }
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * K + 2; i += GIBBS_BLOCK) {
+    double sum = 0.0;
+    for (int ww = 0; ww < GIBBS_BLOCK / WAVE; ++ww) sum += s_w[ww][i];
+    part[(int64_t)blockIdx.x * (3 * K + 2) + i] = sum;
+  }
+}
+
+struct nuts_gibbs {
+  int64_t n = 0;
+  int K = 0, nblk = 0;
+  hipStream_t stream = nullptr;
+  double *y = nullptr, *par = nullptr, *logu = nullptr, *part = nullptr;
+  int32_t *c = nullptr, *order = nullptr, *cand = nullptr;
+  std::vector<double> part_host;
+};
+
+extern "C" nuts_gibbs* nuts_gibbs_create(int64_t n, int32_t K, const double* y) {
+  if (n <= 0 || K < 2 || K > GIBBS_MAXK || !y) { g_err = "nuts_gibbs_create: bad argument (2 <= K <= 32)"; return nullptr; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device visible: libnuts_mi355 requires an MI355X (gfx950); there is no CPU fallback";
+    return nullptr;
+  }
+  auto* g = new nuts_gibbs();
+  g->n = n; g->K = K; g->nblk = (int)((n + GIBBS_BLOCK - 1) / GIBBS_BLOCK);
+  HIPCHK_NULL(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+  g->y = dev_upload(y, (size_t)n);
+  g->par = dev_alloc<double>(3 * (size_t)K);
+  g->logu = dev_alloc<double>((size_t)n);
+  g->part = dev_alloc<double>((size_t)g->nblk * (3 * K + 2));
+  g->c = dev_alloc<int32_t>((size_t)n); g->order = dev_alloc<int32_t>((size_t)n); g->cand = dev_alloc<int32_t>((size_t)n);
+  if (!g->y || !g->par || !g->logu || !g->part || !g->c || !g->order || !g->cand) { g_err = "device allocation failed"; nuts_gibbs_destroy(g); return nullptr; }
+  g->part_host.resize((size_t)g->nblk * (3 * K + 2));
+  return g;
+}
+
+extern "C" void nuts_gibbs_destroy(nuts_gibbs* g) {
+  if (!g) return;
+  if (g->stream) hipStreamSynchronize(g->stream);
+  for (void* p : {(void*)g->y, (void*)g->par, (void*)g->logu, (void*)g->part, (void*)g->c, (void*)g->order, (void*)g->cand}) if (p) hipFree(p);
+  if (g->stream) hipStreamDestroy(g->stream);
+  delete g;
+}
+
+extern "C" int nuts_gibbs_sweep(nuts_gibbs* g, int32_t* c, const double* log_w, const double* mu, const double* sigma, const int32_t* order,
+                                const int32_t* cand_raw, const double* log_u, int64_t* n_accepted, int64_t* n_nonfinite, double* cnt, double* s1,
+                                double* s2) {
+  if (!g || !c || !log_w || !mu || !sigma || !order || !cand_raw || !log_u || !cnt || !s1 || !s2) { g_err = "null argument"; return NUTS_E_ARG; }
+  const int K = g->K;
+  const size_t n = (size_t)g->n;
+  hipStream_t s = g->stream;
+  std::vector<double> par(3 * (size_t)K);
+  for (int k = 0; k < K; ++k) { par[k] = log_w[k]; par[K + k] = mu[k]; par[2 * K + k] = sigma[k]; }
+  HIPCHK(hipMemcpyAsync(g->par, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->c, c, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->order, order, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->cand, cand_raw, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->logu, log_u, n * sizeof(double), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_gibbs_sweep, dim3(g->nblk), dim3(GIBBS_BLOCK), 0, s, g->n, K, g->y, g->c, g->par, g->order, g->cand, g->logu, g->part);
+  HIPCHK(hipMemcpyAsync(c, g->c, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g->part_host.data(), g->part, g->part_host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  const int stride = 3 * K + 2;
+  double acc = 0.0, nonf = 0.0;
+  for (int k = 0; k < K; ++k) { cnt[k] = s1[k] = s2[k] = 0.0; }
+  for (int b = 0; b < g->nblk; ++b) {   // workgroups in order
+    const double* p = g->part_host.data() + (size_t)b * stride;
+    for (int k = 0; k < K; ++k) { cnt[k] += p[k]; s1[k] += p[K + k]; s2[k] += p[2 * K + k]; }
+    acc += p[3 * K]; nonf += p[3 * K + 1];
+  }
+  if (n_accepted) *n_accepted = (int64_t)acc;
+  if (n_nonfinite) *n_nonfinite = (int64_t)nonf;
   return NUTS_OK;
 }

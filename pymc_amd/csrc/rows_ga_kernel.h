@@ -77,6 +77,42 @@ __device__ __forceinline__ void ga_load(const RowsDev& R, int64_t xoff, int lane
   }
 }
 
+// ---- hand-counted tile loads (D = 8, two rows per lane) ----------------------------------------------------------------------
+// hipcc cannot keep a tile in flight across the loop: it drains every outstanding load (`s_waitcnt vmcnt(0)`) at the loop header
+// before it lets the next request go (the destination registers of the buffers double as its address temporaries), so the
+// stream ran with ONE tile per wave in flight however deep the source-level pipeline was.  The nine loads of a tile are
+// therefore issued from one asm statement (scalar base + per-lane offset, no vector address arithmetic) and waited for with a
+// counted `vmcnt(N)`, N = 9 x (tiles requested after the one needed).  Form (ii) of the guide's inline-asm rules: "=&v" loads,
+// and a wait statement that names every destination "+v" ahead of the first consumer.
+typedef double ga_v2d __attribute__((ext_vector_type(2)));
+struct GaTileRegs { ga_v2d c[8]; uint32_t y; };
+
+__device__ __forceinline__ void ga_issue8(const double* base /* wave-uniform: first element of the tile */, const int8_t* ybase,
+                                          uint32_t voff16, uint32_t voff2, GaTileRegs& t) {
+  const double* base2 = base + 512;   // columns 4 .. 7 (the immediate offset field is 13 bits)
+  asm volatile(
+      "s_nop 4\n\t"
+      "global_load_dwordx4 %0, %9, %10\n\t"
+      "global_load_dwordx4 %1, %9, %10 offset:1024\n\t"
+      "global_load_dwordx4 %2, %9, %10 offset:2048\n\t"
+      "global_load_dwordx4 %3, %9, %10 offset:3072\n\t"
+      "global_load_dwordx4 %4, %9, %11\n\t"
+      "global_load_dwordx4 %5, %9, %11 offset:1024\n\t"
+      "global_load_dwordx4 %6, %9, %11 offset:2048\n\t"
+      "global_load_dwordx4 %7, %9, %11 offset:3072\n\t"
+      "global_load_ushort %8, %12, %13"
+      : "=&v"(t.c[0]), "=&v"(t.c[1]), "=&v"(t.c[2]), "=&v"(t.c[3]), "=&v"(t.c[4]), "=&v"(t.c[5]), "=&v"(t.c[6]), "=&v"(t.c[7]), "=&v"(t.y)
+      : "v"(voff16), "s"(base), "s"(base2), "v"(voff2), "s"(ybase)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void ga_wait8(GaTileRegs& t) {   // at most N loads may still be outstanding; `t` is complete afterwards
+  asm volatile("s_waitcnt vmcnt(%9)"
+               : "+v"(t.c[0]), "+v"(t.c[1]), "+v"(t.c[2]), "+v"(t.c[3]), "+v"(t.c[4]), "+v"(t.c[5]), "+v"(t.c[6]), "+v"(t.c[7]), "+v"(t.y)
+               : "i"(N));
+}
+
 // one tile of SPAN = 64 RPL rows: forward (eta, log-lik) + backward (d/dbeta) in registers
 template <int D, int RPL>
 __device__ __forceinline__ void ga_tile(const double (&x)[D][RPL], uint32_t yb, const double (&beta)[D], int nvalid, int lane,
@@ -175,8 +211,17 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   // PIPE tiles in flight per wave; the first ones are requested before anything else, so HBM is busy during the prologue
   double xa[D][RPL], xb[D][RPL], xc[PIPE == 3 ? D : 1][RPL];
   uint32_t ya = 0, yb = 0, yc = 0;
-  if (n > 0) ga_load<D, RPL>(R, tile_at(0), lane, xa, ya);
-  if (PIPE == 3 && n > 1) ga_load<D, RPL>(R, tile_at(1), lane, xb, yb);
+  GaTileRegs ta, tb, tc;
+  // (a wave without tiles requests the chunk's first tile slot anyway: the layout keeps one tile of slack behind every chunk)
+  if constexpr (D == 8 && RPL == 2) {
+    const uint32_t voff16 = (uint32_t)lane * 16u, voff2 = (uint32_t)lane * 2u;
+    const int64_t o0 = tile_at(0), o1 = tile_at(min(1, max(n - 1, 0)));
+    ga_issue8(R.Xt + o0, R.y + o0 / D, voff16, voff2, ta);
+    ga_issue8(R.Xt + o1, R.y + o1 / D, voff16, voff2, tb);
+  } else {
+    ga_load<D, RPL>(R, tile_at(0), lane, xa, ya);
+    if (PIPE == 3) ga_load<D, RPL>(R, tile_at(min(1, max(n - 1, 0))), lane, xb, yb);
+  }
   if (lane == 0) {
 #pragma unroll
     for (int dd = 0; dd <= D; ++dd) { s_acc[w][0][dd] = 0.0; s_acc[w][1][dd] = 0.0; }
@@ -185,6 +230,7 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
     const uint4* ka = (const uint4*)__builtin_amdgcn_kernarg_segment_ptr();
     for (int t = tid; t < (int)((sizeof(GaArgs) + 15) / 16); t += (int)blockDim.x) reinterpret_cast<uint4*>(s_args)[t] = ka[t];
   }
+  __syncthreads();   // (every wave is still at the top of the kernel: this costs nothing, and the copy is readable from here on)
 
   // ---- prologue: mu', sigma' of this leaf (every wave), z' of this group ----
   double hval0, hph0;   // lane l: q' and p_half of hyper-parameter element l mod 2D
@@ -237,31 +283,75 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
       if ((I) == nsw) flush();                                                               \
       ga_tile<D, RPL>(X, Y, beta, local_at(I) == l_last ? n_last : SPAN, lane, acc, lp);     \
     }
+    const int nm1 = n - 1;
+    if constexpr (D == 8 && RPL == 2) {
+      // hand-counted loads: PIPE tiles in flight per wave; the requests past the end re-read the wave's last tile (an L2 hit) so that
+      // every stage has exactly 9 (PIPE - 1) younger loads behind the tile it waits for
+      const uint32_t voff16 = (uint32_t)lane * 16u, voff2 = (uint32_t)lane * 2u;
+      auto issue = [&](int i, GaTileRegs& t) {
+        const int64_t off = tile_at(min(i, nm1));
+        ga_issue8(R.Xt + off, R.y + off / D, voff16, voff2, t);
+      };
+#define GA_ASTAGE(T, I)                                                                      \
+      {                                                                                      \
+        ga_wait8<9 * (PIPE - 1)>(T);                                                         \
+        if ((I) == nsw) flush();                                                             \
+        double xx[8][2];                                                                     \
+        _Pragma("unroll") for (int dd = 0; dd < 8; ++dd) { xx[dd][0] = T.c[dd].x; xx[dd][1] = T.c[dd].y; } \
+        ga_tile<8, 2>(xx, T.y, beta, local_at(I) == l_last ? n_last : SPAN, lane, acc, lp); \
+      }
+      if constexpr (PIPE == 3) {
+        issue(2, tc);
+        for (int i = 0; i < n; i += 3) {
+          GA_ASTAGE(ta, i)
+          if (i + 1 >= n) break;
+          issue(i + 3, ta);
+          GA_ASTAGE(tb, i + 1)
+          if (i + 2 >= n) break;
+          issue(i + 4, tb);
+          GA_ASTAGE(tc, i + 2)
+          issue(i + 5, tc);
+        }
+        ga_wait8<0>(ta); ga_wait8<0>(tb); ga_wait8<0>(tc);
+      } else {
+        for (int i = 0; i < n; i += 2) {
+          GA_ASTAGE(ta, i)
+          if (i + 1 >= n) break;
+          issue(i + 2, ta);
+          GA_ASTAGE(tb, i + 1)
+          issue(i + 3, tb);
+        }
+        ga_wait8<0>(ta); ga_wait8<0>(tb);
+      }
+#undef GA_ASTAGE
+    } else {
+    // compiler-counted loads.  The prefetch of tile i + PIPE - 1 is UNCONDITIONAL (past the end it re-requests the wave's last tile):
+    // a load inside an `if` makes hipcc drain every outstanding load (`s_waitcnt vmcnt(0)`) at the join.
     if constexpr (PIPE == 3) {
       for (int i = 0; i < n; i += 3) {
-        if (i + 2 < n) ga_load<D, RPL>(R, tile_at(i + 2), lane, xc, yc);
+        ga_load<D, RPL>(R, tile_at(min(i + 2, nm1)), lane, xc, yc);
         GA_STAGE(xa, ya, i)
         if (i + 1 >= n) break;
-        if (i + 3 < n) ga_load<D, RPL>(R, tile_at(i + 3), lane, xa, ya);
+        ga_load<D, RPL>(R, tile_at(min(i + 3, nm1)), lane, xa, ya);
         GA_STAGE(xb, yb, i + 1)
         if (i + 2 >= n) break;
-        if (i + 4 < n) ga_load<D, RPL>(R, tile_at(i + 4), lane, xb, yb);
+        ga_load<D, RPL>(R, tile_at(min(i + 4, nm1)), lane, xb, yb);
         GA_STAGE(xc, yc, i + 2)
       }
     } else {
       for (int i = 0; i < n; i += 2) {
-        if (i + 1 < n) ga_load<D, RPL>(R, tile_at(i + 1), lane, xb, yb);
+        ga_load<D, RPL>(R, tile_at(min(i + 1, nm1)), lane, xb, yb);
         GA_STAGE(xa, ya, i)
         if (i + 1 >= n) break;
-        if (i + 2 < n) ga_load<D, RPL>(R, tile_at(i + 2), lane, xa, ya);
+        ga_load<D, RPL>(R, tile_at(min(i + 2, nm1)), lane, xa, ya);
         GA_STAGE(xb, yb, i + 1)
       }
+    }
     }
 #undef GA_STAGE
     if (n > 0) flush();
   }
 
-  __syncthreads();
   ga_tail<D>(*reinterpret_cast<const GaArgs*>(s_args), g, s_acc, s_red, s_cp, s_info, s_keep);
 }
 
@@ -275,19 +365,21 @@ __device__ __forceinline__ void ga_tail(const GaArgs& T, int g, double (&s_acc)[
   const RowsDev& R = md.lg;
   const int j = T.j, par = T.par, d = T.d;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6, W = (int)blockDim.x >> 6;
-  if (R.ga_flags & GA_F_NOTAIL) return;
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
   const bool leaf = io.mode != MODE_PLAIN;
   const bool tree = io.mode == MODE_TREE;
   const int dl = lane % D;
   const int iz = R.off_z + g * D + dl;
+  // the operands of the first merge levels belong to earlier leaves: wave 0 requests them as soon as its own stream is done,
+  // before it waits for the other waves, so they are in flight during the combine
+  MergePrefetch mpf;
+  if (w == 0 && tree && !(R.ga_flags & GA_F_NOTAIL)) merge_prefetch(A, lf, j, iz, mpf);
+  __syncthreads();
+  if (R.ga_flags & GA_F_NOTAIL) return;
 
   if (w == 0) {
     // ---- wave 0: the group's D z elements (lane = coordinate) ----
-    // (the operands of the first merge levels belong to earlier leaves: requested first, in flight during the rest)
-    MergePrefetch mpf;
-    if (tree) merge_prefetch(A, lf, j, iz, mpf);
     const double hval = s_keep[0][lane], hph = s_keep[1][lane], zq = s_keep[2][lane], zph = s_keep[3][lane], s_lane = s_keep[4][lane];
     double db = 0.0, lpg = 0.0;
     for (int ww = 0; ww < W; ++ww) { db += s_acc[ww][0][dl] + s_acc[ww][1][dl]; lpg += s_acc[ww][0][D] + s_acc[ww][1][D]; }

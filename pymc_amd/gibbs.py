@@ -1,0 +1,236 @@
+"""`CategoricalGibbsMetropolis` on the device for the assignment vector of a Normal mixture (SURVEY.md section 8f-4,
+BASELINE configs[4]: "Gaussian mixture, 100k latent discrete assignments + continuous params -- categorical logp + mixed
+samplers").
+
+Reference: pymc/step_methods/metropolis.py:675-849.  Its sweep proposes one element at a time and evaluates the FULL model
+log-density per proposal (`logp(q)` inside the loop, :773-780): O(N) per element, O(N^2) per sweep.  For
+
+    c_i ~ Categorical(w),   y_i ~ Normal(mu[c_i], sigma[c_i])            (continuous parameters mu held by another step method)
+
+the elements are conditionally independent given mu, so one sweep is N independent acceptance tests; the device runs them
+at once from per-element deltas (`nuts_gibbs_sweep`).  What makes the result the reference's is the random-number stream:
+`rng.shuffle(dimcats)`, then per element `rng.choice(k - 1)` and `np.log(rng.uniform())` in the shuffled order --
+`nuts_gibbs_plan` replays exactly that from the generator's PCG64 state (the `uniform` proposal; the `proportional` one
+draws through `rng.choice(candidates, p=...)` and is not replayed -- it raises here).
+
+The continuous step method sees the assignments as an extra input of its log-density (`ValueGradFunction` extra_vars,
+model/core.py:142-190): sum_i log Normal(y_i | mu[c_i], sigma[c_i]) depends on c through the per-component sufficient
+statistics only, which the sweep kernel returns; `MixtureLink.extras_for` turns them into the data vectors of the NUTS spec
+(`models.normal_mixture`), so that the device NUTS log-density equals the full model log-density for the current c exactly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+
+from pymc_amd import _lib
+from pymc_amd.step import _rng_from_state, _rng_state, get_random_generator
+
+LOG_SQRT_2PI = 0.5 * np.log(2.0 * np.pi)
+
+
+@dataclass
+class MixtureLink:
+    """What ties the two step methods of the mixture model together: the data and constants of the assignment conditional, and
+    the map from (assignments -> extra values of the continuous log-density)."""
+
+    name: str                 # value variable of the assignments ("c")
+    y: np.ndarray             # [N] observations
+    log_w: np.ndarray         # [K]
+    sigma: np.ndarray         # [K]
+    mu_name: str              # value variable holding the component means
+
+    def __post_init__(self):
+        self._cache_key = None
+        self._cache = None
+
+    @property
+    def K(self) -> int:
+        return len(self.log_w)
+
+    def suffstats(self, c: np.ndarray):
+        c = np.asarray(c)
+        key = (id(c), c.ctypes.data if isinstance(c, np.ndarray) else None)
+        if self._cache_key == key:
+            return self._cache
+        cnt = np.bincount(c, minlength=self.K).astype("float64")
+        s1 = np.bincount(c, weights=self.y, minlength=self.K)
+        s2 = np.bincount(c, weights=self.y * self.y, minlength=self.K)
+        return cnt, s1, s2
+
+    def remember(self, c: np.ndarray, stats):
+        """The sweep kernel has just produced the statistics of `c`: the continuous step that follows need not recount."""
+        self._cache_key = (id(c), c.ctypes.data)
+        self._cache = stats
+
+    def extras_for(self, c: np.ndarray) -> Dict[str, np.ndarray]:
+        """Extra values of the NUTS spec for assignments `c`: the log-density of the observations given c collapses to
+        sum_k log Normal(ybar_k | mu_k, sigma_k / sqrt(n_k)) + a term that does not depend on mu."""
+        cnt, s1, s2 = self.suffstats(c)
+        occupied = cnt > 0
+        n1 = np.where(occupied, cnt, 1.0)
+        ybar = np.where(occupied, s1 / n1, 0.0)
+        sd = np.where(occupied, self.sigma / np.sqrt(n1), 1e150)          # an empty component constrains nothing
+        ss = np.where(occupied, s2 - s1 * s1 / n1, 0.0)                   # within-component sum of squares
+        full = np.sum(cnt * (self.log_w - np.log(self.sigma) - LOG_SQRT_2PI) - 0.5 * ss / self.sigma**2)
+        collapsed = np.sum(-np.log(sd) - LOG_SQRT_2PI)
+        return {f"{self.name}__ybar": ybar, f"{self.name}__sd": sd, f"{self.name}__const": np.array([full - collapsed])}
+
+
+def _pcg_to_c(rng: np.random.Generator) -> "_lib.Pcg64":
+    st = rng.bit_generator.state
+    if st["bit_generator"] != "PCG64":
+        raise TypeError("the device Gibbs step replays NumPy's default PCG64 stream")
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return _lib.Pcg64(s >> 64, s & m, inc >> 64, inc & m, st["has_uint32"], st["uinteger"])
+
+
+def _pcg_from_c(rng: np.random.Generator, p) -> None:
+    st = rng.bit_generator.state
+    st["state"]["state"] = (p.state_hi << 64) | p.state_lo
+    st["has_uint32"], st["uinteger"] = int(p.has_uint32), int(p.uinteger)
+    rng.bit_generator.state = st
+
+
+def plan_sweep(rng: np.random.Generator, order: np.ndarray, k_of_dim: np.ndarray, shuffle: bool = True):
+    """What one sweep of `astep_unif` draws (see module docstring): updates `order` in place like `rng.shuffle(dimcats)` and
+    advances `rng`; returns `(cand_raw, log_u)` per position.  Host arithmetic only."""
+    n = len(order)
+    p = _pcg_to_c(rng)
+    cand = np.empty(n, dtype="int32")
+    u = np.empty(n)
+    rc = _lib.load().nuts_gibbs_plan(C.byref(p), n, int(shuffle), order.ctypes.data, k_of_dim.ctypes.data, cand.ctypes.data, _lib.dptr(u))
+    _lib.check(rc, "nuts_gibbs_plan")
+    _pcg_from_c(rng, p)
+    return cand, np.log(u)   # NumPy's log, as `np.log(rng.uniform())` in the reference
+
+
+@dataclass
+class CategoricalGibbsMetropolisState:   # metropolis.py:664-672 + StepMethodState
+    var_names: list
+    rng: dict
+    shuffle_dims: bool
+    dimcats: list
+
+
+class CategoricalGibbsMetropolis:
+    """Signature of metropolis.py:692-703.  `model` is a `ModelSpec` built by `models.normal_mixture` (it carries the
+    `MixtureLink`); `vars` names the assignment variable."""
+
+    name = "categorical_gibbs_metropolis"
+    default_blocked = True
+    stats_dtypes_shapes: dict = {}
+    _state_class = CategoricalGibbsMetropolisState
+
+    def __init__(self, vars=None, *, proposal="uniform", order="random", model=None, rng=None, initial_point=None,
+                 compile_kwargs=None, blocked=True, device: Optional[int] = None):
+        link = getattr(model, "mixture", None)
+        if link is None:
+            raise ValueError("All variables must be categorical or binary for CategoricalGibbsMetropolis")
+        self.link: MixtureLink = link
+        self.vars = [link.name] if vars is None else list(vars)
+        self.var_names = (link.name,)
+        self.stats_dtypes = [{}]
+        n, K = len(link.y), link.K
+        dimcats = [(d, K) for d in range(n)]
+        if order == "random":   # metropolis.py:735-742
+            self.shuffle_dims = True
+        else:
+            if sorted(order) != list(range(n)):
+                raise ValueError("Argument 'order' has to be a permutation")
+            self.shuffle_dims = False
+            dimcats = [dimcats[j] for j in order]
+        self._order = np.array([d for d, _ in dimcats], dtype="int32")
+        self._k_of_dim = np.full(n, K, dtype="int32")
+        if proposal == "proportional":
+            raise NotImplementedError("the `proportional` proposal (metropolis.py:788-826) is not replayed on the device; use proposal='uniform'")
+        if proposal != "uniform":
+            raise ValueError("Argument 'proposal' should either be 'uniform' or 'proportional'")
+        self.rng = get_random_generator(rng)
+        self.tune = True
+        self._device = device
+        self._handle = None
+        self.accepted_last = 0
+
+    @property
+    def dimcats(self):
+        return [(int(d), int(self._k_of_dim[d])) for d in self._order]
+
+    @staticmethod
+    def competence(var):   # metropolis.py:828-849 (IDEAL for > 2 categories, COMPATIBLE for binary)
+        k = getattr(var, "n_categories", None)
+        dt = np.dtype(getattr(var, "dtype", "int64"))
+        if dt.kind not in "iub":
+            return 0
+        return 3 if (k is not None and k > 2) else 1
+
+    def reset_tuning(self):   # metropolis.py:757-759: no tuning parameters
+        return
+
+    def stop_tuning(self):
+        self.tune = False
+
+    def setup_chain(self, rng, tune, draws):
+        self.rng = rng if isinstance(rng, np.random.Generator) else get_random_generator(rng, copy_=False)
+
+    def _engine(self):
+        if self._handle is None:
+            lib = _lib.load()
+            if self._device is not None:
+                _lib.check(lib.nuts_set_device(int(self._device)), "nuts_set_device")
+            y = np.ascontiguousarray(self.link.y, dtype="float64")
+            self._handle = lib.nuts_gibbs_create(len(y), self.link.K, _lib.dptr(y))
+            if not self._handle:
+                raise _lib.EngineError(f"nuts_gibbs_create failed: {_lib.last_error()}")
+        return self._handle
+
+    def step(self, point):
+        """`ArrayStep.step` (arraystep.py:64-80) + `astep_unif` (metropolis.py:761-786)."""
+        link = self.link
+        c = np.ascontiguousarray(point[link.name], dtype="int32").copy()
+        mu = np.ascontiguousarray(point[link.mu_name], dtype="float64")
+        cand, log_u = plan_sweep(self.rng, self._order, self._k_of_dim, self.shuffle_dims)
+        K = link.K
+        cnt, s1, s2 = np.empty(K), np.empty(K), np.empty(K)
+        nacc, nonf = C.c_int64(0), C.c_int64(0)
+        lw, sg = np.ascontiguousarray(link.log_w, dtype="float64"), np.ascontiguousarray(link.sigma, dtype="float64")
+        rc = _lib.load().nuts_gibbs_sweep(self._engine(), c.ctypes.data, _lib.dptr(lw), _lib.dptr(mu), _lib.dptr(sg), self._order.ctypes.data,
+                                          cand.ctypes.data, _lib.dptr(log_u), C.byref(nacc), C.byref(nonf), _lib.dptr(cnt), _lib.dptr(s1), _lib.dptr(s2))
+        _lib.check(rc, "nuts_gibbs_sweep")
+        if nonf.value:
+            raise _lib.EngineError("a proposal had a non-finite log-density difference: the uniform stream cannot be pre-drawn for this sweep")
+        self.accepted_last = int(nacc.value)
+        new_c = c.astype(np.asarray(point[link.name]).dtype, copy=False)
+        new_c = np.ascontiguousarray(new_c)
+        link.remember(new_c, (cnt, s1, s2))
+        new_point = dict(point)
+        new_point[link.name] = new_c
+        return new_point, [{}]
+
+    @property
+    def sampling_state(self):
+        return CategoricalGibbsMetropolisState(list(self.var_names), _rng_state(self.rng), bool(self.shuffle_dims), self.dimcats)
+
+    @sampling_state.setter
+    def sampling_state(self, state):
+        if list(state.var_names) != list(self.var_names):
+            raise ValueError("The received sampling state must have the same values for the frozen fields. Field 'var_names' differs.")
+        self.rng = _rng_from_state(state.rng)
+        self.shuffle_dims = bool(state.shuffle_dims)
+        self._order = np.array([d for d, _ in state.dimcats], dtype="int32")
+
+    def close(self):
+        if self._handle:
+            _lib.load().nuts_gibbs_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -167,6 +167,9 @@ class ModelSpec:
     # "extra" inputs of the log-density (model/core.py:142-190 `extra_vars_and_values`): name -> index into `data`;
     # the caller rewrites them through `set_extra_values` (value variables sampled by another step method)
     extra: Dict[str, int] = field(default_factory=dict)
+    # mixture assignments sampled by another step method (pymc_amd/gibbs.py): extras of this spec that are FUNCTIONS of that
+    # variable (`mixture.extras_for(point[mixture.name])`) rather than entries of the point
+    mixture: Optional[object] = None
 
     @property
     def n(self) -> int:

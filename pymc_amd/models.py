@@ -122,3 +122,34 @@ def std_normal(n: int = 10, mu: float = 2.0, sigma: float = np.sqrt(3.0)) -> Mod
     m = ModelBuilder()
     m.Normal("a", mu, sigma, shape=n)
     return m.build()
+
+
+def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: float = 1.0) -> ModelSpec:
+    """Gaussian mixture with latent discrete assignments (BASELINE configs[4]; the discrete half is sampled by
+    `pymc_amd.gibbs.CategoricalGibbsMetropolis`, the continuous half -- this spec -- by NUTS, mixed by `CompoundStep`):
+
+        mu[K] ~ Normal(0, 10);   c_i ~ Categorical(w), w = 1/K;   y_i ~ Normal(mu[c_i], sigma)     i < N
+
+    In PyMC: `mu = pm.Normal("mu", 0, 10, shape=K); c = pm.Categorical("c", p=w, shape=N);
+    pm.Normal("y", mu[c], sigma, observed=y)`.  The assignments reach this log-density as extra values (core.py:142-190) through
+    their per-component sufficient statistics (`MixtureLink.extras_for`): the factor below plus the constant term equals
+    sum_i [log w_{c_i} + log Normal(y_i | mu[c_i], sigma)] exactly."""
+    from pymc_amd.gibbs import MixtureLink
+
+    rng = np.random.default_rng(seed)
+    mu_true = np.linspace(-3.0, 3.0, K)
+    c_true = rng.integers(0, K, size=N)
+    y = mu_true[c_true] + sigma * rng.normal(size=N)
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 10.0, shape=K)
+    ybar = m.Extra("c__ybar", np.zeros(K))
+    sd = m.Extra("c__sd", np.ones(K))
+    const = m.Extra("c__const", np.zeros(1))
+    # value = ybar (extra), mu = the variable, sigma = sd (extra)
+    from pymc_amd.model_spec import D_NORMAL, Factor
+
+    m.spec.factors.append(Factor(D_NORMAL, K, (ybar.term, mu.term, sd.term), 0.0, "y|c"))
+    m.Potential("c_terms", const)
+    spec = m.build()
+    spec.mixture = MixtureLink("c", y, np.full(K, -np.log(K)), np.full(K, float(sigma)), "mu")
+    return spec

@@ -296,7 +296,12 @@ class _DeviceHMCBase:
     def step(self, point: PointType):
         extra = self.spec.extra
         if extra:   # arraystep.py:109-111: `shared.set_value(point[name])` for the non-gradient value variables
-            self._logp_dlogp_func.set_extra_values({name: point[name] for name in extra})
+            link = getattr(self.spec, "mixture", None)
+            if link is not None:   # extras that are functions of another step method's variable (pymc_amd/gibbs.py)
+                derived = link.extras_for(point[link.name])
+                self._logp_dlogp_func.set_extra_values({name: (derived[name] if name in derived else point[name]) for name in extra})
+            else:
+                self._logp_dlogp_func.set_extra_values({name: point[name] for name in extra})
         sub = {name: point[name] for name in self.var_names}
         q = DictToArrayBijection.map(sub)
         apoint, stats = self.astep(q)

@@ -200,6 +200,31 @@ def load():
     return types.SimpleNamespace(**_LOADED)
 
 
+def load_metropolis():
+    """The reference's `pymc/step_methods/metropolis.py` (for `CategoricalGibbsMetropolis.astep_unif` / `astep_prop`,
+    `sample_except`, `metrop_select`: pure NumPy once a `logp` callable is handed in).  Its PyTensor-side imports are names
+    only; the constructor (which compiles `model.logp`) is bypassed by the callers."""
+    if "metropolis" in _LOADED:
+        return _LOADED["metropolis"]
+    load()
+    _mod("pytensor.tensor", TensorVariable=type("TensorVariable", (), {}), sharedvar=types.SimpleNamespace(TensorSharedVariable=type("TensorSharedVariable", (), {})))
+    sys.modules["pytensor"].tensor = sys.modules["pytensor.tensor"]
+    sys.modules["pytensor"].compile = sys.modules["pytensor.compile"]
+    sys.modules["pytensor.compile"].Function = type("Function", (), {})
+    _mod("pytensor.graph.fg", MissingInputError=type("MissingInputError", (Exception,), {}))
+    _pkg("pytensor.tensor.random")
+    _mod("pytensor.tensor.random.basic", BernoulliRV=type("BernoulliRV", (), {}), CategoricalRV=type("CategoricalRV", (), {}))
+    _mod("pymc.initial_point", PointType=dict)
+    pf = sys.modules["pymc.pytensorf"]
+    for name in ("CallableTensor", "compile", "join_nonshared_inputs", "make_shared_replacements", "replace_rng_nodes"):
+        if not hasattr(pf, name):
+            setattr(pf, name, None)
+    sys.modules["pymc"].modelcontext = lambda m: m
+    m = _load("pymc.step_methods.metropolis", "pymc/step_methods/metropolis.py")
+    _LOADED["metropolis"] = m
+    return m
+
+
 def make_step(kind, f, point, **kwargs):
     """A reference `NUTS` / `HamiltonianMC` over the flat log-density `f(q) -> (logp, grad)`; `point` is the initial
     point in `model.value_vars` order (it fixes the raveled layout, blocking.py:67-75)."""

@@ -1,0 +1,244 @@
+"""`CategoricalGibbsMetropolis` + `CompoundStep` (BASELINE configs[4]).
+
+CPU: the PCG64 stream replay (`nuts_gibbs_plan`) against NumPy bit for bit; the oracle restatement against the fixture made by
+executing the reference's own `CategoricalGibbsMetropolis.astep_unif` (and live where /root/reference exists); the host logic
+of the mixture link (the collapsed NUTS log-density equals the full model log-density).
+GPU: the device sweep reproduces the reference's assignments BITWISE for the same seed; NUTS + Gibbs under `CompoundStep`
+against the oracle pair."""
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ref_gibbs, ref_models, ref_sampler
+from pymc_amd import _lib, models
+from pymc_amd.gibbs import CategoricalGibbsMetropolis, plan_sweep
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "gibbs_mixture.npz")
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def _numpy_plan(rng, n, ks):
+    """What the reference's sweep draws, with NumPy itself (metropolis.py:771-786)."""
+    dimcats = [(d, int(ks[d])) for d in range(n)]
+    rng.shuffle(dimcats)
+    cand, lu = [], []
+    for d, k in dimcats:
+        cand.append(int(rng.choice(k - 1)))
+        lu.append(float(np.log(rng.uniform())))
+    return [d for d, _ in dimcats], cand, lu
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pcg64_replay_matches_numpy_bit_for_bit(seed):
+    import __graft_entry__ as g
+
+    g.build_engine()
+    n = int(np.random.default_rng(seed + 1000).integers(1, 500))
+    ks = np.random.default_rng(seed + 2000).integers(2, 7, size=n).astype("int32")
+    if seed % 4 == 0:
+        ks[:] = 2                       # `rng.choice(1)` draws nothing
+    a, b = np.random.default_rng(seed), np.random.default_rng(seed)
+    if seed % 3 == 1:                   # a generator that holds a cached 32-bit half (mcmc.py:908 leaves chains' generators like that)
+        a.integers(2**30), b.integers(2**30)
+    order = np.arange(n, dtype="int32")
+    for sweep in range(2):              # the permutation carries over: the reference shuffles its list in place
+        o_ref, c_ref, lu_ref = _numpy_plan(a, n, ks) if sweep == 0 else _numpy_plan_from(a, o_prev, ks)
+        cand, log_u = plan_sweep(b, order, ks, True)
+        assert order.tolist() == o_ref and cand.tolist() == c_ref and log_u.tolist() == lu_ref
+        assert a.bit_generator.state == b.bit_generator.state
+        o_prev = o_ref
+
+
+def _numpy_plan_from(rng, order, ks):
+    dimcats = [(d, int(ks[d])) for d in order]
+    rng.shuffle(dimcats)
+    cand, lu = [], []
+    for d, k in dimcats:
+        cand.append(int(rng.choice(k - 1)))
+        lu.append(float(np.log(rng.uniform())))
+    return [d for d, _ in dimcats], cand, lu
+
+
+def _fixture():
+    k = np.load(GOLD)
+    spec = models.normal_mixture(N=int(k["N"]), K=int(k["K"]), seed=int(k["data_seed"]))
+    return k, spec
+
+
+def test_oracle_restatement_reproduces_the_reference_sweeps():
+    k, spec = _fixture()
+    link = spec.mixture
+    rng = np.random.default_rng(int(k["seed"]))
+    rng.integers(2**30)
+    g = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w, link.sigma, rng)
+    c = k["c0"]
+    for s in range(len(k["cs"])):
+        c, _ = g.sweep(c, k["mus"][s])
+        assert np.array_equal(c, k["cs"][s]), s
+    st = rng.bit_generator.state
+    assert [st["state"]["state"] >> 64, st["state"]["state"] & (2**64 - 1), st["has_uint32"], st["uinteger"]] == [int(x) for x in k["final_state"]]
+
+
+def test_reference_class_reproduces_the_committed_fixture():
+    import refrun
+
+    if not refrun.available():
+        pytest.skip("reference checkout not present")
+    import make_gibbs_golden as mg
+
+    k, spec = _fixture()
+    cs, state = mg.reference_sweeps(spec, int(k["seed"]), len(k["cs"]), k["mus"], k["c0"], leave_half_cached=True)
+    assert np.array_equal(cs, k["cs"])
+
+
+def test_host_half_of_the_device_sweep_reproduces_the_fixture():
+    """`plan_sweep` + the acceptance rule evaluated with NumPy (what the kernel does per element) = the reference's sweeps."""
+    k, spec = _fixture()
+    link = spec.mixture
+    rng = np.random.default_rng(int(k["seed"]))
+    rng.integers(2**30)
+    n, K = len(link.y), link.K
+    order, kd = np.arange(n, dtype="int32"), np.full(n, K, dtype="int32")
+    c = k["c0"].copy()
+    for s in range(len(k["cs"])):
+        mu = k["mus"][s]
+        cand, log_u = plan_sweep(rng, order, kd, True)
+        cur = c[order]
+        prop = cand + (cand >= cur)
+        y = link.y[order]
+        term = lambda kk: link.log_w[kk] - np.log(link.sigma[kk]) - 0.5 * ((y - mu[kk]) / link.sigma[kk]) ** 2   # noqa: E731
+        mr = term(prop) - term(cur)
+        c[order] = np.where(np.isfinite(mr) & (log_u < mr), prop, cur)
+        assert np.array_equal(c, k["cs"][s]), s
+
+
+def test_collapsed_continuous_logp_equals_the_full_model_logp():
+    spec = models.normal_mixture(N=700, K=4, seed=2)
+    link = spec.mixture
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        c = rng.integers(0, 4, size=700)
+        c[c == 2] = 1                                   # an empty component
+        mu = rng.normal(size=4) * 3
+        import copy
+
+        s2 = copy.deepcopy(spec)
+        for name, idx in s2.extra.items():
+            s2.data[idx] = np.asarray(link.extras_for(c)[name], dtype="float64")
+        lp, g = ref_models.evaluate(s2, mu)
+        full = ref_gibbs.mixture_full_logp(c, link.y, mu, link.log_w, link.sigma)
+        assert abs(lp - full) <= 1e-11 * abs(full)
+        eps = 1e-6
+        for j in range(4):
+            d = np.zeros(4); d[j] = eps
+            fd = (ref_gibbs.mixture_full_logp(c, link.y, mu + d, link.log_w, link.sigma) - ref_gibbs.mixture_full_logp(c, link.y, mu - d, link.log_w, link.sigma)) / (2 * eps)
+            assert abs(g[j] - fd) <= 1e-5 * max(1.0, abs(fd))
+
+
+def test_step_surface_and_state_roundtrip_without_a_device():
+    spec = models.normal_mixture(N=50, K=3)
+    st = CategoricalGibbsMetropolis(model=spec, rng=4)
+    assert st.name == "categorical_gibbs_metropolis" and st.stats_dtypes_shapes == {} and len(st.dimcats) == 50
+    with pytest.raises(ValueError, match="permutation"):
+        CategoricalGibbsMetropolis(model=spec, order=[0, 1])
+    with pytest.raises(ValueError, match="proposal"):
+        CategoricalGibbsMetropolis(model=spec, proposal="nope")
+    with pytest.raises(ValueError, match="categorical"):
+        CategoricalGibbsMetropolis(model=models.eight_schools())
+    s = st.sampling_state
+    other = CategoricalGibbsMetropolis(model=spec, rng=9)
+    other.sampling_state = s
+    assert other.rng.bit_generator.state == st.rng.bit_generator.state and other.dimcats == st.dimcats
+
+
+# ---------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_sweep_reproduces_the_reference_assignments_bitwise():
+    k, spec = _fixture()
+    st = CategoricalGibbsMetropolis(model=spec, rng=int(k["seed"]), device=0)
+    st.rng.integers(2**30)
+    point = {"mu": k["mus"][0], "c": k["c0"].astype("int64")}
+    for s in range(len(k["cs"])):
+        point["mu"] = k["mus"][s]
+        point, stats = st.step(point)
+        assert stats == [{}] and np.array_equal(point["c"], k["cs"][s]), s
+        assert st.accepted_last == int((k["cs"][s] != (k["c0"] if s == 0 else k["cs"][s - 1])).sum())
+    stt = st.rng.bit_generator.state
+    assert [stt["state"]["state"] >> 64, stt["state"]["state"] & (2**64 - 1), stt["has_uint32"], stt["uinteger"]] == [int(x) for x in k["final_state"]]
+    st.close()
+
+
+@pytest.mark.gpu
+def test_compound_nuts_plus_gibbs_matches_the_oracle_pair():
+    """`CompoundStep([NUTS(mu), CategoricalGibbsMetropolis(c)])` (compound.py:296-305, one spawned generator per method): the
+    device pair against (oracle NUTS over the full-model log-density with c as extra input, oracle Gibbs): identical
+    assignments and identical NUTS integers, iteration by iteration; and at N = 100 000 (configs[4]) one sweep against the
+    vectorised host restatement."""
+    from pymc_amd.compound import CompoundStep
+    from pymc_amd.step import NUTS
+
+    spec = models.normal_mixture(N=2000, K=3, seed=7)
+    link = spec.mixture
+    nuts = NUTS(model=spec, rng=1, device=0)
+    gibbs = CategoricalGibbsMetropolis(model=spec, rng=2, device=0)
+    comp = CompoundStep([nuts, gibbs])
+    assert comp.name == "Compound[nuts, categorical_gibbs_metropolis]"
+    comp.setup_chain(np.random.default_rng(99), 20, 10)
+    rng0 = np.random.default_rng(3)
+    c0 = rng0.integers(0, 3, size=2000)
+    point = {"mu": np.array([-1.0, 0.2, 1.5]), "c": c0.copy()}
+    # the oracle pair, with the generators `CompoundStep.setup_chain` hands out
+    r_nuts, r_gibbs = np.random.default_rng(99).spawn(2)
+    state = {"c": c0.copy()}
+    f = lambda q: _full_logp_grad(q, state["c"], link)    # noqa: E731
+    onuts = ref_sampler.RefNUTS(f, 3, rng=1)
+    onuts.setup_chain(r_nuts, 20, 10)
+    onuts.tune = True
+    onuts.reset_tuning()
+    ogibbs = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w, link.sigma, r_gibbs)
+    q = point["mu"].copy()
+    nuts.tune = True
+    nuts.reset_tuning()
+    nuts.iter_count = 0
+    for it in range(30):
+        if it == 20:
+            comp.stop_tuning()
+            onuts.stop_tuning()
+        point, stats = comp.step(point)
+        q, ost = onuts.astep(q)
+        state["c"], _ = ogibbs.sweep(state["c"], q)
+        assert len(stats) == 2 and stats[1] == {}
+        for key in ("depth", "tree_size", "index_in_trajectory", "diverging"):
+            assert int(stats[0][key]) == int(ost[key]), (it, key)
+        np.testing.assert_allclose(point["mu"], q, rtol=1e-7 if it < 8 else 1e-3, atol=1e-9)
+        assert np.array_equal(point["c"], state["c"]), it
+    comp.close()
+    # configs[4] size: 100 000 assignments, one sweep against the vectorised host restatement of the acceptance rule
+    big = models.normal_mixture(N=100_000, K=3)
+    lb = big.mixture
+    g2 = CategoricalGibbsMetropolis(model=big, rng=5, device=0)
+    shadow = np.random.default_rng(5)
+    c = np.random.default_rng(6).integers(0, 3, size=100_000)
+    mu = np.array([-2.8, 0.1, 3.1])
+    p2, _ = g2.step({"mu": mu, "c": c})
+    order, kd = np.arange(100_000, dtype="int32"), np.full(100_000, 3, dtype="int32")
+    cand, log_u = plan_sweep(shadow, order, kd, True)
+    cur = c[order]; prop = cand + (cand >= cur); y = lb.y[order]
+    term = lambda kk: lb.log_w[kk] - np.log(lb.sigma[kk]) - 0.5 * ((y - mu[kk]) / lb.sigma[kk]) ** 2   # noqa: E731
+    mr = term(prop) - term(cur)
+    expect = c.copy(); expect[order] = np.where(np.isfinite(mr) & (log_u < mr), prop, cur)
+    assert np.array_equal(p2["c"], expect)
+    cnt, s1, s2 = lb.suffstats(p2["c"])
+    np.testing.assert_allclose(cnt, np.bincount(expect, minlength=3)); np.testing.assert_allclose(s1, np.bincount(expect, weights=lb.y, minlength=3), rtol=1e-12)
+    g2.close()
+
+
+def _full_logp_grad(q, c, link):
+    lp = ref_gibbs.mixture_full_logp(c, link.y, q, link.log_w, link.sigma)
+    g = np.bincount(c, weights=(link.y - q[c]) / link.sigma[c] ** 2, minlength=len(q)) - q / 100.0
+    return lp, g
