@@ -328,6 +328,29 @@ int nuts_gibbs_sweep(nuts_gibbs *g, int32_t *c, const double *log_w, const doubl
                      const int32_t *order, const int32_t *cand_raw, const double *log_u, int64_t *n_accepted,
                      int64_t *n_nonfinite, double *cnt, double *s1, double *s2);
 
+/* ---- full-rank minibatch ADVI on a GLM (BASELINE configs[3]) ---------------------------------------
+ * Replaces the compiled step function of `pm.fit(method="fullrank_advi")` (pymc/variational/opvi.py:318-404 over
+ * `FullRankGroup`, variational/approximations.py:118-188, `KL`, variational/operators.py:64-65, `adagrad_window`,
+ * variational/updates.py:542-585) for  y_i ~ family(x_i . beta), beta ~ Normal(0, prior_sd)  with minibatches of `batch` rows
+ * scaled by N / batch (variational/minibatch_rv.py:87-106).  X [N][P] row-major and y [N] are copied to the device once.
+ * family: 0 Normal(eta, sigma) ; 1 Bernoulli(logit_p = eta). */
+typedef struct {
+  int64_t N;
+  int32_t P, family, batch, n_win;
+  double sigma, prior_sd, learning_rate, epsilon;
+  const double *X, *y;
+  const double *start; /* [P] initial mean (NULL: zeros); L_tril starts as eye(P)[tril] (approximations.py:138-141) */
+} nuts_advi_config;
+typedef struct nuts_advi nuts_advi;
+nuts_advi *nuts_advi_create(const nuts_advi_config *cfg);
+void nuts_advi_destroy(nuts_advi *a);
+/* n_steps optimisation steps; step s uses the row indices idx[s][batch] and the standard normals z0[s][P] (the reference draws
+ * both inside the compiled function).  loss[s] = the value the step function returns with score=True (may be NULL). */
+int nuts_advi_steps(nuts_advi *a, int32_t n_steps, const int64_t *idx, const double *z0, double *loss);
+/* Current parameters: mu [P], L_tril [P (P + 1) / 2] in np.tril_indices order (diagonal entries are rho, L_ii = softplus(rho)). */
+int nuts_advi_get_params(nuts_advi *a, double *mu, double *L_tril);
+int nuts_advi_set_params(nuts_advi *a, const double *mu, const double *L_tril);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,12 @@ class Pcg64(C.Structure):
                 ("has_uint32", C.c_int32), ("uinteger", C.c_uint32)]
 
 
+class AdviConfig(C.Structure):
+    _fields_ = [("N", C.c_int64), ("P", C.c_int32), ("family", C.c_int32), ("batch", C.c_int32), ("n_win", C.c_int32),
+                ("sigma", C.c_double), ("prior_sd", C.c_double), ("learning_rate", C.c_double), ("epsilon", C.c_double),
+                ("X", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)), ("start", C.POINTER(C.c_double))]
+
+
 _PD = C.POINTER(C.c_double)
 _VP = C.c_void_p
 
@@ -200,6 +206,11 @@ SYMBOLS = {
     "nuts_gibbs_create": (_VP, [C.c_int64, C.c_int32, _PD]),
     "nuts_gibbs_destroy": (None, [_VP]),
     "nuts_gibbs_sweep": (C.c_int, [_VP, _VP, _PD, _PD, _PD, _VP, _VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _PD, _PD, _PD]),
+    "nuts_advi_create": (_VP, [C.POINTER(AdviConfig)]),
+    "nuts_advi_destroy": (None, [_VP]),
+    "nuts_advi_steps": (C.c_int, [_VP, C.c_int32, _VP, _PD, _PD]),
+    "nuts_advi_get_params": (C.c_int, [_VP, _PD, _PD]),
+    "nuts_advi_set_params": (C.c_int, [_VP, _PD, _PD]),
     "nuts_chain_profile": (C.c_int, [_VP, C.c_int]),
     "nuts_chain_profile_read": (C.c_int, [_VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }

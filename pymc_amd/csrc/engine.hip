@@ -22,6 +22,7 @@
 #include "small_kernel.h"
 #include "nuts_mi355.h"
 #include "pcg64_stream.h"
+#include "advi.h"
 
 static thread_local std::string g_err;
 
@@ -1997,5 +1998,122 @@ extern "C" int nuts_gibbs_sweep(nuts_gibbs* g, int32_t* c, const double* log_w, 
   }
   if (n_accepted) *n_accepted = (int64_t)acc;
   if (n_nonfinite) *n_nonfinite = (int64_t)nonf;
+  return NUTS_OK;
+}
+
+
+// ===========================================================================
+// full-rank minibatch ADVI on a GLM (include/nuts_mi355.h, csrc/advi.h)
+// ===========================================================================
+struct nuts_advi {
+  AdviDev d{};
+  hipStream_t stream = nullptr;
+  std::vector<void*> owned;
+  int64_t steps_done = 0;
+  size_t in_cap = 0, hist_cap = 0;
+  int64_t* idx_dev = nullptr; double* z0_dev = nullptr;
+  template <typename T> T* keep(T* p) { owned.push_back((void*)p); return p; }
+};
+
+extern "C" nuts_advi* nuts_advi_create(const nuts_advi_config* c) {
+  if (!c || !c->X || !c->y || c->N <= 0 || c->P <= 0 || c->P > WAVE * ADVI_MAXP_PER_LANE || c->batch <= 0 || c->n_win <= 0 || c->n_win > 64 ||
+      (c->family != 0 && c->family != 1)) {
+    g_err = "nuts_advi_create: bad configuration (1 <= P <= 1024, family 0 / 1)"; return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device visible: libnuts_mi355 requires an MI355X (gfx950); there is no CPU fallback";
+    return nullptr;
+  }
+  auto* a = new nuts_advi();
+  AdviDev& d = a->d;
+  HIPCHK_NULL(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+  d.N = c->N; d.P = c->P; d.family = c->family; d.B = c->batch; d.n_win = c->n_win;
+  d.sigma = c->sigma; d.prior_sd = c->prior_sd; d.lr = c->learning_rate; d.eps = c->epsilon;
+  const int P = d.P;
+  const size_t T = (size_t)P * (P + 1) / 2;
+  d.X = a->keep(dev_upload(c->X, (size_t)c->N * P));
+  d.y = a->keep(dev_upload(c->y, (size_t)c->N));
+  std::vector<double> mu(P, 0.0), lt(T, 0.0);
+  if (c->start) mu.assign(c->start, c->start + P);
+  for (int i = 0; i < P; ++i) lt[(size_t)i * (i + 1) / 2 + i] = 1.0;   // eye(P)[tril_indices] (approximations.py:138-141)
+  d.mu = a->keep(dev_upload(mu.data(), mu.size()));
+  d.Lt = a->keep(dev_upload(lt.data(), lt.size()));
+  d.acc_mu = a->keep(dev_alloc<double>((size_t)P * d.n_win));
+  d.acc_L = a->keep(dev_alloc<double>(T * d.n_win));
+  d.z = a->keep(dev_alloc<double>(P)); d.diag = a->keep(dev_alloc<double>(P)); d.rowq = a->keep(dev_alloc<double>(P)); d.g = a->keep(dev_alloc<double>(P));
+  const int rows_per_wg = (256 / WAVE) * ADVI_ROWS_PER_WAVE;
+  d.nwg = (d.B + rows_per_wg - 1) / rows_per_wg;
+  d.gpart = a->keep(dev_alloc<double>((size_t)d.nwg * P));
+  d.llpart = a->keep(dev_alloc<double>((size_t)d.nwg));
+  for (void* p : a->owned) if (!p) { g_err = "device allocation failed"; nuts_advi_destroy(a); return nullptr; }
+  hipMemset(d.acc_mu, 0, (size_t)P * d.n_win * sizeof(double));
+  hipMemset(d.acc_L, 0, T * d.n_win * sizeof(double));
+  HIPCHK_NULL(hipDeviceSynchronize());
+  return a;
+}
+
+extern "C" void nuts_advi_destroy(nuts_advi* a) {
+  if (!a) return;
+  if (a->stream) hipStreamSynchronize(a->stream);
+  for (void* p : a->owned) if (p) hipFree(p);
+  if (a->idx_dev) hipFree(a->idx_dev);
+  if (a->z0_dev) hipFree(a->z0_dev);
+  if (a->d.hist) hipFree(a->d.hist);
+  if (a->stream) hipStreamDestroy(a->stream);
+  delete a;
+}
+
+extern "C" int nuts_advi_steps(nuts_advi* a, int32_t n_steps, const int64_t* idx, const double* z0, double* loss) {
+  if (!a || !idx || !z0 || n_steps <= 0) { g_err = "null argument"; return NUTS_E_ARG; }
+  AdviDev& d = a->d;
+  hipStream_t s = a->stream;
+  for (int64_t t = 0; t < (int64_t)n_steps * d.B; ++t)
+    if (idx[t] < 0 || idx[t] >= d.N) { g_err = "minibatch row index out of range"; return NUTS_E_ARG; }
+  if ((size_t)n_steps > a->in_cap) {
+    HIPCHK(hipStreamSynchronize(s));
+    if (a->idx_dev) hipFree(a->idx_dev);
+    if (a->z0_dev) hipFree(a->z0_dev);
+    if (d.hist) hipFree(d.hist);
+    a->idx_dev = nullptr; a->z0_dev = nullptr; d.hist = nullptr;
+    HIPCHK(hipMalloc((void**)&a->idx_dev, (size_t)n_steps * d.B * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void**)&a->z0_dev, (size_t)n_steps * d.P * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&d.hist, (size_t)n_steps * sizeof(double)));
+    a->in_cap = (size_t)n_steps;
+  }
+  HIPCHK(hipMemcpyAsync(a->idx_dev, idx, (size_t)n_steps * d.B * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(a->z0_dev, z0, (size_t)n_steps * d.P * sizeof(double), hipMemcpyHostToDevice, s));
+  const int P = d.P;
+  const int64_t T = (int64_t)P * (P + 1) / 2;
+  const int zgrid = (P + 3) / 4, ggrid = std::max(1, std::min(8, (P + 255) / 256));
+  const int ugrid = (int)std::min<int64_t>(4096, (T + P + 255) / 256);
+  for (int st = 0; st < n_steps; ++st) {
+    const double* z0s = a->z0_dev + (size_t)st * P;
+    hipLaunchKernelGGL(k_advi_z, dim3(zgrid), dim3(256), 0, s, d, z0s);
+    hipLaunchKernelGGL(k_advi_rows, dim3(d.nwg), dim3(256), 0, s, d, a->idx_dev + (size_t)st * d.B);
+    hipLaunchKernelGGL(k_advi_grad, dim3(ggrid), dim3(256), 0, s, d, st);
+    hipLaunchKernelGGL(k_advi_update, dim3(ugrid), dim3(256), 0, s, d, z0s, (int)(a->steps_done % d.n_win));
+    a->steps_done++;
+  }
+  if (loss) HIPCHK(hipMemcpyAsync(loss, d.hist, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  return NUTS_OK;
+}
+
+extern "C" int nuts_advi_get_params(nuts_advi* a, double* mu, double* L_tril) {
+  if (!a) return NUTS_E_ARG;
+  HIPCHK(hipStreamSynchronize(a->stream));
+  const size_t P = a->d.P, T = P * (P + 1) / 2;
+  if (mu) HIPCHK(hipMemcpy(mu, a->d.mu, P * sizeof(double), hipMemcpyDeviceToHost));
+  if (L_tril) HIPCHK(hipMemcpy(L_tril, a->d.Lt, T * sizeof(double), hipMemcpyDeviceToHost));
+  return NUTS_OK;
+}
+extern "C" int nuts_advi_set_params(nuts_advi* a, const double* mu, const double* L_tril) {
+  if (!a) return NUTS_E_ARG;
+  HIPCHK(hipStreamSynchronize(a->stream));
+  const size_t P = a->d.P, T = P * (P + 1) / 2;
+  if (mu) HIPCHK(hipMemcpy(a->d.mu, mu, P * sizeof(double), hipMemcpyHostToDevice));
+  if (L_tril) HIPCHK(hipMemcpy(a->d.Lt, L_tril, T * sizeof(double), hipMemcpyHostToDevice));
   return NUTS_OK;
 }

@@ -153,3 +153,24 @@ def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: f
     spec = m.build()
     spec.mixture = MixtureLink("c", y, np.full(K, -np.log(K)), np.full(K, float(sigma)), "mu")
     return spec
+
+
+def glm(N: int = 1_000_000, P: int = 512, family: str = "normal", batch_size: int = 1024, seed: int = DATA_SEED, sigma: float = 1.0,
+        prior_sd: float = 1.0):
+    """GLM with N observations and P covariates for minibatched full-rank ADVI (BASELINE configs[3]: N = 1 M, P = 512; X fp64 =
+    4.1 GB, resident in HBM).  x_i ~ N(0, 1)^P with x_{i,0} = 1; beta* ~ N(0, 0.3); y = x . beta* + sigma e (or Bernoulli-logit)."""
+    from pymc_amd.variational import GLMSpec
+
+    rng = np.random.default_rng(seed)
+    beta = rng.normal(0, 0.3, size=P)
+    X = np.empty((N, P))
+    y = np.empty(N)
+    chunk = 1 << 16
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        xb = rng.normal(size=(e - s, P))
+        xb[:, 0] = 1.0
+        X[s:e] = xb
+        eta = xb @ beta
+        y[s:e] = eta + sigma * rng.normal(size=e - s) if family == "normal" else (rng.random(e - s) < 1.0 / (1.0 + np.exp(-eta)))
+    return GLMSpec(X, y, family, sigma, prior_sd, batch_size)

@@ -1,0 +1,208 @@
+"""Full-rank minibatch ADVI backed by the device engine (BASELINE configs[3]).
+
+Mirrors the slice of `pymc.variational` a `pm.fit(n, method="fullrank_advi")` call goes through:
+
+* `FullRankADVI(model=..., random_seed=..., start=...)` (variational/inference.py:497-524) with `.fit(n, obj_optimizer=...,
+  obj_n_mc=1, callbacks=...)` (`Inference.fit`, inference.py:115-170) returning the approximation;
+* the approximation's `mean`, `cov`, `std`, `params`, `sample(draws)` (`FullRankGroup`, variational/approximations.py:118-188;
+  `Approximation.sample`, opvi.py:1488-1560), `hist` (loss per step, `Inference.hist`);
+* `adagrad_window(learning_rate, epsilon, n_win)` (variational/updates.py:542-585), the default optimiser.
+
+The model is the GLM of `models.glm` -- `pm.Normal("y", mu=pm.math.dot(X_mb, beta), sigma, observed=y_mb, total_size=N)` with
+`X_mb, y_mb = pm.Minibatch(X, y, batch_size=B)` (pymc/data.py:121-161) -- and the optimisation step runs on the device
+(`nuts_advi_steps`, csrc/advi.h).  Random inputs: the reference draws minibatch indices and z0 with PyTensor RNG ops seeded from
+`random_seed`; here they come from a NumPy generator seeded the same way (uniform row indices with replacement, standard
+normals) -- the streams are not the reference's (unpinned, like the start-point jitter of `init_nuts`).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from functools import partial
+from typing import Optional
+
+import numpy as np
+
+from pymc_amd import _lib
+
+
+@dataclass
+class GLMSpec:
+    """`y ~ family(X beta)`, `beta ~ Normal(0, prior_sd)`; `family` in {"normal", "bernoulli"}; minibatches of `batch_size` rows."""
+
+    X: np.ndarray
+    y: np.ndarray
+    family: str = "normal"
+    sigma: float = 1.0
+    prior_sd: float = 1.0
+    batch_size: int = 512
+    name: str = "beta"
+
+    @property
+    def n(self) -> int:
+        return int(self.X.shape[1])
+
+
+def adagrad_window(learning_rate=0.001, epsilon=0.1, n_win=10):
+    """variational/updates.py:542-585 (called without loss / params it returns the configured optimiser, :565-566)."""
+    return partial(_AdagradWindow, learning_rate=learning_rate, epsilon=epsilon, n_win=n_win)
+
+
+@dataclass
+class _AdagradWindow:
+    learning_rate: float = 0.001
+    epsilon: float = 0.1
+    n_win: int = 10
+
+
+class FullRankApproximation:
+    """What `fit` returns (`Approximation` over one `FullRankGroup`)."""
+
+    def __init__(self, inference: "FullRankADVI"):
+        self._inf = inference
+
+    @property
+    def params(self):
+        return self._inf._params()          # [mu, L_tril] as the reference orders `FullRankGroup.params`
+
+    @property
+    def mean(self):
+        return self.params[0]
+
+    @property
+    def L(self):                             # approximations.py:143-149
+        mu, lt = self.params
+        d = len(mu)
+        L = np.zeros((d, d))
+        L[np.tril_indices(d)] = lt
+        i = np.arange(d)
+        L[i, i] = np.logaddexp(0.0, L[i, i])  # rho2sigma
+        return L
+
+    @property
+    def cov(self):
+        L = self.L
+        return L @ L.T
+
+    @property
+    def std(self):
+        return np.sqrt(np.diag(self.cov))
+
+    @property
+    def hist(self):
+        return self._inf.hist
+
+    def sample(self, draws=500, random_seed=None):
+        """`Approximation.sample` (opvi.py:1488-1560) reduced to arrays: {name: (1, draws, d)}."""
+        rng = np.random.default_rng(random_seed)
+        z0 = rng.normal(size=(draws, len(self.mean)))
+        return {self._inf.model.name: (z0 @ self.L.T + self.mean)[None]}
+
+
+class FullRankADVI:
+    """variational/inference.py:497-524."""
+
+    def __init__(self, model: GLMSpec = None, random_seed=None, start=None, start_sigma=None, device: Optional[int] = None):
+        if not isinstance(model, GLMSpec):
+            raise TypeError("model must be a pymc_amd.variational.GLMSpec")
+        if start_sigma is not None:
+            raise NotImplementedError("start_sigma is a MeanField option (approximations.py:60-84)")
+        self.model = model
+        self.rng = np.random.default_rng(random_seed)
+        self.hist = np.asarray(())
+        self._start = None if start is None else np.ascontiguousarray(start[model.name] if isinstance(start, dict) else start, dtype="float64")
+        self._device = device
+        self._handle = None
+        self._opt = None
+        self.approx = FullRankApproximation(self)
+
+    def _engine(self, opt: _AdagradWindow):
+        if self._handle is not None:
+            if (opt.learning_rate, opt.epsilon, opt.n_win) != self._opt:
+                raise ValueError("the optimiser of a running inference cannot change (the reference compiles it into the step function)")
+            return self._handle
+        lib = _lib.load()
+        if self._device is not None:
+            _lib.check(lib.nuts_set_device(int(self._device)), "nuts_set_device")
+        m = self.model
+        X = np.ascontiguousarray(m.X, dtype="float64")
+        y = np.ascontiguousarray(m.y, dtype="float64")
+        cfg = _lib.AdviConfig()
+        cfg.N, cfg.P = X.shape
+        cfg.family = {"normal": 0, "bernoulli": 1}[m.family]
+        cfg.batch, cfg.n_win = int(m.batch_size), int(opt.n_win)
+        cfg.sigma, cfg.prior_sd, cfg.learning_rate, cfg.epsilon = float(m.sigma), float(m.prior_sd), float(opt.learning_rate), float(opt.epsilon)
+        cfg.X, cfg.y = _lib.dptr(X), _lib.dptr(y)
+        cfg.start = _lib.dptr(self._start) if self._start is not None else None
+        self._handle = lib.nuts_advi_create(C.byref(cfg))
+        if not self._handle:
+            raise _lib.EngineError(f"nuts_advi_create failed: {_lib.last_error()}")
+        self._opt = (opt.learning_rate, opt.epsilon, opt.n_win)
+        return self._handle
+
+    def _params(self):
+        d = self.model.n
+        mu, lt = np.empty(d), np.empty(d * (d + 1) // 2)
+        if self._handle is None:
+            mu[:] = 0.0 if self._start is None else self._start
+            lt[:] = np.eye(d)[np.tril_indices(d)]
+            return [mu, lt]
+        _lib.check(_lib.load().nuts_advi_get_params(self._handle, _lib.dptr(mu), _lib.dptr(lt)), "nuts_advi_get_params")
+        return [mu, lt]
+
+    def draw_inputs(self, n_steps: int):
+        """The random inputs of `n_steps` steps: minibatch row indices (`Minibatch`: uniform with replacement, data.py:121-161)
+        and z0 ~ N(0, I) (`symbolic_initial`, opvi.py:940-972)."""
+        m = self.model
+        idx = self.rng.integers(0, m.X.shape[0], size=(n_steps, m.batch_size), dtype=np.int64)
+        z0 = self.rng.normal(size=(n_steps, m.n))
+        return idx, z0
+
+    def run_steps(self, idx: np.ndarray, z0: np.ndarray, obj_optimizer=None) -> np.ndarray:
+        opt = (obj_optimizer or adagrad_window())()
+        h = self._engine(opt)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        z0 = np.ascontiguousarray(z0, dtype="float64")
+        loss = np.empty(len(idx))
+        _lib.check(_lib.load().nuts_advi_steps(h, len(idx), idx.ctypes.data, _lib.dptr(z0), _lib.dptr(loss)), "nuts_advi_steps")
+        return loss
+
+    def fit(self, n=10000, score=None, callbacks=None, progressbar=False, obj_optimizer=None, obj_n_mc=1, total_grad_norm_constraint=None,
+            chunk=1024, **kwargs):
+        """`Inference.fit` (inference.py:115-170)."""
+        if obj_n_mc != 1 or total_grad_norm_constraint is not None or kwargs:
+            raise NotImplementedError("the device step function implements obj_n_mc=1 without gradient clipping")
+        hist = [self.hist]
+        done = 0
+        while done < n:
+            k = min(chunk, n - done)
+            idx, z0 = self.draw_inputs(k)
+            loss = self.run_steps(idx, z0, obj_optimizer)
+            hist.append(loss)
+            done += k
+            if not np.all(np.isfinite(loss)):
+                raise FloatingPointError(f"NaN occurred in optimization at step {done - k + int(np.argmin(np.isfinite(loss)))}")
+            if callbacks:
+                for cb in callbacks:
+                    cb(self.approx, loss, done)
+        self.hist = np.concatenate(hist)
+        return self.approx
+
+    def close(self):
+        if self._handle:
+            _lib.load().nuts_advi_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fit(n=10000, method="fullrank_advi", model=None, random_seed=None, start=None, **kwargs):
+    """`pm.fit` (inference.py:680-775) for the one method built here."""
+    if method not in ("fullrank_advi", "fullrank"):
+        raise KeyError(f"method should be one of {{'fullrank_advi'}} (got {method!r}); the other families are outside SURVEY 8f-3")
+    return FullRankADVI(model=model, random_seed=random_seed, start=start).fit(n, **kwargs)

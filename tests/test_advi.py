@@ -1,0 +1,112 @@
+"""Full-rank minibatch ADVI: the oracle restatement against torch autograd (CPU), the device step
+function against the oracle on identical random inputs, and the fit against the closed-form posterior of the linear-Gaussian
+GLM (GPU)."""
+
+import numpy as np
+import pytest
+
+from oracle import ref_advi
+from pymc_amd import models
+from pymc_amd.variational import FullRankADVI, GLMSpec, adagrad_window, fit
+
+
+def _small(family, N=600, P=9, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, P)); X[:, 0] = 1.0
+    beta = rng.normal(size=P) * 0.5
+    y = X @ beta + 0.7 * rng.normal(size=N) if family == "normal" else (rng.random(N) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    return GLMSpec(X, y, family, sigma=0.7, prior_sd=2.0, batch_size=48)
+
+
+@pytest.mark.parametrize("family", ["normal", "bernoulli"])
+def test_oracle_gradient_matches_autograd(family):
+    torch = pytest.importorskip("torch")
+    m = _small(family)
+    N, d = m.X.shape
+    rng = np.random.default_rng(1)
+    glm = ref_advi.GLM(m.X, m.y, family, m.sigma, m.prior_sd)
+    st = ref_advi.FullRankState(d, start=rng.normal(size=d) * 0.1)
+    st.L_tril = st.L_tril + 0.1 * rng.normal(size=len(st.L_tril))
+    idx, z0 = rng.integers(0, N, size=48), rng.normal(size=d)
+    mu_t = torch.tensor(st.mu, dtype=torch.float64, requires_grad=True)
+    Lt = torch.tensor(st.L_tril, dtype=torch.float64, requires_grad=True)
+    ti = np.tril_indices(d)
+    L = torch.zeros(d, d, dtype=torch.float64)
+    L[ti[0], ti[1]] = Lt
+    di = torch.arange(d)
+    Ld = torch.nn.functional.softplus(L[di, di])
+    L = L.clone(); L[di, di] = Ld
+    z = torch.tensor(z0) @ L.T + mu_t
+    xb, yb = torch.tensor(m.X[idx]), torch.tensor(m.y[idx])
+    eta = xb @ z
+    ll = (-0.5 * ((yb - eta) / m.sigma) ** 2 - np.log(m.sigma) - 0.5 * np.log(2 * np.pi)).sum() if family == "normal" else (yb * eta - torch.nn.functional.softplus(eta)).sum()
+    vlp = (-0.5 * (z / m.prior_sd) ** 2 - np.log(m.prior_sd) - 0.5 * np.log(2 * np.pi)).sum()
+    logq = (-0.5 * torch.tensor(z0) ** 2 - np.log(np.sqrt(2 * np.pi))).sum() - torch.log(Ld).sum()
+    loss = -ll * N / 48 + (logq - vlp)
+    loss.backward()
+    l, gm, gl = ref_advi.advi_step(glm, st, idx, z0)
+    assert abs(l - loss.item()) <= 1e-12 * abs(l)
+    np.testing.assert_allclose(gm, mu_t.grad.numpy(), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(gl, Lt.grad.numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_surface_without_a_device():
+    m = _small("normal")
+    inf = FullRankADVI(model=m, random_seed=3)
+    mu, lt = inf.approx.params
+    assert np.all(mu == 0) and np.array_equal(lt, np.eye(9)[np.tril_indices(9)])         # approximations.py:136-141
+    np.testing.assert_allclose(np.diag(inf.approx.L), np.log1p(np.e))                      # rho2sigma(1)
+    idx, z0 = inf.draw_inputs(5)
+    assert idx.shape == (5, 48) and z0.shape == (5, 9) and idx.min() >= 0 and idx.max() < 600
+    with pytest.raises(NotImplementedError):
+        inf.fit(10, obj_n_mc=5)
+    with pytest.raises(KeyError):
+        fit(10, method="svgd", model=m)
+    assert adagrad_window(learning_rate=0.01)().learning_rate == 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["normal", "bernoulli"])
+def test_device_steps_match_the_oracle_on_identical_inputs(family):
+    m = _small(family, N=3000, P=70)
+    inf = FullRankADVI(model=m, random_seed=5, device=0)
+    rng = np.random.default_rng(8)
+    steps = 25                                    # > n_win: the adagrad window wraps
+    idx = rng.integers(0, 3000, size=(steps, 48)); z0 = rng.normal(size=(steps, 70))
+    opt = adagrad_window(learning_rate=0.02, epsilon=0.1, n_win=10)
+    loss = inf.run_steps(idx, z0, opt)
+    glm = ref_advi.GLM(m.X, m.y, family, m.sigma, m.prior_sd)
+    st = ref_advi.FullRankState(70)
+    ref_loss = [ref_advi.advi_step(glm, st, idx[s], z0[s], 0.02, 0.1, 10)[0] for s in range(steps)]
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-10)
+    mu, lt = inf.approx.params
+    np.testing.assert_allclose(mu, st.mu, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(lt, st.L_tril, rtol=1e-9, atol=1e-12)
+    inf.close()
+
+
+@pytest.mark.gpu
+def test_fit_converges_to_the_closed_form_posterior():
+    """Linear-Gaussian GLM: the posterior is N(m, S) with S = (X'X / sigma^2 + I / prior_sd^2)^-1, m = S X'y / sigma^2; full-rank ADVI
+    has the exact family, so mean and covariance must come out (to within the optimiser's noise)."""
+    m = models.glm(N=20_000, P=16, batch_size=256, sigma=0.5, prior_sd=2.0, seed=3)
+    S = np.linalg.inv(m.X.T @ m.X / m.sigma**2 + np.eye(16) / m.prior_sd**2)
+    mean = S @ (m.X.T @ m.y) / m.sigma**2
+    approx = fit(12000, model=m, random_seed=1, obj_optimizer=adagrad_window(learning_rate=0.01))
+    assert approx.hist.shape == (12000,) and np.all(np.isfinite(approx.hist))
+    assert approx.hist[-500:].mean() < approx.hist[:500].mean()
+    sd = np.sqrt(np.diag(S))
+    assert np.max(np.abs(approx.mean - mean) / sd) < 1.5
+    np.testing.assert_allclose(approx.std, sd, rtol=0.35)
+    draws = approx.sample(2000, random_seed=2)["beta"]
+    assert draws.shape == (1, 2000, 16)
+
+
+@pytest.mark.gpu
+def test_configs3_shape_runs():
+    """BASELINE configs[3] at a quarter of its rows (250 k x 512, X = 1 GB) keeps the test short; `bench.py --workload advi` times the
+    full 1 M x 512."""
+    m = models.glm(N=250_000, P=512, batch_size=1024, seed=4)
+    approx = fit(300, model=m, random_seed=2)
+    assert approx.hist.shape == (300,) and np.all(np.isfinite(approx.hist))
+    assert approx.params[1].shape == (512 * 513 // 2,)
