@@ -85,21 +85,59 @@ def test_device_steps_match_the_oracle_on_identical_inputs(family):
     inf.close()
 
 
-@pytest.mark.gpu
-def test_fit_converges_to_the_closed_form_posterior():
+def _closed_form(m):
+    P = m.X.shape[1]
+    S = np.linalg.inv(m.X.T @ m.X / m.sigma**2 + np.eye(P) / m.prior_sd**2)
+    return S @ (m.X.T @ m.y) / m.sigma**2, np.sqrt(np.diag(S))
+
+
+def _oracle_fit(m, n, random_seed, learning_rate, chunk=1024):
+    """The oracle run on the random inputs `FullRankADVI.fit` draws (same generator, same chunking)."""
+    glm = ref_advi.GLM(m.X, m.y, m.family, m.sigma, m.prior_sd)
+    st = ref_advi.FullRankState(m.n)
+    rng = np.random.default_rng(random_seed)
+    hist = []
+    for done in range(0, n, chunk):
+        k = min(chunk, n - done)
+        idx = rng.integers(0, m.X.shape[0], size=(k, m.batch_size), dtype=np.int64)
+        z0 = rng.normal(size=(k, m.n))
+        hist += [ref_advi.advi_step(glm, st, idx[s], z0[s], learning_rate, 0.1, 10)[0] for s in range(k)]
+    return st, np.asarray(hist)
+
+
+FIT = dict(N=400, P=8, batch_size=100, sigma=1.0, prior_sd=2.0, seed=3)
+
+
+def test_oracle_fit_converges_to_the_closed_form_posterior():
     """Linear-Gaussian GLM: the posterior is N(m, S) with S = (X'X / sigma^2 + I / prior_sd^2)^-1, m = S X'y / sigma^2; full-rank ADVI
-    has the exact family, so mean and covariance must come out (to within the optimiser's noise)."""
-    m = models.glm(N=20_000, P=16, batch_size=256, sigma=0.5, prior_sd=2.0, seed=3)
-    S = np.linalg.inv(m.X.T @ m.X / m.sigma**2 + np.eye(16) / m.prior_sd**2)
-    mean = S @ (m.X.T @ m.y) / m.sigma**2
-    approx = fit(12000, model=m, random_seed=1, obj_optimizer=adagrad_window(learning_rate=0.01))
-    assert approx.hist.shape == (12000,) and np.all(np.isfinite(approx.hist))
-    assert approx.hist[-500:].mean() < approx.hist[:500].mean()
-    sd = np.sqrt(np.diag(S))
-    assert np.max(np.abs(approx.mean - mean) / sd) < 1.5
+    has the exact family, so mean and standard deviations must come out to within the optimiser's noise (`adagrad_window` keeps a
+    finite step, so the iterate jitters around the optimum: 0.2 posterior sd on the mean, +6..25 % on the sd at this setting --
+    with a posterior as tight as N = 20 000 rows gives, the same jitter is 5 posterior sd, which is the algorithm, not an error)."""
+    m = models.glm(**FIT)
+    mean, sd = _closed_form(m)
+    st, hist = _oracle_fit(m, 20000, 1, 0.005)
+    assert hist[-500:].mean() < hist[:500].mean()
+    L = st.L()
+    assert np.max(np.abs(st.mu - mean) / sd) < 1.0
+    np.testing.assert_allclose(np.sqrt(np.diag(L @ L.T)), sd, rtol=0.35)
+
+
+@pytest.mark.gpu
+def test_fit_matches_the_oracle_fit_and_the_closed_form_posterior():
+    """The whole fit on the device against the oracle's on the same random inputs (20 000 steps: the optimisation is a contraction, so
+    rounding differences do not grow), then against the closed form with the thresholds of the CPU test above."""
+    m = models.glm(**FIT)
+    mean, sd = _closed_form(m)
+    approx = fit(20000, model=m, random_seed=1, obj_optimizer=adagrad_window(learning_rate=0.005))
+    st, hist = _oracle_fit(m, 20000, 1, 0.005)
+    assert approx.hist.shape == (20000,) and np.all(np.isfinite(approx.hist))
+    np.testing.assert_allclose(approx.hist, hist, rtol=1e-7)
+    np.testing.assert_allclose(approx.mean, st.mu, rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(approx.params[1], st.L_tril, rtol=1e-7, atol=1e-10)
+    assert np.max(np.abs(approx.mean - mean) / sd) < 1.0
     np.testing.assert_allclose(approx.std, sd, rtol=0.35)
     draws = approx.sample(2000, random_seed=2)["beta"]
-    assert draws.shape == (1, 2000, 16)
+    assert draws.shape == (1, 2000, 8)
 
 
 @pytest.mark.gpu
