@@ -83,6 +83,9 @@ struct nuts_model {
   int ga_variant = 42;         // 10 x (waves per SIMD of the register budget) + tiles in flight per wave
   int ga_struct_ok = 0;        // the spec is exactly what the group-aligned row pass evaluates in closed form (compile_spec)
   int ga_par = 0;              // parity of the last group-aligned launch (its block partials / local parts are double-buffered)
+  unsigned* ga_sync = nullptr; // progress words of the persistent tree kernel (rows_ga_tree.h)
+  int ga_tree_ok = 0;          // the whole grid of k_tree_ga is resident at once on this device (checked at model creation)
+  int64_t dom_units = 0;       // leapfrog passes covered by the timed launches (a tree launch covers a whole tree)
   int explicit_pre = 0;        // the position must be materialised before the dense pass (MvNormal node)
   int64_t alg_bytes = 0;
   // profiling of the dominant kernel
@@ -177,7 +180,7 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid + (mfold ? 1 : 0)), dim3(MVN_BLOCK), 0, m->stream, md, A, io, j, mfold, d, Emax,
                        max_depth, st);
   }
-  if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; }
+  if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; m->dom_units += 1; }
   m->dom_launches++;
 }
 
@@ -505,7 +508,22 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         if (lg.ga_part) hipMemset(lg.ga_part, 0, (size_t)lg.G * PART_STRIDE * sizeof(double));
         if (lg.ga_bpart) hipMemset(lg.ga_bpart, 0, 2 * (size_t)lg.ga_nblk * PART_STRIDE * sizeof(double));
         if (lg.ga_ticket) hipMemset(lg.ga_ticket, 0, lg.ga_nblk * sizeof(unsigned));
+        m->ga_sync = m->keep(dev_alloc<unsigned>(GA_SYNC_WORDS));
+        if (m->ga_sync) hipMemset(m->ga_sync, 0, GA_SYNC_WORDS * sizeof(unsigned));
         m->rows_grid = lg.G;
+        // persistent tree kernel (rows_ga_tree.h): needs every one of its G + 1 workgroups resident at once.  The occupancy
+        // query is asked for the real block size and capped by the wave slots of the register budget; the query can be
+        // optimistic (MI355X guide, "Residency and cooperative launch"), which is why every wait in the kernel is bounded.
+        m->ga_tree_ok = 0;
+        // (only at the 168-register budget, variant 32: at 128 registers the allocator spills inside the streaming loop)
+        if (D == 8 && m->ga_variant == 32 && env_int("NUTS_GA_TREE", 1) != 0) {
+          int per_cu = 0;
+          const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3>, WAVE * W, 0);
+          if (e == hipSuccess) {
+            const int hw = std::min(per_cu, (4 * occ) / std::max(W, 1));   // `occ` waves per SIMD at this register budget
+            m->ga_tree_ok = (int64_t)hw * cus >= (int64_t)lg.G + 1;
+          }
+        }
       }
     }
     if (!lg.ga) {
@@ -652,6 +670,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   if (k == "rows_group_aligned") *out = m->md.lg.ga;
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
   else if (k == "lean") *out = m->md.lean_ok;
+  else if (k == "tree_kernel_ok") *out = m->ga_tree_ok;
   else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
@@ -678,6 +697,7 @@ static void profile_enable(nuts_model* m, bool on, int sample_every, size_t max_
   m->sample_every = std::max(1, sample_every);
   m->ev_used = 0;
   m->dom_launches = 0;
+  m->dom_units = 0;
   while (on && m->ev.size() < 2 * max_pairs) {
     hipEvent_t e;
     hipEventCreate(&e);
@@ -793,6 +813,9 @@ struct nuts_chain {
   double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
   int64_t cache_epoch = -1;      // model data epoch the start-state cache belongs to
   int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
+  int tree_mode = 0;             // group-aligned row pass: one persistent launch per NUTS tree (rows_ga_tree.h)
+  int64_t tree_launches = 0;
+  int tree_prof_pending = 0;     // the last tree launch is being timed: its leaf count is added when the draw's record arrives
   int spec_max = 3, last_depth = 0;   // look-ahead over the short doublings (nuts_chain_draw)
   int logs_done = 0, logs_total = 0;  // logarithms of the pre-drawn uniforms taken / needed at most this draw
   // staging of nuts_chain_draw_many (grown on demand)
@@ -879,6 +902,9 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->wb_mean = c->keep(dev_alloc<double>(n)); c->wb_m2 = c->keep(dev_alloc<double>(n));
   A.var = c->var; A.inv_stds = c->inv_stds;
   A.ga_ticket = m->md.lg.ga ? m->md.lg.ga_ticket : nullptr; A.ga_nticket = m->md.lg.ga ? m->md.lg.ga_nblk : 0;
+  A.ga_sync = m->md.lg.ga ? m->ga_sync : nullptr;
+  // NUTS_GA_TREE=0: one launch per leapfrog (also what several chains SHARING a GPU must use: the tree kernel needs the chip)
+  c->tree_mode = m->md.lg.ga && m->ga_tree_ok && !c->dense && m->md.lean_ok && env_int("NUTS_GA_TREE", 1) != 0;
   if (c->dense) {
     c->dense_C = c->keep(dev_upload(cfg->dense_cov, (size_t)n * n));
     c->dense_W = c->keep(dev_upload(cfg->dense_rand, (size_t)n * n));
@@ -1138,6 +1164,45 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   c->leapfrogs++;
 }
 
+// The same transition as ONE launch of the persistent tree kernel (rows_ga_tree.h): the leaf loop and the doubling loop run on
+// the device, the host waits for the status word of the whole tree.  Every logarithm the tree can consume must be on the
+// device before the launch (`ensure_logs` up to the worst case).
+static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, int max_depth, unsigned* flags_out, bool* exhausted_out) {
+  nuts_model* m = c->m;
+  ArenaDev& A = c->A;
+  int rc = ensure_logs(c, (1 << max_depth) + max_depth + 1);
+  if (rc) return rc;
+  const int seq = ++c->seq;
+  GaTreeArgs ga{};
+  ga.md = m->md; ga.A = A;
+  ga.max_depth = max_depth;
+  ga.spec_depth = c->last_depth - 1;   // speculate across doubling boundaries as deep as the previous draw's tree went
+  ga.rev0 = m->rows_flip; ga.par0 = m->ga_par; ga.alternate = m->rows_alternate;
+  ga.first_dir = uniforms[0] < 0.5 ? 1 : -1;
+  ga.seq = seq;
+  ga.Emax = c->cfg.Emax; ga.eps_abs = step_size;
+  ga.st = c->st_dev;
+  ga.timeout = (long long)env_int("NUTS_GA_TREE_TIMEOUT_MS", 50) * 100000ll;   // 100 MHz ticks
+  const bool prof = m->profile && m->ev_used + 2 <= m->ev.size();
+  if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
+  hipLaunchKernelGGL(k_tree_ga<3>, dim3(m->rows_grid + 1), dim3(WAVE * m->md.lg.ga_w), 0, m->stream, ga);
+  if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; c->tree_prof_pending = 1; }
+  m->dom_launches++;
+  c->tree_launches++;
+  unsigned flags = 0;
+  rc = wait_status(c, seq, &flags);
+  if (rc) return rc;
+  if (flags & ST_TIMEOUT) {
+    g_err = "persistent tree kernel: a wait between workgroups timed out (are all of its workgroups resident? another process on "
+            "this GPU? run with NUTS_GA_TREE=0)";
+    hipStreamSynchronize(m->stream);
+    return NUTS_E_HIP;
+  }
+  *flags_out = flags;
+  *exhausted_out = !(flags & (ST_DIVERGING | ST_TURNING));
+  return NUTS_OK;
+}
+
 // The doubling loop of one transition (NUTS._hamiltonian_step, nuts.py:204-225): queue the leaves of each doubling, wait for the
 // status word of its last leaf.  `uniforms`: the host copy of the pre-drawn `step.rng.random()` values of THIS draw.
 static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int max_depth, unsigned* flags_out, bool* exhausted_out) {
@@ -1217,6 +1282,11 @@ static int finish_draw_host(nuts_chain* c, const DrawOut& o, bool adapt, bool ex
   const int n = c->n;
   ArenaDev& A = c->A;
   const double accept = std::exp(o.log_accept_sum) / o.n_proposals;
+  if (c->tree_mode) {
+    c->last_depth = o.depth;
+    c->leapfrogs += o.n_proposals;
+    if (c->tree_prof_pending) { c->m->dom_units += o.n_proposals; c->tree_prof_pending = 0; }
+  }
   c->da.update(accept, adapt);
   int rc = potential_update(c, result_dev);
   if (rc) return rc;
@@ -1309,7 +1379,8 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
   const auto tb = clk::now();
   c->t_begin += std::chrono::duration<double>(tb - t0).count();
   unsigned flags = 0;
-  rc = run_tree(c, uniforms, step_size, max_depth, &flags, &exhausted);
+  rc = c->tree_mode ? run_tree_ga(c, uniforms, step_size, max_depth, &flags, &exhausted)
+                    : run_tree(c, uniforms, step_size, max_depth, &flags, &exhausted);
   if (rc) return rc;
   const auto tl = clk::now();
   c->t_loop += std::chrono::duration<double>(tl - tb).count();
@@ -1426,7 +1497,8 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
                        c->last_logp, k > 0 ? (const DrawOut*)c->do_dev : (const DrawOut*)nullptr);
     unsigned flags = 0;
     bool exhausted = true;
-    rc = run_tree(c, h_u + consumed, step_size, max_depth, &flags, &exhausted);
+    rc = c->tree_mode ? run_tree_ga(c, h_u + consumed, step_size, max_depth, &flags, &exhausted)
+                      : run_tree(c, h_u + consumed, step_size, max_depth, &flags, &exhausted);
     if (rc) break;
     if (flags & ST_BAD_ENERGY) {
       rc = check_mass_matrix(c);
@@ -1747,6 +1819,8 @@ extern "C" int nuts_chain_get_scalar(nuts_chain* c, const char* name, double* ou
   else if (k == "bg_count") *out = c->bg_count;
   else if (k == "step_size") *out = c->step_size;
   else if (k == "leapfrogs") *out = (double)c->leapfrogs;
+  else if (k == "tree_kernel") *out = (double)c->tree_mode;
+  else if (k == "tree_launches") *out = (double)c->tree_launches;
   else if (k == "single_launch") *out = c->small ? 1.0 : 0.0;
   else if (k == "window_switched") *out = c->window_switched ? 1.0 : 0.0;
   else if (k == "t_begin") *out = c->t_begin;
@@ -1849,7 +1923,8 @@ extern "C" int nuts_chain_profile_read(nuts_chain* c, double* ms_sum, int64_t* l
   int64_t pairs = 0;
   const double tot = profile_sum_ms(c->m, &pairs);
   if (ms_sum) *ms_sum = tot;
-  if (launches) *launches = pairs;
+  // (passes over the model data covered by the timed launches: one per launch, or the leaves of the tree for a tree launch)
+  if (launches) *launches = c->m->dom_units;
   if (leapfrogs) *leapfrogs = c->leapfrogs;
   return NUTS_OK;
 }

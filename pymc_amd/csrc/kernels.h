@@ -79,7 +79,12 @@ struct ArenaDev {
                                // nullptr (single-launch path): the control code takes log(u) itself
   unsigned* ga_ticket;         // arrival counters of the group-aligned row pass (rows_ga_kernel.h), reset at the end of a draw
   int ga_nticket;
+  unsigned* ga_sync;           // [GA_SYNC_WORDS] progress words of the persistent tree kernel (rows_ga_tree.h), reset at the start of a draw
 };
+#define GA_SYNC_DONE 0         // number of block partials published since the start of the draw: leaf L is complete at (L + 1) ga_nblk
+#define GA_SYNC_CTL 1          // leaves whose control work is finished (and written back)
+#define GA_SYNC_ERR 2          // != 0: a wait inside the tree kernel timed out (1: row workgroup, 2: control workgroup)
+#define GA_SYNC_WORDS 4
 
 // Lives in pinned, device-mapped host memory.  `word[seq % ST_SLOTS]` = (sequence number << 32) | ST_* flags is written with ONE
 // system-scope store by the control work of the LAST leaf of a doubling; the host spins on it instead of paying a stream
@@ -91,6 +96,7 @@ struct ArenaDev {
 #define ST_DIVERGING 4u
 #define ST_BAD_ENERGY 8u
 #define ST_DIR_POS 16u
+#define ST_TIMEOUT 32u   // persistent tree kernel: a wait on another workgroup did not complete (not all workgroups resident?)
 #define ST_SLOTS 4   // doublings publish round-robin (the host may have queued the next doubling before reading this one)
 struct HostStatus {
   unsigned long long word[ST_SLOTS];
@@ -896,6 +902,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
 // pass); `def_loc`: the local parts of its deferred elements; runs in any workgroup of 64 .. 256 threads.
 struct LeanSrc { const double* part; int stride, nblk; const double* def_loc; };
 
+// AGENT: the records were written by other workgroups of THIS launch (persistent tree kernel, rows_ga_tree.h).
+template <bool AGENT = false>
 __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
                                              int max_depth, HostStatus* st, int seq, const LeanSrc src) {
   Leaf lf; QView qv;
@@ -922,8 +930,14 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   double2 l01 = make_double2(0.0, 1.0), l23 = make_double2(0.0, 0.0);
   if (mine) {
     def_i = md.deferred_g[2 * tid]; def_k = md.deferred_g[2 * tid + 1];
-    l01 = reinterpret_cast<const double2*>(src.def_loc)[2 * tid];
-    l23 = reinterpret_cast<const double2*>(src.def_loc)[2 * tid + 1];
+    if (AGENT) {
+      const double* dl = src.def_loc + 4 * tid;
+      l01 = make_double2(ld_agent(dl), ld_agent(dl + 1));
+      l23 = make_double2(ld_agent(dl + 2), ld_agent(dl + 3));
+    } else {
+      l01 = reinterpret_cast<const double2*>(src.def_loc)[2 * tid];
+      l23 = reinterpret_cast<const double2*>(src.def_loc)[2 * tid + 1];
+    }
   }
   // ---- fixed-order sums of the per-workgroup partials this leaf needs: (slot, chunk) pairs in parallel ----
   const int nlg = md.has_logit ? lg.D : 0;
@@ -943,7 +957,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     for (int t = tid; t < nn * CTL_CHUNKS; t += NT) {
       const int c = t % CTL_CHUNKS, k = need_slot(t / CTL_CHUNKS);
       const int b0 = c * per, b1 = min(src.nblk, (c + 1) * per);
-      s_chunk[c][k] = sum_strided(src.part + k, src.stride, b0, b1);
+      s_chunk[c][k] = sum_strided<AGENT>(src.part + k, src.stride, b0, b1);
     }
   }
   __syncthreads();
@@ -1205,6 +1219,7 @@ __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part
     else if (!c->aborted && max_depth > 0) ctl_next_direction(c, A.uniforms);
     if (st) publish_fields(c, st);
   }
+  if (A.ga_sync && threadIdx.x < GA_SYNC_WORDS) A.ga_sync[threadIdx.x] = 0u;
 }
 
 
@@ -1276,3 +1291,4 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update(int n, const d
 }
 
 #include "rows_ga_kernel.h"
+#include "rows_ga_tree.h"

@@ -152,14 +152,31 @@ __device__ __forceinline__ long long tick_now() {   // drains outstanding memory
 #define TICK(md, cond, slot) do { } while (0)
 #endif
 
+// Agent-scope accesses for data that crosses workgroups INSIDE one launch (group-aligned row pass, rows_ga_kernel.h /
+// rows_ga_tree.h): write-through store (visible to every XCD's L2) and an L1-bypassing load.  Both sides of a hand-off use
+// them (MI355X guide: "sc1 stores AND sc1 loads"); the flag / counter that orders the hand-off is stored after
+// `s_waitcnt vmcnt(0)`.
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool AGENT>
+__device__ __forceinline__ double ld_maybe_agent(const double* p) { return AGENT ? ld_agent(p) : *p; }
+
 // sum_{s in [s0, s1)} base[s * stride], in index order, with up to 8 loads in flight at a time
+// (AGENT: the records were written by other workgroups of THIS launch)
+template <bool AGENT = false>
 __device__ __forceinline__ double sum_strided(const double* base, int stride, int s0, int s1) {
   double acc = 0.0;
   for (int s = s0; s < s1; s += 8) {
     double v[8];
     // unconditional loads from a clamped index (a predicated load would sit in its own branch and serialise)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = base[(int64_t)min(s + u, s1 - 1) * stride];
+    for (int u = 0; u < 8; ++u) v[u] = ld_maybe_agent<AGENT>(base + (int64_t)min(s + u, s1 - 1) * stride);
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc += (s + u < s1) ? v[u] : 0.0;
   }

@@ -50,15 +50,6 @@ __device__ __forceinline__ void ga_def_local(const RowsDev& R, bool is_mu, doubl
   }
 }
 
-__device__ __forceinline__ void st_agent(double* p, double v) {   // write-through store (visible to every XCD's L2)
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_agent(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
-}
-
 // X tile at element offset `xoff` of Xt ([D][SPAN] doubles; its y bytes at xoff / D): lane l holds rows RPL*l .. RPL*l+RPL-1
 template <int D, int RPL>
 __device__ __forceinline__ void ga_load(const RowsDev& R, int64_t xoff, int lane, double (&x)[D][RPL], uint32_t& ybits) {

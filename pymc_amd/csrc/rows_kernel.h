@@ -84,7 +84,8 @@ __device__ __forceinline__ void rows_hyper(const RowsDev& R, const QView& qv, in
 // `part` / `stride` / `nblk` / `def_loc`: where the previous leaf left its partial sums and local parts (kernel B's records, or
 // the block partials of the group-aligned row pass).  Lane l returns, for hyper-parameter element e = l mod 2D
 // (mu[0..D), sigma[0..D)), this leaf's q' (`val`) and p_half (`ph`).
-template <int D>
+// AGENT: partials, local parts and the source state's q were written by other workgroups of THIS launch (rows_ga_tree.h).
+template <int D, bool AGENT = false>
 __device__ __forceinline__ void rows_hyper_fold_elem(const RowsDev& R, const double* part, int stride, int nblk, const double* def_loc,
                                                      const QView& qv, int lane, double& val, double& ph) {
   constexpr int NE = 2 * D;                 // mu[0..D), sigma[0..D)
@@ -95,9 +96,19 @@ __device__ __forceinline__ void rows_hyper_fold_elem(const RowsDev& R, const dou
   const int dd = is_mu ? e : e - D;
   const int i = (is_mu ? R.off_mu : R.off_sigma) + dd;
   const int slot = (is_mu ? R.def_mu : R.def_sigma) + dd;
-  const double2 l01 = reinterpret_cast<const double2*>(def_loc)[2 * slot];       // {gx local, dx/dq}
-  const double2 l23 = reinterpret_cast<const double2*>(def_loc)[2 * slot + 1];   // {dlog|J|/dq, p_half}
-  const double qi = qv.q[i], vi = qv.var[i];
+  double2 l01, l23;   // {gx local, dx/dq}, {dlog|J|/dq, p_half}
+  double qi;
+  if (AGENT) {
+    const double* dl = def_loc + 4 * slot;
+    l01 = make_double2(ld_agent(dl), ld_agent(dl + 1));
+    l23 = make_double2(ld_agent(dl + 2), ld_agent(dl + 3));
+    qi = ld_agent(qv.q + i);
+  } else {
+    l01 = reinterpret_cast<const double2*>(def_loc)[2 * slot];
+    l23 = reinterpret_cast<const double2*>(def_loc)[2 * slot + 1];
+    qi = qv.q[i];
+  }
+  const double vi = qv.var[i];
   const int per = (nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
   double cs[NS];
 #pragma unroll
@@ -105,7 +116,7 @@ __device__ __forceinline__ void rows_hyper_fold_elem(const RowsDev& R, const dou
     const int pair = (lane + WAVE * s) % NP;
     const int pe = pair % NE, c = pair / NE;
     const int k = pe < D ? PART_DMU + pe : PART_DSG + (pe - D);
-    cs[s] = sum_strided(part + k, stride, c * per, min(nblk, (c + 1) * per));
+    cs[s] = sum_strided<AGENT>(part + k, stride, c * per, min(nblk, (c + 1) * per));
   }
   double S = 0.0;
 #pragma unroll

@@ -339,3 +339,44 @@ def test_dense_mass_matrix_on_a_group_aligned_model_switches_the_row_pass(monkey
         point, st = step.step(point)
     assert np.isfinite(st[0]["energy"])
     step.close()
+
+
+STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth", "mean_tree_accept", "energy",
+             "energy_error", "max_energy_error", "model_logp", "step_size", "step_size_bar")
+
+
+def _run_schedule(spec, env, monkeypatch, tune, draws, seed):
+    from pymc_amd.sampling import sample
+
+    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA")
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, discard_tuned_samples=False)
+    step = res["step"]
+    info = (step._scalar("tree_kernel"), step._scalar("tree_launches"))
+    out = (np.array(res["draws"][0]), res["stats"][0], info)
+    step.close()
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
+    return out
+
+
+@pytest.mark.parametrize("which", ["c2s", "c2l"])
+def test_tree_kernel_is_a_pure_rescheduling(which, c2l, c2s, monkeypatch):
+    """The persistent tree kernel (csrc/rows_ga_tree.h: one launch per NUTS transition, leaf loop and doubling loop on the device,
+    counters instead of kernel boundaries) against one launch per leapfrog of the same row pass: positions and every statistic
+    BITWISE equal through tuning (trees of 1 .. 255 leaves, both directions, U-turns inside and at the end of doublings)."""
+    # (C2-S has ONE tile per group: the group-aligned pass is not what the engine would choose for it -- forced here, it runs the
+    # kernel with a wave that has no tiles at all)
+    spec, tune, draws = (c2s, 40, 20) if which == "c2s" else (c2l, 14, 6)
+    base = {"NUTS_GA_VARIANT": "32", "NUTS_ROWS_GA": "2"}
+    d0, s0, i0 = _run_schedule(spec, {**base, "NUTS_GA_TREE": "0"}, monkeypatch, tune, draws, 77)
+    d1, s1, i1 = _run_schedule(spec, {**base, "NUTS_GA_TREE": "1"}, monkeypatch, tune, draws, 77)
+    assert i0[0] == 0.0 and i1[0] == 1.0 and i1[1] == tune + draws, (i0, i1)
+    assert np.array_equal(d0, d1)
+    for a, b in zip(s0, s1):
+        for k in STAT_KEYS:
+            assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (k, a[k], b[k])
+    print(f"{which}: tree sizes {[int(s['tree_size']) for s in s1]}")
