@@ -140,6 +140,10 @@ int nuts_model_time_logp_grad(nuts_model *m, const double *q, int reps, double *
 /* Diagnostics: 64 shader-clock timestamps of the phases of the last O(n) / control launches (all zero unless
  * the library was built with -DNUTS_KTIMING). */
 int nuts_model_debug_ticks(nuts_model *m, int64_t *out /* [64] */);
+/* Diagnostics of the persistent tree kernel (csrc/rows_ga_tree.h): 8 timestamps (100 MHz) per workgroup of the leaf selected
+ * with NUTS_GA_TREE_DBG=<leaf + 1> at model creation: {top, beta ready (wave 0), stream end (wave 0), beta ready (wave 1),
+ * stream end (wave 1), tail end, hardware id, end of the leaf}.  `cap`: capacity of `out` in words (G * 8 are written). */
+int nuts_model_debug_tree(nuts_model *m, int64_t *out, int64_t cap);
 /* Algorithmic HBM bytes of one model pass (SURVEY.md section 8d B_model). */
 int64_t nuts_model_algorithmic_bytes(const nuts_model *m);
 /* Named properties of the compiled model (what `compile` decided, cf. pymc/pytensorf.py:924-1008):

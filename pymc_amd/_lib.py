@@ -180,6 +180,7 @@ SYMBOLS = {
     "nuts_model_time_logp_grad": (C.c_int, [_VP, _PD, C.c_int, _PD, _PD]),
     "nuts_model_algorithmic_bytes": (C.c_int64, [_VP]),
     "nuts_model_debug_ticks": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    "nuts_model_debug_tree": (C.c_int, [_VP, C.POINTER(C.c_int64), C.c_int64]),
     "nuts_model_get_scalar": (C.c_int, [_VP, C.c_char_p, _PD]),
     "nuts_chain_config_default": (None, [C.POINTER(ChainConfig)]),
     "nuts_chain_create": (_VP, [_VP, C.POINTER(ChainConfig)]),
@@ -239,13 +240,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PYMC_AMD_LIB", LIB_PATH)   # (another build of the same library: A/B measurements)
+    if not os.path.exists(path):
         raise EngineError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). pymc_amd has no CPU fallback."
         )
     _init_torch_runtime_first()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

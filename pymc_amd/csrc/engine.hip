@@ -85,6 +85,7 @@ struct nuts_model {
   int ga_par = 0;              // parity of the last group-aligned launch (its block partials / local parts are double-buffered)
   unsigned* ga_sync = nullptr; // progress words of the persistent tree kernel (rows_ga_tree.h)
   int ga_tree_ok = 0;          // the whole grid of k_tree_ga is resident at once on this device (checked at model creation)
+  long long* tree_dbg = nullptr; int tree_dbg_leaf = 0;   // NUTS_GA_TREE_DBG=<leaf + 1>: per-workgroup timeline of one leaf
   int64_t dom_units = 0;       // leapfrog passes covered by the timed launches (a tree launch covers a whole tree)
   int explicit_pre = 0;        // the position must be materialised before the dense pass (MvNormal node)
   int64_t alg_bytes = 0;
@@ -127,8 +128,11 @@ static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, in
 
 // kernel A of the pipeline: the pass over the model data (timed when profiling is on)
 // `fold` (lean path only, kernels.h): workgroup 0 of the row pass does the control work of leaf j-1
+struct CtlJob {   // control work riding in workgroup 0 of a group-aligned row pass (rows_ga_kernel.h, GaArgs)
+  EvalIO io; int j, d, seq; bool src_prev;
+};
 static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int fold = 0, int d = 0, double Emax = 0.0,
-                         int max_depth = 0, HostStatus* st = nullptr) {
+                         int max_depth = 0, HostStatus* st = nullptr, const CtlJob* job = nullptr) {
   ModelDev& md = m->md;
   if (!md.has_logit && !md.has_mvn) return;
   const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
@@ -137,7 +141,11 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
     const int par = (m->ga_par ^= 1);
     const dim3 grid(m->rows_grid + (fold ? 1 : 0)), block(WAVE * md.lg.ga_w);
-    GaArgs ga{md, A, io, j, rev, fold, par, d, max_depth, Emax, st};
+    GaArgs ga{md, A, io, j, rev, fold ? (GA_FOLD_CTL | GA_FOLD_SRC) : 0, par, d, max_depth, Emax, st, io, j - 1, d, 0, 0};
+    if (fold && job) {   // the control work of another doubling's last leaf
+      ga.fold = GA_FOLD_CTL | (job->src_prev ? GA_FOLD_SRC : 0);
+      ga.cio = job->io; ga.cj = job->j; ga.cd = job->d; ga.cseq = job->seq;
+    }
 #define GA_LAUNCH(DD, OO, PP) hipLaunchKernelGGL((k_rows_ga<DD, 2, OO, PP>), grid, block, 0, m->stream, ga)
 #define GA_BY_D(OO, PP)                      \
     switch (md.lg.D) {                       \
@@ -508,6 +516,11 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         if (lg.ga_part) hipMemset(lg.ga_part, 0, (size_t)lg.G * PART_STRIDE * sizeof(double));
         if (lg.ga_bpart) hipMemset(lg.ga_bpart, 0, 2 * (size_t)lg.ga_nblk * PART_STRIDE * sizeof(double));
         if (lg.ga_ticket) hipMemset(lg.ga_ticket, 0, lg.ga_nblk * sizeof(unsigned));
+        if (env_int("NUTS_GA_TREE_DBG", 0) > 0) {
+          m->tree_dbg_leaf = env_int("NUTS_GA_TREE_DBG", 0) - 1;
+          m->tree_dbg = m->keep(dev_alloc<long long>((size_t)lg.G * 8));
+          if (m->tree_dbg) hipMemset(m->tree_dbg, 0, (size_t)lg.G * 8 * sizeof(long long));
+        }
         m->ga_sync = m->keep(dev_alloc<unsigned>(GA_SYNC_WORDS));
         if (m->ga_sync) hipMemset(m->ga_sync, 0, GA_SYNC_WORDS * sizeof(unsigned));
         m->rows_grid = lg.G;
@@ -663,6 +676,14 @@ extern "C" int nuts_model_debug_ticks(nuts_model* m, int64_t* out) {
   return NUTS_OK;
 }
 
+extern "C" int nuts_model_debug_tree(nuts_model* m, int64_t* out, int64_t cap) {
+  if (!m || !out) return NUTS_E_ARG;
+  if (!m->tree_dbg) { g_err = "no per-workgroup timeline (create the model with NUTS_GA_TREE_DBG=<leaf + 1>)"; return NUTS_E_ARG; }
+  HIPCHK(hipStreamSynchronize(m->stream));
+  const int64_t nwords = std::min<int64_t>(cap, (int64_t)m->md.lg.G * 8);
+  HIPCHK(hipMemcpy(out, m->tree_dbg, (size_t)nwords * sizeof(long long), hipMemcpyDeviceToHost));
+  return NUTS_OK;
+}
 extern "C" int32_t nuts_model_ndim(const nuts_model* m) { return m ? m->md.n : -1; }
 extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, double* out) {
   if (!m || !name || !out) return NUTS_E_ARG;
@@ -815,8 +836,11 @@ struct nuts_chain {
   int fold_ctl = 1;              // lean path: overlap the control work of leaf j with the row pass of leaf j+1
   int tree_mode = 0;             // group-aligned row pass: one persistent launch per NUTS tree (rows_ga_tree.h)
   int64_t tree_launches = 0;
+  CtlJob pend{}; bool pend_valid = false;   // control work of a doubling's last leaf waiting for the next doubling's first row pass
+  bool defer_last_ctl = false; int xfold = 1;   // NUTS_XFOLD: fold control work across doublings (group-aligned row pass)
+  int tree_opts = 0;             // GA_TREE_* switches (NUTS_GA_TREE_OPTS, NUTS_GA_TREE_TICKS)
   int tree_prof_pending = 0;     // the last tree launch is being timed: its leaf count is added when the draw's record arrives
-  int spec_max = 3, last_depth = 0;   // look-ahead over the short doublings (nuts_chain_draw)
+  int spec_max = 10, last_depth = 0;   // look-ahead over the doublings, as deep as the previous tree went (run_tree)
   int logs_done = 0, logs_total = 0;  // logarithms of the pre-drawn uniforms taken / needed at most this draw
   // staging of nuts_chain_draw_many (grown on demand)
   double* many_in_host = nullptr; double* many_in_dev = nullptr; char* many_out_host = nullptr; char* many_out_dev = nullptr;
@@ -904,6 +928,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   A.ga_ticket = m->md.lg.ga ? m->md.lg.ga_ticket : nullptr; A.ga_nticket = m->md.lg.ga ? m->md.lg.ga_nblk : 0;
   A.ga_sync = m->md.lg.ga ? m->ga_sync : nullptr;
   // NUTS_GA_TREE=0: one launch per leapfrog (also what several chains SHARING a GPU must use: the tree kernel needs the chip)
+  c->tree_opts = env_int("NUTS_GA_TREE_OPTS", 0) | (env_int("NUTS_GA_TREE_TICKS", 0) << GA_TREE_TICK_SHIFT);
   c->tree_mode = m->md.lg.ga && m->ga_tree_ok && !c->dense && m->md.lean_ok && env_int("NUTS_GA_TREE", 1) != 0;
   if (c->dense) {
     c->dense_C = c->keep(dev_upload(cfg->dense_cov, (size_t)n * n));
@@ -915,7 +940,8 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
   c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n + 2));
   c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0;
-  c->spec_max = env_int("NUTS_SPEC_MAX", 3);
+  c->spec_max = env_int("NUTS_SPEC_MAX", 10);
+  c->xfold = env_int("NUTS_XFOLD", 1);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
              cfg->potential != NUTS_POT_FULL;
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
@@ -1139,13 +1165,28 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
     // folded control (kernels.h): the control work of leaf j-1 rides in workgroup 0 of this leaf's row pass; only the
     // last leaf of the doubling (of the fixed-length trajectory) -- whose result the host waits for -- gets a control
     // launch of its own
-    launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
+    // Group-aligned row pass: the control work of a doubling's LAST leaf can ride in the first row pass of the next doubling
+    // when that doubling is queued by the look-ahead right behind it (run_tree sets `defer_last_ctl`): one launch less per
+    // doubling between two row passes.
+    const bool ga_tree_leaf = m->md.lg.ga && mode == MODE_TREE;
+    CtlJob* job = nullptr;
+    if (ga_tree_leaf && j == 0 && c->pend_valid) {
+      c->pend.src_prev = c->pend.io.dir == io.dir;   // growing on the same side: this leaf starts from the leaf just finished
+      job = &c->pend;
+    }
+    launch_dense(m, A, io, j, (j > 0 || job) ? 1 : 0, d, c->cfg.Emax, max_depth, st, job);
+    if (job) c->pend_valid = false;
     launch_vector(m, A, io, j, d);
-    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
+    if (last) {
+      if (ga_tree_leaf && c->defer_last_ctl) { c->pend = CtlJob{io, j, d, seq, false}; c->pend_valid = true; }
+      else hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
+    }
     c->leapfrogs++;
     return;
   }
-  launch_dense(m, A, io, j);
+  // (the group-aligned row pass finishes the leaf's z elements itself -- merges included -- so it needs `d` also when no
+  // control work rides in it)
+  launch_dense(m, A, io, j, 0, d, c->cfg.Emax, max_depth, st);
   launch_vector(m, A, io, j, d);
   if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
   else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
@@ -1183,6 +1224,8 @@ static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, 
   ga.Emax = c->cfg.Emax; ga.eps_abs = step_size;
   ga.st = c->st_dev;
   ga.timeout = (long long)env_int("NUTS_GA_TREE_TIMEOUT_MS", 50) * 100000ll;   // 100 MHz ticks
+  ga.opts = c->tree_opts;
+  ga.dbg = m->tree_dbg; ga.dbg_leaf = m->tree_dbg_leaf;
   const bool prof = m->profile && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
   hipLaunchKernelGGL(k_tree_ga<3>, dim3(m->rows_grid + 1), dim3(WAVE * m->md.lg.ga_w), 0, m->stream, ga);
@@ -1223,12 +1266,26 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
     r.eps = dir > 0 ? step_size : -step_size;
     return r;
   };
+  const int spec = std::min(c->spec_max, c->last_depth - 1);
   auto enqueue_doubling = [&](const Geometry& g, int d) {
     const int nleaf = 1 << d;
     ensure_logs(c, (2 << d) + d + 1);   // this doubling reads uniform indices < 2^(d+1) + d + 1
     const int seq = ++c->seq;
+    // will doubling d + 1 be queued (look-ahead) before the status of this one is waited for?  Then its first row pass takes
+    // this doubling's last control work with it.
+    c->defer_last_ctl = c->xfold && c->fold_ctl && d + 1 < max_depth && d + 1 <= spec;
     for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, g, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
+    c->defer_last_ctl = false;
     return seq;
+  };
+  c->pend_valid = false;   // (a look-ahead doubling behind the end of the previous tree may have left its control work unclaimed: it
+                           // would only have drained)
+  auto flush_pending = [&](int seq_waited) {   // (not pending by construction: never wait on a status nobody will publish)
+    if (!c->pend_valid || c->pend.seq != seq_waited) return;
+    const CtlJob& p = c->pend;
+    hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, c->m->stream, c->m->md, c->A, p.io, p.j, p.d, c->cfg.Emax, max_depth,
+                       c->st_dev, p.seq, c->m->ga_par);
+    c->pend_valid = false;
   };
   // Look-ahead for the short doublings, where the host round trip (status word over PCIe, then the first launch of
   // the next doubling) is comparable to the doubling itself: a doubling that runs to completion consumes a fixed
@@ -1236,7 +1293,6 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
   // d+1 is uniforms[2^(d+1) + d] whenever it is needed at all, and its launches can be queued before the status of
   // doubling d arrives.  If the tree stops at d they drain as no-ops behind the `aborted` flag.  Only done as far as
   // the previous draw's tree went, so a wasted look-ahead is rare.  The prediction is checked against the device.
-  const int spec = std::min(c->spec_max, c->last_depth - 1);
   Geometry ahead{};
   int ahead_seq = 0;
   int seq = enqueue_doubling(gm, 0);
@@ -1246,6 +1302,7 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
       ahead = next_geometry(gm, d, uniforms[(2 << d) + d] < 0.5 ? 1 : -1);
       ahead_seq = enqueue_doubling(ahead, d + 1);
     } else ahead_seq = 0;
+    flush_pending(seq);
     const auto tw0 = clk::now();
     rc = wait_status(c, seq, &flags);
     c->t_wait += std::chrono::duration<double>(clk::now() - tw0).count();
@@ -1264,6 +1321,7 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
     }
   }
   c->last_depth = depth_done;
+  c->pend_valid = false;
   *flags_out = flags;
   *exhausted_out = exhausted;
   return NUTS_OK;

@@ -146,7 +146,17 @@ struct GaArgs {
   int j, rev, fold, par, d, max_depth;
   double Emax;
   HostStatus* st;
+  // `fold` bit 0: workgroup 0 does control work -- of leaf (cio, cj, cd), publishing sequence number cseq when it is the last
+  // leaf of a doubling.  Inside a doubling that is leaf j - 1 of the same doubling; the FIRST leaf of a doubling queued by the
+  // host's look-ahead carries the control work of the previous doubling's last leaf (which would otherwise be a launch of its
+  // own, 10-35 us between two row passes).  `fold` bit 1: the source state of this leaf is the leaf of the previous launch, so
+  // mu' / sigma' come from that launch's block partials (always so inside a doubling; across doublings only when the tree keeps
+  // growing on the same side -- otherwise the source is an older edge state whose entries are complete in the arena).
+  EvalIO cio;
+  int cj, cd, cseq, cpad;
 };
+#define GA_FOLD_CTL 1
+#define GA_FOLD_SRC 2
 
 template <int D, int RPL, int OCC, int PIPE>
 __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
@@ -159,8 +169,8 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   HostStatus* const st = a.st;
   const RowsDev& R = md.lg;
   int b = (int)blockIdx.x;
-  if (fold) {   // workgroup 0: the control work of the previous leaf, from the previous launch's block partials
-    if (b == 0) { control_lean(md, A, io, j - 1, d, Emax, max_depth, st, 0, lean_src(md, par ^ 1)); return; }
+  if (fold & GA_FOLD_CTL) {   // workgroup 0: control work, from the previous launch's block partials
+    if (b == 0) { control_lean(md, A, a.cio, a.cj, a.cd, Emax, max_depth, st, a.cseq, lean_src(md, par ^ 1)); return; }
     --b;
   }
   const int g = b;
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
 
   // ---- prologue: mu', sigma' of this leaf (every wave), z' of this group ----
   double hval0, hph0;   // lane l: q' and p_half of hyper-parameter element l mod 2D
-  if (fold) {
+  if (fold & GA_FOLD_SRC) {
     const LeanSrc prev = lean_src(md, par ^ 1);
     rows_hyper_fold_elem<D>(R, prev.part, prev.stride, prev.nblk, prev.def_loc, qv, lane, hval0, hph0);
   } else {

@@ -40,11 +40,20 @@
 
 struct GaTreeArgs {
   ModelDev md; ArenaDev A;
-  int max_depth, spec_depth, rev0, par0, first_dir, seq, alternate, pad;
+  int max_depth, spec_depth, rev0, par0, first_dir, seq, alternate;
+  int opts;            // GA_TREE_* experiment / diagnostic switches (0 in production)
   double Emax, eps_abs;
   HostStatus* st;
   long long timeout;   // ticks of the constant 100 MHz clock one wait may last
+  long long* dbg;      // diagnostics (NUTS_GA_TREE_DBG): [G][8] per-workgroup timestamps of ONE leaf, or nullptr
+  int dbg_leaf, dbg_pad;
 };
+
+#define GA_TREE_EARLY0 1      // wave 0 also requests its first tiles before it polls (they are in flight during its prologue)
+#define GA_TREE_REVMAP 2
+#define GA_TREE_PHASE_G 4     // experiment: odd groups stream their halves in the opposite order (half the waves hit the
+#define GA_TREE_PHASE_W 8     // Infinity Cache while the other half miss) / odd waves do
+#define GA_TREE_TICK_SHIFT 8  // opts >> 8 = 1 + first leaf whose phase timestamps go to md.ticks (8 leaves x 8 stamps, workgroup G / 2)
 
 __device__ __forceinline__ long long ga_clock() { return (long long)wall_clock64(); }
 
@@ -288,7 +297,9 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
   __shared__ double s_keep[5][WAVE];             // wave 0's per-lane prologue values the tail needs again
   __shared__ __attribute__((aligned(16))) char s_args[(sizeof(GaTreeArgs) + 15) / 16 * 16];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(tid >> 6), W = (int)blockDim.x >> 6;
-  const int g = (int)blockIdx.x - 1;
+  // (GA_TREE_REVMAP, diagnostics: workgroup b streams group G - b instead of b - 1 -- does a slow workgroup follow its place in
+  // the dispatch order or the address of its rows?)
+  const int g = (a.opts & GA_TREE_REVMAP) ? a.md.lg.G - (int)blockIdx.x : (int)blockIdx.x - 1;
   // the tail reads the arguments from an LDS copy of the kernarg segment (rows_ga_kernel.h: nothing it needs has to stay in
   // scalar registers across the streaming loop)
   {
@@ -317,8 +328,18 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
   const int nm1 = max(n - 1, 0);
   const uint32_t voff16 = (uint32_t)lane * 16u, voff2 = (uint32_t)lane * 2u;
   const int max_depth = a.max_depth, spec_depth = a.spec_depth, par0 = a.par0, alternate = a.alternate;
+  const int early0 = a.opts & GA_TREE_EARLY0;
+  const int tick0 = (a.opts >> GA_TREE_TICK_SHIFT) - 1;   // < 0: no timestamps
+  const bool ticker = tick0 >= 0 && g == R.G / 2 && tid == 0;
+#define GA_TICK(K) do { if (ticker && L >= tick0 && L < tick0 + 8) a.md.ticks[(L - tick0) * 8 + (K)] = ga_clock(); } while (0)
+  // per-workgroup timeline of leaf `dbg_leaf`: {top, beta ready w0, stream end w0, beta ready w1, stream end w1, tail end, hw id, leaf end}
+  long long* const dbg = a.dbg;
+  const int dbg_leaf = a.dbg_leaf;
+#define GA_DBG(K, COND) do { if (dbg && L == dbg_leaf && lane == 0 && (COND)) dbg[(int64_t)g * 8 + (K)] = ga_clock(); } while (0)
   int dir = a.first_dir, edge = 0, left = 0, right = 0;
   int rev = alternate ? (a.rev0 ^ 1) : 0;
+  if (a.opts & GA_TREE_PHASE_G) rev ^= g & 1;
+  if (a.opts & GA_TREE_PHASE_W) rev ^= w & 1;
   int L = 0;
   bool src_prev = false;   // the source state of the leaf is the previous leaf of this launch
   for (int d = 0; d < max_depth; ++d) {
@@ -336,10 +357,14 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
       Leaf lf; QView qv;
       resolve_leaf(io, A, j, lf, qv);
       GaTileRegs ta, tb;
-      if (w != 0) {
+      GA_TICK(0);
+      GA_DBG(0, w == 0);
+      if (w != 0 || early0) {
         // X does not depend on the state: the first two tiles are requested before the wait for the other groups
         issue(0, ta);
         issue(1, tb);
+      }
+      if (w != 0) {
         if (lane == 0) {
 #pragma unroll
           for (int dd = 0; dd <= D; ++dd) { s_acc[w][0][dd] = 0.0; s_acc[w][1][dd] = 0.0; }
@@ -351,6 +376,7 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
         if (L > 0) r = ga_wait(A.ga_sync, (unsigned)L * (unsigned)R.ga_nblk, (unsigned)max(L - 1, 0), &A.ctl->aborted, a.timeout);
         else r = __hip_atomic_load(&A.ctl->aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
         if (r == 2) ga_fail(A, 1u);
+        GA_TICK(1);
         if (lane == 0) {
           s_flag[0] = r;
 #pragma unroll
@@ -372,8 +398,11 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
           if (lane < 2 * D) { s_hyp[0][lane] = hval0; s_hyp[1][lane] = hph0; }
         }
         __syncthreads();   // (B)
-        issue(0, ta);
-        issue(1, tb);
+        GA_TICK(2);
+        if (!early0) {
+          issue(0, ta);
+          issue(1, tb);
+        }
       }
       if (s_flag[0]) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
       // ---- z' of this group -> beta (every wave) ----
@@ -394,6 +423,8 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
           s_keep[2][lane] = zq; s_keep[3][lane] = zph; s_keep[4][lane] = s_lane;
         }
       }
+      GA_TICK(3);
+      GA_DBG(1, w == 0); GA_DBG(3, w == 1);
       // ---- the stream: two tiles in flight per wave, hand-counted (rows_ga_kernel.h); the requests past the end re-read the
       // wave's last tile (an L2 hit) so that every stage has exactly 9 younger loads behind the tile it waits for ----
       {
@@ -434,18 +465,27 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
       }
       // ---- back half: wave 0 finishes the group's z elements and publishes the group's record; the block's last arriver sums
       // the block and moves the progress counter ----
+      GA_TICK(4);
+      GA_DBG(2, w == 0); GA_DBG(4, w == 1);
       const GaTreeArgs& Targs = *reinterpret_cast<const GaTreeArgs*>(s_args);
       if (w == 0) {
         // the operands of the first merge levels belong to earlier leaves: requested before the wait for the other waves
         MergePrefetch mpf;
         merge_prefetch(Targs.A, lf, j, Targs.md.lg.off_z + g * D + lane % D, mpf);
         __syncthreads();   // (A) the wave partials are in LDS
+        GA_TICK(5);
         ga_tree_tail<D>(Targs, io, g, j, d, par, mpf, s_acc, s_red, s_info, s_keep);
+        GA_TICK(6);
+        GA_DBG(5, true);
+        if (dbg && L == dbg_leaf && lane == 0)
+          dbg[(int64_t)g * 8 + 6] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
       } else {
         __syncthreads();   // (A)
       }
       __syncthreads();     // (C) wave 0 has taken the ticket
       if (s_info[0]) ga_tree_block_reduce<D>(Targs, g, par, s_cp, s_info);
+      GA_TICK(7);
+      GA_DBG(7, w == 0);
       if (alternate) rev ^= 1;
       src_prev = true;
     }
@@ -467,4 +507,6 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
     dir = ndir;
     edge = dir > 0 ? right : left;
   }
+#undef GA_TICK
+#undef GA_DBG
 }

@@ -39,10 +39,71 @@ __device__ __forceinline__ void rows_flush(double (&acc)[D], double* __restrict_
 
 // log-likelihood and residual of one row given eta:  lp = y eta - softplus(eta),  r = y - sigmoid(eta)
 // (PyTensor's stabilised forms: log(sigmoid(x)) = -softplus(-x), log1p(-sigmoid(x)) = -softplus(x))
+//
+// The row pass is bound by these few lines, not by HBM: with the library's exp / log1p / division a tile of 128 rows costs 680
+// vector instructions per wave (two thirds of them fp64 or the moves that feed `v_fmac`), 1.2 us of a SIMD, and a SIMD holding
+// three waves of 16 tiles is busy for the whole 55 us of the pass (per-workgroup timeline, tools/tree_wg_timeline.py: the
+// workgroups dispatched first finish their stream after 23 us, the last after 55 us).  All three functions are needed only on
+// a narrow domain here -- e = exp(-|eta|) in (0, 1], 1 + e and 2 + e in (1, 3] -- so they are written out for that domain:
+//   exp(x), x <= 0     k = rint(x log2 e), r = x - k ln 2 (two-part), Taylor to r^13 (|r| <= 0.347: 4e-18), v_ldexp_f64
+//   1 / t, t in (1,3]  v_rcp_f64 seed + two Newton steps (no scaling needed in this range)
+//   log1p(e)           = 2 atanh(s), s = e / (2 + e) <= 1/3: 2 s + 2 s z P(z), z = s^2, P of degree 9 (fit on [0, 1/9], 7e-18)
+// 73 fp64 operations per row instead of ~190 + 150 moves; every one of them within about an ulp of the library's result
+// (scratch emulation without fma: 1 / 3 / 4 ulp), far inside the 1e-9 the log-density is held to against the oracle.
+// -DNUTS_LOGIT_LIBM restores the library forms (A/B measurements).
+__device__ __forceinline__ double rcp_nr(double x) {   // 1 / x for x in [1, 4]
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+
 __device__ __forceinline__ void logit_row(double eta, double yk, double& lp, double& r) {
+#ifdef NUTS_LOGIT_LIBM
   const double e = exp(-fabs(eta));
   const double l1p = log1p(e);
   const double inv = 1.0 / (1.0 + e);
+#else
+  // e = exp(-|eta|); beyond 750 the result is 0 either way (the clamp keeps k and r finite; a NaN eta still reaches lp below)
+  const double x = -fmin(fabs(eta), 750.0);
+  const double kd = __builtin_rint(x * 1.4426950408889634);
+  double rr = fma(kd, -6.93147180369123816490e-01, x);
+  rr = fma(kd, -1.90821492927058770002e-10, rr);
+  double q = 1.6059043836821613e-10;                 // 1/13!
+  q = fma(q, rr, 2.08767569878681e-09);              // 1/12!
+  q = fma(q, rr, 2.505210838544172e-08);             // 1/11!
+  q = fma(q, rr, 2.755731922398589e-07);             // 1/10!
+  q = fma(q, rr, 2.7557319223985893e-06);            // 1/9!
+  q = fma(q, rr, 2.48015873015873e-05);              // 1/8!
+  q = fma(q, rr, 0.0001984126984126984);             // 1/7!
+  q = fma(q, rr, 0.001388888888888889);              // 1/6!
+  q = fma(q, rr, 0.008333333333333333);              // 1/5!
+  q = fma(q, rr, 0.041666666666666664);              // 1/4!
+  q = fma(q, rr, 0.16666666666666666);               // 1/3!
+  q = fma(q, rr, 0.5);
+  const double p = fma(rr * rr, q, rr) + 1.0;
+  const double e = __builtin_amdgcn_ldexp(p, (int)kd);
+  const double inv = rcp_nr(1.0 + e);
+  // log1p(e) = 2 atanh(e / (2 + e))
+  const double u = 2.0 + e;
+  const double ru = rcp_nr(u);
+  double s = e * ru;
+  s = fma(fma(-s, u, e), ru, s);
+  const double z = s * s;
+  double P = 0.08082469084735669;
+  P = fma(P, z, 0.04400158825434387);
+  P = fma(P, z, 0.06000577591428889);
+  P = fma(P, z, 0.06657067775440581);
+  P = fma(P, z, 0.07692785296456121);
+  P = fma(P, z, 0.09090894708663223);
+  P = fma(P, z, 0.11111111358900891);
+  P = fma(P, z, 0.1428571428355253);
+  P = fma(P, z, 0.20000000000007298);
+  P = fma(P, z, 0.3333333333333333);
+  const double s2 = s + s;
+  const double l1p = fma(s2 * z, P, s2);
+#endif
   const double sgm = eta >= 0 ? inv : e * inv;
   const double spl = (eta > 0 ? eta : 0.0) + l1p;
   lp = yk * eta - spl;

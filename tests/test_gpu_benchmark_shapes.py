@@ -348,7 +348,7 @@ STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_
 def _run_schedule(spec, env, monkeypatch, tune, draws, seed):
     from pymc_amd.sampling import sample
 
-    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA")
+    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL")
     for k in keys:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -380,3 +380,21 @@ def test_tree_kernel_is_a_pure_rescheduling(which, c2l, c2s, monkeypatch):
         for k in STAT_KEYS:
             assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (k, a[k], b[k])
     print(f"{which}: tree sizes {[int(s['tree_size']) for s in s1]}")
+
+
+def test_cross_doubling_fold_is_a_pure_rescheduling(c2l, monkeypatch):
+    """Group-aligned row pass, one launch per leapfrog: the control work of a doubling's last leaf rides in the first row pass of
+    the next doubling when the host's look-ahead has queued it (engine.hip, run_tree / GaArgs.cio) instead of being a launch of
+    its own.  Same arithmetic, different launches: bitwise equal draws and statistics, also with the look-ahead extended over
+    every doubling and with the folded control switched off altogether."""
+    envs = ({"NUTS_XFOLD": "0"}, {"NUTS_XFOLD": "1"}, {"NUTS_XFOLD": "1", "NUTS_SPEC_MAX": "10"}, {"NUTS_XFOLD": "0", "NUTS_SPEC_MAX": "10"},
+            {"NUTS_FOLD_CTL": "0"})
+    runs = [_run_schedule(c2l, env, monkeypatch, 14, 6, 78) for env in envs]
+    d0, s0, _ = runs[0]
+    for env, (d1, s1, _) in zip(envs[1:], runs[1:]):
+        first = next((i for i in range(len(d0)) if not np.array_equal(d0[i], d1[i])), None)
+        assert first is None, (env, first, [int(s["tree_size"]) for s in s0], [int(s["tree_size"]) for s in s1])
+        for a, b in zip(s0, s1):
+            for k in STAT_KEYS:
+                assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (env, k, a[k], b[k])
+    print(f"tree sizes {[int(s['tree_size']) for s in s0]}")
