@@ -21,11 +21,14 @@ which).  `convergence` carries max R-hat, min / median ESS and WHICH parameter h
 the minimum, so a small min-ESS can be traced to the coordinate that does not mix.
 
 roofline: dominant kernel = the hierarchical-logit row pass (csrc/rows_kernel.h /
-rows_ga_kernel.h); algorithmic bytes per launch = 69 B/row x N (SURVEY.md 8d
-B_model: X row + y + int32 group id), divided by the kernel's average duration
-measured with HIP events on the library stream during the timed region (1 launch in
-8 is bracketed by events; launches that drain after the tree terminated are
-included, exactly as in the rocprofv3 summary under profiles/).  4 of the 69 bytes
+rows_ga_kernel.h; with NUTS_GA_VARIANT=32 the persistent tree kernel of
+rows_ga_tree.h, which runs a whole NUTS tree per launch); algorithmic bytes per pass
+= 69 B/row x N (SURVEY.md 8d B_model: X row + y + int32 group id), divided by the
+average duration of one pass measured with HIP events on the library stream during
+the timed region (1 launch in 8 is bracketed by events; launches that drain after
+the tree terminated are included, exactly as in the rocprofv3 summary under
+profiles/; a tree launch is bracketed whole and its duration divided by the leaves
+the tree ran).  4 of the 69 bytes
 are bytes the kernel AVOIDS (group structure is read as G+1 row pointers), so
 `frac_traffic` = PMC bytes / duration / peak is reported next to `frac`.
 `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of
@@ -347,6 +350,10 @@ def main():
                 "parallelism": f"{world} independent chain(s), one per GPU, no data-path collective",
                 "sampler": "NUTS target_accept=0.8 max_treedepth=10 init=jitter+adapt_diag",
             },
+            "schedule": ("persistent tree kernel: one launch per NUTS tree (csrc/rows_ga_tree.h)" if step._scalar("tree_kernel") else
+                         "group-aligned row pass: one launch per leapfrog, control work folded into the next row pass, also across doublings "
+                         "(csrc/rows_ga_kernel.h)" if (not c3 and step._logp_dlogp_func.model_scalar("rows_group_aligned")) else
+                         "three launches per leapfrog (csrc/kernels.h)"),
             "leapfrog_steps_per_sec": lps_total,
             "leapfrog_steps_per_sec_per_chain": [float(x) for x in (allv[:, 2] / allv[:, 0])],
             "ess_per_sec": (ess_total / T) if ess_ok else None,
@@ -365,7 +372,7 @@ def main():
                 "algorithmic_bytes_note": None if c3 else "69 B/row = 64 (X) + 1 (y) + 4 (int32 group id); the kernel reads G+1 row pointers instead of the "
                 "group ids, so 4 of the 69 are bytes it avoids -- frac_traffic prices the bytes actually moved",
                 "avg_launch_ms": dom_avg_ms,
-                "launches_timed": int(allv[:, 4].sum()),
+                "launches_timed": int(allv[:, 4].sum()),   # (passes over the data covered by the bracketed launches)
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "traffic_build_matches": traffic_match,

@@ -149,7 +149,8 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
 #define GA_LAUNCH(DD, OO, PP) hipLaunchKernelGGL((k_rows_ga<DD, 2, OO, PP>), grid, block, 0, m->stream, ga)
 #define GA_BY_D(OO, PP)                      \
     switch (md.lg.D) {                       \
-      case 8: GA_LAUNCH(8, OO, PP); break;   \
+      case 8: if (md.lg.ga_dx == 7) hipLaunchKernelGGL((k_rows_ga<8, 2, OO, PP, 7>), grid, block, 0, m->stream, ga); \
+              else GA_LAUNCH(8, OO, PP); break;   \
       case 4: GA_LAUNCH(4, OO, PP); break;   \
       default: GA_LAUNCH(2, OO, PP); break;  \
     }
@@ -474,7 +475,17 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         // chunk (g, w) = the tiles wave w of workgroup g streams, [w T_g / W, (w + 1) T_g / W) -- the split the kernel makes.  Chunks
         // are placed one after the other with `GA_SKEW` doubles (8448 B = 33 x 256 B) between them, so consecutive chunk starts
         // differ by an ODD multiple of 256 B modulo any power-of-two channel interleave.
-        const int64_t TS = (int64_t)D * SPAN, GA_SKEW = env_int("NUTS_GA_SKEW", 1056);
+        // An intercept column (x_{i,0} = 1 for every row, SURVEY 8d's C2) carries no information: it is not stored, the tiles
+        // are [D - 1][SPAN] and the kernel multiplies by the literal 1.0 (rows_ga_kernel.h, GaTileRegs7) -- 57 B per row
+        // instead of 65 on a pass that is bound by the bytes it moves.  NUTS_GA_ONES0=0 keeps the column (A/B, tests).
+        bool ones0 = D == 8 && env_int("NUTS_GA_ONES0", 1) != 0 && lg.N > 0;
+        for (int64_t i = 0; ones0 && i < lg.N; ++i) ones0 = s->rows_X[i * D] == 1.0;
+        const int DX = ones0 ? D - 1 : D;
+        lg.ga_dx = DX;
+        // (the skew between chunks is an ODD multiple of 256 B and a multiple of the tile's column count, so that the y bytes
+        // of a tile sit at its element offset / DX)
+        const int64_t TS = (int64_t)DX * SPAN, GA_SKEW = env_int("NUTS_GA_SKEW", DX == 7 ? 1120 : 1056);
+        if (GA_SKEW % DX != 0) { g_err = "NUTS_GA_SKEW must be a multiple of the stored column count"; nuts_model_destroy(m); return nullptr; }
         std::vector<int64_t> coff((size_t)lg.G * W, 0);
         int64_t pos = 0, max_ct = 0;
         for (int g = 0; g < lg.G; ++g) {
@@ -493,7 +504,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         lg.Npad = n_tiles * SPAN; lg.n_spans = n_tiles;
         // (one tile of slack at the end: a wave without tiles still issues its unconditional first request)
         std::vector<double> xt((size_t)(pos + TS), 0.0);
-        yy.assign((size_t)(pos / D + 2 * SPAN), 0);
+        yy.assign((size_t)(pos / DX + 2 * SPAN), 0);
         for (int g = 0; g < lg.G; ++g) {
           const int64_t T = tile0[g + 1] - tile0[g];
           for (int64_t i = gptr[g]; i < gptr[g + 1]; ++i) {
@@ -502,8 +513,8 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
             while (w > 0 && (int64_t)w * T / W > t) --w;
             while (w + 1 < W && (int64_t)(w + 1) * T / W <= t) ++w;
             const int64_t base = coff[(size_t)g * W + w] + (t - (int64_t)w * T / W) * TS;
-            for (int d = 0; d < D; ++d) xt[(size_t)(base + (int64_t)d * SPAN + rr)] = s->rows_X[i * D + d];
-            yy[(size_t)(base / D + rr)] = s->rows_y[i];
+            for (int d = D - DX; d < D; ++d) xt[(size_t)(base + (int64_t)(d - (D - DX)) * SPAN + rr)] = s->rows_X[i * D + d];
+            yy[(size_t)(base / DX + rr)] = s->rows_y[i];
           }
         }
         lg.Xt = m->keep(dev_upload(xt.data(), xt.size()));
@@ -531,7 +542,8 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         // (only at the 168-register budget, variant 32: at 128 registers the allocator spills inside the streaming loop)
         if (D == 8 && m->ga_variant == 32 && env_int("NUTS_GA_TREE", 1) != 0) {
           int per_cu = 0;
-          const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3>, WAVE * W, 0);
+          const hipError_t e = lg.ga_dx == 7 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3, 7>, WAVE * W, 0)
+                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3, 8>, WAVE * W, 0);
           if (e == hipSuccess) {
             const int hw = std::min(per_cu, (4 * occ) / std::max(W, 1));   // `occ` waves per SIMD at this register budget
             m->ga_tree_ok = (int64_t)hw * cus >= (int64_t)lg.G + 1;
@@ -692,6 +704,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
   else if (k == "lean") *out = m->md.lean_ok;
   else if (k == "tree_kernel_ok") *out = m->ga_tree_ok;
+  else if (k == "rows_stored_columns") *out = m->md.lg.ga ? m->md.lg.ga_dx : m->md.lg.D;
   else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
@@ -1228,7 +1241,8 @@ static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, 
   ga.dbg = m->tree_dbg; ga.dbg_leaf = m->tree_dbg_leaf;
   const bool prof = m->profile && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
-  hipLaunchKernelGGL(k_tree_ga<3>, dim3(m->rows_grid + 1), dim3(WAVE * m->md.lg.ga_w), 0, m->stream, ga);
+  if (m->md.lg.ga_dx == 7) hipLaunchKernelGGL((k_tree_ga<3, 7>), dim3(m->rows_grid + 1), dim3(WAVE * m->md.lg.ga_w), 0, m->stream, ga);
+  else hipLaunchKernelGGL((k_tree_ga<3, 8>), dim3(m->rows_grid + 1), dim3(WAVE * m->md.lg.ga_w), 0, m->stream, ga);
   if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; c->tree_prof_pending = 1; }
   m->dom_launches++;
   c->tree_launches++;

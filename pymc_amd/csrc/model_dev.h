@@ -84,6 +84,7 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   // span tables above are not built, and there is no O(n) kernel between two row passes: the workgroup that streamed a
   // group holds that group's complete d logp / d beta and finishes its D z elements itself.
   int32_t ga, ga_w;              // active; waves per workgroup
+  int32_t ga_dx, ga_dx_pad;      // stored columns per tile: D, or D - 1 when column 0 of X is identically 1 (not stored)
   int32_t ga_nblk, ga_bsz;       // second-level reduction: blocks of ga_bsz consecutive groups (ga_bsz <= 64)
   int32_t ga_T_uni, ga_flags;    // > 0: every group has this many tiles (and ga_ng_uni rows): geometry without table look-ups
   int64_t ga_ng_uni;

@@ -104,6 +104,49 @@ __device__ __forceinline__ void ga_wait8(GaTileRegs& t) {   // at most N loads m
                : "i"(N));
 }
 
+// ---- the same with SEVEN stored columns: column 0 of X is identically 1 (the intercept) and is not stored ----
+// Detected when the model is built (engine.hip): the tiles are [7][SPAN], 7 KiB instead of 8, and the kernel multiplies by the
+// literal 1.0 -- fma(1, beta_0, 0) and fma(r, 1, acc) are what the stored column would have produced, bit for bit.  The row
+// pass moves 57 B per row instead of 65 (the ALGORITHMIC figure of SURVEY 8d stays 69: bench.py prices both).
+struct GaTileRegs7 { ga_v2d c[7]; uint32_t y; };
+
+__device__ __forceinline__ void ga_issue8(const double* base, const int8_t* ybase, uint32_t voff16, uint32_t voff2, GaTileRegs7& t) {
+  const double* base2 = base + 512;   // stored columns 4 .. 6
+  asm volatile(
+      "s_nop 4\n\t"
+      "global_load_dwordx4 %0, %8, %9\n\t"
+      "global_load_dwordx4 %1, %8, %9 offset:1024\n\t"
+      "global_load_dwordx4 %2, %8, %9 offset:2048\n\t"
+      "global_load_dwordx4 %3, %8, %9 offset:3072\n\t"
+      "global_load_dwordx4 %4, %8, %10\n\t"
+      "global_load_dwordx4 %5, %8, %10 offset:1024\n\t"
+      "global_load_dwordx4 %6, %8, %10 offset:2048\n\t"
+      "global_load_ushort %7, %11, %12"
+      : "=&v"(t.c[0]), "=&v"(t.c[1]), "=&v"(t.c[2]), "=&v"(t.c[3]), "=&v"(t.c[4]), "=&v"(t.c[5]), "=&v"(t.c[6]), "=&v"(t.y)
+      : "v"(voff16), "s"(base), "s"(base2), "v"(voff2), "s"(ybase)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void ga_wait8(GaTileRegs7& t) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(t.c[0]), "+v"(t.c[1]), "+v"(t.c[2]), "+v"(t.c[3]), "+v"(t.c[4]), "+v"(t.c[5]), "+v"(t.c[6]), "+v"(t.y)
+               : "i"(N));
+}
+
+// tile registers -> the [8][2] operand of ga_tile
+__device__ __forceinline__ void ga_unpack(const GaTileRegs& t, double (&xx)[8][2]) {
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd) { xx[dd][0] = t.c[dd].x; xx[dd][1] = t.c[dd].y; }
+}
+__device__ __forceinline__ void ga_unpack(const GaTileRegs7& t, double (&xx)[8][2]) {
+  xx[0][0] = 1.0; xx[0][1] = 1.0;
+#pragma unroll
+  for (int dd = 1; dd < 8; ++dd) { xx[dd][0] = t.c[dd - 1].x; xx[dd][1] = t.c[dd - 1].y; }
+}
+template <int DX> struct GaTileSel { typedef GaTileRegs type; };
+template <> struct GaTileSel<7> { typedef GaTileRegs7 type; };
+
 // one tile of SPAN = 64 RPL rows: forward (eta, log-lik) + backward (d/dbeta) in registers
 template <int D, int RPL>
 __device__ __forceinline__ void ga_tile(const double (&x)[D][RPL], uint32_t yb, const double (&beta)[D], int nvalid, int lane,
@@ -158,9 +201,13 @@ struct GaArgs {
 #define GA_FOLD_CTL 1
 #define GA_FOLD_SRC 2
 
-template <int D, int RPL, int OCC, int PIPE>
+// DX: stored columns of X per tile (D, or D - 1 = 7 when column 0 is identically 1; only with D = 8)
+template <int D, int RPL, int OCC, int PIPE, int DX = D>
 __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   constexpr int SPAN = WAVE * RPL;
+  static_assert(DX == D || (D == 8 && DX == 7), "only the intercept column of an 8-column model is elided");
+  typedef typename GaTileSel<DX>::type Tile;
+  constexpr int LOADS = DX + 1;   // loads per tile: the stored columns + y
   const ModelDev& md = a.md;
   const ArenaDev& A = a.A;
   const EvalIO& io = a.io;
@@ -204,7 +251,7 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   const int n = c2 - c0;
   const int nA = (n + 1) / 2;                                   // tiles of the first half (chunk-local [0, nA)), second [nA, n)
   const int nsw = rev ? n - nA : nA;                            // position in the sequence where the second-streamed half starts
-  constexpr int64_t TS = (int64_t)D * SPAN;                     // doubles per tile
+  constexpr int64_t TS = (int64_t)DX * SPAN;                    // doubles per tile
   auto local_at = [&](int i) { return rev ? (i < nsw ? nA + i : i - nsw) : i; };
   auto tile_at = [&](int i) { return cbase + (int64_t)local_at(i) * TS; };
   const int l_last = (c2 == T) ? n - 1 : -1;                    // chunk-local index of the group's last (zero-padded) tile, if it is here
@@ -212,13 +259,13 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   // PIPE tiles in flight per wave; the first ones are requested before anything else, so HBM is busy during the prologue
   double xa[D][RPL], xb[D][RPL], xc[PIPE == 3 ? D : 1][RPL];
   uint32_t ya = 0, yb = 0, yc = 0;
-  GaTileRegs ta, tb, tc;
+  Tile ta, tb, tc;
   // (a wave without tiles requests the chunk's first tile slot anyway: the layout keeps one tile of slack behind every chunk)
   if constexpr (D == 8 && RPL == 2) {
     const uint32_t voff16 = (uint32_t)lane * 16u, voff2 = (uint32_t)lane * 2u;
     const int64_t o0 = tile_at(0), o1 = tile_at(min(1, max(n - 1, 0)));
-    ga_issue8(R.Xt + o0, R.y + o0 / D, voff16, voff2, ta);
-    ga_issue8(R.Xt + o1, R.y + o1 / D, voff16, voff2, tb);
+    ga_issue8(R.Xt + o0, R.y + o0 / DX, voff16, voff2, ta);
+    ga_issue8(R.Xt + o1, R.y + o1 / DX, voff16, voff2, tb);
   } else {
     ga_load<D, RPL>(R, tile_at(0), lane, xa, ya);
     if (PIPE == 3) ga_load<D, RPL>(R, tile_at(min(1, max(n - 1, 0))), lane, xb, yb);
@@ -289,16 +336,16 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
       // hand-counted loads: PIPE tiles in flight per wave; the requests past the end re-read the wave's last tile (an L2 hit) so that
       // every stage has exactly 9 (PIPE - 1) younger loads behind the tile it waits for
       const uint32_t voff16 = (uint32_t)lane * 16u, voff2 = (uint32_t)lane * 2u;
-      auto issue = [&](int i, GaTileRegs& t) {
+      auto issue = [&](int i, Tile& t) {
         const int64_t off = tile_at(min(i, nm1));
-        ga_issue8(R.Xt + off, R.y + off / D, voff16, voff2, t);
+        ga_issue8(R.Xt + off, R.y + off / DX, voff16, voff2, t);
       };
 #define GA_ASTAGE(T, I)                                                                      \
       {                                                                                      \
-        ga_wait8<9 * (PIPE - 1)>(T);                                                         \
+        ga_wait8<LOADS * (PIPE - 1)>(T);                                                     \
         if ((I) == nsw) flush();                                                             \
         double xx[8][2];                                                                     \
-        _Pragma("unroll") for (int dd = 0; dd < 8; ++dd) { xx[dd][0] = T.c[dd].x; xx[dd][1] = T.c[dd].y; } \
+        ga_unpack(T, xx);                                                                    \
         ga_tile<8, 2>(xx, T.y, beta, local_at(I) == l_last ? n_last : SPAN, lane, acc, lp); \
       }
       if constexpr (PIPE == 3) {

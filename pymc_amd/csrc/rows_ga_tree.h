@@ -284,9 +284,11 @@ __device__ __noinline__ void ga_tree_control_nf(const GaTreeArgs* args) {
 }
 
 // grid = G + 1 workgroups of W waves (workgroup 0: control), all resident; D = 8, two rows per lane, two tiles in flight per wave
-template <int OCC>
+template <int OCC, int DX = 8>
 __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
   constexpr int D = 8, RPL = 2, SPAN = WAVE * RPL;
+  typedef typename GaTileSel<DX>::type Tile;
+  constexpr int LOADS = DX + 1;
   if (blockIdx.x == 0) { ga_tree_control_nf((const GaTreeArgs*)__builtin_amdgcn_kernarg_segment_ptr()); return; }
   __shared__ double s_acc[GA_MAXW][2][D + 1];   // [wave][first / second half of its tiles][d/dbeta, log-lik]
   __shared__ double s_red[NDOT];
@@ -318,11 +320,11 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
     cbase = ga_uni64(R.ga_coff[g * W + w]);
   }
   const double* const Xw = R.Xt + cbase;        // this wave's chunk
-  const int8_t* const yw = R.y + cbase / D;
+  const int8_t* const yw = R.y + cbase / DX;
   const int c0 = (int)((int64_t)w * T / W), c2 = (int)((int64_t)(w + 1) * T / W);
   const int n = c2 - c0;
   const int nA = (n + 1) / 2;
-  constexpr int64_t TS = (int64_t)D * SPAN;
+  constexpr int64_t TS = (int64_t)DX * SPAN;
   const int l_last = (c2 == T) ? n - 1 : -1;
   const int n_last = (int)(ng - (int64_t)(T - 1) * SPAN);
   const int nm1 = max(n - 1, 0);
@@ -349,14 +351,14 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
       const int nsw = rev ? n - nA : nA;            // position in the sequence where the second-streamed half starts
       // the order of a wave's tiles alternates between leaves (the tail of the previous pass is still in the Infinity Cache)
       auto local_at = [&](int i) { return rev ? (i < nsw ? nA + i : i - nsw) : i; };
-      auto issue = [&](int i, GaTileRegs& t) {
+      auto issue = [&](int i, Tile& t) {
         const int64_t off = (int64_t)local_at(min(i, nm1)) * TS;
-        ga_issue8(Xw + off, yw + off / D, voff16, voff2, t);
+        ga_issue8(Xw + off, yw + off / DX, voff16, voff2, t);
       };
       const EvalIO io = ga_tree_io(dir, edge, left, right, a.eps_abs);
       Leaf lf; QView qv;
       resolve_leaf(io, A, j, lf, qv);
-      GaTileRegs ta, tb;
+      Tile ta, tb;
       GA_TICK(0);
       GA_DBG(0, w == 0);
       if (w != 0 || early0) {
@@ -446,10 +448,10 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_tree_ga(GaTreeArgs a) {
         };
 #define GA_TSTAGE(TR, I)                                                                     \
         {                                                                                    \
-          ga_wait8<9>(TR);                                                                   \
+          ga_wait8<LOADS>(TR);                                                               \
           if ((I) == nsw) flush();                                                           \
           double xx[8][2];                                                                   \
-          _Pragma("unroll") for (int dd = 0; dd < 8; ++dd) { xx[dd][0] = TR.c[dd].x; xx[dd][1] = TR.c[dd].y; } \
+          ga_unpack(TR, xx);                                                                 \
           ga_tile<8, 2>(xx, TR.y, beta, local_at(I) == l_last ? n_last : SPAN, lane, acc, lp); \
         }
         for (int i = 0; i < n; i += 2) {

@@ -348,7 +348,7 @@ STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_
 def _run_schedule(spec, env, monkeypatch, tune, draws, seed):
     from pymc_amd.sampling import sample
 
-    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL")
+    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL", "NUTS_GA_ONES0")
     for k in keys:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -386,9 +386,11 @@ def test_cross_doubling_fold_is_a_pure_rescheduling(c2l, monkeypatch):
     """Group-aligned row pass, one launch per leapfrog: the control work of a doubling's last leaf rides in the first row pass of
     the next doubling when the host's look-ahead has queued it (engine.hip, run_tree / GaArgs.cio) instead of being a launch of
     its own.  Same arithmetic, different launches: bitwise equal draws and statistics, also with the look-ahead extended over
-    every doubling and with the folded control switched off altogether."""
+    every doubling and with the folded control switched off altogether.  The last variant stores the intercept column of X
+    (by default it is elided, csrc/rows_ga_kernel.h GaTileRegs7: multiplying by a stored 1.0 or by the literal is the same
+    arithmetic)."""
     envs = ({"NUTS_XFOLD": "0"}, {"NUTS_XFOLD": "1"}, {"NUTS_XFOLD": "1", "NUTS_SPEC_MAX": "10"}, {"NUTS_XFOLD": "0", "NUTS_SPEC_MAX": "10"},
-            {"NUTS_FOLD_CTL": "0"})
+            {"NUTS_FOLD_CTL": "0"}, {"NUTS_GA_ONES0": "0"})
     runs = [_run_schedule(c2l, env, monkeypatch, 14, 6, 78) for env in envs]
     d0, s0, _ = runs[0]
     for env, (d1, s1, _) in zip(envs[1:], runs[1:]):
