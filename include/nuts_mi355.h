@@ -156,7 +156,15 @@ int nuts_model_get_scalar(const nuts_model *m, const char *name, double *out);
 /* NUTS_POT_FULL covers QuadPotentialFull and QuadPotentialFullInv (quadpotential.py:633-725): the caller passes
  * the dense covariance C (velocity = C p) and the matrix W with potential.random() = W z
  * (Full: W = chol(C)^-T ; FullInv(A): C = A^-1, W = chol(A)). */
-enum { NUTS_POT_DIAG_ADAPT = 0, NUTS_POT_DIAG = 1, NUTS_POT_FULL = 2 };
+enum { NUTS_POT_DIAG_ADAPT = 0, NUTS_POT_DIAG = 1, NUTS_POT_FULL = 2,
+       /* QuadPotentialDiagAdaptExp (quadpotential.py:486-579; init="jitter+adapt_diag_grad", mcmc.py:1894-1911): exponentially
+        * weighted variance of the draws, optionally divided by that of the gradients; estimators on the device, one
+        * element-wise kernel per tuning draw, every operation rounded as NumPy rounds it (no fused multiply-add) */
+       NUTS_POT_DIAG_ADAPT_EXP = 3,
+       /* QuadPotentialFullAdapt (quadpotential.py:748-852) with both `_WeightedCovariance` estimators, the covariance in use and
+        * its Cholesky factor in HBM (csrc/dense_adapt.h): dense_cov = initial covariance, initial_mean, initial_weight,
+        * adaptation_window, adaptation_window_multiplier, fa_update_window.  velocity = cov p, random = solve(chol^T, z). */
+       NUTS_POT_FULL_ADAPT = 4 };
 
 typedef struct {
   /* BaseHMC.__init__ (pymc/step_methods/hmc/base_hmc.py:82-187) */
@@ -179,6 +187,12 @@ typedef struct {
   int32_t pad;
   const double *dense_cov;  /* [n][n] row-major, NUTS_POT_FULL only */
   const double *dense_rand; /* [n][n] row-major, NUTS_POT_FULL only */
+  /* NUTS_POT_DIAG_ADAPT_EXP only (quadpotential.py:494-537): decay rate, last sample count that still adapts (+inf: never
+   * stop), whether the gradients' variance enters (sqrt(var(q) / var(grad))); `discard_window` above applies too */
+  double exp_alpha;
+  double exp_stop_adaptation;
+  int32_t exp_use_grads;
+  int32_t fa_update_window; /* NUTS_POT_FULL_ADAPT: refactor the covariance every this many tuning draws (1) */
 } nuts_chain_config;
 
 void nuts_chain_config_default(nuts_chain_config *cfg);

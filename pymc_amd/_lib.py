@@ -107,6 +107,10 @@ class ChainConfig(C.Structure):
         ("pad", C.c_int32),
         ("dense_cov", C.POINTER(C.c_double)),
         ("dense_rand", C.POINTER(C.c_double)),
+        ("exp_alpha", C.c_double),
+        ("exp_stop_adaptation", C.c_double),
+        ("exp_use_grads", C.c_int32),
+        ("fa_update_window", C.c_int32),
     ]
 
 

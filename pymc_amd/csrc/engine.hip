@@ -800,6 +800,8 @@ struct StateHeader {  // host scalars of the sampling state
   int64_t iter_count, divergences, n_samples, adaptation_window;
   int32_t tune, fg_is_a, pad0, pad1;
   double fg_count, bg_count;
+  int64_t fa_previous_update;   // NUTS_POT_FULL_ADAPT
+  double fa_fg_n, fa_bg_n;
 };
 
 struct nuts_chain {
@@ -812,6 +814,14 @@ struct nuts_chain {
   double *var = nullptr, *stds = nullptr, *inv_stds = nullptr;
   double *dense_C = nullptr, *dense_W = nullptr;   // NUTS_POT_FULL: velocity = C p, random = W z
   int dense = 0, mv_grid = 0;
+  // NUTS_POT_FULL_ADAPT (dense_adapt.h): estimators, factor in use (fa_L), factorisation workspace, counters
+  int full_adapt = 0, fa_mfma = 1;
+  double *fa_L = nullptr, *fa_Lw = nullptr, *fa_fg_mean = nullptr, *fa_fg_raw = nullptr, *fa_bg_mean = nullptr, *fa_bg_raw = nullptr;
+  double *fa_scratch = nullptr, *fa_rhs = nullptr;
+  int *fa_fail = nullptr;          // [2]: {last factorisation failed, any factorisation failed since the last reset}
+  double fa_fg_n = 0, fa_bg_n = 0;
+  int64_t fa_previous_update = 0;
+  std::vector<double> fa_initial_cov;
   double *wa_mean = nullptr, *wa_m2 = nullptr, *wb_mean = nullptr, *wb_m2 = nullptr;  // two Welford estimators
   bool fg_is_a = true;
   double fg_count = 0, bg_count = 0;
@@ -870,7 +880,81 @@ extern "C" void nuts_chain_config_default(nuts_chain_config* c) {
   c->step_scale = 0.25; c->Emax = 1000; c->target_accept = 0.8; c->gamma = 0.05; c->k = 0.75; c->t0 = 10;
   c->adapt_step_size = 1; c->max_treedepth = 10; c->early_max_treedepth = 8;
   c->potential = NUTS_POT_DIAG_ADAPT; c->initial_weight = 0; c->adaptation_window = 101; c->discard_window = 50;
+  c->exp_alpha = 0.02; c->exp_stop_adaptation = INFINITY; c->exp_use_grads = 0;
   c->adaptation_window_multiplier = 1; c->early_update = 0;
+}
+
+// ---- NUTS_POT_FULL_ADAPT (dense_adapt.h) ----
+// cov = raw / denom into dense_C, blocked Cholesky of it in the workspace, committed to the factor in use when it went through
+static void fa_factor(nuts_chain* c, const double* raw, double denom) {
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  const dim3 g2((n + 255) / 256, n);
+  hipLaunchKernelGGL(k_fa_cov, g2, dim3(256), 0, s, n, raw, denom, c->dense_C, c->fa_Lw, c->fa_fail);
+  const int nb = (n + FA_NB - 1) / FA_NB;
+  for (int k = 0; k < nb; ++k) {
+    hipLaunchKernelGGL(k_chol_panel, dim3(nb - k), dim3(256), 0, s, n, c->fa_Lw, k, c->fa_fail);
+    const int m = nb - k - 1;
+    if (m > 0) hipLaunchKernelGGL(k_chol_update, dim3(m * (m + 1) / 2), dim3(256), 0, s, n, c->fa_Lw, k, nb, c->fa_mfma);
+  }
+  hipLaunchKernelGGL(k_fa_commit, dim3(1024), dim3(256), 0, s, (int64_t)n * n, c->fa_Lw, c->fa_L, c->fa_fail, c->fa_fail + 1);
+}
+// random(): p = solve(chol^T, z) (quadpotential.py:709-711)
+static void fa_random(nuts_chain* c, const double* z_dev, double* p_out) {
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  hipMemcpyAsync(c->fa_rhs, z_dev, n * sizeof(double), hipMemcpyDeviceToDevice, s);
+  const int nb = (n + FA_NB - 1) / FA_NB;
+  for (int b = nb - 1; b >= 0; --b)
+    hipLaunchKernelGGL(k_trsv_block, dim3(std::max(1, (b * FA_NB + 255) / 256)), dim3(256), 0, s, n, c->fa_L, c->fa_rhs, p_out, b);
+}
+static int fa_reset(nuts_chain* c) {   // QuadPotentialFullAdapt.reset (quadpotential.py:794-804)
+  const int n = c->n;
+  const size_t nn = (size_t)n * n;
+  const double w = c->cfg.initial_weight;
+  std::vector<double> raw(nn);
+  for (size_t e = 0; e < nn; ++e) raw[e] = c->fa_initial_cov[e] * w;   // `raw_cov[:] *= n_samples`
+  HIPCHK(hipMemcpy(c->fa_fg_raw, raw.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->fa_fg_mean, c->initial_mean.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(c->fa_bg_raw, 0, nn * sizeof(double)));    // `_WeightedCovariance(n)`: eye * 0
+  HIPCHK(hipMemset(c->fa_bg_mean, 0, n * sizeof(double)));
+  HIPCHK(hipMemset(c->fa_fail, 0, 2 * sizeof(int)));
+  c->fa_fg_n = w; c->fa_bg_n = 0; c->fa_previous_update = 0;
+  c->adaptation_window = c->cfg.adaptation_window;
+  // the covariance in use is the INITIAL covariance and its factor (not the estimator's): stage it through the bg buffer
+  HIPCHK(hipMemcpy(c->fa_Lw, c->fa_initial_cov.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+  {
+    hipStream_t s = c->m->stream;
+    HIPCHK(hipMemcpyAsync(c->fa_bg_raw, c->fa_Lw, nn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    fa_factor(c, c->fa_bg_raw, 1.0);
+    HIPCHK(hipMemsetAsync(c->fa_bg_raw, 0, nn * sizeof(double), s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  int fail[2] = {0, 0};
+  HIPCHK(hipMemcpy(fail, c->fa_fail, sizeof(fail), hipMemcpyDeviceToHost));
+  if (fail[0]) { g_err = "the initial covariance of QuadPotentialFullAdapt is not positive definite"; return NUTS_E_LINALG; }
+  return NUTS_OK;
+}
+// QuadPotentialFullAdapt.update (quadpotential.py:819-843)
+static int fa_update(nuts_chain* c, const double* x_dev) {
+  if (!c->tune) return NUTS_OK;
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  const int64_t delta = c->n_samples - c->fa_previous_update;
+  c->fa_fg_n += 1; c->fa_bg_n += 1;
+  hipLaunchKernelGGL(k_fa_diffs, dim3((n + 255) / 256), dim3(256), 0, s, n, x_dev, c->fa_fg_mean, c->fa_bg_mean, c->fa_fg_n, c->fa_bg_n, c->fa_scratch);
+  hipLaunchKernelGGL(k_fa_rank1, dim3((n + 255) / 256, n), dim3(256), 0, s, n, c->fa_scratch, c->fa_fg_raw, c->fa_bg_raw);
+  if ((delta + 1) % c->cfg.fa_update_window == 0) fa_factor(c, c->fa_fg_raw, c->fa_fg_n - 1.0);
+  if (delta >= c->adaptation_window) {   // foreground <- background, fresh background, window grows
+    std::swap(c->fa_fg_raw, c->fa_bg_raw); std::swap(c->fa_fg_mean, c->fa_bg_mean);
+    c->fa_fg_n = c->fa_bg_n; c->fa_bg_n = 0;
+    HIPCHK(hipMemsetAsync(c->fa_bg_raw, 0, (size_t)n * n * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(c->fa_bg_mean, 0, n * sizeof(double), s));
+    c->fa_previous_update = c->n_samples;
+    c->adaptation_window = (int64_t)(c->adaptation_window * c->cfg.adaptation_window_multiplier);
+  }
+  c->n_samples += 1;
+  return NUTS_OK;
 }
 
 static int potential_reset(nuts_chain* c) {  // quadpotential.py:297-306
@@ -892,18 +976,25 @@ static int potential_reset(nuts_chain* c) {  // quadpotential.py:297-306
     HIPCHK(hipMemset(c->wb_m2, 0, n * sizeof(double)));
     c->fg_count = w; c->bg_count = 0;
   }
+  if (c->full_adapt) { const int rc = fa_reset(c); if (rc) return rc; }
+  if (c->cfg.potential == NUTS_POT_DIAG_ADAPT_EXP) {   // the estimators start at sample `discard_window` (kernel flag 1)
+    HIPCHK(hipMemset(c->wa_mean, 0, n * sizeof(double))); HIPCHK(hipMemset(c->wa_m2, 0, n * sizeof(double)));
+    HIPCHK(hipMemset(c->wb_mean, 0, n * sizeof(double))); HIPCHK(hipMemset(c->wb_m2, 0, n * sizeof(double)));
+  }
   c->n_samples = 0;
   return NUTS_OK;
 }
 
 extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config* cfg) {
   if (!m || !cfg) { g_err = "null argument"; return nullptr; }
-  if (cfg->potential != NUTS_POT_DIAG_ADAPT && cfg->potential != NUTS_POT_DIAG && cfg->potential != NUTS_POT_FULL) {
+  if (cfg->potential != NUTS_POT_DIAG_ADAPT && cfg->potential != NUTS_POT_DIAG && cfg->potential != NUTS_POT_FULL &&
+      cfg->potential != NUTS_POT_DIAG_ADAPT_EXP && cfg->potential != NUTS_POT_FULL_ADAPT) {
     g_err = "potential kind not implemented on device (adaptive dense potentials are a later round)"; return nullptr;
   }
   if (cfg->potential == NUTS_POT_FULL && (!cfg->dense_cov || !cfg->dense_rand)) { g_err = "dense potential needs dense_cov and dense_rand"; return nullptr; }
+  if (cfg->potential == NUTS_POT_FULL_ADAPT && !cfg->dense_cov) { g_err = "NUTS_POT_FULL_ADAPT needs dense_cov (the initial covariance)"; return nullptr; }
   if (cfg->max_treedepth < 1 || cfg->max_treedepth > MAX_LEVELS - 1) { g_err = "max_treedepth out of range (1..11)"; return nullptr; }
-  if (cfg->potential == NUTS_POT_FULL && m->md.lg.ga) {
+  if ((cfg->potential == NUTS_POT_FULL || cfg->potential == NUTS_POT_FULL_ADAPT) && m->md.lg.ga) {
     g_err = "a dense mass matrix needs the span-partitioned row pass: create the model with NUTS_ROWS_NO_GROUP_ALIGNED";
     return nullptr;
   }
@@ -916,8 +1007,12 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   if (cfg->initial_diag) c->initial_diag.assign(cfg->initial_diag, cfg->initial_diag + n);
   else if (cfg->potential == NUTS_POT_DIAG_ADAPT) c->cfg.initial_weight = 1;  // quadpotential.py:280-282
   c->cfg.initial_mean = nullptr; c->cfg.initial_diag = nullptr;
-  c->dense = cfg->potential == NUTS_POT_FULL;
+  c->dense = cfg->potential == NUTS_POT_FULL || cfg->potential == NUTS_POT_FULL_ADAPT;
+  c->full_adapt = cfg->potential == NUTS_POT_FULL_ADAPT;
+  c->fa_mfma = env_int("NUTS_FA_MFMA", 1);
+  if (c->cfg.fa_update_window < 1) c->cfg.fa_update_window = 1;
   if (c->dense) c->initial_diag.assign(m->md.n, 1.0);  // the diagonal vectors stay allocated (unused)
+  const double* const cfg_dense_cov = cfg->dense_cov; (void)cfg_dense_cov;
   c->cfg.dense_cov = nullptr; c->cfg.dense_rand = nullptr;
   c->adaptation_window = cfg->adaptation_window;
   ArenaDev& A = c->A;
@@ -943,7 +1038,17 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   // NUTS_GA_TREE=0: one launch per leapfrog (also what several chains SHARING a GPU must use: the tree kernel needs the chip)
   c->tree_opts = env_int("NUTS_GA_TREE_OPTS", 0) | (env_int("NUTS_GA_TREE_TICKS", 0) << GA_TREE_TICK_SHIFT);
   c->tree_mode = m->md.lg.ga && m->ga_tree_ok && !c->dense && m->md.lean_ok && env_int("NUTS_GA_TREE", 1) != 0;
-  if (c->dense) {
+  if (c->full_adapt) {
+    const size_t nn = (size_t)n * n;
+    c->fa_initial_cov.assign(cfg->dense_cov, cfg->dense_cov + nn);
+    c->dense_C = c->keep(dev_alloc<double>(nn));
+    c->fa_L = c->keep(dev_alloc<double>(nn)); c->fa_Lw = c->keep(dev_alloc<double>(nn));
+    c->fa_fg_raw = c->keep(dev_alloc<double>(nn)); c->fa_bg_raw = c->keep(dev_alloc<double>(nn));
+    c->fa_fg_mean = c->keep(dev_alloc<double>(n)); c->fa_bg_mean = c->keep(dev_alloc<double>(n));
+    c->fa_scratch = c->keep(dev_alloc<double>(4 * (size_t)n)); c->fa_rhs = c->keep(dev_alloc<double>(n));
+    c->fa_fail = c->keep(dev_alloc<int>(2));
+    c->mv_grid = (n + (256 / WAVE) - 1) / (256 / WAVE);
+  } else if (c->dense) {
     c->dense_C = c->keep(dev_upload(cfg->dense_cov, (size_t)n * n));
     c->dense_W = c->keep(dev_upload(cfg->dense_rand, (size_t)n * n));
     c->mv_grid = (n + (256 / WAVE) - 1) / (256 / WAVE);
@@ -956,7 +1061,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->spec_max = env_int("NUTS_SPEC_MAX", 10);
   c->xfold = env_int("NUTS_XFOLD", 1);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
-             cfg->potential != NUTS_POT_FULL;
+             cfg->potential != NUTS_POT_FULL && cfg->potential != NUTS_POT_FULL_ADAPT;
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
   A.log_uniforms = A.uniforms + c->n_uni_cap;
@@ -1007,6 +1112,13 @@ extern "C" int nuts_chain_set_tune(nuts_chain* c, int tune) { if (!c) return NUT
 extern "C" int nuts_chain_set_iter_count(nuts_chain* c, int64_t it) { if (!c) return NUTS_E_ARG; c->iter_count = it; return NUTS_OK; }
 
 static int check_mass_matrix(nuts_chain* c) {  // quadpotential.py:357-393 raise_ok
+  if (c->full_adapt) {   // quadpotential.py:845-847: a factorisation that failed during adaptation is reported here
+    int fail[2] = {0, 0};
+    HIPCHK(hipMemcpy(fail, c->fa_fail, sizeof(fail), hipMemcpyDeviceToHost));
+    if (fail[1]) { g_err = "the adapted covariance is not positive definite (Cholesky factorisation failed)"; return NUTS_E_LINALG; }
+    return NUTS_OK;
+  }
+  if (c->dense) return NUTS_OK;
   std::vector<double> st(c->n);
   HIPCHK(hipMemcpy(st.data(), c->stds, c->n * sizeof(double), hipMemcpyDeviceToHost));
   for (double s : st) {
@@ -1016,8 +1128,25 @@ static int check_mass_matrix(nuts_chain* c) {  // quadpotential.py:357-393 raise
   return NUTS_OK;
 }
 
-static int potential_update(nuts_chain* c, const double* x_dev) {  // quadpotential.py:335-355
+static int potential_update(nuts_chain* c, const double* x_dev, const double* g_dev) {  // quadpotential.py:335-355
   c->window_switched = false;
+  if (c->full_adapt) return fa_update(c, x_dev);
+  if (c->cfg.potential == NUTS_POT_DIAG_ADAPT_EXP) {   // quadpotential.py:534-569
+    if (!(c->tune && (double)c->n_samples < c->cfg.exp_stop_adaptation)) return NUTS_OK;
+    const int64_t k = c->n_samples, dw = c->cfg.discard_window;
+    int flags = 0;
+    if (k > dw) flags |= 2;
+    else if (k == dw) flags |= 1;
+    if (k > 2 * dw) flags |= 4;
+    if (flags) {
+      const int grid = std::max(1, std::min(1024, (c->n + VEC_THREADS - 1) / VEC_THREADS));
+      hipLaunchKernelGGL(k_potential_update_exp, dim3(grid), dim3(VEC_THREADS), 0, c->m->stream, c->n, x_dev, g_dev, c->wa_mean,
+                         c->wa_m2, c->wb_mean, c->wb_m2, c->cfg.exp_alpha, 1.0 - c->cfg.exp_alpha, c->cfg.exp_use_grads, c->var, c->stds,
+                         c->inv_stds, flags);
+    }
+    c->n_samples += 1;
+    return NUTS_OK;
+  }
   if (c->cfg.potential != NUTS_POT_DIAG_ADAPT || !c->tune) return NUTS_OK;
   hipStream_t s = c->m->stream;
   int flags = 0;
@@ -1097,6 +1226,7 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
   if (c->dense) {
     // p0 = W z (or the given momentum), v0 = C p0   (quadpotential.py:704-711)
     if (p_exact) HIPCHK(hipMemcpyAsync(A.P, c->stage_dev + n, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    else if (c->full_adapt) fa_random(c, c->stage_dev + n, A.P);
     else hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_W, c->stage_dev + n, A.P, n, (const double*)nullptr,
                             (double*)nullptr, 0.0, (const int*)nullptr);
     hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P, A.V, n, (const double*)nullptr, (double*)nullptr, 0.0,
@@ -1360,7 +1490,7 @@ static int finish_draw_host(nuts_chain* c, const DrawOut& o, bool adapt, bool ex
     if (c->tree_prof_pending) { c->m->dom_units += o.n_proposals; c->tree_prof_pending = 0; }
   }
   c->da.update(accept, adapt);
-  int rc = potential_update(c, result_dev);
+  int rc = potential_update(c, result_dev, result_dev + c->n);
   if (rc) return rc;
   const bool diverging = o.diverging != 0;
   if (diverging) {   // keep the leaf the integrator started from and the one it diverged to (base_hmc.py:249-258)
@@ -1557,7 +1687,8 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
     A.uniforms = d_u + consumed; A.log_uniforms = d_lu + consumed;
     const bool from_prev = k > 0 || cached0;   // the start state is the previous proposal, (q, grad) in out_dev, logp in do_dev / last_logp
     if (c->dense) {
-      hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_W, d_norm + (size_t)k * n, A.P, n, (const double*)nullptr,
+      if (c->full_adapt) fa_random(c, d_norm + (size_t)k * n, A.P);
+      else hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_W, d_norm + (size_t)k * n, A.P, n, (const double*)nullptr,
                          (double*)nullptr, 0.0, (const int*)nullptr);
       hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P, A.V, n, (const double*)nullptr, (double*)nullptr, 0.0,
                          (const int*)nullptr);
@@ -1795,7 +1926,7 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   c->da.update(accept, adapt);
   // (a rejected transition stays at q0, which is still in the staging buffer of this draw)
   const double* xsel = accepted ? (A.Q + (int64_t)last * n) : c->stage_dev;
-  rc = potential_update(c, xsel);
+  rc = potential_update(c, xsel, accepted ? (A.G + (int64_t)last * n) : A.G);   // (gradient at q0: the start state, slot 0)
   if (rc) return rc;
   if (!c->tune) c->divergences += div;
   c->iter_count += 1;
@@ -1843,7 +1974,10 @@ extern "C" int nuts_chain_leapfrog_test(nuts_chain* c, const double* q, const do
 // ---- sampling_state ---------------------------------------------------------
 static const int64_t STATE_MAGIC = 0x4e5554534d493335LL;
 extern "C" int64_t nuts_chain_state_size(const nuts_chain* c) {
-  return c ? (int64_t)(sizeof(StateHeader) + 7 * (size_t)c->n * sizeof(double)) : 0;
+  if (!c) return 0;
+  // (NUTS_POT_FULL_ADAPT: covariance in use, its factor, both estimators)
+  const size_t extra = c->full_adapt ? (4 * (size_t)c->n * c->n + 2 * (size_t)c->n) : 0;
+  return (int64_t)(sizeof(StateHeader) + (7 * (size_t)c->n + extra) * sizeof(double));
 }
 extern "C" int nuts_chain_get_state(nuts_chain* c, void* blob) {
   if (!c || !blob) return NUTS_E_ARG;
@@ -1852,10 +1986,19 @@ extern "C" int nuts_chain_get_state(nuts_chain* c, void* blob) {
   h.magic = STATE_MAGIC; h.n = c->n; h.da = c->da; h.iter_count = c->iter_count; h.divergences = c->divergences;
   h.n_samples = c->n_samples; h.adaptation_window = c->adaptation_window; h.tune = c->tune; h.fg_is_a = c->fg_is_a;
   h.fg_count = c->fg_count; h.bg_count = c->bg_count;
+  h.fa_previous_update = c->fa_previous_update; h.fa_fg_n = c->fa_fg_n; h.fa_bg_n = c->fa_bg_n;
   std::memcpy(blob, &h, sizeof(h));
   double* v = reinterpret_cast<double*>(static_cast<char*>(blob) + sizeof(h));
   const double* src[7] = {c->var, c->stds, c->inv_stds, c->wa_mean, c->wa_m2, c->wb_mean, c->wb_m2};
   for (int k = 0; k < 7; ++k) HIPCHK(hipMemcpy(v + (size_t)k * c->n, src[k], c->n * sizeof(double), hipMemcpyDeviceToHost));
+  if (c->full_adapt) {
+    const size_t n = c->n, nn = n * n;
+    double* w = v + 7 * n;
+    const double* mats[4] = {c->dense_C, c->fa_L, c->fa_fg_raw, c->fa_bg_raw};
+    for (int k = 0; k < 4; ++k) HIPCHK(hipMemcpy(w + (size_t)k * nn, mats[k], nn * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(w + 4 * nn, c->fa_fg_mean, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(w + 4 * nn + n, c->fa_bg_mean, n * sizeof(double), hipMemcpyDeviceToHost));
+  }
   return NUTS_OK;
 }
 extern "C" int nuts_chain_set_state(nuts_chain* c, const void* blob) {
@@ -1868,9 +2011,18 @@ extern "C" int nuts_chain_set_state(nuts_chain* c, const void* blob) {
   c->da = h.da; c->iter_count = h.iter_count; c->divergences = h.divergences; c->n_samples = h.n_samples;
   c->adaptation_window = h.adaptation_window; c->tune = h.tune != 0; c->fg_is_a = h.fg_is_a != 0;
   c->fg_count = h.fg_count; c->bg_count = h.bg_count;
+  c->fa_previous_update = h.fa_previous_update; c->fa_fg_n = h.fa_fg_n; c->fa_bg_n = h.fa_bg_n;
   const double* v = reinterpret_cast<const double*>(static_cast<const char*>(blob) + sizeof(h));
   double* dst[7] = {c->var, c->stds, c->inv_stds, c->wa_mean, c->wa_m2, c->wb_mean, c->wb_m2};
   for (int k = 0; k < 7; ++k) HIPCHK(hipMemcpy(dst[k], v + (size_t)k * c->n, c->n * sizeof(double), hipMemcpyHostToDevice));
+  if (c->full_adapt) {
+    const size_t n = c->n, nn = n * n;
+    const double* w = v + 7 * n;
+    double* mats[4] = {c->dense_C, c->fa_L, c->fa_fg_raw, c->fa_bg_raw};
+    for (int k = 0; k < 4; ++k) HIPCHK(hipMemcpy(mats[k], w + (size_t)k * nn, nn * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->fa_fg_mean, w + 4 * nn, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->fa_bg_mean, w + 4 * nn + n, n * sizeof(double), hipMemcpyHostToDevice));
+  }
   return NUTS_OK;
 }
 
@@ -1892,6 +2044,9 @@ extern "C" int nuts_chain_get_scalar(nuts_chain* c, const char* name, double* ou
   else if (k == "step_size") *out = c->step_size;
   else if (k == "leapfrogs") *out = (double)c->leapfrogs;
   else if (k == "tree_kernel") *out = (double)c->tree_mode;
+  else if (k == "fa_fg_n") *out = c->fa_fg_n;
+  else if (k == "fa_bg_n") *out = c->fa_bg_n;
+  else if (k == "fa_previous_update") *out = (double)c->fa_previous_update;
   else if (k == "tree_launches") *out = (double)c->tree_launches;
   else if (k == "single_launch") *out = c->small ? 1.0 : 0.0;
   else if (k == "window_switched") *out = c->window_switched ? 1.0 : 0.0;
@@ -1919,6 +2074,14 @@ extern "C" int nuts_chain_get_vector(nuts_chain* c, const char* name, double* ou
     std::memcpy(out, v.data(), c->n * sizeof(double));
     return NUTS_OK;
   }
+  else if (c->full_adapt && (k == "fa_cov" || k == "fa_chol" || k == "fa_fg_raw" || k == "fa_bg_raw")) {   // [n][n]
+    src = k == "fa_cov" ? c->dense_C : k == "fa_chol" ? c->fa_L : k == "fa_fg_raw" ? c->fa_fg_raw : c->fa_bg_raw;
+    HIPCHK(hipStreamSynchronize(c->m->stream));
+    HIPCHK(hipMemcpy(out, src, (size_t)c->n * c->n * sizeof(double), hipMemcpyDeviceToHost));
+    return NUTS_OK;
+  }
+  else if (c->full_adapt && (k == "fa_fg_mean" || k == "fa_bg_mean")) src = k == "fa_fg_mean" ? c->fa_fg_mean : c->fa_bg_mean;
+  else if (k == "start_p" || k == "start_v") src = k == "start_p" ? c->A.P : c->A.V;   // momentum / velocity of the last draw's start state (arena slot 0)
   else { g_err = "unknown vector " + k; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(c->m->stream));
   HIPCHK(hipMemcpy(out, src, c->n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1928,7 +2091,7 @@ extern "C" int nuts_chain_get_vector(nuts_chain* c, const char* name, double* ou
 // ---- host-adapted mass matrices: push the new matrix after a host-side update ------------------------------
 extern "C" int nuts_chain_set_dense(nuts_chain* c, const double* cov, const double* rand) {
   if (!c || !cov || !rand) return NUTS_E_ARG;
-  if (!c->dense) { g_err = "nuts_chain_set_dense: the chain was not created with NUTS_POT_FULL"; return NUTS_E_ARG; }
+  if (!c->dense || c->full_adapt) { g_err = "nuts_chain_set_dense: the chain was not created with NUTS_POT_FULL"; return NUTS_E_ARG; }
   const size_t nn = (size_t)c->n * c->n;
   HIPCHK(hipStreamSynchronize(c->m->stream));
   HIPCHK(hipMemcpy(c->dense_C, cov, nn * sizeof(double), hipMemcpyHostToDevice));

@@ -1290,5 +1290,41 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update(int n, const d
   }
 }
 
+// ---- QuadPotentialDiagAdaptExp.update (quadpotential.py:534-579) with `_ExpWeightedVariance.add_sample` (:466-470) ----
+//   flags bit0: start the estimators at this sample (mean = x, variance = 0)   bit1: add the sample   bit2: new variance
+// Every operation is a separate IEEE operation in NumPy's order (`__d*_rn`: no contraction into fma), so the device estimator is
+// bit for bit the host's -- which is what lets the reference-run fixture of `init="jitter+adapt_diag_grad"` pass unchanged.
+__global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, const double* __restrict__ x, const double* __restrict__ g,
+                                                                      double* ms, double* vs, double* mg, double* vg, double alpha,
+                                                                      double one_m_alpha, int use_grads, double* var, double* stds,
+                                                                      double* inv_stds, int flags) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (flags & 1) {
+      ms[i] = x[i]; vs[i] = 0.0;
+      if (use_grads) { mg[i] = g[i]; vg[i] = 0.0; }
+    }
+    if (flags & 2) {
+      {
+        const double delta = __dsub_rn(x[i], ms[i]);
+        ms[i] = __dadd_rn(ms[i], __dmul_rn(alpha, delta));                                              // mean += alpha * delta
+        vs[i] = __dmul_rn(one_m_alpha, __dadd_rn(vs[i], __dmul_rn(alpha, __dmul_rn(delta, delta))));    // (1 - a) (var + a delta**2)
+      }
+      if (use_grads) {
+        const double delta = __dsub_rn(g[i], mg[i]);
+        mg[i] = __dadd_rn(mg[i], __dmul_rn(alpha, delta));
+        vg[i] = __dmul_rn(one_m_alpha, __dadd_rn(vg[i], __dmul_rn(alpha, __dmul_rn(delta, delta))));
+      }
+    }
+    if (flags & 4) {
+      double v;
+      if (use_grads) v = __dsqrt_rn(__ddiv_rn(vs[i], vg[i]));        // _update_from_variances: sqrt(var / inv_var), not clipped
+      else { v = vs[i]; v = fmin(fmax(v, 1e-12), 1e12); if (isnan(vs[i])) v = vs[i]; }   // _update_from_weightvar: np.clip
+      const double sd = __dsqrt_rn(v);
+      var[i] = v; stds[i] = sd; inv_stds[i] = __ddiv_rn(1.0, sd);
+    }
+  }
+}
+
 #include "rows_ga_kernel.h"
 #include "rows_ga_tree.h"
+#include "dense_adapt.h"

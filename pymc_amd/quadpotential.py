@@ -18,7 +18,7 @@ import numpy as np
 
 from pymc_amd import _lib
 
-POT_DIAG_ADAPT, POT_DIAG, POT_FULL = 0, 1, 2
+POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_DIAG_ADAPT_EXP, POT_FULL_ADAPT = 0, 1, 2, 3, 4
 
 _PREFETCH_ON = os.environ.get("PYMC_AMD_PREFETCH_NORMALS", "1") != "0"
 _REQUESTS = None
@@ -316,13 +316,21 @@ class _WeightedCovariance:
 class QuadPotentialFullAdapt(QuadPotentialFull):
     """Dense mass matrix adapted from the sample covariance (quadpotential.py:748-852).
 
-    The estimators and the per-update Cholesky stay on the host (that is where the reference keeps them: an
-    O(n^2) rank-1 update and a LAPACK `potrf` per tuning draw); the adapted covariance and `chol^-T` are pushed to
-    the device (`nuts_chain_set_dense`), where every leapfrog uses them.
+    Two homes for the estimators:
+
+    * **host** (`device_estimator=False`; the default below n = 256): the reference's arithmetic on NumPy arrays -- an
+      O(n^2) rank-1 update of two matrices and a LAPACK `potrf` per tuning draw -- bitwise equal to the reference's class;
+      the adapted covariance and `chol^-T` are pushed to the device (`nuts_chain_set_dense`).
+    * **device** (`device_estimator=True`; the default from n = 256 up, where the host's O(n^3) per tuning draw and
+      67 MB over PCIe would dominate the chain): `NUTS_POT_FULL_ADAPT`, csrc/dense_adapt.h -- both `_WeightedCovariance`
+      estimators, the covariance in use and its Cholesky factor live in HBM; the factorisation is a blocked right-looking
+      Cholesky whose trailing updates run on the matrix cores (`v_mfma_f64_16x16x4_f64`), `random()` a blocked triangular
+      solve.  Same estimator, same windows, same failure reporting (`raise_ok`); agrees with the host path to rounding (the
+      device factorisation does not round like LAPACK's), and nothing happens on the host between two tuning draws.
     """
 
     def __init__(self, n, initial_mean, initial_cov=None, initial_weight=0, adaptation_window=101,
-                 adaptation_window_multiplier=2, update_window=1, dtype=None, rng=None):
+                 adaptation_window_multiplier=2, update_window=1, dtype=None, rng=None, device_estimator=None):
         import warnings
 
         warnings.warn("QuadPotentialFullAdapt is an experimental feature")
@@ -347,7 +355,28 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
         self.adaptation_window = int(adaptation_window)
         self.adaptation_window_multiplier = float(adaptation_window_multiplier)
         self._update_window = int(update_window)
+        self._device_estimator = bool(n >= 256 if device_estimator is None else device_estimator)
         self._host_reset()
+
+    def _fill_config(self, cfg):
+        if not self._device_estimator:
+            return super()._fill_config(cfg)
+        self._cfg_cov = np.ascontiguousarray(self._initial_cov, dtype="float64")
+        self._cfg_mean = np.ascontiguousarray(self._initial_mean, dtype="float64")
+        cfg.potential = POT_FULL_ADAPT
+        cfg.dense_cov = _lib.dptr(self._cfg_cov)
+        cfg.initial_mean = _lib.dptr(self._cfg_mean)
+        cfg.initial_weight = float(self._initial_weight)
+        cfg.adaptation_window = int(self._adaptation_window0)
+        cfg.adaptation_window_multiplier = self.adaptation_window_multiplier
+        cfg.fa_update_window = int(self._update_window)
+        return [self._cfg_cov, self._cfg_mean]
+
+    def _matrix(self, name):
+        """Device mode: a matrix of the chain's estimator state ("fa_cov", "fa_chol", "fa_fg_raw", "fa_bg_raw")."""
+        out = np.empty((self._n, self._n))
+        _lib.check(_lib.load().nuts_chain_get_vector(self._step._chain, name.encode(), _lib.dptr(out)), name)
+        return out
 
     def _factor(self):
         import scipy.linalg
@@ -356,6 +385,9 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
         self._rand = np.ascontiguousarray(scipy.linalg.solve_triangular(self._chol.T, np.eye(self._n), lower=False))
 
     def _host_reset(self):  # quadpotential.py:801-810 (adaptation_window is not reset)
+        self._chol_error = None
+        if self._device_estimator:   # the chain resets its own estimators (engine.hip, fa_reset)
+            return
         self._previous_update = 0
         self._cov = np.array(self._initial_cov, dtype="float64", copy=True)
         self._factor()
@@ -366,7 +398,7 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
         self._push()
 
     def _push(self):
-        if self._step is not None:
+        if self._step is not None and not self._device_estimator:
             lib = _lib.load()
             _lib.check(lib.nuts_chain_set_dense(self._step._chain, _lib.dptr(np.ascontiguousarray(self._cov)), _lib.dptr(self._rand)), "nuts_chain_set_dense")
 
@@ -377,6 +409,10 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
     def _host_update(self, sample, grad, tune):  # quadpotential.py:819-843
         import scipy.linalg
 
+        if self._device_estimator:
+            if self._step is None:
+                raise RuntimeError("device_estimator=True: the estimators live in the device chain (use device_estimator=False for host arrays)")
+            return
         if not tune:
             return
         delta = self._n_samples - self._previous_update
@@ -407,6 +443,8 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
     def _host_state(self):
         import copy
 
+        if self._device_estimator:
+            return None
         return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step", "_prefetch")})
 
     def _set_host_state(self, state):
@@ -437,7 +475,15 @@ class _ExpWeightedVariance:
 
 class QuadPotentialDiagAdaptExp(QuadPotential):
     """Exponentially weighted diagonal adaptation, optionally using gradients (quadpotential.py:486-579;
-    `init="jitter+adapt_diag_grad"`, mcmc.py:1895-1911).  Estimators on the host, the diagonal on the device."""
+    `init="jitter+adapt_diag_grad"`, mcmc.py:1895-1911).
+
+    Bound to a device step method the estimators live ON THE DEVICE (`NUTS_POT_DIAG_ADAPT_EXP`, kernel
+    `k_potential_update_exp`: one element-wise launch per tuning draw, every operation rounded as NumPy rounds it, so the
+    chain is bit for bit the one the host estimator below produces -- the reference-run fixture of this initialiser passes
+    unchanged) and nothing has to happen on the host between two tuning draws (`draw_many` covers tuning).  Unbound, `update`
+    runs the same estimator on host arrays (the reference's class, restated)."""
+
+    _device_estimator = True
 
     def __init__(self, n, initial_mean, initial_diag=None, *, alpha, use_grads=False, stop_adaptation=None, rng=None,
                  discard_window=50, dtype=None):
@@ -454,33 +500,52 @@ class QuadPotentialDiagAdaptExp(QuadPotential):
         self._host_reset()
 
     def _fill_config(self, cfg):
-        cfg.potential = POT_DIAG
+        cfg.potential = POT_DIAG_ADAPT_EXP
         cfg.initial_diag = _lib.dptr(self._initial_diag)
         cfg.initial_weight = 0.0
+        cfg.discard_window = int(self._discard_window)
+        cfg.exp_alpha = float(self._alpha)
+        cfg.exp_stop_adaptation = float(self._stop_adaptation)
+        cfg.exp_use_grads = int(bool(self._use_grads))
         return [self._initial_diag]
 
+    # host mirror (unbound use: `update` on NumPy arrays) ------------------------------------------------------------
     def _host_reset(self):
-        self._hvar = np.array(self._initial_diag, copy=True)
-        self._hstds = np.sqrt(self._initial_diag)
-        self._hinv_stds = 1.0 / self._hstds
+        self._h_var = np.array(self._initial_diag, copy=True)
+        self._h_stds = np.sqrt(self._initial_diag)
+        self._h_inv_stds = 1.0 / self._h_stds
         self._variance_estimator = None
         self._variance_estimator_grad = None
-        self._n_samples_host = 0
-        self._push()
+        self._h_n_samples = 0
 
-    def _push(self):
+    @property
+    def _hvar(self):
+        return self._vec("var") if self._step is not None else self._h_var
+
+    @property
+    def _hstds(self):
+        return self._vec("stds") if self._step is not None else self._h_stds
+
+    @property
+    def _hinv_stds(self):
+        return self._vec("inv_stds") if self._step is not None else self._h_inv_stds
+
+    @property
+    def _n_samples_host(self):
+        return int(self._step._scalar("n_samples")) if self._step is not None else self._h_n_samples
+
+    def _host_update(self, sample, grad, tune):
+        """Called by the step method after every device transition: the device has already updated its estimators
+        (engine.hip, potential_update).  Unbound: the host estimator."""
+        if self._step is None:
+            self.update(sample, grad, tune)
+
+    def update(self, sample, grad, tune):  # quadpotential.py:534-569
         if self._step is not None:
-            lib = _lib.load()
-            _lib.check(lib.nuts_chain_set_diag(self._step._chain, _lib.dptr(self._hvar), _lib.dptr(self._hstds), _lib.dptr(self._hinv_stds)), "nuts_chain_set_diag")
-
-    def _bind(self, step):
-        super()._bind(step)
-        self._push()
-
-    def _host_update(self, sample, grad, tune):  # quadpotential.py:534-569
-        if not (tune and self._n_samples_host < self._stop_adaptation):
+            raise RuntimeError("this potential is bound to a device chain, which updates it itself")
+        if not (tune and self._h_n_samples < self._stop_adaptation):
             return
-        k = self._n_samples_host
+        k = self._h_n_samples
         if k > self._discard_window:
             self._variance_estimator.add_sample(sample)
             if self._use_grads:
@@ -492,25 +557,13 @@ class QuadPotentialDiagAdaptExp(QuadPotential):
         if k > 2 * self._discard_window:
             if self._use_grads:  # quadpotential.py:571-579
                 updated = np.sqrt(self._variance_estimator.current_variance() / self._variance_estimator_grad.current_variance())
-                self._hvar[:] = updated
+                self._h_var[:] = updated
             else:  # quadpotential.py:328-333
-                self._variance_estimator.current_variance(out=self._hvar)
-                self._hvar = np.clip(self._hvar, 1e-12, 1e12)
-            self._hstds = np.sqrt(self._hvar)
-            self._hinv_stds = 1.0 / self._hstds
-            self._push()
-        self._n_samples_host += 1
-
-    def _host_state(self):
-        import copy
-
-        return copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("rng", "_step", "_prefetch")})
-
-    def _set_host_state(self, state):
-        import copy
-
-        self.__dict__.update(copy.deepcopy(state))
-        self._push()
+                self._variance_estimator.current_variance(out=self._h_var)
+                self._h_var = np.clip(self._h_var, 1e-12, 1e12)
+            self._h_stds = np.sqrt(self._h_var)
+            self._h_inv_stds = 1.0 / self._h_stds
+        self._h_n_samples += 1
 
 
 def quad_potential(C, is_cov, rng=None):

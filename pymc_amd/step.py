@@ -473,7 +473,8 @@ class NUTS(_DeviceHMCBase):
             return not self.tune
         from pymc_amd.quadpotential import QuadPotential
 
-        host_adapted = type(self.potential)._host_update is not QuadPotential._host_update
+        host_adapted = (type(self.potential)._host_update is not QuadPotential._host_update
+                        and not getattr(self.potential, "_device_estimator", False))
         return (not self.tune) or not host_adapted
 
     def draw_many(self, point: PointType, K: int):
