@@ -247,9 +247,11 @@ def sample(
     device: Optional[int] = None,
     cores: Optional[int] = None,
     mp_ctx: Optional[str] = None,
+    return_multitrace: bool = False,
     **step_kwargs,
 ):
-    """Reduced `pm.sample` (mcmc.py:620-1190) returning raw arrays.
+    """Reduced `pm.sample` (mcmc.py:620-1190) returning raw arrays (and, with ``return_multitrace=True``, the reference's
+    `MultiTrace` of `return_inferencedata=False` under ``result["trace"]``, pymc_amd/backends.py).
 
     Returns a dict with ``draws`` (chains, draws, n), ``stats`` (per chain list of
     per-draw dicts), ``point_map_info`` and timing.  Under torch.distributed every
@@ -380,6 +382,10 @@ def sample(
     }
     if gather and world > 1:
         result = gather_trace(result, chains, rank, world, device)
+    if return_multitrace and (rank == 0 or not (gather and world > 1)):
+        from pymc_amd.backends import multitrace_from_result
+
+        result["trace"] = multitrace_from_result(spec, result)
     return result
 
 

@@ -142,8 +142,8 @@ def test_fit_matches_the_oracle_fit_and_the_closed_form_posterior():
 
 @pytest.mark.gpu
 def test_configs3_shape_runs():
-    """BASELINE configs[3] at a quarter of its rows (250 k x 512, X = 1 GB) keeps the test short; `bench.py --workload advi` times the
-    full 1 M x 512."""
+    """BASELINE configs[3] at a quarter of its rows (250 k x 512, X = 1 GB) keeps the test short (the full 1 M x 512 is 4 GB of X: it
+    runs, `models.glm()` builds it, but it is a parity-test configuration, not a bench line)."""
     m = models.glm(N=250_000, P=512, batch_size=1024, seed=4)
     approx = fit(300, model=m, random_seed=2)
     assert approx.hist.shape == (300,) and np.all(np.isfinite(approx.hist))

@@ -1,0 +1,146 @@
+"""`pymc_amd.backends`: the `NDArray` / `MultiTrace` surface of the reference
+(pymc/backends/ndarray.py:27-203, base.py:248-650), exercised the way tests/backends/fixtures.py exercises the reference's
+backends -- shapes, burn / thin, slicing, points, sampler statistics, `combine` / `squeeze`, continuing a chain, an
+interrupted run -- plus the device-specific batch recording against draw-by-draw recording."""
+
+import numpy as np
+import pytest
+
+from pymc_amd import models
+from pymc_amd.backends import MultiTrace, NDArray, _choose_chains, multitrace_from_result
+from pymc_amd.trace import backward
+
+SVARS = [{"depth": np.int64, "energy": np.float64, "diverging": bool, "warning": object}]
+
+
+def _spec():
+    return models.eight_schools()          # mu, tau (log-transformed), eta[8]
+
+
+def _points(spec, K, seed):
+    rng = np.random.default_rng(seed)
+    pos = rng.normal(size=(K, spec.n))
+    stats = [[{"depth": int(rng.integers(1, 6)), "energy": float(rng.normal()), "diverging": bool(k % 7 == 0), "warning": None}] for k in range(K)]
+    return pos, stats
+
+
+def _mu(spec):
+    return next(v.offset for v in spec.vars if v.name == "mu")
+
+
+def _point(spec, row):
+    return {v.value_name: row[v.offset : v.offset + v.size].reshape(v.shape) for v in spec.vars}
+
+
+def test_record_and_record_batch_agree_and_layout_follows_the_reference():
+    spec = _spec()
+    pos, stats = _points(spec, 30, 1)
+    a, b = NDArray(model=spec), NDArray(model=spec)
+    a.setup(30, 0, SVARS); b.setup(30, 0, SVARS)
+    for k in range(30):
+        a.record(_point(spec, pos[k]), stats[k], in_warmup=False)
+    b.record_batch(pos[:17], stats[:17]); b.record_batch(pos[17:], stats[17:])
+    a.close(); b.close()
+    assert len(a) == len(b) == 30
+    tau = next(v for v in spec.vars if v.name == "tau")
+    assert a.varnames == b.varnames and "tau" in a.varnames and tau.value_name in a.varnames     # base.py:183-191: both views
+    for nm in a.varnames:
+        np.testing.assert_array_equal(a.get_values(nm), b.get_values(nm))
+    np.testing.assert_array_equal(a.get_values("tau"), np.exp(a.get_values(tau.value_name)))
+    np.testing.assert_array_equal(a.get_values("tau"), backward(tau, pos[:, tau.offset]))
+    assert a.get_values("eta").shape == (30, 8) and a.get_values("mu").shape == (30,)
+    for k in ("depth", "energy", "diverging"):
+        np.testing.assert_array_equal(a.get_sampler_stats(k), b.get_sampler_stats(k))
+    assert a.get_sampler_stats("depth").dtype == np.int64 and a.get_sampler_stats("diverging").dtype == bool
+    assert a.stat_names == {"depth", "energy", "diverging", "warning"}
+    with pytest.raises(KeyError):
+        a.get_sampler_stats("nope")
+
+
+def test_burn_thin_slice_point_like_the_reference_fixtures():
+    spec = _spec()
+    pos, stats = _points(spec, 40, 2)
+    t = NDArray(model=spec)
+    t.setup(40, 3, SVARS)
+    t.record_batch(pos, stats)
+    np.testing.assert_array_equal(t.get_values("mu", burn=5, thin=3), pos[5::3, _mu(spec)])
+    s = t[10:30:2]
+    assert isinstance(s, NDArray) and len(s) == 10 and s.chain == 3
+    np.testing.assert_array_equal(s.get_values("mu"), pos[10:30:2, _mu(spec)])
+    np.testing.assert_array_equal(s.get_sampler_stats("energy"), t.get_sampler_stats("energy")[10:30:2])
+    p = t.point(7)
+    assert set(p) == set(t.varnames) and p["mu"] == pos[7, _mu(spec)] and p["eta"].shape == (8,)
+    assert t[-1]["mu"] == pos[-1, _mu(spec)]
+    with pytest.raises(ValueError):
+        t["mu"]
+    assert [pt["mu"] for pt in t][:3] == list(pos[:3, _mu(spec)])
+
+
+def test_continued_chain_and_interrupted_run():
+    spec = _spec()
+    pos, stats = _points(spec, 25, 3)
+    t = NDArray(model=spec)
+    t.setup(10, 0, SVARS)
+    t.record_batch(pos[:10], stats[:10])
+    t.setup(20, 0, SVARS)                      # ndarray.py:68-75: the chain is continued, the arrays grow
+    t.record_batch(pos[10:25], stats[10:25])   # ... and the run is interrupted 5 draws early
+    assert len(t) == 25 and t.samples["mu"].shape[0] == 30
+    t.close()
+    assert t.samples["mu"].shape[0] == 25 and t.get_sampler_stats("depth").shape == (25,)
+    np.testing.assert_array_equal(t.get_values("mu"), pos[:25, _mu(spec)])
+    with pytest.raises(ValueError, match="can't change"):
+        t.setup(5, 0, [{"depth": np.int64}])
+
+
+def test_multitrace_accessors():
+    spec = _spec()
+    chains = []
+    for c in range(3):
+        pos, stats = _points(spec, 20, 10 + c)
+        t = NDArray(model=spec)
+        t.setup(20, c, SVARS)
+        t.record_batch(pos, stats)
+        chains.append((t, pos))
+    mt = MultiTrace([t for t, _ in chains])
+    assert mt.nchains == 3 and mt.chains == [0, 1, 2] and len(mt) == 20 and "eta" in mt.varnames
+    assert mt.get_values("mu").shape == (60,)                                        # combine=True concatenates the chains
+    sep = mt.get_values("mu", combine=False)
+    assert isinstance(sep, list) and len(sep) == 3 and np.array_equal(sep[1], chains[1][1][:, _mu(spec)])
+    assert np.array_equal(mt.get_values("mu", chains=2, combine=False), chains[2][1][:, _mu(spec)])   # squeeze: a single array
+    assert isinstance(mt.get_values("mu", chains=[2], combine=False, squeeze=False), list)
+    assert mt.get_values("eta", burn=4, thin=2).shape == (24, 8)
+    assert np.array_equal(mt["mu"], mt.get_values("mu")) and np.array_equal(mt.mu, mt.get_values("mu"))
+    assert np.array_equal(mt["mu", 5::2], mt.get_values("mu", burn=5, thin=2))
+    assert mt.get_sampler_stats("depth").shape == (60,) and np.array_equal(mt.depth, mt.get_sampler_stats("depth"))
+    assert mt.point(3, chain=1)["mu"] == chains[1][1][3, _mu(spec)] and mt[3]["mu"] == chains[2][1][3, _mu(spec)]   # highest chain by default
+    sl = mt[5:15]
+    assert isinstance(sl, MultiTrace) and len(sl) == 10 and sl.nchains == 3
+    assert len(list(mt.points())) == 60
+    with pytest.raises(KeyError):
+        mt["nope"]
+    with pytest.raises(AttributeError):
+        mt.nope
+    with pytest.raises(ValueError, match="unique"):
+        MultiTrace([chains[0][0], chains[0][0]])
+
+
+def test_choose_chains_after_an_interruption():
+    class T:
+        def __init__(self, n): self.n = n
+        def __len__(self): return self.n
+    traces = [T(110), T(150), T(20), T(140)]
+    chosen, length = _choose_chains(traces, 10)          # base.py:622-650: maximise chains x shortest length
+    assert sorted(len(t) for t in chosen) == [110, 140, 150] and length == 110
+    with pytest.raises(ValueError):
+        _choose_chains([T(5)], 10)
+
+
+def test_multitrace_from_a_sampling_result_shape():
+    spec = _spec()
+    pos0, st0 = _points(spec, 12, 4)
+    pos1, st1 = _points(spec, 12, 5)
+    result = {"draws": np.stack([pos0, pos1]), "stats": [[s[0] for s in st0], [s[0] for s in st1]]}
+    mt = multitrace_from_result(spec, result)
+    assert mt.nchains == 2 and len(mt) == 12
+    np.testing.assert_array_equal(mt.get_values("mu", combine=False)[1], pos1[:, _mu(spec)])
+    assert mt.get_sampler_stats("depth", combine=False)[0].tolist() == [s[0]["depth"] for s in st0]
