@@ -17,7 +17,7 @@ imports pytensor and looks at nothing but
 
 -- and is exercised on stub graphs that transcribe what the reference's `logp` methods build (tests/stubgraph.py:
 continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390 HalfCauchy, :1478-1486 Exponential,
-discrete.py:351-374 Bernoulli; transforms.py:880-891 log, :1076-1088 logodds).
+:1570-1576 Laplace, :1807-1821 LogNormal, discrete.py:351-374 Bernoulli; transforms.py:880-891 log, :1076-1088 logodds).
 
 How a factor is recognised: the graph is first turned into a small expression tree (constants folded, broadcasts /
 casts / parameter checks stripped -- the device applies its own support and parameter checks), then matched against the
@@ -179,6 +179,10 @@ def _solve_const(t, c, env: Dict[str, Any]) -> bool:
                 if t[0] == "add":
                     return _solve_const(t[o], c - k, env)
                 return _solve_const(t[o], (k - c) if i == 1 else (c + k), env)
+    if t[0] == "mul" and len(t) == 3:      # k * x = c  (e.g. `log(2 * b)` with a constant b)
+        for i, o in ((1, 2), (2, 1)):
+            if not isinstance(t[i], W) and t[i][0] == "const" and float(t[i][1]) != 0.0:
+                return _solve_const(t[o], c / float(t[i][1]), env)
     return False
 
 
@@ -195,7 +199,7 @@ def unify(t, node, env: Dict[str, Any]) -> bool:
         return True
     if t[0] == "const":
         return node[0] == "const" and node[1].size == 1 and math.isclose(float(node[1].reshape(-1)[0]), float(t[1]), rel_tol=1e-12, abs_tol=1e-300)
-    if node[0] == "const" and t[0] in ("log", "neg", "sub", "add"):
+    if node[0] == "const" and t[0] in ("log", "neg", "sub", "add", "mul"):
         return _solve_const(t, node[1], env)
     if node[0] != t[0] or len(node) != len(t):
         return False
@@ -219,7 +223,7 @@ def _zsq(v, loc, scale):
     return ("pow", ("div", ("sub", v, loc), scale), K(2))
 
 
-V, MU, SG, AL, BE, P = W("value"), W("mu"), W("sigma"), W("alpha"), W("beta"), W("p")
+V, MU, SG, AL, BE, P, B = W("value"), W("mu"), W("sigma"), W("alpha"), W("beta"), W("p"), W("b")
 _CAUCHY = ("sub", ("sub", K(-math.log(math.pi)), ("log", BE)), ("log1p", _zsq(V, AL, BE)))
 # (distribution code, template, names of the wildcards in argument order) -- each the unrewritten form of the reference's logp
 TEMPLATES: List[Tuple[int, Any, Tuple[str, ...]]] = [
@@ -231,6 +235,10 @@ TEMPLATES: List[Tuple[int, Any, Tuple[str, ...]]] = [
      ("value", "beta")),                                                                                                                 # continuous.py:2383-2390
     (ms.D_EXPONENTIAL, ("switch", ("ge", V, K(0)), ("sub", ("neg", ("log", MU)), ("div", V, MU)), K(-math.inf)), ("value", "mu")),          # continuous.py:1478-1486
     (ms.D_BERNOULLI, ("switch", ("or", ("lt", V, K(0)), ("gt", V, K(1))), K(-math.inf), ("switch", V, ("log", P), ("log1p", ("neg", P)))), ("value", "p")),   # discrete.py:362-374
+    (ms.D_LAPLACE, ("sub", ("neg", ("log", ("mul", K(2), B))), ("div", ("abs", ("sub", V, MU)), B)), ("value", "mu", "b")),                   # continuous.py:1570-1576
+    (ms.D_LOGNORMAL, ("switch", ("gt", V, K(0)),
+                      ("sub", ("sub", ("sub", ("mul", K(-0.5), ("pow", ("div", ("sub", ("log", V), MU), SG), K(2))), K(0.5 * math.log(2.0 * math.pi))), ("log", SG)), ("log", V)),
+                      K(-math.inf)), ("value", "mu", "sigma")),                                                                           # continuous.py:1807-1821
 ]
 
 

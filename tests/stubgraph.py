@@ -89,7 +89,7 @@ class All:
     pass
 
 
-for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "OR", "AND", "Sigmoid"):
+for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "OR", "AND", "Sigmoid", "Abs"):
     globals()[_n] = type(_n, (), {})
 
 
@@ -123,6 +123,7 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     lt = staticmethod(lambda a, b: elemwise(LT, a, b))
     gt = staticmethod(lambda a, b: elemwise(GT, a, b))
     or_ = staticmethod(lambda a, b: elemwise(OR, a, b))
+    abs = staticmethod(lambda a: elemwise(Abs, a))
 
 
 def check_parameters(expr, *conds, msg=""):   # distributions/dist_math.py:50-74
@@ -151,6 +152,17 @@ def halfcauchy_logp(value, beta):           # distributions/continuous.py:2383-2
     res = pt.log(2) + cauchy_logp(value, 0, beta)
     res = pt.switch(value >= 0, res, -np.inf)
     return check_parameters(res, beta > 0, msg="beta > 0")
+
+
+def laplace_logp(value, mu, b):             # distributions/continuous.py:1570-1576
+    res = -pt.log(2 * b) - pt.abs(value - mu) / b
+    return check_parameters(res, b > 0, msg="b > 0")
+
+
+def lognormal_logp(value, mu, sigma):       # distributions/continuous.py:1807-1821
+    res = -0.5 * pt.pow((pt.log(value) - mu) / sigma, 2) - 0.5 * pt.log(2.0 * np.pi) - pt.log(sigma) - pt.log(value)
+    res = pt.switch(pt.gt(value, 0.0), res, -np.inf)
+    return check_parameters(res, sigma > 0, msg="sigma > 0")
 
 
 def bernoulli_logp(value, p):               # distributions/discrete.py:362-374
@@ -189,6 +201,12 @@ class StubModel:
 
     def HalfCauchy(self, name, beta=1.0, shape=()):
         return self._add(_RV(name, shape, halfcauchy_logp, (as_tensor(beta),), "log"))
+
+    def Laplace(self, name, mu=0.0, b=1.0, shape=(), observed=None):
+        return self._add(_RV(name, shape, laplace_logp, (as_tensor(mu), as_tensor(b)), None, observed))
+
+    def LogNormal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None):
+        return self._add(_RV(name, shape, lognormal_logp, (as_tensor(mu), as_tensor(sigma)), "log" if observed is None else None, observed))
 
     def Bernoulli(self, name, logit_p, observed):
         return self._add(_RV(name, np.shape(observed), bernoulli_logp, (pt.sigmoid(logit_p),), None, observed))   # discrete.py:351-352

@@ -116,3 +116,32 @@ def test_lowered_golden_model_on_the_device():
     lp0, g0 = ref_models.evaluate(ref, q)
     assert abs(lp2 - lp0) <= 1e-9 * abs(lp0) and np.max(np.abs(g2 - g0)) <= 1e-9 * np.max(np.abs(g0))
     f.close(); f2.close()
+
+
+def test_laplace_and_lognormal_lower_to_the_builder_spec():
+    """Two more `logp` bodies (continuous.py:1570-1576 Laplace, :1807-1821 LogNormal, the latter as a free, log-transformed variable
+    and as an observed one with a variable location): the lowered spec is the builder's, and the log-density agrees with SciPy."""
+    from scipy import stats
+
+    from pymc_amd.model_spec import ModelBuilder
+
+    y = np.array([0.3, -1.2, 2.5, 0.1])
+    w = np.array([0.7, 1.9, 3.2])
+    m = sg.StubModel()
+    loc = m.Normal("loc", 0.0, 2.0)
+    s = m.LogNormal("s", 0.5, 0.75)
+    m.Laplace("y", loc, 1.5, observed=y)
+    m.LogNormal("w", loc, s, observed=w)
+    spec = lower_to_spec(m)
+    b = ModelBuilder()
+    bl = b.Normal("loc", 0.0, 2.0)
+    bs = b.LogNormal("s", 0.5, 0.75)
+    b.Laplace("y", bl, 1.5, observed=y)
+    b.LogNormal("w", bl, bs, observed=w)
+    _assert_same_spec(spec, b.build())
+    q = np.array([0.4, -0.3])                       # loc, log s
+    lp, _ = ref_models.evaluate(spec, q)
+    sv = np.exp(q[1])
+    want = (stats.norm(0, 2).logpdf(q[0]) + stats.lognorm(s=0.75, scale=np.exp(0.5)).logpdf(sv) + q[1]
+            + stats.laplace(q[0], 1.5).logpdf(y).sum() + stats.lognorm(s=sv, scale=np.exp(q[0])).logpdf(w).sum())
+    assert abs(lp - want) < 1e-10
