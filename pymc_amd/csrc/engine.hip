@@ -62,7 +62,7 @@ static T* dev_upload(const T* src, size_t count) {
   return p;
 }
 
-#define SMALL_MAX_N 512   // largest model of the single-launch path (small_kernel.h: one thread per parameter)
+#define SMALL_MAX_N 1024  // largest model of the single-launch path (small_kernel.h: one thread per parameter, one workgroup)
 
 // ===========================================================================
 // model
@@ -1474,7 +1474,8 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
 // the single-launch path (small_kernel.h): one workgroup, one thread per parameter
 static void launch_small(nuts_chain* c, const ArenaDev& A, const SmallDrawArgs& a) {
   if (c->n <= 256) hipLaunchKernelGGL(k_small_draw<256>, dim3(1), dim3(256), 0, c->m->stream, c->m->md, A, a);
-  else hipLaunchKernelGGL(k_small_draw<512>, dim3(1), dim3(512), 0, c->m->stream, c->m->md, A, a);
+  else if (c->n <= 512) hipLaunchKernelGGL(k_small_draw<512>, dim3(1), dim3(512), 0, c->m->stream, c->m->md, A, a);
+  else hipLaunchKernelGGL(k_small_draw<1024>, dim3(1), dim3(1024), 0, c->m->stream, c->m->md, A, a);
 }
 
 // What the host does after a transition (nuts.py:478-489, base_hmc.py:238-282): step-size adaptation, mass-matrix update

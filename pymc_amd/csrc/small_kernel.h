@@ -2,7 +2,7 @@
 //
 // For tiny models (SURVEY.md section 7 "small-n latency": eight schools has n = 10 / 26) a leapfrog is a few
 // hundred flops; three launches per leapfrog plus a host round trip per doubling cost two orders of magnitude more
-// than the arithmetic.  When the model fits one workgroup (n <= 512, element-wise factors only, diagonal mass
+// than the arithmetic.  When the model fits one workgroup (n <= 1024, element-wise factors only, diagonal mass
 // matrix) the whole transition -- momentum refresh, start state, every doubling of the tree, proposal gather -- runs
 // inside this kernel: one thread per parameter, `__syncthreads()` instead of kernel boundaries, the control block in
 // LDS for the whole draw.  The arithmetic is the same device code the three-kernel pipeline uses (gather_element,
@@ -43,7 +43,9 @@ struct SmallDrawArgs {
   int seq, pad2;
 };
 
-// NT = threads of the one workgroup (256 or 512: one thread per parameter, so n <= 512 runs here)
+// NT = threads of the one workgroup (256, 512 or 1024: one thread per parameter, so n <= 1024 runs here; at 1024 threads the
+// register budget is 128 and the kernel spills a little -- still 20.6 us per leapfrog against 25.3 us at n = 602 and 23.8
+// against 25.2 at n = 1002, profiles/r02i_latency_regime.json)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, SmallDrawArgs a) {
   constexpr int NW = NT / WAVE;

@@ -432,7 +432,8 @@ def test_nuts_parity_eight_schools():
 def test_nuts_parity_three_kernel_pipeline_on_small_and_multi_workgroup_models(monkeypatch):
     """Small models normally take the single-launch path (small_kernel.h).  The general three-kernel pipeline must
     give the same integers: forced on eight schools and on a schools model that spans two workgroups (n = 302:
-    broadcast terms and deferred scalars across workgroups), and by default above 512 parameters (n = 602)."""
+    broadcast terms and deferred scalars across workgroups), and by default above 1024 parameters (n = 1202); n = 602 runs in
+    ONE 1024-thread workgroup."""
     monkeypatch.setenv("NUTS_SMALL_KERNEL", "0")
     _compare_runs(models.eight_schools(), tune=30, draws=10, seed=20160911, prefix=40)
     big = models.eight_schools(300)   # n = 302: two workgroups of the vector kernel (the single-launch path takes n <= 512)
@@ -441,8 +442,12 @@ def test_nuts_parity_three_kernel_pipeline_on_small_and_multi_workgroup_models(m
     _compare_runs(big, tune=15, draws=5, seed=8, prefix=20)
     monkeypatch.delenv("NUTS_SMALL_KERNEL")
     _compare_runs(big, tune=15, draws=5, seed=8, prefix=20)      # the same model in ONE 512-thread workgroup
-    bigger = models.eight_schools(600)                           # n = 602: three-kernel pipeline by default
+    bigger = models.eight_schools(600)                           # n = 602: one 1024-thread workgroup
     _compare_runs(bigger, tune=12, draws=4, seed=8, prefix=16)
+    monkeypatch.setenv("NUTS_SMALL_KERNEL", "0")
+    _compare_runs(bigger, tune=12, draws=4, seed=8, prefix=16)   # ... and the three-kernel pipeline on the same model
+    monkeypatch.delenv("NUTS_SMALL_KERNEL")
+    _compare_runs(models.eight_schools(1200), tune=5, draws=2, seed=8, prefix=7)     # n = 1202: three-kernel pipeline by default
 
 
 def test_nuts_parity_hier_logit():
