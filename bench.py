@@ -297,6 +297,18 @@ def main():
         conv = {"min_ess": min_ess, "min_ess_param_index": j, "min_ess_param": names[j], "median_ess": float(np.median(ess)),
                 "ess_5pct": float(np.percentile(ess, 5)), "rhat_max": float(np.nanmax(rh)), "rhat_max_param": names[int(np.nanargmax(rh))],
                 "rhat_of_min_ess_param": float(rh[j]), "n_params": int(spec.n), "divergences": n_div}
+        if not c3:
+            # The non-centred parametrisation SURVEY 8 prescribes leaves (mu_d, mean_g z_{g,d}) on a ridge when every group has
+            # thousands of rows: the combination the likelihood identifies, beta_bar_d = mu_d + sigma_d
+            # mean_g z_{g,d}, is reported next to the per-coordinate minimum so that the two can be told apart.
+            v = {x.name: x for x in spec.vars}
+            D_ = v["mu"].size
+            mu_ = draws[:, v["mu"].offset : v["mu"].offset + D_]
+            sg_ = np.exp(draws[:, v["sigma"].offset : v["sigma"].offset + D_])
+            zbar = draws[:, v["z"].offset : v["z"].offset + v["z"].size].reshape(len(draws), -1, D_).mean(axis=1)
+            eb = ess_bulk_many((mu_ + sg_ * zbar)[None])
+            conv["identified_combination"] = {"what": "beta_bar_d = mu_d + sigma_d * mean_g z[g, d]", "min_ess": float(eb.min()),
+                                              "median_ess": float(np.median(eb)), "corr_mu_zbar_d0": float(np.corrcoef(mu_[:, 0], zbar[:, 0])[0, 1])}
 
     vec = [dt, min_ess if ess_ok else 0.0, leap, dom_ms, float(dom_n)]
     if dist is not None:

@@ -1012,7 +1012,6 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->fa_mfma = env_int("NUTS_FA_MFMA", 1);
   if (c->cfg.fa_update_window < 1) c->cfg.fa_update_window = 1;
   if (c->dense) c->initial_diag.assign(m->md.n, 1.0);  // the diagonal vectors stay allocated (unused)
-  const double* const cfg_dense_cov = cfg->dense_cov; (void)cfg_dense_cov;
   c->cfg.dense_cov = nullptr; c->cfg.dense_rand = nullptr;
   c->adaptation_window = cfg->adaptation_window;
   ArenaDev& A = c->A;

@@ -345,7 +345,7 @@ STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_
              "energy_error", "max_energy_error", "model_logp", "step_size", "step_size_bar")
 
 
-def _run_schedule(spec, env, monkeypatch, tune, draws, seed):
+def _run_schedule(spec, env, monkeypatch, tune, draws, seed, **step_kwargs):
     from pymc_amd.sampling import sample
 
     keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL", "NUTS_GA_ONES0")
@@ -353,7 +353,8 @@ def _run_schedule(spec, env, monkeypatch, tune, draws, seed):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, discard_tuned_samples=False)
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, discard_tuned_samples=False,
+                 **step_kwargs)
     step = res["step"]
     info = (step._scalar("tree_kernel"), step._scalar("tree_launches"))
     out = (np.array(res["draws"][0]), res["stats"][0], info)
@@ -400,3 +401,25 @@ def test_cross_doubling_fold_is_a_pure_rescheduling(c2l, monkeypatch):
             for k in STAT_KEYS:
                 assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (env, k, a[k], b[k])
     print(f"tree sizes {[int(s['tree_size']) for s in s0]}")
+
+
+@pytest.mark.parametrize("case", ["divergences", "max_treedepth"])
+def test_tree_kernel_on_trees_that_end_the_hard_way(case, c2l, monkeypatch):
+    """The persistent tree kernel where a tree does not end with a U-turn at the end of a doubling: a step size large enough to
+    diverge (nuts.py:419-435: the leaf's energy error exceeds Emax, inside a doubling) and a depth limit low enough to be reached
+    (nuts.py:218-225; the row workgroups leave after the last doubling without a verdict) -- bitwise against one launch per
+    leapfrog, divergence bookkeeping and `reached_max_treedepth` included."""
+    kw = {"step_scale": 40.0, "adapt_step_size": False} if case == "divergences" else {"max_treedepth": 3, "early_max_treedepth": 2}
+    base = {"NUTS_GA_VARIANT": "32", "NUTS_ROWS_GA": "2"}
+    d0, s0, i0 = _run_schedule(c2l, {**base, "NUTS_GA_TREE": "0"}, monkeypatch, 6, 6, 5, **kw)
+    d1, s1, i1 = _run_schedule(c2l, {**base, "NUTS_GA_TREE": "1"}, monkeypatch, 6, 6, 5, **kw)
+    assert i1[0] == 1.0 and i1[1] == 12
+    assert np.array_equal(d0, d1)
+    for a, b in zip(s0, s1):
+        for k in STAT_KEYS:
+            assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (k, a[k], b[k])
+    if case == "divergences":
+        assert any(s["diverging"] for s in s1)
+    else:
+        assert any(s["reached_max_treedepth"] for s in s1[6:]) and max(int(s["depth"]) for s in s1) == 3
+    print(case, [int(s["tree_size"]) for s in s1], [bool(s["diverging"]) for s in s1])

@@ -46,3 +46,8 @@ if [[ $STAGES == *e* ]]; then
   timeout 900 python tools/ess_study.py > $OUT/ess_study_$TAG.json 2> $OUT/ess_study_$TAG.err
 fi
 tail -3 $OUT/pytest_gpu_$TAG.log 2>/dev/null; head -c 1500 $OUT/bench_$TAG.json 2>/dev/null; echo; head -24 $OUT/profile_$TAG.txt 2>/dev/null
+if [[ $STAGES == *m* ]]; then   # smoke() + the N = 2 launch of bench.py with both ranks on this one GPU (test mode of the distributed path)
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke_$TAG.log
+  NUTS_GA_TREE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --share-gpu --steps 30 --warmup 30 --cpu-leapfrogs 0 > $OUT/bench_n2_shared_$TAG.json 2> $OUT/bench_n2_shared_$TAG.err; echo "n2 rc=$?" >> $OUT/bench_n2_shared_$TAG.err
+  tail -3 $OUT/smoke_$TAG.log; head -c 600 $OUT/bench_n2_shared_$TAG.json; tail -2 $OUT/bench_n2_shared_$TAG.err
+fi
