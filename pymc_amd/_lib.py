@@ -82,6 +82,7 @@ class ModelSpecC(C.Structure):
         ("mvn_mu", C.POINTER(C.c_double)),
         ("mvn_prec", C.POINTER(C.c_double)),
         ("mvn_logdet", C.c_double),
+        ("mvn_winv", C.POINTER(C.c_double)),
     ]
 
 

@@ -184,7 +184,16 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
 #undef ROWS_BY_D
 #undef ROWS_LAUNCH
   }
-  if (md.has_mvn) {
+  if (md.has_mvn && md.mv.winv) {
+    // "cholesky" solver: delta, y = W delta, P delta = W^T y, outputs (chains on such a model do not fold the control work)
+    const MvnDev& mv = md.mv;
+    const int* abort_flag = io.mode == MODE_TREE ? &A.ctl->aborted : nullptr;
+    const dim3 gk((mv.k + 255) / 256), gmv((mv.k + (256 / WAVE) - 1) / (256 / WAVE));
+    hipLaunchKernelGGL(k_mvn_delta, gk, dim3(256), 0, m->stream, mv, A, io, j);
+    hipLaunchKernelGGL(k_dense_mv, gmv, dim3(256), 0, m->stream, mv.winv, mv.wy, mv.wy + mv.k, mv.k, (const double*)nullptr, (double*)nullptr, 0.0, abort_flag);
+    hipLaunchKernelGGL(k_dense_mv, gmv, dim3(256), 0, m->stream, mv.winv_t, mv.wy + mv.k, mv.wy + 2 * mv.k, mv.k, (const double*)nullptr, (double*)nullptr, 0.0, abort_flag);
+    hipLaunchKernelGGL(k_mvn_finish, gk, dim3(256), 0, m->stream, mv, A, io);
+  } else if (md.has_mvn) {
     const int mfold = md.has_logit ? 0 : fold;   // (the control work rides in exactly one launch)
     hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid + (mfold ? 1 : 0)), dim3(MVN_BLOCK), 0, m->stream, md, A, io, j, mfold, d, Emax,
                        max_depth, st);
@@ -649,6 +658,16 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     mv.gdense = m->keep(dev_alloc<double>(n));
     hipMemset(mv.gdense, 0, n * sizeof(double));
     mv.konst = -0.5 * mv.k * std::log(2.0 * M_PI) - s->mvn_logdet;
+    mv.winv = nullptr; mv.winv_t = nullptr; mv.wy = nullptr;
+    if (s->mvn_winv) {   // "cholesky" solver (include/nuts_mi355.h): W and W^T row-major, so that both mat-vecs read rows
+      const size_t kk = (size_t)mv.k * mv.k;
+      std::vector<double> wt(kk);
+      for (int r = 0; r < mv.k; ++r)
+        for (int cc = 0; cc < mv.k; ++cc) wt[(size_t)cc * mv.k + r] = s->mvn_winv[(size_t)r * mv.k + cc];
+      mv.winv = m->keep(dev_upload(s->mvn_winv, kk));
+      mv.winv_t = m->keep(dev_upload(wt.data(), kk));
+      mv.wy = m->keep(dev_alloc<double>(3 * (size_t)mv.k));
+    }
     m->mvn_grid = mv.k;   // one workgroup per row
     m->alg_bytes += 8 * (int64_t)mv.k * mv.k;
   }
@@ -1056,7 +1075,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->stage_dev = c->keep(dev_alloc<double>(2 * (size_t)n + 2 * (size_t)c->n_uni_cap));
   c->out_dev = c->keep(dev_alloc<double>(2 * (size_t)n));
   c->out_dev2 = c->keep(dev_alloc<double>(2 * (size_t)n + 2));
-  c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0;
+  c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0 && !(m->md.has_mvn && m->md.mv.winv);   // (the four-launch MvNormal pass has no workgroup 0 for it)
   c->spec_max = env_int("NUTS_SPEC_MAX", 10);
   c->xfold = env_int("NUTS_XFOLD", 1);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&

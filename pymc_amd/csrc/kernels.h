@@ -1101,6 +1101,25 @@ __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_matvec(ModelDev md, ArenaDev 
   }
 }
 
+// "cholesky" solver of the MvNormal node: delta = q - mu before the two mat-vecs with W = chol(cov)^-1 (k_dense_mv), and the
+// node's outputs from P delta = W^T (W delta) after them
+__global__ __launch_bounds__(256) void k_mvn_delta(MvnDev mv, ArenaDev A, EvalIO io, int j) {
+  Leaf lf; QView qv;
+  if (load_aborted(io, A)) return;
+  resolve_leaf(io, A, j, lf, qv);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < mv.k) mv.wy[i] = qv.q[mv.off + i] - mv.mu[i];
+}
+__global__ __launch_bounds__(256) void k_mvn_finish(MvnDev mv, ArenaDev A, EvalIO io) {
+  if (load_aborted(io, A)) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < mv.k) {
+    const double t = mv.wy[2 * mv.k + i];
+    mv.gdense[mv.off + i] = -t;
+    mv.rowq[i] = mv.wy[i] * t;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // dense mass matrix: energy + tree logic of one leaf (one workgroup), after k_tree_vec
 // ---------------------------------------------------------------------------

@@ -110,6 +110,9 @@ struct MvnDev {
   double konst;        // -k/2 log(2 pi) - logdet
   double* rowq;        // [k] delta_i * (P delta)_i
   double* gdense;      // [n] -(P delta)
+  // "cholesky" solver: W = chol(cov)^-1 and its transpose as full row-major matrices (zeros in the other triangle), scratch
+  const double* winv; const double* winv_t;
+  double* wy;          // [3][k]: delta, y = W delta, P delta = W^T y
 };
 
 // per-workgroup partial record written by the vector kernel, summed (in workgroup order) by the control kernel

@@ -155,6 +155,8 @@ class MvNormalNode:
     mu: np.ndarray
     cov: np.ndarray
     name: str = "x"
+    solver: str = "precision"   # "precision": one mat-vec with cov^-1 per leapfrog; "cholesky": y = L^-1 delta, L^-T y (two
+                                # mat-vecs with the inverse Cholesky factor: the conditioning of the reference's triangular solves)
 
 
 @dataclass
@@ -415,13 +417,15 @@ class ModelBuilder:
             X, np.ascontiguousarray(y, dtype="int8"), g, self._var_id(mu), self._var_id(sigma), self._var_id(z), name
         )
 
-    def MvNormal(self, name, mu, cov):
+    def MvNormal(self, name, mu, cov, solver="precision"):
+        if solver not in ("precision", "cholesky"):
+            raise ValueError("solver must be 'precision' or 'cholesky'")
         mu = np.ascontiguousarray(mu, dtype="float64")
         cov = np.ascontiguousarray(cov, dtype="float64")
         var = FreeVar(name, (len(mu),), TR_NONE, 0.0, 1.0, self.spec.n)
         self.spec.vars.append(var)
         vid = len(self.spec.vars) - 1
-        self.spec.mvnormal = MvNormalNode(vid, mu, cov, name)
+        self.spec.mvnormal = MvNormalNode(vid, mu, cov, name, solver)
         e = Expr(self, Term(Operand(OP_VAR, 0.0, vid)), var.size)
         self._names[name] = e
         return e

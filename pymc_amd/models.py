@@ -105,7 +105,7 @@ def hier_logit(G: int = 1248, D: int = 8, rows_per_group: int = 80, seed: int = 
     return m.build()
 
 
-def mvnormal(n: int = 2048, seed: int = DATA_SEED, cond_lo: float = 0.1, cond_hi: float = 10.0) -> ModelSpec:
+def mvnormal(n: int = 2048, seed: int = DATA_SEED, cond_lo: float = 0.1, cond_hi: float = 10.0, solver: str = "precision") -> ModelSpec:
     """x ~ MvNormal(0, Q diag(lambda) Q^T), lambda log-spaced in [0.1, 10] (C3)."""
     rng = np.random.default_rng(seed)
     Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
@@ -113,7 +113,7 @@ def mvnormal(n: int = 2048, seed: int = DATA_SEED, cond_lo: float = 0.1, cond_hi
     cov = (Q * lam) @ Q.T
     cov = 0.5 * (cov + cov.T)
     m = ModelBuilder()
-    m.MvNormal("x", np.zeros(n), cov)
+    m.MvNormal("x", np.zeros(n), cov, solver=solver)
     return m.build()
 
 

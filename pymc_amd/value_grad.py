@@ -72,6 +72,10 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
         s.mvn_var, s.mvn_k = mv.var, len(mu)
         s.mvn_mu, s.mvn_prec = _lib.dptr(mu), _lib.dptr(prec)
         s.mvn_logdet = float(np.log(np.diag(L)).sum())
+        if getattr(mv, "solver", "precision") == "cholesky":
+            winv = np.ascontiguousarray(np.tril(scipy.linalg.solve_triangular(L, np.eye(len(mu)), lower=True)))
+            keep.append(winv)
+            s.mvn_winv = _lib.dptr(winv)
     return s, keep
 
 
