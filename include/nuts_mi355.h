@@ -27,6 +27,7 @@ extern "C" {
 #define NUTS_E_ARG 2
 #define NUTS_E_HIP 3
 #define NUTS_E_LINALG 4
+#define NUTS_E_CALLBACK 5 /* a host-potential callback returned non-zero (the caller knows why: it owns the callback) */
 
 /* ---- model spec: what `Model.logp_dlogp_function` (pymc/model/core.py:464-529)
  * compiles from the PyTensor graph, restated as a struct-of-arrays IR. -------- */
@@ -169,7 +170,13 @@ enum { NUTS_POT_DIAG_ADAPT = 0, NUTS_POT_DIAG = 1, NUTS_POT_FULL = 2,
        /* QuadPotentialFullAdapt (quadpotential.py:748-852) with both `_WeightedCovariance` estimators, the covariance in use and
         * its Cholesky factor in HBM (csrc/dense_adapt.h): dense_cov = initial covariance, initial_mean, initial_weight,
         * adaptation_window, adaptation_window_multiplier, fa_update_window.  velocity = cov p, random = solve(chol^T, z). */
-       NUTS_POT_FULL_ADAPT = 4 };
+       NUTS_POT_FULL_ADAPT = 4,
+       /* A potential the HOST owns -- `NUTS(potential=<a user's subclass of QuadPotential>)`, the contract of
+        * tests/step_methods/hmc/test_quadpotential.py:138-158: `velocity`, `energy`, `velocity_energy` are called back where the
+        * reference's integrator calls them (integration.py:72-73,121,134), `random()` is what the caller passes as `normals`.
+        * Logp/gradient, the kicks, the tree and the acceptance arithmetic stay on the device; each leapfrog pays two stream
+        * synchronisations and 4 n doubles over PCIe.  nuts_chain_set_host_potential() must be called before the first draw. */
+       NUTS_POT_HOST = 5 };
 
 typedef struct {
   /* BaseHMC.__init__ (pymc/step_methods/hmc/base_hmc.py:82-187) */
@@ -241,6 +248,7 @@ int nuts_chain_set_iter_count(nuts_chain *c, int64_t iter_count);
  *   q0        [n]  current position
  *   normals   [n]  standard normals for `potential.random()` (quadpotential.py:323-326);
  *                  the host owns the NumPy stream so draws are seed-identical
+ *                  (NUTS_POT_HOST chains: the momentum `potential.random()` returned, taken as it is)
  *   uniforms  [n_uniforms] pre-drawn `step.rng.random()` values; the device
  *                  consumes a prefix, stats->n_uniforms_consumed says how many
  *   q_out     [n]  new position;  grad_out [n] its gradient (may be NULL)
@@ -302,6 +310,18 @@ int nuts_chain_get_vector(nuts_chain *c, const char *name, double *out /* [n] */
  *   nuts_chain_set_diag : var, stds, inv_stds [n],                     chain created with NUTS_POT_DIAG        */
 int nuts_chain_set_dense(nuts_chain *c, const double *cov, const double *rand);
 int nuts_chain_set_diag(nuts_chain *c, const double *var, const double *stds, const double *inv_stds);
+
+/* Callbacks of a NUTS_POT_HOST chain, one per abstract method of `QuadPotential` the integrator uses
+ * (quadpotential.py:133-152); `p`, `v` are host arrays of n doubles owned by the engine, valid during the call; a
+ * non-zero return aborts the draw with NUTS_E_CALLBACK.
+ *   velocity        : potential.velocity(p, out=v_out)                    integration.py:72,121
+ *   energy          : *kinetic_out = potential.energy(p, velocity=v)      integration.py:73   (start state of a draw)
+ *   velocity_energy : *kinetic_out = potential.velocity_energy(p, v_out)  integration.py:134  (every new leaf) */
+typedef int (*nuts_velocity_fn)(void *user, int32_t n, const double *p, double *v_out);
+typedef int (*nuts_energy_fn)(void *user, int32_t n, const double *p, const double *v, double *kinetic_out);
+typedef int (*nuts_velocity_energy_fn)(void *user, int32_t n, const double *p, double *v_out, double *kinetic_out);
+int nuts_chain_set_host_potential(nuts_chain *c, nuts_velocity_fn velocity, nuts_energy_fn energy,
+                                  nuts_velocity_energy_fn velocity_energy, void *user);
 
 /* Pooled adaptation (opt-in, NOT reference behaviour):
  * export/import the foreground+background Welford partials as

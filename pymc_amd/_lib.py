@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnuts_mi355.so")
 
-NUTS_OK, NUTS_E_BAD_ENERGY, NUTS_E_ARG, NUTS_E_HIP, NUTS_E_LINALG = 0, 1, 2, 3, 4
+NUTS_OK, NUTS_E_BAD_ENERGY, NUTS_E_ARG, NUTS_E_HIP, NUTS_E_LINALG, NUTS_E_CALLBACK = 0, 1, 2, 3, 4, 5
 
 
 class EngineError(RuntimeError):
@@ -173,6 +173,11 @@ class AdviConfig(C.Structure):
 _PD = C.POINTER(C.c_double)
 _VP = C.c_void_p
 
+# callbacks of a host-owned potential (NUTS_POT_HOST; include/nuts_mi355.h)
+VelocityFn = C.CFUNCTYPE(C.c_int, _VP, C.c_int32, _PD, _PD)
+EnergyFn = C.CFUNCTYPE(C.c_int, _VP, C.c_int32, _PD, _PD, _PD)
+VelocityEnergyFn = C.CFUNCTYPE(C.c_int, _VP, C.c_int32, _PD, _PD, _PD)
+
 # every symbol include/nuts_mi355.h declares: (restype, argtypes)
 SYMBOLS = {
     "nuts_device_count": (C.c_int, []),
@@ -205,6 +210,7 @@ SYMBOLS = {
     "nuts_chain_get_vector": (C.c_int, [_VP, C.c_char_p, _PD]),
     "nuts_chain_set_dense": (C.c_int, [_VP, _PD, _PD]),
     "nuts_chain_set_diag": (C.c_int, [_VP, _PD, _PD, _PD]),
+    "nuts_chain_set_host_potential": (C.c_int, [_VP, VelocityFn, EnergyFn, VelocityEnergyFn, _VP]),
     "nuts_chain_welford_export": (C.c_int, [_VP, _VP]),
     "nuts_chain_welford_import": (C.c_int, [_VP, _VP]),
     "nuts_chain_set_log_step_bar": (C.c_int, [_VP, C.c_double, C.c_double]),

@@ -833,6 +833,14 @@ struct nuts_chain {
   double *var = nullptr, *stds = nullptr, *inv_stds = nullptr;
   double *dense_C = nullptr, *dense_W = nullptr;   // NUTS_POT_FULL: velocity = C p, random = W z
   int dense = 0, mv_grid = 0;
+  // NUTS_POT_HOST: the potential's methods are callbacks into the caller (nuts_chain_set_host_potential)
+  int host_pot = 0, cb_err = 0;
+  nuts_velocity_fn hp_velocity = nullptr;
+  nuts_energy_fn hp_energy = nullptr;
+  nuts_velocity_energy_fn hp_velocity_energy = nullptr;
+  void* hp_user = nullptr;
+  std::vector<double> hp_p, hp_v;
+  double* kin_user_dev = nullptr;
   // NUTS_POT_FULL_ADAPT (dense_adapt.h): estimators, factor in use (fa_L), factorisation workspace, counters
   int full_adapt = 0, fa_mfma = 1;
   double *fa_L = nullptr, *fa_Lw = nullptr, *fa_fg_mean = nullptr, *fa_fg_raw = nullptr, *fa_bg_mean = nullptr, *fa_bg_raw = nullptr;
@@ -1006,14 +1014,12 @@ static int potential_reset(nuts_chain* c) {  // quadpotential.py:297-306
 
 extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config* cfg) {
   if (!m || !cfg) { g_err = "null argument"; return nullptr; }
-  if (cfg->potential != NUTS_POT_DIAG_ADAPT && cfg->potential != NUTS_POT_DIAG && cfg->potential != NUTS_POT_FULL &&
-      cfg->potential != NUTS_POT_DIAG_ADAPT_EXP && cfg->potential != NUTS_POT_FULL_ADAPT) {
-    g_err = "potential kind not implemented on device (adaptive dense potentials are a later round)"; return nullptr;
+  if (cfg->potential < NUTS_POT_DIAG_ADAPT || cfg->potential > NUTS_POT_HOST) { g_err = "unknown potential kind"; return nullptr;
   }
   if (cfg->potential == NUTS_POT_FULL && (!cfg->dense_cov || !cfg->dense_rand)) { g_err = "dense potential needs dense_cov and dense_rand"; return nullptr; }
   if (cfg->potential == NUTS_POT_FULL_ADAPT && !cfg->dense_cov) { g_err = "NUTS_POT_FULL_ADAPT needs dense_cov (the initial covariance)"; return nullptr; }
   if (cfg->max_treedepth < 1 || cfg->max_treedepth > MAX_LEVELS - 1) { g_err = "max_treedepth out of range (1..11)"; return nullptr; }
-  if ((cfg->potential == NUTS_POT_FULL || cfg->potential == NUTS_POT_FULL_ADAPT) && m->md.lg.ga) {
+  if ((cfg->potential == NUTS_POT_FULL || cfg->potential == NUTS_POT_FULL_ADAPT || cfg->potential == NUTS_POT_HOST) && m->md.lg.ga) {
     g_err = "a dense mass matrix needs the span-partitioned row pass: create the model with NUTS_ROWS_NO_GROUP_ALIGNED";
     return nullptr;
   }
@@ -1026,7 +1032,9 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   if (cfg->initial_diag) c->initial_diag.assign(cfg->initial_diag, cfg->initial_diag + n);
   else if (cfg->potential == NUTS_POT_DIAG_ADAPT) c->cfg.initial_weight = 1;  // quadpotential.py:280-282
   c->cfg.initial_mean = nullptr; c->cfg.initial_diag = nullptr;
-  c->dense = cfg->potential == NUTS_POT_FULL || cfg->potential == NUTS_POT_FULL_ADAPT;
+  c->host_pot = cfg->potential == NUTS_POT_HOST;
+  // (a host potential runs the dense schedule: the velocity is produced BETWEEN kernels, there by a mat-vec, here by the callback)
+  c->dense = cfg->potential == NUTS_POT_FULL || cfg->potential == NUTS_POT_FULL_ADAPT || c->host_pot;
   c->full_adapt = cfg->potential == NUTS_POT_FULL_ADAPT;
   c->fa_mfma = env_int("NUTS_FA_MFMA", 1);
   if (c->cfg.fa_update_window < 1) c->cfg.fa_update_window = 1;
@@ -1066,6 +1074,10 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
     c->fa_scratch = c->keep(dev_alloc<double>(4 * (size_t)n)); c->fa_rhs = c->keep(dev_alloc<double>(n));
     c->fa_fail = c->keep(dev_alloc<int>(2));
     c->mv_grid = (n + (256 / WAVE) - 1) / (256 / WAVE);
+  } else if (c->host_pot) {
+    c->hp_p.assign(n, 0.0); c->hp_v.assign(n, 0.0);
+    c->kin_user_dev = c->keep(dev_alloc<double>(1));
+    A.kin_user = c->kin_user_dev;
   } else if (c->dense) {
     c->dense_C = c->keep(dev_upload(cfg->dense_cov, (size_t)n * n));
     c->dense_W = c->keep(dev_upload(cfg->dense_rand, (size_t)n * n));
@@ -1079,7 +1091,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->spec_max = env_int("NUTS_SPEC_MAX", 10);
   c->xfold = env_int("NUTS_XFOLD", 1);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
-             cfg->potential != NUTS_POT_FULL && cfg->potential != NUTS_POT_FULL_ADAPT;
+             !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
   A.log_uniforms = A.uniforms + c->n_uni_cap;
@@ -1210,9 +1222,62 @@ static int ensure_logs(nuts_chain* c, int upto) {
   return NUTS_OK;
 }
 
+// velocity of a chain whose potential is not diagonal, y = velocity(x) for device vectors x, y (and q_out = q_in + eps y when
+// given: the first half of a leapfrog, integration.py:121-127).  Dense matrices: one mat-vec launch.  Host potentials
+// (NUTS_POT_HOST): the stream is drained, x goes to the host, the caller's method runs, y comes back -- `site` says which of the
+// reference's three call sites this is, because `energy` / `velocity_energy` also return the kinetic energy the next control
+// kernel must use (kernels.h, ArenaDev.kin_user).  Errors are parked in c->cb_err (the callers queue launches and cannot return).
+enum { VEL_ONLY = 0, VEL_START = 1, VEL_LEAF = 2 };
+static void dense_velocity(nuts_chain* c, const double* x, double* y, const double* q_in, double* q_out, double eps, const int* abort_flag,
+                           int site) {
+  const int n = c->n;
+  hipStream_t s = c->m->stream;
+  if (!c->host_pot) {
+    hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, x, y, n, q_in, q_out, eps, abort_flag);
+    return;
+  }
+  if (c->cb_err) return;
+  auto hip_failed = [&](hipError_t e) {
+    if (e == hipSuccess) return false;
+    g_err = std::string("host potential: ") + hipGetErrorString(e); c->cb_err = NUTS_E_HIP;
+    return true;
+  };
+  if (hip_failed(hipStreamSynchronize(s))) return;
+  if (abort_flag) {   // the tree already ended inside this doubling: the remaining leaves only drain, the caller's code is not run for them
+    int ab = 0;
+    if (hip_failed(hipMemcpy(&ab, abort_flag, sizeof(int), hipMemcpyDeviceToHost))) return;
+    if (ab) return;
+  }
+  if (hip_failed(hipMemcpy(c->hp_p.data(), x, n * sizeof(double), hipMemcpyDeviceToHost))) return;
+  double kin = 0.0;
+  int rc;
+  if (site == VEL_LEAF) rc = c->hp_velocity_energy(c->hp_user, n, c->hp_p.data(), c->hp_v.data(), &kin);
+  else {
+    rc = c->hp_velocity(c->hp_user, n, c->hp_p.data(), c->hp_v.data());
+    if (!rc && site == VEL_START) rc = c->hp_energy(c->hp_user, n, c->hp_p.data(), c->hp_v.data(), &kin);
+  }
+  if (rc) { g_err = "host potential: a callback reported an error"; c->cb_err = NUTS_E_CALLBACK; return; }
+  if (hip_failed(hipMemcpy(y, c->hp_v.data(), n * sizeof(double), hipMemcpyHostToDevice))) return;
+  if (site != VEL_ONLY && hip_failed(hipMemcpy(c->kin_user_dev, &kin, sizeof(double), hipMemcpyHostToDevice))) return;
+  if (q_out) hipLaunchKernelGGL(k_host_pot_drift, dim3((n + 255) / 256), dim3(256), 0, s, q_in, (const double*)y, q_out, eps, n);
+}
+
+// a failed host-potential callback: whatever was queued behind it is drained, the error goes to the caller
+static int host_pot_error(nuts_chain* c) {
+  const int rc = c->cb_err;
+  c->cb_err = 0;
+  (void)hipStreamSynchronize(c->m->stream);
+  c->cache_ok = false;
+  return rc;
+}
+
 static int draw_begin(nuts_chain* c, const double* q0, const double* normals, const double* uniforms, int n_uniforms,
                       double step_size, int max_depth, bool p_exact, int dir_forced, bool allow_cache = false) {
   const int n = c->n;
+  if (c->host_pot) {
+    if (!c->hp_velocity) { g_err = "NUTS_POT_HOST chain: nuts_chain_set_host_potential has not been called"; return NUTS_E_ARG; }
+    p_exact = true;   // `normals` IS potential.random()
+  }
   // the usual case inside a chain: q0 is bit for bit the proposal this chain returned last time, whose gradient and
   // logp are still on the device -- the model pass at q0 would reproduce exactly those numbers
   const bool cached = allow_cache && c->cache_ok && c->cache_epoch == c->m->data_epoch && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
@@ -1247,8 +1312,8 @@ static int draw_begin(nuts_chain* c, const double* q0, const double* normals, co
     else if (c->full_adapt) fa_random(c, c->stage_dev + n, A.P);
     else hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_W, c->stage_dev + n, A.P, n, (const double*)nullptr,
                             (double*)nullptr, 0.0, (const int*)nullptr);
-    hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P, A.V, n, (const double*)nullptr, (double*)nullptr, 0.0,
-                       (const int*)nullptr);
+    dense_velocity(c, A.P, A.V, nullptr, nullptr, 0.0, nullptr, VEL_START);
+    if (c->cb_err) return host_pot_error(c);
   }
   hipLaunchKernelGGL(k_draw_start, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, c->stage_dev + n,
                      p_exact ? (const double*)(c->stage_dev + n) : (const double*)nullptr, c->kin_part,
@@ -1320,8 +1385,7 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   }
   if (io.explicit_pre) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
   if (c->dense)   // v = C p_half ; q' = q + eps v   (integration.py:121-127 with a dense velocity)
-    hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, A.Q + so, A.Q + d_o, gm.eps,
-                       abort_flag);
+    dense_velocity(c, A.P + d_o, A.V + d_o, A.Q + so, A.Q + d_o, gm.eps, abort_flag, VEL_ONLY);
   if (io.lean && foldable) {
     // folded control (kernels.h): the control work of leaf j-1 rides in workgroup 0 of this leaf's row pass; only the
     // last leaf of the doubling (of the fixed-length trajectory) -- whose result the host waits for -- gets a control
@@ -1352,8 +1416,7 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
   else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
   if (c->dense) {   // v' = C p', then the tree work on the stored (p', v')
-    hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_C, A.P + d_o, A.V + d_o, A.n, (const double*)nullptr,
-                       (double*)nullptr, 0.0, abort_flag);
+    dense_velocity(c, A.P + d_o, A.V + d_o, nullptr, nullptr, 0.0, abort_flag, VEL_LEAF);
     const dim3 grid(m->md.nblk);
     switch (m->ept) {
       case 1: hipLaunchKernelGGL(k_tree_vec<1>, grid, dim3(VEC_THREADS), 0, s, m->md, A, io, j, d); break;
@@ -1428,7 +1491,8 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
     r.eps = dir > 0 ? step_size : -step_size;
     return r;
   };
-  const int spec = std::min(c->spec_max, c->last_depth - 1);
+  // (a host potential is called back leaf by leaf: nothing is queued ahead of a status it has not seen)
+  const int spec = c->host_pot ? 0 : std::min(c->spec_max, c->last_depth - 1);
   auto enqueue_doubling = [&](const Geometry& g, int d) {
     const int nleaf = 1 << d;
     ensure_logs(c, (2 << d) + d + 1);   // this doubling reads uniform indices < 2^(d+1) + d + 1
@@ -1465,6 +1529,7 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
       ahead_seq = enqueue_doubling(ahead, d + 1);
     } else ahead_seq = 0;
     flush_pending(seq);
+    if (c->cb_err) return host_pot_error(c);
     const auto tw0 = clk::now();
     rc = wait_status(c, seq, &flags);
     c->t_wait += std::chrono::duration<double>(clk::now() - tw0).count();
@@ -1781,6 +1846,7 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
 extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const double* normals, const double* uniforms,
                                     int32_t n_uniforms, int32_t K, double* q_out, nuts_draw_stats* stats, int32_t* n_done) {
   if (!c || !q0 || !normals || !uniforms || !q_out || !stats || !n_done || K <= 0) { g_err = "null argument"; return NUTS_E_ARG; }
+  if (c->host_pot) { g_err = "nuts_chain_draw_many: a host potential is consulted between draws (random, update): one nuts_chain_draw per transition"; return NUTS_E_ARG; }
   if (!c->small) return draw_many_general(c, q0, normals, uniforms, n_uniforms, K, q_out, stats, n_done);
   if (c->tune) { g_err = "nuts_chain_draw_many: the chain is still tuning (the single-launch batch has no adaptation between its draws)"; return NUTS_E_ARG; }
   using clk = std::chrono::steady_clock;
@@ -1917,6 +1983,7 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   HIPCHK(hipMemcpyAsync(start_keep + n + 1, A.LOGP, sizeof(double), hipMemcpyDeviceToDevice, s));
   const Geometry gm{+1, 0, 0, 0, step_size};
   for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1, 0, n_steps);
+  if (c->cb_err) return host_pot_error(c);
   std::vector<double> Eh(2), lph(2);
   const int last = n_steps & (A.S - 1);
   HIPCHK(hipMemcpyAsync(c->out_host, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1982,11 +2049,20 @@ extern "C" int nuts_chain_leapfrog_test(nuts_chain* c, const double* q, const do
   if (rc) return rc;
   const Geometry gm{dir, 0, 0, 0, eps};
   for (int j = 0; j < n_steps; ++j) enqueue_leaf(c, gm, j, 0, MODE_SIMPLE, 1, 0, n_steps);
+  if (c->cb_err) return host_pot_error(c);
   const int last = (dir * n_steps) & (A.S - 1);
   HIPCHK(hipStreamSynchronize(s));
   if (q_out) HIPCHK(hipMemcpy(q_out, A.Q + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost));
   if (p_out) HIPCHK(hipMemcpy(p_out, A.P + (int64_t)last * n, n * sizeof(double), hipMemcpyDeviceToHost));
   if (energy_out) HIPCHK(hipMemcpy(energy_out, A.E + last, sizeof(double), hipMemcpyDeviceToHost));
+  return NUTS_OK;
+}
+
+extern "C" int nuts_chain_set_host_potential(nuts_chain* c, nuts_velocity_fn velocity, nuts_energy_fn energy,
+                                             nuts_velocity_energy_fn velocity_energy, void* user) {
+  if (!c || !velocity || !energy || !velocity_energy) { g_err = "nuts_chain_set_host_potential: null argument"; return NUTS_E_ARG; }
+  if (!c->host_pot) { g_err = "nuts_chain_set_host_potential: the chain was not created with NUTS_POT_HOST"; return NUTS_E_ARG; }
+  c->hp_velocity = velocity; c->hp_energy = energy; c->hp_velocity_energy = velocity_energy; c->hp_user = user;
   return NUTS_OK;
 }
 

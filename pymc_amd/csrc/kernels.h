@@ -80,6 +80,8 @@ struct ArenaDev {
   unsigned* ga_ticket;         // arrival counters of the group-aligned row pass (rows_ga_kernel.h), reset at the end of a draw
   int ga_nticket;
   unsigned* ga_sync;           // [GA_SYNC_WORDS] progress words of the persistent tree kernel (rows_ga_tree.h), reset at the start of a draw
+  const double* kin_user;      // NUTS_POT_HOST: the kinetic energy the host's `energy` / `velocity_energy` returned for the state the
+                               // next control kernel looks at (nullptr: kinetic = p.v / 2, the dots the kernels took)
 };
 #define GA_SYNC_DONE 0         // number of block partials published since the start of the draw: leaf L is complete at (L + 1) ga_nblk
 #define GA_SYNC_CTL 1          // leaves whose control work is finished (and written back)
@@ -214,6 +216,13 @@ __global__ __launch_bounds__(256) void k_dense_mv(const double* __restrict__ C, 
     y[row] = s;
     if (q_out) q_out[row] = fma(eps, s, q_in[row]);
   }
+}
+
+// NUTS_POT_HOST: the position update behind a velocity the host produced, q' = q + eps v  (integration.py:124-127)
+__global__ __launch_bounds__(256) void k_host_pot_drift(const double* __restrict__ q_in, const double* __restrict__ v, double* __restrict__ q_out,
+                                                        double eps, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) q_out[i] = fma(eps, v[i], q_in[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1165,7 +1174,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_tree_ctl(ModelDev md, ArenaDev 
   }
   __syncthreads();
   if (tid != 0) return;
-  const double E = 0.5 * s_dot[0] - logp;  // integration.py:133-134
+  const double E = (A.kin_user ? *A.kin_user : 0.5 * s_dot[0]) - logp;  // integration.py:133-134
   A.E[ts] = E;
   if (!tree) return;
   tree_decide(&s_ctl, A, lf, s_dot, E, m, last, Emax, max_depth);
@@ -1220,7 +1229,7 @@ __global__ void k_draw_ctl_start(ArenaDev A, const double* __restrict__ kin_part
     Ctl* c = A.ctl;
     if (use_cached_logp) A.LOGP[0] = prev ? prev->logp : cached_logp;   // (`prev`: the record of the previous draw, still on the device)
     const double logp = A.LOGP[0];
-    const double E = 0.5 * s - logp;  // integration.py:72-74
+    const double E = (A.kin_user ? *A.kin_user : 0.5 * s) - logp;  // integration.py:72-74
     A.E[0] = E;
     c->E0 = E;
     c->log_size = 0.0;

@@ -18,7 +18,7 @@ import numpy as np
 
 from pymc_amd import _lib
 
-POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_DIAG_ADAPT_EXP, POT_FULL_ADAPT = 0, 1, 2, 3, 4
+POT_DIAG_ADAPT, POT_DIAG, POT_FULL, POT_DIAG_ADAPT_EXP, POT_FULL_ADAPT, POT_HOST = 0, 1, 2, 3, 4, 5
 
 _PREFETCH_ON = os.environ.get("PYMC_AMD_PREFETCH_NORMALS", "1") != "0"
 _REQUESTS = None
@@ -66,6 +66,21 @@ def partial_check_positive_definite(C):
     (i,) = np.nonzero(np.logical_or(np.isnan(d), d <= 0))
     if len(i):
         raise PositiveDefiniteError("Simple check failed. Diagonal contains negatives", i)
+
+
+_COMPUTE_METHODS = ("velocity", "energy", "velocity_energy", "random")
+
+
+def _user_overrides(potential, names=_COMPUTE_METHODS):
+    """The methods among `names` whose implementation `potential` gets from a class outside this module."""
+    found = []
+    for name in names:
+        for klass in type(potential).__mro__:
+            if name in vars(klass):
+                if klass.__module__ != __name__:
+                    found.append(name)
+                break
+    return found
 
 
 class QuadPotential:
@@ -125,6 +140,30 @@ class QuadPotential:
 
     def stats(self):  # quadpotential.py:177-178
         return {"largest_eigval": np.nan, "smallest_eigval": np.nan}
+
+    # ---- the reference's overridable surface (quadpotential.py:133-175) -------------------------------------------------
+    # The library's own classes run on the DEVICE (`_fill_config` says how); their host versions of these four methods are
+    # what `super()` reaches from a user's subclass and what anybody calling them on NumPy arrays gets.  A potential whose
+    # class overrides one of them (tests/step_methods/hmc/test_quadpotential.py:138-158 `test_user_potential`) belongs to
+    # the caller: the step method then creates a NUTS_POT_HOST chain that calls these methods back where the reference's
+    # integrator calls them (`_user_overrides`, step.py `_HostPotentialBridge`).
+    def velocity(self, x, out=None):
+        raise NotImplementedError("Abstract method")
+
+    def energy(self, x, velocity=None):
+        raise NotImplementedError("Abstract method")
+
+    def random(self):
+        raise NotImplementedError("Abstract method")
+
+    def velocity_energy(self, x, v_out):
+        raise NotImplementedError("Abstract method")
+
+    def update(self, sample, grad, tune):   # quadpotential.py:147-153
+        return self._host_update(sample, grad, tune)
+
+    def reset(self):                        # quadpotential.py:174-175
+        return self._host_reset()
 
     # potentials whose estimators live on the host (FullAdapt, DiagAdaptExp) override these three
     def _host_update(self, sample, grad, tune):
@@ -234,6 +273,31 @@ class QuadPotentialDiag(QuadPotential):
         cfg.initial_weight = 0.0
         return [self.v]
 
+    # host versions (quadpotential.py:611-630); the device chain does the same arithmetic in its vector kernels
+    @property
+    def s(self):
+        return np.sqrt(self.v)
+
+    @property
+    def inv_s(self):
+        return 1.0 / np.sqrt(self.v)
+
+    def velocity(self, x, out=None):
+        if out is None:
+            return self.v * x
+        np.multiply(x, self.v, out=out)
+        return None
+
+    def random(self):
+        return self._draw_normals() * self.inv_s
+
+    def energy(self, x, velocity=None):
+        return 0.5 * np.dot(x, self.v * x if velocity is None else velocity)
+
+    def velocity_energy(self, x, v_out):
+        np.multiply(x, self.v, out=v_out)
+        return 0.5 * np.dot(x, v_out)
+
 
 class QuadPotentialFull(QuadPotential):
     """Dense covariance (quadpotential.py:680-725): velocity = cov @ p, random = solve(chol^T, z).
@@ -262,6 +326,20 @@ class QuadPotentialFull(QuadPotential):
         cfg.dense_cov = _lib.dptr(self._cov)
         cfg.dense_rand = _lib.dptr(self._rand)
         return [self._cov, self._rand]
+
+    # host versions (quadpotential.py:704-725 / :658-677): velocity = cov p, random() = W z with the W the device uses
+    def velocity(self, x, out=None):
+        return np.dot(self._cov, x, out=out)
+
+    def random(self):
+        return self._rand @ self._draw_normals()
+
+    def energy(self, x, velocity=None):
+        return 0.5 * np.dot(x, self.velocity(x) if velocity is None else velocity)
+
+    def velocity_energy(self, x, v_out):
+        self.velocity(x, out=v_out)
+        return 0.5 * np.dot(x, v_out)
 
 
 class QuadPotentialFullInv(QuadPotentialFull):
@@ -538,11 +616,11 @@ class QuadPotentialDiagAdaptExp(QuadPotential):
         """Called by the step method after every device transition: the device has already updated its estimators
         (engine.hip, potential_update).  Unbound: the host estimator."""
         if self._step is None:
-            self.update(sample, grad, tune)
+            QuadPotentialDiagAdaptExp.update(self, sample, grad, tune)
 
     def update(self, sample, grad, tune):  # quadpotential.py:534-569
-        if self._step is not None:
-            raise RuntimeError("this potential is bound to a device chain, which updates it itself")
+        if self._step is not None:   # bound to a device chain: the chain has already updated its estimators (engine.hip, potential_update)
+            return
         if not (tune and self._h_n_samples < self._stop_adaptation):
             return
         k = self._h_n_samples

@@ -36,7 +36,10 @@ import numpy as np
 from pymc_amd import _lib
 from pymc_amd.blocking import DictToArrayBijection, PointType, RaveledVars
 from pymc_amd.model_spec import ModelSpec
-from pymc_amd.quadpotential import QuadPotentialDiagAdapt, quad_potential
+from pymc_amd.quadpotential import (
+    POT_HOST, QuadPotential, QuadPotentialDiag, QuadPotentialDiagAdapt, QuadPotentialFull, QuadPotentialFullAdapt, _user_overrides,
+    quad_potential,
+)
 from pymc_amd.value_grad import DeviceValueGradFunction
 
 
@@ -89,6 +92,76 @@ def get_random_generator(seed=None, copy_: bool = True) -> np.random.Generator:
         seed = copy.deepcopy(seed)
     return np.random.default_rng(seed)
 
+
+
+class _HostPotentialBridge:
+    """The callbacks of a NUTS_POT_HOST chain (include/nuts_mi355.h), bound to a potential whose class overrides `velocity`,
+    `energy`, `velocity_energy` or `random` -- the contract of the reference's `test_user_potential`
+    (tests/step_methods/hmc/test_quadpotential.py:138-158).  The engine calls them where the reference's integrator calls the
+    methods (integration.py:72-73,121,134), on host arrays it owns; an exception raised by the user's code is kept and
+    re-raised by `astep` once the C call has returned (`NUTS_E_CALLBACK`)."""
+
+    def __init__(self, potential, n):
+        self.error = None
+
+        def view(ptr, writeable):
+            a = np.ctypeslib.as_array(ptr, shape=(n,))
+            a.flags.writeable = writeable
+            return a
+
+        def guarded(fn):
+            def call(*args):
+                try:
+                    fn(*args)
+                    return 0
+                except BaseException as err:  # noqa: BLE001 -- nothing may propagate through the C frames
+                    self.error = err
+                    return 1
+            return call
+
+        def fill(out, result):   # an override may return the array instead of writing into `out`
+            if result is not None and result is not out:
+                out[:] = result
+
+        @guarded
+        def velocity(_user, _n, p, v_out):
+            out = view(v_out, True)
+            fill(out, potential.velocity(view(p, False), out=out))
+
+        @guarded
+        def energy(_user, _n, p, v, kinetic_out):
+            kinetic_out[0] = float(potential.energy(view(p, False), velocity=view(v, False)))
+
+        @guarded
+        def velocity_energy(_user, _n, p, v_out, kinetic_out):
+            kinetic_out[0] = float(potential.velocity_energy(view(p, False), view(v_out, True)))
+
+        self.velocity = _lib.VelocityFn(velocity)
+        self.energy = _lib.EnergyFn(energy)
+        self.velocity_energy = _lib.VelocityEnergyFn(velocity_energy)
+
+    def reraise(self):
+        err, self.error = self.error, None
+        if err is not None:
+            raise err
+
+
+def _host_potential_wanted(potential) -> bool:
+    """Does the potential's class override what the integrator calls per leapfrog?  Then the chain is a NUTS_POT_HOST chain."""
+    overridden = _user_overrides(potential)
+    if not overridden:
+        return False
+    # the nearest library ancestor decides what `super()` means: only the fixed potentials have host arithmetic to fall back on
+    for klass in type(potential).__mro__:
+        if klass.__module__ == QuadPotential.__module__:
+            fixed = klass in (QuadPotential, QuadPotentialDiag, QuadPotentialFull) or (
+                issubclass(klass, QuadPotentialFull) and not issubclass(klass, QuadPotentialFullAdapt))
+            if not fixed:
+                raise TypeError(
+                    f"{type(potential).__name__} overrides {overridden} of {klass.__name__}, whose estimators live in the device "
+                    "chain: subclass QuadPotential (or a fixed potential) and keep the adaptation in `update`")
+            break
+    return True
 
 class _DeviceHMCBase:
     default_blocked = True
@@ -151,6 +224,7 @@ class _DeviceHMCBase:
             self.stats_dtypes = [{k: v[0] for k, v in self.stats_dtypes_shapes.items()}]
         self._func = logp_dlogp_func
         self._chain_h = None
+        self._host_bridge = None
         self._device = device if logp_dlogp_func is None else logp_dlogp_func.device
         self._pending_state = None
         self._pending_extra = None
@@ -206,20 +280,31 @@ class _DeviceHMCBase:
         if self._chain_h is not None:
             return
         func = self._logp_dlogp_func
-        if getattr(self.potential, "_dense", False) and func.model_scalar("rows_group_aligned"):
+        host_potential = _host_potential_wanted(self.potential)
+        if (host_potential or getattr(self.potential, "_dense", False)) and func.model_scalar("rows_group_aligned"):
             func = self._func = DeviceValueGradFunction(self.spec, device=func.device, rows_group_aligned=False)
         lib = _lib.load()
         cfg = _lib.ChainConfig()
         lib.nuts_chain_config_default(C.byref(cfg))
         for key, val in self._cfg.items():
             setattr(cfg, key, val)
-        keep = self.potential._fill_config(cfg)
+        if host_potential:
+            cfg.potential = POT_HOST
+            keep = None
+        else:
+            keep = self.potential._fill_config(cfg)
         chain = lib.nuts_chain_create(func._handle, C.byref(cfg))
         del keep
         if not chain:
             raise _lib.EngineError(f"nuts_chain_create failed: {_lib.last_error()}")
         self._chain_h = chain
-        self.potential._bind(self)
+        if host_potential:   # the potential stays the caller's object: the chain calls it back, nothing of it lives on the device
+            self._host_bridge = _HostPotentialBridge(self.potential, self._n)
+            _lib.check(lib.nuts_chain_set_host_potential(chain, self._host_bridge.velocity, self._host_bridge.energy,
+                                                         self._host_bridge.velocity_energy, None), "nuts_chain_set_host_potential")
+        else:
+            self._host_bridge = None
+            self.potential._bind(self)
         lib.nuts_chain_set_tune(chain, int(self._tune))
         if self._pending_state is not None:
             state, self._pending_state = self._pending_state, None
@@ -233,12 +318,33 @@ class _DeviceHMCBase:
             d["_pending_extra"] = self._func.get_extra_values()
         d["_chain_h"] = None
         d["_func"] = None
+        d["_host_bridge"] = None   # (ctypes callbacks: rebuilt with the chain)
         return d
 
     def __setstate__(self, d):
         self.__dict__.update(d)
         self._chain_h = None
+        self._host_bridge = None
         self._func = None
+
+    # ---- what a transition takes from / reports to the potential -----------------
+    def _momentum_source(self) -> np.ndarray:
+        """The `normals` argument of a draw: standard normals the device scales (`potential.random()` = z / sigma or W z,
+        quadpotential.py:323-326) -- or, for a host-owned potential, `potential.random()` itself (base_hmc.py:201)."""
+        self._chain   # (decides which of the two it is)
+        if self._host_bridge is None:
+            return self.potential._draw_normals()
+        p0 = np.ascontiguousarray(self.potential.random(), dtype="float64")
+        if p0.shape != (self._n,):
+            raise ValueError(f"potential.random() returned shape {p0.shape}, expected ({self._n},)")
+        return p0
+
+    def _raise_draw_error(self, rc, what, q0):
+        if rc == _lib.NUTS_E_CALLBACK and self._host_bridge is not None:
+            self._host_bridge.reraise()
+        if rc == _lib.NUTS_E_BAD_ENERGY:
+            self.potential.raise_ok(q0.point_map_info)   # base_hmc.py:212: the potential's own diagnosis comes first
+        _lib.check(rc, what)
 
     # ---- tuning control (compound.py:229-231, base_hmc.py:290-298) -------------
     @property
@@ -257,7 +363,7 @@ class _DeviceHMCBase:
     def reset_tuning(self, start=None):
         _lib.check(_lib.load().nuts_chain_reset_tuning(self._chain), "nuts_chain_reset_tuning")
         self._tune = True
-        self.potential._host_reset()
+        self.potential.reset()   # base_hmc.py:298
 
     reset = reset_tuning
 
@@ -471,8 +577,8 @@ class NUTS(_DeviceHMCBase):
             return False
         if bool(self._scalar("single_launch")):
             return not self.tune
-        from pymc_amd.quadpotential import QuadPotential
-
+        if _user_overrides(self.potential, ("velocity", "energy", "velocity_energy", "random", "update", "stats", "raise_ok")):
+            return False   # the caller's code runs between (or inside) the draws
         host_adapted = (type(self.potential)._host_update is not QuadPotential._host_update
                         and not getattr(self.potential, "_device_estimator", False))
         return (not self.tune) or not host_adapted
@@ -524,7 +630,7 @@ class NUTS(_DeviceHMCBase):
     def astep(self, q0: RaveledVars):
         """BaseHMC.astep (base_hmc.py:196-288) -- one device transition."""
         q = np.ascontiguousarray(q0.data, dtype="float64")
-        normals = self.potential._draw_normals()  # potential.random(): rng.normal(size=n) (quadpotential.py:323-326)
+        normals = self._momentum_source()
         # pre-draw the uniform stream; rewind and advance by what the tree consumed
         bg = self.rng.bit_generator
         saved = bg.state
@@ -536,7 +642,7 @@ class NUTS(_DeviceHMCBase):
         )
         bg.state = saved
         if rc != _lib.NUTS_OK:
-            _lib.check(rc, "nuts_chain_draw")
+            self._raise_draw_error(rc, "nuts_chain_draw", q0)
         bg.advance(st.n_uniforms_consumed)
         # `advance` drops the cached half of a 32-bit draw (e.g. the seed draw of mcmc.py:908); `random()` never
         # touches it, so the reference generator still holds it: put it back for exact stream identity
@@ -544,7 +650,8 @@ class NUTS(_DeviceHMCBase):
         adv["has_uint32"], adv["uinteger"] = saved["has_uint32"], saved["uinteger"]
         bg.state = adv
         stats = self._stats_dict(st, q0.point_map_info)
-        self.potential._host_update(self._q_out, self._g_out, self.tune)   # base_hmc.py:239 for host-adapted potentials
+        self.potential.update(self._q_out, self._g_out, self.tune)   # base_hmc.py:239 (device-resident estimators: a no-op here)
+        stats.update(self.potential.stats())                         # base_hmc.py:286
         return RaveledVars(self._q_out.copy(), q0.point_map_info), [stats]
 
 
@@ -605,7 +712,7 @@ class HamiltonianMC(_DeviceHMCBase):
 
     def astep(self, q0: RaveledVars):
         q = np.ascontiguousarray(q0.data, dtype="float64")
-        normals = self.potential._draw_normals()
+        normals = self._momentum_source()
         # hmc.py:35-36 `rng.uniform(elow, ehigh)` (one double), then hmc.py:162 `rng.random()` -- which the
         # reference only draws when the trajectory did not diverge (short-circuit `or`)
         u0 = self.rng.random()
@@ -617,7 +724,7 @@ class HamiltonianMC(_DeviceHMCBase):
             _lib.dptr(self._q_out), _lib.dptr(self._g_out), C.byref(st),
         )
         if rc != _lib.NUTS_OK:
-            _lib.check(rc, "nuts_chain_draw_hmc")
+            self._raise_draw_error(rc, "nuts_chain_draw_hmc", q0)
         if st.diverging:
             self.rng.bit_generator.state = after_jitter
         warning = None
@@ -637,5 +744,6 @@ class HamiltonianMC(_DeviceHMCBase):
             "model_logp": st.model_logp, "step_size": st.step_size, "step_size_bar": st.step_size_bar,
             "largest_eigval": np.nan, "smallest_eigval": np.nan,
         }
-        self.potential._host_update(self._q_out, self._g_out, self.tune)
+        self.potential.update(self._q_out, self._g_out, self.tune)
+        stats.update(self.potential.stats())   # hmc.py:199
         return RaveledVars(self._q_out.copy(), q0.point_map_info), [stats]

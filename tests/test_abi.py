@@ -104,3 +104,32 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "oracle/" not in txt or f.endswith(".md"), f
+
+
+def test_streaming_kernels_hold_their_tiles_in_registers(lib, tmp_path):
+    """The group-aligned row pass (csrc/rows_ga_kernel.h) issues its tile loads from inline assembly into registers the compiler
+    does not know are pending: a spill of one of them would store a register whose load has not landed yet -- wrong numbers,
+    no fault.  The code object's own metadata says whether the register allocator spilled: every `k_rows_ga` instantiation
+    must report zero spilled VGPRs and no scratch.  (The span-partitioned `k_rows` uses ordinary loads: a spill there is correct
+    and only costs time, so it is not part of this guard.)"""
+    from pymc_amd import _lib
+
+    tools = "/opt/rocm/lib/llvm/bin"
+    needed = [os.path.join(tools, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in needed):
+        pytest.skip("LLVM binutils of the ROCm toolchain not present")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "gfx950.co")
+    subprocess.check_call([needed[0], f"--dump-section=.hip_fatbin={fat}", os.environ.get("PYMC_AMD_LIB", _lib.LIB_PATH), str(tmp_path / "copy.so")])
+    subprocess.check_call([needed[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    notes = subprocess.check_output([needed[2], "--notes", co], text=True)
+    kernels = {}
+    for block in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        spills = re.search(r"\.vgpr_spill_count:\s+(\d+)", block)
+        scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+        if name and spills and scratch:
+            kernels[name.group(1)] = (int(spills.group(1)), int(scratch.group(1)))
+    ga = {k: v for k, v in kernels.items() if re.match(r"_Z\d+k_rows_ga", k)}
+    assert len(ga) >= 8, sorted(kernels)[:10]
+    for name, (spills, scratch) in ga.items():
+        assert spills == 0 and scratch == 0, (name, spills, scratch)
