@@ -337,7 +337,10 @@ def main():
         leap_bytes = alg_bytes + 144 * spec.n
         if c3:
             workload = f"C3 mvn-{args.mvn_k}: MvNormal, full {args.mvn_k}x{args.mvn_k} covariance, n={spec.n}"
-            kernel = "k_mvn_matvec (precision mat-vec, cache-resident: 33.5 MB < 256 MiB Infinity Cache -- the HBM line does not bound it)"
+            aligned = int(step._logp_dlogp_func.model_scalar("mvn_row_aligned"))
+            kernel = (f"k_mvn_aligned<{aligned}> (precision mat-vec whose workgroups also finish the leapfrog: one launch per leapfrog"
+                      if aligned else "k_mvn_matvec (precision mat-vec") + \
+                "; cache-resident: 33.5 MB < 256 MiB Infinity Cache -- the HBM line does not bound it)"
         else:
             workload = f"C2-{'L' if args.rows_per_group >= 1000 else 'S'} hier-logit-10k: G={args.groups} D=8 rows={N} n={spec.n}"
             kernel = "hierarchical-logit row pass (k_rows_ga / k_rows)"
@@ -365,7 +368,9 @@ def main():
             "schedule": ("persistent tree kernel: one launch per NUTS tree (csrc/rows_ga_tree.h)" if step._scalar("tree_kernel") else
                          "group-aligned row pass: one launch per leapfrog, control work folded into the next row pass, also across doublings "
                          "(csrc/rows_ga_kernel.h)" if (not c3 and step._logp_dlogp_func.model_scalar("rows_group_aligned")) else
-                         "three launches per leapfrog (csrc/kernels.h)"),
+                         "row-aligned MvNormal pass: one launch per leapfrog, control work folded into the next launch, also across doublings "
+                         "(csrc/kernels.h, k_mvn_aligned)" if (c3 and step._logp_dlogp_func.model_scalar("mvn_row_aligned")) else
+                         "two launches per leapfrog (data pass + O(n) kernel), control work folded into the next data pass (csrc/kernels.h)"),
             "leapfrog_steps_per_sec": lps_total,
             "leapfrog_steps_per_sec_per_chain": [float(x) for x in (allv[:, 2] / allv[:, 0])],
             "ess_per_sec": (ess_total / T) if ess_ok else None,

@@ -155,6 +155,8 @@ int64_t nuts_model_algorithmic_bytes(const nuts_model *m);
 /* Named properties of the compiled model (what `compile` decided, cf. pymc/pytensorf.py:924-1008):
  *   "rows_group_aligned"  1 when the hierarchical-logit rows use the group-aligned pass (one launch per leapfrog;
  *                         diagonal mass matrices only -- a chain with a dense one needs NUTS_ROWS_NO_GROUP_ALIGNED),
+ *   "mvn_row_aligned"     1 when the model is one MvNormal node and the row-aligned pass finishes the leapfrog in the
+ *                         mat-vec's own workgroups (one launch per leapfrog),
  *   "rows_waves", "lean", "single_workgroup_ok". */
 int nuts_model_get_scalar(const nuts_model *m, const char *name, double *out);
 

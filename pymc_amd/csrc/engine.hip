@@ -114,9 +114,20 @@ extern "C" int nuts_set_device(int device) {
 }
 extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
 
+// the control work of a leaf on the lean path as a launch of its own (kernels.h: control_lean; the row-aligned MvNormal pass
+// leaves per-workgroup records that `mva_control` sums first)
+static void launch_control_lean(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax, int max_depth,
+                                HostStatus* st, int seq) {
+  if (m->md.has_mvn && m->md.mv.aligned)
+    hipLaunchKernelGGL(k_mva_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, j, d, Emax, max_depth, st, seq, m->ga_par);
+  else
+    hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, j, d, Emax, max_depth, st, seq, m->ga_par);
+}
+
 static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int d) {
   const ModelDev& md = m->md;
   if (md.lg.ga) return;   // group-aligned row pass: the O(n) work rides in the row pass itself (rows_ga_kernel.h)
+  if (md.has_mvn && md.mv.aligned && io.lean) return;   // (the row-aligned MvNormal pass has finished the leapfrog itself)
   // small models: 8x oversubscribed launch, one XCD does the work (see k_vector); large ones use the whole chip
   const dim3 grid(m->vector_one_xcd ? md.nblk * 8 : md.nblk);
   switch (m->ept) {
@@ -193,6 +204,19 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     hipLaunchKernelGGL(k_dense_mv, gmv, dim3(256), 0, m->stream, mv.winv, mv.wy, mv.wy + mv.k, mv.k, (const double*)nullptr, (double*)nullptr, 0.0, abort_flag);
     hipLaunchKernelGGL(k_dense_mv, gmv, dim3(256), 0, m->stream, mv.winv_t, mv.wy + mv.k, mv.wy + 2 * mv.k, mv.k, (const double*)nullptr, (double*)nullptr, 0.0, abort_flag);
     hipLaunchKernelGGL(k_mvn_finish, gk, dim3(256), 0, m->stream, mv, A, io);
+  } else if (md.has_mvn && md.mv.aligned && io.lean) {
+    const int par = (m->ga_par ^= 1);
+    // control work riding in workgroup 0: leaf j - 1 of this doubling, or (look-ahead) the last leaf of the previous doubling
+    const EvalIO& cio = job ? job->io : io;
+    const int cj = job ? job->j : j - 1, cd = job ? job->d : d, cseq = job ? job->seq : 0;
+#define MVA_LAUNCH(RR) hipLaunchKernelGGL(k_mvn_aligned<RR>, dim3(md.mv.al_nwg + (fold ? 1 : 0)), dim3(MVN_BLOCK), 0, m->stream, md, A, io, j, \
+                                           fold, d, Emax, max_depth, st, par, cio, cj, cd, cseq)
+    switch (md.mv.aligned) {
+      case 2: MVA_LAUNCH(2); break;
+      case 8: MVA_LAUNCH(8); break;
+      default: MVA_LAUNCH(4); break;
+    }
+#undef MVA_LAUNCH
   } else if (md.has_mvn) {
     const int mfold = md.has_logit ? 0 : fold;   // (the control work rides in exactly one launch)
     hipLaunchKernelGGL(k_mvn_matvec, dim3(m->mvn_grid + (mfold ? 1 : 0)), dim3(MVN_BLOCK), 0, m->stream, md, A, io, j, mfold, d, Emax,
@@ -210,7 +234,7 @@ static void model_enqueue_plain(nuts_model* m, const double* q_dev, double* g_de
   io.mode = MODE_PLAIN; io.q = q_dev; io.grad = g_dev; io.logp = lp_dev; io.lean = m->md.lean_ok;
   launch_dense(m, A, io, 0);
   launch_vector(m, A, io, 0, 0);
-  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0, m->ga_par);
+  if (io.lean) launch_control_lean(m, A, io, 0, 0, 0.0, 0, nullptr, 0);
   else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
 }
 
@@ -670,6 +694,19 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     }
     m->mvn_grid = mv.k;   // one workgroup per row
     m->alg_bytes += 8 * (int64_t)mv.k * mv.k;
+    // the model IS this node (one untransformed vector variable, no other factor): the row-aligned pass finishes the leapfrog
+    // in the mat-vec's own workgroups (kernels.h, k_mvn_aligned)
+    mv.aligned = 0; mv.al_nwg = 0; mv.al_part = nullptr;
+    if (md.lean_ok && !md.has_logit && !mv.winv && mv.off == 0 && mv.k == n && s->n_vars == 1 && s->n_factors == 0 &&
+        s->vars[0].transform == NUTS_TR_NONE && md.n_deferred == 0 && md.n_orphans == 0) {
+      const int R = env_int("NUTS_MVN_ALIGNED", 4);   // rows per workgroup; 0: the two-kernel leapfrog
+      if (R == 2 || R == 4 || R == 8) {
+        mv.aligned = R;
+        mv.al_nwg = (mv.k + R - 1) / R;
+        mv.al_part = m->keep(dev_alloc<double>(2 * (size_t)PART_STRIDE * mv.al_nwg));
+        if (mv.al_part) hipMemset(mv.al_part, 0, 2 * (size_t)PART_STRIDE * mv.al_nwg * sizeof(double));
+      }
+    }
   }
   for (void* p : m->owned)
     if (!p) { g_err = "device allocation failed"; nuts_model_destroy(m); return nullptr; }
@@ -720,6 +757,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   if (!m || !name || !out) return NUTS_E_ARG;
   const std::string k(name);
   if (k == "rows_group_aligned") *out = m->md.lg.ga;
+  else if (k == "mvn_row_aligned") *out = m->md.has_mvn ? m->md.mv.aligned : 0;
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
   else if (k == "lean") *out = m->md.lean_ok;
   else if (k == "tree_kernel_ok") *out = m->ga_tree_ok;
@@ -1377,9 +1415,17 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
     // work of leaf j-1 rides in workgroup 0 of this leaf's mat-vec; the last leaf gets a control launch of its own
     if (j == 0) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
     io.pre_next = last ? 0 : 1;
-    launch_dense(m, A, io, j, j > 0 ? 1 : 0, d, c->cfg.Emax, max_depth, st);
+    // row-aligned pass: as for the group-aligned row pass below, the control work of a doubling's LAST leaf rides in the first
+    // launch of the next doubling when the look-ahead queues that doubling right behind it (run_tree sets `defer_last_ctl`)
+    const bool al_tree_leaf = m->md.mv.aligned && mode == MODE_TREE;
+    CtlJob* job = (al_tree_leaf && j == 0 && c->pend_valid) ? &c->pend : nullptr;
+    launch_dense(m, A, io, j, (j > 0 || job) ? 1 : 0, d, c->cfg.Emax, max_depth, st, job);
+    if (job) c->pend_valid = false;
     launch_vector(m, A, io, j, d);
-    if (last) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
+    if (last) {
+      if (al_tree_leaf && c->defer_last_ctl) { c->pend = CtlJob{io, j, d, seq, false}; c->pend_valid = true; }
+      else launch_control_lean(m, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+    }
     c->leapfrogs++;
     return;
   }
@@ -1404,7 +1450,7 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
     launch_vector(m, A, io, j, d);
     if (last) {
       if (ga_tree_leaf && c->defer_last_ctl) { c->pend = CtlJob{io, j, d, seq, false}; c->pend_valid = true; }
-      else hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
+      else launch_control_lean(m, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
     }
     c->leapfrogs++;
     return;
@@ -1413,7 +1459,7 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   // control work rides in it)
   launch_dense(m, A, io, j, 0, d, c->cfg.Emax, max_depth, st);
   launch_vector(m, A, io, j, d);
-  if (io.lean) hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq, m->ga_par);
+  if (io.lean) launch_control_lean(m, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
   else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
   if (c->dense) {   // v' = C p', then the tree work on the stored (p', v')
     dense_velocity(c, A.P + d_o, A.V + d_o, nullptr, nullptr, 0.0, abort_flag, VEL_LEAF);
@@ -1509,8 +1555,7 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
   auto flush_pending = [&](int seq_waited) {   // (not pending by construction: never wait on a status nobody will publish)
     if (!c->pend_valid || c->pend.seq != seq_waited) return;
     const CtlJob& p = c->pend;
-    hipLaunchKernelGGL(k_control_lean, dim3(1), dim3(VEC_THREADS), 0, c->m->stream, c->m->md, c->A, p.io, p.j, p.d, c->cfg.Emax, max_depth,
-                       c->st_dev, p.seq, c->m->ga_par);
+    launch_control_lean(c->m, c->A, p.io, p.j, p.d, c->cfg.Emax, max_depth, c->st_dev, p.seq);
     c->pend_valid = false;
   };
   // Look-ahead for the short doublings, where the host round trip (status word over PCIe, then the first launch of

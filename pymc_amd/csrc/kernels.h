@@ -1110,6 +1110,165 @@ __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_matvec(ModelDev md, ArenaDev 
   }
 }
 
+// Row-aligned pass for models that ARE one MvNormal node (C3): the second kernel of the leapfrog (k_vector: 8 workgroups, pure
+// latency -- as long as the mat-vec itself, profiles/r02j_profile_c3_mvn2048.txt) disappears.  The workgroup that produced
+// (P delta)_i for its R rows finishes those R elements in its own tail: gradient, second kick, v' = M^-1 p', the tree-merge dot
+// products of `leaf_post` restricted to its elements, and the first half of the NEXT leaf (the position is always materialised
+// for this node).  What crosses workgroups is one record per workgroup [logp share, dots], stored slot-major with plain
+// stores; it is read after the kernel boundary by the control work (`mva_control`: workgroup 0 of the next leaf's launch, or a
+// launch of its own behind the last leaf of a doubling), which sums the records in workgroup order -- fixed order, no
+// floating-point atomics, and no hand-off inside a launch (a ticket + write-through records per workgroup, as the row pass of
+// the logit node does it, cost 16 us here: the kernel is too short to hide them; measured).  Records are double-buffered by
+// launch parity: the control work of leaf j rides in leaf j+1's launch, whose rows are already writing theirs.
+__device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax, int max_depth,
+                                            HostStatus* st, int seq, int par) {
+  const MvnDev& mv = md.mv;
+  __shared__ double s_rec[PART_STRIDE];
+  __shared__ double s_wp[VEC_THREADS / WAVE][NDOT + 1];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6, NT = (int)blockDim.x;
+  const bool leaf = io.mode != MODE_PLAIN, tree = io.mode == MODE_TREE;
+  int m = 0;
+  bool last = false;
+  if (tree) {
+    while (((j >> m) & 1) && m < d) ++m;
+    last = (j + 1 == (1 << d));
+  }
+  const int nn = 1 + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
+  auto need_slot = [&](int qq) {
+    if (qq < 1) return PART_LP;
+    if (qq < 2 + 6 * m) return PART_DOT + (qq - 1);
+    return PART_DOT + DOT_TOP + (qq - 2 - 6 * m);
+  };
+  const int nwg = mv.al_nwg;
+  const double* rec = mv.al_part + (int64_t)par * PART_STRIDE * nwg;
+  // every thread sums its share (records tid, tid + NT, ...) of each needed slot; the loads of MVA_BATCH slots are in flight
+  // together -- the records were written by every XCD, so each batch costs one trip to memory and the number of batches is
+  // what this workgroup's latency is made of
+  constexpr int MVA_BATCH = 16;
+  for (int q0 = 0; q0 < nn; q0 += MVA_BATCH) {
+    double v[MVA_BATCH];
+    const double* src[MVA_BATCH];
+#pragma unroll
+    for (int u = 0; u < MVA_BATCH; ++u) { v[u] = 0.0; src[u] = rec + (int64_t)need_slot(min(q0 + u, nn - 1)) * nwg; }
+    for (int i = tid; i < nwg; i += NT) {
+#pragma unroll
+      for (int u = 0; u < MVA_BATCH; ++u) v[u] += src[u][i];
+    }
+#pragma unroll
+    for (int u = 0; u < MVA_BATCH; ++u) {
+      const double sw = wave_sum(v[u]);
+      if (lane == 0 && q0 + u < nn) s_wp[w][q0 + u] = sw;
+    }
+  }
+  __syncthreads();
+  for (int qq = tid; qq < nn; qq += NT) {
+    double t = 0.0;
+    for (int ww = 0; ww < NT / WAVE; ++ww) t += s_wp[ww][qq];
+    s_rec[need_slot(qq)] = t;
+  }
+  __syncthreads();
+  control_lean(md, A, io, j, d, Emax, max_depth, st, seq, LeanSrc{s_rec, PART_STRIDE, 1, md.def_loc});
+}
+
+__global__ __launch_bounds__(VEC_THREADS) void k_mva_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax, int max_depth,
+                                                            HostStatus* st, int seq, int par) {
+  mva_control(md, A, io, j, d, Emax, max_depth, st, seq, par);
+}
+
+// `fold`: workgroup 0 does the control work of the leaf of the PREVIOUS row-aligned launch -- leaf (cio, cj, cd): normally leaf
+// j - 1 of this doubling (cseq = 0), or the last leaf of the previous doubling when this launch was queued by the look-ahead
+// right behind it (cseq = that doubling's sequence number: it publishes the status word the host waits for).
+template <int R>
+__global__ __launch_bounds__(MVN_BLOCK) void k_mvn_aligned(ModelDev md, ArenaDev A, EvalIO io, int j, int fold, int d, double Emax,
+                                                         int max_depth, HostStatus* st, int par, EvalIO cio, int cj, int cd, int cseq) {
+  const MvnDev& mv = md.mv;
+  int b = (int)blockIdx.x;
+  if (fold) {
+    if (b == 0) { mva_control(md, A, cio, cj, cd, Emax, max_depth, st, cseq, par ^ 1); return; }
+    --b;
+  }
+  Leaf lf; QView qv;
+  if (load_aborted(io, A)) return;
+  resolve_leaf(io, A, j, lf, qv);
+  __shared__ double s_w[R][MVN_BLOCK / WAVE];
+  __shared__ double s_red[NDOT];
+  const double* __restrict__ q = qv.q;
+  const double* __restrict__ mu = mv.mu;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+  const int K = mv.k, row0 = b * R;
+  const bool leaf = io.mode != MODE_PLAIN, tree = io.mode == MODE_TREE;
+  // wave 0, lane l < R: everything of element row0 + l whose address is known now is requested before the rows are streamed
+  const int my = min(row0 + min(lane, R - 1), K - 1);
+  MergePrefetch mpf;
+  double phv = 0.0, qr = 0.0, mur = 0.0, var_r = 0.0;
+  if (w == 0) {
+    if (tree) merge_prefetch(A, lf, j, my, mpf);
+    if (leaf) { phv = A.P[lf.d_o + my]; var_r = A.var[my]; }
+    qr = q[my]; mur = mu[my];
+  }
+  const double* pr[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) pr[r] = mv.prec + (int64_t)min(row0 + r, K - 1) * K;
+  double s[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = 0.0;
+  const int k2 = K & ~1;
+#pragma unroll 4
+  for (int c = 2 * tid; c < k2; c += 2 * MVN_BLOCK) {
+    const double d0 = q[c] - mu[c], d1 = q[c + 1] - mu[c + 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const double2 p = *reinterpret_cast<const double2*>(pr[r] + c);
+      s[r] = fma(p.x, d0, s[r]);
+      s[r] = fma(p.y, d1, s[r]);
+    }
+  }
+  if (tid == 0 && (K & 1)) {
+    const double dl = q[K - 1] - mu[K - 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = fma(pr[r][K - 1], dl, s[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const double t = wave_sum(s[r]);
+    if (lane == 0) s_w[r][w] = t;
+  }
+  __syncthreads();
+  if (w != 0) return;
+  // ---- wave 0: the R elements of this workgroup, lane = element ----
+  const bool a0 = lane < R && row0 + lane < K;
+  double t = 0.0;
+#pragma unroll
+  for (int ww = 0; ww < MVN_BLOCK / WAVE; ++ww) t += s_w[min(lane, R - 1)][ww];
+  int idx[1] = {my};
+  bool act[1] = {a0};
+  double grad[1] = {-t}, ph[1] = {phv};
+  if (a0) {
+    if (leaf) A.G[lf.d_o + my] = -t;
+    else io.grad[my] = -t;
+  }
+  int m = 0; bool last = false;
+  if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);
+  if (leaf && io.pre_next && a0) {   // first half of the next leaf (integration.py:118-127): the arithmetic of k_leaf_pre
+    const int64_t no = slot_off(A, lf.t + lf.dir);
+    const double p = fma(lf.half, -t, phv);   // p' of this leaf, as leaf_post computed it
+    const double phn = fma(lf.half, -t, p);
+    A.P[no + my] = phn;
+    A.Q[no + my] = fma(lf.eps, var_r * phn, qr);
+  }
+  const double lp = wave_sum(a0 ? -0.5 * (qr - mur) * t : 0.0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (s_red was written by lane 0 of this wave inside leaf_post)
+  __builtin_amdgcn_wave_barrier();
+  // ---- this workgroup's record: slot-major, so that the control work reads each slot as one contiguous run ----
+  const int nwg = mv.al_nwg;
+  double* rec = mv.al_part + (int64_t)par * PART_STRIDE * nwg + b;
+  if (lane == 0) rec[(int64_t)PART_LP * nwg] = lp;
+  if (leaf) {
+    for (int k = lane; k < NDOT; k += WAVE)
+      if (dot_needed(k, m, last)) rec[(int64_t)(PART_DOT + k) * nwg] = s_red[k];
+  }
+}
+
 // "cholesky" solver of the MvNormal node: delta = q - mu before the two mat-vecs with W = chol(cov)^-1 (k_dense_mv), and the
 // node's outputs from P delta = W^T (W delta) after them
 __global__ __launch_bounds__(256) void k_mvn_delta(MvnDev mv, ArenaDev A, EvalIO io, int j) {

@@ -113,6 +113,10 @@ struct MvnDev {
   // "cholesky" solver: W = chol(cov)^-1 and its transpose as full row-major matrices (zeros in the other triangle), scratch
   const double* winv; const double* winv_t;
   double* wy;          // [3][k]: delta, y = W delta, P delta = W^T y
+  // row-aligned pass (kernels.h, k_mvn_aligned): the model IS the MvNormal node, so the workgroup that owns rows [bR, bR + R) also
+  // finishes those elements of the leapfrog and leaves one record for the control work
+  int32_t aligned, al_nwg;   // rows per workgroup (0: off), workgroups
+  double* al_part;           // [2][PART_STRIDE][al_nwg] per-workgroup records, slot-major, double-buffered by launch parity
 };
 
 // per-workgroup partial record written by the vector kernel, summed (in workgroup order) by the control kernel

@@ -348,7 +348,7 @@ STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_
 def _run_schedule(spec, env, monkeypatch, tune, draws, seed, **step_kwargs):
     from pymc_amd.sampling import sample
 
-    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL", "NUTS_GA_ONES0")
+    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL", "NUTS_GA_ONES0", "NUTS_MVN_ALIGNED")
     for k in keys:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -423,3 +423,45 @@ def test_tree_kernel_on_trees_that_end_the_hard_way(case, c2l, monkeypatch):
     else:
         assert any(s["reached_max_treedepth"] for s in s1[6:]) and max(int(s["depth"]) for s in s1) == 3
     print(case, [int(s["tree_size"]) for s in s1], [bool(s["diverging"]) for s in s1])
+
+
+def test_row_aligned_mvnormal_pass(monkeypatch):
+    """Models that ARE one MvNormal node (C3): the workgroups of the mat-vec finish the leapfrog themselves (kernels.h,
+    k_mvn_aligned), one launch per leapfrog instead of two.
+      * every re-scheduling of the row-aligned pass is BITWISE the same chain: control work folded across doublings or not,
+        look-ahead off / over every doubling, folded control off altogether;
+      * the number of rows per workgroup changes the order of the cross-workgroup sums and nothing else: same integers as the
+        two-kernel leapfrog (NUTS_MVN_ALIGNED=0) over the first 15 transitions (beyond that the re-ordered sums have been
+        amplified by the dynamics into a different multinomial pick somewhere), positions to rounding on the first draws;
+      * a dimension that is not a multiple of the rows per workgroup (k = 301: the last workgroup owns one row, and the odd
+        column count takes the scalar tail of the dot product)."""
+    from pymc_amd import models
+
+    for k, tune, draws in ((512, 30, 10), (301, 20, 6)):
+        spec = models.mvnormal(n=k, seed=5)
+        envs = ({}, {"NUTS_XFOLD": "0"}, {"NUTS_SPEC_MAX": "0"}, {"NUTS_XFOLD": "0", "NUTS_SPEC_MAX": "10"}, {"NUTS_FOLD_CTL": "0"})
+        runs = [_run_schedule(spec, env, monkeypatch, tune, draws, 79) for env in envs]
+        d0, s0, _ = runs[0]
+        for env, (d1, s1, _) in zip(envs[1:], runs[1:]):
+            assert np.array_equal(d0, d1), (k, env)
+            for a, b in zip(s0, s1):
+                for key in STAT_KEYS:
+                    assert a[key] == b[key] or (a[key] != a[key] and b[key] != b[key]), (k, env, key, a[key], b[key])
+        for rows in ("0", "2", "8"):
+            d1, s1, _ = _run_schedule(spec, {"NUTS_MVN_ALIGNED": rows}, monkeypatch, tune, draws, 79)
+            for i, (a, b) in enumerate(zip(s0[:15], s1[:15])):
+                for key in ("depth", "tree_size", "index_in_trajectory", "diverging"):
+                    assert int(a[key]) == int(b[key]), (k, rows, i, key, a[key], b[key])
+            np.testing.assert_allclose(d1[:8], d0[:8], rtol=1e-7, atol=1e-9)
+        print(f"k = {k}: tree sizes {[int(s['tree_size']) for s in s0]}")
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    f = DeviceValueGradFunction(models.mvnormal(n=301, seed=5), device=0)
+    assert f.model_scalar("mvn_row_aligned") == 4
+    monkeypatch.setenv("NUTS_MVN_ALIGNED", "0")
+    g = DeviceValueGradFunction(models.mvnormal(n=301, seed=5), device=0)
+    assert g.model_scalar("mvn_row_aligned") == 0
+    q = np.random.default_rng(1).normal(size=301)
+    (lp_a, gr_a), (lp_b, gr_b) = f._pytensor_function(q), g._pytensor_function(q)
+    np.testing.assert_allclose(lp_a, lp_b, rtol=1e-13)
+    np.testing.assert_allclose(gr_a, gr_b, rtol=1e-13, atol=1e-13)   # (the same dot product per row; only the logp sum is re-ordered)
