@@ -102,7 +102,8 @@ def _dist(dist, konst, a):
     Every support / parameter check of the reference is a ``switch(cond, logp, -inf)``
     (pymc/distributions/dist_math.py:50-74; `check_parameters` rewritten by
     pymc/logprob/utils.py:209-225), whose reverse-mode gradient is 0 where the
-    check fails: partials are zeroed wherever logp == -inf.
+    check fails: element-wise for the support checks on the value (`_guard`), for the whole
+    factor when a parameter check fails (`_param`).
     """
     ok = [np.asarray(True)]
     lp, partials = _dist_raw(dist, konst, a, ok)
@@ -113,9 +114,20 @@ def _dist(dist, konst, a):
 
 
 def _guard(ok, cond, lp):
-    """``switch(cond, lp, -inf)`` that also records where the switch failed."""
+    """``switch(cond, lp, -inf)`` that also records where the switch failed: a support check on the VALUE, element-wise in the
+    reference (e.g. continuous.py:913 ``pt.switch(pt.ge(value, loc), res, -np.inf)``)."""
     ok[0] = ok[0] & cond
     return np.where(cond, lp, -np.inf)
+
+
+def _param(ok, cond, lp):
+    """``check_parameters(lp, cond)`` (pymc/distributions/dist_math.py:50-74): the conditions are reduced with ``pt.all`` to ONE
+    scalar, and `local_check_parameter_to_ninf_switch` (pymc/logprob/utils.py:209-225) turns the check into
+    ``switch(all(cond), lp, -inf)`` -- a failed parameter check kills the WHOLE factor, and with it the gradient of every one of
+    its elements."""
+    c = bool(np.all(cond))
+    ok[0] = ok[0] & c
+    return lp if c else np.full(np.shape(lp), -np.inf)
 
 
 def _dist_raw(dist, konst, a, ok):
@@ -124,20 +136,20 @@ def _dist_raw(dist, konst, a, ok):
         v, mu, sg = a
         z = (v - mu) / sg
         lp = -0.5 * z * z - LOG_SQRT_2PI - np.log(sg)
-        lp = _guard(ok, sg > 0, lp)
+        lp = _param(ok, sg > 0, lp)
         return lp, [-z / sg, z / sg, (z * z - 1) / sg]
     if dist == D_HALFNORMAL:  # continuous.py:909-916 (loc = 0)
         v, sg = a
         z = v / sg
         lp = -0.5 * z * z + LOG_SQRT_2_OVER_PI - np.log(sg)
         lp = _guard(ok, v >= 0, lp)
-        lp = _guard(ok, sg > 0, lp)
+        lp = _param(ok, sg > 0, lp)
         return lp, [-z / sg, (z * z - 1) / sg]
     if dist == D_CAUCHY:  # continuous.py:2287-2293
         v, al, be = a
         z = (v - al) / be
         lp = -LOG_PI - np.log(be) - np.log1p(z * z)
-        lp = _guard(ok, be > 0, lp)
+        lp = _param(ok, be > 0, lp)
         w = 2 * z / (1 + z * z)
         return lp, [-w / be, w / be, (-1 + w * z) / be]
     if dist == D_HALFCAUCHY:  # continuous.py:2383-2390
@@ -145,14 +157,14 @@ def _dist_raw(dist, konst, a, ok):
         z = v / be
         lp = LOG_2 - LOG_PI - np.log(be) - np.log1p(z * z)
         lp = _guard(ok, v >= 0, lp)
-        lp = _guard(ok, be > 0, lp)
+        lp = _param(ok, be > 0, lp)
         w = 2 * z / (1 + z * z)
         return lp, [-w / be, (-1 + w * z) / be]
     if dist == D_STUDENTT:  # continuous.py:1935-1950 ; nu constant, lam = sigma^-2
         v, nu, mu, sg = a
         z = (v - mu) / sg
         lp = konst - np.log(sg) - (nu + 1.0) / 2.0 * np.log1p(z * z / nu)
-        lp = _guard(ok, sg > 0, lp)
+        lp = _param(ok, sg > 0, lp)
         w = (nu + 1.0) * z / (nu + z * z)
         return lp, [-w / sg, np.zeros_like(lp), w / sg, (-1 + w * z) / sg]
     if dist == D_BETA:  # continuous.py:1248-1262 ; alpha, beta constant
@@ -166,12 +178,12 @@ def _dist_raw(dist, konst, a, ok):
         v, lam = a
         lp = np.log(lam) - v * lam
         lp = _guard(ok, v >= 0, lp)
-        lp = _guard(ok, lam > 0, lp)
+        lp = _param(ok, lam > 0, lp)
         return lp, [-lam * np.ones_like(lp), 1 / lam - v]
     if dist == D_UNIFORM:  # continuous.py:309-321 ; bounds constant
         v, lo, hi = a
         lp = _guard(ok, (v >= lo) & (v <= hi), -np.log(hi - lo) * np.ones_like(v))
-        lp = _guard(ok, lo <= hi, lp)
+        lp = _param(ok, lo <= hi, lp)
         return lp, [np.zeros_like(lp)] * 3
     if dist == D_BERNOULLI_LOGIT:  # discrete.py:351-352,362-374 ; value is data in {0,1}
         y, eta = a
@@ -185,7 +197,7 @@ def _dist_raw(dist, konst, a, ok):
             z = (lv - mu) / sg
             lp = -0.5 * z * z - 0.5 * math.log(2.0 * math.pi) - np.log(sg) - lv
         lp = _guard(ok, v > 0, lp)
-        lp = _guard(ok, sg > 0, lp)
+        lp = _param(ok, sg > 0, lp)
         return lp, [(-z / sg - 1) / v, z / sg, (z * z - 1) / sg]
     if dist == D_BERNOULLI:  # discrete.py:362-374
         y, p = a
@@ -193,7 +205,7 @@ def _dist_raw(dist, konst, a, ok):
             lp = np.where(y != 0, np.log(p), np.log1p(-p))
             dp = np.where(y != 0, 1 / p, -1 / (1 - p))
         lp = _guard(ok, ~((y < 0) | (y > 1)), lp)
-        lp = _guard(ok, (p >= 0) & (p <= 1), lp)
+        lp = _param(ok, (p >= 0) & (p <= 1), lp)
         return lp, [np.zeros_like(lp), dp]
     if dist == D_TRUNCNORMAL:  # continuous.py:720-746 ; bounds constant: lower = a[3], upper = konst
         v, mu, sg, lo = a
@@ -215,13 +227,13 @@ def _dist_raw(dist, konst, a, ok):
             lp = -0.5 * z * z - LOG_SQRT_2PI - np.log(sg) - norm
             ra = np.exp(-0.5 * za * za - LOG_SQRT_2PI - norm) if lb else 0.0
             rb = np.exp(-0.5 * zb * zb - LOG_SQRT_2PI - norm) if ub else 0.0
-        lp = _guard(ok, sg > 0, lp)
+        lp = _param(ok, sg > 0, lp)
         if lb:
             lp = _guard(ok, ~(v < lo), lp)
         if ub:
             lp = _guard(ok, ~(v > hi), lp)
         if lb and ub:
-            lp = _guard(ok, lo <= hi, lp)
+            lp = _param(ok, lo <= hi, lp)
         dmu = z / sg - (ra - rb) / sg
         dsg = (z * z - 1) / sg - ((za * ra if lb else 0.0) - (zb * rb if ub else 0.0)) / sg
         return lp, [-z / sg, dmu, dsg, np.zeros_like(lp)]
@@ -236,8 +248,8 @@ def _dist_raw(dist, konst, a, ok):
             lp = lbc + t1 + t2
             dp = np.where(z1, 0.0, y / p) - np.where(z2, 0.0, m2 / (1 - p))
         lp = _guard(ok, ~((y < 0) | (y > nn)), lp)
-        lp = _guard(ok, nn >= 0, lp)
-        lp = _guard(ok, (p >= 0) & (p <= 1), lp)
+        lp = _param(ok, nn >= 0, lp)
+        lp = _param(ok, (p >= 0) & (p <= 1), lp)
         return lp, [np.zeros_like(lp), np.zeros_like(lp), dp, np.zeros_like(lp)]
     if dist in (D_GAMMA, D_INVGAMMA):  # continuous.py:2512-2521 / 2631-2639 ; alpha constant, konst = -gammaln(alpha)
         v, al, be = a
@@ -258,14 +270,14 @@ def _dist_raw(dist, konst, a, ok):
                 lp = konst + t1 - be / v + t2
                 dv, db = be / (v * v) + m2 / v, al / be - 1.0 / v
         lp = _guard(ok, v >= 0, lp)
-        lp = _guard(ok, al > 0, lp)
-        lp = _guard(ok, be > 0, lp)
+        lp = _param(ok, al > 0, lp)
+        lp = _param(ok, be > 0, lp)
         return lp, [dv * np.ones_like(lp), np.zeros_like(lp), db * np.ones_like(lp)]
     if dist == D_LAPLACE:  # continuous.py:1570-1576
         v, mu, b = a
         r = v - mu
         lp = -np.log(2 * b) - np.abs(r) / b
-        lp = _guard(ok, b > 0, lp)
+        lp = _param(ok, b > 0, lp)
         sg = np.sign(r)
         return lp, [-sg / b, sg / b, -1 / b + np.abs(r) / (b * b)]
     if dist == D_POISSON:  # discrete.py:581-597 ; factln(y) arrives as data
@@ -277,7 +289,7 @@ def _dist_raw(dist, konst, a, ok):
             dmu = np.where(z, 0.0, y / mu) - 1.0
         lp = np.where((mu == 0) & (y == 0), 0.0, lp)
         lp = _guard(ok, ~(y < 0), lp)
-        lp = _guard(ok, mu >= 0, lp)
+        lp = _param(ok, mu >= 0, lp)
         return lp, [np.zeros_like(lp), dmu * np.ones_like(lp), np.zeros_like(lp)]
     if dist == D_POTENTIAL:  # pm.Potential: the term is added to the joint log-density (model/core.py:666-695)
         (v,) = a

@@ -409,6 +409,9 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   int n = 0;
   for (int i = 0; i < s->n_vars; ++i) n = std::max(n, s->vars[i].offset + s->vars[i].size);
   md.n = n; md.n_vars = s->n_vars; md.n_factors = s->n_factors; md.n_data = s->n_data;
+  md.fdead_mode = 0;
+  md.fdead = m->keep(dev_alloc<int32_t>((size_t)std::max(s->n_factors, 1)));
+  if (md.fdead) hipMemset(md.fdead, 0, (size_t)std::max(s->n_factors, 1) * sizeof(int32_t));
   std::vector<VarDev> vars;
   if (!compile_spec(m, s, vars)) { nuts_model_destroy(m); return nullptr; }
   md.pool = m->keep(dev_upload(s->data_pool, s->data_pool_len));
@@ -773,12 +776,33 @@ extern "C" int nuts_model_logp_grad(nuts_model* m, const double* q, double* logp
   const int n = m->md.n;
   std::memcpy(m->host_pin, q, n * sizeof(double));
   HIPCHK(hipMemcpyAsync(m->q_dev, m->host_pin, n * sizeof(double), hipMemcpyHostToDevice, m->stream));
+  m->md.fdead_mode = 1;   // (record factors whose parameter check fails; costs nothing unless one does)
   model_enqueue_plain(m, m->q_dev, m->g_dev, m->lp_dev);
+  m->md.fdead_mode = 0;
   HIPCHK(hipMemcpyAsync(m->host_pin + n, m->g_dev, n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipMemcpyAsync(m->host_pin + 2 * n, m->lp_dev, sizeof(double), hipMemcpyDeviceToHost, m->stream));
   HIPCHK(hipStreamSynchronize(m->stream));
   HIPCHK(hipGetLastError());
   *logp = m->host_pin[2 * n];
+  if (m->md.n_factors > 0 && !std::isfinite(*logp)) {
+    // logp = -inf: did a PARAMETER check fail?  Then the reference's gradient is 0 for every element of that factor, not only
+    // for the offending one (ModelDev.fdead): the pass above recorded such factors, a second pass honours the record.
+    std::vector<int32_t> fd(m->md.n_factors);
+    HIPCHK(hipMemcpy(fd.data(), m->md.fdead, fd.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    bool any = false;
+    for (int32_t v : fd) any = any || v != 0;
+    if (any) {
+      if (grad) {
+        m->md.fdead_mode = 2;
+        model_enqueue_plain(m, m->q_dev, m->g_dev, m->lp_dev);
+        m->md.fdead_mode = 0;
+        HIPCHK(hipMemcpyAsync(m->host_pin + n, m->g_dev, n * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+      }
+      HIPCHK(hipMemsetAsync(m->md.fdead, 0, fd.size() * sizeof(int32_t), m->stream));   // (the record is empty between calls)
+      HIPCHK(hipStreamSynchronize(m->stream));
+      HIPCHK(hipGetLastError());
+    }
+  }
   if (grad) std::memcpy(grad, m->host_pin + n, n * sizeof(double));
   return NUTS_OK;
 }

@@ -565,7 +565,10 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     const FactorBT& bt = pg.fbt[fi];
     for (int li = bid * VEC_THREADS + tid; li < f.size; li += nb * VEC_THREADS) {
       double dv[4], bv[4], cv[4];
-      lp += factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv);
+      int pdead = 0;
+      double lpo = factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
+      factor_kill(pg, fi, pdead, lpo, dv);
+      lp += lpo;
       for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm][tid] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
     }
   }

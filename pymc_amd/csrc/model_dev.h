@@ -146,7 +146,14 @@ struct ModelDev {
   const char* prog;
   int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_deferred;
   long long* ticks;           // [64] phase timestamps of the last B / C launch (only written in -DNUTS_KTIMING builds)
-  int32_t tick_j, tick_pad;   // restrict the timestamps to leaf j of a doubling (-1: every leaf)
+  int32_t tick_j;             // restrict the timestamps to leaf j of a doubling (-1: every leaf)
+  // A failed PARAMETER check kills the reference's whole factor -- `check_parameters` reduces its conditions with `all`
+  // (dist_math.py:68-74, logprob/utils.py:209-225), so where it fails the gradient of EVERY element of that factor is 0.
+  // The sampler never looks at a gradient behind logp = -inf; `nuts_model_logp_grad` (the ValueGradFunction call) does:
+  // its pass records the factors with a failed check here (mode 1) and, if there are any, a second pass treats those
+  // factors as dead for all their elements (mode 2).  Mode 0 (every pass inside a transition): element-wise, nothing recorded.
+  int32_t fdead_mode;
+  int32_t* fdead;             // [n_factors]
 };
 
 #ifdef NUTS_KTIMING
@@ -213,6 +220,8 @@ struct Prog {
   const int32_t* deferred;   // [n_deferred][2] = (element, variable)
   const double* pool;
   int n_vars;
+  int fdead_mode;            // see ModelDev
+  int32_t* fdead;
 };
 
 // Cooperative copy of the program blob into LDS (all threads of a 256-thread workgroup; ends with a barrier).
@@ -247,6 +256,7 @@ __device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog, cons
   pg.deferred = reinterpret_cast<const int32_t*>(base + md.po_deferred);
   pg.pool = md.pool;
   pg.n_vars = md.n_vars;
+  pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
   return pg;
 }
 
@@ -324,7 +334,9 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 // log-density of one element and its partials w.r.t. each argument.
 // (not inlined: one copy of the 18-way switch and its libm expansions per kernel keeps kernels B and C small
 // enough for the instruction cache -- they are launched once per leapfrog between two passes of kernel A)
-__device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d) {
+// `pdead` is set when a PARAMETER check failed (the reference's `check_parameters`; the support checks on the value are plain
+// element-wise switches there): the caller decides what that means for the factor's other elements (factor_kill below).
+__device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d, int* pdead) {
   const double NINF = -INFINITY;
   const double LOG_SQRT_2PI = 0.91893853320467274178;
   const double LOG_SQRT_2_OVER_PI = -0.22579135264472743236;
@@ -332,26 +344,27 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
   const double LOG_2 = 0.69314718055994530942;
   double lp = 0.0;
   bool dead = false;
-#define KILL_UNLESS(cond) if (!(cond)) { lp = NINF; dead = true; }
+#define KILL_UNLESS(cond) if (!(cond)) { lp = NINF; dead = true; }                  /* support of the value: element-wise switch */
+#define KILL_PARAM(cond) if (!(cond)) { lp = NINF; dead = true; *pdead = 1; }     /* check_parameters(...) */
   d[0] = d[1] = d[2] = d[3] = 0.0;
   switch (dist) {
     case NUTS_D_NORMAL: {  // continuous.py:526-532
       double sg = a[2], z = (a[0] - a[1]) / sg;
       lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg);
-      KILL_UNLESS(sg > 0)
+      KILL_PARAM(sg > 0)
       d[0] = -z / sg; d[1] = z / sg; d[2] = (z * z - 1.0) / sg;
     } break;
     case NUTS_D_HALFNORMAL: {  // continuous.py:909-916
       double sg = a[1], z = a[0] / sg;
       lp = -0.5 * z * z + LOG_SQRT_2_OVER_PI - log(sg);
       KILL_UNLESS(a[0] >= 0)
-      KILL_UNLESS(sg > 0)
+      KILL_PARAM(sg > 0)
       d[0] = -z / sg; d[1] = (z * z - 1.0) / sg;
     } break;
     case NUTS_D_CAUCHY: {  // continuous.py:2287-2293
       double be = a[2], z = (a[0] - a[1]) / be;
       lp = -LOG_PI - log(be) - log1p(z * z);
-      KILL_UNLESS(be > 0)
+      KILL_PARAM(be > 0)
       double w = 2.0 * z / (1.0 + z * z);
       d[0] = -w / be; d[1] = w / be; d[2] = (-1.0 + w * z) / be;
     } break;
@@ -359,14 +372,14 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       double be = a[1], z = a[0] / be;
       lp = LOG_2 - LOG_PI - log(be) - log1p(z * z);
       KILL_UNLESS(a[0] >= 0)
-      KILL_UNLESS(be > 0)
+      KILL_PARAM(be > 0)
       double w = 2.0 * z / (1.0 + z * z);
       d[0] = -w / be; d[1] = (-1.0 + w * z) / be;
     } break;
     case NUTS_D_STUDENTT: {  // continuous.py:1935-1950 (nu constant)
       double nu = a[1], sg = a[3], z = (a[0] - a[2]) / sg;
       lp = konst - log(sg) - (nu + 1.0) / 2.0 * log1p(z * z / nu);
-      KILL_UNLESS(sg > 0)
+      KILL_PARAM(sg > 0)
       double w = (nu + 1.0) * z / (nu + z * z);
       d[0] = -w / sg; d[2] = w / sg; d[3] = (-1.0 + w * z) / sg;
     } break;
@@ -380,14 +393,14 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       double v = a[0], lam = a[1];
       lp = log(lam) - v * lam;
       KILL_UNLESS(v >= 0)
-      KILL_UNLESS(lam > 0)
+      KILL_PARAM(lam > 0)
       d[0] = -lam; d[1] = 1.0 / lam - v;
     } break;
     case NUTS_D_UNIFORM: {  // continuous.py:309-321
       double v = a[0], lo = a[1], hi = a[2];
       lp = -log(hi - lo);
       KILL_UNLESS(v >= lo && v <= hi)
-      KILL_UNLESS(lo <= hi)
+      KILL_PARAM(lo <= hi)
     } break;
     case NUTS_D_BERNOULLI_LOGIT: {  // discrete.py:351-352,362-374
       double y = a[0], eta = a[1];
@@ -399,7 +412,7 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       double v = a[0], sg = a[2], lv = log(v), z = (lv - a[1]) / sg;
       lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg) - lv;
       KILL_UNLESS(v > 0)
-      KILL_UNLESS(sg > 0)
+      KILL_PARAM(sg > 0)
       d[0] = (-z / sg - 1.0) / v; d[1] = z / sg; d[2] = (z * z - 1.0) / sg;
     } break;
     case NUTS_D_BERNOULLI: {  // discrete.py:362-374
@@ -407,7 +420,7 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       lp = (y != 0.0) ? log(p) : log1p(-p);
       d[1] = (y != 0.0) ? 1.0 / p : -1.0 / (1.0 - p);
       KILL_UNLESS(y >= 0 && y <= 1)
-      KILL_UNLESS(p >= 0 && p <= 1)
+      KILL_PARAM(p >= 0 && p <= 1)
     } break;
     case NUTS_D_TRUNCNORMAL: {  // continuous.py:720-746; bounds constant (lower = a[3], upper = konst)
       const double v = a[0], mu = a[1], sg = a[2], lo = a[3], hi = konst;
@@ -428,10 +441,10 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
         norm = zb < -1.0 ? log(erfcx(-zb / 1.4142135623730951) / 2.0) - zb * zb / 2.0 : log1p(-erfc(zb / 1.4142135623730951) / 2.0);
       }
       lp = -0.5 * z * z - LOG_SQRT_2PI - log(sg) - norm;
-      KILL_UNLESS(sg > 0)
+      KILL_PARAM(sg > 0)
       if (lb) KILL_UNLESS(!(v < lo))
       if (ub) KILL_UNLESS(!(v > hi))
-      if (lb && ub) KILL_UNLESS(lo <= hi)
+      if (lb && ub) KILL_PARAM(lo <= hi)
       // d norm / d mu = (phi(za) - phi(zb)) / (sigma Z), d norm / d sigma = (za phi(za) - zb phi(zb)) / (sigma Z),
       // with phi / Z taken in log space through `norm` = log Z
       const double ra = lb ? exp(-0.5 * za * za - LOG_SQRT_2PI - norm) : 0.0;
@@ -449,8 +462,8 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       lp = a[3] + t1 + t2;
       d[2] = (z1 ? 0.0 : y / p) - (z2 ? 0.0 : m2 / (1.0 - p));
       KILL_UNLESS(!(y < 0 || y > nn))
-      KILL_UNLESS(nn >= 0)
-      KILL_UNLESS(p >= 0 && p <= 1)
+      KILL_PARAM(nn >= 0)
+      KILL_PARAM(p >= 0 && p <= 1)
     } break;
     case NUTS_D_GAMMA: {  // continuous.py:2512-2521 (alpha constant; the reference goes through scale = 1/beta)
       const double v = a[0], al = a[1], be = 1.0 / (1.0 / a[2]);
@@ -462,8 +475,8 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       d[0] = -be + (z2 ? 0.0 : m2 / v);
       d[2] = al / be - v;
       KILL_UNLESS(v >= 0)
-      KILL_UNLESS(al > 0)
-      KILL_UNLESS(be > 0)
+      KILL_PARAM(al > 0)
+      KILL_PARAM(be > 0)
     } break;
     case NUTS_D_INVGAMMA: {  // continuous.py:2631-2639 (alpha constant)
       const double v = a[0], al = a[1], be = a[2];
@@ -474,15 +487,15 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       d[0] = be / (v * v) + m2 / v;
       d[2] = al / be - 1.0 / v;
       KILL_UNLESS(v >= 0)
-      KILL_UNLESS(al > 0)
-      KILL_UNLESS(be > 0)
+      KILL_PARAM(al > 0)
+      KILL_PARAM(be > 0)
     } break;
     case NUTS_D_LAPLACE: {  // continuous.py:1570-1576
       const double r = a[0] - a[1], b = a[2];
       const double sg = r > 0 ? 1.0 : (r < 0 ? -1.0 : 0.0);
       lp = -log(2.0 * b) - fabs(r) / b;
       d[0] = -sg / b; d[1] = sg / b; d[2] = -1.0 / b + fabs(r) / (b * b);
-      KILL_UNLESS(b > 0)
+      KILL_PARAM(b > 0)
     } break;
     case NUTS_D_POISSON: {  // discrete.py:581-597; factln(y) arrives as data
       const double y = a[0], mu = a[1];
@@ -492,7 +505,7 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
       d[1] = (z ? 0.0 : y / mu) - 1.0;
       if (mu == 0 && y == 0) lp = 0.0;
       KILL_UNLESS(!(y < 0))
-      KILL_UNLESS(mu >= 0)
+      KILL_PARAM(mu >= 0)
     } break;
     case NUTS_D_POTENTIAL: {  // pm.Potential: the term itself is the log-density contribution
       lp = a[0];
@@ -504,13 +517,14 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
   // (dist_math.py:50-74, logprob/utils.py:209-225): its gradient is 0 where the check fails.
   if (dead) d[0] = d[1] = d[2] = d[3] = 0.0;
 #undef KILL_UNLESS
+#undef KILL_PARAM
   return lp;
 }
 
 // Evaluate element `li` of factor `f`: returns its logp, fills d[k] (partials w.r.t. argument k)
 // and the b / c operand values of every argument (needed for the chain rule through a + b*c).
 __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var,
-                                              double own_x, double* d, double* bv, double* cv) {
+                                              double own_x, double* d, double* bv, double* cv, int* pdead) {
   double a[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -524,7 +538,14 @@ __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, c
       a[k] = 0.0; bv[k] = cv[k] = 0.0;
     }
   }
-  return dist_eval(f.dist, f.konst, a, d);
+  return dist_eval(f.dist, f.konst, a, d, pdead);
+}
+
+// what a failed parameter check of factor `f` means for the element just evaluated (ModelDev.fdead_mode)
+__device__ __forceinline__ void factor_kill(const Prog& pg, int f, int pdead, double& lpf, double* d) {
+  if (pg.fdead_mode == 0) return;
+  if (pg.fdead_mode == 1) { if (pdead) pg.fdead[f] = 1; return; }   // (every writer stores the same value)
+  if (pg.fdead[f]) { lpf = -INFINITY; d[0] = d[1] = d[2] = d[3] = 0.0; }
 }
 
 __device__ __forceinline__ double slot_grad(const double* d, const double* bv, const double* cv, int arg, int slot) {
@@ -552,14 +573,18 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
     if (cb.fast) {
       double a[4] = {cb.p[0], cb.p[1], cb.p[2], cb.p[3]}, d[4];
       a[0] = cb.arg == 0 ? x : a[0]; a[1] = cb.arg == 1 ? x : a[1]; a[2] = cb.arg == 2 ? x : a[2]; a[3] = cb.arg == 3 ? x : a[3];
-      const double lpf = dist_eval(cb.dist, cb.konst, a, d);
+      int pdead = 0;
+      double lpf = dist_eval(cb.dist, cb.konst, a, d, &pdead);
+      factor_kill(pg, cb.f, pdead, lpf, d);
       gx += cb.arg == 0 ? d[0] : (cb.arg == 1 ? d[1] : (cb.arg == 2 ? d[2] : d[3]));
       if (cb.owner) lp += lpf;
       continue;
     }
     const nuts_factor& f = pg.factors[cb.f];
     double d[4], bv[4], cv[4];
-    const double lpf = factor_eval(pg, qv, f, li, k, x, d, bv, cv);
+    int pdead = 0;
+    double lpf = factor_eval(pg, qv, f, li, k, x, d, bv, cv, &pdead);
+    factor_kill(pg, cb.f, pdead, lpf, d);
     gx += slot_grad(d, bv, cv, cb.arg, cb.slot);
     if (cb.owner) {
       lp += lpf;

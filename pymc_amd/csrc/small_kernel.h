@@ -91,7 +91,10 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
       const FactorBT& bt = pg.fbt[fi];
       for (int li = tid; li < f.size; li += NT) {
         double dv[4], bv[4], cv[4];
-        lp += factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv);
+        int pdead = 0;
+        double lpo = factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
+        factor_kill(pg, fi, pdead, lpo, dv);
+        lp += lpo;
         for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm][tid] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
       }
     }

@@ -307,6 +307,61 @@ def test_invalid_parameter_gives_minus_inf():
     f.close()
 
 
+def test_a_failed_parameter_check_kills_the_whole_factor_in_the_value_grad_function():
+    """`check_parameters` is `switch(all(cond), logp, -inf)` (dist_math.py:68-74, logprob/utils.py:209-225): one invalid scale in a
+    vector of scales zeroes the factor's gradient for EVERY element; a value outside the support kills its own element only.
+    `nuts_model_logp_grad` records the factors with a failed parameter check in its pass and, when there are any, evaluates the
+    gradient again with those factors dead (engine.hip); device == oracle (pinned against autograd of the reference's graph in
+    tests/test_oracle_models.py), also for factors evaluated through the constant-parameter fast path, an orphan factor whose
+    only variable is a broadcast scalar, and on the next call (the record does not leak)."""
+    y = np.array([0.3, -0.2, 0.5, 1.1])
+    m = ModelBuilder()
+    s = m.Normal("s", 1.0, 2.0, shape=4)
+    m.Normal("y", 0.0, s, observed=y)                    # fast path: `s` is the whole third argument, the others are constants
+    mu = m.Normal("mu", 0.0, 1.0)
+    m.Normal("w", mu, s, observed=2.0 * y)               # general path: two variables in one factor
+    b = m.Normal("b", 0.5, 1.0)                          # a scalar is a `deferred` element: finished by the control kernel
+    m.Laplace("u", 0.0, b, observed=y)                   # orphan factor: its only variable is a broadcast scalar
+    spec = m.build()
+    f = _vg(spec)
+    names = [i[0] for i in spec.point_map_info]
+    q_ok = np.array([0.7, 0.4, 1.3, 0.9, 0.2, 0.6])
+    cases = {"all valid": q_ok.copy()}
+    bad = q_ok.copy(); bad[1] = -0.4
+    cases["one invalid scale"] = bad
+    bad = q_ok.copy(); bad[5] = -0.3
+    cases["invalid scalar scale of the orphan factor"] = bad
+    bad = q_ok.copy(); bad[1] = -0.4; bad[5] = -0.3
+    cases["both"] = bad
+    cases["valid again"] = q_ok.copy()
+    assert names == ["s", "mu", "b"]
+    for what, q in cases.items():
+        lp_d, g_d = f._pytensor_function(q)
+        lp_o, g_o = ref_models.evaluate(spec, q)
+        assert (lp_d == lp_o) or abs(lp_d - lp_o) <= 1e-12 * abs(lp_o), (what, lp_d, lp_o)
+        np.testing.assert_allclose(g_d, g_o, rtol=1e-12, atol=1e-14, err_msg=what)
+    lp, g = f._pytensor_function(cases["one invalid scale"])
+    assert lp == -np.inf
+    np.testing.assert_allclose(g[:4], -(cases["one invalid scale"][:4] - 1.0) / 4.0, rtol=1e-13)   # priors only: y and w are dead
+    assert g[4] == pytest.approx(-q_ok[4])                                                           # mu: prior only (w is dead)
+    assert abs(g[5] + (q_ok[5] - 0.5)) > 1e-3                                                        # b: the Laplace factor is alive
+    f.close()
+
+    # element-wise support check next to it: the other elements keep their gradient
+    m = ModelBuilder()
+    sg = m.Normal("sg", 1.0, 1.0)
+    m.HalfNormal("v", sg, shape=3, transform=None)
+    spec = m.build()
+    f = _vg(spec)
+    q = np.array([1.3, 0.4, -0.2, 0.7])
+    lp_d, g_d = f._pytensor_function(q)
+    lp_o, g_o = ref_models.evaluate(spec, q)
+    assert lp_d == lp_o == -np.inf
+    np.testing.assert_allclose(g_d, g_o, rtol=1e-12)
+    assert g_d[2] == 0.0 and g_d[1] != 0.0 and g_d[3] != 0.0
+    f.close()
+
+
 def test_edge_case_dlogp_zero():
     """tests/model/test_core.py:404-421: LogNormal(0,1)[3] + HalfCauchy(10) at the initial point."""
     m = ModelBuilder()

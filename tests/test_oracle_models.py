@@ -249,6 +249,56 @@ def test_invalid_parameter_is_minus_inf_with_zero_gradient():
     assert g[0] == pytest.approx(1.0)  # only the prior's gradient survives the dead switch
 
 
+def test_a_failed_parameter_check_kills_the_whole_factor():
+    """`check_parameters` reduces its conditions with `pt.all` to one scalar (dist_math.py:68-74) and the rewrite makes it
+    `switch(all(cond), logp, -inf)` (logprob/utils.py:209-225): with a VECTOR of scales of which one is invalid, the gradient of
+    the factor is 0 for every element -- not only for the offending one -- while a support check on the value
+    (`pt.switch(pt.ge(value, 0), ...)`, continuous.py:913) stays element-wise.  Checked against torch autograd of exactly that
+    graph."""
+    import torch
+
+    y = np.array([0.3, -0.2, 0.5, 1.1])
+    m = ModelBuilder()
+    s = m.Normal("s", 1.0, 2.0, shape=4)                 # unconstrained scales: a negative one is an invalid parameter
+    m.Normal("y", 0.0, s, observed=y)
+    m.Normal("h", 0.5, 1.0, shape=4)                     # (an unrelated factor: untouched)
+    spec = m.build()
+    q = np.array([0.7, -0.4, 1.3, 0.9, 0.2, 0.1, 0.4, 0.3])
+    lp, g = ref_models.evaluate(spec, q)
+    assert lp == -np.inf
+
+    t = torch.tensor(q, dtype=torch.float64, requires_grad=True)
+    ts, th = t[:4], t[4:]
+    prior_s = (-0.5 * ((ts - 1.0) / 2.0) ** 2 - math.log(2.0) - 0.5 * math.log(2 * math.pi)).sum()
+    prior_h = (-0.5 * (th - 0.5) ** 2 - 0.5 * math.log(2 * math.pi)).sum()
+    like = -0.5 * (torch.tensor(y) / ts) ** 2 - torch.log(ts) - 0.5 * math.log(2 * math.pi)
+    like = torch.where(torch.all(ts > 0), like, torch.full_like(like, -math.inf)).sum()
+    total = prior_s + prior_h + like
+    total.backward()
+    assert total.item() == -math.inf
+    np.testing.assert_allclose(g, t.grad.numpy(), rtol=1e-13)
+    np.testing.assert_allclose(g[:4], -(q[:4] - 1.0) / 4.0, rtol=1e-13)   # only the prior's gradient is left, for ALL four scales
+
+    # the same scales, all valid: the likelihood's gradient is there
+    q2 = q.copy(); q2[1] = 0.4
+    lp2, g2 = ref_models.evaluate(spec, q2)
+    assert np.isfinite(lp2) and np.all(np.abs(g2[:4] + (q2[:4] - 1.0) / 4.0) > 1e-3)
+
+
+def test_a_value_outside_the_support_kills_its_own_element_only():
+    m = ModelBuilder()
+    sg = m.Normal("sg", 1.0, 1.0)                        # scalar scale, valid below
+    m.HalfNormal("v", sg, shape=3, transform=None)       # free value with no transform: a negative element is outside the support
+    spec = m.build()
+    q = np.array([1.3, 0.4, -0.2, 0.7])
+    lp, g = ref_models.evaluate(spec, q)
+    assert lp == -np.inf
+    v, s = q[1:], q[0]
+    np.testing.assert_allclose(g[1:], np.where(v >= 0, -v / s**2, 0.0), rtol=1e-13)
+    ok = v >= 0
+    np.testing.assert_allclose(g[0], -(s - 1.0) + np.sum((v[ok] ** 2 / s**2 - 1.0) / s), rtol=1e-13)
+
+
 # ---------------------------------------------------------------------------
 # gradients vs torch float64 autograd of independently written densities
 # ---------------------------------------------------------------------------
