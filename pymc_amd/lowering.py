@@ -17,7 +17,8 @@ imports pytensor and looks at nothing but
 
 -- and is exercised on stub graphs that transcribe what the reference's `logp` methods build (tests/stubgraph.py:
 continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390 HalfCauchy, :1478-1486 Exponential,
-:1570-1576 Laplace, :1807-1821 LogNormal, discrete.py:351-374 Bernoulli; transforms.py:880-891 log, :1076-1088 logodds).
+:1570-1576 Laplace, :1807-1821 LogNormal, :1935-1950 StudentT, :1248-1262 Beta, :2512-2521 Gamma, :2631-2639 InverseGamma,
+discrete.py:351-374 Bernoulli, :581-597 Poisson; transforms.py:880-891 log, :1076-1088 logodds).
 
 How a factor is recognised: the graph is first turned into a small expression tree (constants folded, broadcasts /
 casts / parameter checks stripped -- the device applies its own support and parameter checks), then matched against the
@@ -30,8 +31,9 @@ caller hands over a REWRITTEN graph); (2) that `pt.pow(x, 2)` is still emitted a
 is accepted too); (3) constant folding of `pt.log(pt.sqrt(2.0 * np.pi))` is done here numerically, the tolerance on
 matched constants is 1e-12; (4) dims / coords, `pm.Data` containers (shared variables are read with `.get_value()` at
 lowering time; re-lowering or `set_extra_values` is needed when they change); (5) the distributions of the spec IR not
-listed above (StudentT, Beta, Gamma, ... have templates to be written the same way) and everything outside the IR, for
-which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU path for that model.
+listed above (Uniform with its interval transform, TruncatedNormal, Binomial: templates to be written the same way) and
+everything outside the IR, for which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU
+path for that model.
 """
 
 from __future__ import annotations
@@ -55,11 +57,18 @@ class NotLowerable(NotImplementedError):
 #        ("sum", axis, x), ("take", x, idx), ("dot", a, b)
 
 _ELEMWISE_ALIASES = {"truediv": "div", "true_div": "div", "scalarsigmoid": "sigmoid", "scalarsoftplus": "softplus", "second": "second",
-                     "identity": "identity", "and_": "and", "or_": "or"}
+                     "identity": "identity", "and_": "and", "or_": "or", "sgn": "sign", "reciprocal": "reciprocal"}
 _NUMPY_FOLD = {
     "add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "neg": np.negative, "exp": np.exp, "log": np.log,
     "log1p": np.log1p, "sqrt": np.sqrt, "sqr": np.square, "pow": np.power, "abs": np.abs, "reciprocal": np.reciprocal,
+    "sign": np.sign, "gammaln": lambda x: _gammaln(x),
 }
+
+
+def _gammaln(x):
+    from scipy.special import gammaln
+
+    return gammaln(x)
 
 
 def _opname(op) -> str:
@@ -199,6 +208,8 @@ def unify(t, node, env: Dict[str, Any]) -> bool:
         return True
     if t[0] == "const":
         return node[0] == "const" and node[1].size == 1 and math.isclose(float(node[1].reshape(-1)[0]), float(t[1]), rel_tol=1e-12, abs_tol=1e-300)
+    if t[0] == "__logpow__":
+        return _unify_logpow(t[1], t[2], node, env)
     if node[0] == "const" and t[0] in ("log", "neg", "sub", "add", "mul"):
         return _solve_const(t, node[1], env)
     if node[0] != t[0] or len(node) != len(t):
@@ -213,6 +224,33 @@ def unify(t, node, env: Dict[str, Any]) -> bool:
             env.update(trial)
             return True
     return False
+
+
+def _unify_logpow(xt, mt, node, env: Dict[str, Any]) -> bool:
+    """`logpow(x, m)` (dist_math.py:92-107): switch(and(eq(log x, -inf), le(m, 0)), switch(eq(m, 0), 0, -inf), m * log x).  When x and
+    m are both constants the product arrives folded to a number (array): it is then checked against the x and m that the
+    condition part binds."""
+    if node[0] != "switch" or len(node) != 4:
+        return False
+    trial = {k: (set(v) if isinstance(v, set) else v) for k, v in env.items()}
+    if not unify(("and", ("eq", ("log", xt), K(-math.inf)), ("le", mt, K(0))), node[1], trial):
+        return False
+    if not unify(("switch", ("eq", mt, K(0)), K(0.0), K(-math.inf)), node[2], trial):
+        return False
+    third = node[3]
+    if third[0] == "const":
+        x, m = (trial.get(w.name) if isinstance(w, W) else w for w in (xt, mt))
+        if x is None or m is None or x[0] != "const" or m[0] != "const":
+            return False
+        with np.errstate(all="ignore"):
+            want = m[1] * np.log(x[1])
+        if not np.allclose(third[1], want, rtol=1e-12, atol=1e-300, equal_nan=True):
+            return False
+    elif not unify(("mul", mt, ("log", xt)), third, trial):
+        return False
+    env.clear()
+    env.update(trial)
+    return True
 
 
 LOG_SQRT_2PI = math.log(math.sqrt(2.0 * math.pi))
@@ -239,6 +277,135 @@ TEMPLATES: List[Tuple[int, Any, Tuple[str, ...]]] = [
     (ms.D_LOGNORMAL, ("switch", ("gt", V, K(0)),
                       ("sub", ("sub", ("sub", ("mul", K(-0.5), ("pow", ("div", ("sub", ("log", V), MU), SG), K(2))), K(0.5 * math.log(2.0 * math.pi))), ("log", SG)), ("log", V)),
                       K(-math.inf)), ("value", "mu", "sigma")),                                                                           # continuous.py:1807-1821
+]
+
+
+
+
+# ---- distributions whose constants depend on a shape parameter (nu, alpha): matched with wildcards for those constants, the
+# ---- relations between them checked afterwards.  The IR keeps the shape parameter constant (model_spec.py: digamma stays out of
+# ---- the device gradient), so a graph in which it is a variable is refused by name.
+def _logpow(x, m):   # dist_math.py:92-107 (matched by `_unify_logpow`)
+    return ("__logpow__", x, m)
+
+
+def _num(node) -> Optional[float]:
+    if node[0] == "const" and node[1].size == 1:
+        return float(node[1].reshape(-1)[0])
+    return None
+
+
+def _close(a, b) -> bool:
+    return a is not None and b is not None and math.isclose(a, b, rel_tol=1e-12, abs_tol=1e-300)
+
+
+def _post_studentt(env):
+    """lam = sigma**-2 * sign(sigma) (continuous.py:234-239); constants: gammaln((nu+1)/2), nu*pi, gammaln(nu/2), (nu+1)/2, nu."""
+    nu = _num(env["c_nu"])
+    if nu is None:
+        raise NotLowerable("StudentT with a non-constant nu (the IR keeps nu constant)")
+    if not _close(_num(env["c_half"]), (nu + 1.0) / 2.0):
+        return None
+    lam = env["lam"]
+    if lam[0] == "const":                       # constant sigma: lam arrives folded, and so does the whole normalising part
+        sigma = ("const", np.asarray(lam[1], dtype="float64") ** -0.5)
+        want = math.lgamma((nu + 1.0) / 2.0) + 0.5 * np.log(lam[1] / (nu * math.pi)) - math.lgamma(nu / 2.0)
+        if env["norm"][0] != "const" or not np.allclose(env["norm"][1], want, rtol=1e-12, atol=0):
+            return None
+    else:
+        e2: Dict[str, Any] = {}
+        if not unify(("mul", ("pow", W("s"), K(-2.0)), ("sign", W("s"))), lam, e2):
+            return None
+        sigma = e2["s"]
+        e3: Dict[str, Any] = {"lam": lam}
+        if not unify(("sub", ("add", W("g1"), ("mul", K(0.5), ("log", ("div", W("lam"), W("nupi"))))), W("g2")), env["norm"], e3):
+            return None
+        if not (_close(_num(e3["g1"]), math.lgamma((nu + 1.0) / 2.0)) and _close(_num(e3["nupi"]), nu * math.pi) and _close(_num(e3["g2"]), math.lgamma(nu / 2.0))):
+            return None
+    konst = math.lgamma((nu + 1.0) / 2.0) - math.lgamma(nu / 2.0) - 0.5 * math.log(nu * math.pi)
+    return {"value": env["value"], "nu": ("const", np.asarray(nu)), "mu": env["mu"], "sigma": sigma}, konst
+
+
+def _shape_and_norm(env, shape_from, norm_of):
+    """The shape parameter alpha (a constant in the IR) from the exponent of `logpow(value, .)`, and the check of the part
+    `-gammaln(alpha) + logpow(beta, alpha)`, which arrives as ONE number when beta is a constant too."""
+    al = shape_from(_num(env["expo"])) if _num(env["expo"]) is not None else None
+    if al is None:
+        raise NotLowerable("Gamma / InverseGamma with a non-constant alpha (the IR keeps alpha constant)")
+    k1, beta = env["k1"], env["beta"]
+    if k1[0] == "const":
+        if beta[0] != "const":
+            return None
+        with np.errstate(all="ignore"):
+            want = -math.lgamma(al) + al * np.log(norm_of(beta[1]))
+        if not np.allclose(k1[1], want, rtol=1e-12, atol=1e-300):
+            return None
+    else:
+        e2: Dict[str, Any] = {"beta": beta}
+        if not unify(("add", W("c_g"), _logpow(W("beta"), W("alpha"))), k1, e2):
+            return None
+        if not (_close(_num(e2["alpha"]), al) and _close(_num(e2["c_g"]), -math.lgamma(al))):
+            return None
+    return al
+
+
+def _post_gamma(env):
+    """-gammaln(alpha) + logpow(beta, alpha) - beta * value + logpow(value, alpha - 1), beta = reciprocal(scale) (continuous.py:2512-2521)."""
+    al = _shape_and_norm(env, lambda e: e + 1.0, lambda b: b)
+    if al is None:
+        return None
+    beta = env["beta"]
+    e2: Dict[str, Any] = {}
+    if unify(("reciprocal", ("reciprocal", W("b"))), beta, e2):     # scale = reciprocal(beta) (Gamma.dist), beta' = reciprocal(scale)
+        beta = e2["b"]
+    elif beta[0] == "const":                                        # folded 1 / (1 / b): the number the model states, to the last bit or two
+        c = np.asarray(beta[1], dtype="float64")
+        r = np.round(c, 12)
+        beta = ("const", np.where(1.0 / (1.0 / r) == c, r, c))
+    return {"value": env["value"], "alpha": ("const", np.asarray(al)), "beta": beta}, -math.lgamma(al)
+
+
+def _post_invgamma(env):
+    al = _shape_and_norm(env, lambda e: -e - 1.0, lambda b: b)
+    if al is None:
+        return None
+    return {"value": env["value"], "alpha": ("const", np.asarray(al)), "beta": env["beta"]}, -math.lgamma(al)
+
+
+def _post_beta(env):
+    al, be = _num(env["alpha"]), _num(env["beta"])
+    if al is None or be is None:
+        raise NotLowerable("Beta with non-constant alpha / beta (the IR keeps them constant)")
+    betaln = math.lgamma(al) + math.lgamma(be) - math.lgamma(al + be)
+    if not (_close(_num(env["am1"]), al - 1.0) and _close(_num(env["bm1"]), be - 1.0) and _close(_num(env["c_b"]), betaln)):
+        return None
+    return {"value": env["value"], "alpha": ("const", np.asarray(al)), "beta": ("const", np.asarray(be))}, -betaln
+
+
+def _post_poisson(env):
+    val, fl = env["value"], env["factln"]
+    if val[0] != "const" or fl[0] != "const":
+        raise NotLowerable("a free Poisson variable is not a NUTS variable")
+    if not np.allclose(fl[1], _gammaln(np.asarray(val[1], dtype="float64") + 1.0), rtol=1e-12, atol=1e-300):
+        return None
+    return {"value": val, "mu": env["mu"], "factln": fl}, 0.0
+
+
+_ST_LAM, _GB = W("lam"), W("beta")
+TEMPLATES_POST: List[Tuple[int, Any, Tuple[str, ...], Any]] = [
+    (ms.D_STUDENTT, ("sub", W("norm"), ("mul", W("c_half"), ("log1p", ("div", ("mul", _ST_LAM, ("pow", ("sub", V, MU), K(2))), W("c_nu"))))),
+     ("value", "nu", "mu", "sigma"), _post_studentt),                                                                                    # continuous.py:1935-1950
+    (ms.D_GAMMA, ("switch", ("ge", V, K(0)), ("add", ("sub", W("k1"), ("mul", _GB, V)), _logpow(V, W("expo"))), K(-math.inf)),
+     ("value", "alpha", "beta"), _post_gamma),                                                                                           # continuous.py:2512-2521
+    (ms.D_INVGAMMA, ("switch", ("ge", V, K(0)), ("add", ("sub", W("k1"), ("div", _GB, V)), _logpow(V, W("expo"))), K(-math.inf)),
+     ("value", "alpha", "beta"), _post_invgamma),                                                                                        # continuous.py:2631-2639
+    (ms.D_BETA, ("switch", ("and", ("ge", V, K(0)), ("le", V, K(1))),
+                 ("sub", ("add", ("switch", ("eq", W("alpha"), K(1)), K(0), ("mul", W("am1"), ("log", V))),
+                                 ("switch", ("eq", W("beta"), K(1)), K(0), ("mul", W("bm1"), ("log1p", ("neg", V))))), W("c_b")), K(-math.inf)),
+     ("value", "alpha", "beta"), _post_beta),                                                                                            # continuous.py:1248-1262
+    (ms.D_POISSON, ("switch", ("mul", ("eq", MU, K(0)), ("eq", V, K(0))), K(0),
+                    ("switch", ("lt", V, K(0)), K(-math.inf), ("sub", ("sub", _logpow(MU, V), W("factln")), MU))),
+     ("value", "mu", "factln"), _post_poisson),                                                                                          # discrete.py:581-597
 ]
 
 
@@ -390,6 +557,18 @@ class _Lowering:
                     raise NotLowerable("Exponential with a non-constant scale")
                 args = (args[0], ms.Term(ms.Operand(ms.OP_CONST, 1.0 / mu.a.c)))
             self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), args, 0.0, name))
+            return
+        for dist, tmpl, argnames, post in TEMPLATES_POST:
+            env = {}
+            if not unify(tmpl, node, env):
+                continue
+            res = post(env)
+            if res is None:
+                continue
+            nodes, konst = res
+            lowered = {a: self.term(nodes[a]) for a in argnames[1:] + argnames[:1]}
+            args = tuple(lowered[a] for a in argnames)
+            self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), args, konst, name))
             return
         # a potential: the expression itself is the contribution (model/core.py:666-695)
         t = self.term(node)

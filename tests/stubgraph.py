@@ -3,7 +3,7 @@ the build image).  TEST INFRASTRUCTURE.
 
 * graph protocol: `Variable(owner, name)`, `Apply(op, inputs)`, ops named as PyTensor names them (`Elemwise` with a
   `scalar_op` object whose class is `Add`, `Mul`, `Sub`, `TrueDiv`, `Pow`, `Exp`, `Log`, `Log1p`, `Sqrt`, `Neg`, `Switch`, `GE`,
-  `GT`, `LT`, `OR`, `Sigmoid`; `DimShuffle`; `Sum` with `.axis`; `AdvancedSubtensor1`; `CheckParameterValue`; constants carry
+  `GT`, `LT`, `LE`, `EQ`, `OR`, `AND`, `Sigmoid`, `GammaLn`, `Reciprocal`, `Sign`; `DimShuffle`; `Sum` with `.axis`; `AdvancedSubtensor1`; `CheckParameterValue`; constants carry
   `.data`), with operator overloading so that the distribution code below reads like the reference's;
 * distributions: `logp` bodies TRANSCRIBED from the reference, each citing its lines -- these build exactly the expression a
   `pm.Model` would hand to the compiler BEFORE rewrites (`Model.logp`, model/core.py:612-695);
@@ -46,6 +46,7 @@ class Variable:
     def __ge__(self, o): return self._bin(o, GE)
     def __lt__(self, o): return self._bin(o, LT)
     def __le__(self, o): return self._bin(o, LE)
+    def __pow__(self, o): return self._bin(o, Pow)
     def __getitem__(self, idx): return Variable(Apply(AdvancedSubtensor1(), [self, as_tensor(idx)]), shape=(len(np.asarray(idx)),) + self.type.shape[1:])
     def sum(self, axis=None): return Variable(Apply(Sum(axis), [self]), shape=())
 
@@ -89,7 +90,8 @@ class All:
     pass
 
 
-for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "OR", "AND", "Sigmoid", "Abs"):
+for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "EQ", "OR", "AND", "Sigmoid", "Abs",
+           "GammaLn", "Reciprocal", "Sign"):
     globals()[_n] = type(_n, (), {})
 
 
@@ -124,6 +126,16 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     gt = staticmethod(lambda a, b: elemwise(GT, a, b))
     or_ = staticmethod(lambda a, b: elemwise(OR, a, b))
     abs = staticmethod(lambda a: elemwise(Abs, a))
+    eq = staticmethod(lambda a, b: elemwise(EQ, a, b))
+    le = staticmethod(lambda a, b: elemwise(LE, a, b))
+    and_ = staticmethod(lambda a, b: elemwise(AND, a, b))
+    bitwise_and = staticmethod(lambda a, b: elemwise(AND, a, b))
+    gammaln = staticmethod(lambda a: elemwise(GammaLn, a))
+    reciprocal = staticmethod(lambda a: elemwise(Reciprocal, a))
+    sign = staticmethod(lambda a: elemwise(Sign, a))
+
+
+gammaln = pt.gammaln
 
 
 def check_parameters(expr, *conds, msg=""):   # distributions/dist_math.py:50-74
@@ -163,6 +175,54 @@ def lognormal_logp(value, mu, sigma):       # distributions/continuous.py:1807-1
     res = -0.5 * pt.pow((pt.log(value) - mu) / sigma, 2) - 0.5 * pt.log(2.0 * np.pi) - pt.log(sigma) - pt.log(value)
     res = pt.switch(pt.gt(value, 0.0), res, -np.inf)
     return check_parameters(res, sigma > 0, msg="sigma > 0")
+
+
+def logpow(x, m):                           # distributions/dist_math.py:92-107
+    log_x = pt.log(x)
+    return pt.switch(pt.and_(pt.eq(log_x, -np.inf), pt.le(m, 0)), pt.switch(pt.eq(m, 0), 0.0, -np.inf), m * log_x)
+
+
+def factln(n):                              # distributions/dist_math.py:110-111
+    return gammaln(n + 1)
+
+
+def get_tau_sigma(sigma):                   # distributions/continuous.py:234-239 (the `tau is None` branch)
+    sigma = as_tensor(sigma)
+    return (sigma ** -2.0) * pt.sign(sigma), sigma
+
+
+def studentt_logp(value, nu, mu, sigma):    # distributions/continuous.py:1935-1950
+    lam, _ = get_tau_sigma(sigma=sigma)
+    res = (gammaln((nu + 1.0) / 2.0) + 0.5 * pt.log(lam / (nu * np.pi)) - gammaln(nu / 2.0)
+           - (nu + 1.0) / 2.0 * pt.log1p(lam * (value - mu) ** 2 / nu))
+    return check_parameters(res, lam > 0, nu > 0, msg="lam > 0, nu > 0")
+
+
+def beta_logp(value, alpha, beta):          # distributions/continuous.py:1248-1262
+    res = (pt.switch(pt.eq(alpha, 1.0), 0.0, (alpha - 1.0) * pt.log(value))
+           + pt.switch(pt.eq(beta, 1.0), 0.0, (beta - 1.0) * pt.log1p(-value))
+           - (pt.gammaln(alpha) + pt.gammaln(beta) - pt.gammaln(alpha + beta)))
+    res = pt.switch(pt.bitwise_and(pt.ge(value, 0.0), pt.le(value, 1.0)), res, -np.inf)
+    return check_parameters(res, alpha > 0, beta > 0, msg="alpha > 0, beta > 0")
+
+
+def gamma_logp(value, alpha, scale):        # distributions/continuous.py:2512-2521 (`scale = reciprocal(beta)`, :2484-2492)
+    beta = pt.reciprocal(scale)
+    res = -pt.gammaln(alpha) + logpow(beta, alpha) - beta * value + logpow(value, alpha - 1)
+    res = pt.switch(pt.ge(value, 0.0), res, -np.inf)
+    return check_parameters(res, alpha > 0, beta > 0, msg="alpha > 0, beta > 0")
+
+
+def invgamma_logp(value, alpha, beta):      # distributions/continuous.py:2631-2639
+    res = -pt.gammaln(alpha) + logpow(beta, alpha) - beta / value + logpow(value, -alpha - 1)
+    res = pt.switch(pt.ge(value, 0.0), res, -np.inf)
+    return check_parameters(res, alpha > 0, beta > 0, msg="alpha > 0, beta > 0")
+
+
+def poisson_logp(value, mu):                # distributions/discrete.py:581-597
+    res = pt.switch(pt.lt(value, 0), -np.inf, logpow(mu, value) - factln(value) - mu)
+    res = pt.switch(pt.eq(mu, 0) * pt.eq(value, 0), 0, res)
+    return check_parameters(res, mu >= 0, msg="mu >= 0")
 
 
 def bernoulli_logp(value, p):               # distributions/discrete.py:362-374
@@ -208,6 +268,22 @@ class StubModel:
     def LogNormal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None):
         return self._add(_RV(name, shape, lognormal_logp, (as_tensor(mu), as_tensor(sigma)), "log" if observed is None else None, observed))
 
+    def StudentT(self, name, nu, mu=0.0, sigma=1.0, shape=(), observed=None):
+        return self._add(_RV(name, shape, lambda v, m_, s_: studentt_logp(v, as_tensor(float(nu)), m_, s_), (as_tensor(mu), as_tensor(sigma)), None, observed))
+
+    def Beta(self, name, alpha, beta, shape=()):
+        return self._add(_RV(name, shape, beta_logp, (as_tensor(float(alpha)), as_tensor(float(beta))), "logodds"))
+
+    def Gamma(self, name, alpha, beta, shape=(), observed=None):
+        scale = pt.reciprocal(as_tensor(beta))       # Gamma.dist (continuous.py:2484-2492) hands `scale` to the logp
+        return self._add(_RV(name, shape, gamma_logp, (as_tensor(float(alpha)), scale), "log" if observed is None else None, observed))
+
+    def InverseGamma(self, name, alpha, beta, shape=(), observed=None):
+        return self._add(_RV(name, shape, invgamma_logp, (as_tensor(float(alpha)), as_tensor(beta)), "log" if observed is None else None, observed))
+
+    def Poisson(self, name, mu, observed):
+        return self._add(_RV(name, np.shape(observed), poisson_logp, (as_tensor(mu),), None, observed))
+
     def Bernoulli(self, name, logit_p, observed):
         return self._add(_RV(name, np.shape(observed), bernoulli_logp, (pt.sigmoid(logit_p),), None, observed))   # discrete.py:351-352
 
@@ -239,5 +315,8 @@ class StubModel:
             lp = rv.logp_fn(rv.expr, *rv.params)
             if rv.transform == "log":      # + log|J| = value (LogTransform.log_jac_det, transforms.py:880-891)
                 lp = lp + rv.value
+            if rv.transform == "logodds":  # + log|J| = log sigmoid(v) + log1p(-sigmoid(v)) (LogOddsTransform, transforms.py:1076-1088)
+                sv = pt.sigmoid(rv.value)
+                lp = lp + (pt.log(sv) + pt.log1p(-sv))
             out.append(lp)
         return out
