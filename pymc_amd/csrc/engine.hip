@@ -209,7 +209,7 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     // control work riding in workgroup 0: leaf j - 1 of this doubling, or (look-ahead) the last leaf of the previous doubling
     const EvalIO& cio = job ? job->io : io;
     const int cj = job ? job->j : j - 1, cd = job ? job->d : d, cseq = job ? job->seq : 0;
-#define MVA_LAUNCH(RR) hipLaunchKernelGGL(k_mvn_aligned<RR>, dim3(md.mv.al_nwg + (fold ? 1 : 0)), dim3(MVN_BLOCK), 0, m->stream, md, A, io, j, \
+#define MVA_LAUNCH(RR) hipLaunchKernelGGL(k_mvn_aligned<RR>, dim3(md.mv.al_nwg + 1), dim3(MVA_THREADS), 0, m->stream, md, A, io, j, \
                                            fold, d, Emax, max_depth, st, par, cio, cj, cd, cseq)
     switch (md.mv.aligned) {
       case 2: MVA_LAUNCH(2); break;

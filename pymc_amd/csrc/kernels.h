@@ -915,13 +915,14 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
 struct LeanSrc { const double* part; int stride, nblk; const double* def_loc; };
 
 // AGENT: the records were written by other workgroups of THIS launch (persistent tree kernel, rows_ga_tree.h).
+// `nt` (optional): the number of threads of the workgroup that take part (the others have left), if not all of them.
 template <bool AGENT = false>
 __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
-                                             int max_depth, HostStatus* st, int seq, const LeanSrc src) {
+                                             int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt = 0) {
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
   constexpr int NWMAX = VEC_THREADS / WAVE;
-  const int NT = (int)blockDim.x, NW = NT / WAVE;
+  const int NT = nt ? nt : (int)blockDim.x, NW = NT / WAVE;
   __shared__ double s_sum[PART_STRIDE];
   __shared__ double s_chunk[CTL_CHUNKS][PART_STRIDE];
   __shared__ double s_red[NDOT * NWMAX];
@@ -1124,11 +1125,11 @@ __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_matvec(ModelDev md, ArenaDev 
 // the logit node does it, cost 16 us here: the kernel is too short to hide them; measured).  Records are double-buffered by
 // launch parity: the control work of leaf j rides in leaf j+1's launch, whose rows are already writing theirs.
 __device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax, int max_depth,
-                                            HostStatus* st, int seq, int par) {
+                                            HostStatus* st, int seq, int par, int nt) {
   const MvnDev& mv = md.mv;
   __shared__ double s_rec[PART_STRIDE];
   __shared__ double s_wp[VEC_THREADS / WAVE][NDOT + 1];
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6, NT = (int)blockDim.x;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6, NT = nt;   // (`nt` threads of the workgroup take part)
   const bool leaf = io.mode != MODE_PLAIN, tree = io.mode == MODE_TREE;
   int m = 0;
   bool last = false;
@@ -1170,75 +1171,86 @@ __device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& 
     s_rec[need_slot(qq)] = t;
   }
   __syncthreads();
-  control_lean(md, A, io, j, d, Emax, max_depth, st, seq, LeanSrc{s_rec, PART_STRIDE, 1, md.def_loc});
+  control_lean(md, A, io, j, d, Emax, max_depth, st, seq, LeanSrc{s_rec, PART_STRIDE, 1, md.def_loc}, nt);
 }
 
 __global__ __launch_bounds__(VEC_THREADS) void k_mva_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax, int max_depth,
                                                             HostStatus* st, int seq, int par) {
-  mva_control(md, A, io, j, d, Emax, max_depth, st, seq, par);
+  mva_control(md, A, io, j, d, Emax, max_depth, st, seq, par, VEC_THREADS);
 }
 
 // `fold`: workgroup 0 does the control work of the leaf of the PREVIOUS row-aligned launch -- leaf (cio, cj, cd): normally leaf
 // j - 1 of this doubling (cseq = 0), or the last leaf of the previous doubling when this launch was queued by the look-ahead
 // right behind it (cseq = that doubling's sequence number: it publishes the status word the host waits for).
+//
+// Five waves: four stream the rows; the fifth requests, while they stream, everything of the workgroup's R elements whose
+// address is known at launch (p_half, the operands of the first merge levels: written by the previous launch on other XCDs,
+// i.e. misses) and finishes the elements when the dot products arrive.  Loads return in order within a wave: with the requests
+// in a streaming wave, that wave's first fma waited behind every one of those misses.
+#define MVA_THREADS (MVN_BLOCK + WAVE)
 template <int R>
-__global__ __launch_bounds__(MVN_BLOCK) void k_mvn_aligned(ModelDev md, ArenaDev A, EvalIO io, int j, int fold, int d, double Emax,
-                                                         int max_depth, HostStatus* st, int par, EvalIO cio, int cj, int cd, int cseq) {
+__global__ __launch_bounds__(MVA_THREADS) void k_mvn_aligned(ModelDev md, ArenaDev A, EvalIO io, int j, int fold, int d, double Emax,
+                                                           int max_depth, HostStatus* st, int par, EvalIO cio, int cj, int cd, int cseq) {
   const MvnDev& mv = md.mv;
-  int b = (int)blockIdx.x;
-  if (fold) {
-    if (b == 0) { mva_control(md, A, cio, cj, cd, Emax, max_depth, st, cseq, par ^ 1); return; }
-    --b;
+  // Workgroup 0 is the control workgroup in EVERY launch (idle when there is nothing to fold): rows [R (b - 1), R b) then always
+  // belong to workgroup b, hence to the same XCD, whose L2 keeps its eighth of P from launch to launch.
+  if (blockIdx.x == 0) {
+    if (!fold || threadIdx.x >= VEC_THREADS) return;   // (the control code is written for VEC_THREADS threads)
+    mva_control(md, A, cio, cj, cd, Emax, max_depth, st, cseq, par ^ 1, VEC_THREADS);
+    return;
   }
+  const int b = (int)blockIdx.x - 1;
   Leaf lf; QView qv;
   if (load_aborted(io, A)) return;
   resolve_leaf(io, A, j, lf, qv);
   __shared__ double s_w[R][MVN_BLOCK / WAVE];
-  __shared__ double s_red[NDOT];
+  constexpr int TW = MVN_BLOCK / WAVE;      // index of the tail wave: leaf_post files a wave's sums under its index
+  __shared__ double s_red[NDOT + TW];
   const double* __restrict__ q = qv.q;
   const double* __restrict__ mu = mv.mu;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
   const int K = mv.k, row0 = b * R;
   const bool leaf = io.mode != MODE_PLAIN, tree = io.mode == MODE_TREE;
-  // wave 0, lane l < R: everything of element row0 + l whose address is known now is requested before the rows are streamed
-  const int my = min(row0 + min(lane, R - 1), K - 1);
+  const bool tailwave = w == TW;
+  const int my = min(row0 + min(lane, R - 1), K - 1);   // tail wave, lane l < R: element row0 + l
   MergePrefetch mpf;
   double phv = 0.0, qr = 0.0, mur = 0.0, var_r = 0.0;
-  if (w == 0) {
-    if (tree) merge_prefetch(A, lf, j, my, mpf);
+  if (tailwave) {
     if (leaf) { phv = A.P[lf.d_o + my]; var_r = A.var[my]; }
     qr = q[my]; mur = mu[my];
-  }
-  const double* pr[R];
+    if (tree) merge_prefetch(A, lf, j, my, mpf);
+  } else {
+    const double* pr[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) pr[r] = mv.prec + (int64_t)min(row0 + r, K - 1) * K;
-  double s[R];
+    for (int r = 0; r < R; ++r) pr[r] = mv.prec + (int64_t)min(row0 + r, K - 1) * K;
+    double s[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) s[r] = 0.0;
-  const int k2 = K & ~1;
+    for (int r = 0; r < R; ++r) s[r] = 0.0;
+    const int k2 = K & ~1;
 #pragma unroll 4
-  for (int c = 2 * tid; c < k2; c += 2 * MVN_BLOCK) {
-    const double d0 = q[c] - mu[c], d1 = q[c + 1] - mu[c + 1];
+    for (int c = 2 * tid; c < k2; c += 2 * MVN_BLOCK) {
+      const double d0 = q[c] - mu[c], d1 = q[c + 1] - mu[c + 1];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const double2 p = *reinterpret_cast<const double2*>(pr[r] + c);
+        s[r] = fma(p.x, d0, s[r]);
+        s[r] = fma(p.y, d1, s[r]);
+      }
+    }
+    if (tid == 0 && (K & 1)) {
+      const double dl = q[K - 1] - mu[K - 1];
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = fma(pr[r][K - 1], dl, s[r]);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const double2 p = *reinterpret_cast<const double2*>(pr[r] + c);
-      s[r] = fma(p.x, d0, s[r]);
-      s[r] = fma(p.y, d1, s[r]);
+      const double t = wave_sum(s[r]);
+      if (lane == 0) s_w[r][w] = t;
     }
   }
-  if (tid == 0 && (K & 1)) {
-    const double dl = q[K - 1] - mu[K - 1];
-#pragma unroll
-    for (int r = 0; r < R; ++r) s[r] = fma(pr[r][K - 1], dl, s[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const double t = wave_sum(s[r]);
-    if (lane == 0) s_w[r][w] = t;
-  }
   __syncthreads();
-  if (w != 0) return;
-  // ---- wave 0: the R elements of this workgroup, lane = element ----
+  if (!tailwave) return;
+  // ---- the tail wave: the R elements of this workgroup, lane = element ----
   const bool a0 = lane < R && row0 + lane < K;
   double t = 0.0;
 #pragma unroll
@@ -1251,7 +1263,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_aligned(ModelDev md, ArenaDev
     else io.grad[my] = -t;
   }
   int m = 0; bool last = false;
-  if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);
+  if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);   // -> s_red[k + TW]
   if (leaf && io.pre_next && a0) {   // first half of the next leaf (integration.py:118-127): the arithmetic of k_leaf_pre
     const int64_t no = slot_off(A, lf.t + lf.dir);
     const double p = fma(lf.half, -t, phv);   // p' of this leaf, as leaf_post computed it
@@ -1268,7 +1280,7 @@ __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_aligned(ModelDev md, ArenaDev
   if (lane == 0) rec[(int64_t)PART_LP * nwg] = lp;
   if (leaf) {
     for (int k = lane; k < NDOT; k += WAVE)
-      if (dot_needed(k, m, last)) rec[(int64_t)(PART_DOT + k) * nwg] = s_red[k];
+      if (dot_needed(k, m, last)) rec[(int64_t)(PART_DOT + k) * nwg] = s_red[k + TW];
   }
 }
 
