@@ -1186,13 +1186,18 @@ def test_nuts_adapt_diag_grad_matches_oracle():
     step.close()
 
 
-def test_hmc_matches_oracle():
+@pytest.mark.parametrize("which", ["std_normal", "mvnormal_row_aligned"])
+def test_hmc_matches_oracle(which):
+    """`HamiltonianMC._hamiltonian_step` (hmc.py:130-184), fixed-length trajectories: on the single-workgroup path (std_normal)
+    and on the row-aligned MvNormal pass (one launch per leapfrog, the control work of step j - 1 folded into the launch of step j)."""
     from pymc_amd.blocking import RaveledVars
     from pymc_amd.step import HamiltonianMC
 
-    spec = models.std_normal(6)
+    spec = models.std_normal(6) if which == "std_normal" else models.mvnormal(n=96, seed=2)
     f = ref_models.SpecLogpGrad(spec)
     step = HamiltonianMC(model=spec, rng=4, device=0)
+    if which != "std_normal":
+        assert step._logp_dlogp_func.model_scalar("mvn_row_aligned") == 4
     ref = ref_sampler.RefHMC(f, spec.n, rng=4)
     rng_a, rng_b = np.random.default_rng(8), np.random.default_rng(8)
     step.setup_chain(rng_a, 10, 10)
