@@ -18,7 +18,8 @@ imports pytensor and looks at nothing but
 -- and is exercised on stub graphs that transcribe what the reference's `logp` methods build (tests/stubgraph.py:
 continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390 HalfCauchy, :1478-1486 Exponential,
 :1570-1576 Laplace, :1807-1821 LogNormal, :1935-1950 StudentT, :1248-1262 Beta, :2512-2521 Gamma, :2631-2639 InverseGamma,
-discrete.py:351-374 Bernoulli, :581-597 Poisson; transforms.py:880-891 log, :1076-1088 logodds).
+:309-321 Uniform, discrete.py:351-374 Bernoulli, :141-154 Binomial, :581-597 Poisson; transforms.py:880-891 log, :1026-1070 interval,
+:1076-1088 logodds).
 
 How a factor is recognised: the graph is first turned into a small expression tree (constants folded, broadcasts /
 casts / parameter checks stripped -- the device applies its own support and parameter checks), then matched against the
@@ -31,8 +32,7 @@ caller hands over a REWRITTEN graph); (2) that `pt.pow(x, 2)` is still emitted a
 is accepted too); (3) constant folding of `pt.log(pt.sqrt(2.0 * np.pi))` is done here numerically, the tolerance on
 matched constants is 1e-12; (4) dims / coords, `pm.Data` containers (shared variables are read with `.get_value()` at
 lowering time; re-lowering or `set_extra_values` is needed when they change); (5) the distributions of the spec IR not
-listed above (Uniform with its interval transform, TruncatedNormal, Binomial: templates to be written the same way) and
-everything outside the IR, for which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU
+listed above (TruncatedNormal: its template is to be written the same way) and everything outside the IR, for which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU
 path for that model.
 """
 
@@ -63,6 +63,11 @@ _NUMPY_FOLD = {
     "log1p": np.log1p, "sqrt": np.sqrt, "sqr": np.square, "pow": np.power, "abs": np.abs, "reciprocal": np.reciprocal,
     "sign": np.sign, "gammaln": lambda x: _gammaln(x),
 }
+
+
+_COND_FOLD = {"neq": np.not_equal}
+# (`and` / `or` fold only when BOTH operands have already folded to constants, i.e. were `neq` tests of constants)
+_COND_FOLD.update({"and": lambda a, b: np.logical_and(a != 0, b != 0), "or": lambda a, b: np.logical_or(a != 0, b != 0)})
 
 
 def _gammaln(x):
@@ -119,8 +124,14 @@ def build_tree(v, memo: Optional[dict] = None):
             if sn in _NUMPY_FOLD and all(k[0] == "const" for k in kids):
                 with np.errstate(all="ignore"):
                     out = _const(_NUMPY_FOLD[sn](*[k[1] for k in kids]))
+            elif sn in _COND_FOLD and all(k[0] == "const" for k in kids):
+                # conditions on CONSTANTS only (`neq(a, -inf)` of the interval transform, transforms.py:1034-1049, and the and / or
+                # of such): decided here; comparisons that involve the value or a parameter stay in the tree
+                out = _const(_COND_FOLD[sn](*[k[1] for k in kids]).astype("float64"))
+            elif sn in ("switch", "where") and kids[0][0] == "const" and kids[0][1].size == 1:
+                out = kids[1] if bool(kids[0][1].reshape(-1)[0]) else kids[2]
             else:
-                out = (sn, *kids)
+                out = ("switch" if sn == "where" else sn, *kids)
     elif name in ("Sum", "CAReduce"):
         out = ("sum", getattr(op, "axis", None), build_tree(ins[0], memo))
     elif name in ("AdvancedSubtensor1", "AdvancedSubtensor"):
@@ -382,6 +393,30 @@ def _post_beta(env):
     return {"value": env["value"], "alpha": ("const", np.asarray(al)), "beta": ("const", np.asarray(be))}, -betaln
 
 
+def _post_uniform(env):
+    """switch(and(ge(v, lower), le(v, upper)), fill(v, -log(upper - lower)), -inf) (continuous.py:309-321); constant bounds in the IR."""
+    lo, hi = _num(env["lower"]), _num(env["upper"])
+    if lo is None or hi is None:
+        raise NotLowerable("Uniform with non-constant bounds (the IR keeps them constant)")
+    if not _close(_num(env["c"]), -math.log(hi - lo)):
+        return None
+    return {"value": env["value"], "lower": env["lower"], "upper": env["upper"]}, 0.0
+
+
+def _post_binomial(env):
+    """binomln(n, y) + logpow(p, y) + logpow(1 - p, n - y) (discrete.py:141-154); y and n are data, `binomln` arrives as numbers."""
+    val, n, lbc, nmy = env["value"], env["n"], env["lbc"], env["nmy"]
+    if val[0] != "const" or n[0] != "const":
+        raise NotLowerable("a free Binomial variable (or a variable n) is not a NUTS variable")
+    y, nn = np.asarray(val[1], dtype="float64"), np.asarray(n[1], dtype="float64")
+    if lbc[0] != "const" or nmy[0] != "const":
+        return None
+    if not (np.allclose(nmy[1], nn - y, rtol=1e-12, atol=0) and
+            np.allclose(lbc[1], _gammaln(nn + 1) - _gammaln(y + 1) - _gammaln(nn - y + 1), rtol=1e-12, atol=1e-300)):
+        return None
+    return {"value": val, "n": n, "p": env["p"], "lbc": lbc}, 0.0
+
+
 def _post_poisson(env):
     val, fl = env["value"], env["factln"]
     if val[0] != "const" or fl[0] != "const":
@@ -403,6 +438,11 @@ TEMPLATES_POST: List[Tuple[int, Any, Tuple[str, ...], Any]] = [
                  ("sub", ("add", ("switch", ("eq", W("alpha"), K(1)), K(0), ("mul", W("am1"), ("log", V))),
                                  ("switch", ("eq", W("beta"), K(1)), K(0), ("mul", W("bm1"), ("log1p", ("neg", V))))), W("c_b")), K(-math.inf)),
      ("value", "alpha", "beta"), _post_beta),                                                                                            # continuous.py:1248-1262
+    (ms.D_UNIFORM, ("switch", ("and", ("ge", V, W("lower")), ("le", V, W("upper"))), W("c"), K(-math.inf)),
+     ("value", "lower", "upper"), lambda env: _post_uniform(env)),                                                                       # continuous.py:309-321
+    (ms.D_BINOMIAL, ("switch", ("or", ("lt", V, K(0)), ("gt", V, W("n"))), K(-math.inf),
+                     ("add", ("add", W("lbc"), _logpow(P, V)), _logpow(("sub", K(1), P), W("nmy")))),
+     ("value", "n", "p", "lbc"), lambda env: _post_binomial(env)),                                                                       # discrete.py:141-154
     (ms.D_POISSON, ("switch", ("mul", ("eq", MU, K(0)), ("eq", V, K(0))), K(0),
                     ("switch", ("lt", V, K(0)), K(-math.inf), ("sub", ("sub", _logpow(MU, V), W("factln")), MU))),
      ("value", "mu", "factln"), _post_poisson),                                                                                          # discrete.py:581-597
@@ -439,6 +479,15 @@ class _Lowering:
         if node[0] == "sigmoid" and node[1][0] == "input" and id(node[1][1]) in self.var_id:
             k = self.var_id[id(node[1][1])]
             return k if self.spec.vars[k].transform == ms.TR_LOGODDS else None
+        if node[0] == "add":   # interval: sigmoid(v) * b + (1 - sigmoid(v)) * a with the variable's own bounds (transforms.py:1036-1037)
+            env: Dict[str, Any] = {}
+            sv = ("sigmoid", W("in"))
+            if unify(("add", ("mul", sv, W("b")), ("mul", ("sub", K(1), sv), W("a"))), node, env) and env["in"][0] == "input" \
+                    and id(env["in"][1]) in self.var_id:
+                k = self.var_id[id(env["in"][1])]
+                fv = self.spec.vars[k]
+                if fv.transform == ms.TR_INTERVAL and _close(_num(env["a"]), fv.lower) and _close(_num(env["b"]), fv.upper):
+                    return k
         return None
 
     def _operand(self, node) -> Optional[ms.Operand]:
@@ -495,6 +544,11 @@ class _Lowering:
                 return x
             if fv.transform == ms.TR_LOGODDS and y[0] == "add":                                        # log|J| = log sigmoid(v) + log1p(-sigmoid(v))
                 return x
+            if fv.transform == ms.TR_INTERVAL:                                                          # log|J| = log(b - a) - 2 softplus(-v) - v
+                env: Dict[str, Any] = {}
+                if unify(("sub", ("sub", W("c"), ("mul", K(2), ("softplus", ("neg", W("in"))))), W("in")), y, env) and env["in"][0] == "input" \
+                        and self.var_id.get(id(env["in"][1])) == own and _close(_num(env["c"]), math.log(fv.upper - fv.lower)):
+                    return x
         return node
 
     def _logit_rows(self, eta, observed) -> bool:

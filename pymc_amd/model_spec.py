@@ -394,7 +394,8 @@ class ModelBuilder:
         y = np.asarray(observed, dtype="float64")
         nn = np.broadcast_to(np.asarray(n, dtype="float64"), y.shape)
         lbc = gammaln(nn + 1) - gammaln(y + 1) - gammaln(nn - y + 1)
-        return self._register(D_BINOMIAL, name, (nn if nn.size > 1 else float(nn.reshape(-1)[0]), p, lbc), None, y, TR_NONE)
+        n_arg = float(np.asarray(n)) if np.ndim(n) == 0 else nn   # a scalar n stays a constant of the factor
+        return self._register(D_BINOMIAL, name, (n_arg, p, lbc), None, y, TR_NONE)
 
     def BernoulliLogit(self, name, logit_p, observed):
         """`pm.Bernoulli(name, logit_p=..., observed=...)` (pymc/distributions/discrete.py:343-374)."""

@@ -91,7 +91,7 @@ class All:
 
 
 for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "EQ", "OR", "AND", "Sigmoid", "Abs",
-           "GammaLn", "Reciprocal", "Sign"):
+           "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus"):
     globals()[_n] = type(_n, (), {})
 
 
@@ -133,6 +133,11 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     gammaln = staticmethod(lambda a: elemwise(GammaLn, a))
     reciprocal = staticmethod(lambda a: elemwise(Reciprocal, a))
     sign = staticmethod(lambda a: elemwise(Sign, a))
+    neq = staticmethod(lambda a, b: elemwise(NEQ, a, b))
+    where = staticmethod(lambda c, a, b: elemwise(Switch, c, a, b))
+    fill = staticmethod(lambda a, b: elemwise(Second, a, b))
+    softplus = staticmethod(lambda a: elemwise(Softplus, a))
+    inf = np.inf
 
 
 gammaln = pt.gammaln
@@ -225,20 +230,53 @@ def poisson_logp(value, mu):                # distributions/discrete.py:581-597
     return check_parameters(res, mu >= 0, msg="mu >= 0")
 
 
+def binomln(n, k):                          # distributions/dist_math.py:114-115
+    return factln(n) - factln(k) - factln(n - k)
+
+
+def uniform_logp(value, lower, upper):      # distributions/continuous.py:309-321
+    res = pt.switch(pt.bitwise_and(pt.ge(value, lower), pt.le(value, upper)), pt.fill(value, -pt.log(upper - lower)), -np.inf)
+    return check_parameters(res, lower <= upper, msg="lower <= upper")
+
+
+def binomial_logp(value, n, p):             # distributions/discrete.py:141-154
+    res = pt.switch(pt.or_(pt.lt(value, 0), pt.gt(value, n)), -np.inf, binomln(n, value) + logpow(p, value) + logpow(1 - p, n - value))
+    return check_parameters(res, n >= 0, 0 <= p, p <= 1, msg="n >= 0, 0 <= p <= 1")
+
+
+def interval_backward(value, a, b):         # logprob/transforms.py:1026-1053 (both bounds given)
+    a, b = as_tensor(a), as_tensor(b)
+    exp_value = pt.exp(value)
+    sigmoid_x = pt.sigmoid(value)
+    lower_distance = exp_value + a
+    upper_distance = b - exp_value
+    return pt.where(pt.and_(pt.neq(a, -pt.inf), pt.neq(b, pt.inf)), sigmoid_x * b + (1 - sigmoid_x) * a,
+                    pt.where(pt.neq(a, -pt.inf), lower_distance, pt.where(pt.neq(b, pt.inf), upper_distance, value)))
+
+
+def interval_log_jac_det(value, a, b):      # logprob/transforms.py:1055-1070
+    a, b = as_tensor(a), as_tensor(b)
+    s = pt.softplus(-value)
+    return pt.where(pt.and_(pt.neq(a, -pt.inf), pt.neq(b, pt.inf)), pt.log(b - a) - 2 * s - value,
+                    pt.where(pt.or_(pt.neq(a, -pt.inf), pt.neq(b, pt.inf)), value, value * 0.0))
+
+
 def bernoulli_logp(value, p):               # distributions/discrete.py:362-374
     res = pt.switch(pt.or_(pt.lt(value, 0), pt.gt(value, 1)), -np.inf, pt.switch(value, pt.log(p), pt.log1p(-p)))
     return check_parameters(res, 0 <= p, p <= 1, msg="0 <= p <= 1")
 
 
 class _RV:
-    def __init__(self, name, shape, logp_fn, params, transform=None, observed=None):
+    def __init__(self, name, shape, logp_fn, params, transform=None, observed=None, bounds=None):
         self.name, self.shape, self.logp_fn, self.params, self.transform, self.observed = name, tuple(shape), logp_fn, params, transform, observed
+        self.bounds = bounds
         if observed is None:
             vname = name if transform is None else f"{name}_{transform}__"   # util.py:138-155
             self.value = Variable(None, vname, self.shape)
-            # what the rest of the graph sees in place of the RV: transform.backward(value) (logprob/transforms.py:880-891, 1076-1088)
+            # what the rest of the graph sees in place of the RV: transform.backward(value) (logprob/transforms.py:880-891, 1026-1053, 1076-1088)
             self.expr = {None: self.value, "log": pt.exp(self.value) if transform == "log" else None,
-                         "logodds": pt.sigmoid(self.value) if transform == "logodds" else None}[transform]
+                         "logodds": pt.sigmoid(self.value) if transform == "logodds" else None,
+                         "interval": interval_backward(self.value, *bounds) if transform == "interval" else None}[transform]
         else:
             self.value, self.expr = None, TensorConstant(np.asarray(observed, dtype="float64"))
 
@@ -281,6 +319,12 @@ class StubModel:
     def InverseGamma(self, name, alpha, beta, shape=(), observed=None):
         return self._add(_RV(name, shape, invgamma_logp, (as_tensor(float(alpha)), as_tensor(beta)), "log" if observed is None else None, observed))
 
+    def Uniform(self, name, lower=0.0, upper=1.0, shape=()):
+        return self._add(_RV(name, shape, uniform_logp, (as_tensor(float(lower)), as_tensor(float(upper))), "interval", bounds=(float(lower), float(upper))))
+
+    def Binomial(self, name, n, p, observed):
+        return self._add(_RV(name, np.shape(observed), binomial_logp, (as_tensor(n), as_tensor(p)), None, observed))
+
     def Poisson(self, name, mu, observed):
         return self._add(_RV(name, np.shape(observed), poisson_logp, (as_tensor(mu),), None, observed))
 
@@ -298,8 +342,8 @@ class StubModel:
 
     @property
     def value_transforms(self):
-        code = {"log": 1, "logodds": 2}
-        return {rv.value.name: (code[rv.transform], 0.0, 1.0) for rv in self.free if rv.transform}
+        code = {"log": 1, "logodds": 2, "interval": 3}
+        return {rv.value.name: (code[rv.transform], *(rv.bounds or (0.0, 1.0))) for rv in self.free if rv.transform}
 
     @property
     def logp_owners(self):
@@ -315,6 +359,8 @@ class StubModel:
             lp = rv.logp_fn(rv.expr, *rv.params)
             if rv.transform == "log":      # + log|J| = value (LogTransform.log_jac_det, transforms.py:880-891)
                 lp = lp + rv.value
+            if rv.transform == "interval":   # + log|J| (IntervalTransform.log_jac_det, transforms.py:1055-1070)
+                lp = lp + interval_log_jac_det(rv.value, *rv.bounds)
             if rv.transform == "logodds":  # + log|J| = log sigmoid(v) + log1p(-sigmoid(v)) (LogOddsTransform, transforms.py:1076-1088)
                 sv = pt.sigmoid(rv.value)
                 lp = lp + (pt.log(sv) + pt.log1p(-sv))

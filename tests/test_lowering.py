@@ -220,3 +220,39 @@ def test_shape_parameter_distributions_lower_to_the_builder_spec():
     bad._add(sg._RV("g", (), sg.gamma_logp, (al, sg.pt.reciprocal(rate)), None, w))
     with pytest.raises(NotLowerable, match="non-constant alpha"):
         lower_to_spec(bad)
+
+
+def test_uniform_with_its_interval_transform_and_binomial_lower_to_the_builder_spec():
+    """Uniform (continuous.py:309-321) as a free variable: the value variable is `u_interval__`, what the graph sees is
+    `IntervalTransform.backward` (logprob/transforms.py:1026-1053: nested `where` on `neq(a, -inf)` / `neq(b, inf)`, constant
+    conditions that the walker decides) and the factor carries `log_jac_det` (:1055-1070).  Binomial (discrete.py:141-154) with
+    data `n` (vector and scalar): `binomln` arrives as numbers and is checked against n and y."""
+    from scipy import stats
+
+    from pymc_amd.model_spec import ModelBuilder
+
+    cnt = np.array([0.0, 3.0, 1.0, 7.0, 2.0])
+    nn = np.array([5.0, 9.0, 4.0, 7.0, 10.0])
+    m = sg.StubModel()
+    u = m.Uniform("u", 0.2, 0.9)
+    m.Binomial("k", nn, u, observed=cnt)
+    m.Binomial("k2", 12, u, observed=cnt)
+    spec = lower_to_spec(m)
+    b = ModelBuilder()
+    bu = b.Uniform("u", 0.2, 0.9)
+    b.Binomial("k", nn, bu, observed=cnt)
+    b.Binomial("k2", 12, bu, observed=cnt)
+    want = b.build()
+    assert [(v.name, v.value_name, v.shape, v.transform, v.lower, v.upper, v.offset) for v in spec.vars] == \
+        [(v.name, v.value_name, v.shape, v.transform, v.lower, v.upper, v.offset) for v in want.vars]
+    assert spec.vars[0].value_name == "u_interval__"
+    assert len(spec.data) == len(want.data) and all(np.allclose(x, z, rtol=1e-14, atol=0) for x, z in zip(spec.data, want.data))
+    for fa, fb in zip(spec.factors, want.factors):
+        assert (fa.dist, fa.size, fa.args, fa.konst, fa.name) == (fb.dist, fb.size, fb.args, fb.konst, fb.name), (fa, fb)
+    q = np.array([0.3])
+    lp, _ = ref_models.evaluate(spec, q)
+    sig = 1.0 / (1.0 + np.exp(-q[0]))
+    uv = 0.2 + 0.7 * sig
+    want_lp = (stats.uniform(0.2, 0.7).logpdf(uv) + np.log(0.7) + np.log(sig) + np.log1p(-sig)
+               + stats.binom(nn, uv).logpmf(cnt).sum() + stats.binom(12, uv).logpmf(cnt).sum())
+    assert abs(lp - want_lp) < 1e-10
