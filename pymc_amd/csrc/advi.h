@@ -11,8 +11,9 @@
 //   k_advi_rows    the B drawn rows of X (4 KiB each at P = 512; a random gather -- the HBM-bound part): one wave per row holds
 //                  the row in registers, eta = x . z by a wave reduction, residual, log-lik, and r x accumulated over the rows a
 //                  wave owns; per-workgroup partial gradients in fixed order
-//   k_advi_grad    d logp / dz = (N / B) sum of the partials + prior; the loss of the step
-//   k_advi_update  one thread per parameter of (mu, L_tril): gradient of the loss, windowed adagrad
+//   k_advi_grad    d logp / dz = (N / B) sum of the partials + prior (sixteen waves per 64 columns: the chain of dependent loads is
+//                  nwg / 16 long); the loss of the step
+//   k_advi_update  one thread per parameter of (mu, L_tril): gradient of the loss, windowed adagrad over a slot-major ring
 //
 // The random inputs of a step (row indices, z0) are arguments of the step function: the reference
 // draws them with PyTensor RNG ops whose streams do not exist outside it.
@@ -30,8 +31,8 @@ struct AdviDev {
   const double* y;   // [N]
   double* mu;        // [P]
   double* Lt;        // [P (P + 1) / 2] packed rows; diagonal entries are rho (L_ii = softplus(rho_ii))
-  double* acc_mu;    // [P][n_win]
-  double* acc_L;     // [T][n_win]
+  double* acc_mu;    // [n_win][P]   adagrad_window's ring of squared gradients, SLOT-major: a step writes one contiguous slot
+  double* acc_L;     // [n_win][T]   (parameter-major dirtied every line of the 10.5 MB ring per step: a 9 us write-back at the kernel boundary)
   double* z;         // [P]
   double* diag;      // [P] softplus(rho_ii)
   double* rowq;      // [P] per-row logq terms
@@ -109,24 +110,41 @@ __global__ __launch_bounds__(256) void k_advi_rows(AdviDev a, const int64_t* __r
   if (threadIdx.x == 0) { double s = 0.0; for (int ww = 0; ww < 256 / WAVE; ++ww) s += s_ll[ww]; a.llpart[blockIdx.x] = s; }
 }
 
-__global__ __launch_bounds__(256) void k_advi_grad(AdviDev a, int step) {
-  __shared__ double sm[256 / WAVE];
+// sixteen waves per 64 columns: wave w sums workgroups w, w + 16, ... of its columns (the partials of the row pass), the sixteen
+// wave sums are combined in wave order -- fixed order, and the chain of dependent loads is nwg / 16 long instead of nwg
+#define ADVI_GRAD_THREADS 1024
+__global__ __launch_bounds__(ADVI_GRAD_THREADS) void k_advi_grad(AdviDev a, int step) {
+  constexpr int NWV = ADVI_GRAD_THREADS / WAVE;
+  __shared__ double sm[NWV];
+  __shared__ double s_p[NWV][WAVE];
   const double scale = (double)a.N / (double)a.B;   // minibatch_rv.py:87-106
-  double vl = 0.0, q = 0.0;
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < a.P; j += gridDim.x * 256) {
+  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+  const int j = blockIdx.x * WAVE + lane;
+  {
     double s = 0.0;
-    for (int wg = 0; wg < a.nwg; ++wg) s += a.gpart[(int64_t)wg * a.P + j];
+    if (j < a.P) {
+#pragma unroll 8
+      for (int wg = w; wg < a.nwg; wg += NWV) s += a.gpart[(int64_t)wg * a.P + j];
+    }
+    s_p[w][lane] = s;
+  }
+  __syncthreads();
+  if (w == 0 && j < a.P) {
+    double t = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < NWV; ++ww) t += s_p[ww][lane];
     const double zz = a.z[j] / a.prior_sd;
-    a.g[j] = scale * s - zz / a.prior_sd;
+    a.g[j] = scale * t - zz / a.prior_sd;
   }
   if (blockIdx.x == 0) {   // the loss of this step: -datalogp + (logq - varlogp)   (operators.py:64-65)
-    for (int j = threadIdx.x; j < a.P; j += 256) {
-      const double zz = a.z[j] / a.prior_sd;
+    double vl = 0.0, q = 0.0;
+    for (int jj = threadIdx.x; jj < a.P; jj += ADVI_GRAD_THREADS) {
+      const double zz = a.z[jj] / a.prior_sd;
       vl += -0.5 * zz * zz - log(a.prior_sd) - 0.91893853320467274178;
-      q += a.rowq[j];
+      q += a.rowq[jj];
     }
     double ll = 0.0;
-    for (int wg = threadIdx.x; wg < a.nwg; wg += 256) ll += a.llpart[wg];
+    for (int wg = threadIdx.x; wg < a.nwg; wg += ADVI_GRAD_THREADS) ll += a.llpart[wg];
     const double tvl = block_sum<true>(vl, sm), tq = block_sum<true>(q, sm), tll = block_sum<true>(ll, sm);
     if (threadIdx.x == 0) a.hist[step] = -scale * tll + (tq - tvl);
   }
@@ -136,9 +154,10 @@ __global__ __launch_bounds__(256) void k_advi_update(AdviDev a, const double* __
   const int64_t T = (int64_t)a.P * (a.P + 1) / 2;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < T + a.P; t += (int64_t)gridDim.x * 256) {
     double grad, *param, *acc;
+    int64_t stride;
     if (t < a.P) {                      // mu
       grad = -a.g[t];
-      param = a.mu + t; acc = a.acc_mu + t * a.n_win;
+      param = a.mu + t; acc = a.acc_mu + t; stride = a.P;
     } else {                            // L_tril entry (i, j), j <= i, packed row-major
       const int64_t u = t - a.P;
       int i = (int)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
@@ -146,12 +165,12 @@ __global__ __launch_bounds__(256) void k_advi_update(AdviDev a, const double* __
       while ((int64_t)i * (i + 1) / 2 > u) --i;
       const int j = (int)(u - (int64_t)i * (i + 1) / 2);
       grad = -a.g[i] * z0[j];
-      param = a.Lt + u; acc = a.acc_L + u * a.n_win;
+      param = a.Lt + u; acc = a.acc_L + u; stride = T;
       if (i == j) grad = (grad - 1.0 / a.diag[i]) * sigmoid_d(*param);   // entropy term, then through rho2sigma
     }
-    acc[slot] = grad * grad;            // adagrad_window (updates.py:571-584)
+    acc[slot * stride] = grad * grad;   // adagrad_window (updates.py:571-584)
     double s = 0.0;
-    for (int k = 0; k < a.n_win; ++k) s += acc[k];
+    for (int k = 0; k < a.n_win; ++k) s += acc[k * stride];
     *param = *param - a.lr * grad / sqrt(s + a.eps);
   }
 }

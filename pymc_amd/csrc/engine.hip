@@ -2559,13 +2559,13 @@ extern "C" int nuts_advi_steps(nuts_advi* a, int32_t n_steps, const int64_t* idx
   HIPCHK(hipMemcpyAsync(a->z0_dev, z0, (size_t)n_steps * d.P * sizeof(double), hipMemcpyHostToDevice, s));
   const int P = d.P;
   const int64_t T = (int64_t)P * (P + 1) / 2;
-  const int zgrid = (P + 3) / 4, ggrid = std::max(1, std::min(8, (P + 255) / 256));
+  const int zgrid = (P + 3) / 4, ggrid = (P + WAVE - 1) / WAVE;
   const int ugrid = (int)std::min<int64_t>(4096, (T + P + 255) / 256);
   for (int st = 0; st < n_steps; ++st) {
     const double* z0s = a->z0_dev + (size_t)st * P;
     hipLaunchKernelGGL(k_advi_z, dim3(zgrid), dim3(256), 0, s, d, z0s);
     hipLaunchKernelGGL(k_advi_rows, dim3(d.nwg), dim3(256), 0, s, d, a->idx_dev + (size_t)st * d.B);
-    hipLaunchKernelGGL(k_advi_grad, dim3(ggrid), dim3(256), 0, s, d, st);
+    hipLaunchKernelGGL(k_advi_grad, dim3(ggrid), dim3(ADVI_GRAD_THREADS), 0, s, d, st);
     hipLaunchKernelGGL(k_advi_update, dim3(ugrid), dim3(256), 0, s, d, z0s, (int)(a->steps_done % d.n_win));
     a->steps_done++;
   }
