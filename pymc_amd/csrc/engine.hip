@@ -2515,7 +2515,9 @@ extern "C" nuts_advi* nuts_advi_create(const nuts_advi_config* c) {
   d.Lt = a->keep(dev_upload(lt.data(), lt.size()));
   d.acc_mu = a->keep(dev_alloc<double>((size_t)P * d.n_win));
   d.acc_L = a->keep(dev_alloc<double>(T * d.n_win));
-  d.z = a->keep(dev_alloc<double>(P)); d.diag = a->keep(dev_alloc<double>(P)); d.rowq = a->keep(dev_alloc<double>(P)); d.g = a->keep(dev_alloc<double>(P));
+  d.z = a->keep(dev_alloc<double>(2 * (size_t)P)); d.diag = a->keep(dev_alloc<double>(2 * (size_t)P)); d.rowq = a->keep(dev_alloc<double>(2 * (size_t)P));
+  d.g = a->keep(dev_alloc<double>(P));
+  d.par = 0; d.pad_ = 0;
   const int rows_per_wg = (256 / WAVE) * ADVI_ROWS_PER_WAVE;
   d.nwg = (d.B + rows_per_wg - 1) / rows_per_wg;
   d.gpart = a->keep(dev_alloc<double>((size_t)d.nwg * P));
@@ -2559,14 +2561,19 @@ extern "C" int nuts_advi_steps(nuts_advi* a, int32_t n_steps, const int64_t* idx
   HIPCHK(hipMemcpyAsync(a->z0_dev, z0, (size_t)n_steps * d.P * sizeof(double), hipMemcpyHostToDevice, s));
   const int P = d.P;
   const int64_t T = (int64_t)P * (P + 1) / 2;
-  const int zgrid = (P + 3) / 4, ggrid = (P + WAVE - 1) / WAVE;
-  const int ugrid = (int)std::min<int64_t>(4096, (T + P + 255) / 256);
+  const int zgrid = (P + 3) / 4, ugrid = (P + 1) / 2;
   for (int st = 0; st < n_steps; ++st) {
     const double* z0s = a->z0_dev + (size_t)st * P;
-    hipLaunchKernelGGL(k_advi_z, dim3(zgrid), dim3(256), 0, s, d, z0s);
+    // (z of step t + 1 is formed by the update of step t from the entries it has just written; only the first step of a call
+    // reads L for it)
+    if (st == 0) hipLaunchKernelGGL(k_advi_z, dim3(zgrid), dim3(256), 0, s, d, z0s);
     hipLaunchKernelGGL(k_advi_rows, dim3(d.nwg), dim3(256), 0, s, d, a->idx_dev + (size_t)st * d.B);
-    hipLaunchKernelGGL(k_advi_grad, dim3(ggrid), dim3(ADVI_GRAD_THREADS), 0, s, d, st);
-    hipLaunchKernelGGL(k_advi_update, dim3(ugrid), dim3(256), 0, s, d, z0s, (int)(a->steps_done % d.n_win));
+    const double* z0n = st + 1 < n_steps ? z0s + P : (const double*)nullptr;
+    const int slot = (int)(a->steps_done % d.n_win);
+    if (P <= 256) hipLaunchKernelGGL(k_advi_row_update<1>, dim3(ugrid), dim3(256), 0, s, d, z0s, z0n, slot, st);
+    else if (P <= 512) hipLaunchKernelGGL(k_advi_row_update<2>, dim3(ugrid), dim3(256), 0, s, d, z0s, z0n, slot, st);
+    else hipLaunchKernelGGL(k_advi_row_update<4>, dim3(ugrid), dim3(256), 0, s, d, z0s, z0n, slot, st);
+    d.par ^= 1;
     a->steps_done++;
   }
   if (loss) HIPCHK(hipMemcpyAsync(loss, d.hist, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -1,8 +1,8 @@
 """Throughput of the two BASELINE.json workloads next to the NUTS path, on one GPU:
 
   --workload c4   configs[3]: GLM, N = 1 M observations x P = 512 covariates, full-rank ADVI on minibatches of 1024 rows
-                  -> optimisation steps per second (one step = `nuts_advi_steps`' four launches: z = L z0 + mu, the gathered
-                     rows, d/dmu and d/dL, the adagrad_window update), with the bytes a step has to move and the CPU oracle's
+                  -> optimisation steps per second (one step = `nuts_advi_steps`' two launches: the gathered rows, then the
+                     row-aligned update that also finishes d logp / dz and forms the next step's z), with the bytes a step has to move and the CPU oracle's
                      steps per second beside it;
   --workload c5   configs[4]: Normal mixture, N = 100 k latent assignments + K component means:
                   `CompoundStep([NUTS(mu), CategoricalGibbsMetropolis(c)])` iterations per second, the Gibbs sweep alone, and the
@@ -48,9 +48,9 @@ def bench_c4(args):
     out = {
         "workload": f"C4 glm-advi: N={m.X.shape[0]} P={P}, full-rank ADVI, minibatch {B}, adagrad_window(n_win={n_win})",
         "metric": "ADVI optimisation steps/sec", "value": args.steps / T, "unit": "steps/s", "steps": args.steps, "warmup": args.warmup,
-        "us_per_step": 1e6 * T / args.steps, "launches_per_step": 4, "dtype": "f64", "data": "synthetic",
+        "us_per_step": 1e6 * T / args.steps, "launches_per_step": 2, "dtype": "f64", "data": "synthetic",
         "step_bytes_algorithmic": step_bytes, "achieved_GBps": step_bytes * args.steps / T / 1e9,
-        "note": "latency-bound: four dependent launches per step move ~%.1f MB; X (%.1f GB) stays resident in HBM, only the drawn rows are read"
+        "note": "latency-bound: two dependent launches per step move ~%.1f MB; X (%.1f GB) stays resident in HBM, only the drawn rows are read"
                 % (step_bytes / 1e6, m.X.nbytes / 1e9),
         "final_loss": float(loss[-1]), "host_build_s": t_build, "first_call_s_incl_upload": t_first,
     }
