@@ -18,7 +18,7 @@ imports pytensor and looks at nothing but
 -- and is exercised on stub graphs that transcribe what the reference's `logp` methods build (tests/stubgraph.py:
 continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390 HalfCauchy, :1478-1486 Exponential,
 :1570-1576 Laplace, :1807-1821 LogNormal, :1935-1950 StudentT, :1248-1262 Beta, :2512-2521 Gamma, :2631-2639 InverseGamma,
-:309-321 Uniform, discrete.py:351-374 Bernoulli, :141-154 Binomial, :581-597 Poisson; transforms.py:880-891 log, :1026-1070 interval,
+:309-321 Uniform, :720-746 TruncatedNormal, discrete.py:351-374 Bernoulli, :141-154 Binomial, :581-597 Poisson; transforms.py:880-891 log, :1026-1070 interval,
 :1076-1088 logodds).
 
 How a factor is recognised: the graph is first turned into a small expression tree (constants folded, broadcasts /
@@ -32,7 +32,8 @@ caller hands over a REWRITTEN graph); (2) that `pt.pow(x, 2)` is still emitted a
 is accepted too); (3) constant folding of `pt.log(pt.sqrt(2.0 * np.pi))` is done here numerically, the tolerance on
 matched constants is 1e-12; (4) dims / coords, `pm.Data` containers (shared variables are read with `.get_value()` at
 lowering time; re-lowering or `set_extra_values` is needed when they change); (5) the distributions of the spec IR not
-listed above (TruncatedNormal: its template is to be written the same way) and everything outside the IR, for which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU
+listed above -- none is left: TruncatedNormal (continuous.py:720-746) is matched by its outer shape and its normalising term
+verified by evaluation (`_match_truncnormal`) -- and everything outside the IR, for which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU
 path for that model.
 """
 
@@ -192,6 +193,22 @@ def _solve_const(t, c, env: Dict[str, Any]) -> bool:
         return _solve_const(t[1], np.exp(c), env)
     if t[0] == "neg":
         return _solve_const(t[1], -c, env)
+    if t[0] == "sub" and len(t) == 3 and isinstance(t[1], W) and isinstance(t[2], W):
+        # `value - mu` with both constants arrives as one array.  If one of the two is known already (TruncatedNormal: the value
+        # also stands in the bound switches) the other follows; otherwise the difference is taken as the value and mu as 0 --
+        # the same density, stated about the shifted data.
+        a, b = env.get(t[1].name), env.get(t[2].name)
+        if a is not None and a[0] == "const" and b is None:
+            other = np.asarray(a[1], dtype="float64") - c
+            r = np.round(np.mean(other), 12)             # a scalar mu shows up as an array of (nearly) equal numbers: state it as the scalar
+            if other.size > 1 and np.all(np.asarray(a[1], dtype="float64") - r == c):
+                other = np.asarray(r)
+            return _solve_const(t[2], other, env)
+        if b is not None and b[0] == "const" and a is None:
+            return _solve_const(t[1], c + np.asarray(b[1], dtype="float64"), env)
+        if a is None and b is None:
+            return _solve_const(t[1], c, env) and _solve_const(t[2], np.asarray(0.0), env)
+        return a is not None and b is not None and a[0] == "const" and b[0] == "const" and np.allclose(a[1] - b[1], c, rtol=1e-12, atol=1e-300)
     if t[0] in ("sub", "add") and len(t) == 3:
         for i, o in ((1, 2), (2, 1)):
             if not isinstance(t[i], W) and t[i][0] == "const":
@@ -449,6 +466,110 @@ TEMPLATES_POST: List[Tuple[int, Any, Tuple[str, ...], Any]] = [
 ]
 
 
+# ---- TruncatedNormal: the outer shape is matched structurally (bound switches around Normal.logp - norm), the normalising term
+# ---- -- a deep graph of erfcx / erf / switch whose constant sub-expressions arrive folded in every combination of constant and
+# ---- variable mu / sigma -- is VERIFIED BY EVALUATION against the closed form at random points of its inputs.
+def _eval_tree(node, values: Dict[int, Any]):
+    """Numerical value of an expression tree; `values[id(input variable)]` supplies the leaves."""
+    from scipy import special as sp
+
+    kind = node[0]
+    if kind == "const":
+        return node[1]
+    if kind == "input":
+        return values[id(node[1])]
+    a = [_eval_tree(k, values) for k in node[1:] if isinstance(k, tuple)]
+    with np.errstate(all="ignore"):
+        if kind in _NUMPY_FOLD:
+            return _NUMPY_FOLD[kind](*a)
+        simple = {"erf": sp.erf, "erfc": sp.erfc, "erfcx": sp.erfcx, "sigmoid": sp.expit, "softplus": lambda x: np.logaddexp(0.0, x),
+                  "gt": np.greater, "lt": np.less, "ge": np.greater_equal, "le": np.less_equal, "eq": np.equal, "neq": np.not_equal,
+                  "and": np.logical_and, "or": np.logical_or}
+        if kind in simple:
+            return simple[kind](*a)
+        if kind == "switch":
+            return np.where(np.asarray(a[0]) != 0, a[1], a[2])
+    raise NotLowerable(f"cannot evaluate `{kind}` while verifying a sub-expression")
+
+
+def _inputs_of(node, acc: Dict[int, Any]):
+    if node[0] == "input":
+        acc[id(node[1])] = node[1]
+    elif node[0] != "const":
+        for k in node[1:]:
+            if isinstance(k, tuple):
+                _inputs_of(k, acc)
+    return acc
+
+
+def _match_truncnormal(node):
+    """continuous.py:720-746.  Returns (value, mu, sigma, lower, upper) nodes / numbers, or None."""
+    from scipy import special as sp
+
+    lo = hi = None
+    inner = node
+    vnode = None
+    # `value > upper` / `value < lower` are written with operators in the reference: when the bound is a constant (a subclass of the
+    # variable class) Python dispatches to the REFLECTED comparison of the bound, so both spellings of each test are accepted
+    def bound_switch(tree, op_direct, op_reflected):
+        for tmpl in (("switch", (op_direct, W("v"), W("b")), K(-math.inf), W("in")), ("switch", (op_reflected, W("b"), W("v")), K(-math.inf), W("in"))):
+            env: Dict[str, Any] = {}
+            if unify(tmpl, tree, env) and _num(env["b"]) is not None:
+                return _num(env["b"]), env["in"], env["v"]
+        return None
+
+    for _ in range(2):
+        got = bound_switch(inner, "gt", "lt") if (hi is None and lo is None) else None
+        if got is not None:
+            hi, inner, vnode = got
+            continue
+        got = bound_switch(inner, "lt", "gt") if lo is None else None
+        if got is not None:
+            if vnode is not None and not _same(vnode, got[2]):
+                return None
+            lo, inner, vnode = got
+    if lo is None and hi is None:
+        return None
+    env = {}
+    if not unify(("sub", W("npart"), W("norm")), inner, env):
+        return None
+    nenv: Dict[str, Any] = {"value": vnode}   # (known from the bound switches: a folded `value - mu` can then be split)
+    if not unify(TEMPLATES[0][1], env["npart"], nenv) or not _same(nenv["value"], vnode):
+        return None
+    mu_n, sg_n, norm = nenv["mu"], nenv["sigma"], env["norm"]
+    # verify `norm` = log(Phi((hi - mu) / sigma) - Phi((lo - mu) / sigma)) (one-sided: the log-cdf / log-survival function)
+    inputs = _inputs_of(norm, _inputs_of(sg_n, _inputs_of(mu_n, {})))
+    rng = np.random.default_rng(20240607)
+    checked = 0
+    for _try in range(40):
+        vals = {k: rng.normal(size=tuple(getattr(getattr(v, "type", None), "shape", ()) or ())) for k, v in inputs.items()}
+        mu_v, sg_v = np.asarray(_eval_tree(mu_n, vals), dtype="float64"), np.asarray(_eval_tree(sg_n, vals), dtype="float64")
+        if not np.all(sg_v > 0):
+            continue
+        a_, b_ = ((lo - mu_v) / sg_v if lo is not None else -np.inf), ((hi - mu_v) / sg_v if hi is not None else np.inf)
+        with np.errstate(all="ignore"):
+            if lo is not None and hi is not None:
+                # log(Phi(b) - Phi(a)) through the tail that keeps precision
+                want = np.where(a_ > 0, sp.log_ndtr(-a_) + np.log1p(-np.exp(sp.log_ndtr(-b_) - sp.log_ndtr(-a_))),
+                                sp.log_ndtr(b_) + np.log1p(-np.exp(sp.log_ndtr(a_) - sp.log_ndtr(b_))))
+            elif lo is not None:
+                want = sp.log_ndtr(-a_)
+            else:
+                want = sp.log_ndtr(b_)
+            got = np.asarray(_eval_tree(norm, vals), dtype="float64")
+        ok = np.isfinite(want)
+        if not np.any(ok):
+            continue
+        if not np.allclose(np.broadcast_to(got, np.shape(want))[ok], want[ok], rtol=1e-9, atol=1e-12):
+            return None
+        checked += 1
+        if checked >= 3:
+            break
+    if checked == 0:
+        return None
+    return vnode, mu_n, sg_n, lo, hi
+
+
 # ---------------------------------------------------------------------------
 # the walker
 # ---------------------------------------------------------------------------
@@ -611,6 +732,13 @@ class _Lowering:
                     raise NotLowerable("Exponential with a non-constant scale")
                 args = (args[0], ms.Term(ms.Operand(ms.OP_CONST, 1.0 / mu.a.c)))
             self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), args, 0.0, name))
+            return
+        tn = _match_truncnormal(node)
+        if tn is not None:
+            vnode, mu_n, sg_n, lo, hi = tn
+            t_mu, t_sg = self.term(mu_n), self.term(sg_n)
+            args = (self.term(vnode), t_mu, t_sg, ms.Term(ms.Operand(ms.OP_CONST, -math.inf if lo is None else lo)))
+            self.spec.factors.append(ms.Factor(ms.D_TRUNCNORMAL, max(self._size(a) for a in args), args, math.inf if hi is None else hi, name))
             return
         for dist, tmpl, argnames, post in TEMPLATES_POST:
             env = {}

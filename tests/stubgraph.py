@@ -3,7 +3,7 @@ the build image).  TEST INFRASTRUCTURE.
 
 * graph protocol: `Variable(owner, name)`, `Apply(op, inputs)`, ops named as PyTensor names them (`Elemwise` with a
   `scalar_op` object whose class is `Add`, `Mul`, `Sub`, `TrueDiv`, `Pow`, `Exp`, `Log`, `Log1p`, `Sqrt`, `Neg`, `Switch`, `GE`,
-  `GT`, `LT`, `LE`, `EQ`, `OR`, `AND`, `Sigmoid`, `GammaLn`, `Reciprocal`, `Sign`; `DimShuffle`; `Sum` with `.axis`; `AdvancedSubtensor1`; `CheckParameterValue`; constants carry
+  `GT`, `LT`, `LE`, `EQ`, `NEQ`, `OR`, `AND`, `Sigmoid`, `Softplus`, `GammaLn`, `Reciprocal`, `Sign`, `Erf`, `Erfc`, `Erfcx`, `Sqr`, `Second`; `DimShuffle`; `Sum` with `.axis`; `AdvancedSubtensor1`; `CheckParameterValue`; constants carry
   `.data`), with operator overloading so that the distribution code below reads like the reference's;
 * distributions: `logp` bodies TRANSCRIBED from the reference, each citing its lines -- these build exactly the expression a
   `pm.Model` would hand to the compiler BEFORE rewrites (`Model.logp`, model/core.py:612-695);
@@ -91,7 +91,7 @@ class All:
 
 
 for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "EQ", "OR", "AND", "Sigmoid", "Abs",
-           "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus"):
+           "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus", "Erf", "Erfc", "Erfcx", "Sqr"):
     globals()[_n] = type(_n, (), {})
 
 
@@ -137,6 +137,11 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     where = staticmethod(lambda c, a, b: elemwise(Switch, c, a, b))
     fill = staticmethod(lambda a, b: elemwise(Second, a, b))
     softplus = staticmethod(lambda a: elemwise(Softplus, a))
+    erf = staticmethod(lambda a: elemwise(Erf, a))
+    erfc = staticmethod(lambda a: elemwise(Erfc, a))
+    erfcx = staticmethod(lambda a: elemwise(Erfcx, a))
+    sqr = staticmethod(lambda a: elemwise(Sqr, a))
+    square = staticmethod(lambda a: elemwise(Sqr, a))
     inf = np.inf
 
 
@@ -261,6 +266,46 @@ def interval_log_jac_det(value, a, b):      # logprob/transforms.py:1055-1070
                     pt.where(pt.or_(pt.neq(a, -pt.inf), pt.neq(b, pt.inf)), value, value * 0.0))
 
 
+def normal_lcdf(mu, sigma, x):              # distributions/dist_math.py:126-133
+    z = (x - mu) / sigma
+    return pt.switch(pt.lt(z, -1.0), pt.log(pt.erfcx(-z / pt.sqrt(2.0)) / 2.0) - pt.sqr(z) / 2.0, pt.log1p(-pt.erfc(z / pt.sqrt(2.0)) / 2.0))
+
+
+def normal_lccdf(mu, sigma, x):             # distributions/dist_math.py:136-142
+    z = (x - mu) / sigma
+    return pt.switch(pt.gt(z, 1.0), pt.log(pt.erfcx(z / pt.sqrt(2.0)) / 2.0) - pt.sqr(z) / 2.0, pt.log1p(-pt.erfc(-z / pt.sqrt(2.0)) / 2.0))
+
+
+def log_diff_normal_cdf(mu, sigma, x, y):   # distributions/dist_math.py:145-183
+    x = (x - mu) / sigma / pt.sqrt(2.0)
+    y = (y - mu) / sigma / pt.sqrt(2.0)
+    return pt.log(0.5) + pt.switch(
+        pt.gt(y, 0),
+        -pt.square(y) + pt.log(pt.erfcx(y) - pt.exp(pt.square(y) - pt.square(x)) * pt.erfcx(x)),
+        pt.switch(pt.lt(x, 0), -pt.square(x) + pt.log(pt.erfcx(-x) - pt.exp(pt.square(x) - pt.square(y)) * pt.erfcx(-y)),
+                  pt.log(pt.erf(x) - pt.erf(y))))
+
+
+def truncnormal_logp(value, mu, sigma, lower, upper):   # distributions/continuous.py:720-746 (`None` = unbounded on that side)
+    lb, ub = lower is not None, upper is not None
+    if lb and ub:
+        norm = log_diff_normal_cdf(mu, sigma, upper, lower)
+    elif lb:
+        norm = normal_lccdf(mu, sigma, lower)
+    elif ub:
+        norm = normal_lcdf(mu, sigma, upper)
+    else:
+        norm = 0.0
+    logp = normal_logp(value, mu, sigma) - norm          # `_logprob_helper(Normal.dist(mu, sigma), value)`
+    if lb:
+        logp = pt.switch(value < lower, -np.inf, logp)
+    if ub:
+        logp = pt.switch(value > upper, -np.inf, logp)
+    if lb and ub:
+        logp = check_parameters(logp, pt.le(lower, upper), msg="lower_bound <= upper_bound")
+    return logp
+
+
 def bernoulli_logp(value, p):               # distributions/discrete.py:362-374
     res = pt.switch(pt.or_(pt.lt(value, 0), pt.gt(value, 1)), -np.inf, pt.switch(value, pt.log(p), pt.log1p(-p)))
     return check_parameters(res, 0 <= p, p <= 1, msg="0 <= p <= 1")
@@ -321,6 +366,14 @@ class StubModel:
 
     def Uniform(self, name, lower=0.0, upper=1.0, shape=()):
         return self._add(_RV(name, shape, uniform_logp, (as_tensor(float(lower)), as_tensor(float(upper))), "interval", bounds=(float(lower), float(upper))))
+
+    def TruncatedNormal(self, name, mu=0.0, sigma=1.0, lower=None, upper=None, shape=(), observed=None):
+        lo = None if lower is None else as_tensor(float(lower))
+        hi = None if upper is None else as_tensor(float(upper))
+        fn = lambda v, m_, s_: truncnormal_logp(v, m_, s_, lo, hi)   # noqa: E731
+        if observed is None:   # the reference's default transform of a doubly bounded distribution: interval
+            return self._add(_RV(name, shape, fn, (as_tensor(mu), as_tensor(sigma)), "interval", bounds=(float(lower), float(upper))))
+        return self._add(_RV(name, shape, fn, (as_tensor(mu), as_tensor(sigma)), None, observed))
 
     def Binomial(self, name, n, p, observed):
         return self._add(_RV(name, np.shape(observed), binomial_logp, (as_tensor(n), as_tensor(p)), None, observed))

@@ -256,3 +256,58 @@ def test_uniform_with_its_interval_transform_and_binomial_lower_to_the_builder_s
     want_lp = (stats.uniform(0.2, 0.7).logpdf(uv) + np.log(0.7) + np.log(sig) + np.log1p(-sig)
                + stats.binom(nn, uv).logpmf(cnt).sum() + stats.binom(12, uv).logpmf(cnt).sum())
     assert abs(lp - want_lp) < 1e-10
+
+
+@pytest.mark.parametrize("kw", [dict(lower=-1.0, upper=2.0), dict(lower=-0.8), dict(upper=1.5)])
+def test_truncated_normal_lowers_to_the_builder_spec(kw):
+    """TruncatedNormal (continuous.py:720-746): bound switches around `Normal.logp - norm`, `norm` one of `log_diff_normal_cdf`,
+    `normal_lccdf`, `normal_lcdf` (dist_math.py:126-183).  The outer shape is matched structurally -- with both spellings of the
+    bound tests, because `value > upper` dispatches to the reflected comparison when the bound is a constant -- and `norm` is
+    verified by evaluating it against the closed form at random inputs.  Observed with variable / constant location and scale
+    (a constant location arrives folded into `value - mu` and is recovered from the value the bound tests name); free (both bounds,
+    interval transform).  Field for field the builder's spec; log-density against scipy.stats.truncnorm."""
+    from scipy import stats
+
+    from pymc_amd.model_spec import ModelBuilder
+
+    d = np.array([0.3, -0.5, 1.2, 0.1])
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 5.0)
+    s_ = m.HalfNormal("sg", 2.0)
+    m.TruncatedNormal("obs", mu, s_, observed=d, **kw)
+    m.TruncatedNormal("obs2", 0.25, s_, observed=d, **kw)
+    m.TruncatedNormal("obs3", mu, 1.5, observed=d, **kw)
+    spec = lower_to_spec(m)
+    b = ModelBuilder()
+    bm = b.Normal("mu", 0.0, 5.0)
+    bs = b.HalfNormal("sg", 2.0)
+    b.TruncatedNormal("obs", mu=bm, sigma=bs, observed=d, **kw)
+    b.TruncatedNormal("obs2", mu=0.25, sigma=bs, observed=d, **kw)
+    b.TruncatedNormal("obs3", mu=bm, sigma=1.5, observed=d, **kw)
+    _assert_same_spec(spec, b.build())
+    q = np.array([0.3, -0.2])
+    lp, _ = ref_models.evaluate(spec, q)
+    s = np.exp(-0.2)
+    lo, hi = kw.get("lower", -np.inf), kw.get("upper", np.inf)
+    tn = lambda loc, sc: stats.truncnorm.logpdf(d, (lo - loc) / sc, (hi - loc) / sc, loc=loc, scale=sc).sum()   # noqa: E731
+    want = stats.norm(0, 5).logpdf(0.3) + stats.halfnorm(scale=2.0).logpdf(s) - 0.2 + tn(0.3, s) + tn(0.25, s) + tn(0.3, 1.5)
+    assert abs(lp - want) < 1e-10
+
+    if "lower" in kw and "upper" in kw:   # a free one: `t_interval__`, IntervalTransform.backward inside both bound tests
+        m = sg.StubModel()
+        t = m.TruncatedNormal("t", 0.5, 2.0, **kw)
+        m.Normal("y", t, 1.0, observed=d)
+        spec = lower_to_spec(m)
+        b = ModelBuilder()
+        bt = b.TruncatedNormal("t", mu=0.5, sigma=2.0, **kw)
+        b.Normal("y", bt, 1.0, observed=d)
+        _assert_same_spec(spec, b.build())
+        assert spec.vars[0].value_name == "t_interval__" and (spec.vars[0].lower, spec.vars[0].upper) == (-1.0, 2.0)
+
+    # a normalising term that is NOT the truncated normal's is not accepted on the strength of the outer shape
+    bad = sg.StubModel()
+    loc = bad.Normal("loc", 0.0, 1.0)
+    fake = lambda v, l_: sg.pt.switch(v > 2.0, -np.inf, sg.normal_logp(v, l_, 1.0) - sg.normal_lcdf(l_, 1.0, 1.9))   # noqa: E731
+    bad._add(sg._RV("z", (), fake, (loc,), None, d))
+    with pytest.raises(NotLowerable):
+        lower_to_spec(bad)
