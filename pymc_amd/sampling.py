@@ -61,10 +61,12 @@ def init_nuts(
     jitter_max_retries: int = 10,
     device: Optional[int] = None,
     tune: Optional[int] = None,
+    n_init: int = 200_000,
     **step_kwargs,
 ):
-    """`init_nuts` (mcmc.py:1759-2021): adapt_diag, jitter+adapt_diag, jitter+adapt_diag_grad, adapt_full,
-    jitter+adapt_full."""
+    """`init_nuts` (mcmc.py:1759-2021), all nine modes: adapt_diag, jitter+adapt_diag, jitter+adapt_diag_grad, adapt_full,
+    jitter+adapt_full; advi, advi+adapt_diag, advi_map (mean-field ADVI over the device log-density, `pymc_amd/variational.py`)
+    and map (`pymc_amd/tuning.py`)."""
     from pymc_amd.value_grad import DeviceValueGradFunction
 
     if logp_dlogp_func is None:
@@ -101,9 +103,30 @@ def init_nuts(
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             potential = QuadPotentialFullAdapt(n, mean, np.eye(n), 10, rng=random_seed_list[0])
+    elif init in ("advi+adapt_diag", "advi", "advi_map"):  # mcmc.py:1912-1978
+        from pymc_amd.quadpotential import QuadPotentialDiag
+        from pymc_amd.tuning import find_MAP
+        from pymc_amd.variational import ADVI, CheckParametersConvergence, adagrad_window
+
+        cb = [CheckParametersConvergence(tolerance=1e-2, diff="absolute"), CheckParametersConvergence(tolerance=1e-2, diff="relative")]  # mcmc.py:1860-1863
+        start = find_MAP(spec, logp_dlogp_func, start=points[0]) if init == "advi_map" else points[0]
+        approx = ADVI(spec, logp_dlogp_func, random_seed=random_seed_list[0], start=start).fit(n_init, callbacks=cb, obj_optimizer=adagrad_window)
+        points = approx.sample(draws=chains, random_seed=random_seed_list[0])
+        cov = approx.std ** 2
+        if init == "advi+adapt_diag":
+            potential = QuadPotentialDiagAdapt(n, np.array(approx.mean, copy=True), cov, 50, rng=random_seed_list[0])
+        else:
+            potential = QuadPotentialDiag(cov, rng=random_seed_list[0])
+    elif init == "map":  # mcmc.py:1979-1983 (the negated Hessian of the log-density is handed over AS the covariance, as there)
+        from pymc_amd.quadpotential import QuadPotentialFull
+        from pymc_amd.tuning import find_hessian, find_MAP
+
+        start = find_MAP(spec, logp_dlogp_func, start=points[0])
+        cov = -find_hessian(spec, logp_dlogp_func, start, negate_output=False)
+        points = [start] * chains
+        potential = QuadPotentialFull(cov, rng=random_seed_list[0])
     else:
-        # advi / advi_map / map initialisers need variational inference and find_MAP: outside the NUTS path
-        raise ValueError(f"Unknown or unsupported initializer: {init}.")
+        raise ValueError(f"Unknown initializer: {init}.")
     step = NUTS(
         potential=potential, model=spec, rng=random_seed_list[0], initial_point=points[0],
         logp_dlogp_func=logp_dlogp_func, **step_kwargs,

@@ -56,6 +56,17 @@ class _AdagradWindow:
     n_win: int = 10
 
 
+def _resolve_optimizer(obj_optimizer) -> "_AdagradWindow":
+    """`obj_optimizer` as the reference accepts it: `pm.adagrad_window` itself (mcmc.py:1919) or a configured
+    `pm.adagrad_window(learning_rate=...)` (updates.py:565-566 returns a partial when called without loss / params)."""
+    o = adagrad_window if obj_optimizer is None else obj_optimizer
+    for _ in range(3):
+        if isinstance(o, _AdagradWindow):
+            return o
+        o = o()
+    raise TypeError("obj_optimizer must be pymc_amd.variational.adagrad_window or a configured instance of it")
+
+
 class FullRankApproximation:
     """What `fit` returns (`Approximation` over one `FullRankGroup`)."""
 
@@ -160,7 +171,7 @@ class FullRankADVI:
         return idx, z0
 
     def run_steps(self, idx: np.ndarray, z0: np.ndarray, obj_optimizer=None) -> np.ndarray:
-        opt = (obj_optimizer or adagrad_window())()
+        opt = _resolve_optimizer(obj_optimizer)
         h = self._engine(opt)
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         z0 = np.ascontiguousarray(z0, dtype="float64")
@@ -201,8 +212,119 @@ class FullRankADVI:
             pass
 
 
-def fit(n=10000, method="fullrank_advi", model=None, random_seed=None, start=None, **kwargs):
-    """`pm.fit` (inference.py:680-775) for the one method built here."""
-    if method not in ("fullrank_advi", "fullrank"):
-        raise KeyError(f"method should be one of {{'fullrank_advi'}} (got {method!r}); the other families are outside SURVEY 8f-3")
-    return FullRankADVI(model=model, random_seed=random_seed, start=start).fit(n, **kwargs)
+# ---- mean-field ADVI on an arbitrary model spec: what `init_nuts` runs for its "advi*" modes (mcmc.py:1912-1978) -----------------
+class CheckParametersConvergence:
+    """variational/callbacks.py:41-95: every `every` steps, stop when the largest (absolute / relative) parameter change is below
+    `tolerance`."""
+
+    def __init__(self, every=100, tolerance=1e-3, diff="relative", ord=np.inf):
+        self.every, self.tolerance, self.ord, self.prev = every, tolerance, ord, None
+        self._diff = {"relative": lambda c, p: (np.abs(c - p) + 1e-6) / (np.abs(p) + 1e-6), "absolute": lambda c, p: np.abs(c - p)}[diff]
+
+    def __call__(self, approx, _, i):
+        if self.prev is None:
+            self.prev = np.concatenate([np.ravel(p) for p in approx.params])
+            return
+        if i % self.every or i < self.every:
+            return
+        current = np.concatenate([np.ravel(p) for p in approx.params])
+        delta = self._diff(current, self.prev)
+        self.prev = current
+        if np.linalg.norm(delta, self.ord) < self.tolerance:
+            raise StopIteration(f"Convergence achieved at {i}")
+
+
+class MeanFieldApproximation:
+    """`MeanFieldGroup` (variational/approximations.py:46-116): q(z) = N(mu, diag(softplus(rho))^2) over the raveled unconstrained
+    vector."""
+
+    def __init__(self, spec, start=None):
+        from pymc_amd.blocking import DictToArrayBijection
+        from pymc_amd.sampling import initial_point
+
+        point = dict(initial_point(spec))
+        if start:
+            point.update({k: np.asarray(v, dtype="float64") for k, v in start.items()})
+        self.spec = spec
+        self._map = DictToArrayBijection.map({v.value_name: point[v.value_name] for v in spec.vars})
+        self.mu = np.array(self._map.data, dtype="float64")
+        self.rho = np.zeros_like(self.mu)               # approximations.py:70-84: rho = 0, i.e. std = log 2
+        self.hist = np.asarray(())
+
+    @property
+    def params(self):
+        return [self.mu, self.rho]
+
+    @property
+    def mean(self):
+        return self.mu
+
+    @property
+    def std(self):
+        return np.logaddexp(0.0, self.rho)              # rho2sigma
+
+    def sample(self, draws=500, random_seed=None):
+        """`draws` points (dicts over the value variables), opvi.py:1488-1560."""
+        from pymc_amd.blocking import DictToArrayBijection, RaveledVars
+
+        rng = np.random.default_rng(random_seed)
+        z = self.mu + self.std * rng.normal(size=(draws, len(self.mu)))
+        return [DictToArrayBijection.rmap(RaveledVars(z[i], self._map.point_map_info)) for i in range(draws)]
+
+
+class ADVI:
+    """`pm.ADVI` / `KLqp(MeanField)` (variational/inference.py:438-494): single-sample reparametrised gradient of
+    KL(q || p) = E_q[log q - log p], `adagrad_window` by default.  The log-density and its gradient at z = mu + sigma * eps are
+    ONE call of the device `ValueGradFunction` per step; the update of the 2 n parameters is host arithmetic (this is an
+    initialiser that runs once before sampling, not a hot path).  The standard normals are NumPy's, not PyTensor's stream
+    (unpinned, like the start-point jitter)."""
+
+    def __init__(self, spec, logp_dlogp_func, random_seed=None, start=None, approx=None):
+        self.spec, self.func = spec, logp_dlogp_func
+        self.rng = np.random.default_rng(random_seed)
+        self.approx = approx if approx is not None else MeanFieldApproximation(spec, start)
+
+    def fit(self, n=10000, callbacks=None, obj_optimizer=None, progressbar=False, **_ignored):
+        a = self.approx
+        opt = _resolve_optimizer(obj_optimizer)
+        d = len(a.mu)
+        acc = np.zeros((2 * d, opt.n_win))
+        hist = []
+        LOG_SQRT_2PI = 0.5 * np.log(2.0 * np.pi)
+        try:
+            for i in range(n):
+                eps = self.rng.normal(size=d)
+                sigma = np.logaddexp(0.0, a.rho)
+                z = a.mu + sigma * eps
+                lp, g = self.func._pytensor_function(np.ascontiguousarray(z))
+                g = np.asarray(g)
+                logq = np.sum(-0.5 * eps * eps - LOG_SQRT_2PI - np.log(sigma))
+                loss = logq - lp
+                if not np.isfinite(loss):
+                    raise FloatingPointError(f"NaN occurred in optimization at step {i}")
+                grad = np.concatenate([-g, (-g * eps - 1.0 / sigma) / (1.0 + np.exp(-a.rho))])     # d loss / d(mu, rho)
+                acc[:, i % opt.n_win] = grad * grad                                                  # updates.py:571-584
+                step = opt.learning_rate * grad / np.sqrt(acc.sum(axis=1) + opt.epsilon)
+                a.mu -= step[:d]
+                a.rho -= step[d:]
+                hist.append(loss)
+                if callbacks:
+                    for cb in callbacks:
+                        cb(a, loss, i + 1)
+        except StopIteration:
+            pass
+        a.hist = np.concatenate([a.hist, np.asarray(hist)])
+        return a
+
+
+def fit(n=10000, method="fullrank_advi", model=None, random_seed=None, start=None, logp_dlogp_func=None, **kwargs):
+    """`pm.fit` (inference.py:680-775): `fullrank_advi` on a `GLMSpec` (device step function), `advi` on any model spec (device
+    log-density, host update)."""
+    if method in ("fullrank_advi", "fullrank"):
+        return FullRankADVI(model=model, random_seed=random_seed, start=start).fit(n, **kwargs)
+    if method == "advi":
+        from pymc_amd.value_grad import DeviceValueGradFunction
+
+        func = logp_dlogp_func if logp_dlogp_func is not None else DeviceValueGradFunction(model)
+        return ADVI(model, func, random_seed=random_seed, start=start).fit(n, **kwargs)
+    raise KeyError(f"method should be one of {{'fullrank_advi', 'advi'}} (got {method!r})")
