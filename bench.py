@@ -334,6 +334,11 @@ def main():
             tr = json.load(open(tj))
             traffic, traffic_src = tr["k_rows_bytes_per_launch"], tr["source"]
             traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
+        tj3 = os.path.join(ROOT, "profiles", "traffic_c3.json")
+        if c3 and os.path.exists(tj3) and args.mvn_k == 2048:
+            tr = json.load(open(tj3))
+            traffic, traffic_src = tr["k_mvn_aligned_bytes_per_launch"], tr["source"]
+            traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
         leap_bytes = alg_bytes + 144 * spec.n
         if c3:
             workload = f"C3 mvn-{args.mvn_k}: MvNormal, full {args.mvn_k}x{args.mvn_k} covariance, n={spec.n}"
