@@ -163,6 +163,7 @@ def _host_potential_wanted(potential) -> bool:
             break
     return True
 
+
 class _DeviceHMCBase:
     default_blocked = True
     default_tune_steps = None          # compound.py:129-130
