@@ -242,3 +242,35 @@ def _full_logp_grad(q, c, link):
     lp = ref_gibbs.mixture_full_logp(c, link.y, q, link.log_w, link.sigma)
     g = np.bincount(c, weights=(link.y - q[c]) / link.sigma[c] ** 2, minlength=len(q)) - q / 100.0
     return lp, g
+
+
+def test_the_plan_of_the_next_sweep_is_drawn_ahead_without_changing_the_stream(monkeypatch):
+    """The worker thread draws sweep k + 1's plan (shuffle, `choice(k - 1)`, `uniform`) from a private copy of (generator state,
+    order) while sweep k runs: plans, order and generator state are those of drawing each plan when it is needed -- also when
+    somebody uses or replaces the step's generator in between (the plan drawn ahead is then dropped), and the state of the step
+    read between two sweeps is the reference's (nothing of the look-ahead shows)."""
+    import pymc_amd.gibbs as G
+
+    spec = models.normal_mixture(N=20_000, K=3, seed=7)
+
+    def run(prefetch, disturb):
+        monkeypatch.setattr(G, "_PLAN_PREFETCH_ON", prefetch)
+        st = G.CategoricalGibbsMetropolis(model=spec, rng=5)
+        out = []
+        for i in range(7):
+            if disturb and i == 3:
+                st.rng.random()                                   # the generator moved: a plan drawn ahead no longer applies
+            if disturb and i == 5:
+                st.sampling_state = st.sampling_state             # state round trip between two sweeps
+            c, lu = st._next_plan()
+            out.append((c.copy(), lu.copy(), st._order.copy(), st.rng.bit_generator.state["state"]["state"], st.sampling_state.rng))
+        return out
+
+    for disturb in (False, True):
+        a, b = run(False, disturb), run(True, disturb)
+        for x, y in zip(a, b):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3] and x[4] == y[4]
+    # below the size threshold nothing is requested
+    small = G.CategoricalGibbsMetropolis(model=models.normal_mixture(N=200, K=3, seed=7), rng=5)
+    small._next_plan()
+    assert small._plan_ahead is None
