@@ -17,6 +17,7 @@ that changes results relative to the reference and is therefore off by default.
 
 from __future__ import annotations
 
+import logging
 import os
 import time
 from typing import Dict, List, Optional, Sequence
@@ -27,6 +28,26 @@ from pymc_amd.blocking import DictToArrayBijection
 from pymc_amd.model_spec import ModelSpec
 from pymc_amd.quadpotential import QuadPotentialDiagAdapt, QuadPotentialDiagAdaptExp, QuadPotentialFullAdapt
 from pymc_amd.step import NUTS, get_random_generator
+
+
+_log = logging.getLogger("pymc_amd")   # (the reference logs under "pymc", sampling/mcmc.py:94)
+_LEVELS = {"info": logging.INFO, "error": logging.ERROR, "warn": logging.WARNING, "debug": logging.DEBUG, "critical": logging.CRITICAL}
+
+
+def log_warning_stats(stats) -> None:
+    """stats/convergence.py:196-210, called per draw by `_iter_sample` (mcmc.py:1564): the `warning` statistic of a draw -- a
+    `SamplerWarning` at level "debug" for a divergence (base_hmc.py:241-268: "Energy change in leapfrog step is too large: ...") --
+    goes to the logger at its own level."""
+    if stats is None:
+        return
+    for sts in stats:
+        warn = sts.get("warning", None)
+        if warn is None:
+            continue
+        if hasattr(warn, "message"):
+            _log.log(_LEVELS.get(getattr(warn, "level", "warn"), logging.WARNING), warn.message)
+        else:
+            _log.warning(warn)
 
 
 def initial_point(spec: ModelSpec) -> Dict[str, np.ndarray]:
@@ -163,11 +184,13 @@ def sample_draws(step: NUTS, point, K: int, callback=None, first_index: int = 0,
             pos, point, st = step.draw_many(point, min(batch, K - i))
             out[i : i + len(st)] = pos
             stats_out.extend(st)
+            log_warning_stats(st)
             i += len(st)
             continue
         point, stats = step.step(point)
         out[i] = DictToArrayBijection.map({k: point[k] for k in step.var_names}).data
         stats_out.append(stats[0])
+        log_warning_stats(stats)
         if each_draw is not None:
             each_draw(first_index + i)
         if callback is not None:

@@ -6,6 +6,8 @@ index_in_trajectory, diverging) over a prefix of draws and positions within 1e-6
 (the dynamics amplify last-bit differences between fused and unfused arithmetic).
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -1210,3 +1212,25 @@ def test_hmc_matches_oracle(which):
         assert st[0]["n_steps"] == sr["n_steps"] and st[0]["accepted"] == sr["accepted"], i
         np.testing.assert_allclose(q.data, qr, rtol=1e-9, atol=1e-11)
     step.close()
+
+
+def test_emits_energy_warnings(caplog):
+    """tests/step_methods/hmc/test_nuts.py:130-142: divergent transitions show up in the log as "Energy change ..." at DEBUG level
+    (here under the logger "pymc_amd"), through `log_warning_stats` in the sampling loop -- draw by draw and for batched draws."""
+    import logging
+
+    from pymc_amd.sampling import sample
+
+    spec = models.eight_schools()
+    for batch in ("1", "64"):
+        caplog.clear()
+        os.environ["PYMC_AMD_DRAW_BATCH"] = batch
+        try:
+            with caplog.at_level(logging.DEBUG, logger="pymc_amd"):
+                res = sample(20, tune=5, chains=2, model=spec, random_seed=526, device=0, step_scale=40.0, adapt_step_size=False, discard_tuned_samples=False)
+        finally:
+            os.environ.pop("PYMC_AMD_DRAW_BATCH", None)
+        n_div = sum(bool(s["diverging"]) for chain in res["stats"] for s in chain)
+        assert n_div > 0
+        assert any("Energy change" in r.getMessage() for r in caplog.records)
+        assert sum("Energy change" in r.getMessage() for r in caplog.records) == n_div

@@ -475,3 +475,20 @@ def test_prefetched_momentum_normals_are_transparent():
     clone = pickle.loads(pickle.dumps(pot))           # a pending prefetch does not travel
     assert clone._prefetch is None
     assert np.array_equal(clone._draw_normals(), ref.normal(size=n))
+
+
+def test_log_warning_stats_sends_the_warning_statistic_to_the_logger(caplog):
+    """stats/convergence.py:196-210 (`_iter_sample` calls it per draw, mcmc.py:1564): a divergence's `SamplerWarning` is logged at
+    its own level ("debug"), anything else that sits in the `warning` slot at WARNING; draws without a warning log nothing."""
+    import logging
+
+    from pymc_amd.sampling import log_warning_stats
+    from pymc_amd.step import SamplerWarning
+
+    w = SamplerWarning("DIVERGENCE", "Energy change in leapfrog step is too large: 1234.5.", "debug", 7)
+    with caplog.at_level(logging.DEBUG, logger="pymc_amd"):
+        log_warning_stats([{"warning": None, "depth": 3}])
+        assert not caplog.records
+        log_warning_stats([{"warning": w}, {"warning": "plain text"}])
+    assert [(r.levelno, r.getMessage()) for r in caplog.records] == [(logging.DEBUG, w.message), (logging.WARNING, "plain text")]
+    log_warning_stats(None)
