@@ -90,6 +90,13 @@ def init_nuts(
     and map (`pymc_amd/tuning.py`)."""
     from pymc_amd.value_grad import DeviceValueGradFunction
 
+    if not isinstance(init, str):
+        raise TypeError("init must be a string.")       # mcmc.py:1838-1839
+    init = init.lower()                                 # mcmc.py:1841-1844
+    if init == "auto":
+        init = "jitter+adapt_diag"
+    if len(random_seed_list) != chains:                 # mcmc.py:1846-1853 (`test_checks_seeds_kwarg`)
+        raise ValueError(f"Number of seeds ({len(random_seed_list)}) does not match the number of chains ({chains}).")
     if logp_dlogp_func is None:
         logp_dlogp_func = DeviceValueGradFunction(spec, device=device)  # mcmc.py:1865-1866
     base = initial_point(spec)

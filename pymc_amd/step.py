@@ -146,6 +146,20 @@ class _HostPotentialBridge:
             raise err
 
 
+class _StepAdaptView:
+    def __init__(self, step):
+        self._step = step
+
+    _count = property(lambda self: int(self._step._scalar("count")))
+    _log_step = property(lambda self: self._step._scalar("log_step"))
+    _log_bar = property(lambda self: self._step._scalar("log_bar"))
+    _hbar = property(lambda self: self._step._scalar("hbar"))
+    _mu = property(lambda self: self._step._scalar("mu"))
+
+    def stats(self):   # step_sizes.py:80-84
+        return {"step_size": float(np.exp(self._log_step)), "step_size_bar": float(np.exp(self._log_bar))}
+
+
 def _host_potential_wanted(potential) -> bool:
     """Does the potential's class override what the integrator calls per leapfrog?  Then the chain is a NUTS_POT_HOST chain."""
     overridden = _user_overrides(potential)
@@ -383,6 +397,12 @@ class _DeviceHMCBase:
     @property
     def step_size(self):
         return self._scalar("step_size")
+
+    @property
+    def step_adapt(self):
+        """Read-only view of the dual-averaging state the engine keeps (`DualAverageAdaptation`, step_sizes.py:41-105): `_count`,
+        `_log_step`, `_log_bar`, `_hbar`, `_mu`, `stats()` -- what the reference's tests look at (tests/sampling/test_mcmc.py:210-219)."""
+        return _StepAdaptView(self)
 
     def _scalar(self, name: str) -> float:
         out = C.c_double()

@@ -104,3 +104,58 @@ def test_init_nuts_modes_on_the_device(init):
     res = sample(draws=300, tune=300, chains=2, model=spec, init=init, random_seed=5, device=0, n_init=20_000)
     lam = np.exp(res["draws"][..., 0])
     assert abs(lam.mean() - a / b) < 0.25        # posterior mean of Gamma(a, b), sd 0.5
+
+
+def test_checks_seeds_kwarg():
+    """tests/sampling/test_mcmc.py:57-60: one seed for two chains is refused (before anything touches the device)."""
+    from pymc_amd.sampling import init_nuts
+
+    with pytest.raises(ValueError, match="number of chains"):
+        init_nuts(models.eight_schools(), chains=2, random_seed_list=[1])
+    with pytest.raises(TypeError, match="init must be a string"):
+        init_nuts(models.eight_schools(), init=None, chains=1, random_seed_list=[1])
+
+
+def _ab_model():
+    m = ModelBuilder()
+    m.Normal("a", 0.0, 1.0, shape=2)
+    m.HalfNormal("b", 1.0)
+    return m.build()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["advi", "ADVI+adapt_diag", "advi_map", "jitter+adapt_diag", "adapt_diag", "map", "adapt_full",
+                                    "jitter+adapt_full", "jitter+adapt_diag_grad", "auto"])
+def test_exec_nuts_init(method):
+    """tests/sampling/test_mcmc.py:680-717 (`check_exec_nuts_init`), every mode, names case-insensitive: the start points are a list of
+    one dict per chain over the model's value variables."""
+    import warnings
+
+    from pymc_amd.sampling import init_nuts
+
+    spec = _ab_model()
+    names = {v.value_name for v in spec.vars}
+    assert names == {"a", "b_log__"}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)     # (adapt_full: "experimental feature")
+        for chains, seeds in ((1, [1]), (2, [1, 2])):
+            start, step = init_nuts(spec, init=method, n_init=10, chains=chains, random_seed_list=seeds, device=0)
+            assert isinstance(start, list) and len(start) == chains and isinstance(start[0], dict)
+            assert set(start[0].keys()) == names
+            step.close()
+
+
+@pytest.mark.gpu
+def test_reset_tuning():
+    """tests/sampling/test_mcmc.py:210-219: one step object reused for two chains is reset in between -- after the run the potential
+    has seen `tune` samples and the dual averaging `tune + 1` counts, not twice that."""
+    from pymc_amd.sampling import init_nuts, sample
+
+    spec = _ab_model()
+    tune, chains = 50, 2
+    start, step = init_nuts(spec, chains=chains, random_seed_list=[1, 2], device=0)
+    sample(draws=2, tune=tune, chains=chains, step=step, initvals=start, model=spec, random_seed=3)
+    assert step.potential._n_samples == tune
+    assert step.step_adapt._count == tune + 1
+    assert set(step.step_adapt.stats()) == {"step_size", "step_size_bar"}
+    step.close()
