@@ -346,7 +346,7 @@ class _DeviceHMCBase:
     def _momentum_source(self) -> np.ndarray:
         """The `normals` argument of a draw: standard normals the device scales (`potential.random()` = z / sigma or W z,
         quadpotential.py:323-326) -- or, for a host-owned potential, `potential.random()` itself (base_hmc.py:201)."""
-        self._chain   # (decides which of the two it is)
+        self._materialize()   # (creating the chain decides which of the two it is)
         if self._host_bridge is None:
             return self.potential._draw_normals()
         p0 = np.ascontiguousarray(self.potential.random(), dtype="float64")
