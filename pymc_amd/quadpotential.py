@@ -360,35 +360,38 @@ class QuadPotentialFullInv(QuadPotentialFull):
 
 
 class _WeightedCovariance:
-    """Welford mean / covariance with a prior block (quadpotential.py:855-910)."""
+    """Running mean / scatter matrix with a prior block of `initial_weight` pseudo-samples (the estimator of quadpotential.py:855-910,
+    same operations in the same order: the host potential built on it is bitwise the reference's).  On the device the same
+    recurrence is `k_fa_diffs` + `k_fa_rank1` (csrc/dense_adapt.h)."""
 
     def __init__(self, nelem, initial_mean=None, initial_covariance=None, initial_weight=0):
         self.n_samples = float(initial_weight)
         self.mean = np.zeros(nelem) if initial_mean is None else np.array(initial_mean, dtype="d", copy=True)
         self.raw_cov = np.eye(nelem) if initial_covariance is None else np.array(initial_covariance, dtype="d", copy=True)
-        self.raw_cov[:] *= self.n_samples
-        if self.raw_cov.shape != (nelem, nelem):
-            raise ValueError("Invalid shape for initial covariance.")
-        if self.mean.shape != (nelem,):
-            raise ValueError("Invalid shape for initial mean.")
+        np.multiply(self.raw_cov, self.n_samples, out=self.raw_cov)   # a covariance enters as the scatter of its pseudo-samples
+        for what, arr, shape in (("covariance", self.raw_cov, (nelem, nelem)), ("mean", self.mean, (nelem,))):
+            if arr.shape != shape:
+                raise ValueError(f"Invalid shape for initial {what}.")
 
     def add_sample(self, x):
-        x = np.asarray(x)
-        self.n_samples += 1
-        old_diff = x - self.mean
-        self.mean[:] += old_diff / self.n_samples
-        new_diff = x - self.mean
-        self.raw_cov[:] += new_diff[:, None] * old_diff[None, :]
+        v = np.asarray(x)
+        k = self.n_samples + 1
+        before = v - self.mean                                  # deviation from the mean of the samples so far
+        np.add(self.mean, before / k, out=self.mean)
+        after = v - self.mean                                   # ... and from the mean that includes this one
+        np.add(self.raw_cov, np.multiply.outer(after, before), out=self.raw_cov)
+        self.n_samples = k
 
     def current_covariance(self, out=None):
         if self.n_samples == 0:
             raise ValueError("Can not compute covariance without samples.")
-        if out is not None:
-            return np.divide(self.raw_cov, self.n_samples - 1, out=out)
-        return self.raw_cov / (self.n_samples - 1)
+        dof = self.n_samples - 1
+        if out is None:
+            return self.raw_cov / dof
+        return np.divide(self.raw_cov, dof, out=out)
 
     def current_mean(self):
-        return np.array(self.mean)
+        return self.mean.copy()
 
 
 class QuadPotentialFullAdapt(QuadPotentialFull):
@@ -485,30 +488,39 @@ class QuadPotentialFullAdapt(QuadPotentialFull):
         self._push()
 
     def _host_update(self, sample, grad, tune):  # quadpotential.py:819-843
-        import scipy.linalg
-
         if self._device_estimator:
             if self._step is None:
                 raise RuntimeError("device_estimator=True: the estimators live in the device chain (use device_estimator=False for host arrays)")
             return
         if not tune:
             return
-        delta = self._n_samples - self._previous_update
-        self._foreground_cov.add_sample(sample)
-        self._background_cov.add_sample(sample)
-        if (delta + 1) % self._update_window == 0:
-            self._foreground_cov.current_covariance(out=self._cov)
-            try:
-                self._factor()
-            except (scipy.linalg.LinAlgError, ValueError) as error:
-                self._chol_error = error
-            self._push()
-        if delta >= self.adaptation_window:
-            self._foreground_cov = self._background_cov
-            self._background_cov = _WeightedCovariance(self._n)
-            self._previous_update = self._n_samples
-            self.adaptation_window = int(self.adaptation_window * self.adaptation_window_multiplier)
+        since_switch = self._n_samples - self._previous_update
+        for estimator in (self._foreground_cov, self._background_cov):
+            estimator.add_sample(sample)
+        if (since_switch + 1) % self._update_window == 0:
+            self._refresh_from_foreground()
+        if since_switch >= self.adaptation_window:
+            self._switch_windows()
         self._n_samples += 1
+
+    def _refresh_from_foreground(self):
+        """The covariance in use <- the foreground estimate, factorised; a factorisation that fails is kept for `raise_ok`
+        (quadpotential.py:806-812, 845-847)."""
+        import scipy.linalg
+
+        self._foreground_cov.current_covariance(out=self._cov)
+        try:
+            self._factor()
+        except (scipy.linalg.LinAlgError, ValueError) as error:
+            self._chol_error = error
+        self._push()
+
+    def _switch_windows(self):
+        """The background estimator becomes the foreground one, a fresh background starts, the next window is longer
+        (quadpotential.py:834-841)."""
+        self._foreground_cov, self._background_cov = self._background_cov, _WeightedCovariance(self._n)
+        self._previous_update = self._n_samples
+        self.adaptation_window = int(self.adaptation_window * self.adaptation_window_multiplier)
 
     def update(self, sample, grad, tune):
         """`QuadPotentialFullAdapt.update` (quadpotential.py:819-843): this estimator really lives on the host."""
@@ -539,14 +551,14 @@ class _ExpWeightedVariance:
         self._variance, self._mean, self._alpha = init_var, init_mean, alpha
 
     def add_sample(self, value):
-        alpha = self._alpha
-        delta = value - self._mean
-        self._mean[...] += alpha * delta
-        self._variance[...] = (1 - alpha) * (self._variance + alpha * delta**2)
+        a = self._alpha
+        dev = value - self._mean
+        np.add(self._mean, a * dev, out=self._mean)
+        np.multiply(1 - a, self._variance + a * dev**2, out=self._variance)
 
     def current_variance(self, out=None):
         if out is None:
-            out = np.empty_like(self._variance)
+            return self._variance.copy()
         np.copyto(out, self._variance)
         return out
 
