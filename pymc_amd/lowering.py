@@ -27,8 +27,9 @@ unrewritten FORM of each distribution's logp (the graph `Model.logp` returns is 
 `compile`, pytensorf.py:924-1008).  The wildcards of the matched form (value, parameters) are lowered to affine terms.
 
 What remains to validate on a box where PyTensor imports (cannot be checked here): (1) the exact op class names above
-against the installed PyTensor (`Sum` vs `CAReduce`, `Second`/`Alloc` for broadcasts, the `Composite` ops that appear if a
-caller hands over a REWRITTEN graph); (2) that `pt.pow(x, 2)` is still emitted as `Pow` with a constant exponent (a `Sqr`
+against the installed PyTensor (`Sum` vs `CAReduce`, `Second`/`Alloc` for broadcasts; `Composite` ops of a REWRITTEN graph are
+inlined through `fgraph.inputs` / `fgraph.outputs`, but a rewritten graph has also been canonicalised, which the templates do not
+follow -- hand over the graph `Model.logp` returns); (2) that `pt.pow(x, 2)` is still emitted as `Pow` with a constant exponent (a `Sqr`
 is accepted too); (3) constant folding of `pt.log(pt.sqrt(2.0 * np.pi))` is done here numerically, the tolerance on
 matched constants is 1e-12; (4) dims / coords, `pm.Data` containers (shared variables are read with `.get_value()` at
 lowering time; re-lowering or `set_extra_values` is needed when they change); (5) the distributions of the spec IR not
@@ -114,6 +115,10 @@ def build_tree(v, memo: Optional[dict] = None):
         out = build_tree(ins[0], memo)          # the device applies its own parameter checks (model_dev.h KILL_UNLESS)
     elif name in ("Alloc",):
         out = build_tree(ins[0], memo)          # pt.full(size, x): a broadcast
+    elif name == "Elemwise" and type(op.scalar_op).__name__ == "Composite":
+        # a fused element-wise sub-graph (what PyTensor's fusion rewrite leaves in a REWRITTEN graph): inlined -- its inner scalar
+        # graph is walked with the same node protocol (`fgraph.inputs` / `fgraph.outputs`, `var.owner.op`, `.inputs`, constants' `.data`)
+        out = _inline_composite(op.scalar_op, [build_tree(i, memo) for i in ins])
     elif name == "Elemwise":
         sn = _scalar_name(op)
         if sn == "cast" or sn == "identity":
@@ -145,6 +150,50 @@ def build_tree(v, memo: Optional[dict] = None):
         raise NotLowerable(f"op {name} is outside the lowering protocol")
     memo[key] = out
     return out
+
+
+def _fold_or_node(sn, kids):
+    """One scalar operation on expression trees: folded when every operand is a constant, as `build_tree` does for Elemwise nodes."""
+    sn = _ELEMWISE_ALIASES.get(sn, sn)
+    if sn in ("cast", "identity"):
+        return kids[0]
+    if sn == "second":
+        return kids[1]
+    if sn in _NUMPY_FOLD and all(k[0] == "const" for k in kids):
+        with np.errstate(all="ignore"):
+            return _const(_NUMPY_FOLD[sn](*[k[1] for k in kids]))
+    if sn in _COND_FOLD and all(k[0] == "const" for k in kids):
+        return _const(_COND_FOLD[sn](*[k[1] for k in kids]).astype("float64"))
+    if sn in ("switch", "where") and kids[0][0] == "const" and kids[0][1].size == 1:
+        return kids[1] if bool(kids[0][1].reshape(-1)[0]) else kids[2]
+    return ("switch" if sn == "where" else sn, *kids)
+
+
+def _inline_composite(comp, outer_kids):
+    """Expression tree of the (single) output of a `Composite` scalar op applied to `outer_kids`."""
+    fg = getattr(comp, "fgraph", comp)
+    inputs, outputs = list(fg.inputs), list(fg.outputs)
+    if len(outputs) != 1 or len(inputs) != len(outer_kids):
+        raise NotLowerable("Composite with several outputs (or an arity that does not match its Elemwise) is outside the lowering protocol")
+    env = {id(v): k for v, k in zip(inputs, outer_kids)}
+
+    def walk(v):
+        if id(v) in env:
+            return env[id(v)]
+        owner = getattr(v, "owner", None)
+        if owner is None:
+            if hasattr(v, "data"):
+                out = _const(v.data)
+            else:
+                raise NotLowerable("free scalar inside a Composite")
+        elif type(owner.op).__name__ == "Composite":
+            out = _inline_composite(owner.op, [walk(i) for i in owner.inputs])
+        else:
+            out = _fold_or_node(type(owner.op).__name__.lower(), [walk(i) for i in owner.inputs])
+        env[id(v)] = out
+        return out
+
+    return walk(outputs[0])
 
 
 # ---------------------------------------------------------------------------

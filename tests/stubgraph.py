@@ -95,6 +95,40 @@ for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt",
     globals()[_n] = type(_n, (), {})
 
 
+class _ScalarVar:
+    """A scalar variable of a `Composite`'s inner graph (`pytensor.scalar`): `.owner.op` is the scalar op itself."""
+
+    def __init__(self, owner=None, data=None):
+        self.owner = owner
+        if data is not None:
+            self.data = np.asarray(data)
+
+
+class Composite:
+    """`pytensor.scalar.basic.Composite`: a fused scalar sub-graph, reduced to `inputs`, `outputs` and the inner nodes' protocol.
+    `build(n_in, fn)`: `fn` receives scalar placeholders and composes them with `Composite.op(cls, *args)`."""
+
+    def __init__(self, inputs, outputs):
+        self.inputs, self.outputs = list(inputs), list(outputs)
+        self.fgraph = self
+
+    @staticmethod
+    def op(cls, *args):
+        args = [a if isinstance(a, _ScalarVar) else _ScalarVar(data=a) for a in args]
+        return _ScalarVar(owner=Apply(cls(), args))
+
+    @classmethod
+    def build(cls, n_in, fn):
+        ins = [_ScalarVar() for _ in range(n_in)]
+        return cls(ins, [fn(*ins)])
+
+
+def fused(comp, *ins):
+    """`Elemwise(Composite)(*ins)`."""
+    ins = [as_tensor(i) for i in ins]
+    return Variable(Apply(Elemwise(comp), ins), shape=_bshape(*ins))
+
+
 def _bshape(*vs):
     return np.broadcast_shapes(*[v.type.shape for v in vs])
 

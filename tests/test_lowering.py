@@ -311,3 +311,40 @@ def test_truncated_normal_lowers_to_the_builder_spec(kw):
     bad._add(sg._RV("z", (), fake, (loc,), None, d))
     with pytest.raises(NotLowerable):
         lower_to_spec(bad)
+
+
+def test_composite_elemwise_nodes_are_inlined():
+    """A fused element-wise node (`Elemwise(Composite)`, what PyTensor's fusion rewrite leaves): the walker inlines the inner scalar
+    graph through `fgraph.inputs` / `fgraph.outputs`, folding constants as everywhere else -- a Normal log-density whose standardised
+    residual and whose constant are computed inside Composites lowers to the same factor as the plain graph; nested Composites too;
+    several outputs are refused by name."""
+    y = np.array([0.3, -1.2, 2.5])
+    C = sg.Composite
+
+    def fused_normal_logp(value, mu, sigma):
+        zsq = C.build(3, lambda v, m_, s_: C.op(sg.Pow, C.op(sg.TrueDiv, C.op(sg.Sub, v, m_), s_), 2.0))
+        inner = C.build(1, lambda s_: C.op(sg.Log, s_))
+        # (the association of the reference's expression is kept: ((-0.5 z^2) - log sqrt(2 pi)) - log sigma; a fusion rewrite does not
+        # re-associate, canonicalisation would -- see the module docstring of pymc_amd/lowering.py)
+        tail = C.build(2, lambda t, s_: C.op(sg.Sub, C.op(sg.Sub, t, C.op(sg.Log, C.op(sg.Sqrt, 2.0 * np.pi))), _ScalarApply(inner, s_)))
+        return sg.fused(tail, -0.5 * sg.fused(zsq, value, mu, sigma), sigma)
+
+    def _ScalarApply(comp, *args):      # a Composite used as the op of an inner node (nesting)
+        return sg._ScalarVar(owner=sg.Apply(comp, list(args)))
+
+    plain, fusedm = sg.StubModel(), sg.StubModel()
+    for m, fn in ((plain, sg.normal_logp), (fusedm, fused_normal_logp)):
+        mu = m.Normal("mu", 0.0, 2.0)
+        s = m.HalfNormal("s", 1.5)
+        m._add(sg._RV("y", y.shape, fn, (mu, s), None, y))
+    a, b = lower_to_spec(plain), lower_to_spec(fusedm)
+    _assert_same_spec(a, b)
+    q = np.array([0.4, -0.3])
+    assert ref_models.evaluate(a, q)[0] == ref_models.evaluate(b, q)[0]
+
+    two = C([sg._ScalarVar()], [sg._ScalarVar(), sg._ScalarVar()])
+    bad = sg.StubModel()
+    x = bad.Normal("x", 0.0, 1.0)
+    bad._add(sg._RV("p", (), lambda v, x_: sg.fused(two, x_), (x,), None, y))
+    with pytest.raises(NotLowerable, match="several outputs"):
+        lower_to_spec(bad)
