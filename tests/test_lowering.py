@@ -348,3 +348,28 @@ def test_composite_elemwise_nodes_are_inlined():
     bad._add(sg._RV("p", (), lambda v, x_: sg.fused(two, x_), (x,), None, y))
     with pytest.raises(NotLowerable, match="several outputs"):
         lower_to_spec(bad)
+
+
+def test_shared_variables_are_read_when_the_model_is_lowered():
+    """`pm.Data` containers are shared variables: no `.owner`, no `.data`, a `.get_value()` -- read at lowering time and lowered
+    as data vectors of the spec (a later `set_value` needs a re-lowering or `set_extra_values`, as the module docstring says)."""
+    from pymc_amd.model_spec import ModelBuilder
+
+    class Shared(sg.Variable):
+        def __init__(self, value):
+            super().__init__(None, "shared", np.shape(value))
+            self._value = np.asarray(value, dtype="float64")
+
+        def get_value(self):
+            return self._value
+
+    y = np.array([0.3, -1.2, 2.5])
+    sd = np.array([1.0, 2.0, 0.5])
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 2.0)
+    m._add(sg._RV("y", y.shape, sg.normal_logp, (mu, Shared(sd)), None, y))
+    spec = lower_to_spec(m)
+    b = ModelBuilder()
+    bm = b.Normal("mu", 0.0, 2.0)
+    b.Normal("y", bm, sd, observed=y)
+    _assert_same_spec(spec, b.build())
