@@ -82,6 +82,10 @@ def parse():
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-file", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses GPU 0 (exercises the N > 1 logic on a 1-GPU box)")
+    ap.add_argument("--stub-engine", action="store_true", help="TEST ONLY: no device work at all; drives launcher + gather + report on a CPU box")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="self-launched ranks are stopped after this many seconds")
+    ap.add_argument("--ess-tune", type=int, default=1000, help="warmup of the separate ESS chain run when --steps/--warmup are too short for an ESS (0 disables)")
+    ap.add_argument("--ess-draws", type=int, default=1000)
     return ap.parse_args()
 
 
@@ -209,137 +213,233 @@ def cpu_baseline_c3(spec, q, step_size, inv_mass, n_leap):
 
 
 # ---------------------------------------------------------------------------
+# `python bench.py --gpus N` without a launcher: one process per chain / GPU, the parent collects
+# (the reference's layout for cores > 1: pymc/sampling/parallel.py:477-589, mcmc.py:1203-1224)
+# ---------------------------------------------------------------------------
 
-def main():
-    args = parse()
-    if args.cpu_worker is not None:
-        return cpu_worker_main(args)
+def visible_gpus():
+    """Devices this process could hand to ranks (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES respected by the runtime)."""
+    try:
+        import torch
+
+        return int(torch.cuda.device_count()) if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """No WORLD_SIZE in the environment and --gpus N > 1: start N copies of this script as ranks 0..N-1 (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* exactly as `torch.distributed.run` would set them), rank r on GPU r, RCCL group over the N devices;
+    rank 0 prints the one JSON line.  Refuses (exit code 2) when fewer than N devices are visible -- a silent 1-GPU run under
+    `--gpus 8` would be a wrong scaling point.  Returns the exit code."""
+    import subprocess
+
+    n = args.gpus
+    if not (args.stub_engine or args.share_gpu):
+        have = visible_gpus()
+        if have < n:
+            print(f"bench: --gpus {n} requested but {have} GPU(s) visible; refusing to run fewer ranks than asked "
+                  "(--share-gpu puts every rank on GPU 0 for TESTING the launch path)", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_WORLD_SIZE=str(n), PYMC_AMD_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + args.launch_timeout
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:
+                rc = rc or code
+        if (rc != 0 or time.time() > deadline) and alive:
+            # one rank died (or the run overran): the others would wait in a collective for ever -- stop exactly the processes
+            # started here
+            for p in alive:
+                p.kill()
+            for p in alive:
+                p.wait()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+class _StubChain:
+    """TEST ONLY (`--stub-engine`): stands where one rank's device chain stands so that the launcher, the process group, the
+    gather and the report can be driven on a box without a GPU (tests/test_bench_launch.py).  Fabricates tree sizes; measures
+    nothing."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def run(self, K):
+        if os.environ.get("PYMC_AMD_BENCH_STUB_FAIL_RANK") == str(self.rank):
+            sys.exit(3)          # (a rank that dies: the launcher must stop the others, which wait in a collective)
+        rng = np.random.default_rng(1000 + self.rank)
+        tree = rng.choice([15, 31, 63], size=K).astype(float)
+        time.sleep(0.002 * K)
+        return tree
+
+
+def run_rank(args):
+    """One rank = one chain on one GPU: W untimed tuning draws, K timed draws between barriers; returns what rank 0 needs."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = args.stub_engine
     import torch
 
     dist = None
-    if args.share_gpu:
+    if args.share_gpu or stub:
         local = 0
         args.backend = "gloo"   # RCCL refuses two ranks on one device ("Duplicate GPU detected")
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local)
+        if not stub:
+            torch.cuda.set_device(local)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
-    else:
+    elif not stub:
         torch.cuda.set_device(0)
     comm_dev = "cuda" if args.backend == "nccl" else "cpu"
 
-    from pymc_amd import models
-    from pymc_amd.sampling import init_nuts, sample_draws
-    from pymc_amd.step import get_random_generator
-    from pymc_amd.stats import ess_bulk_many, rhat_many
-
-    c3 = args.workload == "c3"
-    if c3:
-        spec = models.mvnormal(n=args.mvn_k)
-        N = 0
-    else:
-        spec = models.hier_logit(G=args.groups, D=8, rows_per_group=args.rows_per_group, seed=20160911)
-        N = spec.logit_rows.X.shape[0]
-    chains = world
-    rngs = get_random_generator(args.seed).spawn(chains)  # mcmc.py:907-908
-    seed_list = [int(r.integers(2**30)) for r in rngs]
-    points, step = init_nuts(spec, init="jitter+adapt_diag", chains=chains, random_seed_list=seed_list, device=local)
-    alg_bytes = step._logp_dlogp_func.algorithmic_bytes
-
     def barrier():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     W, K = args.warmup, args.steps
-    os.environ["PYMC_AMD_DRAW_BATCH"] = str(args.draw_batch)
-    # the per-chain loop of `_iter_sample` (mcmc.py:1503-1583), split at the end of tuning so that exactly the K
-    # post-warmup transitions sit between the two barriers
-    step.setup_chain(rngs[rank], W, K)
-    step.tune = bool(W)
-    step.reset_tuning()
-    point = points[rank]
-    step.iter_count = 0
-    _, _, point = sample_draws(step, point, W)
-    step.stop_tuning()
+    c3 = args.workload == "c3"
+    meta = {}
+    if stub:
+        chain = _StubChain(rank)
+        barrier()
+        t0 = time.perf_counter()
+        tree = chain.run(K)
+        barrier()
+        dt = time.perf_counter() - t0
+        leap = float(tree.sum())
+        vec = [dt, 0.0, leap, 0.0, 0.0]        # (no kernel: the roofline block of a stub line reads 0)
+        conv, ess_run = None, None
+        meta = dict(alg_bytes=344448000, n=10000, N=4992000, workload="STUB ENGINE (test of the launch path; nothing measured)", kernel="stub",
+                    schedule="stub", traffic_ok=False)
+        ess_ok = False
+        draws = step = spec = None
+    else:
+        from pymc_amd import models
+        from pymc_amd.sampling import init_nuts, sample_draws
+        from pymc_amd.step import get_random_generator
+        from pymc_amd.stats import ess_bulk_many, rhat_many
 
-    step.profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    draws, stats_list, point = sample_draws(step, point, K)
-    barrier()
-    dt = time.perf_counter() - t0
-    dom_ms, dom_n, _ = step.profile_read()
-    step.profile(False)
-    tree = np.array([s["tree_size"] for s in stats_list])
-    n_div = int(sum(bool(s["diverging"]) for s in stats_list))
-    leap = float(tree.sum())
+        if c3:
+            spec = models.mvnormal(n=args.mvn_k)
+            N = 0
+        else:
+            spec = models.hier_logit(G=args.groups, D=8, rows_per_group=args.rows_per_group, seed=20160911)
+            N = spec.logit_rows.X.shape[0]
+        chains = world
+        rngs = get_random_generator(args.seed).spawn(chains)  # mcmc.py:907-908
+        seed_list = [int(r.integers(2**30)) for r in rngs]
+        points, step = init_nuts(spec, init="jitter+adapt_diag", chains=chains, random_seed_list=seed_list, device=local)
+        alg_bytes = step._logp_dlogp_func.algorithmic_bytes
+        os.environ["PYMC_AMD_DRAW_BATCH"] = str(args.draw_batch)
+        initial_state = step.sampling_state
+        # the per-chain loop of `_iter_sample` (mcmc.py:1503-1583), split at the end of tuning so that exactly the K
+        # post-warmup transitions sit between the two barriers
+        step.setup_chain(rngs[rank], W, K)
+        step.tune = bool(W)
+        step.reset_tuning()
+        point = points[rank]
+        step.iter_count = 0
+        _, _, point = sample_draws(step, point, W)
+        step.stop_tuning()
 
-    ess_ok = K >= ESS_MIN_DRAWS and W >= ESS_MIN_DRAWS
-    conv = None
-    min_ess = float("nan")
-    if ess_ok:
-        ess = ess_bulk_many(draws[None])
-        rh = rhat_many(draws[None])          # split R-hat of the one chain this rank ran
-        j = int(np.nanargmin(ess))
+        step.profile(True)
+        barrier()
+        t0 = time.perf_counter()
+        draws, stats_list, point = sample_draws(step, point, K)
+        barrier()
+        dt = time.perf_counter() - t0
+        dom_ms, dom_n, _ = step.profile_read()
+        step.profile(False)
+        tree = np.array([s["tree_size"] for s in stats_list])
+        n_div = int(sum(bool(s["diverging"]) for s in stats_list))
+        leap = float(tree.sum())
+
         names = []
         for v in spec.vars:
             names += [f"{v.value_name}[{k}]" for k in range(v.size)]
-        min_ess = float(ess[j])
-        conv = {"min_ess": min_ess, "min_ess_param_index": j, "min_ess_param": names[j], "median_ess": float(np.median(ess)),
-                "ess_5pct": float(np.percentile(ess, 5)), "rhat_max": float(np.nanmax(rh)), "rhat_max_param": names[int(np.nanargmax(rh))],
-                "rhat_of_min_ess_param": float(rh[j]), "n_params": int(spec.n), "divergences": n_div}
-        if not c3:
-            # The non-centred parametrisation SURVEY 8 prescribes leaves (mu_d, mean_g z_{g,d}) on a ridge when every group has
-            # thousands of rows: the combination the likelihood identifies, beta_bar_d = mu_d + sigma_d
-            # mean_g z_{g,d}, is reported next to the per-coordinate minimum so that the two can be told apart.
-            v = {x.name: x for x in spec.vars}
-            D_ = v["mu"].size
-            mu_ = draws[:, v["mu"].offset : v["mu"].offset + D_]
-            sg_ = np.exp(draws[:, v["sigma"].offset : v["sigma"].offset + D_])
-            zbar = draws[:, v["z"].offset : v["z"].offset + v["z"].size].reshape(len(draws), -1, D_).mean(axis=1)
-            eb = ess_bulk_many((mu_ + sg_ * zbar)[None])
-            conv["identified_combination"] = {"what": "beta_bar_d = mu_d + sigma_d * mean_g z[g, d]", "min_ess": float(eb.min()),
-                                              "median_ess": float(np.median(eb)), "corr_mu_zbar_d0": float(np.corrcoef(mu_[:, 0], zbar[:, 0])[0, 1])}
 
-    vec = [dt, min_ess if ess_ok else 0.0, leap, dom_ms, float(dom_n)]
-    if dist is not None:
-        t = torch.tensor(vec, dtype=torch.float64, device=comm_dev)
-        allt = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        allv = torch.stack(allt).cpu().numpy()
-        convs = [None] * world
-        dist.all_gather_object(convs, conv)
-    else:
-        allv = np.array([vec])
-        convs = [conv]
-    if rank == 0:
-        T = float(allv[:, 0].max())
-        leap_total = float(allv[:, 2].sum())
-        lps_total = leap_total / T
-        dom_avg_ms = float(allv[:, 3].sum() / max(allv[:, 4].sum(), 1))
-        ess_total = float(allv[:, 1].sum()) if ess_ok else None
-        achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-        traffic, traffic_src, traffic_match = None, None, None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if not c3 and os.path.exists(tj) and args.rows_per_group == 4000 and args.groups == 1248:
-            tr = json.load(open(tj))
-            traffic, traffic_src = tr["k_rows_bytes_per_launch"], tr["source"]
-            traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
-        tj3 = os.path.join(ROOT, "profiles", "traffic_c3.json")
-        if c3 and os.path.exists(tj3) and args.mvn_k == 2048:
-            tr = json.load(open(tj3))
-            traffic, traffic_src = tr["k_mvn_aligned_bytes_per_launch"], tr["source"]
-            traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
-        leap_bytes = alg_bytes + 144 * spec.n
+        def convergence(d, n_div_):
+            ess = ess_bulk_many(d[None])
+            rh = rhat_many(d[None])          # split R-hat of the one chain this rank ran
+            j = int(np.nanargmin(ess))
+            cv = {"min_ess": float(ess[j]), "min_ess_param_index": j, "min_ess_param": names[j], "median_ess": float(np.median(ess)),
+                  "ess_5pct": float(np.percentile(ess, 5)), "rhat_max": float(np.nanmax(rh)), "rhat_max_param": names[int(np.nanargmax(rh))],
+                  "rhat_of_min_ess_param": float(rh[j]), "n_params": int(spec.n), "divergences": n_div_}
+            if not c3:
+                # The non-centred parametrisation SURVEY 8 prescribes leaves (mu_d, mean_g z_{g,d}) on a ridge when every group has
+                # thousands of rows (DESIGN.md section 5): the combination the likelihood identifies, beta_bar_d = mu_d + sigma_d
+                # mean_g z_{g,d}, is reported next to the per-coordinate minimum so that the two can be told apart.
+                v = {x.name: x for x in spec.vars}
+                D_ = v["mu"].size
+                mu_ = d[:, v["mu"].offset : v["mu"].offset + D_]
+                sg_ = np.exp(d[:, v["sigma"].offset : v["sigma"].offset + D_])
+                zbar = d[:, v["z"].offset : v["z"].offset + v["z"].size].reshape(len(d), -1, D_).mean(axis=1)
+                eb = ess_bulk_many((mu_ + sg_ * zbar)[None])
+                cv["identified_combination"] = {"what": "beta_bar_d = mu_d + sigma_d * mean_g z[g, d]", "min_ess": float(eb.min()),
+                                                "median_ess": float(np.median(eb)), "corr_mu_zbar_d0": float(np.corrcoef(mu_[:, 0], zbar[:, 0])[0, 1])}
+            return cv
+
+        ess_ok = K >= ESS_MIN_DRAWS and W >= ESS_MIN_DRAWS
+        conv = convergence(draws, n_div) if ess_ok else None
+        min_ess = conv["min_ess"] if ess_ok else 0.0
+        vec = [dt, min_ess, leap, dom_ms, float(dom_n)]
+
+        # The metric's other half when the timed region is too short to carry it (a driver run with K = 20): a SEPARATE whole chain
+        # of ess_tune + ess_draws transitions from a fresh sampling state, timed INCLUDING its warmup as the reference's benchmark
+        # does (benchmarks/benchmarks/benchmarks.py:180-198: min ESS / total sampling time).  Reported under "ess_run"; it
+        # never enters `value`, `ms_per_step` or the roofline block, which describe exactly the K timed steps above.
+        ess_run = None
+        if not ess_ok and args.ess_draws >= ESS_MIN_DRAWS and args.ess_tune >= ESS_MIN_DRAWS:
+            from pymc_amd.sampling import sample_chain
+
+            step.sampling_state = initial_state
+            barrier()
+            t1 = time.perf_counter()
+            d_all, st_all = sample_chain(step, points[rank], get_random_generator(args.seed).spawn(chains)[rank], args.ess_tune, args.ess_draws)
+            barrier()
+            wall = time.perf_counter() - t1
+            st_post = st_all[args.ess_tune:]
+            cv = convergence(d_all[args.ess_tune:], int(sum(bool(s_["diverging"]) for s_ in st_post)))
+            ess_run = {"wall_s": wall, "min_ess": cv["min_ess"], "leapfrogs_post_warmup": float(sum(s_["tree_size"] for s_ in st_post)),
+                       "leapfrogs_total": float(sum(s_["tree_size"] for s_ in st_all)),
+                       "sampling_s_post_warmup": float(sum(s_["perf_counter_diff"] for s_ in st_post)),
+                       "step_size_bar": float(st_all[-1]["step_size_bar"]), "convergence": cv}
         if c3:
             workload = f"C3 mvn-{args.mvn_k}: MvNormal, full {args.mvn_k}x{args.mvn_k} covariance, n={spec.n}"
             aligned = int(step._logp_dlogp_func.model_scalar("mvn_row_aligned"))
@@ -349,74 +449,172 @@ def main():
         else:
             workload = f"C2-{'L' if args.rows_per_group >= 1000 else 'S'} hier-logit-10k: G={args.groups} D=8 rows={N} n={spec.n}"
             kernel = "hierarchical-logit row pass (k_rows_ga / k_rows)"
-        out = {
-            "metric": "effective samples/sec (and leapfrog steps/sec), 10k-param hierarchical logistic regression, one NUTS chain per GPU"
-            if not c3 else "leapfrog steps/sec (and effective samples/sec), MvNormal 2048, one NUTS chain per GPU",
-            "value": (ess_total / T) if ess_ok else lps_total,
-            "unit": "ESS/s (aggregate over chains; min-over-all-parameters bulk-ESS)" if ess_ok else "leapfrog steps/s (aggregate over chains)",
-            "value_is": "ess_per_sec" if ess_ok else f"leapfrog_steps_per_sec (ESS needs steps >= {ESS_MIN_DRAWS} and warmup >= {ESS_MIN_DRAWS})",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": 1e3 * T / K,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": workload,
-                "chains": chains,
-                "parallelism": f"{world} independent chain(s), one per GPU, no data-path collective",
-                "sampler": "NUTS target_accept=0.8 max_treedepth=10 init=jitter+adapt_diag",
-            },
-            "schedule": ("persistent tree kernel: one launch per NUTS tree (csrc/rows_ga_tree.h)" if step._scalar("tree_kernel") else
-                         "group-aligned row pass: one launch per leapfrog, control work folded into the next row pass, also across doublings "
-                         "(csrc/rows_ga_kernel.h)" if (not c3 and step._logp_dlogp_func.model_scalar("rows_group_aligned")) else
-                         "row-aligned MvNormal pass: one launch per leapfrog, control work folded into the next launch, also across doublings "
-                         "(csrc/kernels.h, k_mvn_aligned)" if (c3 and step._logp_dlogp_func.model_scalar("mvn_row_aligned")) else
-                         "two launches per leapfrog (data pass + O(n) kernel), control work folded into the next data pass (csrc/kernels.h)"),
-            "leapfrog_steps_per_sec": lps_total,
-            "leapfrog_steps_per_sec_per_chain": [float(x) for x in (allv[:, 2] / allv[:, 0])],
-            "ess_per_sec": (ess_total / T) if ess_ok else None,
-            "ess_per_chain": [float(x) for x in allv[:, 1]] if ess_ok else None,
-            "convergence": convs if ess_ok else None,
-            "mean_tree_size": leap_total / (K * world),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel,
-                "achieved": achieved,
-                "peak": 8000.0,
-                "unit": "GB/s",
-                "frac": achieved / 8000.0,
-                "frac_of_achievable_6.3TBps": achieved / 6300.0,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_bytes_note": None if c3 else "69 B/row = 64 (X) + 1 (y) + 4 (int32 group id); the kernel reads G+1 row pointers instead of the "
-                "group ids, so 4 of the 69 are bytes it avoids -- frac_traffic prices the bytes actually moved",
-                "avg_launch_ms": dom_avg_ms,
-                "launches_timed": int(allv[:, 4].sum()),   # (passes over the data covered by the bracketed launches)
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "traffic_build_matches": traffic_match,
-                "frac_traffic": (traffic / (dom_avg_ms * 1e-3) / 8.0e12) if (traffic and dom_avg_ms > 0) else None,
-                # the whole leapfrog (row pass + O(n) work + launch gaps + the per-draw / per-doubling host round trips of
-                # the timed region) against the same line: SURVEY 8d bytes per leapfrog x leapfrogs/s per chain
-                "leapfrog_algorithmic_bytes": leap_bytes,
-                "leapfrog_frac": leap_bytes * (lps_total / world) / 8.0e12,
-            },
-        }
-        if world == 1 and args.cpu_leapfrogs > 0:
+        schedule = ("persistent tree kernel: one launch per NUTS tree (csrc/rows_ga_tree.h)" if step._scalar("tree_kernel") else
+                    "group-aligned row pass: one launch per leapfrog, control work folded into the next row pass, also across doublings "
+                    "(csrc/rows_ga_kernel.h)" if (not c3 and step._logp_dlogp_func.model_scalar("rows_group_aligned")) else
+                    "row-aligned MvNormal pass: one launch per leapfrog, control work folded into the next launch, also across doublings "
+                    "(csrc/kernels.h, k_mvn_aligned)" if (c3 and step._logp_dlogp_func.model_scalar("mvn_row_aligned")) else
+                    "two launches per leapfrog (data pass + O(n) kernel), control work folded into the next data pass (csrc/kernels.h)")
+        meta = dict(alg_bytes=alg_bytes, n=int(spec.n), N=N, workload=workload, kernel=kernel, schedule=schedule, traffic_ok=True)
+
+    if dist is not None:
+        t = torch.tensor(vec, dtype=torch.float64, device=comm_dev)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        allv = torch.stack(allt).cpu().numpy()
+        convs = [None] * world
+        dist.all_gather_object(convs, conv)
+        ess_runs = [None] * world
+        dist.all_gather_object(ess_runs, ess_run)
+    else:
+        allv = np.array([vec])
+        convs = [conv]
+        ess_runs = [ess_run]
+    if rank == 0:
+        out = report(args, world, allv, convs, ess_runs, meta, ess_ok)
+        if world == 1 and args.cpu_leapfrogs > 0 and not stub:
             inv_mass = step._vector("var")
             eps = float(step._scalar("step_size"))
             if c3:
                 out["cpu_baseline"] = cpu_baseline_c3(spec, draws[-1], eps, inv_mass, args.cpu_leapfrogs)
             else:
-                out["cpu_baseline"] = cpu_baseline_c2(args, spec, draws[-1], eps, inv_mass, args.cpu_leapfrogs, (min_ess / max(leap, 1.0)) if ess_ok else None)
+                out["cpu_baseline"] = cpu_baseline_c2(args, spec, draws[-1], eps, inv_mass, args.cpu_leapfrogs,
+                                                      (vec[1] / max(leap, 1.0)) if ess_ok else
+                                                      (ess_run["min_ess"] / max(ess_run["leapfrogs_total"], 1.0)) if ess_run else None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def oracle_convergence(args):
+    """What the CPU ORACLE's own four chains of the benchmarked shape look like (tests/golden/c2l_chains.npz, written by
+    tests/golden/make_c2_fixtures.py from oracle/ref_sampler.py: a committed fixture, read as data -- nothing of oracle/ is
+    imported): if the reference sampler shows the same R-hat on this model, a large R-hat of the device chain is the model."""
+    if args.workload != "c2" or args.groups != 1248:
+        return None
+    f = os.path.join(ROOT, "tests", "golden", "c2l_chains.npz" if args.rows_per_group == 4000 else "c2s_chains.npz" if args.rows_per_group == 80 else "-")
+    if not os.path.exists(f):
+        return None
+    k = np.load(f)
+    tune = int(k["config"][3])
+    return {"source": os.path.relpath(f, ROOT), "chains": int(k["config"][5]), "tune": tune, "draws": int(k["config"][4]),
+            "oracle_rhat_max": float(k["rhat"].max()), "oracle_n_rhat_gt_1.01": int((k["rhat"] > 1.01).sum()),
+            "oracle_min_ess": float(k["ess_bulk"].min()), "oracle_median_ess": float(np.median(k["ess_bulk"])),
+            "oracle_mean_tree_size": float(k["stat_tree_size"][:, tune:].mean()),
+            "oracle_step_size_bar": [float(x) for x in k["stat_step_size_bar"][:, -1]]}
+
+
+def report(args, world, allv, convs, ess_runs, meta, ess_ok):
+    """The one JSON line (rank 0)."""
+    K, W = args.steps, args.warmup
+    c3 = args.workload == "c3"
+    alg_bytes, n = meta["alg_bytes"], meta["n"]
+    T = float(allv[:, 0].max())
+    leap_total = float(allv[:, 2].sum())
+    lps_total = leap_total / T
+    lps_chain = allv[:, 2] / allv[:, 0]
+    dom_avg_ms = float(allv[:, 3].sum() / max(allv[:, 4].sum(), 1))
+    ess_total = float(allv[:, 1].sum()) if ess_ok else None
+    achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+    traffic, traffic_src, traffic_match = None, None, None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if meta["traffic_ok"] and not c3 and os.path.exists(tj) and args.rows_per_group == 4000 and args.groups == 1248:
+        tr = json.load(open(tj))
+        traffic, traffic_src = tr["k_rows_bytes_per_launch"], tr["source"]
+        traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
+    tj3 = os.path.join(ROOT, "profiles", "traffic_c3.json")
+    if meta["traffic_ok"] and c3 and os.path.exists(tj3) and args.mvn_k == 2048:
+        tr = json.load(open(tj3))
+        traffic, traffic_src = tr["k_mvn_aligned_bytes_per_launch"], tr["source"]
+        traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
+    leap_bytes = alg_bytes + 144 * n
+    er = [e for e in ess_runs if e]
+    ess_run = None
+    if er and len(er) == world:
+        wall = max(e["wall_s"] for e in er)
+        ess_run = {
+            "what": f"a separate whole chain per GPU, {args.ess_tune} tune + {args.ess_draws} draws from a fresh sampling state, timed INCLUDING warmup "
+                    "(benchmarks/benchmarks/benchmarks.py:180-198); not part of the K timed steps `value` describes",
+            "ess_per_sec": sum(e["min_ess"] for e in er) / wall, "wall_s": wall, "min_ess_per_chain": [e["min_ess"] for e in er],
+            "leapfrog_steps_per_sec_post_warmup_per_chain": [e["leapfrogs_post_warmup"] / max(e["sampling_s_post_warmup"], 1e-9) for e in er],
+            "mean_tree_size_post_warmup": sum(e["leapfrogs_post_warmup"] for e in er) / (args.ess_draws * world),
+            "step_size_bar": [e["step_size_bar"] for e in er], "convergence": [e["convergence"] for e in er],
+            "oracle": oracle_convergence(args),
+        }
+    return {
+        "metric": "effective samples/sec (and leapfrog steps/sec), 10k-param hierarchical logistic regression, one NUTS chain per GPU"
+        if not c3 else "leapfrog steps/sec (and effective samples/sec), MvNormal 2048, one NUTS chain per GPU",
+        "value": (ess_total / T) if ess_ok else lps_total,
+        "unit": "ESS/s (aggregate over chains; min-over-all-parameters bulk-ESS)" if ess_ok else "leapfrog steps/s (aggregate over chains)",
+        "value_is": "ess_per_sec" if ess_ok else f"leapfrog_steps_per_sec (ESS needs steps >= {ESS_MIN_DRAWS} and warmup >= {ESS_MIN_DRAWS}; see ess_run)",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": 1e3 * T / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": meta["workload"],
+            "chains": world,
+            "parallelism": f"{world} independent chain(s), one per GPU, no data-path collective",
+            "sampler": "NUTS target_accept=0.8 max_treedepth=10 init=jitter+adapt_diag",
+        },
+        "launch": ("self-launched: bench.py started one process per GPU" if os.environ.get("PYMC_AMD_BENCH_SELF_LAUNCHED") else
+                   "launched by torch.distributed.run" if world > 1 else "single process"),
+        "collective_backend": None if world == 1 else ("rccl" if args.backend == "nccl" else args.backend),
+        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+        "schedule": meta["schedule"],
+        "leapfrog_steps_per_sec": lps_total,
+        "leapfrog_steps_per_sec_per_chain": [float(x) for x in lps_chain],
+        "leapfrog_frac_per_chain": [float(leap_bytes * x / 8.0e12) for x in lps_chain],
+        "ess_per_sec": (ess_total / T) if ess_ok else (ess_run["ess_per_sec"] if ess_run else None),
+        "ess_per_sec_is": "the K timed steps" if ess_ok else ("ess_run (separate chain, wall time incl. warmup)" if ess_run else None),
+        "ess_per_chain": [float(x) for x in allv[:, 1]] if ess_ok else None,
+        "convergence": convs if ess_ok else None,
+        "oracle_convergence": oracle_convergence(args) if ess_ok else None,
+        "ess_run": ess_run,
+        "mean_tree_size": leap_total / (K * world),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": meta["kernel"],
+            "achieved": achieved,
+            "peak": 8000.0,
+            "unit": "GB/s",
+            "frac": achieved / 8000.0,
+            "frac_of_achievable_6.3TBps": achieved / 6300.0,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_note": None if c3 else "69 B/row = 64 (X) + 1 (y) + 4 (int32 group id); the kernel reads G+1 row pointers instead of the "
+            "group ids, so 4 of the 69 are bytes it avoids -- frac_traffic prices the bytes actually moved",
+            "avg_launch_ms": dom_avg_ms,
+            "launches_timed": int(allv[:, 4].sum()),   # (passes over the data covered by the bracketed launches)
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "traffic_build_matches": traffic_match,
+            "frac_traffic": (traffic / (dom_avg_ms * 1e-3) / 8.0e12) if (traffic and dom_avg_ms > 0) else None,
+            # the whole leapfrog (row pass + O(n) work + launch gaps + the per-draw / per-doubling host round trips of
+            # the timed region) against the same line: SURVEY 8d bytes per leapfrog x leapfrogs/s per chain
+            "leapfrog_algorithmic_bytes": leap_bytes,
+            "leapfrog_frac": leap_bytes * (lps_total / world) / 8.0e12,
+        },
+    }
+
+
+def main():
+    args = parse()
+    if args.cpu_worker is not None:
+        return cpu_worker_main(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" in os.environ and args.gpus != world and args.gpus != 1:
+        print(f"bench: --gpus {args.gpus} under a launcher with WORLD_SIZE={world}; the launcher's world is what runs", file=sys.stderr)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

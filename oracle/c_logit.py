@@ -26,7 +26,7 @@ def build_native() -> str:
     src = os.path.join(_DIR, "csrc", "oracle_logit.c")
     try:
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", src, "-o", out, "-lm"],
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", src, src.replace("oracle_logit.c", "oracle_logit_stat.c"), "-o", out, "-lmvec", "-lm"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         return out
     except Exception:
@@ -36,9 +36,11 @@ def build_native() -> str:
 class CHierLogit:
     """``q -> (logp, grad)`` for a ModelSpec built by `pymc_amd.models.hier_logit`."""
 
-    def __init__(self, spec, so_path=None):
+    def __init__(self, spec, so_path=None, fn="oracle_hier_logit"):
+        # fn="oracle_hier_logit_stat": the libmvec arrangement of the same formulas (oracle/csrc/oracle_logit_stat.c), for the
+        # long statistical fixtures only
         lib = C.CDLL(so_path or _SO)
-        self._fn = lib.oracle_hier_logit
+        self._fn = getattr(lib, fn)
         self._fn.restype = C.c_double
         self._fn.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         r = spec.logit_rows

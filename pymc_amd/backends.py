@@ -329,14 +329,18 @@ def multitrace_from_result(spec: ModelSpec, result: dict, include_transformed: b
     step = result.get("step")
     sdt = getattr(step, "stats_dtypes_shapes", None)
     traces = []
+    # chain ids are the sampler's (`result["chains"]`: under torch.distributed without a gather every rank holds a subset, and
+    # positional ids would collide across ranks and disagree with the chain generators)
+    ids = list(result.get("chains", range(draws.shape[0])))
     for c in range(draws.shape[0]):
         chain_stats = stats[c]
+        first = chain_stats[0] if len(chain_stats) else None    # (draws == 0: the statistics' names come from the step method)
         if sdt is not None:
-            svars = [{k: (object if k == "warning" else v[0]) for k, v in sdt.items() if k in chain_stats[0]}]
+            svars = [{k: (object if k == "warning" else v[0]) for k, v in sdt.items() if first is None or k in first}]
         else:
-            svars = [{k: (object if k == "warning" else np.asarray(chain_stats[0][k]).dtype) for k in chain_stats[0]}]
+            svars = [{k: (object if k == "warning" else np.asarray(first[k]).dtype) for k in (first or {})}]
         t = NDArray(model=spec, include_transformed=include_transformed)
-        t.setup(draws.shape[1], c, svars)
+        t.setup(draws.shape[1], ids[c], svars)
         t.record_batch(draws[c], [[s] for s in chain_stats])
         t.close()
         traces.append(t)

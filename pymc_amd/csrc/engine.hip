@@ -2081,7 +2081,8 @@ extern "C" int nuts_chain_draw_hmc(nuts_chain* c, const double* q0, const double
   c->da.update(accept, adapt);
   // (a rejected transition stays at q0, which is still in the staging buffer of this draw)
   const double* xsel = accepted ? (A.Q + (int64_t)last * n) : c->stage_dev;
-  rc = potential_update(c, xsel, accepted ? (A.G + (int64_t)last * n) : A.G);   // (gradient at q0: the start state, slot 0)
+  // (gradient at q0 on a rejection: the copy kept aside above -- slot 0 of the ring is overwritten once n_steps >= S)
+  rc = potential_update(c, xsel, accepted ? (A.G + (int64_t)last * n) : start_keep);
   if (rc) return rc;
   if (!c->tune) c->divergences += div;
   c->iter_count += 1;

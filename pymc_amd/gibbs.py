@@ -48,7 +48,8 @@ class MixtureLink:
     mu_name: str              # value variable holding the component means
 
     def __post_init__(self):
-        self._cache_key = None
+        self._cache_for = None    # the array object the sweep produced (a strong reference: its id cannot be reused while cached)
+        self._cache_copy = None   # its contents at that moment (an in-place edit of the same object must not hit the cache)
         self._cache = None
 
     @property
@@ -57,8 +58,7 @@ class MixtureLink:
 
     def suffstats(self, c: np.ndarray):
         c = np.asarray(c)
-        key = (id(c), c.ctypes.data if isinstance(c, np.ndarray) else None)
-        if self._cache_key == key:
+        if self._cache_for is c and np.array_equal(self._cache_copy, c):    # (one memcmp-sized pass instead of three bincounts)
             return self._cache
         cnt = np.bincount(c, minlength=self.K).astype("float64")
         s1 = np.bincount(c, weights=self.y, minlength=self.K)
@@ -67,8 +67,7 @@ class MixtureLink:
 
     def remember(self, c: np.ndarray, stats):
         """The sweep kernel has just produced the statistics of `c`: the continuous step that follows need not recount."""
-        self._cache_key = (id(c), c.ctypes.data)
-        self._cache = stats
+        self._cache_for, self._cache_copy, self._cache = c, c.copy(), stats
 
     def extras_for(self, c: np.ndarray) -> Dict[str, np.ndarray]:
         """Extra values of the NUTS spec for assignments `c`: the log-density of the observations given c collapses to

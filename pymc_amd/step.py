@@ -322,8 +322,15 @@ class _DeviceHMCBase:
             self.potential._bind(self)
         lib.nuts_chain_set_tune(chain, int(self._tune))
         if self._pending_state is not None:
+            # The parked state carries the generators of the moment it was parked.  Whatever replaced them since -- `setup_chain`
+            # in a worker process, which runs BEFORE anything touches the engine (parallel.py:504-524: the step arrives
+            # pickled, then the chain's own generator is installed) -- wins: only the engine blob and the potential's host
+            # state are restored, the generator OBJECTS stay the ones the step holds (compound.py:250 assigns without a copy).
             state, self._pending_state = self._pending_state, None
+            rng, pot_rng = self.rng, self.potential.rng
             self.sampling_state = state
+            self.rng = rng
+            self.potential.set_rng(pot_rng)
 
     def __getstate__(self):
         d = dict(self.__dict__)

@@ -186,17 +186,36 @@ class FullRankADVI:
             raise NotImplementedError("the device step function implements obj_n_mc=1 without gradient clipping")
         hist = [self.hist]
         done = 0
-        while done < n:
-            k = min(chunk, n - done)
-            idx, z0 = self.draw_inputs(k)
-            loss = self.run_steps(idx, z0, obj_optimizer)
-            hist.append(loss)
-            done += k
-            if not np.all(np.isfinite(loss)):
-                raise FloatingPointError(f"NaN occurred in optimization at step {done - k + int(np.argmin(np.isfinite(loss)))}")
-            if callbacks:
-                for cb in callbacks:
-                    cb(self.approx, loss, done)
+        callbacks = list(callbacks or [])
+        # `_iterate_with_loss` (inference.py:230-290) calls every callback after EVERY step with (approx, scores[:i + 1], i + 1).  The
+        # device runs `chunk` steps per C call, so a callback can only see the approximation at chunk ends: the chunks are cut so
+        # that every multiple of a callback's `every` (CheckParametersConvergence, Tracker-like objects) IS a chunk end, and the
+        # callbacks run there with the step count and the whole score history so far; callbacks without an `every` attribute
+        # run at each chunk end.  StopIteration ends the fit as in the reference (inference.py:283-286).
+        everys = [int(getattr(cb, "every")) for cb in callbacks if getattr(cb, "every", None)]
+        stride = int(np.lcm.reduce(everys)) if everys else None
+        if stride is not None and stride > chunk:
+            stride = min(everys)   # (incommensurate periods: the shortest one is honoured exactly, the others at its multiples)
+        scores = np.empty(0)
+        try:
+            while done < n:
+                k = min(chunk, n - done)
+                if stride is not None:
+                    k = min(k, stride - done % stride)
+                idx, z0 = self.draw_inputs(k)
+                loss = self.run_steps(idx, z0, obj_optimizer)
+                hist.append(loss)
+                done += k
+                if not np.all(np.isfinite(loss)):
+                    raise FloatingPointError(f"NaN occurred in optimization at step {done - k + int(np.argmin(np.isfinite(loss)))}")
+                if callbacks:
+                    scores = np.concatenate([scores, loss])
+                    for cb in callbacks:
+                        cb(self.approx, scores, done)
+        except StopIteration as e:
+            import logging
+
+            logging.getLogger("pymc_amd").info(str(e))
         self.hist = np.concatenate(hist)
         return self.approx
 

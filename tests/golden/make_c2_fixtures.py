@@ -13,7 +13,12 @@ tests/golden/refrun.py) over the gcc restatement of the hierarchical-logit log-d
                         same configuration must agree within Monte-Carlo error (positions are chaotic beyond a few
                         dozen draws, so this fixture is statistical by construction).
 
-    python tests/golden/make_c2_fixtures.py [c2l] [c2s]
+  c2l_chains.npz        the same four-chain summary at C2-L itself (4000 rows per group, the benchmarked shape): ~90 k oracle
+                        leapfrogs per chain at ~0.1 s each over `oracle_hier_logit_stat` (the libmvec arrangement of the same
+                        formulas, pinned to the plain loop at 1e-12) -- hours on four host cores, run once (`c2lfull`); each
+                        chain is also written to scratch/ as it finishes.
+
+    python tests/golden/make_c2_fixtures.py [c2l] [c2s] [c2lfull]
 """
 
 import multiprocessing as mp
@@ -30,6 +35,7 @@ if ROOT not in sys.path:
 
 C2L = dict(G=1248, D=8, rows_per_group=4000, tune=20, draws=10, seed=20160911)
 C2S = dict(G=1248, D=8, rows_per_group=80, tune=1000, draws=1000, chains=4, seed=20160911, start_seed=77)
+C2LFULL = dict(G=1248, D=8, rows_per_group=4000, tune=1000, draws=1000, chains=4, seed=20160911, start_seed=77)
 STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth", "mean_tree_accept", "energy",
              "energy_error", "max_energy_error", "model_logp", "step_size", "step_size_bar")
 
@@ -64,31 +70,41 @@ def make_c2l():
     print(f"c2l: {time.time() - t0:.0f} s, tree sizes {out['tree_size'].astype(int).tolist()}", flush=True)
 
 
-def _c2s_chain(c):
+def _c2s_chain(c, cfg=C2S, fn="oracle_hier_logit"):
     from oracle import c_logit, ref_sampler
     from pymc_amd import models
 
-    cfg = C2S
     spec = models.hier_logit(G=cfg["G"], D=cfg["D"], rows_per_group=cfg["rows_per_group"])
-    f = c_logit.CHierLogit(spec)
+    f = c_logit.CHierLogit(spec, fn=fn)
     starts = c2s_starts(spec.n, cfg["chains"], cfg["start_seed"])
     rngs, seeds = ref_sampler.spawn_chain_rngs(cfg["seed"], cfg["chains"])      # mcmc.py:907-908
     pot = ref_sampler.adapt_diag_potential(starts, seeds[0])                     # mcmc.py:1886-1894
     step = ref_sampler.RefNUTS(f, spec.n, potential=pot, rng=seeds[0])
     t0 = time.time()
     d, s = ref_sampler.run_chain(step, starts[c], rngs[c], cfg["tune"], cfg["draws"])
-    print(f"c2s chain {c}: {time.time() - t0:.0f} s", flush=True)
+    print(f"chain {c} ({cfg['rows_per_group']} rows per group): {time.time() - t0:.0f} s", flush=True)
     return d[cfg["tune"]:], {k: np.array([x[k] for x in s]) for k in STAT_KEYS}
 
 
-def make_c2s():
+def _c2l_chain(c):
+    d, s = _c2s_chain(c, C2LFULL, "oracle_hier_logit_stat")
+    os.makedirs(os.path.join(ROOT, "scratch"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "scratch", f"c2l_chain{c}.npz"), draws=d, **{"stat_" + k: v for k, v in s.items()})
+    return d, s
+
+
+def make_c2s(cfg=C2S, chain_fn=_c2s_chain, name="c2s_chains.npz"):
     from pymc_amd import stats as st
 
-    cfg = C2S
     with mp.get_context("fork").Pool(cfg["chains"]) as pool:
-        res = pool.map(_c2s_chain, range(cfg["chains"]))
+        res = pool.map(chain_fn, range(cfg["chains"]))
     draws = np.stack([r[0] for r in res])                   # (chains, draws, n)
+    D, G = cfg["D"], cfg["G"]
+    zbar = draws[:, :, 2 * D:].reshape(draws.shape[0], draws.shape[1], G, D).mean(axis=2)
     out = {
+        # the group mean of z per covariate and the combination the likelihood pins (mu + sigma * zbar): the diagnostics of
+        # the non-centred ridge (tools/ess_study.py)
+        "zbar_draws": zbar.astype("float32"), "beta_bar_draws": (draws[:, :, :D] + np.exp(draws[:, :, D:2 * D]) * zbar).astype("float32"),
         "mean": draws.mean(axis=(0, 1)), "sd": draws.std(axis=(0, 1), ddof=1),
         "chain_mean": draws.mean(axis=1).astype("float32"), "chain_sd": draws.std(axis=1, ddof=1).astype("float32"),
         "ess_bulk": st.ess_bulk_many(draws), "rhat": st.rhat_many(draws),
@@ -97,8 +113,8 @@ def make_c2s():
     }
     for k in ("tree_size", "step_size_bar", "depth", "diverging", "mean_tree_accept"):
         out["stat_" + k] = np.stack([r[1][k] for r in res])
-    np.savez_compressed(os.path.join(HERE, "c2s_chains.npz"), **out)
-    print("c2s: min ESS", out["ess_bulk"].min(), "argmin", int(out["ess_bulk"].argmin()), "max rhat", out["rhat"].max(),
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, ": min ESS", out["ess_bulk"].min(), "argmin", int(out["ess_bulk"].argmin()), "max rhat", out["rhat"].max(),
           "mean tree", out["stat_tree_size"][:, cfg["tune"]:].mean(), flush=True)
 
 
@@ -108,3 +124,5 @@ if __name__ == "__main__":
         make_c2s()
     if "c2l" in which:
         make_c2l()
+    if "c2lfull" in which:
+        make_c2s(C2LFULL, _c2l_chain, "c2l_chains.npz")

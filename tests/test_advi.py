@@ -148,3 +148,44 @@ def test_configs3_shape_runs():
     approx = fit(300, model=m, random_seed=2)
     assert approx.hist.shape == (300,) and np.all(np.isfinite(approx.hist))
     assert approx.params[1].shape == (512 * 513 // 2,)
+
+
+def test_fit_cuts_its_chunks_where_the_callbacks_look(monkeypatch):
+    """the reference calls every callback after every step (inference.py:230-290); the device runs a chunk of steps per
+    call, so the chunks end on every multiple of a callback's `every` and a `StopIteration` ends the fit there."""
+    m = _small("normal")
+    inf = FullRankADVI(model=m, random_seed=3)
+    sizes = []
+
+    def fake_steps(idx, z0, obj_optimizer=None):
+        sizes.append(len(idx))
+        return np.arange(len(idx), dtype="float64")
+
+    monkeypatch.setattr(inf, "run_steps", fake_steps)
+
+    class Every:
+        def __init__(self, every, stop_at=None):
+            self.every, self.stop_at, self.seen = every, stop_at, []
+
+        def __call__(self, approx, scores, i):
+            assert len(scores) == i                      # the whole history so far, as scores[:i + 1] with i + 1 == step count
+            self.seen.append(i)
+            if self.stop_at is not None and i >= self.stop_at:
+                raise StopIteration(f"Convergence achieved at {i}")
+
+    cb = Every(100)
+    inf.fit(2500, callbacks=[cb], chunk=1024)
+    assert all(i % 100 == 0 or i == 2500 for i in cb.seen) and set(range(100, 2501, 100)) <= set(cb.seen)
+    assert sum(sizes) == 2500 and len(inf.hist) == 2500
+    # convergence stopping fires at the first multiple of `every` past the criterion, not 25 chunks later
+    inf2 = FullRankADVI(model=m, random_seed=3)
+    monkeypatch.setattr(inf2, "run_steps", fake_steps)
+    cb2 = Every(100, stop_at=300)
+    inf2.fit(10_000, callbacks=[cb2], chunk=1024)
+    assert cb2.seen[-1] == 300 and len(inf2.hist) == 300
+    # without callbacks nothing is cut
+    sizes.clear()
+    inf3 = FullRankADVI(model=m, random_seed=3)
+    monkeypatch.setattr(inf3, "run_steps", fake_steps)
+    inf3.fit(2500, chunk=1024)
+    assert sizes == [1024, 1024, 452]

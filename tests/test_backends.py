@@ -144,3 +144,24 @@ def test_multitrace_from_a_sampling_result_shape():
     assert mt.nchains == 2 and len(mt) == 12
     np.testing.assert_array_equal(mt.get_values("mu", combine=False)[1], pos1[:, _mu(spec)])
     assert mt.get_sampler_stats("depth", combine=False)[0].tolist() == [s[0]["depth"] for s in st0]
+
+
+def test_multitrace_keeps_the_samplers_chain_ids_and_survives_zero_draws():
+    """a rank that holds chains [1, 3] (world 2, no gather) must label its traces 1 and 3, and a result without
+    draws takes the statistics' names from the step method instead of indexing an empty list."""
+    from pymc_amd.step import NUTS
+
+    spec = _spec()
+    pos0, st0 = _points(spec, 6, 4)
+    pos1, st1 = _points(spec, 6, 5)
+    result = {"draws": np.stack([pos0, pos1]), "stats": [[s[0] for s in st0], [s[0] for s in st1]], "chains": [1, 3]}
+    mt = multitrace_from_result(spec, result)
+    assert mt.chains == [1, 3]
+    np.testing.assert_array_equal(mt.get_values("mu", chains=[3]), pos1[:, _mu(spec)])
+
+    class StepStub:
+        stats_dtypes_shapes = NUTS.stats_dtypes_shapes
+
+    empty = {"draws": np.empty((1, 0, spec.n)), "stats": [[]], "chains": [0], "step": StepStub()}
+    mt0 = multitrace_from_result(spec, empty)
+    assert mt0.nchains == 1 and len(mt0) == 0 and "depth" in mt0.stat_names

@@ -190,3 +190,54 @@ def test_device_step_is_a_blockedstep_under_the_reference_compound_machinery():
 
     back = cloudpickle.loads(cloudpickle.dumps(step2))
     assert isinstance(back, ref.compound.BlockedStep) and back.var_names == step2.var_names
+
+
+class _FakeLib:
+    """Every entry point succeeds and does nothing (the handles are never dereferenced): enough to walk the HOST side of
+    `_materialize` / `sampling_state` on a box without a GPU."""
+
+    def __getattr__(self, name):
+        if name == "nuts_chain_create":
+            return lambda *a: 1
+        if name == "nuts_chain_state_size":
+            return lambda *a: 8
+        return lambda *a: 0
+
+
+class _FakeFunc:
+    _handle, device, _extra_are_set = 1, 0, False
+
+    def model_scalar(self, name):
+        return 0.0
+
+
+def test_a_worker_keeps_the_generator_setup_chain_gave_it(monkeypatch):
+    """a step pickled AFTER its engine handles existed carries the parent's `sampling_state`, generators
+    included.  In the worker `setup_chain(rngs[c])` runs first (parallel.py:504-524), the handles are created on the first use
+    after it -- and applying the parked state must not put the parent's generators back, or every worker chain draws the same
+    momenta and uniforms."""
+    from pymc_amd import _lib, step as step_mod
+
+    monkeypatch.setattr(_lib, "load", lambda: _FakeLib())
+    spec = models.eight_schools()
+    parent = NUTS(model=spec, rng=0, defer_device=True)
+    parent._func = _FakeFunc()
+    parent._materialize()                                    # "the parent had touched the engine"
+    assert parent._chain_h == 1
+    blob = pickle.dumps(parent)
+    parent._chain_h = None                                   # (nothing to destroy)
+    states = []
+    for c, rng in enumerate(np.random.default_rng(123).spawn(2)):
+        w = pickle.loads(blob)
+        assert w._pending_state is not None and w._chain_h is None
+        w._func = _FakeFunc()
+        w.setup_chain(rng, 10, 10)                           # compound.py:233-250 + base_hmc.py:300-302
+        expect = (rng.bit_generator.state, w.potential.rng.bit_generator.state)
+        w._materialize()                                     # first use: handles created, parked state applied
+        assert w.rng is rng                                  # the OBJECT setup_chain assigned (no copy, compound.py:250)
+        assert (w.rng.bit_generator.state, w.potential.rng.bit_generator.state) == expect
+        assert w._pending_state is None
+        states.append(expect)
+        w._chain_h = None
+    assert states[0] != states[1]
+    assert states[0][0] != parent.rng.bit_generator.state

@@ -140,6 +140,28 @@ def test_collapsed_continuous_logp_equals_the_full_model_logp():
             assert abs(g[j] - fd) <= 1e-5 * max(1.0, abs(fd))
 
 
+def test_remembered_statistics_are_not_served_for_other_assignments():
+    """the statistics the sweep hands over are remembered for THE array it produced, contents included --
+    an in-place edit of that array, or another array that happens to land on its address, is recounted."""
+    spec = models.normal_mixture(N=300, K=3, seed=5)
+    link = spec.mixture
+    rng = np.random.default_rng(1)
+    c = rng.integers(0, 3, size=300)
+    count = lambda a: tuple(np.bincount(a, weights=w, minlength=3) for w in (None, link.y, link.y * link.y))
+    link.remember(c, tuple(np.asarray(x, dtype="float64") for x in count(c)))
+    assert link.suffstats(c) is link._cache                                   # the hand-over itself
+    c[:40] = (c[:40] + 1) % 3                                                 # same object, same address, new contents
+    for got, want in zip(link.suffstats(c), count(c)):
+        np.testing.assert_array_equal(got, want)
+    link.remember(c, count(c))
+    addr = c.ctypes.data
+    del c                                                                     # the link still holds it: the address cannot be reused
+    other = rng.integers(0, 3, size=300)
+    assert other.ctypes.data != addr
+    for got, want in zip(link.suffstats(other), count(other)):
+        np.testing.assert_array_equal(got, want)
+
+
 def test_step_surface_and_state_roundtrip_without_a_device():
     spec = models.normal_mixture(N=50, K=3)
     st = CategoricalGibbsMetropolis(model=spec, rng=4)

@@ -1234,3 +1234,52 @@ def test_emits_energy_warnings(caplog):
         assert n_div > 0
         assert any("Energy change" in r.getMessage() for r in caplog.records)
         assert sum("Energy change" in r.getMessage() for r in caplog.records) == n_div
+
+
+def test_hmc_rejection_hands_the_start_gradient_to_the_potential_after_the_ring_wrapped():
+    """a fixed-length trajectory of n_steps >= S leapfrogs uses the arena as a ring, so slot 0 no longer holds the
+    start state when the transition is REJECTED; `QuadPotentialDiagAdaptExp(use_grads=True)` must then adapt on the gradient
+    kept aside at the start (hmc.py:162-166 returns `start`, base_hmc.py:236 updates the potential with its gradient)."""
+    from pymc_amd.blocking import RaveledVars
+    from pymc_amd.quadpotential import QuadPotentialDiagAdaptExp
+    from pymc_amd.step import HamiltonianMC
+
+    spec = models.std_normal(6, 1.0, 2.0)
+    f = ref_models.SpecLogpGrad(spec)
+    n = spec.n
+    kw = dict(path_length=4000.0, max_steps=1024, step_scale=1.9, adapt_step_size=False)
+    step = HamiltonianMC(model=spec, potential=QuadPotentialDiagAdaptExp(n, np.zeros(n), alpha=0.05, use_grads=True, rng=1), rng=4, device=0, **kw)
+    ref = ref_sampler.RefHMC(f, n, potential=ref_sampler.DiagAdaptExpPotential(n, np.zeros(n), alpha=0.05, use_grads=True, rng=1), rng=4, **kw)
+    step.setup_chain(np.random.default_rng(8), 140, 0)
+    ref.setup_chain(np.random.default_rng(8), 140, 0)
+    q = RaveledVars(np.zeros(n), spec.point_map_info)
+    qr = np.zeros(n)
+    rejected = 0
+    for i in range(125):
+        q, st = step.astep(q)
+        qr, sr = ref.astep(qr)
+        assert st[0]["n_steps"] == sr["n_steps"] == 1024 and st[0]["accepted"] == sr["accepted"], i
+        rejected += not sr["accepted"]
+        np.testing.assert_allclose(step.potential._hvar, ref.potential.var, rtol=1e-8, err_msg=f"transition {i}")
+    assert rejected >= 5 and not np.allclose(ref.potential.var, 1.0)
+    step.close()
+
+
+def test_chains_in_worker_processes_equal_the_sequential_chains():
+    """`pm.sample(cores > 1)` (parallel.py:352-524; tests/sampling/test_parallel.py:270-287 asks identical draws of the worker
+    processes): the step is cloudpickled AFTER its engine handles existed (so it carries a parked sampling state), every worker
+    installs its own chain generator first and creates its handles on first use.  ADVICE r02 (high): the parked state used to put
+    the parent's generators back -- identical chains.  Here: bitwise the sequential chains, and the chains differ from each other."""
+    from pymc_amd.sampling import sample
+
+    spec = models.eight_schools()
+    kw = dict(draws=30, tune=40, chains=3, model=spec, random_seed=11, device=0, init="adapt_diag")
+    a = sample(**kw)
+    b = sample(mp_ctx="spawn", **kw)
+    assert np.array_equal(a["draws"], b["draws"])
+    assert not np.array_equal(b["draws"][0], b["draws"][1]) and not np.array_equal(b["draws"][1], b["draws"][2])
+    for sa, sb in zip(a["stats"], b["stats"]):
+        for x, y in zip(sa, sb):
+            for k in INT_KEYS + ("energy", "step_size"):
+                assert x[k] == y[k], k
+    a["step"].close(); b["step"].close()
