@@ -15,11 +15,15 @@ imports pytensor and looks at nothing but
     type(op).__name__ in {Elemwise, DimShuffle, Sum / CAReduce, AdvancedSubtensor1, Subtensor, Dot, Join, Cast, Alloc,
                           CheckParameterValue, SpecifyShape},  Elemwise: type(op.scalar_op).__name__,  Sum: op.axis
 
--- and is exercised on stub graphs that transcribe what the reference's `logp` methods build (tests/stubgraph.py:
-continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390 HalfCauchy, :1478-1486 Exponential,
-:1570-1576 Laplace, :1807-1821 LogNormal, :1935-1950 StudentT, :1248-1262 Beta, :2512-2521 Gamma, :2631-2639 InverseGamma,
-:309-321 Uniform, :720-746 TruncatedNormal, discrete.py:351-374 Bernoulli, :141-154 Binomial, :581-597 Poisson; transforms.py:880-891 log, :1026-1070 interval,
-:1076-1088 logodds).
+-- and is exercised on graphs that THE REFERENCE'S OWN CODE builds: tests/stubgraph.py loads `Dist.dist` / `Dist.logp` of every
+distribution below, `check_parameters`, `logpow`, `factln`, `binomln`, `normal_lcdf` & co., `get_tau_sigma`, `bounded_cont_transform`
+and the value transforms (`LogTransform`, `IntervalTransform`, `LogOddsTransform`: `backward`, `log_jac_det`) from the reference
+checkout by `ast` and executes them on a stand-in for the graph protocol above; the resulting graphs are committed
+(tests/golden/ref_graphs.npz) so that they travel (continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390
+HalfCauchy, :1478-1486 Exponential, :1570-1576 Laplace, :1807-1821 LogNormal, :1935-1950 StudentT, :1248-1262 Beta, :2512-2521 Gamma,
+:2631-2639 InverseGamma, :309-321 Uniform, :720-746 TruncatedNormal, discrete.py:351-374 Bernoulli, :141-154 Binomial, :581-597
+Poisson; transforms.py:880-891 log, :1026-1070 interval, :1076-1088 logodds).  What is still written by hand in the tests is only
+what IS PyTensor (operator overloading, op class names) and the assembly `Model.logp` performs around those bodies.
 
 How a factor is recognised: the graph is first turned into a small expression tree (constants folded, broadcasts /
 casts / parameter checks stripped -- the device applies its own support and parameter checks), then matched against the
@@ -772,10 +776,18 @@ class _Lowering:
                 args = (self.term(val), t_eta)
                 self.spec.factors.append(ms.Factor(ms.D_BERNOULLI_LOGIT, max(self._size(a) for a in args), args, 0.0, name))
                 return
+            lam_direct = None
+            if dist == ms.D_EXPONENTIAL and env["mu"][0] == "reciprocal":
+                # `Exponential.dist(lam=...)` hands `scale = reciprocal(lam)` to the logp (continuous.py:1448-1459); with a
+                # non-constant rate the reciprocal is still in the graph, and the IR's Exponential takes the rate itself
+                lam_direct = self.term(env["mu"][1])
+                env = dict(env, mu=K(1.0))
             # (parameters first, then the value: the order in which `ModelBuilder` registers data vectors)
             lowered = {a: self.term(env[a]) for a in argnames[1:] + argnames[:1]}
             args = tuple(lowered[a] for a in argnames)
-            if dist == ms.D_EXPONENTIAL:   # the IR's Exponential takes lam = 1 / mu
+            if lam_direct is not None:
+                args = (args[0], lam_direct)
+            elif dist == ms.D_EXPONENTIAL:   # the IR's Exponential takes lam = 1 / mu
                 mu = args[1]
                 if not (mu.b == ms.ZERO or mu.c == ms.ZERO) or mu.a.kind != ms.OP_CONST:
                     raise NotLowerable("Exponential with a non-constant scale")

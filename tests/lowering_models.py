@@ -1,0 +1,135 @@
+"""Named models for the lowering tests: each entry gives the model as the REFERENCE's code builds its log-density graphs
+(`stubgraph.StubModel`: the reference's `dist` / `logp` / transform bodies executed on the graph protocol) and as `ModelBuilder`
+assembles the spec by hand.  `tests/golden/make_ref_graphs.py` writes the graphs of every entry to tests/golden/ref_graphs.npz, so
+that boxes without /root/reference (the GPU box) lower exactly what the reference's code built here.  TEST INFRASTRUCTURE."""
+
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stubgraph as sg  # noqa: E402
+
+from pymc_amd import models  # noqa: E402
+from pymc_amd.model_spec import ModelBuilder  # noqa: E402
+
+Y4 = np.array([0.3, -1.2, 2.5, 0.1])
+W3 = np.array([0.7, 1.9, 3.2])
+CNT = np.array([0.0, 3.0, 1.0, 7.0, 2.0])
+NN = np.array([5.0, 9.0, 4.0, 7.0, 10.0])
+D4 = np.array([0.3, -0.5, 1.2, 0.1])
+
+
+def golden():
+    m = sg.StubModel()
+    mu_pop = m.Normal("mu_pop")
+    sigma_pop = m.HalfNormal("sigma_pop")
+    mu = m.Normal("mu", mu_pop, sigma_pop, shape=(3,))
+    m.Normal("y", mu, 1.0, observed=[0.0, 1.0, 2.0])
+    return m
+
+
+def schools(J=8):
+    ref = models.eight_schools(J)
+    y, sigma = ref.data[1], ref.data[0]
+    m = sg.StubModel()
+    eta = m.Normal("eta", 0.0, 1.0, shape=(J,))
+    mu = m.Normal("mu", 0.0, 1e6)
+    tau = m.HalfCauchy("tau", 25.0)
+    m.Normal("obs", mu + tau * eta, sigma, observed=y)
+    return m
+
+
+def hier_logit(G=6, D=8, rpg=5):
+    ref = models.hier_logit(G=G, D=D, rows_per_group=rpg, seed=3)
+    r = ref.logit_rows
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 1.0, shape=(D,))
+    sigma = m.HalfNormal("sigma", 1.0, shape=(D,))
+    z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    beta = mu + sigma * z                                   # (G, D)
+    eta = (sg.as_tensor(r.X) * beta[r.group_idx]).sum(axis=1)
+    m.Bernoulli("y", logit_p=eta, observed=r.y)
+    return m
+
+
+def laplace_lognormal(b=None):
+    m = b or sg.StubModel()
+    loc = m.Normal("loc", 0.0, 2.0)
+    s = m.LogNormal("s", 0.5, 0.75)
+    m.Laplace("y", loc, 1.5, observed=Y4)
+    m.LogNormal("w", loc, s, observed=W3)
+    return m
+
+
+def shape_parameters(b=None):
+    m = b or sg.StubModel()
+    loc = m.Normal("loc", 0.0, 2.0)
+    s = m.HalfNormal("s", 1.5)
+    g = m.Gamma("g", 2.5, 1.7)
+    ig = m.InverseGamma("ig", 3.0, 0.8)
+    m.Beta("bb", 2.0, 3.5)
+    m.StudentT("y", 4.0, loc, s, observed=Y4)
+    m.StudentT("y2", 7.0, loc, 1.25, observed=Y4)
+    m.Gamma("w", 2.0, g, observed=W3)
+    m.InverseGamma("w2", 1.5, ig, observed=W3)
+    m.Poisson("c", g, observed=CNT)
+    return m
+
+
+def uniform_binomial(b=None):
+    m = b or sg.StubModel()
+    u = m.Uniform("u", 0.2, 0.9)
+    m.Binomial("k", NN, u, observed=CNT)
+    m.Binomial("k2", 12, u, observed=CNT)
+    return m
+
+
+def truncated(kw, b=None):
+    m = b or sg.StubModel()
+    mu = m.Normal("mu", 0.0, 5.0)
+    s_ = m.HalfNormal("sg", 2.0)
+    m.TruncatedNormal("obs", mu=mu, sigma=s_, observed=D4, **kw)
+    m.TruncatedNormal("obs2", mu=0.25, sigma=s_, observed=D4, **kw)
+    m.TruncatedNormal("obs3", mu=mu, sigma=1.5, observed=D4, **kw)
+    return m
+
+
+def truncated_free(b=None):
+    m = b or sg.StubModel()
+    t = m.TruncatedNormal("t", mu=0.5, sigma=2.0, lower=-1.0, upper=2.0)
+    m.Normal("y", t, 1.0, observed=D4)
+    return m
+
+
+def cauchy_exponential(b=None):
+    m = b or sg.StubModel()
+    a = m.Cauchy("a", 0.5, 2.0)
+    r = m.Exponential("r", 1.5)
+    m.Cauchy("y", a, r, observed=Y4)
+    m.Exponential("w", r, observed=W3)
+    return m
+
+
+def _built(fn, *a):
+    return fn(*a, ModelBuilder()).build()
+
+
+# name -> (graphs from the reference's code, the hand-assembled spec)
+ENTRIES = {
+    "golden": (golden, models.golden_hier_normal),
+    "schools8": (lambda: schools(8), lambda: models.eight_schools(8)),
+    "schools24": (lambda: schools(24), lambda: models.eight_schools(24)),
+    "hier_logit_6x5": (hier_logit, lambda: models.hier_logit(G=6, D=8, rows_per_group=5, seed=3)),
+    "hier_logit_40x33": (lambda: hier_logit(40, 8, 33), lambda: models.hier_logit(G=40, D=8, rows_per_group=33, seed=3)),
+    "laplace_lognormal": (laplace_lognormal, lambda: _built(laplace_lognormal)),
+    "shape_parameters": (shape_parameters, lambda: _built(shape_parameters)),
+    "uniform_binomial": (uniform_binomial, lambda: _built(uniform_binomial)),
+    "truncated_both": (lambda: truncated(dict(lower=-1.0, upper=2.0)), lambda: _built(truncated, dict(lower=-1.0, upper=2.0))),
+    "truncated_lower": (lambda: truncated(dict(lower=-0.8)), lambda: _built(truncated, dict(lower=-0.8))),
+    "truncated_upper": (lambda: truncated(dict(upper=1.5)), lambda: _built(truncated, dict(upper=1.5))),
+    "truncated_free": (truncated_free, lambda: _built(truncated_free)),
+    "cauchy_exponential": (cauchy_exponential, lambda: _built(cauchy_exponential)),
+}
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")

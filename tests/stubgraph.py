@@ -1,15 +1,25 @@
-"""A stand-in for the slice of PyTensor / PyMC that `pymc_amd.lowering.lower_to_spec` walks (PyTensor cannot be imported in
-the build image).  TEST INFRASTRUCTURE.
+"""A stand-in for the slice of PyTensor that `pymc_amd.lowering.lower_to_spec` walks, and a loader that EXECUTES THE REFERENCE'S
+OWN distribution code on it (PyTensor cannot be imported in the build image).  TEST INFRASTRUCTURE.
 
-* graph protocol: `Variable(owner, name)`, `Apply(op, inputs)`, ops named as PyTensor names them (`Elemwise` with a
-  `scalar_op` object whose class is `Add`, `Mul`, `Sub`, `TrueDiv`, `Pow`, `Exp`, `Log`, `Log1p`, `Sqrt`, `Neg`, `Switch`, `GE`,
-  `GT`, `LT`, `LE`, `EQ`, `NEQ`, `OR`, `AND`, `Sigmoid`, `Softplus`, `GammaLn`, `Reciprocal`, `Sign`, `Erf`, `Erfc`, `Erfcx`, `Sqr`, `Second`; `DimShuffle`; `Sum` with `.axis`; `AdvancedSubtensor1`; `CheckParameterValue`; constants carry
-  `.data`), with operator overloading so that the distribution code below reads like the reference's;
-* distributions: `logp` bodies TRANSCRIBED from the reference, each citing its lines -- these build exactly the expression a
-  `pm.Model` would hand to the compiler BEFORE rewrites (`Model.logp`, model/core.py:612-695);
-* `StubModel`: `value_vars`, value transforms (`rvs_to_transforms`), `logp(sum=False)` in the reference's order (free RVs,
-  observed RVs, potentials) with the Jacobian term added to transformed variables' own factors
-  (`transformed_conditional_logp`, logprob/basic.py:618-667).
+Three layers, only the first written here by hand:
+
+* graph protocol (what cannot be traced because it IS PyTensor): `Variable(owner, name)`, `Apply(op, inputs)`, ops named as
+  PyTensor names them (`Elemwise` with a `scalar_op` object whose class is `Add`, `Mul`, `Sub`, `TrueDiv`, `Pow`, `Exp`, `Log`, `Log1p`,
+  `Sqrt`, `Neg`, `Switch`, `GE`, `GT`, `LT`, `LE`, `EQ`, `NEQ`, `OR`, `AND`, `Sigmoid`, `Softplus`, `GammaLn`, `Reciprocal`, `Sign`, `Erf`,
+  `Erfc`, `Erfcx`, `Sqr`, `Second`; `DimShuffle`; `Sum` / `All` with `.axis`; `MakeVector`; `AdvancedSubtensor1`; `CheckParameterValue`;
+  constants carry `.data`), operator overloading, and the `pt.*` names the reference's bodies call;
+* the reference's code, loaded from `/root/reference` by `ast` (never copied: the source segments are compiled and executed in
+  memory) and run on that protocol -- `check_parameters`, `logpow`, `factln`, `binomln`, `betaln`, `normal_lcdf`, `normal_lccdf`,
+  `log_diff_normal_cdf` (distributions/dist_math.py), `get_tau_sigma`, `_truncation_is_bounded`, `bounded_cont_transform` and the
+  `dist` / `logp` (+ `get_alpha_beta`) methods of Normal, HalfNormal, Cauchy, HalfCauchy, Exponential, Laplace, LogNormal, StudentT,
+  Beta, Gamma, InverseGamma, Uniform, TruncatedNormal (distributions/continuous.py), Bernoulli, Binomial, Poisson
+  (distributions/discrete.py), `LogTransform`, `IntervalTransform`, `LogOddsTransform` whole (logprob/transforms.py) and `Interval`
+  (distributions/transforms.py).  So every graph the lowering is tested on was BUILT BY THE REFERENCE'S `dist`, `logp`,
+  `backward` and `log_jac_det` bodies; where `/root/reference` is absent the tests that need them skip;
+* `StubModel`: the assembly `Model.logp(sum=False)` performs around those bodies (model/core.py:612-695 order: free RVs, observed
+  RVs, potentials; a transformed variable's factor is `logp(transform.backward(value), *params) + transform.log_jac_det(value, *rv
+  inputs)`, logprob/transform_value.py:80-138; default transforms as registered in continuous.py:156-201, 345-347, 817-819), which
+  is dispatch machinery (`_logprob`, `TransformValuesRewrite`) and cannot be executed without PyTensor.
 """
 import numpy as np
 
@@ -47,8 +57,15 @@ class Variable:
     def __lt__(self, o): return self._bin(o, LT)
     def __le__(self, o): return self._bin(o, LE)
     def __pow__(self, o): return self._bin(o, Pow)
+    def __rpow__(self, o): return self._bin(o, Pow, True)
+    def __and__(self, o): return self._bin(o, AND)
+    def __or__(self, o): return self._bin(o, OR)
     def __getitem__(self, idx): return Variable(Apply(AdvancedSubtensor1(), [self, as_tensor(idx)]), shape=(len(np.asarray(idx)),) + self.type.shape[1:])
     def sum(self, axis=None): return Variable(Apply(Sum(axis), [self]), shape=())
+    def copy(self): return self          # (`log_jac_det(...).copy()`, transform_value.py:102: an identity node in PyTensor)
+
+    @property
+    def ndim(self): return len(self.type.shape)
 
 
 class TensorConstant(Variable):
@@ -56,6 +73,10 @@ class TensorConstant(Variable):
         data = np.asarray(data)
         super().__init__(None, None, data.shape)
         self.data = data
+
+    @property
+    def value(self):                     # `TensorConstant.value` (continuous.py:591-592)
+        return self.data
 
 
 def as_tensor(x):
@@ -82,11 +103,21 @@ class Sum:
 
 
 class CheckParameterValue:
-    def __init__(self, msg):
-        self.msg = msg
+    """`CheckParameterValue(msg, can_be_replaced_by_ninf)(expr, all_true_scalar)` (logprob/utils.py:209-225)."""
+
+    def __init__(self, msg="", can_be_replaced_by_ninf=False):
+        self.msg, self.can_be_replaced_by_ninf = msg, can_be_replaced_by_ninf
+
+    def __call__(self, expr, cond):
+        return Variable(Apply(self, [as_tensor(expr), as_tensor(cond)]), shape=as_tensor(expr).type.shape)
 
 
 class All:
+    def __init__(self, axis=None):
+        self.axis = axis
+
+
+class MakeVector:
     pass
 
 
@@ -176,188 +207,205 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     erfcx = staticmethod(lambda a: elemwise(Erfcx, a))
     sqr = staticmethod(lambda a: elemwise(Sqr, a))
     square = staticmethod(lambda a: elemwise(Sqr, a))
+    expit = sigmoid
     inf = np.inf
+    constant = staticmethod(lambda x, **kw: TensorConstant(x))
+    as_tensor_variable = staticmethod(lambda x, dtype=None, **kw: as_tensor(x))
+    zeros_like = staticmethod(lambda a: elemwise(Second, a, 0.0))     # pt.zeros_like = fill(a, 0)
+
+    @staticmethod
+    def all(x, axis=None):
+        """`pt.all`: a list goes through `as_tensor_variable` (a `MakeVector` of its scalars) first, as in PyTensor."""
+        if isinstance(x, (list, tuple)):
+            x = Variable(Apply(MakeVector(), [as_tensor(i) for i in x]), shape=(len(x),))
+        return Variable(Apply(All(axis), [as_tensor(x)]), shape=())
 
 
-gammaln = pt.gammaln
+# ---------------------------------------------------------------------------
+# the reference's own code, executed on the protocol above
+# ---------------------------------------------------------------------------
+import __future__  # noqa: E402
+import ast  # noqa: E402
+import os  # noqa: E402
+import textwrap  # noqa: E402
+
+REF = os.environ.get("PYMC_REFERENCE", "/root/reference")
 
 
-def check_parameters(expr, *conds, msg=""):   # distributions/dist_math.py:50-74
-    allc = Variable(Apply(All(), [as_tensor(c) for c in conds]), shape=())
-    return Variable(Apply(CheckParameterValue(msg), [expr, allc]), shape=expr.type.shape)
+def available() -> bool:
+    return os.path.isfile(os.path.join(REF, "pymc", "distributions", "continuous.py"))
 
 
-# ---- logp bodies, transcribed ----
-def normal_logp(value, mu, sigma):          # distributions/continuous.py:526-532
-    res = -0.5 * pt.pow((value - mu) / sigma, 2) - pt.log(pt.sqrt(2.0 * np.pi)) - pt.log(sigma)
-    return check_parameters(res, sigma > 0, msg="sigma > 0")
+_AST = {}
 
 
-def halfnormal_logp(value, loc, sigma):     # distributions/continuous.py:909-916
-    res = -0.5 * pt.pow((value - loc) / sigma, 2) + pt.log(pt.sqrt(2.0 / np.pi)) - pt.log(sigma)
-    res = pt.switch(pt.ge(value, loc), res, -np.inf)
-    return check_parameters(res, sigma > 0, msg="sigma > 0")
+def _parsed(rel):
+    if rel not in _AST:
+        with open(os.path.join(REF, "pymc", rel)) as fh:
+            src = fh.read()
+        _AST[rel] = (src.splitlines(), ast.parse(src))
+    return _AST[rel]
 
 
-def cauchy_logp(value, alpha, beta):        # distributions/continuous.py:2287-2293
-    res = -pt.log(np.pi) - pt.log(beta) - pt.log1p(pt.pow((value - alpha) / beta, 2))
-    return check_parameters(res, beta > 0, msg="beta > 0")
+def _find(tree, qualname):
+    node = tree
+    for part in qualname.split("."):
+        for child in node.body:
+            if isinstance(child, (ast.ClassDef, ast.FunctionDef)) and child.name == part:
+                node = child
+                break
+        else:
+            raise LookupError(f"{qualname} not found")
+    return node
 
 
-def halfcauchy_logp(value, beta):           # distributions/continuous.py:2383-2390
-    res = pt.log(2) + cauchy_logp(value, 0, beta)
-    res = pt.switch(value >= 0, res, -np.inf)
-    return check_parameters(res, beta > 0, msg="beta > 0")
+def _segment(lines, node):
+    """Source lines of a def / class, decorators included, dedented."""
+    first = min([node.lineno] + [d.lineno for d in node.decorator_list if not _is_registration(d)]) - 1
+    return textwrap.dedent("\n".join(lines[first:node.end_lineno]))
 
 
-def laplace_logp(value, mu, b):             # distributions/continuous.py:1570-1576
-    res = -pt.log(2 * b) - pt.abs(value - mu) / b
-    return check_parameters(res, b > 0, msg="b > 0")
+def _is_registration(dec):   # `@_default_transform.register(...)`: dispatch machinery, not part of the body
+    return isinstance(dec, ast.Call) and isinstance(dec.func, ast.Attribute) and dec.func.attr == "register"
 
 
-def lognormal_logp(value, mu, sigma):       # distributions/continuous.py:1807-1821
-    res = -0.5 * pt.pow((pt.log(value) - mu) / sigma, 2) - 0.5 * pt.log(2.0 * np.pi) - pt.log(sigma) - pt.log(value)
-    res = pt.switch(pt.gt(value, 0.0), res, -np.inf)
-    return check_parameters(res, sigma > 0, msg="sigma > 0")
+def _exec(code_text, where, ns):
+    # (annotations stay strings: the signatures name typing-only PyTensor types)
+    exec(compile(code_text, f"<reference {where}>", "exec", flags=__future__.annotations.compiler_flag), ns)
 
 
-def logpow(x, m):                           # distributions/dist_math.py:92-107
-    log_x = pt.log(x)
-    return pt.switch(pt.and_(pt.eq(log_x, -np.inf), pt.le(m, 0)), pt.switch(pt.eq(m, 0), 0.0, -np.inf), m * log_x)
+def ref_function(rel, qualname, ns):
+    """The reference's function `qualname` of pymc/`rel`, compiled from its own source lines and bound in `ns`."""
+    lines, tree = _parsed(rel)
+    node = _find(tree, qualname)
+    _exec(_segment(lines, node), f"{rel}:{node.lineno}", ns)
+    return ns[node.name]
 
 
-def factln(n):                              # distributions/dist_math.py:110-111
-    return gammaln(n + 1)
+def ref_class(rel, classname, members, base, ns):
+    """A class holding the reference's `members` of class `classname` (their source lines, decorators included, compiled under a
+    `class` header so that zero-argument `super()` and `cls.` look-ups work) on top of the stand-in `base`."""
+    lines, tree = _parsed(rel)
+    cls = _find(tree, classname)
+    body = []
+    for m in members:
+        node = _find(cls, m)
+        body.append(textwrap.indent(_segment(lines, node), "    "))
+    for stmt in cls.body:                      # plain class attributes the bodies read (`bound_args_indices`, `name`, `ndim_supp`)
+        if isinstance(stmt, ast.Assign) and isinstance(stmt.value, (ast.Constant, ast.Tuple)):
+            body.append("    " + ast.unparse(stmt))
+    ns["__base__"] = base
+    _exec(f"class {classname}(__base__):\n" + "\n\n".join(body) + "\n", f"{rel}:{cls.lineno}", ns)
+    return ns[classname]
 
 
-def get_tau_sigma(sigma):                   # distributions/continuous.py:234-239 (the `tau is None` branch)
-    sigma = as_tensor(sigma)
-    return (sigma ** -2.0) * pt.sign(sigma), sigma
+class _Params(list):
+    """The parameter list of an RV node, remembering which distribution made it (`rv.owner.op` in the reference)."""
+
+    def __init__(self, params, dist_cls):
+        super().__init__(params)
+        self.dist_cls = dist_cls
 
 
-def studentt_logp(value, nu, mu, sigma):    # distributions/continuous.py:1935-1950
-    lam, _ = get_tau_sigma(sigma=sigma)
-    res = (gammaln((nu + 1.0) / 2.0) + 0.5 * pt.log(lam / (nu * np.pi)) - gammaln(nu / 2.0)
-           - (nu + 1.0) / 2.0 * pt.log1p(lam * (value - mu) ** 2 / nu))
-    return check_parameters(res, lam > 0, nu > 0, msg="lam > 0, nu > 0")
+class _DistBase:
+    """What `Distribution.dist` is to the bodies loaded here: the end of the `super().dist([params...])` chain.  Returns the
+    parameter list the RV node would carry after (rng, size)."""
+
+    @classmethod
+    def dist(cls, dist_params, *args, **kwargs):
+        return _Params([as_tensor(p) for p in dist_params], cls)
 
 
-def beta_logp(value, alpha, beta):          # distributions/continuous.py:1248-1262
-    res = (pt.switch(pt.eq(alpha, 1.0), 0.0, (alpha - 1.0) * pt.log(value))
-           + pt.switch(pt.eq(beta, 1.0), 0.0, (beta - 1.0) * pt.log1p(-value))
-           - (pt.gammaln(alpha) + pt.gammaln(beta) - pt.gammaln(alpha + beta)))
-    res = pt.switch(pt.bitwise_and(pt.ge(value, 0.0), pt.le(value, 1.0)), res, -np.inf)
-    return check_parameters(res, alpha > 0, beta > 0, msg="alpha > 0, beta > 0")
+class _TransformBase:   # logprob/abstract.py `Transform`: an interface
+    pass
 
 
-def gamma_logp(value, alpha, scale):        # distributions/continuous.py:2512-2521 (`scale = reciprocal(beta)`, :2484-2492)
-    beta = pt.reciprocal(scale)
-    res = -pt.gammaln(alpha) + logpow(beta, alpha) - beta * value + logpow(value, alpha - 1)
-    res = pt.switch(pt.ge(value, 0.0), res, -np.inf)
-    return check_parameters(res, alpha > 0, beta > 0, msg="alpha > 0, beta > 0")
+class _NotScalarConstantError(Exception):
+    pass
 
 
-def invgamma_logp(value, alpha, beta):      # distributions/continuous.py:2631-2639
-    res = -pt.gammaln(alpha) + logpow(beta, alpha) - beta / value + logpow(value, -alpha - 1)
-    res = pt.switch(pt.ge(value, 0.0), res, -np.inf)
-    return check_parameters(res, alpha > 0, beta > 0, msg="alpha > 0, beta > 0")
+def _get_underlying_scalar_constant_value(v, *a, **k):
+    if isinstance(v, TensorConstant) and v.data.size == 1:
+        return v.data.reshape(-1)[0]
+    raise _NotScalarConstantError()
 
 
-def poisson_logp(value, mu):                # distributions/discrete.py:581-597
-    res = pt.switch(pt.lt(value, 0), -np.inf, logpow(mu, value) - factln(value) - mu)
-    res = pt.switch(pt.eq(mu, 0) * pt.eq(value, 0), 0, res)
-    return check_parameters(res, mu >= 0, msg="mu >= 0")
+_NS = None
+_CONT = ("Normal", "HalfNormal", "Cauchy", "HalfCauchy", "Exponential", "Laplace", "LogNormal", "StudentT", "Beta", "Gamma", "InverseGamma",
+         "Uniform", "TruncatedNormal")
+_DISC = ("Bernoulli", "Binomial", "Poisson")
 
 
-def binomln(n, k):                          # distributions/dist_math.py:114-115
-    return factln(n) - factln(k) - factln(n - k)
+def reference():
+    """Namespace with the reference's functions and classes listed in the module docstring, loaded once."""
+    global _NS
+    if _NS is not None:
+        return _NS
+    if not available():
+        import pytest
+
+        pytest.skip(f"the reference checkout ({REF}) is needed to build graphs with the reference's own logp / dist / transform code")
+    ns = {"np": np, "pt": pt, "gammaln": pt.gammaln, "Variable": Variable, "TensorVariable": Variable, "TensorConstant": TensorConstant,
+          "CheckParameterValue": CheckParameterValue, "NotScalarConstantError": _NotScalarConstantError,
+          "get_underlying_scalar_constant_value": _get_underlying_scalar_constant_value}
+    for fn in ("check_parameters", "logpow", "factln", "binomln", "betaln", "normal_lcdf", "normal_lccdf", "log_diff_normal_cdf"):
+        ref_function("distributions/dist_math.py", fn, ns)
+    for fn in ("get_tau_sigma", "_truncation_is_bounded"):
+        ref_function("distributions/continuous.py", fn, ns)
+    for rel, names in (("distributions/continuous.py", _CONT), ("distributions/discrete.py", _DISC)):
+        _, tree = _parsed(rel)
+        for name in names:
+            have = {c.name for c in _find(tree, name).body if isinstance(c, ast.FunctionDef)}
+            ref_class(rel, name, [m for m in ("dist", "get_alpha_beta", "_get_alpha_beta", "logp") if m in have], _DistBase, ns)
+    # `_logprob_helper(Normal.dist(mu, sigma), value)` (continuous.py:731, :2384): dispatch to the logp of the RV's distribution
+    ns["_logprob_helper"] = lambda rv, value: rv.dist_cls.logp(value, *rv)
+    for name in ("LogTransform", "IntervalTransform", "LogOddsTransform"):
+        ref_class("logprob/transforms.py", name, [c.name for c in _find(_parsed("logprob/transforms.py")[1], name).body if isinstance(c, ast.FunctionDef)],
+                  _TransformBase, ns)
+    ref_class("distributions/transforms.py", "Interval", ["__init__"], ns["IntervalTransform"], ns)
+    ns["transforms"] = type("transforms", (), {"Interval": ns["Interval"], "log": ns["LogTransform"](), "logodds": ns["LogOddsTransform"]()})
+    ref_function("distributions/continuous.py", "bounded_cont_transform", ns)
+    _NS = ns
+    return ns
 
 
-def uniform_logp(value, lower, upper):      # distributions/continuous.py:309-321
-    res = pt.switch(pt.bitwise_and(pt.ge(value, lower), pt.le(value, upper)), pt.fill(value, -pt.log(upper - lower)), -np.inf)
-    return check_parameters(res, lower <= upper, msg="lower <= upper")
+def _ref_logp(cls_name):
+    return lambda *a: getattr(reference()[cls_name], "logp")(*a)
 
 
-def binomial_logp(value, n, p):             # distributions/discrete.py:141-154
-    res = pt.switch(pt.or_(pt.lt(value, 0), pt.gt(value, n)), -np.inf, binomln(n, value) + logpow(p, value) + logpow(1 - p, n - value))
-    return check_parameters(res, n >= 0, 0 <= p, p <= 1, msg="n >= 0, 0 <= p <= 1")
+# the names the tests use for the reference's logp bodies (each call runs the reference's own code)
+normal_logp = _ref_logp("Normal")
+studentt_logp = _ref_logp("StudentT")
+gamma_logp = _ref_logp("Gamma")
 
 
-def interval_backward(value, a, b):         # logprob/transforms.py:1026-1053 (both bounds given)
-    a, b = as_tensor(a), as_tensor(b)
-    exp_value = pt.exp(value)
-    sigmoid_x = pt.sigmoid(value)
-    lower_distance = exp_value + a
-    upper_distance = b - exp_value
-    return pt.where(pt.and_(pt.neq(a, -pt.inf), pt.neq(b, pt.inf)), sigmoid_x * b + (1 - sigmoid_x) * a,
-                    pt.where(pt.neq(a, -pt.inf), lower_distance, pt.where(pt.neq(b, pt.inf), upper_distance, value)))
-
-
-def interval_log_jac_det(value, a, b):      # logprob/transforms.py:1055-1070
-    a, b = as_tensor(a), as_tensor(b)
-    s = pt.softplus(-value)
-    return pt.where(pt.and_(pt.neq(a, -pt.inf), pt.neq(b, pt.inf)), pt.log(b - a) - 2 * s - value,
-                    pt.where(pt.or_(pt.neq(a, -pt.inf), pt.neq(b, pt.inf)), value, value * 0.0))
-
-
-def normal_lcdf(mu, sigma, x):              # distributions/dist_math.py:126-133
-    z = (x - mu) / sigma
-    return pt.switch(pt.lt(z, -1.0), pt.log(pt.erfcx(-z / pt.sqrt(2.0)) / 2.0) - pt.sqr(z) / 2.0, pt.log1p(-pt.erfc(z / pt.sqrt(2.0)) / 2.0))
-
-
-def normal_lccdf(mu, sigma, x):             # distributions/dist_math.py:136-142
-    z = (x - mu) / sigma
-    return pt.switch(pt.gt(z, 1.0), pt.log(pt.erfcx(z / pt.sqrt(2.0)) / 2.0) - pt.sqr(z) / 2.0, pt.log1p(-pt.erfc(-z / pt.sqrt(2.0)) / 2.0))
-
-
-def log_diff_normal_cdf(mu, sigma, x, y):   # distributions/dist_math.py:145-183
-    x = (x - mu) / sigma / pt.sqrt(2.0)
-    y = (y - mu) / sigma / pt.sqrt(2.0)
-    return pt.log(0.5) + pt.switch(
-        pt.gt(y, 0),
-        -pt.square(y) + pt.log(pt.erfcx(y) - pt.exp(pt.square(y) - pt.square(x)) * pt.erfcx(x)),
-        pt.switch(pt.lt(x, 0), -pt.square(x) + pt.log(pt.erfcx(-x) - pt.exp(pt.square(x) - pt.square(y)) * pt.erfcx(-y)),
-                  pt.log(pt.erf(x) - pt.erf(y))))
-
-
-def truncnormal_logp(value, mu, sigma, lower, upper):   # distributions/continuous.py:720-746 (`None` = unbounded on that side)
-    lb, ub = lower is not None, upper is not None
-    if lb and ub:
-        norm = log_diff_normal_cdf(mu, sigma, upper, lower)
-    elif lb:
-        norm = normal_lccdf(mu, sigma, lower)
-    elif ub:
-        norm = normal_lcdf(mu, sigma, upper)
-    else:
-        norm = 0.0
-    logp = normal_logp(value, mu, sigma) - norm          # `_logprob_helper(Normal.dist(mu, sigma), value)`
-    if lb:
-        logp = pt.switch(value < lower, -np.inf, logp)
-    if ub:
-        logp = pt.switch(value > upper, -np.inf, logp)
-    if lb and ub:
-        logp = check_parameters(logp, pt.le(lower, upper), msg="lower_bound <= upper_bound")
-    return logp
-
-
-def bernoulli_logp(value, p):               # distributions/discrete.py:362-374
-    res = pt.switch(pt.or_(pt.lt(value, 0), pt.gt(value, 1)), -np.inf, pt.switch(value, pt.log(p), pt.log1p(-p)))
-    return check_parameters(res, 0 <= p, p <= 1, msg="0 <= p <= 1")
+def normal_lcdf(mu, sigma, x):
+    return reference()["normal_lcdf"](mu, sigma, x)
 
 
 class _RV:
-    def __init__(self, name, shape, logp_fn, params, transform=None, observed=None, bounds=None):
+    """One random variable of a `StubModel`: the reference's `Dist.dist(...)` gives the parameter list, the default transform is the
+    one the reference registers for the distribution's family, `logp` is the reference's `Dist.logp`."""
+
+    def __init__(self, name, shape, logp_fn, params, transform=None, observed=None, bounds=None, transform_obj=None):
         self.name, self.shape, self.logp_fn, self.params, self.transform, self.observed = name, tuple(shape), logp_fn, params, transform, observed
         self.bounds = bounds
+        self.rv_inputs = (None, None, *params)          # (rng, size, *dist_params): what a transform's methods receive
+        if transform is not None and transform_obj is None:
+            ref = reference()
+            transform_obj = {"log": ref["transforms"].log, "logodds": ref["transforms"].logodds}[transform]
+        self.transform_obj = transform_obj
         if observed is None:
             vname = name if transform is None else f"{name}_{transform}__"   # util.py:138-155
             self.value = Variable(None, vname, self.shape)
-            # what the rest of the graph sees in place of the RV: transform.backward(value) (logprob/transforms.py:880-891, 1026-1053, 1076-1088)
-            self.expr = {None: self.value, "log": pt.exp(self.value) if transform == "log" else None,
-                         "logodds": pt.sigmoid(self.value) if transform == "logodds" else None,
-                         "interval": interval_backward(self.value, *bounds) if transform == "interval" else None}[transform]
+            # what the rest of the graph sees in place of the RV: transform.backward(value, *rv_inputs)
+            self.expr = self.value if transform is None else transform_obj.backward(self.value, *self.rv_inputs)
         else:
             self.value, self.expr = None, TensorConstant(np.asarray(observed, dtype="float64"))
+
+
+def _dist(name, *args, **kw):
+    return reference()[name].dist(*args, **kw)
 
 
 class StubModel:
@@ -370,53 +418,64 @@ class StubModel:
         (self.free if rv.observed is None else self.obs).append(rv)
         return rv.expr
 
+    def _rv(self, cls_name, name, shape, params, transform, observed, **kw):
+        return self._add(_RV(name, shape, _ref_logp(cls_name), params, transform if observed is None else None, observed, **kw))
+
+    def _bounded(self, cls_name, name, shape, params, lower, upper):
+        ref = reference()
+        tr = ref["bounded_cont_transform"](None, None, ref[cls_name].bound_args_indices)   # continuous.py:345-347, 817-819
+        return self._add(_RV(name, shape, _ref_logp(cls_name), params, "interval", None, bounds=(float(lower), float(upper)), transform_obj=tr))
+
     def Normal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None):
-        return self._add(_RV(name, shape, normal_logp, (as_tensor(mu), as_tensor(sigma)), None, observed))
+        return self._rv("Normal", name, shape, _dist("Normal", mu=mu, sigma=sigma), None, observed)
 
     def HalfNormal(self, name, sigma=1.0, shape=()):
-        return self._add(_RV(name, shape, lambda v, s: halfnormal_logp(v, 0.0, s), (as_tensor(sigma),), "log"))
+        return self._rv("HalfNormal", name, shape, _dist("HalfNormal", sigma=sigma), "log", None)
 
     def HalfCauchy(self, name, beta=1.0, shape=()):
-        return self._add(_RV(name, shape, halfcauchy_logp, (as_tensor(beta),), "log"))
+        return self._rv("HalfCauchy", name, shape, _dist("HalfCauchy", beta=beta), "log", None)
+
+    def Cauchy(self, name, alpha=0.0, beta=1.0, shape=(), observed=None):
+        return self._rv("Cauchy", name, shape, _dist("Cauchy", alpha, beta), None, observed)
+
+    def Exponential(self, name, lam=1.0, shape=(), observed=None):
+        return self._rv("Exponential", name, shape, _dist("Exponential", lam=lam), "log", observed)
 
     def Laplace(self, name, mu=0.0, b=1.0, shape=(), observed=None):
-        return self._add(_RV(name, shape, laplace_logp, (as_tensor(mu), as_tensor(b)), None, observed))
+        return self._rv("Laplace", name, shape, _dist("Laplace", mu, b), None, observed)
 
     def LogNormal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None):
-        return self._add(_RV(name, shape, lognormal_logp, (as_tensor(mu), as_tensor(sigma)), "log" if observed is None else None, observed))
+        return self._rv("LogNormal", name, shape, _dist("LogNormal", mu=mu, sigma=sigma), "log", observed)
 
     def StudentT(self, name, nu, mu=0.0, sigma=1.0, shape=(), observed=None):
-        return self._add(_RV(name, shape, lambda v, m_, s_: studentt_logp(v, as_tensor(float(nu)), m_, s_), (as_tensor(mu), as_tensor(sigma)), None, observed))
+        return self._rv("StudentT", name, shape, _dist("StudentT", float(nu), mu=mu, sigma=sigma), None, observed)
 
     def Beta(self, name, alpha, beta, shape=()):
-        return self._add(_RV(name, shape, beta_logp, (as_tensor(float(alpha)), as_tensor(float(beta))), "logodds"))
+        return self._rv("Beta", name, shape, _dist("Beta", alpha=float(alpha), beta=float(beta)), "logodds", None)
 
     def Gamma(self, name, alpha, beta, shape=(), observed=None):
-        scale = pt.reciprocal(as_tensor(beta))       # Gamma.dist (continuous.py:2484-2492) hands `scale` to the logp
-        return self._add(_RV(name, shape, gamma_logp, (as_tensor(float(alpha)), scale), "log" if observed is None else None, observed))
+        return self._rv("Gamma", name, shape, _dist("Gamma", alpha=float(alpha), beta=beta), "log", observed)
 
     def InverseGamma(self, name, alpha, beta, shape=(), observed=None):
-        return self._add(_RV(name, shape, invgamma_logp, (as_tensor(float(alpha)), as_tensor(beta)), "log" if observed is None else None, observed))
+        return self._rv("InverseGamma", name, shape, _dist("InverseGamma", alpha=float(alpha), beta=beta), "log", observed)
 
     def Uniform(self, name, lower=0.0, upper=1.0, shape=()):
-        return self._add(_RV(name, shape, uniform_logp, (as_tensor(float(lower)), as_tensor(float(upper))), "interval", bounds=(float(lower), float(upper))))
+        return self._bounded("Uniform", name, shape, _dist("Uniform", lower=float(lower), upper=float(upper)), lower, upper)
 
     def TruncatedNormal(self, name, mu=0.0, sigma=1.0, lower=None, upper=None, shape=(), observed=None):
-        lo = None if lower is None else as_tensor(float(lower))
-        hi = None if upper is None else as_tensor(float(upper))
-        fn = lambda v, m_, s_: truncnormal_logp(v, m_, s_, lo, hi)   # noqa: E731
-        if observed is None:   # the reference's default transform of a doubly bounded distribution: interval
-            return self._add(_RV(name, shape, fn, (as_tensor(mu), as_tensor(sigma)), "interval", bounds=(float(lower), float(upper))))
-        return self._add(_RV(name, shape, fn, (as_tensor(mu), as_tensor(sigma)), None, observed))
+        params = _dist("TruncatedNormal", mu=mu, sigma=sigma, lower=None if lower is None else float(lower), upper=None if upper is None else float(upper))
+        if observed is None:   # the reference's default transform of a bounded distribution: interval over the bound arguments
+            return self._bounded("TruncatedNormal", name, shape, params, lower, upper)
+        return self._rv("TruncatedNormal", name, shape, params, None, observed)
 
     def Binomial(self, name, n, p, observed):
-        return self._add(_RV(name, np.shape(observed), binomial_logp, (as_tensor(n), as_tensor(p)), None, observed))
+        return self._rv("Binomial", name, np.shape(observed), _dist("Binomial", n, p=p), None, observed)
 
     def Poisson(self, name, mu, observed):
-        return self._add(_RV(name, np.shape(observed), poisson_logp, (as_tensor(mu),), None, observed))
+        return self._rv("Poisson", name, np.shape(observed), _dist("Poisson", mu), None, observed)
 
     def Bernoulli(self, name, logit_p, observed):
-        return self._add(_RV(name, np.shape(observed), bernoulli_logp, (pt.sigmoid(logit_p),), None, observed))   # discrete.py:351-352
+        return self._rv("Bernoulli", name, np.shape(observed), _dist("Bernoulli", logit_p=logit_p), None, observed)   # discrete.py:351-352
 
     # ---- the model protocol of `lower_to_spec` ----
     @property
@@ -444,12 +503,115 @@ class StubModel:
         out = []
         for rv in self.free + self.obs:
             lp = rv.logp_fn(rv.expr, *rv.params)
-            if rv.transform == "log":      # + log|J| = value (LogTransform.log_jac_det, transforms.py:880-891)
-                lp = lp + rv.value
-            if rv.transform == "interval":   # + log|J| (IntervalTransform.log_jac_det, transforms.py:1055-1070)
-                lp = lp + interval_log_jac_det(rv.value, *rv.bounds)
-            if rv.transform == "logodds":  # + log|J| = log sigmoid(v) + log1p(-sigmoid(v)) (LogOddsTransform, transforms.py:1076-1088)
-                sv = pt.sigmoid(rv.value)
-                lp = lp + (pt.log(sv) + pt.log1p(-sv))
+            if rv.transform is not None:     # transform_value.py:95-133: + transform.log_jac_det(value, *rv_inputs)
+                lp = lp + rv.transform_obj.log_jac_det(rv.value, *rv.rv_inputs).copy()
             out.append(lp)
         return out
+
+
+# ---------------------------------------------------------------------------
+# graphs as fixtures: what the reference's code built, written down so that it travels to boxes without /root/reference
+# (tests/golden/make_ref_graphs.py writes tests/golden/ref_graphs.npz; tests/test_lowering.py checks it is current)
+# ---------------------------------------------------------------------------
+def dump_model(m) -> dict:
+    """A `StubModel` (its value variables, transforms and `logp(sum=False)` graphs) as plain data: a node table in topological
+    order -- {"k": "in" | "const" | "op", ...} -- with arrays kept aside under "arrays"."""
+    nodes, index, arrays = [], {}, {}
+
+    def visit(v):
+        if id(v) in index:
+            return index[id(v)]
+        if getattr(v, "owner", None) is None:
+            if hasattr(v, "data"):
+                d = np.asarray(v.data)
+                if d.size <= 16:
+                    rec = {"k": "const", "data": d.astype("float64").tolist(), "dtype": str(d.dtype)}
+                else:
+                    key = f"a{len(arrays)}"
+                    arrays[key] = d
+                    rec = {"k": "const", "array": key}
+            else:
+                rec = {"k": "in", "name": v.name, "shape": list(v.type.shape)}
+        else:
+            op = v.owner.op
+            ins = [visit(i) for i in v.owner.inputs]
+            rec = {"k": "op", "op": type(op).__name__, "ins": ins, "shape": list(v.type.shape)}
+            if hasattr(op, "scalar_op"):
+                if type(op.scalar_op).__name__ == "Composite":
+                    raise TypeError("Composite nodes are not written down (they only occur in rewritten graphs)")
+                rec["scalar"] = type(op.scalar_op).__name__
+            if hasattr(op, "axis"):
+                rec["axis"] = op.axis
+            if hasattr(op, "msg"):
+                rec["msg"] = op.msg
+        index[id(v)] = len(nodes)
+        nodes.append(rec)
+        return index[id(v)]
+
+    outs = [visit(lp) for lp in m.logp(sum=False)]
+    return {
+        "nodes": nodes, "outs": outs, "arrays": arrays,
+        "value_vars": [visit(v) for v in m.value_vars], "value_shapes": {k: list(s) for k, s in m.value_shapes.items()},
+        "value_transforms": {k: list(t) for k, t in m.value_transforms.items()},
+        "logp_owners": [None if o is None else visit(o) for o in m.logp_owners], "logp_names": list(m.logp_names),
+    }
+
+
+_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector)}
+
+
+class FrozenModel:
+    """The model protocol of `lower_to_spec` over a written-down graph (`dump_model`)."""
+
+    def __init__(self, d: dict):
+        vs = []
+        for rec in d["nodes"]:
+            if rec["k"] == "in":
+                v = Variable(None, rec["name"], rec["shape"])
+            elif rec["k"] == "const":
+                v = TensorConstant(np.asarray(d["arrays"][rec["array"]]) if "array" in rec else np.asarray(rec["data"], dtype=rec["dtype"]))
+            else:
+                ins = [vs[i] for i in rec["ins"]]
+                if rec["op"] == "Elemwise":
+                    op = Elemwise(globals()[rec["scalar"]]())
+                elif rec["op"] in ("Sum", "All"):
+                    op = _OPS[rec["op"]](rec.get("axis"))
+                elif rec["op"] == "CheckParameterValue":
+                    op = CheckParameterValue(rec.get("msg", ""))
+                else:
+                    op = _OPS[rec["op"]]()
+                v = Variable(Apply(op, ins), shape=rec["shape"])
+            vs.append(v)
+        self._outs = [vs[i] for i in d["outs"]]
+        self.value_vars = [vs[i] for i in d["value_vars"]]
+        self.value_shapes = {k: tuple(s) for k, s in d["value_shapes"].items()}
+        self.value_transforms = {k: tuple(t) for k, t in d["value_transforms"].items()}
+        self.logp_owners = [None if i is None else vs[i] for i in d["logp_owners"]]
+        self.logp_names = list(d["logp_names"])
+
+    def logp(self, sum=False):
+        return list(self._outs)
+
+
+def save_models(path, models_by_name: dict):
+    import json
+
+    arrays, meta = {}, {}
+    for name, m in models_by_name.items():
+        d = dump_model(m)
+        for k, a in d.pop("arrays").items():
+            arrays[f"{name}__{k}"] = a
+        meta[name] = d
+    np.savez_compressed(path, __meta__=np.frombuffer(json.dumps(meta, sort_keys=True).encode(), dtype=np.uint8), **arrays)
+
+
+def load_models(path) -> dict:
+    import json
+
+    z = np.load(path)
+    meta = json.loads(bytes(z["__meta__"]).decode())
+    out = {}
+    for name, d in meta.items():
+        d["arrays"] = {k[len(name) + 2:]: z[k] for k in z.files if k.startswith(name + "__")}
+        out[name] = d
+    return out

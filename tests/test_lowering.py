@@ -1,7 +1,10 @@
-"""`lower_to_spec` on stub graphs that transcribe what `Model.logp(sum=False)` builds for the
-golden hierarchical Normal (pytensorf.py:514-546), eight schools (tests/test_model_graph.py:44-57) and the hierarchical
-logistic regression of the benchmark: the lowered spec must be the `ModelBuilder` spec field for field, and evaluate to the
-reference's literal -12.691227342634292 through the oracle (and, on the GPU box, through the device)."""
+"""`lower_to_spec` on the log-density graphs THE REFERENCE'S OWN CODE builds (tests/stubgraph.py loads
+`Dist.dist`, `Dist.logp`, `check_parameters`, `logpow` & co. and the value transforms from /root/reference and executes them on a
+stand-in for PyTensor's graph protocol) for the golden hierarchical Normal (pytensorf.py:514-546), eight schools
+(tests/test_model_graph.py:44-57), the hierarchical logistic regression of the benchmark and one model per distribution of the
+IR: the lowered spec must be the `ModelBuilder` spec field for field, and evaluate to the reference's literal
+-12.691227342634292 through the oracle (and, on the GPU box, through the device).  The same graphs are committed as a fixture
+(tests/golden/ref_graphs.npz) for boxes without the reference."""
 
 import os
 import sys
@@ -10,6 +13,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lowering_models as lm  # noqa: E402
 import stubgraph as sg  # noqa: E402
 
 from oracle import ref_models  # noqa: E402
@@ -105,11 +109,12 @@ def test_what_the_ir_cannot_express_is_refused_by_name():
 def test_lowered_golden_model_on_the_device():
     from pymc_amd.value_grad import DeviceValueGradFunction
 
-    f = DeviceValueGradFunction(lower_to_spec(_golden()), device=0)
+    committed = sg.load_models(lm.FIXTURE)      # the graphs the reference's code built (they travel; /root/reference does not)
+    f = DeviceValueGradFunction(lower_to_spec(sg.FrozenModel(committed["golden"])), device=0)
     lp, g = f._pytensor_function(np.array([0.0, 1.0, 0.0, 1.0, 2.0]))
     assert abs(lp - (-12.691227342634292)) < 1e-12
-    m, ref = _hier_logit(G=40, D=8, rpg=33)
-    spec = lower_to_spec(m)
+    ref = lm.ENTRIES["hier_logit_40x33"][1]()
+    spec = lower_to_spec(sg.FrozenModel(committed["hier_logit_40x33"]))
     f2 = DeviceValueGradFunction(spec, device=0)
     q = np.random.default_rng(0).normal(size=spec.n) * 0.4
     lp2, g2 = f2._pytensor_function(q)
@@ -373,3 +378,52 @@ def test_shared_variables_are_read_when_the_model_is_lowered():
     bm = b.Normal("mu", 0.0, 2.0)
     b.Normal("y", bm, sd, observed=y)
     _assert_same_spec(spec, b.build())
+
+
+
+# ---- the committed graphs (tests/golden/ref_graphs.npz, written by tests/golden/make_ref_graphs.py) ---------------------------
+@pytest.mark.parametrize("name", sorted(lm.ENTRIES))
+def test_committed_reference_graphs_lower_to_the_builder_spec(name):
+    """Runs everywhere (no /root/reference needed): every committed graph -- built by the reference's own `dist` / `logp` /
+    transform code -- lowers to the spec `ModelBuilder` assembles by hand, and both evaluate alike through the oracle."""
+    spec = lower_to_spec(sg.FrozenModel(sg.load_models(lm.FIXTURE)[name]))
+    want = lm.ENTRIES[name][1]()
+    assert [(v.name, v.value_name, tuple(v.shape), v.transform, v.offset) for v in spec.vars] == \
+        [(v.name, v.value_name, tuple(v.shape), v.transform, v.offset) for v in want.vars]
+    assert len(spec.factors) == len(want.factors) and [(f.dist, f.size, f.name) for f in spec.factors] == [(f.dist, f.size, f.name) for f in want.factors]
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        q = rng.normal(size=spec.n) * 0.5
+        lp, g = ref_models.evaluate(spec, q)
+        lp0, g0 = ref_models.evaluate(want, q)
+        assert np.isfinite(lp0) and abs(lp - lp0) <= 1e-12 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-12 * max(1.0, np.max(np.abs(g0)))
+
+
+def test_committed_reference_graphs_are_current():
+    """Where the reference exists: re-run its code and compare with the fixture node for node (op names, constants, wiring)."""
+    if not sg.available():
+        pytest.skip("needs /root/reference")
+    committed = sg.load_models(lm.FIXTURE)
+    assert sorted(committed) == sorted(lm.ENTRIES)
+    for name, (make, _) in lm.ENTRIES.items():
+        now = sg.dump_model(make())
+        arrays_now, arrays_then = now.pop("arrays"), committed[name].pop("arrays")
+        import json
+
+        assert json.loads(json.dumps(now)) == committed[name], name
+        assert sorted(arrays_now) == sorted(arrays_then) and all(np.array_equal(arrays_now[k], arrays_then[k]) for k in arrays_now), name
+
+
+def test_the_graphs_come_from_the_references_source_lines():
+    """The loader compiles the reference's own source segments: the code objects of the loaded functions carry the reference's file
+    and line, and the module holds no transcription of a `logp` body."""
+    if not sg.available():
+        pytest.skip("needs /root/reference")
+    ref = sg.reference()
+    for name, rel in (("Normal", "distributions/continuous.py"), ("Gamma", "distributions/continuous.py"), ("Bernoulli", "distributions/discrete.py")):
+        code = ref[name].logp.__code__
+        assert code.co_filename.startswith(f"<reference {rel}:")
+    assert ref["check_parameters"].__code__.co_filename.startswith("<reference distributions/dist_math.py:")
+    assert ref["IntervalTransform"].backward.__code__.co_filename.startswith("<reference logprob/transforms.py:")
+    src = open(sg.__file__).read()
+    assert "def normal_logp(value, mu, sigma)" not in src and "pt.log(pt.sqrt(2.0 * np.pi))" not in src
