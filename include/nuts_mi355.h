@@ -373,6 +373,23 @@ int nuts_gibbs_sweep(nuts_gibbs *g, int32_t *c, const double *log_w, const doubl
                      const int32_t *order, const int32_t *cand_raw, const double *log_u, int64_t *n_accepted,
                      int64_t *n_nonfinite, double *cnt, double *s1, double *s2);
 
+/* `proposal="proportional"` (`astep_prop` / `metropolis_proportional`, metropolis.py:788-826): per element the conditional
+ * probabilities of ALL K categories (softmax of the log-densities, scipy.special.softmax's arithmetic, NumPy's pairwise sum), the
+ * current one zeroed and the rest renormalised, one category drawn with `rng.choice(K, p=probs)` (NumPy: cumulative sums divided
+ * by the last one, `searchsorted(..., side="right")` of ONE `random()`), accepted with probability (1 - p_cur) / (1 - p_prop)
+ * against ONE `uniform()` -- which the reference draws only when that ratio is finite (short-circuit `or`).
+ * `nuts_gibbs_plan_doubles` replays the shuffle from the PCG64 state (left AFTER the shuffle) and returns the next `n_doubles`
+ * doubles of the stream without consuming them; the caller hands element t the doubles at the stream positions the sequential
+ * loop would have reached (2 t when every ratio so far was finite), `nuts_gibbs_sweep_prop` reports per element whether the
+ * ratio was finite (flags [n], plan order), and the caller advances the generator by the doubles really consumed
+ * (`bit_generator.advance`).  c_in is not modified: the sweep can be re-evaluated with corrected positions. */
+int nuts_gibbs_plan_doubles(nuts_pcg64 *rng, int64_t n, int32_t shuffle, int32_t *order /* [n] in/out */, int64_t n_doubles,
+                            double *out /* [n_doubles] */);
+int nuts_gibbs_sweep_prop(nuts_gibbs *g, const int32_t *c_in, int32_t *c_out, const double *log_w, const double *mu,
+                          const double *sigma, const int32_t *order, const double *u_choice /* [n] */,
+                          const double *u_accept /* [n] */, int8_t *finite_flags /* [n] */, int64_t *n_accepted, double *cnt,
+                          double *s1, double *s2);
+
 /* ---- full-rank minibatch ADVI on a GLM (BASELINE configs[3]) ---------------------------------------
  * Replaces the compiled step function of `pm.fit(method="fullrank_advi")` (pymc/variational/opvi.py:318-404 over
  * `FullRankGroup`, variational/approximations.py:118-188, `KL`, variational/operators.py:64-65, `adagrad_window`,
@@ -385,6 +402,10 @@ typedef struct {
   double sigma, prior_sd, learning_rate, epsilon;
   const double *X, *y;
   const double *start; /* [P] initial mean (NULL: zeros); L_tril starts as eye(P)[tril] (approximations.py:138-141) */
+  /* opvi.py:1264, 1306-1332 `Approximation.scale_cost_to_minibatch` (the reference's default: 1): every term of the objective --
+   * hence the loss and both gradients -- is divided by the normalising constant N / batch */
+  int32_t scale_cost_to_minibatch;
+  int32_t reserved0;
 } nuts_advi_config;
 typedef struct nuts_advi nuts_advi;
 nuts_advi *nuts_advi_create(const nuts_advi_config *cfg);

@@ -1,8 +1,11 @@
 """CPU oracle of full-rank minibatch ADVI on a GLM (TEST INFRASTRUCTURE; see oracle/__init__.py).
 
-PARITY UNPINNED against an execution of the reference: `pymc.variational` is PyTensor code (symbolic graphs, `pytensor.grad`,
-compiled `updates`), which cannot run here, and the reference holds no golden vectors for it (its tests are statistical:
-tests/variational/test_inference.py).  What this file restates, formula by formula:
+Pinned by EXECUTING the reference: tests/golden/refrun_advi.py loads `FullRankGroup`, the normalised terms of `Group` /
+`Approximation`, `KL.apply`, `get_scaling`, `adagrad_window`, `rho2sigma` and the distributions' `logp` bodies from the reference
+checkout and runs them eagerly on torch float64 tensors (`pytensor.grad` = torch autograd); a step of this file must reproduce
+the loss, both gradients, both parameters and both adagrad rings of that execution to 1e-13, step after step through a wrap of
+the window (tests/test_advi.py, committed fixture tests/golden/advi_reference_steps.npz).  That execution is what showed the
+normalising constant missing here in round 2 (`scale_cost_to_minibatch`, below).  What this file restates, formula by formula:
 
   * `FullRankGroup` (variational/approximations.py:118-188): parameters mu [d] and L_tril [d (d + 1) / 2] in `np.tril_indices`
     order, initialised to `start` and `eye(d)[tril]`; the diagonal of L goes through `rho2sigma` = softplus (`L`, :141-147);
@@ -11,8 +14,10 @@ tests/variational/test_inference.py).  What this file restates, formula by formu
   * `MinibatchRandomVariable` logp (variational/minibatch_rv.py:87-106): the likelihood of the B drawn rows times N / B.
   * `adagrad_window` (variational/updates.py:542-585): per-parameter window of the last `n_win` squared gradients.
 
-and what pins it instead: the gradient against torch float64 autograd of the same loss, and the closed-form Gaussian posterior
-of the linear-Gaussian GLM that the fit must converge to (tests/test_advi.py).  The random inputs of a step (minibatch row
+  * `symbolic_normalizing_constant` (variational/opvi.py:1314-1332) with `scale_cost_to_minibatch` on: every term divided by N / B.
+
+Also checked: the gradient against torch float64 autograd of the same loss, and the closed-form Gaussian posterior of the
+linear-Gaussian GLM that the fit must converge to (tests/test_advi.py).  The random inputs of a step (minibatch row
 indices, z0) are ARGUMENTS here: the reference draws them with PyTensor RNG ops whose streams are not reproducible outside it.
 """
 
@@ -73,15 +78,21 @@ class GLM:
         return np.sum(-0.5 * z * z - np.log(self.prior_sd) - 0.5 * np.log(2 * np.pi)), -z / self.prior_sd
 
 
-def advi_step(glm: GLM, st: FullRankState, idx, z0, learning_rate=0.001, epsilon=0.1, n_win=10):
-    """One call of the compiled step function (opvi.py:318-404): returns the loss; updates `st` in place."""
+def advi_step(glm: GLM, st: FullRankState, idx, z0, learning_rate=0.001, epsilon=0.1, n_win=10, scale_cost_to_minibatch=True):
+    """One call of the compiled step function (opvi.py:318-404): returns the loss; updates `st` in place.
+
+    `scale_cost_to_minibatch` (opvi.py:1264, default on in the reference): every term of the objective is divided by the
+    normalising constant = the largest minibatch scaling N / B (`symbolic_normalizing_constant`, opvi.py:1314-1332;
+    `datalogp_norm`, `varlogp_norm`, `logq_norm`, :1344-1421) -- the loss is on the scale of ONE minibatch, and so are the
+    gradients adagrad_window sees (its epsilon is not scale free, so this changes the path of the fit)."""
     L = st.L()
     z = z0 @ L.T + st.mu                                              # approximations.py:184-188
     dlp, dg = glm.datalogp_grad(z, idx)
     vlp, vg = glm.varlogp_grad(z)
     diag = np.diag(L)
     logq = np.sum(-0.5 * z0**2 - np.log(np.sqrt(2 * np.pi))) - np.sum(np.log(diag))
-    loss = -dlp + (logq - vlp)                                        # operators.py:64-65
+    nc = (glm.N / len(idx)) if scale_cost_to_minibatch else 1.0       # opvi.py:1314-1332
+    loss = -(dlp / nc) + (logq / nc - vlp / nc)                       # operators.py:64-65 on the normalised terms
     g = dg + vg                                                       # d logp / dz
     grad_mu = -g
     GL = -np.outer(g, z0)                                             # d loss / dL (lower triangle used)
@@ -91,6 +102,8 @@ def advi_step(glm: GLM, st: FullRankState, idx, z0, learning_rate=0.001, epsilon
     rho = st.L_tril[[i * (i + 1) // 2 + i for i in range(st.d)]]
     dpos = np.array([i * (i + 1) // 2 + i for i in range(st.d)])
     grad_tril[dpos] *= sigmoid(rho)                                   # through rho2sigma
+    grad_mu = grad_mu / nc
+    grad_tril = grad_tril / nc
     # adagrad_window (updates.py:571-584)
     if st.acc_mu.shape[1] != n_win:
         st.acc_mu = np.zeros((st.d, n_win))

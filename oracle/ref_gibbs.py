@@ -1,6 +1,6 @@
-"""CPU oracle of `CategoricalGibbsMetropolis.astep_unif` for mixture assignments (TEST INFRASTRUCTURE; see oracle/__init__.py).
+"""CPU oracle of `CategoricalGibbsMetropolis.astep_unif` / `astep_prop` for mixture assignments (TEST INFRASTRUCTURE; see oracle/__init__.py).
 
-A restatement of pymc/step_methods/metropolis.py:761-786 with `sample_except` (:1225-1229) and `metrop_select`
+A restatement of pymc/step_methods/metropolis.py:761-786 (uniform proposal) and :788-826 (proportional proposal) with `sample_except` (:1225-1229) and `metrop_select`
 (pymc/step_methods/arraystep.py:208-235): the same calls on the same NumPy generator in the same order, one element at a
 time.  The only liberty: the full-model log-density difference `logp(q') - logp(q)` is evaluated as the difference of the two
 terms that change (the model is a sum over observations), which the reference obtains by evaluating the full model twice.
@@ -51,4 +51,28 @@ class RefCategoricalGibbs:
             if np.isfinite(mr) and np.log(self.rng.uniform()) < mr:   # metrop_select
                 c[dim] = cand
                 accepted += 1
+        return c, accepted
+
+    def sweep_prop(self, c, mu):
+        """metropolis.py:788-826 (`astep_prop` + `metropolis_proportional`).  The reference takes the softmax of FULL-model
+        log-densities; the terms shared by all categories cancel in it, so the per-element terms are used here (same liberty as
+        above)."""
+        from scipy import special
+
+        c = np.array(c, copy=True)
+        if self.shuffle_dims:
+            self.rng.shuffle(self.dimcats)
+        accepted = 0
+        for dim, k in self.dimcats:
+            given = int(c[dim])
+            log_probs = np.array([self._term(dim, j, mu) for j in range(k)])
+            probs = special.softmax(log_probs, axis=0)
+            prob_curr, probs[given] = probs[given], 0.0
+            probs /= 1.0 - prob_curr
+            proposed = self.rng.choice(list(range(k)), p=probs)
+            accept_ratio = (1.0 - prob_curr) / (1.0 - probs[proposed])
+            if not np.isfinite(accept_ratio) or self.rng.uniform() >= accept_ratio:
+                continue
+            c[dim] = proposed
+            accepted += 1
         return c, accepted

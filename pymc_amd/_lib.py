@@ -167,7 +167,8 @@ class Pcg64(C.Structure):
 class AdviConfig(C.Structure):
     _fields_ = [("N", C.c_int64), ("P", C.c_int32), ("family", C.c_int32), ("batch", C.c_int32), ("n_win", C.c_int32),
                 ("sigma", C.c_double), ("prior_sd", C.c_double), ("learning_rate", C.c_double), ("epsilon", C.c_double),
-                ("X", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)), ("start", C.POINTER(C.c_double))]
+                ("X", C.POINTER(C.c_double)), ("y", C.POINTER(C.c_double)), ("start", C.POINTER(C.c_double)),
+                ("scale_cost_to_minibatch", C.c_int32), ("reserved0", C.c_int32)]
 
 
 _PD = C.POINTER(C.c_double)
@@ -218,6 +219,8 @@ SYMBOLS = {
     "nuts_gibbs_create": (_VP, [C.c_int64, C.c_int32, _PD]),
     "nuts_gibbs_destroy": (None, [_VP]),
     "nuts_gibbs_sweep": (C.c_int, [_VP, _VP, _PD, _PD, _PD, _VP, _VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _PD, _PD, _PD]),
+    "nuts_gibbs_plan_doubles": (C.c_int, [C.POINTER(Pcg64), C.c_int64, C.c_int32, _VP, C.c_int64, _PD]),
+    "nuts_gibbs_sweep_prop": (C.c_int, [_VP, _VP, _VP, _PD, _PD, _PD, _VP, _PD, _PD, _VP, C.POINTER(C.c_int64), _PD, _PD, _PD]),
     "nuts_advi_create": (_VP, [C.POINTER(AdviConfig)]),
     "nuts_advi_destroy": (None, [_VP]),
     "nuts_advi_steps": (C.c_int, [_VP, C.c_int32, _VP, _PD, _PD]),

@@ -3,7 +3,8 @@
 // One optimisation step of the reference is one call of a compiled function with `updates` and no inputs
 // (`ObjectiveFunction.step_function`, pymc/variational/opvi.py:318-404): draw a minibatch (pymc/data.py:121-161) and z0, form
 // z = z0 L^T + mu (`FullRankGroup`, variational/approximations.py:118-188), evaluate KL's single-sample estimate
-// -datalogp (N / B) + logq - varlogp (variational/operators.py:64-65, minibatch_rv.py:87-106), back-propagate to (mu, L_tril)
+// (-datalogp (N / B) + logq - varlogp) / nc (variational/operators.py:64-65 on the normalised terms of opvi.py:1314-1421: nc = N / B
+// unless scale_cost_to_minibatch is off; minibatch_rv.py:87-106), back-propagate to (mu, L_tril)
 // and apply `adagrad_window` (variational/updates.py:542-585).  Here a step is TWO launches with nothing returning to the
 // host (the loss history stays in a device buffer until the caller asks for it):
 //
@@ -32,6 +33,7 @@ struct AdviDev {
   int64_t N;
   int P, family, B, n_win;
   double sigma, prior_sd, lr, eps;
+  double nc;         // normalising constant of the objective: N / B with scale_cost_to_minibatch (opvi.py:1264, 1314-1332), else 1
   const double* X;   // [N][P]
   const double* y;   // [N]
   double* mu;        // [P]
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void k_advi_row_update(AdviDev a, const double
   // ---- (2) mu ----
   if (tid < 2 && (tid == 0 || two)) {
     const int i = rows[tid];
-    const double grad = -G[tid];
+    const double grad = -G[tid] / a.nc;                       // every term of the objective is divided by nc (opvi.py:1344-1421)
     a.acc_mu[(int64_t)slot * P + i] = grad * grad;            // adagrad_window (updates.py:571-584)
     const double mu_new = mu_old - a.lr * grad / sqrt((mu_so + grad * grad) + a.eps);
     a.mu[i] = mu_new;
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void k_advi_row_update(AdviDev a, const double
       const int64_t u = base + j;
       double grad = -G[r] * z0v[r][e];
       if (j == i) grad = (grad - 1.0 / dci) * sigmoid_d(pv[r][e]);   // entropy term, then through rho2sigma
+      grad /= a.nc;
       a.acc_L[(int64_t)slot * T + u] = grad * grad;
       const double nv = pv[r][e] - a.lr * grad / sqrt((so[r][e] + grad * grad) + a.eps);
       a.Lt[u] = nv;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_advi_row_update(AdviDev a, const double
       qn[i] = (-0.5 * zi * zi - 0.91893853320467274178) - log(d_new);   // approximations.py:175-182
     }
   }
-  if (blockIdx.x == 0) {   // the loss of this step: -datalogp + (logq - varlogp)   (operators.py:64-65)
+  if (blockIdx.x == 0) {   // the loss of this step: -datalogp_norm + (logq_norm - varlogp_norm)   (operators.py:64-65)
     double red[3] = {0.0, 0.0, 0.0};
     for (int j = tid; j < P; j += 256) {
       const double zz = zc[j] / a.prior_sd;
@@ -240,6 +243,6 @@ __global__ __launch_bounds__(256) void k_advi_row_update(AdviDev a, const double
     for (int wg = tid; wg < a.nwg; wg += 256) red[2] += a.llpart[wg];
     __shared__ double sm3[256 / WAVE][3];
     block_sum_n<3>(red, sm3);
-    if (tid == 0) a.hist[step] = -scale * red[2] + (red[1] - red[0]);
+    if (tid == 0) a.hist[step] = -((scale * red[2]) / a.nc) + (red[1] / a.nc - red[0] / a.nc);
   }
 }

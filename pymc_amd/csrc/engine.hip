@@ -2357,6 +2357,26 @@ extern "C" int nuts_gibbs_plan(nuts_pcg64* rng, int64_t n, int32_t shuffle, int3
   return NUTS_OK;
 }
 
+extern "C" int nuts_gibbs_plan_doubles(nuts_pcg64* rng, int64_t n, int32_t shuffle, int32_t* order, int64_t n_doubles, double* out) {
+  if (!rng || !order || (n_doubles > 0 && !out) || n < 0 || n_doubles < 0) { g_err = "null argument"; return NUTS_E_ARG; }
+  Pcg64Replay r;
+  r.state = ((unsigned __int128)rng->state_hi << 64) | rng->state_lo;
+  r.inc = ((unsigned __int128)rng->inc_hi << 64) | rng->inc_lo;
+  r.has_uint32 = rng->has_uint32; r.uinteger = rng->uinteger;
+  if (shuffle) {
+    for (int64_t i = n - 1; i >= 1; --i) {
+      const int64_t j = (int64_t)r.interval((uint64_t)i);
+      std::swap(order[i], order[j]);
+    }
+  }
+  // the generator is handed back as it stands AFTER the shuffle: the doubles are looked at, not consumed (a double never touches
+  // the buffered 32-bit half, so the caller's `advance(k)` lands exactly where k `random()` calls would)
+  rng->state_hi = (uint64_t)(r.state >> 64); rng->state_lo = (uint64_t)r.state;
+  rng->has_uint32 = r.has_uint32; rng->uinteger = r.uinteger;
+  for (int64_t t = 0; t < n_doubles; ++t) out[t] = r.next_double();
+  return NUTS_OK;
+}
+
 #define GIBBS_BLOCK 256
 #define GIBBS_MAXK 32
 // one thread per position of the plan; per-workgroup sufficient statistics in fixed order (wave sums, waves in order)
@@ -2413,6 +2433,7 @@ struct nuts_gibbs {
   hipStream_t stream = nullptr;
   double *y = nullptr, *par = nullptr, *logu = nullptr, *part = nullptr;
   int32_t *c = nullptr, *order = nullptr, *cand = nullptr;
+  int32_t* c2 = nullptr; double* u2 = nullptr; int8_t* flags = nullptr;   // proposal="proportional": output assignment, second uniform, finite flags
   std::vector<double> part_host;
 };
 
@@ -2439,7 +2460,8 @@ extern "C" nuts_gibbs* nuts_gibbs_create(int64_t n, int32_t K, const double* y) 
 extern "C" void nuts_gibbs_destroy(nuts_gibbs* g) {
   if (!g) return;
   if (g->stream) hipStreamSynchronize(g->stream);
-  for (void* p : {(void*)g->y, (void*)g->par, (void*)g->logu, (void*)g->part, (void*)g->c, (void*)g->order, (void*)g->cand}) if (p) hipFree(p);
+  for (void* p : {(void*)g->y, (void*)g->par, (void*)g->logu, (void*)g->part, (void*)g->c, (void*)g->order, (void*)g->cand, (void*)g->c2, (void*)g->u2,
+                  (void*)g->flags}) if (p) hipFree(p);
   if (g->stream) hipStreamDestroy(g->stream);
   delete g;
 }
@@ -2477,6 +2499,131 @@ extern "C" int nuts_gibbs_sweep(nuts_gibbs* g, int32_t* c, const double* log_w, 
 }
 
 
+// NumPy's float64 `add.reduce` over a short contiguous vector (numpy/_core/src/umath/loops_utils.h.src, pairwise sum): fewer than 8
+// elements are added in order; up to 128 go through eight running sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the
+// remainder is added in order.  K <= 32 here, so the recursive split above 128 never happens.
+__device__ __forceinline__ double np_sum_k(const double* a, int n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+
+// `metropolis_proportional` (metropolis.py:803-826) for every element at once; one thread per position of the plan
+__global__ __launch_bounds__(GIBBS_BLOCK) void k_gibbs_sweep_prop(int64_t n, int K, const double* __restrict__ y, const int32_t* __restrict__ c_in,
+                                                                 int32_t* __restrict__ c_out, const double* __restrict__ par,
+                                                                 const int32_t* __restrict__ order, const double* __restrict__ u_choice,
+                                                                 const double* __restrict__ u_accept, int8_t* __restrict__ fin_flags,
+                                                                 double* __restrict__ part /* [nblk][3 K + 2] */) {
+  __shared__ double s_par[3 * GIBBS_MAXK];
+  __shared__ double s_w[GIBBS_BLOCK / WAVE][3 * GIBBS_MAXK + 2];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
+  for (int i = tid; i < 3 * K; i += GIBBS_BLOCK) s_par[i] = par[i];
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * GIBBS_BLOCK + tid;
+  int knew = -1;
+  double yi = 0.0, acc = 0.0;
+  if (t < n) {
+    const int dim = order[t];
+    const int cur = c_in[dim];
+    yi = y[dim];
+    double p[GIBBS_MAXK];
+    double mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {          // log w_k + log Normal(y | mu_k, sigma_k) up to the constant every category shares
+      const double sg = s_par[2 * K + k], z = (yi - s_par[K + k]) / sg;
+      p[k] = s_par[k] - log(sg) - 0.5 * z * z;
+      mx = fmax(mx, p[k]);
+    }
+    for (int k = 0; k < K; ++k) p[k] = exp(p[k] - mx);       // scipy.special.softmax: exp(x - max) / sum(exp(x - max))
+    const double tot = np_sum_k(p, K);
+    for (int k = 0; k < K; ++k) p[k] = p[k] / tot;
+    const double prob_curr = p[cur];
+    p[cur] = 0.0;
+    const double rem = 1.0 - prob_curr;
+    for (int k = 0; k < K; ++k) p[k] = p[k] / rem;           // probs /= 1.0 - prob_curr
+    // Generator.choice(K, p=probs): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side="right")
+    double cdf[GIBBS_MAXK];
+    double run = 0.0;
+    for (int k = 0; k < K; ++k) { run = (k == 0) ? p[0] : run + p[k]; cdf[k] = run; }
+    const double last = cdf[K - 1];
+    const double u = u_choice[t];
+    int prop = 0;
+    for (int k = 0; k < K; ++k) prop += (cdf[k] / last <= u) ? 1 : 0;
+    if (prop > K - 1) prop = K - 1;
+    const double ratio = rem / (1.0 - p[prop]);              // (1 - prob_curr) / (1 - probs[proposed])
+    const bool fin = isfinite(ratio);
+    const bool ok = fin && !(u_accept[t] >= ratio);          // `not isfinite(r) or uniform() >= r` -> stay
+    knew = ok ? prop : cur;
+    c_out[dim] = knew;
+    fin_flags[t] = fin ? 1 : 0;
+    acc = ok ? 1.0 : 0.0;
+  }
+  for (int k = 0; k < K; ++k) {
+    const bool m = knew == k;
+    const double a = wave_sum(m ? 1.0 : 0.0), b = wave_sum(m ? yi : 0.0), d2 = wave_sum(m ? yi * yi : 0.0);
+    if (lane == 0) { s_w[w][k] = a; s_w[w][K + k] = b; s_w[w][2 * K + k] = d2; }
+  }
+  {
+    const double a = wave_sum(acc);
+    if (lane == 0) { s_w[w][3 * K] = a; s_w[w][3 * K + 1] = 0.0; }
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * K + 2; i += GIBBS_BLOCK) {
+    double sum = 0.0;
+    for (int ww = 0; ww < GIBBS_BLOCK / WAVE; ++ww) sum += s_w[ww][i];
+    part[(int64_t)blockIdx.x * (3 * K + 2) + i] = sum;
+  }
+}
+
+extern "C" int nuts_gibbs_sweep_prop(nuts_gibbs* g, const int32_t* c_in, int32_t* c_out, const double* log_w, const double* mu, const double* sigma,
+                                     const int32_t* order, const double* u_choice, const double* u_accept, int8_t* finite_flags,
+                                     int64_t* n_accepted, double* cnt, double* s1, double* s2) {
+  if (!g || !c_in || !c_out || !log_w || !mu || !sigma || !order || !u_choice || !u_accept || !finite_flags || !cnt || !s1 || !s2) {
+    g_err = "null argument"; return NUTS_E_ARG;
+  }
+  const int K = g->K;
+  const size_t n = (size_t)g->n;
+  hipStream_t s = g->stream;
+  if (!g->c2) {
+    g->c2 = dev_alloc<int32_t>(n); g->u2 = dev_alloc<double>(n); g->flags = (int8_t*)dev_alloc<int32_t>((n + 3) / 4);
+    if (!g->c2 || !g->u2 || !g->flags) { g_err = "device allocation failed"; return NUTS_E_HIP; }
+  }
+  std::vector<double> par(3 * (size_t)K);
+  for (int k = 0; k < K; ++k) { par[k] = log_w[k]; par[K + k] = mu[k]; par[2 * K + k] = sigma[k]; }
+  HIPCHK(hipMemcpyAsync(g->par, par.data(), par.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->c, c_in, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->c2, c_in, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->order, order, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->logu, u_choice, n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(g->u2, u_accept, n * sizeof(double), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_gibbs_sweep_prop, dim3(g->nblk), dim3(GIBBS_BLOCK), 0, s, g->n, K, g->y, g->c, g->c2, g->par, g->order, g->logu, g->u2, g->flags, g->part);
+  HIPCHK(hipMemcpyAsync(c_out, g->c2, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(finite_flags, g->flags, n * sizeof(int8_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g->part_host.data(), g->part, g->part_host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  const int stride = 3 * K + 2;
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) { cnt[k] = s1[k] = s2[k] = 0.0; }
+  for (int b = 0; b < g->nblk; ++b) {   // workgroups in order
+    const double* p = g->part_host.data() + (size_t)b * stride;
+    for (int k = 0; k < K; ++k) { cnt[k] += p[k]; s1[k] += p[K + k]; s2[k] += p[2 * K + k]; }
+    acc += p[3 * K];
+  }
+  if (n_accepted) *n_accepted = (int64_t)acc;
+  return NUTS_OK;
+}
+
+
 // ===========================================================================
 // full-rank minibatch ADVI on a GLM (include/nuts_mi355.h, csrc/advi.h)
 // ===========================================================================
@@ -2505,6 +2652,7 @@ extern "C" nuts_advi* nuts_advi_create(const nuts_advi_config* c) {
   HIPCHK_NULL(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
   d.N = c->N; d.P = c->P; d.family = c->family; d.B = c->batch; d.n_win = c->n_win;
   d.sigma = c->sigma; d.prior_sd = c->prior_sd; d.lr = c->learning_rate; d.eps = c->epsilon;
+  d.nc = c->scale_cost_to_minibatch ? (double)c->N / (double)c->batch : 1.0;   // opvi.py:1314-1332
   const int P = d.P;
   const size_t T = (size_t)P * (P + 1) / 2;
   d.X = a->keep(dev_upload(c->X, (size_t)c->N * P));

@@ -189,10 +189,9 @@ class CategoricalGibbsMetropolis:
             dimcats = [dimcats[j] for j in order]
         self._order = np.array([d for d, _ in dimcats], dtype="int32")
         self._k_of_dim = np.full(n, K, dtype="int32")
-        if proposal == "proportional":
-            raise NotImplementedError("the `proportional` proposal (metropolis.py:788-826) is not replayed on the device; use proposal='uniform'")
-        if proposal != "uniform":
+        if proposal not in ("uniform", "proportional"):     # metropolis.py:744-749
             raise ValueError("Argument 'proposal' should either be 'uniform' or 'proportional'")
+        self.proposal = proposal
         self.rng = get_random_generator(rng)
         self.tune = True
         self._device = device
@@ -260,8 +259,58 @@ class CategoricalGibbsMetropolis:
                 raise _lib.EngineError(f"nuts_gibbs_create failed: {_lib.last_error()}")
         return self._handle
 
+    def _step_proportional(self, point):
+        """`astep_prop` / `metropolis_proportional` (metropolis.py:788-826).  What an element draws: one `random()` inside
+        `rng.choice(K, p=probs)`, then one `uniform()` -- but only if its acceptance ratio is finite (short-circuit `or`).  Element t's
+        doubles therefore sit at stream position t + (number of finite ratios before it).  The sweep is evaluated for all elements
+        at once under the assumption "every ratio is finite" (true for any mixture whose components overlap); the device reports
+        which were not, the positions are corrected and the sweep re-evaluated until the flags reproduce themselves -- every element
+        before the first wrong flag is already final, so each pass fixes at least one more."""
+        link = self.link
+        lib = _lib.load()
+        c_in = np.ascontiguousarray(point[link.name], dtype="int32")
+        mu = np.ascontiguousarray(point[link.mu_name], dtype="float64")
+        n, K = len(c_in), link.K
+        p = _pcg_to_c(self.rng)
+        pool = np.empty(2 * n + 2)
+        _lib.check(lib.nuts_gibbs_plan_doubles(C.byref(p), n, int(self.shuffle_dims), self._order.ctypes.data, len(pool), _lib.dptr(pool)), "nuts_gibbs_plan_doubles")
+        _pcg_from_c(self.rng, p)                       # the generator as it stands after the shuffle
+        lw, sg = np.ascontiguousarray(link.log_w, dtype="float64"), np.ascontiguousarray(link.sigma, dtype="float64")
+        cnt, s1, s2 = np.empty(K), np.empty(K), np.empty(K)
+        nacc = C.c_int64(0)
+        flags = np.ones(n, dtype="int8")
+        c_out = np.empty(n, dtype="int32")
+        new_flags = np.empty(n, dtype="int8")
+        for sweep_pass in range(self.max_prop_passes):
+            pos = np.arange(n, dtype=np.int64)
+            pos[1:] += np.cumsum(flags[:-1], dtype=np.int64)
+            u1, u2 = np.ascontiguousarray(pool[pos]), np.ascontiguousarray(pool[pos + 1])
+            rc = lib.nuts_gibbs_sweep_prop(self._engine(), c_in.ctypes.data, c_out.ctypes.data, _lib.dptr(lw), _lib.dptr(mu), _lib.dptr(sg),
+                                           self._order.ctypes.data, _lib.dptr(u1), _lib.dptr(u2), new_flags.ctypes.data, C.byref(nacc),
+                                           _lib.dptr(cnt), _lib.dptr(s1), _lib.dptr(s2))
+            _lib.check(rc, "nuts_gibbs_sweep_prop")
+            if np.array_equal(new_flags, flags):
+                break
+            flags, new_flags = new_flags, flags
+        else:
+            raise _lib.EngineError(f"proposal='proportional': the positions of the uniform stream did not settle in {self.max_prop_passes} passes "
+                                   "(many acceptance ratios are not finite: components that do not overlap); use proposal='uniform'")
+        self.prop_passes_last = sweep_pass + 1
+        self.rng.bit_generator.advance(int(n + int(flags.sum(dtype=np.int64))))     # the doubles the sequential loop would have consumed
+        self.accepted_last = int(nacc.value)
+        new_c = np.ascontiguousarray(c_out.astype(np.asarray(point[link.name]).dtype, copy=False))
+        link.remember(new_c, (cnt, s1, s2))
+        new_point = dict(point)
+        new_point[link.name] = new_c
+        return new_point, [{}]
+
+    max_prop_passes = 64
+    prop_passes_last = 0
+
     def step(self, point):
-        """`ArrayStep.step` (arraystep.py:64-80) + `astep_unif` (metropolis.py:761-786)."""
+        """`ArrayStep.step` (arraystep.py:64-80) + `astep_unif` (metropolis.py:761-786) / `astep_prop` (:788-826)."""
+        if getattr(self, "proposal", "uniform") == "proportional":
+            return self._step_proportional(point)
         link = self.link
         c = np.ascontiguousarray(point[link.name], dtype="int32").copy()
         mu = np.ascontiguousarray(point[link.mu_name], dtype="float64")

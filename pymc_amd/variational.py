@@ -114,7 +114,8 @@ class FullRankApproximation:
 class FullRankADVI:
     """variational/inference.py:497-524."""
 
-    def __init__(self, model: GLMSpec = None, random_seed=None, start=None, start_sigma=None, device: Optional[int] = None):
+    def __init__(self, model: GLMSpec = None, random_seed=None, start=None, start_sigma=None, device: Optional[int] = None,
+                 scale_cost_to_minibatch: bool = True):
         if not isinstance(model, GLMSpec):
             raise TypeError("model must be a pymc_amd.variational.GLMSpec")
         if start_sigma is not None:
@@ -126,6 +127,9 @@ class FullRankADVI:
         self._device = device
         self._handle = None
         self._opt = None
+        # `Approximation.scale_cost_to_minibatch` (opvi.py:1264, 1306-1332; on by default in the reference): the objective is
+        # divided by the normalising constant N / batch.  Fixed when the engine is created, as the reference compiles it in.
+        self.scale_cost_to_minibatch = bool(scale_cost_to_minibatch)
         self.approx = FullRankApproximation(self)
 
     def _engine(self, opt: _AdagradWindow):
@@ -146,6 +150,7 @@ class FullRankADVI:
         cfg.sigma, cfg.prior_sd, cfg.learning_rate, cfg.epsilon = float(m.sigma), float(m.prior_sd), float(opt.learning_rate), float(opt.epsilon)
         cfg.X, cfg.y = _lib.dptr(X), _lib.dptr(y)
         cfg.start = _lib.dptr(self._start) if self._start is not None else None
+        cfg.scale_cost_to_minibatch = int(self.scale_cost_to_minibatch)
         self._handle = lib.nuts_advi_create(C.byref(cfg))
         if not self._handle:
             raise _lib.EngineError(f"nuts_advi_create failed: {_lib.last_error()}")

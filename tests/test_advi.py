@@ -2,6 +2,9 @@
 function against the oracle on identical random inputs, and the fit against the closed-form posterior of the linear-Gaussian
 GLM (GPU)."""
 
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -42,12 +45,47 @@ def test_oracle_gradient_matches_autograd(family):
     ll = (-0.5 * ((yb - eta) / m.sigma) ** 2 - np.log(m.sigma) - 0.5 * np.log(2 * np.pi)).sum() if family == "normal" else (yb * eta - torch.nn.functional.softplus(eta)).sum()
     vlp = (-0.5 * (z / m.prior_sd) ** 2 - np.log(m.prior_sd) - 0.5 * np.log(2 * np.pi)).sum()
     logq = (-0.5 * torch.tensor(z0) ** 2 - np.log(np.sqrt(2 * np.pi))).sum() - torch.log(Ld).sum()
-    loss = -ll * N / 48 + (logq - vlp)
+    loss = (-ll * N / 48 + (logq - vlp)) / (N / 48)      # scale_cost_to_minibatch (opvi.py:1314-1421): every term over N / B
     loss.backward()
     l, gm, gl = ref_advi.advi_step(glm, st, idx, z0)
     assert abs(l - loss.item()) <= 1e-12 * abs(l)
     np.testing.assert_allclose(gm, mu_t.grad.numpy(), rtol=1e-10, atol=1e-10)
     np.testing.assert_allclose(gl, Lt.grad.numpy(), rtol=1e-10, atol=1e-10)
+
+
+REF_STEPS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "advi_reference_steps.npz")
+
+
+@pytest.mark.parametrize("family", ["normal", "bernoulli"])
+def test_oracle_reproduces_the_executed_reference_step_by_step(family):
+    """THE PIN of the ADVI oracle: tests/golden/advi_reference_steps.npz holds 14 consecutive steps (the adagrad window of 10 wraps)
+    of the REFERENCE's own `FullRankGroup` / `KL.apply` / normalised terms / `adagrad_window` / `logp` bodies, executed eagerly by
+    tests/golden/refrun_advi.py; the oracle, fed the same rows and z0, must give the same loss, gradients, parameters and rings."""
+    k = np.load(REF_STEPS)
+    X, y = k["X"], k[f"y_{family}"]
+    glm = ref_advi.GLM(X, y, family, float(k["sigma"]), float(k["prior_sd"]))
+    st = ref_advi.FullRankState(X.shape[1])
+    for s in range(len(k["idx"])):
+        l, gm, gl = ref_advi.advi_step(glm, st, k["idx"][s], k["z0"][s], learning_rate=float(k["learning_rate"]))
+        assert abs(l - k[f"{family}_loss"][s]) <= 1e-13 * abs(l), s
+        for got, want in ((gm, k[f"{family}_grad_mu"][s]), (gl, k[f"{family}_grad_L"][s]), (st.mu, k[f"{family}_mu"][s]), (st.L_tril, k[f"{family}_L"][s]),
+                          (st.acc_mu, k[f"{family}_ring_mu"][s]), (st.acc_L, k[f"{family}_ring_L"][s])):
+            assert np.max(np.abs(got - want)) <= 1e-13 * max(1.0, np.max(np.abs(want))), s
+        assert st.i == int(k[f"{family}_ring_i"][s])
+
+
+def test_committed_reference_steps_are_current():
+    """Where the reference exists: run its code again and compare with the fixture."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_advi_golden
+    import refrun_advi
+
+    if not refrun_advi.available():
+        pytest.skip("needs /root/reference")
+    now, then = make_advi_golden.run(), np.load(REF_STEPS)
+    assert sorted(now) == sorted(then.files)
+    for key in now:
+        np.testing.assert_allclose(now[key], then[key], rtol=1e-14, atol=1e-300, err_msg=key)
 
 
 def test_surface_without_a_device():

@@ -96,6 +96,146 @@ def test_reference_class_reproduces_the_committed_fixture():
     assert np.array_equal(cs, k["cs"])
 
 
+GOLD_PROP = os.path.join(os.path.dirname(GOLD), "gibbs_mixture_prop.npz")
+
+
+def _state_words(rng):
+    st = rng.bit_generator.state
+    return [st["state"]["state"] >> 64, st["state"]["state"] & (2**64 - 1), st["has_uint32"], st["uinteger"]]
+
+
+def test_oracle_restatement_reproduces_the_reference_proportional_sweeps():
+    """`proposal="proportional"` (metropolis.py:788-826): the fixture is the reference's `astep_prop` executed over a full-model
+    `logp`; the restatement must give the same assignments and leave the generator in the same state."""
+    k = np.load(GOLD_PROP)
+    link = models.normal_mixture(N=int(k["N"]), K=int(k["K"]), seed=int(k["data_seed"])).mixture
+    rng = np.random.default_rng(int(k["seed"]))
+    rng.integers(2**30)
+    g = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w, link.sigma, rng)
+    c = k["c0"]
+    for s in range(len(k["cs"])):
+        c, _ = g.sweep_prop(c, k["mus"][s])
+        assert np.array_equal(c, k["cs"][s]), s
+    assert _state_words(rng) == [int(x) for x in k["final_state"]]
+
+
+def test_reference_class_reproduces_the_committed_proportional_fixture():
+    import refrun
+
+    if not refrun.available():
+        pytest.skip("reference checkout not present")
+    import make_gibbs_golden as mg
+
+    k = np.load(GOLD_PROP)
+    spec = models.normal_mixture(N=int(k["N"]), K=int(k["K"]), seed=int(k["data_seed"]))
+    cs, state = mg.reference_sweeps(spec, int(k["seed"]), len(k["cs"]), k["mus"], k["c0"], leave_half_cached=True, proposal="proportional")
+    assert np.array_equal(cs, k["cs"])
+
+
+class _PropShim:
+    """The real library for the host-only entry points + a NumPy stand-in for the ONE device entry point of the proportional sweep
+    (per-element arithmetic as the kernel does it), so that the stream-position logic of `_step_proportional` runs without a GPU."""
+
+    def __init__(self, real, y, force_nonfinite=()):
+        self._real, self._y, self._force, self.calls = real, y, set(force_nonfinite), 0
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    def nuts_gibbs_create(self, *a):
+        return 1
+
+    def nuts_gibbs_destroy(self, *a):
+        return None
+
+    def nuts_gibbs_sweep_prop(self, g, c_in, c_out, lw, mu, sg, order, u1, u2, flags, nacc, cnt, s1, s2):
+        import ctypes as C
+        from scipy import special
+
+        self.calls += 1
+        n = len(self._y)
+        arr = lambda p, t, m: np.ctypeslib.as_array(C.cast(p, C.POINTER(t)), (m,))   # noqa: E731
+        K = 3
+        c_in, c_out, order = arr(c_in, C.c_int32, n), arr(c_out, C.c_int32, n), arr(order, C.c_int32, n)
+        lw, mu, sg = (np.ctypeslib.as_array(x, (K,)) for x in (lw, mu, sg))
+        u1, u2, flags = np.ctypeslib.as_array(u1, (n,)), np.ctypeslib.as_array(u2, (n,)), arr(flags, C.c_int8, n)
+        c_out[:] = c_in
+        acc = 0
+        for t in range(n):
+            d = order[t]
+            cur = int(c_in[d])
+            lp = lw - np.log(sg) - 0.5 * ((self._y[d] - mu) / sg) ** 2
+            probs = special.softmax(lp)
+            pc, probs[cur] = probs[cur], 0.0
+            probs /= 1.0 - pc
+            cdf = probs.cumsum()
+            cdf /= cdf[-1]
+            prop = int(cdf.searchsorted(u1[t], side="right"))
+            ratio = (1.0 - pc) / (1.0 - probs[prop])
+            fin = bool(np.isfinite(ratio)) and int(d) not in self._force
+            flags[t] = fin
+            if fin and not (u2[t] >= ratio):
+                c_out[d] = prop
+                acc += 1
+        nacc._obj.value = acc
+        for k in range(K):
+            m = c_out == k
+            cnt[k], s1[k], s2[k] = m.sum(), self._y[m].sum(), (self._y[m] ** 2).sum()
+        return 0
+
+
+def test_proportional_stream_positions_on_the_host(monkeypatch):
+    """`_step_proportional` without a GPU: shuffle replay + look-ahead doubles from the real library, the per-element arithmetic from
+    a NumPy stand-in.  (1) the committed reference sweeps come out, generator state included; (2) when some ratios are declared
+    non-finite, the positions settle in a few passes and equal a sequential replay of the same rule."""
+    from pymc_amd import _lib
+
+    k = np.load(GOLD_PROP)
+    spec = models.normal_mixture(N=int(k["N"]), K=int(k["K"]), seed=int(k["data_seed"]))
+    real = _lib.load()
+    shim = _PropShim(real, spec.mixture.y)
+    monkeypatch.setattr(_lib, "load", lambda: shim)
+    st = CategoricalGibbsMetropolis(model=spec, rng=int(k["seed"]), proposal="proportional")
+    st.rng.integers(2**30)
+    point = {"mu": k["mus"][0], "c": k["c0"].astype("int64")}
+    for s in range(len(k["cs"])):
+        point["mu"] = k["mus"][s]
+        point, stats = st.step(point)
+        assert stats == [{}] and np.array_equal(point["c"], k["cs"][s]), s
+        assert st.prop_passes_last == 1                       # every ratio finite on this mixture: the optimistic pass is final
+    assert _state_words(st.rng) == [int(x) for x in k["final_state"]]
+
+    # (2) elements 7, 50 and 51 "non-finite": they consume ONE double; everything behind them shifts
+    forced = (7, 50, 51)
+    shim2 = _PropShim(real, spec.mixture.y, force_nonfinite=forced)
+    monkeypatch.setattr(_lib, "load", lambda: shim2)
+    st2 = CategoricalGibbsMetropolis(model=spec, rng=3, proposal="proportional")
+    ref_rng = np.random.default_rng(3)
+    c0, mu = k["c0"].astype("int64"), k["mus"][0]
+    out, _ = st2.step({"mu": mu, "c": c0})
+    assert 2 <= st2.prop_passes_last <= 5
+    # sequential replay of the same rule on a generator of the same seed
+    from scipy import special
+
+    link = spec.mixture
+    dimcats = list(range(len(c0)))
+    ref_rng.shuffle(dimcats)
+    c = c0.copy()
+    for d in dimcats:
+        cur = int(c[d])
+        lp = link.log_w - np.log(link.sigma) - 0.5 * ((link.y[d] - mu) / link.sigma) ** 2
+        probs = special.softmax(lp)
+        pc, probs[cur] = probs[cur], 0.0
+        probs /= 1.0 - pc
+        prop = ref_rng.choice(3, p=probs)
+        ratio = (1.0 - pc) / (1.0 - probs[prop])
+        if not (np.isfinite(ratio) and d not in forced) or ref_rng.uniform() >= ratio:
+            continue
+        c[d] = prop
+    assert np.array_equal(out["c"], c)
+    assert st2.rng.bit_generator.state == ref_rng.bit_generator.state
+
+
 def test_host_half_of_the_device_sweep_reproduces_the_fixture():
     """`plan_sweep` + the acceptance rule evaluated with NumPy (what the kernel does per element) = the reference's sweeps."""
     k, spec = _fixture()
@@ -170,6 +310,7 @@ def test_step_surface_and_state_roundtrip_without_a_device():
         CategoricalGibbsMetropolis(model=spec, order=[0, 1])
     with pytest.raises(ValueError, match="proposal"):
         CategoricalGibbsMetropolis(model=spec, proposal="nope")
+    assert CategoricalGibbsMetropolis(model=spec, proposal="proportional").proposal == "proportional"
     with pytest.raises(ValueError, match="categorical"):
         CategoricalGibbsMetropolis(model=models.eight_schools())
     s = st.sampling_state
@@ -193,6 +334,37 @@ def test_device_sweep_reproduces_the_reference_assignments_bitwise():
     stt = st.rng.bit_generator.state
     assert [stt["state"]["state"] >> 64, stt["state"]["state"] & (2**64 - 1), stt["has_uint32"], stt["uinteger"]] == [int(x) for x in k["final_state"]]
     st.close()
+
+
+@pytest.mark.gpu
+def test_device_proportional_sweep_reproduces_the_reference_assignments_bitwise():
+    """`proposal="proportional"` on the device against the reference's `astep_prop` (fixture from the reference's class)."""
+    k = np.load(GOLD_PROP)
+    spec = models.normal_mixture(N=int(k["N"]), K=int(k["K"]), seed=int(k["data_seed"]))
+    st = CategoricalGibbsMetropolis(model=spec, rng=int(k["seed"]), proposal="proportional", device=0)
+    st.rng.integers(2**30)
+    point = {"mu": k["mus"][0], "c": k["c0"].astype("int64")}
+    for s in range(len(k["cs"])):
+        point["mu"] = k["mus"][s]
+        point, stats = st.step(point)
+        assert stats == [{}] and np.array_equal(point["c"], k["cs"][s]), s
+        assert st.accepted_last == int((k["cs"][s] != (k["c0"] if s == 0 else k["cs"][s - 1])).sum())
+    assert _state_words(st.rng) == [int(x) for x in k["final_state"]]
+    # a larger one against the oracle restatement (K = 8: NumPy's pairwise sum takes its eight-accumulator path)
+    big = models.normal_mixture(N=20_000, K=8, seed=9)
+    link = big.mixture
+    rng_a, rng_b = np.random.default_rng(12), np.random.default_rng(12)
+    dev = CategoricalGibbsMetropolis(model=big, rng=rng_a, proposal="proportional", device=0)
+    ref = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w, link.sigma, rng_b)
+    mu = np.linspace(-6, 6, 8) + 0.2 * np.random.default_rng(1).normal(size=8)
+    c = np.random.default_rng(2).integers(0, 8, size=20_000)
+    p = {"mu": mu, "c": c}
+    for s in range(2):
+        p, _ = dev.step(p)
+        c, _ = ref.sweep_prop(c, mu)
+        assert np.array_equal(p["c"], c), (s, int((p["c"] != c).sum()))
+    assert dev.rng.bit_generator.state == rng_b.bit_generator.state
+    st.close(); dev.close()
 
 
 @pytest.mark.gpu
