@@ -296,7 +296,14 @@ class CategoricalGibbsMetropolis:
             raise _lib.EngineError(f"proposal='proportional': the positions of the uniform stream did not settle in {self.max_prop_passes} passes "
                                    "(many acceptance ratios are not finite: components that do not overlap); use proposal='uniform'")
         self.prop_passes_last = sweep_pass + 1
-        self.rng.bit_generator.advance(int(n + int(flags.sum(dtype=np.int64))))     # the doubles the sequential loop would have consumed
+        # the doubles the sequential loop would have consumed.  (`advance` also clears NumPy's buffered 32-bit half, which doubles
+        # never touch and the NEXT sweep's shuffle will read: it is put back)
+        bg = self.rng.bit_generator
+        before = bg.state
+        bg.advance(int(n + int(flags.sum(dtype=np.int64))))
+        after = bg.state
+        after["has_uint32"], after["uinteger"] = before["has_uint32"], before["uinteger"]
+        bg.state = after
         self.accepted_last = int(nacc.value)
         new_c = np.ascontiguousarray(c_out.astype(np.asarray(point[link.name]).dtype, copy=False))
         link.remember(new_c, (cnt, s1, s2))
