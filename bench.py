@@ -448,8 +448,11 @@ def run_rank(args):
                 "; cache-resident: 33.5 MB < 256 MiB Infinity Cache -- the HBM line does not bound it)"
         else:
             workload = f"C2-{'L' if args.rows_per_group >= 1000 else 'S'} hier-logit-10k: G={args.groups} D=8 rows={N} n={spec.n}"
-            kernel = "hierarchical-logit row pass (k_rows_ga / k_rows)"
+            kernel = "hierarchical-logit row pass (k_rows_ga / k_rows_gb / k_rows)"
         schedule = ("persistent tree kernel: one launch per NUTS tree (csrc/rows_ga_tree.h)" if step._scalar("tree_kernel") else
+                    f"group-block row pass: one launch per leapfrog, {int(step._logp_dlogp_func.model_scalar('rows_group_block'))} groups per workgroup, block "
+                    "partials cross the kernel boundary, control work folded into the next row pass, also across doublings (csrc/rows_gb_kernel.h)"
+                    if (not c3 and step._logp_dlogp_func.model_scalar("rows_group_block")) else
                     "group-aligned row pass: one launch per leapfrog, control work folded into the next row pass, also across doublings "
                     "(csrc/rows_ga_kernel.h)" if (not c3 and step._logp_dlogp_func.model_scalar("rows_group_aligned")) else
                     "row-aligned MvNormal pass: one launch per leapfrog, control work folded into the next launch, also across doublings "

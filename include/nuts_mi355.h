@@ -91,7 +91,10 @@ typedef struct {
 } nuts_data_ref;
 
 /* nuts_model_spec.rows_opts */
-enum { NUTS_ROWS_NO_GROUP_ALIGNED = 1 };
+enum {
+  NUTS_ROWS_NO_GROUP_ALIGNED = 1, /* neither one-launch row pass (a chain with a dense mass matrix needs the velocity between kernels) */
+  NUTS_ROWS_NO_GROUP_BLOCK = 2    /* small groups stay on the general path instead of the group-block pass (rows_gb_kernel.h) */
+};
 
 typedef struct {
   int32_t n_vars, n_factors, n_data, pad;

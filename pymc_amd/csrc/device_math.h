@@ -38,6 +38,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __device__ __forceinline__ double wave_sum_all(double v) { return wave_sum(v); }
 
+// The same sum when only lanes 0 .. 7 can be non-zero (a group's D <= 8 z elements, rows_gb_kernel.h): after the first three
+// steps lane 7 holds ((v7+v6)+(v5+v4))+((v3+v2)+(v1+v0)), and every later step of wave_sum only adds zeros to it -- the same
+// number with half the dependent DPP steps.
+__device__ __forceinline__ double wave_sum8(double v) {
+  v += dpp_move_d<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_move_d<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_move_d<0x114, 0xf>(v);  // row_shr:4
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, 7);
+  hi = __builtin_amdgcn_readlane(hi, 7);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) {

@@ -157,6 +157,14 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
       ga.fold = GA_FOLD_CTL | (job->src_prev ? GA_FOLD_SRC : 0);
       ga.cio = job->io; ga.cj = job->j; ga.cd = job->d; ga.cseq = job->seq;
     }
+    if (md.lg.ga_gpw) {   // group-block pass (small groups): same arguments, same protocol
+      switch (md.lg.D) {
+        case 8: if (md.lg.ga_dx == 7) hipLaunchKernelGGL((k_rows_gb<8, 7>), grid, block, 0, m->stream, ga);
+                else hipLaunchKernelGGL((k_rows_gb<8>), grid, block, 0, m->stream, ga); break;
+        case 4: hipLaunchKernelGGL((k_rows_gb<4>), grid, block, 0, m->stream, ga); break;
+        default: hipLaunchKernelGGL((k_rows_gb<2>), grid, block, 0, m->stream, ga); break;
+      }
+    } else {
 #define GA_LAUNCH(DD, OO, PP) hipLaunchKernelGGL((k_rows_ga<DD, 2, OO, PP>), grid, block, 0, m->stream, ga)
 #define GA_BY_D(OO, PP)                      \
     switch (md.lg.D) {                       \
@@ -172,6 +180,7 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     }
 #undef GA_BY_D
 #undef GA_LAUNCH
+    }
   } else if (md.has_logit) {
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
     const dim3 grid(m->rows_grid + (fold ? 1 : 0)), block(ROWS_BLOCK);
@@ -497,9 +506,21 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       bool use = false;
       if (want >= 2) { use = m->ga_struct_ok && m->ept == 1; W = std::max(1, W); }
       else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && W >= 1 && lg.G >= 2 * cus && meanT >= 4.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
-      if (use && n_tiles * (int64_t)SPAN < ((int64_t)1 << 31) && lg.G <= 32 * 8 * GA_MAXCHUNK) {
-        lg.ga = 1; lg.ga_w = W;
-        lg.ga_bsz = (lg.G + 31) / 32;
+      // group-BLOCK pass (rows_gb_kernel.h) for small groups: the same closed-form model, a workgroup owns GPW whole groups and
+      // nothing crosses workgroups inside the launch.  NUTS_ROWS_GB=0 keeps such models on the general path (A/B, tests).
+      int gpw = 0;
+      if (!use && want == 1 && !(s->rows_opts & NUTS_ROWS_NO_GROUP_BLOCK) && env_int("NUTS_ROWS_GB", 1) && m->ga_struct_ok && m->ept == 1 &&
+          lg.G >= 64 && maxT <= 16) {
+        gpw = 4 * (int)((lg.G + 4 * 512 - 1) / (4 * 512));          // <= 512 workgroups where GB_MAXGPW allows it
+        gpw = std::min(gpw, GB_MAXGPW);
+        if (env_int("NUTS_ROWS_GPW", 0) > 0) gpw = std::max(1, std::min(GB_MAXGPW, env_int("NUTS_ROWS_GPW", 0)));
+        if ((lg.G + gpw - 1) / gpw > WAVE * SLOT_SUM_MAXR) gpw = 0;   // (slot_sum: at most SLOT_SUM_MAXR records per lane)
+      }
+      if (gpw) { use = true; W = 1; }   // (layout: one chunk per group)
+      if (use && n_tiles * (int64_t)SPAN < ((int64_t)1 << 31) && (gpw || lg.G <= 32 * 8 * GA_MAXCHUNK)) {
+        lg.ga = 1; lg.ga_w = gpw ? GB_W : W;
+        lg.ga_gpw = gpw;
+        lg.ga_bsz = gpw ? gpw : (lg.G + 31) / 32;
         lg.ga_flags = env_int("NUTS_GA_FLAGS", 0);
         lg.ga_T_uni = 0; lg.ga_ng_uni = 0;
         {
@@ -558,10 +579,12 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         lg.ga_coff = m->keep(dev_upload(coff.data(), coff.size()));
         lg.ga_tile0 = m->keep(dev_upload(tile0.data(), tile0.size()));
         lg.ga_part = m->keep(dev_alloc<double>((size_t)lg.G * PART_STRIDE));
-        lg.ga_bpart = m->keep(dev_alloc<double>(2 * (size_t)lg.ga_nblk * PART_STRIDE));
+        // (group-block pass: slot-major, every slot padded to a multiple of 64 records -- the padding stays zero)
+        const size_t bpart_len = gpw ? 2 * (size_t)PART_STRIDE * ((lg.ga_nblk + WAVE - 1) / WAVE * WAVE) : 2 * (size_t)lg.ga_nblk * PART_STRIDE;
+        lg.ga_bpart = m->keep(dev_alloc<double>(bpart_len));
         lg.ga_ticket = m->keep(dev_alloc<unsigned>(lg.ga_nblk));
         if (lg.ga_part) hipMemset(lg.ga_part, 0, (size_t)lg.G * PART_STRIDE * sizeof(double));
-        if (lg.ga_bpart) hipMemset(lg.ga_bpart, 0, 2 * (size_t)lg.ga_nblk * PART_STRIDE * sizeof(double));
+        if (lg.ga_bpart) hipMemset(lg.ga_bpart, 0, bpart_len * sizeof(double));
         if (lg.ga_ticket) hipMemset(lg.ga_ticket, 0, lg.ga_nblk * sizeof(unsigned));
         if (env_int("NUTS_GA_TREE_DBG", 0) > 0) {
           m->tree_dbg_leaf = env_int("NUTS_GA_TREE_DBG", 0) - 1;
@@ -570,13 +593,13 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         }
         m->ga_sync = m->keep(dev_alloc<unsigned>(GA_SYNC_WORDS));
         if (m->ga_sync) hipMemset(m->ga_sync, 0, GA_SYNC_WORDS * sizeof(unsigned));
-        m->rows_grid = lg.G;
+        m->rows_grid = gpw ? lg.ga_nblk : lg.G;
         // persistent tree kernel (rows_ga_tree.h): needs every one of its G + 1 workgroups resident at once.  The occupancy
         // query is asked for the real block size and capped by the wave slots of the register budget; the query can be
         // optimistic (MI355X guide, "Residency and cooperative launch"), which is why every wait in the kernel is bounded.
         m->ga_tree_ok = 0;
         // (only at the 168-register budget, variant 32: at 128 registers the allocator spills inside the streaming loop)
-        if (D == 8 && m->ga_variant == 32 && env_int("NUTS_GA_TREE", 1) != 0) {
+        if (D == 8 && m->ga_variant == 32 && !gpw && env_int("NUTS_GA_TREE", 1) != 0) {
           int per_cu = 0;
           const hipError_t e = lg.ga_dx == 7 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3, 7>, WAVE * W, 0)
                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3, 8>, WAVE * W, 0);
@@ -760,6 +783,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   if (!m || !name || !out) return NUTS_E_ARG;
   const std::string k(name);
   if (k == "rows_group_aligned") *out = m->md.lg.ga;
+  else if (k == "rows_group_block") *out = m->md.lg.ga_gpw;
   else if (k == "mvn_row_aligned") *out = m->md.has_mvn ? m->md.mv.aligned : 0;
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
   else if (k == "lean") *out = m->md.lean_ok;

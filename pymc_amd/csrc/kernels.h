@@ -261,12 +261,14 @@ __device__ __forceinline__ void merge_prefetch(const ArenaDev& A, const Leaf& lf
 
 // FROM_ARENA (dense mass matrix, k_tree_vec): p' and v' = C p' of the new leaf were stored by B/C and k_dense_mv and are read
 // back instead of being produced here; everything after that is the same code.
-template <int E, bool FROM_ARENA = false>
+// L8: only lanes 0 .. 7 of the wave hold elements (E == 1, one group of D <= 8 elements per wave): the reductions stop after three steps
+template <int E, bool FROM_ARENA = false, bool L8 = false>
 __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int j, int d, bool tree,
                                           const int (&idx)[E], const bool (&act)[E], const double (&grad)[E],
                                           const double (&ph)[E], double* red, int nwaves, int& m_out, bool& last_out,
-                                          const MergePrefetch* pf = nullptr) {
-  const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x >> 6;
+                                          const MergePrefetch* pf = nullptr, int wsel = -1) {
+  // `wsel` >= 0: `red` is this wave's own scratch (rows_gb_kernel.h: every wave finishes a group of its own)
+  const int lane = threadIdx.x & (WAVE - 1), w = wsel >= 0 ? wsel : (int)(threadIdx.x >> 6);
   const int dir = lf.dir, edge = lf.edge, t = lf.t;
   const int64_t to = lf.d_o;
   double acc[E], vt[E], pt[E];
@@ -288,7 +290,7 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
     }
   }
   {
-    const double s = wave_sum(kin);
+    const double s = (L8 ? wave_sum8 : wave_sum)(kin);
     if (lane == 0) red[0 * nwaves + w] = s;
   }
   int m = 0;
@@ -330,7 +332,7 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
         }
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(1 + 6 * l + k) * nwaves + w] = s; }
+      for (int k = 0; k < 6; ++k) { const double s = (L8 ? wave_sum8 : wave_sum)(dd[k]); if (lane == 0) red[(1 + 6 * l + k) * nwaves + w] = s; }
     };
     if (E == 1 && pf) {
 #pragma unroll
@@ -383,7 +385,7 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
         }
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { const double s = wave_sum(dd[k]); if (lane == 0) red[(DOT_TOP + k) * nwaves + w] = s; }
+      for (int k = 0; k < 6; ++k) { const double s = (L8 ? wave_sum8 : wave_sum)(dd[k]); if (lane == 0) red[(DOT_TOP + k) * nwaves + w] = s; }
     }
   }
   m_out = m; last_out = last;
@@ -912,11 +914,33 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
 // the flag and the trajectory arena is never touched by a speculative leaf.
 // `part` / `nblk`: the per-workgroup partial records of this leaf (kernel B's, or the block partials of the group-aligned row
 // pass); `def_loc`: the local parts of its deferred elements; runs in any workgroup of 64 .. 256 threads.
-struct LeanSrc { const double* part; int stride, nblk; const double* def_loc; };
+// `slot_major` > 0 (group-block pass, rows_gb_kernel.h): the records are stored slot by slot, part[k * slot_major + r] with
+// slot_major = the padded record count (a multiple of 64, padding zero), and a slot's total is `slot_sum` below instead of
+// the chunked sum -- hundreds of records read as a few coalesced wave loads.
+struct LeanSrc { const double* part; int stride, nblk; const double* def_loc; int slot_major = 0; };
+
+// Total of one slot over all records of a slot-major table: lane l adds records l, l + 64, ... in order, then the wave's fixed
+// DPP tree.  Used by everything that needs such a total (control_lean and the prologue of k_rows_gb), so they agree bit for bit.
+#define SLOT_SUM_MAXR 8   // records per lane: ga_nblk <= 512
+__device__ __forceinline__ void slot_sum_issue(const double* slot, int npad, int lane, double (&v)[SLOT_SUM_MAXR]) {
+#pragma unroll
+  for (int u = 0; u < SLOT_SUM_MAXR; ++u) v[u] = slot[min(lane + WAVE * u, npad - 1)];   // (clamped: unconditional loads)
+}
+__device__ __forceinline__ double slot_sum_finish(const double (&v)[SLOT_SUM_MAXR], int npad, int lane) {
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < SLOT_SUM_MAXR; ++u) acc += (lane + WAVE * u < npad) ? v[u] : 0.0;
+  return wave_sum(acc);
+}
 
 // AGENT: the records were written by other workgroups of THIS launch (persistent tree kernel, rows_ga_tree.h).
 // `nt` (optional): the number of threads of the workgroup that take part (the others have left), if not all of them.
-template <bool AGENT = false>
+// BATCH: partial records in flight per thread while they are summed (sum_strided): 8 covers the paths with a few dozen records;
+// the group-block pass (rows_gb_kernel.h) has hundreds and asks for more -- a template parameter so that the register needs of
+// the larger batch stay out of the kernels that do not want it.
+// PF: the operands of the first merge levels of the deferred elements are requested at the top, with everything else whose address
+// is known (they belong to earlier leaves) -- otherwise every merge level costs the control workgroup a round of far loads.
+template <bool AGENT = false, int BATCH = 8, bool PF = false>
 __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
                                              int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt = 0) {
   Leaf lf; QView qv;
@@ -931,6 +955,8 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   const bool leaf = io.mode != MODE_PLAIN;
   const bool tree = io.mode == MODE_TREE;
   const RowsDev& lg = md.lg;
+  const bool ctk = tid == 0 && (md.tick_j < 0 || j == md.tick_j);   // NUTS_KTIMING builds: slots 8 .. 13 (tools/gb_ticks.py)
+  TICK(md, ctk, 8);
   int m = 0;
   bool last = false;
   if (tree) {
@@ -939,10 +965,12 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   }
   if (leaf) for (int t = tid; t < (int)(sizeof(Ctl) / sizeof(int)); t += NT) reinterpret_cast<int*>(&s_ctl)[t] = reinterpret_cast<const int*>(A.ctl)[t];
   const bool mine = tid < md.n_deferred;
+  MergePrefetch mpf;
   int def_i = 0, def_k = 0;
   double2 l01 = make_double2(0.0, 1.0), l23 = make_double2(0.0, 0.0);
   if (mine) {
     def_i = md.deferred_g[2 * tid]; def_k = md.deferred_g[2 * tid + 1];
+    if (PF && tree) merge_prefetch(A, lf, j, def_i, mpf);
     if (AGENT) {
       const double* dl = src.def_loc + 4 * tid;
       l01 = make_double2(ld_agent(dl), ld_agent(dl + 1));
@@ -965,25 +993,41 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     if (q < 1 + 6 * m) return PART_DOT + q;
     return PART_DOT + DOT_TOP + (q - 1 - 6 * m);
   };
-  {
+  if (src.slot_major) {
+    // slot-major records: wave w totals slots w, w + NW, ... four at a time (their loads in flight together)
+    const int lane = tid & (WAVE - 1), w = tid >> 6;
+    for (int q0 = w; q0 < nn; q0 += 4 * NW) {
+      double v[4][SLOT_SUM_MAXR];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) slot_sum_issue(src.part + (int64_t)need_slot(min(q0 + u * NW, nn - 1)) * src.slot_major, src.slot_major, lane, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double tot = slot_sum_finish(v[u], src.slot_major, lane);
+        if (q0 + u * NW < nn && lane == 0) s_sum[need_slot(q0 + u * NW)] = tot;
+      }
+    }
+  } else {
     const int per = (src.nblk + CTL_CHUNKS - 1) / CTL_CHUNKS;
     for (int t = tid; t < nn * CTL_CHUNKS; t += NT) {
       const int c = t % CTL_CHUNKS, k = need_slot(t / CTL_CHUNKS);
       const int b0 = c * per, b1 = min(src.nblk, (c + 1) * per);
-      s_chunk[c][k] = sum_strided<AGENT>(src.part + k, src.stride, b0, b1);
+      s_chunk[c][k] = sum_strided<AGENT, BATCH>(src.part + k, src.stride, b0, b1);
     }
   }
   __syncthreads();
+  TICK(md, ctk, 9);
   if (tree && s_ctl.aborted) {   // terminated earlier in this doubling: drain
     if (tid == 0 && st) publish_status(&s_ctl, st, seq);
     return;
   }
-  for (int t = tid; t < nn; t += NT) {
-    const int k = need_slot(t);
-    double sacc = 0.0;
+  if (!src.slot_major) {
+    for (int t = tid; t < nn; t += NT) {
+      const int k = need_slot(t);
+      double sacc = 0.0;
 #pragma unroll
-    for (int c = 0; c < CTL_CHUNKS; ++c) sacc += s_chunk[c][k];
-    s_sum[k] = sacc;
+      for (int c = 0; c < CTL_CHUNKS; ++c) sacc += s_chunk[c][k];
+      s_sum[k] = sacc;
+    }
   }
   __syncthreads();
   // ---- deferred elements: one thread each ----
@@ -1003,8 +1047,10 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     return;
   }
   int m2 = 0; bool last2 = false;
-  leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2);
+  TICK(md, ctk, 10);
+  leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2, (PF && tree) ? &mpf : nullptr);
   __syncthreads();
+  TICK(md, ctk, 11);
   // totals: workgroup partials (in order) + the deferred elements' share
   for (int q = tid; q < NDOT; q += NT) {
     if (!dot_needed(q, m, last)) continue;
@@ -1020,13 +1066,19 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   const double E = 0.5 * dot[0] - logp;  // integration.py:133-134
   A.E[ts] = E;
   if (!tree) return;
+  TICK(md, ctk, 12);
   tree_decide(&s_ctl, A, lf, dot, E, m, last, Emax, max_depth);
   *A.ctl = s_ctl;
   if (st) publish_status(&s_ctl, st, seq);
+  TICK(md, ctk, 13);
 }
 
 // `par`: launch parity of the leaf's row pass (group-aligned row pass only; its partials are double-buffered)
 __device__ __forceinline__ LeanSrc lean_src(const ModelDev& md, int par) {
+  if (md.lg.ga && md.lg.ga_gpw) {   // group-block pass: slot-major block partials, [2][PART_STRIDE][npad]
+    const int npad = (md.lg.ga_nblk + WAVE - 1) / WAVE * WAVE;
+    return LeanSrc{md.lg.ga_bpart + (int64_t)par * PART_STRIDE * npad, 1, md.lg.ga_nblk, md.def_loc + (int64_t)par * 4 * MAX_DEFERRED, npad};
+  }
   if (md.lg.ga) return LeanSrc{md.lg.ga_bpart + (int64_t)par * md.lg.ga_nblk * PART_STRIDE, PART_STRIDE, md.lg.ga_nblk, md.def_loc + (int64_t)par * 4 * MAX_DEFERRED};
   return LeanSrc{md.part, md.part_stride, md.nblk, md.def_loc};
 }
@@ -1529,4 +1581,5 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, con
 
 #include "rows_ga_kernel.h"
 #include "rows_ga_tree.h"
+#include "rows_gb_kernel.h"
 #include "dense_adapt.h"

@@ -84,7 +84,8 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   // span tables above are not built, and there is no O(n) kernel between two row passes: the workgroup that streamed a
   // group holds that group's complete d logp / d beta and finishes its D z elements itself.
   int32_t ga, ga_w;              // active; waves per workgroup
-  int32_t ga_dx, ga_dx_pad;      // stored columns per tile: D, or D - 1 when column 0 of X is identically 1 (not stored)
+  int32_t ga_dx, ga_gpw;         // stored columns per tile: D, or D - 1 when column 0 of X is identically 1 (not stored);
+                                 // ga_gpw > 0: group-BLOCK pass (rows_gb_kernel.h), a workgroup owns ga_gpw consecutive groups
   int32_t ga_nblk, ga_bsz;       // second-level reduction: blocks of ga_bsz consecutive groups (ga_bsz <= 64)
   int32_t ga_T_uni, ga_flags;    // > 0: every group has this many tiles (and ga_ng_uni rows): geometry without table look-ups
   int64_t ga_ng_uni;
@@ -184,16 +185,18 @@ __device__ __forceinline__ double ld_maybe_agent(const double* p) { return AGENT
 
 // sum_{s in [s0, s1)} base[s * stride], in index order, with up to 8 loads in flight at a time
 // (AGENT: the records were written by other workgroups of THIS launch)
-template <bool AGENT = false>
+template <bool AGENT = false, int BATCH = 8>
 __device__ __forceinline__ double sum_strided(const double* base, int stride, int s0, int s1) {
+  // BATCH loads are in flight together, the additions are in index order whatever BATCH is (same bits).  A round of loads of
+  // records another XCD wrote costs ~1300 cycles: callers that sum dozens of records per thread ask for a batch that covers them.
   double acc = 0.0;
-  for (int s = s0; s < s1; s += 8) {
-    double v[8];
+  for (int s = s0; s < s1; s += BATCH) {
+    double v[BATCH];
     // unconditional loads from a clamped index (a predicated load would sit in its own branch and serialise)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ld_maybe_agent<AGENT>(base + (int64_t)min(s + u, s1 - 1) * stride);
+    for (int u = 0; u < BATCH; ++u) v[u] = ld_maybe_agent<AGENT>(base + (int64_t)min(s + u, s1 - 1) * stride);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += (s + u < s1) ? v[u] : 0.0;
+    for (int u = 0; u < BATCH; ++u) acc += (s + u < s1) ? v[u] : 0.0;
   }
   return acc;
 }

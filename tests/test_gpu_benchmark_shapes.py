@@ -322,6 +322,84 @@ def test_group_aligned_rows_on_ragged_empty_and_tiny_groups(waves, monkeypatch):
     res["step"].close()
 
 
+# ---------------------------------------------------------------------------
+# the group-block row pass (rows_gb_kernel.h): small groups, one launch per leapfrog, nothing crosses workgroups in the launch
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("gpw", [0, 1, 5, 16])
+def test_group_block_rows_on_ragged_empty_and_tiny_groups(gpw, monkeypatch):
+    """The pass that small-group models (C2-S: 1248 groups x 80 rows) take by default, on shapes that stress its tables: ragged
+    groups of 0 .. 700 rows (several tiles, the last one masked), groups without rows (first, middle, last), single-row groups, a
+    last workgroup with fewer groups than the others, D = 2 and 4, non-default prior parameters; groups per workgroup = the
+    engine's choice (0) or forced.  logp / gradient against the NumPy oracle (also through MODE_PLAIN, the `ValueGradFunction`
+    call), a leapfrog trajectory under the schedules that only reorder launches (bitwise equal to each other), the general path
+    on the same model (agrees to rounding: another association of the cross-group sums), and a NUTS run with the oracle's integers."""
+    from pymc_amd.sampling import sample
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    if gpw:
+        monkeypatch.setenv("NUTS_ROWS_GPW", str(gpw))
+    rng = np.random.default_rng(20 + gpw)
+    cases = [(rng.integers(0, 90, size=70), 8), (rng.integers(1, 700, size=101), 8), (np.ones(200, dtype=int), 8),
+             (np.concatenate([[0, 0], rng.integers(0, 300, size=66), [0]]), 8), (rng.integers(1, 200, size=80), 4), (rng.integers(1, 400, size=64), 2)]
+    for sizes, D in cases:
+        spec = _ragged_spec(np.asarray(sizes), D=D, seed=len(sizes))
+        f = DeviceValueGradFunction(spec, device=0)
+        assert f.model_scalar("rows_group_aligned") == 1.0 and f.model_scalar("rows_group_block") == (gpw or 4)
+        for q in [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.5 for _ in range(2)]:
+            lp, g = f._pytensor_function(q)
+            lp0, g0 = ref_models.evaluate(spec, q)
+            assert abs(lp - lp0) <= 1e-9 * max(1.0, abs(lp0)), (len(sizes), D, lp, lp0)
+            assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.abs(g0).max())
+        f.close()
+    spec = _ragged_spec(rng.integers(20, 400, size=90), seed=2)
+    var = rng.uniform(0.5, 2.0, size=spec.n)
+    q0, p0 = rng.normal(size=spec.n) * 0.3, rng.normal(size=spec.n)
+    integ = ref_sampler.Leapfrog(ref_sampler.DiagPotential(var), ref_models.SpecLogpGrad(spec))
+    s = integ.compute_state(q0, p0)
+    for _ in range(7):
+        s = integ.step(-0.04, s)
+    runs = []
+    for env in ({}, {"NUTS_FOLD_CTL": "0"}, {"NUTS_ROWS_GB": "0"}):
+        for k in ("NUTS_FOLD_CTL", "NUTS_ROWS_GB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        q1, p1, e1 = _leapfrog(spec, var, q0, p0, -0.04, 7)
+        np.testing.assert_allclose(q1, s.q, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(p1, s.p, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(e1, s.energy, rtol=1e-11)
+        runs.append((q1, p1, e1))
+    assert np.array_equal(runs[1][0], runs[0][0]) and np.array_equal(runs[1][1], runs[0][1]) and runs[1][2] == runs[0][2]   # folded control: a pure re-ordering
+    for k in ("NUTS_FOLD_CTL", "NUTS_ROWS_GB"):
+        monkeypatch.delenv(k, raising=False)
+    tune, draws, seed = 25, 15, 7
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
+    assert res["step"]._logp_dlogp_func.model_scalar("rows_group_block") == (gpw or 4)
+    ref_draws, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    dev = res["warmup_stats"][0] + res["stats"][0]
+    for i in range(tune + draws):
+        for k in INT_KEYS:
+            assert int(dev[i][k]) == int(ref_stats[0][i][k]), (i, k, dev[i][k], ref_stats[0][i][k])
+    res["step"].close()
+
+
+def test_group_block_pass_is_what_c2s_runs_and_every_reordering_of_it_is_bitwise(c2s, monkeypatch):
+    """C2-S takes the group-block pass by default (312 workgroups of four groups); look-ahead depth, folding the control work across
+    doublings or not at all, and draw-by-draw against batched draws are re-orderings of the same launches: bitwise the same chain."""
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    f = DeviceValueGradFunction(c2s, device=0)
+    assert f.model_scalar("rows_group_block") == 4.0 and f.model_scalar("rows_group_aligned") == 1.0
+    f.close()
+    base = _run_schedule(c2s, {}, monkeypatch, 14, 8, 31)
+    for env in ({"NUTS_XFOLD": "0"}, {"NUTS_XFOLD": "1", "NUTS_SPEC_MAX": "10"}, {"NUTS_FOLD_CTL": "0"}):
+        d1, s1, _ = _run_schedule(c2s, env, monkeypatch, 14, 8, 31)
+        assert np.array_equal(d1, base[0]), env
+        for a, b in zip(s1, base[1]):
+            for k in STAT_KEYS:
+                assert a[k] == b[k], (env, k)
+
+
 def test_dense_mass_matrix_on_a_group_aligned_model_switches_the_row_pass(monkeypatch):
     """A dense potential (`scaling=<matrix>`) cannot ride in the group-aligned pass: the step method rebuilds the model with
     the span-partitioned pass and samples as before."""
