@@ -35,7 +35,24 @@ extern "C" {
 /* value-variable transforms (pymc/logprob/transforms.py:880-891, 967-1088) */
 enum { NUTS_TR_NONE = 0, NUTS_TR_LOG = 1, NUTS_TR_LOGODDS = 2, NUTS_TR_INTERVAL = 3 };
 /* operand kinds */
-enum { NUTS_OP_CONST = 0, NUTS_OP_DATA = 1, NUTS_OP_VAR = 2 };
+enum {
+  NUTS_OP_CONST = 0, NUTS_OP_DATA = 1, NUTS_OP_VAR = 2,
+  NUTS_OP_TMP = 3 /* the result of instruction `ref` of the factor's expression program (below); only earlier instructions */
+};
+/* Expression programs.  An argument of a factor is `a + b * c`; where the model's expression is not of that form (a link
+ * function, a Deterministic, a product of three quantities: whatever `pytensor.grad` would differentiate in the reference,
+ * model/core.py:213-267) the factor carries a small SSA program -- n_instr instructions starting at instrs[instr_off], each
+ * `tmp[i] = op(x, y)` element-wise over the factor's elements with size-1 operands broadcast -- and its arguments refer to the
+ * results through NUTS_OP_TMP operands.  The device interprets the program per element; the gradient w.r.t. a variable that
+ * occurs in it is the forward-mode tangent of the arguments through the same program (a deterministic gather per element, like
+ * every other gradient of the element-wise interpreter). */
+enum {
+  NUTS_E_ADD = 0, NUTS_E_SUB = 1, NUTS_E_MUL = 2, NUTS_E_DIV = 3, /* x (op) y */
+  NUTS_E_NEG = 4, NUTS_E_EXP = 5, NUTS_E_LOG = 6, NUTS_E_LOG1P = 7, /* f(x) */
+  NUTS_E_SIGMOID = 8, NUTS_E_SOFTPLUS = 9, NUTS_E_SQRT = 10, NUTS_E_SQR = 11, NUTS_E_RECIPROCAL = 12, NUTS_E_TANH = 13, NUTS_E_ABS = 14,
+  NUTS_E_POWC = 15 /* x ** k, k the instruction's constant */
+};
+#define NUTS_MAX_FACTOR_INSTR 16
 /* element-wise distributions (pymc/distributions/continuous.py, discrete.py) */
 enum {
   NUTS_D_NORMAL = 0,      /* args: value, mu, sigma         continuous.py:526-532  */
@@ -71,13 +88,20 @@ typedef struct { /* value = a + b * c, size-1 operands broadcast */
   nuts_operand a, b, c;
 } nuts_term;
 
+typedef struct { /* tmp[i] = op(x, y)  (NUTS_E_*; unary ops ignore y) */
+  int32_t op, pad;
+  double k; /* NUTS_E_POWC: the exponent */
+  nuts_operand x, y;
+} nuts_instr;
+
 typedef struct {
-  int32_t dist;  /* NUTS_D_* */
-  int32_t size;  /* number of elements */
-  int32_t nargs; /* incl. value (arg[0]) */
-  int32_t pad;
+  int32_t dist;    /* NUTS_D_* */
+  int32_t size;    /* number of elements */
+  int32_t nargs;   /* incl. value (arg[0]) */
+  int32_t n_instr; /* instructions of the factor's expression program (0: every argument is a plain term) */
   double konst; /* parameter-only normaliser (lgamma terms), computed by caller */
   nuts_term arg[4];
+  int32_t instr_off, pad; /* the program is nuts_model_spec.instrs[instr_off .. instr_off + n_instr) */
 } nuts_factor;
 
 typedef struct { /* one value variable = a slice of the raveled vector
@@ -124,6 +148,9 @@ typedef struct {
      y = W delta, P delta = W^T y -- two mat-vecs per leapfrog whose error grows with cond(chol) = sqrt(cond(cov)) instead of
      cond(cov) (1e-12 instead of 1e-8 at condition number 1e8). */
   const double *mvn_winv;
+  /* expression programs of the factors (nuts_factor.instr_off / n_instr); NULL when no factor has one */
+  const nuts_instr *instrs;
+  int32_t n_instrs, pad2;
 } nuts_model_spec;
 
 typedef struct nuts_model nuts_model;

@@ -308,7 +308,55 @@ def _log_diff_normal_cdf(x, y):
     return math.log(0.5) + np.where(y > 0, r1, np.where(x < 0, r2, r3))
 
 
-def _operand(op, spec, x):
+OP_TMP = 3
+(E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC) = range(16)
+
+
+def _instr_value(op, k, vx, vy):
+    """Value of one instruction of a factor's expression program and its local partials (d/dx, d/dy)."""
+    one = np.ones_like(np.asarray(vx, dtype="d"))
+    if op == E_ADD:
+        return vx + vy, one, one
+    if op == E_SUB:
+        return vx - vy, one, -one
+    if op == E_MUL:
+        return vx * vy, vy * one, vx * one
+    if op == E_DIV:
+        return vx / vy, one / vy, -vx / (vy * vy)
+    if op == E_NEG:
+        return -vx, -one, None
+    if op == E_EXP:
+        e = np.exp(vx)
+        return e, e, None
+    if op == E_LOG:
+        return np.log(vx), one / vx, None
+    if op == E_LOG1P:
+        return np.log1p(vx), one / (1.0 + vx), None
+    if op == E_SIGMOID:
+        s_ = expit(vx)
+        return s_, s_ * (1.0 - s_), None
+    if op == E_SOFTPLUS:
+        return softplus(vx), expit(vx), None
+    if op == E_SQRT:
+        r = np.sqrt(vx)
+        return r, 0.5 / r, None
+    if op == E_SQR:
+        return vx * vx, 2.0 * vx, None
+    if op == E_RECIPROCAL:
+        return one / vx, -one / (vx * vx), None
+    if op == E_TANH:
+        t = np.tanh(vx)
+        return t, 1.0 - t * t, None
+    if op == E_ABS:
+        return np.abs(vx), np.sign(vx), None
+    if op == E_POWC:
+        return np.power(vx, k), k * np.power(vx, k - 1.0), None
+    raise ValueError(op)
+
+
+def _operand(op, spec, x, tmp=None):
+    if op.kind == OP_TMP:
+        return tmp[op.ref]
     if op.kind == OP_CONST:
         return np.asarray(op.c, dtype="d")
     if op.kind == OP_DATA:
@@ -319,8 +367,11 @@ def _operand(op, spec, x):
     return s if v.size > 1 else s.reshape(())
 
 
-def _push(op, spec, gx, g):
-    """Accumulate d logp / d operand into the constrained-space gradient."""
+def _push(op, spec, gx, g, adj=None):
+    """Accumulate d logp / d operand into the constrained-space gradient (or, for a program result, into its adjoint)."""
+    if op.kind == OP_TMP:
+        adj[op.ref] = adj[op.ref] + g
+        return
     if op.kind != OP_VAR:
         return
     v = spec.vars[op.ref]
@@ -350,17 +401,33 @@ def evaluate(spec, q):
     gx = np.zeros(n)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         for f in spec.factors:
+            # the factor's expression program, forward (values and local partials), then its arguments
+            prog = getattr(f, "prog", ())
+            tmp, loc = [], []
+            for ins in prog:
+                vx, vy = _operand(ins.x, spec, x, tmp), _operand(ins.y, spec, x, tmp)
+                v, dx_, dy_ = _instr_value(ins.op, ins.k, np.asarray(vx, dtype="d"), np.asarray(vy, dtype="d"))
+                tmp.append(v)
+                loc.append((dx_, dy_))
             args, ops = [], []
             for t in f.args:
-                a, b, c = (_operand(o, spec, x) for o in (t.a, t.b, t.c))
+                a, b, c = (_operand(o, spec, x, tmp) for o in (t.a, t.b, t.c))
                 args.append(np.broadcast_to(a + b * c, (f.size,)))
                 ops.append((t, b, c))
             lp, partials = _dist(f.dist, f.konst, args)
             logp += float(np.sum(lp))
+            adj = [0.0] * len(prog)
             for (t, b, c), g in zip(ops, partials):
-                _push(t.a, spec, gx, g)
-                _push(t.b, spec, gx, g * c)
-                _push(t.c, spec, gx, g * b)
+                _push(t.a, spec, gx, g, adj)
+                _push(t.b, spec, gx, g * c, adj)
+                _push(t.c, spec, gx, g * b, adj)
+            for i in range(len(prog) - 1, -1, -1):      # reverse sweep through the program
+                ins, (dx_, dy_) = prog[i], loc[i]
+                if np.ndim(adj[i]) == 0 and adj[i] == 0.0:
+                    continue
+                _push(ins.x, spec, gx, adj[i] * dx_, adj)
+                if dy_ is not None:
+                    _push(ins.y, spec, gx, adj[i] * dy_, adj)
         if spec.logit_rows is not None:
             lp, g_extra = _logit_rows(spec, spec.logit_rows, x)
             logp += lp

@@ -30,14 +30,20 @@ class Term(C.Structure):
     _fields_ = [("a", Operand), ("b", Operand), ("c", Operand)]
 
 
+class Instr(C.Structure):
+    _fields_ = [("op", C.c_int32), ("pad", C.c_int32), ("k", C.c_double), ("x", Operand), ("y", Operand)]
+
+
 class Factor(C.Structure):
     _fields_ = [
         ("dist", C.c_int32),
         ("size", C.c_int32),
         ("nargs", C.c_int32),
-        ("pad", C.c_int32),
+        ("n_instr", C.c_int32),
         ("konst", C.c_double),
         ("arg", Term * 4),
+        ("instr_off", C.c_int32),
+        ("pad", C.c_int32),
     ]
 
 
@@ -83,6 +89,9 @@ class ModelSpecC(C.Structure):
         ("mvn_prec", C.POINTER(C.c_double)),
         ("mvn_logdet", C.c_double),
         ("mvn_winv", C.POINTER(C.c_double)),
+        ("instrs", C.POINTER(Instr)),
+        ("n_instrs", C.c_int32),
+        ("pad2", C.c_int32),
     ]
 
 

@@ -56,6 +56,12 @@ class NDArray:
         self._layout = [(nm, v, u) for nm, v, u in _var_layout(model, include_transformed) if vars is None or nm in vars]
         self.varnames = [nm for nm, _, _ in self._layout]
         self.var_shapes = {nm: tuple(v.shape) for nm, v, _ in self._layout}
+        # `pm.Deterministic` variables (model/core.py:1940-2005) follow the free variables in `model.unobserved_RVs`; their values
+        # are functions of the constrained values, evaluated when a draw is recorded (backends/base.py:183-191)
+        self._dets = [(nm, d) for nm, d in getattr(model, "deterministics", {}).items() if vars is None or nm in vars]
+        for nm, (_, _, size) in self._dets:
+            self.varnames.append(nm)
+            self.var_shapes[nm] = () if size == 1 else (size,)
         self.var_dtypes = {nm: np.dtype("float64") for nm in self.varnames}
         self.chain = None
         self.sampler_vars = None
@@ -118,8 +124,22 @@ class NDArray:
         for nm, v, untransformed in self._layout:
             val = np.asarray(point[v.value_name], dtype="float64")
             self.samples[nm][i] = backward(v, val) if untransformed else val
+        if self._dets:
+            q = np.concatenate([np.ravel(np.asarray(point[v.value_name], dtype="float64")) for v in self.model.vars])
+            self._record_deterministics(q[None], i)
         self._store_stats(i, sampler_stats)
         self.draw_idx += 1
+
+    def _record_deterministics(self, positions: np.ndarray, i: int) -> None:
+        from pymc_amd.model_spec import eval_program
+
+        x = np.empty_like(positions)                    # constrained values, spec layout
+        for v in self.model.vars:
+            blk = positions[:, v.offset : v.offset + v.size]
+            x[:, v.offset : v.offset + v.size] = backward(v, blk)
+        for nm, (prog, term, size) in self._dets:
+            val = eval_program(self.model, prog, term, x)
+            self.samples[nm][i : i + len(positions)] = np.broadcast_to(val, (len(positions), size)).reshape((len(positions), *self.var_shapes[nm]))
 
     def record_batch(self, positions: np.ndarray, stats_list: Sequence[Sequence[dict]], *, in_warmup: bool = False) -> None:
         """K raveled positions `(K, n)` in `model.value_vars` order (a multi-draw call of the device step) and their K stats
@@ -132,6 +152,8 @@ class NDArray:
         for nm, v, untransformed in self._layout:
             block = positions[:, v.offset : v.offset + v.size].reshape((K, *v.shape))
             self.samples[nm][i : i + K] = backward(v, block) if untransformed else block
+        if self._dets:
+            self._record_deterministics(positions, i)
         for k in range(K):
             self._store_stats(i + k, stats_list[k] if stats_list is not None else None)
         self.draw_idx += K

@@ -270,16 +270,73 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     if (f.dist < 0 || f.dist > NUTS_D_POISSON) { g_err = "factor with an unknown distribution code"; return false; }
     if (f.dist == NUTS_D_TRUNCNORMAL) {   // the bounds carry no gradient here: lower must be a constant (upper is `konst`)
       const nuts_term& lo = f.arg[3];
-      if (f.nargs != 4 || lo.a.kind == NUTS_OP_VAR || lo.b.kind == NUTS_OP_VAR || lo.c.kind == NUTS_OP_VAR) {
+      if (f.nargs != 4 || lo.a.kind >= NUTS_OP_VAR || lo.b.kind >= NUTS_OP_VAR || lo.c.kind >= NUTS_OP_VAR) {
         g_err = "TruncatedNormal: the bounds must be constants";
         return false;
       }
     }
     bool owned_already = false;
+    if (f.n_instr > 0) {
+      // ---- a factor with an expression program (include/nuts_mi355.h): one contribution per VARIABLE that occurs anywhere in
+      // its arguments or instructions (the device differentiates through the program, model_dev.h factor_eval_prog) ----
+      if (f.n_instr > NUTS_MAX_FACTOR_INSTR || f.instr_off < 0 || !s->instrs || (int64_t)f.instr_off + f.n_instr > s->n_instrs) {
+        g_err = "factor with a bad expression program (offset / length)"; return false;
+      }
+      std::vector<const nuts_operand*> ops;
+      for (int i = 0; i < f.n_instr; ++i) {
+        const nuts_instr& I = s->instrs[f.instr_off + i];
+        if (I.op < 0 || I.op > NUTS_E_POWC) { g_err = "expression program with an unknown opcode"; return false; }
+        const bool binary = I.op <= NUTS_E_DIV;
+        if ((I.x.kind == NUTS_OP_TMP && (I.x.ref < 0 || I.x.ref >= i)) || (binary && I.y.kind == NUTS_OP_TMP && (I.y.ref < 0 || I.y.ref >= i))) {
+          g_err = "expression program: an instruction may only use the results of earlier instructions"; return false;
+        }
+        ops.push_back(&I.x);
+        if (binary) ops.push_back(&I.y);
+      }
+      for (int a = 0; a < f.nargs; ++a)
+        for (const nuts_operand* o : {&f.arg[a].a, &f.arg[a].b, &f.arg[a].c}) {
+          if (o->kind == NUTS_OP_TMP && (o->ref < 0 || o->ref >= f.n_instr)) { g_err = "factor argument refers to a missing instruction"; return false; }
+          ops.push_back(o);
+        }
+      std::vector<int> seen;
+      for (const nuts_operand* o : ops) {
+        if (o->kind < NUTS_OP_CONST || o->kind > NUTS_OP_TMP) { g_err = "operand of an unknown kind"; return false; }
+        if (o->kind == NUTS_OP_DATA) {
+          if (o->ref < 0 || o->ref >= s->n_data) { g_err = "factor refers to a missing data vector"; return false; }
+          const int64_t ds = s->data[o->ref].size;
+          if (ds != 1 && ds != f.size) { g_err = "data vector does not broadcast against its factor"; return false; }
+        }
+        if (o->kind != NUTS_OP_VAR) continue;
+        if (o->ref < 0 || o->ref >= nv) { g_err = "factor refers to a missing variable"; return false; }
+        if (std::find(seen.begin(), seen.end(), o->ref) != seen.end()) continue;
+        seen.push_back(o->ref);
+        const VarDev& v = vars[o->ref];
+        if (v.size == f.size) {
+          Contrib cb{};
+          cb.f = fi; cb.arg = -1; cb.slot = -1; cb.owner = owned_already ? 0 : 1; cb.fast = 0; cb.dist = f.dist; cb.konst = f.konst;
+          per_var[o->ref].push_back(cb);
+          owned_already = true;
+        } else if (v.size == 1) {
+          int b = -1;
+          for (size_t t = 0; t < bterm_var.size(); ++t) if (bterm_var[t] == o->ref) b = (int)t;
+          if (b < 0) {
+            if ((int)bterm_var.size() >= MAX_BTERMS) { g_err = "too many scalar variables broadcast against vector factors (MAX_BTERMS)"; return false; }
+            b = (int)bterm_var.size();
+            bterm_var.push_back(o->ref);
+          }
+          if (fbt[fi].n >= MAX_FACTOR_BT) { g_err = "too many scalar operands in one factor (MAX_FACTOR_BT)"; return false; }
+          fbt[fi].e[fbt[fi].n].arg = -1; fbt[fi].e[fbt[fi].n].slot = -1; fbt[fi].e[fbt[fi].n].bterm = b;
+          fbt[fi].n++;
+        } else { g_err = "variable does not broadcast against its factor"; return false; }
+      }
+      if (!owned_already) orphans.push_back(fi);
+      continue;
+    }
     for (int a = 0; a < f.nargs; ++a) {
       const nuts_operand* ops[3] = {&f.arg[a].a, &f.arg[a].b, &f.arg[a].c};
       for (int sl = 0; sl < 3; ++sl) {
         const nuts_operand& o = *ops[sl];
+        if (o.kind == NUTS_OP_TMP) { g_err = "factor argument refers to an instruction but the factor has no program"; return false; }
         if (o.kind == NUTS_OP_DATA) {
           if (o.ref < 0 || o.ref >= s->n_data) { g_err = "factor refers to a missing data vector"; return false; }
           const int64_t ds = s->data[o.ref].size;
@@ -399,6 +456,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.po_btvar = put(bterm_var.data(), bterm_var.size() * sizeof(int32_t));
   md.po_data = put(s->data, (size_t)s->n_data * sizeof(nuts_data_ref));
   md.po_deferred = put(deferred.data(), deferred.size() * sizeof(int32_t));
+  md.po_instrs = put(s->instrs, s->instrs ? (size_t)std::max(s->n_instrs, 0) * sizeof(nuts_instr) : 0);
   blob.resize((blob.size() + 15) & ~(size_t)15, 0);
   md.prog_bytes = (int32_t)blob.size();
   md.prog = m->keep(dev_upload(blob.data(), blob.size()));

@@ -563,16 +563,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   // factors without an owning variable (only scalars and data): grid-stride over their elements
   for (int o = 0; o < md.n_orphans; ++o) {
     const int fi = md.orphans[o];
-    const nuts_factor& f = pg.factors[fi];
-    const FactorBT& bt = pg.fbt[fi];
-    for (int li = bid * VEC_THREADS + tid; li < f.size; li += nb * VEC_THREADS) {
-      double dv[4], bv[4], cv[4];
-      int pdead = 0;
-      double lpo = factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
-      factor_kill(pg, fi, pdead, lpo, dv);
-      lp += lpo;
-      for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm][tid] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
-    }
+    const int fsize = pg.factors[fi].size;
+    for (int li = bid * VEC_THREADS + tid; li < fsize; li += nb * VEC_THREADS) lp += orphan_element(pg, qv, fi, li, &s_bacc[0][tid], VEC_THREADS);
   }
 
   // ---- second half kick + tree-merge dot products (wave partials land in s_red) ----

@@ -145,7 +145,7 @@ struct ModelDev {
   int32_t lean_ok, lean_pad;
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
   const char* prog;
-  int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_deferred;
+  int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_deferred, po_instrs, po_pad;
   long long* ticks;           // [64] phase timestamps of the last B / C launch (only written in -DNUTS_KTIMING builds)
   int32_t tick_j;             // restrict the timestamps to leaf j of a doubling (-1: every leaf)
   // A failed PARAMETER check kills the reference's whole factor -- `check_parameters` reduces its conditions with `all`
@@ -214,6 +214,7 @@ __device__ __forceinline__ double deferred_finish(double gx_local, double S, dou
 // The interpreter's view of the model tables (LDS copy when it fits, the global blob otherwise).
 struct Prog {
   const VarDev* vars;
+  const nuts_instr* instrs;   // expression programs of the factors (nuts_factor.instr_off / n_instr)
   const int32_t* var_cptr;
   const Contrib* contrib;
   const nuts_factor* factors;
@@ -257,6 +258,7 @@ __device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog, cons
   pg.bterm_var = reinterpret_cast<const int32_t*>(base + md.po_btvar);
   pg.data = reinterpret_cast<const nuts_data_ref*>(base + md.po_data);
   pg.deferred = reinterpret_cast<const int32_t*>(base + md.po_deferred);
+  pg.instrs = reinterpret_cast<const nuts_instr*>(base + md.po_instrs);
   pg.pool = md.pool;
   pg.n_vars = md.n_vars;
   pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
@@ -544,6 +546,58 @@ __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, c
   return dist_eval(f.dist, f.konst, a, d, pdead);
 }
 
+// ---- expression programs (include/nuts_mi355.h): a factor whose arguments are not plain terms --------------------------------
+// Element `li` of a factor WITH a program: the instructions are interpreted in order (values `tv`), together with their
+// forward-mode tangents `tt` w.r.t. the constrained value of variable `wrt` (its own element if it is element-aligned with the
+// factor, the scalar itself if it broadcasts; wrt < 0: values only).  Returns the element's logp, d[k] = d logp / d arg_k and
+// darg[k] = d arg_k / d wrt -- the caller's chain rule is sum_k d[k] darg[k], then the variable's transform as everywhere else.
+// (not inlined, and its two 16-entry scratch arrays are indexed dynamically: only models that carry a program pay for them)
+__device__ __noinline__ double factor_eval_prog(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var, double own_x,
+                                                int wrt, double* d, double* darg, int* pdead) {
+  double tv[NUTS_MAX_FACTOR_INSTR], tt[NUTS_MAX_FACTOR_INSTR];
+  auto val = [&](const nuts_operand& o) { return o.kind == NUTS_OP_TMP ? tv[o.ref] : op_value(o, li, pg, qv, own_var, own_x); };
+  auto tan_ = [&](const nuts_operand& o) { return o.kind == NUTS_OP_TMP ? tt[o.ref] : ((o.kind == NUTS_OP_VAR && o.ref == wrt) ? 1.0 : 0.0); };
+  const nuts_instr* ins = pg.instrs + f.instr_off;
+  for (int i = 0; i < f.n_instr; ++i) {
+    const nuts_instr I = ins[i];
+    const double x = val(I.x), tx = tan_(I.x);
+    double v, t;
+    switch (I.op) {
+      case NUTS_E_ADD: { v = x + val(I.y); t = tx + tan_(I.y); } break;
+      case NUTS_E_SUB: { v = x - val(I.y); t = tx - tan_(I.y); } break;
+      case NUTS_E_MUL: { const double y = val(I.y); v = x * y; t = tx * y + x * tan_(I.y); } break;
+      case NUTS_E_DIV: { const double y = val(I.y); v = x / y; t = (tx - v * tan_(I.y)) / y; } break;
+      case NUTS_E_NEG: v = -x; t = -tx; break;
+      case NUTS_E_EXP: v = exp(x); t = v * tx; break;
+      case NUTS_E_LOG: v = log(x); t = tx / x; break;
+      case NUTS_E_LOG1P: v = log1p(x); t = tx / (1.0 + x); break;
+      case NUTS_E_SIGMOID: v = sigmoid_d(x); t = v * (1.0 - v) * tx; break;
+      case NUTS_E_SOFTPLUS: v = softplus_d(x); t = sigmoid_d(x) * tx; break;
+      case NUTS_E_SQRT: v = sqrt(x); t = 0.5 * tx / v; break;
+      case NUTS_E_SQR: v = x * x; t = 2.0 * x * tx; break;
+      case NUTS_E_RECIPROCAL: v = 1.0 / x; t = -tx * v * v; break;
+      case NUTS_E_TANH: v = tanh(x); t = (1.0 - v * v) * tx; break;
+      case NUTS_E_ABS: v = fabs(x); t = (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0)) * tx; break;
+      case NUTS_E_POWC: v = pow(x, I.k); t = I.k * pow(x, I.k - 1.0) * tx; break;
+      default: v = NAN; t = NAN;
+    }
+    tv[i] = v; tt[i] = t;
+  }
+  double a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < f.nargs) {
+      const nuts_term& tm = f.arg[k];
+      const double bv = val(tm.b), cv = val(tm.c);
+      a[k] = val(tm.a) + bv * cv;
+      darg[k] = tan_(tm.a) + tan_(tm.b) * cv + bv * tan_(tm.c);
+    } else { a[k] = 0.0; darg[k] = 0.0; }
+  }
+  return dist_eval(f.dist, f.konst, a, d, pdead);
+}
+
+__device__ __forceinline__ double dot4(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
 // what a failed parameter check of factor `f` means for the element just evaluated (ModelDev.fdead_mode)
 __device__ __forceinline__ void factor_kill(const Prog& pg, int f, int pdead, double& lpf, double* d) {
   if (pg.fdead_mode == 0) return;
@@ -584,6 +638,25 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       continue;
     }
     const nuts_factor& f = pg.factors[cb.f];
+    if (f.n_instr > 0) {   // expression program: the tangent of the arguments w.r.t. this variable, through the program
+      double d[4], darg[4];
+      int pdead = 0;
+      double lpf = factor_eval_prog(pg, qv, f, li, k, x, k, d, darg, &pdead);
+      factor_kill(pg, cb.f, pdead, lpf, d);
+      gx += dot4(d, darg);
+      if (cb.owner) {
+        lp += lpf;
+        const FactorBT& bt = pg.fbt[cb.f];
+        for (int b = 0; b < bt.n; ++b) {   // scalars that broadcast into this factor: one more pass per scalar
+          double d2[4], da2[4];
+          int pd2 = 0;
+          double l2 = factor_eval_prog(pg, qv, f, li, k, x, pg.bterm_var[bt.e[b].bterm], d2, da2, &pd2);
+          factor_kill(pg, cb.f, pd2, l2, d2);
+          s_bacc[bt.e[b].bterm * bstride] += dot4(d2, da2);
+        }
+      }
+      continue;
+    }
     double d[4], bv[4], cv[4];
     int pdead = 0;
     double lpf = factor_eval(pg, qv, f, li, k, x, d, bv, cv, &pdead);
@@ -595,4 +668,29 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm * bstride] += slot_grad(d, bv, cv, bt.e[b].arg, bt.e[b].slot);
     }
   }
+}
+
+// One element of a factor WITHOUT an owning variable (only scalars and data): its logp and the broadcast terms of its scalars.
+// Shared by the orphan loops of kernel B (kernels.h) and of the single-workgroup kernel (small_kernel.h).
+__device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv, int fi, int li, double* s_bacc, int bstride) {
+  const nuts_factor& f = pg.factors[fi];
+  const FactorBT& bt = pg.fbt[fi];
+  if (f.n_instr > 0) {
+    double lpo = 0.0;
+    for (int b = 0; b < (bt.n > 0 ? bt.n : 1); ++b) {
+      double d[4], darg[4];
+      int pdead = 0;
+      const int wrt = bt.n > 0 ? pg.bterm_var[bt.e[b].bterm] : -1;
+      lpo = factor_eval_prog(pg, qv, f, li, -1, 0.0, wrt, d, darg, &pdead);
+      factor_kill(pg, fi, pdead, lpo, d);
+      if (bt.n > 0) s_bacc[bt.e[b].bterm * bstride] += dot4(d, darg);
+    }
+    return lpo;
+  }
+  double dv[4], bv[4], cv[4];
+  int pdead = 0;
+  double lpo = factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
+  factor_kill(pg, fi, pdead, lpo, dv);
+  for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm * bstride] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
+  return lpo;
 }

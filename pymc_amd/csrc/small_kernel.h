@@ -87,16 +87,8 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
     }
     for (int o = 0; o < md.n_orphans; ++o) {   // factors without an owning variable
       const int fi = md.orphans[o];
-      const nuts_factor& f = pg.factors[fi];
-      const FactorBT& bt = pg.fbt[fi];
-      for (int li = tid; li < f.size; li += NT) {
-        double dv[4], bv[4], cv[4];
-        int pdead = 0;
-        double lpo = factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
-        factor_kill(pg, fi, pdead, lpo, dv);
-        lp += lpo;
-        for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm][tid] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
-      }
+      const int fsize = pg.factors[fi].size;
+      for (int li = tid; li < fsize; li += NT) lp += orphan_element(pg, qv, fi, li, &s_bacc[0][tid], NT);
     }
     for (int b = 0; b < md.n_bterms; ++b) {   // scalars that broadcast against vector factors
       const double t = block_sum<true>(s_bacc[b][tid], s_w);

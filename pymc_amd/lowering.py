@@ -697,16 +697,58 @@ class _Lowering:
                     b, c = self._operand(y[1]), self._operand(y[2])
                     if b is not None and c is not None:
                         return ms.Term(a, b, c)
-        raise NotLowerable(f"expression is outside the affine IR `a + b*c`: {_show(node)}")
+        # not affine: an expression program of the factor being lowered (include/nuts_mi355.h, "Expression programs")
+        return ms.Term(self._program(node))
+
+    _PROG_OPS = {"add": ms.E_ADD, "sub": ms.E_SUB, "mul": ms.E_MUL, "div": ms.E_DIV, "neg": ms.E_NEG, "exp": ms.E_EXP, "log": ms.E_LOG,
+                 "log1p": ms.E_LOG1P, "sigmoid": ms.E_SIGMOID, "softplus": ms.E_SOFTPLUS, "sqrt": ms.E_SQRT, "sqr": ms.E_SQR,
+                 "reciprocal": ms.E_RECIPROCAL, "tanh": ms.E_TANH, "abs": ms.E_ABS}
+
+    def _program(self, node) -> ms.Operand:
+        """Expression tree -> instructions of the current factor's program; returns the operand that holds the node's value.
+        Leaves are what `_operand` accepts (constants, data, the CONSTRAINED value of a variable); shared sub-trees (the walker's
+        memo hands the same tuple back) are emitted once."""
+        if self._prog is None:
+            raise NotLowerable(f"expression is outside the affine IR `a + b*c`: {_show(node)}")
+        o = self._operand(node)
+        if o is not None:
+            return o
+        if id(node) in self._prog_memo:
+            return self._prog_memo[id(node)]
+        op = node[0]
+        k = 0.0
+        if op == "pow":
+            e = _num(node[2])
+            if e is None:
+                raise NotLowerable(f"a power with a non-constant exponent: {_show(node)}")
+            kids = [self._program(node[1])]
+            code, k = (ms.E_SQR, 0.0) if e == 2.0 else (ms.E_POWC, e)
+        elif op in self._PROG_OPS:
+            kids = [self._program(x) for x in node[1:]]
+            code = self._PROG_OPS[op]
+        elif op == "input":
+            raise NotLowerable(f"the unconstrained value of transformed variable {getattr(node[1], 'name', '?')} inside an expression")
+        else:
+            raise NotLowerable(f"expression is outside the affine IR `a + b*c` and the expression programs: {_show(node)}")
+        if len(self._prog) >= ms.MAX_FACTOR_INSTR:
+            raise NotLowerable(f"expression needs more than {ms.MAX_FACTOR_INSTR} instructions in one factor: {_show(node)}")
+        self._prog.append(ms.Instr(code, kids[0], kids[1] if len(kids) > 1 else ms.ZERO, k))
+        self._prog_size.append(max(self._osize(x) for x in kids))
+        out = ms.Operand(ms.OP_TMP, 0.0, len(self._prog) - 1)
+        self._prog_memo[id(node)] = out
+        return out
+
+    def _osize(self, o: ms.Operand) -> int:
+        if o.kind == ms.OP_VAR:
+            return self.spec.vars[o.ref].size
+        if o.kind == ms.OP_DATA:
+            return self.spec.data[o.ref].size
+        if o.kind == ms.OP_TMP:
+            return self._prog_size[o.ref]
+        return 1
 
     def _size(self, t: ms.Term) -> int:
-        n = 1
-        for o in (t.a, t.b, t.c):
-            if o.kind == ms.OP_VAR:
-                n = max(n, self.spec.vars[o.ref].size)
-            elif o.kind == ms.OP_DATA:
-                n = max(n, self.spec.data[o.ref].size)
-        return n
+        return max(self._osize(o) for o in (t.a, t.b, t.c))
 
     # Jacobian term of a transformed value variable, added to its own factor (logprob/basic.py:618-667)
     def _strip_jacobian(self, node, own: Optional[int]):
@@ -757,7 +799,19 @@ class _Lowering:
                     return True
         return False
 
+    _prog = None
+
     def factor(self, node, name: str, own_value=None):
+        self._prog, self._prog_size, self._prog_memo = [], [], {}
+        try:
+            self._factor(node, name, own_value)
+        finally:
+            self._prog = None
+
+    def _emit(self, dist, args, konst, name):
+        self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), tuple(args), konst, name, tuple(self._prog)))
+
+    def _factor(self, node, name: str, own_value=None):
         own = self.var_id.get(id(own_value)) if own_value is not None else None
         node = self._strip_jacobian(node, own)
         for dist, tmpl, argnames in TEMPLATES:
@@ -774,7 +828,7 @@ class _Lowering:
                     return
                 t_eta = self.term(env["p"][1])
                 args = (self.term(val), t_eta)
-                self.spec.factors.append(ms.Factor(ms.D_BERNOULLI_LOGIT, max(self._size(a) for a in args), args, 0.0, name))
+                self._emit(ms.D_BERNOULLI_LOGIT, args, 0.0, name)
                 return
             lam_direct = None
             if dist == ms.D_EXPONENTIAL and env["mu"][0] == "reciprocal":
@@ -792,14 +846,14 @@ class _Lowering:
                 if not (mu.b == ms.ZERO or mu.c == ms.ZERO) or mu.a.kind != ms.OP_CONST:
                     raise NotLowerable("Exponential with a non-constant scale")
                 args = (args[0], ms.Term(ms.Operand(ms.OP_CONST, 1.0 / mu.a.c)))
-            self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), args, 0.0, name))
+            self._emit(dist, args, 0.0, name)
             return
         tn = _match_truncnormal(node)
         if tn is not None:
             vnode, mu_n, sg_n, lo, hi = tn
             t_mu, t_sg = self.term(mu_n), self.term(sg_n)
             args = (self.term(vnode), t_mu, t_sg, ms.Term(ms.Operand(ms.OP_CONST, -math.inf if lo is None else lo)))
-            self.spec.factors.append(ms.Factor(ms.D_TRUNCNORMAL, max(self._size(a) for a in args), args, math.inf if hi is None else hi, name))
+            self._emit(ms.D_TRUNCNORMAL, args, math.inf if hi is None else hi, name)
             return
         for dist, tmpl, argnames, post in TEMPLATES_POST:
             env = {}
@@ -811,11 +865,11 @@ class _Lowering:
             nodes, konst = res
             lowered = {a: self.term(nodes[a]) for a in argnames[1:] + argnames[:1]}
             args = tuple(lowered[a] for a in argnames)
-            self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), args, konst, name))
+            self._emit(dist, args, konst, name)
             return
         # a potential: the expression itself is the contribution (model/core.py:666-695)
         t = self.term(node)
-        self.spec.factors.append(ms.Factor(ms.D_POTENTIAL, self._size(t), (t,), 0.0, name))
+        self._emit(ms.D_POTENTIAL, (t,), 0.0, name)
 
 
 def _show(node, depth=0) -> str:

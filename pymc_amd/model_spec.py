@@ -35,7 +35,14 @@ TR_NONE, TR_LOG, TR_LOGODDS, TR_INTERVAL = 0, 1, 2, 3
 TRANSFORM_NAMES = {TR_NONE: None, TR_LOG: "log", TR_LOGODDS: "logodds", TR_INTERVAL: "interval"}
 
 # operand kinds
-OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
+OP_CONST, OP_DATA, OP_VAR, OP_TMP = 0, 1, 2, 3
+
+# expression-program opcodes (must match include/nuts_mi355.h NUTS_E_*)
+(E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC) = range(16)
+E_NAMES = {"add": E_ADD, "sub": E_SUB, "mul": E_MUL, "div": E_DIV, "neg": E_NEG, "exp": E_EXP, "log": E_LOG, "log1p": E_LOG1P, "sigmoid": E_SIGMOID,
+           "softplus": E_SOFTPLUS, "sqrt": E_SQRT, "sqr": E_SQR, "reciprocal": E_RECIPROCAL, "tanh": E_TANH, "abs": E_ABS, "pow": E_POWC}
+E_BINARY = (E_ADD, E_SUB, E_MUL, E_DIV)
+MAX_FACTOR_INSTR = 16
 
 # distribution codes (must match include/nuts_mi355.h)
 (
@@ -100,6 +107,16 @@ class Term:
     c: Operand = ZERO
 
 
+@dataclass(frozen=True)
+class Instr:
+    """tmp[i] = op(x, y), element-wise over the factor's elements (size-1 operands broadcast); unary ops ignore y."""
+
+    op: int
+    x: Operand = ZERO
+    y: Operand = ZERO
+    k: float = 0.0
+
+
 @dataclass
 class FreeVar:
     """One value variable (a slice of the raveled vector)."""
@@ -129,6 +146,8 @@ class Factor:
     args: Tuple[Term, ...]  # args[0] is the value
     konst: float = 0.0  # parameter-only normaliser precomputed on host (lgamma terms)
     name: str = ""
+    # expression program (include/nuts_mi355.h, "Expression programs"): what the arguments' OP_TMP operands refer to
+    prog: Tuple[Instr, ...] = ()
 
 
 @dataclass
@@ -172,6 +191,9 @@ class ModelSpec:
     # mixture assignments sampled by another step method (pymc_amd/gibbs.py): extras of this spec that are FUNCTIONS of that
     # variable (`mixture.extras_for(point[mixture.name])`) rather than entries of the point
     mixture: Optional[object] = None
+    # `pm.Deterministic(name, expr)` (model/core.py:1940-2005): named functions of the variables, evaluated for the trace
+    # (backends/base.py:183-191 records them next to the untransformed variables): name -> (program, result term, size)
+    deterministics: Dict[str, Tuple[Tuple["Instr", ...], "Term", int]] = field(default_factory=dict)
 
     @property
     def n(self) -> int:
@@ -189,20 +211,39 @@ class ModelSpec:
 
 
 class Expr:
-    """An affine expression over model quantities (at most ``a + b*c``)."""
+    """An expression over model quantities: an affine term ``a + b*c`` where it can be one (then `term` is it and nothing else is
+    stored), otherwise a node ``op(x, y)`` over other expressions (`node`), which `ModelBuilder` turns into the factor's
+    expression program (include/nuts_mi355.h)."""
 
-    def __init__(self, builder: "ModelBuilder", term: Term, size: int):
-        self._b, self.term, self.size = builder, term, size
+    def __init__(self, builder: "ModelBuilder", term: Optional[Term], size: int, node=None):
+        self._b, self._term, self.size, self.node = builder, term, size, node
+
+    @property
+    def term(self) -> Term:
+        if self.node is not None:
+            raise NotImplementedError("expression is outside the affine IR `a + b*c`: it needs an expression program (handled by the "
+                                      "distribution / Potential / Deterministic it is handed to)")
+        return self._term
+
+    @classmethod
+    def op(cls, builder, opcode, x, y=None, k=0.0):
+        x = builder.as_expr(x)
+        y = builder.as_expr(y) if y is not None else None
+        return cls(builder, None, max(x.size, y.size if y is not None else 1), (opcode, x, y, float(k)))
 
     # -- helpers -----------------------------------------------------------
     def _simple(self) -> Optional[Operand]:
-        t = self.term
+        if self.node is not None:
+            return None
+        t = self._term
         if t.b == ZERO or t.c == ZERO:
             return t.a
         return None
 
     def _product(self) -> Optional[Tuple[Operand, Operand]]:
-        t = self.term
+        if self.node is not None:
+            return None
+        t = self._term
         if t.a == ZERO:
             return t.b, t.c
         return None
@@ -219,7 +260,7 @@ class Expr:
             return Expr(self._b, Term(s, *other._product()), size)
         if o is not None and self._product() is not None:
             return Expr(self._b, Term(o, *self._product()), size)
-        raise NotImplementedError("expression is outside the affine IR `a + b*c` (graph lowering is a next row)")
+        return Expr.op(self._b, E_ADD, self, other)
 
     __radd__ = __add__
 
@@ -231,9 +272,95 @@ class Expr:
             if s.kind == OP_CONST and o.kind == OP_CONST:
                 return Expr(self._b, Term(Operand(OP_CONST, s.c * o.c)), size)
             return Expr(self._b, Term(ZERO, s, o), size)
-        raise NotImplementedError("expression is outside the affine IR `a + b*c` (graph lowering is a next row)")
+        return Expr.op(self._b, E_MUL, self, other)
 
     __rmul__ = __mul__
+
+    def __sub__(self, other):
+        other = self._b.as_expr(other)
+        o = other._simple()
+        if o is not None and o.kind == OP_CONST:
+            return self + (-o.c)
+        if o is not None and self._simple() is not None:
+            return Expr(self._b, Term(self._simple(), Operand(OP_CONST, -1.0), o), max(self.size, other.size))
+        return Expr.op(self._b, E_SUB, self, other)
+
+    def __rsub__(self, other):
+        return self._b.as_expr(other) - self
+
+    def __neg__(self):
+        s = self._simple()
+        if s is not None:
+            return Expr(self._b, Term(ZERO, Operand(OP_CONST, -1.0), s), self.size) if s.kind != OP_CONST else Expr(self._b, Term(Operand(OP_CONST, -s.c)), self.size)
+        return Expr.op(self._b, E_NEG, self)
+
+    def __truediv__(self, other):
+        other = self._b.as_expr(other)
+        o = other._simple()
+        if o is not None and o.kind == OP_CONST:
+            return self * (1.0 / o.c)
+        return Expr.op(self._b, E_DIV, self, other)
+
+    def __rtruediv__(self, other):
+        return Expr.op(self._b, E_DIV, self._b.as_expr(other), self)
+
+    def __pow__(self, k):
+        if float(k) == 2.0:
+            return Expr.op(self._b, E_SQR, self)
+        return Expr.op(self._b, E_POWC, self, None, float(k))
+
+
+class _Math:
+    """`pm.math.*` (pymc/math.py) for builder expressions."""
+
+    def __init__(self, builder):
+        self._b = builder
+
+    def _un(self, opcode, x):
+        return Expr.op(self._b, opcode, x)
+
+    def exp(self, x): return self._un(E_EXP, x)
+    def log(self, x): return self._un(E_LOG, x)
+    def log1p(self, x): return self._un(E_LOG1P, x)
+    def sigmoid(self, x): return self._un(E_SIGMOID, x)
+    invlogit = sigmoid
+    def softplus(self, x): return self._un(E_SOFTPLUS, x)
+    def sqrt(self, x): return self._un(E_SQRT, x)
+    def sqr(self, x): return self._un(E_SQR, x)
+    def tanh(self, x): return self._un(E_TANH, x)
+    def abs(self, x): return self._un(E_ABS, x)
+    def reciprocal(self, x): return self._un(E_RECIPROCAL, x)
+
+
+def eval_program(spec: "ModelSpec", prog, term: Term, x: np.ndarray) -> np.ndarray:
+    """Value of `term` over the expression program `prog` at the CONSTRAINED values `x` (raveled, spec layout).  Host arithmetic
+    for the trace's Deterministics only -- the log-density's programs are interpreted on the device."""
+    tmp: List[np.ndarray] = []
+
+    def val(o: Operand):
+        if o.kind == OP_CONST:
+            return np.asarray(o.c)
+        if o.kind == OP_DATA:
+            d = spec.data[o.ref]
+            return d if d.size > 1 else d.reshape(())
+        if o.kind == OP_TMP:
+            return tmp[o.ref]
+        v = spec.vars[o.ref]
+        blk = x[..., v.offset : v.offset + v.size]
+        return blk if v.size > 1 else blk[..., 0:1] if x.ndim > 1 else blk.reshape(())
+
+    un = {E_NEG: np.negative, E_EXP: np.exp, E_LOG: np.log, E_LOG1P: np.log1p, E_SIGMOID: lambda a: 1.0 / (1.0 + np.exp(-a)),
+          E_SOFTPLUS: lambda a: np.logaddexp(0.0, a), E_SQRT: np.sqrt, E_SQR: np.square, E_RECIPROCAL: np.reciprocal, E_TANH: np.tanh, E_ABS: np.abs}
+    bi = {E_ADD: np.add, E_SUB: np.subtract, E_MUL: np.multiply, E_DIV: np.divide}
+    with np.errstate(all="ignore"):
+        for ins in prog:
+            if ins.op in bi:
+                tmp.append(bi[ins.op](val(ins.x), val(ins.y)))
+            elif ins.op == E_POWC:
+                tmp.append(np.power(val(ins.x), ins.k))
+            else:
+                tmp.append(un[ins.op](val(ins.x)))
+        return np.asarray(val(term.a) + val(term.b) * val(term.c), dtype="float64")
 
 
 _DEFAULT_TRANSFORM = {
@@ -255,6 +382,47 @@ class ModelBuilder:
     def __init__(self):
         self.spec = ModelSpec()
         self._names: Dict[str, Expr] = {}
+        self.math = _Math(self)
+
+    # -- expression programs -------------------------------------------------
+    def _lower_args(self, exprs: List[Expr]):
+        """[Expr] -> (terms, program): affine expressions stay plain terms; the others become instructions of ONE program shared by
+        the factor's arguments (common sub-expressions, by identity, are emitted once)."""
+        prog: List[Instr] = []
+        memo: Dict[int, Operand] = {}
+
+        def emit(op, x, y=ZERO, k=0.0) -> Operand:
+            prog.append(Instr(op, x, y, k))
+            if len(prog) > MAX_FACTOR_INSTR:
+                raise NotImplementedError(f"expression needs more than {MAX_FACTOR_INSTR} instructions in one factor")
+            return Operand(OP_TMP, 0.0, len(prog) - 1)
+
+        def operand(e: Expr) -> Operand:
+            if e.node is None:
+                s_ = e._simple()
+                if s_ is not None:
+                    return s_
+                t = e._term
+                if t.c == ONE or t.b == ONE:           # a + b: one instruction
+                    return emit(E_ADD, t.a, t.b if t.c == ONE else t.c)
+                prod = emit(E_MUL, t.b, t.c)
+                return prod if t.a == ZERO else emit(E_ADD, t.a, prod)
+            if id(e) in memo:
+                return memo[id(e)]
+            op, x, y, k = e.node
+            out = emit(op, operand(x), operand(y) if y is not None else ZERO, k)
+            memo[id(e)] = out
+            return out
+
+        terms = [e._term if e.node is None else Term(operand(e)) for e in exprs]
+        return tuple(terms), tuple(prog)
+
+    def Deterministic(self, name, expr):
+        """`pm.Deterministic(name, expr)` (model/core.py:1940-2005): recorded in the trace, no contribution to the log-density."""
+        e = self.as_expr(expr)
+        (term,), prog = self._lower_args([e])
+        self.spec.deterministics[name] = (prog, term, e.size)
+        return e
 
     # -- operands ----------------------------------------------------------
     def as_expr(self, x) -> Expr:
@@ -277,7 +445,8 @@ class ModelBuilder:
     def Potential(self, name, expr):
         """`pm.Potential(name, expr)`: adds sum(expr) to the joint log-density (model/core.py:666-695)."""
         e = self.as_expr(expr)
-        self.spec.factors.append(Factor(D_POTENTIAL, e.size, (e.term,), 0.0, name))
+        terms, prog = self._lower_args([e])
+        self.spec.factors.append(Factor(D_POTENTIAL, e.size, terms, 0.0, name, prog))
         return None
 
     def _register(self, dist, name, params, shape, observed, transform, bounds=(0.0, 1.0), konst=0.0):
@@ -288,7 +457,8 @@ class ModelBuilder:
                 self.spec.data.append(np.array([val.term.a.c]))
                 val = Expr(self, Term(Operand(OP_DATA, 0.0, len(self.spec.data) - 1)), 1)
             size = max([val.size] + [p.size for p in params])
-            self.spec.factors.append(Factor(dist, size, (val.term, *[p.term for p in params]), konst, name))
+            terms, prog = self._lower_args([val, *params])
+            self.spec.factors.append(Factor(dist, size, terms, konst, name, prog))
             return None
         if shape is None:
             shape = ()
@@ -302,7 +472,8 @@ class ModelBuilder:
         for p in params:
             if p.size not in (1, var.size):
                 raise ValueError(f"parameter of size {p.size} does not broadcast to {name} of size {var.size}")
-        self.spec.factors.append(Factor(dist, var.size, (e.term, *[p.term for p in params]), konst, name))
+        terms, prog = self._lower_args([e, *params])
+        self.spec.factors.append(Factor(dist, var.size, terms, konst, name, prog))
         self._names[name] = e
         return e
 

@@ -28,6 +28,9 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
     for i, v in enumerate(spec.vars):
         vars_c[i] = _lib.Var(v.offset, v.size, v.transform, 0, v.lower, v.upper)
     fac_c = (_lib.Factor * max(nf, 1))()
+    n_instr = sum(len(getattr(f, "prog", ())) for f in spec.factors)
+    ins_c = (_lib.Instr * max(n_instr, 1))()
+    ioff = 0
     for i, f in enumerate(spec.factors):
         fc = _lib.Factor()
         fc.dist, fc.size, fc.nargs, fc.konst = f.dist, f.size, len(f.args), f.konst
@@ -35,6 +38,11 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
             for nm in ("a", "b", "c"):
                 o = getattr(t, nm)
                 setattr(fc.arg[k], nm, _lib.Operand(o.kind, max(o.ref, 0), o.c))
+        prog = getattr(f, "prog", ())
+        fc.n_instr, fc.instr_off = len(prog), ioff
+        for ins in prog:
+            ins_c[ioff] = _lib.Instr(ins.op, 0, ins.k, _lib.Operand(ins.x.kind, max(ins.x.ref, 0), ins.x.c), _lib.Operand(ins.y.kind, max(ins.y.ref, 0), ins.y.c))
+            ioff += 1
         fac_c[i] = fc
     refs = (_lib.DataRef * max(nd, 1))()
     off = 0
@@ -42,8 +50,9 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
         refs[i] = _lib.DataRef(off, d.size)
         off += d.size
     pool = np.concatenate(spec.data).astype("float64") if nd else np.zeros(1)
-    keep += [vars_c, fac_c, refs, pool]
+    keep += [vars_c, fac_c, refs, pool, ins_c]
     s = _lib.ModelSpecC()
+    s.instrs, s.n_instrs = (ins_c if n_instr else None), n_instr
     s.n_vars, s.n_factors, s.n_data = nv, nf, nd
     s.vars, s.factors, s.data = vars_c, fac_c, refs
     s.data_pool, s.data_pool_len = _lib.dptr(pool), off

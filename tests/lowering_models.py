@@ -112,6 +112,44 @@ def cauchy_exponential(b=None):
     return m
 
 
+XS = np.linspace(-1.5, 2.0, 40)
+YC = np.random.default_rng(11).poisson(np.exp(0.3 + 0.5 * XS)).astype("float64")
+Y5 = np.array([0.4, -0.9, 1.7, 0.2, -0.3])
+
+
+def poisson_loglink(b=None):
+    """A Poisson regression with a log link, the rate a named Deterministic: `exp(a + b x)` is not of the form
+    `a + b*c`, so the factor carries an expression program."""
+    m = b or sg.StubModel()
+    a = m.Normal("a", 0.0, 2.0)
+    bb = m.Normal("b", 0.0, 2.0)
+    rate = m.Deterministic("rate", m.math.exp(a + bb * XS))
+    m.Poisson("y", rate, observed=YC)
+    return m
+
+
+def hier_normal_exp_sigma(b=None):
+    """A hierarchical Normal whose scale is written as an EXPRESSION, exp(log_sigma) of an untransformed variable (not a value
+    transform): a scalar that broadcasts into a vector factor through an expression program."""
+    m = b or sg.StubModel()
+    mu = m.Normal("mu", 0.0, 5.0)
+    ls = m.Normal("log_sigma", 0.0, 1.0)
+    x = m.Normal("x", mu, m.math.exp(ls), shape=(5,))
+    m.Normal("y", x, 0.7, observed=Y5)
+    return m
+
+
+def cubic_and_friends(b=None):
+    """Products of three quantities, a ratio, a softplus and a power inside distribution arguments."""
+    m = b or sg.StubModel()
+    a = m.Normal("a", 0.0, 1.0, shape=(4,))
+    bq = m.Normal("b", 0.0, 1.0, shape=(4,))
+    c = m.HalfNormal("c", 1.0)
+    m.Normal("y", a * bq * c + a, m.math.softplus(bq) + 0.5, observed=Y4)
+    m.Normal("w", (a / (1.0 + c)) ** 2, 1.5, observed=Y4)
+    return m
+
+
 def _built(fn, *a):
     return fn(*a, ModelBuilder()).build()
 
@@ -131,5 +169,8 @@ ENTRIES = {
     "truncated_upper": (lambda: truncated(dict(upper=1.5)), lambda: _built(truncated, dict(upper=1.5))),
     "truncated_free": (truncated_free, lambda: _built(truncated_free)),
     "cauchy_exponential": (cauchy_exponential, lambda: _built(cauchy_exponential)),
+    "poisson_loglink": (poisson_loglink, lambda: _built(poisson_loglink)),
+    "hier_normal_exp_sigma": (hier_normal_exp_sigma, lambda: _built(hier_normal_exp_sigma)),
+    "cubic_and_friends": (cubic_and_friends, lambda: _built(cubic_and_friends)),
 }
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")

@@ -408,11 +408,27 @@ def _dist(name, *args, **kw):
     return reference()[name].dist(*args, **kw)
 
 
+class _PtMath:
+    """`pm.math.*` as the model code calls it: the `pytensor.tensor` functions of the same name (pymc/math.py re-exports them)."""
+
+    exp, log, log1p, sqrt, abs = pt.exp, pt.log, pt.log1p, pt.sqrt, pt.abs
+    sigmoid = invlogit = pt.sigmoid
+    softplus, sqr = pt.softplus, pt.sqr
+
+
 class StubModel:
     """`with pm.Model(): ...` reduced to what the lowering reads."""
 
+    math = _PtMath
+
     def __init__(self):
         self.free, self.obs, self.pots = [], [], []
+        self.deterministics = {}
+
+    def Deterministic(self, name, expr):
+        """`pm.Deterministic` (model/core.py:1940-2005): a name for an expression; the log-density graph contains the expression."""
+        self.deterministics[name] = expr
+        return expr
 
     def _add(self, rv):
         (self.free if rv.observed is None else self.obs).append(rv)

@@ -52,7 +52,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
     from pymc_amd import _lib
 
     structs = {
-        "nuts_operand": _lib.Operand, "nuts_term": _lib.Term, "nuts_factor": _lib.Factor, "nuts_var": _lib.Var,
+        "nuts_operand": _lib.Operand, "nuts_term": _lib.Term, "nuts_instr": _lib.Instr, "nuts_factor": _lib.Factor, "nuts_var": _lib.Var,
         "nuts_data_ref": _lib.DataRef, "nuts_model_spec": _lib.ModelSpecC, "nuts_chain_config": _lib.ChainConfig,
         "nuts_draw_stats": _lib.DrawStats, "nuts_hmc_stats": _lib.HmcStats,
     }

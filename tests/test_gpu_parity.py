@@ -1283,3 +1283,66 @@ def test_chains_in_worker_processes_equal_the_sequential_chains():
             for k in INT_KEYS + ("energy", "step_size"):
                 assert x[k] == y[k], k
     a["step"].close(); b["step"].close()
+
+
+# ---------------------------------------------------------------------------
+# expression programs (include/nuts_mi355.h): arguments that are not `a + b*c`
+# ---------------------------------------------------------------------------
+def _expr_models():
+    """Models whose factors carry expression programs, small (single-workgroup kernel) and wide (three-kernel pipeline: the
+    interpreter of kernel B, broadcast terms across workgroups, deferred scalars in the control kernel, an orphan factor)."""
+    rng = np.random.default_rng(21)
+    out = {}
+    xs = np.linspace(-1.5, 2.0, 40)
+    yc = rng.poisson(np.exp(0.3 + 0.5 * xs)).astype("float64")
+    m = ModelBuilder()                                       # Poisson regression, log link behind a Deterministic (orphan factor: scalars + data only)
+    a, b = m.Normal("a", 0.0, 2.0), m.Normal("b", 0.0, 2.0)
+    m.Poisson("y", m.Deterministic("rate", m.math.exp(a + b * xs)), observed=yc)
+    out["poisson_loglink"] = m.build()
+    m = ModelBuilder()                                       # hierarchical Normal, scale = exp(log_sigma) as an expression
+    mu, ls = m.Normal("mu", 0.0, 5.0), m.Normal("log_sigma", 0.0, 1.0)
+    x = m.Normal("x", mu, m.math.exp(ls), shape=(5,))
+    m.Normal("y", x, 0.7, observed=np.array([0.4, -0.9, 1.7, 0.2, -0.3]))
+    out["hier_normal_exp_sigma"] = m.build()
+    n = 3000                                                 # the same two ideas on 3000 elements: several workgroups of kernel B
+    xw = rng.normal(size=n)
+    m = ModelBuilder()
+    mu, ls = m.Normal("mu", 0.0, 5.0), m.Normal("log_sigma", 0.0, 1.0)
+    x = m.Normal("x", mu, m.math.exp(ls), shape=(n,))
+    slope = m.HalfNormal("slope", 1.0)
+    rate = m.math.exp(0.1 * x + slope * xw * 0.2)
+    m.Poisson("cnt", rate, observed=rng.poisson(1.5, size=n).astype("float64"))
+    m.Normal("w", m.math.tanh(x) * slope + m.math.softplus(x) / (1.0 + m.math.sqr(x)), m.math.sqrt(1.0 + m.math.sqr(x * 0.3)), observed=rng.normal(size=n))
+    out["wide"] = m.build()
+    return out
+
+
+@pytest.mark.parametrize("name", ["poisson_loglink", "hier_normal_exp_sigma", "wide"])
+def test_expression_programs_logp_grad_and_nuts(name):
+    """logp / gradient of models with expression programs against the oracle (whose programs are pinned against
+    torch autograd of the models written directly in torch, tests/test_lowering.py) to 1e-9, and a NUTS run with the oracle
+    sampler's integers."""
+    spec = _expr_models()[name]
+    assert any(f.prog for f in spec.factors)
+    rng = np.random.default_rng(5)
+    _check_logp_grad(spec, [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.5 for _ in range(4)])
+    _compare_runs(spec, tune=25, draws=10, seed=4, prefix=25 if name == "wide" else 35)
+
+
+def test_expression_program_models_lowered_from_the_reference_graphs():
+    """The committed graphs the reference's code built for the expression-program models (tests/golden/ref_graphs.npz), lowered and
+    evaluated on the device against the oracle."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lowering_models as lm
+    import stubgraph as sg
+
+    from pymc_amd.lowering import lower_to_spec
+
+    committed = sg.load_models(lm.FIXTURE)
+    rng = np.random.default_rng(6)
+    for name in ("poisson_loglink", "hier_normal_exp_sigma", "cubic_and_friends"):
+        spec = lower_to_spec(sg.FrozenModel(committed[name]))
+        assert any(f.prog for f in spec.factors)
+        _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.5 for _ in range(3)])

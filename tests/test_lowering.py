@@ -98,11 +98,77 @@ def test_tree_building_strips_broadcasts_and_checks_and_folds_constants():
 def test_what_the_ir_cannot_express_is_refused_by_name():
     m = sg.StubModel()
     a = m.Normal("a", 0.0, 1.0, shape=(4,))
-    b = m.Normal("b", 0.0, 1.0, shape=(4,))
-    c = m.Normal("c", 0.0, 1.0, shape=(4,))
-    m.Normal("y", a * b * c + a, 1.0, observed=np.zeros(4))    # a cubic term: outside `a + b*c`
-    with pytest.raises(NotLowerable, match="affine IR"):
+    b = m.HalfNormal("b", 1.0, shape=(4,))
+    m.Normal("y", a ** b, 1.0, observed=np.zeros(4))           # a power with a VARIABLE exponent
+    with pytest.raises(NotLowerable, match="non-constant exponent"):
         lower_to_spec(m)
+    m = sg.StubModel()
+    z = m.Normal("z", 0.0, 1.0, shape=(3,))
+    m.Normal("y", z[np.array([0, 2, 1, 1])], 1.0, observed=np.zeros(4))   # a gather outside the hierarchical-logit pattern
+    with pytest.raises(NotLowerable):
+        lower_to_spec(m)
+
+
+def _torch_reference(name, q):
+    """The three expression-program models written directly in torch (independent of spec, oracle and lowering): joint logp with
+    Jacobians at the raveled unconstrained q, and its autograd gradient."""
+    import torch
+
+    t = torch.tensor(q, dtype=torch.float64, requires_grad=True)
+    c64 = lambda v: v if torch.is_tensor(v) else torch.tensor(v, dtype=torch.float64)   # noqa: E731 (Python floats would become float32 parameters)
+    N = lambda mu, sd: torch.distributions.Normal(c64(mu), c64(sd))   # noqa: E731
+    if name == "poisson_loglink":
+        a, b = t[0], t[1]
+        lp = N(0.0, 2.0).log_prob(a) + N(0.0, 2.0).log_prob(b) + torch.distributions.Poisson(torch.exp(a + b * torch.tensor(lm.XS))).log_prob(torch.tensor(lm.YC)).sum()
+    elif name == "hier_normal_exp_sigma":
+        mu, ls, x = t[0], t[1], t[2:7]
+        lp = N(0.0, 5.0).log_prob(mu) + N(0.0, 1.0).log_prob(ls) + N(mu, torch.exp(ls)).log_prob(x).sum() + N(x, 0.7).log_prob(torch.tensor(lm.Y5)).sum()
+    else:
+        a, b, lc = t[0:4], t[4:8], t[8]
+        c = torch.exp(lc)
+        hn = torch.distributions.HalfNormal(c64(1.0)).log_prob(c) + lc                       # HalfNormal prior + log-Jacobian of the log transform
+        y = torch.tensor(lm.Y4)
+        lp = (N(0.0, 1.0).log_prob(a).sum() + N(0.0, 1.0).log_prob(b).sum() + hn
+              + N(a * b * c + a, torch.nn.functional.softplus(b) + 0.5).log_prob(y).sum() + N((a / (1.0 + c)) ** 2, 1.5).log_prob(y).sum())
+    lp.backward()
+    return lp.item(), t.grad.numpy()
+
+
+@pytest.mark.parametrize("name", ["poisson_loglink", "hier_normal_exp_sigma", "cubic_and_friends"])
+def test_expression_programs_lower_and_match_autograd(name):
+    """what is not `a + b*c` -- a log link behind a Deterministic, exp(log_sigma) written as an expression, a cubic
+    term, a ratio, a softplus, a power -- lowers to an expression program (graphs built by the reference's own logp bodies), is the
+    program `ModelBuilder` emits for the same model, and the oracle's logp / gradient through the program equal torch autograd of
+    the model written directly in torch."""
+    make, built = lm.ENTRIES[name]
+    spec, want = lower_to_spec(make()), built()
+    assert any(f.prog for f in spec.factors)
+    assert [bool(f.prog) for f in spec.factors] == [bool(f.prog) for f in want.factors]
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        q = rng.normal(size=spec.n) * 0.6
+        lp, g = ref_models.evaluate(spec, q)
+        lp_b, g_b = ref_models.evaluate(want, q)
+        lp_t, g_t = _torch_reference(name, q)
+        assert abs(lp - lp_t) <= 1e-10 * abs(lp_t) and np.max(np.abs(g - g_t)) <= 1e-10 * max(1.0, np.max(np.abs(g_t)))
+        assert abs(lp - lp_b) <= 1e-13 * abs(lp_b) and np.max(np.abs(g - g_b)) <= 1e-12 * max(1.0, np.max(np.abs(g_b)))
+
+
+def test_deterministics_are_recorded_in_the_trace():
+    """`pm.Deterministic`: no contribution to the log-density, one more variable of the trace (backends/base.py:183-191)."""
+    from pymc_amd.backends import NDArray
+    from pymc_amd.model_spec import ModelBuilder
+
+    spec = lm.poisson_loglink(ModelBuilder()).build()
+    assert list(spec.deterministics) == ["rate"] and len(spec.factors) == 3
+    t = NDArray(model=spec)
+    assert t.varnames == ["a", "b", "rate"]
+    t.setup(3, 0)
+    pts = np.array([[0.1, 0.2], [0.3, -0.4], [-0.5, 0.6]])
+    t.record_batch(pts, None)
+    t.close()
+    np.testing.assert_allclose(t.get_values("rate"), np.exp(pts[:, :1] + pts[:, 1:2] * lm.XS), rtol=1e-15)
+    assert t.get_values("rate").shape == (3, 40)
 
 
 @pytest.mark.gpu
