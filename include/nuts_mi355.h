@@ -157,6 +157,14 @@ typedef struct nuts_model nuts_model;
 typedef struct nuts_chain nuts_chain;
 
 /* ---- runtime --------------------------------------------------------------- */
+/* Schedule options.  Several launch schedules of the same arithmetic exist side by side (group-aligned / group-block / span-
+ * partitioned row pass, folded control, look-ahead depth, ...: DESIGN.md section 4); the defaults are what the product runs and
+ * what bench.py measures.  A non-default one is selected here -- by the parity tests that run every schedule against the
+ * oracle and against each other, and by the A/B scripts under tools/ -- for the models and chains created AFTERWARDS in this
+ * process.  The library itself never reads the environment.  Names: "NUTS_ROWS_GA", "NUTS_FOLD_CTL", ... (engine.hip). */
+int nuts_set_option(const char *name, int32_t value);
+void nuts_clear_options(void);
+
 int nuts_device_count(void);
 int nuts_set_device(int device);
 const char *nuts_last_error(void);

@@ -230,6 +230,8 @@ SYMBOLS = {
     "nuts_gibbs_sweep": (C.c_int, [_VP, _VP, _PD, _PD, _PD, _VP, _VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _PD, _PD, _PD]),
     "nuts_gibbs_plan_doubles": (C.c_int, [C.POINTER(Pcg64), C.c_int64, C.c_int32, _VP, C.c_int64, _PD]),
     "nuts_gibbs_sweep_prop": (C.c_int, [_VP, _VP, _VP, _PD, _PD, _PD, _VP, _PD, _PD, _VP, C.POINTER(C.c_int64), _PD, _PD, _PD]),
+    "nuts_set_option": (C.c_int, [C.c_char_p, C.c_int32]),
+    "nuts_clear_options": (None, []),
     "nuts_advi_create": (_VP, [C.POINTER(AdviConfig)]),
     "nuts_advi_destroy": (None, [_VP]),
     "nuts_advi_steps": (C.c_int, [_VP, C.c_int32, _VP, _PD, _PD]),
@@ -277,6 +279,27 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_engine_option(name: str, value: int) -> None:
+    """Select a non-default launch schedule for the models / chains created from now on (include/nuts_mi355.h, nuts_set_option)."""
+    check(load().nuts_set_option(name.encode(), int(value)), "nuts_set_option")
+
+
+def sync_options_from_env() -> None:
+    """TESTS AND tools/ ONLY.  With PYMC_AMD_HONOUR_NUTS_ENV=1 in the environment, the NUTS_* variables of the moment become the
+    engine's schedule options (the engine itself never reads the environment).  Called when a model or chain is about to be
+    created, so `monkeypatch.setenv("NUTS_ROWS_GA", "0")` in a test acts on the model the test creates next."""
+    if os.environ.get("PYMC_AMD_HONOUR_NUTS_ENV") != "1":
+        return
+    lib = load()
+    lib.nuts_clear_options()
+    for k, v in os.environ.items():
+        if k.startswith("NUTS_"):
+            try:
+                lib.nuts_set_option(k.encode(), int(v))
+            except ValueError:
+                pass
 
 
 def last_error() -> str:

@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
 #include <ctime>
 #include <string>
 #include <vector>
@@ -44,9 +46,26 @@ static thread_local std::string g_err;
     }                                                                                       \
   } while (0)
 
+// Schedule options (include/nuts_mi355.h, nuts_set_option): which of several equivalent kernel schedules a model / chain created
+// from now on uses.  The library never reads the environment: whoever wants a non-default schedule (parity tests of every
+// schedule, A/B measurements in tools/) says so through the ABI.  Process-wide, read when a model or chain is created.
+static std::mutex g_opt_mu;
+static std::vector<std::pair<std::string, int>> g_opts;
 static int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return (v && *v) ? std::atoi(v) : dflt;
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  for (const auto& kv : g_opts) if (kv.first == name) return kv.second;
+  return dflt;
+}
+extern "C" int nuts_set_option(const char* name, int32_t value) {
+  if (!name || std::strncmp(name, "NUTS_", 5) != 0) { g_err = "option names start with NUTS_"; return NUTS_E_ARG; }
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  for (auto& kv : g_opts) if (kv.first == name) { kv.second = value; return NUTS_OK; }
+  g_opts.emplace_back(name, value);
+  return NUTS_OK;
+}
+extern "C" void nuts_clear_options(void) {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  g_opts.clear();
 }
 
 template <typename T>

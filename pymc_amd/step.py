@@ -308,6 +308,7 @@ class _DeviceHMCBase:
             keep = None
         else:
             keep = self.potential._fill_config(cfg)
+        _lib.sync_options_from_env()     # (tests / tools only: see _lib.py)
         chain = lib.nuts_chain_create(func._handle, C.byref(cfg))
         del keep
         if not chain:

@@ -104,6 +104,7 @@ class DeviceValueGradFunction:
         self.trust_input = True
         self.rows_group_aligned_allowed = rows_group_aligned
         cspec, keep = _pack(spec, rows_group_aligned)
+        _lib.sync_options_from_env()     # (tests / tools only: see _lib.py)
         self._handle = lib.nuts_model_create(C.byref(cspec))
         del keep
         if not self._handle:

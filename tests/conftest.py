@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# The engine never reads the environment; the schedule tests select schedules with `monkeypatch.setenv("NUTS_...")`, which
+# pymc_amd._lib.sync_options_from_env forwards to `nuts_set_option` when a model / chain is created -- only under this switch.
+os.environ["PYMC_AMD_HONOUR_NUTS_ENV"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

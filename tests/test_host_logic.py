@@ -94,15 +94,25 @@ def test_hier_logit_rows_get_sorted_by_group():
     npt.assert_array_equal(r.y, y[order])
 
 
-def test_affine_ir_rejects_what_it_cannot_express():
+def test_affine_terms_stay_terms_and_the_rest_becomes_an_expression_program():
     m = ModelBuilder()
     a = m.Normal("a", 0, 1, shape=3)
     b = m.Normal("b", 0, 1, shape=3)
     c = m.Normal("c", 0, 1)
-    e = a + b * c  # a + b*c is the IR's shape
-    assert e.size == 3
-    with pytest.raises(NotImplementedError):
-        (a * b) * c
+    e = a + b * c  # a + b*c is a plain term: no program
+    assert e.size == 3 and e.node is None
+    cubic = (a * b) * c          # not a term: a node, lowered to instructions by the factor it is handed to
+    assert cubic.node is not None and cubic.size == 3
+    with pytest.raises(NotImplementedError, match="expression program"):
+        cubic.term
+    m.Normal("y", cubic + m.math.exp(c), 1.0, observed=np.zeros(3))
+    f = m.build().factors[-1]
+    assert len(f.prog) == 4 and f.args[1].a.kind == 3     # mul, mul, exp, add; the mean is the last instruction's result (OP_TMP)
+    big = a
+    for _ in range(20):
+        big = m.math.exp(big)
+    with pytest.raises(NotImplementedError, match="more than 16 instructions"):
+        m.Normal("z", big, 1.0, observed=np.zeros(3))
     with pytest.raises(ValueError):
         m.Normal("bad", np.zeros(4), 1.0, shape=3)
 

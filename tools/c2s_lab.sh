@@ -1,6 +1,7 @@
 #!/bin/bash
 # C2-S (cache-resident size) under the schedules the engine has: group-block pass (default for small groups), general path,
 # group-aligned pass forced.  usage: bash tools/c2s_lab.sh [tag]
+export PYMC_AMD_HONOUR_NUTS_ENV=1   # the NUTS_* variables below reach the engine as schedule options (nuts_set_option)
 TAG=${1:-lab}
 OUT=gpurun_out; mkdir -p $OUT
 B="python bench.py --rows-per-group 80 --steps 400 --warmup 400 --cpu-leapfrogs 0 --ess-tune 0"

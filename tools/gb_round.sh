@@ -1,5 +1,6 @@
 #!/bin/bash
 # one measurement round of the group-block pass: C2-S bench (default build) + phase stamps of leaves j = 0, 1, 3, 7 (ticks build)
+export PYMC_AMD_HONOUR_NUTS_ENV=1   # the NUTS_* variables below reach the engine as schedule options (nuts_set_option)
 TAG=${1:-lab}; OUT=gpurun_out; mkdir -p $OUT
 B="python bench.py --rows-per-group 80 --steps 400 --warmup 400 --cpu-leapfrogs 0 --ess-tune 0"
 {

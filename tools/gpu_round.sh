@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU-box round script: parity tests, bench, rocprofv3 kernel trace + PMC passes, summarised into gpurun_out/.
 # usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [stages]   stages: any of t(ests) b(ench) p(rofile) c(3) s(C2-S) e(ss study)
+export PYMC_AMD_HONOUR_NUTS_ENV=1   # the NUTS_* variables below reach the engine as schedule options (nuts_set_option)
 TAG=${1:-r02}
 STAGES=${2:-tbp}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd)

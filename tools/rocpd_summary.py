@@ -50,25 +50,34 @@ def pmc_stats(path):
 
 
 def traffic_json(fetch_db, write_db, out_path, kernel_like, tag, src_hash):
-    """HBM bytes per launch of the dominant kernel from the two PMC passes (non-drained launches = the per-kernel maximum),
-    with the guide's gfx950 correction: read side = 2 x FETCH_SIZE (KiB), write side = WRITE_SIZE (KiB)."""
+    """HBM bytes per launch of the dominant kernel from the two PMC passes, with the guide's gfx950 correction: read side =
+    2 x FETCH_SIZE (KiB), write side = WRITE_SIZE (KiB).  The MEAN over FULL launches: launches queued behind a tree that had
+    already terminated drain as no-ops (they read a flag and leave) and are told apart by their counter value -- less than half of
+    the largest one -- instead of being averaged in (their share is reported)."""
     import json
 
-    def mx(path, counter):
+    def stats(path, counter):
         cur = sqlite3.connect(path).cursor()
-        rows = list(cur.execute("select max(value), avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
-                                (counter, f"%{kernel_like}%")))
-        return rows[0]
+        vals = [r[0] for r in cur.execute("select value from counters_collection where counter_name = ? and kernel_name like ?", (counter, f"%{kernel_like}%"))]
+        if not vals:
+            return None
+        top = max(vals)
+        full = [v for v in vals if v >= 0.5 * top]
+        return {"max": top, "mean_all": sum(vals) / len(vals), "mean_full": sum(full) / len(full), "n": len(vals), "n_full": len(full)}
 
-    f, w = mx(fetch_db, "FETCH_SIZE"), mx(write_db, "WRITE_SIZE")
-    if f[0] is None or w[0] is None:
+    f, w = stats(fetch_db, "FETCH_SIZE"), stats(write_db, "WRITE_SIZE")
+    if f is None or w is None:
         return
+    # (the write counter of a drained launch is not far from a full one's -- a few KB either way -- so the split is made on the read side)
     out = {
-        "k_rows_bytes_per_launch": int(2 * f[0] * 1024 + w[0] * 1024),
-        "fetch_size_kib_max": f[0], "fetch_size_kib_avg": f[1], "write_size_kib_max": w[0], "write_size_kib_avg": w[1], "launches": f[2],
+        "k_rows_bytes_per_launch": int(2 * f["mean_full"] * 1024 + w["mean_all"] * 1024),
+        "fetch_size_kib_mean_full_launches": f["mean_full"], "fetch_size_kib_max": f["max"], "fetch_size_kib_mean_all": f["mean_all"],
+        "write_size_kib_mean": w["mean_all"], "write_size_kib_max": w["max"],
+        "launches": f["n"], "full_launches": f["n_full"], "drained_launches": f["n"] - f["n_full"],
         "kernel": kernel_like, "kernel_source_hash": src_hash,
-        "source": f"profiles/{tag}_profile.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), non-drained launches "
-                  "(per-kernel maximum); read side doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)",
+        "source": f"profiles/{tag}_profile.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), MEAN over the full launches "
+                  "(drained launches, recognised by a read counter below half the maximum, are left out); read side doubled per MI355X_MICROARCH.md "
+                  "(gfx950 counts 128-B requests as 64 B)",
     }
     json.dump(out, open(out_path, "w"), indent=1)
 

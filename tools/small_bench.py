@@ -2,6 +2,7 @@
 """Latency regime: microseconds per leapfrog of the single-workgroup kernel against the three-kernel pipeline at a few sizes
 (schools model, 1 chain, 200 tune + 300 draws).  usage (GPU box): python tools/small_bench.py"""
 import json, os, subprocess, sys, time
+os.environ["PYMC_AMD_HONOUR_NUTS_ENV"] = "1"   # NUTS_* variables reach the engine as schedule options (nuts_set_option)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
