@@ -18,11 +18,11 @@ if [[ $STAGES == *b* ]]; then
 fi
 if [[ $STAGES == *p* ]]; then
   cd /tmp
-  PROF_ARGS="--steps 30 --warmup 60 --cpu-leapfrogs 0"
+  PROF_ARGS="--steps 30 --warmup 60 --cpu-leapfrogs 0 --ess-tune 0"
   rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o trace -- python $R/bench.py $PROF_ARGS > $OUT/prof_$TAG.log 2>&1; echo "prof rc=$?" >> $OUT/prof_$TAG.log
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 > $OUT/pmc_fetch_$TAG.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 > $OUT/pmc_write_$TAG.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 --ess-tune 0 > $OUT/pmc_fetch_$TAG.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_$TAG -o pmc -- python $R/bench.py --steps 4 --warmup 8 --cpu-leapfrogs 0 --ess-tune 0 > $OUT/pmc_write_$TAG.log 2>&1
   {
     echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py $PROF_ARGS   (tag $TAG, kernel source hash $HASH)"
     grep -E '^\{' $OUT/prof_$TAG.log | head -1
@@ -41,6 +41,7 @@ if [[ $STAGES == *c* ]]; then
   rm -rf $OUT/prof_c3_$TAG; cd $R
 fi
 if [[ $STAGES == *s* ]]; then
+  bash tools/c2s_profile.sh $TAG > /dev/null 2>&1
   timeout 600 python bench.py --rows-per-group 80 --cpu-leapfrogs 0 > $OUT/bench_c2s_$TAG.json 2> $OUT/bench_c2s_$TAG.err
 fi
 if [[ $STAGES == *e* ]]; then
