@@ -1077,7 +1077,9 @@ __device__ __forceinline__ LeanSrc lean_src(const ModelDev& md, int par) {
 
 __global__ __launch_bounds__(VEC_THREADS) void k_control_lean(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
                                                              int max_depth, HostStatus* st, int seq, int par) {
-  control_lean(md, A, io, j, d, Emax, max_depth, st, seq, lean_src(md, par));
+  // (standalone: the last leaf of a tree, whose control work has no next launch to ride in and sits between two draws -- the
+  // operands of its merge levels are requested up front, PF)
+  control_lean<false, 8, true>(md, A, io, j, d, Emax, max_depth, st, seq, lean_src(md, par));
 }
 
 // ---------------------------------------------------------------------------

@@ -151,7 +151,9 @@ def test_c2s_nuts_integer_parity_through_tuning(c2s):
     # The bar: the first 12 transitions exact; after that the trees still have the same sizes to within the sampler's noise.
     first_diff = next((i for i in range(tune + draws) if any(int(dev[i][k]) != int(ref_stats[0][i][k]) for k in INT_KEYS)), tune + draws)
     print(f"C2-S: integer statistics identical for the first {first_diff} of {tune + draws} transitions")
-    assert first_diff >= 12, (first_diff, {k: (dev[first_diff][k], ref_stats[0][first_diff][k]) for k in INT_KEYS})
+    # measured 18 (r02 on the general path, r03 on the group-block pass alike); the bar is what is measured minus two, so that a
+    # regression shows
+    assert first_diff >= 16, (first_diff, {k: (dev[first_diff][k], ref_stats[0][first_diff][k]) for k in INT_KEYS})
     for i in range(6):
         for k in ("mean_tree_accept", "energy", "model_logp", "step_size", "step_size_bar"):
             np.testing.assert_allclose(dev[i][k], ref_stats[0][i][k], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
@@ -173,7 +175,8 @@ def test_c2l_nuts_prefix_matches_golden_fixture(c2l):
     assert len(dev) == tune + draws
     first_diff = next((i for i in range(tune + draws) if any(int(dev[i][k]) != int(gold[k][i]) for k in INT_KEYS)), tune + draws)
     print(f"C2-L: integer statistics identical for the first {first_diff} of {tune + draws} transitions")
-    assert first_diff >= 12, (first_diff, {k: (dev[first_diff][k], gold[k][first_diff]) for k in INT_KEYS})
+    # measured: all 30 transitions of the committed oracle run; bar = measured minus two
+    assert first_diff >= 28, (first_diff, {k: (dev[min(first_diff, tune + draws - 1)][k], gold[k][min(first_diff, tune + draws - 1)]) for k in INT_KEYS})
     for i in range(5):
         for k in ("mean_tree_accept", "energy", "model_logp", "step_size", "step_size_bar"):
             np.testing.assert_allclose(dev[i][k], gold[k][i], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
@@ -378,9 +381,10 @@ def test_group_block_rows_on_ragged_empty_and_tiny_groups(gpw, monkeypatch):
     ref_draws, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
     dev = res["warmup_stats"][0] + res["stats"][0]
     # (the cross-group sums are associated differently from the oracle's loop: as at C2-S, one multinomial pick inside a tree flips
-    # after a couple of dozen transitions -- measured 24 with the engine's own block size; the bar is the C2-S test's)
+    # after a couple of dozen transitions -- measured 22 .. 24 over the four block sizes; the bar is what is measured minus two)
     first_diff = next((i for i in range(tune + draws) if any(int(dev[i][k]) != int(ref_stats[0][i][k]) for k in INT_KEYS)), tune + draws)
-    assert first_diff >= 12, first_diff
+    print(f"group-block gpw={gpw}: integer statistics identical for the first {first_diff} of {tune + draws} transitions")
+    assert first_diff >= 20, first_diff
     res["step"].close()
 
 
