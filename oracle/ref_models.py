@@ -308,7 +308,7 @@ def _log_diff_normal_cdf(x, y):
     return math.log(0.5) + np.where(y > 0, r1, np.where(x < 0, r2, r3))
 
 
-OP_TMP = 3
+OP_TMP, OP_GATHER = 3, 4
 (E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC) = range(16)
 
 
@@ -357,6 +357,9 @@ def _instr_value(op, k, vx, vy):
 def _operand(op, spec, x, tmp=None):
     if op.kind == OP_TMP:
         return tmp[op.ref]
+    if op.kind == OP_GATHER:   # var[idx[i]] (include/nuts_mi355.h NUTS_OP_GATHER)
+        v = spec.vars[op.ref]
+        return x[v.offset + spec.data[int(op.c)].astype(np.int64)]
     if op.kind == OP_CONST:
         return np.asarray(op.c, dtype="d")
     if op.kind == OP_DATA:
@@ -371,6 +374,11 @@ def _push(op, spec, gx, g, adj=None):
     """Accumulate d logp / d operand into the constrained-space gradient (or, for a program result, into its adjoint)."""
     if op.kind == OP_TMP:
         adj[op.ref] = adj[op.ref] + g
+        return
+    if op.kind == OP_GATHER:
+        v = spec.vars[op.ref]
+        idx = spec.data[int(op.c)].astype(np.int64)
+        np.add.at(gx, v.offset + idx, np.broadcast_to(g, idx.shape))
         return
     if op.kind != OP_VAR:
         return

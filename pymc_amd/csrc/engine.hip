@@ -282,8 +282,45 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   std::vector<std::vector<Contrib>> per_var(nv);
   std::vector<FactorBT> fbt(std::max(nf, 1));
   std::vector<int32_t> bterm_var, orphans;
+  std::vector<nuts_factor> fac(s->factors, s->factors + nf);   // (pad is rewritten: 1 = the factor has gathered operands)
+  std::vector<int32_t> csr;
+  std::vector<std::pair<int, int>> gathered;   // (variable, index data id) pairs of the factor being compiled
+  // NUTS_OP_GATHER operand of factor fi: the inverse index (which factor elements read element e of the variable, in order)
+  auto add_gather = [&](int fi, const nuts_operand& o) -> bool {
+    const nuts_factor& f = s->factors[fi];
+    const int did = (int)o.c;
+    if (o.ref < 0 || o.ref >= nv) { g_err = "gather refers to a missing variable"; return false; }
+    if (did < 0 || did >= s->n_data || (double)did != o.c) { g_err = "gather refers to a missing index vector"; return false; }
+    if (s->data[did].size != f.size) { g_err = "gather: one index per element of the factor"; return false; }
+    for (const auto& gv : gathered)
+      if (gv.first == o.ref) {
+        if (gv.second != did) { g_err = "a variable is gathered into one factor through ONE index vector"; return false; }
+        return true;   // second occurrence of the same gather: already registered
+      }
+    gathered.emplace_back(o.ref, did);
+    const int vs = vars[o.ref].size;
+    const double* idx = s->data_pool + s->data[did].offset;
+    std::vector<int32_t> ptr(vs + 1, 0), lst(f.size);
+    for (int i = 0; i < f.size; ++i) {
+      const int e = (int)idx[i];
+      if ((double)e != idx[i] || e < 0 || e >= vs) { g_err = "gather index out of range for its variable"; return false; }
+      ptr[e + 1]++;
+    }
+    for (int e = 0; e < vs; ++e) ptr[e + 1] += ptr[e];
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int i = 0; i < f.size; ++i) lst[fill[(int)idx[i]]++] = i;   // increasing i within an element: fixed summation order
+    Contrib cb{};
+    cb.f = fi; cb.arg = -2; cb.slot = -1; cb.owner = 0; cb.fast = 0;
+    cb.dist = (int32_t)csr.size(); csr.insert(csr.end(), ptr.begin(), ptr.end());
+    cb.pad = (int32_t)csr.size(); csr.insert(csr.end(), lst.begin(), lst.end());
+    per_var[o.ref].push_back(cb);
+    fac[fi].pad = 1;
+    return true;
+  };
   for (int fi = 0; fi < nf; ++fi) {
     const nuts_factor& f = s->factors[fi];
+    fac[fi].pad = 0;
+    gathered.clear();
     fbt[fi].n = 0; fbt[fi].pad = 0;
     if (f.nargs < 1 || f.nargs > 4 || f.size < 1) { g_err = "factor with a bad argument count or size"; return false; }
     if (f.dist < 0 || f.dist > NUTS_D_POISSON) { g_err = "factor with an unknown distribution code"; return false; }
@@ -319,7 +356,8 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         }
       std::vector<int> seen;
       for (const nuts_operand* o : ops) {
-        if (o->kind < NUTS_OP_CONST || o->kind > NUTS_OP_TMP) { g_err = "operand of an unknown kind"; return false; }
+        if (o->kind < NUTS_OP_CONST || o->kind > NUTS_OP_GATHER) { g_err = "operand of an unknown kind"; return false; }
+        if (o->kind == NUTS_OP_GATHER) { if (!add_gather(fi, *o)) return false; continue; }
         if (o->kind == NUTS_OP_DATA) {
           if (o->ref < 0 || o->ref >= s->n_data) { g_err = "factor refers to a missing data vector"; return false; }
           const int64_t ds = s->data[o->ref].size;
@@ -348,6 +386,8 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
           fbt[fi].n++;
         } else { g_err = "variable does not broadcast against its factor"; return false; }
       }
+      for (const auto& gv : gathered)
+        if (std::find(seen.begin(), seen.end(), gv.first) != seen.end()) { g_err = "a variable is both gathered into a factor and a direct operand of it"; return false; }
       if (!owned_already) orphans.push_back(fi);
       continue;
     }
@@ -356,6 +396,13 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       for (int sl = 0; sl < 3; ++sl) {
         const nuts_operand& o = *ops[sl];
         if (o.kind == NUTS_OP_TMP) { g_err = "factor argument refers to an instruction but the factor has no program"; return false; }
+        if (o.kind == NUTS_OP_GATHER) {
+          if (!add_gather(fi, o)) return false;
+          for (int a2 = 0; a2 < f.nargs; ++a2)
+            for (const nuts_operand* o2 : {&f.arg[a2].a, &f.arg[a2].b, &f.arg[a2].c})
+              if (o2->kind == NUTS_OP_VAR && o2->ref == o.ref) { g_err = "a variable is both gathered into a factor and a direct operand of it"; return false; }
+          continue;
+        }
         if (o.kind == NUTS_OP_DATA) {
           if (o.ref < 0 || o.ref >= s->n_data) { g_err = "factor refers to a missing data vector"; return false; }
           const int64_t ds = s->data[o.ref].size;
@@ -470,7 +517,8 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.po_vars = put(vars.data(), vars.size() * sizeof(VarDev));
   md.po_cptr = put(cptr.data(), cptr.size() * sizeof(int32_t));
   md.po_contrib = put(contrib.data(), contrib.size() * sizeof(Contrib));
-  md.po_factors = put(s->factors, (size_t)nf * sizeof(nuts_factor));
+  md.po_factors = put(fac.data(), (size_t)nf * sizeof(nuts_factor));
+  md.csr = m->keep(dev_upload(csr.data(), csr.size()));
   md.po_fbt = put(fbt.data(), (size_t)nf * sizeof(FactorBT));
   md.po_btvar = put(bterm_var.data(), bterm_var.size() * sizeof(int32_t));
   md.po_data = put(s->data, (size_t)s->n_data * sizeof(nuts_data_ref));

@@ -34,6 +34,9 @@ struct VarDev {  // nuts_var + what the spec compiler derived
   double np_mu, np_inv_var, np_lognorm;
 };
 
+// arg == -1: the variable occurs somewhere in a factor WITH an expression program (differentiated through the program);
+// arg == -2: the variable is GATHERED into the factor (NUTS_OP_GATHER): `dist` / `pad` are the offsets in ModelDev.csr of the
+//            row pointers [size + 1] and of the factor-element list of the inverse index, never an owner
 struct Contrib {  // "variable k is operand `slot` (0=a,1=b,2=c) of argument `arg` of factor f"
   int32_t f;
   int16_t arg, slot;
@@ -141,6 +144,7 @@ struct ModelDev {
   // "lean" control path (see kernels.h): the only deferred elements are the hierarchical-logit node's mu / sigma, so
   // kernel B evaluates everything of them that does not need the cross-workgroup sums and leaves
   // {d logp/dx local part, dx/dq, dlog|J|/dq, p_half} per deferred element here
+  const int32_t* csr;         // inverse indices of gathered variables: per (factor, variable) [size + 1] row pointers, then the factor elements
   double* def_loc;            // [2][MAX_DEFERRED][4] (second copy: the group-aligned row pass double-buffers by launch parity)
   int32_t lean_ok, lean_pad;
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
@@ -215,6 +219,7 @@ __device__ __forceinline__ double deferred_finish(double gx_local, double S, dou
 struct Prog {
   const VarDev* vars;
   const nuts_instr* instrs;   // expression programs of the factors (nuts_factor.instr_off / n_instr)
+  const int32_t* csr;         // inverse indices of the gathered variables (NUTS_OP_GATHER): global memory, see Contrib
   const int32_t* var_cptr;
   const Contrib* contrib;
   const nuts_factor* factors;
@@ -259,6 +264,7 @@ __device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog, cons
   pg.data = reinterpret_cast<const nuts_data_ref*>(base + md.po_data);
   pg.deferred = reinterpret_cast<const int32_t*>(base + md.po_deferred);
   pg.instrs = reinterpret_cast<const nuts_instr*>(base + md.po_instrs);
+  pg.csr = md.csr;
   pg.pool = md.pool;
   pg.n_vars = md.n_vars;
   pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
@@ -330,6 +336,11 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
   if (o.kind == NUTS_OP_DATA) {
     const nuts_data_ref r = pg.data[o.ref];
     return pg.pool[r.offset + (r.size > 1 ? li : 0)];
+  }
+  if (o.kind == NUTS_OP_GATHER) {   // var[idx[li]]
+    const nuts_data_ref r = pg.data[(int)o.c];
+    const VarDev v = pg.vars[o.ref];
+    return transform_x(v, qv.at(v.offset + (int)pg.pool[r.offset + li]));
   }
   if (o.ref == own_var) return own_x;
   const VarDev v = pg.vars[o.ref];
@@ -556,7 +567,9 @@ __device__ __noinline__ double factor_eval_prog(const Prog& pg, const QView& qv,
                                                 int wrt, double* d, double* darg, int* pdead) {
   double tv[NUTS_MAX_FACTOR_INSTR], tt[NUTS_MAX_FACTOR_INSTR];
   auto val = [&](const nuts_operand& o) { return o.kind == NUTS_OP_TMP ? tv[o.ref] : op_value(o, li, pg, qv, own_var, own_x); };
-  auto tan_ = [&](const nuts_operand& o) { return o.kind == NUTS_OP_TMP ? tt[o.ref] : ((o.kind == NUTS_OP_VAR && o.ref == wrt) ? 1.0 : 0.0); };
+  auto tan_ = [&](const nuts_operand& o) {
+    return o.kind == NUTS_OP_TMP ? tt[o.ref] : (((o.kind == NUTS_OP_VAR || o.kind == NUTS_OP_GATHER) && o.ref == wrt) ? 1.0 : 0.0);
+  };
   const nuts_instr* ins = pg.instrs + f.instr_off;
   for (int i = 0; i < f.n_instr; ++i) {
     const nuts_instr I = ins[i];
@@ -638,6 +651,18 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       continue;
     }
     const nuts_factor& f = pg.factors[cb.f];
+    if (cb.arg == -2) {    // gathered into the factor: every factor element that indexes this element, in index order
+      const int32_t* ptr = pg.csr + cb.dist;
+      const int32_t* lst = pg.csr + cb.pad;
+      for (int t = ptr[li]; t < ptr[li + 1]; ++t) {
+        double d[4], darg[4];
+        int pdead = 0;
+        double lpf = factor_eval_prog(pg, qv, f, lst[t], -1, 0.0, k, d, darg, &pdead);
+        factor_kill(pg, cb.f, pdead, lpf, d);
+        gx += dot4(d, darg);
+      }
+      continue;
+    }
     if (f.n_instr > 0) {   // expression program: the tangent of the arguments w.r.t. this variable, through the program
       double d[4], darg[4];
       int pdead = 0;
@@ -675,7 +700,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
 __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv, int fi, int li, double* s_bacc, int bstride) {
   const nuts_factor& f = pg.factors[fi];
   const FactorBT& bt = pg.fbt[fi];
-  if (f.n_instr > 0) {
+  if (f.n_instr > 0 || f.pad) {   // (pad != 0: the spec compiler marks factors with gathered operands; they take the general evaluator)
     double lpo = 0.0;
     for (int b = 0; b < (bt.n > 0 ? bt.n : 1); ++b) {
       double d[4], darg[4];

@@ -668,6 +668,18 @@ class _Lowering:
         k = self._as_var(node)
         if k is not None:
             return ms.Operand(ms.OP_VAR, 0.0, k)
+        if node[0] == "take":   # a[idx] with a constant integer index vector: a gather (NUTS_OP_GATHER), e.g. varying intercepts
+            kv = self._as_var(node[1])
+            if kv is not None and node[2][0] == "const" and np.asarray(node[2][1]).ndim == 1:
+                idx = np.asarray(node[2][1], dtype="float64")
+                n = self.spec.vars[kv].size
+                if idx.size and np.all(idx == np.round(idx)) and idx.min() >= 0 and idx.max() < n:
+                    key = ("gather", kv, idx.tobytes())
+                    if key not in self._gather_ids:      # one data vector per (variable, index vector)
+                        self.spec.data.append(np.ascontiguousarray(idx))
+                        self._gather_ids[key] = len(self.spec.data) - 1
+                    return ms.Operand(ms.OP_GATHER, float(self._gather_ids[key]), kv)
+            return None
         if node[0] == "const":
             arr = np.asarray(node[1], dtype="float64")
             if arr.size == 1:
@@ -745,6 +757,8 @@ class _Lowering:
             return self.spec.data[o.ref].size
         if o.kind == ms.OP_TMP:
             return self._prog_size[o.ref]
+        if o.kind == ms.OP_GATHER:
+            return self.spec.data[int(o.c)].size
         return 1
 
     def _size(self, t: ms.Term) -> int:
@@ -800,8 +814,11 @@ class _Lowering:
         return False
 
     _prog = None
+    _gather_ids: Dict[Any, int] = {}
 
     def factor(self, node, name: str, own_value=None):
+        if "_gather_ids" not in self.__dict__:
+            self._gather_ids = {}
         self._prog, self._prog_size, self._prog_memo = [], [], {}
         try:
             self._factor(node, name, own_value)

@@ -35,7 +35,7 @@ TR_NONE, TR_LOG, TR_LOGODDS, TR_INTERVAL = 0, 1, 2, 3
 TRANSFORM_NAMES = {TR_NONE: None, TR_LOG: "log", TR_LOGODDS: "logodds", TR_INTERVAL: "interval"}
 
 # operand kinds
-OP_CONST, OP_DATA, OP_VAR, OP_TMP = 0, 1, 2, 3
+OP_CONST, OP_DATA, OP_VAR, OP_TMP, OP_GATHER = 0, 1, 2, 3, 4   # OP_GATHER: var[idx[i]], `c` = id of the index data vector
 
 # expression-program opcodes (must match include/nuts_mi355.h NUTS_E_*)
 (E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC) = range(16)
@@ -304,6 +304,20 @@ class Expr:
     def __rtruediv__(self, other):
         return Expr.op(self._b, E_DIV, self._b.as_expr(other), self)
 
+    def __getitem__(self, idx):
+        """`a[group_idx]` for a free variable `a`: a gather (varying intercepts / slopes)."""
+        s_ = self._simple()
+        if s_ is None or s_.kind != OP_VAR:
+            raise NotImplementedError("only a free variable itself can be indexed")
+        idx = np.asarray(idx)
+        if idx.ndim != 1 or idx.dtype.kind not in "iu":
+            raise NotImplementedError("index with a one-dimensional integer array")
+        n = self._b.spec.vars[s_.ref].size
+        if idx.size and (idx.min() < 0 or idx.max() >= n):
+            raise IndexError("index out of range for the variable")
+        self._b.spec.data.append(np.ascontiguousarray(idx, dtype="float64"))
+        return Expr(self._b, Term(Operand(OP_GATHER, float(len(self._b.spec.data) - 1), s_.ref)), idx.size)
+
     def __pow__(self, k):
         if float(k) == 2.0:
             return Expr.op(self._b, E_SQR, self)
@@ -346,6 +360,8 @@ def eval_program(spec: "ModelSpec", prog, term: Term, x: np.ndarray) -> np.ndarr
         if o.kind == OP_TMP:
             return tmp[o.ref]
         v = spec.vars[o.ref]
+        if o.kind == OP_GATHER:
+            return x[..., v.offset + spec.data[int(o.c)].astype(np.int64)]
         blk = x[..., v.offset : v.offset + v.size]
         return blk if v.size > 1 else blk[..., 0:1] if x.ndim > 1 else blk.reshape(())
 

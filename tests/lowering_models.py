@@ -150,6 +150,25 @@ def cubic_and_friends(b=None):
     return m
 
 
+GI = np.random.default_rng(12).integers(0, 7, size=60)
+XR = np.random.default_rng(13).normal(size=60)
+YR = np.random.default_rng(14).normal(size=60)
+
+
+def varying_intercepts_and_slopes(b=None):
+    """The hierarchical regression of every multilevel-modelling tutorial: group-level intercepts and slopes gathered by a
+    group index, `a[idx] + b[idx] * x` (NUTS_OP_GATHER), partially pooled intercepts, a rate behind an exp of a gathered effect."""
+    m = b or sg.StubModel()
+    mu_a = m.Normal("mu_a", 0.0, 2.0)
+    sg_a = m.HalfNormal("sg_a", 1.0)
+    a = m.Normal("a", mu_a, sg_a, shape=(7,))
+    bb = m.Normal("b", 0.0, 1.0, shape=(7,))
+    s_ = m.HalfNormal("s", 1.0)
+    m.Normal("y", a[GI] + bb[GI] * XR, s_, observed=YR)
+    m.Poisson("cnt", m.math.exp(0.3 * a[GI]), observed=np.abs(np.round(YR * 2)))
+    return m
+
+
 def _built(fn, *a):
     return fn(*a, ModelBuilder()).build()
 
@@ -172,5 +191,6 @@ ENTRIES = {
     "poisson_loglink": (poisson_loglink, lambda: _built(poisson_loglink)),
     "hier_normal_exp_sigma": (hier_normal_exp_sigma, lambda: _built(hier_normal_exp_sigma)),
     "cubic_and_friends": (cubic_and_friends, lambda: _built(cubic_and_friends)),
+    "varying_intercepts_and_slopes": (varying_intercepts_and_slopes, lambda: _built(varying_intercepts_and_slopes)),
 }
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")

@@ -1346,3 +1346,32 @@ def test_expression_program_models_lowered_from_the_reference_graphs():
         spec = lower_to_spec(sg.FrozenModel(committed[name]))
         assert any(f.prog for f in spec.factors)
         _check_logp_grad(spec, [rng.normal(size=spec.n) * 0.5 for _ in range(3)])
+
+
+def _varying_effects(G=7, N=60, seed=12, wide=False):
+    rng = np.random.default_rng(seed)
+    gi = rng.integers(0, G, size=N)
+    xr, yr = rng.normal(size=N), rng.normal(size=N)
+    m = ModelBuilder()
+    mu_a, sg_a = m.Normal("mu_a", 0.0, 2.0), m.HalfNormal("sg_a", 1.0)
+    a = m.Normal("a", mu_a, sg_a, shape=(G,))
+    b = m.Normal("b", 0.0, 1.0, shape=(G,))
+    s_ = m.HalfNormal("s", 1.0)
+    m.Normal("y", a[gi] + b[gi] * xr, s_, observed=yr)
+    m.Poisson("cnt", m.math.exp(0.3 * a[gi]), observed=np.abs(np.round(yr * 2)))
+    if wide:   # an element-aligned variable in the same factor as a gather, and a group without any observation
+        e = m.Normal("e", 0.0, 0.5, shape=(N,))
+        m.Normal("y2", a[np.minimum(gi, G - 2)] + e, 1.0, observed=yr)
+    return m.build()
+
+
+@pytest.mark.parametrize("shape", ["small", "wide"])
+def test_gathered_variables_logp_grad_and_nuts(shape):
+    """NUTS_OP_GATHER: `a[group_idx] + b[group_idx] * x` (varying intercepts and slopes) in a plain term and inside an expression
+    program; the gradient of a group's element is the sum over the observations that index it (inverse index, fixed order).
+    Small: the single-workgroup kernel; wide: 1500 groups x 6000 observations through the three-kernel pipeline, a gather next to an
+    element-aligned variable, a group nobody indexes."""
+    spec = _varying_effects() if shape == "small" else _varying_effects(G=1500, N=6000, seed=3, wide=True)
+    rng = np.random.default_rng(8)
+    _check_logp_grad(spec, [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.4 for _ in range(3)])
+    _compare_runs(spec, tune=25, draws=10, seed=6, prefix=30 if shape == "small" else 20)

@@ -104,7 +104,8 @@ def test_what_the_ir_cannot_express_is_refused_by_name():
         lower_to_spec(m)
     m = sg.StubModel()
     z = m.Normal("z", 0.0, 1.0, shape=(3,))
-    m.Normal("y", z[np.array([0, 2, 1, 1])], 1.0, observed=np.zeros(4))   # a gather outside the hierarchical-logit pattern
+    w = m.Normal("w", 0.0, 1.0, shape=(3,))
+    m.Normal("y", (z * w)[np.array([0, 2, 1, 1])], 1.0, observed=np.zeros(4))   # a gather of an EXPRESSION (only a variable itself is gathered)
     with pytest.raises(NotLowerable):
         lower_to_spec(m)
 
@@ -123,6 +124,13 @@ def _torch_reference(name, q):
     elif name == "hier_normal_exp_sigma":
         mu, ls, x = t[0], t[1], t[2:7]
         lp = N(0.0, 5.0).log_prob(mu) + N(0.0, 1.0).log_prob(ls) + N(mu, torch.exp(ls)).log_prob(x).sum() + N(x, 0.7).log_prob(torch.tensor(lm.Y5)).sum()
+    elif name == "varying_intercepts_and_slopes":
+        mu_a, lsa, a, b, ls = t[0], t[1], t[2:9], t[9:16], t[16]
+        hn = lambda l_: torch.distributions.HalfNormal(c64(1.0)).log_prob(torch.exp(l_)) + l_   # noqa: E731
+        gi = torch.tensor(lm.GI)
+        lp = (N(0.0, 2.0).log_prob(mu_a) + hn(lsa) + N(mu_a, torch.exp(lsa)).log_prob(a).sum() + N(0.0, 1.0).log_prob(b).sum() + hn(ls)
+              + N(a[gi] + b[gi] * torch.tensor(lm.XR), torch.exp(ls)).log_prob(torch.tensor(lm.YR)).sum()
+              + torch.distributions.Poisson(torch.exp(0.3 * a[gi])).log_prob(torch.tensor(np.abs(np.round(lm.YR * 2)))).sum())
     else:
         a, b, lc = t[0:4], t[4:8], t[8]
         c = torch.exp(lc)
@@ -134,7 +142,7 @@ def _torch_reference(name, q):
     return lp.item(), t.grad.numpy()
 
 
-@pytest.mark.parametrize("name", ["poisson_loglink", "hier_normal_exp_sigma", "cubic_and_friends"])
+@pytest.mark.parametrize("name", ["poisson_loglink", "hier_normal_exp_sigma", "cubic_and_friends", "varying_intercepts_and_slopes"])
 def test_expression_programs_lower_and_match_autograd(name):
     """what is not `a + b*c` -- a log link behind a Deterministic, exp(log_sigma) written as an expression, a cubic
     term, a ratio, a softplus, a power -- lowers to an expression program (graphs built by the reference's own logp bodies), is the
@@ -144,6 +152,11 @@ def test_expression_programs_lower_and_match_autograd(name):
     spec, want = lower_to_spec(make()), built()
     assert any(f.prog for f in spec.factors)
     assert [bool(f.prog) for f in spec.factors] == [bool(f.prog) for f in want.factors]
+    if name == "varying_intercepts_and_slopes":      # gathers: `a[idx]` in a plain term and inside a program
+        from pymc_amd import model_spec as ms_
+
+        kinds = [o.kind for f in spec.factors for t in f.args for o in (t.a, t.b, t.c)] + [o.kind for f in spec.factors for i in f.prog for o in (i.x, i.y)]
+        assert kinds.count(ms_.OP_GATHER) == 3
     rng = np.random.default_rng(3)
     for _ in range(4):
         q = rng.normal(size=spec.n) * 0.6
