@@ -367,3 +367,42 @@ def multitrace_from_result(spec: ModelSpec, result: dict, include_transformed: b
         t.close()
         traces.append(t)
     return MultiTrace(traces)
+
+
+# ---- InferenceData layout (pymc/backends/arviz.py:283-470), as plain arrays -------------------------------------------------------
+_STAT_RENAME = {"model_logp": "lp", "mean_tree_accept": "acceptance_rate", "depth": "tree_depth", "tree_size": "n_steps"}   # arviz.py:426-431
+
+
+def to_inference_dict(trace: MultiTrace, *, n_tune: int = 0, save_warmup: bool = False, include_transformed: bool = False,
+                      sampling_time: Optional[float] = None) -> Dict[str, Dict[str, np.ndarray]]:
+    """What `pm.to_inference_data(trace)` puts into an `InferenceData` (`DataTreeConverter.posterior_to_xarray` /
+    `sample_stats_to_xarray`, arviz.py:370-470) as a dict of groups of plain arrays -- ArviZ and xarray are not installable
+    here, so the xarray wrapping is left to the caller (`arviz.from_dict(**groups)` takes exactly this):
+
+      posterior          {variable: (chain, draw, *shape)}   untransformed variables and Deterministics (transformed value variables,
+                                                              names ending in "__", only with `include_transformed`, arviz.py:380-384)
+      sample_stats       {statistic: (chain, draw)}          the step method's statistics under ArviZ's names: model_logp -> lp,
+                                                              mean_tree_accept -> acceptance_rate, depth -> tree_depth, tree_size -> n_steps
+      warmup_posterior / warmup_sample_stats                  the first `n_tune` draws of every chain, with `save_warmup`
+      attrs              {"sampling_time", "tuning_steps"}
+
+    `trace` holds tune + draws iterations per chain when it was sampled with `discard_tuned_samples=False`; `n_tune` says how many
+    of them are warm-up (arviz.py:331-340 splits the same way)."""
+    names = [v for v in trace.varnames if include_transformed or not v.endswith("__")]
+    out: Dict[str, Dict[str, np.ndarray]] = {}
+
+    def group(sl):
+        post = {v: np.stack([np.asarray(x)[sl] for x in trace.get_values(v, combine=False, squeeze=False)]) for v in names}
+        stats = {}
+        for s_ in trace.stat_names:
+            nm = _STAT_RENAME.get(s_, s_)
+            if nm in ("tune", "in_warmup"):
+                continue
+            stats[nm] = np.stack([np.asarray(x)[sl] for x in trace.get_sampler_stats(s_, combine=False, squeeze=False)])
+        return post, stats
+
+    if n_tune and save_warmup:
+        out["warmup_posterior"], out["warmup_sample_stats"] = group(slice(0, n_tune))
+    out["posterior"], out["sample_stats"] = group(slice(n_tune, None))
+    out["attrs"] = {"sampling_time": sampling_time, "tuning_steps": n_tune}
+    return out

@@ -165,3 +165,25 @@ def test_multitrace_keeps_the_samplers_chain_ids_and_survives_zero_draws():
     empty = {"draws": np.empty((1, 0, spec.n)), "stats": [[]], "chains": [0], "step": StepStub()}
     mt0 = multitrace_from_result(spec, empty)
     assert mt0.nchains == 1 and len(mt0) == 0 and "depth" in mt0.stat_names
+
+
+def test_inference_data_layout_as_plain_arrays():
+    """`pm.to_inference_data` (backends/arviz.py:283-470) without ArviZ: groups of (chain, draw, *shape) arrays, untransformed
+    variables only by default, the sampler statistics under ArviZ's names, the warm-up split off by `n_tune`."""
+    from pymc_amd.backends import to_inference_dict
+
+    spec = _spec()
+    result = {"draws": np.stack([_points(spec, 10, 4)[0], _points(spec, 10, 5)[0]]),
+              "stats": [[s[0] for s in _points(spec, 10, 4)[1]], [s[0] for s in _points(spec, 10, 5)[1]]]}
+    mt = multitrace_from_result(spec, result)
+    idata = to_inference_dict(mt, n_tune=4, save_warmup=True, sampling_time=1.5)
+    assert set(idata) == {"posterior", "sample_stats", "warmup_posterior", "warmup_sample_stats", "attrs"}
+    assert not any(v.endswith("__") for v in idata["posterior"])
+    for v, a in idata["posterior"].items():
+        assert a.shape[:2] == (2, 6) and idata["warmup_posterior"][v].shape[:2] == (2, 4)
+    assert "tree_depth" in idata["sample_stats"] and "depth" not in idata["sample_stats"]
+    assert idata["sample_stats"]["tree_depth"].shape == (2, 6)
+    np.testing.assert_array_equal(idata["sample_stats"]["tree_depth"][0], mt.get_sampler_stats("depth", combine=False)[0][4:])
+    assert idata["attrs"] == {"sampling_time": 1.5, "tuning_steps": 4}
+    with_tr = to_inference_dict(mt, include_transformed=True)
+    assert any(v.endswith("__") for v in with_tr["posterior"]) and set(with_tr) == {"posterior", "sample_stats", "attrs"}
