@@ -1107,6 +1107,11 @@ struct nuts_chain {
   double* many_in_host = nullptr; double* many_in_dev = nullptr; char* many_out_host = nullptr; char* many_out_dev = nullptr;
   size_t many_in_cap = 0, many_out_cap = 0;
   double t_begin = 0, t_loop = 0, t_wait = 0, t_finish = 0, t_post = 0;   // host seconds per phase of nuts_chain_draw, summed
+  // host seconds per phase of nuts_chain_draw_many, summed (tools/draw_host_phases.py): batch set-up before the first launch,
+  // launching a draw's start kernels, the doubling loop (`t_wait` of it spinning on status words), draw-finish launch until its
+  // record is seen, host arithmetic per draw, batch tear-down (trace copy-back)
+  double tm_pre = 0, tm_start = 0, tm_tree = 0, tm_record = 0, tm_host = 0, tm_post = 0;
+  int64_t tm_draws = 0, tm_batches = 0;
   int64_t leapfrogs = 0;
   int n_uni_cap = 0;
   template <typename T>
@@ -1948,6 +1953,8 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
     HIPCHK(hipMalloc((void**)&c->many_out_dev, out_bytes));
     c->many_in_cap = in_doubles; c->many_out_cap = out_bytes;
   }
+  const auto tm0 = clk::now();
+  auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   const bool cached0 = c->cache_ok && c->cache_epoch == c->m->data_epoch && std::memcmp(q0, c->last_q.data(), n * sizeof(double)) == 0;
   c->cache_ok = false;
   double* const h_q = c->many_in_host;
@@ -1973,6 +1980,7 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
   int rc = NUTS_OK, done = 0;
   size_t consumed = 0;
   const int fgrid = std::max(1, std::min(256, (n + VEC_THREADS - 1) / VEC_THREADS));
+  c->tm_pre += secs(tm0, clk::now()); c->tm_batches++;
   for (int k = 0; k < K; ++k) {
     const auto t0 = clk::now();
     const double perf_start = std::chrono::duration<double>(t0.time_since_epoch()).count();
@@ -2002,8 +2010,12 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
                        c->last_logp, k > 0 ? (const DrawOut*)c->do_dev : (const DrawOut*)nullptr);
     unsigned flags = 0;
     bool exhausted = true;
+    const auto ta = clk::now();
+    c->tm_start += secs(t0, ta);
     rc = c->tree_mode ? run_tree_ga(c, h_u + consumed, step_size, max_depth, &flags, &exhausted)
                       : run_tree(c, h_u + consumed, step_size, max_depth, &flags, &exhausted);
+    const auto tb = clk::now();
+    c->tm_tree += secs(ta, tb);
     if (rc) break;
     if (flags & ST_BAD_ENERGY) {
       rc = check_mass_matrix(c);
@@ -2028,9 +2040,11 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
     }
     const DrawOut o = c->dom_host->o;
     const auto t1 = clk::now();
+    c->tm_record += secs(tb, t1);
     const std::clock_t c1 = std::clock();
     rc = finish_draw_host(c, o, adapt, exhausted, c->out_dev, o.n_proposals + ((k == 0 && !cached0) ? 1 : 0), perf_start,
                           std::chrono::duration<double>(t1 - t0).count(), (double)(c1 - c0) / CLOCKS_PER_SEC, stats + k);
+    c->tm_host += secs(t1, clk::now()); c->tm_draws++;
     if (rc) break;
     consumed += (size_t)o.cursor;
     stats[k].n_uniforms_consumed = (int32_t)consumed;
@@ -2041,6 +2055,8 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
   A.uniforms = save_u; A.log_uniforms = save_lu;
   c->logs_done = save_done; c->logs_total = save_total;
   *n_done = done;
+  const auto tm1 = clk::now();
+  struct PostTimer { nuts_chain* c; clk::time_point t; ~PostTimer() { c->tm_post += std::chrono::duration<double>(clk::now() - t).count(); } } post_timer{c, tm1};
   if (done > 0) {
     HIPCHK(hipMemcpyAsync(c->many_out_host, c->many_out_dev, (size_t)done * n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -2367,6 +2383,14 @@ extern "C" int nuts_chain_get_scalar(nuts_chain* c, const char* name, double* ou
   else if (k == "t_begin") *out = c->t_begin;
   else if (k == "t_loop") *out = c->t_loop;
   else if (k == "t_wait") *out = c->t_wait;
+  else if (k == "tm_pre") *out = c->tm_pre;
+  else if (k == "tm_start") *out = c->tm_start;
+  else if (k == "tm_tree") *out = c->tm_tree;
+  else if (k == "tm_record") *out = c->tm_record;
+  else if (k == "tm_host") *out = c->tm_host;
+  else if (k == "tm_post") *out = c->tm_post;
+  else if (k == "tm_draws") *out = (double)c->tm_draws;
+  else if (k == "tm_batches") *out = (double)c->tm_batches;
   else if (k == "t_finish") *out = c->t_finish;
   else { g_err = "unknown scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;

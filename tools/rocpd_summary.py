@@ -82,6 +82,40 @@ def traffic_json(fetch_db, write_db, out_path, kernel_like, tag, src_hash):
     json.dump(out, open(out_path, "w"), indent=1)
 
 
+def draw_timeline(path, tail_frac=0.5):
+    """Per-draw anatomy of the LAST `tail_frac` of the trace (the timed, post-warm-up part of a bench run): a draw = the dispatches
+    from one k_draw_start to the next; time inside the row-pass / data-pass kernels, inside the other kernels, and idle, by what
+    the GPU was waiting to start."""
+    cur = sqlite3.connect(path).cursor()
+    rows = list(cur.execute("select name, start, end from kernels order by start"))
+    if not rows:
+        return
+    t_lo = rows[0][1] + (1.0 - tail_frac) * (rows[-1][2] - rows[0][1])
+    rows = [r for r in rows if r[1] >= t_lo]
+    starts = [i for i, r in enumerate(rows) if r[0].startswith("k_draw_start")]
+    if len(starts) < 3:
+        return
+    tot = {"draws": 0, "span": 0.0, "dominant": 0.0, "other_kernels": 0.0, "idle": 0.0}
+    idle_by, other_by = {}, {}
+    for a, b in zip(starts, starts[1:]):
+        seg = rows[a:b + 1]
+        tot["draws"] += 1
+        tot["span"] += seg[-1][1] - seg[0][1]
+        for (n0, s0, e0), (n1, s1, e1) in zip(seg, seg[1:]):
+            dom = "k_rows" in n0 or "k_mvn_aligned" in n0 or "k_tree_ga" in n0
+            tot["dominant" if dom else "other_kernels"] += e0 - s0
+            if not dom:
+                other_by[n0[:40]] = other_by.get(n0[:40], 0.0) + (e0 - s0)
+            g = max(0, s1 - e0)
+            tot["idle"] += g
+            idle_by[n1[:40]] = idle_by.get(n1[:40], 0.0) + g
+    n = tot["draws"]
+    print(f"\n# per-draw anatomy over the last {int(100 * tail_frac)} % of the trace ({n} draws): us per draw")
+    print(f"span {tot['span']/n/1e3:9.2f}   dominant kernels {tot['dominant']/n/1e3:9.2f}   other kernels {tot['other_kernels']/n/1e3:8.2f}   idle {tot['idle']/n/1e3:8.2f}")
+    print("other kernels:  " + ", ".join(f"{k} {v/n/1e3:.2f}" for k, v in sorted(other_by.items(), key=lambda kv: -kv[1])))
+    print("idle before:    " + ", ".join(f"{k} {v/n/1e3:.2f}" for k, v in sorted(idle_by.items(), key=lambda kv: -kv[1])))
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     if args[0] == "--traffic":   # --traffic <fetch.db> <write.db> <out.json> <kernel substring> <tag> <source hash>
@@ -89,6 +123,7 @@ if __name__ == "__main__":
         sys.exit(0)
     kernel_stats(args[0])
     gap_stats(args[0])
+    draw_timeline(args[0])
     rest = args[1:]
     for a in rest:
         if a != "--pmc":
