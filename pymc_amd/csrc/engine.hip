@@ -1099,6 +1099,10 @@ struct nuts_chain {
   int64_t tree_launches = 0;
   CtlJob pend{}; bool pend_valid = false;   // control work of a doubling's last leaf waiting for the next doubling's first row pass
   bool defer_last_ctl = false; int xfold = 1;   // NUTS_XFOLD: fold control work across doublings (group-aligned row pass)
+  // row-aligned MvNormal pass: the doubling being queued will be followed (look-ahead) by one in direction `next_dir`; its last
+  // leaf then also materialises the first half of that doubling's first leaf (EvalIO.pre_next 1 / 3), and `pre_done` tells the
+  // first leaf of the next doubling that its k_leaf_pre launch is not needed
+  int next_dir = 0; bool pre_done = false; int xpre = 1;
   int tree_opts = 0;             // GA_TREE_* switches (NUTS_GA_TREE_OPTS, NUTS_GA_TREE_TICKS)
   int tree_prof_pending = 0;     // the last tree launch is being timed: its leaf count is added when the draw's record arrives
   int spec_max = 10, last_depth = 0;   // look-ahead over the doublings, as deep as the previous tree went (run_tree)
@@ -1306,6 +1310,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0 && !(m->md.has_mvn && m->md.mv.winv);   // (the four-launch MvNormal pass has no workgroup 0 for it)
   c->spec_max = env_int("NUTS_SPEC_MAX", 10);
   c->xfold = env_int("NUTS_XFOLD", 1);
+  c->xpre = env_int("NUTS_XPRE", 1);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
              !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
@@ -1591,8 +1596,16 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   if (io.lean && io.explicit_pre && foldable) {
     // MvNormal model on the lean path: kernel B of leaf j also materialises the first half of leaf j+1, the control
     // work of leaf j-1 rides in workgroup 0 of this leaf's mat-vec; the last leaf gets a control launch of its own
-    if (j == 0) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
+    const bool al_xpre = m->md.mv.aligned && mode == MODE_TREE && c->xpre;
+    if (j == 0 && !(al_xpre && c->pre_done)) hipLaunchKernelGGL(k_leaf_pre, dim3(A.nblk), dim3(VEC_THREADS), 0, s, A, io, j);
+    if (j == 0) c->pre_done = false;
     io.pre_next = last ? 0 : 1;
+    if (last && al_xpre && c->defer_last_ctl && c->next_dir != 0) {
+      // the next doubling is queued right behind this leaf: same side -> its first leaf starts from this one (what pre_next = 1
+      // writes); other side -> from the tree's other edge state (pre_next = 3: k_leaf_pre's arithmetic on this workgroup's rows)
+      io.pre_next = c->next_dir == gm.dir ? 1 : 3;
+      c->pre_done = true;
+    }
     // row-aligned pass: as for the group-aligned row pass below, the control work of a doubling's LAST leaf rides in the first
     // launch of the next doubling when the look-ahead queues that doubling right behind it (run_tree sets `defer_last_ctl`)
     const bool al_tree_leaf = m->md.mv.aligned && mode == MODE_TREE;
@@ -1724,10 +1737,12 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
     // will doubling d + 1 be queued (look-ahead) before the status of this one is waited for?  Then its first row pass takes
     // this doubling's last control work with it.
     c->defer_last_ctl = c->xfold && c->fold_ctl && d + 1 < max_depth && d + 1 <= spec;
+    c->next_dir = c->defer_last_ctl ? (uniforms[(2 << d) + d] < 0.5 ? 1 : -1) : 0;   // (the direction of doubling d + 1 whenever it is needed at all)
     for (int j = 0; j < nleaf; ++j) enqueue_leaf(c, g, j, d, MODE_TREE, max_depth, j + 1 == nleaf ? seq : 0);
     c->defer_last_ctl = false;
     return seq;
   };
+  c->pre_done = false;
   c->pend_valid = false;   // (a look-ahead doubling behind the end of the previous tree may have left its control work unclaimed: it
                            // would only have drained)
   auto flush_pending = [&](int seq_waited) {   // (not pending by construction: never wait on a status nobody will publish)

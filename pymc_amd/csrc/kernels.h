@@ -1310,7 +1310,16 @@ __global__ __launch_bounds__(MVA_THREADS) void k_mvn_aligned(ModelDev md, ArenaD
   }
   int m = 0; bool last = false;
   if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);   // -> s_red[k + TW]
-  if (leaf && io.pre_next && a0) {   // first half of the next leaf (integration.py:118-127): the arithmetic of k_leaf_pre
+  if (leaf && io.pre_next == 3 && a0) {
+    // last leaf of a doubling, the next one (queued behind it) grows on the OTHER side: first half of its first leaf from the tree's
+    // other edge state -- k_leaf_pre's arithmetic (signed step of the other direction) on this workgroup's rows
+    const int e = lf.dir > 0 ? lf.left : lf.right;
+    const int64_t eo = slot_off(A, e), no = slot_off(A, e - lf.dir);
+    const double eps2 = -lf.eps, half2 = 0.5 * eps2;
+    const double ph2 = fma(half2, A.G[eo + my], A.P[eo + my]);
+    A.P[no + my] = ph2;
+    A.Q[no + my] = fma(eps2, var_r * ph2, A.Q[eo + my]);
+  } else if (leaf && io.pre_next && a0) {   // first half of the next leaf (integration.py:118-127): the arithmetic of k_leaf_pre
     const int64_t no = slot_off(A, lf.t + lf.dir);
     const double p = fma(lf.half, -t, phv);   // p' of this leaf, as leaf_post computed it
     const double phn = fma(lf.half, -t, p);

@@ -487,7 +487,7 @@ STAT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_
 def _run_schedule(spec, env, monkeypatch, tune, draws, seed, **step_kwargs):
     from pymc_amd.sampling import sample
 
-    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL", "NUTS_GA_ONES0", "NUTS_MVN_ALIGNED")
+    keys = ("NUTS_GA_VARIANT", "NUTS_GA_TREE", "NUTS_ROWS_GA", "NUTS_XFOLD", "NUTS_SPEC_MAX", "NUTS_FOLD_CTL", "NUTS_GA_ONES0", "NUTS_MVN_ALIGNED", "NUTS_XPRE")
     for k in keys:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -578,7 +578,8 @@ def test_row_aligned_mvnormal_pass(monkeypatch):
 
     for k, tune, draws in ((512, 30, 10), (301, 20, 6)):
         spec = models.mvnormal(n=k, seed=5)
-        envs = ({}, {"NUTS_XFOLD": "0"}, {"NUTS_SPEC_MAX": "0"}, {"NUTS_XFOLD": "0", "NUTS_SPEC_MAX": "10"}, {"NUTS_FOLD_CTL": "0"})
+        envs = ({}, {"NUTS_XFOLD": "0"}, {"NUTS_SPEC_MAX": "0"}, {"NUTS_XFOLD": "0", "NUTS_SPEC_MAX": "10"}, {"NUTS_FOLD_CTL": "0"},
+                {"NUTS_XPRE": "0"})   # (XPRE: the first half of a doubling's first leaf materialised by the previous doubling's last leaf)
         runs = [_run_schedule(spec, env, monkeypatch, tune, draws, 79) for env in envs]
         d0, s0, _ = runs[0]
         for env, (d1, s1, _) in zip(envs[1:], runs[1:]):
