@@ -248,8 +248,20 @@ def _init_torch_runtime_first():
     """PyTorch wheels bundle their own copy of the HIP runtime (torch/lib/libamdhip64.so) while this library links
     the system one (/opt/rocm).  Both can live in one process, but only if torch's copy initialises FIRST; if the
     engine touched the GPU before `torch.cuda` did, torch later reports "no GPUs found" and the RCCL plumbing
-    (trace gather, pooled adaptation) cannot start.  So: bring torch's runtime up before loading ours."""
+    (trace gather, pooled adaptation) cannot start.  torch is plumbing for the collectives only, so it is brought up first only
+    where it can matter: when the process has already imported it, when it runs under a distributed launcher (WORLD_SIZE > 1),
+    or when asked to (PYMC_AMD_TORCH_FIRST=1: a process that will import torch LATER, e.g. the test suite).  A single-GPU
+    user of the sampler never imports torch."""
     if os.environ.get("PYMC_AMD_SKIP_TORCH_INIT"):
+        return
+    import sys
+
+    wanted = "torch" in sys.modules or os.environ.get("PYMC_AMD_TORCH_FIRST") == "1"
+    try:
+        wanted = wanted or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    except ValueError:
+        pass
+    if not wanted:
         return
     try:
         import torch

@@ -6,6 +6,9 @@ import pytest
 # The engine never reads the environment; the schedule tests select schedules with `monkeypatch.setenv("NUTS_...")`, which
 # pymc_amd._lib.sync_options_from_env forwards to `nuts_set_option` when a model / chain is created -- only under this switch.
 os.environ["PYMC_AMD_HONOUR_NUTS_ENV"] = "1"
+# some GPU tests import torch (RCCL plumbing) AFTER the engine has been loaded by earlier tests: torch's bundled HIP runtime
+# must come up first in such a process (pymc_amd._lib._init_torch_runtime_first)
+os.environ.setdefault("PYMC_AMD_TORCH_FIRST", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
