@@ -30,6 +30,8 @@ from pymc_amd.quadpotential import QuadPotentialDiagAdapt, QuadPotentialDiagAdap
 from pymc_amd.step import NUTS, get_random_generator
 
 
+CONCURRENT_CHAINS_BELOW_BYTES = 64 << 20   # data pass of a leapfrog smaller than this: cache-resident, chains of a rank run concurrently
+
 _log = logging.getLogger("pymc_amd")   # (the reference logs under "pymc", sampling/mcmc.py:94)
 _LEVELS = {"info": logging.INFO, "error": logging.ERROR, "warn": logging.WARNING, "debug": logging.DEBUG, "critical": logging.CRITICAL}
 
@@ -313,8 +315,9 @@ def sample(
     ``cores`` (mcmc.py:690-693 `cores`: "number of chains to run in parallel"): the reference runs chains in
     worker processes on host cores (parallel.py:352-372).  Here a chain of a model on the single-launch path keeps
     ONE workgroup of the GPU busy, so the chains of a rank run concurrently from host threads, each with its own
-    engine handles and stream; default min(4, chains on this rank) for such models, 1 otherwise (a C2-sized chain
-    saturates the GPU by itself).  Every chain starts from the same `sampling_state` and its own generator, so the
+    engine handles and stream; default min(4, chains on this rank) for such models and for models whose data pass is
+    cache-resident (latency-bound: chains sharing the GPU fill each other's gaps), 1 otherwise (a C2-L-sized chain saturates the
+    GPU by itself).  Every chain starts from the same `sampling_state` and its own generator, so the
     result does not depend on `cores`.
 
     ``mp_ctx`` (mcmc.py `mp_ctx`: "spawn" / "forkserver"): run the chains of this rank in WORKER PROCESSES instead, one per
@@ -374,7 +377,16 @@ def sample(
     t0 = time.perf_counter()
     t_sampling = 0.0
     single_launch = bool(step._scalar("single_launch")) if hasattr(step, "_scalar") else False
-    n_par = min(len(mine), cores if cores is not None else (4 if single_launch else 1))
+    # Latency-bound models -- the single-launch path, and models whose data pass is cache-resident (C2-S: 6.9 MB, C3: 33.5 MB per
+    # leapfrog against the 256 MiB Infinity Cache) -- leave most of the GPU idle between dependent launches: chains that share the
+    # GPU fill each other's gaps (measured, profiles/r03h_shared_gpu.txt: C2-S 58.7 k leapfrog/s for one chain, 102.8 k for two,
+    # 140.9 k for four; C3 85 k -> 179.6 k for four).  An HBM-bound model (C2-L) saturates the GPU by itself.
+    latency_bound = single_launch
+    try:
+        latency_bound = latency_bound or 0 < int(step._logp_dlogp_func.algorithmic_bytes) < CONCURRENT_CHAINS_BELOW_BYTES
+    except Exception:
+        pass
+    n_par = min(len(mine), cores if cores is not None else (4 if latency_bound else 1))
     if pooled is not None or step_given or n_par < 1:
         n_par = 1
     if mp_ctx is not None and pooled is None and len(mine) > 0:

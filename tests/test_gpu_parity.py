@@ -1375,3 +1375,20 @@ def test_gathered_variables_logp_grad_and_nuts(shape):
     rng = np.random.default_rng(8)
     _check_logp_grad(spec, [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.4 for _ in range(3)])
     _compare_runs(spec, tune=25, draws=10, seed=6, prefix=30 if shape == "small" else 20)
+
+
+def test_cache_resident_models_run_their_chains_concurrently_with_the_same_result():
+    """`sample()` runs the chains of a rank concurrently (host threads, one engine handle set and stream each) when the model is
+    latency-bound -- now also when its data pass is cache-resident (mid-size hierarchical logit, MvNormal) -- and every chain is
+    bitwise the chain sequential sampling gives."""
+    from pymc_amd.sampling import sample
+
+    for spec in (models.hier_logit(G=256, D=8, rows_per_group=60, seed=4), models.mvnormal(n=192, seed=3)):
+        a = sample(draws=20, tune=30, chains=3, model=spec, random_seed=5, device=0, cores=1)
+        b = sample(draws=20, tune=30, chains=3, model=spec, random_seed=5, device=0)          # default: concurrent for such models
+        assert np.array_equal(a["draws"], b["draws"])
+        for sa, sb in zip(a["stats"], b["stats"]):
+            for x, y in zip(sa, sb):
+                for k in INT_KEYS + ("energy", "step_size"):
+                    assert x[k] == y[k], k
+        a["step"].close(); b["step"].close()
