@@ -136,7 +136,7 @@ typedef struct {
      rows sorted by group (rows_gid non-decreasing). rows_N == 0 disables. */
   int64_t rows_N;
   int32_t rows_D, rows_G;
-  const double *rows_X;    /* [N][D] row-major (re-laid out column-major in HBM) */
+  const double *rows_X;    /* [N][D] row-major, 1 <= D <= 8 (re-laid out column-major in HBM) */
   const int8_t *rows_y;    /* [N] */
   const int32_t *rows_gid; /* [N] */
   int32_t rows_mu, rows_sigma, rows_z; /* var ids */

@@ -181,7 +181,12 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
         case 8: if (md.lg.ga_dx == 7) hipLaunchKernelGGL((k_rows_gb<8, 7>), grid, block, 0, m->stream, ga);
                 else hipLaunchKernelGGL((k_rows_gb<8>), grid, block, 0, m->stream, ga); break;
         case 4: hipLaunchKernelGGL((k_rows_gb<4>), grid, block, 0, m->stream, ga); break;
-        default: hipLaunchKernelGGL((k_rows_gb<2>), grid, block, 0, m->stream, ga); break;
+        case 2: hipLaunchKernelGGL((k_rows_gb<2>), grid, block, 0, m->stream, ga); break;
+        case 1: hipLaunchKernelGGL((k_rows_gb<1>), grid, block, 0, m->stream, ga); break;
+        case 3: hipLaunchKernelGGL((k_rows_gb<3>), grid, block, 0, m->stream, ga); break;
+        case 5: hipLaunchKernelGGL((k_rows_gb<5>), grid, block, 0, m->stream, ga); break;
+        case 6: hipLaunchKernelGGL((k_rows_gb<6>), grid, block, 0, m->stream, ga); break;
+        default: hipLaunchKernelGGL((k_rows_gb<7>), grid, block, 0, m->stream, ga); break;
       }
     } else {
 #define GA_LAUNCH(DD, OO, PP) hipLaunchKernelGGL((k_rows_ga<DD, 2, OO, PP>), grid, block, 0, m->stream, ga)
@@ -218,7 +223,14 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
       case 6: ROWS_BY_D(RR, 6) break;                       \
       default: ROWS_BY_D(RR, 4) break;                      \
     }
-    if (m->rows_rpl == 2) { ROWS_BY_OCC(2) } else { ROWS_BY_OCC(4) }
+    switch (md.lg.D) {   // (widths that are not a power of two: one launch geometry)
+      case 1: ROWS_LAUNCH(1, 2, 4); break;
+      case 3: ROWS_LAUNCH(3, 2, 4); break;
+      case 5: ROWS_LAUNCH(5, 2, 4); break;
+      case 6: ROWS_LAUNCH(6, 2, 4); break;
+      case 7: ROWS_LAUNCH(7, 2, 4); break;
+      default: if (m->rows_rpl == 2) { ROWS_BY_OCC(2) } else { ROWS_BY_OCC(4) }
+    }
 #undef ROWS_BY_OCC
 #undef ROWS_BY_D
 #undef ROWS_LAUNCH
@@ -573,7 +585,11 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
 
   if (s->rows_N > 0) {
     const int D = s->rows_D;
-    if (!(D == 8 || D == 4 || D == 2)) { g_err = "logit rows: D must be 2, 4 or 8"; nuts_model_destroy(m); return nullptr; }
+    if (D < 1 || D > LOGIT_MAXD) { g_err = "logit rows: 1 <= D <= 8 covariates"; nuts_model_destroy(m); return nullptr; }
+    // (D = 2, 4, 8 have every schedule; the other widths run the span-partitioned pass and the group-block pass, one element per
+    // thread in kernel B)
+    const bool d_pow2 = D == 8 || D == 4 || D == 2;
+    if (!d_pow2 && m->ept != 1) { g_err = "logit rows: D must be 2, 4 or 8 for models beyond 65 536 parameters"; nuts_model_destroy(m); return nullptr; }
     RowsDev& lg = md.lg;
     md.has_logit = 1;
     // launch geometry (tunable for experiments; defaults chosen from measurements)
@@ -629,8 +645,8 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       if (env_int("NUTS_ROWS_GA_W", 0) > 0) W = std::max(1, std::min(GA_MAXW, env_int("NUTS_ROWS_GA_W", 0)));
       const double meanT = (double)n_tiles / std::max(lg.G, 1);
       bool use = false;
-      if (want >= 2) { use = m->ga_struct_ok && m->ept == 1; W = std::max(1, W); }
-      else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && W >= 1 && lg.G >= 2 * cus && meanT >= 4.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
+      if (want >= 2) { use = m->ga_struct_ok && m->ept == 1 && d_pow2; W = std::max(1, W); }
+      else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && d_pow2 && W >= 1 && lg.G >= 2 * cus && meanT >= 4.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
       // group-BLOCK pass (rows_gb_kernel.h) for small groups: the same closed-form model, a workgroup owns GPW whole groups and
       // nothing crosses workgroups inside the launch.  NUTS_ROWS_GB=0 keeps such models on the general path (A/B, tests).
       int gpw = 0;
@@ -666,7 +682,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         lg.ga_dx = DX;
         // (the skew between chunks is an ODD multiple of 256 B and a multiple of the tile's column count, so that the y bytes
         // of a tile sit at its element offset / DX)
-        const int64_t TS = (int64_t)DX * SPAN, GA_SKEW = env_int("NUTS_GA_SKEW", DX == 7 ? 1120 : 1056);
+        const int64_t TS = (int64_t)DX * SPAN, GA_SKEW = env_int("NUTS_GA_SKEW", DX == 7 || DX == 5 ? 1120 : 1056);   // 32 x 35, 32 x 33
         if (GA_SKEW % DX != 0) { g_err = "NUTS_GA_SKEW must be a multiple of the stored column count"; nuts_model_destroy(m); return nullptr; }
         std::vector<int64_t> coff((size_t)lg.G * W, 0);
         int64_t pos = 0, max_ct = 0;

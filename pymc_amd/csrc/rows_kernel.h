@@ -180,8 +180,22 @@ __device__ __forceinline__ void rows_hyper_fold_elem(const RowsDev& R, const dou
     cs[s] = sum_strided<AGENT>(part + k, stride, c * per, min(nblk, (c + 1) * per));
   }
   double S = 0.0;
+  if constexpr (WAVE % NE == 0) {   // D a power of two: the pairs of a chunk never straddle two of the per-lane slots
 #pragma unroll
-  for (int c = 0; c < CTL_CHUNKS; ++c) S += __shfl(cs[(NE * c) / WAVE], (NE * c) % WAVE + e);
+    for (int c = 0; c < CTL_CHUNKS; ++c) S += __shfl(cs[(NE * c) / WAVE], (NE * c) % WAVE + e);
+  } else {                          // any D: pair (e, c) is number NE c + e, i.e. slot (NE c + e) / 64 of lane (NE c + e) % 64
+#pragma unroll
+    for (int c = 0; c < CTL_CHUNKS; ++c) {
+      const int p = NE * c + e;
+      double got = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        const double t = __shfl(cs[sl], p % WAVE);
+        got = (p / WAVE == sl) ? t : got;
+      }
+      S += got;
+    }
+  }
   const double g = deferred_finish(l01.x, S, l01.y, l23.x);
   const double p_src = fma(qv.half, g, l23.y);                       // p' of the previous leaf (integration.py:131)
   ph = fma(qv.half, g, p_src);                                       // this leaf's p_half

@@ -156,12 +156,22 @@ def test_truncated_normal_known_answer():
 
 @pytest.mark.parametrize(
     "G,D,rpg",
-    [(1, 8, 7), (3, 8, 1), (5, 8, 300), (40, 8, 13), (17, 4, 129), (9, 2, 1000), (64, 8, 256)],
+    [(1, 8, 7), (3, 8, 1), (5, 8, 300), (40, 8, 13), (17, 4, 129), (9, 2, 1000), (64, 8, 256),
+     # covariate counts that are not a power of two (span-partitioned pass; from 64 groups on the group-block pass), and D = 1
+     (11, 3, 70), (6, 5, 400), (30, 6, 17), (9, 7, 129), (13, 1, 50), (80, 3, 90), (100, 5, 37), (70, 7, 200), (64, 1, 130), (90, 6, 5)],
 )
 def test_hier_logit_logp_grad(G, D, rpg):
     spec = models.hier_logit(G=G, D=D, rows_per_group=rpg, seed=G * 100 + rpg)
     rng = np.random.default_rng(3)
     _check_logp_grad(spec, [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.5 for _ in range(3)])
+
+
+@pytest.mark.parametrize("G,D,rpg", [(12, 3, 60), (96, 5, 40), (70, 7, 150)])
+def test_nuts_parity_hier_logit_any_covariate_count(G, D, rpg):
+    """The logit node with 3, 5 and 7 covariates (general path below 64 groups, group-block pass from there): a NUTS run with the
+    oracle sampler's integers."""
+    spec = models.hier_logit(G=G, D=D, rows_per_group=rpg, seed=G + D)
+    _compare_runs(spec, tune=20, draws=8, seed=9, prefix=22)
 
 
 def test_large_n_multi_element_threads():
@@ -230,11 +240,11 @@ def test_abi_rejects_malformed_specs():
     with pytest.raises(_lib.EngineError, match="sorted"):
         DeviceValueGradFunction(spec, device=0)
     m = ModelBuilder()
-    mu = m.Normal("mu", 0.0, 1.0, shape=3)
-    sg = m.HalfNormal("sigma", 1.0, shape=3)
-    z = m.Normal("z", 0.0, 1.0, shape=(2, 3))
-    m.HierLogitRows("y", rng.normal(size=(4, 3)), np.zeros(4), np.array([0, 0, 1, 1]), mu, sg, z)
-    with pytest.raises(_lib.EngineError, match="D must be"):
+    mu = m.Normal("mu", 0.0, 1.0, shape=9)
+    sg = m.HalfNormal("sigma", 1.0, shape=9)
+    z = m.Normal("z", 0.0, 1.0, shape=(2, 9))
+    m.HierLogitRows("y", rng.normal(size=(4, 9)), np.zeros(4), np.array([0, 0, 1, 1]), mu, sg, z)
+    with pytest.raises(_lib.EngineError, match="1 <= D <= 8"):
         DeviceValueGradFunction(m.build(), device=0)
     step_spec = models.std_normal(3)
     from pymc_amd.step import NUTS
