@@ -870,8 +870,8 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       if (R == 2 || R == 4 || R == 8) {
         mv.aligned = R;
         mv.al_nwg = (mv.k + R - 1) / R;
-        mv.al_part = m->keep(dev_alloc<double>(2 * (size_t)PART_STRIDE * mv.al_nwg));
-        if (mv.al_part) hipMemset(mv.al_part, 0, 2 * (size_t)PART_STRIDE * mv.al_nwg * sizeof(double));
+        mv.al_part = m->keep(dev_alloc<double>(2 * (size_t)MVA_RS * mv.al_nwg));
+        if (mv.al_part) hipMemset(mv.al_part, 0, 2 * (size_t)MVA_RS * mv.al_nwg * sizeof(double));
       }
     }
   }

@@ -667,9 +667,50 @@ __global__ __launch_bounds__(VEC_THREADS) void k_tree_vec(ModelDev md, ArenaDev 
 // C: the control kernel (one workgroup)
 // ---------------------------------------------------------------------------
 
+// The uniforms a leaf's decisions may consume -- log u of its m merges and of `extend`, the raw u of the next direction -- sit at
+// cursor, cursor + 1, ...: addresses known as soon as the control block is.  Read one after the other inside tree_decide each
+// was a dependent miss on the single lane that decides (~1300 cycles per merge level, profiles/r03f_gb_round.txt: 26 -> 82 hundred
+// cycles from m = 0 to m = 3); requested together, up front, they cost one.  Entries beyond `n` are read the old way.
+#define UNI_PF 6
+struct UniPrefetch { double lu0, lu1, lu2, lu3, lu4, lu5, un; int base, n, un_idx; };   // (scalars: an array member ended up in scratch)
+__device__ __forceinline__ double uni_log_at(const ArenaDev& A, int i) { return A.log_uniforms ? A.log_uniforms[i] : log(A.uniforms[i]); }
+__device__ __forceinline__ void uni_prefetch_none(UniPrefetch& pf) {
+  pf.base = 0; pf.n = 0; pf.un_idx = -1; pf.un = 0.0;
+  pf.lu0 = pf.lu1 = pf.lu2 = pf.lu3 = pf.lu4 = pf.lu5 = 0.0;
+}
+__device__ __forceinline__ void uni_prefetch(const ArenaDev& A, int cursor, int m, bool last, UniPrefetch& pf) {
+  pf.base = cursor;
+  const int want = m + (last ? 1 : 0);
+  const int n = want < UNI_PF ? want : UNI_PF;
+  pf.n = n;
+  // (indices <= cursor + m + 1: what this leaf consumes if nothing stops it, inside the draw's worst-case budget)
+  pf.lu0 = uni_log_at(A, cursor + min(0, max(n - 1, 0)));
+  pf.lu1 = uni_log_at(A, cursor + min(1, max(n - 1, 0)));
+  pf.lu2 = uni_log_at(A, cursor + min(2, max(n - 1, 0)));
+  pf.lu3 = uni_log_at(A, cursor + min(3, max(n - 1, 0)));
+  pf.lu4 = uni_log_at(A, cursor + min(4, max(n - 1, 0)));
+  pf.lu5 = uni_log_at(A, cursor + min(5, max(n - 1, 0)));
+  pf.un_idx = last ? cursor + m + 1 : -1;
+  pf.un = A.uniforms[cursor + (last ? m + 1 : 0)];
+}
+// tree_decide picks the values by a run-time index: they are parked in LDS by the deciding lane itself just before it decides (a select
+// chain over registers is turned into a scratch look-up table by the compiler).  `lds` holds UNI_PF doubles.
+struct UniView { const double* lds; double un; int base, n, un_idx; };
+__device__ __forceinline__ UniView uni_stash(const UniPrefetch& pf, double* lds) {
+  lds[0] = pf.lu0; lds[1] = pf.lu1; lds[2] = pf.lu2; lds[3] = pf.lu3; lds[4] = pf.lu4; lds[5] = pf.lu5;
+  return UniView{lds, pf.un, pf.base, pf.n, pf.un_idx};
+}
+__device__ __forceinline__ UniView uni_view_none() { return UniView{nullptr, 0.0, 0, 0, -1}; }
+__device__ __forceinline__ double ctl_log_uniform(const ArenaDev& A, int cursor, const UniView& pf) {
+  const int r = cursor - pf.base;
+  if (r >= 0 && r < pf.n) return pf.lds[r];
+  return uni_log_at(A, cursor);
+}
+
 // direction of the next doubling: `(rng.random() < 0.5) * 2 - 1` (nuts.py:215)
-__device__ __forceinline__ void ctl_next_direction(Ctl* c, const double* uniforms) {
-  const double u = uniforms[c->cursor++];
+__device__ __forceinline__ void ctl_next_direction(Ctl* c, const double* uniforms, double u_pf = 0.0, int u_pf_idx = -1) {
+  const double u = u_pf_idx == c->cursor ? u_pf : uniforms[c->cursor];
+  c->cursor++;
   c->dir = (u < 0.5) ? 1 : -1;
   c->eps = c->dir > 0 ? c->eps_abs : -c->eps_abs;
   c->edge = c->dir > 0 ? c->right : c->left;
@@ -678,7 +719,7 @@ __device__ __forceinline__ void ctl_next_direction(Ctl* c, const double* uniform
 // Scalar decisions of one leaf (nuts.py:394-476 and, on the last leaf, `extend` 334-392), on the LDS copy of the
 // control block.  `dot` = the reduced dot products of this leaf, E its energy.
 __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Leaf& lf, const double* dot, double E, int m, bool last,
-                                            double Emax, int max_depth) {
+                                            double Emax, int max_depth, const UniView upf) {
   const int t = lf.t;
   const int dir = lf.dir;
   double dE = E - c->E0;                 // nuts.py:408-410
@@ -702,7 +743,7 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
         if (!turning) turning = (dd[4] <= 0) || (dd[5] <= 0);
       }
       const double ls = logaddexp_d(c->st_ls[l], cur_ls);                   // nuts.py:464
-      const double logu = A.log_uniforms ? A.log_uniforms[c->cursor] : log(A.uniforms[c->cursor]);
+      const double logu = ctl_log_uniform(A, c->cursor, upf);
       c->cursor++;
       if (logu < cur_ls - ls) { /* keep tree2's proposal */ } else cur_prop = c->st_prop[l];
       cur_ls = ls;
@@ -715,7 +756,7 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
       // extend (nuts.py:365-392)
       if (dir > 0) c->right = t; else c->left = t;
       c->depth += 1;
-      const double logu = A.log_uniforms ? A.log_uniforms[c->cursor] : log(A.uniforms[c->cursor]);
+      const double logu = ctl_log_uniform(A, c->cursor, upf);
       c->cursor++;
       if (logu < cur_ls - c->log_size) c->proposal = cur_prop;
       c->log_size = logaddexp_d(cur_ls, c->log_size);
@@ -724,7 +765,7 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
       if (!turn) turn = (dd[2] <= 0) || (dd[3] <= 0);
       if (!turn) turn = (dd[4] <= 0) || (dd[5] <= 0);
       if (turn) { c->turning = 1; c->aborted = 1; }
-      else if (c->depth < max_depth) ctl_next_direction(c, A.uniforms);
+      else if (c->depth < max_depth) ctl_next_direction(c, A.uniforms, upf.un, upf.un_idx);
     }
   }
 }
@@ -885,7 +926,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
   A.E[ts] = E;
   if (!tree) return;
 
-  tree_decide(&s_ctl, A, lf, dot, E, m, last, Emax, max_depth);
+  tree_decide(&s_ctl, A, lf, dot, E, m, last, Emax, max_depth, uni_view_none());
   Ctl* c = &s_ctl;
   TICK(md, tk, 24);
   *A.ctl = *c;
@@ -916,7 +957,7 @@ struct LeanSrc { const double* part; int stride, nblk; const double* def_loc; in
 #define SLOT_SUM_MAXR 8   // records per lane: ga_nblk <= 512
 __device__ __forceinline__ void slot_sum_issue(const double* slot, int npad, int lane, double (&v)[SLOT_SUM_MAXR]) {
 #pragma unroll
-  for (int u = 0; u < SLOT_SUM_MAXR; ++u) v[u] = slot[min(lane + WAVE * u, npad - 1)];   // (clamped: unconditional loads)
+  for (int u = 0; u < SLOT_SUM_MAXR; ++u) v[u] = WAVE * u < npad ? slot[lane + WAVE * u] : 0.0;   // (npad is a multiple of 64: a uniform test per load)
 }
 __device__ __forceinline__ double slot_sum_finish(const double (&v)[SLOT_SUM_MAXR], int npad, int lane) {
   double acc = 0.0;
@@ -934,7 +975,8 @@ __device__ __forceinline__ double slot_sum_finish(const double (&v)[SLOT_SUM_MAX
 // is known (they belong to earlier leaves) -- otherwise every merge level costs the control workgroup a round of far loads.
 template <bool AGENT = false, int BATCH = 8, bool PF = false>
 __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
-                                             int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt = 0) {
+                                             int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt, bool have_upf,
+                                             UniPrefetch upf) {
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
   constexpr int NWMAX = VEC_THREADS / WAVE;
@@ -942,6 +984,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   __shared__ double s_sum[PART_STRIDE];
   __shared__ double s_chunk[CTL_CHUNKS][PART_STRIDE];
   __shared__ double s_red[NDOT * NWMAX];
+  __shared__ double s_lu[UNI_PF];
   __shared__ Ctl s_ctl;
   const int tid = threadIdx.x;
   const bool leaf = io.mode != MODE_PLAIN;
@@ -1012,6 +1055,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     if (tid == 0 && st) publish_status(&s_ctl, st, seq);
     return;
   }
+  if (tree && tid == 0 && !have_upf) uni_prefetch(A, s_ctl.cursor, m, last, upf);   // lands while the elements below are finished
   if (!src.slot_major) {
     for (int t = tid; t < nn; t += NT) {
       const int k = need_slot(t);
@@ -1040,17 +1084,20 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   }
   int m2 = 0; bool last2 = false;
   TICK(md, ctk, 10);
-  leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2, (PF && tree) ? &mpf : nullptr);
-  __syncthreads();
-  TICK(md, ctk, 11);
-  // totals: workgroup partials (in order) + the deferred elements' share
-  for (int q = tid; q < NDOT; q += NT) {
-    if (!dot_needed(q, m, last)) continue;
-    double r = 0.0;
-    for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];
-    s_sum[PART_DOT + q] += r;
+  if (md.n_deferred > 0) {   // (a model without deferred elements -- the MvNormal node -- has nothing to add to the dot products: no
+                             // merge-level wave sums of zeros on the path the launch waits for)
+    leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, NW, m2, last2, (PF && tree) ? &mpf : nullptr);
+    __syncthreads();
+    TICK(md, ctk, 11);
+    // totals: workgroup partials (in order) + the deferred elements' share
+    for (int q = tid; q < NDOT; q += NT) {
+      if (!dot_needed(q, m, last)) continue;
+      double r = 0.0;
+      for (int w = 0; w < NW; ++w) r += s_red[q * NW + w];
+      s_sum[PART_DOT + q] += r;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (tid != 0) return;
   const double* dot = &s_sum[PART_DOT];
   const int t = lf.t, ts = t & (A.S - 1);
@@ -1059,10 +1106,18 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   A.E[ts] = E;
   if (!tree) return;
   TICK(md, ctk, 12);
-  tree_decide(&s_ctl, A, lf, dot, E, m, last, Emax, max_depth);
+  tree_decide(&s_ctl, A, lf, dot, E, m, last, Emax, max_depth, uni_stash(upf, s_lu));
   *A.ctl = s_ctl;
   if (st) publish_status(&s_ctl, st, seq);
   TICK(md, ctk, 13);
+}
+
+template <bool AGENT = false, int BATCH = 8, bool PF = false>
+__device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
+                                             int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt = 0) {
+  UniPrefetch upf;
+  uni_prefetch_none(upf);
+  control_lean<AGENT, BATCH, PF>(md, A, io, j, d, Emax, max_depth, st, seq, src, nt, false, upf);
 }
 
 // `par`: launch parity of the leaf's row pass (group-aligned row pass only; its partials are double-buffered)
@@ -1170,6 +1225,9 @@ __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_matvec(ModelDev md, ArenaDev 
 // floating-point atomics, and no hand-off inside a launch (a ticket + write-through records per workgroup, as the row pass of
 // the logit node does it, cost 16 us here: the kernel is too short to hide them; measured).  Records are double-buffered by
 // launch parity: the control work of leaf j rides in leaf j+1's launch, whose rows are already writing theirs.
+#define MVA_RS 80   // doubles per record: logp share, p'.v', six dots per merge level (<= MAX_LEVELS), the six of `extend`
+#define MVA_SW 16   // slots per load window (a wave's load covers 4 records x 16 slots)
+#define MVA_U 32    // loads in flight per lane
 __device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax, int max_depth,
                                             HostStatus* st, int seq, int par, int nt) {
   const MvnDev& mv = md.mv;
@@ -1190,34 +1248,50 @@ __device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& 
     return PART_DOT + DOT_TOP + (qq - 2 - 6 * m);
   };
   const int nwg = mv.al_nwg;
-  const double* rec = mv.al_part + (int64_t)par * PART_STRIDE * nwg;
-  // every thread sums its share (records tid, tid + NT, ...) of each needed slot; the loads of MVA_BATCH slots are in flight
-  // together -- the records were written by every XCD, so each batch costs one trip to memory and the number of batches is
-  // what this workgroup's latency is made of
-  constexpr int MVA_BATCH = 16;
-  for (int q0 = 0; q0 < nn; q0 += MVA_BATCH) {
-    double v[MVA_BATCH];
-    const double* src[MVA_BATCH];
+  const double* rec = mv.al_part + (int64_t)par * MVA_RS * nwg;
+  // the uniforms this leaf may consume: the cursor is read straight from the control block with the very first loads
+  UniPrefetch upf;
+  uni_prefetch_none(upf);
+  int cur0 = 0;
+  if (tree && tid == 0) cur0 = A.ctl->cursor;
+  // Records are RECORD-major and compact (slot qq of a record = the qq-th number this leaf needs): a wave reads MVA_SW slots of
+  // four records with one coalesced load, lane = (record mod 4, slot), and keeps MVA_U such loads in flight -- the 512 records
+  // of C3 cost every lane ONE trip to memory however many slots the leaf needs up to 16 (m <= 2: 7 of 8 leaves), where the
+  // slot-major layout with a wave sum per slot cost a trip plus sixteen DPP trees per 16 slots.  Fixed order: a lane adds its records in
+  // index order, the four record classes pair up (0 + 1) + (2 + 3), the waves are added in wave order.
+  // (addresses = a wave-uniform base per load + ONE per-lane offset: 64 registers of data in flight, not 64 more of addresses --
+  // the row waves of this kernel need the occupancy)
+  constexpr int NW = VEC_THREADS / WAVE;
+  const int rsub = lane >> 4, sl = lane & (MVA_SW - 1), wv = __builtin_amdgcn_readfirstlane(w);
+  for (int win = 0; win * MVA_SW < nn; ++win) {
+    const int qq = win * MVA_SW + sl;
+    const bool on = qq < nn;
+    const unsigned loff = (unsigned)(rsub * MVA_RS + qq);
+    double acc = 0.0;
+    for (int ib = 4 * wv; ib < nwg; ib += 4 * NW * MVA_U) {
+      double v[MVA_U];
 #pragma unroll
-    for (int u = 0; u < MVA_BATCH; ++u) { v[u] = 0.0; src[u] = rec + (int64_t)need_slot(min(q0 + u, nn - 1)) * nwg; }
-    for (int i = tid; i < nwg; i += NT) {
+      for (int u = 0; u < MVA_U; ++u) {
+        const int i = ib + 4 * NW * u;                          // (uniform)
+        const double* bu = rec + (int64_t)min(i, nwg - 1) * MVA_RS;
+        v[u] = (on && i + rsub < nwg) ? bu[loff] : 0.0;
+      }
 #pragma unroll
-      for (int u = 0; u < MVA_BATCH; ++u) v[u] += src[u][i];
+      for (int u = 0; u < MVA_U; ++u) acc += v[u];
     }
-#pragma unroll
-    for (int u = 0; u < MVA_BATCH; ++u) {
-      const double sw = wave_sum(v[u]);
-      if (lane == 0 && q0 + u < nn) s_wp[w][q0 + u] = sw;
-    }
+    acc += __shfl_xor(acc, 16, WAVE);
+    acc += __shfl_xor(acc, 32, WAVE);
+    if (rsub == 0 && on) s_wp[w][qq] = acc;
   }
+  if (tree && tid == 0) uni_prefetch(A, cur0, m, last, upf);
   __syncthreads();
   for (int qq = tid; qq < nn; qq += NT) {
     double t = 0.0;
-    for (int ww = 0; ww < NT / WAVE; ++ww) t += s_wp[ww][qq];
+    for (int ww = 0; ww < NW; ++ww) t += s_wp[ww][qq];
     s_rec[need_slot(qq)] = t;
   }
   __syncthreads();
-  control_lean(md, A, io, j, d, Emax, max_depth, st, seq, LeanSrc{s_rec, PART_STRIDE, 1, md.def_loc}, nt);
+  control_lean<false, 8, false>(md, A, io, j, d, Emax, max_depth, st, seq, LeanSrc{s_rec, PART_STRIDE, 1, md.def_loc}, nt, tree, upf);
 }
 
 __global__ __launch_bounds__(VEC_THREADS) void k_mva_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax, int max_depth,
@@ -1329,13 +1403,13 @@ __global__ __launch_bounds__(MVA_THREADS) void k_mvn_aligned(ModelDev md, ArenaD
   const double lp = wave_sum(a0 ? -0.5 * (qr - mur) * t : 0.0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (s_red was written by lane 0 of this wave inside leaf_post)
   __builtin_amdgcn_wave_barrier();
-  // ---- this workgroup's record: slot-major, so that the control work reads each slot as one contiguous run ----
+  // ---- this workgroup's record: compact (the numbers this leaf needs, in mva_control's order), one coalesced store ----
   const int nwg = mv.al_nwg;
-  double* rec = mv.al_part + (int64_t)par * PART_STRIDE * nwg + b;
-  if (lane == 0) rec[(int64_t)PART_LP * nwg] = lp;
-  if (leaf) {
-    for (int k = lane; k < NDOT; k += WAVE)
-      if (dot_needed(k, m, last)) rec[(int64_t)(PART_DOT + k) * nwg] = s_red[k + TW];
+  double* rec = mv.al_part + ((int64_t)par * nwg + b) * MVA_RS;
+  const int nn = 1 + (leaf ? 1 + 6 * m + (last ? 6 : 0) : 0);
+  for (int qq = lane; qq < nn; qq += WAVE) {
+    const int k = qq < 2 + 6 * m ? max(qq - 1, 0) : DOT_TOP + (qq - 2 - 6 * m);
+    rec[qq] = qq == 0 ? lp : s_red[k + TW];
   }
 }
 
@@ -1406,7 +1480,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_tree_ctl(ModelDev md, ArenaDev 
   const double E = (A.kin_user ? *A.kin_user : 0.5 * s_dot[0]) - logp;  // integration.py:133-134
   A.E[ts] = E;
   if (!tree) return;
-  tree_decide(&s_ctl, A, lf, s_dot, E, m, last, Emax, max_depth);
+  tree_decide(&s_ctl, A, lf, s_dot, E, m, last, Emax, max_depth, uni_view_none());
   *A.ctl = s_ctl;
   if (st) publish_status(&s_ctl, st, seq);
 }

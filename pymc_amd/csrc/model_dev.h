@@ -120,7 +120,7 @@ struct MvnDev {
   // row-aligned pass (kernels.h, k_mvn_aligned): the model IS the MvNormal node, so the workgroup that owns rows [bR, bR + R) also
   // finishes those elements of the leapfrog and leaves one record for the control work
   int32_t aligned, al_nwg;   // rows per workgroup (0: off), workgroups
-  double* al_part;           // [2][PART_STRIDE][al_nwg] per-workgroup records, slot-major, double-buffered by launch parity
+  double* al_part;           // [2][al_nwg][MVA_RS] per-workgroup records (record-major, compact), double-buffered by launch parity
 };
 
 // per-workgroup partial record written by the vector kernel, summed (in workgroup order) by the control kernel

@@ -22,6 +22,20 @@
 #pragma once
 #include "rows_ga_kernel.h"
 
+// ga_flags, TIMING EXPERIMENTS ONLY, compiled in by -DNUTS_KNOCKOUT (tools/build_ticks.sh knockout, tools/gb_knockout.py; results are
+// wrong with any of them set)
+#define GB_F_EMPTY 2        // every workgroup returns at once: the launch's fixed cost
+#define GB_F_NOSUMS 4       // the prologue does not total the block partials
+#define GB_F_NOSTREAM 8     // no tiles
+#define GB_F_NOPOST 16      // no leaf_post
+#define GB_F_NOBPART 32     // no block partial
+#define GB_F_NOCTL 64       // the control workgroup returns at once
+#define GB_F_PROLOGUE 128   // row workgroups return after the prologue
+#ifdef NUTS_KNOCKOUT
+#define GB_XF(bit) ((R.ga_flags & (bit)) != 0)
+#else
+#define GB_XF(bit) false
+#endif
 #define GB_W 4            // waves per workgroup
 #define GB_MAXGPW 16      // groups per workgroup (LDS records)
 
@@ -49,7 +63,9 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
   const RowsDev& R = md.lg;
   const int j = a.j, fold = a.fold, par = a.par, d = a.d;
   int b = (int)blockIdx.x;
+  if (GB_XF(GB_F_EMPTY)) return;
   if (fold & GA_FOLD_CTL) {   // workgroup 0: control work, from the previous launch's block partials
+    if (b == 0 && GB_XF(GB_F_NOCTL)) return;
     if (b == 0) { control_lean<false, 8, true>(md, A, a.cio, a.cj, a.cd, a.Emax, a.max_depth, a.st, a.cseq, lean_src(md, par ^ 1)); return; }
     --b;
   }
@@ -101,6 +117,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
     hl01 = reinterpret_cast<const double2*>(prev.def_loc)[2 * slot];
     hl23 = reinterpret_cast<const double2*>(prev.def_loc)[2 * slot + 1];
     hq = qv.q[hi]; hv = qv.var[hi];
+    if (GB_XF(GB_F_NOSUMS)) { if (tid < 2 * D) s_hS[tid] = 0.0; } else {
     // wave w totals hyper slots w, w + GB_W, ... (slot-major block partials: coalesced wave loads, all in flight)
     constexpr int PERW = (2 * D + GB_W - 1) / GB_W;
     double v[PERW][SLOT_SUM_MAXR];
@@ -114,6 +131,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
     for (int u = 0; u < PERW; ++u) {
       const double tot = slot_sum_finish(v[u], prev.slot_major, lane);
       if (w + u * GB_W < 2 * D && lane == 0) s_hS[w + u * GB_W] = tot;
+    }
     }
   }
   // z' of this wave's first group: its loads do not depend on the hyper-parameters
@@ -140,6 +158,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
   const double sraw = __shfl(hval0, D + dl);
   const double s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(sraw) : sraw;
   if (aborted) return;
+  if (GB_XF(GB_F_PROLOGUE)) { if (m_lane + s_lane == 12345.678) A.Q[lf.d_o] = 0.0; return; }
   int m = 0; bool last = false;
   TICK(md, tk, 1);
 
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
     for (int dd = 0; dd < D; ++dd) acc[dd] = 0.0;
     const int n_last = ng - (T - 1) * SPAN;
     if (gl != w) gb_load<D, DX>(R, cbase, lane, xa, ya);
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < (GB_XF(GB_F_NOSTREAM) ? 0 : T); ++t) {
       double xb[D][2];
       uint32_t yb;
       gb_load<D, DX>(R, cbase + (int64_t)min(t + 1, T - 1) * TS, lane, xb, yb);   // unconditional prefetch (re-reads the last tile at the end)
@@ -215,7 +234,8 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
       }
     }
     TICK(md, tk && gl == w, 4);
-    if (leaf) leaf_post<1, false, D <= 8>(A, lf, j, d, tree, idx, act, grad, ph, &s_red[w][0], 1, m, last, tree ? &mpf : nullptr, 0);
+    if (leaf && !GB_XF(GB_F_NOPOST))
+      leaf_post<1, false, D <= 8>(A, lf, j, d, tree, idx, act, grad, ph, &s_red[w][0], 1, m, last, tree ? &mpf : nullptr, 0);
     TICK(md, tk && gl == w, 5);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -232,7 +252,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
   __syncthreads();
 
   // ---- block partial: the workgroup's records summed in group order ----
-  {
+  if (!GB_XF(GB_F_NOBPART)) {
     const int mm = (leaf && tree) ? s_ml[0] : 0;
     const bool ll = (leaf && tree) ? s_ml[1] != 0 : false;
     const int nn = 1 + 2 * D + (leaf ? 1 + 6 * mm + (ll ? 6 : 0) : 0);

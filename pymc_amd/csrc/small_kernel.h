@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
           const int ts = lf.t & (A.S - 1);
           const double E = 0.5 * s_dot[0] - logp;  // integration.py:133-134
           A.LOGP[ts] = logp; A.E[ts] = E;
-          tree_decide(&s_ctl, A, lf, s_dot, E, m, last, a.Emax, a.max_depth);
+          tree_decide(&s_ctl, A, lf, s_dot, E, m, last, a.Emax, a.max_depth, uni_view_none());
         }
         __syncthreads();   // also makes this leaf's arena stores visible to the whole workgroup
         if (s_ctl.aborted) break;

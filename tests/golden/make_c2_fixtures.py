@@ -18,7 +18,7 @@ tests/golden/refrun.py) over the gcc restatement of the hierarchical-logit log-d
                         formulas, pinned to the plain loop at 1e-12) -- hours on four host cores, run once (`c2lfull`); each
                         chain is also written to scratch/ as it finishes.
 
-    python tests/golden/make_c2_fixtures.py [c2l] [c2s] [c2lfull]
+    python tests/golden/make_c2_fixtures.py [c2l] [c2s] [c2lfull] [c2lsum]   (c2lsum: the summary again from the chains in scratch/)
 """
 
 import multiprocessing as mp
@@ -93,15 +93,29 @@ def _c2l_chain(c):
     return d, s
 
 
-def make_c2s(cfg=C2S, chain_fn=_c2s_chain, name="c2s_chains.npz"):
+def _c2l_chain_from_scratch(c):
+    """The chain `_c2l_chain` wrote to scratch/ (re-summarising without the hours of sampling: `c2lsum`)."""
+    f = np.load(os.path.join(ROOT, "scratch", f"c2l_chain{c}.npz"))
+    return f["draws"], {k: f["stat_" + k] for k in STAT_KEYS}
+
+
+def make_c2s(cfg=C2S, chain_fn=_c2s_chain, name="c2s_chains.npz", pool=True):
     from pymc_amd import stats as st
 
-    with mp.get_context("fork").Pool(cfg["chains"]) as pool:
-        res = pool.map(chain_fn, range(cfg["chains"]))
+    if pool:
+        with mp.get_context("fork").Pool(cfg["chains"]) as p:
+            res = p.map(chain_fn, range(cfg["chains"]))
+    else:
+        res = [chain_fn(c) for c in range(cfg["chains"])]
     draws = np.stack([r[0] for r in res])                   # (chains, draws, n)
     D, G = cfg["D"], cfg["G"]
-    zbar = draws[:, :, 2 * D:].reshape(draws.shape[0], draws.shape[1], G, D).mean(axis=2)
+    z = draws[:, :, 2 * D:].reshape(draws.shape[0], draws.shape[1], G, D)
+    zbar = z.mean(axis=2)
+    # what the likelihood of group g identifies: beta_gd - beta_bar_d = sigma_d (z_gd - mean_g z_gd) -- z without the ridge direction
+    # (mean_g z_gd against mu_d) and without the scale direction (sigma_d against the spread of z_.d)
+    bdev = (np.exp(draws[:, :, D:2 * D])[:, :, None, :] * (z - zbar[:, :, None, :])).reshape(draws.shape[0], draws.shape[1], G * D)
     out = {
+        "bdev_mean": bdev.mean(axis=(0, 1)), "bdev_sd": bdev.std(axis=(0, 1), ddof=1), "bdev_ess": st.ess_bulk_many(bdev),
         # the group mean of z per covariate and the combination the likelihood pins (mu + sigma * zbar): the diagnostics of
         # the non-centred ridge (tools/ess_study.py)
         "zbar_draws": zbar.astype("float32"), "beta_bar_draws": (draws[:, :, :D] + np.exp(draws[:, :, D:2 * D]) * zbar).astype("float32"),
@@ -126,3 +140,5 @@ if __name__ == "__main__":
         make_c2l()
     if "c2lfull" in which:
         make_c2s(C2LFULL, _c2l_chain, "c2l_chains.npz")
+    if "c2lsum" in which:
+        make_c2s(C2LFULL, _c2l_chain_from_scratch, "c2l_chains.npz", pool=False)

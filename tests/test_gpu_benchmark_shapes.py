@@ -291,11 +291,23 @@ def test_c2l_four_chains_agree_with_oracle_chains_within_monte_carlo_error(c2l):
         assert abs(bb_dev[:, :, k].mean() - bb_ref[:, :, k].mean()) < 5.0 * se, (k, bb_dev[:, :, k].mean(), bb_ref[:, :, k].mean(), se)
         assert abs(np.log(bb_dev[:, :, k].std() / bb_ref[:, :, k].std())) < 0.25
         assert e_d > 400 and e_r > 400                      # ... and it DOES mix, on both sides
-    # the z elements: joint Monte-Carlo error
+    # the group effects the likelihood identifies, beta_gd - beta_bar_d = sigma_d (z_gd - mean_g z_gd): z without the ridge direction and
+    # without the scale direction (sigma_d has R-hat 1.1 on both sides).  These mix on both sides, so the joint Monte-Carlo error
+    # criterion applies in full
+    zd = d[:, :, 2 * D:].reshape(chains, draws, G, D)
+    bdev = (np.exp(d[:, :, D:2 * D])[:, :, None, :] * (zd - zbar[:, :, None, :])).reshape(chains, draws, G * D)
+    bdev_ess = st.ess_bulk_many(bdev)
+    se = np.sqrt(bdev.std(axis=(0, 1), ddof=1) ** 2 / np.maximum(bdev_ess, 4.0) + gold["bdev_sd"] ** 2 / np.maximum(gold["bdev_ess"], 4.0))
+    zscore = np.abs(bdev.mean(axis=(0, 1)) - gold["bdev_mean"]) / se
+    print(f"group effects: median ESS device {np.median(bdev_ess):.0f} oracle {np.median(gold['bdev_ess']):.0f}; |z| > 3: {np.mean(zscore > 3.0):.4f}, max {zscore.max():.2f}")
+    assert np.median(bdev_ess) > 1500 and np.median(gold["bdev_ess"]) > 1500
+    assert np.mean(zscore > 3.0) < 0.02 and zscore.max() < 6.0, (np.mean(zscore > 3.0), zscore.max())
+    # the raw z elements carry the unconverged ridge coordinate of BOTH runs (their per-element ESS estimates are of chains that have not
+    # mixed): only a loose bound
     mean_dev, sd_dev = d.mean(axis=(0, 1))[2 * D:], d.std(axis=(0, 1), ddof=1)[2 * D:]
     se = np.sqrt(sd_dev**2 / np.maximum(ess_dev[2 * D:], 4.0) + gold["sd"][2 * D:] ** 2 / np.maximum(ess_ref[2 * D:], 4.0))
     zscore = np.abs(mean_dev - gold["mean"][2 * D:]) / se
-    assert np.mean(zscore > 3.0) < 0.03 and zscore.max() < 7.0, (np.mean(zscore > 3.0), zscore.max())
+    assert np.mean(zscore > 3.0) < 0.10 and zscore.max() < 8.0, (np.mean(zscore > 3.0), zscore.max())
     # mixing diagnostics: the same picture on both sides (hyper-parameters barely move, z elements mix slowly)
     assert abs(np.log(np.median(ess_dev) / np.median(ess_ref))) < np.log(1.6)
     assert abs(np.log(np.median(ess_dev[:2 * D]) / np.median(ess_ref[:2 * D]))) < np.log(4.0)

@@ -6,4 +6,4 @@ cd /tmp; rm -rf $OUT/prof_da_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_da_$TAG -o trace -- python $R/bench.py --cpu-leapfrogs 0 --ess-tune 0 "$@" > $OUT/prof_da_$TAG.log 2>&1
 { echo "# bench.py --cpu-leapfrogs 0 --ess-tune 0 $@"; python $R/tools/rocpd_summary.py $OUT/prof_da_$TAG/trace_results.db; } > $OUT/draw_anatomy_$TAG.txt 2>&1
 rm -rf $OUT/prof_da_$TAG
-tail -6 $OUT/draw_anatomy_$TAG.txt
+tail -50 $OUT/draw_anatomy_$TAG.txt

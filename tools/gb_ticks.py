@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Phase timestamps of the group-block row pass (csrc/rows_gb_kernel.h) at C2-S: where a launch's time goes.
 
-Needs a library built with -DNUTS_KTIMING (tools/build_ticks.sh -> scratch/libnuts_ticks.so, loaded through PYMC_AMD_LIB); the
+Needs a library built with -DNUTS_KTIMING (tools/build_ticks.sh -> build/libnuts_ticks.so, loaded through PYMC_AMD_LIB); the
 stamps are taken by workgroup nblk / 2, thread 0, with the memory queue drained at every stamp (true phase boundaries; the
 launch is slower than in a product build).  100 MHz constant clock.  usage (GPU box): python tools/gb_ticks.py [rows_per_group]
 """
@@ -15,7 +15,7 @@ import numpy as np
 os.environ["PYMC_AMD_HONOUR_NUTS_ENV"] = "1"   # NUTS_* variables reach the engine as schedule options (nuts_set_option)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("PYMC_AMD_LIB", os.path.join(ROOT, "scratch", "libnuts_ticks.so"))
+os.environ.setdefault("PYMC_AMD_LIB", os.path.join(ROOT, "build", "libnuts_ticks.so"))
 
 
 def main():

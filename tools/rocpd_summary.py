@@ -116,6 +116,50 @@ def draw_timeline(path, tail_frac=0.5):
     print("idle before:    " + ", ".join(f"{k} {v/n/1e3:.2f}" for k, v in sorted(idle_by.items(), key=lambda kv: -kv[1])))
 
 
+def launch_positions(path, tail_frac=0.5):
+    """Mean duration of the dominant kernel by its POSITION in the draw, over the draws of the most common launch count (the
+    tuned tree): position p is leaf j of doubling d in queue order, and -- with the control work folded into the next launch --
+    carries the control work of position p - 1, whose merge depth is ctz(~j) of THAT leaf."""
+    cur = sqlite3.connect(path).cursor()
+    rows = list(cur.execute("select name, start, end from kernels order by start"))
+    if not rows:
+        return
+    t_lo = rows[0][1] + (1.0 - tail_frac) * (rows[-1][2] - rows[0][1])
+    rows = [r for r in rows if r[1] >= t_lo]
+    starts = [i for i, r in enumerate(rows) if r[0].startswith("k_draw_start")]
+    draws = []
+    for a, b in zip(starts, starts[1:]):
+        seg = [(e - s0) / 1e3 for n, s0, e in rows[a:b] if "k_rows" in n or "k_mvn_aligned" in n]
+        draws.append(seg)
+    if not draws:
+        return
+    from collections import Counter
+    L = Counter(len(d) for d in draws).most_common(1)[0][0]
+    sel = [d for d in draws if len(d) == L]
+    print(f"\n# dominant kernel by position in the draw ({len(sel)} draws of {L} launches): mean us  [doubling d, leaf j, merge depth of the control work it carries]")
+    pos = []
+    d = 0
+    while len(pos) < L:
+        for j in range(1 << d):
+            pos.append((d, j))
+        d += 1
+    pos = pos[:L]
+    by_m = {}
+    for p in range(L):
+        mean = sum(x[p] for x in sel) / len(sel)
+        if p == 0:
+            carried = "-"
+        else:
+            dp, jp = pos[p - 1]
+            m = 0
+            while (jp >> m) & 1 and m < dp:
+                m += 1
+            carried = f"m={m}" + (" last" if jp + 1 == (1 << dp) else "")
+            by_m.setdefault(carried, []).append(mean)
+        print(f"  p={p:3d} d={pos[p][0]} j={pos[p][1]:3d} carries {carried:10s} {mean:7.2f}")
+    print("# by carried control work: " + ", ".join(f"{k}: {sum(v)/len(v):.2f} us (n={len(v)})" for k, v in sorted(by_m.items())))
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     if args[0] == "--traffic":   # --traffic <fetch.db> <write.db> <out.json> <kernel substring> <tag> <source hash>
@@ -124,6 +168,7 @@ if __name__ == "__main__":
     kernel_stats(args[0])
     gap_stats(args[0])
     draw_timeline(args[0])
+    launch_positions(args[0])
     rest = args[1:]
     for a in rest:
         if a != "--pmc":
