@@ -1050,6 +1050,7 @@ struct StateHeader {  // host scalars of the sampling state
   double fa_fg_n, fa_bg_n;
 };
 
+#define DOM_RING 4
 struct nuts_chain {
   nuts_model* m = nullptr;
   nuts_chain_config cfg{};
@@ -1105,7 +1106,7 @@ struct nuts_chain {
   double last_logp = 0.0;
   DrawOut* do_dev = nullptr;
   DrawOut* do_host = nullptr;
-  DrawOutMapped* dom_host = nullptr;   // pinned + device-mapped copy of the last draw's record (multi-draw calls)
+  DrawOutMapped* dom_host = nullptr;   // pinned + device-mapped copies of the last DOM_RING draws' records (multi-draw calls), slot = seq % DOM_RING
   DrawOutMapped* dom_dev = nullptr;
   unsigned dom_seq = 0;
   double* kin_part = nullptr;    // [nblk] kinetic-energy partials of the initial state
@@ -1339,13 +1340,13 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
       hipHostMalloc((void**)&c->st_host, sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->st_dev, c->st_host, 0) != hipSuccess ||
       hipHostMalloc((void**)&c->do_host, sizeof(DrawOut), hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void**)&c->dom_host, sizeof(DrawOutMapped), hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc((void**)&c->dom_host, DOM_RING * sizeof(DrawOutMapped), hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->dom_dev, c->dom_host, 0) != hipSuccess) {
     g_err = "pinned host allocation failed"; nuts_chain_destroy(c); return nullptr;
   }
   hipMemset(A.ctl, 0, sizeof(Ctl));
   std::memset(c->st_host, 0, sizeof(HostStatus));
-  std::memset(c->dom_host, 0, sizeof(DrawOutMapped));
+  std::memset(c->dom_host, 0, DOM_RING * sizeof(DrawOutMapped));
   c->step_size = cfg->step_scale / std::pow((double)n, 0.25);  // base_hmc.py:161
   c->da = DualAvg{c->step_size, cfg->target_accept, cfg->gamma, cfg->k, cfg->t0, 0, 0, 0, 0, 1};
   c->da.reset();
@@ -1568,7 +1569,7 @@ static int sync_status(nuts_chain* c) {   // the status record is host memory: a
 
 // Wait until the control kernel of the last leaf of a doubling has published sequence number `seq`
 // (spin on the mapped record; falls back to an error after 60 s so that a lost kernel cannot hang the process).
-static int wait_status(nuts_chain* c, int seq, unsigned* flags) {
+static int wait_status(nuts_chain* c, int seq, unsigned* flags, int* cursor = nullptr) {
   volatile unsigned long long* word = &c->st_host->word[seq & (ST_SLOTS - 1)];
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long long w;
@@ -1582,7 +1583,8 @@ static int wait_status(nuts_chain* c, int seq, unsigned* flags) {
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  *flags = (unsigned)w;
+  *flags = (unsigned)w & 0xffu;
+  if (cursor) *cursor = (int)(((unsigned)w >> 8) & 0xffffffu);
   return NUTS_OK;
 }
 
@@ -1685,7 +1687,8 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
 // The same transition as ONE launch of the persistent tree kernel (rows_ga_tree.h): the leaf loop and the doubling loop run on
 // the device, the host waits for the status word of the whole tree.  Every logarithm the tree can consume must be on the
 // device before the launch (`ensure_logs` up to the worst case).
-static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, int max_depth, unsigned* flags_out, bool* exhausted_out) {
+static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, int max_depth, unsigned* flags_out, bool* exhausted_out,
+                       int* cursor_out = nullptr) {
   nuts_model* m = c->m;
   ArenaDev& A = c->A;
   int rc = ensure_logs(c, (1 << max_depth) + max_depth + 1);
@@ -1711,7 +1714,7 @@ static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, 
   m->dom_launches++;
   c->tree_launches++;
   unsigned flags = 0;
-  rc = wait_status(c, seq, &flags);
+  rc = wait_status(c, seq, &flags, cursor_out);
   if (rc) return rc;
   if (flags & ST_TIMEOUT) {
     g_err = "persistent tree kernel: a wait between workgroups timed out (are all of its workgroups resident? another process on "
@@ -1726,7 +1729,8 @@ static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, 
 
 // The doubling loop of one transition (NUTS._hamiltonian_step, nuts.py:204-225): queue the leaves of each doubling, wait for the
 // status word of its last leaf.  `uniforms`: the host copy of the pre-drawn `step.rng.random()` values of THIS draw.
-static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int max_depth, unsigned* flags_out, bool* exhausted_out) {
+static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int max_depth, unsigned* flags_out, bool* exhausted_out,
+                    int* cursor_out = nullptr) {
   using clk = std::chrono::steady_clock;
   int rc = NUTS_OK;
   bool exhausted = true;
@@ -1785,7 +1789,7 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
     flush_pending(seq);
     if (c->cb_err) return host_pot_error(c);
     const auto tw0 = clk::now();
-    rc = wait_status(c, seq, &flags);
+    rc = wait_status(c, seq, &flags, cursor_out);
     c->t_wait += std::chrono::duration<double>(clk::now() - tw0).count();
     if (rc) return rc;
     depth_done = d + 1;
@@ -2012,21 +2016,17 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
   size_t consumed = 0;
   const int fgrid = std::max(1, std::min(256, (n + VEC_THREADS - 1) / VEC_THREADS));
   c->tm_pre += secs(tm0, clk::now()); c->tm_batches++;
-  for (int k = 0; k < K; ++k) {
-    const auto t0 = clk::now();
-    const double perf_start = std::chrono::duration<double>(t0.time_since_epoch()).count();
-    const std::clock_t c0 = std::clock();
-    const bool adapt = c->tune && c->cfg.adapt_step_size;
-    const double step_size = c->da.current(adapt);
-    c->step_size = step_size;
-    const int max_depth = (c->tune && c->iter_count < 200) ? c->cfg.early_max_treedepth : c->cfg.max_treedepth;
-    const size_t need_uni = ((size_t)1 << max_depth) + max_depth + 1;
-    if (U - consumed < need_uni) {
-      if (k == 0) { g_err = "not enough uniforms for the worst-case tree"; rc = NUTS_E_ARG; }
-      break;
-    }
-    A.uniforms = d_u + consumed; A.log_uniforms = d_lu + consumed;
-    const bool from_prev = k > 0 || cached0;   // the start state is the previous proposal, (q, grad) in out_dev, logp in do_dev / last_logp
+  // After tuning nothing the host computes between two draws feeds the next one (step size and mass matrix are fixed): the status word of
+  // the tree's last doubling carries the uniform cursor, so the NEXT draw's start kernels are queued right behind this draw's finish
+  // kernel, and this draw's record -- statistics only -- is read while the next tree is already running.  One host round trip per draw
+  // (the status) instead of three (status, record, then an idle queue to restart): ~50 us of GPU idle per draw on C2-S / C3
+  // (profiles/r03g_profile_c3.txt: 50.7 us idle before k_draw_start).  A divergent draw is finished synchronously, as before.
+  const bool pipe = !c->tune && !c->tree_mode && !c->full_adapt && env_int("NUTS_PIPE_DRAWS", 1) != 0;
+  struct Pending {
+    bool valid = false; int k = 0; unsigned seq = 0; bool exhausted = false, adapt = false; size_t consumed_after = 0; int cursor = 0;
+    double perf_start = 0.0, wall = 0.0, cpu = 0.0;
+  } pend;
+  auto enqueue_start = [&](int k, double step_size, int max_depth, bool from_prev) {   // momentum, start state, control block of draw k
     if (c->dense) {
       if (c->full_adapt) fa_random(c, d_norm + (size_t)k * n, A.P);
       else hipLaunchKernelGGL(k_dense_mv, dim3(c->mv_grid), dim3(256), 0, s, c->dense_W, d_norm + (size_t)k * n, A.P, n, (const double*)nullptr,
@@ -2039,16 +2039,64 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
                        from_prev ? (const double*)(c->out_dev + n) : (const double*)nullptr, c->dense);
     hipLaunchKernelGGL(k_draw_ctl_start, dim3(1), dim3(64), 0, s, A, c->kin_part, step_size, 0, max_depth, c->st_dev, from_prev ? 1 : 0,
                        c->last_logp, k > 0 ? (const DrawOut*)c->do_dev : (const DrawOut*)nullptr);
+  };
+  // host side of a draw whose finish kernel has been queued: wait for its record, adaptation + statistics
+  auto complete = [&](const Pending& p, bool* diverged) -> int {
+    const auto tb = clk::now();
+    DrawOutMapped* slot = c->dom_host + (p.seq % DOM_RING);
+    volatile unsigned long long* w = &slot->seq;
+    for (unsigned spins = 0; (unsigned)*w != p.seq; ++spins) {
+      if ((spins & 0xfffff) == 0xfffff) {
+        if (hipStreamQuery(s) == hipSuccess && (unsigned)*w != p.seq) { g_err = "k_draw_finish ended without publishing its record"; return NUTS_E_HIP; }
+        if (clk::now() - tb > std::chrono::seconds(60)) { g_err = "timed out waiting for the device"; return NUTS_E_HIP; }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const DrawOut o = slot->o;
+    const auto t1 = clk::now();
+    c->tm_record += secs(tb, t1);
+    if (o.cursor != p.cursor) { g_err = "internal error: the status word and the draw record disagree on the uniforms consumed"; return NUTS_E_HIP; }
+    int r = finish_draw_host(c, o, p.adapt, p.exhausted, c->out_dev, o.n_proposals + ((p.k == 0 && !cached0) ? 1 : 0), p.perf_start, p.wall, p.cpu,
+                             stats + p.k);
+    c->tm_host += secs(t1, clk::now()); c->tm_draws++;
+    if (r) return r;
+    stats[p.k].n_uniforms_consumed = (int32_t)p.consumed_after;
+    c->last_logp = o.logp;
+    done = p.k + 1;
+    *diverged = o.diverging != 0;
+    return NUTS_OK;
+  };
+  bool started = false;   // the start kernels of draw k are already in the queue (put there behind draw k - 1's finish kernel)
+  for (int k = 0; k < K; ++k) {
+    const auto t0 = clk::now();
+    const double perf_start = std::chrono::duration<double>(t0.time_since_epoch()).count();
+    const std::clock_t c0 = std::clock();
+    const bool adapt = c->tune && c->cfg.adapt_step_size;
+    const double step_size = c->da.current(adapt);
+    c->step_size = step_size;
+    const int max_depth = (c->tune && c->iter_count < 200) ? c->cfg.early_max_treedepth : c->cfg.max_treedepth;
+    const size_t need_uni = ((size_t)1 << max_depth) + max_depth + 1;
+    if (!started) {
+      if (U - consumed < need_uni) {
+        if (k == 0) { g_err = "not enough uniforms for the worst-case tree"; rc = NUTS_E_ARG; }
+        break;
+      }
+      A.uniforms = d_u + consumed; A.log_uniforms = d_lu + consumed;
+      enqueue_start(k, step_size, max_depth, k > 0 || cached0);   // (from the previous proposal: (q, grad) in out_dev, logp in do_dev / last_logp)
+    }
+    started = false;
     unsigned flags = 0;
     bool exhausted = true;
+    int cursor = 0;
     const auto ta = clk::now();
     c->tm_start += secs(t0, ta);
-    rc = c->tree_mode ? run_tree_ga(c, h_u + consumed, step_size, max_depth, &flags, &exhausted)
-                      : run_tree(c, h_u + consumed, step_size, max_depth, &flags, &exhausted);
+    rc = c->tree_mode ? run_tree_ga(c, h_u + consumed, step_size, max_depth, &flags, &exhausted, &cursor)
+                      : run_tree(c, h_u + consumed, step_size, max_depth, &flags, &exhausted, &cursor);
     const auto tb = clk::now();
     c->tm_tree += secs(ta, tb);
     if (rc) break;
     if (flags & ST_BAD_ENERGY) {
+      if (pend.valid) { bool dv = false; rc = complete(pend, &dv); pend.valid = false; if (rc) break; }
       rc = check_mass_matrix(c);
       if (rc == NUTS_OK) g_err = "Bad initial energy, check any log probabilities that are inf or -inf, nan or very small";
       rc = NUTS_E_BAD_ENERGY;
@@ -2056,32 +2104,30 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
     }
     const unsigned seq = ++c->dom_seq;
     hipLaunchKernelGGL(k_draw_finish, dim3(fgrid), dim3(VEC_THREADS), 0, s, A, c->out_dev, c->out_dev + n, c->do_dev, trace_dev + (size_t)k * n,
-                       c->dom_dev, seq);
-    {   // the record of this draw, through pinned mapped memory
-      volatile unsigned long long* w = &c->dom_host->seq;
-      const auto tw = clk::now();
-      for (unsigned spins = 0; (unsigned)*w != seq; ++spins) {
-        if ((spins & 0xfffff) == 0xfffff) {
-          if (hipStreamQuery(s) == hipSuccess && (unsigned)*w != seq) { g_err = "k_draw_finish ended without publishing its record"; rc = NUTS_E_HIP; break; }
-          if (clk::now() - tw > std::chrono::seconds(60)) { g_err = "timed out waiting for the device"; rc = NUTS_E_HIP; break; }
-        }
-      }
-      if (rc) break;
-      std::atomic_thread_fence(std::memory_order_acquire);
+                       c->dom_dev + (seq % DOM_RING), seq);
+    const size_t consumed_after = consumed + (size_t)cursor;
+    if (pipe && !(flags & ST_DIVERGING) && k + 1 < K && U - consumed_after >= need_uni) {
+      A.uniforms = d_u + consumed_after; A.log_uniforms = d_lu + consumed_after;
+      enqueue_start(k + 1, step_size, max_depth, true);
+      started = true;
     }
-    const DrawOut o = c->dom_host->o;
-    const auto t1 = clk::now();
-    c->tm_record += secs(tb, t1);
-    const std::clock_t c1 = std::clock();
-    rc = finish_draw_host(c, o, adapt, exhausted, c->out_dev, o.n_proposals + ((k == 0 && !cached0) ? 1 : 0), perf_start,
-                          std::chrono::duration<double>(t1 - t0).count(), (double)(c1 - c0) / CLOCKS_PER_SEC, stats + k);
-    c->tm_host += secs(t1, clk::now()); c->tm_draws++;
-    if (rc) break;
-    consumed += (size_t)o.cursor;
-    stats[k].n_uniforms_consumed = (int32_t)consumed;
-    c->last_logp = o.logp;
-    done = k + 1;
-    if (o.diverging) break;   // its two phase-space points were read from the arena; the caller sees the warning before going on
+    Pending cur;
+    cur.valid = true; cur.k = k; cur.seq = seq; cur.exhausted = exhausted; cur.adapt = adapt; cur.consumed_after = consumed_after; cur.cursor = cursor;
+    cur.perf_start = perf_start;
+    cur.wall = std::chrono::duration<double>(clk::now() - t0).count();
+    cur.cpu = (double)(std::clock() - c0) / CLOCKS_PER_SEC;
+    bool diverged = false;
+    if (pend.valid) { rc = complete(pend, &diverged); pend.valid = false; if (rc) break; }   // (draw k - 1: never divergent, see above)
+    if (started) pend = cur;                                  // its record is read while draw k + 1 runs
+    else { rc = complete(cur, &diverged); if (rc) break; }
+    consumed = consumed_after;
+    if (diverged) break;   // its two phase-space points were read from the arena; the caller sees the warning before going on
+  }
+  if (pend.valid) {   // (left over by an error in the draw behind it)
+    bool dv = false;
+    const int r2 = complete(pend, &dv);
+    pend.valid = false;
+    if (!rc) rc = r2;
   }
   A.uniforms = save_u; A.log_uniforms = save_lu;
   c->logs_done = save_done; c->logs_total = save_total;
@@ -2517,7 +2563,11 @@ extern "C" int nuts_chain_set_log_step_bar(nuts_chain* c, double log_step, doubl
 extern "C" int nuts_chain_profile(nuts_chain* c, int enable) {
   if (!c) return NUTS_E_ARG;
   HIPCHK(hipStreamSynchronize(c->m->stream));
-  profile_enable(c->m, enable != 0, 8, 4096);
+  // every 61st launch of the dominant kernel is bracketed by a pair of events (a prime: no resonance with the 2^d leaves of a doubling,
+  // every position of the tree gets sampled).  The pair is not free -- two marker packets the queue waits for, ~7 us: at one launch
+  // in 8 the C2-S bench ran 14 % below the un-instrumented loop (54.8 k vs 63.8 k leapfrog/s, tools/draw_host_phases.py); at one
+  // in 61 the cost is below 1 %
+  profile_enable(c->m, enable != 0, 61, 4096);
   c->leapfrogs = 0;
   return NUTS_OK;
 }

@@ -162,8 +162,11 @@ __device__ __forceinline__ void publish_status(const Ctl* c, HostStatus* st, int
   if (!seq) return;   // only the last leaf of a doubling reports
   const unsigned flags = (c->aborted ? ST_ABORTED : 0u) | (c->turning ? ST_TURNING : 0u) | (c->diverging ? ST_DIVERGING : 0u) |
                          (c->bad_energy ? ST_BAD_ENERGY : 0u) | (c->dir > 0 ? ST_DIR_POS : 0u);
-  __hip_atomic_store(&st->word[seq & (ST_SLOTS - 1)], ((unsigned long long)(unsigned)seq << 32) | flags, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_SYSTEM);
+  // (bits 8 .. 31: the uniforms this draw has consumed so far -- with it the host can queue the NEXT draw's start behind this tree
+  // without waiting for the draw's record)
+  __hip_atomic_store(&st->word[seq & (ST_SLOTS - 1)],
+                     ((unsigned long long)(unsigned)seq << 32) | ((unsigned long long)((unsigned)c->cursor & 0xffffffu) << 8) | flags,
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ void publish_fields(const Ctl* c, HostStatus* st) {
@@ -957,7 +960,7 @@ struct LeanSrc { const double* part; int stride, nblk; const double* def_loc; in
 #define SLOT_SUM_MAXR 8   // records per lane: ga_nblk <= 512
 __device__ __forceinline__ void slot_sum_issue(const double* slot, int npad, int lane, double (&v)[SLOT_SUM_MAXR]) {
 #pragma unroll
-  for (int u = 0; u < SLOT_SUM_MAXR; ++u) v[u] = WAVE * u < npad ? slot[lane + WAVE * u] : 0.0;   // (npad is a multiple of 64: a uniform test per load)
+  for (int u = 0; u < SLOT_SUM_MAXR; ++u) v[u] = slot[min(lane + WAVE * u, npad - 1)];   // (clamped: unconditional loads -- a test per load measured 0.4 us slower per launch)
 }
 __device__ __forceinline__ double slot_sum_finish(const double (&v)[SLOT_SUM_MAXR], int npad, int lane) {
   double acc = 0.0;

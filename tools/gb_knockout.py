@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pymc_amd import _lib, models  # noqa: E402
 from pymc_amd.step import NUTS  # noqa: E402
 
-rpg = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+rpg = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 80
 spec = models.hier_logit(rows_per_group=rpg)
 rng = np.random.default_rng(3)
 q0 = 0.1 * rng.normal(size=spec.n)
@@ -22,6 +22,8 @@ VARIANTS = [("full", 0), ("empty launch", 2), ("no control workgroup", 64), ("ro
             ("rows: prologue without the sums", 128 + 4), ("no block-partial sums", 4), ("no stream", 8), ("no leaf_post", 16),
             ("no block partial", 32), ("no stream, post, partial", 8 + 16 + 32), ("no stream, post, partial, control", 8 + 16 + 32 + 64),
             ("no sums, stream, post, partial, control", 4 + 8 + 16 + 32 + 64)]
+if "--full" in sys.argv:   # the production library: only the un-knocked-out launch, five times
+    VARIANTS = [("full", 0)] * 5
 for name, flags in VARIANTS:
     os.environ["NUTS_GA_FLAGS"] = str(flags)
     step = NUTS(model=spec, scaling=np.ones(spec.n), is_cov=True, rng=1, device=0)
