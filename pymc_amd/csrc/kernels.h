@@ -1386,7 +1386,8 @@ __global__ __launch_bounds__(MVA_THREADS) void k_mvn_aligned(ModelDev md, ArenaD
     else io.grad[my] = -t;
   }
   int m = 0; bool last = false;
-  if (leaf) leaf_post<1>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);   // -> s_red[k + TW]
+  // (only lanes 0 .. R - 1 hold elements: for R <= 8 the wave sums stop after three DPP steps -- the same bits, device_math.h wave_sum8)
+  if (leaf) leaf_post<1, false, R <= 8>(A, lf, j, d, tree, idx, act, grad, ph, s_red, 1, m, last, tree ? &mpf : nullptr);   // -> s_red[k + TW]
   if (leaf && io.pre_next == 3 && a0) {
     // last leaf of a doubling, the next one (queued behind it) grows on the OTHER side: first half of its first leaf from the tree's
     // other edge state -- k_leaf_pre's arithmetic (signed step of the other direction) on this workgroup's rows
@@ -1403,7 +1404,7 @@ __global__ __launch_bounds__(MVA_THREADS) void k_mvn_aligned(ModelDev md, ArenaD
     A.P[no + my] = phn;
     A.Q[no + my] = fma(lf.eps, var_r * phn, qr);
   }
-  const double lp = wave_sum(a0 ? -0.5 * (qr - mur) * t : 0.0);
+  const double lp = (R <= 8 ? wave_sum8(a0 ? -0.5 * (qr - mur) * t : 0.0) : wave_sum(a0 ? -0.5 * (qr - mur) * t : 0.0));
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (s_red was written by lane 0 of this wave inside leaf_post)
   __builtin_amdgcn_wave_barrier();
   // ---- this workgroup's record: compact (the numbers this leaf needs, in mva_control's order), one coalesced store ----
