@@ -97,6 +97,7 @@ struct nuts_model {
   std::vector<nuts_data_ref> data_refs;   // (offset, size) of every data vector in the device pool
   int64_t data_epoch = 0;                 // bumped by nuts_model_set_data: start-state caches of older epochs are stale
   int rows_grid = 0, mvn_grid = 0, ept = 1;
+  bool has_prog = false;   // some factor carries an expression program or a gathered operand: kernels with the interpreter compiled in
   int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
   int vector_one_xcd = 0;
   int ga_variant = 42;         // 10 x (waves per SIMD of the register budget) + tiles in flight per wave
@@ -149,11 +150,14 @@ static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, in
   if (md.has_mvn && md.mv.aligned && io.lean) return;   // (the row-aligned MvNormal pass has finished the leapfrog itself)
   // small models: 8x oversubscribed launch, one XCD does the work (see k_vector); large ones use the whole chip
   const dim3 grid(m->vector_one_xcd ? md.nblk * 8 : md.nblk);
+  // (has_prog: the instantiation that carries the expression-program interpreter, model_dev.h gather_element)
+#define VEC_LAUNCH(E, P) hipLaunchKernelGGL((k_vector<E, P>), grid, dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d)
   switch (m->ept) {
-    case 1: hipLaunchKernelGGL(k_vector<1>, grid, dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
-    case 4: hipLaunchKernelGGL(k_vector<4>, grid, dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
-    default: hipLaunchKernelGGL(k_vector<16>, grid, dim3(VEC_THREADS), 0, m->stream, md, A, io, j, d); break;
+    case 1: if (m->has_prog) VEC_LAUNCH(1, true); else VEC_LAUNCH(1, false); break;
+    case 4: if (m->has_prog) VEC_LAUNCH(4, true); else VEC_LAUNCH(4, false); break;
+    default: if (m->has_prog) VEC_LAUNCH(16, true); else VEC_LAUNCH(16, false); break;
   }
+#undef VEC_LAUNCH
 }
 
 // kernel A of the pipeline: the pass over the model data (timed when profiling is on)
@@ -275,7 +279,8 @@ static void model_enqueue_plain(nuts_model* m, const double* q_dev, double* g_de
   launch_dense(m, A, io, 0);
   launch_vector(m, A, io, 0, 0);
   if (io.lean) launch_control_lean(m, A, io, 0, 0, 0.0, 0, nullptr, 0);
-  else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
+  else if (m->has_prog) hipLaunchKernelGGL(k_control<true>, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
+  else hipLaunchKernelGGL(k_control<false>, dim3(1), dim3(VEC_THREADS), 0, m->stream, m->md, A, io, 0, 0, 0.0, 0, (HostStatus*)nullptr, 0);
 }
 
 // "Compile" the spec: contributions per variable, broadcast terms, deferred elements, orphan factors.
@@ -327,6 +332,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     cb.pad = (int32_t)csr.size(); csr.insert(csr.end(), lst.begin(), lst.end());
     per_var[o.ref].push_back(cb);
     fac[fi].pad = 1;
+    m->has_prog = true;
     return true;
   };
   for (int fi = 0; fi < nf; ++fi) {
@@ -344,6 +350,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       }
     }
     bool owned_already = false;
+    if (f.n_instr > 0) m->has_prog = true;
     if (f.n_instr > 0) {
       // ---- a factor with an expression program (include/nuts_mi355.h): one contribution per VARIABLE that occurs anywhere in
       // its arguments or instructions (the device differentiates through the program, model_dev.h factor_eval_prog) ----
@@ -1669,7 +1676,8 @@ static inline void enqueue_leaf(nuts_chain* c, const Geometry& gm, int j, int d,
   launch_dense(m, A, io, j, 0, d, c->cfg.Emax, max_depth, st);
   launch_vector(m, A, io, j, d);
   if (io.lean) launch_control_lean(m, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
-  else hipLaunchKernelGGL(k_control, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+  else if (m->has_prog) hipLaunchKernelGGL(k_control<true>, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
+  else hipLaunchKernelGGL(k_control<false>, dim3(1), dim3(VEC_THREADS), 0, s, m->md, A, io, j, d, c->cfg.Emax, max_depth, st, seq);
   if (c->dense) {   // v' = C p', then the tree work on the stored (p', v')
     dense_velocity(c, A.P + d_o, A.V + d_o, nullptr, nullptr, 0.0, abort_flag, VEL_LEAF);
     const dim3 grid(m->md.nblk);
@@ -1814,9 +1822,12 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
 
 // the single-launch path (small_kernel.h): one workgroup, one thread per parameter
 static void launch_small(nuts_chain* c, const ArenaDev& A, const SmallDrawArgs& a) {
-  if (c->n <= 256) hipLaunchKernelGGL(k_small_draw<256>, dim3(1), dim3(256), 0, c->m->stream, c->m->md, A, a);
-  else if (c->n <= 512) hipLaunchKernelGGL(k_small_draw<512>, dim3(1), dim3(512), 0, c->m->stream, c->m->md, A, a);
-  else hipLaunchKernelGGL(k_small_draw<1024>, dim3(1), dim3(1024), 0, c->m->stream, c->m->md, A, a);
+#define SMALL_LAUNCH(NT, P) hipLaunchKernelGGL((k_small_draw<NT, P>), dim3(1), dim3(NT), 0, c->m->stream, c->m->md, A, a)
+  const bool hp = c->m->has_prog;
+  if (c->n <= 256) { if (hp) SMALL_LAUNCH(256, true); else SMALL_LAUNCH(256, false); }
+  else if (c->n <= 512) { if (hp) SMALL_LAUNCH(512, true); else SMALL_LAUNCH(512, false); }
+  else { if (hp) SMALL_LAUNCH(1024, true); else SMALL_LAUNCH(1024, false); }
+#undef SMALL_LAUNCH
 }
 
 // What the host does after a transition (nuts.py:478-489, base_hmc.py:238-282): step-size adaptation, mass-matrix update

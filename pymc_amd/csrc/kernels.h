@@ -269,7 +269,7 @@ template <int E, bool FROM_ARENA = false, bool L8 = false>
 __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int j, int d, bool tree,
                                           const int (&idx)[E], const bool (&act)[E], const double (&grad)[E],
                                           const double (&ph)[E], double* red, int nwaves, int& m_out, bool& last_out,
-                                          const MergePrefetch* pf = nullptr, int wsel = -1) {
+                                          const MergePrefetch* pf = nullptr, int wsel = -1, bool pf_on = true) {
   // `wsel` >= 0: `red` is this wave's own scratch (rows_gb_kernel.h: every wave finishes a group of its own)
   const int lane = threadIdx.x & (WAVE - 1), w = wsel >= 0 ? wsel : (int)(threadIdx.x >> 6);
   const int dir = lf.dir, edge = lf.edge, t = lf.t;
@@ -337,7 +337,7 @@ __device__ __forceinline__ void leaf_post(const ArenaDev& A, const Leaf& lf, int
 #pragma unroll
       for (int k = 0; k < 6; ++k) { const double s = (L8 ? wave_sum8 : wave_sum)(dd[k]); if (lane == 0) red[(1 + 6 * l + k) * nwaves + w] = s; }
     };
-    if (E == 1 && pf) {
+    if (E == 1 && pf && pf_on) {
 #pragma unroll
       for (int l = 0; l < MERGE_PF; ++l) if (l < m) level(l, pf->v[l]);
       for (int l = MERGE_PF; l < m; ++l) level(l, nullptr);
@@ -401,7 +401,7 @@ __device__ __forceinline__ bool dot_needed(int k, int m, bool last) {
 // ---------------------------------------------------------------------------
 // B: the O(n) kernel
 // ---------------------------------------------------------------------------
-template <int EPT>
+template <int EPT, bool PROG>
 __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A, EvalIO io, int j, int d) {
   Leaf lf; QView qv;
   const int aborted = load_aborted(io, A);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
         double x, dxdq, lj, dj, gx = 0.0;
         transform_full(v, qn[e], x, dxdq, lj, dj);
         lp += lj;
-        gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+        gather_element<PROG>(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
         double2* loc = reinterpret_cast<double2*>(md.def_loc) + 2 * (v.def_base + (i - v.offset));
         loc[0] = make_double2(gx, dxdq);
         loc[1] = make_double2(dj, ph[e]);
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     } else {
       transform_full(v, qn[e], x, dxdq, lj, dj);
       lp += lj;
-      gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+      gather_element<PROG>(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
     }
     if (is_z) {
       const double sgd = lg.sigma_tr == NUTS_TR_LOG ? exp(zsig[e]) : zsig[e];
@@ -567,13 +567,13 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   for (int o = 0; o < md.n_orphans; ++o) {
     const int fi = md.orphans[o];
     const int fsize = pg.factors[fi].size;
-    for (int li = bid * VEC_THREADS + tid; li < fsize; li += nb * VEC_THREADS) lp += orphan_element(pg, qv, fi, li, &s_bacc[0][tid], VEC_THREADS);
+    for (int li = bid * VEC_THREADS + tid; li < fsize; li += nb * VEC_THREADS) lp += orphan_element<PROG>(pg, qv, fi, li, &s_bacc[0][tid], VEC_THREADS);
   }
 
   // ---- second half kick + tree-merge dot products (wave partials land in s_red) ----
   int m = 0; bool last = false;
   TICK(md, tk, 5);
-  if (leaf && !io.dense) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last, use_mpf ? &mpf : nullptr);
+  if (leaf && !io.dense) leaf_post<EPT>(A, lf, j, d, io.mode == MODE_TREE, idx, act, grad, ph, s_red, NW, m, last, &mpf, -1, use_mpf);
   if (leaf && io.pre_next) {
     // first half of the next leaf (integration.py:118-127) from this leaf's registers: the same arithmetic as k_leaf_pre
     const int64_t no = slot_off(A, lf.t + lf.dir);
@@ -773,6 +773,7 @@ __device__ __forceinline__ void tree_decide(Ctl* c, const ArenaDev& A, const Lea
   }
 }
 
+template <bool PROG>
 __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax,
                                                         int max_depth, HostStatus* st, int seq) {
   Leaf lf; QView qv;
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
     double x, lj;
     transform_full(v, qn, x, dxdq, lj, dj);
     lp += lj;
-    gather_element(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
+    gather_element<PROG>(pg, qv, k, i - v.offset, x, gx, lp, &s_bacc[0][tid], VEC_THREADS);
     if (md.has_logit) {
       if (k == lg.var_mu) gx += s_sum[PART_DMU + (i - lg.off_mu)];
       else if (k == lg.var_sigma) gx += s_sum[PART_DSG + (i - lg.off_sigma)];

@@ -618,13 +618,21 @@ __device__ __forceinline__ void factor_kill(const Prog& pg, int f, int pdead, do
   if (pg.fdead[f]) { lpf = -INFINITY; d[0] = d[1] = d[2] = d[3] = 0.0; }
 }
 
+// (selects, not d[arg]: a run-time index into the four-entry arrays put all of them in scratch -- 144 B in every kernel that evaluates
+// factors)
+__device__ __forceinline__ double pick4(const double* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ double slot_grad(const double* d, const double* bv, const double* cv, int arg, int slot) {
-  return slot == 0 ? d[arg] : (slot == 1 ? d[arg] * cv[arg] : d[arg] * bv[arg]);
+  const double dd = pick4(d, arg);
+  return slot == 0 ? dd : (slot == 1 ? dd * pick4(cv, arg) : dd * pick4(bv, arg));
 }
 
 // Reverse-mode gather for element i (local index li) of variable k: d logp / d x_i from every factor the
 // variable appears in, plus (for owning contributions) the factor's logp and its broadcast terms.
 // `s_bacc` is the calling thread's column of the LDS broadcast accumulators ([MAX_BTERMS][blockDim]).
+// PROG = false: the model carries neither an expression program nor a gathered operand (the host picks the instantiation,
+// nuts_model::has_prog) -- the call into the out-of-line interpreter and everything it keeps alive across the call are compiled
+// out: with it k_small_draw<1024> spilled 357 registers and ran 59 us per leapfrog at n = 1002 instead of 24.
+template <bool PROG = true>
 __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, int k, int li, double x, double& gx, double& lp,
                                                double* s_bacc, int bstride) {
   for (int c = pg.var_cptr[k]; c < pg.var_cptr[k + 1]; ++c) {
@@ -651,6 +659,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       continue;
     }
     const nuts_factor& f = pg.factors[cb.f];
+    if constexpr (PROG) {
     if (cb.arg == -2) {    // gathered into the factor: every factor element that indexes this element, in index order
       const int32_t* ptr = pg.csr + cb.dist;
       const int32_t* lst = pg.csr + cb.pad;
@@ -682,6 +691,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       }
       continue;
     }
+    }
     double d[4], bv[4], cv[4];
     int pdead = 0;
     double lpf = factor_eval(pg, qv, f, li, k, x, d, bv, cv, &pdead);
@@ -697,10 +707,11 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
 
 // One element of a factor WITHOUT an owning variable (only scalars and data): its logp and the broadcast terms of its scalars.
 // Shared by the orphan loops of kernel B (kernels.h) and of the single-workgroup kernel (small_kernel.h).
+template <bool PROG = true>
 __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv, int fi, int li, double* s_bacc, int bstride) {
   const nuts_factor& f = pg.factors[fi];
   const FactorBT& bt = pg.fbt[fi];
-  if (f.n_instr > 0 || f.pad) {   // (pad != 0: the spec compiler marks factors with gathered operands; they take the general evaluator)
+  if constexpr (PROG) if (f.n_instr > 0 || f.pad) {   // (pad != 0: the spec compiler marks factors with gathered operands; they take the general evaluator)
     double lpo = 0.0;
     for (int b = 0; b < (bt.n > 0 ? bt.n : 1); ++b) {
       double d[4], darg[4];

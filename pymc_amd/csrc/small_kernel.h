@@ -46,7 +46,7 @@ struct SmallDrawArgs {
 // NT = threads of the one workgroup (256, 512 or 1024: one thread per parameter, so n <= 1024 runs here; at 1024 threads the
 // register budget is 128 and the kernel spills a little -- still 20.6 us per leapfrog against 25.3 us at n = 602 and 23.8
 // against 25.2 at n = 1002, profiles/r02i_latency_regime.json)
-template <int NT>
+template <int NT, bool PROG>
 __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, SmallDrawArgs a) {
   constexpr int NW = NT / WAVE;
   __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
@@ -82,13 +82,13 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
       } else {
         transform_full(v, qn, x, dxdq, lj, dj);
         lp = lj;
-        gather_element(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], NT);
+        gather_element<PROG>(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], NT);
       }
     }
     for (int o = 0; o < md.n_orphans; ++o) {   // factors without an owning variable
       const int fi = md.orphans[o];
       const int fsize = pg.factors[fi].size;
-      for (int li = tid; li < fsize; li += NT) lp += orphan_element(pg, qv, fi, li, &s_bacc[0][tid], NT);
+      for (int li = tid; li < fsize; li += NT) lp += orphan_element<PROG>(pg, qv, fi, li, &s_bacc[0][tid], NT);
     }
     for (int b = 0; b < md.n_bterms; ++b) {   // scalars that broadcast against vector factors
       const double t = block_sum<true>(s_bacc[b][tid], s_w);

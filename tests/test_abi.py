@@ -138,3 +138,12 @@ def test_streaming_kernels_hold_their_tiles_in_registers(lib, tmp_path):
     ga.update(gb)
     for name, (spills, scratch) in ga.items():
         assert spills == 0 and scratch == 0, (name, spills, scratch)
+    # kernels that evaluate factors exist twice: with the expression-program interpreter (an out-of-line call with two 16-entry
+    # scratch arrays) and without it; a model without programs must get the second -- with the call compiled in, k_small_draw<1024>
+    # spilled 357 registers and ran 59 us per leapfrog instead of 24 at n = 1002 (tools/small_bench.py)
+    for nt in (256, 512):
+        lean = kernels[next(k for k in kernels if re.match(rf"_Z12k_small_drawILi{nt}ELb0E", k))]
+        fat = kernels[next(k for k in kernels if re.match(rf"_Z12k_small_drawILi{nt}ELb1E", k))]
+        assert lean[0] == 0 and lean[1] <= 144 and fat[1] > 1000, (nt, lean, fat)
+    vec = kernels[next(k for k in kernels if re.match(r"_Z8k_vectorILi1ELb0E", k))]
+    assert vec[0] == 0 and vec[1] <= 144, vec
