@@ -659,7 +659,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       int gpw = 0;
       if (!use && want == 1 && !(s->rows_opts & NUTS_ROWS_NO_GROUP_BLOCK) && env_int("NUTS_ROWS_GB", 1) && m->ga_struct_ok && m->ept == 1 &&
           lg.G >= 64 && maxT <= 16) {
-        gpw = 4 * (int)((lg.G + 4 * 512 - 1) / (4 * 512));          // <= 512 workgroups where GB_MAXGPW allows it
+        gpw = GB_W * (int)((lg.G + GB_W * 512 - 1) / (GB_W * 512));   // a group per wave; more (in sequence) only to stay <= 512 workgroups
         gpw = std::min(gpw, GB_MAXGPW);
         if (env_int("NUTS_ROWS_GPW", 0) > 0) gpw = std::max(1, std::min(GB_MAXGPW, env_int("NUTS_ROWS_GPW", 0)));
         if ((lg.G + gpw - 1) / gpw > WAVE * SLOT_SUM_MAXR) gpw = 0;   // (slot_sum: at most SLOT_SUM_MAXR records per lane)

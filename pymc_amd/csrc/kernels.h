@@ -1034,15 +1034,17 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   };
   if (src.slot_major) {
     // slot-major records: wave w totals slots w, w + NW, ... four at a time (their loads in flight together)
-    const int lane = tid & (WAVE - 1), w = tid >> 6;
-    for (int q0 = w; q0 < nn; q0 += 4 * NW) {
+    // (every wave of the workgroup helps here, also those beyond `nt`, which leave after the barrier below; a slot is totalled by ONE
+    // wave in lane order + the fixed DPP tree, so its bits do not depend on which wave that is)
+    const int lane = tid & (WAVE - 1), w = tid >> 6, NWS = (int)blockDim.x >> 6;
+    for (int q0 = w; q0 < nn; q0 += 4 * NWS) {
       double v[4][SLOT_SUM_MAXR];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) slot_sum_issue(src.part + (int64_t)need_slot(min(q0 + u * NW, nn - 1)) * src.slot_major, src.slot_major, lane, v[u]);
+      for (int u = 0; u < 4; ++u) slot_sum_issue(src.part + (int64_t)need_slot(min(q0 + u * NWS, nn - 1)) * src.slot_major, src.slot_major, lane, v[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const double tot = slot_sum_finish(v[u], src.slot_major, lane);
-        if (q0 + u * NW < nn && lane == 0) s_sum[need_slot(q0 + u * NW)] = tot;
+        if (q0 + u * NWS < nn && lane == 0) s_sum[need_slot(q0 + u * NWS)] = tot;
       }
     }
   } else {
@@ -1054,6 +1056,7 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
     }
   }
   __syncthreads();
+  if (tid >= NT) return;   // (helper waves of a larger workgroup: only the sums above)
   TICK(md, ctk, 9);
   if (tree && s_ctl.aborted) {   // terminated earlier in this doubling: drain
     if (tid == 0 && st) publish_status(&s_ctl, st, seq);

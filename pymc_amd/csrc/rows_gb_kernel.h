@@ -36,7 +36,9 @@
 #else
 #define GB_XF(bit) false
 #endif
-#define GB_W 4            // waves per workgroup
+#ifndef GB_W
+#define GB_W 8            // waves per workgroup (8 x 8 groups: half the block partials of 4 x 4 -- 10.9 vs 11.8 us per launch at C2-S)
+#endif
 #define GB_MAXGPW 16      // groups per workgroup (LDS records)
 
 // one tile ([DX][SPAN] doubles at element offset xoff, y bytes at xoff / DX) into the [D][2] operand of ga_tile
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
   if (GB_XF(GB_F_EMPTY)) return;
   if (fold & GA_FOLD_CTL) {   // workgroup 0: control work, from the previous launch's block partials
     if (b == 0 && GB_XF(GB_F_NOCTL)) return;
-    if (b == 0) { control_lean<false, 8, true>(md, A, a.cio, a.cj, a.cd, a.Emax, a.max_depth, a.st, a.cseq, lean_src(md, par ^ 1)); return; }
+    if (b == 0) { control_lean<false, 8, true>(md, A, a.cio, a.cj, a.cd, a.Emax, a.max_depth, a.st, a.cseq, lean_src(md, par ^ 1), GB_W * WAVE > VEC_THREADS ? VEC_THREADS : 0); return; }
     --b;
   }
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(tid >> 6);

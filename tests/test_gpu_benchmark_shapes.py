@@ -415,7 +415,7 @@ def test_group_block_rows_on_ragged_empty_and_tiny_groups(gpw, monkeypatch):
     for sizes, D in cases:
         spec = _ragged_spec(np.asarray(sizes), D=D, seed=len(sizes))
         f = DeviceValueGradFunction(spec, device=0)
-        assert f.model_scalar("rows_group_aligned") == 1.0 and f.model_scalar("rows_group_block") == (gpw or 4)
+        assert f.model_scalar("rows_group_aligned") == 1.0 and f.model_scalar("rows_group_block") == (gpw or 8)
         for q in [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.5 for _ in range(2)]:
             lp, g = f._pytensor_function(q)
             lp0, g0 = ref_models.evaluate(spec, q)
@@ -445,7 +445,7 @@ def test_group_block_rows_on_ragged_empty_and_tiny_groups(gpw, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     tune, draws, seed = 25, 15, 7
     res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
-    assert res["step"]._logp_dlogp_func.model_scalar("rows_group_block") == (gpw or 4)
+    assert res["step"]._logp_dlogp_func.model_scalar("rows_group_block") == (gpw or 8)
     ref_draws, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
     dev = res["warmup_stats"][0] + res["stats"][0]
     # (the cross-group sums are associated differently from the oracle's loop: as at C2-S, one multinomial pick inside a tree flips
@@ -462,7 +462,7 @@ def test_group_block_pass_is_what_c2s_runs_and_every_reordering_of_it_is_bitwise
     from pymc_amd.value_grad import DeviceValueGradFunction
 
     f = DeviceValueGradFunction(c2s, device=0)
-    assert f.model_scalar("rows_group_block") == 4.0 and f.model_scalar("rows_group_aligned") == 1.0
+    assert f.model_scalar("rows_group_block") == 8.0 and f.model_scalar("rows_group_aligned") == 1.0
     f.close()
     base = _run_schedule(c2s, {}, monkeypatch, 14, 8, 31)
     for env in ({"NUTS_XFOLD": "0"}, {"NUTS_XFOLD": "1", "NUTS_SPEC_MAX": "10"}, {"NUTS_FOLD_CTL": "0"}):
