@@ -258,6 +258,7 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     switch (md.mv.aligned) {
       case 2: MVA_LAUNCH(2); break;
       case 8: MVA_LAUNCH(8); break;
+      case 16: MVA_LAUNCH(16); break;
       default: MVA_LAUNCH(4); break;
     }
 #undef MVA_LAUNCH
@@ -873,8 +874,10 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     mv.aligned = 0; mv.al_nwg = 0; mv.al_part = nullptr;
     if (md.lean_ok && !md.has_logit && !mv.winv && mv.off == 0 && mv.k == n && s->n_vars == 1 && s->n_factors == 0 &&
         s->vars[0].transform == NUTS_TR_NONE && md.n_deferred == 0 && md.n_orphans == 0) {
-      const int R = env_int("NUTS_MVN_ALIGNED", 4);   // rows per workgroup; 0: the two-kernel leapfrog
-      if (R == 2 || R == 4 || R == 8) {
+      // rows per workgroup; 0: the two-kernel leapfrog.  Fewer, larger workgroups = fewer records for the control work to total and
+      // a cheaper launch: at k = 2048 (C3) 8 rows measured 120 k leapfrog/s against 108 k with 4 and 88 k with 2
+      const int R = env_int("NUTS_MVN_ALIGNED", mv.k >= 1024 ? 8 : 4);
+      if (R == 2 || R == 4 || R == 8 || R == 16) {
         mv.aligned = R;
         mv.al_nwg = (mv.k + R - 1) / R;
         mv.al_part = m->keep(dev_alloc<double>(2 * (size_t)MVA_RS * mv.al_nwg));

@@ -599,7 +599,7 @@ def test_row_aligned_mvnormal_pass(monkeypatch):
             for a, b in zip(s0, s1):
                 for key in STAT_KEYS:
                     assert a[key] == b[key] or (a[key] != a[key] and b[key] != b[key]), (k, env, key, a[key], b[key])
-        for rows in ("0", "2", "8"):
+        for rows in ("0", "2", "4", "8", "16"):
             d1, s1, _ = _run_schedule(spec, {"NUTS_MVN_ALIGNED": rows}, monkeypatch, tune, draws, 79)
             for i, (a, b) in enumerate(zip(s0[:15], s1[:15])):
                 for key in ("depth", "tree_size", "index_in_trajectory", "diverging"):
