@@ -444,6 +444,10 @@ def evaluate(spec, q):
             lp, g_extra = _mvnormal(spec, spec.mvnormal, x)
             logp += lp
             gx += g_extra
+        if getattr(spec, "mixture_rows", None) is not None:
+            lp, g_extra = _mixture_rows(spec, spec.mixture_rows, x)
+            logp += lp
+            gx += g_extra
     grad = gx * dxdq + djac
     return logp, grad
 
@@ -473,6 +477,59 @@ def _logit_rows(spec, node, x):
     g[vs.offset : vs.offset + D] = (dbeta * z).sum(0)
     g[vz.offset : vz.offset + vz.size] = (dbeta * sg).ravel()
     return float(lp.sum()), g
+
+
+def _mixture_rows(spec, node, x):
+    """Normal mixture over observed rows (pymc_amd/model_spec.py MixtureRows).
+
+    marginal:     mixture.py:469-495 -- logsumexp(log(weights) + components_logp, axis=-1), components_logp = Normal.logp
+                  (continuous.py:526-532) of every row under every component;
+    conditional:  discrete.py:1179-1205 -- log(p[c_i]), -inf outside [0, K) -- plus Normal.logp(y_i | mu[c_i], sigma[c_i]).
+    Weights: constants, or softmax(logits) (a PyMC model writes `pm.math.softmax(logits)`; d log w_j / d logit_k = [j == k] - w_k).
+    Returns (logp, gradient w.r.t. the CONSTRAINED values)."""
+    K = node.K
+    y = node.y
+    vm = spec.vars[node.mu]
+    mu = x[vm.offset : vm.offset + K]
+    if node.sigma is not None:
+        vs = spec.vars[node.sigma]
+        sigma = x[vs.offset : vs.offset + K]
+    else:
+        sigma = np.asarray(node.sigma_const, dtype="d")
+    if node.w_logits is not None:
+        vw = spec.vars[node.w_logits]
+        eta = x[vw.offset : vw.offset + K]
+        e = np.exp(eta - eta.max())
+        w = e / e.sum()
+    else:
+        w = np.asarray(node.w_const, dtype="d")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        logw = np.log(w)
+        r = y[:, None] - mu[None, :]
+        comp = -0.5 * (r / sigma) ** 2 - np.log(np.sqrt(2.0 * np.pi)) - np.log(sigma)       # continuous.py:526-532
+        a = logw[None, :] + comp
+        if node.assign is None:
+            amax = a.max(axis=1)
+            lse = amax + np.log(np.exp(a - amax[:, None]).sum(axis=1))
+            resp = np.exp(a - lse[:, None])
+            lp = lse.sum()
+        else:
+            c = np.asarray(spec.data[node.assign]).astype("int64")
+            ok = (c >= 0) & (c < K)
+            cc = np.clip(c, 0, K - 1)
+            resp = np.zeros_like(a)
+            resp[np.arange(y.size), cc] = 1.0
+            lp = float(np.where(ok, a[np.arange(y.size), cc], -np.inf).sum())
+    R = resp.sum(axis=0)
+    A = (resp * r).sum(axis=0)
+    B = (resp * r * r).sum(axis=0)
+    g = np.zeros(spec.n)
+    g[vm.offset : vm.offset + K] = A / sigma**2
+    if node.sigma is not None:
+        g[vs.offset : vs.offset + K] = B / sigma**3 - R / sigma
+    if node.w_logits is not None:
+        g[vw.offset : vw.offset + K] = R - y.size * w
+    return float(lp), g
 
 
 def _mvnormal(spec, node, x):

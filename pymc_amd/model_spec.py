@@ -179,12 +179,37 @@ class MvNormalNode:
 
 
 @dataclass
+class MixtureRows:
+    """A Normal mixture over N observed rows with K components, in one of the two forms PyMC writes it:
+
+    * marginal (`assign is None`):  y_i ~ NormalMixture(w, mu, sigma) -- `Mixture` with Normal components,
+      logp_i = logsumexp_k(log w_k + logNormal(y_i | mu_k, sigma_k))   (pymc/distributions/mixture.py:469-495);
+    * conditional (`assign` = data id of the assignments c):  c_i ~ Categorical(w), y_i ~ Normal(mu[c_i], sigma[c_i]),
+      logp_i = log w_{c_i} + logNormal(y_i | mu_{c_i}, sigma_{c_i})    (pymc/distributions/discrete.py:1179-1205,
+      continuous.py:526-532); c is an integer-valued entry of `data` that another step method rewrites.
+
+    `mu` is a variable of size K.  `sigma` is a variable of size K (its constrained value is used) or a constant vector.  The
+    weights are a constant vector (sum 1) or `softmax(logits)` of a variable of size K (`w_logits`)."""
+
+    y: np.ndarray                     # [N] float64
+    K: int
+    mu: int                           # var id
+    sigma: Optional[int] = None       # var id, or None with sigma_const
+    sigma_const: Optional[np.ndarray] = None
+    w_logits: Optional[int] = None    # var id, or None with w_const
+    w_const: Optional[np.ndarray] = None
+    assign: Optional[int] = None      # data id of the assignments (float-coded integers in [0, K)), None: marginal
+    name: str = "y"
+
+
+@dataclass
 class ModelSpec:
     vars: List[FreeVar] = field(default_factory=list)
     data: List[np.ndarray] = field(default_factory=list)
     factors: List[Factor] = field(default_factory=list)
     logit_rows: Optional[LogitRows] = None
     mvnormal: Optional[MvNormalNode] = None
+    mixture_rows: Optional[MixtureRows] = None
     # "extra" inputs of the log-density (model/core.py:142-190 `extra_vars_and_values`): name -> index into `data`;
     # the caller rewrites them through `set_extra_values` (value variables sampled by another step method)
     extra: Dict[str, int] = field(default_factory=dict)
@@ -617,6 +642,37 @@ class ModelBuilder:
         e = Expr(self, Term(Operand(OP_VAR, 0.0, vid)), var.size)
         self._names[name] = e
         return e
+
+    def NormalMixture(self, name, w, mu: Expr, sigma, observed, assign: Optional[Expr] = None):
+        """`pm.NormalMixture(name, w=w, mu=mu, sigma=sigma, observed=y)` (marginal form), or with `assign` = an `Extra` holding the
+        assignments c: `pm.Categorical("c", p=w, shape=N)` + `pm.Normal(name, mu[c], sigma[c], observed=y)` evaluated for the
+        continuous variables.  `w`: a constant vector, or `m.math.softmax(logits)` written as `("softmax", logits_expr)`;
+        `sigma`: a variable of size K or a constant (scalar / vector)."""
+        y = np.ascontiguousarray(observed, dtype="float64").ravel()
+        K = mu.size
+        node = MixtureRows(y, K, self._var_id(mu), name=name)
+        if isinstance(sigma, Expr):
+            node.sigma = self._var_id(sigma)
+        else:
+            node.sigma_const = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype="float64"), (K,)))
+        if isinstance(w, tuple) and len(w) == 2 and w[0] == "softmax":
+            node.w_logits = self._var_id(w[1])
+        else:
+            wc = np.ascontiguousarray(w, dtype="float64")
+            if wc.shape != (K,) or np.any(wc < 0) or not np.isclose(wc.sum(), 1.0):
+                raise ValueError("constant mixture weights: a vector of K non-negative numbers that sum to 1")
+            node.w_const = wc
+        if assign is not None:
+            t = assign.term
+            if t.a.kind != OP_DATA or t.b.kind != OP_CONST or t.b.c != 0.0:
+                raise ValueError("assign must be an Extra / Data entry holding the assignments")
+            node.assign = int(t.a.ref)
+            if self.spec.data[node.assign].size != y.size:
+                raise ValueError("one assignment per observed row")
+        for vid in (node.mu, node.sigma, node.w_logits):
+            if vid is not None and self.spec.vars[vid].size != K:
+                raise ValueError("mixture parameters must have K elements")
+        self.spec.mixture_rows = node
 
     def build(self) -> ModelSpec:
         return self.spec
