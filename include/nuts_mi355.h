@@ -156,6 +156,19 @@ typedef struct {
   /* expression programs of the factors (nuts_factor.instr_off / n_instr); NULL when no factor has one */
   const nuts_instr *instrs;
   int32_t n_instrs, pad2;
+  /* dense node 3: a Normal mixture over mix_N observed rows with mix_K <= 16 components.  mix_N == 0 disables.
+       mix_assign < 0   y_i ~ NormalMixture(w, mu, sigma): logp_i = logsumexp_k(log w_k + logNormal(y_i | mu_k, sigma_k))
+                        (pymc/distributions/mixture.py:469-495 with Normal components, continuous.py:526-532)
+       mix_assign >= 0  c_i ~ Categorical(w), y_i ~ Normal(mu[c_i], sigma[c_i]) given the assignments c = data vector mix_assign
+                        (float-coded integers; an assignment outside [0, K) makes the logp -inf: discrete.py:1179-1205)
+     mix_mu: variable of size K.  mix_sigma: variable of size K (untransformed or log-transformed: its constrained value is
+     used), or -1 with mix_sigma_const.  Weights: w = softmax(variable mix_w_logits), or mix_w_logits = -1 with the constant
+     weights mix_w_const (non-negative, sum 1).  The parameter variables may not be scalars that broadcast into other factors. */
+  int64_t mix_N;
+  int32_t mix_K, mix_mu, mix_sigma, mix_w_logits, mix_assign, mix_pad;
+  const double *mix_y;           /* [N] */
+  const double *mix_sigma_const; /* [K] or NULL */
+  const double *mix_w_const;     /* [K] or NULL */
 } nuts_model_spec;
 
 typedef struct nuts_model nuts_model;
@@ -200,6 +213,9 @@ int64_t nuts_model_algorithmic_bytes(const nuts_model *m);
  *                         diagonal mass matrices only -- a chain with a dense one needs NUTS_ROWS_NO_GROUP_ALIGNED),
  *   "mvn_row_aligned"     1 when the model is one MvNormal node and the row-aligned pass finishes the leapfrog in the
  *                         mat-vec's own workgroups (one launch per leapfrog),
+ *   "mvn_row_aligned" is the rows per workgroup of that pass (0: the two-kernel leapfrog), "rows_group_block" the groups per
+ *                         workgroup of the group-block pass (0: not used), "mixture_workgroups" the grid of the mixture node's
+ *                         row kernel (0: no such node),
  *   "rows_waves", "lean", "single_workgroup_ok". */
 int nuts_model_get_scalar(const nuts_model *m, const char *name, double *out);
 

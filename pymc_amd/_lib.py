@@ -92,6 +92,16 @@ class ModelSpecC(C.Structure):
         ("instrs", C.POINTER(Instr)),
         ("n_instrs", C.c_int32),
         ("pad2", C.c_int32),
+        ("mix_N", C.c_int64),
+        ("mix_K", C.c_int32),
+        ("mix_mu", C.c_int32),
+        ("mix_sigma", C.c_int32),
+        ("mix_w_logits", C.c_int32),
+        ("mix_assign", C.c_int32),
+        ("mix_pad", C.c_int32),
+        ("mix_y", C.POINTER(C.c_double)),
+        ("mix_sigma_const", C.POINTER(C.c_double)),
+        ("mix_w_const", C.POINTER(C.c_double)),
     ]
 
 

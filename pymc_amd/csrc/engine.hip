@@ -22,6 +22,7 @@
 
 #include "kernels.h"
 #include "small_kernel.h"
+#include "mixture_kernel.h"
 #include "nuts_mi355.h"
 #include "pcg64_stream.h"
 #include "advi.h"
@@ -168,6 +169,13 @@ struct CtlJob {   // control work riding in workgroup 0 of a group-aligned row p
 static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int fold = 0, int d = 0, double Emax = 0.0,
                          int max_depth = 0, HostStatus* st = nullptr, const CtlJob* job = nullptr) {
   ModelDev& md = m->md;
+  if (md.has_mix) {   // mixture node (mixture_kernel.h): per-workgroup sums over the rows, then their total and the node's outputs
+    const dim3 grid(md.mix.nwg), block(MIX_BLOCK);
+    if (md.mix.K <= 4) hipLaunchKernelGGL(k_mix_rows<4>, grid, block, 0, m->stream, md, A, io, j);
+    else if (md.mix.K <= 8) hipLaunchKernelGGL(k_mix_rows<8>, grid, block, 0, m->stream, md, A, io, j);
+    else hipLaunchKernelGGL(k_mix_rows<16>, grid, block, 0, m->stream, md, A, io, j);
+    hipLaunchKernelGGL(k_mix_reduce, dim3(1), dim3(WAVE), 0, m->stream, md, A, io, j);
+  }
   if (!md.has_logit && !md.has_mvn) return;
   const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
@@ -885,6 +893,52 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       }
     }
   }
+  md.has_mix = 0;
+  if (s->mix_N > 0) {
+    MixDev& mx = md.mix;
+    auto bad = [&](const char* msg) { g_err = msg; nuts_model_destroy(m); return (nuts_model*)nullptr; };
+    if (s->rows_N > 0 || s->mvn_k > 0) return bad("mixture node: not together with another dense node");
+    if (s->mix_K < 1 || s->mix_K > MIX_MAXK) return bad("mixture node: 1 <= K <= 16 components");
+    if (!s->mix_y) return bad("mixture node: no observations");
+    auto var_ok = [&](int v) { return v >= 0 && v < s->n_vars && s->vars[v].size == s->mix_K && !vars[v].deferred; };
+    if (!var_ok(s->mix_mu)) return bad("mixture node: mu must be a variable with K elements (not a scalar that broadcasts into another factor)");
+    if (s->mix_sigma >= 0 && (!var_ok(s->mix_sigma) || (s->vars[s->mix_sigma].transform != NUTS_TR_NONE && s->vars[s->mix_sigma].transform != NUTS_TR_LOG)))
+      return bad("mixture node: sigma must be a variable with K elements, untransformed or log-transformed");
+    if (s->mix_sigma < 0 && !s->mix_sigma_const) return bad("mixture node: sigma is neither a variable nor a constant");
+    if (s->mix_w_logits >= 0 && (!var_ok(s->mix_w_logits) || s->vars[s->mix_w_logits].transform != NUTS_TR_NONE))
+      return bad("mixture node: the weight logits must be an untransformed variable with K elements");
+    if (s->mix_w_logits < 0 && !s->mix_w_const) return bad("mixture node: the weights are neither softmax(logits) nor constants");
+    if (s->vars[s->mix_mu].transform != NUTS_TR_NONE) return bad("mixture node: mu must be untransformed");
+    if (s->mix_assign >= s->n_data || (s->mix_assign >= 0 && s->data[s->mix_assign].size != s->mix_N))
+      return bad("mixture node: one assignment per observed row");
+    mx.N = s->mix_N; mx.K = s->mix_K;
+    mx.off_mu = s->vars[s->mix_mu].offset;
+    mx.off_sigma = s->mix_sigma >= 0 ? s->vars[s->mix_sigma].offset : -1;
+    mx.tr_sigma = s->mix_sigma >= 0 ? s->vars[s->mix_sigma].transform : NUTS_TR_NONE;
+    mx.off_w = s->mix_w_logits >= 0 ? s->vars[s->mix_w_logits].offset : -1;
+    for (int k = 0; k < MIX_MAXK; ++k) { mx.sigma_c[k] = 1.0; mx.logw_c[k] = 0.0; }
+    if (s->mix_sigma < 0)
+      for (int k = 0; k < mx.K; ++k) {
+        if (!(s->mix_sigma_const[k] > 0)) return bad("mixture node: sigma > 0");   // continuous.py:532 check_parameters
+        mx.sigma_c[k] = s->mix_sigma_const[k];
+      }
+    if (s->mix_w_logits < 0) {
+      double sum = 0.0;
+      for (int k = 0; k < mx.K; ++k) { if (!(s->mix_w_const[k] >= 0 && s->mix_w_const[k] <= 1)) return bad("mixture node: 0 <= weights <= 1, sum(weights) == 1"); sum += s->mix_w_const[k]; }
+      if (std::fabs(sum - 1.0) > 1e-8) return bad("mixture node: 0 <= weights <= 1, sum(weights) == 1");   // mixture.py:487-493
+      for (int k = 0; k < mx.K; ++k) mx.logw_c[k] = std::log(s->mix_w_const[k]);
+    }
+    mx.y = m->keep(dev_upload(s->mix_y, (size_t)s->mix_N));
+    mx.assign = s->mix_assign >= 0 ? md.pool + s->data[s->mix_assign].offset : nullptr;
+    mx.nwg = (int)std::max<int64_t>(1, std::min<int64_t>(512, (s->mix_N + 4 * MIX_BLOCK - 1) / (4 * MIX_BLOCK)));
+    mx.part = m->keep(dev_alloc<double>((size_t)mx.nwg * (3 * MIX_MAXK + 1)));
+    mx.gdense = m->keep(dev_alloc<double>((size_t)n + 1));
+    mx.lp = mx.gdense + n;
+    if (mx.part) hipMemset(mx.part, 0, (size_t)mx.nwg * (3 * MIX_MAXK + 1) * sizeof(double));
+    if (mx.gdense) hipMemset(mx.gdense, 0, ((size_t)n + 1) * sizeof(double));
+    md.has_mix = 1;
+    m->alg_bytes += 8 * s->mix_N + (s->mix_assign >= 0 ? 8 * s->mix_N : 0);
+  }
   for (void* p : m->owned)
     if (!p) { g_err = "device allocation failed"; nuts_model_destroy(m); return nullptr; }
   HIPCHK_NULL(hipDeviceSynchronize());
@@ -935,6 +989,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   const std::string k(name);
   if (k == "rows_group_aligned") *out = m->md.lg.ga;
   else if (k == "rows_group_block") *out = m->md.lg.ga_gpw;
+  else if (k == "mixture_workgroups") *out = m->md.has_mix ? m->md.mix.nwg : 0;
   else if (k == "mvn_row_aligned") *out = m->md.has_mvn ? m->md.mv.aligned : 0;
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
   else if (k == "lean") *out = m->md.lean_ok;
@@ -1338,7 +1393,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->spec_max = env_int("NUTS_SPEC_MAX", 10);
   c->xfold = env_int("NUTS_XFOLD", 1);
   c->xpre = env_int("NUTS_XPRE", 1);
-  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn &&
+  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix &&
              !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     for (int w = (bid + nb) * VEC_THREADS + tid; w < nlp; w += nb * VEC_THREADS) lp += lg.wave_lp[w];
   }
   if (md.has_mvn) for (int r = bid * VEC_THREADS + tid; r < md.mv.k; r += nb * VEC_THREADS) lp -= 0.5 * md.mv.rowq[r];
+  if (md.has_mix && bid == 0 && tid == 0) lp += *md.mix.lp;   // (mixture_kernel.h: k_mix_reduce ran before this kernel)
 
   for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
   double db_acc = 0.0, dbz_acc = 0.0;
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
       dbz_acc += db * x;
     }
     if (md.has_mvn && i >= md.mv.off && i < md.mv.off + md.mv.k) gd += md.mv.gdense[i];
+    if (md.has_mix) gd += md.mix.gdense[i];
     grad[e] = (gx + gd) * dxdq + dj;
     act[e] = true;
     if (leaf) A.G[lf.d_o + i] = grad[e];

@@ -123,6 +123,20 @@ struct MvnDev {
   double* al_part;           // [2][al_nwg][MVA_RS] per-workgroup records (record-major, compact), double-buffered by launch parity
 };
 
+// dense node 3: Normal mixture over observed rows (mixture_kernel.h)
+#define MIX_MAXK 16
+struct MixDev {
+  int64_t N;
+  int32_t K, off_mu, off_sigma, off_w;   // element offsets of the parameter variables (off_sigma / off_w < 0: the constants below)
+  int32_t tr_sigma, nwg;
+  const double* y;        // [N]
+  const double* assign;   // [N] assignments in the data pool (float-coded integers), nullptr: marginal form
+  double sigma_c[MIX_MAXK], logw_c[MIX_MAXK];
+  double* part;           // [nwg][3 MIX_MAXK + 1] per-workgroup sums {R_k, A_k, B_k, logp}
+  double* gdense;         // [n] the node's gradient w.r.t. the constrained values (zero outside its parameters)
+  double* lp;             // the node's logp
+};
+
 // per-workgroup partial record written by the vector kernel, summed (in workgroup order) by the control kernel
 #define PART_LP 0
 #define PART_BT 1
@@ -139,6 +153,8 @@ struct ModelDev {
   int has_logit, has_mvn;
   RowsDev lg;
   MvnDev mv;
+  int has_mix, mix_pad;
+  MixDev mix;
   double* part;               // [nblk][part_stride]
   int32_t part_stride, prog_bytes;
   // "lean" control path (see kernels.h): the only deferred elements are the hierarchical-logit node's mu / sigma, so

@@ -85,6 +85,23 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
             winv = np.ascontiguousarray(np.tril(scipy.linalg.solve_triangular(L, np.eye(len(mu)), lower=True)))
             keep.append(winv)
             s.mvn_winv = _lib.dptr(winv)
+    mx = getattr(spec, "mixture_rows", None)
+    if mx is not None:
+        y = np.ascontiguousarray(mx.y, dtype="float64")
+        keep.append(y)
+        s.mix_N, s.mix_K, s.mix_mu = y.size, mx.K, mx.mu
+        s.mix_y = _lib.dptr(y)
+        s.mix_sigma = -1 if mx.sigma is None else mx.sigma
+        s.mix_w_logits = -1 if mx.w_logits is None else mx.w_logits
+        s.mix_assign = -1 if mx.assign is None else mx.assign
+        if mx.sigma is None:
+            sc = np.ascontiguousarray(mx.sigma_const, dtype="float64")
+            keep.append(sc)
+            s.mix_sigma_const = _lib.dptr(sc)
+        if mx.w_logits is None:
+            wc = np.ascontiguousarray(mx.w_const, dtype="float64")
+            keep.append(wc)
+            s.mix_w_const = _lib.dptr(wc)
     return s, keep
 
 

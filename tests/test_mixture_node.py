@@ -104,3 +104,92 @@ def test_golden_file_is_what_the_reference_computes_today():
         np.testing.assert_array_equal(g[f"case{i}_categorical_logp"], np.asarray(R["categorical_logp"](c, w)))
     with pytest.raises(R["ParameterValueError"]):    # weights that do not sum to one fail the reference's check
         R["mixture_logprob"](np.zeros(2), np.array([0.5, 0.6]), np.zeros(2), np.ones(2))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# device (csrc/mixture_kernel.h) against the oracle
+# ---------------------------------------------------------------------------------------------------------------------------
+
+def _mix_data(rng, K, N):
+    mu = np.sort(rng.normal(0, 3, size=K))
+    sigma = rng.uniform(0.4, 1.5, size=K)
+    comp = rng.integers(0, K, size=N)
+    return mu[comp] + sigma[comp] * rng.normal(size=N)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,K,N", [("marginal", 3, 50), ("marginal", 2, 4097), ("marginal", 5, 20_000), ("marginal", 8, 3000),
+                                      ("marginal", 16, 1500), ("marginal_logits", 3, 100_000), ("marginal_logits", 7, 999),
+                                      ("conditional", 3, 100_000), ("conditional", 4, 77), ("const_sigma", 3, 5000)])
+def test_device_logp_grad_matches_the_oracle(form, K, N):
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    rng = np.random.default_rng(K * 1000 + N)
+    y = _mix_data(rng, K, N)
+    w = rng.dirichlet(np.ones(K) * 3.0)
+    spec = _spec(y, w, K, sigma=(rng.uniform(0.5, 1.5, size=K) if form == "const_sigma" else "var"), logits=form == "marginal_logits",
+                 assign=rng.integers(0, K, size=N) if form == "conditional" else None)
+    f = DeviceValueGradFunction(spec, device=0)
+    assert f.model_scalar("mixture_workgroups") >= 1
+    for q in [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.7 for _ in range(3)]:
+        lp, g = f._pytensor_function(q)
+        lp0, g0 = ref_models.evaluate(spec, q)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.abs(g0).max()), np.max(np.abs(g - g0))
+    f.close()
+
+
+@pytest.mark.gpu
+def test_assignments_are_extra_values_another_step_rewrites():
+    """The conditional form reads the assignments from the data pool: `set_extra_values` (model/core.py:286-300) changes what the
+    next evaluation sees; an assignment outside [0, K) makes the log-density -inf (discrete.py:1190-1196)."""
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    rng = np.random.default_rng(3)
+    K, N = 3, 6000
+    y = _mix_data(rng, K, N)
+    c0, c1 = rng.integers(0, K, size=N), rng.integers(0, K, size=N)
+    spec = _spec(y, np.array([0.2, 0.5, 0.3]), K, assign=c0)
+    f = DeviceValueGradFunction(spec, device=0)
+    q = rng.normal(size=spec.n) * 0.5
+    for c in (c0, c1):
+        f.set_extra_values({"c": c.astype("float64")})
+        spec.data[spec.extra["c"]][:] = c
+        lp, g = f._pytensor_function(q)
+        lp0, g0 = ref_models.evaluate(spec, q)
+        assert abs(lp - lp0) <= 1e-10 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-9 * np.abs(g0).max()
+    bad = c1.astype("float64")
+    bad[17] = K
+    f.set_extra_values({"c": bad})
+    lp, _ = f._pytensor_function(q)
+    assert lp == -np.inf
+    f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["marginal", "marginal_logits"])
+def test_nuts_on_a_marginalised_mixture_has_the_oracle_samplers_integers(form):
+    import test_gpu_parity as tp
+
+    rng = np.random.default_rng(11)
+    K, N = 3, 3000
+    y = np.concatenate([rng.normal(-4, 0.6, N // 3), rng.normal(0, 1.0, N // 3), rng.normal(5, 0.8, N - 2 * (N // 3))])
+    spec = _spec(y, np.array([0.3, 0.4, 0.3]), K, logits=form == "marginal_logits")
+    tp._compare_runs(spec, tune=25, draws=10, seed=5, prefix=30)
+
+
+@pytest.mark.gpu
+def test_device_rejects_a_malformed_mixture_node():
+    from pymc_amd import _lib
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 1.0, shape=17)
+    m.NormalMixture("y", np.full(17, 1 / 17), mu, 1.0, np.zeros(10))
+    with pytest.raises(_lib.EngineError, match="1 <= K <= 16"):
+        DeviceValueGradFunction(m.build(), device=0)
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 1.0, shape=3)
+    m.NormalMixture("y", np.full(3, 1 / 3), mu, np.array([1.0, 0.0, 1.0]), np.zeros(10))
+    with pytest.raises(_lib.EngineError, match="sigma > 0"):
+        DeviceValueGradFunction(m.build(), device=0)
