@@ -124,7 +124,7 @@ def std_normal(n: int = 10, mu: float = 2.0, sigma: float = np.sqrt(3.0)) -> Mod
     return m.build()
 
 
-def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: float = 1.0) -> ModelSpec:
+def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: float = 1.0, form: str = "sufficient") -> ModelSpec:
     """Gaussian mixture with latent discrete assignments (BASELINE configs[4]; the discrete half is sampled by
     `pymc_amd.gibbs.CategoricalGibbsMetropolis`, the continuous half -- this spec -- by NUTS, mixed by `CompoundStep`):
 
@@ -133,8 +133,13 @@ def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: f
     In PyMC: `mu = pm.Normal("mu", 0, 10, shape=K); c = pm.Categorical("c", p=w, shape=N);
     pm.Normal("y", mu[c], sigma, observed=y)`.  The assignments reach this log-density as extra values (core.py:142-190) through
     their per-component sufficient statistics (`MixtureLink.extras_for`): the factor below plus the constant term equals
-    sum_i [log w_{c_i} + log Normal(y_i | mu[c_i], sigma)] exactly."""
+    sum_i [log w_{c_i} + log Normal(y_i | mu[c_i], sigma)] exactly.  `form="node"`: the same log-density evaluated row by row
+    by the mixture node (`ModelBuilder.NormalMixture(..., assign=c)`: Categorical.logp + indexed Normal.logp as PyMC writes them),
+    with the assignments themselves as the extra value."""
     from pymc_amd.gibbs import MixtureLink
+
+    if form not in ("sufficient", "node"):
+        raise ValueError("form must be 'sufficient' or 'node'")
 
     rng = np.random.default_rng(seed)
     mu_true = np.linspace(-3.0, 3.0, K)
@@ -142,6 +147,12 @@ def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: f
     y = mu_true[c_true] + sigma * rng.normal(size=N)
     m = ModelBuilder()
     mu = m.Normal("mu", 0.0, 10.0, shape=K)
+    if form == "node":
+        c = m.Extra("c", np.zeros(N))
+        m.NormalMixture("y", np.full(K, 1.0 / K), mu, float(sigma), y, assign=c)
+        spec = m.build()
+        spec.mixture = MixtureLink("c", y, np.full(K, -np.log(K)), np.full(K, float(sigma)), "mu")
+        return spec
     ybar = m.Extra("c__ybar", np.zeros(K))
     sd = m.Extra("c__sd", np.ones(K))
     const = m.Extra("c__const", np.zeros(1))

@@ -434,7 +434,8 @@ class _DeviceHMCBase:
         extra = self.spec.extra
         if extra:   # arraystep.py:109-111: `shared.set_value(point[name])` for the non-gradient value variables
             link = getattr(self.spec, "mixture", None)
-            if link is not None:   # extras that are functions of another step method's variable (pymc_amd/gibbs.py)
+            if link is not None and any(name.startswith(link.name + "__") for name in extra):
+                # extras that are functions of another step method's variable (pymc_amd/gibbs.py)
                 derived = link.extras_for(point[link.name])
                 self._logp_dlogp_func.set_extra_values({name: (derived[name] if name in derived else point[name]) for name in extra})
             else:

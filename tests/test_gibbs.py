@@ -368,7 +368,8 @@ def test_device_proportional_sweep_reproduces_the_reference_assignments_bitwise(
 
 
 @pytest.mark.gpu
-def test_compound_nuts_plus_gibbs_matches_the_oracle_pair():
+@pytest.mark.parametrize("form", ["sufficient", "node"])
+def test_compound_nuts_plus_gibbs_matches_the_oracle_pair(form):
     """`CompoundStep([NUTS(mu), CategoricalGibbsMetropolis(c)])` (compound.py:296-305, one spawned generator per method): the
     device pair against (oracle NUTS over the full-model log-density with c as extra input, oracle Gibbs): identical
     assignments and identical NUTS integers, iteration by iteration; and at N = 100 000 (configs[4]) one sweep against the
@@ -376,7 +377,9 @@ def test_compound_nuts_plus_gibbs_matches_the_oracle_pair():
     from pymc_amd.compound import CompoundStep
     from pymc_amd.step import NUTS
 
-    spec = models.normal_mixture(N=2000, K=3, seed=7)
+    # (form "node": the continuous log-density evaluated row by row by the mixture node, the assignments as its extra value;
+    # "sufficient": through the per-component statistics of the assignments -- the same function of (mu, c))
+    spec = models.normal_mixture(N=2000, K=3, seed=7, form=form)
     link = spec.mixture
     nuts = NUTS(model=spec, rng=1, device=0)
     gibbs = CategoricalGibbsMetropolis(model=spec, rng=2, device=0)
