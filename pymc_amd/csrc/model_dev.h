@@ -368,7 +368,14 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 // enough for the instruction cache -- they are launched once per leapfrog between two passes of kernel A)
 // `pdead` is set when a PARAMETER check failed (the reference's `check_parameters`; the support checks on the value are plain
 // element-wise switches there): the caller decides what that means for the factor's other elements (factor_kill below).
-__device__ __noinline__ double dist_eval(int dist, double konst, const double* a, double* d, int* pdead) {
+// Arguments and results travel BY VALUE (registers under the device calling convention): with pointer parameters the caller's a[4],
+// d[4] and the flag had to live in scratch -- 80 to 144 B in every kernel that evaluates factors.
+struct DistOut { double lp, d0, d1, d2, d3; int dead; };
+__device__ __noinline__ DistOut dist_eval_v(int dist, double konst, double a0, double a1, double a2, double a3) {
+  const double a[4] = {a0, a1, a2, a3};
+  double d[4];
+  int pdead_v = 0;
+  int* const pdead = &pdead_v;
   const double NINF = -INFINITY;
   const double LOG_SQRT_2PI = 0.91893853320467274178;
   const double LOG_SQRT_2_OVER_PI = -0.22579135264472743236;
@@ -550,7 +557,13 @@ __device__ __noinline__ double dist_eval(int dist, double konst, const double* a
   if (dead) d[0] = d[1] = d[2] = d[3] = 0.0;
 #undef KILL_UNLESS
 #undef KILL_PARAM
-  return lp;
+  return DistOut{lp, d[0], d[1], d[2], d[3], pdead_v};
+}
+__device__ __forceinline__ double dist_eval(int dist, double konst, const double* a, double* d, int* pdead) {
+  const DistOut o = dist_eval_v(dist, konst, a[0], a[1], a[2], a[3]);
+  d[0] = o.d0; d[1] = o.d1; d[2] = o.d2; d[3] = o.d3;
+  if (o.dead) *pdead = 1;
+  return o.lp;
 }
 
 // Evaluate element `li` of factor `f`: returns its logp, fills d[k] (partials w.r.t. argument k)
@@ -636,7 +649,13 @@ __device__ __forceinline__ void factor_kill(const Prog& pg, int f, int pdead, do
 
 // (selects, not d[arg]: a run-time index into the four-entry arrays put all of them in scratch -- 144 B in every kernel that evaluates
 // factors)
-__device__ __forceinline__ double pick4(const double* v, int i) { return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3])); }
+// (bit masks rather than a select chain: selects between loads of one array are folded back into an indexed load)
+__device__ __forceinline__ double pick4(const double* v, int i) {
+  unsigned long long r = 0ull;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r |= (unsigned long long)__double_as_longlong(v[k]) & (0ull - (unsigned long long)(i == k || (k == 3 && i > 3)));
+  return __longlong_as_double((long long)r);
+}
 __device__ __forceinline__ double slot_grad(const double* d, const double* bv, const double* cv, int arg, int slot) {
   const double dd = pick4(d, arg);
   return slot == 0 ? dd : (slot == 1 ? dd * pick4(cv, arg) : dd * pick4(bv, arg));
