@@ -5,7 +5,8 @@ foreign backend walking that graph: pymc/sampling/jax.py:102-125).  Here the wal
 graphs `model.logp(sum=False)` (core.py:612-695: one element-wise graph per free RV, observed RV and potential, Jacobian
 terms of the value transforms included) into a `ModelSpec`: free value variables in `model.value_vars` order with their
 transforms, one distribution factor per graph with affine arguments `a + b * c`, and the dense nodes that have their own
-streaming kernels (hierarchical Bernoulli-logit rows, MvNormal).
+streaming kernels (hierarchical Bernoulli-logit rows; the marginalised Normal mixture over observed rows that `pm.NormalMixture`
+builds through `mixture_logprob`, mixture.py:469-495; MvNormal through `ModelBuilder` only).
 
 PyTensor cannot be imported in the build image, so the walker is written against the node PROTOCOL only -- it never
 imports pytensor and looks at nothing but
@@ -22,7 +23,8 @@ checkout by `ast` and executes them on a stand-in for the graph protocol above; 
 (tests/golden/ref_graphs.npz) so that they travel (continuous.py:526-532 Normal, :909-916 HalfNormal, :2287-2293 Cauchy, :2383-2390
 HalfCauchy, :1478-1486 Exponential, :1570-1576 Laplace, :1807-1821 LogNormal, :1935-1950 StudentT, :1248-1262 Beta, :2512-2521 Gamma,
 :2631-2639 InverseGamma, :309-321 Uniform, :720-746 TruncatedNormal, discrete.py:351-374 Bernoulli, :141-154 Binomial, :581-597
-Poisson; transforms.py:880-891 log, :1026-1070 interval, :1076-1088 logodds).  What is still written by hand in the tests is only
+Poisson; mixture.py:469-495 `mixture_logprob` over one batched Normal component; transforms.py:880-891 log, :1026-1070 interval,
+:1076-1088 logodds).  What is still written by hand in the tests is only
 what IS PyTensor (operator overloading, op class names) and the assembly `Model.logp` performs around those bodies.
 
 How a factor is recognised: the graph is first turned into a small expression tree (constants folded, broadcasts /
@@ -36,7 +38,9 @@ inlined through `fgraph.inputs` / `fgraph.outputs`, but a rewritten graph has al
 follow -- hand over the graph `Model.logp` returns); (2) that `pt.pow(x, 2)` is still emitted as `Pow` with a constant exponent (a `Sqr`
 is accepted too); (3) constant folding of `pt.log(pt.sqrt(2.0 * np.pi))` is done here numerically, the tolerance on
 matched constants is 1e-12; (4) dims / coords, `pm.Data` containers (shared variables are read with `.get_value()` at
-lowering time; re-lowering or `set_extra_values` is needed when they change); (5) the distributions of the spec IR not
+lowering time; re-lowering or `set_extra_values` is needed when they change); (4b) that `pt.logsumexp` is still
+`log(sum(exp(x), axis))` in the unrewritten graph and `pm.math.softmax` a `Softmax` node (the mixture matcher keys on both);
+(5) the distributions of the spec IR not
 listed above -- none is left: TruncatedNormal (continuous.py:720-746) is matched by its outer shape and its normalising term
 verified by evaluation (`_match_truncnormal`) -- and everything outside the IR, for which `lower_to_spec` raises `NotLowerable` -- the caller then keeps the reference's CPU
 path for that model.
@@ -148,6 +152,8 @@ def build_tree(v, memo: Optional[dict] = None):
         out = ("take", build_tree(ins[0], memo), build_tree(ins[1], memo))
     elif name == "Dot":
         out = ("dot", build_tree(ins[0], memo), build_tree(ins[1], memo))
+    elif name == "Softmax":
+        out = ("softmax", build_tree(ins[0], memo))
     elif name in ("All", "Any", "MakeVector"):
         out = (name.lower(), *[build_tree(i, memo) for i in ins])
     else:
@@ -813,6 +819,53 @@ class _Lowering:
                     return True
         return False
 
+    def _mixture(self, node) -> bool:
+        """`mixture_logprob` over one batched Normal component (mixture.py:469-495, what `pm.NormalMixture` builds):
+        log(sum(exp(log(weights) + Normal.logp(value[..., None], mu, sigma)), axis=-1)) -- `logsumexp` unrewritten -- with the
+        observations a constant vector, mu a variable of K elements, sigma a variable of K elements or a constant, the weights a
+        constant vector or softmax(variable)  ->  the mixture node (model_spec.MixtureRows, marginal form)."""
+        if node[0] != "log" or node[1][0] != "sum" or node[1][2][0] != "exp":
+            return False
+        body = node[1][2][1]
+        if body[0] != "add":
+            return False
+        normal = next(t for d, t, _ in TEMPLATES if d == ms.D_NORMAL)
+        for wt, nl in ((body[1], body[2]), (body[2], body[1])):
+            env: Dict[str, Any] = {}
+            if not unify(normal, nl, env):
+                continue
+            val, mu_n, sg_n = env["value"], env["mu"], env["sigma"]
+            km = self._as_var(mu_n)
+            if val[0] != "const" or km is None:
+                continue
+            K_ = self.spec.vars[km].size
+            node_ = ms.MixtureRows(np.ascontiguousarray(val[1], dtype="float64").ravel(), K_, km, name="y")
+            ks = self._as_var(sg_n)
+            if ks is not None and self.spec.vars[ks].size == K_:
+                node_.sigma = ks
+            elif sg_n[0] == "const":
+                node_.sigma_const = np.ascontiguousarray(np.broadcast_to(np.asarray(sg_n[1], dtype="float64"), (K_,)))
+            else:
+                continue
+            if wt[0] == "const":                                  # log(w) of constant weights, folded
+                lw = np.broadcast_to(np.asarray(wt[1], dtype="float64"), (K_,))
+                w = np.exp(lw)
+                if not np.isclose(w.sum(), 1.0):
+                    raise NotLowerable("mixture weights that do not sum to one")
+                node_.w_const = np.ascontiguousarray(w)
+            elif wt[0] == "log" and wt[1][0] == "softmax":
+                kw = self._as_var(wt[1][1])
+                if kw is None or self.spec.vars[kw].size != K_:
+                    continue
+                node_.w_logits = kw
+            else:
+                continue
+            if self.spec.mixture_rows is not None:
+                raise NotLowerable("more than one mixture over observed rows")
+            self.spec.mixture_rows = node_
+            return True
+        return False
+
     _prog = None
     _gather_ids: Dict[Any, int] = {}
 
@@ -831,6 +884,9 @@ class _Lowering:
     def _factor(self, node, name: str, own_value=None):
         own = self.var_id.get(id(own_value)) if own_value is not None else None
         node = self._strip_jacobian(node, own)
+        if own is None and self._mixture(node):
+            self.spec.mixture_rows.name = name
+            return
         for dist, tmpl, argnames in TEMPLATES:
             env: Dict[str, Any] = {}
             if not unify(tmpl, node, env):

@@ -169,6 +169,44 @@ def varying_intercepts_and_slopes(b=None):
     return m
 
 
+YM = np.concatenate([np.random.default_rng(15).normal(-3, 0.6, 40), np.random.default_rng(16).normal(0.5, 1.0, 50), np.random.default_rng(17).normal(4, 0.8, 30)])
+WM = np.array([0.3, 0.45, 0.25])
+
+
+def normal_mixture_marginal():
+    """`pm.NormalMixture("y", w, mu, sigma, observed=y)` with constant weights: the marginalised mixture over the observed rows."""
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 5.0, shape=(3,))
+    sigma = m.HalfNormal("sigma", 2.0, shape=(3,))
+    m.NormalMixture("y", WM, mu, sigma, observed=YM)
+    return m
+
+
+def _normal_mixture_marginal_built():
+    b = ModelBuilder()
+    mu = b.Normal("mu", 0.0, 5.0, shape=3)
+    sigma = b.HalfNormal("sigma", 2.0, shape=3)
+    b.NormalMixture("y", WM, mu, sigma, YM)
+    return b.build()
+
+
+def normal_mixture_softmax():
+    """Weights `pm.math.softmax(logits)` of a free vector, a common scale for the components."""
+    m = sg.StubModel()
+    logits = m.Normal("logits", 0.0, 1.5, shape=(3,))
+    mu = m.Normal("mu", 0.0, 5.0, shape=(3,))
+    m.NormalMixture("y", m.math.softmax(logits), mu, 0.9, observed=YM)
+    return m
+
+
+def _normal_mixture_softmax_built():
+    b = ModelBuilder()
+    logits = b.Normal("logits", 0.0, 1.5, shape=3)
+    mu = b.Normal("mu", 0.0, 5.0, shape=3)
+    b.NormalMixture("y", ("softmax", logits), mu, 0.9, YM)
+    return b.build()
+
+
 def _built(fn, *a):
     return fn(*a, ModelBuilder()).build()
 
@@ -192,5 +230,7 @@ ENTRIES = {
     "hier_normal_exp_sigma": (hier_normal_exp_sigma, lambda: _built(hier_normal_exp_sigma)),
     "cubic_and_friends": (cubic_and_friends, lambda: _built(cubic_and_friends)),
     "varying_intercepts_and_slopes": (varying_intercepts_and_slopes, lambda: _built(varying_intercepts_and_slopes)),
+    "normal_mixture_marginal": (normal_mixture_marginal, _normal_mixture_marginal_built),
+    "normal_mixture_softmax": (normal_mixture_softmax, _normal_mixture_softmax_built),
 }
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")

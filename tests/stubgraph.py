@@ -121,8 +121,15 @@ class MakeVector:
     pass
 
 
+class Softmax:
+    """`pytensor.tensor.special.Softmax(axis)` (what `pm.math.softmax` builds)."""
+
+    def __init__(self, axis=-1):
+        self.axis = axis
+
+
 for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "EQ", "OR", "AND", "Sigmoid", "Abs",
-           "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus", "Erf", "Erfc", "Erfcx", "Sqr"):
+           "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus", "Erf", "Erfc", "Erfcx", "Sqr", "IsClose"):
     globals()[_n] = type(_n, (), {})
 
 
@@ -212,6 +219,38 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     constant = staticmethod(lambda x, **kw: TensorConstant(x))
     as_tensor_variable = staticmethod(lambda x, dtype=None, **kw: as_tensor(x))
     zeros_like = staticmethod(lambda a: elemwise(Second, a, 0.0))     # pt.zeros_like = fill(a, 0)
+
+    @staticmethod
+    def sum(x, axis=None, keepdims=False):
+        x = as_tensor(x)
+        shp = x.type.shape
+        if axis is None:
+            out = ()
+        else:
+            ax = axis % max(len(shp), 1)
+            out = tuple(s for i, s in enumerate(shp) if i != ax)
+        return Variable(Apply(Sum(axis), [x]), shape=out)
+
+    @staticmethod
+    def logsumexp(x, axis=None, keepdims=False):
+        """`pytensor.tensor.math.logsumexp`: `log(sum(exp(x), axis=axis, keepdims=keepdims))` -- that IS its body (the max-shifted
+        form is a graph rewrite, applied when a function is compiled; `Model.logp` hands out the unrewritten graph)."""
+        return pt.log(pt.sum(pt.exp(x), axis=axis, keepdims=keepdims))
+
+    @staticmethod
+    def expand_dims(x, axis):
+        x = as_tensor(x)
+        shp = list(x.type.shape)
+        ax = axis if axis >= 0 else len(shp) + 1 + axis
+        shp.insert(ax, 1)
+        return Variable(Apply(DimShuffle(), [x]), shape=tuple(shp))
+
+    isclose = staticmethod(lambda a, b: elemwise(IsClose, a, b))
+
+    @staticmethod
+    def softmax(x, axis=-1):
+        x = as_tensor(x)
+        return Variable(Apply(Softmax(axis), [x]), shape=x.type.shape)
 
     @staticmethod
     def all(x, axis=None):
@@ -365,6 +404,10 @@ def reference():
     ref_class("distributions/transforms.py", "Interval", ["__init__"], ns["IntervalTransform"], ns)
     ns["transforms"] = type("transforms", (), {"Interval": ns["Interval"], "log": ns["LogTransform"](), "logodds": ns["LogOddsTransform"]()})
     ref_function("distributions/continuous.py", "bounded_cont_transform", ns)
+    # `logp(component, value)` inside mixture_logprob (mixture.py:477-483): pymc.logprob.basic.logp dispatches to the logp of the
+    # component RV's distribution
+    ns["logp"] = lambda rv, value: rv.dist_cls.logp(value, *rv.params)
+    ref_function("distributions/mixture.py", "mixture_logprob", ns)
     _NS = ns
     return ns
 
@@ -408,8 +451,26 @@ def _dist(name, *args, **kw):
     return reference()[name].dist(*args, **kw)
 
 
+class _ComponentRV:
+    """The batched component of a `pm.NormalMixture` (`Normal.dist(mu, sigma)`, mixture.py:598-607) as `mixture_logprob` sees it:
+    an RV variable whose op has `ndim_supp` and whose distribution's logp the dispatcher calls."""
+
+    class _Op:
+        ndim_supp = 0
+
+    class _Owner:
+        pass
+
+    def __init__(self, dist_cls, params):
+        self.dist_cls, self.params = dist_cls, params
+        self.owner = self._Owner()
+        self.owner.op = self._Op()
+
+
 class _PtMath:
     """`pm.math.*` as the model code calls it: the `pytensor.tensor` functions of the same name (pymc/math.py re-exports them)."""
+
+    softmax = pt.softmax
 
     exp, log, log1p, sqrt, abs = pt.exp, pt.log, pt.log1p, pt.sqrt, pt.abs
     sigmoid = invlogit = pt.sigmoid
@@ -489,6 +550,14 @@ class StubModel:
 
     def Poisson(self, name, mu, observed):
         return self._rv("Poisson", name, np.shape(observed), _dist("Poisson", mu), None, observed)
+
+    def NormalMixture(self, name, w, mu, sigma, observed):
+        """`pm.NormalMixture(name, w=w, mu=mu, sigma=sigma, observed=y)` (mixture.py:598-607: `Mixture` over ONE batched
+        `Normal.dist(mu, sigma)`); its log-density graph is what the reference's `mixture_logprob` builds (mixture.py:469-495)."""
+        ref = reference()
+        comp = _ComponentRV(ref["Normal"], _dist("Normal", mu=mu, sigma=sigma))
+        fn = lambda value, w_, comp_: ref["mixture_logprob"](None, (value,), None, w_, comp_)   # noqa: E731
+        return self._add(_RV(name, np.shape(observed), fn, (as_tensor(w), comp), None, observed))
 
     def Bernoulli(self, name, logit_p, observed):
         return self._rv("Bernoulli", name, np.shape(observed), _dist("Bernoulli", logit_p=logit_p), None, observed)   # discrete.py:351-352
@@ -573,7 +642,7 @@ def dump_model(m) -> dict:
     }
 
 
-_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector)}
+_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax)}
 
 
 class FrozenModel:
@@ -590,7 +659,7 @@ class FrozenModel:
                 ins = [vs[i] for i in rec["ins"]]
                 if rec["op"] == "Elemwise":
                     op = Elemwise(globals()[rec["scalar"]]())
-                elif rec["op"] in ("Sum", "All"):
+                elif rec["op"] in ("Sum", "All", "Softmax"):
                     op = _OPS[rec["op"]](rec.get("axis"))
                 elif rec["op"] == "CheckParameterValue":
                     op = CheckParameterValue(rec.get("msg", ""))
