@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box round script: parity tests, bench, rocprofv3 kernel trace + PMC passes, summarised into gpurun_out/.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [stages]   stages: any of t(ests) b(ench) p(rofile) c(3) s(C2-S) e(ss study)
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [stages]   stages: any of t(ests) b(ench) p(rofile) c(3) x (only C3's counter passes) s(C2-S) e(ss study) m (smoke + N = 2 on one GPU)
 export PYMC_AMD_HONOUR_NUTS_ENV=1   # the NUTS_* variables below reach the engine as schedule options (nuts_set_option)
 TAG=${1:-r02}
 STAGES=${2:-tbp}
@@ -39,6 +39,15 @@ if [[ $STAGES == *c* ]]; then
   { echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --workload c3 --steps 100 --warmup 200 --cpu-leapfrogs 0 (tag $TAG)"; grep -E '^\{' $OUT/prof_c3_$TAG.log | head -1
     python $R/tools/rocpd_summary.py $OUT/prof_c3_$TAG/trace_results.db; } > $OUT/profile_c3_$TAG.txt 2>&1
   rm -rf $OUT/prof_c3_$TAG; cd $R
+fi
+if [[ $STAGES == *c* || $STAGES == *x* ]]; then   # (x: only these) counter passes of the C3 launch -- what crosses the fabric into the XCDs' L2s
+  cd /tmp; rm -rf $OUT/pmc_c3_f_$TAG $OUT/pmc_c3_w_$TAG
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_c3_f_$TAG -o pmc -- python $R/bench.py --workload c3 --steps 30 --warmup 60 --cpu-leapfrogs 0 --ess-tune 0 > $OUT/pmc_c3_f_$TAG.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_c3_w_$TAG -o pmc -- python $R/bench.py --workload c3 --steps 30 --warmup 60 --cpu-leapfrogs 0 --ess-tune 0 > $OUT/pmc_c3_w_$TAG.log 2>&1
+  python $R/tools/rocpd_summary.py --traffic $OUT/pmc_c3_f_$TAG/pmc_results.db $OUT/pmc_c3_w_$TAG/pmc_results.db $OUT/traffic_c3_$TAG.json k_mvn_aligned $TAG $HASH k_mvn_aligned_bytes_per_launch ". What the counter sees crosses the fabric into the XCDs' L2s: with P (33.5 MB) resident in the 256 MiB Infinity Cache it is not HBM traffic"
+  { echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE -- python bench.py --workload c3 --steps 30 --warmup 60 --cpu-leapfrogs 0 --ess-tune 0 (tag $TAG, kernel source hash $HASH)"
+    python $R/tools/rocpd_summary.py $OUT/pmc_c3_f_$TAG/pmc_results.db --pmc $OUT/pmc_c3_f_$TAG/pmc_results.db $OUT/pmc_c3_w_$TAG/pmc_results.db; } > $OUT/pmc_c3_$TAG.txt 2>&1
+  rm -rf $OUT/pmc_c3_f_$TAG $OUT/pmc_c3_w_$TAG; cd $R
 fi
 if [[ $STAGES == *s* ]]; then
   bash tools/c2s_profile.sh $TAG > /dev/null 2>&1

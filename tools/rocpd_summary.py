@@ -49,7 +49,7 @@ def pmc_stats(path):
         print(f"{r[0][:70]:70s} {r[1]:>14s} {r[2]:6d} {r[3]:14.3f} {r[4]:14.3f}")
 
 
-def traffic_json(fetch_db, write_db, out_path, kernel_like, tag, src_hash):
+def traffic_json(fetch_db, write_db, out_path, kernel_like, tag, src_hash, key="k_rows_bytes_per_launch", note=""):
     """HBM bytes per launch of the dominant kernel from the two PMC passes, with the guide's gfx950 correction: read side =
     2 x FETCH_SIZE (KiB), write side = WRITE_SIZE (KiB).  The MEAN over FULL launches: launches queued behind a tree that had
     already terminated drain as no-ops (they read a flag and leave) and are told apart by their counter value -- less than half of
@@ -70,14 +70,14 @@ def traffic_json(fetch_db, write_db, out_path, kernel_like, tag, src_hash):
         return
     # (the write counter of a drained launch is not far from a full one's -- a few KB either way -- so the split is made on the read side)
     out = {
-        "k_rows_bytes_per_launch": int(2 * f["mean_full"] * 1024 + w["mean_all"] * 1024),
+        key: int(2 * f["mean_full"] * 1024 + w["mean_all"] * 1024),
         "fetch_size_kib_mean_full_launches": f["mean_full"], "fetch_size_kib_max": f["max"], "fetch_size_kib_mean_all": f["mean_all"],
         "write_size_kib_mean": w["mean_all"], "write_size_kib_max": w["max"],
         "launches": f["n"], "full_launches": f["n_full"], "drained_launches": f["n"] - f["n_full"],
         "kernel": kernel_like, "kernel_source_hash": src_hash,
         "source": f"profiles/{tag}_profile.txt: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), MEAN over the full launches "
                   "(drained launches, recognised by a read counter below half the maximum, are left out); read side doubled per MI355X_MICROARCH.md "
-                  "(gfx950 counts 128-B requests as 64 B)",
+                  "(gfx950 counts 128-B requests as 64 B)" + note,
     }
     json.dump(out, open(out_path, "w"), indent=1)
 
@@ -162,8 +162,8 @@ def launch_positions(path, tail_frac=0.5):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args[0] == "--traffic":   # --traffic <fetch.db> <write.db> <out.json> <kernel substring> <tag> <source hash>
-        traffic_json(*args[1:7])
+    if args[0] == "--traffic":   # --traffic <fetch.db> <write.db> <out.json> <kernel substring> <tag> <source hash> [json key] [note]
+        traffic_json(*args[1:9])
         sys.exit(0)
     kernel_stats(args[0])
     gap_stats(args[0])
