@@ -228,22 +228,16 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
       case 4: ROWS_LAUNCH(4, RR, OO); break;                \
       default: ROWS_LAUNCH(2, RR, OO); break;               \
     }
-#define ROWS_BY_OCC(RR)                                     \
-    switch (m->rows_occ) {                                  \
-      case 3: ROWS_BY_D(RR, 3) break;                       \
-      case 5: ROWS_BY_D(RR, 5) break;                       \
-      case 6: ROWS_BY_D(RR, 6) break;                       \
-      default: ROWS_BY_D(RR, 4) break;                      \
-    }
-    switch (md.lg.D) {   // (widths that are not a power of two: one launch geometry)
+    // (one launch geometry: two rows per lane, launch bounds for four waves per SIMD -- the variants with 3 / 5 / 6 waves and four
+    // rows per lane lost their A/Bs in round 1 and were 21 more instantiations of the kernel to compile)
+    switch (md.lg.D) {   // (widths that are not a power of two take the same geometry)
       case 1: ROWS_LAUNCH(1, 2, 4); break;
       case 3: ROWS_LAUNCH(3, 2, 4); break;
       case 5: ROWS_LAUNCH(5, 2, 4); break;
       case 6: ROWS_LAUNCH(6, 2, 4); break;
       case 7: ROWS_LAUNCH(7, 2, 4); break;
-      default: if (m->rows_rpl == 2) { ROWS_BY_OCC(2) } else { ROWS_BY_OCC(4) }
+      default: ROWS_BY_D(2, 4)
     }
-#undef ROWS_BY_OCC
 #undef ROWS_BY_D
 #undef ROWS_LAUNCH
   }
@@ -609,9 +603,9 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     RowsDev& lg = md.lg;
     md.has_logit = 1;
     // launch geometry (tunable for experiments; defaults chosen from measurements)
-    m->rows_rpl = env_int("NUTS_ROWS_RPL", 2) == 4 ? 4 : 2;
+    m->rows_rpl = 2;
     m->rows_alternate = env_int("NUTS_ROWS_ALTERNATE", 1) ? 1 : 0;
-    m->rows_occ = env_int("NUTS_ROWS_OCC", 4);
+    m->rows_occ = 4;
     // 16 waves per CU are resident at a time (4 per SIMD at 113 VGPRs); two such sets of shorter waves balance the
     // tail better than one (measured with the folded control: 61.3 us per pass vs 63.0 us at 16, 62.8 at 48, 65.8 at 64)
     // -- for passes long enough to give every wave a few spans (C2-L: 4.8 per wave); shorter, cache-resident passes are
