@@ -217,3 +217,35 @@ def test_lowered_reference_graph_runs_on_the_device(name):
         lp0, g0 = ref_models.evaluate(want, q)
         assert abs(lp - lp0) <= 1e-10 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.abs(g0).max())
     f.close()
+
+
+def _deterministic_case():
+    rng = np.random.default_rng(8)
+    y = rng.normal(-10, 1e-3, size=60)
+    return y, np.array([1.0, 0.0]), np.array([-10.0, 10.0]), np.array([1e-3, 1e-3])
+
+
+def test_deterministic_weights_select_one_component():
+    """tests/distributions/test_mixture.py:146-181 (`test_single_univariate_component_deterministic_weights`): with weights (1, 0) the
+    mixture's logp is the selected component's logp; log(0) = -inf for the other one must not leak a NaN."""
+    y, w, mu, sigma = _deterministic_case()
+    spec = _spec(y, w, 2)
+    lp, g = ref_models._mixture_rows(spec, spec.mixture_rows, np.concatenate([mu, sigma]))
+    want = np.sum(-0.5 * ((y - mu[0]) / sigma[0]) ** 2 - np.log(np.sqrt(2 * np.pi)) - np.log(sigma[0]))
+    np.testing.assert_allclose(lp, want, rtol=1e-13)
+    assert np.all(np.isfinite(g)) and g[1] == 0.0 and g[3] == 0.0      # the excluded component gets no gradient
+
+
+@pytest.mark.gpu
+def test_deterministic_weights_on_the_device():
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    y, w, mu, sigma = _deterministic_case()
+    spec = _spec(y, w, 2)
+    f = DeviceValueGradFunction(spec, device=0)
+    q = _q_for(spec, mu, sigma)
+    lp, g = f._pytensor_function(q)
+    lp0, g0 = ref_models.evaluate(spec, q)
+    assert np.isfinite(lp) and abs(lp - lp0) <= 1e-10 * abs(lp0) and np.all(np.isfinite(g))
+    assert np.max(np.abs(g - g0)) <= 1e-9 * np.abs(g0).max()
+    f.close()
