@@ -190,9 +190,9 @@ def sample_draws(step: NUTS, point, K: int, callback=None, first_index: int = 0,
     i = 0
     while i < K:
         if batch > 1 and callback is None and each_draw is None and getattr(step, "can_draw_many", False):
-            pos, point, st = step.draw_many(point, min(batch, K - i))
-            out[i : i + len(st)] = pos
-            stats_out.extend(st)
+            kb = min(batch, K - i)
+            _, point, st = step.draw_many(point, kb, out=out[i : i + kb])   # (written in place; a short batch's tail rows are
+            stats_out.extend(st)                                            # overwritten by the next one)
             log_warning_stats(st)
             i += len(st)
             continue

@@ -615,11 +615,12 @@ class NUTS(_DeviceHMCBase):
                         and not getattr(self.potential, "_device_estimator", False))
         return (not self.tune) or not host_adapted
 
-    def draw_many(self, point: PointType, K: int):
+    def draw_many(self, point: PointType, K: int, out: Optional[np.ndarray] = None):
         """K consecutive transitions from `point` inside one C call (`nuts_chain_draw_many`).  Returns
         `(positions [k][n], last point, [stats] * k)` with k <= K: the engine stops a batch after a divergent draw and
         when the pre-drawn uniforms could not cover another worst-case tree; the caller just asks again.  Both
-        generators end exactly where k calls of `astep` would have left them."""
+        generators end exactly where k calls of `astep` would have left them.  `out`: a C-contiguous float64 (K, n) array the
+        positions are written to (the caller's trace: no intermediate copy); its first k rows are returned."""
         sub = {name: point[name] for name in self.var_names}
         q0 = DictToArrayBijection.map(sub)
         q = np.ascontiguousarray(q0.data, dtype="float64")
@@ -632,7 +633,10 @@ class NUTS(_DeviceHMCBase):
         per_draw = min(self._n_uniforms, getattr(self, "_uniforms_per_draw", UNIFORMS_PER_EXTRA_DRAW))
         n_uni = self._n_uniforms + per_draw * K   # one worst-case tree + a recent tree's worth (with a margin) per further draw
         uniforms = self.rng.random(n_uni)
-        out = np.empty((K, n))
+        if out is None:
+            out = np.empty((K, n))
+        elif out.shape != (K, n) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float64 array of shape (K, n)")
         stats = (_lib.DrawStats * K)()
         n_done = C.c_int32(0)
         was_tuning = self.tune
