@@ -193,20 +193,19 @@ class FullRankADVI:
         done = 0
         callbacks = list(callbacks or [])
         # `_iterate_with_loss` (inference.py:230-290) calls every callback after EVERY step with (approx, scores[:i + 1], i + 1).  The
-        # device runs `chunk` steps per C call, so a callback can only see the approximation at chunk ends: the chunks are cut so
-        # that every multiple of a callback's `every` (CheckParametersConvergence, Tracker-like objects) IS a chunk end, and the
-        # callbacks run there with the step count and the whole score history so far; callbacks without an `every` attribute
-        # run at each chunk end.  StopIteration ends the fit as in the reference (inference.py:283-286).
-        everys = [int(getattr(cb, "every")) for cb in callbacks if getattr(cb, "every", None)]
-        stride = int(np.lcm.reduce(everys)) if everys else None
-        if stride is not None and stride > chunk:
-            stride = min(everys)   # (incommensurate periods: the shortest one is honoured exactly, the others at its multiples)
+        # device runs `chunk` steps per C call, so a callback can only see the approximation at chunk ends: a chunk ends at the
+        # NEXT multiple of ANY callback's `every` (CheckParametersConvergence, Tracker-like objects), so every multiple of every
+        # period is a chunk end whether or not the periods divide each other (100 and 150: ends at 100, 150, 200, 300, ...), and
+        # all callbacks run there with the step count and the whole score history so far -- the ones with a period ignore the
+        # steps that are not theirs, exactly as they do in the reference, where they are called after every step; callbacks
+        # without an `every` attribute run at each chunk end.  StopIteration ends the fit as in the reference (inference.py:283-286).
+        everys = sorted({int(getattr(cb, "every")) for cb in callbacks if getattr(cb, "every", None)})
         scores = np.empty(0)
         try:
             while done < n:
                 k = min(chunk, n - done)
-                if stride is not None:
-                    k = min(k, stride - done % stride)
+                for ev in everys:
+                    k = min(k, ev - done % ev)
                 idx, z0 = self.draw_inputs(k)
                 loss = self.run_steps(idx, z0, obj_optimizer)
                 hist.append(loss)

@@ -179,13 +179,33 @@ def test_fit_matches_the_oracle_fit_and_the_closed_form_posterior():
 
 
 @pytest.mark.gpu
-def test_configs3_shape_runs():
-    """BASELINE configs[3] at a quarter of its rows (250 k x 512, X = 1 GB) keeps the test short (the full 1 M x 512 is 4 GB of X: it
-    runs, `models.glm()` builds it, but it is a parity-test configuration, not a bench line)."""
-    m = models.glm(N=250_000, P=512, batch_size=1024, seed=4)
-    approx = fit(300, model=m, random_seed=2)
-    assert approx.hist.shape == (300,) and np.all(np.isfinite(approx.hist))
-    assert approx.params[1].shape == (512 * 513 // 2,)
+def test_configs3_literal_shape_matches_the_oracle_step_by_step():
+    """BASELINE configs[3] at its LITERAL shape -- 1 M observations x 512 covariates (X = 4.1 GB resident in HBM), minibatches of
+    1024 rows, full-rank ADVI -- device against the oracle on identical row indices and z0.  A step touches
+    the 1024 drawn rows whatever N is, so the oracle is as cheap here as on the small shapes; 12 steps wrap the adagrad window.
+    Tolerances: loss 1e-10 relative, parameters 1e-9 (the device sums the minibatch in a different order)."""
+    m = models.glm(N=1_000_000, P=512, batch_size=1024, seed=4)
+    assert m.X.shape == (1_000_000, 512)
+    inf = FullRankADVI(model=m, random_seed=2, device=0)
+    rng = np.random.default_rng(11)
+    steps = 12
+    idx = rng.integers(0, m.X.shape[0], size=(steps, 1024), dtype=np.int64)
+    idx[0, :4] = [0, m.X.shape[0] - 1, 0, m.X.shape[0] - 1]            # first and last row, repeated inside a batch
+    z0 = rng.normal(size=(steps, 512))
+    opt = adagrad_window(learning_rate=0.001, epsilon=0.1, n_win=10)
+    loss = inf.run_steps(idx, z0, opt)
+    glm = ref_advi.GLM(m.X, m.y, m.family, m.sigma, m.prior_sd)
+    st = ref_advi.FullRankState(512)
+    ref_loss = [ref_advi.advi_step(glm, st, idx[s], z0[s], 0.001, 0.1, 10)[0] for s in range(steps)]
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-10)
+    mu, lt = inf.approx.params
+    assert lt.shape == (512 * 513 // 2,)
+    np.testing.assert_allclose(mu, st.mu, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(lt, st.L_tril, rtol=1e-9, atol=1e-12)
+    # and the fit itself keeps going from there (finite losses over a few hundred more steps of its own random inputs)
+    approx = inf.fit(200)
+    assert approx.hist.shape == (200,) and np.all(np.isfinite(approx.hist))
+    inf.close()
 
 
 def test_fit_cuts_its_chunks_where_the_callbacks_look(monkeypatch):
@@ -221,6 +241,15 @@ def test_fit_cuts_its_chunks_where_the_callbacks_look(monkeypatch):
     cb2 = Every(100, stop_at=300)
     inf2.fit(10_000, callbacks=[cb2], chunk=1024)
     assert cb2.seen[-1] == 300 and len(inf2.hist) == 300
+    # two periods that do not divide each other: EVERY multiple of each is a chunk end, so each callback sees all of
+    # its own steps -- the reference calls both after every step (inference.py:230-290) and they pick theirs
+    inf4 = FullRankADVI(model=m, random_seed=3)
+    monkeypatch.setattr(inf4, "run_steps", fake_steps)
+    ca, cb150 = Every(100), Every(150)
+    inf4.fit(1000, callbacks=[ca, cb150], chunk=1024)
+    assert set(range(100, 1001, 100)) <= set(ca.seen) and set(range(150, 1001, 150)) <= set(cb150.seen)
+    assert ca.seen == cb150.seen == sorted(set(range(100, 1001, 100)) | set(range(150, 1001, 150)))
+    assert len(inf4.hist) == 1000
     # without callbacks nothing is cut
     sizes.clear()
     inf3 = FullRankADVI(model=m, random_seed=3)
