@@ -31,12 +31,11 @@ def gap_stats(path):
     rows = list(cur.execute("select name, start, end from kernels order by start"))
     agg = {}
     for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
-        a = agg.setdefault(n1, [0, 0.0])
-        a[0] += 1
-        a[1] += max(0, s1 - e0)
-    print("\n# idle gap before each kernel (us, mean over dispatches)")
-    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        print(f"{n[:70]:70s} {c:8d} {t/c/1e3:9.2f}")
+        agg.setdefault(n1, []).append(max(0, s1 - e0))
+    print("\n# idle gap before each kernel (us): mean and median over dispatches")
+    for n, g in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        g = sorted(g)
+        print(f"{n[:70]:70s} {len(g):8d} {sum(g)/len(g)/1e3:9.2f} {g[len(g)//2]/1e3:9.2f}")
 
 
 def pmc_stats(path):
@@ -160,6 +159,49 @@ def launch_positions(path, tail_frac=0.5):
     print("# by carried control work: " + ", ".join(f"{k}: {sum(v)/len(v):.2f} us (n={len(v)})" for k, v in sorted(by_m.items())))
 
 
+def gap_positions(path, tail_frac=0.5):
+    """Idle gap before the dominant kernel: quantiles over all its dispatches in the tail of the trace, and mean / median by POSITION
+    in the draw (same draws as launch_positions).  A gap every launch pays (CP dispatch, cache maintenance at the kernel boundary)
+    shows as a flat floor; one the host causes (a doubling queued late) shows at the first leaf of a doubling only."""
+    cur = sqlite3.connect(path).cursor()
+    rows = list(cur.execute("select name, start, end from kernels order by start"))
+    if not rows:
+        return
+    t_lo = rows[0][1] + (1.0 - tail_frac) * (rows[-1][2] - rows[0][1])
+    rows = [r for r in rows if r[1] >= t_lo]
+    dom = lambda n: "k_rows" in n or "k_mvn_aligned" in n
+    gaps_all = sorted(max(0, s1 - e0) / 1e3 for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]) if dom(n1) and dom(n0))
+    if not gaps_all:
+        return
+    q = lambda f: gaps_all[min(len(gaps_all) - 1, int(f * len(gaps_all)))]
+    print(f"\n# idle gap between two consecutive dominant launches (us, {len(gaps_all)} gaps): min {gaps_all[0]:.2f}  p10 {q(0.1):.2f}  p50 {q(0.5):.2f}  "
+          f"p90 {q(0.9):.2f}  p99 {q(0.99):.2f}  max {gaps_all[-1]:.2f}  mean {sum(gaps_all)/len(gaps_all):.2f}")
+    starts = [i for i, r in enumerate(rows) if r[0].startswith("k_draw_start")]
+    draws = []
+    for a, b in zip(starts, starts[1:]):
+        seg = rows[a:b]
+        g = [max(0, seg[i][1] - seg[i - 1][2]) / 1e3 for i in range(1, len(seg)) if dom(seg[i][0])]
+        draws.append(g)
+    if not draws:
+        return
+    from collections import Counter
+    L = Counter(len(d) for d in draws).most_common(1)[0][0]
+    sel = [d for d in draws if len(d) == L]
+    pos = []
+    d = 0
+    while len(pos) < L:
+        for j in range(1 << d):
+            pos.append((d, j))
+        d += 1
+    first, inner = [], []
+    for p in range(L):
+        col = sorted(x[p] for x in sel)
+        (first if pos[p][1] == 0 else inner).append((sum(col) / len(col), col[len(col) // 2]))
+    fm = lambda v, k: sum(x[k] for x in v) / max(len(v), 1)
+    print(f"# by position ({len(sel)} draws of {L} launches): first leaf of a doubling mean {fm(first, 0):.2f} median {fm(first, 1):.2f} us (n={len(first)});  "
+          f"inner leaves mean {fm(inner, 0):.2f} median {fm(inner, 1):.2f} us (n={len(inner)})")
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     if args[0] == "--traffic":   # --traffic <fetch.db> <write.db> <out.json> <kernel substring> <tag> <source hash> [json key] [note]
@@ -169,6 +211,7 @@ if __name__ == "__main__":
     gap_stats(args[0])
     draw_timeline(args[0])
     launch_positions(args[0])
+    gap_positions(args[0])
     rest = args[1:]
     for a in rest:
         if a != "--pmc":
