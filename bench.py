@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"], help="c2 = hier-logit-10k (the headline), c3 = MvNormal 2048")
     ap.add_argument("--rows-per-group", type=int, default=4000, help="4000 = C2-L (HBM regime), 80 = C2-S (cache resident)")
     ap.add_argument("--groups", type=int, default=1248)
+    ap.add_argument("--variant", default=None, help="NOT the headline: the same rows under another model around them (pymc_amd.models.HIER_LOGIT_VARIANTS: "
+                    "other hyper-priors, further variables) -- A/B of the generalised one-launch row pass against the benchmark's own model")
     ap.add_argument("--mvn-k", type=int, default=2048)
     ap.add_argument("--seed", type=int, default=20160911)
     ap.add_argument("--cpu-leapfrogs", type=int, default=100, help="bounded CPU-baseline sample per leg (0 disables)")
@@ -359,7 +361,10 @@ def run_rank(args):
             spec = models.mvnormal(n=args.mvn_k)
             N = 0
         else:
-            spec = models.hier_logit(G=args.groups, D=8, rows_per_group=args.rows_per_group, seed=20160911)
+            if args.variant:
+                spec = models.hier_logit_variant(args.variant, G=args.groups, D=8, rows_per_group=args.rows_per_group, seed=20160911)
+            else:
+                spec = models.hier_logit(G=args.groups, D=8, rows_per_group=args.rows_per_group, seed=20160911)
             N = spec.logit_rows.X.shape[0]
         chains = world
         rngs = get_random_generator(args.seed).spawn(chains)  # mcmc.py:907-908
@@ -448,6 +453,9 @@ def run_rank(args):
                 "; cache-resident: 33.5 MB < 256 MiB Infinity Cache -- the HBM line does not bound it)"
         else:
             workload = f"C2-{'L' if args.rows_per_group >= 1000 else 'S'} hier-logit-10k: G={args.groups} D=8 rows={N} n={spec.n}"
+            if args.variant:
+                workload += (f" [VARIANT {args.variant}: not the headline model; {int(step._logp_dlogp_func.model_scalar('rows_aux_workgroups'))} "
+                             "auxiliary workgroup(s) per launch, csrc/rows_aux.h]")
             kernel = "hierarchical-logit row pass (k_rows_ga / k_rows_gb / k_rows)"
         schedule = ("persistent tree kernel: one launch per NUTS tree (csrc/rows_ga_tree.h)" if step._scalar("tree_kernel") else
                     f"group-block row pass: one launch per leapfrog, {int(step._logp_dlogp_func.model_scalar('rows_group_block'))} groups per workgroup, block "
@@ -495,7 +503,7 @@ def oracle_convergence(args):
     """What the CPU ORACLE's own four chains of the benchmarked shape look like (tests/golden/c2l_chains.npz, written by
     tests/golden/make_c2_fixtures.py from oracle/ref_sampler.py: a committed fixture, read as data -- nothing of oracle/ is
     imported): if the reference sampler shows the same R-hat on this model, a large R-hat of the device chain is the model."""
-    if args.workload != "c2" or args.groups != 1248:
+    if args.workload != "c2" or args.groups != 1248 or args.variant:
         return None
     f = os.path.join(ROOT, "tests", "golden", "c2l_chains.npz" if args.rows_per_group == 4000 else "c2s_chains.npz" if args.rows_per_group == 80 else "-")
     if not os.path.exists(f):

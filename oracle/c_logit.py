@@ -58,3 +58,48 @@ class CHierLogit:
         grad = np.empty(self.n)
         lp = self._fn(self.N, self.D, self.G, self.X.ctypes.data, self.y.ctypes.data, self.g.ctypes.data, q.ctypes.data, grad.ctypes.data)
         return lp, grad
+
+
+class CRowsSpecLogpGrad:
+    """``q -> (logp, grad)`` for ANY ModelSpec with a logit node: everything but the rows through the NumPy restatement
+    (`oracle/ref_models.py`: priors of any family, further variables, Jacobians), the rows through the gcc loop
+    `oracle_logit_rows` (the formulas of `ref_models._logit_rows`; pinned to it in tests/test_oracle_models.py).  What the
+    generalised one-launch row passes are compared with at the benchmark's size, where the NumPy rows take seconds per call."""
+
+    def __init__(self, spec, so_path=None):
+        from oracle import ref_models
+
+        self._ref = ref_models
+        lib = C.CDLL(so_path or _SO)
+        self._fn = lib.oracle_logit_rows
+        self._fn.restype = C.c_double
+        self._fn.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.spec = spec
+        self.n = spec.n
+        r = spec.logit_rows
+        self.X = np.ascontiguousarray(r.X, dtype="float64")
+        self.y = np.ascontiguousarray(r.y, dtype="int8")
+        self.g = np.ascontiguousarray(r.group_idx, dtype="int32")
+        self.calls = 0
+
+    def _rows(self, spec, node, x):
+        vm, vs, vz = (spec.vars[i] for i in (node.mu, node.sigma, node.z))
+        D = vm.size
+        mu, sg = x[vm.offset : vm.offset + D], x[vs.offset : vs.offset + D]
+        z = x[vz.offset : vz.offset + vz.size].reshape(-1, D)
+        G = z.shape[0]
+        beta = np.ascontiguousarray(mu + sg * z)
+        dbeta = np.empty((G, D))
+        lp = self._fn(self.X.shape[0], D, G, self.X.ctypes.data, self.y.ctypes.data, self.g.ctypes.data, beta.ctypes.data, dbeta.ctypes.data)
+        g = np.zeros(spec.n)
+        g[vm.offset : vm.offset + D] = dbeta.sum(0)
+        g[vs.offset : vs.offset + D] = (dbeta * z).sum(0)
+        g[vz.offset : vz.offset + vz.size] = (dbeta * sg).ravel()
+        return float(lp), g
+
+    def set_extra_values(self, extra_vars):
+        self._ref.SpecLogpGrad.set_extra_values(self, extra_vars)
+
+    def __call__(self, q):
+        self.calls += 1
+        return self._ref.evaluate(self.spec, q, rows_fn=self._rows)

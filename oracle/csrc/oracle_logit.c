@@ -72,3 +72,28 @@ double oracle_hier_logit(int64_t N, int D, int G, const double* X, const int8_t*
   }
   return lp_mu + (lp_sg + lj) + lp_z + lp_y;
 }
+
+/* The likelihood rows alone, for models that keep the logit node but change everything around it (other hyper-priors, further
+ * variables: oracle/c_logit.py CRowsSpecLogpGrad evaluates those through the NumPy restatement, oracle/ref_models.py):
+ *   beta [G][D] in, returns sum_i log Bernoulli(y_i | logit_p = x_i . beta_g(i)) and dbeta [G][D] = d / d beta_g.
+ * Same formulas and the same loop as oracle_hier_logit above (discrete.py:351-352,362-374 in the stabilised softplus form). */
+double oracle_logit_rows(int64_t N, int D, int G, const double* X, const int8_t* y, const int32_t* gid, const double* beta, double* dbeta) {
+  double lp_y = 0.0, db[64];
+  memset(dbeta, 0, sizeof(double) * (size_t)G * D);
+  int64_t i = 0;
+  while (i < N) {
+    const int g = gid[i];
+    const double* b = beta + (int64_t)g * D;
+    for (int d = 0; d < D; ++d) db[d] = 0.0;
+    for (; i < N && gid[i] == g; ++i) {
+      const double* x = X + i * D;
+      double eta = 0.0;
+      for (int d = 0; d < D; ++d) eta += x[d] * b[d];
+      lp_y += y[i] ? -softplus(-eta) : -softplus(eta);
+      const double r = (double)y[i] - expit(eta);
+      for (int d = 0; d < D; ++d) db[d] += r * x[d];
+    }
+    for (int d = 0; d < D; ++d) dbeta[(int64_t)g * D + d] += db[d];
+  }
+  return lp_y;
+}

@@ -389,8 +389,11 @@ def _push(op, spec, gx, g, adj=None):
         gx[v.offset : v.offset + v.size] += np.broadcast_to(g, (v.size,))
 
 
-def evaluate(spec, q):
+def evaluate(spec, q, rows_fn=None):
     """Joint logp and gradient w.r.t. the raveled unconstrained vector.
+
+    `rows_fn(spec, node, x) -> (logp, grad w.r.t. the constrained values)`: another evaluation of the logit node with the
+    contract of `_logit_rows` (oracle/c_logit.py passes the gcc loop: the same formulas, fast enough for the benchmark's shape).
 
     Assembly follows pymc/model/core.py:666-695: every factor is summed on its
     own, then the factor sums are added; Jacobian terms come from
@@ -437,7 +440,7 @@ def evaluate(spec, q):
                 if dy_ is not None:
                     _push(ins.y, spec, gx, adj[i] * dy_, adj)
         if spec.logit_rows is not None:
-            lp, g_extra = _logit_rows(spec, spec.logit_rows, x)
+            lp, g_extra = (rows_fn or _logit_rows)(spec, spec.logit_rows, x)
             logp += lp
             gx += g_extra
         if spec.mvnormal is not None:

@@ -182,7 +182,7 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
   if (md.has_logit && md.lg.ga) {
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
     const int par = (m->ga_par ^= 1);
-    const dim3 grid(m->rows_grid + (fold ? 1 : 0)), block(WAVE * md.lg.ga_w);
+    const dim3 grid(m->rows_grid + (fold ? 1 : 0) + md.lg.ga_naux), block(WAVE * md.lg.ga_w);   // [control] + groups / blocks + auxiliary
     GaArgs ga{md, A, io, j, rev, fold ? (GA_FOLD_CTL | GA_FOLD_SRC) : 0, par, d, max_depth, Emax, st, io, j - 1, d, 0, 0};
     if (fold && job) {   // the control work of another doubling's last leaf
       ga.fold = GA_FOLD_CTL | (job->src_prev ? GA_FOLD_SRC : 0);
@@ -209,6 +209,15 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
       case 4: GA_LAUNCH(4, OO, PP); break;   \
       default: GA_LAUNCH(2, OO, PP); break;  \
     }
+    if (md.lg.D != 8 && md.lg.D != 4 && md.lg.D != 2) {   // the other covariate counts: the default budget only
+      switch (md.lg.D) {
+        case 1: GA_LAUNCH(1, 4, 2); break;
+        case 3: GA_LAUNCH(3, 4, 2); break;
+        case 5: GA_LAUNCH(5, 4, 2); break;
+        case 6: GA_LAUNCH(6, 4, 2); break;
+        default: GA_LAUNCH(7, 4, 2); break;
+      }
+    } else
     switch (m->ga_variant) {   // (register budget, tiles in flight): see rows_ga_kernel.h
       case 32: GA_BY_D(3, 2) break;
       case 33: GA_BY_D(3, 3) break;
@@ -497,35 +506,48 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.deferred_g = m->keep(dev_upload(deferred.data(), deferred.size()));
   md.def_loc = m->keep(dev_alloc<double>(2 * 4 * (size_t)MAX_DEFERRED));
   hipMemset(md.def_loc, 0, 2 * 4 * (size_t)MAX_DEFERRED * sizeof(double));
-  // lean control path (kernels.h), no broadcast terms and either
-  // (a) the only deferred elements are the logit node's mu / sigma, or
+  // lean control path (kernels.h): no broadcast terms, and either
+  // (a) a logit node (and no MvNormal node): the deferred elements are its mu / sigma, whose gradient is the local part + a
+  //     cross-workgroup sum of the row pass, and possibly scalars with factors of their own, whose gradient IS the local part
+  //     (a scalar that broadcasts into a vector factor would be a broadcast term) -- one control thread each, or
   md.lean_ok = 0;
   // (b) no deferred element at all and an MvNormal node: the control work is sums and tree logic only
   if (md.n_bterms == 0 && env_int("NUTS_LEAN", 1)) {
     if (s->rows_N > 0 && s->mvn_k <= 0) {
-      md.lean_ok = 1;
-      for (int k = 0; k < nv; ++k) if (vars[k].deferred && k != s->rows_mu && k != s->rows_sigma) md.lean_ok = 0;
+      md.lean_ok = md.n_deferred <= GA_AUX_MAXDEF ? 1 : 0;
+      // NUTS_LEAN_STRICT=1: only the round-3 shape of the lean path (mu / sigma the only deferred elements) -- A/B and tests
+      if (env_int("NUTS_LEAN_STRICT", 0))
+        for (int k = 0; k < nv; ++k) if (vars[k].deferred && k != s->rows_mu && k != s->rows_sigma) md.lean_ok = 0;
       md.lg.def_mu = vars[s->rows_mu].def_base; md.lg.def_sigma = vars[s->rows_sigma].def_base;
     } else if (s->rows_N <= 0 && s->mvn_k > 0 && md.n_deferred == 0) {
       md.lean_ok = 1;
     }
   }
-  // group-aligned row pass (rows_ga_kernel.h): evaluates mu ~ Normal, sigma ~ HalfNormal (log-transformed or not), z ~ Normal with
-  // constant parameters in closed form and nothing else -- the model must be exactly that
+  // one-launch row passes (rows_ga_kernel.h, rows_gb_kernel.h): the row stream + the per-group finish of the z elements, which
+  // needs z ~ Normal with constant parameters as its only factor (closed form in the group's own workgroup).  Everything else:
+  //   ga_struct_ok = 1  exactly mu ~ Normal, sigma ~ HalfNormal (log-transformed or not) with constant parameters and nothing
+  //                     else: closed forms in workgroup 0's tail (ga_def_local), no auxiliary workgroup -- the benchmark's model;
+  //   ga_struct_ok = 2  any other hyper-prior, further variables and factors (no expression programs / gathers): auxiliary
+  //                     workgroups run the interpreter over every element that is not a z element (rows_aux.h).
+  // NUTS_GA_AUX=1 sends the closed-form model through the auxiliary workgroups too (tests: both routes, same model);
+  // NUTS_GA_AUX=0 keeps models that would need them off the one-launch passes (A/B against the general path).
   m->ga_struct_ok = 0;
-  if (md.lean_ok && s->rows_N > 0 && nv == 3 && orphans.empty()) {
+  if (md.lean_ok && s->rows_N > 0 && !m->has_prog) {
     const int km = s->rows_mu, ks = s->rows_sigma, kz = s->rows_z;
     auto only_prior = [&](int k, int dist) {
       return per_var[k].size() == 1 && per_var[k][0].fast == 2 && per_var[k][0].owner && per_var[k][0].arg == 0 && per_var[k][0].dist == dist;
     };
-    if (vars[kz].normal_prior && only_prior(km, NUTS_D_NORMAL) && only_prior(ks, NUTS_D_HALFNORMAL) && vars[km].transform == NUTS_TR_NONE &&
-        (vars[ks].transform == NUTS_TR_LOG || vars[ks].transform == NUTS_TR_NONE)) {
-      m->ga_struct_ok = 1;
+    if (vars[kz].normal_prior && vars[km].transform == NUTS_TR_NONE && (vars[ks].transform == NUTS_TR_LOG || vars[ks].transform == NUTS_TR_NONE)) {
       md.lg.z_np_mu = vars[kz].np_mu; md.lg.z_np_inv_var = vars[kz].np_inv_var; md.lg.z_np_lognorm = vars[kz].np_lognorm;
-      const Contrib& cm = per_var[km][0];
-      md.lg.mu_c[0] = cm.p[1]; md.lg.mu_c[1] = cm.p[2]; md.lg.mu_c[2] = cm.p[3];
-      const Contrib& cs = per_var[ks][0];
-      md.lg.sg_c[0] = cs.p[2]; md.lg.sg_c[1] = cs.p[3];
+      const bool closed = nv == 3 && orphans.empty() && only_prior(km, NUTS_D_NORMAL) && only_prior(ks, NUTS_D_HALFNORMAL);
+      const int aux_opt = env_int("NUTS_GA_AUX", -1);
+      if (closed && aux_opt != 1) {
+        m->ga_struct_ok = 1;
+        const Contrib& cm = per_var[km][0];
+        md.lg.mu_c[0] = cm.p[1]; md.lg.mu_c[1] = cm.p[2]; md.lg.mu_c[2] = cm.p[3];
+        const Contrib& cs = per_var[ks][0];
+        md.lg.sg_c[0] = cs.p[2]; md.lg.sg_c[1] = cs.p[3];
+      } else if (aux_opt != 0) m->ga_struct_ok = 2;
     }
   }
   // pack the interpreter's tables into one blob (copied into LDS by kernels B and C)
@@ -655,8 +677,11 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       if (env_int("NUTS_ROWS_GA_W", 0) > 0) W = std::max(1, std::min(GA_MAXW, env_int("NUTS_ROWS_GA_W", 0)));
       const double meanT = (double)n_tiles / std::max(lg.G, 1);
       bool use = false;
-      if (want >= 2) { use = m->ga_struct_ok && m->ept == 1 && d_pow2; W = std::max(1, W); }
-      else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && d_pow2 && W >= 1 && lg.G >= 2 * cus && meanT >= 4.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
+      // (every covariate count 1 .. 8 has an instantiation of the group-aligned pass; the register-budget variants 32 / 33 exist
+      // for D = 2, 4, 8 only)
+      if (!d_pow2) m->ga_variant = 42;
+      if (want >= 2) { use = m->ga_struct_ok && m->ept == 1; W = std::max(1, W); }
+      else if (want == 1) use = m->ga_struct_ok && m->ept == 1 && W >= 1 && lg.G >= 2 * cus && meanT >= 4.0 * W && (double)maxT <= 1.5 * meanT + 1.0;
       // group-BLOCK pass (rows_gb_kernel.h) for small groups: the same closed-form model, a workgroup owns GPW whole groups and
       // nothing crosses workgroups inside the launch.  NUTS_ROWS_GB=0 keeps such models on the general path (A/B, tests).
       int gpw = 0;
@@ -665,7 +690,10 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         gpw = GB_W * (int)((lg.G + GB_W * 512 - 1) / (GB_W * 512));   // a group per wave; more (in sequence) only to stay <= 512 workgroups
         gpw = std::min(gpw, GB_MAXGPW);
         if (env_int("NUTS_ROWS_GPW", 0) > 0) gpw = std::max(1, std::min(GB_MAXGPW, env_int("NUTS_ROWS_GPW", 0)));
-        if ((lg.G + gpw - 1) / gpw > WAVE * SLOT_SUM_MAXR) gpw = 0;   // (slot_sum: at most SLOT_SUM_MAXR records per lane)
+        // (slot_sum: at most SLOT_SUM_MAXR records per lane -- block partials + the records of the auxiliary workgroups)
+        const int aux_threads = WAVE * GB_W, auxel = n - lg.G * D;
+        const int naux = m->ga_struct_ok == 2 ? (auxel + aux_threads - 1) / aux_threads : 0;
+        if ((lg.G + gpw - 1) / gpw + naux > WAVE * SLOT_SUM_MAXR) gpw = 0;
       }
       if (gpw) { use = true; W = 1; }   // (layout: one chunk per group)
       if (use && n_tiles * (int64_t)SPAN < ((int64_t)1 << 31) && (gpw || lg.G <= 32 * 8 * GA_MAXCHUNK)) {
@@ -680,6 +708,10 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
           if (uni && maxT > 0) { lg.ga_T_uni = (int32_t)maxT; lg.ga_ng_uni = gptr[1] - gptr[0]; }
         }
         lg.ga_nblk = (lg.G + lg.ga_bsz - 1) / lg.ga_bsz;
+        // auxiliary workgroups (rows_aux.h): one thread per element that is not a z element
+        lg.ga_auxel = n - lg.G * D;
+        lg.ga_naux = m->ga_struct_ok == 2 ? (lg.ga_auxel + WAVE * lg.ga_w - 1) / (WAVE * lg.ga_w) : 0;
+        lg.ga_nrec = lg.ga_nblk + lg.ga_naux;
         // chunk (g, w) = the tiles wave w of workgroup g streams, [w T_g / W, (w + 1) T_g / W) -- the split the kernel makes.  Chunks
         // are placed one after the other with `GA_SKEW` doubles (8448 B = 33 x 256 B) between them, so consecutive chunk starts
         // differ by an ODD multiple of 256 B modulo any power-of-two channel interleave.
@@ -731,7 +763,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         lg.ga_tile0 = m->keep(dev_upload(tile0.data(), tile0.size()));
         lg.ga_part = m->keep(dev_alloc<double>((size_t)lg.G * PART_STRIDE));
         // (group-block pass: slot-major, every slot padded to a multiple of 64 records -- the padding stays zero)
-        const size_t bpart_len = gpw ? 2 * (size_t)PART_STRIDE * ((lg.ga_nblk + WAVE - 1) / WAVE * WAVE) : 2 * (size_t)lg.ga_nblk * PART_STRIDE;
+        const size_t bpart_len = gpw ? 2 * (size_t)PART_STRIDE * ((lg.ga_nrec + WAVE - 1) / WAVE * WAVE) : 2 * (size_t)lg.ga_nrec * PART_STRIDE;
         lg.ga_bpart = m->keep(dev_alloc<double>(bpart_len));
         lg.ga_ticket = m->keep(dev_alloc<unsigned>(lg.ga_nblk));
         if (lg.ga_part) hipMemset(lg.ga_part, 0, (size_t)lg.G * PART_STRIDE * sizeof(double));
@@ -750,7 +782,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         // optimistic (MI355X guide, "Residency and cooperative launch"), which is why every wait in the kernel is bounded.
         m->ga_tree_ok = 0;
         // (only at the 168-register budget, variant 32: at 128 registers the allocator spills inside the streaming loop)
-        if (D == 8 && m->ga_variant == 32 && !gpw && env_int("NUTS_GA_TREE", 1) != 0) {
+        if (D == 8 && m->ga_variant == 32 && !gpw && lg.ga_naux == 0 && env_int("NUTS_GA_TREE", 1) != 0) {
           int per_cu = 0;
           const hipError_t e = lg.ga_dx == 7 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3, 7>, WAVE * W, 0)
                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tree_ga<3, 8>, WAVE * W, 0);
@@ -983,6 +1015,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   const std::string k(name);
   if (k == "rows_group_aligned") *out = m->md.lg.ga;
   else if (k == "rows_group_block") *out = m->md.lg.ga_gpw;
+  else if (k == "rows_aux_workgroups") *out = m->md.lg.ga ? m->md.lg.ga_naux : 0;
   else if (k == "mixture_workgroups") *out = m->md.has_mix ? m->md.mix.nwg : 0;
   else if (k == "mvn_row_aligned") *out = m->md.has_mvn ? m->md.mv.aligned : 0;
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;

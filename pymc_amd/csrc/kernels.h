@@ -1080,7 +1080,10 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   bool act[1] = {false};
   double grad[1] = {0.0}, ph[1] = {l23.y};
   if (mine) {
-    const double S = def_k == lg.var_mu ? s_sum[PART_DMU + (def_i - lg.off_mu)] : s_sum[PART_DSG + (def_i - lg.off_sigma)];
+    // (a deferred element that is neither mu nor sigma of the logit node -- a scalar with factors of its own -- has no share in the
+    // cross-workgroup sums: its gradient is its local part)
+    const double S = !md.has_logit ? 0.0 : (def_k == lg.var_mu ? s_sum[PART_DMU + (def_i - lg.off_mu)]
+                                           : (def_k == lg.var_sigma ? s_sum[PART_DSG + (def_i - lg.off_sigma)] : 0.0));
     grad[0] = deferred_finish(l01.x, S, l01.y, l23.x);
     act[0] = true;
     if (leaf) A.G[lf.d_o + def_i] = grad[0];
@@ -1132,10 +1135,11 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
 // `par`: launch parity of the leaf's row pass (group-aligned row pass only; its partials are double-buffered)
 __device__ __forceinline__ LeanSrc lean_src(const ModelDev& md, int par) {
   if (md.lg.ga && md.lg.ga_gpw) {   // group-block pass: slot-major block partials, [2][PART_STRIDE][npad]
-    const int npad = (md.lg.ga_nblk + WAVE - 1) / WAVE * WAVE;
-    return LeanSrc{md.lg.ga_bpart + (int64_t)par * PART_STRIDE * npad, 1, md.lg.ga_nblk, md.def_loc + (int64_t)par * 4 * MAX_DEFERRED, npad};
+    const int npad = (md.lg.ga_nrec + WAVE - 1) / WAVE * WAVE;
+    return LeanSrc{md.lg.ga_bpart + (int64_t)par * PART_STRIDE * npad, 1, md.lg.ga_nrec, md.def_loc + (int64_t)par * 4 * MAX_DEFERRED, npad};
   }
-  if (md.lg.ga) return LeanSrc{md.lg.ga_bpart + (int64_t)par * md.lg.ga_nblk * PART_STRIDE, PART_STRIDE, md.lg.ga_nblk, md.def_loc + (int64_t)par * 4 * MAX_DEFERRED};
+  // (ga_nrec = the block partials + the records of the auxiliary workgroups, rows_aux.h; equal to ga_nblk for the closed-form model)
+  if (md.lg.ga) return LeanSrc{md.lg.ga_bpart + (int64_t)par * md.lg.ga_nrec * PART_STRIDE, PART_STRIDE, md.lg.ga_nrec, md.def_loc + (int64_t)par * 4 * MAX_DEFERRED};
   return LeanSrc{md.part, md.part_stride, md.nblk, md.def_loc};
 }
 

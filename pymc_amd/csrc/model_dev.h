@@ -100,7 +100,12 @@ struct RowsDev {  // hierarchical Bernoulli-logit node (rows sorted by group); s
   int64_t ga_cstride_uni;        // uniform geometry: ga_coff[c] = c * ga_cstride_uni (no table look-up)
   unsigned* ga_ticket;           // [ga_nblk] arrivals of the block's groups in the current launch (self-resetting)
   double* ga_part;               // [G][PART_STRIDE] per-group partial record (written write-through, read by the block's last arriver)
-  double* ga_bpart;              // [2][ga_nblk][PART_STRIDE] block partials, double-buffered by launch parity
+  double* ga_bpart;              // [2][ga_nrec][PART_STRIDE] block partials (+ the records of the auxiliary workgroups), double-buffered by launch parity
+  // Auxiliary workgroups (rows_aux.h): when the model is more than the closed forms below -- other hyper-prior families, further
+  // scalar or vector variables with their own factors -- ga_naux extra workgroups of the same launch run the element-wise
+  // interpreter over every element that is not a z element (ga_auxel of them) and leave one record each behind the ga_nblk block
+  // partials: ga_nrec = ga_nblk + ga_naux records per launch.  ga_naux == 0: the closed forms (the benchmark's model).
+  int32_t ga_naux, ga_nrec, ga_auxel, ga_pad2;
   // closed forms of what the interpreter would evaluate for this model (checked by the spec compiler):
   double z_np_mu, z_np_inv_var, z_np_lognorm;   // z ~ Normal(mu0, s0) untransformed
   double mu_c[3];                               // mu ~ Normal(p1, .): {p1, 1/sigma, log sigma}
@@ -249,6 +254,24 @@ struct Prog {
   int32_t* fdead;
 };
 
+__device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) {
+  Prog pg;
+  pg.vars = reinterpret_cast<const VarDev*>(base + md.po_vars);
+  pg.var_cptr = reinterpret_cast<const int32_t*>(base + md.po_cptr);
+  pg.contrib = reinterpret_cast<const Contrib*>(base + md.po_contrib);
+  pg.factors = reinterpret_cast<const nuts_factor*>(base + md.po_factors);
+  pg.fbt = reinterpret_cast<const FactorBT*>(base + md.po_fbt);
+  pg.bterm_var = reinterpret_cast<const int32_t*>(base + md.po_btvar);
+  pg.data = reinterpret_cast<const nuts_data_ref*>(base + md.po_data);
+  pg.deferred = reinterpret_cast<const int32_t*>(base + md.po_deferred);
+  pg.instrs = reinterpret_cast<const nuts_instr*>(base + md.po_instrs);
+  pg.csr = md.csr;
+  pg.pool = md.pool;
+  pg.n_vars = md.n_vars;
+  pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
+  return pg;
+}
+
 // Cooperative copy of the program blob into LDS (all threads of a 256-thread workgroup; ends with a barrier).
 // Split in two so that the global loads are in flight together with the caller's own first loads.
 struct ProgRegs { uint4 r[PROG_LDS_MAX / 16 / 256]; };
@@ -270,21 +293,7 @@ __device__ __forceinline__ Prog load_prog(const ModelDev& md, char* s_prog, cons
     __syncthreads();
     base = s_prog;
   }
-  Prog pg;
-  pg.vars = reinterpret_cast<const VarDev*>(base + md.po_vars);
-  pg.var_cptr = reinterpret_cast<const int32_t*>(base + md.po_cptr);
-  pg.contrib = reinterpret_cast<const Contrib*>(base + md.po_contrib);
-  pg.factors = reinterpret_cast<const nuts_factor*>(base + md.po_factors);
-  pg.fbt = reinterpret_cast<const FactorBT*>(base + md.po_fbt);
-  pg.bterm_var = reinterpret_cast<const int32_t*>(base + md.po_btvar);
-  pg.data = reinterpret_cast<const nuts_data_ref*>(base + md.po_data);
-  pg.deferred = reinterpret_cast<const int32_t*>(base + md.po_deferred);
-  pg.instrs = reinterpret_cast<const nuts_instr*>(base + md.po_instrs);
-  pg.csr = md.csr;
-  pg.pool = md.pool;
-  pg.n_vars = md.n_vars;
-  pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
-  return pg;
+  return prog_view(md, base);
 }
 
 // How a kernel obtains the position vector it evaluates the model at.  In "composed" mode the
@@ -297,6 +306,11 @@ struct QView {
   const double* var;
   double eps, half;
   int composed;
+  // Auxiliary workgroups of the one-launch row passes (rows_aux.h) only: q' of the model's DEFERRED elements, by position in the
+  // deferred list.  Those workgroups run next to the control work of the previous leaf, which is still writing the source state's
+  // gradient and momentum of exactly these elements, so they compose them from the previous launch's records themselves and the
+  // interpreter reads them here instead of through the arena.  nullptr everywhere else (folded away at compile time).
+  const double* defq = nullptr;
   __device__ __forceinline__ double p_half(int64_t i) const { return fma(half, g[i], p[i]); }
   __device__ __forceinline__ double at(int64_t i) const {
     if (!composed) return q[i];
@@ -346,6 +360,9 @@ __device__ __forceinline__ int find_var(const Prog& pg, int i) {
 
 // `own_var` / `own_x`: the calling thread's own element (same local index li) -- its constrained value is
 // already in a register, everything else is recomposed through the view.
+// DEFQ: the caller is an auxiliary workgroup of a one-launch row pass (rows_aux.h) and qv.defq holds q' of the deferred elements
+// (a template parameter, not a run-time test of the pointer: the test alone cost k_small_draw 16 registers and 1.3 KB of scratch)
+template <bool DEFQ = false>
 __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const Prog& pg, const QView& qv, int own_var,
                                            double own_x) {
   if (o.kind == NUTS_OP_CONST) return o.c;
@@ -360,6 +377,7 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
   }
   if (o.ref == own_var) return own_x;
   const VarDev v = pg.vars[o.ref];
+  if constexpr (DEFQ) { if (v.deferred) return transform_x(v, qv.defq[v.def_base + (v.size > 1 ? li : 0)]); }
   return transform_x(v, qv.at(v.offset + (v.size > 1 ? li : 0)));
 }
 
@@ -568,6 +586,7 @@ __device__ __forceinline__ double dist_eval(int dist, double konst, const double
 
 // Evaluate element `li` of factor `f`: returns its logp, fills d[k] (partials w.r.t. argument k)
 // and the b / c operand values of every argument (needed for the chain rule through a + b*c).
+template <bool DEFQ = false>
 __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var,
                                               double own_x, double* d, double* bv, double* cv, int* pdead) {
   double a[4];
@@ -575,9 +594,9 @@ __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, c
   for (int k = 0; k < 4; ++k) {
     if (k < f.nargs) {
       const nuts_term& t = f.arg[k];
-      const double av = op_value(t.a, li, pg, qv, own_var, own_x);
-      bv[k] = op_value(t.b, li, pg, qv, own_var, own_x);
-      cv[k] = op_value(t.c, li, pg, qv, own_var, own_x);
+      const double av = op_value<DEFQ>(t.a, li, pg, qv, own_var, own_x);
+      bv[k] = op_value<DEFQ>(t.b, li, pg, qv, own_var, own_x);
+      cv[k] = op_value<DEFQ>(t.c, li, pg, qv, own_var, own_x);
       a[k] = av + bv[k] * cv[k];
     } else {
       a[k] = 0.0; bv[k] = cv[k] = 0.0;
@@ -667,7 +686,7 @@ __device__ __forceinline__ double slot_grad(const double* d, const double* bv, c
 // PROG = false: the model carries neither an expression program nor a gathered operand (the host picks the instantiation,
 // nuts_model::has_prog) -- the call into the out-of-line interpreter and everything it keeps alive across the call are compiled
 // out: with it k_small_draw<1024> spilled 357 registers and ran 59 us per leapfrog at n = 1002 instead of 24.
-template <bool PROG = true>
+template <bool PROG = true, bool DEFQ = false>
 __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, int k, int li, double x, double& gx, double& lp,
                                                double* s_bacc, int bstride) {
   for (int c = pg.var_cptr[k]; c < pg.var_cptr[k + 1]; ++c) {
@@ -729,7 +748,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
     }
     double d[4], bv[4], cv[4];
     int pdead = 0;
-    double lpf = factor_eval(pg, qv, f, li, k, x, d, bv, cv, &pdead);
+    double lpf = factor_eval<DEFQ>(pg, qv, f, li, k, x, d, bv, cv, &pdead);
     factor_kill(pg, cb.f, pdead, lpf, d);
     gx += slot_grad(d, bv, cv, cb.arg, cb.slot);
     if (cb.owner) {
@@ -742,7 +761,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
 
 // One element of a factor WITHOUT an owning variable (only scalars and data): its logp and the broadcast terms of its scalars.
 // Shared by the orphan loops of kernel B (kernels.h) and of the single-workgroup kernel (small_kernel.h).
-template <bool PROG = true>
+template <bool PROG = true, bool DEFQ = false>
 __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv, int fi, int li, double* s_bacc, int bstride) {
   const nuts_factor& f = pg.factors[fi];
   const FactorBT& bt = pg.fbt[fi];
@@ -760,7 +779,7 @@ __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv
   }
   double dv[4], bv[4], cv[4];
   int pdead = 0;
-  double lpo = factor_eval(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
+  double lpo = factor_eval<DEFQ>(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
   factor_kill(pg, fi, pdead, lpo, dv);
   for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm * bstride] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
   return lpo;

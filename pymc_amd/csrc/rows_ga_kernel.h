@@ -200,6 +200,23 @@ struct GaArgs {
 };
 #define GA_FOLD_CTL 1
 #define GA_FOLD_SRC 2
+#include "rows_aux.h"
+
+// mu', sigma' of this leaf: lane l gets q' (`hval0`) and p_half (`hph0`) of hyper-parameter element l mod 2D.  GA_FOLD_SRC: the source
+// state is the leaf of the previous launch, whose mu / sigma gradient is finished here from that launch's records.
+template <int D>
+__device__ __forceinline__ void ga_hyper(const ModelDev& md, const QView& qv, int fold, int par, int lane, double& hval0, double& hph0) {
+  const RowsDev& R = md.lg;
+  if (fold & GA_FOLD_SRC) {
+    const LeanSrc prev = lean_src(md, par ^ 1);
+    rows_hyper_fold_elem<D>(R, prev.part, prev.stride, prev.nblk, prev.def_loc, qv, lane, hval0, hph0);
+  } else {
+    const int e = lane % (2 * D);
+    const int i = e < D ? R.off_mu + e : R.off_sigma + (e - D);
+    if (qv.composed) { hph0 = qv.p_half(i); hval0 = fma(qv.eps, qv.var[i] * hph0, qv.q[i]); }
+    else { hph0 = 0.0; hval0 = qv.q[i]; }
+  }
+}
 
 // DX: stored columns of X per tile (D, or D - 1 = 7 when column 0 is identically 1; only with D = 8)
 template <int D, int RPL, int OCC, int PIPE, int DX = D>
@@ -234,6 +251,19 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   __shared__ int s_info[4];                      // {this workgroup is its block's last arriver, m, last}
   __shared__ double s_keep[5][WAVE];             // wave 0's per-lane prologue values the tail needs again (kept out of the stream's registers)
   __shared__ __attribute__((aligned(16))) char s_args[(sizeof(GaArgs) + 15) / 16 * 16];
+  // workgroups behind the G groups: the auxiliary workgroups (rows_aux.h).  They take mu', sigma' of this leaf from the same
+  // prologue arithmetic as everybody else and leave BEFORE any tile is requested: the call below may save registers around it,
+  // and a register with a hand-counted load in flight must never be stored (tests/test_abi.py guards that).
+  if (b >= R.G) {
+    static_assert(GA_AUX_SCRATCH_DOUBLES(GA_MAXW) <= GA_MAXCHUNK * PART_STRIDE, "auxiliary scratch does not fit the chunk buffer");
+    double hv, hp;
+    ga_hyper<D>(md, qv, fold, par, lane, hv, hp);
+    const int aux_id = b - R.G;
+    // (LDS lent from the block reduce's chunk buffer, which only a block's last arriver uses)
+    ga_aux<OCC>((const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr(), aux_id, hv, hp, &s_cp[0][0], GA_MAXW,
+                R.ga_bpart + ((int64_t)par * R.ga_nrec + R.ga_nblk + aux_id) * PART_STRIDE, 1);
+    return;
+  }
 
   // ---- geometry of this wave's stream (no memory access when every group has the same number of rows) ----
   int T; int64_t ng, cbase;
@@ -282,15 +312,7 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
 
   // ---- prologue: mu', sigma' of this leaf (every wave), z' of this group ----
   double hval0, hph0;   // lane l: q' and p_half of hyper-parameter element l mod 2D
-  if (fold & GA_FOLD_SRC) {
-    const LeanSrc prev = lean_src(md, par ^ 1);
-    rows_hyper_fold_elem<D>(R, prev.part, prev.stride, prev.nblk, prev.def_loc, qv, lane, hval0, hph0);
-  } else {
-    const int e = lane % (2 * D);
-    const int i = e < D ? R.off_mu + e : R.off_sigma + (e - D);
-    if (qv.composed) { hph0 = qv.p_half(i); hval0 = fma(qv.eps, qv.var[i] * hph0, qv.q[i]); }
-    else { hph0 = 0.0; hval0 = qv.q[i]; }
-  }
+  ga_hyper<D>(md, qv, fold, par, lane, hval0, hph0);
   const int dl = lane % D;
   const int iz = R.off_z + g * D + dl;
   double beta[D];
@@ -446,8 +468,8 @@ __device__ __forceinline__ void ga_tail(const GaArgs& T, int g, double (&s_acc)[
         else io.grad[iz] = grad[0];
       }
     }
-    // the hyper-parameter elements' local parts + their q' (one workgroup does it for the launch)
-    if (g == 0) {
+    // the hyper-parameter elements' local parts + their q' (one workgroup does it for the launch; with auxiliary workgroups, they do)
+    if (g == 0 && R.ga_naux == 0) {
       const int e = lane;
       const bool hact = e < 2 * D, is_mu = e < D;
       double gx, dxdq, dj, lpd;
@@ -519,7 +541,7 @@ __device__ __forceinline__ void ga_tail(const GaArgs& T, int g, double (&s_acc)[
       s_cp[c][k] = sum;
     }
     __syncthreads();
-    double* bp = R.ga_bpart + ((int64_t)par * R.ga_nblk + blk) * PART_STRIDE;
+    double* bp = R.ga_bpart + ((int64_t)par * R.ga_nrec + blk) * PART_STRIDE;
     for (int q = tid; q < nn; q += NT) {
       const int k = need_slot(q);
       double sum = 0.0;

@@ -255,7 +255,7 @@ __device__ __forceinline__ void ga_tree_block_reduce(const GaTreeArgs& T, int g,
     s_cp[c][k] = sum;
   }
   __syncthreads();
-  double* bp = R.ga_bpart + ((int64_t)par * R.ga_nblk + blk) * PART_STRIDE;
+  double* bp = R.ga_bpart + ((int64_t)par * R.ga_nrec + blk) * PART_STRIDE;
   for (int q = tid; q < nn; q += NT) {
     const int k = need_slot(q);
     double sum = 0.0;

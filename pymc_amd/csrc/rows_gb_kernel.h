@@ -160,6 +160,14 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
   const double sraw = __shfl(hval0, D + dl);
   const double s_lane = R.sigma_tr == NUTS_TR_LOG ? exp(sraw) : sraw;
   if (aborted) return;
+  if (b >= R.ga_nblk) {   // auxiliary workgroup (rows_aux.h): everything of the model that is not a z element
+    static_assert(GA_AUX_SCRATCH_DOUBLES(GB_W) <= GB_MAXGPW * PART_STRIDE, "auxiliary scratch does not fit the record buffer");
+    const int aux_id = b - R.ga_nblk;
+    const int npad = (R.ga_nrec + WAVE - 1) / WAVE * WAVE;
+    ga_aux<0>((const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr(), aux_id, hval0, hph0, &s_rec[0][0], GB_W,
+           R.ga_bpart + (int64_t)par * PART_STRIDE * npad + (R.ga_nblk + aux_id), npad);
+    return;
+  }
   if (GB_XF(GB_F_PROLOGUE)) { if (m_lane + s_lane == 12345.678) A.Q[lf.d_o] = 0.0; return; }
   int m = 0; bool last = false;
   TICK(md, tk, 1);
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
         else io.grad[iz] = grad[0];
       }
     }
-    if (g == 0) {   // the hyper-parameter elements' local parts + their q' (one wave does it for the launch)
+    if (g == 0 && R.ga_naux == 0) {   // the hyper-parameter elements' local parts + their q' (one wave does it for the launch; with auxiliary workgroups, they do)
       const int e = lane;
       const bool hact = e < 2 * D, is_mu = e < D;
       double gx, dxdq, dj, lpd;
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
     const int mm = (leaf && tree) ? s_ml[0] : 0;
     const bool ll = (leaf && tree) ? s_ml[1] != 0 : false;
     const int nn = 1 + 2 * D + (leaf ? 1 + 6 * mm + (ll ? 6 : 0) : 0);
-    const int npad = (R.ga_nblk + WAVE - 1) / WAVE * WAVE;            // slot-major: bp[k * npad + b] (lean_src)
+    const int npad = (R.ga_nrec + WAVE - 1) / WAVE * WAVE;            // slot-major: bp[k * npad + b] (lean_src)
     double* bp = R.ga_bpart + (int64_t)par * PART_STRIDE * npad + b;
     for (int q = tid; q < nn; q += (int)blockDim.x) {
       int k;

@@ -73,14 +73,9 @@ def eight_schools(J: int = 8, seed: int = DATA_SEED) -> ModelSpec:
     return m.build()
 
 
-def hier_logit(G: int = 1248, D: int = 8, rows_per_group: int = 80, seed: int = DATA_SEED) -> ModelSpec:
-    """Hierarchical logistic regression, n = 2 D + G D (C2; 10 000 at the defaults).
-
-    mu[D] ~ N(0,1); sigma[D] ~ HalfNormal(1) (log-transformed); z[G,D] ~ N(0,1);
-    beta_g = mu + sigma * z_g;  y_i ~ Bernoulli(logit_p = x_i . beta_{g(i)}),
-    x_i ~ N(0,1)^D with x_{i,0} = 1, rows sorted by group.
-    C2-S: rows_per_group=80 (N = 99 840); C2-L: rows_per_group=4000 (N = 4 992 000).
-    """
+def _hier_logit_data(G: int, D: int, rows_per_group: int, seed: int):
+    """Synthetic rows of C2: x_i ~ N(0,1)^D with x_{i,0} = 1, rows sorted by group, ground truth mu* ~ N(0, 0.5),
+    sigma* = 0.5."""
     rng = np.random.default_rng(seed)
     N = G * rows_per_group
     mu_true = rng.normal(0, 0.5, size=D)
@@ -97,10 +92,83 @@ def hier_logit(G: int = 1248, D: int = 8, rows_per_group: int = 80, seed: int = 
         X[s:e] = xb
         eta = np.einsum("nd,nd->n", xb, beta[gidx[s:e]])
         y[s:e] = (rng.random(e - s) < 1.0 / (1.0 + np.exp(-eta))).astype("int8")
+    return X, y, gidx
+
+
+def hier_logit(G: int = 1248, D: int = 8, rows_per_group: int = 80, seed: int = DATA_SEED) -> ModelSpec:
+    """Hierarchical logistic regression, n = 2 D + G D (C2; 10 000 at the defaults).
+
+    mu[D] ~ N(0,1); sigma[D] ~ HalfNormal(1) (log-transformed); z[G,D] ~ N(0,1);
+    beta_g = mu + sigma * z_g;  y_i ~ Bernoulli(logit_p = x_i . beta_{g(i)}),
+    x_i ~ N(0,1)^D with x_{i,0} = 1, rows sorted by group.
+    C2-S: rows_per_group=80 (N = 99 840); C2-L: rows_per_group=4000 (N = 4 992 000).
+    """
+    X, y, gidx = _hier_logit_data(G, D, rows_per_group, seed)
     m = ModelBuilder()
     mu = m.Normal("mu", 0.0, 1.0, shape=D)
     sigma = m.HalfNormal("sigma", 1.0, shape=D)
     z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    m.HierLogitRows("y", X, y, gidx, mu, sigma, z)
+    return m.build()
+
+
+HIER_LOGIT_VARIANTS = ("halfcauchy", "exponential", "lognormal", "gamma", "zscale", "datapriors", "extra")
+
+
+def hier_logit_variant(kind: str, G: int = 1248, D: int = 8, rows_per_group: int = 80, seed: int = DATA_SEED, data=None) -> ModelSpec:
+    """The same rows as `hier_logit` under the other ways a PyMC user writes the model around them -- what the reference
+    differentiates as readily as the benchmark's own priors (model/core.py:612-695: any sum of factors):
+
+      halfcauchy   sigma ~ HalfCauchy(1)                            (continuous.py:2383-2390; Gelman's default scale prior)
+      exponential  mu ~ StudentT(4, 0, 2.5), sigma ~ Exponential(2) (continuous.py:1935-1950, 1478-1486)
+      lognormal    mu ~ Cauchy(0, 2.5), sigma ~ LogNormal(-1, 0.5)  (continuous.py:2287-2293, 1807-1819)
+      gamma        mu ~ Laplace(0, 1), sigma ~ Gamma(2, 4)          (continuous.py:1570-1576, 2512-2521)
+      zscale       z ~ Normal(0.1, 2), sigma ~ HalfNormal(0.5), mu ~ Normal(0.3, 2): constants other than the standard ones
+      datapriors   mu_d ~ Normal(m_d, s_d), sigma_d ~ HalfNormal(t_d) with per-coordinate parameter VECTORS
+      extra        further variables: tau ~ HalfCauchy(1), alpha ~ Normal(0, tau) (two scalars, one factor between them),
+                   theta[K] ~ Normal(0.2, 1.5) with y2 ~ Normal(theta, 0.7) observed (a vector variable with its own likelihood),
+                   nu ~ Exponential(1), and sigma ~ HalfCauchy(1)
+    `data`: (X, y, gidx) to reuse across variants (the rows of C2-L take a minute to draw)."""
+    X, y, gidx = data if data is not None else _hier_logit_data(G, D, rows_per_group, seed)
+    m = ModelBuilder()
+    if kind == "halfcauchy":
+        mu = m.Normal("mu", 0.0, 1.0, shape=D)
+        sigma = m.HalfCauchy("sigma", 1.0, shape=D)
+        z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    elif kind == "exponential":
+        mu = m.StudentT("mu", 4.0, 0.0, 2.5, shape=D)
+        sigma = m.Exponential("sigma", 2.0, shape=D)
+        z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    elif kind == "lognormal":
+        mu = m.Cauchy("mu", 0.0, 2.5, shape=D)
+        sigma = m.LogNormal("sigma", -1.0, 0.5, shape=D)
+        z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    elif kind == "gamma":
+        mu = m.Laplace("mu", 0.0, 1.0, shape=D)
+        sigma = m.Gamma("sigma", 2.0, 4.0, shape=D)
+        z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    elif kind == "zscale":
+        mu = m.Normal("mu", 0.3, 2.0, shape=D)
+        sigma = m.HalfNormal("sigma", 0.5, shape=D)
+        z = m.Normal("z", 0.1, 2.0, shape=(G, D))
+    elif kind == "datapriors":
+        rng = np.random.default_rng(seed + 1)
+        mu = m.Normal("mu", rng.normal(0, 0.3, size=D), rng.uniform(0.5, 2.0, size=D), shape=D)
+        sigma = m.HalfNormal("sigma", rng.uniform(0.5, 1.5, size=D), shape=D)
+        z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    elif kind == "extra":
+        rng = np.random.default_rng(seed + 2)
+        K = 300
+        tau = m.HalfCauchy("tau", 1.0)
+        alpha = m.Normal("alpha", 0.0, tau)
+        mu = m.Normal("mu", 0.0, 1.0, shape=D)
+        theta = m.Normal("theta", 0.2, 1.5, shape=K)
+        sigma = m.HalfCauchy("sigma", 1.0, shape=D)
+        z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+        m.Exponential("nu", 1.0)
+        m.Normal("y2", theta, 0.7, observed=rng.normal(0.5, 1.0, size=K))
+    else:
+        raise ValueError(f"unknown variant {kind!r}: one of {HIER_LOGIT_VARIANTS}")
     m.HierLogitRows("y", X, y, gidx, mu, sigma, z)
     return m.build()
 

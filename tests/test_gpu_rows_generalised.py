@@ -1,0 +1,228 @@
+"""The one-launch row passes beyond the benchmark's exact model (VERDICT r03 "next round" 2).
+
+`k_rows_ga` / `k_rows_gb` (csrc/rows_ga_kernel.h, rows_gb_kernel.h) keep the row stream and the per-group finish of the z elements;
+everything else of the model -- hyper-priors of any family and parameterisation, further scalar / vector variables with factors of
+their own -- runs through the element-wise interpreter in auxiliary workgroups of the same launch (csrc/rows_aux.h), and every
+covariate count 1..8 has an instantiation.  What the reference differentiates without a second thought (model/core.py:612-695:
+any sum of factors; continuous.py:2383-2390 HalfCauchy, :1478-1486 Exponential, :1807-1819 LogNormal, :2512-2521 Gamma, ...).
+
+Oracle: `oracle/ref_models.py` (NumPy, every factor) on the small shapes; at the benchmark's size `oracle/c_logit.CRowsSpecLogpGrad`
+(the same NumPy restatement with the gcc loop for the 5 M rows) through the committed fixture
+`tests/golden/nuts_c2l_variants.npz` (`make_c2l_variant_fixtures.py`).  Tolerances: logp / gradient 1e-9 relative (north-star bar
+1e-6); identical seed => identical integer tree statistics.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_models, ref_sampler
+from pymc_amd import models
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
+SCHED_VARS = ("NUTS_ROWS_GA", "NUTS_ROWS_GB", "NUTS_GA_AUX", "NUTS_ROWS_GA_W", "NUTS_FOLD_CTL", "NUTS_LEAN_STRICT")
+
+
+def _vg(spec):
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    return DeviceValueGradFunction(spec, device=0)
+
+
+def _clear(monkeypatch):
+    for k in SCHED_VARS:
+        monkeypatch.delenv(k, raising=False)
+
+
+def _points(n, seed=3):
+    rng = np.random.default_rng(seed)
+    return [np.zeros(n)] + [rng.normal(size=n) * s for s in (0.3, 0.7)]
+
+
+def _check(spec, f_ref=None, rtol=1e-9, expect=None):
+    """logp / gradient of the device against the oracle at three points; `expect`: model scalars that must hold (which pass runs)."""
+    f = _vg(spec)
+    if expect:
+        for k, want in expect.items():
+            got = f.model_scalar(k)
+            assert (got > 0) == (want > 0) if isinstance(want, bool) else got == want, (k, got, want)
+    f_ref = f_ref or ref_models.SpecLogpGrad(spec)
+    for q in _points(spec.n):
+        lp, g = f._pytensor_function(q)
+        lp0, g0 = f_ref(q)
+        assert abs(lp - lp0) <= rtol * max(1.0, abs(lp0)), (lp, lp0)
+        assert np.max(np.abs(g - g0)) <= rtol * max(1.0, np.abs(g0).max()), np.max(np.abs(g - g0))
+    f.close()
+
+
+def _nuts_integers(spec, tune, draws, seed, f_ref=None):
+    from pymc_amd.sampling import sample
+
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
+    f_ref = f_ref or ref_models.SpecLogpGrad(spec)
+    ref_draws, ref_stats = ref_sampler.sample_reference(f_ref, [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    dev = res["warmup_stats"][0] + res["stats"][0]
+    for i in range(tune + draws):
+        for k in INT_KEYS:
+            assert int(dev[i][k]) == int(ref_stats[0][i][k]), (i, k, dev[i][k], ref_stats[0][i][k])
+    for i in range(min(6, tune + draws)):
+        for k in ("mean_tree_accept", "energy", "model_logp", "step_size"):
+            np.testing.assert_allclose(dev[i][k], ref_stats[0][i][k], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
+    res["step"].close()
+    return dev
+
+
+# the pass each shape selects: group-aligned forced on a small model (NUTS_ROWS_GA=2: the kernel of C2-L on ragged-size inputs),
+# group-block by default from 64 groups on, and the general lean path (k_rows + k_vector, folded control) below that
+SHAPES = {
+    "ga": dict(G=24, D=8, rows_per_group=300, env={"NUTS_ROWS_GA": "2"}, expect={"rows_group_aligned": 1.0, "rows_group_block": 0.0}),
+    "ga_w1": dict(G=12, D=8, rows_per_group=130, env={"NUTS_ROWS_GA": "2", "NUTS_ROWS_GA_W": "1"}, expect={"rows_group_aligned": 1.0}),
+    "gb": dict(G=80, D=8, rows_per_group=90, env={}, expect={"rows_group_aligned": 1.0, "rows_group_block": True}),
+    "general": dict(G=20, D=8, rows_per_group=60, env={}, expect={"rows_group_aligned": 0.0, "lean": 1.0}),
+}
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+@pytest.mark.parametrize("kind", models.HIER_LOGIT_VARIANTS)
+def test_variant_logp_grad_on_every_pass(kind, shape, monkeypatch):
+    """Every variant of the model around the rows, on each pass, against the NumPy oracle; the variants that are not the closed form
+    carry auxiliary workgroups on the one-launch passes (`zscale` only changes constants of the closed form: none)."""
+    _clear(monkeypatch)
+    sh = SHAPES[shape]
+    for k, v in sh["env"].items():
+        monkeypatch.setenv(k, v)
+    spec = models.hier_logit_variant(kind, G=sh["G"], D=sh["D"], rows_per_group=sh["rows_per_group"], seed=11)
+    expect = dict(sh["expect"])
+    if shape != "general":
+        expect["rows_aux_workgroups"] = kind != "zscale"
+    _check(spec, expect=expect)
+
+
+@pytest.mark.parametrize("shape", ["ga", "gb", "general"])
+@pytest.mark.parametrize("kind", ["halfcauchy", "lognormal", "datapriors", "extra"])
+def test_variant_nuts_integers_on_every_pass(kind, shape, monkeypatch):
+    """A NUTS run (tuning included: folded control, look-ahead across doublings, batched post-tuning draws) with the oracle
+    sampler's integers: the auxiliary workgroups feed the next launch's prologue and the control work exactly what the
+    interpreter of the general path feeds them."""
+    _clear(monkeypatch)
+    sh = SHAPES[shape]
+    for k, v in sh["env"].items():
+        monkeypatch.setenv(k, v)
+    spec = models.hier_logit_variant(kind, G=sh["G"], D=sh["D"], rows_per_group=sh["rows_per_group"], seed=5)
+    _nuts_integers(spec, tune=25, draws=10, seed=9)
+
+
+@pytest.mark.parametrize("D", [1, 3, 5, 6, 7])
+def test_group_aligned_pass_any_covariate_count(D, monkeypatch):
+    """The group-aligned pass with 1, 3, 5, 6, 7 covariates (it used to exist for 2, 4, 8): logp / gradient and a NUTS run, closed
+    form and with auxiliary workgroups."""
+    _clear(monkeypatch)
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    spec = models.hier_logit(G=18, D=D, rows_per_group=270, seed=D)
+    _check(spec, expect={"rows_group_aligned": 1.0, "rows_group_block": 0.0, "rows_aux_workgroups": 0.0})
+    _nuts_integers(spec, tune=15, draws=6, seed=4)
+    spec2 = models.hier_logit_variant("halfcauchy", G=18, D=D, rows_per_group=270, seed=D)
+    _check(spec2, expect={"rows_group_aligned": 1.0, "rows_aux_workgroups": True})
+    _nuts_integers(spec2, tune=15, draws=6, seed=4)
+
+
+@pytest.mark.parametrize("shape", ["ga", "gb"])
+def test_closed_form_and_auxiliary_route_agree(shape, monkeypatch):
+    """The benchmark's own model through the auxiliary workgroups (NUTS_GA_AUX=1) instead of the closed forms in workgroup 0's
+    tail: the same numbers to rounding (the hyper-parameters' logp joins the total in another place), the same NUTS integers."""
+    from pymc_amd.sampling import sample
+
+    _clear(monkeypatch)
+    sh = SHAPES[shape]
+    for k, v in sh["env"].items():
+        monkeypatch.setenv(k, v)
+    spec = models.hier_logit(G=sh["G"], D=8, rows_per_group=sh["rows_per_group"], seed=2)
+    runs = []
+    for aux in ("0", "1"):
+        monkeypatch.setenv("NUTS_GA_AUX", aux)
+        f = _vg(spec)
+        assert (f.model_scalar("rows_aux_workgroups") > 0) == (aux == "1")
+        vals = [f._pytensor_function(q) for q in _points(spec.n)]
+        f.close()
+        res = sample(draws=8, tune=20, chains=1, model=spec, init="adapt_diag", random_seed=3, device=0)
+        runs.append((vals, res["warmup_stats"][0] + res["stats"][0]))
+        res["step"].close()
+    for (lp0, g0), (lp1, g1) in zip(runs[0][0], runs[1][0]):
+        assert abs(lp0 - lp1) <= 1e-12 * abs(lp0)
+        assert np.max(np.abs(g0 - g1)) <= 1e-12 * np.abs(g0).max()
+    for a, b in zip(runs[0][1], runs[1][1]):
+        for k in INT_KEYS:
+            assert int(a[k]) == int(b[k])
+
+
+def test_lean_path_with_further_scalars_matches_the_three_kernel_path(monkeypatch):
+    """The lean control path now also takes models whose deferred elements are more than mu / sigma (scalars with factors of
+    their own): the same model with NUTS_LEAN_STRICT=1 (round-3 behaviour: three launches per leapfrog) gives the same integers."""
+    from pymc_amd.sampling import sample
+
+    _clear(monkeypatch)
+    spec = models.hier_logit_variant("extra", G=20, D=8, rows_per_group=60, seed=8)
+    out = []
+    for strict in ("0", "1"):
+        monkeypatch.setenv("NUTS_LEAN_STRICT", strict)
+        f = _vg(spec)
+        assert f.model_scalar("lean") == (0.0 if strict == "1" else 1.0)
+        f.close()
+        res = sample(draws=8, tune=20, chains=1, model=spec, init="adapt_diag", random_seed=6, device=0)
+        out.append(res["warmup_stats"][0] + res["stats"][0])
+        res["step"].close()
+    for a, b in zip(*out):
+        for k in INT_KEYS:
+            assert int(a[k]) == int(b[k])
+
+
+# ---- at the benchmark's own size -----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2l_rows():
+    return models._hier_logit_data(1248, 8, 4000, models.DATA_SEED)
+
+
+@pytest.mark.parametrize("kind", ["halfcauchy", "exponential", "lognormal", "extra"])
+def test_c2l_variants_match_the_committed_oracle_run(kind, c2l_rows, monkeypatch):
+    """C2-L (4 992 000 rows, the shape `bench.py` times) with other hyper-priors / further variables: the default schedule must be the
+    group-aligned pass with auxiliary workgroups; logp / gradient 1e-9 against the oracle's values at two points and the first
+    transitions of a chain with the oracle's integers (committed fixture)."""
+    from pymc_amd.sampling import sample
+
+    _clear(monkeypatch)
+    path = os.path.join(GOLDEN, "nuts_c2l_variants.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/nuts_c2l_variants.npz not generated")
+    gold = np.load(path)
+    G, D, rpg, tune, draws, seed = (int(x) for x in gold["config"])
+    assert (G, D, rpg) == (1248, 8, 4000)
+    spec = models.hier_logit_variant(kind, G=G, D=D, rows_per_group=rpg, data=c2l_rows)
+    assert spec.n == int(gold[f"{kind}_n"])
+    f = _vg(spec)
+    assert f.model_scalar("rows_group_aligned") == 1.0 and f.model_scalar("rows_group_block") == 0.0 and f.model_scalar("rows_aux_workgroups") > 0
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_c2l_variant_fixtures as mk
+
+    for i, q in enumerate(mk.points(spec.n)):
+        lp, g = f._pytensor_function(q)
+        lp0, g0 = float(gold[f"{kind}_logp{i}"]), gold[f"{kind}_grad{i}"]
+        assert abs(lp - lp0) <= 1e-9 * abs(lp0), (lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * np.abs(g0).max()
+    f.close()
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, discard_tuned_samples=False)
+    dev = res["stats"][0]
+    assert len(dev) == tune + draws
+    for i in range(tune + draws):
+        for k in INT_KEYS:
+            assert int(dev[i][k]) == int(gold[f"{kind}_{k}"][i]), (i, k, dev[i][k], gold[f"{kind}_{k}"][i])
+    for i in range(4):
+        for k in ("mean_tree_accept", "energy", "model_logp", "step_size"):
+            np.testing.assert_allclose(dev[i][k], gold[f"{kind}_{k}"][i], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
+    c = gold[f"{kind}_coords"]
+    np.testing.assert_allclose(res["draws"][0][:4][:, c], gold[f"{kind}_draws_subset"][:4], rtol=1e-6, atol=1e-8)
+    res["step"].close()
