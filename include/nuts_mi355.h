@@ -169,7 +169,27 @@ typedef struct {
   const double *mix_y;           /* [N] */
   const double *mix_sigma_const; /* [K] or NULL */
   const double *mix_w_const;     /* [K] or NULL */
+  /* dense node 4: a generalised linear model over glm_N observed rows with glm_P <= 512 covariates -- the linear predictor
+       eta_i = intercept + x_i . beta          (`pm.math.dot(X, beta)`, pymc/math.py:56; what `pytensor.grad` differentiates
+                                                inside ValueGradFunction, model/core.py:213-267)
+     under a likelihood family evaluated per row:
+       NUTS_GLM_NORMAL     y_i ~ Normal(eta_i, sigma)          continuous.py:526-532
+       NUTS_GLM_BERNOULLI  y_i ~ Bernoulli(logit_p = eta_i)    discrete.py:351-352,362-374 (stabilised softplus form)
+       NUTS_GLM_POISSON    y_i ~ Poisson(mu = exp(eta_i))      discrete.py:581-597 (the factln(y) terms carry no gradient: their
+                                                               sum is taken when the model is created)
+     One fused pass over X per evaluation: forward (eta_i, the row's log-likelihood, r_i = d logp_i / d eta_i) and backward
+     (d logp / d beta += r_i x_i) from the same registers -- 8 N P bytes, the algorithmic traffic of the node.  glm_N == 0 disables.
+     glm_beta: variable of size P, untransformed.  glm_intercept: a scalar untransformed variable, or -1 (no intercept).
+     glm_sigma (NUTS_GLM_NORMAL): a scalar variable (untransformed or log-transformed: its constrained value is used), or -1 with
+     the constant glm_sigma_const.  The node may not be combined with another dense node. */
+  int64_t glm_N;
+  int32_t glm_P, glm_family, glm_beta, glm_intercept, glm_sigma, glm_pad;
+  double glm_sigma_const;
+  const double *glm_X; /* [N][P] row-major */
+  const double *glm_y; /* [N] */
 } nuts_model_spec;
+enum { NUTS_GLM_NORMAL = 0, NUTS_GLM_BERNOULLI = 1, NUTS_GLM_POISSON = 2 };
+#define NUTS_GLM_MAXP 512
 
 typedef struct nuts_model nuts_model;
 typedef struct nuts_chain nuts_chain;

@@ -451,6 +451,10 @@ def evaluate(spec, q, rows_fn=None):
             lp, g_extra = _mixture_rows(spec, spec.mixture_rows, x)
             logp += lp
             gx += g_extra
+        if getattr(spec, "glm_rows", None) is not None:
+            lp, g_extra = _glm_rows(spec, spec.glm_rows, x)
+            logp += lp
+            gx += g_extra
     grad = gx * dxdq + djac
     return logp, grad
 
@@ -480,6 +484,46 @@ def _logit_rows(spec, node, x):
     g[vs.offset : vs.offset + D] = (dbeta * z).sum(0)
     g[vz.offset : vz.offset + vz.size] = (dbeta * sg).ravel()
     return float(lp.sum()), g
+
+
+def _glm_rows(spec, node, x):
+    """Generalised linear model rows (pymc_amd/model_spec.py GlmRows): eta = intercept + X @ beta (`pm.math.dot`, math.py:56);
+
+    normal     Normal.logp(y | eta, sigma)                    continuous.py:526-532
+    bernoulli  Bernoulli.logp(y | logit_p = eta)              discrete.py:351-352,362-374 -- p = sigmoid(eta), switch(y, log p,
+               log1p(-p)) in PyTensor's stabilised form -softplus(-eta) / -softplus(eta), as for the logit rows above
+    poisson    Poisson.logp(y | mu = exp(eta))                discrete.py:581-597: logpow(mu, y) - factln(y) - mu
+    Pinned by executing those `logp` bodies of the reference on torch tensors (tests/golden/refrun_glm.py).
+    Returns (logp, gradient w.r.t. the CONSTRAINED values): d/dbeta = X^T r, d/dintercept = sum r, r = d logp_i / d eta_i."""
+    from scipy.special import gammaln
+
+    vb = spec.vars[node.beta]
+    beta = x[vb.offset : vb.offset + vb.size]
+    eta = node.X @ beta
+    if node.intercept is not None:
+        eta = eta + x[spec.vars[node.intercept].offset]
+    y = node.y
+    g = np.zeros(spec.n)
+    if node.family == 0:
+        sigma = x[spec.vars[node.sigma].offset] if node.sigma is not None else node.sigma_const
+        z = (y - eta) / sigma
+        lp = -0.5 * z * z - np.log(np.sqrt(2.0 * np.pi)) - np.log(sigma)
+        r = z / sigma
+        if node.sigma is not None:
+            g[spec.vars[node.sigma].offset] = np.sum((z * z - 1.0) / sigma)
+        if not sigma > 0:
+            return -np.inf, g * 0.0
+    elif node.family == 1:
+        lp = np.where(y != 0, -softplus(-eta), -softplus(eta))
+        r = y - expit(eta)
+    else:
+        mu = np.exp(eta)
+        lp = y * eta - gammaln(y + 1.0) - mu
+        r = y - mu
+    g[vb.offset : vb.offset + vb.size] = node.X.T @ r
+    if node.intercept is not None:
+        g[spec.vars[node.intercept].offset] = np.sum(r)
+    return float(np.sum(lp)), g
 
 
 def _mixture_rows(spec, node, x):

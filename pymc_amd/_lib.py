@@ -102,6 +102,16 @@ class ModelSpecC(C.Structure):
         ("mix_y", C.POINTER(C.c_double)),
         ("mix_sigma_const", C.POINTER(C.c_double)),
         ("mix_w_const", C.POINTER(C.c_double)),
+        ("glm_N", C.c_int64),
+        ("glm_P", C.c_int32),
+        ("glm_family", C.c_int32),
+        ("glm_beta", C.c_int32),
+        ("glm_intercept", C.c_int32),
+        ("glm_sigma", C.c_int32),
+        ("glm_pad", C.c_int32),
+        ("glm_sigma_const", C.c_double),
+        ("glm_X", C.POINTER(C.c_double)),
+        ("glm_y", C.POINTER(C.c_double)),
     ]
 
 

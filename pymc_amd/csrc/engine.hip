@@ -176,9 +176,31 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     else hipLaunchKernelGGL(k_mix_rows<16>, grid, block, 0, m->stream, md, A, io, j);
     hipLaunchKernelGGL(k_mix_reduce, dim3(1), dim3(WAVE), 0, m->stream, md, A, io, j);
   }
-  if (!md.has_logit && !md.has_mvn) return;
+  if (!md.has_logit && !md.has_mvn && !md.has_glm) return;
   const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
+  if (md.has_glm) {   // GLM node (glm_kernel.h): the fused pass over X (the timed kernel), then the totals of its records
+    const dim3 grid(md.glm.nwg), block(GLM_BLOCK);
+#define GLM_LAUNCH(LL, CC) hipLaunchKernelGGL((k_glm_rows<LL, CC>), grid, block, 0, m->stream, md, A, io, j)
+    switch (md.glm.lpr * 8 + md.glm.ch) {
+      case 1 * 8 + 1: GLM_LAUNCH(1, 1); break;
+      case 1 * 8 + 2: GLM_LAUNCH(1, 2); break;
+      case 1 * 8 + 4: GLM_LAUNCH(1, 4); break;
+      case 2 * 8 + 4: GLM_LAUNCH(2, 4); break;
+      case 4 * 8 + 4: GLM_LAUNCH(4, 4); break;
+      case 8 * 8 + 4: GLM_LAUNCH(8, 4); break;
+      case 16 * 8 + 4: GLM_LAUNCH(16, 4); break;
+      case 32 * 8 + 3: GLM_LAUNCH(32, 3); break;
+      case 32 * 8 + 4: GLM_LAUNCH(32, 4); break;
+      case 64 * 8 + 3: GLM_LAUNCH(64, 3); break;
+      default: GLM_LAUNCH(64, 4); break;
+    }
+#undef GLM_LAUNCH
+    if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; m->dom_units += 1; }
+    m->dom_launches++;
+    hipLaunchKernelGGL(k_glm_reduce, dim3((md.glm.Ppad + 3 + GLM_RED_COLS - 1) / GLM_RED_COLS), dim3(GLM_RED_CHUNKS * GLM_RED_COLS), 0, m->stream, md, A, io, j);
+    return;
+  }
   if (md.has_logit && md.lg.ga) {
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
     const int par = (m->ga_par ^= 1);
@@ -965,6 +987,77 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     md.has_mix = 1;
     m->alg_bytes += 8 * s->mix_N + (s->mix_assign >= 0 ? 8 * s->mix_N : 0);
   }
+  md.has_glm = 0;
+  if (s->glm_N > 0) {
+    GlmDev& gm = md.glm;
+    auto bad = [&](const char* msg) { g_err = msg; nuts_model_destroy(m); return (nuts_model*)nullptr; };
+    if (s->rows_N > 0 || s->mvn_k > 0 || s->mix_N > 0) return bad("GLM node: not together with another dense node");
+    if (s->glm_P < 1 || s->glm_P > NUTS_GLM_MAXP) return bad("GLM node: 1 <= P <= 512 covariates");
+    if (!s->glm_X || !s->glm_y) return bad("GLM node: no design matrix / observations");
+    if (s->glm_family < NUTS_GLM_NORMAL || s->glm_family > NUTS_GLM_POISSON) return bad("GLM node: unknown family");
+    const int vb = s->glm_beta;
+    if (vb < 0 || vb >= s->n_vars || s->vars[vb].size != s->glm_P || s->vars[vb].transform != NUTS_TR_NONE)
+      return bad("GLM node: beta must be an untransformed variable with P elements");
+    auto scalar_ok = [&](int v, bool log_ok) {
+      return v >= 0 && v < s->n_vars && s->vars[v].size == 1 && (s->vars[v].transform == NUTS_TR_NONE || (log_ok && s->vars[v].transform == NUTS_TR_LOG));
+    };
+    if (s->glm_intercept >= 0 && !scalar_ok(s->glm_intercept, false)) return bad("GLM node: the intercept must be an untransformed scalar variable");
+    if (s->glm_family == NUTS_GLM_NORMAL) {
+      if (s->glm_sigma >= 0 && !scalar_ok(s->glm_sigma, true)) return bad("GLM node: sigma must be a scalar variable, untransformed or log-transformed");
+      if (s->glm_sigma < 0 && !(s->glm_sigma_const > 0)) return bad("GLM node: sigma > 0");   // continuous.py:532 check_parameters
+    } else if (s->glm_sigma >= 0) return bad("GLM node: only the Normal family has a sigma");
+    gm.N = s->glm_N; gm.P = s->glm_P; gm.family = s->glm_family;
+    // register layout: a row in the lanes of a group of `lpr`, `ch` 16-byte chunks per lane (glm_kernel.h)
+    int lpr = 1;
+    while (8 * lpr < gm.P) lpr *= 2;
+    int ch = (gm.P + 2 * lpr - 1) / (2 * lpr);
+    if (lpr == 1) ch = ch == 3 ? 4 : ch;       // instantiated: 1, 2, 4
+    else if (lpr < 32) ch = 4;                 // 4 only
+    else ch = std::max(ch, 3);                 // 3 or 4
+    gm.lpr = lpr; gm.ch = ch; gm.Ppad = 2 * lpr * ch;
+    gm.off_beta = s->vars[vb].offset;
+    gm.off_icpt = s->glm_intercept >= 0 ? s->vars[s->glm_intercept].offset : -1;
+    gm.off_sigma = s->glm_sigma >= 0 ? s->vars[s->glm_sigma].offset : -1;
+    gm.tr_sigma = s->glm_sigma >= 0 ? s->vars[s->glm_sigma].transform : NUTS_TR_NONE;
+    gm.sigma_c = s->glm_sigma >= 0 ? 1.0 : (s->glm_family == NUTS_GLM_NORMAL ? s->glm_sigma_const : 1.0);
+    gm.konst = 0.0;
+    for (int64_t i = 0; i < gm.N; ++i) {
+      const double yi = s->glm_y[i];
+      if (s->glm_family == NUTS_GLM_BERNOULLI && !(yi == 0.0 || yi == 1.0)) return bad("GLM node: Bernoulli observations must be 0 or 1");
+      if (s->glm_family == NUTS_GLM_POISSON) {
+        if (!(yi >= 0.0) || yi != std::floor(yi)) return bad("GLM node: Poisson observations must be non-negative integers");
+        gm.konst -= std::lgamma(yi + 1.0);     // factln(y): parameter-free (discrete.py:581-597)
+      }
+    }
+    if (gm.Ppad == gm.P) gm.X = m->keep(dev_upload(s->glm_X, (size_t)gm.N * gm.P));
+    else {   // zero-padded rows, uploaded in slabs (the padded copy of a large X never exists on the host)
+      double* xd = m->keep(dev_alloc<double>((size_t)gm.N * gm.Ppad));
+      gm.X = xd;
+      if (xd) {
+        const int64_t slab = std::max<int64_t>(1, (int64_t)(1 << 22) / gm.Ppad);
+        std::vector<double> buf((size_t)slab * gm.Ppad, 0.0);
+        for (int64_t r0 = 0; r0 < gm.N; r0 += slab) {
+          const int64_t nr = std::min<int64_t>(slab, gm.N - r0);
+          for (int64_t r = 0; r < nr; ++r) std::memcpy(&buf[(size_t)r * gm.Ppad], s->glm_X + (size_t)(r0 + r) * gm.P, (size_t)gm.P * sizeof(double));
+          hipMemcpy(xd + (size_t)r0 * gm.Ppad, buf.data(), (size_t)nr * gm.Ppad * sizeof(double), hipMemcpyHostToDevice);
+        }
+      }
+    }
+    gm.y = m->keep(dev_upload(s->glm_y, (size_t)gm.N));
+    // grid: every CU gets NUTS_GLM_WG_PER_CU workgroups of four waves (default 8: 32 waves per CU, each with one row-iteration in
+    // flight and one being evaluated), fewer when there are not enough rows to give every wave a few iterations
+    const int64_t iters = (gm.N + (WAVE / lpr) - 1) / (WAVE / lpr);
+    int64_t nwg = (int64_t)cus * std::max(1, env_int("NUTS_GLM_WG_PER_CU", 8));
+    nwg = std::max<int64_t>(1, std::min<int64_t>(nwg, (iters + 4 * (GLM_BLOCK / WAVE) - 1) / (4 * (GLM_BLOCK / WAVE))));
+    gm.nwg = (int)nwg;
+    gm.part = m->keep(dev_alloc<double>((size_t)gm.nwg * (gm.Ppad + 4)));
+    gm.gdense = m->keep(dev_alloc<double>((size_t)n + 1));
+    gm.lp = gm.gdense ? gm.gdense + n : nullptr;
+    if (gm.part) hipMemset(gm.part, 0, (size_t)gm.nwg * (gm.Ppad + 4) * sizeof(double));
+    if (gm.gdense) hipMemset(gm.gdense, 0, ((size_t)n + 1) * sizeof(double));
+    md.has_glm = 1;
+    m->alg_bytes += 8 * gm.N * (int64_t)gm.P;   // one read of X (SURVEY 8d convention: the node's data once per evaluation)
+  }
   for (void* p : m->owned)
     if (!p) { g_err = "device allocation failed"; nuts_model_destroy(m); return nullptr; }
   HIPCHK_NULL(hipDeviceSynchronize());
@@ -1017,12 +1110,14 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   else if (k == "rows_group_block") *out = m->md.lg.ga_gpw;
   else if (k == "rows_aux_workgroups") *out = m->md.lg.ga ? m->md.lg.ga_naux : 0;
   else if (k == "mixture_workgroups") *out = m->md.has_mix ? m->md.mix.nwg : 0;
+  else if (k == "glm_workgroups") *out = m->md.has_glm ? m->md.glm.nwg : 0;
+  else if (k == "glm_row_stride") *out = m->md.has_glm ? m->md.glm.Ppad : 0;
   else if (k == "mvn_row_aligned") *out = m->md.has_mvn ? m->md.mv.aligned : 0;
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
   else if (k == "lean") *out = m->md.lean_ok;
   else if (k == "tree_kernel_ok") *out = m->ga_tree_ok;
   else if (k == "rows_stored_columns") *out = m->md.lg.ga ? m->md.lg.ga_dx : m->md.lg.D;
-  else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn) ? 1.0 : 0.0;
+  else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
 }
@@ -1420,7 +1515,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->spec_max = env_int("NUTS_SPEC_MAX", 10);
   c->xfold = env_int("NUTS_XFOLD", 1);
   c->xpre = env_int("NUTS_XPRE", 1);
-  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix &&
+  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
              !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;

@@ -499,6 +499,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
   }
   if (md.has_mvn) for (int r = bid * VEC_THREADS + tid; r < md.mv.k; r += nb * VEC_THREADS) lp -= 0.5 * md.mv.rowq[r];
   if (md.has_mix && bid == 0 && tid == 0) lp += *md.mix.lp;   // (mixture_kernel.h: k_mix_reduce ran before this kernel)
+  if (md.has_glm && bid == 0 && tid == 0) lp += *md.glm.lp;   // (glm_kernel.h: k_glm_reduce ran before this kernel)
 
   for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
   double db_acc = 0.0, dbz_acc = 0.0;
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     }
     if (md.has_mvn && i >= md.mv.off && i < md.mv.off + md.mv.k) gd += md.mv.gdense[i];
     if (md.has_mix) gd += md.mix.gdense[i];
+    if (md.has_glm) gd += md.glm.gdense[i];
     grad[e] = (gx + gd) * dxdq + dj;
     act[e] = true;
     if (leaf) A.G[lf.d_o + i] = grad[e];
@@ -880,6 +882,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
       if (k == lg.var_mu) gx += s_sum[PART_DMU + (i - lg.off_mu)];
       else if (k == lg.var_sigma) gx += s_sum[PART_DSG + (i - lg.off_sigma)];
     }
+    if (md.has_glm) gx += md.glm.gdense[i];   // the GLM node's scalar parameters (intercept, sigma): glm_kernel.h; zero elsewhere
   }
   TICK(md, tk, 20);
   // broadcast terms: the share of the ordinary elements (kernel B) + the share of deferred vector elements (here)
@@ -1674,3 +1677,4 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, con
 #include "rows_ga_tree.h"
 #include "rows_gb_kernel.h"
 #include "dense_adapt.h"
+#include "glm_kernel.h"

@@ -142,6 +142,21 @@ struct MixDev {
   double* lp;             // the node's logp
 };
 
+// dense node 4: generalised linear model rows (glm_kernel.h)
+struct GlmDev {
+  int64_t N;
+  int32_t P, Ppad;          // covariates; stored row length (a multiple of 2 LPR, zero-padded)
+  int32_t family, lpr, ch;  // NUTS_GLM_*; lanes per row (a power of two); 16-byte chunks per lane: Ppad = 2 lpr ch
+  int32_t off_beta, off_icpt, off_sigma, tr_sigma, nwg;   // element offsets (off_icpt / off_sigma < 0: none / the constant)
+  double sigma_c;           // constant sigma (Normal family without a sigma variable)
+  double konst;             // parameter-free part of the log-likelihood (Poisson: -sum_i factln(y_i))
+  const double* X;          // [N][Ppad]
+  const double* y;          // [N]
+  double* part;             // [nwg][Ppad + 4] per-workgroup sums: d/dbeta[Ppad], d/dintercept, d/dsigma, logp, (pad)
+  double* gdense;           // [n] the node's gradient w.r.t. the constrained values (zero outside its parameters)
+  double* lp;               // the node's logp
+};
+
 // per-workgroup partial record written by the vector kernel, summed (in workgroup order) by the control kernel
 #define PART_LP 0
 #define PART_BT 1
@@ -158,8 +173,9 @@ struct ModelDev {
   int has_logit, has_mvn;
   RowsDev lg;
   MvnDev mv;
-  int has_mix, mix_pad;
+  int has_mix, has_glm;
   MixDev mix;
+  GlmDev glm;
   double* part;               // [nblk][part_stride]
   int32_t part_stride, prog_bytes;
   // "lean" control path (see kernels.h): the only deferred elements are the hierarchical-logit node's mu / sigma, so

@@ -33,6 +33,9 @@
 #pragma once
 
 #define GA_AUX_MAXDEF 64   // deferred elements of a model on a one-launch pass (one LDS slot each; also: one control thread each)
+#define GA_AUX_PROG_LDS 6144   // LDS the row kernels set aside for the interpreter's tables (a model whose tables are larger reads them from
+                               // global memory: correct, but every table look-up is then a dependent trip to L2, and at ~60 us the auxiliary
+                               // workgroup of a 300-element extra variable outlasted the 57 us row stream of C2-L: profiles/r04c_variants_ab.txt)
 
 struct AuxScratch {   // LDS the caller lends (aliased onto arrays the row workgroups use for something else)
   double* red;        // [NDOT * waves]
@@ -54,7 +57,7 @@ struct AuxScratch {   // LDS the caller lends (aliased onto arrays the row workg
 // callers: a copy shared by the 128-register streaming kernel and the 256-register group-block kernel took 248 and halved the
 // occupancy of the former) -- 4 / 3: group-aligned pass at that many waves per SIMD, 0: group-block pass.
 template <int BUDGET>
-__device__ __noinline__ void ga_aux(const GaArgs* ap, int aux_id, double hval0, double hph0, double* lds, int nw_lds, double* rec, int64_t rs) {
+__device__ __noinline__ void ga_aux(const GaArgs* ap, int aux_id, double hval0, double hph0, double* lds, int nw_lds, char* lds_prog, double* rec, int64_t rs) {
   const GaArgs& a = *ap;
   const AuxScratch sc{lds, lds + NDOT * nw_lds, lds + NDOT * nw_lds + GA_AUX_MAXDEF, lds + NDOT * nw_lds + 2 * GA_AUX_MAXDEF};
   const ModelDev& md = a.md;
@@ -68,26 +71,43 @@ __device__ __noinline__ void ga_aux(const GaArgs* ap, int aux_id, double hval0, 
   const int aborted = load_aborted(io, A);
   resolve_leaf(io, A, j, lf, qv);
   const bool leaf = io.mode != MODE_PLAIN, tree = io.mode == MODE_TREE;
-  const Prog pg = prog_view(md, md.prog);   // the tables straight from the global blob: read-only, L2-resident, off the critical path
+  // The auxiliary workgroup is a chain of dependent trips to memory (tables -> element -> operands -> merge operands), and under a
+  // row stream that saturates HBM every trip costs microseconds: the tables go to LDS first (constant data, L2 hits).  Measured
+  // and declined (profiles/r04e_variants_ab.txt ... r04g): requesting every thread's source state and merge operands up front
+  // (most threads of a small model own a deferred element or nothing, and the tables then waited behind loads nobody needed), and
+  // prefetching the operands of the first three merge levels as the row workgroups do (18 far loads per element and leaf, where
+  // half the leaves complete no merge at all: +4.7 us per launch on a 300-element extra variable at C2-L).
+  const int ai = aux_id * NT + tid;
+  const bool valid = ai < R.ga_auxel;
+  const int i = valid ? (ai < R.off_z ? ai : ai + R.G * D) : 0;   // (the z elements are the row workgroups')
+  // (loads return in order: first what is needed first -- the tables and the deferred list, constant data that sits in L2 --
+  // then, in one batch, everything that was written by the previous launch on other XCDs and comes from far away)
+  const bool has_def = tid < md.n_deferred;                      // (n_deferred <= GA_AUX_MAXDEF <= the threads of a workgroup)
+  int def_i = 0, def_k = 0;
+  if (has_def) { def_i = md.deferred_g[2 * tid]; def_k = md.deferred_g[2 * tid + 1]; }
+  const bool prog_in_lds = md.prog_bytes <= GA_AUX_PROG_LDS;
+  if (prog_in_lds) {
+    const int n16 = (md.prog_bytes + 15) >> 4;
+    for (int t = tid; t < n16; t += NT) reinterpret_cast<uint4*>(lds_prog)[t] = reinterpret_cast<const uint4*>(md.prog)[t];
+  }
+  const Prog pg = prog_view(md, prog_in_lds ? lds_prog : md.prog);   // (first used behind the barrier below)
 
   // ---- q' and p_half of every deferred element of this leaf -> LDS ----
   const bool from_prev = (a.fold & GA_FOLD_SRC) != 0;
   const double2* prev_loc = reinterpret_cast<const double2*>(md.def_loc + (int64_t)(par ^ 1) * 4 * MAX_DEFERRED);
-  for (int t = tid; t < md.n_deferred; t += NT) {
-    const int i = md.deferred_g[2 * t], k = md.deferred_g[2 * t + 1];
-    if (k == R.var_mu || k == R.var_sigma) continue;   // (below: the caller's prologue values)
+  if (has_def && def_k != R.var_mu && def_k != R.var_sigma) {   // (mu / sigma below: the caller's prologue values)
     double qn, ph;
     if (from_prev) {
       // the source state is the leaf of the previous launch: its gradient is the local part that launch left (no cross-workgroup
       // share), its p' the second half kick of it -- the arithmetic of control_lean / rows_hyper_fold_elem, the same bits
-      const double2 l01 = prev_loc[2 * t], l23 = prev_loc[2 * t + 1];
+      const double2 l01 = prev_loc[2 * tid], l23 = prev_loc[2 * tid + 1];
       const double g = deferred_finish(l01.x, 0.0, l01.y, l23.x);
       const double p_src = fma(qv.half, g, l23.y);
       ph = fma(qv.half, g, p_src);
-      qn = fma(qv.eps, qv.var[i] * ph, qv.q[i]);
-    } else if (qv.composed) { ph = qv.p_half(i); qn = fma(qv.eps, qv.var[i] * ph, qv.q[i]); }
-    else { ph = 0.0; qn = qv.q[i]; }
-    sc.defq[t] = qn; sc.defph[t] = ph;
+      qn = fma(qv.eps, qv.var[def_i] * ph, qv.q[def_i]);
+    } else if (qv.composed) { ph = qv.p_half(def_i); qn = fma(qv.eps, qv.var[def_i] * ph, qv.q[def_i]); }
+    else { ph = 0.0; qn = qv.q[def_i]; }
+    sc.defq[tid] = qn; sc.defph[tid] = ph;
   }
   if (w == 0 && lane < 2 * D) {
     const int slot = lane < D ? R.def_mu + lane : R.def_sigma + (lane - D);
@@ -99,9 +119,6 @@ __device__ __noinline__ void ga_aux(const GaArgs* ap, int aux_id, double hval0, 
   qd.defq = sc.defq;
 
   // ---- this thread's element ----
-  const int ai = aux_id * NT + tid;
-  const bool valid = ai < R.ga_auxel;
-  const int i = valid ? (ai < R.off_z ? ai : ai + R.G * D) : 0;   // (the z elements are the row workgroups')
   int idx[1] = {i};
   bool act[1] = {false};
   double grad[1] = {0.0}, ph[1] = {0.0};
@@ -111,8 +128,10 @@ __device__ __noinline__ void ga_aux(const GaArgs* ap, int aux_id, double hval0, 
     const VarDev v = pg.vars[k];
     double qn;
     if (v.deferred) { const int slot = v.def_base + (i - v.offset); qn = sc.defq[slot]; ph[0] = sc.defph[slot]; }
-    else if (leaf) { ph[0] = fma(lf.half, A.G[lf.so + i], A.P[lf.so + i]); qn = fma(lf.eps, A.var[i] * ph[0], A.Q[lf.so + i]); }   // integration.py:118-127
-    else qn = io.q[i];
+    else if (leaf) {
+      const double own_g = A.G[lf.so + i], own_p = A.P[lf.so + i], own_q = A.Q[lf.so + i], own_var = A.var[i];
+      ph[0] = fma(lf.half, own_g, own_p); qn = fma(lf.eps, own_var * ph[0], own_q);   // integration.py:118-127
+    } else qn = io.q[i];
     double x, dxdq, lj, dj, gx = 0.0;
     transform_full(v, qn, x, dxdq, lj, dj);
     lp += lj;

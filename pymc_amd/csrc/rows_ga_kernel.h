@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
   __shared__ int s_info[4];                      // {this workgroup is its block's last arriver, m, last}
   __shared__ double s_keep[5][WAVE];             // wave 0's per-lane prologue values the tail needs again (kept out of the stream's registers)
   __shared__ __attribute__((aligned(16))) char s_args[(sizeof(GaArgs) + 15) / 16 * 16];
+  __shared__ __attribute__((aligned(16))) char s_auxprog[GA_AUX_PROG_LDS];   // auxiliary workgroups only (28 KB per workgroup in all: five per CU still fit)
   // workgroups behind the G groups: the auxiliary workgroups (rows_aux.h).  They take mu', sigma' of this leaf from the same
   // prologue arithmetic as everybody else and leave BEFORE any tile is requested: the call below may save registers around it,
   // and a register with a hand-counted load in flight must never be stored (tests/test_abi.py guards that).
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga(GaArgs a) {
     ga_hyper<D>(md, qv, fold, par, lane, hv, hp);
     const int aux_id = b - R.G;
     // (LDS lent from the block reduce's chunk buffer, which only a block's last arriver uses)
-    ga_aux<OCC>((const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr(), aux_id, hv, hp, &s_cp[0][0], GA_MAXW,
+    ga_aux<OCC>((const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr(), aux_id, hv, hp, &s_cp[0][0], GA_MAXW, s_auxprog,
                 R.ga_bpart + ((int64_t)par * R.ga_nrec + R.ga_nblk + aux_id) * PART_STRIDE, 1);
     return;
   }

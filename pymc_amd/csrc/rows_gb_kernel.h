@@ -81,6 +81,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
   __shared__ double s_rec[GB_MAXGPW][PART_STRIDE];   // per-group records {logp, d/dmu[D], d/dsigma[D], dots}
   __shared__ double s_red[GB_W][NDOT];               // a wave's dot products of the group it is finishing
   __shared__ int s_ml[2];
+  __shared__ __attribute__((aligned(16))) char s_auxprog[GA_AUX_PROG_LDS];   // auxiliary workgroups only (rows_aux.h)
   const bool tk = b == (int)(R.ga_nblk / 2) && tid == 0 && (md.tick_j < 0 || j == md.tick_j);   // NUTS_KTIMING builds only
   TICK(md, tk, 0);
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
     static_assert(GA_AUX_SCRATCH_DOUBLES(GB_W) <= GB_MAXGPW * PART_STRIDE, "auxiliary scratch does not fit the record buffer");
     const int aux_id = b - R.ga_nblk;
     const int npad = (R.ga_nrec + WAVE - 1) / WAVE * WAVE;
-    ga_aux<0>((const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr(), aux_id, hval0, hph0, &s_rec[0][0], GB_W,
+    ga_aux<0>((const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr(), aux_id, hval0, hph0, &s_rec[0][0], GB_W, s_auxprog,
            R.ga_bpart + (int64_t)par * PART_STRIDE * npad + (R.ga_nblk + aux_id), npad);
     return;
   }

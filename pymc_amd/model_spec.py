@@ -202,6 +202,32 @@ class MixtureRows:
     name: str = "y"
 
 
+GLM_NORMAL, GLM_BERNOULLI, GLM_POISSON = 0, 1, 2
+GLM_FAMILIES = {"normal": GLM_NORMAL, "bernoulli": GLM_BERNOULLI, "poisson": GLM_POISSON}
+
+
+@dataclass
+class GlmRows:
+    """A generalised linear model over N observed rows: eta = intercept + X @ beta (`pm.math.dot`, pymc/math.py:56) as the
+    location / logit / log-mean of the likelihood --
+
+        pm.Normal(name, mu=alpha + pm.math.dot(X, beta), sigma=sigma, observed=y)        continuous.py:526-532
+        pm.Bernoulli(name, logit_p=alpha + pm.math.dot(X, beta), observed=y)             discrete.py:351-352,362-374
+        pm.Poisson(name, mu=pm.math.exp(alpha + pm.math.dot(X, beta)), observed=y)       discrete.py:581-597
+
+    `beta`: variable of size P <= 512; `intercept`: scalar variable or None; `sigma` (Normal): scalar variable (its constrained
+    value) or None with `sigma_const`."""
+
+    X: np.ndarray                     # [N, P] float64
+    y: np.ndarray                     # [N] float64
+    family: int                       # GLM_*
+    beta: int                         # var id
+    intercept: Optional[int] = None   # var id
+    sigma: Optional[int] = None       # var id, or None with sigma_const
+    sigma_const: float = 1.0
+    name: str = "y"
+
+
 @dataclass
 class ModelSpec:
     vars: List[FreeVar] = field(default_factory=list)
@@ -210,6 +236,7 @@ class ModelSpec:
     logit_rows: Optional[LogitRows] = None
     mvnormal: Optional[MvNormalNode] = None
     mixture_rows: Optional[MixtureRows] = None
+    glm_rows: Optional[GlmRows] = None
     # "extra" inputs of the log-density (model/core.py:142-190 `extra_vars_and_values`): name -> index into `data`;
     # the caller rewrites them through `set_extra_values` (value variables sampled by another step method)
     extra: Dict[str, int] = field(default_factory=dict)
@@ -629,6 +656,22 @@ class ModelBuilder:
         self.spec.logit_rows = LogitRows(
             X, np.ascontiguousarray(y, dtype="int8"), g, self._var_id(mu), self._var_id(sigma), self._var_id(z), name
         )
+
+    def GLM(self, name, X, beta: Expr, observed, family="normal", intercept: Optional[Expr] = None, sigma=1.0):
+        """The likelihood of a generalised linear model (`GlmRows`): `family` "normal" (with `sigma` a scalar variable or a
+        constant), "bernoulli" (logit link) or "poisson" (log link); eta = intercept + X @ beta."""
+        X = np.ascontiguousarray(X, dtype="float64")
+        y = np.ascontiguousarray(observed, dtype="float64").ravel()
+        if X.ndim != 2 or X.shape[0] != y.size or X.shape[1] != beta.size:
+            raise ValueError("GLM: X is [N, P], beta has P elements, one observation per row")
+        node = GlmRows(X, y, GLM_FAMILIES[family], self._var_id(beta), name=name)
+        if intercept is not None:
+            node.intercept = self._var_id(intercept)
+        if isinstance(sigma, Expr):
+            node.sigma = self._var_id(sigma)
+        else:
+            node.sigma_const = float(sigma)
+        self.spec.glm_rows = node
 
     def MvNormal(self, name, mu, cov, solver="precision"):
         if solver not in ("precision", "cholesky"):

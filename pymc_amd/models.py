@@ -234,6 +234,40 @@ def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: f
     return spec
 
 
+def glm_nuts(N: int = 1_000_000, P: int = 512, family: str = "bernoulli", seed: int = DATA_SEED, intercept: bool = True, sigma: str = "var",
+             prior_sd: float = 1.0) -> ModelSpec:
+    """The GLM of BASELINE configs[3] (1 M observations x 512 covariates) as a model NUTS samples: beta[P] ~ Normal(0, prior_sd),
+    alpha ~ Normal(0, 5), y_i ~ family(alpha + x_i . beta) -- Bernoulli with logit link, Poisson with log link, or Normal with
+    sigma ~ HalfNormal(1) (`sigma="var"`) / a known sigma (`sigma=<float as str>`).  x_i ~ N(0, 1 / P)^P so that eta = O(1);
+    beta* ~ N(0, 1).  X fp64 = 8 N P bytes (4.1 GB at the defaults), resident in HBM: one fused read per logp + gradient."""
+    rng = np.random.default_rng(seed)
+    beta = rng.normal(0, 1.0, size=P)
+    a0 = 0.3 if intercept else 0.0
+    X = np.empty((N, P))
+    y = np.empty(N)
+    chunk = 1 << 16
+    sc = 1.0 / np.sqrt(P)
+    for s0 in range(0, N, chunk):
+        e = min(N, s0 + chunk)
+        xb = rng.normal(size=(e - s0, P)) * sc
+        X[s0:e] = xb
+        eta = a0 + xb @ beta
+        if family == "normal":
+            y[s0:e] = eta + 0.7 * rng.normal(size=e - s0)
+        elif family == "bernoulli":
+            y[s0:e] = rng.random(e - s0) < 1.0 / (1.0 + np.exp(-eta))
+        else:
+            y[s0:e] = rng.poisson(np.exp(np.clip(eta, -6, 3)))
+    m = ModelBuilder()
+    alpha = m.Normal("alpha", 0.0, 5.0) if intercept else None
+    b = m.Normal("beta", 0.0, prior_sd, shape=P)
+    sg = 1.0
+    if family == "normal":
+        sg = m.HalfNormal("sigma", 1.0) if sigma == "var" else float(sigma)
+    m.GLM("y", X, b, y, family=family, intercept=alpha, sigma=sg)
+    return m.build()
+
+
 def glm(N: int = 1_000_000, P: int = 512, family: str = "normal", batch_size: int = 1024, seed: int = DATA_SEED, sigma: float = 1.0,
         prior_sd: float = 1.0):
     """GLM with N observations and P covariates for minibatched full-rank ADVI (BASELINE configs[3]: N = 1 M, P = 512; X fp64 =

@@ -102,6 +102,17 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
             wc = np.ascontiguousarray(mx.w_const, dtype="float64")
             keep.append(wc)
             s.mix_w_const = _lib.dptr(wc)
+    gl = getattr(spec, "glm_rows", None)
+    if gl is not None:
+        X = np.ascontiguousarray(gl.X, dtype="float64")
+        y = np.ascontiguousarray(gl.y, dtype="float64")
+        keep += [X, y]
+        s.glm_N, s.glm_P = X.shape
+        s.glm_family, s.glm_beta = gl.family, gl.beta
+        s.glm_intercept = -1 if gl.intercept is None else gl.intercept
+        s.glm_sigma = -1 if gl.sigma is None else gl.sigma
+        s.glm_sigma_const = float(gl.sigma_const)
+        s.glm_X, s.glm_y = _lib.dptr(X), _lib.dptr(y)
     return s, keep
 
 

@@ -82,21 +82,36 @@ def _c2s_chain(c, cfg=C2S, fn="oracle_hier_logit"):
     step = ref_sampler.RefNUTS(f, spec.n, potential=pot, rng=seeds[0])
     t0 = time.time()
     d, s = ref_sampler.run_chain(step, starts[c], rngs[c], cfg["tune"], cfg["draws"])
-    print(f"chain {c} ({cfg['rows_per_group']} rows per group): {time.time() - t0:.0f} s", flush=True)
-    return d[cfg["tune"]:], {k: np.array([x[k] for x in s]) for k in STAT_KEYS}
+    wall = time.time() - t0          # the whole chain, warmup included: the time base of the reference's ESS/s (benchmarks.py:180-198)
+    print(f"chain {c} ({cfg['rows_per_group']} rows per group): {wall:.0f} s", flush=True)
+    return d[cfg["tune"]:], {k: np.array([x[k] for x in s]) for k in STAT_KEYS}, wall
 
 
 def _c2l_chain(c):
-    d, s = _c2s_chain(c, C2LFULL, "oracle_hier_logit_stat")
+    d, s, wall = _c2s_chain(c, C2LFULL, "oracle_hier_logit_stat")
     os.makedirs(os.path.join(ROOT, "scratch"), exist_ok=True)
-    np.savez_compressed(os.path.join(ROOT, "scratch", f"c2l_chain{c}.npz"), draws=d, **{"stat_" + k: v for k, v in s.items()})
-    return d, s
+    np.savez_compressed(os.path.join(ROOT, "scratch", f"c2l_chain{c}.npz"), draws=d, wall_s=wall, **{"stat_" + k: v for k, v in s.items()})
+    return d, s, wall
 
 
 def _c2l_chain_from_scratch(c):
-    """The chain `_c2l_chain` wrote to scratch/ (re-summarising without the hours of sampling: `c2lsum`)."""
+    """The chain `_c2l_chain` wrote to scratch/ (re-summarising without the hours of sampling: `c2lsum`).  Its wall time: from the
+    file, or (chains written before the time was stored) from the run's own log, scratch/c2lfull.log ("chain c (...): NNNN s")."""
+    import re
+
     f = np.load(os.path.join(ROOT, "scratch", f"c2l_chain{c}.npz"))
-    return f["draws"], {k: f["stat_" + k] for k in STAT_KEYS}
+    if "wall_s" in f.files:
+        wall = float(f["wall_s"])
+    else:
+        log = open(os.path.join(ROOT, "scratch", "c2lfull.log")).read()
+        wall = float(re.search(rf"chain {c} \(4000 rows per group\): (\d+) s", log).group(1))
+    return f["draws"], {k: f["stat_" + k] for k in STAT_KEYS}, wall
+
+
+def host_note():
+    """Where the chains ran (the wall times are THIS host's: one chain per process, `chains` processes at once)."""
+    model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown CPU")
+    return f"{model}, {os.cpu_count()} logical cores, one oracle chain per process, all chains concurrently"
 
 
 def make_c2s(cfg=C2S, chain_fn=_c2s_chain, name="c2s_chains.npz", pool=True):
@@ -127,6 +142,9 @@ def make_c2s(cfg=C2S, chain_fn=_c2s_chain, name="c2s_chains.npz", pool=True):
     }
     for k in ("tree_size", "step_size_bar", "depth", "diverging", "mean_tree_accept"):
         out["stat_" + k] = np.stack([r[1][k] for r in res])
+    # measured CPU time base of ESS/s: seconds per chain, tuning included
+    out["wall_s"] = np.array([r[2] for r in res], dtype="float64")
+    out["wall_host"] = np.array(host_note())
     np.savez_compressed(os.path.join(HERE, name), **out)
     print(name, ": min ESS", out["ess_bulk"].min(), "argmin", int(out["ess_bulk"].argmin()), "max rhat", out["rhat"].max(),
           "mean tree", out["stat_tree_size"][:, cfg["tune"]:].mean(), flush=True)

@@ -14,10 +14,10 @@ pick() { python -c "import json,sys; j=json.loads([l for l in open(sys.argv[1]) 
 echo "# $B [--rows-per-group 80] [--variant V]   (tag $TAG; one box, one after the other)"
 for RPG in 4000 80; do
   $B --rows-per-group $RPG > $OUT/var_base_$TAG.json 2> $OUT/var_base_$TAG.err; pick $OUT/var_base_$TAG.json "rows/group $RPG  benchmark model        "
-  for V in halfcauchy exponential lognormal gamma datapriors extra; do
+  for V in ${VLIST:-halfcauchy exponential lognormal gamma datapriors extra}; do
     $B --rows-per-group $RPG --variant $V > $OUT/var_${V}_$TAG.json 2> $OUT/var_${V}_$TAG.err; pick $OUT/var_${V}_$TAG.json "rows/group $RPG  $(printf %-12s $V) one-launch "
   done
-  for V in halfcauchy extra; do
+  for V in ${GLIST-halfcauchy extra}; do
     NUTS_GA_AUX=0 $B --rows-per-group $RPG --variant $V > $OUT/var_${V}_gen_$TAG.json 2> $OUT/var_${V}_gen_$TAG.err; pick $OUT/var_${V}_gen_$TAG.json "rows/group $RPG  $(printf %-12s $V) round-3 path"
   done
   $B --rows-per-group $RPG > $OUT/var_base2_$TAG.json 2> $OUT/var_base2_$TAG.err; pick $OUT/var_base2_$TAG.json "rows/group $RPG  benchmark model (again)"
