@@ -71,7 +71,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"], help="c2 = hier-logit-10k (the headline), c3 = MvNormal 2048")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "glm"],
+                    help="c2 = hier-logit-10k (the headline), c3 = MvNormal 2048, glm = NUTS on configs[3]'s GLM (1 M rows x 512 covariates, the dense "
+                         "linear-predictor node of csrc/glm_kernel.h) -- not the headline either")
+    ap.add_argument("--glm-rows", type=int, default=1_000_000)
+    ap.add_argument("--glm-cols", type=int, default=512)
+    ap.add_argument("--glm-family", default="bernoulli", choices=["normal", "bernoulli", "poisson"])
     ap.add_argument("--rows-per-group", type=int, default=4000, help="4000 = C2-L (HBM regime), 80 = C2-S (cache resident)")
     ap.add_argument("--groups", type=int, default=1248)
     ap.add_argument("--variant", default=None, help="NOT the headline: the same rows under another model around them (pymc_amd.models.HIER_LOGIT_VARIANTS: "
@@ -196,7 +201,7 @@ def cpu_baseline_c2(args, spec, q, step_size, inv_mass, n_leap, ess_per_leapfrog
     }
 
 
-def cpu_baseline_c3(spec, q, step_size, inv_mass, n_leap):
+def cpu_baseline_c3(spec, q, step_size, inv_mass, n_leap, what="SciPy Cholesky-solve logp/grad"):
     from oracle import ref_models
 
     try:
@@ -210,7 +215,7 @@ def cpu_baseline_c3(spec, q, step_size, inv_mass, n_leap):
     return {
         "value": lps, "unit": "leapfrog steps/s (one chain on one host core)", "leapfrog_steps_per_sec": lps, "cores": 1, "kind": "port",
         "host_cores_available": os.cpu_count(),
-        "sample": f"{n_leap} reference-order leapfrog steps (oracle integrator + SciPy Cholesky-solve logp/grad, BLAS threads = 1) in {time.perf_counter() - t0:.1f} s",
+        "sample": f"{n_leap} reference-order leapfrog steps (oracle integrator + {what}, BLAS threads = 1) in {time.perf_counter() - t0:.1f} s",
     }
 
 
@@ -336,6 +341,7 @@ def run_rank(args):
 
     W, K = args.warmup, args.steps
     c3 = args.workload == "c3"
+    glm = args.workload == "glm"
     meta = {}
     if stub:
         chain = _StubChain(rank)
@@ -360,6 +366,9 @@ def run_rank(args):
         if c3:
             spec = models.mvnormal(n=args.mvn_k)
             N = 0
+        elif glm:
+            spec = models.glm_nuts(N=args.glm_rows, P=args.glm_cols, family=args.glm_family)
+            N = args.glm_rows
         else:
             if args.variant:
                 spec = models.hier_logit_variant(args.variant, G=args.groups, D=8, rows_per_group=args.rows_per_group, seed=20160911)
@@ -406,7 +415,7 @@ def run_rank(args):
             cv = {"min_ess": float(ess[j]), "min_ess_param_index": j, "min_ess_param": names[j], "median_ess": float(np.median(ess)),
                   "ess_5pct": float(np.percentile(ess, 5)), "rhat_max": float(np.nanmax(rh)), "rhat_max_param": names[int(np.nanargmax(rh))],
                   "rhat_of_min_ess_param": float(rh[j]), "n_params": int(spec.n), "divergences": n_div_}
-            if not c3:
+            if not c3 and not glm:
                 # The non-centred parametrisation SURVEY 8 prescribes leaves (mu_d, mean_g z_{g,d}) on a ridge when every group has
                 # thousands of rows: the combination the likelihood identifies, beta_bar_d = mu_d + sigma_d
                 # mean_g z_{g,d}, is reported next to the per-coordinate minimum so that the two can be told apart.
@@ -451,6 +460,11 @@ def run_rank(args):
             kernel = (f"k_mvn_aligned<{aligned}> (precision mat-vec whose workgroups also finish the leapfrog: one launch per leapfrog"
                       if aligned else "k_mvn_matvec (precision mat-vec") + \
                 "; cache-resident: 33.5 MB < 256 MiB Infinity Cache -- the HBM line does not bound it)"
+        elif glm:
+            workload = (f"GLM NUTS (configs[3]'s model under NUTS): N={args.glm_rows} observations x P={args.glm_cols} covariates, {args.glm_family} family, "
+                        f"alpha + X beta, n={spec.n}")
+            kernel = (f"k_glm_rows (one fused forward + backward read of X per leapfrog, row stride {int(step._logp_dlogp_func.model_scalar('glm_row_stride'))} doubles, "
+                      f"{int(step._logp_dlogp_func.model_scalar('glm_workgroups'))} workgroups; csrc/glm_kernel.h)")
         else:
             workload = f"C2-{'L' if args.rows_per_group >= 1000 else 'S'} hier-logit-10k: G={args.groups} D=8 rows={N} n={spec.n}"
             if args.variant:
@@ -465,6 +479,7 @@ def run_rank(args):
                     "(csrc/rows_ga_kernel.h)" if (not c3 and step._logp_dlogp_func.model_scalar("rows_group_aligned")) else
                     "row-aligned MvNormal pass: one launch per leapfrog, control work folded into the next launch, also across doublings "
                     "(csrc/kernels.h, k_mvn_aligned)" if (c3 and step._logp_dlogp_func.model_scalar("mvn_row_aligned")) else
+                    "four launches per leapfrog: the fused pass over X, the totals of its records, the O(n) kernel, the control kernel (csrc/glm_kernel.h)" if glm else
                     "two launches per leapfrog (data pass + O(n) kernel), control work folded into the next data pass (csrc/kernels.h)")
         meta = dict(alg_bytes=alg_bytes, n=int(spec.n), N=N, workload=workload, kernel=kernel, schedule=schedule, traffic_ok=True)
 
@@ -486,8 +501,10 @@ def run_rank(args):
         if world == 1 and args.cpu_leapfrogs > 0 and not stub:
             inv_mass = step._vector("var")
             eps = float(step._scalar("step_size"))
-            if c3:
-                out["cpu_baseline"] = cpu_baseline_c3(spec, draws[-1], eps, inv_mass, args.cpu_leapfrogs)
+            if c3 or glm:
+                # (a GLM leapfrog on one core is two passes over 4 GB of X: a bounded sample of 20)
+                out["cpu_baseline"] = (cpu_baseline_c3(spec, draws[-1], eps, inv_mass, min(args.cpu_leapfrogs, 20), "NumPy X @ beta / X^T r logp/grad") if glm else
+                                       cpu_baseline_c3(spec, draws[-1], eps, inv_mass, args.cpu_leapfrogs))
             else:
                 out["cpu_baseline"] = cpu_baseline_c2(args, spec, draws[-1], eps, inv_mass, args.cpu_leapfrogs,
                                                       (vec[1] / max(leap, 1.0)) if ess_ok else
@@ -521,6 +538,7 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok):
     """The one JSON line (rank 0)."""
     K, W = args.steps, args.warmup
     c3 = args.workload == "c3"
+    glm = args.workload == "glm"
     alg_bytes, n = meta["alg_bytes"], meta["n"]
     T = float(allv[:, 0].max())
     leap_total = float(allv[:, 2].sum())
@@ -531,9 +549,14 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok):
     achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
     traffic, traffic_src, traffic_match = None, None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if meta["traffic_ok"] and not c3 and os.path.exists(tj) and args.rows_per_group == 4000 and args.groups == 1248:
+    if meta["traffic_ok"] and not c3 and not glm and not args.variant and os.path.exists(tj) and args.rows_per_group == 4000 and args.groups == 1248:
         tr = json.load(open(tj))
         traffic, traffic_src = tr["k_rows_bytes_per_launch"], tr["source"]
+        traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
+    tjg = os.path.join(ROOT, "profiles", "traffic_glm.json")
+    if meta["traffic_ok"] and glm and os.path.exists(tjg) and args.glm_rows == 1_000_000 and args.glm_cols == 512:
+        tr = json.load(open(tjg))
+        traffic, traffic_src = tr["k_glm_rows_bytes_per_launch"], tr["source"]
         traffic_match = tr.get("kernel_source_hash") == kernel_source_hash()
     tj3 = os.path.join(ROOT, "profiles", "traffic_c3.json")
     if meta["traffic_ok"] and c3 and os.path.exists(tj3) and args.mvn_k == 2048:
@@ -556,7 +579,8 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok):
         }
     return {
         "metric": "effective samples/sec (and leapfrog steps/sec), 10k-param hierarchical logistic regression, one NUTS chain per GPU"
-        if not c3 else "leapfrog steps/sec (and effective samples/sec), MvNormal 2048, one NUTS chain per GPU",
+        if not (c3 or glm) else "leapfrog steps/sec (and effective samples/sec), MvNormal 2048, one NUTS chain per GPU" if c3 else
+        "leapfrog steps/sec (and effective samples/sec), GLM with 1M observations x 512 covariates under NUTS, one chain per GPU",
         "value": (ess_total / T) if ess_ok else lps_total,
         "unit": "ESS/s (aggregate over chains; min-over-all-parameters bulk-ESS)" if ess_ok else "leapfrog steps/s (aggregate over chains)",
         "value_is": "ess_per_sec" if ess_ok else f"leapfrog_steps_per_sec (ESS needs steps >= {ESS_MIN_DRAWS} and warmup >= {ESS_MIN_DRAWS}; see ess_run)",
@@ -599,7 +623,7 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok):
             "frac": achieved / 8000.0,
             "frac_of_achievable_6.3TBps": achieved / 6300.0,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "algorithmic_bytes_note": None if c3 else "69 B/row = 64 (X) + 1 (y) + 4 (int32 group id); the kernel reads G+1 row pointers instead of the "
+            "algorithmic_bytes_note": None if c3 else "8 N P: one read of the fp64 design matrix per logp + gradient (y: 8 N more, not counted)" if glm else "69 B/row = 64 (X) + 1 (y) + 4 (int32 group id); the kernel reads G+1 row pointers instead of the "
             "group ids, so 4 of the 69 are bytes it avoids -- frac_traffic prices the bytes actually moved",
             "avg_launch_ms": dom_avg_ms,
             "launches_timed": int(allv[:, 4].sum()),   # (passes over the data covered by the bracketed launches)

@@ -18,7 +18,7 @@
 //   * a wave streams a CONTIGUOUS range of rows (sequential 4 KB rows: DRAM pages are used whole), the next iteration's rows are
 //     requested before the current ones are evaluated;
 //   * wave partials -> LDS -> one record per workgroup [d/dbeta (Ppad), d/dintercept, d/dsigma, logp] with plain stores;
-//     k_glm_reduce (after the kernel boundary) totals the records per column in 16 chunks of consecutive workgroups, chunks in
+//     k_glm_reduce (after the kernel boundary) totals the records per column in 64 chunks of consecutive workgroups, chunks in
 //     order -- fixed association, no floating-point atomics, bit-reproducible run to run -- and writes the node's gradient w.r.t.
 //     the constrained values of its parameters, which kernel B / the control kernel add to the elements' gradients before the
 //     chain rule of their transforms: the protocol of the mixture node (MixDev.gdense).
@@ -31,8 +31,9 @@
 
 #define GLM_BLOCK 256
 #define GLM_MAXCH 4
-#define GLM_RED_CHUNKS 16   // k_glm_reduce: records are totalled in this many chunks of consecutive workgroups, chunks in order
-#define GLM_RED_COLS 16     // columns per workgroup of k_glm_reduce
+#define GLM_RED_CHUNKS 64   // k_glm_reduce: records are totalled in this many chunks of consecutive workgroups, chunks in order
+#define GLM_RED_COLS 4      // columns per workgroup of k_glm_reduce (64 x 4: with 16 x 16 a thread added 128 - 256 records one round of
+                            // eight after the other and the reduce took 13 us at 2048 records, 90 at 4096: profiles/r04h_glm_sweep_workgroups_per_cu.txt)
 
 // all-reduce over the LPR lanes of a row's group (LPR a power of two): a fixed butterfly, the same bits in every lane of the group
 template <int LPR>
