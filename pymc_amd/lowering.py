@@ -819,6 +819,51 @@ class _Lowering:
                     return True
         return False
 
+    def _glm(self, family: int, eta, observed, sigma_node=None) -> bool:
+        """eta = [intercept +] dot(X, beta) with a constant design matrix X [N, P <= 512], beta a value variable of P elements and the
+        intercept a scalar value variable, as the location of an observed Normal, the `logit_p` of an observed Bernoulli or inside
+        the `exp` of an observed Poisson's rate  ->  the GLM node (model_spec.GlmRows; `pm.math.dot`, pymc/math.py:56)."""
+        def dot_of(n):
+            if n[0] != "dot" or n[1][0] != "const" or np.asarray(n[1][1]).ndim != 2:
+                return None
+            kb = self._as_var(n[2])
+            X = np.asarray(n[1][1], dtype="float64")
+            if kb is None or self.spec.vars[kb].transform != ms.TR_NONE or self.spec.vars[kb].size != X.shape[1] or not 1 <= X.shape[1] <= 512:
+                return None
+            return X, kb
+
+        got, icpt = dot_of(eta), None
+        if got is None and eta[0] == "add":
+            for x, y in ((eta[1], eta[2]), (eta[2], eta[1])):
+                got = dot_of(x)
+                if got is None:
+                    continue
+                ki = self._as_var(y)
+                if ki is None or self.spec.vars[ki].size != 1 or self.spec.vars[ki].transform != ms.TR_NONE:
+                    got = None
+                    continue
+                icpt = ki
+                break
+        if got is None:
+            return False
+        X, kb = got
+        y = np.asarray(observed, dtype="float64").ravel()
+        if y.size != X.shape[0]:
+            return False
+        node = ms.GlmRows(np.ascontiguousarray(X), np.ascontiguousarray(y), family, kb, intercept=icpt)
+        if family == ms.GLM_NORMAL:
+            ks = self._as_var(sigma_node)
+            if ks is not None and self.spec.vars[ks].size == 1:
+                node.sigma = ks
+            elif sigma_node[0] == "const" and np.asarray(sigma_node[1]).size == 1:
+                node.sigma_const = float(np.asarray(sigma_node[1]).reshape(-1)[0])
+            else:
+                return False
+        if self.spec.glm_rows is not None or self.spec.logit_rows is not None or self.spec.mvnormal is not None or self.spec.mixture_rows is not None:
+            raise NotLowerable("more than one dense node in a model")
+        self.spec.glm_rows = node
+        return True
+
     def _mixture(self, node) -> bool:
         """`mixture_logprob` over one batched Normal component (mixture.py:469-495, what `pm.NormalMixture` builds):
         log(sum(exp(log(weights) + Normal.logp(value[..., None], mu, sigma)), axis=-1)) -- `logsumexp` unrewritten -- with the
@@ -899,9 +944,15 @@ class _Lowering:
                     raise NotLowerable("a free Bernoulli variable is not a NUTS variable")
                 if self._logit_rows(env["p"][1], val[1]):
                     return
+                if self._glm(ms.GLM_BERNOULLI, env["p"][1], val[1]):
+                    self.spec.glm_rows.name = name
+                    return
                 t_eta = self.term(env["p"][1])
                 args = (self.term(val), t_eta)
                 self._emit(ms.D_BERNOULLI_LOGIT, args, 0.0, name)
+                return
+            if dist == ms.D_NORMAL and own is None and env["value"][0] == "const" and self._glm(ms.GLM_NORMAL, env["mu"], env["value"][1], env["sigma"]):
+                self.spec.glm_rows.name = name
                 return
             lam_direct = None
             if dist == ms.D_EXPONENTIAL and env["mu"][0] == "reciprocal":
@@ -936,6 +987,9 @@ class _Lowering:
             if res is None:
                 continue
             nodes, konst = res
+            if dist == ms.D_POISSON and nodes["mu"][0] == "exp" and self._glm(ms.GLM_POISSON, nodes["mu"][1], nodes["value"][1]):
+                self.spec.glm_rows.name = name
+                return
             lowered = {a: self.term(nodes[a]) for a in argnames[1:] + argnames[:1]}
             args = tuple(lowered[a] for a in argnames)
             self._emit(dist, args, konst, name)

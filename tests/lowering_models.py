@@ -207,6 +207,63 @@ def _normal_mixture_softmax_built():
     return b.build()
 
 
+XG = np.random.default_rng(21).normal(size=(50, 6)) * 0.5
+YG_N = np.random.default_rng(22).normal(size=50)
+YG_B = (np.random.default_rng(23).random(50) < 0.45).astype("float64")
+YG_P = np.random.default_rng(24).poisson(1.7, size=50).astype("float64")
+
+
+def glm_normal():
+    """`pm.Normal("y", mu=alpha + pm.math.dot(X, beta), sigma=sigma, observed=y)`: the linear predictor is a `Dot` node."""
+    m = sg.StubModel()
+    alpha = m.Normal("alpha", 0.0, 5.0)
+    beta = m.Normal("beta", 0.0, 1.0, shape=(6,))
+    sigma = m.HalfNormal("sigma", 1.0)
+    m.Normal("y", alpha + m.math.dot(XG, beta), sigma, observed=YG_N)
+    return m
+
+
+def _glm_normal_built():
+    b = ModelBuilder()
+    alpha = b.Normal("alpha", 0.0, 5.0)
+    beta = b.Normal("beta", 0.0, 1.0, shape=6)
+    sigma = b.HalfNormal("sigma", 1.0)
+    b.GLM("y", XG, beta, YG_N, family="normal", intercept=alpha, sigma=sigma)
+    return b.build()
+
+
+def glm_bernoulli():
+    """`pm.Bernoulli("y", logit_p=pm.math.dot(X, beta) + alpha, observed=y)` (the intercept written second)."""
+    m = sg.StubModel()
+    alpha = m.Normal("alpha", 0.0, 5.0)
+    beta = m.Normal("beta", 0.0, 1.0, shape=(6,))
+    m.Bernoulli("y", logit_p=m.math.dot(XG, beta) + alpha, observed=YG_B)
+    return m
+
+
+def _glm_bernoulli_built():
+    b = ModelBuilder()
+    alpha = b.Normal("alpha", 0.0, 5.0)
+    beta = b.Normal("beta", 0.0, 1.0, shape=6)
+    b.GLM("y", XG, beta, YG_B, family="bernoulli", intercept=alpha)
+    return b.build()
+
+
+def glm_poisson():
+    """`pm.Poisson("y", mu=pm.math.exp(XG @ beta), observed=y)`: no intercept, the matrix product written with `@`, known sigma n/a."""
+    m = sg.StubModel()
+    beta = m.Normal("beta", 0.0, 1.0, shape=(6,))
+    m.Poisson("y", m.math.exp(sg.as_tensor(XG) @ beta), observed=YG_P)
+    return m
+
+
+def _glm_poisson_built():
+    b = ModelBuilder()
+    beta = b.Normal("beta", 0.0, 1.0, shape=6)
+    b.GLM("y", XG, beta, YG_P, family="poisson")
+    return b.build()
+
+
 def _built(fn, *a):
     return fn(*a, ModelBuilder()).build()
 
@@ -232,5 +289,8 @@ ENTRIES = {
     "varying_intercepts_and_slopes": (varying_intercepts_and_slopes, lambda: _built(varying_intercepts_and_slopes)),
     "normal_mixture_marginal": (normal_mixture_marginal, _normal_mixture_marginal_built),
     "normal_mixture_softmax": (normal_mixture_softmax, _normal_mixture_softmax_built),
+    "glm_normal": (glm_normal, _glm_normal_built),
+    "glm_bernoulli": (glm_bernoulli, _glm_bernoulli_built),
+    "glm_poisson": (glm_poisson, _glm_poisson_built),
 }
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")

@@ -62,6 +62,8 @@ class Variable:
     def __or__(self, o): return self._bin(o, OR)
     def __getitem__(self, idx): return Variable(Apply(AdvancedSubtensor1(), [self, as_tensor(idx)]), shape=(len(np.asarray(idx)),) + self.type.shape[1:])
     def sum(self, axis=None): return Variable(Apply(Sum(axis), [self]), shape=())
+    def __matmul__(self, o): return pt.dot(self, o)
+    def __rmatmul__(self, o): return pt.dot(o, self)
     def copy(self): return self          # (`log_jac_det(...).copy()`, transform_value.py:102: an identity node in PyTensor)
 
     @property
@@ -100,6 +102,10 @@ class AdvancedSubtensor1:
 class Sum:
     def __init__(self, axis):
         self.axis = axis
+
+
+class Dot:
+    """`pytensor.tensor.math.Dot`: what `pm.math.dot(X, beta)` / `X @ beta` puts in the graph for a matrix and a vector."""
 
 
 class CheckParameterValue:
@@ -246,6 +252,11 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         return Variable(Apply(DimShuffle(), [x]), shape=tuple(shp))
 
     isclose = staticmethod(lambda a, b: elemwise(IsClose, a, b))
+
+    @staticmethod
+    def dot(a, b):
+        a, b = as_tensor(a), as_tensor(b)
+        return Variable(Apply(Dot(), [a, b]), shape=a.type.shape[:-1] + b.type.shape[1:])
 
     @staticmethod
     def softmax(x, axis=-1):
@@ -471,6 +482,7 @@ class _PtMath:
     """`pm.math.*` as the model code calls it: the `pytensor.tensor` functions of the same name (pymc/math.py re-exports them)."""
 
     softmax = pt.softmax
+    dot = pt.dot
 
     exp, log, log1p, sqrt, abs = pt.exp, pt.log, pt.log1p, pt.sqrt, pt.abs
     sigmoid = invlogit = pt.sigmoid
@@ -642,7 +654,7 @@ def dump_model(m) -> dict:
     }
 
 
-_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax)}
+_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot)}
 
 
 class FrozenModel:

@@ -227,3 +227,23 @@ def test_configs3_shape_glm_nuts_logp_grad_and_integer_prefix():
         for k in ("mean_tree_accept", "energy", "model_logp"):
             np.testing.assert_allclose(dev[i][k], ref_stats[0][i][k], rtol=1e-7, atol=1e-9, err_msg=f"{i} {k}")
     res["step"].close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["glm_normal", "glm_bernoulli", "glm_poisson"])
+def test_reference_built_graphs_with_a_dot_lower_to_the_glm_node_and_run_on_the_device(name):
+    """graph -> spec -> device: the committed graphs (tests/golden/ref_graphs.npz) of models whose likelihood's parameter contains
+    `pm.math.dot(X, beta)` -- built by the reference's own `Normal.dist / logp`, `Bernoulli.dist(logit_p=) / logp`, `Poisson.logp`
+    bodies -- lower to the GLM node; logp / gradient on the device against the oracle, and a NUTS run with the oracle's integers."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lowering_models as lm
+    import stubgraph as sg
+
+    from pymc_amd.lowering import lower_to_spec
+
+    spec = lower_to_spec(sg.FrozenModel(sg.load_models(lm.FIXTURE)[name]))
+    assert spec.glm_rows is not None and spec.glm_rows.X.shape == (50, 6)
+    _check(spec).close()
+    _nuts_integers(spec, tune=30, draws=10, seed=3)

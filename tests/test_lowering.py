@@ -470,6 +470,13 @@ def test_committed_reference_graphs_lower_to_the_builder_spec(name):
     assert [(v.name, v.value_name, tuple(v.shape), v.transform, v.offset) for v in spec.vars] == \
         [(v.name, v.value_name, tuple(v.shape), v.transform, v.offset) for v in want.vars]
     assert len(spec.factors) == len(want.factors) and [(f.dist, f.size, f.name) for f in spec.factors] == [(f.dist, f.size, f.name) for f in want.factors]
+    # the dense nodes: the same node kind, wired to the same variables, over the same data
+    for attr in ("logit_rows", "mvnormal", "mixture_rows", "glm_rows"):
+        assert (getattr(spec, attr, None) is None) == (getattr(want, attr, None) is None), attr
+    if want.glm_rows is not None:
+        ga, gb = spec.glm_rows, want.glm_rows
+        assert (ga.family, ga.beta, ga.intercept, ga.sigma, ga.sigma_const, ga.name) == (gb.family, gb.beta, gb.intercept, gb.sigma, gb.sigma_const, gb.name)
+        assert np.array_equal(ga.X, gb.X) and np.array_equal(ga.y, gb.y)
     rng = np.random.default_rng(5)
     for _ in range(3):
         q = rng.normal(size=spec.n) * 0.5
