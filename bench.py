@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="self-launched ranks are stopped after this many seconds")
     ap.add_argument("--ess-tune", type=int, default=1000, help="warmup of the separate ESS chain run when --steps/--warmup are too short for an ESS (0 disables)")
     ap.add_argument("--ess-draws", type=int, default=1000)
+    ap.add_argument("--ess-chains", type=int, default=4, help="chains of the ESS run on each GPU, one after the other (world == 1 only): min-ESS and "
+                    "R-hat over several chains instead of a one-chain estimate (0 / 1: the single chain)")
     return ap.parse_args()
 
 
@@ -146,6 +148,16 @@ def cpu_worker_main(args):
     print(json.dumps({"core": args.cpu_worker, "leapfrog_steps_per_sec": lps}), flush=True)
 
 
+def _measured_cpu_ess(args):
+    """The oracle's own chains of this shape (committed fixture: four chains x (1000 + 1000), one per core, concurrently): min
+    bulk-ESS of the pooled chains / their wall time -- measured where the fixture was made, stated with its host."""
+    oc = oracle_convergence(args)
+    if not oc or oc.get("oracle_ess_per_sec_measured") is None:
+        return None
+    return {"value": oc["oracle_ess_per_sec_measured"], "unit": "ESS/s (min bulk-ESS over all parameters, 4 chains on 4 cores concurrently, wall time incl. tuning)",
+            "min_ess": oc["oracle_min_ess"], "wall_s": max(oc["oracle_wall_s_per_chain"]), "host": oc["oracle_wall_host"], "source": oc["source"]}
+
+
 def cpu_baseline_c2(args, spec, q, step_size, inv_mass, n_leap, ess_per_leapfrog):
     import subprocess
     import tempfile
@@ -187,6 +199,7 @@ def cpu_baseline_c2(args, spec, q, step_size, inv_mass, n_leap, ess_per_leapfrog
         "unit": "leapfrog steps/s" if ess_derived is None else "ESS/s (derived: measured leapfrog steps/s x the GPU run's ESS per leapfrog)",
         "leapfrog_steps_per_sec": lps_c1,
         "ess_per_sec_derived": ess_derived,
+        "ess_per_sec_measured": _measured_cpu_ess(args),
         "cores": 1,
         "kind": "port",
         "host_cores_available": os.cpu_count(),
@@ -454,6 +467,29 @@ def run_rank(args):
                        "leapfrogs_total": float(sum(s_["tree_size"] for s_ in st_all)),
                        "sampling_s_post_warmup": float(sum(s_["perf_counter_diff"] for s_ in st_post)),
                        "step_size_bar": float(st_all[-1]["step_size_bar"]), "convergence": cv}
+            if world == 1 and args.ess_chains > 1:
+                # the same run with several chains on this GPU, one after the other (the reference's
+                # `pm.sample(chains=4, cores=1)`, mcmc.py:1385-1430), so that min-ESS and R-hat are multi-chain estimates -- the
+                # reference's benchmark divides the ESS of ALL chains by the total sampling time (benchmarks.py:180-198)
+                post = [d_all[args.ess_tune:]]
+                walls = [wall]
+                more = get_random_generator(args.seed + 1).spawn(args.ess_chains)
+                for cc in range(1, args.ess_chains):
+                    start = {k_: np.asarray(v_) + more[cc].uniform(-1, 1, size=np.shape(v_)) for k_, v_ in points[rank].items()} \
+                        if isinstance(points[rank], dict) else np.asarray(points[rank]) + more[cc].uniform(-1, 1, size=np.shape(points[rank]))
+                    step.sampling_state = initial_state
+                    t2 = time.perf_counter()
+                    d_c, _ = sample_chain(step, start, more[cc], args.ess_tune, args.ess_draws)
+                    walls.append(time.perf_counter() - t2)
+                    post.append(d_c[args.ess_tune:])
+                stack = np.stack(post)
+                ess_c, rh_c = ess_bulk_many(stack), rhat_many(stack)
+                ess_run["multi_chain"] = {
+                    "chains": args.ess_chains, "how": "one after the other on this GPU, each tuned on its own from a jittered start",
+                    "wall_s_total": float(sum(walls)), "wall_s_per_chain": [float(x) for x in walls],
+                    "min_ess": float(ess_c.min()), "median_ess": float(np.median(ess_c)), "rhat_max": float(np.nanmax(rh_c)),
+                    "n_rhat_gt_1.01": int((rh_c > 1.01).sum()), "ess_per_sec": float(ess_c.min() / sum(walls)),
+                }
         if c3:
             workload = f"C3 mvn-{args.mvn_k}: MvNormal, full {args.mvn_k}x{args.mvn_k} covariance, n={spec.n}"
             aligned = int(step._logp_dlogp_func.model_scalar("mvn_row_aligned"))
@@ -531,7 +567,13 @@ def oracle_convergence(args):
             "oracle_rhat_max": float(k["rhat"].max()), "oracle_n_rhat_gt_1.01": int((k["rhat"] > 1.01).sum()),
             "oracle_min_ess": float(k["ess_bulk"].min()), "oracle_median_ess": float(np.median(k["ess_bulk"])),
             "oracle_mean_tree_size": float(k["stat_tree_size"][:, tune:].mean()),
-            "oracle_step_size_bar": [float(x) for x in k["stat_step_size_bar"][:, -1]]}
+            "oracle_step_size_bar": [float(x) for x in k["stat_step_size_bar"][:, -1]],
+            # MEASURED CPU ESS/s of the restated reference sampler: the chains' own wall time, tuning included,
+            # on the host that generated the fixture (not this box: a 2.7-hour chain is not a bench leg) -- min bulk-ESS over
+            # all parameters of the pooled chains / the time the concurrently running chains took
+            "oracle_wall_s_per_chain": [float(x) for x in k["wall_s"]] if "wall_s" in k.files else None,
+            "oracle_wall_host": str(k["wall_host"]) if "wall_host" in k.files else None,
+            "oracle_ess_per_sec_measured": float(k["ess_bulk"].min() / k["wall_s"].max()) if "wall_s" in k.files else None}
 
 
 def report(args, world, allv, convs, ess_runs, meta, ess_ok):
@@ -575,6 +617,7 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok):
             "leapfrog_steps_per_sec_post_warmup_per_chain": [e["leapfrogs_post_warmup"] / max(e["sampling_s_post_warmup"], 1e-9) for e in er],
             "mean_tree_size_post_warmup": sum(e["leapfrogs_post_warmup"] for e in er) / (args.ess_draws * world),
             "step_size_bar": [e["step_size_bar"] for e in er], "convergence": [e["convergence"] for e in er],
+            "multi_chain": er[0].get("multi_chain") if world == 1 else None,
             "oracle": oracle_convergence(args),
         }
     return {
