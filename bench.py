@@ -328,21 +328,50 @@ def run_rank(args):
     import torch
 
     dist = None
+    rccl = {"group": None, "ranks": 0, "why_not": None}
     if args.share_gpu or stub:
         local = 0
-        args.backend = "gloo"   # RCCL refuses two ranks on one device ("Duplicate GPU detected")
+        if os.environ.get("PYMC_AMD_BENCH_STUB_TRY_RCCL") != "1":   # (the test of the fall-back below leaves RCCL requested on a box without a GPU)
+            args.backend = "gloo"   # RCCL refuses two ranks on one device ("Duplicate GPU detected")
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
+        # The control plane -- barriers around the timed region, the gather of the ranks' small result records -- is a gloo group
+        # on the host: it cannot fail for a reason that has to do with the GPU runtimes, and chains exchange
+        # nothing on the data path.  RCCL is brought up NEXT TO it, as a second group, for what the north star gives it (the final
+        # gather of device-resident results, the opt-in pooled adaptation); it is probed with one all-reduce whose answer every
+        # rank checks, and the ranks agree through the gloo group whether it is usable.  If it is not, the run goes on over gloo
+        # and says so in `collective_backend` instead of dying in the launcher.
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
         if not stub:
             torch.cuda.set_device(local)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(args.backend)
+            ok = 1
+            try:
+                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                one = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local))
+                dist.all_reduce(one, group=grp)
+                torch.cuda.synchronize()
+                if int(round(float(one.item()))) != world:
+                    raise RuntimeError(f"all-reduce of ones over RCCL gave {float(one.item())}, not {world}")
+                rccl["group"] = grp
+            except Exception as e:   # noqa: BLE001  (whatever RCCL / the runtime raises: the bench must still produce its line)
+                ok = 0
+                rccl["why_not"] = f"{type(e).__name__}: {str(e)[:300]}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                rccl["ranks"] = world
+            else:
+                rccl["group"] = None
+                whys = [None] * world
+                dist.all_gather_object(whys, rccl["why_not"])
+                rccl["why_not"] = next((w_ for w_ in whys if w_), "another rank could not bring RCCL up")
+                args.backend = "gloo"
     elif not stub:
         torch.cuda.set_device(0)
-    comm_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     def barrier():
         if not stub:
@@ -520,9 +549,17 @@ def run_rank(args):
         meta = dict(alg_bytes=alg_bytes, n=int(spec.n), N=N, workload=workload, kernel=kernel, schedule=schedule, traffic_ok=True)
 
     if dist is not None:
-        t = torch.tensor(vec, dtype=torch.float64, device=comm_dev)
-        allt = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
+        # the final gather: over RCCL from device memory when it is up (one 40-byte record per rank here; `sample(...)` gathers
+        # the draws the same way, pymc_amd/sampling.py), over the host group otherwise
+        if rccl["group"] is not None:
+            t = torch.tensor(vec, dtype=torch.float64, device=torch.device("cuda", local))
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t, group=rccl["group"])
+            torch.cuda.synchronize()
+        else:
+            t = torch.tensor(vec, dtype=torch.float64)
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
         allv = torch.stack(allt).cpu().numpy()
         convs = [None] * world
         dist.all_gather_object(convs, conv)
@@ -533,7 +570,7 @@ def run_rank(args):
         convs = [conv]
         ess_runs = [ess_run]
     if rank == 0:
-        out = report(args, world, allv, convs, ess_runs, meta, ess_ok)
+        out = report(args, world, allv, convs, ess_runs, meta, ess_ok, rccl)
         if world == 1 and args.cpu_leapfrogs > 0 and not stub:
             inv_mass = step._vector("var")
             eps = float(step._scalar("step_size"))
@@ -576,7 +613,7 @@ def oracle_convergence(args):
             "oracle_ess_per_sec_measured": float(k["ess_bulk"].min() / k["wall_s"].max()) if "wall_s" in k.files else None}
 
 
-def report(args, world, allv, convs, ess_runs, meta, ess_ok):
+def report(args, world, allv, convs, ess_runs, meta, ess_ok, rccl=None):
     """The one JSON line (rank 0)."""
     K, W = args.steps, args.warmup
     c3 = args.workload == "c3"
@@ -644,8 +681,10 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok):
         },
         "launch": ("self-launched: bench.py started one process per GPU" if os.environ.get("PYMC_AMD_BENCH_SELF_LAUNCHED") else
                    "launched by torch.distributed.run" if world > 1 else "single process"),
-        "collective_backend": None if world == 1 else ("rccl" if args.backend == "nccl" else args.backend),
-        "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+        "collective_backend": None if world == 1 else ("rccl (final gather; barriers and result records over a gloo host group)" if (rccl and rccl["ranks"]) else
+                                                       "gloo" + (f" (RCCL could not be brought up: {rccl['why_not']})" if (rccl and rccl["why_not"]) else "")),
+        # ranks that answered the RCCL probe (an all-reduce of ones that must sum to the world size on every rank)
+        "rccl_ranks": int(rccl["ranks"]) if (rccl and world > 1) else 0,
         "schedule": meta["schedule"],
         "leapfrog_steps_per_sec": lps_total,
         "leapfrog_steps_per_sec_per_chain": [float(x) for x in lps_chain],

@@ -40,6 +40,21 @@ def test_gpus_2_self_launches_two_ranks_and_prints_one_line():
     assert out["roofline"]["achieved"] == 0.0                # a stub line claims no kernel
 
 
+@pytest.mark.timeout(300)
+def test_rccl_that_cannot_come_up_falls_back_to_the_host_group_and_says_so():
+    """the barriers and the gather of the result records run over a gloo host group; RCCL is a second
+    group, probed with an all-reduce every rank checks.  On this box it cannot come up (no GPU): every rank must agree on that
+    through the host group, the run must finish, and the line must say what happened -- `rccl_ranks` 0, the reason in
+    `collective_backend` -- instead of the launch dying or hanging."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--stub-engine", "--backend", "nccl", "--steps", "10", "--warmup", "2"],
+                       capture_output=True, text=True, env=_env(PYMC_AMD_BENCH_STUB_TRY_RCCL="1"), timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 0
+    assert out["collective_backend"].startswith("gloo (RCCL could not be brought up")
+    assert len(out["leapfrog_steps_per_sec_per_chain"]) == 2
+
+
 @pytest.mark.timeout(120)
 def test_gpus_n_refuses_when_fewer_devices_are_visible():
     """No silent 1-GPU run under `--gpus 8`: exit code 2 and a message (this box has no GPU at all)."""
