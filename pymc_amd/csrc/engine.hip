@@ -1044,11 +1044,13 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       }
     }
     gm.y = m->keep(dev_upload(s->glm_y, (size_t)gm.N));
-    // grid: every CU gets NUTS_GLM_WG_PER_CU workgroups of four waves (default 12: 48 waves per CU over time, each with one
-    // row-iteration in flight and one being evaluated -- 643 us per pass at configs[3]'s shape against 681 at 8 and 672 at 4,
-    // profiles/r04h_glm_sweep_workgroups_per_cu.txt), fewer when there are not enough rows to give every wave a few iterations
+    // grid: every CU gets NUTS_GLM_WG_PER_CU workgroups of four waves (default 4: 16 waves per CU, each with one row-iteration in
+    // flight and one being evaluated).  Measured at configs[3]'s shape on two boxes (profiles/r04h_glm_sweep_workgroups_per_cu.txt,
+    // r04i): 1421 / 1381 / 1380 / 1328 and 1426 / 1387 / 1365 / 1345 leapfrog/s at 4 / 8 / 12 / 16 -- more workgroups shave the
+    // tail of the pass itself but leave more records for k_glm_reduce and a longer launch ramp; the whole leapfrog is fastest at 4
+    // (rocprofv3, same command: 4351 ms of GPU time for 7610 launches at 4 against 5591 ms for 8826 at 12).
     const int64_t iters = (gm.N + (WAVE / lpr) - 1) / (WAVE / lpr);
-    int64_t nwg = (int64_t)cus * std::max(1, env_int("NUTS_GLM_WG_PER_CU", 12));
+    int64_t nwg = (int64_t)cus * std::max(1, env_int("NUTS_GLM_WG_PER_CU", 4));
     nwg = std::max<int64_t>(1, std::min<int64_t>(nwg, (iters + 4 * (GLM_BLOCK / WAVE) - 1) / (4 * (GLM_BLOCK / WAVE))));
     gm.nwg = (int)nwg;
     gm.part = m->keep(dev_alloc<double>((size_t)gm.nwg * (gm.Ppad + 4)));

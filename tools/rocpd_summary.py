@@ -16,13 +16,17 @@ def kernel_stats(path):
     cur = sqlite3.connect(path).cursor()
     rows = list(cur.execute(
         "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc"))
+    med = {}
+    for name, dur in cur.execute("select name, end-start from kernels"):
+        med.setdefault(name, []).append(dur)
+    med = {k: sorted(v)[len(v) // 2] for k, v in med.items()}
     tot = sum(r[2] for r in rows) or 1
     t0, t1 = list(cur.execute("select min(start), max(end) from kernels"))[0]
     print(f"# kernel trace: {path}")
     print(f"# GPU busy {tot/1e6:.3f} ms over a {(t1-t0)/1e6:.3f} ms span ({100*tot/(t1-t0):.1f}% busy)")
-    print(f"{'kernel':70s} {'calls':>8s} {'total_ms':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+    print(f"{'kernel':70s} {'calls':>8s} {'total_ms':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'median_us':>10s}")
     for r in rows:
-        print(f"{r[0][:70]:70s} {r[1]:8d} {r[2]/1e6:11.3f} {r[3]/1e3:9.2f} {r[4]/1e3:9.2f} {r[5]/1e3:9.2f} {100*r[2]/tot:6.2f}")
+        print(f"{r[0][:70]:70s} {r[1]:8d} {r[2]/1e6:11.3f} {r[3]/1e3:9.2f} {r[4]/1e3:9.2f} {r[5]/1e3:9.2f} {100*r[2]/tot:6.2f} {med[r[0]]/1e3:10.2f}")
 
 
 def gap_stats(path):
