@@ -117,7 +117,10 @@ def build_tree(v, memo: Optional[dict] = None):
         return out
     op, ins = owner.op, list(owner.inputs)
     name = _opname(op)
-    if name in ("DimShuffle", "Cast", "SpecifyShape", "Rebroadcast", "Unbroadcast"):
+    if name == "Blockwise":                       # a core op batched over leading dimensions (`Blockwise(SolveTriangular)`): its core op decides
+        op = op.core_op
+        name = _opname(op)
+    if name in ("DimShuffle", "Cast", "SpecifyShape", "Rebroadcast", "Unbroadcast", "ExpandDims"):
         out = build_tree(ins[0], memo)
     elif name in ("CheckParameterValue", "Assert", "CheckAndRaise"):
         out = build_tree(ins[0], memo)          # the device applies its own parameter checks (model_dev.h KILL_UNLESS)
@@ -147,13 +150,66 @@ def build_tree(v, memo: Optional[dict] = None):
             else:
                 out = ("switch" if sn == "where" else sn, *kids)
     elif name in ("Sum", "CAReduce"):
-        out = ("sum", getattr(op, "axis", None), build_tree(ins[0], memo))
+        kid = build_tree(ins[0], memo)
+        ax = getattr(op, "axis", None)
+        if kid[0] == "const":                    # a reduction of a constant (`log(diag(cholesky(cov))).sum()` with a constant covariance)
+            out = _const(np.sum(kid[1], axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax))
+        else:
+            out = ("sum", ax, kid)
+    elif name == "Shape":                         # `x.shape`: static in every model the IR takes (value variables have fixed shapes)
+        shp = getattr(getattr(ins[0], "type", None), "shape", None)
+        if shp is None or any(d is None for d in shp):
+            raise NotLowerable("a shape that is not static")
+        out = _const(np.asarray(shp, dtype="float64"))
+    elif name == "Subtensor":                     # basic indexing: of a constant it folds; `x[0]` of a leading dimension of one is x
+        kid = build_tree(ins[0], memo)
+        idx = tuple(getattr(op, "idx_list", ()))
+        if len(ins) > 1:
+            raise NotLowerable("Subtensor with a symbolic index")
+        if kid[0] == "const":
+            out = _const(np.asarray(kid[1])[idx if len(idx) != 1 else idx[0]])
+        else:
+            shp = getattr(getattr(ins[0], "type", None), "shape", None)
+            if len(idx) == 1 and idx[0] == 0 and shp is not None and len(shp) >= 1 and shp[0] == 1:
+                out = kid
+            else:
+                raise NotLowerable("Subtensor of a non-constant beyond x[0] of a leading dimension of one")
+    elif name == "Transpose":
+        kid = build_tree(ins[0], memo)
+        out = _const(np.swapaxes(kid[1], -1, -2)) if kid[0] == "const" else ("transpose", kid)
+    elif name == "Cholesky":
+        kid = build_tree(ins[0], memo)
+        if kid[0] != "const":
+            raise NotLowerable("Cholesky of a non-constant matrix (the MvNormal node takes a constant covariance)")
+        L = np.linalg.cholesky(np.asarray(kid[1], dtype="float64"))
+        out = _const(L if getattr(op, "lower", True) else np.swapaxes(L, -1, -2))
+    elif name == "MatrixInverse":
+        kid = build_tree(ins[0], memo)
+        if kid[0] != "const":
+            raise NotLowerable("inverse of a non-constant matrix")
+        out = _const(np.linalg.inv(np.asarray(kid[1], dtype="float64")))
+    elif name == "ExtractDiag":
+        kid = build_tree(ins[0], memo)
+        if kid[0] != "const":
+            raise NotLowerable("diagonal of a non-constant matrix")
+        out = _const(np.diagonal(kid[1], axis1=-2, axis2=-1))
+    elif name in ("SolveTriangular", "Solve"):
+        a, b = build_tree(ins[0], memo), build_tree(ins[1], memo)
+        if a[0] == "const" and b[0] == "const":
+            import scipy.linalg
+
+            out = _const(scipy.linalg.solve_triangular(a[1], b[1].T, lower=getattr(op, "lower", False)).T)
+        else:
+            out = ("solve_lower" if getattr(op, "lower", False) else "solve_upper", a, b)
     elif name in ("AdvancedSubtensor1", "AdvancedSubtensor"):
         out = ("take", build_tree(ins[0], memo), build_tree(ins[1], memo))
-    elif name == "Dot":
-        out = ("dot", build_tree(ins[0], memo), build_tree(ins[1], memo))
+    elif name in ("Dot", "Matmul"):
+        a, b = build_tree(ins[0], memo), build_tree(ins[1], memo)
+        out = _const(np.asarray(a[1]) @ np.asarray(b[1])) if (a[0] == "const" and b[0] == "const") else ("dot", a, b)
     elif name == "Softmax":
         out = ("softmax", build_tree(ins[0], memo))
+    elif name == "TakeAlongAxis":
+        out = ("take_along_axis", build_tree(ins[0], memo), build_tree(ins[1], memo))
     elif name in ("All", "Any", "MakeVector"):
         out = (name.lower(), *[build_tree(i, memo) for i in ins])
     else:
@@ -633,9 +689,18 @@ def _match_truncnormal(node):
 # the walker
 # ---------------------------------------------------------------------------
 class _Lowering:
-    def __init__(self, value_vars, transforms, shapes):
+    def __init__(self, value_vars, transforms, shapes, extra_vars=(), extra_values=None):
         self.spec = ms.ModelSpec()
         self.var_id: Dict[int, int] = {}
+        # value variables that are inputs of the log-density but not of its gradient (discrete variables another step method
+        # updates; model/core.py:142-190 `extra_vars`): data vectors the caller rewrites (`set_extra_values`), registered by name
+        self.extra_id: Dict[int, int] = {}
+        self._cat: Dict[int, np.ndarray] = {}    # data id of a Categorical variable -> its constant probabilities
+        for v in extra_vars:
+            val = np.ascontiguousarray(np.asarray((extra_values or {})[v.name], dtype="float64").ravel())
+            self.spec.data.append(val)
+            self.extra_id[id(v)] = len(self.spec.data) - 1
+            self.spec.extra[v.name] = len(self.spec.data) - 1
         off = 0
         for v in value_vars:
             tr, lo, hi = transforms.get(v.name, (ms.TR_NONE, 0.0, 1.0))
@@ -686,6 +751,8 @@ class _Lowering:
                         self._gather_ids[key] = len(self.spec.data) - 1
                     return ms.Operand(ms.OP_GATHER, float(self._gather_ids[key]), kv)
             return None
+        if node[0] == "input" and id(node[1]) in self.extra_id:
+            return ms.Operand(ms.OP_DATA, 0.0, self.extra_id[id(node[1])])
         if node[0] == "const":
             arr = np.asarray(node[1], dtype="float64")
             if arr.size == 1:
@@ -819,6 +886,96 @@ class _Lowering:
                     return True
         return False
 
+    def _categorical(self, node) -> bool:
+        """`Categorical.logp` (discrete.py:1171-1205) of a DISCRETE value variable c with constant probabilities p:
+        switch(or(c < 0, c > k - 1), -inf, log(take_along_axis(p, clip(c, 0, k - 1)[..., None], -1))).  The variable is an extra
+        input; the factor is remembered and becomes the `log w[c_i]` part of the conditional mixture node when an observed Normal
+        indexed by the same c follows (`_mixture_conditional`)."""
+        env: Dict[str, Any] = {}
+        tmpl = ("switch", ("or", ("lt", W("c"), K(0)), ("gt", W("c"), W("km1"))), K(-math.inf),
+                ("log", ("take_along_axis", W("p"), ("clip", W("c"), K(0), W("km1")))))
+        if not unify(tmpl, node, env):
+            return False
+        c, p_, km1 = env["c"], env["p"], _num(env["km1"])
+        if c[0] != "input" or id(c[1]) not in self.extra_id or p_[0] != "const" or km1 is None:
+            return False
+        w = np.asarray(p_[1], dtype="float64").reshape(-1)
+        if w.size != int(km1) + 1:
+            return False
+        self._cat[self.extra_id[id(c[1])]] = w
+        return True
+
+    def _mixture_conditional(self, val, mu_n, sg_n) -> bool:
+        """y ~ Normal(mu[c], sigma | sigma[c]) observed, c a Categorical extra variable seen before (`_categorical`)  ->  the
+        mixture node in its conditional form (model_spec.MixtureRows with `assign`): logp_i = log w[c_i] + Normal.logp(y_i | mu[c_i],
+        sigma[c_i]) -- the Categorical factor and this one together (discrete.py:1179-1205, continuous.py:526-532)."""
+        if val[0] != "const" or mu_n[0] != "take" or mu_n[2][0] != "input" or id(mu_n[2][1]) not in self.extra_id:
+            return False
+        did = self.extra_id[id(mu_n[2][1])]
+        km = self._as_var(mu_n[1])
+        if km is None or did not in self._cat:
+            return False
+        K_ = self.spec.vars[km].size
+        w = self._cat[did]
+        if w.size != K_:
+            return False
+        y = np.ascontiguousarray(val[1], dtype="float64").ravel()
+        if y.size != self.spec.data[did].size:
+            return False
+        node_ = ms.MixtureRows(y, K_, km, name="y")
+        if sg_n[0] == "const":
+            node_.sigma_const = np.ascontiguousarray(np.broadcast_to(np.asarray(sg_n[1], dtype="float64"), (K_,)))
+        elif sg_n[0] == "take" and sg_n[2][0] == "input" and sg_n[2][1] is mu_n[2][1] and self._as_var(sg_n[1]) is not None \
+                and self.spec.vars[self._as_var(sg_n[1])].size == K_:
+            node_.sigma = self._as_var(sg_n[1])
+        else:
+            return False
+        if not np.isclose(w.sum(), 1.0):
+            raise NotLowerable("mixture weights that do not sum to one")
+        node_.w_const = np.ascontiguousarray(w)
+        node_.assign = did
+        if self.spec.mixture_rows is not None or self.spec.logit_rows is not None or self.spec.mvnormal is not None or self.spec.glm_rows is not None:
+            raise NotLowerable("more than one dense node in a model")
+        self.spec.mixture_rows = node_
+        del self._cat[did]
+        return True
+
+    def _mvnormal(self, node, own: Optional[int]) -> bool:
+        """`MvNormal.logp` (multivariate.py:275-295 over `quaddist_chol`, :165-185): norm - 0.5 * quaddist - logdet with
+        quaddist = sum(solve_lower(cholesky(cov), value - mu) ** 2, axis=-1), logdet = sum(log(diag(cholesky(cov)))), norm =
+        -0.5 k log(2 pi) -- cov (or chol / tau, through `quaddist_matrix`) and mu constants, the value one whole free variable
+        ->  the MvNormal node (model_spec.MvNormalNode; the device evaluates it through the precision matrix or the inverse
+        Cholesky factor).  The constant parts arrive folded: they are checked numerically against the factor that was matched."""
+        if own is None:
+            return False
+        env: Dict[str, Any] = {}
+        if not unify(("sub", ("sub", W("norm"), ("mul", K(0.5), W("quad"))), W("logdet")), node, env):
+            return False
+        q = env["quad"]
+        if q[0] != "sum" or q[2][0] not in ("pow", "sqr"):
+            return False
+        if q[2][0] == "pow" and not (_num(q[2][2]) is not None and _close(_num(q[2][2]), 2.0)):
+            return False
+        sol = q[2][1]
+        if sol[0] != "solve_lower" or sol[1][0] != "const" or sol[2][0] != "sub":
+            return False
+        L = np.asarray(sol[1][1], dtype="float64")
+        val, mu_n = sol[2][1], sol[2][2]
+        if self._as_var(val) != own or mu_n[0] != "const" or L.ndim != 2 or L.shape[0] != L.shape[1]:
+            return False
+        k = L.shape[0]
+        fv = self.spec.vars[own]
+        if fv.size != k or fv.transform != ms.TR_NONE:
+            return False
+        norm, logdet = _num(env["norm"]), _num(env["logdet"])
+        if norm is None or logdet is None or not _close(norm, -0.5 * k * math.log(2.0 * math.pi)) or not _close(logdet, float(np.sum(np.log(np.diag(L))))):
+            return False
+        if self.spec.mvnormal is not None or self.spec.logit_rows is not None or self.spec.mixture_rows is not None or self.spec.glm_rows is not None:
+            raise NotLowerable("more than one dense node in a model")
+        mu = np.ascontiguousarray(np.broadcast_to(np.asarray(mu_n[1], dtype="float64").reshape(-1) if np.asarray(mu_n[1]).size > 1 else np.asarray(mu_n[1], dtype="float64").reshape(()), (k,)))
+        self.spec.mvnormal = ms.MvNormalNode(own, mu, L @ L.T, fv.name)
+        return True
+
     def _glm(self, family: int, eta, observed, sigma_node=None) -> bool:
         """eta = [intercept +] dot(X, beta) with a constant design matrix X [N, P <= 512], beta a value variable of P elements and the
         intercept a scalar value variable, as the location of an observed Normal, the `logit_p` of an observed Bernoulli or inside
@@ -932,6 +1089,10 @@ class _Lowering:
         if own is None and self._mixture(node):
             self.spec.mixture_rows.name = name
             return
+        if self._mvnormal(node, own):
+            return
+        if own is None and self.extra_id and self._categorical(node):
+            return
         for dist, tmpl, argnames in TEMPLATES:
             env: Dict[str, Any] = {}
             if not unify(tmpl, node, env):
@@ -953,6 +1114,9 @@ class _Lowering:
                 return
             if dist == ms.D_NORMAL and own is None and env["value"][0] == "const" and self._glm(ms.GLM_NORMAL, env["mu"], env["value"][1], env["sigma"]):
                 self.spec.glm_rows.name = name
+                return
+            if dist == ms.D_NORMAL and own is None and self.extra_id and self._mixture_conditional(env["value"], env["mu"], env["sigma"]):
+                self.spec.mixture_rows.name = name
                 return
             lam_direct = None
             if dist == ms.D_EXPONENTIAL and env["mu"][0] == "reciprocal":
@@ -1026,11 +1190,13 @@ def lower_to_spec(model) -> ms.ModelSpec:
             tr = (code, getattr(tr, "lower", 0.0), getattr(tr, "upper", 1.0))
         if tr is not None:
             transforms[v.name] = tr
-    low = _Lowering(list(model.value_vars), transforms, shapes)
+    low = _Lowering(list(model.value_vars), transforms, shapes, list(getattr(model, "extra_vars", ())), getattr(model, "extra_values", None))
     factors = model.logp(sum=False)
     owners = list(getattr(model, "logp_owners", [None] * len(factors)))
     names = list(getattr(model, "logp_names", [f"factor{i}" for i in range(len(factors))]))
     memo: dict = {}
     for g, own, nm in zip(factors, owners, names):
         low.factor(build_tree(g, memo), nm, own)
+    if low._cat:
+        raise NotLowerable("a Categorical variable that does not index an observed Normal (the IR has no free-standing Categorical factor)")
     return low.spec

@@ -264,6 +264,63 @@ def _glm_poisson_built():
     return b.build()
 
 
+C0 = np.random.default_rng(18).integers(0, 3, size=YM.size)
+
+
+def mixture_categorical_indexed(sigma_var=False):
+    """The CompoundStep form of BASELINE configs[4]: discrete assignments `c ~ Categorical(w)` (sampled by
+    `CategoricalGibbsMetropolis`) and `y ~ Normal(mu[c], sigma)` observed -- for NUTS the assignments are an extra input."""
+    m = sg.StubModel()
+    c = m.Categorical("c", WM, shape=(YM.size,), initval=C0)
+    mu = m.Normal("mu", 0.0, 5.0, shape=(3,))
+    if sigma_var:
+        sigma = m.HalfNormal("sigma", 2.0, shape=(3,))
+        m.Normal("y", mu[c], sigma[c], observed=YM)
+    else:
+        m.Normal("y", mu[c], 0.9, observed=YM)
+    return m
+
+
+def _mixture_categorical_indexed_built(sigma_var=False):
+    b = ModelBuilder()
+    ce = b.Extra("c", C0.astype("float64"))
+    mu = b.Normal("mu", 0.0, 5.0, shape=3)
+    sigma = b.HalfNormal("sigma", 2.0, shape=3) if sigma_var else 0.9
+    b.NormalMixture("y", WM, mu, sigma, YM, assign=ce)
+    return b.build()
+
+
+_AM = np.random.default_rng(31).normal(size=(6, 6))
+COV6 = _AM @ _AM.T + 0.5 * np.eye(6)
+MU6 = np.linspace(-0.5, 0.7, 6)
+
+
+def mvnormal_cov():
+    """`pm.MvNormal("x", mu=mu, cov=cov)` with a constant covariance: `quaddist_chol` (Cholesky + triangular solve) in the logp."""
+    m = sg.StubModel()
+    m.MvNormal("x", MU6, cov=COV6)
+    return m
+
+
+def mvnormal_chol():
+    """The same density stated through `chol=` (`quaddist_matrix`: cov = chol @ chol.mT)."""
+    m = sg.StubModel()
+    m.MvNormal("x", MU6, chol=np.linalg.cholesky(COV6))
+    return m
+
+
+def mvnormal_tau():
+    m = sg.StubModel()
+    m.MvNormal("x", MU6, tau=np.linalg.inv(COV6))
+    return m
+
+
+def _mvnormal_built():
+    b = ModelBuilder()
+    b.MvNormal("x", MU6, COV6)
+    return b.build()
+
+
 def _built(fn, *a):
     return fn(*a, ModelBuilder()).build()
 
@@ -289,6 +346,11 @@ ENTRIES = {
     "varying_intercepts_and_slopes": (varying_intercepts_and_slopes, lambda: _built(varying_intercepts_and_slopes)),
     "normal_mixture_marginal": (normal_mixture_marginal, _normal_mixture_marginal_built),
     "normal_mixture_softmax": (normal_mixture_softmax, _normal_mixture_softmax_built),
+    "mixture_categorical_indexed": (mixture_categorical_indexed, _mixture_categorical_indexed_built),
+    "mixture_categorical_indexed_sigma": (lambda: mixture_categorical_indexed(True), lambda: _mixture_categorical_indexed_built(True)),
+    "mvnormal_cov": (mvnormal_cov, _mvnormal_built),
+    "mvnormal_chol": (mvnormal_chol, _mvnormal_built),
+    "mvnormal_tau": (mvnormal_tau, _mvnormal_built),
     "glm_normal": (glm_normal, _glm_normal_built),
     "glm_bernoulli": (glm_bernoulli, _glm_bernoulli_built),
     "glm_poisson": (glm_poisson, _glm_poisson_built),

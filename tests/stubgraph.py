@@ -33,6 +33,10 @@ class _Type:
     def __init__(self, shape):
         self.shape = tuple(shape)
 
+    @property
+    def ndim(self):
+        return len(self.shape)
+
 
 class Variable:
     def __init__(self, owner=None, name=None, shape=()):
@@ -60,14 +64,57 @@ class Variable:
     def __rpow__(self, o): return self._bin(o, Pow, True)
     def __and__(self, o): return self._bin(o, AND)
     def __or__(self, o): return self._bin(o, OR)
-    def __getitem__(self, idx): return Variable(Apply(AdvancedSubtensor1(), [self, as_tensor(idx)]), shape=(len(np.asarray(idx)),) + self.type.shape[1:])
-    def sum(self, axis=None): return Variable(Apply(Sum(axis), [self]), shape=())
+    def __getitem__(self, idx):
+        """Integer-array index -> `AdvancedSubtensor1`; `None` entries -> the `DimShuffle` PyTensor inserts for `x[None, :]`; integers /
+        slices / Ellipsis -> `Subtensor` (its `idx_list` kept on the op)."""
+        if isinstance(idx, (np.ndarray, list)) or (isinstance(idx, TensorConstant) and idx.data.ndim == 1):
+            return Variable(Apply(AdvancedSubtensor1(), [self, as_tensor(idx)]), shape=(len(np.asarray(getattr(idx, "data", idx))),) + self.type.shape[1:])
+        if isinstance(idx, Variable):   # a symbolic integer vector (`mu[c]` with c another variable of the model)
+            return Variable(Apply(AdvancedSubtensor1(), [self, idx]), shape=idx.type.shape + self.type.shape[1:])
+        tup = idx if isinstance(idx, tuple) else (idx,)
+        if any(i is None for i in tup):
+            shp, src = [], list(self.type.shape)
+            for i in tup:
+                if i is None:
+                    shp.append(1)
+                elif i is Ellipsis:
+                    shp.extend(src)
+                    src = []
+                elif i == slice(None):
+                    shp.append(src.pop(0))
+                else:
+                    raise NotImplementedError("stub: None mixed with a non-trivial index")
+            return Variable(Apply(DimShuffle(), [self]), shape=tuple(shp + src))
+        shape = np.empty(self.type.shape, dtype=np.int8)[idx].shape
+        return Variable(Apply(Subtensor(tup), [self]), shape=shape)
+
+    @property
+    def shape(self): return Variable(Apply(Shape(), [self]), shape=(len(self.type.shape),))
+    def astype(self, dtype): return elemwise(Cast, self)
+    def squeeze(self, axis=None):
+        n = len(self.type.shape)
+        return Variable(Apply(DimShuffle(), [self]), shape=tuple(s_ for i, s_ in enumerate(self.type.shape) if not (s_ == 1 and (axis is None or i == axis % n))))
+    @property
+    def mT(self): return _transpose(self)
+    @property
+    def tag(self): return _Tag()
+    def sum(self, axis=None): return pt.sum(self, axis=axis)
     def __matmul__(self, o): return pt.dot(self, o)
     def __rmatmul__(self, o): return pt.dot(o, self)
     def copy(self): return self          # (`log_jac_det(...).copy()`, transform_value.py:102: an identity node in PyTensor)
 
     @property
     def ndim(self): return len(self.type.shape)
+
+
+class _Tag:
+    """`var.tag`: a bag of attributes (`chol.tag.lower_triangular = True`, multivariate.py:150)."""
+
+
+def _transpose(v):
+    if isinstance(v, TensorConstant):
+        return TensorConstant(np.swapaxes(v.data, -1, -2))
+    return Variable(Apply(Transpose(), [v]), shape=v.type.shape[:-2] + v.type.shape[-2:][::-1])
 
 
 class TensorConstant(Variable):
@@ -108,6 +155,51 @@ class Dot:
     """`pytensor.tensor.math.Dot`: what `pm.math.dot(X, beta)` / `X @ beta` puts in the graph for a matrix and a vector."""
 
 
+class Subtensor:
+    """`pytensor.tensor.subtensor.Subtensor`: basic indexing with integers / slices (`quaddist[0]`, `x.shape[-1]`)."""
+
+    def __init__(self, idx_list):
+        self.idx_list = tuple(idx_list)
+
+
+class Shape:
+    """`pytensor.tensor.shape.Shape`: `x.shape`."""
+
+
+class Transpose:
+    """(a DimShuffle with a permutation in PyTensor; named here so that the written-down graph keeps the difference)"""
+
+
+class TakeAlongAxis:
+    """What `pt.take_along_axis(arr, indices, axis)` stands for (in PyTensor it expands into advanced indexing with `arange`s of the
+    other axes; the stand-in keeps it one node)."""
+
+    def __init__(self, axis=-1):
+        self.axis = axis
+
+
+class Cholesky:
+    """`pytensor.tensor.slinalg.Cholesky` (`pt.linalg.cholesky(cov, lower=True)`)."""
+
+    def __init__(self, lower=True):
+        self.lower = lower
+
+
+class SolveTriangular:
+    """`pytensor.tensor.slinalg.SolveTriangular` (`solve_triangular(a, b, lower=True, b_ndim=1)`)."""
+
+    def __init__(self, lower=True, b_ndim=1):
+        self.lower, self.b_ndim = lower, b_ndim
+
+
+class ExtractDiag:
+    """`pytensor.tensor.basic.ExtractDiag` (`pt.diagonal(x, axis1=-2, axis2=-1)`)."""
+
+
+class MatrixInverse:
+    """`pytensor.tensor.nlinalg.MatrixInverse` (`matrix_inverse(tau)`)."""
+
+
 class CheckParameterValue:
     """`CheckParameterValue(msg, can_be_replaced_by_ninf)(expr, all_true_scalar)` (logprob/utils.py:209-225)."""
 
@@ -134,7 +226,7 @@ class Softmax:
         self.axis = axis
 
 
-for _n in ("Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "EQ", "OR", "AND", "Sigmoid", "Abs",
+for _n in ("Clip", "Cast", "Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "EQ", "OR", "AND", "Sigmoid", "Abs",
            "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus", "Erf", "Erfc", "Erfcx", "Sqr", "IsClose"):
     globals()[_n] = type(_n, (), {})
 
@@ -175,6 +267,17 @@ def fused(comp, *ins):
 
 def _bshape(*vs):
     return np.broadcast_shapes(*[v.type.shape for v in vs])
+
+
+def solve_triangular(a, b, lower=False, b_ndim=None, **kw):
+    """`pytensor.tensor.slinalg.solve_triangular`."""
+    a, b = as_tensor(a), as_tensor(b)
+    return Variable(Apply(SolveTriangular(lower, b_ndim), [a, b]), shape=b.type.shape)
+
+
+def matrix_inverse(x):
+    x = as_tensor(x)
+    return Variable(Apply(MatrixInverse(), [x]), shape=x.type.shape)
 
 
 def _dimshuffle_to(v, shape):
@@ -252,6 +355,38 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         return Variable(Apply(DimShuffle(), [x]), shape=tuple(shp))
 
     isclose = staticmethod(lambda a, b: elemwise(IsClose, a, b))
+
+    clip = staticmethod(lambda x, lo, hi: elemwise(Clip, x, lo, hi))
+    shape = staticmethod(lambda x: as_tensor(x).shape)
+
+    @staticmethod
+    def shape_padleft(x, n_ones=1):
+        x = as_tensor(x)
+        return Variable(Apply(DimShuffle(), [x]), shape=(1,) * n_ones + x.type.shape)
+
+    @staticmethod
+    def take_along_axis(arr, indices, axis=-1):
+        arr, indices = as_tensor(arr), as_tensor(indices)
+        return Variable(Apply(TakeAlongAxis(axis), [arr, indices]), shape=np.broadcast_shapes(arr.type.shape[:-1], indices.type.shape[:-1]) + indices.type.shape[-1:])
+
+    @staticmethod
+    def diagonal(x, axis1=-2, axis2=-1):
+        x = as_tensor(x)
+        return Variable(Apply(ExtractDiag(), [x]), shape=x.type.shape[:-2] + (min(x.type.shape[-2:]),))
+
+    @staticmethod
+    def broadcast_arrays(*xs):
+        return [as_tensor(x) for x in xs]     # (mu against cov[..., -1] in MvNormal.dist: the shapes already agree in the test models)
+
+    @staticmethod
+    def squeeze(x, axis=None):
+        return as_tensor(x).squeeze(axis)
+
+    class linalg:
+        @staticmethod
+        def cholesky(x, lower=True):
+            x = as_tensor(x)
+            return Variable(Apply(Cholesky(lower), [x]), shape=x.type.shape)
 
     @staticmethod
     def dot(a, b):
@@ -419,6 +554,20 @@ def reference():
     # component RV's distribution
     ns["logp"] = lambda rv, value: rv.dist_cls.logp(value, *rv.params)
     ref_function("distributions/mixture.py", "mixture_logprob", ns)
+    # MvNormal (distributions/multivariate.py:127-185, 258-295): `quaddist_matrix`, `_logdet_from_cholesky`, `quaddist_chol`, and the
+    # class's `dist` / `logp`.  `solve_lower` is a module-level `partial(solve_triangular, lower=True)` there (:108)
+    from functools import partial
+
+    ns.update(solve_triangular=solve_triangular, solve_lower=partial(solve_triangular, lower=True), solve_upper=partial(solve_triangular, lower=False),
+              matrix_inverse=matrix_inverse)
+    for fn in ("quaddist_matrix", "_logdet_from_cholesky", "quaddist_chol"):
+        ref_function("distributions/multivariate.py", fn, ns)
+    ref_class("distributions/multivariate.py", "MvNormal", ["dist", "logp"], _DistBase, ns)
+    # Categorical (distributions/discrete.py:1140-1205): `dist`, `_safe_index_value_p`, `logp`
+    import warnings
+
+    ns["warnings"] = warnings
+    ref_class("distributions/discrete.py", "Categorical", ["dist", "_safe_index_value_p", "logp"], _DistBase, ns)
     _NS = ns
     return ns
 
@@ -571,13 +720,36 @@ class StubModel:
         fn = lambda value, w_, comp_: ref["mixture_logprob"](None, (value,), None, w_, comp_)   # noqa: E731
         return self._add(_RV(name, np.shape(observed), fn, (as_tensor(w), comp), None, observed))
 
+    def Categorical(self, name, p, shape, initval=None):
+        """`pm.Categorical(name, p=p, shape=N)`: a DISCRETE free variable -- not a gradient variable of NUTS but an input of the
+        log-density that another step method updates (`extra_vars`, model/core.py:142-190); `initval`: its value in the initial point."""
+        rv = _RV(name, shape, _ref_logp("Categorical"), _dist("Categorical", p=p), None, None)
+        rv.discrete = True
+        rv.initval = np.zeros(shape) if initval is None else np.asarray(initval, dtype="float64")
+        return self._add(rv)
+
+    def MvNormal(self, name, mu, cov=None, chol=None, tau=None, shape=None, observed=None):
+        """`pm.MvNormal(name, mu=mu, cov=cov | chol=chol | tau=tau)` (multivariate.py:258-295)."""
+        params = _dist("MvNormal", mu=mu, cov=cov, chol=chol, tau=tau)
+        k = np.shape(mu)[-1] if np.ndim(mu) else np.shape(cov if cov is not None else chol if chol is not None else tau)[-1]
+        return self._rv("MvNormal", name, shape or (k,), params, None, observed)
+
     def Bernoulli(self, name, logit_p, observed):
         return self._rv("Bernoulli", name, np.shape(observed), _dist("Bernoulli", logit_p=logit_p), None, observed)   # discrete.py:351-352
 
     # ---- the model protocol of `lower_to_spec` ----
     @property
     def value_vars(self):
-        return [rv.value for rv in self.free]
+        return [rv.value for rv in self.free if not getattr(rv, "discrete", False)]
+
+    @property
+    def extra_vars(self):
+        """Value variables that are inputs of the log-density but not of its gradient (the discrete ones)."""
+        return [rv.value for rv in self.free if getattr(rv, "discrete", False)]
+
+    @property
+    def extra_values(self):
+        return {rv.value.name: rv.initval for rv in self.free if getattr(rv, "discrete", False)}
 
     @property
     def value_shapes(self):
@@ -641,6 +813,12 @@ def dump_model(m) -> dict:
                 rec["axis"] = op.axis
             if hasattr(op, "msg"):
                 rec["msg"] = op.msg
+            if hasattr(op, "idx_list"):
+                rec["idx_list"] = [("slice", i.start, i.stop, i.step) if isinstance(i, slice) else ("ellipsis",) if i is Ellipsis else int(i) for i in op.idx_list]
+            if hasattr(op, "lower"):
+                rec["lower"] = bool(op.lower)
+            if hasattr(op, "b_ndim"):
+                rec["b_ndim"] = op.b_ndim
         index[id(v)] = len(nodes)
         nodes.append(rec)
         return index[id(v)]
@@ -651,10 +829,13 @@ def dump_model(m) -> dict:
         "value_vars": [visit(v) for v in m.value_vars], "value_shapes": {k: list(s) for k, s in m.value_shapes.items()},
         "value_transforms": {k: list(t) for k, t in m.value_transforms.items()},
         "logp_owners": [None if o is None else visit(o) for o in m.logp_owners], "logp_names": list(m.logp_names),
+        "extra_vars": [visit(v) for v in getattr(m, "extra_vars", [])],
+        "extra_values": {k: np.asarray(v, dtype="float64").tolist() for k, v in getattr(m, "extra_values", {}).items()},
     }
 
 
-_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot)}
+_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot, Shape, Transpose, ExtractDiag, MatrixInverse)}
+_OPS_AXIS = ("Sum", "All", "Softmax", "TakeAlongAxis")
 
 
 class FrozenModel:
@@ -673,8 +854,16 @@ class FrozenModel:
                     op = Elemwise(globals()[rec["scalar"]]())
                 elif rec["op"] in ("Sum", "All", "Softmax"):
                     op = _OPS[rec["op"]](rec.get("axis"))
+                elif rec["op"] == "TakeAlongAxis":
+                    op = TakeAlongAxis(rec.get("axis", -1))
                 elif rec["op"] == "CheckParameterValue":
                     op = CheckParameterValue(rec.get("msg", ""))
+                elif rec["op"] == "Subtensor":
+                    op = Subtensor([slice(*i[1:]) if isinstance(i, (list, tuple)) and i[0] == "slice" else Ellipsis if isinstance(i, (list, tuple)) else i for i in rec["idx_list"]])
+                elif rec["op"] == "Cholesky":
+                    op = Cholesky(rec.get("lower", True))
+                elif rec["op"] == "SolveTriangular":
+                    op = SolveTriangular(rec.get("lower", True), rec.get("b_ndim"))
                 else:
                     op = _OPS[rec["op"]]()
                 v = Variable(Apply(op, ins), shape=rec["shape"])
@@ -685,6 +874,8 @@ class FrozenModel:
         self.value_transforms = {k: tuple(t) for k, t in d["value_transforms"].items()}
         self.logp_owners = [None if i is None else vs[i] for i in d["logp_owners"]]
         self.logp_names = list(d["logp_names"])
+        self.extra_vars = [vs[i] for i in d.get("extra_vars", [])]
+        self.extra_values = {k: np.asarray(v, dtype="float64") for k, v in d.get("extra_values", {}).items()}
 
     def logp(self, sum=False):
         return list(self._outs)

@@ -473,6 +473,13 @@ def test_committed_reference_graphs_lower_to_the_builder_spec(name):
     # the dense nodes: the same node kind, wired to the same variables, over the same data
     for attr in ("logit_rows", "mvnormal", "mixture_rows", "glm_rows"):
         assert (getattr(spec, attr, None) is None) == (getattr(want, attr, None) is None), attr
+    assert dict(spec.extra) == dict(want.extra)
+    if want.mixture_rows is not None:
+        xa, xb = spec.mixture_rows, want.mixture_rows
+        assert (xa.K, xa.mu, xa.sigma, xa.w_logits, xa.assign) == (xb.K, xb.mu, xb.sigma, xb.w_logits, xb.assign) and np.array_equal(xa.y, xb.y)
+    if want.mvnormal is not None:
+        ma, mb = spec.mvnormal, want.mvnormal
+        assert ma.var == mb.var and np.allclose(ma.mu, mb.mu, rtol=1e-13, atol=0) and np.allclose(ma.cov, mb.cov, rtol=1e-10, atol=1e-13)
     if want.glm_rows is not None:
         ga, gb = spec.glm_rows, want.glm_rows
         assert (ga.family, ga.beta, ga.intercept, ga.sigma, ga.sigma_const, ga.name) == (gb.family, gb.beta, gb.intercept, gb.sigma, gb.sigma_const, gb.name)
@@ -483,6 +490,24 @@ def test_committed_reference_graphs_lower_to_the_builder_spec(name):
         lp, g = ref_models.evaluate(spec, q)
         lp0, g0 = ref_models.evaluate(want, q)
         assert np.isfinite(lp0) and abs(lp - lp0) <= 1e-12 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-12 * max(1.0, np.max(np.abs(g0)))
+
+
+def test_configs2_mvnormal_2048_graph_lowers_to_the_c3_spec():
+    """BASELINE configs[2] at its own size: the graph the reference's `MvNormal.dist` / `MvNormal.logp` / `quaddist_chol` build for
+    `pm.MvNormal("x", mu=0, cov=Sigma)` with the 2048 x 2048 covariance of `models.mvnormal` lowers to the MvNormal node of the spec
+    bench.py --workload c3 runs (the 33 MB constant is not committed: built where the reference exists)."""
+    if not sg.available():
+        pytest.skip("needs /root/reference")
+    want = models.mvnormal(n=2048)
+    m = sg.StubModel()
+    m.MvNormal("x", want.mvnormal.mu, cov=want.mvnormal.cov)
+    spec = lower_to_spec(m)
+    assert spec.n == 2048 and spec.factors == [] and spec.mvnormal.var == 0
+    np.testing.assert_allclose(spec.mvnormal.cov, want.mvnormal.cov, rtol=1e-9, atol=1e-12)
+    q = np.random.default_rng(1).normal(size=2048)
+    lp, g = ref_models.evaluate(spec, q)
+    lp0, g0 = ref_models.evaluate(want, q)
+    assert abs(lp - lp0) <= 1e-9 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-8 * np.max(np.abs(g0))
 
 
 def test_committed_reference_graphs_are_current():
