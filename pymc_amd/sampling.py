@@ -60,17 +60,28 @@ def initial_point(spec: ModelSpec) -> Dict[str, np.ndarray]:
     (pymc/initial_point.py:187-340); models with other support points pass
     explicit `initvals`.
     """
-    return {v.value_name: np.zeros(v.shape, dtype="float64") for v in spec.vars}
+    pt = {v.value_name: np.zeros(v.shape, dtype="float64") for v in spec.vars}
+    # value variables that are inputs of the log-density without being gradient variables (discrete variables another step method
+    # updates) are part of the reference's initial point too (initial_point.py:187-340 covers every value variable): their initial
+    # values are the ones the model states
+    for name, did in getattr(spec, "extra", {}).items():
+        pt[name] = np.array(spec.data[did], dtype="float64", copy=True)
+    return pt
 
 
-def _jitter_point(point, seed):
+def _grad_part(spec, point):
+    """The gradient variables of a point, in `value_vars` order (what `DictToArrayBijection.map` ravels for the step method)."""
+    return {v.value_name: point[v.value_name] for v in spec.vars}
+
+
+def _jitter_point(point, seed, extra=None):
     """U(-1,1) jitter in unconstrained space (`_init_jitter`, mcmc.py:1695-1756).
 
     The reference draws the jitter through PyTensor RNG ops whose stream order is
     a PyTensor internal: the jitter VALUES are parity-unpinned.
     """
     rng = np.random.default_rng(seed)
-    return {k: v + rng.uniform(-1, 1, size=np.shape(v)) for k, v in point.items()}
+    return {k: (v + rng.uniform(-1, 1, size=np.shape(v)) if k not in (extra or ()) else v) for k, v in point.items()}
 
 
 def init_nuts(
@@ -112,14 +123,14 @@ def init_nuts(
             seed = random_seed_list[c]
             rng = np.random.default_rng(seed)
             for i in range(jitter_max_retries + 1):
-                cand = _jitter_point(p, seed)
-                lp, _ = logp_dlogp_func._pytensor_function(DictToArrayBijection.map(cand).data)
+                cand = _jitter_point(p, seed, extra=spec.extra)
+                lp, _ = logp_dlogp_func._pytensor_function(DictToArrayBijection.map(_grad_part(spec, cand)).data)
                 if np.isfinite(lp):
                     break
                 seed = int(rng.integers(2**30, dtype=np.int64))
             p = cand
         points.append(p)
-    apoints = [DictToArrayBijection.map(p).data for p in points]
+    apoints = [DictToArrayBijection.map(_grad_part(spec, p)).data for p in points]
     mean = np.mean(apoints, axis=0)
     n = len(mean)
     if init in ("adapt_diag", "jitter+adapt_diag"):  # mcmc.py:1884-1893
