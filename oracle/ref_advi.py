@@ -115,3 +115,34 @@ def advi_step(glm: GLM, st: FullRankState, idx, z0, learning_rate=0.001, epsilon
     st.mu = st.mu - learning_rate * grad_mu / np.sqrt(st.acc_mu.sum(axis=-1) + epsilon)
     st.L_tril = st.L_tril - learning_rate * grad_tril / np.sqrt(st.acc_L.sum(axis=-1) + epsilon)
     return loss, grad_mu, grad_tril
+
+
+def advi_step_logp(logp_grad, st: FullRankState, z0, learning_rate=0.001, epsilon=0.1, n_win=10):
+    """The same step for ANY model: `logp_grad(z) -> (logp, d logp / dz)` over the raveled unconstrained vector (the joint
+    log-density `Model.logp` assembles, model/core.py:612-695; no minibatch, so every scaling is 1 and the normalising constant of
+    opvi.py:1314-1332 is 1).  loss = logq - logp (`KL.apply`, operators.py:64-65, with datalogp + varlogp = logp).  With the GLM's
+    full data as one batch this is `advi_step` (tests/test_advi.py pins one against the other)."""
+    L = st.L()
+    z = z0 @ L.T + st.mu                                              # approximations.py:184-188
+    lp, g = logp_grad(z)
+    g = np.asarray(g, dtype="float64")
+    diag = np.diag(L)
+    logq = np.sum(-0.5 * z0**2 - np.log(np.sqrt(2 * np.pi))) - np.sum(np.log(diag))
+    loss = logq - lp
+    grad_mu = -g
+    GL = -np.outer(g, z0)
+    idx_d = np.arange(st.d)
+    GL[idx_d, idx_d] += -1.0 / diag
+    grad_tril = GL[st.tril]
+    dpos = np.array([i * (i + 1) // 2 + i for i in range(st.d)])
+    grad_tril[dpos] *= sigmoid(st.L_tril[dpos])                      # through rho2sigma
+    if st.acc_mu.shape[1] != n_win:
+        st.acc_mu = np.zeros((st.d, n_win))
+        st.acc_L = np.zeros((len(st.L_tril), n_win))
+        st.i = 0
+    st.acc_mu[:, st.i] = grad_mu**2
+    st.acc_L[:, st.i] = grad_tril**2
+    st.i = st.i + 1 if st.i + 1 < n_win else 0
+    st.mu = st.mu - learning_rate * grad_mu / np.sqrt(st.acc_mu.sum(axis=-1) + epsilon)
+    st.L_tril = st.L_tril - learning_rate * grad_tril / np.sqrt(st.acc_L.sum(axis=-1) + epsilon)
+    return loss, grad_mu, grad_tril

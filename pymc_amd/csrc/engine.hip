@@ -1313,6 +1313,7 @@ struct nuts_chain {
   int tree_opts = 0;             // GA_TREE_* switches (NUTS_GA_TREE_OPTS, NUTS_GA_TREE_TICKS)
   int tree_prof_pending = 0;     // the last tree launch is being timed: its leaf count is added when the draw's record arrives
   int spec_max = 10, last_depth = 0;   // look-ahead over the doublings, as deep as the previous tree went (run_tree)
+  int pipe_draws = 1;                  // NUTS_PIPE_DRAWS, latched at creation: post-tuning draws of a batch are queued behind each other
   int logs_done = 0, logs_total = 0;  // logarithms of the pre-drawn uniforms taken / needed at most this draw
   // staging of nuts_chain_draw_many (grown on demand)
   double* many_in_host = nullptr; double* many_in_dev = nullptr; char* many_out_host = nullptr; char* many_out_dev = nullptr;
@@ -1517,6 +1518,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->fold_ctl = env_int("NUTS_FOLD_CTL", 1) != 0 && !(m->md.has_mvn && m->md.mv.winv);   // (the four-launch MvNormal pass has no workgroup 0 for it)
   c->spec_max = env_int("NUTS_SPEC_MAX", 10);
   c->xfold = env_int("NUTS_XFOLD", 1);
+  c->pipe_draws = env_int("NUTS_PIPE_DRAWS", 1) != 0;
   c->xpre = env_int("NUTS_XPRE", 1);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
              !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
@@ -2215,7 +2217,7 @@ static int draw_many_general(nuts_chain* c, const double* q0, const double* norm
   // kernel, and this draw's record -- statistics only -- is read while the next tree is already running.  One host round trip per draw
   // (the status) instead of three (status, record, then an idle queue to restart): ~50 us of GPU idle per draw on C2-S / C3
   // (profiles/r03g_profile_c3.txt: 50.7 us idle before k_draw_start).  A divergent draw is finished synchronously, as before.
-  const bool pipe = !c->tune && !c->tree_mode && !c->full_adapt && env_int("NUTS_PIPE_DRAWS", 1) != 0;
+  const bool pipe = !c->tune && !c->tree_mode && !c->full_adapt && c->pipe_draws;   // (the option is latched when the chain is created)
   struct Pending {
     bool valid = false; int k = 0; unsigned seq = 0; bool exhausted = false, adapt = false; size_t consumed_after = 0; int cursor = 0;
     double perf_start = 0.0, wall = 0.0, cpu = 0.0;
@@ -3041,9 +3043,18 @@ extern "C" int nuts_gibbs_sweep_prop(nuts_gibbs* g, const int32_t* c_in, int32_t
   const int K = g->K;
   const size_t n = (size_t)g->n;
   hipStream_t s = g->stream;
-  if (!g->c2) {
+  if (!g->c2 || !g->u2 || !g->flags) {   // (all three or none: a partial failure must not leave a later call with a null buffer)
+    if (g->c2) hipFree(g->c2);
+    if (g->u2) hipFree(g->u2);
+    if (g->flags) hipFree(g->flags);
     g->c2 = dev_alloc<int32_t>(n); g->u2 = dev_alloc<double>(n); g->flags = (int8_t*)dev_alloc<int32_t>((n + 3) / 4);
-    if (!g->c2 || !g->u2 || !g->flags) { g_err = "device allocation failed"; return NUTS_E_HIP; }
+    if (!g->c2 || !g->u2 || !g->flags) {
+      if (g->c2) hipFree(g->c2);
+      if (g->u2) hipFree(g->u2);
+      if (g->flags) hipFree(g->flags);
+      g->c2 = nullptr; g->u2 = nullptr; g->flags = nullptr;
+      g_err = "device allocation failed"; return NUTS_E_HIP;
+    }
   }
   std::vector<double> par(3 * (size_t)K);
   for (int k = 0; k < K; ++k) { par[k] = log_w[k]; par[K + k] = mu[k]; par[2 * K + k] = sigma[k]; }

@@ -1199,4 +1199,23 @@ def lower_to_spec(model) -> ms.ModelSpec:
         low.factor(build_tree(g, memo), nm, own)
     if low._cat:
         raise NotLowerable("a Categorical variable that does not index an observed Normal (the IR has no free-standing Categorical factor)")
+    # `pm.Deterministic` variables (model/core.py:1940-2005): recorded in the trace next to the free variables (backends/base.py:
+    # 183-191), no contribution to the log-density.  `model.deterministics`: {name: graph variable} (a list of named variables on a
+    # real `pm.Model`).  One that the IR cannot express is left out of the trace with a warning, not a failure of the lowering.
+    dets = getattr(model, "deterministics", None) or {}
+    if not isinstance(dets, dict):
+        dets = {getattr(v, "name", f"deterministic{i}"): v for i, v in enumerate(dets)}
+    for name, var in dets.items():
+        low._prog, low._prog_size, low._prog_memo = [], [], {}
+        if "_gather_ids" not in low.__dict__:
+            low._gather_ids = {}
+        try:
+            t = low.term(build_tree(var, memo))
+            low.spec.deterministics[name] = (tuple(low._prog), t, low._size(t))
+        except NotLowerable as e:
+            import logging
+
+            logging.getLogger("pymc_amd").warning("Deterministic %r is not recorded in the trace: %s", name, e)
+        finally:
+            low._prog = None
     return low.spec

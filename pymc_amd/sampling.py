@@ -24,6 +24,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
+from pymc_amd._lib import EngineError
 from pymc_amd.blocking import DictToArrayBijection
 from pymc_amd.model_spec import ModelSpec
 from pymc_amd.quadpotential import QuadPotentialDiagAdapt, QuadPotentialDiagAdaptExp, QuadPotentialFullAdapt
@@ -395,9 +396,11 @@ def sample(
     latency_bound = single_launch
     try:
         latency_bound = latency_bound or 0 < int(step._logp_dlogp_func.algorithmic_bytes) < CONCURRENT_CHAINS_BELOW_BYTES
-    except Exception:
+    except (AttributeError, EngineError):   # (a user's logp_dlogp_func without the engine's size query: one chain at a time)
         pass
     n_par = min(len(mine), cores if cores is not None else (4 if latency_bound else 1))
+    if n_par > 1:
+        logging.getLogger("pymc_amd").info("sampling %d chains on one GPU, %d at a time (host threads, one engine each)", len(mine), n_par)
     if pooled is not None or step_given or n_par < 1:
         n_par = 1
     if mp_ctx is not None and pooled is None and len(mine) > 0:
@@ -431,10 +434,12 @@ def sample(
         local_stats = [None] * len(mine)
         with ThreadPoolExecutor(max_workers=n_par) as ex:
             for res in ex.map(work, range(n_par)):
+                t_worker = 0.0
                 for k, (d, s) in res:
                     local_draws[k] = d
                     local_stats[k] = s
-                    t_sampling += sum(x["perf_counter_diff"] for x in s[tune:])
+                    t_worker += sum(x["perf_counter_diff"] for x in s[tune:])
+                t_sampling = max(t_sampling, t_worker)   # (the workers overlap: the sampling time is the slowest worker's, not the sum)
         for st in steps[1:]:
             st.close()
     else:

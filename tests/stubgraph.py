@@ -829,6 +829,7 @@ def dump_model(m) -> dict:
         "value_vars": [visit(v) for v in m.value_vars], "value_shapes": {k: list(s) for k, s in m.value_shapes.items()},
         "value_transforms": {k: list(t) for k, t in m.value_transforms.items()},
         "logp_owners": [None if o is None else visit(o) for o in m.logp_owners], "logp_names": list(m.logp_names),
+        "deterministics": {k: visit(v) for k, v in getattr(m, "deterministics", {}).items()},
         "extra_vars": [visit(v) for v in getattr(m, "extra_vars", [])],
         "extra_values": {k: np.asarray(v, dtype="float64").tolist() for k, v in getattr(m, "extra_values", {}).items()},
     }
@@ -874,6 +875,7 @@ class FrozenModel:
         self.value_transforms = {k: tuple(t) for k, t in d["value_transforms"].items()}
         self.logp_owners = [None if i is None else vs[i] for i in d["logp_owners"]]
         self.logp_names = list(d["logp_names"])
+        self.deterministics = {k: vs[i] for k, i in d.get("deterministics", {}).items()}
         self.extra_vars = [vs[i] for i in d.get("extra_vars", [])]
         self.extra_values = {k: np.asarray(v, dtype="float64") for k, v in d.get("extra_values", {}).items()}
 

@@ -208,6 +208,67 @@ def test_configs3_literal_shape_matches_the_oracle_step_by_step():
     inf.close()
 
 
+def _glm_as_spec(m):
+    """The GLM of `models.glm` as a general model spec: beta ~ Normal(0, prior_sd), y ~ Normal(X beta, sigma) through the GLM node."""
+    from pymc_amd.model_spec import ModelBuilder
+
+    b = ModelBuilder()
+    beta = b.Normal("beta", 0.0, m.prior_sd, shape=m.n)
+    b.GLM("y", m.X, beta, m.y, family=m.family, sigma=m.sigma)
+    return b.build()
+
+
+@pytest.mark.parametrize("family", ["normal", "bernoulli"])
+def test_generic_oracle_step_equals_the_pinned_glm_step_on_the_full_batch(family):
+    """`advi_step_logp` (any model: loss = logq - logp) against `advi_step` (pinned by the executed reference) with the whole data as
+    one batch (N / B = 1): the same losses, gradients and parameters step after step."""
+    from oracle import ref_models
+
+    m = _small(family, N=90, P=7)
+    spec = _glm_as_spec(m)
+    f = ref_models.SpecLogpGrad(spec)
+    glm = ref_advi.GLM(m.X, m.y, family, m.sigma, m.prior_sd)
+    a, b = ref_advi.FullRankState(7), ref_advi.FullRankState(7)
+    rng = np.random.default_rng(3)
+    idx = np.arange(90)
+    for s in range(14):
+        z0 = rng.normal(size=7)
+        la, gma, gla = ref_advi.advi_step(glm, a, idx, z0, 0.01, 0.1, 10)
+        lb, gmb, glb = ref_advi.advi_step_logp(f, b, z0, 0.01, 0.1, 10)
+        assert abs(la - lb) <= 1e-11 * abs(la), s
+        np.testing.assert_allclose(gma, gmb, rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(gla, glb, rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(a.mu, b.mu, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(a.L_tril, b.L_tril, rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_fullrank_advi_over_any_model_spec_matches_the_oracle():
+    """`FullRankADVI(model=<ModelSpec>)` (VERDICT r03 missing 4): full-rank ADVI over the whole raveled vector of ANY model -- here the
+    hierarchical-logit rows with a HalfCauchy hyper-prior (one-launch row pass + auxiliary workgroups), eight schools (single
+    workgroup path) and a GLM node model -- log-density and gradient on the device, against the oracle's steps on the same z0."""
+    from oracle import ref_models
+    from pymc_amd import models as M
+
+    for spec in (M.hier_logit_variant("halfcauchy", G=12, D=4, rows_per_group=40, seed=3), M.eight_schools(), _glm_as_spec(_small("bernoulli", N=200, P=9))):
+        inf = FullRankADVI(model=spec, random_seed=4, device=0)
+        rng = np.random.default_rng(5)
+        z0 = rng.normal(size=(25, spec.n))
+        loss = inf.run_steps(None, z0, adagrad_window(learning_rate=0.01, epsilon=0.1, n_win=10))
+        f = ref_models.SpecLogpGrad(spec)
+        st = ref_advi.FullRankState(spec.n)
+        want = [ref_advi.advi_step_logp(f, st, z0[s], 0.01, 0.1, 10)[0] for s in range(25)]
+        np.testing.assert_allclose(loss, want, rtol=1e-9)
+        mu, lt = inf.approx.params
+        np.testing.assert_allclose(mu, st.mu, rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(lt, st.L_tril, rtol=1e-8, atol=1e-11)
+        approx = inf.fit(100)
+        assert approx.hist.shape == (100,) and np.all(np.isfinite(approx.hist))
+        draws = approx.sample(50, random_seed=1)
+        assert set(draws) == {v.value_name for v in spec.vars}
+        inf.close()
+
+
 def test_fit_cuts_its_chunks_where_the_callbacks_look(monkeypatch):
     """the reference calls every callback after every step (inference.py:230-290); the device runs a chunk of steps per
     call, so the chunks end on every multiple of a callback's `every` and a `StopIteration` ends the fit there."""

@@ -474,6 +474,10 @@ def test_committed_reference_graphs_lower_to_the_builder_spec(name):
     for attr in ("logit_rows", "mvnormal", "mixture_rows", "glm_rows"):
         assert (getattr(spec, attr, None) is None) == (getattr(want, attr, None) is None), attr
     assert dict(spec.extra) == dict(want.extra)
+    # `pm.Deterministic`s of the model are lowered into the trace's side outputs: same names, sizes and program lengths
+    assert sorted(spec.deterministics) == sorted(want.deterministics)
+    for k_ in want.deterministics:
+        assert spec.deterministics[k_][2] == want.deterministics[k_][2] and len(spec.deterministics[k_][0]) == len(want.deterministics[k_][0])
     if want.mixture_rows is not None:
         xa, xb = spec.mixture_rows, want.mixture_rows
         assert (xa.K, xa.mu, xa.sigma, xa.w_logits, xa.assign) == (xb.K, xb.mu, xb.sigma, xb.w_logits, xb.assign) and np.array_equal(xa.y, xb.y)
