@@ -254,7 +254,8 @@ def test_fullrank_advi_over_any_model_spec_matches_the_oracle():
         inf = FullRankADVI(model=spec, random_seed=4, device=0)
         rng = np.random.default_rng(5)
         z0 = rng.normal(size=(25, spec.n))
-        loss = inf.run_steps(None, z0, adagrad_window(learning_rate=0.01, epsilon=0.1, n_win=10))
+        opt = adagrad_window(learning_rate=0.01, epsilon=0.1, n_win=10)
+        loss = inf.run_steps(None, z0, opt)
         f = ref_models.SpecLogpGrad(spec)
         st = ref_advi.FullRankState(spec.n)
         want = [ref_advi.advi_step_logp(f, st, z0[s], 0.01, 0.1, 10)[0] for s in range(25)]
@@ -262,7 +263,7 @@ def test_fullrank_advi_over_any_model_spec_matches_the_oracle():
         mu, lt = inf.approx.params
         np.testing.assert_allclose(mu, st.mu, rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(lt, st.L_tril, rtol=1e-8, atol=1e-11)
-        approx = inf.fit(100)
+        approx = inf.fit(100, obj_optimizer=opt)
         assert approx.hist.shape == (100,) and np.all(np.isfinite(approx.hist))
         draws = approx.sample(50, random_seed=1)
         assert set(draws) == {v.value_name for v in spec.vars}
