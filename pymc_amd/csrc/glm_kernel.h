@@ -31,6 +31,10 @@
 
 #define GLM_BLOCK 256
 #define GLM_MAXCH 4
+#ifndef GLM_PF
+#define GLM_PF 1            // row-iterations in flight per wave while one is evaluated.  Measured at configs[3]'s shape, one box,
+#endif                      // 4 workgroups per CU (profiles/r04o_glm_prefetch_depth_ab.txt): 1 -> 631.6 us per pass (6.49 TB/s, 0.81 of
+                            // peak: the copy ceiling of this part), 2 -> 645.0, 3 -> 653.6 -- bytes in flight are not what bounds it
 #define GLM_RED_CHUNKS 64   // k_glm_reduce: records are totalled in this many chunks of consecutive workgroups, chunks in order
 #define GLM_RED_COLS 4      // columns per workgroup of k_glm_reduce (64 x 4: with 16 x 16 a thread added 128 - 256 records one round of
                             // eight after the other and the reduce took 13 us at 2048 records, 90 at 4096: profiles/r04h_glm_sweep_workgroups_per_cu.txt)
@@ -90,10 +94,10 @@ __global__ __launch_bounds__(GLM_BLOCK) void k_glm_rows(ModelDev md, ArenaDev A,
   const int64_t nwv = (int64_t)gridDim.x * NW, wv = (int64_t)blockIdx.x * NW + w;
   const int64_t per = ((gm.N + nwv - 1) / nwv + RPW - 1) / RPW * RPW;
   const int64_t r0 = wv * per, r1 = min(gm.N, r0 + per);
-  // the first rows are requested before the position is composed
+  // the first rows are requested before the position is composed: GLM_PF row-iterations stay in flight per wave while one is evaluated
   const double* __restrict__ X = gm.X;
-  double2 xn[CH];
-  double yn;
+  double2 xn[GLM_PF][CH];
+  double yn[GLM_PF];
   auto request = [&](int64_t r, double2 (&x)[CH], double& yv) {
     const int64_t row = min(r + grp, gm.N - 1);   // (rows past the range: valid addresses, masked below)
     const double2* p = reinterpret_cast<const double2*>(X + row * Ppad) + sub;
@@ -101,7 +105,8 @@ __global__ __launch_bounds__(GLM_BLOCK) void k_glm_rows(ModelDev md, ArenaDev A,
     for (int c = 0; c < CH; ++c) x[c] = p[c * LPR];
     yv = gm.y[row];
   };
-  request(r0, xn, yn);
+#pragma unroll
+  for (int u = 0; u < GLM_PF; ++u) request(r0 + (int64_t)u * RPW, xn[u], yn[u]);
 
   // beta' of this lane's columns, the scalars
   double2 b[CH];
@@ -119,26 +124,31 @@ __global__ __launch_bounds__(GLM_BLOCK) void k_glm_rows(ModelDev md, ArenaDev A,
 #pragma unroll
   for (int c = 0; c < CH; ++c) acc[c] = make_double2(0.0, 0.0);
   double lp_acc = 0.0, r_acc = 0.0, ds_acc = 0.0;
-  for (int64_t r = r0; r < r1; r += RPW) {
-    double2 x[CH];
+  // (the ring of requested rows is rotated by hand, GLM_PF iterations per trip, so that every buffer is a fixed set of registers)
+  for (int64_t rb = r0; rb < r1; rb += (int64_t)GLM_PF * RPW) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) x[c] = xn[c];
-    const double y = yn;
-    request(r + RPW, xn, yn);   // unconditional (past the end it re-reads clamped rows): the loads stay in flight during the arithmetic
-    double part = 0.0;
+    for (int u = 0; u < GLM_PF; ++u) {
+      const int64_t r = rb + (int64_t)u * RPW;
+      double2 x[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { part = fma(x[c].x, b[c].x, part); part = fma(x[c].y, b[c].y, part); }
-    const double eta = glm_group_sum<LPR>(part) + icpt;
-    double lp, rr, ds;
-    glm_row(FAMILY, eta, y, sigma, inv_sigma, log_sigma, lp, rr, ds);
-    const bool in = r + grp < r1;
-    rr = in ? rr : 0.0;
+      for (int c = 0; c < CH; ++c) x[c] = xn[u][c];
+      const double y = yn[u];
+      request(r + (int64_t)GLM_PF * RPW, xn[u], yn[u]);   // unconditional (past the end it re-reads clamped rows): stays in flight during the arithmetic
+      double part = 0.0;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { acc[c].x = fma(rr, x[c].x, acc[c].x); acc[c].y = fma(rr, x[c].y, acc[c].y); }
-    const bool first = in && sub == 0;   // one lane per row carries the row's scalars
-    lp_acc += first ? lp : 0.0;
-    r_acc += first ? rr : 0.0;
-    ds_acc += first ? ds : 0.0;
+      for (int c = 0; c < CH; ++c) { part = fma(x[c].x, b[c].x, part); part = fma(x[c].y, b[c].y, part); }
+      const double eta = glm_group_sum<LPR>(part) + icpt;
+      double lp, rr, ds;
+      glm_row(FAMILY, eta, y, sigma, inv_sigma, log_sigma, lp, rr, ds);
+      const bool in = r + grp < r1;
+      rr = in ? rr : 0.0;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { acc[c].x = fma(rr, x[c].x, acc[c].x); acc[c].y = fma(rr, x[c].y, acc[c].y); }
+      const bool first = in && sub == 0;   // one lane per row carries the row's scalars
+      lp_acc += first ? lp : 0.0;
+      r_acc += first ? rr : 0.0;
+      ds_acc += first ? ds : 0.0;
+    }
   }
   // ---- wave totals: over the wave's row groups (butterfly over the group index), then the workgroup's waves in order ----
 #pragma unroll
