@@ -344,32 +344,14 @@ def run_rank(args):
         # gather of device-resident results, the opt-in pooled adaptation); it is probed with one all-reduce whose answer every
         # rank checks, and the ranks agree through the gloo group whether it is usable.  If it is not, the run goes on over gloo
         # and says so in `collective_backend` instead of dying in the launcher.
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        from pymc_amd.parallel import init_process_groups, rccl_group
+
         if not stub:
             torch.cuda.set_device(local)
-        if args.backend == "nccl":
-            ok = 1
-            try:
-                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
-                one = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local))
-                dist.all_reduce(one, group=grp)
-                torch.cuda.synchronize()
-                if int(round(float(one.item()))) != world:
-                    raise RuntimeError(f"all-reduce of ones over RCCL gave {float(one.item())}, not {world}")
-                rccl["group"] = grp
-            except Exception as e:   # noqa: BLE001  (whatever RCCL / the runtime raises: the bench must still produce its line)
-                ok = 0
-                rccl["why_not"] = f"{type(e).__name__}: {str(e)[:300]}"
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                rccl["ranks"] = world
-            else:
-                rccl["group"] = None
-                whys = [None] * world
-                dist.all_gather_object(whys, rccl["why_not"])
-                rccl["why_not"] = next((w_ for w_ in whys if w_), "another rank could not bring RCCL up")
-                args.backend = "gloo"
+        status = init_process_groups(args.backend, local_device=local)    # (pymc_amd/parallel.py: the same bring-up `sample()` launches use)
+        rccl.update(group=rccl_group(), ranks=status["ranks"], why_not=status["why_not"])
+        if args.backend == "nccl" and not rccl["ranks"]:
+            args.backend = "gloo"
     elif not stub:
         torch.cuda.set_device(0)
 

@@ -92,3 +92,62 @@ def sample_in_processes(step, starts: Sequence[dict], rngs: Sequence[np.random.G
     if err is not None:
         raise ParallelSamplingError(f"Chain {err[1]} failed with: {err[2]}\n{err[3]}", err[1])
     return np.stack(out_draws), out_stats, out_state
+
+
+# ---- process groups for one-rank-per-GPU launches (`torch.distributed.run`) ----------------------------------------------------------
+_RCCL = {"group": None, "ranks": 0, "why_not": None}
+
+
+def rccl_group():
+    """The RCCL group `init_process_groups` brought up (None: not requested, or it could not come up -- see `rccl_status()`)."""
+    return _RCCL["group"]
+
+
+def rccl_status() -> dict:
+    return {"ranks": _RCCL["ranks"], "why_not": _RCCL["why_not"]}
+
+
+def init_process_groups(backend: str = "nccl", local_device=None, timeout_s: float = 120.0) -> dict:
+    """Bring up the process groups of a one-rank-per-GPU launch (RANK / WORLD_SIZE / MASTER_* in the environment).
+
+    The DEFAULT group is gloo, on the host: barriers and the exchange of small Python objects cannot fail for a reason that has to
+    do with the GPU runtimes, and independent chains exchange nothing on the data path.  With
+    `backend="nccl"` RCCL is brought up NEXT TO it as a second group -- for the final gather of the draws and the opt-in pooled
+    adaptation -- and probed with one all-reduce of ones whose sum every rank checks; the ranks agree through the host group
+    whether it is usable.  If it is not, everything runs over the host group and `rccl_status()["why_not"]` says why, instead of
+    the launch dying or hanging.  Returns `rccl_status()`."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+    world = dist.get_world_size()
+    _RCCL.update(group=None, ranks=0, why_not=None)
+    if backend != "nccl" or world < 2:
+        return rccl_status()
+    ok = 1
+    try:
+        if local_device is not None:
+            torch.cuda.set_device(int(local_device))
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        one = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", int(local_device or 0)))
+        dist.all_reduce(one, group=grp)
+        torch.cuda.synchronize()
+        if int(round(float(one.item()))) != world:
+            raise RuntimeError(f"all-reduce of ones over RCCL gave {float(one.item())}, not {world}")
+        _RCCL["group"] = grp
+    except Exception as e:   # noqa: BLE001  (whatever RCCL / the runtime raises: the caller goes on over the host group)
+        ok = 0
+        _RCCL["why_not"] = f"{type(e).__name__}: {str(e)[:300]}"
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        _RCCL["ranks"] = world
+    else:
+        _RCCL["group"] = None
+        whys = [None] * world
+        dist.all_gather_object(whys, _RCCL["why_not"])
+        _RCCL["why_not"] = next((w for w in whys if w), "another rank could not bring RCCL up")
+    return rccl_status()

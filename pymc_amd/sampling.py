@@ -252,12 +252,13 @@ class PooledAdaptation:
     estimator (160 KB at n = 10 000): latency-bound on xGMI.
     """
 
-    def __init__(self, n: int, device):
+    def __init__(self, n: int, device, group=None):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
         self.n = n
+        self.group = group    # (None: the default group; `parallel.rccl_group()` when RCCL runs next to a gloo default group)
         self.buf = torch.zeros(2 * (2 * n + 1), dtype=torch.float64, device=device)
 
     def _merge(self, part):
@@ -265,12 +266,12 @@ class PooledAdaptation:
         torch, dist, n = self.torch, self.dist, self.n
         cnt, mean, m2 = part[0:1], part[1 : 1 + n], part[1 + n : 1 + 2 * n]
         tot = cnt.clone()
-        dist.all_reduce(tot)
+        dist.all_reduce(tot, group=getattr(self, "group", None))
         wmean = mean * cnt
-        dist.all_reduce(wmean)
+        dist.all_reduce(wmean, group=getattr(self, "group", None))
         pooled_mean = wmean / torch.clamp(tot, min=1e-300)
         m2p = m2 + cnt * (mean - pooled_mean) ** 2
-        dist.all_reduce(m2p)
+        dist.all_reduce(m2p, group=getattr(self, "group", None))
         cnt.copy_(tot)
         mean.copy_(pooled_mean)
         m2.copy_(m2p)
@@ -293,7 +294,7 @@ class PooledAdaptation:
         from pymc_amd import _lib
 
         t = self.torch.tensor([step._scalar("log_step"), step._scalar("log_bar")], dtype=self.torch.float64, device=self.buf.device)
-        self.dist.all_reduce(t)
+        self.dist.all_reduce(t, group=getattr(self, "group", None))
         t /= self.dist.get_world_size()
         _lib.load().nuts_chain_set_log_step_bar(step._chain, float(t[0]), float(t[1]))
 
@@ -381,8 +382,15 @@ def sample(
             raise ValueError(f"pooled_adaptation needs the chains ({chains}) to divide evenly over the ranks ({world})")
         if type(step.potential) is not QuadPotentialDiagAdapt:
             raise ValueError("pooled_adaptation pools the Welford windows of QuadPotentialDiagAdapt (init='adapt_diag' / 'jitter+adapt_diag')")
-        dev = torch.device("cuda", device if device is not None else 0)
-        pooled = PooledAdaptation(spec.n, dev)
+        from pymc_amd.parallel import rccl_group
+
+        import torch.distributed as _dist
+
+        # device buffers when the Welford partials can travel over RCCL (a group next to a gloo default, or an nccl default group);
+        # host buffers over the gloo default group otherwise
+        on_gpu = rccl_group() is not None or _dist.get_backend() == "nccl"
+        dev = torch.device("cuda", device if device is not None else 0) if on_gpu else torch.device("cpu")
+        pooled = PooledAdaptation(spec.n, dev, group=rccl_group())
     total = tune + draws
     local_draws = np.empty((len(mine), total, spec.n))
     local_stats = []
@@ -477,15 +485,20 @@ def gather_trace(result, chains: int, rank: int, world: int, device):
     import torch
     import torch.distributed as dist
 
-    backend = dist.get_backend()
-    dev = torch.device("cuda", device if device is not None else 0) if backend == "nccl" else torch.device("cpu")
+    from pymc_amd.parallel import rccl_group
+
+    # the draws travel over RCCL when a group is up (`parallel.init_process_groups`, or a default group the caller initialised with
+    # the nccl backend), over the host group otherwise; the statistics are Python objects and always take the default group
+    grp = rccl_group()
+    on_gpu = grp is not None or dist.get_backend() == "nccl"
+    dev = torch.device("cuda", device if device is not None else 0) if on_gpu else torch.device("cpu")
     per_rank = (chains + world - 1) // world
     d = result["draws"]
     pad = np.zeros((per_rank,) + d.shape[1:])
     pad[: d.shape[0]] = d
     t = torch.from_numpy(pad).to(dev)
     out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-    dist.gather(t, out, dst=0)
+    dist.gather(t, out, dst=0, group=grp)
     mine_stats = {"stats": result["stats"], "warmup_stats": result.get("warmup_stats", []), "sampling_time": result.get("sampling_time", 0.0)}
     all_stats = [None] * world if rank == 0 else None
     dist.gather_object(mine_stats, all_stats, dst=0)
