@@ -486,8 +486,10 @@ def run_rank(args):
                 walls = [wall]
                 more = get_random_generator(args.seed + 1).spawn(args.ess_chains)
                 for cc in range(1, args.ess_chains):
-                    start = {k_: np.asarray(v_) + more[cc].uniform(-1, 1, size=np.shape(v_)) for k_, v_ in points[rank].items()} \
-                        if isinstance(points[rank], dict) else np.asarray(points[rank]) + more[cc].uniform(-1, 1, size=np.shape(points[rank]))
+                    # (U(-1, 1) around the model's initial point, as `jitter+adapt_diag` starts every chain: mcmc.py:1695-1756)
+                    from pymc_amd.sampling import _jitter_point, initial_point
+
+                    start = _jitter_point(initial_point(spec), int(more[cc].integers(2**30)), extra=spec.extra)
                     step.sampling_state = initial_state
                     t2 = time.perf_counter()
                     d_c, _ = sample_chain(step, start, more[cc], args.ess_tune, args.ess_draws)
