@@ -180,6 +180,40 @@ def test_lean_path_with_further_scalars_matches_the_three_kernel_path(monkeypatc
             assert int(a[k]) == int(b[k])
 
 
+@pytest.mark.parametrize("env", [{"NUTS_ROWS_GA": "2"}, {"NUTS_ROWS_GA": "2", "NUTS_ROWS_GA_W": "2"}, {}])
+def test_auxiliary_workgroups_on_ragged_and_empty_groups(env, monkeypatch):
+    """Ragged group sizes, groups without any row (first, middle, last) and single-row groups under a HalfCauchy hyper-prior and with
+    further variables: the auxiliary workgroups do not depend on the row geometry (forced group-aligned pass with one / two waves per
+    group; default: the group-block pass from 64 groups on)."""
+    from pymc_amd.model_spec import ModelBuilder
+
+    _clear(monkeypatch)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(13)
+    G, D = 70, 8
+    sizes = rng.integers(0, 260, size=G)
+    sizes[[0, 17, 18, G - 1]] = 0
+    sizes[[5, 6]] = 1
+    gidx = np.repeat(np.arange(G), sizes).astype("int32")
+    N = len(gidx)
+    X = rng.normal(size=(N, D))
+    X[:, 0] = 1.0
+    y = (rng.random(N) < 0.45).astype("int8")
+    m = ModelBuilder()
+    tau = m.HalfCauchy("tau", 1.0)
+    m.Normal("alpha", 0.0, tau)
+    mu = m.StudentT("mu", 5.0, 0.0, 2.0, shape=D)
+    sigma = m.HalfCauchy("sigma", 1.0, shape=D)
+    z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    theta = m.Normal("theta", 0.0, 1.0, shape=37)
+    m.Normal("y2", theta, 0.5, observed=rng.normal(size=37))
+    m.HierLogitRows("y", X, y, gidx, mu, sigma, z)
+    spec = m.build()
+    _check(spec, expect={"rows_group_aligned": 1.0, "rows_aux_workgroups": True})
+    _nuts_integers(spec, tune=20, draws=8, seed=2)
+
+
 # ---- at the benchmark's own size -----------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def c2l_rows():
