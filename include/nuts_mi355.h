@@ -418,6 +418,27 @@ int nuts_chain_profile(nuts_chain *c, int enable);
 int nuts_chain_profile_read(nuts_chain *c, double *dominant_ms_sum, int64_t *dominant_launches,
                             int64_t *leapfrogs);
 
+/* ---- chain groups: lockstep chains of one model on one GPU (BASELINE configs[2]: "chains": 4) --------------------------------
+ * The reference runs the chains of `pm.sample(chains=4)` as independent workers (pymc/sampling/mcmc.py:1385-1500,
+ * sampling/parallel.py:477-589); its accelerator path advances them together (`jax.vmap` over the chain axis,
+ * sampling/jax.py:341-348).  A group is the device-side form of the latter for models that are one constant-covariance MvNormal
+ * node on the row-aligned pass: up to 4 chains, each created on its OWN model handle built from the same spec, each driven by its
+ * own host thread through the ordinary nuts_chain_draw / nuts_chain_draw_many calls.  While they are members, the chains submit
+ * to one stream and the leapfrog launches of chains that stand inside a tree at the same time are merged into ONE launch that
+ * reads the precision matrix once for all of them (csrc/mvn_multi_kernel.h).  Chains keep their own state, random streams, tree
+ * shapes and lengths; a chain in a group produces BITWISE the draws and statistics it produces alone.
+ *
+ * nuts_group_add: the chain's model must carry exactly this one chain and the same node data as the members before it (checked
+ * bit by bit); NUTS_E_ARG with a text otherwise.  Call it (and nuts_group_remove / nuts_group_destroy, which restore the models'
+ * own streams) while no thread is inside a draw call of a member.  nuts_chain_destroy / nuts_model_destroy of a member remove it
+ * first.  nuts_group_launches: by_chains[c], c = 1..4 = submitted launches that carried c chains ([0] unused). */
+typedef struct nuts_group nuts_group;
+nuts_group *nuts_group_create(void);
+int nuts_group_add(nuts_group *g, nuts_chain *c);
+int nuts_group_remove(nuts_group *g, nuts_chain *c);
+void nuts_group_destroy(nuts_group *g);
+int nuts_group_launches(nuts_group *g, int64_t *by_chains /* [5] */);
+
 /* ---- categorical Gibbs within Metropolis for mixture assignments (BASELINE configs[4]) ----------
  * Replaces `CategoricalGibbsMetropolis.astep_unif` (pymc/step_methods/metropolis.py:771-786) for the assignment vector of a
  * Normal mixture, c_i ~ Categorical(w), y_i ~ Normal(mu[c_i], sigma[c_i]): the reference proposes one element at a time and

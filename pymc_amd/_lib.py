@@ -259,6 +259,11 @@ SYMBOLS = {
     "nuts_advi_set_params": (C.c_int, [_VP, _PD, _PD]),
     "nuts_chain_profile": (C.c_int, [_VP, C.c_int]),
     "nuts_chain_profile_read": (C.c_int, [_VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "nuts_group_create": (_VP, []),
+    "nuts_group_add": (C.c_int, [_VP, _VP]),
+    "nuts_group_remove": (C.c_int, [_VP, _VP]),
+    "nuts_group_destroy": (None, [_VP]),
+    "nuts_group_launches": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

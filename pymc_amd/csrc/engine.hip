@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <ctime>
 #include <string>
@@ -116,6 +117,12 @@ struct nuts_model {
   size_t ev_used = 0;
   int64_t dom_launches = 0;
   int sample_every = 1;
+  // chain group (lockstep chains of one MvNormal model, mvn_multi_kernel.h): while a member, `stream` is the group's stream
+  hipStream_t own_stream = nullptr;
+  struct nuts_group* group = nullptr;
+  bool g_active = false;       // the model's chain is inside a tree (its leaf launches are deposited with the group)
+  int gslot = 0;               // the model's place in the group
+  int n_chains = 0;            // chains created on this model
 
   template <typename T>
   T* keep(T* p) {
@@ -134,6 +141,94 @@ extern "C" int nuts_set_device(int device) {
   return NUTS_OK;
 }
 extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
+
+// ---- chain group: chains of the same MvNormal model advance through ONE launch per leapfrog (mvn_multi_kernel.h) ----
+// Every member chain is driven by its own host thread exactly as a chain alone (same calls, same order); all members submit to one
+// in-order stream.  The only thing that changes is the leaf launch of the row-aligned pass inside a tree: the thread DEPOSITS its
+// arguments and returns once the launch that carries them has been submitted -- by whichever thread completes the set of chains
+// that are inside a tree.  A chain between two trees (finishing a draw, adapting, starting the next one) or past the end of its
+// run is not waited for: the others go on without it, and it joins the next launch it is ready for.
+struct nuts_group {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  nuts_model* member[MVM_MAXC] = {};
+  int n = 0;
+  int nactive = 0, npend = 0;
+  std::atomic<unsigned> gen{0};
+  MvaLeafArgs pend[MVM_MAXC];
+  int64_t launches[MVM_MAXC + 1] = {};   // submitted launches by the number of chains they carried
+};
+
+static nuts_model* group_base(nuts_group* g) {   // whose copy of (P, mu) every launch reads: one copy stays cache-resident
+  for (int i = 0; i < MVM_MAXC; ++i) if (g->member[i]) return g->member[i];
+  return nullptr;
+}
+
+static void group_flush_locked(nuts_group* g) {
+  const int nc = g->npend;
+  if (!nc) return;
+  const ModelDev& md = group_base(g)->md;
+  const dim3 grid(MVM_MAXC + md.mv.al_nwg);
+  int order[MVM_MAXC] = {0, 1, 2, 3};   // (by place in the group, not by arrival: the launch does not depend on who came first)
+  for (int a = 1; a < nc; ++a)
+    for (int b = a; b > 0 && g->pend[order[b]].slot < g->pend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
+#define MVM_LAUNCH(RR, NC)                                                                                                   \
+  {                                                                                                                          \
+    MvaMultiArgs<NC> ma;                                                                                                     \
+    for (int c = 0; c < NC; ++c) ma.c[c] = g->pend[order[c]];                                                                \
+    hipLaunchKernelGGL((k_mvn_aligned_multi<RR, NC>), grid, dim3(MVM_THREADS(NC)), 0, g->stream, md, ma);                    \
+  }
+#define MVM_BY_NC(RR)                                                                                                        \
+  switch (nc) {                                                                                                              \
+    case 1: MVM_LAUNCH(RR, 1) break;                                                                                         \
+    case 2: MVM_LAUNCH(RR, 2) break;                                                                                         \
+    case 3: MVM_LAUNCH(RR, 3) break;                                                                                         \
+    default: MVM_LAUNCH(RR, 4) break;                                                                                        \
+  }
+  if (md.mv.aligned == 8) MVM_BY_NC(8) else MVM_BY_NC(4)
+#undef MVM_BY_NC
+#undef MVM_LAUNCH
+  g->launches[nc]++;
+  g->npend = 0;
+  g->gen.fetch_add(1, std::memory_order_release);
+}
+
+static void group_deposit(nuts_model* m, const MvaLeafArgs& L) {
+  nuts_group* g = m->group;
+  unsigned mine;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->pend[g->npend++] = L;
+    mine = g->gen.load(std::memory_order_relaxed);
+    if (g->npend >= g->nactive) { group_flush_locked(g); return; }
+  }
+  for (unsigned spins = 0; g->gen.load(std::memory_order_acquire) == mine; ++spins) {
+    if ((spins & 0x3ff) == 0x3ff) std::this_thread::yield();
+    else __builtin_ia32_pause();
+  }
+}
+
+static void group_enter(nuts_model* m) {
+  if (!m->group || m->g_active) return;
+  std::lock_guard<std::mutex> lk(m->group->mu);
+  m->group->nactive++;
+  m->g_active = true;
+}
+
+static void group_leave(nuts_model* m) {
+  if (!m->group || !m->g_active) return;
+  nuts_group* g = m->group;
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->nactive--;
+  m->g_active = false;
+  if (g->npend && g->npend >= g->nactive) group_flush_locked(g);   // the others were only waiting for this chain
+}
+
+struct GroupTreeScope {   // a chain is a lockstep partner from the first leaf of a tree to the tree's last status
+  nuts_model* m;
+  explicit GroupTreeScope(nuts_model* mm) : m(mm) { group_enter(m); }
+  ~GroupTreeScope() { group_leave(m); }
+};
 
 // the control work of a leaf on the lean path as a launch of its own (kernels.h: control_lean; the row-aligned MvNormal pass
 // leaves per-workgroup records that `mva_control` sums first)
@@ -177,7 +272,8 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     hipLaunchKernelGGL(k_mix_reduce, dim3(1), dim3(WAVE), 0, m->stream, md, A, io, j);
   }
   if (!md.has_logit && !md.has_mvn && !md.has_glm) return;
-  const bool prof = m->profile && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
+  // (a member of a chain group shares its launches and its stream with other chains: event pairs around them would time the company)
+  const bool prof = m->profile && !m->group && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
   if (md.has_glm) {   // GLM node (glm_kernel.h): the fused pass over X (the timed kernel), then the totals of its records
     const dim3 grid(md.glm.nwg), block(GLM_BLOCK);
@@ -288,6 +384,13 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     const int cj = job ? job->j : j - 1, cd = job ? job->d : d, cseq = job ? job->seq : 0;
 #define MVA_LAUNCH(RR) hipLaunchKernelGGL(k_mvn_aligned<RR>, dim3(md.mv.al_nwg + 1), dim3(MVA_THREADS), 0, m->stream, md, A, io, j, \
                                            fold, d, Emax, max_depth, st, par, cio, cj, cd, cseq)
+    if (m->group && m->g_active && io.mode == MODE_TREE) {
+      MvaLeafArgs L;
+      L.A = A; L.io = io; L.cio = cio; L.Emax = Emax; L.st = st; L.al_part = md.mv.al_part;
+      L.j = j; L.fold = fold; L.d = d; L.max_depth = max_depth; L.par = par; L.cj = cj; L.cd = cd; L.cseq = cseq;
+      L.slot = m->gslot; L.pad = 0;
+      group_deposit(m, L);
+    } else
     switch (md.mv.aligned) {
       case 2: MVA_LAUNCH(2); break;
       case 8: MVA_LAUNCH(8); break;
@@ -606,6 +709,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   auto* m = new nuts_model();
   ModelDev& md = m->md;
   HIPCHK_NULL(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  m->own_stream = m->stream;
   int n = 0;
   for (int i = 0; i < s->n_vars; ++i) n = std::max(n, s->vars[i].offset + s->vars[i].size);
   md.n = n; md.n_vars = s->n_vars; md.n_factors = s->n_factors; md.n_data = s->n_data;
@@ -1078,13 +1182,15 @@ extern "C" int nuts_model_set_data(nuts_model* m, int32_t data_id, const double*
   return NUTS_OK;
 }
 
+static void group_remove_model(struct nuts_group* g, nuts_model* m);
 extern "C" void nuts_model_destroy(nuts_model* m) {
   if (!m) return;
   if (m->stream) hipStreamSynchronize(m->stream);
+  if (m->group) group_remove_model(m->group, m);
   for (void* p : m->owned) if (p) hipFree(p);
   for (auto e : m->ev) hipEventDestroy(e);
   if (m->host_pin) hipHostFree(m->host_pin);
-  if (m->stream) hipStreamDestroy(m->stream);
+  if (m->own_stream) hipStreamDestroy(m->own_stream);
   delete m;
 }
 
@@ -1453,6 +1559,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   }
   auto* c = new nuts_chain();
   c->m = m; c->cfg = *cfg; c->n = m->md.n;
+  m->n_chains++;
   const int n = c->n;
   c->initial_mean.assign(n, 0.0);
   c->initial_diag.assign(n, 1.0);
@@ -1549,6 +1656,8 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
 extern "C" void nuts_chain_destroy(nuts_chain* c) {
   if (!c) return;
   if (c->m) hipStreamSynchronize(c->m->stream);
+  if (c->m && c->m->group) group_remove_model(c->m->group, c->m);
+  if (c->m) c->m->n_chains--;
   for (void* p : c->owned) if (p) hipFree(p);
   if (c->stage_host) hipHostFree(c->stage_host);
   if (c->out_host) hipHostFree(c->out_host);
@@ -1560,6 +1669,79 @@ extern "C" void nuts_chain_destroy(nuts_chain* c) {
   if (c->many_in_dev) hipFree(c->many_in_dev);
   if (c->many_out_dev) hipFree(c->many_out_dev);
   delete c;
+}
+
+// ---- chain groups (include/nuts_mi355.h) ----
+static void group_remove_model(nuts_group* g, nuts_model* m) {
+  if (!g || !m || m->group != g) return;
+  hipStreamSynchronize(g->stream);
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (int i = 0; i < MVM_MAXC; ++i)
+    if (g->member[i] == m) { g->member[i] = nullptr; g->n--; }
+  if (m->g_active) { g->nactive--; m->g_active = false; }
+  m->group = nullptr;
+  m->stream = m->own_stream;
+}
+
+extern "C" nuts_group* nuts_group_create(void) {
+  nuts_group* g = new nuts_group();
+  if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) { g_err = "nuts_group_create: no stream"; delete g; return nullptr; }
+  return g;
+}
+
+extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
+  if (!g || !c || !c->m) return NUTS_E_ARG;
+  nuts_model* m = c->m;
+  const MvnDev& mv = m->md.mv;
+  if (m->group) { g_err = "nuts_group_add: the chain's model already belongs to a group"; return NUTS_E_ARG; }
+  if (m->n_chains != 1) { g_err = "nuts_group_add: a member model carries exactly one chain (its launch parity and records are the chain's)"; return NUTS_E_ARG; }
+  if (!(m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8)) || c->dense || c->host_pot) {
+    g_err = "nuts_group_add: chain groups advance models that are one constant-covariance MvNormal node on the row-aligned pass "
+            "(diagonal mass matrix); this chain is not one";
+    return NUTS_E_ARG;
+  }
+  if (g->n >= MVM_MAXC) { g_err = "nuts_group_add: a group holds at most 4 chains"; return NUTS_E_ARG; }
+  HIPCHK(hipStreamSynchronize(m->stream));
+  if (nuts_model* base = group_base(g)) {
+    // every launch reads the first member's (P, mu): the newcomer's must be the same numbers
+    const MvnDev& bv = base->md.mv;
+    if (bv.k != mv.k || bv.aligned != mv.aligned || bv.konst != mv.konst) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
+    const size_t kk = (size_t)mv.k * mv.k;
+    std::vector<double> a(kk + mv.k), b(kk + mv.k);
+    HIPCHK(hipMemcpy(a.data(), bv.prec, kk * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data(), mv.prec, kk * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(a.data() + kk, bv.mu, mv.k * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(b.data() + kk, mv.mu, mv.k * sizeof(double), hipMemcpyDeviceToHost));
+    if (std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) != 0) { g_err = "nuts_group_add: not the same model as the group's (precision or mean differ)"; return NUTS_E_ARG; }
+  }
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (int i = 0; i < MVM_MAXC; ++i)
+    if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
+  g->n++;
+  m->group = g;
+  m->stream = g->stream;
+  return NUTS_OK;
+}
+
+extern "C" int nuts_group_remove(nuts_group* g, nuts_chain* c) {
+  if (!g || !c || !c->m || c->m->group != g) return NUTS_E_ARG;
+  group_remove_model(g, c->m);
+  return NUTS_OK;
+}
+
+extern "C" void nuts_group_destroy(nuts_group* g) {
+  if (!g) return;
+  for (int i = 0; i < MVM_MAXC; ++i)
+    if (g->member[i]) group_remove_model(g, g->member[i]);
+  hipStreamDestroy(g->stream);
+  delete g;
+}
+
+extern "C" int nuts_group_launches(nuts_group* g, int64_t* by_chains) {
+  if (!g || !by_chains) return NUTS_E_ARG;
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (int i = 0; i <= MVM_MAXC; ++i) by_chains[i] = g->launches[i];
+  return NUTS_OK;
 }
 
 extern "C" int nuts_chain_reset_tuning(nuts_chain* c) {  // base_hmc.py:290-298
@@ -1765,6 +1947,11 @@ static int wait_status(nuts_chain* c, int seq, unsigned* flags, int* cursor = nu
   volatile unsigned long long* word = &c->st_host->word[seq & (ST_SLOTS - 1)];
   const auto t0 = std::chrono::steady_clock::now();
   unsigned long long w;
+  // (member of a chain group: the chain stays a lockstep partner while it waits -- everything this status depends on has been
+  // submitted, since a deposit returns only after its launch was; partners that are ahead wait at their next deposit until this
+  // chain has seen its status and deposits too, which keeps the chains of a group leaf by leaf in the same launches.  Letting
+  // the others go on instead was measured: the host runs far ahead of the device, every chain spends most of its time here, and
+  // the chains took turns -- 1.17 chains per launch.)
   for (unsigned spins = 0; (unsigned)((w = *word) >> 32) != (unsigned)seq; ++spins) {
     if ((spins & 0xfffff) == 0xfffff) {
       if (hipStreamQuery(c->m->stream) == hipSuccess && (unsigned)(*word >> 32) != (unsigned)seq) {
@@ -1927,6 +2114,7 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
   using clk = std::chrono::steady_clock;
   int rc = NUTS_OK;
   bool exhausted = true;
+  GroupTreeScope lockstep(c->m);
   // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
   // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
   unsigned flags = 0;

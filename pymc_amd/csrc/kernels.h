@@ -1245,7 +1245,9 @@ __global__ __launch_bounds__(MVN_BLOCK) void k_mvn_matvec(ModelDev md, ArenaDev 
 #define MVA_SW 16   // slots per load window (a wave's load covers 4 records x 16 slots)
 #define MVA_U 32    // loads in flight per lane
 __device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax, int max_depth,
-                                            HostStatus* st, int seq, int par, int nt) {
+                                            HostStatus* st, int seq, int par, int nt, const double* al_part) {
+  // (`al_part`: the records of THIS chain -- md.mv.al_part for a chain alone on its model, the chain's own buffer when several
+  // chains of a group share one launch, mvn_multi_kernel.h)
   const MvnDev& mv = md.mv;
   __shared__ double s_rec[PART_STRIDE];
   __shared__ double s_wp[VEC_THREADS / WAVE][NDOT + 1];
@@ -1264,7 +1266,7 @@ __device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& 
     return PART_DOT + DOT_TOP + (qq - 2 - 6 * m);
   };
   const int nwg = mv.al_nwg;
-  const double* rec = mv.al_part + (int64_t)par * MVA_RS * nwg;
+  const double* rec = al_part + (int64_t)par * MVA_RS * nwg;
   // the uniforms this leaf may consume: the cursor is read straight from the control block with the very first loads
   UniPrefetch upf;
   uni_prefetch_none(upf);
@@ -1312,7 +1314,7 @@ __device__ __forceinline__ void mva_control(const ModelDev& md, const ArenaDev& 
 
 __global__ __launch_bounds__(VEC_THREADS) void k_mva_control(ModelDev md, ArenaDev A, EvalIO io, int j, int d, double Emax, int max_depth,
                                                             HostStatus* st, int seq, int par) {
-  mva_control(md, A, io, j, d, Emax, max_depth, st, seq, par, VEC_THREADS);
+  mva_control(md, A, io, j, d, Emax, max_depth, st, seq, par, VEC_THREADS, md.mv.al_part);
 }
 
 // `fold`: workgroup 0 does the control work of the leaf of the PREVIOUS row-aligned launch -- leaf (cio, cj, cd): normally leaf
@@ -1332,7 +1334,7 @@ __global__ __launch_bounds__(MVA_THREADS) void k_mvn_aligned(ModelDev md, ArenaD
   // belong to workgroup b, hence to the same XCD, whose L2 keeps its eighth of P from launch to launch.
   if (blockIdx.x == 0) {
     if (!fold || threadIdx.x >= VEC_THREADS) return;   // (the control code is written for VEC_THREADS threads)
-    mva_control(md, A, cio, cj, cd, Emax, max_depth, st, cseq, par ^ 1, VEC_THREADS);
+    mva_control(md, A, cio, cj, cd, Emax, max_depth, st, cseq, par ^ 1, VEC_THREADS, mv.al_part);
     return;
   }
   const int b = (int)blockIdx.x - 1;
@@ -1678,3 +1680,4 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, con
 #include "rows_gb_kernel.h"
 #include "dense_adapt.h"
 #include "glm_kernel.h"
+#include "mvn_multi_kernel.h"

@@ -316,6 +316,7 @@ def sample(
     cores: Optional[int] = None,
     mp_ctx: Optional[str] = None,
     return_multitrace: bool = False,
+    lockstep: Optional[bool] = None,
     **step_kwargs,
 ):
     """Reduced `pm.sample` (mcmc.py:620-1190) returning raw arrays (and, with ``return_multitrace=True``, the reference's
@@ -324,6 +325,10 @@ def sample(
     Returns a dict with ``draws`` (chains, draws, n), ``stats`` (per chain list of
     per-draw dicts), ``point_map_info`` and timing.  Under torch.distributed every
     rank samples its chains and rank 0 receives the gathered draws.
+
+    ``lockstep`` (chains of a rank that run concurrently, see ``cores``): None = let the engine merge the leapfrog launches of the
+    chains when it can (`pymc_amd/chain_group.py`: models that are one MvNormal node; the draws are bitwise those of independent
+    chains), False = never, True = raise if it cannot.
 
     ``cores`` (mcmc.py:690-693 `cores`: "number of chains to run in parallel"): the reference runs chains in
     worker processes on host cores (parallel.py:352-372).  Here a chain of a model on the single-launch path keeps
@@ -392,6 +397,7 @@ def sample(
         dev = torch.device("cuda", device if device is not None else 0) if on_gpu else torch.device("cpu")
         pooled = PooledAdaptation(spec.n, dev, group=rccl_group())
     total = tune + draws
+    lockstep_launches = None
     local_draws = np.empty((len(mine), total, spec.n))
     local_stats = []
     t0 = time.perf_counter()
@@ -430,6 +436,16 @@ def sample(
             for _ in range(n_par - 1)
         ]
 
+        # chains of a model the engine can advance in lockstep (one MvNormal node, pymc_amd/chain_group.py) share their leapfrog
+        # launches: the precision matrix is read once for all chains that stand at a leaf together.  Same draws, bit for bit.
+        group = None
+        if lockstep or lockstep is None:
+            from pymc_amd.chain_group import ChainGroup
+
+            group = ChainGroup.try_create(steps)
+            if group is None and lockstep:
+                raise ValueError("lockstep=True: the engine cannot advance this model's chains in one launch (pymc_amd/chain_group.py)")
+
         def work(w):
             st = steps[w]
             st._logp_dlogp_func.bind_thread()
@@ -440,16 +456,21 @@ def sample(
             return res
 
         local_stats = [None] * len(mine)
-        with ThreadPoolExecutor(max_workers=n_par) as ex:
-            for res in ex.map(work, range(n_par)):
-                t_worker = 0.0
-                for k, (d, s) in res:
-                    local_draws[k] = d
-                    local_stats[k] = s
-                    t_worker += sum(x["perf_counter_diff"] for x in s[tune:])
-                t_sampling = max(t_sampling, t_worker)   # (the workers overlap: the sampling time is the slowest worker's, not the sum)
-        for st in steps[1:]:
-            st.close()
+        try:
+            with ThreadPoolExecutor(max_workers=n_par) as ex:
+                for res in ex.map(work, range(n_par)):
+                    t_worker = 0.0
+                    for k, (d, s) in res:
+                        local_draws[k] = d
+                        local_stats[k] = s
+                        t_worker += sum(x["perf_counter_diff"] for x in s[tune:])
+                    t_sampling = max(t_sampling, t_worker)   # (the workers overlap: the sampling time is the slowest worker's, not the sum)
+        finally:
+            if group is not None:
+                lockstep_launches = group.launches()
+                group.close()
+            for st in steps[1:]:
+                st.close()
     else:
         for k, c in enumerate(mine):
             step.sampling_state = initial_state
@@ -467,6 +488,7 @@ def sample(
         "point_map_info": spec.point_map_info,
         "wall_time": wall,
         "sampling_time": t_sampling,
+        "lockstep_launches": lockstep_launches,   # [_, n1..n4]: leapfrog launches that carried 1..4 chains (None: chains not grouped)
         "step": step,
     }
     if gather and world > 1:

@@ -1,0 +1,140 @@
+"""Lockstep chains of one MvNormal model on one GPU (csrc/mvn_multi_kernel.h, include/nuts_mi355.h "chain groups",
+pymc_amd/chain_group.py): `pm.sample(chains=4)` of BASELINE configs[2].
+
+The reference's chains are independent (pymc/sampling/mcmc.py:1385-1500): whatever a chain's company on the device, it must
+produce the draws and statistics it produces alone -- here bit for bit, because a chain's numbers inside a merged launch are
+formed from its own operands in the single-chain kernel's order."""
+
+import threading
+
+import numpy as np
+import pytest
+
+from pymc_amd import _lib, models
+
+pytestmark = pytest.mark.gpu
+
+TIMING = ("perf_counter_diff", "perf_counter_start", "process_time_diff")
+
+
+def _same_stats(a, b, what):
+    assert len(a) == len(b), what
+    for i, (x, y) in enumerate(zip(a, b)):
+        for key in x:
+            if key in TIMING:
+                continue
+            if key == "warning":
+                assert str(x[key]) == str(y[key]), (what, i, x[key], y[key])
+                continue
+            xv, yv = np.asarray(x[key]), np.asarray(y[key])
+            assert np.array_equal(xv, yv, equal_nan=xv.dtype.kind == "f"), (what, i, key, x[key], y[key])
+
+
+def _sample(spec, chains, lockstep, cores, tune, draws, seed):
+    from pymc_amd.sampling import sample
+
+    res = sample(draws=draws, tune=tune, chains=chains, model=spec, init="jitter+adapt_diag", random_seed=seed, device=0, cores=cores,
+                 lockstep=lockstep, discard_tuned_samples=False)
+    res["step"].close()
+    return res
+
+
+@pytest.mark.parametrize("k,chains,tune,draws", [(512, 4, 40, 20), (301, 3, 30, 10), (2048, 4, 12, 6), (1024, 2, 20, 10)])
+def test_grouped_chains_are_bitwise_the_chains_alone(k, chains, tune, draws):
+    """Four (three, two) chains from jittered starts, trees of different shapes and lengths while the step size adapts: sampled one
+    after the other, concurrently as independent engines, and concurrently in a group.  Rows per workgroup 4 (k < 1024) and 8;
+    k = 301: a last workgroup with one row and an odd column count."""
+    spec = models.mvnormal(n=k, seed=5)
+    alone = _sample(spec, chains, False, 1, tune, draws, 31)
+    threads = _sample(spec, chains, False, chains, tune, draws, 31)
+    group = _sample(spec, chains, True, chains, tune, draws, 31)
+    assert alone["lockstep_launches"] is None and threads["lockstep_launches"] is None
+    n = group["lockstep_launches"]
+    assert n is not None and sum(n[2:]) > 0, n          # launches that carried more than one chain
+    leapfrogs = sum(int(s["tree_size"]) for c in range(chains) for s in group["stats"][c])
+    # every leapfrog of every chain went through the group (plus the look-ahead launches that drained behind a finished tree)
+    assert leapfrogs <= sum(c * n[c] for c in range(1, 5)) <= 1.5 * leapfrogs, (n, leapfrogs)
+    for other, what in ((threads, "independent engines"), (group, "group")):
+        assert np.array_equal(alone["draws"], other["draws"]), (k, what)
+        for c in range(chains):
+            _same_stats(alone["stats"][c], other["stats"][c], (k, what, c))
+    sizes = [[int(s["tree_size"]) for s in group["stats"][c]] for c in range(chains)]
+    assert len({tuple(s) for s in sizes}) == chains          # (the chains really grew different trees)
+    print(f"k = {k}: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, 5)) / sum(n[1:]):.2f}")
+
+
+def test_chains_of_different_length_leave_and_join():
+    """The group through its own interface: one chain stops early, one starts late, one is sampled in two calls with a pause in
+    between -- whoever is inside a tree shares its launches, everybody else is simply not waited for."""
+    from pymc_amd.chain_group import ChainGroup
+    from pymc_amd.sampling import init_nuts, sample_chain
+
+    spec = models.mvnormal(n=512, seed=7)
+    lengths = [(15, 5), (30, 20), (10, 2)]
+
+    def make():
+        out = []
+        for _ in lengths:
+            start, step = init_nuts(spec, init="adapt_diag", chains=1, random_seed_list=[3], device=0, tune=30)
+            out.append((start[0], step))
+        return out
+
+    def run(pairs, grouped):
+        res = [None] * len(pairs)
+        group = ChainGroup([st for _, st in pairs]) if grouped else None
+
+        def work(i):
+            import time
+
+            start, st = pairs[i]
+            st._logp_dlogp_func.bind_thread()
+            if i == 2:
+                time.sleep(0.05)
+            tune, draws = lengths[i]
+            res[i] = sample_chain(st, start, np.random.default_rng(100 + i), tune, draws)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(pairs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        launches = group.launches() if group else None
+        if group:
+            group.close()
+        # (after the group is gone the chains are engines of their own again)
+        tail = [sample_chain(st, pairs[i][0], np.random.default_rng(7), 2, 3) for i, (_, st) in enumerate(pairs)]
+        for _, st in pairs:
+            st.close()
+        return res, tail, launches
+
+    a, a_tail, _ = run(make(), False)
+    b, b_tail, n = run(make(), True)
+    assert sum(n[2:]) > 0 and n[1] > 0, n
+    for i in range(len(lengths)):
+        assert np.array_equal(a[i][0], b[i][0]), i
+        _same_stats(a[i][1], b[i][1], i)
+        assert np.array_equal(a_tail[i][0], b_tail[i][0]), i
+
+
+def test_what_a_group_refuses():
+    from pymc_amd.chain_group import ChainGroup
+    from pymc_amd.sampling import init_nuts
+
+    def step_of(spec, **kw):
+        return init_nuts(spec, init="adapt_diag", chains=1, random_seed_list=[1], device=0, tune=10, **kw)[1]
+
+    a, b = step_of(models.mvnormal(n=256, seed=5)), step_of(models.mvnormal(n=256, seed=6))
+    with pytest.raises(ValueError, match="not the same model"):
+        ChainGroup([a, b])
+    c = step_of(models.hier_logit(G=32, D=8, rows_per_group=40))
+    with pytest.raises(ValueError, match="MvNormal"):
+        ChainGroup([c])
+    assert ChainGroup.try_create([a, c]) is None
+    g = ChainGroup([a])
+    with pytest.raises(ValueError, match="already belongs"):
+        ChainGroup([a])
+    g.close()
+    g2 = ChainGroup([a])     # (free again)
+    g2.close()
+    for st in (a, b, c):
+        st.close()
