@@ -19,9 +19,6 @@
 #ifndef MVM_OCC
 #define MVM_OCC 4            // waves per SIMD the register budget allows: 4 = two workgroups of 4 + NC waves per CU
 #endif
-#ifndef MVM_UNROLL
-#define MVM_UNROLL(NC) 2
-#endif
 
 struct MvaLeafArgs {   // one chain's arguments of k_mvn_aligned
   ArenaDev A;
@@ -207,7 +204,10 @@ __global__ __launch_bounds__(MVM_THREADS(NC), MVM_OCC) void k_mvn_aligned_multi(
 #pragma unroll
       for (int r = 0; r < R; ++r) s[c][r] = 0.0;
     const unsigned k2b = (unsigned)(K & ~1) * 8u;
-#pragma unroll(MVM_UNROLL(NC))
+#ifdef NUTS_KTIMING
+    int it = 0;
+#endif
+#pragma unroll 2
     for (unsigned off = 16u * (unsigned)tid; off < k2b; off += 16u * MVN_BLOCK) {
       const double2 m2 = *reinterpret_cast<const double2*>(mub + off);
       double d0[NC], d1[NC];
@@ -230,6 +230,10 @@ __global__ __launch_bounds__(MVM_THREADS(NC), MVM_OCC) void k_mvn_aligned_multi(
           s[c][r] = fma(p.y, d1[c], s[c][r]);
         }
       }
+#ifdef NUTS_KTIMING
+      TICK(md, tk && w == 0 && it < 4, 26 + it);   // (column steps one by one: slots 26 .. 29)
+      ++it;
+#endif
     }
     if (tid == 0 && (K & 1)) {
 #pragma unroll

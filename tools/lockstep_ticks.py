@@ -26,14 +26,16 @@ def main():
     out = (C.c_int64 * 64)()
     _lib.check(_lib.load().nuts_model_debug_ticks(step._logp_dlogp_func._handle, out), "ticks")
     t = np.array(out[:], dtype=np.int64)
-    t0 = min(int(t[16]), int(t[20]), int(t[24]))
-    rel = lambda i: int(t[i]) - t0
+    # (counters of different XCDs are not aligned: differences inside one workgroup only)
+    d = lambda a, b: int(t[b]) - int(t[a])
     print(json.dumps({
         "launches_by_chains": res["lockstep_launches"],
-        "stream wave 0": {"start": rel(16), "loop done": rel(17), "sums done": rel(18), "past barrier": rel(19)},
-        "tail wave (chain 0)": {"start": rel(20), "prefetch landed": rel(21), "past barrier": rel(22), "end": rel(23)},
-        "control workgroup (chain 0)": {"start": rel(24), "end": rel(25), "inside control_lean": [int(x) - t0 for x in t[8:14]]},
-    }, indent=1))
+        "row workgroup, streaming wave 0": {"loop": d(16, 17), "column steps": [d(16, 26), d(26, 27), d(27, 28), d(28, 29)], "sums": d(17, 18),
+                                            "wait at the barrier": d(18, 19)},
+        "row workgroup, tail wave of chain 0": {"requests landed": d(20, 21), "wait at the barrier": d(21, 22), "tail": d(22, 23)},
+        "row workgroup, first stamp to last": d(16, 23),
+        "control workgroup of chain 0": d(24, 25),
+    }))
     step.close()
 
 
