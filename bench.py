@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--variant", default=None, help="NOT the headline: the same rows under another model around them (pymc_amd.models.HIER_LOGIT_VARIANTS: "
                     "other hyper-priors, further variables) -- A/B of the generalised one-launch row pass against the benchmark's own model")
     ap.add_argument("--mvn-k", type=int, default=2048)
+    ap.add_argument("--chains-per-gpu", type=int, default=4, help="--workload c3, one GPU: after the timed single-chain run, BASELINE configs[2]'s "
+                    "4 chains on this GPU -- as independent engines and as a chain group (pymc_amd/chain_group.py) -- reported under "
+                    "`chains_on_one_gpu` (0 or 1 disables; NOT part of `value`)")
     ap.add_argument("--seed", type=int, default=20160911)
     ap.add_argument("--cpu-leapfrogs", type=int, default=100, help="bounded CPU-baseline sample per leg (0 disables)")
     ap.add_argument("--draw-batch", type=int, default=int(os.environ.get("PYMC_AMD_DRAW_BATCH", "64")), help="post-tuning transitions per C call")
@@ -566,11 +569,37 @@ def run_rank(args):
                 out["cpu_baseline"] = cpu_baseline_c2(args, spec, draws[-1], eps, inv_mass, args.cpu_leapfrogs,
                                                       (vec[1] / max(leap, 1.0)) if ess_ok else
                                                       (ess_run["min_ess"] / max(ess_run["leapfrogs_total"], 1.0)) if ess_run else None)
+        if c3 and world == 1 and not stub and 2 <= args.chains_per_gpu <= 4:
+            out["chains_on_one_gpu"] = chains_on_one_gpu(args, spec, local)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def chains_on_one_gpu(args, spec, device, tune=300, draws=300):
+    """BASELINE configs[2] says `"chains": 4`: the same model's four chains on ONE GPU, from host threads -- each with an engine and
+    a stream of its own, and as a chain group whose members share one launch per leapfrog (csrc/mvn_multi_kernel.h; the draws are
+    bitwise the independent chains').  Aggregate leapfrog steps/s over the post-tuning draws = all chains' leapfrogs / the slowest
+    worker's sampling time.  A separate, bounded run: not part of `value`."""
+    from pymc_amd.sampling import sample
+
+    out, ref = {"chains": args.chains_per_gpu, "tune": tune, "draws": draws}, None
+    for mode, lockstep in (("independent_engines", False), ("chain_group", True)):
+        res = sample(draws=draws, tune=tune, chains=args.chains_per_gpu, model=spec, init="jitter+adapt_diag", random_seed=args.seed, device=device,
+                     cores=args.chains_per_gpu, lockstep=lockstep)
+        res["step"].close()
+        lf = sum(int(s_["tree_size"]) for c in range(args.chains_per_gpu) for s_ in res["stats"][c])
+        n = res["lockstep_launches"]
+        out[mode] = {"leapfrog_steps_per_sec": lf / res["sampling_time"], "sampling_time_s": res["sampling_time"],
+                     "launches_by_chains_carried": n[1:] if n else None,
+                     "mean_chains_per_launch": (sum(c * n[c] for c in range(1, 5)) / max(1, sum(n[1:]))) if n else None}
+        if ref is None:
+            ref = res["draws"]
+        else:
+            out["draws_bitwise_equal"] = bool(np.array_equal(ref, res["draws"]))
+    return out
 
 
 def oracle_convergence(args):

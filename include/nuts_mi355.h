@@ -162,13 +162,21 @@ typedef struct {
        mix_assign >= 0  c_i ~ Categorical(w), y_i ~ Normal(mu[c_i], sigma[c_i]) given the assignments c = data vector mix_assign
                         (float-coded integers; an assignment outside [0, K) makes the logp -inf: discrete.py:1179-1205)
      mix_mu: variable of size K.  mix_sigma: variable of size K (untransformed or log-transformed: its constrained value is
-     used), or -1 with mix_sigma_const.  Weights: w = softmax(variable mix_w_logits), or mix_w_logits = -1 with the constant
-     weights mix_w_const (non-negative, sum 1).  The parameter variables may not be scalars that broadcast into other factors. */
+     used), or -1 with mix_sigma_const.  Weights, one of
+       w = softmax(variable mix_w_logits of size K)                         (`pm.math.softmax(logits)`), mix_w_simplex = 0;
+       w ~ Dirichlet(mix_w_alpha) under PyMC's default `simplex` transform, mix_w_simplex = 1: the variable mix_w_logits is the
+           transformed VALUE y of size K - 1 (K >= 3), w = softmax([y, -sum(y)]) (logprob/transforms.py:1091-1115 `backward`), and
+           the node adds the prior and the transform's Jacobian itself -- Dirichlet.logp(w) = sum((a - 1) log w) - sum(gammaln(a))
+           + gammaln(sum(a)) (distributions/multivariate.py `Dirichlet.logp`) + `SimplexTransform.log_jac_det`: the variable
+           carries no factor of its own;
+       mix_w_logits = -1 with the constant weights mix_w_const (non-negative, sum 1).
+     The parameter variables may not be scalars that broadcast into other factors. */
   int64_t mix_N;
-  int32_t mix_K, mix_mu, mix_sigma, mix_w_logits, mix_assign, mix_pad;
+  int32_t mix_K, mix_mu, mix_sigma, mix_w_logits, mix_assign, mix_w_simplex;
   const double *mix_y;           /* [N] */
   const double *mix_sigma_const; /* [K] or NULL */
   const double *mix_w_const;     /* [K] or NULL */
+  const double *mix_w_alpha;     /* [K] (> 0) with mix_w_simplex, else NULL */
   /* dense node 4: a generalised linear model over glm_N observed rows with glm_P <= 512 covariates -- the linear predictor
        eta_i = intercept + x_i . beta          (`pm.math.dot(X, beta)`, pymc/math.py:56; what `pytensor.grad` differentiates
                                                 inside ValueGradFunction, model/core.py:213-267)

@@ -19,6 +19,7 @@ import math
 
 import numpy as np
 import scipy.linalg
+import scipy.special
 from scipy.special import erf, erfc, erfcx, expit
 
 LOG_SQRT_2PI = math.log(math.sqrt(2.0 * math.pi))
@@ -543,7 +544,16 @@ def _mixture_rows(spec, node, x):
         sigma = x[vs.offset : vs.offset + K]
     else:
         sigma = np.asarray(node.sigma_const, dtype="d")
-    if node.w_logits is not None:
+    simplex = getattr(node, "w_alpha", None) is not None
+    if simplex:
+        # w ~ Dirichlet(a) under the default simplex transform: the value is y (K - 1 elements),
+        #   w = softmax([y, -sum(y)])                                                  logprob/transforms.py:1101-1104 (`backward`)
+        vw = spec.vars[node.w_logits]
+        yv = x[vw.offset : vw.offset + K - 1]
+        eta = np.concatenate([yv, [-yv.sum()]])
+        e = np.exp(eta - eta.max())
+        w = e / e.sum()
+    elif node.w_logits is not None:
         vw = spec.vars[node.w_logits]
         eta = x[vw.offset : vw.offset + K]
         e = np.exp(eta - eta.max())
@@ -574,7 +584,23 @@ def _mixture_rows(spec, node, x):
     g[vm.offset : vm.offset + K] = A / sigma**2
     if node.sigma is not None:
         g[vs.offset : vs.offset + K] = B / sigma**3 - R / sigma
-    if node.w_logits is not None:
+    if simplex:
+        a_ = np.asarray(node.w_alpha, dtype="d")
+        # Dirichlet.logp(w) = sum(logpow(w, a - 1) - gammaln(a)) + gammaln(sum(a))      distributions/multivariate.py (Dirichlet.logp)
+        lp_prior = float(np.sum((a_ - 1.0) * logw) - np.sum(scipy.special.gammaln(a_)) + scipy.special.gammaln(a_.sum()))
+        # SimplexTransform.log_jac_det (logprob/transforms.py:1106-1115), restated literally:
+        #   N = K; s = sum(y); res = log(N) + N * s - N * logsumexp([y + s, 0]); sum(res)
+        sv = yv.sum()
+        ext = np.concatenate([yv + sv, [0.0]])
+        lse_ext = ext.max() + np.log(np.exp(ext - ext.max()).sum())
+        lp_jac = float(np.log(K) + K * sv - K * lse_ext)
+        lp += lp_prior + lp_jac
+        # gradient w.r.t. the full logits eta (log w_k = eta_k - logsumexp(eta), and logsumexp([y + s, 0]) = s + logsumexp(eta)):
+        #   d/d eta_k [ sum_k c_k log w_k - K logsumexp(eta) ] = c_k - (sum(c) + K) w_k,   c_k = R_k + a_k - 1, sum(R) = N rows
+        c_ = R + a_ - 1.0
+        gfull = c_ - (y.size + np.sum(a_ - 1.0) + K) * w
+        g[vw.offset : vw.offset + K - 1] = gfull[:-1] - gfull[-1]       # eta_{K-1} = -sum(y)
+    elif node.w_logits is not None:
         g[vw.offset : vw.offset + K] = R - y.size * w
     return float(lp), g
 

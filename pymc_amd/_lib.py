@@ -98,10 +98,11 @@ class ModelSpecC(C.Structure):
         ("mix_sigma", C.c_int32),
         ("mix_w_logits", C.c_int32),
         ("mix_assign", C.c_int32),
-        ("mix_pad", C.c_int32),
+        ("mix_w_simplex", C.c_int32),
         ("mix_y", C.POINTER(C.c_double)),
         ("mix_sigma_const", C.POINTER(C.c_double)),
         ("mix_w_const", C.POINTER(C.c_double)),
+        ("mix_w_alpha", C.POINTER(C.c_double)),
         ("glm_N", C.c_int64),
         ("glm_P", C.c_int32),
         ("glm_family", C.c_int32),

@@ -55,7 +55,7 @@ class NDArray:
         self.model = model
         self._layout = [(nm, v, u) for nm, v, u in _var_layout(model, include_transformed) if vars is None or nm in vars]
         self.varnames = [nm for nm, _, _ in self._layout]
-        self.var_shapes = {nm: tuple(v.shape) for nm, v, _ in self._layout}
+        self.var_shapes = {nm: tuple(v.constrained_shape if u else v.shape) for nm, v, u in self._layout}
         # `pm.Deterministic` variables (model/core.py:1940-2005) follow the free variables in `model.unobserved_RVs`; their values
         # are functions of the constrained values, evaluated when a draw is recorded (backends/base.py:183-191)
         self._dets = [(nm, d) for nm, d in getattr(model, "deterministics", {}).items() if vars is None or nm in vars]

@@ -209,14 +209,14 @@ static void group_deposit(nuts_model* m, const MvaLeafArgs& L) {
 }
 
 static void group_enter(nuts_model* m) {
-  if (!m->group || m->g_active) return;
+  if (!m || !m->group || m->g_active) return;
   std::lock_guard<std::mutex> lk(m->group->mu);
   m->group->nactive++;
   m->g_active = true;
 }
 
 static void group_leave(nuts_model* m) {
-  if (!m->group || !m->g_active) return;
+  if (!m || !m->group || !m->g_active) return;
   nuts_group* g = m->group;
   std::lock_guard<std::mutex> lk(g->mu);
   g->nactive--;
@@ -1057,6 +1057,13 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     if (s->mix_sigma >= 0 && (!var_ok(s->mix_sigma) || (s->vars[s->mix_sigma].transform != NUTS_TR_NONE && s->vars[s->mix_sigma].transform != NUTS_TR_LOG)))
       return bad("mixture node: sigma must be a variable with K elements, untransformed or log-transformed");
     if (s->mix_sigma < 0 && !s->mix_sigma_const) return bad("mixture node: sigma is neither a variable nor a constant");
+    if (s->mix_w_simplex) {
+      const int v = s->mix_w_logits;
+      if (s->mix_K < 3 || v < 0 || v >= s->n_vars || s->vars[v].size != s->mix_K - 1 || vars[v].deferred || s->vars[v].transform != NUTS_TR_NONE || !s->mix_w_alpha)
+        return bad("mixture node: Dirichlet weights are a variable of K - 1 elements (the simplex-transformed value, K >= 3) with K concentrations");
+      for (int k = 0; k < s->mix_K; ++k)
+        if (!(s->mix_w_alpha[k] > 0)) return bad("mixture node: Dirichlet concentrations a > 0");   // multivariate.py Dirichlet.logp check_parameters
+    } else
     if (s->mix_w_logits >= 0 && (!var_ok(s->mix_w_logits) || s->vars[s->mix_w_logits].transform != NUTS_TR_NONE))
       return bad("mixture node: the weight logits must be an untransformed variable with K elements");
     if (s->mix_w_logits < 0 && !s->mix_w_const) return bad("mixture node: the weights are neither softmax(logits) nor constants");
@@ -1068,7 +1075,13 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     mx.off_sigma = s->mix_sigma >= 0 ? s->vars[s->mix_sigma].offset : -1;
     mx.tr_sigma = s->mix_sigma >= 0 ? s->vars[s->mix_sigma].transform : NUTS_TR_NONE;
     mx.off_w = s->mix_w_logits >= 0 ? s->vars[s->mix_w_logits].offset : -1;
-    for (int k = 0; k < MIX_MAXK; ++k) { mx.sigma_c[k] = 1.0; mx.logw_c[k] = 0.0; }
+    for (int k = 0; k < MIX_MAXK; ++k) { mx.sigma_c[k] = 1.0; mx.logw_c[k] = 0.0; mx.alpha[k] = 1.0; }
+    mx.w_simplex = s->mix_w_simplex ? 1 : 0; mx.pad_ = 0; mx.w_konst = 0.0;
+    if (mx.w_simplex) {
+      double sa = 0.0, sl = 0.0;
+      for (int k = 0; k < mx.K; ++k) { mx.alpha[k] = s->mix_w_alpha[k]; sa += mx.alpha[k]; sl += std::lgamma(mx.alpha[k]); }
+      mx.w_konst = std::lgamma(sa) - sl + std::log((double)mx.K);
+    }
     if (s->mix_sigma < 0)
       for (int k = 0; k < mx.K; ++k) {
         if (!(s->mix_sigma_const[k] > 0)) return bad("mixture node: sigma > 0");   // continuous.py:532 check_parameters
@@ -2114,7 +2127,9 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
   using clk = std::chrono::steady_clock;
   int rc = NUTS_OK;
   bool exhausted = true;
-  GroupTreeScope lockstep(c->m);
+  // (a chain whose leaves do not go through the row-aligned launch -- a dense mass matrix set after it joined -- is nobody's partner:
+  // the others would wait for deposits that never come)
+  GroupTreeScope lockstep(c->dense || c->host_pot ? nullptr : c->m);
   // geometry of the first doubling: `(rng.random() < 0.5) * 2 - 1` on uniforms[0] (nuts.py:215); later ones come
   // back in the status record (the device advances the uniform cursor, the host only mirrors the result)
   unsigned flags = 0;

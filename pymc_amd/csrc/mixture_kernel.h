@@ -18,24 +18,35 @@
 
 #define MIX_BLOCK 256
 
-// constrained parameter values at this leaf's position: (mu_k, sigma_k, log w_k) for lane k < K of the calling wave (others: junk)
-__device__ __forceinline__ void mix_params(const MixDev& mx, const QView& qv, int k, double& mu, double& sigma, double& logw) {
+// constrained parameter values at this leaf's position: (mu_k, sigma_k, log w_k) for lane k < K of the calling wave (others: junk);
+// `lse`: logsumexp of the weights' logits (what the simplex transform's Jacobian needs), 0 for constant weights
+__device__ __forceinline__ void mix_params(const MixDev& mx, const QView& qv, int k, double& mu, double& sigma, double& logw, double& lse) {
   const int kk = min(k, mx.K - 1);
   mu = qv.at(mx.off_mu + kk);
   if (mx.off_sigma >= 0) {
     const double s = qv.at(mx.off_sigma + kk);
     sigma = mx.tr_sigma == NUTS_TR_LOG ? exp(s) : s;
   } else sigma = mx.sigma_c[kk];
+  lse = 0.0;
   if (mx.off_w >= 0) {
     // log softmax over the first K lanes (fixed butterfly: the same bits in every wave and in both kernels)
-    const double eta = k < mx.K ? qv.at(mx.off_w + kk) : -INFINITY;
+    double eta;
+    if (mx.w_simplex) {
+      // logits [y_0 .. y_{K-2}, -sum(y)]  (SimplexTransform.backward, logprob/transforms.py:1101-1104)
+      const double yk = k < mx.K - 1 ? qv.at(mx.off_w + min(k, mx.K - 2)) : 0.0;
+      double sy = yk;
+#pragma unroll
+      for (int o = MIX_MAXK / 2; o > 0; o >>= 1) sy += __shfl_xor(sy, o, WAVE);
+      eta = k < mx.K - 1 ? yk : (k == mx.K - 1 ? -sy : -INFINITY);
+    } else eta = k < mx.K ? qv.at(mx.off_w + kk) : -INFINITY;
     double m = eta;
 #pragma unroll
     for (int o = MIX_MAXK / 2; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, WAVE));
     double e = k < mx.K ? exp(eta - m) : 0.0;
 #pragma unroll
     for (int o = MIX_MAXK / 2; o > 0; o >>= 1) e += __shfl_xor(e, o, WAVE);
-    logw = eta - m - log(e);
+    lse = m + log(e);
+    logw = eta - lse;
   } else logw = mx.logw_c[kk];
 }
 
@@ -49,8 +60,8 @@ __global__ __launch_bounds__(MIX_BLOCK) void k_mix_rows(ModelDev md, ArenaDev A,
   __shared__ double s_acc[MIX_BLOCK / WAVE][3 * MIX_MAXK + 1];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6, K = mx.K;
   if (w == 0) {
-    double mu, sg, lw;
-    mix_params(mx, qv, lane & (MIX_MAXK - 1), mu, sg, lw);
+    double mu, sg, lw, lse;
+    mix_params(mx, qv, lane & (MIX_MAXK - 1), mu, sg, lw, lse);
     if (lane < K) { s_par[0][lane] = mu; s_par[1][lane] = sg; s_par[2][lane] = lw; }
   }
   __syncthreads();
@@ -151,15 +162,30 @@ __global__ __launch_bounds__(WAVE) void k_mix_reduce(ModelDev md, ArenaDev A, Ev
     }
     s_tot[q] = t;
   }
-  double mu, sg, lw;
-  mix_params(mx, qv, lane & (MIX_MAXK - 1), mu, sg, lw);
+  double mu, sg, lw, lse;
+  mix_params(mx, qv, lane & (MIX_MAXK - 1), mu, sg, lw, lse);
   __syncthreads();
+  double lp_w = 0.0;
+  if (mx.w_simplex) {
+    // Dirichlet weights: with c_k = R_k + alpha_k - 1 the weights' part of the log-density is sum_k c_k log w_k - K lse + const, so
+    // d/d eta_k = c_k - (N + sum(alpha - 1) + K) w_k, and eta_{K-1} = -sum(y) hands its share to every y_j with a minus sign
+    const int kk = lane & (MIX_MAXK - 1);
+    const bool on = kk < K && lane < MIX_MAXK;
+    const double am1 = on ? mx.alpha[min(kk, K - 1)] - 1.0 : 0.0;
+    double sa = am1, sp = on ? am1 * lw : 0.0;
+#pragma unroll
+    for (int o = MIX_MAXK / 2; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, WAVE); sp += __shfl_xor(sp, o, WAVE); }
+    const double gfull = on ? (s_tot[min(kk, K - 1)] + am1) - ((double)mx.N + sa + (double)K) * exp(lw) : 0.0;
+    const double glast = __shfl(gfull, K - 1, WAVE);
+    if (lane < K - 1) mx.gdense[mx.off_w + lane] = gfull - glast;
+    lp_w = sp + mx.w_konst - (double)K * lse;
+  }
   if (lane < K) {
     const double R = s_tot[lane], Am = s_tot[MIX_MAXK + lane], Bm = s_tot[2 * MIX_MAXK + lane];
     const double is = 1.0 / sg;
     mx.gdense[mx.off_mu + lane] = Am * is * is;
     if (mx.off_sigma >= 0) mx.gdense[mx.off_sigma + lane] = Bm * is * is * is - R * is;
-    if (mx.off_w >= 0) mx.gdense[mx.off_w + lane] = R - (double)mx.N * exp(lw);
+    if (mx.off_w >= 0 && !mx.w_simplex) mx.gdense[mx.off_w + lane] = R - (double)mx.N * exp(lw);
   }
-  if (lane == 0) *mx.lp = s_tot[3 * MIX_MAXK];
+  if (lane == 0) *mx.lp = s_tot[3 * MIX_MAXK] + lp_w;
 }

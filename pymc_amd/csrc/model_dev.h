@@ -134,6 +134,11 @@ struct MixDev {
   int64_t N;
   int32_t K, off_mu, off_sigma, off_w;   // element offsets of the parameter variables (off_sigma / off_w < 0: the constants below)
   int32_t tr_sigma, nwg;
+  // Dirichlet weights under the simplex transform (w_simplex != 0): the variable at off_w is the transformed value y of K - 1
+  // elements, w = softmax([y, -sum(y)]); the node adds sum((alpha - 1) log w) + w_konst - K logsumexp([y, -sum(y)])
+  // (Dirichlet.logp + SimplexTransform.log_jac_det; w_konst = gammaln(sum(alpha)) - sum(gammaln(alpha)) + log(K))
+  int32_t w_simplex, pad_;
+  double alpha[MIX_MAXK], w_konst;
   const double* y;        // [N]
   const double* assign;   // [N] assignments in the data pool (float-coded integers), nullptr: marginal form
   double sigma_c[MIX_MAXK], logw_c[MIX_MAXK];

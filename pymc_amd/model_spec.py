@@ -127,15 +127,23 @@ class FreeVar:
     lower: float = 0.0
     upper: float = 1.0
     offset: int = 0
+    # the value variable of a simplex-transformed vector (`SimplexTransform`, logprob/transforms.py:1091-1115): K - 1 free elements
+    # (`shape`), the variable itself has K.  Element-wise the engine sees an untransformed vector; the node that consumes it (the
+    # mixture's Dirichlet weights) owns the transform and its Jacobian.
+    simplex: bool = False
 
     @property
     def size(self) -> int:
         return int(np.prod(self.shape)) if self.shape else 1
 
     @property
+    def constrained_shape(self) -> Tuple[int, ...]:
+        return tuple(self.shape[:-1]) + (self.shape[-1] + 1,) if self.simplex else tuple(self.shape)
+
+    @property
     def value_name(self) -> str:
         """`{name}_{transform}__` (pymc/util.py:138-155)."""
-        t = TRANSFORM_NAMES[self.transform]
+        t = "simplex" if self.simplex else TRANSFORM_NAMES[self.transform]
         return self.name if t is None else f"{self.name}_{t}__"
 
 
@@ -189,7 +197,9 @@ class MixtureRows:
       continuous.py:526-532); c is an integer-valued entry of `data` that another step method rewrites.
 
     `mu` is a variable of size K.  `sigma` is a variable of size K (its constrained value is used) or a constant vector.  The
-    weights are a constant vector (sum 1) or `softmax(logits)` of a variable of size K (`w_logits`)."""
+    weights are a constant vector (sum 1), `softmax(logits)` of a variable of size K (`w_logits`), or `w ~ Dirichlet(w_alpha)` under
+    PyMC's default simplex transform: then `w_logits` is the value variable `<w>_simplex__` of size K - 1 and the node itself adds
+    Dirichlet.logp(w) and the transform's log-Jacobian (`w_alpha` is not None; logprob/transforms.py:1091-1115)."""
 
     y: np.ndarray                     # [N] float64
     K: int
@@ -198,6 +208,7 @@ class MixtureRows:
     sigma_const: Optional[np.ndarray] = None
     w_logits: Optional[int] = None    # var id, or None with w_const
     w_const: Optional[np.ndarray] = None
+    w_alpha: Optional[np.ndarray] = None   # Dirichlet concentration [K]: `w_logits` is the simplex-transformed value (size K - 1)
     assign: Optional[int] = None      # data id of the assignments (float-coded integers in [0, K)), None: marginal
     name: str = "y"
 
@@ -558,6 +569,20 @@ class ModelBuilder:
         self._names[name] = e
         return e
 
+    def Dirichlet(self, name, a):
+        """`pm.Dirichlet(name, a=a)` (pymc/distributions/multivariate.py `Dirichlet`) as the weights of a mixture: the value
+        variable is `<name>_simplex__` with K - 1 elements (the default transform, distributions/transforms.py `simplex`); hand the
+        result to `NormalMixture(w=...)`, which owns the prior's log-density and the transform's Jacobian (K >= 3)."""
+        a = np.ascontiguousarray(a, dtype="float64").ravel()
+        if a.size < 3 or np.any(a <= 0):
+            raise ValueError("Dirichlet: K >= 3 concentrations, all > 0")     # multivariate.py: check_parameters(a > 0)
+        var = FreeVar(name, (a.size - 1,), TR_NONE, 0.0, 1.0, self.spec.n, simplex=True)
+        self.spec.vars.append(var)
+        e = Expr(self, Term(Operand(OP_VAR, 0.0, len(self.spec.vars) - 1)), var.size)
+        e.dirichlet_alpha = a
+        self._names[name] = e
+        return e
+
     # -- distributions (signatures follow pymc/distributions/continuous.py) --
     def Normal(self, name, mu=0.0, sigma=1.0, shape=None, observed=None):
         return self._register(D_NORMAL, name, (mu, sigma), shape, observed, TR_NONE)
@@ -700,6 +725,11 @@ class ModelBuilder:
             node.sigma_const = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype="float64"), (K,)))
         if isinstance(w, tuple) and len(w) == 2 and w[0] == "softmax":
             node.w_logits = self._var_id(w[1])
+        elif isinstance(w, Expr) and getattr(w, "dirichlet_alpha", None) is not None:
+            node.w_logits = self._var_id(w)
+            node.w_alpha = np.ascontiguousarray(w.dirichlet_alpha, dtype="float64")
+            if node.w_alpha.shape != (K,) or K < 3:
+                raise ValueError("Dirichlet mixture weights: K >= 3 components, one concentration per component")
         else:
             wc = np.ascontiguousarray(w, dtype="float64")
             if wc.shape != (K,) or np.any(wc < 0) or not np.isclose(wc.sum(), 1.0):
@@ -713,8 +743,9 @@ class ModelBuilder:
             if self.spec.data[node.assign].size != y.size:
                 raise ValueError("one assignment per observed row")
         for vid in (node.mu, node.sigma, node.w_logits):
-            if vid is not None and self.spec.vars[vid].size != K:
-                raise ValueError("mixture parameters must have K elements")
+            want = K - 1 if (vid == node.w_logits and node.w_alpha is not None) else K
+            if vid is not None and self.spec.vars[vid].size != want:
+                raise ValueError("mixture parameters must have K elements (K - 1 for simplex-transformed Dirichlet weights)")
         self.spec.mixture_rows = node
 
     def build(self) -> ModelSpec:

@@ -19,7 +19,11 @@ from pymc_amd.model_spec import TR_INTERVAL, TR_LOG, TR_LOGODDS, TR_NONE, ModelS
 
 
 def backward(var, values: np.ndarray) -> np.ndarray:
-    """Value variable -> untransformed variable (pymc/logprob/transforms.py:880-891, 1017-1088)."""
+    """Value variable -> untransformed variable (pymc/logprob/transforms.py:880-891, 1017-1088; simplex: 1101-1104)."""
+    if getattr(var, "simplex", False):
+        full = np.concatenate([values, -np.sum(values, axis=-1, keepdims=True)], axis=-1)
+        e = np.exp(full - np.max(full, axis=-1, keepdims=True))
+        return e / np.sum(e, axis=-1, keepdims=True)
     if var.transform == TR_NONE:
         return values
     if var.transform == TR_LOG:
@@ -40,7 +44,7 @@ def posterior(spec: ModelSpec, draws: np.ndarray, include_transformed: bool = Fa
         block = draws[..., v.offset : v.offset + v.size].reshape(draws.shape[:2] + tuple(v.shape))
         if include_transformed and v.value_name != v.name:
             out[v.value_name] = block
-        out[v.name] = backward(v, block)
+        out[v.name] = backward(v, block)   # (a simplex variable comes back with K elements from its K - 1)
     return out
 
 

@@ -102,6 +102,11 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
             wc = np.ascontiguousarray(mx.w_const, dtype="float64")
             keep.append(wc)
             s.mix_w_const = _lib.dptr(wc)
+        elif getattr(mx, "w_alpha", None) is not None:
+            wa = np.ascontiguousarray(mx.w_alpha, dtype="float64")
+            keep.append(wa)
+            s.mix_w_simplex = 1
+            s.mix_w_alpha = _lib.dptr(wa)
     gl = getattr(spec, "glm_rows", None)
     if gl is not None:
         X = np.ascontiguousarray(gl.X, dtype="float64")

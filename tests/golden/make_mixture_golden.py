@@ -34,6 +34,18 @@ if __name__ == "__main__":
         d[f"case{i}_mixture_logp"] = np.asarray(R["mixture_logprob"](y, w, mu, sigma))
         d[f"case{i}_categorical_logp"] = np.asarray(R["categorical_logp"](c, w))
         d[f"case{i}_normal_logp"] = np.asarray(R["normal_logp"](y, mu[c], sigma[c]))
+    # Dirichlet weights under the default simplex transform (K >= 3): value y of K - 1 elements -> w, Dirichlet.logp(w | a), the
+    # transform's log-Jacobian, and forward(backward(y)) == y
+    rng = np.random.default_rng(77)
+    for i, K in enumerate((3, 4, 7, 16)):
+        yv = rng.normal(size=K - 1) * (0.3 + i)
+        a = rng.uniform(0.4, 4.0, size=K)
+        w = np.asarray(R["simplex_backward"](yv))
+        d[f"simplex{i}_y"], d[f"simplex{i}_a"], d[f"simplex{i}_w"] = yv, a, w
+        d[f"simplex{i}_dirichlet_logp"] = np.asarray(R["dirichlet_logp"](w, a))
+        d[f"simplex{i}_log_jac_det"] = np.asarray(R["simplex_log_jac_det"](yv))
+        d[f"simplex{i}_forward_of_w"] = np.asarray(R["simplex_forward"](w))
+    d["n_simplex"] = np.array(4)
     # Categorical.logp outside the support (-inf) and a failing parameter check
     d["cat_out_of_range"] = np.asarray(R["categorical_logp"](np.array([-1, 0, 2, 3]), np.array([0.2, 0.5, 0.3])))
     d["n_cases"] = np.array(len(cases()))

@@ -21,11 +21,16 @@ available = sg.available
 
 
 class A(np.ndarray):
-    """ndarray with the two attributes the bodies read off a TensorVariable (`.type.ndim`, `.astype(int)` works already)."""
+    """ndarray with the attributes the bodies read off a TensorVariable (`.type.ndim`; `.shape[-1].astype(dtype)`: the symbolic
+    shape of a tensor is a tensor; `.astype(int)` works already)."""
 
     @property
     def type(self):
         return self
+
+    @property
+    def shape(self):
+        return tuple(np.int64(n) for n in np.ndarray.shape.__get__(self))
 
 
 def arr(x):
@@ -51,10 +56,23 @@ class pt:
         r = m + np.log(np.sum(np.exp(x - m), axis=axis, keepdims=True))
         return arr(r if keepdims else np.squeeze(r, axis=axis))
 
-    log = staticmethod(lambda x: arr(np.log(x)))
+    @staticmethod
+    def log(x):
+        with np.errstate(divide="ignore"):
+            return arr(np.log(x))
+
+    as_tensor = staticmethod(lambda x: arr(np.asarray(x, dtype="float64")))
+    exp = staticmethod(lambda x: arr(np.exp(x)))
+    max = staticmethod(lambda x, axis=None, keepdims=False: arr(np.max(x, axis=axis, keepdims=keepdims)))
+    concatenate = staticmethod(lambda xs, axis=0: arr(np.concatenate([np.asarray(x) for x in xs], axis=axis)))
+    zeros_like = staticmethod(lambda x: arr(np.zeros_like(np.asarray(x))))
+    any = staticmethod(lambda x, axis=None: np.any(x, axis=axis))
+    and_ = staticmethod(np.logical_and)
+    eq = staticmethod(np.equal)
+    le = staticmethod(np.less_equal)
     sqrt = staticmethod(lambda x: arr(np.sqrt(x)))
     pow = staticmethod(lambda x, y: arr(np.power(x, y)))
-    sum = staticmethod(lambda x, axis=None: arr(np.sum(x, axis=axis)))
+    sum = staticmethod(lambda x, axis=None, keepdims=False: arr(np.sum(x, axis=axis, keepdims=keepdims)))
     isclose = staticmethod(lambda a, b: np.isclose(a, b))
     stack = staticmethod(lambda xs, axis=0: arr(np.stack(xs, axis=axis)))
     expand_dims = staticmethod(lambda x, axis: arr(np.expand_dims(x, axis)))
@@ -91,7 +109,18 @@ def reference():
 
     ns2 = dict(ns, logp=logp)
     mix = sg.ref_function("distributions/mixture.py", "mixture_logprob", ns2)
-    return {"normal_logp": lambda v, mu, s: normal.logp(arr(v), arr(mu), arr(s)),
+    # Dirichlet weights under the default transform: `Dirichlet.logp` (multivariate.py:557-584) with the reference's own `logpow`
+    # (dist_math.py:92-108), and `SimplexTransform` (logprob/transforms.py:1091-1115)
+    from scipy.special import gammaln
+
+    ns3 = dict(ns, gammaln=lambda x: arr(gammaln(np.asarray(x, dtype="float64"))))
+    ns3["logpow"] = sg.ref_function("distributions/dist_math.py", "logpow", ns3)
+    diri = sg.ref_class("distributions/multivariate.py", "Dirichlet", ["logp"], object, ns3)
+    simplex = sg.ref_class("logprob/transforms.py", "SimplexTransform", ["forward", "backward", "log_jac_det"], object, dict(ns))()
+    return {"dirichlet_logp": lambda w, a: diri.logp(arr(w), arr(a)),
+            "simplex_forward": lambda w: simplex.forward(arr(w)), "simplex_backward": lambda y: simplex.backward(arr(y)),
+            "simplex_log_jac_det": lambda y: simplex.log_jac_det(arr(y)),
+            "normal_logp": lambda v, mu, s: normal.logp(arr(v), arr(mu), arr(s)),
             "categorical_logp": lambda v, p: cat.logp(arr(np.asarray(v)), arr(p)),
             "mixture_logprob": lambda y, w, mu, s: mix(None, (arr(y),), None, arr(w), Component(mu, s)),
             "ParameterValueError": ParameterValueError}

@@ -63,6 +63,62 @@ def test_oracle_reproduces_the_reference_bodies():
     assert lp == -np.inf
 
 
+def _dirichlet_spec(y, a, K, assign=None):
+    m = ModelBuilder()
+    w = m.Dirichlet("w", a)
+    mu = m.Normal("mu", 0.0, 5.0, shape=K)
+    sg = m.HalfNormal("sigma", 2.0, shape=K)
+    c = m.Extra("c", assign) if assign is not None else None
+    m.NormalMixture("y", w, mu, sg, y, assign=c)
+    return m.build()
+
+
+def test_dirichlet_weights_reproduce_the_reference_bodies():
+    """`w ~ Dirichlet(a)` under PyMC's default simplex transform as the mixture's weights: the node's share of the log-density is the
+    reference's `mixture_logprob` at w = `SimplexTransform.backward(y)` + `Dirichlet.logp(w, a)` + `SimplexTransform.log_jac_det(y)`,
+    all three executed from the reference's source (tests/golden/refrun_mixture.py)."""
+    from pymc_amd.trace import backward
+
+    g = np.load(os.path.join(GOLDEN, "mixture_reference.npz"))
+    rng = np.random.default_rng(4)
+    for i in range(int(g["n_simplex"])):
+        yv, a, w = g[f"simplex{i}_y"], g[f"simplex{i}_a"], g[f"simplex{i}_w"]
+        K = a.size
+        obs = rng.normal(size=50) * 2.0
+        spec = _dirichlet_spec(obs, a, K)
+        vw = spec.vars[spec.mixture_rows.w_logits]
+        assert (vw.value_name, vw.shape, vw.constrained_shape) == ("w_simplex__", (K - 1,), (K,))
+        np.testing.assert_allclose(backward(vw, yv), w, rtol=1e-15, atol=1e-17)     # the trace's view of the variable
+        mu, sigma = np.sort(rng.normal(size=K)) * 2.0, rng.uniform(0.5, 1.5, size=K)
+        x = np.zeros(spec.n)
+        for v, val in (("w", yv), ("mu", mu), ("sigma", sigma)):
+            vv = next(u for u in spec.vars if u.name == v)
+            x[vv.offset:vv.offset + vv.size] = val
+        lp_node, _ = ref_models._mixture_rows(spec, spec.mixture_rows, x)
+        # the same rows under CONSTANT weights w: what `mixture_logprob` gives (pinned above) -- the rest is prior + Jacobian
+        m = ModelBuilder()
+        mu_e, sg_e = m.Normal("mu", 0.0, 5.0, shape=K), m.HalfNormal("sigma", 2.0, shape=K)
+        m.NormalMixture("y", w / w.sum(), mu_e, sg_e, obs)
+        sc = m.build()
+        lp_rows, _ = ref_models._mixture_rows(sc, sc.mixture_rows, np.concatenate([mu, sigma]))
+        np.testing.assert_allclose(lp_node - lp_rows, g[f"simplex{i}_dirichlet_logp"] + g[f"simplex{i}_log_jac_det"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("form", ["marginal", "conditional"])
+def test_dirichlet_weights_gradient_against_finite_differences(form):
+    rng = np.random.default_rng(8)
+    K, N = 5, 200
+    y = rng.normal(size=N) * 2.0
+    spec = _dirichlet_spec(y, rng.uniform(0.5, 3.0, size=K), K, assign=rng.integers(0, K, size=N) if form == "conditional" else None)
+    f = ref_models.SpecLogpGrad(spec)
+    q = rng.normal(size=spec.n) * 0.5
+    lp, g = f(q)
+    for i in range(spec.n):
+        e = np.zeros(spec.n); e[i] = 1e-6
+        num = (f(q + e)[0] - f(q - e)[0]) / 2e-6
+        assert abs(num - g[i]) <= 1e-6 * max(1.0, abs(num)), (i, num, g[i])
+
+
 @pytest.mark.parametrize("form", ["marginal", "marginal_logits", "conditional", "const_sigma"])
 def test_oracle_gradient_against_finite_differences(form):
     rng = np.random.default_rng(5)
@@ -137,6 +193,56 @@ def test_device_logp_grad_matches_the_oracle(form, K, N):
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.abs(g0).max()), np.max(np.abs(g - g0))
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,K,N", [("marginal", 3, 50), ("marginal", 4, 30_000), ("marginal", 16, 2000), ("conditional", 5, 10_000)])
+def test_device_dirichlet_weights_match_the_oracle(form, K, N):
+    """`w ~ Dirichlet(a)` under the simplex transform (the usual way a PyMC mixture model is written): the node evaluates the prior
+    and the Jacobian next to the rows, the variable has K - 1 free elements."""
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    rng = np.random.default_rng(K * 77 + N)
+    y = _mix_data(rng, K, N)
+    spec = _dirichlet_spec(y, rng.uniform(0.5, 4.0, size=K), K, assign=rng.integers(0, K, size=N) if form == "conditional" else None)
+    assert spec.n == 3 * K - 1
+    f = DeviceValueGradFunction(spec, device=0)
+    for q in [np.zeros(spec.n)] + [rng.normal(size=spec.n) * 0.7 for _ in range(3)]:
+        lp, g = f._pytensor_function(q)
+        lp0, g0 = ref_models.evaluate(spec, q)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.abs(g0).max()), np.max(np.abs(g - g0))
+    f.close()
+
+
+@pytest.mark.gpu
+def test_nuts_on_a_mixture_with_dirichlet_weights_has_the_oracle_samplers_integers():
+    from oracle import ref_sampler
+    from pymc_amd.sampling import sample
+
+    rng = np.random.default_rng(12)
+    K, N = 3, 4000
+    y = np.concatenate([rng.normal(m, s, size=n) for m, s, n in ((-4.0, 0.8, 1000), (0.5, 0.6, 2000), (5.0, 1.0, 1000))])
+    spec = _dirichlet_spec(y, np.ones(K), K)
+    tune, draws, seed = 30, 15, 9
+    start = {"w_simplex__": np.zeros(K - 1), "mu": np.array([-3.0, 0.0, 4.0]), "sigma_log__": np.zeros(K)}
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, initvals=[start],
+                 discard_tuned_samples=False, return_multitrace=True)
+    q0 = np.concatenate([start[v.value_name] for v in spec.vars])
+    ref_draws, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [q0], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    dev = res["stats"][0]
+    same = 0
+    for a_, b_ in zip(dev, ref_stats[0]):
+        if all(int(a_[k]) == int(b_[k]) for k in ("depth", "tree_size", "index_in_trajectory", "diverging")):
+            same += 1
+        else:
+            break
+    assert same >= 25, same
+    np.testing.assert_allclose(res["draws"][0][:10], ref_draws[0][:10], rtol=1e-6, atol=1e-8)
+    # the trace shows the weights themselves (K elements, on the simplex) next to the value variable
+    w = res["trace"].get_values("w")
+    assert w.shape == (tune + draws, K) and np.allclose(w.sum(axis=1), 1.0) and np.all(w > 0)
+    res["step"].close()
 
 
 @pytest.mark.gpu
