@@ -156,6 +156,17 @@ def build_tree(v, memo: Optional[dict] = None):
             out = _const(np.sum(kid[1], axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax))
         else:
             out = ("sum", ax, kid)
+    elif name == "Max":                           # `pt.max(x, axis)` (the shift of a softmax / logsumexp written out by hand)
+        kid = build_tree(ins[0], memo)
+        ax = getattr(op, "axis", None)
+        out = _const(np.max(kid[1], axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax)) if kid[0] == "const" else ("max", ax, kid)
+    elif name == "Join":                          # `pt.concatenate(tensors, axis)`
+        kids = [build_tree(i, memo) for i in ins]
+        ax = getattr(op, "axis", 0)
+        if all(k[0] == "const" for k in kids):
+            out = _const(np.concatenate([np.atleast_1d(k[1]) for k in kids], axis=ax))
+        else:
+            out = ("join", ax, *kids)
     elif name == "Shape":                         # `x.shape`: static in every model the IR takes (value variables have fixed shapes)
         shp = getattr(getattr(ins[0], "type", None), "shape", None)
         if shp is None or any(d is None for d in shp):
@@ -593,7 +604,18 @@ def _eval_tree(node, values: Dict[int, Any]):
         return node[1]
     if kind == "input":
         return values[id(node[1])]
+    if kind in ("sum", "max"):      # (opname, axis, x); a kept dimension is not tracked by the tree: reductions of vectors give scalars
+        x = np.asarray(_eval_tree(node[2], values))
+        ax = node[1]
+        if x.ndim == 0:
+            return x
+        with np.errstate(all="ignore"):
+            return (np.sum if kind == "sum" else np.max)(x, axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax)
+    if kind == "join":
+        return np.concatenate([np.atleast_1d(_eval_tree(k, values)) for k in node[2:]], axis=node[1])
     a = [_eval_tree(k, values) for k in node[1:] if isinstance(k, tuple)]
+    if kind in ("any", "all"):
+        return (np.any if kind == "any" else np.all)(np.asarray(a[0]) != 0)
     with np.errstate(all="ignore"):
         if kind in _NUMPY_FOLD:
             return _NUMPY_FOLD[kind](*a)
@@ -688,9 +710,21 @@ def _match_truncnormal(node):
 # ---------------------------------------------------------------------------
 # the walker
 # ---------------------------------------------------------------------------
+_TR_SIMPLEX = 4   # (a code of THIS module: `SimplexTransform` is owned by the node that consumes the variable, model_spec.FreeVar.simplex)
+
+
+def _simplex_backward(y):
+    """`SimplexTransform.backward` (logprob/transforms.py:1101-1104) in closed form: (w, logsumexp of the full logits)."""
+    full = np.concatenate([y, [-np.sum(y)]])
+    m = full.max()
+    lse = m + np.log(np.sum(np.exp(full - m)))
+    return np.exp(full - lse), full - lse, lse
+
+
 class _Lowering:
     def __init__(self, value_vars, transforms, shapes, extra_vars=(), extra_values=None):
         self.spec = ms.ModelSpec()
+        self._dirichlet: Dict[int, np.ndarray] = {}     # simplex variable -> its Dirichlet concentrations, until a mixture takes it as its weights
         self.var_id: Dict[int, int] = {}
         # value variables that are inputs of the log-density but not of its gradient (discrete variables another step method
         # updates; model/core.py:142-190 `extra_vars`): data vectors the caller rewrites (`set_extra_values`), registered by name
@@ -708,7 +742,13 @@ class _Lowering:
             suffix = {ms.TR_LOG: "_log__", ms.TR_LOGODDS: "_logodds__", ms.TR_INTERVAL: "_interval__"}.get(tr)
             if suffix and rv_name.endswith(suffix):
                 rv_name = rv_name[: -len(suffix)]
-            fv = ms.FreeVar(rv_name, tuple(shapes[v.name]), tr, float(lo), float(hi), off)
+            if tr == _TR_SIMPLEX:
+                rv_name = rv_name[: -len("_simplex__")] if rv_name.endswith("_simplex__") else rv_name
+                if len(shapes[v.name]) != 1:
+                    raise NotLowerable("a simplex-transformed variable that is not a vector")
+                fv = ms.FreeVar(rv_name, tuple(shapes[v.name]), ms.TR_NONE, 0.0, 1.0, off, simplex=True)
+            else:
+                fv = ms.FreeVar(rv_name, tuple(shapes[v.name]), tr, float(lo), float(hi), off)
             off += fv.size
             self.var_id[id(v)] = len(self.spec.vars)
             self.spec.vars.append(fv)
@@ -717,7 +757,7 @@ class _Lowering:
     def _as_var(self, node) -> Optional[int]:
         if node[0] == "input" and id(node[1]) in self.var_id:
             k = self.var_id[id(node[1])]
-            return k if self.spec.vars[k].transform == ms.TR_NONE else None
+            return k if self.spec.vars[k].transform == ms.TR_NONE and not self.spec.vars[k].simplex else None
         if node[0] == "exp" and node[1][0] == "input" and id(node[1][1]) in self.var_id:
             k = self.var_id[id(node[1][1])]
             return k if self.spec.vars[k].transform == ms.TR_LOG else None
@@ -1060,6 +1100,11 @@ class _Lowering:
                 if kw is None or self.spec.vars[kw].size != K_:
                     continue
                 node_.w_logits = kw
+            elif wt[0] == "log" and self._simplex_weights(wt[1]) is not None:     # w = pm.Dirichlet(...) under its default transform
+                kw = self._simplex_weights(wt[1])
+                if self.spec.vars[kw].size != K_ - 1 or K_ < 3:
+                    raise NotLowerable("Dirichlet mixture weights need K >= 3 components (a variable of K - 1 free elements)")
+                node_.w_logits, node_.w_alpha = kw, self._dirichlet.pop(kw)
             else:
                 continue
             if self.spec.mixture_rows is not None:
@@ -1083,8 +1128,63 @@ class _Lowering:
     def _emit(self, dist, args, konst, name):
         self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), tuple(args), konst, name, tuple(self._prog)))
 
+    def _dirichlet_factor(self, node, own: int, own_value) -> None:
+        """The factor of a simplex-transformed variable y (K - 1 elements): `Dirichlet.logp(backward(y), a)` + `log_jac_det(y)`
+        (multivariate.py:557-584, logprob/transforms.py:1101-1115, transform_value.py:95-133).  Like TruncatedNormal's normalising term,
+        the graph -- joins, a max-shifted softmax, `logpow` switches, support tests -- is IDENTIFIED BY EVALUATION: with
+        log w(y) and the Jacobian in closed form, F(y) - log_jac_det(y) must be an affine function of log w(y); its slope is a - 1, its
+        intercept gammaln(sum a) - sum gammaln(a); both are checked at fresh points.  The concentrations wait for the mixture that
+        uses the variable as its weights (the node evaluates prior and Jacobian itself, model_spec.MixtureRows.w_alpha)."""
+        from scipy.special import gammaln
+
+        inputs = _inputs_of(node, {})
+        if set(inputs) != {id(own_value)}:
+            raise NotLowerable("a simplex-transformed variable whose prior has parameters that are not constants")
+        K1 = self.spec.vars[own].size
+        Kc = K1 + 1
+        rng = np.random.default_rng(20240924)
+        pts = [rng.normal(size=K1) * 1.2 for _ in range(Kc + 8)]
+        F = np.array([float(_eval_tree(node, {id(own_value): y})) for y in pts])
+        LW = np.array([_simplex_backward(y)[1] for y in pts])
+        jac = np.array([np.log(Kc) - Kc * _simplex_backward(y)[2] for y in pts])
+        A = np.concatenate([LW, np.ones((len(pts), 1))], axis=1)
+        fit, n_fit = None, Kc + 2
+        if np.all(np.isfinite(F)):
+            fit = np.linalg.lstsq(A[:n_fit], (F - jac)[:n_fit], rcond=None)[0]
+        if fit is None:
+            raise NotLowerable("the prior of a simplex-transformed variable is not a Dirichlet density")
+        a = fit[:Kc] + 1.0
+        resid = A @ fit - (F - jac)
+        ok = np.all(a > 0) and np.max(np.abs(resid)) <= 1e-9 * max(1.0, np.max(np.abs(F))) \
+            and abs(fit[Kc] - (gammaln(a.sum()) - gammaln(a).sum())) <= 1e-8 * max(1.0, abs(fit[Kc]))
+        if not ok:
+            raise NotLowerable("the prior of a simplex-transformed variable is not a Dirichlet density")
+        rounded = np.round(a, 12)       # (the least-squares solution carries rounding: concentrations are what the model states)
+        self._dirichlet[own] = np.where(np.abs(rounded - a) < 1e-9, rounded, a)
+
+    def _simplex_weights(self, wnode) -> Optional[int]:
+        """`wnode` = the weights of a mixture: the simplex variable whose `SimplexTransform.backward` it is (verified by evaluation)."""
+        inputs = _inputs_of(wnode, {})
+        if len(inputs) != 1:
+            return None
+        (vid, var), = inputs.items()
+        k = self.var_id.get(vid)
+        if k is None or not self.spec.vars[k].simplex or k not in self._dirichlet:
+            return None
+        rng = np.random.default_rng(7)
+        for _ in range(6):
+            y = rng.normal(size=self.spec.vars[k].size) * 1.5
+            got = np.asarray(_eval_tree(wnode, {vid: y}), dtype="float64")
+            want = _simplex_backward(y)[0]
+            if got.shape != want.shape or np.max(np.abs(got - want)) > 1e-12:
+                return None
+        return k
+
     def _factor(self, node, name: str, own_value=None):
         own = self.var_id.get(id(own_value)) if own_value is not None else None
+        if own is not None and self.spec.vars[own].simplex:
+            self._dirichlet_factor(node, own, own_value)
+            return
         node = self._strip_jacobian(node, own)
         if own is None and self._mixture(node):
             self.spec.mixture_rows.name = name
@@ -1186,7 +1286,7 @@ def lower_to_spec(model) -> ms.ModelSpec:
         shapes[v.name] = shp
         tr = getattr(model, "value_transforms", {}).get(v.name)
         if tr is not None and not isinstance(tr, tuple):
-            code = {"log": ms.TR_LOG, "logodds": ms.TR_LOGODDS, "interval": ms.TR_INTERVAL}[tr.name]
+            code = {"log": ms.TR_LOG, "logodds": ms.TR_LOGODDS, "interval": ms.TR_INTERVAL, "simplex": _TR_SIMPLEX}[tr.name]
             tr = (code, getattr(tr, "lower", 0.0), getattr(tr, "upper", 1.0))
         if tr is not None:
             transforms[v.name] = tr
@@ -1199,6 +1299,8 @@ def lower_to_spec(model) -> ms.ModelSpec:
         low.factor(build_tree(g, memo), nm, own)
     if low._cat:
         raise NotLowerable("a Categorical variable that does not index an observed Normal (the IR has no free-standing Categorical factor)")
+    if low._dirichlet:
+        raise NotLowerable("a Dirichlet variable that is not the weight vector of a mixture over observed rows (the IR has no free-standing Dirichlet factor)")
     # `pm.Deterministic` variables (model/core.py:1940-2005): recorded in the trace next to the free variables (backends/base.py:
     # 183-191), no contribution to the log-density.  `model.deterministics`: {name: graph variable} (a list of named variables on a
     # real `pm.Model`).  One that the IR cannot express is left out of the trace with a warning, not a failure of the lowering.

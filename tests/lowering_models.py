@@ -207,6 +207,29 @@ def _normal_mixture_softmax_built():
     return b.build()
 
 
+A_DIRICHLET = np.array([1.0, 2.5, 0.7, 4.0])
+
+
+def normal_mixture_dirichlet():
+    """The way a PyMC mixture model is usually written: `w = pm.Dirichlet("w", a)` (default transform: simplex, a value variable of
+    K - 1 elements) as the weights of `pm.NormalMixture`."""
+    m = sg.StubModel()
+    w = m.Dirichlet("w", A_DIRICHLET)
+    mu = m.Normal("mu", 0.0, 5.0, shape=(4,))
+    sigma = m.HalfNormal("sigma", 2.0, shape=(4,))
+    m.NormalMixture("y", w, mu, sigma, observed=YM)
+    return m
+
+
+def _normal_mixture_dirichlet_built():
+    b = ModelBuilder()
+    w = b.Dirichlet("w", A_DIRICHLET)
+    mu = b.Normal("mu", 0.0, 5.0, shape=4)
+    sigma = b.HalfNormal("sigma", 2.0, shape=4)
+    b.NormalMixture("y", w, mu, sigma, YM)
+    return b.build()
+
+
 XG = np.random.default_rng(21).normal(size=(50, 6)) * 0.5
 YG_N = np.random.default_rng(22).normal(size=50)
 YG_B = (np.random.default_rng(23).random(50) < 0.45).astype("float64")
@@ -346,6 +369,7 @@ ENTRIES = {
     "varying_intercepts_and_slopes": (varying_intercepts_and_slopes, lambda: _built(varying_intercepts_and_slopes)),
     "normal_mixture_marginal": (normal_mixture_marginal, _normal_mixture_marginal_built),
     "normal_mixture_softmax": (normal_mixture_softmax, _normal_mixture_softmax_built),
+    "normal_mixture_dirichlet": (normal_mixture_dirichlet, _normal_mixture_dirichlet_built),
     "mixture_categorical_indexed": (mixture_categorical_indexed, _mixture_categorical_indexed_built),
     "mixture_categorical_indexed_sigma": (lambda: mixture_categorical_indexed(True), lambda: _mixture_categorical_indexed_built(True)),
     "mvnormal_cov": (mvnormal_cov, _mvnormal_built),

@@ -91,6 +91,7 @@ class Variable:
     @property
     def shape(self): return Variable(Apply(Shape(), [self]), shape=(len(self.type.shape),))
     def astype(self, dtype): return elemwise(Cast, self)
+    dtype = "float64"
     def squeeze(self, axis=None):
         n = len(self.type.shape)
         return Variable(Apply(DimShuffle(), [self]), shape=tuple(s_ for i, s_ in enumerate(self.type.shape) if not (s_ == 1 and (axis is None or i == axis % n))))
@@ -219,6 +220,25 @@ class MakeVector:
     pass
 
 
+class Any:
+    def __init__(self, axis=None):
+        self.axis = axis
+
+
+class Max:
+    """`pytensor.tensor.math.Max(axis)` (`pt.max(x, axis)`; a CAReduce like Sum)."""
+
+    def __init__(self, axis=None):
+        self.axis = axis
+
+
+class Join:
+    """`pytensor.tensor.basic.Join` (`pt.concatenate(tensors, axis)`; the stand-in keeps the axis as an attribute)."""
+
+    def __init__(self, axis=0):
+        self.axis = axis
+
+
 class Softmax:
     """`pytensor.tensor.special.Softmax(axis)` (what `pm.math.softmax` builds)."""
 
@@ -330,15 +350,40 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     zeros_like = staticmethod(lambda a: elemwise(Second, a, 0.0))     # pt.zeros_like = fill(a, 0)
 
     @staticmethod
-    def sum(x, axis=None, keepdims=False):
+    def _reduce(op_cls, x, axis, keepdims):
         x = as_tensor(x)
         shp = x.type.shape
         if axis is None:
-            out = ()
+            out, kept = (), (1,) * len(shp)
         else:
             ax = axis % max(len(shp), 1)
             out = tuple(s for i, s in enumerate(shp) if i != ax)
-        return Variable(Apply(Sum(axis), [x]), shape=out)
+            kept = tuple(1 if i == ax else s for i, s in enumerate(shp))
+        r = Variable(Apply(op_cls(axis), [x]), shape=out)
+        # (keepdims: PyTensor reduces and puts the axis back with a DimShuffle)
+        return Variable(Apply(DimShuffle(), [r]), shape=kept) if keepdims and kept != out else r
+
+    @staticmethod
+    def sum(x, axis=None, keepdims=False):
+        return pt._reduce(Sum, x, axis, keepdims)
+
+    @staticmethod
+    def max(x, axis=None, keepdims=False):
+        return pt._reduce(Max, x, axis, keepdims)
+
+    @staticmethod
+    def any(x, axis=None):
+        return pt._reduce(Any, x, axis, False)
+
+    @staticmethod
+    def concatenate(tensors, axis=0):
+        ts = [as_tensor(t) for t in tensors]
+        ax = axis % max(len(ts[0].type.shape), 1)
+        shp = list(ts[0].type.shape)
+        shp[ax] = sum(t.type.shape[ax] for t in ts)
+        return Variable(Apply(Join(axis), ts), shape=tuple(shp))
+
+    as_tensor = staticmethod(lambda x, **kw: as_tensor(x))
 
     @staticmethod
     def logsumexp(x, axis=None, keepdims=False):
@@ -568,6 +613,11 @@ def reference():
 
     ns["warnings"] = warnings
     ref_class("distributions/discrete.py", "Categorical", ["dist", "_safe_index_value_p", "logp"], _DistBase, ns)
+    # Dirichlet (distributions/multivariate.py:543-584: `dist`, `logp`) under its default transform (`simplex_cont_transform`,
+    # multivariate.py:126-127 -> `transforms.simplex` = `SimplexTransform()`, logprob/transforms.py:1091-1115)
+    ref_class("distributions/multivariate.py", "Dirichlet", ["dist", "logp"], _DistBase, ns)
+    ref_class("logprob/transforms.py", "SimplexTransform", ["forward", "backward", "log_jac_det"], _TransformBase, ns)
+    ns["transforms"].simplex = ns["SimplexTransform"]()
     _NS = ns
     return ns
 
@@ -596,11 +646,12 @@ class _RV:
         self.rv_inputs = (None, None, *params)          # (rng, size, *dist_params): what a transform's methods receive
         if transform is not None and transform_obj is None:
             ref = reference()
-            transform_obj = {"log": ref["transforms"].log, "logodds": ref["transforms"].logodds}[transform]
+            transform_obj = {"log": ref["transforms"].log, "logodds": ref["transforms"].logodds, "simplex": ref["transforms"].simplex}[transform]
         self.transform_obj = transform_obj
         if observed is None:
             vname = name if transform is None else f"{name}_{transform}__"   # util.py:138-155
-            self.value = Variable(None, vname, self.shape)
+            # (the simplex transform's value has one element less than the variable: transforms.py:1094-1099 `forward`)
+            self.value = Variable(None, vname, self.shape[:-1] + (self.shape[-1] - 1,) if transform == "simplex" else self.shape)
             # what the rest of the graph sees in place of the RV: transform.backward(value, *rv_inputs)
             self.expr = self.value if transform is None else transform_obj.backward(self.value, *self.rv_inputs)
         else:
@@ -712,6 +763,10 @@ class StubModel:
     def Poisson(self, name, mu, observed):
         return self._rv("Poisson", name, np.shape(observed), _dist("Poisson", mu), None, observed)
 
+    def Dirichlet(self, name, a):
+        """`pm.Dirichlet(name, a=a)`: a vector on the simplex; value variable `<name>_simplex__` with K - 1 elements."""
+        return self._rv("Dirichlet", name, (np.shape(a)[-1],), _dist("Dirichlet", a=a), "simplex", None)
+
     def NormalMixture(self, name, w, mu, sigma, observed):
         """`pm.NormalMixture(name, w=w, mu=mu, sigma=sigma, observed=y)` (mixture.py:598-607: `Mixture` over ONE batched
         `Normal.dist(mu, sigma)`); its log-density graph is what the reference's `mixture_logprob` builds (mixture.py:469-495)."""
@@ -753,11 +808,11 @@ class StubModel:
 
     @property
     def value_shapes(self):
-        return {rv.value.name: rv.shape for rv in self.free}
+        return {rv.value.name: tuple(rv.value.type.shape) for rv in self.free}
 
     @property
     def value_transforms(self):
-        code = {"log": 1, "logodds": 2, "interval": 3}
+        code = {"log": 1, "logodds": 2, "interval": 3, "simplex": 4}
         return {rv.value.name: (code[rv.transform], *(rv.bounds or (0.0, 1.0))) for rv in self.free if rv.transform}
 
     @property
@@ -835,7 +890,8 @@ def dump_model(m) -> dict:
     }
 
 
-_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot, Shape, Transpose, ExtractDiag, MatrixInverse)}
+_OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot, Shape, Transpose, ExtractDiag, MatrixInverse,
+                                Any, Max, Join)}
 _OPS_AXIS = ("Sum", "All", "Softmax", "TakeAlongAxis")
 
 
@@ -853,7 +909,7 @@ class FrozenModel:
                 ins = [vs[i] for i in rec["ins"]]
                 if rec["op"] == "Elemwise":
                     op = Elemwise(globals()[rec["scalar"]]())
-                elif rec["op"] in ("Sum", "All", "Softmax"):
+                elif rec["op"] in ("Sum", "All", "Softmax", "Any", "Max", "Join"):
                     op = _OPS[rec["op"]](rec.get("axis"))
                 elif rec["op"] == "TakeAlongAxis":
                     op = TakeAlongAxis(rec.get("axis", -1))

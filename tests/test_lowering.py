@@ -481,6 +481,8 @@ def test_committed_reference_graphs_lower_to_the_builder_spec(name):
     if want.mixture_rows is not None:
         xa, xb = spec.mixture_rows, want.mixture_rows
         assert (xa.K, xa.mu, xa.sigma, xa.w_logits, xa.assign) == (xb.K, xb.mu, xb.sigma, xb.w_logits, xb.assign) and np.array_equal(xa.y, xb.y)
+        assert (xa.w_alpha is None) == (xb.w_alpha is None) and (xa.w_alpha is None or np.allclose(xa.w_alpha, xb.w_alpha, rtol=0, atol=1e-12))
+        assert [v.simplex for v in spec.vars] == [v.simplex for v in want.vars]
     if want.mvnormal is not None:
         ma, mb = spec.mvnormal, want.mvnormal
         assert ma.var == mb.var and np.allclose(ma.mu, mb.mu, rtol=1e-13, atol=0) and np.allclose(ma.cov, mb.cov, rtol=1e-10, atol=1e-13)
@@ -494,6 +496,24 @@ def test_committed_reference_graphs_lower_to_the_builder_spec(name):
         lp, g = ref_models.evaluate(spec, q)
         lp0, g0 = ref_models.evaluate(want, q)
         assert np.isfinite(lp0) and abs(lp - lp0) <= 1e-12 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-12 * max(1.0, np.max(np.abs(g0)))
+
+
+def test_dirichlet_variables_the_ir_cannot_place_are_refused():
+    """A simplex-transformed variable is lowered as the weight vector of a mixture over observed rows (the node evaluates prior and
+    Jacobian); on its own, with two components, or with a prior that is not a Dirichlet density, the graph is not lowerable."""
+    if not sg.available():
+        pytest.skip("builds graphs with the reference's code")
+    m = sg.StubModel()
+    m.Dirichlet("w", np.array([1.0, 2.0, 3.0]))
+    m.Normal("x", 0.0, 1.0, shape=(2,))
+    with pytest.raises(NotLowerable, match="not the weight vector of a mixture"):
+        lower_to_spec(m)
+    m = sg.StubModel()
+    w = m.Dirichlet("w", np.array([1.0, 2.0]))
+    mu = m.Normal("mu", 0.0, 5.0, shape=(2,))
+    m.NormalMixture("y", w, mu, 1.0, observed=lm.YM)
+    with pytest.raises(NotLowerable, match="K >= 3"):
+        lower_to_spec(m)
 
 
 def test_configs2_mvnormal_2048_graph_lowers_to_the_c3_spec():

@@ -302,7 +302,7 @@ def test_device_rejects_a_malformed_mixture_node():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["normal_mixture_marginal", "normal_mixture_softmax"])
+@pytest.mark.parametrize("name", ["normal_mixture_marginal", "normal_mixture_softmax", "normal_mixture_dirichlet"])
 def test_lowered_reference_graph_runs_on_the_device(name):
     """Graph -> spec -> device: the committed graph the reference's `mixture_logprob` built (tests/golden/ref_graphs.npz) is lowered
     and evaluated through the C ABI; same numbers as the oracle on the hand-assembled spec."""
@@ -313,7 +313,10 @@ def test_lowered_reference_graph_runs_on_the_device(name):
     from pymc_amd.value_grad import DeviceValueGradFunction
 
     spec = lower_to_spec(sg.FrozenModel(sg.load_models(lm.FIXTURE)[name]))
-    assert spec.mixture_rows is not None and spec.mixture_rows.K == 3
+    assert spec.mixture_rows is not None and spec.mixture_rows.K == (4 if name.endswith("dirichlet") else 3)
+    if name.endswith("dirichlet"):      # the concentrations were read off the graph the reference's Dirichlet.logp + SimplexTransform built
+        np.testing.assert_allclose(spec.mixture_rows.w_alpha, lm.A_DIRICHLET, rtol=0, atol=1e-12)
+        assert [v.value_name for v in spec.vars] == ["w_simplex__", "mu", "sigma_log__"]
     want = lm.ENTRIES[name][1]()
     f = DeviceValueGradFunction(spec, device=0)
     rng = np.random.default_rng(2)
