@@ -578,12 +578,14 @@ def run_rank(args):
     return 0
 
 
-def chains_on_one_gpu(args, spec, device, tune=300, draws=300):
+def chains_on_one_gpu(args, spec, device, tune=500, draws=1000):
     """BASELINE configs[2] says `"chains": 4`: the same model's four chains on ONE GPU, from host threads -- each with an engine and
     a stream of its own, and as a chain group whose members share one launch per leapfrog (csrc/mvn_multi_kernel.h; the draws are
     bitwise the independent chains').  Aggregate leapfrog steps/s over the post-tuning draws = all chains' leapfrogs / the slowest
-    worker's sampling time.  A separate, bounded run: not part of `value`."""
+    worker's sampling time; `ess_per_sec` = the pooled four-chain bulk-ESS of the worst parameter over the same time (BASELINE's
+    metric for this config).  A separate, bounded run: not part of `value`."""
     from pymc_amd.sampling import sample
+    from pymc_amd.stats import ess_bulk_many, rhat_many
 
     out, ref = {"chains": args.chains_per_gpu, "tune": tune, "draws": draws}, None
     for mode, lockstep in (("independent_engines", False), ("chain_group", True)):
@@ -592,7 +594,9 @@ def chains_on_one_gpu(args, spec, device, tune=300, draws=300):
         res["step"].close()
         lf = sum(int(s_["tree_size"]) for c in range(args.chains_per_gpu) for s_ in res["stats"][c])
         n = res["lockstep_launches"]
+        ess = ess_bulk_many(res["draws"])
         out[mode] = {"leapfrog_steps_per_sec": lf / res["sampling_time"], "sampling_time_s": res["sampling_time"],
+                     "min_ess": float(ess.min()), "ess_per_sec": float(ess.min()) / res["sampling_time"], "rhat_max": float(rhat_many(res["draws"]).max()),
                      "launches_by_chains_carried": n[1:] if n else None,
                      "mean_chains_per_launch": (sum(c * n[c] for c in range(1, 5)) / max(1, sum(n[1:]))) if n else None}
         if ref is None:

@@ -63,6 +63,22 @@ def test_grouped_chains_are_bitwise_the_chains_alone(k, chains, tune, draws):
     print(f"k = {k}: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, 5)) / sum(n[1:]):.2f}")
 
 
+def test_sample_groups_the_chains_of_such_a_model_by_default():
+    """`sample(chains=3)` with nothing else said: the model's data pass is cache-resident, so the chains of the rank run concurrently,
+    and -- the model being one MvNormal node -- as a chain group; a model the engine cannot group runs them as independent engines."""
+    from pymc_amd.sampling import sample
+
+    res = sample(draws=5, tune=10, chains=3, model=models.mvnormal(n=256, seed=5), random_seed=3, device=0)
+    res["step"].close()
+    n = res["lockstep_launches"]
+    assert n is not None and sum(n[2:]) > 0, n
+    res = sample(draws=5, tune=10, chains=3, model=models.hier_logit(G=32, D=8, rows_per_group=40), random_seed=3, device=0, cores=3)
+    res["step"].close()
+    assert res["lockstep_launches"] is None
+    with pytest.raises(ValueError, match="lockstep=True"):
+        sample(draws=5, tune=10, chains=2, model=models.hier_logit(G=32, D=8, rows_per_group=40), random_seed=3, device=0, cores=2, lockstep=True)
+
+
 def test_chains_of_different_length_leave_and_join():
     """The group through its own interface: one chain stops early, one starts late, one is sampled in two calls with a pause in
     between -- whoever is inside a tree shares its launches, everybody else is simply not waited for."""
