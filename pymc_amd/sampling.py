@@ -62,6 +62,12 @@ def initial_point(spec: ModelSpec) -> Dict[str, np.ndarray]:
     explicit `initvals`.
     """
     pt = {v.value_name: np.zeros(v.shape, dtype="float64") for v in spec.vars}
+    # Dirichlet weights: the support point a / sum(a) (multivariate.py:550-555) through `SimplexTransform.forward`
+    # (logprob/transforms.py:1094-1099): log(w) - mean(log(w)), last element dropped -- zero only for equal concentrations
+    mx = getattr(spec, "mixture_rows", None)
+    if mx is not None and getattr(mx, "w_alpha", None) is not None:
+        la = np.log(np.asarray(mx.w_alpha, dtype="float64"))
+        pt[spec.vars[mx.w_logits].value_name] = (la - la.mean())[:-1]
     # value variables that are inputs of the log-density without being gradient variables (discrete variables another step method
     # updates) are part of the reference's initial point too (initial_point.py:187-340 covers every value variable): their initial
     # values are the ones the model states

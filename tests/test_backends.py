@@ -187,3 +187,47 @@ def test_inference_data_layout_as_plain_arrays():
     assert idata["attrs"] == {"sampling_time": 1.5, "tuning_steps": 4}
     with_tr = to_inference_dict(mt, include_transformed=True)
     assert any(v.endswith("__") for v in with_tr["posterior"]) and set(with_tr) == {"posterior", "sample_stats", "attrs"}
+
+
+def test_simplex_variables_are_recorded_with_their_k_elements():
+    """`w ~ Dirichlet(a)`: the value variable `w_simplex__` has K - 1 elements, the trace shows `w` itself -- K elements on the simplex
+    (`SimplexTransform.backward`, logprob/transforms.py:1101-1104) -- next to it when transformed variables are asked for; one draw
+    at a time and in batches alike."""
+    from pymc_amd.model_spec import ModelBuilder
+    from pymc_amd.trace import posterior
+
+    m = ModelBuilder()
+    w = m.Dirichlet("w", [1.0, 2.0, 3.0, 4.0])
+    mu = m.Normal("mu", 0.0, 5.0, shape=4)
+    m.NormalMixture("y", w, mu, 1.0, np.linspace(-3, 3, 20))
+    spec = m.build()
+    assert [(v.name, v.value_name, v.shape, v.constrained_shape) for v in spec.vars] == [("w", "w_simplex__", (3,), (4,)), ("mu", "mu", (4,), (4,))]
+    pos, stats = _points(spec, 12, 4)
+    a, b = NDArray(model=spec, include_transformed=True), NDArray(model=spec, include_transformed=True)
+    a.setup(12, 0, SVARS); b.setup(12, 0, SVARS)
+    for k in range(12):
+        a.record(_point(spec, pos[k]), stats[k])
+    b.record_batch(pos, stats)
+    for tr in (a, b):
+        wv, yv = tr.get_values("w"), tr.get_values("w_simplex__")
+        assert wv.shape == (12, 4) and yv.shape == (12, 3)
+        assert np.allclose(wv.sum(axis=1), 1.0) and np.all(wv > 0)
+        np.testing.assert_allclose(np.log(wv[:, :3]) - np.log(wv[:, 3:]), yv + yv.sum(axis=1, keepdims=True), rtol=1e-12, atol=1e-12)
+    assert np.array_equal(a.get_values("w"), b.get_values("w"))
+    post = posterior(spec, pos[None], include_transformed=True)
+    assert post["w"].shape == (1, 12, 4) and post["w_simplex__"].shape == (1, 12, 3)
+
+
+def test_initial_point_of_dirichlet_weights_is_the_reference_support_point():
+    """initial_point.py:187-340: the support point a / sum(a) (multivariate.py:550-555) mapped through the transform's `forward`."""
+    from pymc_amd.model_spec import ModelBuilder
+    from pymc_amd.sampling import initial_point
+
+    a = np.array([1.0, 2.0, 3.0, 4.0])
+    m = ModelBuilder()
+    w = m.Dirichlet("w", a)
+    m.NormalMixture("y", w, m.Normal("mu", 0.0, 5.0, shape=4), 1.0, np.zeros(5))
+    spec = m.build()
+    p = initial_point(spec)
+    np.testing.assert_allclose(backward(spec.vars[0], p["w_simplex__"]), a / a.sum(), rtol=1e-14)
+    assert np.all(p["mu"] == 0)
