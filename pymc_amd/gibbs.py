@@ -43,9 +43,14 @@ class MixtureLink:
 
     name: str                 # value variable of the assignments ("c")
     y: np.ndarray             # [N] observations
-    log_w: np.ndarray         # [K]
-    sigma: np.ndarray         # [K]
+    log_w: np.ndarray         # [K]  (constants; with `w_name`: the initial weights, only their count is used)
+    sigma: np.ndarray         # [K]  (constants; with `sigma_name`: likewise)
     mu_name: str              # value variable holding the component means
+    # the fully Bayesian mixture: weights and scales are variables of the continuous step as well -- the assignment conditional is
+    # evaluated at the point's CURRENT values, as the reference's full-model log-density is (metropolis.py:771-786 `self.logp(q)`)
+    w_name: Optional[str] = None       # value variable of simplex-transformed Dirichlet weights (`<w>_simplex__`, K - 1 elements)
+    sigma_name: Optional[str] = None   # value variable of the component scales (K elements)
+    sigma_log: bool = True             # ... log-transformed (`<sigma>_log__`)
 
     def __post_init__(self):
         self._cache_for = None    # the array object the sweep produced (a strong reference: its id cannot be reused while cached)
@@ -55,6 +60,20 @@ class MixtureLink:
     @property
     def K(self) -> int:
         return len(self.log_w)
+
+    def log_w_at(self, point) -> np.ndarray:
+        if self.w_name is None:
+            return self.log_w
+        yv = np.asarray(point[self.w_name], dtype="float64")
+        full = np.concatenate([yv, [-yv.sum()]])       # SimplexTransform.backward, logprob/transforms.py:1101-1104
+        m = full.max()
+        return full - (m + np.log(np.exp(full - m).sum()))
+
+    def sigma_at(self, point) -> np.ndarray:
+        if self.sigma_name is None:
+            return self.sigma
+        v = np.asarray(point[self.sigma_name], dtype="float64")
+        return np.exp(v) if self.sigma_log else v
 
     def suffstats(self, c: np.ndarray):
         c = np.asarray(c)
@@ -275,7 +294,7 @@ class CategoricalGibbsMetropolis:
         pool = np.empty(2 * n + 2)
         _lib.check(lib.nuts_gibbs_plan_doubles(C.byref(p), n, int(self.shuffle_dims), self._order.ctypes.data, len(pool), _lib.dptr(pool)), "nuts_gibbs_plan_doubles")
         _pcg_from_c(self.rng, p)                       # the generator as it stands after the shuffle
-        lw, sg = np.ascontiguousarray(link.log_w, dtype="float64"), np.ascontiguousarray(link.sigma, dtype="float64")
+        lw, sg = np.ascontiguousarray(link.log_w_at(point), dtype="float64"), np.ascontiguousarray(link.sigma_at(point), dtype="float64")
         cnt, s1, s2 = np.empty(K), np.empty(K), np.empty(K)
         nacc = C.c_int64(0)
         flags = np.ones(n, dtype="int8")
@@ -325,7 +344,7 @@ class CategoricalGibbsMetropolis:
         K = link.K
         cnt, s1, s2 = np.empty(K), np.empty(K), np.empty(K)
         nacc, nonf = C.c_int64(0), C.c_int64(0)
-        lw, sg = np.ascontiguousarray(link.log_w, dtype="float64"), np.ascontiguousarray(link.sigma, dtype="float64")
+        lw, sg = np.ascontiguousarray(link.log_w_at(point), dtype="float64"), np.ascontiguousarray(link.sigma_at(point), dtype="float64")
         rc = _lib.load().nuts_gibbs_sweep(self._engine(), c.ctypes.data, _lib.dptr(lw), _lib.dptr(mu), _lib.dptr(sg), self._order.ctypes.data,
                                           cand.ctypes.data, _lib.dptr(log_u), C.byref(nacc), C.byref(nonf), _lib.dptr(cnt), _lib.dptr(s1), _lib.dptr(s2))
         _lib.check(rc, "nuts_gibbs_sweep")

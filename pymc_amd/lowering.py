@@ -937,8 +937,16 @@ class _Lowering:
         if not unify(tmpl, node, env):
             return False
         c, p_, km1 = env["c"], env["p"], _num(env["km1"])
-        if c[0] != "input" or id(c[1]) not in self.extra_id or p_[0] != "const" or km1 is None:
+        if c[0] != "input" or id(c[1]) not in self.extra_id or km1 is None:
             return False
+        if p_[0] != "const":
+            # p = a `pm.Dirichlet` variable under its default transform (the fully Bayesian mixture: weights learned by NUTS, the
+            # assignments by the Gibbs step): remembered as the simplex variable itself
+            kw = self._simplex_weights(p_)
+            if kw is None or self.spec.vars[kw].size != int(km1):
+                return False
+            self._cat[self.extra_id[id(c[1])]] = ("simplex", kw)
+            return True
         w = np.asarray(p_[1], dtype="float64").reshape(-1)
         if w.size != int(km1) + 1:
             return False
@@ -957,7 +965,8 @@ class _Lowering:
             return False
         K_ = self.spec.vars[km].size
         w = self._cat[did]
-        if w.size != K_:
+        simplex_w = isinstance(w, tuple)
+        if (self.spec.vars[w[1]].size + 1 if simplex_w else w.size) != K_:
             return False
         y = np.ascontiguousarray(val[1], dtype="float64").ravel()
         if y.size != self.spec.data[did].size:
@@ -970,9 +979,14 @@ class _Lowering:
             node_.sigma = self._as_var(sg_n[1])
         else:
             return False
-        if not np.isclose(w.sum(), 1.0):
-            raise NotLowerable("mixture weights that do not sum to one")
-        node_.w_const = np.ascontiguousarray(w)
+        if simplex_w:
+            if K_ < 3:
+                raise NotLowerable("Dirichlet mixture weights need K >= 3 components (a variable of K - 1 free elements)")
+            node_.w_logits, node_.w_alpha = w[1], self._dirichlet.pop(w[1])
+        else:
+            if not np.isclose(w.sum(), 1.0):
+                raise NotLowerable("mixture weights that do not sum to one")
+            node_.w_const = np.ascontiguousarray(w)
         node_.assign = did
         if self.spec.mixture_rows is not None or self.spec.logit_rows is not None or self.spec.mvnormal is not None or self.spec.glm_rows is not None:
             raise NotLowerable("more than one dense node in a model")

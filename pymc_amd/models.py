@@ -234,6 +234,33 @@ def normal_mixture(N: int = 100_000, K: int = 3, seed: int = DATA_SEED, sigma: f
     return spec
 
 
+def normal_mixture_bayes(N: int = 2000, K: int = 3, seed: int = DATA_SEED, alpha=None) -> ModelSpec:
+    """The fully Bayesian Gaussian mixture under `CompoundStep` (K >= 3):
+
+        w ~ Dirichlet(alpha);  mu[K] ~ Normal(0, 10);  sigma[K] ~ HalfNormal(2);  c_i ~ Categorical(w);  y_i ~ Normal(mu[c_i], sigma[c_i])
+
+    NUTS samples (w, mu, sigma) -- value variables `w_simplex__` (K - 1 elements), `mu`, `sigma_log__` -- through the mixture node
+    given the assignments (prior and Jacobian of the simplex-transformed weights evaluated by the node), the Gibbs step samples c
+    at the point's current weights, means and scales (`MixtureLink.w_name / sigma_name`)."""
+    from pymc_amd.gibbs import MixtureLink
+
+    rng = np.random.default_rng(seed)
+    alpha = np.ones(K) if alpha is None else np.asarray(alpha, dtype="float64")
+    mu_true = np.linspace(-4.0, 4.0, K)
+    sd_true = np.linspace(0.6, 1.2, K)
+    c_true = rng.integers(0, K, size=N)
+    y = mu_true[c_true] + sd_true[c_true] * rng.normal(size=N)
+    m = ModelBuilder()
+    w = m.Dirichlet("w", alpha)
+    mu = m.Normal("mu", 0.0, 10.0, shape=K)
+    sigma = m.HalfNormal("sigma", 2.0, shape=K)
+    c = m.Extra("c", np.zeros(N))
+    m.NormalMixture("y", w, mu, sigma, y, assign=c)
+    spec = m.build()
+    spec.mixture = MixtureLink("c", y, np.full(K, -np.log(K)), np.ones(K), "mu", w_name="w_simplex__", sigma_name="sigma_log__", sigma_log=True)
+    return spec
+
+
 def glm_nuts(N: int = 1_000_000, P: int = 512, family: str = "bernoulli", seed: int = DATA_SEED, intercept: bool = True, sigma: str = "var",
              prior_sd: float = 1.0) -> ModelSpec:
     """The GLM of BASELINE configs[3] (1 M observations x 512 covariates) as a model NUTS samples: beta[P] ~ Normal(0, prior_sd),

@@ -313,6 +313,31 @@ def _mixture_categorical_indexed_built(sigma_var=False):
     return b.build()
 
 
+C0_4 = np.random.default_rng(19).integers(0, 4, size=YM.size)
+
+
+def mixture_categorical_dirichlet():
+    """The fully Bayesian mixture under `CompoundStep`: `w ~ Dirichlet(a)` and the component parameters sampled by NUTS, the
+    assignments `c ~ Categorical(w)` by the Gibbs step, `y ~ Normal(mu[c], sigma[c])` observed."""
+    m = sg.StubModel()
+    w = m.Dirichlet("w", A_DIRICHLET)
+    c = m.Categorical("c", w, shape=(YM.size,), initval=C0_4)
+    mu = m.Normal("mu", 0.0, 5.0, shape=(4,))
+    sigma = m.HalfNormal("sigma", 2.0, shape=(4,))
+    m.Normal("y", mu[c], sigma[c], observed=YM)
+    return m
+
+
+def _mixture_categorical_dirichlet_built():
+    b = ModelBuilder()
+    w = b.Dirichlet("w", A_DIRICHLET)
+    ce = b.Extra("c", C0_4.astype("float64"))
+    mu = b.Normal("mu", 0.0, 5.0, shape=4)
+    sigma = b.HalfNormal("sigma", 2.0, shape=4)
+    b.NormalMixture("y", w, mu, sigma, YM, assign=ce)
+    return b.build()
+
+
 _AM = np.random.default_rng(31).normal(size=(6, 6))
 COV6 = _AM @ _AM.T + 0.5 * np.eye(6)
 MU6 = np.linspace(-0.5, 0.7, 6)
@@ -372,6 +397,7 @@ ENTRIES = {
     "normal_mixture_dirichlet": (normal_mixture_dirichlet, _normal_mixture_dirichlet_built),
     "mixture_categorical_indexed": (mixture_categorical_indexed, _mixture_categorical_indexed_built),
     "mixture_categorical_indexed_sigma": (lambda: mixture_categorical_indexed(True), lambda: _mixture_categorical_indexed_built(True)),
+    "mixture_categorical_dirichlet": (mixture_categorical_dirichlet, _mixture_categorical_dirichlet_built),
     "mvnormal_cov": (mvnormal_cov, _mvnormal_built),
     "mvnormal_chol": (mvnormal_chol, _mvnormal_built),
     "mvnormal_tau": (mvnormal_tau, _mvnormal_built),

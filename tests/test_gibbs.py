@@ -435,6 +435,71 @@ def test_compound_nuts_plus_gibbs_matches_the_oracle_pair(form):
     g2.close()
 
 
+@pytest.mark.gpu
+def test_compound_on_the_fully_bayesian_mixture_matches_the_oracle_pair():
+    """`w ~ Dirichlet`, mu, sigma sampled by NUTS through the mixture node given the assignments; the assignments by the Gibbs step at
+    the point's current weights, means and scales: the device pair against (oracle NUTS over the spec's log-density with c as its
+    extra value, oracle Gibbs with log w, sigma taken from the same point), iteration by iteration."""
+    from oracle import ref_models
+    from pymc_amd.compound import CompoundStep
+    from pymc_amd.step import NUTS
+
+    N, K = 1500, 3
+    spec = models.normal_mixture_bayes(N=N, K=K, seed=11, alpha=[2.0, 1.0, 3.0])
+    link = spec.mixture
+    nuts = NUTS(model=spec, rng=1, device=0)
+    gibbs = CategoricalGibbsMetropolis(model=spec, rng=2, device=0)
+    comp = CompoundStep([nuts, gibbs])
+    comp.setup_chain(np.random.default_rng(5), 15, 10)
+    c0 = np.random.default_rng(3).integers(0, K, size=N)
+    point = {"w_simplex__": np.array([0.1, -0.2]), "mu": np.array([-3.0, 0.3, 3.5]), "sigma_log__": np.zeros(K), "c": c0.copy()}
+    r_nuts, r_gibbs = np.random.default_rng(5).spawn(2)
+    f = ref_models.SpecLogpGrad(spec)
+    onuts = ref_sampler.RefNUTS(f, spec.n, rng=1)
+    onuts.setup_chain(r_nuts, 15, 10)
+    onuts.tune = True
+    onuts.reset_tuning()
+    ogibbs = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w, link.sigma, r_gibbs)
+    q = np.concatenate([point[v.value_name] for v in spec.vars])
+    c_ref = c0.copy()
+    nuts.tune = True
+    nuts.reset_tuning()
+    nuts.iter_count = 0
+    same_integers = 0
+    for it in range(25):
+        if it == 15:
+            comp.stop_tuning()
+            onuts.stop_tuning()
+        point, stats = comp.step(point)
+        f.set_extra_values({"c": c_ref.astype("float64")})
+        q, ost = onuts.astep(q)
+        pt_ref = {v.value_name: q[v.offset:v.offset + v.size] for v in spec.vars}
+        ogibbs.log_w, ogibbs.sigma = link.log_w_at(pt_ref), link.sigma_at(pt_ref)
+        c_ref, _ = ogibbs.sweep(c_ref, pt_ref["mu"])
+        if all(int(stats[0][key]) == int(ost[key]) for key in ("depth", "tree_size", "index_in_trajectory", "diverging")) and np.array_equal(point["c"], c_ref):
+            same_integers += 1
+        else:
+            break
+        np.testing.assert_allclose(np.concatenate([point[v.value_name] for v in spec.vars]), q, rtol=1e-6 if it < 6 else 1e-2, atol=1e-8)
+    assert same_integers >= 12, same_integers     # (two chaotic maps in turn: a rounding difference flips an assignment sooner or later)
+    w = link.log_w_at(point)
+    assert np.isclose(np.exp(w).sum(), 1.0)
+    comp.close()
+
+
+def test_link_reads_weights_and_scales_from_the_point():
+    from pymc_amd.gibbs import MixtureLink
+    from pymc_amd.trace import backward
+
+    spec = models.normal_mixture_bayes(N=50, K=4)
+    link = spec.mixture
+    pt = {"w_simplex__": np.array([0.3, -0.1, 0.8]), "sigma_log__": np.log([0.5, 1.0, 1.5, 2.0]), "mu": np.zeros(4)}
+    np.testing.assert_allclose(np.exp(link.log_w_at(pt)), backward(spec.vars[0], pt["w_simplex__"]), rtol=1e-14)
+    np.testing.assert_allclose(link.sigma_at(pt), [0.5, 1.0, 1.5, 2.0], rtol=1e-14)
+    const = MixtureLink("c", np.zeros(3), np.log([0.2, 0.8]), np.array([1.0, 2.0]), "mu")
+    assert const.log_w_at(pt) is const.log_w and const.sigma_at(pt) is const.sigma
+
+
 def _full_logp_grad(q, c, link):
     lp = ref_gibbs.mixture_full_logp(c, link.y, q, link.log_w, link.sigma)
     g = np.bincount(c, weights=(link.y - q[c]) / link.sigma[c] ** 2, minlength=len(q)) - q / 100.0

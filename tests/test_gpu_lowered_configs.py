@@ -45,10 +45,13 @@ def _check(spec, want, rtol=1e-9):
 
 
 def _nuts(spec, want, tune=25, draws=10, seed=5):
-    from pymc_amd.sampling import sample
+    from pymc_amd.sampling import initial_point, sample
 
     res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
-    _, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(want), [np.zeros(want.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    # (the initial point: zeros in the unconstrained space, except Dirichlet weights -- their support point through the transform)
+    ip = initial_point(want)
+    q0 = np.concatenate([np.ravel(ip[v.value_name]) for v in want.vars])
+    _, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(want), [q0], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
     dev = res["warmup_stats"][0] + res["stats"][0]
     for i in range(tune + draws):
         for k in INT_KEYS:
@@ -64,7 +67,7 @@ def test_configs_1_and_2_graphs_on_the_device(name):
     _nuts(spec, want)
 
 
-@pytest.mark.parametrize("name", ["mixture_categorical_indexed", "mixture_categorical_indexed_sigma"])
+@pytest.mark.parametrize("name", ["mixture_categorical_indexed", "mixture_categorical_indexed_sigma", "mixture_categorical_dirichlet"])
 def test_configs_4_compound_form_graph_on_the_device(name):
     """The assignments are an extra input: logp / gradient at the initial assignments, a NUTS run on the continuous variables, then
     new assignments through `set_extra_values` (what `CompoundStep` does between the two step methods, arraystep.py:109-111)."""
@@ -72,7 +75,7 @@ def test_configs_4_compound_form_graph_on_the_device(name):
     assert spec.mixture_rows is not None and spec.mixture_rows.assign is not None and list(spec.extra) == ["c"]
     f = _check(spec, want)
     rng = np.random.default_rng(9)
-    c1 = rng.integers(0, 3, size=lm.YM.size).astype("float64")
+    c1 = rng.integers(0, spec.mixture_rows.K, size=lm.YM.size).astype("float64")
     f.set_extra_values({"c": c1})
     ref = ref_models.SpecLogpGrad(want)
     ref.set_extra_values({"c": c1})
