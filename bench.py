@@ -337,8 +337,6 @@ def run_rank(args):
         if os.environ.get("PYMC_AMD_BENCH_STUB_TRY_RCCL") != "1":   # (the test of the fall-back below leaves RCCL requested on a box without a GPU)
             args.backend = "gloo"   # RCCL refuses two ranks on one device ("Duplicate GPU detected")
     if world > 1:
-        import datetime
-
         import torch.distributed as dist
 
         # The control plane -- barriers around the timed region, the gather of the ranks' small result records -- is a gloo group
