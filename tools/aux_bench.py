@@ -75,7 +75,9 @@ def bench_c5(args):
     from pymc_amd.gibbs import CategoricalGibbsMetropolis
     from pymc_amd.step import NUTS
 
-    spec = models.normal_mixture(N=args.mix_n, K=3, seed=7)
+    # --bayes: the fully Bayesian mixture -- Dirichlet weights and component scales are NUTS variables as well (mixture node given
+    # the assignments; models.normal_mixture_bayes), the Gibbs step reads them from the point
+    spec = models.normal_mixture_bayes(N=args.mix_n, K=3, seed=7) if args.bayes else models.normal_mixture(N=args.mix_n, K=3, seed=7)
     link = spec.mixture
     nuts = NUTS(model=spec, rng=1, device=0)
     gibbs = CategoricalGibbsMetropolis(model=spec, rng=2, device=0)
@@ -83,6 +85,8 @@ def bench_c5(args):
     comp.setup_chain(np.random.default_rng(99), args.warmup, args.steps)
     c0 = np.random.default_rng(3).integers(0, 3, size=args.mix_n)
     point = {"mu": np.array([-1.0, 0.2, 1.5]), "c": c0.copy()}
+    if args.bayes:
+        point.update({"w_simplex__": np.zeros(2), "sigma_log__": np.zeros(3), "mu": np.array([-3.0, 0.2, 3.5])})
     nuts.tune = True
     nuts.reset_tuning()
     nuts.iter_count = 0
@@ -102,7 +106,9 @@ def bench_c5(args):
     Tg = time.perf_counter() - t0
     N = args.mix_n
     out = {
-        "workload": f"C5 mixture: N={N} latent assignments, K=3 component means; CompoundStep([NUTS(mu), CategoricalGibbsMetropolis(c)])",
+        "workload": (f"C5 mixture, fully Bayesian: N={N} latent assignments, K=3; CompoundStep([NUTS(w ~ Dirichlet, mu, sigma), CategoricalGibbsMetropolis(c)])"
+                     if args.bayes else
+                     f"C5 mixture: N={N} latent assignments, K=3 component means; CompoundStep([NUTS(mu), CategoricalGibbsMetropolis(c)])"),
         "metric": "compound iterations/sec", "value": args.steps / T, "unit": "iterations/s", "steps": args.steps, "warmup": args.warmup,
         "ms_per_iteration": 1e3 * T / args.steps, "mean_tree_size": trees / args.steps,
         "gibbs_sweep_ms": 1e3 * Tg / args.steps, "gibbs_elements_per_sec": N * args.steps / Tg,
@@ -114,7 +120,7 @@ def bench_c5(args):
     if args.cpu_steps > 0:
         from oracle import ref_gibbs
 
-        og = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w, link.sigma, np.random.default_rng(5))
+        og = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w_at(point), link.sigma_at(point), np.random.default_rng(5))
         c = c0.copy()
         k = max(1, min(args.cpu_steps, 3))
         t0 = time.perf_counter()
@@ -138,5 +144,6 @@ if __name__ == "__main__":
     ap.add_argument("--glm-cols", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--mix-n", type=int, default=100_000)
+    ap.add_argument("--bayes", action="store_true", help="c5: weights (Dirichlet) and component scales are NUTS variables too")
     a = ap.parse_args()
     (bench_c4 if a.workload == "c4" else bench_c5)(a)
