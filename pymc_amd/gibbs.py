@@ -61,6 +61,34 @@ class MixtureLink:
     def K(self) -> int:
         return len(self.log_w)
 
+    @classmethod
+    def from_spec(cls, spec) -> Optional["MixtureLink"]:
+        """The link of a spec whose mixture node is in its conditional form (`Categorical` + indexed `Normal`, the assignments an
+        extra value -- hand-assembled or lowered from the model graph): everything the assignment conditional needs is in the node."""
+        node = getattr(spec, "mixture_rows", None)
+        if node is None or node.assign is None:
+            return None
+        name = next((nm for nm, did in getattr(spec, "extra", {}).items() if did == node.assign), None)
+        if name is None:
+            return None
+        K = node.K
+        kw = {}
+        if getattr(node, "w_alpha", None) is not None:
+            kw["w_name"] = spec.vars[node.w_logits].value_name
+            log_w = np.full(K, -np.log(K))
+        elif node.w_logits is not None:
+            return None        # (softmax(logits) weights: not a form the Gibbs step reads from the point yet)
+        else:
+            with np.errstate(divide="ignore"):
+                log_w = np.log(np.asarray(node.w_const, dtype="float64"))
+        if node.sigma is not None:
+            sv = spec.vars[node.sigma]
+            kw.update(sigma_name=sv.value_name, sigma_log=sv.value_name != sv.name)
+            sigma = np.ones(K)
+        else:
+            sigma = np.asarray(node.sigma_const, dtype="float64")
+        return cls(name, np.asarray(node.y, dtype="float64"), log_w, sigma, spec.vars[node.mu].value_name, **kw)
+
     def log_w_at(self, point) -> np.ndarray:
         if self.w_name is None:
             return self.log_w
@@ -180,8 +208,9 @@ class CategoricalGibbsMetropolisState:   # metropolis.py:664-672 + StepMethodSta
 
 
 class CategoricalGibbsMetropolis:
-    """Signature of metropolis.py:692-703.  `model` is a `ModelSpec` built by `models.normal_mixture` (it carries the
-    `MixtureLink`); `vars` names the assignment variable."""
+    """Signature of metropolis.py:692-703.  `model` is a `ModelSpec` with a mixture node in its conditional form -- built by
+    `models.normal_mixture*` (which attach the `MixtureLink`) or lowered from the model graph (`MixtureLink.from_spec`); `vars` names
+    the assignment variable."""
 
     name = "categorical_gibbs_metropolis"
     default_blocked = True
@@ -191,6 +220,8 @@ class CategoricalGibbsMetropolis:
     def __init__(self, vars=None, *, proposal="uniform", order="random", model=None, rng=None, initial_point=None,
                  compile_kwargs=None, blocked=True, device: Optional[int] = None):
         link = getattr(model, "mixture", None)
+        if link is None:
+            link = MixtureLink.from_spec(model)     # (a spec lowered from the model graph carries the node, not the link)
         if link is None:
             raise ValueError("All variables must be categorical or binary for CategoricalGibbsMetropolis")
         self.link: MixtureLink = link

@@ -500,6 +500,66 @@ def test_link_reads_weights_and_scales_from_the_point():
     assert const.log_w_at(pt) is const.log_w and const.sigma_at(pt) is const.sigma
 
 
+def test_link_from_a_lowered_spec():
+    """Graph -> spec -> CompoundStep: the Gibbs step finds what it needs in the mixture node of a spec the graph walker produced
+    (configs[4]'s model as PyMC writes it, with constant weights and with Dirichlet weights), no hand-made link."""
+    import lowering_models as lm
+    import stubgraph as sg
+
+    from pymc_amd.gibbs import MixtureLink
+    from pymc_amd.lowering import lower_to_spec
+
+    graphs = sg.load_models(lm.FIXTURE)
+    spec = lower_to_spec(sg.FrozenModel(graphs["mixture_categorical_indexed_sigma"]))
+    link = MixtureLink.from_spec(spec)
+    assert (link.name, link.mu_name, link.w_name, link.sigma_name, link.sigma_log, link.K) == ("c", "mu", None, "sigma_log__", True, 3)
+    np.testing.assert_allclose(np.exp(link.log_w), lm.WM, rtol=1e-13)
+    assert np.array_equal(link.y, lm.YM)
+    spec = lower_to_spec(sg.FrozenModel(graphs["mixture_categorical_indexed"]))
+    link = MixtureLink.from_spec(spec)
+    assert link.sigma_name is None and np.allclose(link.sigma, 0.9)
+    spec = lower_to_spec(sg.FrozenModel(graphs["mixture_categorical_dirichlet"]))
+    link = MixtureLink.from_spec(spec)
+    assert (link.w_name, link.sigma_name, link.K) == ("w_simplex__", "sigma_log__", 4)
+    step = CategoricalGibbsMetropolis(model=spec, rng=1)       # (no device needed until the first sweep)
+    assert step.var_names == ("c",) and len(step._order) == lm.YM.size
+    assert MixtureLink.from_spec(lower_to_spec(sg.FrozenModel(graphs["normal_mixture_marginal"]))) is None   # marginal form: no assignments
+
+
+@pytest.mark.gpu
+def test_compound_on_a_lowered_graph_equals_the_hand_assembled_model():
+    """The same fully Bayesian mixture twice -- lowered from the graph the reference's code built, and assembled with `ModelBuilder`
+    plus a hand-made link: CompoundStep([NUTS, CategoricalGibbsMetropolis]) walks the same path, bit for bit."""
+    import lowering_models as lm
+    import stubgraph as sg
+
+    from pymc_amd.compound import CompoundStep
+    from pymc_amd.lowering import lower_to_spec
+    from pymc_amd.step import NUTS
+
+    def run(spec):
+        nuts, gibbs = NUTS(model=spec, rng=1, device=0), CategoricalGibbsMetropolis(model=spec, rng=2, device=0)
+        comp = CompoundStep([nuts, gibbs])
+        comp.setup_chain(np.random.default_rng(8), 10, 5)
+        point = {"w_simplex__": np.zeros(3), "mu": np.array([-2.0, -0.5, 0.5, 2.0]), "sigma_log__": np.zeros(4), "c": lm.C0_4.copy()}
+        nuts.tune = True
+        nuts.reset_tuning()
+        nuts.iter_count = 0
+        out = []
+        for it in range(15):
+            if it == 10:
+                comp.stop_tuning()
+            point, stats = comp.step(point)
+            out.append((np.concatenate([np.ravel(point[k]) for k in ("w_simplex__", "mu", "sigma_log__")]), point["c"].copy(), int(stats[0]["tree_size"])))
+        comp.close()
+        return out
+
+    a = run(lower_to_spec(sg.FrozenModel(sg.load_models(lm.FIXTURE)["mixture_categorical_dirichlet"])))
+    b = run(lm.ENTRIES["mixture_categorical_dirichlet"][1]())
+    for (qa, ca, ta), (qb, cb, tb) in zip(a, b):
+        assert np.array_equal(qa, qb) and np.array_equal(ca, cb) and ta == tb
+
+
 def _full_logp_grad(q, c, link):
     lp = ref_gibbs.mixture_full_logp(c, link.y, q, link.log_w, link.sigma)
     g = np.bincount(c, weights=(link.y - q[c]) / link.sigma[c] ** 2, minlength=len(q)) - q / 100.0
