@@ -189,6 +189,84 @@ def _dist_info():
     return rank, world, local
 
 
+def assign_step_methods(spec: ModelSpec, nuts_step, device=None):
+    """`assign_step_methods` + `instantiate_steppers` (mcmc.py:108-258) for what the IR holds: the continuous variables go to NUTS;
+    a categorical variable (the assignments of a mixture, an extra value of the NUTS log-density) goes to
+    `CategoricalGibbsMetropolis`; more than one method -> `CompoundStep`.  Returns the step to sample with."""
+    from pymc_amd.compound import CompoundStep
+    from pymc_amd.gibbs import CategoricalGibbsMetropolis, MixtureLink
+
+    if not getattr(spec, "extra", None):
+        return nuts_step
+    link = getattr(spec, "mixture", None) or MixtureLink.from_spec(spec)
+    if link is None or link.name not in spec.extra:
+        return nuts_step     # (extras that are plain data of the caller: `set_extra_values` is theirs to call)
+    logging.getLogger("pymc").info("CompoundStep")
+    logging.getLogger("pymc").info(">NUTS: [%s]", ", ".join(v.name for v in spec.vars))
+    logging.getLogger("pymc").info(">CategoricalGibbsMetropolis: [%s]", link.name)
+    return CompoundStep([nuts_step, CategoricalGibbsMetropolis(model=spec, device=device)])
+
+
+def _sample_compound(comp, spec, points, rngs, mine, tune, draws, discard_tuned_samples):
+    """`_iter_sample` (mcmc.py:1503-1583) for a `CompoundStep`: every iteration hands the point through the methods; the gradient
+    variables are recorded raveled (as for NUTS alone), the other value variables (the discrete ones) by name."""
+    import time as _time
+
+    total = tune + draws
+    n = spec.n
+    extra_names = [k for k in getattr(spec, "extra", {})]
+    gvars = [v.value_name for v in spec.vars]
+    local_draws = np.empty((len(mine), total, n))
+    extra_draws = {k: [] for k in extra_names}
+    all_stats = []
+    t0 = _time.perf_counter()
+    t_sampling = 0.0
+    initial_state = comp.sampling_state
+    for k, c in enumerate(mine):
+        comp.sampling_state = initial_state
+        comp.setup_chain(rngs[c], tune, draws)
+        comp.tune = bool(tune)
+        for m in comp.methods:
+            m.tune = bool(tune)
+            if hasattr(m, "iter_count"):
+                m.iter_count = 0
+        comp.reset_tuning()
+        point = dict(points[c])
+        ex = {nm: np.empty((total,) + np.shape(point[nm]), dtype=np.asarray(point[nm]).dtype) for nm in extra_names}
+        chain_stats = []
+        for i in range(total):
+            if i == tune:
+                comp.stop_tuning()
+                ts = _time.perf_counter()
+            point, stats = comp.step(point)
+            local_draws[k, i] = DictToArrayBijection.map({nm: point[nm] for nm in gvars}).data
+            for nm in extra_names:
+                ex[nm][i] = point[nm]
+            chain_stats.append(stats)
+            log_warning_stats(stats)
+        t_sampling += _time.perf_counter() - ts if total > tune else 0.0
+        for nm in extra_names:
+            extra_draws[nm].append(ex[nm])
+        all_stats.append(chain_stats)
+    keep = slice(tune, None) if discard_tuned_samples else slice(None)
+    # the statistics of the gradient-based method (the first dict of every draw that has any) under the usual keys; everything,
+    # method by method, under "all_stats" (what the reference keeps per sampler, base.py:215-229)
+    main = [[next((d for d in st if d), {}) for st in chain] for chain in all_stats]
+    return {
+        "chains": mine,
+        "draws": local_draws[:, keep],
+        "extra_draws": {nm: np.stack(v)[:, keep] for nm, v in extra_draws.items()},
+        "stats": [s_[keep] for s_ in main],
+        "warmup_stats": [s_[:tune] for s_ in main],
+        "all_stats": [s_[keep] for s_ in all_stats],
+        "point_map_info": spec.point_map_info,
+        "wall_time": _time.perf_counter() - t0,
+        "sampling_time": t_sampling,
+        "lockstep_launches": None,
+        "step": comp,
+    }
+
+
 def assign_chains(chains: int, rank: int, world: int) -> List[int]:
     """chain c <-> rank c % world (one chain per GPU when chains == world)."""
     return [c for c in range(chains) if c % world == rank]
@@ -358,10 +436,15 @@ def sample(
     random_seed_list = [int(r.integers(2**30)) for r in rngs]
     mine = assign_chains(chains, rank, world)
     step_given = step is not None
+    if isinstance(step, (list, tuple)):     # `pm.sample(step=[nuts, gibbs])`: mcmc.py:200-258 wraps several methods in a CompoundStep
+        from pymc_amd.compound import CompoundStep
+
+        step = CompoundStep(list(step)) if len(step) > 1 else step[0]
     if step is None:
         points, step = init_nuts(
             spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device, tune=tune, **step_kwargs
         )
+        step = assign_step_methods(spec, step, device=device)
     else:
         points = []
         for c in range(chains):   # mcmc.py:867-881: `initvals` also apply when the caller brings the step method
@@ -370,9 +453,18 @@ def sample(
             if iv:
                 pt.update({k: np.asarray(v, dtype="float64") for k, v in iv.items()})
             points.append(pt)
+    compound = step if hasattr(step, "methods") else None
+    if compound is not None:
+        if world > 1 or mp_ctx is not None or pooled_adaptation:
+            raise NotImplementedError("a CompoundStep is sampled chain by chain on one rank (no gather / worker processes / pooled adaptation yet)")
+        grad_step = next(m for m in compound.methods if hasattr(m, "_logp_dlogp_func"))
+    else:
+        grad_step = step
     # `model.check_start_vals` (mcmc.py:883-887, model/core.py:1319-1373): the log-density must be finite where a chain starts
     for c in mine:
-        lp, _ = step._logp_dlogp_func._pytensor_function(DictToArrayBijection.map({k: points[c][k] for k in step.var_names}).data)
+        if getattr(spec, "extra", None):
+            grad_step._logp_dlogp_func.set_extra_values({k: points[c][k] for k in spec.extra if k in points[c]})
+        lp, _ = grad_step._logp_dlogp_func._pytensor_function(DictToArrayBijection.map({k: points[c][k] for k in grad_step.var_names}).data)
         if not np.isfinite(lp):
             from pymc_amd.exceptions import SamplingError
 
@@ -382,6 +474,8 @@ def sample(
                 f"Logp initial evaluation results:\n{ {'joint': lp} }\n"
                 "You can call `model.debug()` for more details."
             )
+    if compound is not None:
+        return _sample_compound(compound, spec, points, rngs, mine, tune, draws, discard_tuned_samples)
     initial_state = step.sampling_state  # mcmc.py:1411,1423: the same step object is reset between chains
     pooled = None
     if pooled_adaptation and world > 1:

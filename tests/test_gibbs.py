@@ -596,3 +596,44 @@ def test_the_plan_of_the_next_sweep_is_drawn_ahead_without_changing_the_stream(m
     small = G.CategoricalGibbsMetropolis(model=models.normal_mixture(N=200, K=3, seed=7), rng=5)
     small._next_plan()
     assert small._plan_ahead is None
+
+
+@pytest.mark.gpu
+def test_sample_assigns_nuts_and_gibbs_to_a_mixture_with_assignments():
+    """`pm.sample()` on configs[4]'s model as PyMC writes it: `assign_step_methods` (mcmc.py:108-258) gives the continuous variables
+    to NUTS and the categorical one to `CategoricalGibbsMetropolis`, wrapped in a `CompoundStep`; the trace holds both.  Here for the
+    fully Bayesian mixture, hand-assembled and lowered from the reference-built graph; `step=[nuts, gibbs]` given by the caller is
+    the same run."""
+    import lowering_models as lm
+    import stubgraph as sg
+
+    from pymc_amd.compound import CompoundStep
+    from pymc_amd.lowering import lower_to_spec
+    from pymc_amd.sampling import init_nuts, sample
+
+    spec = models.normal_mixture_bayes(N=1200, K=3, seed=3)
+    kw = dict(draws=8, tune=12, chains=2, random_seed=21, device=0, init="adapt_diag")
+    a = sample(model=spec, **kw)
+    assert isinstance(a["step"], CompoundStep) and a["step"].name == "Compound[nuts, categorical_gibbs_metropolis]"
+    assert a["draws"].shape == (2, 8, spec.n) and a["extra_draws"]["c"].shape == (2, 8, 1200)
+    c = a["extra_draws"]["c"]
+    assert c.min() >= 0 and c.max() <= 2 and not np.array_equal(c[0, 0], c[0, -1])          # the assignments move
+    assert all(int(s["tree_size"]) >= 1 for ch in a["stats"] for s in ch) and len(a["all_stats"][0][0]) == 2
+    assert not np.array_equal(a["draws"][0], a["draws"][1])                                  # two chains, two streams
+    a["step"].close()
+    b = sample(model=models.normal_mixture_bayes(N=1200, K=3, seed=3), **kw)                 # same seed, same run
+    assert np.array_equal(a["draws"], b["draws"]) and np.array_equal(a["extra_draws"]["c"], b["extra_draws"]["c"])
+    b["step"].close()
+    # the caller's own methods
+    spec2 = models.normal_mixture_bayes(N=1200, K=3, seed=3)
+    seeds = [int(r.integers(2**30)) for r in np.random.default_rng(21).spawn(2)]
+    _, nuts = init_nuts(spec2, init="adapt_diag", chains=2, random_seed_list=seeds, device=0, tune=12)
+    gibbs = CategoricalGibbsMetropolis(model=spec2, device=0)
+    c2 = sample(model=spec2, step=[nuts, gibbs], **kw)
+    assert np.array_equal(a["draws"], c2["draws"]) and np.array_equal(a["extra_draws"]["c"], c2["extra_draws"]["c"])
+    c2["step"].close()
+    # lowered from the graph the reference's code built
+    low = lower_to_spec(sg.FrozenModel(sg.load_models(lm.FIXTURE)["mixture_categorical_dirichlet"]))
+    d = sample(model=low, draws=5, tune=10, chains=1, random_seed=2, device=0, init="adapt_diag")
+    assert d["draws"].shape == (1, 5, low.n) and d["extra_draws"]["c"].shape == (1, 5, lm.YM.size) and d["extra_draws"]["c"].max() <= 3
+    d["step"].close()
