@@ -45,9 +45,15 @@ def _check(spec, want, rtol=1e-9):
 
 
 def _nuts(spec, want, tune=25, draws=10, seed=5):
-    from pymc_amd.sampling import initial_point, sample
+    from pymc_amd.sampling import init_nuts, initial_point, sample
 
-    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
+    step = None
+    if getattr(spec, "extra", None):
+        # NUTS alone, the assignments held fixed (what this helper compares with the oracle): `sample()` itself would give the
+        # categorical variable to a Gibbs step, as `pm.sample` does (tests/test_gibbs.py)
+        seeds = [int(r.integers(2**30)) for r in np.random.default_rng(seed).spawn(1)]
+        _, step = init_nuts(spec, init="adapt_diag", chains=1, random_seed_list=seeds, device=0, tune=tune)
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0, step=step)
     # (the initial point: zeros in the unconstrained space, except Dirichlet weights -- their support point through the transform)
     ip = initial_point(want)
     q0 = np.concatenate([np.ravel(ip[v.value_name]) for v in want.vars])
