@@ -183,8 +183,13 @@ def build_tree(v, memo: Optional[dict] = None):
             shp = getattr(getattr(ins[0], "type", None), "shape", None)
             if len(idx) == 1 and idx[0] == 0 and shp is not None and len(shp) >= 1 and shp[0] == 1:
                 out = kid
+            elif len(idx) == 1 and isinstance(idx[0], (int, np.integer)) and shp is not None and len(shp) == 1 and shp[0] is not None \
+                    and -shp[0] <= idx[0] < shp[0]:
+                # `beta[k]`: one element of a vector (`mu = alpha + beta[0] * X1 + beta[1] * X2`, the way a regression is usually
+                # written out): kept as a node; a linear predictor made of such terms becomes the GLM node (`_Lowering._glm`)
+                out = ("index", kid, int(idx[0]) % int(shp[0]))
             else:
-                raise NotLowerable("Subtensor of a non-constant beyond x[0] of a leading dimension of one")
+                raise NotLowerable("Subtensor of a non-constant beyond x[0] of a leading dimension of one and beta[k] of a vector")
     elif name == "Transpose":
         kid = build_tree(ins[0], memo)
         out = _const(np.swapaxes(kid[1], -1, -2)) if kid[0] == "const" else ("transpose", kid)
@@ -1043,7 +1048,48 @@ class _Lowering:
                 return None
             return X, kb
 
+        def written_out(n):
+            """eta = [alpha +] beta[i] * x_i + beta[j] * x_j + ... : terms of ONE vector variable's elements times constant data
+            vectors (and at most one scalar variable: the intercept)  ->  (X with the data vectors as its columns, beta, intercept)."""
+            terms, stack = [], [n]
+            while stack:
+                t = stack.pop()
+                if t[0] == "add":
+                    stack.extend([t[1], t[2]])
+                else:
+                    terms.append(t)
+            kb, icpt_, cols, N = None, None, {}, np.asarray(observed).size
+            for t in terms:
+                elem, vec = None, None
+                if t[0] == "index":
+                    elem, vec = t, np.ones(N)
+                elif t[0] == "mul":
+                    for x, y in ((t[1], t[2]), (t[2], t[1])):
+                        if x[0] == "index" and y[0] == "const" and np.asarray(y[1]).size in (1, N):
+                            elem, vec = x, np.broadcast_to(np.asarray(y[1], dtype="float64").reshape(-1), (N,))
+                if elem is not None:
+                    k = self._as_var(elem[1])
+                    if k is None or (kb is not None and k != kb):
+                        return None
+                    kb = k
+                    cols[elem[2]] = cols.get(elem[2], 0.0) + vec
+                    continue
+                ki = self._as_var(t)
+                if ki is not None and self.spec.vars[ki].size == 1 and self.spec.vars[ki].transform == ms.TR_NONE and icpt_ is None:
+                    icpt_ = ki
+                    continue
+                return None
+            if kb is None or self.spec.vars[kb].transform != ms.TR_NONE or len(self.spec.vars[kb].shape) != 1 or not 1 <= self.spec.vars[kb].size <= 512:
+                return None
+            if sorted(cols) != list(range(self.spec.vars[kb].size)):
+                return None       # (an element of beta that the predictor does not use would be a column of zeros: left to the element-wise path)
+            return np.column_stack([cols[k] for k in range(self.spec.vars[kb].size)]), kb, icpt_
+
         got, icpt = dot_of(eta), None
+        if got is None:
+            wo = written_out(eta)
+            if wo is not None:
+                got, icpt = (wo[0], wo[1]), wo[2]
         if got is None and eta[0] == "add":
             for x, y in ((eta[1], eta[2]), (eta[2], eta[1])):
                 got = dot_of(x)

@@ -290,6 +290,31 @@ def _glm_poisson_built():
 C0 = np.random.default_rng(18).integers(0, 3, size=YM.size)
 
 
+X1_LR = np.random.default_rng(41).normal(size=70)
+X2_LR = np.random.default_rng(42).normal(size=70) * 0.2
+Y_LR = 1.0 + X1_LR + 2.5 * X2_LR + np.random.default_rng(43).normal(size=70)
+
+
+def linear_regression_written_out():
+    """The linear regression of PyMC's introductory example: `mu = alpha + beta[0] * X1 + beta[1] * X2`, elements of one coefficient
+    vector times data vectors, written out term by term instead of `pm.math.dot(X, beta)`."""
+    m = sg.StubModel()
+    alpha = m.Normal("alpha", 0.0, 10.0)
+    beta = m.Normal("beta", 0.0, 10.0, shape=(2,))
+    sigma = m.HalfNormal("sigma", 1.0)
+    m.Normal("Y_obs", alpha + beta[0] * X1_LR + beta[1] * X2_LR, sigma, observed=Y_LR)
+    return m
+
+
+def _linear_regression_written_out_built():
+    b = ModelBuilder()
+    alpha = b.Normal("alpha", 0.0, 10.0)
+    beta = b.Normal("beta", 0.0, 10.0, shape=2)
+    sigma = b.HalfNormal("sigma", 1.0)
+    b.GLM("Y_obs", np.column_stack([X1_LR, X2_LR]), beta, Y_LR, "normal", intercept=alpha, sigma=sigma)
+    return b.build()
+
+
 def mixture_categorical_indexed(sigma_var=False):
     """The CompoundStep form of BASELINE configs[4]: discrete assignments `c ~ Categorical(w)` (sampled by
     `CategoricalGibbsMetropolis`) and `y ~ Normal(mu[c], sigma)` observed -- for NUTS the assignments are an extra input."""
@@ -404,5 +429,6 @@ ENTRIES = {
     "glm_normal": (glm_normal, _glm_normal_built),
     "glm_bernoulli": (glm_bernoulli, _glm_bernoulli_built),
     "glm_poisson": (glm_poisson, _glm_poisson_built),
+    "linear_regression_written_out": (linear_regression_written_out, _linear_regression_written_out_built),
 }
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")

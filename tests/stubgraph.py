@@ -92,6 +92,7 @@ class Variable:
     def shape(self): return Variable(Apply(Shape(), [self]), shape=(len(self.type.shape),))
     def astype(self, dtype): return elemwise(Cast, self)
     dtype = "float64"
+    __array_ufunc__ = None      # `ndarray * variable` defers to the variable's reflected operator, as with a TensorVariable
     def squeeze(self, axis=None):
         n = len(self.type.shape)
         return Variable(Apply(DimShuffle(), [self]), shape=tuple(s_ for i, s_ in enumerate(self.type.shape) if not (s_ == 1 and (axis is None or i == axis % n))))

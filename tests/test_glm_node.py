@@ -230,7 +230,7 @@ def test_configs3_shape_glm_nuts_logp_grad_and_integer_prefix():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["glm_normal", "glm_bernoulli", "glm_poisson"])
+@pytest.mark.parametrize("name", ["glm_normal", "glm_bernoulli", "glm_poisson", "linear_regression_written_out"])
 def test_reference_built_graphs_with_a_dot_lower_to_the_glm_node_and_run_on_the_device(name):
     """graph -> spec -> device: the committed graphs (tests/golden/ref_graphs.npz) of models whose likelihood's parameter contains
     `pm.math.dot(X, beta)` -- built by the reference's own `Normal.dist / logp`, `Bernoulli.dist(logit_p=) / logp`, `Poisson.logp`
@@ -244,6 +244,8 @@ def test_reference_built_graphs_with_a_dot_lower_to_the_glm_node_and_run_on_the_
     from pymc_amd.lowering import lower_to_spec
 
     spec = lower_to_spec(sg.FrozenModel(sg.load_models(lm.FIXTURE)[name]))
-    assert spec.glm_rows is not None and spec.glm_rows.X.shape == (50, 6)
+    # (`linear_regression_written_out`: no `dot` in the graph -- `alpha + beta[0] * X1 + beta[1] * X2`, PyMC's introductory example,
+    # whose data vectors become the columns of X)
+    assert spec.glm_rows is not None and spec.glm_rows.X.shape == ((70, 2) if name.startswith("linear") else (50, 6))
     _check(spec).close()
     _nuts_integers(spec, tune=30, draws=10, seed=3)

@@ -562,3 +562,29 @@ def test_the_graphs_come_from_the_references_source_lines():
     assert ref["IntervalTransform"].backward.__code__.co_filename.startswith("<reference logprob/transforms.py:")
     src = open(sg.__file__).read()
     assert "def normal_logp(value, mu, sigma)" not in src and "pt.log(pt.sqrt(2.0 * np.pi))" not in src
+
+
+def test_a_stray_element_of_a_vector_is_refused_by_name():
+    """`beta[k]` is kept as a node for the written-out linear predictor (`alpha + beta[0] * X1 + beta[1] * X2` -> the GLM node);
+    anywhere else -- or when the predictor leaves an element of beta unused -- the graph is not lowerable and says what it met."""
+    if not sg.available():
+        pytest.skip("builds graphs with the reference's code")
+    m = sg.StubModel()
+    beta = m.Normal("beta", 0.0, 10.0, shape=(3,))
+    m.Normal("x", beta[0], 1.0, shape=(4,))
+    with pytest.raises(NotLowerable, match=r"index\(beta, 0\)"):
+        lower_to_spec(m)
+    m = sg.StubModel()
+    beta = m.Normal("beta", 0.0, 10.0, shape=(2,))
+    m.Normal("y", beta[0] * np.linspace(0, 1, 10), 1.0, observed=np.zeros(10))
+    with pytest.raises(NotLowerable):
+        lower_to_spec(m)
+    # the same coefficient twice, a negative index, a Bernoulli likelihood: still one design matrix
+    m = sg.StubModel()
+    beta = m.Normal("beta", 0.0, 2.0, shape=(2,))
+    x1, x2 = np.linspace(-1, 1, 12), np.cos(np.arange(12.0))
+    y = (np.arange(12) % 2).astype("float64")
+    m.Bernoulli("y", logit_p=beta[0] * x1 + x2 * beta[-1] + beta[0] * x2, observed=y)
+    spec = lower_to_spec(m)
+    assert spec.glm_rows is not None and spec.glm_rows.intercept is None
+    np.testing.assert_allclose(spec.glm_rows.X, np.column_stack([x1 + x2, x2]), rtol=1e-15)
