@@ -290,6 +290,17 @@ def _glm_poisson_built():
 C0 = np.random.default_rng(18).integers(0, 3, size=YM.size)
 
 
+def potentials(b=None):
+    """`pm.Potential`: a soft constraint on a vector (element-wise, summed by the model) and a penalty on a transformed scalar."""
+    m = b or sg.StubModel()
+    x = m.Normal("x", 0.0, 3.0, shape=(5,) if b is None else 5)
+    s = m.HalfNormal("s", 1.0)
+    m.Normal("y", x, s, observed=np.linspace(-1.0, 1.0, 5))
+    m.Potential("soft", -0.5 * ((x - 1.0) / 0.5) ** 2)
+    m.Potential("penalty", -2.0 * s)
+    return m
+
+
 X1_LR = np.random.default_rng(41).normal(size=70)
 X2_LR = np.random.default_rng(42).normal(size=70) * 0.2
 Y_LR = 1.0 + X1_LR + 2.5 * X2_LR + np.random.default_rng(43).normal(size=70)
@@ -430,5 +441,6 @@ ENTRIES = {
     "glm_bernoulli": (glm_bernoulli, _glm_bernoulli_built),
     "glm_poisson": (glm_poisson, _glm_poisson_built),
     "linear_regression_written_out": (linear_regression_written_out, _linear_regression_written_out_built),
+    "potentials": (potentials, lambda: _built(potentials)),
 }
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")

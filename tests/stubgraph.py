@@ -704,6 +704,12 @@ class StubModel:
         self.deterministics[name] = expr
         return expr
 
+    def Potential(self, name, expr):
+        """`pm.Potential(name, expr)` (model/core.py:2007-2124): an arbitrary term of the joint log-density; `Model.logp(sum=False)` lists the
+        potentials after the observed variables (model/core.py:666-695)."""
+        self.pots.append((name, as_tensor(expr)))
+        return expr
+
     def _add(self, rv):
         (self.free if rv.observed is None else self.obs).append(rv)
         return rv.expr
@@ -818,11 +824,11 @@ class StubModel:
 
     @property
     def logp_owners(self):
-        return [rv.value for rv in self.free] + [None] * len(self.obs)
+        return [rv.value for rv in self.free] + [None] * (len(self.obs) + len(self.pots))
 
     @property
     def logp_names(self):
-        return [rv.name for rv in self.free + self.obs]
+        return [rv.name for rv in self.free + self.obs] + [nm for nm, _ in self.pots]
 
     def logp(self, sum=False):
         out = []
@@ -831,6 +837,7 @@ class StubModel:
             if rv.transform is not None:     # transform_value.py:95-133: + transform.log_jac_det(value, *rv_inputs)
                 lp = lp + rv.transform_obj.log_jac_det(rv.value, *rv.rv_inputs).copy()
             out.append(lp)
+        out.extend(e for _, e in self.pots)
         return out
 
 
