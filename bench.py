@@ -568,7 +568,10 @@ def run_rank(args):
                                                       (vec[1] / max(leap, 1.0)) if ess_ok else
                                                       (ess_run["min_ess"] / max(ess_run["leapfrogs_total"], 1.0)) if ess_run else None)
         if c3 and world == 1 and not stub and 2 <= args.chains_per_gpu <= 4:
-            out["chains_on_one_gpu"] = chains_on_one_gpu(args, spec, local)
+            try:
+                out["chains_on_one_gpu"] = chains_on_one_gpu(args, spec, local)
+            except Exception as e:     # (an extra leg: the line of the timed region is printed whatever happens here)
+                out["chains_on_one_gpu"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
