@@ -349,7 +349,10 @@ def multitrace_from_result(spec: ModelSpec, result: dict, include_transformed: b
     draws = np.asarray(result["draws"])
     stats = result["stats"]
     step = result.get("step")
-    sdt = getattr(step, "stats_dtypes_shapes", None)
+    # (a CompoundStep names its statistics per sampler, `sampler_0__depth`; `result["stats"]` holds the gradient method's under
+    # their own names, whose dtypes are then read off the values)
+    sdt = None if hasattr(step, "methods") else getattr(step, "stats_dtypes_shapes", None)
+    extras = result.get("extra_draws") or {}     # value variables another step method owns (the discrete ones of a CompoundStep)
     traces = []
     # chain ids are the sampler's (`result["chains"]`: under torch.distributed without a gather every rank holds a subset, and
     # positional ids would collide across ranks and disagree with the chain generators)
@@ -365,6 +368,11 @@ def multitrace_from_result(spec: ModelSpec, result: dict, include_transformed: b
         t.setup(draws.shape[1], ids[c], svars)
         t.record_batch(draws[c], [[s] for s in chain_stats])
         t.close()
+        for nm, arr in extras.items():
+            arr = np.asarray(arr)
+            t.varnames.append(nm)
+            t.var_shapes[nm], t.var_dtypes[nm] = tuple(arr.shape[2:]), arr.dtype
+            t.samples[nm] = arr[c]
         traces.append(t)
     return MultiTrace(traces)
 

@@ -475,7 +475,12 @@ def sample(
                 "You can call `model.debug()` for more details."
             )
     if compound is not None:
-        return _sample_compound(compound, spec, points, rngs, mine, tune, draws, discard_tuned_samples)
+        result = _sample_compound(compound, spec, points, rngs, mine, tune, draws, discard_tuned_samples)
+        if return_multitrace:
+            from pymc_amd.backends import multitrace_from_result
+
+            result["trace"] = multitrace_from_result(spec, result)
+        return result
     initial_state = step.sampling_state  # mcmc.py:1411,1423: the same step object is reset between chains
     pooled = None
     if pooled_adaptation and world > 1:

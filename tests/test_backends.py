@@ -231,3 +231,29 @@ def test_initial_point_of_dirichlet_weights_is_the_reference_support_point():
     p = initial_point(spec)
     np.testing.assert_allclose(backward(spec.vars[0], p["w_simplex__"]), a / a.sum(), rtol=1e-14)
     assert np.all(p["mu"] == 0)
+
+
+def test_a_compound_result_carries_the_discrete_variable_into_the_trace():
+    """`sample()` under a CompoundStep returns the other methods' variables under `extra_draws`; the MultiTrace and the
+    InferenceData-shaped dict show them next to the continuous ones (mcmc.py:1232-1357: every value variable is in the trace)."""
+    from pymc_amd.backends import to_inference_dict
+
+    spec = models.normal_mixture_bayes(N=30, K=3)
+    rng = np.random.default_rng(0)
+    draws = rng.normal(size=(2, 6, spec.n))
+    c = rng.integers(0, 3, size=(2, 6, 30))
+    stats = [[{"depth": 2, "tree_size": 3, "energy": 0.1, "diverging": False, "warning": None} for _ in range(6)] for _ in range(2)]
+
+    class FakeCompound:
+        methods = []
+        stats_dtypes_shapes = {"sampler_0__depth": (np.int64, [])}
+
+    res = {"draws": draws, "stats": stats, "extra_draws": {"c": c}, "chains": [0, 1], "step": FakeCompound()}
+    tr = multitrace_from_result(spec, res)
+    assert "c" in tr.varnames and tr.get_values("c", combine=False)[1].shape == (6, 30)
+    assert np.array_equal(np.stack(tr.get_values("c", combine=False)), c)
+    assert tr.get_values("w").shape == (12, 3) and np.allclose(tr.get_values("w").sum(axis=1), 1.0)
+    assert np.array_equal(tr.get_sampler_stats("tree_size"), np.full(12, 3))
+    groups = to_inference_dict(tr)
+    assert groups["posterior"]["c"].shape == (2, 6, 30) and groups["posterior"]["w"].shape == (2, 6, 3)
+    assert groups["sample_stats"]["n_steps"].shape == (2, 6)
