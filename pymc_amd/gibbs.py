@@ -49,6 +49,7 @@ class MixtureLink:
     # the fully Bayesian mixture: weights and scales are variables of the continuous step as well -- the assignment conditional is
     # evaluated at the point's CURRENT values, as the reference's full-model log-density is (metropolis.py:771-786 `self.logp(q)`)
     w_name: Optional[str] = None       # value variable of simplex-transformed Dirichlet weights (`<w>_simplex__`, K - 1 elements)
+    w_softmax: bool = False            # ... or of K logits with w = softmax(logits) (`pm.math.softmax`)
     sigma_name: Optional[str] = None   # value variable of the component scales (K elements)
     sigma_log: bool = True             # ... log-transformed (`<sigma>_log__`)
 
@@ -77,7 +78,8 @@ class MixtureLink:
             kw["w_name"] = spec.vars[node.w_logits].value_name
             log_w = np.full(K, -np.log(K))
         elif node.w_logits is not None:
-            return None        # (softmax(logits) weights: not a form the Gibbs step reads from the point yet)
+            kw.update(w_name=spec.vars[node.w_logits].value_name, w_softmax=True)
+            log_w = np.full(K, -np.log(K))
         else:
             with np.errstate(divide="ignore"):
                 log_w = np.log(np.asarray(node.w_const, dtype="float64"))
@@ -93,7 +95,7 @@ class MixtureLink:
         if self.w_name is None:
             return self.log_w
         yv = np.asarray(point[self.w_name], dtype="float64")
-        full = np.concatenate([yv, [-yv.sum()]])       # SimplexTransform.backward, logprob/transforms.py:1101-1104
+        full = yv if self.w_softmax else np.concatenate([yv, [-yv.sum()]])   # SimplexTransform.backward, logprob/transforms.py:1101-1104
         m = full.max()
         return full - (m + np.log(np.exp(full - m).sum()))
 

@@ -496,6 +496,16 @@ def test_link_reads_weights_and_scales_from_the_point():
     pt = {"w_simplex__": np.array([0.3, -0.1, 0.8]), "sigma_log__": np.log([0.5, 1.0, 1.5, 2.0]), "mu": np.zeros(4)}
     np.testing.assert_allclose(np.exp(link.log_w_at(pt)), backward(spec.vars[0], pt["w_simplex__"]), rtol=1e-14)
     np.testing.assert_allclose(link.sigma_at(pt), [0.5, 1.0, 1.5, 2.0], rtol=1e-14)
+    soft = MixtureLink("c", np.zeros(3), np.zeros(3), np.ones(3), "mu", w_name="logits", w_softmax=True)
+    lg = np.array([0.2, -1.0, 3.0])
+    np.testing.assert_allclose(soft.log_w_at({"logits": lg}), lg - np.log(np.exp(lg).sum()), rtol=1e-14)
+    from pymc_amd.model_spec import ModelBuilder
+
+    b = ModelBuilder()
+    logits, mu = b.Normal("logits", 0.0, 1.5, shape=3), b.Normal("mu", 0.0, 5.0, shape=3)
+    b.NormalMixture("y", ("softmax", logits), mu, 0.9, np.zeros(7), assign=b.Extra("c", np.zeros(7)))
+    ls = MixtureLink.from_spec(b.build())
+    assert (ls.w_name, ls.w_softmax, ls.sigma_name) == ("logits", True, None) and np.allclose(ls.sigma, 0.9)
     const = MixtureLink("c", np.zeros(3), np.log([0.2, 0.8]), np.array([1.0, 2.0]), "mu")
     assert const.log_w_at(pt) is const.log_w and const.sigma_at(pt) is const.sigma
 
