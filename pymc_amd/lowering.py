@@ -944,6 +944,12 @@ class _Lowering:
         c, p_, km1 = env["c"], env["p"], _num(env["km1"])
         if c[0] != "input" or id(c[1]) not in self.extra_id or km1 is None:
             return False
+        if p_[0] == "softmax":      # p = pm.math.softmax(logits) of a free vector
+            kw = self._as_var(p_[1])
+            if kw is None or self.spec.vars[kw].size != int(km1) + 1:
+                return False
+            self._cat[self.extra_id[id(c[1])]] = ("softmax", kw)
+            return True
         if p_[0] != "const":
             # p = a `pm.Dirichlet` variable under its default transform (the fully Bayesian mixture: weights learned by NUTS, the
             # assignments by the Gibbs step): remembered as the simplex variable itself
@@ -970,8 +976,9 @@ class _Lowering:
             return False
         K_ = self.spec.vars[km].size
         w = self._cat[did]
-        simplex_w = isinstance(w, tuple)
-        if (self.spec.vars[w[1]].size + 1 if simplex_w else w.size) != K_:
+        simplex_w = isinstance(w, tuple) and w[0] == "simplex"
+        softmax_w = isinstance(w, tuple) and w[0] == "softmax"
+        if (self.spec.vars[w[1]].size + 1 if simplex_w else self.spec.vars[w[1]].size if softmax_w else w.size) != K_:
             return False
         y = np.ascontiguousarray(val[1], dtype="float64").ravel()
         if y.size != self.spec.data[did].size:
@@ -988,6 +995,8 @@ class _Lowering:
             if K_ < 3:
                 raise NotLowerable("Dirichlet mixture weights need K >= 3 components (a variable of K - 1 free elements)")
             node_.w_logits, node_.w_alpha = w[1], self._dirichlet.pop(w[1])
+        elif softmax_w:
+            node_.w_logits = w[1]
         else:
             if not np.isclose(w.sum(), 1.0):
                 raise NotLowerable("mixture weights that do not sum to one")

@@ -374,6 +374,25 @@ def _mixture_categorical_dirichlet_built():
     return b.build()
 
 
+def mixture_categorical_softmax():
+    """Assignments `c ~ Categorical(softmax(logits))` with free logits, `y ~ Normal(mu[c], 0.9)` observed."""
+    m = sg.StubModel()
+    logits = m.Normal("logits", 0.0, 1.5, shape=(3,))
+    c = m.Categorical("c", m.math.softmax(logits), shape=(YM.size,), initval=C0)
+    mu = m.Normal("mu", 0.0, 5.0, shape=(3,))
+    m.Normal("y", mu[c], 0.9, observed=YM)
+    return m
+
+
+def _mixture_categorical_softmax_built():
+    b = ModelBuilder()
+    logits = b.Normal("logits", 0.0, 1.5, shape=3)
+    ce = b.Extra("c", C0.astype("float64"))
+    mu = b.Normal("mu", 0.0, 5.0, shape=3)
+    b.NormalMixture("y", ("softmax", logits), mu, 0.9, YM, assign=ce)
+    return b.build()
+
+
 _AM = np.random.default_rng(31).normal(size=(6, 6))
 COV6 = _AM @ _AM.T + 0.5 * np.eye(6)
 MU6 = np.linspace(-0.5, 0.7, 6)
@@ -434,6 +453,7 @@ ENTRIES = {
     "mixture_categorical_indexed": (mixture_categorical_indexed, _mixture_categorical_indexed_built),
     "mixture_categorical_indexed_sigma": (lambda: mixture_categorical_indexed(True), lambda: _mixture_categorical_indexed_built(True)),
     "mixture_categorical_dirichlet": (mixture_categorical_dirichlet, _mixture_categorical_dirichlet_built),
+    "mixture_categorical_softmax": (mixture_categorical_softmax, _mixture_categorical_softmax_built),
     "mvnormal_cov": (mvnormal_cov, _mvnormal_built),
     "mvnormal_chol": (mvnormal_chol, _mvnormal_built),
     "mvnormal_tau": (mvnormal_tau, _mvnormal_built),

@@ -73,7 +73,8 @@ def test_configs_1_and_2_graphs_on_the_device(name):
     _nuts(spec, want)
 
 
-@pytest.mark.parametrize("name", ["mixture_categorical_indexed", "mixture_categorical_indexed_sigma", "mixture_categorical_dirichlet"])
+@pytest.mark.parametrize("name", ["mixture_categorical_indexed", "mixture_categorical_indexed_sigma", "mixture_categorical_dirichlet",
+                                  "mixture_categorical_softmax"])
 def test_configs_4_compound_form_graph_on_the_device(name):
     """The assignments are an extra input: logp / gradient at the initial assignments, a NUTS run on the continuous variables, then
     new assignments through `set_extra_values` (what `CompoundStep` does between the two step methods, arraystep.py:109-111)."""
