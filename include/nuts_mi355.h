@@ -45,19 +45,42 @@ enum {
                         is created keeps it a deterministic gather) */
 };
 /* Expression programs.  An argument of a factor is `a + b * c`; where the model's expression is not of that form (a link
- * function, a Deterministic, a product of three quantities: whatever `pytensor.grad` would differentiate in the reference,
- * model/core.py:213-267) the factor carries a small SSA program -- n_instr instructions starting at instrs[instr_off], each
- * `tmp[i] = op(x, y)` element-wise over the factor's elements with size-1 operands broadcast -- and its arguments refer to the
- * results through NUTS_OP_TMP operands.  The device interprets the program per element; the gradient w.r.t. a variable that
- * occurs in it is the forward-mode tangent of the arguments through the same program (a deterministic gather per element, like
- * every other gradient of the element-wise interpreter). */
+ * function, a Deterministic, a product of three quantities, a distribution whose density is written out op by op: whatever
+ * `pytensor.grad` would differentiate in the reference, model/core.py:213-267) the factor carries a small SSA program -- n_instr
+ * instructions starting at instrs[instr_off], each `tmp[i] = op(x, y, z)` element-wise over the factor's elements with size-1
+ * operands broadcast -- and its arguments refer to the results through NUTS_OP_TMP operands.  The device interprets the program
+ * per element: one forward sweep (values), the factor's density, then ONE REVERSE sweep that carries d logp / d tmp[i] back to
+ * every variable that occurs in the program (a deterministic gather per element, like every other gradient of the element-wise
+ * interpreter): the cost of a factor does not grow with the number of variables in it.
+ * The opcodes are the scalar ops the reference's log-density bodies are made of (pymc/distributions/continuous.py, discrete.py,
+ * dist_math.py: `pt.switch`, comparisons, `pt.gammaln`, `pt.erfcx`, `logpow`, ...), so that a density that has no distribution
+ * code of its own below is lowered op by op (pymc_amd/lowering.py) and evaluated as a NUTS_D_POTENTIAL whose term is the
+ * program's result.  Comparisons and logical ops give 1.0 / 0.0 and have zero gradient; NUTS_E_SWITCH passes the adjoint to the
+ * selected branch only; an adjoint that is exactly zero is not propagated (no 0 * inf). */
 enum {
   NUTS_E_ADD = 0, NUTS_E_SUB = 1, NUTS_E_MUL = 2, NUTS_E_DIV = 3, /* x (op) y */
   NUTS_E_NEG = 4, NUTS_E_EXP = 5, NUTS_E_LOG = 6, NUTS_E_LOG1P = 7, /* f(x) */
   NUTS_E_SIGMOID = 8, NUTS_E_SOFTPLUS = 9, NUTS_E_SQRT = 10, NUTS_E_SQR = 11, NUTS_E_RECIPROCAL = 12, NUTS_E_TANH = 13, NUTS_E_ABS = 14,
-  NUTS_E_POWC = 15 /* x ** k, k the instruction's constant */
+  NUTS_E_POWC = 15, /* x ** k, k the instruction's constant */
+  /* comparisons / logic: 1.0 or 0.0 */
+  NUTS_E_GT = 16, NUTS_E_GE = 17, NUTS_E_LT = 18, NUTS_E_LE = 19, NUTS_E_EQ = 20, NUTS_E_NEQ = 21, NUTS_E_AND = 22, NUTS_E_OR = 23,
+  NUTS_E_NOT = 24,
+  NUTS_E_SWITCH = 25,  /* x != 0 ? y : z */
+  NUTS_E_GAMMALN = 26, /* log|Gamma(x)|; derivative digamma(x) */
+  NUTS_E_ERF = 27, NUTS_E_ERFC = 28, NUTS_E_ERFCX = 29,
+  NUTS_E_LOG1MEXP = 30, /* log(1 - exp(x)), x < 0 (pytensor `log1mexp`) */
+  NUTS_E_EXPM1 = 31, NUTS_E_SIGN = 32, NUTS_E_MAXIMUM = 33, NUTS_E_MINIMUM = 34,
+  NUTS_E_POW = 35,     /* x ** y, both operands */
+  NUTS_E_FLOOR = 36, NUTS_E_CEIL = 37, NUTS_E_SIN = 38, NUTS_E_COS = 39, NUTS_E_ARCTAN = 40,
+  NUTS_E_LOGADDEXP = 41,
+  NUTS_E_CLIP = 42,    /* min(max(x, y), z) */
+  NUTS_E_CHECK = 43,   /* tmp = x; if y == 0 a PARAMETER check of the reference failed (`check_parameters`, dist_math.py:50-74,
+                          rewritten to switch(all(cond), logp, -inf) by logprob/utils.py:209-225): the factor's log-density is -inf
+                          with zero gradient, for all of its elements */
+  NUTS_E_LOG2 = 44, NUTS_E_LOG10 = 45, NUTS_E_DIGAMMA = 46,
+  NUTS_E_LAST = 46
 };
-#define NUTS_MAX_FACTOR_INSTR 16
+#define NUTS_MAX_FACTOR_INSTR 128
 /* element-wise distributions (pymc/distributions/continuous.py, discrete.py) */
 enum {
   NUTS_D_NORMAL = 0,      /* args: value, mu, sigma         continuous.py:526-532  */
@@ -80,7 +103,13 @@ enum {
   NUTS_D_GAMMA = 14,      /* args: value, alpha(const), beta; konst = -gammaln(alpha)   continuous.py:2512-2521 */
   NUTS_D_INVGAMMA = 15,   /* args: value, alpha(const), beta; konst = -gammaln(alpha)   continuous.py:2631-2639 */
   NUTS_D_LAPLACE = 16,    /* args: value, mu, b                                         continuous.py:1570-1576 */
-  NUTS_D_POISSON = 17     /* args: y(data), mu, factln(y)(data)                         discrete.py:581-597 */
+  NUTS_D_POISSON = 17,    /* args: y(data), mu, factln(y)(data)                         discrete.py:581-597 */
+  NUTS_D_DERIVED = 18     /* args: term.  A DERIVED VECTOR: element i = term_i (an affine term or the result of the factor's
+                             expression program), e.g. the coefficients `mu + sigma * z` of a non-centred hierarchical regression.
+                             It contributes nothing to the log-density by itself: a dense node that names this factor as one of its
+                             parameters (glm_beta_derived) reads the vector and hands d logp / d element back, which the interpreter
+                             carries to the variables of the term like the gradient of any other factor -- `pytensor.grad` through
+                             `pm.math.dot(X, mu + sigma * z)` (pymc/math.py:56, model/core.py:213-267) */
 };
 
 typedef struct {
@@ -93,10 +122,10 @@ typedef struct { /* value = a + b * c, size-1 operands broadcast */
   nuts_operand a, b, c;
 } nuts_term;
 
-typedef struct { /* tmp[i] = op(x, y)  (NUTS_E_*; unary ops ignore y) */
+typedef struct { /* tmp[i] = op(x, y, z)  (NUTS_E_*; unary ops ignore y and z, binary ops ignore z) */
   int32_t op, pad;
   double k; /* NUTS_E_POWC: the exponent */
-  nuts_operand x, y;
+  nuts_operand x, y, z;
 } nuts_instr;
 
 typedef struct {
@@ -187,11 +216,13 @@ typedef struct {
                                                                sum is taken when the model is created)
      One fused pass over X per evaluation: forward (eta_i, the row's log-likelihood, r_i = d logp_i / d eta_i) and backward
      (d logp / d beta += r_i x_i) from the same registers -- 8 N P bytes, the algorithmic traffic of the node.  glm_N == 0 disables.
-     glm_beta: variable of size P, untransformed.  glm_intercept: a scalar untransformed variable, or -1 (no intercept).
+     glm_beta: variable of size P, untransformed -- or -1 with glm_beta_derived = the index of a NUTS_D_DERIVED factor of P elements
+     (beta an expression of the model's variables).  glm_intercept: a scalar untransformed variable, or -1 (no intercept).
      glm_sigma (NUTS_GLM_NORMAL): a scalar variable (untransformed or log-transformed: its constrained value is used), or -1 with
-     the constant glm_sigma_const.  The node may not be combined with another dense node. */
+     the constant glm_sigma_const.  The node may be combined with an MvNormal node (dense node 2; e.g. a multivariate-normal
+     prior on beta): a model is the sum of its factors (model/core.py:612-695), and each node adds its own share of the gradient. */
   int64_t glm_N;
-  int32_t glm_P, glm_family, glm_beta, glm_intercept, glm_sigma, glm_pad;
+  int32_t glm_P, glm_family, glm_beta, glm_intercept, glm_sigma, glm_beta_derived;
   double glm_sigma_const;
   const double *glm_X; /* [N][P] row-major */
   const double *glm_y; /* [N] */

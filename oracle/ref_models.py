@@ -49,7 +49,8 @@ OP_CONST, OP_DATA, OP_VAR = 0, 1, 2
     D_INVGAMMA,
     D_LAPLACE,
     D_POISSON,
-) = range(18)
+    D_DERIVED,
+) = range(19)
 
 
 def softplus(x):
@@ -310,48 +311,111 @@ def _log_diff_normal_cdf(x, y):
 
 
 OP_TMP, OP_GATHER = 3, 4
-(E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC) = range(16)
+(E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC,
+ E_GT, E_GE, E_LT, E_LE, E_EQ, E_NEQ, E_AND, E_OR, E_NOT, E_SWITCH, E_GAMMALN, E_ERF, E_ERFC, E_ERFCX, E_LOG1MEXP, E_EXPM1, E_SIGN,
+ E_MAXIMUM, E_MINIMUM, E_POW, E_FLOOR, E_CEIL, E_SIN, E_COS, E_ARCTAN, E_LOGADDEXP, E_CLIP, E_CHECK, E_LOG2, E_LOG10, E_DIGAMMA) = range(47)
 
 
-def _instr_value(op, k, vx, vy):
-    """Value of one instruction of a factor's expression program and its local partials (d/dx, d/dy)."""
-    one = np.ones_like(np.asarray(vx, dtype="d"))
+def _instr_value(op, k, vx, vy, vz=None):
+    """Value of one instruction of a factor's expression program and its local partials (d/dx, d/dy, d/dz): the scalar ops of the
+    reference's density bodies with the derivatives `pytensor.grad` gives them (comparisons / logic / sign / floor / ceil: zero;
+    `switch`: the selected branch; `maximum` / `minimum`: the operand(s) equal to the result)."""
+    vx = np.asarray(vx, dtype="d")
+    one = np.ones_like(vx)
+    zero = np.zeros_like(vx)
     if op == E_ADD:
-        return vx + vy, one, one
+        return vx + vy, one, one, None
     if op == E_SUB:
-        return vx - vy, one, -one
+        return vx - vy, one, -one, None
     if op == E_MUL:
-        return vx * vy, vy * one, vx * one
+        return vx * vy, vy * one, vx * one, None
     if op == E_DIV:
-        return vx / vy, one / vy, -vx / (vy * vy)
+        return vx / vy, one / vy, -vx / (vy * vy), None
     if op == E_NEG:
-        return -vx, -one, None
+        return -vx, -one, None, None
     if op == E_EXP:
         e = np.exp(vx)
-        return e, e, None
+        return e, e, None, None
     if op == E_LOG:
-        return np.log(vx), one / vx, None
+        return np.log(vx), one / vx, None, None
     if op == E_LOG1P:
-        return np.log1p(vx), one / (1.0 + vx), None
+        return np.log1p(vx), one / (1.0 + vx), None, None
     if op == E_SIGMOID:
         s_ = expit(vx)
-        return s_, s_ * (1.0 - s_), None
+        return s_, s_ * (1.0 - s_), None, None
     if op == E_SOFTPLUS:
-        return softplus(vx), expit(vx), None
+        return softplus(vx), expit(vx), None, None
     if op == E_SQRT:
         r = np.sqrt(vx)
-        return r, 0.5 / r, None
+        return r, 0.5 / r, None, None
     if op == E_SQR:
-        return vx * vx, 2.0 * vx, None
+        return vx * vx, 2.0 * vx, None, None
     if op == E_RECIPROCAL:
-        return one / vx, -one / (vx * vx), None
+        return one / vx, -one / (vx * vx), None, None
     if op == E_TANH:
         t = np.tanh(vx)
-        return t, 1.0 - t * t, None
+        return t, 1.0 - t * t, None, None
     if op == E_ABS:
-        return np.abs(vx), np.sign(vx), None
+        return np.abs(vx), np.sign(vx), None, None
     if op == E_POWC:
-        return np.power(vx, k), k * np.power(vx, k - 1.0), None
+        return np.power(vx, k), k * np.power(vx, k - 1.0), None, None
+    cmp_ = {E_GT: np.greater, E_GE: np.greater_equal, E_LT: np.less, E_LE: np.less_equal, E_EQ: np.equal, E_NEQ: np.not_equal}
+    if op in cmp_:
+        return cmp_[op](vx, vy).astype("d") * one, None, None, None
+    if op == E_AND:
+        return ((vx != 0) & (np.asarray(vy) != 0)).astype("d") * one, None, None, None
+    if op == E_OR:
+        return ((vx != 0) | (np.asarray(vy) != 0)).astype("d") * one, None, None, None
+    if op == E_NOT:
+        return (vx == 0).astype("d"), None, None, None
+    if op == E_SWITCH:
+        c = vx != 0
+        return np.where(c, vy, vz), None, np.where(c, 1.0, 0.0), np.where(c, 0.0, 1.0)
+    if op == E_GAMMALN:
+        return scipy.special.gammaln(vx), scipy.special.digamma(vx), None, None
+    if op == E_ERF:
+        return erf(vx), 2.0 / math.sqrt(math.pi) * np.exp(-vx * vx), None, None
+    if op == E_ERFC:
+        return erfc(vx), -2.0 / math.sqrt(math.pi) * np.exp(-vx * vx), None, None
+    if op == E_ERFCX:
+        v = erfcx(vx)
+        return v, 2.0 * vx * v - 2.0 / math.sqrt(math.pi), None, None
+    if op == E_LOG1MEXP:
+        return np.where(vx > -LOG_2, np.log(-np.expm1(vx)), np.log1p(-np.exp(vx))), -1.0 / np.expm1(-vx), None, None
+    if op == E_EXPM1:
+        v = np.expm1(vx)
+        return v, v + 1.0, None, None
+    if op == E_SIGN:
+        return np.sign(vx), None, None, None
+    if op in (E_MAXIMUM, E_MINIMUM):
+        v = (np.maximum if op == E_MAXIMUM else np.minimum)(vx, vy)
+        return v, (v == vx).astype("d"), (v == vy).astype("d") * one, None
+    if op == E_POW:
+        v = np.power(vx, vy)
+        return v, vy * np.power(vx, vy - 1.0), np.where(vx != 0, v * np.log(np.where(vx != 0, vx, 1.0)), 0.0), None
+    if op == E_FLOOR:
+        return np.floor(vx), None, None, None
+    if op == E_CEIL:
+        return np.ceil(vx), None, None, None
+    if op == E_SIN:
+        return np.sin(vx), np.cos(vx), None, None
+    if op == E_COS:
+        return np.cos(vx), -np.sin(vx), None, None
+    if op == E_ARCTAN:
+        return np.arctan(vx), 1.0 / (1.0 + vx * vx), None, None
+    if op == E_LOGADDEXP:
+        return np.logaddexp(vx, vy), expit(vx - vy), expit(vy - vx), None
+    if op == E_CLIP:
+        lo_, hi_ = vx < vy, vx > vz
+        return np.minimum(np.maximum(vx, vy), vz), np.where(lo_ | hi_, 0.0, 1.0), np.where(lo_, 1.0, 0.0), np.where(hi_ & ~lo_, 1.0, 0.0)
+    if op == E_CHECK:
+        return vx * one, one, None, None
+    if op == E_LOG2:
+        return np.log2(vx), one / (vx * LOG_2), None, None
+    if op == E_LOG10:
+        return np.log10(vx), one / (vx * math.log(10.0)), None, None
+    if op == E_DIGAMMA:
+        return scipy.special.digamma(vx), scipy.special.polygamma(1, vx), None, None
     raise ValueError(op)
 
 
@@ -390,6 +454,28 @@ def _push(op, spec, gx, g, adj=None):
         gx[v.offset : v.offset + v.size] += np.broadcast_to(g, (v.size,))
 
 
+def _forward(spec, f, x):
+    """Forward sweep of factor `f` at the constrained values x: (argument arrays, (term, b, c) triples, instruction values,
+    local partials, whether a NUTS_E_CHECK failed)."""
+    prog = getattr(f, "prog", ())
+    tmp, loc = [], []
+    dead = False
+    for ins in prog:
+        vx, vy = _operand(ins.x, spec, x, tmp), _operand(ins.y, spec, x, tmp)
+        vz = _operand(ins.z, spec, x, tmp) if getattr(ins, "z", None) is not None else None
+        v, dx_, dy_, dz_ = _instr_value(ins.op, ins.k, np.asarray(vx, dtype="d"), np.asarray(vy, dtype="d"), None if vz is None else np.asarray(vz, dtype="d"))
+        if ins.op == E_CHECK and not np.all(np.asarray(vy) != 0):
+            dead = True
+        tmp.append(v)
+        loc.append((dx_, dy_, dz_))
+    args, ops = [], []
+    for t in f.args:
+        a, b, c = (_operand(o, spec, x, tmp) for o in (t.a, t.b, t.c))
+        args.append(np.broadcast_to(a + b * c, (f.size,)))
+        ops.append((t, b, c))
+    return args, ops, tmp, loc, dead
+
+
 def evaluate(spec, q, rows_fn=None):
     """Joint logp and gradient w.r.t. the raveled unconstrained vector.
 
@@ -412,21 +498,22 @@ def evaluate(spec, q, rows_fn=None):
         logp += float(np.sum(lj))
     gx = np.zeros(n)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-        for f in spec.factors:
-            # the factor's expression program, forward (values and local partials), then its arguments
+        # derived vectors (D_DERIVED: a dense node's parameter that is an expression of the variables): their values are needed by
+        # the dense node, whose d logp / d element is the seed of the factor's reverse pass -- so those factors come last; every
+        # other factor and node is visited in the order `Model.logp` adds them (the committed fixtures pin that order bitwise)
+        derived = {fi: np.broadcast_to(_forward(spec, f, x)[0][0], (f.size,)) for fi, f in enumerate(spec.factors) if f.dist == D_DERIVED}
+        seeds = {}
+
+        def one_factor(fi, f):
+            nonlocal logp
             prog = getattr(f, "prog", ())
-            tmp, loc = [], []
-            for ins in prog:
-                vx, vy = _operand(ins.x, spec, x, tmp), _operand(ins.y, spec, x, tmp)
-                v, dx_, dy_ = _instr_value(ins.op, ins.k, np.asarray(vx, dtype="d"), np.asarray(vy, dtype="d"))
-                tmp.append(v)
-                loc.append((dx_, dy_))
-            args, ops = [], []
-            for t in f.args:
-                a, b, c = (_operand(o, spec, x, tmp) for o in (t.a, t.b, t.c))
-                args.append(np.broadcast_to(a + b * c, (f.size,)))
-                ops.append((t, b, c))
-            lp, partials = _dist(f.dist, f.konst, args)
+            args, ops, tmp, loc, dead = _forward(spec, f, x)
+            if f.dist == D_DERIVED:
+                lp, partials = np.zeros(f.size), [np.asarray(seeds.get(fi, np.zeros(f.size)), dtype="d")]
+            else:
+                lp, partials = _dist(f.dist, f.konst, args)
+            if dead:                     # a failed NUTS_E_CHECK (`check_parameters`): the whole factor is -inf with zero gradient
+                lp, partials = np.full(np.shape(lp), -np.inf), [np.zeros_like(np.asarray(g, dtype="d")) for g in partials]
             logp += float(np.sum(lp))
             adj = [0.0] * len(prog)
             for (t, b, c), g in zip(ops, partials):
@@ -434,12 +521,22 @@ def evaluate(spec, q, rows_fn=None):
                 _push(t.b, spec, gx, g * c, adj)
                 _push(t.c, spec, gx, g * b, adj)
             for i in range(len(prog) - 1, -1, -1):      # reverse sweep through the program
-                ins, (dx_, dy_) = prog[i], loc[i]
-                if np.ndim(adj[i]) == 0 and adj[i] == 0.0:
+                ins, (dx_, dy_, dz_) = prog[i], loc[i]
+                a_i = np.asarray(adj[i], dtype="d")
+                if not np.any(a_i != 0.0):
                     continue
-                _push(ins.x, spec, gx, adj[i] * dx_, adj)
+                # an adjoint that is exactly zero is not propagated (the unselected branch of a switch: no 0 * inf)
+                nz = lambda d_: a_i * d_ if np.all(a_i != 0.0) else np.where(a_i != 0.0, a_i * np.where(a_i != 0.0, d_, 0.0), 0.0)   # noqa: E731
+                if dx_ is not None:
+                    _push(ins.x, spec, gx, nz(dx_), adj)
                 if dy_ is not None:
-                    _push(ins.y, spec, gx, adj[i] * dy_, adj)
+                    _push(ins.y, spec, gx, nz(dy_), adj)
+                if dz_ is not None:
+                    _push(getattr(ins, "z", None), spec, gx, nz(dz_), adj)
+
+        for fi, f in enumerate(spec.factors):
+            if f.dist != D_DERIVED:
+                one_factor(fi, f)
         if spec.logit_rows is not None:
             lp, g_extra = (rows_fn or _logit_rows)(spec, spec.logit_rows, x)
             logp += lp
@@ -453,9 +550,16 @@ def evaluate(spec, q, rows_fn=None):
             logp += lp
             gx += g_extra
         if getattr(spec, "glm_rows", None) is not None:
-            lp, g_extra = _glm_rows(spec, spec.glm_rows, x)
+            node = spec.glm_rows
+            bd = getattr(node, "beta_derived", None)
+            lp, g_extra, gbeta = _glm_rows(spec, node, x, derived[bd] if bd is not None else None)
             logp += lp
             gx += g_extra
+            if bd is not None:
+                seeds[bd] = gbeta
+        for fi, f in enumerate(spec.factors):
+            if f.dist == D_DERIVED:
+                one_factor(fi, f)
     grad = gx * dxdq + djac
     return logp, grad
 
@@ -487,7 +591,7 @@ def _logit_rows(spec, node, x):
     return float(lp.sum()), g
 
 
-def _glm_rows(spec, node, x):
+def _glm_rows(spec, node, x, beta_values=None):
     """Generalised linear model rows (pymc_amd/model_spec.py GlmRows): eta = intercept + X @ beta (`pm.math.dot`, math.py:56);
 
     normal     Normal.logp(y | eta, sigma)                    continuous.py:526-532
@@ -498,8 +602,11 @@ def _glm_rows(spec, node, x):
     Returns (logp, gradient w.r.t. the CONSTRAINED values): d/dbeta = X^T r, d/dintercept = sum r, r = d logp_i / d eta_i."""
     from scipy.special import gammaln
 
-    vb = spec.vars[node.beta]
-    beta = x[vb.offset : vb.offset + vb.size]
+    if beta_values is None:
+        vb = spec.vars[node.beta]
+        beta = x[vb.offset : vb.offset + vb.size]
+    else:                                  # beta a derived vector: d logp / d beta is handed back as the third result
+        vb, beta = None, np.asarray(beta_values, dtype="d")
     eta = node.X @ beta
     if node.intercept is not None:
         eta = eta + x[spec.vars[node.intercept].offset]
@@ -513,7 +620,7 @@ def _glm_rows(spec, node, x):
         if node.sigma is not None:
             g[spec.vars[node.sigma].offset] = np.sum((z * z - 1.0) / sigma)
         if not sigma > 0:
-            return -np.inf, g * 0.0
+            return -np.inf, g * 0.0, np.zeros(node.X.shape[1])
     elif node.family == 1:
         lp = np.where(y != 0, -softplus(-eta), -softplus(eta))
         r = y - expit(eta)
@@ -521,10 +628,12 @@ def _glm_rows(spec, node, x):
         mu = np.exp(eta)
         lp = y * eta - gammaln(y + 1.0) - mu
         r = y - mu
-    g[vb.offset : vb.offset + vb.size] = node.X.T @ r
+    gbeta = node.X.T @ r
+    if vb is not None:
+        g[vb.offset : vb.offset + vb.size] = gbeta
     if node.intercept is not None:
         g[spec.vars[node.intercept].offset] = np.sum(r)
-    return float(np.sum(lp)), g
+    return float(np.sum(lp)), g, gbeta
 
 
 def _mixture_rows(spec, node, x):

@@ -31,7 +31,7 @@ class Term(C.Structure):
 
 
 class Instr(C.Structure):
-    _fields_ = [("op", C.c_int32), ("pad", C.c_int32), ("k", C.c_double), ("x", Operand), ("y", Operand)]
+    _fields_ = [("op", C.c_int32), ("pad", C.c_int32), ("k", C.c_double), ("x", Operand), ("y", Operand), ("z", Operand)]
 
 
 class Factor(C.Structure):
@@ -109,7 +109,7 @@ class ModelSpecC(C.Structure):
         ("glm_beta", C.c_int32),
         ("glm_intercept", C.c_int32),
         ("glm_sigma", C.c_int32),
-        ("glm_pad", C.c_int32),
+        ("glm_beta_derived", C.c_int32),
         ("glm_sigma_const", C.c_double),
         ("glm_X", C.POINTER(C.c_double)),
         ("glm_y", C.POINTER(C.c_double)),

@@ -107,3 +107,39 @@ __host__ __device__ __forceinline__ double logaddexp_d(double x, double y) {
   if (t <= 0) return y + log1p(exp(t));
   return t;  // NaN
 }
+
+// digamma / trigamma (the derivatives of `gammaln`, which the reference's densities with a VARIABLE shape parameter differentiate:
+// StudentT nu, Gamma / InverseGamma alpha, Beta alpha / beta, NegativeBinomial alpha -- continuous.py:1936-1950, 2512-2521,
+// 1250-1262, discrete.py:727).  Recurrence up to x >= 10, then the asymptotic series (next term 1/(12 x^14) < 1e-15); reflection for
+// x < 0.5 (x <= 0 integer: pole, NaN like scipy.special.psi's +-inf convention is not needed by any density).
+__device__ __forceinline__ double digamma_d(double x) {
+  double r = 0.0;
+  if (x < 0.5) {   // psi(1 - x) - pi / tan(pi x)
+    const double PI = 3.14159265358979323846;
+    r = -PI / tan(PI * x);
+    x = 1.0 - x;
+  }
+  while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+  const double i = 1.0 / x, i2 = i * i;
+  // ln x - 1/(2x) - sum B_2k / (2k x^2k)
+  const double s = i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0 - i2 * (1.0 / 132.0 - i2 * (691.0 / 32760.0 - i2 * (1.0 / 12.0)))))));
+  return r + log(x) - 0.5 * i - s;
+}
+__device__ __forceinline__ double trigamma_d(double x) {
+  double r = 0.0, sgn = 1.0;
+  if (x < 0.5) {   // psi1(1 - x) + psi1(x) = pi^2 / sin^2(pi x)
+    const double PI = 3.14159265358979323846;
+    const double sn = sin(PI * x);
+    r = PI * PI / (sn * sn);
+    sgn = -1.0;
+    x = 1.0 - x;
+  }
+  double acc = 0.0;
+  while (x < 10.0) { acc += 1.0 / (x * x); x += 1.0; }
+  const double i = 1.0 / x, i2 = i * i;
+  // 1/x + 1/(2x^2) + sum B_2k / x^(2k+1)
+  const double s = i * (1.0 + i * 0.5 + i2 * (1.0 / 6.0 - i2 * (1.0 / 30.0 - i2 * (1.0 / 42.0 - i2 * (1.0 / 30.0 - i2 * (5.0 / 66.0 - i2 * (691.0 / 2730.0 - i2 * (7.0 / 6.0))))))));
+  return r + sgn * (acc + s);
+}
+// pytensor `log1mexp` (scalar/math.py Log1mexp): log(1 - exp(x)) for x < 0, log(-expm1(x)) above -log 2, log1p(-exp(x)) below
+__device__ __forceinline__ double log1mexp_d(double x) { return x > -0.6931471805599453094 ? log(-expm1(x)) : log1p(-exp(x)); }

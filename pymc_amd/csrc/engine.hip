@@ -123,6 +123,8 @@ struct nuts_model {
   bool g_active = false;       // the model's chain is inside a tree (its leaf launches are deposited with the group)
   int gslot = 0;               // the model's place in the group
   int n_chains = 0;            // chains created on this model
+  std::vector<int32_t> derived;   // NUTS_D_DERIVED factors (compile_spec)
+  int64_t pool_extra = 0;         // doubles behind the spec's data pool: (values, seed) of every derived vector
 
   template <typename T>
   T* keep(T* p) {
@@ -272,8 +274,10 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     hipLaunchKernelGGL(k_mix_reduce, dim3(1), dim3(WAVE), 0, m->stream, md, A, io, j);
   }
   if (!md.has_logit && !md.has_mvn && !md.has_glm) return;
+  // derived vectors (a dense node's parameter that is an expression of the model's variables): evaluated before the pass reads them
+  if (md.n_derived > 0) hipLaunchKernelGGL(k_derive, dim3(2), dim3(256), 0, m->stream, md, A, io, j);
   // (a member of a chain group shares its launches and its stream with other chains: event pairs around them would time the company)
-  const bool prof = m->profile && !m->group && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
+  bool prof = m->profile && !m->group && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
   if (md.has_glm) {   // GLM node (glm_kernel.h): the fused pass over X (the timed kernel), then the totals of its records
     const dim3 grid(md.glm.nwg), block(GLM_BLOCK);
@@ -295,7 +299,10 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
     if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; m->dom_units += 1; }
     m->dom_launches++;
     hipLaunchKernelGGL(k_glm_reduce, dim3((md.glm.Ppad + 3 + GLM_RED_COLS - 1) / GLM_RED_COLS), dim3(GLM_RED_CHUNKS * GLM_RED_COLS), 0, m->stream, md, A, io, j);
-    return;
+    if (!md.has_mvn) return;
+    // an MvNormal node next to the GLM node (e.g. a multivariate-normal prior on the coefficients): its mat-vec follows; the timed
+    // kernel of such a model is the pass over X above
+    prof = false; m->dom_launches--;
   }
   if (md.has_logit && md.lg.ga) {
     const int rev = m->rows_alternate ? (m->rows_flip ^= 1) : 0;
@@ -439,6 +446,8 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   std::vector<nuts_factor> fac(s->factors, s->factors + nf);   // (pad is rewritten: 1 = the factor has gathered operands)
   std::vector<int32_t> csr;
   std::vector<std::pair<int, int>> gathered;   // (variable, index data id) pairs of the factor being compiled
+  std::vector<int32_t>& derived = m->derived;  // NUTS_D_DERIVED factors, in factor order
+  derived.clear();
   // NUTS_OP_GATHER operand of factor fi: the inverse index (which factor elements read element e of the variable, in order)
   auto add_gather = [&](int fi, const nuts_operand& o) -> bool {
     const nuts_factor& f = s->factors[fi];
@@ -478,7 +487,21 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     gathered.clear();
     fbt[fi].n = 0; fbt[fi].pad = 0;
     if (f.nargs < 1 || f.nargs > 4 || f.size < 1) { g_err = "factor with a bad argument count or size"; return false; }
-    if (f.dist < 0 || f.dist > NUTS_D_POISSON) { g_err = "factor with an unknown distribution code"; return false; }
+    if (f.dist < 0 || f.dist > NUTS_D_DERIVED) { g_err = "factor with an unknown distribution code"; return false; }
+    if (f.dist == NUTS_D_DERIVED) {
+      // a derived vector (include/nuts_mi355.h): two internal data vectors behind the spec's own -- the values (written by k_derive
+      // before the dense pass) and the seed d logp / d element (written by the dense node that reads the vector) -- become the
+      // factor's second and third argument, so that the interpreter sees an ordinary factor with logp 0 and d logp / d term = seed
+      if (f.nargs != 1) { g_err = "a derived vector has one argument (its term)"; return false; }
+      if ((int)derived.size() >= MAX_DERIVED) { g_err = "too many derived vectors (MAX_DERIVED)"; return false; }
+      const int did = s->n_data + 2 * (int)derived.size();
+      derived.push_back(fi);
+      fac[fi].nargs = 3;
+      for (int a = 1; a <= 2; ++a) {
+        fac[fi].arg[a] = nuts_term{};
+        fac[fi].arg[a].a.kind = NUTS_OP_DATA; fac[fi].arg[a].a.ref = did + (a - 1);
+      }
+    }
     if (f.dist == NUTS_D_TRUNCNORMAL) {   // the bounds carry no gradient here: lower must be a constant (upper is `konst`)
       const nuts_term& lo = f.arg[3];
       if (f.nargs != 4 || lo.a.kind >= NUTS_OP_VAR || lo.b.kind >= NUTS_OP_VAR || lo.c.kind >= NUTS_OP_VAR) {
@@ -497,13 +520,17 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       std::vector<const nuts_operand*> ops;
       for (int i = 0; i < f.n_instr; ++i) {
         const nuts_instr& I = s->instrs[f.instr_off + i];
-        if (I.op < 0 || I.op > NUTS_E_POWC) { g_err = "expression program with an unknown opcode"; return false; }
-        const bool binary = I.op <= NUTS_E_DIV;
-        if ((I.x.kind == NUTS_OP_TMP && (I.x.ref < 0 || I.x.ref >= i)) || (binary && I.y.kind == NUTS_OP_TMP && (I.y.ref < 0 || I.y.ref >= i))) {
+        if (I.op < 0 || I.op > NUTS_E_LAST) { g_err = "expression program with an unknown opcode"; return false; }
+        const bool ternary = I.op == NUTS_E_SWITCH || I.op == NUTS_E_CLIP;
+        const bool binary = ternary || I.op <= NUTS_E_DIV || (I.op >= NUTS_E_GT && I.op <= NUTS_E_OR) || I.op == NUTS_E_MAXIMUM || I.op == NUTS_E_MINIMUM ||
+                            I.op == NUTS_E_POW || I.op == NUTS_E_LOGADDEXP || I.op == NUTS_E_CHECK;
+        if ((I.x.kind == NUTS_OP_TMP && (I.x.ref < 0 || I.x.ref >= i)) || (binary && I.y.kind == NUTS_OP_TMP && (I.y.ref < 0 || I.y.ref >= i)) ||
+            (ternary && I.z.kind == NUTS_OP_TMP && (I.z.ref < 0 || I.z.ref >= i))) {
           g_err = "expression program: an instruction may only use the results of earlier instructions"; return false;
         }
         ops.push_back(&I.x);
         if (binary) ops.push_back(&I.y);
+        if (ternary) ops.push_back(&I.z);
       }
       for (int a = 0; a < f.nargs; ++a)
         for (const nuts_operand* o : {&f.arg[a].a, &f.arg[a].b, &f.arg[a].c}) {
@@ -571,7 +598,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
           Contrib cb{};
           cb.f = fi; cb.arg = (int16_t)a; cb.slot = (int16_t)sl; cb.owner = owned_already ? 0 : 1;
           // fast form: this operand is the whole argument (a + 0), every other argument folds to a constant
-          bool fast = sl == 0;
+          bool fast = sl == 0 && f.dist != NUTS_D_DERIVED;   // (a derived vector's seed is a data operand the engine adds)
           for (int a2 = 0; a2 < f.nargs && fast; ++a2) {
             const nuts_term& t = f.arg[a2];
             const bool bc_zero = (t.b.kind == NUTS_OP_CONST && t.b.c == 0.0) || (t.c.kind == NUTS_OP_CONST && t.c.c == 0.0);
@@ -644,7 +671,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       if (env_int("NUTS_LEAN_STRICT", 0))
         for (int k = 0; k < nv; ++k) if (vars[k].deferred && k != s->rows_mu && k != s->rows_sigma) md.lean_ok = 0;
       md.lg.def_mu = vars[s->rows_mu].def_base; md.lg.def_sigma = vars[s->rows_sigma].def_base;
-    } else if (s->rows_N <= 0 && s->mvn_k > 0 && md.n_deferred == 0) {
+    } else if (s->rows_N <= 0 && s->mvn_k > 0 && md.n_deferred == 0 && s->glm_N <= 0) {
       md.lean_ok = 1;
     }
   }
@@ -690,7 +717,19 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.csr = m->keep(dev_upload(csr.data(), csr.size()));
   md.po_fbt = put(fbt.data(), (size_t)nf * sizeof(FactorBT));
   md.po_btvar = put(bterm_var.data(), bterm_var.size() * sizeof(int32_t));
-  md.po_data = put(s->data, (size_t)s->n_data * sizeof(nuts_data_ref));
+  // data table: the spec's vectors, then (values, seed) of every derived vector behind the spec's pool
+  std::vector<nuts_data_ref> drefs(s->data, s->data + s->n_data);
+  m->pool_extra = 0;
+  md.n_derived = (int32_t)derived.size();
+  for (size_t t = 0; t < derived.size(); ++t) {
+    const int64_t sz = s->factors[derived[t]].size;
+    md.derived_f[t] = derived[t];
+    md.derived_off[t] = s->data_pool_len + m->pool_extra;
+    drefs.push_back(nuts_data_ref{s->data_pool_len + m->pool_extra, sz});
+    drefs.push_back(nuts_data_ref{s->data_pool_len + m->pool_extra + sz, sz});
+    m->pool_extra += 2 * sz;
+  }
+  md.po_data = put(drefs.data(), drefs.size() * sizeof(nuts_data_ref));
   md.po_deferred = put(deferred.data(), deferred.size() * sizeof(int32_t));
   md.po_instrs = put(s->instrs, s->instrs ? (size_t)std::max(s->n_instrs, 0) * sizeof(nuts_instr) : 0);
   blob.resize((blob.size() + 15) & ~(size_t)15, 0);
@@ -718,7 +757,14 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   if (md.fdead) hipMemset(md.fdead, 0, (size_t)std::max(s->n_factors, 1) * sizeof(int32_t));
   std::vector<VarDev> vars;
   if (!compile_spec(m, s, vars)) { nuts_model_destroy(m); return nullptr; }
-  md.pool = m->keep(dev_upload(s->data_pool, s->data_pool_len));
+  {   // the spec's data pool, then the engine's own vectors (derived values / seeds), zeroed
+    double* pool = m->keep(dev_alloc<double>((size_t)std::max<int64_t>(s->data_pool_len + m->pool_extra, 1)));
+    if (pool) {
+      hipMemset(pool, 0, (size_t)std::max<int64_t>(s->data_pool_len + m->pool_extra, 1) * sizeof(double));
+      if (s->data_pool_len > 0) hipMemcpy(pool, s->data_pool, (size_t)s->data_pool_len * sizeof(double), hipMemcpyHostToDevice);
+    }
+    md.pool = pool;
+  }
   m->data_refs.assign(s->data, s->data + s->n_data);
   m->ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
   md.nblk = (n + VEC_THREADS * m->ept - 1) / (VEC_THREADS * m->ept);
@@ -1108,13 +1154,18 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   if (s->glm_N > 0) {
     GlmDev& gm = md.glm;
     auto bad = [&](const char* msg) { g_err = msg; nuts_model_destroy(m); return (nuts_model*)nullptr; };
-    if (s->rows_N > 0 || s->mvn_k > 0 || s->mix_N > 0) return bad("GLM node: not together with another dense node");
+    if (s->rows_N > 0 || s->mix_N > 0) return bad("GLM node: together with an MvNormal node only, not with the logit rows or the mixture node");
+    if (s->mvn_k > 0 && s->mvn_winv) return bad("GLM node next to an MvNormal node: the MvNormal node's precision solver only");
     if (s->glm_P < 1 || s->glm_P > NUTS_GLM_MAXP) return bad("GLM node: 1 <= P <= 512 covariates");
     if (!s->glm_X || !s->glm_y) return bad("GLM node: no design matrix / observations");
     if (s->glm_family < NUTS_GLM_NORMAL || s->glm_family > NUTS_GLM_POISSON) return bad("GLM node: unknown family");
     const int vb = s->glm_beta;
-    if (vb < 0 || vb >= s->n_vars || s->vars[vb].size != s->glm_P || s->vars[vb].transform != NUTS_TR_NONE)
-      return bad("GLM node: beta must be an untransformed variable with P elements");
+    int dslot = -1;   // beta a derived vector: its place in the model's list of derived vectors
+    if (vb < 0) {
+      for (int t = 0; t < md.n_derived; ++t) if (md.derived_f[t] == s->glm_beta_derived) dslot = t;
+      if (dslot < 0 || s->factors[s->glm_beta_derived].size != s->glm_P) return bad("GLM node: glm_beta_derived must name a NUTS_D_DERIVED factor of P elements");
+    } else if (vb >= s->n_vars || s->vars[vb].size != s->glm_P || s->vars[vb].transform != NUTS_TR_NONE)
+      return bad("GLM node: beta must be an untransformed variable with P elements (or a derived vector)");
     auto scalar_ok = [&](int v, bool log_ok) {
       return v >= 0 && v < s->n_vars && s->vars[v].size == 1 && (s->vars[v].transform == NUTS_TR_NONE || (log_ok && s->vars[v].transform == NUTS_TR_LOG));
     };
@@ -1132,7 +1183,9 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     else if (lpr < 32) ch = 4;                 // 4 only
     else ch = std::max(ch, 3);                 // 3 or 4
     gm.lpr = lpr; gm.ch = ch; gm.Ppad = 2 * lpr * ch;
-    gm.off_beta = s->vars[vb].offset;
+    gm.off_beta = vb >= 0 ? s->vars[vb].offset : -1;
+    gm.beta_buf = dslot >= 0 ? const_cast<double*>(md.pool) + md.derived_off[dslot] : nullptr;
+    gm.beta_seed = dslot >= 0 ? const_cast<double*>(md.pool) + md.derived_off[dslot] + gm.P : nullptr;
     gm.off_icpt = s->glm_intercept >= 0 ? s->vars[s->glm_intercept].offset : -1;
     gm.off_sigma = s->glm_sigma >= 0 ? s->vars[s->glm_sigma].offset : -1;
     gm.tr_sigma = s->glm_sigma >= 0 ? s->vars[s->glm_sigma].transform : NUTS_TR_NONE;

@@ -113,8 +113,13 @@ __global__ __launch_bounds__(GLM_BLOCK) void k_glm_rows(ModelDev md, ArenaDev A,
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int col = 2 * (c * LPR + sub);
-    b[c].x = col < gm.P ? qv.at(gm.off_beta + col) : 0.0;
-    b[c].y = col + 1 < gm.P ? qv.at(gm.off_beta + col + 1) : 0.0;
+    if (gm.beta_buf) {   // beta an expression of the model's variables: evaluated by k_derive before this launch
+      b[c].x = col < gm.P ? gm.beta_buf[col] : 0.0;
+      b[c].y = col + 1 < gm.P ? gm.beta_buf[col + 1] : 0.0;
+    } else {
+      b[c].x = col < gm.P ? qv.at(gm.off_beta + col) : 0.0;
+      b[c].y = col + 1 < gm.P ? qv.at(gm.off_beta + col + 1) : 0.0;
+    }
   }
   double icpt, sigma;
   glm_scalars(gm, qv, icpt, sigma);
@@ -188,8 +193,23 @@ __global__ __launch_bounds__(GLM_RED_CHUNKS * GLM_RED_COLS) void k_glm_reduce(Mo
   double t = 0.0;
 #pragma unroll
   for (int c = 0; c < GLM_RED_CHUNKS; ++c) t += s_ch[c][cl];
-  if (slot < gm.Ppad) { if (slot < gm.P) gm.gdense[gm.off_beta + slot] = t; }
+  if (slot < gm.Ppad) { if (slot < gm.P) { if (gm.beta_seed) gm.beta_seed[slot] = t; else gm.gdense[gm.off_beta + slot] = t; } }
   else if (slot == gm.Ppad) { if (gm.off_icpt >= 0) gm.gdense[gm.off_icpt] = t; }
   else if (slot == gm.Ppad + 1) { if (gm.off_sigma >= 0) gm.gdense[gm.off_sigma] = t; }
   else *gm.lp = t + gm.konst;
+}
+
+// Derived vectors (NUTS_D_DERIVED, include/nuts_mi355.h): element li of factor f = the factor's term at this leaf's position,
+// written into the model's data pool before the dense pass that reads it.  (P <= 512 elements: one small launch; the interpreter's
+// tables are read from global memory.)
+__global__ __launch_bounds__(256) void k_derive(ModelDev md, ArenaDev A, EvalIO io, int j) {
+  Leaf lf; QView qv;
+  if (load_aborted(io, A)) return;
+  resolve_leaf(io, A, j, lf, qv);
+  const Prog pg = prog_view(md, md.prog);
+  for (int t = 0; t < md.n_derived; ++t) {
+    const nuts_factor& f = pg.factors[md.derived_f[t]];
+    double* out = const_cast<double*>(md.pool) + md.derived_off[t];
+    for (int li = blockIdx.x * 256 + threadIdx.x; li < f.size; li += gridDim.x * 256) out[li] = factor_arg0_value(pg, qv, f, li);
+  }
 }

@@ -18,6 +18,7 @@
 #include "nuts_mi355.h"
 
 #define MAX_BTERMS 8        // broadcast terms per model
+#define MAX_DERIVED 4       // derived vectors (NUTS_D_DERIVED factors) per model
 #define MAX_FACTOR_BT 6     // broadcast operands per factor
 #define MAX_DEFERRED 256    // deferred elements per model (one control-kernel thread each)
 #define LOGIT_MAXD 8
@@ -153,6 +154,9 @@ struct GlmDev {
   int32_t P, Ppad;          // covariates; stored row length (a multiple of 2 LPR, zero-padded)
   int32_t family, lpr, ch;  // NUTS_GLM_*; lanes per row (a power of two); 16-byte chunks per lane: Ppad = 2 lpr ch
   int32_t off_beta, off_icpt, off_sigma, tr_sigma, nwg;   // element offsets (off_icpt / off_sigma < 0: none / the constant)
+  // beta a DERIVED vector (NUTS_D_DERIVED, off_beta < 0): its values, written by k_derive before the pass, and where the node leaves
+  // d logp / d beta for the interpreter to carry on to the variables of the expression (both in the model's data pool)
+  const double* beta_buf; double* beta_seed;
   double sigma_c;           // constant sigma (Normal family without a sigma variable)
   double konst;             // parameter-free part of the log-likelihood (Poisson: -sum_i factln(y_i))
   const double* X;          // [N][Ppad]
@@ -189,6 +193,10 @@ struct ModelDev {
   const int32_t* csr;         // inverse indices of gathered variables: per (factor, variable) [size + 1] row pointers, then the factor elements
   double* def_loc;            // [2][MAX_DEFERRED][4] (second copy: the group-aligned row pass double-buffers by launch parity)
   int32_t lean_ok, lean_pad;
+  // derived vectors (NUTS_D_DERIVED): factor ids and the offset of each one's values in `pool` (its seed follows the values)
+  int32_t n_derived, derived_pad;
+  int32_t derived_f[MAX_DERIVED];
+  int64_t derived_off[MAX_DERIVED];
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)
   const char* prog;
   int32_t po_vars, po_cptr, po_contrib, po_factors, po_fbt, po_btvar, po_data, po_deferred, po_instrs, po_pad;
@@ -589,6 +597,10 @@ __device__ __noinline__ DistOut dist_eval_v(int dist, double konst, double a0, d
       lp = a[0];
       d[0] = 1.0;
     } break;
+    case NUTS_D_DERIVED: {  // a derived vector (include/nuts_mi355.h): no density of its own; d logp / d element = the seed the
+      lp = 0.0;             // dense node that reads the vector left in the factor's third argument
+      d[0] = a[2];
+    } break;
     default: lp = NAN;
   }
   // every support / parameter check is a `switch(cond, logp, -inf)` in the reference graph
@@ -626,66 +638,192 @@ __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, c
   return dist_eval(f.dist, f.konst, a, d, pdead);
 }
 
-// ---- expression programs (include/nuts_mi355.h): a factor whose arguments are not plain terms --------------------------------
-// Element `li` of a factor WITH a program: the instructions are interpreted in order (values `tv`), together with their
-// forward-mode tangents `tt` w.r.t. the constrained value of variable `wrt` (its own element if it is element-aligned with the
-// factor, the scalar itself if it broadcasts; wrt < 0: values only).  Returns the element's logp, d[k] = d logp / d arg_k and
-// darg[k] = d arg_k / d wrt -- the caller's chain rule is sum_k d[k] darg[k], then the variable's transform as everywhere else.
-// (not inlined, and its two 16-entry scratch arrays are indexed dynamically: only models that carry a program pay for them)
-__device__ __noinline__ double factor_eval_prog(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var, double own_x,
-                                                int wrt, double* d, double* darg, int* pdead) {
-  double tv[NUTS_MAX_FACTOR_INSTR], tt[NUTS_MAX_FACTOR_INSTR];
-  auto val = [&](const nuts_operand& o) { return o.kind == NUTS_OP_TMP ? tv[o.ref] : op_value(o, li, pg, qv, own_var, own_x); };
-  auto tan_ = [&](const nuts_operand& o) {
-    return o.kind == NUTS_OP_TMP ? tt[o.ref] : (((o.kind == NUTS_OP_VAR || o.kind == NUTS_OP_GATHER) && o.ref == wrt) ? 1.0 : 0.0);
-  };
-  const nuts_instr* ins = pg.instrs + f.instr_off;
-  for (int i = 0; i < f.n_instr; ++i) {
-    const nuts_instr I = ins[i];
-    const double x = val(I.x), tx = tan_(I.x);
-    double v, t;
-    switch (I.op) {
-      case NUTS_E_ADD: { v = x + val(I.y); t = tx + tan_(I.y); } break;
-      case NUTS_E_SUB: { v = x - val(I.y); t = tx - tan_(I.y); } break;
-      case NUTS_E_MUL: { const double y = val(I.y); v = x * y; t = tx * y + x * tan_(I.y); } break;
-      case NUTS_E_DIV: { const double y = val(I.y); v = x / y; t = (tx - v * tan_(I.y)) / y; } break;
-      case NUTS_E_NEG: v = -x; t = -tx; break;
-      case NUTS_E_EXP: v = exp(x); t = v * tx; break;
-      case NUTS_E_LOG: v = log(x); t = tx / x; break;
-      case NUTS_E_LOG1P: v = log1p(x); t = tx / (1.0 + x); break;
-      case NUTS_E_SIGMOID: v = sigmoid_d(x); t = v * (1.0 - v) * tx; break;
-      case NUTS_E_SOFTPLUS: v = softplus_d(x); t = sigmoid_d(x) * tx; break;
-      case NUTS_E_SQRT: v = sqrt(x); t = 0.5 * tx / v; break;
-      case NUTS_E_SQR: v = x * x; t = 2.0 * x * tx; break;
-      case NUTS_E_RECIPROCAL: v = 1.0 / x; t = -tx * v * v; break;
-      case NUTS_E_TANH: v = tanh(x); t = (1.0 - v * v) * tx; break;
-      case NUTS_E_ABS: v = fabs(x); t = (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0)) * tx; break;
-      case NUTS_E_POWC: v = pow(x, I.k); t = I.k * pow(x, I.k - 1.0) * tx; break;
-      default: v = NAN; t = NAN;
-    }
-    tv[i] = v; tt[i] = t;
-  }
-  double a[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k < f.nargs) {
-      const nuts_term& tm = f.arg[k];
-      const double bv = val(tm.b), cv = val(tm.c);
-      a[k] = val(tm.a) + bv * cv;
-      darg[k] = tan_(tm.a) + tan_(tm.b) * cv + bv * tan_(tm.c);
-    } else { a[k] = 0.0; darg[k] = 0.0; }
-  }
-  return dist_eval(f.dist, f.konst, a, d, pdead);
-}
-
-__device__ __forceinline__ double dot4(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
-
 // what a failed parameter check of factor `f` means for the element just evaluated (ModelDev.fdead_mode)
 __device__ __forceinline__ void factor_kill(const Prog& pg, int f, int pdead, double& lpf, double* d) {
   if (pg.fdead_mode == 0) return;
   if (pg.fdead_mode == 1) { if (pdead) pg.fdead[f] = 1; return; }   // (every writer stores the same value)
   if (pg.fdead[f]) { lpf = -INFINITY; d[0] = d[1] = d[2] = d[3] = 0.0; }
 }
+
+// ---- expression programs (include/nuts_mi355.h): a factor whose arguments are not plain terms --------------------------------
+// Element `li` of a factor WITH a program, in reverse mode: one forward sweep over the instructions (values `tv`), the factor's
+// density and its partials w.r.t. the arguments, then ONE reverse sweep that carries the adjoints `ta` back through the
+// instructions.  What arrives at a leaf operand that is a variable goes
+//   * into `gwrt` when the variable is `wrt` (the calling thread's own element of it: element-aligned with the factor, or the
+//     element a NUTS_OP_GATHER operand picked for this factor element), and
+//   * when `want_bt` (the caller owns the factor's log-density), into the LDS accumulator of the broadcast term of every scalar
+//     variable that occurs in the program --
+// so a factor costs one forward and one reverse sweep however many variables it mentions (round 4: one forward-tangent pass per
+// variable).  An adjoint that is exactly zero is not propagated: the unselected branch of a `switch` stays out of the gradient
+// even where its own partial is infinite.
+// (not inlined, and its two scratch arrays are indexed dynamically: only models that carry a program pay for them)
+struct ProgFwd { double a[4], bv[4], cv[4]; int pdead; };
+
+__device__ __forceinline__ double prog_op_value(int op, double k, double x, double y, double z) {
+  switch (op) {
+    case NUTS_E_ADD: return x + y;
+    case NUTS_E_SUB: return x - y;
+    case NUTS_E_MUL: return x * y;
+    case NUTS_E_DIV: return x / y;
+    case NUTS_E_NEG: return -x;
+    case NUTS_E_EXP: return exp(x);
+    case NUTS_E_LOG: return log(x);
+    case NUTS_E_LOG1P: return log1p(x);
+    case NUTS_E_SIGMOID: return sigmoid_d(x);
+    case NUTS_E_SOFTPLUS: return softplus_d(x);
+    case NUTS_E_SQRT: return sqrt(x);
+    case NUTS_E_SQR: return x * x;
+    case NUTS_E_RECIPROCAL: return 1.0 / x;
+    case NUTS_E_TANH: return tanh(x);
+    case NUTS_E_ABS: return fabs(x);
+    case NUTS_E_POWC: return pow(x, k);
+    case NUTS_E_GT: return x > y ? 1.0 : 0.0;
+    case NUTS_E_GE: return x >= y ? 1.0 : 0.0;
+    case NUTS_E_LT: return x < y ? 1.0 : 0.0;
+    case NUTS_E_LE: return x <= y ? 1.0 : 0.0;
+    case NUTS_E_EQ: return x == y ? 1.0 : 0.0;
+    case NUTS_E_NEQ: return x != y ? 1.0 : 0.0;
+    case NUTS_E_AND: return (x != 0.0 && y != 0.0) ? 1.0 : 0.0;
+    case NUTS_E_OR: return (x != 0.0 || y != 0.0) ? 1.0 : 0.0;
+    case NUTS_E_NOT: return x != 0.0 ? 0.0 : 1.0;
+    case NUTS_E_SWITCH: return x != 0.0 ? y : z;
+    case NUTS_E_GAMMALN: return lgamma(x);
+    case NUTS_E_ERF: return erf(x);
+    case NUTS_E_ERFC: return erfc(x);
+    case NUTS_E_ERFCX: return erfcx(x);
+    case NUTS_E_LOG1MEXP: return log1mexp_d(x);
+    case NUTS_E_EXPM1: return expm1(x);
+    case NUTS_E_SIGN: return x > 0 ? 1.0 : (x < 0 ? -1.0 : (x == 0 ? 0.0 : x));
+    case NUTS_E_MAXIMUM: return (x != x || y != y) ? NAN : (x > y ? x : y);
+    case NUTS_E_MINIMUM: return (x != x || y != y) ? NAN : (x < y ? x : y);
+    case NUTS_E_POW: return pow(x, y);
+    case NUTS_E_FLOOR: return floor(x);
+    case NUTS_E_CEIL: return ceil(x);
+    case NUTS_E_SIN: return sin(x);
+    case NUTS_E_COS: return cos(x);
+    case NUTS_E_ARCTAN: return atan(x);
+    case NUTS_E_LOGADDEXP: return logaddexp_d(x, y);
+    case NUTS_E_CLIP: return x < y ? y : (x > z ? z : x);
+    case NUTS_E_CHECK: return x;
+    case NUTS_E_LOG2: return log2(x);
+    case NUTS_E_LOG10: return log10(x);
+    case NUTS_E_DIGAMMA: return digamma_d(x);
+    default: return NAN;
+  }
+}
+
+// forward sweep: tv[i] for every instruction, then the factor's arguments
+__device__ __forceinline__ void prog_forward(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var, double own_x,
+                                             double* tv, ProgFwd& o) {
+  auto val = [&](const nuts_operand& q) { return q.kind == NUTS_OP_TMP ? tv[q.ref] : op_value(q, li, pg, qv, own_var, own_x); };
+  const nuts_instr* ins = pg.instrs + f.instr_off;
+  o.pdead = 0;
+  for (int i = 0; i < f.n_instr; ++i) {
+    const nuts_instr& I = ins[i];
+    const int op = I.op;
+    const double x = val(I.x);
+    const bool has_y = op <= NUTS_E_DIV || (op >= NUTS_E_GT && op <= NUTS_E_OR) || op == NUTS_E_SWITCH || op == NUTS_E_MAXIMUM || op == NUTS_E_MINIMUM ||
+                       op == NUTS_E_POW || op == NUTS_E_LOGADDEXP || op == NUTS_E_CLIP || op == NUTS_E_CHECK;
+    const double y = has_y ? val(I.y) : 0.0;
+    const double z = (op == NUTS_E_SWITCH || op == NUTS_E_CLIP) ? val(I.z) : 0.0;
+    if (op == NUTS_E_CHECK && y == 0.0) o.pdead = 1;
+    tv[i] = prog_op_value(op, I.k, x, y, z);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < f.nargs) {
+      const nuts_term& tm = f.arg[k];
+      o.bv[k] = val(tm.b); o.cv[k] = val(tm.c);
+      o.a[k] = val(tm.a) + o.bv[k] * o.cv[k];
+    } else { o.a[k] = 0.0; o.bv[k] = o.cv[k] = 0.0; }
+  }
+}
+
+// value of argument 0 of element `li` (a NUTS_D_DERIVED factor's vector element)
+__device__ __noinline__ double factor_arg0_value(const Prog& pg, const QView& qv, const nuts_factor& f, int li) {
+  double tv[NUTS_MAX_FACTOR_INSTR];
+  ProgFwd o;
+  prog_forward(pg, qv, f, li, -1, 0.0, tv, o);
+  return o.a[0];
+}
+
+__device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int own_var, double own_x,
+                                               int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out) {
+  double tv[NUTS_MAX_FACTOR_INSTR], ta[NUTS_MAX_FACTOR_INSTR];
+  ProgFwd o;
+  prog_forward(pg, qv, f, li, own_var, own_x, tv, o);
+  double d[4];
+  int pdead = o.pdead;
+  double lp = dist_eval(f.dist, f.konst, o.a, d, &pdead);
+  if (o.pdead) { lp = -INFINITY; d[0] = d[1] = d[2] = d[3] = 0.0; }   // a failed NUTS_E_CHECK: as a failed check inside a density
+  factor_kill(pg, fi, pdead, lp, d);
+  double gw = 0.0;
+  const FactorBT& bt = pg.fbt[fi];
+  auto val = [&](const nuts_operand& q) { return q.kind == NUTS_OP_TMP ? tv[q.ref] : op_value(q, li, pg, qv, own_var, own_x); };
+  auto push = [&](const nuts_operand& q, double g) {
+    if (q.kind == NUTS_OP_TMP) { ta[q.ref] += g; return; }
+    if (q.kind != NUTS_OP_VAR && q.kind != NUTS_OP_GATHER) return;
+    if (q.ref == wrt) { gw += g; return; }
+    if (want_bt && q.kind == NUTS_OP_VAR)
+      for (int b = 0; b < bt.n; ++b)
+        if (pg.bterm_var[bt.e[b].bterm] == q.ref) { s_bacc[bt.e[b].bterm * bstride] += g; break; }
+  };
+  for (int i = 0; i < f.n_instr; ++i) ta[i] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < f.nargs && d[k] != 0.0) {
+      const nuts_term& tm = f.arg[k];
+      push(tm.a, d[k]); push(tm.b, d[k] * o.cv[k]); push(tm.c, d[k] * o.bv[k]);
+    }
+  const nuts_instr* ins = pg.instrs + f.instr_off;
+  for (int i = f.n_instr - 1; i >= 0; --i) {
+    const double g = ta[i];
+    if (g == 0.0) continue;
+    const nuts_instr& I = ins[i];
+    const double v = tv[i];
+    switch (I.op) {
+      case NUTS_E_ADD: push(I.x, g); push(I.y, g); break;
+      case NUTS_E_SUB: push(I.x, g); push(I.y, -g); break;
+      case NUTS_E_MUL: { const double x = val(I.x), y = val(I.y); push(I.x, g * y); push(I.y, g * x); } break;
+      case NUTS_E_DIV: { const double y = val(I.y); push(I.x, g / y); push(I.y, -g * v / y); } break;
+      case NUTS_E_NEG: push(I.x, -g); break;
+      case NUTS_E_EXP: push(I.x, g * v); break;
+      case NUTS_E_LOG: push(I.x, g / val(I.x)); break;
+      case NUTS_E_LOG1P: push(I.x, g / (1.0 + val(I.x))); break;
+      case NUTS_E_SIGMOID: push(I.x, g * v * (1.0 - v)); break;
+      case NUTS_E_SOFTPLUS: push(I.x, g * sigmoid_d(val(I.x))); break;
+      case NUTS_E_SQRT: push(I.x, g * 0.5 / v); break;
+      case NUTS_E_SQR: push(I.x, g * 2.0 * val(I.x)); break;
+      case NUTS_E_RECIPROCAL: push(I.x, -g * v * v); break;
+      case NUTS_E_TANH: push(I.x, g * (1.0 - v * v)); break;
+      case NUTS_E_ABS: { const double x = val(I.x); push(I.x, g * (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0))); } break;
+      case NUTS_E_POWC: push(I.x, g * I.k * pow(val(I.x), I.k - 1.0)); break;
+      case NUTS_E_SWITCH: if (val(I.x) != 0.0) push(I.y, g); else push(I.z, g); break;
+      case NUTS_E_GAMMALN: push(I.x, g * digamma_d(val(I.x))); break;
+      case NUTS_E_ERF: { const double x = val(I.x); push(I.x, g * 1.1283791670955126 * exp(-x * x)); } break;
+      case NUTS_E_ERFC: { const double x = val(I.x); push(I.x, -g * 1.1283791670955126 * exp(-x * x)); } break;
+      case NUTS_E_ERFCX: push(I.x, g * (2.0 * val(I.x) * v - 1.1283791670955126)); break;
+      case NUTS_E_LOG1MEXP: push(I.x, -g / expm1(-val(I.x))); break;
+      case NUTS_E_EXPM1: push(I.x, g * (v + 1.0)); break;
+      case NUTS_E_MAXIMUM: case NUTS_E_MINIMUM: { const double x = val(I.x), y = val(I.y); if (v == x) push(I.x, g); if (v == y) push(I.y, g); } break;
+      case NUTS_E_POW: { const double x = val(I.x), y = val(I.y); push(I.x, g * y * pow(x, y - 1.0)); if (x != 0.0) push(I.y, g * v * log(x)); } break;
+      case NUTS_E_SIN: push(I.x, g * cos(val(I.x))); break;
+      case NUTS_E_COS: push(I.x, -g * sin(val(I.x))); break;
+      case NUTS_E_ARCTAN: { const double x = val(I.x); push(I.x, g / (1.0 + x * x)); } break;
+      case NUTS_E_LOGADDEXP: { const double x = val(I.x), y = val(I.y); push(I.x, g * sigmoid_d(x - y)); push(I.y, g * sigmoid_d(y - x)); } break;
+      case NUTS_E_CLIP: { const double x = val(I.x), y = val(I.y), z = val(I.z); if (x < y) push(I.y, g); else if (x > z) push(I.z, g); else push(I.x, g); } break;
+      case NUTS_E_CHECK: push(I.x, g); break;
+      case NUTS_E_LOG2: push(I.x, g / (val(I.x) * 0.6931471805599453094)); break;
+      case NUTS_E_LOG10: push(I.x, g / (val(I.x) * 2.3025850929940456840)); break;
+      case NUTS_E_DIGAMMA: push(I.x, g * trigamma_d(val(I.x))); break;
+      default: break;   // comparisons, logic, sign, floor, ceil: piecewise constant
+    }
+  }
+  *gwrt_out = gw;
+  return lp;
+}
+
+__device__ __forceinline__ double dot4(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 // (selects, not d[arg]: a run-time index into the four-entry arrays put all of them in scratch -- 144 B in every kernel that evaluates
 // factors)
@@ -739,31 +877,17 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       const int32_t* ptr = pg.csr + cb.dist;
       const int32_t* lst = pg.csr + cb.pad;
       for (int t = ptr[li]; t < ptr[li + 1]; ++t) {
-        double d[4], darg[4];
-        int pdead = 0;
-        double lpf = factor_eval_prog(pg, qv, f, lst[t], -1, 0.0, k, d, darg, &pdead);
-        factor_kill(pg, cb.f, pdead, lpf, d);
-        gx += dot4(d, darg);
+        double gw;
+        factor_prog_rev(pg, qv, f, cb.f, lst[t], -1, 0.0, k, 0, s_bacc, bstride, &gw);
+        gx += gw;
       }
       continue;
     }
-    if (f.n_instr > 0) {   // expression program: the tangent of the arguments w.r.t. this variable, through the program
-      double d[4], darg[4];
-      int pdead = 0;
-      double lpf = factor_eval_prog(pg, qv, f, li, k, x, k, d, darg, &pdead);
-      factor_kill(pg, cb.f, pdead, lpf, d);
-      gx += dot4(d, darg);
-      if (cb.owner) {
-        lp += lpf;
-        const FactorBT& bt = pg.fbt[cb.f];
-        for (int b = 0; b < bt.n; ++b) {   // scalars that broadcast into this factor: one more pass per scalar
-          double d2[4], da2[4];
-          int pd2 = 0;
-          double l2 = factor_eval_prog(pg, qv, f, li, k, x, pg.bterm_var[bt.e[b].bterm], d2, da2, &pd2);
-          factor_kill(pg, cb.f, pd2, l2, d2);
-          s_bacc[bt.e[b].bterm * bstride] += dot4(d2, da2);
-        }
-      }
+    if (f.n_instr > 0) {   // expression program: one forward + one reverse sweep; the owner also collects the factor's logp and
+      double gw;           // the adjoints of the scalars that broadcast into it
+      const double lpf = factor_prog_rev(pg, qv, f, cb.f, li, k, x, k, cb.owner, s_bacc, bstride, &gw);
+      gx += gw;
+      if (cb.owner) lp += lpf;
       continue;
     }
     }
@@ -787,16 +911,8 @@ __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv
   const nuts_factor& f = pg.factors[fi];
   const FactorBT& bt = pg.fbt[fi];
   if constexpr (PROG) if (f.n_instr > 0 || f.pad) {   // (pad != 0: the spec compiler marks factors with gathered operands; they take the general evaluator)
-    double lpo = 0.0;
-    for (int b = 0; b < (bt.n > 0 ? bt.n : 1); ++b) {
-      double d[4], darg[4];
-      int pdead = 0;
-      const int wrt = bt.n > 0 ? pg.bterm_var[bt.e[b].bterm] : -1;
-      lpo = factor_eval_prog(pg, qv, f, li, -1, 0.0, wrt, d, darg, &pdead);
-      factor_kill(pg, fi, pdead, lpo, d);
-      if (bt.n > 0) s_bacc[bt.e[b].bterm * bstride] += dot4(d, darg);
-    }
-    return lpo;
+    double gw;
+    return factor_prog_rev(pg, qv, f, fi, li, -1, 0.0, -1, 1, s_bacc, bstride, &gw);
   }
   double dv[4], bv[4], cv[4];
   int pdead = 0;

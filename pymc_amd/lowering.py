@@ -67,11 +67,14 @@ class NotLowerable(NotImplementedError):
 #        ("sum", axis, x), ("take", x, idx), ("dot", a, b)
 
 _ELEMWISE_ALIASES = {"truediv": "div", "true_div": "div", "scalarsigmoid": "sigmoid", "scalarsoftplus": "softplus", "second": "second",
-                     "identity": "identity", "and_": "and", "or_": "or", "sgn": "sign", "reciprocal": "reciprocal"}
+                     "identity": "identity", "and_": "and", "or_": "or", "sgn": "sign", "reciprocal": "reciprocal",
+                     "scalarmaximum": "maximum", "scalarminimum": "minimum", "psi": "digamma", "invert": "not", "log1pexp": "softplus",
+                     "scalarlogaddexp": "logaddexp", "arctan": "arctan", "bitwise_and": "and", "bitwise_or": "or"}
 _NUMPY_FOLD = {
     "add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "neg": np.negative, "exp": np.exp, "log": np.log,
     "log1p": np.log1p, "sqrt": np.sqrt, "sqr": np.square, "pow": np.power, "abs": np.abs, "reciprocal": np.reciprocal,
-    "sign": np.sign, "gammaln": lambda x: _gammaln(x),
+    "sign": np.sign, "gammaln": lambda x: _gammaln(x), "maximum": np.maximum, "minimum": np.minimum, "floor": np.floor, "ceil": np.ceil,
+    "expm1": np.expm1, "sin": np.sin, "cos": np.cos, "arctan": np.arctan, "log2": np.log2, "log10": np.log10, "tanh": np.tanh,
 }
 
 
@@ -123,7 +126,15 @@ def build_tree(v, memo: Optional[dict] = None):
     if name in ("DimShuffle", "Cast", "SpecifyShape", "Rebroadcast", "Unbroadcast", "ExpandDims"):
         out = build_tree(ins[0], memo)
     elif name in ("CheckParameterValue", "Assert", "CheckAndRaise"):
-        out = build_tree(ins[0], memo)          # the device applies its own parameter checks (model_dev.h KILL_UNLESS)
+        if memo.get("__keep_checks__"):
+            # the op-by-op lowering keeps the reference's parameter checks (`check_parameters`, dist_math.py:50-74): a NUTS_E_CHECK
+            # instruction; checks whose conditions fold to true constants disappear
+            conds = [build_tree(i, memo) for i in ins[1:]]
+            body = build_tree(ins[0], memo)
+            live = [c for c in conds if not (c[0] == "const" and np.all(np.asarray(c[1]) != 0))]
+            out = ("check", body, *live) if live else body
+        else:
+            out = build_tree(ins[0], memo)          # the device applies its own parameter checks (model_dev.h KILL_UNLESS)
     elif name in ("Alloc",):
         out = build_tree(ins[0], memo)          # pt.full(size, x): a broadcast
     elif name == "Elemwise" and type(op.scalar_op).__name__ == "Composite":
@@ -227,7 +238,11 @@ def build_tree(v, memo: Optional[dict] = None):
     elif name == "TakeAlongAxis":
         out = ("take_along_axis", build_tree(ins[0], memo), build_tree(ins[1], memo))
     elif name in ("All", "Any", "MakeVector"):
-        out = (name.lower(), *[build_tree(i, memo) for i in ins])
+        kids = [build_tree(i, memo) for i in ins]
+        if name in ("All", "Any") and kids[0][0] == "const":
+            out = _const(float((np.all if name == "All" else np.any)(np.asarray(kids[0][1]) != 0)))
+        else:
+            out = (name.lower(), *kids)
     else:
         raise NotLowerable(f"op {name} is outside the lowering protocol")
     memo[key] = out
@@ -462,7 +477,7 @@ def _post_studentt(env):
     """lam = sigma**-2 * sign(sigma) (continuous.py:234-239); constants: gammaln((nu+1)/2), nu*pi, gammaln(nu/2), (nu+1)/2, nu."""
     nu = _num(env["c_nu"])
     if nu is None:
-        raise NotLowerable("StudentT with a non-constant nu (the IR keeps nu constant)")
+        return None     # a VARIABLE shape parameter / bound: no distribution code -- the density is lowered op by op (`_general`)
     if not _close(_num(env["c_half"]), (nu + 1.0) / 2.0):
         return None
     lam = env["lam"]
@@ -490,7 +505,7 @@ def _shape_and_norm(env, shape_from, norm_of):
     `-gammaln(alpha) + logpow(beta, alpha)`, which arrives as ONE number when beta is a constant too."""
     al = shape_from(_num(env["expo"])) if _num(env["expo"]) is not None else None
     if al is None:
-        raise NotLowerable("Gamma / InverseGamma with a non-constant alpha (the IR keeps alpha constant)")
+        return None     # a VARIABLE shape parameter / bound: no distribution code -- the density is lowered op by op (`_general`)
     k1, beta = env["k1"], env["beta"]
     if k1[0] == "const":
         if beta[0] != "const":
@@ -534,7 +549,7 @@ def _post_invgamma(env):
 def _post_beta(env):
     al, be = _num(env["alpha"]), _num(env["beta"])
     if al is None or be is None:
-        raise NotLowerable("Beta with non-constant alpha / beta (the IR keeps them constant)")
+        return None     # a VARIABLE shape parameter / bound: no distribution code -- the density is lowered op by op (`_general`)
     betaln = math.lgamma(al) + math.lgamma(be) - math.lgamma(al + be)
     if not (_close(_num(env["am1"]), al - 1.0) and _close(_num(env["bm1"]), be - 1.0) and _close(_num(env["c_b"]), betaln)):
         return None
@@ -545,7 +560,7 @@ def _post_uniform(env):
     """switch(and(ge(v, lower), le(v, upper)), fill(v, -log(upper - lower)), -inf) (continuous.py:309-321); constant bounds in the IR."""
     lo, hi = _num(env["lower"]), _num(env["upper"])
     if lo is None or hi is None:
-        raise NotLowerable("Uniform with non-constant bounds (the IR keeps them constant)")
+        return None     # a VARIABLE shape parameter / bound: no distribution code -- the density is lowered op by op (`_general`)
     if not _close(_num(env["c"]), -math.log(hi - lo)):
         return None
     return {"value": env["value"], "lower": env["lower"], "upper": env["upper"]}, 0.0
@@ -802,9 +817,17 @@ class _Lowering:
             arr = np.asarray(node[1], dtype="float64")
             if arr.size == 1:
                 return ms.Operand(ms.OP_CONST, float(arr.reshape(-1)[0]))
-            self.spec.data.append(np.ascontiguousarray(arr.ravel()))
+            flat = np.ascontiguousarray(arr.ravel())
+            if self._const_cache is not None:       # (the op-by-op lowering meets the same constant many times: `value` in every
+                key = flat.tobytes()                #  switch of a `logpow`)
+                if key in self._const_cache:
+                    return ms.Operand(ms.OP_DATA, 0.0, self._const_cache[key])
+                self._const_cache[key] = len(self.spec.data)
+            self.spec.data.append(flat)
             return ms.Operand(ms.OP_DATA, 0.0, len(self.spec.data) - 1)
         return None
+
+    _const_cache = None
 
     def term(self, node) -> ms.Term:
         """`a + b * c` over constants, data vectors and value variables."""
@@ -832,12 +855,19 @@ class _Lowering:
 
     _PROG_OPS = {"add": ms.E_ADD, "sub": ms.E_SUB, "mul": ms.E_MUL, "div": ms.E_DIV, "neg": ms.E_NEG, "exp": ms.E_EXP, "log": ms.E_LOG,
                  "log1p": ms.E_LOG1P, "sigmoid": ms.E_SIGMOID, "softplus": ms.E_SOFTPLUS, "sqrt": ms.E_SQRT, "sqr": ms.E_SQR,
-                 "reciprocal": ms.E_RECIPROCAL, "tanh": ms.E_TANH, "abs": ms.E_ABS}
+                 "reciprocal": ms.E_RECIPROCAL, "tanh": ms.E_TANH, "abs": ms.E_ABS,
+                 # the scalar ops of the reference's log-density bodies (continuous.py, discrete.py, dist_math.py): with them a density
+                 # that matches no template is lowered op by op
+                 "gt": ms.E_GT, "ge": ms.E_GE, "lt": ms.E_LT, "le": ms.E_LE, "eq": ms.E_EQ, "neq": ms.E_NEQ, "and": ms.E_AND, "or": ms.E_OR,
+                 "not": ms.E_NOT, "switch": ms.E_SWITCH, "gammaln": ms.E_GAMMALN, "erf": ms.E_ERF, "erfc": ms.E_ERFC, "erfcx": ms.E_ERFCX,
+                 "log1mexp": ms.E_LOG1MEXP, "expm1": ms.E_EXPM1, "sign": ms.E_SIGN, "maximum": ms.E_MAXIMUM, "minimum": ms.E_MINIMUM,
+                 "floor": ms.E_FLOOR, "ceil": ms.E_CEIL, "sin": ms.E_SIN, "cos": ms.E_COS, "arctan": ms.E_ARCTAN, "logaddexp": ms.E_LOGADDEXP,
+                 "clip": ms.E_CLIP, "log2": ms.E_LOG2, "log10": ms.E_LOG10, "digamma": ms.E_DIGAMMA}
 
     def _program(self, node) -> ms.Operand:
         """Expression tree -> instructions of the current factor's program; returns the operand that holds the node's value.
-        Leaves are what `_operand` accepts (constants, data, the CONSTRAINED value of a variable); shared sub-trees (the walker's
-        memo hands the same tuple back) are emitted once."""
+        Leaves are what `_operand` accepts (constants, data, the CONSTRAINED value of a variable, gathers); shared sub-trees (the
+        walker's memo hands the same tuple back) and structurally equal instructions are emitted once."""
         if self._prog is None:
             raise NotLowerable(f"expression is outside the affine IR `a + b*c`: {_show(node)}")
         o = self._operand(node)
@@ -849,10 +879,21 @@ class _Lowering:
         k = 0.0
         if op == "pow":
             e = _num(node[2])
-            if e is None:
-                raise NotLowerable(f"a power with a non-constant exponent: {_show(node)}")
-            kids = [self._program(node[1])]
-            code, k = (ms.E_SQR, 0.0) if e == 2.0 else (ms.E_POWC, e)
+            if e is None:                       # a variable exponent (`value ** alpha`): x ** y
+                kids, code = [self._program(node[1]), self._program(node[2])], ms.E_POW
+            else:
+                kids = [self._program(node[1])]
+                code, k = (ms.E_SQR, 0.0) if e == 2.0 else (ms.E_POWC, e)
+        elif op == "check":                      # check_parameters(expr, *conds): one NUTS_E_CHECK per condition
+            out = self._program(node[1])
+            for c in node[2:]:
+                out = self._emit_instr(ms.E_CHECK, [out, self._program(self._cond(c))])
+            self._prog_memo[id(node)] = out
+            return out
+        elif op in ("all", "any", "makevector"):
+            out = self._program(self._cond(node))
+            self._prog_memo[id(node)] = out
+            return out
         elif op in self._PROG_OPS:
             kids = [self._program(x) for x in node[1:]]
             code = self._PROG_OPS[op]
@@ -860,12 +901,50 @@ class _Lowering:
             raise NotLowerable(f"the unconstrained value of transformed variable {getattr(node[1], 'name', '?')} inside an expression")
         else:
             raise NotLowerable(f"expression is outside the affine IR `a + b*c` and the expression programs: {_show(node)}")
+        out = self._emit_instr(code, kids, k)
+        self._prog_memo[id(node)] = out
+        return out
+
+    def _cond(self, node):
+        """The conditions of a `check_parameters` / `pt.all([...])`: element-wise AND (OR for `any`) of the listed conditions -- the
+        reduction to one scalar over the factor's elements (`pt.all`) is what NUTS_E_CHECK means on the device (a failed check kills
+        the whole factor)."""
+        if node[0] in ("all", "any"):
+            inner = node[1]
+            parts = list(inner[1:]) if inner[0] == "makevector" else [inner]
+            parts = [self._cond(p) for p in parts]
+            out = parts[0]
+            for p_ in parts[1:]:
+                out = ("and" if node[0] == "all" else "or", out, p_)
+            return out
+        if node[0] == "makevector":
+            parts = [self._cond(p) for p in node[1:]]
+            out = parts[0]
+            for p_ in parts[1:]:
+                out = ("and", out, p_)
+            return out
+        return node
+
+    def _emit_instr(self, code, kids, k=0.0) -> ms.Operand:
+        # constants fold (an `eq(alpha, 1)` of a constant alpha, the `-inf` branch of a decided switch)
+        if all(x.kind == ms.OP_CONST for x in kids) and code not in (ms.E_CHECK,):
+            ins = ms.Instr(code, kids[0], kids[1] if len(kids) > 1 else ms.ZERO, k, kids[2] if len(kids) > 2 else ms.ZERO)
+            with np.errstate(all="ignore"):
+                v = ms.eval_program(self.spec, (ins,), ms.Term(ms.Operand(ms.OP_TMP, 0.0, 0)), np.zeros(max(self.spec.n, 1)))
+            return ms.Operand(ms.OP_CONST, float(np.asarray(v).reshape(-1)[0]))
+        if code == ms.E_SWITCH and kids[0].kind == ms.OP_CONST:
+            return kids[1] if kids[0].c != 0.0 else kids[2]
+        if code == ms.E_CHECK and kids[1].kind == ms.OP_CONST and kids[1].c != 0.0:
+            return kids[0]
+        key = (code, k, *kids)
+        if key in self._prog_cse:
+            return self._prog_cse[key]
         if len(self._prog) >= ms.MAX_FACTOR_INSTR:
-            raise NotLowerable(f"expression needs more than {ms.MAX_FACTOR_INSTR} instructions in one factor: {_show(node)}")
-        self._prog.append(ms.Instr(code, kids[0], kids[1] if len(kids) > 1 else ms.ZERO, k))
+            raise NotLowerable(f"expression needs more than {ms.MAX_FACTOR_INSTR} instructions in one factor")
+        self._prog.append(ms.Instr(code, kids[0], kids[1] if len(kids) > 1 else ms.ZERO, k, kids[2] if len(kids) > 2 else ms.ZERO))
         self._prog_size.append(max(self._osize(x) for x in kids))
         out = ms.Operand(ms.OP_TMP, 0.0, len(self._prog) - 1)
-        self._prog_memo[id(node)] = out
+        self._prog_cse[key] = out
         return out
 
     def _osize(self, o: ms.Operand) -> int:
@@ -1038,8 +1117,8 @@ class _Lowering:
         norm, logdet = _num(env["norm"]), _num(env["logdet"])
         if norm is None or logdet is None or not _close(norm, -0.5 * k * math.log(2.0 * math.pi)) or not _close(logdet, float(np.sum(np.log(np.diag(L))))):
             return False
-        if self.spec.mvnormal is not None or self.spec.logit_rows is not None or self.spec.mixture_rows is not None or self.spec.glm_rows is not None:
-            raise NotLowerable("more than one dense node in a model")
+        if self.spec.mvnormal is not None or self.spec.logit_rows is not None or self.spec.mixture_rows is not None:
+            raise NotLowerable("a second MvNormal variable / an MvNormal next to the logit rows or a mixture")
         mu = np.ascontiguousarray(np.broadcast_to(np.asarray(mu_n[1], dtype="float64").reshape(-1) if np.asarray(mu_n[1]).size > 1 else np.asarray(mu_n[1], dtype="float64").reshape(()), (k,)))
         self.spec.mvnormal = ms.MvNormalNode(own, mu, L @ L.T, fv.name)
         return True
@@ -1053,7 +1132,13 @@ class _Lowering:
                 return None
             kb = self._as_var(n[2])
             X = np.asarray(n[1][1], dtype="float64")
-            if kb is None or self.spec.vars[kb].transform != ms.TR_NONE or self.spec.vars[kb].size != X.shape[1] or not 1 <= X.shape[1] <= 512:
+            if not 1 <= X.shape[1] <= 512:
+                return None
+            if kb is None or self.spec.vars[kb].transform != ms.TR_NONE:
+                # beta an EXPRESSION of the model's variables (`pm.math.dot(X, mu + sigma * z)`, the non-centred hierarchical
+                # regression; a transformed variable's constrained value): a derived vector (NUTS_D_DERIVED) with a program of its own
+                return X, ("derived", n[2])
+            if self.spec.vars[kb].size != X.shape[1]:
                 return None
             return X, kb
 
@@ -1116,7 +1201,19 @@ class _Lowering:
         y = np.asarray(observed, dtype="float64").ravel()
         if y.size != X.shape[0]:
             return False
-        node = ms.GlmRows(np.ascontiguousarray(X), np.ascontiguousarray(y), family, kb, intercept=icpt)
+        if isinstance(kb, tuple):     # ("derived", expression tree)
+            saved = (self._prog, self._prog_size, self._prog_memo, self._prog_cse)
+            self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+            try:
+                bt = self.term(kb[1])
+                if self._size(bt) != X.shape[1]:
+                    return False
+                self.spec.factors.append(ms.Factor(ms.D_DERIVED, X.shape[1], (bt,), 0.0, "beta", tuple(self._prog)))
+            finally:
+                self._prog, self._prog_size, self._prog_memo, self._prog_cse = saved
+            node = ms.GlmRows(np.ascontiguousarray(X), np.ascontiguousarray(y), family, None, intercept=icpt, beta_derived=len(self.spec.factors) - 1)
+        else:
+            node = ms.GlmRows(np.ascontiguousarray(X), np.ascontiguousarray(y), family, kb, intercept=icpt)
         if family == ms.GLM_NORMAL:
             ks = self._as_var(sigma_node)
             if ks is not None and self.spec.vars[ks].size == 1:
@@ -1125,8 +1222,10 @@ class _Lowering:
                 node.sigma_const = float(np.asarray(sigma_node[1]).reshape(-1)[0])
             else:
                 return False
-        if self.spec.glm_rows is not None or self.spec.logit_rows is not None or self.spec.mvnormal is not None or self.spec.mixture_rows is not None:
-            raise NotLowerable("more than one dense node in a model")
+        # (a model is the sum of its factors, model/core.py:612-695: the GLM node may stand next to an MvNormal node -- a
+        # multivariate-normal prior on its coefficients, say; the other pairs have no kernel schedule of their own)
+        if self.spec.glm_rows is not None or self.spec.logit_rows is not None or self.spec.mixture_rows is not None:
+            raise NotLowerable("a second regression likelihood / a GLM likelihood next to the logit rows or a mixture: one of them has to be a dense node")
         self.spec.glm_rows = node
         return True
 
@@ -1185,16 +1284,22 @@ class _Lowering:
     _prog = None
     _gather_ids: Dict[Any, int] = {}
 
-    def factor(self, node, name: str, own_value=None):
+    def factor(self, node, name: str, own_value=None, graph=None):
         if "_gather_ids" not in self.__dict__:
             self._gather_ids = {}
-        self._prog, self._prog_size, self._prog_memo = [], [], {}
+        self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+        self._graph = graph
         try:
             self._factor(node, name, own_value)
         finally:
             self._prog = None
 
     def _emit(self, dist, args, konst, name):
+        size = max(self._size(a) for a in args)
+        for o in [o for t in args for o in (t.a, t.b, t.c)] + [o for ins in self._prog for o in (ins.x, ins.y, ins.z)]:
+            if self._osize(o) not in (1, size):     # every operand broadcasts against the factor: one element or the factor's size
+                raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
+                                   "between different shapes is outside the element-wise factors")
         self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), tuple(args), konst, name, tuple(self._prog)))
 
     def _dirichlet_factor(self, node, own: int, own_value) -> None:
@@ -1301,8 +1406,9 @@ class _Lowering:
             elif dist == ms.D_EXPONENTIAL:   # the IR's Exponential takes lam = 1 / mu
                 mu = args[1]
                 if not (mu.b == ms.ZERO or mu.c == ms.ZERO) or mu.a.kind != ms.OP_CONST:
-                    raise NotLowerable("Exponential with a non-constant scale")
-                args = (args[0], ms.Term(ms.Operand(ms.OP_CONST, 1.0 / mu.a.c)))
+                    args = (args[0], ms.Term(self._emit_instr(ms.E_RECIPROCAL, [self._program(env["mu"])])))   # lam = 1 / scale, by program
+                else:
+                    args = (args[0], ms.Term(ms.Operand(ms.OP_CONST, 1.0 / mu.a.c)))
             self._emit(dist, args, 0.0, name)
             return
         tn = _match_truncnormal(node)
@@ -1327,8 +1433,32 @@ class _Lowering:
             args = tuple(lowered[a] for a in argnames)
             self._emit(dist, args, konst, name)
             return
-        # a potential: the expression itself is the contribution (model/core.py:666-695)
-        t = self.term(node)
+        self._general(node, name, own)
+
+    def _general(self, node, name: str, own: Optional[int]):
+        """No template matched: the factor is lowered OP BY OP -- the graph itself becomes the factor's expression program (the scalar
+        ops of the reference's density bodies are the program's opcodes, include/nuts_mi355.h), evaluated on the device as a
+        NUTS_D_POTENTIAL whose term is the program's result and differentiated by the interpreter's reverse sweep: what
+        `pytensor.grad` does with the same graph (model/core.py:213-267).  This is how `pm.Potential` terms have always been lowered;
+        it now also takes every density whose parameters keep it out of the templates (StudentT with a random nu, Gamma / Beta with
+        random shape parameters, NegativeBinomial, Weibull, Logistic, ...).  The reference's parameter checks stay in the program
+        (NUTS_E_CHECK), which is why the tree is rebuilt from the graph with the checks kept."""
+        if self._graph is not None:
+            node = self._strip_jacobian(build_tree(self._graph, {"__keep_checks__": True}), own)
+            self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+        self._const_cache = {}
+        try:
+            t = self.term(node)
+        finally:
+            self._const_cache = None
+        size = self._size(t)
+        for ins in self._prog:        # every operand broadcasts against the factor: size 1 or the factor's size
+            for o in (ins.x, ins.y, ins.z):
+                if self._osize(o) not in (1, size):
+                    raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
+                                       "between different shapes is outside the element-wise programs")
+        if own is not None and self.spec.vars[own].size not in (1, size) :
+            raise NotLowerable(f"the factor of {self.spec.vars[own].name} does not have the variable's shape")
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)
 
 
@@ -1365,7 +1495,7 @@ def lower_to_spec(model) -> ms.ModelSpec:
     names = list(getattr(model, "logp_names", [f"factor{i}" for i in range(len(factors))]))
     memo: dict = {}
     for g, own, nm in zip(factors, owners, names):
-        low.factor(build_tree(g, memo), nm, own)
+        low.factor(build_tree(g, memo), nm, own, graph=g)
     if low._cat:
         raise NotLowerable("a Categorical variable that does not index an observed Normal (the IR has no free-standing Categorical factor)")
     if low._dirichlet:
@@ -1377,7 +1507,7 @@ def lower_to_spec(model) -> ms.ModelSpec:
     if not isinstance(dets, dict):
         dets = {getattr(v, "name", f"deterministic{i}"): v for i, v in enumerate(dets)}
     for name, var in dets.items():
-        low._prog, low._prog_size, low._prog_memo = [], [], {}
+        low._prog, low._prog_size, low._prog_memo, low._prog_cse = [], [], {}, {}
         if "_gather_ids" not in low.__dict__:
             low._gather_ids = {}
         try:

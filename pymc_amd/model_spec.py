@@ -38,11 +38,18 @@ TRANSFORM_NAMES = {TR_NONE: None, TR_LOG: "log", TR_LOGODDS: "logodds", TR_INTER
 OP_CONST, OP_DATA, OP_VAR, OP_TMP, OP_GATHER = 0, 1, 2, 3, 4   # OP_GATHER: var[idx[i]], `c` = id of the index data vector
 
 # expression-program opcodes (must match include/nuts_mi355.h NUTS_E_*)
-(E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC) = range(16)
+(E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC,
+ E_GT, E_GE, E_LT, E_LE, E_EQ, E_NEQ, E_AND, E_OR, E_NOT, E_SWITCH, E_GAMMALN, E_ERF, E_ERFC, E_ERFCX, E_LOG1MEXP, E_EXPM1, E_SIGN,
+ E_MAXIMUM, E_MINIMUM, E_POW, E_FLOOR, E_CEIL, E_SIN, E_COS, E_ARCTAN, E_LOGADDEXP, E_CLIP, E_CHECK, E_LOG2, E_LOG10, E_DIGAMMA) = range(47)
 E_NAMES = {"add": E_ADD, "sub": E_SUB, "mul": E_MUL, "div": E_DIV, "neg": E_NEG, "exp": E_EXP, "log": E_LOG, "log1p": E_LOG1P, "sigmoid": E_SIGMOID,
-           "softplus": E_SOFTPLUS, "sqrt": E_SQRT, "sqr": E_SQR, "reciprocal": E_RECIPROCAL, "tanh": E_TANH, "abs": E_ABS, "pow": E_POWC}
-E_BINARY = (E_ADD, E_SUB, E_MUL, E_DIV)
-MAX_FACTOR_INSTR = 16
+           "softplus": E_SOFTPLUS, "sqrt": E_SQRT, "sqr": E_SQR, "reciprocal": E_RECIPROCAL, "tanh": E_TANH, "abs": E_ABS, "pow": E_POWC,
+           "gt": E_GT, "ge": E_GE, "lt": E_LT, "le": E_LE, "eq": E_EQ, "neq": E_NEQ, "and": E_AND, "or": E_OR, "not": E_NOT, "switch": E_SWITCH,
+           "gammaln": E_GAMMALN, "erf": E_ERF, "erfc": E_ERFC, "erfcx": E_ERFCX, "log1mexp": E_LOG1MEXP, "expm1": E_EXPM1, "sign": E_SIGN,
+           "maximum": E_MAXIMUM, "minimum": E_MINIMUM, "floor": E_FLOOR, "ceil": E_CEIL, "sin": E_SIN, "cos": E_COS, "arctan": E_ARCTAN,
+           "logaddexp": E_LOGADDEXP, "clip": E_CLIP, "check": E_CHECK, "log2": E_LOG2, "log10": E_LOG10, "digamma": E_DIGAMMA}
+E_TERNARY = (E_SWITCH, E_CLIP)
+E_BINARY = (E_ADD, E_SUB, E_MUL, E_DIV, E_GT, E_GE, E_LT, E_LE, E_EQ, E_NEQ, E_AND, E_OR, E_MAXIMUM, E_MINIMUM, E_POW, E_LOGADDEXP, E_CHECK) + E_TERNARY
+MAX_FACTOR_INSTR = 128
 
 # distribution codes (must match include/nuts_mi355.h)
 (
@@ -64,7 +71,8 @@ MAX_FACTOR_INSTR = 16
     D_INVGAMMA,
     D_LAPLACE,
     D_POISSON,
-) = range(18)
+    D_DERIVED,
+) = range(19)
 DIST_NAMES = {
     D_NORMAL: "Normal",
     D_HALFNORMAL: "HalfNormal",
@@ -84,6 +92,7 @@ DIST_NAMES = {
     D_INVGAMMA: "InverseGamma",
     D_LAPLACE: "Laplace",
     D_POISSON: "Poisson",
+    D_DERIVED: "Derived",
 }
 
 
@@ -115,6 +124,7 @@ class Instr:
     x: Operand = ZERO
     y: Operand = ZERO
     k: float = 0.0
+    z: Operand = ZERO       # third operand (E_SWITCH: the `else` branch; E_CLIP: the upper bound)
 
 
 @dataclass
@@ -226,17 +236,20 @@ class GlmRows:
         pm.Bernoulli(name, logit_p=alpha + pm.math.dot(X, beta), observed=y)             discrete.py:351-352,362-374
         pm.Poisson(name, mu=pm.math.exp(alpha + pm.math.dot(X, beta)), observed=y)       discrete.py:581-597
 
-    `beta`: variable of size P <= 512; `intercept`: scalar variable or None; `sigma` (Normal): scalar variable (its constrained
-    value) or None with `sigma_const`."""
+    `beta`: variable of size P <= 512 -- or an EXPRESSION of the model's variables (`pm.math.dot(X, mu + sigma * z)`, the
+    non-centred hierarchical regression): then `beta` is None and `beta_derived` the index of a D_DERIVED factor of P elements whose
+    term is the expression; `intercept`: scalar variable or None; `sigma` (Normal): scalar variable (its constrained value) or None
+    with `sigma_const`."""
 
     X: np.ndarray                     # [N, P] float64
     y: np.ndarray                     # [N] float64
     family: int                       # GLM_*
-    beta: int                         # var id
+    beta: Optional[int]               # var id, or None with beta_derived
     intercept: Optional[int] = None   # var id
     sigma: Optional[int] = None       # var id, or None with sigma_const
     sigma_const: float = 1.0
     name: str = "y"
+    beta_derived: Optional[int] = None   # index (into ModelSpec.factors) of the D_DERIVED factor that is beta
 
 
 @dataclass
@@ -289,10 +302,11 @@ class Expr:
         return self._term
 
     @classmethod
-    def op(cls, builder, opcode, x, y=None, k=0.0):
+    def op(cls, builder, opcode, x, y=None, k=0.0, z=None):
         x = builder.as_expr(x)
         y = builder.as_expr(y) if y is not None else None
-        return cls(builder, None, max(x.size, y.size if y is not None else 1), (opcode, x, y, float(k)))
+        z = builder.as_expr(z) if z is not None else None
+        return cls(builder, None, max(x.size, y.size if y is not None else 1, z.size if z is not None else 1), (opcode, x, y, float(k), z))
 
     # -- helpers -----------------------------------------------------------
     def _simple(self) -> Optional[Operand]:
@@ -407,6 +421,37 @@ class _Math:
     def tanh(self, x): return self._un(E_TANH, x)
     def abs(self, x): return self._un(E_ABS, x)
     def reciprocal(self, x): return self._un(E_RECIPROCAL, x)
+    # the scalar ops of the reference's density bodies (include/nuts_mi355.h NUTS_E_*): a density written out op by op
+    def gammaln(self, x): return self._un(E_GAMMALN, x)
+    def erf(self, x): return self._un(E_ERF, x)
+    def erfc(self, x): return self._un(E_ERFC, x)
+    def erfcx(self, x): return self._un(E_ERFCX, x)
+    def log1mexp(self, x): return self._un(E_LOG1MEXP, x)
+    def expm1(self, x): return self._un(E_EXPM1, x)
+    def sign(self, x): return self._un(E_SIGN, x)
+    def floor(self, x): return self._un(E_FLOOR, x)
+    def ceil(self, x): return self._un(E_CEIL, x)
+    def sin(self, x): return self._un(E_SIN, x)
+    def cos(self, x): return self._un(E_COS, x)
+    def arctan(self, x): return self._un(E_ARCTAN, x)
+    def digamma(self, x): return self._un(E_DIGAMMA, x)
+    def gt(self, x, y): return Expr.op(self._b, E_GT, x, y)
+    def ge(self, x, y): return Expr.op(self._b, E_GE, x, y)
+    def lt(self, x, y): return Expr.op(self._b, E_LT, x, y)
+    def le(self, x, y): return Expr.op(self._b, E_LE, x, y)
+    def eq(self, x, y): return Expr.op(self._b, E_EQ, x, y)
+    def neq(self, x, y): return Expr.op(self._b, E_NEQ, x, y)
+    def and_(self, x, y): return Expr.op(self._b, E_AND, x, y)
+    def or_(self, x, y): return Expr.op(self._b, E_OR, x, y)
+    def maximum(self, x, y): return Expr.op(self._b, E_MAXIMUM, x, y)
+    def minimum(self, x, y): return Expr.op(self._b, E_MINIMUM, x, y)
+    def pow(self, x, y): return Expr.op(self._b, E_POW, x, y)
+    def logaddexp(self, x, y): return Expr.op(self._b, E_LOGADDEXP, x, y)
+    def switch(self, c, x, y): return Expr.op(self._b, E_SWITCH, c, x, z=y)
+    def clip(self, x, lo, hi): return Expr.op(self._b, E_CLIP, x, lo, z=hi)
+    def check(self, x, cond):
+        """`check_parameters(x, cond)` (dist_math.py:50-74): x where cond holds for every element of the factor, else the factor is -inf."""
+        return Expr.op(self._b, E_CHECK, x, cond)
 
 
 def eval_program(spec: "ModelSpec", prog, term: Term, x: np.ndarray) -> np.ndarray:
@@ -428,13 +473,26 @@ def eval_program(spec: "ModelSpec", prog, term: Term, x: np.ndarray) -> np.ndarr
         blk = x[..., v.offset : v.offset + v.size]
         return blk if v.size > 1 else blk[..., 0:1] if x.ndim > 1 else blk.reshape(())
 
+    from scipy import special as _sp
+
     un = {E_NEG: np.negative, E_EXP: np.exp, E_LOG: np.log, E_LOG1P: np.log1p, E_SIGMOID: lambda a: 1.0 / (1.0 + np.exp(-a)),
-          E_SOFTPLUS: lambda a: np.logaddexp(0.0, a), E_SQRT: np.sqrt, E_SQR: np.square, E_RECIPROCAL: np.reciprocal, E_TANH: np.tanh, E_ABS: np.abs}
-    bi = {E_ADD: np.add, E_SUB: np.subtract, E_MUL: np.multiply, E_DIV: np.divide}
+          E_SOFTPLUS: lambda a: np.logaddexp(0.0, a), E_SQRT: np.sqrt, E_SQR: np.square, E_RECIPROCAL: np.reciprocal, E_TANH: np.tanh, E_ABS: np.abs,
+          E_NOT: lambda a: (np.asarray(a) == 0).astype("float64"), E_GAMMALN: _sp.gammaln, E_ERF: _sp.erf, E_ERFC: _sp.erfc, E_ERFCX: _sp.erfcx,
+          E_LOG1MEXP: lambda a: np.where(a > -math.log(2.0), np.log(-np.expm1(a)), np.log1p(-np.exp(a))), E_EXPM1: np.expm1, E_SIGN: np.sign,
+          E_FLOOR: np.floor, E_CEIL: np.ceil, E_SIN: np.sin, E_COS: np.cos, E_ARCTAN: np.arctan, E_LOG2: np.log2, E_LOG10: np.log10, E_DIGAMMA: _sp.digamma}
+    f64 = lambda fn: (lambda a, b: np.asarray(fn(a, b), dtype="float64"))   # noqa: E731
+    bi = {E_ADD: np.add, E_SUB: np.subtract, E_MUL: np.multiply, E_DIV: np.divide, E_GT: f64(np.greater), E_GE: f64(np.greater_equal), E_LT: f64(np.less),
+          E_LE: f64(np.less_equal), E_EQ: f64(np.equal), E_NEQ: f64(np.not_equal), E_AND: f64(lambda a, b: (np.asarray(a) != 0) & (np.asarray(b) != 0)),
+          E_OR: f64(lambda a, b: (np.asarray(a) != 0) | (np.asarray(b) != 0)), E_MAXIMUM: np.maximum, E_MINIMUM: np.minimum, E_POW: np.power,
+          E_LOGADDEXP: np.logaddexp, E_CHECK: lambda a, b: np.where(np.asarray(b) != 0, a, np.nan)}
     with np.errstate(all="ignore"):
         for ins in prog:
             if ins.op in bi:
                 tmp.append(bi[ins.op](val(ins.x), val(ins.y)))
+            elif ins.op == E_SWITCH:
+                tmp.append(np.where(np.asarray(val(ins.x)) != 0, val(ins.y), val(ins.z)))
+            elif ins.op == E_CLIP:
+                tmp.append(np.minimum(np.maximum(val(ins.x), val(ins.y)), val(ins.z)))
             elif ins.op == E_POWC:
                 tmp.append(np.power(val(ins.x), ins.k))
             else:
@@ -470,8 +528,8 @@ class ModelBuilder:
         prog: List[Instr] = []
         memo: Dict[int, Operand] = {}
 
-        def emit(op, x, y=ZERO, k=0.0) -> Operand:
-            prog.append(Instr(op, x, y, k))
+        def emit(op, x, y=ZERO, k=0.0, z=ZERO) -> Operand:
+            prog.append(Instr(op, x, y, k, z))
             if len(prog) > MAX_FACTOR_INSTR:
                 raise NotImplementedError(f"expression needs more than {MAX_FACTOR_INSTR} instructions in one factor")
             return Operand(OP_TMP, 0.0, len(prog) - 1)
@@ -488,8 +546,8 @@ class ModelBuilder:
                 return prod if t.a == ZERO else emit(E_ADD, t.a, prod)
             if id(e) in memo:
                 return memo[id(e)]
-            op, x, y, k = e.node
-            out = emit(op, operand(x), operand(y) if y is not None else ZERO, k)
+            op, x, y, k, z = e.node
+            out = emit(op, operand(x), operand(y) if y is not None else ZERO, k, operand(z) if z is not None else ZERO)
             memo[id(e)] = out
             return out
 
@@ -687,9 +745,16 @@ class ModelBuilder:
         constant), "bernoulli" (logit link) or "poisson" (log link); eta = intercept + X @ beta."""
         X = np.ascontiguousarray(X, dtype="float64")
         y = np.ascontiguousarray(observed, dtype="float64").ravel()
+        beta = self.as_expr(beta)
         if X.ndim != 2 or X.shape[0] != y.size or X.shape[1] != beta.size:
             raise ValueError("GLM: X is [N, P], beta has P elements, one observation per row")
-        node = GlmRows(X, y, GLM_FAMILIES[family], self._var_id(beta), name=name)
+        bo = beta._simple()
+        if bo is not None and bo.kind == OP_VAR and self.spec.vars[bo.ref].transform == TR_NONE:
+            node = GlmRows(X, y, GLM_FAMILIES[family], bo.ref, name=name)
+        else:    # beta an expression: a derived vector the node reads (include/nuts_mi355.h NUTS_D_DERIVED)
+            terms, prog = self._lower_args([beta])
+            self.spec.factors.append(Factor(D_DERIVED, beta.size, terms, 0.0, name + "_beta", prog))
+            node = GlmRows(X, y, GLM_FAMILIES[family], None, name=name, beta_derived=len(self.spec.factors) - 1)
         if intercept is not None:
             node.intercept = self._var_id(intercept)
         if isinstance(sigma, Expr):

@@ -41,7 +41,9 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
         prog = getattr(f, "prog", ())
         fc.n_instr, fc.instr_off = len(prog), ioff
         for ins in prog:
-            ins_c[ioff] = _lib.Instr(ins.op, 0, ins.k, _lib.Operand(ins.x.kind, max(ins.x.ref, 0), ins.x.c), _lib.Operand(ins.y.kind, max(ins.y.ref, 0), ins.y.c))
+            z = getattr(ins, "z", None) or ins.y
+            ins_c[ioff] = _lib.Instr(ins.op, 0, ins.k, _lib.Operand(ins.x.kind, max(ins.x.ref, 0), ins.x.c), _lib.Operand(ins.y.kind, max(ins.y.ref, 0), ins.y.c),
+                                     _lib.Operand(z.kind, max(z.ref, 0), z.c))
             ioff += 1
         fac_c[i] = fc
     refs = (_lib.DataRef * max(nd, 1))()
@@ -113,7 +115,9 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
         y = np.ascontiguousarray(gl.y, dtype="float64")
         keep += [X, y]
         s.glm_N, s.glm_P = X.shape
-        s.glm_family, s.glm_beta = gl.family, gl.beta
+        s.glm_family = gl.family
+        s.glm_beta = -1 if gl.beta is None else gl.beta
+        s.glm_beta_derived = -1 if getattr(gl, "beta_derived", None) is None else gl.beta_derived
         s.glm_intercept = -1 if gl.intercept is None else gl.intercept
         s.glm_sigma = -1 if gl.sigma is None else gl.sigma
         s.glm_sigma_const = float(gl.sigma_const)

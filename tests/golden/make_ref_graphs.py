@@ -16,5 +16,7 @@ import lowering_models as lm  # noqa: E402
 import stubgraph as sg  # noqa: E402
 
 if __name__ == "__main__":
-    sg.save_models(lm.FIXTURE, {name: make() for name, (make, _) in lm.ENTRIES.items()})
-    print(lm.FIXTURE, os.path.getsize(lm.FIXTURE), "bytes,", len(lm.ENTRIES), "models")
+    graphs = {name: make() for name, (make, _) in lm.ENTRIES.items()}
+    graphs.update({name: make() for name, make in lm.GENERAL.items()})   # the op-by-op / multi-node models (no ModelBuilder twin)
+    sg.save_models(lm.FIXTURE, graphs)
+    print(lm.FIXTURE, os.path.getsize(lm.FIXTURE), "bytes,", len(graphs), "models")

@@ -464,3 +464,127 @@ ENTRIES = {
     "potentials": (potentials, lambda: _built(potentials)),
 }
 FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_graphs.npz")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Models that match NO distribution template: their densities are lowered op by op (the graph becomes the factor's expression
+# program, differentiated by the device's reverse sweep), or one of their dense nodes takes an expression / stands next to another.
+# No `ModelBuilder` twin: they are pinned by evaluating the reference-built graph itself with torch autograd (tests/graph_torch.py;
+# golden values in tests/golden/general_graphs_golden.npz, written by tests/golden/make_general_golden.py).
+# ---------------------------------------------------------------------------------------------------------------------------------
+XGEN = np.linspace(-1.0, 1.5, 30)
+_rg = np.random.default_rng(20160911)
+YGEN = 0.4 + 1.3 * XGEN + 0.5 * _rg.standard_t(4, size=30)
+WPOS = np.abs(_rg.normal(size=12)) + 0.2
+CNT2 = _rg.poisson(3.0, size=25).astype("float64")
+UNIT = _rg.uniform(0.05, 0.95, size=9)
+
+
+def robust_regression():
+    """`nu ~ Gamma(2, 0.1); y ~ StudentT(nu, a + b x, sigma)`: StudentT with a RANDOM nu (continuous.py:1936-1950: gammaln of a variable)."""
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 2.0)
+    b = m.Normal("b", 0.0, 2.0)
+    sigma = m.HalfNormal("sigma", 1.0)
+    nu = m.Gamma("nu", 2.0, 0.1)
+    m.StudentT("y", nu, a + b * XGEN, sigma, observed=YGEN)
+    return m
+
+
+def random_shape_parameters():
+    """Gamma / InverseGamma / Beta with RANDOM shape parameters (continuous.py:2512-2521, 2631-2639, 1250-1262), as likelihoods and as the
+    prior of a free variable (`p ~ Beta(a, b)` with a, b variables; `k ~ Binomial(n, p)`)."""
+    m = sg.StubModel()
+    al = m.HalfNormal("al", 2.0)
+    be = m.Exponential("be", 1.0)
+    m.Gamma("w", al, be, observed=WPOS)
+    m.InverseGamma("w2", al, 0.7, observed=WPOS)
+    a_ = m.Gamma("a_", 2.0, 1.0)
+    b_ = m.Gamma("b_", 3.0, 1.5)
+    pp = m.Beta("pp", a_, b_)
+    m.Binomial("k", NN, pp, observed=CNT)
+    m.Beta("u", a_, 2.5, observed=UNIT)
+    return m
+
+
+def negative_binomial_regression():
+    """`y ~ NegativeBinomial(mu = exp(a + b x), alpha)` with a random dispersion (discrete.py:727: binomln / logpow / the Poisson-limit switch)."""
+    m = sg.StubModel()
+    a = m.Normal("a", 1.0, 1.0)
+    b = m.Normal("b", 0.0, 1.0)
+    alpha = m.Exponential("alpha", 0.5)
+    m.NegativeBinomial("y", m.math.exp(a + b * XGEN[:25]), alpha, observed=CNT2)
+    return m
+
+
+def density_zoo():
+    """Densities the IR has no distribution code for at all: Weibull, Logistic, Gumbel, SkewNormal, BetaBinomial, Geometric, and a
+    power with a VARIABLE exponent inside a likelihood's location."""
+    m = sg.StubModel()
+    k = m.HalfNormal("k", 2.0)
+    lam = m.HalfNormal("lam", 2.0)
+    loc = m.Normal("loc", 0.0, 2.0)
+    s = m.HalfNormal("s", 1.0)
+    sk = m.Normal("sk", 0.0, 2.0)
+    a_ = m.HalfNormal("a_", 2.0)
+    pg = m.Beta("pg", 2.0, 2.0)
+    m.Weibull("w", k, lam, observed=WPOS)
+    m.Logistic("l", loc, s, observed=YGEN[:10])
+    m.Gumbel("g", loc, s, observed=YGEN[10:20])
+    m.SkewNormal("sn", alpha=sk, mu=loc, sigma=s, observed=YGEN[20:])
+    m.BetaBinomial("bb", a_, 2.0, NN, observed=CNT)
+    m.Geometric("ge", pg, observed=CNT + 1.0)
+    m.Normal("pw", lam ** k, 1.0, observed=np.full(3, 0.8))
+    return m
+
+
+XH = _rg.normal(size=(60, 7))
+YH = XH @ (0.3 + 0.8 * _rg.normal(size=7)) + 0.4 * _rg.normal(size=60)
+YHB = (_rg.uniform(size=60) < 1.0 / (1.0 + np.exp(-(XH @ (0.5 * _rg.normal(size=7)))))).astype("float64")
+
+
+def hierarchical_regression_noncentred():
+    """The model BASELINE's metric names, written the usual way: `beta = mu + sigma * z; y ~ Normal(pm.math.dot(X, beta), s)` -- a dense
+    node whose parameter is an EXPRESSION of the model's variables (pymc/math.py:56; `pytensor.grad` through the Dot)."""
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 1.0)
+    sigma = m.HalfNormal("sigma", 1.0)
+    z = m.Normal("z", 0.0, 1.0, shape=(7,))
+    s = m.HalfNormal("s", 1.0)
+    alpha = m.Normal("alpha", 0.0, 2.0)
+    m.Normal("y", alpha + m.math.dot(sg.as_tensor(XH), mu + sigma * z), s, observed=YH)
+    return m
+
+
+def hierarchical_logistic_vector_hyper():
+    """The same with per-coefficient hyper-parameters and a Bernoulli likelihood: `beta_j = mu_j + sigma_j z_j`."""
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 1.0, shape=(7,))
+    sigma = m.HalfNormal("sigma", 1.0, shape=(7,))
+    z = m.Normal("z", 0.0, 1.0, shape=(7,))
+    m.Bernoulli("y", logit_p=m.math.dot(sg.as_tensor(XH), mu + sigma * z), observed=YHB)
+    return m
+
+
+_A7 = _rg.normal(size=(7, 7))
+COV7 = _A7 @ _A7.T / 7.0 + 0.5 * np.eye(7)
+
+
+def glm_with_mvnormal_prior():
+    """TWO dense nodes in one model: `beta ~ MvNormal(0, Sigma); y ~ Bernoulli(logit_p = dot(X, beta))` (multivariate.py:275-295 + math.py:56)."""
+    m = sg.StubModel()
+    beta = m.MvNormal("beta", np.zeros(7), cov=COV7)
+    m.Bernoulli("y", logit_p=m.math.dot(sg.as_tensor(XH), beta), observed=YHB)
+    return m
+
+
+GENERAL = {
+    "robust_regression": robust_regression,
+    "random_shape_parameters": random_shape_parameters,
+    "negative_binomial_regression": negative_binomial_regression,
+    "density_zoo": density_zoo,
+    "hierarchical_regression_noncentred": hierarchical_regression_noncentred,
+    "hierarchical_logistic_vector_hyper": hierarchical_logistic_vector_hyper,
+    "glm_with_mvnormal_prior": glm_with_mvnormal_prior,
+}
+GENERAL_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "general_graphs_golden.npz")

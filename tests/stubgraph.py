@@ -248,7 +248,8 @@ class Softmax:
 
 
 for _n in ("Clip", "Cast", "Add", "Sub", "Mul", "TrueDiv", "Pow", "Exp", "Log", "Log1p", "Sqrt", "Neg", "Switch", "GE", "GT", "LT", "LE", "EQ", "OR", "AND", "Sigmoid", "Abs",
-           "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus", "Erf", "Erfc", "Erfcx", "Sqr", "IsClose"):
+           "GammaLn", "Reciprocal", "Sign", "NEQ", "Second", "Softplus", "Erf", "Erfc", "Erfcx", "Sqr", "IsClose", "Floor", "Maximum", "Minimum", "Expm1",
+           "Log1mexp", "Tanh"):
     globals()[_n] = type(_n, (), {})
 
 
@@ -401,6 +402,13 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         return Variable(Apply(DimShuffle(), [x]), shape=tuple(shp))
 
     isclose = staticmethod(lambda a, b: elemwise(IsClose, a, b))
+    power = pow
+    floor = staticmethod(lambda a: elemwise(Floor, a))
+    maximum = staticmethod(lambda a, b: elemwise(Maximum, a, b))
+    minimum = staticmethod(lambda a, b: elemwise(Minimum, a, b))
+    expm1 = staticmethod(lambda a: elemwise(Expm1, a))
+    log1mexp = staticmethod(lambda a: elemwise(Log1mexp, a))
+    tanh = staticmethod(lambda a: elemwise(Tanh, a))
 
     clip = staticmethod(lambda x, lo, hi: elemwise(Clip, x, lo, hi))
     shape = staticmethod(lambda x: as_tensor(x).shape)
@@ -563,8 +571,8 @@ def _get_underlying_scalar_constant_value(v, *a, **k):
 
 _NS = None
 _CONT = ("Normal", "HalfNormal", "Cauchy", "HalfCauchy", "Exponential", "Laplace", "LogNormal", "StudentT", "Beta", "Gamma", "InverseGamma",
-         "Uniform", "TruncatedNormal")
-_DISC = ("Bernoulli", "Binomial", "Poisson")
+         "Uniform", "TruncatedNormal", "Weibull", "Logistic", "Gumbel", "SkewNormal")
+_DISC = ("Bernoulli", "Binomial", "Poisson", "NegativeBinomial", "BetaBinomial", "Geometric")
 
 
 def reference():
@@ -587,7 +595,7 @@ def reference():
         _, tree = _parsed(rel)
         for name in names:
             have = {c.name for c in _find(tree, name).body if isinstance(c, ast.FunctionDef)}
-            ref_class(rel, name, [m for m in ("dist", "get_alpha_beta", "_get_alpha_beta", "logp") if m in have], _DistBase, ns)
+            ref_class(rel, name, [m for m in ("dist", "get_alpha_beta", "_get_alpha_beta", "get_n_p", "logp") if m in have], _DistBase, ns)
     # `_logprob_helper(Normal.dist(mu, sigma), value)` (continuous.py:731, :2384): dispatch to the logp of the RV's distribution
     ns["_logprob_helper"] = lambda rv, value: rv.dist_cls.logp(value, *rv)
     for name in ("LogTransform", "IntervalTransform", "LogOddsTransform"):
@@ -663,6 +671,10 @@ def _dist(name, *args, **kw):
     return reference()[name].dist(*args, **kw)
 
 
+def _num_or_var(x):
+    return x if isinstance(x, Variable) else float(x)
+
+
 class _ComponentRV:
     """The batched component of a `pm.NormalMixture` (`Normal.dist(mu, sigma)`, mixture.py:598-607) as `mixture_logprob` sees it:
     an RV variable whose op has `ndim_supp` and whose distribution's logp the dispatcher calls."""
@@ -686,6 +698,7 @@ class _PtMath:
     dot = pt.dot
 
     exp, log, log1p, sqrt, abs = pt.exp, pt.log, pt.log1p, pt.sqrt, pt.abs
+    tanh, maximum, minimum = pt.tanh, pt.maximum, pt.minimum
     sigmoid = invlogit = pt.sigmoid
     softplus, sqr = pt.softplus, pt.sqr
 
@@ -743,17 +756,39 @@ class StubModel:
     def LogNormal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None):
         return self._rv("LogNormal", name, shape, _dist("LogNormal", mu=mu, sigma=sigma), "log", observed)
 
+    # (a shape parameter may be a number or another variable of the model: `nu ~ Gamma; y ~ StudentT(nu, ...)`)
     def StudentT(self, name, nu, mu=0.0, sigma=1.0, shape=(), observed=None):
-        return self._rv("StudentT", name, shape, _dist("StudentT", float(nu), mu=mu, sigma=sigma), None, observed)
+        return self._rv("StudentT", name, shape, _dist("StudentT", _num_or_var(nu), mu=mu, sigma=sigma), None, observed)
 
-    def Beta(self, name, alpha, beta, shape=()):
-        return self._rv("Beta", name, shape, _dist("Beta", alpha=float(alpha), beta=float(beta)), "logodds", None)
+    def Beta(self, name, alpha, beta, shape=(), observed=None):
+        return self._rv("Beta", name, shape, _dist("Beta", alpha=_num_or_var(alpha), beta=_num_or_var(beta)), "logodds", observed)
 
     def Gamma(self, name, alpha, beta, shape=(), observed=None):
-        return self._rv("Gamma", name, shape, _dist("Gamma", alpha=float(alpha), beta=beta), "log", observed)
+        return self._rv("Gamma", name, shape, _dist("Gamma", alpha=_num_or_var(alpha), beta=beta), "log", observed)
 
     def InverseGamma(self, name, alpha, beta, shape=(), observed=None):
-        return self._rv("InverseGamma", name, shape, _dist("InverseGamma", alpha=float(alpha), beta=beta), "log", observed)
+        return self._rv("InverseGamma", name, shape, _dist("InverseGamma", alpha=_num_or_var(alpha), beta=beta), "log", observed)
+
+    def Weibull(self, name, alpha, beta, shape=(), observed=None):
+        return self._rv("Weibull", name, shape, _dist("Weibull", alpha, beta), "log", observed)          # continuous.py `Weibull`
+
+    def Logistic(self, name, mu=0.0, s=1.0, shape=(), observed=None):
+        return self._rv("Logistic", name, shape, _dist("Logistic", mu, s), None, observed)
+
+    def Gumbel(self, name, mu, beta, shape=(), observed=None):
+        return self._rv("Gumbel", name, shape, _dist("Gumbel", mu, beta), None, observed)
+
+    def SkewNormal(self, name, alpha=1.0, mu=0.0, sigma=1.0, shape=(), observed=None):
+        return self._rv("SkewNormal", name, shape, _dist("SkewNormal", alpha=alpha, mu=mu, sigma=sigma), None, observed)
+
+    def NegativeBinomial(self, name, mu, alpha, observed):
+        return self._rv("NegativeBinomial", name, np.shape(observed), _dist("NegativeBinomial", mu=mu, alpha=alpha), None, observed)   # discrete.py:727
+
+    def BetaBinomial(self, name, alpha, beta, n, observed):
+        return self._rv("BetaBinomial", name, np.shape(observed), _dist("BetaBinomial", alpha, beta, n), None, observed)
+
+    def Geometric(self, name, p, observed):
+        return self._rv("Geometric", name, np.shape(observed), _dist("Geometric", p), None, observed)
 
     def Uniform(self, name, lower=0.0, upper=1.0, shape=()):
         return self._bounded("Uniform", name, shape, _dist("Uniform", lower=float(lower), upper=float(upper)), lower, upper)

@@ -109,9 +109,9 @@ def test_affine_terms_stay_terms_and_the_rest_becomes_an_expression_program():
     f = m.build().factors[-1]
     assert len(f.prog) == 4 and f.args[1].a.kind == 3     # mul, mul, exp, add; the mean is the last instruction's result (OP_TMP)
     big = a
-    for _ in range(20):
-        big = m.math.exp(big)
-    with pytest.raises(NotImplementedError, match="more than 16 instructions"):
+    for _ in range(130):
+        big = m.math.tanh(big)
+    with pytest.raises(NotImplementedError, match="more than 128 instructions"):
         m.Normal("z", big, 1.0, observed=np.zeros(3))
     with pytest.raises(ValueError):
         m.Normal("bad", np.zeros(4), 1.0, shape=3)

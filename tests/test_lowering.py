@@ -18,6 +18,7 @@ import stubgraph as sg  # noqa: E402
 
 from oracle import ref_models  # noqa: E402
 from pymc_amd import models  # noqa: E402
+from pymc_amd import model_spec as ms_mod  # noqa: E402
 from pymc_amd.lowering import NotLowerable, build_tree, lower_to_spec  # noqa: E402
 
 
@@ -99,8 +100,14 @@ def test_what_the_ir_cannot_express_is_refused_by_name():
     m = sg.StubModel()
     a = m.Normal("a", 0.0, 1.0, shape=(4,))
     b = m.HalfNormal("b", 1.0, shape=(4,))
-    m.Normal("y", a ** b, 1.0, observed=np.zeros(4))           # a power with a VARIABLE exponent
-    with pytest.raises(NotLowerable, match="non-constant exponent"):
+    m.Normal("y", a ** b, 1.0, observed=np.zeros(4))           # a power with a VARIABLE exponent: refused until round 5, now x ** y of the
+    spec = lower_to_spec(m)                                    # expression programs (NUTS_E_POW; tests/test_general_lowering.py)
+    assert [i.op for i in spec.factors[-1].prog] == [ms_mod.E_POW]
+    m = sg.StubModel()
+    z2 = m.Normal("z2", 0.0, 1.0, shape=(2, 3))
+    s3 = m.HalfNormal("s3", 1.0, shape=(3,))
+    m.Normal("y", z2 * s3, 1.0, observed=np.zeros((2, 3)))     # a broadcast between different shapes inside an element-wise factor
+    with pytest.raises(NotLowerable, match="broadcast|does not"):
         lower_to_spec(m)
     m = sg.StubModel()
     z = m.Normal("z", 0.0, 1.0, shape=(3,))
@@ -296,14 +303,24 @@ def test_shape_parameter_distributions_lower_to_the_builder_spec():
     nu = bad.HalfNormal("nu", 5.0)
     lc = bad.Normal("lc", 0.0, 1.0)
     bad._add(sg._RV("t", (), lambda v, n_, l_: sg.studentt_logp(v, n_, l_, 1.0), (nu, lc), None, y))
-    with pytest.raises(NotLowerable, match="non-constant nu"):
-        lower_to_spec(bad)
+    # a RANDOM nu / alpha was refused by name until round 5 ("the IR keeps nu constant"); now the density is lowered op by op and
+    # evaluates to what SciPy gives (tests/test_general_lowering.py pins the gradient against autograd of the graph)
+    from pymc_amd import model_spec as ms_
+
+    sp_ = lower_to_spec(bad)
+    assert sp_.factors[-1].dist == ms_.D_POTENTIAL and ms_.E_GAMMALN in [i.op for i in sp_.factors[-1].prog]
+    qq = np.array([0.7, -0.2])
+    want = stats.halfnorm(scale=5.0).logpdf(np.exp(qq[0])) + qq[0] + stats.norm(0, 1).logpdf(qq[1]) + stats.t(np.exp(qq[0]), qq[1], 1.0).logpdf(y).sum()
+    assert abs(ref_models.evaluate(sp_, qq)[0] - want) < 1e-10
     bad = sg.StubModel()
     al = bad.HalfNormal("al", 5.0)
     rate = bad.HalfNormal("rate", 2.0)
     bad._add(sg._RV("g", (), sg.gamma_logp, (al, sg.pt.reciprocal(rate)), None, w))
-    with pytest.raises(NotLowerable, match="non-constant alpha"):
-        lower_to_spec(bad)
+    sp_ = lower_to_spec(bad)
+    qq = np.array([0.3, 0.4])
+    want = (stats.halfnorm(scale=5.0).logpdf(np.exp(qq[0])) + qq[0] + stats.halfnorm(scale=2.0).logpdf(np.exp(qq[1])) + qq[1]
+            + stats.gamma(np.exp(qq[0]), scale=1.0 / np.exp(qq[1])).logpdf(w).sum())
+    assert abs(ref_models.evaluate(sp_, qq)[0] - want) < 1e-10
 
 
 def test_uniform_with_its_interval_transform_and_binomial_lower_to_the_builder_spec():
@@ -393,8 +410,13 @@ def test_truncated_normal_lowers_to_the_builder_spec(kw):
     loc = bad.Normal("loc", 0.0, 1.0)
     fake = lambda v, l_: sg.pt.switch(v > 2.0, -np.inf, sg.normal_logp(v, l_, 1.0) - sg.normal_lcdf(l_, 1.0, 1.9))   # noqa: E731
     bad._add(sg._RV("z", (), fake, (loc,), None, d))
-    with pytest.raises(NotLowerable):
-        lower_to_spec(bad)
+    # (round 5: such a density is no longer refused -- it is lowered op by op and evaluates to what it says, not to a TruncatedNormal)
+    from pymc_amd import model_spec as ms_
+
+    sp_ = lower_to_spec(bad)
+    assert sp_.factors[-1].dist == ms_.D_POTENTIAL and ms_.D_TRUNCNORMAL not in [f.dist for f in sp_.factors]
+    want = stats.norm(0, 1).logpdf(0.3) + (stats.norm(0.3, 1.0).logpdf(d) - stats.norm(0.3, 1.0).logcdf(1.9)).sum()
+    assert abs(ref_models.evaluate(sp_, np.array([0.3]))[0] - want) < 1e-10
 
 
 def test_composite_elemwise_nodes_are_inlined():
@@ -539,8 +561,10 @@ def test_committed_reference_graphs_are_current():
     if not sg.available():
         pytest.skip("needs /root/reference")
     committed = sg.load_models(lm.FIXTURE)
-    assert sorted(committed) == sorted(lm.ENTRIES)
-    for name, (make, _) in lm.ENTRIES.items():
+    makers = {name: make for name, (make, _) in lm.ENTRIES.items()}
+    makers.update(lm.GENERAL)
+    assert sorted(committed) == sorted(makers)
+    for name, make in makers.items():
         now = sg.dump_model(make())
         arrays_now, arrays_then = now.pop("arrays"), committed[name].pop("arrays")
         import json
