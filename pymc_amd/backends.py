@@ -136,7 +136,10 @@ class NDArray:
         x = np.empty_like(positions)                    # constrained values, spec layout
         for v in self.model.vars:
             blk = positions[:, v.offset : v.offset + v.size]
-            x[:, v.offset : v.offset + v.size] = backward(v, blk)
+            # (a simplex-transformed variable has K constrained elements for its K - 1 stored ones: no slot in this layout.  No
+            # Deterministic can refer to it -- the lowering leaves such a one out of the trace with a warning, `ModelBuilder` has no
+            # operand for it -- so its block keeps the stored values)
+            x[:, v.offset : v.offset + v.size] = blk if getattr(v, "simplex", False) else backward(v, blk)
         for nm, (prog, term, size) in self._dets:
             val = eval_program(self.model, prog, term, x)
             self.samples[nm][i : i + len(positions)] = np.broadcast_to(val, (len(positions), size)).reshape((len(positions), *self.var_shapes[nm]))

@@ -1426,7 +1426,7 @@ class _Lowering:
             if res is None:
                 continue
             nodes, konst = res
-            if dist == ms.D_POISSON and nodes["mu"][0] == "exp" and self._glm(ms.GLM_POISSON, nodes["mu"][1], nodes["value"][1]):
+            if dist == ms.D_POISSON and nodes["mu"][0] == "exp" and nodes["value"][0] == "const" and self._glm(ms.GLM_POISSON, nodes["mu"][1], nodes["value"][1]):
                 self.spec.glm_rows.name = name
                 return
             lowered = {a: self.term(nodes[a]) for a in argnames[1:] + argnames[:1]}
@@ -1472,11 +1472,33 @@ def _show(node, depth=0) -> str:
     return node[0] + "(" + ", ".join(_show(k, depth + 1) if isinstance(k, tuple) else str(k) for k in node[1:]) + ")"
 
 
-def lower_to_spec(model) -> ms.ModelSpec:
-    """`model` needs: `value_vars` (ordered; `.name`, static shape via `model.value_shapes[name]` or `.type.shape`),
+def as_model_spec(model) -> ms.ModelSpec:
+    """What `NUTS(model=...)` / `sample(model=...)` accept: a `ModelSpec`, an object that carries one (`.spec`), or a MODEL OBJECT
+    with the protocol of `lower_to_spec` (`value_vars`, `logp(sum=False)`; a `pm.Model` with the few derived attributes listed there),
+    which is lowered here -- the step method's constructor is where the reference compiles the model too (`GradientSharedStep.__init__`,
+    arraystep.py:174-205 -> `model.logp_dlogp_function`).  A graph outside the IR raises `NotLowerable` (a `NotImplementedError`):
+    the caller keeps the reference's own CPU step method for that model."""
+    if isinstance(model, ms.ModelSpec):
+        return model
+    spec = getattr(model, "spec", None)
+    if isinstance(spec, ms.ModelSpec):
+        return spec
+    if hasattr(model, "value_vars") and callable(getattr(model, "logp", None)):
+        return lower_to_spec(model)
+    raise TypeError("model must be a pymc_amd ModelSpec, carry one as `.spec`, or be a model object `lower_to_spec` can walk (`value_vars`, `logp(sum=False)`)")
+
+
+def lower_to_spec(model, vars=None) -> ms.ModelSpec:
+    """`vars` (optional): the value variables the step method samples -- they must be `model.value_vars` (every continuous value
+    variable in the model's order: the one NUTS step of `assign_step_methods`); value variables another step method updates are
+    `model.extra_vars`.
+
+    `model` needs: `value_vars` (ordered; `.name`, static shape via `model.value_shapes[name]` or `.type.shape`),
     `rvs_to_transforms`-derived `model.value_transforms[name] -> (code, lower, upper)` (or transform objects with a `.name` in
     {"log", "logodds", "interval"}), `logp(sum=False)` and the aligned list `model.logp_owners` = the value variable of each free
     RV factor (None for observed RVs / potentials) -- on a real `pm.Model`: `[model.rvs_to_values[rv] for rv in free_RVs]`."""
+    if vars is not None and [id(v) for v in vars] != [id(v) for v in model.value_vars]:
+        raise NotLowerable("the step's variables must be the model's continuous value variables, in the model's order")
     shapes, transforms = {}, {}
     for v in model.value_vars:
         shp = getattr(model, "value_shapes", {}).get(v.name)

@@ -131,6 +131,8 @@ def init_nuts(
             rng = np.random.default_rng(seed)
             for i in range(jitter_max_retries + 1):
                 cand = _jitter_point(p, seed, extra=spec.extra)
+                if getattr(spec, "extra", None):     # the non-gradient inputs of THIS candidate (an `initvals` entry of a discrete variable)
+                    _push_extras(spec, logp_dlogp_func, cand)
                 lp, _ = logp_dlogp_func._pytensor_function(DictToArrayBijection.map(_grad_part(spec, cand)).data)
                 if np.isfinite(lp):
                     break
@@ -270,6 +272,18 @@ def _sample_compound(comp, spec, points, rngs, mine, tune, draws, discard_tuned_
 def assign_chains(chains: int, rank: int, world: int) -> List[int]:
     """chain c <-> rank c % world (one chain per GPU when chains == world)."""
     return [c for c in range(chains) if c % world == rank]
+
+
+def _push_extras(spec, func, point):
+    """`set_extra_values` for a point: the spec's extra inputs, those that are FUNCTIONS of a discrete variable another step method
+    samples (the mixture link's `c__*` vectors) derived from the point's own value of that variable, as `NUTS.step` does."""
+    extras = {k: point[k] for k in spec.extra if k in point}
+    link = getattr(spec, "mixture", None)
+    if link is not None and link.name in point and any(name.startswith(link.name + "__") for name in spec.extra):
+        derived = link.extras_for(np.asarray(point[link.name]))
+        extras.update({name: derived[name] for name in spec.extra if name in derived})
+    if extras:
+        func.set_extra_values(extras)
 
 
 def sample_draws(step: NUTS, point, K: int, callback=None, first_index: int = 0, each_draw=None):
@@ -428,7 +442,9 @@ def sample(
     (`pymc_amd/parallel.py`); the result is the one sequential sampling gives.
     """
     rank, world, local = _dist_info()
-    spec = model
+    from pymc_amd.lowering import as_model_spec
+
+    spec = model = as_model_spec(model)      # a ModelSpec, or a model object whose graphs are lowered here (`NotLowerable` otherwise)
     if device is None and world > 1:
         device = local
     # mcmc.py:907-908 -- every rank derives ALL chain generators so chain c is the same stream on any layout
@@ -463,7 +479,7 @@ def sample(
     # `model.check_start_vals` (mcmc.py:883-887, model/core.py:1319-1373): the log-density must be finite where a chain starts
     for c in mine:
         if getattr(spec, "extra", None):
-            grad_step._logp_dlogp_func.set_extra_values({k: points[c][k] for k in spec.extra if k in points[c]})
+            _push_extras(spec, grad_step._logp_dlogp_func, points[c])
         lp, _ = grad_step._logp_dlogp_func._pytensor_function(DictToArrayBijection.map({k: points[c][k] for k in grad_step.var_names}).data)
         if not np.isfinite(lp):
             from pymc_amd.exceptions import SamplingError
@@ -515,7 +531,7 @@ def sample(
     latency_bound = single_launch
     try:
         latency_bound = latency_bound or 0 < int(step._logp_dlogp_func.algorithmic_bytes) < CONCURRENT_CHAINS_BELOW_BYTES
-    except (AttributeError, EngineError):   # (a user's logp_dlogp_func without the engine's size query: one chain at a time)
+    except (AttributeError, EngineError, ValueError):   # (a user's logp_dlogp_func without the engine's size query: one chain at a time)
         pass
     n_par = min(len(mine), cores if cores is not None else (4 if latency_bound else 1))
     if n_par > 1:
@@ -570,12 +586,18 @@ def sample(
                         local_stats[k] = s
                         t_worker += sum(x["perf_counter_diff"] for x in s[tune:])
                     t_sampling = max(t_sampling, t_worker)   # (the workers overlap: the sampling time is the slowest worker's, not the sum)
-        finally:
-            if group is not None:
-                lockstep_launches = group.launches()
-                group.close()
-            for st in steps[1:]:
-                st.close()
+        finally:   # (always close the group and the extra engines: a failing `launches()` must neither leak them nor mask the error)
+            try:
+                if group is not None:
+                    try:
+                        lockstep_launches = group.launches()
+                    except Exception:      # noqa: BLE001 -- diagnostics only
+                        lockstep_launches = None
+                    finally:
+                        group.close()
+            finally:
+                for st in steps[1:]:
+                    st.close()
     else:
         for k, c in enumerate(mine):
             step.sampling_state = initial_state

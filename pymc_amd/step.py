@@ -230,11 +230,15 @@ class _DeviceHMCBase:
         (pymc/sampling/parallel.py:504-507 cloudpickles the step for `spawn` / `forkserver` workers)."""
         if unknown:   # a typo or an unsupported option must not pass silently
             raise TypeError(f"{type(self).__name__}.__init__() got unexpected keyword argument(s): {sorted(unknown)}")
-        spec = model.spec if hasattr(model, "spec") else model
         if logp_dlogp_func is not None:
             spec = logp_dlogp_func.spec
-        if not isinstance(spec, ModelSpec):
-            raise TypeError("model must be a pymc_amd ModelSpec (or carry `.spec`) when logp_dlogp_func is not given")
+        else:
+            # a ModelSpec, an object carrying one, or a MODEL OBJECT whose log-density graphs are lowered here -- where the reference's
+            # step method compiles the model (arraystep.py:174-205); `NotLowerable` (a NotImplementedError) tells the caller to keep the
+            # reference's CPU step for this model
+            from pymc_amd.lowering import as_model_spec
+
+            spec = as_model_spec(model)
         # (the reference accepts only ONE of the two class attributes, compound.py:62-99; `BlockedStep.__new__` derives the
         # deprecated list per instance, and so does this class when it is used without that base)
         if not self.__dict__.get("stats_dtypes"):

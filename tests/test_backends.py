@@ -257,3 +257,31 @@ def test_a_compound_result_carries_the_discrete_variable_into_the_trace():
     groups = to_inference_dict(tr)
     assert groups["posterior"]["c"].shape == (2, 6, 30) and groups["posterior"]["w"].shape == (2, 6, 3)
     assert groups["sample_stats"]["n_steps"].shape == (2, 6)
+
+
+def test_a_deterministic_next_to_dirichlet_mixture_weights_is_recorded():
+    """a simplex-transformed variable (K constrained elements for K - 1 stored ones) next to a `Deterministic` crashed
+    `record` / `record_batch` (the constrained layout had no slot for the K weights).  The Deterministic cannot refer to the weights;
+    everything else is recorded as before."""
+    import numpy as np
+
+    from pymc_amd.backends import NDArray
+    from pymc_amd.model_spec import ModelBuilder
+
+    b = ModelBuilder()
+    w = b.Dirichlet("w", np.array([1.0, 2.0, 3.0]))
+    mu = b.Normal("mu", 0.0, 5.0, shape=3)
+    b.Deterministic("mu2", mu * 2.0)
+    b.NormalMixture("y", w, mu, 1.0, observed=np.array([0.1, -0.3, 2.0, 1.4]))
+    spec = b.build()
+    t = NDArray(model=spec)
+    t.setup(5, 0)
+    pts = np.random.default_rng(0).normal(size=(4, spec.n))
+    t.record_batch(pts, None)
+    point = {v.value_name: pts[0, v.offset:v.offset + v.size].reshape(v.shape) for v in spec.vars}
+    t.record(point)
+    t.close()
+    mu_v = spec.vars[1]
+    np.testing.assert_allclose(t.get_values("mu2")[:4], 2.0 * pts[:, mu_v.offset:mu_v.offset + 3], rtol=1e-15)
+    np.testing.assert_allclose(t.get_values("mu2")[4], t.get_values("mu2")[0], rtol=0)
+    assert t.get_values("w").shape == (5, 3) and np.allclose(t.get_values("w").sum(axis=1), 1.0)

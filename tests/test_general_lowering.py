@@ -159,3 +159,37 @@ def test_device_kills_the_factor_of_a_failed_parameter_check():
         assert (lp == lp0 == -np.inf) if q[0] < 0 else abs(lp - lp0) <= 1e-12 * abs(lp0)
         assert np.max(np.abs(g - g0)) <= 1e-12 * max(1.0, np.max(np.abs(g0)))
     f.close()
+
+
+def test_a_model_object_that_is_outside_the_ir_raises_notlowerable_from_the_step_constructor():
+    """`NUTS(model=<model object>)` lowers inside its constructor; what the IR cannot express raises
+    `NotLowerable` (a NotImplementedError) BEFORE any device handle exists, so the caller's `except` keeps the reference's CPU step."""
+    from pymc_amd.lowering import NotLowerable, as_model_spec
+    from pymc_amd.step import NUTS
+
+    if not sg.available():
+        pytest.skip("builds a graph with the reference's code")
+    m = sg.StubModel()
+    z2 = m.Normal("z2", 0.0, 1.0, shape=(2, 3))
+    s3 = m.HalfNormal("s3", 1.0, shape=(3,))
+    m.Normal("y", (z2 * s3).sum(axis=1), 1.0, observed=np.zeros(2))     # a reduction inside a likelihood's parameter
+    with pytest.raises(NotLowerable):
+        NUTS(model=m, defer_device=True)
+    with pytest.raises(NotImplementedError):
+        as_model_spec(m)
+    with pytest.raises(TypeError):
+        as_model_spec(object())
+    ok = NUTS(model=lm.GENERAL["robust_regression"](), defer_device=True)      # host side only: no GPU needed
+    assert ok.spec.n == 4 and [v.value_name for v in ok.vars] == ["a", "b", "sigma_log__", "nu_log__"]
+
+
+@pytest.mark.gpu
+def test_a_model_object_goes_through_the_step_constructor_in_one_call():
+    """model object -> `sample(model=...)` (which builds `NUTS(model=...)`) -> draws, in one call; the same draws as from the lowered spec."""
+    from pymc_amd.sampling import sample
+
+    m = sg.FrozenModel(sg.load_models(lm.FIXTURE)["hierarchical_regression_noncentred"])
+    a = sample(draws=8, tune=16, chains=1, model=m, init="adapt_diag", random_seed=3, device=0)
+    b = sample(draws=8, tune=16, chains=1, model=lower_to_spec(m), init="adapt_diag", random_seed=3, device=0)
+    assert np.array_equal(a["draws"], b["draws"]) and a["draws"].shape == (1, 8, 11)
+    a["step"].close(); b["step"].close()
