@@ -125,6 +125,7 @@ struct nuts_model {
   int n_chains = 0;            // chains created on this model
   std::vector<int32_t> derived;   // NUTS_D_DERIVED factors (compile_spec)
   int64_t pool_extra = 0;         // doubles behind the spec's data pool: (values, seed) of every derived vector
+  int64_t rows_xt_len = 0, rows_y_len = 0;   // group-aligned row pass: elements of the tiled X / y copies (chain groups compare them)
 
   template <typename T>
   T* keep(T* p) {
@@ -159,16 +160,24 @@ struct nuts_group {
   std::atomic<unsigned> gen{0};
   MvaLeafArgs pend[MVM_MAXC];
   int64_t launches[MVM_MAXC + 1] = {};   // submitted launches by the number of chains they carried
+  // kind of the members' models: 1 = one MvNormal node on the row-aligned pass (mvn_multi_kernel.h), 2 = the hierarchical-logit rows
+  // on the group-aligned pass (rows_ga_multi_kernel.h); fixed by the first member
+  int kind = 0;
+  GaLeafArgs gpend[GAM_MAXC];
+  int rows_flip = 0;
 };
+static_assert(GAM_MAXC == MVM_MAXC, "one group size");
 
 static nuts_model* group_base(nuts_group* g) {   // whose copy of (P, mu) every launch reads: one copy stays cache-resident
   for (int i = 0; i < MVM_MAXC; ++i) if (g->member[i]) return g->member[i];
   return nullptr;
 }
 
+static void group_flush_rows_locked(nuts_group* g);
 static void group_flush_locked(nuts_group* g) {
   const int nc = g->npend;
   if (!nc) return;
+  if (g->kind == 2) { group_flush_rows_locked(g); return; }
   const ModelDev& md = group_base(g)->md;
   const dim3 grid(MVM_MAXC + md.mv.al_nwg);
   int order[MVM_MAXC] = {0, 1, 2, 3};   // (by place in the group, not by arrival: the launch does not depend on who came first)
@@ -195,6 +204,63 @@ static void group_flush_locked(nuts_group* g) {
   g->gen.fetch_add(1, std::memory_order_release);
 }
 
+// The merged launch of the group-aligned row pass: the base member's model (X, y, the closed-form priors), every pending chain's
+// own arena / records / tickets.  Register budget by the number of chains: two sets of accumulators still fit the single-chain
+// kernel's 128 registers (five workgroups of W waves per CU: all groups resident), three and four need the 168-register budget.
+static void group_flush_rows_locked(nuts_group* g) {
+  const int nc = g->npend;
+  const nuts_model* base = group_base(g);
+  const ModelDev& md = base->md;
+  const dim3 grid(GAM_MAXC + md.lg.G), block(WAVE * md.lg.ga_w);
+  int order[GAM_MAXC] = {0, 1, 2, 3};   // (by place in the group, not by arrival)
+  for (int a = 1; a < nc; ++a)
+    for (int b = a; b > 0 && g->gpend[order[b]].slot < g->gpend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
+  const int rev = base->rows_alternate ? (g->rows_flip ^= 1) : 0;
+#define GAM_LAUNCH(NC, OCC, DXX)                                                                                     \
+  {                                                                                                                  \
+    GaMultiArgs<NC> ma;                                                                                              \
+    for (int c = 0; c < NC; ++c) ma.c[c] = g->gpend[order[c]];                                                       \
+    ma.rev = rev; ma.pad = 0;                                                                                        \
+    hipLaunchKernelGGL((k_rows_ga_multi<NC, OCC, DXX>), grid, block, 0, g->stream, md, ma);                          \
+  }
+#define GAM_BY_NC(DXX)                                                                                               \
+  switch (nc) {                                                                                                      \
+    case 1: GAM_LAUNCH(1, 4, DXX) break;                                                                             \
+    case 2: GAM_LAUNCH(2, 3, DXX) break;                                                                             \
+    case 3: GAM_LAUNCH(3, 3, DXX) break;                                                                             \
+    default: GAM_LAUNCH(4, 3, DXX) break;                                                                            \
+  }
+  if (md.lg.ga_dx == 7) GAM_BY_NC(7) else GAM_BY_NC(8)
+#undef GAM_BY_NC
+#undef GAM_LAUNCH
+  g->launches[nc]++;
+  g->npend = 0;
+  g->gen.fetch_add(1, std::memory_order_release);
+}
+
+// A deposit waits until the launch that carries it has been submitted -- by the partner that completes the set of chains standing
+// inside a tree.  The wait is bounded: every partner is inside engine code with no callback into Python, so a launch follows within
+// microseconds; should one not come for GROUP_WAIT_S seconds (a partner's thread died, a debugger holds it), the waiter submits
+// what is pending itself and goes on -- lockstep is an optimisation, never a condition of progress.
+#define GROUP_WAIT_S 2.0
+static void group_wait(nuts_group* g, unsigned mine) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; g->gen.load(std::memory_order_acquire) == mine; ++spins) {
+    if ((spins & 0x3ff) != 0x3ff) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#endif
+      continue;
+    }
+    std::this_thread::yield();
+    if ((spins & 0xfffff) == 0xfffff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > GROUP_WAIT_S) {
+      std::lock_guard<std::mutex> lk(g->mu);
+      if (g->gen.load(std::memory_order_relaxed) == mine) group_flush_locked(g);
+      return;
+    }
+  }
+}
+
 static void group_deposit(nuts_model* m, const MvaLeafArgs& L) {
   nuts_group* g = m->group;
   unsigned mine;
@@ -204,10 +270,19 @@ static void group_deposit(nuts_model* m, const MvaLeafArgs& L) {
     mine = g->gen.load(std::memory_order_relaxed);
     if (g->npend >= g->nactive) { group_flush_locked(g); return; }
   }
-  for (unsigned spins = 0; g->gen.load(std::memory_order_acquire) == mine; ++spins) {
-    if ((spins & 0x3ff) == 0x3ff) std::this_thread::yield();
-    else __builtin_ia32_pause();
+  group_wait(g, mine);
+}
+
+static void group_deposit(nuts_model* m, const GaLeafArgs& L) {
+  nuts_group* g = m->group;
+  unsigned mine;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->gpend[g->npend++] = L;
+    mine = g->gen.load(std::memory_order_relaxed);
+    if (g->npend >= g->nactive) { group_flush_locked(g); return; }
   }
+  group_wait(g, mine);
 }
 
 static void group_enter(nuts_model* m) {
@@ -313,6 +388,16 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
       ga.fold = GA_FOLD_CTL | (job->src_prev ? GA_FOLD_SRC : 0);
       ga.cio = job->io; ga.cj = job->j; ga.cd = job->d; ga.cseq = job->seq;
     }
+    if (m->group && m->g_active && io.mode == MODE_TREE && m->group->kind == 2) {
+      // a member of a chain group inside a tree: the launch is deposited; the partner that completes the set submits ONE launch
+      // that streams X once for all of them (rows_ga_multi_kernel.h)
+      GaLeafArgs L;
+      L.A = A; L.io = io; L.cio = ga.cio; L.Emax = Emax; L.st = st;
+      L.ga_part = md.lg.ga_part; L.ga_bpart = md.lg.ga_bpart; L.ga_ticket = md.lg.ga_ticket; L.def_loc = md.def_loc;
+      L.j = j; L.fold = ga.fold; L.par = par; L.d = d; L.max_depth = max_depth; L.cj = ga.cj; L.cd = ga.cd; L.cseq = ga.cseq;
+      L.slot = m->gslot; L.pad = 0;
+      group_deposit(m, L);
+    } else
     if (md.lg.ga_gpw) {   // group-block pass (small groups): same arguments, same protocol
       switch (md.lg.D) {
         case 8: if (md.lg.ga_dx == 7) hipLaunchKernelGGL((k_rows_gb<8, 7>), grid, block, 0, m->stream, ga);
@@ -931,6 +1016,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         }
         lg.Xt = m->keep(dev_upload(xt.data(), xt.size()));
         lg.y = m->keep(dev_upload(yy.data(), yy.size()));
+        m->rows_xt_len = (int64_t)xt.size(); m->rows_y_len = (int64_t)yy.size();
         lg.ga_coff = m->keep(dev_upload(coff.data(), coff.size()));
         lg.ga_tile0 = m->keep(dev_upload(tile0.data(), tile0.size()));
         lg.ga_part = m->keep(dev_alloc<double>((size_t)lg.G * PART_STRIDE));
@@ -1292,6 +1378,12 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   else if (k == "lean") *out = m->md.lean_ok;
   else if (k == "tree_kernel_ok") *out = m->ga_tree_ok;
   else if (k == "rows_stored_columns") *out = m->md.lg.ga ? m->md.lg.ga_dx : m->md.lg.D;
+  else if (k == "chain_group_kind") {   // what a chain group of this model's chains would merge: 0 nothing, 1 the MvNormal row-aligned pass, 2 the group-aligned row pass
+    const RowsDev& lg = m->md.lg;
+    const bool is_mvn = m->md.has_mvn && (m->md.mv.aligned == 4 || m->md.mv.aligned == 8);
+    const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && !lg.ga_gpw && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && m->ga_variant == 42;
+    *out = is_mvn ? 1.0 : (is_rows ? 2.0 : 0.0);
+  }
   else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
@@ -1761,13 +1853,45 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   const MvnDev& mv = m->md.mv;
   if (m->group) { g_err = "nuts_group_add: the chain's model already belongs to a group"; return NUTS_E_ARG; }
   if (m->n_chains != 1) { g_err = "nuts_group_add: a member model carries exactly one chain (its launch parity and records are the chain's)"; return NUTS_E_ARG; }
-  if (!(m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8)) || c->dense || c->host_pot) {
-    g_err = "nuts_group_add: chain groups advance models that are one constant-covariance MvNormal node on the row-aligned pass "
-            "(diagonal mass matrix); this chain is not one";
+  const RowsDev& lg = m->md.lg;
+  const bool is_mvn = m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8);
+  // the hierarchical-logit rows on the group-aligned pass, closed-form model (the benchmark's), D = 8: rows_ga_multi_kernel.h
+  const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && !lg.ga_gpw && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && m->ga_variant == 42;
+  if (!(is_mvn || is_rows) || c->dense || c->host_pot) {
+    g_err = "nuts_group_add: chain groups advance models that are one constant-covariance MvNormal node on the row-aligned pass or the "
+            "hierarchical-logit rows on the group-aligned pass (diagonal mass matrix); this chain is neither";
     return NUTS_E_ARG;
   }
   if (g->n >= MVM_MAXC) { g_err = "nuts_group_add: a group holds at most 4 chains"; return NUTS_E_ARG; }
+  if (g->n > 0 && g->kind != (is_rows ? 2 : 1)) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(m->stream));
+  if (is_rows) {
+    if (nuts_model* base = group_base(g)) {
+      // every launch streams the first member's copy of (X, y): the newcomer's must be the same numbers in the same layout
+      const RowsDev& bl = base->md.lg;
+      if (bl.N != lg.N || bl.G != lg.G || bl.D != lg.D || bl.ga_dx != lg.ga_dx || bl.ga_w != lg.ga_w || bl.Npad != lg.Npad || bl.ga_T_uni != lg.ga_T_uni ||
+          bl.ga_cstride_uni != lg.ga_cstride_uni || bl.ga_bsz != lg.ga_bsz || bl.ga_nrec != lg.ga_nrec || bl.sigma_tr != lg.sigma_tr ||
+          bl.off_mu != lg.off_mu || bl.off_sigma != lg.off_sigma || bl.off_z != lg.off_z || base->md.n != m->md.n ||
+          std::memcmp(&bl.z_np_mu, &lg.z_np_mu, 8 * sizeof(double)) != 0) {
+        g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG;
+      }
+      const size_t nx = (size_t)base->rows_xt_len, ny = (size_t)base->rows_y_len;
+      if (nx != (size_t)m->rows_xt_len || ny != (size_t)m->rows_y_len) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
+      // (compared in slabs: X is 320 MB at the benchmark's shape)
+      const size_t slab = (size_t)1 << 22;
+      std::vector<double> a(slab), b(slab);
+      for (size_t o = 0; o < nx; o += slab) {
+        const size_t k = std::min(slab, nx - o);
+        HIPCHK(hipMemcpy(a.data(), bl.Xt + o, k * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b.data(), lg.Xt + o, k * sizeof(double), hipMemcpyDeviceToHost));
+        if (std::memcmp(a.data(), b.data(), k * sizeof(double)) != 0) { g_err = "nuts_group_add: not the same model as the group's (the design matrices differ)"; return NUTS_E_ARG; }
+      }
+      std::vector<int8_t> ya(ny), yb(ny);
+      HIPCHK(hipMemcpy(ya.data(), bl.y, ny, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(yb.data(), lg.y, ny, hipMemcpyDeviceToHost));
+      if (std::memcmp(ya.data(), yb.data(), ny) != 0) { g_err = "nuts_group_add: not the same model as the group's (the observations differ)"; return NUTS_E_ARG; }
+    }
+  } else
   if (nuts_model* base = group_base(g)) {
     // every launch reads the first member's (P, mu): the newcomer's must be the same numbers
     const MvnDev& bv = base->md.mv;
@@ -1784,6 +1908,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   for (int i = 0; i < MVM_MAXC; ++i)
     if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
   g->n++;
+  g->kind = is_rows ? 2 : 1;
   m->group = g;
   m->stream = g->stream;
   return NUTS_OK;

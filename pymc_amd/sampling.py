@@ -533,7 +533,15 @@ def sample(
         latency_bound = latency_bound or 0 < int(step._logp_dlogp_func.algorithmic_bytes) < CONCURRENT_CHAINS_BELOW_BYTES
     except (AttributeError, EngineError, ValueError):   # (a user's logp_dlogp_func without the engine's size query: one chain at a time)
         pass
-    n_par = min(len(mine), cores if cores is not None else (4 if latency_bound else 1))
+    # ... unless its chains can advance through ONE launch per leapfrog that streams the data once for all of them (the
+    # group-aligned row pass, csrc/rows_ga_multi_kernel.h: the pass is then bound by its arithmetic, not by HBM)
+    rows_group = False
+    if lockstep is not False:
+        try:
+            rows_group = int(step._logp_dlogp_func.model_scalar("chain_group_kind")) == 2 and not getattr(step.potential, "_dense", False)
+        except (AttributeError, EngineError, ValueError):
+            pass
+    n_par = min(len(mine), cores if cores is not None else (4 if (latency_bound or rows_group) else 1))
     if n_par > 1:
         logging.getLogger("pymc_amd").info("sampling %d chains on one GPU, %d at a time (host threads, one engine each)", len(mine), n_par)
     if pooled is not None or step_given or n_par < 1:

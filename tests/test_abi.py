@@ -129,7 +129,8 @@ def test_streaming_kernels_hold_their_tiles_in_registers(lib, tmp_path):
         scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
         if name and spills and scratch:
             kernels[name.group(1)] = (int(spills.group(1)), int(scratch.group(1)))
-    ga = {k: v for k, v in kernels.items() if re.match(r"_Z\d+k_rows_ga", k)}
+    # (`k_rows_ga_multi`, the chain-group form, uses ordinary loads -- csrc/rows_ga_multi_kernel.h says why -- and is not part of this guard)
+    ga = {k: v for k, v in kernels.items() if re.match(r"_Z\d+k_rows_gaI", k)}
     assert len(ga) >= 8, sorted(kernels)[:10]
     # the group-block pass (rows_gb_kernel.h) uses ordinary loads; it is held to the same bar because a spill inside its short
     # per-group loop would cost more than the loop itself (`k_vector`, which it replaces at C2-S, carries 144 B of scratch)

@@ -157,3 +157,36 @@ def test_what_a_group_refuses():
     g2.close()
     for st in (a, b, c):
         st.close()
+
+
+# ---- the hierarchical-logit rows on the group-aligned pass (csrc/rows_ga_multi_kernel.h) --------------------------------------
+@pytest.mark.parametrize("G,rpg,chains,tune,draws", [(40, 300, 4, 30, 12), (24, 517, 3, 20, 8), (64, 130, 2, 20, 8)])
+def test_grouped_chains_of_the_logit_rows_are_bitwise_the_chains_alone(G, rpg, chains, tune, draws, monkeypatch):
+    """The benchmark's model (BASELINE configs[1]) at small sizes, forced onto the group-aligned pass: chains sampled one after the
+    other, and concurrently as a chain group whose launches stream X once for all chains standing at a leaf.  rpg = 517: a padded
+    last tile; 130: a single tile and a bit; chains = 3, 2: the three- and two-chain instantiations (four: also chains that leave)."""
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    spec = models.hier_logit(G=G, D=8, rows_per_group=rpg, seed=3)
+    alone = _sample(spec, chains, False, 1, tune, draws, 17)
+    group = _sample(spec, chains, True, chains, tune, draws, 17)
+    assert alone["lockstep_launches"] is None
+    n = group["lockstep_launches"]
+    assert n is not None and sum(n[2:]) > 0, n
+    assert np.array_equal(alone["draws"], group["draws"]), (G, rpg)
+    for c in range(chains):
+        _same_stats(alone["stats"][c], group["stats"][c], (G, rpg, c))
+    sizes = [[int(s["tree_size"]) for s in group["stats"][c]] for c in range(chains)]
+    assert len({tuple(s) for s in sizes}) == chains
+    print(f"G = {G} x {rpg}: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, 5)) / sum(n[1:]):.2f}")
+
+
+def test_sample_groups_the_chains_of_the_benchmark_model_by_default(monkeypatch):
+    """`sample(chains=2)` of a model on the group-aligned pass, nothing else said: the chains run concurrently as a chain group (the
+    pass is HBM-bound for one chain; two chains share one read of X)."""
+    from pymc_amd.sampling import sample
+
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    res = sample(draws=5, tune=10, chains=2, model=models.hier_logit(G=32, D=8, rows_per_group=260, seed=1), random_seed=3, device=0)
+    res["step"].close()
+    n = res["lockstep_launches"]
+    assert n is not None and sum(n[1:]) > 0, n
