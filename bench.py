@@ -480,29 +480,32 @@ def run_rank(args):
                        "sampling_s_post_warmup": float(sum(s_["perf_counter_diff"] for s_ in st_post)),
                        "step_size_bar": float(st_all[-1]["step_size_bar"]), "convergence": cv}
             if world == 1 and args.ess_chains > 1:
-                # the same run with several chains on this GPU, one after the other (the reference's
-                # `pm.sample(chains=4, cores=1)`, mcmc.py:1385-1430), so that min-ESS and R-hat are multi-chain estimates -- the
-                # reference's benchmark divides the ESS of ALL chains by the total sampling time (benchmarks.py:180-198)
-                post = [d_all[args.ess_tune:]]
-                walls = [wall]
-                more = get_random_generator(args.seed + 1).spawn(args.ess_chains)
-                for cc in range(1, args.ess_chains):
-                    # (U(-1, 1) around the model's initial point, as `jitter+adapt_diag` starts every chain: mcmc.py:1695-1756)
-                    from pymc_amd.sampling import _jitter_point, initial_point
+                # The same run with several chains on this GPU (the reference's `pm.sample(chains=4)`, mcmc.py:1385-1430), so that
+                # min-ESS and R-hat are multi-chain estimates -- the reference's benchmark divides the ESS of ALL chains by the total
+                # sampling time (benchmarks.py:180-198).  Round 5: the chains run CONCURRENTLY as a chain group where the engine can
+                # merge their leapfrog launches (the group-aligned row pass streams X once for all chains standing at a leaf,
+                # csrc/rows_ga_multi_kernel.h; draws bitwise those of the chains alone), one after the other otherwise.
+                from pymc_amd.sampling import sample
 
-                    start = _jitter_point(initial_point(spec), int(more[cc].integers(2**30)), extra=spec.extra)
-                    step.sampling_state = initial_state
-                    t2 = time.perf_counter()
-                    d_c, _ = sample_chain(step, start, more[cc], args.ess_tune, args.ess_draws)
-                    walls.append(time.perf_counter() - t2)
-                    post.append(d_c[args.ess_tune:])
-                stack = np.stack(post)
+                t2 = time.perf_counter()
+                res_mc = sample(draws=args.ess_draws, tune=args.ess_tune, chains=args.ess_chains, model=spec, init="jitter+adapt_diag",
+                                random_seed=args.seed + 1, device=device)
+                wall_mc = time.perf_counter() - t2
+                res_mc["step"].close()
+                stack = res_mc["draws"]
                 ess_c, rh_c = ess_bulk_many(stack), rhat_many(stack)
+                n_l = res_mc["lockstep_launches"]
+                lf_post = float(sum(s_["tree_size"] for c_ in range(args.ess_chains) for s_ in res_mc["stats"][c_]))
                 ess_run["multi_chain"] = {
-                    "chains": args.ess_chains, "how": "one after the other on this GPU, each tuned on its own from a jittered start",
-                    "wall_s_total": float(sum(walls)), "wall_s_per_chain": [float(x) for x in walls],
+                    "chains": args.ess_chains,
+                    "how": ("concurrently as a chain group: one launch per leapfrog streams the data once for the chains standing at a leaf"
+                            if n_l else "one after the other on this GPU") + ", each tuned on its own from a jittered start",
+                    "wall_s_total": float(wall_mc), "sampling_s": float(res_mc["wall_time"]), "sampling_s_post_warmup": float(res_mc["sampling_time"]),
                     "min_ess": float(ess_c.min()), "median_ess": float(np.median(ess_c)), "rhat_max": float(np.nanmax(rh_c)),
-                    "n_rhat_gt_1.01": int((rh_c > 1.01).sum()), "ess_per_sec": float(ess_c.min() / sum(walls)),
+                    "n_rhat_gt_1.01": int((rh_c > 1.01).sum()), "ess_per_sec": float(ess_c.min() / res_mc["wall_time"]),
+                    "aggregate_leapfrog_steps_per_sec_post_warmup": lf_post / float(res_mc["sampling_time"]),
+                    "launches_by_chains_carried": n_l[1:] if n_l else None,
+                    "mean_chains_per_launch": (sum(c_ * n_l[c_] for c_ in range(1, 5)) / max(1, sum(n_l[1:]))) if n_l else None,
                 }
         if c3:
             workload = f"C3 mvn-{args.mvn_k}: MvNormal, full {args.mvn_k}x{args.mvn_k} covariance, n={spec.n}"

@@ -500,6 +500,17 @@ int nuts_gibbs_plan(nuts_pcg64 *rng, int64_t n, int32_t shuffle, int32_t *order 
                     const int32_t *k_of_dim /* [n] categories of each dimension */, int32_t *cand_raw /* [n] */,
                     double *uniform /* [n] */);
 
+/* The two halves of nuts_gibbs_plan as calls of their own, and a jump over the second one: the per-element draws of sweep k and the
+ * shuffle of sweep k + 1 can then be replayed at the same time on two host threads (the replay, not the device, sets the pace of
+ * the compound step at n = 100 000).  `nuts_gibbs_plan_shuffle`: `rng.shuffle(dimcats)` only.  `nuts_gibbs_plan_draws`: the
+ * per-element `rng.choice(k - 1)` / `rng.uniform()` from the generator as it stands; `*clean` = 1 when every dimension has the same
+ * k and no bounded draw was rejected -- the assumptions of `nuts_gibbs_plan_skip(rng, n, k)`, which advances the generator over
+ * those n elements without producing them (PCG64 jump-ahead, the buffered 32-bit half included). */
+int nuts_gibbs_plan_shuffle(nuts_pcg64 *rng, int64_t n, int32_t *order /* [n] in/out */);
+int nuts_gibbs_plan_draws(nuts_pcg64 *rng, int64_t n, const int32_t *order, const int32_t *k_of_dim, int32_t *cand_raw /* [n] */,
+                          double *uniform /* [n] */, int32_t *clean);
+int nuts_gibbs_plan_skip(nuts_pcg64 *rng, int64_t n, int32_t k);
+
 typedef struct nuts_gibbs nuts_gibbs;
 nuts_gibbs *nuts_gibbs_create(int64_t n, int32_t K, const double *y /* [n] observations */);
 void nuts_gibbs_destroy(nuts_gibbs *g);

@@ -246,6 +246,9 @@ SYMBOLS = {
     "nuts_chain_welford_import": (C.c_int, [_VP, _VP]),
     "nuts_chain_set_log_step_bar": (C.c_int, [_VP, C.c_double, C.c_double]),
     "nuts_gibbs_plan": (C.c_int, [C.POINTER(Pcg64), C.c_int64, C.c_int32, _VP, _VP, _VP, _PD]),
+    "nuts_gibbs_plan_shuffle": (C.c_int, [C.POINTER(Pcg64), C.c_int64, _VP]),
+    "nuts_gibbs_plan_draws": (C.c_int, [C.POINTER(Pcg64), C.c_int64, _VP, _VP, _VP, _PD, C.POINTER(C.c_int32)]),
+    "nuts_gibbs_plan_skip": (C.c_int, [C.POINTER(Pcg64), C.c_int64, C.c_int32]),
     "nuts_gibbs_create": (_VP, [C.c_int64, C.c_int32, _PD]),
     "nuts_gibbs_destroy": (None, [_VP]),
     "nuts_gibbs_sweep": (C.c_int, [_VP, _VP, _PD, _PD, _PD, _VP, _VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _PD, _PD, _PD]),

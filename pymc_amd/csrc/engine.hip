@@ -3171,20 +3171,78 @@ extern "C" int nuts_gibbs_plan(nuts_pcg64* rng, int64_t n, int32_t shuffle, int3
   r.state = ((unsigned __int128)rng->state_hi << 64) | rng->state_lo;
   r.inc = ((unsigned __int128)rng->inc_hi << 64) | rng->inc_lo;
   r.has_uint32 = rng->has_uint32; r.uinteger = rng->uinteger;
+  r.begin_bulk();   // the raw outputs a block ahead, four interleaved lanes (pcg64_stream.h)
   if (shuffle) {   // Generator.shuffle on a Python list: Fisher-Yates from the top (numpy/random/_generator.pyx, untyped path)
     for (int64_t i = n - 1; i >= 1; --i) {
       const int64_t j = (int64_t)r.interval((uint64_t)i);
       std::swap(order[i], order[j]);
     }
   }
+  bool same_k = n > 0;   // (every dimension with the same number of categories -- a mixture's assignments: no gather through the shuffled order)
+  for (int64_t t = 1; t < n && same_k; ++t) same_k = k_of_dim[t] == k_of_dim[0];
   for (int64_t t = 0; t < n; ++t) {
-    const int32_t k = k_of_dim[order[t]];
+    const int32_t k = same_k ? k_of_dim[0] : k_of_dim[order[t]];
     if (k < 2) { g_err = "a categorical dimension needs at least two categories"; return NUTS_E_ARG; }
     cand_raw[t] = (int32_t)r.integers((uint32_t)(k - 1));   // rng.choice(k - 1)
     uniform[t] = r.next_double();                           // rng.uniform()
   }
+  r.end_bulk();
   rng->state_hi = (uint64_t)(r.state >> 64); rng->state_lo = (uint64_t)r.state;
   rng->has_uint32 = r.has_uint32; rng->uinteger = r.uinteger;
+  return NUTS_OK;
+}
+
+// The two halves of `nuts_gibbs_plan` as calls of their own, so that a sweep's per-element draws and the NEXT sweep's shuffle can be
+// replayed at the same time on two host threads (pymc_amd/gibbs.py `_PlanPipeline`): `..._shuffle` leaves the generator as it
+// stands after `rng.shuffle`, `..._draws` replays the per-element loop from there, `..._skip` jumps over that loop without replaying
+// it (every dimension with the same k; `*clean` of `..._draws` says whether the jump's assumption -- no Lemire rejection -- held).
+static void pcg_load(Pcg64Replay& r, const nuts_pcg64* rng) {
+  r.state = ((unsigned __int128)rng->state_hi << 64) | rng->state_lo;
+  r.inc = ((unsigned __int128)rng->inc_hi << 64) | rng->inc_lo;
+  r.has_uint32 = rng->has_uint32; r.uinteger = rng->uinteger;
+}
+static void pcg_store(const Pcg64Replay& r, nuts_pcg64* rng) {
+  rng->state_hi = (uint64_t)(r.state >> 64); rng->state_lo = (uint64_t)r.state;
+  rng->has_uint32 = r.has_uint32; rng->uinteger = r.uinteger;
+}
+extern "C" int nuts_gibbs_plan_shuffle(nuts_pcg64* rng, int64_t n, int32_t* order) {
+  if (!rng || !order || n < 0) { g_err = "null argument"; return NUTS_E_ARG; }
+  Pcg64Replay r;
+  pcg_load(r, rng);
+  r.begin_bulk();
+  for (int64_t i = n - 1; i >= 1; --i) {
+    const int64_t j = (int64_t)r.interval((uint64_t)i);
+    std::swap(order[i], order[j]);
+  }
+  r.end_bulk();
+  pcg_store(r, rng);
+  return NUTS_OK;
+}
+extern "C" int nuts_gibbs_plan_draws(nuts_pcg64* rng, int64_t n, const int32_t* order, const int32_t* k_of_dim, int32_t* cand_raw, double* uniform,
+                                     int32_t* clean) {
+  if (!rng || !order || !k_of_dim || !cand_raw || !uniform || n < 0) { g_err = "null argument"; return NUTS_E_ARG; }
+  Pcg64Replay r;
+  pcg_load(r, rng);
+  r.begin_bulk();
+  bool same_k = n > 0;
+  for (int64_t t = 1; t < n && same_k; ++t) same_k = k_of_dim[t] == k_of_dim[0];
+  for (int64_t t = 0; t < n; ++t) {
+    const int32_t k = same_k ? k_of_dim[0] : k_of_dim[order[t]];
+    if (k < 2) { g_err = "a categorical dimension needs at least two categories"; return NUTS_E_ARG; }
+    cand_raw[t] = (int32_t)r.integers((uint32_t)(k - 1));
+    uniform[t] = r.next_double();
+  }
+  r.end_bulk();
+  pcg_store(r, rng);
+  if (clean) *clean = (same_k && r.rejections == 0) ? 1 : 0;
+  return NUTS_OK;
+}
+extern "C" int nuts_gibbs_plan_skip(nuts_pcg64* rng, int64_t n, int32_t k) {
+  if (!rng || n < 0 || k < 2) { g_err = "bad argument"; return NUTS_E_ARG; }
+  Pcg64Replay r;
+  pcg_load(r, rng);
+  r.skip_draws((uint64_t)n, (uint32_t)k);
+  pcg_store(r, rng);
   return NUTS_OK;
 }
 

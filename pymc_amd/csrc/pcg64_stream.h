@@ -17,20 +17,85 @@
 #include <cmath>
 #include <cstdint>
 
+// The raw 64-bit outputs in BULK: a 128-bit LCG step costs a dependent 128 x 128 multiply, and a sweep at n = 100 000 consumes
+// ~230 000 of them one after the other -- two thirds of the 0.74 ms a plan took (profiles/r04a_profile_c5.txt: the host thread that
+// replays the stream, not the device, set the pace of configs[4]'s compound step).  The outputs do not depend on what is done with
+// them, so they are produced a block ahead by FOUR interleaved lanes of the same sequence, lane j holding every fourth state:
+// S_{k+4} = a^4 S_k + c (a^3 + a^2 + a + 1) -- four independent multiply chains the core overlaps -- and the consumers below
+// (`next32` buffering, `random_interval`, Lemire, `next_double`) read them from the block.  The generator state handed back is
+// S_{consumed}: the initial state advanced by the number of outputs actually used (`advance`, the O(log n) jump of an LCG).
 struct Pcg64Replay {
   unsigned __int128 state, inc;
   int has_uint32;
   uint32_t uinteger;
+  // bulk mode (begin_bulk): outputs of the states after `bstate`, consumed in order
+  static constexpr int BLK = 2048;
+  bool bulk = false;
+  unsigned __int128 bstate = 0, state0 = 0;   // state at the start of the current block / when bulk mode began
+  uint64_t consumed = 0;                      // outputs handed out since begin_bulk
+  int bpos = BLK;
+  uint64_t buf[BLK];
 
   static unsigned __int128 mult() {
     return ((unsigned __int128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;   // PCG_DEFAULT_MULTIPLIER_128
   }
-  uint64_t next64() {
-    state = state * mult() + inc;
-    const uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;
-    const unsigned rot = (unsigned)(state >> 122);
+  static uint64_t output(unsigned __int128 st) {   // XSL-RR 128/64
+    const uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
+    const unsigned rot = (unsigned)(st >> 122);
     const uint64_t x = hi ^ lo;
     return (x >> rot) | (x << ((-rot) & 63));
+  }
+  // state after `delta` steps (pcg_advance_lcg_128)
+  static unsigned __int128 advance(unsigned __int128 st, unsigned __int128 inc_, uint64_t delta) {
+    unsigned __int128 acc_mult = 1, acc_plus = 0, cur_mult = mult(), cur_plus = inc_;
+    while (delta > 0) {
+      if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+      cur_plus = (cur_mult + 1) * cur_plus;
+      cur_mult *= cur_mult;
+      delta >>= 1;
+    }
+    return acc_mult * st + acc_plus;
+  }
+  void begin_bulk() { bulk = true; bstate = state0 = state; consumed = 0; bpos = BLK; }
+  void end_bulk() { state = advance(state0, inc, consumed); bulk = false; }
+  void refill() {
+    const unsigned __int128 a = mult(), a2 = a * a, a4 = a2 * a2, c4 = inc * (a2 * a + a2 + a + 1);
+    unsigned __int128 l0 = bstate * a + inc, l1 = l0 * a + inc, l2 = l1 * a + inc, l3 = l2 * a + inc;
+    for (int i = 0; i < BLK; i += 4) {
+      buf[i] = output(l0); buf[i + 1] = output(l1); buf[i + 2] = output(l2); buf[i + 3] = output(l3);
+      if (i + 4 == BLK) bstate = l3;
+      l0 = l0 * a4 + c4; l1 = l1 * a4 + c4; l2 = l2 * a4 + c4; l3 = l3 * a4 + c4;
+    }
+    bpos = 0;
+  }
+  uint64_t next64() {
+    if (bulk) {
+      if (bpos == BLK) refill();
+      ++consumed;
+      return buf[bpos++];
+    }
+    state = state * mult() + inc;
+    return output(state);
+  }
+  // The generator after n elements of the per-element loop (`choice(k - 1)` + `uniform()`, every dimension with the SAME k), assuming
+  // no Lemire rejection (probability (2^32 mod (k-1)) / 2^32 per draw: zero for k - 1 a power of two; the caller checks what the
+  // real pass reports): element t takes a 32-bit half (the buffered one, or the low half of a fresh output whose high half is then
+  // buffered) and one whole output for the double -- so the number of outputs consumed, the buffered flag and the buffered half
+  // follow from n and the flag alone.  Lets the NEXT sweep's shuffle start while this sweep's draws are still being replayed.
+  void skip_draws(uint64_t n, uint32_t k) {
+    if (n == 0) return;
+    if (k <= 2) { state = advance(state, inc, n); return; }   // choice(1) draws nothing
+    const uint64_t need = n - (has_uint32 ? 1 : 0);            // halves that must come from fresh outputs
+    const uint64_t refills = (need + 1) / 2;
+    if (refills > 0) {
+      // the last refill happens at element t_last = (has_uint32 ? 1 : 0) + 2 (refills - 1); before it: t_last doubles + refills - 1 refills
+      const uint64_t t_last = (has_uint32 ? 1 : 0) + 2 * (refills - 1);
+      const uint64_t pos = t_last + (refills - 1);            // outputs consumed before that refill
+      const uint64_t o = output(advance(state, inc, pos + 1));
+      uinteger = (uint32_t)(o >> 32);
+      has_uint32 = (need & 1) ? 1 : 0;                        // an odd number of fresh halves leaves the last high half buffered
+    } else has_uint32 = 0;                                     // (n == 1 and the buffered half was used)
+    state = advance(state, inc, n + refills);
   }
   uint32_t next32() {   // NumPy's pcg64_next32: the high half of a 64-bit output is kept for the next call
     if (has_uint32) { has_uint32 = 0; return uinteger; }
@@ -48,6 +113,7 @@ struct Pcg64Replay {
     else { while ((value = (next64() & mask)) > max) {} }
     return value;
   }
+  int rejections = 0;   // Lemire rejections since the object was set up (skip_draws assumes there are none)
   uint32_t lemire32(uint32_t rng) {   // buffered_bounded_lemire_uint32: uniform on [0, rng]
     const uint32_t rng_excl = rng + 1;
     uint64_t m = (uint64_t)next32() * rng_excl;
@@ -55,6 +121,7 @@ struct Pcg64Replay {
     if (leftover < rng_excl) {
       const uint32_t threshold = (0xffffffffu - rng) % rng_excl;
       while (leftover < threshold) {
+        ++rejections;
         m = (uint64_t)next32() * rng_excl;
         leftover = (uint32_t)(m & 0xffffffffu);
       }

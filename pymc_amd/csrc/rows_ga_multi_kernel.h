@@ -266,11 +266,16 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga_multi(ModelDev md
     s_keep[c][0][lane] = hval0; s_keep[c][1][lane] = hph0; s_keep[c][2][lane] = zq; s_keep[c][3][lane] = zph; s_keep[c][4][lane] = s_lane;
   }
   __syncthreads();
+  // Two tile buffers per wave (one being evaluated, one requested) up to three chains; with FOUR sets of accumulators the second
+  // buffer is what pushed the allocator into spilling inside the loop (107 us per launch against 80 for three chains, rocprofv3
+  // r05c): one buffer then, the wave's next tile is requested when the current one has been evaluated -- at ~1.3 us of arithmetic
+  // per tile and twelve waves per CU the other waves cover the wait.
+  constexpr bool TWO = NC <= 3;
   Tile ta, tb;
   {
     const int64_t o0 = tile_at(0), o1 = tile_at(min(1, max(n - 1, 0)));
     gam_load<DX>(R.Xt + o0, R.y + o0 / DX, lane, ta);
-    gam_load<DX>(R.Xt + o1, R.y + o1 / DX, lane, tb);
+    if constexpr (TWO) gam_load<DX>(R.Xt + o1, R.y + o1 / DX, lane, tb);
   }
   double beta[NC][D];   // wave-uniform: scalar registers
 #pragma unroll
@@ -325,12 +330,19 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga_multi(ModelDev md
       const int nv = local_at(I) == l_last ? n_last : SPAN;                                  \
       _Pragma("unroll") for (int c = 0; c < NC; ++c) ga_tile<8, 2>(xx, yy, beta[c], nv, lane, acc[c], lp[c]); \
     }
-    for (int i = 0; i < n; i += 2) {
-      GAM_STAGE(ta, i)
-      if (i + 1 >= n) break;
-      issue(i + 2, ta);
-      GAM_STAGE(tb, i + 1)
-      issue(i + 3, tb);
+    if constexpr (TWO) {
+      for (int i = 0; i < n; i += 2) {
+        GAM_STAGE(ta, i)
+        if (i + 1 >= n) break;
+        issue(i + 2, ta);
+        GAM_STAGE(tb, i + 1)
+        issue(i + 3, tb);
+      }
+    } else {
+      for (int i = 0; i < n; ++i) {
+        GAM_STAGE(ta, i)
+        issue(i + 1, ta);
+      }
     }
 #undef GAM_STAGE
     if (n > 0) flush();

@@ -161,44 +161,100 @@ def plan_sweep(rng: np.random.Generator, order: np.ndarray, k_of_dim: np.ndarray
     return cand, np.log(u)   # NumPy's log, as `np.log(rng.uniform())` in the reference
 
 
-# ---- the plan of sweep k + 1 while sweep k (and the other step methods of the CompoundStep) run ---------------------------------------
+# ---- the plans of the NEXT sweeps while sweep k (and the other step methods of the CompoundStep) run ----------------------------------
 # What a sweep draws does not depend on the state of the chain: `rng.shuffle(dimcats)`, then per position `rng.choice(k - 1)` and
 # `rng.uniform()` -- the raw candidate is turned into a category against the CURRENT assignment on the device.  So, exactly as for
-# the momentum normals of the HMC steps (quadpotential.py, `_draw_normals`), the plan of the NEXT sweep is drawn on a worker thread
-# from a private copy of (generator state, order) while the device works; `step.rng` and `step._order` only move forward when that
-# plan is consumed, and only if they are still what the copy started from -- anyone who looks at, saves or replaces the
-# generator in between sees exactly what the reference's generator would hold.  At N = 100 000 the replay is ~1-2 ms of host
-# time, more than the rest of a compound iteration (profiles/r02m_aux_c5_mixture.json).
-_PLAN_REQUESTS = None
-_PLAN_LOCK = threading.Lock()
+# the momentum normals of the HMC steps (quadpotential.py, `_draw_normals`), the plans are drawn ahead on host threads from private
+# copies of (generator state, order) while the device works; `step.rng` and `step._order` only move forward when a plan is
+# consumed, and only if they are still what the plan started from -- anyone who looks at, saves or replaces the generator in
+# between sees exactly what the reference's generator would hold.
+#
+# Round 5 (VERDICT r04 "next" 4): at N = 100 000 the replay of ONE plan (0.74 ms on the GPU box's host) was longer than everything
+# else in a compound iteration, so drawing one plan ahead on one thread capped configs[4] at ~1 100 iterations/s.  A plan has two
+# halves -- the shuffle (inherently sequential: Fisher-Yates with rejection) and the per-element draws -- and the generator state
+# after the SECOND half follows from the state after the first by a jump (`nuts_gibbs_plan_skip`: n doubles + n buffered 32-bit
+# halves, no Lemire rejection -- checked against what the real replay reports).  `_PlanPipeline` therefore runs them as a
+# two-stage pipeline: the shuffler thread goes from the shuffle of sweep k straight on to the shuffle of sweep k + 1 while the
+# drawer thread replays sweep k's per-element draws and takes NumPy's log of them; up to DEPTH plans are kept ready.
 _PLAN_PREFETCH_ON = os.environ.get("PYMC_AMD_GIBBS_PREFETCH", "1") != "0"
 _PLAN_PREFETCH_MIN = 4096
 
 
-def _plan_worker(requests):
-    gen = np.random.Generator(np.random.PCG64(0))
-    while True:
-        state, order, k_of_dim, shuffle, reply = requests.get()
+def _state_key(st):
+    """A PCG64 `bit_generator.state` as a comparable tuple (the buffered half only counts when there is one)."""
+    return (st["state"]["state"], st["state"]["inc"], int(st["has_uint32"]), int(st["uinteger"]) if st["has_uint32"] else 0)
+
+
+class _PlanPipeline:
+    DEPTH = 3
+
+    def __init__(self, state, order, k_of_dim, shuffle):
+        self.k_of_dim, self.shuffle = k_of_dim, bool(shuffle)
+        self.K = int(k_of_dim[0])
+        self.closed = False
+        self._slots = threading.Semaphore(self.DEPTH)
+        self._to_draw = queue.SimpleQueue()
+        self.out = queue.SimpleQueue()
+        self._start = (state, order.copy())
+        threading.Thread(target=self._shuffler, daemon=True, name="pymc_amd_gibbs_shuffle").start()
+        threading.Thread(target=self._drawer, daemon=True, name="pymc_amd_gibbs_draws").start()
+
+    def close(self):
+        self.closed = True
+        self._slots.release()          # (wake a shuffler that waits for a free slot)
+        self._to_draw.put(None)
+
+    def _shuffler(self):
+        lib = _lib.load()
+        gen = np.random.Generator(np.random.PCG64(0))
+        state, order = self._start
+        n = len(order)
         try:
-            gen.bit_generator.state = state
-            order = order.copy()
-            cand, log_u = plan_sweep(gen, order, k_of_dim, shuffle)
-            reply.put((cand, log_u, order, gen.bit_generator.state))
+            while True:
+                self._slots.acquire()
+                if self.closed:
+                    return
+                gen.bit_generator.state = state
+                base_state, base_order = state, order
+                order = order.copy()
+                p = _pcg_to_c(gen)
+                if self.shuffle:
+                    _lib.check(lib.nuts_gibbs_plan_shuffle(C.byref(p), n, order.ctypes.data), "nuts_gibbs_plan_shuffle")
+                _pcg_from_c(gen, p)
+                after_shuffle = gen.bit_generator.state
+                self._to_draw.put((base_state, base_order, order, after_shuffle))
+                # the generator after this sweep's per-element draws, without replaying them: where the next shuffle starts
+                _lib.check(lib.nuts_gibbs_plan_skip(C.byref(p), n, self.K), "nuts_gibbs_plan_skip")
+                _pcg_from_c(gen, p)
+                state = gen.bit_generator.state
         except BaseException as err:  # noqa: BLE001 -- the consumer falls back to drawing the plan itself
-            reply.put(err)
+            self.out.put(err)
 
+    def _drawer(self):
+        lib = _lib.load()
+        gen = np.random.Generator(np.random.PCG64(0))
+        try:
+            while True:
+                item = self._to_draw.get()
+                if item is None or self.closed:
+                    return
+                base_state, base_order, order, after_shuffle = item
+                n = len(order)
+                gen.bit_generator.state = after_shuffle
+                p = _pcg_to_c(gen)
+                cand, u, clean = np.empty(n, dtype="int32"), np.empty(n), C.c_int32(0)
+                _lib.check(lib.nuts_gibbs_plan_draws(C.byref(p), n, order.ctypes.data, self.k_of_dim.ctypes.data, cand.ctypes.data, _lib.dptr(u),
+                                                     C.byref(clean)), "nuts_gibbs_plan_draws")
+                _pcg_from_c(gen, p)
+                self.out.put((base_state, base_order, cand, np.log(u), order, gen.bit_generator.state, bool(clean.value)))
+        except BaseException as err:  # noqa: BLE001
+            self.out.put(err)
 
-def _request_plan(state, order, k_of_dim, shuffle):
-    global _PLAN_REQUESTS
-    if _PLAN_REQUESTS is None:
-        with _PLAN_LOCK:
-            if _PLAN_REQUESTS is None:
-                q = queue.SimpleQueue()
-                threading.Thread(target=_plan_worker, args=(q,), daemon=True, name="pymc_amd_gibbs_plan").start()
-                _PLAN_REQUESTS = q
-    reply = queue.SimpleQueue()
-    _PLAN_REQUESTS.put((state, order.copy(), k_of_dim, shuffle, reply))
-    return reply
+    def take(self):
+        """The next plan in line (blocks until the drawer has it); its slot is free for the shuffler again."""
+        res = self.out.get()
+        self._slots.release()
+        return res
 
 
 @dataclass
@@ -249,28 +305,36 @@ class CategoricalGibbsMetropolis:
         self._device = device
         self._handle = None
         self.accepted_last = 0
-        self._plan_ahead = None   # (reply queue, generator state and order the worker started from)
+        self._plan_ahead = None   # the `_PlanPipeline` that draws the next sweeps' plans ahead (None: not running)
 
     def _next_plan(self):
-        """(cand_raw, log_u) of this sweep, `self._order` and `self.rng` advanced as `plan_sweep` advances them; the plan of the
-        following sweep is requested from the worker thread before returning."""
+        """(cand_raw, log_u) of this sweep, `self._order` and `self.rng` advanced as `plan_sweep` advances them.  The plans come from
+        the step's `_PlanPipeline` when it is still in step with (`self.rng`, `self._order`); otherwise -- the first sweep of a chain, a
+        generator someone replaced, a Lemire rejection that invalidated the jump -- the plan is drawn here and the pipeline restarted
+        behind it."""
         bg = self.rng.bit_generator
         got = None
-        ahead, self._plan_ahead = self._plan_ahead, None
-        if ahead is not None:
-            reply, base_state, base_order = ahead
-            if bg.state == base_state and np.array_equal(self._order, base_order):
-                res = reply.get()
-                if not isinstance(res, BaseException):
-                    cand, log_u, order, after = res
-                    self._order[:] = order
-                    bg.state = after
-                    got = (cand, log_u)
+        pipe = self._plan_ahead
+        if pipe is not None:
+            res = pipe.take()
+            ok = not isinstance(res, BaseException)
+            if ok:
+                base_state, base_order, cand, log_u, order, after, clean = res
+                ok = _state_key(bg.state) == _state_key(base_state) and np.array_equal(self._order, base_order)
+            if ok:
+                self._order[:] = order
+                bg.state = after
+                got = (cand, log_u)
+                if not clean:          # the plans behind this one started from a generator state the jump mispredicted
+                    ok = False
+            if not ok:
+                pipe.close()
+                self._plan_ahead = None
         if got is None:
             got = plan_sweep(self.rng, self._order, self._k_of_dim, self.shuffle_dims)
-        if _PLAN_PREFETCH_ON and len(self._order) >= _PLAN_PREFETCH_MIN and bg.state.get("bit_generator") == "PCG64":
-            base = bg.state
-            self._plan_ahead = (_request_plan(base, self._order, self._k_of_dim, self.shuffle_dims), base, self._order.copy())
+        if (self._plan_ahead is None and _PLAN_PREFETCH_ON and len(self._order) >= _PLAN_PREFETCH_MIN and bg.state.get("bit_generator") == "PCG64"
+                and bool(np.all(self._k_of_dim == self._k_of_dim[0]))):
+            self._plan_ahead = _PlanPipeline(bg.state, self._order, self._k_of_dim, self.shuffle_dims)
         return got
 
     def __getstate__(self):   # (a pending plan and the engine handle do not travel)
@@ -404,6 +468,9 @@ class CategoricalGibbsMetropolis:
         self._order = np.array([d for d, _ in state.dimcats], dtype="int32")
 
     def close(self):
+        if getattr(self, "_plan_ahead", None) is not None:
+            self._plan_ahead.close()
+            self._plan_ahead = None
         if self._handle:
             _lib.load().nuts_gibbs_destroy(self._handle)
             self._handle = None

@@ -209,47 +209,159 @@ def assign_step_methods(spec: ModelSpec, nuts_step, device=None):
     return CompoundStep([nuts_step, CategoricalGibbsMetropolis(model=spec, device=device)])
 
 
-def _sample_compound(comp, spec, points, rngs, mine, tune, draws, discard_tuned_samples):
-    """`_iter_sample` (mcmc.py:1503-1583) for a `CompoundStep`: every iteration hands the point through the methods; the gradient
-    variables are recorded raveled (as for NUTS alone), the other value variables (the discrete ones) by name."""
+def _compound_chain(comp, spec, start, rng, tune: int, draws: int):
+    """One chain of `_iter_sample` (mcmc.py:1503-1583) under a `CompoundStep`: every iteration hands the point through the methods;
+    the gradient variables are recorded raveled (as for NUTS alone), the other value variables (the discrete ones) by name.
+    Returns `(positions [tune + draws][n], {extra name: [tune + draws][...]}, per-iteration stats lists, post-warmup seconds)`."""
     import time as _time
 
     total = tune + draws
-    n = spec.n
     extra_names = [k for k in getattr(spec, "extra", {})]
     gvars = [v.value_name for v in spec.vars]
+    comp.setup_chain(rng, tune, draws)
+    comp.tune = bool(tune)
+    for m in comp.methods:
+        m.tune = bool(tune)
+        if hasattr(m, "iter_count"):
+            m.iter_count = 0
+    comp.reset_tuning()
+    point = dict(start)
+    out = np.empty((total, spec.n))
+    ex = {nm: np.empty((total,) + np.shape(point[nm]), dtype=np.asarray(point[nm]).dtype) for nm in extra_names}
+    chain_stats = []
+    ts = _time.perf_counter()
+    for i in range(total):
+        if i == tune:
+            comp.stop_tuning()
+            ts = _time.perf_counter()
+        point, stats = comp.step(point)
+        out[i] = DictToArrayBijection.map({nm: point[nm] for nm in gvars}).data
+        for nm in extra_names:
+            ex[nm][i] = point[nm]
+        chain_stats.append(stats)
+        log_warning_stats(stats)
+    t_post = _time.perf_counter() - ts if total > tune else 0.0
+    return out, ex, chain_stats, t_post
+
+
+def _compound_worker(conn, comp_blob, device, start, rng_blob, spec_blob, tune, draws, chain):
+    """A worker process of `sample(mp_ctx=...)` under a CompoundStep (pymc/sampling/parallel.py:352-524: the step method travels
+    cloudpickled, the worker picks its GPU and re-creates the engine handles on first use)."""
+    import pickle
+    import traceback
+
+    try:
+        import cloudpickle
+
+        comp = cloudpickle.loads(comp_blob)
+        spec = cloudpickle.loads(spec_blob)
+        if device is not None:
+            for m in comp.methods:
+                m._device = int(device)
+        res = _compound_chain(comp, spec, start, pickle.loads(rng_blob), tune, draws)
+        comp.close()
+        conn.send(("ok", chain, res))
+    except BaseException as e:  # noqa: BLE001 -- reported to the parent, which raises
+        conn.send(("error", chain, f"{type(e).__name__}: {e}", traceback.format_exc()))
+    finally:
+        conn.close()
+
+
+def _sample_compound(comp, spec, points, rngs, mine, tune, draws, discard_tuned_samples, mp_ctx=None, device=None, make_compound=None, n_par=1):
+    """The chains of this rank under a `CompoundStep`: one after the other on the given step object (the reference resets one step
+    object between sequential chains, mcmc.py:1411,1423), in worker processes (`mp_ctx`, one per chain: chain c on GPU c mod
+    visible devices), or `n_par` at a time from host threads, each with a compound step of its own (`make_compound()`).  Every chain
+    starts from the same sampling state and its own generator: the result does not depend on the layout."""
+    import time as _time
+
+    n = spec.n
+    extra_names = [k for k in getattr(spec, "extra", {})]
+    total = tune + draws
     local_draws = np.empty((len(mine), total, n))
-    extra_draws = {k: [] for k in extra_names}
-    all_stats = []
+    extra_draws = {k: [None] * len(mine) for k in extra_names}
+    all_stats = [None] * len(mine)
     t0 = _time.perf_counter()
     t_sampling = 0.0
     initial_state = comp.sampling_state
-    for k, c in enumerate(mine):
-        comp.sampling_state = initial_state
-        comp.setup_chain(rngs[c], tune, draws)
-        comp.tune = bool(tune)
-        for m in comp.methods:
-            m.tune = bool(tune)
-            if hasattr(m, "iter_count"):
-                m.iter_count = 0
-        comp.reset_tuning()
-        point = dict(points[c])
-        ex = {nm: np.empty((total,) + np.shape(point[nm]), dtype=np.asarray(point[nm]).dtype) for nm in extra_names}
-        chain_stats = []
-        for i in range(total):
-            if i == tune:
-                comp.stop_tuning()
-                ts = _time.perf_counter()
-            point, stats = comp.step(point)
-            local_draws[k, i] = DictToArrayBijection.map({nm: point[nm] for nm in gvars}).data
-            for nm in extra_names:
-                ex[nm][i] = point[nm]
-            chain_stats.append(stats)
-            log_warning_stats(stats)
-        t_sampling += _time.perf_counter() - ts if total > tune else 0.0
+
+    def put(k, res):
+        d, ex, st, _ = res
+        local_draws[k] = d
         for nm in extra_names:
-            extra_draws[nm].append(ex[nm])
-        all_stats.append(chain_stats)
+            extra_draws[nm][k] = ex[nm]
+        all_stats[k] = st
+
+    if mp_ctx is not None and len(mine) > 0:
+        import multiprocessing as mp
+        import pickle
+
+        import cloudpickle
+
+        from pymc_amd import _lib
+        from pymc_amd.parallel import ParallelSamplingError
+
+        comp.sampling_state = initial_state
+        blob, spec_blob = cloudpickle.dumps(comp), cloudpickle.dumps(spec)
+        ndev = max(1, _lib.load().nuts_device_count())
+        ctx = mp.get_context(mp_ctx)
+        procs, conns = [], []
+        for k, c in enumerate(mine):
+            parent, child = ctx.Pipe(duplex=False)
+            dev = device if device is not None else c % ndev
+            pr = ctx.Process(target=_compound_worker, args=(child, blob, dev, points[c], pickle.dumps(rngs[c]), spec_blob, tune, draws, c), daemon=True)
+            pr.start()
+            child.close()
+            procs.append(pr)
+            conns.append(parent)
+        err = None
+        for k, conn in enumerate(conns):
+            try:
+                msg = conn.recv()
+            except EOFError:
+                msg = ("error", mine[k], "worker exited without a result", "")
+            if msg[0] == "ok":
+                put(k, msg[2])
+                t_sampling = max(t_sampling, msg[2][3])
+            elif err is None:
+                err = msg
+        for pr in procs:
+            pr.join(timeout=60)
+        if err is not None:
+            raise ParallelSamplingError(f"Chain {err[1]} failed with: {err[2]}\n{err[3]}", err[1])
+    elif n_par > 1 and make_compound is not None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        comps = [comp] + [make_compound() for _ in range(n_par - 1)]
+
+        def work(w):
+            cw = comps[w]
+            for m in cw.methods:
+                f = getattr(m, "_logp_dlogp_func", None)
+                if f is not None:
+                    f.bind_thread()
+            got = []
+            for k in range(w, len(mine), n_par):
+                cw.sampling_state = initial_state
+                got.append((k, _compound_chain(cw, spec, points[mine[k]], rngs[mine[k]], tune, draws)))
+            return got
+
+        try:
+            with ThreadPoolExecutor(max_workers=n_par) as exr:
+                for got in exr.map(work, range(n_par)):
+                    tw = 0.0
+                    for k, res in got:
+                        put(k, res)
+                        tw += res[3]
+                    t_sampling = max(t_sampling, tw)
+        finally:
+            for cw in comps[1:]:
+                cw.close()
+    else:
+        for k, c in enumerate(mine):
+            comp.sampling_state = initial_state
+            res = _compound_chain(comp, spec, points[c], rngs[c], tune, draws)
+            put(k, res)
+            t_sampling += res[3]
     keep = slice(tune, None) if discard_tuned_samples else slice(None)
     # the statistics of the gradient-based method (the first dict of every draw that has any) under the usual keys; everything,
     # method by method, under "all_stats" (what the reference keeps per sampler, base.py:215-229)
@@ -257,7 +369,7 @@ def _sample_compound(comp, spec, points, rngs, mine, tune, draws, discard_tuned_
     return {
         "chains": mine,
         "draws": local_draws[:, keep],
-        "extra_draws": {nm: np.stack(v)[:, keep] for nm, v in extra_draws.items()},
+        "extra_draws": {nm: np.stack(v)[:, keep] if len(v) else np.empty((0,)) for nm, v in extra_draws.items()},
         "stats": [s_[keep] for s_ in main],
         "warmup_stats": [s_[:tune] for s_ in main],
         "all_stats": [s_[keep] for s_ in all_stats],
@@ -471,8 +583,8 @@ def sample(
             points.append(pt)
     compound = step if hasattr(step, "methods") else None
     if compound is not None:
-        if world > 1 or mp_ctx is not None or pooled_adaptation:
-            raise NotImplementedError("a CompoundStep is sampled chain by chain on one rank (no gather / worker processes / pooled adaptation yet)")
+        if pooled_adaptation:
+            raise NotImplementedError("pooled adaptation pools the Welford windows of ONE gradient-based step method (not a CompoundStep)")
         grad_step = next(m for m in compound.methods if hasattr(m, "_logp_dlogp_func"))
     else:
         grad_step = step
@@ -491,8 +603,19 @@ def sample(
                 "You can call `model.debug()` for more details."
             )
     if compound is not None:
-        result = _sample_compound(compound, spec, points, rngs, mine, tune, draws, discard_tuned_samples)
-        if return_multitrace:
+        # chain c <-> rank c mod world as for NUTS alone (mcmc.py:1586-1692, parallel.py:477-589); on a rank: worker processes
+        # (`mp_ctx`), host threads with a compound step each (`cores`), or one after the other
+        make = None
+        if not step_given:
+            def make():
+                _, st2 = init_nuts(spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device, tune=tune, **step_kwargs)
+                return assign_step_methods(spec, st2, device=device)
+        n_par_c = min(len(mine), cores) if (cores is not None and make is not None) else 1
+        result = _sample_compound(compound, spec, points, rngs, mine, tune, draws, discard_tuned_samples, mp_ctx=mp_ctx, device=device,
+                                  make_compound=make, n_par=max(1, n_par_c))
+        if gather and world > 1:
+            result = gather_trace(result, chains, rank, world, device)
+        if return_multitrace and (rank == 0 or not (gather and world > 1)):
             from pymc_amd.backends import multitrace_from_result
 
             result["trace"] = multitrace_from_result(spec, result)
@@ -636,40 +759,59 @@ def sample(
 
 
 def gather_trace(result, chains: int, rank: int, world: int, device):
-    """Final trace gather to rank 0: positions (draws x n x 8 B per chain) as one padded tensor
-    gather over RCCL / gloo, and the per-draw sampler statistics of every chain (`sample_stats`, the 19 NUTS keys of
-    nuts.py:110-130 incl. the warning objects) with `gather_object` -- a few KB per chain."""
+    """Final trace gather to rank 0: positions (draws x n x 8 B per chain) as one padded tensor gather, the
+    value variables another step method of a CompoundStep sampled (`extra_draws`: the discrete assignments) the same way, and the
+    per-draw sampler statistics of every chain (`sample_stats`, the 19 NUTS keys of nuts.py:110-130 incl. the warning objects) with
+    `gather_object` -- a few KB per chain.
+
+    The draws are HOST arrays when sampling ends (the engine hands positions back once per batch of draws), so they travel over
+    the host group whenever the default group is one (gloo: `parallel.init_process_groups` brings it up as the control plane) --
+    no hop through device memory and no dependence on RCCL; only a default group that IS nccl (a caller who initialised
+    `torch.distributed` that way) makes them take the device route."""
     import torch
     import torch.distributed as dist
 
-    from pymc_amd.parallel import rccl_group
-
-    # the draws travel over RCCL when a group is up (`parallel.init_process_groups`, or a default group the caller initialised with
-    # the nccl backend), over the host group otherwise; the statistics are Python objects and always take the default group
-    grp = rccl_group()
-    on_gpu = grp is not None or dist.get_backend() == "nccl"
+    on_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", device if device is not None else 0) if on_gpu else torch.device("cpu")
     per_rank = (chains + world - 1) // world
-    d = result["draws"]
-    pad = np.zeros((per_rank,) + d.shape[1:])
-    pad[: d.shape[0]] = d
-    t = torch.from_numpy(pad).to(dev)
-    out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-    dist.gather(t, out, dst=0, group=grp)
-    mine_stats = {"stats": result["stats"], "warmup_stats": result.get("warmup_stats", []), "sampling_time": result.get("sampling_time", 0.0)}
-    all_stats = [None] * world if rank == 0 else None
-    dist.gather_object(mine_stats, all_stats, dst=0)
-    if rank == 0:
-        full = np.empty((chains,) + d.shape[1:])
-        stats = [None] * chains
-        warm = [None] * chains
+
+    def gather_array(d):
+        d = np.ascontiguousarray(d)
+        pad = np.zeros((per_rank,) + d.shape[1:], dtype=d.dtype)
+        pad[: d.shape[0]] = d
+        t = torch.from_numpy(pad).to(dev)
+        out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        dist.gather(t, out, dst=0)
+        if rank != 0:
+            return None
+        full = np.empty((chains,) + d.shape[1:], dtype=d.dtype)
         for r in range(world):
             for k, c in enumerate(assign_chains(chains, r, world)):
                 full[c] = out[r][k].cpu().numpy()
+        return full
+
+    full = gather_array(result["draws"])
+    extras = {nm: gather_array(v) for nm, v in sorted(result.get("extra_draws", {}).items())}
+    mine_stats = {"stats": result["stats"], "warmup_stats": result.get("warmup_stats", []), "sampling_time": result.get("sampling_time", 0.0),
+                  "all_stats": result.get("all_stats")}
+    all_stats = [None] * world if rank == 0 else None
+    dist.gather_object(mine_stats, all_stats, dst=0)
+    if rank == 0:
+        stats = [None] * chains
+        warm = [None] * chains
+        every = [None] * chains
+        for r in range(world):
+            for k, c in enumerate(assign_chains(chains, r, world)):
                 stats[c] = all_stats[r]["stats"][k]
                 warm[c] = all_stats[r]["warmup_stats"][k] if all_stats[r]["warmup_stats"] else []
+                if all_stats[r].get("all_stats") is not None:
+                    every[c] = all_stats[r]["all_stats"][k]
         result = dict(result)
         result["draws"] = full
+        if extras:
+            result["extra_draws"] = extras
+        if result.get("all_stats") is not None:
+            result["all_stats"] = every
         result["stats"] = stats
         result["warmup_stats"] = warm
         result["sampling_time_per_rank"] = [a["sampling_time"] for a in all_stats]

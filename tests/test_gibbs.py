@@ -647,3 +647,53 @@ def test_sample_assigns_nuts_and_gibbs_to_a_mixture_with_assignments():
     d = sample(model=low, draws=5, tune=10, chains=1, random_seed=2, device=0, init="adapt_diag")
     assert d["draws"].shape == (1, 5, low.n) and d["extra_draws"]["c"].shape == (1, 5, lm.YM.size) and d["extra_draws"]["c"].max() <= 3
     d["step"].close()
+
+
+@pytest.mark.parametrize("K,n", [(3, 5000), (5, 4097), (2, 4500)])
+def test_the_plan_pipeline_hands_out_the_plans_of_the_sequential_replay(K, n):
+    """Round 5: shuffle and per-element draws of a sweep are replayed by two host threads as a pipeline, the shuffle of sweep k + 1
+    starting from a generator state reached by a JUMP over sweep k's draws (`nuts_gibbs_plan_skip`).  Whatever the threads do, the
+    plans that come out are, sweep by sweep, the ones the sequential replay (`plan_sweep`, itself pinned to NumPy's generator above)
+    produces: candidates, logarithms, order and generator state, bit for bit."""
+    from pymc_amd import gibbs
+
+    k_of_dim = np.full(n, K, dtype="int32")
+    ref_rng, ref_order = np.random.default_rng(11), np.arange(n, dtype="int32")
+    rng = np.random.default_rng(11)
+    rng.integers(0, 7, dtype=np.uint32), ref_rng.integers(0, 7, dtype=np.uint32)      # (start with a buffered 32-bit half)
+    pipe = gibbs._PlanPipeline(rng.bit_generator.state, np.arange(n, dtype="int32"), k_of_dim, True)
+    try:
+        order = np.arange(n, dtype="int32")
+        for sweep in range(7):
+            want_cand, want_logu = gibbs.plan_sweep(ref_rng, ref_order, k_of_dim, True)
+            base_state, base_order, cand, log_u, order_after, after, clean = pipe.take()
+            assert clean
+            assert gibbs._state_key(base_state) == gibbs._state_key(rng.bit_generator.state) and np.array_equal(base_order, order), sweep
+            assert np.array_equal(cand, want_cand) and np.array_equal(log_u, want_logu) and np.array_equal(order_after, ref_order), sweep
+            assert gibbs._state_key(after) == gibbs._state_key(ref_rng.bit_generator.state), sweep
+            rng.bit_generator.state = after
+            order = order_after
+    finally:
+        pipe.close()
+
+
+@pytest.mark.gpu
+def test_compound_chains_from_threads_and_worker_processes_equal_the_sequential_run():
+    """BASELINE configs[4] names eight chains: the chains of a `CompoundStep([NUTS, CategoricalGibbsMetropolis])` run one after the
+    other, `cores` at a time from host threads (a compound step with its own engines per thread) or in worker processes
+    (`mp_ctx="spawn"`, pymc/sampling/parallel.py:352-524) -- positions, assignments and statistics are the same arrays.  N above the
+    plan pipeline's threshold, so the two-thread replay of the sweeps' random numbers is part of what is compared."""
+    from pymc_amd.sampling import sample
+
+    spec = models.normal_mixture(N=6000, K=3, seed=4)
+    kw = dict(draws=6, tune=8, chains=3, random_seed=9, device=0, init="adapt_diag")
+    seq = sample(model=spec, **kw)
+    seq["step"].close()
+    thr = sample(model=spec, cores=3, **kw)
+    thr["step"].close()
+    wrk = sample(model=spec, mp_ctx="spawn", **kw)
+    wrk["step"].close()
+    for other in (thr, wrk):
+        assert np.array_equal(seq["draws"], other["draws"]) and np.array_equal(seq["extra_draws"]["c"], other["extra_draws"]["c"])
+        assert [[int(s["tree_size"]) for s in ch] for ch in seq["stats"]] == [[int(s["tree_size"]) for s in ch] for ch in other["stats"]]
+    assert seq["extra_draws"]["c"].shape == (3, 6, 6000) and len({seq["draws"][c].tobytes() for c in range(3)}) == 3
