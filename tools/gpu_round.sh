@@ -28,6 +28,7 @@ if [[ $STAGES == *p* ]]; then
     grep -E '^\{' $OUT/prof_$TAG.log | head -1
     python $R/tools/rocpd_summary.py $OUT/prof_$TAG/trace_results.db --pmc $OUT/pmc_fetch_$TAG/pmc_results.db $OUT/pmc_write_$TAG/pmc_results.db
   } > $OUT/profile_$TAG.txt 2>&1
+  python $R/tools/rocpd_summary.py --launch-time $OUT/prof_$TAG/trace_results.db $OUT/launch_time_$TAG.json "k_rows_ga<" $TAG $HASH "python bench.py $PROF_ARGS"
   python $R/tools/rocpd_summary.py --traffic $OUT/pmc_fetch_$TAG/pmc_results.db $OUT/pmc_write_$TAG/pmc_results.db $OUT/traffic_$TAG.json k_rows $TAG $HASH
   rm -rf $OUT/prof_$TAG $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG   # raw rocpd databases are large; the summary is what is kept
   cd $R

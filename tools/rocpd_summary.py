@@ -206,8 +206,30 @@ def gap_positions(path, tail_frac=0.5):
           f"inner leaves mean {fm(inner, 0):.2f} median {fm(inner, 1):.2f} us (n={len(inner)})")
 
 
+def launch_time_json(trace_db, out_path, kernel_like, tag, src_hash, command=""):
+    """Duration of the dominant kernel's launches from a `rocprofv3 --kernel-trace` run (no counters, no marker packets): median and
+    mean over FULL launches (launches that drain behind a finished tree are told apart by their duration, less than half the
+    median).  bench.py carries these next to its own HIP-event figure (whose marker packets inflate the bracketed launch)."""
+    import json
+
+    cur = sqlite3.connect(trace_db).cursor()
+    dur = sorted(d for (d,) in cur.execute("select end-start from kernels where name like ?", (f"%{kernel_like}%",)))
+    if not dur:
+        raise SystemExit(f"no kernel like {kernel_like!r} in {trace_db}")
+    med_all = dur[len(dur) // 2]
+    full = [d for d in dur if d >= 0.5 * med_all]
+    out = {"kernel_like": kernel_like, "launches": len(dur), "full_launches": len(full), "median_us": full[len(full) // 2] / 1e3,
+           "mean_us": sum(full) / len(full) / 1e3, "mean_us_all_launches": sum(dur) / len(dur) / 1e3,
+           "source": f"rocprofv3 --kernel-trace --stats -- {command}".strip(" -") + f" (tag {tag})", "kernel_source_hash": src_hash}
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps(out))
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args[0] == "--launch-time":   # --launch-time <trace.db> <out.json> <kernel substring> <tag> <source hash> [command]
+        launch_time_json(*args[1:7])
+        sys.exit(0)
     if args[0] == "--traffic":   # --traffic <fetch.db> <write.db> <out.json> <kernel substring> <tag> <source hash> [json key] [note]
         traffic_json(*args[1:9])
         sys.exit(0)
