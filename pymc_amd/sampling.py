@@ -73,6 +73,12 @@ def initial_point(spec: ModelSpec) -> Dict[str, np.ndarray]:
     # values are the ones the model states
     for name, did in getattr(spec, "extra", {}).items():
         pt[name] = np.array(spec.data[did], dtype="float64", copy=True)
+    # a mixture whose assignments reach the log-density through their sufficient statistics (`models.normal_mixture`, the default
+    # form): the assignment variable itself is part of the point -- Categorical's support point is the mode of p
+    # (distributions/discrete.py `Categorical.support_point`: argmax), component 0 for equal weights
+    link = getattr(spec, "mixture", None)
+    if link is not None and link.name not in pt:
+        pt[link.name] = np.full(len(link.y), int(np.argmax(link.log_w)), dtype="int64")
     return pt
 
 
@@ -88,7 +94,9 @@ def _jitter_point(point, seed, extra=None):
     a PyTensor internal: the jitter VALUES are parity-unpinned.
     """
     rng = np.random.default_rng(seed)
-    return {k: (v + rng.uniform(-1, 1, size=np.shape(v)) if k not in (extra or ()) else v) for k, v in point.items()}
+    # (only floating-point entries are jittered: the discrete value variables of the point -- extra inputs of the log-density, or
+    # the assignment variable their statistics are derived from -- start where the model puts them)
+    return {k: (v + rng.uniform(-1, 1, size=np.shape(v)) if (k not in (extra or ()) and np.asarray(v).dtype.kind == "f") else v) for k, v in point.items()}
 
 
 def init_nuts(
@@ -201,12 +209,22 @@ def assign_step_methods(spec: ModelSpec, nuts_step, device=None):
     if not getattr(spec, "extra", None):
         return nuts_step
     link = getattr(spec, "mixture", None) or MixtureLink.from_spec(spec)
-    if link is None or link.name not in spec.extra:
+    if link is None or not (link.name in spec.extra or any(nm.startswith(link.name + "__") for nm in spec.extra)):
         return nuts_step     # (extras that are plain data of the caller: `set_extra_values` is theirs to call)
     logging.getLogger("pymc").info("CompoundStep")
     logging.getLogger("pymc").info(">NUTS: [%s]", ", ".join(v.name for v in spec.vars))
     logging.getLogger("pymc").info(">CategoricalGibbsMetropolis: [%s]", link.name)
     return CompoundStep([nuts_step, CategoricalGibbsMetropolis(model=spec, device=device)])
+
+
+def _recorded_extras(spec, point):
+    """The value variables of a point that are not gradient variables (what another step method samples): the spec's extra inputs
+    that are entries of the point, and the assignment variable of a mixture whose extras are FUNCTIONS of it."""
+    names = [k for k in getattr(spec, "extra", {}) if k in point]
+    link = getattr(spec, "mixture", None)
+    if link is not None and link.name in point and link.name not in names:
+        names.append(link.name)
+    return names
 
 
 def _compound_chain(comp, spec, start, rng, tune: int, draws: int):
@@ -216,7 +234,7 @@ def _compound_chain(comp, spec, start, rng, tune: int, draws: int):
     import time as _time
 
     total = tune + draws
-    extra_names = [k for k in getattr(spec, "extra", {})]
+    extra_names = _recorded_extras(spec, start)
     gvars = [v.value_name for v in spec.vars]
     comp.setup_chain(rng, tune, draws)
     comp.tune = bool(tune)
@@ -275,7 +293,7 @@ def _sample_compound(comp, spec, points, rngs, mine, tune, draws, discard_tuned_
     import time as _time
 
     n = spec.n
-    extra_names = [k for k in getattr(spec, "extra", {})]
+    extra_names = _recorded_extras(spec, points[mine[0]]) if len(mine) else []
     total = tune + draws
     local_draws = np.empty((len(mine), total, n))
     extra_draws = {k: [None] * len(mine) for k in extra_names}

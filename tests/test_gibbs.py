@@ -685,8 +685,8 @@ def test_compound_chains_from_threads_and_worker_processes_equal_the_sequential_
     plan pipeline's threshold, so the two-thread replay of the sweeps' random numbers is part of what is compared."""
     from pymc_amd.sampling import sample
 
-    spec = models.normal_mixture(N=6000, K=3, seed=4)
-    kw = dict(draws=6, tune=8, chains=3, random_seed=9, device=0, init="adapt_diag")
+    spec = models.normal_mixture(N=6000, K=3, seed=4)       # (the default form: the assignments reach NUTS through their sufficient statistics)
+    kw = dict(draws=6, tune=8, chains=3, random_seed=9, device=0, init="jitter+adapt_diag")
     seq = sample(model=spec, **kw)
     seq["step"].close()
     thr = sample(model=spec, cores=3, **kw)
