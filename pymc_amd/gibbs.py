@@ -54,9 +54,25 @@ class MixtureLink:
     sigma_log: bool = True             # ... log-transformed (`<sigma>_log__`)
 
     def __post_init__(self):
-        self._cache_for = None    # the array object the sweep produced (a strong reference: its id cannot be reused while cached)
-        self._cache_copy = None   # its contents at that moment (an in-place edit of the same object must not hit the cache)
-        self._cache = None
+        # What the sweep kernel just counted, per THREAD: the link is one object per model spec, shared by the step methods of every
+        # chain sampled from it -- also by chains that run concurrently from host threads (`sample(cores=...)`), each of which must
+        # only ever see the statistics of its own assignments.
+        self._tls = threading.local()
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_tls", None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self._tls = threading.local()
+
+    # the array object the sweep produced (a strong reference: its id cannot be reused while cached), its contents at that moment
+    # (an in-place edit of the same object must not hit the cache), and the statistics
+    _cache_for = property(lambda self: getattr(self._tls, "cache_for", None), lambda self, v: setattr(self._tls, "cache_for", v))
+    _cache_copy = property(lambda self: getattr(self._tls, "cache_copy", None), lambda self, v: setattr(self._tls, "cache_copy", v))
+    _cache = property(lambda self: getattr(self._tls, "cache", None), lambda self, v: setattr(self._tls, "cache", v))
 
     @property
     def K(self) -> int:
