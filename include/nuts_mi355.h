@@ -40,9 +40,10 @@ enum {
   NUTS_OP_TMP = 3, /* the result of instruction `ref` of the factor's expression program (below); only earlier instructions */
   NUTS_OP_GATHER = 4 /* var[idx[i]]: element idx[i] of variable `ref` for element i of the factor; `c` holds the id of the data
                         vector with the indices (stored as doubles, one per factor element) -- varying intercepts / slopes
-                        `a[group_idx]`.  A variable is gathered into a factor through ONE index vector; the gradient of element e
-                        is the sum over the factor elements that index e, in index order (an inverse index built when the model
-                        is created keeps it a deterministic gather) */
+                        `a[group_idx]`, or a broadcast of a vector against a matrix-shaped factor.  A variable may be gathered into
+                        a factor through several index vectors (and be a direct operand of it as well); per (variable, index
+                        vector) the gradient of element e is the sum over the factor elements that index e, in index order (an
+                        inverse index built when the model is created keeps it a deterministic gather) */
 };
 /* Expression programs.  An argument of a factor is `a + b * c`; where the model's expression is not of that form (a link
  * function, a Deterministic, a product of three quantities, a distribution whose density is written out op by op: whatever

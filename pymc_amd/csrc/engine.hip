@@ -540,11 +540,11 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     if (o.ref < 0 || o.ref >= nv) { g_err = "gather refers to a missing variable"; return false; }
     if (did < 0 || did >= s->n_data || (double)did != o.c) { g_err = "gather refers to a missing index vector"; return false; }
     if (s->data[did].size != f.size) { g_err = "gather: one index per element of the factor"; return false; }
+    // (a variable may be gathered into a factor through several index vectors -- the columns of `beta[idx]` summed over a small axis,
+    // a broadcast of a vector against a matrix -- and be a direct operand of it as well: every (variable, index vector) pair is a
+    // contribution of its own, and the reverse sweep credits a gather operand only to the pair it belongs to)
     for (const auto& gv : gathered)
-      if (gv.first == o.ref) {
-        if (gv.second != did) { g_err = "a variable is gathered into one factor through ONE index vector"; return false; }
-        return true;   // second occurrence of the same gather: already registered
-      }
+      if (gv.first == o.ref && gv.second == did) return true;   // second occurrence of the same gather: already registered
     gathered.emplace_back(o.ref, did);
     const int vs = vars[o.ref].size;
     const double* idx = s->data_pool + s->data[did].offset;
@@ -561,6 +561,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     cb.f = fi; cb.arg = -2; cb.slot = -1; cb.owner = 0; cb.fast = 0;
     cb.dist = (int32_t)csr.size(); csr.insert(csr.end(), ptr.begin(), ptr.end());
     cb.pad = (int32_t)csr.size(); csr.insert(csr.end(), lst.begin(), lst.end());
+    cb.p[0] = (double)did;   // which gather operands of the factor this contribution stands for
     per_var[o.ref].push_back(cb);
     fac[fi].pad = 1;
     m->has_prog = true;
@@ -654,8 +655,6 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
           fbt[fi].n++;
         } else { g_err = "variable does not broadcast against its factor"; return false; }
       }
-      for (const auto& gv : gathered)
-        if (std::find(seen.begin(), seen.end(), gv.first) != seen.end()) { g_err = "a variable is both gathered into a factor and a direct operand of it"; return false; }
       if (!owned_already) orphans.push_back(fi);
       continue;
     }
@@ -666,9 +665,6 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         if (o.kind == NUTS_OP_TMP) { g_err = "factor argument refers to an instruction but the factor has no program"; return false; }
         if (o.kind == NUTS_OP_GATHER) {
           if (!add_gather(fi, o)) return false;
-          for (int a2 = 0; a2 < f.nargs; ++a2)
-            for (const nuts_operand* o2 : {&f.arg[a2].a, &f.arg[a2].b, &f.arg[a2].c})
-              if (o2->kind == NUTS_OP_VAR && o2->ref == o.ref) { g_err = "a variable is both gathered into a factor and a direct operand of it"; return false; }
           continue;
         }
         if (o.kind == NUTS_OP_DATA) {

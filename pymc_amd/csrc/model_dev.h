@@ -748,7 +748,7 @@ __device__ __noinline__ double factor_arg0_value(const Prog& pg, const QView& qv
 }
 
 __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int own_var, double own_x,
-                                               int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out) {
+                                               int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out, int wrt_did = -1) {
   double tv[NUTS_MAX_FACTOR_INSTR], ta[NUTS_MAX_FACTOR_INSTR];
   ProgFwd o;
   prog_forward(pg, qv, f, li, own_var, own_x, tv, o);
@@ -763,7 +763,9 @@ __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, 
   auto push = [&](const nuts_operand& q, double g) {
     if (q.kind == NUTS_OP_TMP) { ta[q.ref] += g; return; }
     if (q.kind != NUTS_OP_VAR && q.kind != NUTS_OP_GATHER) return;
-    if (q.ref == wrt) { gw += g; return; }
+    // `wrt_did` < 0: the caller owns an element-aligned (or scalar) occurrence of `wrt`: its direct operands; >= 0: it stands for the
+    // gather of `wrt` through index vector `wrt_did`: those operands only (the others belong to other contributions of the variable)
+    if (q.ref == wrt && (wrt_did < 0 ? q.kind == NUTS_OP_VAR : (q.kind == NUTS_OP_GATHER && (int)q.c == wrt_did))) { gw += g; return; }
     if (want_bt && q.kind == NUTS_OP_VAR)
       for (int b = 0; b < bt.n; ++b)
         if (pg.bterm_var[bt.e[b].bterm] == q.ref) { s_bacc[bt.e[b].bterm * bstride] += g; break; }
@@ -878,7 +880,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       const int32_t* lst = pg.csr + cb.pad;
       for (int t = ptr[li]; t < ptr[li + 1]; ++t) {
         double gw;
-        factor_prog_rev(pg, qv, f, cb.f, lst[t], -1, 0.0, k, 0, s_bacc, bstride, &gw);
+        factor_prog_rev(pg, qv, f, cb.f, lst[t], -1, 0.0, k, 0, s_bacc, bstride, &gw, (int)cb.p[0]);
         gx += gw;
       }
       continue;

@@ -149,6 +149,8 @@ def build_tree(v, memo: Optional[dict] = None):
             out = build_tree(ins[1], memo)
         else:
             kids = [build_tree(i, memo) for i in ins]
+            if memo.get("__shapes__"):
+                kids = _wrap_broadcasts(v, ins, kids)
             if sn in _NUMPY_FOLD and all(k[0] == "const" for k in kids):
                 with np.errstate(all="ignore"):
                     out = _const(_NUMPY_FOLD[sn](*[k[1] for k in kids]))
@@ -165,6 +167,8 @@ def build_tree(v, memo: Optional[dict] = None):
         ax = getattr(op, "axis", None)
         if kid[0] == "const":                    # a reduction of a constant (`log(diag(cholesky(cov))).sum()` with a constant covariance)
             out = _const(np.sum(kid[1], axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax))
+        elif memo.get("__shapes__"):
+            out = ("sum", ax, kid, _eff_shape(ins[0]))      # (the op-by-op lowering unrolls a reduction over a short axis)
         else:
             out = ("sum", ax, kid)
     elif name == "Max":                           # `pt.max(x, axis)` (the shift of a softmax / logsumexp written out by hand)
@@ -229,7 +233,15 @@ def build_tree(v, memo: Optional[dict] = None):
         else:
             out = ("solve_lower" if getattr(op, "lower", False) else "solve_upper", a, b)
     elif name in ("AdvancedSubtensor1", "AdvancedSubtensor"):
-        out = ("take", build_tree(ins[0], memo), build_tree(ins[1], memo))
+        kid, ik = build_tree(ins[0], memo), build_tree(ins[1], memo)
+        shp = _eff_shape(ins[0]) if memo.get("__shapes__") else None
+        if shp is not None and len(shp) > 1 and ik[0] == "const" and np.asarray(ik[1]).ndim == 1:
+            # rows of a matrix-shaped operand (`beta[group_idx]` with beta [G, D]): as an index into the RAVELED operand, so that the
+            # element-wise programs can push it down to the leaves
+            inner = _numel(shp[1:])
+            rows = np.asarray(ik[1], dtype=np.int64)
+            ik = _const((rows[:, None] * inner + np.arange(inner)[None, :]).ravel())
+        out = ("take", kid, ik)
     elif name in ("Dot", "Matmul"):
         a, b = build_tree(ins[0], memo), build_tree(ins[1], memo)
         out = _const(np.asarray(a[1]) @ np.asarray(b[1])) if (a[0] == "const" and b[0] == "const") else ("dot", a, b)
@@ -246,6 +258,50 @@ def build_tree(v, memo: Optional[dict] = None):
     else:
         raise NotLowerable(f"op {name} is outside the lowering protocol")
     memo[key] = out
+    return out
+
+
+def _numel(shape) -> int:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
+def _eff_shape(v):
+    """The static shape of a graph variable as an operand: PyTensor's `DimShuffle` only adds / drops / permutes dimensions (the
+    result's `type.shape` has 1s where it broadcasts); the stand-in of the tests lets a DimShuffle claim the broadcast shape, so a
+    DimShuffle whose input has fewer ELEMENTS than it claims is looked through."""
+    shp = getattr(getattr(v, "type", None), "shape", None)
+    owner = getattr(v, "owner", None)
+    if owner is not None and type(owner.op).__name__ in ("DimShuffle", "ExpandDims") and shp is not None and all(d is not None for d in shp):
+        src = _eff_shape(owner.inputs[0])
+        if src is not None and _numel(src) != _numel(shp):
+            return src
+    if shp is None or any(d is None for d in shp):
+        return None
+    return tuple(int(d) for d in shp)
+
+
+def _wrap_broadcasts(v, ins, kids):
+    """Operands of an Elemwise node that have more than one element but fewer than the result: ("bcast", kid, idx, ishape, oshape),
+    idx[i] = the element of the operand that element i of the (raveled) result reads -- a broadcast between different shapes made
+    explicit, so that the element-wise programs (whose operands have one element or the factor's size) can express it as a gather."""
+    oshape = _eff_shape(v)
+    if oshape is None:
+        return kids
+    on = _numel(oshape)
+    out = []
+    for iv, kid in zip(ins, kids):
+        ishape = _eff_shape(iv)
+        if ishape is None or _numel(ishape) in (1, on) or kid[0] == "const" and np.asarray(kid[1]).size == 1:
+            out.append(kid)
+            continue
+        try:
+            idx = np.broadcast_to(np.arange(_numel(ishape)).reshape(ishape), oshape).ravel()
+        except ValueError:
+            raise NotLowerable(f"operand of shape {ishape} does not broadcast to {oshape}")
+        out.append(("bcast", kid, idx, ishape, oshape))
     return out
 
 
@@ -631,9 +687,11 @@ def _eval_tree(node, values: Dict[int, Any]):
             return x
         with np.errstate(all="ignore"):
             return (np.sum if kind == "sum" else np.max)(x, axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax)
+    if kind == "bcast":
+        return np.broadcast_to(np.reshape(np.asarray(_eval_tree(node[1], values)), node[3]), node[4])
     if kind == "join":
         return np.concatenate([np.atleast_1d(_eval_tree(k, values)) for k in node[2:]], axis=node[1])
-    a = [_eval_tree(k, values) for k in node[1:] if isinstance(k, tuple)]
+    a = [_eval_tree(k, values) for k in node[1:] if _is_node(k)]
     if kind in ("any", "all"):
         return (np.any if kind == "any" else np.all)(np.asarray(a[0]) != 0)
     with np.errstate(all="ignore"):
@@ -654,7 +712,7 @@ def _inputs_of(node, acc: Dict[int, Any]):
         acc[id(node[1])] = node[1]
     elif node[0] != "const":
         for k in node[1:]:
-            if isinstance(k, tuple):
+            if _is_node(k):
                 _inputs_of(k, acc)
     return acc
 
@@ -811,6 +869,18 @@ class _Lowering:
                         self._gather_ids[key] = len(self.spec.data) - 1
                     return ms.Operand(ms.OP_GATHER, float(self._gather_ids[key]), kv)
             return None
+        if node[0] == "bcast":   # a broadcast between shapes: a gather of the variable / a folded constant
+            kv = self._as_var(node[1])
+            idx = np.asarray(node[2], dtype="float64")
+            if kv is not None:
+                key = ("gather", kv, idx.tobytes())
+                if key not in self._gather_ids:
+                    self.spec.data.append(np.ascontiguousarray(idx))
+                    self._gather_ids[key] = len(self.spec.data) - 1
+                return ms.Operand(ms.OP_GATHER, float(self._gather_ids[key]), kv)
+            if node[1][0] == "const":
+                return self._operand(("const", np.asarray(node[1][1], dtype="float64").ravel()[np.asarray(node[2], dtype=np.int64)]))
+            return None
         if node[0] == "input" and id(node[1]) in self.extra_id:
             return ms.Operand(ms.OP_DATA, 0.0, self.extra_id[id(node[1])])
         if node[0] == "const":
@@ -894,6 +964,15 @@ class _Lowering:
             out = self._program(self._cond(node))
             self._prog_memo[id(node)] = out
             return out
+        elif op == "bcast" or (op == "take" and node[2][0] == "const"):
+            # a broadcast / a gather of an EXPRESSION (`(mu + sigma * z)[idx]`): the index is pushed down to the expression's leaves
+            out = self._program(self._index(node[1], np.asarray(node[2][1] if op == "take" else node[2], dtype=np.int64)))
+            self._prog_memo[id(node)] = out
+            return out
+        elif op == "sum" and len(node) == 4 and node[3] is not None:
+            out = self._program(self._unrolled_sum(node))
+            self._prog_memo[id(node)] = out
+            return out
         elif op in self._PROG_OPS:
             kids = [self._program(x) for x in node[1:]]
             code = self._PROG_OPS[op]
@@ -903,6 +982,76 @@ class _Lowering:
             raise NotLowerable(f"expression is outside the affine IR `a + b*c` and the expression programs: {_show(node)}")
         out = self._emit_instr(code, kids, k)
         self._prog_memo[id(node)] = out
+        return out
+
+    MAX_UNROLLED_SUM = 32
+
+    def _tsize(self, node) -> int:
+        """Number of elements an expression tree evaluates to (operands that broadcast were wrapped when the tree was built, so an
+        element-wise node has the size of its largest operand)."""
+        k = node[0]
+        if k == "const":
+            return int(np.asarray(node[1]).size)
+        if k == "input":
+            if id(node[1]) in self.var_id:
+                return self.spec.vars[self.var_id[id(node[1])]].size
+            if id(node[1]) in self.extra_id:
+                return int(self.spec.data[self.extra_id[id(node[1])]].size)
+            return 1
+        if k == "bcast":
+            return len(node[2])
+        if k == "take":
+            return self._tsize(node[2])
+        if k == "sum" and len(node) == 4 and node[3] is not None:
+            shp, ax = node[3], node[1]
+            if ax is None:
+                return 1
+            axes = [a % len(shp) for a in (ax if isinstance(ax, (list, tuple)) else [ax])]
+            return _numel([d for i, d in enumerate(shp) if i not in axes])
+        return max([self._tsize(x) for x in node[1:] if _is_node(x)] or [1])
+
+    def _index(self, node, idx):
+        """`node[idx]` with the index pushed down to the leaves: constants are indexed numerically, (backward-transformed) value
+        variables become gathers, index vectors compose, one-element operands stay as they are."""
+        if self._tsize(node) == 1:
+            return node
+        k = node[0]
+        if k == "const":
+            return ("const", np.asarray(node[1], dtype="float64").ravel()[idx])
+        if self._as_var(node) is not None or k == "input":
+            return ("take", node, ("const", np.asarray(idx, dtype="float64")))
+        if k == "take" and node[2][0] == "const":
+            return self._index(node[1], np.asarray(node[2][1], dtype=np.int64).ravel()[idx])
+        if k == "bcast":
+            return self._index(node[1], np.asarray(node[2], dtype=np.int64)[idx])
+        if k == "sum" and len(node) == 4 and node[3] is not None:
+            return self._index(self._unrolled_sum(node), idx)
+        if k in self._PROG_OPS or k in ("pow", "check", "all", "any", "makevector"):
+            return (k, *[self._index(x, idx) if _is_node(x) else x for x in node[1:]])
+        raise NotLowerable(f"an index / broadcast of `{k}` is outside the element-wise programs: {_show(node)}")
+
+    def _unrolled_sum(self, node):
+        """`expr.sum(axis)` over ONE short axis of an element-wise expression, written out: sum_r expr[..., r, ...] -- each term the
+        expression with the index of that slice pushed down to its leaves (`(X * beta[g]).sum(axis=1)`: D products and D - 1 sums)."""
+        _, ax, kid, shp = node
+        if ax is None:
+            axes = list(range(len(shp)))
+        else:
+            axes = sorted(a % len(shp) for a in (ax if isinstance(ax, (list, tuple)) else [ax]))
+        if len(axes) != 1:
+            if _numel(shp) <= self.MAX_UNROLLED_SUM:      # a full reduction of a small expression: element by element
+                terms = [self._index(kid, np.array([i])) for i in range(_numel(shp))]
+            else:
+                raise NotLowerable(f"a reduction over several axes inside an expression: {_show(node)}")
+        else:
+            a = axes[0]
+            if shp[a] > self.MAX_UNROLLED_SUM:
+                raise NotLowerable(f"a reduction over {shp[a]} elements inside an expression (a mat-vec: the dense nodes take `pm.math.dot`): {_show(node)}")
+            pos = np.arange(_numel(shp)).reshape(shp)
+            terms = [self._index(kid, np.take(pos, r, axis=a).ravel()) for r in range(shp[a])]
+        out = terms[0]
+        for t in terms[1:]:
+            out = ("add", out, t)
         return out
 
     def _cond(self, node):
@@ -1289,8 +1438,29 @@ class _Lowering:
             self._gather_ids = {}
         self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
         self._graph = graph
+        n_data, n_fac = len(self.spec.data), len(self.spec.factors)
         try:
-            self._factor(node, name, own_value)
+            try:
+                self._factor(node, name, own_value)
+            except NotLowerable as first:
+                # a template matched but its arguments are outside the affine terms' reach (operands of different shapes, a gather of an
+                # expression, a reduction over a short axis): the factor is lowered op by op from the graph itself, shapes and all
+                own = self.var_id.get(id(own_value)) if own_value is not None else None
+                if graph is None or (own is not None and self.spec.vars[own].simplex):
+                    raise
+                del self.spec.data[n_data:]
+                del self.spec.factors[n_fac:]
+                self._gather_ids = {k: v for k, v in self._gather_ids.items() if v < n_data}
+                self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+                try:
+                    self._general(node, name, own)
+                except NotLowerable as second:
+                    # (a refusal that names what the MODEL is -- Dirichlet weights with two components, a second regression likelihood --
+                    # says more than what the op-by-op path then met; a generic "outside the affine terms" says less)
+                    generic = str(first).startswith(("expression is outside", "operands of", "a power with", "the unconstrained value", "expression needs"))
+                    if generic:
+                        raise second from first
+                    raise first from second
         finally:
             self._prog = None
 
@@ -1444,8 +1614,10 @@ class _Lowering:
         random shape parameters, NegativeBinomial, Weibull, Logistic, ...).  The reference's parameter checks stay in the program
         (NUTS_E_CHECK), which is why the tree is rebuilt from the graph with the checks kept."""
         if self._graph is not None:
-            node = self._strip_jacobian(build_tree(self._graph, {"__keep_checks__": True}), own)
+            node = self._strip_jacobian(build_tree(self._graph, {"__keep_checks__": True, "__shapes__": True}), own)
             self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+        while node[0] == "sum" and (node[1] is None or (len(node) == 4 and node[3] is not None and len(node[3]) <= 1)):
+            node = node[2]        # `Model.logp` sums every factor anyway (model/core.py:666-695): a full reduction at a factor's root is the factor
         self._const_cache = {}
         try:
             t = self.term(node)
@@ -1462,6 +1634,10 @@ class _Lowering:
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)
 
 
+def _is_node(x) -> bool:
+    return isinstance(x, tuple) and len(x) > 0 and isinstance(x[0], str)
+
+
 def _show(node, depth=0) -> str:
     if node[0] == "const":
         return f"const{tuple(node[1].shape)}"
@@ -1469,7 +1645,9 @@ def _show(node, depth=0) -> str:
         return getattr(node[1], "name", "input")
     if depth > 3:
         return node[0] + "(...)"
-    return node[0] + "(" + ", ".join(_show(k, depth + 1) if isinstance(k, tuple) else str(k) for k in node[1:]) + ")"
+    if node[0] == "bcast":
+        return f"broadcast({_show(node[1], depth + 1)} -> {tuple(node[4])})"
+    return node[0] + "(" + ", ".join(_show(k, depth + 1) if _is_node(k) else str(k) for k in node[1:]) + ")"
 
 
 def as_model_spec(model) -> ms.ModelSpec:

@@ -578,7 +578,37 @@ def glm_with_mvnormal_prior():
     return m
 
 
+_GI6 = np.array([0, 2, 1, 1, 3, 0, 2, 3, 3, 1])
+_XS10 = np.linspace(-1.2, 1.4, 10)
+_YS10 = np.sin(np.arange(10.0)) + 0.3
+_XP = _rg.normal(size=(24, 3))
+_GP = np.sort(_rg.integers(0, 5, size=24))
+_YP = _rg.poisson(2.0, size=24).astype("float64")
+
+
+def shapes_broadcast_gather_and_rowsum():
+    """What the element-wise path could not express until round 5, in one model: a broadcast between shapes (`z2 [2, 3]` against
+    `s3 [3]`), a gather of an EXPRESSION (`(m0 + sd * zz)[idx] * x`: non-centred varying slopes) and a reduction over a short axis --
+    `(X * (mu + sigma * z)[g]).sum(axis=1)`, the hierarchical predictor as it is usually written, under a Poisson likelihood (no dense
+    node): z is gathered through one index vector per column."""
+    m = sg.StubModel()
+    z2 = m.Normal("z2", 0.0, 1.0, shape=(2, 3))
+    s3 = m.HalfNormal("s3", 1.0, shape=(3,))
+    m.Normal("yb", z2 * s3, 1.0, observed=np.arange(6.0).reshape(2, 3) * 0.1)
+    m0 = m.Normal("m0", 0.0, 1.0)
+    sd = m.HalfNormal("sd", 1.0)
+    zz = m.Normal("zz", 0.0, 1.0, shape=(4,))
+    m.Normal("yg", (m0 + sd * zz)[_GI6] * _XS10, 0.7, observed=_YS10)
+    mu = m.Normal("mu", 0.0, 1.0, shape=(3,))
+    sigma = m.HalfNormal("sigma", 1.0, shape=(3,))
+    z = m.Normal("z", 0.0, 1.0, shape=(5, 3))
+    eta = (sg.as_tensor(_XP) * (mu + sigma * z)[_GP]).sum(axis=1)
+    m.Poisson("yp", m.math.exp(0.3 * eta), observed=_YP)
+    return m
+
+
 GENERAL = {
+    "shapes_broadcast_gather_and_rowsum": shapes_broadcast_gather_and_rowsum,
     "robust_regression": robust_regression,
     "random_shape_parameters": random_shape_parameters,
     "negative_binomial_regression": negative_binomial_regression,

@@ -170,9 +170,9 @@ def test_a_model_object_that_is_outside_the_ir_raises_notlowerable_from_the_step
     if not sg.available():
         pytest.skip("builds a graph with the reference's code")
     m = sg.StubModel()
-    z2 = m.Normal("z2", 0.0, 1.0, shape=(2, 3))
-    s3 = m.HalfNormal("s3", 1.0, shape=(3,))
-    m.Normal("y", (z2 * s3).sum(axis=1), 1.0, observed=np.zeros(2))     # a reduction inside a likelihood's parameter
+    z2 = m.Normal("z2", 0.0, 1.0, shape=(2, 40))
+    s3 = m.HalfNormal("s3", 1.0, shape=(40,))
+    m.Normal("y", (z2 * s3).sum(axis=1), 1.0, observed=np.zeros(2))     # a LONG reduction inside a likelihood's parameter: a mat-vec that is not `dot(X, beta)`
     with pytest.raises(NotLowerable):
         NUTS(model=m, defer_device=True)
     with pytest.raises(NotImplementedError):

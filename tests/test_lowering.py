@@ -103,18 +103,59 @@ def test_what_the_ir_cannot_express_is_refused_by_name():
     m.Normal("y", a ** b, 1.0, observed=np.zeros(4))           # a power with a VARIABLE exponent: refused until round 5, now x ** y of the
     spec = lower_to_spec(m)                                    # expression programs (NUTS_E_POW; tests/test_general_lowering.py)
     assert [i.op for i in spec.factors[-1].prog] == [ms_mod.E_POW]
+    # what is still refused, by name: a reduction over a long axis inside an argument (a mat-vec that is not `pm.math.dot(X, beta)` with a
+    # constant X: the dense nodes' business), a Cholesky of a non-constant matrix
+    m = sg.StubModel()
+    zb = m.Normal("zb", 0.0, 1.0, shape=(40,))
+    wb = m.Normal("wb", 0.0, 1.0, shape=(40,))
+    m.Normal("y", (zb * wb).sum(), 1.0, observed=np.zeros(1))
+    with pytest.raises(NotLowerable, match="reduction over 40 elements"):
+        lower_to_spec(m)
+
+
+def test_broadcasts_gathers_of_expressions_and_short_reductions_lower_op_by_op():
+    """Refused until round 5 ("operands of different shapes", "a gather of an EXPRESSION", "sum inside an argument"), now lowered by
+    the shape-aware op-by-op path: a broadcast between shapes becomes a gather, an index of an expression is pushed down to its
+    leaves, a reduction over a short axis is written out -- `(X * (mu + sigma * z)[g]).sum(axis=1)`, the hierarchical predictor as it
+    is usually written, under a likelihood that has no dense node (Poisson), z gathered through one index vector per column.  Pinned
+    by autograd of the graphs themselves (tests/graph_torch.py)."""
+    import graph_torch as gt
+
+    def check(m, n_gather_vectors=None):
+        spec = lower_to_spec(m)
+        rng = np.random.default_rng(1)
+        for _ in range(3):
+            q = rng.normal(size=spec.n) * 0.5
+            lp, g = ref_models.evaluate(spec, q)
+            lp0, g0 = gt.joint_logp_grad(m, q)
+            assert abs(lp - lp0) <= 1e-12 * max(1.0, abs(lp0)) and np.max(np.abs(g - g0)) <= 1e-11 * max(1.0, np.max(np.abs(g0)))
+        return spec
+
     m = sg.StubModel()
     z2 = m.Normal("z2", 0.0, 1.0, shape=(2, 3))
     s3 = m.HalfNormal("s3", 1.0, shape=(3,))
-    m.Normal("y", z2 * s3, 1.0, observed=np.zeros((2, 3)))     # a broadcast between different shapes inside an element-wise factor
-    with pytest.raises(NotLowerable, match="broadcast|does not"):
-        lower_to_spec(m)
+    m.Normal("y", z2 * s3, 1.0, observed=np.arange(6.0).reshape(2, 3) * 0.1)     # (3,) against (2, 3)
+    spec = check(m)
+    assert any(o.kind == ms_mod.OP_GATHER for i in spec.factors[-1].prog for o in (i.x, i.y, i.z))
     m = sg.StubModel()
-    z = m.Normal("z", 0.0, 1.0, shape=(3,))
-    w = m.Normal("w", 0.0, 1.0, shape=(3,))
-    m.Normal("y", (z * w)[np.array([0, 2, 1, 1])], 1.0, observed=np.zeros(4))   # a gather of an EXPRESSION (only a variable itself is gathered)
-    with pytest.raises(NotLowerable):
-        lower_to_spec(m)
+    mu = m.Normal("mu", 0.0, 1.0)
+    sd = m.HalfNormal("sd", 1.0)
+    z = m.Normal("z", 0.0, 1.0, shape=(4,))
+    m.Normal("y", (mu + sd * z)[np.array([0, 2, 1, 1, 3, 0])] * np.linspace(-1, 1, 6), 0.7, observed=np.sin(np.arange(6.0)))   # a gather of an EXPRESSION
+    check(m)
+    rng = np.random.default_rng(0)
+    G, D, N = 5, 3, 20
+    X, gi, yc = rng.normal(size=(N, D)), np.sort(rng.integers(0, G, size=N)), rng.poisson(2.0, size=N).astype(float)
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 1.0, shape=(D,))
+    sigma = m.HalfNormal("sigma", 1.0, shape=(D,))
+    z = m.Normal("z", 0.0, 1.0, shape=(G, D))
+    eta = (sg.as_tensor(X) * (mu + sigma * z)[gi]).sum(axis=1)
+    m.Poisson("y", m.math.exp(0.3 * eta), observed=yc)
+    spec = check(m)
+    zi = [v.name for v in spec.vars].index("z")
+    vecs = {int(o.c) for i in spec.factors[-1].prog for o in (i.x, i.y, i.z) if o.kind == ms_mod.OP_GATHER and o.ref == zi}
+    assert len(vecs) == D            # z is gathered through one index vector per column
 
 
 def _torch_reference(name, q):
