@@ -1281,17 +1281,22 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
         gm.konst -= std::lgamma(yi + 1.0);     // factln(y): parameter-free (discrete.py:581-597)
       }
     }
-    if (gm.Ppad == gm.P) gm.X = m->keep(dev_upload(s->glm_X, (size_t)gm.N * gm.P));
-    else {   // zero-padded rows, uploaded in slabs (the padded copy of a large X never exists on the host)
-      double* xd = m->keep(dev_alloc<double>((size_t)gm.N * gm.Ppad));
+    gm.xstride = (gm.P + 1) & ~1; gm.xpad_ = 0;   // 16-byte rows; the layout's last chunks read on into the next row (glm_kernel.h)
+    {   // rows at their own stride + one layout width of zeros behind the last row (what its last chunks read), uploaded in slabs
+      const size_t total = (size_t)gm.N * gm.xstride + (size_t)gm.Ppad;
+      double* xd = m->keep(dev_alloc<double>(total));
       gm.X = xd;
       if (xd) {
-        const int64_t slab = std::max<int64_t>(1, (int64_t)(1 << 22) / gm.Ppad);
-        std::vector<double> buf((size_t)slab * gm.Ppad, 0.0);
-        for (int64_t r0 = 0; r0 < gm.N; r0 += slab) {
-          const int64_t nr = std::min<int64_t>(slab, gm.N - r0);
-          for (int64_t r = 0; r < nr; ++r) std::memcpy(&buf[(size_t)r * gm.Ppad], s->glm_X + (size_t)(r0 + r) * gm.P, (size_t)gm.P * sizeof(double));
-          hipMemcpy(xd + (size_t)r0 * gm.Ppad, buf.data(), (size_t)nr * gm.Ppad * sizeof(double), hipMemcpyHostToDevice);
+        hipMemset(xd + (size_t)gm.N * gm.xstride, 0, (size_t)gm.Ppad * sizeof(double));
+        if (gm.xstride == gm.P) hipMemcpy(xd, s->glm_X, (size_t)gm.N * gm.P * sizeof(double), hipMemcpyHostToDevice);
+        else {
+          const int64_t slab = std::max<int64_t>(1, (int64_t)(1 << 22) / gm.xstride);
+          std::vector<double> buf((size_t)slab * gm.xstride, 0.0);
+          for (int64_t r0 = 0; r0 < gm.N; r0 += slab) {
+            const int64_t nr = std::min<int64_t>(slab, gm.N - r0);
+            for (int64_t r = 0; r < nr; ++r) std::memcpy(&buf[(size_t)r * gm.xstride], s->glm_X + (size_t)(r0 + r) * gm.P, (size_t)gm.P * sizeof(double));
+            hipMemcpy(xd + (size_t)r0 * gm.xstride, buf.data(), (size_t)nr * gm.xstride * sizeof(double), hipMemcpyHostToDevice);
+          }
         }
       }
     }
@@ -1368,7 +1373,8 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   else if (k == "rows_aux_workgroups") *out = m->md.lg.ga ? m->md.lg.ga_naux : 0;
   else if (k == "mixture_workgroups") *out = m->md.has_mix ? m->md.mix.nwg : 0;
   else if (k == "glm_workgroups") *out = m->md.has_glm ? m->md.glm.nwg : 0;
-  else if (k == "glm_row_stride") *out = m->md.has_glm ? m->md.glm.Ppad : 0;
+  else if (k == "glm_row_stride") *out = m->md.has_glm ? m->md.glm.xstride : 0;
+  else if (k == "glm_layout_width") *out = m->md.has_glm ? m->md.glm.Ppad : 0;
   else if (k == "mvn_row_aligned") *out = m->md.has_mvn ? m->md.mv.aligned : 0;
   else if (k == "rows_waves") *out = m->md.lg.ga ? m->md.lg.ga_w : m->md.lg.n_waves;
   else if (k == "lean") *out = m->md.lean_ok;

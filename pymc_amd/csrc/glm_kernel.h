@@ -8,6 +8,10 @@
 // The most common PyMC model, and configs[3]'s own (1 M rows x 512 covariates: X = 4.1 GB, resident in HBM).  A leapfrog needs X
 // twice -- forward for eta, backward for X^T r -- and the pass is bound by the bytes of X, so both are done from ONE read:
 //
+//   * rows are stored with a stride of P rounded up to even (16-byte rows), not of the register layout's width: the chunks of a row
+//     that lie beyond P read on into the next row -- bytes the pass reads anyway -- where beta' is 0 (forward) and whose gradient
+//     slots are dropped (backward); the pass moves 8 N P bytes for every P (round 4 padded the rows to the layout's width: up to
+//     1.97 x at P = 65);
 //   * a row lives in the registers of `lpr` consecutive lanes (a power of two: 64 for P = 512 -- one row per wave-iteration, 8
 //     doubles per lane -- down to 1 for P <= 8: 64 rows per wave-iteration), `ch` 16-byte chunks per lane; chunk c of a row is the
 //     columns [2 lpr c, 2 lpr (c + 1)), lane s of the row's group holding columns 2 (lpr c + s), + 1: every load instruction of a
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(GLM_BLOCK) void k_glm_rows(ModelDev md, ArenaDev A,
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
   const int sub = lane & (LPR - 1), grp = lane / LPR;
   const int Ppad = 2 * LPR * CH;
+  const int64_t xstride = gm.xstride;
   __shared__ double s_part[NW][2 * LPR * CH];
   __shared__ double s_sc[NW][4];
 
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(GLM_BLOCK) void k_glm_rows(ModelDev md, ArenaDev A,
   double yn[GLM_PF];
   auto request = [&](int64_t r, double2 (&x)[CH], double& yv) {
     const int64_t row = min(r + grp, gm.N - 1);   // (rows past the range: valid addresses, masked below)
-    const double2* p = reinterpret_cast<const double2*>(X + row * Ppad) + sub;
+    const double2* p = reinterpret_cast<const double2*>(X + row * xstride) + sub;
 #pragma unroll
     for (int c = 0; c < CH; ++c) x[c] = p[c * LPR];
     yv = gm.y[row];

@@ -151,7 +151,10 @@ struct MixDev {
 // dense node 4: generalised linear model rows (glm_kernel.h)
 struct GlmDev {
   int64_t N;
-  int32_t P, Ppad;          // covariates; stored row length (a multiple of 2 LPR, zero-padded)
+  int32_t P, Ppad;          // covariates; width of the register layout = 2 lpr ch >= P (also the length of a workgroup's record)
+  int32_t xstride, xpad_;   // stored row length in doubles: P rounded up to even (16-byte rows), NOT Ppad -- a row's last chunks
+                            // read on into the next row (whose bytes the pass reads anyway; beta is 0 there and the gradient slots
+                            // beyond P are dropped), so the pass moves 8 N P bytes whatever the layout's width
   int32_t family, lpr, ch;  // NUTS_GLM_*; lanes per row (a power of two); 16-byte chunks per lane: Ppad = 2 lpr ch
   int32_t off_beta, off_icpt, off_sigma, tr_sigma, nwg;   // element offsets (off_icpt / off_sigma < 0: none / the constant)
   // beta a DERIVED vector (NUTS_D_DERIVED, off_beta < 0): its values, written by k_derive before the pass, and where the node leaves

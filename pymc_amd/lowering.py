@@ -69,7 +69,7 @@ class NotLowerable(NotImplementedError):
 _ELEMWISE_ALIASES = {"truediv": "div", "true_div": "div", "scalarsigmoid": "sigmoid", "scalarsoftplus": "softplus", "second": "second",
                      "identity": "identity", "and_": "and", "or_": "or", "sgn": "sign", "reciprocal": "reciprocal",
                      "scalarmaximum": "maximum", "scalarminimum": "minimum", "psi": "digamma", "invert": "not", "log1pexp": "softplus",
-                     "scalarlogaddexp": "logaddexp", "arctan": "arctan", "bitwise_and": "and", "bitwise_or": "or"}
+                     "scalarlogaddexp": "logaddexp", "arctan": "arctan", "bitwise_and": "and", "bitwise_or": "or", "isclose": "isclose"}
 _NUMPY_FOLD = {
     "add": np.add, "sub": np.subtract, "mul": np.multiply, "div": np.divide, "neg": np.negative, "exp": np.exp, "log": np.log,
     "log1p": np.log1p, "sqrt": np.sqrt, "sqr": np.square, "pow": np.power, "abs": np.abs, "reciprocal": np.reciprocal,
@@ -174,7 +174,10 @@ def build_tree(v, memo: Optional[dict] = None):
     elif name == "Max":                           # `pt.max(x, axis)` (the shift of a softmax / logsumexp written out by hand)
         kid = build_tree(ins[0], memo)
         ax = getattr(op, "axis", None)
-        out = _const(np.max(kid[1], axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax)) if kid[0] == "const" else ("max", ax, kid)
+        if kid[0] == "const":
+            out = _const(np.max(kid[1], axis=tuple(ax) if isinstance(ax, (list, tuple)) else ax))
+        else:
+            out = ("max", ax, kid, _eff_shape(ins[0])) if memo.get("__shapes__") else ("max", ax, kid)
     elif name == "Join":                          # `pt.concatenate(tensors, axis)`
         kids = [build_tree(i, memo) for i in ins]
         ax = getattr(op, "axis", 0)
@@ -253,6 +256,8 @@ def build_tree(v, memo: Optional[dict] = None):
         kids = [build_tree(i, memo) for i in ins]
         if name in ("All", "Any") and kids[0][0] == "const":
             out = _const(float((np.all if name == "All" else np.any)(np.asarray(kids[0][1]) != 0)))
+        elif name in ("All", "Any") and memo.get("__shapes__"):
+            out = (name.lower(), kids[0], getattr(op, "axis", None), _eff_shape(ins[0]))   # (a reduction: the op-by-op lowering unrolls it)
         else:
             out = (name.lower(), *kids)
     else:
@@ -803,6 +808,7 @@ class _Lowering:
     def __init__(self, value_vars, transforms, shapes, extra_vars=(), extra_values=None):
         self.spec = ms.ModelSpec()
         self._dirichlet: Dict[int, np.ndarray] = {}     # simplex variable -> its Dirichlet concentrations, until a mixture takes it as its weights
+        self._dirichlet_graph: Dict[int, Any] = {}      # ... and (graph, name) of its factor, for the variables no mixture takes
         self.var_id: Dict[int, int] = {}
         # value variables that are inputs of the log-density but not of its gradient (discrete variables another step method
         # updates; model/core.py:142-190 `extra_vars`): data vectors the caller rewrites (`set_extra_values`), registered by name
@@ -859,6 +865,9 @@ class _Lowering:
             return ms.Operand(ms.OP_VAR, 0.0, k)
         if node[0] == "take":   # a[idx] with a constant integer index vector: a gather (NUTS_OP_GATHER), e.g. varying intercepts
             kv = self._as_var(node[1])
+            if kv is None and self._const_cache is not None and node[1][0] == "input" and id(node[1][1]) in self.var_id \
+                    and self.spec.vars[self.var_id[id(node[1][1])]].simplex:
+                kv = self.var_id[id(node[1][1])]
             if kv is not None and node[2][0] == "const" and np.asarray(node[2][1]).ndim == 1:
                 idx = np.asarray(node[2][1], dtype="float64")
                 n = self.spec.vars[kv].size
@@ -869,6 +878,10 @@ class _Lowering:
                         self._gather_ids[key] = len(self.spec.data) - 1
                     return ms.Operand(ms.OP_GATHER, float(self._gather_ids[key]), kv)
             return None
+        if node[0] == "input" and self._const_cache is not None and id(node[1]) in self.var_id and self.spec.vars[self.var_id[id(node[1])]].simplex:
+            # (op-by-op lowering only) the stored value of a simplex-transformed variable: `SimplexTransform.backward` is part of the
+            # graph, the device hands the K - 1 stored elements out as they are
+            return ms.Operand(ms.OP_VAR, 0.0, self.var_id[id(node[1])])
         if node[0] == "bcast":   # a broadcast between shapes: a gather of the variable / a folded constant
             kv = self._as_var(node[1])
             idx = np.asarray(node[2], dtype="float64")
@@ -898,6 +911,7 @@ class _Lowering:
         return None
 
     _const_cache = None
+    _fsize = 0     # elements of the factor being lowered op by op (`_general`)
 
     def term(self, node) -> ms.Term:
         """`a + b * c` over constants, data vectors and value variables."""
@@ -943,8 +957,9 @@ class _Lowering:
         o = self._operand(node)
         if o is not None:
             return o
-        if id(node) in self._prog_memo:
-            return self._prog_memo[id(node)]
+        hit = self._prog_memo.get(id(node))
+        if hit is not None and hit[0] is node:      # (the node itself is kept: trees made on the fly by `_index` die, and ids are reused)
+            return hit[1]
         op = node[0]
         k = 0.0
         if op == "pow":
@@ -958,21 +973,32 @@ class _Lowering:
             out = self._program(node[1])
             for c in node[2:]:
                 out = self._emit_instr(ms.E_CHECK, [out, self._program(self._cond(c))])
-            self._prog_memo[id(node)] = out
+            self._prog_memo[id(node)] = (node, out)
             return out
         elif op in ("all", "any", "makevector"):
             out = self._program(self._cond(node))
-            self._prog_memo[id(node)] = out
+            self._prog_memo[id(node)] = (node, out)
             return out
         elif op == "bcast" or (op == "take" and node[2][0] == "const"):
             # a broadcast / a gather of an EXPRESSION (`(mu + sigma * z)[idx]`): the index is pushed down to the expression's leaves
             out = self._program(self._index(node[1], np.asarray(node[2][1] if op == "take" else node[2], dtype=np.int64)))
-            self._prog_memo[id(node)] = out
+            self._prog_memo[id(node)] = (node, out)
             return out
-        elif op == "sum" and len(node) == 4 and node[3] is not None:
+        elif op in ("sum", "max") and len(node) == 4 and node[3] is not None:
             out = self._program(self._unrolled_sum(node))
-            self._prog_memo[id(node)] = out
+            self._prog_memo[id(node)] = (node, out)
             return out
+        elif op in ("all", "any") and len(node) == 4 and node[3] is not None and _numel(node[3]) > 1:
+            out = self._program(self._unrolled_sum((op, node[2], node[1], node[3])))
+            self._prog_memo[id(node)] = (node, out)
+            return out
+        elif op == "isclose":                     # pytensor `isclose(a, b)`: |a - b| <= atol + rtol |b| (rtol 1e-5, atol 1e-8)
+            a_, b_ = node[1], node[2]
+            out = self._program(("le", ("abs", ("sub", a_, b_)), ("add", _const(1e-8), ("mul", _const(1e-5), ("abs", b_)))))
+            self._prog_memo[id(node)] = (node, out)
+            return out
+        elif op == "join":
+            raise NotLowerable(f"a concatenation that is not reduced or indexed element by element: {_show(node)}")
         elif op in self._PROG_OPS:
             kids = [self._program(x) for x in node[1:]]
             code = self._PROG_OPS[op]
@@ -981,7 +1007,7 @@ class _Lowering:
         else:
             raise NotLowerable(f"expression is outside the affine IR `a + b*c` and the expression programs: {_show(node)}")
         out = self._emit_instr(code, kids, k)
-        self._prog_memo[id(node)] = out
+        self._prog_memo[id(node)] = (node, out)
         return out
 
     MAX_UNROLLED_SUM = 32
@@ -1002,7 +1028,12 @@ class _Lowering:
             return len(node[2])
         if k == "take":
             return self._tsize(node[2])
-        if k == "sum" and len(node) == 4 and node[3] is not None:
+        if k == "join":
+            return sum(self._tsize(x) for x in node[2:])
+        if k in ("all", "any") and len(node) == 4 and node[3] is not None:
+            node = (k, node[2], node[1], node[3])
+            k = "sum"
+        if k in ("sum", "max") and len(node) == 4 and node[3] is not None:
             shp, ax = node[3], node[1]
             if ax is None:
                 return 1
@@ -1019,13 +1050,23 @@ class _Lowering:
         if k == "const":
             return ("const", np.asarray(node[1], dtype="float64").ravel()[idx])
         if self._as_var(node) is not None or k == "input":
-            return ("take", node, ("const", np.asarray(idx, dtype="float64")))
+            return ("take", node, ("const", np.asarray(idx, dtype="float64")))      # (`_operand` turns it into a gather)
         if k == "take" and node[2][0] == "const":
             return self._index(node[1], np.asarray(node[2][1], dtype=np.int64).ravel()[idx])
         if k == "bcast":
             return self._index(node[1], np.asarray(node[2], dtype=np.int64)[idx])
-        if k == "sum" and len(node) == 4 and node[3] is not None:
+        if k in ("sum", "max") and len(node) == 4 and node[3] is not None:
             return self._index(self._unrolled_sum(node), idx)
+        if k in ("all", "any") and len(node) == 4 and node[3] is not None:
+            return self._index(self._unrolled_sum((k, node[2], node[1], node[3])), idx)
+        if k == "join":        # one-dimensional concatenation: the indexed elements must come from ONE of the joined pieces
+            sizes = [self._tsize(x) for x in node[2:]]
+            starts = np.concatenate([[0], np.cumsum(sizes)])
+            idx = np.asarray(idx, dtype=np.int64)
+            for j, piece in enumerate(node[2:]):
+                if np.all((idx >= starts[j]) & (idx < starts[j + 1])):
+                    return self._index(piece, idx - starts[j]) if sizes[j] > 1 else piece
+            raise NotLowerable(f"an index that spans several pieces of a concatenation: {_show(node)}")
         if k in self._PROG_OPS or k in ("pow", "check", "all", "any", "makevector"):
             return (k, *[self._index(x, idx) if _is_node(x) else x for x in node[1:]])
         raise NotLowerable(f"an index / broadcast of `{k}` is outside the element-wise programs: {_show(node)}")
@@ -1033,7 +1074,8 @@ class _Lowering:
     def _unrolled_sum(self, node):
         """`expr.sum(axis)` over ONE short axis of an element-wise expression, written out: sum_r expr[..., r, ...] -- each term the
         expression with the index of that slice pushed down to its leaves (`(X * beta[g]).sum(axis=1)`: D products and D - 1 sums)."""
-        _, ax, kid, shp = node
+        kind, ax, kid, shp = node
+        comb = {"sum": "add", "max": "maximum", "all": "and", "any": "or"}[kind]
         if ax is None:
             axes = list(range(len(shp)))
         else:
@@ -1051,13 +1093,19 @@ class _Lowering:
             terms = [self._index(kid, np.take(pos, r, axis=a).ravel()) for r in range(shp[a])]
         out = terms[0]
         for t in terms[1:]:
-            out = ("add", out, t)
+            out = (comb, out, t)
         return out
 
     def _cond(self, node):
         """The conditions of a `check_parameters` / `pt.all([...])`: element-wise AND (OR for `any`) of the listed conditions -- the
         reduction to one scalar over the factor's elements (`pt.all`) is what NUTS_E_CHECK means on the device (a failed check kills
         the whole factor)."""
+        if node[0] in ("all", "any") and len(node) == 4 and node[3] is not None and node[1][0] != "makevector" \
+                and 1 < _numel(node[3]) <= self.MAX_UNROLLED_SUM and _numel(node[3]) != self._fsize:
+            # a vector-valued condition inside a factor of another size (`a > 0` of a Dirichlet's K concentrations, whose density is
+            # one number): every element, written out.  A condition with one value per element of the factor stays element-wise --
+            # the reduction over the factor's elements is what NUTS_E_CHECK means.
+            return self._unrolled_sum((node[0], None, node[1], node[3]))
         if node[0] in ("all", "any"):
             inner = node[1]
             parts = list(inner[1:]) if inner[0] == "makevector" else [inner]
@@ -1472,7 +1520,7 @@ class _Lowering:
                                    "between different shapes is outside the element-wise factors")
         self.spec.factors.append(ms.Factor(dist, max(self._size(a) for a in args), tuple(args), konst, name, tuple(self._prog)))
 
-    def _dirichlet_factor(self, node, own: int, own_value) -> None:
+    def _dirichlet_factor(self, node, own: int, own_value, name: str = "") -> None:
         """The factor of a simplex-transformed variable y (K - 1 elements): `Dirichlet.logp(backward(y), a)` + `log_jac_det(y)`
         (multivariate.py:557-584, logprob/transforms.py:1101-1115, transform_value.py:95-133).  Like TruncatedNormal's normalising term,
         the graph -- joins, a max-shifted softmax, `logpow` switches, support tests -- is IDENTIFIED BY EVALUATION: with
@@ -1505,6 +1553,7 @@ class _Lowering:
             raise NotLowerable("the prior of a simplex-transformed variable is not a Dirichlet density")
         rounded = np.round(a, 12)       # (the least-squares solution carries rounding: concentrations are what the model states)
         self._dirichlet[own] = np.where(np.abs(rounded - a) < 1e-9, rounded, a)
+        self._dirichlet_graph[own] = (self._graph, name)   # (if no mixture claims the variable: lowered op by op at the end)
 
     def _simplex_weights(self, wnode) -> Optional[int]:
         """`wnode` = the weights of a mixture: the simplex variable whose `SimplexTransform.backward` it is (verified by evaluation)."""
@@ -1527,7 +1576,7 @@ class _Lowering:
     def _factor(self, node, name: str, own_value=None):
         own = self.var_id.get(id(own_value)) if own_value is not None else None
         if own is not None and self.spec.vars[own].simplex:
-            self._dirichlet_factor(node, own, own_value)
+            self._dirichlet_factor(node, own, own_value, name)
             return
         node = self._strip_jacobian(node, own)
         if own is None and self._mixture(node):
@@ -1620,16 +1669,18 @@ class _Lowering:
             node = node[2]        # `Model.logp` sums every factor anyway (model/core.py:666-695): a full reduction at a factor's root is the factor
         self._const_cache = {}
         try:
+            self._fsize = self._tsize(node)
             t = self.term(node)
         finally:
             self._const_cache = None
+            self._fsize = 0
         size = self._size(t)
         for ins in self._prog:        # every operand broadcasts against the factor: size 1 or the factor's size
             for o in (ins.x, ins.y, ins.z):
                 if self._osize(o) not in (1, size):
                     raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
                                        "between different shapes is outside the element-wise programs")
-        if own is not None and self.spec.vars[own].size not in (1, size) :
+        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex:
             raise NotLowerable(f"the factor of {self.spec.vars[own].name} does not have the variable's shape")
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)
 
@@ -1698,8 +1749,21 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
         low.factor(build_tree(g, memo), nm, own, graph=g)
     if low._cat:
         raise NotLowerable("a Categorical variable that does not index an observed Normal (the IR has no free-standing Categorical factor)")
-    if low._dirichlet:
-        raise NotLowerable("a Dirichlet variable that is not the weight vector of a mixture over observed rows (the IR has no free-standing Dirichlet factor)")
+    # Dirichlet variables no mixture node took as its weights (`w ~ Dirichlet; counts ~ Multinomial(n, w)`, a Dirichlet with K = 2 next to
+    # anything): their factor -- `Dirichlet.logp(SimplexTransform.backward(y))` + `log_jac_det(y)`, reductions over the K elements
+    # written out -- is lowered op by op like any other density that has no code of its own
+    for own in list(low._dirichlet):
+        graph, nm = low._dirichlet_graph[own]
+        low._prog, low._prog_size, low._prog_memo, low._prog_cse = [], [], {}, {}
+        low._graph = graph
+        try:
+            low._general(None, nm, own)
+        except NotLowerable as e:
+            raise NotLowerable(f"a Dirichlet variable that is neither the weight vector of a mixture over observed rows nor small enough to be "
+                               f"written out element by element: {e}")
+        finally:
+            low._prog = None
+        del low._dirichlet[own]
     # `pm.Deterministic` variables (model/core.py:1940-2005): recorded in the trace next to the free variables (backends/base.py:
     # 183-191), no contribution to the log-density.  `model.deterministics`: {name: graph variable} (a list of named variables on a
     # real `pm.Model`).  One that the IR cannot express is left out of the trace with a warning, not a failure of the lowering.

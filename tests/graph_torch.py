@@ -36,7 +36,7 @@ def _scalar_fns():
         "Erf": torch.erf, "Erfc": torch.erfc, "Erfcx": torch.special.erfcx, "Sqr": lambda a: F(a) * F(a), "Cast": lambda a: F(a),
         "Clip": lambda x, lo, hi: torch.minimum(torch.maximum(F(x), F(lo)), F(hi)), "Log1mexp": log1mexp, "Expm1": torch.expm1,
         "Floor": torch.floor, "Ceil": torch.ceil, "Maximum": lambda a, b: torch.maximum(F(a), F(b)), "Minimum": lambda a, b: torch.minimum(F(a), F(b)),
-        "Tanh": torch.tanh,
+        "Tanh": torch.tanh, "IsClose": lambda a, b: torch.isclose(F(T(a)), F(T(b)), rtol=1e-5, atol=1e-8),
     }
 
 
@@ -72,7 +72,11 @@ def evaluate(var, values: dict, memo: dict | None = None):
             elif name in ("All", "Any"):
                 x = ev(ins[0])
                 x = x if x.dtype == torch.bool else (x != 0)
-                out = x.all() if name == "All" else x.any()
+                ax = getattr(op, "axis", None)
+                if ax is None or x.ndim == 0:
+                    out = x.all() if name == "All" else x.any()
+                else:
+                    out = x.all(dim=ax) if name == "All" else x.any(dim=ax)
             elif name == "MakeVector":
                 out = torch.stack([torch.as_tensor(ev(i)).to(torch.float64).reshape(()) if torch.as_tensor(ev(i)).numel() == 1
                                    else torch.as_tensor(ev(i)).to(torch.float64).all().to(torch.float64) for i in ins])

@@ -607,7 +607,21 @@ def shapes_broadcast_gather_and_rowsum():
     return m
 
 
+def dirichlet_multinomial():
+    """`w ~ Dirichlet(a); counts ~ Multinomial(n, w)` and a second Dirichlet with K = 2 (multivariate.py `Dirichlet.logp`, `Multinomial.logp`,
+    logprob/transforms.py `SimplexTransform.backward / log_jac_det`): Dirichlet variables that are NOT the weights of a mixture node.
+    Reductions over the K elements (sums, a max, `any`), a concatenation and `isclose` are written out element by element; the
+    simplex-transformed value variables keep K - 1 stored elements."""
+    m = sg.StubModel()
+    w = m.Dirichlet("w", np.array([1.5, 2.0, 3.0, 0.7]))
+    m.Multinomial("counts", 20, w, observed=np.array([5.0, 7.0, 6.0, 2.0]))
+    w2 = m.Dirichlet("w2", np.array([1.5, 2.0]))
+    m.Multinomial("counts2", 9, w2, observed=np.array([5.0, 4.0]))
+    return m
+
+
 GENERAL = {
+    "dirichlet_multinomial": dirichlet_multinomial,
     "shapes_broadcast_gather_and_rowsum": shapes_broadcast_gather_and_rowsum,
     "robust_regression": robust_regression,
     "random_shape_parameters": random_shape_parameters,

@@ -625,6 +625,7 @@ def reference():
     # Dirichlet (distributions/multivariate.py:543-584: `dist`, `logp`) under its default transform (`simplex_cont_transform`,
     # multivariate.py:126-127 -> `transforms.simplex` = `SimplexTransform()`, logprob/transforms.py:1091-1115)
     ref_class("distributions/multivariate.py", "Dirichlet", ["dist", "logp"], _DistBase, ns)
+    ref_class("distributions/multivariate.py", "Multinomial", ["dist", "logp"], _DistBase, ns)
     ref_class("logprob/transforms.py", "SimplexTransform", ["forward", "backward", "log_jac_det"], _TransformBase, ns)
     ns["transforms"].simplex = ns["SimplexTransform"]()
     _NS = ns
@@ -808,6 +809,10 @@ class StubModel:
     def Dirichlet(self, name, a):
         """`pm.Dirichlet(name, a=a)`: a vector on the simplex; value variable `<name>_simplex__` with K - 1 elements."""
         return self._rv("Dirichlet", name, (np.shape(a)[-1],), _dist("Dirichlet", a=a), "simplex", None)
+
+    def Multinomial(self, name, n, p, observed):
+        """`pm.Multinomial(name, n=n, p=p, observed=counts)` (multivariate.py `Multinomial`)."""
+        return self._rv("Multinomial", name, np.shape(observed), _dist("Multinomial", n, p), None, observed)
 
     def NormalMixture(self, name, w, mu, sigma, observed):
         """`pm.NormalMixture(name, w=w, mu=mu, sigma=sigma, observed=y)` (mixture.py:598-607: `Mixture` over ONE batched

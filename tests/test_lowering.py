@@ -566,17 +566,27 @@ def test_dirichlet_variables_the_ir_cannot_place_are_refused():
     Jacobian); on its own, with two components, or with a prior that is not a Dirichlet density, the graph is not lowerable."""
     if not sg.available():
         pytest.skip("builds graphs with the reference's code")
+    # (round 5: a Dirichlet variable on its own is no longer refused -- its density is lowered op by op, reductions over the K elements
+    # written out: tests/test_general_lowering.py `dirichlet_multinomial`)
     m = sg.StubModel()
     m.Dirichlet("w", np.array([1.0, 2.0, 3.0]))
     m.Normal("x", 0.0, 1.0, shape=(2,))
-    with pytest.raises(NotLowerable, match="not the weight vector of a mixture"):
-        lower_to_spec(m)
+    free = lower_to_spec(m)
+    assert free.vars[0].simplex and free.factors[-1].name == "w" and free.factors[-1].size == 1 and free.factors[-1].prog
     m = sg.StubModel()
     w = m.Dirichlet("w", np.array([1.0, 2.0]))
     mu = m.Normal("mu", 0.0, 5.0, shape=(2,))
     m.NormalMixture("y", w, mu, 1.0, observed=lm.YM)
-    with pytest.raises(NotLowerable, match="K >= 3"):
-        lower_to_spec(m)
+    # Dirichlet weights with K = 2: the mixture NODE wants K >= 3 (a scalar value variable is a deferred element of the engine); the
+    # model is not refused any more -- the marginal likelihood `log(sum(exp(log w + Normal.logp), axis=-1))` is written out over
+    # the two components and evaluated row by row by the element-wise interpreter, the prior of w op by op as above
+    import graph_torch as gt
+
+    two = lower_to_spec(m)
+    assert two.mixture_rows is None and [f.name for f in two.factors] == ["mu", "y", "w"] and two.factors[1].size == lm.YM.size
+    q = np.array([0.3, -0.8, 1.1])
+    (lp, g), (lp0, g0) = ref_models.evaluate(two, q), gt.joint_logp_grad(m, q)
+    assert abs(lp - lp0) <= 1e-12 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-11 * max(1.0, np.max(np.abs(g0)))
 
 
 def test_configs2_mvnormal_2048_graph_lowers_to_the_c3_spec():
