@@ -493,7 +493,7 @@ def run_rank(args):
 
                 t2 = time.perf_counter()
                 res_mc = sample(draws=args.ess_draws, tune=args.ess_tune, chains=args.ess_chains, model=spec, init="jitter+adapt_diag",
-                                random_seed=args.seed + 1, device=device)
+                                random_seed=args.seed + 1, device=local)
                 wall_mc = time.perf_counter() - t2
                 res_mc["step"].close()
                 stack = res_mc["draws"]
