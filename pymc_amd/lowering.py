@@ -184,7 +184,16 @@ def build_tree(v, memo: Optional[dict] = None):
         if all(k[0] == "const" for k in kids):
             out = _const(np.concatenate([np.atleast_1d(k[1]) for k in kids], axis=ax))
         else:
-            out = ("join", ax, *kids)
+            shapes = [_eff_shape(i) for i in ins] if memo.get("__shapes__") else None
+            if shapes and all(sh is not None for sh in shapes) and len(shapes[0]) > 1:
+                # a concatenation along one axis of several (`pt.stack(logps, axis=-1)` of a mixture's components): for every element
+                # of the (raveled) result, the piece it comes from and its position inside that piece
+                a_ = ax % len(shapes[0])
+                tags = [np.stack([np.full(sh, j, dtype=np.int64), np.arange(_numel(sh), dtype=np.int64).reshape(sh)]) for j, sh in enumerate(shapes)]
+                both = np.concatenate(tags, axis=a_ + 1)
+                out = ("joinnd", both[0].ravel(), both[1].ravel(), tuple(both.shape[1:]), *kids)
+            else:
+                out = ("join", ax, *kids)
     elif name == "Shape":                         # `x.shape`: static in every model the IR takes (value variables have fixed shapes)
         shp = getattr(getattr(ins[0], "type", None), "shape", None)
         if shp is None or any(d is None for d in shp):
@@ -250,8 +259,12 @@ def build_tree(v, memo: Optional[dict] = None):
         out = _const(np.asarray(a[1]) @ np.asarray(b[1])) if (a[0] == "const" and b[0] == "const") else ("dot", a, b)
     elif name == "Softmax":
         out = ("softmax", build_tree(ins[0], memo))
+        if memo.get("__shapes__") and _eff_shape(ins[0]) is not None:
+            out = (*out, getattr(op, "axis", -1), _eff_shape(ins[0]))
     elif name == "TakeAlongAxis":
         out = ("take_along_axis", build_tree(ins[0], memo), build_tree(ins[1], memo))
+        if memo.get("__shapes__") and _eff_shape(ins[0]) is not None:
+            out = (*out, _eff_shape(ins[0]))
     elif name in ("All", "Any", "MakeVector"):
         kids = [build_tree(i, memo) for i in ins]
         if name in ("All", "Any") and kids[0][0] == "const":
@@ -696,6 +709,9 @@ def _eval_tree(node, values: Dict[int, Any]):
         return np.broadcast_to(np.reshape(np.asarray(_eval_tree(node[1], values)), node[3]), node[4])
     if kind == "join":
         return np.concatenate([np.atleast_1d(_eval_tree(k, values)) for k in node[2:]], axis=node[1])
+    if kind == "joinnd":
+        pieces = [np.ravel(_eval_tree(k, values)) for k in node[4:]]
+        return np.array([pieces[j][i if pieces[j].size > 1 else 0] for j, i in zip(node[1], node[2])]).reshape(node[3])
     a = [_eval_tree(k, values) for k in node[1:] if _is_node(k)]
     if kind in ("any", "all"):
         return (np.any if kind == "any" else np.all)(np.asarray(a[0]) != 0)
@@ -814,6 +830,7 @@ class _Lowering:
         # updates; model/core.py:142-190 `extra_vars`): data vectors the caller rewrites (`set_extra_values`), registered by name
         self.extra_id: Dict[int, int] = {}
         self._cat: Dict[int, np.ndarray] = {}    # data id of a Categorical variable -> its constant probabilities
+        self._cat_graph: Dict[int, Any] = {}     # ... and (graph, name) of its factor, for the variables no mixture node takes
         for v in extra_vars:
             val = np.ascontiguousarray(np.asarray((extra_values or {})[v.name], dtype="float64").ravel())
             self.spec.data.append(val)
@@ -872,6 +889,8 @@ class _Lowering:
                 idx = np.asarray(node[2][1], dtype="float64")
                 n = self.spec.vars[kv].size
                 if idx.size and np.all(idx == np.round(idx)) and idx.min() >= 0 and idx.max() < n:
+                    if idx.size == 1 and self._const_cache is not None and getattr(self, "_fsize", 1) > 1:
+                        idx = np.full(self._fsize, idx[0])      # ONE element of a vector inside a larger factor: an index per element
                     key = ("gather", kv, idx.tobytes())
                     if key not in self._gather_ids:      # one data vector per (variable, index vector)
                         self.spec.data.append(np.ascontiguousarray(idx))
@@ -984,7 +1003,14 @@ class _Lowering:
             out = self._program(self._index(node[1], np.asarray(node[2][1] if op == "take" else node[2], dtype=np.int64)))
             self._prog_memo[id(node)] = (node, out)
             return out
-        elif op in ("sum", "max") and len(node) == 4 and node[3] is not None:
+        elif op == "log" and _is_node(node[1]) and node[1][0] == "sum" and len(node[1]) == 4 and node[1][3] is not None \
+                and _is_node(node[1][2]) and node[1][2][0] == "exp":
+            # `pt.logsumexp(x, axis)` = log(sum(exp(x))) as `Model.logp` hands it out; compiled, PyTensor's `local_log_sum_exp`
+            # rewrite makes it max-shifted -- here: a chain of logaddexp over the short axis (the marginalised mixture's K components)
+            out = self._program(self._unrolled_sum(("lse", node[1][1], node[1][2][1], node[1][3])))
+            self._prog_memo[id(node)] = (node, out)
+            return out
+        elif op in ("sum", "max", "lse") and len(node) == 4 and node[3] is not None:
             out = self._program(self._unrolled_sum(node))
             self._prog_memo[id(node)] = (node, out)
             return out
@@ -997,7 +1023,11 @@ class _Lowering:
             out = self._program(("le", ("abs", ("sub", a_, b_)), ("add", _const(1e-8), ("mul", _const(1e-5), ("abs", b_)))))
             self._prog_memo[id(node)] = (node, out)
             return out
-        elif op == "join":
+        elif op == "take_along_axis" and len(node) == 4:
+            out = self._program(self._select_chain(node))
+            self._prog_memo[id(node)] = (node, out)
+            return out
+        elif op in ("join", "joinnd"):
             raise NotLowerable(f"a concatenation that is not reduced or indexed element by element: {_show(node)}")
         elif op in self._PROG_OPS:
             kids = [self._program(x) for x in node[1:]]
@@ -1030,10 +1060,14 @@ class _Lowering:
             return self._tsize(node[2])
         if k == "join":
             return sum(self._tsize(x) for x in node[2:])
+        if k == "joinnd":
+            return len(node[1])
+        if k == "take_along_axis":
+            return self._tsize(node[2])
         if k in ("all", "any") and len(node) == 4 and node[3] is not None:
             node = (k, node[2], node[1], node[3])
             k = "sum"
-        if k in ("sum", "max") and len(node) == 4 and node[3] is not None:
+        if k in ("sum", "max", "lse") and len(node) == 4 and node[3] is not None:
             shp, ax = node[3], node[1]
             if ax is None:
                 return 1
@@ -1055,8 +1089,17 @@ class _Lowering:
             return self._index(node[1], np.asarray(node[2][1], dtype=np.int64).ravel()[idx])
         if k == "bcast":
             return self._index(node[1], np.asarray(node[2], dtype=np.int64)[idx])
-        if k in ("sum", "max") and len(node) == 4 and node[3] is not None:
+        if k in ("sum", "max", "lse") and len(node) == 4 and node[3] is not None:
             return self._index(self._unrolled_sum(node), idx)
+        if k == "softmax" and len(node) == 4:
+            # `pt.special.softmax(x, axis=-1)` over a short axis, element by element: exp(x_i - logsumexp(x over the axis))
+            x_, shp = node[1], tuple(node[3])
+            if node[2] is None or node[2] % len(shp) != len(shp) - 1:
+                raise NotLowerable(f"a softmax over another axis than the last: {_show(node)}")
+            lse = ("lse", len(shp) - 1, x_, shp)
+            idx = np.asarray(idx, dtype=np.int64)
+            lse_i = self._index(lse, idx // shp[-1]) if _numel(shp) > shp[-1] else lse
+            return ("exp", ("sub", self._index(x_, idx), lse_i))
         if k in ("all", "any") and len(node) == 4 and node[3] is not None:
             return self._index(self._unrolled_sum((k, node[2], node[1], node[3])), idx)
         if k == "join":        # one-dimensional concatenation: the indexed elements must come from ONE of the joined pieces
@@ -1067,15 +1110,42 @@ class _Lowering:
                 if np.all((idx >= starts[j]) & (idx < starts[j + 1])):
                     return self._index(piece, idx - starts[j]) if sizes[j] > 1 else piece
             raise NotLowerable(f"an index that spans several pieces of a concatenation: {_show(node)}")
+        if k == "take_along_axis" and len(node) == 4:
+            return self._index(self._select_chain(node), idx)
+        if k == "joinnd":
+            idx = np.asarray(idx, dtype=np.int64)
+            which = np.unique(node[1][idx])
+            if len(which) != 1:
+                raise NotLowerable(f"an index that spans several pieces of a concatenation: {_show(node)}")
+            return self._index(node[4 + int(which[0])], node[2][idx])
         if k in self._PROG_OPS or k in ("pow", "check", "all", "any", "makevector"):
             return (k, *[self._index(x, idx) if _is_node(x) else x for x in node[1:]])
         raise NotLowerable(f"an index / broadcast of `{k}` is outside the element-wise programs: {_show(node)}")
+
+    def _select_chain(self, node):
+        """`take_along_axis(p, idx[..., None], axis=-1)` over a SHORT last axis (`Categorical.logp`'s `p[value]`, discrete.py:1173-1188)
+        with an index that is data or a discrete variable another step method updates: switch(idx == 0, p_0, switch(idx == 1, p_1,
+        ... p_{K-1})) -- the K slices are expressions (elements of a simplex variable, columns of a softmax), the index is read per
+        element at run time, so new assignments need no new program."""
+        _, pnode, inode, pshape = node
+        K_ = int(pshape[-1])
+        if K_ > self.MAX_UNROLLED_SUM:
+            raise NotLowerable(f"take_along_axis over {K_} alternatives inside an expression: {_show(node)}")
+        if self._tsize(pnode) <= K_:
+            sl = [self._index(pnode, np.array([k_])) for k_ in range(K_)]
+        else:
+            pos = np.arange(_numel(pshape)).reshape(pshape)
+            sl = [self._index(pnode, pos[..., k_].ravel()) for k_ in range(K_)]
+        out = sl[K_ - 1]
+        for k_ in range(K_ - 2, -1, -1):
+            out = ("switch", ("eq", inode, _const(float(k_))), sl[k_], out)
+        return out
 
     def _unrolled_sum(self, node):
         """`expr.sum(axis)` over ONE short axis of an element-wise expression, written out: sum_r expr[..., r, ...] -- each term the
         expression with the index of that slice pushed down to its leaves (`(X * beta[g]).sum(axis=1)`: D products and D - 1 sums)."""
         kind, ax, kid, shp = node
-        comb = {"sum": "add", "max": "maximum", "all": "and", "any": "or"}[kind]
+        comb = {"sum": "add", "max": "maximum", "all": "and", "any": "or", "lse": "logaddexp"}[kind]
         if ax is None:
             axes = list(range(len(shp)))
         else:
@@ -1225,6 +1295,7 @@ class _Lowering:
             if kw is None or self.spec.vars[kw].size != int(km1) + 1:
                 return False
             self._cat[self.extra_id[id(c[1])]] = ("softmax", kw)
+            self._cat_graph[self.extra_id[id(c[1])]] = (self._graph, self._name_now)
             return True
         if p_[0] != "const":
             # p = a `pm.Dirichlet` variable under its default transform (the fully Bayesian mixture: weights learned by NUTS, the
@@ -1233,11 +1304,13 @@ class _Lowering:
             if kw is None or self.spec.vars[kw].size != int(km1):
                 return False
             self._cat[self.extra_id[id(c[1])]] = ("simplex", kw)
+            self._cat_graph[self.extra_id[id(c[1])]] = (self._graph, self._name_now)
             return True
         w = np.asarray(p_[1], dtype="float64").reshape(-1)
         if w.size != int(km1) + 1:
             return False
         self._cat[self.extra_id[id(c[1])]] = w
+        self._cat_graph[self.extra_id[id(c[1])]] = (self._graph, self._name_now)
         return True
 
     def _mixture_conditional(self, val, mu_n, sg_n) -> bool:
@@ -1485,7 +1558,7 @@ class _Lowering:
         if "_gather_ids" not in self.__dict__:
             self._gather_ids = {}
         self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
-        self._graph = graph
+        self._graph, self._name_now = graph, name
         n_data, n_fac = len(self.spec.data), len(self.spec.factors)
         try:
             try:
@@ -1747,8 +1820,20 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
     memo: dict = {}
     for g, own, nm in zip(factors, owners, names):
         low.factor(build_tree(g, memo), nm, own, graph=g)
-    if low._cat:
-        raise NotLowerable("a Categorical variable that does not index an observed Normal (the IR has no free-standing Categorical factor)")
+    # Categorical variables no conditional mixture claimed (`c ~ Categorical(w)` next to anything but `y ~ Normal(mu[c], ...)`): the
+    # factor `log p[c]` is lowered op by op -- a selection among the K probabilities by the CURRENT value of c (`_select_chain`)
+    for did in list(low._cat):
+        graph, nm = low._cat_graph[did]
+        low._prog, low._prog_size, low._prog_memo, low._prog_cse = [], [], {}, {}
+        low._graph = graph
+        try:
+            low._general(None, nm, None)
+        except NotLowerable as e:
+            raise NotLowerable(f"a Categorical variable that neither indexes an observed Normal nor has few enough categories to be "
+                               f"written out: {e}")
+        finally:
+            low._prog = None
+        del low._cat[did]
     # Dirichlet variables no mixture node took as its weights (`w ~ Dirichlet; counts ~ Multinomial(n, w)`, a Dirichlet with K = 2 next to
     # anything): their factor -- `Dirichlet.logp(SimplexTransform.backward(y))` + `log_jac_det(y)`, reductions over the K elements
     # written out -- is lowered op by op like any other density that has no code of its own

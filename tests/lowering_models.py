@@ -620,7 +620,45 @@ def dirichlet_multinomial():
     return m
 
 
+_YMIXP = np.concatenate([_rg.poisson(1.5, size=18), _rg.poisson(9.0, size=14)]).astype("float64")
+_YMIXT = np.concatenate([_rg.normal(0.3, 1.0, size=20), 0.3 + 2.5 * _rg.standard_t(4, size=9)])
+_YMIXG = np.concatenate([_rg.gamma(2.0, 0.5, size=15), _rg.gamma(6.0, 1.2, size=12), _rg.gamma(1.2, 4.0, size=6)])
+
+
+def mixtures_of_other_families():
+    """`pm.Mixture` beyond Normal components (mixture.py:469-495, the three docstring forms): two Poisson rates as ONE batched component
+    `Poisson.dist(mu=pm.math.stack([lam1, lam2]))` under Dirichlet weights with K = 2; a LIST of components of different families
+    (`[Normal.dist(mu, 1), StudentT.dist(4, mu, 2.5)]`: `pt.stack` of their logps); three Gamma components with random shapes under
+    constant weights.  `logsumexp` over the K components is written out per row (the max-shifted form PyTensor's rewrite gives)."""
+    m = sg.StubModel()
+    w = m.Dirichlet("w", np.array([1.0, 1.0]))
+    lam1 = m.Exponential("lam1", 1.0)
+    lam2 = m.Exponential("lam2", 0.2)
+    m.Mixture("yp", w, ("Poisson", dict(mu=sg.pt.stack([lam1, lam2]))), observed=_YMIXP)
+    w2 = m.Dirichlet("w2", np.array([2.0, 1.0]))
+    mu = m.Normal("mu", 0.0, 1.0)
+    m.Mixture("yt", w2, [("Normal", dict(mu=mu, sigma=1.0)), ("StudentT", dict(nu=4.0, mu=mu, sigma=2.5))], observed=_YMIXT)
+    a = m.HalfNormal("a", 3.0, shape=(3,))
+    b = m.HalfNormal("b", 2.0, shape=(3,))
+    m.Mixture("yg", np.array([0.45, 0.35, 0.2]), ("Gamma", dict(alpha=a, beta=b)), observed=_YMIXG)
+    return m
+
+
+def categorical_free_standing():
+    """`Categorical` factors that are NOT the assignments of a mixture node (discrete.py:1171-1205): observed categories under
+    Dirichlet probabilities (the Dirichlet-categorical model), and a discrete free variable `c ~ Categorical(softmax(logits))` with
+    nothing indexed by it -- `p[value]` is a selection among the K probabilities by the current category."""
+    m = sg.StubModel()
+    w = m.Dirichlet("w", np.array([1.0, 2.0, 1.5]))
+    m.Categorical("cobs", p=w, observed=np.array([0, 1, 2, 1, 1, 0, 2, 1, 1, 0, 1, 2], dtype="float64"))
+    logits = m.Normal("logits", 0.0, 1.5, shape=(4,))
+    m.Categorical("c", p=m.math.softmax(logits), shape=(9,), initval=np.array([3, 0, 1, 1, 2, 3, 3, 0, 1], dtype="float64"))
+    return m
+
+
 GENERAL = {
+    "categorical_free_standing": categorical_free_standing,
+    "mixtures_of_other_families": mixtures_of_other_families,
     "dirichlet_multinomial": dirichlet_multinomial,
     "shapes_broadcast_gather_and_rowsum": shapes_broadcast_gather_and_rowsum,
     "robust_regression": robust_regression,

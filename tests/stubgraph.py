@@ -385,6 +385,14 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         shp[ax] = sum(t.type.shape[ax] for t in ts)
         return Variable(Apply(Join(axis), ts), shape=tuple(shp))
 
+    @staticmethod
+    def stack(tensors, axis=0):
+        """`pt.stack(tensors, axis)`: `join(axis, *[shape_padaxis(t, axis) for t in tensors])` -- a Join of DimShuffles."""
+        ts = [as_tensor(t) for t in tensors]
+        nd = len(ts[0].type.shape) + 1
+        ax = axis % nd
+        return pt.concatenate([pt.expand_dims(t, ax) for t in ts], axis=ax)
+
     as_tensor = staticmethod(lambda x, **kw: as_tensor(x))
 
     @staticmethod
@@ -822,9 +830,23 @@ class StubModel:
         fn = lambda value, w_, comp_: ref["mixture_logprob"](None, (value,), None, w_, comp_)   # noqa: E731
         return self._add(_RV(name, np.shape(observed), fn, (as_tensor(w), comp), None, observed))
 
-    def Categorical(self, name, p, shape, initval=None):
+    def Mixture(self, name, w, comp_dists, observed):
+        """`pm.Mixture(name, w=w, comp_dists=..., observed=y)` (mixture.py:166-176, 469-495): `comp_dists` is ONE batched component
+        `("Poisson", dict(mu=...))` (mixture axis last) or a LIST of scalar components of any families
+        `[("Normal", dict(mu=mu, sigma=1)), ("StudentT", dict(nu=4, mu=mu, sigma=1))]` -- the `Dist.dist(...)` calls of the docstring
+        examples; the log-density graph is what the reference's `mixture_logprob` builds out of the components' own `logp`."""
+        ref = reference()
+        comps = [comp_dists] if isinstance(comp_dists, tuple) else list(comp_dists)
+        comps = [_ComponentRV(ref[c], _dist(c, **kw)) for c, kw in comps]
+        fn = lambda value, w_, *cs: ref["mixture_logprob"](None, (value,), None, w_, *cs)   # noqa: E731
+        return self._add(_RV(name, np.shape(observed), fn, (as_tensor(w), *comps), None, observed))
+
+    def Categorical(self, name, p, shape=None, initval=None, observed=None):
         """`pm.Categorical(name, p=p, shape=N)`: a DISCRETE free variable -- not a gradient variable of NUTS but an input of the
-        log-density that another step method updates (`extra_vars`, model/core.py:142-190); `initval`: its value in the initial point."""
+        log-density that another step method updates (`extra_vars`, model/core.py:142-190); `initval`: its value in the initial point.
+        With `observed=`: an observed factor like any other."""
+        if observed is not None:
+            return self._rv("Categorical", name, np.shape(observed), _dist("Categorical", p=p), None, observed)
         rv = _RV(name, shape, _ref_logp("Categorical"), _dist("Categorical", p=p), None, None)
         rv.discrete = True
         rv.initval = np.zeros(shape) if initval is None else np.asarray(initval, dtype="float64")

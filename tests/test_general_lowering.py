@@ -80,6 +80,12 @@ def test_what_each_model_lowers_to():
         assert spec.glm_rows.beta is None and d.dist == ms.D_DERIVED and d.size == 7 and not d.prog      # beta = mu + sigma * z: one affine term
         t = d.args[0]
         assert (t.a.kind, t.b.kind, t.c.kind) == (ms.OP_VAR, ms.OP_VAR, ms.OP_VAR)
+    spec = _committed("mixtures_of_other_families")           # pm.Mixture of Poisson / Normal + StudentT / Gamma components: no node,
+    assert spec.mixture is None                               # the K components per row and their logsumexp written out
+    for name, n_lae in (("yp", 1), ("yt", 1), ("yg", 2)):
+        f = [f for f in spec.factors if f.name == name][0]
+        ops = [i.op for i in f.prog]
+        assert f.dist == ms.D_POTENTIAL and ops.count(ms.E_LOGADDEXP) == n_lae and len(ops) <= ms.MAX_FACTOR_INSTR
     spec = _committed("glm_with_mvnormal_prior")
     assert spec.mvnormal is not None and spec.glm_rows is not None and spec.glm_rows.beta == spec.mvnormal.var and not spec.factors
 
