@@ -524,6 +524,18 @@ int nuts_gibbs_sweep(nuts_gibbs *g, int32_t *c, const double *log_w, const doubl
                      const int32_t *order, const int32_t *cand_raw, const double *log_u, int64_t *n_accepted,
                      int64_t *n_nonfinite, double *cnt, double *s1, double *s2);
 
+/* The same sweep with its plan ALREADY ON THE DEVICE.  `nuts_gibbs_stage` uploads a plan (what `nuts_gibbs_plan` produced, with
+ * `log_u` = NumPy's log of the uniforms) into one of `nuts_gibbs_stage_slots()` device slots and returns when it is there; it may
+ * be called from any host thread -- the thread that drew the plan while an earlier sweep and the continuous step were running.
+ * `nuts_gibbs_sweep_staged` then runs the sweep of slot `slot`: `c_in` (int32 [n]) is uploaded when given, NULL = the assignments
+ * this handle's previous sweep left on the device; the new assignments come back in `c_out` as int64 (`c_out_is64` != 0) or int32
+ * [n].  Same outputs, same arithmetic and the same order of additions as `nuts_gibbs_sweep` (reference: metropolis.py:761-786). */
+int nuts_gibbs_stage_slots(void);
+int nuts_gibbs_stage(nuts_gibbs *g, int32_t slot, const int32_t *order, const int32_t *cand_raw, const double *log_u);
+int nuts_gibbs_sweep_staged(nuts_gibbs *g, int32_t slot, const int32_t *c_in, void *c_out, int32_t c_out_is64,
+                            const double *log_w, const double *mu, const double *sigma, int64_t *n_accepted,
+                            int64_t *n_nonfinite, double *cnt, double *s1, double *s2);
+
 /* `proposal="proportional"` (`astep_prop` / `metropolis_proportional`, metropolis.py:788-826): per element the conditional
  * probabilities of ALL K categories (softmax of the log-densities, scipy.special.softmax's arithmetic, NumPy's pairwise sum), the
  * current one zeroed and the rest renormalised, one category drawn with `rng.choice(K, p=probs)` (NumPy: cumulative sums divided

@@ -251,6 +251,9 @@ SYMBOLS = {
     "nuts_gibbs_plan_skip": (C.c_int, [C.POINTER(Pcg64), C.c_int64, C.c_int32]),
     "nuts_gibbs_create": (_VP, [C.c_int64, C.c_int32, _PD]),
     "nuts_gibbs_destroy": (None, [_VP]),
+    "nuts_gibbs_stage_slots": (C.c_int, []),
+    "nuts_gibbs_stage": (C.c_int, [_VP, C.c_int32, _VP, _VP, _PD]),
+    "nuts_gibbs_sweep_staged": (C.c_int, [_VP, C.c_int32, _VP, _VP, C.c_int32, _PD, _PD, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _PD, _PD, _PD]),
     "nuts_gibbs_sweep": (C.c_int, [_VP, _VP, _PD, _PD, _PD, _VP, _VP, _PD, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _PD, _PD, _PD]),
     "nuts_gibbs_plan_doubles": (C.c_int, [C.POINTER(Pcg64), C.c_int64, C.c_int32, _VP, C.c_int64, _PD]),
     "nuts_gibbs_sweep_prop": (C.c_int, [_VP, _VP, _VP, _PD, _PD, _PD, _VP, _PD, _PD, _VP, C.POINTER(C.c_int64), _PD, _PD, _PD]),

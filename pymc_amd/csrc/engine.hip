@@ -3166,6 +3166,14 @@ extern "C" int nuts_chain_profile_read(nuts_chain* c, double* ms_sum, int64_t* l
 // ===========================================================================
 // categorical Gibbs within Metropolis for mixture assignments (include/nuts_mi355.h)
 // ===========================================================================
+// `rng.shuffle(order)` (pcg64_stream.h `shuffle`: the candidates without a branch on acceptance, then the swaps); the scratch
+// index vector is kept per host thread
+static void shuffle_order(Pcg64Replay& r, int64_t n, int32_t* order) {
+  static thread_local std::vector<int32_t> js;
+  if ((int64_t)js.size() < n) js.resize((size_t)n);
+  r.shuffle(n, order, js.data());
+}
+
 extern "C" int nuts_gibbs_plan(nuts_pcg64* rng, int64_t n, int32_t shuffle, int32_t* order, const int32_t* k_of_dim, int32_t* cand_raw,
                                double* uniform) {
   if (!rng || !order || !k_of_dim || !cand_raw || !uniform || n < 0) { g_err = "null argument"; return NUTS_E_ARG; }
@@ -3173,16 +3181,13 @@ extern "C" int nuts_gibbs_plan(nuts_pcg64* rng, int64_t n, int32_t shuffle, int3
   r.state = ((unsigned __int128)rng->state_hi << 64) | rng->state_lo;
   r.inc = ((unsigned __int128)rng->inc_hi << 64) | rng->inc_lo;
   r.has_uint32 = rng->has_uint32; r.uinteger = rng->uinteger;
+  if (shuffle) shuffle_order(r, n, order);   // Generator.shuffle on a Python list: Fisher-Yates from the top (numpy/random/_generator.pyx, untyped path)
   r.begin_bulk();   // the raw outputs a block ahead, four interleaved lanes (pcg64_stream.h)
-  if (shuffle) {   // Generator.shuffle on a Python list: Fisher-Yates from the top (numpy/random/_generator.pyx, untyped path)
-    for (int64_t i = n - 1; i >= 1; --i) {
-      const int64_t j = (int64_t)r.interval((uint64_t)i);
-      std::swap(order[i], order[j]);
-    }
-  }
   bool same_k = n > 0;   // (every dimension with the same number of categories -- a mixture's assignments: no gather through the shuffled order)
   for (int64_t t = 1; t < n && same_k; ++t) same_k = k_of_dim[t] == k_of_dim[0];
-  for (int64_t t = 0; t < n; ++t) {
+  int64_t t0 = 0;
+  if (same_k && k_of_dim[0] > 2) { r.end_bulk(); t0 = r.draws_same_k(n, (uint32_t)k_of_dim[0], cand_raw, uniform); r.begin_bulk(); }
+  for (int64_t t = t0; t < n; ++t) {
     const int32_t k = same_k ? k_of_dim[0] : k_of_dim[order[t]];
     if (k < 2) { g_err = "a categorical dimension needs at least two categories"; return NUTS_E_ARG; }
     cand_raw[t] = (int32_t)r.integers((uint32_t)(k - 1));   // rng.choice(k - 1)
@@ -3211,12 +3216,7 @@ extern "C" int nuts_gibbs_plan_shuffle(nuts_pcg64* rng, int64_t n, int32_t* orde
   if (!rng || !order || n < 0) { g_err = "null argument"; return NUTS_E_ARG; }
   Pcg64Replay r;
   pcg_load(r, rng);
-  r.begin_bulk();
-  for (int64_t i = n - 1; i >= 1; --i) {
-    const int64_t j = (int64_t)r.interval((uint64_t)i);
-    std::swap(order[i], order[j]);
-  }
-  r.end_bulk();
+  shuffle_order(r, n, order);
   pcg_store(r, rng);
   return NUTS_OK;
 }
@@ -3228,7 +3228,9 @@ extern "C" int nuts_gibbs_plan_draws(nuts_pcg64* rng, int64_t n, const int32_t* 
   r.begin_bulk();
   bool same_k = n > 0;
   for (int64_t t = 1; t < n && same_k; ++t) same_k = k_of_dim[t] == k_of_dim[0];
-  for (int64_t t = 0; t < n; ++t) {
+  int64_t t0 = 0;
+  if (same_k && k_of_dim[0] > 2) { r.end_bulk(); t0 = r.draws_same_k(n, (uint32_t)k_of_dim[0], cand_raw, uniform); r.begin_bulk(); }
+  for (int64_t t = t0; t < n; ++t) {
     const int32_t k = same_k ? k_of_dim[0] : k_of_dim[order[t]];
     if (k < 2) { g_err = "a categorical dimension needs at least two categories"; return NUTS_E_ARG; }
     cand_raw[t] = (int32_t)r.integers((uint32_t)(k - 1));
@@ -3254,12 +3256,7 @@ extern "C" int nuts_gibbs_plan_doubles(nuts_pcg64* rng, int64_t n, int32_t shuff
   r.state = ((unsigned __int128)rng->state_hi << 64) | rng->state_lo;
   r.inc = ((unsigned __int128)rng->inc_hi << 64) | rng->inc_lo;
   r.has_uint32 = rng->has_uint32; r.uinteger = rng->uinteger;
-  if (shuffle) {
-    for (int64_t i = n - 1; i >= 1; --i) {
-      const int64_t j = (int64_t)r.interval((uint64_t)i);
-      std::swap(order[i], order[j]);
-    }
-  }
+  if (shuffle) shuffle_order(r, n, order);
   // the generator is handed back as it stands AFTER the shuffle: the doubles are looked at, not consumed (a double never touches
   // the buffered 32-bit half, so the caller's `advance(k)` lands exactly where k `random()` calls would)
   rng->state_hi = (uint64_t)(r.state >> 64); rng->state_lo = (uint64_t)r.state;
@@ -3326,6 +3323,15 @@ struct nuts_gibbs {
   int32_t *c = nullptr, *order = nullptr, *cand = nullptr;
   int32_t* c2 = nullptr; double* u2 = nullptr; int8_t* flags = nullptr;   // proposal="proportional": output assignment, second uniform, finite flags
   std::vector<double> part_host;
+  // plans staged on the device ahead of their sweep (nuts_gibbs_stage, called from the host thread that drew the plan) and pinned
+  // landing buffers for what a sweep hands back: the sweep's own host thread then issues ONE launch and two small copies
+  static constexpr int NSLOT = 8;
+  int device = 0;
+  hipStream_t up_stream = nullptr;
+  int32_t *s_order[NSLOT] = {}, *s_cand[NSLOT] = {};
+  double* s_logu[NSLOT] = {};
+  int32_t* c_pinned = nullptr;
+  double *part_pinned = nullptr, *par_pinned = nullptr;
 };
 
 extern "C" nuts_gibbs* nuts_gibbs_create(int64_t n, int32_t K, const double* y) {
@@ -3345,6 +3351,7 @@ extern "C" nuts_gibbs* nuts_gibbs_create(int64_t n, int32_t K, const double* y) 
   g->c = dev_alloc<int32_t>((size_t)n); g->order = dev_alloc<int32_t>((size_t)n); g->cand = dev_alloc<int32_t>((size_t)n);
   if (!g->y || !g->par || !g->logu || !g->part || !g->c || !g->order || !g->cand) { g_err = "device allocation failed"; nuts_gibbs_destroy(g); return nullptr; }
   g->part_host.resize((size_t)g->nblk * (3 * K + 2));
+  HIPCHK_NULL(hipGetDevice(&g->device));
   return g;
 }
 
@@ -3353,8 +3360,76 @@ extern "C" void nuts_gibbs_destroy(nuts_gibbs* g) {
   if (g->stream) hipStreamSynchronize(g->stream);
   for (void* p : {(void*)g->y, (void*)g->par, (void*)g->logu, (void*)g->part, (void*)g->c, (void*)g->order, (void*)g->cand, (void*)g->c2, (void*)g->u2,
                   (void*)g->flags}) if (p) hipFree(p);
+  if (g->up_stream) { hipStreamSynchronize(g->up_stream); hipStreamDestroy(g->up_stream); }
+  for (int i = 0; i < nuts_gibbs::NSLOT; ++i)
+    for (void* p : {(void*)g->s_order[i], (void*)g->s_cand[i], (void*)g->s_logu[i]}) if (p) hipFree(p);
+  for (void* p : {(void*)g->c_pinned, (void*)g->part_pinned, (void*)g->par_pinned}) if (p) hipHostFree(p);
   if (g->stream) hipStreamDestroy(g->stream);
   delete g;
+}
+
+// Number of device slots a plan can be staged into (the look-ahead of pymc_amd/gibbs.py's plan pipeline must stay below it).
+extern "C" int nuts_gibbs_stage_slots(void) { return nuts_gibbs::NSLOT; }
+
+// Upload one sweep's plan (shuffled order, raw candidates, log-uniforms: what nuts_gibbs_plan produced) into device slot `slot`,
+// from whatever host thread drew it; returns when the plan is on the device.  The sweep that uses it (nuts_gibbs_sweep_staged)
+// then has nothing to upload but the 3 K parameters.
+extern "C" int nuts_gibbs_stage(nuts_gibbs* g, int32_t slot, const int32_t* order, const int32_t* cand_raw, const double* log_u) {
+  if (!g || !order || !cand_raw || !log_u || slot < 0 || slot >= nuts_gibbs::NSLOT) { g_err = "nuts_gibbs_stage: bad argument"; return NUTS_E_ARG; }
+  HIPCHK(hipSetDevice(g->device));
+  const size_t n = (size_t)g->n;
+  if (!g->up_stream) HIPCHK(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
+  if (!g->s_order[slot]) {
+    g->s_order[slot] = dev_alloc<int32_t>(n); g->s_cand[slot] = dev_alloc<int32_t>(n); g->s_logu[slot] = dev_alloc<double>(n);
+    if (!g->s_order[slot] || !g->s_cand[slot] || !g->s_logu[slot]) { g_err = "device allocation failed"; return NUTS_E_HIP; }
+  }
+  HIPCHK(hipMemcpyAsync(g->s_order[slot], order, n * sizeof(int32_t), hipMemcpyHostToDevice, g->up_stream));
+  HIPCHK(hipMemcpyAsync(g->s_cand[slot], cand_raw, n * sizeof(int32_t), hipMemcpyHostToDevice, g->up_stream));
+  HIPCHK(hipMemcpyAsync(g->s_logu[slot], log_u, n * sizeof(double), hipMemcpyHostToDevice, g->up_stream));
+  HIPCHK(hipStreamSynchronize(g->up_stream));
+  return NUTS_OK;
+}
+
+// One sweep on a staged plan.  `c_in` (int32, n entries) is uploaded when given; NULL = the assignments the previous sweep of this
+// handle left on the device (the caller knows that nothing else has touched them).  The new assignments are written to `c_out`
+// as int64 (`c_out_is64`) or int32 -- the dtype the point carries, so that the caller converts nothing.
+extern "C" int nuts_gibbs_sweep_staged(nuts_gibbs* g, int32_t slot, const int32_t* c_in, void* c_out, int32_t c_out_is64, const double* log_w,
+                                       const double* mu, const double* sigma, int64_t* n_accepted, int64_t* n_nonfinite, double* cnt, double* s1,
+                                       double* s2) {
+  if (!g || !c_out || !log_w || !mu || !sigma || !cnt || !s1 || !s2 || slot < 0 || slot >= nuts_gibbs::NSLOT || !g->s_order[slot]) {
+    g_err = "nuts_gibbs_sweep_staged: bad argument (or a slot nothing was staged into)"; return NUTS_E_ARG;
+  }
+  const int K = g->K;
+  const size_t n = (size_t)g->n;
+  const size_t npart = (size_t)g->nblk * (3 * K + 2);
+  hipStream_t s = g->stream;
+  if (!g->c_pinned) {
+    HIPCHK(hipHostMalloc((void**)&g->c_pinned, n * sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&g->part_pinned, npart * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&g->par_pinned, 3 * (size_t)GIBBS_MAXK * sizeof(double), hipHostMallocDefault));
+  }
+  for (int k = 0; k < K; ++k) { g->par_pinned[k] = log_w[k]; g->par_pinned[K + k] = mu[k]; g->par_pinned[2 * K + k] = sigma[k]; }
+  HIPCHK(hipMemcpyAsync(g->par, g->par_pinned, 3 * (size_t)K * sizeof(double), hipMemcpyHostToDevice, s));
+  if (c_in) HIPCHK(hipMemcpyAsync(g->c, c_in, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_gibbs_sweep, dim3(g->nblk), dim3(GIBBS_BLOCK), 0, s, g->n, K, g->y, g->c, g->par, g->s_order[slot], g->s_cand[slot],
+                     g->s_logu[slot], g->part);
+  HIPCHK(hipMemcpyAsync(g->c_pinned, g->c, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g->part_pinned, g->part, npart * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  if (c_out_is64) { int64_t* o = (int64_t*)c_out; for (size_t i = 0; i < n; ++i) o[i] = g->c_pinned[i]; }
+  else std::memcpy(c_out, g->c_pinned, n * sizeof(int32_t));
+  const int stride = 3 * K + 2;
+  double acc = 0.0, nonf = 0.0;
+  for (int k = 0; k < K; ++k) { cnt[k] = s1[k] = s2[k] = 0.0; }
+  for (int b = 0; b < g->nblk; ++b) {   // workgroups in order, as nuts_gibbs_sweep adds them
+    const double* p = g->part_pinned + (size_t)b * stride;
+    for (int k = 0; k < K; ++k) { cnt[k] += p[k]; s1[k] += p[K + k]; s2[k] += p[2 * K + k]; }
+    acc += p[3 * K]; nonf += p[3 * K + 1];
+  }
+  if (n_accepted) *n_accepted = (int64_t)acc;
+  if (n_nonfinite) *n_nonfinite = (int64_t)nonf;
+  return NUTS_OK;
 }
 
 extern "C" int nuts_gibbs_sweep(nuts_gibbs* g, int32_t* c, const double* log_w, const double* mu, const double* sigma, const int32_t* order,

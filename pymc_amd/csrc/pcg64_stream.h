@@ -113,6 +113,122 @@ struct Pcg64Replay {
     else { while ((value = (next64() & mask)) > max) {} }
     return value;
   }
+  // `Generator.shuffle` of a list / 1-d array of n entries (Fisher-Yates from the top: j = random_interval(i) for i = n-1 .. 1,
+  // swap(order[i], order[j])) in two passes.  The masked-rejection loop of `random_interval` is a data-dependent branch that
+  // fails 0-50 % of the time -- mispredicted every third element or so, which (with the swap's dependent loads behind it) made the
+  // shuffle the longest stage of a plan.  Here the stream of 32-bit halves is walked WITHOUT a branch on acceptance: the
+  // candidate is stored to js[i] whatever it is and i only steps down when it was accepted (`i -= v <= i`); the mask is constant
+  // while i stays between two powers of two.  The swaps then run over known indices (independent loads the core overlaps).
+  // Exactly the halves `interval()` would consume are consumed, in the same order (buffered half first, then low / high of each
+  // output).  n - 1 <= 2^32 - 1 (a 32-bit interval).
+  template <typename T>
+  void shuffle(int64_t n, T* order, int32_t* js /* scratch, n entries */) {
+    if (n < 2) return;
+    int64_t i = n - 1;
+    uint64_t half_buf[BLK];
+    const uint32_t* hp = nullptr;
+    const uint32_t* hend = nullptr;
+    bool first = has_uint32 != 0;
+    uint32_t pend = uinteger;
+    uint64_t fresh_halves = 0;       // halves taken from fresh outputs
+    unsigned __int128 st = state;
+    const unsigned __int128 a = mult(), a2 = a * a, a4 = a2 * a2, c4 = inc * (a2 * a + a2 + a + 1);
+    uint32_t last_hi = 0;
+    while (i >= 1) {
+      uint64_t mask = (uint64_t)i;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+      const int64_t lo = (int64_t)(mask >> 1) + 1;
+      if (first) {                  // the half NumPy had buffered before the shuffle began
+        first = false;
+        const int64_t v = (int64_t)(pend & mask);
+        js[i] = (int32_t)v;
+        i -= v <= i;
+        continue;
+      }
+      if (hp == hend) {             // the next BLK outputs: four interleaved lanes of the LCG
+        unsigned __int128 l0 = st * a + inc, l1 = l0 * a + inc, l2 = l1 * a + inc, l3 = l2 * a + inc;
+        for (int q = 0; q < BLK; q += 4) {
+          half_buf[q] = output(l0); half_buf[q + 1] = output(l1); half_buf[q + 2] = output(l2); half_buf[q + 3] = output(l3);
+          if (q + 4 == BLK) st = l3;
+          l0 = l0 * a4 + c4; l1 = l1 * a4 + c4; l2 = l2 * a4 + c4; l3 = l3 * a4 + c4;
+        }
+        hp = reinterpret_cast<const uint32_t*>(half_buf);    // (little-endian: low half, then high half -- next32's order)
+        hend = hp + 2 * BLK;
+      }
+      const uint32_t* h = hp;
+      const uint32_t m32 = (uint32_t)mask;
+      while (h < hend && i >= lo) {
+        const int64_t v = (int64_t)(*h++ & m32);
+        js[i] = (int32_t)v;
+        i -= v <= i;
+      }
+      fresh_halves += (uint64_t)(h - hp);
+      if (h > hp) last_hi = h[-1];
+      hp = h;
+    }
+    // the generator as `interval()` calls would have left it
+    const uint64_t outs = (fresh_halves + 1) / 2;
+    if (fresh_halves > 0) {
+      if (fresh_halves & 1) {        // the low half of the last output was the last one used: its high half stays buffered
+        has_uint32 = 1;
+        uinteger = hp[0];            // (the half that follows the last one consumed, inside the same output)
+      } else { has_uint32 = 0; uinteger = last_hi; }   // (NumPy keeps the used half in `uinteger`)
+    } else has_uint32 = 0;           // only the buffered half was needed
+    state = advance(state, inc, outs);
+    for (int64_t q = n - 1; q >= 1; --q) {
+      const T t = order[q];
+      const int32_t j = js[q];
+      order[q] = order[j];
+      order[j] = t;
+    }
+  }
+  // The per-element loop for n elements that all have the same k > 2 (`choice(k - 1)` then `uniform()`), written against the raw
+  // output stream directly: a 32-bit half for Lemire's draw (the buffered one, or the low half of a fresh output whose high half
+  // is buffered for the next element), then one whole output for the double.  Returns the number of elements done: n, or the
+  // index of the first element whose Lemire draw needs the rejection loop (probability < k / 2^32 per element) -- the caller
+  // continues from there with `integers()` / `next_double()`, the generator standing exactly before that element.
+  int64_t draws_same_k(int64_t n, uint32_t k, int32_t* cand, double* uniform) {
+    const uint32_t rng_excl = k - 1;
+    uint64_t raw[BLK];
+    int pos = BLK;
+    unsigned __int128 st = state;
+    const unsigned __int128 a = mult(), a2 = a * a, a4 = a2 * a2, c4 = inc * (a2 * a + a2 + a + 1);
+    uint64_t used = 0;
+    auto refill_raw = [&]() {
+      unsigned __int128 l0 = st * a + inc, l1 = l0 * a + inc, l2 = l1 * a + inc, l3 = l2 * a + inc;
+      for (int q = 0; q < BLK; q += 4) {
+        raw[q] = output(l0); raw[q + 1] = output(l1); raw[q + 2] = output(l2); raw[q + 3] = output(l3);
+        if (q + 4 == BLK) st = l3;
+        l0 = l0 * a4 + c4; l1 = l1 * a4 + c4; l2 = l2 * a4 + c4; l3 = l3 * a4 + c4;
+      }
+      pos = 0;
+    };
+    int have = has_uint32;
+    uint32_t pend = uinteger;
+    int64_t t = 0;
+    for (; t < n; ++t) {
+      // (state before this element, should the slow path have to take over)
+      const int have0 = have; const uint32_t pend0 = pend; const uint64_t used0 = used;
+      uint32_t h;
+      if (have) { h = pend; have = 0; }
+      else {
+        if (pos == BLK) refill_raw();
+        const uint64_t o = raw[pos++]; ++used;
+        h = (uint32_t)o; pend = (uint32_t)(o >> 32); have = 1;
+      }
+      const uint64_t m = (uint64_t)h * rng_excl;
+      if ((uint32_t)m < rng_excl) {     // Lemire's test may reject: hand this element back untouched
+        have = have0; pend = pend0; used = used0;
+        break;
+      }
+      cand[t] = (int32_t)(m >> 32);
+      if (pos == BLK) refill_raw();
+      uniform[t] = (double)(raw[pos++] >> 11) * (1.0 / 9007199254740992.0); ++used;
+    }
+    has_uint32 = have; uinteger = pend;
+    state = advance(state, inc, used);
+    return t;
+  }
   int rejections = 0;   // Lemire rejections since the object was set up (skip_draws assumes there are none)
   uint32_t lemire32(uint32_t rng) {   // buffered_bounded_lemire_uint32: uniform on [0, rng]
     const uint32_t rng_excl = rng + 1;

@@ -123,7 +123,7 @@ class MixtureLink:
 
     def suffstats(self, c: np.ndarray):
         c = np.asarray(c)
-        if self._cache_for is c and np.array_equal(self._cache_copy, c):    # (one memcmp-sized pass instead of three bincounts)
+        if self._cache_for is c and (self._cache_copy is c or np.array_equal(self._cache_copy, c)):   # (at most one memcmp-sized pass instead of three bincounts)
             return self._cache
         cnt = np.bincount(c, minlength=self.K).astype("float64")
         s1 = np.bincount(c, weights=self.y, minlength=self.K)
@@ -132,7 +132,8 @@ class MixtureLink:
 
     def remember(self, c: np.ndarray, stats):
         """The sweep kernel has just produced the statistics of `c`: the continuous step that follows need not recount."""
-        self._cache_for, self._cache_copy, self._cache = c, c.copy(), stats
+        # (a read-only array -- what the sweep hands out -- cannot be edited in place: no copy to compare against is needed)
+        self._cache_for, self._cache_copy, self._cache = c, (c if not c.flags.writeable else c.copy()), stats
 
     def extras_for(self, c: np.ndarray) -> Dict[str, np.ndarray]:
         """Extra values of the NUTS spec for assignments `c`: the log-density of the observations given c collapses to
@@ -202,29 +203,51 @@ def _state_key(st):
 
 
 class _PlanPipeline:
-    DEPTH = 3
+    """Shuffler thread -> NDRAW drawer threads (alternating sweeps: a sweep's per-element draws only need the generator as the
+    shuffle left it, which the shuffler knows for every sweep by the jump) -> the consumer, in sweep order.  With `stage` (a callable
+    `(slot, order, cand, log_u)`: `nuts_gibbs_stage` of the step's engine handle) a drawer also uploads its plan into a device slot,
+    so that the sweep's own thread uploads nothing.  The plan arrays handed out are slots of a ring: valid until DEPTH + 1 further
+    plans have been taken."""
 
-    def __init__(self, state, order, k_of_dim, shuffle):
+    DEPTH = 4
+    NDRAW = 2
+
+    def __init__(self, state, order, k_of_dim, shuffle, stage=None, n_stage_slots=0):
         self.k_of_dim, self.shuffle = k_of_dim, bool(shuffle)
         self.K = int(k_of_dim[0])
         self.closed = False
+        self.nring = self.DEPTH + 2
+        self.stage = stage if n_stage_slots >= self.nring else None
+        n = len(order)
+        self._cand = [np.empty(n, dtype="int32") for _ in range(self.nring)]
+        self._logu = [np.empty(n) for _ in range(self.nring)]
         self._slots = threading.Semaphore(self.DEPTH)
-        self._to_draw = queue.SimpleQueue()
-        self.out = queue.SimpleQueue()
+        self._to_draw = [queue.SimpleQueue() for _ in range(self.NDRAW)]
+        self._out = [queue.SimpleQueue() for _ in range(self.NDRAW)]
+        self._taken = 0
         self._start = (state, order.copy())
-        threading.Thread(target=self._shuffler, daemon=True, name="pymc_amd_gibbs_shuffle").start()
-        threading.Thread(target=self._drawer, daemon=True, name="pymc_amd_gibbs_draws").start()
+        self._threads = [threading.Thread(target=self._shuffler, daemon=True, name="pymc_amd_gibbs_shuffle")]
+        self._threads += [threading.Thread(target=self._drawer, args=(j,), daemon=True, name=f"pymc_amd_gibbs_draws{j}") for j in range(self.NDRAW)]
+        for t in self._threads:
+            t.start()
 
     def close(self):
+        """Stops the threads and waits for them: a drawer may be in the middle of an upload into the engine handle's slots."""
         self.closed = True
         self._slots.release()          # (wake a shuffler that waits for a free slot)
-        self._to_draw.put(None)
+        for q in self._to_draw:
+            q.put(None)
+        me = threading.current_thread()
+        for t in self._threads:
+            if t is not me:
+                t.join(timeout=5.0)
 
     def _shuffler(self):
         lib = _lib.load()
         gen = np.random.Generator(np.random.PCG64(0))
         state, order = self._start
         n = len(order)
+        seq = 0
         try:
             while True:
                 self._slots.acquire()
@@ -238,37 +261,49 @@ class _PlanPipeline:
                     _lib.check(lib.nuts_gibbs_plan_shuffle(C.byref(p), n, order.ctypes.data), "nuts_gibbs_plan_shuffle")
                 _pcg_from_c(gen, p)
                 after_shuffle = gen.bit_generator.state
-                self._to_draw.put((base_state, base_order, order, after_shuffle))
+                self._to_draw[seq % self.NDRAW].put((seq, base_state, base_order, order, after_shuffle))
+                seq += 1
                 # the generator after this sweep's per-element draws, without replaying them: where the next shuffle starts
                 _lib.check(lib.nuts_gibbs_plan_skip(C.byref(p), n, self.K), "nuts_gibbs_plan_skip")
                 _pcg_from_c(gen, p)
                 state = gen.bit_generator.state
         except BaseException as err:  # noqa: BLE001 -- the consumer falls back to drawing the plan itself
-            self.out.put(err)
+            for q in self._out:
+                q.put(err)
 
-    def _drawer(self):
+    def _drawer(self, j):
         lib = _lib.load()
         gen = np.random.Generator(np.random.PCG64(0))
+        u = None
         try:
             while True:
-                item = self._to_draw.get()
+                item = self._to_draw[j].get()
                 if item is None or self.closed:
                     return
-                base_state, base_order, order, after_shuffle = item
+                seq, base_state, base_order, order, after_shuffle = item
                 n = len(order)
+                ring = seq % self.nring
+                cand, log_u = self._cand[ring], self._logu[ring]
+                u = np.empty(n) if u is None else u
                 gen.bit_generator.state = after_shuffle
                 p = _pcg_to_c(gen)
-                cand, u, clean = np.empty(n, dtype="int32"), np.empty(n), C.c_int32(0)
+                clean = C.c_int32(0)
                 _lib.check(lib.nuts_gibbs_plan_draws(C.byref(p), n, order.ctypes.data, self.k_of_dim.ctypes.data, cand.ctypes.data, _lib.dptr(u),
                                                      C.byref(clean)), "nuts_gibbs_plan_draws")
                 _pcg_from_c(gen, p)
-                self.out.put((base_state, base_order, cand, np.log(u), order, gen.bit_generator.state, bool(clean.value)))
+                np.log(u, out=log_u)       # NumPy's log, as `np.log(rng.uniform())` in the reference
+                slot = None
+                if self.stage is not None and not self.closed:
+                    self.stage(ring, order, cand, log_u)
+                    slot = ring
+                self._out[j].put((base_state, base_order, cand, log_u, order, gen.bit_generator.state, bool(clean.value), slot))
         except BaseException as err:  # noqa: BLE001
-            self.out.put(err)
+            self._out[j].put(err)
 
     def take(self):
-        """The next plan in line (blocks until the drawer has it); its slot is free for the shuffler again."""
-        res = self.out.get()
+        """The next plan in line (blocks until its drawer has it); its place in the look-ahead is free for the shuffler again."""
+        res = self._out[self._taken % self.NDRAW].get()
+        self._taken += 1
         self._slots.release()
         return res
 
@@ -324,7 +359,7 @@ class CategoricalGibbsMetropolis:
         self._plan_ahead = None   # the `_PlanPipeline` that draws the next sweeps' plans ahead (None: not running)
 
     def _next_plan(self):
-        """(cand_raw, log_u) of this sweep, `self._order` and `self.rng` advanced as `plan_sweep` advances them.  The plans come from
+        """(cand_raw, log_u, device slot the plan is staged in | None) of this sweep, `self._order` and `self.rng` advanced as `plan_sweep` advances them.  The plans come from
         the step's `_PlanPipeline` when it is still in step with (`self.rng`, `self._order`); otherwise -- the first sweep of a chain, a
         generator someone replaced, a Lemire rejection that invalidated the jump -- the plan is drawn here and the pipeline restarted
         behind it."""
@@ -335,28 +370,35 @@ class CategoricalGibbsMetropolis:
             res = pipe.take()
             ok = not isinstance(res, BaseException)
             if ok:
-                base_state, base_order, cand, log_u, order, after, clean = res
+                base_state, base_order, cand, log_u, order, after, clean, slot = res
                 ok = _state_key(bg.state) == _state_key(base_state) and np.array_equal(self._order, base_order)
             if ok:
                 self._order[:] = order
                 bg.state = after
-                got = (cand, log_u)
+                got = (cand, log_u, slot)
                 if not clean:          # the plans behind this one started from a generator state the jump mispredicted
                     ok = False
             if not ok:
                 pipe.close()
                 self._plan_ahead = None
         if got is None:
-            got = plan_sweep(self.rng, self._order, self._k_of_dim, self.shuffle_dims)
+            got = (*plan_sweep(self.rng, self._order, self._k_of_dim, self.shuffle_dims), None)
         if (self._plan_ahead is None and _PLAN_PREFETCH_ON and len(self._order) >= _PLAN_PREFETCH_MIN and bg.state.get("bit_generator") == "PCG64"
                 and bool(np.all(self._k_of_dim == self._k_of_dim[0]))):
-            self._plan_ahead = _PlanPipeline(bg.state, self._order, self._k_of_dim, self.shuffle_dims)
+            lib, g = _lib.load(), self._handle      # (no handle yet -- host-only use of the plans: nothing is staged)
+
+            def stage(slot, order, cand, log_u):
+                _lib.check(lib.nuts_gibbs_stage(g, slot, order.ctypes.data, cand.ctypes.data, _lib.dptr(log_u)), "nuts_gibbs_stage")
+
+            self._plan_ahead = _PlanPipeline(bg.state, self._order, self._k_of_dim, self.shuffle_dims, stage if g else None,
+                                             int(lib.nuts_gibbs_stage_slots()))
         return got
 
     def __getstate__(self):   # (a pending plan and the engine handle do not travel)
         d = dict(self.__dict__)
         d["_plan_ahead"] = None
         d["_handle"] = None
+        d["_c_last"] = None
         return d
 
     @property
@@ -451,21 +493,34 @@ class CategoricalGibbsMetropolis:
         if getattr(self, "proposal", "uniform") == "proportional":
             return self._step_proportional(point)
         link = self.link
-        c = np.ascontiguousarray(point[link.name], dtype="int32").copy()
+        lib, g = _lib.load(), self._engine()
+        c_obj = point[link.name]
+        # the assignments the previous sweep of this step left on the device are the ones handed in (the array it returned is
+        # read-only, so identity is enough): nothing to upload.  Anything else -- the first sweep, a point someone built -- is uploaded.
+        c_in = None if (c_obj is getattr(self, "_c_last", None) and c_obj is not None) else np.ascontiguousarray(c_obj, dtype="int32")
         mu = np.ascontiguousarray(point[link.mu_name], dtype="float64")
-        cand, log_u = self._next_plan()
+        cand, log_u, slot = self._next_plan()
+        if slot is None:      # a plan drawn on this thread (the first sweep of a chain, a generator someone replaced): staged from here
+            slot = int(lib.nuts_gibbs_stage_slots()) - 1
+            _lib.check(lib.nuts_gibbs_stage(g, slot, self._order.ctypes.data, cand.ctypes.data, _lib.dptr(log_u)), "nuts_gibbs_stage")
         K = link.K
         cnt, s1, s2 = np.empty(K), np.empty(K), np.empty(K)
         nacc, nonf = C.c_int64(0), C.c_int64(0)
         lw, sg = np.ascontiguousarray(link.log_w_at(point), dtype="float64"), np.ascontiguousarray(link.sigma_at(point), dtype="float64")
-        rc = _lib.load().nuts_gibbs_sweep(self._engine(), c.ctypes.data, _lib.dptr(lw), _lib.dptr(mu), _lib.dptr(sg), self._order.ctypes.data,
-                                          cand.ctypes.data, _lib.dptr(log_u), C.byref(nacc), C.byref(nonf), _lib.dptr(cnt), _lib.dptr(s1), _lib.dptr(s2))
-        _lib.check(rc, "nuts_gibbs_sweep")
+        dt = np.asarray(c_obj).dtype
+        new_c = np.empty(len(link.y), dtype="int64" if dt != np.int32 else "int32")
+        rc = lib.nuts_gibbs_sweep_staged(g, slot, None if c_in is None else c_in.ctypes.data, new_c.ctypes.data, int(new_c.dtype == np.int64),
+                                         _lib.dptr(lw), _lib.dptr(mu), _lib.dptr(sg), C.byref(nacc), C.byref(nonf), _lib.dptr(cnt), _lib.dptr(s1),
+                                         _lib.dptr(s2))
+        _lib.check(rc, "nuts_gibbs_sweep_staged")
         if nonf.value:
+            self._c_last = None
             raise _lib.EngineError("a proposal had a non-finite log-density difference: the uniform stream cannot be pre-drawn for this sweep")
         self.accepted_last = int(nacc.value)
-        new_c = c.astype(np.asarray(point[link.name]).dtype, copy=False)
-        new_c = np.ascontiguousarray(new_c)
+        if new_c.dtype != dt:
+            new_c = new_c.astype(dt)
+        new_c.flags.writeable = False
+        self._c_last = new_c
         link.remember(new_c, (cnt, s1, s2))
         new_point = dict(point)
         new_point[link.name] = new_c
@@ -490,6 +545,7 @@ class CategoricalGibbsMetropolis:
         if self._handle:
             _lib.load().nuts_gibbs_destroy(self._handle)
             self._handle = None
+        self._c_last = None
 
     def __del__(self):
         try:

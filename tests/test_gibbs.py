@@ -33,12 +33,14 @@ def _numpy_plan(rng, n, ks):
     return [d for d, _ in dimcats], cand, lu
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(14))
 def test_pcg64_replay_matches_numpy_bit_for_bit(seed):
     import __graft_entry__ as g
 
     g.build_engine()
     n = int(np.random.default_rng(seed + 1000).integers(1, 500))
+    if seed >= 10:
+        n = 9000 + 37 * seed            # longer than one block of the bulk replay (2048 outputs = 4096 halves): blocks are crossed
     ks = np.random.default_rng(seed + 2000).integers(2, 7, size=n).astype("int32")
     if seed % 4 == 0:
         ks[:] = 2                       # `rng.choice(1)` draws nothing
@@ -589,12 +591,13 @@ def test_the_plan_of_the_next_sweep_is_drawn_ahead_without_changing_the_stream(m
         monkeypatch.setattr(G, "_PLAN_PREFETCH_ON", prefetch)
         st = G.CategoricalGibbsMetropolis(model=spec, rng=5)
         out = []
-        for i in range(7):
+        for i in range(12):            # (longer than the look-ahead's ring of plan buffers)
             if disturb and i == 3:
                 st.rng.random()                                   # the generator moved: a plan drawn ahead no longer applies
             if disturb and i == 5:
                 st.sampling_state = st.sampling_state             # state round trip between two sweeps
-            c, lu = st._next_plan()
+            c, lu, slot = st._next_plan()
+            assert slot is None                                   # (no engine handle: the plans stay on the host)
             out.append((c.copy(), lu.copy(), st._order.copy(), st.rng.bit_generator.state["state"]["state"], st.sampling_state.rng))
         return out
 
@@ -651,7 +654,8 @@ def test_sample_assigns_nuts_and_gibbs_to_a_mixture_with_assignments():
 
 @pytest.mark.parametrize("K,n", [(3, 5000), (5, 4097), (2, 4500)])
 def test_the_plan_pipeline_hands_out_the_plans_of_the_sequential_replay(K, n):
-    """Round 5: shuffle and per-element draws of a sweep are replayed by two host threads as a pipeline, the shuffle of sweep k + 1
+    """Round 5: shuffle and per-element draws of a sweep are replayed by host threads as a pipeline (one shuffler, two drawers taking
+    alternate sweeps), the shuffle of sweep k + 1
     starting from a generator state reached by a JUMP over sweep k's draws (`nuts_gibbs_plan_skip`).  Whatever the threads do, the
     plans that come out are, sweep by sweep, the ones the sequential replay (`plan_sweep`, itself pinned to NumPy's generator above)
     produces: candidates, logarithms, order and generator state, bit for bit."""
@@ -664,10 +668,10 @@ def test_the_plan_pipeline_hands_out_the_plans_of_the_sequential_replay(K, n):
     pipe = gibbs._PlanPipeline(rng.bit_generator.state, np.arange(n, dtype="int32"), k_of_dim, True)
     try:
         order = np.arange(n, dtype="int32")
-        for sweep in range(7):
+        for sweep in range(14):           # (twice around the ring of plan buffers, both drawer threads several times)
             want_cand, want_logu = gibbs.plan_sweep(ref_rng, ref_order, k_of_dim, True)
-            base_state, base_order, cand, log_u, order_after, after, clean = pipe.take()
-            assert clean
+            base_state, base_order, cand, log_u, order_after, after, clean, slot = pipe.take()
+            assert clean and slot is None
             assert gibbs._state_key(base_state) == gibbs._state_key(rng.bit_generator.state) and np.array_equal(base_order, order), sweep
             assert np.array_equal(cand, want_cand) and np.array_equal(log_u, want_logu) and np.array_equal(order_after, ref_order), sweep
             assert gibbs._state_key(after) == gibbs._state_key(ref_rng.bit_generator.state), sweep

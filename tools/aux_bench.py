@@ -93,12 +93,39 @@ def bench_c5(args):
     for _ in range(args.warmup):
         point, _ = comp.step(point)
     comp.stop_tuning()
+    prof = None
+    if args.profile_host:
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     trees = 0
     for _ in range(args.steps):
         point, st = comp.step(point)
         trees += int(st[0]["tree_size"])
     T = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        import sys
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)
+    # the NUTS step alone (the assignments fixed), and what the plan look-ahead can supply when nothing else runs
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        point, _ = nuts.step(point)
+    Tn = time.perf_counter() - t0
+    from pymc_amd import gibbs as G
+
+    pipe = G._PlanPipeline(np.random.default_rng(4).bit_generator.state, np.arange(args.mix_n, dtype="int32"), np.full(args.mix_n, 3, dtype="int32"), True)
+    for _ in range(5):
+        pipe.take()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        pipe.take()
+    Tp = (time.perf_counter() - t0) / 200
+    pipe.close()
     # the sweep alone
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -112,9 +139,11 @@ def bench_c5(args):
         "metric": "compound iterations/sec", "value": args.steps / T, "unit": "iterations/s", "steps": args.steps, "warmup": args.warmup,
         "ms_per_iteration": 1e3 * T / args.steps, "mean_tree_size": trees / args.steps,
         "gibbs_sweep_ms": 1e3 * Tg / args.steps, "gibbs_elements_per_sec": N * args.steps / Tg,
+        "nuts_step_ms": 1e3 * Tn / args.steps, "plan_lookahead_ms_per_plan": 1e3 * Tp,
         "sweep_bytes_algorithmic": N * (8 + 8 + 8 + 8 + 8 + 8),
-        "note": "a sweep = host replay of the reference's PCG64 stream (shuffle, choice(k-1), uniform; nuts_gibbs_plan) + one device "
-                "launch of N acceptance tests; the per-sweep host work and the PCIe round trip of the plan dominate at this N",
+        "note": "a sweep = one device launch of N acceptance tests on a plan (the reference's PCG64 stream: shuffle, choice(k-1), uniform) that "
+                "host threads replayed and uploaded while earlier sweeps ran (pymc_amd/gibbs.py _PlanPipeline); the sweep's own thread uploads "
+                "3 K parameters and reads the assignments back.  plan_lookahead_ms_per_plan = what those threads can supply on this host",
         "dtype": "f64 / int64", "data": "synthetic",
     }
     if args.cpu_steps > 0:
@@ -144,6 +173,7 @@ if __name__ == "__main__":
     ap.add_argument("--glm-cols", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--mix-n", type=int, default=100_000)
+    ap.add_argument("--profile-host", action="store_true", help="c5: cProfile of the timed loop's host thread, to stderr")
     ap.add_argument("--bayes", action="store_true", help="c5: weights (Dirichlet) and component scales are NUTS variables too")
     a = ap.parse_args()
     (bench_c4 if a.workload == "c4" else bench_c5)(a)
