@@ -382,6 +382,9 @@ int nuts_chain_draw(nuts_chain *c, const double *q0, const double *normals, cons
  * but not of its gradient (e.g. discrete latents updated by another step of a CompoundStep, arraystep.py:109-111)
  * are data vectors that the caller rewrites before a transition.  Invalidates every chain's start-state cache. */
 int nuts_model_set_data(nuts_model *m, int32_t data_id, const double *values, int64_t n);
+/* Several at once: `values` = the vectors one after the other, lens[i] = length of vector data_ids[i].  Stream-ordered (no host
+ * synchronisation): what is launched afterwards sees the new values. */
+int nuts_model_set_data_many(nuts_model *m, int32_t count, const int32_t *data_ids, const double *values, const int64_t *lens);
 
 /* K consecutive post-tuning transitions in one device launch (removes the per-draw host round trip
  * of sampling/mcmc.py:1556-1572 for models on the single-workgroup path).  Between two draws of the sampling phase

@@ -231,6 +231,7 @@ SYMBOLS = {
     "nuts_chain_set_iter_count": (C.c_int, [_VP, C.c_int64]),
     "nuts_chain_draw": (C.c_int, [_VP, _PD, _PD, _PD, C.c_int32, _PD, _PD, C.POINTER(DrawStats)]),
     "nuts_model_set_data": (C.c_int, [_VP, C.c_int32, _PD, C.c_int64]),
+    "nuts_model_set_data_many": (C.c_int, [_VP, C.c_int32, _VP, _PD, _VP]),
     "nuts_chain_draw_many": (C.c_int, [_VP, _PD, _PD, _PD, C.c_int32, C.c_int32, _PD, C.POINTER(DrawStats), C.POINTER(C.c_int32)]),
     "nuts_chain_draw_hmc": (C.c_int, [_VP, _PD, _PD, _PD, C.c_double, C.c_int32, _PD, _PD, C.POINTER(HmcStats)]),
     "nuts_chain_leapfrog_test": (C.c_int, [_VP, _PD, _PD, C.c_double, C.c_int32, _PD, _PD, _PD]),

@@ -98,6 +98,7 @@ struct nuts_model {
   double* host_pin = nullptr;  // pinned [2n+2]
   std::vector<nuts_data_ref> data_refs;   // (offset, size) of every data vector in the device pool
   int64_t data_epoch = 0;                 // bumped by nuts_model_set_data: start-state caches of older epochs are stale
+  double* set_pin = nullptr; int64_t set_pin_len = 0; hipEvent_t set_ev = nullptr;   // nuts_model_set_data_many's staging buffer
   int rows_grid = 0, mvn_grid = 0, ept = 1;
   bool has_prog = false;   // some factor carries an expression program or a gathered operand: kernels with the interpreter compiled in
   int rows_rpl = 2, rows_alternate = 1, rows_flip = 0, rows_occ = 4;
@@ -1335,10 +1336,51 @@ extern "C" int nuts_model_set_data(nuts_model* m, int32_t data_id, const double*
   return NUTS_OK;
 }
 
+// Several data vectors at once (the extra inputs another step method has just changed: `ValueGradFunction.set_extra_values`,
+// model/core.py:275-278): `values` holds them one after the other.  The bytes go through a pinned staging buffer and ONE
+// stream-ordered copy per run of vectors that are neighbours in the data pool -- no host synchronisation: launches submitted
+// afterwards see the new values, launches in flight the old ones.
+extern "C" int nuts_model_set_data_many(nuts_model* m, int32_t count, const int32_t* data_ids, const double* values, const int64_t* lens) {
+  if (!m || count < 0 || (count > 0 && (!data_ids || !values || !lens))) { g_err = "null argument"; return NUTS_E_ARG; }
+  int64_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    if (data_ids[i] < 0 || data_ids[i] >= (int)m->data_refs.size()) { g_err = "nuts_model_set_data_many: no such data vector"; return NUTS_E_ARG; }
+    if (lens[i] != m->data_refs[data_ids[i]].size) { g_err = "nuts_model_set_data_many: the length of a data vector cannot change"; return NUTS_E_ARG; }
+    total += lens[i];
+  }
+  if (total == 0) return NUTS_OK;
+  if (m->set_pin_len < total) {
+    if (m->set_ev) HIPCHK(hipEventSynchronize(m->set_ev));
+    if (m->set_pin) hipHostFree(m->set_pin);
+    m->set_pin = nullptr; m->set_pin_len = 0;
+    HIPCHK(hipHostMalloc((void**)&m->set_pin, (size_t)total * sizeof(double), hipHostMallocDefault));
+    m->set_pin_len = total;
+  }
+  if (!m->set_ev) HIPCHK(hipEventCreateWithFlags(&m->set_ev, hipEventDisableTiming));
+  else HIPCHK(hipEventSynchronize(m->set_ev));          // the previous call's copies have left the staging buffer
+  std::memcpy(m->set_pin, values, (size_t)total * sizeof(double));
+  int64_t at = 0;
+  for (int i = 0; i < count;) {
+    const int64_t off0 = m->data_refs[data_ids[i]].offset;
+    int64_t run = lens[i];
+    int j = i + 1;
+    while (j < count && m->data_refs[data_ids[j]].offset == off0 + run) { run += lens[j]; ++j; }
+    if (run > 0)
+      HIPCHK(hipMemcpyAsync(const_cast<double*>(m->md.pool) + off0, m->set_pin + at, (size_t)run * sizeof(double), hipMemcpyHostToDevice, m->stream));
+    at += run;
+    i = j;
+  }
+  HIPCHK(hipEventRecord(m->set_ev, m->stream));
+  m->data_epoch++;
+  return NUTS_OK;
+}
+
 static void group_remove_model(struct nuts_group* g, nuts_model* m);
 extern "C" void nuts_model_destroy(nuts_model* m) {
   if (!m) return;
   if (m->stream) hipStreamSynchronize(m->stream);
+  if (m->set_ev) hipEventDestroy(m->set_ev);
+  if (m->set_pin) hipHostFree(m->set_pin);
   if (m->group) group_remove_model(m->group, m);
   for (void* p : m->owned) if (p) hipFree(p);
   for (auto e : m->ev) hipEventDestroy(e);

@@ -371,9 +371,10 @@ class CategoricalGibbsMetropolis:
             ok = not isinstance(res, BaseException)
             if ok:
                 base_state, base_order, cand, log_u, order, after, clean, slot = res
-                ok = _state_key(bg.state) == _state_key(base_state) and np.array_equal(self._order, base_order)
+                # (the order this plan started from is the array the previous plan handed over, unless someone replaced it)
+                ok = _state_key(bg.state) == _state_key(base_state) and (base_order is self._order or np.array_equal(self._order, base_order))
             if ok:
-                self._order[:] = order
+                self._order = order          # (the pipeline never writes to an order it has handed out)
                 bg.state = after
                 got = (cand, log_u, slot)
                 if not clean:          # the plans behind this one started from a generator state the jump mispredicted

@@ -187,13 +187,20 @@ class DeviceValueGradFunction:
         """core.py:275-278: the non-gradient inputs are data vectors of the spec, rewritten on the device
         (`nuts_model_set_data`; values that did not change are not sent again)."""
         lib = _lib.load()
+        ids, vals = [], []
         for name, idx in self.spec.extra.items():
             v = np.ascontiguousarray(np.asarray(extra_vars[name], dtype="float64").ravel())
             old = self._extra_vars_shared.get(name)
             if old is not None and old.shape == v.shape and np.array_equal(old, v):
                 continue
-            _lib.check(lib.nuts_model_set_data(self._handle, idx, _lib.dptr(v), v.size), "nuts_model_set_data")
+            ids.append(idx)
+            vals.append(v)
             self._extra_vars_shared[name] = v.copy()
+        if ids:     # ONE call, stream-ordered (no host synchronisation per vector)
+            ids_a = np.asarray(ids, dtype="int32")
+            lens = np.asarray([v.size for v in vals], dtype="int64")
+            flat = np.concatenate(vals) if len(vals) > 1 else vals[0]
+            _lib.check(lib.nuts_model_set_data_many(self._handle, len(ids), ids_a.ctypes.data, _lib.dptr(flat), lens.ctypes.data), "nuts_model_set_data_many")
         self._extra_are_set = True
 
     def get_extra_values(self):  # core.py:280-284
