@@ -846,6 +846,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       if (s->data_pool_len > 0) hipMemcpy(pool, s->data_pool, (size_t)s->data_pool_len * sizeof(double), hipMemcpyHostToDevice);
     }
     md.pool = pool;
+    md.pool_len = (int32_t)std::min<int64_t>(s->data_pool_len + m->pool_extra, INT32_MAX);
   }
   m->data_refs.assign(s->data, s->data + s->n_data);
   m->ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
@@ -1592,6 +1593,7 @@ struct nuts_chain {
   double* out_dev = nullptr;     // [2n]
   double* out_dev2 = nullptr;    // [2n] second output buffer (single-launch path: output and start-state cache alternate)
   bool small = false;            // latency regime: whole draw in one launch (small_kernel.h)
+  int small_lds_slots = 0;       // SmallDrawArgs.lds_slots
   double* out_host = nullptr;    // pinned [2n]
   HostStatus* st_dev = nullptr;
   HostStatus* st_host = nullptr;   // pinned + device-mapped; st_dev is its device alias
@@ -1829,6 +1831,9 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->xfold = env_int("NUTS_XFOLD", 1);
   c->pipe_draws = env_int("NUTS_PIPE_DRAWS", 1) != 0;
   c->xpre = env_int("NUTS_XPRE", 1);
+  // NUTS_SMALL_LDS=0: the single-workgroup kernel with its tree in global memory, as before round 5 (A/B); NUTS_SMALL_LDS_SLOTS=k
+  // (a power of two): at most k slots in LDS, so that ordinary trees cross over to the global arena (tests)
+  c->small_lds_slots = env_int("NUTS_SMALL_LDS", 1) == 0 ? -1 : env_int("NUTS_SMALL_LDS_SLOTS", 0);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
              !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
@@ -2524,7 +2529,7 @@ extern "C" int nuts_chain_draw(nuts_chain* c, const double* q0, const double* no
     a.q_src = cached ? c->out_dev2 : nullptr; a.g_src = cached ? c->out_dev2 + n : nullptr; a.cached_logp = c->last_logp;
     a.step_size = step_size; a.Emax = c->cfg.Emax; a.max_depth = max_depth;
     a.n_draws = 1; a.n_uniforms = need_uni; a.worst_uniforms = need_uni;
-    a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = nullptr; a.out = c->do_dev; a.n_done = nullptr; a.st = nullptr; a.seq = 0;
+    a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = nullptr; a.out = c->do_dev; a.n_done = nullptr; a.st = nullptr; a.seq = 0; a.lds_slots = c->small_lds_slots;
     launch_small(c, A, a);
     // the next draw's start-state cache must not alias this draw's output buffer
     std::swap(c->out_dev, c->out_dev2);
@@ -2827,7 +2832,7 @@ extern "C" int nuts_chain_draw_many(nuts_chain* c, const double* q0, const doubl
   a.q_src = cached ? c->out_dev2 : nullptr; a.g_src = cached ? c->out_dev2 + n : nullptr; a.cached_logp = c->last_logp;
   a.step_size = step_size; a.Emax = c->cfg.Emax; a.max_depth = max_depth;
   a.n_draws = K; a.n_uniforms = n_uniforms; a.worst_uniforms = need_uni;
-  a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = trace_dev; a.out = outs_dev; a.n_done = ndone_dev; a.st = nullptr; a.seq = 0;
+  a.q_out = c->out_dev; a.g_out = c->out_dev + n; a.trace_q = trace_dev; a.out = outs_dev; a.n_done = ndone_dev; a.st = nullptr; a.seq = 0; a.lds_slots = c->small_lds_slots;
   launch_small(c, Am, a);
   std::swap(c->out_dev, c->out_dev2);   // (q, grad) of the last proposal: the next call's start-state cache
   HIPCHK(hipMemcpyAsync(c->many_out_host, c->many_out_dev, out_bytes, hipMemcpyDeviceToHost, s));

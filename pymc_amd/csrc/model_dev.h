@@ -197,7 +197,7 @@ struct ModelDev {
   double* def_loc;            // [2][MAX_DEFERRED][4] (second copy: the group-aligned row pass double-buffers by launch parity)
   int32_t lean_ok, lean_pad;
   // derived vectors (NUTS_D_DERIVED): factor ids and the offset of each one's values in `pool` (its seed follows the values)
-  int32_t n_derived, derived_pad;
+  int32_t n_derived, pool_len;   // (pool_len: doubles in `pool`, derived vectors included)
   int32_t derived_f[MAX_DERIVED];
   int64_t derived_off[MAX_DERIVED];
   // the tables above packed into one blob (kernels copy it into LDS: the interpreter then never waits on HBM)

@@ -40,15 +40,31 @@ struct SmallDrawArgs {
   DrawOut* out;            // [n_draws]
   int* n_done;             // draws actually made (device int)
   HostStatus* st;
-  int seq, pad2;
+  int seq, lds_slots;      // 0: the tree in LDS when it fits; -1: in the global arena whatever the size (A/B); k > 0: at most k LDS slots (tests of the hand-over)
 };
 
 // NT = threads of the one workgroup (256, 512 or 1024: one thread per parameter, so n <= 1024 runs here; at 1024 threads the
 // register budget is 128 and the kernel spills a little -- still 20.6 us per leapfrog against 25.3 us at n = 602 and 23.8
 // against 25.2 at n = 1002, profiles/r02i_latency_regime.json)
+//
+// Round 5 -- the tree in LDS.  Every leaf of the launch above made six to eight dependent round trips to the arena, the data pool
+// and the uniform stream in global memory (~0.7 us each out of L2): 10 us per leapfrog at n = 3, whatever the arithmetic.  For
+// n <= SMALL_LDS_N the 256-thread kernel keeps them in LDS instead: the arena as S' = the largest power of two of slots that fit
+// SMALL_ARENA_DBL doubles (512 slots at n = 3, 256 at n = 10, 64 at n = 26, 32 at n = 64), the pending-sibling sums, the
+// potential's diagonal, the model's data pool (up to SMALL_POOL_DBL doubles) and the draw's window of uniforms.  The device
+// functions of the tree (leaf_post, tree_decide, gather_element) take the arena as pointers + slot count and do not care where it
+// lives.  A tree that outgrows the LDS slots (a doubling that would hold more than S' leaves) is copied out to the global arena,
+// slot by slot, and goes on there; so does the tree of a draw that diverged, because the host fetches the two points of a
+// divergence from the global arena (engine.hip finish_draw_host).  Same arithmetic in the same order either way: identical results.
+#define SMALL_LDS_N 64
+#define SMALL_ARENA_DBL 11264
+#define SMALL_POOL_DBL 1024
+#define SMALL_UNI_DBL 1100
+
 template <int NT, bool PROG>
-__global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, SmallDrawArgs a) {
+__global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, SmallDrawArgs a) {
   constexpr int NW = NT / WAVE;
+  constexpr bool LDSV = NT == 256;     // the variant that may keep the tree in LDS
   __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
   __shared__ double s_bacc[MAX_BTERMS][NT];
   __shared__ double s_red[NDOT * NW];
@@ -56,12 +72,54 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
   __shared__ double s_w[NW];
   __shared__ Ctl s_ctl;
   __shared__ int s_stop;
+  __shared__ double s_arena[LDSV ? SMALL_ARENA_DBL : 1];
+  __shared__ double s_ps[LDSV ? (MAX_LEVELS + 1) * SMALL_LDS_N : 1];
+  __shared__ double s_diag[LDSV ? 2 * SMALL_LDS_N : 1];
+  __shared__ double s_pool[LDSV ? SMALL_POOL_DBL : 1];
+  __shared__ double s_uni[LDSV ? SMALL_UNI_DBL : 1];
   const int tid = threadIdx.x;
   const int n = md.n;
   const bool mine = tid < n;
   ProgRegs pregs;
   prog_issue(md, pregs);
-  const Prog pg = load_prog(md, s_prog, pregs);
+  Prog pg = load_prog(md, s_prog, pregs);
+  // ---- where the tree lives ----
+  int S_lds = 0;
+  if (LDSV && n <= SMALL_LDS_N && a.lds_slots >= 0) {
+    S_lds = a.lds_slots > 0 ? min(Ag.S, a.lds_slots) : Ag.S;
+    while (S_lds > 1 && (int64_t)S_lds * (4 * n + 2) > SMALL_ARENA_DBL) S_lds >>= 1;
+    if (S_lds < 4) S_lds = 0;
+  }
+  ArenaDev A = Ag;
+  ArenaDev Al = Ag;       // the arena in LDS (S_lds > 0)
+  if (LDSV && S_lds > 0) {
+    double* base = s_arena;
+    Al.S = S_lds;
+    Al.Q = base; Al.P = base + (int64_t)S_lds * n; Al.V = base + 2 * (int64_t)S_lds * n; Al.G = base + 3 * (int64_t)S_lds * n;
+    Al.E = base + 4 * (int64_t)S_lds * n; Al.LOGP = Al.E + S_lds;
+    Al.PS = s_ps; Al.PSUM = s_ps + (int64_t)MAX_LEVELS * n;
+    if (mine) { s_diag[tid] = Ag.var[tid]; s_diag[SMALL_LDS_N + tid] = Ag.inv_stds[tid]; }
+    Al.var = s_diag; Al.inv_stds = s_diag + SMALL_LDS_N;
+    if (md.pool_len <= SMALL_POOL_DBL) {
+      for (int i = tid; i < md.pool_len; i += NT) s_pool[i] = pg.pool[i];
+      pg.pool = s_pool;
+    }
+  }
+  // the live leaves [left, right] of the tree in LDS -> their slots of the global arena (every thread calls it)
+  auto spill_tree = [&](int left, int right) {
+    const int cnt = (right - left + 1) * n;
+    for (int i = tid; i < cnt; i += NT) {
+      const int t = left + i / n, e = i - (i / n) * n;
+      const int64_t lo = (int64_t)(t & (S_lds - 1)) * n + e, go = (int64_t)(t & (Ag.S - 1)) * n + e;
+      Ag.Q[go] = Al.Q[lo]; Ag.P[go] = Al.P[lo]; Ag.V[go] = Al.V[lo]; Ag.G[go] = Al.G[lo];
+    }
+    for (int t = left + tid; t <= right; t += NT) {
+      Ag.E[t & (Ag.S - 1)] = Al.E[t & (S_lds - 1)];
+      Ag.LOGP[t & (Ag.S - 1)] = Al.LOGP[t & (S_lds - 1)];
+    }
+    __threadfence_block();
+    __syncthreads();
+  };
   int k = 0;
   VarDev v{};
   if (mine) { k = find_var(pg, tid); v = pg.vars[k]; }
@@ -99,10 +157,23 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
     logp = block_sum<true>(lp, s_w);
   };
 
-  A.log_uniforms = nullptr;   // log(u) is taken by the control thread (header comment)
+  Ag.log_uniforms = nullptr;   // log(u) is taken by the control thread (header comment)
+  Al.log_uniforms = nullptr;
+  bool in_lds = false;
   int done = 0;
   double q_prop = 0.0, g_prop = 0.0, logp_prop = 0.0;   // previous draw's proposal (this thread's coordinate)
   for (int it = 0; it < a.n_draws; ++it) {
+    // every draw starts in LDS when the model allows; its window of the uniform stream comes along (the cursor runs on from draw to draw)
+    in_lds = LDSV && S_lds > 0;
+    A = in_lds ? Al : Ag;
+    if (in_lds) {
+      const int base = s_ctl.cursor;
+      const int cnt = min(min(a.worst_uniforms + 2, SMALL_UNI_DBL), a.n_uniforms - base);
+      for (int i = tid; i < cnt; i += NT) s_uni[i] = Ag.uniforms[base + i];
+      if (a.worst_uniforms + 2 <= SMALL_UNI_DBL) A.uniforms = s_uni - base;   // (index = the stream's own cursor)
+      if (it == 0 && !a.q_src && mine) A.Q[tid] = Ag.Q[tid];                   // (the host put q0 into slot 0 of the global arena)
+      __syncthreads();
+    }
     // ---- start state (base_hmc.py:201-202): q0, its gradient and logp; p0 = z / sigma; E0 ----
     double logp0 = a.cached_logp;
     if (it > 0) {
@@ -142,6 +213,12 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
 
     // ---- the tree (nuts.py:204-225) ----
     for (int d = 0; d < a.max_depth && !s_ctl.aborted; ++d) {
+      if (in_lds && (2 << d) > S_lds) {   // this doubling would hold more leaves than the LDS arena has slots: on in global memory
+        spill_tree(s_ctl.left, s_ctl.right);
+        const double* uni = A.uniforms;
+        A = Ag; A.uniforms = uni; A.PS = Al.PS; A.PSUM = Al.PSUM; A.var = Al.var; A.inv_stds = Al.inv_stds;
+        in_lds = false;
+      }
       Leaf lf;
       lf.dir = s_ctl.dir; lf.edge = s_ctl.edge; lf.left = s_ctl.left; lf.right = s_ctl.right;
       lf.eps = s_ctl.eps; lf.half = 0.5 * s_ctl.eps;
@@ -210,12 +287,13 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev A, Smal
     }
     done = it + 1;
     __syncthreads();   // every thread has read the proposal before slot 0 is overwritten; s_stop is visible
+    if (in_lds && s_ctl.diverging) spill_tree(s_ctl.left, s_ctl.right);   // (the host reads the two points of the divergence)
     if (s_stop) break;
   }
   if (mine) { a.q_out[tid] = q_prop; a.g_out[tid] = g_prop; }
   if (tid == 0) {
     if (a.n_done) *a.n_done = done;
-    *A.ctl = s_ctl;
+    *Ag.ctl = s_ctl;
     if (a.st) publish_status(&s_ctl, a.st, a.seq);
   }
 }

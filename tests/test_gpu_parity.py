@@ -549,6 +549,59 @@ def test_nuts_parity_three_kernel_pipeline_on_small_and_multi_workgroup_models(m
     _compare_runs(models.eight_schools(1200), tune=5, draws=2, seed=8, prefix=7)     # n = 1202: three-kernel pipeline by default
 
 
+def test_single_workgroup_kernel_gives_the_same_chain_with_its_tree_in_lds_in_global_memory_and_handed_over(monkeypatch):
+    """Round 5: for n <= 64 the single-workgroup kernel keeps the tree's arena, the data pool and the uniforms in LDS
+    (csrc/small_kernel.h).  The arithmetic and its order do not depend on where the arena lives: the chain is BITWISE the one with
+    the tree in global memory (NUTS_SMALL_LDS=0), also when the LDS arena is capped at 4 or 16 slots so that every tree deeper than
+    1 / 3 doublings is copied out to the global arena mid-draw (NUTS_SMALL_LDS_SLOTS), during tuning (draw by draw) and after it
+    (batches of draws inside one launch); and the integers are the oracle sampler's."""
+    from pymc_amd.sampling import sample
+
+    def run(spec, **env):
+        for k in ("NUTS_SMALL_LDS", "NUTS_SMALL_LDS_SLOTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res = sample(draws=40, tune=60, chains=1, model=spec, init="adapt_diag", random_seed=11, device=0)
+        res["step"].close()
+        stats = res["warmup_stats"][0] + res["stats"][0]
+        return res["draws"][0], [tuple(int(s[k]) for k in INT_KEYS) for s in stats], np.array([s["energy"] for s in stats])
+
+    for spec in (models.eight_schools(), models.eight_schools(24), models.eight_schools(60), models.std_normal(3)):
+        base = run(spec, NUTS_SMALL_LDS="0")
+        assert max(t[0] for t in base[1]) >= 3              # (trees deep enough to cross the capped arenas)
+        for env in ({}, {"NUTS_SMALL_LDS_SLOTS": "4"}, {"NUTS_SMALL_LDS_SLOTS": "16"}):
+            got = run(spec, **env)
+            assert got[1] == base[1], (spec.n, env)
+            assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2]), (spec.n, env)
+    _compare_runs(models.eight_schools(24), tune=30, draws=20, seed=5, prefix=45)
+
+
+def test_a_divergence_inside_the_lds_tree_reaches_the_host_with_its_two_points(monkeypatch):
+    """The host fetches the start and end point of a divergent leapfrog from the GLOBAL arena (base_hmc.py:249-258): a tree that
+    diverged while it lived in LDS is copied out before the kernel ends -- same divergence records as with the tree in global memory."""
+    from pymc_amd.sampling import sample
+
+    spec = models.eight_schools()      # the centred parameterisation diverges readily at a large step size
+
+    def run(lds):
+        monkeypatch.setenv("NUTS_SMALL_LDS", lds)
+        res = sample(draws=60, tune=20, chains=1, model=spec, init="adapt_diag", random_seed=2, device=0, target_accept=0.5)
+        res["step"].close()
+        stats = res["warmup_stats"][0] + res["stats"][0]
+        div = [int(s["diverging"]) for s in stats]
+        pts = [(w.divergence_point_source, w.divergence_point_dest) for w in (s["warning"] for s in res["stats"][0]) if w is not None]
+        return div, pts, res["draws"][0]
+
+    a, b = run("1"), run("0")
+    assert a[0] == b[0] and np.array_equal(a[2], b[2])
+    assert len(a[1]) == len(b[1]) and len(a[1]) >= 1           # (divergences after tuning: their points are kept)
+    for (sa, da), (sb, db) in zip(a[1], b[1]):
+        assert sa is not None and sb is not None
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]) and np.array_equal(da[k], db[k]) and np.all(np.isfinite(sa[k]))
+
+
 def test_nuts_parity_hier_logit():
     _compare_runs(models.hier_logit(G=16, D=8, rows_per_group=33, seed=3), tune=25, draws=15, seed=7, prefix=40)
 
