@@ -1594,6 +1594,7 @@ struct nuts_chain {
   double* out_dev2 = nullptr;    // [2n] second output buffer (single-launch path: output and start-state cache alternate)
   bool small = false;            // latency regime: whole draw in one launch (small_kernel.h)
   int small_lds_slots = 0;       // SmallDrawArgs.lds_slots
+  int small_one_wave = 1;        // n <= 64: the single-workgroup kernel with ONE wave (NUTS_SMALL_ONE_WAVE=0: four, as before round 5)
   double* out_host = nullptr;    // pinned [2n]
   HostStatus* st_dev = nullptr;
   HostStatus* st_host = nullptr;   // pinned + device-mapped; st_dev is its device alias
@@ -1834,6 +1835,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   // NUTS_SMALL_LDS=0: the single-workgroup kernel with its tree in global memory, as before round 5 (A/B); NUTS_SMALL_LDS_SLOTS=k
   // (a power of two): at most k slots in LDS, so that ordinary trees cross over to the global arena (tests)
   c->small_lds_slots = env_int("NUTS_SMALL_LDS", 1) == 0 ? -1 : env_int("NUTS_SMALL_LDS_SLOTS", 0);
+  c->small_one_wave = env_int("NUTS_SMALL_ONE_WAVE", 1);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
              !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
@@ -2439,7 +2441,8 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
 static void launch_small(nuts_chain* c, const ArenaDev& A, const SmallDrawArgs& a) {
 #define SMALL_LAUNCH(NT, P) hipLaunchKernelGGL((k_small_draw<NT, P>), dim3(1), dim3(NT), 0, c->m->stream, c->m->md, A, a)
   const bool hp = c->m->has_prog;
-  if (c->n <= 256) { if (hp) SMALL_LAUNCH(256, true); else SMALL_LAUNCH(256, false); }
+  if (c->n <= WAVE && c->small_one_wave) { if (hp) SMALL_LAUNCH(64, true); else SMALL_LAUNCH(64, false); }
+  else if (c->n <= 256) { if (hp) SMALL_LAUNCH(256, true); else SMALL_LAUNCH(256, false); }
   else if (c->n <= 512) { if (hp) SMALL_LAUNCH(512, true); else SMALL_LAUNCH(512, false); }
   else { if (hp) SMALL_LAUNCH(1024, true); else SMALL_LAUNCH(1024, false); }
 #undef SMALL_LAUNCH

@@ -394,7 +394,30 @@ __device__ __forceinline__ int find_var(const Prog& pg, int i) {
 // already in a register, everything else is recomposed through the view.
 // DEFQ: the caller is an auxiliary workgroup of a one-launch row pass (rows_aux.h) and qv.defq holds q' of the deferred elements
 // (a template parameter, not a run-time test of the pointer: the test alone cost k_small_draw 16 registers and 1.3 KB of scratch)
-template <bool DEFQ = false>
+// OL: a non-identity transform is applied by a CALL (transform_x_ol) instead of inline.  A factor evaluated through the general path
+// expands twelve operands, each with its own copy of exp / sigmoid / their divisions: 160 instructions per operand, 18 000 per
+// instance of the model evaluation in the single-workgroup kernel -- 42 000 instructions (340 KB) of which a leaf executes a few
+// hundred scattered over all of it, every one fetched from L2 (the instruction cache holds 64 KB).  The latency-bound caller takes
+// the call; the throughput-bound kernels keep the inline form.
+__device__ __noinline__ double transform_x_ol(int transform, double lower, double upper, double qi) {
+  switch (transform) {
+    case NUTS_TR_LOG: return exp(qi);
+    case NUTS_TR_LOGODDS: return sigmoid_d(qi);
+    case NUTS_TR_INTERVAL: { double s = sigmoid_d(qi); return s * upper + (1.0 - s) * lower; }
+    default: return qi;
+  }
+}
+template <bool OL>
+__device__ __forceinline__ double transform_x_sel(const VarDev& v, double qi) {
+  if constexpr (OL) {
+    if (v.transform != NUTS_TR_LOG && v.transform != NUTS_TR_LOGODDS && v.transform != NUTS_TR_INTERVAL) return qi;
+    return transform_x_ol(v.transform, v.lower, v.upper, qi);
+  } else {
+    return transform_x(v, qi);
+  }
+}
+
+template <bool DEFQ = false, bool OL = false>
 __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const Prog& pg, const QView& qv, int own_var,
                                            double own_x) {
   if (o.kind == NUTS_OP_CONST) return o.c;
@@ -405,12 +428,12 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
   if (o.kind == NUTS_OP_GATHER) {   // var[idx[li]]
     const nuts_data_ref r = pg.data[(int)o.c];
     const VarDev v = pg.vars[o.ref];
-    return transform_x(v, qv.at(v.offset + (int)pg.pool[r.offset + li]));
+    return transform_x_sel<OL>(v, qv.at(v.offset + (int)pg.pool[r.offset + li]));
   }
   if (o.ref == own_var) return own_x;
   const VarDev v = pg.vars[o.ref];
-  if constexpr (DEFQ) { if (v.deferred) return transform_x(v, qv.defq[v.def_base + (v.size > 1 ? li : 0)]); }
-  return transform_x(v, qv.at(v.offset + (v.size > 1 ? li : 0)));
+  if constexpr (DEFQ) { if (v.deferred) return transform_x_sel<OL>(v, qv.defq[v.def_base + (v.size > 1 ? li : 0)]); }
+  return transform_x_sel<OL>(v, qv.at(v.offset + (v.size > 1 ? li : 0)));
 }
 
 // log-density of one element and its partials w.r.t. each argument.
@@ -622,7 +645,7 @@ __device__ __forceinline__ double dist_eval(int dist, double konst, const double
 
 // Evaluate element `li` of factor `f`: returns its logp, fills d[k] (partials w.r.t. argument k)
 // and the b / c operand values of every argument (needed for the chain rule through a + b*c).
-template <bool DEFQ = false>
+template <bool DEFQ = false, bool OL = false>
 __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var,
                                               double own_x, double* d, double* bv, double* cv, int* pdead) {
   double a[4];
@@ -630,9 +653,9 @@ __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, c
   for (int k = 0; k < 4; ++k) {
     if (k < f.nargs) {
       const nuts_term& t = f.arg[k];
-      const double av = op_value<DEFQ>(t.a, li, pg, qv, own_var, own_x);
-      bv[k] = op_value<DEFQ>(t.b, li, pg, qv, own_var, own_x);
-      cv[k] = op_value<DEFQ>(t.c, li, pg, qv, own_var, own_x);
+      const double av = op_value<DEFQ, OL>(t.a, li, pg, qv, own_var, own_x);
+      bv[k] = op_value<DEFQ, OL>(t.b, li, pg, qv, own_var, own_x);
+      cv[k] = op_value<DEFQ, OL>(t.c, li, pg, qv, own_var, own_x);
       a[k] = av + bv[k] * cv[k];
     } else {
       a[k] = 0.0; bv[k] = cv[k] = 0.0;
@@ -850,7 +873,7 @@ __device__ __forceinline__ double slot_grad(const double* d, const double* bv, c
 // PROG = false: the model carries neither an expression program nor a gathered operand (the host picks the instantiation,
 // nuts_model::has_prog) -- the call into the out-of-line interpreter and everything it keeps alive across the call are compiled
 // out: with it k_small_draw<1024> spilled 357 registers and ran 59 us per leapfrog at n = 1002 instead of 24.
-template <bool PROG = true, bool DEFQ = false>
+template <bool PROG = true, bool DEFQ = false, bool OL = false>
 __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, int k, int li, double x, double& gx, double& lp,
                                                double* s_bacc, int bstride) {
   for (int c = pg.var_cptr[k]; c < pg.var_cptr[k + 1]; ++c) {
@@ -898,7 +921,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
     }
     double d[4], bv[4], cv[4];
     int pdead = 0;
-    double lpf = factor_eval<DEFQ>(pg, qv, f, li, k, x, d, bv, cv, &pdead);
+    double lpf = factor_eval<DEFQ, OL>(pg, qv, f, li, k, x, d, bv, cv, &pdead);
     factor_kill(pg, cb.f, pdead, lpf, d);
     gx += slot_grad(d, bv, cv, cb.arg, cb.slot);
     if (cb.owner) {
@@ -911,7 +934,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
 
 // One element of a factor WITHOUT an owning variable (only scalars and data): its logp and the broadcast terms of its scalars.
 // Shared by the orphan loops of kernel B (kernels.h) and of the single-workgroup kernel (small_kernel.h).
-template <bool PROG = true, bool DEFQ = false>
+template <bool PROG = true, bool DEFQ = false, bool OL = false>
 __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv, int fi, int li, double* s_bacc, int bstride) {
   const nuts_factor& f = pg.factors[fi];
   const FactorBT& bt = pg.fbt[fi];
@@ -921,7 +944,7 @@ __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv
   }
   double dv[4], bv[4], cv[4];
   int pdead = 0;
-  double lpo = factor_eval<DEFQ>(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
+  double lpo = factor_eval<DEFQ, OL>(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
   factor_kill(pg, fi, pdead, lpo, dv);
   for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm * bstride] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
   return lpo;

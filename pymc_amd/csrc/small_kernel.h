@@ -64,7 +64,7 @@ struct SmallDrawArgs {
 template <int NT, bool PROG>
 __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, SmallDrawArgs a) {
   constexpr int NW = NT / WAVE;
-  constexpr bool LDSV = NT == 256;     // the variant that may keep the tree in LDS
+  constexpr bool LDSV = NT <= 256;     // the variants that may keep the tree in LDS (NT = 64: one wave, n <= 64 -- every barrier and block sum of a leaf is then a wave's own business)
   __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
   __shared__ double s_bacc[MAX_BTERMS][NT];
   __shared__ double s_red[NDOT * NW];
@@ -80,9 +80,29 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
   const int tid = threadIdx.x;
   const int n = md.n;
   const bool mine = tid < n;
-  ProgRegs pregs;
-  prog_issue(md, pregs);
-  Prog pg = load_prog(md, s_prog, pregs);
+#ifdef NUTS_KTIMING   // (lab build, tools/small_ticks.py: where a draw's time goes inside the kernel -- thread 0's clock, summed over launches)
+  long long tk_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tk_last = tick_now();
+  const long long tk_begin = tk_last;
+#define SMALL_TICK(i) do { if (tid == 0) { const long long now_ = tick_now(); tk_acc[i] += now_ - tk_last; tk_last = now_; } } while (0)
+#else
+#define SMALL_TICK(i) do { } while (0)
+#endif
+  Prog pg;
+  if constexpr (NT >= 256) {
+    ProgRegs pregs;
+    prog_issue(md, pregs);
+    pg = load_prog(md, s_prog, pregs);
+  } else {   // (prog_issue / load_prog copy with 256 threads)
+    const char* base = md.prog;
+    if (md.prog_bytes <= PROG_LDS_MAX) {
+      const int n16 = (md.prog_bytes + 15) >> 4;
+      for (int i = tid; i < n16; i += NT) reinterpret_cast<uint4*>(s_prog)[i] = reinterpret_cast<const uint4*>(md.prog)[i];
+      __syncthreads();
+      base = s_prog;
+    }
+    pg = prog_view(md, base);
+  }
   // ---- where the tree lives ----
   int S_lds = 0;
   if (LDSV && n <= SMALL_LDS_N && a.lds_slots >= 0) {
@@ -140,21 +160,25 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
       } else {
         transform_full(v, qn, x, dxdq, lj, dj);
         lp = lj;
-        gather_element<PROG>(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], NT);
+        gather_element<PROG, false, true>(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], NT);
       }
     }
+    SMALL_TICK(8);     // (thread 0's own element)
     for (int o = 0; o < md.n_orphans; ++o) {   // factors without an owning variable
       const int fi = md.orphans[o];
       const int fsize = pg.factors[fi].size;
-      for (int li = tid; li < fsize; li += NT) lp += orphan_element<PROG>(pg, qv, fi, li, &s_bacc[0][tid], NT);
+      for (int li = tid; li < fsize; li += NT) lp += orphan_element<PROG, false, true>(pg, qv, fi, li, &s_bacc[0][tid], NT);
     }
+    SMALL_TICK(9);     // (thread 0's share of the orphan factors)
     for (int b = 0; b < md.n_bterms; ++b) {   // scalars that broadcast against vector factors
       const double t = block_sum<true>(s_bacc[b][tid], s_w);
       if (mine && v.size == 1 && pg.bterm_var[b] == k) gx += t;
       s_bacc[b][tid] = 0.0;
     }
+    SMALL_TICK(10);    // (the broadcast terms' sums: includes waiting for the slowest thread's element)
     grad_i = gx * dxdq + dj;
     logp = block_sum<true>(lp, s_w);
+    SMALL_TICK(11);
   };
 
   Ag.log_uniforms = nullptr;   // log(u) is taken by the control thread (header comment)
@@ -174,6 +198,7 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
       if (it == 0 && !a.q_src && mine) A.Q[tid] = Ag.Q[tid];                   // (the host put q0 into slot 0 of the global arena)
       __syncthreads();
     }
+    SMALL_TICK(0);    // setup (first draw) / the previous draw's hand-over
     // ---- start state (base_hmc.py:201-202): q0, its gradient and logp; p0 = z / sigma; E0 ----
     double logp0 = a.cached_logp;
     if (it > 0) {
@@ -211,6 +236,7 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
     }
     __syncthreads();
 
+    SMALL_TICK(1);    // start state
     // ---- the tree (nuts.py:204-225) ----
     for (int d = 0; d < a.max_depth && !s_ctl.aborted; ++d) {
       if (in_lds && (2 << d) > S_lds) {   // this doubling would hold more leaves than the LDS arena has slots: on in global memory
@@ -240,12 +266,15 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
           qn = qv.at(tid);
           A.Q[lf.d_o + tid] = qn;
         }
+        SMALL_TICK(2);    // leaf set-up, first half of the leapfrog
         eval_model(qv, qn, grad[0], logp);
+        SMALL_TICK(3);    // the model
         if (mine) A.G[lf.d_o + tid] = grad[0];
         // second half kick, v', kinetic energy and the U-turn dots of the merges this leaf completes
         int m; bool last;
         leaf_post<1>(A, lf, j, d, true, idx, act, grad, ph, s_red, NW, m, last);
         __syncthreads();
+        SMALL_TICK(4);    // second kick, merge dot products
         for (int q = tid; q < NDOT; q += NT) {
           if (!dot_needed(q, m, last)) continue;
           double r = 0.0;
@@ -260,6 +289,10 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
           tree_decide(&s_ctl, A, lf, s_dot, E, m, last, a.Emax, a.max_depth, uni_view_none());
         }
         __syncthreads();   // also makes this leaf's arena stores visible to the whole workgroup
+        SMALL_TICK(5);    // dots combined, the tree's decision
+#ifdef NUTS_KTIMING
+        if (tid == 0) tk_acc[7] += 1;
+#endif
         if (s_ctl.aborted) break;
       }
       if (s_ctl.depth >= a.max_depth) break;
@@ -287,9 +320,20 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
     }
     done = it + 1;
     __syncthreads();   // every thread has read the proposal before slot 0 is overwritten; s_stop is visible
-    if (in_lds && s_ctl.diverging) spill_tree(s_ctl.left, s_ctl.right);   // (the host reads the two points of the divergence)
+    // (the host reads the two points of the divergence; the leaf that diverged belongs to a subtree that was never merged, so it
+    // lies outside [left, right])
+    if (in_lds && s_ctl.diverging) spill_tree(min(s_ctl.left, s_ctl.div_t), max(s_ctl.right, s_ctl.div_t));
     if (s_stop) break;
   }
+  SMALL_TICK(6);      // proposal, statistics
+#ifdef NUTS_KTIMING
+  if (tid == 0) {
+    for (int i = 0; i < 8; ++i) md.ticks[40 + i] += tk_acc[i];
+    md.ticks[48] += tick_now() - tk_begin;
+    md.ticks[49] += 1;
+    for (int i = 8; i < 12; ++i) md.ticks[42 + i] += tk_acc[i];   // slots 50 .. 53: inside the model evaluation
+  }
+#endif
   if (mine) { a.q_out[tid] = q_prop; a.g_out[tid] = g_prop; }
   if (tid == 0) {
     if (a.n_done) *a.n_done = done;

@@ -551,14 +551,14 @@ def test_nuts_parity_three_kernel_pipeline_on_small_and_multi_workgroup_models(m
 
 def test_single_workgroup_kernel_gives_the_same_chain_with_its_tree_in_lds_in_global_memory_and_handed_over(monkeypatch):
     """Round 5: for n <= 64 the single-workgroup kernel keeps the tree's arena, the data pool and the uniforms in LDS
-    (csrc/small_kernel.h).  The arithmetic and its order do not depend on where the arena lives: the chain is BITWISE the one with
-    the tree in global memory (NUTS_SMALL_LDS=0), also when the LDS arena is capped at 4 or 16 slots so that every tree deeper than
+    (csrc/small_kernel.h) and runs as ONE wave.  The arithmetic and its order depend neither on where the arena lives nor on the idle
+    waves: the chain is BITWISE the one of the four-wave kernel with the tree in global memory (NUTS_SMALL_LDS=0, NUTS_SMALL_ONE_WAVE=0), also when the LDS arena is capped at 4 or 16 slots so that every tree deeper than
     1 / 3 doublings is copied out to the global arena mid-draw (NUTS_SMALL_LDS_SLOTS), during tuning (draw by draw) and after it
     (batches of draws inside one launch); and the integers are the oracle sampler's."""
     from pymc_amd.sampling import sample
 
     def run(spec, **env):
-        for k in ("NUTS_SMALL_LDS", "NUTS_SMALL_LDS_SLOTS"):
+        for k in ("NUTS_SMALL_LDS", "NUTS_SMALL_LDS_SLOTS", "NUTS_SMALL_ONE_WAVE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -568,9 +568,10 @@ def test_single_workgroup_kernel_gives_the_same_chain_with_its_tree_in_lds_in_gl
         return res["draws"][0], [tuple(int(s[k]) for k in INT_KEYS) for s in stats], np.array([s["energy"] for s in stats])
 
     for spec in (models.eight_schools(), models.eight_schools(24), models.eight_schools(60), models.std_normal(3)):
-        base = run(spec, NUTS_SMALL_LDS="0")
+        base = run(spec, NUTS_SMALL_LDS="0", NUTS_SMALL_ONE_WAVE="0")     # (the kernel as it was before round 5: four waves, global arena)
         assert max(t[0] for t in base[1]) >= 3              # (trees deep enough to cross the capped arenas)
-        for env in ({}, {"NUTS_SMALL_LDS_SLOTS": "4"}, {"NUTS_SMALL_LDS_SLOTS": "16"}):
+        for env in ({}, {"NUTS_SMALL_LDS_SLOTS": "4"}, {"NUTS_SMALL_LDS_SLOTS": "16"}, {"NUTS_SMALL_ONE_WAVE": "0"},
+                    {"NUTS_SMALL_ONE_WAVE": "0", "NUTS_SMALL_LDS_SLOTS": "8"}, {"NUTS_SMALL_LDS": "0"}):
             got = run(spec, **env)
             assert got[1] == base[1], (spec.n, env)
             assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2]), (spec.n, env)
