@@ -272,6 +272,8 @@ SYMBOLS = {
     "nuts_group_remove": (C.c_int, [_VP, _VP]),
     "nuts_group_destroy": (None, [_VP]),
     "nuts_group_launches": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    "nuts_group_launches_wide": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "nuts_unset_option": (C.c_int, [C.c_char_p]),
 }
 
 _lib = None
@@ -329,6 +331,10 @@ def load():
 def set_engine_option(name: str, value: int) -> None:
     """Select a non-default launch schedule for the models / chains created from now on (include/nuts_mi355.h, nuts_set_option)."""
     check(load().nuts_set_option(name.encode(), int(value)), "nuts_set_option")
+
+
+def unset_option(name: str) -> None:
+    check(load().nuts_unset_option(name.encode()), "nuts_unset_option")
 
 
 def sync_options_from_env() -> None:

@@ -18,7 +18,9 @@ from pymc_amd import _lib
 
 
 class ChainGroup:
-    MAX_CHAINS = 4
+    MAX_CHAINS = 4        # on the plain-fma kernels: a chain in the group is bitwise the chain alone
+    MAX_CHAINS_WIDE = 16  # models laid out 16 rows per workgroup (option NUTS_MVN_ALIGNED = 16): the merged launch runs on the matrix
+                          # cores (csrc/mvn_mfma_kernel.h); chains are then held to the oracle, not to bitwise equality with themselves alone
 
     def __init__(self, steps):
         lib = _lib.load()
@@ -38,7 +40,7 @@ class ChainGroup:
     def try_create(cls, steps) -> Optional["ChainGroup"]:
         """The group, or None when the engine declines (a model that is not one MvNormal node on the row-aligned pass, a dense or
         host mass matrix, more than four chains): the chains then run as independent engines, as before."""
-        if not 2 <= len(steps) <= cls.MAX_CHAINS:
+        if not 2 <= len(steps) <= cls.MAX_CHAINS_WIDE:
             return None
         try:
             return cls(steps)
@@ -47,14 +49,14 @@ class ChainGroup:
 
     def launches(self) -> List[int]:
         """``[_, n1, n2, n3, n4]``: leapfrog launches submitted so far that carried 1, 2, 3, 4 chains."""
-        out = (C.c_int64 * 5)()
-        _lib.check(_lib.load().nuts_group_launches(self._handle, out), "nuts_group_launches")
-        return [int(v) for v in out]
+        out, cap = (C.c_int64 * 17)(), C.c_int32(0)
+        _lib.check(_lib.load().nuts_group_launches_wide(self._handle, out, C.byref(cap)), "nuts_group_launches_wide")
+        return [int(v) for v in out[: int(cap.value) + 1]]      # ([_, n1..n4], or [_, n1..n16] for a wide group)
 
     def mean_chains_per_launch(self) -> float:
         n = self.launches()
         tot = sum(n[1:])
-        return sum(c * n[c] for c in range(1, 5)) / tot if tot else 0.0
+        return sum(c * n[c] for c in range(1, len(n))) / tot if tot else 0.0
 
     def close(self) -> None:
         if getattr(self, "_handle", None):

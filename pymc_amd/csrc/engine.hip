@@ -152,15 +152,23 @@ extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
 // arguments and returns once the launch that carries them has been submitted -- by whichever thread completes the set of chains
 // that are inside a tree.  A chain between two trees (finishing a draw, adapting, starting the next one) or past the end of its
 // run is not waited for: the others go on without it, and it joins the next launch it is ready for.
+#define GRP_MAXC MFM_MAXC        // members of a group: 4 on the plain-fma kernels, up to 16 on the matrix cores (mvn_mfma_kernel.h)
+#define GRP_RING 64              // launches' argument blocks in pinned memory (a launch has long read its block when the ring comes round)
 struct nuts_group {
   std::mutex mu;
   hipStream_t stream = nullptr;
-  nuts_model* member[MVM_MAXC] = {};
+  nuts_model* member[GRP_MAXC] = {};
   int n = 0;
   int nactive = 0, npend = 0;
   std::atomic<unsigned> gen{0};
-  MvaLeafArgs pend[MVM_MAXC];
-  int64_t launches[MVM_MAXC + 1] = {};   // submitted launches by the number of chains they carried
+  MvaLeafArgs pend[GRP_MAXC];
+  int64_t launches[GRP_MAXC + 1] = {};   // submitted launches by the number of chains they carried
+  // wide group (MvNormal models laid out 16 rows per workgroup): every merged launch goes through k_mvn_mfma_multi, whose chains'
+  // arguments are read from a ring of blocks in pinned, device-visible host memory
+  int cap = MVM_MAXC;
+  MvaLeafArgs* ring_host = nullptr;
+  MvaLeafArgs* ring_dev = nullptr;
+  unsigned ring_at = 0;
   // kind of the members' models: 1 = one MvNormal node on the row-aligned pass (mvn_multi_kernel.h), 2 = the hierarchical-logit rows
   // on the group-aligned pass (rows_ga_multi_kernel.h); fixed by the first member
   int kind = 0;
@@ -170,7 +178,7 @@ struct nuts_group {
 static_assert(GAM_MAXC == MVM_MAXC, "one group size");
 
 static nuts_model* group_base(nuts_group* g) {   // whose copy of (P, mu) every launch reads: one copy stays cache-resident
-  for (int i = 0; i < MVM_MAXC; ++i) if (g->member[i]) return g->member[i];
+  for (int i = 0; i < GRP_MAXC; ++i) if (g->member[i]) return g->member[i];
   return nullptr;
 }
 
@@ -180,10 +188,23 @@ static void group_flush_locked(nuts_group* g) {
   if (!nc) return;
   if (g->kind == 2) { group_flush_rows_locked(g); return; }
   const ModelDev& md = group_base(g)->md;
-  const dim3 grid(MVM_MAXC + md.mv.al_nwg);
-  int order[MVM_MAXC] = {0, 1, 2, 3};   // (by place in the group, not by arrival: the launch does not depend on who came first)
+  int order[GRP_MAXC];   // (by place in the group, not by arrival: the launch does not depend on who came first)
+  for (int a = 0; a < GRP_MAXC; ++a) order[a] = a;
   for (int a = 1; a < nc; ++a)
     for (int b = a; b > 0 && g->pend[order[b]].slot < g->pend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
+  if (g->cap > MVM_MAXC) {   // the wide group: matrix cores, whatever the number of chains in this launch
+    MvaLeafArgs* blk = g->ring_host + (size_t)(g->ring_at % GRP_RING) * GRP_MAXC;
+    for (int c = 0; c < nc; ++c) blk[c] = g->pend[order[c]];
+    std::atomic_thread_fence(std::memory_order_release);
+    hipLaunchKernelGGL(k_mvn_mfma_multi, dim3(MFM_MAXC + md.mv.al_nwg), dim3(MFM_WAVES * WAVE), 0, g->stream, md,
+                       (const MvaLeafArgs*)(g->ring_dev + (size_t)(g->ring_at % GRP_RING) * GRP_MAXC), nc);
+    g->ring_at++;
+    g->launches[nc]++;
+    g->npend = 0;
+    g->gen.fetch_add(1, std::memory_order_release);
+    return;
+  }
+  const dim3 grid(MVM_MAXC + md.mv.al_nwg);
 #define MVM_LAUNCH(RR, NC)                                                                                                   \
   {                                                                                                                          \
     MvaMultiArgs<NC> ma;                                                                                                     \
@@ -1425,10 +1446,13 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   else if (k == "rows_stored_columns") *out = m->md.lg.ga ? m->md.lg.ga_dx : m->md.lg.D;
   else if (k == "chain_group_kind") {   // what a chain group of this model's chains would merge: 0 nothing, 1 the MvNormal row-aligned pass, 2 the group-aligned row pass
     const RowsDev& lg = m->md.lg;
-    const bool is_mvn = m->md.has_mvn && (m->md.mv.aligned == 4 || m->md.mv.aligned == 8);
+    const bool is_mvn = m->md.has_mvn && (m->md.mv.aligned == 4 || m->md.mv.aligned == 8 || m->md.mv.aligned == 16);
     const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && !lg.ga_gpw && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && m->ga_variant == 42;
     *out = is_mvn ? 1.0 : (is_rows ? 2.0 : 0.0);
   }
+  // 1: chains of this model can form a WIDE group (up to 16 chains per launch through the matrix cores, mvn_mfma_kernel.h) once the
+  // model is laid out 16 rows per workgroup (NUTS_MVN_ALIGNED = 16)
+  else if (k == "chain_group_wide_ok") *out = (m->md.has_mvn && m->md.mv.aligned > 0 && m->md.mv.k % 16 == 0) ? 1.0 : 0.0;
   else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
@@ -1885,7 +1909,7 @@ static void group_remove_model(nuts_group* g, nuts_model* m) {
   if (!g || !m || m->group != g) return;
   hipStreamSynchronize(g->stream);
   std::lock_guard<std::mutex> lk(g->mu);
-  for (int i = 0; i < MVM_MAXC; ++i)
+  for (int i = 0; i < GRP_MAXC; ++i)
     if (g->member[i] == m) { g->member[i] = nullptr; g->n--; }
   if (m->g_active) { g->nactive--; m->g_active = false; }
   m->group = nullptr;
@@ -1905,7 +1929,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   if (m->group) { g_err = "nuts_group_add: the chain's model already belongs to a group"; return NUTS_E_ARG; }
   if (m->n_chains != 1) { g_err = "nuts_group_add: a member model carries exactly one chain (its launch parity and records are the chain's)"; return NUTS_E_ARG; }
   const RowsDev& lg = m->md.lg;
-  const bool is_mvn = m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8);
+  const bool is_mvn = m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8 || (mv.aligned == 16 && mv.k % 16 == 0));
   // the hierarchical-logit rows on the group-aligned pass, closed-form model (the benchmark's), D = 8: rows_ga_multi_kernel.h
   const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && !lg.ga_gpw && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && m->ga_variant == 42;
   if (!(is_mvn || is_rows) || c->dense || c->host_pot) {
@@ -1913,7 +1937,9 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
             "hierarchical-logit rows on the group-aligned pass (diagonal mass matrix); this chain is neither";
     return NUTS_E_ARG;
   }
-  if (g->n >= MVM_MAXC) { g_err = "nuts_group_add: a group holds at most 4 chains"; return NUTS_E_ARG; }
+  // a group of MvNormal models laid out 16 rows per workgroup is WIDE: up to 16 chains per launch through the matrix cores
+  const int cap = g->n == 0 ? ((is_mvn && mv.aligned == 16) ? GRP_MAXC : MVM_MAXC) : g->cap;
+  if (g->n >= cap) { g_err = cap > MVM_MAXC ? "nuts_group_add: a wide group holds at most 16 chains" : "nuts_group_add: a group holds at most 4 chains"; return NUTS_E_ARG; }
   if (g->n > 0 && g->kind != (is_rows ? 2 : 1)) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(m->stream));
   if (is_rows) {
@@ -1955,8 +1981,13 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
     HIPCHK(hipMemcpy(b.data() + kk, mv.mu, mv.k * sizeof(double), hipMemcpyDeviceToHost));
     if (std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) != 0) { g_err = "nuts_group_add: not the same model as the group's (precision or mean differ)"; return NUTS_E_ARG; }
   }
+  if (cap > MVM_MAXC && !g->ring_host) {
+    HIPCHK(hipHostMalloc((void**)&g->ring_host, (size_t)GRP_RING * GRP_MAXC * sizeof(MvaLeafArgs), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&g->ring_dev, g->ring_host, 0));
+  }
   std::lock_guard<std::mutex> lk(g->mu);
-  for (int i = 0; i < MVM_MAXC; ++i)
+  g->cap = cap;
+  for (int i = 0; i < cap; ++i)
     if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
   g->n++;
   g->kind = is_rows ? 2 : 1;
@@ -1973,9 +2004,10 @@ extern "C" int nuts_group_remove(nuts_group* g, nuts_chain* c) {
 
 extern "C" void nuts_group_destroy(nuts_group* g) {
   if (!g) return;
-  for (int i = 0; i < MVM_MAXC; ++i)
+  for (int i = 0; i < GRP_MAXC; ++i)
     if (g->member[i]) group_remove_model(g, g->member[i]);
   hipStreamDestroy(g->stream);
+  if (g->ring_host) hipHostFree(g->ring_host);
   delete g;
 }
 
@@ -1983,6 +2015,20 @@ extern "C" int nuts_group_launches(nuts_group* g, int64_t* by_chains) {
   if (!g || !by_chains) return NUTS_E_ARG;
   std::lock_guard<std::mutex> lk(g->mu);
   for (int i = 0; i <= MVM_MAXC; ++i) by_chains[i] = g->launches[i];
+  return NUTS_OK;
+}
+// ... of a wide group: by_chains [17]; returns the group's capacity (4 or 16) in *cap
+extern "C" int nuts_group_launches_wide(nuts_group* g, int64_t* by_chains, int32_t* cap) {
+  if (!g || !by_chains) return NUTS_E_ARG;
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (int i = 0; i <= GRP_MAXC; ++i) by_chains[i] = g->launches[i];
+  if (cap) *cap = g->cap;
+  return NUTS_OK;
+}
+extern "C" int nuts_unset_option(const char* name) {
+  if (!name) return NUTS_E_ARG;
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  for (size_t i = 0; i < g_opts.size(); ++i) if (g_opts[i].first == name) { g_opts.erase(g_opts.begin() + i); break; }
   return NUTS_OK;
 }
 

@@ -1681,4 +1681,5 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, con
 #include "dense_adapt.h"
 #include "glm_kernel.h"
 #include "mvn_multi_kernel.h"
+#include "mvn_mfma_kernel.h"
 #include "rows_ga_multi_kernel.h"

@@ -82,10 +82,11 @@ __device__ __forceinline__ double wave_sum_many(const double (&in)[NV], int lane
 }
 
 // the tail wave of chain `L` in workgroup b (lane = element row0 + lane): k_mvn_aligned's, on this chain's sums
+// (`t`: this lane's row of P (q - mu), summed over the workgroup -- by whatever streamed the rows)
 template <int R>
-__device__ __forceinline__ void mvm_tail(const MvnDev& mv, const MvaLeafArgs& L, int b, const double (*s_w)[MVN_BLOCK / WAVE], double* s_red,
-                                         const Leaf& lf, const QView& qv, double phv, double var_r, double qr, double mur,
-                                         const MergePrefetch& mpf) {
+__device__ __forceinline__ void mvm_tail_core(const MvnDev& mv, const MvaLeafArgs& L, int b, double t, double* s_red,
+                                              const Leaf& lf, const QView& qv, double phv, double var_r, double qr, double mur,
+                                              const MergePrefetch& mpf) {
   const ArenaDev& A = L.A;
   const EvalIO& io = L.io;
   const int lane = threadIdx.x & (WAVE - 1);
@@ -93,9 +94,6 @@ __device__ __forceinline__ void mvm_tail(const MvnDev& mv, const MvaLeafArgs& L,
   const bool leaf = io.mode != MODE_PLAIN, tree = io.mode == MODE_TREE;
   const int my = min(row0 + min(lane, R - 1), K - 1);
   const bool a0 = lane < R && row0 + lane < K;
-  double t = 0.0;
-#pragma unroll
-  for (int ww = 0; ww < MVN_BLOCK / WAVE; ++ww) t += s_w[min(lane, R - 1)][ww];
   int idx[1] = {my};
   bool act[1] = {a0};
   double grad[1] = {-t}, ph[1] = {phv};
@@ -129,6 +127,17 @@ __device__ __forceinline__ void mvm_tail(const MvnDev& mv, const MvaLeafArgs& L,
     const int k = qq < 2 + 6 * m ? max(qq - 1, 0) : DOT_TOP + (qq - 2 - 6 * m);
     rec[qq] = qq == 0 ? lp : s_red[k];
   }
+}
+
+template <int R>
+__device__ __forceinline__ void mvm_tail(const MvnDev& mv, const MvaLeafArgs& L, int b, const double (*s_w)[MVN_BLOCK / WAVE], double* s_red,
+                                         const Leaf& lf, const QView& qv, double phv, double var_r, double qr, double mur,
+                                         const MergePrefetch& mpf) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  double t = 0.0;
+#pragma unroll
+  for (int ww = 0; ww < MVN_BLOCK / WAVE; ++ww) t += s_w[min(lane, R - 1)][ww];
+  mvm_tail_core<R>(mv, L, b, t, s_red, lf, qv, phv, var_r, qr, mur, mpf);
 }
 
 // Grid: MVM_MAXC control workgroups (a chain's in workgroup `slot`; the others leave at once) + al_nwg row workgroups, so that the rows of

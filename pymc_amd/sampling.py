@@ -700,11 +700,30 @@ def sample(
         from concurrent.futures import ThreadPoolExecutor
 
         # one step object (own model + chain handles, own stream) per concurrent chain; all start from `initial_state`
-        steps = [step] + [
-            init_nuts(spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device,
-                      tune=tune, **step_kwargs)[1]
-            for _ in range(n_par - 1)
-        ]
+        def more_steps(k):
+            return [init_nuts(spec, init=init, chains=chains, random_seed_list=random_seed_list, initvals=initvals, device=device,
+                              tune=tune, **step_kwargs)[1] for _ in range(k)]
+
+        wide = False
+        if n_par > 4 and lockstep is not False:
+            try:
+                wide = int(step._logp_dlogp_func.model_scalar("chain_group_wide_ok")) == 1 and not getattr(step.potential, "_dense", False)
+            except (AttributeError, EngineError, ValueError):
+                wide = False
+        if wide:
+            # more than four concurrent chains of an MvNormal model: the WIDE chain group (matrix cores, csrc/mvn_mfma_kernel.h) needs
+            # every member's model laid out 16 rows per workgroup -- the step the caller's arguments built is replaced by one that is
+            from pymc_amd import _lib as _engine_lib
+
+            _engine_lib.set_option("NUTS_MVN_ALIGNED", 16)
+            try:
+                steps = more_steps(n_par)
+            finally:
+                _engine_lib.unset_option("NUTS_MVN_ALIGNED")
+            step.close()
+            step = steps[0]
+        else:
+            steps = [step] + more_steps(n_par - 1)
 
         # chains of a model the engine can advance in lockstep (one MvNormal node, pymc_amd/chain_group.py) share their leapfrog
         # launches: the precision matrix is read once for all chains that stand at a leaf together.  Same draws, bit for bit.

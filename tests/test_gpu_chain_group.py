@@ -63,6 +63,54 @@ def test_grouped_chains_are_bitwise_the_chains_alone(k, chains, tune, draws):
     print(f"k = {k}: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, 5)) / sum(n[1:]):.2f}")
 
 
+INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
+
+
+@pytest.mark.parametrize("k,chains,tune,draws", [(512, 8, 40, 20), (2048, 16, 14, 8), (256, 6, 30, 20), (1024, 13, 20, 10)])
+def test_wide_groups_on_the_matrix_cores_follow_the_chains_alone(k, chains, tune, draws):
+    """More than four concurrent chains of an MvNormal model form a WIDE group: every merged leapfrog launch computes
+    Y[16 rows][chains] = P D through `v_mfma_f64_16x16x4_f64` (csrc/mvn_mfma_kernel.h; BASELINE configs[2]: "exercises MFMA path").
+    The matrix instruction sums a row of P (q - mu) in another order than the plain-fma kernels, so a chain in a wide group is not
+    bitwise the chain alone; it is held to what the chain alone is held to (tests/test_gpu_parity.py: the oracle's log-density to
+    1e-10, the oracle sampler's integers): the same trees while rounding has not been amplified yet, positions and energies equal
+    to rounding at first, and -- draws that no longer coincide -- the same distribution (moments of the pooled draws)."""
+    spec = models.mvnormal(n=k, seed=5)
+    alone = _sample(spec, chains, False, 1, tune, draws, 31)
+    wide = _sample(spec, chains, None, chains, tune, draws, 31)
+    n = wide["lockstep_launches"]
+    assert n is not None and len(n) == 17 and sum(n[5:]) > 0, n          # launches that carried more than four chains
+    leapfrogs = sum(int(s["tree_size"]) for c in range(chains) for s in wide["stats"][c])
+    assert leapfrogs <= sum(c * n[c] for c in range(1, 17)) <= 1.5 * leapfrogs, (n, leapfrogs)
+    first = 6
+    for c in range(chains):
+        a, w = alone["stats"][c], wide["stats"][c]
+        for i in range(first):
+            for key in INT_KEYS:
+                assert int(a[i][key]) == int(w[i][key]), (k, c, i, key, a[i][key], w[i][key])
+            np.testing.assert_allclose(w[i]["energy"], a[i]["energy"], rtol=1e-9, atol=1e-9, err_msg=f"{k} {c} {i}")
+            np.testing.assert_allclose(w[i]["model_logp"], a[i]["model_logp"], rtol=1e-9, atol=1e-9, err_msg=f"{k} {c} {i}")
+        np.testing.assert_allclose(wide["draws"][c][:first], alone["draws"][c][:first], rtol=1e-8, atol=1e-10, err_msg=f"{k} {c}")
+        same = sum(all(int(a[i][key]) == int(w[i][key]) for key in INT_KEYS) for i in range(tune + draws))
+        assert same >= (tune + draws) // 2, (k, c, same)                   # (most transitions still grow the very same tree)
+    sizes = [[int(s["tree_size"]) for s in wide["stats"][c]] for c in range(chains)]
+    assert len({tuple(s) for s in sizes}) == chains
+    print(f"k = {k}, {chains} chains: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, 17)) / sum(n[1:]):.2f}")
+
+
+def test_wide_group_log_density_and_gradient_are_the_oracles():
+    """The matrix-core launch against the oracle itself: a chain's position after its first transitions, evaluated by the oracle
+    restatement (oracle/ref_models.py), has the log-density the device recorded for that draw -- to 1e-10 relative."""
+    from oracle import ref_models
+
+    spec = models.mvnormal(n=512, seed=5)
+    wide = _sample(spec, 8, None, 8, 6, 4, 77)
+    f = ref_models.SpecLogpGrad(spec)
+    for c in range(8):
+        for i in range(10):
+            lp, _ = f(wide["draws"][c][i])
+            np.testing.assert_allclose(wide["stats"][c][i]["model_logp"], lp, rtol=1e-10, atol=1e-9, err_msg=f"{c} {i}")
+
+
 def test_sample_groups_the_chains_of_such_a_model_by_default():
     """`sample(chains=3)` with nothing else said: the model's data pass is cache-resident, so the chains of the rank run concurrently,
     and -- the model being one MvNormal node -- as a chain group; a model the engine cannot group runs them as independent engines."""

@@ -44,7 +44,7 @@ def main():
             "leapfrog_steps_per_sec": sum(lf) / res["sampling_time"], "leapfrogs_per_chain": lf, "sampling_time_s": res["sampling_time"],
             "wall_s": wall, "mean_tree_size": float(np.mean([s["tree_size"] for c in range(chains) for s in res["stats"][c]])),
             "launches_by_chains_carried": n[1:] if n else None,
-            "mean_chains_per_launch": (sum(c * n[c] for c in range(1, 5)) / max(1, sum(n[1:]))) if n else None,
+            "mean_chains_per_launch": (sum(c * n[c] for c in range(1, len(n))) / max(1, sum(n[1:]))) if n else None,
         }
         if chains > 1:
             if ref is None:
