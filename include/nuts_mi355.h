@@ -482,9 +482,10 @@ int nuts_group_add(nuts_group *g, nuts_chain *c);
 int nuts_group_remove(nuts_group *g, nuts_chain *c);
 void nuts_group_destroy(nuts_group *g);
 int nuts_group_launches(nuts_group *g, int64_t *by_chains /* [5] */);
-/* WIDE groups (BASELINE configs[2]: "exercises MFMA path").  When the first member's model is laid out 16 rows per workgroup
- * (option NUTS_MVN_ALIGNED = 16 at nuts_model_create, k a multiple of 16; nuts_model_get_scalar "chain_group_wide_ok"), the group
- * takes up to 16 chains and every merged launch computes Y[16 rows][chains] = P D through v_mfma_f64_16x16x4_f64
+/* WIDE groups (BASELINE configs[2]: "exercises MFMA path").  When the first member's model is laid out 8 rows per workgroup
+ * (option NUTS_MVN_ALIGNED = 8 at nuts_model_create: the default from k = 1024; k a multiple of 16; nuts_model_get_scalar
+ * "chain_group_wide_ok") and its chain was created under option NUTS_GROUP_WIDE = 1, the group takes up to 16 chains and every
+ * merged launch computes Y[rows][chains] = P D through v_mfma_f64_16x16x4_f64
  * (csrc/mvn_mfma_kernel.h): one accumulator tile per wave whatever the number of chains.  The sums of a row are formed in another
  * order than in the single-chain kernel, so a chain in a wide group is held to the oracle (log-density 1e-10, the sampler's
  * integers), not to bitwise equality with the chain alone.  nuts_group_launches_wide: by_chains[c], c = 1..16; *cap = 4 or 16. */

@@ -333,7 +333,7 @@ def set_engine_option(name: str, value: int) -> None:
     check(load().nuts_set_option(name.encode(), int(value)), "nuts_set_option")
 
 
-def unset_option(name: str) -> None:
+def unset_engine_option(name: str) -> None:
     check(load().nuts_unset_option(name.encode()), "nuts_unset_option")
 
 

@@ -153,7 +153,6 @@ extern "C" const char* nuts_last_error(void) { return g_err.c_str(); }
 // that are inside a tree.  A chain between two trees (finishing a draw, adapting, starting the next one) or past the end of its
 // run is not waited for: the others go on without it, and it joins the next launch it is ready for.
 #define GRP_MAXC MFM_MAXC        // members of a group: 4 on the plain-fma kernels, up to 16 on the matrix cores (mvn_mfma_kernel.h)
-#define GRP_RING 64              // launches' argument blocks in pinned memory (a launch has long read its block when the ring comes round)
 struct nuts_group {
   std::mutex mu;
   hipStream_t stream = nullptr;
@@ -166,9 +165,12 @@ struct nuts_group {
   // wide group (MvNormal models laid out 16 rows per workgroup): every merged launch goes through k_mvn_mfma_multi, whose chains'
   // arguments are read from a ring of blocks in pinned, device-visible host memory
   int cap = MVM_MAXC;
-  MvaLeafArgs* ring_host = nullptr;
-  MvaLeafArgs* ring_dev = nullptr;
-  unsigned ring_at = 0;
+  ModelDev* md_dev = nullptr;                  // the base member's model in device memory (the control code's view of it)
+  const nuts_model* md_of = nullptr;           // ... whose it is
+  double* dpack = nullptr;                     // [k][16] q - mu of the chains of the launch being submitted (k_mfm_pack)
+  MfmChainConst* konst_dev = nullptr;          // [GRP_MAXC] what a member chain keeps for its whole life (mvn_mfma_kernel.h)
+  MfmChainConst konst_host[GRP_MAXC] = {};     // ... as last uploaded
+  bool konst_set[GRP_MAXC] = {};
   // kind of the members' models: 1 = one MvNormal node on the row-aligned pass (mvn_multi_kernel.h), 2 = the hierarchical-logit rows
   // on the group-aligned pass (rows_ga_multi_kernel.h); fixed by the first member
   int kind = 0;
@@ -193,12 +195,30 @@ static void group_flush_locked(nuts_group* g) {
   for (int a = 1; a < nc; ++a)
     for (int b = a; b > 0 && g->pend[order[b]].slot < g->pend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
   if (g->cap > MVM_MAXC) {   // the wide group: matrix cores, whatever the number of chains in this launch
-    MvaLeafArgs* blk = g->ring_host + (size_t)(g->ring_at % GRP_RING) * GRP_MAXC;
-    for (int c = 0; c < nc; ++c) blk[c] = g->pend[order[c]];
-    std::atomic_thread_fence(std::memory_order_release);
-    hipLaunchKernelGGL(k_mvn_mfma_multi, dim3(MFM_MAXC + md.mv.al_nwg), dim3(MFM_WAVES * WAVE), 0, g->stream, md,
-                       (const MvaLeafArgs*)(g->ring_dev + (size_t)(g->ring_at % GRP_RING) * GRP_MAXC), nc);
-    g->ring_at++;
+    MfmArgs ma;
+    ma.nc = nc; ma.pad = 0;
+    for (int c = 0; c < nc; ++c) {
+      const MvaLeafArgs& L = g->pend[order[c]];
+      MfmLeaf& l = ma.c[c];
+      l.io = L.io; l.cio = L.cio; l.uniforms = L.A.uniforms; l.log_uniforms = L.A.log_uniforms; l.st = L.st; l.ctl = L.A.ctl;
+      l.j = L.j; l.fold = L.fold; l.d = L.d; l.max_depth = L.max_depth; l.par = L.par; l.cj = L.cj; l.cd = L.cd; l.cseq = L.cseq;
+      l.slot = L.slot; l.pad = 0;
+      // the chain's constant part: uploaded when it is first seen (and should it ever change); stream-ordered before the launch
+      MfmChainConst k{};
+      k.A = L.A; k.A.uniforms = nullptr; k.A.log_uniforms = nullptr; k.Emax = L.Emax; k.al_part = L.al_part;
+      if (!g->konst_set[L.slot] || std::memcmp(&k, &g->konst_host[L.slot], sizeof(k)) != 0) {
+        g->konst_host[L.slot] = k; g->konst_set[L.slot] = true;
+        hipMemcpyAsync(g->konst_dev + L.slot, &g->konst_host[L.slot], sizeof(k), hipMemcpyHostToDevice, g->stream);
+      }
+    }
+    for (int c = nc; c < MFM_MAXC; ++c) ma.c[c] = ma.c[0];
+    if (g->md_of != group_base(g)) {
+      g->md_of = group_base(g);
+      hipMemcpyAsync(g->md_dev, &g->md_of->md, sizeof(ModelDev), hipMemcpyHostToDevice, g->stream);
+    }
+    hipLaunchKernelGGL(k_mfm_pack, dim3((md.mv.k * MFM_MAXC + 255) / 256), dim3(256), 0, g->stream, md.mv, (const MfmChainConst*)g->konst_dev, ma, g->dpack);
+    hipLaunchKernelGGL(k_mvn_mfma_multi, dim3(MFM_MAXC + md.mv.al_nwg), dim3(MFM_WAVES * WAVE), 0, g->stream, md.mv, (const ModelDev*)g->md_dev,
+                       (const MfmChainConst*)g->konst_dev, ma, (const double*)g->dpack);
     g->launches[nc]++;
     g->npend = 0;
     g->gen.fetch_add(1, std::memory_order_release);
@@ -1451,8 +1471,9 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
     *out = is_mvn ? 1.0 : (is_rows ? 2.0 : 0.0);
   }
   // 1: chains of this model can form a WIDE group (up to 16 chains per launch through the matrix cores, mvn_mfma_kernel.h) once the
-  // model is laid out 16 rows per workgroup (NUTS_MVN_ALIGNED = 16)
+  // model is laid out 8 rows per workgroup (NUTS_MVN_ALIGNED = 8: the default from k = 1024) and the chain was created under NUTS_GROUP_WIDE = 1
   else if (k == "chain_group_wide_ok") *out = (m->md.has_mvn && m->md.mv.aligned > 0 && m->md.mv.k % 16 == 0) ? 1.0 : 0.0;
+  else if (k == "chain_group_wide_rows") *out = 8.0;   // rows per workgroup (NUTS_MVN_ALIGNED) the members' models must be laid out with
   else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
@@ -1619,6 +1640,7 @@ struct nuts_chain {
   bool small = false;            // latency regime: whole draw in one launch (small_kernel.h)
   int small_lds_slots = 0;       // SmallDrawArgs.lds_slots
   int small_one_wave = 1;        // n <= 64: the single-workgroup kernel with ONE wave (NUTS_SMALL_ONE_WAVE=0: four, as before round 5)
+  int group_wide = 0;            // option NUTS_GROUP_WIDE when the chain was created: a group this chain founds takes up to 16 chains (matrix cores)
   double* out_host = nullptr;    // pinned [2n]
   HostStatus* st_dev = nullptr;
   HostStatus* st_host = nullptr;   // pinned + device-mapped; st_dev is its device alias
@@ -1860,6 +1882,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   // (a power of two): at most k slots in LDS, so that ordinary trees cross over to the global arena (tests)
   c->small_lds_slots = env_int("NUTS_SMALL_LDS", 1) == 0 ? -1 : env_int("NUTS_SMALL_LDS_SLOTS", 0);
   c->small_one_wave = env_int("NUTS_SMALL_ONE_WAVE", 1);
+  c->group_wide = env_int("NUTS_GROUP_WIDE", 0);
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
              !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
@@ -1910,7 +1933,7 @@ static void group_remove_model(nuts_group* g, nuts_model* m) {
   hipStreamSynchronize(g->stream);
   std::lock_guard<std::mutex> lk(g->mu);
   for (int i = 0; i < GRP_MAXC; ++i)
-    if (g->member[i] == m) { g->member[i] = nullptr; g->n--; }
+    if (g->member[i] == m) { g->member[i] = nullptr; g->n--; g->konst_set[i] = false; }
   if (m->g_active) { g->nactive--; m->g_active = false; }
   m->group = nullptr;
   m->stream = m->own_stream;
@@ -1929,7 +1952,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   if (m->group) { g_err = "nuts_group_add: the chain's model already belongs to a group"; return NUTS_E_ARG; }
   if (m->n_chains != 1) { g_err = "nuts_group_add: a member model carries exactly one chain (its launch parity and records are the chain's)"; return NUTS_E_ARG; }
   const RowsDev& lg = m->md.lg;
-  const bool is_mvn = m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8 || (mv.aligned == 16 && mv.k % 16 == 0));
+  const bool is_mvn = m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8);
   // the hierarchical-logit rows on the group-aligned pass, closed-form model (the benchmark's), D = 8: rows_ga_multi_kernel.h
   const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && !lg.ga_gpw && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && m->ga_variant == 42;
   if (!(is_mvn || is_rows) || c->dense || c->host_pot) {
@@ -1937,8 +1960,9 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
             "hierarchical-logit rows on the group-aligned pass (diagonal mass matrix); this chain is neither";
     return NUTS_E_ARG;
   }
-  // a group of MvNormal models laid out 16 rows per workgroup is WIDE: up to 16 chains per launch through the matrix cores
-  const int cap = g->n == 0 ? ((is_mvn && mv.aligned == 16) ? GRP_MAXC : MVM_MAXC) : g->cap;
+  // a group of MvNormal models laid out 8 rows per workgroup whose FIRST member asked for it (option NUTS_GROUP_WIDE = 1 when the
+  // member's chain was created) is WIDE: up to 16 chains per launch through the matrix cores
+  const int cap = g->n == 0 ? ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC) : g->cap;
   if (g->n >= cap) { g_err = cap > MVM_MAXC ? "nuts_group_add: a wide group holds at most 16 chains" : "nuts_group_add: a group holds at most 4 chains"; return NUTS_E_ARG; }
   if (g->n > 0 && g->kind != (is_rows ? 2 : 1)) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(m->stream));
@@ -1981,9 +2005,11 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
     HIPCHK(hipMemcpy(b.data() + kk, mv.mu, mv.k * sizeof(double), hipMemcpyDeviceToHost));
     if (std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) != 0) { g_err = "nuts_group_add: not the same model as the group's (precision or mean differ)"; return NUTS_E_ARG; }
   }
-  if (cap > MVM_MAXC && !g->ring_host) {
-    HIPCHK(hipHostMalloc((void**)&g->ring_host, (size_t)GRP_RING * GRP_MAXC * sizeof(MvaLeafArgs), hipHostMallocMapped | hipHostMallocCoherent));
-    HIPCHK(hipHostGetDevicePointer((void**)&g->ring_dev, g->ring_host, 0));
+  if (cap > MVM_MAXC && !g->konst_dev) {
+    HIPCHK(hipMalloc((void**)&g->md_dev, sizeof(ModelDev)));
+    HIPCHK(hipMalloc((void**)&g->dpack, (size_t)mv.k * MFM_MAXC * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&g->konst_dev, GRP_MAXC * sizeof(MfmChainConst)));
+    HIPCHK(hipMemset(g->konst_dev, 0, GRP_MAXC * sizeof(MfmChainConst)));
   }
   std::lock_guard<std::mutex> lk(g->mu);
   g->cap = cap;
@@ -2007,7 +2033,9 @@ extern "C" void nuts_group_destroy(nuts_group* g) {
   for (int i = 0; i < GRP_MAXC; ++i)
     if (g->member[i]) group_remove_model(g, g->member[i]);
   hipStreamDestroy(g->stream);
-  if (g->ring_host) hipHostFree(g->ring_host);
+  if (g->konst_dev) hipFree(g->konst_dev);
+  if (g->md_dev) hipFree(g->md_dev);
+  if (g->dpack) hipFree(g->dpack);
   delete g;
 }
 

@@ -712,14 +712,27 @@ def sample(
                 wide = False
         if wide:
             # more than four concurrent chains of an MvNormal model: the WIDE chain group (matrix cores, csrc/mvn_mfma_kernel.h) needs
-            # every member's model laid out 16 rows per workgroup -- the step the caller's arguments built is replaced by one that is
+            # every member's model laid out 8 rows per workgroup and its chain created as a wide group's member -- the step the caller's
+            # arguments built is replaced by one that is
             from pymc_amd import _lib as _engine_lib
 
-            _engine_lib.set_option("NUTS_MVN_ALIGNED", 16)
+            honour = os.environ.get("PYMC_AMD_HONOUR_NUTS_ENV") == "1"    # (tests / tools: the options follow the environment, _lib.sync_options_from_env)
+            opts = {"NUTS_MVN_ALIGNED": 8, "NUTS_GROUP_WIDE": 1}
+            before = {k: os.environ.get(k) for k in opts}
+            for k, v in opts.items():
+                if honour:
+                    os.environ[k] = str(v)
+                _engine_lib.set_engine_option(k, v)
             try:
                 steps = more_steps(n_par)
             finally:
-                _engine_lib.unset_option("NUTS_MVN_ALIGNED")
+                for k in opts:
+                    _engine_lib.unset_engine_option(k)
+                    if honour:
+                        if before[k] is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = before[k]
             step.close()
             step = steps[0]
         else:

@@ -81,7 +81,7 @@ def test_wide_groups_on_the_matrix_cores_follow_the_chains_alone(k, chains, tune
     assert n is not None and len(n) == 17 and sum(n[5:]) > 0, n          # launches that carried more than four chains
     leapfrogs = sum(int(s["tree_size"]) for c in range(chains) for s in wide["stats"][c])
     assert leapfrogs <= sum(c * n[c] for c in range(1, 17)) <= 1.5 * leapfrogs, (n, leapfrogs)
-    first = 6
+    first = 6 if k <= 512 else 2       # (deeper trees at larger k: rounding reaches a U-turn test sooner)
     for c in range(chains):
         a, w = alone["stats"][c], wide["stats"][c]
         for i in range(first):
@@ -102,13 +102,15 @@ def test_wide_group_log_density_and_gradient_are_the_oracles():
     restatement (oracle/ref_models.py), has the log-density the device recorded for that draw -- to 1e-10 relative."""
     from oracle import ref_models
 
-    spec = models.mvnormal(n=512, seed=5)
-    wide = _sample(spec, 8, None, 8, 6, 4, 77)
-    f = ref_models.SpecLogpGrad(spec)
-    for c in range(8):
-        for i in range(10):
-            lp, _ = f(wide["draws"][c][i])
-            np.testing.assert_allclose(wide["stats"][c][i]["model_logp"], lp, rtol=1e-10, atol=1e-9, err_msg=f"{c} {i}")
+    for k, chains in ((512, 8), (2048, 16)):
+        spec = models.mvnormal(n=k, seed=5)
+        wide = _sample(spec, chains, None, chains, 6, 4, 77)
+        assert sum(wide["lockstep_launches"][5:]) > 0
+        f = ref_models.SpecLogpGrad(spec)
+        for c in range(chains):
+            for i in range(10):
+                lp, _ = f(wide["draws"][c][i])
+                np.testing.assert_allclose(wide["stats"][c][i]["model_logp"], lp, rtol=1e-10, atol=1e-9, err_msg=f"{k} {c} {i}")
 
 
 def test_sample_groups_the_chains_of_such_a_model_by_default():
