@@ -611,6 +611,17 @@ def chains_on_one_gpu(args, spec, device, tune=500, draws=1000):
             ref = res["draws"]
         else:
             out["draws_bitwise_equal"] = bool(np.array_equal(ref, res["draws"]))
+    # sixteen chains as a WIDE group: every merged launch through the matrix cores (csrc/mvn_mfma_kernel.h, v_mfma_f64_16x16x4_f64)
+    wide = 16
+    res = sample(draws=draws, tune=tune, chains=wide, model=spec, init="jitter+adapt_diag", random_seed=args.seed, device=device, cores=wide, lockstep=True)
+    res["step"].close()
+    lf = sum(int(s_["tree_size"]) for c in range(wide) for s_ in res["stats"][c])
+    n = res["lockstep_launches"]
+    ess = ess_bulk_many(res["draws"])
+    out["wide_chain_group_mfma"] = {"chains": wide, "leapfrog_steps_per_sec": lf / res["sampling_time"], "sampling_time_s": res["sampling_time"],
+                                    "min_ess": float(ess.min()), "ess_per_sec": float(ess.min()) / res["sampling_time"],
+                                    "rhat_max": float(rhat_many(res["draws"]).max()), "launches_by_chains_carried": n[1:] if n else None,
+                                    "mean_chains_per_launch": (sum(c * n[c] for c in range(1, len(n))) / max(1, sum(n[1:]))) if n else None}
     return out
 
 
