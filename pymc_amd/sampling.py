@@ -711,6 +711,7 @@ def sample(
             except (AttributeError, EngineError, ValueError):
                 wide = False
         if wide:
+            n_par = min(n_par, 16)      # (a wide chain group carries at most sixteen chains; further chains follow in the same workers)
             # more than four concurrent chains of an MvNormal model: the WIDE chain group (matrix cores, csrc/mvn_mfma_kernel.h) needs
             # every member's model laid out 8 rows per workgroup and its chain created as a wide group's member -- the step the caller's
             # arguments built is replaced by one that is
