@@ -538,6 +538,38 @@ def density_zoo():
     return m
 
 
+_YPOS = np.abs(_rg.normal(size=14)) * 1.5 + 0.3
+_YUNIT = _rg.uniform(0.08, 0.92, size=11)
+
+
+def density_zoo_2():
+    """Eight more densities without a code of their own, with RANDOM parameters (continuous.py `Wald`, `Kumaraswamy`,
+    `AsymmetricLaplace`, `Pareto`, `HalfStudentT`, `ExGaussian`, `Triangular`, `Moyal`): powers with variable exponents (`kappa **
+    sign(value)`, `value ** a`), `logpow` switches, the `normal_lcdf` branches inside a switch on the parameters (ExGaussian),
+    support switches against a random bound (Pareto's `value >= m`), gammaln of a random nu."""
+    m = sg.StubModel()
+    mu = m.HalfNormal("mu", 2.0)
+    lam = m.HalfNormal("lam", 3.0)
+    m.Wald("wa", mu, lam, observed=_YPOS)
+    a = m.HalfNormal("a", 2.0)
+    b = m.HalfNormal("b", 2.0)
+    m.Kumaraswamy("ku", a, b, observed=_YUNIT)
+    kap = m.HalfNormal("kap", 1.5)
+    loc = m.Normal("loc", 0.0, 2.0)
+    sc = m.HalfNormal("sc", 1.5)
+    m.AsymmetricLaplace("al", kap, loc, sc, observed=YGEN[:12])
+    al = m.HalfNormal("al_p", 3.0)
+    m.Pareto("pa", al, 0.25, observed=_YPOS)
+    nu = m.Gamma("nu", 2.0, 0.3)
+    m.HalfStudentT("ht", nu, sc, observed=_YPOS)
+    en = m.HalfNormal("en", 2.0)
+    m.ExGaussian("eg", loc, sc, en, observed=YGEN[12:])
+    cc = m.Beta("cc", 2.0, 2.0)
+    m.Triangular("tr", 0.0, 1.0, cc, observed=_YUNIT)
+    m.Moyal("mo", loc, sc, observed=YGEN[5:17])
+    return m
+
+
 XH = _rg.normal(size=(60, 7))
 YH = XH @ (0.3 + 0.8 * _rg.normal(size=7)) + 0.4 * _rg.normal(size=60)
 YHB = (_rg.uniform(size=60) < 1.0 / (1.0 + np.exp(-(XH @ (0.5 * _rg.normal(size=7)))))).astype("float64")
@@ -665,6 +697,7 @@ GENERAL = {
     "random_shape_parameters": random_shape_parameters,
     "negative_binomial_regression": negative_binomial_regression,
     "density_zoo": density_zoo,
+    "density_zoo_2": density_zoo_2,
     "hierarchical_regression_noncentred": hierarchical_regression_noncentred,
     "hierarchical_logistic_vector_hyper": hierarchical_logistic_vector_hyper,
     "glm_with_mvnormal_prior": glm_with_mvnormal_prior,

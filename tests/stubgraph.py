@@ -579,7 +579,8 @@ def _get_underlying_scalar_constant_value(v, *a, **k):
 
 _NS = None
 _CONT = ("Normal", "HalfNormal", "Cauchy", "HalfCauchy", "Exponential", "Laplace", "LogNormal", "StudentT", "Beta", "Gamma", "InverseGamma",
-         "Uniform", "TruncatedNormal", "Weibull", "Logistic", "Gumbel", "SkewNormal")
+         "Uniform", "TruncatedNormal", "Weibull", "Logistic", "Gumbel", "SkewNormal", "Wald", "Kumaraswamy", "AsymmetricLaplace", "Pareto",
+         "HalfStudentT", "ExGaussian", "Triangular", "Moyal")
 _DISC = ("Bernoulli", "Binomial", "Poisson", "NegativeBinomial", "BetaBinomial", "Geometric")
 
 
@@ -595,7 +596,9 @@ def reference():
     ns = {"np": np, "pt": pt, "gammaln": pt.gammaln, "Variable": Variable, "TensorVariable": Variable, "TensorConstant": TensorConstant,
           "CheckParameterValue": CheckParameterValue, "NotScalarConstantError": _NotScalarConstantError,
           "get_underlying_scalar_constant_value": _get_underlying_scalar_constant_value}
-    for fn in ("check_parameters", "logpow", "factln", "binomln", "betaln", "normal_lcdf", "normal_lccdf", "log_diff_normal_cdf"):
+    ns["f"] = lambda x: np.float64(x)          # dist_math.py:42-43: `f = floatX`, `c = -0.5 * np.log(2.0 * np.pi)` (module constants of log_normal)
+    ns["c"] = -0.5 * np.log(2.0 * np.pi)
+    for fn in ("check_parameters", "logpow", "factln", "binomln", "betaln", "normal_lcdf", "normal_lccdf", "log_diff_normal_cdf", "log_normal"):
         ref_function("distributions/dist_math.py", fn, ns)
     for fn in ("get_tau_sigma", "_truncation_is_bounded"):
         ref_function("distributions/continuous.py", fn, ns)
@@ -603,7 +606,7 @@ def reference():
         _, tree = _parsed(rel)
         for name in names:
             have = {c.name for c in _find(tree, name).body if isinstance(c, ast.FunctionDef)}
-            ref_class(rel, name, [m for m in ("dist", "get_alpha_beta", "_get_alpha_beta", "get_n_p", "logp") if m in have], _DistBase, ns)
+            ref_class(rel, name, [m for m in ("dist", "get_alpha_beta", "_get_alpha_beta", "get_n_p", "get_mu_lam_phi", "get_kappa", "logp") if m in have], _DistBase, ns)
     # `_logprob_helper(Normal.dist(mu, sigma), value)` (continuous.py:731, :2384): dispatch to the logp of the RV's distribution
     ns["_logprob_helper"] = lambda rv, value: rv.dist_cls.logp(value, *rv)
     for name in ("LogTransform", "IntervalTransform", "LogOddsTransform"):
@@ -786,6 +789,32 @@ class StubModel:
 
     def Gumbel(self, name, mu, beta, shape=(), observed=None):
         return self._rv("Gumbel", name, shape, _dist("Gumbel", mu, beta), None, observed)
+
+    # round 5, second batch: densities lowered op by op (continuous.py `Wald`, `Kumaraswamy`, `AsymmetricLaplace`, `Pareto`,
+    # `HalfStudentT`, `ExGaussian`, `Triangular`, `Moyal`) -- as observed likelihoods with random parameters
+    def Wald(self, name, mu, lam, observed, alpha=0.0):
+        return self._rv("Wald", name, np.shape(observed), _dist("Wald", mu=mu, lam=lam, alpha=alpha), None, observed)
+
+    def Kumaraswamy(self, name, a, b, observed):
+        return self._rv("Kumaraswamy", name, np.shape(observed), _dist("Kumaraswamy", a, b), None, observed)
+
+    def AsymmetricLaplace(self, name, kappa, mu, b, observed):
+        return self._rv("AsymmetricLaplace", name, np.shape(observed), _dist("AsymmetricLaplace", kappa=kappa, mu=mu, b=b), None, observed)
+
+    def Pareto(self, name, alpha, m, observed):
+        return self._rv("Pareto", name, np.shape(observed), _dist("Pareto", alpha, m), None, observed)
+
+    def HalfStudentT(self, name, nu, sigma, observed):
+        return self._rv("HalfStudentT", name, np.shape(observed), _dist("HalfStudentT", nu, sigma=sigma), None, observed)
+
+    def ExGaussian(self, name, mu, sigma, nu, observed):
+        return self._rv("ExGaussian", name, np.shape(observed), _dist("ExGaussian", mu, sigma, nu=nu), None, observed)
+
+    def Triangular(self, name, lower, upper, c, observed):
+        return self._rv("Triangular", name, np.shape(observed), _dist("Triangular", lower, upper, c), None, observed)
+
+    def Moyal(self, name, mu, sigma, observed):
+        return self._rv("Moyal", name, np.shape(observed), _dist("Moyal", mu, sigma), None, observed)
 
     def SkewNormal(self, name, alpha=1.0, mu=0.0, sigma=1.0, shape=(), observed=None):
         return self._rv("SkewNormal", name, shape, _dist("SkewNormal", alpha=alpha, mu=mu, sigma=sigma), None, observed)
