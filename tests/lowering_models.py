@@ -544,7 +544,7 @@ _YUNIT = _rg.uniform(0.08, 0.92, size=11)
 
 def density_zoo_2():
     """Eight more densities without a code of their own, with RANDOM parameters (continuous.py `Wald`, `Kumaraswamy`,
-    `AsymmetricLaplace`, `Pareto`, `HalfStudentT`, `ExGaussian`, `Triangular`, `Moyal`): powers with variable exponents (`kappa **
+    `AsymmetricLaplace`, `Moyal` here; `Pareto`, `HalfStudentT`, `ExGaussian`, `Triangular` in density_zoo_3): powers with variable exponents (`kappa **
     sign(value)`, `value ** a`), `logpow` switches, the `normal_lcdf` branches inside a switch on the parameters (ExGaussian),
     support switches against a random bound (Pareto's `value >= m`), gammaln of a random nu."""
     m = sg.StubModel()
@@ -558,6 +558,15 @@ def density_zoo_2():
     loc = m.Normal("loc", 0.0, 2.0)
     sc = m.HalfNormal("sc", 1.5)
     m.AsymmetricLaplace("al", kap, loc, sc, observed=YGEN[:12])
+    m.Moyal("mo", loc, sc, observed=YGEN[5:17])
+    return m
+
+
+def density_zoo_3():
+    """(the second half: a model carries at most eight scalars that broadcast against vector factors, csrc/model_dev.h MAX_BTERMS)"""
+    m = sg.StubModel()
+    loc = m.Normal("loc", 0.0, 2.0)
+    sc = m.HalfNormal("sc", 1.5)
     al = m.HalfNormal("al_p", 3.0)
     m.Pareto("pa", al, 0.25, observed=_YPOS)
     nu = m.Gamma("nu", 2.0, 0.3)
@@ -566,7 +575,6 @@ def density_zoo_2():
     m.ExGaussian("eg", loc, sc, en, observed=YGEN[12:])
     cc = m.Beta("cc", 2.0, 2.0)
     m.Triangular("tr", 0.0, 1.0, cc, observed=_YUNIT)
-    m.Moyal("mo", loc, sc, observed=YGEN[5:17])
     return m
 
 
@@ -698,6 +706,7 @@ GENERAL = {
     "negative_binomial_regression": negative_binomial_regression,
     "density_zoo": density_zoo,
     "density_zoo_2": density_zoo_2,
+    "density_zoo_3": density_zoo_3,
     "hierarchical_regression_noncentred": hierarchical_regression_noncentred,
     "hierarchical_logistic_vector_hyper": hierarchical_logistic_vector_hyper,
     "glm_with_mvnormal_prior": glm_with_mvnormal_prior,
