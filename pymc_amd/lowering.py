@@ -215,6 +215,13 @@ def build_tree(v, memo: Optional[dict] = None):
                 # `beta[k]`: one element of a vector (`mu = alpha + beta[0] * X1 + beta[1] * X2`, the way a regression is usually
                 # written out): kept as a node; a linear predictor made of such terms becomes the GLM node (`_Lowering._glm`)
                 out = ("index", kid, int(idx[0]) % int(shp[0]))
+            elif memo.get("__shapes__") and _eff_shape(ins[0]) is not None:
+                # basic indexing of an expression with integers / slices (`p_cum[..., 1:] - p_cum[..., :-1]` of OrderedLogistic,
+                # discrete.py:1325): which elements of the (raveled) operand the result reads -- a gather the op-by-op lowering
+                # pushes down to the leaves like a broadcast
+                ishape = _eff_shape(ins[0])
+                pos = np.arange(_numel(ishape), dtype=np.int64).reshape(ishape)[idx if len(idx) != 1 else idx[0]]
+                out = ("bcast", kid, np.atleast_1d(pos).ravel(), ishape, tuple(np.shape(pos)))
             else:
                 raise NotLowerable("Subtensor of a non-constant beyond x[0] of a leading dimension of one and beta[k] of a vector")
     elif name == "Transpose":
@@ -1176,6 +1183,11 @@ class _Lowering:
             # one number): every element, written out.  A condition with one value per element of the factor stays element-wise --
             # the reduction over the factor's elements is what NUTS_E_CHECK means.
             return self._unrolled_sum((node[0], None, node[1], node[3]))
+        if node[0] in ("all", "any") and len(node) == 4 and node[3] is not None and node[1][0] != "makevector" and len(node[3]) >= 2 \
+                and _numel(node[3]) != self._fsize and _numel(node[3][:-1]) == self._fsize and node[3][-1] <= self.MAX_UNROLLED_SUM:
+            # a condition with K values per element of the factor (`0 <= p` of a Categorical whose p has a row per observation): reduced
+            # over its last axis, one value per element remains -- the reduction over the elements is what NUTS_E_CHECK means
+            return self._unrolled_sum((node[0], len(node[3]) - 1, node[1], node[3]))
         if node[0] in ("all", "any"):
             inner = node[1]
             parts = list(inner[1:]) if inner[0] == "makevector" else [inner]
@@ -1562,6 +1574,8 @@ class _Lowering:
         n_data, n_fac = len(self.spec.data), len(self.spec.factors)
         try:
             try:
+                if node is None:
+                    raise NotLowerable("expression is outside the affine IR `a + b*c` (no template tree)")
                 self._factor(node, name, own_value)
             except NotLowerable as first:
                 # a template matched but its arguments are outside the affine terms' reach (operands of different shapes, a gather of an
@@ -1819,7 +1833,11 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
     names = list(getattr(model, "logp_names", [f"factor{i}" for i in range(len(factors))]))
     memo: dict = {}
     for g, own, nm in zip(factors, owners, names):
-        low.factor(build_tree(g, memo), nm, own, graph=g)
+        try:
+            tree = build_tree(g, memo)
+        except NotLowerable:
+            tree = None         # (only the shape-aware walk can express it -- slices of an expression: straight to the op-by-op lowering)
+        low.factor(tree, nm, own, graph=g)
     # Categorical variables no conditional mixture claimed (`c ~ Categorical(w)` next to anything but `y ~ Normal(mu[c], ...)`): the
     # factor `log p[c]` is lowered op by op -- a selection among the K probabilities by the CURRENT value of c (`_select_chain`)
     for did in list(low._cat):

@@ -578,6 +578,25 @@ def density_zoo_3():
     return m
 
 
+_XORD = _rg.normal(size=40)
+_YORD = np.clip(np.round(1.5 + 0.9 * _XORD + 0.7 * _rg.normal(size=40)), 0, 3)
+
+
+def ordinal_regression():
+    """`pm.OrderedLogistic("y", eta=a x, cutpoints=c, observed=y)` (discrete.py:1231-1326): a Categorical whose probabilities have a
+    ROW PER OBSERVATION -- p = diff(concat([0, sigmoid(c - eta[:, None]), 1])) with slices of an expression, a concatenation along
+    the last axis with constant pieces, checks over [N, K] -- and ordered cutpoints written out (c0, c0 + exp(d1), c0 + exp(d1) + exp(d2))."""
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 2.0)
+    c0 = m.Normal("c0", -1.0, 2.0)
+    d1 = m.Normal("d1", 0.0, 1.0)
+    d2 = m.Normal("d2", 0.0, 1.0)
+    c1 = c0 + m.math.exp(d1)
+    cut = sg.pt.stack([c0, c1, c1 + m.math.exp(d2)])
+    m.OrderedLogistic("y", a * sg.as_tensor(_XORD), cut, observed=_YORD)
+    return m
+
+
 XH = _rg.normal(size=(60, 7))
 YH = XH @ (0.3 + 0.8 * _rg.normal(size=7)) + 0.4 * _rg.normal(size=60)
 YHB = (_rg.uniform(size=60) < 1.0 / (1.0 + np.exp(-(XH @ (0.5 * _rg.normal(size=7)))))).astype("float64")
@@ -707,6 +726,7 @@ GENERAL = {
     "density_zoo": density_zoo,
     "density_zoo_2": density_zoo_2,
     "density_zoo_3": density_zoo_3,
+    "ordinal_regression": ordinal_regression,
     "hierarchical_regression_noncentred": hierarchical_regression_noncentred,
     "hierarchical_logistic_vector_hyper": hierarchical_logistic_vector_hyper,
     "glm_with_mvnormal_prior": glm_with_mvnormal_prior,

@@ -386,6 +386,19 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         return Variable(Apply(Join(axis), ts), shape=tuple(shp))
 
     @staticmethod
+    def shape_padright(x, n_ones=1):
+        x = as_tensor(x)
+        return Variable(Apply(DimShuffle(), [x]), shape=x.type.shape + (1,) * n_ones)
+
+    @staticmethod
+    def zeros_like(x, dtype=None):
+        return TensorConstant(np.zeros(as_tensor(x).type.shape))     # (`fill(x, 0)`: a constant once the shape is static)
+
+    @staticmethod
+    def ones_like(x, dtype=None):
+        return TensorConstant(np.ones(as_tensor(x).type.shape))
+
+    @staticmethod
     def stack(tensors, axis=0):
         """`pt.stack(tensors, axis)`: `join(axis, *[shape_padaxis(t, axis) for t in tensors])` -- a Join of DimShuffles."""
         ts = [as_tensor(t) for t in tensors]
@@ -633,6 +646,8 @@ def reference():
 
     ns["warnings"] = warnings
     ref_class("distributions/discrete.py", "Categorical", ["dist", "_safe_index_value_p", "logp"], _DistBase, ns)
+    ns["sigmoid"] = pt.sigmoid          # discrete.py:52 `from pymc.math import sigmoid`
+    ref_class("distributions/discrete.py", "OrderedLogistic", ["compute_p"], object, ns)
     # Dirichlet (distributions/multivariate.py:543-584: `dist`, `logp`) under its default transform (`simplex_cont_transform`,
     # multivariate.py:126-127 -> `transforms.simplex` = `SimplexTransform()`, logprob/transforms.py:1091-1115)
     ref_class("distributions/multivariate.py", "Dirichlet", ["dist", "logp"], _DistBase, ns)
@@ -858,6 +873,12 @@ class StubModel:
         comp = _ComponentRV(ref["Normal"], _dist("Normal", mu=mu, sigma=sigma))
         fn = lambda value, w_, comp_: ref["mixture_logprob"](None, (value,), None, w_, comp_)   # noqa: E731
         return self._add(_RV(name, np.shape(observed), fn, (as_tensor(w), comp), None, observed))
+
+    def OrderedLogistic(self, name, eta, cutpoints, observed):
+        """`pm.OrderedLogistic(name, eta=eta, cutpoints=cutpoints, observed=y)` (discrete.py:1231-1326): `Categorical` over
+        p = diff(concat([0, sigmoid(cutpoints - eta[..., None]), 1])) -- the reference's own `compute_p`."""
+        p = reference()["OrderedLogistic"].compute_p(eta, cutpoints)
+        return self.Categorical(name, p=p, observed=observed)
 
     def Mixture(self, name, w, comp_dists, observed):
         """`pm.Mixture(name, w=w, comp_dists=..., observed=y)` (mixture.py:166-176, 469-495): `comp_dists` is ONE batched component
