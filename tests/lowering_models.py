@@ -597,6 +597,20 @@ def ordinal_regression():
     return m
 
 
+_YZIP = np.where(_rg.uniform(size=36) < 0.35, 0.0, _rg.poisson(3.5, size=36)).astype("float64")
+
+
+def zero_inflated_poisson():
+    """`pm.ZeroInflatedPoisson("y", psi, mu, observed=y)` with psi ~ Beta and a log-linear rate (mixture.py:560-575: a `Mixture` of
+    `DiracDelta(0)` and `Poisson(mu)` under weights `stack([1 - psi, psi])`): a component whose log-density is -inf off its atom."""
+    m = sg.StubModel()
+    psi = m.Beta("psi", 2.0, 2.0)
+    a = m.Normal("a", 1.0, 1.0)
+    b = m.Normal("b", 0.0, 1.0)
+    m.ZeroInflatedPoisson("y", psi, m.math.exp(a + b * sg.as_tensor(np.linspace(-1.0, 1.0, 36))), observed=_YZIP)
+    return m
+
+
 XH = _rg.normal(size=(60, 7))
 YH = XH @ (0.3 + 0.8 * _rg.normal(size=7)) + 0.4 * _rg.normal(size=60)
 YHB = (_rg.uniform(size=60) < 1.0 / (1.0 + np.exp(-(XH @ (0.5 * _rg.normal(size=7)))))).astype("float64")
@@ -727,6 +741,7 @@ GENERAL = {
     "density_zoo_2": density_zoo_2,
     "density_zoo_3": density_zoo_3,
     "ordinal_regression": ordinal_regression,
+    "zero_inflated_poisson": zero_inflated_poisson,
     "hierarchical_regression_noncentred": hierarchical_regression_noncentred,
     "hierarchical_logistic_vector_hyper": hierarchical_logistic_vector_hyper,
     "glm_with_mvnormal_prior": glm_with_mvnormal_prior,

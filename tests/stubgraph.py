@@ -646,6 +646,11 @@ def reference():
 
     ns["warnings"] = warnings
     ref_class("distributions/discrete.py", "Categorical", ["dist", "_safe_index_value_p", "logp"], _DistBase, ns)
+    ns["continuous_types"] = ("float64",)      # distribution.py DiracDelta.dist: `if c.dtype in continuous_types: c = floatX(c)`
+    ns["floatX"] = lambda x: x
+    ref_class("distributions/distribution.py", "DiracDelta", ["dist", "logp"], _DistBase, ns)
+    ns["Mixture"] = type("Mixture", (), {"dist": staticmethod(lambda w, comp_dists, **kw: (w, comp_dists))})   # (what `_zero_inflated_mixture(name=None, ...)` returns: its arguments)
+    ref_function("distributions/mixture.py", "_zero_inflated_mixture", ns)
     ns["sigmoid"] = pt.sigmoid          # discrete.py:52 `from pymc.math import sigmoid`
     ref_class("distributions/discrete.py", "OrderedLogistic", ["compute_p"], object, ns)
     # Dirichlet (distributions/multivariate.py:543-584: `dist`, `logp`) under its default transform (`simplex_cont_transform`,
@@ -879,6 +884,16 @@ class StubModel:
         p = diff(concat([0, sigmoid(cutpoints - eta[..., None]), 1])) -- the reference's own `compute_p`."""
         p = reference()["OrderedLogistic"].compute_p(eta, cutpoints)
         return self.Categorical(name, p=p, observed=observed)
+
+    def ZeroInflatedPoisson(self, name, psi, mu, observed):
+        """`pm.ZeroInflatedPoisson(name, psi=psi, mu=mu, observed=y)` (mixture.py:560-575, 577-640): the reference's
+        `_zero_inflated_mixture` -- weights `stack([1 - psi, psi])`, components `[DiracDelta.dist(0), Poisson.dist(mu)]` -- under `Mixture`."""
+        ref = reference()
+        nonzero = _ComponentRV(ref["Poisson"], _dist("Poisson", mu))
+        w, comps = ref["_zero_inflated_mixture"](name=None, nonzero_p=psi, nonzero_dist=nonzero)
+        comps = [c if isinstance(c, _ComponentRV) else _ComponentRV(ref["DiracDelta"], c) for c in comps]
+        fn = lambda value, w_, *cs: ref["mixture_logprob"](None, (value,), None, w_, *cs)   # noqa: E731
+        return self._add(_RV(name, np.shape(observed), fn, (w, *comps), None, observed))
 
     def Mixture(self, name, w, comp_dists, observed):
         """`pm.Mixture(name, w=w, comp_dists=..., observed=y)` (mixture.py:166-176, 469-495): `comp_dists` is ONE batched component
