@@ -224,6 +224,42 @@ def build_tree(v, memo: Optional[dict] = None):
                 out = ("bcast", kid, np.atleast_1d(pos).ravel(), ishape, tuple(np.shape(pos)))
             else:
                 raise NotLowerable("Subtensor of a non-constant beyond x[0] of a leading dimension of one and beta[k] of a vector")
+    elif name in ("IncSubtensor", "CumOp") and not memo.get("__shapes__"):
+        raise NotLowerable(f"{name} needs the shape-aware walk")
+    elif name == "IncSubtensor":                  # `pt.set_subtensor(x[idx], y)`: x with the indexed region replaced by y
+        if not getattr(op, "set_instead_of_inc", False) or len(ins) != 2:
+            raise NotLowerable("IncSubtensor that increments, or with a symbolic index")
+        xk, yk = build_tree(ins[0], memo), build_tree(ins[1], memo)
+        xs, ys = _eff_shape(ins[0]), _eff_shape(ins[1])
+        if xs is None or ys is None:
+            raise NotLowerable("set_subtensor of a shape that is not static")
+        idx = tuple(getattr(op, "idx_list", ()))
+        idx = idx if len(idx) != 1 else idx[0]
+        piece = np.zeros(xs, dtype=np.int64)
+        inner = np.arange(_numel(xs), dtype=np.int64).reshape(xs)
+        region = inner[idx]
+        piece[idx] = 1
+        inner[idx] = np.broadcast_to(np.arange(_numel(ys), dtype=np.int64).reshape(ys), np.shape(region)) if _numel(ys) > 1 else 0
+        out = ("joinnd", piece.ravel(), inner.ravel(), tuple(xs), xk, yk)
+    elif name == "CumOp":                         # `pt.cumsum(x, axis)` over a short axis: every prefix sum written out
+        if getattr(op, "mode", "add") != "add":
+            raise NotLowerable("a cumulative product")
+        kid = build_tree(ins[0], memo)
+        shp = _eff_shape(ins[0])
+        ax = getattr(op, "axis", None)
+        if shp is None or ax is None or shp[ax % len(shp)] > 32:
+            raise NotLowerable("a cumulative sum over a long or unknown axis")
+        ax %= len(shp)
+        pos = np.arange(_numel(shp), dtype=np.int64).reshape(shp)
+        sl_shape = tuple(d for i, d in enumerate(shp) if i != ax)
+        pieces, run = [], None
+        for k_ in range(shp[ax]):
+            sl = ("bcast", kid, np.take(pos, k_, axis=ax).ravel(), tuple(shp), sl_shape)
+            run = sl if run is None else ("add", run, sl)
+            pieces.append(run)
+        piece = np.broadcast_to(np.arange(shp[ax], dtype=np.int64).reshape([-1 if i == ax else 1 for i in range(len(shp))]), shp)
+        inner = np.broadcast_to(np.expand_dims(np.arange(_numel(sl_shape), dtype=np.int64).reshape(sl_shape), ax), shp)
+        out = ("joinnd", np.ascontiguousarray(piece).ravel(), np.ascontiguousarray(inner).ravel(), tuple(shp), *pieces)
     elif name == "Transpose":
         kid = build_tree(ins[0], memo)
         out = _const(np.swapaxes(kid[1], -1, -2)) if kid[0] == "const" else ("transpose", kid)
@@ -912,6 +948,8 @@ class _Lowering:
             kv = self._as_var(node[1])
             idx = np.asarray(node[2], dtype="float64")
             if kv is not None:
+                if idx.size == 1 and self._const_cache is not None and getattr(self, "_fsize", 1) > 1:
+                    idx = np.full(self._fsize, idx.reshape(-1)[0])      # ONE element of a vector inside a larger factor: an index per element
                 key = ("gather", kv, idx.tobytes())
                 if key not in self._gather_ids:
                     self.spec.data.append(np.ascontiguousarray(idx))
@@ -1755,9 +1793,29 @@ class _Lowering:
         while node[0] == "sum" and (node[1] is None or (len(node) == 4 and node[3] is not None and len(node[3]) <= 1)):
             node = node[2]        # `Model.logp` sums every factor anyway (model/core.py:666-695): a full reduction at a factor's root is the factor
         self._const_cache = {}
+        written_out = False
         try:
             self._fsize = self._tsize(node)
-            t = self.term(node)
+            try:
+                t = self.term(node)
+            except NotLowerable as first:
+                # a small factor whose elements are assembled piecewise (an ordered vector: `cumsum` of a `set_subtensor`; a
+                # concatenation used element-wise): written out element by element -- one number, the sum `Model.logp` takes anyway
+                if not 1 < self._fsize <= self.MAX_UNROLLED_SUM:
+                    raise
+                n_el = self._fsize
+                self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+                self._const_cache = {}
+                self._fsize = 1
+                try:
+                    total = None
+                    for i_ in range(n_el):
+                        el = self._index(node, np.array([i_]))
+                        total = el if total is None else ("add", total, el)
+                    t = self.term(total)
+                    written_out = True
+                except NotLowerable:
+                    raise first
         finally:
             self._const_cache = None
             self._fsize = 0
@@ -1767,7 +1825,7 @@ class _Lowering:
                 if self._osize(o) not in (1, size):
                     raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
                                        "between different shapes is outside the element-wise programs")
-        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex:
+        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out:
             raise NotLowerable(f"the factor of {self.spec.vars[own].name} does not have the variable's shape")
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)
 
@@ -1823,8 +1881,15 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
         shapes[v.name] = shp
         tr = getattr(model, "value_transforms", {}).get(v.name)
         if tr is not None and not isinstance(tr, tuple):
-            code = {"log": ms.TR_LOG, "logodds": ms.TR_LOGODDS, "interval": ms.TR_INTERVAL, "simplex": _TR_SIMPLEX}[tr.name]
-            tr = (code, getattr(tr, "lower", 0.0), getattr(tr, "upper", 1.0))
+            if tr.name == "ordered":
+                tr = None
+            else:
+                code = {"log": ms.TR_LOG, "logodds": ms.TR_LOGODDS, "interval": ms.TR_INTERVAL, "simplex": _TR_SIMPLEX}[tr.name]
+                tr = (code, getattr(tr, "lower", 0.0), getattr(tr, "upper", 1.0))
+        # `transforms.ordered` (distributions/transforms.py:79-125): no transform code in the IR -- the value variable is stored as it
+        # is, `Ordered.backward` (a cumulative sum of [v0, exp(v1), ...]) and its log-Jacobian are part of the graphs and lower op by op
+        if tr is not None and int(tr[0]) == 5:
+            tr = None
         if tr is not None:
             transforms[v.name] = tr
     low = _Lowering(list(model.value_vars), transforms, shapes, list(getattr(model, "extra_vars", ())), getattr(model, "extra_values", None))

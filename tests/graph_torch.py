@@ -92,6 +92,12 @@ def evaluate(var, values: dict, memo: dict | None = None):
             elif name == "TakeAlongAxis":
                 arr, ind = ev(ins[0]), ev(ins[1]).to(torch.int64)
                 out = torch.take_along_dim(arr if arr.ndim == ind.ndim else arr.expand(*ind.shape[:-1], arr.shape[-1]), ind, dim=-1)
+            elif name == "IncSubtensor":
+                idx = tuple(op.idx_list)
+                out = ev(ins[0]).clone()
+                out[idx if len(idx) != 1 else idx[0]] = ev(ins[1])
+            elif name == "CumOp":
+                out = torch.cumsum(ev(ins[0]), dim=op.axis)
             elif name == "Dot":
                 out = ev(ins[0]) @ ev(ins[1])
             elif name == "Join":

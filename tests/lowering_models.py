@@ -611,6 +611,22 @@ def zero_inflated_poisson():
     return m
 
 
+_YMIXO = np.concatenate([_rg.normal(-2.0, 0.6, size=14), _rg.normal(0.5, 0.8, size=18), _rg.normal(3.0, 0.5, size=10)])
+
+
+def mixture_with_ordered_means():
+    """The mixture model of the reference's own NormalMixture docstring (mixture.py:633-648): component means under
+    `transform=pm.distributions.transforms.ordered` (distributions/transforms.py:79-125: x = cumsum([v0, exp(v1), exp(v2)]),
+    log|J| = v1 + v2), HalfNormal scales, Dirichlet weights, `pm.NormalMixture` over the observations.  `set_subtensor` and `cumsum`
+    are written out; the prior of the ordered vector is a factor of its three elements."""
+    m = sg.StubModel()
+    mu = m.Normal("mu", np.array([-1.0, 0.0, 1.0]), 5.0, shape=(3,), transform="ordered")
+    sigma = m.HalfNormal("sigma", 2.0, shape=(3,))
+    w = m.Dirichlet("w", np.ones(3))
+    m.NormalMixture("y", w, mu, sigma, observed=_YMIXO)
+    return m
+
+
 XH = _rg.normal(size=(60, 7))
 YH = XH @ (0.3 + 0.8 * _rg.normal(size=7)) + 0.4 * _rg.normal(size=60)
 YHB = (_rg.uniform(size=60) < 1.0 / (1.0 + np.exp(-(XH @ (0.5 * _rg.normal(size=7)))))).astype("float64")
@@ -742,6 +758,7 @@ GENERAL = {
     "density_zoo_3": density_zoo_3,
     "ordinal_regression": ordinal_regression,
     "zero_inflated_poisson": zero_inflated_poisson,
+    "mixture_with_ordered_means": mixture_with_ordered_means,
     "hierarchical_regression_noncentred": hierarchical_regression_noncentred,
     "hierarchical_logistic_vector_hyper": hierarchical_logistic_vector_hyper,
     "glm_with_mvnormal_prior": glm_with_mvnormal_prior,

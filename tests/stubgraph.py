@@ -164,6 +164,21 @@ class Subtensor:
         self.idx_list = tuple(idx_list)
 
 
+class IncSubtensor:
+    """`pytensor.tensor.subtensor.IncSubtensor` with `set_instead_of_inc=True`: `pt.set_subtensor(x[idx], y)` -- inputs (x, y), the
+    basic index kept on the op."""
+
+    def __init__(self, idx_list, set_instead_of_inc=True):
+        self.idx_list, self.set_instead_of_inc = tuple(idx_list), bool(set_instead_of_inc)
+
+
+class CumOp:
+    """`pytensor.tensor.extra_ops.CumOp` (`pt.cumsum(x, axis)`: mode "add")."""
+
+    def __init__(self, axis, mode="add"):
+        self.axis, self.mode = axis, mode
+
+
 class Shape:
     """`pytensor.tensor.shape.Shape`: `x.shape`."""
 
@@ -384,6 +399,26 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         shp = list(ts[0].type.shape)
         shp[ax] = sum(t.type.shape[ax] for t in ts)
         return Variable(Apply(Join(axis), ts), shape=tuple(shp))
+
+    @staticmethod
+    def empty(shape, dtype=None):
+        """`pt.empty(value.shape)`: an uninitialised tensor of a static shape (here: zeros -- every element is set before it is read)."""
+        if isinstance(shape, Variable) and shape.owner is not None and isinstance(shape.owner.op, Shape):
+            shape = shape.owner.inputs[0].type.shape
+        return TensorConstant(np.zeros(tuple(int(d) for d in shape)))
+
+    @staticmethod
+    def set_subtensor(x_sub, y):
+        """`pt.set_subtensor(x[idx], y)`: `x_sub` is the Subtensor node `x[idx]`; the result has x's shape."""
+        if x_sub.owner is None or not isinstance(x_sub.owner.op, Subtensor):
+            raise NotImplementedError("stub: set_subtensor of something that is not x[basic index]")
+        x = x_sub.owner.inputs[0]
+        return Variable(Apply(IncSubtensor(x_sub.owner.op.idx_list, True), [x, as_tensor(y)]), shape=x.type.shape)
+
+    @staticmethod
+    def cumsum(x, axis=None):
+        x = as_tensor(x)
+        return Variable(Apply(CumOp(axis, "add"), [x]), shape=x.type.shape)
 
     @staticmethod
     def shape_padright(x, n_ones=1):
@@ -659,6 +694,9 @@ def reference():
     ref_class("distributions/multivariate.py", "Multinomial", ["dist", "logp"], _DistBase, ns)
     ref_class("logprob/transforms.py", "SimplexTransform", ["forward", "backward", "log_jac_det"], _TransformBase, ns)
     ns["transforms"].simplex = ns["SimplexTransform"]()
+    # `pm.distributions.transforms.ordered` (distributions/transforms.py:79-125, 704): the identifiability constraint of a mixture's means
+    ref_class("distributions/transforms.py", "Ordered", ["__init__", "backward", "forward", "log_jac_det"], _TransformBase, ns)
+    ns["transforms"].ordered = ns["Ordered"]()
     _NS = ns
     return ns
 
@@ -687,7 +725,8 @@ class _RV:
         self.rv_inputs = (None, None, *params)          # (rng, size, *dist_params): what a transform's methods receive
         if transform is not None and transform_obj is None:
             ref = reference()
-            transform_obj = {"log": ref["transforms"].log, "logodds": ref["transforms"].logodds, "simplex": ref["transforms"].simplex}[transform]
+            transform_obj = {"log": ref["transforms"].log, "logodds": ref["transforms"].logodds, "simplex": ref["transforms"].simplex,
+                             "ordered": ref["transforms"].ordered}[transform]
         self.transform_obj = transform_obj
         if observed is None:
             vname = name if transform is None else f"{name}_{transform}__"   # util.py:138-155
@@ -767,8 +806,9 @@ class StubModel:
         tr = ref["bounded_cont_transform"](None, None, ref[cls_name].bound_args_indices)   # continuous.py:345-347, 817-819
         return self._add(_RV(name, shape, _ref_logp(cls_name), params, "interval", None, bounds=(float(lower), float(upper)), transform_obj=tr))
 
-    def Normal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None):
-        return self._rv("Normal", name, shape, _dist("Normal", mu=mu, sigma=sigma), None, observed)
+    def Normal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None, transform=None):
+        """(`transform="ordered"`: `pm.Normal(..., transform=pm.distributions.transforms.ordered)`)"""
+        return self._rv("Normal", name, shape, _dist("Normal", mu=mu, sigma=sigma), transform, observed)
 
     def HalfNormal(self, name, sigma=1.0, shape=()):
         return self._rv("HalfNormal", name, shape, _dist("HalfNormal", sigma=sigma), "log", None)
@@ -946,7 +986,9 @@ class StubModel:
 
     @property
     def value_transforms(self):
-        code = {"log": 1, "logodds": 2, "interval": 3, "simplex": 4}
+        # ("ordered" has no code of its own: the value variable is stored as it is, `Ordered.backward` and `log_jac_det` are part of the
+        # graphs -- 5 tells the lowering so)
+        code = {"log": 1, "logodds": 2, "interval": 3, "simplex": 4, "ordered": 5}
         return {rv.value.name: (code[rv.transform], *(rv.bounds or (0.0, 1.0))) for rv in self.free if rv.transform}
 
     @property
@@ -1005,6 +1047,10 @@ def dump_model(m) -> dict:
                 rec["msg"] = op.msg
             if hasattr(op, "idx_list"):
                 rec["idx_list"] = [("slice", i.start, i.stop, i.step) if isinstance(i, slice) else ("ellipsis",) if i is Ellipsis else int(i) for i in op.idx_list]
+            if hasattr(op, "set_instead_of_inc"):
+                rec["set"] = bool(op.set_instead_of_inc)
+            if hasattr(op, "mode"):
+                rec["mode"] = op.mode
             if hasattr(op, "lower"):
                 rec["lower"] = bool(op.lower)
             if hasattr(op, "b_ndim"):
@@ -1052,6 +1098,11 @@ class FrozenModel:
                     op = CheckParameterValue(rec.get("msg", ""))
                 elif rec["op"] == "Subtensor":
                     op = Subtensor([slice(*i[1:]) if isinstance(i, (list, tuple)) and i[0] == "slice" else Ellipsis if isinstance(i, (list, tuple)) else i for i in rec["idx_list"]])
+                elif rec["op"] == "IncSubtensor":
+                    op = IncSubtensor([slice(*i[1:]) if isinstance(i, (list, tuple)) and i[0] == "slice" else Ellipsis if isinstance(i, (list, tuple)) else i for i in rec["idx_list"]],
+                                      rec.get("set", True))
+                elif rec["op"] == "CumOp":
+                    op = CumOp(rec.get("axis"), rec.get("mode", "add"))
                 elif rec["op"] == "Cholesky":
                     op = Cholesky(rec.get("lower", True))
                 elif rec["op"] == "SolveTriangular":
