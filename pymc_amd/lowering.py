@@ -1073,7 +1073,28 @@ class _Lowering:
             self._prog_memo[id(node)] = (node, out)
             return out
         elif op in ("join", "joinnd"):
-            raise NotLowerable(f"a concatenation that is not reduced or indexed element by element: {_show(node)}")
+            # a concatenation / piecewise assembly used ELEMENT-WISE (an ordered vector, `cumsum` of a `set_subtensor`): element i is
+            # piece j(i) at position p(i) -- a chain of selections over constant masks, every piece gathered at positions that are
+            # valid for all i (the mask decides which one counts)
+            if op == "join":
+                sizes = [self._tsize(x) for x in node[2:]]
+                piece_of = np.concatenate([np.full(sz, j, dtype=np.int64) for j, sz in enumerate(sizes)])
+                inner_of = np.concatenate([np.arange(sz, dtype=np.int64) for sz in sizes])
+                pieces = node[2:]
+            else:
+                piece_of, inner_of, pieces = np.asarray(node[1]), np.asarray(node[2]), node[4:]
+            if len(pieces) > self.MAX_UNROLLED_SUM:
+                raise NotLowerable(f"a concatenation of {len(pieces)} pieces used element-wise: {_show(node)}")
+            sel = None
+            for j_, piece in enumerate(pieces):
+                mask = piece_of == j_
+                if not mask.any():
+                    continue
+                pj = piece if self._tsize(piece) == 1 else self._index(piece, np.where(mask, inner_of, inner_of[mask][0]))
+                sel = pj if sel is None else ("switch", _const(mask.astype("float64")), pj, sel)
+            out = self._program(sel)
+            self._prog_memo[id(node)] = (node, out)
+            return out
         elif op in self._PROG_OPS:
             kids = [self._program(x) for x in node[1:]]
             code = self._PROG_OPS[op]
