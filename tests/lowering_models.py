@@ -538,8 +538,9 @@ def density_zoo():
     return m
 
 
-_YPOS = np.abs(_rg.normal(size=14)) * 1.5 + 0.3
-_YUNIT = _rg.uniform(0.08, 0.92, size=11)
+_rg2 = np.random.default_rng(20240924)      # (its own stream: data added later must not shift the draws of the models below)
+_YPOS = np.abs(_rg2.normal(size=14)) * 1.5 + 0.3
+_YUNIT = _rg2.uniform(0.08, 0.92, size=11)
 
 
 def density_zoo_2():
@@ -578,8 +579,8 @@ def density_zoo_3():
     return m
 
 
-_XORD = _rg.normal(size=40)
-_YORD = np.clip(np.round(1.5 + 0.9 * _XORD + 0.7 * _rg.normal(size=40)), 0, 3)
+_XORD = _rg2.normal(size=40)
+_YORD = np.clip(np.round(1.5 + 0.9 * _XORD + 0.7 * _rg2.normal(size=40)), 0, 3)
 
 
 def ordinal_regression():
@@ -597,7 +598,7 @@ def ordinal_regression():
     return m
 
 
-_YZIP = np.where(_rg.uniform(size=36) < 0.35, 0.0, _rg.poisson(3.5, size=36)).astype("float64")
+_YZIP = np.where(_rg2.uniform(size=36) < 0.35, 0.0, _rg2.poisson(3.5, size=36)).astype("float64")
 
 
 def zero_inflated_poisson():
@@ -611,7 +612,7 @@ def zero_inflated_poisson():
     return m
 
 
-_YMIXO = np.concatenate([_rg.normal(-2.0, 0.6, size=14), _rg.normal(0.5, 0.8, size=18), _rg.normal(3.0, 0.5, size=10)])
+_YMIXO = np.concatenate([_rg2.normal(-2.0, 0.6, size=14), _rg2.normal(0.5, 0.8, size=18), _rg2.normal(3.0, 0.5, size=10)])
 
 
 def mixture_with_ordered_means():

@@ -364,7 +364,7 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     inf = np.inf
     constant = staticmethod(lambda x, **kw: TensorConstant(x))
     as_tensor_variable = staticmethod(lambda x, dtype=None, **kw: as_tensor(x))
-    zeros_like = staticmethod(lambda a: elemwise(Second, a, 0.0))     # pt.zeros_like = fill(a, 0)
+    zeros_like = staticmethod(lambda a, dtype=None: elemwise(Second, a, 0.0))     # pt.zeros_like = fill(a, 0)
 
     @staticmethod
     def _reduce(op_cls, x, axis, keepdims):
@@ -425,13 +425,7 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         x = as_tensor(x)
         return Variable(Apply(DimShuffle(), [x]), shape=x.type.shape + (1,) * n_ones)
 
-    @staticmethod
-    def zeros_like(x, dtype=None):
-        return TensorConstant(np.zeros(as_tensor(x).type.shape))     # (`fill(x, 0)`: a constant once the shape is static)
-
-    @staticmethod
-    def ones_like(x, dtype=None):
-        return TensorConstant(np.ones(as_tensor(x).type.shape))
+    ones_like = staticmethod(lambda a, dtype=None: elemwise(Second, a, 1.0))      # pt.ones_like = fill(a, 1)
 
     @staticmethod
     def stack(tensors, axis=0):
