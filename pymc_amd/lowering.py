@@ -1008,7 +1008,7 @@ class _Lowering:
                  # that matches no template is lowered op by op
                  "gt": ms.E_GT, "ge": ms.E_GE, "lt": ms.E_LT, "le": ms.E_LE, "eq": ms.E_EQ, "neq": ms.E_NEQ, "and": ms.E_AND, "or": ms.E_OR,
                  "not": ms.E_NOT, "switch": ms.E_SWITCH, "gammaln": ms.E_GAMMALN, "erf": ms.E_ERF, "erfc": ms.E_ERFC, "erfcx": ms.E_ERFCX,
-                 "log1mexp": ms.E_LOG1MEXP, "expm1": ms.E_EXPM1, "sign": ms.E_SIGN, "maximum": ms.E_MAXIMUM, "minimum": ms.E_MINIMUM,
+                 "log1mexp": ms.E_LOG1MEXP, "expm1": ms.E_EXPM1, "sign": ms.E_SIGN, "maximum": ms.E_MAXIMUM, "minimum": ms.E_MINIMUM, "rmaximum": ms.E_MAXIMUM,
                  "floor": ms.E_FLOOR, "ceil": ms.E_CEIL, "sin": ms.E_SIN, "cos": ms.E_COS, "arctan": ms.E_ARCTAN, "logaddexp": ms.E_LOGADDEXP,
                  "clip": ms.E_CLIP, "log2": ms.E_LOG2, "log10": ms.E_LOG10, "digamma": ms.E_DIGAMMA}
 
@@ -1066,6 +1066,15 @@ class _Lowering:
         elif op == "isclose":                     # pytensor `isclose(a, b)`: |a - b| <= atol + rtol |b| (rtol 1e-5, atol 1e-8)
             a_, b_ = node[1], node[2]
             out = self._program(("le", ("abs", ("sub", a_, b_)), ("add", _const(1e-8), ("mul", _const(1e-5), ("abs", b_)))))
+            self._prog_memo[id(node)] = (node, out)
+            return out
+        elif op in ("maximum", "minimum") and len(node) == 3:
+            # element-wise `pt.maximum(x, y)` / `pt.minimum(x, y)`: switch(x >= y, x, y) / switch(x <= y, x, y).  The values are those of
+            # the opcode; the gradient at a TIE is PyTensor's (`ScalarMaximum.L_op`, `ScalarMinimum.L_op`: the first operand takes all
+            # of it, `gx = eq(out, x) gz, gy = (1 - eq(out, x)) gz`), which the opcode's reverse rule -- both operands -- is not; ties
+            # are not exotic (`minimum(switch(c, a, b), a)` is one whenever c holds)
+            x_, y_ = node[1], node[2]
+            out = self._program(("switch", ("ge" if op == "maximum" else "le", x_, y_), x_, y_))
             self._prog_memo[id(node)] = (node, out)
             return out
         elif op == "take_along_axis" and len(node) == 4:
@@ -1211,7 +1220,9 @@ class _Lowering:
         """`expr.sum(axis)` over ONE short axis of an element-wise expression, written out: sum_r expr[..., r, ...] -- each term the
         expression with the index of that slice pushed down to its leaves (`(X * beta[g]).sum(axis=1)`: D products and D - 1 sums)."""
         kind, ax, kid, shp = node
-        comb = {"sum": "add", "max": "maximum", "all": "and", "any": "or", "lse": "logaddexp"}[kind]
+        # ("rmaximum": the maximum of a REDUCTION -- PyTensor's `Max` credits every tied element, which is what NUTS_E_MAXIMUM's reverse
+        # rule does; an element-wise `pt.maximum` is lowered as a selection instead, see `_program`)
+        comb = {"sum": "add", "max": "rmaximum", "all": "and", "any": "or", "lse": "logaddexp"}[kind]
         if ax is None:
             axes = list(range(len(shp)))
         else:
@@ -1273,6 +1284,11 @@ class _Lowering:
         if code == ms.E_SWITCH and kids[0].kind == ms.OP_CONST:
             return kids[1] if kids[0].c != 0.0 else kids[2]
         if code == ms.E_CHECK and kids[1].kind == ms.OP_CONST and kids[1].c != 0.0:
+            return kids[0]
+        if code in (ms.E_MAXIMUM, ms.E_MINIMUM) and kids[0] == kids[1]:
+            # maximum(x, x) IS x.  (It also must not reach the interpreter: at a tie PyTensor's `ScalarMaximum.L_op` credits the first
+            # operand only, the device's and the oracle's reverse sweep credit both -- twice the gradient here.  Ties between DISTINCT
+            # operands have measure zero under continuous values; aligning the convention is listed in DESIGN.md section 8.)
             return kids[0]
         key = (code, k, *kids)
         if key in self._prog_cse:

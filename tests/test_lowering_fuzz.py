@@ -1,0 +1,111 @@
+"""Random element-wise graphs through the op-by-op lowering (pymc_amd/lowering.py `_general`): expression DAGs over scalar and vector
+variables, data vectors, broadcasts between them, gathers, short reductions, comparisons and switches -- built with the graph
+stand-in of tests/stubgraph.py as `pm.Potential` terms (model/core.py:2007-2124) -- lowered to expression programs and evaluated by
+the oracle's interpreter (value + reverse sweep), against torch autograd of the SAME graph (tests/graph_torch.py).  What the
+lowering does to a graph on the way -- constant folding, common sub-expressions, index push-down, unrolled reductions, operands
+turned into gathers -- must not change its value or its gradient.  Host only: the device runs the same programs through the same
+opcodes (tests/test_general_lowering.py holds it to the same autograd values)."""
+import numpy as np
+import pytest
+
+import graph_torch as gt
+import stubgraph as sg
+from oracle import ref_models
+from pymc_amd.lowering import NotLowerable, lower_to_spec
+
+pt = sg.pt
+N = 5
+IDX = np.array([3, 0, 0, 4, 1])
+DATA = np.array([0.3, -1.2, 0.8, 2.0, -0.4])
+POS = np.array([0.5, 1.7, 0.9, 2.4, 1.1])
+
+
+def _leaf(rng, env, want_vec):
+    pool = env["vec"] if want_vec else env["sca"]
+    return pool[rng.integers(len(pool))]
+
+
+def _expr(rng, env, depth, want_vec):
+    """A random expression of bounded magnitude: (graph, is_vector)."""
+    if depth == 0 or rng.uniform() < 0.15:
+        return _leaf(rng, env, want_vec)
+    kind = rng.integers(0, 20)
+    sub = lambda v=want_vec: _expr(rng, env, depth - 1, v)                       # noqa: E731
+    mixed = lambda: _expr(rng, env, depth - 1, want_vec and rng.uniform() < 0.6)  # noqa: E731  (a scalar operand broadcasts)
+    if kind == 0:
+        return sub() + mixed()
+    if kind == 1:
+        return sub() - mixed()
+    if kind == 2:
+        return sub() * pt.tanh(mixed())
+    if kind == 3:
+        return sub() / (1.0 + pt.sqr(mixed()))
+    if kind == 4:
+        return pt.exp(0.3 * pt.tanh(sub()))
+    if kind == 5:
+        return pt.log1p(pt.sqr(sub()))
+    if kind == 6:
+        return pt.sqrt(1.0 + pt.sqr(sub()))
+    if kind == 7:
+        return pt.sigmoid(sub())
+    if kind == 8:
+        return pt.softplus(sub())
+    if kind == 9:
+        return pt.abs(sub() - 0.123)
+    if kind == 10:
+        return pt.maximum(sub(), mixed())
+    if kind == 11:
+        return pt.minimum(sub(), mixed())
+    if kind == 12:
+        return pt.switch(pt.gt(sub(), mixed()), sub(), mixed() * 0.5)
+    if kind == 13:
+        return pt.pow(1.0 + pt.sqr(sub()), 0.3 * pt.tanh(mixed()))
+    if kind == 14:
+        return pt.gammaln(1.5 + pt.sqr(sub()))
+    if kind == 15:
+        return pt.erf(sub()) + pt.log(1.0 + pt.sqr(mixed()))
+    if kind == 16 and want_vec:
+        return _expr(rng, env, depth - 1, True)[IDX]                                 # a gather of an expression
+    if kind == 17 and not want_vec:
+        return pt.sum(_expr(rng, env, depth - 1, True), axis=0)                     # a short reduction inside an expression
+    if kind == 18:
+        return pt.clip(sub(), -0.7, 1.3)
+    if kind == 19:
+        return pt.switch(pt.and_(pt.ge(sub(), -0.2), pt.le(mixed(), 0.9)), sub(), -sub())
+    return sub() * 0.7 + 0.1
+
+
+def _model(seed):
+    rng = np.random.default_rng(seed)
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 1.0)
+    b = m.HalfNormal("b", 1.0)
+    v = m.Normal("v", 0.0, 1.0, shape=(N,))
+    u = m.Beta("u", 2.0, 2.0, shape=(N,))
+    env = {"sca": [a, b, sg.as_tensor(0.37)], "vec": [v, u, sg.as_tensor(DATA), sg.as_tensor(POS), v[IDX]]}
+    for k in range(3):
+        m.Potential(f"pot{k}", _expr(rng, env, 4, bool(k % 2 == 0)))
+    return m
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_graphs_lower_to_programs_that_keep_value_and_gradient(seed):
+    m = _model(seed)
+    try:
+        spec = lower_to_spec(m)
+    except NotLowerable as e:      # (a program longer than the IR's 128 instructions is a refusal, not an error)
+        assert "instruction" in str(e) or "MAX_FACTOR_INSTR" in str(e) or "longer" in str(e), str(e)
+        pytest.skip(f"refused: {e}")
+    n = spec.n
+    rng = np.random.default_rng(1000 + seed)
+    # (not at q = 0: every variable equal means exact ties of DIFFERENT variables in maximum / minimum, where conventions differ --
+    # torch splits the gradient, PyTensor's `ScalarMaximum.L_op` credits the first operand, which is what the lowering emits.  Ties
+    # of the SAME quantity reached along two paths -- `minimum(switch(c, a, b), a)` -- are not exotic and are covered: this test
+    # found the opcode's own reverse rule crediting both operands there, twice the gradient)
+    for scale in (0.3, 0.6, 1.0):
+        q = rng.normal(size=n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert np.isfinite(lp0)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
