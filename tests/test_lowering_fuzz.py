@@ -109,3 +109,129 @@ def test_random_graphs_lower_to_programs_that_keep_value_and_gradient(seed):
         assert np.isfinite(lp0)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
+
+
+# ---- random MODELS: priors and likelihoods of the template families with parameters that are numbers, earlier variables or
+# expressions of them -- the template path (`_Lowering._factor`: unification against the reference's own `logp` forms, the Jacobian
+# terms of the value transforms, fast flags, the fall-back to the op-by-op path when a template's arguments are outside the affine
+# terms) against torch autograd of the graphs the reference's code built ----------------------------------------------------------
+_YR = np.array([0.3, -0.7, 1.9, 0.4, -1.1, 0.8])
+_YP = np.array([0.6, 1.4, 0.2, 2.7, 0.9, 1.1])
+_YU = np.array([0.12, 0.55, 0.81, 0.33, 0.67, 0.45])
+_YC = np.array([0.0, 3.0, 1.0, 2.0, 5.0, 1.0])
+_YB = np.array([1.0, 0.0, 1.0, 1.0, 0.0, 0.0])
+_G6 = np.array([2, 0, 1, 1, 2, 0])
+
+
+def _dist_model(seed):
+    rng = np.random.default_rng(7000 + seed)
+    m = sg.StubModel()
+    real, pos, unit = [], [], []            # variables (and expressions) by support
+
+    vec_ok = [False]        # (a scalar variable takes scalar parameters: with a vector parameter PyMC would make the variable a vector)
+
+    def pick(pool, const):
+        pool = [v for v in pool if vec_ok[0] or not v.type.shape]
+        if pool and rng.uniform() < 0.7:
+            return pool[rng.integers(len(pool))]
+        return const
+
+    def real_param():
+        r = pick(real, float(np.round(rng.normal(), 2)))
+        if isinstance(r, sg.Variable) and pos and rng.uniform() < 0.4:
+            return r + 0.5 * pick(pos, 1.0) * float(np.round(rng.normal(), 2))      # an affine / product term
+        return r
+
+    def pos_param():
+        p = pick(pos, float(np.round(rng.uniform(0.4, 2.5), 2)))
+        if isinstance(p, sg.Variable) and rng.uniform() < 0.3:
+            return m.math.exp(0.3 * pick(real, 0.2)) * p if real else 1.5 * p
+        return p
+
+    n_free = int(rng.integers(3, 7))
+    for i in range(n_free):
+        kind = rng.integers(0, 14)
+        shape = (3,) if rng.uniform() < 0.3 else ()
+        vec_ok[0] = bool(shape)
+        nm = f"x{i}"
+        if kind == 11:        # interval transform with constant bounds
+            lo = float(np.round(rng.uniform(-2.0, 0.0), 2))
+            (pos if lo >= 0 else real).append(m.Uniform(nm, lo, lo + float(np.round(rng.uniform(1.0, 3.0), 2)), shape=shape))
+            continue
+        if kind == 12:        # TruncatedNormal between constant bounds: interval transform over the bound arguments
+            lo = float(np.round(rng.uniform(-1.5, 0.0), 2))
+            up = lo + float(np.round(rng.uniform(1.5, 3.0), 2))
+            real.append(m.TruncatedNormal(nm, real_param(), pos_param(), lower=lo, upper=up, shape=shape))
+            continue
+        if kind == 13:
+            unit.append(m.Uniform(nm, 0.0, 1.0, shape=shape))
+            continue
+        if kind == 0:
+            real.append(m.Normal(nm, real_param(), pos_param(), shape=shape))
+        elif kind == 1:
+            pos.append(m.HalfNormal(nm, pos_param(), shape=shape))
+        elif kind == 2:
+            pos.append(m.HalfCauchy(nm, pos_param(), shape=shape))
+        elif kind == 3:
+            pos.append(m.Exponential(nm, pos_param(), shape=shape))
+        elif kind == 4:
+            pos.append(m.Gamma(nm, float(np.round(rng.uniform(1.2, 3.0), 2)), pos_param(), shape=shape))
+        elif kind == 5:
+            unit.append(m.Beta(nm, float(np.round(rng.uniform(1.2, 3.0), 2)), float(np.round(rng.uniform(1.2, 3.0), 2)), shape=shape))
+        elif kind == 6:
+            real.append(m.StudentT(nm, float(np.round(rng.uniform(2.5, 8.0), 1)), real_param(), pos_param(), shape=shape))
+        elif kind == 7:
+            real.append(m.Laplace(nm, real_param(), pos_param(), shape=shape))
+        elif kind == 8:
+            real.append(m.Cauchy(nm, real_param(), pos_param(), shape=shape))
+        elif kind == 9:
+            pos.append(m.LogNormal(nm, real_param(), pos_param(), shape=shape))
+        else:
+            pos.append(m.InverseGamma(nm, float(np.round(rng.uniform(2.2, 4.0), 2)), pos_param(), shape=shape))
+    vec_ok[0] = False
+    scal = lambda pool: [v for v in pool if not v.type.shape]              # noqa: E731  (likelihood parameters: scalars broadcast)
+    vecs = [v for v in real if v.type.shape]
+    for j in range(int(rng.integers(1, 4))):
+        kind = rng.integers(0, 10)
+        nm = f"y{j}"
+        if kind == 7 and vecs:      # varying intercepts: a vector variable gathered by a constant index, plus a scalar
+            m.Normal(nm, vecs[rng.integers(len(vecs))][_G6] + pick(scal(real), 0.3), pick(scal(pos), 0.9), observed=_YR)
+            continue
+        if kind == 8:               # a logit link written out
+            m.Bernoulli(nm, pick(scal(real), 0.2) + pick(scal(real), -0.4) * sg.as_tensor(_YR), observed=_YB)
+            continue
+        if kind == 9 and scal(unit):
+            m.Binomial(nm, 7.0, scal(unit)[rng.integers(len(scal(unit)))], observed=_YC)
+            continue
+        kind = kind % 7
+        rp = lambda: pick(scal(real), float(np.round(rng.normal(), 2)))          # noqa: E731
+        pp = lambda: pick(scal(pos), float(np.round(rng.uniform(0.5, 2.0), 2)))  # noqa: E731
+        if kind == 0:
+            m.Normal(nm, rp(), pp(), observed=_YR)
+        elif kind == 1:
+            m.StudentT(nm, 4.0, rp(), pp(), observed=_YR)
+        elif kind == 2:
+            m.Gamma(nm, float(np.round(rng.uniform(1.5, 3.0), 2)), pp(), observed=_YP)
+        elif kind == 3:
+            m.Poisson(nm, pp(), observed=_YC)
+        elif kind == 4:
+            m.LogNormal(nm, rp(), pp(), observed=_YP)
+        elif kind == 5:
+            m.Laplace(nm, rp(), pp(), observed=_YR)
+        else:
+            m.Exponential(nm, pp(), observed=_YP)
+    return m
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_models_of_the_template_families_keep_value_and_gradient(seed):
+    m = _dist_model(seed)
+    spec = lower_to_spec(m)
+    rng = np.random.default_rng(2000 + seed)
+    for scale in (0.0, 0.4, 0.8):
+        q = rng.normal(size=spec.n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert np.isfinite(lp0)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
