@@ -1536,28 +1536,104 @@ class _Lowering:
                 return None       # (an element of beta that the predictor does not use would be a column of zeros: left to the element-wise path)
             return np.column_stack([cols[k] for k in range(self.spec.vars[kb].size)]), kb, icpt_
 
-        got, icpt = dot_of(eta), None
+        def peeled(n):
+            """eta = c0 * dot(X, beta) [+ alpha] [+ constants]: the predictor of an everyday regression written with an offset
+            (`+ np.log(exposure)` under a Poisson likelihood), a constant intercept, a scaled or negated product, a difference.
+            -> (X scaled, beta, intercept variable | None, offset [N] | None, beta's tree), or None."""
+            N_ = np.asarray(observed).size
+            terms, stack = [], [(n, 1.0)]
+            while stack:
+                t, sc = stack.pop()
+                if t[0] == "add":
+                    stack.extend([(t[1], sc), (t[2], sc)])
+                elif t[0] == "sub":
+                    stack.extend([(t[1], sc), (t[2], -sc)])
+                elif t[0] == "neg":
+                    stack.append((t[1], -sc))
+                elif t[0] == "mul" and t[1][0] == "const" and np.asarray(t[1][1]).size == 1 and t[2][0] != "const":
+                    stack.append((t[2], sc * float(np.asarray(t[1][1]).reshape(-1)[0])))
+                elif t[0] == "mul" and t[2][0] == "const" and np.asarray(t[2][1]).size == 1 and t[1][0] != "const":
+                    stack.append((t[1], sc * float(np.asarray(t[2][1]).reshape(-1)[0])))
+                else:
+                    terms.append((t, sc))
+            dots = [(t, sc) for t, sc in terms if t[0] == "dot"]
+            if len(dots) > 1:
+                return None
+            X_, kb_, btree = None, None, None
+            if dots:
+                got_ = dot_of(dots[0][0])
+                if got_ is None:
+                    return None
+                X_, kb_, btree = got_[0] * dots[0][1], got_[1], dots[0][0][2]
+            icpt_, off, cols, kvec, extra = None, np.zeros(N_), {}, None, []
+            for t, sc in terms:
+                if t[0] == "dot":
+                    continue
+                if t[0] == "const" and np.asarray(t[1]).size in (1, N_):
+                    off = off + sc * np.broadcast_to(np.asarray(t[1], dtype="float64").reshape(-1), (N_,))
+                    continue
+                # an element of ONE vector variable times a constant data vector: a column of the written-out form
+                elem, vec = None, None
+                if t[0] == "index":
+                    elem, vec = t, np.ones(N_)
+                elif t[0] == "mul":
+                    for x, y_ in ((t[1], t[2]), (t[2], t[1])):
+                        if x[0] == "index" and y_[0] == "const" and np.asarray(y_[1]).size in (1, N_):
+                            elem, vec = x, np.broadcast_to(np.asarray(y_[1], dtype="float64").reshape(-1), (N_,))
+                if elem is not None and not dots:
+                    k = self._as_var(elem[1])
+                    if k is None or (kvec is not None and k != kvec):
+                        return None
+                    kvec, btree = k, elem[1]
+                    cols[elem[2]] = cols.get(elem[2], 0.0) + sc * vec
+                    continue
+                ki = self._as_var(t)
+                if ki is not None and sc == 1.0 and icpt_ is None and self.spec.vars[ki].size == 1 and self.spec.vars[ki].transform == ms.TR_NONE:
+                    icpt_ = ki
+                    continue
+                if self._tsize(t) == 1:
+                    # any other scalar term (a scaled intercept, a second intercept, a scalar expression): a constant column
+                    # against a coefficient that is that scalar
+                    extra.append((t, sc))
+                    continue
+                return None
+            if not dots:
+                if kvec is None:
+                    return None
+                fv = self.spec.vars[kvec]
+                if fv.transform != ms.TR_NONE or len(fv.shape) != 1 or not 1 <= fv.size <= 512 or sorted(cols) != list(range(fv.size)):
+                    return None
+                X_, kb_ = np.column_stack([cols[k] for k in range(fv.size)]), kvec
+            return X_, kb_, icpt_, (off if np.any(off != 0.0) else None), btree, extra
+
+        got, icpt, offset, beta_tree, extra = None, None, None, None, []
+        pe = peeled(eta)
+        if pe is not None:
+            got, icpt, offset, beta_tree, extra = (pe[0], pe[1]), pe[2], pe[3], pe[4], pe[5]
         if got is None:
             wo = written_out(eta)
             if wo is not None:
                 got, icpt = (wo[0], wo[1]), wo[2]
-        if got is None and eta[0] == "add":
-            for x, y in ((eta[1], eta[2]), (eta[2], eta[1])):
-                got = dot_of(x)
-                if got is None:
-                    continue
-                ki = self._as_var(y)
-                if ki is None or self.spec.vars[ki].size != 1 or self.spec.vars[ki].transform != ms.TR_NONE:
-                    got = None
-                    continue
-                icpt = ki
-                break
         if got is None:
             return False
         X, kb = got
         y = np.asarray(observed, dtype="float64").ravel()
         if y.size != X.shape[0]:
             return False
+        if offset is not None or extra:
+            # a constant added to the predictor: one more column of X (the offsets) against a coefficient that is the constant 1;
+            # a further scalar term c * s: a column of c against the coefficient s -- beta becomes a derived vector
+            # [beta..., s..., 1] (NUTS_D_DERIVED; the concatenation is a selection over constant masks)
+            pieces = [kb[1] if isinstance(kb, tuple) else beta_tree]
+            for t_, sc_ in extra:
+                X = np.column_stack([X, np.full(X.shape[0], sc_)])
+                pieces.append(t_)
+            if offset is not None:
+                X = np.column_stack([X, offset])
+                pieces.append(_const(np.array([1.0])))
+            if X.shape[1] > 512:
+                return False
+            kb = ("derived", ("join", 0, *pieces))
         if isinstance(kb, tuple):     # ("derived", expression tree)
             saved = (self._prog, self._prog_size, self._prog_memo, self._prog_cse)
             self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}

@@ -235,3 +235,64 @@ def test_random_models_of_the_template_families_keep_value_and_gradient(seed):
         assert np.isfinite(lp0)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
+
+
+# ---- random WRITINGS of a regression: the linear predictor as `pm.math.dot(X, beta)`, `X @ beta`, written out column by column, with
+# the intercept before or after, coefficients that are a variable or an expression of variables (non-centred), three families -- the
+# GLM node's recognition (`_Lowering._glm`) and its derived-vector form against torch autograd of the graph ----------------------
+def _glm_model(seed):
+    rng = np.random.default_rng(9000 + seed)
+    P, N = int(rng.integers(2, 7)), 14
+    X = np.round(rng.normal(size=(N, P)), 3)
+    m = sg.StubModel()
+    how = rng.integers(0, 3)
+    if how == 0:
+        beta = m.Normal("beta", 0.0, 1.5, shape=(P,))
+    elif how == 1:                               # non-centred with scalar hyper-parameters
+        mu = m.Normal("mu", 0.0, 1.0)
+        tau = m.HalfNormal("tau", 1.0)
+        beta = mu + tau * m.Normal("z", 0.0, 1.0, shape=(P,))
+    else:                                        # ... with a hyper-parameter per coefficient
+        mu = m.Normal("mu", 0.0, 1.0, shape=(P,))
+        tau = m.HalfNormal("tau", 1.0, shape=(P,))
+        beta = mu + tau * m.Normal("z", 0.0, 1.0, shape=(P,))
+    writing = rng.integers(0, 3)
+    if writing == 0:
+        eta = m.math.dot(sg.as_tensor(X), beta)
+    elif writing == 1:
+        eta = sg.as_tensor(X) @ beta
+    elif how == 0:                               # written out (elements of a VARIABLE: `beta[0] * x0 + beta[1] * x1 + ...`)
+        eta = beta[0] * sg.as_tensor(X[:, 0])
+        for k in range(1, P):
+            eta = eta + beta[k] * sg.as_tensor(X[:, k])
+    else:
+        eta = m.math.dot(sg.as_tensor(X), beta)
+    icpt = rng.integers(0, 3)
+    if icpt == 1:
+        a = m.Normal("alpha", 0.0, 2.0)
+        eta = a + eta if rng.uniform() < 0.5 else eta + a
+    elif icpt == 2:
+        eta = eta + 0.35
+    fam = rng.integers(0, 3)
+    if fam == 0:
+        s_ = m.HalfNormal("s", 1.0) if rng.uniform() < 0.6 else 0.8
+        m.Normal("y", eta, s_, observed=np.round(rng.normal(size=N), 3))
+    elif fam == 1:
+        m.Bernoulli("y", eta, observed=(rng.uniform(size=N) < 0.5).astype("float64"))
+    else:
+        m.Poisson("y", m.math.exp(0.3 * eta) if rng.uniform() < 0.5 else m.math.exp(eta), observed=rng.poisson(2.0, size=N).astype("float64"))
+    return m
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_writings_of_a_regression_keep_value_and_gradient(seed):
+    m = _glm_model(seed)
+    spec = lower_to_spec(m)
+    rng = np.random.default_rng(3000 + seed)
+    for scale in (0.0, 0.3, 0.6):
+        q = rng.normal(size=spec.n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert np.isfinite(lp0)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
