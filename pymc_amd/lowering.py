@@ -1340,6 +1340,15 @@ class _Lowering:
         if body[0] != "mul":
             return False
         for xs, bs in ((body[1], body[2]), (body[2], body[1])):
+            if xs[0] == "const" and xs[1].ndim == 2 and bs[0] == "add":
+                # the gather written inside: mu + sigma * z[g] -- the same rows as (mu + sigma * z)[g] (mu and sigma broadcast over them)
+                for m_, sz in ((bs[1], bs[2]), (bs[2], bs[1])):
+                    if sz[0] != "mul":
+                        continue
+                    for s_, zt in ((sz[1], sz[2]), (sz[2], sz[1])):
+                        if zt[0] == "take" and zt[2][0] == "const" and self._as_var(zt[1]) is not None and self._as_var(m_) is not None \
+                                and self._as_var(s_) is not None:
+                            bs = ("take", ("add", m_, ("mul", s_, zt[1])), zt[2])
             if xs[0] != "const" or xs[1].ndim != 2 or bs[0] != "take" or bs[2][0] != "const":
                 continue
             X, gidx, beta = xs[1], bs[2][1], bs[1]
