@@ -1068,6 +1068,10 @@ class _Lowering:
             out = self._program(("le", ("abs", ("sub", a_, b_)), ("add", _const(1e-8), ("mul", _const(1e-5), ("abs", b_)))))
             self._prog_memo[id(node)] = (node, out)
             return out
+        elif op == "index":                       # `beta[k]`: one element of a vector (kept as a node for the GLM's written-out form)
+            out = self._program(self._index(node[1], np.array([int(node[2])])))
+            self._prog_memo[id(node)] = (node, out)
+            return out
         elif op in ("maximum", "minimum") and len(node) == 3:
             # element-wise `pt.maximum(x, y)` / `pt.minimum(x, y)`: switch(x >= y, x, y) / switch(x <= y, x, y).  The values are those of
             # the opcode; the gradient at a TIE is PyTensor's (`ScalarMaximum.L_op`, `ScalarMinimum.L_op`: the first operand takes all
@@ -1137,6 +1141,8 @@ class _Lowering:
             return sum(self._tsize(x) for x in node[2:])
         if k == "joinnd":
             return len(node[1])
+        if k == "index":
+            return 1
         if k == "take_along_axis":
             return self._tsize(node[2])
         if k in ("all", "any") and len(node) == 4 and node[3] is not None:

@@ -296,3 +296,88 @@ def test_random_writings_of_a_regression_keep_value_and_gradient(seed):
         assert np.isfinite(lp0)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
+
+
+# ---- shapes: matrices built by broadcasting a vector [5] against a vector [3], reduced along either axis (sum, max, logsumexp),
+# softmax rows, columns picked by slices, stacks and concatenations, cumulative sums, piecewise assembly (`set_subtensor`) -- the
+# shape-aware half of the op-by-op lowering (broadcasts -> gathers, index push-down, unrolled reductions) --------------------------
+W3 = np.array([0.7, -0.4, 1.2])
+
+
+def _shape_model(seed):
+    rng = np.random.default_rng(11000 + seed)
+    m = sg.StubModel()
+    v = m.Normal("v", 0.0, 1.0, shape=(N,))
+    w = m.Normal("w", 0.0, 1.0, shape=(3,))
+    s = m.HalfNormal("s", 1.0)
+    col = lambda x: x[:, None]          # noqa: E731
+    row = lambda x: x[None, :]          # noqa: E731
+
+    def mat():
+        k = rng.integers(0, 6)
+        if k == 0:
+            return col(v) * row(w)
+        if k == 1:
+            return col(v) + row(sg.as_tensor(W3)) * s
+        if k == 2:
+            return pt.tanh(col(sg.as_tensor(DATA)) - row(w))
+        if k == 3:
+            return col(pt.sigmoid(v)) * row(pt.exp(0.3 * w))
+        if k == 4:
+            return pt.sqr(col(v) - row(w)) * 0.5
+        return col(v) * row(sg.as_tensor(W3)) + s
+
+    def vec5():
+        k = rng.integers(0, 8)
+        M = mat()
+        if k == 0:
+            return M.sum(axis=1)
+        if k == 1:
+            return pt.logsumexp(M, axis=1)
+        if k == 2:
+            return pt.max(M, axis=1) if hasattr(pt, "max") else M.sum(axis=1)
+        if k == 3:
+            return M[:, int(rng.integers(0, 3))]
+        if k == 4:
+            return pt.log(pt.softmax(M, axis=-1)[:, int(rng.integers(0, 3))])
+        if k == 5:
+            return (M[:, 1:] - M[:, :-1]).sum(axis=1)
+        if k == 6:
+            return pt.cumsum(pt.softplus(M), axis=1)[:, 2]
+        return (M * row(sg.as_tensor(W3))).sum(axis=-1)
+
+    def vec3():
+        k = rng.integers(0, 5)
+        if k == 0:
+            return mat().sum(axis=0)
+        if k == 1:
+            return pt.cumsum(pt.exp(0.2 * w), axis=0)
+        if k == 2:
+            return pt.stack([w[0], w[1] * s, pt.tanh(w[2])])
+        if k == 3:
+            x = pt.set_subtensor(pt.empty((3,))[0:1], w[0:1])
+            return pt.set_subtensor(x[1:], pt.exp(0.3 * w[1:]))
+        return pt.concatenate([w[:2], sg.as_tensor(np.array([0.25]))])
+
+    m.Potential("p5", pt.tanh(vec5()) + 0.1 * vec5())
+    m.Potential("p3", pt.sqr(vec3()) * -0.5)
+    m.Potential("p1", pt.sum(vec3() * sg.as_tensor(W3), axis=0) + pt.sum(pt.tanh(vec5()), axis=0))
+    return m
+
+
+@pytest.mark.parametrize("seed", range(100))
+def test_random_shapes_keep_value_and_gradient(seed):
+    m = _shape_model(seed)
+    try:
+        spec = lower_to_spec(m)
+    except NotLowerable as e:
+        assert "instruction" in str(e), str(e)
+        pytest.skip(f"refused: {e}")
+    rng = np.random.default_rng(4000 + seed)
+    for scale in (0.3, 0.6, 1.0):
+        q = rng.normal(size=spec.n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert np.isfinite(lp0)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
