@@ -1765,8 +1765,25 @@ class _Lowering:
         finally:
             self._prog = None
 
+    def _widen_gathers(self, args, size):
+        """A gather whose index vector has ONE entry inside a factor of `size` elements (`beta[0]` as the mean of a vector variable): the
+        engine wants an index per element of the factor (include/nuts_mi355.h NUTS_OP_GATHER) -- the entry repeated."""
+        def wide(o):
+            if o.kind != ms.OP_GATHER or size <= 1 or self.spec.data[int(o.c)].size != 1:
+                return o
+            idx = np.full(size, float(np.asarray(self.spec.data[int(o.c)]).reshape(-1)[0]))
+            key = ("gather", o.ref, idx.tobytes())
+            if key not in self._gather_ids:
+                self.spec.data.append(np.ascontiguousarray(idx))
+                self._gather_ids[key] = len(self.spec.data) - 1
+            return ms.Operand(ms.OP_GATHER, float(self._gather_ids[key]), o.ref)
+        if self._prog:
+            self._prog[:] = [ms.Instr(i.op, wide(i.x), wide(i.y), i.k, wide(i.z)) for i in self._prog]
+        return tuple(ms.Term(wide(t.a), wide(t.b), wide(t.c)) for t in args)
+
     def _emit(self, dist, args, konst, name):
         size = max(self._size(a) for a in args)
+        args = self._widen_gathers(args, size)
         for o in [o for t in args for o in (t.a, t.b, t.c)] + [o for ins in self._prog for o in (ins.x, ins.y, ins.z)]:
             if self._osize(o) not in (1, size):     # every operand broadcasts against the factor: one element or the factor's size
                 raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
