@@ -673,3 +673,20 @@ def test_a_stray_element_of_a_vector_is_an_ordinary_operand():
     spec = lower_to_spec(m)
     assert spec.glm_rows is not None and spec.glm_rows.intercept is None
     np.testing.assert_allclose(spec.glm_rows.X, np.column_stack([x1 + x2, x2]), rtol=1e-15)
+
+
+def test_the_lowered_specs_of_the_committed_graphs_are_the_ones_the_device_tests_ran_on():
+    """tests/golden/lowered_spec_digests.json: a digest of the spec every committed reference-built graph lowers to (variables,
+    factors with their programs, data vectors, dense nodes).  The `-m gpu` tests of these models ran on exactly these specs; a change
+    to the lowering that alters one of them must be a decision (re-run the device tests, then `python
+    tests/golden/make_spec_digests.py`), not a side effect."""
+    import json
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_spec_digests as msd
+
+    with open(msd.OUT) as fh:
+        want = json.load(fh)
+    got = msd.run()
+    assert sorted(got) == sorted(want)
+    assert [k for k in got if got[k] != want[k]] == []
