@@ -648,7 +648,8 @@ def reference():
         _, tree = _parsed(rel)
         for name in names:
             have = {c.name for c in _find(tree, name).body if isinstance(c, ast.FunctionDef)}
-            ref_class(rel, name, [m for m in ("dist", "get_alpha_beta", "_get_alpha_beta", "get_n_p", "get_mu_lam_phi", "get_kappa", "logp") if m in have], _DistBase, ns)
+            ref_class(rel, name, [m for m in ("dist", "get_alpha_beta", "_get_alpha_beta", "get_n_p", "get_mu_lam_phi", "get_kappa", "logp", "logcdf", "logccdf")
+                                  if m in have], _DistBase, ns)
     # `_logprob_helper(Normal.dist(mu, sigma), value)` (continuous.py:731, :2384): dispatch to the logp of the RV's distribution
     ns["_logprob_helper"] = lambda rv, value: rv.dist_cls.logp(value, *rv)
     for name in ("LogTransform", "IntervalTransform", "LogOddsTransform"):
@@ -680,6 +681,20 @@ def reference():
     ref_class("distributions/distribution.py", "DiracDelta", ["dist", "logp"], _DistBase, ns)
     ns["Mixture"] = type("Mixture", (), {"dist": staticmethod(lambda w, comp_dists, **kw: (w, comp_dists))})   # (what `_zero_inflated_mixture(name=None, ...)` returns: its arguments)
     ref_function("distributions/mixture.py", "_zero_inflated_mixture", ns)
+    # `pm.Censored` (distributions/censored.py:132-146 -> `clip` of the base variable; logprob/censoring.py:198-250 `clip_logprob`): the
+    # dispatchers it calls resolve to the base distribution's own `logp` / `logcdf` / `logccdf` (logprob/abstract.py:129-145: log1mexp of
+    # the logcdf when the distribution registers no logccdf)
+    ns["_logprob"] = lambda op, values, *inputs, **kw: op.dist_cls.logp(values[0], *inputs)
+    ns["_logcdf"] = lambda op, value, *inputs: op.dist_cls.logcdf(value, *inputs)
+
+    def _logccdf_helper(rv, value):
+        cls_ = rv.owner.op.dist_cls
+        if hasattr(cls_, "logccdf"):
+            return cls_.logccdf(value, *rv.owner.inputs)
+        return pt.log1mexp(cls_.logcdf(value, *rv.owner.inputs))
+
+    ns["_logccdf_helper"] = _logccdf_helper
+    ref_function("logprob/censoring.py", "clip_logprob", ns)
     ns["sigmoid"] = pt.sigmoid          # discrete.py:52 `from pymc.math import sigmoid`
     ref_class("distributions/discrete.py", "OrderedLogistic", ["compute_p"], object, ns)
     # Dirichlet (distributions/multivariate.py:543-584: `dist`, `logp`) under its default transform (`simplex_cont_transform`,
@@ -918,6 +933,31 @@ class StubModel:
         p = diff(concat([0, sigmoid(cutpoints - eta[..., None]), 1])) -- the reference's own `compute_p`."""
         p = reference()["OrderedLogistic"].compute_p(eta, cutpoints)
         return self.Categorical(name, p=p, observed=observed)
+
+    def Censored(self, name, dist, lower, upper, observed):
+        """`pm.Censored(name, Dist.dist(...), lower=, upper=, observed=y)` (distributions/censored.py): the reference's `clip_logprob` over
+        the base distribution's logp / logcdf / logccdf; `dist` = ("Normal", dict(mu=..., sigma=...)); a bound of None is open."""
+        ref = reference()
+        cls_name, kw = dist
+
+        class _Op:
+            dist_cls = ref[cls_name]
+            name = None
+
+        class _Owner:
+            op = _Op()
+            inputs = list(_dist(cls_name, **kw))
+
+        class _Base:
+            owner = _Owner()
+            dtype = "float64"
+            name = None
+
+        base = _Base()
+        lo = base if lower is None else as_tensor(lower)
+        up = base if upper is None else as_tensor(upper)
+        fn = lambda value: ref["clip_logprob"](None, (value,), base, lo, up)   # noqa: E731
+        return self._add(_RV(name, np.shape(observed), fn, (), None, observed))
 
     def ZeroInflatedPoisson(self, name, psi, mu, observed):
         """`pm.ZeroInflatedPoisson(name, psi=psi, mu=mu, observed=y)` (mixture.py:560-575, 577-640): the reference's

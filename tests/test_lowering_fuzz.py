@@ -381,3 +381,34 @@ def test_random_shapes_keep_value_and_gradient(seed):
         assert np.isfinite(lp0)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
+
+
+def test_censored_likelihoods_lower_op_by_op():
+    """`pm.Censored(name, Normal.dist(mu, sigma), lower, upper, observed=y)` (distributions/censored.py; logprob/censoring.py:198-250
+    `clip_logprob` over the base distribution's own `logp`, `logcdf`, `logccdf` -- executed from the reference by tests/stubgraph.py):
+    two-sided, right-censored, and an Exponential whose logccdf is `log1mexp(logcdf)`.  Host only (see the module docstring)."""
+    rng = np.random.default_rng(0)
+    raw = rng.normal(0.5, 1.2, size=20)
+
+    def both(m):
+        m.Censored("y", ("Normal", dict(mu=m.Normal("mu", 0.0, 2.0), sigma=m.HalfNormal("s", 1.0))), -0.5, 1.5, observed=np.clip(raw, -0.5, 1.5))
+
+    def right(m):
+        m.Censored("y", ("Normal", dict(mu=m.Normal("mu", 0.0, 2.0), sigma=m.HalfNormal("s", 1.0))), None, 1.5, observed=np.minimum(raw, 1.5))
+
+    def expo(m):
+        m.Censored("y", ("Exponential", dict(lam=m.HalfNormal("l", 1.0))), None, 2.0, observed=np.minimum(rng.exponential(1.0, size=15), 2.0))
+
+    for build in (both, right, expo):
+        m = sg.StubModel()
+        build(m)
+        spec = lower_to_spec(m)
+        assert spec.factors[-1].prog            # (no template: the graph itself is the program)
+        for scale in (0.0, 0.2, 0.4):
+            q = np.random.default_rng(3).normal(size=spec.n) * scale
+            lp0, g0 = gt.joint_logp_grad(m, q)
+            lp, g = ref_models.evaluate(spec, q)
+            # (far in the tails autograd multiplies the zero adjoint of an unselected `switch` branch by an infinite derivative -- NaN, in
+            # torch as in PyTensor; the interpreter does not propagate zero adjoints.  Compared where autograd is finite.)
+            assert np.all(np.isfinite(g0))
+            assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)) and np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
