@@ -204,8 +204,17 @@ def _dist_model(seed):
             m.Binomial(nm, 7.0, scal(unit)[rng.integers(len(scal(unit)))], observed=_YC)
             continue
         kind = kind % 7
-        rp = lambda: pick(scal(real), float(np.round(rng.normal(), 2)))          # noqa: E731
-        pp = lambda: pick(scal(pos), float(np.round(rng.uniform(0.5, 2.0), 2)))  # noqa: E731
+        def rp():      # a likelihood's location: a number, a scalar variable, or a vector variable gathered per observation
+            vr = [v for v in real if v.type.shape]
+            if vr and rng.uniform() < 0.3:
+                return vr[rng.integers(len(vr))][_G6]
+            return pick(scal(real), float(np.round(rng.normal(), 2)))
+
+        def pp():      # ... its scale / rate likewise
+            vp = [v for v in pos if v.type.shape]
+            if vp and rng.uniform() < 0.3:
+                return vp[rng.integers(len(vp))][_G6]
+            return pick(scal(pos), float(np.round(rng.uniform(0.5, 2.0), 2)))
         if kind == 0:
             m.Normal(nm, rp(), pp(), observed=_YR)
         elif kind == 1:
