@@ -384,6 +384,14 @@ class CategoricalGibbsMetropolis:
                 self._plan_ahead = None
         if got is None:
             got = (*plan_sweep(self.rng, self._order, self._k_of_dim, self.shuffle_dims), None)
+            if self._handle:
+                # a plan drawn on this thread is staged from this thread, into the slot the look-ahead never uses -- and BEFORE the
+                # look-ahead's threads exist: the engine creates its upload stream on the first staging call, which two drawer threads
+                # arriving together must not both believe to be theirs
+                lib_ = _lib.load()
+                slot_ = int(lib_.nuts_gibbs_stage_slots()) - 1
+                _lib.check(lib_.nuts_gibbs_stage(self._handle, slot_, self._order.ctypes.data, got[0].ctypes.data, _lib.dptr(got[1])), "nuts_gibbs_stage")
+                got = (got[0], got[1], slot_)
         if (self._plan_ahead is None and _PLAN_PREFETCH_ON and len(self._order) >= _PLAN_PREFETCH_MIN and bg.state.get("bit_generator") == "PCG64"
                 and bool(np.all(self._k_of_dim == self._k_of_dim[0]))):
             lib, g = _lib.load(), self._handle      # (no handle yet -- host-only use of the plans: nothing is staged)
