@@ -2083,12 +2083,28 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
     dets = getattr(model, "deterministics", None) or {}
     if not isinstance(dets, dict):
         dets = {getattr(v, "name", f"deterministic{i}"): v for i, v in enumerate(dets)}
+    n_host_only = None
     for name, var in dets.items():
         low._prog, low._prog_size, low._prog_memo, low._prog_cse = [], [], {}, {}
         if "_gather_ids" not in low.__dict__:
             low._gather_ids = {}
         try:
-            t = low.term(build_tree(var, memo))
+            try:
+                t = low.term(build_tree(var, memo))
+            except NotLowerable:
+                # shapes, slices, piecewise vectors (the constrained value of an ordered variable: `cumsum` of a `set_subtensor`): the
+                # shape-aware walk, element-wise over the Deterministic's own elements
+                low._prog, low._prog_size, low._prog_memo, low._prog_cse = [], [], {}, {}
+                if n_host_only is None:
+                    n_host_only = len(low.spec.data)       # masks and index vectors from here on are read by the host's evaluation only
+                node = build_tree(var, {"__shapes__": True})
+                low._const_cache = {}
+                try:
+                    low._fsize = low._tsize(node)
+                    t = low.term(node)
+                finally:
+                    low._const_cache, low._fsize = None, 0
+            t = low._widen_gathers((t,), low._size(t))[0]
             low.spec.deterministics[name] = (tuple(low._prog), t, low._size(t))
         except NotLowerable as e:
             import logging
@@ -2096,4 +2112,6 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
             logging.getLogger("pymc_amd").warning("Deterministic %r is not recorded in the trace: %s", name, e)
         finally:
             low._prog = None
+    if n_host_only is not None and len(low.spec.data) > n_host_only and all(i < n_host_only for i in low.spec.extra.values()):
+        low.spec.n_device_data = n_host_only      # (a `pm.Data` that only a Deterministic reads stays settable: then everything is uploaded)
     return low.spec

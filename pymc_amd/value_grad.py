@@ -23,7 +23,8 @@ from pymc_amd.model_spec import ModelSpec
 def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
     """ModelSpec -> nuts_model_spec (+ the numpy buffers that must outlive the call)."""
     keep = []
-    nv, nf, nd = len(spec.vars), len(spec.factors), len(spec.data)
+    data = spec.data if getattr(spec, "n_device_data", None) is None else spec.data[: spec.n_device_data]   # (the rest: host-only constants of Deterministics)
+    nv, nf, nd = len(spec.vars), len(spec.factors), len(data)
     vars_c = (_lib.Var * max(nv, 1))()
     for i, v in enumerate(spec.vars):
         vars_c[i] = _lib.Var(v.offset, v.size, v.transform, 0, v.lower, v.upper)
@@ -48,10 +49,10 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
         fac_c[i] = fc
     refs = (_lib.DataRef * max(nd, 1))()
     off = 0
-    for i, d in enumerate(spec.data):
+    for i, d in enumerate(data):
         refs[i] = _lib.DataRef(off, d.size)
         off += d.size
-    pool = np.concatenate(spec.data).astype("float64") if nd else np.zeros(1)
+    pool = np.concatenate(data).astype("float64") if nd else np.zeros(1)
     keep += [vars_c, fac_c, refs, pool, ins_c]
     s = _lib.ModelSpecC()
     s.instrs, s.n_instrs = (ins_c if n_instr else None), n_instr

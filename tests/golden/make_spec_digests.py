@@ -31,7 +31,7 @@ def digest(spec) -> str:
     put([(v.name, v.value_name, tuple(v.shape), v.transform, v.offset, float(v.lower), float(v.upper)) for v in spec.vars])
     for f in spec.factors:
         put((f.name, f.dist, f.size, float(f.konst), f.args, [(i.op, i.x, i.y, i.z, float(i.k)) for i in f.prog]))
-    for d in spec.data:
+    for d in spec.data[: getattr(spec, "n_device_data", None)]:      # (what the device is given: not the host-only constants of Deterministics)
         h.update(np.ascontiguousarray(np.asarray(d, dtype="float64")).tobytes())
     for node in (spec.logit_rows, spec.mvnormal, getattr(spec, "mixture_rows", None), getattr(spec, "glm_rows", None)):
         if node is None:

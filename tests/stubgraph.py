@@ -805,6 +805,10 @@ class StubModel:
 
     def _add(self, rv):
         (self.free if rv.observed is None else self.obs).append(rv)
+        if rv.observed is None and rv.transform == "ordered":
+            # the trace holds the variable itself next to its value variable (`model.unobserved_value_vars`, model/core.py:944-966): for
+            # the transforms the IR has a code for, the backend applies `backward`; for this one the graph is the recipe
+            self.deterministics[rv.name] = rv.expr
         return rv.expr
 
     def _rv(self, cls_name, name, shape, params, transform, observed, **kw):

@@ -90,6 +90,27 @@ def test_what_each_model_lowers_to():
     assert spec.mvnormal is not None and spec.glm_rows is not None and spec.glm_rows.beta == spec.mvnormal.var and not spec.factors
 
 
+def test_an_ordered_variable_is_recorded_in_the_trace_beside_its_value_variable():
+    """`model.unobserved_value_vars` (model/core.py:944-966) puts the variable itself in the trace next to `mu_ordered__`.  The IR has no
+    code for `Ordered` (distributions/transforms.py:86-117), so `backward` -- `cumsum(set_subtensor(x[..., 1:], exp(x[..., 1:])))`, as the
+    reference's code wrote it into the committed graph -- is lowered as a Deterministic by the shape-aware walk; its mask constants stay
+    on the host (`n_device_data`)."""
+    from pymc_amd.backends import NDArray
+
+    spec = _committed("mixture_with_ordered_means")
+    prog, term, size = spec.deterministics["mu"]
+    assert size == 3 and spec.n_device_data is not None and spec.n_device_data < len(spec.data)
+    tr = NDArray(model=spec)
+    tr.setup(3, 0)
+    q = np.random.default_rng(5).normal(size=(3, spec.n))
+    tr.record_batch(q, None)
+    off = [v.offset for v in spec.vars if v.value_name == "mu_ordered__"][0]
+    x = q[:, off : off + 3]
+    np.testing.assert_allclose(tr.samples["mu"], np.cumsum(np.concatenate([x[:, :1], np.exp(x[:, 1:])], axis=1), axis=1), rtol=1e-15)
+    np.testing.assert_array_equal(tr.samples["mu_ordered__"], x)
+    assert np.all(np.diff(tr.samples["mu"], axis=1) > 0)
+
+
 def test_a_failed_parameter_check_kills_the_whole_factor():
     """`check_parameters` (dist_math.py:50-74) stays in the program as NUTS_E_CHECK: nu <= 0 cannot happen under the log transform, so the
     check is exercised on an untransformed parameter."""

@@ -421,3 +421,62 @@ def test_censored_likelihoods_lower_op_by_op():
             # torch as in PyTensor; the interpreter does not propagate zero adjoints.  Compared where autograd is finite.)
             assert np.all(np.isfinite(g0))
             assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)) and np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
+
+
+# ---- the same random graphs as `pm.Deterministic`s (model/core.py:1940-2005): what the trace records (backends/base.py:183-191) is the
+# graph's value at the draw -- the lowered program evaluated by the host at the constrained values (pymc_amd/model_spec.py
+# `eval_program`), against torch evaluation of the graph at the raw point --------------------------------------------------------------
+def _recorded(m, spec, qs):
+    from pymc_amd.backends import NDArray
+
+    tr = NDArray(model=spec)
+    tr.setup(len(qs), 0)
+    tr.record_batch(np.asarray(qs), None)
+    torch = gt._torch()
+    want = {}
+    for name, var in m.deterministics.items():
+        rows = []
+        for q in qs:
+            qt = torch.tensor(q, dtype=torch.float64)
+            values, off = {}, 0
+            for v in m.value_vars:
+                shp = tuple(m.value_shapes[v.name])
+                size = int(np.prod(shp)) if shp else 1
+                values[id(v)] = qt[off:off + size].reshape(shp)
+                off += size
+            rows.append(np.asarray(gt.evaluate(var, values, {}).to(torch.float64).numpy(), dtype="float64").ravel())
+        want[name] = np.stack(rows)
+    return tr, want
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_graphs_as_deterministics_are_recorded_with_the_graphs_values(seed, caplog):
+    rng = np.random.default_rng(21000 + seed)
+    if seed % 2:
+        m = _shape_model(seed)
+        v, w, s = (r.expr for r in m.free)
+        d = {"d_cum": pt.cumsum(pt.exp(0.2 * w), axis=0), "d_outer": (v[:, None] * w[None, :]).sum(axis=1) + s,
+             "d_piece": pt.set_subtensor(pt.set_subtensor(pt.empty((3,))[0:1], w[0:1])[1:], pt.exp(0.3 * w[1:])),
+             "d_soft": pt.softmax(v[:, None] * sg.as_tensor(W3)[None, :] + s, axis=-1)[:, int(rng.integers(0, 3))],
+             "d_cat": pt.concatenate([w[:2] * s, sg.as_tensor(np.array([0.25]))])}
+    else:
+        m = _model(seed)
+        a, b, v, u = (r.expr for r in m.free)
+        env = {"sca": [a, b, sg.as_tensor(0.37)], "vec": [v, u, sg.as_tensor(DATA), sg.as_tensor(POS), v[IDX]]}
+        d = {f"d{k}": _expr(rng, env, 4, bool(k % 2 == 0)) for k in range(3)}
+    for name, g in d.items():
+        m.Deterministic(name, g)
+    try:
+        with caplog.at_level("WARNING", logger="pymc_amd"):
+            spec = lower_to_spec(m)
+    except NotLowerable as e:
+        assert "instruction" in str(e) or "longer" in str(e), str(e)
+        pytest.skip(f"refused: {e}")
+    left_out = [r.getMessage() for r in caplog.records if "not recorded" in r.getMessage()]
+    assert all("instruction" in t or "longer" in t for t in left_out), left_out      # (only the program-length limit may leave one out)
+    qs = np.random.default_rng(5000 + seed).normal(size=(3, spec.n)) * 0.7
+    tr, want = _recorded(m, spec, qs)
+    assert len(spec.deterministics) + len(left_out) == len(d)
+    for name in spec.deterministics:
+        got = tr.samples[name].reshape(len(qs), -1)
+        np.testing.assert_allclose(got, np.broadcast_to(want[name], got.shape), rtol=1e-12, atol=1e-13, err_msg=f"{seed} {name}")
