@@ -1935,8 +1935,38 @@ class _Lowering:
         if self._graph is not None:
             node = self._strip_jacobian(build_tree(self._graph, {"__keep_checks__": True, "__shapes__": True}), own)
             self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
-        while node[0] == "sum" and (node[1] is None or (len(node) == 4 and node[3] is not None and len(node[3]) <= 1)):
+        full = lambda nd: nd[0] == "sum" and (nd[1] is None or (len(nd) == 4 and nd[3] is not None and len(nd[3]) <= 1))   # noqa: E731
+        while full(node):
             node = node[2]        # `Model.logp` sums every factor anyway (model/core.py:666-695): a full reduction at a factor's root is the factor
+        # a SUM of full reductions at the root -- `init_logp.sum(-1) + innov_logp.sum(-1)` of a time series (timeseries.py:669-676): the
+        # first `ar_order` values under the initial distribution, the rest under the innovations' -- is as many factors, each with the
+        # length of its own reduction; what is not a reduction goes into one more
+        addends, stack = [], [node]
+        while stack:
+            nd = stack.pop()
+            if nd[0] == "add" and len(nd) == 3:
+                stack += [nd[2], nd[1]]
+            else:
+                addends.append(nd)
+        if len(addends) > 1 and any(full(a) and self._tsize(a[2]) > 1 for a in addends) and all(self._tsize(a) == 1 for a in addends):
+            rest = None
+            k = 0
+            for a in addends:
+                if full(a) and self._tsize(a[2]) > 1:
+                    self._general_tree(a, name if k == 0 else f"{name}.{k}", own, piece=True)
+                    self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+                    k += 1
+                else:
+                    rest = a if rest is None else ("add", rest, a)
+            if rest is not None:
+                self._general_tree(rest, f"{name}.{k}", own, piece=True)
+            return
+        self._general_tree(node, name, own)
+
+    def _general_tree(self, node, name: str, own: Optional[int], piece: bool = False):
+        full = lambda nd: nd[0] == "sum" and (nd[1] is None or (len(nd) == 4 and nd[3] is not None and len(nd[3]) <= 1))   # noqa: E731
+        while full(node):
+            node = node[2]
         self._const_cache = {}
         written_out = False
         try:
@@ -1970,7 +2000,7 @@ class _Lowering:
                 if self._osize(o) not in (1, size):
                     raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
                                        "between different shapes is outside the element-wise programs")
-        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out:
+        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out and not piece:
             raise NotLowerable(f"the factor of {self.spec.vars[own].name} does not have the variable's shape")
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)
 

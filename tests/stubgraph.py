@@ -82,8 +82,9 @@ class Variable:
                     src = []
                 elif i == slice(None):
                     shp.append(src.pop(0))
-                else:
-                    raise NotImplementedError("stub: None mixed with a non-trivial index")
+                else:      # `rhos[..., 0, None]`: PyTensor takes the Subtensor first and pads the result with a DimShuffle
+                    sub = self[tuple(j for j in tup if j is not None)]
+                    return Variable(Apply(DimShuffle(), [sub]), shape=np.empty(self.type.shape, dtype=np.int8)[idx].shape)
             return Variable(Apply(DimShuffle(), [self]), shape=tuple(shp + src))
         shape = np.empty(self.type.shape, dtype=np.int8)[idx].shape
         return Variable(Apply(Subtensor(tup), [self]), shape=shape)
@@ -503,6 +504,50 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         return Variable(Apply(Softmax(axis), [x]), shape=x.type.shape)
 
     @staticmethod
+    def add(*xs):
+        """`pt.add(a, b, c, ...)`: one variadic Elemwise(Add) in PyTensor; here the left-to-right chain of binary ones (same value)."""
+        out = as_tensor(xs[0])
+        for x in xs[1:]:
+            out = out + x
+        return out
+
+    @staticmethod
+    def diff(x, n=1, axis=-1):
+        """`pytensor.tensor.extra_ops.diff` (n = 1): `x[1:] - x[:-1]` along `axis` -- two Subtensors and a Sub, as PyTensor builds it."""
+        assert n == 1
+        x = as_tensor(x)
+        ax = axis % x.ndim
+        pre = (slice(None),) * ax
+        return x[pre + (slice(1, None),)] - x[pre + (slice(None, -1),)]
+
+    @staticmethod
+    def take(x, indices, axis=None):
+        """`pt.take(x, i, axis)` with an integer `i`: `x[:, ..., i]` (tensor/subtensor.py `take` reduces it to basic indexing)."""
+        x = as_tensor(x)
+        if not isinstance(indices, (int, np.integer)):
+            raise NotImplementedError("stub: take with a non-integer index")
+        return x[(slice(None),) * (axis % x.ndim) + (int(indices),)]
+
+    @staticmethod
+    def shape_padaxis(x, axis):
+        return pt.expand_dims(x, axis if axis >= 0 else as_tensor(x).ndim + 1 + axis)
+
+    @staticmethod
+    def split(x, splits_size, n_splits, axis=0):
+        """`pt.split`: consecutive pieces of the given sizes along `axis` (a `Split` op in PyTensor, whose outputs are these slices)."""
+        x = as_tensor(x)
+        pre, out, at = (slice(None),) * (axis % x.ndim), [], 0
+        for k in range(n_splits):
+            out.append(x[pre + (slice(at, at + int(splits_size[k])),)])
+            at += int(splits_size[k])
+        return out
+
+    @staticmethod
+    def atleast_1d(x):
+        x = as_tensor(x)
+        return x if x.ndim >= 1 else pt.expand_dims(x, 0)
+
+    @staticmethod
     def all(x, axis=None):
         """`pt.all`: a list goes through `as_tensor_variable` (a `MakeVector` of its scalars) first, as in PyTensor."""
         if isinstance(x, (list, tuple)):
@@ -706,8 +751,36 @@ def reference():
     # `pm.distributions.transforms.ordered` (distributions/transforms.py:79-125, 704): the identifiability constraint of a mixture's means
     ref_class("distributions/transforms.py", "Ordered", ["__init__", "backward", "forward", "log_jac_det"], _TransformBase, ns)
     ns["transforms"].ordered = ns["Ordered"]()
+    # time series (distributions/timeseries.py): a random walk is `cumsum(concatenate([init, innovations]))` of two measurable variables
+    # (:100-105) and its log-density is DERIVED -- `random_walk_logp` (:234-244) asks `logp(rv, value)`, which the reference's own
+    # logprob rules answer: `logprob_cumsum` (logprob/cumsum.py:53-74: the value's differences under the base variable) over
+    # `logprob_join` (logprob/tensor.py:115-157: the value split at the pieces' lengths, each piece under its own distribution).
+    # `AR` registers its density directly (`ar_logp`, :646-676).  All four bodies are the reference's, executed here.
+    ts = dict(ns)
+
+    def _ts_logp(rv, value):
+        if isinstance(rv, _Measurable):
+            return ts[rv.rule](rv.op, (value,), *rv.bases)
+        return rv.dist_cls.logp(value, *(rv.params if isinstance(rv, _ComponentRV) else rv))
+
+    ts.update(_logprob_helper=_ts_logp, logp=_ts_logp, remove_promised_valued_rvs=lambda rvs: rvs,
+              constant_fold=lambda xs, raise_not_constant=True: [int(x) for x in xs], replace_rvs_by_values=lambda logps, rvs_to_values: logps)
+    ref_function("logprob/cumsum.py", "logprob_cumsum", ts)
+    ref_function("logprob/tensor.py", "logprob_join", ts)
+    ref_function("distributions/timeseries.py", "random_walk_logp", ts)
+    ref_function("distributions/timeseries.py", "ar_logp", ts)
+    ns["timeseries"] = ts
     _NS = ns
     return ns
+
+
+class _Measurable:
+    """A variable the reference's logprob rewrites made measurable (`MeasurableCumsum`, `MeasurableJoin`): the op's axis, the base
+    variables, and which rule gives its log-density."""
+
+    def __init__(self, rule, axis, bases, shape):
+        self.rule, self.bases, self.shape = rule, tuple(bases), tuple(shape)
+        self.op = type("op", (), {"axis": axis})()
 
 
 def _ref_logp(cls_name):
@@ -842,8 +915,9 @@ class StubModel:
         return self._rv("LogNormal", name, shape, _dist("LogNormal", mu=mu, sigma=sigma), "log", observed)
 
     # (a shape parameter may be a number or another variable of the model: `nu ~ Gamma; y ~ StudentT(nu, ...)`)
-    def StudentT(self, name, nu, mu=0.0, sigma=1.0, shape=(), observed=None):
-        return self._rv("StudentT", name, shape, _dist("StudentT", _num_or_var(nu), mu=mu, sigma=sigma), None, observed)
+    def StudentT(self, name, nu, mu=0.0, sigma=None, lam=None, shape=(), observed=None):
+        sigma = 1.0 if sigma is None and lam is None else sigma           # (`get_tau_sigma`, continuous.py:221-268: one of the two, or sigma = 1)
+        return self._rv("StudentT", name, shape, _dist("StudentT", _num_or_var(nu), mu=mu, sigma=sigma, lam=lam), None, observed)
 
     def Beta(self, name, alpha, beta, shape=(), observed=None):
         return self._rv("Beta", name, shape, _dist("Beta", alpha=_num_or_var(alpha), beta=_num_or_var(beta)), "logodds", observed)
@@ -962,6 +1036,39 @@ class StubModel:
         up = base if upper is None else as_tensor(upper)
         fn = lambda value: ref["clip_logprob"](None, (value,), base, lo, up)   # noqa: E731
         return self._add(_RV(name, np.shape(observed), fn, (), None, observed))
+
+    def GaussianRandomWalk(self, name, mu=0.0, sigma=1.0, init_dist=("Normal", dict(mu=0.0, sigma=100.0)), shape=None):
+        """`pm.GaussianRandomWalk(name, mu=, sigma=, init_dist=pm.Normal.dist(...), shape=T)` (timeseries.py:264-296): `RandomWalk` with
+        `Normal.dist(mu, sigma)` innovations; no transform.  The inner graph is `RandomWalkRV.rv_op`'s (:100-105) on measurable
+        variables, the density what the reference's `random_walk_logp` derives from it."""
+        ref = reference()
+        ts = ref["timeseries"]
+        (T,) = shape = tuple(shape)
+        cls_name, kw = init_dist
+        init = _ComponentRV(ref[cls_name], _dist(cls_name, **kw))
+        innov = _ComponentRV(ref["Normal"], _dist("Normal", mu=mu, sigma=sigma))
+        init.shape, innov.shape = (1,), (T - 1,)
+        grw = _Measurable("logprob_cumsum", 0, [_Measurable("logprob_join", 0, [init, innov], shape)], shape)
+
+        class _Op:      # (`op.make_node(*inputs)` / `op.fgraph.bind(...)[op.default_output]`: the RV's inner graph re-created on the inputs)
+            default_output = 0
+            make_node = staticmethod(lambda *inputs: type("node", (), {"inputs": inputs})())
+            fgraph = type("fgraph", (), {"bind": staticmethod(lambda inputs: [grw])})
+
+        fn = lambda value: ts["random_walk_logp"](_Op(), (value,))   # noqa: E731
+        return self._add(_RV(name, shape, fn, (), None, None))
+
+    def AR(self, name, rho, sigma=1.0, init_dist=("Normal", dict(mu=0.0, sigma=100.0)), constant=False, shape=None):
+        """`pm.AR(name, rho=, sigma=, constant=, init_dist=pm.Normal.dist(...), shape=T)` (timeseries.py:420-644): the order is the length
+        of `rho` (less one with a constant term, :553-556); density: the reference's `ar_logp`."""
+        ref = reference()
+        rhos = pt.atleast_1d(as_tensor(rho))           # timeseries.py:520
+        order = int(rhos.type.shape[-1]) - int(bool(constant))
+        cls_name, kw = init_dist
+        init = _ComponentRV(ref[cls_name], _dist(cls_name, **kw))
+        op = type("op", (), {"ar_order": order, "constant_term": bool(constant)})()
+        fn = lambda value, rhos_, sigma_: ref["timeseries"]["ar_logp"](op, (value,), rhos_, sigma_, init, None, None)   # noqa: E731
+        return self._add(_RV(name, tuple(shape), fn, (rhos, as_tensor(sigma)), None, None))
 
     def ZeroInflatedPoisson(self, name, psi, mu, observed):
         """`pm.ZeroInflatedPoisson(name, psi=psi, mu=mu, observed=y)` (mixture.py:560-575, 577-640): the reference's

@@ -1,0 +1,139 @@
+"""Time-series models through the lowering (distributions/timeseries.py: `GaussianRandomWalk`, `AR`): the stochastic-volatility model of
+the reference's example gallery, autoregressions, a random-walk rate under counts.
+
+The graphs are what THE REFERENCE'S OWN CODE builds: a random walk's density is derived -- `random_walk_logp` (timeseries.py:234-244) ->
+`logprob_cumsum` (logprob/cumsum.py:53-74: the differences of the value) -> `logprob_join` (logprob/tensor.py:115-157: the first value
+under the initial distribution, the rest under the innovations') -- and `AR` registers `ar_logp` (timeseries.py:646-676); tests/stubgraph.py
+executes those bodies and the distributions' `logp`.  Committed: the graphs (tests/golden/ts_graphs.npz) and torch autograd of them
+at seeded points (tests/golden/ts_graphs_golden.npz).  Checked here: the lowered spec through the oracle's interpreter == those
+numbers; the same densities written independently with SciPy; a short NUTS run by the oracle's sampler.
+
+Host only (tests/timeseries_models.py says why): no `-m gpu` twin this round."""
+import os
+import sys
+
+import numpy as np
+import pytest
+from scipy import stats
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stubgraph as sg  # noqa: E402
+import timeseries_models as tm  # noqa: E402
+
+from oracle import ref_models, ref_sampler  # noqa: E402
+from pymc_amd import model_spec as ms  # noqa: E402
+from pymc_amd.lowering import lower_to_spec  # noqa: E402
+
+NAMES = sorted(tm.MODELS)
+
+
+def _committed(name):
+    return lower_to_spec(sg.FrozenModel(sg.load_models(tm.FIXTURE)[name]))
+
+
+def _golden(name):
+    z = np.load(tm.GOLDEN)
+    return z[f"{name}__q"], z[f"{name}__logp"], z[f"{name}__grad"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_committed_graphs_lower_and_the_oracle_reproduces_autograd_of_the_graph(name):
+    spec = _committed(name)
+    qs, lps, grads = _golden(name)
+    assert spec.n == qs.shape[1]
+    for q, lp0, g0 in zip(qs, lps, grads):
+        lp, g = ref_models.evaluate(spec, q)
+        assert abs(lp - lp0) <= 1e-11 * max(1.0, abs(lp0)), (name, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-10 * max(1.0, np.max(np.abs(g0))), name
+
+
+def test_the_committed_graphs_and_values_are_what_the_reference_code_gives_now():
+    if not sg.available():
+        pytest.skip("needs /root/reference")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_timeseries_golden as mg
+
+    now = mg.run()
+    z = np.load(tm.GOLDEN)
+    assert sorted(now) == sorted(z.files)
+    for k in now:
+        np.testing.assert_allclose(now[k], z[k], rtol=1e-12, atol=1e-12, err_msg=k)
+    for name, make in tm.MODELS.items():      # the committed graph lowers to the spec the freshly built one lowers to
+        a, b = lower_to_spec(make()), _committed(name)
+        assert a.factors == b.factors and a.vars == b.vars and all(np.array_equal(x, y) for x, y in zip(a.data, b.data)), name
+
+
+# ---- the same densities, written down independently (SciPy): that the chain of derivation rules was followed correctly -------------
+def _sv(q):
+    T = tm.T_SV
+    step, vol, nu = np.exp(q[0]), q[1 : 1 + T], np.exp(q[1 + T])
+    lp = stats.expon(scale=1 / 10.0).logpdf(step) + q[0] + stats.expon(scale=1 / 0.1).logpdf(nu) + q[1 + T]
+    lp += stats.norm(0.0, 100.0).logpdf(vol[0]) + stats.norm(0.0, step).logpdf(np.diff(vol)).sum()
+    return lp + stats.t(nu, 0.0, np.exp(vol)).logpdf(tm.RETURNS).sum()          # lam = exp(-2 vol): sigma = exp(vol)
+
+
+def _ar2(q):
+    T = tm.T_AR
+    rho, s, x, tau = q[:3], np.exp(q[3]), q[4 : 4 + T], np.exp(q[4 + T])
+    lp = stats.norm(0, 0.5).logpdf(rho).sum() + stats.halfnorm(scale=1.0).logpdf(s) + q[3] + stats.halfnorm(scale=0.5).logpdf(tau) + q[4 + T]
+    mean = rho[0] + rho[1] * x[1:-1] + rho[2] * x[:-2]
+    lp += stats.norm(0, 2.0).logpdf(x[:2]).sum() + stats.norm(mean, s).logpdf(x[2:]).sum()
+    return lp + stats.norm(x, tau).logpdf(tm.Y_AR).sum()
+
+
+def _ar1(q):
+    T = tm.T_AR
+    r = -1.0 + 2.0 / (1.0 + np.exp(-q[0]))
+    x = q[1 : 1 + T]
+    lp = np.log(0.5) + np.log(2.0) + q[0] - 2.0 * np.logaddexp(0.0, q[0])        # Uniform(-1, 1) and the interval transform's Jacobian
+    lp += stats.norm(0, 1.0).logpdf(x[0]) + stats.norm(r * x[:-1], 0.4).logpdf(x[1:]).sum()
+    return lp + stats.norm(x, 0.3).logpdf(tm.Y_AR).sum()
+
+
+def _rate(q):
+    T = tm.T_LL
+    drift, step, level = q[0], np.exp(q[1]), q[2 : 2 + T]
+    lp = stats.norm(0, 0.1).logpdf(drift) + stats.halfnorm(scale=0.3).logpdf(step) + q[1]
+    lp += stats.norm(1.0, 2.0).logpdf(level[0]) + stats.norm(drift, step).logpdf(np.diff(level)).sum()
+    return lp + stats.poisson(np.exp(level)).logpmf(tm.COUNTS).sum()
+
+
+@pytest.mark.parametrize("name, dens", [("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
+def test_the_densities_are_the_textbook_ones(name, dens):
+    spec = _committed(name)
+    qs, lps, _ = _golden(name)
+    for q, lp0 in zip(qs, lps):
+        want = dens(q)
+        assert abs(lp0 - want) <= 1e-9 * max(1.0, abs(want)), (name, lp0, want)
+        assert abs(ref_models.evaluate(spec, q)[0] - want) <= 1e-9 * max(1.0, abs(want))
+
+
+def test_what_the_time_series_lower_to():
+    """A random walk of T values: ONE element-wise factor of T elements -- the pieces of `logprob_join`'s concatenation selected by
+    constant masks, the differences two gathers of the value.  An AR(p): the root `init_logp.sum(-1) + innov_logp.sum(-1)` becomes a
+    factor of p elements and one of T - p."""
+    spec = _committed("stochastic_volatility")
+    vol = [f for f in spec.factors if f.name == "volatility"]
+    assert len(vol) == 1 and vol[0].dist == ms.D_POTENTIAL and vol[0].size == tm.T_SV and len(vol[0].prog) <= 24
+    ret = [f for f in spec.factors if f.name == "returns"][0]
+    assert ret.size == tm.T_SV and [i.op for i in ret.prog].count(ms.E_GAMMALN) == 2
+    spec = _committed("ar2_with_constant")
+    sizes = sorted(f.size for f in spec.factors if f.name.split(".")[0] == "x")
+    assert sizes == [2, tm.T_AR - 2]
+    spec = _committed("ar1_latent")
+    assert sorted(f.size for f in spec.factors if f.name.split(".")[0] == "x") == [1, tm.T_AR - 1]
+    spec = _committed("random_walk_rate_under_counts")
+    assert [f.size for f in spec.factors if f.name == "level"] == [tm.T_LL]
+
+
+def test_nuts_on_the_lowered_autoregression_recovers_the_latent_path():
+    """The oracle's sampler (oracle/ref_sampler.py: the reference's NUTS restated) on the lowered AR(1) model: a short run ends near the
+    observations it was given (observation noise 0.3 against innovations of 0.4)."""
+    spec = _committed("ar1_latent")
+    draws, st = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=60, tune=120, random_seed=5, init="adapt_diag")
+    post = draws[0][120:]
+    assert np.all(np.isfinite(post)) and not any(s["diverging"] for s in st[0][120:])
+    x = post[:, 1:].mean(axis=0)
+    assert np.corrcoef(x, tm.Y_AR)[0, 1] > 0.9
+    rho = -1.0 + 2.0 / (1.0 + np.exp(-post[:, 0]))
+    assert 0.0 < rho.mean() < 0.9            # (the series was generated with 0.55 x[t-1] - 0.25 x[t-2])

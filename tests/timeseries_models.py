@@ -1,0 +1,77 @@
+"""Time-series models (distributions/timeseries.py) for tests/test_timeseries_lowering.py: the stochastic-volatility model of the
+reference's own example gallery, autoregressions, a random-walk rate under counts.  Built on tests/stubgraph.py: the densities are the
+reference's `random_walk_logp` / `logprob_cumsum` / `logprob_join` / `ar_logp` bodies and its distributions' `logp`, executed.
+
+HOST ONLY this round: these specs use nothing the device has not run (element-wise programs over gathers, the opcodes of
+tests/test_general_lowering.py's models), but no GPU minutes were left to run THEM on the device, so they are kept out of
+`lowering_models.GENERAL` (whose members the `-m gpu` tests are parametrised over) and out of tests/golden/lowered_spec_digests.json."""
+import os
+
+import numpy as np
+
+import stubgraph as sg
+
+pt = sg.pt
+_rg = np.random.default_rng(20240925)
+T_SV = 100
+_vol_true = np.cumsum(_rg.normal(size=T_SV) * 0.12) - 3.5
+RETURNS = _rg.standard_t(6.0, size=T_SV) * np.exp(_vol_true)
+T_AR = 60
+_x = np.zeros(T_AR)
+for _t in range(2, T_AR):
+    _x[_t] = 0.3 + 0.55 * _x[_t - 1] - 0.25 * _x[_t - 2] + 0.4 * _rg.normal()
+Y_AR = _x + 0.3 * _rg.normal(size=T_AR)
+T_LL = 48
+COUNTS = _rg.poisson(np.exp(1.0 + np.cumsum(_rg.normal(size=T_LL) * 0.15))).astype("float64")
+
+
+def stochastic_volatility():
+    """The reference gallery's stochastic-volatility model: `step_size ~ Exponential(10)`; `volatility ~ GaussianRandomWalk(sigma =
+    step_size, init_dist = Normal.dist(0, 100))`; `nu ~ Exponential(0.1)`; `returns ~ StudentT(nu, lam = exp(-2 volatility))`."""
+    m = sg.StubModel()
+    step = m.Exponential("step_size", 10.0)
+    vol = m.GaussianRandomWalk("volatility", sigma=step, init_dist=("Normal", dict(mu=0.0, sigma=100.0)), shape=(T_SV,))
+    nu = m.Exponential("nu", 0.1)
+    m.StudentT("returns", nu, lam=pt.exp(-2.0 * vol), observed=RETURNS)
+    return m
+
+
+def ar2_with_constant():
+    """`pm.AR(rho = [c, r1, r2], constant = True)` (timeseries.py:420-644) as a latent state under noisy observations."""
+    m = sg.StubModel()
+    rho = m.Normal("rho", 0.0, 0.5, shape=(3,))
+    s = m.HalfNormal("s", 1.0)
+    x = m.AR("x", rho, sigma=s, init_dist=("Normal", dict(mu=0.0, sigma=2.0)), constant=True, shape=(T_AR,))
+    tau = m.HalfNormal("tau", 0.5)
+    m.Normal("y", mu=x, sigma=tau, observed=Y_AR)
+    return m
+
+
+def ar1_latent():
+    """AR(1) without a constant term: one coefficient under a Uniform(-1, 1) prior (interval transform)."""
+    m = sg.StubModel()
+    rho = m.Uniform("rho", -1.0, 1.0, shape=(1,))
+    x = m.AR("x", rho, sigma=0.4, init_dist=("Normal", dict(mu=0.0, sigma=1.0)), constant=False, shape=(T_AR,))
+    m.Normal("y", mu=x, sigma=0.3, observed=Y_AR)
+    return m
+
+
+def random_walk_rate_under_counts():
+    """A local-level model of counts: the log-rate is a Gaussian random walk with a drift, `counts ~ Poisson(exp(level))`."""
+    m = sg.StubModel()
+    drift = m.Normal("drift", 0.0, 0.1)
+    step = m.HalfNormal("step", 0.3)
+    level = m.GaussianRandomWalk("level", mu=drift, sigma=step, init_dist=("Normal", dict(mu=1.0, sigma=2.0)), shape=(T_LL,))
+    m.Poisson("counts", pt.exp(level), observed=COUNTS)
+    return m
+
+
+MODELS = {
+    "stochastic_volatility": stochastic_volatility,
+    "ar2_with_constant": ar2_with_constant,
+    "ar1_latent": ar1_latent,
+    "random_walk_rate_under_counts": random_walk_rate_under_counts,
+}
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "ts_graphs.npz")
+GOLDEN = os.path.join(HERE, "golden", "ts_graphs_golden.npz")
