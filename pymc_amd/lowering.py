@@ -224,6 +224,24 @@ def build_tree(v, memo: Optional[dict] = None):
                 out = ("bcast", kid, np.atleast_1d(pos).ravel(), ishape, tuple(np.shape(pos)))
             else:
                 raise NotLowerable("Subtensor of a non-constant beyond x[0] of a leading dimension of one and beta[k] of a vector")
+    elif name == "Prod":                          # shape arithmetic (`pt.prod(value.shape)`): of a constant it folds
+        kid = build_tree(ins[0], memo)
+        if kid[0] != "const":
+            raise NotLowerable("a product reduction of a non-constant")
+        out = _const(np.prod(np.asarray(kid[1]), axis=getattr(op, "axis", None)))
+    elif name == "IncSubtensor" and len(ins) == 2 and all(_is_constant_graph(i) for i in ins):
+        # `pt.inc_subtensor(shape[-n:], -1)` (multivariate.py:2792): arithmetic on a static shape
+        xk, yk = build_tree(ins[0], memo), build_tree(ins[1], memo)
+        if xk[0] != "const" or yk[0] != "const":
+            raise NotLowerable("IncSubtensor of constants that did not fold")
+        arr = np.array(xk[1], dtype="float64", copy=True)
+        idx = tuple(getattr(op, "idx_list", ()))
+        idx = idx if len(idx) != 1 else idx[0]
+        if getattr(op, "set_instead_of_inc", False):
+            arr[idx] = yk[1]
+        else:
+            arr[idx] += yk[1]
+        out = _const(arr)
     elif name in ("IncSubtensor", "CumOp") and not memo.get("__shapes__"):
         raise NotLowerable(f"{name} needs the shape-aware walk")
     elif name == "IncSubtensor":                  # `pt.set_subtensor(x[idx], y)`: x with the indexed region replaced by y
@@ -1190,14 +1208,17 @@ class _Lowering:
             for j, piece in enumerate(node[2:]):
                 if np.all((idx >= starts[j]) & (idx < starts[j + 1])):
                     return self._index(piece, idx - starts[j]) if sizes[j] > 1 else piece
-            raise NotLowerable(f"an index that spans several pieces of a concatenation: {_show(node)}")
+            # the indexed elements come from several pieces (`z[group]` of a zero-sum vector: K - 1 free values and the one that balances
+            # them): a piecewise assembly of len(idx) elements, selected by constant masks like any other
+            piece_of = np.concatenate([np.full(sz, j, dtype=np.int64) for j, sz in enumerate(sizes)])
+            return ("joinnd", piece_of[idx], (np.arange(int(starts[-1])) - starts[piece_of])[idx], (len(idx),), *node[2:])
         if k == "take_along_axis" and len(node) == 4:
             return self._index(self._select_chain(node), idx)
         if k == "joinnd":
             idx = np.asarray(idx, dtype=np.int64)
             which = np.unique(node[1][idx])
             if len(which) != 1:
-                raise NotLowerable(f"an index that spans several pieces of a concatenation: {_show(node)}")
+                return ("joinnd", np.asarray(node[1])[idx], np.asarray(node[2])[idx], (len(idx),), *node[4:])
             return self._index(node[4 + int(which[0])], node[2][idx])
         if k in self._PROG_OPS or k in ("pow", "check", "all", "any", "makevector"):
             return (k, *[self._index(x, idx) if _is_node(x) else x for x in node[1:]])
@@ -1936,8 +1957,14 @@ class _Lowering:
             node = self._strip_jacobian(build_tree(self._graph, {"__keep_checks__": True, "__shapes__": True}), own)
             self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
         full = lambda nd: nd[0] == "sum" and (nd[1] is None or (len(nd) == 4 and nd[3] is not None and len(nd[3]) <= 1))   # noqa: E731
-        while full(node):
-            node = node[2]        # `Model.logp` sums every factor anyway (model/core.py:666-695): a full reduction at a factor's root is the factor
+        zero = lambda nd: nd[0] == "const" and not np.any(np.asarray(nd[1]))   # noqa: E731
+        while node[0] == "add" and len(node) == 3 and (zero(node[1]) or zero(node[2])) and self._tsize(node[1]) == self._tsize(node[2]):
+            node = node[2] if zero(node[1]) else node[1]     # (`+ log_jac_det` of a transform whose Jacobian is one: `zeros_like`, transforms.py:695-696)
+        while full(node) or (node[0] == "check" and full(node[1]) and all(self._tsize(c) == 1 for c in node[2:] if _is_node(c))):
+            # `Model.logp` sums every factor anyway (model/core.py:666-695): a full reduction at a factor's root is the factor.  A parameter
+            # check AROUND the reduction (`check_parameters(pt.sum(...), *zerosums)`, multivariate.py:2801-2807) moves onto the elements: a
+            # failed check makes every one of them -inf, and so their sum
+            node = node[2] if node[0] == "sum" else ("check", node[1][2], *node[2:])
         # a SUM of full reductions at the root -- `init_logp.sum(-1) + innov_logp.sum(-1)` of a time series (timeseries.py:669-676): the
         # first `ar_order` values under the initial distribution, the rest under the innovations' -- is as many factors, each with the
         # length of its own reduction; what is not a reduction goes into one more
@@ -2000,9 +2027,20 @@ class _Lowering:
                 if self._osize(o) not in (1, size):
                     raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
                                        "between different shapes is outside the element-wise programs")
-        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out and not piece:
+        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out and not piece \
+                and self.spec.vars[own].value_name not in getattr(self, "_resized", ()):
             raise NotLowerable(f"the factor of {self.spec.vars[own].name} does not have the variable's shape")
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)
+
+
+def _is_constant_graph(v) -> bool:
+    """No value variable below `v`: constants, and shapes of anything (static in every model the IR takes)."""
+    owner = getattr(v, "owner", None)
+    if owner is None:
+        return hasattr(v, "data")
+    if type(owner.op).__name__ == "Shape":
+        return True
+    return all(_is_constant_graph(i) for i in owner.inputs)
 
 
 def _is_node(x) -> bool:
@@ -2048,7 +2086,7 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
     RV factor (None for observed RVs / potentials) -- on a real `pm.Model`: `[model.rvs_to_values[rv] for rv in free_RVs]`."""
     if vars is not None and [id(v) for v in vars] != [id(v) for v in model.value_vars]:
         raise NotLowerable("the step's variables must be the model's continuous value variables, in the model's order")
-    shapes, transforms = {}, {}
+    shapes, transforms, resized = {}, {}, set()
     for v in model.value_vars:
         shp = getattr(model, "value_shapes", {}).get(v.name)
         if shp is None:
@@ -2056,18 +2094,21 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
         shapes[v.name] = shp
         tr = getattr(model, "value_transforms", {}).get(v.name)
         if tr is not None and not isinstance(tr, tuple):
-            if tr.name == "ordered":
-                tr = None
+            if tr.name in ("ordered", "zerosum"):
+                tr = (5 if tr.name == "ordered" else 6, 0.0, 1.0)
             else:
                 code = {"log": ms.TR_LOG, "logodds": ms.TR_LOGODDS, "interval": ms.TR_INTERVAL, "simplex": _TR_SIMPLEX}[tr.name]
                 tr = (code, getattr(tr, "lower", 0.0), getattr(tr, "upper", 1.0))
         # `transforms.ordered` (distributions/transforms.py:79-125): no transform code in the IR -- the value variable is stored as it
         # is, `Ordered.backward` (a cumulative sum of [v0, exp(v1), ...]) and its log-Jacobian are part of the graphs and lower op by op
-        if tr is not None and int(tr[0]) == 5:
+        if tr is not None and int(tr[0]) in (5, 6):      # (6: `ZeroSumTransform`, transforms.py:644-696 -- likewise part of the graphs)
+            if int(tr[0]) == 6:
+                resized.add(v.name)                       # (K - 1 free values for K constrained ones: the prior's factor has K elements)
             tr = None
         if tr is not None:
             transforms[v.name] = tr
     low = _Lowering(list(model.value_vars), transforms, shapes, list(getattr(model, "extra_vars", ())), getattr(model, "extra_values", None))
+    low._resized = resized
     factors = model.logp(sum=False)
     owners = list(getattr(model, "logp_owners", [None] * len(factors)))
     names = list(getattr(model, "logp_names", [f"factor{i}" for i in range(len(factors))]))

@@ -1,8 +1,8 @@
-"""Writes tests/golden/ts_graphs.npz (the log-density graphs of tests/timeseries_models.py as the reference's own code builds them on the
-graph protocol of tests/stubgraph.py) and tests/golden/ts_graphs_golden.npz (their joint log-density and gradient at seeded points:
+"""Writes tests/golden/more_graphs.npz (the log-density graphs of tests/more_models.py as the reference's own code builds them on the
+graph protocol of tests/stubgraph.py) and tests/golden/more_graphs_golden.npz (their joint log-density and gradient at seeded points:
 the graphs evaluated on torch float64 tensors and differentiated with autograd, tests/graph_torch.py).
 
-    python tests/golden/make_timeseries_golden.py"""
+    python tests/golden/make_more_golden.py"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import graph_torch as gt  # noqa: E402
 import stubgraph as sg  # noqa: E402
-import timeseries_models as tm  # noqa: E402
+import more_models as tm  # noqa: E402
 from make_general_golden import points  # noqa: E402
 
 

@@ -95,7 +95,12 @@ def evaluate(var, values: dict, memo: dict | None = None):
             elif name == "IncSubtensor":
                 idx = tuple(op.idx_list)
                 out = ev(ins[0]).clone()
-                out[idx if len(idx) != 1 else idx[0]] = ev(ins[1])
+                if getattr(op, "set_instead_of_inc", True):
+                    out[idx if len(idx) != 1 else idx[0]] = ev(ins[1])
+                else:
+                    out[idx if len(idx) != 1 else idx[0]] += ev(ins[1])
+            elif name == "Prod":
+                out = ev(ins[0]).prod() if op.axis is None else ev(ins[0]).prod(dim=op.axis)
             elif name == "CumOp":
                 out = torch.cumsum(ev(ins[0]), dim=op.axis)
             elif name == "Dot":

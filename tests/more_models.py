@@ -1,6 +1,8 @@
-"""Time-series models (distributions/timeseries.py) for tests/test_timeseries_lowering.py: the stochastic-volatility model of the
-reference's own example gallery, autoregressions, a random-walk rate under counts.  Built on tests/stubgraph.py: the densities are the
-reference's `random_walk_logp` / `logprob_cumsum` / `logprob_join` / `ar_logp` bodies and its distributions' `logp`, executed.
+"""More models for the lowering (tests/test_more_lowering.py).  Time series (distributions/timeseries.py): the stochastic-volatility model
+of the reference's own example gallery, autoregressions, a random-walk rate under counts -- the densities are the reference's
+`random_walk_logp` / `logprob_cumsum` / `logprob_join` / `ar_logp` bodies and its distributions' `logp`, executed on tests/stubgraph.py.
+Zero-sum effects (`pm.ZeroSumNormal`, multivariate.py:2654-2807, under `ZeroSumTransform`, transforms.py:644-696): group effects that sum
+to zero next to an intercept.
 
 HOST ONLY this round: these specs use nothing the device has not run (element-wise programs over gathers, the opcodes of
 tests/test_general_lowering.py's models), but no GPU minutes were left to run THEM on the device, so they are kept out of
@@ -66,12 +68,43 @@ def random_walk_rate_under_counts():
     return m
 
 
+K_ZS, N_ZS = 9, 72
+G_ZS = _rg.integers(0, K_ZS, size=N_ZS)
+_eff = _rg.normal(size=K_ZS) * 0.8
+Y_ZS = 1.5 + (_eff - _eff.mean())[G_ZS] + 0.5 * _rg.normal(size=N_ZS)
+Y_ZS2 = _rg.poisson(np.exp(0.8 + 0.4 * (_eff - _eff.mean()))).astype("float64")
+
+
+def zero_sum_group_effects():
+    """An intercept and group effects that sum to zero (the identifiable form of a one-way layout): `z ~ ZeroSumNormal(sigma, shape=K)`,
+    `y ~ Normal(a + z[group], s)`.  K - 1 free values; the K-th effect balances them (`ZeroSumTransform.extend_axis`), so `z[group]` is a
+    gather that spans both pieces of a concatenation."""
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 5.0)
+    tau = m.HalfNormal("tau", 1.0)
+    z = m.ZeroSumNormal("z", sigma=tau, shape=(K_ZS,))
+    s = m.HalfNormal("s", 1.0)
+    m.Normal("y", mu=a + z[G_ZS], sigma=s, observed=Y_ZS)
+    return m
+
+
+def zero_sum_log_rates():
+    """The zero-sum vector used element-wise: one count per group, `counts ~ Poisson(exp(a + z))`."""
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 2.0)
+    z = m.ZeroSumNormal("z", sigma=0.7, shape=(K_ZS,))
+    m.Poisson("counts", pt.exp(a + z), observed=Y_ZS2)
+    return m
+
+
 MODELS = {
+    "zero_sum_group_effects": zero_sum_group_effects,
+    "zero_sum_log_rates": zero_sum_log_rates,
     "stochastic_volatility": stochastic_volatility,
     "ar2_with_constant": ar2_with_constant,
     "ar1_latent": ar1_latent,
     "random_walk_rate_under_counts": random_walk_rate_under_counts,
 }
 HERE = os.path.dirname(os.path.abspath(__file__))
-FIXTURE = os.path.join(HERE, "golden", "ts_graphs.npz")
-GOLDEN = os.path.join(HERE, "golden", "ts_graphs_golden.npz")
+FIXTURE = os.path.join(HERE, "golden", "more_graphs.npz")
+GOLDEN = os.path.join(HERE, "golden", "more_graphs_golden.npz")

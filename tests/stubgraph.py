@@ -101,7 +101,8 @@ class Variable:
     def mT(self): return _transpose(self)
     @property
     def tag(self): return _Tag()
-    def sum(self, axis=None): return pt.sum(self, axis=axis)
+    def sum(self, axis=None, keepdims=False): return pt.sum(self, axis=axis, keepdims=keepdims)
+    def zeros_like(self, dtype=None): return pt.zeros_like(self)
     def __matmul__(self, o): return pt.dot(self, o)
     def __rmatmul__(self, o): return pt.dot(o, self)
     def copy(self): return self          # (`log_jac_det(...).copy()`, transform_value.py:102: an identity node in PyTensor)
@@ -150,6 +151,11 @@ class AdvancedSubtensor1:
 
 
 class Sum:
+    def __init__(self, axis):
+        self.axis = axis
+
+
+class Prod:
     def __init__(self, axis):
         self.axis = axis
 
@@ -371,6 +377,10 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     def _reduce(op_cls, x, axis, keepdims):
         x = as_tensor(x)
         shp = x.type.shape
+        if isinstance(axis, (tuple, list, np.ndarray)):       # (`axis=tuple(np.arange(-n_zerosum_axes, 0))`, `value.sum(self.zerosum_axes)`)
+            if len(axis) != 1:
+                raise NotImplementedError("stub: a reduction over several axes")
+            axis = int(axis[0])
         if axis is None:
             out, kept = (), (1,) * len(shp)
         else:
@@ -452,7 +462,33 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         shp.insert(ax, 1)
         return Variable(Apply(DimShuffle(), [x]), shape=tuple(shp))
 
-    isclose = staticmethod(lambda a, b: elemwise(IsClose, a, b))
+    @staticmethod
+    def isclose(a, b, rtol=1e-05, atol=1e-08):
+        """`pt.isclose`: |a - b| <= atol + rtol |b| (tensor/math.py `isclose`; the default tolerances keep the one-node form the committed
+        graphs hold, given ones are written out)."""
+        if rtol == 1e-05 and atol == 1e-08:
+            return elemwise(IsClose, a, b)
+        return pt.le(pt.abs(as_tensor(a) - b), atol + rtol * pt.abs(as_tensor(b)))
+
+    @staticmethod
+    def mean(x, axis=None):
+        """`pt.mean`: the sum over the axis divided by its (static) length (tensor/math.py `mean`)."""
+        x = as_tensor(x)
+        n = x.type.shape[axis % x.ndim] if axis is not None else int(np.prod(x.type.shape))
+        return pt.sum(x, axis=axis) / float(n)
+
+    @staticmethod
+    def prod(x, axis=None):
+        x = as_tensor(x)
+        return Variable(Apply(Prod(axis), [x]), shape=() if axis is None else tuple(d for i, d in enumerate(x.type.shape) if i != axis % x.ndim))
+
+    @staticmethod
+    def inc_subtensor(x_sub, y):
+        """`pt.inc_subtensor(x[idx], y)`: the IncSubtensor node that increments (`set_instead_of_inc=False`)."""
+        if x_sub.owner is None or not isinstance(x_sub.owner.op, Subtensor):
+            raise NotImplementedError("stub: inc_subtensor of something that is not x[basic index]")
+        x = x_sub.owner.inputs[0]
+        return Variable(Apply(IncSubtensor(x_sub.owner.op.idx_list, False), [x, as_tensor(y)]), shape=x.type.shape)
     power = pow
     floor = staticmethod(lambda a: elemwise(Floor, a))
     maximum = staticmethod(lambda a, b: elemwise(Maximum, a, b))
@@ -751,6 +787,10 @@ def reference():
     # `pm.distributions.transforms.ordered` (distributions/transforms.py:79-125, 704): the identifiability constraint of a mixture's means
     ref_class("distributions/transforms.py", "Ordered", ["__init__", "backward", "forward", "log_jac_det"], _TransformBase, ns)
     ns["transforms"].ordered = ns["Ordered"]()
+    # `pm.ZeroSumNormal` (multivariate.py:2654-2807): the density `zerosumnormal_logp` under `ZeroSumTransform` (transforms.py:644-696), one
+    # zero-sum axis (the last)
+    ref_class("distributions/transforms.py", "ZeroSumTransform", ["__init__", "extend_axis", "backward", "log_jac_det"], _TransformBase, ns)
+    ref_function("distributions/multivariate.py", "zerosumnormal_logp", ns)
     # time series (distributions/timeseries.py): a random walk is `cumsum(concatenate([init, innovations]))` of two measurable variables
     # (:100-105) and its log-density is DERIVED -- `random_walk_logp` (:234-244) asks `logp(rv, value)`, which the reference's own
     # logprob rules answer: `logprob_cumsum` (logprob/cumsum.py:53-74: the value's differences under the base variable) over
@@ -808,12 +848,13 @@ class _RV:
         if transform is not None and transform_obj is None:
             ref = reference()
             transform_obj = {"log": ref["transforms"].log, "logodds": ref["transforms"].logodds, "simplex": ref["transforms"].simplex,
-                             "ordered": ref["transforms"].ordered}[transform]
+                             "ordered": ref["transforms"].ordered, "zerosum": ref["ZeroSumTransform"]([-1])}[transform]
         self.transform_obj = transform_obj
         if observed is None:
             vname = name if transform is None else f"{name}_{transform}__"   # util.py:138-155
             # (the simplex transform's value has one element less than the variable: transforms.py:1094-1099 `forward`)
-            self.value = Variable(None, vname, self.shape[:-1] + (self.shape[-1] - 1,) if transform == "simplex" else self.shape)
+            # (so does the zero-sum transform's: transforms.py:672-688 `extend_axis_rev`)
+            self.value = Variable(None, vname, self.shape[:-1] + (self.shape[-1] - 1,) if transform in ("simplex", "zerosum") else self.shape)
             # what the rest of the graph sees in place of the RV: transform.backward(value, *rv_inputs)
             self.expr = self.value if transform is None else transform_obj.backward(self.value, *self.rv_inputs)
         else:
@@ -878,7 +919,7 @@ class StubModel:
 
     def _add(self, rv):
         (self.free if rv.observed is None else self.obs).append(rv)
-        if rv.observed is None and rv.transform == "ordered":
+        if rv.observed is None and rv.transform in ("ordered", "zerosum"):
             # the trace holds the variable itself next to its value variable (`model.unobserved_value_vars`, model/core.py:944-966): for
             # the transforms the IR has a code for, the backend applies `backward`; for this one the graph is the recipe
             self.deterministics[rv.name] = rv.expr
@@ -1037,6 +1078,14 @@ class StubModel:
         fn = lambda value: ref["clip_logprob"](None, (value,), base, lo, up)   # noqa: E731
         return self._add(_RV(name, np.shape(observed), fn, (), None, observed))
 
+    def ZeroSumNormal(self, name, sigma=1.0, shape=None):
+        """`pm.ZeroSumNormal(name, sigma=, shape=K)` (multivariate.py:2654-2784): K values that sum to zero, sampled as K - 1 free ones
+        (`<name>_zerosum__`) under `ZeroSumTransform([-1])`."""
+        ref = reference()
+        op = type("op", (), {"ndim_supp": 1})()
+        fn = lambda value, sigma_: ref["zerosumnormal_logp"](op, (value,), None, None, sigma_, None)   # noqa: E731
+        return self._add(_RV(name, tuple(shape), fn, (as_tensor(sigma),), "zerosum", None))
+
     def GaussianRandomWalk(self, name, mu=0.0, sigma=1.0, init_dist=("Normal", dict(mu=0.0, sigma=100.0)), shape=None):
         """`pm.GaussianRandomWalk(name, mu=, sigma=, init_dist=pm.Normal.dist(...), shape=T)` (timeseries.py:264-296): `RandomWalk` with
         `Normal.dist(mu, sigma)` innovations; no transform.  The inner graph is `RandomWalkRV.rv_op`'s (:100-105) on measurable
@@ -1133,7 +1182,7 @@ class StubModel:
     def value_transforms(self):
         # ("ordered" has no code of its own: the value variable is stored as it is, `Ordered.backward` and `log_jac_det` are part of the
         # graphs -- 5 tells the lowering so)
-        code = {"log": 1, "logodds": 2, "interval": 3, "simplex": 4, "ordered": 5}
+        code = {"log": 1, "logodds": 2, "interval": 3, "simplex": 4, "ordered": 5, "zerosum": 6}      # (6: like 5 -- `ZeroSumTransform.backward` is in the graphs)
         return {rv.value.name: (code[rv.transform], *(rv.bounds or (0.0, 1.0))) for rv in self.free if rv.transform}
 
     @property
@@ -1217,7 +1266,7 @@ def dump_model(m) -> dict:
 
 
 _OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot, Shape, Transpose, ExtractDiag, MatrixInverse,
-                                Any, Max, Join)}
+                                Any, Max, Join, Prod)}
 _OPS_AXIS = ("Sum", "All", "Softmax", "TakeAlongAxis")
 
 
@@ -1235,7 +1284,7 @@ class FrozenModel:
                 ins = [vs[i] for i in rec["ins"]]
                 if rec["op"] == "Elemwise":
                     op = Elemwise(globals()[rec["scalar"]]())
-                elif rec["op"] in ("Sum", "All", "Softmax", "Any", "Max", "Join"):
+                elif rec["op"] in ("Sum", "All", "Softmax", "Any", "Max", "Join", "Prod"):
                     op = _OPS[rec["op"]](rec.get("axis"))
                 elif rec["op"] == "TakeAlongAxis":
                     op = TakeAlongAxis(rec.get("axis", -1))

@@ -1,14 +1,16 @@
-"""Time-series models through the lowering (distributions/timeseries.py: `GaussianRandomWalk`, `AR`): the stochastic-volatility model of
-the reference's example gallery, autoregressions, a random-walk rate under counts.
+"""More of the reference's model vocabulary through the lowering.  Time series (distributions/timeseries.py: `GaussianRandomWalk`, `AR`):
+the stochastic-volatility model of the reference's example gallery, autoregressions, a random-walk rate under counts.  Zero-sum effects
+(`pm.ZeroSumNormal`, multivariate.py:2654-2807: `zerosumnormal_logp` under `ZeroSumTransform`, transforms.py:644-696).
 
 The graphs are what THE REFERENCE'S OWN CODE builds: a random walk's density is derived -- `random_walk_logp` (timeseries.py:234-244) ->
 `logprob_cumsum` (logprob/cumsum.py:53-74: the differences of the value) -> `logprob_join` (logprob/tensor.py:115-157: the first value
 under the initial distribution, the rest under the innovations') -- and `AR` registers `ar_logp` (timeseries.py:646-676); tests/stubgraph.py
-executes those bodies and the distributions' `logp`.  Committed: the graphs (tests/golden/ts_graphs.npz) and torch autograd of them
-at seeded points (tests/golden/ts_graphs_golden.npz).  Checked here: the lowered spec through the oracle's interpreter == those
+executes those bodies and the distributions' `logp`.  Committed: the graphs (tests/golden/more_graphs.npz) and torch autograd of them
+at seeded points (tests/golden/more_graphs_golden.npz).  Checked here: the lowered spec through the oracle's interpreter == those
 numbers; the same densities written independently with SciPy; a short NUTS run by the oracle's sampler.
 
-Host only (tests/timeseries_models.py says why): no `-m gpu` twin this round."""
+Host only (tests/more_models.py says why): no `-m gpu` twin this round."""
+# (file renamed from the time-series-only version: the zero-sum models joined it)
 import os
 import sys
 
@@ -18,7 +20,7 @@ from scipy import stats
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import stubgraph as sg  # noqa: E402
-import timeseries_models as tm  # noqa: E402
+import more_models as tm  # noqa: E402
 
 from oracle import ref_models, ref_sampler  # noqa: E402
 from pymc_amd import model_spec as ms  # noqa: E402
@@ -51,7 +53,7 @@ def test_the_committed_graphs_and_values_are_what_the_reference_code_gives_now()
     if not sg.available():
         pytest.skip("needs /root/reference")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-    import make_timeseries_golden as mg
+    import make_more_golden as mg
 
     now = mg.run()
     z = np.load(tm.GOLDEN)
@@ -98,7 +100,31 @@ def _rate(q):
     return lp + stats.poisson(np.exp(level)).logpmf(tm.COUNTS).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
+def _zs_backward(v):
+    n = len(v) + 1
+    sv = v.sum()
+    norm = sv / (np.sqrt(n) + n)
+    return np.concatenate([v, [norm - sv / np.sqrt(n)]]) - norm
+
+
+def _zs_prior(z, sigma):
+    K = len(z)            # a Normal(0, sigma) on the K - 1 dimensional subspace: the Gaussian kernel over all K, the normaliser K - 1 times
+    return (-0.5 * (z / sigma) ** 2).sum() - (np.log(np.sqrt(2.0 * np.pi)) + np.log(sigma)) * (K - 1)
+
+
+def _zs_groups(q):
+    K = tm.K_ZS
+    a, tau, z, s = q[0], np.exp(q[1]), _zs_backward(q[2 : 2 + K - 1]), np.exp(q[2 + K - 1])
+    lp = stats.norm(0, 5.0).logpdf(a) + stats.halfnorm(scale=1.0).logpdf(tau) + q[1] + stats.halfnorm(scale=1.0).logpdf(s) + q[2 + K - 1]
+    return lp + _zs_prior(z, tau) + stats.norm(a + z[tm.G_ZS], s).logpdf(tm.Y_ZS).sum()
+
+
+def _zs_rates(q):
+    a, z = q[0], _zs_backward(q[1:])
+    return stats.norm(0, 2.0).logpdf(a) + _zs_prior(z, 0.7) + stats.poisson(np.exp(a + z)).logpmf(tm.Y_ZS2).sum()
+
+
+@pytest.mark.parametrize("name, dens", [("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
     spec = _committed(name)
     qs, lps, _ = _golden(name)
@@ -124,6 +150,38 @@ def test_what_the_time_series_lower_to():
     assert sorted(f.size for f in spec.factors if f.name.split(".")[0] == "x") == [1, tm.T_AR - 1]
     spec = _committed("random_walk_rate_under_counts")
     assert [f.size for f in spec.factors if f.name == "level"] == [tm.T_LL]
+
+
+def test_what_the_zero_sum_models_lower_to_and_what_their_trace_holds():
+    """K - 1 free values (`z_zerosum__`); the prior is ONE factor over the K constrained ones -- the `check_parameters` around its
+    reduction moved onto the elements, the unit Jacobian's `zeros_like` dropped -- and `z[group]` a selection between the free values and the
+    balancing one.  The trace holds `z` itself (`ZeroSumTransform.backward`, lowered as a Deterministic): it sums to zero."""
+    from pymc_amd.backends import NDArray
+
+    spec = _committed("zero_sum_group_effects")
+    zv = [v for v in spec.vars if v.value_name == "z_zerosum__"][0]
+    assert zv.size == tm.K_ZS - 1 and zv.transform == 0
+    zf = [f for f in spec.factors if f.name == "z"]
+    assert len(zf) == 1 and zf[0].size == tm.K_ZS and ms.E_CHECK in [i.op for i in zf[0].prog]
+    yf = [f for f in spec.factors if f.name == "y"][0]
+    assert yf.size == tm.N_ZS and [i.op for i in yf.prog].count(ms.E_SWITCH) == 1
+    tr = NDArray(model=spec)
+    tr.setup(4, 0)
+    q = np.random.default_rng(2).normal(size=(4, spec.n))
+    tr.record_batch(q, None)
+    assert tr.samples["z"].shape == (4, tm.K_ZS) and np.max(np.abs(tr.samples["z"].sum(axis=1))) < 1e-14
+    np.testing.assert_allclose(tr.samples["z"], np.stack([_zs_backward(r[zv.offset : zv.offset + zv.size]) for r in q]), rtol=1e-14, atol=1e-15)
+
+
+def test_nuts_on_the_zero_sum_model_recovers_the_group_effects():
+    spec = _committed("zero_sum_group_effects")
+    draws, st = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=80, tune=150, random_seed=9, init="adapt_diag")
+    post = draws[0][150:]
+    assert np.all(np.isfinite(post)) and sum(bool(s["diverging"]) for s in st[0][150:]) <= 2
+    z = np.stack([_zs_backward(r[2 : 2 + tm.K_ZS - 1]) for r in post]).mean(axis=0)
+    group_means = np.array([tm.Y_ZS[tm.G_ZS == k].mean() for k in range(tm.K_ZS)])
+    assert np.corrcoef(z, group_means - group_means.mean())[0, 1] > 0.95
+    assert abs(post[:, 0].mean() - group_means.mean()) < 0.3
 
 
 def test_nuts_on_the_lowered_autoregression_recovers_the_latent_path():
