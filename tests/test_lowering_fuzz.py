@@ -480,3 +480,54 @@ def test_random_graphs_as_deterministics_are_recorded_with_the_graphs_values(see
     for name in spec.deterministics:
         got = tr.samples[name].reshape(len(qs), -1)
         np.testing.assert_allclose(got, np.broadcast_to(want[name], got.shape), rtol=1e-12, atol=1e-13, err_msg=f"{seed} {name}")
+
+
+# ---- random models over the structured priors: zero-sum vectors (multivariate.py:2654-2807), Gaussian random walks and autoregressions
+# (timeseries.py) of random lengths and orders, used through gathers, element-wise and under short reductions ------------------------------
+def _structured_model(seed):
+    rng = np.random.default_rng(31000 + seed)
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 1.0)
+    s = m.HalfNormal("s", 1.0)
+    K = int(rng.integers(2, 13))
+    z = m.ZeroSumNormal("z", sigma=s if rng.uniform() < 0.5 else float(rng.uniform(0.3, 2.0)), shape=(K,))
+    n_obs = int(rng.integers(K, 3 * K + 2))
+    g = rng.integers(0, K, size=n_obs)
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        m.Normal("y", mu=a + z[g], sigma=0.6, observed=rng.normal(size=n_obs))
+    elif kind == 1:
+        m.Poisson("y", pt.exp(0.3 * a + 0.5 * z), observed=rng.poisson(2.0, size=K).astype("float64"))
+    elif kind == 2:
+        m.Bernoulli("y", logit_p=a + z[g] * s, observed=(rng.uniform(size=n_obs) < 0.5).astype("float64"))
+    else:
+        m.Potential("pz", -0.5 * pt.sqr(pt.sum(pt.tanh(z) * sg.as_tensor(rng.normal(size=K)), axis=0) - a))
+    T = int(rng.integers(4, 40))
+    if rng.uniform() < 0.5:
+        w = m.GaussianRandomWalk("w", mu=0.1 * a if rng.uniform() < 0.5 else 0.0, sigma=s if rng.uniform() < 0.6 else 0.5,
+                                 init_dist=("Normal", dict(mu=0.0, sigma=float(rng.uniform(0.5, 3.0)))), shape=(T,))
+    else:
+        p = int(rng.integers(1, min(4, T - 1)))
+        const = bool(rng.uniform() < 0.5)
+        rho = m.Normal("rho", 0.0, 0.4, shape=(p + int(const),))
+        w = m.AR("w", rho, sigma=s if rng.uniform() < 0.6 else 0.5, init_dist=("Normal", dict(mu=0.0, sigma=1.5)), constant=const, shape=(T,))
+    if rng.uniform() < 0.5:
+        m.Normal("yw", mu=w, sigma=0.4, observed=rng.normal(size=T))
+    else:
+        m.StudentT("yw", 4.0, mu=0.0, sigma=pt.exp(0.3 * w), observed=rng.normal(size=T))
+    return m
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_models_over_zero_sum_vectors_and_time_series_keep_value_and_gradient(seed):
+    m = _structured_model(seed)
+    spec = lower_to_spec(m)
+    rng = np.random.default_rng(6000 + seed)
+    for scale in (0.3, 0.8):
+        q = rng.normal(size=spec.n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert np.isfinite(lp0)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
+    assert "z" in spec.deterministics
