@@ -317,7 +317,24 @@ def build_tree(v, memo: Optional[dict] = None):
         out = ("take", kid, ik)
     elif name in ("Dot", "Matmul"):
         a, b = build_tree(ins[0], memo), build_tree(ins[1], memo)
-        out = _const(np.asarray(a[1]) @ np.asarray(b[1])) if (a[0] == "const" and b[0] == "const") else ("dot", a, b)
+        sa, sb = (_eff_shape(ins[0]), _eff_shape(ins[1])) if memo.get("__shapes__") else (None, None)
+        if a[0] == "const" and b[0] == "const":
+            out = _const(np.asarray(a[1]) @ np.asarray(b[1]))
+        elif sa is not None and sb is not None and 1 <= len(sa) <= 2 and 1 <= len(sb) <= 2 and sa[-1] == sb[0] and sa[-1] <= MAX_DOT_INNER:
+            # a product over a SHORT inner dimension outside the dense nodes (`X @ B` with B a [P, K] matrix of coefficients under a softmax;
+            # `pm.math.dot(X, beta)` as the location of a StudentT): element (n, k) = sum_p A[n, p] B[p, k], written out -- every term a
+            # product of two broadcasts, which the element-wise programs turn into gathers / folded constants
+            P, oshape = sa[-1], tuple(sa[:-1]) + tuple(sb[1:])
+            n_out = _numel(oshape)
+            K = _numel(sb[1:])
+            e = np.arange(n_out, dtype=np.int64)
+            out = None
+            for p_ in range(P):
+                term = ("mul", ("bcast", a, (e // K) * P + p_, tuple(sa), oshape) if _numel(sa) > 1 else a,
+                        ("bcast", b, p_ * K + e % K, tuple(sb), oshape) if _numel(sb) > 1 else b)
+                out = term if out is None else ("add", out, term)
+        else:
+            out = ("dot", a, b)
     elif name == "Softmax":
         out = ("softmax", build_tree(ins[0], memo))
         if memo.get("__shapes__") and _eff_shape(ins[0]) is not None:
@@ -345,6 +362,9 @@ def _numel(shape) -> int:
     for d in shape:
         n *= int(d)
     return n
+
+
+MAX_DOT_INNER = 32     # (the inner dimension of a `Dot` that is written out term by term: the limit of the unrolled reductions)
 
 
 def _eff_shape(v):
@@ -1274,17 +1294,18 @@ class _Lowering:
         """The conditions of a `check_parameters` / `pt.all([...])`: element-wise AND (OR for `any`) of the listed conditions -- the
         reduction to one scalar over the factor's elements (`pt.all`) is what NUTS_E_CHECK means on the device (a failed check kills
         the whole factor)."""
+        if node[0] in ("all", "any") and len(node) == 4 and node[3] is not None and node[1][0] != "makevector" and len(node[3]) >= 2 \
+                and _numel(node[3]) != self._fsize and _numel(node[3][:-1]) == self._fsize and node[3][-1] <= self.MAX_UNROLLED_SUM:
+            # a condition with K values per element of the factor (`0 <= p` of a Categorical whose p has a row per observation): reduced
+            # over its last axis, one value per element remains -- the reduction over the elements is what NUTS_E_CHECK means.  (Asked first: a few short rows
+            # are also a small vector, and writing ALL their elements out would cost the factor's size times the program)
+            return self._unrolled_sum((node[0], len(node[3]) - 1, node[1], node[3]))
         if node[0] in ("all", "any") and len(node) == 4 and node[3] is not None and node[1][0] != "makevector" \
                 and 1 < _numel(node[3]) <= self.MAX_UNROLLED_SUM and _numel(node[3]) != self._fsize:
             # a vector-valued condition inside a factor of another size (`a > 0` of a Dirichlet's K concentrations, whose density is
             # one number): every element, written out.  A condition with one value per element of the factor stays element-wise --
             # the reduction over the factor's elements is what NUTS_E_CHECK means.
             return self._unrolled_sum((node[0], None, node[1], node[3]))
-        if node[0] in ("all", "any") and len(node) == 4 and node[3] is not None and node[1][0] != "makevector" and len(node[3]) >= 2 \
-                and _numel(node[3]) != self._fsize and _numel(node[3][:-1]) == self._fsize and node[3][-1] <= self.MAX_UNROLLED_SUM:
-            # a condition with K values per element of the factor (`0 <= p` of a Categorical whose p has a row per observation): reduced
-            # over its last axis, one value per element remains -- the reduction over the elements is what NUTS_E_CHECK means
-            return self._unrolled_sum((node[0], len(node[3]) - 1, node[1], node[3]))
         if node[0] in ("all", "any"):
             inner = node[1]
             parts = list(inner[1:]) if inner[0] == "makevector" else [inner]

@@ -2,7 +2,8 @@
 of the reference's own example gallery, autoregressions, a random-walk rate under counts -- the densities are the reference's
 `random_walk_logp` / `logprob_cumsum` / `logprob_join` / `ar_logp` bodies and its distributions' `logp`, executed on tests/stubgraph.py.
 Zero-sum effects (`pm.ZeroSumNormal`, multivariate.py:2654-2807, under `ZeroSumTransform`, transforms.py:644-696): group effects that sum
-to zero next to an intercept.
+to zero next to an intercept.  Matrix products outside the dense nodes: a softmax regression with a [P, K] coefficient matrix, a robust
+regression whose location is `pm.math.dot(X, beta)`.
 
 HOST ONLY this round: these specs use nothing the device has not run (element-wise programs over gathers, the opcodes of
 tests/test_general_lowering.py's models), but no GPU minutes were left to run THEM on the device, so they are kept out of
@@ -97,7 +98,39 @@ def zero_sum_log_rates():
     return m
 
 
+N_SM, P_SM, K_SM = 90, 4, 3
+X_SM = _rg.normal(size=(N_SM, P_SM))
+_B = _rg.normal(size=(P_SM, K_SM)) * 1.2
+Y_SM = np.array([_rg.choice(K_SM, p=np.exp(e - e.max()) / np.exp(e - e.max()).sum()) for e in X_SM @ _B + np.array([0.3, -0.2, 0.0])], dtype="float64")
+Y_RB = X_SM @ np.array([0.8, -0.5, 0.0, 1.1]) + 0.4 * _rg.standard_t(3.0, size=N_SM)
+
+
+def softmax_regression():
+    """Multinomial logistic regression, the way it is usually written: `B` a [P, K] matrix of coefficients, `a` K intercepts,
+    `y ~ Categorical(p = softmax(X @ B + a))`.  The matrix product is no dense node's: over a short inner dimension it is written out
+    (element (n, k) = sum_p X[n, p] B[p, k]: the column of X a data vector, the element of B a gather), then the softmax row and
+    `Categorical.logp`'s selection of the observed category."""
+    m = sg.StubModel()
+    B = m.Normal("B", 0.0, 2.0, shape=(P_SM, K_SM))
+    a = m.Normal("a", 0.0, 2.0, shape=(K_SM,))
+    m.Categorical("y", p=pt.softmax(pt.dot(sg.as_tensor(X_SM), B) + a[None, :], axis=-1), observed=Y_SM)
+    return m
+
+
+def robust_regression_with_dot():
+    """`pm.math.dot(X, beta)` as the location of a StudentT with a random nu: not the GLM node's families, so the product is written out
+    inside the likelihood's program."""
+    m = sg.StubModel()
+    b = m.Normal("b", 0.0, 2.0, shape=(P_SM,))
+    s = m.HalfNormal("s", 1.0)
+    nu = m.Gamma("nu", 2.0, 0.1)
+    m.StudentT("y", nu, mu=pt.dot(sg.as_tensor(X_SM), b), sigma=s, observed=Y_RB)
+    return m
+
+
 MODELS = {
+    "softmax_regression": softmax_regression,
+    "robust_regression_with_dot": robust_regression_with_dot,
     "zero_sum_group_effects": zero_sum_group_effects,
     "zero_sum_log_rates": zero_sum_log_rates,
     "stochastic_volatility": stochastic_volatility,

@@ -531,3 +531,57 @@ def test_random_models_over_zero_sum_vectors_and_time_series_keep_value_and_grad
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
     assert "z" in spec.deterministics
+
+
+# ---- matrix products over a short inner dimension, outside the dense nodes: [N, P] @ [P], [N, P] @ [P, K], [P] @ [P, K]; either operand
+# a constant, a variable or an expression; the result under an element-wise function, a softmax row, a reduction ---------------------------
+def _dot_model(seed):
+    rng = np.random.default_rng(41000 + seed)
+    m = sg.StubModel()
+    Nr, P, K = int(rng.integers(3, 9)), int(rng.integers(1, 5)), int(rng.integers(2, 4))      # (P K terms per row: the programs' 128 instructions)
+    X = sg.as_tensor(rng.normal(size=(Nr, P)))
+    B = m.Normal("B", 0.0, 1.0, shape=(P, K))
+    b = m.Normal("b", 0.0, 1.0, shape=(P,))
+    s = m.HalfNormal("s", 1.0)
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        eta = pt.dot(X, B)                                              # [N, K]
+    elif kind == 1:
+        eta = pt.dot(X * s, pt.tanh(B))                                 # expressions on both sides
+    elif kind == 2:
+        eta = pt.dot(X, B) + pt.dot(X, b)[:, None]                      # a mat-mat next to a mat-vec
+    elif kind == 3:
+        eta = pt.dot(pt.tanh(X + s), B * 0.5)
+    elif kind == 4:
+        eta = pt.dot(X, B) * pt.dot(b, B)[None, :]                      # [P] @ [P, K] -> [K]
+    else:
+        eta = pt.dot(X, pt.exp(0.2 * B)) - s
+    use = rng.integers(0, 4)
+    if use == 0:
+        yc = rng.integers(0, K, size=Nr).astype("float64")
+        m.Categorical("y", p=pt.softmax(eta, axis=-1), observed=yc)
+    elif use == 1:
+        m.Potential("p", -0.5 * pt.sqr(eta - 0.3).sum(axis=1))
+    elif use == 2:
+        m.Potential("p", pt.logsumexp(eta, axis=1) * -0.7 + pt.tanh(eta[:, 0]))
+    else:
+        m.StudentT("y", 4.0, mu=pt.dot(X, b) + 0.1 * eta[:, int(rng.integers(0, K))], sigma=s, observed=rng.normal(size=Nr))
+    return m
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_matrix_products_keep_value_and_gradient(seed):
+    m = _dot_model(seed)
+    try:
+        spec = lower_to_spec(m)
+    except NotLowerable as e:
+        assert "instruction" in str(e) or "longer" in str(e), str(e)
+        pytest.skip(f"refused: {e}")
+    rng = np.random.default_rng(7000 + seed)
+    for scale in (0.3, 0.8):
+        q = rng.normal(size=spec.n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert np.isfinite(lp0)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))

@@ -1,6 +1,7 @@
 """More of the reference's model vocabulary through the lowering.  Time series (distributions/timeseries.py: `GaussianRandomWalk`, `AR`):
 the stochastic-volatility model of the reference's example gallery, autoregressions, a random-walk rate under counts.  Zero-sum effects
-(`pm.ZeroSumNormal`, multivariate.py:2654-2807: `zerosumnormal_logp` under `ZeroSumTransform`, transforms.py:644-696).
+(`pm.ZeroSumNormal`, multivariate.py:2654-2807: `zerosumnormal_logp` under `ZeroSumTransform`, transforms.py:644-696).  Matrix products
+over a short inner dimension outside the dense nodes (`softmax(X @ B + a)`, `StudentT(mu = pm.math.dot(X, beta))`).
 
 The graphs are what THE REFERENCE'S OWN CODE builds: a random walk's density is derived -- `random_walk_logp` (timeseries.py:234-244) ->
 `logprob_cumsum` (logprob/cumsum.py:53-74: the differences of the value) -> `logprob_join` (logprob/tensor.py:115-157: the first value
@@ -124,7 +125,22 @@ def _zs_rates(q):
     return stats.norm(0, 2.0).logpdf(a) + _zs_prior(z, 0.7) + stats.poisson(np.exp(a + z)).logpmf(tm.Y_ZS2).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
+def _softmax_reg(q):
+    P, K = tm.P_SM, tm.K_SM
+    B, a = q[: P * K].reshape(P, K), q[P * K :]
+    eta = tm.X_SM @ B + a
+    logp_rows = eta - np.logaddexp.reduce(eta, axis=1)[:, None]
+    return stats.norm(0, 2.0).logpdf(q).sum() + logp_rows[np.arange(tm.N_SM), tm.Y_SM.astype(int)].sum()
+
+
+def _robust_dot(q):
+    P = tm.P_SM
+    b, s, nu = q[:P], np.exp(q[P]), np.exp(q[P + 1])
+    lp = stats.norm(0, 2.0).logpdf(b).sum() + stats.halfnorm(scale=1.0).logpdf(s) + q[P] + stats.gamma(2.0, scale=1 / 0.1).logpdf(nu) + q[P + 1]
+    return lp + stats.t(nu, tm.X_SM @ b, s).logpdf(tm.Y_RB).sum()
+
+
+@pytest.mark.parametrize("name, dens", [("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
     spec = _committed(name)
     qs, lps, _ = _golden(name)
@@ -171,6 +187,17 @@ def test_what_the_zero_sum_models_lower_to_and_what_their_trace_holds():
     tr.record_batch(q, None)
     assert tr.samples["z"].shape == (4, tm.K_ZS) and np.max(np.abs(tr.samples["z"].sum(axis=1))) < 1e-14
     np.testing.assert_allclose(tr.samples["z"], np.stack([_zs_backward(r[zv.offset : zv.offset + zv.size]) for r in q]), rtol=1e-14, atol=1e-15)
+
+
+def test_what_the_matrix_products_lower_to():
+    spec = _committed("softmax_regression")
+    assert spec.glm_rows is None and spec.logit_rows is None
+    y = [f for f in spec.factors if f.name == "y"][0]
+    ops = [i.op for i in y.prog]
+    assert y.dist == ms.D_POTENTIAL and y.size == tm.N_SM and ops.count(ms.E_MUL) >= tm.P_SM * tm.K_SM and len(ops) <= ms.MAX_FACTOR_INSTR
+    spec = _committed("robust_regression_with_dot")
+    y = [f for f in spec.factors if f.name == "y"][0]
+    assert spec.glm_rows is None and y.size == tm.N_SM and [i.op for i in y.prog].count(ms.E_GAMMALN) == 2
 
 
 def test_nuts_on_the_zero_sum_model_recovers_the_group_effects():
