@@ -128,7 +128,41 @@ def robust_regression_with_dot():
     return m
 
 
+N_OP = 54
+X_OP = _rg.normal(size=N_OP)
+Y_OP = np.digitize(1.1 * X_OP + _rg.normal(size=N_OP), [-0.8, 0.9]).astype("float64")
+N_ZI = 60
+_zi_keep = _rg.uniform(size=N_ZI) < 0.65
+Y_ZIB = (_rg.binomial(12, 0.3, size=N_ZI) * _zi_keep).astype("float64")
+Y_ZINB = (_rg.negative_binomial(2.0, 2.0 / (2.0 + 3.0), size=N_ZI) * _zi_keep).astype("float64")
+
+
+def ordered_probit_three_levels():
+    """`pm.OrderedProbit` (discrete.py:1329-1432) with ordered cutpoints: three levels -- every level's probability is a
+    `log_diff_normal_cdf` / `normal_lcdf` body of some twenty-five instructions and `Categorical.logp` checks all of them, so four levels
+    no longer fit a factor's 128 instructions (refused by name)."""
+    m = sg.StubModel()
+    b = m.Normal("b", 0.0, 2.0)
+    c = m.Normal("c", np.array([-1.0, 1.0]), 2.0, shape=(2,), transform="ordered")
+    m.OrderedProbit("y", eta=b * sg.as_tensor(X_OP), cutpoints=c, observed=Y_OP)
+    return m
+
+
+def zero_inflated_binomial_and_negative_binomial():
+    """`pm.ZeroInflatedBinomial`, `pm.ZeroInflatedNegativeBinomial` (mixture.py:641-800) sharing one inflation probability."""
+    m = sg.StubModel()
+    psi = m.Beta("psi", 2.0, 2.0)
+    p = m.Beta("p", 2.0, 2.0)
+    m.ZeroInflatedBinomial("yb", psi, 12, p, observed=Y_ZIB)
+    mu = m.Gamma("mu", 2.0, 0.5)
+    al = m.Exponential("al", 0.5)
+    m.ZeroInflatedNegativeBinomial("ynb", psi, mu, al, observed=Y_ZINB)
+    return m
+
+
 MODELS = {
+    "ordered_probit_three_levels": ordered_probit_three_levels,
+    "zero_inflated_binomial_and_negative_binomial": zero_inflated_binomial_and_negative_binomial,
     "softmax_regression": softmax_regression,
     "robust_regression_with_dot": robust_regression_with_dot,
     "zero_sum_group_effects": zero_sum_group_effects,

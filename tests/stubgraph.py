@@ -778,6 +778,7 @@ def reference():
     ref_function("logprob/censoring.py", "clip_logprob", ns)
     ns["sigmoid"] = pt.sigmoid          # discrete.py:52 `from pymc.math import sigmoid`
     ref_class("distributions/discrete.py", "OrderedLogistic", ["compute_p"], object, ns)
+    ref_class("distributions/discrete.py", "OrderedProbit", ["compute_p"], object, ns)       # (discrete.py:1415-1432: normal_lccdf / log_diff_normal_cdf / normal_lcdf)
     # Dirichlet (distributions/multivariate.py:543-584: `dist`, `logp`) under its default transform (`simplex_cont_transform`,
     # multivariate.py:126-127 -> `transforms.simplex` = `SimplexTransform()`, logprob/transforms.py:1091-1115)
     ref_class("distributions/multivariate.py", "Dirichlet", ["dist", "logp"], _DistBase, ns)
@@ -1053,6 +1054,28 @@ class StubModel:
         p = reference()["OrderedLogistic"].compute_p(eta, cutpoints)
         return self.Categorical(name, p=p, observed=observed)
 
+    def OrderedProbit(self, name, eta, cutpoints, observed, sigma=1.0):
+        """`pm.OrderedProbit(name, eta=, cutpoints=, sigma=, observed=y)` (discrete.py:1329-1432): `Categorical` over the reference's own
+        `compute_p` -- exp of [normal_lccdf, log_diff_normal_cdf ..., normal_lcdf] of `eta[..., None] - cutpoints`."""
+        p = reference()["OrderedProbit"].compute_p(eta, cutpoints, sigma)
+        return self.Categorical(name, p=p, observed=observed)
+
+    def _zero_inflated(self, name, psi, nonzero_cls, nonzero_params, observed):
+        ref = reference()
+        nonzero = _ComponentRV(ref[nonzero_cls], nonzero_params)
+        w, comps = ref["_zero_inflated_mixture"](name=None, nonzero_p=psi, nonzero_dist=nonzero)
+        comps = [c if isinstance(c, _ComponentRV) else _ComponentRV(ref["DiracDelta"], c) for c in comps]
+        fn = lambda value, w_, *cs: ref["mixture_logprob"](None, (value,), None, w_, *cs)   # noqa: E731
+        return self._add(_RV(name, np.shape(observed), fn, (w, *comps), None, observed))
+
+    def ZeroInflatedBinomial(self, name, psi, n, p, observed):
+        """`pm.ZeroInflatedBinomial(name, psi=, n=, p=, observed=y)` (mixture.py:641-702)."""
+        return self._zero_inflated(name, psi, "Binomial", _dist("Binomial", n=n, p=p), observed)
+
+    def ZeroInflatedNegativeBinomial(self, name, psi, mu, alpha, observed):
+        """`pm.ZeroInflatedNegativeBinomial(name, psi=, mu=, alpha=, observed=y)` (mixture.py:705-800)."""
+        return self._zero_inflated(name, psi, "NegativeBinomial", _dist("NegativeBinomial", mu=mu, alpha=alpha), observed)
+
     def Censored(self, name, dist, lower, upper, observed):
         """`pm.Censored(name, Dist.dist(...), lower=, upper=, observed=y)` (distributions/censored.py): the reference's `clip_logprob` over
         the base distribution's logp / logcdf / logccdf; `dist` = ("Normal", dict(mu=..., sigma=...)); a bound of None is open."""
@@ -1198,7 +1221,12 @@ class StubModel:
         for rv in self.free + self.obs:
             lp = rv.logp_fn(rv.expr, *rv.params)
             if rv.transform is not None:     # transform_value.py:95-133: + transform.log_jac_det(value, *rv_inputs)
-                lp = lp + rv.transform_obj.log_jac_det(rv.value, *rv.rv_inputs).copy()
+                jac = rv.transform_obj.log_jac_det(rv.value, *rv.rv_inputs).copy()
+                # (:103-108) a multivariate transform on a univariate distribution (`Normal(..., transform=ordered)`): the Jacobian has
+                # fewer dimensions than the logp, whose last ones are reduced first -- they are no longer independent
+                if jac.ndim < lp.ndim:
+                    lp = lp.sum(axis=np.arange(jac.ndim - lp.ndim, 0))
+                lp = lp + jac
             out.append(lp)
         out.extend(e for _, e in self.pots)
         return out

@@ -23,6 +23,10 @@ from pymc_amd import model_spec as ms  # noqa: E402
 from pymc_amd.lowering import lower_to_spec  # noqa: E402
 
 NAMES = sorted(lm.GENERAL)
+# `mixture_with_ordered_means`: its committed graph was corrected after the round's last device run (the ordered transform's Jacobian
+# counted once, as logprob/transform_value.py:103-108 does -- tests/golden/make_spec_digests.py tells the story), so the device has
+# not seen this spec: its two device tests run at the end of the session
+DEVICE_NAMES = [pytest.param(n, marks=pytest.mark.not_yet_run_on_device) if n == "mixture_with_ordered_means" else n for n in NAMES]
 INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
 
 
@@ -134,7 +138,7 @@ def _prior_only():
 
 # ---- device ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", DEVICE_NAMES)
 def test_device_reproduces_autograd_of_the_reference_graph(name):
     from pymc_amd.value_grad import DeviceValueGradFunction
 
@@ -149,7 +153,7 @@ def test_device_reproduces_autograd_of_the_reference_graph(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", DEVICE_NAMES)
 def test_nuts_on_the_lowered_graph_has_the_oracle_samplers_integers(name):
     from pymc_amd.sampling import sample
 
@@ -167,7 +171,10 @@ def test_nuts_on_the_lowered_graph_has_the_oracle_samplers_integers(name):
         same += 1
     # (one late multinomial pick may flip on a last-bit difference; the model with erfcx / gammaln / pow of random parameters in one
     # density -- ExGaussian, HalfStudentT, Pareto -- amplifies the device's vs SciPy's last bits sooner: 26 of 42 transitions measured)
-    assert same >= (20 if name == "density_zoo_3" else tune + draws - 2), (name, same)
+    # (`mixture_with_ordered_means`: 14 transitions of up to a thousand leaves each on a spec the device has not run -- the bar is where a
+    # wrong program must fail and a last-bit flip in a late multinomial pick cannot)
+    bar = {"density_zoo_3": 20, "mixture_with_ordered_means": 6}.get(name, tune + draws - 2)
+    assert same >= bar, (name, same)
     res["step"].close()
 
 

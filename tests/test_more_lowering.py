@@ -140,7 +140,28 @@ def _robust_dot(q):
     return lp + stats.t(nu, tm.X_SM @ b, s).logpdf(tm.Y_RB).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
+def _ordered_probit(q):
+    b, c = q[0], np.array([q[1], q[1] + np.exp(q[2])])
+    lp = stats.norm(0, 2.0).logpdf(b) + stats.norm([-1.0, 1.0], 2.0).logpdf(c).sum() + q[2]          # (the ordered transform's Jacobian)
+    z = (b * tm.X_OP)[:, None] - c[None, :]                                                               # eta - cutpoints
+    cdf = stats.norm.cdf(z)
+    p = np.stack([1.0 - cdf[:, 0], cdf[:, 0] - cdf[:, 1], cdf[:, 1]], axis=1)
+    return lp + np.log(p[np.arange(tm.N_OP), tm.Y_OP.astype(int)]).sum()
+
+
+def _zi_counts(q):
+    from scipy.special import expit
+
+    psi, p, mu, al = expit(q[0]), expit(q[1]), np.exp(q[2]), np.exp(q[3])
+    lp = stats.beta(2, 2).logpdf(psi) + np.log(psi * (1 - psi)) + stats.beta(2, 2).logpdf(p) + np.log(p * (1 - p))
+    lp += stats.gamma(2.0, scale=1 / 0.5).logpdf(mu) + q[2] + stats.expon(scale=1 / 0.5).logpdf(al) + q[3]
+    for y, base in ((tm.Y_ZIB, stats.binom(12, p)), (tm.Y_ZINB, stats.nbinom(al, al / (al + mu)))):
+        lp += np.where(y == 0, np.log((1 - psi) + psi * base.pmf(0)), np.log(psi) + base.logpmf(y)).sum()
+    return lp
+
+
+@pytest.mark.parametrize("name, dens", [("ordered_probit_three_levels", _ordered_probit), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
+                                        ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
     spec = _committed(name)
     qs, lps, _ = _golden(name)
