@@ -585,3 +585,23 @@ def test_random_matrix_products_keep_value_and_gradient(seed):
         assert np.isfinite(lp0)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
+
+
+def test_a_second_regression_likelihood_next_to_the_glm_node_is_written_out():
+    """Two outcomes that share their coefficients: the first likelihood takes the model's ONE GLM node; the second one's `dot` (inner
+    dimension 5) is written out inside its own element-wise factor instead of the refusal `more than one dense node`."""
+    rng = np.random.default_rng(3)
+    N, P = 40, 5
+    X, X2 = rng.normal(size=(N, P)), rng.normal(size=(25, P))
+    m = sg.StubModel()
+    b = m.Normal("b", 0.0, 1.0, shape=(P,))
+    s = m.HalfNormal("s", 1.0)
+    m.Normal("y1", mu=pt.dot(sg.as_tensor(X), b), sigma=s, observed=rng.normal(size=N))
+    m.Poisson("y2", pt.exp(pt.dot(sg.as_tensor(X2), b)), observed=rng.poisson(2.0, size=25).astype("float64"))
+    spec = lower_to_spec(m)
+    assert spec.glm_rows is not None and spec.glm_rows.X.shape == (N, P) and [f.size for f in spec.factors if f.name == "y2"] == [25]
+    for scale in (0.2, 0.7):
+        q = rng.normal(size=spec.n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)) and np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
