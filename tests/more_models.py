@@ -160,7 +160,27 @@ def zero_inflated_binomial_and_negative_binomial():
     return m
 
 
+Y_TR1 = _rg.uniform(0.3, 2.4, size=20)
+Y_TR2 = _rg.uniform(1.1, 6.0, size=15)
+Y_TR3 = _rg.uniform(-3.0, 0.9, size=12)
+
+
+def truncated_likelihoods():
+    """`pm.Truncated` (distributions/truncated.py:418-458) over three base families, truncated on both sides, below only, above only: the
+    base density less the log of the mass between the bounds -- `logdiffexp` of the base's `logcdf` at the two bounds, its `logccdf` at
+    the lower one, its `logcdf` at the upper one -- behind the support switches."""
+    m = sg.StubModel()
+    lam = m.HalfNormal("lam", 2.0)
+    m.Truncated("e", ("Exponential", dict(lam=lam)), 0.2, 2.5, observed=Y_TR1)
+    mu = m.Normal("mu", 0.0, 2.0)
+    s = m.HalfNormal("s", 2.0)
+    m.Truncated("lo", ("Laplace", dict(mu=mu, b=s)), 1.0, None, observed=Y_TR2)
+    m.Truncated("up", ("Logistic", dict(mu=mu, s=s)), None, 1.0, observed=Y_TR3)
+    return m
+
+
 MODELS = {
+    "truncated_likelihoods": truncated_likelihoods,
     "ordered_probit_three_levels": ordered_probit_three_levels,
     "zero_inflated_binomial_and_negative_binomial": zero_inflated_binomial_and_negative_binomial,
     "softmax_regression": softmax_regression,

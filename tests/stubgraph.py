@@ -362,6 +362,7 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     where = staticmethod(lambda c, a, b: elemwise(Switch, c, a, b))
     fill = staticmethod(lambda a, b: elemwise(Second, a, b))
     softplus = staticmethod(lambda a: elemwise(Softplus, a))
+    log1pexp = softplus                     # (`pt.log1pexp` IS `softplus`: tensor/math.py)
     erf = staticmethod(lambda a: elemwise(Erf, a))
     erfc = staticmethod(lambda a: elemwise(Erfc, a))
     erfcx = staticmethod(lambda a: elemwise(Erfcx, a))
@@ -538,6 +539,16 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     def softmax(x, axis=-1):
         x = as_tensor(x)
         return Variable(Apply(Softmax(axis), [x]), shape=x.type.shape)
+
+    @staticmethod
+    def full_like(x, fill_value, dtype=None):
+        """`pt.full_like(x, v)` = `fill(x, v)` (tensor/basic.py `full_like`)."""
+        return elemwise(Second, x, fill_value)
+
+    @staticmethod
+    def isneginf(x):
+        """`pt.isneginf(x)`: `isinf(x) & (x < 0)` in PyTensor; the same truth table written with the comparison the programs have."""
+        return pt.eq(x, -np.inf)
 
     @staticmethod
     def add(*xs):
@@ -792,6 +803,19 @@ def reference():
     # zero-sum axis (the last)
     ref_class("distributions/transforms.py", "ZeroSumTransform", ["__init__", "extend_axis", "backward", "log_jac_det"], _TransformBase, ns)
     ref_function("distributions/multivariate.py", "zerosumnormal_logp", ns)
+    # `pm.Truncated(name, Dist.dist(...), lower=, upper=)` (distributions/truncated.py:418-458 `truncated_logprob`, :213-247 its two helper
+    # expressions, math.py:389-396 `logdiffexp`): the base density less the log of the mass between the bounds, taken from the base
+    # distribution's own `logcdf` (`logccdf` for an open upper side); `graph_replace` re-uses the lower bound's logcdf graph at the upper
+    tr = dict(ns)
+    tr["config"] = type("config", (), {"floatX": "float64"})
+    tr["logp"] = lambda rv, value, **kw: rv.owner.op.dist_cls.logp(value, *rv.owner.inputs)
+    tr["logcdf"] = lambda rv, value, **kw: rv.owner.op.dist_cls.logcdf(value, *rv.owner.inputs)
+    tr["logccdf"] = lambda rv, value, **kw: _logccdf_helper(rv, value)
+    tr["graph_replace"] = _graph_replace
+    ref_function("math.py", "logdiffexp", tr)
+    ref_class("distributions/truncated.py", "TruncatedRV", ["_create_logcdf_exprs", "_create_lower_logccdf_expr"], object, tr)
+    ref_function("distributions/truncated.py", "truncated_logprob", tr)
+    ns["truncated"] = tr
     # time series (distributions/timeseries.py): a random walk is `cumsum(concatenate([init, innovations]))` of two measurable variables
     # (:100-105) and its log-density is DERIVED -- `random_walk_logp` (:234-244) asks `logp(rv, value)`, which the reference's own
     # logprob rules answer: `logprob_cumsum` (logprob/cumsum.py:53-74: the value's differences under the base variable) over
@@ -813,6 +837,24 @@ def reference():
     ns["timeseries"] = ts
     _NS = ns
     return ns
+
+
+def _graph_replace(out, replace):
+    """`pytensor.graph.replace.graph_replace(out, {old: new})`: the graph of `out` with `old` replaced -- rebuilt above the replaced
+    variables, shared below them."""
+    done = {id(k): v for k, v in replace.items()}
+
+    def go(v):
+        if id(v) in done:
+            return done[id(v)]
+        if getattr(v, "owner", None) is None:
+            return v
+        ins = [go(i) for i in v.owner.inputs]
+        out_ = v if all(a is b for a, b in zip(ins, v.owner.inputs)) else Variable(Apply(v.owner.op, ins), shape=v.type.shape)
+        done[id(v)] = out_
+        return out_
+
+    return go(out)
 
 
 class _Measurable:
@@ -1141,6 +1183,21 @@ class StubModel:
         op = type("op", (), {"ar_order": order, "constant_term": bool(constant)})()
         fn = lambda value, rhos_, sigma_: ref["timeseries"]["ar_logp"](op, (value,), rhos_, sigma_, init, None, None)   # noqa: E731
         return self._add(_RV(name, tuple(shape), fn, (rhos, as_tensor(sigma)), None, None))
+
+    def Truncated(self, name, dist, lower, upper, observed):
+        """`pm.Truncated(name, Dist.dist(...), lower=, upper=, observed=y)`; `dist` = ("Exponential", dict(lam=...)); a bound of None is open."""
+        ref = reference()
+        tr = ref["truncated"]
+        cls_name, kw = dist
+        params = list(_dist(cls_name, **kw))
+        base_op = type("base_op", (), {"dist_cls": ref[cls_name], "name": None})()
+        base_rv = type("base_rv", (), {"owner": type("owner", (), {"op": base_op, "inputs": params})(), "type": type("type", (), {"dtype": "float64"})()})()
+        base_op.make_node = lambda *rv_inputs: type("node", (), {"default_output": staticmethod(lambda: base_rv)})()
+        op = type("op", (), {"base_rv_op": base_op})()
+        lo = TensorConstant(-np.inf) if lower is None else as_tensor(lower)
+        up = TensorConstant(np.inf) if upper is None else as_tensor(upper)
+        fn = lambda value: tr["truncated_logprob"](op, (value,), *params, lo, up)   # noqa: E731
+        return self._add(_RV(name, np.shape(observed), fn, (), None, observed))
 
     def ZeroInflatedPoisson(self, name, psi, mu, observed):
         """`pm.ZeroInflatedPoisson(name, psi=psi, mu=mu, observed=y)` (mixture.py:560-575, 577-640): the reference's

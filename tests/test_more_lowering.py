@@ -1,7 +1,8 @@
 """More of the reference's model vocabulary through the lowering.  Time series (distributions/timeseries.py: `GaussianRandomWalk`, `AR`):
 the stochastic-volatility model of the reference's example gallery, autoregressions, a random-walk rate under counts.  Zero-sum effects
 (`pm.ZeroSumNormal`, multivariate.py:2654-2807: `zerosumnormal_logp` under `ZeroSumTransform`, transforms.py:644-696).  Matrix products
-over a short inner dimension outside the dense nodes (`softmax(X @ B + a)`, `StudentT(mu = pm.math.dot(X, beta))`).
+over a short inner dimension outside the dense nodes (`softmax(X @ B + a)`, `StudentT(mu = pm.math.dot(X, beta))`).  `pm.Truncated`
+(distributions/truncated.py), `pm.OrderedProbit`, the zero-inflated Binomial and NegativeBinomial.
 
 The graphs are what THE REFERENCE'S OWN CODE builds: a random walk's density is derived -- `random_walk_logp` (timeseries.py:234-244) ->
 `logprob_cumsum` (logprob/cumsum.py:53-74: the differences of the value) -> `logprob_join` (logprob/tensor.py:115-157: the first value
@@ -160,7 +161,16 @@ def _zi_counts(q):
     return lp
 
 
-@pytest.mark.parametrize("name, dens", [("ordered_probit_three_levels", _ordered_probit), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
+def _truncated(q):
+    lam, mu, s = np.exp(q[0]), q[1], np.exp(q[2])
+    lp = stats.halfnorm(scale=2).logpdf(lam) + q[0] + stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=2).logpdf(s) + q[2]
+    E, L, G = stats.expon(scale=1 / lam), stats.laplace(mu, s), stats.logistic(mu, s)
+    lp += (E.logpdf(tm.Y_TR1) - np.log(E.cdf(2.5) - E.cdf(0.2))).sum()
+    lp += (L.logpdf(tm.Y_TR2) - np.log(L.sf(1.0))).sum()
+    return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
+
+
+@pytest.mark.parametrize("name, dens", [("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
     spec = _committed(name)
