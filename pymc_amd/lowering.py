@@ -2012,6 +2012,42 @@ class _Lowering:
         self._general_tree(node, name, own)
 
     def _general_tree(self, node, name: str, own: Optional[int], piece: bool = False):
+        """One factor from one tree -- or two, when its program would not fit: the parameter checks that wrap a density
+        (`check_parameters(res, 0 <= p, p <= 1, isclose(sum(p), 1))` of a Categorical whose every probability is a long expression:
+        `pm.OrderedProbit`) become a factor of their own, `check(0, conds)`: 0 where they hold, -inf where they fail, which is what they
+        add to the density either way."""
+        n_data, n_fac = len(self.spec.data), len(self.spec.factors)
+        try:
+            self._general_tree_one(node, name, own, piece)
+            return
+        except NotLowerable as e:
+            full = lambda nd: nd[0] == "sum" and (nd[1] is None or (len(nd) == 4 and nd[3] is not None and len(nd[3]) <= 1))   # noqa: E731
+            while full(node):
+                node = node[2]
+            if "instructions" not in str(e) or node[0] != "check" or len(node) < 3:
+                raise
+            first = e
+        conds = []           # the listed conditions, one by one (`all(makevector(c1, c2, ...))` is their conjunction)
+        for c in node[2:]:
+            inner = c[1] if c[0] == "all" and _is_node(c[1]) and c[1][0] == "makevector" else None
+            conds += list(inner[1:]) if inner is not None else [c]
+        for attempt in ([conds], [[c] for c in conds]):        # all checks in one factor; failing that, a factor per condition
+            del self.spec.data[n_data:]
+            del self.spec.factors[n_fac:]
+            self._gather_ids = {k: v for k, v in self._gather_ids.items() if v < n_data}
+            try:
+                self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+                self._general_tree_one(node[1], name, own, True)
+                for j, cs in enumerate(attempt):
+                    self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
+                    self._general_tree_one(("check", _const(0.0), *cs), f"{name}.checks" + (f".{j}" if len(attempt) > 1 else ""), own, True)
+                return
+            except NotLowerable as e2:
+                if "instructions" not in str(e2) or len(conds) == 1:
+                    raise first
+        raise first
+
+    def _general_tree_one(self, node, name: str, own: Optional[int], piece: bool = False):
         full = lambda nd: nd[0] == "sum" and (nd[1] is None or (len(nd) == 4 and nd[3] is not None and len(nd[3]) <= 1))   # noqa: E731
         while full(node):
             node = node[2]

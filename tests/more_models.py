@@ -131,6 +131,7 @@ def robust_regression_with_dot():
 N_OP = 54
 X_OP = _rg.normal(size=N_OP)
 Y_OP = np.digitize(1.1 * X_OP + _rg.normal(size=N_OP), [-0.8, 0.9]).astype("float64")
+Y_OP4 = np.digitize(0.9 * X_OP - 0.2 + 0.8 * np.cos(np.arange(N_OP) * 1.7), [-0.9, 0.1, 1.0]).astype("float64")   # (no new random draws: later data stay put)
 N_ZI = 60
 _zi_keep = _rg.uniform(size=N_ZI) < 0.65
 Y_ZIB = (_rg.binomial(12, 0.3, size=N_ZI) * _zi_keep).astype("float64")
@@ -139,12 +140,22 @@ Y_ZINB = (_rg.negative_binomial(2.0, 2.0 / (2.0 + 3.0), size=N_ZI) * _zi_keep).a
 
 def ordered_probit_three_levels():
     """`pm.OrderedProbit` (discrete.py:1329-1432) with ordered cutpoints: three levels -- every level's probability is a
-    `log_diff_normal_cdf` / `normal_lcdf` body of some twenty-five instructions and `Categorical.logp` checks all of them, so four levels
-    no longer fit a factor's 128 instructions (refused by name)."""
+    `log_diff_normal_cdf` / `normal_lcdf` body of some twenty-five instructions and `Categorical.logp` checks all of them: 100 of a
+    factor's 128 instructions."""
     m = sg.StubModel()
     b = m.Normal("b", 0.0, 2.0)
     c = m.Normal("c", np.array([-1.0, 1.0]), 2.0, shape=(2,), transform="ordered")
     m.OrderedProbit("y", eta=b * sg.as_tensor(X_OP), cutpoints=c, observed=Y_OP)
+    return m
+
+
+def ordered_probit_four_levels():
+    """Four levels: density and checks no longer fit ONE program of 128 instructions -- the density keeps the factor, each of
+    `Categorical.logp`'s three parameter checks (`0 <= p`, `p <= 1`, `isclose(sum(p), 1)`) becomes a factor `check(0, cond)` of its own."""
+    m = sg.StubModel()
+    b = m.Normal("b", 0.0, 2.0)
+    c = m.Normal("c", np.array([-1.0, 0.0, 1.0]), 2.0, shape=(3,), transform="ordered")
+    m.OrderedProbit("y", eta=b * sg.as_tensor(X_OP), cutpoints=c, observed=Y_OP4)
     return m
 
 
@@ -182,6 +193,7 @@ def truncated_likelihoods():
 MODELS = {
     "truncated_likelihoods": truncated_likelihoods,
     "ordered_probit_three_levels": ordered_probit_three_levels,
+    "ordered_probit_four_levels": ordered_probit_four_levels,
     "zero_inflated_binomial_and_negative_binomial": zero_inflated_binomial_and_negative_binomial,
     "softmax_regression": softmax_regression,
     "robust_regression_with_dot": robust_regression_with_dot,

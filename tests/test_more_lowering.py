@@ -150,6 +150,14 @@ def _ordered_probit(q):
     return lp + np.log(p[np.arange(tm.N_OP), tm.Y_OP.astype(int)]).sum()
 
 
+def _ordered_probit4(q):
+    b, c = q[0], np.cumsum([q[1], np.exp(q[2]), np.exp(q[3])])
+    lp = stats.norm(0, 2.0).logpdf(b) + stats.norm([-1.0, 0.0, 1.0], 2.0).logpdf(c).sum() + q[2] + q[3]
+    cdf = stats.norm.cdf((b * tm.X_OP)[:, None] - c[None, :])
+    p = np.concatenate([1.0 - cdf[:, :1], cdf[:, :-1] - cdf[:, 1:], cdf[:, -1:]], axis=1)
+    return lp + np.log(p[np.arange(tm.N_OP), tm.Y_OP4.astype(int)]).sum()
+
+
 def _zi_counts(q):
     from scipy.special import expit
 
@@ -170,7 +178,8 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
+@pytest.mark.parametrize("name, dens", [("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+                                        ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
     spec = _committed(name)
@@ -218,6 +227,18 @@ def test_what_the_zero_sum_models_lower_to_and_what_their_trace_holds():
     tr.record_batch(q, None)
     assert tr.samples["z"].shape == (4, tm.K_ZS) and np.max(np.abs(tr.samples["z"].sum(axis=1))) < 1e-14
     np.testing.assert_allclose(tr.samples["z"], np.stack([_zs_backward(r[zv.offset : zv.offset + zv.size]) for r in q]), rtol=1e-14, atol=1e-15)
+
+
+def test_a_density_whose_checks_do_not_fit_its_program_gets_them_as_factors_of_their_own():
+    spec = _committed("ordered_probit_four_levels")
+    ys = [f for f in spec.factors if f.name.split(".")[0] == "y"]
+    assert [f.name for f in ys] == ["y", "y.checks.0", "y.checks.1", "y.checks.2"] and all(len(f.prog) <= ms.MAX_FACTOR_INSTR for f in ys)
+    assert ms.E_CHECK not in [i.op for i in ys[0].prog] and all([i.op for i in f.prog].count(ms.E_CHECK) == 1 for f in ys[1:])
+    q = _golden("ordered_probit_four_levels")[0][1]
+    lp = ref_models.evaluate(spec, q)[0]
+    assert np.isfinite(lp)
+    spec3 = _committed("ordered_probit_three_levels")          # (three levels: one factor, checks inside)
+    assert [f.name for f in spec3.factors if f.name.split(".")[0] == "y"] == ["y"]
 
 
 def test_what_the_matrix_products_lower_to():
