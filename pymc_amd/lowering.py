@@ -242,23 +242,51 @@ def build_tree(v, memo: Optional[dict] = None):
         else:
             arr[idx] += yk[1]
         out = _const(arr)
-    elif name in ("IncSubtensor", "CumOp") and not memo.get("__shapes__"):
+    elif name == "CumOp" and _is_constant_graph(ins[0]) and getattr(op, "mode", "add") == "add":
+        kid = build_tree(ins[0], memo)            # index arithmetic (`pt.cumsum(pt.arange(1, n + 1)) - 1`, multivariate.py:1278): folds
+        if kid[0] != "const":
+            raise NotLowerable("a cumulative sum of constants that did not fold")
+        out = _const(np.cumsum(np.asarray(kid[1]), axis=getattr(op, "axis", None)))
+    elif name in ("IncSubtensor", "CumOp", "AdvancedIncSubtensor1", "AdvancedIncSubtensor") and not memo.get("__shapes__"):
         raise NotLowerable(f"{name} needs the shape-aware walk")
-    elif name == "IncSubtensor":                  # `pt.set_subtensor(x[idx], y)`: x with the indexed region replaced by y
-        if not getattr(op, "set_instead_of_inc", False) or len(ins) != 2:
-            raise NotLowerable("IncSubtensor that increments, or with a symbolic index")
+    elif name in ("IncSubtensor", "AdvancedIncSubtensor1", "AdvancedIncSubtensor"):
+        # `pt.set_subtensor(x[idx], y)` / `pt.inc_subtensor(x[idx], y)`: x with the indexed region replaced by y / incremented by y.  idx:
+        # integers and slices (`idx_list` of the op), or constant integer arrays (further inputs: `value[diag_idxs]`, `out[tril_indices]`)
         xk, yk = build_tree(ins[0], memo), build_tree(ins[1], memo)
         xs, ys = _eff_shape(ins[0]), _eff_shape(ins[1])
         if xs is None or ys is None:
             raise NotLowerable("set_subtensor of a shape that is not static")
-        idx = tuple(getattr(op, "idx_list", ()))
+        if name == "IncSubtensor":
+            if len(ins) != 2:
+                raise NotLowerable("IncSubtensor with a symbolic index")
+            idx = tuple(getattr(op, "idx_list", ()))
+        else:
+            iks = [build_tree(i, memo) for i in ins[2:]]
+            if any(k_[0] != "const" for k_ in iks):
+                raise NotLowerable(f"{name} with an index that is not a constant")
+            idx = tuple(np.asarray(k_[1]).astype(np.int64) for k_ in iks)
         idx = idx if len(idx) != 1 else idx[0]
         piece = np.zeros(xs, dtype=np.int64)
         inner = np.arange(_numel(xs), dtype=np.int64).reshape(xs)
         region = inner[idx]
+        if np.unique(region).size != np.size(region):
+            raise NotLowerable(f"{name}: the same element indexed twice")
         piece[idx] = 1
         inner[idx] = np.broadcast_to(np.arange(_numel(ys), dtype=np.int64).reshape(ys), np.shape(region)) if _numel(ys) > 1 else 0
-        out = ("joinnd", piece.ravel(), inner.ravel(), tuple(xs), xk, yk)
+        if getattr(op, "set_instead_of_inc", False):
+            out = ("joinnd", piece.ravel(), inner.ravel(), tuple(xs), xk, yk)
+        else:                                     # x + [y at the indexed places, 0 elsewhere]
+            inner[piece == 0] = 0
+            placed = ("joinnd", piece.ravel(), inner.ravel(), tuple(xs), _const(0.0), yk)
+            out = placed if (xk[0] == "const" and not np.any(xk[1])) else ("add", xk, placed)
+    elif name == "AdvancedSubtensor":             # `x[rows, cols]` with constant integer arrays: positions in the raveled operand
+        kid = build_tree(ins[0], memo)
+        iks = [build_tree(i, memo) for i in ins[1:]]
+        shp = _eff_shape(ins[0])
+        if shp is None or any(k_[0] != "const" for k_ in iks) or len(iks) != len(shp):
+            raise NotLowerable("AdvancedSubtensor beyond one constant integer array per dimension")
+        flat = np.ravel_multi_index(tuple(np.asarray(k_[1]).astype(np.int64) for k_ in iks), shp).ravel()
+        out = _const(np.asarray(kid[1]).ravel()[flat]) if kid[0] == "const" else ("take", kid, _const(flat))
     elif name == "CumOp":                         # `pt.cumsum(x, axis)` over a short axis: every prefix sum written out
         if getattr(op, "mode", "add") != "add":
             raise NotLowerable("a cumulative product")
@@ -2151,14 +2179,14 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
         shapes[v.name] = shp
         tr = getattr(model, "value_transforms", {}).get(v.name)
         if tr is not None and not isinstance(tr, tuple):
-            if tr.name in ("ordered", "zerosum"):
-                tr = (5 if tr.name == "ordered" else 6, 0.0, 1.0)
+            if tr.name in ("ordered", "zerosum", "cholesky-cov-packed"):
+                tr = ({"ordered": 5, "zerosum": 6, "cholesky-cov-packed": 7}[tr.name], 0.0, 1.0)
             else:
                 code = {"log": ms.TR_LOG, "logodds": ms.TR_LOGODDS, "interval": ms.TR_INTERVAL, "simplex": _TR_SIMPLEX}[tr.name]
                 tr = (code, getattr(tr, "lower", 0.0), getattr(tr, "upper", 1.0))
         # `transforms.ordered` (distributions/transforms.py:79-125): no transform code in the IR -- the value variable is stored as it
         # is, `Ordered.backward` (a cumulative sum of [v0, exp(v1), ...]) and its log-Jacobian are part of the graphs and lower op by op
-        if tr is not None and int(tr[0]) in (5, 6):      # (6: `ZeroSumTransform`, transforms.py:644-696 -- likewise part of the graphs)
+        if tr is not None and int(tr[0]) in (5, 6, 7):   # (6: `ZeroSumTransform`, transforms.py:644-696; 7: `CholeskyCovPacked`, :430-453 -- likewise part of the graphs)
             if int(tr[0]) == 6:
                 resized.add(v.name)                       # (K - 1 free values for K constrained ones: the prior's factor has K elements)
             tr = None

@@ -99,6 +99,16 @@ def evaluate(var, values: dict, memo: dict | None = None):
                     out[idx if len(idx) != 1 else idx[0]] = ev(ins[1])
                 else:
                     out[idx if len(idx) != 1 else idx[0]] += ev(ins[1])
+            elif name == "AdvancedSubtensor":
+                out = ev(ins[0])[tuple(ev(i).to(torch.int64) for i in ins[1:])]
+            elif name in ("AdvancedIncSubtensor1", "AdvancedIncSubtensor"):
+                out = ev(ins[0]).clone().to(torch.float64)
+                idx = tuple(ev(i).to(torch.int64) for i in ins[2:])
+                y = ev(ins[1]).to(torch.float64)
+                if op.set_instead_of_inc:
+                    out[idx] = y
+                else:
+                    out[idx] = out[idx] + y
             elif name == "Prod":
                 out = ev(ins[0]).prod() if op.axis is None else ev(ins[0]).prod(dim=op.axis)
             elif name == "CumOp":

@@ -190,7 +190,41 @@ def truncated_likelihoods():
     return m
 
 
+J_VS, N_VS = 7, 56
+CTY_VS = np.arange(N_VS) % J_VS
+FLOOR_VS = ((np.arange(N_VS) * 7) % 3 == 0).astype("float64")
+Y_VS = 1.4 + 0.3 * np.sin(CTY_VS * 1.3) - (0.6 + 0.2 * np.cos(CTY_VS * 0.7)) * FLOOR_VS + 0.35 * np.sin(np.arange(N_VS) * 2.1)   # (no random draws)
+
+
+def varying_slopes_lkj():
+    """Varying intercepts and slopes with an LKJ prior, non-centred -- the multilevel model of the reference's gallery: `chol, _, _ =
+    pm.LKJCholeskyCov("chol", n=2, eta=2, sd_dist=pm.Exponential.dist(1))`, `z ~ Normal(0, 1, shape=(2, J))`, `ab = pm.math.dot(chol, z)`,
+    `y ~ Normal((mu[0] + ab[0][county]) + (mu[1] + ab[1][county]) * floor, s)`.  The packed factor's density (multivariate.py:1271-1310) is
+    cumulative sums, `inc_subtensor`s and integer-array indices over three values; `expand_packed_triangular` a `set_subtensor` at
+    `np.tril_indices`; the product with z has an inner dimension of two."""
+    m = sg.StubModel()
+    chol = m.LKJCholeskyCov("chol", n=2, eta=2.0, sd_dist=("Exponential", dict(lam=1.0)))
+    z = m.Normal("z", 0.0, 1.0, shape=(2, J_VS))
+    mu = m.Normal("mu", 0.0, 5.0, shape=(2,))
+    ab = pt.dot(chol, z)
+    s = m.HalfNormal("s", 1.0)
+    m.Normal("y", mu=(mu[0] + ab[0][CTY_VS]) + (mu[1] + ab[1][CTY_VS]) * FLOOR_VS, sigma=s, observed=Y_VS)
+    return m
+
+
+def three_correlated_effects_lkj():
+    """n = 3, eta = 1 (the other branch of `_lkj_normalizing_constant`), HalfNormal standard deviations."""
+    m = sg.StubModel()
+    chol = m.LKJCholeskyCov("chol", n=3, eta=1.0, sd_dist=("HalfNormal", dict(sigma=2.0)))
+    z = m.Normal("z", 0.0, 1.0, shape=(3, J_VS))
+    ab = pt.dot(chol, z)
+    m.Normal("y", mu=ab[0][CTY_VS] + ab[1][CTY_VS] * FLOOR_VS + 0.5 * ab[2][CTY_VS], sigma=0.6, observed=Y_VS)
+    return m
+
+
 MODELS = {
+    "varying_slopes_lkj": varying_slopes_lkj,
+    "three_correlated_effects_lkj": three_correlated_effects_lkj,
     "truncated_likelihoods": truncated_likelihoods,
     "ordered_probit_three_levels": ordered_probit_three_levels,
     "ordered_probit_four_levels": ordered_probit_four_levels,

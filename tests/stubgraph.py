@@ -72,6 +72,11 @@ class Variable:
         if isinstance(idx, Variable):   # a symbolic integer vector (`mu[c]` with c another variable of the model)
             return Variable(Apply(AdvancedSubtensor1(), [self, idx]), shape=idx.type.shape + self.type.shape[1:])
         tup = idx if isinstance(idx, tuple) else (idx,)
+        if len(tup) == 2 and tup[0] is Ellipsis and len(self.type.shape) == 1 and isinstance(tup[1], (np.ndarray, list, Variable)):
+            return self[tup[1]]          # `value[..., self.diag_idxs]` of a vector value (transforms.py:447): the leading dimensions are none
+        if len(tup) == len(self.type.shape) >= 2 and all(isinstance(i, np.ndarray) and i.dtype.kind in "iu" for i in tup):
+            # `out[np.tril_indices(n)]` (math.py:526-528): one constant integer array per dimension -> `AdvancedSubtensor`, inputs (x, *indices)
+            return Variable(Apply(AdvancedSubtensor(), [self, *[TensorConstant(i) for i in tup]]), shape=np.broadcast_shapes(*[i.shape for i in tup]))
         if any(i is None for i in tup):
             shp, src = [], list(self.type.shape)
             for i in tup:
@@ -103,6 +108,7 @@ class Variable:
     def tag(self): return _Tag()
     def sum(self, axis=None, keepdims=False): return pt.sum(self, axis=axis, keepdims=keepdims)
     def zeros_like(self, dtype=None): return pt.zeros_like(self)
+    def cumsum(self, axis=None): return pt.cumsum(self, axis=axis)
     def __matmul__(self, o): return pt.dot(self, o)
     def __rmatmul__(self, o): return pt.dot(o, self)
     def copy(self): return self          # (`log_jac_det(...).copy()`, transform_value.py:102: an identity node in PyTensor)
@@ -148,6 +154,24 @@ class DimShuffle:
 
 class AdvancedSubtensor1:
     pass
+
+
+class AdvancedSubtensor:
+    """`pytensor.tensor.subtensor.AdvancedSubtensor`: inputs (x, *index arrays), one integer array per dimension here."""
+
+
+class AdvancedIncSubtensor1:
+    """`pt.set_subtensor(x[idx], y)` / `pt.inc_subtensor(x[idx], y)` with one integer vector on the first dimension: inputs (x, y, idx)."""
+
+    def __init__(self, set_instead_of_inc):
+        self.set_instead_of_inc = set_instead_of_inc
+
+
+class AdvancedIncSubtensor:
+    """... with one integer array per dimension: inputs (x, y, *index arrays)."""
+
+    def __init__(self, set_instead_of_inc):
+        self.set_instead_of_inc = set_instead_of_inc
 
 
 class Sum:
@@ -422,14 +446,24 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     @staticmethod
     def set_subtensor(x_sub, y):
         """`pt.set_subtensor(x[idx], y)`: `x_sub` is the Subtensor node `x[idx]`; the result has x's shape."""
+        if x_sub.owner is not None and isinstance(x_sub.owner.op, (AdvancedSubtensor1, AdvancedSubtensor)):
+            return pt._adv_inc(x_sub, y, True)
         if x_sub.owner is None or not isinstance(x_sub.owner.op, Subtensor):
             raise NotImplementedError("stub: set_subtensor of something that is not x[basic index]")
         x = x_sub.owner.inputs[0]
         return Variable(Apply(IncSubtensor(x_sub.owner.op.idx_list, True), [x, as_tensor(y)]), shape=x.type.shape)
 
     @staticmethod
+    def _adv_inc(x_sub, y, set_):
+        x, *idx = x_sub.owner.inputs
+        op = AdvancedIncSubtensor1(set_) if isinstance(x_sub.owner.op, AdvancedSubtensor1) else AdvancedIncSubtensor(set_)
+        return Variable(Apply(op, [x, as_tensor(y), *idx]), shape=x.type.shape)
+
+    @staticmethod
     def cumsum(x, axis=None):
         x = as_tensor(x)
+        if axis is None and x.ndim == 1:
+            axis = 0                      # (`CumOp(axis=None)` ravels first: the same thing for a vector)
         return Variable(Apply(CumOp(axis, "add"), [x]), shape=x.type.shape)
 
     @staticmethod
@@ -486,6 +520,8 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     @staticmethod
     def inc_subtensor(x_sub, y):
         """`pt.inc_subtensor(x[idx], y)`: the IncSubtensor node that increments (`set_instead_of_inc=False`)."""
+        if x_sub.owner is not None and isinstance(x_sub.owner.op, (AdvancedSubtensor1, AdvancedSubtensor)):
+            return pt._adv_inc(x_sub, y, False)
         if x_sub.owner is None or not isinstance(x_sub.owner.op, Subtensor):
             raise NotImplementedError("stub: inc_subtensor of something that is not x[basic index]")
         x = x_sub.owner.inputs[0]
@@ -541,6 +577,17 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
         return Variable(Apply(Softmax(axis), [x]), shape=x.type.shape)
 
     @staticmethod
+    def arange(start, stop=None, step=1):
+        """`pt.arange` of Python numbers: a constant (PyTensor folds it when the bounds are constants)."""
+        return TensorConstant(np.arange(start, stop, step) if stop is not None else np.arange(start))
+
+    @staticmethod
+    def zeros(shape, dtype=None):
+        if isinstance(shape, TensorConstant):
+            shape = tuple(int(d) for d in np.atleast_1d(shape.data))
+        return TensorConstant(np.zeros(shape if isinstance(shape, tuple) else (int(shape),)))
+
+    @staticmethod
     def full_like(x, fill_value, dtype=None):
         """`pt.full_like(x, v)` = `fill(x, v)` (tensor/basic.py `full_like`)."""
         return elemwise(Second, x, fill_value)
@@ -592,6 +639,8 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     @staticmethod
     def atleast_1d(x):
         x = as_tensor(x)
+        if isinstance(x, TensorConstant):
+            return TensorConstant(np.atleast_1d(x.data))
         return x if x.ndim >= 1 else pt.expand_dims(x, 0)
 
     @staticmethod
@@ -706,6 +755,8 @@ class _NotScalarConstantError(Exception):
 
 
 def _get_underlying_scalar_constant_value(v, *a, **k):
+    if isinstance(v, (int, float, np.integer, np.floating)):       # (PyTensor's accepts plain numbers)
+        return v
     if isinstance(v, TensorConstant) and v.data.size == 1:
         return v.data.reshape(-1)[0]
     raise _NotScalarConstantError()
@@ -803,6 +854,18 @@ def reference():
     # zero-sum axis (the last)
     ref_class("distributions/transforms.py", "ZeroSumTransform", ["__init__", "extend_axis", "backward", "log_jac_det"], _TransformBase, ns)
     ref_function("distributions/multivariate.py", "zerosumnormal_logp", ns)
+    # `pm.LKJCholeskyCov(name, n=, eta=, sd_dist=)` (multivariate.py:1140-1164 `_lkj_normalizing_constant`, :1271-1310 the density of the
+    # PACKED Cholesky factor of a covariance matrix: standard deviations under `sd_dist`, correlations under LKJ(eta), the Jacobian between
+    # the two parameterisations) under its default transform `CholeskyCovPacked(n)` (transforms.py:430-453: the diagonal on the log
+    # scale), and `pm.expand_packed_triangular` (math.py:490-537) that makes the matrix of it
+    lk = dict(ns)
+    lk["pm"] = type("pm", (), {"logp": staticmethod(lambda rv, value: rv.dist_cls.logp(value, *rv.params))})
+    lk["pytensor"] = type("pytensor", (), {"config": type("config", (), {"floatX": "float64"})})
+    ref_function("distributions/multivariate.py", "_lkj_normalizing_constant", lk)
+    ref_function("distributions/multivariate.py", "_LKJCholeksyCovRV_logp", lk)
+    ref_class("distributions/transforms.py", "CholeskyCovPacked", ["__init__", "backward", "log_jac_det"], _TransformBase, lk)
+    ref_function("math.py", "expand_packed_triangular", lk)
+    ns["lkj"] = lk
     # `pm.Truncated(name, Dist.dist(...), lower=, upper=)` (distributions/truncated.py:418-458 `truncated_logprob`, :213-247 its two helper
     # expressions, math.py:389-396 `logdiffexp`): the base density less the log of the mass between the bounds, taken from the base
     # distribution's own `logcdf` (`logccdf` for an open upper side); `graph_replace` re-uses the lower bound's logcdf graph at the upper
@@ -962,7 +1025,7 @@ class StubModel:
 
     def _add(self, rv):
         (self.free if rv.observed is None else self.obs).append(rv)
-        if rv.observed is None and rv.transform in ("ordered", "zerosum"):
+        if rv.observed is None and rv.transform in ("ordered", "zerosum", "cholesky-cov-packed"):
             # the trace holds the variable itself next to its value variable (`model.unobserved_value_vars`, model/core.py:944-966): for
             # the transforms the IR has a code for, the backend applies `backward`; for this one the graph is the recipe
             self.deterministics[rv.name] = rv.expr
@@ -1184,6 +1247,20 @@ class StubModel:
         fn = lambda value, rhos_, sigma_: ref["timeseries"]["ar_logp"](op, (value,), rhos_, sigma_, init, None, None)   # noqa: E731
         return self._add(_RV(name, tuple(shape), fn, (rhos, as_tensor(sigma)), None, None))
 
+    def LKJCholeskyCov(self, name, n, eta, sd_dist):
+        """`chol, _, _ = pm.LKJCholeskyCov(name, n=n, eta=eta, sd_dist=pm.Exponential.dist(1.0), compute_corr=True)` (multivariate.py:1313-1500):
+        the free variable is the packed factor (n (n + 1) / 2 values, `<name>_cholesky-cov-packed__`); returned: the [n, n] lower-triangular
+        matrix `pm.expand_packed_triangular(n, packed, lower=True)` (:1466-1467)."""
+        ref = reference()
+        lk = ref["lkj"]
+        cls_name, kw = sd_dist
+        sd = _ComponentRV(ref[cls_name], _dist(cls_name, **kw))
+        tr = lk["CholeskyCovPacked"](n)
+        fn = lambda value: lk["_LKJCholeksyCovRV_logp"](None, (value,), None, int(n), float(eta), sd)   # noqa: E731  (n, eta: constants of the RV node)
+        rv = _RV(name, (n * (n + 1) // 2,), fn, (), "cholesky-cov-packed", None, transform_obj=tr)
+        packed = self._add(rv)
+        return lk["expand_packed_triangular"](n, packed, lower=True)
+
     def Truncated(self, name, dist, lower, upper, observed):
         """`pm.Truncated(name, Dist.dist(...), lower=, upper=, observed=y)`; `dist` = ("Exponential", dict(lam=...)); a bound of None is open."""
         ref = reference()
@@ -1262,7 +1339,7 @@ class StubModel:
     def value_transforms(self):
         # ("ordered" has no code of its own: the value variable is stored as it is, `Ordered.backward` and `log_jac_det` are part of the
         # graphs -- 5 tells the lowering so)
-        code = {"log": 1, "logodds": 2, "interval": 3, "simplex": 4, "ordered": 5, "zerosum": 6}      # (6: like 5 -- `ZeroSumTransform.backward` is in the graphs)
+        code = {"log": 1, "logodds": 2, "interval": 3, "simplex": 4, "ordered": 5, "zerosum": 6, "cholesky-cov-packed": 7}      # (6: like 5 -- `ZeroSumTransform.backward` is in the graphs)
         return {rv.value.name: (code[rv.transform], *(rv.bounds or (0.0, 1.0))) for rv in self.free if rv.transform}
 
     @property
@@ -1351,7 +1428,7 @@ def dump_model(m) -> dict:
 
 
 _OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot, Shape, Transpose, ExtractDiag, MatrixInverse,
-                                Any, Max, Join, Prod)}
+                                Any, Max, Join, Prod, AdvancedSubtensor)}
 _OPS_AXIS = ("Sum", "All", "Softmax", "TakeAlongAxis")
 
 
@@ -1382,6 +1459,8 @@ class FrozenModel:
                                       rec.get("set", True))
                 elif rec["op"] == "CumOp":
                     op = CumOp(rec.get("axis"), rec.get("mode", "add"))
+                elif rec["op"] in ("AdvancedIncSubtensor1", "AdvancedIncSubtensor"):
+                    op = globals()[rec["op"]](rec.get("set", True))
                 elif rec["op"] == "Cholesky":
                     op = Cholesky(rec.get("lower", True))
                 elif rec["op"] == "SolveTriangular":

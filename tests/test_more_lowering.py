@@ -2,7 +2,8 @@
 the stochastic-volatility model of the reference's example gallery, autoregressions, a random-walk rate under counts.  Zero-sum effects
 (`pm.ZeroSumNormal`, multivariate.py:2654-2807: `zerosumnormal_logp` under `ZeroSumTransform`, transforms.py:644-696).  Matrix products
 over a short inner dimension outside the dense nodes (`softmax(X @ B + a)`, `StudentT(mu = pm.math.dot(X, beta))`).  `pm.Truncated`
-(distributions/truncated.py), `pm.OrderedProbit`, the zero-inflated Binomial and NegativeBinomial.
+(distributions/truncated.py), `pm.OrderedProbit`, the zero-inflated Binomial and NegativeBinomial.  `pm.LKJCholeskyCov` with
+`pm.expand_packed_triangular` and a non-centred product (the gallery's varying-intercepts-and-slopes model).
 
 The graphs are what THE REFERENCE'S OWN CODE builds: a random walk's density is derived -- `random_walk_logp` (timeseries.py:234-244) ->
 `logprob_cumsum` (logprob/cumsum.py:53-74: the differences of the value) -> `logprob_join` (logprob/tensor.py:115-157: the first value
@@ -169,6 +170,32 @@ def _zi_counts(q):
     return lp
 
 
+def _lkj2_packed(v, eta, sd_logpdf):
+    """Density of the free values v of a packed 2 x 2 Cholesky factor L = [[e^v0, 0], [v1, e^v2]], from first principles: the standard
+    deviations (s1, s2) under `sd_dist`, the correlation r under LKJ(eta) -- for n = 2, (r + 1) / 2 ~ Beta(eta, eta) --, the Jacobian of
+    (s1, s2, r) -> (L11, L21, L22) = (s1, s2 r, s2 sqrt(1 - r^2)), which is s2 / sqrt(1 - r^2), and of the exponentials on the diagonal.
+    NORMALISED -- the reference's `_lkj_normalizing_constant` is not: for n = 2 it returns +log(4 / 3) at eta = 2 where the Beta's
+    constant is log(3 / 4) (the NEGATIVE of LKJ's c_k is what it computes); a constant, immaterial to MCMC, restated as the reference has it
+    by the caller."""
+    from scipy import special
+
+    L11, L21, L22 = np.exp(v[0]), v[1], np.exp(v[2])
+    s1, s2 = L11, np.hypot(L21, L22)
+    r = L21 / s2
+    lp_r = (eta - 1) * np.log1p(-r * r) - ((2 * eta - 1) * np.log(2.0) + special.betaln(eta, eta))
+    return sd_logpdf(s1) + sd_logpdf(s2) + lp_r - np.log(s2 / np.sqrt(1 - r * r)) + v[0] + v[2]
+
+
+def _varying_slopes(q):
+    J = tm.J_VS
+    v, z, mu, s = q[:3], q[3 : 3 + 2 * J].reshape(2, J), q[3 + 2 * J : 5 + 2 * J], np.exp(q[5 + 2 * J])
+    lp = _lkj2_packed(v, 2.0, stats.expon.logpdf) + 2.0 * np.log(4.0 / 3.0)            # (the reference's constant: see `_lkj2_packed`)
+    L = np.array([[np.exp(v[0]), 0.0], [v[1], np.exp(v[2])]])
+    ab = L @ z
+    lp += stats.norm(0, 1).logpdf(z).sum() + stats.norm(0, 5).logpdf(mu).sum() + stats.halfnorm(scale=1.0).logpdf(s) + q[5 + 2 * J]
+    return lp + stats.norm((mu[0] + ab[0][tm.CTY_VS]) + (mu[1] + ab[1][tm.CTY_VS]) * tm.FLOOR_VS, s).logpdf(tm.Y_VS).sum()
+
+
 def _truncated(q):
     lam, mu, s = np.exp(q[0]), q[1], np.exp(q[2])
     lp = stats.halfnorm(scale=2).logpdf(lam) + q[0] + stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=2).logpdf(s) + q[2]
@@ -178,7 +205,7 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+@pytest.mark.parametrize("name, dens", [("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
                                         ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
@@ -227,6 +254,26 @@ def test_what_the_zero_sum_models_lower_to_and_what_their_trace_holds():
     tr.record_batch(q, None)
     assert tr.samples["z"].shape == (4, tm.K_ZS) and np.max(np.abs(tr.samples["z"].sum(axis=1))) < 1e-14
     np.testing.assert_allclose(tr.samples["z"], np.stack([_zs_backward(r[zv.offset : zv.offset + zv.size]) for r in q]), rtol=1e-14, atol=1e-15)
+
+
+def test_the_lkj_models_lower_and_their_trace_holds_the_packed_factor():
+    """`LKJCholeskyCov`'s density is a sum of reductions (standard deviations, correlations, two Jacobians): a factor each.  The trace holds
+    the packed factor with its diagonal back on the natural scale (`CholeskyCovPacked.backward`, lowered as a Deterministic)."""
+    from pymc_amd.backends import NDArray
+
+    for name, n in (("varying_slopes_lkj", 2), ("three_correlated_effects_lkj", 3)):
+        spec = _committed(name)
+        cv = [v for v in spec.vars if v.value_name == "chol_cholesky-cov-packed__"][0]
+        assert cv.size == n * (n + 1) // 2 and cv.transform == 0 and spec.glm_rows is None
+        assert len([f for f in spec.factors if f.name.split(".")[0] == "chol"]) >= 3
+        tr = NDArray(model=spec)
+        tr.setup(3, 0)
+        q = np.random.default_rng(4).normal(size=(3, spec.n))
+        tr.record_batch(q, None)
+        want = q[:, cv.offset : cv.offset + cv.size].copy()
+        diag = np.cumsum(np.arange(1, n + 1)) - 1
+        want[:, diag] = np.exp(want[:, diag])
+        np.testing.assert_allclose(tr.samples["chol"], want, rtol=1e-15)
 
 
 def test_a_density_whose_checks_do_not_fit_its_program_gets_them_as_factors_of_their_own():
