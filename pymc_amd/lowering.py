@@ -309,6 +309,10 @@ def build_tree(v, memo: Optional[dict] = None):
     elif name == "Transpose":
         kid = build_tree(ins[0], memo)
         out = _const(np.swapaxes(kid[1], -1, -2)) if kid[0] == "const" else ("transpose", kid)
+    elif name == "Cholesky" and _ldlt_factor(ins[0]) is not None and getattr(op, "lower", True):
+        # `cholesky(L @ L.mT)` of a matrix tagged lower-triangular (`quaddist_matrix(chol=...)`, multivariate.py:148-151, tags it for exactly
+        # this): L -- PyTensor's `cholesky_ldotlt` rewrite
+        out = build_tree(_ldlt_factor(ins[0]), memo)
     elif name == "Cholesky":
         kid = build_tree(ins[0], memo)
         if kid[0] != "const":
@@ -322,15 +326,36 @@ def build_tree(v, memo: Optional[dict] = None):
         out = _const(np.linalg.inv(np.asarray(kid[1], dtype="float64")))
     elif name == "ExtractDiag":
         kid = build_tree(ins[0], memo)
-        if kid[0] != "const":
+        shp = _eff_shape(ins[0]) if memo.get("__shapes__") else None
+        if kid[0] == "const":
+            out = _const(np.diagonal(kid[1], axis1=-2, axis2=-1))
+        elif shp is not None and len(shp) == 2 and shp[0] == shp[1]:
+            out = ("take", kid, _const(np.arange(shp[0]) * (shp[0] + 1)))          # the diagonal of a small matrix of expressions
+        else:
             raise NotLowerable("diagonal of a non-constant matrix")
-        out = _const(np.diagonal(kid[1], axis1=-2, axis2=-1))
     elif name in ("SolveTriangular", "Solve"):
         a, b = build_tree(ins[0], memo), build_tree(ins[1], memo)
+        sa, sb = (_eff_shape(ins[0]), _eff_shape(ins[1])) if memo.get("__shapes__") else (None, None)
         if a[0] == "const" and b[0] == "const":
             import scipy.linalg
 
             out = _const(scipy.linalg.solve_triangular(a[1], b[1].T, lower=getattr(op, "lower", False)).T)
+        elif name == "SolveTriangular" and getattr(op, "lower", False) and sa is not None and sb is not None and len(sa) == 2 and sa[0] == sa[1] <= MAX_SOLVE \
+                and getattr(op, "b_ndim", 1) in (1, None) and len(sb) in (1, 2) and sb[-1] == sa[0]:
+            # `solve_lower(chol, delta, b_ndim=1)` with a SMALL lower-triangular matrix of expressions (a covariance factor that is a
+            # variable of the model): forward substitution written out, x_i = (b_i - sum_{j<i} L_ij x_j) / L_ii, every x_i a vector over
+            # the rows of b; the result assembled like any concatenation
+            k_, rows = sa[0], (sb[0] if len(sb) == 2 else 1)
+            cols = []
+            for i in range(k_):
+                bi = ("bcast", b, np.arange(rows, dtype=np.int64) * k_ + i, tuple(sb), (rows,)) if rows > 1 else ("index", b, i)
+                acc = bi
+                for j in range(i):
+                    acc = ("sub", acc, ("mul", ("index", a, i * k_ + j), cols[j]))
+                cols.append(("div", acc, ("index", a, i * k_ + i)))
+            piece = np.tile(np.arange(k_, dtype=np.int64), rows)
+            inner = np.repeat(np.arange(rows, dtype=np.int64), k_)
+            out = ("joinnd", piece, inner, tuple(sb), *cols)
         else:
             out = ("solve_lower" if getattr(op, "lower", False) else "solve_upper", a, b)
     elif name in ("AdvancedSubtensor1", "AdvancedSubtensor"):
@@ -390,6 +415,23 @@ def _numel(shape) -> int:
     for d in shape:
         n *= int(d)
     return n
+
+
+MAX_SOLVE = 8          # (the side of a lower-triangular matrix of expressions whose `solve_triangular` is written out)
+
+
+def _ldlt_factor(v):
+    """L when `v` is `L @ L.mT` and L carries `tag.lower_triangular` (multivariate.py:148-151, math.py:527-529), else None."""
+    owner = getattr(v, "owner", None)
+    if owner is None or _opname(owner.op) not in ("Dot", "Matmul") or len(owner.inputs) != 2:
+        return None
+    L, Lt = owner.inputs
+    t_owner = getattr(Lt, "owner", None)
+    if t_owner is None or t_owner.inputs[0] is not L:
+        return None
+    tname = _opname(t_owner.op)
+    swaps = tname == "Transpose" or (tname == "DimShuffle" and list(getattr(t_owner.op, "new_order", ())[-2:]) == [len(getattr(t_owner.op, "new_order", ())) - 1, len(getattr(t_owner.op, "new_order", ())) - 2])
+    return L if swaps and getattr(getattr(L, "tag", None), "lower_triangular", False) else None
 
 
 MAX_DOT_INNER = 32     # (the inner dimension of a `Dot` that is written out term by term: the limit of the unrolled reductions)

@@ -222,7 +222,33 @@ def three_correlated_effects_lkj():
     return m
 
 
+Y_MV2 = np.stack([0.8 * np.sin(np.arange(24) * 0.9) + 0.5, 0.6 * np.sin(np.arange(24) * 0.9 + 0.4) - 0.3 + 0.2 * np.cos(np.arange(24) * 2.3)], axis=1)
+Y_MV3 = np.concatenate([Y_MV2, (0.5 * Y_MV2[:, :1] - 0.7 * Y_MV2[:, 1:] + 0.3 * np.cos(np.arange(24) * 1.1)[:, None])], axis=1)
+
+
+def multivariate_outcomes_lkj():
+    """`y ~ MvNormal(mu, chol=chol)` with `chol` from `pm.LKJCholeskyCov`: a covariance factor that is a VARIABLE of the model.
+    `quaddist_matrix(chol=...)` forms `chol @ chol.mT` and tags chol lower-triangular, `quaddist_chol` takes `cholesky` of that product
+    (-> chol: the rewrite the tag exists for), `solve_lower(chol, y - mu, b_ndim=1)` is forward substitution over two columns, the log-
+    determinant the log of the diagonal (multivariate.py:128-185)."""
+    m = sg.StubModel()
+    chol = m.LKJCholeskyCov("chol", n=2, eta=2.0, sd_dist=("Exponential", dict(lam=1.0)))
+    mu = m.Normal("mu", 0.0, 3.0, shape=(2,))
+    m.MvNormal("y", mu=mu, chol=chol, observed=Y_MV2)
+    return m
+
+
+def three_outcomes_lkj():
+    m = sg.StubModel()
+    chol = m.LKJCholeskyCov("chol", n=3, eta=1.5, sd_dist=("HalfNormal", dict(sigma=2.0)))
+    mu = m.Normal("mu", 0.0, 3.0, shape=(3,))
+    m.MvNormal("y", mu=mu, chol=chol, observed=Y_MV3)
+    return m
+
+
 MODELS = {
+    "multivariate_outcomes_lkj": multivariate_outcomes_lkj,
+    "three_outcomes_lkj": three_outcomes_lkj,
     "varying_slopes_lkj": varying_slopes_lkj,
     "three_correlated_effects_lkj": three_correlated_effects_lkj,
     "truncated_likelihoods": truncated_likelihoods,

@@ -105,7 +105,10 @@ class Variable:
     @property
     def mT(self): return _transpose(self)
     @property
-    def tag(self): return _Tag()
+    def tag(self):
+        if "_tag" not in self.__dict__:
+            self._tag = _Tag()
+        return self._tag
     def sum(self, axis=None, keepdims=False): return pt.sum(self, axis=axis, keepdims=keepdims)
     def zeros_like(self, dtype=None): return pt.zeros_like(self)
     def cumsum(self, axis=None): return pt.cumsum(self, axis=axis)
@@ -1393,6 +1396,8 @@ def dump_model(m) -> dict:
             op = v.owner.op
             ins = [visit(i) for i in v.owner.inputs]
             rec = {"k": "op", "op": type(op).__name__, "ins": ins, "shape": list(v.type.shape)}
+            if getattr(v.tag, "lower_triangular", False):
+                rec["lower_triangular"] = True
             if hasattr(op, "scalar_op"):
                 if type(op.scalar_op).__name__ == "Composite":
                     raise TypeError("Composite nodes are not written down (they only occur in rewritten graphs)")
@@ -1468,6 +1473,8 @@ class FrozenModel:
                 else:
                     op = _OPS[rec["op"]]()
                 v = Variable(Apply(op, ins), shape=rec["shape"])
+                if rec.get("lower_triangular"):
+                    v.tag.lower_triangular = True
             vs.append(v)
         self._outs = [vs[i] for i in d["outs"]]
         self.value_vars = [vs[i] for i in d["value_vars"]]

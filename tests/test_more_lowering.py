@@ -196,6 +196,28 @@ def _varying_slopes(q):
     return lp + stats.norm((mu[0] + ab[0][tm.CTY_VS]) + (mu[1] + ab[1][tm.CTY_VS]) * tm.FLOOR_VS, s).logpdf(tm.Y_VS).sum()
 
 
+def _mv_outcomes(q):
+    v, mu = q[:3], q[3:5]
+    L = np.array([[np.exp(v[0]), 0.0], [v[1], np.exp(v[2])]])
+    lp = _lkj2_packed(v, 2.0, stats.expon.logpdf) + 2.0 * np.log(4.0 / 3.0) + stats.norm(0, 3).logpdf(mu).sum()
+    return lp + stats.multivariate_normal(mu, L @ L.T).logpdf(tm.Y_MV2).sum()
+
+
+def test_the_likelihood_of_the_three_outcome_model_is_scipys_multivariate_normal():
+    """n = 3: the prior's constant aside (`_lkj2_packed` tells why only n = 2 is restated whole), the observed factor alone against
+    SciPy -- Cholesky of the product, triangular solve and log-determinant written out over three columns."""
+    spec = _committed("three_outcomes_lkj")
+    y = [i for i, f in enumerate(spec.factors) if f.name.split(".")[0] == "y"]
+    only = ms.ModelSpec(vars=spec.vars, data=spec.data, factors=[spec.factors[i] for i in y])
+    for q in _golden("three_outcomes_lkj")[0]:
+        v = q[:6].copy()
+        v[[0, 2, 5]] = np.exp(v[[0, 2, 5]])
+        L = np.zeros((3, 3))
+        L[np.tril_indices(3)] = v
+        want = stats.multivariate_normal(q[6:9], L @ L.T).logpdf(tm.Y_MV3).sum()
+        assert abs(ref_models.evaluate(only, q)[0] - want) <= 1e-10 * abs(want)
+
+
 def _truncated(q):
     lam, mu, s = np.exp(q[0]), q[1], np.exp(q[2])
     lp = stats.halfnorm(scale=2).logpdf(lam) + q[0] + stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=2).logpdf(s) + q[2]
@@ -205,7 +227,7 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+@pytest.mark.parametrize("name, dens", [("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
                                         ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
@@ -261,7 +283,7 @@ def test_the_lkj_models_lower_and_their_trace_holds_the_packed_factor():
     the packed factor with its diagonal back on the natural scale (`CholeskyCovPacked.backward`, lowered as a Deterministic)."""
     from pymc_amd.backends import NDArray
 
-    for name, n in (("varying_slopes_lkj", 2), ("three_correlated_effects_lkj", 3)):
+    for name, n in (("varying_slopes_lkj", 2), ("three_correlated_effects_lkj", 3), ("multivariate_outcomes_lkj", 2), ("three_outcomes_lkj", 3)):
         spec = _committed(name)
         cv = [v for v in spec.vars if v.value_name == "chol_cholesky-cov-packed__"][0]
         assert cv.size == n * (n + 1) // 2 and cv.transform == 0 and spec.glm_rows is None
