@@ -605,3 +605,41 @@ def test_a_second_regression_likelihood_next_to_the_glm_node_is_written_out():
         lp0, g0 = gt.joint_logp_grad(m, q)
         lp, g = ref_models.evaluate(spec, q)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)) and np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
+
+
+# ---- covariance factors that are variables of the model: `pm.LKJCholeskyCov` of random size, concentration and standard-deviation prior, used
+# through a non-centred product, as the `chol` of an observed `pm.MvNormal`, or both ----------------------------------------------------
+def _lkj_model(seed):
+    rng = np.random.default_rng(51000 + seed)
+    n = int(rng.integers(2, 5))
+    m = sg.StubModel()
+    sd = [("Exponential", dict(lam=float(rng.uniform(0.5, 2.0)))), ("HalfNormal", dict(sigma=float(rng.uniform(0.5, 3.0)))), ("Gamma", dict(alpha=2.0, beta=1.5))][int(rng.integers(0, 3))]
+    chol = m.LKJCholeskyCov("chol", n=n, eta=float([1.0, 1.5, 2.0, 4.0][int(rng.integers(0, 4))]), sd_dist=sd)
+    use = int(rng.integers(0, 3))
+    if use in (0, 2):
+        J = int(rng.integers(2, 6))
+        z = m.Normal("z", 0.0, 1.0, shape=(n, J))
+        ab = pt.dot(chol, z)
+        g = rng.integers(0, J, size=12)
+        x = rng.normal(size=12)
+        m.Normal("y1", mu=ab[0][g] + ab[n - 1][g] * x, sigma=0.7, observed=rng.normal(size=12))
+    if use in (1, 2):
+        mu = m.Normal("mu", 0.0, 2.0, shape=(n,))
+        rows = int(rng.integers(1, 7))
+        Y = rng.normal(size=(rows, n)) if rows > 1 else rng.normal(size=(n,))
+        m.MvNormal("y2", mu=mu * 0.5 if rng.uniform() < 0.5 else mu, chol=chol, observed=Y)
+    return m
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_models_with_a_random_covariance_factor_keep_value_and_gradient(seed):
+    m = _lkj_model(seed)
+    spec = lower_to_spec(m)
+    rng = np.random.default_rng(8000 + seed)
+    for scale in (0.3, 0.7):
+        q = rng.normal(size=spec.n) * scale
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert np.isfinite(lp0)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
