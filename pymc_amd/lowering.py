@@ -356,6 +356,15 @@ def build_tree(v, memo: Optional[dict] = None):
             piece = np.tile(np.arange(k_, dtype=np.int64), rows)
             inner = np.repeat(np.arange(rows, dtype=np.int64), k_)
             out = ("joinnd", piece, inner, tuple(sb), *cols)
+        elif a[0] == "const" and sb is not None and np.asarray(a[1]).ndim == 2 and np.asarray(a[1]).shape[0] <= MAX_DOT_INNER and getattr(op, "b_ndim", 1) in (1, None) \
+                and len(sb) in (1, 2) and sb[-1] == np.asarray(a[1]).shape[0]:
+            # a CONSTANT triangular matrix against a vector (rows of vectors) of expressions (`MvNormal(mu = <expression>, cov = <constant>)`
+            # of a few dimensions: `solve_lower(cholesky(cov), value - mu, b_ndim=1)`): rows @ inv(A).T, a short product
+            import scipy.linalg
+
+            A = np.asarray(a[1], dtype="float64")
+            inv_t = scipy.linalg.solve_triangular(A, np.eye(A.shape[0]), lower=getattr(op, "lower", False)).T
+            out = _written_out_dot(b, _const(inv_t), tuple(sb), inv_t.shape)
         else:
             out = ("solve_lower" if getattr(op, "lower", False) else "solve_upper", a, b)
     elif name in ("AdvancedSubtensor1", "AdvancedSubtensor"):
@@ -374,18 +383,7 @@ def build_tree(v, memo: Optional[dict] = None):
         if a[0] == "const" and b[0] == "const":
             out = _const(np.asarray(a[1]) @ np.asarray(b[1]))
         elif sa is not None and sb is not None and 1 <= len(sa) <= 2 and 1 <= len(sb) <= 2 and sa[-1] == sb[0] and sa[-1] <= MAX_DOT_INNER:
-            # a product over a SHORT inner dimension outside the dense nodes (`X @ B` with B a [P, K] matrix of coefficients under a softmax;
-            # `pm.math.dot(X, beta)` as the location of a StudentT): element (n, k) = sum_p A[n, p] B[p, k], written out -- every term a
-            # product of two broadcasts, which the element-wise programs turn into gathers / folded constants
-            P, oshape = sa[-1], tuple(sa[:-1]) + tuple(sb[1:])
-            n_out = _numel(oshape)
-            K = _numel(sb[1:])
-            e = np.arange(n_out, dtype=np.int64)
-            out = None
-            for p_ in range(P):
-                term = ("mul", ("bcast", a, (e // K) * P + p_, tuple(sa), oshape) if _numel(sa) > 1 else a,
-                        ("bcast", b, p_ * K + e % K, tuple(sb), oshape) if _numel(sb) > 1 else b)
-                out = term if out is None else ("add", out, term)
+            out = _written_out_dot(a, b, sa, sb)
         else:
             out = ("dot", a, b)
     elif name == "Softmax":
@@ -418,6 +416,22 @@ def _numel(shape) -> int:
 
 
 MAX_SOLVE = 8          # (the side of a lower-triangular matrix of expressions whose `solve_triangular` is written out)
+
+
+def _written_out_dot(a, b, sa, sb):
+    """A product over a SHORT inner dimension outside the dense nodes (`X @ B` with B a [P, K] matrix of coefficients under a softmax;
+    `pm.math.dot(X, beta)` as the location of a StudentT): element (n, k) = sum_p A[n, p] B[p, k], written out -- every term a product of
+    two broadcasts, which the element-wise programs turn into gathers / folded constants."""
+    P, oshape = sa[-1], tuple(sa[:-1]) + tuple(sb[1:])
+    n_out = _numel(oshape)
+    K = _numel(sb[1:])
+    e = np.arange(n_out, dtype=np.int64)
+    out = None
+    for p_ in range(P):
+        term = ("mul", ("bcast", a, (e // K) * P + p_, tuple(sa), oshape) if _numel(sa) > 1 else a,
+                ("bcast", b, p_ * K + e % K, tuple(sb), oshape) if _numel(sb) > 1 else b)
+        out = term if out is None else ("add", out, term)
+    return out
 
 
 def _ldlt_factor(v):
@@ -2154,7 +2168,9 @@ class _Lowering:
                 if self._osize(o) not in (1, size):
                     raise NotLowerable(f"operands of {self._osize(o)} and {size} elements in one element-wise factor ({name}): a broadcast "
                                        "between different shapes is outside the element-wise programs")
-        if own is not None and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out and not piece \
+        # (a factor of ONE element is a density that reduced over the variable's elements itself -- a multivariate prior written out: every
+        # operand of its program has one element, checked above, so nothing was broadcast by accident)
+        if own is not None and size != 1 and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out and not piece \
                 and self.spec.vars[own].value_name not in getattr(self, "_resized", ()):
             raise NotLowerable(f"the factor of {self.spec.vars[own].name} does not have the variable's shape")
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)

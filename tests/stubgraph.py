@@ -1314,7 +1314,8 @@ class StubModel:
     def MvNormal(self, name, mu, cov=None, chol=None, tau=None, shape=None, observed=None):
         """`pm.MvNormal(name, mu=mu, cov=cov | chol=chol | tau=tau)` (multivariate.py:258-295)."""
         params = _dist("MvNormal", mu=mu, cov=cov, chol=chol, tau=tau)
-        k = np.shape(mu)[-1] if np.ndim(mu) else np.shape(cov if cov is not None else chol if chol is not None else tau)[-1]
+        shp = lambda a: a.type.shape if isinstance(a, Variable) else np.shape(a)      # noqa: E731
+        k = shp(mu)[-1] if len(shp(mu)) else shp(cov if cov is not None else chol if chol is not None else tau)[-1]
         return self._rv("MvNormal", name, shape or (k,), params, None, observed)
 
     def Bernoulli(self, name, logit_p, observed):

@@ -643,3 +643,33 @@ def test_random_models_with_a_random_covariance_factor_keep_value_and_gradient(s
         assert np.isfinite(lp0)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)), (seed, scale, lp, lp0)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (seed, scale, float(np.max(np.abs(g - g0))))
+
+
+def test_a_multivariate_normal_with_an_expression_for_its_mean_and_a_constant_covariance_is_written_out():
+    """`y ~ MvNormal(a + b x, cov)` observed (a small Gaussian process with a fixed kernel and a parametric mean) and `beta ~
+    MvNormal(m0 1, cov)` free: not the MvNormal node's (its mean is a constant) -- `solve_lower(cholesky(cov), value - mu)` with the
+    constant factor against a vector of expressions is a short product with its inverse.  Against SciPy's multivariate normal."""
+    from scipy import stats
+
+    rng = np.random.default_rng(12)
+    k = 5
+    A = rng.normal(size=(k, k))
+    S = A @ A.T / k + 0.5 * np.eye(k)
+    xs, Y, y2 = np.linspace(-1, 1, k), rng.normal(size=(3, k)), rng.normal(size=k)
+    m = sg.StubModel()
+    a = m.Normal("a", 0.0, 2.0)
+    b = m.Normal("b", 0.0, 2.0)
+    m.MvNormal("y", mu=a + b * sg.as_tensor(xs), cov=S, observed=Y)
+    m0 = m.Normal("m0", 0.0, 1.0)
+    beta = m.MvNormal("beta", mu=m0 * sg.as_tensor(np.ones(k)), cov=S)
+    m.Normal("y2", mu=beta, sigma=0.5, observed=y2)
+    spec = lower_to_spec(m)
+    assert spec.mvnormal is None and [f.size for f in spec.factors if f.name == "beta"] == [1]
+    for scale in (0.3, 0.8):
+        q = rng.normal(size=spec.n) * scale
+        want = stats.norm(0, 2).logpdf(q[:2]).sum() + stats.multivariate_normal(np.zeros(k), S).logpdf(Y - (q[0] + q[1] * xs)).sum() + stats.norm(0, 1).logpdf(q[2])
+        want += stats.multivariate_normal(q[2] * np.ones(k), S).logpdf(q[3:]) + stats.norm(q[3:], 0.5).logpdf(y2).sum()
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert abs(lp0 - want) <= 1e-10 * abs(want) and abs(lp - want) <= 1e-10 * abs(want)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
