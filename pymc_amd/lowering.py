@@ -2328,4 +2328,9 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
             low._prog = None
     if n_host_only is not None and len(low.spec.data) > n_host_only and all(i < n_host_only for i in low.spec.extra.values()):
         low.spec.n_device_data = n_host_only      # (a `pm.Data` that only a Deterministic reads stays settable: then everything is uploaded)
+    # the engine's fixed-size tables (eight scalars that broadcast against vector factors, six per factor, 256 scalar elements): said
+    # here, by name, rather than by `nuts_model_create` when a device is first asked
+    why = ms.engine_refusal(low.spec)
+    if why is not None:
+        raise NotLowerable(f"the model lowers, but the engine would refuse the spec: {why}")
     return low.spec

@@ -457,6 +457,87 @@ class _Math:
         return Expr.op(self._b, E_CHECK, x, cond)
 
 
+# the engine's structural limits (csrc/model_dev.h MAX_BTERMS / MAX_FACTOR_BT / MAX_DEFERRED / MAX_DERIVED): what `nuts_model_create`
+# checks when it compiles a spec (csrc/engine.hip `compile_spec`)
+MAX_BTERMS, MAX_FACTOR_BT, MAX_DEFERRED, MAX_DERIVED = 8, 6, 256, 4
+
+
+def engine_refusal(spec: "ModelSpec") -> Optional[str]:
+    """The reason `nuts_model_create` would refuse the element-wise part of `spec`, or None -- `compile_spec` (csrc/engine.hip)
+    restated on the host: operand kinds and references, what broadcasts against what, gather index vectors, the counts the device
+    has fixed-size tables for.  A lowering that ends in a refusal can say so before a device is asked; tests hold host-validated
+    specs to the limits the device will apply.  (The dense nodes' own shape checks are not restated.)"""
+    nv = len(spec.vars)
+    data = spec.data if getattr(spec, "n_device_data", None) is None else spec.data[: spec.n_device_data]
+    nd = len(data)
+    deferred = sum(v.size for v in spec.vars if v.size == 1)
+    rows = spec.logit_rows
+    if rows is not None:
+        deferred += sum(spec.vars[k].size for k in (rows.mu, rows.sigma) if spec.vars[k].size != 1)
+    bterm_vars: List[int] = []
+    n_derived = 0
+    for f in spec.factors:
+        prog = tuple(getattr(f, "prog", ()) or ())
+        if not 1 <= len(f.args) <= 4 or f.size < 1:
+            return "factor with a bad argument count or size"
+        if f.dist == D_DERIVED:
+            n_derived += 1
+            if n_derived > MAX_DERIVED:
+                return "too many derived vectors (MAX_DERIVED)"
+        if len(prog) > MAX_FACTOR_INSTR:
+            return "factor with a bad expression program (offset / length)"
+        ops = []
+        for i, ins in enumerate(prog):
+            used = [ins.x] + ([ins.y] if ins.op in E_BINARY else []) + ([ins.z] if ins.op in E_TERNARY else [])
+            if any(o.kind == OP_TMP and not 0 <= o.ref < i for o in used):
+                return "expression program: an instruction may only use the results of earlier instructions"
+            ops += used
+        for t in f.args:
+            for o in (t.a, t.b, t.c):
+                if o.kind == OP_TMP and not 0 <= o.ref < len(prog):
+                    return "factor argument refers to a missing instruction" if prog else "factor argument refers to an instruction but the factor has no program"
+                ops.append(o)
+        n_bt, seen = 0, set()
+        for o in ops:
+            if o.kind == OP_GATHER:
+                did = int(o.c)
+                if not 0 <= o.ref < nv:
+                    return "gather refers to a missing variable"
+                if not 0 <= did < nd or float(did) != float(o.c):
+                    return "gather refers to a missing index vector"
+                idx = np.asarray(data[did])
+                if idx.size != f.size:
+                    return "gather: one index per element of the factor"
+                if np.any(idx != np.floor(idx)) or np.any(idx < 0) or np.any(idx >= spec.vars[o.ref].size):
+                    return "gather index out of range for its variable"
+            elif o.kind == OP_DATA:
+                if not 0 <= o.ref < nd:
+                    return "factor refers to a missing data vector"
+                if np.asarray(data[o.ref]).size not in (1, f.size):
+                    return "data vector does not broadcast against its factor"
+            elif o.kind == OP_VAR:
+                if not 0 <= o.ref < nv:
+                    return "factor refers to a missing variable"
+                if prog and o.ref in seen:          # (a program's variables are registered once each; plain arguments per occurrence)
+                    continue
+                seen.add(o.ref)
+                vs = spec.vars[o.ref].size
+                if vs == f.size:
+                    continue
+                if vs != 1:
+                    return "variable does not broadcast against its factor"
+                if o.ref not in bterm_vars:
+                    if len(bterm_vars) >= MAX_BTERMS:
+                        return "too many scalar variables broadcast against vector factors (MAX_BTERMS)"
+                    bterm_vars.append(o.ref)
+                n_bt += 1
+                if n_bt > MAX_FACTOR_BT:
+                    return "too many scalar operands in one factor (MAX_FACTOR_BT)"
+    if deferred > MAX_DEFERRED:
+        return "too many scalar / hyper-parameter elements (MAX_DEFERRED)"
+    return None
+
+
 def eval_program(spec: "ModelSpec", prog, term: Term, x: np.ndarray) -> np.ndarray:
     """Value of `term` over the expression program `prog` at the CONSTRAINED values `x` (raveled, spec layout).  Host arithmetic
     for the trace's Deterministics only -- the log-density's programs are interpreted on the device."""

@@ -502,3 +502,39 @@ def test_log_warning_stats_sends_the_warning_statistic_to_the_logger(caplog):
         log_warning_stats([{"warning": w}, {"warning": "plain text"}])
     assert [(r.levelno, r.getMessage()) for r in caplog.records] == [(logging.DEBUG, w.message), (logging.WARNING, "plain text")]
     log_warning_stats(None)
+
+
+# ---- `model_spec.engine_refusal`: csrc/engine.hip `compile_spec`'s structural checks restated on the host ---------------------------
+def test_engine_refusal_names_what_the_engine_would_refuse():
+    from pymc_amd import model_spec as ms
+    from pymc_amd.model_spec import ModelBuilder
+
+    def model(n_scalars, vec=12):
+        b = ModelBuilder()
+        y = np.linspace(-1.0, 1.0, vec)
+        s = [b.Normal(f"s{i}", 0.0, 1.0) for i in range(n_scalars)]
+        for i in range(0, n_scalars, 2):          # two scalars per vector likelihood
+            b.Normal(f"y{i}", s[i], 1.0, observed=y + i) if i + 1 >= n_scalars else b.Normal(f"y{i}", s[i] + s[i + 1] * 0.5, 1.0, observed=y + i)
+        return b.spec
+
+    assert ms.engine_refusal(model(8)) is None
+    assert "MAX_BTERMS" in ms.engine_refusal(model(10))
+    b = ModelBuilder()
+    for i in range(ms.MAX_DEFERRED + 1):
+        b.Normal(f"v{i}", 0.0, 1.0)
+    assert "MAX_DEFERRED" in ms.engine_refusal(b.spec)
+    b = ModelBuilder()
+    z = b.Normal("z", 0.0, 1.0, shape=4)
+    b.Normal("y", z[np.array([0, 1, 3, 3, 2])], 1.0, observed=np.zeros(5))
+    spec = b.spec
+    assert ms.engine_refusal(spec) is None
+    gid = [int(o.c) for f in spec.factors for t in f.args for o in (t.a, t.b, t.c) if o.kind == ms.OP_GATHER][0]
+    good = spec.data[gid]
+    spec.data[gid] = np.array([0.0, 1.0, 4.0, 3.0, 2.0])
+    assert "out of range" in ms.engine_refusal(spec)
+    spec.data[gid] = good[:4]
+    assert "one index per element" in ms.engine_refusal(spec)
+    spec.data[gid] = good
+    v = b.Normal("w", 0.0, 1.0, shape=3)
+    b.Normal("y3", v, 1.0, observed=np.zeros(5))          # three elements against five
+    assert "does not broadcast" in ms.engine_refusal(b.spec)

@@ -52,6 +52,13 @@ def test_committed_graphs_lower_and_the_oracle_reproduces_autograd_of_the_graph(
         assert np.max(np.abs(g - g0)) <= 1e-10 * max(1.0, np.max(np.abs(g0))), name
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_the_engines_structural_limits_admit_every_one_of_these_specs(name):
+    """`model_spec.engine_refusal` (csrc/engine.hip `compile_spec` restated: operand kinds, what broadcasts against what, gather index
+    vectors, the fixed-size tables) -- the part of "would run on the device" that can be checked without one."""
+    assert ms.engine_refusal(_committed(name)) is None
+
+
 def test_the_committed_graphs_and_values_are_what_the_reference_code_gives_now():
     if not sg.available():
         pytest.skip("needs /root/reference")
