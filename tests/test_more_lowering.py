@@ -59,6 +59,20 @@ def test_the_engines_structural_limits_admit_every_one_of_these_specs(name):
     assert ms.engine_refusal(_committed(name)) is None
 
 
+def test_every_committed_spec_packs_into_the_c_structs():
+    """`value_grad._pack`: ModelSpec -> `nuts_model_spec` (ctypes; no device involved) -- the hand-over `nuts_model_create` receives; the
+    host-only constants of Deterministics (`n_device_data`) stay behind."""
+    import lowering_models as lm
+    from pymc_amd import value_grad as vg
+
+    for fx in (lm.FIXTURE, tm.FIXTURE):
+        for name, d in sg.load_models(fx).items():
+            spec = lower_to_spec(sg.FrozenModel(d))
+            s_c = vg._pack(spec)[0]
+            assert s_c.n_vars == len(spec.vars) and s_c.n_factors == len(spec.factors), name
+            assert s_c.n_data == (len(spec.data) if spec.n_device_data is None else spec.n_device_data), name
+
+
 def test_the_committed_graphs_and_values_are_what_the_reference_code_gives_now():
     if not sg.available():
         pytest.skip("needs /root/reference")
