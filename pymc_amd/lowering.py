@@ -2170,7 +2170,11 @@ class _Lowering:
                                        "between different shapes is outside the element-wise programs")
         # (a factor of ONE element is a density that reduced over the variable's elements itself -- a multivariate prior written out: every
         # operand of its program has one element, checked above, so nothing was broadcast by accident)
-        if own is not None and size != 1 and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out and not piece \
+        # (nor does a factor that reads its variable through index vectors only -- the rows of a [J, n] variable under a multivariate
+        # density give J values: `ab ~ MvNormal(mu, chol=chol, shape=(J, 2))`; the engine's own rule is per operand, `engine_refusal`)
+        direct = any(o.kind == ms.OP_VAR and o.ref == own for ins in self._prog for o in (ins.x, ins.y, ins.z)) or \
+            any(o.kind == ms.OP_VAR and o.ref == own for o in (t.a, t.b, t.c))
+        if own is not None and size != 1 and direct and self.spec.vars[own].size not in (1, size) and not self.spec.vars[own].simplex and not written_out and not piece \
                 and self.spec.vars[own].value_name not in getattr(self, "_resized", ()):
             raise NotLowerable(f"the factor of {self.spec.vars[own].name} does not have the variable's shape")
         self._emit(ms.D_POTENTIAL, (t,), 0.0, name)

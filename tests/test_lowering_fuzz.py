@@ -615,7 +615,14 @@ def _lkj_model(seed):
     m = sg.StubModel()
     sd = [("Exponential", dict(lam=float(rng.uniform(0.5, 2.0)))), ("HalfNormal", dict(sigma=float(rng.uniform(0.5, 3.0)))), ("Gamma", dict(alpha=2.0, beta=1.5))][int(rng.integers(0, 3))]
     chol = m.LKJCholeskyCov("chol", n=n, eta=float([1.0, 1.5, 2.0, 4.0][int(rng.integers(0, 4))]), sd_dist=sd)
-    use = int(rng.integers(0, 3))
+    use = int(rng.integers(0, 4))
+    if use == 3:          # centred: the effects themselves under `MvNormal(mu, chol=chol)`, a row per group
+        J = int(rng.integers(2, 6))
+        mu = m.Normal("mu", 0.0, 2.0, shape=(n,))
+        ab = m.MvNormal("ab", mu=mu, chol=chol, shape=(J, n))
+        g = rng.integers(0, J, size=12)
+        m.Normal("y3", mu=ab[:, 0][g] + ab[:, n - 1][g] * rng.normal(size=12), sigma=0.7, observed=rng.normal(size=12))
+        return m
     if use in (0, 2):
         J = int(rng.integers(2, 6))
         z = m.Normal("z", 0.0, 1.0, shape=(n, J))
@@ -673,3 +680,32 @@ def test_a_multivariate_normal_with_an_expression_for_its_mean_and_a_constant_co
         lp, g = ref_models.evaluate(spec, q)
         assert abs(lp0 - want) <= 1e-10 * abs(want) and abs(lp - want) <= 1e-10 * abs(want)
         assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
+
+
+def test_the_centred_multivariate_hierarchy_has_scipys_multivariate_normal_for_its_effects():
+    """`ab ~ MvNormal(mu, chol=chol, shape=(J, 2))` with `chol` from `LKJCholeskyCov`: J values of the density for a variable of 2 J
+    elements, read through index vectors -- against SciPy's `multivariate_normal(mu, L L^T)` over the rows."""
+    from scipy import stats
+
+    from pymc_amd import model_spec as ms
+
+    rng = np.random.default_rng(21)
+    J, N = 6, 30
+    cty, x, y = rng.integers(0, J, size=N), rng.normal(size=N), rng.normal(size=N)
+    m = sg.StubModel()
+    chol = m.LKJCholeskyCov("chol", n=2, eta=2.0, sd_dist=("Exponential", dict(lam=1.0)))
+    mu = m.Normal("mu", 0.0, 3.0, shape=(2,))
+    ab = m.MvNormal("ab", mu=mu, chol=chol, shape=(J, 2))
+    m.Normal("y", mu=ab[:, 0][cty] + ab[:, 1][cty] * x, sigma=0.6, observed=y)
+    spec = lower_to_spec(m)
+    only = ms.ModelSpec(vars=spec.vars, data=spec.data, factors=[f for f in spec.factors if f.name.split(".")[0] == "ab"])
+    assert [f.size for f in only.factors] == [J] and ms.engine_refusal(spec) is None
+    for scale in (0.3, 0.8):
+        q = rng.normal(size=spec.n) * scale
+        v = q[:3]
+        L = np.array([[np.exp(v[0]), 0.0], [v[1], np.exp(v[2])]])
+        want = stats.multivariate_normal(q[3:5], L @ L.T).logpdf(q[5:].reshape(J, 2)).sum()
+        assert abs(ref_models.evaluate(only, q)[0] - want) <= 1e-10 * max(1.0, abs(want))
+        lp0, g0 = gt.joint_logp_grad(m, q)
+        lp, g = ref_models.evaluate(spec, q)
+        assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)) and np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
