@@ -246,7 +246,21 @@ def three_outcomes_lkj():
     return m
 
 
+COUNTS_DM = np.array([[2, 6, 8, 4], [1, 9, 7, 3], [4, 4, 6, 6], [0, 7, 10, 3], [3, 5, 9, 3], [2, 8, 5, 5], [1, 4, 12, 3], [5, 6, 6, 3], [2, 7, 7, 4]], dtype="float64")
+
+
+def over_dispersed_counts():
+    """`counts ~ DirichletMultinomial(n, a = frac * conc)` (multivariate.py:690-790) with `frac ~ Dirichlet(1)`, `conc ~ LogNormal(1, 1)`: the
+    reference's own docstring example.  K gammaln terms per row, reduced over the short axis."""
+    m = sg.StubModel()
+    frac = m.Dirichlet("frac", np.ones(4))
+    conc = m.LogNormal("conc", 1.0, 1.0)
+    m.DirichletMultinomial("counts", n=20, a=frac * conc, observed=COUNTS_DM)
+    return m
+
+
 MODELS = {
+    "over_dispersed_counts": over_dispersed_counts,
     "multivariate_outcomes_lkj": multivariate_outcomes_lkj,
     "three_outcomes_lkj": three_outcomes_lkj,
     "varying_slopes_lkj": varying_slopes_lkj,

@@ -848,6 +848,7 @@ def reference():
     # multivariate.py:126-127 -> `transforms.simplex` = `SimplexTransform()`, logprob/transforms.py:1091-1115)
     ref_class("distributions/multivariate.py", "Dirichlet", ["dist", "logp"], _DistBase, ns)
     ref_class("distributions/multivariate.py", "Multinomial", ["dist", "logp"], _DistBase, ns)
+    ref_class("distributions/multivariate.py", "DirichletMultinomial", ["dist", "logp"], _DistBase, ns)      # (multivariate.py:690-790)
     ref_class("logprob/transforms.py", "SimplexTransform", ["forward", "backward", "log_jac_det"], _TransformBase, ns)
     ns["transforms"].simplex = ns["SimplexTransform"]()
     # `pm.distributions.transforms.ordered` (distributions/transforms.py:79-125, 704): the identifiability constraint of a mixture's means
@@ -1147,6 +1148,10 @@ class StubModel:
     def Multinomial(self, name, n, p, observed):
         """`pm.Multinomial(name, n=n, p=p, observed=counts)` (multivariate.py `Multinomial`)."""
         return self._rv("Multinomial", name, np.shape(observed), _dist("Multinomial", n, p), None, observed)
+
+    def DirichletMultinomial(self, name, n, a, observed):
+        """`pm.DirichletMultinomial(name, n=n, a=a, observed=counts)` (multivariate.py:690-790): over-dispersed counts, rows of K categories."""
+        return self._rv("DirichletMultinomial", name, np.shape(observed), _dist("DirichletMultinomial", n, a), None, observed)
 
     def NormalMixture(self, name, w, mu, sigma, observed):
         """`pm.NormalMixture(name, w=w, mu=mu, sigma=sigma, observed=y)` (mixture.py:598-607: `Mixture` over ONE batched
