@@ -19,7 +19,20 @@ Three layers, only the first written here by hand:
 * `StubModel`: the assembly `Model.logp(sum=False)` performs around those bodies (model/core.py:612-695 order: free RVs, observed
   RVs, potentials; a transformed variable's factor is `logp(transform.backward(value), *params) + transform.log_jac_det(value, *rv
   inputs)`, logprob/transform_value.py:80-138; default transforms as registered in continuous.py:156-201, 345-347, 817-819), which
-  is dispatch machinery (`_logprob`, `TransformValuesRewrite`) and cannot be executed without PyTensor.
+  is dispatch machinery (`_logprob`, `TransformValuesRewrite`) and cannot be executed without PyTensor.  What is hand-written HERE can be
+  wrong without any golden made from it noticing: the densities of the models that have no `ModelBuilder` twin are therefore written a
+  second time with SciPy (tests/test_general_scipy.py, tests/test_more_lowering.py) -- which is how the missing reduction of a
+  univariate logp under a multivariate transform (transform_value.py:103-108) was found.
+
+Loaded since (round 5; each named where it is loaded, in `reference()`): the densities without a code in the IR (Weibull ... Moyal,
+NegativeBinomial, BetaBinomial, Geometric, Multinomial, DirichletMultinomial), `Dirichlet` + `SimplexTransform`, `MvNormal` with
+`quaddist_matrix` / `quaddist_chol`, `Categorical`, `mixture_logprob` and `_zero_inflated_mixture`, `clip_logprob` (Censored),
+`truncated_logprob` with its helper expressions and `logdiffexp` (Truncated), `OrderedLogistic` / `OrderedProbit.compute_p`, the
+`Ordered`, `ZeroSumTransform` and `CholeskyCovPacked` transforms, `zerosumnormal_logp`, `_LKJCholeksyCovRV_logp` +
+`_lkj_normalizing_constant` + `expand_packed_triangular`, and the derivation of a random walk's density (`random_walk_logp` ->
+`logprob_cumsum` -> `logprob_join`) and `ar_logp`.  The PyTensor functions those bodies call that are restated here rather than loaded
+(`pt.diff`, `pt.take`, `pt.split`, `pt.mean`, `pt.isclose` with tolerances, `pt.full_like`, `graph_replace`, ...) say so where they
+are defined.
 """
 import numpy as np
 
