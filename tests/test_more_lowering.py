@@ -59,6 +59,16 @@ def test_the_engines_structural_limits_admit_every_one_of_these_specs(name):
     assert ms.engine_refusal(_committed(name)) is None
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_the_oracle_sampler_runs_on_every_one_of_these_specs(name):
+    """33 NUTS transitions from zeros by the oracle's sampler (the start and the adaptation the device tests of the other models use):
+    finite throughout, dual averaging settles near its target."""
+    spec = _committed(name)
+    draws, st = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=8, tune=25, random_seed=3, init="adapt_diag")
+    assert np.all(np.isfinite(draws)) and all(np.isfinite(s["energy"]) for s in st[0])
+    assert 0.6 < np.mean([s["mean_tree_accept"] for s in st[0][10:]]) <= 1.0
+
+
 def test_every_committed_spec_packs_into_the_c_structs():
     """`value_grad._pack`: ModelSpec -> `nuts_model_spec` (ctypes; no device involved) -- the hand-over `nuts_model_create` receives; the
     host-only constants of Deterministics (`n_device_data`) stay behind."""
