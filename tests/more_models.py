@@ -259,7 +259,23 @@ def over_dispersed_counts():
     return m
 
 
+T_EM, DT_EM = 64, 0.1
+Y_EM = np.tanh(np.sin(np.arange(T_EM) * 0.35) * 2.0) + 0.15 * np.cos(np.arange(T_EM) * 2.9)
+
+
+def double_well_sde():
+    """`pm.EulerMaruyama` (timeseries.py:861-1003): dx = a (x - x^3) dt + s dW, the user's `sde_fn` called by the reference's
+    `eulermaruyama_logp` -- x[t] ~ Normal(x[t-1] + dt f(x[t-1]), sqrt(dt) g) over slices of the path --, under noisy observations."""
+    m = sg.StubModel()
+    a = m.HalfNormal("a", 2.0)
+    s = m.HalfNormal("s", 1.0)
+    x = m.EulerMaruyama("x", DT_EM, lambda x_, a_, s_: (a_ * (x_ - x_ ** 3), s_), (a, s), init_dist=("Normal", dict(mu=0.0, sigma=2.0)), shape=(T_EM,))
+    m.Normal("y", mu=x, sigma=0.2, observed=Y_EM)
+    return m
+
+
 MODELS = {
+    "double_well_sde": double_well_sde,
     "over_dispersed_counts": over_dispersed_counts,
     "multivariate_outcomes_lkj": multivariate_outcomes_lkj,
     "three_outcomes_lkj": three_outcomes_lkj,

@@ -914,6 +914,7 @@ def reference():
     ref_function("logprob/tensor.py", "logprob_join", ts)
     ref_function("distributions/timeseries.py", "random_walk_logp", ts)
     ref_function("distributions/timeseries.py", "ar_logp", ts)
+    ref_function("distributions/timeseries.py", "eulermaruyama_logp", ts)       # (timeseries.py:986-1003)
     ns["timeseries"] = ts
     _NS = ns
     return ns
@@ -1296,6 +1297,19 @@ class StubModel:
         up = TensorConstant(np.inf) if upper is None else as_tensor(upper)
         fn = lambda value: tr["truncated_logprob"](op, (value,), *params, lo, up)   # noqa: E731
         return self._add(_RV(name, np.shape(observed), fn, (), None, observed))
+
+    def EulerMaruyama(self, name, dt, sde_fn, sde_pars, init_dist=("Normal", dict(mu=0.0, sigma=100.0)), shape=None, observed=None):
+        """`pm.EulerMaruyama(name, dt=, sde_fn=, sde_pars=, init_dist=, steps=)` (timeseries.py:861-1003): the Euler-Maruyama discretisation of
+        dx = f(x) dt + g(x) dW; `sde_fn(x, *pars) -> (f, g)` is the USER's function of graph variables, called by the reference's
+        `eulermaruyama_logp`."""
+        ref = reference()
+        cls_name, kw = init_dist
+        init = _ComponentRV(ref[cls_name], _dist(cls_name, **kw))
+        op = type("op", (), {"sde_fn": staticmethod(sde_fn), "dt": float(dt)})()
+        pars = tuple(as_tensor(p_) for p_ in sde_pars)
+        fn = lambda value, *pars_: ref["timeseries"]["eulermaruyama_logp"](op, (value,), init, None, *pars_, None)   # noqa: E731
+        shape = tuple(shape) if shape is not None else np.shape(observed)
+        return self._add(_RV(name, shape, fn, pars, None, observed))
 
     def ZeroInflatedPoisson(self, name, psi, mu, observed):
         """`pm.ZeroInflatedPoisson(name, psi=psi, mu=mu, observed=y)` (mixture.py:560-575, 577-640): the reference's

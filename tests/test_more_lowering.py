@@ -290,6 +290,13 @@ def test_the_lkj_prior_for_three_dimensions_is_the_textbook_density_up_to_its_co
         assert np.ptp(diffs) < 1e-6, (name, diffs)
 
 
+def _double_well(q):
+    a, s, x = np.exp(q[0]), np.exp(q[1]), q[2:]
+    lp = stats.halfnorm(scale=2.0).logpdf(a) + q[0] + stats.halfnorm(scale=1.0).logpdf(s) + q[1] + stats.norm(0, 2.0).logpdf(x[0])
+    lp += stats.norm(x[:-1] + tm.DT_EM * a * (x[:-1] - x[:-1] ** 3), np.sqrt(tm.DT_EM) * s).logpdf(x[1:]).sum()
+    return lp + stats.norm(x, 0.2).logpdf(tm.Y_EM).sum()
+
+
 def _truncated(q):
     lam, mu, s = np.exp(q[0]), q[1], np.exp(q[2])
     lp = stats.halfnorm(scale=2).logpdf(lam) + q[0] + stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=2).logpdf(s) + q[2]
@@ -299,7 +306,7 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+@pytest.mark.parametrize("name, dens", [("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
                                         ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
