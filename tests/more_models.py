@@ -274,7 +274,25 @@ def double_well_sde():
     return m
 
 
+N_NN = 80
+X_NN = np.stack([np.cos(np.arange(N_NN) * 0.41) * (1.0 + 0.3 * (np.arange(N_NN) % 2)), np.sin(np.arange(N_NN) * 0.41) + 0.5 * (np.arange(N_NN) % 2)], axis=1)
+Y_NN = (np.arange(N_NN) % 2).astype("float64")
+
+
+def bayesian_neural_network():
+    """The gallery's small network: two hidden layers of five tanh units, `out ~ Bernoulli(p = sigmoid(dot(tanh(dot(tanh(dot(X, W1)), W2)),
+    w3)))`.  Three matrix products over short inner dimensions (2, 5, 5), none a dense node's: one program of 92 instructions."""
+    m = sg.StubModel()
+    W1 = m.Normal("w_in_1", 0.0, 1.0, shape=(2, 5))
+    W2 = m.Normal("w_1_2", 0.0, 1.0, shape=(5, 5))
+    w3 = m.Normal("w_2_out", 0.0, 1.0, shape=(5,))
+    act = pt.tanh(pt.dot(pt.tanh(pt.dot(sg.as_tensor(X_NN), W1)), W2))
+    m._rv("Bernoulli", "out", np.shape(Y_NN), sg._dist("Bernoulli", p=pt.sigmoid(pt.dot(act, w3))), None, Y_NN)
+    return m
+
+
 MODELS = {
+    "bayesian_neural_network": bayesian_neural_network,
     "double_well_sde": double_well_sde,
     "over_dispersed_counts": over_dispersed_counts,
     "multivariate_outcomes_lkj": multivariate_outcomes_lkj,

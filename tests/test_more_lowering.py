@@ -297,6 +297,14 @@ def _double_well(q):
     return lp + stats.norm(x, 0.2).logpdf(tm.Y_EM).sum()
 
 
+def _bnn(q):
+    from scipy.special import expit
+
+    W1, W2, w3 = q[:10].reshape(2, 5), q[10:35].reshape(5, 5), q[35:]
+    p = expit(np.tanh(np.tanh(tm.X_NN @ W1) @ W2) @ w3)
+    return stats.norm(0, 1).logpdf(q).sum() + stats.bernoulli(p).logpmf(tm.Y_NN).sum()
+
+
 def _truncated(q):
     lam, mu, s = np.exp(q[0]), q[1], np.exp(q[2])
     lp = stats.halfnorm(scale=2).logpdf(lam) + q[0] + stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=2).logpdf(s) + q[2]
@@ -306,7 +314,7 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+@pytest.mark.parametrize("name, dens", [("bayesian_neural_network", _bnn), ("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
                                         ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
