@@ -61,7 +61,7 @@ class NDArray:
         self._dets = [(nm, d) for nm, d in getattr(model, "deterministics", {}).items() if vars is None or nm in vars]
         for nm, (_, _, size) in self._dets:
             self.varnames.append(nm)
-            self.var_shapes[nm] = () if size == 1 else (size,)
+            self.var_shapes[nm] = getattr(model, "deterministic_shapes", {}).get(nm, () if size == 1 else (size,))
         self.var_dtypes = {nm: np.dtype("float64") for nm in self.varnames}
         self.chain = None
         self.sampler_vars = None

@@ -2324,6 +2324,9 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
                     low._const_cache, low._fsize = None, 0
             t = low._widen_gathers((t,), low._size(t))[0]
             low.spec.deterministics[name] = (tuple(low._prog), t, low._size(t))
+            shp = _eff_shape(var)
+            if shp is not None and len(shp) > 1 and _numel(shp) == low._size(t):
+                low.spec.deterministic_shapes[name] = tuple(shp)
         except NotLowerable as e:
             import logging
 

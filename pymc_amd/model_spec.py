@@ -270,6 +270,8 @@ class ModelSpec:
     # `pm.Deterministic(name, expr)` (model/core.py:1940-2005): named functions of the variables, evaluated for the trace
     # (backends/base.py:183-191 records them next to the untransformed variables): name -> (program, result term, size)
     deterministics: Dict[str, Tuple[Tuple["Instr", ...], "Term", int]] = field(default_factory=dict)
+    # ... and their shapes where they are not vectors (a [N, K] matrix of probabilities): name -> shape; absent: () or (size,)
+    deterministic_shapes: Dict[str, Tuple[int, ...]] = field(default_factory=dict)
     # data vectors [n_device_data:] are constants of the Deterministics only (masks, index vectors): the host evaluates those, the
     # device never reads them and they are not uploaded.  None: every vector is the device's
     n_device_data: Optional[int] = None

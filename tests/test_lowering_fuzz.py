@@ -709,3 +709,25 @@ def test_the_centred_multivariate_hierarchy_has_scipys_multivariate_normal_for_i
         lp0, g0 = gt.joint_logp_grad(m, q)
         lp, g = ref_models.evaluate(spec, q)
         assert abs(lp - lp0) <= 1e-10 * max(1.0, abs(lp0)) and np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0)))
+
+
+def test_a_matrix_valued_deterministic_keeps_its_shape_in_the_trace():
+    """`pm.OrderedProbit(..., compute_p=True)` registers its [N, K] probabilities as `<name>_probs` (discrete.py:1403-1408): the trace holds
+    (draws, N, K), every row summing to one."""
+    from pymc_amd.backends import NDArray
+
+    rng = np.random.default_rng(2)
+    N = 6
+    m = sg.StubModel()
+    b = m.Normal("b", 0.0, 2.0)
+    c = m.Normal("c", np.array([-1.0, 1.0]), 2.0, shape=(2,), transform="ordered")
+    p = sg.reference()["OrderedProbit"].compute_p(b * sg.as_tensor(rng.normal(size=N)), c, 1.0)
+    m.Deterministic("y_probs", p)
+    m.Categorical("y", p=p, observed=rng.integers(0, 3, size=N).astype("float64"))
+    spec = lower_to_spec(m)
+    assert spec.deterministic_shapes == {"y_probs": (N, 3)}
+    tr = NDArray(model=spec)
+    tr.setup(3, 0)
+    tr.record_batch(rng.normal(size=(3, spec.n)), None)
+    assert tr.samples["y_probs"].shape == (3, N, 3) and np.allclose(tr.samples["y_probs"].sum(axis=-1), 1.0, atol=1e-14)
+    assert tr.samples["c"].shape == (3, 2) and np.all(np.diff(tr.samples["c"], axis=1) > 0)
