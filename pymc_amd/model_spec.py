@@ -440,6 +440,9 @@ class _Math:
     def cos(self, x): return self._un(E_COS, x)
     def arctan(self, x): return self._un(E_ARCTAN, x)
     def digamma(self, x): return self._un(E_DIGAMMA, x)
+    def log2(self, x): return self._un(E_LOG2, x)
+    def log10(self, x): return self._un(E_LOG10, x)
+    def not_(self, x): return self._un(E_NOT, x)
     def gt(self, x, y): return Expr.op(self._b, E_GT, x, y)
     def ge(self, x, y): return Expr.op(self._b, E_GE, x, y)
     def lt(self, x, y): return Expr.op(self._b, E_LT, x, y)

@@ -5,8 +5,8 @@ Zero-sum effects (`pm.ZeroSumNormal`, multivariate.py:2654-2807, under `ZeroSumT
 to zero next to an intercept.  Matrix products outside the dense nodes: a softmax regression with a [P, K] coefficient matrix, a robust
 regression whose location is `pm.math.dot(X, beta)`.
 
-HOST ONLY this round: these specs use nothing the device has not run (element-wise programs over gathers, the opcodes of
-tests/test_general_lowering.py's models), but no GPU minutes were left to run THEM on the device, so they are kept out of
+HOST ONLY this round: these specs use operand kinds and -- `log1mexp` in the truncated likelihoods aside (tests/test_opcode_coverage.py) --
+opcodes the device tests exercise, but no GPU minutes were left to run THEM on the device, so they are kept out of
 `lowering_models.GENERAL` (whose members the `-m gpu` tests are parametrised over) and out of tests/golden/lowered_spec_digests.json."""
 import os
 
