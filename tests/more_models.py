@@ -291,7 +291,33 @@ def bayesian_neural_network():
     return m
 
 
+N_SV2 = 44
+X_SURV = np.sin(np.arange(N_SV2) * 0.8) + 0.3 * np.cos(np.arange(N_SV2) * 2.1)
+T_SURV = 0.4 + 1.8 * np.abs(np.sin(np.arange(N_SV2) * 1.27)) + 0.6 * (np.arange(N_SV2) % 3)
+EVENT_SURV = ((np.arange(N_SV2) * 5) % 7 != 0).astype("float64")
+
+
+def _weibull_censored(value, log_scale, shape_k, event):
+    """The right-censored Weibull log-likelihood a user writes for `pm.CustomDist`: event * log h(t) + log S(t), h = k / lam (t / lam)^(k - 1),
+    S = exp(-(t / lam)^k), lam = exp(log_scale)."""
+    z = (pt.log(value) - log_scale) * shape_k
+    return event * (pt.log(shape_k) - pt.log(value) + z) - pt.exp(z)
+
+
+def survival_with_a_custom_density():
+    """`pm.CustomDist(name, *params, logp=fn, observed=t)` (distributions/custom.py): the density is the USER's function of graph variables --
+    a right-censored Weibull regression -- under improper priors (`pm.Flat`, `pm.HalfFlat`: continuous.py:364-443) and a `pm.Potential`."""
+    m = sg.StubModel()
+    b0 = m.Flat("b0")
+    b1 = m.Normal("b1", 0.0, 1.0)
+    k = m.HalfFlat("k")
+    m.CustomDist("t", b0 + b1 * sg.as_tensor(X_SURV), k, sg.as_tensor(EVENT_SURV), logp=_weibull_censored, observed=T_SURV)
+    m.Potential("k_prior", -0.5 * pt.sqr(pt.log(k)))
+    return m
+
+
 MODELS = {
+    "survival_with_a_custom_density": survival_with_a_custom_density,
     "bayesian_neural_network": bayesian_neural_network,
     "double_well_sde": double_well_sde,
     "over_dispersed_counts": over_dispersed_counts,

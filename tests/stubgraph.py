@@ -803,6 +803,8 @@ def reference():
         ref_function("distributions/dist_math.py", fn, ns)
     for fn in ("get_tau_sigma", "_truncation_is_bounded"):
         ref_function("distributions/continuous.py", fn, ns)
+    for name in ("Flat", "HalfFlat"):                    # (improper priors: continuous.py:364-443)
+        ref_class("distributions/continuous.py", name, ["logp"], _DistBase, ns)
     for rel, names in (("distributions/continuous.py", _CONT), ("distributions/discrete.py", _DISC)):
         _, tree = _parsed(rel)
         for name in names:
@@ -1060,6 +1062,19 @@ class StubModel:
     def Normal(self, name, mu=0.0, sigma=1.0, shape=(), observed=None, transform=None):
         """(`transform="ordered"`: `pm.Normal(..., transform=pm.distributions.transforms.ordered)`)"""
         return self._rv("Normal", name, shape, _dist("Normal", mu=mu, sigma=sigma), transform, observed)
+
+    def Flat(self, name, shape=()):
+        """`pm.Flat(name)` (continuous.py:364-384): logp 0 everywhere; no transform."""
+        return self._add(_RV(name, shape, lambda value: reference()["Flat"].logp(value), (), None, None))
+
+    def HalfFlat(self, name, shape=()):
+        """`pm.HalfFlat(name)` (continuous.py:400-443): 0 on the positive half-line; PositiveContinuous -> the log transform."""
+        return self._add(_RV(name, shape, lambda value: reference()["HalfFlat"].logp(value), (), "log", None))
+
+    def CustomDist(self, name, *dist_params, logp, observed):
+        """`pm.CustomDist(name, *dist_params, logp=fn, observed=y)` (distributions/custom.py): the USER's `logp(value, *dist_params)`, a
+        function of graph variables, is the density."""
+        return self._add(_RV(name, np.shape(observed), logp, tuple(as_tensor(p_) for p_ in dist_params), None, observed))
 
     def HalfNormal(self, name, sigma=1.0, shape=()):
         return self._rv("HalfNormal", name, shape, _dist("HalfNormal", sigma=sigma), "log", None)

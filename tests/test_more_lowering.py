@@ -305,6 +305,14 @@ def _bnn(q):
     return stats.norm(0, 1).logpdf(q).sum() + stats.bernoulli(p).logpmf(tm.Y_NN).sum()
 
 
+def _survival(q):
+    b0, b1, k = q[0], q[1], np.exp(q[2])
+    lam = np.exp(b0 + b1 * tm.X_SURV)
+    W = stats.weibull_min(k, scale=lam)
+    lp = stats.norm(0, 1).logpdf(b1) + q[2] - 0.5 * np.log(k) ** 2                 # Flat: 0; HalfFlat: 0 and the log transform's Jacobian
+    return lp + (tm.EVENT_SURV * (W.logpdf(tm.T_SURV) - W.logsf(tm.T_SURV)) + W.logsf(tm.T_SURV)).sum()
+
+
 def _truncated(q):
     lam, mu, s = np.exp(q[0]), q[1], np.exp(q[2])
     lp = stats.halfnorm(scale=2).logpdf(lam) + q[0] + stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=2).logpdf(s) + q[2]
@@ -314,7 +322,7 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("bayesian_neural_network", _bnn), ("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+@pytest.mark.parametrize("name, dens", [("survival_with_a_custom_density", _survival), ("bayesian_neural_network", _bnn), ("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
                                         ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
