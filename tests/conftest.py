@@ -18,11 +18,15 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "not_yet_run_on_device: a gpu test whose spec / code changed after the round's last device run (scheduled last)")
+    config.addinivalue_line("markers", "known_intermittent: a gpu test with an open, documented intermittent failure (DESIGN.md section 8; scheduled late)")
 
 
 def pytest_collection_modifyitems(config, items):
     """GPU tests that could not be run on the device after their last change go to the END of the run: under `-x` a failure there
     cannot hide the tests that have run on the device."""
+    # (likewise the one test with an open intermittent failure -- the two-chain rows group, DESIGN.md section 8: after everything that
+    # is known to be stable, before what has never run)
+    flaky = [it for it in items if it.get_closest_marker("known_intermittent")]
     late = [it for it in items if it.get_closest_marker("not_yet_run_on_device")]
-    if late:
-        items[:] = [it for it in items if not it.get_closest_marker("not_yet_run_on_device")] + late
+    if flaky or late:
+        items[:] = [it for it in items if not (it.get_closest_marker("not_yet_run_on_device") or it.get_closest_marker("known_intermittent"))] + flaky + late

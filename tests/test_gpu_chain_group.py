@@ -210,7 +210,8 @@ def test_what_a_group_refuses():
 
 
 # ---- the hierarchical-logit rows on the group-aligned pass (csrc/rows_ga_multi_kernel.h) --------------------------------------
-@pytest.mark.parametrize("G,rpg,chains,tune,draws", [(40, 300, 4, 30, 12), (24, 517, 3, 20, 8), (64, 130, 2, 20, 8)])
+@pytest.mark.parametrize("G,rpg,chains,tune,draws", [(40, 300, 4, 30, 12), (24, 517, 3, 20, 8),
+                                                     pytest.param(64, 130, 2, 20, 8, marks=pytest.mark.known_intermittent)])
 def test_grouped_chains_of_the_logit_rows_are_bitwise_the_chains_alone(G, rpg, chains, tune, draws, monkeypatch):
     """The benchmark's model (BASELINE configs[1]) at small sizes, forced onto the group-aligned pass: chains sampled one after the
     other, and concurrently as a chain group whose launches stream X once for all chains standing at a leaf.  rpg = 517: a padded
