@@ -316,7 +316,26 @@ def survival_with_a_custom_density():
     return m
 
 
+_raw_c = 0.9 * np.sin(np.arange(36) * 0.77) + 0.4 * np.cos(np.arange(36) * 1.9) + 0.2
+Y_CENS_N = np.clip(_raw_c, -0.5, 0.8)                       # a Normal measurement with a detection floor and a saturation ceiling
+_raw_e = 0.15 + 1.6 * np.abs(np.sin(np.arange(30) * 0.53)) ** 2
+Y_CENS_E = np.minimum(_raw_e, 1.2)                          # waiting times followed up to t = 1.2
+
+
+def censored_measurements():
+    """`pm.Censored` (distributions/censored.py; logprob/censoring.py:198-250 `clip_logprob`): an interval-censored Normal (the density between
+    the bounds, the base's `logcdf` at the floor, its `logccdf` at the ceiling) and a right-censored Exponential."""
+    m = sg.StubModel()
+    mu = m.Normal("mu", 0.0, 2.0)
+    s = m.HalfNormal("s", 1.0)
+    m.Censored("yn", ("Normal", dict(mu=mu, sigma=s)), -0.5, 0.8, observed=Y_CENS_N)
+    lam = m.HalfNormal("lam", 2.0)
+    m.Censored("ye", ("Exponential", dict(lam=lam)), None, 1.2, observed=Y_CENS_E)
+    return m
+
+
 MODELS = {
+    "censored_measurements": censored_measurements,
     "survival_with_a_custom_density": survival_with_a_custom_density,
     "bayesian_neural_network": bayesian_neural_network,
     "double_well_sde": double_well_sde,

@@ -313,6 +313,15 @@ def _survival(q):
     return lp + (tm.EVENT_SURV * (W.logpdf(tm.T_SURV) - W.logsf(tm.T_SURV)) + W.logsf(tm.T_SURV)).sum()
 
 
+def _censored(q):
+    mu, s, lam = q[0], np.exp(q[1]), np.exp(q[2])
+    lp = stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=1.0).logpdf(s) + q[1] + stats.halfnorm(scale=2.0).logpdf(lam) + q[2]
+    Nn, y = stats.norm(mu, s), tm.Y_CENS_N
+    lp += np.where(y <= -0.5, Nn.logcdf(-0.5), np.where(y >= 0.8, Nn.logsf(0.8), Nn.logpdf(y))).sum()
+    E, t = stats.expon(scale=1 / lam), tm.Y_CENS_E
+    return lp + np.where(t >= 1.2, E.logsf(1.2), E.logpdf(t)).sum()
+
+
 def _truncated(q):
     lam, mu, s = np.exp(q[0]), q[1], np.exp(q[2])
     lp = stats.halfnorm(scale=2).logpdf(lam) + q[0] + stats.norm(0, 2).logpdf(mu) + stats.halfnorm(scale=2).logpdf(s) + q[2]
@@ -322,7 +331,7 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("survival_with_a_custom_density", _survival), ("bayesian_neural_network", _bnn), ("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+@pytest.mark.parametrize("name, dens", [("censored_measurements", _censored), ("survival_with_a_custom_density", _survival), ("bayesian_neural_network", _bnn), ("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
                                         ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
