@@ -444,7 +444,8 @@ def _ldlt_factor(v):
     if t_owner is None or t_owner.inputs[0] is not L:
         return None
     tname = _opname(t_owner.op)
-    swaps = tname == "Transpose" or (tname == "DimShuffle" and list(getattr(t_owner.op, "new_order", ())[-2:]) == [len(getattr(t_owner.op, "new_order", ())) - 1, len(getattr(t_owner.op, "new_order", ())) - 2])
+    order = list(getattr(t_owner.op, "new_order", ()))              # (`L.mT` is a DimShuffle that swaps the last two dimensions)
+    swaps = tname == "Transpose" or (tname == "DimShuffle" and len(order) >= 2 and order[-2:] == [len(order) - 1, len(order) - 2])
     return L if swaps and getattr(getattr(L, "tag", None), "lower_triangular", False) else None
 
 
