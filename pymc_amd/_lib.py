@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -330,11 +331,15 @@ def load():
 
 def set_engine_option(name: str, value: int) -> None:
     """Select a non-default launch schedule for the models / chains created from now on (include/nuts_mi355.h, nuts_set_option)."""
-    check(load().nuts_set_option(name.encode(), int(value)), "nuts_set_option")
+    with _sync_lock:
+        _synced.pop(name, None)      # (sync_options_from_env sets it again from the environment if it is there)
+        check(load().nuts_set_option(name.encode(), int(value)), "nuts_set_option")
 
 
 def unset_engine_option(name: str) -> None:
-    check(load().nuts_unset_option(name.encode()), "nuts_unset_option")
+    with _sync_lock:
+        _synced.pop(name, None)
+        check(load().nuts_unset_option(name.encode()), "nuts_unset_option")
 
 
 def sync_options_from_env() -> None:
@@ -344,13 +349,28 @@ def sync_options_from_env() -> None:
     if os.environ.get("PYMC_AMD_HONOUR_NUTS_ENV") != "1":
         return
     lib = load()
-    lib.nuts_clear_options()
+    wanted = {}
     for k, v in os.environ.items():
         if k.startswith("NUTS_"):
             try:
-                lib.nuts_set_option(k.encode(), int(v))
+                wanted[k] = int(v)
             except ValueError:
                 pass
+    # Chains are materialised from worker threads too: the table is never cleared (another thread creating a chain at that moment
+    # would read defaults for options the environment sets) -- under one lock, the options that left the environment are unset, the
+    # others (re)set; an option that did not change keeps its value throughout.
+    with _sync_lock:
+        for k in [k for k in _synced if k not in wanted]:
+            lib.nuts_unset_option(k.encode())
+            del _synced[k]
+        for k, v in wanted.items():
+            if _synced.get(k) != v:
+                lib.nuts_set_option(k.encode(), v)
+                _synced[k] = v
+
+
+_sync_lock = threading.Lock()
+_synced: dict = {}
 
 
 def last_error() -> str:

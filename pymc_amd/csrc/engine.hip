@@ -73,7 +73,12 @@ extern "C" void nuts_clear_options(void) {
 template <typename T>
 static T* dev_alloc(size_t count) {
   void* p = nullptr;
-  if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  // NUTS_POISON_ALLOC=1 (tests): every fresh allocation is filled with 0xFF bytes -- NaN as a double, 0xffffffff as a counter -- so
+  // that a read of memory nobody wrote shows up in a process of any history (hipMalloc hands out zero pages in a fresh process and
+  // whatever a freed block held in an old one)
+  if (env_int("NUTS_POISON_ALLOC", 0)) { hipMemset(p, 0xFF, bytes); hipDeviceSynchronize(); }
   return static_cast<T*>(p);
 }
 template <typename T>

@@ -102,6 +102,14 @@ def _const(x):
     return ("const", np.asarray(x, dtype="float64"))
 
 
+def _last_axis_or_all(ax, ndim) -> bool:
+    """The recorded axis of an `all` / `any`: every axis (None: the reduction over the elements follows anyway) or the last one."""
+    if ax is None:
+        return True
+    axes = sorted(a % ndim for a in (ax if isinstance(ax, (list, tuple)) else [ax]))
+    return axes == [ndim - 1] or axes == list(range(ndim))
+
+
 def build_tree(v, memo: Optional[dict] = None):
     """Expression tree of graph variable `v` (see the module docstring for the protocol it relies on)."""
     memo = {} if memo is None else memo
@@ -279,13 +287,21 @@ def build_tree(v, memo: Optional[dict] = None):
             inner[piece == 0] = 0
             placed = ("joinnd", piece.ravel(), inner.ravel(), tuple(xs), _const(0.0), yk)
             out = placed if (xk[0] == "const" and not np.any(xk[1])) else ("add", xk, placed)
-    elif name == "AdvancedSubtensor":             # `x[rows, cols]` with constant integer arrays: positions in the raveled operand
+    elif name == "AdvancedSubtensor" and len(ins) > 2:   # `x[rows, cols]` with constant integer arrays: positions in the raveled operand
+        # (ONE index input -- `z[group_idx]`, `mu[c]` with c another step method's variable -- is the gather below, whichever of the two
+        # op names PyTensor gave it)
         kid = build_tree(ins[0], memo)
         iks = [build_tree(i, memo) for i in ins[1:]]
         shp = _eff_shape(ins[0])
         if shp is None or any(k_[0] != "const" for k_ in iks) or len(iks) != len(shp):
             raise NotLowerable("AdvancedSubtensor beyond one constant integer array per dimension")
-        flat = np.ravel_multi_index(tuple(np.asarray(k_[1]).astype(np.int64) for k_ in iks), shp).ravel()
+        try:
+            ix = np.broadcast_arrays(*[np.asarray(k_[1]).astype(np.int64) for k_ in iks])
+            if any(np.any((i_ < -d_) | (i_ >= d_)) for i_, d_ in zip(ix, shp)):
+                raise NotLowerable("AdvancedSubtensor: an index outside its dimension")
+            flat = np.ravel_multi_index(tuple(np.where(i_ < 0, i_ + d_, i_) for i_, d_ in zip(ix, shp)), shp).ravel()
+        except ValueError as e:
+            raise NotLowerable(f"AdvancedSubtensor: {e}") from None
         out = _const(np.asarray(kid[1]).ravel()[flat]) if kid[0] == "const" else ("take", kid, _const(flat))
     elif name == "CumOp":                         # `pt.cumsum(x, axis)` over a short axis: every prefix sum written out
         if getattr(op, "mode", "add") != "add":
@@ -370,6 +386,12 @@ def build_tree(v, memo: Optional[dict] = None):
     elif name in ("AdvancedSubtensor1", "AdvancedSubtensor"):
         kid, ik = build_tree(ins[0], memo), build_tree(ins[1], memo)
         shp = _eff_shape(ins[0]) if memo.get("__shapes__") else None
+        if ik[0] == "const" and np.asarray(ik[1]).size and np.min(ik[1]) < 0:
+            rows = np.asarray(ik[1]).astype(np.int64)             # (negative indices count from the end of the FIRST dimension)
+            full = shp if shp is not None else _eff_shape(ins[0])
+            if full is None or np.min(rows) < -full[0]:
+                raise NotLowerable("a negative index into an operand of unknown length, or outside its dimension")
+            ik = _const(np.where(rows < 0, rows + full[0], rows))
         if shp is not None and len(shp) > 1 and ik[0] == "const" and np.asarray(ik[1]).ndim == 1:
             # rows of a matrix-shaped operand (`beta[group_idx]` with beta [G, D]): as an index into the RAVELED operand, so that the
             # element-wise programs can push it down to the leaves
@@ -1163,7 +1185,15 @@ class _Lowering:
             self._prog_memo[id(node)] = (node, out)
             return out
         elif op in ("all", "any", "makevector"):
-            out = self._program(self._cond(node))
+            # (strict: where `_cond` would keep the condition element-wise and leave the reduction over the factor's elements to the
+            # caller -- right under NUTS_E_CHECK and `switch(cond, logp, -inf)`, whose callers go through `_cond` themselves -- the
+            # reduction is real here, e.g. `pt.switch(pt.all(c), a, b)` with a finite b in a Potential, and cannot be dropped)
+            out = self._program(self._cond(node, strict=op != "makevector"))
+            self._prog_memo[id(node)] = (node, out)
+            return out
+        elif op == "switch" and _is_node(node[1]) and node[1][0] in ("all", "any") and _num(node[3]) == -math.inf:
+            # `switch(all(cond), logp, -inf)`: a failed element kills the factor either way (-inf in the factor's sum)
+            out = self._emit_instr(ms.E_SWITCH, [self._program(self._cond(node[1])), self._program(node[2]), self._program(node[3])])
             self._prog_memo[id(node)] = (node, out)
             return out
         elif op == "bcast" or (op == "take" and node[2][0] == "const"):
@@ -1375,12 +1405,13 @@ class _Lowering:
             out = (comb, out, t)
         return out
 
-    def _cond(self, node):
+    def _cond(self, node, strict=False):
         """The conditions of a `check_parameters` / `pt.all([...])`: element-wise AND (OR for `any`) of the listed conditions -- the
         reduction to one scalar over the factor's elements (`pt.all`) is what NUTS_E_CHECK means on the device (a failed check kills
         the whole factor)."""
         if node[0] in ("all", "any") and len(node) == 4 and node[3] is not None and node[1][0] != "makevector" and len(node[3]) >= 2 \
-                and _numel(node[3]) != self._fsize and _numel(node[3][:-1]) == self._fsize and node[3][-1] <= self.MAX_UNROLLED_SUM:
+                and _numel(node[3]) != self._fsize and _numel(node[3][:-1]) == self._fsize and node[3][-1] <= self.MAX_UNROLLED_SUM \
+                and _last_axis_or_all(node[2], len(node[3])):
             # a condition with K values per element of the factor (`0 <= p` of a Categorical whose p has a row per observation): reduced
             # over its last axis, one value per element remains -- the reduction over the elements is what NUTS_E_CHECK means.  (Asked first: a few short rows
             # are also a small vector, and writing ALL their elements out would cost the factor's size times the program)
@@ -1393,6 +1424,9 @@ class _Lowering:
             return self._unrolled_sum((node[0], None, node[1], node[3]))
         if node[0] in ("all", "any"):
             inner = node[1]
+            if strict and inner[0] != "makevector" and self._tsize(inner) > 1 and \
+                    (len(node) != 4 or node[3] is None or self._tsize(node) < self._tsize(inner)):
+                raise NotLowerable("all / any over the factor's elements outside a parameter check or a -inf switch")
             parts = list(inner[1:]) if inner[0] == "makevector" else [inner]
             parts = [self._cond(p) for p in parts]
             out = parts[0]

@@ -842,7 +842,20 @@ def gather_trace(result, chains: int, rank: int, world: int, device):
         return full
 
     full = gather_array(result["draws"])
-    extras = {nm: gather_array(v) for nm, v in sorted(result.get("extra_draws", {}).items())}
+    # A rank without chains (chains < world) has no extras of its own: every rank must still enter the SAME gathers, so the names,
+    # trailing shapes and dtypes are agreed first (all ranks contribute, the first rank that has any decides) and an empty rank
+    # sends zero rows of that shape.
+    mine_extra = {nm: np.asarray(v) for nm, v in result.get("extra_draws", {}).items()}
+    meta = [None] * world
+    dist.all_gather_object(meta, {nm: (tuple(v.shape[1:]), v.dtype.str) for nm, v in mine_extra.items()})
+    agreed = next((m_ for m_ in meta if m_), {})
+    extras = {}
+    for nm in sorted(agreed):
+        shp, dt = agreed[nm]
+        v = mine_extra.get(nm)
+        if v is None or v.shape[0] == 0:
+            v = np.zeros((0,) + tuple(shp), dtype=np.dtype(dt))
+        extras[nm] = gather_array(v)
     mine_stats = {"stats": result["stats"], "warmup_stats": result.get("warmup_stats", []), "sampling_time": result.get("sampling_time", 0.0),
                   "all_stats": result.get("all_stats")}
     all_stats = [None] * world if rank == 0 else None

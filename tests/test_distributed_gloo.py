@@ -46,6 +46,18 @@ def _worker(rank, world, port, q):
             len(res["stats"]) == chains and all(len(res["stats"][c]) == draws and all(s["depth"] == c for s in res["stats"][c]) for c in range(chains))
             and res["sampling_time_per_rank"] == [1.0, 2.0]
         )
+    # ---- fewer chains than ranks, under a CompoundStep: rank 1 has no chain and therefore no `extra_draws` of its own -- it must still
+    # enter the same collectives as rank 0 (mismatched gathers hang or corrupt the `gather_object` that follows) ----
+    mine1 = assign_chains(1, rank, world)
+    res1 = {"draws": np.full((len(mine1), draws, n), 3.0), "chains": mine1, "stats": [[{"depth": 9}] * draws for _ in mine1],
+            "warmup_stats": [[] for _ in mine1], "sampling_time": 0.5}
+    if mine1:
+        res1["extra_draws"] = {"c": [np.arange(draws * 4, dtype=np.int64).reshape(draws, 4)], "w": np.ones((1, draws, 2))}
+    res1 = gather_trace(res1, 1, rank, world, None)
+    if rank == 0:
+        out["empty_rank_ok"] = bool(res1["draws"].shape == (1, draws, n) and res1["extra_draws"]["c"].dtype == np.int64
+                                    and np.array_equal(res1["extra_draws"]["c"][0], np.arange(draws * 4).reshape(draws, 4))
+                                    and res1["extra_draws"]["w"].shape == (1, draws, 2) and res1["stats"][0][0]["depth"] == 9)
     # ---- Chan merge of Welford partials == pooled statistics ----
     nn = 6
     rng = np.random.default_rng(100 + rank)
@@ -75,7 +87,7 @@ def test_gloo_world2_gather_and_pooled_merge():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0]["gather_ok"] and got[0]["stats_ok"]
+    assert got[0]["gather_ok"] and got[0]["stats_ok"] and got[0]["empty_rank_ok"]
     allx = np.concatenate([got[0]["x"], got[1]["x"]])
     for r in range(2):
         m = got[r]["merged"]

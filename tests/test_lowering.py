@@ -690,3 +690,34 @@ def test_the_lowered_specs_of_the_committed_graphs_are_the_ones_the_device_tests
     got = msd.run()
     assert sorted(got) == sorted(want)
     assert [k for k in got if got[k] != want[k]] == []
+
+
+def test_a_one_index_gather_lowers_under_either_op_name(monkeypatch):
+    """Recent PyTensor hands `x[idx]` over as `AdvancedSubtensor` before its rewrites specialise it to `AdvancedSubtensor1`
+    (ADVICE r05): one index input is the gather whichever name the op carries -- also with negative indices, counted from the end --
+    and an index outside its dimension is `NotLowerable`, never a bare ValueError (the caller's fallback to the reference's step
+    catches NotImplementedError)."""
+    if not sg.available():
+        pytest.skip("builds a graph with the reference's code")
+    from pymc_amd.lowering import NotLowerable
+
+    want = lower_to_spec(lm.varying_intercepts_and_slopes())
+    monkeypatch.setattr(sg, "AdvancedSubtensor1", sg.AdvancedSubtensor)     # (the stand-in now emits the general op for `x[idx]`)
+    got = lower_to_spec(lm.varying_intercepts_and_slopes())
+    q = np.random.default_rng(2).normal(size=want.n) * 0.5
+    lp_a, g_a = ref_models.evaluate(want, q)
+    lp_b, g_b = ref_models.evaluate(got, q)
+    assert lp_a == lp_b and np.array_equal(g_a, g_b)
+
+    def model(idx):
+        m = sg.StubModel()
+        a = m.Normal("a", 0.0, 1.0, shape=(7,))
+        m.Normal("y", a[idx], 1.0, observed=lm.YR[: len(idx)])
+        return m
+
+    pos, neg = np.array([0, 6, 3, 6]), np.array([0, -1, 3, -1])
+    lp_p, g_p = ref_models.evaluate(lower_to_spec(model(pos)), q[:7])
+    lp_n, g_n = ref_models.evaluate(lower_to_spec(model(neg)), q[:7])
+    assert lp_p == lp_n and np.array_equal(g_p, g_n)
+    with pytest.raises(NotLowerable):
+        lower_to_spec(model(np.array([0, -8, 3])))

@@ -448,3 +448,48 @@ def test_nuts_on_the_lowered_autoregression_recovers_the_latent_path():
     assert np.corrcoef(x, tm.Y_AR)[0, 1] > 0.9
     rho = -1.0 + 2.0 / (1.0 + np.exp(-post[:, 0]))
     assert 0.0 < rho.mean() < 0.9            # (the series was generated with 0.55 x[t-1] - 0.25 x[t-2])
+
+
+# ---- device (round 6: these specs were host-validated only until then) ------------------------------------------------------------
+INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_device_reproduces_autograd_of_the_reference_graph(name):
+    """`nuts_model_create` takes the spec and `nuts_model_logp_grad` returns, at the committed points, what torch autograd of the
+    reference-built graph returned (tests/golden/more_graphs_golden.npz: nothing of the lowering, the IR or the oracle is in them)."""
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    spec = _committed(name)
+    f = DeviceValueGradFunction(spec, device=0)
+    qs, lps, grads = _golden(name)
+    for q, lp0, g0 in zip(qs, lps, grads):
+        lp, g = f._pytensor_function(q)
+        assert abs(lp - lp0) <= 1e-9 * max(1.0, abs(lp0)), (name, lp, lp0)
+        assert np.max(np.abs(g - g0)) <= 1e-9 * max(1.0, np.max(np.abs(g0))), (name, np.max(np.abs(g - g0)))
+    f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_nuts_on_the_device_has_the_oracle_samplers_integers(name):
+    """Identical seed => identical integer statistics, transition by transition, against the oracle's sampler on the same spec."""
+    from pymc_amd.sampling import sample
+
+    spec = _committed(name)
+    tune, draws, seed = 25, 8, 3
+    res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
+    _, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+    got = res["warmup_stats"][0] + res["stats"][0]
+    same = 0
+    for a, b in zip(got, ref_stats[0]):
+        if not all(int(a[k]) == int(b[k]) for k in INT_KEYS):
+            break
+        same += 1
+    res["step"].close()
+    assert same >= DEVICE_BAR.get(name, tune + draws - 2), (name, same)
+
+
+# transitions (of 33) that must carry the oracle sampler's integers; the default allows one late multinomial pick to flip on a last bit
+DEVICE_BAR = {}
