@@ -19,6 +19,7 @@ from pymc_amd import _lib
 
 class ChainGroup:
     MAX_CHAINS = 4        # on the plain-fma kernels: a chain in the group is bitwise the chain alone
+    MAX_CHAINS_ROWS = 8   # ... of the hierarchical-logit rows (csrc/rows_gal_kernel.h: one wave per chain, tiles shared through LDS), bitwise too
     MAX_CHAINS_WIDE = 16  # chains created under the options NUTS_MVN_ALIGNED = 8, NUTS_GROUP_WIDE = 1: the merged launch runs on the matrix
                           # cores (csrc/mvn_mfma_kernel.h); chains are then held to the oracle, not to bitwise equality with themselves alone
 

@@ -179,10 +179,15 @@ struct nuts_group {
   // kind of the members' models: 1 = one MvNormal node on the row-aligned pass (mvn_multi_kernel.h), 2 = the hierarchical-logit rows
   // on the group-aligned pass (rows_ga_multi_kernel.h); fixed by the first member
   int kind = 0;
-  GaLeafArgs gpend[GAM_MAXC];
+  GaLeafArgs gpend[GAL_MAXC];
   int rows_flip = 0;
+  // kind 2, launches that carry two chains or more (rows_gal_kernel.h): a member chain's constant arguments in device memory
+  GalConst* gal_konst_dev = nullptr;           // [GAL_MAXC]
+  GalConst gal_konst_host[GAL_MAXC] = {};      // ... as last uploaded
+  bool gal_konst_set[GAL_MAXC] = {};
+  int rows_lds = 1;                            // option NUTS_ROWS_GROUP_LDS (read when the first member joins); 0: the round-5 kernel (<= 4 chains)
 };
-static_assert(GAM_MAXC == MVM_MAXC, "one group size");
+static_assert(GAM_MAXC == MVM_MAXC && GAL_MAXC <= GRP_MAXC, "group sizes");
 
 static nuts_model* group_base(nuts_group* g) {   // whose copy of (P, mu) every launch reads: one copy stays cache-resident
   for (int i = 0; i < GRP_MAXC; ++i) if (g->member[i]) return g->member[i];
@@ -258,11 +263,58 @@ static void group_flush_rows_locked(nuts_group* g) {
   const int nc = g->npend;
   const nuts_model* base = group_base(g);
   const ModelDev& md = base->md;
-  const dim3 grid(GAM_MAXC + md.lg.G), block(WAVE * md.lg.ga_w);
-  int order[GAM_MAXC] = {0, 1, 2, 3};   // (by place in the group, not by arrival)
+  int order[GAL_MAXC];   // (by place in the group, not by arrival)
+  for (int a = 0; a < GAL_MAXC; ++a) order[a] = a;
   for (int a = 1; a < nc; ++a)
     for (int b = a; b > 0 && g->gpend[order[b]].slot < g->gpend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
   const int rev = base->rows_alternate ? (g->rows_flip ^= 1) : 0;
+  if (nc >= 2 && g->rows_lds) {
+    // one wave per chain, the tiles shared through LDS (rows_gal_kernel.h).  OCC: waves per SIMD the register budget is sized for --
+    // five workgroups of four waves per CU (5 per SIMD, 96 registers) keep all 1248 groups of the benchmark resident; eight-wave
+    // workgroups: two per CU at 128 registers.
+    const dim3 grid(GAL_MAXC + md.lg.G);
+#define GAL_LAUNCH(NC, DXX, OCC)                                                                                     \
+  {                                                                                                                  \
+    GalArgs<NC> la;                                                                                                  \
+    for (int c = 0; c < NC; ++c) {                                                                                   \
+      const GaLeafArgs& L = g->gpend[order[c]];                                                                      \
+      GalLeaf& l = la.c[c];                                                                                          \
+      l.io = L.io; l.cio = L.cio; l.uniforms = L.A.uniforms; l.log_uniforms = L.A.log_uniforms;                      \
+      l.j = L.j; l.fold = L.fold; l.par = L.par; l.d = L.d; l.cj = L.cj; l.cd = L.cd; l.cseq = L.cseq; l.slot = L.slot; \
+    }                                                                                                                \
+    la.rev = rev; la.pad = 0;                                                                                        \
+    hipLaunchKernelGGL((k_rows_gal<NC, DXX, OCC>), grid, dim3(WAVE * NC), 0, g->stream, md, (const GalConst*)g->gal_konst_dev, la); \
+  }
+#define GAL_BY_NC(DXX)                                                                                               \
+  switch (nc) {                                                                                                      \
+    case 2: GAL_LAUNCH(2, DXX, 4) break;                                                                             \
+    case 3: GAL_LAUNCH(3, DXX, 4) break;                                                                             \
+    case 4: GAL_LAUNCH(4, DXX, 5) break;                                                                             \
+    case 5: GAL_LAUNCH(5, DXX, 5) break;                                                                             \
+    case 6: GAL_LAUNCH(6, DXX, 5) break;                                                                             \
+    case 7: GAL_LAUNCH(7, DXX, 4) break;                                                                             \
+    default: GAL_LAUNCH(8, DXX, 4) break;                                                                            \
+  }
+    // the chains' constant parts: uploaded when a chain is first seen (and should it ever change); stream-ordered before the launch
+    for (int c = 0; c < nc; ++c) {
+      const GaLeafArgs& L = g->gpend[order[c]];
+      GalConst k{};
+      k.A = L.A; k.A.uniforms = nullptr; k.A.log_uniforms = nullptr; k.Emax = L.Emax; k.st = L.st;
+      k.ga_part = L.ga_part; k.ga_bpart = L.ga_bpart; k.ga_ticket = L.ga_ticket; k.def_loc = L.def_loc; k.max_depth = L.max_depth; k.slot = L.slot;
+      if (!g->gal_konst_set[L.slot] || std::memcmp(&k, &g->gal_konst_host[L.slot], sizeof(k)) != 0) {
+        g->gal_konst_host[L.slot] = k; g->gal_konst_set[L.slot] = true;
+        hipMemcpyAsync(g->gal_konst_dev + L.slot, &g->gal_konst_host[L.slot], sizeof(k), hipMemcpyHostToDevice, g->stream);
+      }
+    }
+    if (md.lg.ga_dx == 7) GAL_BY_NC(7) else GAL_BY_NC(8)
+#undef GAL_BY_NC
+#undef GAL_LAUNCH
+    g->launches[nc]++;
+    g->npend = 0;
+    g->gen.fetch_add(1, std::memory_order_release);
+    return;
+  }
+  const dim3 grid(GAM_MAXC + md.lg.G), block(WAVE * md.lg.ga_w);
 #define GAM_LAUNCH(NC, OCC, DXX)                                                                                     \
   {                                                                                                                  \
     GaMultiArgs<NC> ma;                                                                                              \
@@ -1938,7 +1990,7 @@ static void group_remove_model(nuts_group* g, nuts_model* m) {
   hipStreamSynchronize(g->stream);
   std::lock_guard<std::mutex> lk(g->mu);
   for (int i = 0; i < GRP_MAXC; ++i)
-    if (g->member[i] == m) { g->member[i] = nullptr; g->n--; g->konst_set[i] = false; }
+    if (g->member[i] == m) { g->member[i] = nullptr; g->n--; g->konst_set[i] = false; if (i < GAL_MAXC) g->gal_konst_set[i] = false; }
   if (m->g_active) { g->nactive--; m->g_active = false; }
   m->group = nullptr;
   m->stream = m->own_stream;
@@ -1967,8 +2019,14 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   }
   // a group of MvNormal models laid out 8 rows per workgroup whose FIRST member asked for it (option NUTS_GROUP_WIDE = 1 when the
   // member's chain was created) is WIDE: up to 16 chains per launch through the matrix cores
-  const int cap = g->n == 0 ? ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC) : g->cap;
-  if (g->n >= cap) { g_err = cap > MVM_MAXC ? "nuts_group_add: a wide group holds at most 16 chains" : "nuts_group_add: a group holds at most 4 chains"; return NUTS_E_ARG; }
+  // (the rows group carries up to eight chains through the LDS-shared launch, rows_gal_kernel.h; NUTS_ROWS_GROUP_LDS = 0 when the first
+  // member joins: the round-5 kernel and its four)
+  const int rows_lds = g->n == 0 ? (env_int("NUTS_ROWS_GROUP_LDS", 1) != 0) : g->rows_lds;
+  const int cap = g->n == 0 ? (is_rows ? (rows_lds ? GAL_MAXC : GAM_MAXC) : ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC)) : g->cap;
+  if (g->n >= cap) {
+    g_err = cap == GRP_MAXC ? "nuts_group_add: a wide group holds at most 16 chains" : (cap == GAL_MAXC ? "nuts_group_add: a rows group holds at most 8 chains" : "nuts_group_add: a group holds at most 4 chains");
+    return NUTS_E_ARG;
+  }
   if (g->n > 0 && g->kind != (is_rows ? 2 : 1)) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(m->stream));
   if (is_rows) {
@@ -2010,7 +2068,11 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
     HIPCHK(hipMemcpy(b.data() + kk, mv.mu, mv.k * sizeof(double), hipMemcpyDeviceToHost));
     if (std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) != 0) { g_err = "nuts_group_add: not the same model as the group's (precision or mean differ)"; return NUTS_E_ARG; }
   }
-  if (cap > MVM_MAXC && !g->konst_dev) {
+  if (is_rows && rows_lds && !g->gal_konst_dev) {
+    HIPCHK(hipMalloc((void**)&g->gal_konst_dev, GAL_MAXC * sizeof(GalConst)));
+    HIPCHK(hipMemset(g->gal_konst_dev, 0, GAL_MAXC * sizeof(GalConst)));
+  }
+  if (!is_rows && cap > MVM_MAXC && !g->konst_dev) {
     HIPCHK(hipMalloc((void**)&g->md_dev, sizeof(ModelDev)));
     HIPCHK(hipMalloc((void**)&g->dpack, (size_t)mv.k * MFM_MAXC * sizeof(double)));
     HIPCHK(hipMalloc((void**)&g->konst_dev, GRP_MAXC * sizeof(MfmChainConst)));
@@ -2018,6 +2080,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   }
   std::lock_guard<std::mutex> lk(g->mu);
   g->cap = cap;
+  g->rows_lds = rows_lds;
   for (int i = 0; i < cap; ++i)
     if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
   g->n++;
@@ -2039,6 +2102,7 @@ extern "C" void nuts_group_destroy(nuts_group* g) {
     if (g->member[i]) group_remove_model(g, g->member[i]);
   hipStreamDestroy(g->stream);
   if (g->konst_dev) hipFree(g->konst_dev);
+  if (g->gal_konst_dev) hipFree(g->gal_konst_dev);
   if (g->md_dev) hipFree(g->md_dev);
   if (g->dpack) hipFree(g->dpack);
   delete g;

@@ -982,19 +982,29 @@ __device__ __forceinline__ double slot_sum_finish(const double (&v)[SLOT_SUM_MAX
 // the larger batch stay out of the kernels that do not want it.
 // PF: the operands of the first merge levels of the deferred elements are requested at the top, with everything else whose address
 // is known (they belong to earlier leaves) -- otherwise every merge level costs the control workgroup a round of far loads.
+// The control work's LDS (10 KB).  A kernel whose control workgroup needs none of the kernel's other LDS hands in bytes of its own
+// (rows_gal_kernel.h: the tile ring of the row workgroups) -- static LDS of an inlined function is added to EVERY workgroup's footprint.
+struct CtlLds {
+  double s_sum[PART_STRIDE];
+  double s_chunk[CTL_CHUNKS][PART_STRIDE];
+  double s_red[NDOT * (VEC_THREADS / WAVE)];
+  double s_lu[UNI_PF];
+  Ctl s_ctl;
+};
+
 template <bool AGENT = false, int BATCH = 8, bool PF = false>
-__device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
-                                             int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt, bool have_upf,
-                                             UniPrefetch upf) {
+__device__ __forceinline__ void control_lean_in(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
+                                                int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt, bool have_upf,
+                                                UniPrefetch upf, CtlLds& lds) {
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
   constexpr int NWMAX = VEC_THREADS / WAVE;
   const int NT = nt ? nt : (int)blockDim.x, NW = NT / WAVE;
-  __shared__ double s_sum[PART_STRIDE];
-  __shared__ double s_chunk[CTL_CHUNKS][PART_STRIDE];
-  __shared__ double s_red[NDOT * NWMAX];
-  __shared__ double s_lu[UNI_PF];
-  __shared__ Ctl s_ctl;
+  double (&s_sum)[PART_STRIDE] = lds.s_sum;
+  double (&s_chunk)[CTL_CHUNKS][PART_STRIDE] = lds.s_chunk;
+  double (&s_red)[NDOT * NWMAX] = lds.s_red;
+  double (&s_lu)[UNI_PF] = lds.s_lu;
+  Ctl& s_ctl = lds.s_ctl;
   const int tid = threadIdx.x;
   const bool leaf = io.mode != MODE_PLAIN;
   const bool tree = io.mode == MODE_TREE;
@@ -1125,6 +1135,14 @@ __device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev&
   *A.ctl = s_ctl;
   if (st) publish_status(&s_ctl, st, seq);
   TICK(md, ctk, 13);
+}
+
+template <bool AGENT = false, int BATCH = 8, bool PF = false>
+__device__ __forceinline__ void control_lean(const ModelDev& md, const ArenaDev& A, const EvalIO& io, int j, int d, double Emax,
+                                             int max_depth, HostStatus* st, int seq, const LeanSrc src, int nt, bool have_upf,
+                                             UniPrefetch upf) {
+  __shared__ CtlLds lds;
+  control_lean_in<AGENT, BATCH, PF>(md, A, io, j, d, Emax, max_depth, st, seq, src, nt, have_upf, upf, lds);
 }
 
 template <bool AGENT = false, int BATCH = 8, bool PF = false>
@@ -1683,3 +1701,4 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, con
 #include "mvn_multi_kernel.h"
 #include "mvn_mfma_kernel.h"
 #include "rows_ga_multi_kernel.h"
+#include "rows_gal_kernel.h"

@@ -682,7 +682,8 @@ def sample(
             rows_group = int(step._logp_dlogp_func.model_scalar("chain_group_kind")) == 2 and not getattr(step.potential, "_dense", False)
         except (AttributeError, EngineError, ValueError):
             pass
-    n_par = min(len(mine), cores if cores is not None else (4 if (latency_bound or rows_group) else 1))
+    # (the rows group carries up to eight chains per launch -- BASELINE configs[1]'s eight chains share ONE read of X on one GPU)
+    n_par = min(len(mine), cores if cores is not None else (8 if rows_group else 4 if latency_bound else 1))
     if n_par > 1:
         logging.getLogger("pymc_amd").info("sampling %d chains on one GPU, %d at a time (host threads, one engine each)", len(mine), n_par)
     if pooled is not None or step_given or n_par < 1:

@@ -5,6 +5,7 @@ The reference's chains are independent (pymc/sampling/mcmc.py:1385-1500): whatev
 produce the draws and statistics it produces alone -- here bit for bit, because a chain's numbers inside a merged launch are
 formed from its own operands in the single-chain kernel's order."""
 
+import os
 import threading
 
 import numpy as np
@@ -210,12 +211,13 @@ def test_what_a_group_refuses():
 
 
 # ---- the hierarchical-logit rows on the group-aligned pass (csrc/rows_ga_multi_kernel.h) --------------------------------------
-@pytest.mark.parametrize("G,rpg,chains,tune,draws", [(40, 300, 4, 30, 12), (24, 517, 3, 20, 8),
-                                                     pytest.param(64, 130, 2, 20, 8, marks=pytest.mark.known_intermittent)])
+@pytest.mark.parametrize("G,rpg,chains,tune,draws", [(40, 300, 4, 30, 12), (24, 517, 3, 20, 8), (64, 130, 2, 20, 8),
+                                                     (30, 900, 8, 20, 8), (24, 517, 5, 16, 6), (16, 260, 7, 16, 6), (20, 1300, 6, 12, 5)])
 def test_grouped_chains_of_the_logit_rows_are_bitwise_the_chains_alone(G, rpg, chains, tune, draws, monkeypatch):
     """The benchmark's model (BASELINE configs[1]) at small sizes, forced onto the group-aligned pass: chains sampled one after the
     other, and concurrently as a chain group whose launches stream X once for all chains standing at a leaf.  rpg = 517: a padded
-    last tile; 130: a single tile and a bit; chains = 3, 2: the three- and two-chain instantiations (four: also chains that leave)."""
+    last tile; 130: a single tile and a bit (a chunk of the layout without tiles); chains = 2 .. 8: every instantiation of the merged
+    launch (csrc/rows_gal_kernel.h: one wave per chain, the tiles shared through LDS; chains that leave and join all the time)."""
     monkeypatch.setenv("NUTS_ROWS_GA", "2")
     spec = models.hier_logit(G=G, D=8, rows_per_group=rpg, seed=3)
     alone = _sample(spec, chains, False, 1, tune, draws, 17)
@@ -240,7 +242,7 @@ def test_grouped_chains_of_the_logit_rows_are_bitwise_the_chains_alone(G, rpg, c
         _same_stats(alone["stats"][c], group["stats"][c], (G, rpg, c))
     sizes = [[int(s["tree_size"]) for s in group["stats"][c]] for c in range(chains)]
     assert len({tuple(s) for s in sizes}) == chains
-    print(f"G = {G} x {rpg}: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, 5)) / sum(n[1:]):.2f}")
+    print(f"G = {G} x {rpg}: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, len(n))) / sum(n[1:]):.2f}")
 
 
 def test_sample_groups_the_chains_of_the_benchmark_model_by_default(monkeypatch):
@@ -253,3 +255,67 @@ def test_sample_groups_the_chains_of_the_benchmark_model_by_default(monkeypatch)
     res["step"].close()
     n = res["lockstep_launches"]
     assert n is not None and sum(n[1:]) > 0, n
+
+
+# ---- the rows chain group against the ORACLE, at the benchmark's shapes ------------------------------------------------------------
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# transitions from the start over which a grouped chain must carry the committed oracle chain's integers (measured on the device, minus
+# two -- as in tests/test_gpu_benchmark_shapes.py; the oracle chains of C2-L come from the libmvec arrangement of the C loop)
+ORACLE_BAR = {"c2l": 14, "c2s": 6}
+
+
+@pytest.mark.parametrize("shape,chains", [("c2l", 4), ("c2l", 3), ("c2l", 2), ("c2s", 4), ("c2s", 2)])
+def test_grouped_rows_chains_carry_the_oracle_chains_integers_at_the_benchmark_shapes(shape, chains, monkeypatch):
+    """BASELINE configs[1] AT ITS OWN SHAPES through the merged launch (`k_rows_ga_multi<NC>`; C2-L is what `bench.py` times the group
+    on): the first transitions of `chains` chains from the committed over-dispersed starts, sampled as a chain group, against the
+    CPU oracle's chains (tests/golden/c2l_chains.npz, c2s_chains.npz: `oracle/ref_sampler.py` over the gcc restatement, per-transition
+    tree sizes and depths of four chains).  Trees of different lengths -- among them trees that end in a divergence (sizes 208, 163,
+    6, 5 in the committed runs) -- make the chains leave and join launches all the time.  Identical seed => identical integers; and the
+    group is bitwise the chains alone at this shape too."""
+    from pymc_amd.sampling import sample
+
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")      # (C2-S runs the group-block pass by default; the group is the group-aligned pass's)
+    gold = np.load(os.path.join(GOLDEN, f"{shape}_chains.npz"))
+    G, D, rpg, _tune, _draws, gchains, seed, start_seed = (int(x) for x in gold["config"])
+    assert (G, D, gchains) == (1248, 8, 4) and rpg == (4000 if shape == "c2l" else 80)
+    spec = models.hier_logit(G=G, D=D, rows_per_group=rpg)
+    rng = np.random.default_rng(start_seed)
+    starts = [rng.uniform(-1, 1, size=spec.n) for _ in range(gchains)]
+    initvals = [{"mu": s[:8], "sigma_log__": s[8:16], "z": s[16:].reshape(G, D)} for s in starts]
+    # (chain c's generators are child c of the seed's SeedSequence whatever the number of chains, mcmc.py:907-908; the initial diagonal
+    # potential's mean is the mean of the starts: all four are handed over, the first `chains` are sampled)
+    K = 18 if shape == "c2l" else 9
+    kw = dict(draws=1, tune=K, chains=gchains, model=spec, init="adapt_diag", random_seed=seed, initvals=initvals, device=0,
+              discard_tuned_samples=False)
+    group = sample(cores=chains, lockstep=True, **kw)
+    n = group["lockstep_launches"]
+    group["step"].close()
+    assert n is not None and sum(n[2:]) > 0, n
+    firsts = []
+    for c in range(gchains):
+        got = group["stats"][c]
+        first = next((i for i in range(K) if int(got[i]["tree_size"]) != int(gold["stat_tree_size"][c][i]) or int(got[i]["depth"]) != int(gold["stat_depth"][c][i])
+                      or bool(got[i]["diverging"]) != bool(gold["stat_diverging"][c][i])), K)
+        firsts.append(first)
+    print(f"{shape}, {chains} chains per launch at most: integers identical to the oracle chains' for the first {firsts} of {K} transitions; launches {n[1:]}")
+    assert min(firsts) >= ORACLE_BAR[shape], (firsts, n)
+    alone = sample(cores=1, lockstep=False, **kw)
+    alone["step"].close()
+    assert np.array_equal(alone["draws"], group["draws"])
+    for c in range(gchains):
+        _same_stats(alone["stats"][c], group["stats"][c], (shape, chains, c))
+
+
+def test_the_round_5_rows_group_kernel_is_still_bitwise(monkeypatch):
+    """NUTS_ROWS_GROUP_LDS = 0 (read when a group's first member joins): the merged launch of round 5 (csrc/rows_ga_multi_kernel.h: every
+    wave all chains, at most four) -- kept for A/B measurements, held to the same bar."""
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    monkeypatch.setenv("NUTS_ROWS_GROUP_LDS", "0")
+    spec = models.hier_logit(G=40, D=8, rows_per_group=300, seed=3)
+    alone = _sample(spec, 4, False, 1, 20, 8, 17)
+    group = _sample(spec, 4, True, 4, 20, 8, 17)
+    n = group["lockstep_launches"]
+    assert n is not None and len(n) == 5 and sum(n[2:]) > 0, n
+    assert np.array_equal(alone["draws"], group["draws"])
+    for c in range(4):
+        _same_stats(alone["stats"][c], group["stats"][c], c)

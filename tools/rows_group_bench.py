@@ -18,7 +18,8 @@ draws = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 spec = models.hier_logit(G=1248, D=8, rows_per_group=rpg)
 out = {"rows_per_group": rpg, "chains": chains, "tune": tune, "draws": draws}
 ref = None
-for mode, lockstep, cores in (("one_after_the_other", False, 1), ("chain_group", True, chains)):
+only_group = len(sys.argv) > 5 and sys.argv[5] == "group"
+for mode, lockstep, cores in ((("chain_group", True, chains),) if only_group else (("one_after_the_other", False, 1), ("chain_group", True, chains))):
     t0 = time.perf_counter()
     res = sample(draws=draws, tune=tune, chains=chains, model=spec, init="jitter+adapt_diag", random_seed=11, device=0, cores=cores, lockstep=lockstep,
                  discard_tuned_samples=False)
@@ -29,7 +30,7 @@ for mode, lockstep, cores in (("one_after_the_other", False, 1), ("chain_group",
     n = res["lockstep_launches"]
     out[mode] = {"wall_s_incl_setup": wall, "sampling_s_post_warmup": res["sampling_time"], "leapfrogs_total": lf_all,
                  "leapfrog_per_s_post_warmup": lf_post / res["sampling_time"], "launches_by_chains_carried": n[1:] if n else None,
-                 "mean_chains_per_launch": (sum(c * n[c] for c in range(1, 5)) / max(1, sum(n[1:]))) if n else None}
+                 "mean_chains_per_launch": (sum(c * n[c] for c in range(1, len(n))) / max(1, sum(n[1:]))) if n else None}
     if ref is None:
         ref = res["draws"]
     else:
