@@ -185,9 +185,10 @@ struct nuts_group {
   GalConst* gal_konst_dev = nullptr;           // [GAL_MAXC]
   GalConst gal_konst_host[GAL_MAXC] = {};      // ... as last uploaded
   bool gal_konst_set[GAL_MAXC] = {};
+  int gal_occ5 = 0;                            // option NUTS_GAL_OCC5 (A/B): four chains at 96 registers (five workgroups per CU, spills in the loop) instead of 128
   int rows_lds = 1;                            // option NUTS_ROWS_GROUP_LDS (read when the first member joins); 0: the round-5 kernel (<= 4 chains)
 };
-static_assert(GAM_MAXC == MVM_MAXC && GAL_MAXC <= GRP_MAXC, "group sizes");
+static_assert(GAM_MAXNC == MVM_MAXC && GAL_MAXC == GAM_MAXC && GAL_MAXC <= GRP_MAXC, "group sizes");
 
 static nuts_model* group_base(nuts_group* g) {   // whose copy of (P, mu) every launch reads: one copy stays cache-resident
   for (int i = 0; i < GRP_MAXC; ++i) if (g->member[i]) return g->member[i];
@@ -269,9 +270,8 @@ static void group_flush_rows_locked(nuts_group* g) {
     for (int b = a; b > 0 && g->gpend[order[b]].slot < g->gpend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
   const int rev = base->rows_alternate ? (g->rows_flip ^= 1) : 0;
   if (nc >= 2 && g->rows_lds) {
-    // one wave per chain, the tiles shared through LDS (rows_gal_kernel.h).  OCC: waves per SIMD the register budget is sized for --
-    // five workgroups of four waves per CU (5 per SIMD, 96 registers) keep all 1248 groups of the benchmark resident; eight-wave
-    // workgroups: two per CU at 128 registers.
+    // one wave per chain, the tiles shared through LDS (rows_gal_kernel.h).  OCC: waves per SIMD the register budget is sized for:
+    // four (128 registers: the two rows of a lane side by side without a spill in the stream).
     const dim3 grid(GAL_MAXC + md.lg.G);
 #define GAL_LAUNCH(NC, DXX, OCC)                                                                                     \
   {                                                                                                                  \
@@ -289,9 +289,9 @@ static void group_flush_rows_locked(nuts_group* g) {
   switch (nc) {                                                                                                      \
     case 2: GAL_LAUNCH(2, DXX, 4) break;                                                                             \
     case 3: GAL_LAUNCH(3, DXX, 4) break;                                                                             \
-    case 4: GAL_LAUNCH(4, DXX, 5) break;                                                                             \
-    case 5: GAL_LAUNCH(5, DXX, 5) break;                                                                             \
-    case 6: GAL_LAUNCH(6, DXX, 5) break;                                                                             \
+    case 4: if (g->gal_occ5) GAL_LAUNCH(4, DXX, 5) else GAL_LAUNCH(4, DXX, 4) break;                                 \
+    case 5: GAL_LAUNCH(5, DXX, 4) break;                                                                             \
+    case 6: GAL_LAUNCH(6, DXX, 4) break;                                                                             \
     case 7: GAL_LAUNCH(7, DXX, 4) break;                                                                             \
     default: GAL_LAUNCH(8, DXX, 4) break;                                                                            \
   }
@@ -418,6 +418,10 @@ static void launch_control_lean(nuts_model* m, const ArenaDev& A, const EvalIO& 
 
 static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int d) {
   const ModelDev& md = m->md;
+  // gathered adjoints (model_dev.h GSlot): every element of the factors that read variables through index vectors is swept once,
+  // before the kernels whose gathers add the results up (B and C below; the dense node's seed of a derived vector is already there)
+  if (md.n_gsf > 0)
+    hipLaunchKernelGGL(k_gsweep, dim3(std::max(1, std::min(2048, (md.n_gs_elems + 255) / 256))), dim3(256), 0, m->stream, md, A, io, j);
   if (md.lg.ga) return;   // group-aligned row pass: the O(n) work rides in the row pass itself (rows_ga_kernel.h)
   if (md.has_mvn && md.mv.aligned && io.lean) return;   // (the row-aligned MvNormal pass has finished the leapfrog itself)
   // small models: 8x oversubscribed launch, one XCD does the work (see k_vector); large ones use the whole chip
@@ -632,6 +636,26 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   std::vector<std::pair<int, int>> gathered;   // (variable, index data id) pairs of the factor being compiled
   std::vector<int32_t>& derived = m->derived;  // NUTS_D_DERIVED factors, in factor order
   derived.clear();
+  // gathered adjoints (model_dev.h GSlot): the factors whose elements are swept once, ahead of the gathers that read the result
+  std::vector<GSweepFactor> gsf;
+  std::vector<GSlot> gslots;
+  int64_t adj_len = 0;
+  int32_t gs_elems = 0;
+  const bool gsweep_on = env_int("NUTS_GSWEEP", 1) != 0;
+  auto finish_gather = [&](int fi) {
+    if (!gsweep_on || gathered.empty() || (int)gathered.size() > MAX_GSLOTS) return;
+    const int64_t fsize = s->factors[fi].size;
+    if (adj_len + (int64_t)gathered.size() * fsize > ((int64_t)1 << 28) || (int64_t)gs_elems + fsize > ((int64_t)1 << 30)) return;   // (2 GiB of adjoints: keep the old path)
+    GSweepFactor sf{fi, (int32_t)gslots.size(), (int32_t)gathered.size(), gs_elems};
+    for (const auto& gv : gathered) {
+      gslots.push_back(GSlot{gv.first, gv.second, adj_len});
+      for (Contrib& cb : per_var[gv.first])
+        if (cb.f == fi && cb.arg == -2 && (int)cb.p[0] == gv.second) { cb.p[1] = (double)adj_len; cb.p[2] = 1.0; }
+      adj_len += fsize;
+    }
+    gs_elems += (int32_t)fsize;
+    gsf.push_back(sf);
+  };
   // NUTS_OP_GATHER operand of factor fi: the inverse index (which factor elements read element e of the variable, in order)
   auto add_gather = [&](int fi, const nuts_operand& o) -> bool {
     const nuts_factor& f = s->factors[fi];
@@ -755,6 +779,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         } else { g_err = "variable does not broadcast against its factor"; return false; }
       }
       if (!owned_already) orphans.push_back(fi);
+      finish_gather(fi);
       continue;
     }
     for (int a = 0; a < f.nargs; ++a) {
@@ -808,6 +833,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       }
     }
     if (!owned_already) orphans.push_back(fi);
+    finish_gather(fi);
   }
   // peephole: untransformed vector variable whose only contribution is its own constant-parameter Normal prior
   for (int k = 0; k < nv; ++k) {
@@ -912,6 +938,15 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.po_data = put(drefs.data(), drefs.size() * sizeof(nuts_data_ref));
   md.po_deferred = put(deferred.data(), deferred.size() * sizeof(int32_t));
   md.po_instrs = put(s->instrs, s->instrs ? (size_t)std::max(s->n_instrs, 0) * sizeof(nuts_instr) : 0);
+  md.n_gsf = (int32_t)gsf.size(); md.n_gs_elems = gs_elems;
+  md.po_gsf = put(gsf.data(), gsf.size() * sizeof(GSweepFactor));
+  md.po_gslot = put(gslots.data(), gslots.size() * sizeof(GSlot));
+  md.adj = nullptr;
+  if (adj_len > 0) {
+    md.adj = m->keep(dev_alloc<double>((size_t)adj_len));
+    if (!md.adj) { g_err = "device allocation failed (gathered adjoints)"; return false; }
+    hipMemset(md.adj, 0, (size_t)adj_len * sizeof(double));
+  }
   blob.resize((blob.size() + 15) & ~(size_t)15, 0);
   md.prog_bytes = (int32_t)blob.size();
   md.prog = m->keep(dev_upload(blob.data(), blob.size()));
@@ -2022,7 +2057,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   // (the rows group carries up to eight chains through the LDS-shared launch, rows_gal_kernel.h; NUTS_ROWS_GROUP_LDS = 0 when the first
   // member joins: the round-5 kernel and its four)
   const int rows_lds = g->n == 0 ? (env_int("NUTS_ROWS_GROUP_LDS", 1) != 0) : g->rows_lds;
-  const int cap = g->n == 0 ? (is_rows ? (rows_lds ? GAL_MAXC : GAM_MAXC) : ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC)) : g->cap;
+  const int cap = g->n == 0 ? (is_rows ? (rows_lds ? GAL_MAXC : GAM_MAXNC) : ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC)) : g->cap;
   if (g->n >= cap) {
     g_err = cap == GRP_MAXC ? "nuts_group_add: a wide group holds at most 16 chains" : (cap == GAL_MAXC ? "nuts_group_add: a rows group holds at most 8 chains" : "nuts_group_add: a group holds at most 4 chains");
     return NUTS_E_ARG;
@@ -2081,6 +2116,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   std::lock_guard<std::mutex> lk(g->mu);
   g->cap = cap;
   g->rows_lds = rows_lds;
+  if (g->n == 0) g->gal_occ5 = env_int("NUTS_GAL_OCC5", 0);
   for (int i = 0; i < cap; ++i)
     if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
   g->n++;

@@ -399,6 +399,21 @@ __device__ __forceinline__ bool dot_needed(int k, int m, bool last) {
 }
 
 // ---------------------------------------------------------------------------
+// gathered adjoints (model_dev.h GSlot): one forward + reverse sweep per element of the factors that read variables through index
+// vectors, ahead of kernel B / C, whose gathers add the stored adjoints up
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gsweep(ModelDev md, ArenaDev A, EvalIO io, int j) {
+  if (load_aborted(io, A)) return;
+  __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
+  ProgRegs pregs;
+  prog_issue(md, pregs);
+  const Prog pg = load_prog(md, s_prog, pregs);
+  Leaf lf; QView qv;
+  resolve_leaf(io, A, j, lf, qv);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < md.n_gs_elems; e += gridDim.x * 256) gsweep_element(pg, qv, e);
+}
+
+// ---------------------------------------------------------------------------
 // B: the O(n) kernel
 // ---------------------------------------------------------------------------
 template <int EPT, bool PROG>

@@ -50,6 +50,18 @@ struct Contrib {  // "variable k is operand `slot` (0=a,1=b,2=c) of argument `ar
   double p[4];
 };
 
+// Gathered adjoints (round 6).  A variable that enters a factor through NUTS_OP_GATHER operands used to have its gradient formed by the
+// PARAMETER element: one forward + reverse sweep of the factor's program per (element of the variable, factor element that indexes it)
+// -- a weight matrix broadcast over the rows of a likelihood (a neural network, a softmax regression: every coefficient is read by
+// every row) cost (number of coefficients) x (rows) sweeps per gradient, executed one parameter at a time.  Now every element of
+// such a factor is swept ONCE, ahead of everything else of the leaf (k_gsweep, kernels.h; a phase of the single-workgroup kernel):
+// the sweep leaves, per (variable, index vector) pair of the factor -- a "slot" --, d logp_element / d (that gather) in
+// ModelDev.adj[slot.adj_off + element]; the parameter element then adds up the entries its inverse index lists, in index order
+// (the same numbers in the same order as before).
+#define MAX_GSLOTS 64       // (variable, index vector) pairs per factor served this way; a factor with more keeps the old path
+struct GSlot { int32_t var, did; int64_t adj_off; };
+struct GSweepFactor { int32_t f, slot0, n_slots, elem0; };   // slots [slot0, slot0 + n_slots) of ModelDev's slot table; elem0: first of its elements in the sweep's numbering
+
 struct FactorBT {  // broadcast (size-1 variable) operands of a factor whose size is > 1
   int32_t n, pad;
   struct { int16_t arg, slot; int32_t bterm; } e[MAX_FACTOR_BT];
@@ -212,6 +224,10 @@ struct ModelDev {
   // factors as dead for all their elements (mode 2).  Mode 0 (every pass inside a transition): element-wise, nothing recorded.
   int32_t fdead_mode;
   int32_t* fdead;             // [n_factors]
+  // gathered adjoints (see GSlot): the factors swept ahead of the leaf's other work, their slots, the adjoint pool
+  int32_t n_gsf, n_gs_elems;  // factors; their elements in all
+  int32_t po_gsf, po_gslot;   // tables in the program blob
+  double* adj;
 };
 
 #ifdef NUTS_KTIMING
@@ -284,6 +300,10 @@ struct Prog {
   int n_vars;
   int fdead_mode;            // see ModelDev
   int32_t* fdead;
+  const GSweepFactor* gsf;   // gathered adjoints (see GSlot)
+  const GSlot* gslot;
+  double* adj;
+  int n_gsf;
 };
 
 __device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) {
@@ -301,6 +321,9 @@ __device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) 
   pg.pool = md.pool;
   pg.n_vars = md.n_vars;
   pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
+  pg.gsf = reinterpret_cast<const GSweepFactor*>(base + md.po_gsf);
+  pg.gslot = reinterpret_cast<const GSlot*>(base + md.po_gslot);
+  pg.adj = md.adj; pg.n_gsf = md.n_gsf;
   return pg;
 }
 
@@ -773,9 +796,14 @@ __device__ __noinline__ double factor_arg0_value(const Prog& pg, const QView& qv
   return o.a[0];
 }
 
+// `gs` / `ngs` (the sweep of k_gsweep only): the factor's slots; the adjoint of every gather operand is added up per slot and
+// stored at adj[slot.adj_off + li] -- nothing else of the sweep is kept.
 __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int own_var, double own_x,
-                                               int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out, int wrt_did = -1) {
+                                               int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out, int wrt_did = -1,
+                                               const GSlot* gs = nullptr, int ngs = 0) {
   double tv[NUTS_MAX_FACTOR_INSTR], ta[NUTS_MAX_FACTOR_INSTR];
+  double gadj[MAX_GSLOTS];
+  if (gs) for (int sl = 0; sl < ngs; ++sl) gadj[sl] = 0.0;
   ProgFwd o;
   prog_forward(pg, qv, f, li, own_var, own_x, tv, o);
   double d[4];
@@ -789,6 +817,12 @@ __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, 
   auto push = [&](const nuts_operand& q, double g) {
     if (q.kind == NUTS_OP_TMP) { ta[q.ref] += g; return; }
     if (q.kind != NUTS_OP_VAR && q.kind != NUTS_OP_GATHER) return;
+    if (gs) {
+      if (q.kind == NUTS_OP_GATHER)
+        for (int sl = 0; sl < ngs; ++sl)
+          if (gs[sl].var == q.ref && gs[sl].did == (int)q.c) { gadj[sl] += g; break; }
+      return;
+    }
     // `wrt_did` < 0: the caller owns an element-aligned (or scalar) occurrence of `wrt`: its direct operands; >= 0: it stands for the
     // gather of `wrt` through index vector `wrt_did`: those operands only (the others belong to other contributions of the variable)
     if (q.ref == wrt && (wrt_did < 0 ? q.kind == NUTS_OP_VAR : (q.kind == NUTS_OP_GATHER && (int)q.c == wrt_did))) { gw += g; return; }
@@ -847,8 +881,18 @@ __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, 
       default: break;   // comparisons, logic, sign, floor, ceil: piecewise constant
     }
   }
+  if (gs) for (int sl = 0; sl < ngs; ++sl) pg.adj[gs[sl].adj_off + li] = gadj[sl];
   *gwrt_out = gw;
   return lp;
+}
+
+// element `e` (in the sweep's numbering) of the factors with gathered adjoints: one forward + reverse sweep, the slots' adjoints stored
+__device__ __forceinline__ void gsweep_element(const Prog& pg, const QView& qv, int e) {
+  int t = 0;
+  while (t + 1 < pg.n_gsf && e >= pg.gsf[t + 1].elem0) ++t;
+  const GSweepFactor sf = pg.gsf[t];
+  double gw;
+  factor_prog_rev(pg, qv, pg.factors[sf.f], sf.f, e - sf.elem0, -1, 0.0, -1, 0, nullptr, 0, &gw, -1, pg.gslot + sf.slot0, sf.n_slots);
 }
 
 __device__ __forceinline__ double dot4(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -904,6 +948,18 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
     if (cb.arg == -2) {    // gathered into the factor: every factor element that indexes this element, in index order
       const int32_t* ptr = pg.csr + cb.dist;
       const int32_t* lst = pg.csr + cb.pad;
+      if (cb.p[2] != 0.0) {   // the factor's elements have been swept (k_gsweep): their adjoints of this (variable, index vector) pair
+        const double* adj = pg.adj + (int64_t)cb.p[1];
+        const int t1 = ptr[li + 1];
+        for (int t = ptr[li]; t < t1; t += 8) {   // (eight loads in flight, added in index order)
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = adj[lst[min(t + u, t1 - 1)]];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) gx += (t + u < t1) ? v[u] : 0.0;
+        }
+        continue;
+      }
       for (int t = ptr[li]; t < ptr[li + 1]; ++t) {
         double gw;
         factor_prog_rev(pg, qv, f, cb.f, lst[t], -1, 0.0, k, 0, s_bacc, bstride, &gw, (int)cb.p[0]);

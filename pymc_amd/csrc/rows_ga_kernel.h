@@ -148,9 +148,28 @@ template <int DX> struct GaTileSel { typedef GaTileRegs type; };
 template <> struct GaTileSel<7> { typedef GaTileRegs7 type; };
 
 // one tile of SPAN = 64 RPL rows: forward (eta, log-lik) + backward (d/dbeta) in registers
-template <int D, int RPL>
+// ILV: the rows of a lane may be interleaved by the scheduler (rows_gal_kernel.h: a dependent fp64 fma issues every ~24 cycles, and
+// a wave that holds ONE tile has the registers for two rows' temporaries; per row the operations and their order are the same)
+template <int D, int RPL, bool ILV = false>
 __device__ __forceinline__ void ga_tile(const double (&x)[D][RPL], uint32_t yb, const double (&beta)[D], int nvalid, int lane,
                                         double (&acc)[D], double& lp) {
+  if constexpr (ILV && RPL == 2) {
+    double eta[2] = {0.0, 0.0}, yk[2], l[2], rr[2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { eta[0] = fma(x[d][0], beta[d], eta[0]); eta[1] = fma(x[d][1], beta[d], eta[1]); }
+    yk[0] = (double)(yb & 0xffu); yk[1] = (double)((yb >> 8) & 0xffu);
+    logit_row2(eta, yk, l, rr);
+    // (row 0's contributions enter the lane's sums before row 1's, as in the loop below)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool in = lane * 2 + k < nvalid;
+      lp += in ? l[k] : 0.0;
+      rr[k] = in ? rr[k] : 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { acc[d] = fma(rr[0], x[d][0], acc[d]); acc[d] = fma(rr[1], x[d][1], acc[d]); }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < RPL; ++k) {
     double eta = 0.0;
@@ -165,7 +184,7 @@ __device__ __forceinline__ void ga_tile(const double (&x)[D][RPL], uint32_t yb, 
     for (int d = 0; d < D; ++d) acc[d] = fma(rr, x[d][k], acc[d]);
     // rows are finished one after the other: interleaving the two rows of a lane would double the live temporaries of the
     // exp / log1p / reciprocal sequences, and the registers are better spent on tiles in flight
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!ILV) __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -24,7 +24,8 @@
 #pragma once
 #include "mvn_multi_kernel.h"   // (wave_sum_many)
 
-#define GAM_MAXC 4
+#define GAM_MAXC 8   // control workgroups of a launch = places in a rows group (round 6: eight, rows_gal_kernel.h; THIS kernel carries at most GAM_MAXNC chains)
+#define GAM_MAXNC 4
 
 struct GaLeafArgs {   // one chain's arguments of k_rows_ga (GaArgs without the model)
   ArenaDev A;

@@ -27,7 +27,7 @@
 #pragma once
 #include "rows_ga_multi_kernel.h"
 
-#define GAL_MAXC 8          // chains per launch (BASELINE configs[1]: eight chains)
+#define GAL_MAXC GAM_MAXC   // chains per launch (BASELINE configs[1]: eight chains); the single-chain launches of a group go through k_rows_ga_multi<1>, same grid
 #define GAL_PF 2            // tiles requested ahead of the one being evaluated
 #define GAL_RING (GAL_PF + 1)
 
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
   __shared__ double s_acc[NC][GA_MAXW][2][D + 1];            // [chain][chunk][first / second half of its tiles][d/dbeta, log-lik]
   __shared__ int s_info[NC][4];
   __shared__ int s_dead[NC];
+  __shared__ double s_keep[NC][5][2 * D];                    // the prologue values the chain's tail needs again (lanes < 2 D), out of the stream's registers
   const uint32_t ring0 = (uint32_t)(uintptr_t)(&s_ring[0]);   // (LDS addresses are 32-bit offsets)
 
   // ---- the chains' arguments -> LDS ----
@@ -250,9 +251,9 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
   }
 
   // ---- prologue of this wave's chain: mu', sigma' of its leaf, z' of this group, beta_g (the first tiles are in flight) ----
-  double hval0 = 0.0, hph0 = 0.0, zq = 0.0, zph = 0.0, s_lane = 0.0;
   double beta[D];
   {
+    double hval0 = 0.0, hph0 = 0.0, zq = 0.0, zph = 0.0, s_lane = 0.0;
     Leaf lf; QView qv;
     resolve_leaf(L.io, L.A, L.j, lf, qv);
     double bl = 0.0;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
     }
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) beta[dd] = readlane_d(bl, dd);
+    if (lane < 2 * D) { s_keep[w][0][lane] = hval0; s_keep[w][1][lane] = hph0; s_keep[w][2][lane] = zq; s_keep[w][3][lane] = zph; s_keep[w][4][lane] = s_lane; }
   }
   __syncthreads();   // (s_dead, s_acc; hipcc waits for the prologue's own loads here -- and for the first tiles with them, once per launch)
   int alldead = 1;
@@ -301,19 +303,40 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
       if (ld.ww < W) { lastreq = ld; request(ld, (s + GAL_PF) % GAL_RING); ld.pos++; it_skip_empty(ld); }
       else request(lastreq, (s + GAL_PF) % GAL_RING);
       const char* slot = s_ring + (s % GAL_RING) * SLOT;
-      double xx[8][2];
-      if constexpr (DX == 7) { xx[0][0] = 1.0; xx[0][1] = 1.0; }
-#pragma unroll
-      for (int k = 0; k < DX; ++k) {
-        const ga_v2d v = *reinterpret_cast<const ga_v2d*>(slot + k * 1024 + lane * 16);
-        xx[k + (8 - DX)][0] = v.x; xx[k + (8 - DX)][1] = v.y;
-      }
       const uint32_t yy = *reinterpret_cast<const uint16_t*>(slot + DX * 1024 + lane * 2);
       const int local = it_local(ev);
       // the flush between the two halves of a chunk comes BEFORE the first tile of the second-streamed half (k_rows_ga: `if (I == nsw) flush()`)
       if (ev.pos == ev.nsw) flush(ev.ww, rev ? 1 : 0);
       const int nv = (ev.has_last && local == ev.n - 1) ? n_last : SPAN;
-      if (!dead) ga_tile<8, 2>(xx, yy, beta, nv, lane, acc, lp);
+      if (!dead) {
+        // ga_tile<8, 2>'s arithmetic, row by row the same operations in the same order -- with the tile read from LDS TWICE (forward:
+        // eta; backward: d/dbeta) instead of held in 28 registers across the exp / log1p / reciprocal sequences, whose two rows run
+        // side by side (logit_row2, rows_kernel.h): 96 registers, five waves per SIMD, two dependent chains in flight per wave
+        auto col = [&](int k) { return *reinterpret_cast<const ga_v2d*>(slot + k * 1024 + lane * 16); };
+        double eta[2] = {0.0, 0.0}, yk[2], l[2], rr[2];
+        if constexpr (DX == 7) { eta[0] = fma(1.0, beta[0], eta[0]); eta[1] = fma(1.0, beta[0], eta[1]); }
+#pragma unroll
+        for (int k = 0; k < DX; ++k) {
+          const ga_v2d v = col(k);
+          eta[0] = fma(v.x, beta[k + (8 - DX)], eta[0]); eta[1] = fma(v.y, beta[k + (8 - DX)], eta[1]);
+        }
+        yk[0] = (double)(yy & 0xffu); yk[1] = (double)((yy >> 8) & 0xffu);
+        asm volatile("" ::: "memory");   // (the columns are read AGAIN below: without this hipcc keeps the first reads alive in registers)
+        logit_row2(eta, yk, l, rr);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool in = lane * 2 + k < nv;
+          lp += in ? l[k] : 0.0;
+          rr[k] = in ? rr[k] : 0.0;
+        }
+        if constexpr (DX == 7) { acc[0] = fma(rr[0], 1.0, acc[0]); acc[0] = fma(rr[1], 1.0, acc[0]); }
+#pragma unroll
+        for (int k = 0; k < DX; ++k) {
+          const ga_v2d v = col(k);
+          acc[k + (8 - DX)] = fma(rr[0], v.x, acc[k + (8 - DX)]); acc[k + (8 - DX)] = fma(rr[1], v.y, acc[k + (8 - DX)]);
+        }
+      }
       ev.pos++;
       if (ev.pos >= ev.n) {        // the chunk is done: its last-streamed half
         flush(ev.ww, (ev.pos > ev.nsw ? 1 : 0) ^ (rev ? 1 : 0));
@@ -331,7 +354,9 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
     resolve_leaf(L.io, L.A, L.j, lf, qv);
     MergePrefetch mpf;
     merge_prefetch(L.A, lf, L.j, R.off_z + g * D + lane % D, mpf);
-    gal_tail_wave<D>(md, L, g, W, s_acc[w], s_red, s_info[w], hval0, hph0, zq, zph, s_lane, mpf);
+    // (lanes >= 2 D: values nobody looks at -- hval / hph feed the hyper-parameter elements' lanes, zq / zph / s_lane the D z lanes)
+    const int kl = lane < 2 * D ? lane : 0;
+    gal_tail_wave<D>(md, L, g, W, s_acc[w], s_red, s_info[w], s_keep[w][0][kl], s_keep[w][1][kl], s_keep[w][2][kl], s_keep[w][3][kl], s_keep[w][4][kl], mpf);
   } else if (lane == 0) s_info[w][0] = 0;
   __syncthreads();
 #pragma unroll

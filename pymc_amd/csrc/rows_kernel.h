@@ -110,6 +110,65 @@ __device__ __forceinline__ void logit_row(double eta, double yk, double& lp, dou
   r = yk - sgm;
 }
 
+// logit_row for the TWO rows of a lane, statement by statement side by side: per row the same operations in the same order (the
+// same bits), but a dependent fp64 operation issues only every ~24 cycles (tools/fp64_rate_lab.hip: 32 cycles of a 2.4 GHz SIMD
+// for a single chain, 5.3 with sixteen in flight) and hipcc keeps each row's Horner chains together when it is given them one
+// row after the other -- written out interleaved, a wave has two chains in flight instead of one.
+#define L2(stmt) { constexpr int k = 0; stmt; } { constexpr int k = 1; stmt; }
+__device__ __forceinline__ void logit_row2(const double (&eta)[2], const double (&yk)[2], double (&lp)[2], double (&r)[2]) {
+  double x[2], kd[2], rr[2], q[2], p[2], e[2], inv[2], u[2], ru[2], s[2], z[2], P[2], s2[2], l1p[2];
+  double t[2], ye[2], yv[2];
+  L2(x[k] = -fmin(fabs(eta[k]), 750.0))
+  L2(kd[k] = __builtin_rint(x[k] * 1.4426950408889634))
+  L2(rr[k] = fma(kd[k], -6.93147180369123816490e-01, x[k]))
+  L2(rr[k] = fma(kd[k], -1.90821492927058770002e-10, rr[k]))
+  L2(q[k] = 1.6059043836821613e-10)
+  L2(q[k] = fma(q[k], rr[k], 2.08767569878681e-09))
+  L2(q[k] = fma(q[k], rr[k], 2.505210838544172e-08))
+  L2(q[k] = fma(q[k], rr[k], 2.755731922398589e-07))
+  L2(q[k] = fma(q[k], rr[k], 2.7557319223985893e-06))
+  L2(q[k] = fma(q[k], rr[k], 2.48015873015873e-05))
+  L2(q[k] = fma(q[k], rr[k], 0.0001984126984126984))
+  L2(q[k] = fma(q[k], rr[k], 0.001388888888888889))
+  L2(q[k] = fma(q[k], rr[k], 0.008333333333333333))
+  L2(q[k] = fma(q[k], rr[k], 0.041666666666666664))
+  L2(q[k] = fma(q[k], rr[k], 0.16666666666666666))
+  L2(q[k] = fma(q[k], rr[k], 0.5))
+  L2(p[k] = fma(rr[k] * rr[k], q[k], rr[k]) + 1.0)
+  L2(e[k] = __builtin_amdgcn_ldexp(p[k], (int)kd[k]))
+  // inv = rcp_nr(1 + e), ru = rcp_nr(2 + e): seed + two Newton steps each, the four chains side by side
+  L2(t[k] = 1.0 + e[k])
+  L2(u[k] = 2.0 + e[k])
+  L2(inv[k] = __builtin_amdgcn_rcp(t[k]))
+  L2(ru[k] = __builtin_amdgcn_rcp(u[k]))
+  L2(ye[k] = fma(-t[k], inv[k], 1.0))
+  L2(yv[k] = fma(-u[k], ru[k], 1.0))
+  L2(inv[k] = fma(inv[k], ye[k], inv[k]))
+  L2(ru[k] = fma(ru[k], yv[k], ru[k]))
+  L2(ye[k] = fma(-t[k], inv[k], 1.0))
+  L2(yv[k] = fma(-u[k], ru[k], 1.0))
+  L2(inv[k] = fma(inv[k], ye[k], inv[k]))
+  L2(ru[k] = fma(ru[k], yv[k], ru[k]))
+  L2(s[k] = e[k] * ru[k])
+  L2(s[k] = fma(fma(-s[k], u[k], e[k]), ru[k], s[k]))
+  L2(z[k] = s[k] * s[k])
+  L2(P[k] = 0.08082469084735669)
+  L2(P[k] = fma(P[k], z[k], 0.04400158825434387))
+  L2(P[k] = fma(P[k], z[k], 0.06000577591428889))
+  L2(P[k] = fma(P[k], z[k], 0.06657067775440581))
+  L2(P[k] = fma(P[k], z[k], 0.07692785296456121))
+  L2(P[k] = fma(P[k], z[k], 0.09090894708663223))
+  L2(P[k] = fma(P[k], z[k], 0.11111111358900891))
+  L2(P[k] = fma(P[k], z[k], 0.1428571428355253))
+  L2(P[k] = fma(P[k], z[k], 0.20000000000007298))
+  L2(P[k] = fma(P[k], z[k], 0.3333333333333333))
+  L2(s2[k] = s[k] + s[k])
+  L2(l1p[k] = fma(s2[k] * z[k], P[k], s2[k]))
+  L2(const double sgm = eta[k] >= 0 ? inv[k] : e[k] * inv[k]; const double spl = (eta[k] > 0 ? eta[k] : 0.0) + l1p[k];
+     lp[k] = yk[k] * eta[k] - spl; r[k] = yk[k] - sgm)
+}
+#undef L2
+
 // X tile of one span: [D][SPAN] doubles, lane l holds rows RPL*l .. RPL*l+RPL-1 of every column
 template <int D, int RPL>
 __device__ __forceinline__ void rows_load(const RowsDev& R, int64_t sp, int lane, double (&x)[D][RPL], uint32_t& ybits) {

@@ -150,6 +150,13 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
   // logp and d logp / dq_i at the position seen through `qv` (this thread's coordinate is `qn`)
   auto eval_model = [&](const QView& qv, double qn, double& grad_i, double& logp) {
     double lp = 0.0, gx = 0.0, dxdq = 1.0, dj = 0.0;
+    if constexpr (PROG) {
+      if (md.n_gsf > 0) {   // gathered adjoints (model_dev.h GSlot): every element of those factors swept once, then the gathers below
+        for (int e = tid; e < md.n_gs_elems; e += NT) gsweep_element(pg, qv, e);
+        __threadfence_block();
+        __syncthreads();
+      }
+    }
     if (mine) {
       double x, lj;
       if (v.normal_prior) {
