@@ -96,7 +96,7 @@ def parse():
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="self-launched ranks are stopped after this many seconds")
     ap.add_argument("--ess-tune", type=int, default=1000, help="warmup of the separate ESS chain run when --steps/--warmup are too short for an ESS (0 disables)")
     ap.add_argument("--ess-draws", type=int, default=1000)
-    ap.add_argument("--ess-chains", type=int, default=4, help="chains of the ESS run on each GPU, one after the other (world == 1 only): min-ESS and "
+    ap.add_argument("--ess-chains", type=int, default=8, help="chains of the ESS run on each GPU, one after the other (world == 1 only): min-ESS and "
                     "R-hat over several chains instead of a one-chain estimate (0 / 1: the single chain)")
     return ap.parse_args()
 
@@ -487,8 +487,8 @@ def run_rank(args):
                 # The same run with several chains on this GPU (the reference's `pm.sample(chains=4)`, mcmc.py:1385-1430), so that
                 # min-ESS and R-hat are multi-chain estimates -- the reference's benchmark divides the ESS of ALL chains by the total
                 # sampling time (benchmarks.py:180-198).  Round 5: the chains run CONCURRENTLY as a chain group where the engine can
-                # merge their leapfrog launches (the group-aligned row pass streams X once for all chains standing at a leaf,
-                # csrc/rows_ga_multi_kernel.h; draws bitwise those of the chains alone), one after the other otherwise.
+                # merge their leapfrog launches (the group-aligned row pass streams X once for up to EIGHT chains standing at a leaf -- BASELINE
+                # configs[1]'s eight --, csrc/rows_gal_kernel.h; draws bitwise those of the chains alone), one after the other otherwise.
                 from pymc_amd.sampling import sample
 
                 t2 = time.perf_counter()
@@ -498,6 +498,19 @@ def run_rank(args):
                 res_mc["step"].close()
                 stack = res_mc["draws"]
                 ess_c, rh_c = ess_bulk_many(stack), rhat_many(stack)
+                ident = None
+                if not c3 and not glm:
+                    # the combination the likelihood identifies (see `convergence`): THIS is what has converged in such a run -- its
+                    # multi-chain ESS over the same wall time next to the minimum over the 10 000 raw coordinates, which has not
+                    v_ = {x.name: x for x in spec.vars}
+                    D_ = v_["mu"].size
+                    mu_ = stack[:, :, v_["mu"].offset : v_["mu"].offset + D_]
+                    sg_ = np.exp(stack[:, :, v_["sigma"].offset : v_["sigma"].offset + D_])
+                    zb_ = stack[:, :, v_["z"].offset : v_["z"].offset + v_["z"].size].reshape(stack.shape[0], stack.shape[1], -1, D_).mean(axis=2)
+                    bb_ = mu_ + sg_ * zb_
+                    eb_, rb_ = ess_bulk_many(bb_), rhat_many(bb_)
+                    ident = {"what": "beta_bar_d = mu_d + sigma_d * mean_g z[g, d], d = 0..7 (what the likelihood identifies)", "min_ess": float(eb_.min()),
+                             "rhat_max": float(np.nanmax(rb_)), "ess_per_sec": float(eb_.min() / res_mc["wall_time"])}
                 n_l = res_mc["lockstep_launches"]
                 lf_post = float(sum(s_["tree_size"] for c_ in range(args.ess_chains) for s_ in res_mc["stats"][c_]))
                 ess_run["multi_chain"] = {
@@ -509,7 +522,9 @@ def run_rank(args):
                     "n_rhat_gt_1.01": int((rh_c > 1.01).sum()), "ess_per_sec": float(ess_c.min() / res_mc["wall_time"]),
                     "aggregate_leapfrog_steps_per_sec_post_warmup": lf_post / float(res_mc["sampling_time"]),
                     "launches_by_chains_carried": n_l[1:] if n_l else None,
-                    "mean_chains_per_launch": (sum(c_ * n_l[c_] for c_ in range(1, 5)) / max(1, sum(n_l[1:]))) if n_l else None,
+                    "mean_chains_per_launch": (sum(c_ * n_l[c_] for c_ in range(1, len(n_l))) / max(1, sum(n_l[1:]))) if n_l else None,
+                    # a converged quantity of the same run
+                    "identified_combination": ident,
                 }
         if c3:
             workload = f"C3 mvn-{args.mvn_k}: MvNormal, full {args.mvn_k}x{args.mvn_k} covariance, n={spec.n}"
@@ -682,8 +697,10 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok, rccl=None):
     # two of them on the stream, which stretches the bracketed launch by ~2 us -- VERDICT r04 weak 4), for the committed kernel
     # sources: `profiles/launch_time.json`, written by tools/rocpd_summary.py --launch-time from the round's profile run
     lt, lt_match = None, None
-    ltj = os.path.join(ROOT, "profiles", "launch_time.json")
-    if meta["traffic_ok"] and not c3 and not glm and not args.variant and os.path.exists(ltj) and args.rows_per_group == 4000 and args.groups == 1248:
+    ltj = os.path.join(ROOT, "profiles", "launch_time_c3.json" if c3 else "launch_time_glm.json" if glm else "launch_time.json")
+    shape_ok = (args.mvn_k == 2048) if c3 else (args.glm_rows == 1_000_000 and args.glm_cols == 512) if glm else \
+        (not args.variant and args.rows_per_group == 4000 and args.groups == 1248)
+    if meta["traffic_ok"] and shape_ok and os.path.exists(ltj):
         lt = json.load(open(ltj))
         lt_match = lt.get("kernel_source_hash") == kernel_source_hash()
     leap_bytes = alg_bytes + 144 * n
@@ -755,8 +772,13 @@ def report(args, world, allv, convs, ess_runs, meta, ess_ok, rccl=None):
             "algorithmic_bytes_note": None if c3 else "8 N P: one read of the fp64 design matrix per logp + gradient (y: 8 N more, not counted)" if glm else "69 B/row = 64 (X) + 1 (y) + 4 (int32 group id); the kernel reads G+1 row pointers instead of the "
             "group ids, so 4 of the 69 are bytes it avoids -- frac_traffic prices the bytes actually moved",
             "avg_launch_ms": dom_avg_ms,
-            "avg_launch_ms_is": "HIP events around single launches inside the timed region (their marker packets stretch the bracketed launch: an upper bound)",
+            "avg_launch_ms_is": ("HIP events on the kernel's own stream inside the timed region.  Inside a tree, doublings of 16 leaves or more -- back-to-back "
+                                 "launches of this kernel -- are bracketed WHOLE (two marker packets per run, not per launch) and the time divided by the "
+                                 "launches covered; runs that contain launches drained behind a finished tree are dropped; shallower trees: single launches"),
             "launches_timed": int(allv[:, 4].sum()),   # (passes over the data covered by the bracketed launches)
+            # the figure must be consistent with the step time it is part of: (launches per step) x (average launch) <= ms_per_step
+            "launches_per_step_x_avg_launch_ms": (leap_total / (K * world)) * dom_avg_ms,
+            "consistent_with_ms_per_step": bool((leap_total / (K * world)) * dom_avg_ms <= 1e3 * T / K * 1.001),
             # the kernel trace's figure for the same launch, and the fraction it gives (consistent with ms_per_step: launches x median <= step)
             "rocprof_launch_us_median": lt["median_us"] if lt else None,
             "rocprof_launch_us_mean": lt["mean_us"] if lt else None,

@@ -88,6 +88,7 @@ static T* dev_upload(const T* src, size_t count) {
   return p;
 }
 
+#define PROF_RUN_MIN 16    // profiling: doublings of this many leaves or more are timed as ONE run of back-to-back launches
 #define SMALL_MAX_N 1024  // largest model of the single-launch path (small_kernel.h: one thread per parameter, one workgroup)
 
 // ===========================================================================
@@ -120,6 +121,9 @@ struct nuts_model {
   // profiling of the dominant kernel
   bool profile = false;
   std::vector<hipEvent_t> ev;  // pairs
+  std::vector<int32_t> ev_units;   // passes over the model data each pair covers (a single launch: 1; a bracketed run of launches: its length)
+  int run_open = 0;            // a run of back-to-back launches (the leaves of one doubling) is being bracketed
+  int64_t runs_seen = 0;
   size_t ev_used = 0;
   int64_t dom_launches = 0;
   int sample_every = 1;
@@ -185,7 +189,8 @@ struct nuts_group {
   GalConst* gal_konst_dev = nullptr;           // [GAL_MAXC]
   GalConst gal_konst_host[GAL_MAXC] = {};      // ... as last uploaded
   bool gal_konst_set[GAL_MAXC] = {};
-  int gal_occ5 = 0;                            // option NUTS_GAL_OCC5 (A/B): four chains at 96 registers (five workgroups per CU, spills in the loop) instead of 128
+  int gal_pf3 = 0;                             // option NUTS_GAL_PF3 (A/B): tiles requested three ahead instead of two (four and eight chains)
+  int gal_occ5 = 1;                            // option NUTS_GAL_OCC5 (A/B, default 1): four to six chains at the 96-register budget (five waves per SIMD: every group of the benchmark resident) instead of 128
   int rows_lds = 1;                            // option NUTS_ROWS_GROUP_LDS (read when the first member joins); 0: the round-5 kernel (<= 4 chains)
 };
 static_assert(GAM_MAXNC == MVM_MAXC && GAL_MAXC == GAM_MAXC && GAL_MAXC <= GRP_MAXC, "group sizes");
@@ -269,7 +274,11 @@ static void group_flush_rows_locked(nuts_group* g) {
   for (int a = 1; a < nc; ++a)
     for (int b = a; b > 0 && g->gpend[order[b]].slot < g->gpend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
   const int rev = base->rows_alternate ? (g->rows_flip ^= 1) : 0;
-  if (nc >= 2 && g->rows_lds) {
+  // Which merged launch: up to four chains the round-5 kernel (every wave all chains: 70 / 81 / 106 us at C2-L), five to eight the
+  // LDS-shared one (one wave per chain: 213 - 234 us; its two- to four-chain instantiations measure 80 / 100 / 119 us).  Both are
+  // bitwise the chain alone, so a chain may pass through either from one leaf to the next.  NUTS_ROWS_GROUP_LDS = 2: the LDS-shared
+  // kernel for every launch of two chains or more (tests, A/B).
+  if (g->rows_lds && (nc > GAM_MAXNC || (nc >= 2 && g->rows_lds == 2))) {
     // one wave per chain, the tiles shared through LDS (rows_gal_kernel.h).  OCC: waves per SIMD the register budget is sized for:
     // four (128 registers: the two rows of a lane side by side without a spill in the stream).
     const dim3 grid(GAL_MAXC + md.lg.G);
@@ -285,15 +294,27 @@ static void group_flush_rows_locked(nuts_group* g) {
     la.rev = rev; la.pad = 0;                                                                                        \
     hipLaunchKernelGGL((k_rows_gal<NC, DXX, OCC>), grid, dim3(WAVE * NC), 0, g->stream, md, (const GalConst*)g->gal_konst_dev, la); \
   }
+#define GAL_LAUNCH3(NC, DXX, OCC)   /* three tiles requested ahead (A/B: NUTS_GAL_PF3) */                             \
+  {                                                                                                                  \
+    GalArgs<NC> la;                                                                                                  \
+    for (int c = 0; c < NC; ++c) {                                                                                   \
+      const GaLeafArgs& L = g->gpend[order[c]];                                                                      \
+      GalLeaf& l = la.c[c];                                                                                          \
+      l.io = L.io; l.cio = L.cio; l.uniforms = L.A.uniforms; l.log_uniforms = L.A.log_uniforms;                      \
+      l.j = L.j; l.fold = L.fold; l.par = L.par; l.d = L.d; l.cj = L.cj; l.cd = L.cd; l.cseq = L.cseq; l.slot = L.slot; \
+    }                                                                                                                \
+    la.rev = rev; la.pad = 0;                                                                                        \
+    hipLaunchKernelGGL((k_rows_gal<NC, DXX, OCC, 3>), grid, dim3(WAVE * NC), 0, g->stream, md, (const GalConst*)g->gal_konst_dev, la); \
+  }
 #define GAL_BY_NC(DXX)                                                                                               \
   switch (nc) {                                                                                                      \
     case 2: GAL_LAUNCH(2, DXX, 4) break;                                                                             \
     case 3: GAL_LAUNCH(3, DXX, 4) break;                                                                             \
-    case 4: if (g->gal_occ5) GAL_LAUNCH(4, DXX, 5) else GAL_LAUNCH(4, DXX, 4) break;                                 \
-    case 5: GAL_LAUNCH(5, DXX, 4) break;                                                                             \
-    case 6: GAL_LAUNCH(6, DXX, 4) break;                                                                             \
+    case 4: if (g->gal_occ5) GAL_LAUNCH(4, DXX, 5) else if (g->gal_pf3) GAL_LAUNCH3(4, DXX, 4) else GAL_LAUNCH(4, DXX, 4) break; \
+    case 5: if (g->gal_occ5) GAL_LAUNCH(5, DXX, 5) else GAL_LAUNCH(5, DXX, 4) break;                                 \
+    case 6: if (g->gal_occ5) GAL_LAUNCH(6, DXX, 5) else GAL_LAUNCH(6, DXX, 4) break;                                 \
     case 7: GAL_LAUNCH(7, DXX, 4) break;                                                                             \
-    default: GAL_LAUNCH(8, DXX, 4) break;                                                                            \
+    default: if (g->gal_pf3) GAL_LAUNCH3(8, DXX, 4) else GAL_LAUNCH(8, DXX, 4) break;                                \
   }
     // the chains' constant parts: uploaded when a chain is first seen (and should it ever change); stream-ordered before the launch
     for (int c = 0; c < nc; ++c) {
@@ -309,6 +330,7 @@ static void group_flush_rows_locked(nuts_group* g) {
     if (md.lg.ga_dx == 7) GAL_BY_NC(7) else GAL_BY_NC(8)
 #undef GAL_BY_NC
 #undef GAL_LAUNCH
+#undef GAL_LAUNCH3
     g->launches[nc]++;
     g->npend = 0;
     g->gen.fetch_add(1, std::memory_order_release);
@@ -456,6 +478,24 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
   if (md.n_derived > 0) hipLaunchKernelGGL(k_derive, dim3(2), dim3(256), 0, m->stream, md, A, io, j);
   // (a member of a chain group shares its launches and its stream with other chains: event pairs around them would time the company)
   bool prof = m->profile && !m->group && (m->dom_launches % m->sample_every == 0) && m->ev_used + 2 <= m->ev.size();
+  // Inside a tree the leaves of a doubling are back-to-back launches of the timed kernel (control folded into them): doublings of
+  // PROF_RUN_MIN leaves or more are bracketed WHOLE -- two marker packets per run instead of two per launch (which stretch a
+  // bracketed launch by ~2 us: the per-launch figure then did not add up to the step time) -- and single launches
+  // are not sampled there.  A run some of whose launches drained behind a finished tree is dropped when the figures are read
+  // (its average is far below the others': profile_sum_ms).
+  bool run_begin = false, run_end = false;
+  if (io.mode == MODE_TREE && (1 << d) >= PROF_RUN_MIN && !md.has_glm) {
+    prof = false;
+    if (m->profile && !m->group) {
+      if (j == 0 && !m->run_open && m->ev_used + 2 <= m->ev.size() && (m->runs_seen++ % 2 == 0)) run_begin = true;
+      if (j == (1 << d) - 1 && (m->run_open || run_begin)) run_end = true;
+    }
+  }
+  if (run_begin) { hipEventRecord(m->ev[m->ev_used], m->stream); m->run_open = 1; }
+  struct RunEnd {   // (after the launch, whichever branch below submits it)
+    nuts_model* m; bool on; int units;
+    ~RunEnd() { if (on) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_units[m->ev_used / 2] = units; m->ev_used += 2; m->dom_units += units; m->run_open = 0; } }
+  } run_end_guard{m, run_end, 1 << d};
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
   if (md.has_glm) {   // GLM node (glm_kernel.h): the fused pass over X (the timed kernel), then the totals of its records
     const dim3 grid(md.glm.nwg), block(GLM_BLOCK);
@@ -1614,19 +1654,35 @@ static void profile_enable(nuts_model* m, bool on, int sample_every, size_t max_
   m->ev_used = 0;
   m->dom_launches = 0;
   m->dom_units = 0;
+  m->run_open = 0; m->runs_seen = 0;
   while (on && m->ev.size() < 2 * max_pairs) {
     hipEvent_t e;
     hipEventCreate(&e);
     m->ev.push_back(e);
   }
+  m->ev_units.assign(m->ev.size() / 2 + 1, 1);
 }
+// Sum of the bracketed times; `m->dom_units` is set to the passes they cover.  Runs (pairs that cover more than one launch) whose
+// average per launch is below 0.8 x the median run's contained launches that drained behind a finished tree: dropped.
 static double profile_sum_ms(nuts_model* m, int64_t* pairs) {
-  double tot = 0.0;
+  std::vector<float> ms(m->ev_used / 2, 0.f);
+  std::vector<double> run_avg;
   for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) tot += ms;
+    if (hipEventElapsedTime(&ms[i / 2], m->ev[i], m->ev[i + 1]) != hipSuccess) ms[i / 2] = -1.f;
+    else if (m->ev_units[i / 2] > 1) run_avg.push_back(ms[i / 2] / m->ev_units[i / 2]);
   }
-  if (pairs) *pairs = (int64_t)(m->ev_used / 2);
+  double med = 0.0;
+  if (!run_avg.empty()) { std::sort(run_avg.begin(), run_avg.end()); med = run_avg[run_avg.size() / 2]; }
+  double tot = 0.0;
+  int64_t units = 0, kept = 0;
+  for (size_t p = 0; p < ms.size(); ++p) {
+    if (ms[p] < 0.f) continue;
+    const int u = m->ev_units[p];
+    if (u > 1 && ms[p] / u < 0.8 * med) continue;
+    tot += ms[p]; units += u; kept++;
+  }
+  m->dom_units = units;
+  if (pairs) *pairs = kept;
   return tot;
 }
 
@@ -1760,6 +1816,7 @@ struct nuts_chain {
   // first leaf of the next doubling that its k_leaf_pre launch is not needed
   int next_dir = 0; bool pre_done = false; int xpre = 1;
   int tree_opts = 0;             // GA_TREE_* switches (NUTS_GA_TREE_OPTS, NUTS_GA_TREE_TICKS)
+  int tree_prof_pair = 0;        // ... which event pair that is
   int tree_prof_pending = 0;     // the last tree launch is being timed: its leaf count is added when the draw's record arrives
   int spec_max = 10, last_depth = 0;   // look-ahead over the doublings, as deep as the previous tree went (run_tree)
   int pipe_draws = 1;                  // NUTS_PIPE_DRAWS, latched at creation: post-tuning draws of a batch are queued behind each other
@@ -2056,7 +2113,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   // member's chain was created) is WIDE: up to 16 chains per launch through the matrix cores
   // (the rows group carries up to eight chains through the LDS-shared launch, rows_gal_kernel.h; NUTS_ROWS_GROUP_LDS = 0 when the first
   // member joins: the round-5 kernel and its four)
-  const int rows_lds = g->n == 0 ? (env_int("NUTS_ROWS_GROUP_LDS", 1) != 0) : g->rows_lds;
+  const int rows_lds = g->n == 0 ? env_int("NUTS_ROWS_GROUP_LDS", 1) : g->rows_lds;
   const int cap = g->n == 0 ? (is_rows ? (rows_lds ? GAL_MAXC : GAM_MAXNC) : ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC)) : g->cap;
   if (g->n >= cap) {
     g_err = cap == GRP_MAXC ? "nuts_group_add: a wide group holds at most 16 chains" : (cap == GAL_MAXC ? "nuts_group_add: a rows group holds at most 8 chains" : "nuts_group_add: a group holds at most 4 chains");
@@ -2116,7 +2173,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   std::lock_guard<std::mutex> lk(g->mu);
   g->cap = cap;
   g->rows_lds = rows_lds;
-  if (g->n == 0) g->gal_occ5 = env_int("NUTS_GAL_OCC5", 0);
+  if (g->n == 0) { g->gal_occ5 = env_int("NUTS_GAL_OCC5", 1); g->gal_pf3 = env_int("NUTS_GAL_PF3", 0); }
   for (int i = 0; i < cap; ++i)
     if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
   g->n++;
@@ -2511,7 +2568,7 @@ static int run_tree_ga(nuts_chain* c, const double* uniforms, double step_size, 
   if (prof) hipEventRecord(m->ev[m->ev_used], m->stream);
   if (m->md.lg.ga_dx == 7) hipLaunchKernelGGL((k_tree_ga<3, 7>), dim3(m->rows_grid + 1), dim3(WAVE * m->md.lg.ga_w), 0, m->stream, ga);
   else hipLaunchKernelGGL((k_tree_ga<3, 8>), dim3(m->rows_grid + 1), dim3(WAVE * m->md.lg.ga_w), 0, m->stream, ga);
-  if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); m->ev_used += 2; c->tree_prof_pending = 1; }
+  if (prof) { hipEventRecord(m->ev[m->ev_used + 1], m->stream); c->tree_prof_pair = (int)(m->ev_used / 2); m->ev_used += 2; c->tree_prof_pending = 1; }
   m->dom_launches++;
   c->tree_launches++;
   unsigned flags = 0;
@@ -2637,7 +2694,7 @@ static int finish_draw_host(nuts_chain* c, const DrawOut& o, bool adapt, bool ex
   if (c->tree_mode) {
     c->last_depth = o.depth;
     c->leapfrogs += o.n_proposals;
-    if (c->tree_prof_pending) { c->m->dom_units += o.n_proposals; c->tree_prof_pending = 0; }
+    if (c->tree_prof_pending) { c->m->dom_units += o.n_proposals; c->m->ev_units[c->tree_prof_pair] = std::max(1, (int)o.n_proposals); c->tree_prof_pending = 0; }
   }
   c->da.update(accept, adapt);
   int rc = potential_update(c, result_dev, result_dev + c->n);
@@ -3497,14 +3554,18 @@ extern "C" int nuts_gibbs_plan_doubles(nuts_pcg64* rng, int64_t n, int32_t shuff
 #define GIBBS_BLOCK 256
 #define GIBBS_MAXK 32
 // one thread per position of the plan; per-workgroup sufficient statistics in fixed order (wave sums, waves in order)
+// PARV: the 3 K parameters travel in the kernel arguments (the staged sweep: nothing to upload but the plan, which is already there)
+struct GibbsParV { double v[3 * GIBBS_MAXK]; };
+template <bool PARV>
 __global__ __launch_bounds__(GIBBS_BLOCK) void k_gibbs_sweep(int64_t n, int K, const double* __restrict__ y, int32_t* __restrict__ c,
                                                             const double* __restrict__ par /* [3][K]: log w, mu, sigma */,
                                                             const int32_t* __restrict__ order, const int32_t* __restrict__ cand_raw,
-                                                            const double* __restrict__ log_u, double* __restrict__ part /* [nblk][3 K + 2] */) {
+                                                            const double* __restrict__ log_u, double* __restrict__ part /* [nblk][3 K + 2] */,
+                                                            GibbsParV parv) {
   __shared__ double s_par[3 * GIBBS_MAXK];
   __shared__ double s_w[GIBBS_BLOCK / WAVE][3 * GIBBS_MAXK + 2];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = tid >> 6;
-  for (int i = tid; i < 3 * K; i += GIBBS_BLOCK) s_par[i] = par[i];
+  for (int i = tid; i < 3 * K; i += GIBBS_BLOCK) s_par[i] = PARV ? parv.v[i] : par[i];
   __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * GIBBS_BLOCK + tid;
   int knew = -1;
@@ -3557,10 +3618,18 @@ struct nuts_gibbs {
   static constexpr int NSLOT = 8;
   int device = 0;
   hipStream_t up_stream = nullptr;
+  // (round 6: ONE upload per staged plan and ONE download per sweep -- order | candidates | log-uniforms packed into one pinned block
+  // and one device block per slot; assignments and per-workgroup sums side by side in one device block and one pinned landing
+  // buffer; the 3 K parameters in the kernel arguments.  Round 5 issued six copies per sweep: 27 % of the GPU's time on configs[4])
+  char* s_plan[NSLOT] = {};          // device: [order int32 n | cand int32 n | log u double n]
+  char* s_plan_pinned[NSLOT] = {};
   int32_t *s_order[NSLOT] = {}, *s_cand[NSLOT] = {};
   double* s_logu[NSLOT] = {};
+  char* cpart = nullptr;             // device: [c int32 n (padded to 8 bytes) | part double nblk (3 K + 2)]
+  char* cpart_pinned = nullptr;
+  size_t c_bytes = 0;
   int32_t* c_pinned = nullptr;
-  double *part_pinned = nullptr, *par_pinned = nullptr;
+  double *part_pinned = nullptr;
 };
 
 extern "C" nuts_gibbs* nuts_gibbs_create(int64_t n, int32_t K, const double* y) {
@@ -3576,8 +3645,11 @@ extern "C" nuts_gibbs* nuts_gibbs_create(int64_t n, int32_t K, const double* y) 
   g->y = dev_upload(y, (size_t)n);
   g->par = dev_alloc<double>(3 * (size_t)K);
   g->logu = dev_alloc<double>((size_t)n);
-  g->part = dev_alloc<double>((size_t)g->nblk * (3 * K + 2));
-  g->c = dev_alloc<int32_t>((size_t)n); g->order = dev_alloc<int32_t>((size_t)n); g->cand = dev_alloc<int32_t>((size_t)n);
+  g->c_bytes = (((size_t)n * sizeof(int32_t)) + 7) & ~(size_t)7;
+  g->cpart = dev_alloc<char>(g->c_bytes + (size_t)g->nblk * (3 * K + 2) * sizeof(double));
+  g->c = (int32_t*)g->cpart;
+  g->part = g->cpart ? (double*)(g->cpart + g->c_bytes) : nullptr;
+  g->order = dev_alloc<int32_t>((size_t)n); g->cand = dev_alloc<int32_t>((size_t)n);
   if (!g->y || !g->par || !g->logu || !g->part || !g->c || !g->order || !g->cand) { g_err = "device allocation failed"; nuts_gibbs_destroy(g); return nullptr; }
   g->part_host.resize((size_t)g->nblk * (3 * K + 2));
   HIPCHK_NULL(hipGetDevice(&g->device));
@@ -3587,12 +3659,14 @@ extern "C" nuts_gibbs* nuts_gibbs_create(int64_t n, int32_t K, const double* y) 
 extern "C" void nuts_gibbs_destroy(nuts_gibbs* g) {
   if (!g) return;
   if (g->stream) hipStreamSynchronize(g->stream);
-  for (void* p : {(void*)g->y, (void*)g->par, (void*)g->logu, (void*)g->part, (void*)g->c, (void*)g->order, (void*)g->cand, (void*)g->c2, (void*)g->u2,
+  for (void* p : {(void*)g->y, (void*)g->par, (void*)g->logu, (void*)g->cpart, (void*)g->order, (void*)g->cand, (void*)g->c2, (void*)g->u2,
                   (void*)g->flags}) if (p) hipFree(p);
   if (g->up_stream) { hipStreamSynchronize(g->up_stream); hipStreamDestroy(g->up_stream); }
-  for (int i = 0; i < nuts_gibbs::NSLOT; ++i)
-    for (void* p : {(void*)g->s_order[i], (void*)g->s_cand[i], (void*)g->s_logu[i]}) if (p) hipFree(p);
-  for (void* p : {(void*)g->c_pinned, (void*)g->part_pinned, (void*)g->par_pinned}) if (p) hipHostFree(p);
+  for (int i = 0; i < nuts_gibbs::NSLOT; ++i) {
+    if (g->s_plan[i]) hipFree(g->s_plan[i]);
+    if (g->s_plan_pinned[i]) hipHostFree(g->s_plan_pinned[i]);
+  }
+  if (g->cpart_pinned) hipHostFree(g->cpart_pinned);
   if (g->stream) hipStreamDestroy(g->stream);
   delete g;
 }
@@ -3608,13 +3682,18 @@ extern "C" int nuts_gibbs_stage(nuts_gibbs* g, int32_t slot, const int32_t* orde
   HIPCHK(hipSetDevice(g->device));
   const size_t n = (size_t)g->n;
   if (!g->up_stream) HIPCHK(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
-  if (!g->s_order[slot]) {
-    g->s_order[slot] = dev_alloc<int32_t>(n); g->s_cand[slot] = dev_alloc<int32_t>(n); g->s_logu[slot] = dev_alloc<double>(n);
-    if (!g->s_order[slot] || !g->s_cand[slot] || !g->s_logu[slot]) { g_err = "device allocation failed"; return NUTS_E_HIP; }
+  const size_t bytes = 2 * n * sizeof(int32_t) + n * sizeof(double);   // (2 n int32 = 8 n bytes: the doubles behind them are aligned)
+  if (!g->s_plan[slot]) {
+    g->s_plan[slot] = dev_alloc<char>(bytes);
+    if (!g->s_plan[slot]) { g_err = "device allocation failed"; return NUTS_E_HIP; }
+    HIPCHK(hipHostMalloc((void**)&g->s_plan_pinned[slot], bytes, hipHostMallocDefault));
+    g->s_order[slot] = (int32_t*)g->s_plan[slot]; g->s_cand[slot] = g->s_order[slot] + n; g->s_logu[slot] = (double*)(g->s_plan[slot] + 2 * n * sizeof(int32_t));
   }
-  HIPCHK(hipMemcpyAsync(g->s_order[slot], order, n * sizeof(int32_t), hipMemcpyHostToDevice, g->up_stream));
-  HIPCHK(hipMemcpyAsync(g->s_cand[slot], cand_raw, n * sizeof(int32_t), hipMemcpyHostToDevice, g->up_stream));
-  HIPCHK(hipMemcpyAsync(g->s_logu[slot], log_u, n * sizeof(double), hipMemcpyHostToDevice, g->up_stream));
+  char* pin = g->s_plan_pinned[slot];
+  std::memcpy(pin, order, n * sizeof(int32_t));
+  std::memcpy(pin + n * sizeof(int32_t), cand_raw, n * sizeof(int32_t));
+  std::memcpy(pin + 2 * n * sizeof(int32_t), log_u, n * sizeof(double));
+  HIPCHK(hipMemcpyAsync(g->s_plan[slot], pin, bytes, hipMemcpyHostToDevice, g->up_stream));   // ONE upload per plan
   HIPCHK(hipStreamSynchronize(g->up_stream));
   return NUTS_OK;
 }
@@ -3632,18 +3711,16 @@ extern "C" int nuts_gibbs_sweep_staged(nuts_gibbs* g, int32_t slot, const int32_
   const size_t n = (size_t)g->n;
   const size_t npart = (size_t)g->nblk * (3 * K + 2);
   hipStream_t s = g->stream;
-  if (!g->c_pinned) {
-    HIPCHK(hipHostMalloc((void**)&g->c_pinned, n * sizeof(int32_t), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&g->part_pinned, npart * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&g->par_pinned, 3 * (size_t)GIBBS_MAXK * sizeof(double), hipHostMallocDefault));
+  if (!g->cpart_pinned) {
+    HIPCHK(hipHostMalloc((void**)&g->cpart_pinned, g->c_bytes + npart * sizeof(double), hipHostMallocDefault));
+    g->c_pinned = (int32_t*)g->cpart_pinned; g->part_pinned = (double*)(g->cpart_pinned + g->c_bytes);
   }
-  for (int k = 0; k < K; ++k) { g->par_pinned[k] = log_w[k]; g->par_pinned[K + k] = mu[k]; g->par_pinned[2 * K + k] = sigma[k]; }
-  HIPCHK(hipMemcpyAsync(g->par, g->par_pinned, 3 * (size_t)K * sizeof(double), hipMemcpyHostToDevice, s));
+  GibbsParV pv;
+  for (int k = 0; k < K; ++k) { pv.v[k] = log_w[k]; pv.v[K + k] = mu[k]; pv.v[2 * K + k] = sigma[k]; }
   if (c_in) HIPCHK(hipMemcpyAsync(g->c, c_in, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_gibbs_sweep, dim3(g->nblk), dim3(GIBBS_BLOCK), 0, s, g->n, K, g->y, g->c, g->par, g->s_order[slot], g->s_cand[slot],
-                     g->s_logu[slot], g->part);
-  HIPCHK(hipMemcpyAsync(g->c_pinned, g->c, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(g->part_pinned, g->part, npart * sizeof(double), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(k_gibbs_sweep<true>, dim3(g->nblk), dim3(GIBBS_BLOCK), 0, s, g->n, K, g->y, g->c, (const double*)nullptr, g->s_order[slot],
+                     g->s_cand[slot], g->s_logu[slot], g->part, pv);
+  HIPCHK(hipMemcpyAsync(g->cpart_pinned, g->cpart, g->c_bytes + npart * sizeof(double), hipMemcpyDeviceToHost, s));   // ONE download per sweep
   HIPCHK(hipStreamSynchronize(s));
   HIPCHK(hipGetLastError());
   if (c_out_is64) { int64_t* o = (int64_t*)c_out; for (size_t i = 0; i < n; ++i) o[i] = g->c_pinned[i]; }
@@ -3675,7 +3752,7 @@ extern "C" int nuts_gibbs_sweep(nuts_gibbs* g, int32_t* c, const double* log_w, 
   HIPCHK(hipMemcpyAsync(g->order, order, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(g->cand, cand_raw, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
   HIPCHK(hipMemcpyAsync(g->logu, log_u, n * sizeof(double), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_gibbs_sweep, dim3(g->nblk), dim3(GIBBS_BLOCK), 0, s, g->n, K, g->y, g->c, g->par, g->order, g->cand, g->logu, g->part);
+  hipLaunchKernelGGL(k_gibbs_sweep<false>, dim3(g->nblk), dim3(GIBBS_BLOCK), 0, s, g->n, K, g->y, g->c, g->par, g->order, g->cand, g->logu, g->part, GibbsParV{});
   HIPCHK(hipMemcpyAsync(c, g->c, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(g->part_host.data(), g->part, g->part_host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));

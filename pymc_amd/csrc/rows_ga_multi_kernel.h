@@ -329,7 +329,8 @@ __global__ __launch_bounds__(64 * GA_MAXW, OCC) void k_rows_ga_multi(ModelDev md
       ga_unpack(TT, xx);                                                                     \
       const uint32_t yy = TT.y;                                                              \
       const int nv = local_at(I) == l_last ? n_last : SPAN;                                  \
-      _Pragma("unroll") for (int c = 0; c < NC; ++c) ga_tile<8, 2>(xx, yy, beta[c], nv, lane, acc[c], lp[c]); \
+      /* (two chains and more: the rows of a lane side by side, logit_row2 -- the launch is bound by dependent fp64 issue, not HBM) */ \
+      _Pragma("unroll") for (int c = 0; c < NC; ++c) ga_tile<8, 2, (NC == 2)>(xx, yy, beta[c], nv, lane, acc[c], lp[c]); \
     }
     if constexpr (TWO) {
       for (int i = 0; i < n; i += 2) {

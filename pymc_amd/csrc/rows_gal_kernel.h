@@ -141,9 +141,9 @@ __device__ __forceinline__ void gal_tail_wave(const ModelDev& md, const GaLeafAr
 
 // D = 8 covariates, two rows per lane; DX stored columns (7: the intercept column is not stored).  Grid: GAL_MAXC control workgroups +
 // G group workgroups; block: NC waves, wave c = chain c of this launch.  OCC: waves per SIMD the register budget is sized for.
-template <int NC, int DX, int OCC>
+template <int NC, int DX, int OCC, int PF = GAL_PF>
 __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const GalConst* __restrict__ konst, GalArgs<NC> la) {
-  constexpr int D = 8, SPAN = WAVE * 2;
+  constexpr int D = 8, SPAN = WAVE * 2, RING = PF + 1;
   constexpr int ITEMS = DX + 1;                              // requests of a tile: DX columns of 1 KiB + the 128 y bytes (as 64 x 4 B)
   constexpr int LPT = (ITEMS + NC - 1) / NC;                 // ... per wave (the same count in every wave: the waits are immediates)
   constexpr int SLOT = DX * 1024 + 256;                      // bytes of a ring slot
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
   // the tile ring; after the stream the same bytes hold the tails' dot products and the block reduce's chunk buffer; in a control
   // workgroup they are the control work's LDS
   constexpr int TAILB = NC * NDOT * 8 + GA_MAXCHUNK * PART_STRIDE * 8;
-  constexpr int RINGB = GAL_RING * SLOT > TAILB ? GAL_RING * SLOT : TAILB;
+  constexpr int RINGB = RING * SLOT > TAILB ? RING * SLOT : TAILB;
   static_assert(sizeof(CtlLds) <= RINGB, "the control work's LDS is lent from the tile ring");
   __shared__ __attribute__((aligned(16))) char s_ring[RINGB];
   if ((int)blockIdx.x < GAL_MAXC) {   // control workgroups: chain `slot`'s folded control work in workgroup `slot`
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
   It ev = ld;                                    // the tile to evaluate next
   It lastreq = ld;                               // (past the end the last tile is requested again: the counts stay what the waits assume)
 #pragma unroll
-  for (int p = 0; p < GAL_PF; ++p) {
-    if (ld.ww < W) { lastreq = ld; request(ld, p % GAL_RING); ld.pos++; it_skip_empty(ld); }
-    else request(lastreq, p % GAL_RING);
+  for (int p = 0; p < PF; ++p) {
+    if (ld.ww < W) { lastreq = ld; request(ld, p % RING); ld.pos++; it_skip_empty(ld); }
+    else request(lastreq, p % RING);
   }
 
   // ---- prologue of this wave's chain: mu', sigma' of its leaf, z' of this group, beta_g (the first tiles are in flight) ----
@@ -296,13 +296,13 @@ __global__ __launch_bounds__(64 * NC, OCC) void k_rows_gal(ModelDev md, const Ga
       lp = 0.0;
     };
     for (int s = 0; s < T; ++s) {
-      // tile s has landed when at most the requests of the GAL_PF - 1 younger tiles are outstanding -- in every wave
-      gal_wait<LPT * (GAL_PF - 1)>();
+      // tile s has landed when at most the requests of the PF - 1 younger tiles are outstanding -- in every wave
+      gal_wait<LPT * (PF - 1)>();
       gal_barrier();
-      // (behind the barrier every wave has finished tile s - 1: its slot takes tile s + GAL_PF)
-      if (ld.ww < W) { lastreq = ld; request(ld, (s + GAL_PF) % GAL_RING); ld.pos++; it_skip_empty(ld); }
-      else request(lastreq, (s + GAL_PF) % GAL_RING);
-      const char* slot = s_ring + (s % GAL_RING) * SLOT;
+      // (behind the barrier every wave has finished tile s - 1: its slot takes tile s + PF)
+      if (ld.ww < W) { lastreq = ld; request(ld, (s + PF) % RING); ld.pos++; it_skip_empty(ld); }
+      else request(lastreq, (s + PF) % RING);
+      const char* slot = s_ring + (s % RING) * SLOT;
       const uint32_t yy = *reinterpret_cast<const uint16_t*>(slot + DX * 1024 + lane * 2);
       const int local = it_local(ev);
       // the flush between the two halves of a chunk comes BEFORE the first tile of the second-streamed half (k_rows_ga: `if (I == nsw) flush()`)

@@ -115,25 +115,37 @@ __device__ __forceinline__ void logit_row(double eta, double yk, double& lp, dou
 // for a single chain, 5.3 with sixteen in flight) and hipcc keeps each row's Horner chains together when it is given them one
 // row after the other -- written out interleaved, a wave has two chains in flight instead of one.
 #define L2(stmt) { constexpr int k = 0; stmt; } { constexpr int k = 1; stmt; }
+// q[k] = fma(q[k], r[k], C) for both rows, issued back to back; C in scalar registers.  An asm statement because hipcc's scheduler
+// undoes a source-level interleave (it puts each row's chain back together to save registers) and feeds `v_fmac` from constants it
+// first moves into vector registers -- two `v_mov_b32` per step: a third of the vector instructions of a tile.
+#define HORNER2(q, r, C) asm volatile("v_fma_f64 %0, %0, %2, %4\n\tv_fma_f64 %1, %1, %3, %4" : "+v"(q[0]), "+v"(q[1]) : "v"(r[0]), "v"(r[1]), "s"((double)(C)))
+// one Newton step of both reciprocals of both rows (four chains): e = fma(-x, y, 1); y = fma(y, e, y)
+#define NEWTON4(x0, y0, x1, y1)                                                                                               \
+  { double e0_[2], e1_[2];                                                                                                    \
+    asm volatile("v_fma_f64 %0, -%4, %8, 1.0\n\tv_fma_f64 %1, -%5, %9, 1.0\n\tv_fma_f64 %2, -%6, %10, 1.0\n\tv_fma_f64 %3, -%7, %11, 1.0" \
+                 : "=&v"(e0_[0]), "=&v"(e0_[1]), "=&v"(e1_[0]), "=&v"(e1_[1])                                                  \
+                 : "v"(x0[0]), "v"(x0[1]), "v"(x1[0]), "v"(x1[1]), "v"(y0[0]), "v"(y0[1]), "v"(y1[0]), "v"(y1[1]));            \
+    asm volatile("v_fma_f64 %0, %0, %4, %0\n\tv_fma_f64 %1, %1, %5, %1\n\tv_fma_f64 %2, %2, %6, %2\n\tv_fma_f64 %3, %3, %7, %3" \
+                 : "+v"(y0[0]), "+v"(y0[1]), "+v"(y1[0]), "+v"(y1[1]) : "v"(e0_[0]), "v"(e0_[1]), "v"(e1_[0]), "v"(e1_[1])); }
 __device__ __forceinline__ void logit_row2(const double (&eta)[2], const double (&yk)[2], double (&lp)[2], double (&r)[2]) {
   double x[2], kd[2], rr[2], q[2], p[2], e[2], inv[2], u[2], ru[2], s[2], z[2], P[2], s2[2], l1p[2];
-  double t[2], ye[2], yv[2];
+  double t[2];
   L2(x[k] = -fmin(fabs(eta[k]), 750.0))
   L2(kd[k] = __builtin_rint(x[k] * 1.4426950408889634))
   L2(rr[k] = fma(kd[k], -6.93147180369123816490e-01, x[k]))
   L2(rr[k] = fma(kd[k], -1.90821492927058770002e-10, rr[k]))
   L2(q[k] = 1.6059043836821613e-10)
-  L2(q[k] = fma(q[k], rr[k], 2.08767569878681e-09))
-  L2(q[k] = fma(q[k], rr[k], 2.505210838544172e-08))
-  L2(q[k] = fma(q[k], rr[k], 2.755731922398589e-07))
-  L2(q[k] = fma(q[k], rr[k], 2.7557319223985893e-06))
-  L2(q[k] = fma(q[k], rr[k], 2.48015873015873e-05))
-  L2(q[k] = fma(q[k], rr[k], 0.0001984126984126984))
-  L2(q[k] = fma(q[k], rr[k], 0.001388888888888889))
-  L2(q[k] = fma(q[k], rr[k], 0.008333333333333333))
-  L2(q[k] = fma(q[k], rr[k], 0.041666666666666664))
-  L2(q[k] = fma(q[k], rr[k], 0.16666666666666666))
-  L2(q[k] = fma(q[k], rr[k], 0.5))
+  HORNER2(q, rr, 2.08767569878681e-09);
+  HORNER2(q, rr, 2.505210838544172e-08);
+  HORNER2(q, rr, 2.755731922398589e-07);
+  HORNER2(q, rr, 2.7557319223985893e-06);
+  HORNER2(q, rr, 2.48015873015873e-05);
+  HORNER2(q, rr, 0.0001984126984126984);
+  HORNER2(q, rr, 0.001388888888888889);
+  HORNER2(q, rr, 0.008333333333333333);
+  HORNER2(q, rr, 0.041666666666666664);
+  HORNER2(q, rr, 0.16666666666666666);
+  HORNER2(q, rr, 0.5);
   L2(p[k] = fma(rr[k] * rr[k], q[k], rr[k]) + 1.0)
   L2(e[k] = __builtin_amdgcn_ldexp(p[k], (int)kd[k]))
   // inv = rcp_nr(1 + e), ru = rcp_nr(2 + e): seed + two Newton steps each, the four chains side by side
@@ -141,32 +153,28 @@ __device__ __forceinline__ void logit_row2(const double (&eta)[2], const double 
   L2(u[k] = 2.0 + e[k])
   L2(inv[k] = __builtin_amdgcn_rcp(t[k]))
   L2(ru[k] = __builtin_amdgcn_rcp(u[k]))
-  L2(ye[k] = fma(-t[k], inv[k], 1.0))
-  L2(yv[k] = fma(-u[k], ru[k], 1.0))
-  L2(inv[k] = fma(inv[k], ye[k], inv[k]))
-  L2(ru[k] = fma(ru[k], yv[k], ru[k]))
-  L2(ye[k] = fma(-t[k], inv[k], 1.0))
-  L2(yv[k] = fma(-u[k], ru[k], 1.0))
-  L2(inv[k] = fma(inv[k], ye[k], inv[k]))
-  L2(ru[k] = fma(ru[k], yv[k], ru[k]))
+  NEWTON4(t, inv, u, ru)
+  NEWTON4(t, inv, u, ru)
   L2(s[k] = e[k] * ru[k])
   L2(s[k] = fma(fma(-s[k], u[k], e[k]), ru[k], s[k]))
   L2(z[k] = s[k] * s[k])
   L2(P[k] = 0.08082469084735669)
-  L2(P[k] = fma(P[k], z[k], 0.04400158825434387))
-  L2(P[k] = fma(P[k], z[k], 0.06000577591428889))
-  L2(P[k] = fma(P[k], z[k], 0.06657067775440581))
-  L2(P[k] = fma(P[k], z[k], 0.07692785296456121))
-  L2(P[k] = fma(P[k], z[k], 0.09090894708663223))
-  L2(P[k] = fma(P[k], z[k], 0.11111111358900891))
-  L2(P[k] = fma(P[k], z[k], 0.1428571428355253))
-  L2(P[k] = fma(P[k], z[k], 0.20000000000007298))
-  L2(P[k] = fma(P[k], z[k], 0.3333333333333333))
+  HORNER2(P, z, 0.04400158825434387);
+  HORNER2(P, z, 0.06000577591428889);
+  HORNER2(P, z, 0.06657067775440581);
+  HORNER2(P, z, 0.07692785296456121);
+  HORNER2(P, z, 0.09090894708663223);
+  HORNER2(P, z, 0.11111111358900891);
+  HORNER2(P, z, 0.1428571428355253);
+  HORNER2(P, z, 0.20000000000007298);
+  HORNER2(P, z, 0.3333333333333333);
   L2(s2[k] = s[k] + s[k])
   L2(l1p[k] = fma(s2[k] * z[k], P[k], s2[k]))
   L2(const double sgm = eta[k] >= 0 ? inv[k] : e[k] * inv[k]; const double spl = (eta[k] > 0 ? eta[k] : 0.0) + l1p[k];
      lp[k] = yk[k] * eta[k] - spl; r[k] = yk[k] - sgm)
 }
+#undef NEWTON4
+#undef HORNER2
 #undef L2
 
 // X tile of one span: [D][SPAN] doubles, lane l holds rows RPL*l .. RPL*l+RPL-1 of every column

@@ -306,6 +306,22 @@ def test_grouped_rows_chains_carry_the_oracle_chains_integers_at_the_benchmark_s
         _same_stats(alone["stats"][c], group["stats"][c], (shape, chains, c))
 
 
+@pytest.mark.parametrize("G,rpg,chains", [(40, 300, 4), (24, 517, 3), (64, 130, 2)])
+def test_the_lds_shared_kernel_is_bitwise_for_two_to_four_chains_too(G, rpg, chains, monkeypatch):
+    """NUTS_ROWS_GROUP_LDS = 2: launches of two to four chains through `k_rows_gal` as well (by default they take the round-5 kernel,
+    which is faster there) -- every instantiation of the LDS-shared kernel is held to the chains alone."""
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    monkeypatch.setenv("NUTS_ROWS_GROUP_LDS", "2")
+    spec = models.hier_logit(G=G, D=8, rows_per_group=rpg, seed=3)
+    alone = _sample(spec, chains, False, 1, 16, 6, 17)
+    group = _sample(spec, chains, True, chains, 16, 6, 17)
+    n = group["lockstep_launches"]
+    assert n is not None and sum(n[2:]) > 0, n
+    assert np.array_equal(alone["draws"], group["draws"])
+    for c in range(chains):
+        _same_stats(alone["stats"][c], group["stats"][c], c)
+
+
 def test_the_round_5_rows_group_kernel_is_still_bitwise(monkeypatch):
     """NUTS_ROWS_GROUP_LDS = 0 (read when a group's first member joins): the merged launch of round 5 (csrc/rows_ga_multi_kernel.h: every
     wave all chains, at most four) -- kept for A/B measurements, held to the same bar."""

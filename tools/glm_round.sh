@@ -31,6 +31,7 @@ if [[ $STAGES == *p* ]]; then
     python $R/tools/rocpd_summary.py $OUT/prof_glm_$TAG/trace_results.db --pmc $OUT/pmc_glm_f_$TAG/pmc_results.db $OUT/pmc_glm_w_$TAG/pmc_results.db
   } > $OUT/profile_glm_$TAG.txt 2>&1
   python $R/tools/rocpd_summary.py --traffic $OUT/pmc_glm_f_$TAG/pmc_results.db $OUT/pmc_glm_w_$TAG/pmc_results.db $OUT/traffic_glm_$TAG.json k_glm_rows $TAG $HASH k_glm_rows_bytes_per_launch
+  python $R/tools/rocpd_summary.py --launch-time $OUT/prof_glm_$TAG/trace_results.db $OUT/launch_time_glm_$TAG.json "k_glm_rows<" $TAG $HASH "python bench.py $PA"
   rm -rf $OUT/prof_glm_$TAG $OUT/pmc_glm_f_$TAG $OUT/pmc_glm_w_$TAG
   cd $R
   head -14 $OUT/profile_glm_$TAG.txt | cut -c1-200; cat $OUT/traffic_glm_$TAG.json | head -12

@@ -39,6 +39,7 @@ if [[ $STAGES == *c* ]]; then
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_c3_$TAG -o trace -- python $R/bench.py --workload c3 --steps 100 --warmup 200 --cpu-leapfrogs 0 > $OUT/prof_c3_$TAG.log 2>&1
   { echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --workload c3 --steps 100 --warmup 200 --cpu-leapfrogs 0 (tag $TAG)"; grep -E '^\{' $OUT/prof_c3_$TAG.log | head -1
     python $R/tools/rocpd_summary.py $OUT/prof_c3_$TAG/trace_results.db; } > $OUT/profile_c3_$TAG.txt 2>&1
+  python $R/tools/rocpd_summary.py --launch-time $OUT/prof_c3_$TAG/trace_results.db $OUT/launch_time_c3_$TAG.json "k_mvn_aligned<" $TAG $HASH "python bench.py --workload c3 --steps 100 --warmup 200 --cpu-leapfrogs 0"
   rm -rf $OUT/prof_c3_$TAG; cd $R
 fi
 if [[ $STAGES == *c* || $STAGES == *x* ]]; then   # (x: only these) counter passes of the C3 launch -- what crosses the fabric into the XCDs' L2s
