@@ -182,7 +182,7 @@ struct nuts_group {
   bool konst_set[GRP_MAXC] = {};
   // kind of the members' models: 1 = one MvNormal node on the row-aligned pass (mvn_multi_kernel.h), 2 = the hierarchical-logit rows
   // on the group-aligned pass (rows_ga_multi_kernel.h); fixed by the first member
-  int kind = 0;
+  int kind = 0;                                // (3: the hierarchical-logit rows on the group-BLOCK pass, rows_gb_multi_kernel.h -- round 6)
   GaLeafArgs gpend[GAL_MAXC];
   int rows_flip = 0;
   // kind 2, launches that carry two chains or more (rows_gal_kernel.h): a member chain's constant arguments in device memory
@@ -204,7 +204,7 @@ static void group_flush_rows_locked(nuts_group* g);
 static void group_flush_locked(nuts_group* g) {
   const int nc = g->npend;
   if (!nc) return;
-  if (g->kind == 2) { group_flush_rows_locked(g); return; }
+  if (g->kind >= 2) { group_flush_rows_locked(g); return; }
   const ModelDev& md = group_base(g)->md;
   int order[GRP_MAXC];   // (by place in the group, not by arrival: the launch does not depend on who came first)
   for (int a = 0; a < GRP_MAXC; ++a) order[a] = a;
@@ -274,6 +274,38 @@ static void group_flush_rows_locked(nuts_group* g) {
   for (int a = 1; a < nc; ++a)
     for (int b = a; b > 0 && g->gpend[order[b]].slot < g->gpend[order[b - 1]].slot; --b) std::swap(order[b], order[b - 1]);
   const int rev = base->rows_alternate ? (g->rows_flip ^= 1) : 0;
+  auto gal_leaf = [&](GalLeaf& l, const GaLeafArgs& L) {
+    l.io = L.io; l.cio = L.cio; l.uniforms = L.A.uniforms; l.log_uniforms = L.A.log_uniforms;
+    l.j = L.j; l.fold = L.fold; l.par = L.par; l.d = L.d; l.cj = L.cj; l.cd = L.cd; l.cseq = L.cseq; l.slot = L.slot;
+  };
+  auto gal_upload_consts = [&]() {   // the chains' constant parts: uploaded when a chain is first seen (and should it ever change); stream-ordered before the launch
+    for (int c = 0; c < nc; ++c) {
+      const GaLeafArgs& L = g->gpend[order[c]];
+      GalConst k{};
+      k.A = L.A; k.A.uniforms = nullptr; k.A.log_uniforms = nullptr; k.Emax = L.Emax; k.st = L.st;
+      k.ga_part = L.ga_part; k.ga_bpart = L.ga_bpart; k.ga_ticket = L.ga_ticket; k.def_loc = L.def_loc; k.max_depth = L.max_depth; k.slot = L.slot;
+      if (!g->gal_konst_set[L.slot] || std::memcmp(&k, &g->gal_konst_host[L.slot], sizeof(k)) != 0) {
+        g->gal_konst_host[L.slot] = k; g->gal_konst_set[L.slot] = true;
+        hipMemcpyAsync(g->gal_konst_dev + L.slot, &g->gal_konst_host[L.slot], sizeof(k), hipMemcpyHostToDevice, g->stream);
+      }
+    }
+  };
+  if (g->kind == 3) {
+    // the group-block pass (C2-S): the chains share the LAUNCH -- one control slot + ga_nblk row workgroups per chain, each running
+    // the single-chain body on its chain's arguments (rows_gb_multi_kernel.h)
+    GbmArgs ma;
+    for (int c = 0; c < nc; ++c) gal_leaf(ma.c[c], g->gpend[order[c]]);
+    for (int c = nc; c < GAL_MAXC; ++c) ma.c[c] = ma.c[0];
+    ma.nc = nc; ma.rev = rev;
+    gal_upload_consts();
+    const dim3 grid(nc * (md.lg.ga_nblk + 1)), block(WAVE * GB_W);
+    if (md.lg.ga_dx == 7) hipLaunchKernelGGL((k_rows_gb_multi<8, 7>), grid, block, 0, g->stream, md, (const GalConst*)g->gal_konst_dev, ma);
+    else hipLaunchKernelGGL((k_rows_gb_multi<8, 8>), grid, block, 0, g->stream, md, (const GalConst*)g->gal_konst_dev, ma);
+    g->launches[nc]++;
+    g->npend = 0;
+    g->gen.fetch_add(1, std::memory_order_release);
+    return;
+  }
   // Which merged launch: up to four chains the round-5 kernel (every wave all chains: 70 / 81 / 106 us at C2-L), five to eight the
   // LDS-shared one (one wave per chain: 213 - 234 us; its two- to four-chain instantiations measure 80 / 100 / 119 us).  Both are
   // bitwise the chain alone, so a chain may pass through either from one leaf to the next.  NUTS_ROWS_GROUP_LDS = 2: the LDS-shared
@@ -285,24 +317,14 @@ static void group_flush_rows_locked(nuts_group* g) {
 #define GAL_LAUNCH(NC, DXX, OCC)                                                                                     \
   {                                                                                                                  \
     GalArgs<NC> la;                                                                                                  \
-    for (int c = 0; c < NC; ++c) {                                                                                   \
-      const GaLeafArgs& L = g->gpend[order[c]];                                                                      \
-      GalLeaf& l = la.c[c];                                                                                          \
-      l.io = L.io; l.cio = L.cio; l.uniforms = L.A.uniforms; l.log_uniforms = L.A.log_uniforms;                      \
-      l.j = L.j; l.fold = L.fold; l.par = L.par; l.d = L.d; l.cj = L.cj; l.cd = L.cd; l.cseq = L.cseq; l.slot = L.slot; \
-    }                                                                                                                \
+    for (int c = 0; c < NC; ++c) gal_leaf(la.c[c], g->gpend[order[c]]);                                              \
     la.rev = rev; la.pad = 0;                                                                                        \
     hipLaunchKernelGGL((k_rows_gal<NC, DXX, OCC>), grid, dim3(WAVE * NC), 0, g->stream, md, (const GalConst*)g->gal_konst_dev, la); \
   }
 #define GAL_LAUNCH3(NC, DXX, OCC)   /* three tiles requested ahead (A/B: NUTS_GAL_PF3) */                             \
   {                                                                                                                  \
     GalArgs<NC> la;                                                                                                  \
-    for (int c = 0; c < NC; ++c) {                                                                                   \
-      const GaLeafArgs& L = g->gpend[order[c]];                                                                      \
-      GalLeaf& l = la.c[c];                                                                                          \
-      l.io = L.io; l.cio = L.cio; l.uniforms = L.A.uniforms; l.log_uniforms = L.A.log_uniforms;                      \
-      l.j = L.j; l.fold = L.fold; l.par = L.par; l.d = L.d; l.cj = L.cj; l.cd = L.cd; l.cseq = L.cseq; l.slot = L.slot; \
-    }                                                                                                                \
+    for (int c = 0; c < NC; ++c) gal_leaf(la.c[c], g->gpend[order[c]]);                                              \
     la.rev = rev; la.pad = 0;                                                                                        \
     hipLaunchKernelGGL((k_rows_gal<NC, DXX, OCC, 3>), grid, dim3(WAVE * NC), 0, g->stream, md, (const GalConst*)g->gal_konst_dev, la); \
   }
@@ -316,17 +338,7 @@ static void group_flush_rows_locked(nuts_group* g) {
     case 7: GAL_LAUNCH(7, DXX, 4) break;                                                                             \
     default: if (g->gal_pf3) GAL_LAUNCH3(8, DXX, 4) else GAL_LAUNCH(8, DXX, 4) break;                                \
   }
-    // the chains' constant parts: uploaded when a chain is first seen (and should it ever change); stream-ordered before the launch
-    for (int c = 0; c < nc; ++c) {
-      const GaLeafArgs& L = g->gpend[order[c]];
-      GalConst k{};
-      k.A = L.A; k.A.uniforms = nullptr; k.A.log_uniforms = nullptr; k.Emax = L.Emax; k.st = L.st;
-      k.ga_part = L.ga_part; k.ga_bpart = L.ga_bpart; k.ga_ticket = L.ga_ticket; k.def_loc = L.def_loc; k.max_depth = L.max_depth; k.slot = L.slot;
-      if (!g->gal_konst_set[L.slot] || std::memcmp(&k, &g->gal_konst_host[L.slot], sizeof(k)) != 0) {
-        g->gal_konst_host[L.slot] = k; g->gal_konst_set[L.slot] = true;
-        hipMemcpyAsync(g->gal_konst_dev + L.slot, &g->gal_konst_host[L.slot], sizeof(k), hipMemcpyHostToDevice, g->stream);
-      }
-    }
+    gal_upload_consts();
     if (md.lg.ga_dx == 7) GAL_BY_NC(7) else GAL_BY_NC(8)
 #undef GAL_BY_NC
 #undef GAL_LAUNCH
@@ -531,7 +543,7 @@ static void launch_dense(nuts_model* m, const ArenaDev& A, const EvalIO& io, int
       ga.fold = GA_FOLD_CTL | (job->src_prev ? GA_FOLD_SRC : 0);
       ga.cio = job->io; ga.cj = job->j; ga.cd = job->d; ga.cseq = job->seq;
     }
-    if (m->group && m->g_active && io.mode == MODE_TREE && m->group->kind == 2) {
+    if (m->group && m->g_active && io.mode == MODE_TREE && m->group->kind >= 2) {
       // a member of a chain group inside a tree: the launch is deposited; the partner that completes the set submits ONE launch
       // that streams X once for all of them (rows_ga_multi_kernel.h)
       GaLeafArgs L;
@@ -1599,8 +1611,8 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   else if (k == "chain_group_kind") {   // what a chain group of this model's chains would merge: 0 nothing, 1 the MvNormal row-aligned pass, 2 the group-aligned row pass
     const RowsDev& lg = m->md.lg;
     const bool is_mvn = m->md.has_mvn && (m->md.mv.aligned == 4 || m->md.mv.aligned == 8 || m->md.mv.aligned == 16);
-    const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && !lg.ga_gpw && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && m->ga_variant == 42;
-    *out = is_mvn ? 1.0 : (is_rows ? 2.0 : 0.0);
+    const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && (lg.ga_gpw > 0 || m->ga_variant == 42);
+    *out = is_mvn ? 1.0 : (is_rows ? (lg.ga_gpw > 0 ? 3.0 : 2.0) : 0.0);   // (3: the group-block row pass, round 6)
   }
   // 1: chains of this model can form a WIDE group (up to 16 chains per launch through the matrix cores, mvn_mfma_kernel.h) once the
   // model is laid out 8 rows per workgroup (NUTS_MVN_ALIGNED = 8: the default from k = 1024) and the chain was created under NUTS_GROUP_WIDE = 1
@@ -2103,7 +2115,9 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   const RowsDev& lg = m->md.lg;
   const bool is_mvn = m->md.has_mvn && (mv.aligned == 4 || mv.aligned == 8);
   // the hierarchical-logit rows on the group-aligned pass, closed-form model (the benchmark's), D = 8: rows_ga_multi_kernel.h
-  const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && !lg.ga_gpw && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && m->ga_variant == 42;
+  // ... or on the group-BLOCK pass (small groups, C2-S): rows_gb_multi_kernel.h
+  const bool is_rows = m->md.has_logit && !m->md.has_mvn && lg.ga && lg.ga_naux == 0 && lg.D == 8 && m->ga_struct_ok == 1 && (lg.ga_gpw > 0 || m->ga_variant == 42);
+  const int rows_kind = lg.ga_gpw > 0 ? 3 : 2;
   if (!(is_mvn || is_rows) || c->dense || c->host_pot) {
     g_err = "nuts_group_add: chain groups advance models that are one constant-covariance MvNormal node on the row-aligned pass or the "
             "hierarchical-logit rows on the group-aligned pass (diagonal mass matrix); this chain is neither";
@@ -2114,18 +2128,18 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   // (the rows group carries up to eight chains through the LDS-shared launch, rows_gal_kernel.h; NUTS_ROWS_GROUP_LDS = 0 when the first
   // member joins: the round-5 kernel and its four)
   const int rows_lds = g->n == 0 ? env_int("NUTS_ROWS_GROUP_LDS", 1) : g->rows_lds;
-  const int cap = g->n == 0 ? (is_rows ? (rows_lds ? GAL_MAXC : GAM_MAXNC) : ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC)) : g->cap;
+  const int cap = g->n == 0 ? (is_rows ? ((rows_lds || rows_kind == 3) ? GAL_MAXC : GAM_MAXNC) : ((is_mvn && mv.aligned == 8 && mv.k % 16 == 0 && c->group_wide) ? GRP_MAXC : MVM_MAXC)) : g->cap;
   if (g->n >= cap) {
     g_err = cap == GRP_MAXC ? "nuts_group_add: a wide group holds at most 16 chains" : (cap == GAL_MAXC ? "nuts_group_add: a rows group holds at most 8 chains" : "nuts_group_add: a group holds at most 4 chains");
     return NUTS_E_ARG;
   }
-  if (g->n > 0 && g->kind != (is_rows ? 2 : 1)) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
+  if (g->n > 0 && g->kind != (is_rows ? rows_kind : 1)) { g_err = "nuts_group_add: not the same model as the group's"; return NUTS_E_ARG; }
   HIPCHK(hipStreamSynchronize(m->stream));
   if (is_rows) {
     if (nuts_model* base = group_base(g)) {
       // every launch streams the first member's copy of (X, y): the newcomer's must be the same numbers in the same layout
       const RowsDev& bl = base->md.lg;
-      if (bl.N != lg.N || bl.G != lg.G || bl.D != lg.D || bl.ga_dx != lg.ga_dx || bl.ga_w != lg.ga_w || bl.Npad != lg.Npad || bl.ga_T_uni != lg.ga_T_uni ||
+      if (bl.N != lg.N || bl.G != lg.G || bl.D != lg.D || bl.ga_dx != lg.ga_dx || bl.ga_w != lg.ga_w || bl.ga_gpw != lg.ga_gpw || bl.ga_nblk != lg.ga_nblk || bl.Npad != lg.Npad || bl.ga_T_uni != lg.ga_T_uni ||
           bl.ga_cstride_uni != lg.ga_cstride_uni || bl.ga_bsz != lg.ga_bsz || bl.ga_nrec != lg.ga_nrec || bl.sigma_tr != lg.sigma_tr ||
           bl.off_mu != lg.off_mu || bl.off_sigma != lg.off_sigma || bl.off_z != lg.off_z || base->md.n != m->md.n ||
           std::memcmp(&bl.z_np_mu, &lg.z_np_mu, 8 * sizeof(double)) != 0) {
@@ -2160,7 +2174,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
     HIPCHK(hipMemcpy(b.data() + kk, mv.mu, mv.k * sizeof(double), hipMemcpyDeviceToHost));
     if (std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) != 0) { g_err = "nuts_group_add: not the same model as the group's (precision or mean differ)"; return NUTS_E_ARG; }
   }
-  if (is_rows && rows_lds && !g->gal_konst_dev) {
+  if (is_rows && (rows_lds || rows_kind == 3) && !g->gal_konst_dev) {
     HIPCHK(hipMalloc((void**)&g->gal_konst_dev, GAL_MAXC * sizeof(GalConst)));
     HIPCHK(hipMemset(g->gal_konst_dev, 0, GAL_MAXC * sizeof(GalConst)));
   }
@@ -2177,7 +2191,7 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   for (int i = 0; i < cap; ++i)
     if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
   g->n++;
-  g->kind = is_rows ? 2 : 1;
+  g->kind = is_rows ? rows_kind : 1;
   m->group = g;
   m->stream = g->stream;
   return NUTS_OK;

@@ -1717,3 +1717,4 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, con
 #include "mvn_mfma_kernel.h"
 #include "rows_ga_multi_kernel.h"
 #include "rows_gal_kernel.h"
+#include "rows_gb_multi_kernel.h"

@@ -55,8 +55,11 @@ __device__ __forceinline__ void gb_load(const RowsDev& R, int64_t xoff, int lane
   }
 }
 
-template <int D, int DX = D>
-__global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
+// The launch's body for workgroup `b_in` of one chain's arguments `a`.  `karg`: the kernel's own argument block when `a` is it (the
+// auxiliary workgroups re-read it, rows_aux.h), nullptr for the merged launch of a chain group (k_rows_gb_multi below: `a` then lives
+// in LDS, b_in == 0 is ALWAYS the chain's control slot, and there are no auxiliary workgroups).
+template <int D, int DX>
+__device__ __forceinline__ void gb_body(const GaArgs& a, int b_in, const GaArgs* karg) {
   constexpr int SPAN = WAVE * 2;
   constexpr int64_t TS = (int64_t)DX * SPAN;
   const ModelDev& md = a.md;
@@ -64,10 +67,10 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
   const EvalIO& io = a.io;
   const RowsDev& R = md.lg;
   const int j = a.j, fold = a.fold, par = a.par, d = a.d;
-  int b = (int)blockIdx.x;
+  int b = b_in;
   if (GB_XF(GB_F_EMPTY)) return;
-  if (fold & GA_FOLD_CTL) {   // workgroup 0: control work, from the previous launch's block partials
-    if (b == 0 && GB_XF(GB_F_NOCTL)) return;
+  if ((fold & GA_FOLD_CTL) || !karg) {   // workgroup 0: control work, from the previous launch's block partials
+    if (b == 0 && (GB_XF(GB_F_NOCTL) || !(fold & GA_FOLD_CTL))) return;
     if (b == 0) { control_lean<false, 8, true>(md, A, a.cio, a.cj, a.cd, a.Emax, a.max_depth, a.st, a.cseq, lean_src(md, par ^ 1), GB_W * WAVE > VEC_THREADS ? VEC_THREADS : 0); return; }
     --b;
   }
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
     static_assert(GA_AUX_SCRATCH_DOUBLES(GB_W) <= GB_MAXGPW * PART_STRIDE, "auxiliary scratch does not fit the record buffer");
     const int aux_id = b - R.ga_nblk;
     const int npad = (R.ga_nrec + WAVE - 1) / WAVE * WAVE;
-    ga_aux<0>((const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr(), aux_id, hval0, hph0, &s_rec[0][0], GB_W, s_auxprog,
-           R.ga_bpart + (int64_t)par * PART_STRIDE * npad + (R.ga_nblk + aux_id), npad);
+    if (karg) ga_aux<0>(karg, aux_id, hval0, hph0, &s_rec[0][0], GB_W, s_auxprog,
+                        R.ga_bpart + (int64_t)par * PART_STRIDE * npad + (R.ga_nblk + aux_id), npad);
     return;
   }
   if (GB_XF(GB_F_PROLOGUE)) { if (m_lane + s_lane == 12345.678) A.Q[lf.d_o] = 0.0; return; }
@@ -282,4 +285,9 @@ __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
     }
   }
   TICK(md, tk, 7);
+}
+
+template <int D, int DX = D>
+__global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
+  gb_body<D, DX>(a, (int)blockIdx.x, (const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr());
 }

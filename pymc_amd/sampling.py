@@ -677,9 +677,14 @@ def sample(
     # ... unless its chains can advance through ONE launch per leapfrog that streams the data once for all of them (the
     # group-aligned row pass, csrc/rows_ga_multi_kernel.h: the pass is then bound by its arithmetic, not by HBM)
     rows_group = False
+    kind_ = 0
     if lockstep is not False:
         try:
-            rows_group = int(step._logp_dlogp_func.model_scalar("chain_group_kind")) == 2 and not getattr(step.potential, "_dense", False)
+            kind_ = int(step._logp_dlogp_func.model_scalar("chain_group_kind"))
+            # (kind 3, the group-block pass of small groups: its merged launch is built and bitwise, but measured no faster than the
+            # same chains as independent engines -- C2-S, eight chains: 135 k against 150 k aggregate leapfrog/s,
+            # profiles/r06i_rows_group_c2s_8_chains.json -- so it is formed on request only, `lockstep=True`)
+            rows_group = (kind_ == 2 or (kind_ == 3 and lockstep is True)) and not getattr(step.potential, "_dense", False)
         except (AttributeError, EngineError, ValueError):
             pass
     # (the rows group carries up to eight chains per launch -- BASELINE configs[1]'s eight chains share ONE read of X on one GPU)
@@ -743,7 +748,7 @@ def sample(
         # chains of a model the engine can advance in lockstep (one MvNormal node, pymc_amd/chain_group.py) share their leapfrog
         # launches: the precision matrix is read once for all chains that stand at a leaf together.  Same draws, bit for bit.
         group = None
-        if lockstep or lockstep is None:
+        if lockstep or (lockstep is None and kind_ != 3):
             from pymc_amd.chain_group import ChainGroup
 
             group = ChainGroup.try_create(steps)

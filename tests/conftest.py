@@ -18,7 +18,7 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "not_yet_run_on_device: a gpu test whose spec / code changed after the round's last device run (scheduled last)")
-    config.addinivalue_line("markers", "known_intermittent: a gpu test with an open, documented intermittent failure (DESIGN.md section 8; scheduled late)")
+    config.addinivalue_line("markers", "known_intermittent: a gpu test with an open, documented intermittent failure (none at present: DESIGN.md section 8 item 1; scheduled late)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -5,9 +5,9 @@ Zero-sum effects (`pm.ZeroSumNormal`, multivariate.py:2654-2807, under `ZeroSumT
 to zero next to an intercept.  Matrix products outside the dense nodes: a softmax regression with a [P, K] coefficient matrix, a robust
 regression whose location is `pm.math.dot(X, beta)`.
 
-HOST ONLY this round: these specs use operand kinds and -- `log1mexp` in the truncated likelihoods aside (tests/test_opcode_coverage.py) --
-opcodes the device tests exercise, but no GPU minutes were left to run THEM on the device, so they are kept out of
-`lowering_models.GENERAL` (whose members the `-m gpu` tests are parametrised over) and out of tests/golden/lowered_spec_digests.json."""
+Round 5 validated these specs on the host only; since round 6 `tests/test_more_lowering.py` has a `-m gpu` half over all of them (device
+log-density / gradient against the committed autograd goldens, NUTS integers against the oracle sampler).  They stay out of
+`lowering_models.GENERAL` and of tests/golden/lowered_spec_digests.json (their own fixture: tests/golden/more_graphs.npz)."""
 import os
 
 import numpy as np

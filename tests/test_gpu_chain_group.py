@@ -264,7 +264,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ORACLE_BAR = {"c2l": 14, "c2s": 6}
 
 
-@pytest.mark.parametrize("shape,chains", [("c2l", 4), ("c2l", 3), ("c2l", 2), ("c2s", 4), ("c2s", 2)])
+@pytest.mark.parametrize("shape,chains", [("c2l", 4), ("c2l", 3), ("c2l", 2), ("c2s", 4), ("c2s", 2), ("c2s-gb", 4), ("c2s-gb", 3)])
 def test_grouped_rows_chains_carry_the_oracle_chains_integers_at_the_benchmark_shapes(shape, chains, monkeypatch):
     """BASELINE configs[1] AT ITS OWN SHAPES through the merged launch (`k_rows_ga_multi<NC>`; C2-L is what `bench.py` times the group
     on): the first transitions of `chains` chains from the committed over-dispersed starts, sampled as a chain group, against the
@@ -274,7 +274,12 @@ def test_grouped_rows_chains_carry_the_oracle_chains_integers_at_the_benchmark_s
     group is bitwise the chains alone at this shape too."""
     from pymc_amd.sampling import sample
 
-    monkeypatch.setenv("NUTS_ROWS_GA", "2")      # (C2-S runs the group-block pass by default; the group is the group-aligned pass's)
+    # (C2-S runs the group-BLOCK pass by default -- "c2s-gb": its own merged launch, csrc/rows_gb_multi_kernel.h; "c2s": forced onto the
+    # group-aligned pass, whose merged launches are the ones C2-L uses)
+    if shape != "c2s-gb":
+        monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    gb = shape == "c2s-gb"
+    shape = shape.split("-")[0]
     gold = np.load(os.path.join(GOLDEN, f"{shape}_chains.npz"))
     G, D, rpg, _tune, _draws, gchains, seed, start_seed = (int(x) for x in gold["config"])
     assert (G, D, gchains) == (1248, 8, 4) and rpg == (4000 if shape == "c2l" else 80)
@@ -297,7 +302,7 @@ def test_grouped_rows_chains_carry_the_oracle_chains_integers_at_the_benchmark_s
         first = next((i for i in range(K) if int(got[i]["tree_size"]) != int(gold["stat_tree_size"][c][i]) or int(got[i]["depth"]) != int(gold["stat_depth"][c][i])
                       or bool(got[i]["diverging"]) != bool(gold["stat_diverging"][c][i])), K)
         firsts.append(first)
-    print(f"{shape}, {chains} chains per launch at most: integers identical to the oracle chains' for the first {firsts} of {K} transitions; launches {n[1:]}")
+    print(f"{shape}{' (group-block pass)' if gb else ''}, {chains} chains per launch at most: integers identical to the oracle chains' for the first {firsts} of {K} transitions; launches {n[1:]}")
     assert min(firsts) >= ORACLE_BAR[shape], (firsts, n)
     alone = sample(cores=1, lockstep=False, **kw)
     alone["step"].close()
@@ -335,3 +340,64 @@ def test_the_round_5_rows_group_kernel_is_still_bitwise(monkeypatch):
     assert np.array_equal(alone["draws"], group["draws"])
     for c in range(4):
         _same_stats(alone["stats"][c], group["stats"][c], c)
+
+
+@pytest.mark.parametrize("chains,lds", [(3, 2), (6, 1), (2, 1)])
+def test_rows_groups_stream_all_eight_columns_when_there_is_no_intercept_column(chains, lds, monkeypatch):
+    """A design matrix whose first column is NOT identically one: the tiles keep all eight columns (DX = 8; the benchmark's own X stores
+    seven and multiplies by the literal 1) -- the other instantiation of both merged launches, nine requests per tile in the
+    LDS-shared one."""
+    from pymc_amd.model_spec import ModelBuilder
+
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    monkeypatch.setenv("NUTS_ROWS_GROUP_LDS", str(lds))
+    X, y, gidx = models._hier_logit_data(24, 8, 400, 3)
+    X = X.copy()
+    X[:, 0] = np.random.default_rng(1).normal(size=len(X))
+    m = ModelBuilder()
+    mu = m.Normal("mu", 0.0, 1.0, shape=8)
+    sigma = m.HalfNormal("sigma", 1.0, shape=8)
+    z = m.Normal("z", 0.0, 1.0, shape=(24, 8))
+    m.HierLogitRows("y", X, y, gidx, mu, sigma, z)
+    spec = m.build()
+    alone = _sample(spec, chains, False, 1, 14, 5, 17)
+    group = _sample(spec, chains, True, chains, 14, 5, 17)
+    n = group["lockstep_launches"]
+    assert n is not None and sum(n[2:]) > 0, n
+    assert np.array_equal(alone["draws"], group["draws"])
+    for c in range(chains):
+        _same_stats(alone["stats"][c], group["stats"][c], c)
+
+
+# ---- the hierarchical-logit rows on the group-BLOCK pass (small groups, C2-S; csrc/rows_gb_multi_kernel.h) ---------------------------
+@pytest.mark.parametrize("G,rpg,chains,tune,draws", [(128, 80, 4, 20, 8), (70, 200, 8, 16, 6), (96, 33, 2, 16, 6), (200, 300, 5, 12, 5)])
+def test_grouped_chains_on_the_group_block_pass_are_bitwise_the_chains_alone(G, rpg, chains, tune, draws):
+    """Small groups (the default pass from G = 64 on when a group has few tiles): a merged launch runs the single-chain body once per
+    chain standing at a leaf -- (chains) x (control slot + row workgroups) workgroups in ONE launch, the chain's arguments assembled
+    in LDS.  Two to eight chains, a last workgroup with fewer groups (G = 70, 200: not a multiple of the groups per workgroup)."""
+    spec = models.hier_logit(G=G, D=8, rows_per_group=rpg, seed=3)
+    alone = _sample(spec, chains, False, 1, tune, draws, 17)
+    group = _sample(spec, chains, True, chains, tune, draws, 17)
+    assert alone["lockstep_launches"] is None
+    n = group["lockstep_launches"]
+    assert n is not None and sum(n[2:]) > 0, n
+    assert np.array_equal(alone["draws"], group["draws"]), (G, rpg)
+    for c in range(chains):
+        _same_stats(alone["stats"][c], group["stats"][c], (G, rpg, c))
+    print(f"group-block G = {G} x {rpg}: launches by chains carried {n[1:]}, mean {sum(c * n[c] for c in range(1, len(n))) / sum(n[1:]):.2f}")
+
+
+def test_a_small_group_model_is_grouped_on_request_only():
+    """The group-block pass's merged launch measured no faster than the same chains as independent engines (C2-S, eight chains: 135 k
+    against 150 k aggregate leapfrog/s, profiles/r06i_*): `sample()` forms that group with `lockstep=True`, not by default."""
+    from pymc_amd.sampling import sample
+
+    spec = models.hier_logit(G=128, D=8, rows_per_group=80, seed=1)
+    res = sample(draws=5, tune=10, chains=3, model=spec, random_seed=3, device=0)
+    res["step"].close()
+    assert res["lockstep_launches"] is None
+    res2 = sample(draws=5, tune=10, chains=3, model=spec, random_seed=3, device=0, cores=3, lockstep=True)
+    res2["step"].close()
+    n = res2["lockstep_launches"]
+    assert n is not None and sum(n[1:]) > 0, n
+    assert np.array_equal(res["draws"], res2["draws"])

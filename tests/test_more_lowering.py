@@ -12,7 +12,7 @@ executes those bodies and the distributions' `logp`.  Committed: the graphs (tes
 at seeded points (tests/golden/more_graphs_golden.npz).  Checked here: the lowered spec through the oracle's interpreter == those
 numbers; the same densities written independently with SciPy; a short NUTS run by the oracle's sampler.
 
-Host only (tests/more_models.py says why): no `-m gpu` twin this round."""
+The `-m gpu` half (round 6) is at the end of the file."""
 # (file renamed from the time-series-only version: the zero-sum models joined it)
 import os
 import sys

@@ -3,8 +3,8 @@
 Why this file exists: fourteen opcodes -- arctan, ceil, cos, digamma, expm1, floor, log10, log1mexp, log2, minimum, neq, not, sin,
 tanh -- occur in no spec the device had run when the round's GPU minutes were spent (the lowered reference graphs never needed them;
 tanh alone is in a hand-built device test).  The oracle's interpreter is held here to torch autograd of the same expression written
-directly in torch (host); the device test holds the engine to the oracle and is scheduled at the END of a `-m gpu` session
-(`not_yet_run_on_device`: it has not run yet, and a failure there must not hide tests that have)."""
+directly in torch (host); the device test holds the engine to the oracle (it first ran on the device in round 5's driver session and
+runs in every `-m gpu` session since: `profiles/r06f_lowering_device_tests.log`)."""
 import numpy as np
 import pytest
 
@@ -82,7 +82,6 @@ def test_the_oracles_interpreter_agrees_with_torch_autograd_on_every_opcode():
 
 
 @pytest.mark.gpu
-@pytest.mark.not_yet_run_on_device
 def test_the_device_agrees_with_the_oracle_on_every_opcode():
     from pymc_amd.value_grad import DeviceValueGradFunction
 

@@ -19,7 +19,11 @@ spec = models.hier_logit(G=1248, D=8, rows_per_group=rpg)
 out = {"rows_per_group": rpg, "chains": chains, "tune": tune, "draws": draws}
 ref = None
 only_group = len(sys.argv) > 5 and sys.argv[5] == "group"
-for mode, lockstep, cores in ((("chain_group", True, chains),) if only_group else (("one_after_the_other", False, 1), ("chain_group", True, chains))):
+with_engines = len(sys.argv) > 5 and sys.argv[5] == "engines"      # ... and the chains as independent engines from host threads (no merged launches)
+modes = (("chain_group", True, chains),) if only_group else (("one_after_the_other", False, 1), ("chain_group", True, chains))
+if with_engines:
+    modes = (("one_after_the_other", False, 1), ("independent_engines", False, chains), ("chain_group", True, chains))
+for mode, lockstep, cores in modes:
     t0 = time.perf_counter()
     res = sample(draws=draws, tune=tune, chains=chains, model=spec, init="jitter+adapt_diag", random_seed=11, device=0, cores=cores, lockstep=lockstep,
                  discard_tuned_samples=False)
