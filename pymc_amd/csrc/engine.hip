@@ -189,6 +189,7 @@ struct nuts_group {
   GalConst* gal_konst_dev = nullptr;           // [GAL_MAXC]
   GalConst gal_konst_host[GAL_MAXC] = {};      // ... as last uploaded
   bool gal_konst_set[GAL_MAXC] = {};
+  int gbm_occ = 2;                             // option NUTS_GBM_OCC (A/B): register budget of the group-block pass's merged launch
   int gal_pf3 = 0;                             // option NUTS_GAL_PF3 (A/B): tiles requested three ahead instead of two (four and eight chains)
   int gal_occ5 = 1;                            // option NUTS_GAL_OCC5 (A/B, default 1): four to six chains at the 96-register budget (five waves per SIMD: every group of the benchmark resident) instead of 128
   int rows_lds = 1;                            // option NUTS_ROWS_GROUP_LDS (read when the first member joins); 0: the round-5 kernel (<= 4 chains)
@@ -294,13 +295,25 @@ static void group_flush_rows_locked(nuts_group* g) {
     // the group-block pass (C2-S): the chains share the LAUNCH -- one control slot + ga_nblk row workgroups per chain, each running
     // the single-chain body on its chain's arguments (rows_gb_multi_kernel.h)
     GbmArgs ma;
-    for (int c = 0; c < nc; ++c) gal_leaf(ma.c[c], g->gpend[order[c]]);
-    for (int c = nc; c < GAL_MAXC; ++c) ma.c[c] = ma.c[0];
+    for (int c = 0; c < nc; ++c) {
+      const GaLeafArgs& L = g->gpend[order[c]];
+      gal_leaf(ma.c[c], L);
+      GalConst& k = ma.k[c];
+      k.A = L.A; k.A.uniforms = nullptr; k.A.log_uniforms = nullptr; k.Emax = L.Emax; k.st = L.st;
+      k.ga_part = L.ga_part; k.ga_bpart = L.ga_bpart; k.ga_ticket = L.ga_ticket; k.def_loc = L.def_loc; k.max_depth = L.max_depth; k.slot = L.slot;
+    }
+    for (int c = nc; c < GAL_MAXC; ++c) { ma.c[c] = ma.c[0]; ma.k[c] = ma.k[0]; }
     ma.nc = nc; ma.rev = rev;
-    gal_upload_consts();
     const dim3 grid(nc * (md.lg.ga_nblk + 1)), block(WAVE * GB_W);
-    if (md.lg.ga_dx == 7) hipLaunchKernelGGL((k_rows_gb_multi<8, 7>), grid, block, 0, g->stream, md, (const GalConst*)g->gal_konst_dev, ma);
-    else hipLaunchKernelGGL((k_rows_gb_multi<8, 8>), grid, block, 0, g->stream, md, (const GalConst*)g->gal_konst_dev, ma);
+    // (register budget by the rounds the grid needs: NUTS_GBM_OCC = 2 / 4 / 6 waves per SIMD, i.e. 1 / 2 / 3 workgroups per CU)
+#define GBM_LAUNCH(DXX)                                                                                              \
+    switch (g->gbm_occ) {                                                                                            \
+      default: hipLaunchKernelGGL((k_rows_gb_multi<8, DXX, 2>), grid, block, 0, g->stream, md, ma); break;           \
+      case 6: hipLaunchKernelGGL((k_rows_gb_multi<8, DXX, 6>), grid, block, 0, g->stream, md, ma); break;            \
+      case 4: hipLaunchKernelGGL((k_rows_gb_multi<8, DXX, 4>), grid, block, 0, g->stream, md, ma); break;            \
+    }
+    if (md.lg.ga_dx == 7) GBM_LAUNCH(7) else GBM_LAUNCH(8)
+#undef GBM_LAUNCH
     g->launches[nc]++;
     g->npend = 0;
     g->gen.fetch_add(1, std::memory_order_release);
@@ -456,6 +469,7 @@ static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, in
   // before the kernels whose gathers add the results up (B and C below; the dense node's seed of a derived vector is already there)
   if (md.n_gsf > 0)
     hipLaunchKernelGGL(k_gsweep, dim3(std::max(1, std::min(2048, (md.n_gs_elems + 255) / 256))), dim3(256), 0, m->stream, md, A, io, j);
+  if (md.n_glong > 0) hipLaunchKernelGGL(k_gadj_reduce, dim3(md.n_glong), dim3(256), 0, m->stream, md, A, io);
   if (md.lg.ga) return;   // group-aligned row pass: the O(n) work rides in the row pass itself (rows_ga_kernel.h)
   if (md.has_mvn && md.mv.aligned && io.lean) return;   // (the row-aligned MvNormal pass has finished the leapfrog itself)
   // small models: 8x oversubscribed launch, one XCD does the work (see k_vector); large ones use the whole chip
@@ -691,6 +705,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   // gathered adjoints (model_dev.h GSlot): the factors whose elements are swept once, ahead of the gathers that read the result
   std::vector<GSweepFactor> gsf;
   std::vector<GSlot> gslots;
+  std::vector<GLong> glong;
   int64_t adj_len = 0;
   int32_t gs_elems = 0;
   const bool gsweep_on = env_int("NUTS_GSWEEP", 1) != 0;
@@ -702,7 +717,24 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     for (const auto& gv : gathered) {
       gslots.push_back(GSlot{gv.first, gv.second, adj_len});
       for (Contrib& cb : per_var[gv.first])
-        if (cb.f == fi && cb.arg == -2 && (int)cb.p[0] == gv.second) { cb.p[1] = (double)adj_len; cb.p[2] = 1.0; }
+        if (cb.f == fi && cb.arg == -2 && (int)cb.p[0] == gv.second) {
+          cb.p[1] = (double)adj_len; cb.p[2] = 1.0; cb.p[3] = -1.0;
+          // elements of the variable that many factor elements index: their lists are totalled by a workgroup each (GLong)
+          const int vs = vars[gv.first].size;
+          const int32_t* ptr = csr.data() + cb.dist;
+          bool any = false;
+          for (int e = 0; e < vs; ++e) any = any || (ptr[e + 1] - ptr[e] >= GADJ_LONG);
+          if (any && glong.size() + (size_t)vs <= 4096) {
+            std::vector<int32_t> map(vs, -1);
+            for (int e = 0; e < vs; ++e)
+              if (ptr[e + 1] - ptr[e] >= GADJ_LONG) {
+                map[e] = (int32_t)glong.size();
+                glong.push_back(GLong{adj_len, cb.pad + ptr[e], ptr[e + 1] - ptr[e]});
+              }
+            cb.p[3] = (double)csr.size();
+            csr.insert(csr.end(), map.begin(), map.end());
+          }
+        }
       adj_len += fsize;
     }
     gs_elems += (int32_t)fsize;
@@ -993,7 +1025,14 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   md.n_gsf = (int32_t)gsf.size(); md.n_gs_elems = gs_elems;
   md.po_gsf = put(gsf.data(), gsf.size() * sizeof(GSweepFactor));
   md.po_gslot = put(gslots.data(), gslots.size() * sizeof(GSlot));
-  md.adj = nullptr;
+  md.adj = nullptr; md.adj_red = nullptr; md.glong = nullptr;
+  md.n_glong = (int32_t)glong.size(); md.glong_pad = 0;
+  if (!glong.empty()) {
+    md.glong = m->keep(dev_upload(glong.data(), glong.size()));
+    md.adj_red = m->keep(dev_alloc<double>(glong.size()));
+    if (!md.glong || !md.adj_red) { g_err = "device allocation failed (gathered adjoints)"; return false; }
+    hipMemset(md.adj_red, 0, glong.size() * sizeof(double));
+  }
   if (adj_len > 0) {
     md.adj = m->keep(dev_alloc<double>((size_t)adj_len));
     if (!md.adj) { g_err = "device allocation failed (gathered adjoints)"; return false; }
@@ -2187,7 +2226,9 @@ extern "C" int nuts_group_add(nuts_group* g, nuts_chain* c) {
   std::lock_guard<std::mutex> lk(g->mu);
   g->cap = cap;
   g->rows_lds = rows_lds;
-  if (g->n == 0) { g->gal_occ5 = env_int("NUTS_GAL_OCC5", 1); g->gal_pf3 = env_int("NUTS_GAL_PF3", 0); }
+  // (NUTS_GBM_OCC, measured at C2-S with 4 / 8 chains: 107 k / 128 k at the unbounded 175 registers, 88 k / 114 k at 128, 58 k / 66 k
+  // at 80 -- the spills cost more than the rounds they save)
+  if (g->n == 0) { g->gal_occ5 = env_int("NUTS_GAL_OCC5", 1); g->gal_pf3 = env_int("NUTS_GAL_PF3", 0); g->gbm_occ = env_int("NUTS_GBM_OCC", 2); }
   for (int i = 0; i < cap; ++i)
     if (!g->member[i]) { g->member[i] = m; m->gslot = i; break; }
   g->n++;

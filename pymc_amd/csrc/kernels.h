@@ -413,6 +413,14 @@ __global__ __launch_bounds__(256) void k_gsweep(ModelDev md, ArenaDev A, EvalIO 
   for (int e = blockIdx.x * 256 + threadIdx.x; e < md.n_gs_elems; e += gridDim.x * 256) gsweep_element(pg, qv, e);
 }
 
+// ... and the totals of the long inverse-index lists (model_dev.h GLong): one workgroup per list
+__global__ __launch_bounds__(256) void k_gadj_reduce(ModelDev md, ArenaDev A, EvalIO io) {
+  if (load_aborted(io, A)) return;
+  __shared__ double s_w[256 / WAVE];
+  const double tot = gadj_long_total(md, md.glong[blockIdx.x], s_w);
+  if (threadIdx.x == 0) md.adj_red[blockIdx.x] = tot;
+}
+
 // ---------------------------------------------------------------------------
 // B: the O(n) kernel
 // ---------------------------------------------------------------------------

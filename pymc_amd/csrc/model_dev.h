@@ -60,7 +60,13 @@ struct Contrib {  // "variable k is operand `slot` (0=a,1=b,2=c) of argument `ar
 // (the same numbers in the same order as before).
 #define MAX_GSLOTS 64       // (variable, index vector) pairs per factor served this way; a factor with more keeps the old path
 struct GSlot { int32_t var, did; int64_t adj_off; };
-struct GSweepFactor { int32_t f, slot0, n_slots, elem0; };   // slots [slot0, slot0 + n_slots) of ModelDev's slot table; elem0: first of its elements in the sweep's numbering
+struct GSweepFactor { int32_t f, slot0, n_slots, elem0; };
+// A variable element that MANY factor elements index (a regression coefficient read by every row: an inverse-index list of 10^5
+// entries) is not added up by the one thread that owns the element: a workgroup of its own totals the list first (k_gadj_reduce, a
+// phase of the single-workgroup kernel) -- thread t adds entries t, t + 256, ... in order, the threads' partials are combined in the
+// fixed order of `block_sum` -- and the owner reads one number.
+#define GADJ_LONG 512       // lists from this length on
+struct GLong { int64_t adj_off; int32_t lst_off, len; };   // slots [slot0, slot0 + n_slots) of ModelDev's slot table; elem0: first of its elements in the sweep's numbering
 
 struct FactorBT {  // broadcast (size-1 variable) operands of a factor whose size is > 1
   int32_t n, pad;
@@ -228,6 +234,9 @@ struct ModelDev {
   int32_t n_gsf, n_gs_elems;  // factors; their elements in all
   int32_t po_gsf, po_gslot;   // tables in the program blob
   double* adj;
+  int32_t n_glong, glong_pad; // long inverse-index lists (GLong): entries, in global memory next to their totals
+  const GLong* glong;
+  double* adj_red;            // [n_glong]
 };
 
 #ifdef NUTS_KTIMING
@@ -303,6 +312,7 @@ struct Prog {
   const GSweepFactor* gsf;   // gathered adjoints (see GSlot)
   const GSlot* gslot;
   double* adj;
+  const double* adj_red;
   int n_gsf;
 };
 
@@ -323,7 +333,7 @@ __device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) 
   pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
   pg.gsf = reinterpret_cast<const GSweepFactor*>(base + md.po_gsf);
   pg.gslot = reinterpret_cast<const GSlot*>(base + md.po_gslot);
-  pg.adj = md.adj; pg.n_gsf = md.n_gsf;
+  pg.adj = md.adj; pg.adj_red = md.adj_red; pg.n_gsf = md.n_gsf;
   return pg;
 }
 
@@ -886,6 +896,22 @@ __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, 
   return lp;
 }
 
+// total of one long inverse-index list (whole workgroup; `sm`: blockDim.x / 64 doubles); the result is valid in thread 0
+__device__ __forceinline__ double gadj_long_total(const ModelDev& md, const GLong& L, double* sm) {
+  const int32_t* lst = md.csr + L.lst_off;
+  const double* adj = md.adj + L.adj_off;
+  double acc = 0.0;
+  const int nt = (int)blockDim.x;
+  for (int t0 = threadIdx.x; t0 < L.len; t0 += 8 * nt) {   // (eight loads in flight per thread, added in index order)
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = adj[lst[min(t0 + u * nt, L.len - 1)]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (t0 + u * nt < L.len) ? v[u] : 0.0;
+  }
+  return block_sum<false>(acc, sm);
+}
+
 // element `e` (in the sweep's numbering) of the factors with gathered adjoints: one forward + reverse sweep, the slots' adjoints stored
 __device__ __forceinline__ void gsweep_element(const Prog& pg, const QView& qv, int e) {
   int t = 0;
@@ -949,6 +975,10 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       const int32_t* ptr = pg.csr + cb.dist;
       const int32_t* lst = pg.csr + cb.pad;
       if (cb.p[2] != 0.0) {   // the factor's elements have been swept (k_gsweep): their adjoints of this (variable, index vector) pair
+        if (cb.p[3] >= 0.0) {   // ... and some of this variable's lists are long: totalled by k_gadj_reduce (csr: per element, the entry or -1)
+          const int lg_ = (pg.csr + (int64_t)cb.p[3])[li];
+          if (lg_ >= 0) { gx += pg.adj_red[lg_]; continue; }
+        }
         const double* adj = pg.adj + (int64_t)cb.p[1];
         const int t1 = ptr[li + 1];
         for (int t = ptr[li]; t < t1; t += 8) {   // (eight loads in flight, added in index order)

@@ -55,23 +55,36 @@ __device__ __forceinline__ void gb_load(const RowsDev& R, int64_t xoff, int lane
   }
 }
 
-// The launch's body for workgroup `b_in` of one chain's arguments `a`.  `karg`: the kernel's own argument block when `a` is it (the
-// auxiliary workgroups re-read it, rows_aux.h), nullptr for the merged launch of a chain group (k_rows_gb_multi below: `a` then lives
-// in LDS, b_in == 0 is ALWAYS the chain's control slot, and there are no auxiliary workgroups).
+// The launch's body for workgroup `b_in` of one chain `a` of model `md`.  `karg`: the kernel's own argument block in a launch of the
+// chain's own (the auxiliary workgroups re-read it, rows_aux.h), nullptr for the merged launch of a chain group
+// (rows_gb_multi_kernel.h: b_in == 0 is then ALWAYS the chain's control slot, and there are no auxiliary workgroups).
+// What one chain brings to a launch (everything of GaArgs but the model); in the merged launch of a chain group the model is the
+// base member's and `ga_bpart` / `def_loc` -- fields of the MODEL in a launch of its own -- are the chain's.
+struct GbChain {
+  const ArenaDev& A; const EvalIO& io; const EvalIO& cio;
+  int j, fold, par, d, max_depth, cj, cd, cseq;
+  double Emax; HostStatus* st;
+  double* ga_bpart; double* def_loc;
+};
+
 template <int D, int DX>
-__device__ __forceinline__ void gb_body(const GaArgs& a, int b_in, const GaArgs* karg) {
+__device__ __forceinline__ void gb_body(const ModelDev& md, const GbChain& a, int b_in, const GaArgs* karg) {
   constexpr int SPAN = WAVE * 2;
   constexpr int64_t TS = (int64_t)DX * SPAN;
-  const ModelDev& md = a.md;
   const ArenaDev& A = a.A;
   const EvalIO& io = a.io;
   const RowsDev& R = md.lg;
   const int j = a.j, fold = a.fold, par = a.par, d = a.d;
+  // (lean_src(md, par) on the chain's own records: slot-major block partials [2][PART_STRIDE][npad], local parts [2][MAX_DEFERRED][4])
+  auto src_of = [&](int pp) {
+    const int npad_ = (R.ga_nrec + WAVE - 1) / WAVE * WAVE;
+    return LeanSrc{a.ga_bpart + (int64_t)pp * PART_STRIDE * npad_, 1, R.ga_nrec, a.def_loc + (int64_t)pp * 4 * MAX_DEFERRED, npad_};
+  };
   int b = b_in;
   if (GB_XF(GB_F_EMPTY)) return;
   if ((fold & GA_FOLD_CTL) || !karg) {   // workgroup 0: control work, from the previous launch's block partials
     if (b == 0 && (GB_XF(GB_F_NOCTL) || !(fold & GA_FOLD_CTL))) return;
-    if (b == 0) { control_lean<false, 8, true>(md, A, a.cio, a.cj, a.cd, a.Emax, a.max_depth, a.st, a.cseq, lean_src(md, par ^ 1), GB_W * WAVE > VEC_THREADS ? VEC_THREADS : 0); return; }
+    if (b == 0) { control_lean<false, 8, true>(md, A, a.cio, a.cj, a.cd, a.Emax, a.max_depth, a.st, a.cseq, src_of(par ^ 1), GB_W * WAVE > VEC_THREADS ? VEC_THREADS : 0); return; }
     --b;
   }
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,7 +131,7 @@ __device__ __forceinline__ void gb_body(const GaArgs& a, int b_in, const GaArgs*
   double2 hl01 = make_double2(0.0, 1.0), hl23 = make_double2(0.0, 0.0);
   double hq = 0.0, hv = 0.0;
   if (fold & GA_FOLD_SRC) {
-    const LeanSrc prev = lean_src(md, par ^ 1);
+    const LeanSrc prev = src_of(par ^ 1);
     const int slot = (h_mu ? R.def_mu : R.def_sigma) + (h_mu ? he : he - D);
     hl01 = reinterpret_cast<const double2*>(prev.def_loc)[2 * slot];
     hl23 = reinterpret_cast<const double2*>(prev.def_loc)[2 * slot + 1];
@@ -169,7 +182,7 @@ __device__ __forceinline__ void gb_body(const GaArgs& a, int b_in, const GaArgs*
     const int aux_id = b - R.ga_nblk;
     const int npad = (R.ga_nrec + WAVE - 1) / WAVE * WAVE;
     if (karg) ga_aux<0>(karg, aux_id, hval0, hph0, &s_rec[0][0], GB_W, s_auxprog,
-                        R.ga_bpart + (int64_t)par * PART_STRIDE * npad + (R.ga_nblk + aux_id), npad);
+                        a.ga_bpart + (int64_t)par * PART_STRIDE * npad + (R.ga_nblk + aux_id), npad);
     return;
   }
   if (GB_XF(GB_F_PROLOGUE)) { if (m_lane + s_lane == 12345.678) A.Q[lf.d_o] = 0.0; return; }
@@ -241,7 +254,7 @@ __device__ __forceinline__ void gb_body(const GaArgs& a, int b_in, const GaArgs*
       if (hact) {
         const int dd = is_mu ? e : e - D;
         const int slot = (is_mu ? R.def_mu : R.def_sigma) + dd;
-        double2* loc = reinterpret_cast<double2*>(md.def_loc + (int64_t)par * 4 * MAX_DEFERRED) + 2 * slot;
+        double2* loc = reinterpret_cast<double2*>(a.def_loc + (int64_t)par * 4 * MAX_DEFERRED) + 2 * slot;
         loc[0] = make_double2(gx, dxdq);
         loc[1] = make_double2(dj, hph0);
         if (leaf) A.Q[lf.d_o + (is_mu ? R.off_mu : R.off_sigma) + dd] = hval0;
@@ -271,7 +284,7 @@ __device__ __forceinline__ void gb_body(const GaArgs& a, int b_in, const GaArgs*
     const bool ll = (leaf && tree) ? s_ml[1] != 0 : false;
     const int nn = 1 + 2 * D + (leaf ? 1 + 6 * mm + (ll ? 6 : 0) : 0);
     const int npad = (R.ga_nrec + WAVE - 1) / WAVE * WAVE;            // slot-major: bp[k * npad + b] (lean_src)
-    double* bp = R.ga_bpart + (int64_t)par * PART_STRIDE * npad + b;
+    double* bp = a.ga_bpart + (int64_t)par * PART_STRIDE * npad + b;
     for (int q = tid; q < nn; q += (int)blockDim.x) {
       int k;
       if (q < 1) k = PART_LP;
@@ -289,5 +302,6 @@ __device__ __forceinline__ void gb_body(const GaArgs& a, int b_in, const GaArgs*
 
 template <int D, int DX = D>
 __global__ __launch_bounds__(64 * GB_W) void k_rows_gb(GaArgs a) {
-  gb_body<D, DX>(a, (int)blockIdx.x, (const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+  const GbChain ch{a.A, a.io, a.cio, a.j, a.fold, a.par, a.d, a.max_depth, a.cj, a.cd, a.cseq, a.Emax, a.st, a.md.lg.ga_bpart, a.md.def_loc};
+  gb_body<D, DX>(a.md, ch, (int)blockIdx.x, (const GaArgs*)__builtin_amdgcn_kernarg_segment_ptr());
 }

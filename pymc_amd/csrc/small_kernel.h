@@ -155,6 +155,11 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
         for (int e = tid; e < md.n_gs_elems; e += NT) gsweep_element(pg, qv, e);
         __threadfence_block();
         __syncthreads();
+        for (int t = 0; t < md.n_glong; ++t) {   // long inverse-index lists: the whole workgroup totals each
+          const double tot = gadj_long_total(md, md.glong[t], s_w);
+          if (tid == 0) md.adj_red[t] = tot;
+        }
+        if (md.n_glong > 0) { __threadfence_block(); __syncthreads(); }
       }
     }
     if (mine) {

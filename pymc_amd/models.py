@@ -314,3 +314,36 @@ def glm(N: int = 1_000_000, P: int = 512, family: str = "normal", batch_size: in
         eta = xb @ beta
         y[s:e] = eta + sigma * rng.normal(size=e - s) if family == "normal" else (rng.random(e - s) < 1.0 / (1.0 + np.exp(-eta)))
     return GLMSpec(X, y, family, sigma, prior_sd, batch_size)
+
+
+def softmax_regression(N: int = 100_000, P: int = 4, K: int = 3, seed: int = DATA_SEED) -> ModelSpec:
+    """Multinomial logistic regression with a [P, K] coefficient matrix, written the way the lowering writes `softmax(X @ B + a)` under a
+    Categorical likelihood (`pm.math.dot` over a short inner dimension written out, the K logits joined by a logaddexp chain:
+    pymc/math.py `softmax` / `logsumexp`, distributions/discrete.py:1173-1205): every coefficient is read by EVERY row through an index
+    vector that is constant -- (P + 1) K gathers in one N-element factor.  The shape the gathered-adjoint sweep exists for
+    (csrc/model_dev.h GSlot): one forward + reverse sweep per row instead of one per (coefficient, row)."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, P))
+    B0 = rng.normal(size=(P, K)) * 1.2
+    a0 = rng.normal(size=K) * 0.3
+    eta = X @ B0 + a0
+    pr = np.exp(eta - eta.max(axis=1, keepdims=True))
+    pr /= pr.sum(axis=1, keepdims=True)
+    y = (rng.random(N)[:, None] > np.cumsum(pr, axis=1)).sum(axis=1).clip(0, K - 1)
+    m = ModelBuilder()
+    B = m.Normal("B", 0.0, 2.0, shape=(P, K))
+    a = m.Normal("a", 0.0, 2.0, shape=(K,))
+    etas = []
+    for k in range(K):
+        e = a[np.full(N, k)]
+        for p in range(P):
+            e = e + m.as_expr(X[:, p]) * B[np.full(N, p * K + k)]
+        etas.append(e)
+    lse = etas[0]
+    for k in range(1, K):
+        lse = m.math.logaddexp(lse, etas[k])
+    picked = m.as_expr((y == 0).astype("float64")) * etas[0]
+    for k in range(1, K):
+        picked = picked + m.as_expr((y == k).astype("float64")) * etas[k]
+    m.Potential("y", picked - lse)
+    return m.build()

@@ -555,16 +555,23 @@ def sample(
     rank samples its chains and rank 0 receives the gathered draws.
 
     ``lockstep`` (chains of a rank that run concurrently, see ``cores``): None = let the engine merge the leapfrog launches of the
-    chains when it can (`pymc_amd/chain_group.py`: models that are one MvNormal node; the draws are bitwise those of independent
-    chains), False = never, True = raise if it cannot.
+    chains when it can and when that is measured to pay (`pymc_amd/chain_group.py`: models that are one MvNormal node -- up to four
+    chains; the hierarchical-logit rows on the group-aligned pass, the benchmark's model -- up to EIGHT; the draws are bitwise those
+    of independent chains), False = never, True = raise if it cannot (also forms the group on the group-block pass of small groups,
+    which None leaves as independent engines).  ONE exception to "bitwise": ``cores`` > 4 on an MvNormal model whose k is a multiple
+    of 16 forms a WIDE group whose merged launch runs on the matrix cores -- the step object is REPLACED by one built for that
+    layout, and its chains are held to the oracle (log-density 1e-10, the first transitions equal the chains alone), not to bitwise
+    equality with other values of ``cores``; ``lockstep=False`` keeps the plain engines.  (The two engine options that select the
+    wide layout are set process-wide while those steps are built: do not create other engines from other threads meanwhile.)
 
     ``cores`` (mcmc.py:690-693 `cores`: "number of chains to run in parallel"): the reference runs chains in
     worker processes on host cores (parallel.py:352-372).  Here a chain of a model on the single-launch path keeps
     ONE workgroup of the GPU busy, so the chains of a rank run concurrently from host threads, each with its own
     engine handles and stream; default min(4, chains on this rank) for such models and for models whose data pass is
-    cache-resident (latency-bound: chains sharing the GPU fill each other's gaps), 1 otherwise (a C2-L-sized chain saturates the
+    cache-resident (latency-bound: chains sharing the GPU fill each other's gaps), min(8, chains) for the benchmark's model on the
+    group-aligned pass (one chain group: X is read once for all of them), 1 otherwise (a C2-L-sized chain saturates the
     GPU by itself).  Every chain starts from the same `sampling_state` and its own generator, so the
-    result does not depend on `cores`.
+    result does not depend on `cores` (wide groups excepted, see ``lockstep``).
 
     ``mp_ctx`` (mcmc.py `mp_ctx`: "spawn" / "forkserver"): run the chains of this rank in WORKER PROCESSES instead, one per
     chain, chain c on GPU c mod (visible devices) -- the reference's `cores > 1` layout (parallel.py:352-524) and the

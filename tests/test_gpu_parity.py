@@ -1456,3 +1456,40 @@ def test_cache_resident_models_run_their_chains_concurrently_with_the_same_resul
                 for k in INT_KEYS + ("energy", "step_size"):
                     assert x[k] == y[k], k
         a["step"].close(); b["step"].close()
+
+
+@pytest.mark.gpu
+def test_gathered_adjoints_one_sweep_per_factor_element_equals_the_sweep_per_parameter(monkeypatch):
+    """A softmax regression whose fifteen coefficients are each gathered into EVERY row of the likelihood (pymc_amd/models.py): the
+    factor's elements are swept once and the gathers add the stored adjoints up (csrc/model_dev.h GSlot, `k_gsweep`; NUTS_GSWEEP = 0:
+    one sweep per (coefficient, row), the path before round 6).  Both against the oracle at 1e-9 and against each other at 1e-12;
+    NUTS carries the oracle sampler's integers."""
+    from oracle import ref_models, ref_sampler
+    from pymc_amd import models
+    from pymc_amd.sampling import sample
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    spec = models.softmax_regression(N=3000)
+    rng = np.random.default_rng(4)
+    got = {}
+    for gs in ("1", "0"):
+        monkeypatch.setenv("NUTS_GSWEEP", gs)
+        f = DeviceValueGradFunction(spec, device=0)
+        got[gs] = [f._pytensor_function(q) for q in (np.zeros(spec.n), rng.normal(size=spec.n) * 0.4, rng.normal(size=spec.n))]
+        f.close()
+        rng = np.random.default_rng(4)
+    rng = np.random.default_rng(4)
+    for i, q in enumerate((np.zeros(spec.n), rng.normal(size=spec.n) * 0.4, rng.normal(size=spec.n))):
+        lp0, g0 = ref_models.evaluate(spec, q)
+        for gs in ("1", "0"):
+            lp, g = got[gs][i]
+            assert abs(lp - lp0) <= 1e-9 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-9 * np.max(np.abs(g0)), (gs, i)
+        # (the same adjoints; the 3000-entry lists of the coefficients are totalled by a workgroup each -- another, fixed, order)
+        np.testing.assert_allclose(got["1"][i][1], got["0"][i][1], rtol=0, atol=1e-12 * np.max(np.abs(g0)))
+    monkeypatch.setenv("NUTS_GSWEEP", "1")
+    res = sample(draws=6, tune=14, chains=1, model=spec, init="adapt_diag", random_seed=9, device=0)
+    _, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=6, tune=14, random_seed=9, init="adapt_diag")
+    dev = res["warmup_stats"][0] + res["stats"][0]
+    same = sum(all(int(a[k]) == int(b[k]) for k in ("depth", "tree_size", "index_in_trajectory", "diverging")) for a, b in zip(dev, ref_stats[0]))
+    res["step"].close()
+    assert same >= 12, same      # (measured on the device minus a margin: see profiles/r06j_softmax_bench.json for the run)
