@@ -89,6 +89,7 @@ static T* dev_upload(const T* src, size_t count) {
 }
 
 #define PROF_RUN_MIN 16    // profiling: doublings of this many leaves or more are timed as ONE run of back-to-back launches
+#define SMALL_MAX_ELEMS 16384   // ... and the most factor elements it walks per gradient
 #define SMALL_MAX_N 1024  // largest model of the single-launch path (small_kernel.h: one thread per parameter, one workgroup)
 
 // ===========================================================================
@@ -135,6 +136,7 @@ struct nuts_model {
   int n_chains = 0;            // chains created on this model
   std::vector<int32_t> derived;   // NUTS_D_DERIVED factors (compile_spec)
   int64_t pool_extra = 0;         // doubles behind the spec's data pool: (values, seed) of every derived vector
+  int64_t orphan_elems = 0, factor_elems = 0;   // elements of the factors without an owning variable / of all factors (compile_spec)
   int64_t rows_xt_len = 0, rows_y_len = 0;   // group-aligned row pass: elements of the tiled X / y copies (chain groups compare them)
 
   template <typename T>
@@ -944,6 +946,9 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     }
   if ((int)deferred.size() / 2 > MAX_DEFERRED) { g_err = "too many scalar / hyper-parameter elements (MAX_DEFERRED)"; return false; }
   md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size() / 2;
+  m->orphan_elems = 0; m->factor_elems = 0;
+  for (int fi : orphans) m->orphan_elems += s->factors[fi].size;
+  for (int fi = 0; fi < nf; ++fi) m->factor_elems += s->factors[fi].size;
   md.orphans = m->keep(dev_upload(orphans.data(), orphans.size()));
   md.deferred_g = m->keep(dev_upload(deferred.data(), deferred.size()));
   md.def_loc = m->keep(dev_alloc<double>(2 * 4 * (size_t)MAX_DEFERRED));
@@ -1075,6 +1080,10 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
   m->data_refs.assign(s->data, s->data + s->n_data);
   m->ept = n <= 65536 ? 1 : (n <= 262144 ? 4 : 16);
   md.nblk = (n + VEC_THREADS * m->ept - 1) / (VEC_THREADS * m->ept);
+  // (round 6) ... and enough workgroups for the factors without an owning variable, whose elements kernel B walks grid-stride: a
+  // 100 000-row likelihood over fifteen coefficients was ONE workgroup's work (36 ms per gradient; four elements per thread now)
+  if (m->orphan_elems > 4 * VEC_THREADS * (int64_t)md.nblk)
+    md.nblk = (int)std::min<int64_t>(256, (m->orphan_elems + 4 * VEC_THREADS - 1) / (4 * VEC_THREADS));
   md.tick_j = env_int("NUTS_TICK_J", -1);
   md.ticks = m->keep(dev_alloc<long long>(64));
   hipMemset(md.ticks, 0, 64 * sizeof(long long));
@@ -1657,7 +1666,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   // model is laid out 8 rows per workgroup (NUTS_MVN_ALIGNED = 8: the default from k = 1024) and the chain was created under NUTS_GROUP_WIDE = 1
   else if (k == "chain_group_wide_ok") *out = (m->md.has_mvn && m->md.mv.aligned > 0 && m->md.mv.k % 16 == 0) ? 1.0 : 0.0;
   else if (k == "chain_group_wide_rows") *out = 8.0;   // rows per workgroup (NUTS_MVN_ALIGNED) the members' models must be laid out with
-  else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm) ? 1.0 : 0.0;
+  else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm && m->factor_elems <= SMALL_MAX_ELEMS) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
 }
@@ -2083,8 +2092,9 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->small_lds_slots = env_int("NUTS_SMALL_LDS", 1) == 0 ? -1 : env_int("NUTS_SMALL_LDS_SLOTS", 0);
   c->small_one_wave = env_int("NUTS_SMALL_ONE_WAVE", 1);
   c->group_wide = env_int("NUTS_GROUP_WIDE", 0);
+  // (... and whose factors are small too: the single workgroup walks every factor element itself -- SMALL_MAX_ELEMS, round 6)
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
-             !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
+             m->factor_elems <= SMALL_MAX_ELEMS && !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
   A.log_uniforms = A.uniforms + c->n_uni_cap;

@@ -45,14 +45,17 @@ def main():
         out[f"N={n},gsweep={gs}"] = {"ms_per_logp_grad": 1e3 * dt, "rel_err_logp": abs(lp - lp0) / abs(lp0),
                                      "rel_err_grad": float(np.max(np.abs(g - g0)) / np.max(np.abs(g0)))}
         print(f"N={n},gsweep={gs}", out[f"N={n},gsweep={gs}"], file=sys.stderr, flush=True)
+    if os.environ.get("SOFTMAX_BENCH_NO_NUTS"):     # (profiling runs: the log-density + gradient calls only)
+        print(json.dumps(out, indent=1))
+        return
     os.environ["NUTS_GSWEEP"] = "1"
     spec = models.softmax_regression(N=N)
     t0 = time.perf_counter()
-    res = sample(draws=100, tune=100, chains=1, model=spec, init="adapt_diag", random_seed=5, device=0)
+    res = sample(draws=40, tune=60, chains=1, model=spec, init="adapt_diag", random_seed=5, device=0)
     wall = time.perf_counter() - t0
     res["step"].close()
     lf = sum(int(s["tree_size"]) for s in res["stats"][0])
-    out["nuts"] = {"N": N, "wall_s_100_tune_100_draws": wall, "leapfrog_per_s_post_warmup": lf / res["sampling_time"], "mean_tree_size": lf / 100.0,
+    out["nuts"] = {"N": N, "wall_s_60_tune_40_draws": wall, "leapfrog_per_s_post_warmup": lf / res["sampling_time"], "mean_tree_size": lf / 40.0,
                    "posterior_mean_B00": float(res["draws"][0][:, 0].mean())}
     a, b = out[f"N={N_old},gsweep=0"]["ms_per_logp_grad"], out[f"N={N_old},gsweep=1"]["ms_per_logp_grad"]
     out["speedup_at_N_old"] = a / b
