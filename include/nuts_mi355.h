@@ -38,12 +38,14 @@ enum { NUTS_TR_NONE = 0, NUTS_TR_LOG = 1, NUTS_TR_LOGODDS = 2, NUTS_TR_INTERVAL 
 enum {
   NUTS_OP_CONST = 0, NUTS_OP_DATA = 1, NUTS_OP_VAR = 2,
   NUTS_OP_TMP = 3, /* the result of instruction `ref` of the factor's expression program (below); only earlier instructions */
-  NUTS_OP_GATHER = 4 /* var[idx[i]]: element idx[i] of variable `ref` for element i of the factor; `c` holds the id of the data
+  NUTS_OP_GATHER = 4, /* var[idx[i]]: element idx[i] of variable `ref` for element i of the factor; `c` holds the id of the data
                         vector with the indices (stored as doubles, one per factor element) -- varying intercepts / slopes
                         `a[group_idx]`, or a broadcast of a vector against a matrix-shaped factor.  A variable may be gathered into
                         a factor through several index vectors (and be a direct operand of it as well); per (variable, index
                         vector) the gradient of element e is the sum over the factor elements that index e, in index order (an
                         inverse index built when the model is created keeps it a deterministic gather) */
+  NUTS_OP_LIN = 5    /* eta[i]: element i of LINEAR PREDICTOR column (int)c of nuts_model_spec.lins[ref] (dense node 5 below) for
+                        element i of the factor; a predictor with one row (N == 1: a weighted sum over a long axis) broadcasts */
 };
 /* Expression programs.  An argument of a factor is `a + b * c`; where the model's expression is not of that form (a link
  * function, a Deterministic, a product of three quantities, a distribution whose density is written out op by op: whatever
@@ -155,6 +157,22 @@ enum {
   NUTS_ROWS_NO_GROUP_BLOCK = 2    /* small groups stay on the general path instead of the group-block pass (rows_gb_kernel.h) */
 };
 
+/* dense node 5 of the model spec (described there) */
+#define NUTS_LIN_MAXK 16   /* predictors (columns) that share one X */
+#define NUTS_MAX_LINS 4
+#define NUTS_LIN_MAXP 512  /* covariates of a predictor with N > 1 rows; K P <= 4096.  N == 1: any P */
+typedef struct nuts_lin {
+  int64_t N;        /* rows of X = elements of each predictor */
+  int32_t P, K;     /* columns of X; predictors sharing X (1 <= K <= NUTS_LIN_MAXK) */
+  const double *X;  /* [N][P] row-major */
+  /* predictor k: eta_k[i] = sum_p X[i][p] * coef_k[p], where coef_k[p] is
+       var[k] >= 0: the CONSTRAINED value of element off[k] + p * stride[k] of variable var[k]  (a column of a [P][K] matrix
+                    variable: off = k, stride = K; a vector: off = 0, stride = 1),
+       var[k] <  0: element off[k] + p * stride[k] of the NUTS_D_DERIVED factor -(var[k] + 1) (coefficients that are an expression
+                    of the variables: `dot(X, mu + sigma * z)`). */
+  int32_t var[NUTS_LIN_MAXK], off[NUTS_LIN_MAXK], stride[NUTS_LIN_MAXK];
+} nuts_lin;
+
 typedef struct {
   int32_t n_vars, n_factors, n_data, pad;
   const nuts_var *vars;
@@ -227,6 +245,17 @@ typedef struct {
   double glm_sigma_const;
   const double *glm_X; /* [N][P] row-major */
   const double *glm_y; /* [N] */
+  /* dense node 5: LINEAR PREDICTORS inside any factor argument -- `pm.math.dot(X, beta)` (pymc/math.py:56) with X constant data,
+     wherever the model uses it: eta = X @ beta as the location of a StudentT, the log-mean of a NegativeBinomial, K columns
+     eta_k = X @ B[:, k] under a softmax (`pm.Categorical(p=softmax(X @ B))`, discrete.py:1173-1205), and -- X with ONE row --
+     reductions over a long axis (`pt.sum(x)`, `x.mean()`: X = ones / N).  What `pytensor.grad` does with a `Dot` node inside
+     ValueGradFunction (model/core.py:213-267), cut in three: a mat-vec kernel writes the predictors ahead of the element-wise
+     work, the factors read them through NUTS_OP_LIN operands and the one sweep per factor element (the gathered-adjoint sweep)
+     leaves d logp / d eta, a transposed mat-vec kernel carries that to the coefficients.  X is read twice per evaluation
+     (16 N P bytes); the three likelihood families of node 4 keep their fused single pass.
+     n_lins == 0 disables.  Not combined with nodes 1, 3, 4. */
+  int32_t n_lins, pad3;
+  const nuts_lin *lins;
 } nuts_model_spec;
 enum { NUTS_GLM_NORMAL = 0, NUTS_GLM_BERNOULLI = 1, NUTS_GLM_POISSON = 2 };
 #define NUTS_GLM_MAXP 512

@@ -310,7 +310,7 @@ def _log_diff_normal_cdf(x, y):
     return math.log(0.5) + np.where(y > 0, r1, np.where(x < 0, r2, r3))
 
 
-OP_TMP, OP_GATHER = 3, 4
+OP_TMP, OP_GATHER, OP_LIN = 3, 4, 5
 (E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC,
  E_GT, E_GE, E_LT, E_LE, E_EQ, E_NEQ, E_AND, E_OR, E_NOT, E_SWITCH, E_GAMMALN, E_ERF, E_ERFC, E_ERFCX, E_LOG1MEXP, E_EXPM1, E_SIGN,
  E_MAXIMUM, E_MINIMUM, E_POW, E_FLOOR, E_CEIL, E_SIN, E_COS, E_ARCTAN, E_LOGADDEXP, E_CLIP, E_CHECK, E_LOG2, E_LOG10, E_DIGAMMA) = range(47)
@@ -419,9 +419,23 @@ def _instr_value(op, k, vx, vy, vz=None):
     raise ValueError(op)
 
 
-def _operand(op, spec, x, tmp=None):
+def _lin_coef(spec, L, k, x, derived=None):
+    """Coefficients of column k of linear predictor L (pymc_amd/model_spec.py LinPredictors): elements of a variable's constrained
+    value, or of a derived vector."""
+    var, off, stride = L.cols[k]
+    idx = off + stride * np.arange(L.X.shape[1])
+    if var >= 0:
+        return x[spec.vars[var].offset + idx]
+    return np.asarray(derived[-(var + 1)], dtype="d")[idx]
+
+
+def _operand(op, spec, x, tmp=None, derived=None):
     if op.kind == OP_TMP:
         return tmp[op.ref]
+    if op.kind == OP_LIN:      # eta = X @ coef (`pm.math.dot`, pymc/math.py:56); a one-row predictor broadcasts
+        L = spec.lins[op.ref]
+        eta = L.X @ _lin_coef(spec, L, int(op.c), x, derived)
+        return eta if eta.size > 1 else eta.reshape(())
     if op.kind == OP_GATHER:   # var[idx[i]] (include/nuts_mi355.h NUTS_OP_GATHER)
         v = spec.vars[op.ref]
         return x[v.offset + spec.data[int(op.c)].astype(np.int64)]
@@ -435,10 +449,25 @@ def _operand(op, spec, x, tmp=None):
     return s if v.size > 1 else s.reshape(())
 
 
-def _push(op, spec, gx, g, adj=None):
+def _push(op, spec, gx, g, adj=None, fsize=None, seeds=None):
     """Accumulate d logp / d operand into the constrained-space gradient (or, for a program result, into its adjoint)."""
     if op.kind == OP_TMP:
         adj[op.ref] = adj[op.ref] + g
+        return
+    if op.kind == OP_LIN:      # d logp / d coef = X^T (d logp / d eta); the adjoint of a one-row predictor is summed over the factor
+        L = spec.lins[op.ref]
+        N = L.X.shape[0]
+        ge = np.broadcast_to(np.asarray(g, dtype="d"), (fsize,))
+        ge = ge if N > 1 else np.array([ge.sum()])
+        gc = L.X.T @ ge
+        var, off, stride = L.cols[int(op.c)]
+        idx = off + stride * np.arange(L.X.shape[1])
+        if var >= 0:
+            np.add.at(gx, spec.vars[var].offset + idx, gc)
+        else:
+            fi = -(var + 1)
+            sd = seeds.setdefault(fi, np.zeros(spec.factors[fi].size))
+            np.add.at(sd, idx, gc)
         return
     if op.kind == OP_GATHER:
         v = spec.vars[op.ref]
@@ -454,15 +483,17 @@ def _push(op, spec, gx, g, adj=None):
         gx[v.offset : v.offset + v.size] += np.broadcast_to(g, (v.size,))
 
 
-def _forward(spec, f, x):
+def _forward(spec, f, x, derived=None):
     """Forward sweep of factor `f` at the constrained values x: (argument arrays, (term, b, c) triples, instruction values,
     local partials, whether a NUTS_E_CHECK failed)."""
     prog = getattr(f, "prog", ())
     tmp, loc = [], []
     dead = False
+    _op = _operand
+    _operand_ = lambda o, sp, xx, tt=None: _op(o, sp, xx, tt, derived)   # noqa: E731
     for ins in prog:
-        vx, vy = _operand(ins.x, spec, x, tmp), _operand(ins.y, spec, x, tmp)
-        vz = _operand(ins.z, spec, x, tmp) if getattr(ins, "z", None) is not None else None
+        vx, vy = _operand_(ins.x, spec, x, tmp), _operand_(ins.y, spec, x, tmp)
+        vz = _operand_(ins.z, spec, x, tmp) if getattr(ins, "z", None) is not None else None
         v, dx_, dy_, dz_ = _instr_value(ins.op, ins.k, np.asarray(vx, dtype="d"), np.asarray(vy, dtype="d"), None if vz is None else np.asarray(vz, dtype="d"))
         if ins.op == E_CHECK and not np.all(np.asarray(vy) != 0):
             dead = True
@@ -470,7 +501,7 @@ def _forward(spec, f, x):
         loc.append((dx_, dy_, dz_))
     args, ops = [], []
     for t in f.args:
-        a, b, c = (_operand(o, spec, x, tmp) for o in (t.a, t.b, t.c))
+        a, b, c = (_operand_(o, spec, x, tmp) for o in (t.a, t.b, t.c))
         args.append(np.broadcast_to(a + b * c, (f.size,)))
         ops.append((t, b, c))
     return args, ops, tmp, loc, dead
@@ -507,7 +538,7 @@ def evaluate(spec, q, rows_fn=None):
         def one_factor(fi, f):
             nonlocal logp
             prog = getattr(f, "prog", ())
-            args, ops, tmp, loc, dead = _forward(spec, f, x)
+            args, ops, tmp, loc, dead = _forward(spec, f, x, derived)
             if f.dist == D_DERIVED:
                 lp, partials = np.zeros(f.size), [np.asarray(seeds.get(fi, np.zeros(f.size)), dtype="d")]
             else:
@@ -516,10 +547,12 @@ def evaluate(spec, q, rows_fn=None):
                 lp, partials = np.full(np.shape(lp), -np.inf), [np.zeros_like(np.asarray(g, dtype="d")) for g in partials]
             logp += float(np.sum(lp))
             adj = [0.0] * len(prog)
+            _p = _push
+            _push_ = lambda o, sp, gx_, g_, adj_=None: _p(o, sp, gx_, g_, adj_, f.size, seeds)   # noqa: E731
             for (t, b, c), g in zip(ops, partials):
-                _push(t.a, spec, gx, g, adj)
-                _push(t.b, spec, gx, g * c, adj)
-                _push(t.c, spec, gx, g * b, adj)
+                _push_(t.a, spec, gx, g, adj)
+                _push_(t.b, spec, gx, g * c, adj)
+                _push_(t.c, spec, gx, g * b, adj)
             for i in range(len(prog) - 1, -1, -1):      # reverse sweep through the program
                 ins, (dx_, dy_, dz_) = prog[i], loc[i]
                 a_i = np.asarray(adj[i], dtype="d")
@@ -528,11 +561,11 @@ def evaluate(spec, q, rows_fn=None):
                 # an adjoint that is exactly zero is not propagated (the unselected branch of a switch: no 0 * inf)
                 nz = lambda d_: a_i * d_ if np.all(a_i != 0.0) else np.where(a_i != 0.0, a_i * np.where(a_i != 0.0, d_, 0.0), 0.0)   # noqa: E731
                 if dx_ is not None:
-                    _push(ins.x, spec, gx, nz(dx_), adj)
+                    _push_(ins.x, spec, gx, nz(dx_), adj)
                 if dy_ is not None:
-                    _push(ins.y, spec, gx, nz(dy_), adj)
+                    _push_(ins.y, spec, gx, nz(dy_), adj)
                 if dz_ is not None:
-                    _push(getattr(ins, "z", None), spec, gx, nz(dz_), adj)
+                    _push_(getattr(ins, "z", None), spec, gx, nz(dz_), adj)
 
         for fi, f in enumerate(spec.factors):
             if f.dist != D_DERIVED:

@@ -63,6 +63,11 @@ class DataRef(C.Structure):
     _fields_ = [("offset", C.c_int64), ("size", C.c_int64)]
 
 
+class Lin(C.Structure):     # nuts_lin
+    _fields_ = [("N", C.c_int64), ("P", C.c_int32), ("K", C.c_int32), ("X", C.POINTER(C.c_double)),
+                ("var", C.c_int32 * 16), ("off", C.c_int32 * 16), ("stride", C.c_int32 * 16)]
+
+
 class ModelSpecC(C.Structure):
     _fields_ = [
         ("n_vars", C.c_int32),
@@ -114,6 +119,9 @@ class ModelSpecC(C.Structure):
         ("glm_sigma_const", C.c_double),
         ("glm_X", C.POINTER(C.c_double)),
         ("glm_y", C.POINTER(C.c_double)),
+        ("n_lins", C.c_int32),
+        ("pad3", C.c_int32),
+        ("lins", C.POINTER(Lin)),
     ]
 
 

@@ -138,6 +138,11 @@ struct nuts_model {
   int64_t pool_extra = 0;         // doubles behind the spec's data pool: (values, seed) of every derived vector
   int64_t orphan_elems = 0, factor_elems = 0;   // elements of the factors without an owning variable / of all factors (compile_spec)
   int64_t rows_xt_len = 0, rows_y_len = 0;   // group-aligned row pass: elements of the tiled X / y copies (chain groups compare them)
+  // linear predictors (dense node 5, lin_kernel.h): per (predictor, column) the factors that read it = (offset of their adjoints in
+  // ModelDev.adj, factor size), collected by compile_spec; the device tables are built by build_lins once the data pool exists
+  struct LinUse { int64_t adj_off; int32_t size; };
+  std::vector<std::vector<std::vector<LinUse>>> lin_uses;
+  std::vector<LinDev> lins_host;
 
   template <typename T>
   T* keep(T* p) {
@@ -467,11 +472,39 @@ static void launch_control_lean(nuts_model* m, const ArenaDev& A, const EvalIO& 
 
 static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, int j, int d) {
   const ModelDev& md = m->md;
+  // linear predictors (lin_kernel.h): eta = X coef at this leaf's position, before the factors that read them are swept
+  if (md.n_lins > 0) {
+    if (md.n_derived > 0) hipLaunchKernelGGL(k_derive, dim3(2), dim3(256), 0, m->stream, md, A, io, j);   // (coefficients that are a derived vector)
+    for (int l = 0; l < md.n_lins; ++l) {
+      const LinDev& L = m->lins_host[l];
+      if (L.N == 1) { hipLaunchKernelGGL(k_lin_fwd1, dim3(L.K), dim3(1024), 0, m->stream, md, A, io, j, l); continue; }
+      const dim3 grid((unsigned)std::min<int64_t>(4096, (L.N + 255) / 256));
+      const size_t lds = (size_t)L.K * L.P * sizeof(double);
+#define LIN_FWD(KT) hipLaunchKernelGGL(k_lin_fwd<KT>, grid, dim3(256), lds, m->stream, md, A, io, j, l)
+      if (L.K == 1) LIN_FWD(1); else if (L.K == 2) LIN_FWD(2); else if (L.K <= 4) LIN_FWD(4); else if (L.K <= 8) LIN_FWD(8); else LIN_FWD(16);
+#undef LIN_FWD
+    }
+  }
   // gathered adjoints (model_dev.h GSlot): every element of the factors that read variables through index vectors is swept once,
   // before the kernels whose gathers add the results up (B and C below; the dense node's seed of a derived vector is already there)
   if (md.n_gsf > 0)
-    hipLaunchKernelGGL(k_gsweep, dim3(std::max(1, std::min(2048, (md.n_gs_elems + 255) / 256))), dim3(256), 0, m->stream, md, A, io, j);
+    if (md.gs_lds_rows > 0)
+      hipLaunchKernelGGL(k_gsweep_lds, dim3(md.n_gs_blocks), dim3(GSL_THREADS), (size_t)md.gs_lds_bytes, m->stream, md, A, io, j);
+    else
+      hipLaunchKernelGGL(k_gsweep, dim3(md.n_gs_blocks), dim3(256), 0, m->stream, md, A, io, j);
   if (md.n_glong > 0) hipLaunchKernelGGL(k_gadj_reduce, dim3(md.n_glong), dim3(256), 0, m->stream, md, A, io);
+  // ... and the predictors' adjoints go back to the coefficients: X^T adj in row chunks, then every coefficient adds its partials up
+  if (md.n_lins > 0) {
+    for (int l = 0; l < md.n_lins; ++l) {
+      const LinDev& L = m->lins_host[l];
+      if (L.N == 1) { hipLaunchKernelGGL(k_lin_bwd1, dim3(L.K), dim3(1024), 0, m->stream, md, A, io, l); continue; }
+      const dim3 grid((unsigned)L.nchunk, (unsigned)L.P);
+#define LIN_BWD(KT) hipLaunchKernelGGL(k_lin_bwd<KT>, grid, dim3(256), 0, m->stream, md, A, io, l)
+      if (L.K == 1) LIN_BWD(1); else if (L.K == 2) LIN_BWD(2); else if (L.K <= 4) LIN_BWD(4); else if (L.K <= 8) LIN_BWD(8); else LIN_BWD(16);
+#undef LIN_BWD
+    }
+    if (md.n_lin_targets > 0) hipLaunchKernelGGL(k_lin_fin, dim3((md.n_lin_targets + 255) / 256), dim3(256), 0, m->stream, md, A, io);
+  }
   if (md.lg.ga) return;   // group-aligned row pass: the O(n) work rides in the row pass itself (rows_ga_kernel.h)
   if (md.has_mvn && md.mv.aligned && io.lean) return;   // (the row-aligned MvNormal pass has finished the leapfrog itself)
   // small models: 8x oversubscribed launch, one XCD does the work (see k_vector); large ones use the whole chip
@@ -696,6 +729,14 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     if (v.size <= 0) { g_err = "empty value variable"; return false; }
   }
   if (s->rows_N > 0) { vars[s->rows_mu].deferred = 1; vars[s->rows_sigma].deferred = 1; }
+  if (s->n_lins < 0 || s->n_lins > NUTS_MAX_LINS || (s->n_lins > 0 && !s->lins)) { g_err = "bad number of linear predictors (NUTS_MAX_LINS)"; return false; }
+  if (s->n_lins > 0 && (s->rows_N > 0 || s->mix_N > 0 || s->glm_N > 0)) { g_err = "linear predictors are not combined with the logit-rows, mixture or GLM node"; return false; }
+  for (int l = 0; l < s->n_lins; ++l) {
+    const nuts_lin& L = s->lins[l];
+    if (L.N < 1 || L.P < 1 || L.K < 1 || L.K > NUTS_LIN_MAXK || !L.X) { g_err = "linear predictor with bad dimensions"; return false; }
+    if (L.N > 1 && (L.P > NUTS_LIN_MAXP || (int64_t)L.K * L.P > 4096)) { g_err = "linear predictor: P <= 512 and K P <= 4096 for predictors with more than one row"; return false; }
+    if (L.N * (int64_t)L.P > ((int64_t)1 << 31) || L.N > (int64_t)INT32_MAX) { g_err = "linear predictor: X too large"; return false; }
+  }
   std::vector<std::vector<Contrib>> per_var(nv);
   std::vector<FactorBT> fbt(std::max(nf, 1));
   std::vector<int32_t> bterm_var, orphans;
@@ -711,11 +752,19 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   int64_t adj_len = 0;
   int32_t gs_elems = 0;
   const bool gsweep_on = env_int("NUTS_GSWEEP", 1) != 0;
-  auto finish_gather = [&](int fi) {
-    if (!gsweep_on || gathered.empty() || (int)gathered.size() > MAX_GSLOTS) return;
+  std::vector<std::pair<int, int>> lin_used;   // (predictor, column) pairs of the factor being compiled (NUTS_OP_LIN operands)
+  m->lin_uses.assign(std::max(s->n_lins, 0), {});
+  for (int l = 0; l < s->n_lins; ++l) m->lin_uses[l].assign(std::max(std::min(s->lins[l].K, NUTS_LIN_MAXK), 0), {});
+  auto finish_gather = [&](int fi) -> bool {
+    // (a factor that reads a linear predictor MUST be swept: the sweep is where d logp / d eta comes from)
+    const bool need = !lin_used.empty();
+    if (gathered.empty() && !need) return true;
     const int64_t fsize = s->factors[fi].size;
-    if (adj_len + (int64_t)gathered.size() * fsize > ((int64_t)1 << 28) || (int64_t)gs_elems + fsize > ((int64_t)1 << 30)) return;   // (2 GiB of adjoints: keep the old path)
-    GSweepFactor sf{fi, (int32_t)gslots.size(), (int32_t)gathered.size(), gs_elems};
+    const size_t nsl = gathered.size() + lin_used.size();
+    const bool fits = nsl <= MAX_GSLOTS && adj_len + (int64_t)nsl * fsize <= ((int64_t)1 << 28) && (int64_t)gs_elems + fsize <= ((int64_t)1 << 30);   // (2 GiB of adjoints)
+    if (need && !fits) { g_err = "a factor that reads linear predictors has too many gathered operands / elements for the adjoint sweep"; return false; }
+    if ((!gsweep_on && !need) || !fits) return true;   // (keep the old path)
+    GSweepFactor sf{fi, (int32_t)gslots.size(), (int32_t)nsl, gs_elems, 0, 0};
     for (const auto& gv : gathered) {
       gslots.push_back(GSlot{gv.first, gv.second, adj_len});
       for (Contrib& cb : per_var[gv.first])
@@ -726,12 +775,14 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
           const int32_t* ptr = csr.data() + cb.dist;
           bool any = false;
           for (int e = 0; e < vs; ++e) any = any || (ptr[e + 1] - ptr[e] >= GADJ_LONG);
-          if (any && glong.size() + (size_t)vs <= 4096) {
+          if (any && glong.size() + (size_t)vs <= 16384) {
             std::vector<int32_t> map(vs, -1);
             for (int e = 0; e < vs; ++e)
               if (ptr[e + 1] - ptr[e] >= GADJ_LONG) {
+                const int len = ptr[e + 1] - ptr[e], nc = (len + GADJ_CHUNK - 1) / GADJ_CHUNK;
                 map[e] = (int32_t)glong.size();
-                glong.push_back(GLong{adj_len, cb.pad + ptr[e], ptr[e + 1] - ptr[e]});
+                for (int c = 0; c < nc; ++c)   // (chunk c: entries [c GADJ_CHUNK, ...) of the list, a workgroup's work)
+                  glong.push_back(GLong{adj_len, cb.pad + ptr[e] + c * GADJ_CHUNK, std::min(GADJ_CHUNK, len - c * GADJ_CHUNK), c == 0 ? nc : 0, 0});
               }
             cb.p[3] = (double)csr.size();
             csr.insert(csr.end(), map.begin(), map.end());
@@ -739,8 +790,29 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         }
       adj_len += fsize;
     }
+    for (const auto& lv : lin_used) {   // a predictor column is a slot too: var = -1 - predictor, did = column (model_dev.h push)
+      gslots.push_back(GSlot{-1 - lv.first, lv.second, adj_len});
+      m->lin_uses[lv.first][lv.second].push_back(nuts_model::LinUse{adj_len, (int32_t)fsize});
+      adj_len += fsize;
+    }
     gs_elems += (int32_t)fsize;
     gsf.push_back(sf);
+    return true;
+  };
+  // NUTS_OP_LIN operand of factor fi: element-aligned with the factor, or a one-row predictor that broadcasts
+  auto add_lin = [&](int fi, const nuts_operand& o) -> bool {
+    const nuts_factor& f = s->factors[fi];
+    const int k = (int)o.c;
+    if (o.ref < 0 || o.ref >= s->n_lins || !s->lins) { g_err = "operand refers to a missing linear predictor"; return false; }
+    const nuts_lin& L = s->lins[o.ref];
+    if (k < 0 || k >= L.K || (double)k != o.c) { g_err = "operand refers to a missing column of a linear predictor"; return false; }
+    if (L.N != f.size && L.N != 1) { g_err = "linear predictor: one row per element of the factor (or a single row that broadcasts)"; return false; }
+    if (f.dist == NUTS_D_DERIVED) { g_err = "a derived vector cannot read a linear predictor"; return false; }
+    for (const auto& lv : lin_used) if (lv.first == o.ref && lv.second == k) return true;
+    lin_used.emplace_back(o.ref, k);
+    fac[fi].pad = 1;
+    m->has_prog = true;
+    return true;
   };
   // NUTS_OP_GATHER operand of factor fi: the inverse index (which factor elements read element e of the variable, in order)
   auto add_gather = [&](int fi, const nuts_operand& o) -> bool {
@@ -779,7 +851,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   for (int fi = 0; fi < nf; ++fi) {
     const nuts_factor& f = s->factors[fi];
     fac[fi].pad = 0;
-    gathered.clear();
+    gathered.clear(); lin_used.clear();
     fbt[fi].n = 0; fbt[fi].pad = 0;
     if (f.nargs < 1 || f.nargs > 4 || f.size < 1) { g_err = "factor with a bad argument count or size"; return false; }
     if (f.dist < 0 || f.dist > NUTS_D_DERIVED) { g_err = "factor with an unknown distribution code"; return false; }
@@ -834,8 +906,9 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         }
       std::vector<int> seen;
       for (const nuts_operand* o : ops) {
-        if (o->kind < NUTS_OP_CONST || o->kind > NUTS_OP_GATHER) { g_err = "operand of an unknown kind"; return false; }
+        if (o->kind < NUTS_OP_CONST || o->kind > NUTS_OP_LIN) { g_err = "operand of an unknown kind"; return false; }
         if (o->kind == NUTS_OP_GATHER) { if (!add_gather(fi, *o)) return false; continue; }
+        if (o->kind == NUTS_OP_LIN) { if (!add_lin(fi, *o)) return false; continue; }
         if (o->kind == NUTS_OP_DATA) {
           if (o->ref < 0 || o->ref >= s->n_data) { g_err = "factor refers to a missing data vector"; return false; }
           const int64_t ds = s->data[o->ref].size;
@@ -865,7 +938,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         } else { g_err = "variable does not broadcast against its factor"; return false; }
       }
       if (!owned_already) orphans.push_back(fi);
-      finish_gather(fi);
+      if (!finish_gather(fi)) return false;
       continue;
     }
     for (int a = 0; a < f.nargs; ++a) {
@@ -877,6 +950,11 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
           if (!add_gather(fi, o)) return false;
           continue;
         }
+        if (o.kind == NUTS_OP_LIN) {
+          if (!add_lin(fi, o)) return false;
+          continue;
+        }
+        if (o.kind < NUTS_OP_CONST || o.kind > NUTS_OP_LIN) { g_err = "operand of an unknown kind"; return false; }
         if (o.kind == NUTS_OP_DATA) {
           if (o.ref < 0 || o.ref >= s->n_data) { g_err = "factor refers to a missing data vector"; return false; }
           const int64_t ds = s->data[o.ref].size;
@@ -919,7 +997,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       }
     }
     if (!owned_already) orphans.push_back(fi);
-    finish_gather(fi);
+    if (!finish_gather(fi)) return false;
   }
   // peephole: untransformed vector variable whose only contribution is its own constant-parameter Normal prior
   for (int k = 0; k < nv; ++k) {
@@ -946,8 +1024,18 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     }
   if ((int)deferred.size() / 2 > MAX_DEFERRED) { g_err = "too many scalar / hyper-parameter elements (MAX_DEFERRED)"; return false; }
   md.n_bterms = (int)bterm_var.size(); md.n_orphans = (int)orphans.size(); md.n_deferred = (int)deferred.size() / 2;
+  // the orphans the adjoint sweep covers go behind the others: k_gsweep accounts their log-density and their scalars' adjoints, kernel
+  // B walks the first n_orphans_b only (NUTS_GSWEEP_LP = 0: kernel B walks all of them, as before -- A/B)
+  md.n_orphans_b = md.n_orphans;
+  if (env_int("NUTS_GSWEEP_LP", 1) != 0) {
+    auto swept = [&](int fi) { for (const GSweepFactor& g : gsf) if (g.f == fi) return true; return false; };
+    std::stable_partition(orphans.begin(), orphans.end(), [&](int fi) { return !swept(fi); });
+    md.n_orphans_b = 0;
+    for (int fi : orphans) if (!swept(fi)) md.n_orphans_b++;
+    for (GSweepFactor& g : gsf) g.orphan = std::find(orphans.begin() + md.n_orphans_b, orphans.end(), g.f) != orphans.end() ? 1 : 0;
+  }
   m->orphan_elems = 0; m->factor_elems = 0;
-  for (int fi : orphans) m->orphan_elems += s->factors[fi].size;
+  for (int o = 0; o < md.n_orphans_b; ++o) m->orphan_elems += s->factors[orphans[o]].size;
   for (int fi = 0; fi < nf; ++fi) m->factor_elems += s->factors[fi].size;
   md.orphans = m->keep(dev_upload(orphans.data(), orphans.size()));
   md.deferred_g = m->keep(dev_upload(deferred.data(), deferred.size()));
@@ -966,7 +1054,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       if (env_int("NUTS_LEAN_STRICT", 0))
         for (int k = 0; k < nv; ++k) if (vars[k].deferred && k != s->rows_mu && k != s->rows_sigma) md.lean_ok = 0;
       md.lg.def_mu = vars[s->rows_mu].def_base; md.lg.def_sigma = vars[s->rows_sigma].def_base;
-    } else if (s->rows_N <= 0 && s->mvn_k > 0 && md.n_deferred == 0 && s->glm_N <= 0) {
+    } else if (s->rows_N <= 0 && s->mvn_k > 0 && md.n_deferred == 0 && s->glm_N <= 0 && s->n_lins <= 0) {
       md.lean_ok = 1;
     }
   }
@@ -1045,7 +1133,106 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   }
   blob.resize((blob.size() + 15) & ~(size_t)15, 0);
   md.prog_bytes = (int32_t)blob.size();
+  // the sweep's arrays in LDS (k_gsweep_lds, one wave per workgroup; the interpreter's tables and the broadcast accumulators share the
+  // launch's dynamic LDS) -- when every element's wave is resident at once: with LDS as the limit a second round of workgroups costs
+  // more than the scratch version's trips to the L2 (measured: a 79-row block at 100 000 elements 363 us against 190)
+  md.gs_lds_rows = 0; md.gs_lds_bytes = 0;
+  if (!gsf.empty() && env_int("NUTS_GSWEEP_LDS", 1) != 0) {
+    int max_instr = 0, max_slots = 0;
+    for (const GSweepFactor& g : gsf) { max_instr = std::max(max_instr, s->factors[g.f].n_instr); max_slots = std::max(max_slots, g.n_slots); }
+    const int rows = std::max(2 * max_instr + max_slots, 1) + md.n_bterms;
+    const int64_t bytes = (int64_t)rows * 64 * 8 + (int64_t)md.prog_bytes + 64;
+    const int64_t waves = ((int64_t)gs_elems + 63) / 64;
+    const int64_t per_cu = std::min<int64_t>(32, (160 * 1024) / std::max<int64_t>(bytes, 1));
+    if (bytes <= 60 * 1024 && (waves <= 256 * per_cu || env_int("NUTS_GSWEEP_LDS", 1) == 2)) { md.gs_lds_rows = rows; md.gs_lds_bytes = (int32_t)bytes; }
+  }
+  md.n_gs_blocks = gsf.empty() ? 0 : (md.gs_lds_rows > 0 ? std::max(1, std::min(8192, (gs_elems + 63) / 64)) : std::max(1, std::min(2048, (gs_elems + 255) / 256)));
+  md.gs_part = nullptr;
+  if (md.n_gs_blocks > 0) {
+    md.gs_part = m->keep(dev_alloc<double>((size_t)md.n_gs_blocks * (1 + MAX_BTERMS)));
+    if (!md.gs_part) { g_err = "device allocation failed (gathered adjoints)"; return false; }
+    hipMemset(md.gs_part, 0, (size_t)md.n_gs_blocks * (1 + MAX_BTERMS) * sizeof(double));
+  }
   md.prog = m->keep(dev_upload(blob.data(), blob.size()));
+  return true;
+}
+
+// Linear predictors (dense node 5, lin_kernel.h): X transposed, the predictors' buffers, where every coefficient lives and which
+// partial sums make up its gradient.  Runs once the data pool exists (a coefficient may be an element of a derived vector).
+static bool build_lins(nuts_model* m, const nuts_model_spec* s, const std::vector<VarDev>& vars) {
+  ModelDev& md = m->md;
+  md.n_lins = 0; md.n_lin_targets = 0; md.lins = nullptr; md.lin_targets = nullptr; md.lin_srcs = nullptr; md.lin_gdense = nullptr;
+  if (s->n_lins <= 0) return true;
+  const int n = md.n;
+  md.lin_gdense = m->keep(dev_alloc<double>((size_t)n));
+  if (!md.lin_gdense) { g_err = "device allocation failed (linear predictors)"; return false; }
+  hipMemset(md.lin_gdense, 0, (size_t)n * sizeof(double));
+  struct Src { int64_t key; LinSrc src; double* dst; };
+  std::vector<Src> srcs;
+  m->lins_host.assign(s->n_lins, LinDev{});
+  for (int l = 0; l < s->n_lins; ++l) {
+    const nuts_lin& L = s->lins[l];
+    LinDev& D = m->lins_host[l];
+    D.N = L.N; D.P = L.P; D.K = L.K;
+    D.nchunk = L.N > 1 ? (int32_t)((L.N + LIN_CHUNK - 1) / LIN_CHUNK) : 1;
+    std::vector<double> xt((size_t)L.N * L.P);
+    for (int64_t i = 0; i < L.N; ++i)
+      for (int p = 0; p < L.P; ++p) xt[(size_t)p * L.N + i] = L.X[(size_t)i * L.P + p];
+    D.Xt = m->keep(dev_upload(xt.data(), xt.size()));
+    D.eta = m->keep(dev_alloc<double>((size_t)L.K * L.N));
+    const size_t npart = L.N > 1 ? (size_t)L.K * L.P * D.nchunk : (size_t)L.K;
+    D.part = m->keep(dev_alloc<double>(npart));
+    if (!D.Xt || !D.eta || !D.part) { g_err = "device allocation failed (linear predictors)"; return false; }
+    hipMemset(D.eta, 0, (size_t)L.K * L.N * sizeof(double));
+    hipMemset(D.part, 0, npart * sizeof(double));
+    std::vector<int32_t> coef((size_t)L.K * L.P);
+    for (int k = 0; k < L.K; ++k) {
+      LinCol& C = D.col[k];
+      const auto& uses = m->lin_uses[l][k];
+      if (uses.size() > LIN_MAXUSE) { g_err = "a linear predictor column is read by too many factors (LIN_MAXUSE)"; return false; }
+      C.n_use = (int32_t)uses.size();
+      for (size_t u = 0; u < uses.size(); ++u) { C.adj_off[u] = uses[u].adj_off; C.use_size[u] = uses[u].size; }
+      const int64_t last = (int64_t)L.off[k] + (int64_t)(L.P - 1) * L.stride[k];
+      if (L.off[k] < 0 || L.stride[k] < 0 || (L.stride[k] == 0 && L.P > 1)) { g_err = "linear predictor: bad coefficient offset / stride"; return false; }
+      double* dst_base = nullptr; int64_t cbase = 0;
+      if (L.var[k] >= 0) {
+        if (L.var[k] >= md.n_vars) { g_err = "linear predictor refers to a missing variable"; return false; }
+        const VarDev& v = vars[L.var[k]];
+        if (last >= v.size) { g_err = "linear predictor: coefficients beyond the end of their variable"; return false; }
+        C.transform = v.transform; C.lower = v.lower; C.upper = v.upper;
+        cbase = v.offset; dst_base = md.lin_gdense + v.offset;
+      } else {
+        const int fi = -(L.var[k] + 1);
+        int t = -1;
+        for (int u = 0; u < md.n_derived; ++u) if (md.derived_f[u] == fi) t = u;
+        if (t < 0) { g_err = "linear predictor: coefficients must be a variable or a NUTS_D_DERIVED factor"; return false; }
+        const int64_t sz = s->factors[fi].size;
+        if (last >= sz) { g_err = "linear predictor: coefficients beyond the end of their derived vector"; return false; }
+        C.transform = -1; C.lower = 0.0; C.upper = 0.0;
+        cbase = md.derived_off[t]; dst_base = const_cast<double*>(md.pool) + md.derived_off[t] + sz;   // (the vector's seed follows its values)
+      }
+      for (int p = 0; p < L.P; ++p) {
+        const int64_t e = (int64_t)L.off[k] + (int64_t)p * L.stride[k];
+        coef[(size_t)k * L.P + p] = (int32_t)(cbase + e);
+        if (C.n_use > 0) srcs.push_back(Src{(int64_t)reinterpret_cast<intptr_t>(dst_base + e), LinSrc{l, k, p, 0}, dst_base + e});
+      }
+    }
+    D.coef = m->keep(dev_upload(coef.data(), coef.size()));
+    m->alg_bytes += 16 * L.N * (int64_t)L.P;   // X once forwards, once backwards
+  }
+  // a coefficient that several columns share (the same vector against two matrices) adds their partial sums up, in table order
+  std::stable_sort(srcs.begin(), srcs.end(), [](const Src& a, const Src& b) { return a.key < b.key; });
+  std::vector<LinTarget> targets;
+  std::vector<LinSrc> flat;
+  for (size_t i = 0; i < srcs.size(); ++i) {
+    if (i == 0 || srcs[i].key != srcs[i - 1].key) targets.push_back(LinTarget{srcs[i].dst, (int32_t)flat.size(), 0});
+    targets.back().n_src++;
+    flat.push_back(srcs[i].src);
+  }
+  md.n_lins = s->n_lins; md.n_lin_targets = (int32_t)targets.size();
+  md.lins = m->keep(dev_upload(m->lins_host.data(), m->lins_host.size()));
+  md.lin_targets = m->keep(dev_upload(targets.data(), targets.size()));
+  md.lin_srcs = m->keep(dev_upload(flat.data(), flat.size()));
   return true;
 }
 
@@ -1553,6 +1740,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     md.has_glm = 1;
     m->alg_bytes += 8 * gm.N * (int64_t)gm.P;   // one read of X (SURVEY 8d convention: the node's data once per evaluation)
   }
+  if (!build_lins(m, s, vars)) { nuts_model_destroy(m); return nullptr; }
   for (void* p : m->owned)
     if (!p) { g_err = "device allocation failed"; nuts_model_destroy(m); return nullptr; }
   HIPCHK_NULL(hipDeviceSynchronize());
@@ -1666,7 +1854,7 @@ extern "C" int nuts_model_get_scalar(const nuts_model* m, const char* name, doub
   // model is laid out 8 rows per workgroup (NUTS_MVN_ALIGNED = 8: the default from k = 1024) and the chain was created under NUTS_GROUP_WIDE = 1
   else if (k == "chain_group_wide_ok") *out = (m->md.has_mvn && m->md.mv.aligned > 0 && m->md.mv.k % 16 == 0) ? 1.0 : 0.0;
   else if (k == "chain_group_wide_rows") *out = 8.0;   // rows per workgroup (NUTS_MVN_ALIGNED) the members' models must be laid out with
-  else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm && m->factor_elems <= SMALL_MAX_ELEMS) ? 1.0 : 0.0;
+  else if (k == "single_workgroup_ok") *out = (m->md.n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm && m->md.n_lins == 0 && m->factor_elems <= SMALL_MAX_ELEMS) ? 1.0 : 0.0;
   else { g_err = "unknown model scalar " + k; return NUTS_E_ARG; }
   return NUTS_OK;
 }
@@ -2094,7 +2282,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->group_wide = env_int("NUTS_GROUP_WIDE", 0);
   // (... and whose factors are small too: the single workgroup walks every factor element itself -- SMALL_MAX_ELEMS, round 6)
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
-             m->factor_elems <= SMALL_MAX_ELEMS && !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
+             m->md.n_lins == 0 && m->factor_elems <= SMALL_MAX_ELEMS && !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
   A.log_uniforms = A.uniforms + c->n_uni_cap;

@@ -405,15 +405,63 @@ __device__ __forceinline__ bool dot_needed(int k, int m, bool last) {
 __global__ __launch_bounds__(256) void k_gsweep(ModelDev md, ArenaDev A, EvalIO io, int j) {
   if (load_aborted(io, A)) return;
   __shared__ __attribute__((aligned(16))) char s_prog[PROG_LDS_MAX];
+  __shared__ double s_bacc[MAX_BTERMS][256];
+  __shared__ double s_w[256 / WAVE];
   ProgRegs pregs;
   prog_issue(md, pregs);
   const Prog pg = load_prog(md, s_prog, pregs);
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < md.n_gs_elems; e += gridDim.x * 256) gsweep_element(pg, qv, e);
+  const int tid = threadIdx.x;
+  for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] = 0.0;
+  double lp = 0.0;
+  for (int e = blockIdx.x * 256 + tid; e < md.n_gs_elems; e += gridDim.x * 256) lp += gsweep_element<true>(pg, qv, e, &s_bacc[0][tid], 256);
+  // this workgroup's share of the orphan factors' log-density and of their scalars' adjoints (kernel B's workgroup 0 adds the records up)
+  double* rec = md.gs_part + (int64_t)blockIdx.x * (1 + MAX_BTERMS);
+  const double t = block_sum<false>(lp, s_w);
+  if (tid == 0) rec[0] = t;
+  for (int b = 0; b < md.n_bterms; ++b) {
+    const double tb = block_sum<false>(s_bacc[b][tid], s_w);
+    if (tid == 0) rec[1 + b] = tb;
+  }
 }
 
-// ... and the totals of the long inverse-index lists (model_dev.h GLong): one workgroup per list
+// The same sweep with the instructions' values, their adjoints and the slots' totals in LDS instead of scratch (model_dev.h LdsVec): one
+// WAVE per workgroup, (2 x longest program + most slots) KB/2 of dynamic LDS; chosen when that fits 40 KB (engine.hip).  Same
+// arithmetic in the same order: the bits of the scratch version.
+#define GSL_THREADS 64
+__global__ __launch_bounds__(GSL_THREADS) void k_gsweep_lds(ModelDev md, ArenaDev A, EvalIO io, int j) {
+  if (load_aborted(io, A)) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // [gs_lds_rows][64] doubles, then the interpreter's tables
+  const int tid = threadIdx.x;
+  char* s_prog = reinterpret_cast<char*>(s_dyn + (size_t)md.gs_lds_rows * GSL_THREADS);
+  {   // (one wave: the blob is copied 64 x 16 B at a time)
+    const int n16 = (md.prog_bytes + 15) >> 4;
+    for (int i = tid; i < n16; i += GSL_THREADS) reinterpret_cast<uint4*>(s_prog)[i] = reinterpret_cast<const uint4*>(md.prog)[i];
+    __syncthreads();
+  }
+  const Prog pg = prog_view(md, s_prog);
+  Leaf lf; QView qv;
+  resolve_leaf(io, A, j, lf, qv);
+  int max_instr = 0;
+  for (int t = 0; t < pg.n_gsf; ++t) max_instr = max(max_instr, pg.factors[pg.gsf[t].f].n_instr);
+  double* s_bacc = s_dyn + tid;                                           // rows [0, n_bterms): the broadcast accumulators
+  for (int b = 0; b < md.n_bterms; ++b) s_bacc[b * GSL_THREADS] = 0.0;
+  double* col = s_dyn + (size_t)md.n_bterms * GSL_THREADS + tid;
+  const LdsVec tv{col, GSL_THREADS}, ta{col + (size_t)max_instr * GSL_THREADS, GSL_THREADS}, gadj{col + (size_t)2 * max_instr * GSL_THREADS, GSL_THREADS};
+  double lp = 0.0;
+  for (int e = blockIdx.x * GSL_THREADS + tid; e < md.n_gs_elems; e += gridDim.x * GSL_THREADS)
+    lp += gsweep_element_lds<true>(pg, qv, e, s_bacc, GSL_THREADS, tv, ta, gadj);
+  double* rec = md.gs_part + (int64_t)blockIdx.x * (1 + MAX_BTERMS);
+  const double t = wave_sum(lp);
+  if (tid == 0) rec[0] = t;
+  for (int b = 0; b < md.n_bterms; ++b) {
+    const double tb = wave_sum(s_bacc[b * GSL_THREADS]);
+    if (tid == 0) rec[1 + b] = tb;
+  }
+}
+
+// ... and the totals of the long inverse-index lists (model_dev.h GLong): one workgroup per chunk of a list
 __global__ __launch_bounds__(256) void k_gadj_reduce(ModelDev md, ArenaDev A, EvalIO io) {
   if (load_aborted(io, A)) return;
   __shared__ double s_w[256 / WAVE];
@@ -583,6 +631,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
     if (md.has_mvn && i >= md.mv.off && i < md.mv.off + md.mv.k) gd += md.mv.gdense[i];
     if (md.has_mix) gd += md.mix.gdense[i];
     if (md.has_glm) gd += md.glm.gdense[i];
+    if (md.n_lins > 0) gd += md.lin_gdense[i];   // the coefficients of linear predictors (lin_kernel.h); zero elsewhere
     grad[e] = (gx + gd) * dxdq + dj;
     act[e] = true;
     if (leaf) A.G[lf.d_o + i] = grad[e];
@@ -591,11 +640,18 @@ __global__ __launch_bounds__(VEC_THREADS) void k_vector(ModelDev md, ArenaDev A,
 
   TICK(md, tk, 4);
   // factors without an owning variable (only scalars and data): grid-stride over their elements
-  for (int o = 0; o < md.n_orphans; ++o) {
+  for (int o = 0; o < md.n_orphans_b; ++o) {
     const int fi = md.orphans[o];
     const int fsize = pg.factors[fi].size;
     for (int li = bid * VEC_THREADS + tid; li < fsize; li += nb * VEC_THREADS) lp += orphan_element<PROG>(pg, qv, fi, li, &s_bacc[0][tid], VEC_THREADS);
   }
+  // ... the swept ones among them were accounted by k_gsweep (ModelDev.gs_part): its per-workgroup records, in order
+  if (PROG && bid == 0 && md.n_orphans_b < md.n_orphans)
+    for (int r = tid; r < md.n_gs_blocks; r += VEC_THREADS) {
+      const double* rec = md.gs_part + (int64_t)r * (1 + MAX_BTERMS);
+      lp += rec[0];
+      for (int b = 0; b < md.n_bterms; ++b) s_bacc[b][tid] += rec[1 + b];
+    }
 
   // ---- second half kick + tree-merge dot products (wave partials land in s_red) ----
   int m = 0; bool last = false;
@@ -906,6 +962,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_control(ModelDev md, ArenaDev A
       else if (k == lg.var_sigma) gx += s_sum[PART_DSG + (i - lg.off_sigma)];
     }
     if (md.has_glm) gx += md.glm.gdense[i];   // the GLM node's scalar parameters (intercept, sigma): glm_kernel.h; zero elsewhere
+    if (md.n_lins > 0) gx += md.lin_gdense[i]; // a scalar coefficient of a linear predictor (lin_kernel.h)
   }
   TICK(md, tk, 20);
   // broadcast terms: the share of the ordinary elements (kernel B) + the share of deferred vector elements (here)
@@ -1726,3 +1783,4 @@ __global__ __launch_bounds__(VEC_THREADS) void k_potential_update_exp(int n, con
 #include "rows_ga_multi_kernel.h"
 #include "rows_gal_kernel.h"
 #include "rows_gb_multi_kernel.h"
+#include "lin_kernel.h"

@@ -60,13 +60,14 @@ struct Contrib {  // "variable k is operand `slot` (0=a,1=b,2=c) of argument `ar
 // (the same numbers in the same order as before).
 #define MAX_GSLOTS 64       // (variable, index vector) pairs per factor served this way; a factor with more keeps the old path
 struct GSlot { int32_t var, did; int64_t adj_off; };
-struct GSweepFactor { int32_t f, slot0, n_slots, elem0; };
+struct GSweepFactor { int32_t f, slot0, n_slots, elem0; int32_t orphan, pad; };   // orphan: no variable owns the factor -- the sweep also accounts its log-density and its scalars' adjoints (k_gsweep)
 // A variable element that MANY factor elements index (a regression coefficient read by every row: an inverse-index list of 10^5
 // entries) is not added up by the one thread that owns the element: a workgroup of its own totals the list first (k_gadj_reduce, a
 // phase of the single-workgroup kernel) -- thread t adds entries t, t + 256, ... in order, the threads' partials are combined in the
 // fixed order of `block_sum` -- and the owner reads one number.
 #define GADJ_LONG 512       // lists from this length on
-struct GLong { int64_t adj_off; int32_t lst_off, len; };   // slots [slot0, slot0 + n_slots) of ModelDev's slot table; elem0: first of its elements in the sweep's numbering
+#define GADJ_CHUNK 4096     // entries of a long list one workgroup totals (16 per thread); a list of 10^5 entries is 25 workgroups' work
+struct GLong { int64_t adj_off; int32_t lst_off, len; int32_t nchunk, pad; };   // one CHUNK of a long list; nchunk (on a list's first chunk): how many follow each other   // slots [slot0, slot0 + n_slots) of ModelDev's slot table; elem0: first of its elements in the sweep's numbering
 
 struct FactorBT {  // broadcast (size-1 variable) operands of a factor whose size is > 1
   int32_t n, pad;
@@ -187,6 +188,28 @@ struct GlmDev {
   double* lp;               // the node's logp
 };
 
+// dense node 5: linear predictors read by the factors through NUTS_OP_LIN operands (lin_kernel.h)
+#define LIN_MAXUSE 4     // factors that may read one predictor column
+#define LIN_CHUNK 2048   // rows per workgroup of the transposed mat-vec (8 per thread)
+struct LinCol {
+  int32_t transform, n_use;        // transform of the coefficient variable (its constrained value is the coefficient); -1: a derived vector
+  double lower, upper;
+  int64_t adj_off[LIN_MAXUSE];     // where the sweep of each reading factor leaves d logp / d eta of this column (ModelDev.adj)
+  int32_t use_size[LIN_MAXUSE];    // elements of that factor (N, or anything when the predictor has one row and broadcasts)
+};
+struct LinDev {
+  int64_t N;
+  int32_t P, K, nchunk, pad;
+  const double* Xt;                // [P][N]: X transposed -- a thread per row reads it coalesced, forwards and backwards
+  double* eta;                     // [K][N] the predictors at this leaf's position
+  double* part;                    // N > 1: [K][P][nchunk] partial sums of X^T adj over row chunks; N == 1: [K] total adjoint of the column
+  const int32_t* coef;             // [K][P] where coefficient p of column k lives: element of the raveled vector, or (derived) index into pool
+  LinCol col[NUTS_LIN_MAXK];
+};
+// one entry per coefficient that receives a gradient from the node: target address and the partial sums that make it up, in order
+struct LinTarget { double* dst; int32_t src0, n_src; };
+struct LinSrc { int32_t lin, k, p, pad; };
+
 // per-workgroup partial record written by the vector kernel, summed (in workgroup order) by the control kernel
 #define PART_LP 0
 #define PART_BT 1
@@ -196,7 +219,7 @@ struct GlmDev {
 
 struct ModelDev {
   int32_t n, n_vars, n_factors, n_data;
-  int32_t n_bterms, n_orphans, n_deferred, nblk;
+  int32_t n_bterms, n_orphans, n_deferred, nblk;   // (n_orphans: all of them -- the single-workgroup kernel walks every one)
   const double* pool;         // data vectors of the spec
   const int32_t* orphans;     // [n_orphans] factors without an owning variable
   const int32_t* deferred_g;  // [n_deferred][2] (element, variable): global copy of the program's list
@@ -233,10 +256,24 @@ struct ModelDev {
   // gathered adjoints (see GSlot): the factors swept ahead of the leaf's other work, their slots, the adjoint pool
   int32_t n_gsf, n_gs_elems;  // factors; their elements in all
   int32_t po_gsf, po_gslot;   // tables in the program blob
+  // Swept factors WITHOUT an owning variable: kernel B used to walk their elements a second time (another forward + reverse sweep per
+  // element) for nothing but the factor's log-density and the adjoints of the scalars that broadcast into it.  k_gsweep now leaves
+  // both, per workgroup, in gs_part [n_gs_blocks][1 + MAX_BTERMS]; kernel B's workgroup 0 adds the records up in order and walks only
+  // orphans [0, n_orphans_b) of the list (the swept ones are sorted behind them).
+  int32_t n_gs_blocks, n_orphans_b;
+  double* gs_part;
+  int32_t gs_lds_rows, gs_lds_bytes;   // > 0: k_gsweep_lds -- rows (doubles per thread) of the sweep's LDS block: 2 x (longest program) + (most slots); the launch's dynamic LDS in all
   double* adj;
   int32_t n_glong, glong_pad; // long inverse-index lists (GLong): entries, in global memory next to their totals
   const GLong* glong;
   double* adj_red;            // [n_glong]
+  // dense node 5 (LinDev): the predictors' tables live in global memory; lin_gdense [n]: the node's gradient w.r.t. the constrained
+  // values (zero outside the coefficients), the protocol of the other dense nodes
+  int32_t n_lins, n_lin_targets;
+  const LinDev* lins;
+  const LinTarget* lin_targets;
+  const LinSrc* lin_srcs;
+  double* lin_gdense;
 };
 
 #ifdef NUTS_KTIMING
@@ -313,7 +350,9 @@ struct Prog {
   const GSlot* gslot;
   double* adj;
   const double* adj_red;
+  const GLong* glong;
   int n_gsf;
+  const LinDev* lins;        // linear predictors (NUTS_OP_LIN operands)
 };
 
 __device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) {
@@ -333,7 +372,8 @@ __device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) 
   pg.fdead_mode = md.fdead_mode; pg.fdead = md.fdead;
   pg.gsf = reinterpret_cast<const GSweepFactor*>(base + md.po_gsf);
   pg.gslot = reinterpret_cast<const GSlot*>(base + md.po_gslot);
-  pg.adj = md.adj; pg.adj_red = md.adj_red; pg.n_gsf = md.n_gsf;
+  pg.adj = md.adj; pg.adj_red = md.adj_red; pg.glong = md.glong; pg.n_gsf = md.n_gsf;
+  pg.lins = md.lins;
   return pg;
 }
 
@@ -450,7 +490,9 @@ __device__ __forceinline__ double transform_x_sel(const VarDev& v, double qi) {
   }
 }
 
-template <bool DEFQ = false, bool OL = false>
+// LIN: the kernel may meet NUTS_OP_LIN operands (a model with linear predictors always runs the instantiations that carry the
+// expression-program interpreter; the lean ones compile the branch out)
+template <bool DEFQ = false, bool OL = false, bool LIN = true>
 __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const Prog& pg, const QView& qv, int own_var,
                                            double own_x) {
   if (o.kind == NUTS_OP_CONST) return o.c;
@@ -462,6 +504,10 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
     const nuts_data_ref r = pg.data[(int)o.c];
     const VarDev v = pg.vars[o.ref];
     return transform_x_sel<OL>(v, qv.at(v.offset + (int)pg.pool[r.offset + li]));
+  }
+  if constexpr (LIN) if (o.kind == NUTS_OP_LIN) {      // eta_k[li], written by k_lin_fwd ahead of this kernel (one row: broadcast)
+    const LinDev& L = pg.lins[o.ref];
+    return L.eta[(int64_t)(int)o.c * L.N + (L.N > 1 ? li : 0)];
   }
   if (o.ref == own_var) return own_x;
   const VarDev v = pg.vars[o.ref];
@@ -678,7 +724,7 @@ __device__ __forceinline__ double dist_eval(int dist, double konst, const double
 
 // Evaluate element `li` of factor `f`: returns its logp, fills d[k] (partials w.r.t. argument k)
 // and the b / c operand values of every argument (needed for the chain rule through a + b*c).
-template <bool DEFQ = false, bool OL = false>
+template <bool DEFQ = false, bool OL = false, bool LIN = true>
 __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var,
                                               double own_x, double* d, double* bv, double* cv, int* pdead) {
   double a[4];
@@ -686,9 +732,9 @@ __device__ __forceinline__ double factor_eval(const Prog& pg, const QView& qv, c
   for (int k = 0; k < 4; ++k) {
     if (k < f.nargs) {
       const nuts_term& t = f.arg[k];
-      const double av = op_value<DEFQ, OL>(t.a, li, pg, qv, own_var, own_x);
-      bv[k] = op_value<DEFQ, OL>(t.b, li, pg, qv, own_var, own_x);
-      cv[k] = op_value<DEFQ, OL>(t.c, li, pg, qv, own_var, own_x);
+      const double av = op_value<DEFQ, OL, LIN>(t.a, li, pg, qv, own_var, own_x);
+      bv[k] = op_value<DEFQ, OL, LIN>(t.b, li, pg, qv, own_var, own_x);
+      cv[k] = op_value<DEFQ, OL, LIN>(t.c, li, pg, qv, own_var, own_x);
       a[k] = av + bv[k] * cv[k];
     } else {
       a[k] = 0.0; bv[k] = cv[k] = 0.0;
@@ -771,12 +817,35 @@ __device__ __forceinline__ double prog_op_value(int op, double k, double x, doub
   }
 }
 
+// Where a sweep keeps the instructions' values and adjoints: a thread's own arrays (scratch memory: every kernel but one) or, for the
+// adjoint sweep's kernel (k_gsweep_lds), a column of an LDS block -- element i of thread t at base[i * stride + t], conflict-free.
+// A sweep is a chain of dependent reads and writes of these arrays; in scratch each is a trip to the L2 (500+ cycles), in LDS ~100.
+struct LdsVec {
+  double* base; int stride;
+  __device__ __forceinline__ double& operator[](int i) const { return base[i * stride]; }
+};
+
 // forward sweep: tv[i] for every instruction, then the factor's arguments
+// (selects, not d[arg]: a run-time index into the four-entry arrays put all of them in scratch -- 144 B in every kernel that evaluates
+// factors, VERDICT r02)
+// (bit masks rather than a select chain: selects between loads of one array are folded back into an indexed load)
+__device__ __forceinline__ double pick4(const double* v, int i) {
+  unsigned long long r = 0ull;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r |= (unsigned long long)__double_as_longlong(v[k]) & (0ull - (unsigned long long)(i == k || (k == 3 && i > 3)));
+  return __longlong_as_double((long long)r);
+}
+// (Code size is what this interpreter is bound by: with the operand fetch -- five operand kinds, three transforms -- inlined at every
+// use, one instantiation was 330 KB of code against a 64 KB instruction cache, and an interpreted instruction cost ~4 000 cycles of
+// instruction fetch.  The fetch and the adjoint's `push` are therefore inlined at a handful of sites only: loops stay rolled, the
+// reverse rules compute what to push and ONE tail pushes it, transforms are calls.)
+template <typename TV>
 __device__ __forceinline__ void prog_forward(const Prog& pg, const QView& qv, const nuts_factor& f, int li, int own_var, double own_x,
-                                             double* tv, ProgFwd& o) {
-  auto val = [&](const nuts_operand& q) { return q.kind == NUTS_OP_TMP ? tv[q.ref] : op_value(q, li, pg, qv, own_var, own_x); };
+                                             TV tv, ProgFwd& o) {
+  auto val = [&](const nuts_operand& q) { return q.kind == NUTS_OP_TMP ? tv[q.ref] : op_value<false, true>(q, li, pg, qv, own_var, own_x); };
   const nuts_instr* ins = pg.instrs + f.instr_off;
   o.pdead = 0;
+#pragma unroll 1
   for (int i = 0; i < f.n_instr; ++i) {
     const nuts_instr& I = ins[i];
     const int op = I.op;
@@ -789,12 +858,16 @@ __device__ __forceinline__ void prog_forward(const Prog& pg, const QView& qv, co
     tv[i] = prog_op_value(op, I.k, x, y, z);
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k < f.nargs) {
-      const nuts_term& tm = f.arg[k];
-      o.bv[k] = val(tm.b); o.cv[k] = val(tm.c);
-      o.a[k] = val(tm.a) + o.bv[k] * o.cv[k];
-    } else { o.a[k] = 0.0; o.bv[k] = o.cv[k] = 0.0; }
+  for (int k = 0; k < 4; ++k) { o.a[k] = 0.0; o.bv[k] = o.cv[k] = 0.0; }
+#pragma unroll 1
+  for (int k = 0; k < f.nargs; ++k) {
+    const nuts_term& tm = f.arg[k];
+    const double b = val(tm.b), c = val(tm.c);
+    const double a = val(tm.a) + b * c;
+    // (selects, not o.a[k]: a run-time index would put the three arrays in scratch)
+    o.a[0] = k == 0 ? a : o.a[0]; o.a[1] = k == 1 ? a : o.a[1]; o.a[2] = k == 2 ? a : o.a[2]; o.a[3] = k == 3 ? a : o.a[3];
+    o.bv[0] = k == 0 ? b : o.bv[0]; o.bv[1] = k == 1 ? b : o.bv[1]; o.bv[2] = k == 2 ? b : o.bv[2]; o.bv[3] = k == 3 ? b : o.bv[3];
+    o.cv[0] = k == 0 ? c : o.cv[0]; o.cv[1] = k == 1 ? c : o.cv[1]; o.cv[2] = k == 2 ? c : o.cv[2]; o.cv[3] = k == 3 ? c : o.cv[3];
   }
 }
 
@@ -808,11 +881,10 @@ __device__ __noinline__ double factor_arg0_value(const Prog& pg, const QView& qv
 
 // `gs` / `ngs` (the sweep of k_gsweep only): the factor's slots; the adjoint of every gather operand is added up per slot and
 // stored at adj[slot.adj_off + li] -- nothing else of the sweep is kept.
-__device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int own_var, double own_x,
-                                               int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out, int wrt_did = -1,
-                                               const GSlot* gs = nullptr, int ngs = 0) {
-  double tv[NUTS_MAX_FACTOR_INSTR], ta[NUTS_MAX_FACTOR_INSTR];
-  double gadj[MAX_GSLOTS];
+template <typename TV>
+__device__ __forceinline__ double factor_prog_rev_t(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int own_var, double own_x,
+                                                    int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out, int wrt_did,
+                                                    const GSlot* gs, int ngs, TV tv, TV ta, TV gadj) {
   if (gs) for (int sl = 0; sl < ngs; ++sl) gadj[sl] = 0.0;
   ProgFwd o;
   prog_forward(pg, qv, f, li, own_var, own_x, tv, o);
@@ -823,16 +895,23 @@ __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, 
   factor_kill(pg, fi, pdead, lp, d);
   double gw = 0.0;
   const FactorBT& bt = pg.fbt[fi];
-  auto val = [&](const nuts_operand& q) { return q.kind == NUTS_OP_TMP ? tv[q.ref] : op_value(q, li, pg, qv, own_var, own_x); };
+  auto val = [&](const nuts_operand& q) { return q.kind == NUTS_OP_TMP ? tv[q.ref] : op_value<false, true>(q, li, pg, qv, own_var, own_x); };
   auto push = [&](const nuts_operand& q, double g) {
     if (q.kind == NUTS_OP_TMP) { ta[q.ref] += g; return; }
-    if (q.kind != NUTS_OP_VAR && q.kind != NUTS_OP_GATHER) return;
+    if (q.kind != NUTS_OP_VAR && q.kind != NUTS_OP_GATHER && q.kind != NUTS_OP_LIN) return;
     if (gs) {
-      if (q.kind == NUTS_OP_GATHER)
+      // (a predictor column is a slot like a gathered variable: var = -1 - predictor, did = column)
+      if (q.kind == NUTS_OP_GATHER || q.kind == NUTS_OP_LIN) {
+        const int sv = q.kind == NUTS_OP_LIN ? -1 - q.ref : q.ref;
         for (int sl = 0; sl < ngs; ++sl)
-          if (gs[sl].var == q.ref && gs[sl].did == (int)q.c) { gadj[sl] += g; break; }
+          if (gs[sl].var == sv && gs[sl].did == (int)q.c) { gadj[sl] += g; break; }
+      } else if (want_bt) {   // (the sweep owns this factor's log-density: the scalars that broadcast into it are credited here)
+        for (int b = 0; b < bt.n; ++b)
+          if (pg.bterm_var[bt.e[b].bterm] == q.ref) { s_bacc[bt.e[b].bterm * bstride] += g; break; }
+      }
       return;
     }
+    if (q.kind == NUTS_OP_LIN) return;   // (outside the sweep: the predictor's adjoint is the sweep's business)
     // `wrt_did` < 0: the caller owns an element-aligned (or scalar) occurrence of `wrt`: its direct operands; >= 0: it stands for the
     // gather of `wrt` through index vector `wrt_did`: those operands only (the others belong to other contributions of the variable)
     if (q.ref == wrt && (wrt_did < 0 ? q.kind == NUTS_OP_VAR : (q.kind == NUTS_OP_GATHER && (int)q.c == wrt_did))) { gw += g; return; }
@@ -841,59 +920,93 @@ __device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, 
         if (pg.bterm_var[bt.e[b].bterm] == q.ref) { s_bacc[bt.e[b].bterm * bstride] += g; break; }
   };
   for (int i = 0; i < f.n_instr; ++i) ta[i] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < f.nargs && d[k] != 0.0) {
+#pragma unroll 1
+  for (int k = 0; k < f.nargs; ++k) {
+    const double dk = pick4(d, k);
+    if (dk != 0.0) {
       const nuts_term& tm = f.arg[k];
-      push(tm.a, d[k]); push(tm.b, d[k] * o.cv[k]); push(tm.c, d[k] * o.bv[k]);
+      push(tm.a, dk); push(tm.b, dk * pick4(o.cv, k)); push(tm.c, dk * pick4(o.bv, k));
     }
+  }
   const nuts_instr* ins = pg.instrs + f.instr_off;
+  // operands whose VALUE a reverse rule reads (bit i: opcode i)
+  constexpr unsigned long long NEED_X =
+      (1ull << NUTS_E_MUL) | (1ull << NUTS_E_LOG) | (1ull << NUTS_E_LOG1P) | (1ull << NUTS_E_SOFTPLUS) | (1ull << NUTS_E_SQR) | (1ull << NUTS_E_ABS) |
+      (1ull << NUTS_E_POWC) | (1ull << NUTS_E_SWITCH) | (1ull << NUTS_E_GAMMALN) | (1ull << NUTS_E_ERF) | (1ull << NUTS_E_ERFC) | (1ull << NUTS_E_ERFCX) |
+      (1ull << NUTS_E_LOG1MEXP) | (1ull << NUTS_E_MAXIMUM) | (1ull << NUTS_E_MINIMUM) | (1ull << NUTS_E_POW) | (1ull << NUTS_E_SIN) | (1ull << NUTS_E_COS) |
+      (1ull << NUTS_E_ARCTAN) | (1ull << NUTS_E_LOGADDEXP) | (1ull << NUTS_E_CLIP) | (1ull << NUTS_E_LOG2) | (1ull << NUTS_E_LOG10) | (1ull << NUTS_E_DIGAMMA);
+  constexpr unsigned long long NEED_Y = (1ull << NUTS_E_MUL) | (1ull << NUTS_E_DIV) | (1ull << NUTS_E_MAXIMUM) | (1ull << NUTS_E_MINIMUM) | (1ull << NUTS_E_POW) |
+                                        (1ull << NUTS_E_LOGADDEXP) | (1ull << NUTS_E_CLIP);
+#pragma unroll 1
   for (int i = f.n_instr - 1; i >= 0; --i) {
     const double g = ta[i];
     if (g == 0.0) continue;
     const nuts_instr& I = ins[i];
     const double v = tv[i];
-    switch (I.op) {
-      case NUTS_E_ADD: push(I.x, g); push(I.y, g); break;
-      case NUTS_E_SUB: push(I.x, g); push(I.y, -g); break;
-      case NUTS_E_MUL: { const double x = val(I.x), y = val(I.y); push(I.x, g * y); push(I.y, g * x); } break;
-      case NUTS_E_DIV: { const double y = val(I.y); push(I.x, g / y); push(I.y, -g * v / y); } break;
-      case NUTS_E_NEG: push(I.x, -g); break;
-      case NUTS_E_EXP: push(I.x, g * v); break;
-      case NUTS_E_LOG: push(I.x, g / val(I.x)); break;
-      case NUTS_E_LOG1P: push(I.x, g / (1.0 + val(I.x))); break;
-      case NUTS_E_SIGMOID: push(I.x, g * v * (1.0 - v)); break;
-      case NUTS_E_SOFTPLUS: push(I.x, g * sigmoid_d(val(I.x))); break;
-      case NUTS_E_SQRT: push(I.x, g * 0.5 / v); break;
-      case NUTS_E_SQR: push(I.x, g * 2.0 * val(I.x)); break;
-      case NUTS_E_RECIPROCAL: push(I.x, -g * v * v); break;
-      case NUTS_E_TANH: push(I.x, g * (1.0 - v * v)); break;
-      case NUTS_E_ABS: { const double x = val(I.x); push(I.x, g * (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0))); } break;
-      case NUTS_E_POWC: push(I.x, g * I.k * pow(val(I.x), I.k - 1.0)); break;
-      case NUTS_E_SWITCH: if (val(I.x) != 0.0) push(I.y, g); else push(I.z, g); break;
-      case NUTS_E_GAMMALN: push(I.x, g * digamma_d(val(I.x))); break;
-      case NUTS_E_ERF: { const double x = val(I.x); push(I.x, g * 1.1283791670955126 * exp(-x * x)); } break;
-      case NUTS_E_ERFC: { const double x = val(I.x); push(I.x, -g * 1.1283791670955126 * exp(-x * x)); } break;
-      case NUTS_E_ERFCX: push(I.x, g * (2.0 * val(I.x) * v - 1.1283791670955126)); break;
-      case NUTS_E_LOG1MEXP: push(I.x, -g / expm1(-val(I.x))); break;
-      case NUTS_E_EXPM1: push(I.x, g * (v + 1.0)); break;
-      case NUTS_E_MAXIMUM: case NUTS_E_MINIMUM: { const double x = val(I.x), y = val(I.y); if (v == x) push(I.x, g); if (v == y) push(I.y, g); } break;
-      case NUTS_E_POW: { const double x = val(I.x), y = val(I.y); push(I.x, g * y * pow(x, y - 1.0)); if (x != 0.0) push(I.y, g * v * log(x)); } break;
-      case NUTS_E_SIN: push(I.x, g * cos(val(I.x))); break;
-      case NUTS_E_COS: push(I.x, -g * sin(val(I.x))); break;
-      case NUTS_E_ARCTAN: { const double x = val(I.x); push(I.x, g / (1.0 + x * x)); } break;
-      case NUTS_E_LOGADDEXP: { const double x = val(I.x), y = val(I.y); push(I.x, g * sigmoid_d(x - y)); push(I.y, g * sigmoid_d(y - x)); } break;
-      case NUTS_E_CLIP: { const double x = val(I.x), y = val(I.y), z = val(I.z); if (x < y) push(I.y, g); else if (x > z) push(I.z, g); else push(I.x, g); } break;
-      case NUTS_E_CHECK: push(I.x, g); break;
-      case NUTS_E_LOG2: push(I.x, g / (val(I.x) * 0.6931471805599453094)); break;
-      case NUTS_E_LOG10: push(I.x, g / (val(I.x) * 2.3025850929940456840)); break;
-      case NUTS_E_DIGAMMA: push(I.x, g * trigamma_d(val(I.x))); break;
+    const int op = I.op;
+    const double x = ((NEED_X >> op) & 1ull) ? val(I.x) : 0.0;
+    const double y = ((NEED_Y >> op) & 1ull) ? val(I.y) : 0.0;
+    const double z = op == NUTS_E_CLIP ? val(I.z) : 0.0;
+    // what each operand receives (the arithmetic of the rules is unchanged: the same expressions, evaluated here, pushed below)
+    double gx = 0.0, gy = 0.0, gz = 0.0;
+    bool px = false, py = false, pz = false;
+    switch (op) {
+      case NUTS_E_ADD: gx = g; gy = g; px = py = true; break;
+      case NUTS_E_SUB: gx = g; gy = -g; px = py = true; break;
+      case NUTS_E_MUL: gx = g * y; gy = g * x; px = py = true; break;
+      case NUTS_E_DIV: gx = g / y; gy = -g * v / y; px = py = true; break;
+      case NUTS_E_NEG: gx = -g; px = true; break;
+      case NUTS_E_EXP: gx = g * v; px = true; break;
+      case NUTS_E_LOG: gx = g / x; px = true; break;
+      case NUTS_E_LOG1P: gx = g / (1.0 + x); px = true; break;
+      case NUTS_E_SIGMOID: gx = g * v * (1.0 - v); px = true; break;
+      case NUTS_E_SOFTPLUS: gx = g * sigmoid_d(x); px = true; break;
+      case NUTS_E_SQRT: gx = g * 0.5 / v; px = true; break;
+      case NUTS_E_SQR: gx = g * 2.0 * x; px = true; break;
+      case NUTS_E_RECIPROCAL: gx = -g * v * v; px = true; break;
+      case NUTS_E_TANH: gx = g * (1.0 - v * v); px = true; break;
+      case NUTS_E_ABS: gx = g * (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0)); px = true; break;
+      case NUTS_E_POWC: gx = g * I.k * pow(x, I.k - 1.0); px = true; break;
+      case NUTS_E_SWITCH: if (x != 0.0) { gy = g; py = true; } else { gz = g; pz = true; } break;
+      case NUTS_E_GAMMALN: gx = g * digamma_d(x); px = true; break;
+      case NUTS_E_ERF: gx = g * 1.1283791670955126 * exp(-x * x); px = true; break;
+      case NUTS_E_ERFC: gx = -g * 1.1283791670955126 * exp(-x * x); px = true; break;
+      case NUTS_E_ERFCX: gx = g * (2.0 * x * v - 1.1283791670955126); px = true; break;
+      case NUTS_E_LOG1MEXP: gx = -g / expm1(-x); px = true; break;
+      case NUTS_E_EXPM1: gx = g * (v + 1.0); px = true; break;
+      case NUTS_E_MAXIMUM: case NUTS_E_MINIMUM: gx = g; gy = g; px = v == x; py = v == y; break;
+      case NUTS_E_POW: gx = g * y * pow(x, y - 1.0); px = true; if (x != 0.0) { gy = g * v * log(x); py = true; } break;
+      case NUTS_E_SIN: gx = g * cos(x); px = true; break;
+      case NUTS_E_COS: gx = -g * sin(x); px = true; break;
+      case NUTS_E_ARCTAN: gx = g / (1.0 + x * x); px = true; break;
+      case NUTS_E_LOGADDEXP: gx = g * sigmoid_d(x - y); gy = g * sigmoid_d(y - x); px = py = true; break;
+      case NUTS_E_CLIP: if (x < y) { gy = g; py = true; } else if (x > z) { gz = g; pz = true; } else { gx = g; px = true; } break;
+      case NUTS_E_CHECK: gx = g; px = true; break;
+      case NUTS_E_LOG2: gx = g / (x * 0.6931471805599453094); px = true; break;
+      case NUTS_E_LOG10: gx = g / (x * 2.3025850929940456840); px = true; break;
+      case NUTS_E_DIGAMMA: gx = g * trigamma_d(x); px = true; break;
       default: break;   // comparisons, logic, sign, floor, ceil: piecewise constant
     }
+    if (px) push(I.x, gx);
+    if (py) push(I.y, gy);
+    if (pz) push(I.z, gz);
   }
   if (gs) for (int sl = 0; sl < ngs; ++sl) pg.adj[gs[sl].adj_off + li] = gadj[sl];
   *gwrt_out = gw;
   return lp;
+}
+__device__ __noinline__ double factor_prog_rev(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int own_var, double own_x,
+                                               int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out, int wrt_did = -1,
+                                               const GSlot* gs = nullptr, int ngs = 0) {
+  double tv[NUTS_MAX_FACTOR_INSTR], ta[NUTS_MAX_FACTOR_INSTR];
+  double gadj[MAX_GSLOTS];
+  return factor_prog_rev_t<double*>(pg, qv, f, fi, li, own_var, own_x, wrt, want_bt, s_bacc, bstride, gwrt_out, wrt_did, gs, ngs, tv, ta, gadj);
+}
+// ... the adjoint sweep with its arrays in LDS (k_gsweep_lds: `tv`, `ta`, `gadj` are this thread's columns)
+__device__ __noinline__ double factor_sweep_lds(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int want_bt, double* s_bacc,
+                                                int bstride, const GSlot* gs, int ngs, LdsVec tv, LdsVec ta, LdsVec gadj) {
+  double gw;
+  return factor_prog_rev_t<LdsVec>(pg, qv, f, fi, li, -1, 0.0, -1, want_bt, s_bacc, bstride, &gw, -1, gs, ngs, tv, ta, gadj);
 }
 
 // total of one long inverse-index list (whole workgroup; `sm`: blockDim.x / 64 doubles); the result is valid in thread 0
@@ -913,25 +1026,31 @@ __device__ __forceinline__ double gadj_long_total(const ModelDev& md, const GLon
 }
 
 // element `e` (in the sweep's numbering) of the factors with gathered adjoints: one forward + reverse sweep, the slots' adjoints stored
-__device__ __forceinline__ void gsweep_element(const Prog& pg, const QView& qv, int e) {
+// ACCOUNT (k_gsweep): returns the element's log-density and credits the factor's broadcast scalars (`s_bacc`) when no variable owns
+// the factor; the single-workgroup kernel keeps walking its orphans itself and passes false
+template <bool ACCOUNT = false>
+__device__ __forceinline__ double gsweep_element(const Prog& pg, const QView& qv, int e, double* s_bacc = nullptr, int bstride = 0) {
   int t = 0;
   while (t + 1 < pg.n_gsf && e >= pg.gsf[t + 1].elem0) ++t;
   const GSweepFactor sf = pg.gsf[t];
   double gw;
-  factor_prog_rev(pg, qv, pg.factors[sf.f], sf.f, e - sf.elem0, -1, 0.0, -1, 0, nullptr, 0, &gw, -1, pg.gslot + sf.slot0, sf.n_slots);
+  const int acct = ACCOUNT && sf.orphan;
+  const double lp = factor_prog_rev(pg, qv, pg.factors[sf.f], sf.f, e - sf.elem0, -1, 0.0, -1, acct, s_bacc, bstride, &gw, -1, pg.gslot + sf.slot0, sf.n_slots);
+  return acct ? lp : 0.0;
+}
+
+template <bool ACCOUNT>
+__device__ __forceinline__ double gsweep_element_lds(const Prog& pg, const QView& qv, int e, double* s_bacc, int bstride, LdsVec tv, LdsVec ta, LdsVec gadj) {
+  int t = 0;
+  while (t + 1 < pg.n_gsf && e >= pg.gsf[t + 1].elem0) ++t;
+  const GSweepFactor sf = pg.gsf[t];
+  const int acct = ACCOUNT && sf.orphan;
+  const double lp = factor_sweep_lds(pg, qv, pg.factors[sf.f], sf.f, e - sf.elem0, acct, s_bacc, bstride, pg.gslot + sf.slot0, sf.n_slots, tv, ta, gadj);
+  return acct ? lp : 0.0;
 }
 
 __device__ __forceinline__ double dot4(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
-// (selects, not d[arg]: a run-time index into the four-entry arrays put all of them in scratch -- 144 B in every kernel that evaluates
-// factors, VERDICT r02)
-// (bit masks rather than a select chain: selects between loads of one array are folded back into an indexed load)
-__device__ __forceinline__ double pick4(const double* v, int i) {
-  unsigned long long r = 0ull;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) r |= (unsigned long long)__double_as_longlong(v[k]) & (0ull - (unsigned long long)(i == k || (k == 3 && i > 3)));
-  return __longlong_as_double((long long)r);
-}
 __device__ __forceinline__ double slot_grad(const double* d, const double* bv, const double* cv, int arg, int slot) {
   const double dd = pick4(d, arg);
   return slot == 0 ? dd : (slot == 1 ? dd * pick4(cv, arg) : dd * pick4(bv, arg));
@@ -977,7 +1096,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
       if (cb.p[2] != 0.0) {   // the factor's elements have been swept (k_gsweep): their adjoints of this (variable, index vector) pair
         if (cb.p[3] >= 0.0) {   // ... and some of this variable's lists are long: totalled by k_gadj_reduce (csr: per element, the entry or -1)
           const int lg_ = (pg.csr + (int64_t)cb.p[3])[li];
-          if (lg_ >= 0) { gx += pg.adj_red[lg_]; continue; }
+          if (lg_ >= 0) { gx += sum_strided(pg.adj_red + lg_, 1, 0, pg.glong[lg_].nchunk); continue; }   // (the chunks' totals, in order)
         }
         const double* adj = pg.adj + (int64_t)cb.p[1];
         const int t1 = ptr[li + 1];
@@ -1007,7 +1126,7 @@ __device__ __forceinline__ void gather_element(const Prog& pg, const QView& qv, 
     }
     double d[4], bv[4], cv[4];
     int pdead = 0;
-    double lpf = factor_eval<DEFQ, OL>(pg, qv, f, li, k, x, d, bv, cv, &pdead);
+    double lpf = factor_eval<DEFQ, OL, PROG>(pg, qv, f, li, k, x, d, bv, cv, &pdead);
     factor_kill(pg, cb.f, pdead, lpf, d);
     gx += slot_grad(d, bv, cv, cb.arg, cb.slot);
     if (cb.owner) {
@@ -1030,7 +1149,7 @@ __device__ __forceinline__ double orphan_element(const Prog& pg, const QView& qv
   }
   double dv[4], bv[4], cv[4];
   int pdead = 0;
-  double lpo = factor_eval<DEFQ, OL>(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
+  double lpo = factor_eval<DEFQ, OL, PROG>(pg, qv, f, li, -1, 0.0, dv, bv, cv, &pdead);
   factor_kill(pg, fi, pdead, lpo, dv);
   for (int b = 0; b < bt.n; ++b) s_bacc[bt.e[b].bterm * bstride] += slot_grad(dv, bv, cv, bt.e[b].arg, bt.e[b].slot);
   return lpo;

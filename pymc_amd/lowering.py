@@ -404,6 +404,10 @@ def build_tree(v, memo: Optional[dict] = None):
         sa, sb = (_eff_shape(ins[0]), _eff_shape(ins[1])) if memo.get("__shapes__") else (None, None)
         if a[0] == "const" and b[0] == "const":
             out = _const(np.asarray(a[1]) @ np.asarray(b[1]))
+        elif a[0] == "const" and np.asarray(a[1]).ndim == 2 and np.asarray(a[1]).shape[0] >= LIN_MIN_ROWS:
+            # a tall constant design matrix: the product stays a node -- the GLM node for its three likelihoods, a linear predictor
+            # (dense node 5, include/nuts_mi355.h) inside any other argument
+            out = ("dot", a, b)
         elif sa is not None and sb is not None and 1 <= len(sa) <= 2 and 1 <= len(sb) <= 2 and sa[-1] == sb[0] and sa[-1] <= MAX_DOT_INNER:
             out = _written_out_dot(a, b, sa, sb)
         else:
@@ -472,6 +476,7 @@ def _ldlt_factor(v):
 
 
 MAX_DOT_INNER = 32     # (the inner dimension of a `Dot` that is written out term by term: the limit of the unrolled reductions)
+LIN_MIN_ROWS = 1024    # (a constant [N, P] matrix with this many rows or more is never written out: its product is a linear predictor)
 
 
 def _eff_shape(v):
@@ -1064,7 +1069,65 @@ class _Lowering:
                     return k
         return None
 
+    def _lin_operand(self, node) -> Optional[ms.Operand]:
+        """`dot(X, b)` with X a constant matrix: a linear predictor (dense node 5, include/nuts_mi355.h `nuts_lin`) read through an
+        OP_LIN operand.  b a value variable (its constrained value): the K columns of one predictor set share X; b an expression of
+        the variables: a derived vector (D_DERIVED) is the coefficient vector.  `dotcol`: column `node[3]` of X @ B."""
+        if node[1][0] != "const" or np.asarray(node[1][1]).ndim != 2:
+            return None
+        X = np.ascontiguousarray(np.asarray(node[1][1], dtype="float64"))
+        N, P = X.shape
+        nb = self._tsize(node[2])
+        if nb % P != 0 or not 1 <= nb // P <= ms.LIN_MAXK:
+            return None
+        K = nb // P
+        col = int(node[3]) if node[0] == "dotcol" else 0
+        if node[0] == "dot" and K != 1:
+            return None          # (a whole [N, K] product is no operand: its columns are, once an index reaches them)
+        if N > 1 and (P > ms.LIN_MAXP or K * P > 4096):
+            raise NotLowerable(f"a matrix product with {P} x {K} coefficients inside an argument (P <= {ms.LIN_MAXP}, K P <= 4096): {_show(node)}")
+        if self.spec.logit_rows is not None or self.spec.mixture_rows is not None or self.spec.glm_rows is not None:
+            raise NotLowerable("a matrix product inside an argument next to the logit rows, a mixture or a GLM likelihood")
+        kv = self._as_var(node[2])
+        xkey = (X.shape, hash(X.tobytes()))
+        if kv is not None:
+            key = ("lin", xkey, kv)
+            if key not in self._lin_ids:
+                if len(self.spec.lins) >= ms.MAX_LINS:
+                    raise NotLowerable(f"more than {ms.MAX_LINS} matrix products inside arguments")
+                self.spec.lins.append(ms.LinPredictors(X, []))
+                self._lin_ids[key] = len(self.spec.lins) - 1
+            lid = self._lin_ids[key]
+            L = self.spec.lins[lid]
+            want = (kv, col, K)      # column `col` of the [P, K] variable (row-major): offset col, stride K
+            if want not in L.cols:
+                L.cols.append(want)
+            return ms.Operand(ms.OP_LIN, float(L.cols.index(want)), lid)
+        # coefficients that are an expression: a derived vector with a program of its own
+        if K != 1:
+            raise NotLowerable(f"a matrix product with a matrix-valued EXPRESSION inside an argument: {_show(node)}")
+        key = ("lin", xkey, id(node[2]))
+        hit = self._lin_ids.get(key)
+        if hit is not None and hit[1] is node[2]:
+            return ms.Operand(ms.OP_LIN, 0.0, hit[0])
+        if len(self.spec.lins) >= ms.MAX_LINS or sum(f.dist == ms.D_DERIVED for f in self.spec.factors) >= ms.MAX_DERIVED:
+            raise NotLowerable("too many matrix products / derived vectors inside arguments")
+        saved = (self._prog, self._prog_size, self._prog_memo, self._prog_cse, self._fsize)
+        self._prog, self._prog_size, self._prog_memo, self._prog_cse, self._fsize = [], [], {}, {}, P
+        try:
+            bt = self.term(node[2])
+            if self._size(bt) != P:
+                raise NotLowerable(f"the coefficients of a matrix product do not have one element per column: {_show(node)}")
+            self.spec.factors.append(ms.Factor(ms.D_DERIVED, P, (bt,), 0.0, f"lin{len(self.spec.lins)}_coef", tuple(self._prog)))
+        finally:
+            self._prog, self._prog_size, self._prog_memo, self._prog_cse, self._fsize = saved
+        self.spec.lins.append(ms.LinPredictors(X, [(-(len(self.spec.factors) - 1) - 1, 0, 1)]))
+        self._lin_ids[key] = (len(self.spec.lins) - 1, node[2])
+        return ms.Operand(ms.OP_LIN, 0.0, len(self.spec.lins) - 1)
+
     def _operand(self, node) -> Optional[ms.Operand]:
+        if node[0] in ("dot", "dotcol"):
+            return self._lin_operand(node)
         k = self._as_var(node)
         if k is not None:
             return ms.Operand(ms.OP_VAR, 0.0, k)
@@ -1298,6 +1361,11 @@ class _Lowering:
             return 1
         if k == "take_along_axis":
             return self._tsize(node[2])
+        if k == "dot" and node[1][0] == "const" and np.asarray(node[1][1]).ndim == 2:
+            N_, P_ = np.asarray(node[1][1]).shape
+            return N_ * max(self._tsize(node[2]) // P_, 1)
+        if k == "dotcol":
+            return int(np.asarray(node[1][1]).shape[0])
         if k in ("all", "any") and len(node) == 4 and node[3] is not None:
             node = (k, node[2], node[1], node[3])
             k = "sum"
@@ -1349,6 +1417,17 @@ class _Lowering:
             return ("joinnd", piece_of[idx], (np.arange(int(starts[-1])) - starts[piece_of])[idx], (len(idx),), *node[2:])
         if k == "take_along_axis" and len(node) == 4:
             return self._index(self._select_chain(node), idx)
+        if k in ("dot", "dotcol") and node[1][0] == "const" and np.asarray(node[1][1]).ndim == 2:
+            # elements of `X @ B` ([N, K], raveled): ONE column k at rows r -- the linear predictor X[r] @ B[:, k]
+            X_ = np.asarray(node[1][1], dtype="float64")
+            K_ = 1 if k == "dotcol" else max(self._tsize(node[2]) // X_.shape[1], 1)
+            idx = np.asarray(idx, dtype=np.int64)
+            rows, cols = idx // K_, idx % K_
+            if len(np.unique(cols)) != 1:
+                raise NotLowerable(f"an index into a matrix product that mixes its columns: {_show(node)}")
+            col = int(node[3]) if k == "dotcol" else int(cols[0])
+            Xr = X_ if np.array_equal(rows, np.arange(X_.shape[0])) else X_[rows]
+            return ("dotcol", ("const", Xr), node[2], col)
         if k == "joinnd":
             idx = np.asarray(idx, dtype=np.int64)
             which = np.unique(node[1][idx])
@@ -1396,6 +1475,15 @@ class _Lowering:
                 raise NotLowerable(f"a reduction over several axes inside an expression: {_show(node)}")
         else:
             a = axes[0]
+            if shp[a] > self.MAX_UNROLLED_SUM and kind == "sum" and len(shp) == 1:
+                # `pt.sum(x)` over a long vector: a linear predictor with ONE row (X = ones; a constant factor of the summand moves into X)
+                w, kid_ = np.ones(shp[0]), kid
+                if kid[0] == "mul":
+                    for x_, y_ in ((kid[1], kid[2]), (kid[2], kid[1])):
+                        if x_[0] == "const" and np.asarray(x_[1]).size in (1, shp[0]):
+                            w, kid_ = np.broadcast_to(np.asarray(x_[1], dtype="float64").reshape(-1), (shp[0],)).copy(), y_
+                            break
+                return ("dotcol", ("const", w[None, :]), kid_, 0)
             if shp[a] > self.MAX_UNROLLED_SUM:
                 raise NotLowerable(f"a reduction over {shp[a]} elements inside an expression (a mat-vec: the dense nodes take `pm.math.dot`): {_show(node)}")
             pos = np.arange(_numel(shp)).reshape(shp)
@@ -1892,13 +1980,27 @@ class _Lowering:
 
     _prog = None
     _gather_ids: Dict[Any, int] = {}
+    _lin_ids: Dict[Any, Any] = {}
+
+    def _lin_mark(self):
+        return [len(L.cols) for L in self.spec.lins]
+
+    def _lin_rollback(self, mark):
+        """Linear predictors registered by an attempt that is being abandoned (`factor` retries op by op) go with its data vectors."""
+        del self.spec.lins[len(mark):]
+        for L, nc in zip(self.spec.lins, mark):
+            del L.cols[nc:]
+        self._lin_ids = {k: v for k, v in self._lin_ids.items() if (v[0] if isinstance(v, tuple) else v) < len(mark)}
 
     def factor(self, node, name: str, own_value=None, graph=None):
         if "_gather_ids" not in self.__dict__:
             self._gather_ids = {}
+        if "_lin_ids" not in self.__dict__:
+            self._lin_ids = {}
         self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
         self._graph, self._name_now = graph, name
         n_data, n_fac = len(self.spec.data), len(self.spec.factors)
+        lin_mark = self._lin_mark()
         try:
             try:
                 if node is None:
@@ -1913,6 +2015,7 @@ class _Lowering:
                 del self.spec.data[n_data:]
                 del self.spec.factors[n_fac:]
                 self._gather_ids = {k: v for k, v in self._gather_ids.items() if v < n_data}
+                self._lin_rollback(lin_mark)
                 self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
                 try:
                     self._general(node, name, own)
@@ -2136,6 +2239,7 @@ class _Lowering:
         `pm.OrderedProbit`) become a factor of their own, `check(0, conds)`: 0 where they hold, -inf where they fail, which is what they
         add to the density either way."""
         n_data, n_fac = len(self.spec.data), len(self.spec.factors)
+        lin_mark = self._lin_mark()
         try:
             self._general_tree_one(node, name, own, piece)
             return
@@ -2154,6 +2258,7 @@ class _Lowering:
             del self.spec.data[n_data:]
             del self.spec.factors[n_fac:]
             self._gather_ids = {k: v for k, v in self._gather_ids.items() if v < n_data}
+            self._lin_rollback(lin_mark)
             try:
                 self._prog, self._prog_size, self._prog_memo, self._prog_cse = [], [], {}, {}
                 self._general_tree_one(node[1], name, own, True)
@@ -2341,6 +2446,8 @@ def lower_to_spec(model, vars=None) -> ms.ModelSpec:
         low._prog, low._prog_size, low._prog_memo, low._prog_cse = [], [], {}, {}
         if "_gather_ids" not in low.__dict__:
             low._gather_ids = {}
+        if "_lin_ids" not in low.__dict__:
+            low._lin_ids = {}
         try:
             try:
                 t = low.term(build_tree(var, memo))

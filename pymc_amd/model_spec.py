@@ -36,6 +36,7 @@ TRANSFORM_NAMES = {TR_NONE: None, TR_LOG: "log", TR_LOGODDS: "logodds", TR_INTER
 
 # operand kinds
 OP_CONST, OP_DATA, OP_VAR, OP_TMP, OP_GATHER = 0, 1, 2, 3, 4   # OP_GATHER: var[idx[i]], `c` = id of the index data vector
+OP_LIN = 5   # element i of column int(c) of linear predictor `ref` (ModelSpec.lins): eta = X @ coefficients
 
 # expression-program opcodes (must match include/nuts_mi355.h NUTS_E_*)
 (E_ADD, E_SUB, E_MUL, E_DIV, E_NEG, E_EXP, E_LOG, E_LOG1P, E_SIGMOID, E_SOFTPLUS, E_SQRT, E_SQR, E_RECIPROCAL, E_TANH, E_ABS, E_POWC,
@@ -252,6 +253,25 @@ class GlmRows:
     beta_derived: Optional[int] = None   # index (into ModelSpec.factors) of the D_DERIVED factor that is beta
 
 
+LIN_MAXK, MAX_LINS, LIN_MAXP = 16, 4, 512
+
+
+@dataclass
+class LinPredictors:
+    """K linear predictors that share one constant matrix X [N, P]: eta_k = X @ coef_k (`pm.math.dot(X, beta)`, pymc/math.py:56),
+    read by any factor through OP_LIN operands (include/nuts_mi355.h, dense node 5).  `cols[k] = (var, off, stride)`: coefficient p of
+    column k is the CONSTRAINED value of element off + p * stride of variable `var` (var >= 0), or that element of the D_DERIVED
+    factor -(var + 1).  N == 1: a weighted sum over a long axis (`pt.sum(x)`: X = ones), which broadcasts against any factor."""
+
+    X: np.ndarray
+    cols: List[Tuple[int, int, int]] = field(default_factory=list)
+
+    def coef_index(self, spec: "ModelSpec", k: int) -> np.ndarray:
+        """Indices of column k's coefficients in the raveled vector (variables only)."""
+        var, off, stride = self.cols[k]
+        return spec.vars[var].offset + off + stride * np.arange(self.X.shape[1])
+
+
 @dataclass
 class ModelSpec:
     vars: List[FreeVar] = field(default_factory=list)
@@ -261,6 +281,7 @@ class ModelSpec:
     mvnormal: Optional[MvNormalNode] = None
     mixture_rows: Optional[MixtureRows] = None
     glm_rows: Optional[GlmRows] = None
+    lins: List[LinPredictors] = field(default_factory=list)
     # "extra" inputs of the log-density (model/core.py:142-190 `extra_vars_and_values`): name -> index into `data`;
     # the caller rewrites them through `set_extra_values` (value variables sampled by another step method)
     extra: Dict[str, int] = field(default_factory=dict)
@@ -515,6 +536,16 @@ def engine_refusal(spec: "ModelSpec") -> Optional[str]:
                     return "gather: one index per element of the factor"
                 if np.any(idx != np.floor(idx)) or np.any(idx < 0) or np.any(idx >= spec.vars[o.ref].size):
                     return "gather index out of range for its variable"
+            elif o.kind == OP_LIN:
+                lins = getattr(spec, "lins", [])
+                if not 0 <= o.ref < len(lins):
+                    return "operand refers to a missing linear predictor"
+                if not 0 <= int(o.c) < len(lins[o.ref].cols) or float(int(o.c)) != float(o.c):
+                    return "operand refers to a missing column of a linear predictor"
+                if lins[o.ref].X.shape[0] not in (1, f.size):
+                    return "linear predictor: one row per element of the factor (or a single row that broadcasts)"
+                if f.dist == D_DERIVED:
+                    return "a derived vector cannot read a linear predictor"
             elif o.kind == OP_DATA:
                 if not 0 <= o.ref < nd:
                     return "factor refers to a missing data vector"
@@ -540,6 +571,24 @@ def engine_refusal(spec: "ModelSpec") -> Optional[str]:
                     return "too many scalar operands in one factor (MAX_FACTOR_BT)"
     if deferred > MAX_DEFERRED:
         return "too many scalar / hyper-parameter elements (MAX_DEFERRED)"
+    lins = getattr(spec, "lins", [])
+    if len(lins) > MAX_LINS:
+        return "bad number of linear predictors (NUTS_MAX_LINS)"
+    if lins and (spec.logit_rows is not None or getattr(spec, "mixture_rows", None) is not None or getattr(spec, "glm_rows", None) is not None):
+        return "linear predictors are not combined with the logit-rows, mixture or GLM node"
+    for L in lins:
+        N, P = L.X.shape
+        K = len(L.cols)
+        if N < 1 or P < 1 or not 1 <= K <= LIN_MAXK:
+            return "linear predictor with bad dimensions"
+        if N > 1 and (P > LIN_MAXP or K * P > 4096):
+            return "linear predictor: P <= 512 and K P <= 4096 for predictors with more than one row"
+        for var, off, stride in L.cols:
+            size = spec.vars[var].size if 0 <= var < nv else (spec.factors[-(var + 1)].size if var < 0 and -(var + 1) < len(spec.factors) and spec.factors[-(var + 1)].dist == D_DERIVED else -1)
+            if size < 0:
+                return "linear predictor: coefficients must be a variable or a NUTS_D_DERIVED factor"
+            if off < 0 or stride < 0 or (stride == 0 and P > 1) or off + (P - 1) * stride >= size:
+                return "linear predictor: coefficients beyond the end of their variable"
     return None
 
 
@@ -556,6 +605,12 @@ def eval_program(spec: "ModelSpec", prog, term: Term, x: np.ndarray) -> np.ndarr
             return d if d.size > 1 else d.reshape(())
         if o.kind == OP_TMP:
             return tmp[o.ref]
+        if o.kind == OP_LIN:
+            L = spec.lins[o.ref]
+            if L.cols[int(o.c)][0] < 0:
+                raise NotImplementedError("a Deterministic over a linear predictor whose coefficients are a derived vector")
+            eta = x[..., L.coef_index(spec, int(o.c))] @ L.X.T
+            return eta if L.X.shape[0] > 1 else (eta[..., 0:1] if x.ndim > 1 else eta.reshape(()))
         v = spec.vars[o.ref]
         if o.kind == OP_GATHER:
             return x[..., v.offset + spec.data[int(o.c)].astype(np.int64)]
@@ -659,6 +714,39 @@ class ModelBuilder:
             return Expr(self, Term(Operand(OP_CONST, float(arr.reshape(-1)[0]))), 1)
         self.spec.data.append(np.ascontiguousarray(arr.ravel()))
         return Expr(self, Term(Operand(OP_DATA, 0.0, len(self.spec.data) - 1)), arr.size)
+
+    def dot(self, X, beta):
+        """`pm.math.dot(X, beta)` (pymc/math.py:56) for a constant matrix X [N, P] and a free variable `beta` of shape (P,) -- one
+        predictor, an expression of N elements -- or (P, K): the K columns of `X @ beta` as a list of expressions.  Usable inside
+        any argument of any factor (dense node 5, include/nuts_mi355.h)."""
+        X = np.ascontiguousarray(np.asarray(X, dtype="float64"))
+        if X.ndim == 1:
+            X = X[None, :]
+        beta = self.as_expr(beta)
+        N, P = X.shape
+        s_ = beta._simple()
+        if s_ is None or s_.kind != OP_VAR:    # coefficients that are an expression of the variables: a derived vector (D_DERIVED)
+            if beta.size != P:
+                raise ValueError(f"dot: X is {X.shape}, beta has {beta.size} elements")
+            terms, prog = self._lower_args([beta])
+            self.spec.factors.append(Factor(D_DERIVED, P, terms, 0.0, f"lin{len(self.spec.lins)}_coef", prog))
+            self.spec.lins.append(LinPredictors(X, [(-(len(self.spec.factors) - 1) - 1, 0, 1)]))
+            return Expr(self, Term(Operand(OP_LIN, 0.0, len(self.spec.lins) - 1)), N)
+        v = self.spec.vars[s_.ref]
+        shp = tuple(v.shape) or (1,)
+        if shp[0] != P or len(shp) > 2:
+            raise ValueError(f"dot: X is {X.shape}, beta is {shp}")
+        K = shp[1] if len(shp) == 2 else 1
+        cols = [(s_.ref, k, K) for k in range(K)] if len(shp) == 2 else [(s_.ref, 0, 1)]
+        self.spec.lins.append(LinPredictors(X, cols))
+        lid = len(self.spec.lins) - 1
+        out = [Expr(self, Term(Operand(OP_LIN, float(k), lid)), N) for k in range(K)]
+        return out if len(shp) == 2 else out[0]
+
+    def sum(self, x):
+        """`pt.sum(x)` of a free vector variable over its (long) axis: a one-row predictor with X = ones."""
+        e = self.as_expr(x)
+        return self.dot(np.ones((1, e.size)), e)
 
     def Extra(self, name, value) -> Expr:
         """A non-gradient input of the log-density (an `extra_var` of `ValueGradFunction`, model/core.py:142-190):

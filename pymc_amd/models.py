@@ -316,12 +316,14 @@ def glm(N: int = 1_000_000, P: int = 512, family: str = "normal", batch_size: in
     return GLMSpec(X, y, family, sigma, prior_sd, batch_size)
 
 
-def softmax_regression(N: int = 100_000, P: int = 4, K: int = 3, seed: int = DATA_SEED) -> ModelSpec:
+def softmax_regression(N: int = 100_000, P: int = 4, K: int = 3, seed: int = DATA_SEED, lin: bool = False) -> ModelSpec:
     """Multinomial logistic regression with a [P, K] coefficient matrix, written the way the lowering writes `softmax(X @ B + a)` under a
     Categorical likelihood (`pm.math.dot` over a short inner dimension written out, the K logits joined by a logaddexp chain:
     pymc/math.py `softmax` / `logsumexp`, distributions/discrete.py:1173-1205): every coefficient is read by EVERY row through an index
     vector that is constant -- (P + 1) K gathers in one N-element factor.  The shape the gathered-adjoint sweep exists for
-    (csrc/model_dev.h GSlot): one forward + reverse sweep per row instead of one per (coefficient, row)."""
+    (csrc/model_dev.h GSlot): one forward + reverse sweep per row instead of one per (coefficient, row).
+    `lin=True`: the same model with `X @ B` as K linear predictors (dense node 5, csrc/lin_kernel.h): the mat-vec and its transpose
+    are kernels of their own, the rows' program only joins the K logits -- any P <= 512 instead of (P + 1) K <= 64 gathers."""
     rng = np.random.default_rng(seed)
     X = rng.normal(size=(N, P))
     B0 = rng.normal(size=(P, K)) * 1.2
@@ -334,7 +336,10 @@ def softmax_regression(N: int = 100_000, P: int = 4, K: int = 3, seed: int = DAT
     B = m.Normal("B", 0.0, 2.0, shape=(P, K))
     a = m.Normal("a", 0.0, 2.0, shape=(K,))
     etas = []
-    for k in range(K):
+    if lin:
+        xb = m.dot(X, B)
+        etas = [xb[k] + a[np.full(N, k)] for k in range(K)]
+    for k in range(0 if lin else K):
         e = a[np.full(N, k)]
         for p in range(P):
             e = e + m.as_expr(X[:, p]) * B[np.full(N, p * K + k)]

@@ -123,6 +123,19 @@ def _pack(spec: ModelSpec, rows_group_aligned: bool = True):
         s.glm_sigma = -1 if gl.sigma is None else gl.sigma
         s.glm_sigma_const = float(gl.sigma_const)
         s.glm_X, s.glm_y = _lib.dptr(X), _lib.dptr(y)
+    lins = getattr(spec, "lins", None) or []
+    if lins:
+        lins_c = (_lib.Lin * len(lins))()
+        for i, L in enumerate(lins):
+            X = np.ascontiguousarray(L.X, dtype="float64")
+            keep.append(X)
+            lins_c[i].N, lins_c[i].P = X.shape
+            lins_c[i].K = len(L.cols)
+            lins_c[i].X = _lib.dptr(X)
+            for k, (var, off_, stride) in enumerate(L.cols[:16]):
+                lins_c[i].var[k], lins_c[i].off[k], lins_c[i].stride[k] = var, off_, stride
+        keep.append(lins_c)
+        s.n_lins, s.lins = len(lins), lins_c
     return s, keep
 
 

@@ -54,7 +54,7 @@ def test_struct_layouts_match_the_c_header(tmp_path):
     structs = {
         "nuts_operand": _lib.Operand, "nuts_term": _lib.Term, "nuts_instr": _lib.Instr, "nuts_factor": _lib.Factor, "nuts_var": _lib.Var,
         "nuts_data_ref": _lib.DataRef, "nuts_model_spec": _lib.ModelSpecC, "nuts_chain_config": _lib.ChainConfig,
-        "nuts_draw_stats": _lib.DrawStats, "nuts_hmc_stats": _lib.HmcStats,
+        "nuts_draw_stats": _lib.DrawStats, "nuts_hmc_stats": _lib.HmcStats, "nuts_lin": _lib.Lin,
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, cls in structs.items():
@@ -134,7 +134,9 @@ def test_streaming_kernels_hold_their_tiles_in_registers(lib, tmp_path):
     assert len(ga) >= 8, sorted(kernels)[:10]
     # the group-block pass (rows_gb_kernel.h) uses ordinary loads; it is held to the same bar because a spill inside its short
     # per-group loop would cost more than the loop itself (`k_vector`, which it replaces at C2-S, carries 144 B of scratch)
-    gb = {k: v for k, v in kernels.items() if re.match(r"_Z\d+k_rows_gb", k)}
+    # (of the merged launch `k_rows_gb_multi` the default register budget only: the 128- / 80-register instantiations exist for the
+    # A/B that showed their spills cost more than the rounds they save)
+    gb = {k: v for k, v in kernels.items() if re.match(r"_Z\d+k_rows_gbI", k) or re.match(r"_Z\d+k_rows_gb_multiILi\d+ELi\d+ELi2EE", k)}
     assert len(gb) >= 4, sorted(kernels)[:10]
     for name, (spills, scratch) in gb.items():
         assert spills == 0, (name, spills, scratch)

@@ -103,12 +103,27 @@ def test_what_the_ir_cannot_express_is_refused_by_name():
     m.Normal("y", a ** b, 1.0, observed=np.zeros(4))           # a power with a VARIABLE exponent: refused until round 5, now x ** y of the
     spec = lower_to_spec(m)                                    # expression programs (NUTS_E_POW; tests/test_general_lowering.py)
     assert [i.op for i in spec.factors[-1].prog] == [ms_mod.E_POW]
-    # what is still refused, by name: a reduction over a long axis inside an argument (a mat-vec that is not `pm.math.dot(X, beta)` with a
-    # constant X: the dense nodes' business), a Cholesky of a non-constant matrix
+    # a reduction over a long axis of a VECTOR inside an argument -- refused by name until round 6 -- is a one-row linear predictor now
+    # (include/nuts_mi355.h `nuts_lin`): `(zb * wb).sum()` = ones @ (zb * wb), the summand a derived vector
+    import graph_torch as gt
+
     m = sg.StubModel()
     zb = m.Normal("zb", 0.0, 1.0, shape=(40,))
     wb = m.Normal("wb", 0.0, 1.0, shape=(40,))
     m.Normal("y", (zb * wb).sum(), 1.0, observed=np.zeros(1))
+    spec = lower_to_spec(m)
+    (L,) = spec.lins
+    assert L.X.shape == (1, 40) and L.cols[0][0] < 0 and spec.factors[-(L.cols[0][0] + 1)].dist == ms_mod.D_DERIVED
+    q = np.random.default_rng(2).normal(size=spec.n)
+    lp, g = ref_models.evaluate(spec, q)
+    lp0, g0 = gt.joint_logp_grad(m, q)
+    assert abs(lp - lp0) <= 1e-11 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-11 * np.max(np.abs(g0))
+    # what is still refused, by name: a reduction over a long axis of a MATRIX-shaped expression (a mat-vec that is not
+    # `pm.math.dot(X, beta)` with a constant X), a Cholesky of a non-constant matrix
+    m = sg.StubModel()
+    zb = m.Normal("zb", 0.0, 1.0, shape=(3, 40))
+    wb = m.Normal("wb", 0.0, 1.0, shape=(40,))
+    m.Normal("y", (zb * wb[None, :]).sum(axis=1), 1.0, observed=np.zeros(3))
     with pytest.raises(NotLowerable, match="reduction over 40 elements"):
         lower_to_spec(m)
 
