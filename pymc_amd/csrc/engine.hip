@@ -143,6 +143,13 @@ struct nuts_model {
   struct LinUse { int64_t adj_off; int32_t size; };
   std::vector<std::vector<std::vector<LinUse>>> lin_uses;
   std::vector<LinDev> lins_host;
+  // what the resolved-operand sweep's tables are built from (build_sweep_fast): compile_spec's sweep lists, the data table with the
+  // derived vectors behind the spec's, the broadcast terms
+  std::vector<GSweepFactor> gsf_host;
+  std::vector<GSlot> gslots_host;
+  std::vector<nuts_data_ref> drefs_host;
+  std::vector<FactorBT> fbt_host;
+  std::vector<int32_t> bterm_var_host;
 
   template <typename T>
   T* keep(T* p) {
@@ -487,11 +494,14 @@ static void launch_vector(nuts_model* m, const ArenaDev& A, const EvalIO& io, in
   }
   // gathered adjoints (model_dev.h GSlot): every element of the factors that read variables through index vectors is swept once,
   // before the kernels whose gathers add the results up (B and C below; the dense node's seed of a derived vector is already there)
-  if (md.n_gsf > 0)
-    if (md.gs_lds_rows > 0)
+  if (md.n_gsf > 0) {
+    if (md.n_swf > 0)
+      hipLaunchKernelGGL(k_gsweep_fast, dim3(md.n_gs_blocks), dim3(GSL_THREADS), (size_t)md.sw_rows * GSL_THREADS * sizeof(double), m->stream, md, A, io, j);
+    else if (md.gs_lds_rows > 0)
       hipLaunchKernelGGL(k_gsweep_lds, dim3(md.n_gs_blocks), dim3(GSL_THREADS), (size_t)md.gs_lds_bytes, m->stream, md, A, io, j);
     else
       hipLaunchKernelGGL(k_gsweep, dim3(md.n_gs_blocks), dim3(256), 0, m->stream, md, A, io, j);
+  }
   if (md.n_glong > 0) hipLaunchKernelGGL(k_gadj_reduce, dim3(md.n_glong), dim3(256), 0, m->stream, md, A, io);
   // ... and the predictors' adjoints go back to the coefficients: X^T adj in row chunks, then every coefficient adds its partials up
   if (md.n_lins > 0) {
@@ -1154,6 +1164,124 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     hipMemset(md.gs_part, 0, (size_t)md.n_gs_blocks * (1 + MAX_BTERMS) * sizeof(double));
   }
   md.prog = m->keep(dev_upload(blob.data(), blob.size()));
+  m->gsf_host = gsf; m->gslots_host = gslots; m->drefs_host = drefs; m->fbt_host = fbt; m->bterm_var_host = bterm_var;
+  return true;
+}
+
+// The adjoint sweep with resolved operands (model_dev.h SwFactor, kernels.h k_gsweep_fast): every distinct leaf operand of a swept
+// factor becomes an entry of the factor's leaf list -- what to load from where, as a pointer --, the programs and arguments are
+// rewritten to refer to those entries, and the slots' adjoint offsets sit in a table of their own.  Runs once the data pool and the
+// predictors' buffers exist.  The kernel reads the tables through the scalar unit (constant address space), one wave per 64-element
+// block of ONE factor (SwFactor.blk0); taken whenever a thread's LDS column fits (NUTS_GSWEEP_FAST = 0: the generic sweeps).
+static bool build_sweep_fast(nuts_model* m, const nuts_model_spec* s, const std::vector<VarDev>& vars) {
+  ModelDev& md = m->md;
+  md.n_swf = 0; md.sw_bytes = 0; md.sw_rows = 0; md.sw_blob = nullptr;
+  const int opt = env_int("NUTS_GSWEEP_FAST", 1);
+  if (m->gsf_host.empty() || opt == 0 || !md.pool) return true;
+  std::vector<SwFactor> swf;
+  std::vector<SwLeaf> leaves;
+  std::vector<nuts_instr> instrs;
+  std::vector<int64_t> slot_off;
+  int max_leaves = 1, max_slots = 1, max_instr = 1;
+  for (const GSweepFactor& g : m->gsf_host) {
+    const nuts_factor& f = s->factors[g.f];
+    SwFactor F{};
+    F.f = g.f; F.elem0 = g.elem0; F.size = f.size; F.orphan = g.orphan;
+    F.n_instr = f.n_instr; F.nargs = f.nargs; F.dist = f.dist; F.konst = f.konst;
+    F.slot0 = (int32_t)slot_off.size(); F.n_slots = g.n_slots;
+    for (int sl = 0; sl < g.n_slots; ++sl) slot_off.push_back(m->gslots_host[g.slot0 + sl].adj_off);
+    struct Key { int kind, ref, did; };
+    std::vector<Key> keys;          // leaves in order of first use
+    std::vector<SwLeaf> lf;
+    std::vector<int> push_to;       // per leaf: >= 0 slot, <= -2 broadcast accumulator, -1 nothing
+    auto leaf_of = [&](const nuts_operand& o) -> int {
+      const int did = (o.kind == NUTS_OP_GATHER || o.kind == NUTS_OP_LIN) ? (int)o.c : 0;
+      for (size_t i = 0; i < keys.size(); ++i) if (keys[i].kind == o.kind && keys[i].ref == o.ref && keys[i].did == did) return (int)i;
+      SwLeaf L{};
+      int pt = -1;
+      if (o.kind == NUTS_OP_DATA) {
+        const nuts_data_ref r = m->drefs_host[o.ref];
+        L.kind = SWL_DATA; L.bcast = r.size > 1 ? 0 : 1; L.ptr = md.pool + r.offset;
+      } else if (o.kind == NUTS_OP_LIN) {
+        const LinDev& D = m->lins_host[o.ref];
+        L.kind = SWL_DATA; L.bcast = D.N > 1 ? 0 : 1; L.ptr = D.eta + (int64_t)did * D.N;
+        for (int sl = 0; sl < g.n_slots; ++sl) { const GSlot& gs = m->gslots_host[g.slot0 + sl]; if (gs.var == -1 - o.ref && gs.did == did) { pt = sl; break; } }
+      } else if (o.kind == NUTS_OP_GATHER) {
+        const nuts_data_ref r = m->drefs_host[did];
+        const VarDev& v = vars[o.ref];
+        L.kind = SWL_GATHER; L.bcast = 0; L.ptr = md.pool + r.offset; L.voff = v.offset; L.transform = v.transform; L.lower = v.lower; L.upper = v.upper;
+        for (int sl = 0; sl < g.n_slots; ++sl) { const GSlot& gs = m->gslots_host[g.slot0 + sl]; if (gs.var == o.ref && gs.did == did) { pt = sl; break; } }
+      } else {   // NUTS_OP_VAR
+        const VarDev& v = vars[o.ref];
+        L.kind = SWL_VAR; L.bcast = v.size > 1 ? 0 : 1; L.ptr = md.pool; L.voff = v.offset; L.transform = v.transform; L.lower = v.lower; L.upper = v.upper;
+        const FactorBT& bt = m->fbt_host[g.f];
+        for (int b = 0; b < bt.n; ++b) if (m->bterm_var_host[bt.e[b].bterm] == o.ref) { pt = -2 - bt.e[b].bterm; break; }
+      }
+      keys.push_back(Key{o.kind, o.ref, did}); lf.push_back(L); push_to.push_back(pt);
+      return (int)keys.size() - 1;
+    };
+    auto rewrite = [&](nuts_operand& o) {
+      if (o.kind == NUTS_OP_CONST || o.kind == NUTS_OP_TMP) return;
+      if (o.kind != NUTS_OP_DATA && o.kind != NUTS_OP_VAR && o.kind != NUTS_OP_GATHER && o.kind != NUTS_OP_LIN) { o.kind = NUTS_OP_CONST; o.c = 0.0; return; }
+      const int l = leaf_of(o);
+      o.kind = SW_LEAF; o.ref = l; o.c = (double)push_to[l];
+    };
+    F.instr0 = (int32_t)instrs.size();
+    for (int i = 0; i < f.n_instr; ++i) {
+      nuts_instr I = s->instrs[f.instr_off + i];
+      rewrite(I.x); rewrite(I.y); rewrite(I.z);
+      instrs.push_back(I);
+    }
+    for (int k = 0; k < 4; ++k) {
+      nuts_operand a{}, b{}, c{};
+      if (k < f.nargs) { a = f.arg[k].a; b = f.arg[k].b; c = f.arg[k].c; rewrite(a); rewrite(b); rewrite(c); }
+      F.arg[k][0] = a; F.arg[k][1] = b; F.arg[k][2] = c;
+    }
+    // the leaves that need the position first (kernel: one pass of direct loads over all leaves, one of position loads over these)
+    std::vector<int> order, where(lf.size());
+    for (size_t i = 0; i < lf.size(); ++i) if (lf[i].kind != SWL_DATA) order.push_back((int)i);
+    F.n2 = (int32_t)order.size();
+    for (size_t i = 0; i < lf.size(); ++i) if (lf[i].kind == SWL_DATA) order.push_back((int)i);
+    for (size_t i = 0; i < order.size(); ++i) where[order[i]] = (int)i;
+    auto remap = [&](nuts_operand& o) { if (o.kind == SW_LEAF) o.ref = where[o.ref]; };
+    for (int i = 0; i < f.n_instr; ++i) { nuts_instr& I = instrs[F.instr0 + i]; remap(I.x); remap(I.y); remap(I.z); }
+    for (int k = 0; k < 4; ++k) for (int u = 0; u < 3; ++u) remap(F.arg[k][u]);
+    F.leaf0 = (int32_t)leaves.size(); F.n_leaves = (int32_t)lf.size();
+    for (int i : order) leaves.push_back(lf[i]);
+    max_leaves = std::max(max_leaves, F.n_leaves); max_slots = std::max(max_slots, F.n_slots); max_instr = std::max(max_instr, F.n_instr);
+    swf.push_back(F);
+  }
+  int32_t n_blocks = 0;
+  for (SwFactor& F : swf) { F.blk0 = n_blocks; n_blocks += (F.size + 63) / 64; }
+  std::vector<char> blob;
+  auto put = [&](const void* src, size_t bytes) {
+    const size_t off = (blob.size() + 63) & ~(size_t)63;
+    blob.resize(off + std::max<size_t>(bytes, 64), 0);
+    if (bytes) std::memcpy(blob.data() + off, src, bytes);
+    return (int32_t)off;
+  };
+  put(swf.data(), swf.size() * sizeof(SwFactor));
+  const int32_t po_leaf = put(leaves.data(), leaves.size() * sizeof(SwLeaf));
+  const int32_t po_instr = put(instrs.data(), instrs.size() * sizeof(nuts_instr));
+  const int32_t po_slot = put(slot_off.data(), slot_off.size() * sizeof(int64_t));
+  blob.resize((blob.size() + 63) & ~(size_t)63, 0);
+  // the launch's LDS: a column per thread of broadcast accumulators, leaf values, slot adjoints, instruction values and adjoints
+  const int rows = md.n_bterms + max_leaves + max_slots + 2 * max_instr;
+  const int64_t bytes = (int64_t)rows * 64 * 8;
+  if (bytes > 64 * 1024) return true;   // (the generic sweeps stay: a program of more than ~ 60 instructions)
+  md.sw_blob = m->keep(dev_upload(blob.data(), blob.size()));
+  if (!md.sw_blob) { g_err = "device allocation failed (resolved-operand sweep)"; return false; }
+  md.n_swf = (int32_t)swf.size(); md.sw_bytes = (int32_t)blob.size(); md.sw_rows = rows;
+  md.sw_po_leaf = po_leaf; md.sw_po_instr = po_instr; md.sw_po_slot = po_slot;
+  md.sw_max_leaves = max_leaves; md.sw_max_slots = max_slots; md.sw_max_instr = max_instr; md.sw_blocks = n_blocks;
+  // (one wave per workgroup and per block; grid-stride beyond 8192 -- the records of gs_part were sized for the generic sweeps' grids)
+  const int nb = std::max(1, std::min(8192, n_blocks));
+  if (nb > md.n_gs_blocks) {
+    md.gs_part = m->keep(dev_alloc<double>((size_t)nb * (1 + MAX_BTERMS)));
+    if (!md.gs_part) { g_err = "device allocation failed (gathered adjoints)"; return false; }
+    hipMemset(md.gs_part, 0, (size_t)nb * (1 + MAX_BTERMS) * sizeof(double));
+  }
+  md.n_gs_blocks = nb;
   return true;
 }
 
@@ -1741,6 +1869,7 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
     m->alg_bytes += 8 * gm.N * (int64_t)gm.P;   // one read of X (SURVEY 8d convention: the node's data once per evaluation)
   }
   if (!build_lins(m, s, vars)) { nuts_model_destroy(m); return nullptr; }
+  if (!build_sweep_fast(m, s, vars)) { nuts_model_destroy(m); return nullptr; }
   for (void* p : m->owned)
     if (!p) { g_err = "device allocation failed"; nuts_model_destroy(m); return nullptr; }
   HIPCHK_NULL(hipDeviceSynchronize());

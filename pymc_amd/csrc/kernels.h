@@ -441,6 +441,10 @@ __global__ __launch_bounds__(GSL_THREADS) void k_gsweep_lds(ModelDev md, ArenaDe
     __syncthreads();
   }
   const Prog pg = prog_view(md, s_prog);
+#ifdef NUTS_KTIMING
+  const bool tk = blockIdx.x == 0 && tid == 0;
+  const long long tk_a = tk ? tick_now() : 0;
+#endif
   Leaf lf; QView qv;
   resolve_leaf(io, A, j, lf, qv);
   int max_instr = 0;
@@ -452,11 +456,210 @@ __global__ __launch_bounds__(GSL_THREADS) void k_gsweep_lds(ModelDev md, ArenaDe
   double lp = 0.0;
   for (int e = blockIdx.x * GSL_THREADS + tid; e < md.n_gs_elems; e += gridDim.x * GSL_THREADS)
     lp += gsweep_element_lds<true>(pg, qv, e, s_bacc, GSL_THREADS, tv, ta, gadj);
+#ifdef NUTS_KTIMING
+  if (tk) md.ticks[39] += tick_now() - tk_a;   // the wave's whole sweep (set-up of the views + element loop)
+#endif
   double* rec = md.gs_part + (int64_t)blockIdx.x * (1 + MAX_BTERMS);
   const double t = wave_sum(lp);
   if (tid == 0) rec[0] = t;
   for (int b = 0; b < md.n_bterms; ++b) {
     const double tb = wave_sum(s_bacc[b * GSL_THREADS]);
+    if (tid == 0) rec[1 + b] = tb;
+  }
+}
+
+// The adjoint sweep with resolved operands, driven by the SCALAR unit (model_dev.h SwFactor; round 6).  One wave per workgroup and per
+// 64-element block of ONE factor, so everything about the program is the same in all lanes -- and the compiler is told so: the
+// sweep's tables are read through the constant address space (s_load into SGPRs: opcode, operand kinds and references, the leaves'
+// pointers), the 47-way opcode switch and the operand kinds are scalar compares and branches, and the vector unit is left with the
+// arithmetic and the LDS columns.  (Read per lane, as the generic sweeps read them, every `switch` is a tree of exec-mask tests
+// with the merged values of all its cases alive: 432 vector registers, one wave per SIMD, ~2 000 cycles per interpreted instruction.)
+// Dynamic LDS = [sw_rows][64] doubles: broadcast accumulators, leaf values, slot adjoints, instruction values, instruction adjoints.
+#define CONSTAS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const CONSTAS T* as_const(const T* p) { return (const CONSTAS T*)(uintptr_t)p; }
+typedef int sw_v16i __attribute__((ext_vector_type(16)));
+typedef int sw_v8i __attribute__((ext_vector_type(8)));
+typedef int sw_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double sw_f64(int lo, int hi) { return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo)); }
+// one instruction of a swept program in scalar registers: a single 64-byte s_load (nuts_instr is 64 bytes: op, pad, k, then three
+// operands of (kind, ref, c)), issued one instruction AHEAD of its use -- a dependent chain of separate scalar loads (opcode, then
+// the operand's kind, then its reference ...) costs a trip to the scalar cache each, 150 - 200 cycles, five or six times per instruction
+struct SwOp { int kind, ref; double c; };
+struct SwInstr { int op; double k; SwOp x, y, z; };
+__device__ __forceinline__ SwInstr sw_load_instr(const CONSTAS nuts_instr* I) {
+  const sw_v16i w = *reinterpret_cast<const CONSTAS sw_v16i*>(I);
+  SwInstr r;
+  r.op = w[0]; r.k = sw_f64(w[2], w[3]);
+  r.x = SwOp{w[4], w[5], sw_f64(w[6], w[7])};
+  r.y = SwOp{w[8], w[9], sw_f64(w[10], w[11])};
+  r.z = SwOp{w[12], w[13], sw_f64(w[14], w[15])};
+  return r;
+}
+__device__ __forceinline__ SwOp sw_load_op(const CONSTAS nuts_operand* q) {
+  const sw_v4i w = *reinterpret_cast<const CONSTAS sw_v4i*>(q);
+  return SwOp{w[0], w[1], sw_f64(w[2], w[3])};
+}
+
+__global__ __launch_bounds__(GSL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gsweep_fast(ModelDev md, ArenaDev A, EvalIO io, int j) {
+  if (load_aborted(io, A)) return;
+  extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+  const int tid = threadIdx.x;
+  constexpr int S = GSL_THREADS;
+  const CONSTAS SwFactor* swf = as_const(reinterpret_cast<const SwFactor*>(md.sw_blob));
+  const CONSTAS SwLeaf* leaves = as_const(reinterpret_cast<const SwLeaf*>(md.sw_blob + md.sw_po_leaf));
+  const CONSTAS nuts_instr* instrs = as_const(reinterpret_cast<const nuts_instr*>(md.sw_blob + md.sw_po_instr));
+  const CONSTAS int64_t* slot_off = as_const(reinterpret_cast<const int64_t*>(md.sw_blob + md.sw_po_slot));
+  Leaf lf; QView qv;
+  resolve_leaf(io, A, j, lf, qv);
+  double* s_bacc = s_dyn + tid;
+  for (int b = 0; b < md.n_bterms; ++b) s_bacc[b * S] = 0.0;
+  double* lv = s_dyn + (size_t)md.n_bterms * S + tid;      // leaf values
+  double* la = lv + (size_t)md.sw_max_leaves * S;           // the slots' adjoints
+  double* tv = la + (size_t)md.sw_max_slots * S;            // instruction values
+  double* ta = tv + (size_t)md.sw_max_instr * S;            // instruction adjoints
+  Prog pgk; pgk.fdead_mode = md.fdead_mode; pgk.fdead = md.fdead;
+  double lp_acc = 0.0;
+#ifdef NUTS_KTIMING
+  // phases of the first block's sweep, wave 0: ticks[32 ..] += {forward, arguments + density, arguments' adjoints, reverse, stores, leaves}; [38]: sweeps
+  const bool tk_ = blockIdx.x == 0;
+  long long tk0_ = tk_ ? tick_now() : 0;
+  const long long tk_a = tk0_;
+#define SWF_TICK(slot) do { if (tk_ && tid == 0) { const long long t_ = tick_now(); md.ticks[slot] += t_ - tk0_; tk0_ = t_; } } while (0)
+#else
+#define SWF_TICK(slot) do { } while (0)
+#endif
+  for (int blk = blockIdx.x; blk < md.sw_blocks; blk += gridDim.x) {
+    int t = 0;
+    while (t + 1 < md.n_swf && blk >= swf[t + 1].blk0) ++t;
+    const CONSTAS SwFactor* F = swf + t;
+    // (the factor's header: two 32-byte loads)
+    const sw_v8i h0 = *reinterpret_cast<const CONSTAS sw_v8i*>(F), h1 = *(reinterpret_cast<const CONSTAS sw_v8i*>(F) + 1);
+    const int ff = h0[0], fsize = h0[2], orphan = h0[3], leaf0 = h0[4], nl = h0[5], n2 = h0[6], instr0 = h0[7];
+    const int n_instr = h1[0], nargs = h1[1], dist = h1[2], slot0 = h1[3], n_slots = h1[4], blk0 = h1[5];
+    const double konst = sw_f64(h1[6], h1[7]);
+    const int li = (blk - blk0) * S + tid;
+    if (li >= fsize) continue;                          // (the factor's last block)
+    const CONSTAS SwLeaf* L = leaves + leaf0;
+    // ---- every leaf, up front: first the direct loads (data, predictor columns, gather indices), four leaves in flight ----
+    for (int l0 = 0; l0 < nl; l0 += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const sw_v8i w = *reinterpret_cast<const CONSTAS sw_v8i*>(L + min(l0 + u, nl - 1));      // kind, bcast, voff, transform, ptr
+        const double* p = reinterpret_cast<const double*>(((unsigned long long)(unsigned)w[5] << 32) | (unsigned)w[4]);
+        v[u] = w[0] == SWL_VAR ? 0.0 : p[w[1] ? 0 : li];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (l0 + u < nl) lv[(l0 + u) * S] = v[u];
+    }
+    // ... then the position's elements behind the gathers and the direct variables (the first n2 leaves)
+    for (int l0 = 0; l0 < n2; l0 += 4) {
+      double v[4];
+      int tr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = min(l0 + u, n2 - 1);
+        const sw_v4i w = *reinterpret_cast<const CONSTAS sw_v4i*>(L + l);
+        tr[u] = w[3];
+        const int i2 = w[2] + (w[0] == SWL_GATHER ? (int)lv[l * S] : (w[1] ? 0 : li));
+        v[u] = qv.at(i2);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (l0 + u < n2) {
+        double x = v[u];
+        if (tr[u] != NUTS_TR_NONE) { const CONSTAS SwLeaf* Lf = L + l0 + u; x = transform_x_ol(tr[u], Lf->lower, Lf->upper, x); }
+        lv[(l0 + u) * S] = x;
+      }
+    }
+    for (int sl = 0; sl < n_slots; ++sl) la[sl * S] = 0.0;
+    SWF_TICK(37);
+    auto val = [&](const SwOp& q) -> double { return q.kind == NUTS_OP_TMP ? tv[q.ref * S] : (q.kind == SW_LEAF ? lv[q.ref * S] : q.c); };
+    // a leaf operand's `c`: >= 0 the factor's slot that collects its adjoint; <= -2 the broadcast accumulator -2 - c of a scalar
+    // (credited when the sweep accounts the factor); -1: nothing is kept (data)
+    auto push = [&](const SwOp& q, double g) {
+      if (q.kind == NUTS_OP_TMP) { ta[q.ref * S] += g; return; }
+      if (q.kind != SW_LEAF) return;
+      const int sl = (int)q.c;
+      if (sl >= 0) la[sl * S] += g;
+      else if (sl <= -2 && orphan) s_bacc[(-2 - sl) * S] += g;
+    };
+    // ---- forward sweep (model_dev.h prog_forward, on LDS only) ----
+    const CONSTAS nuts_instr* ins = instrs + instr0;
+    int pdead0 = 0;
+    {
+      SwInstr nx = sw_load_instr(ins);
+#pragma unroll 1
+      for (int i = 0; i < n_instr; ++i) {
+        const SwInstr I = nx;
+        nx = sw_load_instr(ins + min(i + 1, n_instr - 1));
+        const int op = I.op;
+        const double x = val(I.x);
+        const bool has_y = op <= NUTS_E_DIV || (op >= NUTS_E_GT && op <= NUTS_E_OR) || op == NUTS_E_SWITCH || op == NUTS_E_MAXIMUM || op == NUTS_E_MINIMUM ||
+                           op == NUTS_E_POW || op == NUTS_E_LOGADDEXP || op == NUTS_E_CLIP || op == NUTS_E_CHECK;
+        const double y = has_y ? val(I.y) : 0.0;
+        const double z = (op == NUTS_E_SWITCH || op == NUTS_E_CLIP) ? val(I.z) : 0.0;
+        if (op == NUTS_E_CHECK && y == 0.0) pdead0 = 1;
+        tv[i * S] = prog_op_value(op, I.k, x, y, z);
+        ta[i * S] = 0.0;
+      }
+    }
+    SWF_TICK(32);
+    SwOp arg[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int u = 0; u < 3; ++u) arg[k][u] = sw_load_op(&F->arg[k][u]);
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, bv[4] = {0.0, 0.0, 0.0, 0.0}, cv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nargs) {
+        bv[k] = val(arg[k][1]); cv[k] = val(arg[k][2]);
+        a[k] = val(arg[k][0]) + bv[k] * cv[k];
+      }
+    // ---- the factor's density and its partials ----
+    double d[4];
+    int pdead = pdead0;
+    double lp = dist_eval_uniform(dist, konst, a, d, &pdead);
+    if (pdead0) { lp = -INFINITY; d[0] = d[1] = d[2] = d[3] = 0.0; }
+    factor_kill(pgk, ff, pdead, lp, d);
+    SWF_TICK(33);
+    // ---- reverse sweep (model_dev.h factor_prog_rev_t: the same rules, the same order) ----
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nargs && d[k] != 0.0) { push(arg[k][0], d[k]); push(arg[k][1], d[k] * cv[k]); push(arg[k][2], d[k] * bv[k]); }
+    SWF_TICK(34);
+    if (n_instr > 0) {
+      SwInstr nx = sw_load_instr(ins + n_instr - 1);
+#pragma unroll 1
+      for (int i = n_instr - 1; i >= 0; --i) {
+        const SwInstr I = nx;
+        nx = sw_load_instr(ins + max(i - 1, 0));
+        const double g = ta[i * S];
+        if (g == 0.0) continue;
+        double gx, gy, gz; bool px, py, pz;
+        prog_op_adjoint(I.op, I.k, g, tv[i * S], val(I.x), val(I.y), val(I.z), gx, gy, gz, px, py, pz);
+        if (px) push(I.x, gx);
+        if (py) push(I.y, gy);
+        if (pz) push(I.z, gz);
+      }
+    }
+    SWF_TICK(35);
+    // ---- the slots' adjoints to where the gathers / the transposed mat-vec read them ----
+    const CONSTAS int64_t* so = slot_off + slot0;
+    for (int sl = 0; sl < n_slots; ++sl) md.adj[so[sl] + li] = la[sl * S];
+    SWF_TICK(36);
+    if (orphan) lp_acc += lp;
+  }
+#ifdef NUTS_KTIMING
+  if (tk_ && tid == 0) { md.ticks[39] += tick_now() - tk_a; md.ticks[38] += 1; }
+#endif
+#undef SWF_TICK
+  double* rec = md.gs_part + (int64_t)blockIdx.x * (1 + MAX_BTERMS);
+  const double tsum = wave_sum(lp_acc);
+  if (tid == 0) rec[0] = tsum;
+  for (int b = 0; b < md.n_bterms; ++b) {
+    const double tb = wave_sum(s_bacc[b * S]);
     if (tid == 0) rec[1 + b] = tb;
   }
 }

@@ -188,6 +188,36 @@ struct GlmDev {
   double* lp;               // the node's logp
 };
 
+// The adjoint sweep with its operands RESOLVED (k_gsweep_fast, kernels.h; round 6).  Measured with a phase clock
+// (tools/sweep_ticks.py): an interpreted instruction of the generic sweep costs ~2 700 cycles forwards and ~3 500 backwards, and what
+// it waits for is its LEAF operands -- a gather is an LDS look-up of the data reference, a load of the index, then the loads of the
+// position, each after the other (500 - 700 cycles per trip to the L2), again in the reverse sweep.  Here the host lists every
+// distinct leaf of a swept factor once (SwLeaf: what to load from where, already resolved to pointers), the kernel fetches ALL of
+// them up front with the loads of four leaves in flight together, and the two sweeps run on LDS only: operands are results of
+// earlier instructions, constants, or entries of the leaf array; the adjoint of a leaf is one LDS cell that the end of the sweep
+// hands to its slot (a gather / a predictor column); a scalar's adjoint goes straight to its broadcast accumulator, push by push, as in
+// the generic sweep.  Same arithmetic in the same order.
+#define SW_LEAF 6              // operand kind of the rewritten programs: entry `ref` of the element's leaf array
+#define SWL_DATA 0             // value = ptr[bcast ? 0 : li]                      (data vector, predictor column)
+#define SWL_GATHER 1           // value = transform(q'[voff + (int) ptr[li]])       (var[idx[li]])
+#define SWL_VAR 2              // value = transform(q'[voff + (bcast ? 0 : li)])    (a scalar that broadcasts, an element-aligned vector)
+// (layouts the kernel reads with wide scalar loads: a leaf's first 32 bytes are what every leaf needs, a factor's first 64 its header)
+struct alignas(16) SwLeaf {
+  int32_t kind, bcast, voff, transform;
+  const double* ptr;           // SWL_DATA: the vector; SWL_GATHER: the index vector (as doubles); SWL_VAR: unused
+  int64_t pad;
+  double lower, upper;
+};
+struct alignas(64) SwFactor {
+  int32_t f, elem0, size, orphan;
+  int32_t leaf0, n_leaves, n2, instr0;   // leaves [leaf0, leaf0 + n_leaves); the first n2 need the position (GATHER / VAR)
+  int32_t n_instr, nargs, dist, slot0;   // slot0: first of the factor's n_slots entries in the table of adjoint offsets
+  int32_t n_slots, blk0;                 // blk0: the first of the factor's 64-element blocks in the launch's numbering
+  double konst;
+  nuts_operand arg[4][3];                // the factor's arguments (a, b, c) with their operands rewritten
+};
+static_assert(sizeof(SwLeaf) == 48 && sizeof(nuts_instr) == 64 && sizeof(nuts_operand) == 16 && sizeof(SwFactor) == 256, "the scalar-driven sweep reads these with wide loads");
+
 // dense node 5: linear predictors read by the factors through NUTS_OP_LIN operands (lin_kernel.h)
 #define LIN_MAXUSE 4     // factors that may read one predictor column
 #define LIN_CHUNK 2048   // rows per workgroup of the transposed mat-vec (8 per thread)
@@ -262,6 +292,10 @@ struct ModelDev {
   // orphans [0, n_orphans_b) of the list (the swept ones are sorted behind them).
   int32_t n_gs_blocks, n_orphans_b;
   double* gs_part;
+  // resolved-operand sweep (SwFactor above): tables in one global blob the kernel copies into LDS; sw_rows = LDS doubles per thread
+  int32_t n_swf, sw_bytes, sw_rows, sw_po_leaf, sw_po_instr, sw_po_slot;
+  int32_t sw_max_leaves, sw_max_slots, sw_max_instr, sw_blocks;
+  const char* sw_blob;
   int32_t gs_lds_rows, gs_lds_bytes;   // > 0: k_gsweep_lds -- rows (doubles per thread) of the sweep's LDS block: 2 x (longest program) + (most slots); the launch's dynamic LDS in all
   double* adj;
   int32_t n_glong, glong_pad; // long inverse-index lists (GLong): entries, in global memory next to their totals
@@ -353,6 +387,7 @@ struct Prog {
   const GLong* glong;
   int n_gsf;
   const LinDev* lins;        // linear predictors (NUTS_OP_LIN operands)
+  long long* ticks;          // (lab builds, -DNUTS_KTIMING: ModelDev.ticks)
 };
 
 __device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) {
@@ -374,6 +409,7 @@ __device__ __forceinline__ Prog prog_view(const ModelDev& md, const char* base) 
   pg.gslot = reinterpret_cast<const GSlot*>(base + md.po_gslot);
   pg.adj = md.adj; pg.adj_red = md.adj_red; pg.glong = md.glong; pg.n_gsf = md.n_gsf;
   pg.lins = md.lins;
+  pg.ticks = md.ticks;
   return pg;
 }
 
@@ -523,7 +559,7 @@ __device__ __forceinline__ double op_value(const nuts_operand& o, int li, const 
 // Arguments and results travel BY VALUE (registers under the device calling convention): with pointer parameters the caller's a[4],
 // d[4] and the flag had to live in scratch -- 80 to 144 B in every kernel that evaluates factors.
 struct DistOut { double lp, d0, d1, d2, d3; int dead; };
-__device__ __noinline__ DistOut dist_eval_v(int dist, double konst, double a0, double a1, double a2, double a3) {
+__device__ __forceinline__ DistOut dist_eval_body(int dist, double konst, double a0, double a1, double a2, double a3) {
   const double a[4] = {a0, a1, a2, a3};
   double d[4];
   int pdead_v = 0;
@@ -715,8 +751,22 @@ __device__ __noinline__ DistOut dist_eval_v(int dist, double konst, double a0, d
 #undef KILL_PARAM
   return DistOut{lp, d[0], d[1], d[2], d[3], pdead_v};
 }
+__device__ __noinline__ DistOut dist_eval_v(int dist, double konst, double a0, double a1, double a2, double a3) {
+  return dist_eval_body(dist, konst, a0, a1, a2, a3);
+}
+// ... for a caller whose lanes all evaluate the SAME distribution (the scalar-driven sweep, kernels.h k_gsweep_fast): the code arrives in
+// a vector register like every argument of a call; read back into a scalar one, the 19-way switch is scalar compares and branches
+__device__ __noinline__ DistOut dist_eval_u(int dist, double konst, double a0, double a1, double a2, double a3) {
+  return dist_eval_body(__builtin_amdgcn_readfirstlane(dist), konst, a0, a1, a2, a3);
+}
 __device__ __forceinline__ double dist_eval(int dist, double konst, const double* a, double* d, int* pdead) {
   const DistOut o = dist_eval_v(dist, konst, a[0], a[1], a[2], a[3]);
+  d[0] = o.d0; d[1] = o.d1; d[2] = o.d2; d[3] = o.d3;
+  if (o.dead) *pdead = 1;
+  return o.lp;
+}
+__device__ __forceinline__ double dist_eval_uniform(int dist, double konst, const double* a, double* d, int* pdead) {
+  const DistOut o = dist_eval_u(dist, konst, a[0], a[1], a[2], a[3]);
   d[0] = o.d0; d[1] = o.d1; d[2] = o.d2; d[3] = o.d3;
   if (o.dead) *pdead = 1;
   return o.lp;
@@ -817,6 +867,51 @@ __device__ __forceinline__ double prog_op_value(int op, double k, double x, doub
   }
 }
 
+// The reverse rules: what the operands of instruction `op` receive for the adjoint g of its result v (x, y, z: the operands' values,
+// read only where a rule needs them) -- one copy, shared by the generic sweep and the resolved-operand sweep (k_gsweep_fast).
+__device__ __forceinline__ void prog_op_adjoint(int op, double kconst, double g, double v, double x, double y, double z, double& gx, double& gy,
+                                                double& gz, bool& px, bool& py, bool& pz) {
+  gx = 0.0; gy = 0.0; gz = 0.0;
+  px = false; py = false; pz = false;
+  switch (op) {
+    case NUTS_E_ADD: gx = g; gy = g; px = py = true; break;
+    case NUTS_E_SUB: gx = g; gy = -g; px = py = true; break;
+    case NUTS_E_MUL: gx = g * y; gy = g * x; px = py = true; break;
+    case NUTS_E_DIV: gx = g / y; gy = -g * v / y; px = py = true; break;
+    case NUTS_E_NEG: gx = -g; px = true; break;
+    case NUTS_E_EXP: gx = g * v; px = true; break;
+    case NUTS_E_LOG: gx = g / x; px = true; break;
+    case NUTS_E_LOG1P: gx = g / (1.0 + x); px = true; break;
+    case NUTS_E_SIGMOID: gx = g * v * (1.0 - v); px = true; break;
+    case NUTS_E_SOFTPLUS: gx = g * sigmoid_d(x); px = true; break;
+    case NUTS_E_SQRT: gx = g * 0.5 / v; px = true; break;
+    case NUTS_E_SQR: gx = g * 2.0 * x; px = true; break;
+    case NUTS_E_RECIPROCAL: gx = -g * v * v; px = true; break;
+    case NUTS_E_TANH: gx = g * (1.0 - v * v); px = true; break;
+    case NUTS_E_ABS: gx = g * (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0)); px = true; break;
+    case NUTS_E_POWC: gx = g * kconst * pow(x, kconst - 1.0); px = true; break;
+    case NUTS_E_SWITCH: if (x != 0.0) { gy = g; py = true; } else { gz = g; pz = true; } break;
+    case NUTS_E_GAMMALN: gx = g * digamma_d(x); px = true; break;
+    case NUTS_E_ERF: gx = g * 1.1283791670955126 * exp(-x * x); px = true; break;
+    case NUTS_E_ERFC: gx = -g * 1.1283791670955126 * exp(-x * x); px = true; break;
+    case NUTS_E_ERFCX: gx = g * (2.0 * x * v - 1.1283791670955126); px = true; break;
+    case NUTS_E_LOG1MEXP: gx = -g / expm1(-x); px = true; break;
+    case NUTS_E_EXPM1: gx = g * (v + 1.0); px = true; break;
+    case NUTS_E_MAXIMUM: case NUTS_E_MINIMUM: gx = g; gy = g; px = v == x; py = v == y; break;
+    case NUTS_E_POW: gx = g * y * pow(x, y - 1.0); px = true; if (x != 0.0) { gy = g * v * log(x); py = true; } break;
+    case NUTS_E_SIN: gx = g * cos(x); px = true; break;
+    case NUTS_E_COS: gx = -g * sin(x); px = true; break;
+    case NUTS_E_ARCTAN: gx = g / (1.0 + x * x); px = true; break;
+    case NUTS_E_LOGADDEXP: gx = g * sigmoid_d(x - y); gy = g * sigmoid_d(y - x); px = py = true; break;
+    case NUTS_E_CLIP: if (x < y) { gy = g; py = true; } else if (x > z) { gz = g; pz = true; } else { gx = g; px = true; } break;
+    case NUTS_E_CHECK: gx = g; px = true; break;
+    case NUTS_E_LOG2: gx = g / (x * 0.6931471805599453094); px = true; break;
+    case NUTS_E_LOG10: gx = g / (x * 2.3025850929940456840); px = true; break;
+    case NUTS_E_DIGAMMA: gx = g * trigamma_d(x); px = true; break;
+    default: break;   // comparisons, logic, sign, floor, ceil: piecewise constant
+  }
+}
+
 // Where a sweep keeps the instructions' values and adjoints: a thread's own arrays (scratch memory: every kernel but one) or, for the
 // adjoint sweep's kernel (k_gsweep_lds), a column of an LDS block -- element i of thread t at base[i * stride + t], conflict-free.
 // A sweep is a chain of dependent reads and writes of these arrays; in scratch each is a trip to the L2 (500+ cycles), in LDS ~100.
@@ -885,14 +980,24 @@ template <typename TV>
 __device__ __forceinline__ double factor_prog_rev_t(const Prog& pg, const QView& qv, const nuts_factor& f, int fi, int li, int own_var, double own_x,
                                                     int wrt, int want_bt, double* s_bacc, int bstride, double* gwrt_out, int wrt_did,
                                                     const GSlot* gs, int ngs, TV tv, TV ta, TV gadj) {
+#ifdef NUTS_KTIMING
+  // phases of ONE element's sweep (k_gsweep*, element 0): ticks[32 ..] += {forward, density, arguments' adjoints, reverse, stores}; [38]: sweeps
+  const bool tk_ = gs && li == 0 && blockIdx.x == 0 && threadIdx.x == 0;
+  long long tk0_ = tk_ ? tick_now() : 0;
+#define SWEEP_TICK(slot) do { if (tk_) { const long long t_ = tick_now(); pg.ticks[slot] += t_ - tk0_; tk0_ = t_; } } while (0)
+#else
+#define SWEEP_TICK(slot) do { } while (0)
+#endif
   if (gs) for (int sl = 0; sl < ngs; ++sl) gadj[sl] = 0.0;
   ProgFwd o;
   prog_forward(pg, qv, f, li, own_var, own_x, tv, o);
+  SWEEP_TICK(32);
   double d[4];
   int pdead = o.pdead;
   double lp = dist_eval(f.dist, f.konst, o.a, d, &pdead);
   if (o.pdead) { lp = -INFINITY; d[0] = d[1] = d[2] = d[3] = 0.0; }   // a failed NUTS_E_CHECK: as a failed check inside a density
   factor_kill(pg, fi, pdead, lp, d);
+  SWEEP_TICK(33);
   double gw = 0.0;
   const FactorBT& bt = pg.fbt[fi];
   auto val = [&](const nuts_operand& q) { return q.kind == NUTS_OP_TMP ? tv[q.ref] : op_value<false, true>(q, li, pg, qv, own_var, own_x); };
@@ -928,6 +1033,7 @@ __device__ __forceinline__ double factor_prog_rev_t(const Prog& pg, const QView&
       push(tm.a, dk); push(tm.b, dk * pick4(o.cv, k)); push(tm.c, dk * pick4(o.bv, k));
     }
   }
+  SWEEP_TICK(34);
   const nuts_instr* ins = pg.instrs + f.instr_off;
   // operands whose VALUE a reverse rule reads (bit i: opcode i)
   constexpr unsigned long long NEED_X =
@@ -947,51 +1053,20 @@ __device__ __forceinline__ double factor_prog_rev_t(const Prog& pg, const QView&
     const double x = ((NEED_X >> op) & 1ull) ? val(I.x) : 0.0;
     const double y = ((NEED_Y >> op) & 1ull) ? val(I.y) : 0.0;
     const double z = op == NUTS_E_CLIP ? val(I.z) : 0.0;
-    // what each operand receives (the arithmetic of the rules is unchanged: the same expressions, evaluated here, pushed below)
-    double gx = 0.0, gy = 0.0, gz = 0.0;
-    bool px = false, py = false, pz = false;
-    switch (op) {
-      case NUTS_E_ADD: gx = g; gy = g; px = py = true; break;
-      case NUTS_E_SUB: gx = g; gy = -g; px = py = true; break;
-      case NUTS_E_MUL: gx = g * y; gy = g * x; px = py = true; break;
-      case NUTS_E_DIV: gx = g / y; gy = -g * v / y; px = py = true; break;
-      case NUTS_E_NEG: gx = -g; px = true; break;
-      case NUTS_E_EXP: gx = g * v; px = true; break;
-      case NUTS_E_LOG: gx = g / x; px = true; break;
-      case NUTS_E_LOG1P: gx = g / (1.0 + x); px = true; break;
-      case NUTS_E_SIGMOID: gx = g * v * (1.0 - v); px = true; break;
-      case NUTS_E_SOFTPLUS: gx = g * sigmoid_d(x); px = true; break;
-      case NUTS_E_SQRT: gx = g * 0.5 / v; px = true; break;
-      case NUTS_E_SQR: gx = g * 2.0 * x; px = true; break;
-      case NUTS_E_RECIPROCAL: gx = -g * v * v; px = true; break;
-      case NUTS_E_TANH: gx = g * (1.0 - v * v); px = true; break;
-      case NUTS_E_ABS: gx = g * (x > 0 ? 1.0 : (x < 0 ? -1.0 : 0.0)); px = true; break;
-      case NUTS_E_POWC: gx = g * I.k * pow(x, I.k - 1.0); px = true; break;
-      case NUTS_E_SWITCH: if (x != 0.0) { gy = g; py = true; } else { gz = g; pz = true; } break;
-      case NUTS_E_GAMMALN: gx = g * digamma_d(x); px = true; break;
-      case NUTS_E_ERF: gx = g * 1.1283791670955126 * exp(-x * x); px = true; break;
-      case NUTS_E_ERFC: gx = -g * 1.1283791670955126 * exp(-x * x); px = true; break;
-      case NUTS_E_ERFCX: gx = g * (2.0 * x * v - 1.1283791670955126); px = true; break;
-      case NUTS_E_LOG1MEXP: gx = -g / expm1(-x); px = true; break;
-      case NUTS_E_EXPM1: gx = g * (v + 1.0); px = true; break;
-      case NUTS_E_MAXIMUM: case NUTS_E_MINIMUM: gx = g; gy = g; px = v == x; py = v == y; break;
-      case NUTS_E_POW: gx = g * y * pow(x, y - 1.0); px = true; if (x != 0.0) { gy = g * v * log(x); py = true; } break;
-      case NUTS_E_SIN: gx = g * cos(x); px = true; break;
-      case NUTS_E_COS: gx = -g * sin(x); px = true; break;
-      case NUTS_E_ARCTAN: gx = g / (1.0 + x * x); px = true; break;
-      case NUTS_E_LOGADDEXP: gx = g * sigmoid_d(x - y); gy = g * sigmoid_d(y - x); px = py = true; break;
-      case NUTS_E_CLIP: if (x < y) { gy = g; py = true; } else if (x > z) { gz = g; pz = true; } else { gx = g; px = true; } break;
-      case NUTS_E_CHECK: gx = g; px = true; break;
-      case NUTS_E_LOG2: gx = g / (x * 0.6931471805599453094); px = true; break;
-      case NUTS_E_LOG10: gx = g / (x * 2.3025850929940456840); px = true; break;
-      case NUTS_E_DIGAMMA: gx = g * trigamma_d(x); px = true; break;
-      default: break;   // comparisons, logic, sign, floor, ceil: piecewise constant
-    }
+    double gx, gy, gz;
+    bool px, py, pz;
+    prog_op_adjoint(op, I.k, g, v, x, y, z, gx, gy, gz, px, py, pz);
     if (px) push(I.x, gx);
     if (py) push(I.y, gy);
     if (pz) push(I.z, gz);
   }
+  SWEEP_TICK(35);
   if (gs) for (int sl = 0; sl < ngs; ++sl) pg.adj[gs[sl].adj_off + li] = gadj[sl];
+  SWEEP_TICK(36);
+#ifdef NUTS_KTIMING
+  if (tk_) pg.ticks[38] += 1;
+#endif
+#undef SWEEP_TICK
   *gwrt_out = gw;
   return lp;
 }
