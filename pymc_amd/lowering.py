@@ -148,7 +148,9 @@ def build_tree(v, memo: Optional[dict] = None):
     elif name == "Elemwise" and type(op.scalar_op).__name__ == "Composite":
         # a fused element-wise sub-graph (what PyTensor's fusion rewrite leaves in a REWRITTEN graph): inlined -- its inner scalar
         # graph is walked with the same node protocol (`fgraph.inputs` / `fgraph.outputs`, `var.owner.op`, `.inputs`, constants' `.data`)
-        out = _inline_composite(op.scalar_op, [build_tree(i, memo) for i in ins])
+        # (a Composite with several outputs -- the fusion rewrite merges element-wise nodes that share inputs: this variable is output
+        # number `v.index` of its apply node, PyTensor's `Variable.index`; where that attribute is missing, its place in `owner.outputs`)
+        out = _inline_composite(op.scalar_op, [build_tree(i, memo) for i in ins], _output_index(v, owner))
     elif name == "Elemwise":
         sn = _scalar_name(op)
         if sn == "cast" or sn == "identity":
@@ -533,12 +535,28 @@ def _fold_or_node(sn, kids):
     return ("switch" if sn == "where" else sn, *kids)
 
 
-def _inline_composite(comp, outer_kids):
-    """Expression tree of the (single) output of a `Composite` scalar op applied to `outer_kids`."""
+def _output_index(v, owner) -> int:
+    """Which output of its apply node variable `v` is (`Variable.index` in PyTensor; nodes with one output: 0)."""
+    idx = getattr(v, "index", None)
+    if isinstance(idx, (int, np.integer)):
+        return int(idx)
+    outs = getattr(owner, "outputs", None)
+    if outs is not None:
+        for i, o in enumerate(outs):
+            if o is v:
+                return i
+        raise NotLowerable("a variable that is not among the outputs of its own apply node")
+    return 0
+
+
+def _inline_composite(comp, outer_kids, out_index: int = 0):
+    """Expression tree of output `out_index` of a `Composite` scalar op applied to `outer_kids` (the other outputs are other variables
+    of the outer graph: each is inlined when the walk reaches it; shared inner nodes are then evaluated once per output, which costs
+    instructions, not correctness)."""
     fg = getattr(comp, "fgraph", comp)
     inputs, outputs = list(fg.inputs), list(fg.outputs)
-    if len(outputs) != 1 or len(inputs) != len(outer_kids):
-        raise NotLowerable("Composite with several outputs (or an arity that does not match its Elemwise) is outside the lowering protocol")
+    if not 0 <= out_index < len(outputs) or len(inputs) != len(outer_kids):
+        raise NotLowerable("Composite whose arity does not match its Elemwise (or an output index beyond its outputs) is outside the lowering protocol")
     env = {id(v): k for v, k in zip(inputs, outer_kids)}
 
     def walk(v):
@@ -551,13 +569,13 @@ def _inline_composite(comp, outer_kids):
             else:
                 raise NotLowerable("free scalar inside a Composite")
         elif type(owner.op).__name__ == "Composite":
-            out = _inline_composite(owner.op, [walk(i) for i in owner.inputs])
+            out = _inline_composite(owner.op, [walk(i) for i in owner.inputs], _output_index(v, owner))
         else:
             out = _fold_or_node(type(owner.op).__name__.lower(), [walk(i) for i in owner.inputs])
         env[id(v)] = out
         return out
 
-    return walk(outputs[0])
+    return walk(outputs[out_index])
 
 
 # ---------------------------------------------------------------------------

@@ -349,6 +349,17 @@ def fused(comp, *ins):
     return Variable(Apply(Elemwise(comp), ins), shape=_bshape(*ins))
 
 
+def fused_outputs(comp, *ins):
+    """`Elemwise(Composite)(*ins)` of a Composite with SEVERAL outputs: one variable per output, all owned by one apply node
+    (`owner.outputs`), each knowing its place (`Variable.index`)."""
+    ins = [as_tensor(i) for i in ins]
+    node = Apply(Elemwise(comp), ins)
+    node.outputs = [Variable(node, shape=_bshape(*ins)) for _ in comp.outputs]
+    for i, o in enumerate(node.outputs):
+        o.index = i
+    return node.outputs
+
+
 def _bshape(*vs):
     return np.broadcast_shapes(*[v.type.shape for v in vs])
 

@@ -479,7 +479,7 @@ def test_composite_elemwise_nodes_are_inlined():
     """A fused element-wise node (`Elemwise(Composite)`, what PyTensor's fusion rewrite leaves): the walker inlines the inner scalar
     graph through `fgraph.inputs` / `fgraph.outputs`, folding constants as everywhere else -- a Normal log-density whose standardised
     residual and whose constant are computed inside Composites lowers to the same factor as the plain graph; nested Composites too;
-    several outputs are refused by name."""
+    a Composite with several outputs (round 6) is inlined per output."""
     y = np.array([0.3, -1.2, 2.5])
     C = sg.Composite
 
@@ -504,11 +504,29 @@ def test_composite_elemwise_nodes_are_inlined():
     q = np.array([0.4, -0.3])
     assert ref_models.evaluate(a, q)[0] == ref_models.evaluate(b, q)[0]
 
+    # a Composite with TWO outputs (the fusion rewrite merges element-wise nodes that share inputs): z^2 and log(sigma) from one
+    # apply node, each consumed by the tail -- the same factor again
+    def two_output_normal_logp(value, mu, sigma):
+        v_, m_, s_ = sg._ScalarVar(), sg._ScalarVar(), sg._ScalarVar()
+        both = C([v_, m_, s_], [C.op(sg.Pow, C.op(sg.TrueDiv, C.op(sg.Sub, v_, m_), s_), 2.0), C.op(sg.Log, s_)])
+        zsq, logs = sg.fused_outputs(both, value, mu, sigma)
+        return (-0.5 * zsq - np.log(np.sqrt(2.0 * np.pi))) - logs
+
+    twom = sg.StubModel()
+    mu = twom.Normal("mu", 0.0, 2.0)
+    s_ = twom.HalfNormal("s", 1.5)
+    twom._add(sg._RV("y", y.shape, two_output_normal_logp, (mu, s_), None, y))
+    c = lower_to_spec(twom)
+    _assert_same_spec(a, c)
+    assert ref_models.evaluate(a, q)[0] == ref_models.evaluate(c, q)[0]
+
     two = C([sg._ScalarVar()], [sg._ScalarVar(), sg._ScalarVar()])
     bad = sg.StubModel()
     x = bad.Normal("x", 0.0, 1.0)
-    bad._add(sg._RV("p", (), lambda v, x_: sg.fused(two, x_), (x,), None, y))
-    with pytest.raises(NotLowerable, match="several outputs"):
+    node_out = sg.fused_outputs(two, x)[1]
+    node_out.index = 5                                   # (an output its Composite does not have)
+    bad._add(sg._RV("p", (), lambda v, x_: node_out, (x,), None, y))
+    with pytest.raises(NotLowerable, match="beyond its outputs"):
         lower_to_spec(bad)
 
 
