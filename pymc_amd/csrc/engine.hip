@@ -1851,6 +1851,13 @@ extern "C" nuts_model* nuts_model_create(const nuts_model_spec* s) {
       }
     }
     gm.y = m->keep(dev_upload(s->glm_y, (size_t)gm.N));
+    gm.Xt = nullptr;
+    if (gm.P <= GLM_SMALL_P && gm.N <= GLM_SMALL_N) {   // the single-workgroup kernel's copy (small_kernel.h): columns contiguous
+      std::vector<double> xt((size_t)gm.N * gm.P);
+      for (int64_t i = 0; i < gm.N; ++i)
+        for (int p = 0; p < gm.P; ++p) xt[(size_t)p * gm.N + i] = s->glm_X[(size_t)i * gm.P + p];
+      gm.Xt = m->keep(dev_upload(xt.data(), xt.size()));
+    }
     // grid: every CU gets NUTS_GLM_WG_PER_CU workgroups of four waves (default 4: 16 waves per CU, each with one row-iteration in
     // flight and one being evaluated).  Measured at configs[3]'s shape on two boxes (profiles/r04h_glm_sweep_workgroups_per_cu.txt,
     // r04i): 1421 / 1381 / 1380 / 1328 and 1426 / 1387 / 1365 / 1345 leapfrog/s at 4 / 8 / 12 / 16 -- more workgroups shave the
@@ -2410,7 +2417,11 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   c->small_one_wave = env_int("NUTS_SMALL_ONE_WAVE", 1);
   c->group_wide = env_int("NUTS_GROUP_WIDE", 0);
   // (... and whose factors are small too: the single workgroup walks every factor element itself -- SMALL_MAX_ELEMS, round 6)
-  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix && !m->md.has_glm &&
+  // (round 6: a GLM node with few covariates and rows is evaluated inside that launch -- small_kernel.h GLM_SMALL_P / GLM_SMALL_N;
+  // NUTS_GLM_SMALL = 0: the general path's four launches per leapfrog, A/B and tests)
+  const bool glm_small = m->md.has_glm && env_int("NUTS_GLM_SMALL", 1) != 0 && m->md.glm.Xt && !m->md.glm.beta_buf && m->md.glm.off_beta >= 0 && m->md.n_derived == 0;
+  c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix &&
+             (!m->md.has_glm || glm_small) &&
              m->md.n_lins == 0 && m->factor_elems <= SMALL_MAX_ELEMS && !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)
   c->do_dev = c->keep(dev_alloc<DrawOut>(1));
   A.uniforms = c->stage_dev + 2 * (size_t)n;
@@ -3059,7 +3070,8 @@ static int run_tree(nuts_chain* c, const double* uniforms, double step_size, int
 static void launch_small(nuts_chain* c, const ArenaDev& A, const SmallDrawArgs& a) {
 #define SMALL_LAUNCH(NT, P) hipLaunchKernelGGL((k_small_draw<NT, P>), dim3(1), dim3(NT), 0, c->m->stream, c->m->md, A, a)
   const bool hp = c->m->has_prog;
-  if (c->n <= WAVE && c->small_one_wave) { if (hp) SMALL_LAUNCH(64, true); else SMALL_LAUNCH(64, false); }
+  // (a GLM node's rows are the workgroup's work: four waves at least, the tree still in LDS for n <= 64)
+  if (c->n <= WAVE && c->small_one_wave && !c->m->md.has_glm) { if (hp) SMALL_LAUNCH(64, true); else SMALL_LAUNCH(64, false); }
   else if (c->n <= 256) { if (hp) SMALL_LAUNCH(256, true); else SMALL_LAUNCH(256, false); }
   else if (c->n <= 512) { if (hp) SMALL_LAUNCH(512, true); else SMALL_LAUNCH(512, false); }
   else { if (hp) SMALL_LAUNCH(1024, true); else SMALL_LAUNCH(1024, false); }

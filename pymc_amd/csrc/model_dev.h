@@ -182,6 +182,7 @@ struct GlmDev {
   double sigma_c;           // constant sigma (Normal family without a sigma variable)
   double konst;             // parameter-free part of the log-likelihood (Poisson: -sum_i factln(y_i))
   const double* X;          // [N][Ppad]
+  const double* Xt;         // [P][N] (small nodes only: what the single-workgroup kernel reads, small_kernel.h; else nullptr)
   const double* y;          // [N]
   double* part;             // [nwg][Ppad + 4] per-workgroup sums: d/dbeta[Ppad], d/dintercept, d/dsigma, logp, (pad)
   double* gdense;           // [n] the node's gradient w.r.t. the constrained values (zero outside its parameters)

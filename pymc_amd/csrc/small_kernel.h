@@ -61,6 +61,18 @@ struct SmallDrawArgs {
 #define SMALL_POOL_DBL 1024
 #define SMALL_UNI_DBL 1100
 
+// Round 6 -- the GLM node inside the launch (VERDICT r05 "missing" 6: the everyday regression).  A model whose only dense node is a GLM
+// with few covariates and rows (P <= GLM_SMALL_P, N <= GLM_SMALL_N: ten covariates, a few thousand observations) took the general
+// path's FOUR launches per leapfrog -- the row pass, its reduce, kernels B and C: 31.5 us per leapfrog whatever N, all of it launch
+// latency (profiles/r06w_profile_glm_small.txt).  Here the workgroup evaluates the node itself between two barriers: thread t takes
+// rows t, t + NT, ... two at a time from a TRANSPOSED copy of X (GlmDev.Xt: a column of 64 rows is one coalesced load; a row per
+// thread from the row-major X was 64 cache lines per load instruction: 112 us per leapfrog at 10 000 x 10) (eta = intercept + x . beta' with beta' in LDS, the family's log-likelihood and r = d lp / d eta
+// by glm_kernel.h's `glm_row`, acc_p += r x_p in registers), the waves' totals meet in LDS, and the parameters' threads pick their
+// share up before the chain rule of their transforms -- what k_glm_reduce leaves in GlmDev.gdense on the general path.
+// (pm.math.dot(X, beta) under a Normal / Bernoulli-logit / Poisson-log likelihood: pymc/math.py:56, model/core.py:213-267.)
+#define GLM_SMALL_P 16
+#define GLM_SMALL_N 4096
+
 template <int NT, bool PROG>
 __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, SmallDrawArgs a) {
   constexpr int NW = NT / WAVE;
@@ -77,6 +89,9 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
   __shared__ double s_diag[LDSV ? 2 * SMALL_LDS_N : 1];
   __shared__ double s_pool[LDSV ? SMALL_POOL_DBL : 1];
   __shared__ double s_uni[LDSV ? SMALL_UNI_DBL : 1];
+  __shared__ double s_gbeta[GLM_SMALL_P];                    // the GLM node: beta' at the position being evaluated,
+  __shared__ double s_gpart[NW][GLM_SMALL_P + 3];            // the waves' totals [d/dbeta (P), d/dintercept, d/dsigma, logp],
+  __shared__ double s_gtot[GLM_SMALL_P + 3];                 // and the workgroup's
   const int tid = threadIdx.x;
   const int n = md.n;
   const bool mine = tid < n;
@@ -162,6 +177,61 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
         if (md.n_glong > 0) { __threadfence_block(); __syncthreads(); }
       }
     }
+    if (md.has_glm) {   // the GLM node, evaluated by the whole workgroup (header comment)
+      const GlmDev& gm = md.glm;
+      const int P = gm.P, FAMILY = gm.family;
+      for (int p = tid; p < P; p += NT) s_gbeta[p] = qv.at(gm.off_beta + p);
+      double icpt, sigma;
+      glm_scalars(gm, qv, icpt, sigma);
+      const double inv_sigma = 1.0 / sigma, log_sigma = FAMILY == NUTS_GLM_NORMAL ? log(sigma) : 0.0;
+      __syncthreads();
+      double acc[GLM_SMALL_P];
+#pragma unroll
+      for (int p = 0; p < GLM_SMALL_P; ++p) acc[p] = 0.0;
+      double lp_acc = 0.0, r_acc = 0.0, ds_acc = 0.0;
+      const int N = (int)gm.N;
+      const double* __restrict__ Xt = gm.Xt;     // [P][N]: column p of 64 consecutive rows is one coalesced load
+      for (int i0 = tid; i0 < N; i0 += 2 * NT) {
+        const int i1 = i0 + NT;
+        const bool two = i1 < N;
+        const int j1 = two ? i1 : i0;
+        double x0[GLM_SMALL_P], x1[GLM_SMALL_P];
+#pragma unroll
+        for (int p = 0; p < GLM_SMALL_P; ++p)      // (both rows' columns requested before the first is used)
+          if (p < P) { x0[p] = Xt[(int64_t)p * N + i0]; x1[p] = Xt[(int64_t)p * N + j1]; }
+        const double y0 = gm.y[i0], y1 = gm.y[j1];
+        double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+        for (int p = 0; p < GLM_SMALL_P; ++p)
+          if (p < P) { const double b = s_gbeta[p]; e0 = fma(x0[p], b, e0); e1 = fma(x1[p], b, e1); }
+        double lp0, r0, d0, lp1, r1, d1;
+        glm_row(FAMILY, e0 + icpt, y0, sigma, inv_sigma, log_sigma, lp0, r0, d0);
+        glm_row(FAMILY, e1 + icpt, y1, sigma, inv_sigma, log_sigma, lp1, r1, d1);
+        if (!two) { lp1 = 0.0; r1 = 0.0; d1 = 0.0; }
+#pragma unroll
+        for (int p = 0; p < GLM_SMALL_P; ++p)
+          if (p < P) { acc[p] = fma(r0, x0[p], acc[p]); acc[p] = fma(r1, x1[p], acc[p]); }
+        lp_acc += lp0; lp_acc += lp1;
+        r_acc += r0; r_acc += r1;
+        ds_acc += d0; ds_acc += d1;
+      }
+      const int w = tid >> 6, lane = tid & (WAVE - 1);
+#pragma unroll
+      for (int p = 0; p < GLM_SMALL_P; ++p)
+        if (p < P) { const double t = wave_sum(acc[p]); if (lane == 0) s_gpart[w][p] = t; }
+      {
+        const double t0 = wave_sum(r_acc), t1 = wave_sum(ds_acc), t2 = wave_sum(lp_acc);
+        if (lane == 0) { s_gpart[w][P] = t0; s_gpart[w][P + 1] = t1; s_gpart[w][P + 2] = t2; }
+      }
+      __syncthreads();
+      if (tid < P + 3) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) t += s_gpart[ww][tid];
+        s_gtot[tid] = t;
+      }
+      __syncthreads();
+    }
     if (mine) {
       double x, lj;
       if (v.normal_prior) {
@@ -173,6 +243,13 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
         transform_full(v, qn, x, dxdq, lj, dj);
         lp = lj;
         gather_element<PROG, false, true>(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], NT);
+      }
+      if (md.has_glm) {   // the node's gradient w.r.t. the constrained value of this thread's element (GlmDev.gdense on the general path)
+        const GlmDev& gm = md.glm;
+        if (tid >= gm.off_beta && tid < gm.off_beta + gm.P) gx += s_gtot[tid - gm.off_beta];
+        else if (tid == gm.off_icpt) gx += s_gtot[gm.P];
+        else if (tid == gm.off_sigma) gx += s_gtot[gm.P + 1];
+        if (tid == 0) lp += s_gtot[gm.P + 2] + gm.konst;   // (n >= 1: thread 0 always has an element)
       }
     }
     SMALL_TICK(8);     // (thread 0's own element)
