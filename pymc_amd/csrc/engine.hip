@@ -765,10 +765,18 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   std::vector<std::pair<int, int>> lin_used;   // (predictor, column) pairs of the factor being compiled (NUTS_OP_LIN operands)
   m->lin_uses.assign(std::max(s->n_lins, 0), {});
   for (int l = 0; l < s->n_lins; ++l) m->lin_uses[l].assign(std::max(std::min(s->lins[l].K, NUTS_LIN_MAXK), 0), {});
-  auto finish_gather = [&](int fi) -> bool {
+  // (round 6, last session) a LARGE factor with an expression program and no owning variable -- a likelihood over data whose
+  // parameters are scalars: curve fits, robust regressions written out -- is swept as well, with no slot at all: the sweep accounts
+  // its log-density and its scalars' adjoints (gs_part), and the scalar-driven sweep kernel walks it at a fraction of kernel B's cost
+  // per element (NUTS_GSWEEP_ORPHANS = 0: kernel B walks it, as before).  Models the single-workgroup kernel takes are not touched.
+  const bool sweep_orphans = gsweep_on && env_int("NUTS_GSWEEP_ORPHANS", 1) != 0;
+  auto finish_gather = [&](int fi, bool is_orphan = false) -> bool {
     // (a factor that reads a linear predictor MUST be swept: the sweep is where d logp / d eta comes from)
     const bool need = !lin_used.empty();
-    if (gathered.empty() && !need) return true;
+    const bool big_orphan = sweep_orphans && is_orphan && s->factors[fi].n_instr > 0 && s->factors[fi].size > SMALL_MAX_ELEMS &&
+                            s->factors[fi].dist != NUTS_D_DERIVED;
+    if (gathered.empty() && !need && !big_orphan) return true;
+    if (big_orphan) m->has_prog = true;
     const int64_t fsize = s->factors[fi].size;
     const size_t nsl = gathered.size() + lin_used.size();
     const bool fits = nsl <= MAX_GSLOTS && adj_len + (int64_t)nsl * fsize <= ((int64_t)1 << 28) && (int64_t)gs_elems + fsize <= ((int64_t)1 << 30);   // (2 GiB of adjoints)
@@ -948,7 +956,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
         } else { g_err = "variable does not broadcast against its factor"; return false; }
       }
       if (!owned_already) orphans.push_back(fi);
-      if (!finish_gather(fi)) return false;
+      if (!finish_gather(fi, !owned_already)) return false;
       continue;
     }
     for (int a = 0; a < f.nargs; ++a) {
@@ -1007,7 +1015,7 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
       }
     }
     if (!owned_already) orphans.push_back(fi);
-    if (!finish_gather(fi)) return false;
+    if (!finish_gather(fi, !owned_already)) return false;
   }
   // peephole: untransformed vector variable whose only contribution is its own constant-parameter Normal prior
   for (int k = 0; k < nv; ++k) {
@@ -1268,7 +1276,9 @@ static bool build_sweep_fast(nuts_model* m, const nuts_model_spec* s, const std:
   // the launch's LDS: a column per thread of broadcast accumulators, leaf values, slot adjoints, instruction values and adjoints
   const int rows = md.n_bterms + max_leaves + max_slots + 2 * max_instr;
   const int64_t bytes = (int64_t)rows * 64 * 8;
-  if (bytes > 64 * 1024) return true;   // (the generic sweeps stay: a program of more than ~ 60 instructions)
+  int max_n2 = 0;
+  for (const SwFactor& F : swf) max_n2 = std::max(max_n2, F.n2);
+  if (bytes > 64 * 1024 || max_leaves > SW_MAXL || max_n2 > SW_MAXL2) return true;   // (the generic sweeps stay: a program of more than ~ 60 instructions, more leaves than the kernel holds in registers)
   md.sw_blob = m->keep(dev_upload(blob.data(), blob.size()));
   if (!md.sw_blob) { g_err = "device allocation failed (resolved-operand sweep)"; return false; }
   md.n_swf = (int32_t)swf.size(); md.sw_bytes = (int32_t)blob.size(); md.sw_rows = rows;
@@ -2419,7 +2429,7 @@ extern "C" nuts_chain* nuts_chain_create(nuts_model* m, const nuts_chain_config*
   // (... and whose factors are small too: the single workgroup walks every factor element itself -- SMALL_MAX_ELEMS, round 6)
   // (round 6: a GLM node with few covariates and rows is evaluated inside that launch -- small_kernel.h GLM_SMALL_P / GLM_SMALL_N;
   // NUTS_GLM_SMALL = 0: the general path's four launches per leapfrog, A/B and tests)
-  const bool glm_small = m->md.has_glm && env_int("NUTS_GLM_SMALL", 1) != 0 && m->md.glm.Xt && !m->md.glm.beta_buf && m->md.glm.off_beta >= 0 && m->md.n_derived == 0;
+  const bool glm_small = m->md.has_glm && env_int("NUTS_GLM_SMALL", 1) != 0 && m->md.glm.Xt && !m->md.glm.beta_buf && m->md.glm.off_beta >= 0 && m->md.n_derived == 0 && n <= 256;   // (the 256-thread variant carries the node)
   c->small = env_int("NUTS_SMALL_KERNEL", 1) != 0 && n <= SMALL_MAX_N && m->ept == 1 && !m->md.has_logit && !m->md.has_mvn && !m->md.has_mix &&
              (!m->md.has_glm || glm_small) &&
              m->md.n_lins == 0 && m->factor_elems <= SMALL_MAX_ELEMS && !c->dense;   // (the single-workgroup kernel knows diagonal potentials only)

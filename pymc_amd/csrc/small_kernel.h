@@ -89,9 +89,9 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
   __shared__ double s_diag[LDSV ? 2 * SMALL_LDS_N : 1];
   __shared__ double s_pool[LDSV ? SMALL_POOL_DBL : 1];
   __shared__ double s_uni[LDSV ? SMALL_UNI_DBL : 1];
-  __shared__ double s_gbeta[GLM_SMALL_P];                    // the GLM node: beta' at the position being evaluated,
-  __shared__ double s_gpart[NW][GLM_SMALL_P + 3];            // the waves' totals [d/dbeta (P), d/dintercept, d/dsigma, logp],
-  __shared__ double s_gtot[GLM_SMALL_P + 3];                 // and the workgroup's
+  __shared__ double s_gbeta[NT == 256 ? GLM_SMALL_P : 1];                        // the GLM node: beta' at the position being evaluated,
+  __shared__ double s_gpart[NT == 256 ? NW : 1][NT == 256 ? GLM_SMALL_P + 3 : 1];   // the waves' totals [d/dbeta (P), d/dintercept, d/dsigma, logp],
+  __shared__ double s_gtot[NT == 256 ? GLM_SMALL_P + 3 : 1];                       // and the workgroup's
   const int tid = threadIdx.x;
   const int n = md.n;
   const bool mine = tid < n;
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
         if (md.n_glong > 0) { __threadfence_block(); __syncthreads(); }
       }
     }
-    if (md.has_glm) {   // the GLM node, evaluated by the whole workgroup (header comment)
+    if constexpr (NT == 256) if (md.has_glm) {   // the GLM node, evaluated by the whole workgroup (header comment; the 256-thread variant only: its
+                                                  // register budget holds the rows in flight -- a model with a small GLM node and n <= 256 runs on it)
       const GlmDev& gm = md.glm;
       const int P = gm.P, FAMILY = gm.family;
       for (int p = tid; p < P; p += NT) s_gbeta[p] = qv.at(gm.off_beta + p);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(NT) void k_small_draw(ModelDev md, ArenaDev Ag, Sma
         lp = lj;
         gather_element<PROG, false, true>(pg, qv, k, tid - v.offset, x, gx, lp, &s_bacc[0][tid], NT);
       }
-      if (md.has_glm) {   // the node's gradient w.r.t. the constrained value of this thread's element (GlmDev.gdense on the general path)
+      if constexpr (NT == 256) if (md.has_glm) {   // the node's gradient w.r.t. the constrained value of this thread's element (GlmDev.gdense on the general path)
         const GlmDev& gm = md.glm;
         if (tid >= gm.off_beta && tid < gm.off_beta + gm.P) gx += s_gtot[tid - gm.off_beta];
         else if (tid == gm.off_icpt) gx += s_gtot[gm.P];

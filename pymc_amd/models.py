@@ -352,3 +352,20 @@ def softmax_regression(N: int = 100_000, P: int = 4, K: int = 3, seed: int = DAT
         picked = picked + m.as_expr((y == k).astype("float64")) * etas[k]
     m.Potential("y", picked - lse)
     return m.build()
+
+
+def curve_fit(N: int = 100_000, seed: int = DATA_SEED) -> ModelSpec:
+    """A likelihood over N data points whose parameters are SCALARS, not expressible as a GLM: an exponential decay with an offset
+    under a Student-t noise model, `y_i ~ StudentT(4, a exp(-b t_i) + c, s)` -- the factor has an expression program and no owning
+    variable.  From 16 385 elements on the engine sweeps it with the scalar-driven adjoint sweep (csrc/kernels.h k_gsweep_fast) instead
+    of walking it in kernel B (round 6)."""
+    rng = np.random.default_rng(seed)
+    t = rng.uniform(0.0, 5.0, size=N)
+    y = 2.0 * np.exp(-0.7 * t) + 0.5 + 0.1 * rng.standard_t(4, size=N)
+    m = ModelBuilder()
+    a = m.Normal("a", 0.0, 5.0)
+    b = m.HalfNormal("b", 2.0)
+    c = m.Normal("c", 0.0, 5.0)
+    s = m.HalfNormal("s", 1.0)
+    m.StudentT("y", 4.0, a * m.math.exp(-(b * m.as_expr(t))) + c, s, observed=y)
+    return m.build()

@@ -72,3 +72,43 @@ def test_resolved_operand_sweep_carries_the_bits_of_the_generic_sweep(name, buil
             assert abs(lp1 - lp0) <= 4e-15 * max(1.0, abs(lp0)), (name, lp1, lp0)
         else:
             assert lp1 == lp0 or (np.isnan(lp1) and np.isnan(lp0)), name
+
+
+@pytest.mark.gpu
+def test_a_large_likelihood_with_a_program_and_scalar_parameters_is_swept(monkeypatch):
+    """`y_i ~ StudentT(4, a exp(-b t_i) + c, s)` over 40 000 points (pymc_amd/models.py curve_fit): a factor with an expression program and
+    no owning variable.  Round 6: from 16 385 elements on it is swept by the scalar-driven sweep (no slot: the sweep accounts its
+    log-density and its scalars' adjoints) instead of being walked by kernel B (NUTS_GSWEEP_ORPHANS = 0).  Both against the oracle at
+    1e-9, against each other at 1e-12; NUTS carries the oracle sampler's integers."""
+    from oracle import ref_models, ref_sampler
+    from pymc_amd import models
+    from pymc_amd.sampling import sample
+    from pymc_amd.value_grad import DeviceValueGradFunction
+
+    spec = models.curve_fit(N=40_000)
+    rng = np.random.default_rng(2)
+    qs = [np.array([1.5, -0.2, 0.3, -1.0]), rng.normal(size=spec.n) * 0.5, np.array([2.0, np.log(0.7), 0.5, np.log(0.12)])]
+    got = {}
+    for opt in ("1", "0"):
+        monkeypatch.setenv("NUTS_GSWEEP_ORPHANS", opt)
+        f = DeviceValueGradFunction(spec, device=0)
+        got[opt] = [f._pytensor_function(q) for q in qs]
+        f.close()
+    for i, q in enumerate(qs):
+        lp0, g0 = ref_models.evaluate(spec, q)
+        for opt in ("1", "0"):
+            lp, g = got[opt][i]
+            assert abs(lp - lp0) <= 1e-9 * abs(lp0) and np.max(np.abs(g - g0)) <= 1e-9 * np.max(np.abs(g0)), (opt, i, lp, lp0)
+        assert abs(got["1"][i][0] - got["0"][i][0]) <= 1e-12 * abs(lp0)
+        np.testing.assert_allclose(got["1"][i][1], got["0"][i][1], rtol=0, atol=1e-12 * np.max(np.abs(g0)))
+    monkeypatch.setenv("NUTS_GSWEEP_ORPHANS", "1")
+    res = sample(draws=8, tune=22, chains=1, model=spec, init="adapt_diag", random_seed=4, device=0)
+    _, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=8, tune=22, random_seed=4, init="adapt_diag")
+    dev = res["warmup_stats"][0] + res["stats"][0]
+    same = 0
+    for a_, b_ in zip(dev, ref_stats[0]):
+        if not all(int(a_[k]) == int(b_[k]) for k in ("depth", "tree_size", "index_in_trajectory", "diverging")):
+            break
+        same += 1
+    res["step"].close()
+    assert same >= 24, same      # (a late multinomial pick may flip on a last-bit difference of a 40 000-term sum)
