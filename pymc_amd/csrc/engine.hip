@@ -1276,9 +1276,7 @@ static bool build_sweep_fast(nuts_model* m, const nuts_model_spec* s, const std:
   // the launch's LDS: a column per thread of broadcast accumulators, leaf values, slot adjoints, instruction values and adjoints
   const int rows = md.n_bterms + max_leaves + max_slots + 2 * max_instr;
   const int64_t bytes = (int64_t)rows * 64 * 8;
-  int max_n2 = 0;
-  for (const SwFactor& F : swf) max_n2 = std::max(max_n2, F.n2);
-  if (bytes > 64 * 1024 || max_leaves > SW_MAXL || max_n2 > SW_MAXL2) return true;   // (the generic sweeps stay: a program of more than ~ 60 instructions, more leaves than the kernel holds in registers)
+  if (bytes > 64 * 1024) return true;   // (the generic sweeps stay: a program of more than ~ 60 instructions)
   md.sw_blob = m->keep(dev_upload(blob.data(), blob.size()));
   if (!md.sw_blob) { g_err = "device allocation failed (resolved-operand sweep)"; return false; }
   md.n_swf = (int32_t)swf.size(); md.sw_bytes = (int32_t)blob.size(); md.sw_rows = rows;

@@ -539,45 +539,38 @@ __global__ __launch_bounds__(GSL_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     const int n_instr = h1[0], nargs = h1[1], dist = h1[2], slot0 = h1[3], n_slots = h1[4], blk0 = h1[5];
     const double konst = sw_f64(h1[6], h1[7]);
     const int li = (blk - blk0) * S + tid;
-    // (lane l's copy of leaf l's descriptor -- fetched by EVERY lane, before the lanes beyond the factor's last element leave: a
-    // v_readlane of a lane that did not take part in the load would read whatever its register held)
-    const SwLeaf* Lg = reinterpret_cast<const SwLeaf*>(md.sw_blob + md.sw_po_leaf) + leaf0 + min(tid, nl - 1);
-    const int4 dsc = *reinterpret_cast<const int4*>(Lg);                                   // kind, bcast, voff, transform
-    const unsigned long long dptr = *reinterpret_cast<const unsigned long long*>(&Lg->ptr);
-    const int dlo = (int)(unsigned)dptr, dhi = (int)(unsigned)(dptr >> 32);
     if (li >= fsize) continue;                          // (the factor's last block)
     const CONSTAS SwLeaf* L = leaves + leaf0;
-    // ---- every leaf, up front, in THREE trips to memory whatever their number: lane l fetches leaf l's descriptor (one vector load
-    // instead of a scalar load per leaf: the phase clock showed 25 k cycles here, six to eight dependent trips); every leaf's direct
-    // load (data, predictor column, gather index) is then issued from its lane's copy (v_readlane) before the first is waited for;
-    // then the position's elements behind the gathers and the direct variables, likewise ----
-    {
-      double v[SW_MAXL];
+    // ---- every leaf, up front: first the direct loads (data, predictor columns, gather indices), four leaves in flight ----
+    for (int l0 = 0; l0 < nl; l0 += 4) {
+      double v[4];
 #pragma unroll
-      for (int l = 0; l < SW_MAXL; ++l)
-        if (l < nl) {
-          const int kind = __builtin_amdgcn_readlane(dsc.x, l), bc = __builtin_amdgcn_readlane(dsc.y, l);
-          const double* p = reinterpret_cast<const double*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, l) << 32) |
-                                                            (unsigned)__builtin_amdgcn_readlane(dlo, l));
-          v[l] = kind == SWL_VAR ? 0.0 : p[bc ? 0 : li];
-        }
-      double x[SW_MAXL2];
+      for (int u = 0; u < 4; ++u) {
+        const sw_v8i w = *reinterpret_cast<const CONSTAS sw_v8i*>(L + min(l0 + u, nl - 1));      // kind, bcast, voff, transform, ptr
+        const double* p = reinterpret_cast<const double*>(((unsigned long long)(unsigned)w[5] << 32) | (unsigned)w[4]);
+        v[u] = w[0] == SWL_VAR ? 0.0 : p[w[1] ? 0 : li];
+      }
 #pragma unroll
-      for (int l = 0; l < SW_MAXL2; ++l)
-        if (l < n2) {
-          const int kind = __builtin_amdgcn_readlane(dsc.x, l), bc = __builtin_amdgcn_readlane(dsc.y, l), voff = __builtin_amdgcn_readlane(dsc.z, l);
-          x[l] = qv.at(voff + (kind == SWL_GATHER ? (int)v[l] : (bc ? 0 : li)));
-        }
+      for (int u = 0; u < 4; ++u) if (l0 + u < nl) lv[(l0 + u) * S] = v[u];
+    }
+    // ... then the position's elements behind the gathers and the direct variables (the first n2 leaves)
+    for (int l0 = 0; l0 < n2; l0 += 4) {
+      double v[4];
+      int tr[4];
 #pragma unroll
-      for (int l = 0; l < SW_MAXL2; ++l)
-        if (l < n2) {
-          const int tr = __builtin_amdgcn_readlane(dsc.w, l);
-          if (tr != NUTS_TR_NONE) { const CONSTAS SwLeaf* Lf = L + l; x[l] = transform_x_ol(tr, Lf->lower, Lf->upper, x[l]); }
-          lv[l * S] = x[l];
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int l = min(l0 + u, n2 - 1);
+        const sw_v4i w = *reinterpret_cast<const CONSTAS sw_v4i*>(L + l);
+        tr[u] = w[3];
+        const int i2 = w[2] + (w[0] == SWL_GATHER ? (int)lv[l * S] : (w[1] ? 0 : li));
+        v[u] = qv.at(i2);
+      }
 #pragma unroll
-      for (int l = 0; l < SW_MAXL; ++l)
-        if (l < nl && l >= n2) lv[l * S] = v[l];
+      for (int u = 0; u < 4; ++u) if (l0 + u < n2) {
+        double x = v[u];
+        if (tr[u] != NUTS_TR_NONE) { const CONSTAS SwLeaf* Lf = L + l0 + u; x = transform_x_ol(tr[u], Lf->lower, Lf->upper, x); }
+        lv[(l0 + u) * S] = x;
+      }
     }
     for (int sl = 0; sl < n_slots; ++sl) la[sl * S] = 0.0;
     SWF_TICK(37);

@@ -201,8 +201,6 @@ struct GlmDev {
 #define SW_LEAF 6              // operand kind of the rewritten programs: entry `ref` of the element's leaf array
 #define SWL_DATA 0             // value = ptr[bcast ? 0 : li]                      (data vector, predictor column)
 #define SWL_GATHER 1           // value = transform(q'[voff + (int) ptr[li]])       (var[idx[li]])
-#define SW_MAXL 24             // leaves per factor the kernel holds in registers (more: the generic sweeps); of them at most
-#define SW_MAXL2 16            // ... this many that need the position (gathers, direct variables)
 #define SWL_VAR 2              // value = transform(q'[voff + (bcast ? 0 : li)])    (a scalar that broadcasts, an element-aligned vector)
 // (layouts the kernel reads with wide scalar loads: a leaf's first 32 bytes are what every leaf needs, a factor's first 64 its header)
 struct alignas(16) SwLeaf {

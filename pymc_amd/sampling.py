@@ -762,9 +762,20 @@ def sample(
             if group is None and lockstep:
                 raise ValueError("lockstep=True: the engine cannot advance this model's chains in one launch (pymc_amd/chain_group.py)")
 
+        # (the members of a chain group enter their first trees together: a worker whose thread came up late -- the first process on a
+        # cold box -- found the others' chains finished and the group never merged a launch; the draws do not depend on the company)
+        import threading
+
+        together = threading.Barrier(n_par) if group is not None and n_par > 1 else None
+
         def work(w):
             st = steps[w]
             st._logp_dlogp_func.bind_thread()
+            if together is not None:
+                try:
+                    together.wait(timeout=120.0)
+                except threading.BrokenBarrierError:      # (a worker that failed before it got here: the others go on alone)
+                    pass
             res = []
             for k in range(w, len(mine), n_par):
                 st.sampling_state = initial_state
