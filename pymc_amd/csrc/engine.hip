@@ -769,11 +769,12 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
   // parameters are scalars: curve fits, robust regressions written out -- is swept as well, with no slot at all: the sweep accounts
   // its log-density and its scalars' adjoints (gs_part), and the scalar-driven sweep kernel walks it at a fraction of kernel B's cost
   // per element (NUTS_GSWEEP_ORPHANS = 0: kernel B walks it, as before).  Models the single-workgroup kernel takes are not touched.
-  const bool sweep_orphans = gsweep_on && env_int("NUTS_GSWEEP_ORPHANS", 1) != 0;
+  const int sweep_orphans_opt = env_int("NUTS_GSWEEP_ORPHANS", 1);     // (2: also large orphan factors WITHOUT a program -- A/B)
+  const bool sweep_orphans = gsweep_on && sweep_orphans_opt != 0;
   auto finish_gather = [&](int fi, bool is_orphan = false) -> bool {
     // (a factor that reads a linear predictor MUST be swept: the sweep is where d logp / d eta comes from)
     const bool need = !lin_used.empty();
-    const bool big_orphan = sweep_orphans && is_orphan && s->factors[fi].n_instr > 0 && s->factors[fi].size > SMALL_MAX_ELEMS &&
+    const bool big_orphan = sweep_orphans && is_orphan && (s->factors[fi].n_instr > 0 || sweep_orphans_opt == 2) && s->factors[fi].size > SMALL_MAX_ELEMS &&
                             s->factors[fi].dist != NUTS_D_DERIVED;
     if (gathered.empty() && !need && !big_orphan) return true;
     if (big_orphan) m->has_prog = true;
