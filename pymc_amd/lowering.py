@@ -311,8 +311,15 @@ def build_tree(v, memo: Optional[dict] = None):
         kid = build_tree(ins[0], memo)
         shp = _eff_shape(ins[0])
         ax = getattr(op, "axis", None)
+        if shp is not None and len(shp) == 1 and MAX_DOT_INNER < shp[0] <= ms.LIN_MAXP and kid[0] != "const":
+            # the running sum of a LONG vector (a non-centred random walk: `sigma * pt.cumsum(eps)`, eps ~ Normal(0, 1)[T]) is the product
+            # with the lower-triangular matrix of ones -- a linear predictor with T rows and T columns (dense node 5, round 6): what
+            # `pytensor.grad` does with `CumOp` (a reversed running sum of the adjoints) is that matrix's transpose
+            out = ("dot", _const(np.tril(np.ones((shp[0], shp[0])))), kid)
+            memo[key] = out
+            return out
         if shp is None or ax is None or shp[ax % len(shp)] > 32:
-            raise NotLowerable("a cumulative sum over a long or unknown axis")
+            raise NotLowerable("a cumulative sum over a long or unknown axis (a vector of up to 512 elements is a linear predictor)")
         ax %= len(shp)
         pos = np.arange(_numel(shp), dtype=np.int64).reshape(shp)
         sl_shape = tuple(d for i, d in enumerate(shp) if i != ax)

@@ -24,7 +24,7 @@ def run():
     for name, make in lm.MODELS.items():
         m = make()
         n = sum(int(np.prod(s)) if s else 1 for s in (m.value_shapes[v.name] for v in m.value_vars))
-        qs = points(name, n) * (0.3 if name == "long_sums" else 1.0)
+        qs = points(name, n) * (0.3 if name in ("long_sums", "noncentred_random_walk_rate") else 1.0)
         vals = [gt.joint_logp_grad(m, q) for q in qs]
         out[f"{name}__q"] = qs
         out[f"{name}__logp"] = np.array([a for a, _ in vals])

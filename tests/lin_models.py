@@ -94,7 +94,26 @@ def long_sums():
     return m
 
 
+T_RW = 240
+_h = 1.2 + 0.15 * np.cumsum(_rg.normal(size=T_RW))
+Y_RW = _rg.poisson(np.exp(_h)).astype("float64")
+
+
+def noncentred_random_walk_rate():
+    """A log-rate that wanders, NON-CENTRED: `eps ~ Normal(0, 1)[240]`, `y_t ~ Poisson(exp(h0 + s * cumsum(eps)_t))` -- the running sum
+    of a long vector (`CumOp`; what `pm.GaussianRandomWalk` spares the user is exactly this parameterisation when the data are weak).
+    The lowering reads `cumsum` over more than 32 elements as the product with the lower-triangular matrix of ones: a linear predictor
+    with T rows and T columns (round 6)."""
+    m = sg.StubModel()
+    h0 = m.Normal("h0", 1.0, 2.0)
+    s = m.HalfNormal("s", 0.3)
+    eps = m.Normal("eps", 0.0, 1.0, shape=(T_RW,))
+    m.Poisson("y", mu=pt.exp(h0 + s * pt.cumsum(eps)), observed=Y_RW)
+    return m
+
+
 MODELS = {
+    "noncentred_random_walk_rate": noncentred_random_walk_rate,
     "tall_softmax_regression": tall_softmax_regression,
     "tall_robust_regression": tall_robust_regression,
     "negative_binomial_regression": negative_binomial_regression,

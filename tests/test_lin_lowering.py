@@ -1,6 +1,6 @@
 """Matrix products inside arguments through the lowering: `Dot` over a tall constant design matrix (or over an inner dimension too long
 to write out) becomes a LINEAR PREDICTOR (dense node 5, include/nuts_mi355.h `nuts_lin`, csrc/lin_kernel.h), `pt.sum(x)` over a long
-vector a predictor with one row.  VERDICT r05 listed both as refused by name ("long-axis reductions / `Dot` inside an argument").
+vector a predictor with one row, `pt.cumsum(x)` over a long vector the product with the lower-triangular matrix of ones.  VERDICT r05 listed both as refused by name ("long-axis reductions / `Dot` inside an argument").
 
 The graphs are what the reference's own `logp` bodies build (tests/lin_models.py on tests/stubgraph.py); committed with torch autograd
 of the graph at seeded points (tests/golden/make_lin_golden.py).  Checked here: the lowered spec through the oracle's interpreter ==
@@ -60,6 +60,9 @@ def test_what_the_products_lower_to():
     (L,) = spec.lins
     fi = -(L.cols[0][0] + 1)
     assert L.cols[0][0] < 0 and spec.factors[fi].dist == ms.D_DERIVED and spec.factors[fi].size == lm.P_WC
+    spec = _committed("noncentred_random_walk_rate")      # `cumsum` over 240 elements: the lower-triangular matrix of ones, one column
+    (L,) = spec.lins
+    assert L.X.shape == (lm.T_RW, lm.T_RW) and np.array_equal(L.X, np.tril(np.ones((lm.T_RW, lm.T_RW)))) and len(L.cols) == 1
     spec = _committed("long_sums")
     (L,) = spec.lins
     assert L.X.shape == (1, lm.L_SZ) and np.all(L.X == 1.0) and L.cols == [(1, 0, 1)]
