@@ -340,15 +340,59 @@ def build_tree(v, memo: Optional[dict] = None):
         out = build_tree(_ldlt_factor(ins[0]), memo)
     elif name == "Cholesky":
         kid = build_tree(ins[0], memo)
-        if kid[0] != "const":
-            raise NotLowerable("Cholesky of a non-constant matrix (the MvNormal node takes a constant covariance)")
-        L = np.linalg.cholesky(np.asarray(kid[1], dtype="float64"))
-        out = _const(L if getattr(op, "lower", True) else np.swapaxes(L, -1, -2))
+        shp = _eff_shape(ins[0]) if memo.get("__shapes__") else None
+        if kid[0] == "const":
+            L = np.linalg.cholesky(np.asarray(kid[1], dtype="float64"))
+            out = _const(L if getattr(op, "lower", True) else np.swapaxes(L, -1, -2))
+        elif shp is not None and len(shp) == 2 and shp[0] == shp[1] <= MAX_CHOLESKY:
+            # a SMALL covariance matrix of expressions (`pm.MvNormal(mu, cov=<a matrix built from the model's variables>)`: standard
+            # deviations and a correlation, a kernel over a handful of points): the Cholesky-Banachiewicz recurrence written out over the
+            # elements of the LOWER triangle, L_jj = sqrt(A_jj - sum_p L_jp^2), L_ij = (A_ij - sum_p L_ip L_jp) / L_jj -- LAPACK's `potrf`
+            # reads one triangle only as well.  A matrix that is not positive definite gives NaN on the diagonal, as
+            # `nan_lower_cholesky` does (multivariate.py:120-125: `on_error="nan"`), and `quaddist_chol`'s `diag > 0` check sees it
+            k_ = int(shp[0])
+            el = {}
+            for j in range(k_):
+                acc = ("index", kid, j * k_ + j)
+                for p in range(j):
+                    acc = ("sub", acc, ("sqr", el[j, p]))
+                el[j, j] = ("sqrt", acc)
+                for i in range(j + 1, k_):
+                    acc = ("index", kid, i * k_ + j)
+                    for p in range(j):
+                        acc = ("sub", acc, ("mul", el[i, p], el[j, p]))
+                    el[i, j] = ("div", acc, el[j, j])
+            lower = bool(getattr(op, "lower", True))
+            pieces = [el[(i, j) if lower else (j, i)] if (j <= i if lower else i <= j) else _const(0.0) for i in range(k_) for j in range(k_)]
+            out = ("joinnd", np.arange(k_ * k_, dtype=np.int64), np.zeros(k_ * k_, dtype=np.int64), (k_, k_), *pieces)
+        else:
+            raise NotLowerable(f"Cholesky of a non-constant matrix of more than {MAX_CHOLESKY} x {MAX_CHOLESKY} elements (the MvNormal node takes a constant "
+                               "covariance; a small one is factored element by element)")
     elif name == "MatrixInverse":
         kid = build_tree(ins[0], memo)
-        if kid[0] != "const":
-            raise NotLowerable("inverse of a non-constant matrix")
-        out = _const(np.linalg.inv(np.asarray(kid[1], dtype="float64")))
+        shp = _eff_shape(ins[0]) if memo.get("__shapes__") else None
+        if kid[0] == "const":
+            out = _const(np.linalg.inv(np.asarray(kid[1], dtype="float64")))
+        elif shp is not None and len(shp) == 2 and shp[0] == shp[1] <= 3:
+            # a 2 x 2 or 3 x 3 matrix of expressions (`pm.MvNormal(mu, tau=<a precision matrix built from the model's variables>)`:
+            # `quaddist_matrix` takes `matrix_inverse(tau)`, multivariate.py:137-141): the adjugate over the determinant, element by
+            # element -- no pivoting, any invertible matrix
+            k_ = int(shp[0])
+            a_ = lambda i, j: ("index", kid, i * k_ + j)            # noqa: E731
+            if k_ == 1:
+                adj, det = {(0, 0): _const(1.0)}, a_(0, 0)
+            elif k_ == 2:
+                adj = {(0, 0): a_(1, 1), (0, 1): ("neg", a_(0, 1)), (1, 0): ("neg", a_(1, 0)), (1, 1): a_(0, 0)}
+                det = ("sub", ("mul", a_(0, 0), a_(1, 1)), ("mul", a_(0, 1), a_(1, 0)))
+            else:
+                # adj[i][j] = cofactor(j, i) = the 2 x 2 minor of the cyclically next rows / columns (the sign is in the cyclic order)
+                adj = {(i, j): ("sub", ("mul", a_((j + 1) % 3, (i + 1) % 3), a_((j + 2) % 3, (i + 2) % 3)),
+                                ("mul", a_((j + 1) % 3, (i + 2) % 3), a_((j + 2) % 3, (i + 1) % 3))) for i in range(3) for j in range(3)}
+                det = ("add", ("add", ("mul", a_(0, 0), adj[0, 0]), ("mul", a_(0, 1), adj[1, 0])), ("mul", a_(0, 2), adj[2, 0]))
+            pieces = [("div", adj[i, j], det) for i in range(k_) for j in range(k_)]
+            out = ("joinnd", np.arange(k_ * k_, dtype=np.int64), np.zeros(k_ * k_, dtype=np.int64), (k_, k_), *pieces)
+        else:
+            raise NotLowerable("inverse of a non-constant matrix of more than 3 x 3 elements")
     elif name == "ExtractDiag":
         kid = build_tree(ins[0], memo)
         shp = _eff_shape(ins[0]) if memo.get("__shapes__") else None
@@ -451,6 +495,7 @@ def _numel(shape) -> int:
 
 
 MAX_SOLVE = 8          # (the side of a lower-triangular matrix of expressions whose `solve_triangular` is written out)
+MAX_CHOLESKY = 4       # (the side of a covariance matrix of expressions whose Cholesky factor is written out element by element)
 
 
 def _written_out_dot(a, b, sa, sb):

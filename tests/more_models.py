@@ -246,6 +246,105 @@ def three_outcomes_lkj():
     return m
 
 
+def correlated_outcomes_with_a_correlation_parameter():
+    """`y ~ MvNormal(mu, cov=Sigma)` with Sigma = [[s0^2, rho s0 s1], [rho s0 s1, s1^2]] assembled from the model's own variables
+    (`pt.stack`): the textbook bivariate normal with an explicit correlation.  `quaddist_matrix(cov=...)` hands the matrix over as it
+    is, `quaddist_chol` takes `nan_lower_cholesky` of a matrix that is NOT a tagged product (multivariate.py:120-185): the factor of a
+    small covariance matrix of expressions is written out element by element (`lowering.MAX_CHOLESKY`)."""
+    m = sg.StubModel()
+    s = m.HalfNormal("s", 2.0, shape=(2,))
+    rho = m.Uniform("rho", -1.0, 1.0)
+    mu = m.Normal("mu", 0.0, 3.0, shape=(2,))
+    c = rho * s[0] * s[1]
+    m.MvNormal("y", mu=mu, cov=pt.stack([pt.stack([s[0] ** 2, c]), pt.stack([c, s[1] ** 2])]), observed=Y_MV2)
+    return m
+
+
+def three_outcomes_with_a_banded_precision_matrix():
+    """`y ~ MvNormal(mu, tau=T)` with T a tridiagonal precision matrix assembled from the model's variables (neighbouring outcomes
+    conditionally dependent, the first and the last conditionally independent): `quaddist_matrix(tau=...)` takes `matrix_inverse(tau)`
+    (multivariate.py:137-141) and `quaddist_chol` the Cholesky factor of that -- the 3 x 3 inverse written out as adjugate / determinant,
+    then the factor element by element."""
+    m = sg.StubModel()
+    t = m.Gamma("t", 2.0, 1.0, shape=(3,))
+    r = m.Uniform("r", -0.5, 0.5, shape=(2,))
+    mu = m.Normal("mu", 0.0, 3.0, shape=(3,))
+    z, a, b = sg.as_tensor(0.0), r[0] * pt.sqrt(t[0] * t[1]), r[1] * pt.sqrt(t[1] * t[2])
+    m.MvNormal("y", mu=mu, tau=pt.stack([pt.stack([t[0], a, z]), pt.stack([a, t[1], b]), pt.stack([z, b, t[2]])]), observed=Y_MV3)
+    return m
+
+
+def heavy_tailed_correlated_outcomes():
+    """`y ~ MvStudentT(nu, mu, chol=chol)` (multivariate.py:398-516) with the degrees of freedom, the location and an `LKJCholeskyCov`
+    factor all variables: the same `quaddist_chol` as the MvNormal's, under `log1p(quaddist / nu)` and three `gammaln`s."""
+    m = sg.StubModel()
+    chol = m.LKJCholeskyCov("chol", n=2, eta=2.0, sd_dist=("Exponential", dict(lam=1.0)))
+    nu = m.Gamma("nu", 2.0, 0.1)
+    mu = m.Normal("mu", 0.0, 3.0, shape=(2,))
+    m.MvStudentT("y", nu=nu, mu=mu, chol=chol, observed=Y_MV2)
+    return m
+
+
+Y_SKT = np.sin(np.arange(40) * 1.7) * 1.5 + 0.4 * np.cos(np.arange(40) * 0.3) + 0.8          # (no random draws)
+C_DW = ((np.arange(40) * 7) % 6).astype("float64")
+
+
+def skewed_measurements_and_discrete_lifetimes():
+    """Two likelihoods the vocabulary lacked: the Jones-Faddy `pm.SkewStudentT(a, b, mu, sigma)` (continuous.py:2001-2078: `betaln` of
+    two variables) and `pm.DiscreteWeibull(q, beta)` (discrete.py:430-510: a difference of two powers of powers) -- every parameter a
+    variable of the model, lowered op by op."""
+    m = sg.StubModel()
+    a = m.Gamma("a", 3.0, 1.0)
+    b = m.Gamma("b", 3.0, 1.0)
+    mu = m.Normal("mu", 0.0, 3.0)
+    s = m.HalfNormal("s", 2.0)
+    m.SkewStudentT("y", a=a, b=b, mu=mu, sigma=s, observed=Y_SKT)
+    q = m.Beta("q", 2.0, 2.0)
+    beta = m.Gamma("beta", 2.0, 1.0)
+    m.DiscreteWeibull("c", q=q, beta=beta, observed=C_DW)
+    return m
+
+
+N_HU = 50
+X_HU = np.sin(np.arange(N_HU) * 0.9)
+_Z_HU = ((np.arange(N_HU) * 5) % 4 != 0).astype("float64")
+Y_HU_G = _Z_HU * (0.5 + np.abs(np.sin(np.arange(N_HU) * 1.3)) * 2.0)                      # (no random draws; a quarter of the amounts are zero)
+Y_HU_L = np.roll(_Z_HU, 1) * np.exp(0.3 + 0.8 * np.cos(np.arange(N_HU) * 0.7))
+
+
+def hurdle_models_of_positive_amounts():
+    """`pm.HurdleGamma` and `pm.HurdleLogNormal` (mixture.py:805-870, 981-1090): zeros from a process of their own, positive amounts
+    from a Gamma regression (mean `exp(a + b x)`) / a LogNormal whose hurdle probability depends on x -- the reference's
+    `marginal_hurdle_logprob` with its safe value under the switch."""
+    m = sg.StubModel()
+    psi = m.Beta("psi", 2.0, 2.0)
+    a = m.Normal("a", 0.0, 1.0)
+    b = m.Normal("b", 0.0, 1.0)
+    k = m.Gamma("k", 2.0, 1.0)
+    m.HurdleGamma("y", psi=psi, alpha=k, beta=k / pt.exp(a + b * sg.as_tensor(X_HU)), observed=Y_HU_G)
+    s = m.HalfNormal("s", 1.0)
+    m.HurdleLogNormal("w", psi=pt.sigmoid(0.5 * a + b * sg.as_tensor(X_HU)), mu=b, sigma=s, observed=Y_HU_L)
+    return m
+
+
+X_GP4 = np.array([0.0, 0.7, 1.5, 2.6])
+D2_GP4 = (X_GP4[:, None] - X_GP4[None, :]) ** 2
+Y_GP4 = np.stack([np.sin(X_GP4 * 1.3 + 0.35 * r) * (1.0 + 0.1 * (r % 3)) + 0.12 * np.cos(np.arange(4) * 2.3 + r) for r in range(15)])   # (no random draws)
+
+
+def replicated_curves_under_a_squared_exponential_kernel():
+    """Fifteen curves observed at the same four inputs, `y_r ~ MvNormal(0, K)`, K = eta^2 exp(-d^2 / (2 ell^2)) + sigma^2 I with the
+    amplitude, the length scale and the noise variables of the model: a Gaussian process's marginal likelihood over a handful of
+    inputs (`pm.gp.Marginal` builds exactly this `MvNormal(cov=K)`), the 4 x 4 factor written out."""
+    m = sg.StubModel()
+    eta = m.HalfNormal("eta", 2.0)
+    ell = m.Gamma("ell", 2.0, 2.0)
+    sigma = m.HalfNormal("sigma", 1.0)
+    K = eta ** 2 * pt.exp(sg.as_tensor(-0.5 * D2_GP4) / ell ** 2) + sigma ** 2 * sg.as_tensor(np.eye(4))
+    m.MvNormal("y", mu=sg.as_tensor(np.zeros(4)), cov=K, observed=Y_GP4)
+    return m
+
+
 COUNTS_DM = np.array([[2, 6, 8, 4], [1, 9, 7, 3], [4, 4, 6, 6], [0, 7, 10, 3], [3, 5, 9, 3], [2, 8, 5, 5], [1, 4, 12, 3], [5, 6, 6, 3], [2, 7, 7, 4]], dtype="float64")
 
 
@@ -342,6 +441,12 @@ MODELS = {
     "over_dispersed_counts": over_dispersed_counts,
     "multivariate_outcomes_lkj": multivariate_outcomes_lkj,
     "three_outcomes_lkj": three_outcomes_lkj,
+    "correlated_outcomes_with_a_correlation_parameter": correlated_outcomes_with_a_correlation_parameter,
+    "replicated_curves_under_a_squared_exponential_kernel": replicated_curves_under_a_squared_exponential_kernel,
+    "three_outcomes_with_a_banded_precision_matrix": three_outcomes_with_a_banded_precision_matrix,
+    "heavy_tailed_correlated_outcomes": heavy_tailed_correlated_outcomes,
+    "skewed_measurements_and_discrete_lifetimes": skewed_measurements_and_discrete_lifetimes,
+    "hurdle_models_of_positive_amounts": hurdle_models_of_positive_amounts,
     "varying_slopes_lkj": varying_slopes_lkj,
     "three_correlated_effects_lkj": three_correlated_effects_lkj,
     "truncated_likelihoods": truncated_likelihoods,

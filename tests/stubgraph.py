@@ -587,6 +587,11 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     def squeeze(x, axis=None):
         return as_tensor(x).squeeze(axis)
 
+    class special:
+        @staticmethod
+        def betaln(a, b):         # (`pytensor.tensor.special.betaln`: gammaln(a) + gammaln(b) - gammaln(a + b))
+            return pt.gammaln(a) + pt.gammaln(b) - pt.gammaln(a + b)
+
     class linalg:
         @staticmethod
         def cholesky(x, lower=True):
@@ -792,8 +797,8 @@ def _get_underlying_scalar_constant_value(v, *a, **k):
 _NS = None
 _CONT = ("Normal", "HalfNormal", "Cauchy", "HalfCauchy", "Exponential", "Laplace", "LogNormal", "StudentT", "Beta", "Gamma", "InverseGamma",
          "Uniform", "TruncatedNormal", "Weibull", "Logistic", "Gumbel", "SkewNormal", "Wald", "Kumaraswamy", "AsymmetricLaplace", "Pareto",
-         "HalfStudentT", "ExGaussian", "Triangular", "Moyal")
-_DISC = ("Bernoulli", "Binomial", "Poisson", "NegativeBinomial", "BetaBinomial", "Geometric")
+         "HalfStudentT", "ExGaussian", "Triangular", "Moyal", "SkewStudentT")
+_DISC = ("Bernoulli", "Binomial", "Poisson", "NegativeBinomial", "BetaBinomial", "Geometric", "DiscreteWeibull")
 
 
 def reference():
@@ -843,6 +848,7 @@ def reference():
     for fn in ("quaddist_matrix", "_logdet_from_cholesky", "quaddist_chol"):
         ref_function("distributions/multivariate.py", fn, ns)
     ref_class("distributions/multivariate.py", "MvNormal", ["dist", "logp"], _DistBase, ns)
+    ref_class("distributions/multivariate.py", "MvStudentT", ["dist", "logp"], _DistBase, ns)      # (multivariate.py:398-516: the same `quaddist_chol`)
     # Categorical (distributions/discrete.py:1140-1205): `dist`, `_safe_index_value_p`, `logp`
     import warnings
 
@@ -853,6 +859,7 @@ def reference():
     ref_class("distributions/distribution.py", "DiracDelta", ["dist", "logp"], _DistBase, ns)
     ns["Mixture"] = type("Mixture", (), {"dist": staticmethod(lambda w, comp_dists, **kw: (w, comp_dists))})   # (what `_zero_inflated_mixture(name=None, ...)` returns: its arguments)
     ref_function("distributions/mixture.py", "_zero_inflated_mixture", ns)
+    ref_function("distributions/mixture.py", "marginal_hurdle_logprob", ns)      # (mixture.py:846-870: the hurdle models' density)
     # `pm.Censored` (distributions/censored.py:132-146 -> `clip` of the base variable; logprob/censoring.py:198-250 `clip_logprob`): the
     # dispatchers it calls resolve to the base distribution's own `logp` / `logcdf` / `logccdf` (logprob/abstract.py:129-145: log1mexp of
     # the logcdf when the distribution registers no logccdf)
@@ -1154,6 +1161,12 @@ class StubModel:
     def Moyal(self, name, mu, sigma, observed):
         return self._rv("Moyal", name, np.shape(observed), _dist("Moyal", mu, sigma), None, observed)
 
+    def SkewStudentT(self, name, a, b, mu, sigma, observed):
+        return self._rv("SkewStudentT", name, np.shape(observed), _dist("SkewStudentT", a=a, b=b, mu=mu, sigma=sigma), None, observed)   # continuous.py:2001-2078
+
+    def DiscreteWeibull(self, name, q, beta, observed):
+        return self._rv("DiscreteWeibull", name, np.shape(observed), _dist("DiscreteWeibull", q=q, beta=beta), None, observed)   # discrete.py:430-510
+
     def SkewNormal(self, name, alpha=1.0, mu=0.0, sigma=1.0, shape=(), observed=None):
         return self._rv("SkewNormal", name, shape, _dist("SkewNormal", alpha=alpha, mu=mu, sigma=sigma), None, observed)
 
@@ -1347,6 +1360,24 @@ class StubModel:
         fn = lambda value, w_, *cs: ref["mixture_logprob"](None, (value,), None, w_, *cs)   # noqa: E731
         return self._add(_RV(name, np.shape(observed), fn, (w, *comps), None, observed))
 
+    def _hurdle(self, name, psi, cls_name, params, observed):
+        """`_Hurdle._create` (mixture.py:813-843) for a CONTINUOUS non-zero distribution (no truncation: it has no mass at zero): weights
+        `stack([1 - psi, psi], axis=-1)`, components `[DiracDelta.dist(0), nonzero_dist]`; the density is `marginal_hurdle_logprob`."""
+        ref = reference()
+        psi = as_tensor(psi)
+        w = pt.stack([1 - psi, psi], axis=-1)
+        zero, nonzero = _ComponentRV(ref["DiracDelta"], _dist("DiracDelta", np.asarray(0.0))), _ComponentRV(ref[cls_name], params)
+        fn = lambda value, w_, z_, d_: ref["marginal_hurdle_logprob"](None, (value,), None, w_, z_, d_)   # noqa: E731
+        return self._add(_RV(name, np.shape(observed), fn, (w, zero, nonzero), None, observed))
+
+    def HurdleGamma(self, name, psi, alpha, beta, observed):
+        """`pm.HurdleGamma(name, psi=, alpha=, beta=, observed=y)` (mixture.py:981-1034)."""
+        return self._hurdle(name, psi, "Gamma", _dist("Gamma", alpha=_num_or_var(alpha), beta=beta), observed)
+
+    def HurdleLogNormal(self, name, psi, mu, sigma, observed):
+        """`pm.HurdleLogNormal(name, psi=, mu=, sigma=, observed=y)` (mixture.py:1037-1090)."""
+        return self._hurdle(name, psi, "LogNormal", _dist("LogNormal", mu=mu, sigma=sigma), observed)
+
     def Mixture(self, name, w, comp_dists, observed):
         """`pm.Mixture(name, w=w, comp_dists=..., observed=y)` (mixture.py:166-176, 469-495): `comp_dists` is ONE batched component
         `("Poisson", dict(mu=...))` (mixture axis last) or a LIST of scalar components of any families
@@ -1375,6 +1406,13 @@ class StubModel:
         shp = lambda a: a.type.shape if isinstance(a, Variable) else np.shape(a)      # noqa: E731
         k = shp(mu)[-1] if len(shp(mu)) else shp(cov if cov is not None else chol if chol is not None else tau)[-1]
         return self._rv("MvNormal", name, shape or (k,), params, None, observed)
+
+    def MvStudentT(self, name, nu, mu, scale=None, chol=None, tau=None, shape=None, observed=None):
+        """`pm.MvStudentT(name, nu=nu, mu=mu, scale=scale | chol=chol | tau=tau)` (multivariate.py:398-516)."""
+        params = _dist("MvStudentT", _num_or_var(nu), mu=mu, scale=scale, chol=chol, tau=tau)
+        shp = lambda a: a.type.shape if isinstance(a, Variable) else np.shape(a)      # noqa: E731
+        k = shp(mu)[-1] if len(shp(mu)) else shp(scale if scale is not None else chol if chol is not None else tau)[-1]
+        return self._rv("MvStudentT", name, shape or (k,), params, None, observed)
 
     def Bernoulli(self, name, logit_p, observed):
         return self._rv("Bernoulli", name, np.shape(observed), _dist("Bernoulli", logit_p=logit_p), None, observed)   # discrete.py:351-352
