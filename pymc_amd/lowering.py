@@ -331,6 +331,17 @@ def build_tree(v, memo: Optional[dict] = None):
         piece = np.broadcast_to(np.arange(shp[ax], dtype=np.int64).reshape([-1 if i == ax else 1 for i in range(len(shp))]), shp)
         inner = np.broadcast_to(np.expand_dims(np.arange(_numel(sl_shape), dtype=np.int64).reshape(sl_shape), ax), shp)
         out = ("joinnd", np.ascontiguousarray(piece).ravel(), np.ascontiguousarray(inner).ravel(), tuple(shp), *pieces)
+    elif name == "Nonzero":
+        # `x.nonzero()` of a matrix of CONSTANTS (an adjacency matrix turned into an edge list): output `index` of the node's outputs
+        # (`eq(tril(W), 1).nonzero()`, ICAR's edge list, multivariate.py:2437; comparisons of constants are not folded in general -- the
+        # templates match on them -- so the operand is evaluated here)
+        kid = build_tree(ins[0], memo)
+        try:
+            val = np.asarray(kid[1] if kid[0] == "const" else _eval_tree(kid, {}))
+        except Exception:
+            raise NotLowerable("nonzero of a non-constant") from None
+        shp = _eff_shape(ins[0])
+        out = _const(np.nonzero(val.reshape(shp) if shp is not None else val)[int(getattr(v, "index", 0) or 0)].astype("float64"))
     elif name == "Transpose":
         kid = build_tree(ins[0], memo)
         out = _const(np.swapaxes(kid[1], -1, -2)) if kid[0] == "const" else ("transpose", kid)

@@ -121,6 +121,8 @@ def evaluate(var, values: dict, memo: dict | None = None):
                 out = torch.softmax(ev(ins[0]), dim=op.axis)
             elif name == "Shape":
                 out = torch.as_tensor(np.asarray(ins[0].type.shape, dtype="float64"))
+            elif name == "Nonzero":
+                out = torch.nonzero(ev(ins[0]), as_tuple=True)[int(getattr(v, "index", 0))]
             elif name == "Cholesky":
                 L = torch.linalg.cholesky(ev(ins[0]))
                 out = L if getattr(op, "lower", True) else L.swapaxes(-1, -2)

@@ -112,7 +112,38 @@ def noncentred_random_walk_rate():
     return m
 
 
+def _lattice(rows, cols):
+    n = rows * cols
+    W = np.zeros((n, n), dtype=np.int64)
+    for i in range(rows):
+        for j in range(cols):
+            k = i * cols + j
+            if j + 1 < cols:
+                W[k, k + 1] = W[k + 1, k] = 1
+            if i + 1 < rows:
+                W[k, k + cols] = W[k + cols, k] = 1
+    return W
+
+
+W_ICAR = _lattice(7, 8)
+E_ICAR = 20.0 + 10.0 * np.cos(np.arange(56) * 0.7)
+Y_ICAR = np.floor(E_ICAR * np.exp(0.3 * np.sin(np.arange(56) * 0.5)))                  # (no random draws)
+
+
+def icar_over_fifty_six_areas():
+    """`pm.ICAR` (multivariate.py:2315-2447) over a 7 x 8 lattice: 97 edges and 56 areas -- the sum of the squared differences over the
+    edge list and the sum of the areas' effects are sums over LONG vectors (tests/more_models.py has the same model over 20 areas, written
+    out): linear predictors with a row of ones."""
+    m = sg.StubModel()
+    sigma = m.Exponential("sigma", 1.0)
+    b0 = m.Normal("b0", 0.0, 1.0)
+    phi = m.ICAR("phi", W=W_ICAR, sigma=sigma)
+    m.Poisson("y", mu=pt.exp(sg.as_tensor(np.log(E_ICAR)) + b0 + phi), observed=Y_ICAR)
+    return m
+
+
 MODELS = {
+    "icar_over_fifty_six_areas": icar_over_fifty_six_areas,
     "noncentred_random_walk_rate": noncentred_random_walk_rate,
     "tall_softmax_regression": tall_softmax_regression,
     "tall_robust_regression": tall_robust_regression,

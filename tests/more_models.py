@@ -327,6 +327,38 @@ def hurdle_models_of_positive_amounts():
     return m
 
 
+def lattice_adjacency(rows, cols):
+    """Rook adjacency of a rows x cols lattice: the symmetric 0 / 1 matrix `pm.ICAR` takes."""
+    n = rows * cols
+    W = np.zeros((n, n), dtype=np.int64)
+    for i in range(rows):
+        for j in range(cols):
+            k = i * cols + j
+            if j + 1 < cols:
+                W[k, k + 1] = W[k + 1, k] = 1
+            if i + 1 < rows:
+                W[k, k + cols] = W[k + cols, k] = 1
+    return W
+
+
+W_CAR = lattice_adjacency(4, 5)
+E_CAR = 20.0 + 10.0 * np.cos(np.arange(20) * 0.7)
+Y_CAR = np.floor(E_CAR * np.exp(0.3 * np.sin(np.arange(20) * 0.5)))                    # (no random draws)
+
+
+def disease_counts_over_a_lattice_of_areas():
+    """Counts per area with an intrinsic conditional autoregression over the areas' adjacency (`pm.ICAR`, multivariate.py:2315-2447;
+    the spatial part of the Besag-York-Mollie model of its docstring): `ICAR.logp` turns the constant adjacency matrix into an edge
+    list -- `pt.eq(pt.tril(W), 1).nonzero()`, folded here -- sums the squared differences over the 31 edges and adds a soft
+    sum-to-zero term over the 20 areas."""
+    m = sg.StubModel()
+    sigma = m.Exponential("sigma", 1.0)
+    b0 = m.Normal("b0", 0.0, 1.0)
+    phi = m.ICAR("phi", W=W_CAR, sigma=sigma)
+    m.Poisson("y", mu=pt.exp(sg.as_tensor(np.log(E_CAR)) + b0 + phi), observed=Y_CAR)
+    return m
+
+
 X_GP4 = np.array([0.0, 0.7, 1.5, 2.6])
 D2_GP4 = (X_GP4[:, None] - X_GP4[None, :]) ** 2
 Y_GP4 = np.stack([np.sin(X_GP4 * 1.3 + 0.35 * r) * (1.0 + 0.1 * (r % 3)) + 0.12 * np.cos(np.arange(4) * 2.3 + r) for r in range(15)])   # (no random draws)
@@ -447,6 +479,7 @@ MODELS = {
     "heavy_tailed_correlated_outcomes": heavy_tailed_correlated_outcomes,
     "skewed_measurements_and_discrete_lifetimes": skewed_measurements_and_discrete_lifetimes,
     "hurdle_models_of_positive_amounts": hurdle_models_of_positive_amounts,
+    "disease_counts_over_a_lattice_of_areas": disease_counts_over_a_lattice_of_areas,
     "varying_slopes_lkj": varying_slopes_lkj,
     "three_correlated_effects_lkj": three_correlated_effects_lkj,
     "truncated_likelihoods": truncated_likelihoods,

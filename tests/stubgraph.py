@@ -107,6 +107,15 @@ class Variable:
         shape = np.empty(self.type.shape, dtype=np.int8)[idx].shape
         return Variable(Apply(Subtensor(tup), [self]), shape=shape)
 
+    def nonzero(self):
+        """`x.nonzero()` -> `Nonzero()(x)`: a tuple of index vectors, one per dimension."""
+        idx = np.nonzero(_constant_value(self))
+        node = Apply(Nonzero(), [self])
+        node.outputs = [Variable(node, shape=(len(i),)) for i in idx]
+        for k, o in enumerate(node.outputs):
+            o.index = k
+        return tuple(node.outputs)
+
     @property
     def shape(self): return Variable(Apply(Shape(), [self]), shape=(len(self.type.shape),))
     def astype(self, dtype): return elemwise(Cast, self)
@@ -240,6 +249,30 @@ class TakeAlongAxis:
 
     def __init__(self, axis=-1):
         self.axis = axis
+
+
+class Nonzero:
+    """`pytensor.tensor.basic.Nonzero` (`x.nonzero()`): one integer vector per dimension of x, all of them outputs of ONE apply node
+    (`owner.outputs`, `Variable.index`).  PyTensor's static shape of these outputs is `(None,)`; here the operand has to be a graph of
+    constants (ICAR's adjacency matrix, multivariate.py:2437) and the outputs carry the length the folded operand gives."""
+
+
+def _constant_value(v):
+    """The value of a graph that has constants at all its leaves (what PyTensor's constant folding would leave behind), for the few
+    ops `nonzero` meets here."""
+    if isinstance(v, TensorConstant):
+        return np.asarray(v.data)
+    if v.owner is None:
+        raise TypeError("nonzero of a graph that depends on a variable")
+    kids = [_constant_value(i) for i in v.owner.inputs]
+    name = type(getattr(v.owner.op, "scalar_op", v.owner.op)).__name__
+    if name == "Mul":
+        return kids[0] * kids[1]
+    if name == "EQ":
+        return kids[0] == kids[1]
+    if name == "DimShuffle":
+        return np.reshape(kids[0], v.type.shape)
+    raise TypeError(f"_constant_value: {name}")
 
 
 class Cholesky:
@@ -423,6 +456,8 @@ class pt:   # the `pytensor.tensor` names the reference's logp bodies use
     inf = np.inf
     constant = staticmethod(lambda x, **kw: TensorConstant(x))
     as_tensor_variable = staticmethod(lambda x, dtype=None, **kw: as_tensor(x))
+    # `pt.tril(m, k)` = `m * tri(*m.shape[-2:], k=k, dtype=m.dtype)` (pytensor/tensor/basic.py): the `Tri` of static sizes stated as the constant it folds to
+    tril = staticmethod(lambda m, k=0: as_tensor(m) * TensorConstant(np.tri(*as_tensor(m).type.shape[-2:], k=k)))
     zeros_like = staticmethod(lambda a, dtype=None: elemwise(Second, a, 0.0))     # pt.zeros_like = fill(a, 0)
 
     @staticmethod
@@ -848,6 +883,7 @@ def reference():
     for fn in ("quaddist_matrix", "_logdet_from_cholesky", "quaddist_chol"):
         ref_function("distributions/multivariate.py", fn, ns)
     ref_class("distributions/multivariate.py", "MvNormal", ["dist", "logp"], _DistBase, ns)
+    ref_class("distributions/multivariate.py", "ICAR", ["dist", "logp"], _DistBase, ns)            # (multivariate.py:2315-2447)
     ref_class("distributions/multivariate.py", "MvStudentT", ["dist", "logp"], _DistBase, ns)      # (multivariate.py:398-516: the same `quaddist_chol`)
     # Categorical (distributions/discrete.py:1140-1205): `dist`, `_safe_index_value_p`, `logp`
     import warnings
@@ -1407,6 +1443,12 @@ class StubModel:
         k = shp(mu)[-1] if len(shp(mu)) else shp(cov if cov is not None else chol if chol is not None else tau)[-1]
         return self._rv("MvNormal", name, shape or (k,), params, None, observed)
 
+    def ICAR(self, name, W, sigma=1.0, zero_sum_stdev=0.001):
+        """`pm.ICAR(name, W=W, sigma=sigma, zero_sum_stdev=...)` (multivariate.py:2315-2447): the intrinsic conditional autoregression over
+        the areas of an adjacency matrix -- squared differences over the edge list `eq(tril(W), 1).nonzero()` and a soft sum-to-zero term."""
+        W = np.asarray(W)
+        return self._rv("ICAR", name, (W.shape[0],), _dist("ICAR", W, sigma=sigma, zero_sum_stdev=zero_sum_stdev), None, None)
+
     def MvStudentT(self, name, nu, mu, scale=None, chol=None, tau=None, shape=None, observed=None):
         """`pm.MvStudentT(name, nu=nu, mu=mu, scale=scale | chol=chol | tau=tau)` (multivariate.py:398-516)."""
         params = _dist("MvStudentT", _num_or_var(nu), mu=mu, scale=scale, chol=chol, tau=tau)
@@ -1495,6 +1537,8 @@ def dump_model(m) -> dict:
             rec = {"k": "op", "op": type(op).__name__, "ins": ins, "shape": list(v.type.shape)}
             if getattr(v.tag, "lower_triangular", False):
                 rec["lower_triangular"] = True
+            if type(op).__name__ == "Nonzero":
+                rec["out_index"] = int(v.index)
             if hasattr(op, "scalar_op"):
                 if type(op.scalar_op).__name__ == "Composite":
                     raise TypeError("Composite nodes are not written down (they only occur in rewritten graphs)")
@@ -1530,7 +1574,7 @@ def dump_model(m) -> dict:
 
 
 _OPS = {c.__name__: c for c in (DimShuffle, AdvancedSubtensor1, Sum, CheckParameterValue, All, MakeVector, Softmax, Dot, Shape, Transpose, ExtractDiag, MatrixInverse,
-                                Any, Max, Join, Prod, AdvancedSubtensor)}
+                                Any, Max, Join, Prod, AdvancedSubtensor, Nonzero)}
 _OPS_AXIS = ("Sum", "All", "Softmax", "TakeAlongAxis")
 
 
@@ -1572,6 +1616,8 @@ class FrozenModel:
                 v = Variable(Apply(op, ins), shape=rec["shape"])
                 if rec.get("lower_triangular"):
                     v.tag.lower_triangular = True
+                if "out_index" in rec:
+                    v.index = int(rec["out_index"])
             vs.append(v)
         self._outs = [vs[i] for i in d["outs"]]
         self.value_vars = [vs[i] for i in d["value_vars"]]

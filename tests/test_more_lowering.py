@@ -284,6 +284,17 @@ def _hurdles(q):
     return lp + np.log1p(-pw[~pos]).sum() + np.log(pw[pos]).sum() + stats.lognorm(s, scale=np.exp(b)).logpdf(tm.Y_HU_L[pos]).sum()
 
 
+def _icar_density(phi, W, sigma, zs=0.001):
+    i, j = np.nonzero(np.tril(W))
+    return -np.sum((phi[i] - phi[j]) ** 2) / (2.0 * sigma**2) + stats.norm(0.0, zs * len(phi)).logpdf(phi.sum())
+
+
+def _lattice_counts(q):
+    sigma, b0, phi = np.exp(q[0]), q[1], q[2:]
+    lp = stats.expon.logpdf(sigma) + q[0] + stats.norm(0, 1).logpdf(b0) + _icar_density(phi, tm.W_CAR, sigma)
+    return lp + stats.poisson(tm.E_CAR * np.exp(b0 + phi)).logpmf(tm.Y_CAR).sum()
+
+
 def test_a_covariance_that_is_not_positive_definite_is_minus_infinity_not_an_error():
     """`nan_lower_cholesky` (multivariate.py:120-125) returns NaN for such a matrix and `quaddist_chol`'s `diag > 0` check turns the
     density into -inf; the written-out factor's `sqrt` of a negative pivot does the same.  (No point of this model has one: |rho| < 1 by
@@ -393,7 +404,7 @@ def _truncated(q):
     return lp + (G.logpdf(tm.Y_TR3) - np.log(G.cdf(1.0))).sum()
 
 
-@pytest.mark.parametrize("name, dens", [("censored_measurements", _censored), ("survival_with_a_custom_density", _survival), ("bayesian_neural_network", _bnn), ("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("correlated_outcomes_with_a_correlation_parameter", _correlated_outcomes), ("replicated_curves_under_a_squared_exponential_kernel", _gp_curves), ("three_outcomes_with_a_banded_precision_matrix", _banded_precision), ("heavy_tailed_correlated_outcomes", _heavy_tailed_outcomes), ("skewed_measurements_and_discrete_lifetimes", _skewed_and_lifetimes), ("hurdle_models_of_positive_amounts", _hurdles), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
+@pytest.mark.parametrize("name, dens", [("censored_measurements", _censored), ("survival_with_a_custom_density", _survival), ("bayesian_neural_network", _bnn), ("double_well_sde", _double_well), ("over_dispersed_counts", _dm_counts), ("multivariate_outcomes_lkj", _mv_outcomes), ("correlated_outcomes_with_a_correlation_parameter", _correlated_outcomes), ("replicated_curves_under_a_squared_exponential_kernel", _gp_curves), ("three_outcomes_with_a_banded_precision_matrix", _banded_precision), ("heavy_tailed_correlated_outcomes", _heavy_tailed_outcomes), ("skewed_measurements_and_discrete_lifetimes", _skewed_and_lifetimes), ("hurdle_models_of_positive_amounts", _hurdles), ("disease_counts_over_a_lattice_of_areas", _lattice_counts), ("varying_slopes_lkj", _varying_slopes), ("truncated_likelihoods", _truncated), ("ordered_probit_three_levels", _ordered_probit),
                                         ("ordered_probit_four_levels", _ordered_probit4), ("zero_inflated_binomial_and_negative_binomial", _zi_counts),
                                         ("softmax_regression", _softmax_reg), ("robust_regression_with_dot", _robust_dot), ("zero_sum_group_effects", _zs_groups), ("zero_sum_log_rates", _zs_rates), ("stochastic_volatility", _sv), ("ar2_with_constant", _ar2), ("ar1_latent", _ar1), ("random_walk_rate_under_counts", _rate)])
 def test_the_densities_are_the_textbook_ones(name, dens):
