@@ -142,7 +142,55 @@ def icar_over_fifty_six_areas():
     return m
 
 
+_rg2 = np.random.default_rng(20260931)      # (a generator of its own: the arrays above keep their values)
+REG_RW = (np.arange(T_RW) // 80).astype(np.int64)
+Y_RW3 = _rg2.poisson(np.exp(1.2 + 0.1 * np.cumsum(_rg2.normal(size=T_RW)))).astype("float64")
+
+
+def regime_scaled_random_walk():
+    """The non-centred random walk with an innovation scale PER REGIME: `cumsum(s[regime] * eps)` -- the coefficient vector of the
+    predictor is a derived vector that reads `s` through an index vector (its seed arrives from the predictor's backward pass: the
+    ordering the 56-area ICAR got wrong before the fix, here with an owning variable)."""
+    m = sg.StubModel()
+    h0 = m.Normal("h0", 1.0, 2.0)
+    s = m.HalfNormal("s", 0.3, shape=(3,))
+    eps = m.Normal("eps", 0.0, 1.0, shape=(T_RW,))
+    m.Poisson("y", mu=pt.exp(h0 + pt.cumsum(s[REG_RW] * eps)), observed=Y_RW3)
+    return m
+
+
+G_VS = 12
+GI_VS = ((np.arange(N_TR) * 7) % G_VS).astype(np.int64)
+Y_VS = Y_TR + 0.3 * np.sin(GI_VS)
+X2_TR = _rg2.normal(size=(N_TR, 3))
+
+
+def varying_intercepts_and_scales_under_a_predictor():
+    """`StudentT(nu, mu = dot(X, b) + a[g], sigma = s[g])` over 1 500 rows: a linear predictor, two gathers and a scalar that broadcasts,
+    all operands of one factor's program."""
+    m = sg.StubModel()
+    b = m.Normal("b", 0.0, 2.0, shape=(P_TR,))
+    a = m.Normal("a", 0.0, 1.0, shape=(G_VS,))
+    s = m.HalfNormal("s", 1.0, shape=(G_VS,))
+    nu = m.Gamma("nu", 2.0, 0.1)
+    m.StudentT("y", nu, mu=pt.dot(sg.as_tensor(X_TR), b) + a[GI_VS], sigma=s[GI_VS], observed=Y_VS)
+    return m
+
+
+def two_design_matrices():
+    """`Laplace(mu = dot(X1, b1) + tanh(dot(X2, b2)), b = s)`: two predictors over two different constant matrices in one argument."""
+    m = sg.StubModel()
+    b1 = m.Normal("b1", 0.0, 2.0, shape=(P_TR,))
+    b2 = m.Normal("b2", 0.0, 2.0, shape=(3,))
+    s = m.HalfNormal("s", 1.0)
+    m.Laplace("y", mu=pt.dot(sg.as_tensor(X_TR), b1) + pt.tanh(pt.dot(sg.as_tensor(X2_TR), b2)), b=s, observed=Y_TR)
+    return m
+
+
 MODELS = {
+    "regime_scaled_random_walk": regime_scaled_random_walk,
+    "varying_intercepts_and_scales_under_a_predictor": varying_intercepts_and_scales_under_a_predictor,
+    "two_design_matrices": two_design_matrices,
     "icar_over_fifty_six_areas": icar_over_fifty_six_areas,
     "noncentred_random_walk_rate": noncentred_random_walk_rate,
     "tall_softmax_regression": tall_softmax_regression,
