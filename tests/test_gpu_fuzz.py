@@ -218,3 +218,56 @@ def test_nuts_on_a_drawn_model_has_the_oracle_samplers_integers(case):
 # (tools/fuzz_case_trace.py 81 on the device: step size, energy and acceptance agree with the oracle's to 1e-12 over the first three
 # transitions and part at 6e-6 INSIDE the 127-leaf tree of the fourth -- a kink crossed, not an error that grows)
 DEVICE_BAR = {81: 5}
+
+
+def _small_cases():
+    out = []
+    for case in CASES:
+        spec, _ = fuzz_model(case)
+        if spec.n <= 60 and max(f.size for f in spec.factors) <= 300:
+            out.append(case)
+    return out[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _small_cases())
+def test_a_dense_adapted_mass_matrix_on_a_drawn_model_has_the_oracles_integers(case):
+    """`init="adapt_full"` (mcmc.py:1984-1991: `QuadPotentialFullAdapt`, covariance and Cholesky factor refreshed while tuning) on the
+    small drawn models: the engine's dense-potential kernels under a model of the general IR, against the oracle's sampler."""
+    import warnings
+
+    from pymc_amd.sampling import sample
+
+    spec, desc = fuzz_model(case)
+    tune, draws, seed = 14, 3, 9
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)          # ("QuadPotentialFullAdapt is an experimental feature")
+        res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_full", random_seed=seed, device=0)
+        _, ref_stats = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_full")
+    got = res["warmup_stats"][0] + res["stats"][0]
+    res["step"].close()
+    same = 0
+    for a_, b_ in zip(got, ref_stats[0]):
+        if not all(int(a_[k]) == int(b_[k]) for k in INT_KEYS):
+            break
+        same += 1
+    assert same >= tune + draws - 3, (desc, same)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [3, 17, 42, 77, 101])
+def test_concurrent_chains_of_a_drawn_model_are_the_sequential_chains(case):
+    """`sample(chains=3, cores=3)`: three engines of one model driven by three host threads == the three chains one after the other, bit
+    for bit (draws and integer statistics) -- the general path has no chain group, the chains only share the device."""
+    from pymc_amd.sampling import sample
+
+    spec, desc = fuzz_model(case)
+    kw = dict(draws=4, tune=8, chains=3, model=spec, init="adapt_diag", random_seed=21, device=0)
+    seq = sample(cores=1, **kw)
+    par = sample(cores=3, **kw)
+    seq["step"].close()
+    par["step"].close()
+    assert np.array_equal(seq["draws"], par["draws"]), desc
+    for c in range(3):
+        for a_, b_ in zip(seq["stats"][c], par["stats"][c]):
+            assert all(int(a_[k]) == int(b_[k]) for k in INT_KEYS), (desc, c)
