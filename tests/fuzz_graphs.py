@@ -1,4 +1,4 @@
-"""Drawn model GRAPHS for the lowering (tests/test_fuzz_lowering.py): the counterpart of tests/test_gpu_fuzz.py one level up.  That file
+"""Drawn model GRAPHS for the lowering (tests/test_drawn_likelihood_graphs.py): the counterpart of tests/test_gpu_fuzz.py one level up.  That file
 draws model SPECS (the engine against the oracle's interpreter); this one draws the graphs the lowering has to compile -- random
 expressions over the model's variables in the `pytensor.tensor` vocabulary of tests/stubgraph.py (element-wise ops, comparisons under
 `switch`, gathers, broadcasts between a vector of groups, a [G, D] matrix variable and the rows, reductions over a short axis, `clip`,

@@ -25,8 +25,8 @@ def run():
         m = make()
         n = sum(int(np.prod(s)) if s else 1 for s in (m.value_shapes[v.name] for v in m.value_vars))
         qs = points(name, n) * 0.6
-        # (the all-zero point is replaced: with W = b = 0 distinct sub-expressions TIE inside `maximum` / `max`, where torch hands half of the
-        # adjoint to each operand, PyTensor all of it to both and the IR all of it to the first -- DESIGN 8 item 6; case_34 found it)
+        # (the all-zero point is replaced: with W = b = 0 distinct sub-expressions TIE inside `pt.maximum`, where torch hands half of the adjoint
+        # to each operand, PyTensor -- and the lowering, DESIGN 4.3 -- all of it to the first; case_34 found it)
         qs[0] = np.random.default_rng(n).normal(size=n) * 0.3
         vals = [gt.joint_logp_grad(m, q) for q in qs]
         out[f"{name}__q"] = qs

@@ -3,9 +3,11 @@ element-wise ops, `switch` / `clip` / `maximum`, gathers, broadcasts between gro
 `logsumexp` over a short axis, slices -- as parameters of twelve likelihood families (the reference's own `logp` bodies) and as
 potentials.  Committed with torch autograd of the graph itself at seeded points (tests/golden/make_fuzz_golden.py).  Checked: the
 lowered spec through the oracle's interpreter == those numbers and the engine's structural limits admit it (CPU); the device == those
-numbers (`-m gpu`).  The hand-written parity models cover features; this file covers their combinations.  (The all-zero point is not
-among the seeded points: at W = b = 0 distinct sub-expressions tie inside `maximum`, where torch, PyTensor and the IR split the adjoint
-three different ways -- a set of measure zero; case_34 of the first draw of this file found it.)"""
+numbers (`-m gpu`).  The hand-written parity models cover features; this file covers their combinations.  (tests/test_lowering_fuzz.py draws
+expression DAGs as potentials on the host; this file draws whole models around the reference's likelihood bodies and runs them on the
+device.  The all-zero point is not among the seeded points: at W = b = 0 distinct sub-expressions TIE inside `pt.maximum`, where the
+lowering follows PyTensor's rule -- the first operand takes the whole adjoint, DESIGN 4.3 -- and torch, the ground truth here, hands
+half to each: case_34 of this file's first draw.)"""
 import os
 import sys
 
