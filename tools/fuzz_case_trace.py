@@ -1,5 +1,5 @@
 """One drawn model of tests/test_gpu_fuzz.py sampled by the device and by the oracle's sampler, transition by transition (which statistic
-leaves the oracle's first, and by how much the floating-point ones differed before that).  usage: python tools/fuzz_case_trace.py <case>"""
+leaves the oracle's first, and by how much the floating-point ones differed before that).  usage: python tools/fuzz_case_trace.py <case> | rows:<case>"""
 import os
 import sys
 
@@ -12,10 +12,17 @@ import test_gpu_fuzz as tf  # noqa: E402
 from oracle import ref_models, ref_sampler  # noqa: E402
 from pymc_amd.sampling import sample  # noqa: E402
 
-case = int(sys.argv[1]) if len(sys.argv) > 1 else 81
-spec, desc = tf.fuzz_model(case)
+arg = sys.argv[1] if len(sys.argv) > 1 else "81"
+if arg.startswith("rows:"):        # a drawn model around the logit rows (tests/test_gpu_rows_fuzz.py); NUTS_* variables select the pass
+    import test_gpu_rows_fuzz as tr  # noqa: E402
+
+    spec, _shape, env, desc = tr.rows_fuzz_model(int(arg[5:]))
+    os.environ.update(env)
+    tune, draws, seed = 12, 5, 7
+else:
+    spec, desc = tf.fuzz_model(int(arg))
+    tune, draws, seed = 10, 3, 5
 print(desc)
-tune, draws, seed = 10, 3, 5
 res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
 _, ref = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
 got = res["warmup_stats"][0] + res["stats"][0]
