@@ -401,3 +401,45 @@ def test_a_small_group_model_is_grouped_on_request_only():
     n = res2["lockstep_launches"]
     assert n is not None and sum(n[1:]) > 0, n
     assert np.array_equal(res["draws"], res2["draws"])
+
+
+# ---- drawn shapes: ragged groups, any number of chains, with and without an intercept column ------------------------------------------
+def _drawn_rows_model(case):
+    """The benchmark's model (D = 8: the merged launches' shape) over RAGGED groups -- the committed shapes above all have groups of one
+    size --, constants of the priors other than the standard ones now and then (`zscale`: still the closed form, no auxiliary
+    workgroups), with or without an intercept column."""
+    from pymc_amd.model_spec import ModelBuilder
+
+    rg = np.random.default_rng(52000 + case)
+    G = int(rg.integers(8, 49))
+    base = int(rg.choice([70, 130, 300, 517, 900]))
+    sizes = rg.integers(max(base // 3, 2), base * 3 // 2 + 1, size=G)
+    gidx = np.repeat(np.arange(G), sizes).astype(np.int32)
+    N = int(gidx.size)
+    X = rg.normal(size=(N, 8))
+    intercept = bool(rg.random() < 0.6)
+    if intercept:
+        X[:, 0] = 1.0
+    y = (rg.random(N) < 1.0 / (1.0 + np.exp(-np.einsum("nd,nd->n", X, (rg.normal(size=(G, 8)) * 0.6)[gidx])))).astype(np.int8)
+    m = ModelBuilder()
+    if rg.random() < 0.4:
+        mu, sigma, z = m.Normal("mu", 0.3, 2.0, shape=8), m.HalfNormal("sigma", 0.5, shape=8), m.Normal("z", 0.1, 2.0, shape=(G, 8))
+    else:
+        mu, sigma, z = m.Normal("mu", 0.0, 1.0, shape=8), m.HalfNormal("sigma", 1.0, shape=8), m.Normal("z", 0.0, 1.0, shape=(G, 8))
+    m.HierLogitRows("y", X, y, gidx, mu, sigma, z)
+    chains = int(rg.integers(2, 9))
+    return m.build(), chains, f"case {case}: G = {G}, N = {N} (groups of {sizes.min()} .. {sizes.max()} rows), {chains} chains, intercept column: {intercept}"
+
+
+@pytest.mark.parametrize("case", list(range(10)))
+def test_grouped_chains_over_ragged_groups_are_bitwise_the_chains_alone(case, monkeypatch):
+    monkeypatch.setenv("NUTS_ROWS_GA", "2")
+    spec, chains, desc = _drawn_rows_model(case)
+    alone = _sample(spec, chains, False, 1, 10, 5, 23 + case)
+    group = _sample(spec, chains, True, chains, 10, 5, 23 + case)
+    n = group["lockstep_launches"]
+    assert alone["lockstep_launches"] is None and n is not None and sum(n[2:]) > 0, (desc, n)
+    assert np.array_equal(alone["draws"], group["draws"]), desc
+    for c in range(chains):
+        _same_stats(alone["stats"][c], group["stats"][c], (desc, c))
+    print(f"{desc}: launches by chains carried {n[1:]}")
