@@ -777,13 +777,12 @@ static bool compile_spec(nuts_model* m, const nuts_model_spec* s, std::vector<Va
     const bool big_orphan = sweep_orphans && is_orphan && (s->factors[fi].n_instr > 0 || sweep_orphans_opt == 2) && s->factors[fi].size > SMALL_MAX_ELEMS &&
                             s->factors[fi].dist != NUTS_D_DERIVED;
     if (gathered.empty() && !need && !big_orphan) return true;
-    // (a derived vector that is the COEFFICIENT vector of a linear predictor receives its seed from the predictors' backward pass,
-    // which runs after the sweep (launch_vector): swept, its gathers would hand on the adjoints of a seed that is not there yet --
-    // they stay with kernels B / C, which run behind that pass.  Found by `pm.ICAR` over 56 areas: the sum over the edge list)
-    if (s->factors[fi].dist == NUTS_D_DERIVED)
-      for (int l = 0; l < s->n_lins; ++l)
-        for (int k = 0; k < std::min(s->lins[l].K, NUTS_LIN_MAXK); ++k)
-          if (s->lins[l].var[k] == -(fi + 1)) return true;
+    // (a DERIVED vector is never swept: its "density" is the seed d logp / d element that the node reading it leaves behind -- a
+    // linear predictor's backward pass runs after the sweep (launch_vector), and the sweep does not read the GLM node's seed either
+    // -- so its gathers stay with kernels B / C, which run behind both.  Found on the device by `pm.ICAR` over 56 areas (the sum over
+    // the edge list: a one-row predictor) and by tests/test_gpu_glm_fuzz.py (`beta = a[idx] + s z` under the GLM node): the
+    // gradient of the gathered variable was lost)
+    if (s->factors[fi].dist == NUTS_D_DERIVED) return true;
     if (big_orphan) m->has_prog = true;
     const int64_t fsize = s->factors[fi].size;
     const size_t nsl = gathered.size() + lin_used.size();
