@@ -1,5 +1,5 @@
 """One drawn model of tests/test_gpu_fuzz.py sampled by the device and by the oracle's sampler, transition by transition (which statistic
-leaves the oracle's first, and by how much the floating-point ones differed before that).  usage: python tools/fuzz_case_trace.py <case> | rows:<case>"""
+leaves the oracle's first, and by how much the floating-point ones differed before that).  usage: python tools/fuzz_case_trace.py <case> | rows:<case> | mix:<case>"""
 import os
 import sys
 
@@ -19,12 +19,20 @@ if arg.startswith("rows:"):        # a drawn model around the logit rows (tests/
     spec, _shape, env, desc = tr.rows_fuzz_model(int(arg[5:]))
     os.environ.update(env)
     tune, draws, seed = 12, 5, 7
+elif arg.startswith("mix:"):       # a drawn model around the mixture node (tests/test_gpu_mixture_fuzz.py)
+    import test_gpu_mixture_fuzz as tm  # noqa: E402
+
+    spec, desc = tm.mixture_fuzz_model(int(arg[4:]))
+    tune, draws, seed = 12, 4, 5
 else:
     spec, desc = tf.fuzz_model(int(arg))
     tune, draws, seed = 10, 3, 5
 print(desc)
 res = sample(draws=draws, tune=tune, chains=1, model=spec, init="adapt_diag", random_seed=seed, device=0)
-_, ref = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.zeros(spec.n)], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
+from pymc_amd.sampling import initial_point  # noqa: E402
+
+_pt = initial_point(spec)
+_, ref = ref_sampler.sample_reference(ref_models.SpecLogpGrad(spec), [np.concatenate([np.ravel(_pt[v.value_name]) for v in spec.vars])], draws=draws, tune=tune, random_seed=seed, init="adapt_diag")
 got = res["warmup_stats"][0] + res["stats"][0]
 res["step"].close()
 for i, (a, b) in enumerate(zip(got, ref[0])):
