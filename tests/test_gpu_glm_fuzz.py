@@ -13,7 +13,7 @@ from oracle import ref_models, ref_sampler
 from pymc_amd import model_spec as ms
 from pymc_amd.model_spec import ModelBuilder
 
-N_CASES = 40
+N_CASES = 72
 INT_KEYS = ("depth", "tree_size", "index_in_trajectory", "diverging", "reached_max_treedepth")
 
 
@@ -30,7 +30,7 @@ def glm_fuzz_model(case: int):
          "poisson": lambda: rg.poisson(np.exp(np.clip(eta, -3, 3))).astype("float64")}[family]()
     what = [f"N={N}", f"P={P}", family]
     m = ModelBuilder()
-    kind = pick("plain", "hyper", "noncentred", "noncentred-gather")
+    kind = pick("plain", "hyper", "noncentred", "noncentred-gather", "nonlinear", "gathered-groups")
     what.append(kind)
     if kind == "plain":
         beta = m.Normal("beta", 0.0, 1.5, shape=P)
@@ -43,6 +43,13 @@ def glm_fuzz_model(case: int):
             z = m.Normal("z", 0.0, 1.0, shape=P)
             if kind == "noncentred":
                 beta = mu_b + s_b * z
+            elif kind == "nonlinear":                    # a derived vector with a program: a bounded coefficient
+                beta = m.math.tanh(z) * s_b + mu_b
+            elif kind == "gathered-groups":              # coefficients shared within groups of covariates, scaled: gathers of two variables
+                H = int(pick(2, 3))
+                idx = rg.integers(0, H, size=P)
+                t = m.HalfNormal("t", 1.0, shape=H)
+                beta = z * t[idx] + mu_b
             else:
                 H = int(pick(2, 4))
                 a = m.Normal("a", mu_b, 1.0, shape=H)
