@@ -571,6 +571,8 @@ def engine_refusal(spec: "ModelSpec") -> Optional[str]:
                     return "too many scalar operands in one factor (MAX_FACTOR_BT)"
     if deferred > MAX_DEFERRED:
         return "too many scalar / hyper-parameter elements (MAX_DEFERRED)"
+    if getattr(spec, "glm_rows", None) is not None and spec.mvnormal is not None and spec.mvnormal.solver != "precision":
+        return "GLM node next to an MvNormal node: the MvNormal node's precision solver only"
     lins = getattr(spec, "lins", [])
     if len(lins) > MAX_LINS:
         return "bad number of linear predictors (NUTS_MAX_LINS)"
