@@ -271,3 +271,50 @@ def test_concurrent_chains_of_a_drawn_model_are_the_sequential_chains(case):
     for c in range(3):
         for a_, b_ in zip(seq["stats"][c], par["stats"][c]):
             assert all(int(a_[k]) == int(b_[k]) for k in INT_KEYS), (desc, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [2, 9, 26, 40, 63, 88, 97, 120, 133, 150])
+def test_hamiltonian_mc_on_a_drawn_model_follows_the_oracles_trajectories(case):
+    """`HamiltonianMC._hamiltonian_step` (hmc.py:130-184: fixed-length trajectories, the step size jittered per transition) on the general
+    IR: path length in steps and acceptance identical, positions to 1e-7 over the first transitions."""
+    from pymc_amd.blocking import RaveledVars
+    from pymc_amd.step import HamiltonianMC
+
+    spec, desc = fuzz_model(case)
+    if max(f.size for f in spec.factors) > 5000:
+        pytest.skip("the oracle walks the elements in NumPy")
+    step = HamiltonianMC(model=spec, rng=4, device=0)
+    ref = ref_sampler.RefHMC(ref_models.SpecLogpGrad(spec), spec.n, rng=4)
+    step.setup_chain(np.random.default_rng(8), 8, 6)
+    ref.setup_chain(np.random.default_rng(8), 8, 6)
+    q = RaveledVars(np.zeros(spec.n), spec.point_map_info)
+    qr = np.zeros(spec.n)
+    try:
+        for i in range(12):
+            q, st = step.astep(q)
+            qr, sr = ref.astep(qr)
+            assert st[0]["n_steps"] == sr["n_steps"] and st[0]["accepted"] == sr["accepted"], (desc, i)
+            if i < 6:
+                np.testing.assert_allclose(q.data, qr, rtol=1e-7, atol=1e-9, err_msg=f"{desc}, transition {i}")
+    finally:
+        step.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [1, 14, 33, 58, 90, 111, 144])
+def test_batched_draws_of_a_drawn_model_are_the_draws_one_by_one(case, monkeypatch):
+    """`nuts_chain_draw_many` (a batch of iterations of `_iter_sample`, mcmc.py:1556-1572) against `nuts_chain_draw` per draw: the same
+    chain, bit for bit."""
+    from pymc_amd.sampling import sample
+
+    spec, desc = fuzz_model(case)
+    out = []
+    for batch in ("1", "64"):
+        monkeypatch.setenv("PYMC_AMD_DRAW_BATCH", batch)
+        res = sample(draws=9, tune=7, chains=1, model=spec, init="adapt_diag", random_seed=31, device=0, discard_tuned_samples=False)
+        res["step"].close()
+        out.append(res)
+    assert np.array_equal(out[0]["draws"], out[1]["draws"]), desc
+    for a_, b_ in zip(out[0]["stats"][0], out[1]["stats"][0]):
+        assert all(int(a_[k]) == int(b_[k]) for k in INT_KEYS) and float(a_["energy"]) == float(b_["energy"]), desc
