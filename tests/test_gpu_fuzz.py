@@ -291,13 +291,13 @@ def test_hamiltonian_mc_on_a_drawn_model_follows_the_oracles_trajectories(case):
     q = RaveledVars(np.zeros(spec.n), spec.point_map_info)
     qr = np.zeros(spec.n)
     try:
-        for i in range(12):
+        for i in range(2 if "Laplace" in desc else 12):
             q, st = step.astep(q)
             qr, sr = ref.astep(qr)
             assert st[0]["n_steps"] == sr["n_steps"] and st[0]["accepted"] == sr["accepted"], (desc, i)
             # (a Laplace likelihood has a kink per row: thousands of them are crossed per trajectory, and a last bit of mu on the other
-            # side of one is a gradient component of the other sign -- positions are held over the first two transitions there)
-            if i < (2 if "Laplace" in desc else 6):
+            # side of one is a gradient component of the other sign -- such a model is followed over two transitions only)
+            if i < 6:
                 np.testing.assert_allclose(q.data, qr, rtol=1e-7, atol=1e-9, err_msg=f"{desc}, transition {i}")
     finally:
         step.close()
@@ -320,3 +320,29 @@ def test_batched_draws_of_a_drawn_model_are_the_draws_one_by_one(case, monkeypat
     assert np.array_equal(out[0]["draws"], out[1]["draws"]), desc
     for a_, b_ in zip(out[0]["stats"][0], out[1]["stats"][0]):
         assert all(int(a_[k]) == int(b_[k]) for k in INT_KEYS) and float(a_["energy"]) == float(b_["energy"]), desc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 5, 21, 46, 71, 103, 127, 152])
+def test_full_rank_advi_over_a_drawn_model_takes_the_oracles_steps(case):
+    """`FullRankADVI(model=<ModelSpec>)` (variational/opvi.py:318-404 reduced to the full-rank group): log-density and gradient of the whole
+    model from the device per step, against the oracle's steps on the same standard-normal draws -- loss, mean and Cholesky factor."""
+    from oracle import ref_advi
+    from pymc_amd.variational import FullRankADVI, adagrad_window
+
+    spec, desc = fuzz_model(case)
+    if spec.n > 400 or max(f.size for f in spec.factors) > 5000:
+        pytest.skip("a full-rank approximation of a few hundred dimensions at most, the oracle in NumPy")
+    inf = FullRankADVI(model=spec, random_seed=4, device=0)
+    try:
+        z0 = np.random.default_rng(5).normal(size=(15, spec.n))
+        loss = inf.run_steps(None, z0, adagrad_window(learning_rate=0.01, epsilon=0.1, n_win=10))
+        f = ref_models.SpecLogpGrad(spec)
+        st = ref_advi.FullRankState(spec.n)
+        want = [ref_advi.advi_step_logp(f, st, z0[s], 0.01, 0.1, 10)[0] for s in range(15)]
+        np.testing.assert_allclose(loss, want, rtol=1e-9, err_msg=desc)
+        mu, lt = inf.approx.params
+        np.testing.assert_allclose(mu, st.mu, rtol=1e-8, atol=1e-11, err_msg=desc)
+        np.testing.assert_allclose(lt, st.L_tril, rtol=1e-8, atol=1e-11, err_msg=desc)
+    finally:
+        inf.close()
