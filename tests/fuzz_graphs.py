@@ -13,13 +13,15 @@ import numpy as np
 import stubgraph as sg
 
 pt = sg.pt
-N_CASES = 40
+N_CASES = 52         # (cases 40 ..: 1 300 rows -- `pt.dot(X, b)` over that many rows is a linear predictor, dense node 5, not a written-out product)
 
 
 def fuzz_graph_model(case: int):
     rg = np.random.default_rng(77000 + case)
     pick = lambda *xs: xs[int(rg.integers(len(xs)))]      # noqa: E731
     N = int(pick(12, 60, 250))
+    if case >= 40:
+        N = 1300
     G = int(pick(3, 7))
     D = int(pick(2, 3, 5))
     gi = rg.integers(0, G, size=N)
@@ -35,7 +37,7 @@ def fuzz_graph_model(case: int):
 
     # ---- row-shaped building blocks (N elements each)
     def leaf():
-        k = pick("gather", "slopes", "rowsum", "data", "scalar", "bdot")
+        k = pick("gather", "slopes", "rowsum", "data", "scalar", "bdot") if case < 40 else pick("gather", "bdot", "bdot", "data", "scalar", "slopes")
         if k == "gather":
             return a[gi]
         if k == "slopes":                                   # varying slopes: a row of W per observation, times the covariates, summed
