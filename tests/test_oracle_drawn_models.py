@@ -1,0 +1,79 @@
+"""The oracle's SAMPLER against the EXECUTED reference sampler on drawn models.
+
+Every device test of the drawn-model files compares with `oracle/ref_sampler.py`; that restatement is pinned by executing the reference's
+own `nuts.py` / `base_hmc.py` / `integration.py` / `quadpotential.py` / `step_sizes.py` (tests/golden/refrun.py) on the committed fixtures
+and on eight schools (tests/test_golden.py).  Here the models are the drawn ones of tests/test_gpu_fuzz.py, tests/test_gpu_glm_fuzz.py and
+tests/test_gpu_mixture_fuzz.py (the small ones): the reference's classes over the oracle's log-density of a drawn model, against the
+oracle's sampler -- draws, every statistic and both generators bitwise.  Needs /root/reference (CPU only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as mg  # noqa: E402
+import refrun  # noqa: E402
+import test_gpu_fuzz as tf  # noqa: E402
+import test_gpu_glm_fuzz as tg  # noqa: E402
+import test_gpu_mixture_fuzz as tm  # noqa: E402
+
+from oracle import ref_models, ref_sampler  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not refrun.available(), reason="needs the reference checkout under /root/reference")
+
+
+def _small(gen, cases, limit):
+    out = []
+    for c in cases:
+        spec, desc = gen(c)
+        if spec.n <= 80 and max([f.size for f in spec.factors] + [0]) <= limit:
+            out.append(c)
+    return out
+
+
+GENERAL = _small(tf.fuzz_model, range(0, 60), 400)[:8]
+GLM = [c for c in range(0, 40) if tg.glm_fuzz_model(c)[0].glm_rows.X.shape[0] <= 1000 and tg.glm_fuzz_model(c)[0].n <= 60][:5]
+MIX = [c for c in range(0, 36) if tm.mixture_fuzz_model(c)[0].mixture_rows.y.size <= 300 and tm.mixture_fuzz_model(c)[0].mixture_rows.assign is None][:4]
+
+
+def _compare(spec, desc, kind="nuts", **kw):
+    f = ref_models.SpecLogpGrad(spec)
+    point = {v.value_name: np.zeros(v.shape) for v in spec.vars}
+    step, model = refrun.make_step(kind, f, point, rng=41, **kw)
+    d_ref, s_ref = refrun.run_chain(step, model, np.random.default_rng(6), 14, 5)
+    cls = ref_sampler.RefNUTS if kind == "nuts" else ref_sampler.RefHMC
+    orc = cls(ref_models.SpecLogpGrad(spec), spec.n, rng=41, **kw)
+    d_orc, s_orc = ref_sampler.run_chain(orc, np.zeros(spec.n), np.random.default_rng(6), 14, 5)
+    assert np.array_equal(d_ref, d_orc), desc
+    ik, fk = (mg.INT_KEYS, mg.FLT_KEYS) if kind == "nuts" else (mg.HMC_INT_KEYS, mg.HMC_FLT_KEYS)
+    for k in ik + fk:
+        assert [float(s[k]) for s in s_ref] == [float(s[k]) for s in s_orc], (desc, k)
+    assert step.rng.bit_generator.state == orc.rng.bit_generator.state, desc
+    assert step.potential.rng.bit_generator.state == orc.potential.rng.bit_generator.state, desc
+
+
+@pytest.mark.parametrize("case", GENERAL)
+def test_oracle_sampler_is_the_executed_reference_on_a_drawn_model_of_the_general_ir(case):
+    spec, desc = tf.fuzz_model(case)
+    _compare(spec, desc, max_treedepth=7)
+
+
+@pytest.mark.parametrize("case", GLM)
+def test_oracle_sampler_is_the_executed_reference_on_a_drawn_model_around_the_glm_node(case):
+    spec, desc = tg.glm_fuzz_model(case)
+    _compare(spec, desc, max_treedepth=7)
+
+
+@pytest.mark.parametrize("case", MIX)
+def test_oracle_sampler_is_the_executed_reference_on_a_drawn_model_around_the_mixture_node(case):
+    spec, desc = tm.mixture_fuzz_model(case)
+    _compare(spec, desc, max_treedepth=6)
+
+
+@pytest.mark.parametrize("case", GENERAL[:3])
+def test_oracle_hmc_is_the_executed_reference_on_a_drawn_model(case):
+    spec, desc = tf.fuzz_model(case)
+    _compare(spec, desc, kind="hmc", path_length=1.0, max_steps=9)
