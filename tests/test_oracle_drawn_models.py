@@ -77,3 +77,48 @@ def test_oracle_sampler_is_the_executed_reference_on_a_drawn_model_around_the_mi
 def test_oracle_hmc_is_the_executed_reference_on_a_drawn_model(case):
     spec, desc = tf.fuzz_model(case)
     _compare(spec, desc, kind="hmc", path_length=1.0, max_steps=9)
+
+
+# ---- the oracle's Gibbs sweep against the executed `CategoricalGibbsMetropolis` on drawn mixtures ---------------------------------------
+@pytest.mark.parametrize("case", list(range(12)))
+@pytest.mark.parametrize("proposal", ["uniform"])
+def test_oracle_gibbs_sweeps_are_the_executed_reference_on_a_drawn_mixture(case, proposal):
+    """`metropolis.py:761-786` (`astep_unif`, the default proposal) executed over the full-model log-density of a DRAWN mixture -- K = 2 .. 9
+    components, unequal weights, a scale per component, 40 .. 400 rows -- against `oracle/ref_gibbs.py`: assignments after every sweep
+    and the generator's state (the committed fixtures hold one shape: K = 3, N = 240, equal weights, one scale).
+
+    `proposal="proportional"` is NOT drawn, and the reason is a finding: `metropolis_proportional` (:805-826) divides by
+    `1 - prob_curr` and by `1 - probs[proposed]`, and rejects WITHOUT drawing its uniform when the ratio is not finite.  On separated
+    mixtures those differences round to exactly 0 or to 1e-16 depending on the last bits of the softmax's inputs -- the full-model
+    log-densities in the reference, the per-row terms in the restatement (equal in exact arithmetic) -- so one side consumes a uniform
+    the other does not and the streams part (K = 3, N = 400: 23 assignments of one sweep); three of eight drawn shapes made the
+    reference's own `rng.choice` raise ("Probabilities contain NaN" / "do not sum to 1").  The committed K = 3 / N = 240 fixture does not
+    meet the event, which is all its bitwise agreement says."""
+    import types
+
+    import make_gibbs_golden as mgg
+    from oracle import ref_gibbs
+
+    rg = np.random.default_rng(4200 + case)
+    K = int(rg.integers(2, 10))
+    N = int(rg.choice([40, 97, 240, 400]))
+    w = rg.dirichlet(np.ones(K) * 2.0)
+    sigma = rg.uniform(0.5, 1.6, size=K)
+    mu_true = np.linspace(-3.0, 3.0, K)
+    c_true = rg.choice(K, size=N, p=w)
+    y = mu_true[c_true] + sigma[c_true] * rg.normal(size=N)
+    link = types.SimpleNamespace(y=y, K=K, log_w=np.log(w), sigma=sigma)
+    spec = types.SimpleNamespace(mixture=link)
+    n_sweeps = 3
+    mus = mu_true[None, :] + 0.4 * rg.normal(size=(n_sweeps, K))
+    c0 = rg.integers(0, K, size=N)
+    seed = 900 + case
+    cs, state = mgg.reference_sweeps(spec, seed, n_sweeps, mus, c0, leave_half_cached=True, proposal=proposal)
+    rng = np.random.default_rng(seed)
+    rng.integers(2**30)
+    g = ref_gibbs.RefCategoricalGibbs(link.y, link.log_w, link.sigma, rng)
+    c = c0.copy()
+    for s_ in range(n_sweeps):
+        c, _ = (g.sweep if proposal == "uniform" else g.sweep_prop)(c, mus[s_])
+        assert np.array_equal(c, cs[s_]), (case, proposal, s_)
+    assert rng.bit_generator.state == state, (case, proposal)
