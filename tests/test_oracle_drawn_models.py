@@ -162,3 +162,30 @@ def test_oracle_advi_steps_are_the_executed_reference_on_a_drawn_glm(case):
         for got, want in ((om, gm), (ol, gl), (st.mu, ref.mu), (st.L_tril, ref.L_tril), (st.acc_mu, am), (st.acc_L, aL)):
             assert np.max(np.abs(np.asarray(got) - np.asarray(want))) <= 1e-12 * max(1.0, np.max(np.abs(want))), (case, s_)
         assert st.i == int(im)
+
+
+# ---- every adapting potential on drawn models ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", GENERAL[:4])
+@pytest.mark.parametrize("potential", ["adapt_diag", "full", "fullinv", "full_adapt", "diag_adapt_exp"])
+def test_oracle_potentials_are_the_executed_reference_on_a_drawn_model(case, potential):
+    """The five `QuadPotential` classes the fixtures pin on eight schools / a standard normal (quadpotential.py: DiagAdapt, Full, FullInv,
+    FullAdapt, DiagAdaptExp with gradients) under NUTS on a drawn model: 16 tuning transitions (FullAdapt refreshes its covariance and
+    factor at every one past the first window) + 4 draws, bitwise."""
+    import warnings
+
+    spec, desc = tf.fuzz_model(case)
+    ref = refrun.load()
+    f = ref_models.SpecLogpGrad(spec)
+    rngs, seeds = ref_sampler.spawn_chain_rngs(77 + case, 1)
+    mk_ref, mk_orc = mg._potentials(dict(potential=potential), spec.n, seeds[0])
+    point = {v.value_name: np.zeros(v.shape) for v in spec.vars}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # ("QuadPotentialFullAdapt is an experimental feature")
+        step, model = refrun.make_step("nuts", f, point, potential=mk_ref(ref.quadpotential), rng=seeds[0], max_treedepth=7)
+        d_ref, s_ref = refrun.run_chain(step, model, rngs[0], 16, 4)
+        rngs2, seeds2 = ref_sampler.spawn_chain_rngs(77 + case, 1)
+        orc = ref_sampler.RefNUTS(ref_models.SpecLogpGrad(spec), spec.n, potential=mk_orc(), rng=seeds2[0], max_treedepth=7)
+        d_orc, s_orc = ref_sampler.run_chain(orc, np.zeros(spec.n), rngs2[0], 16, 4)
+    assert np.array_equal(d_ref, d_orc), (desc, potential)
+    for k in mg.INT_KEYS + mg.FLT_KEYS:
+        assert [float(s[k]) for s in s_ref] == [float(s[k]) for s in s_orc], (desc, potential, k)
