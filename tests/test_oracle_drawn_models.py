@@ -189,3 +189,20 @@ def test_oracle_potentials_are_the_executed_reference_on_a_drawn_model(case, pot
     assert np.array_equal(d_ref, d_orc), (desc, potential)
     for k in mg.INT_KEYS + mg.FLT_KEYS:
         assert [float(s[k]) for s in s_ref] == [float(s[k]) for s in s_orc], (desc, potential, k)
+
+
+@pytest.mark.parametrize("case", GENERAL[4:7])
+@pytest.mark.parametrize(
+    "kind,kw",
+    [
+        ("nuts", dict(adapt_step_size=False, step_scale=0.1, max_treedepth=6)),
+        ("nuts", dict(Emax=5.0, early_max_treedepth=3, max_treedepth=5)),       # divergences and depth-limited trees
+        ("nuts", dict(gamma=0.1, k=0.6, t0=5, target_accept=0.9, max_treedepth=6)),
+        ("hmc", dict(path_length=3.0, adapt_step_size=False, step_scale=0.2, max_steps=12)),
+    ],
+)
+def test_oracle_step_options_mean_what_the_references_mean_on_a_drawn_model(case, kind, kw):
+    """The constructor options of `BaseHMC` / `NUTS` / `HamiltonianMC` (base_hmc.py:82-103, nuts.py:132-147, hmc.py:70-77) on drawn models
+    (tests/test_golden.py holds them on eight schools)."""
+    spec, desc = tf.fuzz_model(case)
+    _compare(spec, desc, kind=kind, **kw)
