@@ -100,35 +100,42 @@ def model(case):
     return m, kind
 
 
-lo, hi = int(sys.argv[1]), int(sys.argv[2])
-res, bad = collections.Counter(), []
-for case in range(lo, hi):
-    try:
-        m, kind = model(case)
-    except Exception:   # noqa: BLE001
-        res["stand-in could not build"] += 1
-        bad.append((case, "build", traceback.format_exc()[-250:]))
-        continue
-    try:
-        spec = lowering.lower_to_spec(m)
-    except lowering.NotLowerable as e:
-        res[f"{kind}: not lowerable"] += 1
-        bad.append((case, kind, "NotLowerable", str(e)[:140]))
-        continue
-    except Exception:   # noqa: BLE001
-        res[f"{kind}: lowering raised"] += 1
-        bad.append((case, kind, "raised", traceback.format_exc()[-300:]))
-        continue
-    q = np.random.default_rng(case).normal(size=spec.n) * 0.3
-    lp, g = gt.joint_logp_grad(m, q)
-    lp2, g2 = ref_models.evaluate(spec, q)
-    ok = (not np.isfinite(lp) and not np.isfinite(lp2)) or (abs(lp - lp2) <= 1e-9 * max(1.0, abs(lp)) and np.max(np.abs(g - g2)) <= 1e-9 * max(1.0, np.max(np.abs(g))))
-    res[f"{kind}: ok" if ok else f"{kind}: MISMATCH"] += 1
-    if not ok:
-        bad.append((case, kind, "mismatch", lp, lp2, float(np.max(np.abs(g - g2)))))
-    elif ms.engine_refusal(spec) is not None:
-        res[f"{kind}: engine would refuse"] += 1
-        bad.append((case, kind, "refusal", ms.engine_refusal(spec)))
-print(dict(sorted(res.items())))
-for b in bad[:40]:
-    print("  ", b)
+def sweep(lo, hi):
+    """-> (counts by kind and outcome, list of the cases that are not plain agreement)"""
+    res, bad = collections.Counter(), []
+    for case in range(lo, hi):
+        try:
+            m, kind = model(case)
+        except Exception:   # noqa: BLE001
+            res["stand-in could not build"] += 1
+            bad.append((case, "build", traceback.format_exc()[-250:]))
+            continue
+        try:
+            spec = lowering.lower_to_spec(m)
+        except lowering.NotLowerable as e:
+            res[f"{kind}: not lowerable"] += 1
+            bad.append((case, kind, "NotLowerable", str(e)[:140]))
+            continue
+        except Exception:   # noqa: BLE001
+            res[f"{kind}: lowering raised"] += 1
+            bad.append((case, kind, "raised", traceback.format_exc()[-300:]))
+            continue
+        q = np.random.default_rng(case).normal(size=spec.n) * 0.3
+        lp, g = gt.joint_logp_grad(m, q)
+        lp2, g2 = ref_models.evaluate(spec, q)
+        ok = (not np.isfinite(lp) and not np.isfinite(lp2)) or (abs(lp - lp2) <= 1e-9 * max(1.0, abs(lp)) and np.max(np.abs(g - g2)) <= 1e-9 * max(1.0, np.max(np.abs(g))))
+        res[f"{kind}: ok" if ok else f"{kind}: MISMATCH"] += 1
+        if not ok:
+            bad.append((case, kind, "mismatch", lp, lp2, float(np.max(np.abs(g - g2)))))
+        elif ms.engine_refusal(spec) is not None:
+            res[f"{kind}: engine would refuse"] += 1
+            bad.append((case, kind, "refusal", ms.engine_refusal(spec)))
+
+    return res, bad
+
+
+if __name__ == "__main__":
+    res_, bad_ = sweep(int(sys.argv[1]), int(sys.argv[2]))
+    print(dict(sorted(res_.items())))
+    for b_ in bad_[:40]:
+        print("  ", b_)
